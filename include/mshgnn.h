@@ -1,0 +1,142 @@
+/*
+ * mshgnn.h -- C-ABI of the MI355X-native MS-HGNN message-passing engine (libmshgnn.so).
+ *
+ * The reference (lunarlab-gatech/MorphSym-HGNN) has no FFI layer: its hot path sits behind two Python
+ * surfaces.  This header is the boundary a maintainer would bind instead of
+ *   GRF_HGNN_C2.forward   src/ms_hgnn/lightning_py/hgnn_c2.py:133-182   (+ autograd backward of it)
+ *   GRF_HGNN_K4.forward   src/ms_hgnn/lightning_py/hgnn_k4.py:146-196
+ *   GRF_HGNN.forward      src/ms_hgnn/lightning_py/hgnn.py:57-62
+ *   MSE loss of the Lightning wrapper  gnnLightning.py:633-639, 680-695
+ * i.e. everything `torch_geometric.nn.{HeteroDictLinear, HeteroConv, GraphConv, Linear}` + ATen execute for
+ * one minibatch of time-window graphs (hgnn_c2.py:3, :88, :100-113, :131).
+ *
+ * Conventions: plain pointers and sizes, no torch types; every function returns 0 on success or a negative
+ * MSHGNN_E* code (never throws across the ABI); mshgnn_last_error() gives the text for the calling thread.
+ * All device buffers are caller-allocated (e.g. by the torch caching allocator); no ownership transfer.
+ * forward/backward are asynchronous on the caller's HIP stream (passed as void* = hipStream_t).  A plan is
+ * immutable after creation, so forward/backward are re-entrant from autograd worker threads as long as each
+ * call uses its own workspace.
+ *
+ * Data layout ("dense window-major"): every window graph of a minibatch has the same tiny topology, so the
+ * PyG-batched [B*n_type, F] tensors the reference passes are already [B, n_type, F] contiguous; they are
+ * consumed as-is.  dtype selects storage/operand precision of inputs and activations:
+ *   MSHGNN_F32  : fp32 storage, exact-fp32 MFMA (v_mfma_f32_16x16x4_f32)           -- parity mode (1e-4 rel)
+ *   MSHGNN_BF16 : bf16 storage + bf16 MFMA operands, fp32 accumulate, fp32 weights  -- throughput mode
+ * Parameters and parameter gradients are always one flat fp32 buffer (offsets given in the descriptor).
+ */
+#ifndef MSHGNN_H
+#define MSHGNN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSHGNN_MAX_TYPES 4
+#define MSHGNN_F32 0
+#define MSHGNN_BF16 1
+
+#define MSHGNN_OK 0
+#define MSHGNN_EINVAL (-1)      /* bad descriptor / argument */
+#define MSHGNN_EUNSUPPORTED (-2) /* valid request the engine cannot run (e.g. hidden != 128) */
+#define MSHGNN_EHIP (-3)        /* HIP runtime error */
+#define MSHGNN_ENOMEM (-4)
+
+#define MSHGNN_FLAG_RESIDUAL 1u      /* X <- f(H) + X            (hgnn_c2.py:161-166)                 */
+#define MSHGNN_FLAG_BASE_MLP 2u      /* base_transform on mlp_type (hgnn_c2.py:117-121,156)           */
+
+typedef struct mshgnn_plan mshgnn_plan;
+
+/* One model instance over one robot topology.  Relation r is the reference's edge type
+ * (src_type, rel, dst_type); its GraphConv has lin_rel (weight+bias) and lin_root (weight only).
+ * All offsets are element offsets into the flat fp32 parameter buffer.                              */
+typedef struct mshgnn_desc {
+    int32_t n_types;                              /* node types, in data_metadata[0] order            */
+    int32_t hidden;                               /* hidden_channels (engine: must be 128)            */
+    int32_t num_layers;                           /* message-passing layers                           */
+    int32_t n_rel;                                /* relations, in data_metadata[1] order             */
+    int32_t out_type;                             /* node type the decoder reads ('foot')             */
+    int32_t out_channels;                         /* out_channels_per_foot                            */
+    int32_t mlp_type;                             /* type with the base_transform epilogue, or -1     */
+    uint32_t flags;                               /* MSHGNN_FLAG_*                                    */
+    int32_t dtype;                                /* MSHGNN_F32 | MSHGNN_BF16                         */
+    int32_t type_nodes[MSHGNN_MAX_TYPES];         /* nodes of each type per window                    */
+    int32_t type_width[MSHGNN_MAX_TYPES];         /* input feature width F_type                       */
+    const int32_t* rel_src;                       /* [n_rel] source type                              */
+    const int32_t* rel_dst;                       /* [n_rel] destination type                         */
+    const int32_t* rel_mean;                      /* [n_rel] 1 = 'mean' aggregation, 0 = 'add'        */
+    const int32_t* rel_edge_off;                  /* [n_rel+1] prefix offsets into edges              */
+    const int32_t* edges;                         /* [2*E] (src_node, dst_node) per-window pairs      */
+    const float* in_mask[MSHGNN_MAX_TYPES];       /* [n_t*F_t] +-1 symmetry mask (apply_symmetry), host */
+    const float* out_mask;                        /* [n_out*out_channels] +-1 (ms_foot_decoder), host */
+    /* flat-parameter offsets */
+    const int64_t* off_enc_w;                     /* [n_types]  encoder.lins.<t>.weight [h, F_t]      */
+    const int64_t* off_enc_b;                     /* [n_types]                                        */
+    const int64_t* off_rel_w;                     /* [L*n_rel]  convs.l.convs.<r>.lin_rel.weight      */
+    const int64_t* off_rel_b;                     /* [L*n_rel]                 ...lin_rel.bias        */
+    const int64_t* off_root_w;                    /* [L*n_rel]                 ...lin_root.weight     */
+    int64_t off_mlp[4];                           /* base_transform.0.{w,b}, base_transform.2.{w,b}   */
+    int64_t off_dec_w, off_dec_b;                 /* decoder.{weight,bias}                            */
+    int64_t n_flat;                               /* length of the flat parameter buffer              */
+} mshgnn_desc;
+
+/* Work / traffic the plan executes per window (dead nodes of the last layers are skipped).           */
+typedef struct mshgnn_info {
+    int32_t rows_per_tile;        /* windows per workgroup tile of the layer kernels                   */
+    int32_t total_nodes;          /* nodes per window                                                  */
+    int64_t lds_bytes;            /* dynamic LDS of the layer kernels                                  */
+    double flops_fwd;             /* algorithmic FLOPs / window, forward (2 FLOP per MAC)              */
+    double flops_bwd;             /* algorithmic FLOPs / window, backward (dX chain + all dW)          */
+    double flops_exec_fwd;        /* FLOPs / window the kernels actually issue (per-edge MACs, padding) */
+    double flops_exec_bwd;
+    double bytes_in;              /* input bytes / window at the plan dtype                            */
+    int32_t n_gradw_workgroups;   /* split-K workgroups of the weight-gradient kernel                  */
+    int32_t n_launches_fwd, n_launches_bwd;
+} mshgnn_info;
+
+/* Offsets (bytes) of the per-layer buffers inside the workspace, for tests / debugging.              */
+typedef struct mshgnn_ws_layout {
+    size_t total;
+    size_t x[17];       /* X_l      [B][NN][h]  l = 0..L   (dtype)      hidden state after the encoder / layer l-1 */
+    size_t dx[17];      /* dX_l     [B][NN][h]  l = 0..L   (dtype)                                                  */
+    size_t dh[16];      /* dH_l     [B][NN][h]  l = 0..L-1 (dtype)      gradient w.r.t. the HeteroConv output       */
+    size_t mask[16];    /* relu bits [B][NN][4] uint32                                                             */
+    size_t hb[16], t1[16], du[16];  /* base_transform stash [B][n_mlp][h] (dtype)                                   */
+    size_t wpack;       /* packed weights                                                                          */
+    size_t bias;        /* packed biases (fp32)                                                                    */
+    size_t slabs;       /* split-K partial weight gradients (fp32)                                                 */
+    size_t loss;        /* 16 floats                                                                               */
+} mshgnn_ws_layout;
+
+const char* mshgnn_last_error(void);
+const char* mshgnn_version(void);
+
+int mshgnn_plan_create(const mshgnn_desc* desc, mshgnn_plan** plan_out);
+void mshgnn_plan_destroy(mshgnn_plan* plan);
+int mshgnn_plan_info(const mshgnn_plan* plan, mshgnn_info* info);
+
+/* Workspace for `batch` windows.  training=0: forward-only (no stash beyond what forward needs).    */
+int mshgnn_workspace_layout(const mshgnn_plan* plan, int64_t batch, int training, mshgnn_ws_layout* out);
+
+/* Forward.  x[t]: device pointer [batch][n_t][x_pitch[t]] at the plan dtype (x_pitch[t] >= F_t elements;
+ * NULL pitch array = dense).  params: device fp32 flat buffer.  out: device fp32 [batch][n_out][out_channels]
+ * (== the reference's [B*4, out] and, for C2 3-D GRF, its [B, 12] view; output mask applied).           */
+int mshgnn_forward(const mshgnn_plan* plan, const void* const* x, const int64_t* x_pitch, const float* params,
+                   float* out, void* workspace, int64_t batch, int training, void* stream);
+
+/* Backward of the forward that last ran on `workspace` with the same x/params.  grad_out: device fp32
+ * [batch][n_out][out_channels] (dL/d out).  grad_params: device fp32 flat buffer, fully OVERWRITTEN with
+ * dL/d params (parameters that cannot influence the output get exact zeros).                            */
+int mshgnn_backward(const mshgnn_plan* plan, const void* const* x, const int64_t* x_pitch, const float* params,
+                    const float* grad_out, float* grad_params, void* workspace, int64_t batch, void* stream);
+
+/* Loss of the Lightning wrapper (gnnLightning.py:633-639): loss = mean((out - y)^2) over n elements and
+ * grad_out = 2 (out - y) / n.  loss_out: device float[1].                                               */
+int mshgnn_mse_loss(const float* out, const float* y, int64_t n, float* loss_out, float* grad_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSHGNN_H */

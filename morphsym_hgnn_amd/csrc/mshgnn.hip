@@ -1,0 +1,1032 @@
+// libmshgnn: MI355X (gfx950 / CDNA4) MS-HGNN message-passing engine -- HIP kernels + C-ABI (include/mshgnn.h).
+//
+// Design (DESIGN.md has the long form):
+//   * every window graph shares one tiny topology  => a minibatch is a dense [B][NN][128] tensor per layer;
+//   * a workgroup owns a tile of ROWS windows (16 for fp32, 32 for bf16): all NN node blocks (ROWS x 128, 8 KB
+//     each, XOR-swizzled) are staged into LDS once per layer, and every per-relation linear of the layer is an
+//     MFMA block-GEMM  acc[dst node] += X_lds[src node] . W  with the weight fragment held in registers and reused
+//     for every destination node of the relation (root weights pre-summed per destination type);
+//   * wave w of the workgroup owns output columns [32w, 32w+32) of every node; MFMA operands use a K-permutation
+//     (lane group g owns a contiguous K range) so each lane's A and B data are 128 contiguous bytes;
+//   * bias, ReLU, base_transform MLP, residual, ReLU-bit stash fused in the epilogue; backward reuses the same
+//     engine on the transposed graph with transposed weight images; weight gradients are one split-K MFMA launch
+//     over all layers with deterministic slab reduction (no float atomics).
+//
+// No CPU fallback exists: every entry point launches HIP kernels or fails loudly.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "mshgnn_plan.hpp"
+
+using namespace mshgnn;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// ------------------------------------------------------------------------------------------------------
+// error handling
+// ------------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int set_err(int code, const std::string& m) { g_err = m; return code; }
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return set_err(MSHGNN_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));       \
+    } while (0)
+
+extern "C" const char* mshgnn_last_error(void) { return g_err.c_str(); }
+extern "C" const char* mshgnn_version(void) { return "mshgnn 0.1 (gfx950)"; }
+
+// ------------------------------------------------------------------------------------------------------
+// precision traits
+// ------------------------------------------------------------------------------------------------------
+template <typename T> struct Prec;
+template <> struct Prec<float> {
+    static constexpr int ROWS = 16, EPC = 4, CPR = 32, RB = 512, NREG = 8, NBV = 16;
+    using Vec = f32x4;
+    struct Acc { f32x4 c[2]; };
+    struct AFrag { f32x4 v[8]; };
+    struct BFrag { f32x4 v[16]; };
+};
+template <> struct Prec<__bf16> {
+    static constexpr int ROWS = 32, EPC = 8, CPR = 16, RB = 256, NREG = 16, NBV = 8;
+    using Vec = bf16x8;
+    struct Acc { f32x16 c; };
+    struct AFrag { bf16x8 v[8]; };
+    struct BFrag { bf16x8 v[8]; };
+};
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(__bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ __bf16 from_f32<__bf16>(float v) { return (__bf16)v; }
+
+// C/D fragment maps (cdna_hip_programming.md section 3): fp32 16x16 blocks: col = lane&15, row = 4*(lane>>4)+j;
+// bf16 32x32 block: col = lane&31, row = (q&3) + 8*(q>>2) + 4*(lane>>5).
+template <typename T> __device__ __forceinline__ int c_row(int q, int lane);
+template <typename T> __device__ __forceinline__ int c_col(int q, int lane);
+template <> __device__ __forceinline__ int c_row<float>(int q, int lane) { return ((lane >> 4) << 2) + (q & 3); }
+template <> __device__ __forceinline__ int c_col<float>(int q, int lane) { return ((q >> 2) << 4) + (lane & 15); }
+template <> __device__ __forceinline__ int c_row<__bf16>(int q, int lane) { return (q & 3) + ((q >> 2) << 3) + ((lane >> 5) << 2); }
+template <> __device__ __forceinline__ int c_col<__bf16>(int q, int lane) { return lane & 31; }
+
+__device__ __forceinline__ float acc_ref(const Prec<float>::Acc& a, int q) { return a.c[q >> 2][q & 3]; }
+__device__ __forceinline__ float acc_ref(const Prec<__bf16>::Acc& a, int q) { return a.c[q]; }
+
+__device__ __forceinline__ void acc_fill(Prec<float>::Acc& a, float v0, float v1) {
+    a.c[0] = f32x4{v0, v0, v0, v0}; a.c[1] = f32x4{v1, v1, v1, v1};
+}
+__device__ __forceinline__ void acc_fill(Prec<__bf16>::Acc& a, float v0, float) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) a.c[q] = v0;
+}
+
+// LDS node-block addressing: block = ROWS rows x 128 elements; 16-byte chunk c of row r lives at chunk slot
+// c ^ (r & 15) (conflict-free ds_read_b128 for rows distinct mod 16 -- guide T2).
+template <typename T> __device__ __forceinline__ int lds_chunk(int blk, int row, int c) {
+    return blk * BLK_BYTES + row * Prec<T>::RB + ((c ^ (row & 15)) << 4);
+}
+template <typename T> __device__ __forceinline__ int lds_elem(int blk, int row, int col) {
+    return lds_chunk<T>(blk, row, col / Prec<T>::EPC) + (col % Prec<T>::EPC) * (int)sizeof(T);
+}
+
+// A fragment: lane (row = lane % ROWS, group g = lane / ROWS) reads 8 consecutive chunks = its contiguous K range.
+template <typename T> __device__ __forceinline__ void load_afrag(typename Prec<T>::AFrag& a, const char* smem, int blk, int lane) {
+    const int row = lane % Prec<T>::ROWS, g = lane / Prec<T>::ROWS;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(smem + lds_chunk<T>(blk, row, g * 8 + t));
+        a.v[t] = __builtin_bit_cast(typename Prec<T>::Vec, v);
+    }
+}
+// B fragment: packed by k_prep so that vector (wave, v, lane) is one contiguous 16-byte load.
+template <typename T> __device__ __forceinline__ void load_bfrag(typename Prec<T>::BFrag& b, const T* wpack, int pack, int wv, int lane) {
+    constexpr int NBV = Prec<T>::NBV;
+    const u32x4* base = reinterpret_cast<const u32x4*>(wpack + (size_t)pack * H * H) + (size_t)wv * NBV * 64 + lane;
+#pragma unroll
+    for (int v = 0; v < NBV; ++v) {
+        const u32x4 x = base[v * 64];
+        b.v[v] = __builtin_bit_cast(typename Prec<T>::Vec, x);
+    }
+}
+
+__device__ __forceinline__ void mac(Prec<float>::Acc& acc, const Prec<float>::AFrag& a, const Prec<float>::BFrag& b) {
+#pragma unroll
+    for (int t4 = 0; t4 < 8; ++t4)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            acc.c[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[t4][x], b.v[t4][x], acc.c[0], 0, 0, 0);
+            acc.c[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[t4][x], b.v[8 + t4][x], acc.c[1], 0, 0, 0);
+        }
+}
+__device__ __forceinline__ void mac(Prec<__bf16>::Acc& acc, const Prec<__bf16>::AFrag& a, const Prec<__bf16>::BFrag& b) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc.c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v[t], b.v[t], acc.c, 0, 0, 0);
+}
+
+// bias for this lane's output column(s)
+template <typename T> __device__ __forceinline__ void acc_init_bias(typename Prec<T>::Acc& a, const float* bias, int wv, int lane) {
+    if (bias == nullptr) { acc_fill(a, 0.f, 0.f); return; }
+    if constexpr (sizeof(T) == 4) acc_fill(a, bias[wv * 32 + (lane & 15)], bias[wv * 32 + 16 + (lane & 15)]);
+    else acc_fill(a, bias[wv * 32 + (lane & 31)], 0.f);
+}
+
+// stage node blocks [n0, n1) of an activation tensor [B][NN][128] into LDS (zero rows beyond the batch)
+template <typename T>
+__device__ __forceinline__ void stage_nodes(char* smem, const T* src, int NN, int n0, int n1, int w0, int B, int tid,
+                                            const int* node_kind /* nullable: skip NK_DEAD */) {
+    constexpr int CPR = Prec<T>::CPR, EPC = Prec<T>::EPC;
+    const int c = tid % CPR, r0 = tid / CPR, RSTEP = 256 / CPR;
+    for (int n = n0; n < n1; ++n) {
+        if (node_kind && node_kind[n] == NK_DEAD) continue;
+        u32x4 v[2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int row = r0 + it * RSTEP;
+            v[it] = u32x4{0, 0, 0, 0};
+            if (w0 + row < B) v[it] = *reinterpret_cast<const u32x4*>(src + ((size_t)(w0 + row) * NN + n) * H + c * EPC);
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int row = r0 + it * RSTEP;
+            *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(n, row, c)) = v[it];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// k_prep: pack weights into MFMA B-fragment images (root-sum, transpose, dtype) and sum biases
+// ------------------------------------------------------------------------------------------------------
+struct PrepArgs {
+    const float* params; void* wpack; float* bias; const PackDesc* packs; const BiasDesc* biases; int n_packs; int n_biases;
+};
+
+template <typename T> __global__ void k_prep(PrepArgs a) {
+    constexpr int EPC = Prec<T>::EPC, NBV = Prec<T>::NBV;
+    const int vec_per_pack = H * H / EPC;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = a.n_packs * vec_per_pack;
+    if (gid < total) {
+        const int pack = gid / vec_per_pack, r = gid % vec_per_pack;
+        const int lane = r % 64, v = (r / 64) % NBV, wv = r / (64 * NBV);
+        const PackDesc pd = a.packs[pack];
+        T out[EPC];
+#pragma unroll
+        for (int x = 0; x < EPC; ++x) {
+            int k, col;
+            if constexpr (sizeof(T) == 4) { k = 32 * (lane >> 4) + 4 * (v & 7) + x; col = wv * 32 + (v >> 3) * 16 + (lane & 15); }
+            else { k = 64 * (lane >> 5) + 8 * v + x; col = wv * 32 + (lane & 31); }
+            float s = 0.f;
+            if (pd.orient == 0) { if (k < pd.ncols) for (int i = 0; i < pd.n_src; ++i) s += a.params[pd.src[i] + (int64_t)col * pd.ld + pd.col0 + k]; }
+            else { for (int i = 0; i < pd.n_src; ++i) s += a.params[pd.src[i] + (int64_t)k * pd.ld + col]; }
+            out[x] = from_f32<T>(s);
+        }
+        T* dst = reinterpret_cast<T*>(a.wpack) + (size_t)gid * EPC;
+#pragma unroll
+        for (int x = 0; x < EPC; ++x) dst[x] = out[x];
+    } else {
+        const int b = gid - total;
+        if (b < a.n_biases * H) {
+            const BiasDesc bd = a.biases[b / H];
+            float s = 0.f;
+            for (int i = 0; i < bd.n_src; ++i) s += a.params[bd.src[i] + (b % H)];
+            a.bias[b] = s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// k_enc_fwd: X_0[node] = relu((mask . x) W_enc^T + b)      (hgnn_c2.py:143-147)
+// one workgroup = MB row blocks (MB*ROWS windows) of ONE node; K streamed in chunks of 128 through LDS
+// ------------------------------------------------------------------------------------------------------
+constexpr int ENC_MB = 4;
+struct EncArgs {
+    const void* x[MSHGNN_MAX_TYPES]; int64_t pitch[MSHGNN_MAX_TYPES]; int vb[MSHGNN_MAX_TYPES];
+    int width[MSHGNN_MAX_TYPES], nodes[MSHGNN_MAX_TYPES], tbase[MSHGNN_MAX_TYPES], nkc[MSHGNN_MAX_TYPES];
+    int pack0[MSHGNN_MAX_TYPES], bias_idx[MSHGNN_MAX_TYPES], sign_off[MSHGNN_MAX_TYPES], wg_prefix[MSHGNN_MAX_TYPES + 1];
+    int n_types, tiles, B, NN;
+    const void* wpack; const float* bias; const uint8_t* signs; void* x0;
+};
+
+// load up to EPC elements starting at p with the widest vector the alignment `vb` (bytes) allows
+template <typename T> __device__ __forceinline__ u32x4 load_chunk(const T* p, int nvalid, int vb) {
+    constexpr int EPC = Prec<T>::EPC;
+    u32x4 r = u32x4{0, 0, 0, 0};
+    if (nvalid <= 0) return r;
+    if (nvalid >= EPC && vb >= 16) return *reinterpret_cast<const u32x4*>(p);
+    if (nvalid >= EPC && vb == 8) {
+        const u32x2 a = reinterpret_cast<const u32x2*>(p)[0], b = reinterpret_cast<const u32x2*>(p)[1];
+        return u32x4{a[0], a[1], b[0], b[1]};
+    }
+    if (nvalid >= EPC && vb == 4) {
+        const unsigned* q = reinterpret_cast<const unsigned*>(p);
+        return u32x4{q[0], q[1], q[2], q[3]};
+    }
+    union { T e[EPC]; u32x4 v; } tmp;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) tmp.e[e] = e < nvalid ? p[e] : from_f32<T>(0.f);
+    return tmp.v;
+}
+// XOR sign bits from EPC sign bytes (0/1) starting at s
+template <typename T> __device__ __forceinline__ u32x4 sign_xor(const uint8_t* s) {
+    if constexpr (sizeof(T) == 4) {
+        const unsigned w = *reinterpret_cast<const unsigned*>(s);
+        return u32x4{(w & 1u) << 31, ((w >> 8) & 1u) << 31, ((w >> 16) & 1u) << 31, ((w >> 24) & 1u) << 31};
+    } else {
+        const unsigned w0 = reinterpret_cast<const unsigned*>(s)[0], w1 = reinterpret_cast<const unsigned*>(s)[1];
+        return u32x4{((w0 & 1u) << 15) | (((w0 >> 8) & 1u) << 31), (((w0 >> 16) & 1u) << 15) | (((w0 >> 24) & 1u) << 31),
+                     ((w1 & 1u) << 15) | (((w1 >> 8) & 1u) << 31), (((w1 >> 16) & 1u) << 15) | (((w1 >> 24) & 1u) << 31)};
+    }
+}
+
+template <typename T> __global__ __launch_bounds__(256) void k_enc_fwd(EncArgs a) {
+    using P = Prec<T>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int t = 0;
+    while (t + 1 < a.n_types && (int)blockIdx.x >= a.wg_prefix[t + 1]) ++t;
+    const int local = blockIdx.x - a.wg_prefix[t];
+    const int node = local / a.tiles, tile = local % a.tiles;
+    const int w0 = tile * ENC_MB * P::ROWS;
+    const T* x = reinterpret_cast<const T*>(a.x[t]);
+    const int64_t pitch = a.pitch[t];
+    const int F = a.width[t], nt = a.nodes[t], nkc = a.nkc[t], vb = a.vb[t];
+    const uint8_t* sg = a.signs + a.sign_off[t] + (size_t)node * nkc * H;
+    const T* wpack = reinterpret_cast<const T*>(a.wpack);
+    const float* bias = a.bias + (size_t)a.bias_idx[t] * H;
+
+    typename P::Acc acc[ENC_MB];
+#pragma unroll
+    for (int m = 0; m < ENC_MB; ++m) acc_init_bias<T>(acc[m], bias, wv, lane);
+    const int c = tid % P::CPR, r0 = tid / P::CPR, RSTEP = 256 / P::CPR;
+    typename P::BFrag bf;
+    typename P::AFrag af;
+    for (int kc = 0; kc < nkc; ++kc) {
+        const int k0 = kc * H + c * P::EPC;
+        const int nvalid = min(P::EPC, F - k0);
+        const u32x4 sx = sign_xor<T>(sg + kc * H + c * P::EPC);
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < ENC_MB; ++m) {
+            u32x4 v[2];
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int row = r0 + it * RSTEP, w = w0 + m * P::ROWS + row;
+                v[it] = u32x4{0, 0, 0, 0};
+                if (w < a.B) v[it] = load_chunk<T>(x + ((size_t)w * nt + node) * pitch + k0, nvalid, vb) ^ sx;
+            }
+#pragma unroll
+            for (int it = 0; it < 2; ++it) *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(m, r0 + it * RSTEP, c)) = v[it];
+        }
+        __syncthreads();
+        load_bfrag<T>(bf, wpack, a.pack0[t] + kc, wv, lane);
+#pragma unroll
+        for (int m = 0; m < ENC_MB; ++m) {
+            if (w0 + m * P::ROWS < a.B) {   // uniform
+                load_afrag<T>(af, smem, m, lane);
+                mac(acc[m], af, bf);
+            }
+        }
+    }
+    T* x0 = reinterpret_cast<T*>(a.x0);
+    const int gnode = a.tbase[t] + node;
+#pragma unroll
+    for (int m = 0; m < ENC_MB; ++m)
+#pragma unroll
+        for (int q = 0; q < P::NREG; ++q) {
+            const int w = w0 + m * P::ROWS + c_row<T>(q, lane), col = wv * 32 + c_col<T>(q, lane);
+            if (w < a.B) x0[((size_t)w * a.NN + gnode) * H + col] = from_f32<T>(fmaxf(acc_ref(acc[m], q), 0.f));
+        }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// k_layer_fwd: one HeteroConv layer + activation / base_transform + residual  (hgnn_c2.py:150-166)
+// ------------------------------------------------------------------------------------------------------
+struct LayerArgs {
+    const void* x_in;      // fwd: X_l ;            bwd: dX_{l+1}
+    void* x_out;           // fwd: X_{l+1} ;        bwd: dX_l
+    unsigned* maskbits;    // relu bits of this layer [B][NN][4]
+    void* hb; void* t1;    // base_transform stash of this layer [B][n_mlp][128]
+    void* dh; void* du;    // bwd only: dH_l [B][NN][128], dU_l [B][n_mlp][128]
+    const void* x_act;     // bwd only: X_0 (encoder relu mask) when GF_ENC_MASK
+    const void* wpack; const float* bias; const int* prog;
+    int B, NN, n_mlp;
+};
+
+// store the relu bits of one accumulator (this wave's 32 columns of ROWS windows of node n)
+template <typename T>
+__device__ __forceinline__ void store_relu_bits(typename Prec<T>::Acc& acc, unsigned* maskbits, int NN, int n, int w0, int B, int wv, int lane) {
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned long long b0 = __ballot(acc.c[0][j] > 0.f), b1 = __ballot(acc.c[1][j] > 0.f);
+            if (lane < 4) {
+                const int row = 4 * lane + j;
+                const unsigned word = (unsigned)((b0 >> (16 * lane)) & 0xffffull) | ((unsigned)((b1 >> (16 * lane)) & 0xffffull) << 16);
+                if (w0 + row < B) maskbits[((size_t)(w0 + row) * NN + n) * 4 + wv] = word;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const unsigned long long b = __ballot(acc.c[q] > 0.f);
+            if (lane < 2) {
+                const int row = (q & 3) + ((q >> 2) << 3) + 4 * lane;
+                if (w0 + row < B) maskbits[((size_t)(w0 + row) * NN + n) * 4 + wv] = (unsigned)(b >> (32 * lane));
+            }
+        }
+    }
+}
+
+template <typename T> __global__ __launch_bounds__(256) void k_layer_fwd(LayerArgs a) {
+    using P = Prec<T>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w0 = blockIdx.x * P::ROWS, B = a.B, NN = a.NN;
+    const T* xin = reinterpret_cast<const T*>(a.x_in);
+    T* xout = reinterpret_cast<T*>(a.x_out);
+    const T* wpack = reinterpret_cast<const T*>(a.wpack);
+
+    stage_nodes<T>(smem, xin, NN, 0, NN, w0, B, tid, nullptr);
+    __syncthreads();
+
+    typename P::Acc acc[GMAX];
+    typename P::BFrag bf;
+    typename P::AFrag af;
+    const int* pg = a.prog;
+    const int ngroups = pg[0];
+    int off = 1;
+    for (int g = 0; g < ngroups; ++g) {
+        const int* gh = pg + off;
+        const int kind = gh[GH_KIND], ns = gh[GH_NSLOTS], nent = gh[GH_NENT], flags = gh[GH_FLAGS];
+        const float* bias = a.bias + (size_t)gh[GH_BIAS] * H;
+#pragma unroll
+        for (int u = 0; u < GMAX; ++u) acc_init_bias<T>(acc[u], bias, wv, lane);
+        const int* ent = gh + GH_SIZE;
+        for (int e = 0; e < nent; ++e) {
+            const int op = ent[e * ENT_INTS], slot = ent[e * ENT_INTS + 1], arg = ent[e * ENT_INTS + 2];
+            if (op == OP_LOADW) { load_bfrag<T>(bf, wpack, arg, wv, lane); continue; }
+            load_afrag<T>(af, smem, arg, lane);
+#pragma unroll
+            for (int u = 0; u < GMAX; ++u) if (u == slot) mac(acc[u], af, bf);
+        }
+        if (kind == KIND_RELU) {
+#pragma unroll
+            for (int u = 0; u < GMAX; ++u) {
+                if (u < ns) {
+                    const int n = gh[GH_NODES + u];
+                    if (flags & GF_STORE_MASK) store_relu_bits<T>(acc[u], a.maskbits, NN, n, w0, B, wv, lane);
+#pragma unroll
+                    for (int q = 0; q < P::NREG; ++q) {
+                        const int row = c_row<T>(q, lane), col = wv * 32 + c_col<T>(q, lane);
+                        float y = fmaxf(acc_ref(acc[u], q), 0.f);
+                        if (flags & GF_RESIDUAL) y += to_f32(*reinterpret_cast<const T*>(smem + lds_elem<T>(n, row, col)));
+                        if (w0 + row < B) xout[((size_t)(w0 + row) * NN + n) * H + col] = from_f32<T>(y);
+                    }
+                }
+            }
+        } else {
+            // base_transform: Y = W2 relu(W1 H + b1) + b2, X <- Y + X   (hgnn_c2.py:117-121,156,161-166)
+            T* hb = reinterpret_cast<T*>(a.hb);
+            T* t1 = reinterpret_cast<T*>(a.t1);
+            __syncthreads();   // every wave is done reading the group's source blocks
+#pragma unroll
+            for (int u = 0; u < GMAX; ++u) {
+                if (u < ns) {
+                    const int n = gh[GH_NODES + u], mi = gh[GH_MLPIDX + u];
+#pragma unroll
+                    for (int q = 0; q < P::NREG; ++q) {
+                        const int row = c_row<T>(q, lane), col = wv * 32 + c_col<T>(q, lane);
+                        const T hv = from_f32<T>(acc_ref(acc[u], q));
+                        *reinterpret_cast<T*>(smem + lds_elem<T>(n, row, col)) = hv;
+                        if (w0 + row < B) hb[((size_t)(w0 + row) * a.n_mlp + mi) * H + col] = hv;
+                    }
+                }
+            }
+            __syncthreads();
+            load_bfrag<T>(bf, wpack, gh[GH_W1], wv, lane);
+            const float* b1 = a.bias + (size_t)gh[GH_B1] * H;
+#pragma unroll
+            for (int u = 0; u < GMAX; ++u) {
+                if (u < ns) {
+                    acc_init_bias<T>(acc[u], b1, wv, lane);
+                    load_afrag<T>(af, smem, gh[GH_NODES + u], lane);
+                    mac(acc[u], af, bf);
+                }
+            }
+            __syncthreads();   // all reads of H done before T1 overwrites the blocks
+#pragma unroll
+            for (int u = 0; u < GMAX; ++u) {
+                if (u < ns) {
+                    const int n = gh[GH_NODES + u], mi = gh[GH_MLPIDX + u];
+#pragma unroll
+                    for (int q = 0; q < P::NREG; ++q) {
+                        const int row = c_row<T>(q, lane), col = wv * 32 + c_col<T>(q, lane);
+                        const T tv = from_f32<T>(fmaxf(acc_ref(acc[u], q), 0.f));
+                        *reinterpret_cast<T*>(smem + lds_elem<T>(n, row, col)) = tv;
+                        if (w0 + row < B) t1[((size_t)(w0 + row) * a.n_mlp + mi) * H + col] = tv;
+                    }
+                }
+            }
+            __syncthreads();
+            load_bfrag<T>(bf, wpack, gh[GH_W2], wv, lane);
+            const float* b2 = a.bias + (size_t)gh[GH_B2] * H;
+#pragma unroll
+            for (int u = 0; u < GMAX; ++u) {
+                if (u < ns) {
+                    const int n = gh[GH_NODES + u];
+                    acc_init_bias<T>(acc[u], b2, wv, lane);
+                    load_afrag<T>(af, smem, n, lane);
+                    mac(acc[u], af, bf);
+#pragma unroll
+                    for (int q = 0; q < P::NREG; ++q) {
+                        const int row = c_row<T>(q, lane), col = wv * 32 + c_col<T>(q, lane);
+                        if (w0 + row < B) {
+                            float y = acc_ref(acc[u], q);
+                            if (flags & GF_RESIDUAL) y += to_f32(xin[((size_t)(w0 + row) * NN + n) * H + col]);
+                            xout[((size_t)(w0 + row) * NN + n) * H + col] = from_f32<T>(y);
+                        }
+                    }
+                }
+            }
+        }
+        off += GH_SIZE + nent * ENT_INTS;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// k_layer_bwd: dH_l from dX_{l+1} (relu bits / base_transform chain), then dX_l on the transposed graph
+// ------------------------------------------------------------------------------------------------------
+template <typename T> __global__ __launch_bounds__(256) void k_layer_bwd(LayerArgs a) {
+    using P = Prec<T>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w0 = blockIdx.x * P::ROWS, B = a.B, NN = a.NN;
+    const T* dxn = reinterpret_cast<const T*>(a.x_in);     // dX_{l+1}
+    T* dxo = reinterpret_cast<T*>(a.x_out);                // dX_l
+    T* dh = reinterpret_cast<T*>(a.dh);
+    const T* wpack = reinterpret_cast<const T*>(a.wpack);
+    const int* pg = a.prog;
+    const int ngroups = pg[0], nmlp = pg[1], w2pack = pg[2], w1pack = pg[3];
+    const int* node_kind = pg + 4;
+    const int* mlp_nodes = pg + 4 + 64;
+
+    // stage 1: dX_{l+1} -> LDS, relu nodes masked (-> dH, also written to global for the weight-gradient kernel)
+    {
+        constexpr int CPR = P::CPR, EPC = P::EPC;
+        const int c = tid % CPR, r0 = tid / CPR, RSTEP = 256 / CPR;
+        for (int n = 0; n < NN; ++n) {
+            const int nk = node_kind[n];
+            if (nk == NK_DEAD) continue;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int row = r0 + it * RSTEP, w = w0 + row;
+                u32x4 v = u32x4{0, 0, 0, 0};
+                if (w < B) {
+                    v = *reinterpret_cast<const u32x4*>(dxn + ((size_t)w * NN + n) * H + c * EPC);
+                    if (nk == NK_RELU) {
+                        const unsigned word = a.maskbits[((size_t)w * NN + n) * 4 + (c * EPC) / 32];
+                        const unsigned bits = word >> ((c * EPC) % 32);
+                        if constexpr (sizeof(T) == 4) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) if (!((bits >> e) & 1u)) v[e] = 0u;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                unsigned m = 0;
+                                if ((bits >> (2 * e)) & 1u) m |= 0x0000ffffu;
+                                if ((bits >> (2 * e + 1)) & 1u) m |= 0xffff0000u;
+                                v[e] &= m;
+                            }
+                        }
+                        *reinterpret_cast<u32x4*>(dh + ((size_t)w * NN + n) * H + c * EPC) = v;
+                    }
+                }
+                *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(n, row, c)) = v;
+            }
+        }
+    }
+    __syncthreads();
+
+    typename P::Acc acc[GMAX];
+    typename P::BFrag bf;
+    typename P::AFrag af;
+
+    if (nmlp > 0) {
+        // dT1 = dY W2 ; dU = dT1 . (T1 > 0) ; dH = dU W1     (backward of base_transform)
+        const T* t1 = reinterpret_cast<const T*>(a.t1);
+        T* du = reinterpret_cast<T*>(a.du);
+        load_bfrag<T>(bf, wpack, w2pack, wv, lane);
+#pragma unroll
+        for (int u = 0; u < GMAX; ++u) {
+            if (u < nmlp) {
+                acc_fill(acc[u], 0.f, 0.f);
+                load_afrag<T>(af, smem, mlp_nodes[u], lane);
+                mac(acc[u], af, bf);
+            }
+        }
+        __syncthreads();   // all reads of dY blocks done
+#pragma unroll
+        for (int u = 0; u < GMAX; ++u) {
+            if (u < nmlp) {
+                const int n = mlp_nodes[u];
+#pragma unroll
+                for (int q = 0; q < P::NREG; ++q) {
+                    const int row = c_row<T>(q, lane), col = wv * 32 + c_col<T>(q, lane);
+                    float v = 0.f;
+                    if (w0 + row < B) {
+                        const float tv = to_f32(t1[((size_t)(w0 + row) * a.n_mlp + u) * H + col]);
+                        v = tv > 0.f ? acc_ref(acc[u], q) : 0.f;
+                        du[((size_t)(w0 + row) * a.n_mlp + u) * H + col] = from_f32<T>(v);
+                    }
+                    *reinterpret_cast<T*>(smem + lds_elem<T>(n, row, col)) = from_f32<T>(v);
+                }
+            }
+        }
+        __syncthreads();
+        load_bfrag<T>(bf, wpack, w1pack, wv, lane);
+#pragma unroll
+        for (int u = 0; u < GMAX; ++u) {
+            if (u < nmlp) {
+                acc_fill(acc[u], 0.f, 0.f);
+                load_afrag<T>(af, smem, mlp_nodes[u], lane);
+                mac(acc[u], af, bf);
+            }
+        }
+        __syncthreads();   // all reads of dU blocks done
+#pragma unroll
+        for (int u = 0; u < GMAX; ++u) {
+            if (u < nmlp) {
+                const int n = mlp_nodes[u];
+#pragma unroll
+                for (int q = 0; q < P::NREG; ++q) {
+                    const int row = c_row<T>(q, lane), col = wv * 32 + c_col<T>(q, lane);
+                    const T hv = from_f32<T>(acc_ref(acc[u], q));
+                    *reinterpret_cast<T*>(smem + lds_elem<T>(n, row, col)) = hv;
+                    if (w0 + row < B) dh[((size_t)(w0 + row) * NN + n) * H + col] = hv;
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // stage 2: dX_l[j] = [dX_{l+1}[j]] + dH_j W_rootsum + sum_r sum_{j->i} dH_i W_rel^r
+    const T* xact = reinterpret_cast<const T*>(a.x_act);
+    int off = 4 + 64 + GMAX;
+    for (int g = 0; g < ngroups; ++g) {
+        const int* gh = pg + off;
+        const int ns = gh[GH_NSLOTS], nent = gh[GH_NENT], flags = gh[GH_FLAGS];
+#pragma unroll
+        for (int u = 0; u < GMAX; ++u) acc_fill(acc[u], 0.f, 0.f);
+        const int* ent = gh + GH_SIZE;
+        for (int e = 0; e < nent; ++e) {
+            const int op = ent[e * ENT_INTS], slot = ent[e * ENT_INTS + 1], arg = ent[e * ENT_INTS + 2];
+            if (op == OP_LOADW) { load_bfrag<T>(bf, wpack, arg, wv, lane); continue; }
+            load_afrag<T>(af, smem, arg, lane);
+#pragma unroll
+            for (int u = 0; u < GMAX; ++u) if (u == slot) mac(acc[u], af, bf);
+        }
+#pragma unroll
+        for (int u = 0; u < GMAX; ++u) {
+            if (u < ns) {
+                const int n = gh[GH_NODES + u];
+#pragma unroll
+                for (int q = 0; q < P::NREG; ++q) {
+                    const int row = c_row<T>(q, lane), col = wv * 32 + c_col<T>(q, lane);
+                    if (w0 + row < B) {
+                        const size_t idx = ((size_t)(w0 + row) * NN + n) * H + col;
+                        float y = acc_ref(acc[u], q);
+                        if (flags & GF_RESIDUAL) y += to_f32(dxn[idx]);
+                        if (flags & GF_ENC_MASK) y = to_f32(xact[idx]) > 0.f ? y : 0.f;
+                        dxo[idx] = from_f32<T>(y);
+                    }
+                }
+            }
+        }
+        off += GH_SIZE + nent * ENT_INTS;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// decoder forward / backward (hgnn_c2.py:176-189) and the wrapper's MSE (gnnLightning.py:633-639)
+// ------------------------------------------------------------------------------------------------------
+struct DecArgs {
+    const void* xl; void* dxl; const float* params; const float* out_mask; float* out; const float* gout; float* slabs;
+    int64_t off_w, off_b; int B, NN, node0, n_out, dout, slab0;
+};
+
+template <typename T> __global__ __launch_bounds__(256) void k_dec_fwd(DecArgs a) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wv;
+    if (row >= (int64_t)a.B * a.n_out) return;
+    const int w = (int)(row / a.n_out), f = (int)(row % a.n_out);
+    const T* x = reinterpret_cast<const T*>(a.xl) + ((size_t)w * a.NN + a.node0 + f) * H;
+    const float x0 = to_f32(x[lane]), x1 = to_f32(x[lane + 64]);
+    const float* W = a.params + a.off_w;
+    for (int d = 0; d < a.dout; ++d) {
+        float s = x0 * W[d * H + lane] + x1 * W[d * H + lane + 64];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+        if (lane == 0) a.out[row * a.dout + d] = (s + a.params[a.off_b + d]) * a.out_mask[f * a.dout + d];
+    }
+}
+
+template <typename T> __global__ __launch_bounds__(256) void k_dec_bwd(DecArgs a) {
+    __shared__ float red[2][8 * H + 8];
+    const int k = threadIdx.x & 127, half = threadIdx.x >> 7;
+    const int64_t rows = (int64_t)a.B * a.n_out;
+    const int64_t per = (rows + gridDim.x - 1) / gridDim.x;
+    const int64_t r_begin = (int64_t)blockIdx.x * per, r_end = min(rows, r_begin + per);
+    const T* xl = reinterpret_cast<const T*>(a.xl);
+    T* dxl = reinterpret_cast<T*>(a.dxl);
+    const float* W = a.params + a.off_w;
+    float wk[8], accw[8], accb[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) { wk[d] = d < a.dout ? W[d * H + k] : 0.f; accw[d] = 0.f; accb[d] = 0.f; }
+    for (int64_t r = r_begin + half; r < r_end; r += 2) {
+        const int w = (int)(r / a.n_out), f = (int)(r % a.n_out);
+        const size_t idx = ((size_t)w * a.NN + a.node0 + f) * H + k;
+        const float x = to_f32(xl[idx]);
+        float dx = 0.f;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            if (d < a.dout) {
+                const float g = a.gout[r * a.dout + d] * a.out_mask[f * a.dout + d];
+                accw[d] += g * x; accb[d] += g; dx += g * wk[d];
+            }
+        }
+        dxl[idx] = from_f32<T>(dx);
+    }
+#pragma unroll
+    for (int d = 0; d < 8; ++d) { red[half][d * H + k] = accw[d]; if (k == 0) red[half][8 * H + d] = accb[d]; }
+    __syncthreads();
+    float* slab = a.slabs + (size_t)(a.slab0 + blockIdx.x) * SLAB_FLOATS;
+    if (half == 0) {
+#pragma unroll
+        for (int d = 0; d < 8; ++d) if (d < a.dout) slab[d * H + k] = red[0][d * H + k] + red[1][d * H + k];
+        if (k < a.dout) slab[H * H + k] = red[0][8 * H + k] + red[1][8 * H + k];
+    }
+}
+
+__global__ void k_mse(const float* out, const float* y, int64_t n, float* loss, float* gout) {
+    __shared__ float red[4];
+    float s = 0.f;
+    const float inv = 1.0f / (float)n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float dlt = out[i] - y[i];
+        s += dlt * dlt;
+        if (gout) gout[i] = 2.0f * dlt * inv;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// k_gradw: all weight gradients of the step as one split-K MFMA launch.  dW[o][k] = sum_w P[w][o] Q[w][k]
+// ------------------------------------------------------------------------------------------------------
+struct GradwArgs {
+    const char* ws; size_t buf_off[BUF_COUNT];
+    const void* x[MSHGNN_MAX_TYPES]; int64_t pitch[MSHGNN_MAX_TYPES]; int nodes[MSHGNN_MAX_TYPES];
+    const int* items; const int* targets; const int* wg2t; const uint8_t* signs; float* slabs; int B;
+};
+constexpr int GW_KW = 32;       // windows per staged chunk
+constexpr int GW_PITCH = 144;   // floats per LDS row (bank-conflict-free column reads)
+
+template <typename T> __global__ __launch_bounds__(256) void k_gradw(GradwArgs a) {
+    __shared__ __attribute__((aligned(16))) float Ps[GW_KW * GW_PITCH];
+    __shared__ __attribute__((aligned(16))) float Qs[GW_KW * GW_PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wv >> 1, wc = wv & 1;
+    const int tg = a.wg2t[blockIdx.x];
+    const int* th = a.targets + tg * TGT_INTS;
+    const int it0 = th[0], it1 = th[1], part = blockIdx.x - th[2], nparts = th[3], bias_flag = th[4];
+    const int nchunks = (a.B + GW_KW - 1) / GW_KW;
+    const int ch0 = (int)((int64_t)part * nchunks / nparts), ch1 = (int)((int64_t)(part + 1) * nchunks / nparts);
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+    f32x4 bsum = f32x4{0, 0, 0, 0};
+    const int c = tid & 31, r0 = tid >> 5;   // staging: 32 chunks of 4 floats per row, 8 rows per pass
+    for (int ch = ch0; ch < ch1; ++ch) {
+        const int w0 = ch * GW_KW;
+        for (int it = it0; it < it1; ++it) {
+            const int* im = a.items + it * ITEM_INTS;
+            const T* pb = reinterpret_cast<const T*>(a.ws + a.buf_off[im[0]]);
+            const int ps = im[1], po = im[2], qbuf = im[3], qs = im[4], qo = im[5], qc0 = im[6], qn = im[7], so = im[8];
+            f32x4 pv[4], qv[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int row = r0 + 8 * p, w = w0 + row;
+                pv[p] = f32x4{0, 0, 0, 0}; qv[p] = f32x4{0, 0, 0, 0};
+                if (w < a.B) {
+                    const T* pp = pb + (size_t)w * ps + po + c * 4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pv[p][e] = to_f32(pp[e]);
+                    if (qs >= 0) {
+                        const T* qq = reinterpret_cast<const T*>(a.ws + a.buf_off[qbuf]) + (size_t)w * qs + qo + c * 4;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) qv[p][e] = to_f32(qq[e]);
+                    } else {
+                        const int t = qbuf - BUF_IN;
+                        const T* qq = reinterpret_cast<const T*>(a.x[t]) + ((size_t)w * a.nodes[t] + qo) * a.pitch[t] + qc0 + c * 4;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (c * 4 + e < qn) { const float v = to_f32(qq[e]); qv[p][e] = a.signs[so + c * 4 + e] ? -v : v; }
+                    }
+                }
+            }
+            __syncthreads();   // previous MFMA phase finished reading Ps/Qs
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int row = r0 + 8 * p;
+                *reinterpret_cast<f32x4*>(&Ps[row * GW_PITCH + c * 4]) = pv[p];
+                *reinterpret_cast<f32x4*>(&Qs[row * GW_PITCH + c * 4]) = qv[p];
+                if (bias_flag) bsum += pv[p];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int ks = 0; ks < GW_KW / 4; ++ks) {
+                const int row = 4 * ks + (lane >> 4);
+                float af[4], bq[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    af[i] = Ps[row * GW_PITCH + wr * 64 + i * 16 + (lane & 15)];
+                    bq[i] = Qs[row * GW_PITCH + wc * 64 + i * 16 + (lane & 15)];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bq[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+    float* slab = a.slabs + (size_t)blockIdx.x * SLAB_FLOATS;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int o = wr * 64 + i * 16 + ((lane >> 4) << 2) + q, k = wc * 64 + j * 16 + (lane & 15);
+                slab[o * H + k] = acc[i][j][q];
+            }
+    if (bias_flag) {
+        __syncthreads();
+        *reinterpret_cast<f32x4*>(&Ps[r0 * GW_PITCH + c * 4]) = bsum;
+        __syncthreads();
+        if (tid < H) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) s += Ps[r * GW_PITCH + tid];
+            slab[H * H + tid] = s;
+        }
+    }
+}
+
+// k_finalize: sum split-K slabs in fixed order into the flat gradient buffer (every parameter written once)
+struct FinArgs { const int* fin; const int* targets; const float* slabs; float* grad; int dec_slab0; };
+
+__global__ __launch_bounds__(256) void k_finalize(FinArgs a) {
+    const int* f = a.fin + blockIdx.x * FIN_INTS;
+    const int64_t dst = (int64_t)(unsigned)f[0] | ((int64_t)f[1] << 32);
+    const int rows = f[2], cols = f[3], ld = f[4], tg = f[5], kind = f[6];
+    const int RPB = (rows + gridDim.y - 1) / gridDim.y;
+    const int r0 = blockIdx.y * RPB, r1 = min(rows, r0 + RPB);
+    int s0 = 0, s1 = 0;
+    if (kind == FIN_MATRIX || kind == FIN_BIAS) { s0 = a.targets[tg * TGT_INTS + 2]; s1 = s0 + a.targets[tg * TGT_INTS + 3]; }
+    else if (kind == FIN_DEC_W || kind == FIN_DEC_B) { s0 = a.dec_slab0; s1 = s0 + NWG_DEC; }
+    const int n = (r1 - r0) * cols;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int r = r0 + i / cols, cidx = i % cols;
+        float s = 0.f;
+        if (kind == FIN_MATRIX || kind == FIN_DEC_W) { for (int sl = s0; sl < s1; ++sl) s += a.slabs[(size_t)sl * SLAB_FLOATS + r * H + cidx]; }
+        else if (kind == FIN_BIAS || kind == FIN_DEC_B) { for (int sl = s0; sl < s1; ++sl) s += a.slabs[(size_t)sl * SLAB_FLOATS + H * H + cidx]; }
+        a.grad[dst + (int64_t)r * ld + cidx] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// plan object + C-ABI
+// ------------------------------------------------------------------------------------------------------
+struct mshgnn_plan {
+    HostPlan hp;
+    int* d_tables = nullptr; uint8_t* d_signs = nullptr; float* d_out_mask = nullptr;
+    PackDesc* d_packs = nullptr; BiasDesc* d_biases = nullptr;
+    bool attr_set = false;
+};
+
+template <typename K> static int set_lds_attr(K kernel, int bytes) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    return MSHGNN_OK;
+}
+
+extern "C" int mshgnn_plan_create(const mshgnn_desc* desc, mshgnn_plan** out) {
+    if (!out) return set_err(MSHGNN_EINVAL, "plan_out is null");
+    *out = nullptr;
+    mshgnn_plan* p = new (std::nothrow) mshgnn_plan();
+    if (!p) return set_err(MSHGNN_ENOMEM, "out of host memory");
+    if (!compile_plan(desc, p->hp)) {
+        const std::string m = p->hp.err; delete p;
+        const bool unsup = m.find("supports") != std::string::npos || m.find("not supported") != std::string::npos || m.find("too many") != std::string::npos;
+        return set_err(unsup ? MSHGNN_EUNSUPPORTED : MSHGNN_EINVAL, m);
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        delete p; return set_err(MSHGNN_EHIP, "no HIP device: the MS-HGNN engine has no CPU fallback");
+    }
+    HostPlan& hp = p->hp;
+    auto up = [&](void** dptr, const void* src, size_t bytes) -> int {
+        HIPCHK(hipMalloc(dptr, std::max<size_t>(bytes, 16)));
+        if (bytes) HIPCHK(hipMemcpy(*dptr, src, bytes, hipMemcpyHostToDevice));
+        return MSHGNN_OK;
+    };
+    int rc;
+    if ((rc = up((void**)&p->d_tables, hp.tables.data(), hp.tables.size() * 4)) != 0 ||
+        (rc = up((void**)&p->d_signs, hp.signs.data(), hp.signs.size())) != 0 ||
+        (rc = up((void**)&p->d_out_mask, hp.out_mask_f.data(), hp.out_mask_f.size() * 4)) != 0 ||
+        (rc = up((void**)&p->d_packs, hp.packs.data(), hp.packs.size() * sizeof(PackDesc))) != 0 ||
+        (rc = up((void**)&p->d_biases, hp.biases.data(), hp.biases.size() * sizeof(BiasDesc))) != 0) {
+        mshgnn_plan_destroy(p); return rc;
+    }
+    const int lds = hp.NN * BLK_BYTES;
+    if (hp.d.dtype == MSHGNN_F32) {
+        if ((rc = set_lds_attr(k_layer_fwd<float>, lds)) || (rc = set_lds_attr(k_layer_bwd<float>, lds)) ||
+            (rc = set_lds_attr(k_enc_fwd<float>, ENC_MB * BLK_BYTES))) { mshgnn_plan_destroy(p); return rc; }
+    } else {
+        if ((rc = set_lds_attr(k_layer_fwd<__bf16>, lds)) || (rc = set_lds_attr(k_layer_bwd<__bf16>, lds)) ||
+            (rc = set_lds_attr(k_enc_fwd<__bf16>, ENC_MB * BLK_BYTES))) { mshgnn_plan_destroy(p); return rc; }
+    }
+    *out = p;
+    return MSHGNN_OK;
+}
+
+extern "C" void mshgnn_plan_destroy(mshgnn_plan* p) {
+    if (!p) return;
+    if (p->d_tables) (void)hipFree(p->d_tables);
+    if (p->d_signs) (void)hipFree(p->d_signs);
+    if (p->d_out_mask) (void)hipFree(p->d_out_mask);
+    if (p->d_packs) (void)hipFree(p->d_packs);
+    if (p->d_biases) (void)hipFree(p->d_biases);
+    delete p;
+}
+
+extern "C" int mshgnn_plan_info(const mshgnn_plan* p, mshgnn_info* info) {
+    if (!p || !info) return set_err(MSHGNN_EINVAL, "null argument");
+    *info = p->hp.info;
+    return MSHGNN_OK;
+}
+
+// host-only plan compilation (no GPU needed): used by the CPU test-suite to check the plan compiler
+extern "C" int mshgnn_plan_compile_host(const mshgnn_desc* desc, mshgnn_info* info, int32_t* n_tables_out) {
+    HostPlan hp;
+    if (!compile_plan(desc, hp)) return set_err(MSHGNN_EINVAL, hp.err);
+    if (info) *info = hp.info;
+    if (n_tables_out) *n_tables_out = (int32_t)hp.tables.size();
+    return MSHGNN_OK;
+}
+
+extern "C" int mshgnn_workspace_layout(const mshgnn_plan* p, int64_t batch, int training, mshgnn_ws_layout* out) {
+    if (!p || !out || batch < 1) return set_err(MSHGNN_EINVAL, "bad argument to mshgnn_workspace_layout");
+    layout_workspace(p->hp, batch, training, out);
+    return MSHGNN_OK;
+}
+
+static int vec_bytes(const void* base, int64_t pitch_elems, int esize) {
+    const uint64_t a = (uint64_t)(uintptr_t)base | (uint64_t)(pitch_elems * esize);
+    if ((a & 15) == 0) return 16;
+    if ((a & 7) == 0) return 8;
+    if ((a & 3) == 0) return 4;
+    return esize;
+}
+
+template <typename T>
+static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, float* out,
+                        char* ws, int64_t batch, int training, hipStream_t st) {
+    const HostPlan& hp = p->hp;
+    const mshgnn_desc& d = hp.d;
+    mshgnn_ws_layout lay; layout_workspace(hp, batch, training, &lay);
+    const int B = (int)batch;
+    // 1. weight images
+    {
+        PrepArgs a{params, ws + lay.wpack, reinterpret_cast<float*>(ws + lay.bias), p->d_packs, p->d_biases, (int)hp.packs.size(), (int)hp.biases.size()};
+        const int64_t total = (int64_t)hp.packs.size() * (H * H / Prec<T>::EPC) + (int64_t)hp.biases.size() * H;
+        hipLaunchKernelGGL(k_prep<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
+    }
+    // 2. encoder
+    {
+        EncArgs a{};
+        a.n_types = hp.NT; a.B = B; a.NN = hp.NN; a.tiles = (B + ENC_MB * Prec<T>::ROWS - 1) / (ENC_MB * Prec<T>::ROWS);
+        a.wg_prefix[0] = 0;
+        for (int t = 0; t < hp.NT; ++t) {
+            a.x[t] = x[t]; a.pitch[t] = x_pitch ? x_pitch[t] : d.type_width[t];
+            if (a.pitch[t] < d.type_width[t]) return set_err(MSHGNN_EINVAL, "x_pitch smaller than the feature width");
+            a.vb[t] = vec_bytes(x[t], a.pitch[t], (int)sizeof(T));
+            a.width[t] = d.type_width[t]; a.nodes[t] = d.type_nodes[t]; a.tbase[t] = hp.type_base[t]; a.nkc[t] = hp.enc_nkc[t];
+            a.pack0[t] = hp.pack_enc_base[t]; a.bias_idx[t] = hp.bias_enc[t]; a.sign_off[t] = hp.sign_off[t];
+            a.wg_prefix[t + 1] = a.wg_prefix[t] + d.type_nodes[t] * a.tiles;
+        }
+        a.wpack = ws + lay.wpack; a.bias = reinterpret_cast<const float*>(ws + lay.bias); a.signs = p->d_signs; a.x0 = ws + lay.x[0];
+        hipLaunchKernelGGL(k_enc_fwd<T>, dim3(a.wg_prefix[hp.NT]), dim3(256), ENC_MB * BLK_BYTES, st, a);
+    }
+    // 3. layers
+    const int tiles = (B + Prec<T>::ROWS - 1) / Prec<T>::ROWS;
+    for (int l = 0; l < hp.L; ++l) {
+        LayerArgs a{};
+        a.x_in = ws + lay.x[l]; a.x_out = ws + lay.x[l + 1]; a.maskbits = reinterpret_cast<unsigned*>(ws + lay.mask[l]);
+        a.hb = ws + lay.hb[l]; a.t1 = ws + lay.t1[l]; a.wpack = ws + lay.wpack; a.bias = reinterpret_cast<const float*>(ws + lay.bias);
+        a.prog = p->d_tables + hp.fwd_prog_off[l]; a.B = B; a.NN = hp.NN; a.n_mlp = std::max(1, hp.n_mlp);
+        hipLaunchKernelGGL(k_layer_fwd<T>, dim3(tiles), dim3(256), hp.NN * BLK_BYTES, st, a);
+    }
+    // 4. decoder
+    {
+        DecArgs a{};
+        a.xl = ws + lay.x[hp.L]; a.params = params; a.out_mask = p->d_out_mask; a.out = out; a.off_w = d.off_dec_w; a.off_b = d.off_dec_b;
+        a.B = B; a.NN = hp.NN; a.node0 = hp.type_base[d.out_type]; a.n_out = d.type_nodes[d.out_type]; a.dout = d.out_channels;
+        const int64_t rows = (int64_t)B * a.n_out;
+        hipLaunchKernelGGL(k_dec_fwd<T>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, a);
+    }
+    HIPCHK(hipGetLastError());
+    return MSHGNN_OK;
+}
+
+template <typename T>
+static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, const float* gout,
+                         float* gparams, char* ws, int64_t batch, hipStream_t st) {
+    const HostPlan& hp = p->hp;
+    const mshgnn_desc& d = hp.d;
+    mshgnn_ws_layout lay; layout_workspace(hp, batch, 1, &lay);
+    const int B = (int)batch;
+    {
+        DecArgs a{};
+        a.xl = ws + lay.x[hp.L]; a.dxl = ws + lay.dx[hp.L]; a.params = params; a.out_mask = p->d_out_mask; a.gout = gout;
+        a.slabs = reinterpret_cast<float*>(ws + lay.slabs); a.off_w = d.off_dec_w; a.off_b = d.off_dec_b;
+        a.B = B; a.NN = hp.NN; a.node0 = hp.type_base[d.out_type]; a.n_out = d.type_nodes[d.out_type]; a.dout = d.out_channels; a.slab0 = hp.dec_slab0;
+        hipLaunchKernelGGL(k_dec_bwd<T>, dim3(NWG_DEC), dim3(256), 0, st, a);
+    }
+    const int tiles = (B + Prec<T>::ROWS - 1) / Prec<T>::ROWS;
+    for (int l = hp.L - 1; l >= 0; --l) {
+        LayerArgs a{};
+        a.x_in = ws + lay.dx[l + 1]; a.x_out = ws + lay.dx[l]; a.maskbits = reinterpret_cast<unsigned*>(ws + lay.mask[l]);
+        a.hb = ws + lay.hb[l]; a.t1 = ws + lay.t1[l]; a.dh = ws + lay.dh[l]; a.du = ws + lay.du[l]; a.x_act = ws + lay.x[0];
+        a.wpack = ws + lay.wpack; a.bias = reinterpret_cast<const float*>(ws + lay.bias);
+        a.prog = p->d_tables + hp.bwd_prog_off[l]; a.B = B; a.NN = hp.NN; a.n_mlp = std::max(1, hp.n_mlp);
+        hipLaunchKernelGGL(k_layer_bwd<T>, dim3(tiles), dim3(256), hp.NN * BLK_BYTES, st, a);
+    }
+    {
+        GradwArgs a{};
+        a.ws = ws;
+        for (int l = 0; l <= hp.L; ++l) { a.buf_off[BUF_X + l] = lay.x[l]; a.buf_off[BUF_DX + l] = lay.dx[l]; }
+        for (int l = 0; l < hp.L; ++l) { a.buf_off[BUF_DH + l] = lay.dh[l]; a.buf_off[BUF_HB + l] = lay.hb[l]; a.buf_off[BUF_T1 + l] = lay.t1[l]; a.buf_off[BUF_DU + l] = lay.du[l]; }
+        for (int t = 0; t < hp.NT; ++t) { a.x[t] = x[t]; a.pitch[t] = x_pitch ? x_pitch[t] : d.type_width[t]; a.nodes[t] = d.type_nodes[t]; }
+        a.items = p->d_tables + hp.item_off; a.targets = p->d_tables + hp.tgt_off; a.wg2t = p->d_tables + hp.wg2t_off;
+        a.signs = p->d_signs; a.slabs = reinterpret_cast<float*>(ws + lay.slabs); a.B = B;
+        hipLaunchKernelGGL(k_gradw<T>, dim3(hp.n_wg_gradw), dim3(256), 0, st, a);
+    }
+    {
+        FinArgs a{p->d_tables + hp.fin_off, p->d_tables + hp.tgt_off, reinterpret_cast<const float*>(ws + lay.slabs), gparams, hp.dec_slab0};
+        hipLaunchKernelGGL(k_finalize, dim3(hp.n_fin, 8), dim3(256), 0, st, a);
+    }
+    HIPCHK(hipGetLastError());
+    return MSHGNN_OK;
+}
+
+extern "C" int mshgnn_forward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, float* out,
+                              void* workspace, int64_t batch, int training, void* stream) {
+    if (!p || !x || !params || !out || !workspace) return set_err(MSHGNN_EINVAL, "null argument to mshgnn_forward");
+    if (batch < 1 || batch > (1 << 24)) return set_err(MSHGNN_EINVAL, "batch must be in [1, 2^24]");
+    for (int t = 0; t < p->hp.NT; ++t) if (!x[t]) return set_err(MSHGNN_EINVAL, "null input tensor");
+    if (p->hp.d.dtype == MSHGNN_F32) return forward_impl<float>(p, x, x_pitch, params, out, (char*)workspace, batch, training, (hipStream_t)stream);
+    return forward_impl<__bf16>(p, x, x_pitch, params, out, (char*)workspace, batch, training, (hipStream_t)stream);
+}
+
+extern "C" int mshgnn_backward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, const float* grad_out,
+                               float* grad_params, void* workspace, int64_t batch, void* stream) {
+    if (!p || !x || !params || !grad_out || !grad_params || !workspace) return set_err(MSHGNN_EINVAL, "null argument to mshgnn_backward");
+    if (batch < 1 || batch > (1 << 24)) return set_err(MSHGNN_EINVAL, "batch must be in [1, 2^24]");
+    if (p->hp.d.dtype == MSHGNN_F32) return backward_impl<float>(p, x, x_pitch, params, grad_out, grad_params, (char*)workspace, batch, (hipStream_t)stream);
+    return backward_impl<__bf16>(p, x, x_pitch, params, grad_out, grad_params, (char*)workspace, batch, (hipStream_t)stream);
+}
+
+extern "C" int mshgnn_mse_loss(const float* out, const float* y, int64_t n, float* loss_out, float* grad_out, void* stream) {
+    if (!out || !y || !loss_out || n < 1) return set_err(MSHGNN_EINVAL, "bad argument to mshgnn_mse_loss");
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipMemsetAsync(loss_out, 0, sizeof(float), st));
+    const int blocks = (int)std::min<int64_t>((n + 255) / 256, 1024);
+    hipLaunchKernelGGL(k_mse, dim3(blocks), dim3(256), 0, st, out, y, n, loss_out, grad_out);
+    HIPCHK(hipGetLastError());
+    return MSHGNN_OK;
+}

@@ -1,0 +1,494 @@
+// Host-side plan compiler of the MS-HGNN engine: lowers (topology, model dims, symmetry masks, parameter
+// offsets) to the integer tables the HIP kernels interpret.  No HIP calls in this file, so it is testable
+// on a machine without a GPU (mshgnn_plan_create builds it, then uploads the tables).
+//
+// Path restated: GRF_HGNN_C2.forward hgnn_c2.py:133-182 / GRF_HGNN_K4.forward hgnn_k4.py:146-196 /
+// GRF_HGNN.forward hgnn.py:57-62 with PyG-2.5.0 HeteroConv/GraphConv semantics:
+//   H_d = sum_{r=(s,.,d)} [ W_rel^r Agg_r(X_s) + b_rel^r + W_root^r X_d ]
+// lowered to its algorithmic minimum:  H_d[i] = (sum_r W_root^r) X_d[i] + sum_r b_rel^r
+//                                              + sum_r sum_{j->i in r} W_rel^r X_s[j]
+// Node types whose layer output cannot reach the decoder (e.g. base/joint in the last layer) are dead and
+// skipped in forward and backward; their parameters get exact-zero gradients (the reference leaves them None).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mshgnn.h"
+
+namespace mshgnn {
+
+constexpr int H = 128;            // hidden width the kernels are built for
+constexpr int GMAX = 12;          // accumulator slots (dst nodes) a workgroup keeps live at once
+constexpr int BLK_BYTES = 8192;   // one LDS node block: ROWS windows x 128 features
+constexpr int MAX_L = 16;
+constexpr int LDS_LIMIT = 160 * 1024;
+constexpr int SLAB_FLOATS = H * H + H;   // one split-K partial: 128x128 matrix + 128 column sums
+constexpr int NWG_DEC = 64;              // workgroups of the decoder backward (each writes one slab)
+
+enum { OP_LOADW = 0, OP_MAC = 1 };
+enum { KIND_RELU = 0, KIND_MLP = 1 };
+enum { NK_DEAD = 0, NK_RELU = 1, NK_MLP = 2 };
+enum { GF_RESIDUAL = 1, GF_ENC_MASK = 2, GF_STORE_MASK = 4 };
+
+// group header layout (ints)
+enum { GH_KIND = 0, GH_NSLOTS, GH_BIAS, GH_NENT, GH_W1, GH_W2, GH_B1, GH_B2, GH_FLAGS, GH_PAD0, GH_PAD1, GH_PAD2,
+       GH_NODES = 12, GH_MLPIDX = 12 + GMAX, GH_SIZE = 12 + 2 * GMAX };
+constexpr int ENT_INTS = 4;   // {op, slot, arg, reserved}
+
+// buffer ids used by weight-gradient items
+enum { BUF_X = 0, BUF_DX = 17, BUF_DH = 34, BUF_HB = 50, BUF_T1 = 66, BUF_DU = 82, BUF_IN = 98, BUF_COUNT = 102 };
+constexpr int ITEM_INTS = 10;   // p_buf p_stride p_off q_buf q_stride q_off q_col0 q_ncols sign_off pad
+constexpr int TGT_INTS = 8;     // item_begin item_end wg_begin wg_count bias_flag pad..
+constexpr int FIN_INTS = 8;     // dst_lo dst_hi rows cols dst_ld target kind pad
+enum { FIN_MATRIX = 0, FIN_BIAS = 1, FIN_ZERO = 2, FIN_DEC_W = 3, FIN_DEC_B = 4 };
+
+struct PackDesc {       // one packed 128x128 B-operand image (weights as the MFMA wants them)
+    int orient;         // 0: B[k][c] = W[c][k]  (forward: out = A W^T)   1: B[k][c] = W[k][c]  (backward: dA = dH W)
+    int n_src;          // matrices summed into it (root-sum over relations)
+    int64_t src[8];
+    int ld;             // row pitch of the source matrices
+    int col0;           // first source column (encoder K chunk)
+    int ncols;          // valid source columns from col0 (zero beyond)
+};
+struct BiasDesc { int n_src; int64_t src[8]; };
+
+struct HostPlan {
+    mshgnn_desc d{};
+    std::vector<int32_t> rel_src, rel_dst, rel_mean, rel_edge_off, edges;
+    std::vector<float> in_mask[MSHGNN_MAX_TYPES], out_mask;
+    std::vector<int64_t> off_enc_w, off_enc_b, off_rel_w, off_rel_b, off_root_w;
+    int L = 0, NT = 0, NR = 0, NN = 0;
+    int type_base[MSHGNN_MAX_TYPES + 1]{};
+    int node_type[64]{};
+    int n_mlp = 0;
+    int rows = 16;                 // windows per tile
+    int esize = 4;                 // bytes per stored element
+    bool live[MAX_L][MSHGNN_MAX_TYPES]{};     // layer output of type t reaches the decoder
+    bool need_dx[MAX_L][MSHGNN_MAX_TYPES]{};  // dX_l[t] must be produced
+    // packed operands
+    std::vector<PackDesc> packs;
+    std::vector<BiasDesc> biases;
+    std::vector<int> pack_root[2], pack_rel[2];   // [orient][l*NT+t], [orient][l*NR+r]
+    int pack_mlp[2][2]{};                         // [orient][0|1]
+    std::vector<int> pack_enc_base; std::vector<int> enc_nkc;   // per type
+    std::vector<int> bias_layer;                  // [l*NT+t]
+    int bias_mlp[2]{}; std::vector<int> bias_enc;
+    // sign tables (uint8, [n_t][nkc*128]) concatenated; offset per type
+    std::vector<uint8_t> signs; std::vector<int> sign_off;
+    // programs
+    std::vector<int32_t> tables;                  // everything below lives here (device copy = same layout)
+    int fwd_prog_off[MAX_L]{}, bwd_prog_off[MAX_L]{};
+    int item_off = 0, n_items = 0, tgt_off = 0, n_targets = 0, wg2t_off = 0, n_wg_gradw = 0;
+    int fin_off = 0, n_fin = 0;
+    int enc_tile_mb = 4;
+    int dec_slab0 = 0, n_slabs = 0;
+    std::vector<float> out_mask_f;
+    mshgnn_info info{};
+    std::string err;
+};
+
+inline bool fail(HostPlan& p, const std::string& m) { p.err = m; return false; }
+
+inline int add_pack(HostPlan& p, int orient, const std::vector<int64_t>& src, int ld, int col0, int ncols) {
+    PackDesc q{}; q.orient = orient; q.n_src = (int)src.size(); q.ld = ld; q.col0 = col0; q.ncols = ncols;
+    for (size_t i = 0; i < src.size(); ++i) q.src[i] = src[i];
+    p.packs.push_back(q); return (int)p.packs.size() - 1;
+}
+inline int add_bias(HostPlan& p, const std::vector<int64_t>& src) {
+    BiasDesc b{}; b.n_src = (int)src.size(); for (size_t i = 0; i < src.size(); ++i) b.src[i] = src[i];
+    p.biases.push_back(b); return (int)p.biases.size() - 1;
+}
+
+inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
+    if (!din) return fail(p, "null descriptor");
+    p.d = *din;
+    const mshgnn_desc& d = p.d;
+    if (d.n_types < 1 || d.n_types > MSHGNN_MAX_TYPES) return fail(p, "n_types must be 1..4");
+    if (d.hidden != H) return fail(p, "this build supports hidden_channels == 128 only");
+    if (d.num_layers < 1 || d.num_layers > MAX_L) return fail(p, "num_layers must be 1..16");
+    if (d.n_rel < 1 || d.n_rel > 64) return fail(p, "n_rel must be 1..64");
+    if (d.dtype != MSHGNN_F32 && d.dtype != MSHGNN_BF16) return fail(p, "dtype must be MSHGNN_F32 or MSHGNN_BF16");
+    if (d.out_type < 0 || d.out_type >= d.n_types) return fail(p, "out_type out of range");
+    if (d.out_channels < 1 || d.out_channels > 8) return fail(p, "out_channels must be 1..8");
+    if (!d.rel_src || !d.rel_dst || !d.rel_mean || !d.rel_edge_off || !d.edges) return fail(p, "null relation arrays");
+    if (!d.off_enc_w || !d.off_enc_b || !d.off_rel_w || !d.off_rel_b || !d.off_root_w) return fail(p, "null offset arrays");
+    p.L = d.num_layers; p.NT = d.n_types; p.NR = d.n_rel;
+    const int L = p.L, NT = p.NT, NR = p.NR;
+    const bool has_mlp = (d.flags & MSHGNN_FLAG_BASE_MLP) != 0;
+    const bool residual = (d.flags & MSHGNN_FLAG_RESIDUAL) != 0;
+    if (has_mlp && (d.mlp_type < 0 || d.mlp_type >= NT)) return fail(p, "mlp_type out of range");
+    p.type_base[0] = 0;
+    for (int t = 0; t < NT; ++t) {
+        if (d.type_nodes[t] < 1) return fail(p, "every node type needs >= 1 node");
+        if (d.type_width[t] < 1) return fail(p, "every node type needs input width >= 1");
+        p.type_base[t + 1] = p.type_base[t] + d.type_nodes[t];
+        for (int i = 0; i < d.type_nodes[t]; ++i) p.node_type[p.type_base[t] + i] = t;
+    }
+    p.NN = p.type_base[NT];
+    if ((int64_t)p.NN * BLK_BYTES > LDS_LIMIT)
+        return fail(p, "topology has too many nodes per window for the LDS-resident layer kernel (max 20)");
+    p.rows = d.dtype == MSHGNN_F32 ? 16 : 32;
+    p.esize = d.dtype == MSHGNN_F32 ? 4 : 2;
+    p.n_mlp = has_mlp ? d.type_nodes[d.mlp_type] : 0;
+    if (p.n_mlp > GMAX) return fail(p, "base_transform type has more than 12 nodes");
+
+    // deep copies
+    p.rel_src.assign(d.rel_src, d.rel_src + NR); p.rel_dst.assign(d.rel_dst, d.rel_dst + NR);
+    p.rel_mean.assign(d.rel_mean, d.rel_mean + NR); p.rel_edge_off.assign(d.rel_edge_off, d.rel_edge_off + NR + 1);
+    const int E = p.rel_edge_off[NR];
+    if (p.rel_edge_off[0] != 0 || E < 0) return fail(p, "bad rel_edge_off");
+    p.edges.assign(d.edges, d.edges + 2 * (size_t)E);
+    p.off_enc_w.assign(d.off_enc_w, d.off_enc_w + NT); p.off_enc_b.assign(d.off_enc_b, d.off_enc_b + NT);
+    p.off_rel_w.assign(d.off_rel_w, d.off_rel_w + (size_t)L * NR); p.off_rel_b.assign(d.off_rel_b, d.off_rel_b + (size_t)L * NR);
+    p.off_root_w.assign(d.off_root_w, d.off_root_w + (size_t)L * NR);
+    std::vector<bool> has_in(NT, false);
+    for (int r = 0; r < NR; ++r) {
+        const int s = p.rel_src[r], t = p.rel_dst[r];
+        if (s < 0 || s >= NT || t < 0 || t >= NT) return fail(p, "relation type index out of range");
+        if (p.rel_edge_off[r + 1] < p.rel_edge_off[r]) return fail(p, "rel_edge_off must be non-decreasing");
+        has_in[t] = true;
+        std::vector<int> deg(d.type_nodes[t], 0);
+        for (int e = p.rel_edge_off[r]; e < p.rel_edge_off[r + 1]; ++e) {
+            const int j = p.edges[2 * e], i = p.edges[2 * e + 1];
+            if (j < 0 || j >= d.type_nodes[s] || i < 0 || i >= d.type_nodes[t]) return fail(p, "edge endpoint out of range");
+            deg[i]++;
+        }
+        if (p.rel_mean[r]) for (int i = 0; i < d.type_nodes[t]; ++i)
+            if (deg[i] > 1) return fail(p, "mean aggregation with in-degree > 1 is not supported by this build "
+                                           "(all reference topologies have degree 1 on mean relations)");
+    }
+    for (int t = 0; t < NT; ++t)
+        if (!has_in[t]) return fail(p, "every node type must be the destination of at least one relation "
+                                       "(HeteroConv drops types without incoming relations)");
+    // masks must be +-1
+    p.sign_off.assign(NT, 0); p.enc_nkc.assign(NT, 0);
+    for (int t = 0; t < NT; ++t) {
+        const int F = d.type_width[t], n = d.type_nodes[t];
+        const int nkc = (F + H - 1) / H; p.enc_nkc[t] = nkc;
+        p.sign_off[t] = (int)p.signs.size();
+        p.signs.resize(p.signs.size() + (size_t)n * nkc * H, 0);
+        if (d.in_mask[t]) {
+            for (int i = 0; i < n; ++i) for (int k = 0; k < F; ++k) {
+                const float m = d.in_mask[t][(size_t)i * F + k];
+                if (m != 1.0f && m != -1.0f) return fail(p, "symmetry masks must be +1 or -1");
+                p.signs[p.sign_off[t] + (size_t)i * nkc * H + k] = m < 0 ? 1 : 0;
+            }
+        }
+    }
+    const int n_out = d.type_nodes[d.out_type];
+    p.out_mask_f.assign((size_t)n_out * d.out_channels, 1.0f);
+    if (d.out_mask) for (size_t i = 0; i < p.out_mask_f.size(); ++i) {
+        if (d.out_mask[i] != 1.0f && d.out_mask[i] != -1.0f) return fail(p, "output mask must be +1 or -1");
+        p.out_mask_f[i] = d.out_mask[i];
+    }
+
+    // ---- liveness -------------------------------------------------------------------------------
+    for (int t = 0; t < NT; ++t) p.live[L - 1][t] = (t == d.out_type);
+    for (int l = L - 2; l >= 0; --l)
+        for (int t = 0; t < NT; ++t) {
+            bool v = p.live[l + 1][t];   // root / residual path into its own type
+            for (int r = 0; r < NR; ++r) if (p.rel_src[r] == t && p.live[l + 1][p.rel_dst[r]]) v = true;
+            p.live[l][t] = v;
+        }
+    for (int l = 0; l < L; ++l)
+        for (int t = 0; t < NT; ++t) {
+            if (l >= 1) { p.need_dx[l][t] = p.live[l - 1][t]; continue; }
+            bool v = p.live[0][t];
+            for (int r = 0; r < NR; ++r) if (p.rel_src[r] == t && p.live[0][p.rel_dst[r]]) v = true;
+            p.need_dx[0][t] = v;
+        }
+
+    // ---- packed operands --------------------------------------------------------------------------
+    for (int o = 0; o < 2; ++o) { p.pack_root[o].assign((size_t)L * NT, -1); p.pack_rel[o].assign((size_t)L * NR, -1); }
+    p.bias_layer.assign((size_t)L * NT, -1);
+    for (int l = 0; l < L; ++l) {
+        for (int t = 0; t < NT; ++t) {
+            if (!p.live[l][t]) continue;
+            std::vector<int64_t> ws, bs;
+            for (int r = 0; r < NR; ++r) if (p.rel_dst[r] == t) { ws.push_back(p.off_root_w[l * NR + r]); bs.push_back(p.off_rel_b[l * NR + r]); }
+            if (ws.size() > 8) return fail(p, "more than 8 relations into one node type");
+            p.pack_root[0][l * NT + t] = add_pack(p, 0, ws, H, 0, H);
+            p.pack_root[1][l * NT + t] = add_pack(p, 1, ws, H, 0, H);
+            p.bias_layer[l * NT + t] = add_bias(p, bs);
+        }
+        for (int r = 0; r < NR; ++r) {
+            if (!p.live[l][p.rel_dst[r]] || p.rel_edge_off[r + 1] == p.rel_edge_off[r]) continue;
+            p.pack_rel[0][l * NR + r] = add_pack(p, 0, {p.off_rel_w[l * NR + r]}, H, 0, H);
+            p.pack_rel[1][l * NR + r] = add_pack(p, 1, {p.off_rel_w[l * NR + r]}, H, 0, H);
+        }
+    }
+    if (has_mlp) {
+        for (int o = 0; o < 2; ++o) {
+            p.pack_mlp[o][0] = add_pack(p, o, {d.off_mlp[0]}, H, 0, H);
+            p.pack_mlp[o][1] = add_pack(p, o, {d.off_mlp[2]}, H, 0, H);
+        }
+        p.bias_mlp[0] = add_bias(p, {d.off_mlp[1]});
+        p.bias_mlp[1] = add_bias(p, {d.off_mlp[3]});
+    }
+    p.pack_enc_base.assign(NT, -1); p.bias_enc.assign(NT, -1);
+    for (int t = 0; t < NT; ++t) {
+        const int F = d.type_width[t];
+        for (int kc = 0; kc < p.enc_nkc[t]; ++kc) {
+            const int id = add_pack(p, 0, {p.off_enc_w[t]}, F, kc * H, std::min(H, F - kc * H));
+            if (kc == 0) p.pack_enc_base[t] = id;
+        }
+        p.bias_enc[t] = add_bias(p, {p.off_enc_b[t]});
+    }
+
+    // ---- programs -----------------------------------------------------------------------------------
+    std::vector<int32_t>& T = p.tables;
+    T.clear();
+    auto push_entry = [&](int op, int slot, int arg) { T.push_back(op); T.push_back(slot); T.push_back(arg); T.push_back(0); };
+    std::vector<int> order;
+    for (int t = 0; t < NT; ++t) if (!(has_mlp && t == d.mlp_type)) order.push_back(t);
+    if (has_mlp) order.push_back(d.mlp_type);
+    double exec_fwd = 0, exec_bwd = 0, alg_fwd = 0, alg_bwd = 0;
+    const double NL = 2.0 * H * H;   // FLOPs of one node-linear (one window)
+
+    for (int l = 0; l < L; ++l) {
+        // ---------- forward program ----------
+        p.fwd_prog_off[l] = (int)T.size();
+        const int ng_pos = (int)T.size(); T.push_back(0);
+        int ng = 0;
+        for (int t : order) {
+            if (!p.live[l][t]) continue;
+            const bool mlp = has_mlp && t == d.mlp_type;
+            for (int c0 = 0; c0 < d.type_nodes[t]; c0 += GMAX) {
+                const int ns = std::min(GMAX, d.type_nodes[t] - c0);
+                const int gh = (int)T.size(); T.resize(T.size() + GH_SIZE, 0);
+                T[gh + GH_KIND] = mlp ? KIND_MLP : KIND_RELU; T[gh + GH_NSLOTS] = ns;
+                T[gh + GH_BIAS] = p.bias_layer[l * NT + t];
+                T[gh + GH_FLAGS] = (residual ? GF_RESIDUAL : 0) | GF_STORE_MASK;
+                if (mlp) { T[gh + GH_W1] = p.pack_mlp[0][0]; T[gh + GH_W2] = p.pack_mlp[0][1]; T[gh + GH_B1] = p.bias_mlp[0]; T[gh + GH_B2] = p.bias_mlp[1]; }
+                for (int u = 0; u < ns; ++u) { T[gh + GH_NODES + u] = p.type_base[t] + c0 + u; T[gh + GH_MLPIDX + u] = c0 + u; }
+                int nent = 0;
+                push_entry(OP_LOADW, 0, p.pack_root[0][l * NT + t]); ++nent;
+                for (int u = 0; u < ns; ++u) { push_entry(OP_MAC, u, p.type_base[t] + c0 + u); ++nent; exec_fwd += NL; alg_fwd += NL; }
+                for (int r = 0; r < NR; ++r) {
+                    if (p.rel_dst[r] != t) continue;
+                    bool loaded = false; std::vector<bool> hit(ns, false);
+                    for (int e = p.rel_edge_off[r]; e < p.rel_edge_off[r + 1]; ++e) {
+                        const int j = p.edges[2 * e], i = p.edges[2 * e + 1];
+                        if (i < c0 || i >= c0 + ns) continue;
+                        if (!loaded) { push_entry(OP_LOADW, 0, p.pack_rel[0][l * NR + r]); ++nent; loaded = true; }
+                        push_entry(OP_MAC, i - c0, p.type_base[p.rel_src[r]] + j); ++nent; exec_fwd += NL;
+                        if (!hit[i - c0]) { hit[i - c0] = true; alg_fwd += NL; }
+                    }
+                }
+                if (mlp) { exec_fwd += 2 * NL * ns; alg_fwd += 2 * NL * ns; }
+                T[gh + GH_NENT] = nent; ++ng;
+            }
+        }
+        T[ng_pos] = ng;
+
+        // ---------- backward program ----------
+        p.bwd_prog_off[l] = (int)T.size();
+        // header: [n_groups, n_mlp_live, w2pack, w1pack, node_kind[NN].., mlp_nodes[GMAX]]
+        const int bh = (int)T.size(); T.resize(T.size() + 4 + 64 + GMAX, 0);
+        const bool mlp_live = has_mlp && p.live[l][d.mlp_type];
+        T[bh + 1] = mlp_live ? p.n_mlp : 0;
+        if (mlp_live) { T[bh + 2] = p.pack_mlp[1][1]; T[bh + 3] = p.pack_mlp[1][0]; }
+        for (int n = 0; n < p.NN; ++n) {
+            const int t = p.node_type[n];
+            T[bh + 4 + n] = !p.live[l][t] ? NK_DEAD : ((has_mlp && t == d.mlp_type) ? NK_MLP : NK_RELU);
+        }
+        if (mlp_live) { for (int u = 0; u < p.n_mlp; ++u) T[bh + 4 + 64 + u] = p.type_base[d.mlp_type] + u; exec_bwd += 2 * NL * p.n_mlp; alg_bwd += 2 * NL * p.n_mlp; }
+        int ngb = 0;
+        for (int t = 0; t < NT; ++t) {
+            if (!p.need_dx[l][t]) continue;
+            for (int c0 = 0; c0 < d.type_nodes[t]; c0 += GMAX) {
+                const int ns = std::min(GMAX, d.type_nodes[t] - c0);
+                const int gh = (int)T.size(); T.resize(T.size() + GH_SIZE, 0);
+                T[gh + GH_KIND] = KIND_RELU; T[gh + GH_NSLOTS] = ns; T[gh + GH_BIAS] = -1;
+                T[gh + GH_FLAGS] = ((residual && p.live[l][t]) ? GF_RESIDUAL : 0) | (l == 0 ? GF_ENC_MASK : 0);
+                for (int u = 0; u < ns; ++u) T[gh + GH_NODES + u] = p.type_base[t] + c0 + u;
+                int nent = 0;
+                if (p.live[l][t]) {
+                    push_entry(OP_LOADW, 0, p.pack_root[1][l * NT + t]); ++nent;
+                    for (int u = 0; u < ns; ++u) { push_entry(OP_MAC, u, p.type_base[t] + c0 + u); ++nent; exec_bwd += NL; alg_bwd += NL; }
+                }
+                for (int r = 0; r < NR; ++r) {
+                    if (p.rel_src[r] != t || !p.live[l][p.rel_dst[r]]) continue;
+                    bool loaded = false;
+                    std::vector<bool> hit(ns * 64, false);
+                    for (int e = p.rel_edge_off[r]; e < p.rel_edge_off[r + 1]; ++e) {
+                        const int j = p.edges[2 * e], i = p.edges[2 * e + 1];
+                        if (j < c0 || j >= c0 + ns) continue;
+                        if (!loaded) { push_entry(OP_LOADW, 0, p.pack_rel[1][l * NR + r]); ++nent; loaded = true; }
+                        push_entry(OP_MAC, j - c0, p.type_base[p.rel_dst[r]] + i); ++nent; exec_bwd += NL;
+                    }
+                }
+                T[gh + GH_NENT] = nent; ++ngb;
+            }
+        }
+        T[bh + 0] = ngb;
+    }
+    // algorithmic dX work: one node-linear per (relation, src node with >=1 out-edge into a live dst) -- count below
+    for (int l = 0; l < L; ++l)
+        for (int r = 0; r < NR; ++r) {
+            if (!p.live[l][p.rel_dst[r]] || !p.need_dx[l][p.rel_src[r]]) continue;
+            std::vector<bool> hit(d.type_nodes[p.rel_src[r]], false);
+            for (int e = p.rel_edge_off[r]; e < p.rel_edge_off[r + 1]; ++e) hit[p.edges[2 * e]] = true;
+            for (bool b : hit) if (b) alg_bwd += NL;
+        }
+
+    // ---- weight-gradient targets / items / finalize ops -----------------------------------------------
+    struct Tgt { std::vector<int> items; int bias_flag; };
+    std::vector<std::vector<int32_t>> items;   // each ITEM_INTS
+    std::vector<Tgt> tgts;
+    auto add_item = [&](int pb, int ps, int po, int qb, int qs, int qo, int qc0, int qn, int so) {
+        items.push_back({pb, ps, po, qb, qs, qo, qc0, qn, so, 0}); return (int)items.size() - 1; };
+    const int SN = p.NN * H, SM = std::max(1, p.n_mlp) * H;
+    std::vector<int> tgt_root((size_t)L * NT, -1), tgt_rel((size_t)L * NR, -1);
+    int tgt_mlp[2] = {-1, -1};
+    for (int l = 0; l < L; ++l) {
+        for (int t = 0; t < NT; ++t) {
+            if (!p.live[l][t]) continue;
+            Tgt g; g.bias_flag = 1;
+            for (int i = 0; i < d.type_nodes[t]; ++i) {
+                const int n = p.type_base[t] + i;
+                g.items.push_back(add_item(BUF_DH + l, SN, n * H, BUF_X + l, SN, n * H, 0, H, -1));
+                exec_bwd += NL; alg_bwd += NL;
+            }
+            tgt_root[l * NT + t] = (int)tgts.size(); tgts.push_back(g);
+        }
+        for (int r = 0; r < NR; ++r) {
+            if (p.pack_rel[0][l * NR + r] < 0) continue;
+            Tgt g; g.bias_flag = 0;
+            std::vector<bool> hit(d.type_nodes[p.rel_dst[r]], false);
+            for (int e = p.rel_edge_off[r]; e < p.rel_edge_off[r + 1]; ++e) {
+                const int j = p.edges[2 * e], i = p.edges[2 * e + 1];
+                g.items.push_back(add_item(BUF_DH + l, SN, (p.type_base[p.rel_dst[r]] + i) * H,
+                                           BUF_X + l, SN, (p.type_base[p.rel_src[r]] + j) * H, 0, H, -1));
+                exec_bwd += NL; if (!hit[i]) { hit[i] = true; alg_bwd += NL; }
+            }
+            tgt_rel[l * NR + r] = (int)tgts.size(); tgts.push_back(g);
+        }
+    }
+    if (has_mlp) {
+        Tgt g1, g2; g1.bias_flag = g2.bias_flag = 1;
+        for (int l = 0; l < L; ++l) {
+            if (!p.live[l][d.mlp_type]) continue;
+            for (int u = 0; u < p.n_mlp; ++u) {
+                g1.items.push_back(add_item(BUF_DU + l, SM, u * H, BUF_HB + l, SM, u * H, 0, H, -1));
+                g2.items.push_back(add_item(BUF_DX + l + 1, SN, (p.type_base[d.mlp_type] + u) * H, BUF_T1 + l, SM, u * H, 0, H, -1));
+                exec_bwd += 2 * NL; alg_bwd += 2 * NL;
+            }
+        }
+        if (!g1.items.empty()) { tgt_mlp[0] = (int)tgts.size(); tgts.push_back(g1); tgt_mlp[1] = (int)tgts.size(); tgts.push_back(g2); }
+    }
+    std::vector<std::vector<int>> tgt_enc(NT);
+    for (int t = 0; t < NT; ++t) {
+        if (!p.need_dx[0][t]) continue;
+        const int F = d.type_width[t];
+        for (int kc = 0; kc < p.enc_nkc[t]; ++kc) {
+            Tgt g; g.bias_flag = (kc == 0);
+            const int nc = std::min(H, F - kc * H);
+            for (int i = 0; i < d.type_nodes[t]; ++i) {
+                g.items.push_back(add_item(BUF_DX + 0, SN, (p.type_base[t] + i) * H, BUF_IN + t, -1, i, kc * H, nc,
+                                           p.sign_off[t] + i * p.enc_nkc[t] * H + kc * H));
+                exec_bwd += NL; alg_bwd += 2.0 * H * nc;
+            }
+            tgt_enc[t].push_back((int)tgts.size()); tgts.push_back(g);
+        }
+    }
+    for (int t = 0; t < NT; ++t) {   // encoder forward work
+        exec_fwd += (double)d.type_nodes[t] * p.enc_nkc[t] * NL;
+        alg_fwd += (double)d.type_nodes[t] * 2.0 * H * d.type_width[t];
+    }
+    alg_fwd += 2.0 * n_out * d.out_channels * H; exec_fwd += 2.0 * n_out * d.out_channels * H;
+    alg_bwd += 4.0 * n_out * d.out_channels * H; exec_bwd += 4.0 * n_out * d.out_channels * H;
+
+    // workgroup allocation of the split-K weight-gradient kernel: proportional to item count
+    int total_items = 0; for (auto& g : tgts) total_items += (int)g.items.size();
+    const int NWG_TARGET = 512;
+    std::vector<int> wgc(tgts.size()), wgb(tgts.size());
+    int nwg = 0;
+    for (size_t g = 0; g < tgts.size(); ++g) {
+        int c = (int)std::lround((double)tgts[g].items.size() * NWG_TARGET / std::max(1, total_items));
+        c = std::max(1, std::min(c, 64));
+        wgc[g] = c; wgb[g] = nwg; nwg += c;
+    }
+    p.n_wg_gradw = nwg;
+    p.item_off = (int)T.size(); p.n_items = 0;
+    std::vector<int> tgt_item_begin(tgts.size()), tgt_item_end(tgts.size());
+    for (size_t g = 0; g < tgts.size(); ++g) {
+        tgt_item_begin[g] = p.n_items;
+        for (int it : tgts[g].items) { for (int k = 0; k < ITEM_INTS; ++k) T.push_back(items[it][k]); ++p.n_items; }
+        tgt_item_end[g] = p.n_items;
+    }
+    p.tgt_off = (int)T.size(); p.n_targets = (int)tgts.size();
+    for (size_t g = 0; g < tgts.size(); ++g) {
+        T.push_back(tgt_item_begin[g]); T.push_back(tgt_item_end[g]); T.push_back(wgb[g]); T.push_back(wgc[g]);
+        T.push_back(tgts[g].bias_flag); T.push_back(0); T.push_back(0); T.push_back(0);
+    }
+    p.wg2t_off = (int)T.size();
+    for (size_t g = 0; g < tgts.size(); ++g) for (int c = 0; c < wgc[g]; ++c) T.push_back((int)g);
+    p.dec_slab0 = nwg; p.n_slabs = nwg + NWG_DEC;
+
+    // finalize ops: every parameter is written exactly once
+    p.fin_off = (int)T.size(); p.n_fin = 0;
+    auto add_fin = [&](int64_t dst, int rows, int cols, int ld, int target, int kind) {
+        T.push_back((int32_t)(dst & 0xffffffff)); T.push_back((int32_t)(dst >> 32)); T.push_back(rows); T.push_back(cols);
+        T.push_back(ld); T.push_back(target); T.push_back(kind); T.push_back(0); ++p.n_fin; };
+    for (int t = 0; t < NT; ++t) {
+        const int F = d.type_width[t];
+        for (int kc = 0; kc < p.enc_nkc[t]; ++kc) {
+            const int nc = std::min(H, F - kc * H);
+            const int tg = tgt_enc[t].empty() ? -1 : tgt_enc[t][kc];
+            add_fin(p.off_enc_w[t] + kc * H, H, nc, F, tg, tg < 0 ? FIN_ZERO : FIN_MATRIX);
+        }
+        const int tg0 = tgt_enc[t].empty() ? -1 : tgt_enc[t][0];
+        add_fin(p.off_enc_b[t], 1, H, H, tg0, tg0 < 0 ? FIN_ZERO : FIN_BIAS);
+    }
+    for (int l = 0; l < L; ++l)
+        for (int r = 0; r < NR; ++r) {
+            const int tr = tgt_rel[l * NR + r], to = tgt_root[l * NT + p.rel_dst[r]];
+            add_fin(p.off_rel_w[l * NR + r], H, H, H, tr, tr < 0 ? FIN_ZERO : FIN_MATRIX);
+            add_fin(p.off_rel_b[l * NR + r], 1, H, H, to, to < 0 ? FIN_ZERO : FIN_BIAS);
+            add_fin(p.off_root_w[l * NR + r], H, H, H, to, to < 0 ? FIN_ZERO : FIN_MATRIX);
+        }
+    if (has_mlp) {
+        for (int k = 0; k < 2; ++k) {
+            add_fin(d.off_mlp[2 * k], H, H, H, tgt_mlp[k], tgt_mlp[k] < 0 ? FIN_ZERO : FIN_MATRIX);
+            add_fin(d.off_mlp[2 * k + 1], 1, H, H, tgt_mlp[k], tgt_mlp[k] < 0 ? FIN_ZERO : FIN_BIAS);
+        }
+    }
+    add_fin(d.off_dec_w, d.out_channels, H, H, -2, FIN_DEC_W);
+    add_fin(d.off_dec_b, 1, d.out_channels, d.out_channels, -2, FIN_DEC_B);
+
+    // ---- info ---------------------------------------------------------------------------------------
+    p.info.rows_per_tile = p.rows; p.info.total_nodes = p.NN; p.info.lds_bytes = (int64_t)p.NN * BLK_BYTES;
+    p.info.flops_fwd = alg_fwd; p.info.flops_bwd = alg_bwd; p.info.flops_exec_fwd = exec_fwd; p.info.flops_exec_bwd = exec_bwd;
+    double bytes = 0; for (int t = 0; t < NT; ++t) bytes += (double)d.type_nodes[t] * d.type_width[t] * p.esize;
+    p.info.bytes_in = bytes; p.info.n_gradw_workgroups = nwg;
+    p.info.n_launches_fwd = 3 + L; p.info.n_launches_bwd = 3 + L;
+    return true;
+}
+
+// workspace layout ------------------------------------------------------------------------------------
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+inline void layout_workspace(const HostPlan& p, int64_t B, int training, mshgnn_ws_layout* o) {
+    std::memset(o, 0, sizeof(*o));
+    size_t off = 0;
+    const size_t act = (size_t)B * p.NN * H * p.esize, mlp = (size_t)B * std::max(1, p.n_mlp) * H * p.esize;
+    auto take = [&](size_t bytes) { size_t r = off; off = align_up(off + bytes, 256); return r; };
+    for (int l = 0; l <= p.L; ++l) o->x[l] = take(act);
+    for (int l = 0; l < p.L; ++l) { o->mask[l] = take((size_t)B * p.NN * 4 * 4); o->hb[l] = take(mlp); o->t1[l] = take(mlp); }
+    if (training) {
+        for (int l = 0; l <= p.L; ++l) o->dx[l] = take(act);
+        for (int l = 0; l < p.L; ++l) { o->dh[l] = take(act); o->du[l] = take(mlp); }
+        o->slabs = take((size_t)p.n_slabs * SLAB_FLOATS * 4);
+    }
+    o->wpack = take(p.packs.size() * (size_t)H * H * p.esize);
+    o->bias = take(p.biases.size() * (size_t)H * 4);
+    o->loss = take(64);
+    o->total = off;
+}
+
+}  // namespace mshgnn

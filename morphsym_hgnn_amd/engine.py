@@ -1,0 +1,327 @@
+"""ctypes binding of libmshgnn.so (include/mshgnn.h) and the host-side engine object.
+
+PyTorch is used here for device memory, streams and dtype casts only; all arithmetic of the hot path
+runs in the HIP kernels behind the C-ABI.  There is NO CPU fallback: if the library is missing or no GPU
+is present, construction fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from .spec import ModelSpec, relation_aggr
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmshgnn.so")
+
+MAX_TYPES = 4
+F32, BF16 = 0, 1
+FLAG_RESIDUAL, FLAG_BASE_MLP = 1, 2
+
+
+class MshgnnDesc(C.Structure):
+    _fields_ = [
+        ("n_types", C.c_int32), ("hidden", C.c_int32), ("num_layers", C.c_int32), ("n_rel", C.c_int32),
+        ("out_type", C.c_int32), ("out_channels", C.c_int32), ("mlp_type", C.c_int32), ("flags", C.c_uint32),
+        ("dtype", C.c_int32),
+        ("type_nodes", C.c_int32 * MAX_TYPES), ("type_width", C.c_int32 * MAX_TYPES),
+        ("rel_src", C.POINTER(C.c_int32)), ("rel_dst", C.POINTER(C.c_int32)), ("rel_mean", C.POINTER(C.c_int32)),
+        ("rel_edge_off", C.POINTER(C.c_int32)), ("edges", C.POINTER(C.c_int32)),
+        ("in_mask", C.POINTER(C.c_float) * MAX_TYPES), ("out_mask", C.POINTER(C.c_float)),
+        ("off_enc_w", C.POINTER(C.c_int64)), ("off_enc_b", C.POINTER(C.c_int64)),
+        ("off_rel_w", C.POINTER(C.c_int64)), ("off_rel_b", C.POINTER(C.c_int64)), ("off_root_w", C.POINTER(C.c_int64)),
+        ("off_mlp", C.c_int64 * 4), ("off_dec_w", C.c_int64), ("off_dec_b", C.c_int64), ("n_flat", C.c_int64),
+    ]
+
+
+class MshgnnInfo(C.Structure):
+    _fields_ = [
+        ("rows_per_tile", C.c_int32), ("total_nodes", C.c_int32), ("lds_bytes", C.c_int64),
+        ("flops_fwd", C.c_double), ("flops_bwd", C.c_double), ("flops_exec_fwd", C.c_double), ("flops_exec_bwd", C.c_double),
+        ("bytes_in", C.c_double), ("n_gradw_workgroups", C.c_int32), ("n_launches_fwd", C.c_int32), ("n_launches_bwd", C.c_int32),
+    ]
+
+
+class MshgnnWsLayout(C.Structure):
+    _fields_ = [
+        ("total", C.c_size_t), ("x", C.c_size_t * 17), ("dx", C.c_size_t * 17), ("dh", C.c_size_t * 16),
+        ("mask", C.c_size_t * 16), ("hb", C.c_size_t * 16), ("t1", C.c_size_t * 16), ("du", C.c_size_t * 16),
+        ("wpack", C.c_size_t), ("bias", C.c_size_t), ("slabs", C.c_size_t), ("loss", C.c_size_t),
+    ]
+
+
+EXPORTS = [
+    "mshgnn_last_error", "mshgnn_version", "mshgnn_plan_create", "mshgnn_plan_destroy", "mshgnn_plan_info",
+    "mshgnn_plan_compile_host", "mshgnn_workspace_layout", "mshgnn_forward", "mshgnn_backward", "mshgnn_mse_loss",
+]
+
+_lib = None
+
+
+def build_library(force: bool = False) -> str:
+    """Compile libmshgnn.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    src = os.path.join(_HERE, "csrc")
+    if force and os.path.exists(LIB_PATH):
+        os.remove(LIB_PATH)
+    subprocess.run(["make", "-C", src], check=True)
+    return LIB_PATH
+
+
+def load_library():
+    """Load libmshgnn.so; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "or `make -C morphsym_hgnn_amd/csrc` -- the MS-HGNN engine has no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    lib.mshgnn_last_error.restype = C.c_char_p
+    lib.mshgnn_version.restype = C.c_char_p
+    lib.mshgnn_plan_create.argtypes = [C.POINTER(MshgnnDesc), C.POINTER(C.c_void_p)]
+    lib.mshgnn_plan_destroy.argtypes = [C.c_void_p]
+    lib.mshgnn_plan_destroy.restype = None
+    lib.mshgnn_plan_info.argtypes = [C.c_void_p, C.POINTER(MshgnnInfo)]
+    lib.mshgnn_plan_compile_host.argtypes = [C.POINTER(MshgnnDesc), C.POINTER(MshgnnInfo), C.POINTER(C.c_int32)]
+    lib.mshgnn_workspace_layout.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.POINTER(MshgnnWsLayout)]
+    lib.mshgnn_forward.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+    lib.mshgnn_backward.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.mshgnn_mse_loss.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    _lib = lib
+    return lib
+
+
+class MshgnnError(RuntimeError):
+    pass
+
+
+def _check(lib, rc: int, what: str):
+    if rc != 0:
+        raise MshgnnError(f"{what} failed ({rc}): {lib.mshgnn_last_error().decode()}")
+
+
+class _DescHolder:
+    """Keeps the numpy arrays a MshgnnDesc points into alive."""
+
+    def __init__(self, spec: ModelSpec, dtype: int):
+        self.keep: List[np.ndarray] = []
+        d = MshgnnDesc()
+        types = spec.node_types
+        tix = {t: i for i, t in enumerate(types)}
+        d.n_types = len(types)
+        d.hidden = spec.hidden
+        d.num_layers = spec.num_layers
+        d.n_rel = len(spec.edge_types)
+        d.out_type = tix[spec.out_type]
+        d.out_channels = spec.out_channels
+        d.mlp_type = tix["base"] if spec.has_base_transform else -1
+        d.flags = (FLAG_RESIDUAL if spec.residual else 0) | (FLAG_BASE_MLP if spec.has_base_transform else 0)
+        d.dtype = dtype
+        for i, t in enumerate(types):
+            d.type_nodes[i] = spec.num_nodes[t]
+            d.type_width[i] = spec.widths[t]
+
+        def arr(a, dt):
+            a = np.ascontiguousarray(np.asarray(a, dtype=dt))
+            self.keep.append(a)
+            return a
+
+        def iptr(a):
+            return arr(a, np.int32).ctypes.data_as(C.POINTER(C.c_int32))
+
+        def lptr(a):
+            return arr(a, np.int64).ctypes.data_as(C.POINTER(C.c_int64))
+
+        def fptr(a):
+            return arr(a, np.float32).ctypes.data_as(C.POINTER(C.c_float))
+
+        d.rel_src = iptr([tix[s] for s, _, _ in spec.edge_types])
+        d.rel_dst = iptr([tix[t] for _, _, t in spec.edge_types])
+        d.rel_mean = iptr([1 if relation_aggr(spec.kind, et) == "mean" else 0 for et in spec.edge_types])
+        off, edges = [0], []
+        for et in spec.edge_types:
+            e = spec.topology.edges(et)
+            for s_, d_ in e:
+                edges += [s_, d_]
+            off.append(off[-1] + len(e))
+        d.rel_edge_off = iptr(off)
+        d.edges = iptr(edges if edges else [0])
+        masks = spec.input_masks()
+        for i, t in enumerate(types):
+            d.in_mask[i] = fptr(masks[t].numpy().reshape(-1))
+        d.out_mask = fptr(spec.output_mask().numpy().reshape(-1))
+        po = spec.param_offsets()
+        from .spec import rel_key
+        d.off_enc_w = lptr([po[f"encoder.lins.{t}.weight"][0] for t in types])
+        d.off_enc_b = lptr([po[f"encoder.lins.{t}.bias"][0] for t in types])
+        rw, rb, ro = [], [], []
+        for l in range(spec.num_layers):
+            for et in spec.edge_types:
+                p = f"convs.{l}.convs.{rel_key(et)}."
+                rw.append(po[p + "lin_rel.weight"][0]); rb.append(po[p + "lin_rel.bias"][0]); ro.append(po[p + "lin_root.weight"][0])
+        d.off_rel_w, d.off_rel_b, d.off_root_w = lptr(rw), lptr(rb), lptr(ro)
+        if spec.has_base_transform:
+            for k, name in enumerate(["base_transform.0.weight", "base_transform.0.bias", "base_transform.2.weight", "base_transform.2.bias"]):
+                d.off_mlp[k] = po[name][0]
+        d.off_dec_w = po["decoder.weight"][0]
+        d.off_dec_b = po["decoder.bias"][0]
+        d.n_flat = spec.flat_size()
+        self.desc = d
+
+
+def compile_plan_host(spec: ModelSpec, dtype: str = "f32") -> MshgnnInfo:
+    """Run the plan compiler only (no GPU needed) and return its work/traffic summary."""
+    lib = load_library()
+    h = _DescHolder(spec, F32 if dtype == "f32" else BF16)
+    info = MshgnnInfo()
+    n = C.c_int32(0)
+    _check(lib, lib.mshgnn_plan_compile_host(C.byref(h.desc), C.byref(info), C.byref(n)), "mshgnn_plan_compile_host")
+    return info
+
+
+def flatten_params(spec: ModelSpec, params: Dict[str, torch.Tensor], device=None) -> torch.Tensor:
+    """state_dict-named tensors -> the flat fp32 parameter buffer of the C-ABI."""
+    flat = torch.zeros(spec.flat_size(), dtype=torch.float32)
+    for k, (off, n) in spec.param_offsets().items():
+        flat[off:off + n] = params[k].detach().reshape(-1).to(torch.float32).cpu()
+    return flat.to(device) if device is not None else flat
+
+
+def unflatten(spec: ModelSpec, flat: torch.Tensor) -> Dict[str, torch.Tensor]:
+    """Views of a flat parameter/gradient buffer keyed by state_dict names."""
+    shapes = spec.param_shapes()
+    return {k: flat[off:off + n].view(shapes[k]) for k, (off, n) in spec.param_offsets().items()}
+
+
+class Engine:
+    """One compiled plan (topology x model dims x precision) on one GPU."""
+
+    def __init__(self, spec: ModelSpec, dtype: str = "f32", device: Optional[torch.device] = None):
+        if dtype not in ("f32", "bf16"):
+            raise ValueError("dtype must be 'f32' or 'bf16'")
+        if not torch.cuda.is_available():
+            raise RuntimeError("the MS-HGNN engine needs a HIP device; there is no CPU fallback")
+        self.lib = load_library()
+        self.spec = spec
+        self.dtype = dtype
+        self.torch_dtype = torch.float32 if dtype == "f32" else torch.bfloat16
+        self.device = torch.device(device if device is not None else "cuda:0")
+        self._holder = _DescHolder(spec, F32 if dtype == "f32" else BF16)
+        self._plan = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.mshgnn_plan_create(C.byref(self._holder.desc), C.byref(self._plan)), "mshgnn_plan_create")
+        self.info = MshgnnInfo()
+        _check(self.lib, self.lib.mshgnn_plan_info(self._plan, C.byref(self.info)), "mshgnn_plan_info")
+        self._ws: Dict[Tuple[int, int], torch.Tensor] = {}
+        self._lay: Dict[Tuple[int, int], MshgnnWsLayout] = {}
+        self.types = spec.node_types
+        self.n_out = spec.num_nodes[spec.out_type]
+
+    def __del__(self):
+        try:
+            if getattr(self, "_plan", None) is not None and self._plan.value:
+                self.lib.mshgnn_plan_destroy(self._plan)
+                self._plan = C.c_void_p()
+        except Exception:
+            pass
+
+    # ---- memory ------------------------------------------------------------------------------
+    def layout(self, B: int, training: bool = True) -> MshgnnWsLayout:
+        key = (B, int(training))
+        if key not in self._lay:
+            lay = MshgnnWsLayout()
+            _check(self.lib, self.lib.mshgnn_workspace_layout(self._plan, B, int(training), C.byref(lay)), "mshgnn_workspace_layout")
+            self._lay[key] = lay
+        return self._lay[key]
+
+    def workspace(self, B: int, training: bool = True) -> torch.Tensor:
+        key = (B, int(training))
+        if key not in self._ws:
+            lay = self.layout(B, training)
+            self._ws[key] = torch.empty(lay.total, dtype=torch.uint8, device=self.device)
+        return self._ws[key]
+
+    def cast_inputs(self, x_dict: Dict[str, torch.Tensor]) -> List[torch.Tensor]:
+        """Reference-convention inputs ([B*n_t, F_t], any float dtype) -> plan-dtype device tensors."""
+        return [x_dict[t].to(device=self.device, dtype=self.torch_dtype).contiguous() for t in self.types]
+
+    def _xptrs(self, xs: Sequence[torch.Tensor], B: int):
+        ptrs = (C.c_void_p * len(xs))()
+        for i, (t, x) in enumerate(zip(self.types, xs)):
+            if x.dtype != self.torch_dtype or not x.is_cuda or not x.is_contiguous():
+                raise ValueError(f"input '{t}' must be a contiguous {self.torch_dtype} device tensor")
+            if x.numel() != B * self.spec.num_nodes[t] * self.spec.widths[t]:
+                raise ValueError(f"input '{t}' has {x.numel()} elements, expected "
+                                 f"{B}*{self.spec.num_nodes[t]}*{self.spec.widths[t]}")
+            ptrs[i] = x.data_ptr()
+        return ptrs
+
+    def _check_flat(self, flat: torch.Tensor, name: str):
+        if flat.dtype != torch.float32 or not flat.is_cuda or not flat.is_contiguous() or flat.numel() != self.spec.flat_size():
+            raise ValueError(f"{name} must be a contiguous fp32 device tensor of {self.spec.flat_size()} elements")
+
+    # ---- hot path ------------------------------------------------------------------------------
+    def forward(self, xs: Sequence[torch.Tensor], params_flat: torch.Tensor, B: int, training: bool = True,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        self._check_flat(params_flat, "params_flat")
+        ptrs = self._xptrs(xs, B)
+        if out is None:
+            out = torch.empty(B * self.n_out, self.spec.out_channels, dtype=torch.float32, device=self.device)
+        ws = self.workspace(B, training)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _check(self.lib, self.lib.mshgnn_forward(self._plan, ptrs, None, params_flat.data_ptr(), out.data_ptr(),
+                                                 ws.data_ptr(), B, int(training), stream), "mshgnn_forward")
+        return out
+
+    def backward(self, xs: Sequence[torch.Tensor], params_flat: torch.Tensor, grad_out: torch.Tensor, B: int,
+                 grad_flat: Optional[torch.Tensor] = None) -> torch.Tensor:
+        self._check_flat(params_flat, "params_flat")
+        ptrs = self._xptrs(xs, B)
+        if grad_out.dtype != torch.float32 or not grad_out.is_contiguous() or grad_out.numel() != B * self.n_out * self.spec.out_channels:
+            raise ValueError("grad_out must be contiguous fp32 with B*n_out*out_channels elements")
+        if grad_flat is None:
+            grad_flat = torch.empty(self.spec.flat_size(), dtype=torch.float32, device=self.device)
+        else:
+            self._check_flat(grad_flat, "grad_flat")
+        ws = self.workspace(B, True)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _check(self.lib, self.lib.mshgnn_backward(self._plan, ptrs, None, params_flat.data_ptr(), grad_out.data_ptr(),
+                                                  grad_flat.data_ptr(), ws.data_ptr(), B, stream), "mshgnn_backward")
+        return grad_flat
+
+    def mse_loss(self, out: torch.Tensor, y: torch.Tensor, want_grad: bool = True):
+        """Wrapper loss (gnnLightning.py:633-639): returns (loss[1], dL/d out or None)."""
+        n = out.numel()
+        if y.numel() != n or y.dtype != torch.float32 or out.dtype != torch.float32:
+            raise ValueError("out and y must be fp32 tensors with the same number of elements")
+        loss = torch.empty(1, dtype=torch.float32, device=self.device)
+        g = torch.empty_like(out) if want_grad else None
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _check(self.lib, self.lib.mshgnn_mse_loss(out.data_ptr(), y.data_ptr(), n, loss.data_ptr(),
+                                                  g.data_ptr() if g is not None else None, stream), "mshgnn_mse_loss")
+        return loss, g
+
+    # ---- introspection (tests) -----------------------------------------------------------------
+    def hidden_state(self, B: int, layer: int) -> torch.Tensor:
+        """X_layer as [B, NN, hidden] (a view into the workspace)."""
+        lay = self.layout(B, True)
+        ws = self.workspace(B, True)
+        nn_ = self.info.total_nodes
+        n = B * nn_ * self.spec.hidden
+        es = 4 if self.dtype == "f32" else 2
+        return ws[lay.x[layer]:lay.x[layer] + n * es].view(self.torch_dtype).view(B, nn_, self.spec.hidden)
+
+    def grad_hidden(self, B: int, layer: int) -> torch.Tensor:
+        lay = self.layout(B, True)
+        ws = self.workspace(B, True)
+        nn_ = self.info.total_nodes
+        n = B * nn_ * self.spec.hidden
+        es = 4 if self.dtype == "f32" else 2
+        return ws[lay.dx[layer]:lay.dx[layer] + n * es].view(self.torch_dtype).view(B, nn_, self.spec.hidden)

@@ -108,6 +108,18 @@ class ModelSpec:
             return 3
         return 2
 
+    def live_types(self, layer: int) -> List[str]:
+        """Node types whose output of message-passing layer `layer` can reach the decoder (the engine skips
+        the others: e.g. base/joint outputs of the last layer are never read, hgnn_c2.py:176)."""
+        live = {self.out_type}
+        for l in range(self.num_layers - 2, layer - 1, -1):
+            nxt = set(live)
+            for s, _, d in self.edge_types:
+                if d in live:
+                    nxt.add(s)
+            live = nxt
+        return [t for t in self.node_types if t in live]
+
     # ---- parameters ------------------------------------------------------------------------
     def param_shapes(self) -> "OrderedDict[str, Tuple[int, ...]]":
         """state_dict names -> shapes, in module registration order."""

@@ -89,3 +89,74 @@ def check_against_fixture(fx, out, loss, grads, rtol, what=""):
         assert e2 <= rtol, f"{what} grad-norm {name} rel err {e2:.3e} > {rtol}"
         assert e1 <= 30 * rtol, f"{what} grad samples {name} err/rms {e1:.3e} > {30 * rtol}"
     return err, worst
+
+
+# ---------------------------------------------------------------------------------------------------
+# GPU parity harness (used by tests/test_engine_gpu.py, tools and __graft_entry__.smoke)
+# ---------------------------------------------------------------------------------------------------
+def dense_hidden(spec, hidden_dict, B):
+    """oracle hidden dict {type: [B*n_t, h]} -> [B, NN, h] in the engine's node order."""
+    parts = [hidden_dict[t].view(B, spec.num_nodes[t], -1) for t in spec.node_types]
+    return torch.cat(parts, dim=1)
+
+
+def node_slices(spec):
+    out, o = {}, 0
+    for t in spec.node_types:
+        out[t] = slice(o, o + spec.num_nodes[t])
+        o += spec.num_nodes[t]
+    return out
+
+
+def run_engine_case(spec, x_dict, y, params, ei, B, dtype="f32", device="cuda:0"):
+    """Run fwd + MSE/CE + bwd through the C-ABI and through the oracle; return dict of relative errors
+    (max-abs error / max-abs reference) per stage, plus the raw engine results."""
+    from morphsym_hgnn_amd import engine as eng
+    from oracle import ms_hgnn_oracle as orc
+    cfg = oracle_config(spec)
+    # oracle (fp64, CPU)
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+    o_out, o_hidden = orc.forward(cfg, leaves, {k: v.clone() for k, v in x_dict.items()}, ei, return_hidden=True)
+    yy, yp = orc.wrapper_outputs(cfg, o_out, y, B)
+    o_loss = orc.mse_loss(yy, yp) if spec.regression else orc.cross_entropy_loss(yy, yp, B)
+    gout_ref = torch.autograd.grad(o_loss, o_out, retain_graph=True)[0]
+    o_loss.backward()
+    o_grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaves.items()}
+
+    e = eng.Engine(spec, dtype=dtype, device=device)
+    xs = e.cast_inputs(x_dict)
+    flat = eng.flatten_params(spec, params, device=e.device)
+    out = e.forward(xs, flat, B, training=True)
+    errs = {}
+
+    def rel(a, b):
+        a = a.detach().double().cpu(); b = b.detach().double().cpu()
+        return float((a - b).abs().max() / max(float(b.abs().max()), 1e-300))
+
+    sl = node_slices(spec)
+    for l in range(spec.num_layers + 1):
+        got = e.hidden_state(B, l)
+        ref = dense_hidden(spec, o_hidden[l], B)
+        live = spec.node_types if l == 0 else spec.live_types(l - 1)
+        for t in live:
+            errs[f"X{l}[{t}]"] = rel(got[:, sl[t]], ref[:, sl[t]])
+    errs["out"] = rel(out.view(-1), o_out.detach().reshape(-1))
+    # loss + grad seed: regression uses the engine's fused MSE, classification seeds from the oracle's CE grad
+    if spec.regression:
+        yd = yy.reshape(-1).to(e.device, torch.float32)
+        loss, gout = e.mse_loss(out.view(-1), yd)
+        errs["loss"] = rel(loss, o_loss.reshape(1))
+        errs["grad_out"] = rel(gout, gout_ref.reshape(-1))
+    else:
+        loss = None
+        gout = gout_ref.reshape(-1).to(e.device, torch.float32)
+    gflat = e.backward(xs, flat, gout.contiguous(), B)
+    torch.cuda.synchronize()
+    grads = {k: v.detach().cpu() for k, v in eng.unflatten(spec, gflat).items()}
+    for k, g in o_grads.items():
+        ref_max = float(g.abs().max())
+        if ref_max == 0.0:
+            errs["grad:" + k] = float(grads[k].abs().max())   # must be exactly zero
+        else:
+            errs["grad:" + k] = rel(grads[k], g)
+    return errs, out.detach().cpu(), (loss.detach().cpu() if loss is not None else o_loss.detach()), grads

@@ -1,0 +1,47 @@
+"""CPU tests: the C-ABI library loads, exports every symbol include/mshgnn.h declares, and the host-side plan
+compiler (no GPU involved) produces the expected work counts and rejects bad descriptors."""
+import os
+import re
+
+import pytest
+
+from morphsym_hgnn_amd import engine
+from tests import helpers
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = engine.load_library()
+    hdr = open(os.path.join(ROOT, "include", "mshgnn.h")).read()
+    declared = set(re.findall(r"\b(mshgnn_[a-z_]+)\s*\(", hdr))
+    assert declared, "no declarations found in include/mshgnn.h"
+    for name in declared:
+        assert hasattr(lib, name), f"libmshgnn.so does not export {name}"
+    assert b"gfx950" in lib.mshgnn_version()
+
+
+def test_plan_compiler_work_counts():
+    # A1-C2 h=128 L=3: encoder 1 844 224 + (52 + 40 + 8) live node-linears * 32 768 + decoder 3 072 FLOP / window
+    info = engine.compile_plan_host(helpers.make_spec("c2", "a1-c2", "a1-c2", 128, 3), "f32")
+    assert info.rows_per_tile == 16 and info.total_nodes == 18 and info.lds_bytes == 18 * 8192
+    assert info.flops_fwd == 1844224 + 100 * 32768 + 3072
+    assert info.bytes_in == 7204 * 4
+    info16 = engine.compile_plan_host(helpers.make_spec("c2", "a1-c2", "a1-c2", 128, 3), "bf16")
+    assert info16.rows_per_tile == 32 and info16.bytes_in == 7204 * 2
+    k4 = engine.compile_plan_host(helpers.make_spec("k4", "mini_cheetah-k4", "mini_cheetah-k4", 128, 8, regression=False), "f32")
+    assert k4.total_nodes == 20 and k4.lds_bytes == 160 * 1024
+
+
+def test_plan_compiler_rejects_bad_descriptors():
+    spec = helpers.make_spec("c2", "a1-c2", "a1-c2", 64, 2)   # hidden != 128
+    with pytest.raises(engine.MshgnnError, match="128"):
+        engine.compile_plan_host(spec, "f32")
+
+
+def test_engine_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        engine.Engine(helpers.make_spec("c2", "a1-c2", "a1-c2", 128, 1))

@@ -1,0 +1,120 @@
+"""GPU parity tests (-m gpu): the HIP engine through the C-ABI vs the fp64 oracle and the golden vectors.
+
+Tolerance (BASELINE.json north_star): 1e-4 relative fp32 for the fp32 plan.  "Relative" = max-abs error over a
+tensor / max-abs of the reference tensor (outputs, hidden states, each parameter gradient)."""
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+RTOL_F32 = 1e-4
+
+
+def _require_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device (there is no CPU fallback to fall through to)")
+
+
+@pytest.mark.parametrize("name", helpers.GOLDEN_CASES)
+def test_engine_matches_oracle_and_golden_f32(name):
+    _require_gpu()
+    case, spec, fx, x_dict, y, params, ei = helpers.load_case(name)
+    errs, out, loss, grads = helpers.run_engine_case(spec, x_dict, y, params, ei, case["B"], dtype="f32")
+    bad = {k: v for k, v in errs.items() if v > RTOL_F32}
+    assert not bad, f"{name}: stages above {RTOL_F32}: {bad}"
+    # and against the committed vectors generated from the reference import
+    helpers.check_against_fixture(fx, out, loss if spec.regression else None, grads, rtol=RTOL_F32, what=name)
+
+
+def test_dead_parameters_get_exact_zero_gradients():
+    """Last-layer relations into base/joint cannot influence the foot output: the reference leaves their
+    .grad None, the engine writes exact zeros."""
+    _require_gpu()
+    case, spec, fx, x_dict, y, params, ei = helpers.load_case("a1c2_h128_L3_d3_B3")
+    _, _, _, grads = helpers.run_engine_case(spec, x_dict, y, params, ei, case["B"], dtype="f32")
+    k = "convs.2.convs.<base___front_bj___joint>.lin_rel.weight"
+    assert float(grads[k].abs().max()) == 0.0
+    assert float(fx["gnorm:" + k]) == 0.0
+
+
+def test_ragged_batches_and_repeatability():
+    """Batch sizes that are not a multiple of the window tile (16), incl. B=1; two runs are bit-identical
+    (slab reduction is deterministic, no float atomics on the gradient path)."""
+    _require_gpu()
+    from morphsym_hgnn_amd import engine as eng, synth
+    from oracle import ms_hgnn_oracle as orc
+    spec = helpers.make_spec("c2", "a1-c2", "a1-c2", 128, 2)
+    cfg = helpers.oracle_config(spec)
+    e = eng.Engine(spec, "f32")
+    params = synth.make_params(5, spec.param_shapes())
+    flat = eng.flatten_params(spec, params, e.device)
+    for B in (1, 15, 17, 33):
+        x_dict, y = synth.make_windows(100 + B, B, spec.num_nodes, spec.widths, 12)
+        ei = spec.topology.edge_index_dict(B)
+        o_out, o_loss, o_grads = orc.step(cfg, params, x_dict, ei, y, B)
+        xs = e.cast_inputs(x_dict)
+        out = e.forward(xs, flat, B)
+        loss, g = e.mse_loss(out.view(-1), y.reshape(-1).to(e.device, torch.float32))
+        gf1 = e.backward(xs, flat, g, B).clone()
+        out2 = e.forward(xs, flat, B)
+        gf2 = e.backward(xs, flat, g, B)
+        torch.cuda.synchronize()
+        assert torch.equal(out, out2) and torch.equal(gf1, gf2)
+        assert float((out.cpu().double().view(-1) - o_out.reshape(-1)).abs().max() / o_out.abs().max()) < RTOL_F32
+        grads = eng.unflatten(spec, gf1.cpu())
+        for k, ref in o_grads.items():
+            m = float(ref.abs().max())
+            if m == 0:
+                assert float(grads[k].abs().max()) == 0.0
+            else:
+                assert float((grads[k].double() - ref).abs().max()) / m < RTOL_F32, (B, k)
+
+
+def test_equivariance_identity_on_gpu():
+    """f(g.x) == g.f(x) through the HIP path.  Exact in fp64; in fp32 the two sides round
+    differently only through reassociation, so they agree to 1e-5 relative."""
+    _require_gpu()
+    from morphsym_hgnn_amd import engine as eng, synth
+    from tests.test_oracle import _act_c2
+    spec = helpers.make_spec("c2", "a1-c2", "a1-c2", 128, 3)
+    B = 8
+    x_dict, _ = synth.make_windows(11, B, spec.num_nodes, spec.widths, 12)
+    params = synth.make_params(11, spec.param_shapes())
+    e = eng.Engine(spec, "f32")
+    flat = eng.flatten_params(spec, params, e.device)
+    out = e.forward(e.cast_inputs(x_dict), flat, B, training=False).view(B, 12).cpu().double()
+    out_g = e.forward(e.cast_inputs(_act_c2(spec.group, x_dict)), flat, B, training=False).view(B, 12).cpu().double()
+    pf = torch.tensor(spec.group["permutation_Q_fs"][0])
+    rf = torch.tensor(spec.group["reflection_Q_fs"][0], dtype=torch.float64)
+    assert float((out_g - out[:, pf] * rf).abs().max() / out.abs().max()) < 1e-5
+
+
+def test_full_size_batch_properties():
+    """BASELINE config size (B=8192): linearity of the gradient in grad_out and batch-additivity -- properties
+    that do not need the oracle at full size."""
+    _require_gpu()
+    from morphsym_hgnn_amd import engine as eng, synth
+    spec = helpers.make_spec("c2", "a1-c2", "a1-c2", 128, 3)
+    B = 8192
+    e = eng.Engine(spec, "f32")
+    g = torch.Generator().manual_seed(0)
+    xs = [torch.randn(B * spec.num_nodes[t], spec.widths[t], generator=g).to(e.device) for t in spec.node_types]
+    flat = eng.flatten_params(spec, synth.make_params(3, spec.param_shapes()), e.device)
+    out = e.forward(xs, flat, B)
+    go = torch.randn(B * 4, 3, generator=g).to(e.device)
+    g1 = e.backward(xs, flat, go, B).clone()
+    g2 = e.backward(xs, flat, 2.0 * go, B).clone()
+    assert float((g2 - 2.0 * g1).abs().max() / g1.abs().max()) < 1e-5
+    # batch additivity: the gradient of the two halves adds up to the gradient of the whole
+    h = B // 2
+    xa = [x.view(B, -1)[:h].reshape(h * spec.num_nodes[t], -1).contiguous() for x, t in zip(xs, spec.node_types)]
+    xb = [x.view(B, -1)[h:].reshape(h * spec.num_nodes[t], -1).contiguous() for x, t in zip(xs, spec.node_types)]
+    oa = e.forward(xa, flat, h)
+    ga = e.backward(xa, flat, go[: h * 4].contiguous(), h).clone()
+    ob = e.forward(xb, flat, h)
+    gb = e.backward(xb, flat, go[h * 4:].contiguous(), h).clone()
+    assert torch.allclose(torch.cat([oa, ob]), out, rtol=0, atol=0)
+    assert float((ga + gb - g1).abs().max() / g1.abs().max()) < 1e-4
