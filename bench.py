@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py -- graph-windows/sec, fwd + MSE loss + bwd, A1-C2 GRF regression (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank/GPU)
+
+A "step" is one pass of the hot path over one minibatch of synthetic A1-shaped windows that is already
+resident in HBM: forward (encoder, L message-passing layers, decoder) + MSE loss + backward with every
+parameter gradient materialised (+ the RCCL gradient all-reduce when N > 1).  Prints ONE JSON line on rank 0.
+
+The workload is BASELINE.json configs[1]: A1 C2 GRF regression, h=128, L=3, grf_dimension=3, batch 8192
+time-windows per GPU (weak scaling).  `roofline` is computed for the kernel with the largest share of the
+step, from HIP events recorded around every kernel by the C-ABI (mshgnn_profile_*), in a second pass over
+the same K steps (so the events do not perturb `value`).  `cpu_baseline` times the fp64 oracle (a port of
+the reference's CPU path, oracle/ms_hgnn_oracle.py) on the host cores on a bounded sample (rank 0, N=1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK = {  # /opt/skills/guides/MI355X_MICROARCH.md: chip-level parameters
+    "hbm_GBs": 8000.0,
+    "mfma_TFLOPs": {"f32": 157.3, "bf16": 2500.0},
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8192, help="windows per GPU")
+    ap.add_argument("--layers", type=int, default=3)
+    ap.add_argument("--dtype", default=os.environ.get("MSHGNN_BENCH_DTYPE", "bf16"), choices=["f32", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=256)
+    return ap.parse_args()
+
+
+def build_spec(layers):
+    import yaml
+    from morphsym_hgnn_amd import synth, topology
+    from morphsym_hgnn_amd.spec import ModelSpec
+    with open(os.path.join(ROOT, "morphsym_hgnn_amd", "cfg", "a1-c2.yaml")) as f:
+        group = yaml.safe_load(f)
+    return ModelSpec(kind="c2", topology=topology.a1_c2(), hidden=128, num_layers=layers,
+                     widths=synth.feature_widths("c2", True), regression=True, grf_dimension=3, group=group)
+
+
+def cpu_baseline(spec, batch, budget_s=20.0):
+    """Oracle (port of the reference CPU path, fp64) timed on the host cores: fwd + MSE + bwd."""
+    from morphsym_hgnn_amd import synth
+    from oracle import ms_hgnn_oracle as orc
+    cfg = orc.OracleConfig(kind="c2", num_layers=spec.num_layers, edge_types=spec.edge_types, regression=True,
+                           grf_dimension=3, group=spec.group)
+    x_dict, y = synth.make_windows(1, batch, spec.num_nodes, spec.widths, 12)
+    params = synth.make_params(1, spec.param_shapes())
+    ei = spec.topology.edge_index_dict(batch)
+    orc.step(cfg, params, x_dict, ei, y, batch)  # warm-up
+    times = []
+    t_start = time.perf_counter()
+    while len(times) < 3 or (time.perf_counter() - t_start < budget_s and len(times) < 50):
+        t0 = time.perf_counter()
+        orc.step(cfg, params, x_dict, ei, y, batch)
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": batch / med, "unit": "windows/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle fp64 fwd+MSE+bwd, A1-C2 h128 L{spec.num_layers}, B={batch}, median of {len(times)} steps "
+                      f"({os.cpu_count()} host cpus)"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched through torch.distributed.run (one rank per GPU)")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local))
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+
+    from morphsym_hgnn_amd import engine as eng, synth
+    spec = build_spec(args.layers)
+    e = eng.Engine(spec, dtype=args.dtype, device=device)
+    B = args.batch
+    g = torch.Generator().manual_seed(1234 + rank)
+    # synthetic A1-shaped windows: one IMU window tiled to both base nodes, joints ~N(0,1), foot ones
+    imu = torch.randn(B, 1, 900, generator=g)
+    x = {"base": imu.expand(B, 2, 900).reshape(B * 2, 900), "joint": torch.randn(B * 12, 450, generator=g),
+         "foot": torch.ones(B * 4, 1)}
+    xs = e.cast_inputs(x)
+    y = torch.randn(B * 12, generator=g).to(device)
+    flat = eng.flatten_params(spec, synth.make_params(0, spec.param_shapes()), device)
+    gflat = torch.empty_like(flat)
+    out = torch.empty(B * 4, 3, dtype=torch.float32, device=device)
+
+    def step():
+        e.forward(xs, flat, B, training=True, out=out)
+        loss, gout = e.mse_loss(out.view(-1), y)
+        e.backward(xs, flat, gout, B, grad_flat=gflat)
+        if dist is not None:
+            dist.all_reduce(gflat)   # RCCL sum over ranks (DDP semantics: mean = sum / world, folded into lr)
+        return loss
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    value = world * B * args.steps / dt
+
+    # second pass with per-kernel HIP events -> roofline of the dominant kernel
+    e.profile(True)
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    stats = [s for s in e.profile_read() if s["launches"] > 0]
+    e.profile(False)
+    total_ms = sum(s["total_ms"] for s in stats)
+    dom = max(stats, key=lambda s: s["total_ms"])
+    avg_s = dom["total_ms"] / dom["launches"] * 1e-3
+    if dom["bound"] == "mfma":
+        achieved = dom["flops_per_window"] * B / avg_s / 1e12
+        peak = PEAK["mfma_TFLOPs"][args.dtype if dom["name"] != "gradw" else "f32"]
+        roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None}
+    else:
+        achieved = dom["bytes_per_window"] * B / avg_s / 1e9
+        roof = {"bound": "hbm", "achieved": achieved, "peak": PEAK["hbm_GBs"], "unit": "GB/s", "frac": achieved / PEAK["hbm_GBs"], "traffic": None}
+    roof["kernel"] = dom["name"]
+    roof["avg_us"] = avg_s * 1e6
+    roof["share_of_step"] = dom["total_ms"] / max(total_ms, 1e-9)
+    kernels = {s["name"]: round(s["total_ms"] / s["launches"] * 1e3, 2) for s in stats}
+
+    res = {
+        "metric": "graph-windows/sec fwd+bwd, A1-C2 GRF regression", "value": value, "unit": "windows/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"A1-C2 GRF regression (3-D), h=128, L={args.layers}, T=150, {B} windows/GPU, "
+                               f"fwd+MSE+bwd, all parameter gradients" + (", RCCL all-reduce" if world > 1 else ""),
+                   "global_batch": B * world, "parallelism": f"dp{world}"},
+        "roofline": roof, "kernel_us": kernels,
+        "algorithmic_flops_per_window": e.info.flops_fwd + e.info.flops_bwd,
+        "loss": float(loss.item()),
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(spec, args.cpu_batch)
+    if rank == 0:
+        print(json.dumps(res))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

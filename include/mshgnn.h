@@ -106,9 +106,24 @@ typedef struct mshgnn_ws_layout {
     size_t hb[16], t1[16], du[16];  /* base_transform stash [B][n_mlp][h] (dtype)                                   */
     size_t wpack;       /* packed weights                                                                          */
     size_t bias;        /* packed biases (fp32)                                                                    */
+    size_t dec_slabs;   /* decoder partial gradients (fp32)                                                                         */
     size_t slabs;       /* split-K partial weight gradients (fp32)                                                 */
     size_t loss;        /* 16 floats                                                                               */
 } mshgnn_ws_layout;
+
+/* Per-kernel timing (HIP events on the caller's stream) + the algorithmic work of each kernel of a step.   */
+#define MSHGNN_BOUND_HBM 0
+#define MSHGNN_BOUND_MFMA 1
+typedef struct mshgnn_kernel_stat {
+    char name[32];
+    int32_t launches;             /* launches accumulated since the last read                          */
+    int32_t bound;                /* MSHGNN_BOUND_* : the roofline that bounds this kernel             */
+    float total_ms;               /* sum of event-measured durations                                   */
+    float _pad;
+    double flops_per_window;      /* algorithmic FLOPs / window / launch                                */
+    double flops_exec_per_window; /* FLOPs the kernel issues / window / launch                          */
+    double bytes_per_window;      /* algorithmic HBM bytes / window / launch                            */
+} mshgnn_kernel_stat;
 
 const char* mshgnn_last_error(void);
 const char* mshgnn_version(void);
@@ -116,6 +131,12 @@ const char* mshgnn_version(void);
 int mshgnn_plan_create(const mshgnn_desc* desc, mshgnn_plan** plan_out);
 void mshgnn_plan_destroy(mshgnn_plan* plan);
 int mshgnn_plan_info(const mshgnn_plan* plan, mshgnn_info* info);
+
+/* Profiling: while enabled, forward/backward bracket every kernel with HIP events on the stream (not
+ * graph-capturable, not thread-safe).  mshgnn_profile_read synchronises the recorded events, fills up to
+ * *n_inout stats (one per kernel of a step, in launch order), sets *n_inout and resets the accumulators.   */
+int mshgnn_profile_enable(mshgnn_plan* plan, int on);
+int mshgnn_profile_read(mshgnn_plan* plan, mshgnn_kernel_stat* stats, int32_t* n_inout);
 
 /* Workspace for `batch` windows.  training=0: forward-only (no stash beyond what forward needs).    */
 int mshgnn_workspace_layout(const mshgnn_plan* plan, int64_t batch, int training, mshgnn_ws_layout* out);

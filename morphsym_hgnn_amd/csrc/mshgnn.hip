@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "mshgnn_plan.hpp"
 
@@ -50,19 +51,23 @@ extern "C" const char* mshgnn_version(void) { return "mshgnn 0.1 (gfx950)"; }
 // ------------------------------------------------------------------------------------------------------
 template <typename T> struct Prec;
 template <> struct Prec<float> {
-    static constexpr int ROWS = 16, EPC = 4, CPR = 32, RB = 512, NREG = 8, NBV = 16;
+    static constexpr int ROWS = 16, EPC = 4, CPR = 32, RB = 512, NREG = 8, NBV = 16, HS = 6;
     using Vec = f32x4;
     struct Acc { f32x4 c[2]; };
     struct AFrag { f32x4 v[8]; };
     struct BFrag { f32x4 v[16]; };
 };
 template <> struct Prec<__bf16> {
-    static constexpr int ROWS = 32, EPC = 8, CPR = 16, RB = 256, NREG = 16, NBV = 8;
+    static constexpr int ROWS = 32, EPC = 8, CPR = 16, RB = 256, NREG = 16, NBV = 8, HS = 4;
     using Vec = bf16x8;
     struct Acc { f32x16 c; };
     struct AFrag { bf16x8 v[8]; };
     struct BFrag { bf16x8 v[8]; };
 };
+
+// Make a lane-dependent value opaque so the compiler cannot hoist the address math derived from it out of the
+// group loop (hoisted per-register epilogue addresses were being spilled to scratch -- guide, Appendix B pitfalls).
+__device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); return x; }
 
 __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(__bf16 v) { return (float)v; }
@@ -100,7 +105,8 @@ template <typename T> __device__ __forceinline__ int lds_elem(int blk, int row, 
 }
 
 // A fragment: lane (row = lane % ROWS, group g = lane / ROWS) reads 8 consecutive chunks = its contiguous K range.
-template <typename T> __device__ __forceinline__ void load_afrag(typename Prec<T>::AFrag& a, const char* smem, int blk, int lane) {
+template <typename T> __device__ __forceinline__ void load_afrag(typename Prec<T>::AFrag& a, const char* smem, int blk, int lane_) {
+    const int lane = opaque(lane_);
     const int row = lane % Prec<T>::ROWS, g = lane / Prec<T>::ROWS;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
@@ -140,26 +146,25 @@ template <typename T> __device__ __forceinline__ void acc_init_bias(typename Pre
     else acc_fill(a, bias[wv * 32 + (lane & 31)], 0.f);
 }
 
+// layer kernels: 8 waves = 4 column slices (wn) x 2 slot halves (wh); wave (wn, wh) owns output columns
+// [32 wn, 32 wn + 32) of the destination slots u with (u & 1) == wh  ->  HS = GMAX/2 accumulators per wave.
+constexpr int LAYER_THREADS = 512;
+
 // stage node blocks [n0, n1) of an activation tensor [B][NN][128] into LDS (zero rows beyond the batch)
 template <typename T>
-__device__ __forceinline__ void stage_nodes(char* smem, const T* src, int NN, int n0, int n1, int w0, int B, int tid,
-                                            const int* node_kind /* nullable: skip NK_DEAD */) {
+__device__ __forceinline__ void stage_nodes(char* smem, const T* src, int NN, int n0, int n1, int w0, int B, int tid) {
     constexpr int CPR = Prec<T>::CPR, EPC = Prec<T>::EPC;
-    const int c = tid % CPR, r0 = tid / CPR, RSTEP = 256 / CPR;
-    for (int n = n0; n < n1; ++n) {
-        if (node_kind && node_kind[n] == NK_DEAD) continue;
-        u32x4 v[2];
+    const int c = tid % CPR, row = tid / CPR;   // ROWS * CPR == 512 == LAYER_THREADS
+    for (int nb = n0; nb < n1; nb += 6) {
+        u32x4 v[6];
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int row = r0 + it * RSTEP;
-            v[it] = u32x4{0, 0, 0, 0};
-            if (w0 + row < B) v[it] = *reinterpret_cast<const u32x4*>(src + ((size_t)(w0 + row) * NN + n) * H + c * EPC);
+        for (int i = 0; i < 6; ++i) {
+            v[i] = u32x4{0, 0, 0, 0};
+            if (nb + i < n1 && w0 + row < B) v[i] = *reinterpret_cast<const u32x4*>(src + ((size_t)(w0 + row) * NN + nb + i) * H + c * EPC);
         }
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int row = r0 + it * RSTEP;
-            *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(n, row, c)) = v[it];
-        }
+        for (int i = 0; i < 6; ++i)
+            if (nb + i < n1) *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(nb + i, row, c)) = v[i];
     }
 }
 
@@ -324,7 +329,8 @@ struct LayerArgs {
 
 // store the relu bits of one accumulator (this wave's 32 columns of ROWS windows of node n)
 template <typename T>
-__device__ __forceinline__ void store_relu_bits(typename Prec<T>::Acc& acc, unsigned* maskbits, int NN, int n, int w0, int B, int wv, int lane) {
+__device__ __forceinline__ void store_relu_bits(typename Prec<T>::Acc& acc, unsigned* maskbits, int NN, int n, int w0, int B, int wv, int lane_) {
+    const int lane = opaque(lane_);
     if constexpr (sizeof(T) == 4) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -347,19 +353,20 @@ __device__ __forceinline__ void store_relu_bits(typename Prec<T>::Acc& acc, unsi
     }
 }
 
-template <typename T> __global__ __launch_bounds__(256) void k_layer_fwd(LayerArgs a) {
+template <typename T> __global__ __launch_bounds__(LAYER_THREADS) void k_layer_fwd(LayerArgs a) {
     using P = Prec<T>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wv & 3, wh = wv >> 2;
     const int w0 = blockIdx.x * P::ROWS, B = a.B, NN = a.NN;
     const T* xin = reinterpret_cast<const T*>(a.x_in);
     T* xout = reinterpret_cast<T*>(a.x_out);
     const T* wpack = reinterpret_cast<const T*>(a.wpack);
 
-    stage_nodes<T>(smem, xin, NN, 0, NN, w0, B, tid, nullptr);
+    stage_nodes<T>(smem, xin, NN, 0, NN, w0, B, tid);
     __syncthreads();
 
-    typename P::Acc acc[GMAX];
+    typename P::Acc acc[P::HS];
     typename P::BFrag bf;
     typename P::AFrag af;
     const int* pg = a.prog;
@@ -370,29 +377,34 @@ template <typename T> __global__ __launch_bounds__(256) void k_layer_fwd(LayerAr
         const int kind = gh[GH_KIND], ns = gh[GH_NSLOTS], nent = gh[GH_NENT], flags = gh[GH_FLAGS];
         const float* bias = a.bias + (size_t)gh[GH_BIAS] * H;
 #pragma unroll
-        for (int u = 0; u < GMAX; ++u) acc_init_bias<T>(acc[u], bias, wv, lane);
+        for (int u = 0; u < P::HS; ++u) acc_init_bias<T>(acc[u], bias, wn, lane);
         const int* ent = gh + GH_SIZE;
         for (int e = 0; e < nent; ++e) {
             const int op = ent[e * ENT_INTS], slot = ent[e * ENT_INTS + 1], arg = ent[e * ENT_INTS + 2];
-            if (op == OP_LOADW) { load_bfrag<T>(bf, wpack, arg, wv, lane); continue; }
+            if (op == OP_LOADW) { load_bfrag<T>(bf, wpack, arg, wn, lane); continue; }
+            if ((slot & 1) != wh) continue;
             load_afrag<T>(af, smem, arg, lane);
 #pragma unroll
-            for (int u = 0; u < GMAX; ++u) if (u == slot) mac(acc[u], af, bf);
+            for (int u = 0; u < P::HS; ++u) if (u == (slot >> 1)) mac(acc[u], af, bf);
         }
         if (kind == KIND_RELU) {
 #pragma unroll
-            for (int u = 0; u < GMAX; ++u) {
-                if (u < ns) {
-                    const int n = gh[GH_NODES + u];
-                    if (flags & GF_STORE_MASK) store_relu_bits<T>(acc[u], a.maskbits, NN, n, w0, B, wv, lane);
+            for (int u = 0; u < P::HS; ++u) {
+                const int slot = 2 * u + wh;
+                if (slot < ns) {
+                    const int n = gh[GH_NODES + slot];
+                    if (flags & GF_STORE_MASK) store_relu_bits<T>(acc[u], a.maskbits, NN, n, w0, B, wn, lane);
+                    T* obase = xout + ((size_t)w0 * NN + n) * H + wn * 32;   // wave-uniform
+const int ln = opaque(lane);
 #pragma unroll
                     for (int q = 0; q < P::NREG; ++q) {
-                        const int row = c_row<T>(q, lane), col = wv * 32 + c_col<T>(q, lane);
+                        const int row = c_row<T>(q, ln), col = c_col<T>(q, ln);
                         float y = fmaxf(acc_ref(acc[u], q), 0.f);
-                        if (flags & GF_RESIDUAL) y += to_f32(*reinterpret_cast<const T*>(smem + lds_elem<T>(n, row, col)));
-                        if (w0 + row < B) xout[((size_t)(w0 + row) * NN + n) * H + col] = from_f32<T>(y);
+                        if (flags & GF_RESIDUAL) y += to_f32(*reinterpret_cast<const T*>(smem + lds_elem<T>(n, row, wn * 32 + col)));
+                        if (w0 + row < B) obase[(unsigned)(row * NN * H + col)] = from_f32<T>(y);
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
         } else {
             // base_transform: Y = W2 relu(W1 H + b1) + b2, X <- Y + X   (hgnn_c2.py:117-121,156,161-166)
@@ -400,12 +412,14 @@ template <typename T> __global__ __launch_bounds__(256) void k_layer_fwd(LayerAr
             T* t1 = reinterpret_cast<T*>(a.t1);
             __syncthreads();   // every wave is done reading the group's source blocks
 #pragma unroll
-            for (int u = 0; u < GMAX; ++u) {
-                if (u < ns) {
-                    const int n = gh[GH_NODES + u], mi = gh[GH_MLPIDX + u];
+            for (int u = 0; u < P::HS; ++u) {
+                const int slot = 2 * u + wh;
+                if (slot < ns) {
+                    const int n = gh[GH_NODES + slot], mi = gh[GH_MLPIDX + slot];
+const int ln = opaque(lane);
 #pragma unroll
                     for (int q = 0; q < P::NREG; ++q) {
-                        const int row = c_row<T>(q, lane), col = wv * 32 + c_col<T>(q, lane);
+                        const int row = c_row<T>(q, ln), col = wn * 32 + c_col<T>(q, ln);
                         const T hv = from_f32<T>(acc_ref(acc[u], q));
                         *reinterpret_cast<T*>(smem + lds_elem<T>(n, row, col)) = hv;
                         if (w0 + row < B) hb[((size_t)(w0 + row) * a.n_mlp + mi) * H + col] = hv;
@@ -413,24 +427,27 @@ template <typename T> __global__ __launch_bounds__(256) void k_layer_fwd(LayerAr
                 }
             }
             __syncthreads();
-            load_bfrag<T>(bf, wpack, gh[GH_W1], wv, lane);
+            load_bfrag<T>(bf, wpack, gh[GH_W1], wn, lane);
             const float* b1 = a.bias + (size_t)gh[GH_B1] * H;
 #pragma unroll
-            for (int u = 0; u < GMAX; ++u) {
-                if (u < ns) {
-                    acc_init_bias<T>(acc[u], b1, wv, lane);
-                    load_afrag<T>(af, smem, gh[GH_NODES + u], lane);
+            for (int u = 0; u < P::HS; ++u) {
+                const int slot = 2 * u + wh;
+                if (slot < ns) {
+                    acc_init_bias<T>(acc[u], b1, wn, lane);
+                    load_afrag<T>(af, smem, gh[GH_NODES + slot], lane);
                     mac(acc[u], af, bf);
                 }
             }
             __syncthreads();   // all reads of H done before T1 overwrites the blocks
 #pragma unroll
-            for (int u = 0; u < GMAX; ++u) {
-                if (u < ns) {
-                    const int n = gh[GH_NODES + u], mi = gh[GH_MLPIDX + u];
+            for (int u = 0; u < P::HS; ++u) {
+                const int slot = 2 * u + wh;
+                if (slot < ns) {
+                    const int n = gh[GH_NODES + slot], mi = gh[GH_MLPIDX + slot];
+const int ln = opaque(lane);
 #pragma unroll
                     for (int q = 0; q < P::NREG; ++q) {
-                        const int row = c_row<T>(q, lane), col = wv * 32 + c_col<T>(q, lane);
+                        const int row = c_row<T>(q, ln), col = wn * 32 + c_col<T>(q, ln);
                         const T tv = from_f32<T>(fmaxf(acc_ref(acc[u], q), 0.f));
                         *reinterpret_cast<T*>(smem + lds_elem<T>(n, row, col)) = tv;
                         if (w0 + row < B) t1[((size_t)(w0 + row) * a.n_mlp + mi) * H + col] = tv;
@@ -438,18 +455,20 @@ template <typename T> __global__ __launch_bounds__(256) void k_layer_fwd(LayerAr
                 }
             }
             __syncthreads();
-            load_bfrag<T>(bf, wpack, gh[GH_W2], wv, lane);
+            load_bfrag<T>(bf, wpack, gh[GH_W2], wn, lane);
             const float* b2 = a.bias + (size_t)gh[GH_B2] * H;
 #pragma unroll
-            for (int u = 0; u < GMAX; ++u) {
-                if (u < ns) {
-                    const int n = gh[GH_NODES + u];
-                    acc_init_bias<T>(acc[u], b2, wv, lane);
+            for (int u = 0; u < P::HS; ++u) {
+                const int slot = 2 * u + wh;
+                if (slot < ns) {
+                    const int n = gh[GH_NODES + slot];
+                    acc_init_bias<T>(acc[u], b2, wn, lane);
                     load_afrag<T>(af, smem, n, lane);
                     mac(acc[u], af, bf);
+const int ln = opaque(lane);
 #pragma unroll
                     for (int q = 0; q < P::NREG; ++q) {
-                        const int row = c_row<T>(q, lane), col = wv * 32 + c_col<T>(q, lane);
+                        const int row = c_row<T>(q, ln), col = wn * 32 + c_col<T>(q, ln);
                         if (w0 + row < B) {
                             float y = acc_ref(acc[u], q);
                             if (flags & GF_RESIDUAL) y += to_f32(xin[((size_t)(w0 + row) * NN + n) * H + col]);
@@ -466,10 +485,11 @@ template <typename T> __global__ __launch_bounds__(256) void k_layer_fwd(LayerAr
 // ------------------------------------------------------------------------------------------------------
 // k_layer_bwd: dH_l from dX_{l+1} (relu bits / base_transform chain), then dX_l on the transposed graph
 // ------------------------------------------------------------------------------------------------------
-template <typename T> __global__ __launch_bounds__(256) void k_layer_bwd(LayerArgs a) {
+template <typename T> __global__ __launch_bounds__(LAYER_THREADS) void k_layer_bwd(LayerArgs a) {
     using P = Prec<T>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wv & 3, wh = wv >> 2;
     const int w0 = blockIdx.x * P::ROWS, B = a.B, NN = a.NN;
     const T* dxn = reinterpret_cast<const T*>(a.x_in);     // dX_{l+1}
     T* dxo = reinterpret_cast<T*>(a.x_out);                // dX_l
@@ -483,41 +503,37 @@ template <typename T> __global__ __launch_bounds__(256) void k_layer_bwd(LayerAr
     // stage 1: dX_{l+1} -> LDS, relu nodes masked (-> dH, also written to global for the weight-gradient kernel)
     {
         constexpr int CPR = P::CPR, EPC = P::EPC;
-        const int c = tid % CPR, r0 = tid / CPR, RSTEP = 256 / CPR;
+        const int c = tid % CPR, row = tid / CPR, w = w0 + row;
         for (int n = 0; n < NN; ++n) {
             const int nk = node_kind[n];
             if (nk == NK_DEAD) continue;
+            u32x4 v = u32x4{0, 0, 0, 0};
+            if (w < B) {
+                v = *reinterpret_cast<const u32x4*>(dxn + ((size_t)w * NN + n) * H + c * EPC);
+                if (nk == NK_RELU) {
+                    const unsigned word = a.maskbits[((size_t)w * NN + n) * 4 + (c * EPC) / 32];
+                    const unsigned bits = word >> ((c * EPC) % 32);
+                    if constexpr (sizeof(T) == 4) {
 #pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int row = r0 + it * RSTEP, w = w0 + row;
-                u32x4 v = u32x4{0, 0, 0, 0};
-                if (w < B) {
-                    v = *reinterpret_cast<const u32x4*>(dxn + ((size_t)w * NN + n) * H + c * EPC);
-                    if (nk == NK_RELU) {
-                        const unsigned word = a.maskbits[((size_t)w * NN + n) * 4 + (c * EPC) / 32];
-                        const unsigned bits = word >> ((c * EPC) % 32);
-                        if constexpr (sizeof(T) == 4) {
+                        for (int e = 0; e < 4; ++e) if (!((bits >> e) & 1u)) v[e] = 0u;
+                    } else {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) if (!((bits >> e) & 1u)) v[e] = 0u;
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                unsigned m = 0;
-                                if ((bits >> (2 * e)) & 1u) m |= 0x0000ffffu;
-                                if ((bits >> (2 * e + 1)) & 1u) m |= 0xffff0000u;
-                                v[e] &= m;
-                            }
+                        for (int e = 0; e < 4; ++e) {
+                            unsigned m = 0;
+                            if ((bits >> (2 * e)) & 1u) m |= 0x0000ffffu;
+                            if ((bits >> (2 * e + 1)) & 1u) m |= 0xffff0000u;
+                            v[e] &= m;
                         }
-                        *reinterpret_cast<u32x4*>(dh + ((size_t)w * NN + n) * H + c * EPC) = v;
                     }
+                    *reinterpret_cast<u32x4*>(dh + ((size_t)w * NN + n) * H + c * EPC) = v;
                 }
-                *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(n, row, c)) = v;
             }
+            *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(n, row, c)) = v;
         }
     }
     __syncthreads();
 
-    typename P::Acc acc[GMAX];
+    typename P::Acc acc[P::HS];
     typename P::BFrag bf;
     typename P::AFrag af;
 
@@ -525,51 +541,57 @@ template <typename T> __global__ __launch_bounds__(256) void k_layer_bwd(LayerAr
         // dT1 = dY W2 ; dU = dT1 . (T1 > 0) ; dH = dU W1     (backward of base_transform)
         const T* t1 = reinterpret_cast<const T*>(a.t1);
         T* du = reinterpret_cast<T*>(a.du);
-        load_bfrag<T>(bf, wpack, w2pack, wv, lane);
+        load_bfrag<T>(bf, wpack, w2pack, wn, lane);
 #pragma unroll
-        for (int u = 0; u < GMAX; ++u) {
-            if (u < nmlp) {
+        for (int u = 0; u < P::HS; ++u) {
+            const int slot = 2 * u + wh;
+            if (slot < nmlp) {
                 acc_fill(acc[u], 0.f, 0.f);
-                load_afrag<T>(af, smem, mlp_nodes[u], lane);
+                load_afrag<T>(af, smem, mlp_nodes[slot], lane);
                 mac(acc[u], af, bf);
             }
         }
         __syncthreads();   // all reads of dY blocks done
 #pragma unroll
-        for (int u = 0; u < GMAX; ++u) {
-            if (u < nmlp) {
-                const int n = mlp_nodes[u];
+        for (int u = 0; u < P::HS; ++u) {
+            const int slot = 2 * u + wh;
+            if (slot < nmlp) {
+                const int n = mlp_nodes[slot];
+const int ln = opaque(lane);
 #pragma unroll
                 for (int q = 0; q < P::NREG; ++q) {
-                    const int row = c_row<T>(q, lane), col = wv * 32 + c_col<T>(q, lane);
+                    const int row = c_row<T>(q, ln), col = wn * 32 + c_col<T>(q, ln);
                     float v = 0.f;
                     if (w0 + row < B) {
-                        const float tv = to_f32(t1[((size_t)(w0 + row) * a.n_mlp + u) * H + col]);
+                        const float tv = to_f32(t1[((size_t)(w0 + row) * a.n_mlp + slot) * H + col]);
                         v = tv > 0.f ? acc_ref(acc[u], q) : 0.f;
-                        du[((size_t)(w0 + row) * a.n_mlp + u) * H + col] = from_f32<T>(v);
+                        du[((size_t)(w0 + row) * a.n_mlp + slot) * H + col] = from_f32<T>(v);
                     }
                     *reinterpret_cast<T*>(smem + lds_elem<T>(n, row, col)) = from_f32<T>(v);
                 }
             }
         }
         __syncthreads();
-        load_bfrag<T>(bf, wpack, w1pack, wv, lane);
+        load_bfrag<T>(bf, wpack, w1pack, wn, lane);
 #pragma unroll
-        for (int u = 0; u < GMAX; ++u) {
-            if (u < nmlp) {
+        for (int u = 0; u < P::HS; ++u) {
+            const int slot = 2 * u + wh;
+            if (slot < nmlp) {
                 acc_fill(acc[u], 0.f, 0.f);
-                load_afrag<T>(af, smem, mlp_nodes[u], lane);
+                load_afrag<T>(af, smem, mlp_nodes[slot], lane);
                 mac(acc[u], af, bf);
             }
         }
         __syncthreads();   // all reads of dU blocks done
 #pragma unroll
-        for (int u = 0; u < GMAX; ++u) {
-            if (u < nmlp) {
-                const int n = mlp_nodes[u];
+        for (int u = 0; u < P::HS; ++u) {
+            const int slot = 2 * u + wh;
+            if (slot < nmlp) {
+                const int n = mlp_nodes[slot];
+const int ln = opaque(lane);
 #pragma unroll
                 for (int q = 0; q < P::NREG; ++q) {
-                    const int row = c_row<T>(q, lane), col = wv * 32 + c_col<T>(q, lane);
+                    const int row = c_row<T>(q, ln), col = wn * 32 + c_col<T>(q, ln);
                     const T hv = from_f32<T>(acc_ref(acc[u], q));
                     *reinterpret_cast<T*>(smem + lds_elem<T>(n, row, col)) = hv;
                     if (w0 + row < B) dh[((size_t)(w0 + row) * NN + n) * H + col] = hv;
@@ -586,31 +608,36 @@ template <typename T> __global__ __launch_bounds__(256) void k_layer_bwd(LayerAr
         const int* gh = pg + off;
         const int ns = gh[GH_NSLOTS], nent = gh[GH_NENT], flags = gh[GH_FLAGS];
 #pragma unroll
-        for (int u = 0; u < GMAX; ++u) acc_fill(acc[u], 0.f, 0.f);
+        for (int u = 0; u < P::HS; ++u) acc_fill(acc[u], 0.f, 0.f);
         const int* ent = gh + GH_SIZE;
         for (int e = 0; e < nent; ++e) {
             const int op = ent[e * ENT_INTS], slot = ent[e * ENT_INTS + 1], arg = ent[e * ENT_INTS + 2];
-            if (op == OP_LOADW) { load_bfrag<T>(bf, wpack, arg, wv, lane); continue; }
+            if (op == OP_LOADW) { load_bfrag<T>(bf, wpack, arg, wn, lane); continue; }
+            if ((slot & 1) != wh) continue;
             load_afrag<T>(af, smem, arg, lane);
 #pragma unroll
-            for (int u = 0; u < GMAX; ++u) if (u == slot) mac(acc[u], af, bf);
+            for (int u = 0; u < P::HS; ++u) if (u == (slot >> 1)) mac(acc[u], af, bf);
         }
 #pragma unroll
-        for (int u = 0; u < GMAX; ++u) {
-            if (u < ns) {
-                const int n = gh[GH_NODES + u];
+        for (int u = 0; u < P::HS; ++u) {
+            const int slot = 2 * u + wh;
+            if (slot < ns) {
+                const int n = gh[GH_NODES + slot];
+                const size_t ubase = ((size_t)w0 * NN + n) * H + wn * 32;   // wave-uniform
+const int ln = opaque(lane);
 #pragma unroll
                 for (int q = 0; q < P::NREG; ++q) {
-                    const int row = c_row<T>(q, lane), col = wv * 32 + c_col<T>(q, lane);
+                    const int row = c_row<T>(q, ln), col = c_col<T>(q, ln);
                     if (w0 + row < B) {
-                        const size_t idx = ((size_t)(w0 + row) * NN + n) * H + col;
+                        const unsigned o = (unsigned)(row * NN * H + col);
                         float y = acc_ref(acc[u], q);
-                        if (flags & GF_RESIDUAL) y += to_f32(dxn[idx]);
-                        if (flags & GF_ENC_MASK) y = to_f32(xact[idx]) > 0.f ? y : 0.f;
-                        dxo[idx] = from_f32<T>(y);
+                        if (flags & GF_RESIDUAL) y += to_f32((dxn + ubase)[o]);
+                        if (flags & GF_ENC_MASK) y = to_f32((xact + ubase)[o]) > 0.f ? y : 0.f;
+                        (dxo + ubase)[o] = from_f32<T>(y);
                     }
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         off += GH_SIZE + nent * ENT_INTS;
     }
@@ -641,7 +668,7 @@ template <typename T> __global__ __launch_bounds__(256) void k_dec_fwd(DecArgs a
 }
 
 template <typename T> __global__ __launch_bounds__(256) void k_dec_bwd(DecArgs a) {
-    __shared__ float red[2][8 * H + 8];
+    __shared__ float red[2][DEC_SLAB_FLOATS];
     const int k = threadIdx.x & 127, half = threadIdx.x >> 7;
     const int64_t rows = (int64_t)a.B * a.n_out;
     const int64_t per = (rows + gridDim.x - 1) / gridDim.x;
@@ -652,6 +679,7 @@ template <typename T> __global__ __launch_bounds__(256) void k_dec_bwd(DecArgs a
     float wk[8], accw[8], accb[8];
 #pragma unroll
     for (int d = 0; d < 8; ++d) { wk[d] = d < a.dout ? W[d * H + k] : 0.f; accw[d] = 0.f; accb[d] = 0.f; }
+#pragma unroll 4
     for (int64_t r = r_begin + half; r < r_end; r += 2) {
         const int w = (int)(r / a.n_out), f = (int)(r % a.n_out);
         const size_t idx = ((size_t)w * a.NN + a.node0 + f) * H + k;
@@ -669,11 +697,11 @@ template <typename T> __global__ __launch_bounds__(256) void k_dec_bwd(DecArgs a
 #pragma unroll
     for (int d = 0; d < 8; ++d) { red[half][d * H + k] = accw[d]; if (k == 0) red[half][8 * H + d] = accb[d]; }
     __syncthreads();
-    float* slab = a.slabs + (size_t)(a.slab0 + blockIdx.x) * SLAB_FLOATS;
+    float* slab = a.slabs + (size_t)blockIdx.x * DEC_SLAB_FLOATS;
     if (half == 0) {
 #pragma unroll
-        for (int d = 0; d < 8; ++d) if (d < a.dout) slab[d * H + k] = red[0][d * H + k] + red[1][d * H + k];
-        if (k < a.dout) slab[H * H + k] = red[0][8 * H + k] + red[1][8 * H + k];
+        for (int d = 0; d < 8; ++d) slab[d * H + k] = red[0][d * H + k] + red[1][d * H + k];
+        if (k < 8) slab[8 * H + k] = red[0][8 * H + k] + red[1][8 * H + k];
     }
 }
 
@@ -695,25 +723,27 @@ __global__ void k_mse(const float* out, const float* y, int64_t n, float* loss, 
 
 // ------------------------------------------------------------------------------------------------------
 // k_gradw: all weight gradients of the step as one split-K MFMA launch.  dW[o][k] = sum_w P[w][o] Q[w][k]
+// workgroup = (lane, part): the lane's <= GW_IPL items over window part `part`; slab index = blockIdx.x
 // ------------------------------------------------------------------------------------------------------
 struct GradwArgs {
     const char* ws; size_t buf_off[BUF_COUNT];
-    const void* x[MSHGNN_MAX_TYPES]; int64_t pitch[MSHGNN_MAX_TYPES]; int nodes[MSHGNN_MAX_TYPES];
-    const int* items; const int* targets; const int* wg2t; const uint8_t* signs; float* slabs; int B;
+    const void* x[MSHGNN_MAX_TYPES]; int64_t pitch[MSHGNN_MAX_TYPES]; int nodes[MSHGNN_MAX_TYPES]; int vb[MSHGNN_MAX_TYPES];
+    const int* items; const int* lanes; const uint8_t* signs; float* slabs; int B, n_lanes, n_parts;
 };
-constexpr int GW_KW = 32;       // windows per staged chunk
-constexpr int GW_PITCH = 144;   // floats per LDS row (bank-conflict-free column reads)
+constexpr int GW_KW = 32;       // fp32: windows per staged chunk
+constexpr int GW_PITCH = 144;   // fp32: floats per LDS row (bank-conflict-free column reads)
 
-template <typename T> __global__ __launch_bounds__(256) void k_gradw(GradwArgs a) {
+__global__ __launch_bounds__(256) void k_gradw_f32(GradwArgs a) {
+    using T = float;
     __shared__ __attribute__((aligned(16))) float Ps[GW_KW * GW_PITCH];
     __shared__ __attribute__((aligned(16))) float Qs[GW_KW * GW_PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wv >> 1, wc = wv & 1;
-    const int tg = a.wg2t[blockIdx.x];
-    const int* th = a.targets + tg * TGT_INTS;
-    const int it0 = th[0], it1 = th[1], part = blockIdx.x - th[2], nparts = th[3], bias_flag = th[4];
+    const int ln = blockIdx.x % a.n_lanes, part = blockIdx.x / a.n_lanes;
+    const int* lh = a.lanes + ln * LANE_INTS;
+    const int it0 = lh[0], it1 = lh[1], bias_flag = lh[3];
     const int nchunks = (a.B + GW_KW - 1) / GW_KW;
-    const int ch0 = (int)((int64_t)part * nchunks / nparts), ch1 = (int)((int64_t)(part + 1) * nchunks / nparts);
+    const int ch0 = (int)((int64_t)part * nchunks / a.n_parts), ch1 = (int)((int64_t)(part + 1) * nchunks / a.n_parts);
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -733,19 +763,14 @@ template <typename T> __global__ __launch_bounds__(256) void k_gradw(GradwArgs a
                 const int row = r0 + 8 * p, w = w0 + row;
                 pv[p] = f32x4{0, 0, 0, 0}; qv[p] = f32x4{0, 0, 0, 0};
                 if (w < a.B) {
-                    const T* pp = pb + (size_t)w * ps + po + c * 4;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) pv[p][e] = to_f32(pp[e]);
+                    pv[p] = *reinterpret_cast<const f32x4*>(pb + (size_t)w * ps + po + c * 4);
                     if (qs >= 0) {
-                        const T* qq = reinterpret_cast<const T*>(a.ws + a.buf_off[qbuf]) + (size_t)w * qs + qo + c * 4;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) qv[p][e] = to_f32(qq[e]);
+                        qv[p] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const T*>(a.ws + a.buf_off[qbuf]) + (size_t)w * qs + qo + c * 4);
                     } else {
                         const int t = qbuf - BUF_IN;
                         const T* qq = reinterpret_cast<const T*>(a.x[t]) + ((size_t)w * a.nodes[t] + qo) * a.pitch[t] + qc0 + c * 4;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (c * 4 + e < qn) { const float v = to_f32(qq[e]); qv[p][e] = a.signs[so + c * 4 + e] ? -v : v; }
+                        const u32x4 raw = load_chunk<T>(qq, qn - c * 4, a.vb[t]) ^ sign_xor<T>(a.signs + so + c * 4);
+                        qv[p] = __builtin_bit_cast(f32x4, raw);
                     }
                 }
             }
@@ -797,8 +822,129 @@ template <typename T> __global__ __launch_bounds__(256) void k_gradw(GradwArgs a
     }
 }
 
+// bf16: P/Q staged row-major ([window][feature], pitch 160 elements = 320 B: 4 consecutive windows land on
+// disjoint 16-bank ranges) and read as MFMA operands with the hardware-transposing ds_read_b64_tr_b16 (guide T10):
+// both operands are K(=window)-strided in memory.  32x32x16 bf16 MFMA, wave = 64x64 of the 128x128 tile.
+constexpr int GWB_KW = 64;
+constexpr int GWB_PITCH = 160;
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x8 tr_frag(const __bf16* tile, int w_base, int col_base, int lane) {
+    // lane = 16 g + 4 q + p: supplies the address of row q, columns 4p..4p+3 of its group's 4x16 block;
+    // receives column (lane & 15) of the 4 rows.  g&1 selects the 16-column half, g>>1 the K half (8 windows).
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const __bf16* p0 = tile + (w_base + 8 * (g >> 1) + q) * GWB_PITCH + col_base + 16 * (g & 1) + 4 * pp;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0 + 4 * GWB_PITCH));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(256) void k_gradw_bf16(GradwArgs a) {
+    using T = __bf16;
+    __shared__ __attribute__((aligned(16))) __bf16 Ps[GWB_KW * GWB_PITCH];
+    __shared__ __attribute__((aligned(16))) __bf16 Qs[GWB_KW * GWB_PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wv >> 1, wc = wv & 1;
+    const int ln = blockIdx.x % a.n_lanes, part = blockIdx.x / a.n_lanes;
+    const int* lh = a.lanes + ln * LANE_INTS;
+    const int it0 = lh[0], nit = lh[1] - lh[0], bias_flag = lh[3];
+    const int nchunks = (a.B + GWB_KW - 1) / GWB_KW;
+    const int ch0 = (int)((int64_t)part * nchunks / a.n_parts), ch1 = (int)((int64_t)(part + 1) * nchunks / a.n_parts);
+    const int nsteps = (ch1 - ch0) * nit;    // step s -> chunk ch0 + s / nit, item it0 + s % nit
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+    float bsum[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
+    const int c = tid & 15, r0 = tid >> 4;   // staging: 16 chunks of 8 bf16 per row, 16 rows per pass
+    u32x4 pv[4], qv[4];
+    auto fetch = [&](int s) {
+        const int w0 = (ch0 + s / nit) * GWB_KW;
+        const int* im = a.items + (it0 + s % nit) * ITEM_INTS;
+        const T* pb = reinterpret_cast<const T*>(a.ws + a.buf_off[im[0]]);
+        const int ps = im[1], po = im[2], qbuf = im[3], qs = im[4], qo = im[5], qc0 = im[6], qn = im[7], so = im[8];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int row = r0 + 16 * p, w = w0 + row;
+            pv[p] = u32x4{0, 0, 0, 0}; qv[p] = u32x4{0, 0, 0, 0};
+            if (w < a.B) {
+                pv[p] = *reinterpret_cast<const u32x4*>(pb + (size_t)w * ps + po + c * 8);
+                if (qs >= 0) {
+                    qv[p] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(a.ws + a.buf_off[qbuf]) + (size_t)w * qs + qo + c * 8);
+                } else {
+                    const int t = qbuf - BUF_IN;
+                    const T* qq = reinterpret_cast<const T*>(a.x[t]) + ((size_t)w * a.nodes[t] + qo) * a.pitch[t] + qc0 + c * 8;
+                    qv[p] = load_chunk<T>(qq, qn - c * 8, a.vb[t]) ^ sign_xor<T>(a.signs + so + c * 8);
+                }
+            }
+        }
+    };
+    if (nsteps > 0) fetch(0);
+    for (int s = 0; s < nsteps; ++s) {
+        __syncthreads();   // previous MFMA phase finished reading Ps/Qs
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int row = r0 + 16 * p;
+            *reinterpret_cast<u32x4*>(&Ps[row * GWB_PITCH + c * 8]) = pv[p];
+            *reinterpret_cast<u32x4*>(&Qs[row * GWB_PITCH + c * 8]) = qv[p];
+            if (bias_flag) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bsum[2 * e] += __builtin_bit_cast(float, pv[p][e] << 16);
+                    bsum[2 * e + 1] += __builtin_bit_cast(float, pv[p][e] & 0xffff0000u);
+                }
+            }
+        }
+        __syncthreads();
+        if (s + 1 < nsteps) fetch(s + 1);   // global loads of the next step fly under this step's MFMAs
+#pragma unroll
+        for (int ks = 0; ks < GWB_KW / 16; ++ks) {
+            bf16x8 af[2], bq[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i] = tr_frag(Ps, ks * 16, wr * 64 + i * 32, lane);
+                bq[i] = tr_frag(Qs, ks * 16, wc * 64 + i * 32, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bq[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    float* slab = a.slabs + (size_t)blockIdx.x * SLAB_FLOATS;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int o = wr * 64 + i * 32 + (q & 3) + ((q >> 2) << 3) + ((lane >> 5) << 2), k = wc * 64 + j * 32 + (lane & 31);
+                slab[o * H + k] = acc[i][j][q];
+            }
+    if (bias_flag) {
+        float* red = reinterpret_cast<float*>(Ps);   // 16 x 128 floats = 8 KB <= sizeof(Ps)
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[r0 * H + c * 8 + e] = bsum[e];
+        __syncthreads();
+        if (tid < H) {
+            float s2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s2 += red[r * H + tid];
+            slab[H * H + tid] = s2;
+        }
+    }
+}
+
 // k_finalize: sum split-K slabs in fixed order into the flat gradient buffer (every parameter written once)
-struct FinArgs { const int* fin; const int* targets; const float* slabs; float* grad; int dec_slab0; };
+struct FinArgs { const int* fin; const int* targets; const float* slabs; const float* dec_slabs; float* grad; int n_lanes, n_parts; };
 
 __global__ __launch_bounds__(256) void k_finalize(FinArgs a) {
     const int* f = a.fin + blockIdx.x * FIN_INTS;
@@ -806,15 +952,36 @@ __global__ __launch_bounds__(256) void k_finalize(FinArgs a) {
     const int rows = f[2], cols = f[3], ld = f[4], tg = f[5], kind = f[6];
     const int RPB = (rows + gridDim.y - 1) / gridDim.y;
     const int r0 = blockIdx.y * RPB, r1 = min(rows, r0 + RPB);
-    int s0 = 0, s1 = 0;
-    if (kind == FIN_MATRIX || kind == FIN_BIAS) { s0 = a.targets[tg * TGT_INTS + 2]; s1 = s0 + a.targets[tg * TGT_INTS + 3]; }
-    else if (kind == FIN_DEC_W || kind == FIN_DEC_B) { s0 = a.dec_slab0; s1 = s0 + NWG_DEC; }
     const int n = (r1 - r0) * cols;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    if (n <= 0) return;
+    const bool is_mat = (kind == FIN_MATRIX || kind == FIN_DEC_W);
+    for (int i = threadIdx.x; i < n; i += 256) {
         const int r = r0 + i / cols, cidx = i % cols;
         float s = 0.f;
-        if (kind == FIN_MATRIX || kind == FIN_DEC_W) { for (int sl = s0; sl < s1; ++sl) s += a.slabs[(size_t)sl * SLAB_FLOATS + r * H + cidx]; }
-        else if (kind == FIN_BIAS || kind == FIN_DEC_B) { for (int sl = s0; sl < s1; ++sl) s += a.slabs[(size_t)sl * SLAB_FLOATS + H * H + cidx]; }
+        if (kind == FIN_MATRIX || kind == FIN_BIAS) {
+            const int src = is_mat ? r * H + cidx : H * H + cidx;
+            const int l0 = a.targets[tg * TGT_INTS], nl = a.targets[tg * TGT_INTS + 1] - l0;
+            const int total = nl * a.n_parts;     // slab(k) = (k / nl) * n_lanes + l0 + k % nl   -- fixed summation order
+            int k = 0;
+            for (; k + 8 <= total; k += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int kk = k + u;
+                    v[u] = a.slabs[(size_t)((kk / nl) * a.n_lanes + l0 + kk % nl) * SLAB_FLOATS + src];
+                }
+                s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            }
+            for (; k < total; ++k) s += a.slabs[(size_t)((k / nl) * a.n_lanes + l0 + k % nl) * SLAB_FLOATS + src];
+        } else if (kind == FIN_DEC_W || kind == FIN_DEC_B) {
+            const int src = is_mat ? r * H + cidx : 8 * H + cidx;
+            for (int b = 0; b < NWG_DEC; b += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = a.dec_slabs[(size_t)(b + u) * DEC_SLAB_FLOATS + src];
+                s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            }
+        }
         a.grad[dst + (int64_t)r * ld + cidx] = s;
     }
 }
@@ -822,11 +989,27 @@ __global__ __launch_bounds__(256) void k_finalize(FinArgs a) {
 // ------------------------------------------------------------------------------------------------------
 // plan object + C-ABI
 // ------------------------------------------------------------------------------------------------------
+struct ProfRec { int slot; hipEvent_t a, b; };
 struct mshgnn_plan {
     HostPlan hp;
+    bool prof = false;
+    std::vector<ProfRec> recs;          // recorded, not yet read
+    std::vector<hipEvent_t> free_events;
     int* d_tables = nullptr; uint8_t* d_signs = nullptr; float* d_out_mask = nullptr;
     PackDesc* d_packs = nullptr; BiasDesc* d_biases = nullptr;
     bool attr_set = false;
+};
+
+// bracket one kernel launch with events when profiling
+struct ProfScope {
+    mshgnn_plan* p; hipStream_t st; ProfRec r{}; bool on;
+    ProfScope(const mshgnn_plan* pc, int slot, hipStream_t s) : p(const_cast<mshgnn_plan*>(pc)), st(s), on(pc->prof) {
+        if (!on) return;
+        auto get = [&]() { hipEvent_t e; if (!p->free_events.empty()) { e = p->free_events.back(); p->free_events.pop_back(); } else (void)hipEventCreate(&e); return e; };
+        r.slot = slot; r.a = get(); r.b = get();
+        (void)hipEventRecord(r.a, st);
+    }
+    ~ProfScope() { if (on) { (void)hipEventRecord(r.b, st); p->recs.push_back(r); } }
 };
 
 template <typename K> static int set_lds_attr(K kernel, int bytes) {
@@ -881,7 +1064,32 @@ extern "C" void mshgnn_plan_destroy(mshgnn_plan* p) {
     if (p->d_out_mask) (void)hipFree(p->d_out_mask);
     if (p->d_packs) (void)hipFree(p->d_packs);
     if (p->d_biases) (void)hipFree(p->d_biases);
+    for (ProfRec& r : p->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (hipEvent_t e : p->free_events) (void)hipEventDestroy(e);
     delete p;
+}
+
+extern "C" int mshgnn_profile_enable(mshgnn_plan* p, int on) {
+    if (!p) return set_err(MSHGNN_EINVAL, "null plan");
+    p->prof = on != 0;
+    return MSHGNN_OK;
+}
+
+extern "C" int mshgnn_profile_read(mshgnn_plan* p, mshgnn_kernel_stat* stats, int32_t* n_inout) {
+    if (!p || !stats || !n_inout) return set_err(MSHGNN_EINVAL, "null argument");
+    std::vector<mshgnn_kernel_stat> ks = p->hp.kstats;
+    for (const ProfRec& r : p->recs) {
+        HIPCHK(hipEventSynchronize(r.b));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
+        if (r.slot >= 0 && r.slot < (int)ks.size()) { ks[r.slot].total_ms += ms; ks[r.slot].launches += 1; }
+        p->free_events.push_back(r.a); p->free_events.push_back(r.b);
+    }
+    p->recs.clear();
+    const int n = std::min<int>(*n_inout, (int)ks.size());
+    for (int i = 0; i < n; ++i) stats[i] = ks[i];
+    *n_inout = n;
+    return MSHGNN_OK;
 }
 
 extern "C" int mshgnn_plan_info(const mshgnn_plan* p, mshgnn_info* info) {
@@ -924,6 +1132,7 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
     {
         PrepArgs a{params, ws + lay.wpack, reinterpret_cast<float*>(ws + lay.bias), p->d_packs, p->d_biases, (int)hp.packs.size(), (int)hp.biases.size()};
         const int64_t total = (int64_t)hp.packs.size() * (H * H / Prec<T>::EPC) + (int64_t)hp.biases.size() * H;
+        ProfScope ps(p, hp.ks_prep, st);
         hipLaunchKernelGGL(k_prep<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
     }
     // 2. encoder
@@ -940,6 +1149,7 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
             a.wg_prefix[t + 1] = a.wg_prefix[t] + d.type_nodes[t] * a.tiles;
         }
         a.wpack = ws + lay.wpack; a.bias = reinterpret_cast<const float*>(ws + lay.bias); a.signs = p->d_signs; a.x0 = ws + lay.x[0];
+        ProfScope ps(p, hp.ks_enc, st);
         hipLaunchKernelGGL(k_enc_fwd<T>, dim3(a.wg_prefix[hp.NT]), dim3(256), ENC_MB * BLK_BYTES, st, a);
     }
     // 3. layers
@@ -949,7 +1159,8 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
         a.x_in = ws + lay.x[l]; a.x_out = ws + lay.x[l + 1]; a.maskbits = reinterpret_cast<unsigned*>(ws + lay.mask[l]);
         a.hb = ws + lay.hb[l]; a.t1 = ws + lay.t1[l]; a.wpack = ws + lay.wpack; a.bias = reinterpret_cast<const float*>(ws + lay.bias);
         a.prog = p->d_tables + hp.fwd_prog_off[l]; a.B = B; a.NN = hp.NN; a.n_mlp = std::max(1, hp.n_mlp);
-        hipLaunchKernelGGL(k_layer_fwd<T>, dim3(tiles), dim3(256), hp.NN * BLK_BYTES, st, a);
+        ProfScope ps(p, hp.ks_layer_fwd0 + l, st);
+        hipLaunchKernelGGL(k_layer_fwd<T>, dim3(tiles), dim3(LAYER_THREADS), hp.NN * BLK_BYTES, st, a);
     }
     // 4. decoder
     {
@@ -957,6 +1168,7 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
         a.xl = ws + lay.x[hp.L]; a.params = params; a.out_mask = p->d_out_mask; a.out = out; a.off_w = d.off_dec_w; a.off_b = d.off_dec_b;
         a.B = B; a.NN = hp.NN; a.node0 = hp.type_base[d.out_type]; a.n_out = d.type_nodes[d.out_type]; a.dout = d.out_channels;
         const int64_t rows = (int64_t)B * a.n_out;
+        ProfScope ps(p, hp.ks_dec_fwd, st);
         hipLaunchKernelGGL(k_dec_fwd<T>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, a);
     }
     HIPCHK(hipGetLastError());
@@ -973,8 +1185,9 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
     {
         DecArgs a{};
         a.xl = ws + lay.x[hp.L]; a.dxl = ws + lay.dx[hp.L]; a.params = params; a.out_mask = p->d_out_mask; a.gout = gout;
-        a.slabs = reinterpret_cast<float*>(ws + lay.slabs); a.off_w = d.off_dec_w; a.off_b = d.off_dec_b;
-        a.B = B; a.NN = hp.NN; a.node0 = hp.type_base[d.out_type]; a.n_out = d.type_nodes[d.out_type]; a.dout = d.out_channels; a.slab0 = hp.dec_slab0;
+        a.slabs = reinterpret_cast<float*>(ws + lay.dec_slabs); a.off_w = d.off_dec_w; a.off_b = d.off_dec_b;
+        a.B = B; a.NN = hp.NN; a.node0 = hp.type_base[d.out_type]; a.n_out = d.type_nodes[d.out_type]; a.dout = d.out_channels; a.slab0 = 0;
+        ProfScope ps(p, hp.ks_dec_bwd, st);
         hipLaunchKernelGGL(k_dec_bwd<T>, dim3(NWG_DEC), dim3(256), 0, st, a);
     }
     const int tiles = (B + Prec<T>::ROWS - 1) / Prec<T>::ROWS;
@@ -984,21 +1197,29 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
         a.hb = ws + lay.hb[l]; a.t1 = ws + lay.t1[l]; a.dh = ws + lay.dh[l]; a.du = ws + lay.du[l]; a.x_act = ws + lay.x[0];
         a.wpack = ws + lay.wpack; a.bias = reinterpret_cast<const float*>(ws + lay.bias);
         a.prog = p->d_tables + hp.bwd_prog_off[l]; a.B = B; a.NN = hp.NN; a.n_mlp = std::max(1, hp.n_mlp);
-        hipLaunchKernelGGL(k_layer_bwd<T>, dim3(tiles), dim3(256), hp.NN * BLK_BYTES, st, a);
+        ProfScope ps(p, hp.ks_layer_bwd0 + (hp.L - 1 - l), st);
+        hipLaunchKernelGGL(k_layer_bwd<T>, dim3(tiles), dim3(LAYER_THREADS), hp.NN * BLK_BYTES, st, a);
     }
     {
         GradwArgs a{};
         a.ws = ws;
         for (int l = 0; l <= hp.L; ++l) { a.buf_off[BUF_X + l] = lay.x[l]; a.buf_off[BUF_DX + l] = lay.dx[l]; }
         for (int l = 0; l < hp.L; ++l) { a.buf_off[BUF_DH + l] = lay.dh[l]; a.buf_off[BUF_HB + l] = lay.hb[l]; a.buf_off[BUF_T1 + l] = lay.t1[l]; a.buf_off[BUF_DU + l] = lay.du[l]; }
-        for (int t = 0; t < hp.NT; ++t) { a.x[t] = x[t]; a.pitch[t] = x_pitch ? x_pitch[t] : d.type_width[t]; a.nodes[t] = d.type_nodes[t]; }
-        a.items = p->d_tables + hp.item_off; a.targets = p->d_tables + hp.tgt_off; a.wg2t = p->d_tables + hp.wg2t_off;
-        a.signs = p->d_signs; a.slabs = reinterpret_cast<float*>(ws + lay.slabs); a.B = B;
-        hipLaunchKernelGGL(k_gradw<T>, dim3(hp.n_wg_gradw), dim3(256), 0, st, a);
+        for (int t = 0; t < hp.NT; ++t) {
+            a.x[t] = x[t]; a.pitch[t] = x_pitch ? x_pitch[t] : d.type_width[t]; a.nodes[t] = d.type_nodes[t];
+            a.vb[t] = vec_bytes(x[t], a.pitch[t], (int)sizeof(T));
+        }
+        a.items = p->d_tables + hp.item_off; a.lanes = p->d_tables + hp.lane_off;
+        a.signs = p->d_signs; a.slabs = reinterpret_cast<float*>(ws + lay.slabs); a.B = B; a.n_lanes = hp.n_lanes; a.n_parts = hp.n_parts;
+        ProfScope ps(p, hp.ks_gradw, st);
+        if constexpr (sizeof(T) == 4) hipLaunchKernelGGL(k_gradw_f32, dim3(hp.n_wg_gradw), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(k_gradw_bf16, dim3(hp.n_wg_gradw), dim3(256), 0, st, a);
     }
     {
-        FinArgs a{p->d_tables + hp.fin_off, p->d_tables + hp.tgt_off, reinterpret_cast<const float*>(ws + lay.slabs), gparams, hp.dec_slab0};
-        hipLaunchKernelGGL(k_finalize, dim3(hp.n_fin, 8), dim3(256), 0, st, a);
+        FinArgs a{p->d_tables + hp.fin_off, p->d_tables + hp.tgt_off, reinterpret_cast<const float*>(ws + lay.slabs),
+                  reinterpret_cast<const float*>(ws + lay.dec_slabs), gparams, hp.n_lanes, hp.n_parts};
+        ProfScope ps(p, hp.ks_fin, st);
+        hipLaunchKernelGGL(k_finalize, dim3(hp.n_fin, 32), dim3(256), 0, st, a);
     }
     HIPCHK(hipGetLastError());
     return MSHGNN_OK;

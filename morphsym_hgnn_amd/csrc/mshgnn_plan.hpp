@@ -11,8 +11,10 @@
 // skipped in forward and backward; their parameters get exact-zero gradients (the reference leaves them None).
 #pragma once
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -27,7 +29,9 @@ constexpr int BLK_BYTES = 8192;   // one LDS node block: ROWS windows x 128 feat
 constexpr int MAX_L = 16;
 constexpr int LDS_LIMIT = 160 * 1024;
 constexpr int SLAB_FLOATS = H * H + H;   // one split-K partial: 128x128 matrix + 128 column sums
-constexpr int NWG_DEC = 64;              // workgroups of the decoder backward (each writes one slab)
+constexpr int NWG_DEC = 512;             // workgroups of the decoder backward (each writes one small slab)
+constexpr int DEC_SLAB_FLOATS = 8 * H + 8; // decoder partial: [out_channels<=8][128] + bias[8]
+constexpr int GW_IPL = 2;                // items per weight-gradient lane (all workgroups advance at the same pace)
 
 enum { OP_LOADW = 0, OP_MAC = 1 };
 enum { KIND_RELU = 0, KIND_MLP = 1 };
@@ -42,7 +46,8 @@ constexpr int ENT_INTS = 4;   // {op, slot, arg, reserved}
 // buffer ids used by weight-gradient items
 enum { BUF_X = 0, BUF_DX = 17, BUF_DH = 34, BUF_HB = 50, BUF_T1 = 66, BUF_DU = 82, BUF_IN = 98, BUF_COUNT = 102 };
 constexpr int ITEM_INTS = 10;   // p_buf p_stride p_off q_buf q_stride q_off q_col0 q_ncols sign_off pad
-constexpr int TGT_INTS = 8;     // item_begin item_end wg_begin wg_count bias_flag pad..
+constexpr int TGT_INTS = 8;     // lane_begin lane_end bias_flag pad..
+constexpr int LANE_INTS = 4;    // item_begin item_end target bias_flag
 constexpr int FIN_INTS = 8;     // dst_lo dst_hi rows cols dst_ld target kind pad
 enum { FIN_MATRIX = 0, FIN_BIAS = 1, FIN_ZERO = 2, FIN_DEC_W = 3, FIN_DEC_B = 4 };
 
@@ -66,6 +71,7 @@ struct HostPlan {
     int node_type[64]{};
     int n_mlp = 0;
     int rows = 16;                 // windows per tile
+    int gmax = GMAX;               // destination slots per group (12 fp32, 8 bf16: accumulator registers)
     int esize = 4;                 // bytes per stored element
     bool live[MAX_L][MSHGNN_MAX_TYPES]{};     // layer output of type t reaches the decoder
     bool need_dx[MAX_L][MSHGNN_MAX_TYPES]{};  // dX_l[t] must be produced
@@ -82,11 +88,13 @@ struct HostPlan {
     // programs
     std::vector<int32_t> tables;                  // everything below lives here (device copy = same layout)
     int fwd_prog_off[MAX_L]{}, bwd_prog_off[MAX_L]{};
-    int item_off = 0, n_items = 0, tgt_off = 0, n_targets = 0, wg2t_off = 0, n_wg_gradw = 0;
+    int item_off = 0, n_items = 0, tgt_off = 0, n_targets = 0, lane_off = 0, n_lanes = 0, n_parts = 1, n_wg_gradw = 0;
     int fin_off = 0, n_fin = 0;
     int enc_tile_mb = 4;
-    int dec_slab0 = 0, n_slabs = 0;
+    int n_slabs = 0;
     std::vector<float> out_mask_f;
+    std::vector<mshgnn_kernel_stat> kstats;   // one per kernel of a step, in launch order
+    int ks_prep = 0, ks_enc = 0, ks_layer_fwd0 = 0, ks_dec_fwd = 0, ks_dec_bwd = 0, ks_layer_bwd0 = 0, ks_gradw = 0, ks_fin = 0;
     mshgnn_info info{};
     std::string err;
 };
@@ -132,9 +140,10 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
     if ((int64_t)p.NN * BLK_BYTES > LDS_LIMIT)
         return fail(p, "topology has too many nodes per window for the LDS-resident layer kernel (max 20)");
     p.rows = d.dtype == MSHGNN_F32 ? 16 : 32;
+    p.gmax = d.dtype == MSHGNN_F32 ? GMAX : 8;
     p.esize = d.dtype == MSHGNN_F32 ? 4 : 2;
     p.n_mlp = has_mlp ? d.type_nodes[d.mlp_type] : 0;
-    if (p.n_mlp > GMAX) return fail(p, "base_transform type has more than 12 nodes");
+    if (p.n_mlp > p.gmax) return fail(p, "base_transform type has too many nodes for one accumulator group");
 
     // deep copies
     p.rel_src.assign(d.rel_src, d.rel_src + NR); p.rel_dst.assign(d.rel_dst, d.rel_dst + NR);
@@ -247,9 +256,12 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
     for (int t = 0; t < NT; ++t) if (!(has_mlp && t == d.mlp_type)) order.push_back(t);
     if (has_mlp) order.push_back(d.mlp_type);
     double exec_fwd = 0, exec_bwd = 0, alg_fwd = 0, alg_bwd = 0;
+    std::vector<double> lf_alg(L, 0.0), lf_exec(L, 0.0), lb_alg(L, 0.0), lb_exec(L, 0.0);
+    double gw_alg = 0, gw_exec = 0;
     const double NL = 2.0 * H * H;   // FLOPs of one node-linear (one window)
 
     for (int l = 0; l < L; ++l) {
+        const double ef0 = exec_fwd, af0 = alg_fwd, eb0 = exec_bwd, ab0 = alg_bwd;
         // ---------- forward program ----------
         p.fwd_prog_off[l] = (int)T.size();
         const int ng_pos = (int)T.size(); T.push_back(0);
@@ -257,8 +269,8 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
         for (int t : order) {
             if (!p.live[l][t]) continue;
             const bool mlp = has_mlp && t == d.mlp_type;
-            for (int c0 = 0; c0 < d.type_nodes[t]; c0 += GMAX) {
-                const int ns = std::min(GMAX, d.type_nodes[t] - c0);
+            for (int c0 = 0; c0 < d.type_nodes[t]; c0 += p.gmax) {
+                const int ns = std::min(p.gmax, d.type_nodes[t] - c0);
                 const int gh = (int)T.size(); T.resize(T.size() + GH_SIZE, 0);
                 T[gh + GH_KIND] = mlp ? KIND_MLP : KIND_RELU; T[gh + GH_NSLOTS] = ns;
                 T[gh + GH_BIAS] = p.bias_layer[l * NT + t];
@@ -300,8 +312,8 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
         int ngb = 0;
         for (int t = 0; t < NT; ++t) {
             if (!p.need_dx[l][t]) continue;
-            for (int c0 = 0; c0 < d.type_nodes[t]; c0 += GMAX) {
-                const int ns = std::min(GMAX, d.type_nodes[t] - c0);
+            for (int c0 = 0; c0 < d.type_nodes[t]; c0 += p.gmax) {
+                const int ns = std::min(p.gmax, d.type_nodes[t] - c0);
                 const int gh = (int)T.size(); T.resize(T.size() + GH_SIZE, 0);
                 T[gh + GH_KIND] = KIND_RELU; T[gh + GH_NSLOTS] = ns; T[gh + GH_BIAS] = -1;
                 T[gh + GH_FLAGS] = ((residual && p.live[l][t]) ? GF_RESIDUAL : 0) | (l == 0 ? GF_ENC_MASK : 0);
@@ -326,6 +338,7 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
             }
         }
         T[bh + 0] = ngb;
+        lf_alg[l] = alg_fwd - af0; lf_exec[l] = exec_fwd - ef0; lb_alg[l] = alg_bwd - ab0; lb_exec[l] = exec_bwd - eb0;
     }
     // algorithmic dX work: one node-linear per (relation, src node with >=1 out-edge into a live dst) -- count below
     for (int l = 0; l < L; ++l)
@@ -333,8 +346,9 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
             if (!p.live[l][p.rel_dst[r]] || !p.need_dx[l][p.rel_src[r]]) continue;
             std::vector<bool> hit(d.type_nodes[p.rel_src[r]], false);
             for (int e = p.rel_edge_off[r]; e < p.rel_edge_off[r + 1]; ++e) hit[p.edges[2 * e]] = true;
-            for (bool b : hit) if (b) alg_bwd += NL;
+            for (bool b : hit) if (b) { alg_bwd += NL; lb_alg[l] += NL; }
         }
+    const double gw_e0 = exec_bwd, gw_a0 = alg_bwd;
 
     // ---- weight-gradient targets / items / finalize ops -----------------------------------------------
     struct Tgt { std::vector<int> items; int bias_flag; };
@@ -396,6 +410,9 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
             tgt_enc[t].push_back((int)tgts.size()); tgts.push_back(g);
         }
     }
+    gw_alg = alg_bwd - gw_a0; gw_exec = exec_bwd - gw_e0;
+    double enc_alg = 0, enc_exec = 0;
+    for (int t = 0; t < NT; ++t) { enc_exec += (double)d.type_nodes[t] * p.enc_nkc[t] * NL; enc_alg += (double)d.type_nodes[t] * 2.0 * H * d.type_width[t]; }
     for (int t = 0; t < NT; ++t) {   // encoder forward work
         exec_fwd += (double)d.type_nodes[t] * p.enc_nkc[t] * NL;
         alg_fwd += (double)d.type_nodes[t] * 2.0 * H * d.type_width[t];
@@ -403,32 +420,32 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
     alg_fwd += 2.0 * n_out * d.out_channels * H; exec_fwd += 2.0 * n_out * d.out_channels * H;
     alg_bwd += 4.0 * n_out * d.out_channels * H; exec_bwd += 4.0 * n_out * d.out_channels * H;
 
-    // workgroup allocation of the split-K weight-gradient kernel: proportional to item count
-    int total_items = 0; for (auto& g : tgts) total_items += (int)g.items.size();
-    const int NWG_TARGET = 512;
-    std::vector<int> wgc(tgts.size()), wgb(tgts.size());
-    int nwg = 0;
-    for (size_t g = 0; g < tgts.size(); ++g) {
-        int c = (int)std::lround((double)tgts[g].items.size() * NWG_TARGET / std::max(1, total_items));
-        c = std::max(1, std::min(c, 64));
-        wgc[g] = c; wgb[g] = nwg; nwg += c;
-    }
-    p.n_wg_gradw = nwg;
+    // work split of the split-K weight-gradient kernel: every target's items are cut into lanes of <= GW_IPL
+    // items; workgroup (lane, part) runs its lane's items over window part `part`.  All workgroups do the same
+    // work per window chunk, so they sweep the batch at the same pace and the P/Q rows that several items share
+    // are re-read from L2 / Infinity Cache instead of HBM.
     p.item_off = (int)T.size(); p.n_items = 0;
-    std::vector<int> tgt_item_begin(tgts.size()), tgt_item_end(tgts.size());
+    std::vector<std::array<int, 4>> lanes;
+    std::vector<int> tgt_lane_begin(tgts.size()), tgt_lane_end(tgts.size());
     for (size_t g = 0; g < tgts.size(); ++g) {
-        tgt_item_begin[g] = p.n_items;
+        tgt_lane_begin[g] = (int)lanes.size();
+        const int first = p.n_items;
         for (int it : tgts[g].items) { for (int k = 0; k < ITEM_INTS; ++k) T.push_back(items[it][k]); ++p.n_items; }
-        tgt_item_end[g] = p.n_items;
+        for (int i0 = first; i0 < p.n_items; i0 += GW_IPL)
+            lanes.push_back({i0, std::min(p.n_items, i0 + GW_IPL), (int)g, tgts[g].bias_flag});
+        tgt_lane_end[g] = (int)lanes.size();
     }
+    p.n_lanes = (int)lanes.size();
+    p.n_parts = std::max(1, std::min(16, (int)std::lround(512.0 / std::max(1, p.n_lanes))));
+    p.n_wg_gradw = p.n_lanes * p.n_parts;
     p.tgt_off = (int)T.size(); p.n_targets = (int)tgts.size();
     for (size_t g = 0; g < tgts.size(); ++g) {
-        T.push_back(tgt_item_begin[g]); T.push_back(tgt_item_end[g]); T.push_back(wgb[g]); T.push_back(wgc[g]);
-        T.push_back(tgts[g].bias_flag); T.push_back(0); T.push_back(0); T.push_back(0);
+        T.push_back(tgt_lane_begin[g]); T.push_back(tgt_lane_end[g]); T.push_back(tgts[g].bias_flag);
+        for (int k = 3; k < TGT_INTS; ++k) T.push_back(0);
     }
-    p.wg2t_off = (int)T.size();
-    for (size_t g = 0; g < tgts.size(); ++g) for (int c = 0; c < wgc[g]; ++c) T.push_back((int)g);
-    p.dec_slab0 = nwg; p.n_slabs = nwg + NWG_DEC;
+    p.lane_off = (int)T.size();
+    for (auto& ln : lanes) for (int k = 0; k < LANE_INTS; ++k) T.push_back(ln[k]);
+    p.n_slabs = p.n_wg_gradw;
 
     // finalize ops: every parameter is written exactly once
     p.fin_off = (int)T.size(); p.n_fin = 0;
@@ -465,8 +482,35 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
     p.info.rows_per_tile = p.rows; p.info.total_nodes = p.NN; p.info.lds_bytes = (int64_t)p.NN * BLK_BYTES;
     p.info.flops_fwd = alg_fwd; p.info.flops_bwd = alg_bwd; p.info.flops_exec_fwd = exec_fwd; p.info.flops_exec_bwd = exec_bwd;
     double bytes = 0; for (int t = 0; t < NT; ++t) bytes += (double)d.type_nodes[t] * d.type_width[t] * p.esize;
-    p.info.bytes_in = bytes; p.info.n_gradw_workgroups = nwg;
+    p.info.bytes_in = bytes; p.info.n_gradw_workgroups = p.n_wg_gradw;
     p.info.n_launches_fwd = 3 + L; p.info.n_launches_bwd = 3 + L;
+
+    // ---- per-kernel work table (launch order of one fwd+bwd step) -----------------------------------------
+    {
+        const double es = p.esize, act = (double)p.NN * H * es;
+        auto add = [&](const std::string& name, int bound, double fa, double fe, double by) {
+            mshgnn_kernel_stat k{}; std::snprintf(k.name, sizeof(k.name), "%s", name.c_str());
+            k.bound = bound; k.flops_per_window = fa; k.flops_exec_per_window = fe; k.bytes_per_window = by;
+            p.kstats.push_back(k); return (int)p.kstats.size() - 1; };
+        auto live_nodes = [&](int l) { int n = 0; for (int t = 0; t < NT; ++t) if (p.live[l][t]) n += d.type_nodes[t]; return n; };
+        auto need_nodes = [&](int l) { int n = 0; for (int t = 0; t < NT; ++t) if (p.need_dx[l][t]) n += d.type_nodes[t]; return n; };
+        p.ks_prep = add("prep", MSHGNN_BOUND_HBM, 0, 0, 0);
+        p.ks_enc = add("enc_fwd", d.dtype == MSHGNN_F32 ? MSHGNN_BOUND_MFMA : MSHGNN_BOUND_HBM, enc_alg, enc_exec, bytes + act);
+        for (int l = 0; l < L; ++l) {
+            const int idx = add("layer_fwd" + std::to_string(l), MSHGNN_BOUND_MFMA, lf_alg[l], lf_exec[l],
+                                act + live_nodes(l) * (double)H * es + live_nodes(l) * 16.0);
+            if (l == 0) p.ks_layer_fwd0 = idx;
+        }
+        p.ks_dec_fwd = add("dec_fwd", MSHGNN_BOUND_HBM, 2.0 * n_out * d.out_channels * H, 2.0 * n_out * d.out_channels * H, n_out * (double)H * es);
+        p.ks_dec_bwd = add("dec_bwd", MSHGNN_BOUND_HBM, 4.0 * n_out * d.out_channels * H, 4.0 * n_out * d.out_channels * H, 2.0 * n_out * (double)H * es);
+        for (int l = L - 1; l >= 0; --l) {
+            const int idx = add("layer_bwd" + std::to_string(l), MSHGNN_BOUND_MFMA, lb_alg[l], lb_exec[l],
+                                live_nodes(l) * (double)H * es * 2 + need_nodes(l) * (double)H * es + live_nodes(l) * 16.0);
+            if (l == L - 1) p.ks_layer_bwd0 = idx;
+        }
+        p.ks_gradw = add("gradw", MSHGNN_BOUND_MFMA, gw_alg, gw_exec, bytes + (double)L * 2 * act + act);
+        p.ks_fin = add("finalize", MSHGNN_BOUND_HBM, 0, 0, 0);
+    }
     return true;
 }
 
@@ -484,6 +528,7 @@ inline void layout_workspace(const HostPlan& p, int64_t B, int training, mshgnn_
         for (int l = 0; l <= p.L; ++l) o->dx[l] = take(act);
         for (int l = 0; l < p.L; ++l) { o->dh[l] = take(act); o->du[l] = take(mlp); }
         o->slabs = take((size_t)p.n_slabs * SLAB_FLOATS * 4);
+        o->dec_slabs = take((size_t)NWG_DEC * DEC_SLAB_FLOATS * 4);
     }
     o->wpack = take(p.packs.size() * (size_t)H * H * p.esize);
     o->bias = take(p.biases.size() * (size_t)H * 4);

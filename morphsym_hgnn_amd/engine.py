@@ -51,13 +51,21 @@ class MshgnnWsLayout(C.Structure):
     _fields_ = [
         ("total", C.c_size_t), ("x", C.c_size_t * 17), ("dx", C.c_size_t * 17), ("dh", C.c_size_t * 16),
         ("mask", C.c_size_t * 16), ("hb", C.c_size_t * 16), ("t1", C.c_size_t * 16), ("du", C.c_size_t * 16),
-        ("wpack", C.c_size_t), ("bias", C.c_size_t), ("slabs", C.c_size_t), ("loss", C.c_size_t),
+        ("wpack", C.c_size_t), ("bias", C.c_size_t), ("dec_slabs", C.c_size_t), ("slabs", C.c_size_t), ("loss", C.c_size_t),
+    ]
+
+
+class MshgnnKernelStat(C.Structure):
+    _fields_ = [
+        ("name", C.c_char * 32), ("launches", C.c_int32), ("bound", C.c_int32), ("total_ms", C.c_float), ("_pad", C.c_float),
+        ("flops_per_window", C.c_double), ("flops_exec_per_window", C.c_double), ("bytes_per_window", C.c_double),
     ]
 
 
 EXPORTS = [
     "mshgnn_last_error", "mshgnn_version", "mshgnn_plan_create", "mshgnn_plan_destroy", "mshgnn_plan_info",
     "mshgnn_plan_compile_host", "mshgnn_workspace_layout", "mshgnn_forward", "mshgnn_backward", "mshgnn_mse_loss",
+    "mshgnn_profile_enable", "mshgnn_profile_read",
 ]
 
 _lib = None
@@ -93,6 +101,8 @@ def load_library():
                                    C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
     lib.mshgnn_backward.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.mshgnn_profile_enable.argtypes = [C.c_void_p, C.c_int]
+    lib.mshgnn_profile_read.argtypes = [C.c_void_p, C.POINTER(MshgnnKernelStat), C.POINTER(C.c_int32)]
     lib.mshgnn_mse_loss.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = lib
     return lib
@@ -307,6 +317,23 @@ class Engine:
         _check(self.lib, self.lib.mshgnn_mse_loss(out.data_ptr(), y.data_ptr(), n, loss.data_ptr(),
                                                   g.data_ptr() if g is not None else None, stream), "mshgnn_mse_loss")
         return loss, g
+
+    # ---- per-kernel timing -----------------------------------------------------------------------
+    def profile(self, on: bool):
+        _check(self.lib, self.lib.mshgnn_profile_enable(self._plan, int(on)), "mshgnn_profile_enable")
+
+    def profile_read(self) -> List[dict]:
+        """Per-kernel HIP-event timings accumulated since the last read, with each kernel's algorithmic work."""
+        n = C.c_int32(64)
+        arr = (MshgnnKernelStat * 64)()
+        _check(self.lib, self.lib.mshgnn_profile_read(self._plan, arr, C.byref(n)), "mshgnn_profile_read")
+        out = []
+        for i in range(n.value):
+            k = arr[i]
+            out.append(dict(name=k.name.decode(), launches=k.launches, bound="mfma" if k.bound == 1 else "hbm",
+                            total_ms=float(k.total_ms), flops_per_window=k.flops_per_window,
+                            flops_exec_per_window=k.flops_exec_per_window, bytes_per_window=k.bytes_per_window))
+        return out
 
     # ---- introspection (tests) -----------------------------------------------------------------
     def hidden_state(self, B: int, layer: int) -> torch.Tensor:
