@@ -230,6 +230,7 @@ class Engine:
         self.info = MshgnnInfo()
         _check(self.lib, self.lib.mshgnn_plan_info(self._plan, C.byref(self.info)), "mshgnn_plan_info")
         self._ws: Dict[Tuple[int, int], torch.Tensor] = {}
+        self._tickets: Dict[int, int] = {}
         self._lay: Dict[Tuple[int, int], MshgnnWsLayout] = {}
         self.types = spec.node_types
         self.n_out = spec.num_nodes[spec.out_type]
@@ -285,6 +286,8 @@ class Engine:
         if out is None:
             out = torch.empty(B * self.n_out, self.spec.out_channels, dtype=torch.float32, device=self.device)
         ws = self.workspace(B, training)
+        if training:
+            self._tickets[B] = self._tickets.get(B, 0) + 1
         stream = torch.cuda.current_stream(self.device).cuda_stream
         _check(self.lib, self.lib.mshgnn_forward(self._plan, ptrs, None, params_flat.data_ptr(), out.data_ptr(),
                                                  ws.data_ptr(), B, int(training), stream), "mshgnn_forward")
@@ -317,6 +320,10 @@ class Engine:
         _check(self.lib, self.lib.mshgnn_mse_loss(out.data_ptr(), y.data_ptr(), n, loss.data_ptr(),
                                                   g.data_ptr() if g is not None else None, stream), "mshgnn_mse_loss")
         return loss, g
+
+    def stash_ticket(self, B: int) -> int:
+        """Monotonic id of the last training forward that wrote the activation stash for batch size B."""
+        return self._tickets.get(B, 0)
 
     # ---- per-kernel timing -----------------------------------------------------------------------
     def profile(self, on: bool):

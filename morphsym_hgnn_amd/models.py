@@ -1,0 +1,308 @@
+"""Drop-in model surface of the MS-HGNN hot path: `GRF_HGNN_C2`, `GRF_HGNN_K4`, `GRF_HGNN` with the reference's
+constructor signatures, attributes, parameter names and `forward(x_dict, edge_index_dict) -> Tensor` contract
+(src/ms_hgnn/lightning_py/hgnn_c2.py:10-12,133; hgnn_k4.py:10-11,146; hgnn.py:10-12,57), so the Lightning wrappers
+(gnnLightning.py:564-722) and the research scripts run unchanged on top of it.
+
+All arithmetic runs in the HIP engine behind the C-ABI (engine.py / include/mshgnn.h).  The first forward
+(the wrapper's lazy-init call under no_grad, gnnLightning.py:593-595) materialises the lazy encoder weights,
+recovers the per-window topology from the PyG-batched `edge_index_dict`, verifies the batch really is B copies
+of one graph, and compiles a plan; later calls reuse it.  Precision: `MSHGNN_DTYPE=f32` (default, parity mode,
+1e-4 relative) or `bf16` (throughput mode); `model.set_precision("bf16")` switches at run time.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import yaml
+from torch import nn
+
+from . import nn as pnn
+from .spec import ModelSpec, rel_key
+from .topology import NODE_TYPES, RobotTopology, infer_window_edges
+
+
+class _Flatten(torch.autograd.Function):
+    """named parameters -> the C-ABI's flat fp32 buffer; backward hands each parameter a view of the flat
+    gradient (cast back to the parameter's dtype)."""
+
+    @staticmethod
+    def forward(ctx, size, device, offsets, *params):
+        ctx.offsets = offsets
+        ctx.meta = [(p.shape, p.dtype, p.device) for p in params]
+        flat = torch.zeros(size, dtype=torch.float32, device=device)
+        views = [flat[o:o + n].view(p.shape) for (o, n), p in zip(offsets, params)]
+        torch._foreach_copy_(views, [p.detach() for p in params])
+        return flat
+
+    @staticmethod
+    def backward(ctx, gflat):
+        grads = []
+        for (o, n), (shape, dt, dev) in zip(ctx.offsets, ctx.meta):
+            grads.append(gflat[o:o + n].view(shape).to(device=dev, dtype=dt))
+        return (None, None, None, *grads)
+
+
+class _EngineFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, flat, engine, B, training, *xs):
+        out = engine.forward(xs, flat, B, training=training)
+        ctx.engine, ctx.B, ctx.xs, ctx.flat = engine, B, xs, flat
+        ctx.ticket = engine.stash_ticket(B)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        e = ctx.engine
+        if e.stash_ticket(ctx.B) != ctx.ticket:
+            raise RuntimeError("the activation stash of this forward was overwritten by a later forward of the same "
+                               "batch size on the same engine; call backward before the next forward")
+        gflat = e.backward(ctx.xs, ctx.flat, gout.contiguous().to(torch.float32), ctx.B)
+        return (gflat, None, None, None, *([None] * len(ctx.xs)))
+
+
+class _MSHGNNBase(nn.Module):
+    kind = "c2"
+    num_bases = 2
+
+    def _init_common(self, hidden_channels, num_layers, data_metadata, regression, activation_fn):
+        if not isinstance(activation_fn, nn.ReLU):
+            raise NotImplementedError("the MI355X MS-HGNN engine fuses ReLU; other activation_fn are not supported")
+        self.regression = regression
+        self.activation = activation_fn
+        self.hidden_channels = hidden_channels
+        self.num_layers = num_layers
+        self._node_types = list(data_metadata[0])
+        self._edge_types = [tuple(e) for e in data_metadata[1]]
+        self._engines: Dict[Tuple[str, str], object] = {}
+        self._spec: Optional[ModelSpec] = None
+        self._flat: Optional[torch.Tensor] = None
+        self._checked_batches = set()
+        self._precision = os.environ.get("MSHGNN_DTYPE", "f32")
+        self._group = None
+
+    # ---- construction helpers ---------------------------------------------------------------------
+    def _build_convs(self, mean_rels):
+        self.encoder = pnn.HeteroDictLinear(-1, self.hidden_channels, self._node_types)
+        self.convs = nn.ModuleList()
+        h = self.hidden_channels
+        for _ in range(self.num_layers):
+            conv_dict = {}
+            for et in self._edge_types:
+                conv_dict[et] = pnn.GraphConv(h, h, aggr="mean" if et[1] in mean_rels else "add")
+            self.convs.append(pnn.HeteroConv(conv_dict, aggr="sum"))
+
+    def set_precision(self, dtype: str):
+        if dtype not in ("f32", "bf16"):
+            raise ValueError("precision must be 'f32' or 'bf16'")
+        self._precision = dtype
+        return self
+
+    def reset_parameters(self):
+        """Reset all learnable parameters (hgnn_c2.py:286-293)."""
+        self.encoder.reset_parameters()
+        for conv in self.convs:
+            conv.reset_parameters()
+        if hasattr(self, "base_transform"):
+            self.base_transform[0].reset_parameters()
+            self.base_transform[2].reset_parameters()
+        self.decoder.reset_parameters()
+
+    # ---- plan ---------------------------------------------------------------------------------------
+    def _num_nodes(self, x_dict) -> Tuple[int, Dict[str, int]]:
+        nb = self.num_bases
+        if x_dict["base"].shape[0] % nb:
+            raise ValueError(f"x_dict['base'] has {x_dict['base'].shape[0]} rows, not a multiple of {nb} base nodes")
+        B = x_dict["base"].shape[0] // nb
+        nn_ = {}
+        for t in self._node_types:
+            if x_dict[t].shape[0] % B:
+                raise ValueError(f"x_dict['{t}'] rows ({x_dict[t].shape[0]}) are not a multiple of the batch size {B}")
+            nn_[t] = x_dict[t].shape[0] // B
+        return B, nn_
+
+    def _make_spec(self, x_dict, edge_index_dict) -> ModelSpec:
+        B, nn_ = self._num_nodes(x_dict)
+        rels = []
+        for et in self._edge_types:
+            if et not in edge_index_dict:
+                raise ValueError(f"edge_index_dict lacks relation {et} named in data_metadata")
+            s, _, d = et
+            rels.append((et, infer_window_edges(edge_index_dict[et], nn_[s], nn_[d], B)))
+        topo = RobotTopology(name="from-batch", num_nodes={t: nn_[t] for t in NODE_TYPES if t in nn_}, relations=rels)
+        widths = {t: int(x_dict[t].shape[1]) for t in self._node_types}
+        return ModelSpec(kind=self.kind, topology=topo, hidden=self.hidden_channels, num_layers=self.num_layers,
+                         widths=widths, regression=self.regression, grf_dimension=getattr(self, "grf_dimension", 1),
+                         group=self._group, num_timesteps=getattr(self, "num_timesteps", 150))
+
+    def _named_in_flat_order(self):
+        sd = dict(self.named_parameters())
+        return [sd[k] for k in self._spec.param_offsets().keys()]
+
+    def _engine(self, device):
+        from .engine import Engine
+        key = (self._precision, str(device))
+        if key not in self._engines:
+            self._engines[key] = Engine(self._spec, dtype=self._precision, device=device)
+        return self._engines[key]
+
+    # ---- forward --------------------------------------------------------------------------------------
+    def forward(self, x_dict, edge_index_dict):
+        for t in self._node_types:
+            if t not in x_dict:
+                raise KeyError(f"x_dict lacks node type '{t}'")
+        first = self._spec is None
+        if first:
+            for t in self._node_types:
+                self.encoder.lins[t].materialize(int(x_dict[t].shape[1]))
+                lin = self.encoder.lins[t]
+                ref = self.decoder.weight
+                lin.to(device=ref.device, dtype=ref.dtype)
+            self._spec = self._make_spec(x_dict, edge_index_dict)
+            expect = list(self._spec.param_shapes().keys())
+            have = [k for k, _ in self.named_parameters()]
+            if expect != have:
+                raise RuntimeError(f"parameter layout mismatch: {set(expect) ^ set(have)}")
+        spec = self._spec
+        B, nn_ = self._num_nodes(x_dict)
+        for t in self._node_types:
+            if nn_[t] != spec.num_nodes[t] or x_dict[t].shape[1] != spec.widths[t]:
+                raise ValueError(f"x_dict['{t}'] does not match the compiled topology "
+                                 f"({nn_[t]} nodes x {x_dict[t].shape[1]} vs {spec.num_nodes[t]} x {spec.widths[t]})")
+        if B not in self._checked_batches:   # one host-side check per batch size: B copies of the compiled graph
+            for et in self._edge_types:
+                s, _, d = et
+                if infer_window_edges(edge_index_dict[et], nn_[s], nn_[d], B) != spec.topology.edges(et):
+                    raise ValueError(f"edge_index_dict[{et}] differs from the topology this model was compiled for")
+            self._checked_batches.add(B)
+        pdev = self.decoder.weight.device
+        if pdev.type != "cuda":
+            # parameters still on the host (e.g. the wrapper's lazy-init call, gnnLightning.py:593-595, or
+            # evaluate_model's model.to('cpu'), :1029): the arithmetic STILL runs in the HIP engine, on the current
+            # device, with a device copy of the parameters.  No GPU -> error; there is no CPU implementation.
+            if not torch.cuda.is_available():
+                raise RuntimeError("the MS-HGNN engine needs a HIP device; there is no CPU fallback")
+            pdev = torch.device("cuda", torch.cuda.current_device())
+        e = self._engine(pdev)
+        in_dev, in_dtype = x_dict[self._node_types[0]].device, x_dict[self._node_types[0]].dtype
+        xs = e.cast_inputs(x_dict)
+        if self._flat is None or self._flat.device != pdev:
+            self._flat = torch.zeros(spec.flat_size(), dtype=torch.float32, device=pdev)
+        params = self._named_in_flat_order()
+        offsets = list(spec.param_offsets().values())
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        if need_grad:
+            flat = _Flatten.apply(spec.flat_size(), pdev, offsets, *params)
+            out = _EngineFn.apply(flat, e, B, True, *xs)
+        else:
+            with torch.no_grad():
+                views = [self._flat[o:o + n].view(p.shape) for (o, n), p in zip(offsets, params)]
+                torch._foreach_copy_(views, [p.detach() for p in params])
+                out = e.forward(xs, self._flat, B, training=False)
+        out = out.to(device=in_dev, dtype=in_dtype if in_dtype.is_floating_point else torch.float32)
+        if spec.output_is_window_major:
+            return out.view(B, -1)      # ms_foot_decoder: [B, 4*3]   (hgnn_c2.py:184-189)
+        return out                      # [B*4, out_channels_per_foot]
+
+    # ---- reference helper kept for API compatibility ------------------------------------------------------
+    def apply_symmetry(self, x_dict):
+        """Elementwise +-1 masks equivalent to the reference's apply_symmetry (hgnn_c2.py:191-231).  The engine
+        folds these into its encoder loads; this method exists for callers that use it directly."""
+        spec = self._spec if self._spec is not None else self._make_spec(x_dict, {})
+        masks = spec.input_masks()
+        for t, m in masks.items():
+            x = x_dict[t]
+            n = m.shape[0]
+            x_dict[t] = (x.view(-1, n, x.shape[1]) * m.to(x.device, x.dtype).unsqueeze(0)).reshape(x.shape)
+        return x_dict
+
+
+def _load_group(symmetry_mode, group_operator_path):
+    if symmetry_mode and group_operator_path:
+        with open(group_operator_path, "r") as f:
+            return yaml.safe_load(f)
+    return None
+
+
+class GRF_HGNN_C2(_MSHGNNBase):
+    """MS-HGNN for the C2 graph (2 base nodes) -- drop-in for hgnn_c2.py:GRF_HGNN_C2."""
+    kind = "c2"
+    num_bases = 2
+
+    def __init__(self, hidden_channels: int, num_layers: int, data_metadata, regression: bool = True,
+                 activation_fn=nn.ReLU(), symmetry_mode: str = None, group_operator_path: str = None,
+                 grf_dimension: int = 3):
+        super().__init__()
+        self._init_common(hidden_channels, num_layers, data_metadata, regression, activation_fn)
+        self.num_timesteps = 150           # hard-coded in the reference (hgnn_c2.py:30)
+        self.num_legs = 4
+        self.num_joints = 12
+        self.num_dimensions_per_foot = 3
+        self.num_dimensions_per_base = 3
+        self.num_variables_per_joint = 3 if regression else 2
+        self.grf_dimension = grf_dimension
+        self._group = _load_group(symmetry_mode, group_operator_path)
+        self._build_convs(mean_rels=("center_bb",))
+        h = hidden_channels
+        self.base_transform = nn.Sequential(nn.Linear(h, h), nn.ReLU(), nn.Linear(h, h))
+        if regression and grf_dimension == 1:
+            self.out_channels_per_foot = 1
+        elif regression and grf_dimension == 3:
+            self.out_channels_per_foot = 3
+        else:
+            self.out_channels_per_foot = 2
+        self.decoder = pnn.Linear(h, self.out_channels_per_foot)
+        coeffs = ModelSpec.symmetry_coefficients(self._coeff_probe())
+        self.joints_linear_weights, self.feet_linear_weights, self.base_coefficients_lin, self.base_coefficients_ang = coeffs
+
+    def _coeff_probe(self):
+        class _P:  # minimal duck-type for ModelSpec.symmetry_coefficients
+            pass
+        p = _P()
+        p.kind, p.group, p.num_nodes = self.kind, self._group, {"base": self.num_bases}
+        return p
+
+
+class GRF_HGNN_K4(_MSHGNNBase):
+    """MS-HGNN for the K4 graph (4 base nodes) -- drop-in for hgnn_k4.py:GRF_HGNN_K4."""
+    kind = "k4"
+    num_bases = 4
+
+    def __init__(self, hidden_channels: int, num_layers: int, data_metadata, regression: bool = True,
+                 activation_fn=nn.ReLU(), symmetry_mode: str = None, group_operator_path: str = None):
+        super().__init__()
+        self._init_common(hidden_channels, num_layers, data_metadata, regression, activation_fn)
+        self.num_timesteps = 150           # hgnn_k4.py:29
+        self.num_legs = 4
+        self.num_joints = 12
+        self.num_dimensions_per_foot = 3
+        self.num_dimensions_per_base = 3
+        self._group = _load_group(symmetry_mode, group_operator_path)
+        self._build_convs(mean_rels=("gt", "gs"))
+        h = hidden_channels
+        self.base_transform = nn.Sequential(nn.Linear(h, h), nn.ReLU(), nn.Linear(h, h))
+        self.out_channels_per_foot = 1 if regression else 2
+        self.decoder = pnn.Linear(h, self.out_channels_per_foot)
+        coeffs = ModelSpec.symmetry_coefficients(GRF_HGNN_C2._coeff_probe(self))
+        self.joints_linear_weights, self.feet_linear_weights, self.base_coefficients_lin, self.base_coefficients_ang = coeffs
+
+
+class GRF_HGNN(_MSHGNNBase):
+    """MI-HGNN baseline (1 base node, no masks / base MLP / residual) -- drop-in for hgnn.py:GRF_HGNN."""
+    kind = "mi"
+    num_bases = 1
+
+    def __init__(self, hidden_channels: int, num_layers: int, data_metadata, regression: bool = True,
+                 activation_fn=nn.ReLU(), grf_dimension: int = 1):
+        super().__init__()
+        self._init_common(hidden_channels, num_layers, data_metadata, regression, activation_fn)
+        self.grf_dimension = grf_dimension
+        self._build_convs(mean_rels=())
+        if regression and grf_dimension == 1:
+            self.out_channels_per_foot = 1
+        elif regression and grf_dimension == 3:
+            self.out_channels_per_foot = 3
+        else:
+            self.out_channels_per_foot = 2
+        self.decoder = pnn.Linear(hidden_channels, self.out_channels_per_foot)

@@ -1,0 +1,91 @@
+"""The drop-in nn.Module surface: same constructor, parameter names, state_dict layout and forward contract as the
+reference's GRF_HGNN_C2 / GRF_HGNN_K4 / GRF_HGNN; GPU tests run it against the golden vectors."""
+import os
+
+import pytest
+import torch
+from torch import nn
+
+from morphsym_hgnn_amd import models, nn as pnn
+from tests import helpers
+
+
+def _build(case, spec):
+    _, cfg_path = helpers.load_group(case["cfg"])
+    meta = spec.topology.metadata()
+    if case["kind"] == "c2":
+        return models.GRF_HGNN_C2(case["hidden"], case["layers"], meta, regression=case["regression"],
+                                  symmetry_mode="MorphSym" if cfg_path else None, group_operator_path=cfg_path,
+                                  grf_dimension=case["grf"])
+    if case["kind"] == "k4":
+        return models.GRF_HGNN_K4(case["hidden"], case["layers"], meta, regression=case["regression"],
+                                  symmetry_mode="MorphSym" if cfg_path else None, group_operator_path=cfg_path)
+    return models.GRF_HGNN(case["hidden"], case["layers"], meta, regression=case["regression"], grf_dimension=case["grf"])
+
+
+@pytest.mark.parametrize("name", ["a1c2_h128_L3_d3_B3", "mck4_cls_h128_L2_B3", "mi_h128_L2_d1_B3"])
+def test_state_dict_layout_matches_reference_names(name):
+    torch.set_default_dtype(torch.float64)   # the reference runs in float64 (gnnLightning.py:1183)
+    case, spec, fx, x_dict, y, params, ei = helpers.load_case(name)
+    m = _build(case, spec)
+    for t in spec.node_types:   # what the first forward does
+        m.encoder.lins[t].materialize(spec.widths[t])
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(spec.param_shapes().keys())
+    assert {k: tuple(v.shape) for k, v in sd.items()} == dict(spec.param_shapes())
+    assert sum(p.numel() for p in m.parameters()) == int(fx["n_params"])
+    m.load_state_dict(params)    # golden weights load by name
+    et = spec.edge_types[0]
+    assert m.convs[0].convs[et].lin_rel.weight.shape == (128, 128)   # tuple-key access, hgnn_c2.py:295-306
+    assert m.out_channels_per_foot == spec.out_channels
+    if case["kind"] != "mi":
+        c = spec.symmetry_coefficients()
+        assert torch.equal(m.joints_linear_weights, c[0]) and torch.equal(m.feet_linear_weights, c[1])
+
+
+def test_operator_containers_have_no_eager_path():
+    with pytest.raises(NotImplementedError):
+        pnn.GraphConv(8, 8)(torch.zeros(2, 8), torch.zeros(2, 0, dtype=torch.long))
+    with pytest.raises(NotImplementedError):
+        models.GRF_HGNN_C2(128, 1, (["base", "joint", "foot"], [("base", "x", "joint")]), activation_fn=nn.Tanh())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,param_dev", [("a1c2_h128_L3_d3_B3", "cuda"), ("a1c2_h128_L2_d3_B37", "cpu"),
+                                            ("mck4_cls_h128_L2_B3", "cuda"), ("mi_h128_L2_d3_B2", "cuda")])
+def test_module_forward_backward_matches_golden(name, param_dev):
+    assert torch.cuda.is_available()
+    torch.set_default_dtype(torch.float64)
+    case, spec, fx, x_dict, y, params, ei = helpers.load_case(name)
+    B = case["B"]
+    m = _build(case, spec)
+    if param_dev == "cuda":
+        m = m.cuda()
+    dev = torch.device(param_dev)
+    xd = {k: v.to(dev) for k, v in x_dict.items()}
+    eid = {k: v.to(dev) for k, v in ei.items()}
+    with torch.no_grad():        # lazy init exactly like gnnLightning.py:593-595
+        m(x_dict={k: v.clone() for k, v in xd.items()}, edge_index_dict=eid)
+    m.load_state_dict(params)
+    out = m(x_dict=xd, edge_index_dict=eid)
+    w = m.out_channels_per_foot * 4
+    y_pred = torch.reshape(out.squeeze(), (B, w))                      # gnnLightning.py:691
+    if case["regression"]:
+        loss = ((y_pred.flatten() - y.to(dev).reshape(B, w).flatten()) ** 2).mean()
+    else:
+        loss = torch.nn.functional.cross_entropy(y_pred.reshape(B * 4, 2), y.to(dev).reshape(B, 4).long().flatten())
+    loss.backward()
+    grads = {k: (p.grad.detach().cpu() if p.grad is not None else torch.zeros_like(p).cpu()) for k, p in m.named_parameters()}
+    assert out.dtype == torch.float64 and out.device.type == dev.type
+    helpers.check_against_fixture(fx, out.detach().cpu(), loss.detach().cpu(), grads, rtol=1e-4, what=name)
+    # a second step works (fresh flat buffer, stash ticket advances), and wrong topologies are rejected
+    m.zero_grad()
+    m(x_dict=xd, edge_index_dict=eid).sum().backward()
+    bad = dict(eid)
+    k0 = spec.edge_types[0]
+    bad[k0] = eid[k0].flip(1)
+    m2 = _build(case, spec)
+    if B > 1:
+        with pytest.raises(ValueError):
+            m._checked_batches.clear()
+            m(x_dict=xd, edge_index_dict=bad)
