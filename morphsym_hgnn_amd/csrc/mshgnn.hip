@@ -50,18 +50,21 @@ extern "C" const char* mshgnn_version(void) { return "mshgnn 0.1 (gfx950)"; }
 // precision traits
 // ------------------------------------------------------------------------------------------------------
 template <typename T> struct Prec;
+// Both precisions use window tiles of 16 rows and 16-wide MFMA column blocks; a wave owns 2 column blocks (32 cols).
+//   fp32: v_mfma_f32_16x16x4_f32   (lane group g = lane>>4 owns K range [32g, 32g+32): 8 chunks of 4 floats)
+//   bf16: v_mfma_f32_16x16x32_bf16 (lane group g owns K range [32g, 32g+32): 4 chunks of 8 bf16)
 template <> struct Prec<float> {
-    static constexpr int ROWS = 16, EPC = 4, CPR = 32, RB = 512, NREG = 8, NBV = 16, HS = 6;
+    static constexpr int ROWS = 16, EPC = 4, CPR = 32, RB = 512, NREG = 8, NBV = 16, NAV = 8, HS = 6, BLK = 8192, ENC_MB = 4, WPS = 2;   // WPS: waves/SIMD the layer kernels are built for
     using Vec = f32x4;
     struct Acc { f32x4 c[2]; };
     struct AFrag { f32x4 v[8]; };
     struct BFrag { f32x4 v[16]; };
 };
 template <> struct Prec<__bf16> {
-    static constexpr int ROWS = 32, EPC = 8, CPR = 16, RB = 256, NREG = 16, NBV = 8, HS = 4;
+    static constexpr int ROWS = 16, EPC = 8, CPR = 16, RB = 256, NREG = 8, NBV = 8, NAV = 4, HS = 4, BLK = 4096, ENC_MB = 8, WPS = 4;   // 2 workgroups of 8 waves per CU (80 KB LDS each)
     using Vec = bf16x8;
-    struct Acc { f32x16 c; };
-    struct AFrag { bf16x8 v[8]; };
+    struct Acc { f32x4 c[2]; };
+    struct AFrag { bf16x8 v[4]; };
     struct BFrag { bf16x8 v[8]; };
 };
 
@@ -75,30 +78,46 @@ template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ __bf16 from_f32<__bf16>(float v) { return (__bf16)v; }
 
-// C/D fragment maps (cdna_hip_programming.md section 3): fp32 16x16 blocks: col = lane&15, row = 4*(lane>>4)+j;
-// bf16 32x32 block: col = lane&31, row = (q&3) + 8*(q>>2) + 4*(lane>>5).
-template <typename T> __device__ __forceinline__ int c_row(int q, int lane);
-template <typename T> __device__ __forceinline__ int c_col(int q, int lane);
-template <> __device__ __forceinline__ int c_row<float>(int q, int lane) { return ((lane >> 4) << 2) + (q & 3); }
-template <> __device__ __forceinline__ int c_col<float>(int q, int lane) { return ((q >> 2) << 4) + (lane & 15); }
-template <> __device__ __forceinline__ int c_row<__bf16>(int q, int lane) { return (q & 3) + ((q >> 2) << 3) + ((lane >> 5) << 2); }
-template <> __device__ __forceinline__ int c_col<__bf16>(int q, int lane) { return lane & 31; }
+// Accumulator layout.  The MFMAs are issued as  D^T = W_frag (A operand) x X_frag (B operand), so in the 16x16 C/D map
+// (col = lane&15, row = 4*(lane>>4)+j -- cdna_hip_programming.md section 3) the COLUMN is the window and the ROWS are
+// output features: lane (w = lane&15, g = lane>>4) holds, per 16-feature block fb, the 4 CONSECUTIVE features
+// 16 fb + 4 g + {0..3} of window w.  Epilogue memory traffic is therefore 4-element (8 / 16 byte) vectors.
+__device__ __forceinline__ int c_win(int lane) { return lane & 15; }
+__device__ __forceinline__ int c_feat(int fb, int lane) { return (fb << 4) + ((lane >> 4) << 2); }   // within the wave's 32 columns
 
-__device__ __forceinline__ float acc_ref(const Prec<float>::Acc& a, int q) { return a.c[q >> 2][q & 3]; }
-__device__ __forceinline__ float acc_ref(const Prec<__bf16>::Acc& a, int q) { return a.c[q]; }
+template <typename A> __device__ __forceinline__ void acc_fill(A& a, float v) {
+    a.c[0] = f32x4{v, v, v, v}; a.c[1] = f32x4{v, v, v, v};
+}
 
-__device__ __forceinline__ void acc_fill(Prec<float>::Acc& a, float v0, float v1) {
-    a.c[0] = f32x4{v0, v0, v0, v0}; a.c[1] = f32x4{v1, v1, v1, v1};
+// 4 consecutive elements of T <-> f32x4 (global or LDS; 16-byte aligned for fp32, 8-byte for bf16)
+__device__ __forceinline__ f32x4 load_quad(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 load_quad(const __bf16* p) {
+    const u32x2 r = *reinterpret_cast<const u32x2*>(p);
+    return f32x4{__builtin_bit_cast(float, r[0] << 16), __builtin_bit_cast(float, r[0] & 0xffff0000u),
+                 __builtin_bit_cast(float, r[1] << 16), __builtin_bit_cast(float, r[1] & 0xffff0000u)};
 }
-__device__ __forceinline__ void acc_fill(Prec<__bf16>::Acc& a, float v0, float) {
-#pragma unroll
-    for (int q = 0; q < 16; ++q) a.c[q] = v0;
+__device__ __forceinline__ void store_quad(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void store_quad(__bf16* p, f32x4 v) {
+    union { u32x2 r; __bf16 e[4]; } u;
+    u.e[0] = (__bf16)v[0]; u.e[1] = (__bf16)v[1]; u.e[2] = (__bf16)v[2]; u.e[3] = (__bf16)v[3];
+    *reinterpret_cast<u32x2*>(p) = u.r;
 }
+__device__ __forceinline__ f32x4 relu4(f32x4 v) { return f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)}; }
+// value as it will read back after being stored as T (so LDS/global copies and the register copy agree)
+template <typename T> __device__ __forceinline__ f32x4 round_as(f32x4 v) {
+    if constexpr (sizeof(T) == 4) return v;
+    else return f32x4{(float)(__bf16)v[0], (float)(__bf16)v[1], (float)(__bf16)v[2], (float)(__bf16)v[3]};
+}
+
+// Activation tensors (X_l, dX_l, dH_l, D_l, base_transform stash) are NODE-major in HBM: [node][window][128], so the
+// streams of the encoder epilogue and of the weight-gradient kernel (one node, many windows) are contiguous and a layer
+// tile reads one 16 x 128 block per node.
+__device__ __forceinline__ size_t act_idx(int w, int node, int B) { return ((size_t)node * B + w) * H; }
 
 // LDS node-block addressing: block = ROWS rows x 128 elements; 16-byte chunk c of row r lives at chunk slot
 // c ^ (r & 15) (conflict-free ds_read_b128 for rows distinct mod 16 -- guide T2).
 template <typename T> __device__ __forceinline__ int lds_chunk(int blk, int row, int c) {
-    return blk * BLK_BYTES + row * Prec<T>::RB + ((c ^ (row & 15)) << 4);
+    return blk * Prec<T>::BLK + row * Prec<T>::RB + ((c ^ (row & 15)) << 4);
 }
 template <typename T> __device__ __forceinline__ int lds_elem(int blk, int row, int col) {
     return lds_chunk<T>(blk, row, col / Prec<T>::EPC) + (col % Prec<T>::EPC) * (int)sizeof(T);
@@ -107,10 +126,10 @@ template <typename T> __device__ __forceinline__ int lds_elem(int blk, int row, 
 // A fragment: lane (row = lane % ROWS, group g = lane / ROWS) reads 8 consecutive chunks = its contiguous K range.
 template <typename T> __device__ __forceinline__ void load_afrag(typename Prec<T>::AFrag& a, const char* smem, int blk, int lane_) {
     const int lane = opaque(lane_);
-    const int row = lane % Prec<T>::ROWS, g = lane / Prec<T>::ROWS;
+    const int row = lane & 15, g = lane >> 4;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        const u32x4 v = *reinterpret_cast<const u32x4*>(smem + lds_chunk<T>(blk, row, g * 8 + t));
+    for (int t = 0; t < Prec<T>::NAV; ++t) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(smem + lds_chunk<T>(blk, row, g * Prec<T>::NAV + t));
         a.v[t] = __builtin_bit_cast(typename Prec<T>::Vec, v);
     }
 }
@@ -125,46 +144,61 @@ template <typename T> __device__ __forceinline__ void load_bfrag(typename Prec<T
     }
 }
 
-__device__ __forceinline__ void mac(Prec<float>::Acc& acc, const Prec<float>::AFrag& a, const Prec<float>::BFrag& b) {
+// acc^T += W_frag . X_frag  (A operand = packed weights, B operand = the window tile)
+__device__ __forceinline__ void mac(Prec<float>::Acc& acc, const Prec<float>::AFrag& x, const Prec<float>::BFrag& w) {
 #pragma unroll
     for (int t4 = 0; t4 < 8; ++t4)
 #pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            acc.c[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[t4][x], b.v[t4][x], acc.c[0], 0, 0, 0);
-            acc.c[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[t4][x], b.v[8 + t4][x], acc.c[1], 0, 0, 0);
+        for (int e = 0; e < 4; ++e) {
+            acc.c[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.v[t4][e], x.v[t4][e], acc.c[0], 0, 0, 0);
+            acc.c[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.v[8 + t4][e], x.v[t4][e], acc.c[1], 0, 0, 0);
         }
 }
-__device__ __forceinline__ void mac(Prec<__bf16>::Acc& acc, const Prec<__bf16>::AFrag& a, const Prec<__bf16>::BFrag& b) {
+__device__ __forceinline__ void mac(Prec<__bf16>::Acc& acc, const Prec<__bf16>::AFrag& x, const Prec<__bf16>::BFrag& w) {
 #pragma unroll
-    for (int t = 0; t < 8; ++t) acc.c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v[t], b.v[t], acc.c, 0, 0, 0);
+    for (int t = 0; t < 4; ++t) {
+        acc.c[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.v[t], x.v[t], acc.c[0], 0, 0, 0);
+        acc.c[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.v[4 + t], x.v[t], acc.c[1], 0, 0, 0);
+    }
 }
 
-// bias for this lane's output column(s)
+// bias as the accumulator's initial value: this lane's 4 consecutive features of each 16-feature block
 template <typename T> __device__ __forceinline__ void acc_init_bias(typename Prec<T>::Acc& a, const float* bias, int wv, int lane) {
-    if (bias == nullptr) { acc_fill(a, 0.f, 0.f); return; }
-    if constexpr (sizeof(T) == 4) acc_fill(a, bias[wv * 32 + (lane & 15)], bias[wv * 32 + 16 + (lane & 15)]);
-    else acc_fill(a, bias[wv * 32 + (lane & 31)], 0.f);
+    if (bias == nullptr) { acc_fill(a, 0.f); return; }
+    a.c[0] = *reinterpret_cast<const f32x4*>(bias + wv * 32 + c_feat(0, lane));
+    a.c[1] = *reinterpret_cast<const f32x4*>(bias + wv * 32 + c_feat(1, lane));
 }
 
 // layer kernels: 8 waves = 4 column slices (wn) x 2 slot halves (wh); wave (wn, wh) owns output columns
 // [32 wn, 32 wn + 32) of the destination slots u with (u & 1) == wh  ->  HS = GMAX/2 accumulators per wave.
 constexpr int LAYER_THREADS = 512;
 
-// stage node blocks [n0, n1) of an activation tensor [B][NN][128] into LDS (zero rows beyond the batch)
+// row-major work split of the 512 layer-kernel threads over node blocks: a block has VPB = ROWS*CPR 16-byte chunks
+// (512 fp32 / 256 bf16), so NPB = 512/VPB blocks are covered per pass; thread -> (sub-block, row, chunk)
+template <typename T> struct RowMap {
+    static constexpr int VPB = Prec<T>::ROWS * Prec<T>::CPR, NPB = LAYER_THREADS / VPB;
+    int sub, row, c;
+    __device__ __forceinline__ explicit RowMap(int tid) : sub(tid / VPB), row((tid % VPB) / Prec<T>::CPR), c(tid % Prec<T>::CPR) {}
+};
+
+// stage node blocks [0, NN) of an activation tensor [B][NN][128] into LDS (zero rows beyond the batch)
 template <typename T>
-__device__ __forceinline__ void stage_nodes(char* smem, const T* src, int NN, int n0, int n1, int w0, int B, int tid) {
-    constexpr int CPR = Prec<T>::CPR, EPC = Prec<T>::EPC;
-    const int c = tid % CPR, row = tid / CPR;   // ROWS * CPR == 512 == LAYER_THREADS
-    for (int nb = n0; nb < n1; nb += 6) {
-        u32x4 v[6];
+__device__ __forceinline__ void stage_nodes(char* smem, const T* src, int NN, int w0, int B, int tid) {
+    constexpr int EPC = Prec<T>::EPC, NPB = RowMap<T>::NPB, BATCH = 6;
+    const RowMap<T> m(tid);
+    for (int nb = m.sub; nb < NN; nb += NPB * BATCH) {
+        u32x4 v[BATCH];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
+        for (int i = 0; i < BATCH; ++i) {
+            const int n = nb + i * NPB;
             v[i] = u32x4{0, 0, 0, 0};
-            if (nb + i < n1 && w0 + row < B) v[i] = *reinterpret_cast<const u32x4*>(src + ((size_t)(w0 + row) * NN + nb + i) * H + c * EPC);
+            if (n < NN && w0 + m.row < B) v[i] = *reinterpret_cast<const u32x4*>(src + act_idx(w0 + m.row, n, B) + m.c * EPC);
         }
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
-            if (nb + i < n1) *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(nb + i, row, c)) = v[i];
+        for (int i = 0; i < BATCH; ++i) {
+            const int n = nb + i * NPB;
+            if (n < NN) *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(n, m.row, m.c)) = v[i];
+        }
     }
 }
 
@@ -189,7 +223,7 @@ template <typename T> __global__ void k_prep(PrepArgs a) {
         for (int x = 0; x < EPC; ++x) {
             int k, col;
             if constexpr (sizeof(T) == 4) { k = 32 * (lane >> 4) + 4 * (v & 7) + x; col = wv * 32 + (v >> 3) * 16 + (lane & 15); }
-            else { k = 64 * (lane >> 5) + 8 * v + x; col = wv * 32 + (lane & 31); }
+            else { k = 32 * (lane >> 4) + 8 * (v & 3) + x; col = wv * 32 + (v >> 2) * 16 + (lane & 15); }
             float s = 0.f;
             if (pd.orient == 0) { if (k < pd.ncols) for (int i = 0; i < pd.n_src; ++i) s += a.params[pd.src[i] + (int64_t)col * pd.ld + pd.col0 + k]; }
             else { for (int i = 0; i < pd.n_src; ++i) s += a.params[pd.src[i] + (int64_t)k * pd.ld + col]; }
@@ -213,12 +247,12 @@ template <typename T> __global__ void k_prep(PrepArgs a) {
 // k_enc_fwd: X_0[node] = relu((mask . x) W_enc^T + b)      (hgnn_c2.py:143-147)
 // one workgroup = MB row blocks (MB*ROWS windows) of ONE node; K streamed in chunks of 128 through LDS
 // ------------------------------------------------------------------------------------------------------
-constexpr int ENC_MB = 4;
 struct EncArgs {
     const void* x[MSHGNN_MAX_TYPES]; int64_t pitch[MSHGNN_MAX_TYPES]; int vb[MSHGNN_MAX_TYPES];
     int width[MSHGNN_MAX_TYPES], nodes[MSHGNN_MAX_TYPES], tbase[MSHGNN_MAX_TYPES], nkc[MSHGNN_MAX_TYPES];
     int pack0[MSHGNN_MAX_TYPES], bias_idx[MSHGNN_MAX_TYPES], sign_off[MSHGNN_MAX_TYPES], wg_prefix[MSHGNN_MAX_TYPES + 1];
     int n_types, tiles, B, NN;
+    int aligned;   // every input row starts 16-byte aligned and its pitch is a whole number of 16-byte chunks
     const void* wpack; const float* bias; const uint8_t* signs; void* x0;
 };
 
@@ -241,6 +275,20 @@ template <typename T> __device__ __forceinline__ u32x4 load_chunk(const T* p, in
     for (int e = 0; e < EPC; ++e) tmp.e[e] = e < nvalid ? p[e] : from_f32<T>(0.f);
     return tmp.v;
 }
+// zero every element of a 16-byte chunk beyond the first nv (nv >= EPC keeps all)
+template <typename T> __device__ __forceinline__ u32x4 chunk_keep_first(u32x4 v, int nv) {
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (e >= nv) v[e] = 0u;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned m = (2 * e < nv ? 0x0000ffffu : 0u) | (2 * e + 1 < nv ? 0xffff0000u : 0u);
+            v[e] &= m;
+        }
+    }
+    return v;
+}
 // XOR sign bits from EPC sign bytes (0/1) starting at s
 template <typename T> __device__ __forceinline__ u32x4 sign_xor(const uint8_t* s) {
     if constexpr (sizeof(T) == 4) {
@@ -255,13 +303,15 @@ template <typename T> __device__ __forceinline__ u32x4 sign_xor(const uint8_t* s
 
 template <typename T> __global__ __launch_bounds__(256) void k_enc_fwd(EncArgs a) {
     using P = Prec<T>;
+    constexpr int MB = P::ENC_MB;                       // row blocks (of 16 windows) per workgroup
+    constexpr int VPB = P::ROWS * P::CPR, NIT = VPB / 256 > 0 ? VPB / 256 : 1, BPP = 256 / VPB > 0 ? 256 / VPB : 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     int t = 0;
     while (t + 1 < a.n_types && (int)blockIdx.x >= a.wg_prefix[t + 1]) ++t;
     const int local = blockIdx.x - a.wg_prefix[t];
     const int node = local / a.tiles, tile = local % a.tiles;
-    const int w0 = tile * ENC_MB * P::ROWS;
+    const int w0 = tile * MB * P::ROWS;
     const T* x = reinterpret_cast<const T*>(a.x[t]);
     const int64_t pitch = a.pitch[t];
     const int F = a.width[t], nt = a.nodes[t], nkc = a.nkc[t], vb = a.vb[t];
@@ -269,33 +319,45 @@ template <typename T> __global__ __launch_bounds__(256) void k_enc_fwd(EncArgs a
     const T* wpack = reinterpret_cast<const T*>(a.wpack);
     const float* bias = a.bias + (size_t)a.bias_idx[t] * H;
 
-    typename P::Acc acc[ENC_MB];
+    typename P::Acc acc[MB];
 #pragma unroll
-    for (int m = 0; m < ENC_MB; ++m) acc_init_bias<T>(acc[m], bias, wv, lane);
-    const int c = tid % P::CPR, r0 = tid / P::CPR, RSTEP = 256 / P::CPR;
+    for (int m = 0; m < MB; ++m) acc_init_bias<T>(acc[m], bias, wv, lane);
+    // staging map: fp32 block = 512 chunks -> 2 per thread; bf16 block = 256 chunks -> 1 per thread
+    const int c = tid % P::CPR, r0 = (tid % VPB) / P::CPR, sub = tid / VPB;   // sub is 0 for fp32
     typename P::BFrag bf;
     typename P::AFrag af;
-    for (int kc = 0; kc < nkc; ++kc) {
+    u32x4 v[MB / BPP][NIT];
+    auto fetch = [&](int kc) {
         const int k0 = kc * H + c * P::EPC;
         const int nvalid = min(P::EPC, F - k0);
-        const u32x4 sx = sign_xor<T>(sg + kc * H + c * P::EPC);
-        __syncthreads();
 #pragma unroll
-        for (int m = 0; m < ENC_MB; ++m) {
-            u32x4 v[2];
+        for (int mi = 0; mi < MB / BPP; ++mi)
 #pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int row = r0 + it * RSTEP, w = w0 + m * P::ROWS + row;
-                v[it] = u32x4{0, 0, 0, 0};
-                if (w < a.B) v[it] = load_chunk<T>(x + ((size_t)w * nt + node) * pitch + k0, nvalid, vb) ^ sx;
+            for (int it = 0; it < NIT; ++it) {
+                const int m = mi * BPP + sub, row = r0 + it * (256 / P::CPR), w = w0 + m * P::ROWS + row;
+                v[mi][it] = u32x4{0, 0, 0, 0};
+                if (w < a.B) {
+                    const T* src = x + ((size_t)w * nt + node) * pitch + k0;
+                    if (a.aligned) { if (nvalid > 0) v[mi][it] = *reinterpret_cast<const u32x4*>(src); }   // raw 16-byte load, nothing uses it here
+                    else v[mi][it] = load_chunk<T>(src, nvalid, vb);
+                }
             }
+    };
+    fetch(0);
+    for (int kc = 0; kc < nkc; ++kc) {
+        const u32x4 sx = sign_xor<T>(sg + kc * H + c * P::EPC);   // apply_symmetry: +-1 mask as a sign-bit XOR
+        const int nv = F - (kc * H + c * P::EPC);                  // valid elements of this thread's chunk (pad columns dropped)
+        __syncthreads();   // previous chunk's MFMAs are done reading LDS
 #pragma unroll
-            for (int it = 0; it < 2; ++it) *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(m, r0 + it * RSTEP, c)) = v[it];
-        }
+        for (int mi = 0; mi < MB / BPP; ++mi)
+#pragma unroll
+            for (int it = 0; it < NIT; ++it)
+                *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(mi * BPP + sub, r0 + it * (256 / P::CPR), c)) = chunk_keep_first<T>(v[mi][it], nv) ^ sx;
         __syncthreads();
-        load_bfrag<T>(bf, wpack, a.pack0[t] + kc, wv, lane);
+        load_bfrag<T>(bf, wpack, a.pack0[t] + kc, wv, lane);   // before the prefetch: vmcnt retires in order
+        if (kc + 1 < nkc) fetch(kc + 1);   // the next K chunk streams from HBM under this chunk's MFMAs
 #pragma unroll
-        for (int m = 0; m < ENC_MB; ++m) {
+        for (int m = 0; m < MB; ++m) {
             if (w0 + m * P::ROWS < a.B) {   // uniform
                 load_afrag<T>(af, smem, m, lane);
                 mac(acc[m], af, bf);
@@ -305,55 +367,138 @@ template <typename T> __global__ __launch_bounds__(256) void k_enc_fwd(EncArgs a
     T* x0 = reinterpret_cast<T*>(a.x0);
     const int gnode = a.tbase[t] + node;
 #pragma unroll
-    for (int m = 0; m < ENC_MB; ++m)
+    for (int m = 0; m < MB; ++m) {
+        const int w = w0 + m * P::ROWS + c_win(lane);
+        if (w < a.B) {
 #pragma unroll
-        for (int q = 0; q < P::NREG; ++q) {
-            const int w = w0 + m * P::ROWS + c_row<T>(q, lane), col = wv * 32 + c_col<T>(q, lane);
-            if (w < a.B) x0[((size_t)w * a.NN + gnode) * H + col] = from_f32<T>(fmaxf(acc_ref(acc[m], q), 0.f));
+            for (int fb = 0; fb < 2; ++fb)
+                store_quad(x0 + act_idx(w, gnode, a.B) + wv * 32 + c_feat(fb, lane), relu4(acc[m].c[fb]));
         }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
 // k_layer_fwd: one HeteroConv layer + activation / base_transform + residual  (hgnn_c2.py:150-166)
 // ------------------------------------------------------------------------------------------------------
 struct LayerArgs {
-    const void* x_in;      // fwd: X_l ;            bwd: dX_{l+1}
-    void* x_out;           // fwd: X_{l+1} ;        bwd: dX_l
+    const void* x_in;      // fwd: X_l                    bwd: G_{l+1} = dX_{l+1} (read; written when it is materialised here)
+    void* x_out;           // fwd: X_{l+1}                bwd: layer 0 only: dX_0 = relu'(X_0) . (G_1 + D_0)
     unsigned* maskbits;    // relu bits of this layer [B][NN][4]
     void* hb; void* t1;    // base_transform stash of this layer [B][n_mlp][128]
-    void* dh; void* du;    // bwd only: dH_l [B][NN][128], dU_l [B][n_mlp][128]
-    const void* x_act;     // bwd only: X_0 (encoder relu mask) when GF_ENC_MASK
+    void* dh; void* du;    // bwd: dH_l [B][NN][128], dU_l [B][n_mlp][128]
+    const void* x_act;     // bwd layer 0: X_0 (encoder relu mask)
+    const void* g_prev;    // bwd: G_{l+2}   (residual input of G_{l+1} = G_{l+2} + D_{l+1})
+    const void* d_in;      // bwd: D_{l+1}
+    void* d_out;           // bwd: D_l  (dX_l without its residual term)
     const void* wpack; const float* bias; const int* prog;
     int B, NN, n_mlp;
+    int dbg;               // ablation switches for timing experiments (MSHGNN_DBG): 1 no stage-in, 2 no MACs, 4 no W loads, 8 no group epilogues
 };
 
-// store the relu bits of one accumulator (this wave's 32 columns of ROWS windows of node n)
+// relu bits of one accumulator -> word wn of maskbits[B][NN][4] (bit i <-> feature 32 wn + i).  Each lane owns 8 bits
+// (features 16 fb + 4 g + j) of its window; the 4 lanes of a window are OR-combined with two cross-lane shuffles.
 template <typename T>
-__device__ __forceinline__ void store_relu_bits(typename Prec<T>::Acc& acc, unsigned* maskbits, int NN, int n, int w0, int B, int wv, int lane_) {
-    const int lane = opaque(lane_);
+__device__ __forceinline__ void store_relu_bits(const typename Prec<T>::Acc& acc, unsigned* maskbits, int NN, int n, int w0, int B, int wn, int lane) {
+    const int g = lane >> 4;
+    unsigned bits = 0;
+#pragma unroll
+    for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bits |= (acc.c[fb][j] > 0.f ? 1u : 0u) << (16 * fb + 4 * g + j);
+    bits |= (unsigned)__shfl_xor((int)bits, 16, 64);
+    bits |= (unsigned)__shfl_xor((int)bits, 32, 64);
+    const int w = w0 + c_win(lane);
+    if (g == 0 && w < B) maskbits[((size_t)n * B + w) * 4 + wn] = bits;
+}
+
+// elementwise helpers on one 16-byte chunk of T
+template <typename T> __device__ __forceinline__ u32x4 chunk_add(u32x4 a, u32x4 b) {
+    union U { u32x4 v; T e[Prec<T>::EPC]; } x, y, r;
+    x.v = a; y.v = b;
+#pragma unroll
+    for (int e = 0; e < Prec<T>::EPC; ++e) r.e[e] = from_f32<T>(to_f32(x.e[e]) + to_f32(y.e[e]));
+    return r.v;
+}
+template <typename T> __device__ __forceinline__ u32x4 chunk_mask_pos(u32x4 v, u32x4 act) {   // keep v where act > 0
+    union U { u32x4 v; T e[Prec<T>::EPC]; } x, y;
+    x.v = v; y.v = act;
+#pragma unroll
+    for (int e = 0; e < Prec<T>::EPC; ++e) if (!(to_f32(y.e[e]) > 0.f)) x.e[e] = from_f32<T>(0.f);
+    return x.v;
+}
+template <typename T> __device__ __forceinline__ u32x4 chunk_mask_bits(u32x4 v, unsigned bits) {   // EPC relu bits, LSB first
     if constexpr (sizeof(T) == 4) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const unsigned long long b0 = __ballot(acc.c[0][j] > 0.f), b1 = __ballot(acc.c[1][j] > 0.f);
-            if (lane < 4) {
-                const int row = 4 * lane + j;
-                const unsigned word = (unsigned)((b0 >> (16 * lane)) & 0xffffull) | ((unsigned)((b1 >> (16 * lane)) & 0xffffull) << 16);
-                if (w0 + row < B) maskbits[((size_t)(w0 + row) * NN + n) * 4 + wv] = word;
-            }
-        }
+        for (int e = 0; e < 4; ++e) if (!((bits >> e) & 1u)) v[e] = 0u;
     } else {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const unsigned long long b = __ballot(acc.c[q] > 0.f);
-            if (lane < 2) {
-                const int row = (q & 3) + ((q >> 2) << 3) + 4 * lane;
-                if (w0 + row < B) maskbits[((size_t)(w0 + row) * NN + n) * 4 + wv] = (unsigned)(b >> (32 * lane));
+        for (int e = 0; e < 4; ++e) {
+            unsigned m = 0;
+            if ((bits >> (2 * e)) & 1u) m |= 0x0000ffffu;
+            if ((bits >> (2 * e + 1)) & 1u) m |= 0xffff0000u;
+            v[e] &= m;
+        }
+    }
+    return v;
+}
+
+// The wave's MAC program of a group lives in two VGPRs (entry i in lane i); entries are fetched with v_readlane.
+struct WaveProg {
+    int p0, p1, pc;
+    __device__ __forceinline__ WaveProg(const int* prog, int lane) : p0(prog[lane]), p1(prog[64 + lane]), pc(0) {}
+    __device__ __forceinline__ int next() {
+        const int i = pc++;
+        return i < 64 ? __builtin_amdgcn_readlane(p0, i) : __builtin_amdgcn_readlane(p1, i - 64);
+    }
+};
+
+// run every segment of the group for this wave: per segment load the packed weight fragment once, then walk the
+// accumulators in static order, each with its run-time list of source blocks
+template <typename T>
+__device__ __forceinline__ void run_segments(const int* wprog, typename Prec<T>::Acc (&acc)[Prec<T>::HS], const char* smem,
+                                             const T* wpack, int wn, int lane, int dbg) {
+    using P = Prec<T>;
+    WaveProg wp(wprog, lane);
+    const int nseg = wp.next();
+    typename P::BFrag bf;
+    typename P::AFrag af;
+    for (int s = 0; s < nseg; ++s) {
+        const int pack = wp.next();
+        if (!(dbg & 4) || s == 0) load_bfrag<T>(bf, wpack, pack, wn, lane);
+#pragma unroll
+        for (int u = 0; u < P::HS; ++u) {
+            const int cnt = wp.next();
+            for (int k = 0; k < cnt; ++k) {
+                const int blk = wp.next();
+                if (!(dbg & 2)) {
+                    load_afrag<T>(af, smem, blk, lane);
+                    mac(acc[u], af, bf);
+                }
             }
         }
     }
 }
 
-template <typename T> __global__ __launch_bounds__(LAYER_THREADS) void k_layer_fwd(LayerArgs a) {
+// one extra block-GEMM of the base_transform chain: acc[u] = bias + LDS[blk(slot)] . W(pack) for this wave's slots
+template <typename T>
+__device__ __forceinline__ void mlp_gemm(typename Prec<T>::Acc (&acc)[Prec<T>::HS], const char* smem, const int* blks, int ns,
+                                         const T* wpack, int pack, const float* bias, int wn, int wh, int lane) {
+    using P = Prec<T>;
+    typename P::BFrag bf;
+    typename P::AFrag af;
+    load_bfrag<T>(bf, wpack, pack, wn, lane);
+#pragma unroll
+    for (int u = 0; u < P::HS; ++u) {
+        const int slot = 2 * u + wh;
+        if (slot < ns) {
+            acc_init_bias<T>(acc[u], bias, wn, lane);
+            load_afrag<T>(af, smem, blks[slot], lane);
+            mac(acc[u], af, bf);
+        }
+    }
+}
+
+template <typename T> __global__ __launch_bounds__(LAYER_THREADS, Prec<T>::WPS) void k_layer_fwd(LayerArgs a) {
     using P = Prec<T>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -362,284 +507,303 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS) void k_layer_f
     const T* xin = reinterpret_cast<const T*>(a.x_in);
     T* xout = reinterpret_cast<T*>(a.x_out);
     const T* wpack = reinterpret_cast<const T*>(a.wpack);
+    const int win = c_win(lane), w = w0 + win;
+    const bool w_ok = w < B;
 
-    stage_nodes<T>(smem, xin, NN, 0, NN, w0, B, tid);
+    if (!(a.dbg & 1)) stage_nodes<T>(smem, xin, NN, w0, B, tid);
     __syncthreads();
 
     typename P::Acc acc[P::HS];
-    typename P::BFrag bf;
-    typename P::AFrag af;
     const int* pg = a.prog;
     const int ngroups = pg[0];
-    int off = 1;
-    for (int g = 0; g < ngroups; ++g) {
-        const int* gh = pg + off;
-        const int kind = gh[GH_KIND], ns = gh[GH_NSLOTS], nent = gh[GH_NENT], flags = gh[GH_FLAGS];
+    const int* gh = pg + 1;
+    for (int g = 0; g < ngroups; ++g, gh += GH_SIZE + 2 * WPROG_LEN) {
+        const int kind = gh[GH_KIND], ns = gh[GH_NSLOTS], flags = gh[GH_FLAGS];
         const float* bias = a.bias + (size_t)gh[GH_BIAS] * H;
 #pragma unroll
         for (int u = 0; u < P::HS; ++u) acc_init_bias<T>(acc[u], bias, wn, lane);
-        const int* ent = gh + GH_SIZE;
-        for (int e = 0; e < nent; ++e) {
-            const int op = ent[e * ENT_INTS], slot = ent[e * ENT_INTS + 1], arg = ent[e * ENT_INTS + 2];
-            if (op == OP_LOADW) { load_bfrag<T>(bf, wpack, arg, wn, lane); continue; }
-            if ((slot & 1) != wh) continue;
-            load_afrag<T>(af, smem, arg, lane);
-#pragma unroll
-            for (int u = 0; u < P::HS; ++u) if (u == (slot >> 1)) mac(acc[u], af, bf);
-        }
+        run_segments<T>(gh + GH_SIZE + wh * WPROG_LEN, acc, smem, wpack, wn, lane, a.dbg);
+        if (a.dbg & 8) continue;
         if (kind == KIND_RELU) {
+            const bool lds_epi = (flags & GF_LDS_EPI) != 0;
+            // last group: every source block is dead once all waves are past their MACs -> X_new goes into the nodes'
+            // own LDS blocks (residual read in place) and is then stored as whole rows
+            if (lds_epi) __syncthreads();
 #pragma unroll
             for (int u = 0; u < P::HS; ++u) {
                 const int slot = 2 * u + wh;
                 if (slot < ns) {
                     const int n = gh[GH_NODES + slot];
                     if (flags & GF_STORE_MASK) store_relu_bits<T>(acc[u], a.maskbits, NN, n, w0, B, wn, lane);
-                    T* obase = xout + ((size_t)w0 * NN + n) * H + wn * 32;   // wave-uniform
-const int ln = opaque(lane);
 #pragma unroll
-                    for (int q = 0; q < P::NREG; ++q) {
-                        const int row = c_row<T>(q, ln), col = c_col<T>(q, ln);
-                        float y = fmaxf(acc_ref(acc[u], q), 0.f);
-                        if (flags & GF_RESIDUAL) y += to_f32(*reinterpret_cast<const T*>(smem + lds_elem<T>(n, row, wn * 32 + col)));
-                        if (w0 + row < B) obase[(unsigned)(row * NN * H + col)] = from_f32<T>(y);
+                    for (int fb = 0; fb < 2; ++fb) {
+                        const int col = wn * 32 + c_feat(fb, lane);
+                        T* pe = reinterpret_cast<T*>(smem + lds_elem<T>(n, win, col));
+                        f32x4 y = relu4(acc[u].c[fb]);
+                        if (flags & GF_RESIDUAL) y += load_quad(pe);
+                        if (lds_epi) store_quad(pe, y);
+                        else if (w_ok) store_quad(xout + act_idx(w, n, B) + col, y);
                     }
                 }
-                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (lds_epi) {
+                __syncthreads();
+                const RowMap<T> m(tid);
+                if (w0 + m.row < B)
+                    for (int sl = m.sub; sl < ns; sl += RowMap<T>::NPB) {
+                        const int n = gh[GH_NODES + sl];
+                        const u32x4 v = *reinterpret_cast<const u32x4*>(smem + lds_chunk<T>(n, m.row, m.c));
+                        *reinterpret_cast<u32x4*>(xout + act_idx(w0 + m.row, n, B) + m.c * P::EPC) = v;
+                    }
             }
         } else {
             // base_transform: Y = W2 relu(W1 H + b1) + b2, X <- Y + X   (hgnn_c2.py:117-121,156,161-166)
             T* hb = reinterpret_cast<T*>(a.hb);
             T* t1 = reinterpret_cast<T*>(a.t1);
+            const int* scr = gh + GH_SCR;
+            const bool own = scr[0] == gh[GH_NODES];   // scratch aliases the nodes' own blocks (no spare LDS)
             __syncthreads();   // every wave is done reading the group's source blocks
 #pragma unroll
             for (int u = 0; u < P::HS; ++u) {
                 const int slot = 2 * u + wh;
                 if (slot < ns) {
-                    const int n = gh[GH_NODES + slot], mi = gh[GH_MLPIDX + slot];
-const int ln = opaque(lane);
+                    const int mi = gh[GH_MLPIDX + slot];
 #pragma unroll
-                    for (int q = 0; q < P::NREG; ++q) {
-                        const int row = c_row<T>(q, ln), col = wn * 32 + c_col<T>(q, ln);
-                        const T hv = from_f32<T>(acc_ref(acc[u], q));
-                        *reinterpret_cast<T*>(smem + lds_elem<T>(n, row, col)) = hv;
-                        if (w0 + row < B) hb[((size_t)(w0 + row) * a.n_mlp + mi) * H + col] = hv;
+                    for (int fb = 0; fb < 2; ++fb) {
+                        const int col = wn * 32 + c_feat(fb, lane);
+                        store_quad(reinterpret_cast<T*>(smem + lds_elem<T>(scr[slot], win, col)), acc[u].c[fb]);
+                        if (w_ok) store_quad(hb + act_idx(w, mi, B) + col, acc[u].c[fb]);
                     }
                 }
             }
             __syncthreads();
-            load_bfrag<T>(bf, wpack, gh[GH_W1], wn, lane);
-            const float* b1 = a.bias + (size_t)gh[GH_B1] * H;
-#pragma unroll
-            for (int u = 0; u < P::HS; ++u) {
-                const int slot = 2 * u + wh;
-                if (slot < ns) {
-                    acc_init_bias<T>(acc[u], b1, wn, lane);
-                    load_afrag<T>(af, smem, gh[GH_NODES + slot], lane);
-                    mac(acc[u], af, bf);
-                }
-            }
+            mlp_gemm<T>(acc, smem, scr, ns, wpack, gh[GH_W1], a.bias + (size_t)gh[GH_B1] * H, wn, wh, lane);
             __syncthreads();   // all reads of H done before T1 overwrites the blocks
 #pragma unroll
             for (int u = 0; u < P::HS; ++u) {
                 const int slot = 2 * u + wh;
                 if (slot < ns) {
-                    const int n = gh[GH_NODES + slot], mi = gh[GH_MLPIDX + slot];
-const int ln = opaque(lane);
+                    const int mi = gh[GH_MLPIDX + slot];
 #pragma unroll
-                    for (int q = 0; q < P::NREG; ++q) {
-                        const int row = c_row<T>(q, ln), col = wn * 32 + c_col<T>(q, ln);
-                        const T tv = from_f32<T>(fmaxf(acc_ref(acc[u], q), 0.f));
-                        *reinterpret_cast<T*>(smem + lds_elem<T>(n, row, col)) = tv;
-                        if (w0 + row < B) t1[((size_t)(w0 + row) * a.n_mlp + mi) * H + col] = tv;
+                    for (int fb = 0; fb < 2; ++fb) {
+                        const int col = wn * 32 + c_feat(fb, lane);
+                        const f32x4 tv = relu4(acc[u].c[fb]);
+                        store_quad(reinterpret_cast<T*>(smem + lds_elem<T>(scr[slot], win, col)), tv);
+                        if (w_ok) store_quad(t1 + act_idx(w, mi, B) + col, tv);
                     }
                 }
             }
             __syncthreads();
-            load_bfrag<T>(bf, wpack, gh[GH_W2], wn, lane);
-            const float* b2 = a.bias + (size_t)gh[GH_B2] * H;
+            mlp_gemm<T>(acc, smem, scr, ns, wpack, gh[GH_W2], a.bias + (size_t)gh[GH_B2] * H, wn, wh, lane);
 #pragma unroll
             for (int u = 0; u < P::HS; ++u) {
                 const int slot = 2 * u + wh;
-                if (slot < ns) {
+                if (slot < ns && w_ok) {
                     const int n = gh[GH_NODES + slot];
-                    acc_init_bias<T>(acc[u], b2, wn, lane);
-                    load_afrag<T>(af, smem, n, lane);
-                    mac(acc[u], af, bf);
-const int ln = opaque(lane);
 #pragma unroll
-                    for (int q = 0; q < P::NREG; ++q) {
-                        const int row = c_row<T>(q, ln), col = wn * 32 + c_col<T>(q, ln);
-                        if (w0 + row < B) {
-                            float y = acc_ref(acc[u], q);
-                            if (flags & GF_RESIDUAL) y += to_f32(xin[((size_t)(w0 + row) * NN + n) * H + col]);
-                            xout[((size_t)(w0 + row) * NN + n) * H + col] = from_f32<T>(y);
-                        }
+                    for (int fb = 0; fb < 2; ++fb) {
+                        const int col = wn * 32 + c_feat(fb, lane);
+                        f32x4 y = acc[u].c[fb];
+                        if (flags & GF_RESIDUAL)
+                            y += own ? load_quad(xin + act_idx(w, n, B) + col)
+                                     : load_quad(reinterpret_cast<const T*>(smem + lds_elem<T>(n, win, col)));
+                        store_quad(xout + act_idx(w, n, B) + col, y);
                     }
                 }
             }
         }
-        off += GH_SIZE + nent * ENT_INTS;
     }
 }
 
 // ------------------------------------------------------------------------------------------------------
-// k_layer_bwd: dH_l from dX_{l+1} (relu bits / base_transform chain), then dX_l on the transposed graph
+// k_layer_bwd: G_{l+1} = G_{l+2} + D_{l+1} (coalesced, materialised), dH_l from it (relu bits / base_transform
+// chain), then D_l on the transposed graph.  Layer 0 finishes dX_0 = relu'(X_0) . (G_1 + D_0) itself.
 // ------------------------------------------------------------------------------------------------------
-template <typename T> __global__ __launch_bounds__(LAYER_THREADS) void k_layer_bwd(LayerArgs a) {
+template <typename T> __global__ __launch_bounds__(LAYER_THREADS, Prec<T>::WPS) void k_layer_bwd(LayerArgs a) {
     using P = Prec<T>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wv & 3, wh = wv >> 2;
     const int w0 = blockIdx.x * P::ROWS, B = a.B, NN = a.NN;
-    const T* dxn = reinterpret_cast<const T*>(a.x_in);     // dX_{l+1}
-    T* dxo = reinterpret_cast<T*>(a.x_out);                // dX_l
+    T* gtop = reinterpret_cast<T*>(const_cast<void*>(a.x_in));   // G_{l+1}
+    const T* gprev = reinterpret_cast<const T*>(a.g_prev);
+    const T* din = reinterpret_cast<const T*>(a.d_in);
+    T* dout = reinterpret_cast<T*>(a.d_out);
+    T* dx0 = reinterpret_cast<T*>(a.x_out);
     T* dh = reinterpret_cast<T*>(a.dh);
+    const T* xact = reinterpret_cast<const T*>(a.x_act);
     const T* wpack = reinterpret_cast<const T*>(a.wpack);
     const int* pg = a.prog;
-    const int ngroups = pg[0], nmlp = pg[1], w2pack = pg[2], w1pack = pg[3];
-    const int* node_kind = pg + 4;
-    const int* mlp_nodes = pg + 4 + 64;
+    const int ngroups = pg[BH_NGROUPS], nmlp = pg[BH_NMLP], w2pack = pg[BH_W2], w1pack = pg[BH_W1], has_delta = pg[BH_HAS_DELTA];
+    const int* node_kind = pg + BH_KIND;
+    const int* node_flags = pg + BH_NFLAGS;
+    const int* mlp_nodes = pg + BH_MLPNODES;
+    const int win = c_win(lane), w = w0 + win;
+    const bool w_ok = w < B;
 
-    // stage 1: dX_{l+1} -> LDS, relu nodes masked (-> dH, also written to global for the weight-gradient kernel)
+    // stage 1 (row-major, coalesced): G_{l+1} -> LDS; relu nodes masked (-> dH, also to global for k_gradw)
     {
-        constexpr int CPR = P::CPR, EPC = P::EPC;
-        const int c = tid % CPR, row = tid / CPR, w = w0 + row;
-        for (int n = 0; n < NN; ++n) {
-            const int nk = node_kind[n];
-            if (nk == NK_DEAD) continue;
-            u32x4 v = u32x4{0, 0, 0, 0};
-            if (w < B) {
-                v = *reinterpret_cast<const u32x4*>(dxn + ((size_t)w * NN + n) * H + c * EPC);
-                if (nk == NK_RELU) {
-                    const unsigned word = a.maskbits[((size_t)w * NN + n) * 4 + (c * EPC) / 32];
-                    const unsigned bits = word >> ((c * EPC) % 32);
-                    if constexpr (sizeof(T) == 4) {
+        constexpr int EPC = P::EPC, NPB = RowMap<T>::NPB, BATCH = 3;
+        const RowMap<T> m(tid);
+        const int row = m.row, c = m.c, wr = w0 + row;
+        for (int nb = m.sub; nb < NN; nb += NPB * BATCH) {
+            u32x4 v[BATCH], g2[BATCH]; unsigned word[BATCH]; int nk[BATCH];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) if (!((bits >> e) & 1u)) v[e] = 0u;
+            for (int i = 0; i < BATCH; ++i) {       // issue every load of the batch first
+                const int n = nb + i * NPB;
+                nk[i] = n < NN ? node_kind[n] : NK_DEAD;
+                v[i] = u32x4{0, 0, 0, 0}; g2[i] = u32x4{0, 0, 0, 0}; word[i] = 0;
+                if (nk[i] != NK_DEAD && wr < B) {
+                    const size_t idx = act_idx(wr, n, B) + c * EPC;
+                    if (has_delta) {
+                        v[i] = *reinterpret_cast<const u32x4*>(din + idx);
+                        if (node_flags[n] & NF_RES_IN) g2[i] = *reinterpret_cast<const u32x4*>(gprev + idx);
                     } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            unsigned m = 0;
-                            if ((bits >> (2 * e)) & 1u) m |= 0x0000ffffu;
-                            if ((bits >> (2 * e + 1)) & 1u) m |= 0xffff0000u;
-                            v[e] &= m;
-                        }
+                        v[i] = *reinterpret_cast<const u32x4*>(gtop + idx);
                     }
-                    *reinterpret_cast<u32x4*>(dh + ((size_t)w * NN + n) * H + c * EPC) = v;
+                    if (nk[i] == NK_RELU) word[i] = a.maskbits[((size_t)n * B + wr) * 4 + (c * EPC) / 32];
                 }
             }
-            *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(n, row, c)) = v;
+#pragma unroll
+            for (int i = 0; i < BATCH; ++i) {
+                const int n = nb + i * NPB;
+                if (nk[i] == NK_DEAD) continue;
+                if (wr < B) {
+                    const size_t idx = act_idx(wr, n, B) + c * EPC;
+                    if (has_delta) {
+                        if (node_flags[n] & NF_RES_IN) v[i] = chunk_add<T>(v[i], g2[i]);
+                        *reinterpret_cast<u32x4*>(gtop + idx) = v[i];           // materialise G_{l+1}
+                    }
+                    if (nk[i] == NK_RELU) {
+                        v[i] = chunk_mask_bits<T>(v[i], word[i] >> ((c * EPC) % 32));
+                        *reinterpret_cast<u32x4*>(dh + idx) = v[i];
+                    }
+                }
+                *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(n, row, c)) = v[i];
+            }
         }
     }
     __syncthreads();
 
     typename P::Acc acc[P::HS];
-    typename P::BFrag bf;
-    typename P::AFrag af;
 
     if (nmlp > 0) {
-        // dT1 = dY W2 ; dU = dT1 . (T1 > 0) ; dH = dU W1     (backward of base_transform)
+        // dT1 = dY W2 ; dU = dT1 . (T1 > 0) ; dH = dU W1     (backward of base_transform; re-uses the base blocks)
         const T* t1 = reinterpret_cast<const T*>(a.t1);
         T* du = reinterpret_cast<T*>(a.du);
-        load_bfrag<T>(bf, wpack, w2pack, wn, lane);
-#pragma unroll
-        for (int u = 0; u < P::HS; ++u) {
-            const int slot = 2 * u + wh;
-            if (slot < nmlp) {
-                acc_fill(acc[u], 0.f, 0.f);
-                load_afrag<T>(af, smem, mlp_nodes[slot], lane);
-                mac(acc[u], af, bf);
-            }
-        }
+        mlp_gemm<T>(acc, smem, mlp_nodes, nmlp, wpack, w2pack, nullptr, wn, wh, lane);
         __syncthreads();   // all reads of dY blocks done
 #pragma unroll
         for (int u = 0; u < P::HS; ++u) {
             const int slot = 2 * u + wh;
             if (slot < nmlp) {
-                const int n = mlp_nodes[slot];
-const int ln = opaque(lane);
 #pragma unroll
-                for (int q = 0; q < P::NREG; ++q) {
-                    const int row = c_row<T>(q, ln), col = wn * 32 + c_col<T>(q, ln);
-                    float v = 0.f;
-                    if (w0 + row < B) {
-                        const float tv = to_f32(t1[((size_t)(w0 + row) * a.n_mlp + slot) * H + col]);
-                        v = tv > 0.f ? acc_ref(acc[u], q) : 0.f;
-                        du[((size_t)(w0 + row) * a.n_mlp + slot) * H + col] = from_f32<T>(v);
+                for (int fb = 0; fb < 2; ++fb) {
+                    const int col = wn * 32 + c_feat(fb, lane);
+                    f32x4 r = f32x4{0, 0, 0, 0};
+                    if (w_ok) {
+                        const f32x4 tv = load_quad(t1 + act_idx(w, slot, B) + col);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) r[j] = tv[j] > 0.f ? acc[u].c[fb][j] : 0.f;
+                        store_quad(du + act_idx(w, slot, B) + col, r);
                     }
-                    *reinterpret_cast<T*>(smem + lds_elem<T>(n, row, col)) = from_f32<T>(v);
+                    store_quad(reinterpret_cast<T*>(smem + lds_elem<T>(mlp_nodes[slot], win, col)), r);
                 }
             }
         }
         __syncthreads();
-        load_bfrag<T>(bf, wpack, w1pack, wn, lane);
-#pragma unroll
-        for (int u = 0; u < P::HS; ++u) {
-            const int slot = 2 * u + wh;
-            if (slot < nmlp) {
-                acc_fill(acc[u], 0.f, 0.f);
-                load_afrag<T>(af, smem, mlp_nodes[slot], lane);
-                mac(acc[u], af, bf);
-            }
-        }
+        mlp_gemm<T>(acc, smem, mlp_nodes, nmlp, wpack, w1pack, nullptr, wn, wh, lane);
         __syncthreads();   // all reads of dU blocks done
 #pragma unroll
         for (int u = 0; u < P::HS; ++u) {
             const int slot = 2 * u + wh;
             if (slot < nmlp) {
                 const int n = mlp_nodes[slot];
-const int ln = opaque(lane);
 #pragma unroll
-                for (int q = 0; q < P::NREG; ++q) {
-                    const int row = c_row<T>(q, ln), col = wn * 32 + c_col<T>(q, ln);
-                    const T hv = from_f32<T>(acc_ref(acc[u], q));
-                    *reinterpret_cast<T*>(smem + lds_elem<T>(n, row, col)) = hv;
-                    if (w0 + row < B) dh[((size_t)(w0 + row) * NN + n) * H + col] = hv;
+                for (int fb = 0; fb < 2; ++fb) {
+                    const int col = wn * 32 + c_feat(fb, lane);
+                    store_quad(reinterpret_cast<T*>(smem + lds_elem<T>(n, win, col)), acc[u].c[fb]);
+                    if (w_ok) store_quad(dh + act_idx(w, n, B) + col, acc[u].c[fb]);
                 }
             }
         }
         __syncthreads();
     }
 
-    // stage 2: dX_l[j] = [dX_{l+1}[j]] + dH_j W_rootsum + sum_r sum_{j->i} dH_i W_rel^r
-    const T* xact = reinterpret_cast<const T*>(a.x_act);
-    int off = 4 + 64 + GMAX;
-    for (int g = 0; g < ngroups; ++g) {
-        const int* gh = pg + off;
-        const int ns = gh[GH_NSLOTS], nent = gh[GH_NENT], flags = gh[GH_FLAGS];
+    // stage 2: D_l[j] = dH_j W_rootsum + sum_r sum_{j->i} dH_i W_rel^r
+    const int* gh = pg + BH_SIZE;
+    for (int g = 0; g < ngroups; ++g, gh += GH_SIZE + 2 * WPROG_LEN) {
+        const int ns = gh[GH_NSLOTS], flags = gh[GH_FLAGS];
 #pragma unroll
-        for (int u = 0; u < P::HS; ++u) acc_fill(acc[u], 0.f, 0.f);
-        const int* ent = gh + GH_SIZE;
-        for (int e = 0; e < nent; ++e) {
-            const int op = ent[e * ENT_INTS], slot = ent[e * ENT_INTS + 1], arg = ent[e * ENT_INTS + 2];
-            if (op == OP_LOADW) { load_bfrag<T>(bf, wpack, arg, wn, lane); continue; }
-            if ((slot & 1) != wh) continue;
-            load_afrag<T>(af, smem, arg, lane);
+        for (int u = 0; u < P::HS; ++u) acc_fill(acc[u], 0.f);
+        run_segments<T>(gh + GH_SIZE + wh * WPROG_LEN, acc, smem, wpack, wn, lane, a.dbg);
+        if (flags & GF_LDS_EPI) {
+            __syncthreads();   // last group: all dH blocks are dead -> stage D through LDS, store whole rows
 #pragma unroll
-            for (int u = 0; u < P::HS; ++u) if (u == (slot >> 1)) mac(acc[u], af, bf);
-        }
+            for (int u = 0; u < P::HS; ++u) {
+                const int slot = 2 * u + wh;
+                if (slot < ns) {
 #pragma unroll
-        for (int u = 0; u < P::HS; ++u) {
-            const int slot = 2 * u + wh;
-            if (slot < ns) {
-                const int n = gh[GH_NODES + slot];
-                const size_t ubase = ((size_t)w0 * NN + n) * H + wn * 32;   // wave-uniform
-const int ln = opaque(lane);
+                    for (int fb = 0; fb < 2; ++fb)
+                        store_quad(reinterpret_cast<T*>(smem + lds_elem<T>(gh[GH_NODES + slot], win, wn * 32 + c_feat(fb, lane))), acc[u].c[fb]);
+                }
+            }
+            __syncthreads();
+            const RowMap<T> m(tid);
+            const int row = m.row, c = m.c;
+            if (w0 + row < B)
+                for (int sl0 = m.sub; sl0 < ns; sl0 += 2 * RowMap<T>::NPB) {
+                    u32x4 v[2], g1[2], xa[2]; bool ok[2];
 #pragma unroll
-                for (int q = 0; q < P::NREG; ++q) {
-                    const int row = c_row<T>(q, ln), col = c_col<T>(q, ln);
-                    if (w0 + row < B) {
-                        const unsigned o = (unsigned)(row * NN * H + col);
-                        float y = acc_ref(acc[u], q);
-                        if (flags & GF_RESIDUAL) y += to_f32((dxn + ubase)[o]);
-                        if (flags & GF_ENC_MASK) y = to_f32((xact + ubase)[o]) > 0.f ? y : 0.f;
-                        (dxo + ubase)[o] = from_f32<T>(y);
+                    for (int i = 0; i < 2; ++i) {       // two nodes in flight per thread
+                        const int sl = sl0 + i * RowMap<T>::NPB;
+                        ok[i] = sl < ns;
+                        const int n = gh[GH_NODES + (ok[i] ? sl : 0)];
+                        const size_t idx = act_idx(w0 + row, n, B) + c * P::EPC;
+                        v[i] = *reinterpret_cast<const u32x4*>(smem + lds_chunk<T>(n, row, c));
+                        g1[i] = u32x4{0, 0, 0, 0}; xa[i] = u32x4{0, 0, 0, 0};
+                        if (ok[i] && (flags & GF_ENC_MASK)) {
+                            if (flags & GF_RESIDUAL) g1[i] = *reinterpret_cast<const u32x4*>(gtop + idx);
+                            xa[i] = *reinterpret_cast<const u32x4*>(xact + idx);
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        if (!ok[i]) continue;
+                        const int n = gh[GH_NODES + sl0 + i * RowMap<T>::NPB];
+                        const size_t idx = act_idx(w0 + row, n, B) + c * P::EPC;
+                        if (flags & GF_ENC_MASK) {   // layer 0: finish dX_0 = relu'(X_0) . (G_1 + D_0) here
+                            u32x4 r = v[i];
+                            if (flags & GF_RESIDUAL) r = chunk_add<T>(r, g1[i]);
+                            *reinterpret_cast<u32x4*>(dx0 + idx) = chunk_mask_pos<T>(r, xa[i]);
+                        } else {
+                            *reinterpret_cast<u32x4*>(dout + idx) = v[i];
+                        }
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int u = 0; u < P::HS; ++u) {
+                const int slot = 2 * u + wh;
+                if (slot < ns && w_ok) {
+                    const int n = gh[GH_NODES + slot];
+#pragma unroll
+                    for (int fb = 0; fb < 2; ++fb) {
+                        const size_t idx = act_idx(w, n, B) + wn * 32 + c_feat(fb, lane);
+                        if (flags & GF_ENC_MASK) {
+                            f32x4 y = acc[u].c[fb];
+                            if (flags & GF_RESIDUAL) y = round_as<T>(y) + load_quad(gtop + idx);   // D_0 is rounded like a stored delta
+                            const f32x4 xa = load_quad(xact + idx);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) y[j] = xa[j] > 0.f ? y[j] : 0.f;
+                            store_quad(dx0 + idx, y);
+                        } else {
+                            store_quad(dout + idx, acc[u].c[fb]);
+                        }
                     }
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
-        off += GH_SIZE + nent * ENT_INTS;
     }
 }
 
@@ -651,57 +815,93 @@ struct DecArgs {
     int64_t off_w, off_b; int B, NN, node0, n_out, dout, slab0;
 };
 
+// thread = (row, 8-column chunk): 16 lanes share a row, one wave covers 4 rows; whole rows are read / written coalesced
+template <typename T> __device__ __forceinline__ void load8(const T* p, float (&v)[8]) {
+    if constexpr (sizeof(T) == 4) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(p)[0], b = reinterpret_cast<const f32x4*>(p)[1];
+        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    } else {
+        const u32x4 r = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[2 * e] = __builtin_bit_cast(float, r[e] << 16); v[2 * e + 1] = __builtin_bit_cast(float, r[e] & 0xffff0000u); }
+    }
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float (&v)[8]) {
+    if constexpr (sizeof(T) == 4) {
+        reinterpret_cast<f32x4*>(p)[0] = f32x4{v[0], v[1], v[2], v[3]};
+        reinterpret_cast<f32x4*>(p)[1] = f32x4{v[4], v[5], v[6], v[7]};
+    } else {
+        union { u32x4 r; __bf16 e[8]; } u;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) u.e[e] = (__bf16)v[e];
+        *reinterpret_cast<u32x4*>(p) = u.r;
+    }
+}
+
 template <typename T> __global__ __launch_bounds__(256) void k_dec_fwd(DecArgs a) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t row = (int64_t)blockIdx.x * 4 + wv;
-    if (row >= (int64_t)a.B * a.n_out) return;
-    const int w = (int)(row / a.n_out), f = (int)(row % a.n_out);
-    const T* x = reinterpret_cast<const T*>(a.xl) + ((size_t)w * a.NN + a.node0 + f) * H;
-    const float x0 = to_f32(x[lane]), x1 = to_f32(x[lane + 64]);
+    const int c = threadIdx.x & 15;
+    const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int64_t rows = (int64_t)a.B * a.n_out;
+    const bool ok = row < rows;
+    const int w = ok ? (int)(row / a.n_out) : 0, f = ok ? (int)(row % a.n_out) : 0;
+    float x[8];
+    load8<T>(reinterpret_cast<const T*>(a.xl) + act_idx(w, a.node0 + f, a.B) + c * 8, x);
     const float* W = a.params + a.off_w;
     for (int d = 0; d < a.dout; ++d) {
-        float s = x0 * W[d * H + lane] + x1 * W[d * H + lane + 64];
+        float s = 0.f;
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
-        if (lane == 0) a.out[row * a.dout + d] = (s + a.params[a.off_b + d]) * a.out_mask[f * a.dout + d];
+        for (int e = 0; e < 8; ++e) s += x[e] * W[d * H + c * 8 + e];
+#pragma unroll
+        for (int m = 8; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+        if (c == 0 && ok) a.out[row * a.dout + d] = (s + a.params[a.off_b + d]) * a.out_mask[f * a.dout + d];
     }
 }
 
 template <typename T> __global__ __launch_bounds__(256) void k_dec_bwd(DecArgs a) {
-    __shared__ float red[2][DEC_SLAB_FLOATS];
-    const int k = threadIdx.x & 127, half = threadIdx.x >> 7;
+    __shared__ float red[16][DEC_SLAB_FLOATS];
+    const int c = threadIdx.x & 15, rg = threadIdx.x >> 4;
     const int64_t rows = (int64_t)a.B * a.n_out;
-    const int64_t per = (rows + gridDim.x - 1) / gridDim.x;
+    const int64_t per = ((rows + gridDim.x - 1) / gridDim.x + 15) / 16 * 16;
     const int64_t r_begin = (int64_t)blockIdx.x * per, r_end = min(rows, r_begin + per);
     const T* xl = reinterpret_cast<const T*>(a.xl);
     T* dxl = reinterpret_cast<T*>(a.dxl);
     const float* W = a.params + a.off_w;
-    float wk[8], accw[8], accb[8];
+    float accw[8][8], accb[8];
 #pragma unroll
-    for (int d = 0; d < 8; ++d) { wk[d] = d < a.dout ? W[d * H + k] : 0.f; accw[d] = 0.f; accb[d] = 0.f; }
-#pragma unroll 4
-    for (int64_t r = r_begin + half; r < r_end; r += 2) {
+    for (int d = 0; d < 8; ++d) { accb[d] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) accw[d][e] = 0.f; }
+    for (int64_t r = r_begin + rg; r < r_end; r += 16) {
         const int w = (int)(r / a.n_out), f = (int)(r % a.n_out);
-        const size_t idx = ((size_t)w * a.NN + a.node0 + f) * H + k;
-        const float x = to_f32(xl[idx]);
-        float dx = 0.f;
+        const size_t idx = act_idx(w, a.node0 + f, a.B) + c * 8;
+        float x[8], dx[8];
+        load8<T>(xl + idx, x);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dx[e] = 0.f;
 #pragma unroll
         for (int d = 0; d < 8; ++d) {
             if (d < a.dout) {
                 const float g = a.gout[r * a.dout + d] * a.out_mask[f * a.dout + d];
-                accw[d] += g * x; accb[d] += g; dx += g * wk[d];
+                accb[d] += g;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { accw[d][e] += g * x[e]; dx[e] += g * W[d * H + c * 8 + e]; }
             }
         }
-        dxl[idx] = from_f32<T>(dx);
+        store8<T>(dxl + idx, dx);
     }
 #pragma unroll
-    for (int d = 0; d < 8; ++d) { red[half][d * H + k] = accw[d]; if (k == 0) red[half][8 * H + d] = accb[d]; }
+    for (int d = 0; d < 8; ++d) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[rg][d * H + c * 8 + e] = accw[d][e];
+        if (c == 0) red[rg][8 * H + d] = accb[d];
+    }
     __syncthreads();
     float* slab = a.slabs + (size_t)blockIdx.x * DEC_SLAB_FLOATS;
-    if (half == 0) {
+    for (int i = threadIdx.x; i < DEC_SLAB_FLOATS; i += 256) {
+        float s2 = 0.f;
 #pragma unroll
-        for (int d = 0; d < 8; ++d) slab[d * H + k] = red[0][d * H + k] + red[1][d * H + k];
-        if (k < 8) slab[8 * H + k] = red[0][8 * H + k] + red[1][8 * H + k];
+        for (int r = 0; r < 16; ++r) s2 += red[r][i];
+        slab[i] = s2;
     }
 }
 
@@ -728,7 +928,9 @@ __global__ void k_mse(const float* out, const float* y, int64_t n, float* loss, 
 struct GradwArgs {
     const char* ws; size_t buf_off[BUF_COUNT];
     const void* x[MSHGNN_MAX_TYPES]; int64_t pitch[MSHGNN_MAX_TYPES]; int nodes[MSHGNN_MAX_TYPES]; int vb[MSHGNN_MAX_TYPES];
-    const int* items; const int* lanes; const uint8_t* signs; float* slabs; int B, n_lanes, n_parts;
+    const int* items; const int* lanes; const int* lane_order; const uint8_t* signs; float* slabs; int B, n_lanes, n_parts, n_pad;
+    int aligned;   // all raw-input rows 16-byte aligned with whole-chunk pitch
+    int dbg;   // timing ablations (MSHGNN_DBG_GW): 1 no global loads, 2 no LDS staging, 4 no MFMA phase, 8 no slab store
 };
 constexpr int GW_KW = 32;       // fp32: windows per staged chunk
 constexpr int GW_PITCH = 144;   // fp32: floats per LDS row (bank-conflict-free column reads)
@@ -739,7 +941,10 @@ __global__ __launch_bounds__(256) void k_gradw_f32(GradwArgs a) {
     __shared__ __attribute__((aligned(16))) float Qs[GW_KW * GW_PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wv >> 1, wc = wv & 1;
-    const int ln = blockIdx.x % a.n_lanes, part = blockIdx.x / a.n_lanes;
+    // blocks b and b+8 share an XCD (round-robin dispatch; speed only): lane_order puts the lanes that read the same
+    // dH / X rows on one XCD so they share its L2
+    const int ln = a.lane_order[blockIdx.x % a.n_pad], part = blockIdx.x / a.n_pad;
+    if (ln < 0) return;
     const int* lh = a.lanes + ln * LANE_INTS;
     const int it0 = lh[0], it1 = lh[1], bias_flag = lh[3];
     const int nchunks = (a.B + GW_KW - 1) / GW_KW;
@@ -763,9 +968,9 @@ __global__ __launch_bounds__(256) void k_gradw_f32(GradwArgs a) {
                 const int row = r0 + 8 * p, w = w0 + row;
                 pv[p] = f32x4{0, 0, 0, 0}; qv[p] = f32x4{0, 0, 0, 0};
                 if (w < a.B) {
-                    pv[p] = *reinterpret_cast<const f32x4*>(pb + (size_t)w * ps + po + c * 4);
+                    pv[p] = *reinterpret_cast<const f32x4*>(pb + act_idx(w, po, a.B) + c * 4);
                     if (qs >= 0) {
-                        qv[p] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const T*>(a.ws + a.buf_off[qbuf]) + (size_t)w * qs + qo + c * 4);
+                        qv[p] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const T*>(a.ws + a.buf_off[qbuf]) + act_idx(w, qo, a.B) + c * 4);
                     } else {
                         const int t = qbuf - BUF_IN;
                         const T* qq = reinterpret_cast<const T*>(a.x[t]) + ((size_t)w * a.nodes[t] + qo) * a.pitch[t] + qc0 + c * 4;
@@ -799,7 +1004,7 @@ __global__ __launch_bounds__(256) void k_gradw_f32(GradwArgs a) {
             }
         }
     }
-    float* slab = a.slabs + (size_t)blockIdx.x * SLAB_FLOATS;
+    float* slab = a.slabs + (size_t)(part * a.n_lanes + ln) * SLAB_FLOATS;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -847,12 +1052,35 @@ __global__ __launch_bounds__(256) void k_gradw_bf16(GradwArgs a) {
     __shared__ __attribute__((aligned(16))) __bf16 Qs[GWB_KW * GWB_PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wv >> 1, wc = wv & 1;
-    const int ln = blockIdx.x % a.n_lanes, part = blockIdx.x / a.n_lanes;
+    // blocks b and b+8 share an XCD (round-robin dispatch; speed only): lane_order puts the lanes that read the same
+    // dH / X rows on one XCD so they share its L2
+    const int ln = a.lane_order[blockIdx.x % a.n_pad], part = blockIdx.x / a.n_pad;
+    if (ln < 0) return;
     const int* lh = a.lanes + ln * LANE_INTS;
     const int it0 = lh[0], nit = lh[1] - lh[0], bias_flag = lh[3];
     const int nchunks = (a.B + GWB_KW - 1) / GWB_KW;
     const int ch0 = (int)((int64_t)part * nchunks / a.n_parts), ch1 = (int)((int64_t)(part + 1) * nchunks / a.n_parts);
-    const int nsteps = (ch1 - ch0) * nit;    // step s -> chunk ch0 + s / nit, item it0 + s % nit
+    const int nsteps = (ch1 - ch0) * nit;    // step s -> chunk ch0 + s / nit, item s % nit
+    const int c = tid & 15, r0 = tid >> 4;   // staging: 16 chunks of 8 bf16 per row, 16 rows per pass
+
+    // the lane's (<= GW_IPL = 2) items are resolved ONCE into per-thread base pointers: no dependent scalar loads
+    // inside the streaming loop
+    const T* pbase[GW_IPL]; const T* qbase[GW_IPL]; int64_t qstride[GW_IPL]; int qvalid[GW_IPL], qvb[GW_IPL]; u32x4 qsign[GW_IPL];
+#pragma unroll
+    for (int i = 0; i < GW_IPL; ++i) {
+        const int* im = a.items + (it0 + min(i, nit - 1)) * ITEM_INTS;
+        pbase[i] = reinterpret_cast<const T*>(a.ws + a.buf_off[im[0]]) + act_idx(0, im[2], a.B) + c * 8;
+        qsign[i] = u32x4{0, 0, 0, 0};
+        if (im[4] >= 0) {
+            qbase[i] = reinterpret_cast<const T*>(a.ws + a.buf_off[im[3]]) + act_idx(0, im[5], a.B) + c * 8;
+            qstride[i] = H; qvalid[i] = 8; qvb[i] = 16;
+        } else {
+            const int t = im[3] - BUF_IN;
+            qbase[i] = reinterpret_cast<const T*>(a.x[t]) + (size_t)im[5] * a.pitch[t] + im[6] + c * 8;
+            qstride[i] = (int64_t)a.nodes[t] * a.pitch[t]; qvalid[i] = im[7] - c * 8; qvb[i] = a.vb[t];
+            qsign[i] = sign_xor<T>(a.signs + im[8] + c * 8);
+        }
+    }
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -863,47 +1091,46 @@ __global__ __launch_bounds__(256) void k_gradw_bf16(GradwArgs a) {
     float bsum[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
-    const int c = tid & 15, r0 = tid >> 4;   // staging: 16 chunks of 8 bf16 per row, 16 rows per pass
-    u32x4 pv[4], qv[4];
-    auto fetch = [&](int s) {
+
+    struct Stage { u32x4 pv[4], qv[4]; };
+    auto fetch = [&](Stage& st, int s) {
         const int w0 = (ch0 + s / nit) * GWB_KW;
-        const int* im = a.items + (it0 + s % nit) * ITEM_INTS;
-        const T* pb = reinterpret_cast<const T*>(a.ws + a.buf_off[im[0]]);
-        const int ps = im[1], po = im[2], qbuf = im[3], qs = im[4], qo = im[5], qc0 = im[6], qn = im[7], so = im[8];
+        const int it = (nit == 2) ? (s & 1) : 0;
+        const T* pb = it ? pbase[1] : pbase[0];
+        const T* qb = it ? qbase[1] : qbase[0];
+        const int64_t qs = it ? qstride[1] : qstride[0];
+        const int qn = it ? qvalid[1] : qvalid[0], vb = it ? qvb[1] : qvb[0];
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            const int row = r0 + 16 * p, w = w0 + row;
-            pv[p] = u32x4{0, 0, 0, 0}; qv[p] = u32x4{0, 0, 0, 0};
-            if (w < a.B) {
-                pv[p] = *reinterpret_cast<const u32x4*>(pb + (size_t)w * ps + po + c * 8);
-                if (qs >= 0) {
-                    qv[p] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(a.ws + a.buf_off[qbuf]) + (size_t)w * qs + qo + c * 8);
-                } else {
-                    const int t = qbuf - BUF_IN;
-                    const T* qq = reinterpret_cast<const T*>(a.x[t]) + ((size_t)w * a.nodes[t] + qo) * a.pitch[t] + qc0 + c * 8;
-                    qv[p] = load_chunk<T>(qq, qn - c * 8, a.vb[t]) ^ sign_xor<T>(a.signs + so + c * 8);
-                }
+            const int w = w0 + r0 + 16 * p;
+            st.pv[p] = u32x4{0, 0, 0, 0}; st.qv[p] = u32x4{0, 0, 0, 0};
+            if (w < a.B && !(a.dbg & 1)) {
+                st.pv[p] = *reinterpret_cast<const u32x4*>(pb + (size_t)w * H);
+                if (a.aligned) { if (qn > 0) st.qv[p] = *reinterpret_cast<const u32x4*>(qb + (size_t)w * qs); }   // raw: a use here would serialise the loads
+                else st.qv[p] = load_chunk<T>(qb + (size_t)w * qs, qn, vb);
             }
         }
     };
-    if (nsteps > 0) fetch(0);
-    for (int s = 0; s < nsteps; ++s) {
+    auto consume = [&](const Stage& st, const u32x4 sx, const int qn) {
+        if (a.dbg & 2) { asm volatile("" :: "v"(st.pv[0][0]), "v"(st.qv[3][3])); return; }
         __syncthreads();   // previous MFMA phase finished reading Ps/Qs
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int row = r0 + 16 * p;
-            *reinterpret_cast<u32x4*>(&Ps[row * GWB_PITCH + c * 8]) = pv[p];
-            *reinterpret_cast<u32x4*>(&Qs[row * GWB_PITCH + c * 8]) = qv[p];
+            *reinterpret_cast<u32x4*>(&Ps[row * GWB_PITCH + c * 8]) = st.pv[p];
+            *reinterpret_cast<u32x4*>(&Qs[row * GWB_PITCH + c * 8]) = chunk_keep_first<T>(st.qv[p], qn) ^ sx;   // drop pad columns, symmetry sign mask of encoder inputs
             if (bias_flag) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    bsum[2 * e] += __builtin_bit_cast(float, pv[p][e] << 16);
-                    bsum[2 * e + 1] += __builtin_bit_cast(float, pv[p][e] & 0xffff0000u);
+                    bsum[2 * e] += __builtin_bit_cast(float, st.pv[p][e] << 16);
+                    bsum[2 * e + 1] += __builtin_bit_cast(float, st.pv[p][e] & 0xffff0000u);
                 }
             }
         }
         __syncthreads();
-        if (s + 1 < nsteps) fetch(s + 1);   // global loads of the next step fly under this step's MFMAs
+    };
+    auto mfmas = [&]() {
+        if (a.dbg & 4) return;
 #pragma unroll
         for (int ks = 0; ks < GWB_KW / 16; ++ks) {
             bf16x8 af[2], bq[2];
@@ -917,8 +1144,23 @@ __global__ __launch_bounds__(256) void k_gradw_bf16(GradwArgs a) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bq[j], acc[i][j], 0, 0, 0);
         }
+    };
+    // two register stages: the loads of steps s+1 and s+2 are in flight while step s runs its MFMAs
+    Stage sa, sb;
+    if (nsteps > 0) fetch(sa, 0);
+    if (nsteps > 1) fetch(sb, 1);
+    for (int s = 0; s < nsteps; s += 2) {
+        consume(sa, qsign[0], qvalid[0]);
+        if (s + 2 < nsteps) fetch(sa, s + 2);
+        mfmas();
+        if (s + 1 < nsteps) {
+            consume(sb, nit == 2 ? qsign[1] : qsign[0], nit == 2 ? qvalid[1] : qvalid[0]);
+            if (s + 3 < nsteps) fetch(sb, s + 3);
+            mfmas();
+        }
     }
-    float* slab = a.slabs + (size_t)blockIdx.x * SLAB_FLOATS;
+    float* slab = a.slabs + (size_t)(part * a.n_lanes + ln) * SLAB_FLOATS;
+    if (!(a.dbg & 8))
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1045,13 +1287,13 @@ extern "C" int mshgnn_plan_create(const mshgnn_desc* desc, mshgnn_plan** out) {
         (rc = up((void**)&p->d_biases, hp.biases.data(), hp.biases.size() * sizeof(BiasDesc))) != 0) {
         mshgnn_plan_destroy(p); return rc;
     }
-    const int lds = hp.NN * BLK_BYTES;
+    const int lds = hp.n_blk * hp.blk_bytes;
     if (hp.d.dtype == MSHGNN_F32) {
         if ((rc = set_lds_attr(k_layer_fwd<float>, lds)) || (rc = set_lds_attr(k_layer_bwd<float>, lds)) ||
-            (rc = set_lds_attr(k_enc_fwd<float>, ENC_MB * BLK_BYTES))) { mshgnn_plan_destroy(p); return rc; }
+            (rc = set_lds_attr(k_enc_fwd<float>, Prec<float>::ENC_MB * Prec<float>::BLK))) { mshgnn_plan_destroy(p); return rc; }
     } else {
         if ((rc = set_lds_attr(k_layer_fwd<__bf16>, lds)) || (rc = set_lds_attr(k_layer_bwd<__bf16>, lds)) ||
-            (rc = set_lds_attr(k_enc_fwd<__bf16>, ENC_MB * BLK_BYTES))) { mshgnn_plan_destroy(p); return rc; }
+            (rc = set_lds_attr(k_enc_fwd<__bf16>, Prec<__bf16>::ENC_MB * Prec<__bf16>::BLK))) { mshgnn_plan_destroy(p); return rc; }
     }
     *out = p;
     return MSHGNN_OK;
@@ -1138,19 +1380,21 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
     // 2. encoder
     {
         EncArgs a{};
-        a.n_types = hp.NT; a.B = B; a.NN = hp.NN; a.tiles = (B + ENC_MB * Prec<T>::ROWS - 1) / (ENC_MB * Prec<T>::ROWS);
+        a.n_types = hp.NT; a.B = B; a.NN = hp.NN; a.tiles = (B + Prec<T>::ENC_MB * Prec<T>::ROWS - 1) / (Prec<T>::ENC_MB * Prec<T>::ROWS);
         a.wg_prefix[0] = 0;
         for (int t = 0; t < hp.NT; ++t) {
             a.x[t] = x[t]; a.pitch[t] = x_pitch ? x_pitch[t] : d.type_width[t];
             if (a.pitch[t] < d.type_width[t]) return set_err(MSHGNN_EINVAL, "x_pitch smaller than the feature width");
             a.vb[t] = vec_bytes(x[t], a.pitch[t], (int)sizeof(T));
+            if (t == 0) a.aligned = 1;
+            if (a.vb[t] != 16 || a.pitch[t] % Prec<T>::EPC) a.aligned = 0;
             a.width[t] = d.type_width[t]; a.nodes[t] = d.type_nodes[t]; a.tbase[t] = hp.type_base[t]; a.nkc[t] = hp.enc_nkc[t];
             a.pack0[t] = hp.pack_enc_base[t]; a.bias_idx[t] = hp.bias_enc[t]; a.sign_off[t] = hp.sign_off[t];
             a.wg_prefix[t + 1] = a.wg_prefix[t] + d.type_nodes[t] * a.tiles;
         }
         a.wpack = ws + lay.wpack; a.bias = reinterpret_cast<const float*>(ws + lay.bias); a.signs = p->d_signs; a.x0 = ws + lay.x[0];
         ProfScope ps(p, hp.ks_enc, st);
-        hipLaunchKernelGGL(k_enc_fwd<T>, dim3(a.wg_prefix[hp.NT]), dim3(256), ENC_MB * BLK_BYTES, st, a);
+        hipLaunchKernelGGL(k_enc_fwd<T>, dim3(a.wg_prefix[hp.NT]), dim3(256), Prec<T>::ENC_MB * Prec<T>::BLK, st, a);
     }
     // 3. layers
     const int tiles = (B + Prec<T>::ROWS - 1) / Prec<T>::ROWS;
@@ -1159,8 +1403,9 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
         a.x_in = ws + lay.x[l]; a.x_out = ws + lay.x[l + 1]; a.maskbits = reinterpret_cast<unsigned*>(ws + lay.mask[l]);
         a.hb = ws + lay.hb[l]; a.t1 = ws + lay.t1[l]; a.wpack = ws + lay.wpack; a.bias = reinterpret_cast<const float*>(ws + lay.bias);
         a.prog = p->d_tables + hp.fwd_prog_off[l]; a.B = B; a.NN = hp.NN; a.n_mlp = std::max(1, hp.n_mlp);
+        { const char* e = getenv("MSHGNN_DBG"); a.dbg = e ? atoi(e) : 0; }
         ProfScope ps(p, hp.ks_layer_fwd0 + l, st);
-        hipLaunchKernelGGL(k_layer_fwd<T>, dim3(tiles), dim3(LAYER_THREADS), hp.NN * BLK_BYTES, st, a);
+        hipLaunchKernelGGL(k_layer_fwd<T>, dim3(tiles), dim3(LAYER_THREADS), hp.n_blk * Prec<T>::BLK, st, a);
     }
     // 4. decoder
     {
@@ -1169,7 +1414,7 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
         a.B = B; a.NN = hp.NN; a.node0 = hp.type_base[d.out_type]; a.n_out = d.type_nodes[d.out_type]; a.dout = d.out_channels;
         const int64_t rows = (int64_t)B * a.n_out;
         ProfScope ps(p, hp.ks_dec_fwd, st);
-        hipLaunchKernelGGL(k_dec_fwd<T>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_dec_fwd<T>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, a);
     }
     HIPCHK(hipGetLastError());
     return MSHGNN_OK;
@@ -1193,12 +1438,13 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
     const int tiles = (B + Prec<T>::ROWS - 1) / Prec<T>::ROWS;
     for (int l = hp.L - 1; l >= 0; --l) {
         LayerArgs a{};
-        a.x_in = ws + lay.dx[l + 1]; a.x_out = ws + lay.dx[l]; a.maskbits = reinterpret_cast<unsigned*>(ws + lay.mask[l]);
+        a.x_in = ws + lay.dx[l + 1]; a.x_out = ws + lay.dx[0]; a.maskbits = reinterpret_cast<unsigned*>(ws + lay.mask[l]);
         a.hb = ws + lay.hb[l]; a.t1 = ws + lay.t1[l]; a.dh = ws + lay.dh[l]; a.du = ws + lay.du[l]; a.x_act = ws + lay.x[0];
+        a.g_prev = (l + 2 <= hp.L) ? ws + lay.dx[l + 2] : nullptr; a.d_in = (l + 1 < hp.L) ? ws + lay.dd[l + 1] : nullptr; a.d_out = ws + lay.dd[l];
         a.wpack = ws + lay.wpack; a.bias = reinterpret_cast<const float*>(ws + lay.bias);
         a.prog = p->d_tables + hp.bwd_prog_off[l]; a.B = B; a.NN = hp.NN; a.n_mlp = std::max(1, hp.n_mlp);
         ProfScope ps(p, hp.ks_layer_bwd0 + (hp.L - 1 - l), st);
-        hipLaunchKernelGGL(k_layer_bwd<T>, dim3(tiles), dim3(LAYER_THREADS), hp.NN * BLK_BYTES, st, a);
+        hipLaunchKernelGGL(k_layer_bwd<T>, dim3(tiles), dim3(LAYER_THREADS), hp.n_blk * Prec<T>::BLK, st, a);
     }
     {
         GradwArgs a{};
@@ -1208,12 +1454,15 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
         for (int t = 0; t < hp.NT; ++t) {
             a.x[t] = x[t]; a.pitch[t] = x_pitch ? x_pitch[t] : d.type_width[t]; a.nodes[t] = d.type_nodes[t];
             a.vb[t] = vec_bytes(x[t], a.pitch[t], (int)sizeof(T));
+            if (t == 0) a.aligned = 1;
+            if (a.vb[t] != 16 || a.pitch[t] % Prec<T>::EPC) a.aligned = 0;
         }
-        a.items = p->d_tables + hp.item_off; a.lanes = p->d_tables + hp.lane_off;
+        a.items = p->d_tables + hp.item_off; a.lanes = p->d_tables + hp.lane_off; a.lane_order = p->d_tables + hp.lane_order_off; a.n_pad = hp.n_lanes_pad;
         a.signs = p->d_signs; a.slabs = reinterpret_cast<float*>(ws + lay.slabs); a.B = B; a.n_lanes = hp.n_lanes; a.n_parts = hp.n_parts;
+        { const char* e = getenv("MSHGNN_DBG_GW"); a.dbg = e ? atoi(e) : 0; }
         ProfScope ps(p, hp.ks_gradw, st);
-        if constexpr (sizeof(T) == 4) hipLaunchKernelGGL(k_gradw_f32, dim3(hp.n_wg_gradw), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(k_gradw_bf16, dim3(hp.n_wg_gradw), dim3(256), 0, st, a);
+        if constexpr (sizeof(T) == 4) hipLaunchKernelGGL(k_gradw_f32, dim3(hp.n_lanes_pad * hp.n_parts), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(k_gradw_bf16, dim3(hp.n_lanes_pad * hp.n_parts), dim3(256), 0, st, a);
     }
     {
         FinArgs a{p->d_tables + hp.fin_off, p->d_tables + hp.tgt_off, reinterpret_cast<const float*>(ws + lay.slabs),

@@ -25,7 +25,7 @@ namespace mshgnn {
 
 constexpr int H = 128;            // hidden width the kernels are built for
 constexpr int GMAX = 12;          // accumulator slots (dst nodes) a workgroup keeps live at once
-constexpr int BLK_BYTES = 8192;   // one LDS node block: ROWS windows x 128 features
+constexpr int TILE_ROWS = 16;      // windows per layer-kernel tile (one LDS node block = 16 x 128 elements)
 constexpr int MAX_L = 16;
 constexpr int LDS_LIMIT = 160 * 1024;
 constexpr int SLAB_FLOATS = H * H + H;   // one split-K partial: 128x128 matrix + 128 column sums
@@ -36,16 +36,21 @@ constexpr int GW_IPL = 2;                // items per weight-gradient lane (all 
 enum { OP_LOADW = 0, OP_MAC = 1 };
 enum { KIND_RELU = 0, KIND_MLP = 1 };
 enum { NK_DEAD = 0, NK_RELU = 1, NK_MLP = 2 };
-enum { GF_RESIDUAL = 1, GF_ENC_MASK = 2, GF_STORE_MASK = 4 };
+enum { GF_RESIDUAL = 1, GF_ENC_MASK = 2, GF_STORE_MASK = 4, GF_LDS_EPI = 8 };
+enum { NF_RES_IN = 1 };   // backward node flag: G_{l+2}[n] flows into G_{l+1}[n] through the residual
 
-// group header layout (ints)
-enum { GH_KIND = 0, GH_NSLOTS, GH_BIAS, GH_NENT, GH_W1, GH_W2, GH_B1, GH_B2, GH_FLAGS, GH_PAD0, GH_PAD1, GH_PAD2,
-       GH_NODES = 12, GH_MLPIDX = 12 + GMAX, GH_SIZE = 12 + 2 * GMAX };
-constexpr int ENT_INTS = 4;   // {op, slot, arg, reserved}
+// group header layout (ints); a group is followed by two WAVE PROGRAMS of WPROG_LEN ints (slot half 0, slot half 1).
+// A wave loads its program into two VGPRs once and interprets it with v_readlane (no memory latency in the MAC loop):
+//   [nseg, then per segment: pack, then per accumulator u (slot = 2u + half): count, src blocks...]
+enum { GH_KIND = 0, GH_NSLOTS, GH_BIAS, GH_NSEG, GH_W1, GH_W2, GH_B1, GH_B2, GH_FLAGS, GH_PAD0, GH_PAD1, GH_PAD2,
+       GH_NODES = 12, GH_MLPIDX = 12 + GMAX, GH_SCR = 12 + 2 * GMAX, GH_SIZE = 12 + 3 * GMAX };
+constexpr int WPROG_LEN = 128;
+// backward program header: [n_groups, n_mlp_live, w2pack, w1pack, has_delta, 0,0,0, node_kind[64], node_flags[64], mlp_nodes[GMAX]]
+enum { BH_NGROUPS = 0, BH_NMLP, BH_W2, BH_W1, BH_HAS_DELTA, BH_KIND = 8, BH_NFLAGS = 8 + 64, BH_MLPNODES = 8 + 128, BH_SIZE = 8 + 128 + GMAX };
 
 // buffer ids used by weight-gradient items
-enum { BUF_X = 0, BUF_DX = 17, BUF_DH = 34, BUF_HB = 50, BUF_T1 = 66, BUF_DU = 82, BUF_IN = 98, BUF_COUNT = 102 };
-constexpr int ITEM_INTS = 10;   // p_buf p_stride p_off q_buf q_stride q_off q_col0 q_ncols sign_off pad
+enum { BUF_X = 0, BUF_DX = 17, BUF_DH = 34, BUF_HB = 50, BUF_T1 = 66, BUF_DU = 82, BUF_IN = 98, BUF_COUNT = 102 };   // (dd: D_l deltas are not read by the weight-gradient kernel)
+constexpr int ITEM_INTS = 10;   // p_buf p_nodes*H p_node q_buf (q_nodes*H | -1: raw input) q_node q_col0 q_ncols sign_off pad
 constexpr int TGT_INTS = 8;     // lane_begin lane_end bias_flag pad..
 constexpr int LANE_INTS = 4;    // item_begin item_end target bias_flag
 constexpr int FIN_INTS = 8;     // dst_lo dst_hi rows cols dst_ld target kind pad
@@ -70,7 +75,10 @@ struct HostPlan {
     int type_base[MSHGNN_MAX_TYPES + 1]{};
     int node_type[64]{};
     int n_mlp = 0;
-    int rows = 16;                 // windows per tile
+    int n_blk = 0;                 // LDS node blocks of the layer kernels (NN + scratch blocks)
+    bool mlp_scratch = false;      // base_transform uses dedicated scratch blocks (else its own node blocks, and runs last)
+    int rows = TILE_ROWS;          // windows per tile
+    int blk_bytes = 8192;          // one LDS node block
     int gmax = GMAX;               // destination slots per group (12 fp32, 8 bf16: accumulator registers)
     int esize = 4;                 // bytes per stored element
     bool live[MAX_L][MSHGNN_MAX_TYPES]{};     // layer output of type t reaches the decoder
@@ -89,6 +97,7 @@ struct HostPlan {
     std::vector<int32_t> tables;                  // everything below lives here (device copy = same layout)
     int fwd_prog_off[MAX_L]{}, bwd_prog_off[MAX_L]{};
     int item_off = 0, n_items = 0, tgt_off = 0, n_targets = 0, lane_off = 0, n_lanes = 0, n_parts = 1, n_wg_gradw = 0;
+    int lane_order_off = 0, n_lanes_pad = 0;
     int fin_off = 0, n_fin = 0;
     int enc_tile_mb = 4;
     int n_slabs = 0;
@@ -137,11 +146,12 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
         for (int i = 0; i < d.type_nodes[t]; ++i) p.node_type[p.type_base[t] + i] = t;
     }
     p.NN = p.type_base[NT];
-    if ((int64_t)p.NN * BLK_BYTES > LDS_LIMIT)
-        return fail(p, "topology has too many nodes per window for the LDS-resident layer kernel (max 20)");
-    p.rows = d.dtype == MSHGNN_F32 ? 16 : 32;
-    p.gmax = d.dtype == MSHGNN_F32 ? GMAX : 8;
     p.esize = d.dtype == MSHGNN_F32 ? 4 : 2;
+    p.blk_bytes = TILE_ROWS * H * p.esize;
+    if ((int64_t)p.NN * p.blk_bytes > LDS_LIMIT)
+        return fail(p, "topology has too many nodes per window for the LDS-resident layer kernel (max 20 fp32 / 40 bf16)");
+    p.rows = TILE_ROWS;
+    p.gmax = d.dtype == MSHGNN_F32 ? GMAX : 8;   // bf16: 4 accumulators per wave keep the layer kernels at 128 VGPRs (2 workgroups / CU)
     p.n_mlp = has_mlp ? d.type_nodes[d.mlp_type] : 0;
     if (p.n_mlp > p.gmax) return fail(p, "base_transform type has too many nodes for one accumulator group");
 
@@ -251,95 +261,142 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
     // ---- programs -----------------------------------------------------------------------------------
     std::vector<int32_t>& T = p.tables;
     T.clear();
-    auto push_entry = [&](int op, int slot, int arg) { T.push_back(op); T.push_back(slot); T.push_back(arg); T.push_back(0); };
-    std::vector<int> order;
-    for (int t = 0; t < NT; ++t) if (!(has_mlp && t == d.mlp_type)) order.push_back(t);
-    if (has_mlp) order.push_back(d.mlp_type);
     double exec_fwd = 0, exec_bwd = 0, alg_fwd = 0, alg_bwd = 0;
     std::vector<double> lf_alg(L, 0.0), lf_exec(L, 0.0), lb_alg(L, 0.0), lb_exec(L, 0.0);
     double gw_alg = 0, gw_exec = 0;
     const double NL = 2.0 * H * H;   // FLOPs of one node-linear (one window)
+    p.mlp_scratch = has_mlp && (int64_t)(p.NN + p.n_mlp) * p.blk_bytes <= LDS_LIMIT;
+    p.n_blk = p.NN + (p.mlp_scratch ? p.n_mlp : 0);
+
+    struct Seg { int pack; std::vector<std::pair<int, int>> macs; };   // (slot, src block)
+    bool prog_overflow = false;
+    auto emit_segments = [&](const std::vector<Seg>& segs) {
+        const int hs = p.gmax / 2;
+        for (int half = 0; half < 2; ++half) {
+            std::vector<int> w; w.push_back((int)segs.size());
+            for (const Seg& sg : segs) {
+                w.push_back(sg.pack);
+                for (int u = 0; u < hs; ++u) {
+                    const int slot = 2 * u + half;
+                    const size_t pos = w.size(); w.push_back(0);
+                    for (auto& m : sg.macs) if (m.first == slot) { w.push_back(m.second); w[pos]++; }
+                }
+            }
+            if ((int)w.size() > WPROG_LEN) prog_overflow = true;
+            w.resize(WPROG_LEN, 0);
+            for (int v : w) T.push_back(v);
+        }
+    };
+    struct GroupDef { int type, c0, ns; bool mlp; };
 
     for (int l = 0; l < L; ++l) {
         const double ef0 = exec_fwd, af0 = alg_fwd, eb0 = exec_bwd, ab0 = alg_bwd;
         // ---------- forward program ----------
-        p.fwd_prog_off[l] = (int)T.size();
-        const int ng_pos = (int)T.size(); T.push_back(0);
-        int ng = 0;
-        for (int t : order) {
+        // group order: relu groups by size (largest last: its epilogue goes through LDS with coalesced stores);
+        // the base_transform group second-to-last when it has scratch blocks, else last (it overwrites its own blocks)
+        std::vector<GroupDef> relu_g, mlp_g;
+        for (int t = 0; t < NT; ++t) {
             if (!p.live[l][t]) continue;
             const bool mlp = has_mlp && t == d.mlp_type;
-            for (int c0 = 0; c0 < d.type_nodes[t]; c0 += p.gmax) {
-                const int ns = std::min(p.gmax, d.type_nodes[t] - c0);
-                const int gh = (int)T.size(); T.resize(T.size() + GH_SIZE, 0);
-                T[gh + GH_KIND] = mlp ? KIND_MLP : KIND_RELU; T[gh + GH_NSLOTS] = ns;
-                T[gh + GH_BIAS] = p.bias_layer[l * NT + t];
-                T[gh + GH_FLAGS] = (residual ? GF_RESIDUAL : 0) | GF_STORE_MASK;
-                if (mlp) { T[gh + GH_W1] = p.pack_mlp[0][0]; T[gh + GH_W2] = p.pack_mlp[0][1]; T[gh + GH_B1] = p.bias_mlp[0]; T[gh + GH_B2] = p.bias_mlp[1]; }
-                for (int u = 0; u < ns; ++u) { T[gh + GH_NODES + u] = p.type_base[t] + c0 + u; T[gh + GH_MLPIDX + u] = c0 + u; }
-                int nent = 0;
-                push_entry(OP_LOADW, 0, p.pack_root[0][l * NT + t]); ++nent;
-                for (int u = 0; u < ns; ++u) { push_entry(OP_MAC, u, p.type_base[t] + c0 + u); ++nent; exec_fwd += NL; alg_fwd += NL; }
-                for (int r = 0; r < NR; ++r) {
-                    if (p.rel_dst[r] != t) continue;
-                    bool loaded = false; std::vector<bool> hit(ns, false);
-                    for (int e = p.rel_edge_off[r]; e < p.rel_edge_off[r + 1]; ++e) {
-                        const int j = p.edges[2 * e], i = p.edges[2 * e + 1];
-                        if (i < c0 || i >= c0 + ns) continue;
-                        if (!loaded) { push_entry(OP_LOADW, 0, p.pack_rel[0][l * NR + r]); ++nent; loaded = true; }
-                        push_entry(OP_MAC, i - c0, p.type_base[p.rel_src[r]] + j); ++nent; exec_fwd += NL;
-                        if (!hit[i - c0]) { hit[i - c0] = true; alg_fwd += NL; }
-                    }
-                }
-                if (mlp) { exec_fwd += 2 * NL * ns; alg_fwd += 2 * NL * ns; }
-                T[gh + GH_NENT] = nent; ++ng;
-            }
+            for (int c0 = 0; c0 < d.type_nodes[t]; c0 += p.gmax)
+                (mlp ? mlp_g : relu_g).push_back({t, c0, std::min(p.gmax, d.type_nodes[t] - c0), mlp});
         }
-        T[ng_pos] = ng;
+        std::stable_sort(relu_g.begin(), relu_g.end(), [](const GroupDef& a, const GroupDef& b) { return a.ns < b.ns; });
+        std::vector<GroupDef> fgroups;
+        if (p.mlp_scratch || mlp_g.empty()) {
+            for (size_t i = 0; i + 1 < relu_g.size(); ++i) fgroups.push_back(relu_g[i]);
+            for (auto& g : mlp_g) fgroups.push_back(g);
+            if (!relu_g.empty()) fgroups.push_back(relu_g.back());
+        } else {
+            fgroups = relu_g; for (auto& g : mlp_g) fgroups.push_back(g);
+        }
+        p.fwd_prog_off[l] = (int)T.size();
+        T.push_back((int)fgroups.size());
+        for (size_t gi = 0; gi < fgroups.size(); ++gi) {
+            const GroupDef& G = fgroups[gi];
+            const int t = G.type, c0 = G.c0, ns = G.ns;
+            const int gh = (int)T.size(); T.resize(T.size() + GH_SIZE, 0);
+            T[gh + GH_KIND] = G.mlp ? KIND_MLP : KIND_RELU; T[gh + GH_NSLOTS] = ns;
+            T[gh + GH_BIAS] = p.bias_layer[l * NT + t];
+            const bool lds_epi = !G.mlp && gi + 1 == fgroups.size();
+            T[gh + GH_FLAGS] = (residual ? GF_RESIDUAL : 0) | GF_STORE_MASK | (lds_epi ? GF_LDS_EPI : 0);
+            if (G.mlp) { T[gh + GH_W1] = p.pack_mlp[0][0]; T[gh + GH_W2] = p.pack_mlp[0][1]; T[gh + GH_B1] = p.bias_mlp[0]; T[gh + GH_B2] = p.bias_mlp[1]; }
+            for (int u = 0; u < ns; ++u) {
+                T[gh + GH_NODES + u] = p.type_base[t] + c0 + u; T[gh + GH_MLPIDX + u] = c0 + u;
+                T[gh + GH_SCR + u] = (G.mlp && p.mlp_scratch) ? p.NN + c0 + u : p.type_base[t] + c0 + u;
+            }
+            std::vector<Seg> segs;
+            Seg root; root.pack = p.pack_root[0][l * NT + t];
+            for (int u = 0; u < ns; ++u) { root.macs.push_back({u, p.type_base[t] + c0 + u}); exec_fwd += NL; alg_fwd += NL; }
+            segs.push_back(root);
+            for (int r = 0; r < NR; ++r) {
+                if (p.rel_dst[r] != t) continue;
+                Seg sg; sg.pack = p.pack_rel[0][l * NR + r];
+                std::vector<bool> hit(ns, false);
+                for (int e = p.rel_edge_off[r]; e < p.rel_edge_off[r + 1]; ++e) {
+                    const int j = p.edges[2 * e], i = p.edges[2 * e + 1];
+                    if (i < c0 || i >= c0 + ns) continue;
+                    sg.macs.push_back({i - c0, p.type_base[p.rel_src[r]] + j}); exec_fwd += NL;
+                    if (!hit[i - c0]) { hit[i - c0] = true; alg_fwd += NL; }
+                }
+                if (!sg.macs.empty()) segs.push_back(sg);
+            }
+            if (G.mlp) { exec_fwd += 2 * NL * ns; alg_fwd += 2 * NL * ns; }
+            T[gh + GH_NSEG] = (int)segs.size();
+            emit_segments(segs);
+        }
 
         // ---------- backward program ----------
         p.bwd_prog_off[l] = (int)T.size();
-        // header: [n_groups, n_mlp_live, w2pack, w1pack, node_kind[NN].., mlp_nodes[GMAX]]
-        const int bh = (int)T.size(); T.resize(T.size() + 4 + 64 + GMAX, 0);
+        const int bh = (int)T.size(); T.resize(T.size() + BH_SIZE, 0);
         const bool mlp_live = has_mlp && p.live[l][d.mlp_type];
-        T[bh + 1] = mlp_live ? p.n_mlp : 0;
-        if (mlp_live) { T[bh + 2] = p.pack_mlp[1][1]; T[bh + 3] = p.pack_mlp[1][0]; }
+        T[bh + BH_NMLP] = mlp_live ? p.n_mlp : 0;
+        if (mlp_live) { T[bh + BH_W2] = p.pack_mlp[1][1]; T[bh + BH_W1] = p.pack_mlp[1][0]; }
+        T[bh + BH_HAS_DELTA] = (l < L - 1) ? 1 : 0;
         for (int n = 0; n < p.NN; ++n) {
             const int t = p.node_type[n];
-            T[bh + 4 + n] = !p.live[l][t] ? NK_DEAD : ((has_mlp && t == d.mlp_type) ? NK_MLP : NK_RELU);
+            T[bh + BH_KIND + n] = !p.live[l][t] ? NK_DEAD : ((has_mlp && t == d.mlp_type) ? NK_MLP : NK_RELU);
+            T[bh + BH_NFLAGS + n] = (residual && l + 1 < L && p.live[l + 1][t]) ? NF_RES_IN : 0;
         }
-        if (mlp_live) { for (int u = 0; u < p.n_mlp; ++u) T[bh + 4 + 64 + u] = p.type_base[d.mlp_type] + u; exec_bwd += 2 * NL * p.n_mlp; alg_bwd += 2 * NL * p.n_mlp; }
-        int ngb = 0;
+        if (mlp_live) { for (int u = 0; u < p.n_mlp; ++u) T[bh + BH_MLPNODES + u] = p.type_base[d.mlp_type] + u; exec_bwd += 2 * NL * p.n_mlp; alg_bwd += 2 * NL * p.n_mlp; }
+        std::vector<GroupDef> bgroups;
         for (int t = 0; t < NT; ++t) {
             if (!p.need_dx[l][t]) continue;
-            for (int c0 = 0; c0 < d.type_nodes[t]; c0 += p.gmax) {
-                const int ns = std::min(p.gmax, d.type_nodes[t] - c0);
-                const int gh = (int)T.size(); T.resize(T.size() + GH_SIZE, 0);
-                T[gh + GH_KIND] = KIND_RELU; T[gh + GH_NSLOTS] = ns; T[gh + GH_BIAS] = -1;
-                T[gh + GH_FLAGS] = ((residual && p.live[l][t]) ? GF_RESIDUAL : 0) | (l == 0 ? GF_ENC_MASK : 0);
-                for (int u = 0; u < ns; ++u) T[gh + GH_NODES + u] = p.type_base[t] + c0 + u;
-                int nent = 0;
-                if (p.live[l][t]) {
-                    push_entry(OP_LOADW, 0, p.pack_root[1][l * NT + t]); ++nent;
-                    for (int u = 0; u < ns; ++u) { push_entry(OP_MAC, u, p.type_base[t] + c0 + u); ++nent; exec_bwd += NL; alg_bwd += NL; }
-                }
-                for (int r = 0; r < NR; ++r) {
-                    if (p.rel_src[r] != t || !p.live[l][p.rel_dst[r]]) continue;
-                    bool loaded = false;
-                    std::vector<bool> hit(ns * 64, false);
-                    for (int e = p.rel_edge_off[r]; e < p.rel_edge_off[r + 1]; ++e) {
-                        const int j = p.edges[2 * e], i = p.edges[2 * e + 1];
-                        if (j < c0 || j >= c0 + ns) continue;
-                        if (!loaded) { push_entry(OP_LOADW, 0, p.pack_rel[1][l * NR + r]); ++nent; loaded = true; }
-                        push_entry(OP_MAC, j - c0, p.type_base[p.rel_dst[r]] + i); ++nent; exec_bwd += NL;
-                    }
-                }
-                T[gh + GH_NENT] = nent; ++ngb;
-            }
+            for (int c0 = 0; c0 < d.type_nodes[t]; c0 += p.gmax) bgroups.push_back({t, c0, std::min(p.gmax, d.type_nodes[t] - c0), false});
         }
-        T[bh + 0] = ngb;
+        std::stable_sort(bgroups.begin(), bgroups.end(), [](const GroupDef& a, const GroupDef& b) { return a.ns < b.ns; });
+        for (size_t gi = 0; gi < bgroups.size(); ++gi) {
+            const GroupDef& G = bgroups[gi];
+            const int t = G.type, c0 = G.c0, ns = G.ns;
+            const int gh = (int)T.size(); T.resize(T.size() + GH_SIZE, 0);
+            T[gh + GH_KIND] = KIND_RELU; T[gh + GH_NSLOTS] = ns; T[gh + GH_BIAS] = -1;
+            // at layer 0 the kernel finishes dY_enc = relu'(X_0) . (G_1 + D_0) itself: GF_RESIDUAL = add G_1
+            T[gh + GH_FLAGS] = ((residual && p.live[l][t]) ? GF_RESIDUAL : 0) | (l == 0 ? GF_ENC_MASK : 0) |
+                               (gi + 1 == bgroups.size() ? GF_LDS_EPI : 0);
+            for (int u = 0; u < ns; ++u) T[gh + GH_NODES + u] = p.type_base[t] + c0 + u;
+            std::vector<Seg> segs;
+            if (p.live[l][t]) {
+                Seg root; root.pack = p.pack_root[1][l * NT + t];
+                for (int u = 0; u < ns; ++u) { root.macs.push_back({u, p.type_base[t] + c0 + u}); exec_bwd += NL; alg_bwd += NL; }
+                segs.push_back(root);
+            }
+            for (int r = 0; r < NR; ++r) {
+                if (p.rel_src[r] != t || !p.live[l][p.rel_dst[r]]) continue;
+                Seg sg; sg.pack = p.pack_rel[1][l * NR + r];
+                for (int e = p.rel_edge_off[r]; e < p.rel_edge_off[r + 1]; ++e) {
+                    const int j = p.edges[2 * e], i = p.edges[2 * e + 1];
+                    if (j < c0 || j >= c0 + ns) continue;
+                    sg.macs.push_back({j - c0, p.type_base[p.rel_dst[r]] + i}); exec_bwd += NL;
+                }
+                if (!sg.macs.empty()) segs.push_back(sg);
+            }
+            T[gh + GH_NSEG] = (int)segs.size();
+            emit_segments(segs);
+        }
+        T[bh + BH_NGROUPS] = (int)bgroups.size();
         lf_alg[l] = alg_fwd - af0; lf_exec[l] = exec_fwd - ef0; lb_alg[l] = alg_bwd - ab0; lb_exec[l] = exec_bwd - eb0;
     }
+    if (prog_overflow) return fail(p, "a destination group's MAC program exceeds 128 entries (too many edges per node type for this build)");
     // algorithmic dX work: one node-linear per (relation, src node with >=1 out-edge into a live dst) -- count below
     for (int l = 0; l < L; ++l)
         for (int r = 0; r < NR; ++r) {
@@ -353,9 +410,14 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
     // ---- weight-gradient targets / items / finalize ops -----------------------------------------------
     struct Tgt { std::vector<int> items; int bias_flag; };
     std::vector<std::vector<int32_t>> items;   // each ITEM_INTS
+    std::vector<int> item_cluster;             // L2-sharing cluster of each item (same destination-node quarter / layer)
     std::vector<Tgt> tgts;
     auto add_item = [&](int pb, int ps, int po, int qb, int qs, int qo, int qc0, int qn, int so) {
-        items.push_back({pb, ps, po, qb, qs, qo, qc0, qn, so, 0}); return (int)items.size() - 1; };
+        items.push_back({pb, ps, po, qb, qs, qo, qc0, qn, so, 0});
+        // cluster key: which rows the item's P operand streams (buffer, node quarter): items with the same P share an XCD
+        const int pnode = po, ptype_nodes = std::max(1, ps / H);
+        item_cluster.push_back(pb * 4 + (pnode * 4) / ptype_nodes % 4);
+        return (int)items.size() - 1; };
     const int SN = p.NN * H, SM = std::max(1, p.n_mlp) * H;
     std::vector<int> tgt_root((size_t)L * NT, -1), tgt_rel((size_t)L * NR, -1);
     int tgt_mlp[2] = {-1, -1};
@@ -365,7 +427,7 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
             Tgt g; g.bias_flag = 1;
             for (int i = 0; i < d.type_nodes[t]; ++i) {
                 const int n = p.type_base[t] + i;
-                g.items.push_back(add_item(BUF_DH + l, SN, n * H, BUF_X + l, SN, n * H, 0, H, -1));
+                g.items.push_back(add_item(BUF_DH + l, SN, n, BUF_X + l, SN, n, 0, H, -1));
                 exec_bwd += NL; alg_bwd += NL;
             }
             tgt_root[l * NT + t] = (int)tgts.size(); tgts.push_back(g);
@@ -376,8 +438,8 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
             std::vector<bool> hit(d.type_nodes[p.rel_dst[r]], false);
             for (int e = p.rel_edge_off[r]; e < p.rel_edge_off[r + 1]; ++e) {
                 const int j = p.edges[2 * e], i = p.edges[2 * e + 1];
-                g.items.push_back(add_item(BUF_DH + l, SN, (p.type_base[p.rel_dst[r]] + i) * H,
-                                           BUF_X + l, SN, (p.type_base[p.rel_src[r]] + j) * H, 0, H, -1));
+                g.items.push_back(add_item(BUF_DH + l, SN, p.type_base[p.rel_dst[r]] + i,
+                                           BUF_X + l, SN, p.type_base[p.rel_src[r]] + j, 0, H, -1));
                 exec_bwd += NL; if (!hit[i]) { hit[i] = true; alg_bwd += NL; }
             }
             tgt_rel[l * NR + r] = (int)tgts.size(); tgts.push_back(g);
@@ -388,8 +450,8 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
         for (int l = 0; l < L; ++l) {
             if (!p.live[l][d.mlp_type]) continue;
             for (int u = 0; u < p.n_mlp; ++u) {
-                g1.items.push_back(add_item(BUF_DU + l, SM, u * H, BUF_HB + l, SM, u * H, 0, H, -1));
-                g2.items.push_back(add_item(BUF_DX + l + 1, SN, (p.type_base[d.mlp_type] + u) * H, BUF_T1 + l, SM, u * H, 0, H, -1));
+                g1.items.push_back(add_item(BUF_DU + l, SM, u, BUF_HB + l, SM, u, 0, H, -1));
+                g2.items.push_back(add_item(BUF_DX + l + 1, SN, p.type_base[d.mlp_type] + u, BUF_T1 + l, SM, u, 0, H, -1));
                 exec_bwd += 2 * NL; alg_bwd += 2 * NL;
             }
         }
@@ -403,7 +465,7 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
             Tgt g; g.bias_flag = (kc == 0);
             const int nc = std::min(H, F - kc * H);
             for (int i = 0; i < d.type_nodes[t]; ++i) {
-                g.items.push_back(add_item(BUF_DX + 0, SN, (p.type_base[t] + i) * H, BUF_IN + t, -1, i, kc * H, nc,
+                g.items.push_back(add_item(BUF_DX + 0, SN, p.type_base[t] + i, BUF_IN + t, -1, i, kc * H, nc,
                                            p.sign_off[t] + i * p.enc_nkc[t] * H + kc * H));
                 exec_bwd += NL; alg_bwd += 2.0 * H * nc;
             }
@@ -437,6 +499,28 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
     }
     p.n_lanes = (int)lanes.size();
     p.n_parts = std::max(1, std::min(16, (int)std::lround(512.0 / std::max(1, p.n_lanes))));
+    // XCD placement: cluster -> least-loaded XCD queue (largest clusters first); block b runs queue[b % 8][b / 8]
+    std::vector<int> lane_cluster(p.n_lanes), flat_item_cluster;
+    for (size_t g = 0; g < tgts.size(); ++g) for (int it : tgts[g].items) flat_item_cluster.push_back(item_cluster[it]);
+    for (int ln = 0; ln < p.n_lanes; ++ln) lane_cluster[ln] = flat_item_cluster[lanes[ln][0]];
+    std::vector<int> cl_ids = lane_cluster; std::sort(cl_ids.begin(), cl_ids.end()); cl_ids.erase(std::unique(cl_ids.begin(), cl_ids.end()), cl_ids.end());
+    std::vector<std::pair<int, int>> cl_size;   // (-size, id)
+    for (int c : cl_ids) cl_size.push_back({-(int)std::count(lane_cluster.begin(), lane_cluster.end(), c), c});
+    std::sort(cl_size.begin(), cl_size.end());
+    std::vector<std::vector<int>> xq(8);
+    for (auto& cs : cl_size) {
+        int best = 0; for (int x = 1; x < 8; ++x) if (xq[x].size() < xq[best].size()) best = x;
+        for (int ln = 0; ln < p.n_lanes; ++ln) if (lane_cluster[ln] == cs.second) xq[best].push_back(ln);
+    }
+    size_t qmax = 0; for (auto& q : xq) qmax = std::max(qmax, q.size());
+    // rebalance: move lanes from the longest queue to the shortest while it shortens the maximum
+    for (;;) {
+        int lo = 0, hi = 0; for (int x = 1; x < 8; ++x) { if (xq[x].size() < xq[lo].size()) lo = x; if (xq[x].size() > xq[hi].size()) hi = x; }
+        if (xq[hi].size() <= xq[lo].size() + 1) break;
+        xq[lo].push_back(xq[hi].back()); xq[hi].pop_back();
+    }
+    qmax = 0; for (auto& q : xq) qmax = std::max(qmax, q.size());
+    p.n_lanes_pad = (int)qmax * 8;
     p.n_wg_gradw = p.n_lanes * p.n_parts;
     p.tgt_off = (int)T.size(); p.n_targets = (int)tgts.size();
     for (size_t g = 0; g < tgts.size(); ++g) {
@@ -445,6 +529,8 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
     }
     p.lane_off = (int)T.size();
     for (auto& ln : lanes) for (int k = 0; k < LANE_INTS; ++k) T.push_back(ln[k]);
+    p.lane_order_off = (int)T.size();
+    for (int k = 0; k < (int)qmax; ++k) for (int x = 0; x < 8; ++x) T.push_back(k < (int)xq[x].size() ? xq[x][k] : -1);
     p.n_slabs = p.n_wg_gradw;
 
     // finalize ops: every parameter is written exactly once
@@ -479,7 +565,7 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
     add_fin(d.off_dec_b, 1, d.out_channels, d.out_channels, -2, FIN_DEC_B);
 
     // ---- info ---------------------------------------------------------------------------------------
-    p.info.rows_per_tile = p.rows; p.info.total_nodes = p.NN; p.info.lds_bytes = (int64_t)p.NN * BLK_BYTES;
+    p.info.rows_per_tile = p.rows; p.info.total_nodes = p.NN; p.info.lds_bytes = (int64_t)p.n_blk * p.blk_bytes;
     p.info.flops_fwd = alg_fwd; p.info.flops_bwd = alg_bwd; p.info.flops_exec_fwd = exec_fwd; p.info.flops_exec_bwd = exec_bwd;
     double bytes = 0; for (int t = 0; t < NT; ++t) bytes += (double)d.type_nodes[t] * d.type_width[t] * p.esize;
     p.info.bytes_in = bytes; p.info.n_gradw_workgroups = p.n_wg_gradw;
@@ -526,7 +612,7 @@ inline void layout_workspace(const HostPlan& p, int64_t B, int training, mshgnn_
     for (int l = 0; l < p.L; ++l) { o->mask[l] = take((size_t)B * p.NN * 4 * 4); o->hb[l] = take(mlp); o->t1[l] = take(mlp); }
     if (training) {
         for (int l = 0; l <= p.L; ++l) o->dx[l] = take(act);
-        for (int l = 0; l < p.L; ++l) { o->dh[l] = take(act); o->du[l] = take(mlp); }
+        for (int l = 0; l < p.L; ++l) { o->dh[l] = take(act); o->du[l] = take(mlp); o->dd[l] = take(act); }
         o->slabs = take((size_t)p.n_slabs * SLAB_FLOATS * 4);
         o->dec_slabs = take((size_t)NWG_DEC * DEC_SLAB_FLOATS * 4);
     }

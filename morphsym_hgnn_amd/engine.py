@@ -49,7 +49,7 @@ class MshgnnInfo(C.Structure):
 
 class MshgnnWsLayout(C.Structure):
     _fields_ = [
-        ("total", C.c_size_t), ("x", C.c_size_t * 17), ("dx", C.c_size_t * 17), ("dh", C.c_size_t * 16),
+        ("total", C.c_size_t), ("x", C.c_size_t * 17), ("dx", C.c_size_t * 17), ("dh", C.c_size_t * 16), ("dd", C.c_size_t * 16),
         ("mask", C.c_size_t * 16), ("hb", C.c_size_t * 16), ("t1", C.c_size_t * 16), ("du", C.c_size_t * 16),
         ("wpack", C.c_size_t), ("bias", C.c_size_t), ("dec_slabs", C.c_size_t), ("slabs", C.c_size_t), ("loss", C.c_size_t),
     ]
@@ -259,20 +259,40 @@ class Engine:
             self._ws[key] = torch.empty(lay.total, dtype=torch.uint8, device=self.device)
         return self._ws[key]
 
-    def cast_inputs(self, x_dict: Dict[str, torch.Tensor]) -> List[torch.Tensor]:
-        """Reference-convention inputs ([B*n_t, F_t], any float dtype) -> plan-dtype device tensors."""
-        return [x_dict[t].to(device=self.device, dtype=self.torch_dtype).contiguous() for t in self.types]
+    def padded_width(self, t: str) -> int:
+        """Row pitch (elements) of input type t in engine layout: F_t rounded up so every row starts 16-byte aligned."""
+        q = 4 if self.dtype == "f32" else 8
+        return (self.spec.widths[t] + q - 1) // q * q
+
+    def cast_inputs(self, x_dict: Dict[str, torch.Tensor], pad: bool = True) -> List[torch.Tensor]:
+        """Reference-convention inputs ([B*n_t, F_t], any float dtype) -> plan-dtype device tensors.  The cast writes
+        rows at a 16-byte-aligned pitch (450 -> 456 bf16 elements for A1 joints), so the kernels stream them with
+        16-byte loads; the pad columns are never read as data."""
+        out = []
+        for t in self.types:
+            x = x_dict[t]
+            F = self.spec.widths[t]
+            P = self.padded_width(t) if pad else F
+            if P == F:
+                out.append(x.to(device=self.device, dtype=self.torch_dtype).contiguous())
+            else:
+                buf = torch.zeros(x.shape[0], P, dtype=self.torch_dtype, device=self.device)
+                buf[:, :F] = x.to(device=self.device)
+                out.append(buf)
+        return out
 
     def _xptrs(self, xs: Sequence[torch.Tensor], B: int):
         ptrs = (C.c_void_p * len(xs))()
+        pitch = (C.c_int64 * len(xs))()
         for i, (t, x) in enumerate(zip(self.types, xs)):
             if x.dtype != self.torch_dtype or not x.is_cuda or not x.is_contiguous():
                 raise ValueError(f"input '{t}' must be a contiguous {self.torch_dtype} device tensor")
-            if x.numel() != B * self.spec.num_nodes[t] * self.spec.widths[t]:
-                raise ValueError(f"input '{t}' has {x.numel()} elements, expected "
-                                 f"{B}*{self.spec.num_nodes[t]}*{self.spec.widths[t]}")
+            rows = B * self.spec.num_nodes[t]
+            if x.numel() % rows or x.numel() // rows < self.spec.widths[t]:
+                raise ValueError(f"input '{t}' has {x.numel()} elements, expected {rows} rows of >= {self.spec.widths[t]}")
             ptrs[i] = x.data_ptr()
-        return ptrs
+            pitch[i] = x.numel() // rows
+        return ptrs, pitch
 
     def _check_flat(self, flat: torch.Tensor, name: str):
         if flat.dtype != torch.float32 or not flat.is_cuda or not flat.is_contiguous() or flat.numel() != self.spec.flat_size():
@@ -282,21 +302,21 @@ class Engine:
     def forward(self, xs: Sequence[torch.Tensor], params_flat: torch.Tensor, B: int, training: bool = True,
                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
         self._check_flat(params_flat, "params_flat")
-        ptrs = self._xptrs(xs, B)
+        ptrs, pitch = self._xptrs(xs, B)
         if out is None:
             out = torch.empty(B * self.n_out, self.spec.out_channels, dtype=torch.float32, device=self.device)
         ws = self.workspace(B, training)
         if training:
             self._tickets[B] = self._tickets.get(B, 0) + 1
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        _check(self.lib, self.lib.mshgnn_forward(self._plan, ptrs, None, params_flat.data_ptr(), out.data_ptr(),
+        _check(self.lib, self.lib.mshgnn_forward(self._plan, ptrs, pitch, params_flat.data_ptr(), out.data_ptr(),
                                                  ws.data_ptr(), B, int(training), stream), "mshgnn_forward")
         return out
 
     def backward(self, xs: Sequence[torch.Tensor], params_flat: torch.Tensor, grad_out: torch.Tensor, B: int,
                  grad_flat: Optional[torch.Tensor] = None) -> torch.Tensor:
         self._check_flat(params_flat, "params_flat")
-        ptrs = self._xptrs(xs, B)
+        ptrs, pitch = self._xptrs(xs, B)
         if grad_out.dtype != torch.float32 or not grad_out.is_contiguous() or grad_out.numel() != B * self.n_out * self.spec.out_channels:
             raise ValueError("grad_out must be contiguous fp32 with B*n_out*out_channels elements")
         if grad_flat is None:
@@ -305,7 +325,7 @@ class Engine:
             self._check_flat(grad_flat, "grad_flat")
         ws = self.workspace(B, True)
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        _check(self.lib, self.lib.mshgnn_backward(self._plan, ptrs, None, params_flat.data_ptr(), grad_out.data_ptr(),
+        _check(self.lib, self.lib.mshgnn_backward(self._plan, ptrs, pitch, params_flat.data_ptr(), grad_out.data_ptr(),
                                                   grad_flat.data_ptr(), ws.data_ptr(), B, stream), "mshgnn_backward")
         return grad_flat
 
@@ -344,13 +364,13 @@ class Engine:
 
     # ---- introspection (tests) -----------------------------------------------------------------
     def hidden_state(self, B: int, layer: int) -> torch.Tensor:
-        """X_layer as [B, NN, hidden] (a view into the workspace)."""
+        """X_layer as [B, NN, hidden] (permuted view of the node-major [NN, B, hidden] workspace buffer)."""
         lay = self.layout(B, True)
         ws = self.workspace(B, True)
         nn_ = self.info.total_nodes
         n = B * nn_ * self.spec.hidden
         es = 4 if self.dtype == "f32" else 2
-        return ws[lay.x[layer]:lay.x[layer] + n * es].view(self.torch_dtype).view(B, nn_, self.spec.hidden)
+        return ws[lay.x[layer]:lay.x[layer] + n * es].view(self.torch_dtype).view(nn_, B, self.spec.hidden).permute(1, 0, 2)
 
     def grad_hidden(self, B: int, layer: int) -> torch.Tensor:
         lay = self.layout(B, True)
@@ -358,4 +378,4 @@ class Engine:
         nn_ = self.info.total_nodes
         n = B * nn_ * self.spec.hidden
         es = 4 if self.dtype == "f32" else 2
-        return ws[lay.dx[layer]:lay.dx[layer] + n * es].view(self.torch_dtype).view(B, nn_, self.spec.hidden)
+        return ws[lay.dx[layer]:lay.dx[layer] + n * es].view(self.torch_dtype).view(nn_, B, self.spec.hidden).permute(1, 0, 2)

@@ -24,13 +24,13 @@ def test_library_exports_every_declared_symbol():
 def test_plan_compiler_work_counts():
     # A1-C2 h=128 L=3: encoder 1 844 224 + (52 + 40 + 8) live node-linears * 32 768 + decoder 3 072 FLOP / window
     info = engine.compile_plan_host(helpers.make_spec("c2", "a1-c2", "a1-c2", 128, 3), "f32")
-    assert info.rows_per_tile == 16 and info.total_nodes == 18 and info.lds_bytes == 18 * 8192
+    assert info.rows_per_tile == 16 and info.total_nodes == 18 and info.lds_bytes == 20 * 8192   # 18 node blocks + 2 base_transform scratch
     assert info.flops_fwd == 1844224 + 100 * 32768 + 3072
     assert info.bytes_in == 7204 * 4
     info16 = engine.compile_plan_host(helpers.make_spec("c2", "a1-c2", "a1-c2", 128, 3), "bf16")
-    assert info16.rows_per_tile == 32 and info16.bytes_in == 7204 * 2
+    assert info16.rows_per_tile == 16 and info16.bytes_in == 7204 * 2 and info16.lds_bytes == 20 * 4096
     k4 = engine.compile_plan_host(helpers.make_spec("k4", "mini_cheetah-k4", "mini_cheetah-k4", 128, 8, regression=False), "f32")
-    assert k4.total_nodes == 20 and k4.lds_bytes == 160 * 1024
+    assert k4.total_nodes == 20 and k4.lds_bytes == 160 * 1024   # fp32: no spare LDS, base_transform re-uses its own blocks
 
 
 def test_plan_compiler_rejects_bad_descriptors():
