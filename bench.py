@@ -109,10 +109,11 @@ def main():
     gflat = torch.empty_like(flat)
     out = torch.empty(B * 4, 3, dtype=torch.float32, device=device)
 
+    loss_buf = torch.empty(1, dtype=torch.float32, device=device)
+
     def step():
         e.forward(xs, flat, B, training=True, out=out)
-        loss, gout = e.mse_loss(out.view(-1), y)
-        e.backward(xs, flat, gout, B, grad_flat=gflat)
+        loss, _ = e.backward_mse(xs, flat, out, y, B, grad_flat=gflat, loss=loss_buf)   # MSE fused into the decoder backward
         if dist is not None:
             dist.all_reduce(gflat)   # RCCL sum over ranks (DDP semantics: mean = sum / world, folded into lr)
         return loss

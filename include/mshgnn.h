@@ -154,6 +154,12 @@ int mshgnn_forward(const mshgnn_plan* plan, const void* const* x, const int64_t*
 int mshgnn_backward(const mshgnn_plan* plan, const void* const* x, const int64_t* x_pitch, const float* params,
                     const float* grad_out, float* grad_params, void* workspace, int64_t batch, void* stream);
 
+/* Backward with the wrapper's MSE fused in (one launch less, no grad_out round trip): `out` is the forward's output,
+ * y the labels in the same [batch][n_out][out_channels] order; loss_out (device float[1]) receives mean((out-y)^2). */
+int mshgnn_backward_mse(const mshgnn_plan* plan, const void* const* x, const int64_t* x_pitch, const float* params,
+                        const float* out, const float* y, float* loss_out, float* grad_params, void* workspace,
+                        int64_t batch, void* stream);
+
 /* Loss of the Lightning wrapper (gnnLightning.py:633-639): loss = mean((out - y)^2) over n elements and
  * grad_out = 2 (out - y) / n.  loss_out: device float[1].                                               */
 int mshgnn_mse_loss(const float* out, const float* y, int64_t n, float* loss_out, float* grad_out, void* stream);

@@ -168,6 +168,14 @@ template <typename T> __device__ __forceinline__ void acc_init_bias(typename Pre
     a.c[0] = *reinterpret_cast<const f32x4*>(bias + wv * 32 + c_feat(0, lane));
     a.c[1] = *reinterpret_cast<const f32x4*>(bias + wv * 32 + c_feat(1, lane));
 }
+// this lane's bias values, fetched at group start and ADDED in the epilogue so the load's latency hides under the MACs
+struct BiasQ { f32x4 b[2]; };
+__device__ __forceinline__ BiasQ load_bias(const float* bias, int wv, int lane) {
+    BiasQ q;
+    q.b[0] = *reinterpret_cast<const f32x4*>(bias + wv * 32 + c_feat(0, lane));
+    q.b[1] = *reinterpret_cast<const f32x4*>(bias + wv * 32 + c_feat(1, lane));
+    return q;
+}
 
 // layer kernels: 8 waves = 4 column slices (wn) x 2 slot halves (wh); wave (wn, wh) owns output columns
 // [32 wn, 32 wn + 32) of the destination slots u with (u & 1) == wh  ->  HS = GMAX/2 accumulators per wave.
@@ -219,15 +227,26 @@ template <typename T> __global__ void k_prep(PrepArgs a) {
         const int lane = r % 64, v = (r / 64) % NBV, wv = r / (64 * NBV);
         const PackDesc pd = a.packs[pack];
         T out[EPC];
+        float g[8][EPC];     // up to 8 source matrices (root-sum), every gather issued before the first add
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int x = 0; x < EPC; ++x) {
+                int k, col;
+                if constexpr (sizeof(T) == 4) { k = 32 * (lane >> 4) + 4 * (v & 7) + x; col = wv * 32 + (v >> 3) * 16 + (lane & 15); }
+                else { k = 32 * (lane >> 4) + 8 * (v & 3) + x; col = wv * 32 + (v >> 2) * 16 + (lane & 15); }
+                g[i][x] = 0.f;
+                if (i < pd.n_src) {
+                    if (pd.orient == 0) { if (k < pd.ncols) g[i][x] = a.params[pd.src[i] + (int64_t)col * pd.ld + pd.col0 + k]; }
+                    else g[i][x] = a.params[pd.src[i] + (int64_t)k * pd.ld + col];
+                }
+            }
 #pragma unroll
         for (int x = 0; x < EPC; ++x) {
-            int k, col;
-            if constexpr (sizeof(T) == 4) { k = 32 * (lane >> 4) + 4 * (v & 7) + x; col = wv * 32 + (v >> 3) * 16 + (lane & 15); }
-            else { k = 32 * (lane >> 4) + 8 * (v & 3) + x; col = wv * 32 + (v >> 2) * 16 + (lane & 15); }
-            float s = 0.f;
-            if (pd.orient == 0) { if (k < pd.ncols) for (int i = 0; i < pd.n_src; ++i) s += a.params[pd.src[i] + (int64_t)col * pd.ld + pd.col0 + k]; }
-            else { for (int i = 0; i < pd.n_src; ++i) s += a.params[pd.src[i] + (int64_t)k * pd.ld + col]; }
-            out[x] = from_f32<T>(s);
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sum += g[i][x];     // fixed order: same value every step
+            out[x] = from_f32<T>(sum);
         }
         T* dst = reinterpret_cast<T*>(a.wpack) + (size_t)gid * EPC;
 #pragma unroll
@@ -455,10 +474,10 @@ struct WaveProg {
 // run every segment of the group for this wave: per segment load the packed weight fragment once, then walk the
 // accumulators in static order, each with its run-time list of source blocks
 template <typename T>
-__device__ __forceinline__ void run_segments(const int* wprog, typename Prec<T>::Acc (&acc)[Prec<T>::HS], const char* smem,
+__device__ __forceinline__ void run_segments(WaveProg& wp, int pc0, typename Prec<T>::Acc (&acc)[Prec<T>::HS], const char* smem,
                                              const T* wpack, int wn, int lane, int dbg) {
     using P = Prec<T>;
-    WaveProg wp(wprog, lane);
+    wp.pc = pc0;
     const int nseg = wp.next();
     typename P::BFrag bf;
     typename P::AFrag af;
@@ -510,20 +529,23 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, Prec<T>::WPS) 
     const int win = c_win(lane), w = w0 + win;
     const bool w_ok = w < B;
 
+    const int* pg = a.prog;
+    const int ngroups = pg[0];
+    WaveProg wp(pg + 1 + ngroups * GH_SIZE + wh * WPROG_LEN, lane);   // the whole layer's MAC program of this wave, loaded once
     if (!(a.dbg & 1)) stage_nodes<T>(smem, xin, NN, w0, B, tid);
     __syncthreads();
 
     typename P::Acc acc[P::HS];
-    const int* pg = a.prog;
-    const int ngroups = pg[0];
     const int* gh = pg + 1;
-    for (int g = 0; g < ngroups; ++g, gh += GH_SIZE + 2 * WPROG_LEN) {
+    for (int g = 0; g < ngroups; ++g, gh += GH_SIZE) {
         const int kind = gh[GH_KIND], ns = gh[GH_NSLOTS], flags = gh[GH_FLAGS];
-        const float* bias = a.bias + (size_t)gh[GH_BIAS] * H;
+        const BiasQ bq = load_bias(a.bias + (size_t)gh[GH_BIAS] * H, wn, lane);
 #pragma unroll
-        for (int u = 0; u < P::HS; ++u) acc_init_bias<T>(acc[u], bias, wn, lane);
-        run_segments<T>(gh + GH_SIZE + wh * WPROG_LEN, acc, smem, wpack, wn, lane, a.dbg);
+        for (int u = 0; u < P::HS; ++u) acc_fill(acc[u], 0.f);
+        run_segments<T>(wp, gh[GH_PC0 + wh], acc, smem, wpack, wn, lane, a.dbg);
         if (a.dbg & 8) continue;
+#pragma unroll
+        for (int u = 0; u < P::HS; ++u) { acc[u].c[0] += bq.b[0]; acc[u].c[1] += bq.b[1]; }
         if (kind == KIND_RELU) {
             const bool lds_epi = (flags & GF_LDS_EPI) != 0;
             // last group: every source block is dead once all waves are past their MACs -> X_new goes into the nodes'
@@ -638,6 +660,7 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, Prec<T>::WPS) 
     const int* node_kind = pg + BH_KIND;
     const int* node_flags = pg + BH_NFLAGS;
     const int* mlp_nodes = pg + BH_MLPNODES;
+    WaveProg wp(pg + BH_SIZE + ngroups * GH_SIZE + wh * WPROG_LEN, lane);   // this wave's MAC program of the layer, loaded once
     const int win = c_win(lane), w = w0 + win;
     const bool w_ok = w < B;
 
@@ -732,11 +755,11 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, Prec<T>::WPS) 
 
     // stage 2: D_l[j] = dH_j W_rootsum + sum_r sum_{j->i} dH_i W_rel^r
     const int* gh = pg + BH_SIZE;
-    for (int g = 0; g < ngroups; ++g, gh += GH_SIZE + 2 * WPROG_LEN) {
+    for (int g = 0; g < ngroups; ++g, gh += GH_SIZE) {
         const int ns = gh[GH_NSLOTS], flags = gh[GH_FLAGS];
 #pragma unroll
         for (int u = 0; u < P::HS; ++u) acc_fill(acc[u], 0.f);
-        run_segments<T>(gh + GH_SIZE + wh * WPROG_LEN, acc, smem, wpack, wn, lane, a.dbg);
+        run_segments<T>(wp, gh[GH_PC0 + wh], acc, smem, wpack, wn, lane, a.dbg);
         if (flags & GF_LDS_EPI) {
             __syncthreads();   // last group: all dH blocks are dead -> stage D through LDS, store whole rows
 #pragma unroll
@@ -813,6 +836,7 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, Prec<T>::WPS) 
 struct DecArgs {
     const void* xl; void* dxl; const float* params; const float* out_mask; float* out; const float* gout; float* slabs;
     int64_t off_w, off_b; int B, NN, node0, n_out, dout, slab0;
+    const float* y; float* loss; float inv_n;   // fused MSE: gout = 2 (out - y) / n computed on the fly, loss accumulated
 };
 
 // thread = (row, 8-column chunk): 16 lanes share a row, one wave covers 4 rows; whole rows are read / written coalesced
@@ -871,6 +895,7 @@ template <typename T> __global__ __launch_bounds__(256) void k_dec_bwd(DecArgs a
     for (int d = 0; d < 8; ++d) { accb[d] = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) accw[d][e] = 0.f; }
+    float lsum = 0.f;
     for (int64_t r = r_begin + rg; r < r_end; r += 16) {
         const int w = (int)(r / a.n_out), f = (int)(r % a.n_out);
         const size_t idx = act_idx(w, a.node0 + f, a.B) + c * 8;
@@ -881,7 +906,13 @@ template <typename T> __global__ __launch_bounds__(256) void k_dec_bwd(DecArgs a
 #pragma unroll
         for (int d = 0; d < 8; ++d) {
             if (d < a.dout) {
-                const float g = a.gout[r * a.dout + d] * a.out_mask[f * a.dout + d];
+                float go;
+                if (a.y) {   // wrapper MSE fused (gnnLightning.py:633-639): dL/dout = 2 (out - y) / n
+                    const float dlt = a.out[r * a.dout + d] - a.y[r * a.dout + d];
+                    go = 2.0f * dlt * a.inv_n;
+                    if (c == 0) lsum += dlt * dlt;
+                } else go = a.gout[r * a.dout + d];
+                const float g = go * a.out_mask[f * a.dout + d];
                 accb[d] += g;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { accw[d][e] += g * x[e]; dx[e] += g * W[d * H + c * 8 + e]; }
@@ -897,7 +928,15 @@ template <typename T> __global__ __launch_bounds__(256) void k_dec_bwd(DecArgs a
     }
     __syncthreads();
     float* slab = a.slabs + (size_t)blockIdx.x * DEC_SLAB_FLOATS;
-    for (int i = threadIdx.x; i < DEC_SLAB_FLOATS; i += 256) {
+    {   // per-block loss partial rides in the slab (summed in fixed order by k_finalize: no atomics, deterministic)
+        __shared__ float lred[4];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) lsum += __shfl_xor(lsum, m, 64);
+        if ((threadIdx.x & 63) == 0) lred[threadIdx.x >> 6] = lsum;
+        __syncthreads();
+        if (threadIdx.x == 0) slab[8 * H + 8] = (lred[0] + lred[1]) + (lred[2] + lred[3]);
+    }
+    for (int i = threadIdx.x; i < 8 * H + 8; i += 256) {
         float s2 = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s2 += red[r][i];
@@ -1186,7 +1225,7 @@ __global__ __launch_bounds__(256) void k_gradw_bf16(GradwArgs a) {
 }
 
 // k_finalize: sum split-K slabs in fixed order into the flat gradient buffer (every parameter written once)
-struct FinArgs { const int* fin; const int* targets; const float* slabs; const float* dec_slabs; float* grad; int n_lanes, n_parts; };
+struct FinArgs { const int* fin; const int* targets; const float* slabs; const float* dec_slabs; float* grad; int n_lanes, n_parts; float* loss; float inv_n; };
 
 __global__ __launch_bounds__(256) void k_finalize(FinArgs a) {
     const int* f = a.fin + blockIdx.x * FIN_INTS;
@@ -1195,6 +1234,13 @@ __global__ __launch_bounds__(256) void k_finalize(FinArgs a) {
     const int RPB = (rows + gridDim.y - 1) / gridDim.y;
     const int r0 = blockIdx.y * RPB, r1 = min(rows, r0 + RPB);
     const int n = (r1 - r0) * cols;
+    if (a.loss && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) {   // fused MSE: sum the per-block loss partials
+        float l = 0.f;
+        for (int b = threadIdx.x; b < NWG_DEC; b += 64) l += a.dec_slabs[(size_t)b * DEC_SLAB_FLOATS + 8 * H + 8];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) l += __shfl_xor(l, m, 64);
+        if (threadIdx.x == 0) *a.loss = l * a.inv_n;
+    }
     if (n <= 0) return;
     const bool is_mat = (kind == FIN_MATRIX || kind == FIN_DEC_W);
     for (int i = threadIdx.x; i < n; i += 256) {
@@ -1422,7 +1468,8 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
 
 template <typename T>
 static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, const float* gout,
-                         float* gparams, char* ws, int64_t batch, hipStream_t st) {
+                         float* gparams, char* ws, int64_t batch, hipStream_t st, const float* out = nullptr, const float* y = nullptr,
+                         float* loss = nullptr) {
     const HostPlan& hp = p->hp;
     const mshgnn_desc& d = hp.d;
     mshgnn_ws_layout lay; layout_workspace(hp, batch, 1, &lay);
@@ -1432,6 +1479,9 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
         a.xl = ws + lay.x[hp.L]; a.dxl = ws + lay.dx[hp.L]; a.params = params; a.out_mask = p->d_out_mask; a.gout = gout;
         a.slabs = reinterpret_cast<float*>(ws + lay.dec_slabs); a.off_w = d.off_dec_w; a.off_b = d.off_dec_b;
         a.B = B; a.NN = hp.NN; a.node0 = hp.type_base[d.out_type]; a.n_out = d.type_nodes[d.out_type]; a.dout = d.out_channels; a.slab0 = 0;
+        if (y) {
+            a.y = y; a.out = const_cast<float*>(out); a.loss = loss; a.inv_n = 1.0f / (float)((int64_t)B * a.n_out * a.dout);
+        }
         ProfScope ps(p, hp.ks_dec_bwd, st);
         hipLaunchKernelGGL(k_dec_bwd<T>, dim3(NWG_DEC), dim3(256), 0, st, a);
     }
@@ -1466,7 +1516,8 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
     }
     {
         FinArgs a{p->d_tables + hp.fin_off, p->d_tables + hp.tgt_off, reinterpret_cast<const float*>(ws + lay.slabs),
-                  reinterpret_cast<const float*>(ws + lay.dec_slabs), gparams, hp.n_lanes, hp.n_parts};
+                  reinterpret_cast<const float*>(ws + lay.dec_slabs), gparams, hp.n_lanes, hp.n_parts, y ? loss : nullptr,
+                  1.0f / (float)((int64_t)B * d.type_nodes[d.out_type] * d.out_channels)};
         ProfScope ps(p, hp.ks_fin, st);
         hipLaunchKernelGGL(k_finalize, dim3(hp.n_fin, 32), dim3(256), 0, st, a);
     }
@@ -1489,6 +1540,14 @@ extern "C" int mshgnn_backward(const mshgnn_plan* p, const void* const* x, const
     if (batch < 1 || batch > (1 << 24)) return set_err(MSHGNN_EINVAL, "batch must be in [1, 2^24]");
     if (p->hp.d.dtype == MSHGNN_F32) return backward_impl<float>(p, x, x_pitch, params, grad_out, grad_params, (char*)workspace, batch, (hipStream_t)stream);
     return backward_impl<__bf16>(p, x, x_pitch, params, grad_out, grad_params, (char*)workspace, batch, (hipStream_t)stream);
+}
+
+extern "C" int mshgnn_backward_mse(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, const float* out,
+                                   const float* y, float* loss_out, float* grad_params, void* workspace, int64_t batch, void* stream) {
+    if (!p || !x || !params || !out || !y || !loss_out || !grad_params || !workspace) return set_err(MSHGNN_EINVAL, "null argument to mshgnn_backward_mse");
+    if (batch < 1 || batch > (1 << 24)) return set_err(MSHGNN_EINVAL, "batch must be in [1, 2^24]");
+    if (p->hp.d.dtype == MSHGNN_F32) return backward_impl<float>(p, x, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, (hipStream_t)stream, out, y, loss_out);
+    return backward_impl<__bf16>(p, x, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, (hipStream_t)stream, out, y, loss_out);
 }
 
 extern "C" int mshgnn_mse_loss(const float* out, const float* y, int64_t n, float* loss_out, float* grad_out, void* stream) {

@@ -30,7 +30,7 @@ constexpr int MAX_L = 16;
 constexpr int LDS_LIMIT = 160 * 1024;
 constexpr int SLAB_FLOATS = H * H + H;   // one split-K partial: 128x128 matrix + 128 column sums
 constexpr int NWG_DEC = 512;             // workgroups of the decoder backward (each writes one small slab)
-constexpr int DEC_SLAB_FLOATS = 8 * H + 8; // decoder partial: [out_channels<=8][128] + bias[8]
+constexpr int DEC_SLAB_FLOATS = 8 * H + 16; // decoder partial: [out_channels<=8][128] + bias[8] + loss partial (+pad)
 constexpr int GW_IPL = 2;                // items per weight-gradient lane (all workgroups advance at the same pace)
 
 enum { OP_LOADW = 0, OP_MAC = 1 };
@@ -39,10 +39,11 @@ enum { NK_DEAD = 0, NK_RELU = 1, NK_MLP = 2 };
 enum { GF_RESIDUAL = 1, GF_ENC_MASK = 2, GF_STORE_MASK = 4, GF_LDS_EPI = 8 };
 enum { NF_RES_IN = 1 };   // backward node flag: G_{l+2}[n] flows into G_{l+1}[n] through the residual
 
-// group header layout (ints); a group is followed by two WAVE PROGRAMS of WPROG_LEN ints (slot half 0, slot half 1).
-// A wave loads its program into two VGPRs once and interprets it with v_readlane (no memory latency in the MAC loop):
-//   [nseg, then per segment: pack, then per accumulator u (slot = 2u + half): count, src blocks...]
-enum { GH_KIND = 0, GH_NSLOTS, GH_BIAS, GH_NSEG, GH_W1, GH_W2, GH_B1, GH_B2, GH_FLAGS, GH_PAD0, GH_PAD1, GH_PAD2,
+// layer program = [n_groups] + n_groups group headers (GH_SIZE ints each) + two WAVE PROGRAMS of WPROG_LEN ints (one per
+// slot half) holding every group's MAC program back to back (group g starts at entry GH_PC0/GH_PC1 of its half).
+// A wave loads its program into two VGPRs ONCE per kernel and interprets it with v_readlane (no memory latency in the
+// MAC loop):   per group: [nseg, then per segment: pack, then per accumulator u (slot = 2u + half): count, src blocks...]
+enum { GH_KIND = 0, GH_NSLOTS, GH_BIAS, GH_NSEG, GH_W1, GH_W2, GH_B1, GH_B2, GH_FLAGS, GH_PC0, GH_PC1, GH_PAD2,
        GH_NODES = 12, GH_MLPIDX = 12 + GMAX, GH_SCR = 12 + 2 * GMAX, GH_SIZE = 12 + 3 * GMAX };
 constexpr int WPROG_LEN = 128;
 // backward program header: [n_groups, n_mlp_live, w2pack, w1pack, has_delta, 0,0,0, node_kind[64], node_flags[64], mlp_nodes[GMAX]]
@@ -270,10 +271,13 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
 
     struct Seg { int pack; std::vector<std::pair<int, int>> macs; };   // (slot, src block)
     bool prog_overflow = false;
-    auto emit_segments = [&](const std::vector<Seg>& segs) {
+    std::vector<int> wprog[2];   // the layer's wave programs under construction (half 0 / half 1)
+    auto emit_segments = [&](const std::vector<Seg>& segs, int gh) {
         const int hs = p.gmax / 2;
         for (int half = 0; half < 2; ++half) {
-            std::vector<int> w; w.push_back((int)segs.size());
+            std::vector<int>& w = wprog[half];
+            T[gh + GH_PC0 + half] = (int)w.size();
+            w.push_back((int)segs.size());
             for (const Seg& sg : segs) {
                 w.push_back(sg.pack);
                 for (int u = 0; u < hs; ++u) {
@@ -282,9 +286,14 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
                     for (auto& m : sg.macs) if (m.first == slot) { w.push_back(m.second); w[pos]++; }
                 }
             }
-            if ((int)w.size() > WPROG_LEN) prog_overflow = true;
-            w.resize(WPROG_LEN, 0);
-            for (int v : w) T.push_back(v);
+        }
+    };
+    auto flush_wprog = [&]() {
+        for (int half = 0; half < 2; ++half) {
+            if ((int)wprog[half].size() > WPROG_LEN) prog_overflow = true;
+            wprog[half].resize(WPROG_LEN, 0);
+            for (int v : wprog[half]) T.push_back(v);
+            wprog[half].clear();
         }
     };
     struct GroupDef { int type, c0, ns; bool mlp; };
@@ -343,8 +352,9 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
             }
             if (G.mlp) { exec_fwd += 2 * NL * ns; alg_fwd += 2 * NL * ns; }
             T[gh + GH_NSEG] = (int)segs.size();
-            emit_segments(segs);
+            emit_segments(segs, gh);
         }
+        flush_wprog();
 
         // ---------- backward program ----------
         p.bwd_prog_off[l] = (int)T.size();
@@ -391,12 +401,13 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
                 if (!sg.macs.empty()) segs.push_back(sg);
             }
             T[gh + GH_NSEG] = (int)segs.size();
-            emit_segments(segs);
+            emit_segments(segs, gh);
         }
+        flush_wprog();
         T[bh + BH_NGROUPS] = (int)bgroups.size();
         lf_alg[l] = alg_fwd - af0; lf_exec[l] = exec_fwd - ef0; lb_alg[l] = alg_bwd - ab0; lb_exec[l] = exec_bwd - eb0;
     }
-    if (prog_overflow) return fail(p, "a destination group's MAC program exceeds 128 entries (too many edges per node type for this build)");
+    if (prog_overflow) return fail(p, "a layer's MAC program exceeds 128 entries per wave (too many relations/edges for this build)");
     // algorithmic dX work: one node-linear per (relation, src node with >=1 out-edge into a live dst) -- count below
     for (int l = 0; l < L; ++l)
         for (int r = 0; r < NR; ++r) {

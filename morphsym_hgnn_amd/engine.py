@@ -65,7 +65,7 @@ class MshgnnKernelStat(C.Structure):
 EXPORTS = [
     "mshgnn_last_error", "mshgnn_version", "mshgnn_plan_create", "mshgnn_plan_destroy", "mshgnn_plan_info",
     "mshgnn_plan_compile_host", "mshgnn_workspace_layout", "mshgnn_forward", "mshgnn_backward", "mshgnn_mse_loss",
-    "mshgnn_profile_enable", "mshgnn_profile_read",
+    "mshgnn_profile_enable", "mshgnn_profile_read", "mshgnn_backward_mse",
 ]
 
 _lib = None
@@ -101,6 +101,8 @@ def load_library():
                                    C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
     lib.mshgnn_backward.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.mshgnn_backward_mse.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.mshgnn_profile_enable.argtypes = [C.c_void_p, C.c_int]
     lib.mshgnn_profile_read.argtypes = [C.c_void_p, C.POINTER(MshgnnKernelStat), C.POINTER(C.c_int32)]
     lib.mshgnn_mse_loss.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -328,6 +330,24 @@ class Engine:
         _check(self.lib, self.lib.mshgnn_backward(self._plan, ptrs, pitch, params_flat.data_ptr(), grad_out.data_ptr(),
                                                   grad_flat.data_ptr(), ws.data_ptr(), B, stream), "mshgnn_backward")
         return grad_flat
+
+    def backward_mse(self, xs: Sequence[torch.Tensor], params_flat: torch.Tensor, out: torch.Tensor, y: torch.Tensor, B: int,
+                     grad_flat: Optional[torch.Tensor] = None, loss: Optional[torch.Tensor] = None):
+        """Fused wrapper-MSE + backward (gnnLightning.py:633-639 + autograd): returns (loss[1], grad_flat)."""
+        self._check_flat(params_flat, "params_flat")
+        ptrs, pitch = self._xptrs(xs, B)
+        n = B * self.n_out * self.spec.out_channels
+        if out.dtype != torch.float32 or y.dtype != torch.float32 or out.numel() != n or y.numel() != n:
+            raise ValueError("out and y must be fp32 with B*n_out*out_channels elements")
+        if grad_flat is None:
+            grad_flat = torch.empty(self.spec.flat_size(), dtype=torch.float32, device=self.device)
+        if loss is None:
+            loss = torch.empty(1, dtype=torch.float32, device=self.device)
+        ws = self.workspace(B, True)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _check(self.lib, self.lib.mshgnn_backward_mse(self._plan, ptrs, pitch, params_flat.data_ptr(), out.data_ptr(), y.data_ptr(),
+                                                      loss.data_ptr(), grad_flat.data_ptr(), ws.data_ptr(), B, stream), "mshgnn_backward_mse")
+        return loss, grad_flat
 
     def mse_loss(self, out: torch.Tensor, y: torch.Tensor, want_grad: bool = True):
         """Wrapper loss (gnnLightning.py:633-639): returns (loss[1], dL/d out or None)."""

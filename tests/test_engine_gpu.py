@@ -118,3 +118,23 @@ def test_full_size_batch_properties():
     gb = e.backward(xb, flat, go[h * 4:].contiguous(), h).clone()
     assert torch.allclose(torch.cat([oa, ob]), out, rtol=0, atol=0)
     assert float((ga + gb - g1).abs().max() / g1.abs().max()) < 1e-4
+
+
+def test_fused_mse_backward_equals_two_step():
+    _require_gpu()
+    from morphsym_hgnn_amd import engine as eng, synth
+    spec = helpers.make_spec("c2", "a1-c2", "a1-c2", 128, 3)
+    B = 37
+    e = eng.Engine(spec, "f32")
+    x_dict, y = synth.make_windows(9, B, spec.num_nodes, spec.widths, 12)
+    xs = e.cast_inputs(x_dict)
+    flat = eng.flatten_params(spec, synth.make_params(9, spec.param_shapes()), e.device)
+    yd = y.reshape(-1).to(e.device, torch.float32)
+    out = e.forward(xs, flat, B)
+    loss1, g = e.mse_loss(out.view(-1), yd)
+    g1 = e.backward(xs, flat, g, B).clone()
+    out = e.forward(xs, flat, B)
+    loss2, g2 = e.backward_mse(xs, flat, out, yd, B)
+    torch.cuda.synchronize()
+    assert abs(float(loss1) - float(loss2)) / float(loss1) < 1e-5
+    assert float((g1 - g2).abs().max() / g1.abs().max()) < 1e-6
