@@ -605,7 +605,9 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
                                 live_nodes(l) * (double)H * es * 2 + need_nodes(l) * (double)H * es + live_nodes(l) * 16.0);
             if (l == L - 1) p.ks_layer_bwd0 = idx;
         }
-        p.ks_gradw = add("gradw", MSHGNN_BOUND_MFMA, gw_alg, gw_exec, bytes + (double)L * 2 * act + act);
+        // k_gradw reads every P / Q operand once at best: ~134 FLOP per algorithmic byte at bf16 -> below the ridge
+        // (2.5 PF / 8 TB/s = 312 FLOP/B), so HBM is the bounding roofline (fp32: 157 TF / 8 TB/s = 20 FLOP/B -> MFMA-bound)
+        p.ks_gradw = add("gradw", d.dtype == MSHGNN_F32 ? MSHGNN_BOUND_MFMA : MSHGNN_BOUND_HBM, gw_alg, gw_exec, bytes + (double)L * 2 * act + act);
         p.ks_fin = add("finalize", MSHGNN_BOUND_HBM, 0, 0, 0);
     }
     return true;
