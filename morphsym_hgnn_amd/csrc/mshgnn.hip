@@ -411,7 +411,8 @@ struct LayerArgs {
     void* d_out;           // bwd: D_l  (dX_l without its residual term)
     const void* wpack; const float* bias; const int* prog;
     int B, NN, n_mlp;
-    int dbg;               // ablation switches for timing experiments (MSHGNN_DBG): 1 no stage-in, 2 no MACs, 4 no W loads, 8 no group epilogues
+    int dbg;               // ablation switches for timing experiments (MSHGNN_DBG): 1 no stage-in, 2 no MACs, 4 no W loads, 8 no group epilogues,
+                           // backward: 16 no stage-1 loads/stores, 32 no base_transform chain, 64 no stage-2 epilogues
 };
 
 // relu bits of one accumulator -> word wn of maskbits[B][NN][4] (bit i <-> feature 32 wn + i).  Each lane owns 8 bits
@@ -647,18 +648,14 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, Prec<T>::WPS) 
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wv & 3, wh = wv >> 2;
     const int w0 = blockIdx.x * P::ROWS, B = a.B, NN = a.NN;
-    T* gtop = reinterpret_cast<T*>(const_cast<void*>(a.x_in));   // G_{l+1}
-    const T* gprev = reinterpret_cast<const T*>(a.g_prev);
-    const T* din = reinterpret_cast<const T*>(a.d_in);
-    T* dout = reinterpret_cast<T*>(a.d_out);
-    T* dx0 = reinterpret_cast<T*>(a.x_out);
+    const T* gtop = reinterpret_cast<const T*>(a.x_in);   // dX_{l+1}
+    T* dxo = reinterpret_cast<T*>(a.x_out);               // dX_l
     T* dh = reinterpret_cast<T*>(a.dh);
     const T* xact = reinterpret_cast<const T*>(a.x_act);
     const T* wpack = reinterpret_cast<const T*>(a.wpack);
     const int* pg = a.prog;
-    const int ngroups = pg[BH_NGROUPS], nmlp = pg[BH_NMLP], w2pack = pg[BH_W2], w1pack = pg[BH_W1], has_delta = pg[BH_HAS_DELTA];
+    const int ngroups = pg[BH_NGROUPS], nmlp = pg[BH_NMLP], w2pack = pg[BH_W2], w1pack = pg[BH_W1];
     const int* node_kind = pg + BH_KIND;
-    const int* node_flags = pg + BH_NFLAGS;
     const int* mlp_nodes = pg + BH_MLPNODES;
     WaveProg wp(pg + BH_SIZE + ngroups * GH_SIZE + wh * WPROG_LEN, lane);   // this wave's MAC program of the layer, loaded once
     const int win = c_win(lane), w = w0 + win;
@@ -666,24 +663,18 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, Prec<T>::WPS) 
 
     // stage 1 (row-major, coalesced): G_{l+1} -> LDS; relu nodes masked (-> dH, also to global for k_gradw)
     {
-        constexpr int EPC = P::EPC, NPB = RowMap<T>::NPB, BATCH = 3;
+        constexpr int EPC = P::EPC, NPB = RowMap<T>::NPB, BATCH = 5;
         const RowMap<T> m(tid);
         const int row = m.row, c = m.c, wr = w0 + row;
         for (int nb = m.sub; nb < NN; nb += NPB * BATCH) {
-            u32x4 v[BATCH], g2[BATCH]; unsigned word[BATCH]; int nk[BATCH];
+            u32x4 v[BATCH]; unsigned word[BATCH]; int nk[BATCH];
 #pragma unroll
             for (int i = 0; i < BATCH; ++i) {       // issue every load of the batch first
                 const int n = nb + i * NPB;
                 nk[i] = n < NN ? node_kind[n] : NK_DEAD;
-                v[i] = u32x4{0, 0, 0, 0}; g2[i] = u32x4{0, 0, 0, 0}; word[i] = 0;
-                if (nk[i] != NK_DEAD && wr < B) {
-                    const size_t idx = act_idx(wr, n, B) + c * EPC;
-                    if (has_delta) {
-                        v[i] = *reinterpret_cast<const u32x4*>(din + idx);
-                        if (node_flags[n] & NF_RES_IN) g2[i] = *reinterpret_cast<const u32x4*>(gprev + idx);
-                    } else {
-                        v[i] = *reinterpret_cast<const u32x4*>(gtop + idx);
-                    }
+                v[i] = u32x4{0, 0, 0, 0}; word[i] = 0;
+                if (nk[i] != NK_DEAD && wr < B && !(a.dbg & 16)) {
+                    v[i] = *reinterpret_cast<const u32x4*>(gtop + act_idx(wr, n, B) + c * EPC);
                     if (nk[i] == NK_RELU) word[i] = a.maskbits[((size_t)n * B + wr) * 4 + (c * EPC) / 32];
                 }
             }
@@ -691,16 +682,8 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, Prec<T>::WPS) 
             for (int i = 0; i < BATCH; ++i) {
                 const int n = nb + i * NPB;
                 if (nk[i] == NK_DEAD) continue;
-                if (wr < B) {
-                    const size_t idx = act_idx(wr, n, B) + c * EPC;
-                    if (has_delta) {
-                        if (node_flags[n] & NF_RES_IN) v[i] = chunk_add<T>(v[i], g2[i]);
-                        *reinterpret_cast<u32x4*>(gtop + idx) = v[i];           // materialise G_{l+1}
-                    }
-                    if (nk[i] == NK_RELU) {
-                        v[i] = chunk_mask_bits<T>(v[i], word[i] >> ((c * EPC) % 32));
-                        *reinterpret_cast<u32x4*>(dh + idx) = v[i];
-                    }
+                if (nk[i] == NK_RELU) {
+                    v[i] = chunk_mask_bits<T>(v[i], word[i] >> ((c * EPC) % 32));   // dH (k_gradw recomputes it the same way)
                 }
                 *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(n, row, c)) = v[i];
             }
@@ -710,7 +693,7 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, Prec<T>::WPS) 
 
     typename P::Acc acc[P::HS];
 
-    if (nmlp > 0) {
+    if (nmlp > 0 && !(a.dbg & 32)) {
         // dT1 = dY W2 ; dU = dT1 . (T1 > 0) ; dH = dU W1     (backward of base_transform; re-uses the base blocks)
         const T* t1 = reinterpret_cast<const T*>(a.t1);
         T* du = reinterpret_cast<T*>(a.du);
@@ -760,6 +743,7 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, Prec<T>::WPS) 
 #pragma unroll
         for (int u = 0; u < P::HS; ++u) acc_fill(acc[u], 0.f);
         run_segments<T>(wp, gh[GH_PC0 + wh], acc, smem, wpack, wn, lane, a.dbg);
+        if (a.dbg & 64) continue;
         if (flags & GF_LDS_EPI) {
             __syncthreads();   // last group: all dH blocks are dead -> stage D through LDS, store whole rows
 #pragma unroll
@@ -785,23 +769,18 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, Prec<T>::WPS) 
                         const size_t idx = act_idx(w0 + row, n, B) + c * P::EPC;
                         v[i] = *reinterpret_cast<const u32x4*>(smem + lds_chunk<T>(n, row, c));
                         g1[i] = u32x4{0, 0, 0, 0}; xa[i] = u32x4{0, 0, 0, 0};
-                        if (ok[i] && (flags & GF_ENC_MASK)) {
-                            if (flags & GF_RESIDUAL) g1[i] = *reinterpret_cast<const u32x4*>(gtop + idx);
-                            xa[i] = *reinterpret_cast<const u32x4*>(xact + idx);
-                        }
+                        if (ok[i] && (flags & GF_RESIDUAL)) g1[i] = *reinterpret_cast<const u32x4*>(gtop + idx);
+                        if (ok[i] && (flags & GF_ENC_MASK)) xa[i] = *reinterpret_cast<const u32x4*>(xact + idx);
                     }
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         if (!ok[i]) continue;
                         const int n = gh[GH_NODES + sl0 + i * RowMap<T>::NPB];
                         const size_t idx = act_idx(w0 + row, n, B) + c * P::EPC;
-                        if (flags & GF_ENC_MASK) {   // layer 0: finish dX_0 = relu'(X_0) . (G_1 + D_0) here
-                            u32x4 r = v[i];
-                            if (flags & GF_RESIDUAL) r = chunk_add<T>(r, g1[i]);
-                            *reinterpret_cast<u32x4*>(dx0 + idx) = chunk_mask_pos<T>(r, xa[i]);
-                        } else {
-                            *reinterpret_cast<u32x4*>(dout + idx) = v[i];
-                        }
+                        u32x4 r = v[i];
+                        if (flags & GF_RESIDUAL) r = chunk_add<T>(r, g1[i]);             // dX_l = dX_{l+1} + D_l
+                        if (flags & GF_ENC_MASK) r = chunk_mask_pos<T>(r, xa[i]);        // layer 0: x relu'(X_0)
+                        *reinterpret_cast<u32x4*>(dxo + idx) = r;
                     }
                 }
         } else {
@@ -810,19 +789,20 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, Prec<T>::WPS) 
                 const int slot = 2 * u + wh;
                 if (slot < ns && w_ok) {
                     const int n = gh[GH_NODES + slot];
+                    f32x4 g1[2], xa[2];
+#pragma unroll
+                    for (int fb = 0; fb < 2; ++fb) {     // issue the loads of both feature blocks first
+                        const size_t idx = act_idx(w, n, B) + wn * 32 + c_feat(fb, lane);
+                        g1[fb] = (flags & GF_RESIDUAL) ? load_quad(gtop + idx) : f32x4{0, 0, 0, 0};
+                        xa[fb] = (flags & GF_ENC_MASK) ? load_quad(xact + idx) : f32x4{1, 1, 1, 1};
+                    }
 #pragma unroll
                     for (int fb = 0; fb < 2; ++fb) {
                         const size_t idx = act_idx(w, n, B) + wn * 32 + c_feat(fb, lane);
-                        if (flags & GF_ENC_MASK) {
-                            f32x4 y = acc[u].c[fb];
-                            if (flags & GF_RESIDUAL) y = round_as<T>(y) + load_quad(gtop + idx);   // D_0 is rounded like a stored delta
-                            const f32x4 xa = load_quad(xact + idx);
+                        f32x4 y = round_as<T>(acc[u].c[fb]) + g1[fb];
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) y[j] = xa[j] > 0.f ? y[j] : 0.f;
-                            store_quad(dx0 + idx, y);
-                        } else {
-                            store_quad(dout + idx, acc[u].c[fb]);
-                        }
+                        for (int j = 0; j < 4; ++j) y[j] = xa[fb][j] > 0.f ? y[j] : 0.f;
+                        store_quad(dxo + idx, y);
                     }
                 }
             }
@@ -1008,6 +988,10 @@ __global__ __launch_bounds__(256) void k_gradw_f32(GradwArgs a) {
                 pv[p] = f32x4{0, 0, 0, 0}; qv[p] = f32x4{0, 0, 0, 0};
                 if (w < a.B) {
                     pv[p] = *reinterpret_cast<const f32x4*>(pb + act_idx(w, po, a.B) + c * 4);
+                    if (im[9] >= 0) {   // P = dX_{l+1} . relu bits
+                        const unsigned word = reinterpret_cast<const unsigned*>(a.ws + a.buf_off[im[9]])[((size_t)po * a.B + w) * 4 + c / 8];
+                        pv[p] = __builtin_bit_cast(f32x4, chunk_mask_bits<float>(__builtin_bit_cast(u32x4, pv[p]), word >> ((c * 4) % 32)));
+                    }
                     if (qs >= 0) {
                         qv[p] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const T*>(a.ws + a.buf_off[qbuf]) + act_idx(w, qo, a.B) + c * 4);
                     } else {
@@ -1087,8 +1071,10 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16* tile, int w_base, int co
 
 __global__ __launch_bounds__(256) void k_gradw_bf16(GradwArgs a) {
     using T = __bf16;
-    __shared__ __attribute__((aligned(16))) __bf16 Ps[GWB_KW * GWB_PITCH];
-    __shared__ __attribute__((aligned(16))) __bf16 Qs[GWB_KW * GWB_PITCH];
+    // two LDS stages: the staging writes of step s+1 go to the other stage while step s's MFMAs read this one -> one
+    // barrier per step and LDS writes overlap the MFMAs
+    __shared__ __attribute__((aligned(16))) __bf16 Pbuf[2][GWB_KW * GWB_PITCH];
+    __shared__ __attribute__((aligned(16))) __bf16 Qbuf[2][GWB_KW * GWB_PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wv >> 1, wc = wv & 1;
     // blocks b and b+8 share an XCD (round-robin dispatch; speed only): lane_order puts the lanes that read the same
@@ -1105,10 +1091,12 @@ __global__ __launch_bounds__(256) void k_gradw_bf16(GradwArgs a) {
     // the lane's (<= GW_IPL = 2) items are resolved ONCE into per-thread base pointers: no dependent scalar loads
     // inside the streaming loop
     const T* pbase[GW_IPL]; const T* qbase[GW_IPL]; int64_t qstride[GW_IPL]; int qvalid[GW_IPL], qvb[GW_IPL]; u32x4 qsign[GW_IPL];
+    const unsigned* mbase[GW_IPL];   // relu-bit words of the P rows (nullptr: P is used as stored)
 #pragma unroll
     for (int i = 0; i < GW_IPL; ++i) {
         const int* im = a.items + (it0 + min(i, nit - 1)) * ITEM_INTS;
         pbase[i] = reinterpret_cast<const T*>(a.ws + a.buf_off[im[0]]) + act_idx(0, im[2], a.B) + c * 8;
+        mbase[i] = im[9] >= 0 ? reinterpret_cast<const unsigned*>(a.ws + a.buf_off[im[9]]) + (size_t)im[2] * a.B * 4 + c / 4 : nullptr;
         qsign[i] = u32x4{0, 0, 0, 0};
         if (im[4] >= 0) {
             qbase[i] = reinterpret_cast<const T*>(a.ws + a.buf_off[im[3]]) + act_idx(0, im[5], a.B) + c * 8;
@@ -1131,44 +1119,45 @@ __global__ __launch_bounds__(256) void k_gradw_bf16(GradwArgs a) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
 
-    struct Stage { u32x4 pv[4], qv[4]; };
+    struct Stage { u32x4 pv[4], qv[4]; unsigned mw[4]; };
     auto fetch = [&](Stage& st, int s) {
-        const int w0 = (ch0 + s / nit) * GWB_KW;
+        const int w0 = (ch0 + (nit == 2 ? s >> 1 : s)) * GWB_KW;
         const int it = (nit == 2) ? (s & 1) : 0;
         const T* pb = it ? pbase[1] : pbase[0];
         const T* qb = it ? qbase[1] : qbase[0];
+        const unsigned* mb = it ? mbase[1] : mbase[0];
         const int64_t qs = it ? qstride[1] : qstride[0];
         const int qn = it ? qvalid[1] : qvalid[0], vb = it ? qvb[1] : qvb[0];
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int w = w0 + r0 + 16 * p;
-            st.pv[p] = u32x4{0, 0, 0, 0}; st.qv[p] = u32x4{0, 0, 0, 0};
+            st.pv[p] = u32x4{0, 0, 0, 0}; st.qv[p] = u32x4{0, 0, 0, 0}; st.mw[p] = 0xffffffffu;
             if (w < a.B && !(a.dbg & 1)) {
                 st.pv[p] = *reinterpret_cast<const u32x4*>(pb + (size_t)w * H);
+                if (mb) st.mw[p] = mb[(size_t)w * 4];
                 if (a.aligned) { if (qn > 0) st.qv[p] = *reinterpret_cast<const u32x4*>(qb + (size_t)w * qs); }   // raw: a use here would serialise the loads
                 else st.qv[p] = load_chunk<T>(qb + (size_t)w * qs, qn, vb);
             }
         }
     };
-    auto consume = [&](const Stage& st, const u32x4 sx, const int qn) {
+    auto stage_to_lds = [&](const Stage& st, const u32x4 sx, const int qn, __bf16* Ps, __bf16* Qs) {
         if (a.dbg & 2) { asm volatile("" :: "v"(st.pv[0][0]), "v"(st.qv[3][3])); return; }
-        __syncthreads();   // previous MFMA phase finished reading Ps/Qs
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int row = r0 + 16 * p;
-            *reinterpret_cast<u32x4*>(&Ps[row * GWB_PITCH + c * 8]) = st.pv[p];
+            const u32x4 pm = chunk_mask_bits<T>(st.pv[p], st.mw[p] >> ((c * 8) % 32));   // dH = dX . relu bits (all-ones when P is stored as is)
+            *reinterpret_cast<u32x4*>(&Ps[row * GWB_PITCH + c * 8]) = pm;
             *reinterpret_cast<u32x4*>(&Qs[row * GWB_PITCH + c * 8]) = chunk_keep_first<T>(st.qv[p], qn) ^ sx;   // drop pad columns, symmetry sign mask of encoder inputs
             if (bias_flag) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    bsum[2 * e] += __builtin_bit_cast(float, st.pv[p][e] << 16);
-                    bsum[2 * e + 1] += __builtin_bit_cast(float, st.pv[p][e] & 0xffff0000u);
+                    bsum[2 * e] += __builtin_bit_cast(float, pm[e] << 16);
+                    bsum[2 * e + 1] += __builtin_bit_cast(float, pm[e] & 0xffff0000u);
                 }
             }
         }
-        __syncthreads();
     };
-    auto mfmas = [&]() {
+    auto mfmas = [&](const __bf16* Ps, const __bf16* Qs) {
         if (a.dbg & 4) return;
 #pragma unroll
         for (int ks = 0; ks < GWB_KW / 16; ++ks) {
@@ -1184,18 +1173,29 @@ __global__ __launch_bounds__(256) void k_gradw_bf16(GradwArgs a) {
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bq[j], acc[i][j], 0, 0, 0);
         }
     };
-    // two register stages: the loads of steps s+1 and s+2 are in flight while step s runs its MFMAs
+    // register stages sa / sb hold the global loads of steps s+1, s+2 (in flight under the MFMAs); even steps use LDS
+    // stage 0, odd steps LDS stage 1.  Loop invariant at the top of step s: LDS[s&1] holds step s, registers hold s+1 (and
+    // s+2 is being fetched).
+    const u32x4 sx1 = nit == 2 ? qsign[1] : qsign[0];
+    const int qn1 = nit == 2 ? qvalid[1] : qvalid[0];
     Stage sa, sb;
     if (nsteps > 0) fetch(sa, 0);
     if (nsteps > 1) fetch(sb, 1);
+    if (nsteps > 0) stage_to_lds(sa, qsign[0], qvalid[0], Pbuf[0], Qbuf[0]);
+    if (nsteps > 2) fetch(sa, 2);
+    __syncthreads();
     for (int s = 0; s < nsteps; s += 2) {
-        consume(sa, qsign[0], qvalid[0]);
-        if (s + 2 < nsteps) fetch(sa, s + 2);
-        mfmas();
+        // step s (LDS 0): write step s+1 (registers sb) into LDS 1 while multiplying LDS 0
+        if (s + 1 < nsteps) stage_to_lds(sb, sx1, qn1, Pbuf[1], Qbuf[1]);
+        if (s + 3 < nsteps) fetch(sb, s + 3);
+        mfmas(Pbuf[0], Qbuf[0]);
+        __syncthreads();
         if (s + 1 < nsteps) {
-            consume(sb, nit == 2 ? qsign[1] : qsign[0], nit == 2 ? qvalid[1] : qvalid[0]);
-            if (s + 3 < nsteps) fetch(sb, s + 3);
-            mfmas();
+            // step s+1 (LDS 1): write step s+2 (registers sa) into LDS 0
+            if (s + 2 < nsteps) stage_to_lds(sa, qsign[0], qvalid[0], Pbuf[0], Qbuf[0]);
+            if (s + 4 < nsteps) fetch(sa, s + 4);
+            mfmas(Pbuf[1], Qbuf[1]);
+            __syncthreads();
         }
     }
     float* slab = a.slabs + (size_t)(part * a.n_lanes + ln) * SLAB_FLOATS;
@@ -1210,7 +1210,7 @@ __global__ __launch_bounds__(256) void k_gradw_bf16(GradwArgs a) {
                 slab[o * H + k] = acc[i][j][q];
             }
     if (bias_flag) {
-        float* red = reinterpret_cast<float*>(Ps);   // 16 x 128 floats = 8 KB <= sizeof(Ps)
+        float* red = reinterpret_cast<float*>(Pbuf[0]);   // 16 x 128 floats = 8 KB <= one LDS stage
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < 8; ++e) red[r0 * H + c * 8 + e] = bsum[e];
@@ -1488,11 +1488,12 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
     const int tiles = (B + Prec<T>::ROWS - 1) / Prec<T>::ROWS;
     for (int l = hp.L - 1; l >= 0; --l) {
         LayerArgs a{};
-        a.x_in = ws + lay.dx[l + 1]; a.x_out = ws + lay.dx[0]; a.maskbits = reinterpret_cast<unsigned*>(ws + lay.mask[l]);
+        a.x_in = ws + lay.dx[l + 1]; a.x_out = ws + lay.dx[l]; a.maskbits = reinterpret_cast<unsigned*>(ws + lay.mask[l]);
         a.hb = ws + lay.hb[l]; a.t1 = ws + lay.t1[l]; a.dh = ws + lay.dh[l]; a.du = ws + lay.du[l]; a.x_act = ws + lay.x[0];
         a.g_prev = (l + 2 <= hp.L) ? ws + lay.dx[l + 2] : nullptr; a.d_in = (l + 1 < hp.L) ? ws + lay.dd[l + 1] : nullptr; a.d_out = ws + lay.dd[l];
         a.wpack = ws + lay.wpack; a.bias = reinterpret_cast<const float*>(ws + lay.bias);
         a.prog = p->d_tables + hp.bwd_prog_off[l]; a.B = B; a.NN = hp.NN; a.n_mlp = std::max(1, hp.n_mlp);
+        { const char* e = getenv("MSHGNN_DBG"); a.dbg = e ? atoi(e) : 0; }
         ProfScope ps(p, hp.ks_layer_bwd0 + (hp.L - 1 - l), st);
         hipLaunchKernelGGL(k_layer_bwd<T>, dim3(tiles), dim3(LAYER_THREADS), hp.n_blk * Prec<T>::BLK, st, a);
     }
@@ -1500,6 +1501,7 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
         GradwArgs a{};
         a.ws = ws;
         for (int l = 0; l <= hp.L; ++l) { a.buf_off[BUF_X + l] = lay.x[l]; a.buf_off[BUF_DX + l] = lay.dx[l]; }
+        for (int l = 0; l < hp.L; ++l) a.buf_off[BUF_MASK + l] = lay.mask[l];
         for (int l = 0; l < hp.L; ++l) { a.buf_off[BUF_DH + l] = lay.dh[l]; a.buf_off[BUF_HB + l] = lay.hb[l]; a.buf_off[BUF_T1 + l] = lay.t1[l]; a.buf_off[BUF_DU + l] = lay.du[l]; }
         for (int t = 0; t < hp.NT; ++t) {
             a.x[t] = x[t]; a.pitch[t] = x_pitch ? x_pitch[t] : d.type_width[t]; a.nodes[t] = d.type_nodes[t];

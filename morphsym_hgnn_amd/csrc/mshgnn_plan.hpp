@@ -50,7 +50,9 @@ constexpr int WPROG_LEN = 128;
 enum { BH_NGROUPS = 0, BH_NMLP, BH_W2, BH_W1, BH_HAS_DELTA, BH_KIND = 8, BH_NFLAGS = 8 + 64, BH_MLPNODES = 8 + 128, BH_SIZE = 8 + 128 + GMAX };
 
 // buffer ids used by weight-gradient items
-enum { BUF_X = 0, BUF_DX = 17, BUF_DH = 34, BUF_HB = 50, BUF_T1 = 66, BUF_DU = 82, BUF_IN = 98, BUF_COUNT = 102 };   // (dd: D_l deltas are not read by the weight-gradient kernel)
+enum { BUF_X = 0, BUF_DX = 17, BUF_DH = 34, BUF_HB = 50, BUF_T1 = 66, BUF_DU = 82, BUF_IN = 98, BUF_MASK = 102, BUF_COUNT = 118 };   // (dd: D_l deltas are not read by the weight-gradient kernel)
+// last item int: relu-bit buffer (BUF_MASK + l) when P = dX_{l+1}[node] . relu bits (dH of a relu node is recomputed
+// by the weight-gradient kernel instead of being written by k_layer_bwd and read back), else -1
 constexpr int ITEM_INTS = 10;   // p_buf p_nodes*H p_node q_buf (q_nodes*H | -1: raw input) q_node q_col0 q_ncols sign_off pad
 constexpr int TGT_INTS = 8;     // lane_begin lane_end bias_flag pad..
 constexpr int LANE_INTS = 4;    // item_begin item_end target bias_flag
@@ -424,7 +426,7 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
     std::vector<int> item_cluster;             // L2-sharing cluster of each item (same destination-node quarter / layer)
     std::vector<Tgt> tgts;
     auto add_item = [&](int pb, int ps, int po, int qb, int qs, int qo, int qc0, int qn, int so) {
-        items.push_back({pb, ps, po, qb, qs, qo, qc0, qn, so, 0});
+        items.push_back({pb, ps, po, qb, qs, qo, qc0, qn, so, -1});
         // cluster key: which rows the item's P operand streams (buffer, node quarter): items with the same P share an XCD
         const int pnode = po, ptype_nodes = std::max(1, ps / H);
         item_cluster.push_back(pb * 4 + (pnode * 4) / ptype_nodes % 4);
@@ -439,6 +441,7 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
             for (int i = 0; i < d.type_nodes[t]; ++i) {
                 const int n = p.type_base[t] + i;
                 g.items.push_back(add_item(BUF_DH + l, SN, n, BUF_X + l, SN, n, 0, H, -1));
+                if (!(has_mlp && t == d.mlp_type)) { items.back()[0] = BUF_DX + l + 1; items.back()[9] = BUF_MASK + l; }
                 exec_bwd += NL; alg_bwd += NL;
             }
             tgt_root[l * NT + t] = (int)tgts.size(); tgts.push_back(g);
@@ -451,6 +454,7 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
                 const int j = p.edges[2 * e], i = p.edges[2 * e + 1];
                 g.items.push_back(add_item(BUF_DH + l, SN, p.type_base[p.rel_dst[r]] + i,
                                            BUF_X + l, SN, p.type_base[p.rel_src[r]] + j, 0, H, -1));
+                if (!(has_mlp && p.rel_dst[r] == d.mlp_type)) { items.back()[0] = BUF_DX + l + 1; items.back()[9] = BUF_MASK + l; }
                 exec_bwd += NL; if (!hit[i]) { hit[i] = true; alg_bwd += NL; }
             }
             tgt_rel[l * NR + r] = (int)tgts.size(); tgts.push_back(g);
@@ -625,7 +629,7 @@ inline void layout_workspace(const HostPlan& p, int64_t B, int training, mshgnn_
     for (int l = 0; l < p.L; ++l) { o->mask[l] = take((size_t)B * p.NN * 4 * 4); o->hb[l] = take(mlp); o->t1[l] = take(mlp); }
     if (training) {
         for (int l = 0; l <= p.L; ++l) o->dx[l] = take(act);
-        for (int l = 0; l < p.L; ++l) { o->dh[l] = take(act); o->du[l] = take(mlp); o->dd[l] = take(act); }
+        for (int l = 0; l < p.L; ++l) { o->dh[l] = take(act); o->du[l] = take(mlp); }
         o->slabs = take((size_t)p.n_slabs * SLAB_FLOATS * 4);
         o->dec_slabs = take((size_t)NWG_DEC * DEC_SLAB_FLOATS * 4);
     }
