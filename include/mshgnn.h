@@ -160,6 +160,12 @@ int mshgnn_backward_mse(const mshgnn_plan* plan, const void* const* x, const int
                         const float* out, const float* y, float* loss_out, float* grad_params, void* workspace,
                         int64_t batch, void* stream);
 
+/* Adam on the flat fp32 buffers (configure_optimizers, gnnLightning.py:258-265; torch.optim.Adam defaults, no weight
+ * decay / amsgrad).  step is 1-based; grads are multiplied by grad_scale first (1/world_size after a sum all-reduce).
+ * All four buffers: device fp32, n elements, 16-byte aligned; updated in place.                                     */
+int mshgnn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t step,
+                     float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
+
 /* Loss of the Lightning wrapper (gnnLightning.py:633-639): loss = mean((out - y)^2) over n elements and
  * grad_out = 2 (out - y) / n.  loss_out: device float[1].                                               */
 int mshgnn_mse_loss(const float* out, const float* y, int64_t n, float* loss_out, float* grad_out, void* stream);

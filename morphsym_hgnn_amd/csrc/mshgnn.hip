@@ -15,6 +15,7 @@
 // No CPU fallback exists: every entry point launches HIP kernels or fails loudly.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1550,6 +1551,43 @@ extern "C" int mshgnn_backward_mse(const mshgnn_plan* p, const void* const* x, c
     if (batch < 1 || batch > (1 << 24)) return set_err(MSHGNN_EINVAL, "batch must be in [1, 2^24]");
     if (p->hp.d.dtype == MSHGNN_F32) return backward_impl<float>(p, x, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, (hipStream_t)stream, out, y, loss_out);
     return backward_impl<__bf16>(p, x, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, (hipStream_t)stream, out, y, loss_out);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Adam on the flat fp32 buffers (configure_optimizers: optim.Adam(self.parameters(), lr), gnnLightning.py:258-265;
+// torch defaults beta=(0.9, 0.999), eps=1e-8, no weight decay, no amsgrad).  SURVEY.md section 8(f) row 2.
+// ------------------------------------------------------------------------------------------------------
+__global__ void k_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
+                       float bc1, float bc2_sqrt, float gscale) {
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * blockDim.x * 4) {
+        if (i + 4 <= n) {
+            f32x4 pp = *reinterpret_cast<f32x4*>(p + i), gg = *reinterpret_cast<const f32x4*>(g + i) * gscale;
+            f32x4 mm = *reinterpret_cast<f32x4*>(m + i), vv = *reinterpret_cast<f32x4*>(v + i);
+            mm = b1 * mm + (1.f - b1) * gg;
+            vv = b2 * vv + (1.f - b2) * gg * gg;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pp[e] -= lr / bc1 * mm[e] / (sqrtf(vv[e]) / bc2_sqrt + eps);
+            *reinterpret_cast<f32x4*>(p + i) = pp; *reinterpret_cast<f32x4*>(m + i) = mm; *reinterpret_cast<f32x4*>(v + i) = vv;
+        } else {
+            for (int64_t k = i; k < n; ++k) {
+                const float gg = g[k] * gscale;
+                m[k] = b1 * m[k] + (1.f - b1) * gg; v[k] = b2 * v[k] + (1.f - b2) * gg * gg;
+                p[k] -= lr / bc1 * m[k] / (sqrtf(v[k]) / bc2_sqrt + eps);
+            }
+        }
+    }
+}
+
+extern "C" int mshgnn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t step,
+                                float lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || n < 1 || step < 1) return set_err(MSHGNN_EINVAL, "bad argument to mshgnn_adam_step");
+    if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return set_err(MSHGNN_EINVAL, "adam buffers must be 16-byte aligned");
+    const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+    const int blocks = (int)std::min<int64_t>((n / 4 + 255) / 256 + 1, 2048);
+    hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps,
+                       bc1, sqrtf(bc2), grad_scale);
+    HIPCHK(hipGetLastError());
+    return MSHGNN_OK;
 }
 
 extern "C" int mshgnn_mse_loss(const float* out, const float* y, int64_t n, float* loss_out, float* grad_out, void* stream) {

@@ -65,7 +65,7 @@ class MshgnnKernelStat(C.Structure):
 EXPORTS = [
     "mshgnn_last_error", "mshgnn_version", "mshgnn_plan_create", "mshgnn_plan_destroy", "mshgnn_plan_info",
     "mshgnn_plan_compile_host", "mshgnn_workspace_layout", "mshgnn_forward", "mshgnn_backward", "mshgnn_mse_loss",
-    "mshgnn_profile_enable", "mshgnn_profile_read", "mshgnn_backward_mse",
+    "mshgnn_profile_enable", "mshgnn_profile_read", "mshgnn_backward_mse", "mshgnn_adam_step",
 ]
 
 _lib = None
@@ -103,6 +103,8 @@ def load_library():
                                     C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.mshgnn_backward_mse.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.mshgnn_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_float, C.c_float,
+                                     C.c_float, C.c_float, C.c_float, C.c_void_p]
     lib.mshgnn_profile_enable.argtypes = [C.c_void_p, C.c_int]
     lib.mshgnn_profile_read.argtypes = [C.c_void_p, C.POINTER(MshgnnKernelStat), C.POINTER(C.c_int32)]
     lib.mshgnn_mse_loss.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -348,6 +350,15 @@ class Engine:
         _check(self.lib, self.lib.mshgnn_backward_mse(self._plan, ptrs, pitch, params_flat.data_ptr(), out.data_ptr(), y.data_ptr(),
                                                       loss.data_ptr(), grad_flat.data_ptr(), ws.data_ptr(), B, stream), "mshgnn_backward_mse")
         return loss, grad_flat
+
+    def adam_step(self, params_flat: torch.Tensor, grad_flat: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor,
+                  step: int, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, grad_scale: float = 1.0):
+        """torch.optim.Adam semantics on the flat buffers, in place (gnnLightning.py:258-265)."""
+        for t, n in ((params_flat, "params"), (grad_flat, "grads"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+            self._check_flat(t, n)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _check(self.lib, self.lib.mshgnn_adam_step(params_flat.data_ptr(), grad_flat.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
+                                                   params_flat.numel(), step, lr, betas[0], betas[1], eps, grad_scale, stream), "mshgnn_adam_step")
 
     def mse_loss(self, out: torch.Tensor, y: torch.Tensor, want_grad: bool = True):
         """Wrapper loss (gnnLightning.py:633-639): returns (loss[1], dL/d out or None)."""

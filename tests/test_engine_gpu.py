@@ -138,3 +138,29 @@ def test_fused_mse_backward_equals_two_step():
     torch.cuda.synchronize()
     assert abs(float(loss1) - float(loss2)) / float(loss1) < 1e-5
     assert float((g1 - g2).abs().max() / g1.abs().max()) < 1e-6
+
+
+def test_adam_step_matches_torch_adam():
+    """mshgnn_adam_step vs torch.optim.Adam (fp64, CPU) over 3 steps of the engine's own gradients (optimizer
+    pinned by post-step parameters)."""
+    _require_gpu()
+    from morphsym_hgnn_amd import engine as eng, synth
+    spec = helpers.make_spec("c2", "a1-c2", "a1-c2", 128, 2)
+    B = 5
+    e = eng.Engine(spec, "f32")
+    x_dict, y = synth.make_windows(3, B, spec.num_nodes, spec.widths, 12)
+    xs = e.cast_inputs(x_dict)
+    flat = eng.flatten_params(spec, synth.make_params(3, spec.param_shapes()), e.device)
+    m = torch.zeros_like(flat); v = torch.zeros_like(flat)
+    ref = flat.detach().cpu().double().clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1e-3)
+    yd = y.reshape(-1).to(e.device, torch.float32)
+    for step in range(1, 4):
+        out = e.forward(xs, flat, B)
+        _, g = e.backward_mse(xs, flat, out, yd, B)
+        ref.grad = g.detach().cpu().double()
+        opt.step()
+        e.adam_step(flat, g, m, v, step, lr=1e-3)
+        torch.cuda.synchronize()
+        delta_ref = (ref.detach() - flat.cpu().double()).abs().max()
+        assert float(delta_ref) < 2e-6, (step, float(delta_ref))   # updates are O(lr)=1e-3; fp32 state vs fp64 reference
