@@ -62,7 +62,7 @@ template <> struct Prec<float> {
     struct BFrag { f32x4 v[16]; };
 };
 template <> struct Prec<__bf16> {
-    static constexpr int ROWS = 16, EPC = 8, CPR = 16, RB = 256, NREG = 8, NBV = 8, NAV = 4, HS = 4, BLK = 4096, ENC_MB = 8, WPS = 4;   // 2 workgroups of 8 waves per CU (80 KB LDS each)
+    static constexpr int ROWS = 16, EPC = 8, CPR = 16, RB = 256, NREG = 8, NBV = 8, NAV = 4, HS = 4, BLK = 4096, ENC_MB = 4, WPS = 4;   // 2 workgroups of 8 waves per CU (80 KB LDS each)
     using Vec = bf16x8;
     struct Acc { f32x4 c[2]; };
     struct AFrag { bf16x8 v[4]; };
@@ -1070,12 +1070,18 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16* tile, int w_base, int co
     return __builtin_bit_cast(bf16x8, v);
 }
 
-__global__ __launch_bounds__(256) void k_gradw_bf16(GradwArgs a) {
+#ifndef GW_WPS
+#define GW_WPS 3
+#endif
+__global__ __launch_bounds__(256, GW_WPS) void k_gradw_bf16(GradwArgs a) {
     using T = __bf16;
     // two LDS stages: the staging writes of step s+1 go to the other stage while step s's MFMAs read this one -> one
     // barrier per step and LDS writes overlap the MFMAs
-    __shared__ __attribute__((aligned(16))) __bf16 Pbuf[2][GWB_KW * GWB_PITCH];
-    __shared__ __attribute__((aligned(16))) __bf16 Qbuf[2][GWB_KW * GWB_PITCH];
+#ifndef GW_DEEP
+#define GW_DEEP 0   // measured: the shallow pipeline at 3 workgroups/CU (132 us) beats the deep one at 2 (153 us)
+#endif
+    __shared__ __attribute__((aligned(16))) __bf16 Pbuf[1 + GW_DEEP][GWB_KW * GWB_PITCH];
+    __shared__ __attribute__((aligned(16))) __bf16 Qbuf[1 + GW_DEEP][GWB_KW * GWB_PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wv >> 1, wc = wv & 1;
     // blocks b and b+8 share an XCD (round-robin dispatch; speed only): lane_order puts the lanes that read the same
@@ -1179,6 +1185,7 @@ __global__ __launch_bounds__(256) void k_gradw_bf16(GradwArgs a) {
     // s+2 is being fetched).
     const u32x4 sx1 = nit == 2 ? qsign[1] : qsign[0];
     const int qn1 = nit == 2 ? qvalid[1] : qvalid[0];
+#if GW_DEEP
     Stage sa, sb;
     if (nsteps > 0) fetch(sa, 0);
     if (nsteps > 1) fetch(sb, 1);
@@ -1199,6 +1206,20 @@ __global__ __launch_bounds__(256) void k_gradw_bf16(GradwArgs a) {
             __syncthreads();
         }
     }
+#else
+    // shallow variant: one register stage, one LDS stage, two barriers per step -- fewer registers / less LDS, one more
+    // resident workgroup per CU
+    Stage sa;
+    if (nsteps > 0) fetch(sa, 0);
+    for (int s = 0; s < nsteps; ++s) {
+        __syncthreads();
+        stage_to_lds(sa, (nit == 2 && (s & 1)) ? qsign[1] : qsign[0], (nit == 2 && (s & 1)) ? qvalid[1] : qvalid[0], Pbuf[0], Qbuf[0]);
+        __syncthreads();
+        if (s + 1 < nsteps) fetch(sa, s + 1);
+        mfmas(Pbuf[0], Qbuf[0]);
+    }
+    (void)sx1; (void)qn1;
+#endif
     float* slab = a.slabs + (size_t)(part * a.n_lanes + ln) * SLAB_FLOATS;
     if (!(a.dbg & 8))
 #pragma unroll

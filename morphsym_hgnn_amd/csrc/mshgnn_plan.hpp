@@ -513,7 +513,7 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
         tgt_lane_end[g] = (int)lanes.size();
     }
     p.n_lanes = (int)lanes.size();
-    p.n_parts = std::max(1, std::min(16, (int)std::lround(512.0 / std::max(1, p.n_lanes))));
+    p.n_parts = std::max(1, std::min(16, (int)std::lround(512.0 / std::max(1, p.n_lanes))));   // ~2 per CU: more parts only add slabs (measured)
     // XCD placement: cluster -> least-loaded XCD queue (largest clusters first); block b runs queue[b % 8][b / 8]
     std::vector<int> lane_cluster(p.n_lanes), flat_item_cluster;
     for (size_t g = 0; g < tgts.size(); ++g) for (int it : tgts[g].items) flat_item_cluster.push_back(item_cluster[it]);
@@ -551,8 +551,11 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
     // finalize ops: every parameter is written exactly once
     p.fin_off = (int)T.size(); p.n_fin = 0;
     auto add_fin = [&](int64_t dst, int rows, int cols, int ld, int target, int kind) {
+        // (merging ops that share a slab sum into one multi-destination op was measured slower: the kernel is bound by
+        //  the serial slab chain per thread, so fewer, fatter ops lose parallelism)
         T.push_back((int32_t)(dst & 0xffffffff)); T.push_back((int32_t)(dst >> 32)); T.push_back(rows); T.push_back(cols);
-        T.push_back(ld); T.push_back(target); T.push_back(kind); T.push_back(0); ++p.n_fin; };
+        T.push_back(ld); T.push_back(target); T.push_back(kind); T.push_back(0);
+        ++p.n_fin; };
     for (int t = 0; t < NT; ++t) {
         const int F = d.type_width[t];
         for (int kc = 0; kc < p.enc_nkc[t]; ++kc) {
