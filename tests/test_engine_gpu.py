@@ -164,3 +164,40 @@ def test_adam_step_matches_torch_adam():
         torch.cuda.synchronize()
         delta_ref = (ref.detach() - flat.cpu().double()).abs().max()
         assert float(delta_ref) < 2e-6, (step, float(delta_ref))   # updates are O(lr)=1e-3; fp32 state vs fp64 reference
+
+
+def test_step_is_hip_graph_capturable():
+    """forward + fused-loss backward launch only kernels on the caller's stream (no allocation / sync inside the C-ABI),
+    so a whole step can be captured in a HIP graph and replayed; replay reproduces the eager gradients bit for bit."""
+    _require_gpu()
+    from morphsym_hgnn_amd import engine as eng, synth
+    spec = helpers.make_spec("c2", "a1-c2", "a1-c2", 128, 3)
+    B = 64
+    e = eng.Engine(spec, "bf16")
+    x_dict, y = synth.make_windows(4, B, spec.num_nodes, spec.widths, 12)
+    xs = e.cast_inputs(x_dict)
+    flat = eng.flatten_params(spec, synth.make_params(4, spec.param_shapes()), e.device)
+    yd = y.reshape(-1).to(e.device, torch.float32)
+    out = torch.empty(B * 4, 3, dtype=torch.float32, device=e.device)
+    gflat = torch.empty_like(flat)
+    loss = torch.empty(1, device=e.device)
+
+    def step():
+        e.forward(xs, flat, B, training=True, out=out)
+        e.backward_mse(xs, flat, out, yd, B, grad_flat=gflat, loss=loss)
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        step()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    ref = gflat.clone()
+    ref_loss = float(loss)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        step()
+    gflat.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(gflat, ref) and float(loss) == ref_loss
