@@ -134,7 +134,8 @@ class _MSHGNNBase(nn.Module):
         widths = {t: int(x_dict[t].shape[1]) for t in self._node_types}
         return ModelSpec(kind=self.kind, topology=topo, hidden=self.hidden_channels, num_layers=self.num_layers,
                          widths=widths, regression=self.regression, grf_dimension=getattr(self, "grf_dimension", 1),
-                         group=self._group, num_timesteps=getattr(self, "num_timesteps", 150))
+                         group=self._group, num_timesteps=getattr(self, "num_timesteps", 150),
+                         com_dimension=getattr(self, "num_dimensions_per_base", 6) if self.kind == "s4_com" else 6)
 
     def _named_in_flat_order(self):
         sd = dict(self.named_parameters())
@@ -203,7 +204,9 @@ class _MSHGNNBase(nn.Module):
         out = out.to(device=in_dev, dtype=in_dtype if in_dtype.is_floating_point else torch.float32)
         if spec.output_is_window_major:
             return out.view(B, -1)      # ms_foot_decoder: [B, 4*3]   (hgnn_c2.py:184-189)
-        return out                      # [B*4, out_channels_per_foot]
+        if spec.kind in ("k4_com", "c2_com"):
+            return out.view(B, spec.num_nodes["base"], spec.out_channels)   # morphological_symmetry_decoder, hgnn_k4_com.py:157-165
+        return out                      # [B*4, out_channels_per_foot]  (COM S4 / COM_HGNN: [B, com_dimension])
 
     # ---- reference helper kept for API compatibility ------------------------------------------------------
     def apply_symmetry(self, x_dict):
@@ -306,3 +309,76 @@ class GRF_HGNN(_MSHGNNBase):
         else:
             self.out_channels_per_foot = 2
         self.decoder = pnn.Linear(hidden_channels, self.out_channels_per_foot)
+
+
+class _COMSymBase(_MSHGNNBase):
+    """Shared constructor of the Solo centroidal-momentum MS-HGNNs: joints carry (q, qd) of one time step, the decoder
+    reads the base nodes and emits [lin(3) | ang(3)] per base node (hgnn_k4_com.py:22-123, hgnn_c2_com.py:22-108)."""
+    _mean_rels = ("gt", "gs")
+
+    def __init__(self, hidden_channels: int, num_layers: int, data_metadata, regression: bool = True,
+                 activation_fn=nn.ReLU(), symmetry_mode: str = None, group_operator_path: str = None):
+        super().__init__()
+        self._init_common(hidden_channels, num_layers, data_metadata, regression, activation_fn)
+        self.num_timesteps = 1             # hgnn_k4_com.py:29
+        self.num_legs = 4
+        self.num_joints = 12
+        self.num_dimensions_per_base = 6
+        self._group = _load_group(symmetry_mode, group_operator_path)
+        self._build_convs(mean_rels=self._mean_rels)
+        h = hidden_channels
+        self.base_transform = nn.Sequential(nn.Linear(h, h), nn.ReLU(), nn.Linear(h, h))
+        self.decoder = pnn.Linear(h, self.num_dimensions_per_base)
+        coeffs = ModelSpec.symmetry_coefficients(GRF_HGNN_C2._coeff_probe(self))
+        self.joints_linear_weights, _, self.base_coefficients_lin, self.base_coefficients_ang = coeffs
+
+    def morphological_symmetry_decoder(self, x):
+        """The reference's output mask as a standalone helper (hgnn_k4_com.py:157-165); forward() already applies it
+        inside the decoder kernel."""
+        nb = self.num_bases
+        x = x.reshape(-1, nb, 6)
+        m = torch.cat((self.base_coefficients_lin.view(nb, 3), self.base_coefficients_ang.view(nb, 3)), dim=1)
+        return x * m.to(x.device, x.dtype).unsqueeze(0)
+
+
+class COM_HGNN_K4(_COMSymBase):
+    """Centroidal-momentum MS-HGNN on the Solo K4 graph (4 base nodes) -- drop-in for hgnn_k4_com.py:COM_HGNN_K4."""
+    kind = "k4_com"
+    num_bases = 4
+
+
+class COM_HGNN_C2(_COMSymBase):
+    """Centroidal-momentum MS-HGNN on the Solo C2 graph (2 base nodes) -- drop-in for hgnn_c2_com.py:COM_HGNN_C2."""
+    kind = "c2_com"
+    num_bases = 2
+
+
+class COM_HGNN_S4(_MSHGNNBase):
+    """Centroidal-momentum baseline on the single-base graph (no masks / base MLP / residual) -- drop-in for
+    hgnn_s4_com.py:COM_HGNN_S4.  symmetry_mode / group_operator_path are accepted and unused, as in the reference."""
+    kind = "s4_com"
+    num_bases = 1
+
+    def __init__(self, hidden_channels: int, num_layers: int, data_metadata, regression: bool = True,
+                 activation_fn=nn.ReLU(), symmetry_mode: str = None, group_operator_path: str = None):
+        super().__init__()
+        self._init_common(hidden_channels, num_layers, data_metadata, regression, activation_fn)
+        self.num_legs = 4
+        self.num_joints = 12
+        self.num_dimensions_per_base = 6
+        self._build_convs(mean_rels=())
+        self.decoder = pnn.Linear(hidden_channels, self.num_dimensions_per_base)
+
+
+class COM_HGNN(_MSHGNNBase):
+    """MI-HGNN with the decoder on the base node -- drop-in for hgnn.py:COM_HGNN (hgnn.py:66-117)."""
+    kind = "s4_com"
+    num_bases = 1
+
+    def __init__(self, hidden_channels: int, num_layers: int, data_metadata, regression: bool = True,
+                 activation_fn=nn.ReLU(), com_dimension: int = 6):
+        super().__init__()
+        self._init_common(hidden_channels, num_layers, data_metadata, regression, activation_fn)
+        self.num_dimensions_per_base = com_dimension
+        self._build_convs(mean_rels=())
+        self.decoder = pnn.Linear(hidden_channels, self.num_dimensions_per_base)

@@ -14,7 +14,8 @@ import torch
 
 from .topology import EdgeType, RobotTopology
 
-KINDS = ("c2", "k4", "mi")
+KINDS = ("c2", "k4", "mi", "k4_com", "c2_com", "s4_com")
+COM_KINDS = ("k4_com", "c2_com", "s4_com")   # Solo centroidal-momentum variants: decoder on base nodes, T=1 (hgnn_*_com.py)
 
 
 def rel_key(et: EdgeType) -> str:
@@ -27,7 +28,7 @@ def relation_aggr(kind: str, et: EdgeType) -> str:
     (hgnn_k4.py:107-119), 'add' otherwise."""
     if kind == "c2" and et[1] == "center_bb":
         return "mean"
-    if kind == "k4" and et[1] in ("gt", "gs"):
+    if kind in ("k4", "k4_com", "c2_com") and et[1] in ("gt", "gs"):   # hgnn_k4_com.py:93-103, hgnn_c2_com.py:72-83
         return "mean"
     return "add"
 
@@ -44,6 +45,7 @@ class ModelSpec:
     group: Optional[dict] = None            # parsed group-operator YAML (None => all masks +1)
     num_timesteps: int = 150                # hgnn_c2.py:30 / hgnn_k4.py:29
     out_type: str = "foot"
+    com_dimension: int = 6                   # decoder width per base node of the COM variants (hgnn.py:73,93)
 
     def __post_init__(self):
         if self.kind not in KINDS:
@@ -51,6 +53,17 @@ class ModelSpec:
         for t in self.node_types:
             if t not in self.widths:
                 raise ValueError(f"missing input width for node type {t!r}")
+        if self.kind in COM_KINDS:
+            self.out_type = "base"
+            self.num_timesteps = 1
+            nb = {"k4_com": 4, "c2_com": 2, "s4_com": 1}[self.kind]
+            nn_ = self.topology.num_nodes
+            if nn_.get("base") != nb or (self.kind != "s4_com" and "foot" in nn_):
+                raise ValueError(f"{self.kind} model expects {nb} base nodes and no foot type, got {nn_}")
+            if self.kind != "s4_com" and self.com_dimension != 6:
+                raise ValueError("COM K4/C2 models decode 6 values (lin 3 + ang 3) per base node")
+            if self.kind != "s4_com" and (nn_.get("joint") != 12 or self.widths["joint"] != 2):
+                raise ValueError("COM K4/C2 models expect 12 joint nodes with 2 features (hgnn_k4_com.py:163-166)")
         if self.kind in ("c2", "k4"):
             nb = 2 if self.kind == "c2" else 4
             nn_ = self.topology.num_nodes
@@ -91,15 +104,17 @@ class ModelSpec:
 
     @property
     def has_base_transform(self) -> bool:
-        return self.kind in ("c2", "k4")
+        return self.kind in ("c2", "k4", "k4_com", "c2_com")
 
     @property
     def residual(self) -> bool:
-        return self.kind in ("c2", "k4")
+        return self.kind in ("c2", "k4", "k4_com", "c2_com")
 
     @property
     def out_channels(self) -> int:
-        """out_channels_per_foot (hgnn_c2.py:124-129, hgnn_k4.py:139-143, hgnn.py:49-54)."""
+        """out_channels_per_foot (hgnn_c2.py:124-129, hgnn_k4.py:139-143, hgnn.py:49-54); 6 per base for COM."""
+        if self.kind in COM_KINDS:
+            return self.com_dimension                  # num_dimensions_per_base, hgnn_k4_com.py:34,123
         if self.kind == "k4":
             return 1 if self.regression else 2
         if self.regression and self.grf_dimension == 1:
@@ -174,13 +189,22 @@ class ModelSpec:
         """(joint[12], foot[12], base_lin[3nb], base_ang[3nb]) float64 -- hgnn_c2.py:44-83, hgnn_k4.py:37-95."""
         f64 = torch.float64
         one3 = torch.ones(3, dtype=f64)
-        if self.kind == "mi":
+        if self.kind in ("mi", "s4_com"):
             return None
         nb = self.num_nodes["base"]
         g = self.group
         if g is None:
             return (torch.ones(12, dtype=f64), torch.ones(12, dtype=f64),
                     torch.ones(3 * nb, dtype=f64), torch.ones(3 * nb, dtype=f64))
+        if self.kind in ("k4_com", "c2_com"):   # hgnn_k4_com.py:37-80, hgnn_c2_com.py:37-68 (no foot space)
+            def row3(key, i):
+                return torch.tensor(g[key][i][:3], dtype=f64)
+            j_gs, bl_gs, ba_gs = row3("reflection_Q_js", 0), row3("reflection_Q_bs_lin", 0), row3("reflection_Q_bs_ang", 0)
+            if self.kind == "c2_com":
+                return (torch.cat((one3, one3, j_gs, j_gs)), None, torch.cat((one3, bl_gs)), torch.cat((one3, ba_gs)))
+            j_gt, bl_gt, ba_gt = row3("reflection_Q_js", 1), row3("reflection_Q_bs_lin", 1), row3("reflection_Q_bs_ang", 1)
+            return (torch.cat((one3, j_gt, j_gs, j_gs * j_gt)), None,
+                    torch.cat((one3, bl_gt, bl_gs, bl_gs * bl_gt)), torch.cat((one3, ba_gt, ba_gs, ba_gs * ba_gt)))
 
         def row(key, i):
             return torch.tensor(g[key][i][:3], dtype=f64)
@@ -199,7 +223,11 @@ class ModelSpec:
         """+-1 mask [n_type, F_type] (float64) per node type; all-ones where apply_symmetry does nothing.
         Net effect of apply_symmetry / unpack_data / pack_data (hgnn_c2.py:191-284)."""
         masks = {t: torch.ones(self.num_nodes[t], self.widths[t], dtype=torch.float64) for t in self.node_types}
-        if self.kind == "mi":
+        if self.kind in ("mi", "s4_com"):
+            return masks
+        if self.kind in ("k4_com", "c2_com"):    # only the joints are masked (hgnn_k4_com.py:159-168)
+            cj = self.symmetry_coefficients()[0]
+            masks["joint"] = cj.view(12, 1).expand(12, self.widths["joint"]).clone()
             return masks
         T = self.num_timesteps
         cj, cf, cbl, cba = self.symmetry_coefficients()
@@ -220,6 +248,9 @@ class ModelSpec:
         if self.kind == "c2" and self.regression and self.grf_dimension == 3:
             _, cf, _, _ = self.symmetry_coefficients()
             m = cf.view(n, 3).clone()
+        if self.kind in ("k4_com", "c2_com"):   # morphological_symmetry_decoder: [lin(3) | ang(3)] per base node
+            _, _, cbl, cba = self.symmetry_coefficients()
+            m = torch.cat((cbl.view(n, 3), cba.view(n, 3)), dim=1)
         return m
 
     @property

@@ -49,6 +49,8 @@ def feature_widths(kind: str, regression: bool = True, T: int = 150) -> Dict[str
     """Per-type input width.  A1-C2 regression: 900/450/1 (quadSDKDataset_Morph.py:444-488);
     MiniCheetah (K4, C2-classification): 900/300/900 (LinTzuYaunDataset.py:79-88);
     MI-HGNN on A1: 900/450/1 with a single base node."""
+    if kind in ("k4_com", "c2_com", "s4_com"):       # Solo COM: T=1, joint (q, qd), base 6 (soloDataset.py:382-400)
+        return {"base": 6, "joint": 2}
     if kind == "k4" or (kind == "c2" and not regression):
         return {"base": 6 * T, "joint": 2 * T, "foot": 6 * T}
     return {"base": 6 * T, "joint": 3 * T, "foot": 1}
@@ -69,7 +71,9 @@ def make_windows(seed: int, batch_size: int, num_nodes: Dict[str, int], widths: 
         imu[:, :, 3 * T:] *= 0.5               # ang vel
     base = imu.expand(B, num_nodes["base"], T6).reshape(B * num_nodes["base"], T6).clone()
     joint = det_normal(seed, "joint", (B * num_nodes["joint"], widths["joint"]), std=2.0 if physical_scale else 1.0)
-    if widths["foot"] == 1:
+    if "foot" not in num_nodes:
+        foot = None
+    elif widths["foot"] == 1:
         foot = torch.ones(B * num_nodes["foot"], 1, dtype=torch.float64)
     else:
         foot = det_normal(seed, "foot", (B * num_nodes["foot"], widths["foot"]))
@@ -77,7 +81,10 @@ def make_windows(seed: int, batch_size: int, num_nodes: Dict[str, int], widths: 
         y = (det_uniform(seed, "y", (B, out_width)) > 0).to(torch.float64)
     else:
         y = det_normal(seed, "y", (B, out_width), std=30.0 if physical_scale else 1.0)
-    return {"base": base, "joint": joint, "foot": foot}, y
+    x = {"base": base, "joint": joint}
+    if foot is not None:
+        x["foot"] = foot
+    return x, y
 
 
 def make_params(seed: int, shapes: Dict[str, Tuple[int, ...]]) -> Dict[str, torch.Tensor]:

@@ -158,11 +158,61 @@ def quadruped_mi() -> RobotTopology:
     )
 
 
+def solo_k4_com() -> RobotTopology:
+    """Solo-12 K4 graph of the centroidal-momentum task: 4 base + 12 joint, no foot type, 5 relations
+    (soloDataset.py:207-214 relation order, :455-487 edges; note gs/gt pairs are swapped vs MiniCheetah)."""
+    bj = [[b, 3 * b] for b in range(4)]
+    return RobotTopology(
+        name="solo-k4-com",
+        num_nodes={"base": 4, "joint": 12},
+        relations=[
+            (("base", "connect", "joint"), bj),
+            (("joint", "connect", "base"), [[j, b] for b, j in bj]),
+            (("joint", "connect", "joint"), _leg_chain_edges()),
+            (("base", "gt", "base"), [[0, 2], [2, 0], [1, 3], [3, 1]]),
+            (("base", "gs", "base"), [[0, 1], [1, 0], [2, 3], [3, 2]]),
+        ],
+    )
+
+
+def solo_c2_com() -> RobotTopology:
+    """Solo-12 C2 graph of the COM task: 2 base + 12 joint (soloDataset.py:224-232, :489-512)."""
+    return RobotTopology(
+        name="solo-c2-com",
+        num_nodes={"base": 2, "joint": 12},
+        relations=[
+            (("base", "front_bj", "joint"), [[0, 3], [1, 9]]),
+            (("joint", "front_bj", "base"), [[3, 0], [9, 1]]),
+            (("base", "back_bj", "joint"), [[0, 0], [1, 6]]),
+            (("joint", "back_bj", "base"), [[0, 0], [6, 1]]),
+            (("joint", "connect", "joint"), _leg_chain_edges()),
+            (("base", "center_bb", "base"), [[0, 1], [1, 0]]),
+        ],
+    )
+
+
+def solo_s4_com() -> RobotTopology:
+    """Solo-12 baseline graph of the COM task: 1 base + 12 joint, 3 relations (soloDataset.py:215-220)."""
+    bj = [[0, 3 * leg] for leg in range(4)]
+    return RobotTopology(
+        name="solo-s4-com",
+        num_nodes={"base": 1, "joint": 12},
+        relations=[
+            (("base", "connect", "joint"), bj),
+            (("joint", "connect", "base"), [[j, b] for b, j in bj]),
+            (("joint", "connect", "joint"), _leg_chain_edges()),
+        ],
+    )
+
+
 TOPOLOGIES = {
     "a1-c2": a1_c2,
     "mini_cheetah-c2": mini_cheetah_c2,
     "mini_cheetah-k4": mini_cheetah_k4,
     "quadruped-mi": quadruped_mi,
+    "solo-k4-com": solo_k4_com,
+    "solo-c2-com": solo_c2_com,
+    "solo-s4-com": solo_s4_com,
 }
 
 

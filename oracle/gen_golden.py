@@ -46,6 +46,12 @@ CASES = [
     dict(name="mck4_reg_h128_L1_B2", kind="k4", topo="mini_cheetah-k4", cfg="mini_cheetah-k4", hidden=128, layers=1, B=2, regression=True, grf=3),
     dict(name="mi_h128_L2_d1_B3", kind="mi", topo="quadruped-mi", cfg=None, hidden=128, layers=2, B=3, regression=True, grf=1),
     dict(name="mi_h128_L2_d3_B2", kind="mi", topo="quadruped-mi", cfg=None, hidden=128, layers=2, B=2, regression=True, grf=3),
+    # Solo centroidal-momentum variants (decoder on base nodes, T=1): hgnn_k4_com.py, hgnn_c2_com.py, hgnn_s4_com.py, hgnn.py:COM_HGNN
+    dict(name="solok4com_h128_L3_B5", kind="k4_com", topo="solo-k4-com", cfg="solo-k4", hidden=128, layers=3, B=5, regression=True, grf=3),
+    dict(name="solok4com_nosym_h128_L1_B2", kind="k4_com", topo="solo-k4-com", cfg=None, hidden=128, layers=1, B=2, regression=True, grf=3),
+    dict(name="soloc2com_h128_L2_B4", kind="c2_com", topo="solo-c2-com", cfg="solo-c2", hidden=128, layers=2, B=4, regression=True, grf=3),
+    dict(name="solos4com_h128_L2_B3", kind="s4_com", topo="solo-s4-com", cfg=None, hidden=128, layers=2, B=3, regression=True, grf=3),
+    dict(name="com_hgnn_h128_L2_B3", kind="s4_com", topo="solo-s4-com", cfg=None, hidden=128, layers=2, B=3, regression=True, grf=3, ref="COM_HGNN"),
 ]
 
 
@@ -90,6 +96,15 @@ def run_reference(case, topo, spec, cfg_path, params, x_dict, ei, y):
             m = load_reference_module("hgnn_k4.py").GRF_HGNN_K4(
                 case["hidden"], case["layers"], meta, regression=case["regression"],
                 symmetry_mode="MorphSym" if cfg_path else None, group_operator_path=cfg_path)
+        elif case["kind"] in ("k4_com", "c2_com"):
+            f, cls = {"k4_com": ("hgnn_k4_com.py", "COM_HGNN_K4"), "c2_com": ("hgnn_c2_com.py", "COM_HGNN_C2")}[case["kind"]]
+            m = getattr(load_reference_module(f), cls)(
+                case["hidden"], case["layers"], meta, regression=True,
+                symmetry_mode="MorphSym" if cfg_path else None, group_operator_path=cfg_path)
+        elif case["kind"] == "s4_com" and case.get("ref") == "COM_HGNN":
+            m = load_reference_module("hgnn.py").COM_HGNN(case["hidden"], case["layers"], meta, regression=True, com_dimension=6)
+        elif case["kind"] == "s4_com":
+            m = load_reference_module("hgnn_s4_com.py").COM_HGNN_S4(case["hidden"], case["layers"], meta, regression=True)
         else:
             m = load_reference_module("hgnn.py").GRF_HGNN(
                 case["hidden"], case["layers"], meta, regression=case["regression"], grf_dimension=case["grf"])
@@ -103,6 +118,13 @@ def run_reference(case, topo, spec, cfg_path, params, x_dict, ei, y):
     m.zero_grad()
     out = m({k: v.clone() for k, v in x_dict.items()}, ei)
     B = case["B"]
+    if case["kind"].endswith("_com"):      # gnnLightning_com.py:323-340 (reshape) and :96-97,121 (MSE over everything)
+        w = m.num_bases * m.num_dimensions_per_base
+        y_pred = torch.reshape(out.squeeze(), (B, w))
+        loss = ((y_pred.flatten() - torch.reshape(y, (B, w)).flatten()) ** 2).mean()
+        loss.backward()
+        grads = {k: (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p)) for k, p in m.named_parameters()}
+        return out.detach(), loss.detach(), grads, n_params
     w = m.out_channels_per_foot * 4
     y_pred = torch.reshape(out.squeeze(), (B, w))  # gnnLightning.py:691
     yy = torch.reshape(y, (B, w if case["regression"] else 4))  # gnnLightning.py:694 / :512
@@ -119,13 +141,17 @@ def run_reference(case, topo, spec, cfg_path, params, x_dict, ei, y):
 
 def main():
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
-    summary = {}
+    spath = os.path.join(ROOT, "tests", "golden", "SUMMARY.json")
+    only = sys.argv[1:]                     # optional: case-name substrings; other fixtures are left untouched
+    summary = json.load(open(spath)) if (only and os.path.exists(spath)) else {}
     for case in CASES:
+        if only and not any(o in case["name"] for o in only):
+            continue
         topo, spec, cfg_path = build_case(case)
         seed = 1234 + len(case["name"])
         B = case["B"]
         x_dict, y = synth.make_windows(seed, B, topo.num_nodes, spec.widths,
-                                       spec.out_channels * 4 if case["regression"] else 4,
+                                       spec.out_channels * topo.num_nodes[spec.out_type] if case["regression"] else 4,
                                        classification=not case["regression"])
         params = synth.make_params(seed, spec.param_shapes())
         ei = topo.edge_index_dict(B)
@@ -157,7 +183,7 @@ def main():
         summary[case["name"]] = {"n_params": n_params, "oracle_vs_reference_max_rel_err": worst,
                                  "loss": float(ref_loss)}
         print(f"{case['name']}: params={n_params} loss={float(ref_loss):.6g} oracle-vs-reference max rel err={worst:.2e}")
-    with open(os.path.join(ROOT, "tests", "golden", "SUMMARY.json"), "w") as f:
+    with open(spath, "w") as f:
         json.dump(summary, f, indent=1)
 
 

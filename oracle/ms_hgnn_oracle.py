@@ -37,7 +37,7 @@ EdgeType = Tuple[str, str, str]
 
 @dataclass
 class OracleConfig:
-    kind: str                      # 'c2' | 'k4' | 'mi'
+    kind: str                      # 'c2' | 'k4' | 'mi' | 'k4_com' | 'c2_com' | 's4_com'
     num_layers: int
     edge_types: Sequence[EdgeType]  # relation order of data_metadata[1]
     regression: bool = True
@@ -47,6 +47,8 @@ class OracleConfig:
 
     @property
     def out_channels_per_foot(self) -> int:
+        if self.kind.endswith("_com"):
+            return 6                                    # num_dimensions_per_base, hgnn_k4_com.py:34
         if self.kind == "k4":
             return 1 if self.regression else 2          # hgnn_k4.py:139-143
         if self.regression and self.grf_dimension == 1:  # hgnn_c2.py:124-129 / hgnn.py:49-54
@@ -68,9 +70,23 @@ def symmetry_coefficients(cfg: OracleConfig):
     """Returns (joint[12], foot[12], base_lin[3*nb], base_ang[3*nb]) as float64 tensors."""
     f64 = torch.float64
     one3 = torch.ones(3, dtype=f64)
-    if cfg.kind == "mi":
+    if cfg.kind in ("mi", "s4_com"):
         return None
     g = cfg.group
+    if cfg.kind in ("k4_com", "c2_com"):    # hgnn_k4_com.py:37-80 / hgnn_c2_com.py:37-68: joint + base lin/ang, no foot space
+        nb = 4 if cfg.kind == "k4_com" else 2
+        if g is None:
+            return (torch.ones(12, dtype=f64), None, torch.ones(3 * nb, dtype=f64), torch.ones(3 * nb, dtype=f64))
+        j_gs = torch.tensor(g["reflection_Q_js"][0][:3], dtype=f64)
+        bl_gs = torch.tensor(g["reflection_Q_bs_lin"][0][:3], dtype=f64)
+        ba_gs = torch.tensor(g["reflection_Q_bs_ang"][0][:3], dtype=f64)
+        if cfg.kind == "c2_com":
+            return (torch.cat((one3, one3, j_gs, j_gs)), None, torch.cat((one3, bl_gs)), torch.cat((one3, ba_gs)))
+        j_gt = torch.tensor(g["reflection_Q_js"][1][:3], dtype=f64)
+        bl_gt = torch.tensor(g["reflection_Q_bs_lin"][1][:3], dtype=f64)
+        ba_gt = torch.tensor(g["reflection_Q_bs_ang"][1][:3], dtype=f64)
+        return (torch.cat((one3, j_gt, j_gs, j_gs * j_gt)), None,
+                torch.cat((one3, bl_gt, bl_gs, bl_gs * bl_gt)), torch.cat((one3, ba_gt, ba_gs, ba_gs * ba_gt)))
     if g is None:
         nb = 2 if cfg.kind == "c2" else 4
         return (torch.ones(12, dtype=f64), torch.ones(12, dtype=f64),
@@ -103,8 +119,11 @@ def _axis_major_mask(coeff: torch.Tensor, num_nodes: int, T: int) -> torch.Tenso
 def input_masks(cfg: OracleConfig, num_nodes: Dict[str, int], widths: Dict[str, int]) -> Dict[str, torch.Tensor]:
     """+-1 mask per (node, feature) that `apply_symmetry` applies to each node type
     (hgnn_c2.py:191-231; hgnn_k4.py:198-236).  Types that are not masked are absent."""
-    if cfg.kind == "mi":
+    if cfg.kind in ("mi", "s4_com"):
         return {}
+    if cfg.kind in ("k4_com", "c2_com"):   # apply_symmetry masks the joints only (hgnn_k4_com.py:159-168)
+        cj = symmetry_coefficients(cfg)[0]
+        return {"joint": cj.view(12, 1).expand(12, widths["joint"]).clone()}
     T = cfg.num_timesteps
     cj, cf, cbl, cba = symmetry_coefficients(cfg)
     masks = {}
@@ -123,13 +142,13 @@ def input_masks(cfg: OracleConfig, num_nodes: Dict[str, int], widths: Dict[str, 
 
 def apply_symmetry(cfg: OracleConfig, x_dict: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     """Restatement of apply_symmetry as the elementwise +-1 masks it amounts to."""
-    if cfg.kind == "mi":
+    if cfg.kind in ("mi", "s4_com"):
         return dict(x_dict)
     nj, nf = 12, 4
-    nb = 2 if cfg.kind == "c2" else 4
+    nb = 2 if cfg.kind in ("c2", "c2_com") else 4
     widths = {k: v.shape[1] for k, v in x_dict.items()}
-    T = cfg.num_timesteps
-    if widths["base"] != 6 * T:
+    T = 1 if cfg.kind.endswith("_com") else cfg.num_timesteps
+    if not cfg.kind.endswith("_com") and widths["base"] != 6 * T:
         raise RuntimeError("base feature width must be 6*num_timesteps (hgnn_c2.py:246-251)")
     masks = input_masks(cfg, {"base": nb, "joint": nj, "foot": nf}, widths)
     out = dict(x_dict)
@@ -157,7 +176,7 @@ def relation_aggr(cfg: OracleConfig, et: EdgeType) -> str:
     rel = et[1]
     if cfg.kind == "c2" and rel == "center_bb":   # hgnn_c2.py:98-104
         return "mean"
-    if cfg.kind == "k4" and rel in ("gt", "gs"):  # hgnn_k4.py:107-119
+    if cfg.kind in ("k4", "k4_com", "c2_com") and rel in ("gt", "gs"):  # hgnn_k4.py:107-119, hgnn_k4_com.py:93-103
         return "mean"
     return "add"
 
@@ -189,8 +208,8 @@ def forward(cfg: OracleConfig, params: Dict[str, torch.Tensor], x_dict, edge_ind
     hidden = [x]
     for layer in range(cfg.num_layers):                                 # :150
         h = hetero_conv(cfg, params, layer, x, edge_index_dict)         # :152
-        if cfg.kind == "mi":
-            x = {k: torch.relu(v) for k, v in h.items()}                # hgnn.py:60-61
+        if cfg.kind in ("mi", "s4_com"):
+            x = {k: torch.relu(v) for k, v in h.items()}                # hgnn.py:60-61 / hgnn_s4_com.py:67-69
         else:
             new = {}
             for k, v in h.items():
@@ -201,6 +220,16 @@ def forward(cfg: OracleConfig, params: Dict[str, torch.Tensor], x_dict, edge_ind
                     new[k] = torch.relu(v)
             x = {k: new[k] + x[k] if (k in x and x[k].shape == new[k].shape) else new[k] for k in new}  # :161-166
         hidden.append(x)
+    if cfg.kind.endswith("_com"):
+        out = x["base"] @ params["decoder.weight"].t() + params["decoder.bias"]   # hgnn_k4_com.py:154 (decoder on base nodes)
+        if cfg.kind != "s4_com":                                                   # morphological_symmetry_decoder :157-165
+            _, _, cbl, cba = symmetry_coefficients(cfg)
+            nb = cbl.numel() // 3
+            o = out.reshape(-1, nb, 6)
+            out = torch.cat((o[:, :, :3] * cbl.view(1, nb, 3).to(o.dtype), o[:, :, 3:] * cba.view(1, nb, 3).to(o.dtype)), dim=-1)
+        if return_hidden:
+            return out, hidden
+        return out
     out = x["foot"] @ params["decoder.weight"].t() + params["decoder.bias"]   # :176
     if cfg.kind == "c2" and cfg.regression and cfg.grf_dimension == 3:        # :179-180, 184-189
         _, cf, _, _ = symmetry_coefficients(cfg)
@@ -213,6 +242,8 @@ def forward(cfg: OracleConfig, params: Dict[str, torch.Tensor], x_dict, edge_ind
 def wrapper_outputs(cfg: OracleConfig, out_raw: torch.Tensor, y: torch.Tensor, batch_size: int):
     """step_helper_function reshape contract (gnnLightning.py:680-695 regression; :498-513 classification,
     where labels are one {0,1} per foot: [B, 4])."""
+    if cfg.kind.endswith("_com"):   # COM wrappers compare the [B, n_base*6] prediction with same-shape labels
+        return y.reshape(batch_size, -1), out_raw.reshape(batch_size, -1)
     w = cfg.out_channels_per_foot * 4
     return y.reshape(batch_size, w if cfg.regression else 4), out_raw.squeeze().reshape(batch_size, w)
 

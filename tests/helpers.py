@@ -40,7 +40,7 @@ def load_case(name):
     seed = int(fx["seed"])
     B = case["B"]
     x_dict, y = synth.make_windows(seed, B, spec.num_nodes, spec.widths,
-                                   spec.out_channels * 4 if case["regression"] else 4,
+                                   spec.out_channels * spec.num_nodes[spec.out_type] if case["regression"] else 4,
                                    classification=not case["regression"])
     params = synth.make_params(seed, spec.param_shapes())
     ei = spec.topology.edge_index_dict(B)

@@ -20,10 +20,23 @@ def _build(case, spec):
     if case["kind"] == "k4":
         return models.GRF_HGNN_K4(case["hidden"], case["layers"], meta, regression=case["regression"],
                                   symmetry_mode="MorphSym" if cfg_path else None, group_operator_path=cfg_path)
+    if case["kind"] in ("k4_com", "c2_com"):
+        cls = models.COM_HGNN_K4 if case["kind"] == "k4_com" else models.COM_HGNN_C2
+        return cls(case["hidden"], case["layers"], meta, symmetry_mode="MorphSym" if cfg_path else None,
+                   group_operator_path=cfg_path)
+    if case["kind"] == "s4_com":
+        if case.get("ref") == "COM_HGNN":
+            return models.COM_HGNN(case["hidden"], case["layers"], meta, com_dimension=6)
+        return models.COM_HGNN_S4(case["hidden"], case["layers"], meta)
     return models.GRF_HGNN(case["hidden"], case["layers"], meta, regression=case["regression"], grf_dimension=case["grf"])
 
 
-@pytest.mark.parametrize("name", ["a1c2_h128_L3_d3_B3", "mck4_cls_h128_L2_B3", "mi_h128_L2_d1_B3"])
+def _is_com(case):
+    return case["kind"].endswith("_com")
+
+
+@pytest.mark.parametrize("name", ["a1c2_h128_L3_d3_B3", "mck4_cls_h128_L2_B3", "mi_h128_L2_d1_B3", "solok4com_h128_L3_B5",
+                                  "soloc2com_h128_L2_B4", "solos4com_h128_L2_B3", "com_hgnn_h128_L2_B3"])
 def test_state_dict_layout_matches_reference_names(name):
     torch.set_default_dtype(torch.float64)   # the reference runs in float64 (gnnLightning.py:1183)
     case, spec, fx, x_dict, y, params, ei = helpers.load_case(name)
@@ -37,6 +50,13 @@ def test_state_dict_layout_matches_reference_names(name):
     m.load_state_dict(params)    # golden weights load by name
     et = spec.edge_types[0]
     assert m.convs[0].convs[et].lin_rel.weight.shape == (128, 128)   # tuple-key access, hgnn_c2.py:295-306
+    if _is_com(case):
+        assert m.num_dimensions_per_base == spec.out_channels == 6 and m.num_bases == spec.num_nodes["base"]
+        if case["kind"] != "s4_com":
+            c = spec.symmetry_coefficients()
+            assert torch.equal(m.joints_linear_weights, c[0]) and torch.equal(m.base_coefficients_lin, c[2])
+            assert torch.equal(m.base_coefficients_ang, c[3])
+        return
     assert m.out_channels_per_foot == spec.out_channels
     if case["kind"] != "mi":
         c = spec.symmetry_coefficients()
@@ -52,7 +72,9 @@ def test_operator_containers_have_no_eager_path():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,param_dev", [("a1c2_h128_L3_d3_B3", "cuda"), ("a1c2_h128_L2_d3_B37", "cpu"),
-                                            ("mck4_cls_h128_L2_B3", "cuda"), ("mi_h128_L2_d3_B2", "cuda")])
+                                            ("mck4_cls_h128_L2_B3", "cuda"), ("mi_h128_L2_d3_B2", "cuda"),
+                                            ("solok4com_h128_L3_B5", "cuda"), ("soloc2com_h128_L2_B4", "cpu"),
+                                            ("solos4com_h128_L2_B3", "cuda"), ("com_hgnn_h128_L2_B3", "cuda")])
 def test_module_forward_backward_matches_golden(name, param_dev):
     assert torch.cuda.is_available()
     torch.set_default_dtype(torch.float64)
@@ -68,7 +90,11 @@ def test_module_forward_backward_matches_golden(name, param_dev):
         m(x_dict={k: v.clone() for k, v in xd.items()}, edge_index_dict=eid)
     m.load_state_dict(params)
     out = m(x_dict=xd, edge_index_dict=eid)
-    w = m.out_channels_per_foot * 4
+    if _is_com(case):
+        w = m.num_bases * m.num_dimensions_per_base                    # gnnLightning_com.py:335-338
+        assert tuple(out.shape) == ((B, m.num_bases, 6) if case["kind"] != "s4_com" else (B, 6))
+    else:
+        w = m.out_channels_per_foot * 4
     y_pred = torch.reshape(out.squeeze(), (B, w))                      # gnnLightning.py:691
     if case["regression"]:
         loss = ((y_pred.flatten() - y.to(dev).reshape(B, w).flatten()) ** 2).mean()
