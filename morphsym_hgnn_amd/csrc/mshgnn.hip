@@ -81,10 +81,13 @@ template <> __device__ __forceinline__ __bf16 from_f32<__bf16>(float v) { return
 
 // Accumulator layout.  The MFMAs are issued as  D^T = W_frag (A operand) x X_frag (B operand), so in the 16x16 C/D map
 // (col = lane&15, row = 4*(lane>>4)+j -- cdna_hip_programming.md section 3) the COLUMN is the window and the ROWS are
-// output features: lane (w = lane&15, g = lane>>4) holds, per 16-feature block fb, the 4 CONSECUTIVE features
-// 16 fb + 4 g + {0..3} of window w.  Epilogue memory traffic is therefore 4-element (8 / 16 byte) vectors.
+// output features.  k_prep permutes the weight rows of the wave's two 16-row blocks so that MFMA row 4g+j of block fb is
+// feature 8 g + 4 fb + j: lane (w = lane&15, g = lane>>4) then holds the 8 CONSECUTIVE features 8g..8g+7 of window w
+// (c[0] = first four, c[1] = next four), the 4 lane groups of a window cover 32 contiguous features, and epilogue
+// traffic is one 16-byte (bf16) / 32-byte (fp32) vector per lane and accumulator.
 __device__ __forceinline__ int c_win(int lane) { return lane & 15; }
-__device__ __forceinline__ int c_feat(int fb, int lane) { return (fb << 4) + ((lane >> 4) << 2); }   // within the wave's 32 columns
+__device__ __forceinline__ int c_oct(int lane) { return (lane >> 4) << 3; }                            // within the wave's 32 columns
+__device__ __forceinline__ int c_feat(int fb, int lane) { return c_oct(lane) + (fb << 2); }
 
 template <typename A> __device__ __forceinline__ void acc_fill(A& a, float v) {
     a.c[0] = f32x4{v, v, v, v}; a.c[1] = f32x4{v, v, v, v};
@@ -102,6 +105,26 @@ __device__ __forceinline__ void store_quad(__bf16* p, f32x4 v) {
     union { u32x2 r; __bf16 e[4]; } u;
     u.e[0] = (__bf16)v[0]; u.e[1] = (__bf16)v[1]; u.e[2] = (__bf16)v[2]; u.e[3] = (__bf16)v[3];
     *reinterpret_cast<u32x2*>(p) = u.r;
+}
+// 8 consecutive elements of T <-> two f32x4 (global: 16-byte aligned for bf16, 32-byte for fp32)
+__device__ __forceinline__ void load_oct(const float* p, f32x4& lo, f32x4& hi) {
+    lo = reinterpret_cast<const f32x4*>(p)[0]; hi = reinterpret_cast<const f32x4*>(p)[1];
+}
+__device__ __forceinline__ void load_oct(const __bf16* p, f32x4& lo, f32x4& hi) {
+    const u32x4 r = *reinterpret_cast<const u32x4*>(p);
+    lo = f32x4{__builtin_bit_cast(float, r[0] << 16), __builtin_bit_cast(float, r[0] & 0xffff0000u),
+               __builtin_bit_cast(float, r[1] << 16), __builtin_bit_cast(float, r[1] & 0xffff0000u)};
+    hi = f32x4{__builtin_bit_cast(float, r[2] << 16), __builtin_bit_cast(float, r[2] & 0xffff0000u),
+               __builtin_bit_cast(float, r[3] << 16), __builtin_bit_cast(float, r[3] & 0xffff0000u)};
+}
+__device__ __forceinline__ void store_oct(float* p, f32x4 lo, f32x4 hi) {
+    reinterpret_cast<f32x4*>(p)[0] = lo; reinterpret_cast<f32x4*>(p)[1] = hi;
+}
+__device__ __forceinline__ void store_oct(__bf16* p, f32x4 lo, f32x4 hi) {
+    union { u32x4 r; __bf16 e[8]; } u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { u.e[j] = (__bf16)lo[j]; u.e[4 + j] = (__bf16)hi[j]; }
+    *reinterpret_cast<u32x4*>(p) = u.r;
 }
 __device__ __forceinline__ f32x4 relu4(f32x4 v) { return f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)}; }
 // value as it will read back after being stored as T (so LDS/global copies and the register copy agree)
@@ -122,6 +145,20 @@ template <typename T> __device__ __forceinline__ int lds_chunk(int blk, int row,
 }
 template <typename T> __device__ __forceinline__ int lds_elem(int blk, int row, int col) {
     return lds_chunk<T>(blk, row, col / Prec<T>::EPC) + (col % Prec<T>::EPC) * (int)sizeof(T);
+}
+
+// 8 consecutive features (col % 8 == 0) of one row of an LDS node block: one swizzled chunk (bf16) or two (fp32)
+template <typename T> __device__ __forceinline__ void lds_load_oct(const char* smem, int blk, int row, int col, f32x4& lo, f32x4& hi) {
+    if constexpr (sizeof(T) == 4) {
+        lo = *reinterpret_cast<const f32x4*>(smem + lds_chunk<T>(blk, row, col / 4));
+        hi = *reinterpret_cast<const f32x4*>(smem + lds_chunk<T>(blk, row, col / 4 + 1));
+    } else load_oct(reinterpret_cast<const T*>(smem + lds_chunk<T>(blk, row, col / 8)), lo, hi);
+}
+template <typename T> __device__ __forceinline__ void lds_store_oct(char* smem, int blk, int row, int col, f32x4 lo, f32x4 hi) {
+    if constexpr (sizeof(T) == 4) {
+        *reinterpret_cast<f32x4*>(smem + lds_chunk<T>(blk, row, col / 4)) = lo;
+        *reinterpret_cast<f32x4*>(smem + lds_chunk<T>(blk, row, col / 4 + 1)) = hi;
+    } else store_oct(reinterpret_cast<T*>(smem + lds_chunk<T>(blk, row, col / 8)), lo, hi);
 }
 
 // A fragment: lane (row = lane % ROWS, group g = lane / ROWS) reads 8 consecutive chunks = its contiguous K range.
@@ -234,8 +271,10 @@ template <typename T> __global__ void k_prep(PrepArgs a) {
 #pragma unroll
             for (int x = 0; x < EPC; ++x) {
                 int k, col;
-                if constexpr (sizeof(T) == 4) { k = 32 * (lane >> 4) + 4 * (v & 7) + x; col = wv * 32 + (v >> 3) * 16 + (lane & 15); }
-                else { k = 32 * (lane >> 4) + 8 * (v & 3) + x; col = wv * 32 + (v >> 2) * 16 + (lane & 15); }
+                // MFMA row i = lane & 15 of the wave's 16-row block fb carries output feature 8 (i / 4) + 4 fb + i % 4
+                const int i16 = lane & 15;
+                if constexpr (sizeof(T) == 4) { k = 32 * (lane >> 4) + 4 * (v & 7) + x; col = wv * 32 + 8 * (i16 >> 2) + 4 * (v >> 3) + (i16 & 3); }
+                else { k = 32 * (lane >> 4) + 8 * (v & 3) + x; col = wv * 32 + 8 * (i16 >> 2) + 4 * (v >> 2) + (i16 & 3); }
                 g[i][x] = 0.f;
                 if (i < pd.n_src) {
                     if (pd.orient == 0) { if (k < pd.ncols) g[i][x] = a.params[pd.src[i] + (int64_t)col * pd.ld + pd.col0 + k]; }
@@ -389,11 +428,7 @@ template <typename T> __global__ __launch_bounds__(256) void k_enc_fwd(EncArgs a
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
         const int w = w0 + m * P::ROWS + c_win(lane);
-        if (w < a.B) {
-#pragma unroll
-            for (int fb = 0; fb < 2; ++fb)
-                store_quad(x0 + act_idx(w, gnode, a.B) + wv * 32 + c_feat(fb, lane), relu4(acc[m].c[fb]));
-        }
+        if (w < a.B) store_oct(x0 + act_idx(w, gnode, a.B) + wv * 32 + c_oct(lane), relu4(acc[m].c[0]), relu4(acc[m].c[1]));
     }
 }
 
@@ -403,7 +438,7 @@ template <typename T> __global__ __launch_bounds__(256) void k_enc_fwd(EncArgs a
 struct LayerArgs {
     const void* x_in;      // fwd: X_l                    bwd: G_{l+1} = dX_{l+1} (read; written when it is materialised here)
     void* x_out;           // fwd: X_{l+1}                bwd: layer 0 only: dX_0 = relu'(X_0) . (G_1 + D_0)
-    unsigned* maskbits;    // relu bits of this layer [B][NN][4]
+    unsigned* maskbits;    // relu bits of this layer [NN][4][B]
     void* hb; void* t1;    // base_transform stash of this layer [B][n_mlp][128]
     void* dh; void* du;    // bwd: dH_l [B][NN][128], dU_l [B][n_mlp][128]
     const void* x_act;     // bwd layer 0: X_0 (encoder relu mask)
@@ -416,8 +451,9 @@ struct LayerArgs {
                            // backward: 16 no stage-1 loads/stores, 32 no base_transform chain, 64 no stage-2 epilogues
 };
 
-// relu bits of one accumulator -> word wn of maskbits[B][NN][4] (bit i <-> feature 32 wn + i).  Each lane owns 8 bits
-// (features 16 fb + 4 g + j) of its window; the 4 lanes of a window are OR-combined with two cross-lane shuffles.
+// relu bits of one accumulator -> word (n, wn, w) of maskbits[NN][4][B] (bit i <-> feature 32 wn + i; a wave's 16
+// windows are 64 contiguous bytes).  Each lane owns 8 bits (features 8 g + 4 fb + j) of its window; the 4 lanes of a
+// window are OR-combined with two cross-lane shuffles.
 template <typename T>
 __device__ __forceinline__ void store_relu_bits(const typename Prec<T>::Acc& acc, unsigned* maskbits, int NN, int n, int w0, int B, int wn, int lane) {
     const int g = lane >> 4;
@@ -425,11 +461,11 @@ __device__ __forceinline__ void store_relu_bits(const typename Prec<T>::Acc& acc
 #pragma unroll
     for (int fb = 0; fb < 2; ++fb)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bits |= (acc.c[fb][j] > 0.f ? 1u : 0u) << (16 * fb + 4 * g + j);
+        for (int j = 0; j < 4; ++j) bits |= (acc.c[fb][j] > 0.f ? 1u : 0u) << (8 * g + 4 * fb + j);
     bits |= (unsigned)__shfl_xor((int)bits, 16, 64);
     bits |= (unsigned)__shfl_xor((int)bits, 32, 64);
     const int w = w0 + c_win(lane);
-    if (g == 0 && w < B) maskbits[((size_t)n * B + w) * 4 + wn] = bits;
+    if (g == 0 && w < B) maskbits[((size_t)n * 4 + wn) * B + w] = bits;
 }
 
 // elementwise helpers on one 16-byte chunk of T
@@ -559,15 +595,15 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, Prec<T>::WPS) 
                 if (slot < ns) {
                     const int n = gh[GH_NODES + slot];
                     if (flags & GF_STORE_MASK) store_relu_bits<T>(acc[u], a.maskbits, NN, n, w0, B, wn, lane);
-#pragma unroll
-                    for (int fb = 0; fb < 2; ++fb) {
-                        const int col = wn * 32 + c_feat(fb, lane);
-                        T* pe = reinterpret_cast<T*>(smem + lds_elem<T>(n, win, col));
-                        f32x4 y = relu4(acc[u].c[fb]);
-                        if (flags & GF_RESIDUAL) y += load_quad(pe);
-                        if (lds_epi) store_quad(pe, y);
-                        else if (w_ok) store_quad(xout + act_idx(w, n, B) + col, y);
+                    const int col = wn * 32 + c_oct(lane);
+                    f32x4 y0 = relu4(acc[u].c[0]), y1 = relu4(acc[u].c[1]);
+                    if (flags & GF_RESIDUAL) {
+                        f32x4 r0, r1;
+                        lds_load_oct<T>(smem, n, win, col, r0, r1);
+                        y0 += r0; y1 += r1;
                     }
+                    if (lds_epi) lds_store_oct<T>(smem, n, win, col, y0, y1);
+                    else if (w_ok) store_oct(xout + act_idx(w, n, B) + col, y0, y1);
                 }
             }
             if (lds_epi) {
@@ -591,13 +627,9 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, Prec<T>::WPS) 
             for (int u = 0; u < P::HS; ++u) {
                 const int slot = 2 * u + wh;
                 if (slot < ns) {
-                    const int mi = gh[GH_MLPIDX + slot];
-#pragma unroll
-                    for (int fb = 0; fb < 2; ++fb) {
-                        const int col = wn * 32 + c_feat(fb, lane);
-                        store_quad(reinterpret_cast<T*>(smem + lds_elem<T>(scr[slot], win, col)), acc[u].c[fb]);
-                        if (w_ok) store_quad(hb + act_idx(w, mi, B) + col, acc[u].c[fb]);
-                    }
+                    const int mi = gh[GH_MLPIDX + slot], col = wn * 32 + c_oct(lane);
+                    lds_store_oct<T>(smem, scr[slot], win, col, acc[u].c[0], acc[u].c[1]);
+                    if (w_ok) store_oct(hb + act_idx(w, mi, B) + col, acc[u].c[0], acc[u].c[1]);
                 }
             }
             __syncthreads();
@@ -607,14 +639,10 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, Prec<T>::WPS) 
             for (int u = 0; u < P::HS; ++u) {
                 const int slot = 2 * u + wh;
                 if (slot < ns) {
-                    const int mi = gh[GH_MLPIDX + slot];
-#pragma unroll
-                    for (int fb = 0; fb < 2; ++fb) {
-                        const int col = wn * 32 + c_feat(fb, lane);
-                        const f32x4 tv = relu4(acc[u].c[fb]);
-                        store_quad(reinterpret_cast<T*>(smem + lds_elem<T>(scr[slot], win, col)), tv);
-                        if (w_ok) store_quad(t1 + act_idx(w, mi, B) + col, tv);
-                    }
+                    const int mi = gh[GH_MLPIDX + slot], col = wn * 32 + c_oct(lane);
+                    const f32x4 t0 = relu4(acc[u].c[0]), t1v = relu4(acc[u].c[1]);
+                    lds_store_oct<T>(smem, scr[slot], win, col, t0, t1v);
+                    if (w_ok) store_oct(t1 + act_idx(w, mi, B) + col, t0, t1v);
                 }
             }
             __syncthreads();
@@ -623,16 +651,15 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, Prec<T>::WPS) 
             for (int u = 0; u < P::HS; ++u) {
                 const int slot = 2 * u + wh;
                 if (slot < ns && w_ok) {
-                    const int n = gh[GH_NODES + slot];
-#pragma unroll
-                    for (int fb = 0; fb < 2; ++fb) {
-                        const int col = wn * 32 + c_feat(fb, lane);
-                        f32x4 y = acc[u].c[fb];
-                        if (flags & GF_RESIDUAL)
-                            y += own ? load_quad(xin + act_idx(w, n, B) + col)
-                                     : load_quad(reinterpret_cast<const T*>(smem + lds_elem<T>(n, win, col)));
-                        store_quad(xout + act_idx(w, n, B) + col, y);
+                    const int n = gh[GH_NODES + slot], col = wn * 32 + c_oct(lane);
+                    f32x4 y0 = acc[u].c[0], y1 = acc[u].c[1];
+                    if (flags & GF_RESIDUAL) {
+                        f32x4 r0, r1;
+                        if (own) load_oct(xin + act_idx(w, n, B) + col, r0, r1);
+                        else lds_load_oct<T>(smem, n, win, col, r0, r1);
+                        y0 += r0; y1 += r1;
                     }
+                    store_oct(xout + act_idx(w, n, B) + col, y0, y1);
                 }
             }
         }
@@ -676,7 +703,7 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, Prec<T>::WPS) 
                 v[i] = u32x4{0, 0, 0, 0}; word[i] = 0;
                 if (nk[i] != NK_DEAD && wr < B && !(a.dbg & 16)) {
                     v[i] = *reinterpret_cast<const u32x4*>(gtop + act_idx(wr, n, B) + c * EPC);
-                    if (nk[i] == NK_RELU) word[i] = a.maskbits[((size_t)n * B + wr) * 4 + (c * EPC) / 32];
+                    if (nk[i] == NK_RELU) word[i] = a.maskbits[((size_t)n * 4 + (c * EPC) / 32) * B + wr];
                 }
             }
 #pragma unroll
@@ -704,18 +731,16 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, Prec<T>::WPS) 
         for (int u = 0; u < P::HS; ++u) {
             const int slot = 2 * u + wh;
             if (slot < nmlp) {
+                const int col = wn * 32 + c_oct(lane);
+                f32x4 r0 = f32x4{0, 0, 0, 0}, r1 = f32x4{0, 0, 0, 0};
+                if (w_ok) {
+                    f32x4 tv0, tv1;
+                    load_oct(t1 + act_idx(w, slot, B) + col, tv0, tv1);
 #pragma unroll
-                for (int fb = 0; fb < 2; ++fb) {
-                    const int col = wn * 32 + c_feat(fb, lane);
-                    f32x4 r = f32x4{0, 0, 0, 0};
-                    if (w_ok) {
-                        const f32x4 tv = load_quad(t1 + act_idx(w, slot, B) + col);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) r[j] = tv[j] > 0.f ? acc[u].c[fb][j] : 0.f;
-                        store_quad(du + act_idx(w, slot, B) + col, r);
-                    }
-                    store_quad(reinterpret_cast<T*>(smem + lds_elem<T>(mlp_nodes[slot], win, col)), r);
+                    for (int j = 0; j < 4; ++j) { r0[j] = tv0[j] > 0.f ? acc[u].c[0][j] : 0.f; r1[j] = tv1[j] > 0.f ? acc[u].c[1][j] : 0.f; }
+                    store_oct(du + act_idx(w, slot, B) + col, r0, r1);
                 }
+                lds_store_oct<T>(smem, mlp_nodes[slot], win, col, r0, r1);
             }
         }
         __syncthreads();
@@ -725,13 +750,9 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, Prec<T>::WPS) 
         for (int u = 0; u < P::HS; ++u) {
             const int slot = 2 * u + wh;
             if (slot < nmlp) {
-                const int n = mlp_nodes[slot];
-#pragma unroll
-                for (int fb = 0; fb < 2; ++fb) {
-                    const int col = wn * 32 + c_feat(fb, lane);
-                    store_quad(reinterpret_cast<T*>(smem + lds_elem<T>(n, win, col)), acc[u].c[fb]);
-                    if (w_ok) store_quad(dh + act_idx(w, n, B) + col, acc[u].c[fb]);
-                }
+                const int n = mlp_nodes[slot], col = wn * 32 + c_oct(lane);
+                lds_store_oct<T>(smem, n, win, col, acc[u].c[0], acc[u].c[1]);
+                if (w_ok) store_oct(dh + act_idx(w, n, B) + col, acc[u].c[0], acc[u].c[1]);
             }
         }
         __syncthreads();
@@ -750,11 +771,7 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, Prec<T>::WPS) 
 #pragma unroll
             for (int u = 0; u < P::HS; ++u) {
                 const int slot = 2 * u + wh;
-                if (slot < ns) {
-#pragma unroll
-                    for (int fb = 0; fb < 2; ++fb)
-                        store_quad(reinterpret_cast<T*>(smem + lds_elem<T>(gh[GH_NODES + slot], win, wn * 32 + c_feat(fb, lane))), acc[u].c[fb]);
-                }
+                if (slot < ns) lds_store_oct<T>(smem, gh[GH_NODES + slot], win, wn * 32 + c_oct(lane), acc[u].c[0], acc[u].c[1]);
             }
             __syncthreads();
             const RowMap<T> m(tid);
@@ -790,21 +807,18 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, Prec<T>::WPS) 
                 const int slot = 2 * u + wh;
                 if (slot < ns && w_ok) {
                     const int n = gh[GH_NODES + slot];
-                    f32x4 g1[2], xa[2];
-#pragma unroll
-                    for (int fb = 0; fb < 2; ++fb) {     // issue the loads of both feature blocks first
-                        const size_t idx = act_idx(w, n, B) + wn * 32 + c_feat(fb, lane);
-                        g1[fb] = (flags & GF_RESIDUAL) ? load_quad(gtop + idx) : f32x4{0, 0, 0, 0};
-                        xa[fb] = (flags & GF_ENC_MASK) ? load_quad(xact + idx) : f32x4{1, 1, 1, 1};
-                    }
+                    const size_t idx = act_idx(w, n, B) + wn * 32 + c_oct(lane);
+                    f32x4 g1[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}}, xa[2] = {f32x4{1, 1, 1, 1}, f32x4{1, 1, 1, 1}};
+                    if (flags & GF_RESIDUAL) load_oct(gtop + idx, g1[0], g1[1]);
+                    if (flags & GF_ENC_MASK) load_oct(xact + idx, xa[0], xa[1]);
+                    f32x4 y[2];
 #pragma unroll
                     for (int fb = 0; fb < 2; ++fb) {
-                        const size_t idx = act_idx(w, n, B) + wn * 32 + c_feat(fb, lane);
-                        f32x4 y = round_as<T>(acc[u].c[fb]) + g1[fb];
+                        y[fb] = round_as<T>(acc[u].c[fb]) + g1[fb];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) y[j] = xa[fb][j] > 0.f ? y[j] : 0.f;
-                        store_quad(dxo + idx, y);
+                        for (int j = 0; j < 4; ++j) y[fb][j] = xa[fb][j] > 0.f ? y[fb][j] : 0.f;
                     }
+                    store_oct(dxo + idx, y[0], y[1]);
                 }
             }
         }
@@ -990,7 +1004,7 @@ __global__ __launch_bounds__(256) void k_gradw_f32(GradwArgs a) {
                 if (w < a.B) {
                     pv[p] = *reinterpret_cast<const f32x4*>(pb + act_idx(w, po, a.B) + c * 4);
                     if (im[9] >= 0) {   // P = dX_{l+1} . relu bits
-                        const unsigned word = reinterpret_cast<const unsigned*>(a.ws + a.buf_off[im[9]])[((size_t)po * a.B + w) * 4 + c / 8];
+                        const unsigned word = reinterpret_cast<const unsigned*>(a.ws + a.buf_off[im[9]])[((size_t)po * 4 + c / 8) * a.B + w];
                         pv[p] = __builtin_bit_cast(f32x4, chunk_mask_bits<float>(__builtin_bit_cast(u32x4, pv[p]), word >> ((c * 4) % 32)));
                     }
                     if (qs >= 0) {
@@ -1103,7 +1117,7 @@ __global__ __launch_bounds__(256, GW_WPS) void k_gradw_bf16(GradwArgs a) {
     for (int i = 0; i < GW_IPL; ++i) {
         const int* im = a.items + (it0 + min(i, nit - 1)) * ITEM_INTS;
         pbase[i] = reinterpret_cast<const T*>(a.ws + a.buf_off[im[0]]) + act_idx(0, im[2], a.B) + c * 8;
-        mbase[i] = im[9] >= 0 ? reinterpret_cast<const unsigned*>(a.ws + a.buf_off[im[9]]) + (size_t)im[2] * a.B * 4 + c / 4 : nullptr;
+        mbase[i] = im[9] >= 0 ? reinterpret_cast<const unsigned*>(a.ws + a.buf_off[im[9]]) + ((size_t)im[2] * 4 + c / 4) * a.B : nullptr;
         qsign[i] = u32x4{0, 0, 0, 0};
         if (im[4] >= 0) {
             qbase[i] = reinterpret_cast<const T*>(a.ws + a.buf_off[im[3]]) + act_idx(0, im[5], a.B) + c * 8;
@@ -1141,7 +1155,7 @@ __global__ __launch_bounds__(256, GW_WPS) void k_gradw_bf16(GradwArgs a) {
             st.pv[p] = u32x4{0, 0, 0, 0}; st.qv[p] = u32x4{0, 0, 0, 0}; st.mw[p] = 0xffffffffu;
             if (w < a.B && !(a.dbg & 1)) {
                 st.pv[p] = *reinterpret_cast<const u32x4*>(pb + (size_t)w * H);
-                if (mb) st.mw[p] = mb[(size_t)w * 4];
+                if (mb) st.mw[p] = mb[w];
                 if (a.aligned) { if (qn > 0) st.qv[p] = *reinterpret_cast<const u32x4*>(qb + (size_t)w * qs); }   // raw: a use here would serialise the loads
                 else st.qv[p] = load_chunk<T>(qb + (size_t)w * qs, qn, vb);
             }
