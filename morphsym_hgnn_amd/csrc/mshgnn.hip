@@ -826,6 +826,339 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, Prec<T>::WPS) 
 }
 
 // ------------------------------------------------------------------------------------------------------
+// FUSED STACK kernels (bf16 plan): the whole message-passing stack of one 16-window tile in ONE workgroup.
+//   k_stack_fwd: X_0 tile -> LDS, L x (HeteroConv + relu / base_transform + residual) in place, decoder -> out.
+//   k_stack_bwd: dX_L tile -> LDS, L x (relu' / base_transform backward, transposed HeteroConv, residual) in place.
+// Every node owns one accumulator per wave for the whole layer (node n -> wave half n & 1, accumulator n >> 1), so a
+// layer's epilogue runs once, after every wave has finished reading the previous activations, and overwrites them in
+// place; the stashes the backward pass / k_gradw need are written on the side and never read back by this kernel.
+// One workgroup of 8 waves per CU (<= 256 VGPRs per wave): all accumulators live + double-buffered weight fragments.
+// ------------------------------------------------------------------------------------------------------
+struct StackArgs {
+    const void* tile_in;                          // fwd: X_0                       bwd: dX_L
+    char* ws;
+    size_t x_off[MAX_L + 1], dx_off[MAX_L + 1];   // X_l stashes (fwd: written for l >= 1; bwd: X_0 read for the encoder mask), dX_l (bwd: written)
+    size_t mask_off[MAX_L], hb_off[MAX_L], t1_off[MAX_L], dh_off[MAX_L], du_off[MAX_L];
+    const void* wpack; const float* bias; const int* tables; int prog_off[MAX_L];
+    int B, NN, L, training, dbg;
+    const float* params; const float* out_mask; float* out; int64_t off_dec_w, off_dec_b; int node0, n_out, dout;   // fused decoder (fwd)
+};
+
+// wave program in two VGPRs, fetched with v_readlane: pk = pack id of segment `lane`; pb = 256 byte entries, 4 per lane
+struct FProg {
+    int pk, pb;
+    __device__ __forceinline__ FProg(const int* prog, int lane) : pk(prog[lane]), pb(prog[64 + lane]) {}
+    __device__ __forceinline__ int pack(int sgi) const { return __builtin_amdgcn_readlane(pk, sgi); }
+    __device__ __forceinline__ int at(int i) const { return (__builtin_amdgcn_readlane(pb, i >> 2) >> ((i & 3) << 3)) & 0xff; }
+};
+
+// one segment: walk the accumulators in static order, each with its run-time MAC count; the source blocks come from the
+// program's block stream in execution order, so the fragment of the NEXT MAC is read from LDS under this MAC's MFMAs
+template <typename T>
+__device__ __forceinline__ void fs_walk(const FProg& wp, int& pc, int& pb, typename Prec<T>::AFrag& afn, typename Prec<T>::Acc (&acc)[FS_HS],
+                                        const typename Prec<T>::BFrag& bf, const char* smem, int lane, int dbg = 0) {
+#pragma unroll
+    for (int u = 0; u < FS_HS; ++u) {
+        const int cnt = wp.at(pc++);
+        for (int k = 0; k < cnt; ++k) {
+            const typename Prec<T>::AFrag af = afn;
+            if (!(dbg & 256)) load_afrag<T>(afn, smem, wp.at(++pb), lane);
+            if (!(dbg & 128)) mac(acc[u], af, bf);
+            __builtin_amdgcn_sched_group_barrier(0x100, Prec<T>::NAV, 0);   // the prefetch reads first, then this MAC's MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * Prec<T>::NAV * (sizeof(T) == 4 ? 4 : 1), 0);
+        }
+    }
+}
+// all segments of a layer.  The next segment's weight fragment streams from L2 while the current one is multiplied
+// (two register buffers).
+template <typename T>
+__device__ __forceinline__ void fs_run(const FProg& wp, typename Prec<T>::Acc (&acc)[FS_HS], const char* smem, const T* wpack, int wn, int lane, int dbg = 0) {
+    const int nseg = wp.at(0);
+    int pc = 1, pb = 1 + nseg * FS_HS;
+    typename Prec<T>::BFrag bfa, bfb;
+    typename Prec<T>::AFrag afn;
+    // drain the previous epilogue's memory operations first: with loads AND stores pending the compiler must assume
+    // out-of-order completion and waits vmcnt(0) before every MAC, which would expose each prefetch
+    __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));
+    if (nseg > 0) load_bfrag<T>(bfa, wpack, wp.pack(0), wn, lane);
+    load_afrag<T>(afn, smem, wp.at(pb), lane);
+    // a fragment load is ALWAYS in flight behind the one being multiplied (the last segment re-requests its own pack):
+    // every path then has the same number of younger loads outstanding, so the compiler's in-order vmcnt waits inside
+    // the MAC loops never have to drain the prefetch
+    for (int sgi = 0; sgi < nseg; sgi += 2) {
+        load_bfrag<T>(bfb, wpack, wp.pack(min(sgi + 1, nseg - 1)), wn, lane);
+        fs_walk<T>(wp, pc, pb, afn, acc, bfa, smem, lane, dbg);
+        if (sgi + 1 < nseg) {
+            load_bfrag<T>(bfa, wpack, wp.pack(min(sgi + 2, nseg - 1)), wn, lane);
+            fs_walk<T>(wp, pc, pb, afn, acc, bfb, smem, lane, dbg);
+        }
+    }
+}
+
+template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_fwd(StackArgs a) {
+    using P = Prec<T>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wv & 3, wh = wv >> 2;
+    const int w0 = blockIdx.x * P::ROWS, B = a.B, NN = a.NN;
+    const T* wpack = reinterpret_cast<const T*>(a.wpack);
+    const int win = c_win(lane), w = w0 + win, col = wn * 32 + c_oct(lane);
+    const bool w_ok = w < B, train = a.training != 0;
+
+    stage_nodes<T>(smem, reinterpret_cast<const T*>(a.tile_in), NN, w0, B, tid);
+    __syncthreads();
+
+    typename P::Acc acc[FS_HS];
+    for (int l = 0; l < a.L; ++l) {
+        const int* fh = a.tables + a.prog_off[l];
+        const FProg wp(fh + FH_SIZE + wh * FPROG_LEN, lane);
+        const int nmlp = fh[FH_NMLP], flags = fh[FH_FLAGS];
+        // accumulators start at the bias row of their node's type (the loads hide under the first weight fragment)
+#pragma unroll
+        for (int u = 0; u < FS_HS; ++u) {
+            const int n = 2 * u + wh;
+            if (n < NN && fh[FH_KIND + n] != NK_DEAD) acc_init_bias<T>(acc[u], a.bias + (size_t)fh[FH_BIAS + n] * H, wn, lane);
+            else acc_fill(acc[u], 0.f);
+        }
+        if (!(a.dbg & 2)) fs_run<T>(wp, acc, smem, wpack, wn, lane, a.dbg);
+        __syncthreads();   // every wave is done reading X_l: the node blocks may be overwritten
+        if (a.dbg & 8) continue;
+
+        if (nmlp > 0 && !(a.dbg & 64)) {
+            // base_transform: Y = W2 relu(W1 H + b1) + b2 on the first nmlp nodes (hgnn_c2.py:117-121,156); scratch blocks NN + i
+            T* hb = reinterpret_cast<T*>(a.ws + a.hb_off[l]);
+            T* t1 = reinterpret_cast<T*>(a.ws + a.t1_off[l]);
+            typename P::BFrag bf;
+            typename P::AFrag af;
+            load_bfrag<T>(bf, wpack, fh[FH_W1], wn, lane);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int n = 2 * u + wh;
+                if (n < nmlp) {
+                    lds_store_oct<T>(smem, NN + n, win, col, acc[u].c[0], acc[u].c[1]);
+                    if (train && w_ok) store_oct(hb + act_idx(w, n, B) + col, acc[u].c[0], acc[u].c[1]);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int n = 2 * u + wh;
+                if (n < nmlp) {
+                    acc_init_bias<T>(acc[u], a.bias + (size_t)fh[FH_B1] * H, wn, lane);
+                    load_afrag<T>(af, smem, NN + n, lane);
+                    mac(acc[u], af, bf);
+                }
+            }
+            load_bfrag<T>(bf, wpack, fh[FH_W2], wn, lane);
+            __syncthreads();   // all reads of H done before T1 overwrites the scratch blocks
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int n = 2 * u + wh;
+                if (n < nmlp) {
+                    const f32x4 t0 = relu4(acc[u].c[0]), t1v = relu4(acc[u].c[1]);
+                    lds_store_oct<T>(smem, NN + n, win, col, t0, t1v);
+                    if (train && w_ok) store_oct(t1 + act_idx(w, n, B) + col, t0, t1v);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int n = 2 * u + wh;
+                if (n < nmlp) {
+                    acc_init_bias<T>(acc[u], a.bias + (size_t)fh[FH_B2] * H, wn, lane);
+                    load_afrag<T>(af, smem, NN + n, lane);
+                    mac(acc[u], af, bf);
+                }
+            }
+        }
+
+        // X_{l+1}[n] = f(H[n]) (+ X_l[n]) for every live node, in place; stash + relu bits on the side
+        T* xo = reinterpret_cast<T*>(a.ws + a.x_off[l + 1]);
+        unsigned* maskbits = reinterpret_cast<unsigned*>(a.ws + a.mask_off[l]);
+#pragma unroll
+        for (int u = 0; u < FS_HS; ++u) {
+            const int n = 2 * u + wh;
+            if (n < NN) {
+                const int kind = fh[FH_KIND + n];
+                if (kind != NK_DEAD) {
+                    f32x4 y0 = acc[u].c[0], y1 = acc[u].c[1];
+                    if (kind == NK_RELU) {
+                        if (train && !(a.dbg & 32)) store_relu_bits<T>(acc[u], maskbits, NN, n, w0, B, wn, lane);
+                        y0 = relu4(y0); y1 = relu4(y1);
+                    }
+                    if (flags & FF_RESIDUAL) {
+                        f32x4 r0, r1;
+                        lds_load_oct<T>(smem, n, win, col, r0, r1);
+                        y0 += r0; y1 += r1;
+                    }
+                    lds_store_oct<T>(smem, n, win, col, y0, y1);
+                    if (train && w_ok && !(a.dbg & 16)) store_oct(xo + act_idx(w, n, B) + col, y0, y1);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // decoder on the out-type rows of X_L (hgnn_c2.py:176-189): thread = (node, row, 8-column chunk)
+    {
+        const int c = tid & 15, row = (tid >> 4) & 15;
+        const float* W = a.params + a.off_dec_w;
+        for (int f = tid >> 8; f < a.n_out; f += LAYER_THREADS / 256) {
+            f32x4 x0, x1;
+            lds_load_oct<T>(smem, a.node0 + f, row, c * 8, x0, x1);
+            const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+            for (int dd = 0; dd < a.dout; ++dd) {
+                float sum = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sum += x[e] * W[dd * H + c * 8 + e];
+#pragma unroll
+                for (int m = 8; m >= 1; m >>= 1) sum += __shfl_xor(sum, m, 64);
+                if (c == 0 && w0 + row < B)
+                    a.out[((size_t)(w0 + row) * a.n_out + f) * a.dout + dd] = (sum + a.params[a.off_dec_b + dd]) * a.out_mask[f * a.dout + dd];
+            }
+        }
+    }
+}
+
+template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_bwd(StackArgs a) {
+    using P = Prec<T>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wv & 3, wh = wv >> 2;
+    const int w0 = blockIdx.x * P::ROWS, B = a.B, NN = a.NN;
+    const T* wpack = reinterpret_cast<const T*>(a.wpack);
+    const int win = c_win(lane), w = w0 + win, col = wn * 32 + c_oct(lane), g8 = (lane >> 4) << 3;
+    const bool w_ok = w < B;
+
+    // dX_L tile: only the nodes that are live in the last layer carry a gradient
+    {
+        const int* bh = a.tables + a.prog_off[a.L - 1];
+        const T* src = reinterpret_cast<const T*>(a.tile_in);
+        const RowMap<T> m(tid);
+        for (int n = m.sub; n < NN; n += RowMap<T>::NPB) {
+            if (bh[FH_KIND + n] == NK_DEAD) continue;
+            u32x4 v = u32x4{0, 0, 0, 0};
+            if (w0 + m.row < B) v = *reinterpret_cast<const u32x4*>(src + act_idx(w0 + m.row, n, B) + m.c * P::EPC);
+            *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(n, m.row, m.c)) = v;
+        }
+    }
+    __syncthreads();
+
+    typename P::Acc acc[FS_HS];
+    for (int l = a.L - 1; l >= 0; --l) {
+        const int* bh = a.tables + a.prog_off[l];
+        const FProg wp(bh + FH_SIZE + wh * FPROG_LEN, lane);
+        const int nmlp = bh[FH_NMLP], flags = bh[FH_FLAGS];
+        const unsigned* maskbits = reinterpret_cast<const unsigned*>(a.ws + a.mask_off[l]);
+
+        // phase 1 (each lane on the octets it owns): the accumulator of node n starts at its residual term
+        // G_{l+1}[n]; relu nodes are then masked in place -> dH_l[n]
+#pragma unroll
+        for (int u = 0; u < FS_HS; ++u) {
+            const int n = 2 * u + wh;
+            acc_fill(acc[u], 0.f);
+            if (n < NN) {
+                const int kind = bh[FH_KIND + n];
+                if (kind != NK_DEAD) {
+                    char* pc = smem + lds_chunk<T>(n, win, col / P::EPC);
+                    const u32x4 raw = *reinterpret_cast<const u32x4*>(pc);
+                    if (bh[FH_RES + n]) {
+                        acc[u].c[0] = f32x4{__builtin_bit_cast(float, raw[0] << 16), __builtin_bit_cast(float, raw[0] & 0xffff0000u),
+                                            __builtin_bit_cast(float, raw[1] << 16), __builtin_bit_cast(float, raw[1] & 0xffff0000u)};
+                        acc[u].c[1] = f32x4{__builtin_bit_cast(float, raw[2] << 16), __builtin_bit_cast(float, raw[2] & 0xffff0000u),
+                                            __builtin_bit_cast(float, raw[3] << 16), __builtin_bit_cast(float, raw[3] & 0xffff0000u)};
+                    }
+                    if (kind == NK_RELU) {
+                        const unsigned word = w_ok ? maskbits[((size_t)n * 4 + wn) * B + w] : 0u;
+                        *reinterpret_cast<u32x4*>(pc) = chunk_mask_bits<T>(raw, word >> g8);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        if (nmlp > 0) {
+            // dT1 = dY W2 ; dU = dT1 . (T1 > 0) ; dH = dU W1     (backward of base_transform, in place on nodes 0..nmlp-1)
+            const T* t1 = reinterpret_cast<const T*>(a.ws + a.t1_off[l]);
+            T* du = reinterpret_cast<T*>(a.ws + a.du_off[l]);
+            T* dh = reinterpret_cast<T*>(a.ws + a.dh_off[l]);
+            typename P::BFrag bf;
+            typename P::AFrag af;
+            typename P::Acc tm[2];
+            f32x4 tv0[2], tv1[2];
+            load_bfrag<T>(bf, wpack, bh[FH_W2], wn, lane);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int n = 2 * u + wh;
+                tv0[u] = f32x4{0, 0, 0, 0}; tv1[u] = f32x4{0, 0, 0, 0};
+                if (n < nmlp) {
+                    if (w_ok) load_oct(t1 + act_idx(w, n, B) + col, tv0[u], tv1[u]);
+                    acc_fill(tm[u], 0.f);
+                    load_afrag<T>(af, smem, n, lane);
+                    mac(tm[u], af, bf);
+                }
+            }
+            load_bfrag<T>(bf, wpack, bh[FH_W1], wn, lane);
+            __syncthreads();   // all reads of the dY blocks done
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int n = 2 * u + wh;
+                if (n < nmlp) {
+                    f32x4 r0, r1;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { r0[j] = tv0[u][j] > 0.f ? tm[u].c[0][j] : 0.f; r1[j] = tv1[u][j] > 0.f ? tm[u].c[1][j] : 0.f; }
+                    if (w_ok) store_oct(du + act_idx(w, n, B) + col, r0, r1);
+                    lds_store_oct<T>(smem, n, win, col, r0, r1);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int n = 2 * u + wh;
+                if (n < nmlp) {
+                    acc_fill(tm[u], 0.f);
+                    load_afrag<T>(af, smem, n, lane);
+                    mac(tm[u], af, bf);
+                }
+            }
+            __syncthreads();   // all reads of the dU blocks done
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int n = 2 * u + wh;
+                if (n < nmlp) {
+                    lds_store_oct<T>(smem, n, win, col, tm[u].c[0], tm[u].c[1]);
+                    if (w_ok) store_oct(dh + act_idx(w, n, B) + col, tm[u].c[0], tm[u].c[1]);
+                }
+            }
+            __syncthreads();
+        }
+
+        // phase 2: dX_l[j] = (residual) + dH_j W_rootsum + sum_r sum_{j->i} dH_i W_rel^r
+        fs_run<T>(wp, acc, smem, wpack, wn, lane);
+        __syncthreads();   // every wave is done reading dH_l
+
+        T* dxo = reinterpret_cast<T*>(a.ws + a.dx_off[l]);
+        const T* xact = reinterpret_cast<const T*>(a.ws + a.x_off[0]);
+#pragma unroll
+        for (int u = 0; u < FS_HS; ++u) {
+            const int n = 2 * u + wh;
+            if (n < NN && bh[FH_OUT + n]) {
+                f32x4 y0 = acc[u].c[0], y1 = acc[u].c[1];
+                if ((flags & FF_ENC_MASK) && w_ok) {   // layer 0: x relu'(X_0)  (encoder activation)
+                    f32x4 x0, x1;
+                    load_oct(xact + act_idx(w, n, B) + col, x0, x1);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { y0[j] = x0[j] > 0.f ? y0[j] : 0.f; y1[j] = x1[j] > 0.f ? y1[j] : 0.f; }
+                }
+                if (l > 0) lds_store_oct<T>(smem, n, win, col, y0, y1);
+                if (w_ok) store_oct(dxo + act_idx(w, n, B) + col, y0, y1);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // decoder forward / backward (hgnn_c2.py:176-189) and the wrapper's MSE (gnnLightning.py:633-639)
 // ------------------------------------------------------------------------------------------------------
 struct DecArgs {
@@ -1322,6 +1655,7 @@ struct mshgnn_plan {
     int* d_tables = nullptr; uint8_t* d_signs = nullptr; float* d_out_mask = nullptr;
     PackDesc* d_packs = nullptr; BiasDesc* d_biases = nullptr;
     bool attr_set = false;
+    bool use_fused = false;             // bf16 plan: fused stack kernels (MSHGNN_FUSED=0 selects the per-layer kernels)
 };
 
 // bracket one kernel launch with events when profiling
@@ -1376,6 +1710,12 @@ extern "C" int mshgnn_plan_create(const mshgnn_desc* desc, mshgnn_plan** out) {
     } else {
         if ((rc = set_lds_attr(k_layer_fwd<__bf16>, lds)) || (rc = set_lds_attr(k_layer_bwd<__bf16>, lds)) ||
             (rc = set_lds_attr(k_enc_fwd<__bf16>, Prec<__bf16>::ENC_MB * Prec<__bf16>::BLK))) { mshgnn_plan_destroy(p); return rc; }
+        const char* e = getenv("MSHGNN_FUSED");
+        p->use_fused = hp.fused && !(e && atoi(e) == 0);
+        if (p->use_fused) {
+            const int flds = hp.fs_blk * Prec<__bf16>::BLK;
+            if ((rc = set_lds_attr(k_stack_fwd<__bf16>, flds)) || (rc = set_lds_attr(k_stack_bwd<__bf16>, flds))) { mshgnn_plan_destroy(p); return rc; }
+        }
     }
     *out = p;
     return MSHGNN_OK;
@@ -1478,8 +1818,25 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
         ProfScope ps(p, hp.ks_enc, st);
         hipLaunchKernelGGL(k_enc_fwd<T>, dim3(a.wg_prefix[hp.NT]), dim3(256), Prec<T>::ENC_MB * Prec<T>::BLK, st, a);
     }
-    // 3. layers
+    // 3. layers (+ decoder): one fused launch on the bf16 plan, else one kernel per layer and the decoder kernel
     const int tiles = (B + Prec<T>::ROWS - 1) / Prec<T>::ROWS;
+    if constexpr (sizeof(T) == 2) {
+        if (p->use_fused) {
+            StackArgs a{};
+            a.tile_in = ws + lay.x[0]; a.ws = ws;
+            for (int l = 0; l <= hp.L; ++l) a.x_off[l] = lay.x[l];
+            for (int l = 0; l < hp.L; ++l) { a.mask_off[l] = lay.mask[l]; a.hb_off[l] = lay.hb[l]; a.t1_off[l] = lay.t1[l]; a.prog_off[l] = hp.fs_fwd_off[l]; }
+            a.wpack = ws + lay.wpack; a.bias = reinterpret_cast<const float*>(ws + lay.bias); a.tables = p->d_tables;
+            a.B = B; a.NN = hp.NN; a.L = hp.L; a.training = training;
+            { const char* e = getenv("MSHGNN_DBG"); a.dbg = e ? atoi(e) : 0; }
+            a.params = params; a.out_mask = p->d_out_mask; a.out = out; a.off_dec_w = d.off_dec_w; a.off_dec_b = d.off_dec_b;
+            a.node0 = hp.type_base[d.out_type]; a.n_out = d.type_nodes[d.out_type]; a.dout = d.out_channels;
+            ProfScope ps(p, hp.ks_stack_fwd, st);
+            hipLaunchKernelGGL(k_stack_fwd<T>, dim3(tiles), dim3(LAYER_THREADS), hp.fs_blk * Prec<T>::BLK, st, a);
+            HIPCHK(hipGetLastError());
+            return MSHGNN_OK;
+        }
+    }
     for (int l = 0; l < hp.L; ++l) {
         LayerArgs a{};
         a.x_in = ws + lay.x[l]; a.x_out = ws + lay.x[l + 1]; a.maskbits = reinterpret_cast<unsigned*>(ws + lay.mask[l]);
@@ -1522,7 +1879,21 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
         hipLaunchKernelGGL(k_dec_bwd<T>, dim3(NWG_DEC), dim3(256), 0, st, a);
     }
     const int tiles = (B + Prec<T>::ROWS - 1) / Prec<T>::ROWS;
-    for (int l = hp.L - 1; l >= 0; --l) {
+    bool fused_done = false;
+    if constexpr (sizeof(T) == 2) {
+        if (p->use_fused) {
+            StackArgs a{};
+            a.tile_in = ws + lay.dx[hp.L]; a.ws = ws;
+            for (int l = 0; l <= hp.L; ++l) { a.x_off[l] = lay.x[l]; a.dx_off[l] = lay.dx[l]; }
+            for (int l = 0; l < hp.L; ++l) { a.mask_off[l] = lay.mask[l]; a.t1_off[l] = lay.t1[l]; a.dh_off[l] = lay.dh[l]; a.du_off[l] = lay.du[l]; a.prog_off[l] = hp.fs_bwd_off[l]; }
+            a.wpack = ws + lay.wpack; a.bias = reinterpret_cast<const float*>(ws + lay.bias); a.tables = p->d_tables;
+            a.B = B; a.NN = hp.NN; a.L = hp.L; a.training = 1;
+            ProfScope ps(p, hp.ks_stack_bwd, st);
+            hipLaunchKernelGGL(k_stack_bwd<T>, dim3(tiles), dim3(LAYER_THREADS), hp.fs_blk * Prec<T>::BLK, st, a);
+            fused_done = true;
+        }
+    }
+    for (int l = hp.L - 1; l >= 0 && !fused_done; --l) {
         LayerArgs a{};
         a.x_in = ws + lay.dx[l + 1]; a.x_out = ws + lay.dx[l]; a.maskbits = reinterpret_cast<unsigned*>(ws + lay.mask[l]);
         a.hb = ws + lay.hb[l]; a.t1 = ws + lay.t1[l]; a.dh = ws + lay.dh[l]; a.du = ws + lay.du[l]; a.x_act = ws + lay.x[0];

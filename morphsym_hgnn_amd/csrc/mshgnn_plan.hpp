@@ -49,6 +49,27 @@ constexpr int WPROG_LEN = 128;
 // backward program header: [n_groups, n_mlp_live, w2pack, w1pack, has_delta, 0,0,0, node_kind[64], node_flags[64], mlp_nodes[GMAX]]
 enum { BH_NGROUPS = 0, BH_NMLP, BH_W2, BH_W1, BH_HAS_DELTA, BH_KIND = 8, BH_NFLAGS = 8 + 64, BH_MLPNODES = 8 + 128, BH_SIZE = 8 + 128 + GMAX };
 
+// FUSED STACK kernels (bf16 plan): one workgroup keeps its 16-window tile of ALL nodes in LDS through every layer, so a
+// layer's output never makes a round trip through HBM before the next layer reads it (the stashes for the backward
+// pass are written on the side).  Every node owns one accumulator for the whole layer: node n -> wave half n & 1,
+// accumulator n >> 1, so a layer is ONE group of <= 2 FS_HS slots and its epilogue runs once, after every wave has
+// finished reading the previous activations (which it then overwrites in place).
+constexpr int FS_HS = 10;                // accumulators per wave
+constexpr int FS_MAXN = 2 * FS_HS;       // nodes per window the fused kernels support
+constexpr int FPROG_LEN = 128;           // ints per wave program (two VGPRs): 64 pack ids + 256 byte entries
+// per-layer header (same layout forward / backward), then two wave programs (one per half) of FPROG_LEN ints:
+//   ints [0, 64): pack id of segment s;  ints [64, 128): 256 byte entries, 4 per int, LSB first:
+//   [nseg, then the COUNT stream: per segment, per accumulator u (node 2u + half) its number of MACs, then the BLOCK
+//    stream: the source blocks of all MACs in execution order (+ one pad entry, so the kernel can always fetch the
+//    block after the current one and prefetch its fragment)]
+enum { FH_NSEG = 0, FH_NMLP, FH_W1, FH_W2, FH_B1, FH_B2, FH_FLAGS, FH_MLP0,   // FH_MLP0: first node of the base_transform type
+       FH_KIND = 8,                      // NK_* of node n in this layer
+       FH_BIAS = 8 + FS_MAXN,            // fwd: bias row of node n
+       FH_OUT = 8 + 2 * FS_MAXN,         // bwd: dX_l[n] is produced
+       FH_RES = 8 + 3 * FS_MAXN,         // bwd: dX_{l+1}[n] flows into dX_l[n] through the residual
+       FH_SIZE = 8 + 4 * FS_MAXN };
+enum { FF_RESIDUAL = 1, FF_ENC_MASK = 2 };
+
 // buffer ids used by weight-gradient items
 enum { BUF_X = 0, BUF_DX = 17, BUF_DH = 34, BUF_HB = 50, BUF_T1 = 66, BUF_DU = 82, BUF_IN = 98, BUF_MASK = 102, BUF_COUNT = 118 };   // (dd: D_l deltas are not read by the weight-gradient kernel)
 // last item int: relu-bit buffer (BUF_MASK + l) when P = dX_{l+1}[node] . relu bits (dH of a relu node is recomputed
@@ -99,6 +120,10 @@ struct HostPlan {
     // programs
     std::vector<int32_t> tables;                  // everything below lives here (device copy = same layout)
     int fwd_prog_off[MAX_L]{}, bwd_prog_off[MAX_L]{};
+    bool fused = false;                           // fused stack kernels available (bf16, <= FS_MAXN nodes, programs fit)
+    int fs_fwd_off[MAX_L]{}, fs_bwd_off[MAX_L]{};
+    int fs_blk = 0;                               // LDS blocks of the fused kernels (NN + base_transform scratch)
+    int ks_stack_fwd = -1, ks_stack_bwd = -1;
     int item_off = 0, n_items = 0, tgt_off = 0, n_targets = 0, lane_off = 0, n_lanes = 0, n_parts = 1, n_wg_gradw = 0;
     int lane_order_off = 0, n_lanes_pad = 0;
     int fin_off = 0, n_fin = 0;
@@ -410,6 +435,98 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
         lf_alg[l] = alg_fwd - af0; lf_exec[l] = exec_fwd - ef0; lb_alg[l] = alg_bwd - ab0; lb_exec[l] = exec_bwd - eb0;
     }
     if (prog_overflow) return fail(p, "a layer's MAC program exceeds 128 entries per wave (too many relations/edges for this build)");
+
+    // ---- fused stack programs (bf16 plan) ---------------------------------------------------------------
+    p.fused = d.dtype == MSHGNN_BF16 && p.NN <= FS_MAXN && (int64_t)(p.NN + p.n_mlp) * p.blk_bytes <= LDS_LIMIT &&
+              (!has_mlp || (p.type_base[d.mlp_type] == 0 && p.n_mlp <= 4));   // base_transform nodes are accumulators 0..1 of each wave half
+    p.fs_blk = p.NN + p.n_mlp;
+    if (p.fused) {
+        auto emit_fused = [&](const std::vector<Seg>& segs) {   // Seg.macs = (node, source block)
+            for (int half = 0; half < 2 && p.fused; ++half) {
+                std::vector<int> w, blocks;    // byte entries
+                w.push_back((int)segs.size());
+                for (const Seg& sg : segs) {
+                    for (int u = 0; u < FS_HS; ++u) {
+                        int c = 0;
+                        for (auto& m : sg.macs) if (m.first == 2 * u + half) { blocks.push_back(m.second); ++c; }
+                        w.push_back(c);
+                    }
+                }
+                blocks.push_back(blocks.empty() ? 0 : blocks.back());
+                for (int b : blocks) w.push_back(b);
+                if (segs.size() > 64 || w.size() > 256) { p.fused = false; break; }
+                w.resize(256, 0);
+                for (int sgi = 0; sgi < 64; ++sgi) T.push_back(sgi < (int)segs.size() ? segs[sgi].pack : 0);
+                for (int i = 0; i < 64; ++i) T.push_back(w[4 * i] | (w[4 * i + 1] << 8) | (w[4 * i + 2] << 16) | (w[4 * i + 3] << 24));
+            }
+        };
+        for (int l = 0; l < L && p.fused; ++l) {
+            const bool mlp_live = has_mlp && p.live[l][d.mlp_type];
+            // forward
+            {
+                const int fh = (int)T.size(); T.resize(T.size() + FH_SIZE, 0);
+                p.fs_fwd_off[l] = fh;
+                T[fh + FH_NMLP] = mlp_live ? p.n_mlp : 0; T[fh + FH_FLAGS] = residual ? FF_RESIDUAL : 0;
+                T[fh + FH_MLP0] = has_mlp ? p.type_base[d.mlp_type] : 0;
+                if (mlp_live) { T[fh + FH_W1] = p.pack_mlp[0][0]; T[fh + FH_W2] = p.pack_mlp[0][1]; T[fh + FH_B1] = p.bias_mlp[0]; T[fh + FH_B2] = p.bias_mlp[1]; }
+                for (int n = 0; n < p.NN; ++n) {
+                    const int t = p.node_type[n];
+                    T[fh + FH_KIND + n] = !p.live[l][t] ? NK_DEAD : ((has_mlp && t == d.mlp_type) ? NK_MLP : NK_RELU);
+                    T[fh + FH_BIAS + n] = p.live[l][t] ? p.bias_layer[l * NT + t] : 0;
+                }
+                std::vector<Seg> segs;
+                for (int t = 0; t < NT; ++t) {
+                    if (!p.live[l][t]) continue;
+                    Seg root; root.pack = p.pack_root[0][l * NT + t];
+                    for (int i = 0; i < d.type_nodes[t]; ++i) root.macs.push_back({p.type_base[t] + i, p.type_base[t] + i});
+                    segs.push_back(root);
+                    for (int r = 0; r < NR; ++r) {
+                        if (p.rel_dst[r] != t || p.pack_rel[0][l * NR + r] < 0) continue;
+                        Seg sg; sg.pack = p.pack_rel[0][l * NR + r];
+                        for (int e = p.rel_edge_off[r]; e < p.rel_edge_off[r + 1]; ++e)
+                            sg.macs.push_back({p.type_base[t] + p.edges[2 * e + 1], p.type_base[p.rel_src[r]] + p.edges[2 * e]});
+                        segs.push_back(sg);
+                    }
+                }
+                T[fh + FH_NSEG] = (int)segs.size();
+                emit_fused(segs);
+            }
+            if (!p.fused) break;
+            // backward
+            {
+                const int bh2 = (int)T.size(); T.resize(T.size() + FH_SIZE, 0);
+                p.fs_bwd_off[l] = bh2;
+                T[bh2 + FH_NMLP] = mlp_live ? p.n_mlp : 0;
+                T[bh2 + FH_FLAGS] = (residual ? FF_RESIDUAL : 0) | (l == 0 ? FF_ENC_MASK : 0);
+                T[bh2 + FH_MLP0] = has_mlp ? p.type_base[d.mlp_type] : 0;
+                if (mlp_live) { T[bh2 + FH_W2] = p.pack_mlp[1][1]; T[bh2 + FH_W1] = p.pack_mlp[1][0]; }
+                for (int n = 0; n < p.NN; ++n) {
+                    const int t = p.node_type[n];
+                    T[bh2 + FH_KIND + n] = !p.live[l][t] ? NK_DEAD : ((has_mlp && t == d.mlp_type) ? NK_MLP : NK_RELU);
+                    T[bh2 + FH_OUT + n] = p.need_dx[l][t] ? 1 : 0;
+                    T[bh2 + FH_RES + n] = (residual && p.live[l][t] && p.need_dx[l][t]) ? 1 : 0;
+                }
+                std::vector<Seg> segs;
+                for (int t = 0; t < NT; ++t) {
+                    if (!p.need_dx[l][t]) continue;
+                    if (p.live[l][t]) {
+                        Seg root; root.pack = p.pack_root[1][l * NT + t];
+                        for (int i = 0; i < d.type_nodes[t]; ++i) root.macs.push_back({p.type_base[t] + i, p.type_base[t] + i});
+                        segs.push_back(root);
+                    }
+                    for (int r = 0; r < NR; ++r) {
+                        if (p.rel_src[r] != t || !p.live[l][p.rel_dst[r]] || p.pack_rel[1][l * NR + r] < 0) continue;
+                        Seg sg; sg.pack = p.pack_rel[1][l * NR + r];
+                        for (int e = p.rel_edge_off[r]; e < p.rel_edge_off[r + 1]; ++e)
+                            sg.macs.push_back({p.type_base[t] + p.edges[2 * e], p.type_base[p.rel_dst[r]] + p.edges[2 * e + 1]});
+                        segs.push_back(sg);
+                    }
+                }
+                T[bh2 + FH_NSEG] = (int)segs.size();
+                emit_fused(segs);
+            }
+        }
+    }
     // algorithmic dX work: one node-linear per (relation, src node with >=1 out-edge into a live dst) -- count below
     for (int l = 0; l < L; ++l)
         for (int r = 0; r < NR; ++r) {
@@ -616,6 +733,16 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
         // (2.5 PF / 8 TB/s = 312 FLOP/B), so HBM is the bounding roofline (fp32: 157 TF / 8 TB/s = 20 FLOP/B -> MFMA-bound)
         p.ks_gradw = add("gradw", d.dtype == MSHGNN_F32 ? MSHGNN_BOUND_MFMA : MSHGNN_BOUND_HBM, gw_alg, gw_exec, bytes + (double)L * 2 * act + act);
         p.ks_fin = add("finalize", MSHGNN_BOUND_HBM, 0, 0, 0);
+        if (p.fused) {   // the fused stack kernels replace layer_fwd* + dec_fwd and layer_bwd* of the step
+            double fa = 0, fe = 0, fb = act, ba = 0, be = 0, bb = act;
+            for (int l = 0; l < L; ++l) {
+                fa += lf_alg[l]; fe += lf_exec[l]; fb += live_nodes(l) * (double)H * es + live_nodes(l) * 16.0;
+                ba += lb_alg[l]; be += lb_exec[l]; bb += need_nodes(l) * (double)H * es + live_nodes(l) * 16.0;
+            }
+            fa += 2.0 * n_out * d.out_channels * H; fe += 2.0 * n_out * d.out_channels * H;
+            p.ks_stack_fwd = add("stack_fwd", MSHGNN_BOUND_MFMA, fa, fe, fb);
+            p.ks_stack_bwd = add("stack_bwd", MSHGNN_BOUND_MFMA, ba, be, bb);
+        }
     }
     return true;
 }

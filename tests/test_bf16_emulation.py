@@ -23,13 +23,17 @@ def test_emulation_without_rounding_is_the_oracle(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["a1c2_h128_L2_d3_B37", "a1c2_h128_L3_d3_B3", "mck4_reg_h128_L1_B2", "mi_h128_L2_d1_B3"])
-def test_bf16_plan_matches_rounding_point_emulation(name):
+@pytest.mark.parametrize("fused", ["1", "0"])
+@pytest.mark.parametrize("name", ["a1c2_h128_L2_d3_B37", "a1c2_h128_L3_d3_B3", "mck4_reg_h128_L1_B2", "mi_h128_L2_d1_B3",
+                                  "solok4com_h128_L3_B5", "soloc2com_h128_L2_B4", "solos4com_h128_L2_B3"])
+def test_bf16_plan_matches_rounding_point_emulation(name, fused, monkeypatch):
     """bf16 plan vs the fp64 model with bf16 rounding at the engine's storage points.  Remaining differences: fp32
     accumulation and rare 1-ulp bf16 re-roundings (2^-8 relative on single elements), hence norm-wise tolerances:
-    outputs 4e-3 (max-abs relative), gradients 1.5e-2 (L2 relative)."""
+    outputs 4e-3 (max-abs relative), gradients 1.5e-2 (L2 relative).  Both kernel sets of the bf16 plan are covered:
+    the fused stack kernels (default) and the per-layer kernels (MSHGNN_FUSED=0, read when the plan is created)."""
     assert torch.cuda.is_available()
     from morphsym_hgnn_amd import engine as eng
+    monkeypatch.setenv("MSHGNN_FUSED", fused)
     case, spec, fx, x_dict, y, params, ei = helpers.load_case(name)
     B = case["B"]
     e = eng.Engine(spec, "bf16")
