@@ -1593,6 +1593,7 @@ __global__ __launch_bounds__(256, GW_WPS) void k_gradw_bf16(GradwArgs a) {
     }
 }
 
+static_assert(NWG_DEC == 512, "k_finalize sums 8 decoder slabs per lane");
 // k_finalize: sum split-K slabs in fixed order into the flat gradient buffer (every parameter written once)
 struct FinArgs { const int* fin; const int* targets; const float* slabs; const float* dec_slabs; float* grad; int n_lanes, n_parts; float* loss; float inv_n; };
 
@@ -1610,34 +1611,45 @@ __global__ __launch_bounds__(256) void k_finalize(FinArgs a) {
         for (int m = 32; m >= 1; m >>= 1) l += __shfl_xor(l, m, 64);
         if (threadIdx.x == 0) *a.loss = l * a.inv_n;
     }
-    if (n <= 0) return;
     const bool is_mat = (kind == FIN_MATRIX || kind == FIN_DEC_W);
+    if (kind == FIN_DEC_W || kind == FIN_DEC_B) {
+        // decoder partials: NWG_DEC slabs per element -> one WAVE per element, 8 slabs per lane in flight, then a fixed
+        // xor-shuffle tree (deterministic); elements are dealt round-robin to the (gridDim.y x 4) waves of this op
+        const int lane = threadIdx.x & 63, wave = blockIdx.y * 4 + (threadIdx.x >> 6), nwaves = gridDim.y * 4;
+        for (int e = wave; e < rows * cols; e += nwaves) {
+            const int r = e / cols, cidx = e % cols;
+            const int src = is_mat ? r * H + cidx : 8 * H + cidx;
+            float v[NWG_DEC / 64];
+#pragma unroll
+            for (int u = 0; u < NWG_DEC / 64; ++u) v[u] = a.dec_slabs[(size_t)(lane + 64 * u) * DEC_SLAB_FLOATS + src];
+            float sum = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) sum += __shfl_xor(sum, m, 64);
+            if (lane == 0) a.grad[dst + (int64_t)r * ld + cidx] = sum;
+        }
+        return;
+    }
+    if (n <= 0) return;
     for (int i = threadIdx.x; i < n; i += 256) {
         const int r = r0 + i / cols, cidx = i % cols;
         float s = 0.f;
         if (kind == FIN_MATRIX || kind == FIN_BIAS) {
             const int src = is_mat ? r * H + cidx : H * H + cidx;
             const int l0 = a.targets[tg * TGT_INTS], nl = a.targets[tg * TGT_INTS + 1] - l0;
-            const int total = nl * a.n_parts;     // slab(k) = (k / nl) * n_lanes + l0 + k % nl   -- fixed summation order
-            int k = 0;
-            for (; k + 8 <= total; k += 8) {
-                float v[8];
+            // slab(part, j) = part * n_lanes + l0 + j; summed lane-major in batches of 16 loads -- fixed summation order
+            const float* sp = a.slabs + (size_t)l0 * SLAB_FLOATS + src;
+            const size_t pstride = (size_t)a.n_lanes * SLAB_FLOATS;
+            for (int j0 = 0; j0 < nl; j0 += 4)
+                for (int p0 = 0; p0 < a.n_parts; p0 += 4) {
+                    float v[4][4];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int kk = k + u;
-                    v[u] = a.slabs[(size_t)((kk / nl) * a.n_lanes + l0 + kk % nl) * SLAB_FLOATS + src];
+                    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                        for (int pp = 0; pp < 4; ++pp)
+                            v[jj][pp] = (j0 + jj < nl && p0 + pp < a.n_parts) ? sp[(size_t)(j0 + jj) * SLAB_FLOATS + (size_t)(p0 + pp) * pstride] : 0.f;
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) s += (v[jj][0] + v[jj][1]) + (v[jj][2] + v[jj][3]);
                 }
-                s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-            }
-            for (; k < total; ++k) s += a.slabs[(size_t)((k / nl) * a.n_lanes + l0 + k % nl) * SLAB_FLOATS + src];
-        } else if (kind == FIN_DEC_W || kind == FIN_DEC_B) {
-            const int src = is_mat ? r * H + cidx : 8 * H + cidx;
-            for (int b = 0; b < NWG_DEC; b += 8) {
-                float v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = a.dec_slabs[(size_t)(b + u) * DEC_SLAB_FLOATS + src];
-                s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-            }
         }
         a.grad[dst + (int64_t)r * ld + cidx] = s;
     }
@@ -1928,7 +1940,7 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
                   reinterpret_cast<const float*>(ws + lay.dec_slabs), gparams, hp.n_lanes, hp.n_parts, y ? loss : nullptr,
                   1.0f / (float)((int64_t)B * d.type_nodes[d.out_type] * d.out_channels)};
         ProfScope ps(p, hp.ks_fin, st);
-        hipLaunchKernelGGL(k_finalize, dim3(hp.n_fin, 32), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_finalize, dim3(hp.n_fin, 64), dim3(256), 0, st, a);
     }
     HIPCHK(hipGetLastError());
     return MSHGNN_OK;
