@@ -170,6 +170,26 @@ int mshgnn_adam_step(float* params, const float* grads, float* exp_avg, float* e
  * grad_out = 2 (out - y) / n.  loss_out: device float[1].                                               */
 int mshgnn_mse_loss(const float* out, const float* y, int64_t n, float* loss_out, float* grad_out, void* stream);
 
+/* ---- step metrics of the Lightning wrappers ------------------------------------------
+ * The reference's torchmetrics states are plain sums across steps (gnnLightning.py:52-63, customMetrics.py:11-54); each
+ * call ADDS one step's sums into caller-owned device state (zero it to start an epoch / to get step values).  Math in
+ * fp64, one workgroup with a fixed reduction order (bit-reproducible).
+ *
+ * regression (calculate_losses_step, gnnLightning.py:124-130 / :633-639): state double[3]:
+ *   [0] += sum (y_pred - y)^2   [1] += sum |y_pred - y|   [2] += n        => MSE = [0]/[2], RMSE = sqrt(MSE), L1 = [1]/[2] */
+int mshgnn_metrics_regression(const float* y_pred, const float* y, int64_t n, double* state, void* stream);
+
+/* classification (gnnLightning.py:132-151, 285-348): logits fp32 [batch*4][2] (per foot: no-contact, contact), labels int32
+ * [batch][4] in {0,1}.  ce_state double[2]: [0] += sum of per-foot cross entropies, [1] += 4*batch.  counts int64[18]:
+ *   [0] += batch, [1] += windows whose 16-class argmax (classification_conversion_16_class, :306-348) equals the label
+ *   state 8 y0 + 4 y1 + 2 y2 + y3, [2 + 4k .. 5 + 4k] += tp, fp, fn, tn of leg k (BinaryF1Score, customMetrics.py:26-54). */
+int mshgnn_metrics_classification(const float* logits, const int32_t* y, int64_t batch, double* ce_state, int64_t* counts,
+                                  void* stream);
+
+/* body_frame_to_world_frame (gnnLightning.py:663-676) without the per-step CPU/scipy round trip: quat fp32 [batch][4] is
+ * the world->body rotation, scalar-last (x, y, z, w) as scipy.Rotation.from_quat takes it; grf fp32 [batch][4][3].       */
+int mshgnn_grf_body_to_world(const float* quat, const float* grf_body, float* grf_world, int64_t batch, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

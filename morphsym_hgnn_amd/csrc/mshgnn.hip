@@ -2017,3 +2017,136 @@ extern "C" int mshgnn_mse_loss(const float* out, const float* y, int64_t n, floa
     HIPCHK(hipGetLastError());
     return MSHGNN_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------
+// Step metrics of the Lightning wrappers, on device.  The reference keeps
+// torchmetrics states that are plain sums across steps (gnnLightning.py:52-63, customMetrics.py:11-54); these kernels
+// ADD one step's sums into caller-owned state buffers.  One workgroup, fixed reduction order: deterministic.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ long long wave_sum(long long v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// regression (calculate_losses_step, gnnLightning.py:124-130): state[0] += sum (pred - y)^2, state[1] += sum |pred - y|, state[2] += n
+__global__ __launch_bounds__(1024) void k_metrics_reg(const float* pred, const float* y, int64_t n, double* state) {
+    __shared__ double r0[16], r1[16];
+    double s = 0.0, a = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const double dlt = (double)pred[i] - (double)y[i];
+        s += dlt * dlt; a += fabs(dlt);
+    }
+    s = wave_sum(s); a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) { r0[threadIdx.x >> 6] = s; r1[threadIdx.x >> 6] = a; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ts = 0.0, ta = 0.0;
+        for (int k = 0; k < 16; ++k) { ts += r0[k]; ta += r1[k]; }
+        state[0] += ts; state[1] += ta; state[2] += (double)n;
+    }
+}
+
+// classification (gnnLightning.py:132-151, 285-348): logits [B*4][2], labels [B][4] in {0,1}.
+//   ce_state[0] += sum of per-foot cross entropies, ce_state[1] += 4 B                      (customMetrics.py:17-24)
+//   counts[0] += B, counts[1] += windows whose 16-class argmax equals the label state       (Accuracy, 16 classes)
+//   counts[2 + 4 k + {0,1,2,3}] += tp, fp, fn, tn of leg k                                   (BinaryF1Score)
+// The 16-class probabilities are the reference's products (p or 1 - p per foot, ((f0 f1)(f2 f3)), first maximum wins).
+constexpr int MET_COUNTS = 18;
+__global__ __launch_bounds__(1024) void k_metrics_cls(const float* logits, const int32_t* y, int64_t B, double* ce_state, long long* counts) {
+    __shared__ double rce[16];
+    __shared__ long long rc[16][MET_COUNTS];
+    double ce = 0.0;
+    long long c[MET_COUNTS];
+#pragma unroll
+    for (int k = 0; k < MET_COUNTS; ++k) c[k] = 0;
+    for (int64_t w = threadIdx.x; w < B; w += 1024) {
+        double p1[4];
+        int state = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double l0 = (double)logits[(w * 4 + k) * 2], l1 = (double)logits[(w * 4 + k) * 2 + 1];
+            const double m = fmax(l0, l1), e0 = exp(l0 - m), e1 = exp(l1 - m), se = e0 + e1;
+            const int lab = y[w * 4 + k] != 0;
+            ce += (m + log(se)) - (lab ? l1 : l0);
+            const double p0 = e0 / se; p1[k] = e1 / se;
+            const int pred = p1[k] > p0 ? 1 : 0;             // argmax over (p0, p1): the first maximum wins
+            c[2 + 4 * k + (pred ? (lab ? 0 : 1) : (lab ? 2 : 3))] += 1;
+            state = state * 2 + lab;
+        }
+        int best = 0; double bestv = -1.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const double f0 = (j & 8) ? p1[0] : 1.0 - p1[0], f1 = (j & 4) ? p1[1] : 1.0 - p1[1];
+            const double f2 = (j & 2) ? p1[2] : 1.0 - p1[2], f3 = (j & 1) ? p1[3] : 1.0 - p1[3];
+            const double v = (f0 * f1) * (f2 * f3);
+            if (v > bestv) { bestv = v; best = j; }
+        }
+        c[0] += 1; c[1] += (best == state);
+    }
+    ce = wave_sum(ce);
+#pragma unroll
+    for (int k = 0; k < MET_COUNTS; ++k) c[k] = wave_sum(c[k]);
+    if ((threadIdx.x & 63) == 0) {
+        rce[threadIdx.x >> 6] = ce;
+#pragma unroll
+        for (int k = 0; k < MET_COUNTS; ++k) rc[threadIdx.x >> 6][k] = c[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int k = 0; k < 16; ++k) t += rce[k];
+        ce_state[0] += t; ce_state[1] += (double)(4 * B);
+    }
+    if (threadIdx.x < MET_COUNTS) {
+        long long t = 0;
+        for (int k = 0; k < 16; ++k) t += rc[k][threadIdx.x];
+        counts[threadIdx.x] += t;
+    }
+}
+
+// GRF body frame -> world frame (gnnLightning.py:663-676): quat = world->body rotation, scalar-last (x, y, z, w) as scipy's
+// Rotation.from_quat takes it (normalised here as scipy does); world = R(quat)^-1 f for each of the 4 feet.
+__global__ void k_grf_to_world(const float* quat, const float* body, float* world, int64_t B) {
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= B) return;
+    double x = quat[w * 4], yq = quat[w * 4 + 1], z = quat[w * 4 + 2], s = quat[w * 4 + 3];
+    const double nrm = sqrt(x * x + yq * yq + z * z + s * s);
+    x /= nrm; yq /= nrm; z /= nrm; s /= nrm;
+    // R = matrix of the unit quaternion; its inverse is the transpose
+    const double R[3][3] = {{1 - 2 * (yq * yq + z * z), 2 * (x * yq - z * s), 2 * (x * z + yq * s)},
+                            {2 * (x * yq + z * s), 1 - 2 * (x * x + z * z), 2 * (yq * z - x * s)},
+                            {2 * (x * z - yq * s), 2 * (yq * z + x * s), 1 - 2 * (x * x + yq * yq)}};
+    for (int f = 0; f < 4; ++f) {
+        const double b0 = body[w * 12 + f * 3], b1 = body[w * 12 + f * 3 + 1], b2 = body[w * 12 + f * 3 + 2];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) world[w * 12 + f * 3 + i] = (float)(R[0][i] * b0 + R[1][i] * b1 + R[2][i] * b2);
+    }
+}
+
+extern "C" int mshgnn_metrics_regression(const float* y_pred, const float* y, int64_t n, double* state, void* stream) {
+    if (!y_pred || !y || !state || n < 1) return set_err(MSHGNN_EINVAL, "bad argument to mshgnn_metrics_regression");
+    hipLaunchKernelGGL(k_metrics_reg, dim3(1), dim3(1024), 0, (hipStream_t)stream, y_pred, y, n, state);
+    HIPCHK(hipGetLastError());
+    return MSHGNN_OK;
+}
+
+extern "C" int mshgnn_metrics_classification(const float* logits, const int32_t* y, int64_t batch, double* ce_state, int64_t* counts, void* stream) {
+    if (!logits || !y || !ce_state || !counts || batch < 1) return set_err(MSHGNN_EINVAL, "bad argument to mshgnn_metrics_classification");
+    hipLaunchKernelGGL(k_metrics_cls, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, y, batch, ce_state, reinterpret_cast<long long*>(counts));
+    HIPCHK(hipGetLastError());
+    return MSHGNN_OK;
+}
+
+extern "C" int mshgnn_grf_body_to_world(const float* quat, const float* grf_body, float* grf_world, int64_t batch, void* stream) {
+    if (!quat || !grf_body || !grf_world || batch < 1) return set_err(MSHGNN_EINVAL, "bad argument to mshgnn_grf_body_to_world");
+    hipLaunchKernelGGL(k_grf_to_world, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, (hipStream_t)stream, quat, grf_body, grf_world, batch);
+    HIPCHK(hipGetLastError());
+    return MSHGNN_OK;
+}
+
