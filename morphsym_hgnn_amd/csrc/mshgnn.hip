@@ -2150,3 +2150,110 @@ extern "C" int mshgnn_grf_body_to_world(const float* quat, const float* grf_body
     return MSHGNN_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// On-device window assembly: the raw time series of a sequence stay in HBM and a batch of
+// windows [start, start + T) is gathered straight into the engine's input layout [B][n_t][pitch] at the plan dtype --
+// what the reference does per window in Python (quadSDKDataset_Morph.py:304-369: axis-major flatten('F') of each
+// variable, joint re-ordering, base tiling, all-ones feet) followed by PyG's collate.
+// One wave per RUN = T consecutive features of one node row: feature f0 + t = src[start + t][col] (optionally
+// standardised over the window like flexibleDataset.py:390-396), or the constant 1.
+// ------------------------------------------------------------------------------------------------------
+constexpr int WIN_MAX_SRC = 12;
+struct WindowArgs {
+    const float* src[WIN_MAX_SRC]; int64_t src_pitch[WIN_MAX_SRC];
+    void* x[MSHGNN_MAX_TYPES]; int64_t x_pitch[MSHGNN_MAX_TYPES]; int nodes[MSHGNN_MAX_TYPES];
+    const int* runs; int n_runs;            // per run: type, node, first feature, source (-1: ones) << 8 | column, length
+    const int64_t* starts; int64_t B; int T, normalize;
+    const int* label_cols; int n_label, label_src, label_rotate, quat_src;
+    float* y; float* quat;
+};
+
+template <typename T> __global__ __launch_bounds__(256) void k_assemble_windows(WindowArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t gw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);          // global wave = (window, run)
+    if (gw >= a.B * a.n_runs) return;
+    const int64_t b = gw / a.n_runs; const int r = (int)(gw % a.n_runs);
+    const int* run = a.runs + r * 5;
+    const int t = run[0], node = run[1], f0 = run[2], sc = run[3], len = run[4];
+    T* dst = reinterpret_cast<T*>(a.x[t]) + ((size_t)b * a.nodes[t] + node) * a.x_pitch[t] + f0;
+    if (sc < 0) { for (int k = lane; k < len; k += 64) dst[k] = from_f32<T>(1.0f); return; }
+    const float* src = a.src[sc >> 8] + (size_t)a.starts[b] * a.src_pitch[sc >> 8] + (sc & 0xff);
+    const int64_t pitch = a.src_pitch[sc >> 8];
+    if (!a.normalize) { for (int k = lane; k < len; k += 64) dst[k] = from_f32<T>(src[(size_t)k * pitch]); return; }
+    // (x - mean) / std with the unbiased estimator, NaN -> 0 (flexibleDataset.py:390-396); fp64, two passes
+    double s = 0.0;
+    for (int k = lane; k < len; k += 64) s += (double)src[(size_t)k * pitch];
+    const double mean = wave_sum(s) / (double)len;
+    double q = 0.0;
+    for (int k = lane; k < len; k += 64) { const double dlt = (double)src[(size_t)k * pitch] - mean; q += dlt * dlt; }
+    const double sd = sqrt(wave_sum(q) / (double)(len - 1));
+    for (int k = lane; k < len; k += 64) {
+        const double v = ((double)src[(size_t)k * pitch] - mean) / sd;
+        dst[k] = from_f32<T>(v == v ? (float)v : 0.0f);
+    }
+}
+
+// labels of a window = the label row of its LAST time step (quadSDKDataset.py: grfs[-1]); with label_rotate the world-frame
+// GRFs are taken into the body frame with the world->body quaternion of that step, R f per foot (the as_matrix() @ grfs_T
+// branch of load_data_at_dataset_seq_3d); quat out = that quaternion (data.r_o, quadSDKDataset_Morph.py:365-367)
+__global__ void k_window_labels(WindowArgs a) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.B) return;
+    const int64_t row = a.starts[b] + a.T - 1;
+    const float* lab = a.src[a.label_src] + (size_t)row * a.src_pitch[a.label_src];
+    double R[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    if (a.quat_src >= 0) {
+        const float* qp = a.src[a.quat_src] + (size_t)row * a.src_pitch[a.quat_src];
+        if (a.quat) for (int k = 0; k < 4; ++k) a.quat[b * 4 + k] = qp[k];
+        if (a.label_rotate) {
+            double x = qp[0], yq = qp[1], z = qp[2], s = qp[3];
+            const double nrm = sqrt(x * x + yq * yq + z * z + s * s);
+            x /= nrm; yq /= nrm; z /= nrm; s /= nrm;
+            R[0][0] = 1 - 2 * (yq * yq + z * z); R[0][1] = 2 * (x * yq - z * s); R[0][2] = 2 * (x * z + yq * s);
+            R[1][0] = 2 * (x * yq + z * s); R[1][1] = 1 - 2 * (x * x + z * z); R[1][2] = 2 * (yq * z - x * s);
+            R[2][0] = 2 * (x * z - yq * s); R[2][1] = 2 * (yq * z + x * s); R[2][2] = 1 - 2 * (x * x + yq * yq);
+        }
+    }
+    if (a.label_rotate) {
+        for (int f = 0; f + 2 < a.n_label; f += 3) {
+            const double v0 = lab[a.label_cols[f]], v1 = lab[a.label_cols[f + 1]], v2 = lab[a.label_cols[f + 2]];
+            for (int i = 0; i < 3; ++i) a.y[b * a.n_label + f + i] = (float)(R[i][0] * v0 + R[i][1] * v1 + R[i][2] * v2);
+        }
+    } else {
+        for (int k = 0; k < a.n_label; ++k) a.y[b * a.n_label + k] = lab[a.label_cols[k]];
+    }
+}
+
+extern "C" int mshgnn_assemble_windows(const mshgnn_window_desc* d, const float* const* src, const int64_t* src_pitch, const int64_t* src_rows,
+                                       const int64_t* starts, int64_t batch, void* const* x_out, const int64_t* x_pitch, float* y_out,
+                                       float* quat_out, void* stream) {
+    if (!d || !src || !src_pitch || !src_rows || !starts || !x_out || !x_pitch || batch < 1) return set_err(MSHGNN_EINVAL, "null argument to mshgnn_assemble_windows");
+    if (d->n_types < 1 || d->n_types > MSHGNN_MAX_TYPES || d->n_src < 1 || d->n_src > WIN_MAX_SRC || d->n_runs < 1 || !d->runs)
+        return set_err(MSHGNN_EINVAL, "bad window descriptor");
+    if (d->history < 1 || (d->normalize && d->history < 2)) return set_err(MSHGNN_EINVAL, "history must be >= 1 (>= 2 when normalising)");
+    if (d->dtype != MSHGNN_F32 && d->dtype != MSHGNN_BF16) return set_err(MSHGNN_EINVAL, "dtype must be MSHGNN_F32 or MSHGNN_BF16");
+    if (d->n_label > 0 && (!d->label_cols || !y_out || d->label_src < 0 || d->label_src >= d->n_src)) return set_err(MSHGNN_EINVAL, "bad label description");
+    if (d->label_rotate && (d->n_label % 3 != 0 || d->quat_src < 0)) return set_err(MSHGNN_EINVAL, "label rotation needs 3-D labels and a quaternion source");
+    if (d->quat_src >= d->n_src) return set_err(MSHGNN_EINVAL, "quat_src out of range");
+    WindowArgs a{};
+    for (int i = 0; i < d->n_src; ++i) {
+        if (!src[i] || src_pitch[i] < 1 || src_rows[i] < d->history) return set_err(MSHGNN_EINVAL, "bad source array");
+        a.src[i] = src[i]; a.src_pitch[i] = src_pitch[i];
+    }
+    for (int t = 0; t < d->n_types; ++t) {
+        if (!x_out[t] || d->type_nodes[t] < 1 || x_pitch[t] < d->type_width[t]) return set_err(MSHGNN_EINVAL, "bad output tensor");
+        a.x[t] = x_out[t]; a.x_pitch[t] = x_pitch[t]; a.nodes[t] = d->type_nodes[t];
+    }
+    a.runs = d->runs; a.n_runs = d->n_runs; a.starts = starts; a.B = batch; a.T = d->history; a.normalize = d->normalize;
+    a.label_cols = d->label_cols; a.n_label = d->n_label; a.label_src = d->label_src; a.label_rotate = d->label_rotate; a.quat_src = d->quat_src;
+    a.y = y_out; a.quat = quat_out;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t waves = batch * d->n_runs;
+    if (d->dtype == MSHGNN_F32) hipLaunchKernelGGL(k_assemble_windows<float>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_assemble_windows<__bf16>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a);
+    if (d->n_label > 0 || (quat_out && d->quat_src >= 0))
+        hipLaunchKernelGGL(k_window_labels, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, a);
+    HIPCHK(hipGetLastError());
+    return MSHGNN_OK;
+}
+

@@ -55,6 +55,16 @@ class MshgnnWsLayout(C.Structure):
     ]
 
 
+class MshgnnWindowDesc(C.Structure):
+    _fields_ = [
+        ("n_types", C.c_int32), ("dtype", C.c_int32), ("history", C.c_int32), ("normalize", C.c_int32),
+        ("type_nodes", C.c_int32 * 4), ("type_width", C.c_int32 * 4),
+        ("n_src", C.c_int32), ("n_runs", C.c_int32), ("runs", C.c_void_p),
+        ("n_label", C.c_int32), ("label_src", C.c_int32), ("label_rotate", C.c_int32), ("quat_src", C.c_int32),
+        ("label_cols", C.c_void_p),
+    ]
+
+
 class MshgnnKernelStat(C.Structure):
     _fields_ = [
         ("name", C.c_char * 32), ("launches", C.c_int32), ("bound", C.c_int32), ("total_ms", C.c_float), ("_pad", C.c_float),
@@ -66,7 +76,7 @@ EXPORTS = [
     "mshgnn_last_error", "mshgnn_version", "mshgnn_plan_create", "mshgnn_plan_destroy", "mshgnn_plan_info",
     "mshgnn_plan_compile_host", "mshgnn_workspace_layout", "mshgnn_forward", "mshgnn_backward", "mshgnn_mse_loss",
     "mshgnn_profile_enable", "mshgnn_profile_read", "mshgnn_backward_mse", "mshgnn_adam_step",
-    "mshgnn_metrics_regression", "mshgnn_metrics_classification", "mshgnn_grf_body_to_world",
+    "mshgnn_metrics_regression", "mshgnn_metrics_classification", "mshgnn_grf_body_to_world", "mshgnn_assemble_windows",
 ]
 
 _lib = None
@@ -112,6 +122,9 @@ def load_library():
     lib.mshgnn_metrics_regression.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     lib.mshgnn_metrics_classification.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.mshgnn_grf_body_to_world.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.mshgnn_assemble_windows.argtypes = [C.POINTER(MshgnnWindowDesc), C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                            C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p, C.c_void_p,
+                                            C.c_void_p]
     _lib = lib
     return lib
 

@@ -1,0 +1,163 @@
+"""On-device window assembly: a sequence's raw time series live on the GPU and a minibatch of time windows is gathered
+straight into the engine's input layout by `mshgnn_assemble_windows` (include/mshgnn.h).
+
+This is the device counterpart of the reference's per-window Python path (relative to /root/reference/src/ms_hgnn):
+datasets_py/quadSDKDataset_Morph.py:99-175 (`load_data_sorted_c2`), :304-369 (`get_helper_heterogeneous_gnn_c2`),
+:444-489 (`load_data_at_dataset_seq[_3d]`), datasets_py/flexibleDataset.py:340-400, 563-596 and PyG's collate -- i.e.
+`DataLoader(dataset, batch_size=B)` -> `batch.x_dict`, `batch.y`, `batch.r_o` for B window indices at once.
+
+A `WindowRecipe` says, per node type, which columns of which raw series become the T-long runs of a node's feature row
+(variable-major, axis-major: the reference's `flatten('F')` layout); types without variables are all-ones of width 1
+(flexibleDataset.py:183-190).  No CPU implementation: without a HIP device `SequenceStore` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import engine as eng
+
+
+@dataclass
+class WindowRecipe:
+    node_types: List[str]
+    num_nodes: Dict[str, int]
+    history: int                                            # T
+    # per type: list of variables; a variable = (series name, columns[node][axis])
+    variables: Dict[str, List[Tuple[str, List[List[int]]]]]
+    label_series: Optional[str] = None
+    label_cols: List[int] = field(default_factory=list)
+    label_rotate: bool = False                              # 3-D world-frame labels -> body frame (needs quat_series)
+    quat_series: Optional[str] = None
+    normalize: bool = False                                 # per-window standardisation (flexibleDataset.py:390-396)
+
+    def width(self, t: str) -> int:
+        w = sum(len(cols[0]) * self.history for _, cols in self.variables.get(t, []))
+        return w if w > 0 else 1
+
+    def series(self) -> List[str]:
+        names = []
+        for t in self.node_types:
+            for s, _ in self.variables.get(t, []):
+                if s not in names:
+                    names.append(s)
+        for s in (self.label_series, self.quat_series):
+            if s is not None and s not in names:
+                names.append(s)
+        return names
+
+
+def quadsdk_a1_c2_recipe(joint_perm: Sequence[int], foot_perm: Sequence[int], history: int = 150, grf_dimension: int = 3,
+                         body_frame_labels: bool = False, normalize: bool = False, n_base: int = 2) -> WindowRecipe:
+    """The A1 / Quad-SDK C2 dataset (BASELINE config): base = tiled IMU (lin acc, ang vel), joint = (q, qd, tau) in graph
+    order, feet = ones; labels = GRFs of the window's last step in foot order (quadSDKDataset_Morph.py:99-160, 304-369)."""
+    if grf_dimension == 3:
+        lab = [int(3 * i + k) for i in foot_perm for k in range(3)]
+    elif grf_dimension == 1:
+        lab = [int(3 * i + 2) for i in foot_perm]
+    else:
+        raise ValueError("grf_dimension must be 1 or 3")
+    if body_frame_labels and grf_dimension != 3:
+        # the reference rotates the 3-D GRFs first and then keeps z; on device that is the rotated z, which needs all three
+        raise ValueError("body-frame labels need grf_dimension == 3")
+    return WindowRecipe(
+        node_types=["base", "joint", "foot"], num_nodes={"base": n_base, "joint": len(joint_perm), "foot": len(foot_perm)},
+        history=history,
+        variables={"base": [("imu_acc", [[0, 1, 2]] * n_base), ("imu_omega", [[0, 1, 2]] * n_base)],
+                   "joint": [(s, [[int(j)] for j in joint_perm]) for s in ("q", "qd", "tau")], "foot": []},
+        label_series="F", label_cols=lab, label_rotate=body_frame_labels, quat_series="r_o", normalize=normalize)
+
+
+class SequenceStore:
+    """The raw series of one recorded sequence on the GPU + the recipe that turns window indices into engine inputs."""
+
+    def __init__(self, arrays: Dict[str, np.ndarray], recipe: WindowRecipe, dtype: str = "bf16", device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("window assembly runs on a HIP device; there is no CPU fallback")
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.lib = eng.load_library()
+        self.recipe = recipe
+        self.dtype = dtype
+        self.torch_dtype = torch.float32 if dtype == "f32" else torch.bfloat16
+        self.names = recipe.series()
+        self.series = []
+        n_rows = None
+        for s in self.names:
+            a = torch.as_tensor(np.asarray(arrays[s])).to(self.device, torch.float32)
+            a = a.reshape(a.shape[0], -1).contiguous()
+            n_rows = a.shape[0] if n_rows is None else min(n_rows, a.shape[0])
+            self.series.append(a)
+        self.n_rows = int(n_rows)
+        if self.n_rows < recipe.history:
+            raise ValueError("sequence shorter than one window")
+        sidx = {s: i for i, s in enumerate(self.names)}
+        runs = []
+        for ti, t in enumerate(recipe.node_types):
+            vars_ = recipe.variables.get(t, [])
+            if not vars_:
+                runs += [[ti, n, 0, -1, 1] for n in range(recipe.num_nodes[t])]
+                continue
+            for n in range(recipe.num_nodes[t]):
+                f = 0
+                for s, cols in vars_:
+                    ncol = self.series[sidx[s]].shape[1]
+                    for c in cols[n]:
+                        if not 0 <= c < min(ncol, 256):
+                            raise ValueError(f"column {c} of series '{s}' out of range")
+                        runs.append([ti, n, f, (sidx[s] << 8) | c, recipe.history])
+                        f += recipe.history
+        self.runs = torch.tensor(runs, dtype=torch.int32, device=self.device)
+        self.label_cols = torch.tensor(recipe.label_cols or [0], dtype=torch.int32, device=self.device)
+        d = eng.MshgnnWindowDesc()
+        d.n_types = len(recipe.node_types); d.dtype = 0 if dtype == "f32" else 1; d.history = recipe.history
+        d.normalize = int(recipe.normalize)
+        for i, t in enumerate(recipe.node_types):
+            d.type_nodes[i] = recipe.num_nodes[t]; d.type_width[i] = recipe.width(t)
+        d.n_src = len(self.series); d.n_runs = len(runs); d.runs = self.runs.data_ptr()
+        d.n_label = len(recipe.label_cols); d.label_src = sidx[recipe.label_series] if recipe.label_series else 0
+        d.label_rotate = int(recipe.label_rotate); d.quat_src = sidx[recipe.quat_series] if recipe.quat_series else -1
+        d.label_cols = self.label_cols.data_ptr()
+        self.desc = d
+        self._src = (C.c_void_p * len(self.series))(*[a.data_ptr() for a in self.series])
+        self._pitch = (C.c_int64 * len(self.series))(*[a.shape[1] for a in self.series])
+        self._rows = (C.c_int64 * len(self.series))(*[a.shape[0] for a in self.series])
+
+    def __len__(self) -> int:
+        """Number of windows (the reference's dataset length: rows - history + 1)."""
+        return self.n_rows - self.recipe.history + 1
+
+    def padded_width(self, t: str) -> int:
+        epc = 4 if self.dtype == "f32" else 8
+        return (self.recipe.width(t) + epc - 1) // epc * epc
+
+    def assemble(self, starts) -> Tuple[List[torch.Tensor], Optional[torch.Tensor], Optional[torch.Tensor]]:
+        """starts: window start rows (== the reference's dataset indices).  Returns (xs, y, r_o): xs[t] is
+        [B * n_t, padded width] at the store's dtype -- exactly what `Engine.forward` takes (pad columns are zero) --,
+        y float32 [B, n_label], r_o float32 [B, 4]."""
+        r = self.recipe
+        st = torch.as_tensor(starts, dtype=torch.int64).flatten()
+        if st.numel() < 1:
+            raise ValueError("no window indices")
+        if int(st.min()) < 0 or int(st.max()) + r.history > self.n_rows:
+            raise IndexError("window index out of range")
+        st = st.to(self.device)
+        B = st.numel()
+        xs = []
+        for t in r.node_types:
+            P = self.padded_width(t)
+            x = torch.zeros(B * r.num_nodes[t], P, dtype=self.torch_dtype, device=self.device) if P != r.width(t) else \
+                torch.empty(B * r.num_nodes[t], P, dtype=self.torch_dtype, device=self.device)
+            xs.append(x)
+        y = torch.empty(B, len(r.label_cols), dtype=torch.float32, device=self.device) if r.label_cols else None
+        q = torch.empty(B, 4, dtype=torch.float32, device=self.device) if r.quat_series else None
+        xp = (C.c_void_p * len(xs))(*[x.data_ptr() for x in xs])
+        pitch = (C.c_int64 * len(xs))(*[x.shape[1] for x in xs])
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        rc = self.lib.mshgnn_assemble_windows(C.byref(self.desc), self._src, self._pitch, self._rows, st.data_ptr(), B, xp, pitch,
+                                              y.data_ptr() if y is not None else None, q.data_ptr() if q is not None else None, stream)
+        eng._check(self.lib, rc, "mshgnn_assemble_windows")
+        return xs, y, q

@@ -1,0 +1,110 @@
+"""ORACLE TOOLING -- runs ONLY in the build container (needs /root/reference).  Pins oracle/window_oracle.py against the
+reference's own window-building functions and writes tests/golden/windows_a1c2.npz.
+
+The reference's dataset module is imported BY FILE (oracle/import_stubs provides import-only stand-ins for rosbags /
+torchvision / urchin, oracle/pyg_restated the HeteroData container) and its methods
+`QuadSDKDataset_A1.load_data_at_dataset_seq[_3d]`, `QuadSDKDataset_NewGraph.load_data_sorted_c2` and
+`.get_helper_heterogeneous_gnn_c2` are run on a stub `self` that carries a deterministic synthetic sequence (there is no
+dataset in this image).  For every case the oracle must equal the reference exactly (max abs diff 0; 1e-12 relative for body-frame labels, where
+scipy builds the rotation matrix with a different operation order)."""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(HERE, "pyg_restated"))
+sys.path.insert(0, os.path.join(HERE, "import_stubs"))
+REF = "/root/reference/src/ms_hgnn"
+
+from oracle import window_oracle as wo  # noqa: E402
+
+JOINT_PERM = np.array([6, 7, 8, 0, 1, 2, 9, 10, 11, 3, 4, 5], dtype=np.uint)     # a non-identity order (quadSDKDataset.py:247-258)
+FOOT_PERM = np.array([2, 0, 3, 1], dtype=np.uint)
+
+
+def synthetic_sequence(seed, N):
+    """float32-representable values so that fixtures and device inputs are exact."""
+    rng = np.random.default_rng(seed)
+    f = lambda *s: rng.integers(-2000, 2000, size=s).astype(np.float64) / 64.0
+    seq = {"imu_acc": f(N, 3), "imu_omega": f(N, 3), "q": f(N, 12), "qd": f(N, 12), "tau": f(N, 12), "F": f(N, 12) * 4,
+           "r_p": f(N, 3), "r_o": f(N, 4), "timestamps": f(N, 3)}
+    seq["r_o"][:, 3] += 40.0        # keep the quaternions away from zero norm
+    return seq
+
+
+def reference_module():
+    pk = types.ModuleType("ms_hgnn"); pk.__path__ = [REF]; sys.modules["ms_hgnn"] = pk
+    dp = types.ModuleType("ms_hgnn.datasets_py"); dp.__path__ = [REF + "/datasets_py"]; sys.modules["ms_hgnn.datasets_py"] = dp
+    return importlib.import_module("ms_hgnn.datasets_py.quadSDKDataset_Morph")
+
+
+def stub_dataset(mod, seq, T, grf_dimension, body_frame, normalize):
+    s = types.SimpleNamespace()
+    s.mat_data = seq; s.history_length = T; s.grf_dimension = grf_dimension; s.grf_body_to_world_frame = body_frame
+    s.normalize = normalize; s.symmetry_operator = None
+    s.joint_node_indices_sorted = JOINT_PERM; s.foot_node_indices_sorted = FOOT_PERM
+    s.hgnn_number_nodes = (2, 12, 4); s.base_width = 6 * T; s.joint_width = 3 * T; s.foot_width = 1
+    s.variables_to_use_base = np.array([0, 1]); s.variables_to_use_joint = np.array([0, 1, 2]); s.variables_to_use_foot = np.array([])
+    s.urdf_name_to_graph_index_joint = {str(i): i for i in range(12)}; s.urdf_name_to_graph_index_foot = {f"f{i}": i for i in range(4)}
+    z = torch.zeros(2, 0, dtype=torch.long)
+    for k in ("bj_front", "jb_front", "bj_back", "jb_back", "jj", "fj", "jf", "bb"):
+        setattr(s, k, z)
+    A1, NG = mod.QuadSDKDataset_A1, mod.QuadSDKDataset_NewGraph
+    s.load_data_at_dataset_seq_3d = types.MethodType(A1.load_data_at_dataset_seq_3d, s)
+    s.load_data_at_dataset_seq = types.MethodType(A1.load_data_at_dataset_seq, s)
+    s.load_data_sorted_c2 = types.MethodType(NG.load_data_sorted_c2, s)
+    s.get = types.MethodType(NG.get_helper_heterogeneous_gnn_c2, s)
+    return s
+
+
+CASES = [dict(name="d3", grf=3, body=False, norm=False), dict(name="d3_body", grf=3, body=True, norm=False),
+         dict(name="d1", grf=1, body=False, norm=False), dict(name="d3_norm", grf=3, body=False, norm=True)]
+
+
+def main():
+    mod = reference_module()
+    T, N, seed = 150, 400, 20240915
+    seq = synthetic_sequence(seed, N)
+    starts = [0, 1, 37, 249, 250]
+    fx = {"seed": np.array(seed), "N": np.array(N), "T": np.array(T), "starts": np.array(starts),
+          "joint_perm": JOINT_PERM.astype(np.int64), "foot_perm": FOOT_PERM.astype(np.int64)}
+    for c in CASES:
+        ds = stub_dataset(mod, seq, T, c["grf"], c["body"], c["norm"])
+        for st in starts:
+            if c["norm"]:
+                # the reference's standardisation line (quadSDKDataset_Morph.py:170) calls np.nan_to_num(tensor, copy=False),
+                # which numpy 2.x (this image) rejects, so that branch cannot be executed here: run the reference WITHOUT it
+                # and apply the same torch expression -- (x - mean) / std(correction=1), NaN -> 0 -- to its raw features
+                ds.normalize = False
+                data = ds.get(st)
+                def nz(x, nvar, axes):   # rows [node][var][axis][T] -> standardise every T-run
+                    v = x.reshape(x.shape[0], nvar * axes, T)
+                    v = torch.nan_to_num((v - v.mean(dim=2, keepdim=True)) / v.std(dim=2, correction=1, keepdim=True), nan=0.0)
+                    return v.reshape(x.shape[0], -1).numpy()
+                rb, rj = nz(data["base"].x, 2, 3), nz(data["joint"].x, 3, 1)
+                rf, ry = data["foot"].x.numpy(), data.y.numpy()
+            else:
+                data = ds.get(st)
+                rb, rj, rf, ry = data["base"].x.numpy(), data["joint"].x.numpy(), data["foot"].x.numpy(), data.y.numpy()
+            ob, oj, of, oy, oq = wo.a1_c2_window(seq, st, T, JOINT_PERM.astype(int), FOOT_PERM.astype(int), c["grf"], c["body"], c["norm"])
+            for a, b, what in ((rb, ob, "base"), (rj, oj, "joint"), (rf, of, "foot"), (ry, oy, "y")):
+                tol = 1e-12 * np.abs(a).max() if ((what == "y" and c["body"]) or c["norm"]) else 0.0   # rotated labels: scipy's matrix vs the closed form
+                assert a.shape == b.shape and np.abs(a - b).max() <= tol, (c["name"], st, what, np.abs(a - b).max())
+            if c["body"]:
+                assert np.abs(data.r_o.numpy() - oq).max() == 0.0
+            # fixture: the label vector and a strided sample of the features (the full rows are a pure function of the seed)
+            fx[f"{c['name']}:{st}:y"] = ry
+            fx[f"{c['name']}:{st}:base"] = rb[:, ::7].copy()
+            fx[f"{c['name']}:{st}:joint"] = rj[:, ::11].copy()
+        print(c["name"], "oracle == reference on", len(starts), "windows")
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "windows_a1c2.npz"), **fx)
+
+
+if __name__ == "__main__":
+    main()

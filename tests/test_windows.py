@@ -1,0 +1,80 @@
+"""On-device window assembly: oracle vs the committed fixture (values produced by the reference's
+own dataset functions, oracle/gen_window_golden.py), and the HIP gather kernel through the C-ABI vs the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import window_oracle as wo
+from oracle.gen_window_golden import synthetic_sequence, CASES
+
+FX = np.load(os.path.join(os.path.dirname(__file__), "golden", "windows_a1c2.npz"))
+T, N = int(FX["T"]), int(FX["N"])
+SEQ = synthetic_sequence(int(FX["seed"]), N)
+JP, FP = FX["joint_perm"].astype(int), FX["foot_perm"].astype(int)
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_oracle_matches_reference_fixture(case):
+    for st in FX["starts"]:
+        b, j, f, y, q = wo.a1_c2_window(SEQ, int(st), T, JP, FP, case["grf"], case["body"], case["norm"])
+        tol = 1e-12 if (case["body"] or case["norm"]) else 0.0
+        key = f"{case['name']}:{int(st)}"
+        assert np.abs(y - FX[key + ":y"]).max() <= tol * max(1.0, np.abs(y).max())
+        assert np.abs(b[:, ::7] - FX[key + ":base"]).max() <= tol and np.abs(j[:, ::11] - FX[key + ":joint"]).max() <= tol
+        assert b.shape == (2, 6 * T) and j.shape == (12, 3 * T) and f.shape == (4, 1) and q.shape == (4,)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_device_assembly_matches_oracle(case, dtype):
+    from morphsym_hgnn_amd.windows import SequenceStore, quadsdk_a1_c2_recipe
+    if case["grf"] == 1 and case["body"]:
+        pytest.skip("not a reference configuration")
+    recipe = quadsdk_a1_c2_recipe(JP, FP, T, case["grf"], case["body"], case["norm"])
+    store = SequenceStore(SEQ, recipe, dtype=dtype)
+    assert len(store) == N - T + 1
+    starts = [0, 1, 37, 249, 250, 17, 17, 250, 3]            # repeats and the last valid window
+    xs, y, q = store.assemble(starts)
+    B = len(starts)
+    want = [wo.a1_c2_window(SEQ, s, T, JP, FP, case["grf"], case["body"], case["norm"]) for s in starts]
+    for ti, (name, n) in enumerate((("base", 2), ("joint", 12), ("foot", 4))):
+        ref = np.stack([w[ti] for w in want]).reshape(B * n, -1)
+        got = xs[ti].float().cpu().numpy().astype(np.float64)
+        F = ref.shape[1]
+        assert got.shape[0] == B * n and got.shape[1] >= F and not got[:, F:].any()          # pad columns are zero
+        if dtype == "f32":
+            tol = 0.0 if not case["norm"] else 2e-7 * np.abs(ref).max()      # raw values are fp32-exact; standardised ones round once
+            assert np.abs(got[:, :F] - ref).max() <= tol, name
+        else:
+            want_bf = torch.from_numpy(ref).to(torch.bfloat16).double().numpy()
+            # bit-exact bf16 rounding of the fp32 value (standardised: fp64 -> fp32 -> bf16, may differ from fp64 -> bf16 by 1 ulp)
+            assert np.abs(got[:, :F] - want_bf).max() <= (0.0 if not case["norm"] else 2.0 ** -7 * np.abs(ref).max()), name
+    ref_y = np.stack([w[3] for w in want])
+    assert np.abs(y.cpu().numpy() - ref_y).max() <= (1e-6 * np.abs(ref_y).max() if case["body"] else 0.0)
+    assert np.abs(q.cpu().numpy() - np.stack([w[4] for w in want])).max() == 0.0
+    with pytest.raises(IndexError):
+        store.assemble([N - T + 1])
+
+
+@pytest.mark.gpu
+def test_assembled_windows_feed_the_engine():
+    """Windows gathered on device go straight into Engine.forward and give the same output as the reference-convention
+    x_dict built by the oracle and cast by Engine.cast_inputs."""
+    from morphsym_hgnn_amd import engine as eng, synth
+    from morphsym_hgnn_amd.windows import SequenceStore, quadsdk_a1_c2_recipe
+    from tests import helpers
+    spec = helpers.make_spec("c2", "a1-c2", "a1-c2", 128, 2)
+    e = eng.Engine(spec, "f32")
+    store = SequenceStore(SEQ, quadsdk_a1_c2_recipe(JP, FP, T, 3), dtype="f32")
+    starts = list(range(0, 240, 7))
+    B = len(starts)
+    xs, y, _ = store.assemble(starts)
+    flat = eng.flatten_params(spec, synth.make_params(4, spec.param_shapes()), e.device)
+    out_dev = e.forward(xs, flat, B, training=False).clone()
+    want = [wo.a1_c2_window(SEQ, s, T, JP, FP, 3) for s in starts]
+    x_dict = {t: torch.from_numpy(np.stack([w[i] for w in want]).reshape(B * n, -1)) for i, (t, n) in enumerate((("base", 2), ("joint", 12), ("foot", 4)))}
+    out_ref = e.forward(e.cast_inputs(x_dict), flat, B, training=False)
+    assert torch.equal(out_dev, out_ref)
