@@ -701,6 +701,20 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
     }
     add_fin(d.off_dec_w, d.out_channels, H, H, -2, FIN_DEC_W);
     add_fin(d.off_dec_b, 1, d.out_channels, d.out_channels, -2, FIN_DEC_B);
+    {   // alignment gaps of the flat buffer are zeroed, so grad_params really is fully overwritten
+        std::vector<std::pair<int64_t, int64_t>> spans;    // (offset, length) of every parameter
+        for (int t = 0; t < NT; ++t) { spans.push_back({p.off_enc_w[t], (int64_t)H * d.type_width[t]}); spans.push_back({p.off_enc_b[t], H}); }
+        for (int i = 0; i < L * NR; ++i) { spans.push_back({p.off_rel_w[i], (int64_t)H * H}); spans.push_back({p.off_rel_b[i], H}); spans.push_back({p.off_root_w[i], (int64_t)H * H}); }
+        if (has_mlp) for (int k = 0; k < 2; ++k) { spans.push_back({d.off_mlp[2 * k], (int64_t)H * H}); spans.push_back({d.off_mlp[2 * k + 1], H}); }
+        spans.push_back({d.off_dec_w, (int64_t)d.out_channels * H}); spans.push_back({d.off_dec_b, d.out_channels});
+        std::sort(spans.begin(), spans.end());
+        int64_t pos = 0;
+        for (auto& sp : spans) {
+            if (sp.first > pos && sp.first - pos < 4096) add_fin(pos, 1, (int)(sp.first - pos), (int)(sp.first - pos), -1, FIN_ZERO);
+            pos = std::max(pos, sp.first + sp.second);
+        }
+        if (d.n_flat > pos && d.n_flat - pos < 4096) add_fin(pos, 1, (int)(d.n_flat - pos), (int)(d.n_flat - pos), -1, FIN_ZERO);
+    }
 
     // ---- info ---------------------------------------------------------------------------------------
     p.info.rows_per_tile = p.rows; p.info.total_nodes = p.NN; p.info.lds_bytes = (int64_t)p.n_blk * p.blk_bytes;

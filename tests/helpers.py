@@ -13,7 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 CFG = os.path.join(ROOT, "morphsym_hgnn_amd", "cfg")
 
-GOLDEN_CASES = sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz"))
+# model cases only (the directory also holds the window-assembly fixture)
+GOLDEN_CASES = sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and not f.startswith("windows_"))
 
 
 def load_group(name):
