@@ -192,23 +192,26 @@ int mshgnn_grf_body_to_world(const float* quat, const float* grf_body, float* gr
 
 /* ---- on-device window assembly ---------------------------------------------------------------
  * Replaces the per-window feature building of the dataset classes (quadSDKDataset_Morph.py:304-369, 444-488;
- * flexibleDataset.py:340-400, 563-596) + PyG collate: the sequence's raw series stay in HBM (fp32 [rows][pitch]) and a
- * batch of windows [start, start + history) is gathered into the engine's inputs [batch][n_t][x_pitch[t]] (dtype).
- * runs (DEVICE int32[n_runs][5]): {type, node, first feature, source << 8 | column (or -1: constant 1), length}: features
- * first .. first + length - 1 of that node row = src[start + k][column], k = 0 .. length - 1 (standardised over the window
- * when normalize, as flexibleDataset.py:390-396).  Labels: y[b][k] = src[label_src][start + history - 1][label_cols[k]]
+ * flexibleDataset.py:340-400, 563-596) + PyG collate: the sequence's raw series stay in HBM, fp32 COLUMN-major (element
+ * (row, col) at src[col * src_cstride + row], so a window of one column is one contiguous stretch), and a batch of
+ * windows [start, start + history) is gathered into the engine's inputs [batch][n_t][x_pitch[t]] (dtype).
+ * runs (DEVICE int32[n_runs][5], sorted by (type, node)): {type, node, first feature, source << 8 | column (or -1: constant
+ * 1), length <= 256}: features first .. first + length - 1 of that node row = src(start + k, column), k = 0 .. length - 1
+ * (standardised over the window when normalize, as flexibleDataset.py:390-396).  rows (DEVICE int32[n_rows][2]): the run
+ * range [begin, end) of every node row (one wave assembles one node row of one window).  Labels: y[b][k] = src[label_src][start + history - 1][label_cols[k]]
  * (label_cols: DEVICE int32[n_label]); label_rotate: 3-D world-frame GRFs -> body frame with the quaternion
  * src[quat_src] of that row (quadSDKDataset.py, load_data_at_dataset_seq_3d); quat_out (optional) receives it.         */
 typedef struct mshgnn_window_desc {
     int32_t n_types, dtype, history, normalize;
     int32_t type_nodes[MSHGNN_MAX_TYPES], type_width[MSHGNN_MAX_TYPES];
-    int32_t n_src, n_runs;
+    int32_t n_src, n_runs, n_rows, _pad;
     const int32_t* runs;
+    const int32_t* rows;
     int32_t n_label, label_src, label_rotate, quat_src;      /* quat_src = -1: none */
     const int32_t* label_cols;
 } mshgnn_window_desc;
 
-int mshgnn_assemble_windows(const mshgnn_window_desc* desc, const float* const* src, const int64_t* src_pitch,
+int mshgnn_assemble_windows(const mshgnn_window_desc* desc, const float* const* src, const int64_t* src_cstride,
                             const int64_t* src_rows, const int64_t* starts /* device int64[batch] */, int64_t batch,
                             void* const* x_out, const int64_t* x_pitch, float* y_out, float* quat_out, void* stream);
 

@@ -27,6 +27,7 @@
 using namespace mshgnn;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -2159,37 +2160,93 @@ extern "C" int mshgnn_grf_body_to_world(const float* quat, const float* grf_body
 // standardised over the window like flexibleDataset.py:390-396), or the constant 1.
 // ------------------------------------------------------------------------------------------------------
 constexpr int WIN_MAX_SRC = 12;
+constexpr int WIN_ROW_RUNS = 8;          // runs per node row handled with all loads in flight
 struct WindowArgs {
-    const float* src[WIN_MAX_SRC]; int64_t src_pitch[WIN_MAX_SRC];
+    const float* src[WIN_MAX_SRC]; int64_t src_cstride[WIN_MAX_SRC];       // series are COLUMN-major: element (row, col) at col * cstride + row
     void* x[MSHGNN_MAX_TYPES]; int64_t x_pitch[MSHGNN_MAX_TYPES]; int nodes[MSHGNN_MAX_TYPES];
-    const int* runs; int n_runs;            // per run: type, node, first feature, source (-1: ones) << 8 | column, length
+    const int* runs; int n_runs;            // per run: type, node, first feature, source (-1: ones) << 8 | column, length; sorted by (type, node)
+    const int* rows; int n_rows;            // per node row: first run, end run
     const int64_t* starts; int64_t B; int T, normalize;
     const int* label_cols; int n_label, label_src, label_rotate, quat_src;
     float* y; float* quat;
 };
 
+// one WORKGROUP per window, its 4 waves take the node rows round-robin.  Lane r resolves run r ONCE (source pointer, destination
+// offset, length) and the waves fetch those with v_readlane, so there is no dependent descriptor load per run; every run
+// of a row is a contiguous stretch of a column-major series, read coalesced with all of the row's loads in flight.
 template <typename T> __global__ __launch_bounds__(256) void k_assemble_windows(WindowArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int64_t gw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);          // global wave = (window, run)
-    if (gw >= a.B * a.n_runs) return;
-    const int64_t b = gw / a.n_runs; const int r = (int)(gw % a.n_runs);
-    const int* run = a.runs + r * 5;
-    const int t = run[0], node = run[1], f0 = run[2], sc = run[3], len = run[4];
-    T* dst = reinterpret_cast<T*>(a.x[t]) + ((size_t)b * a.nodes[t] + node) * a.x_pitch[t] + f0;
-    if (sc < 0) { for (int k = lane; k < len; k += 64) dst[k] = from_f32<T>(1.0f); return; }
-    const float* src = a.src[sc >> 8] + (size_t)a.starts[b] * a.src_pitch[sc >> 8] + (sc & 0xff);
-    const int64_t pitch = a.src_pitch[sc >> 8];
-    if (!a.normalize) { for (int k = lane; k < len; k += 64) dst[k] = from_f32<T>(src[(size_t)k * pitch]); return; }
-    // (x - mean) / std with the unbiased estimator, NaN -> 0 (flexibleDataset.py:390-396); fp64, two passes
-    double s = 0.0;
-    for (int k = lane; k < len; k += 64) s += (double)src[(size_t)k * pitch];
-    const double mean = wave_sum(s) / (double)len;
-    double q = 0.0;
-    for (int k = lane; k < len; k += 64) { const double dlt = (double)src[(size_t)k * pitch] - mean; q += dlt * dlt; }
-    const double sd = sqrt(wave_sum(q) / (double)(len - 1));
-    for (int k = lane; k < len; k += 64) {
-        const double v = ((double)src[(size_t)k * pitch] - mean) / sd;
-        dst[k] = from_f32<T>(v == v ? (float)v : 0.0f);
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t b = blockIdx.x;
+    const int64_t start = a.starts[b];
+    // lane r <- run r (n_runs <= 64, checked by the host)
+    int v_lo, v_hi, v_doff, v_len, v_t;
+    {
+        const int* run = a.runs + (size_t)min(lane, a.n_runs - 1) * 5;
+        const int t = run[0], node = run[1], f0 = run[2], sc = run[3];
+        const float* sp = nullptr;
+#pragma unroll
+        for (int k = 0; k < WIN_MAX_SRC; ++k) if (sc >= 0 && (sc >> 8) == k) sp = a.src[k] + (size_t)(sc & 0xff) * a.src_cstride[k] + start;
+        int nodes = 0; int64_t pitch = 0;
+#pragma unroll
+        for (int k = 0; k < MSHGNN_MAX_TYPES; ++k) if (t == k) { nodes = a.nodes[k]; pitch = a.x_pitch[k]; }
+        v_lo = (int)((uintptr_t)sp & 0xffffffffu); v_hi = (int)((uintptr_t)sp >> 32);
+        v_doff = (int)(((size_t)b * nodes + node) * pitch + f0 - (size_t)b * nodes * pitch);     // offset inside the window's block of this type
+        v_len = run[4]; v_t = t;
+    }
+    // lane handles the element pairs (2 lane + 128 j, +1), j = 0, 1: one packed store per pair (runs start at even features
+    // and node rows are 16-byte aligned, so pairs are 4-byte (bf16) / 8-byte (fp32) aligned); lengths up to 256
+    for (int row = wv; row < a.n_rows; row += 4) {
+        const int r_begin = a.rows[2 * row], r_end = a.rows[2 * row + 1];
+        for (int rb = r_begin; rb < r_end; rb += WIN_ROW_RUNS) {
+            float v[WIN_ROW_RUNS][4];
+#pragma unroll
+            for (int i = 0; i < WIN_ROW_RUNS; ++i) {
+                const int r = min(rb + i, r_end - 1);
+                const float* sp = reinterpret_cast<const float*>((uintptr_t)(unsigned)__builtin_amdgcn_readlane(v_lo, r) | ((uintptr_t)(unsigned)__builtin_amdgcn_readlane(v_hi, r) << 32));
+                const int len = __builtin_amdgcn_readlane(v_len, r);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int k = 2 * lane + 128 * (q >> 1) + (q & 1);
+                    v[i][q] = 1.0f;
+                    if (rb + i < r_end && sp != nullptr && k < len) v[i][q] = sp[k];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < WIN_ROW_RUNS; ++i) {
+                if (rb + i >= r_end) break;
+                const int r = rb + i;
+                const int t = __builtin_amdgcn_readlane(v_t, r), len = __builtin_amdgcn_readlane(v_len, r);
+                const bool has_src = (__builtin_amdgcn_readlane(v_lo, r) | __builtin_amdgcn_readlane(v_hi, r)) != 0;
+                T* dst = reinterpret_cast<T*>(a.x[t]) + (size_t)b * a.nodes[t] * a.x_pitch[t] + __builtin_amdgcn_readlane(v_doff, r);
+                if (a.normalize && has_src) {
+                    // (x - mean) / std with the unbiased estimator, NaN -> 0 (flexibleDataset.py:390-396); fp64, two passes over registers
+                    double s1 = 0.0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (2 * lane + 128 * (q >> 1) + (q & 1) < len) s1 += (double)v[i][q];
+                    const double mean = wave_sum(s1) / (double)len;
+                    double qs = 0.0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (2 * lane + 128 * (q >> 1) + (q & 1) < len) { const double dlt = (double)v[i][q] - mean; qs += dlt * dlt; }
+                    const double sd = sqrt(wave_sum(qs) / (double)(len - 1));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { const double z = ((double)v[i][q] - mean) / sd; v[i][q] = z == z ? (float)z : 0.0f; }
+                }
+                const bool even = ((__builtin_amdgcn_readlane(v_doff, r) | len) & 1) == 0;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int k = 2 * lane + 128 * j;
+                    if (even && k < len) {
+                        if constexpr (sizeof(T) == 2) {
+                            union { unsigned u; __bf16 e[2]; } pk; pk.e[0] = (__bf16)v[i][2 * j]; pk.e[1] = (__bf16)v[i][2 * j + 1];
+                            *reinterpret_cast<unsigned*>(dst + k) = pk.u;
+                        } else *reinterpret_cast<f32x2*>(dst + k) = f32x2{v[i][2 * j], v[i][2 * j + 1]};
+                    } else {
+                        if (k < len) dst[k] = from_f32<T>(v[i][2 * j]);
+                        if (k + 1 < len) dst[k + 1] = from_f32<T>(v[i][2 * j + 1]);
+                    }
+                }
+            }
+        }
     }
 }
 
@@ -2200,13 +2257,15 @@ __global__ void k_window_labels(WindowArgs a) {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= a.B) return;
     const int64_t row = a.starts[b] + a.T - 1;
-    const float* lab = a.src[a.label_src] + (size_t)row * a.src_pitch[a.label_src];
+    const float* lab = a.src[a.label_src] + row;                  // column-major: element c at lab[c * cstride]
+    const int64_t lcs = a.src_cstride[a.label_src];
     double R[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
     if (a.quat_src >= 0) {
-        const float* qp = a.src[a.quat_src] + (size_t)row * a.src_pitch[a.quat_src];
-        if (a.quat) for (int k = 0; k < 4; ++k) a.quat[b * 4 + k] = qp[k];
+        const float* qp = a.src[a.quat_src] + row;
+        const int64_t qcs = a.src_cstride[a.quat_src];
+        if (a.quat) for (int k = 0; k < 4; ++k) a.quat[b * 4 + k] = qp[k * qcs];
         if (a.label_rotate) {
-            double x = qp[0], yq = qp[1], z = qp[2], s = qp[3];
+            double x = qp[0], yq = qp[qcs], z = qp[2 * qcs], s = qp[3 * qcs];
             const double nrm = sqrt(x * x + yq * yq + z * z + s * s);
             x /= nrm; yq /= nrm; z /= nrm; s /= nrm;
             R[0][0] = 1 - 2 * (yq * yq + z * z); R[0][1] = 2 * (x * yq - z * s); R[0][2] = 2 * (x * z + yq * s);
@@ -2216,19 +2275,19 @@ __global__ void k_window_labels(WindowArgs a) {
     }
     if (a.label_rotate) {
         for (int f = 0; f + 2 < a.n_label; f += 3) {
-            const double v0 = lab[a.label_cols[f]], v1 = lab[a.label_cols[f + 1]], v2 = lab[a.label_cols[f + 2]];
+            const double v0 = lab[a.label_cols[f] * lcs], v1 = lab[a.label_cols[f + 1] * lcs], v2 = lab[a.label_cols[f + 2] * lcs];
             for (int i = 0; i < 3; ++i) a.y[b * a.n_label + f + i] = (float)(R[i][0] * v0 + R[i][1] * v1 + R[i][2] * v2);
         }
     } else {
-        for (int k = 0; k < a.n_label; ++k) a.y[b * a.n_label + k] = lab[a.label_cols[k]];
+        for (int k = 0; k < a.n_label; ++k) a.y[b * a.n_label + k] = lab[a.label_cols[k] * lcs];
     }
 }
 
-extern "C" int mshgnn_assemble_windows(const mshgnn_window_desc* d, const float* const* src, const int64_t* src_pitch, const int64_t* src_rows,
+extern "C" int mshgnn_assemble_windows(const mshgnn_window_desc* d, const float* const* src, const int64_t* src_cstride, const int64_t* src_rows,
                                        const int64_t* starts, int64_t batch, void* const* x_out, const int64_t* x_pitch, float* y_out,
                                        float* quat_out, void* stream) {
-    if (!d || !src || !src_pitch || !src_rows || !starts || !x_out || !x_pitch || batch < 1) return set_err(MSHGNN_EINVAL, "null argument to mshgnn_assemble_windows");
-    if (d->n_types < 1 || d->n_types > MSHGNN_MAX_TYPES || d->n_src < 1 || d->n_src > WIN_MAX_SRC || d->n_runs < 1 || !d->runs)
+    if (!d || !src || !src_cstride || !src_rows || !starts || !x_out || !x_pitch || batch < 1) return set_err(MSHGNN_EINVAL, "null argument to mshgnn_assemble_windows");
+    if (d->n_types < 1 || d->n_types > MSHGNN_MAX_TYPES || d->n_src < 1 || d->n_src > WIN_MAX_SRC || d->n_runs < 1 || !d->runs || d->n_rows < 1 || !d->rows)
         return set_err(MSHGNN_EINVAL, "bad window descriptor");
     if (d->history < 1 || (d->normalize && d->history < 2)) return set_err(MSHGNN_EINVAL, "history must be >= 1 (>= 2 when normalising)");
     if (d->dtype != MSHGNN_F32 && d->dtype != MSHGNN_BF16) return set_err(MSHGNN_EINVAL, "dtype must be MSHGNN_F32 or MSHGNN_BF16");
@@ -2237,20 +2296,21 @@ extern "C" int mshgnn_assemble_windows(const mshgnn_window_desc* d, const float*
     if (d->quat_src >= d->n_src) return set_err(MSHGNN_EINVAL, "quat_src out of range");
     WindowArgs a{};
     for (int i = 0; i < d->n_src; ++i) {
-        if (!src[i] || src_pitch[i] < 1 || src_rows[i] < d->history) return set_err(MSHGNN_EINVAL, "bad source array");
-        a.src[i] = src[i]; a.src_pitch[i] = src_pitch[i];
+        if (!src[i] || src_cstride[i] < src_rows[i] || src_rows[i] < d->history) return set_err(MSHGNN_EINVAL, "bad source array");
+        a.src[i] = src[i]; a.src_cstride[i] = src_cstride[i];
     }
     for (int t = 0; t < d->n_types; ++t) {
         if (!x_out[t] || d->type_nodes[t] < 1 || x_pitch[t] < d->type_width[t]) return set_err(MSHGNN_EINVAL, "bad output tensor");
         a.x[t] = x_out[t]; a.x_pitch[t] = x_pitch[t]; a.nodes[t] = d->type_nodes[t];
     }
-    a.runs = d->runs; a.n_runs = d->n_runs; a.starts = starts; a.B = batch; a.T = d->history; a.normalize = d->normalize;
+    if (d->history > 256) return set_err(MSHGNN_EUNSUPPORTED, "history longer than 256 steps is not supported by this build");
+    a.runs = d->runs; a.n_runs = d->n_runs; a.rows = d->rows; a.n_rows = d->n_rows; a.starts = starts; a.B = batch; a.T = d->history; a.normalize = d->normalize;
     a.label_cols = d->label_cols; a.n_label = d->n_label; a.label_src = d->label_src; a.label_rotate = d->label_rotate; a.quat_src = d->quat_src;
     a.y = y_out; a.quat = quat_out;
     hipStream_t st = (hipStream_t)stream;
-    const int64_t waves = batch * d->n_runs;
-    if (d->dtype == MSHGNN_F32) hipLaunchKernelGGL(k_assemble_windows<float>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(k_assemble_windows<__bf16>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a);
+    if (d->n_runs > 64) return set_err(MSHGNN_EUNSUPPORTED, "more than 64 feature runs per window are not supported by this build");
+    if (d->dtype == MSHGNN_F32) hipLaunchKernelGGL(k_assemble_windows<float>, dim3((unsigned)batch), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_assemble_windows<__bf16>, dim3((unsigned)batch), dim3(256), 0, st, a);
     if (d->n_label > 0 || (quat_out && d->quat_src >= 0))
         hipLaunchKernelGGL(k_window_labels, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, a);
     HIPCHK(hipGetLastError());

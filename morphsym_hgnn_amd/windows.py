@@ -88,29 +88,33 @@ class SequenceStore:
         n_rows = None
         for s in self.names:
             a = torch.as_tensor(np.asarray(arrays[s])).to(self.device, torch.float32)
-            a = a.reshape(a.shape[0], -1).contiguous()
-            n_rows = a.shape[0] if n_rows is None else min(n_rows, a.shape[0])
+            a = a.reshape(a.shape[0], -1).t().contiguous()          # column-major: one window of one column is contiguous
+            n_rows = a.shape[1] if n_rows is None else min(n_rows, a.shape[1])
             self.series.append(a)
         self.n_rows = int(n_rows)
         if self.n_rows < recipe.history:
             raise ValueError("sequence shorter than one window")
         sidx = {s: i for i, s in enumerate(self.names)}
-        runs = []
+        runs, rows = [], []
         for ti, t in enumerate(recipe.node_types):
             vars_ = recipe.variables.get(t, [])
             if not vars_:
-                runs += [[ti, n, 0, -1, 1] for n in range(recipe.num_nodes[t])]
+                for n in range(recipe.num_nodes[t]):
+                    rows.append([len(runs), len(runs) + 1]); runs.append([ti, n, 0, -1, 1])
                 continue
             for n in range(recipe.num_nodes[t]):
                 f = 0
+                r_begin = len(runs)
                 for s, cols in vars_:
-                    ncol = self.series[sidx[s]].shape[1]
+                    ncol = self.series[sidx[s]].shape[0]
                     for c in cols[n]:
                         if not 0 <= c < min(ncol, 256):
                             raise ValueError(f"column {c} of series '{s}' out of range")
                         runs.append([ti, n, f, (sidx[s] << 8) | c, recipe.history])
                         f += recipe.history
+                rows.append([r_begin, len(runs)])
         self.runs = torch.tensor(runs, dtype=torch.int32, device=self.device)
+        self.rows = torch.tensor(rows, dtype=torch.int32, device=self.device)
         self.label_cols = torch.tensor(recipe.label_cols or [0], dtype=torch.int32, device=self.device)
         d = eng.MshgnnWindowDesc()
         d.n_types = len(recipe.node_types); d.dtype = 0 if dtype == "f32" else 1; d.history = recipe.history
@@ -118,13 +122,15 @@ class SequenceStore:
         for i, t in enumerate(recipe.node_types):
             d.type_nodes[i] = recipe.num_nodes[t]; d.type_width[i] = recipe.width(t)
         d.n_src = len(self.series); d.n_runs = len(runs); d.runs = self.runs.data_ptr()
+        d.n_rows = len(rows); d.rows = self.rows.data_ptr()
         d.n_label = len(recipe.label_cols); d.label_src = sidx[recipe.label_series] if recipe.label_series else 0
         d.label_rotate = int(recipe.label_rotate); d.quat_src = sidx[recipe.quat_series] if recipe.quat_series else -1
         d.label_cols = self.label_cols.data_ptr()
         self.desc = d
+        self._cache = {}
         self._src = (C.c_void_p * len(self.series))(*[a.data_ptr() for a in self.series])
-        self._pitch = (C.c_int64 * len(self.series))(*[a.shape[1] for a in self.series])
-        self._rows = (C.c_int64 * len(self.series))(*[a.shape[0] for a in self.series])
+        self._pitch = (C.c_int64 * len(self.series))(*[a.shape[1] for a in self.series])     # column stride
+        self._rows = (C.c_int64 * len(self.series))(*[a.shape[1] for a in self.series])
 
     def __len__(self) -> int:
         """Number of windows (the reference's dataset length: rows - history + 1)."""
@@ -134,26 +140,39 @@ class SequenceStore:
         epc = 4 if self.dtype == "f32" else 8
         return (self.recipe.width(t) + epc - 1) // epc * epc
 
-    def assemble(self, starts) -> Tuple[List[torch.Tensor], Optional[torch.Tensor], Optional[torch.Tensor]]:
-        """starts: window start rows (== the reference's dataset indices).  Returns (xs, y, r_o): xs[t] is
-        [B * n_t, padded width] at the store's dtype -- exactly what `Engine.forward` takes (pad columns are zero) --,
-        y float32 [B, n_label], r_o float32 [B, 4]."""
+    def _buffers(self, B: int):
+        """Output buffers for a batch of B windows, made once per batch size: the pad columns are zeroed here and never
+        written again (the kernel only writes feature columns)."""
+        if B not in self._cache:
+            r = self.recipe
+            xs = [torch.zeros(B * r.num_nodes[t], self.padded_width(t), dtype=self.torch_dtype, device=self.device) for t in r.node_types]
+            y = torch.empty(B, len(r.label_cols), dtype=torch.float32, device=self.device) if r.label_cols else None
+            q = torch.empty(B, 4, dtype=torch.float32, device=self.device) if r.quat_series else None
+            self._cache = {B: (xs, y, q)}          # one batch size at a time
+        return self._cache[B]
+
+    def assemble(self, starts, reuse_buffers: bool = False) -> Tuple[List[torch.Tensor], Optional[torch.Tensor], Optional[torch.Tensor]]:
+        """starts: window start rows (== the reference's dataset indices), a host sequence / tensor (checked on the host) or
+        a device int64 tensor (trusted).  Returns (xs, y, r_o): xs[t] is [B * n_t, padded width] at the store's dtype --
+        exactly what `Engine.forward` takes (pad columns are zero) --, y float32 [B, n_label], r_o float32 [B, 4].
+        reuse_buffers=True returns the same tensors on every call of one batch size (a training loop that consumes the
+        batch before asking for the next)."""
         r = self.recipe
-        st = torch.as_tensor(starts, dtype=torch.int64).flatten()
+        st = starts if isinstance(starts, torch.Tensor) else torch.as_tensor(np.asarray(starts), dtype=torch.int64)
+        st = st.flatten().to(torch.int64)
         if st.numel() < 1:
             raise ValueError("no window indices")
-        if int(st.min()) < 0 or int(st.max()) + r.history > self.n_rows:
-            raise IndexError("window index out of range")
-        st = st.to(self.device)
+        if not st.is_cuda:
+            if int(st.min()) < 0 or int(st.max()) + r.history > self.n_rows:
+                raise IndexError("window index out of range")
+            st = st.to(self.device, non_blocking=True)
         B = st.numel()
-        xs = []
-        for t in r.node_types:
-            P = self.padded_width(t)
-            x = torch.zeros(B * r.num_nodes[t], P, dtype=self.torch_dtype, device=self.device) if P != r.width(t) else \
-                torch.empty(B * r.num_nodes[t], P, dtype=self.torch_dtype, device=self.device)
-            xs.append(x)
-        y = torch.empty(B, len(r.label_cols), dtype=torch.float32, device=self.device) if r.label_cols else None
-        q = torch.empty(B, 4, dtype=torch.float32, device=self.device) if r.quat_series else None
+        if reuse_buffers:
+            xs, y, q = self._buffers(B)
+        else:
+            xs = [torch.zeros(B * r.num_nodes[t], self.padded_width(t), dtype=self.torch_dtype, device=self.device) for t in r.node_types]
+            y = torch.empty(B, len(r.label_cols), dtype=torch.float32, device=self.device) if r.label_cols else None
+            q = torch.empty(B, 4, dtype=torch.float32, device=self.device) if r.quat_series else None
         xp = (C.c_void_p * len(xs))(*[x.data_ptr() for x in xs])
         pitch = (C.c_int64 * len(xs))(*[x.shape[1] for x in xs])
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

@@ -5,21 +5,22 @@ import collections, csv, glob, json, sys
 
 def per_kernel(pattern, counter):
     agg = collections.defaultdict(list)
-    for path in glob.glob(pattern):
+    for path in glob.glob(pattern, recursive=True):
         for r in csv.DictReader(open(path)):
             if r["Counter_Name"] == counter:
                 agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in agg.items()}
 
 def short(name):
-    for key, s in [("k_prep", "prep"), ("k_enc_fwd", "enc_fwd"), ("k_layer_fwd", "layer_fwd"), ("k_dec_fwd", "dec_fwd"),
+    for key, s in [("k_prep", "prep"), ("k_enc_fwd", "enc_fwd"), ("k_stack_fwd", "stack_fwd"), ("k_stack_bwd", "stack_bwd"),
+                   ("k_layer_fwd", "layer_fwd"), ("k_dec_fwd", "dec_fwd"),
                    ("k_dec_bwd", "dec_bwd"), ("k_layer_bwd", "layer_bwd"), ("k_gradw", "gradw"), ("k_finalize", "finalize"), ("k_mse", "mse")]:
         if key in name:
             return s
     return None
 
-fetch = per_kernel(sys.argv[1] + "/*/*counter_collection.csv", "FETCH_SIZE")
-write = per_kernel(sys.argv[2] + "/*/*counter_collection.csv", "WRITE_SIZE")
+fetch = per_kernel(sys.argv[1] + "/**/*counter_collection.csv", "FETCH_SIZE")
+write = per_kernel(sys.argv[2] + "/**/*counter_collection.csv", "WRITE_SIZE")
 out = {}
 for k, v in fetch.items():
     s = short(k)
