@@ -1,0 +1,79 @@
+"""Lightning checkpoint compatibility.
+
+The reference trains through Lightning (`gnnLightning.py:1346-1380`, `ModelCheckpoint`) and evaluates with
+`<Wrapper>.load_from_checkpoint(path, ...)` (`gnnLightning.py:955-990`).  A Lightning `.ckpt` is a `torch.save`d dict whose
+`"state_dict"` holds the wrapper's tensors -- the model's under the prefix `model.` (`self.model = GRF_HGNN_C2(...)`,
+`gnnLightning.py:580-590`) next to metric states -- and whose `"hyper_parameters"` holds the wrapper's constructor
+arguments (`save_hyperparameters()`, `:596`).  The drop-in modules keep the reference's parameter names, so published
+weights load by name; this module does the prefix / lazy-encoder / hyper-parameter plumbing without Lightning.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+from torch import nn
+
+from . import models
+
+MODEL_CLASSES = {
+    # model_type strings of train_model / evaluate_model (gnnLightning.py:957-990, 1290-1330)
+    "heterogeneous_gnn": models.GRF_HGNN, "heterogeneous_gnn_k4": models.GRF_HGNN_K4, "heterogeneous_gnn_c2": models.GRF_HGNN_C2,
+    "heterogeneous_gnn_k4_com": models.COM_HGNN_K4, "heterogeneous_gnn_c2_com": models.COM_HGNN_C2,
+    "heterogeneous_gnn_s4_com": models.COM_HGNN_S4,
+}
+
+
+def model_state_dict(ckpt: dict, prefix: str = "model.") -> Dict[str, torch.Tensor]:
+    """The model's tensors of a Lightning checkpoint (or of a bare state_dict), prefix stripped, wrapper metric states dropped."""
+    sd = ckpt.get("state_dict", ckpt)
+    out = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+    if not out:      # already a bare model state_dict
+        out = {k: v for k, v in sd.items() if isinstance(v, torch.Tensor) and not k.startswith("metric_")}
+    return out
+
+
+def load_into(model: nn.Module, ckpt, strict: bool = True):
+    """Load a checkpoint (path or dict) into one of the drop-in modules: the lazy encoder is materialised from the
+    checkpoint's weight shapes first (the reference does this with a dummy forward, gnnLightning.py:593-595)."""
+    if not isinstance(ckpt, dict):
+        ckpt = torch.load(ckpt, map_location="cpu", weights_only=False)
+    sd = model_state_dict(ckpt)
+    for t, lin in model.encoder.lins.items():
+        w = sd.get(f"encoder.lins.{t}.weight")
+        if w is not None:
+            lin.materialize(int(w.shape[1]))
+            ref = model.decoder.weight
+            lin.to(device=ref.device, dtype=ref.dtype)
+    return model.load_state_dict(sd, strict=strict)
+
+
+def model_from_checkpoint(ckpt, model_type: str, data_metadata=None, **overrides) -> nn.Module:
+    """Rebuild the model of a checkpoint from its `hyper_parameters` (constructor arguments of the Lightning wrapper) and
+    load its weights.  `overrides` take precedence, exactly like the keyword arguments of `load_from_checkpoint`
+    (`symmetry_mode`, `group_operator_path`, `grf_dimension`, ... -- gnnLightning.py:962-990)."""
+    if not isinstance(ckpt, dict):
+        ckpt = torch.load(ckpt, map_location="cpu", weights_only=False)
+    if model_type not in MODEL_CLASSES:
+        raise ValueError(f"unknown model_type {model_type!r}")
+    hp = dict(ckpt.get("hyper_parameters", {}))
+    hp.update(overrides)
+    meta = data_metadata if data_metadata is not None else hp.get("data_metadata")
+    if meta is None:
+        raise ValueError("data_metadata is neither in the checkpoint's hyper_parameters nor given")
+    cls = MODEL_CLASSES[model_type]
+    kw = {"regression": hp.get("regression", True)}
+    if cls in (models.GRF_HGNN_C2, models.GRF_HGNN_K4, models.COM_HGNN_K4, models.COM_HGNN_C2, models.COM_HGNN_S4):
+        kw["symmetry_mode"] = hp.get("symmetry_mode")
+        kw["group_operator_path"] = hp.get("group_operator_path")
+    if cls in (models.GRF_HGNN_C2, models.GRF_HGNN):
+        kw["grf_dimension"] = hp.get("grf_dimension", 3 if cls is models.GRF_HGNN_C2 else 1)
+    model = cls(int(hp["hidden_channels"]), int(hp["num_layers"]), meta, **kw)
+    load_into(model, ckpt, strict=True)
+    return model
+
+
+def to_lightning_checkpoint(model: nn.Module, hyper_parameters: Optional[dict] = None, prefix: str = "model.") -> dict:
+    """The inverse: a dict in Lightning's layout that the reference's `load_from_checkpoint` accepts for the weights."""
+    return {"state_dict": {prefix + k: v.detach().cpu() for k, v in model.state_dict().items()},
+            "hyper_parameters": dict(hyper_parameters or {}), "pytorch-lightning_version": "2.1.0", "epoch": 0, "global_step": 0}
