@@ -160,6 +160,13 @@ int mshgnn_backward_mse(const mshgnn_plan* plan, const void* const* x, const int
                         const float* out, const float* y, float* loss_out, float* grad_params, void* workspace,
                         int64_t batch, void* stream);
 
+/* Backward with the classification wrapper's cross entropy fused in (gnnLightning.py:640-648: CrossEntropyLoss over the
+ * batch*4 per-foot logit pairs, mean).  `out` = the forward's logits [batch][n_out][2], labels int32 [batch][n_out] in
+ * {0,1}; loss_out (device float[1]) receives the mean cross entropy.  Only for plans with out_channels == 2.            */
+int mshgnn_backward_ce(const mshgnn_plan* plan, const void* const* x, const int64_t* x_pitch, const float* params,
+                       const float* out, const int32_t* labels, float* loss_out, float* grad_params, void* workspace,
+                       int64_t batch, void* stream);
+
 /* Adam on the flat fp32 buffers (configure_optimizers, gnnLightning.py:258-265; torch.optim.Adam defaults, no weight
  * decay / amsgrad).  step is 1-based; grads are multiplied by grad_scale first (1/world_size after a sum all-reduce).
  * All four buffers: device fp32, n elements, 16-byte aligned; updated in place.                                     */

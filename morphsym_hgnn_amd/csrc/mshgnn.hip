@@ -1166,6 +1166,7 @@ struct DecArgs {
     const void* xl; void* dxl; const float* params; const float* out_mask; float* out; const float* gout; float* slabs;
     int64_t off_w, off_b; int B, NN, node0, n_out, dout, slab0;
     const float* y; float* loss; float inv_n;   // fused MSE: gout = 2 (out - y) / n computed on the fly, loss accumulated
+    const int32_t* labels;                      // fused cross entropy (dout == 2): gout = (softmax(out) - onehot) / rows
 };
 
 // thread = (row, 8-column chunk): 16 lanes share a row, one wave covers 4 rows; whole rows are read / written coalesced
@@ -1232,11 +1233,20 @@ template <typename T> __global__ __launch_bounds__(256) void k_dec_bwd(DecArgs a
         load8<T>(xl + idx, x);
 #pragma unroll
         for (int e = 0; e < 8; ++e) dx[e] = 0.f;
+        float ce_g[2] = {0.f, 0.f};
+        if (a.labels) {   // wrapper cross entropy fused (gnnLightning.py:640-648, mean over the batch * 4 feet): dL/dlogit = (p - onehot) / rows
+            const float l0 = a.out[r * 2], l1 = a.out[r * 2 + 1];
+            const float m = fmaxf(l0, l1), e0 = expf(l0 - m), e1 = expf(l1 - m), se = e0 + e1;
+            const int lab = a.labels[r] != 0;
+            ce_g[0] = (e0 / se - (lab ? 0.f : 1.f)) * a.inv_n; ce_g[1] = (e1 / se - (lab ? 1.f : 0.f)) * a.inv_n;
+            if (c == 0) lsum += (m + logf(se)) - (lab ? l1 : l0);
+        }
 #pragma unroll
         for (int d = 0; d < 8; ++d) {
             if (d < a.dout) {
                 float go;
-                if (a.y) {   // wrapper MSE fused (gnnLightning.py:633-639): dL/dout = 2 (out - y) / n
+                if (a.labels) go = ce_g[d & 1];
+                else if (a.y) {   // wrapper MSE fused (gnnLightning.py:633-639): dL/dout = 2 (out - y) / n
                     const float dlt = a.out[r * a.dout + d] - a.y[r * a.dout + d];
                     go = 2.0f * dlt * a.inv_n;
                     if (c == 0) lsum += dlt * dlt;
@@ -1875,7 +1885,7 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
 template <typename T>
 static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, const float* gout,
                          float* gparams, char* ws, int64_t batch, hipStream_t st, const float* out = nullptr, const float* y = nullptr,
-                         float* loss = nullptr) {
+                         float* loss = nullptr, const int32_t* labels = nullptr) {
     const HostPlan& hp = p->hp;
     const mshgnn_desc& d = hp.d;
     mshgnn_ws_layout lay; layout_workspace(hp, batch, 1, &lay);
@@ -1887,6 +1897,9 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
         a.B = B; a.NN = hp.NN; a.node0 = hp.type_base[d.out_type]; a.n_out = d.type_nodes[d.out_type]; a.dout = d.out_channels; a.slab0 = 0;
         if (y) {
             a.y = y; a.out = const_cast<float*>(out); a.loss = loss; a.inv_n = 1.0f / (float)((int64_t)B * a.n_out * a.dout);
+        }
+        if (labels) {
+            a.labels = labels; a.out = const_cast<float*>(out); a.loss = loss; a.inv_n = 1.0f / (float)((int64_t)B * a.n_out);
         }
         ProfScope ps(p, hp.ks_dec_bwd, st);
         hipLaunchKernelGGL(k_dec_bwd<T>, dim3(NWG_DEC), dim3(256), 0, st, a);
@@ -1938,8 +1951,8 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
     }
     {
         FinArgs a{p->d_tables + hp.fin_off, p->d_tables + hp.tgt_off, reinterpret_cast<const float*>(ws + lay.slabs),
-                  reinterpret_cast<const float*>(ws + lay.dec_slabs), gparams, hp.n_lanes, hp.n_parts, y ? loss : nullptr,
-                  1.0f / (float)((int64_t)B * d.type_nodes[d.out_type] * d.out_channels)};
+                  reinterpret_cast<const float*>(ws + lay.dec_slabs), gparams, hp.n_lanes, hp.n_parts, (y || labels) ? loss : nullptr,
+                  1.0f / (float)((int64_t)B * d.type_nodes[d.out_type] * (labels ? 1 : d.out_channels))};
         ProfScope ps(p, hp.ks_fin, st);
         hipLaunchKernelGGL(k_finalize, dim3(hp.n_fin, 64), dim3(256), 0, st, a);
     }
@@ -1970,6 +1983,15 @@ extern "C" int mshgnn_backward_mse(const mshgnn_plan* p, const void* const* x, c
     if (batch < 1 || batch > (1 << 24)) return set_err(MSHGNN_EINVAL, "batch must be in [1, 2^24]");
     if (p->hp.d.dtype == MSHGNN_F32) return backward_impl<float>(p, x, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, (hipStream_t)stream, out, y, loss_out);
     return backward_impl<__bf16>(p, x, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, (hipStream_t)stream, out, y, loss_out);
+}
+
+extern "C" int mshgnn_backward_ce(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, const float* out,
+                                  const int32_t* labels, float* loss_out, float* grad_params, void* workspace, int64_t batch, void* stream) {
+    if (!p || !x || !params || !out || !labels || !loss_out || !grad_params || !workspace) return set_err(MSHGNN_EINVAL, "null argument to mshgnn_backward_ce");
+    if (batch < 1 || batch > (1 << 24)) return set_err(MSHGNN_EINVAL, "batch must be in [1, 2^24]");
+    if (p->hp.d.out_channels != 2) return set_err(MSHGNN_EINVAL, "mshgnn_backward_ce needs a 2-logit (contact classification) plan");
+    if (p->hp.d.dtype == MSHGNN_F32) return backward_impl<float>(p, x, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, (hipStream_t)stream, out, nullptr, loss_out, labels);
+    return backward_impl<__bf16>(p, x, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, (hipStream_t)stream, out, nullptr, loss_out, labels);
 }
 
 // ------------------------------------------------------------------------------------------------------

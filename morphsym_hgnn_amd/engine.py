@@ -77,6 +77,7 @@ EXPORTS = [
     "mshgnn_plan_compile_host", "mshgnn_workspace_layout", "mshgnn_forward", "mshgnn_backward", "mshgnn_mse_loss",
     "mshgnn_profile_enable", "mshgnn_profile_read", "mshgnn_backward_mse", "mshgnn_adam_step",
     "mshgnn_metrics_regression", "mshgnn_metrics_classification", "mshgnn_grf_body_to_world", "mshgnn_assemble_windows",
+    "mshgnn_backward_ce",
 ]
 
 _lib = None
@@ -114,6 +115,8 @@ def load_library():
                                     C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.mshgnn_backward_mse.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.mshgnn_backward_ce.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.mshgnn_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_float, C.c_float,
                                      C.c_float, C.c_float, C.c_float, C.c_void_p]
     lib.mshgnn_profile_enable.argtypes = [C.c_void_p, C.c_int]
@@ -366,6 +369,24 @@ class Engine:
         stream = torch.cuda.current_stream(self.device).cuda_stream
         _check(self.lib, self.lib.mshgnn_backward_mse(self._plan, ptrs, pitch, params_flat.data_ptr(), out.data_ptr(), y.data_ptr(),
                                                       loss.data_ptr(), grad_flat.data_ptr(), ws.data_ptr(), B, stream), "mshgnn_backward_mse")
+        return loss, grad_flat
+
+    def backward_ce(self, xs: Sequence[torch.Tensor], params_flat: torch.Tensor, out: torch.Tensor, labels: torch.Tensor, B: int,
+                    grad_flat: Optional[torch.Tensor] = None, loss: Optional[torch.Tensor] = None):
+        """Fused wrapper cross entropy + backward (gnnLightning.py:640-648 + autograd): labels int32 [B, n_out] in {0,1};
+        returns (loss[1], grad_flat)."""
+        self._check_flat(params_flat, "params_flat")
+        ptrs, pitch = self._xptrs(xs, B)
+        if out.dtype != torch.float32 or out.numel() != B * self.n_out * 2 or labels.dtype != torch.int32 or labels.numel() != B * self.n_out:
+            raise ValueError("out must be fp32 [B*n_out, 2] and labels int32 [B, n_out]")
+        if grad_flat is None:
+            grad_flat = torch.empty(self.spec.flat_size(), dtype=torch.float32, device=self.device)
+        if loss is None:
+            loss = torch.empty(1, dtype=torch.float32, device=self.device)
+        ws = self.workspace(B, True)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _check(self.lib, self.lib.mshgnn_backward_ce(self._plan, ptrs, pitch, params_flat.data_ptr(), out.data_ptr(), labels.data_ptr(),
+                                                     loss.data_ptr(), grad_flat.data_ptr(), ws.data_ptr(), B, stream), "mshgnn_backward_ce")
         return loss, grad_flat
 
     def adam_step(self, params_flat: torch.Tensor, grad_flat: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor,

@@ -140,6 +140,24 @@ def test_fused_mse_backward_equals_two_step():
     assert float((g1 - g2).abs().max() / g1.abs().max()) < 1e-6
 
 
+@pytest.mark.parametrize("name", ["mcc2_cls_h128_L2_B3", "mck4_cls_h128_L2_B3"])
+def test_fused_cross_entropy_backward_matches_golden(name):
+    """Classification wrappers: CE over the per-foot logit pairs fused into the decoder backward (mshgnn_backward_ce) gives
+    the loss and every gradient of the reference run (golden vectors), fp32 plan, 1e-4."""
+    _require_gpu()
+    from morphsym_hgnn_amd import engine as eng
+    case, spec, fx, x_dict, y, params, ei = helpers.load_case(name)
+    B = case["B"]
+    e = eng.Engine(spec, "f32")
+    xs = e.cast_inputs(x_dict)
+    flat = eng.flatten_params(spec, params, e.device)
+    out = e.forward(xs, flat, B, training=True)
+    loss, gflat = e.backward_ce(xs, flat, out, y.reshape(B, 4).to(e.device, torch.int32).contiguous(), B)
+    torch.cuda.synchronize()
+    grads = {k: v.detach().cpu() for k, v in eng.unflatten(spec, gflat).items()}
+    helpers.check_against_fixture(fx, out.detach().cpu(), loss.detach().cpu(), grads, rtol=RTOL_F32, what=name)
+
+
 def test_adam_step_matches_torch_adam():
     """mshgnn_adam_step vs torch.optim.Adam (fp64, CPU) over 3 steps of the engine's own gradients (optimizer
     pinned by post-step parameters)."""
