@@ -39,7 +39,9 @@ def test_bf16_plan_matches_rounding_point_emulation(name, fused, monkeypatch):
     e = eng.Engine(spec, "bf16")
     xs = e.cast_inputs(x_dict)
     flat = eng.flatten_params(spec, params, e.device)
+    out_inf = e.forward(xs, flat, B, training=False).clone()      # inference: no stashes written
     out = e.forward(xs, flat, B)
+    assert torch.equal(out, out_inf)
     loss, g = e.mse_loss(out.view(-1), y.reshape(-1).to(e.device, torch.float32))
     gflat = e.backward(xs, flat, g, B)
     torch.cuda.synchronize()
