@@ -46,6 +46,9 @@ CASES = [
     dict(name="mck4_reg_h128_L1_B2", kind="k4", topo="mini_cheetah-k4", cfg="mini_cheetah-k4", hidden=128, layers=1, B=2, regression=True, grf=3),
     dict(name="mi_h128_L2_d1_B3", kind="mi", topo="quadruped-mi", cfg=None, hidden=128, layers=2, B=3, regression=True, grf=1),
     dict(name="mi_h128_L2_d3_B2", kind="mi", topo="quadruped-mi", cfg=None, hidden=128, layers=2, B=2, regression=True, grf=3),
+    # the paper's depth (train_regression-grf_msgn.py:94) and SURVEY.md 8(d) config 3 (MiniCheetah K4 classification, L=8)
+    dict(name="a1c2_h128_L8_d3_B2", kind="c2", topo="a1-c2", cfg="a1-c2", hidden=128, layers=8, B=2, regression=True, grf=3),
+    dict(name="mck4_cls_h128_L8_B2", kind="k4", topo="mini_cheetah-k4", cfg="mini_cheetah-k4", hidden=128, layers=8, B=2, regression=False, grf=3),
     # Solo centroidal-momentum variants (decoder on base nodes, T=1): hgnn_k4_com.py, hgnn_c2_com.py, hgnn_s4_com.py, hgnn.py:COM_HGNN
     dict(name="solok4com_h128_L3_B5", kind="k4_com", topo="solo-k4-com", cfg="solo-k4", hidden=128, layers=3, B=5, regression=True, grf=3),
     dict(name="solok4com_nosym_h128_L1_B2", kind="k4_com", topo="solo-k4-com", cfg=None, hidden=128, layers=1, B=2, regression=True, grf=3),

@@ -25,7 +25,7 @@ def test_emulation_without_rounding_is_the_oracle(name):
 @pytest.mark.gpu
 @pytest.mark.parametrize("fused", ["1", "0"])
 @pytest.mark.parametrize("name", ["a1c2_h128_L2_d3_B37", "a1c2_h128_L3_d3_B3", "mck4_reg_h128_L1_B2", "mi_h128_L2_d1_B3",
-                                  "solok4com_h128_L3_B5", "soloc2com_h128_L2_B4", "solos4com_h128_L2_B3"])
+                                  "solok4com_h128_L3_B5", "soloc2com_h128_L2_B4", "solos4com_h128_L2_B3", "a1c2_h128_L8_d3_B2"])
 def test_bf16_plan_matches_rounding_point_emulation(name, fused, monkeypatch):
     """bf16 plan vs the fp64 model with bf16 rounding at the engine's storage points.  Remaining differences: fp32
     accumulation and rare 1-ulp bf16 re-roundings (2^-8 relative on single elements), hence norm-wise tolerances:
