@@ -443,9 +443,6 @@ struct LayerArgs {
     void* hb; void* t1;    // base_transform stash of this layer [B][n_mlp][128]
     void* dh; void* du;    // bwd: dH_l [B][NN][128], dU_l [B][n_mlp][128]
     const void* x_act;     // bwd layer 0: X_0 (encoder relu mask)
-    const void* g_prev;    // bwd: G_{l+2}   (residual input of G_{l+1} = G_{l+2} + D_{l+1})
-    const void* d_in;      // bwd: D_{l+1}
-    void* d_out;           // bwd: D_l  (dX_l without its residual term)
     const void* wpack; const float* bias; const int* prog;
     int B, NN, n_mlp;
     int dbg;               // ablation switches for timing experiments (MSHGNN_DBG): 1 no stage-in, 2 no MACs, 4 no W loads, 8 no group epilogues,
@@ -1923,7 +1920,6 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
         LayerArgs a{};
         a.x_in = ws + lay.dx[l + 1]; a.x_out = ws + lay.dx[l]; a.maskbits = reinterpret_cast<unsigned*>(ws + lay.mask[l]);
         a.hb = ws + lay.hb[l]; a.t1 = ws + lay.t1[l]; a.dh = ws + lay.dh[l]; a.du = ws + lay.du[l]; a.x_act = ws + lay.x[0];
-        a.g_prev = (l + 2 <= hp.L) ? ws + lay.dx[l + 2] : nullptr; a.d_in = (l + 1 < hp.L) ? ws + lay.dd[l + 1] : nullptr; a.d_out = ws + lay.dd[l];
         a.wpack = ws + lay.wpack; a.bias = reinterpret_cast<const float*>(ws + lay.bias);
         a.prog = p->d_tables + hp.bwd_prog_off[l]; a.B = B; a.NN = hp.NN; a.n_mlp = std::max(1, hp.n_mlp);
         { const char* e = getenv("MSHGNN_DBG"); a.dbg = e ? atoi(e) : 0; }
@@ -2196,14 +2192,15 @@ struct WindowArgs {
 // one WORKGROUP per window, its 4 waves take the node rows round-robin.  Lane r resolves run r ONCE (source pointer, destination
 // offset, length) and the waves fetch those with v_readlane, so there is no dependent descriptor load per run; every run
 // of a row is a contiguous stretch of a column-major series, read coalesced with all of the row's loads in flight.
-template <typename T> __global__ __launch_bounds__(256) void k_assemble_windows(WindowArgs a) {
+template <typename T, int NSET> __global__ __launch_bounds__(256) void k_assemble_windows(WindowArgs a) {
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t b = blockIdx.x;
     const int64_t start = a.starts[b];
-    // lane r <- run r (n_runs <= 64, checked by the host)
-    int v_lo, v_hi, v_doff, v_len, v_t;
-    {
-        const int* run = a.runs + (size_t)min(lane, a.n_runs - 1) * 5;
+    // lane r & 63 of register set r >> 6 <- run r (n_runs <= 64 NSET, checked by the host)
+    int v_lo[NSET], v_hi[NSET], v_doff[NSET], v_len[NSET], v_t[NSET];
+#pragma unroll
+    for (int set = 0; set < NSET; ++set) {
+        const int* run = a.runs + (size_t)min(lane + 64 * set, a.n_runs - 1) * 5;
         const int t = run[0], node = run[1], f0 = run[2], sc = run[3];
         const float* sp = nullptr;
 #pragma unroll
@@ -2211,10 +2208,14 @@ template <typename T> __global__ __launch_bounds__(256) void k_assemble_windows(
         int nodes = 0; int64_t pitch = 0;
 #pragma unroll
         for (int k = 0; k < MSHGNN_MAX_TYPES; ++k) if (t == k) { nodes = a.nodes[k]; pitch = a.x_pitch[k]; }
-        v_lo = (int)((uintptr_t)sp & 0xffffffffu); v_hi = (int)((uintptr_t)sp >> 32);
-        v_doff = (int)(((size_t)b * nodes + node) * pitch + f0 - (size_t)b * nodes * pitch);     // offset inside the window's block of this type
-        v_len = run[4]; v_t = t;
+        v_lo[set] = (int)((uintptr_t)sp & 0xffffffffu); v_hi[set] = (int)((uintptr_t)sp >> 32);
+        v_doff[set] = (int)(((size_t)b * nodes + node) * pitch + f0 - (size_t)b * nodes * pitch);     // offset inside the window's block of this type
+        v_len[set] = run[4]; v_t[set] = t;
     }
+    auto rl = [&](const int (&v)[NSET], int r) {
+        if constexpr (NSET == 1) return __builtin_amdgcn_readlane(v[0], r);
+        else return r < 64 ? __builtin_amdgcn_readlane(v[0], r & 63) : __builtin_amdgcn_readlane(v[NSET - 1], r & 63);
+    };
     // lane handles the element pairs (2 lane + 128 j, +1), j = 0, 1: one packed store per pair (runs start at even features
     // and node rows are 16-byte aligned, so pairs are 4-byte (bf16) / 8-byte (fp32) aligned); lengths up to 256
     for (int row = wv; row < a.n_rows; row += 4) {
@@ -2224,8 +2225,8 @@ template <typename T> __global__ __launch_bounds__(256) void k_assemble_windows(
 #pragma unroll
             for (int i = 0; i < WIN_ROW_RUNS; ++i) {
                 const int r = min(rb + i, r_end - 1);
-                const float* sp = reinterpret_cast<const float*>((uintptr_t)(unsigned)__builtin_amdgcn_readlane(v_lo, r) | ((uintptr_t)(unsigned)__builtin_amdgcn_readlane(v_hi, r) << 32));
-                const int len = __builtin_amdgcn_readlane(v_len, r);
+                const float* sp = reinterpret_cast<const float*>((uintptr_t)(unsigned)rl(v_lo, r) | ((uintptr_t)(unsigned)rl(v_hi, r) << 32));
+                const int len = rl(v_len, r);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int k = 2 * lane + 128 * (q >> 1) + (q & 1);
@@ -2237,9 +2238,9 @@ template <typename T> __global__ __launch_bounds__(256) void k_assemble_windows(
             for (int i = 0; i < WIN_ROW_RUNS; ++i) {
                 if (rb + i >= r_end) break;
                 const int r = rb + i;
-                const int t = __builtin_amdgcn_readlane(v_t, r), len = __builtin_amdgcn_readlane(v_len, r);
-                const bool has_src = (__builtin_amdgcn_readlane(v_lo, r) | __builtin_amdgcn_readlane(v_hi, r)) != 0;
-                T* dst = reinterpret_cast<T*>(a.x[t]) + (size_t)b * a.nodes[t] * a.x_pitch[t] + __builtin_amdgcn_readlane(v_doff, r);
+                const int t = rl(v_t, r), len = rl(v_len, r), doff = rl(v_doff, r);
+                const bool has_src = (rl(v_lo, r) | rl(v_hi, r)) != 0;
+                T* dst = reinterpret_cast<T*>(a.x[t]) + (size_t)b * a.nodes[t] * a.x_pitch[t] + doff;
                 if (a.normalize && has_src) {
                     // (x - mean) / std with the unbiased estimator, NaN -> 0 (flexibleDataset.py:390-396); fp64, two passes over registers
                     double s1 = 0.0;
@@ -2253,7 +2254,7 @@ template <typename T> __global__ __launch_bounds__(256) void k_assemble_windows(
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { const double z = ((double)v[i][q] - mean) / sd; v[i][q] = z == z ? (float)z : 0.0f; }
                 }
-                const bool even = ((__builtin_amdgcn_readlane(v_doff, r) | len) & 1) == 0;
+                const bool even = ((doff | len) & 1) == 0;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int k = 2 * lane + 128 * j;
@@ -2330,9 +2331,14 @@ extern "C" int mshgnn_assemble_windows(const mshgnn_window_desc* d, const float*
     a.label_cols = d->label_cols; a.n_label = d->n_label; a.label_src = d->label_src; a.label_rotate = d->label_rotate; a.quat_src = d->quat_src;
     a.y = y_out; a.quat = quat_out;
     hipStream_t st = (hipStream_t)stream;
-    if (d->n_runs > 64) return set_err(MSHGNN_EUNSUPPORTED, "more than 64 feature runs per window are not supported by this build");
-    if (d->dtype == MSHGNN_F32) hipLaunchKernelGGL(k_assemble_windows<float>, dim3((unsigned)batch), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(k_assemble_windows<__bf16>, dim3((unsigned)batch), dim3(256), 0, st, a);
+    if (d->n_runs > 128) return set_err(MSHGNN_EUNSUPPORTED, "more than 128 feature runs per window are not supported by this build");
+    if (d->dtype == MSHGNN_F32) {
+        if (d->n_runs <= 64) hipLaunchKernelGGL((k_assemble_windows<float, 1>), dim3((unsigned)batch), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_assemble_windows<float, 2>), dim3((unsigned)batch), dim3(256), 0, st, a);
+    } else {
+        if (d->n_runs <= 64) hipLaunchKernelGGL((k_assemble_windows<__bf16, 1>), dim3((unsigned)batch), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_assemble_windows<__bf16, 2>), dim3((unsigned)batch), dim3(256), 0, st, a);
+    }
     if (d->n_label > 0 || (quat_out && d->quat_src >= 0))
         hipLaunchKernelGGL(k_window_labels, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, a);
     HIPCHK(hipGetLastError());

@@ -40,7 +40,6 @@ enum { OP_LOADW = 0, OP_MAC = 1 };
 enum { KIND_RELU = 0, KIND_MLP = 1 };
 enum { NK_DEAD = 0, NK_RELU = 1, NK_MLP = 2 };
 enum { GF_RESIDUAL = 1, GF_ENC_MASK = 2, GF_STORE_MASK = 4, GF_LDS_EPI = 8 };
-enum { NF_RES_IN = 1 };   // backward node flag: G_{l+2}[n] flows into G_{l+1}[n] through the residual
 
 // layer program = [n_groups] + n_groups group headers (GH_SIZE ints each) + two WAVE PROGRAMS of WPROG_LEN ints (one per
 // slot half) holding every group's MAC program back to back (group g starts at entry GH_PC0/GH_PC1 of its half).
@@ -49,8 +48,8 @@ enum { NF_RES_IN = 1 };   // backward node flag: G_{l+2}[n] flows into G_{l+1}[n
 enum { GH_KIND = 0, GH_NSLOTS, GH_BIAS, GH_NSEG, GH_W1, GH_W2, GH_B1, GH_B2, GH_FLAGS, GH_PC0, GH_PC1, GH_PAD2,
        GH_NODES = 12, GH_MLPIDX = 12 + GMAX, GH_SCR = 12 + 2 * GMAX, GH_SIZE = 12 + 3 * GMAX };
 constexpr int WPROG_LEN = 128;
-// backward program header: [n_groups, n_mlp_live, w2pack, w1pack, has_delta, 0,0,0, node_kind[64], node_flags[64], mlp_nodes[GMAX]]
-enum { BH_NGROUPS = 0, BH_NMLP, BH_W2, BH_W1, BH_HAS_DELTA, BH_KIND = 8, BH_NFLAGS = 8 + 64, BH_MLPNODES = 8 + 128, BH_SIZE = 8 + 128 + GMAX };
+// backward program header: [n_groups, n_mlp_live, w2pack, w1pack, 0,0,0,0, node_kind[64], (64 unused), mlp_nodes[GMAX]]
+enum { BH_NGROUPS = 0, BH_NMLP, BH_W2, BH_W1, BH_KIND = 8, BH_MLPNODES = 8 + 128, BH_SIZE = 8 + 128 + GMAX };
 
 // FUSED STACK kernels (bf16 plan): one workgroup keeps its 16-window tile of ALL nodes in LDS through every layer, so a
 // layer's output never makes a round trip through HBM before the next layer reads it (the stashes for the backward
@@ -74,7 +73,7 @@ enum { FH_NSEG = 0, FH_NMLP, FH_W1, FH_W2, FH_B1, FH_B2, FH_FLAGS, FH_MLP0,   //
 enum { FF_RESIDUAL = 1, FF_ENC_MASK = 2 };
 
 // buffer ids used by weight-gradient items
-enum { BUF_X = 0, BUF_DX = 17, BUF_DH = 34, BUF_HB = 50, BUF_T1 = 66, BUF_DU = 82, BUF_IN = 98, BUF_MASK = 102, BUF_COUNT = 118 };   // (dd: D_l deltas are not read by the weight-gradient kernel)
+enum { BUF_X = 0, BUF_DX = 17, BUF_DH = 34, BUF_HB = 50, BUF_T1 = 66, BUF_DU = 82, BUF_IN = 98, BUF_MASK = 102, BUF_COUNT = 118 };
 // last item int: relu-bit buffer (BUF_MASK + l) when P = dX_{l+1}[node] . relu bits (dH of a relu node is recomputed
 // by the weight-gradient kernel instead of being written by k_layer_bwd and read back), else -1
 constexpr int ITEM_INTS = 10;   // p_buf p_nodes*H p_node q_buf (q_nodes*H | -1: raw input) q_node q_col0 q_ncols sign_off pad
@@ -392,11 +391,9 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
         const bool mlp_live = has_mlp && p.live[l][d.mlp_type];
         T[bh + BH_NMLP] = mlp_live ? p.n_mlp : 0;
         if (mlp_live) { T[bh + BH_W2] = p.pack_mlp[1][1]; T[bh + BH_W1] = p.pack_mlp[1][0]; }
-        T[bh + BH_HAS_DELTA] = (l < L - 1) ? 1 : 0;
         for (int n = 0; n < p.NN; ++n) {
             const int t = p.node_type[n];
             T[bh + BH_KIND + n] = !p.live[l][t] ? NK_DEAD : ((has_mlp && t == d.mlp_type) ? NK_MLP : NK_RELU);
-            T[bh + BH_NFLAGS + n] = (residual && l + 1 < L && p.live[l + 1][t]) ? NF_RES_IN : 0;
         }
         if (mlp_live) { for (int u = 0; u < p.n_mlp; ++u) T[bh + BH_MLPNODES + u] = p.type_base[d.mlp_type] + u; exec_bwd += 2 * NL * p.n_mlp; alg_bwd += 2 * NL * p.n_mlp; }
         std::vector<GroupDef> bgroups;

@@ -72,6 +72,20 @@ def quadsdk_a1_c2_recipe(joint_perm: Sequence[int], foot_perm: Sequence[int], hi
         label_series="F", label_cols=lab, label_rotate=body_frame_labels, quat_series="r_o", normalize=normalize)
 
 
+def minicheetah_k4_recipe(joint_perm: Sequence[int], foot_perm: Sequence[int], history: int = 150, normalize: bool = False,
+                          n_base: int = 4) -> WindowRecipe:
+    """The MiniCheetah (LinTzuYaun) contact dataset on the K4 graph: base = IMU tiled to the 4 base nodes, joint = (q, qd) in
+    graph order, foot = (p, v) 3-D in foot order; labels = contact flags of the window's last step in foot order
+    (LinTzuYaunDataset.py:65-88, LinTzuYaunDataset_Morph.py:251-347, 555-625)."""
+    fcols = [[int(3 * i + k) for k in range(3)] for i in foot_perm]
+    return WindowRecipe(
+        node_types=["base", "joint", "foot"], num_nodes={"base": n_base, "joint": len(joint_perm), "foot": len(foot_perm)}, history=history,
+        variables={"base": [("imu_acc", [[0, 1, 2]] * n_base), ("imu_omega", [[0, 1, 2]] * n_base)],
+                   "joint": [(s, [[int(j)] for j in joint_perm]) for s in ("q", "qd")],
+                   "foot": [("p", fcols), ("v", fcols)]},
+        label_series="contacts", label_cols=[int(i) for i in foot_perm], normalize=normalize)
+
+
 class SequenceStore:
     """The raw series of one recorded sequence on the GPU + the recipe that turns window indices into engine inputs."""
 

@@ -38,6 +38,13 @@ def synthetic_sequence(seed, N):
     return seq
 
 
+def minicheetah_sequence(seed, N):
+    rng = np.random.default_rng(seed)
+    f = lambda *s: rng.integers(-2000, 2000, size=s).astype(np.float64) / 64.0
+    return {"imu_acc": f(N, 3), "imu_omega": f(N, 3), "q": f(N, 12), "qd": f(N, 12), "tau_est": f(N, 12), "p": f(N, 12), "v": f(N, 12),
+            "contacts": rng.integers(0, 2, size=(N, 4)).astype(np.float64)}
+
+
 def reference_module():
     pk = types.ModuleType("ms_hgnn"); pk.__path__ = [REF]; sys.modules["ms_hgnn"] = pk
     dp = types.ModuleType("ms_hgnn.datasets_py"); dp.__path__ = [REF + "/datasets_py"]; sys.modules["ms_hgnn.datasets_py"] = dp
@@ -104,6 +111,36 @@ def main():
             fx[f"{c['name']}:{st}:joint"] = rj[:, ::11].copy()
         print(c["name"], "oracle == reference on", len(starts), "windows")
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "windows_a1c2.npz"), **fx)
+
+    # MiniCheetah K4 (LinTzuYaunDataset_Morph.py): same recipe, foot features and contact labels
+    lm = importlib.import_module("ms_hgnn.datasets_py.LinTzuYaunDataset_Morph")
+    seq4 = minicheetah_sequence(seed + 1, N)
+    fx4 = {"seed": np.array(seed + 1), "N": np.array(N), "T": np.array(T), "starts": np.array(starts),
+           "joint_perm": JOINT_PERM.astype(np.int64), "foot_perm": FOOT_PERM.astype(np.int64)}
+    cls = next(getattr(lm, n) for n in dir(lm) if n.startswith("LinTzuYaunDataset") and hasattr(getattr(lm, n), "load_data_sorted_k4"))
+    base_cls = importlib.import_module("ms_hgnn.datasets_py.LinTzuYaunDataset").LinTzuYaunDataset
+    s4 = types.SimpleNamespace()
+    s4.mat_data = seq4; s4.history_length = T; s4.normalize = False; s4.symmetry_operator = None; s4.swap_legs = None
+    s4.joint_node_indices_sorted = JOINT_PERM; s4.foot_node_indices_sorted = FOOT_PERM
+    s4.hgnn_number_nodes = (4, 12, 4); s4.base_width = 6 * T; s4.joint_width = 2 * T; s4.foot_width = 6 * T
+    s4.variables_to_use_base = np.array([0, 1]); s4.variables_to_use_joint = np.array([0, 1]); s4.variables_to_use_foot = np.array([0, 1])
+    s4.urdf_name_to_graph_index_joint = {str(i): i for i in range(12)}; s4.urdf_name_to_graph_index_foot = {f"f{i}": i for i in range(4)}
+    z = torch.zeros(2, 0, dtype=torch.long)
+    for k in ("bj", "jb", "jj", "fj", "jf", "gt", "gs", "bj_attr", "jb_attr", "jj_attr", "fj_attr", "jf_attr", "gt_attr", "gs_attr"):
+        setattr(s4, k, z)
+    s4.load_data_at_dataset_seq = types.MethodType(base_cls.load_data_at_dataset_seq, s4)
+    s4.load_data_sorted_k4 = types.MethodType(cls.load_data_sorted_k4, s4)
+    s4.get = types.MethodType(cls.get_helper_heterogeneous_gnn, s4)
+    for st in starts:
+        data = s4.get(st)
+        ob, oj, of, oy = wo.minicheetah_k4_window(seq4, st, T, JOINT_PERM.astype(int), FOOT_PERM.astype(int))
+        for a, b, what in ((data["base"].x.numpy(), ob, "base"), (data["joint"].x.numpy(), oj, "joint"), (data["foot"].x.numpy(), of, "foot"),
+                           (data.y.numpy(), oy, "y")):
+            assert a.shape == b.shape and np.abs(a - b).max() == 0.0, ("k4", st, what)
+        fx4[f"k4:{st}:y"] = data.y.numpy(); fx4[f"k4:{st}:base"] = data["base"].x.numpy()[:, ::7].copy()
+        fx4[f"k4:{st}:joint"] = data["joint"].x.numpy()[:, ::11].copy(); fx4[f"k4:{st}:foot"] = data["foot"].x.numpy()[:, ::13].copy()
+    print("k4 oracle == reference on", len(starts), "windows")
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "windows_mck4.npz"), **fx4)
 
 
 if __name__ == "__main__":

@@ -40,3 +40,24 @@ def a1_c2_window(seq, start, T, joint_perm, foot_perm, grf_dimension=3, body_fra
     base = np.stack([np.concatenate([v[:, 3 * i:3 * i + 3].flatten("F") for v in (lin, ang)]) for i in range(n_base)])
     joint = np.stack([np.concatenate([v[:, i] for v in (jp, jv, jt)]) for i in range(len(joint_perm))])
     return base, joint, np.ones((4, 1)), labels, np.asarray(quat, dtype=np.float64)
+
+
+def minicheetah_k4_window(seq, start, T, joint_perm, foot_perm, normalize=False, n_base=4):
+    """MiniCheetah (LinTzuYaun) K4 graph -- LinTzuYaunDataset.py:65-88 (window slicing, contact labels of the last step),
+    LinTzuYaunDataset_Morph.py:251-347 (`load_data_sorted_k4`: IMU tiled to the 4 base nodes, joint / foot / label
+    re-ordering, optional standardisation), :555-625 (`get_helper_heterogeneous_gnn`: flatten('F') per variable).
+    seq: imu_acc, imu_omega [N,3]; q, qd [N,12]; p, v [N,12]; contacts [N,4].  Returns base [4, 6T], joint [12, 2T],
+    foot [4, 6T], y [4]."""
+    sl = slice(start, start + T)
+    lin, ang = np.tile(seq["imu_acc"][sl], (1, n_base)), np.tile(seq["imu_omega"][sl], (1, n_base))
+    jp, jv = (seq[k][sl][:, joint_perm] for k in ("q", "qd"))
+    fidx = [int(i * 3 + k) for i in foot_perm for k in range(3)]
+    fp, fv = seq["p"][sl][:, fidx], seq["v"][sl][:, fidx]
+    labels = np.asarray(seq["contacts"][sl][-1])[foot_perm]
+    if normalize:
+        lin, ang, jp, jv, fp, fv = (_standardise(a) for a in (lin, ang, jp, jv, fp, fv))
+    base = np.stack([np.concatenate([v[:, 3 * i:3 * i + 3].flatten("F") for v in (lin, ang)]) for i in range(n_base)])
+    joint = np.stack([np.concatenate([v[:, i] for v in (jp, jv)]) for i in range(len(joint_perm))])
+    foot = np.stack([np.concatenate([v[:, 3 * i:3 * i + 3].flatten("F") for v in (fp, fv)]) for i in range(len(foot_perm))])
+    return base, joint, foot, labels.astype(np.float64)
+

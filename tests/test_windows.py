@@ -78,3 +78,35 @@ def test_assembled_windows_feed_the_engine():
     x_dict = {t: torch.from_numpy(np.stack([w[i] for w in want]).reshape(B * n, -1)) for i, (t, n) in enumerate((("base", 2), ("joint", 12), ("foot", 4)))}
     out_ref = e.forward(e.cast_inputs(x_dict), flat, B, training=False)
     assert torch.equal(out_dev, out_ref)
+
+
+# --- MiniCheetah K4 (contact classification data format) ----------------------------------------
+from oracle.gen_window_golden import minicheetah_sequence   # noqa: E402
+
+FX4 = np.load(os.path.join(os.path.dirname(__file__), "golden", "windows_mck4.npz"))
+SEQ4 = minicheetah_sequence(int(FX4["seed"]), int(FX4["N"]))
+
+
+def test_k4_oracle_matches_reference_fixture():
+    for st in FX4["starts"]:
+        b, j, f, y = wo.minicheetah_k4_window(SEQ4, int(st), T, JP, FP)
+        k = f"k4:{int(st)}"
+        assert np.array_equal(y, FX4[k + ":y"]) and np.array_equal(b[:, ::7], FX4[k + ":base"])
+        assert np.array_equal(j[:, ::11], FX4[k + ":joint"]) and np.array_equal(f[:, ::13], FX4[k + ":foot"])
+        assert b.shape == (4, 6 * T) and j.shape == (12, 2 * T) and f.shape == (4, 6 * T)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("normalize", [False, True])
+def test_k4_device_assembly_matches_oracle(normalize):
+    from morphsym_hgnn_amd.windows import SequenceStore, minicheetah_k4_recipe
+    store = SequenceStore(SEQ4, minicheetah_k4_recipe(JP, FP, T, normalize), dtype="f32")
+    starts = [250, 0, 99, 99, 13]
+    xs, y, q = store.assemble(starts)
+    want = [wo.minicheetah_k4_window(SEQ4, s, T, JP, FP, normalize) for s in starts]
+    for ti, n in enumerate((4, 12, 4)):
+        ref = np.stack([w[ti] for w in want]).reshape(len(starts) * n, -1)
+        got = xs[ti].cpu().numpy().astype(np.float64)[:, :ref.shape[1]]
+        assert np.abs(got - ref).max() <= (0.0 if not normalize else 2e-7 * np.abs(ref).max())
+    assert np.array_equal(y.cpu().numpy(), np.stack([w[3] for w in want])) and q is None
+
