@@ -180,9 +180,12 @@ class ModelSpec:
         return n
 
     def flat_size(self) -> int:
-        offs = self.param_offsets()
-        last = next(reversed(offs.values()))
-        return (last[0] + last[1] + 15) // 16 * 16
+        cached = self.__dict__.get("_flat_size")          # the spec is immutable after construction; this is on every call path
+        if cached is None:
+            offs = self.param_offsets()
+            last = next(reversed(offs.values()))
+            cached = self.__dict__["_flat_size"] = (last[0] + last[1] + 15) // 16 * 16
+        return cached
 
     # ---- symmetry masks --------------------------------------------------------------------
     def symmetry_coefficients(self):
