@@ -5,7 +5,7 @@
 
 A "step" is one pass of the hot path over one minibatch of synthetic A1-shaped windows that is already
 resident in HBM: forward (encoder, L message-passing layers, decoder) + MSE loss + backward with every
-parameter gradient materialised (+ the RCCL gradient all-reduce when N > 1).  Prints ONE JSON line on rank 0.
+parameter gradient materialised (mshgnn_step_mse; + the RCCL gradient all-reduce when N > 1).  Prints ONE JSON line on rank 0.
 
 The workload is BASELINE.json configs[1]: A1 C2 GRF regression, h=128, L=3, grf_dimension=3, batch 8192
 time-windows per GPU (weak scaling).  `roofline` is computed for the kernel with the largest share of the
@@ -128,8 +128,9 @@ def main():
     loss_buf = torch.empty(1, dtype=torch.float32, device=device)
 
     def step():
-        e.forward(xs, flat, B, training=True, out=out)
-        loss, _ = e.backward_mse(xs, flat, out, y, B, grad_flat=gflat, loss=loss_buf)   # MSE fused into the decoder backward
+        # one C-ABI call per step: forward + MSE + backward (on the bf16 plan the decoder, the loss and the decoder backward run
+        # inside the fused forward kernel; == mshgnn_forward + mshgnn_backward_mse, checked by tests/test_engine_gpu.py)
+        _, loss, _ = e.step_mse(xs, flat, y, B, out=out, grad_flat=gflat, loss=loss_buf)
         if dist is not None:
             dist.all_reduce(gflat)   # RCCL sum over ranks (DDP semantics: mean = sum / world, folded into lr)
         return loss

@@ -160,6 +160,13 @@ int mshgnn_backward_mse(const mshgnn_plan* plan, const void* const* x, const int
                         const float* out, const float* y, float* loss_out, float* grad_params, void* workspace,
                         int64_t batch, void* stream);
 
+/* One whole training step of the regression wrappers: forward + MSE + backward, == mshgnn_forward(training=1) followed by
+ * mshgnn_backward_mse, same results up to fp32 summation order.  On the bf16 plan the decoder, the loss and the decoder
+ * backward all run inside the fused forward kernel (one launch less, no X_L / dX_L round trip); other plans run the
+ * two-call sequence.  out receives the forward output, loss_out mean((out - y)^2), grad_params every gradient.           */
+int mshgnn_step_mse(const mshgnn_plan* plan, const void* const* x, const int64_t* x_pitch, const float* params, const float* y,
+                    float* out, float* loss_out, float* grad_params, void* workspace, int64_t batch, void* stream);
+
 /* Backward with the classification wrapper's cross entropy fused in (gnnLightning.py:640-648: CrossEntropyLoss over the
  * batch*4 per-foot logit pairs, mean).  `out` = the forward's logits [batch][n_out][2], labels int32 [batch][n_out] in
  * {0,1}; loss_out (device float[1]) receives the mean cross entropy.  Only for plans with out_channels == 2.            */

@@ -832,6 +832,29 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, Prec<T>::WPS) 
 // place; the stashes the backward pass / k_gradw need are written on the side and never read back by this kernel.
 // One workgroup of 8 waves per CU (<= 256 VGPRs per wave): all accumulators live + double-buffered weight fragments.
 // ------------------------------------------------------------------------------------------------------
+// thread = (row, 8-column chunk): 16 lanes share a row, one wave covers 4 rows; whole rows are read / written coalesced
+template <typename T> __device__ __forceinline__ void load8(const T* p, float (&v)[8]) {
+    if constexpr (sizeof(T) == 4) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(p)[0], b = reinterpret_cast<const f32x4*>(p)[1];
+        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    } else {
+        const u32x4 r = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[2 * e] = __builtin_bit_cast(float, r[e] << 16); v[2 * e + 1] = __builtin_bit_cast(float, r[e] & 0xffff0000u); }
+    }
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float (&v)[8]) {
+    if constexpr (sizeof(T) == 4) {
+        reinterpret_cast<f32x4*>(p)[0] = f32x4{v[0], v[1], v[2], v[3]};
+        reinterpret_cast<f32x4*>(p)[1] = f32x4{v[4], v[5], v[6], v[7]};
+    } else {
+        union { u32x4 r; __bf16 e[8]; } u;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) u.e[e] = (__bf16)v[e];
+        *reinterpret_cast<u32x4*>(p) = u.r;
+    }
+}
+
 struct StackArgs {
     const void* tile_in;                          // fwd: X_0                       bwd: dX_L
     char* ws;
@@ -840,6 +863,8 @@ struct StackArgs {
     const void* wpack; const float* bias; const int* tables; int prog_off[MAX_L];
     int B, NN, L, training, dbg;
     const float* params; const float* out_mask; float* out; int64_t off_dec_w, off_dec_b; int node0, n_out, dout;   // fused decoder (fwd)
+    // mshgnn_step_mse: the forward also takes the wrapper MSE and the decoder backward (dX_L rows, decoder partial gradients, loss partial)
+    const float* y; float* dec_slabs; float inv_n;
 };
 
 // wave program in two VGPRs, fetched with v_readlane: pk = pack id of segment `lane`; pb = 256 byte entries, 4 per lane
@@ -997,22 +1022,82 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
         __syncthreads();
     }
 
-    // decoder on the out-type rows of X_L (hgnn_c2.py:176-189): thread = (node, row, 8-column chunk)
+    // decoder on the out-type rows of X_L (hgnn_c2.py:176-189): thread = (node, row, 8-column chunk).  With y (mshgnn_step_mse) the
+    // same threads also take the wrapper MSE (gnnLightning.py:633-639) and the decoder backward: dX_L rows to global for
+    // k_stack_bwd, and this tile's partial decoder gradients + loss partial into dec_slabs[tile] (summed by k_finalize).
     {
         const int c = tid & 15, row = (tid >> 4) & 15;
         const float* W = a.params + a.off_dec_w;
+        const bool fuse = a.y != nullptr;
+        T* dxl = reinterpret_cast<T*>(a.ws + a.dx_off[a.L]);
+        float accw[8][8], accb[8], lsum = 0.f;
+        if (fuse) {
+#pragma unroll
+            for (int dd = 0; dd < 8; ++dd) { accb[dd] = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) accw[dd][e] = 0.f; }
+        }
         for (int f = tid >> 8; f < a.n_out; f += LAYER_THREADS / 256) {
             f32x4 x0, x1;
             lds_load_oct<T>(smem, a.node0 + f, row, c * 8, x0, x1);
             const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-            for (int dd = 0; dd < a.dout; ++dd) {
-                float sum = 0.f;
+            float dx[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) sum += x[e] * W[dd * H + c * 8 + e];
+            for (int e = 0; e < 8; ++e) dx[e] = 0.f;
+            const bool ok = w0 + row < B;
+            const size_t r = (size_t)(w0 + row) * a.n_out + f;
 #pragma unroll
-                for (int m = 8; m >= 1; m >>= 1) sum += __shfl_xor(sum, m, 64);
-                if (c == 0 && w0 + row < B)
-                    a.out[((size_t)(w0 + row) * a.n_out + f) * a.dout + dd] = (sum + a.params[a.off_dec_b + dd]) * a.out_mask[f * a.dout + dd];
+            for (int dd = 0; dd < 8; ++dd) {
+                if (dd < a.dout) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) sum += x[e] * W[dd * H + c * 8 + e];
+#pragma unroll
+                    for (int m = 8; m >= 1; m >>= 1) sum += __shfl_xor(sum, m, 64);
+                    const float o = (sum + a.params[a.off_dec_b + dd]) * a.out_mask[f * a.dout + dd];
+                    if (c == 0 && ok) a.out[r * a.dout + dd] = o;
+                    if (fuse && ok) {
+                        const float dlt = o - a.y[r * a.dout + dd];
+                        const float g = 2.0f * dlt * a.inv_n * a.out_mask[f * a.dout + dd];
+                        if (c == 0) lsum += dlt * dlt;
+                        accb[dd] += g;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { accw[dd][e] += g * x[e]; dx[e] += g * W[dd * H + c * 8 + e]; }
+                    }
+                }
+            }
+            if (fuse && ok) store8<T>(dxl + act_idx(w0 + row, a.node0 + f, B) + c * 8, dx);
+        }
+        if (fuse) {
+            // reduce over the 4 rows of the wave (lanes 16 apart), then over the 8 waves through LDS (the X tile is dead after the barrier)
+#pragma unroll
+            for (int dd = 0; dd < 8; ++dd) {
+                if (dd < a.dout) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { accw[dd][e] += __shfl_xor(accw[dd][e], 16, 64); accw[dd][e] += __shfl_xor(accw[dd][e], 32, 64); }
+                    accb[dd] += __shfl_xor(accb[dd], 16, 64); accb[dd] += __shfl_xor(accb[dd], 32, 64);
+                }
+            }
+            lsum += __shfl_xor(lsum, 16, 64); lsum += __shfl_xor(lsum, 32, 64);
+            __syncthreads();
+            float* red = reinterpret_cast<float*>(smem);          // [8 waves][8 H + 16]
+            if (lane < 16) {
+#pragma unroll
+                for (int dd = 0; dd < 8; ++dd) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) red[wv * DEC_SLAB_FLOATS + dd * H + lane * 8 + e] = accw[dd][e];
+                    if (lane == 0) red[wv * DEC_SLAB_FLOATS + 8 * H + dd] = accb[dd];
+                }
+                if (lane == 0) red[wv * DEC_SLAB_FLOATS + 8 * H + 8] = lsum;
+            }
+            __syncthreads();
+            float* slab = a.dec_slabs + (size_t)blockIdx.x * DEC_SLAB_FLOATS;
+            for (int i = tid; i < 8 * H + 9; i += LAYER_THREADS) {
+                if (i >= a.dout * H && i < 8 * H) continue;       // rows of unused output channels (k_finalize reads dout rows only)
+                float s2 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) s2 += red[k * DEC_SLAB_FLOATS + i];
+                slab[i] = s2;
             }
         }
     }
@@ -1165,29 +1250,6 @@ struct DecArgs {
     const float* y; float* loss; float inv_n;   // fused MSE: gout = 2 (out - y) / n computed on the fly, loss accumulated
     const int32_t* labels;                      // fused cross entropy (dout == 2): gout = (softmax(out) - onehot) / rows
 };
-
-// thread = (row, 8-column chunk): 16 lanes share a row, one wave covers 4 rows; whole rows are read / written coalesced
-template <typename T> __device__ __forceinline__ void load8(const T* p, float (&v)[8]) {
-    if constexpr (sizeof(T) == 4) {
-        const f32x4 a = reinterpret_cast<const f32x4*>(p)[0], b = reinterpret_cast<const f32x4*>(p)[1];
-        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
-    } else {
-        const u32x4 r = *reinterpret_cast<const u32x4*>(p);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[2 * e] = __builtin_bit_cast(float, r[e] << 16); v[2 * e + 1] = __builtin_bit_cast(float, r[e] & 0xffff0000u); }
-    }
-}
-template <typename T> __device__ __forceinline__ void store8(T* p, const float (&v)[8]) {
-    if constexpr (sizeof(T) == 4) {
-        reinterpret_cast<f32x4*>(p)[0] = f32x4{v[0], v[1], v[2], v[3]};
-        reinterpret_cast<f32x4*>(p)[1] = f32x4{v[4], v[5], v[6], v[7]};
-    } else {
-        union { u32x4 r; __bf16 e[8]; } u;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) u.e[e] = (__bf16)v[e];
-        *reinterpret_cast<u32x4*>(p) = u.r;
-    }
-}
 
 template <typename T> __global__ __launch_bounds__(256) void k_dec_fwd(DecArgs a) {
     const int c = threadIdx.x & 15;
@@ -1601,9 +1663,9 @@ __global__ __launch_bounds__(256, GW_WPS) void k_gradw_bf16(GradwArgs a) {
     }
 }
 
-static_assert(NWG_DEC == 512, "k_finalize sums 8 decoder slabs per lane");
 // k_finalize: sum split-K slabs in fixed order into the flat gradient buffer (every parameter written once)
-struct FinArgs { const int* fin; const int* targets; const float* slabs; const float* dec_slabs; float* grad; int n_lanes, n_parts; float* loss; float inv_n; };
+struct FinArgs { const int* fin; const int* targets; const float* slabs; const float* dec_slabs; float* grad; int n_lanes, n_parts; float* loss; float inv_n;
+                 int n_dec; };   // decoder partial slabs: NWG_DEC (k_dec_bwd) or one per tile (fused forward)
 
 __global__ __launch_bounds__(256) void k_finalize(FinArgs a) {
     const int* f = a.fin + blockIdx.x * FIN_INTS;
@@ -1614,7 +1676,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinArgs a) {
     const int n = (r1 - r0) * cols;
     if (a.loss && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) {   // fused MSE: sum the per-block loss partials
         float l = 0.f;
-        for (int b = threadIdx.x; b < NWG_DEC; b += 64) l += a.dec_slabs[(size_t)b * DEC_SLAB_FLOATS + 8 * H + 8];
+        for (int b = threadIdx.x; b < a.n_dec; b += 64) l += a.dec_slabs[(size_t)b * DEC_SLAB_FLOATS + 8 * H + 8];
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) l += __shfl_xor(l, m, 64);
         if (threadIdx.x == 0) *a.loss = l * a.inv_n;
@@ -1627,10 +1689,13 @@ __global__ __launch_bounds__(256) void k_finalize(FinArgs a) {
         for (int e = wave; e < rows * cols; e += nwaves) {
             const int r = e / cols, cidx = e % cols;
             const int src = is_mat ? r * H + cidx : 8 * H + cidx;
-            float v[NWG_DEC / 64];
+            float sum = 0.f;
+            for (int b0 = 0; b0 < a.n_dec; b0 += 512) {       // 8 slabs per lane in flight; lane-strided, fixed order
+                float v[8];
 #pragma unroll
-            for (int u = 0; u < NWG_DEC / 64; ++u) v[u] = a.dec_slabs[(size_t)(lane + 64 * u) * DEC_SLAB_FLOATS + src];
-            float sum = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+                for (int u = 0; u < 8; ++u) { const int b = b0 + lane + 64 * u; v[u] = b < a.n_dec ? a.dec_slabs[(size_t)b * DEC_SLAB_FLOATS + src] : 0.f; }
+                sum += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            }
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) sum += __shfl_xor(sum, m, 64);
             if (lane == 0) a.grad[dst + (int64_t)r * ld + cidx] = sum;
@@ -1807,7 +1872,7 @@ static int vec_bytes(const void* base, int64_t pitch_elems, int esize) {
 
 template <typename T>
 static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, float* out,
-                        char* ws, int64_t batch, int training, hipStream_t st) {
+                        char* ws, int64_t batch, int training, hipStream_t st, const float* y_fused = nullptr) {
     const HostPlan& hp = p->hp;
     const mshgnn_desc& d = hp.d;
     mshgnn_ws_layout lay; layout_workspace(hp, batch, training, &lay);
@@ -1851,6 +1916,10 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
             { const char* e = getenv("MSHGNN_DBG"); a.dbg = e ? atoi(e) : 0; }
             a.params = params; a.out_mask = p->d_out_mask; a.out = out; a.off_dec_w = d.off_dec_w; a.off_dec_b = d.off_dec_b;
             a.node0 = hp.type_base[d.out_type]; a.n_out = d.type_nodes[d.out_type]; a.dout = d.out_channels;
+            if (y_fused) {
+                a.y = y_fused; a.dec_slabs = reinterpret_cast<float*>(ws + lay.dec_slabs); a.dx_off[hp.L] = lay.dx[hp.L];
+                a.inv_n = 1.0f / (float)((int64_t)B * a.n_out * a.dout);
+            }
             ProfScope ps(p, hp.ks_stack_fwd, st);
             hipLaunchKernelGGL(k_stack_fwd<T>, dim3(tiles), dim3(LAYER_THREADS), hp.fs_blk * Prec<T>::BLK, st, a);
             HIPCHK(hipGetLastError());
@@ -1882,12 +1951,12 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
 template <typename T>
 static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, const float* gout,
                          float* gparams, char* ws, int64_t batch, hipStream_t st, const float* out = nullptr, const float* y = nullptr,
-                         float* loss = nullptr, const int32_t* labels = nullptr) {
+                         float* loss = nullptr, const int32_t* labels = nullptr, bool dec_done = false) {
     const HostPlan& hp = p->hp;
     const mshgnn_desc& d = hp.d;
     mshgnn_ws_layout lay; layout_workspace(hp, batch, 1, &lay);
     const int B = (int)batch;
-    {
+    if (!dec_done) {
         DecArgs a{};
         a.xl = ws + lay.x[hp.L]; a.dxl = ws + lay.dx[hp.L]; a.params = params; a.out_mask = p->d_out_mask; a.gout = gout;
         a.slabs = reinterpret_cast<float*>(ws + lay.dec_slabs); a.off_w = d.off_dec_w; a.off_b = d.off_dec_b;
@@ -1948,7 +2017,8 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
     {
         FinArgs a{p->d_tables + hp.fin_off, p->d_tables + hp.tgt_off, reinterpret_cast<const float*>(ws + lay.slabs),
                   reinterpret_cast<const float*>(ws + lay.dec_slabs), gparams, hp.n_lanes, hp.n_parts, (y || labels) ? loss : nullptr,
-                  1.0f / (float)((int64_t)B * d.type_nodes[d.out_type] * (labels ? 1 : d.out_channels))};
+                  1.0f / (float)((int64_t)B * d.type_nodes[d.out_type] * (labels ? 1 : d.out_channels)),
+                  dec_done ? (int)((B + TILE_ROWS - 1) / TILE_ROWS) : NWG_DEC};
         ProfScope ps(p, hp.ks_fin, st);
         hipLaunchKernelGGL(k_finalize, dim3(hp.n_fin, 64), dim3(256), 0, st, a);
     }
@@ -1979,6 +2049,24 @@ extern "C" int mshgnn_backward_mse(const mshgnn_plan* p, const void* const* x, c
     if (batch < 1 || batch > (1 << 24)) return set_err(MSHGNN_EINVAL, "batch must be in [1, 2^24]");
     if (p->hp.d.dtype == MSHGNN_F32) return backward_impl<float>(p, x, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, (hipStream_t)stream, out, y, loss_out);
     return backward_impl<__bf16>(p, x, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, (hipStream_t)stream, out, y, loss_out);
+}
+
+extern "C" int mshgnn_step_mse(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, const float* y,
+                               float* out, float* loss_out, float* grad_params, void* workspace, int64_t batch, void* stream) {
+    if (!p || !x || !params || !y || !out || !loss_out || !grad_params || !workspace) return set_err(MSHGNN_EINVAL, "null argument to mshgnn_step_mse");
+    if (batch < 1 || batch > (1 << 24)) return set_err(MSHGNN_EINVAL, "batch must be in [1, 2^24]");
+    for (int t = 0; t < p->hp.NT; ++t) if (!x[t]) return set_err(MSHGNN_EINVAL, "null input tensor");
+    hipStream_t st = (hipStream_t)stream;
+    if (p->hp.d.dtype == MSHGNN_F32 || !p->use_fused) {      // no fused stack kernels on this plan: the two-call sequence
+        int rc = p->hp.d.dtype == MSHGNN_F32 ? forward_impl<float>(p, x, x_pitch, params, out, (char*)workspace, batch, 1, st)
+                                              : forward_impl<__bf16>(p, x, x_pitch, params, out, (char*)workspace, batch, 1, st);
+        if (rc) return rc;
+        return p->hp.d.dtype == MSHGNN_F32 ? backward_impl<float>(p, x, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, st, out, y, loss_out)
+                                           : backward_impl<__bf16>(p, x, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, st, out, y, loss_out);
+    }
+    int rc = forward_impl<__bf16>(p, x, x_pitch, params, out, (char*)workspace, batch, 1, st, y);
+    if (rc) return rc;
+    return backward_impl<__bf16>(p, x, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, st, out, y, loss_out, nullptr, true);
 }
 
 extern "C" int mshgnn_backward_ce(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, const float* out,

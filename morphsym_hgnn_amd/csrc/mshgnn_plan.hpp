@@ -775,7 +775,8 @@ inline void layout_workspace(const HostPlan& p, int64_t B, int training, mshgnn_
         for (int l = 0; l <= p.L; ++l) o->dx[l] = take(act);
         for (int l = 0; l < p.L; ++l) { o->dh[l] = take(act); o->du[l] = take(mlp); }
         o->slabs = take((size_t)p.n_slabs * SLAB_FLOATS * 4);
-        o->dec_slabs = take((size_t)NWG_DEC * DEC_SLAB_FLOATS * 4);
+        // decoder partials: NWG_DEC from k_dec_bwd, or one per 16-window tile when the fused forward produces them (mshgnn_step_mse)
+        o->dec_slabs = take((size_t)std::max<int64_t>(NWG_DEC, (B + TILE_ROWS - 1) / TILE_ROWS) * DEC_SLAB_FLOATS * 4);
     }
     o->wpack = take(p.packs.size() * (size_t)H * H * p.esize);
     o->bias = take(p.biases.size() * (size_t)H * 4);

@@ -77,7 +77,7 @@ EXPORTS = [
     "mshgnn_plan_compile_host", "mshgnn_workspace_layout", "mshgnn_forward", "mshgnn_backward", "mshgnn_mse_loss",
     "mshgnn_profile_enable", "mshgnn_profile_read", "mshgnn_backward_mse", "mshgnn_adam_step",
     "mshgnn_metrics_regression", "mshgnn_metrics_classification", "mshgnn_grf_body_to_world", "mshgnn_assemble_windows",
-    "mshgnn_backward_ce",
+    "mshgnn_backward_ce", "mshgnn_step_mse",
 ]
 
 _lib = None
@@ -117,6 +117,8 @@ def load_library():
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.mshgnn_backward_ce.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.mshgnn_step_mse.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.mshgnn_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_float, C.c_float,
                                      C.c_float, C.c_float, C.c_float, C.c_void_p]
     lib.mshgnn_profile_enable.argtypes = [C.c_void_p, C.c_int]
@@ -370,6 +372,28 @@ class Engine:
         _check(self.lib, self.lib.mshgnn_backward_mse(self._plan, ptrs, pitch, params_flat.data_ptr(), out.data_ptr(), y.data_ptr(),
                                                       loss.data_ptr(), grad_flat.data_ptr(), ws.data_ptr(), B, stream), "mshgnn_backward_mse")
         return loss, grad_flat
+
+    def step_mse(self, xs: Sequence[torch.Tensor], params_flat: torch.Tensor, y: torch.Tensor, B: int, out: Optional[torch.Tensor] = None,
+                 grad_flat: Optional[torch.Tensor] = None, loss: Optional[torch.Tensor] = None):
+        """One training step of the regression wrappers in one call (forward + MSE + backward, mshgnn_step_mse):
+        returns (out, loss[1], grad_flat)."""
+        self._check_flat(params_flat, "params_flat")
+        ptrs, pitch = self._xptrs(xs, B)
+        n = B * self.n_out * self.spec.out_channels
+        if y.dtype != torch.float32 or y.numel() != n or not y.is_contiguous():
+            raise ValueError("y must be contiguous fp32 with B*n_out*out_channels elements")
+        if out is None:
+            out = torch.empty(B * self.n_out, self.spec.out_channels, dtype=torch.float32, device=self.device)
+        if grad_flat is None:
+            grad_flat = torch.empty(self.spec.flat_size(), dtype=torch.float32, device=self.device)
+        if loss is None:
+            loss = torch.empty(1, dtype=torch.float32, device=self.device)
+        ws = self.workspace(B, True)
+        self._tickets[B] = self._tickets.get(B, 0) + 1      # the activation stash of this batch size is overwritten
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _check(self.lib, self.lib.mshgnn_step_mse(self._plan, ptrs, pitch, params_flat.data_ptr(), y.data_ptr(), out.data_ptr(), loss.data_ptr(),
+                                                  grad_flat.data_ptr(), ws.data_ptr(), B, stream), "mshgnn_step_mse")
+        return out, loss, grad_flat
 
     def backward_ce(self, xs: Sequence[torch.Tensor], params_flat: torch.Tensor, out: torch.Tensor, labels: torch.Tensor, B: int,
                     grad_flat: Optional[torch.Tensor] = None, loss: Optional[torch.Tensor] = None):

@@ -158,6 +158,28 @@ def test_fused_cross_entropy_backward_matches_golden(name):
     helpers.check_against_fixture(fx, out.detach().cpu(), loss.detach().cpu(), grads, rtol=RTOL_F32, what=name)
 
 
+@pytest.mark.parametrize("dtype,B", [("bf16", 37), ("bf16", 8192), ("f32", 37)])
+def test_one_call_step_equals_forward_plus_backward(dtype, B):
+    """mshgnn_step_mse (bf16 plan: decoder + MSE + decoder backward inside the fused forward kernel) == forward followed by
+    backward_mse: same output bits, loss and gradients up to fp32 summation order."""
+    _require_gpu()
+    from morphsym_hgnn_amd import engine as eng, synth
+    spec = helpers.make_spec("c2", "a1-c2", "a1-c2", 128, 3)
+    e = eng.Engine(spec, dtype)
+    x_dict, y = synth.make_windows(21, B, spec.num_nodes, spec.widths, 12)
+    xs = e.cast_inputs(x_dict)
+    yd = y.reshape(-1).to(e.device, torch.float32)
+    flat = eng.flatten_params(spec, synth.make_params(21, spec.param_shapes()), e.device)
+    out_a = e.forward(xs, flat, B).clone()
+    loss_a, g_a = e.backward_mse(xs, flat, out_a, yd, B)
+    loss_a, g_a = loss_a.clone(), g_a.clone()
+    out_b, loss_b, g_b = e.step_mse(xs, flat, yd, B)
+    torch.cuda.synchronize()
+    assert torch.equal(out_a, out_b)
+    assert abs(float(loss_a) - float(loss_b)) <= 1e-5 * abs(float(loss_a))
+    assert float((g_a - g_b).abs().max() / g_a.abs().max()) < 2e-5
+
+
 def test_adam_step_matches_torch_adam():
     """mshgnn_adam_step vs torch.optim.Adam (fp64, CPU) over 3 steps of the engine's own gradients (optimizer
     pinned by post-step parameters)."""
