@@ -101,9 +101,10 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched through torch.distributed.run (one rank per GPU)")
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("MSHGNN_BENCH_FORCE_DIST") == "1":   # (FORCE_DIST: a 1-rank RCCL group, to exercise the N > 1 code path on one GPU)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local)
         dist.init_process_group(backend="nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local))
@@ -127,13 +128,29 @@ def main():
 
     loss_buf = torch.empty(1, dtype=torch.float32, device=device)
 
+    split = int(e.info.grad_split)
+    # two-phase step + interleaved all-reduce: OFF by default.  Measured with a 1-rank RCCL group (no wire time): the split
+    # launches and the extra stream hand-offs cost +51 us per step, about what an 8-GPU all-reduce of 3.3 MB could hide, and
+    # more than a 2- or 4-GPU one could -- the plain sequence is at least as fast at this gradient size (4 MB).
+    overlap = dist is not None and split > 0 and os.environ.get("MSHGNN_BENCH_OVERLAP", "0") == "1"
+
     def step():
-        # one C-ABI call per step: forward + MSE + backward (on the bf16 plan the decoder, the loss and the decoder backward run
-        # inside the fused forward kernel; == mshgnn_forward + mshgnn_backward_mse, checked by tests/test_engine_gpu.py)
-        _, loss, _ = e.step_mse(xs, flat, y, B, out=out, grad_flat=gflat, loss=loss_buf)
-        if dist is not None:
-            dist.all_reduce(gflat)   # RCCL sum over ranks (DDP semantics: mean = sum / world, folded into lr)
-        return loss
+        # forward + MSE + backward through the C-ABI (on the bf16 plan the decoder, the loss and the decoder backward run inside
+        # the fused forward kernel; == mshgnn_forward + mshgnn_backward_mse, checked by tests/test_engine_gpu.py)
+        if not overlap:
+            _, loss, _ = e.step_mse(xs, flat, y, B, out=out, grad_flat=gflat, loss=loss_buf)
+            if dist is not None:
+                dist.all_reduce(gflat)   # RCCL sum over ranks (DDP semantics: mean = sum / world, folded into lr)
+            return loss
+        # N > 1: the same step in two calls; the all-reduce of everything but the encoder's gradients (83 % of the buffer) runs on
+        # RCCL's stream while this stream computes the encoder's weight gradients, then the encoder's slice follows.  Both
+        # collectives complete inside the step (wait() makes this stream wait for them).
+        e.step_mse_phase(0, xs, flat, y, B, out, gflat, loss_buf)
+        w1 = dist.all_reduce(gflat[split:], async_op=True)
+        e.step_mse_phase(1, xs, flat, y, B, out, gflat, loss_buf)
+        w2 = dist.all_reduce(gflat[:split], async_op=True)
+        w1.wait(); w2.wait()
+        return loss_buf
 
     def barrier():
         if dist is not None:
@@ -167,6 +184,9 @@ def main():
     total_ms = sum(s["total_ms"] for s in stats)
     dom = max(stats, key=lambda s: s["total_ms"])
     avg_s = dom["total_ms"] / dom["launches"] * 1e-3
+    # the two-phase step (N > 1) launches the weight-gradient kernel twice per step: per-launch work = per-step work / launches
+    per_step = max(1, round(dom["launches"] / args.steps))
+    dom = dict(dom, flops_per_window=dom["flops_per_window"] / per_step, bytes_per_window=dom["bytes_per_window"] / per_step)
     if dom["bound"] == "mfma":
         achieved = dom["flops_per_window"] * B / avg_s / 1e12
         peak = PEAK["mfma_TFLOPs"][args.dtype]
@@ -187,7 +207,10 @@ def main():
                 roof["traffic_source"] = os.path.basename(files[-1])
     except Exception:  # noqa: BLE001
         pass
+    if roof.get("traffic") is not None:
+        roof["traffic"] = roof["traffic"] / per_step
     roof["kernel"] = dom["name"]
+    roof["launches_per_step"] = per_step
     roof["avg_us"] = avg_s * 1e6
     roof["share_of_step"] = dom["total_ms"] / max(total_ms, 1e-9)
     kernels = {s["name"]: round(s["total_ms"] / s["launches"] * 1e3, 2) for s in stats}

@@ -94,6 +94,8 @@ typedef struct mshgnn_info {
     double bytes_in;              /* input bytes / window at the plan dtype                            */
     int32_t n_gradw_workgroups;   /* split-K workgroups of the weight-gradient kernel                  */
     int32_t n_launches_fwd, n_launches_bwd;
+    int64_t grad_split;           /* two-phase step (mshgnn_step_mse_phase): gradients [grad_split, n_flat) are final after
+                                     phase 0, [0, grad_split) (the encoder's) after phase 1; -1: the plan has no split       */
 } mshgnn_info;
 
 /* Offsets (bytes) of the per-layer buffers inside the workspace, for tests / debugging.              */
@@ -166,6 +168,15 @@ int mshgnn_backward_mse(const mshgnn_plan* plan, const void* const* x, const int
  * two-call sequence.  out receives the forward output, loss_out mean((out - y)^2), grad_params every gradient.           */
 int mshgnn_step_mse(const mshgnn_plan* plan, const void* const* x, const int64_t* x_pitch, const float* params, const float* y,
                     float* out, float* loss_out, float* grad_params, void* workspace, int64_t batch, void* stream);
+
+/* The same step in two calls, for overlapping the gradient all-reduce with compute on several GPUs: phase 0 runs the forward,
+ * the loss, the backward sweep and every weight gradient except the encoder's -- grad_params[grad_split, n_flat) and
+ * loss_out are final when it completes; phase 1 finishes the encoder's gradients, grad_params[0, grad_split).  A caller
+ * launches the all-reduce of the first region between the two calls (bench.py, N > 1).  Results are bit-identical to
+ * mshgnn_step_mse.  Plans without a split (mshgnn_info.grad_split < 0) return an error.                                   */
+int mshgnn_step_mse_phase(const mshgnn_plan* plan, const void* const* x, const int64_t* x_pitch, const float* params,
+                          const float* y, float* out, float* loss_out, float* grad_params, void* workspace, int64_t batch,
+                          int phase, void* stream);
 
 /* Backward with the classification wrapper's cross entropy fused in (gnnLightning.py:640-648: CrossEntropyLoss over the
  * batch*4 per-foot logit pairs, mean).  `out` = the forward's logits [batch][n_out][2], labels int32 [batch][n_out] in

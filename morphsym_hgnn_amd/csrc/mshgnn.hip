@@ -1951,12 +1951,14 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
 template <typename T>
 static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, const float* gout,
                          float* gparams, char* ws, int64_t batch, hipStream_t st, const float* out = nullptr, const float* y = nullptr,
-                         float* loss = nullptr, const int32_t* labels = nullptr, bool dec_done = false) {
+                         float* loss = nullptr, const int32_t* labels = nullptr, bool dec_done = false, int gw_phase = -1) {
+    // gw_phase: -1 = everything; 0 = backward sweep + the weight gradients of every parameter but the encoder's; 1 = only the
+    // encoder's weight gradients (the sweep of phase 0 left dX_0 in the workspace)
     const HostPlan& hp = p->hp;
     const mshgnn_desc& d = hp.d;
     mshgnn_ws_layout lay; layout_workspace(hp, batch, 1, &lay);
     const int B = (int)batch;
-    if (!dec_done) {
+    if (!dec_done && gw_phase != 1) {
         DecArgs a{};
         a.xl = ws + lay.x[hp.L]; a.dxl = ws + lay.dx[hp.L]; a.params = params; a.out_mask = p->d_out_mask; a.gout = gout;
         a.slabs = reinterpret_cast<float*>(ws + lay.dec_slabs); a.off_w = d.off_dec_w; a.off_b = d.off_dec_b;
@@ -1971,9 +1973,9 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
         hipLaunchKernelGGL(k_dec_bwd<T>, dim3(NWG_DEC), dim3(256), 0, st, a);
     }
     const int tiles = (B + Prec<T>::ROWS - 1) / Prec<T>::ROWS;
-    bool fused_done = false;
+    bool fused_done = gw_phase == 1;
     if constexpr (sizeof(T) == 2) {
-        if (p->use_fused) {
+        if (p->use_fused && gw_phase != 1) {
             StackArgs a{};
             a.tile_in = ws + lay.dx[hp.L]; a.ws = ws;
             for (int l = 0; l <= hp.L; ++l) { a.x_off[l] = lay.x[l]; a.dx_off[l] = lay.dx[l]; }
@@ -2008,19 +2010,26 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
             if (a.vb[t] != 16 || a.pitch[t] % Prec<T>::EPC) a.aligned = 0;
         }
         a.items = p->d_tables + hp.item_off; a.lanes = p->d_tables + hp.lane_off; a.lane_order = p->d_tables + hp.lane_order_off; a.n_pad = hp.n_lanes_pad;
+        if (gw_phase >= 0) { a.lane_order = p->d_tables + hp.order_ph_off[gw_phase]; a.n_pad = hp.npad_ph[gw_phase]; }
         a.signs = p->d_signs; a.slabs = reinterpret_cast<float*>(ws + lay.slabs); a.B = B; a.n_lanes = hp.n_lanes; a.n_parts = hp.n_parts;
         { const char* e = getenv("MSHGNN_DBG_GW"); a.dbg = e ? atoi(e) : 0; }
         ProfScope ps(p, hp.ks_gradw, st);
-        if constexpr (sizeof(T) == 4) hipLaunchKernelGGL(k_gradw_f32, dim3(hp.n_lanes_pad * hp.n_parts), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(k_gradw_bf16, dim3(hp.n_lanes_pad * hp.n_parts), dim3(256), 0, st, a);
+        if (a.n_pad > 0) {
+            if constexpr (sizeof(T) == 4) hipLaunchKernelGGL(k_gradw_f32, dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL(k_gradw_bf16, dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a);
+        }
     }
     {
         FinArgs a{p->d_tables + hp.fin_off, p->d_tables + hp.tgt_off, reinterpret_cast<const float*>(ws + lay.slabs),
                   reinterpret_cast<const float*>(ws + lay.dec_slabs), gparams, hp.n_lanes, hp.n_parts, (y || labels) ? loss : nullptr,
                   1.0f / (float)((int64_t)B * d.type_nodes[d.out_type] * (labels ? 1 : d.out_channels)),
                   dec_done ? (int)((B + TILE_ROWS - 1) / TILE_ROWS) : NWG_DEC};
+        int f0 = 0, nf = hp.n_fin;
+        if (gw_phase == 0) nf = hp.n_fin_ph0;
+        if (gw_phase == 1) { f0 = hp.n_fin_ph0; nf = hp.n_fin - hp.n_fin_ph0; a.loss = nullptr; }
+        a.fin += (size_t)f0 * FIN_INTS;
         ProfScope ps(p, hp.ks_fin, st);
-        hipLaunchKernelGGL(k_finalize, dim3(hp.n_fin, 64), dim3(256), 0, st, a);
+        if (nf > 0) hipLaunchKernelGGL(k_finalize, dim3(nf, 64), dim3(256), 0, st, a);
     }
     HIPCHK(hipGetLastError());
     return MSHGNN_OK;
@@ -2067,6 +2076,24 @@ extern "C" int mshgnn_step_mse(const mshgnn_plan* p, const void* const* x, const
     int rc = forward_impl<__bf16>(p, x, x_pitch, params, out, (char*)workspace, batch, 1, st, y);
     if (rc) return rc;
     return backward_impl<__bf16>(p, x, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, st, out, y, loss_out, nullptr, true);
+}
+
+extern "C" int mshgnn_step_mse_phase(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, const float* y,
+                                     float* out, float* loss_out, float* grad_params, void* workspace, int64_t batch, int phase, void* stream) {
+    if (!p || !x || !params || !y || !out || !loss_out || !grad_params || !workspace) return set_err(MSHGNN_EINVAL, "null argument to mshgnn_step_mse_phase");
+    if (batch < 1 || batch > (1 << 24)) return set_err(MSHGNN_EINVAL, "batch must be in [1, 2^24]");
+    if (phase != 0 && phase != 1) return set_err(MSHGNN_EINVAL, "phase must be 0 or 1");
+    if (p->hp.grad_split < 0) return set_err(MSHGNN_EUNSUPPORTED, "this plan has no two-phase gradient split");
+    for (int t = 0; t < p->hp.NT; ++t) if (!x[t]) return set_err(MSHGNN_EINVAL, "null input tensor");
+    hipStream_t st = (hipStream_t)stream;
+    const bool f32 = p->hp.d.dtype == MSHGNN_F32, fused = !f32 && p->use_fused;
+    if (phase == 0) {
+        int rc = f32 ? forward_impl<float>(p, x, x_pitch, params, out, (char*)workspace, batch, 1, st)
+                     : forward_impl<__bf16>(p, x, x_pitch, params, out, (char*)workspace, batch, 1, st, fused ? y : nullptr);
+        if (rc) return rc;
+    }
+    return f32 ? backward_impl<float>(p, x, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, st, out, y, loss_out, nullptr, false, phase)
+               : backward_impl<__bf16>(p, x, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, st, out, y, loss_out, nullptr, fused, phase);
 }
 
 extern "C" int mshgnn_backward_ce(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, const float* out,

@@ -128,6 +128,10 @@ struct HostPlan {
     int ks_stack_fwd = -1, ks_stack_bwd = -1;
     int item_off = 0, n_items = 0, tgt_off = 0, n_targets = 0, lane_off = 0, n_lanes = 0, n_parts = 1, n_wg_gradw = 0;
     int lane_order_off = 0, n_lanes_pad = 0;
+    // two-phase weight gradients (multi-GPU overlap): phase 0 = every lane but the encoder's (its gradients are all-reduced
+    // while phase 1 = the encoder lanes runs); fin ops are stored phase 0 first
+    int order_ph_off[2]{}, npad_ph[2]{}, n_fin_ph0 = 0;
+    int64_t grad_split = -1;     // flat offset where the phase-0 parameters start ([0, grad_split) = encoder = phase 1); -1: no split
     int fin_off = 0, n_fin = 0;
     int enc_tile_mb = 4;
     int n_slabs = 0;
@@ -639,19 +643,22 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
     std::vector<std::pair<int, int>> cl_size;   // (-size, id)
     for (int c : cl_ids) cl_size.push_back({-(int)std::count(lane_cluster.begin(), lane_cluster.end(), c), c});
     std::sort(cl_size.begin(), cl_size.end());
-    std::vector<std::vector<int>> xq(8);
-    for (auto& cs : cl_size) {
-        int best = 0; for (int x = 1; x < 8; ++x) if (xq[x].size() < xq[best].size()) best = x;
-        for (int ln = 0; ln < p.n_lanes; ++ln) if (lane_cluster[ln] == cs.second) xq[best].push_back(ln);
-    }
-    size_t qmax = 0; for (auto& q : xq) qmax = std::max(qmax, q.size());
-    // rebalance: move lanes from the longest queue to the shortest while it shortens the maximum
-    for (;;) {
-        int lo = 0, hi = 0; for (int x = 1; x < 8; ++x) { if (xq[x].size() < xq[lo].size()) lo = x; if (xq[x].size() > xq[hi].size()) hi = x; }
-        if (xq[hi].size() <= xq[lo].size() + 1) break;
-        xq[lo].push_back(xq[hi].back()); xq[hi].pop_back();
-    }
-    qmax = 0; for (auto& q : xq) qmax = std::max(qmax, q.size());
+    auto build_queues = [&](const std::vector<bool>& take, std::vector<std::vector<int>>& xq) {
+        xq.assign(8, {});
+        for (auto& cs : cl_size) {
+            int best = 0; for (int x = 1; x < 8; ++x) if (xq[x].size() < xq[best].size()) best = x;
+            for (int ln = 0; ln < p.n_lanes; ++ln) if (take[ln] && lane_cluster[ln] == cs.second) xq[best].push_back(ln);
+        }
+        // rebalance: move lanes from the longest queue to the shortest while it shortens the maximum
+        for (;;) {
+            int lo = 0, hi = 0; for (int x = 1; x < 8; ++x) { if (xq[x].size() < xq[lo].size()) lo = x; if (xq[x].size() > xq[hi].size()) hi = x; }
+            if (xq[hi].size() <= xq[lo].size() + 1) break;
+            xq[lo].push_back(xq[hi].back()); xq[hi].pop_back();
+        }
+        size_t m = 0; for (auto& q : xq) m = std::max(m, q.size());
+        return m; };
+    std::vector<std::vector<int>> xq;
+    size_t qmax = build_queues(std::vector<bool>(p.n_lanes, true), xq);
     p.n_lanes_pad = (int)qmax * 8;
     p.n_wg_gradw = p.n_lanes * p.n_parts;
     p.tgt_off = (int)T.size(); p.n_targets = (int)tgts.size();
@@ -664,15 +671,26 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
     p.lane_order_off = (int)T.size();
     for (int k = 0; k < (int)qmax; ++k) for (int x = 0; x < 8; ++x) T.push_back(k < (int)xq[x].size() ? xq[x][k] : -1);
     p.n_slabs = p.n_wg_gradw;
+    // phase tables: the encoder targets are the last ones, so their lanes are the tail [lane_split, n_lanes)
+    int lane_split = p.n_lanes;
+    std::vector<bool> tgt_is_enc(tgts.size(), false);
+    for (int t = 0; t < NT; ++t) for (int g : tgt_enc[t]) { tgt_is_enc[g] = true; lane_split = std::min(lane_split, tgt_lane_begin[g]); }
+    for (int ph = 0; ph < 2; ++ph) {
+        std::vector<bool> take(p.n_lanes);
+        for (int ln = 0; ln < p.n_lanes; ++ln) take[ln] = (ln >= lane_split) == (ph == 1);
+        std::vector<std::vector<int>> q2;
+        const size_t m = build_queues(take, q2);
+        p.order_ph_off[ph] = (int)T.size(); p.npad_ph[ph] = (int)m * 8;
+        for (int k = 0; k < (int)m; ++k) for (int x = 0; x < 8; ++x) T.push_back(k < (int)q2[x].size() ? q2[x][k] : -1);
+    }
 
     // finalize ops: every parameter is written exactly once
-    p.fin_off = (int)T.size(); p.n_fin = 0;
+    struct FinRec { int64_t dst; int rows, cols, ld, target, kind; };
+    std::vector<FinRec> fins;
     auto add_fin = [&](int64_t dst, int rows, int cols, int ld, int target, int kind) {
         // (merging ops that share a slab sum into one multi-destination op was measured slower: the kernel is bound by
         //  the serial slab chain per thread, so fewer, fatter ops lose parallelism)
-        T.push_back((int32_t)(dst & 0xffffffff)); T.push_back((int32_t)(dst >> 32)); T.push_back(rows); T.push_back(cols);
-        T.push_back(ld); T.push_back(target); T.push_back(kind); T.push_back(0);
-        ++p.n_fin; };
+        fins.push_back({dst, rows, cols, ld, target, kind}); };
     for (int t = 0; t < NT; ++t) {
         const int F = d.type_width[t];
         for (int kc = 0; kc < p.enc_nkc[t]; ++kc) {
@@ -712,6 +730,25 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
         }
         if (d.n_flat > pos && d.n_flat - pos < 4096) add_fin(pos, 1, (int)(d.n_flat - pos), (int)(d.n_flat - pos), -1, FIN_ZERO);
     }
+    {   // phase split of the flat buffer: [0, grad_split) = encoder parameters (phase 1), the rest phase 0 -- only when the
+        // encoder really is a prefix of the buffer (state_dict order: encoder.lins.* first)
+        int64_t enc_end = 0, rest_begin = d.n_flat;
+        for (int t = 0; t < NT; ++t) { enc_end = std::max(enc_end, p.off_enc_w[t] + (int64_t)H * d.type_width[t]); enc_end = std::max(enc_end, p.off_enc_b[t] + (int64_t)H); }
+        for (int i = 0; i < L * NR; ++i) { rest_begin = std::min(rest_begin, std::min(p.off_rel_w[i], std::min(p.off_rel_b[i], p.off_root_w[i]))); }
+        if (has_mlp) for (int k = 0; k < 4; ++k) rest_begin = std::min<int64_t>(rest_begin, d.off_mlp[k]);
+        rest_begin = std::min<int64_t>(rest_begin, std::min(d.off_dec_w, d.off_dec_b));
+        p.grad_split = (enc_end <= rest_begin && lane_split < p.n_lanes) ? rest_begin : -1;
+        auto is_ph1 = [&](const FinRec& f) { return p.grad_split >= 0 && f.dst < p.grad_split; };
+        std::stable_sort(fins.begin(), fins.end(), [&](const FinRec& x, const FinRec& y) { return is_ph1(x) < is_ph1(y); });
+        p.fin_off = (int)T.size(); p.n_fin = (int)fins.size(); p.n_fin_ph0 = 0;
+        for (auto& f : fins) {
+            if (!is_ph1(f)) ++p.n_fin_ph0;
+            if (is_ph1(f) && f.target >= 0 && !tgt_is_enc[f.target]) p.grad_split = -1;      // (cannot happen with the layouts the host produces)
+            T.push_back((int32_t)(f.dst & 0xffffffff)); T.push_back((int32_t)(f.dst >> 32)); T.push_back(f.rows); T.push_back(f.cols);
+            T.push_back(f.ld); T.push_back(f.target); T.push_back(f.kind); T.push_back(0);
+        }
+        if (p.grad_split < 0) p.n_fin_ph0 = p.n_fin;
+    }
 
     // ---- info ---------------------------------------------------------------------------------------
     p.info.rows_per_tile = p.rows; p.info.total_nodes = p.NN; p.info.lds_bytes = (int64_t)p.n_blk * p.blk_bytes;
@@ -719,6 +756,7 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
     double bytes = 0; for (int t = 0; t < NT; ++t) bytes += (double)d.type_nodes[t] * d.type_width[t] * p.esize;
     p.info.bytes_in = bytes; p.info.n_gradw_workgroups = p.n_wg_gradw;
     p.info.n_launches_fwd = 3 + L; p.info.n_launches_bwd = 3 + L;
+    p.info.grad_split = p.grad_split;
 
     // ---- per-kernel work table (launch order of one fwd+bwd step) -----------------------------------------
     {

@@ -44,6 +44,7 @@ class MshgnnInfo(C.Structure):
         ("rows_per_tile", C.c_int32), ("total_nodes", C.c_int32), ("lds_bytes", C.c_int64),
         ("flops_fwd", C.c_double), ("flops_bwd", C.c_double), ("flops_exec_fwd", C.c_double), ("flops_exec_bwd", C.c_double),
         ("bytes_in", C.c_double), ("n_gradw_workgroups", C.c_int32), ("n_launches_fwd", C.c_int32), ("n_launches_bwd", C.c_int32),
+        ("grad_split", C.c_int64),
     ]
 
 
@@ -77,7 +78,7 @@ EXPORTS = [
     "mshgnn_plan_compile_host", "mshgnn_workspace_layout", "mshgnn_forward", "mshgnn_backward", "mshgnn_mse_loss",
     "mshgnn_profile_enable", "mshgnn_profile_read", "mshgnn_backward_mse", "mshgnn_adam_step",
     "mshgnn_metrics_regression", "mshgnn_metrics_classification", "mshgnn_grf_body_to_world", "mshgnn_assemble_windows",
-    "mshgnn_backward_ce", "mshgnn_step_mse",
+    "mshgnn_backward_ce", "mshgnn_step_mse", "mshgnn_step_mse_phase",
 ]
 
 _lib = None
@@ -119,6 +120,8 @@ def load_library():
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.mshgnn_step_mse.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.mshgnn_step_mse_phase.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
     lib.mshgnn_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_float, C.c_float,
                                      C.c_float, C.c_float, C.c_float, C.c_void_p]
     lib.mshgnn_profile_enable.argtypes = [C.c_void_p, C.c_int]
@@ -394,6 +397,19 @@ class Engine:
         _check(self.lib, self.lib.mshgnn_step_mse(self._plan, ptrs, pitch, params_flat.data_ptr(), y.data_ptr(), out.data_ptr(), loss.data_ptr(),
                                                   grad_flat.data_ptr(), ws.data_ptr(), B, stream), "mshgnn_step_mse")
         return out, loss, grad_flat
+
+    def step_mse_phase(self, phase: int, xs: Sequence[torch.Tensor], params_flat: torch.Tensor, y: torch.Tensor, B: int, out: torch.Tensor,
+                       grad_flat: torch.Tensor, loss: torch.Tensor):
+        """mshgnn_step_mse in two calls (phase 0, then 1): after phase 0 grad_flat[self.info.grad_split:] and loss are final,
+        after phase 1 the encoder's gradients grad_flat[:grad_split] -- the caller puts the all-reduce of the first region
+        in between."""
+        ptrs, pitch = self._xptrs(xs, B)
+        ws = self.workspace(B, True)
+        if phase == 0:
+            self._tickets[B] = self._tickets.get(B, 0) + 1
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _check(self.lib, self.lib.mshgnn_step_mse_phase(self._plan, ptrs, pitch, params_flat.data_ptr(), y.data_ptr(), out.data_ptr(),
+                                                        loss.data_ptr(), grad_flat.data_ptr(), ws.data_ptr(), B, phase, stream), "mshgnn_step_mse_phase")
 
     def backward_ce(self, xs: Sequence[torch.Tensor], params_flat: torch.Tensor, out: torch.Tensor, labels: torch.Tensor, B: int,
                     grad_flat: Optional[torch.Tensor] = None, loss: Optional[torch.Tensor] = None):

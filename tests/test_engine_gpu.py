@@ -180,6 +180,34 @@ def test_one_call_step_equals_forward_plus_backward(dtype, B):
     assert float((g_a - g_b).abs().max() / g_a.abs().max()) < 2e-5
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_two_phase_step_is_bit_identical(dtype):
+    """mshgnn_step_mse_phase (what bench.py interleaves with the all-reduce on N > 1 GPUs): after phase 0 everything but the
+    encoder's gradients is final, after phase 1 the whole buffer equals the one-call step bit for bit."""
+    _require_gpu()
+    from morphsym_hgnn_amd import engine as eng, synth
+    spec = helpers.make_spec("c2", "a1-c2", "a1-c2", 128, 3)
+    B = 333
+    e = eng.Engine(spec, dtype)
+    x_dict, y = synth.make_windows(5, B, spec.num_nodes, spec.widths, 12)
+    xs = e.cast_inputs(x_dict)
+    yd = y.reshape(-1).to(e.device, torch.float32)
+    flat = eng.flatten_params(spec, synth.make_params(5, spec.param_shapes()), e.device)
+    out_a, loss_a, g_a = e.step_mse(xs, flat, yd, B)
+    out_a, loss_a, g_a = out_a.clone(), loss_a.clone(), g_a.clone()
+    split = int(e.info.grad_split)
+    offs = spec.param_offsets()
+    assert split == offs["convs.0.convs.<base___front_bj___joint>.lin_rel.weight"][0] == min(o for k, (o, n) in offs.items() if not k.startswith("encoder."))
+    out_b = torch.empty_like(out_a); loss_b = torch.empty(1, device=e.device); g_b = torch.full_like(g_a, float("nan"))
+    e.step_mse_phase(0, xs, flat, yd, B, out_b, g_b, loss_b)
+    torch.cuda.synchronize()
+    assert torch.equal(g_b[split:], g_a[split:]) and torch.equal(loss_b, loss_a) and torch.equal(out_b, out_a)
+    assert bool(torch.isnan(g_b[:split]).all())           # the encoder's slice is untouched until phase 1
+    e.step_mse_phase(1, xs, flat, yd, B, out_b, g_b, loss_b)
+    torch.cuda.synchronize()
+    assert torch.equal(g_b, g_a)
+
+
 def test_adam_step_matches_torch_adam():
     """mshgnn_adam_step vs torch.optim.Adam (fp64, CPU) over 3 steps of the engine's own gradients (optimizer
     pinned by post-step parameters)."""
