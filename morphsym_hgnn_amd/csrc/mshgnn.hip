@@ -865,7 +865,9 @@ struct StackArgs {
     const float* params; const float* out_mask; float* out; int64_t off_dec_w, off_dec_b; int node0, n_out, dout;   // fused decoder (fwd)
     // mshgnn_step_mse: the forward also takes the wrapper MSE and the decoder backward (dX_L rows, decoder partial gradients, loss partial)
     const float* y; float* dec_slabs; float inv_n;
+    long long* stamps;   // timing experiments (MSHGNN_STAMPS): wave 0 of every workgroup records clock64() at phase boundaries
 };
+#define FS_STAMP(k) do { if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 32 + (k)] = clock64(); } while (0)
 
 // wave program in two VGPRs, fetched with v_readlane: pk = pack id of segment `lane`; pb = 256 byte entries, 4 per lane
 struct FProg {
@@ -873,6 +875,15 @@ struct FProg {
     __device__ __forceinline__ FProg(const int* prog, int lane) : pk(prog[lane]), pb(prog[64 + lane]) {}
     __device__ __forceinline__ int pack(int sgi) const { return __builtin_amdgcn_readlane(pk, sgi); }
     __device__ __forceinline__ int at(int i) const { return (__builtin_amdgcn_readlane(pb, i >> 2) >> ((i & 3) << 3)) & 0xff; }
+};
+
+// a layer header (FH_SIZE = 88 ints) held in two VGPRs and read with v_readlane: per-node flags cost no scalar-memory round
+// trip (measured with in-kernel stamps: ~40 dependent s_loads of the header were 6.6k cycles before the first MAC of a layer)
+struct FHdr {
+    int h0, h1;
+    __device__ __forceinline__ FHdr() : h0(0), h1(0) {}
+    __device__ __forceinline__ FHdr(const int* hdr, int lane) : h0(hdr[lane]), h1(lane < FH_SIZE - 64 ? hdr[64 + lane] : 0) {}
+    __device__ __forceinline__ int operator[](int i) const { return i < 64 ? __builtin_amdgcn_readlane(h0, i & 63) : __builtin_amdgcn_readlane(h1, i & 63); }
 };
 
 // one segment: walk the accumulators in static order, each with its run-time MAC count; the source blocks come from the
@@ -928,13 +939,21 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
     const int win = c_win(lane), w = w0 + win, col = wn * 32 + c_oct(lane);
     const bool w_ok = w < B, train = a.training != 0;
 
+    FS_STAMP(0);
     stage_nodes<T>(smem, reinterpret_cast<const T*>(a.tile_in), NN, w0, B, tid);
     __syncthreads();
+    FS_STAMP(1);
 
     typename P::Acc acc[FS_HS];
+    FHdr fhn(a.tables + a.prog_off[0], lane);
+    FProg wpn(a.tables + a.prog_off[0] + FH_SIZE + wh * FPROG_LEN, lane);
     for (int l = 0; l < a.L; ++l) {
-        const int* fh = a.tables + a.prog_off[l];
-        const FProg wp(fh + FH_SIZE + wh * FPROG_LEN, lane);
+        const FHdr fh = fhn;
+        const FProg wp = wpn;
+        if (l + 1 < a.L) {    // the next layer's header and wave program stream in under this layer's MACs
+            fhn = FHdr(a.tables + a.prog_off[l + 1], lane);
+            wpn = FProg(a.tables + a.prog_off[l + 1] + FH_SIZE + wh * FPROG_LEN, lane);
+        }
         const int nmlp = fh[FH_NMLP], flags = fh[FH_FLAGS];
         // accumulators start at the bias row of their node's type (the loads hide under the first weight fragment)
 #pragma unroll
@@ -943,8 +962,11 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
             if (n < NN && fh[FH_KIND + n] != NK_DEAD) acc_init_bias<T>(acc[u], a.bias + (size_t)fh[FH_BIAS + n] * H, wn, lane);
             else acc_fill(acc[u], 0.f);
         }
+        FS_STAMP(2 + 4 * l);
         if (!(a.dbg & 2)) fs_run<T>(wp, acc, smem, wpack, wn, lane, a.dbg);
+        FS_STAMP(3 + 4 * l);
         __syncthreads();   // every wave is done reading X_l: the node blocks may be overwritten
+        FS_STAMP(4 + 4 * l);
         if (a.dbg & 8) continue;
 
         if (nmlp > 0 && !(a.dbg & 64)) {
@@ -998,11 +1020,19 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
         // X_{l+1}[n] = f(H[n]) (+ X_l[n]) for every live node, in place; stash + relu bits on the side
         T* xo = reinterpret_cast<T*>(a.ws + a.x_off[l + 1]);
         unsigned* maskbits = reinterpret_cast<unsigned*>(a.ws + a.mask_off[l]);
+        u32x4 resv[FS_HS]; int kindv[FS_HS];     // the residual octets of every node, all LDS reads in flight together
+#pragma unroll
+        for (int u = 0; u < FS_HS; ++u) {
+            const int n = 2 * u + wh;
+            kindv[u] = n < NN ? fh[FH_KIND + n] : NK_DEAD;
+            resv[u] = u32x4{0, 0, 0, 0};
+            if (kindv[u] != NK_DEAD && (flags & FF_RESIDUAL)) resv[u] = *reinterpret_cast<const u32x4*>(smem + lds_chunk<T>(n, win, col / P::EPC));
+        }
 #pragma unroll
         for (int u = 0; u < FS_HS; ++u) {
             const int n = 2 * u + wh;
             if (n < NN) {
-                const int kind = fh[FH_KIND + n];
+                const int kind = kindv[u];
                 if (kind != NK_DEAD) {
                     f32x4 y0 = acc[u].c[0], y1 = acc[u].c[1];
                     if (kind == NK_RELU) {
@@ -1010,9 +1040,11 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
                         y0 = relu4(y0); y1 = relu4(y1);
                     }
                     if (flags & FF_RESIDUAL) {
-                        f32x4 r0, r1;
-                        lds_load_oct<T>(smem, n, win, col, r0, r1);
-                        y0 += r0; y1 += r1;
+                        const u32x4 r = resv[u];
+                        y0 += f32x4{__builtin_bit_cast(float, r[0] << 16), __builtin_bit_cast(float, r[0] & 0xffff0000u),
+                                    __builtin_bit_cast(float, r[1] << 16), __builtin_bit_cast(float, r[1] & 0xffff0000u)};
+                        y1 += f32x4{__builtin_bit_cast(float, r[2] << 16), __builtin_bit_cast(float, r[2] & 0xffff0000u),
+                                    __builtin_bit_cast(float, r[3] << 16), __builtin_bit_cast(float, r[3] & 0xffff0000u)};
                     }
                     lds_store_oct<T>(smem, n, win, col, y0, y1);
                     if (train && w_ok && !(a.dbg & 16)) store_oct(xo + act_idx(w, n, B) + col, y0, y1);
@@ -1020,6 +1052,7 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
             }
         }
         __syncthreads();
+        FS_STAMP(5 + 4 * l);
     }
 
     // decoder on the out-type rows of X_L (hgnn_c2.py:176-189): thread = (node, row, 8-column chunk).  With y (mshgnn_step_mse) the
@@ -1101,6 +1134,7 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
             }
         }
     }
+    FS_STAMP(30);
 }
 
 template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_bwd(StackArgs a) {
@@ -1115,7 +1149,7 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
 
     // dX_L tile: only the nodes that are live in the last layer carry a gradient
     {
-        const int* bh = a.tables + a.prog_off[a.L - 1];
+        const FHdr bh(a.tables + a.prog_off[a.L - 1], lane);
         const T* src = reinterpret_cast<const T*>(a.tile_in);
         const RowMap<T> m(tid);
         for (int n = m.sub; n < NN; n += RowMap<T>::NPB) {
@@ -1128,33 +1162,45 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
     __syncthreads();
 
     typename P::Acc acc[FS_HS];
+    FHdr bhn(a.tables + a.prog_off[a.L - 1], lane);
+    FProg wpn(a.tables + a.prog_off[a.L - 1] + FH_SIZE + wh * FPROG_LEN, lane);
     for (int l = a.L - 1; l >= 0; --l) {
-        const int* bh = a.tables + a.prog_off[l];
-        const FProg wp(bh + FH_SIZE + wh * FPROG_LEN, lane);
+        const FHdr bh = bhn;
+        const FProg wp = wpn;
+        if (l > 0) {          // the next layer's header and wave program stream in under this layer's MACs
+            bhn = FHdr(a.tables + a.prog_off[l - 1], lane);
+            wpn = FProg(a.tables + a.prog_off[l - 1] + FH_SIZE + wh * FPROG_LEN, lane);
+        }
         const int nmlp = bh[FH_NMLP], flags = bh[FH_FLAGS];
         const unsigned* maskbits = reinterpret_cast<const unsigned*>(a.ws + a.mask_off[l]);
 
         // phase 1 (each lane on the octets it owns): the accumulator of node n starts at its residual term
-        // G_{l+1}[n]; relu nodes are then masked in place -> dH_l[n]
+        // G_{l+1}[n]; relu nodes are then masked in place -> dH_l[n].  Every relu-bit word and every LDS read is issued
+        // before the first use: one memory latency per layer, not one per node.
+        {
+            unsigned mword[FS_HS]; u32x4 rawv[FS_HS]; int kindv[FS_HS];
 #pragma unroll
-        for (int u = 0; u < FS_HS; ++u) {
-            const int n = 2 * u + wh;
-            acc_fill(acc[u], 0.f);
-            if (n < NN) {
-                const int kind = bh[FH_KIND + n];
-                if (kind != NK_DEAD) {
-                    char* pc = smem + lds_chunk<T>(n, win, col / P::EPC);
-                    const u32x4 raw = *reinterpret_cast<const u32x4*>(pc);
+            for (int u = 0; u < FS_HS; ++u) {
+                const int n = 2 * u + wh;
+                kindv[u] = n < NN ? bh[FH_KIND + n] : NK_DEAD;
+                mword[u] = 0u; rawv[u] = u32x4{0, 0, 0, 0};
+                if (kindv[u] == NK_RELU && w_ok) mword[u] = maskbits[((size_t)n * 4 + wn) * B + w];
+                if (kindv[u] != NK_DEAD) rawv[u] = *reinterpret_cast<const u32x4*>(smem + lds_chunk<T>(n, win, col / P::EPC));
+            }
+#pragma unroll
+            for (int u = 0; u < FS_HS; ++u) {
+                const int n = 2 * u + wh;
+                acc_fill(acc[u], 0.f);
+                if (kindv[u] != NK_DEAD) {
+                    const u32x4 raw = rawv[u];
                     if (bh[FH_RES + n]) {
                         acc[u].c[0] = f32x4{__builtin_bit_cast(float, raw[0] << 16), __builtin_bit_cast(float, raw[0] & 0xffff0000u),
                                             __builtin_bit_cast(float, raw[1] << 16), __builtin_bit_cast(float, raw[1] & 0xffff0000u)};
                         acc[u].c[1] = f32x4{__builtin_bit_cast(float, raw[2] << 16), __builtin_bit_cast(float, raw[2] & 0xffff0000u),
                                             __builtin_bit_cast(float, raw[3] << 16), __builtin_bit_cast(float, raw[3] & 0xffff0000u)};
                     }
-                    if (kind == NK_RELU) {
-                        const unsigned word = w_ok ? maskbits[((size_t)n * 4 + wn) * B + w] : 0u;
-                        *reinterpret_cast<u32x4*>(pc) = chunk_mask_bits<T>(raw, word >> g8);
-                    }
+                    if (kindv[u] == NK_RELU)
+                        *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(n, win, col / P::EPC)) = chunk_mask_bits<T>(raw, mword[u] >> g8);
                 }
             }
         }
@@ -1920,6 +1966,7 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
                 a.y = y_fused; a.dec_slabs = reinterpret_cast<float*>(ws + lay.dec_slabs); a.dx_off[hp.L] = lay.dx[hp.L];
                 a.inv_n = 1.0f / (float)((int64_t)B * a.n_out * a.dout);
             }
+            { const char* e = getenv("MSHGNN_STAMPS"); a.stamps = e ? reinterpret_cast<long long*>((uintptr_t)strtoull(e, nullptr, 0)) : nullptr; }
             ProfScope ps(p, hp.ks_stack_fwd, st);
             hipLaunchKernelGGL(k_stack_fwd<T>, dim3(tiles), dim3(LAYER_THREADS), hp.fs_blk * Prec<T>::BLK, st, a);
             HIPCHK(hipGetLastError());
