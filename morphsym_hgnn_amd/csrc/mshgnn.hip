@@ -869,11 +869,13 @@ struct StackArgs {
 };
 #define FS_STAMP(k) do { if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 32 + (k)] = clock64(); } while (0)
 
-// wave program in two VGPRs, fetched with v_readlane: pk = pack id of segment `lane`; pb = 256 byte entries, 4 per lane
+// wave program in three VGPRs, fetched with v_readlane: pk = pack id of segment `lane`; pcnt = its MAC counts (3 bits per
+// accumulator); pb = 256 byte entries, 4 per lane (entry 0 = number of segments, then the block stream)
 struct FProg {
-    int pk, pb;
-    __device__ __forceinline__ FProg(const int* prog, int lane) : pk(prog[lane]), pb(prog[64 + lane]) {}
+    int pk, pcnt, pb;
+    __device__ __forceinline__ FProg(const int* prog, int lane) : pk(prog[lane]), pcnt(prog[64 + lane]), pb(prog[128 + lane]) {}
     __device__ __forceinline__ int pack(int sgi) const { return __builtin_amdgcn_readlane(pk, sgi); }
+    __device__ __forceinline__ int counts(int sgi) const { return __builtin_amdgcn_readlane(pcnt, sgi); }
     __device__ __forceinline__ int at(int i) const { return (__builtin_amdgcn_readlane(pb, i >> 2) >> ((i & 3) << 3)) & 0xff; }
 };
 
@@ -889,17 +891,19 @@ struct FHdr {
 // one segment: walk the accumulators in static order, each with its run-time MAC count; the source blocks come from the
 // program's block stream in execution order, so the fragment of the NEXT MAC is read from LDS under this MAC's MFMAs
 template <typename T>
-__device__ __forceinline__ void fs_walk(const FProg& wp, int& pc, int& pb, typename Prec<T>::AFrag& afn, typename Prec<T>::Acc (&acc)[FS_HS],
+__device__ __forceinline__ void fs_walk(const FProg& wp, int sgi, int& pb, typename Prec<T>::AFrag& afn, typename Prec<T>::Acc (&acc)[FS_HS],
                                         const typename Prec<T>::BFrag& bf, const char* smem, int lane, int dbg = 0) {
+    const int cw = wp.counts(sgi);      // one readlane per segment: 3 bits of MAC count per accumulator
 #pragma unroll
     for (int u = 0; u < FS_HS; ++u) {
-        const int cnt = wp.at(pc++);
+        const int cnt = (cw >> (3 * u)) & 7;
         for (int k = 0; k < cnt; ++k) {
-            const typename Prec<T>::AFrag af = afn;
+            // the MFMAs of this MAC read afn as they issue; the fragment of the NEXT MAC is then read from LDS into the same
+            // registers and lands while those MFMAs execute (no second buffer, no register copies)
+            if (!(dbg & 128)) mac(acc[u], afn, bf);
             if (!(dbg & 256)) load_afrag<T>(afn, smem, wp.at(++pb), lane);
-            if (!(dbg & 128)) mac(acc[u], af, bf);
-            __builtin_amdgcn_sched_group_barrier(0x100, Prec<T>::NAV, 0);   // the prefetch reads first, then this MAC's MFMAs
             __builtin_amdgcn_sched_group_barrier(0x008, 2 * Prec<T>::NAV * (sizeof(T) == 4 ? 4 : 1), 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, Prec<T>::NAV, 0);
         }
     }
 }
@@ -908,7 +912,7 @@ __device__ __forceinline__ void fs_walk(const FProg& wp, int& pc, int& pb, typen
 template <typename T>
 __device__ __forceinline__ void fs_run(const FProg& wp, typename Prec<T>::Acc (&acc)[FS_HS], const char* smem, const T* wpack, int wn, int lane, int dbg = 0) {
     const int nseg = wp.at(0);
-    int pc = 1, pb = 1 + nseg * FS_HS;
+    int pb = 1;
     typename Prec<T>::BFrag bfa, bfb;
     typename Prec<T>::AFrag afn;
     // drain the previous epilogue's memory operations first: with loads AND stores pending the compiler must assume
@@ -921,10 +925,10 @@ __device__ __forceinline__ void fs_run(const FProg& wp, typename Prec<T>::Acc (&
     // the MAC loops never have to drain the prefetch
     for (int sgi = 0; sgi < nseg; sgi += 2) {
         load_bfrag<T>(bfb, wpack, wp.pack(min(sgi + 1, nseg - 1)), wn, lane);
-        fs_walk<T>(wp, pc, pb, afn, acc, bfa, smem, lane, dbg);
+        fs_walk<T>(wp, sgi, pb, afn, acc, bfa, smem, lane, dbg);
         if (sgi + 1 < nseg) {
             load_bfrag<T>(bfa, wpack, wp.pack(min(sgi + 2, nseg - 1)), wn, lane);
-            fs_walk<T>(wp, pc, pb, afn, acc, bfb, smem, lane, dbg);
+            fs_walk<T>(wp, sgi + 1, pb, afn, acc, bfb, smem, lane, dbg);
         }
     }
 }

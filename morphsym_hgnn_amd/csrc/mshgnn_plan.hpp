@@ -58,12 +58,11 @@ enum { BH_NGROUPS = 0, BH_NMLP, BH_W2, BH_W1, BH_KIND = 8, BH_MLPNODES = 8 + 128
 // finished reading the previous activations (which it then overwrites in place).
 constexpr int FS_HS = 10;                // accumulators per wave
 constexpr int FS_MAXN = 2 * FS_HS;       // nodes per window the fused kernels support
-constexpr int FPROG_LEN = 128;           // ints per wave program (two VGPRs): 64 pack ids + 256 byte entries
+constexpr int FPROG_LEN = 192;           // ints per wave program (three VGPRs)
 // per-layer header (same layout forward / backward), then two wave programs (one per half) of FPROG_LEN ints:
-//   ints [0, 64): pack id of segment s;  ints [64, 128): 256 byte entries, 4 per int, LSB first:
-//   [nseg, then the COUNT stream: per segment, per accumulator u (node 2u + half) its number of MACs, then the BLOCK
-//    stream: the source blocks of all MACs in execution order (+ one pad entry, so the kernel can always fetch the
-//    block after the current one and prefetch its fragment)]
+//   ints [0, 64): pack id of segment s;  ints [64, 128): MAC counts of segment s, 3 bits per accumulator u (node 2u + half);
+//   ints [128, 192): 256 byte entries, 4 per int, LSB first: [nseg, then the BLOCK stream: the source blocks of all MACs in
+//   execution order (+ one pad entry, so the kernel can always fetch the block after the current one and prefetch it)]
 enum { FH_NSEG = 0, FH_NMLP, FH_W1, FH_W2, FH_B1, FH_B2, FH_FLAGS, FH_MLP0,   // FH_MLP0: first node of the base_transform type
        FH_KIND = 8,                      // NK_* of node n in this layer
        FH_BIAS = 8 + FS_MAXN,            // fwd: bias row of node n
@@ -447,20 +446,25 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
     if (p.fused) {
         auto emit_fused = [&](const std::vector<Seg>& segs) {   // Seg.macs = (node, source block)
             for (int half = 0; half < 2 && p.fused; ++half) {
-                std::vector<int> w, blocks;    // byte entries
+                std::vector<int> w, blocks, counts;    // byte entries; packed per-segment counts
                 w.push_back((int)segs.size());
+                bool ok = segs.size() <= 64;
                 for (const Seg& sg : segs) {
+                    int cw = 0;
                     for (int u = 0; u < FS_HS; ++u) {
                         int c = 0;
                         for (auto& m : sg.macs) if (m.first == 2 * u + half) { blocks.push_back(m.second); ++c; }
-                        w.push_back(c);
+                        if (c > 7) ok = false;
+                        cw |= (c & 7) << (3 * u);
                     }
+                    counts.push_back(cw);
                 }
                 blocks.push_back(blocks.empty() ? 0 : blocks.back());
                 for (int b : blocks) w.push_back(b);
-                if (segs.size() > 64 || w.size() > 256) { p.fused = false; break; }
-                w.resize(256, 0);
+                if (!ok || w.size() > 256) { p.fused = false; break; }
+                w.resize(256, 0); counts.resize(64, 0);
                 for (int sgi = 0; sgi < 64; ++sgi) T.push_back(sgi < (int)segs.size() ? segs[sgi].pack : 0);
+                for (int sgi = 0; sgi < 64; ++sgi) T.push_back(counts[sgi]);
                 for (int i = 0; i < 64; ++i) T.push_back(w[4 * i] | (w[4 * i + 1] << 8) | (w[4 * i + 2] << 16) | (w[4 * i + 3] << 24));
             }
         };
