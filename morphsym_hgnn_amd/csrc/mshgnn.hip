@@ -1418,6 +1418,7 @@ struct GradwArgs {
     const int* items; const int* lanes; const int* lane_order; const uint8_t* signs; float* slabs; int B, n_lanes, n_parts, n_pad;
     int aligned;   // all raw-input rows 16-byte aligned with whole-chunk pitch
     int dbg;   // timing ablations (MSHGNN_DBG_GW): 1 no global loads, 2 no LDS staging, 4 no MFMA phase, 8 no slab store
+    long long* stamps;   // MSHGNN_STAMPS_GW: thread 0 of every workgroup accumulates clock64() deltas of the step phases
 };
 constexpr int GW_KW = 32;       // fp32: windows per staged chunk
 constexpr int GW_PITCH = 144;   // fp32: floats per LDS row (bank-conflict-free column reads)
@@ -1678,13 +1679,30 @@ __global__ __launch_bounds__(256, GW_WPS) void k_gradw_bf16(GradwArgs a) {
     // resident workgroup per CU
     Stage sa;
     if (nsteps > 0) fetch(sa, 0);
+#ifndef MSHGNN_GW_STAMPS
+#define MSHGNN_GW_STAMPS 0      // build with EXTRA=-DMSHGNN_GW_STAMPS=1 for tools/stamps_gradw.py (costs 6 VGPRs)
+#endif
+#if MSHGNN_GW_STAMPS
+    long long tph[5] = {0, 0, 0, 0, 0}, tprev = a.stamps ? clock64() : 0;
+    auto lap = [&](int k) { if (a.stamps) { const long long t = clock64(); tph[k] += t - tprev; tprev = t; } };
+#else
+    auto lap = [](int) {};
+#endif
     for (int s = 0; s < nsteps; ++s) {
         __syncthreads();
+        lap(0);      // waited for the previous MFMA phase of every wave
         stage_to_lds(sa, (nit == 2 && (s & 1)) ? qsign[1] : qsign[0], (nit == 2 && (s & 1)) ? qvalid[1] : qvalid[0], Pbuf[0], Qbuf[0]);
+        lap(1);      // global loads landed + LDS written
         __syncthreads();
+        lap(2);
         if (s + 1 < nsteps) fetch(sa, s + 1);
+        lap(3);      // next step's loads issued
         mfmas(Pbuf[0], Qbuf[0]);
+        lap(4);
     }
+#if MSHGNN_GW_STAMPS
+    if (a.stamps && tid == 0) { for (int k = 0; k < 5; ++k) a.stamps[(size_t)blockIdx.x * 8 + k] = tph[k]; a.stamps[(size_t)blockIdx.x * 8 + 5] = nsteps; }
+#endif
     (void)sx1; (void)qn1;
 #endif
     float* slab = a.slabs + (size_t)(part * a.n_lanes + ln) * SLAB_FLOATS;
@@ -2064,6 +2082,7 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
         if (gw_phase >= 0) { a.lane_order = p->d_tables + hp.order_ph_off[gw_phase]; a.n_pad = hp.npad_ph[gw_phase]; }
         a.signs = p->d_signs; a.slabs = reinterpret_cast<float*>(ws + lay.slabs); a.B = B; a.n_lanes = hp.n_lanes; a.n_parts = hp.n_parts;
         { const char* e = getenv("MSHGNN_DBG_GW"); a.dbg = e ? atoi(e) : 0; }
+        { const char* e = getenv("MSHGNN_STAMPS_GW"); a.stamps = e ? reinterpret_cast<long long*>((uintptr_t)strtoull(e, nullptr, 0)) : nullptr; }
         ProfScope ps(p, hp.ks_gradw, st);
         if (a.n_pad > 0) {
             if constexpr (sizeof(T) == 4) hipLaunchKernelGGL(k_gradw_f32, dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a);
