@@ -140,9 +140,13 @@ template <typename T> __device__ __forceinline__ f32x4 round_as(f32x4 v) {
 __device__ __forceinline__ size_t act_idx(int w, int node, int B) { return ((size_t)node * B + w) * H; }
 
 // LDS node-block addressing: block = ROWS rows x 128 elements; 16-byte chunk c of row r lives at chunk slot
-// c ^ (r & 15) (conflict-free ds_read_b128 for rows distinct mod 16 -- guide T2).
+// c ^ swz(r), swz(r) = (r & 15) ^ ((r & 4) << 1).  The plain c ^ (r & 15) of guide T2 is 2-way on the 16x16x32 operand
+// read (lane = row + 16 g reads chunk 4 g + t): ds_read_b128 is served in the lane groups {0-3,12-15,20-27}, ..., and rows
+// 0-3 of g collide with rows 4-7 of g + 1.  Folding row bit 2 into bit 3 makes those reads AND the 8-lane ds_write_b128
+// groups of the octet stores conflict-free (exhaustive check over the GF(2)-linear maps: tools/lds_swizzle_search.py).
+__device__ __forceinline__ int lds_swz(int row) { return (row & 15) ^ ((row & 4) << 1); }
 template <typename T> __device__ __forceinline__ int lds_chunk(int blk, int row, int c) {
-    return blk * Prec<T>::BLK + row * Prec<T>::RB + ((c ^ (row & 15)) << 4);
+    return blk * Prec<T>::BLK + row * Prec<T>::RB + ((c ^ lds_swz(row)) << 4);
 }
 template <typename T> __device__ __forceinline__ int lds_elem(int blk, int row, int col) {
     return lds_chunk<T>(blk, row, col / Prec<T>::EPC) + (col % Prec<T>::EPC) * (int)sizeof(T);
@@ -172,12 +176,34 @@ template <typename T> __device__ __forceinline__ void load_afrag(typename Prec<T
         a.v[t] = __builtin_bit_cast(typename Prec<T>::Vec, v);
     }
 }
+// The same read with this lane's NAV chunk offsets computed once per kernel (stack kernels): per MAC only the block base
+// is added, on address registers of their own, so each K-step's read can issue right behind the MFMAs that consumed it.
+template <typename T> struct AOff {
+    int o[Prec<T>::NAV];
+    __device__ __forceinline__ explicit AOff(int lane) {
+        const int row = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int t = 0; t < Prec<T>::NAV; ++t) o[t] = opaque(lds_chunk<T>(0, row, g * Prec<T>::NAV + t));
+    }
+};
+template <typename T> __device__ __forceinline__ void load_afrag(typename Prec<T>::AFrag& a, const char* smem, int blk, const AOff<T>& ao) {
+    const int base = blk * Prec<T>::BLK;
+#pragma unroll
+    for (int t = 0; t < Prec<T>::NAV; ++t) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(smem + base + ao.o[t]);
+        a.v[t] = __builtin_bit_cast(typename Prec<T>::Vec, v);
+    }
+}
 // B fragment: packed by k_prep so that vector (wave, v, lane) is one contiguous 16-byte load.
 template <typename T> __device__ __forceinline__ void load_bfrag(typename Prec<T>::BFrag& b, const T* wpack, int pack, int wv, int lane) {
     constexpr int NBV = Prec<T>::NBV;
     const u32x4* base = reinterpret_cast<const u32x4*>(wpack + (size_t)pack * H * H) + (size_t)wv * NBV * 64 + lane;
 #pragma unroll
+#ifdef MSHGNN_HALF_W
+    for (int v = 0; v < NBV / 2; ++v) {      // timing experiment: half the fragment bytes (wrong results)
+#else
     for (int v = 0; v < NBV; ++v) {
+#endif
         const u32x4 x = base[v * 64];
         b.v[v] = __builtin_bit_cast(typename Prec<T>::Vec, x);
     }
@@ -867,7 +893,16 @@ struct StackArgs {
     const float* y; float* dec_slabs; float inv_n;
     long long* stamps;   // timing experiments (MSHGNN_STAMPS): wave 0 of every workgroup records clock64() at phase boundaries
 };
+#ifdef MSHGNN_SEG_STAMPS
+constexpr int FS_EXTRA_BLK = 6;     // LDS room for the per-segment clocks
+#else
+constexpr int FS_EXTRA_BLK = 0;
+#endif
+#if defined(MSHGNN_FS_STAMPS) || defined(MSHGNN_SEG_STAMPS)
 #define FS_STAMP(k) do { if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 32 + (k)] = clock64(); } while (0)
+#else
+#define FS_STAMP(k) do { } while (0)     // the stamp stores are compiled out of the product build (they cost waits at phase boundaries)
+#endif
 
 // wave program in three VGPRs, fetched with v_readlane: pk = pack id of segment `lane`; pcnt = its MAC counts (3 bits per
 // accumulator); pb = 256 byte entries, 4 per lane (entry 0 = number of segments, then the block stream)
@@ -892,7 +927,7 @@ struct FHdr {
 // program's block stream in execution order, so the fragment of the NEXT MAC is read from LDS under this MAC's MFMAs
 template <typename T>
 __device__ __forceinline__ void fs_walk(const FProg& wp, int sgi, int& pb, typename Prec<T>::AFrag& afn, typename Prec<T>::Acc (&acc)[FS_HS],
-                                        const typename Prec<T>::BFrag& bf, const char* smem, int lane, int dbg = 0) {
+                                        const typename Prec<T>::BFrag& bf, const char* smem, const AOff<T>& lane, int dbg = 0) {
     const int cw = wp.counts(sgi);      // one readlane per segment: 3 bits of MAC count per accumulator
 #pragma unroll
     for (int u = 0; u < FS_HS; ++u) {
@@ -900,37 +935,71 @@ __device__ __forceinline__ void fs_walk(const FProg& wp, int sgi, int& pb, typen
         for (int k = 0; k < cnt; ++k) {
             // the MFMAs of this MAC read afn as they issue; the fragment of the NEXT MAC is then read from LDS into the same
             // registers and lands while those MFMAs execute (no second buffer, no register copies)
+#ifdef MSHGNN_ABLATE
             if (!(dbg & 128)) mac(acc[u], afn, bf);
             if (!(dbg & 256)) load_afrag<T>(afn, smem, wp.at(++pb), lane);
-            __builtin_amdgcn_sched_group_barrier(0x008, 2 * Prec<T>::NAV * (sizeof(T) == 4 ? 4 : 1), 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, Prec<T>::NAV, 0);
+#else
+            mac(acc[u], afn, bf);
+            load_afrag<T>(afn, smem, wp.at(++pb), lane);
+#endif
+            if constexpr (sizeof(T) == 4) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 8 * Prec<T>::NAV, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, Prec<T>::NAV, 0);
+            } else {
+                // K-step t's two MFMAs, then the read that refills x.v[t]: every read gets the rest of the MAC as cover
+#pragma unroll
+                for (int t = 0; t < Prec<T>::NAV; ++t) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            }
         }
     }
 }
 // all segments of a layer.  The next segment's weight fragment streams from L2 while the current one is multiplied
 // (two register buffers).
 template <typename T>
-__device__ __forceinline__ void fs_run(const FProg& wp, typename Prec<T>::Acc (&acc)[FS_HS], const char* smem, const T* wpack, int wn, int lane, int dbg = 0) {
+__device__ __forceinline__ void fs_run(const FProg& wp, typename Prec<T>::Acc (&acc)[FS_HS], const char* smem, const T* wpack, int wn, int lane, int dbg = 0,
+                                       long long* segclk = nullptr) {
     const int nseg = wp.at(0);
     int pb = 1;
     typename Prec<T>::BFrag bfa, bfb;
     typename Prec<T>::AFrag afn;
+    const AOff<T> ao(lane);
     // drain the previous epilogue's memory operations first: with loads AND stores pending the compiler must assume
     // out-of-order completion and waits vmcnt(0) before every MAC, which would expose each prefetch
     __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));
     if (nseg > 0) load_bfrag<T>(bfa, wpack, wp.pack(0), wn, lane);
-    load_afrag<T>(afn, smem, wp.at(pb), lane);
+    load_afrag<T>(afn, smem, wp.at(pb), ao);
     // a fragment load is ALWAYS in flight behind the one being multiplied (the last segment re-requests its own pack):
     // every path then has the same number of younger loads outstanding, so the compiler's in-order vmcnt waits inside
     // the MAC loops never have to drain the prefetch
+#ifdef MSHGNN_ABLATE
+    if (dbg & 512) {     // both register buffers filled once, no weight streaming inside the layer (timing only, wrong results)
+        load_bfrag<T>(bfb, wpack, wp.pack(0), wn, lane);
+        for (int sgi = 0; sgi < nseg; sgi += 2) {
+            fs_walk<T>(wp, sgi, pb, afn, acc, bfa, smem, ao, dbg);
+            if (sgi + 1 < nseg) fs_walk<T>(wp, sgi + 1, pb, afn, acc, bfb, smem, ao, dbg);
+        }
+        return;
+    }
+#endif
+#ifdef MSHGNN_SEG_STAMPS
+#define FS_SEGCLK(i) do { if (segclk && lane == 0) segclk[i] = clock64(); } while (0)
+#else
+#define FS_SEGCLK(i) do { } while (0)
+#endif
     for (int sgi = 0; sgi < nseg; sgi += 2) {
         load_bfrag<T>(bfb, wpack, wp.pack(min(sgi + 1, nseg - 1)), wn, lane);
-        fs_walk<T>(wp, sgi, pb, afn, acc, bfa, smem, lane, dbg);
+        FS_SEGCLK(sgi);
+        fs_walk<T>(wp, sgi, pb, afn, acc, bfa, smem, ao, dbg);
         if (sgi + 1 < nseg) {
             load_bfrag<T>(bfa, wpack, wp.pack(min(sgi + 2, nseg - 1)), wn, lane);
-            fs_walk<T>(wp, sgi + 1, pb, afn, acc, bfb, smem, lane, dbg);
+            FS_SEGCLK(sgi + 1);
+            fs_walk<T>(wp, sgi + 1, pb, afn, acc, bfb, smem, ao, dbg);
         }
     }
+    FS_SEGCLK(nseg);
 }
 
 template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_fwd(StackArgs a) {
@@ -943,6 +1012,9 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
     const int win = c_win(lane), w = w0 + win, col = wn * 32 + c_oct(lane);
     const bool w_ok = w < B, train = a.training != 0;
 
+    // experiment (MSHGNN_DBG >> 16): stagger the first round of workgroups within an XCD so that the CUs of one L2 are not all in
+    // their weight-streaming phase at the same time
+    { const int sg = a.dbg >> 16; if (sg && blockIdx.x < 256) { const int n = ((blockIdx.x >> 3) & 31) * sg; for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1); } }
     FS_STAMP(0);
     stage_nodes<T>(smem, reinterpret_cast<const T*>(a.tile_in), NN, w0, B, tid);
     __syncthreads();
@@ -967,7 +1039,13 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
             else acc_fill(acc[u], 0.f);
         }
         FS_STAMP(2 + 4 * l);
+#ifdef MSHGNN_SEG_STAMPS
+        // per-wave clock at every segment start of every layer: [layer][wave][16] in LDS behind the node blocks, dumped at the end
+        long long* segclk = a.stamps ? reinterpret_cast<long long*>(smem + (NN + 4) * P::BLK) + (l * 8 + wv) * 16 : nullptr;
+        fs_run<T>(wp, acc, smem, wpack, wn, lane, a.dbg, segclk);
+#else
         if (!(a.dbg & 2)) fs_run<T>(wp, acc, smem, wpack, wn, lane, a.dbg);
+#endif
         FS_STAMP(3 + 4 * l);
         __syncthreads();   // every wave is done reading X_l: the node blocks may be overwritten
         FS_STAMP(4 + 4 * l);
@@ -1139,6 +1217,13 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
         }
     }
     FS_STAMP(30);
+#ifdef MSHGNN_SEG_STAMPS
+    if (a.stamps) {
+        __syncthreads();
+        const long long* sc = reinterpret_cast<const long long*>(smem + (NN + 4) * P::BLK);
+        if (tid < 3 * 8 * 16) a.stamps[(size_t)gridDim.x * 32 + (size_t)blockIdx.x * 384 + tid] = sc[tid];
+    }
+#endif
 }
 
 template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_bwd(StackArgs a) {
@@ -1150,6 +1235,9 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
     const T* wpack = reinterpret_cast<const T*>(a.wpack);
     const int win = c_win(lane), w = w0 + win, col = wn * 32 + c_oct(lane), g8 = (lane >> 4) << 3;
     const bool w_ok = w < B;
+    // experiment (MSHGNN_DBG >> 16): stagger the first round of workgroups within an XCD so that the CUs of one L2 are not all in
+    // their weight-streaming phase at the same time
+    { const int sg = a.dbg >> 16; if (sg && blockIdx.x < 256) { const int n = ((blockIdx.x >> 3) & 31) * sg; for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1); } }
 
     // dX_L tile: only the nodes that are live in the last layer carry a gradient
     {
@@ -1866,7 +1954,7 @@ extern "C" int mshgnn_plan_create(const mshgnn_desc* desc, mshgnn_plan** out) {
         const char* e = getenv("MSHGNN_FUSED");
         p->use_fused = hp.fused && !(e && atoi(e) == 0);
         if (p->use_fused) {
-            const int flds = hp.fs_blk * Prec<__bf16>::BLK;
+            const int flds = (hp.fs_blk + FS_EXTRA_BLK) * Prec<__bf16>::BLK;
             if ((rc = set_lds_attr(k_stack_fwd<__bf16>, flds)) || (rc = set_lds_attr(k_stack_bwd<__bf16>, flds))) { mshgnn_plan_destroy(p); return rc; }
         }
     }
@@ -1990,7 +2078,7 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
             }
             { const char* e = getenv("MSHGNN_STAMPS"); a.stamps = e ? reinterpret_cast<long long*>((uintptr_t)strtoull(e, nullptr, 0)) : nullptr; }
             ProfScope ps(p, hp.ks_stack_fwd, st);
-            hipLaunchKernelGGL(k_stack_fwd<T>, dim3(tiles), dim3(LAYER_THREADS), hp.fs_blk * Prec<T>::BLK, st, a);
+            hipLaunchKernelGGL(k_stack_fwd<T>, dim3(tiles), dim3(LAYER_THREADS), (hp.fs_blk + FS_EXTRA_BLK) * Prec<T>::BLK, st, a);
             HIPCHK(hipGetLastError());
             return MSHGNN_OK;
         }
@@ -2052,7 +2140,7 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
             a.wpack = ws + lay.wpack; a.bias = reinterpret_cast<const float*>(ws + lay.bias); a.tables = p->d_tables;
             a.B = B; a.NN = hp.NN; a.L = hp.L; a.training = 1;
             ProfScope ps(p, hp.ks_stack_bwd, st);
-            hipLaunchKernelGGL(k_stack_bwd<T>, dim3(tiles), dim3(LAYER_THREADS), hp.fs_blk * Prec<T>::BLK, st, a);
+            hipLaunchKernelGGL(k_stack_bwd<T>, dim3(tiles), dim3(LAYER_THREADS), (hp.fs_blk + FS_EXTRA_BLK) * Prec<T>::BLK, st, a);
             fused_done = true;
         }
     }
