@@ -105,7 +105,7 @@ typedef struct mshgnn_ws_layout {
     size_t dx[17];      /* dX_l     [B][NN][h]  l = 0..L   (dtype)                                                  */
     size_t dh[16];      /* dH_l     [B][NN][h]  l = 0..L-1 (dtype)      gradient w.r.t. the HeteroConv output       */
     size_t dd[16];      /* reserved (always 0)                                                                     */
-    size_t mask[16];    /* relu bits [B][NN][4] uint32                                                             */
+    size_t mask[16];    /* relu bits, one byte per (node, window, 8 features): [NN][4][ceil(B/16)][4][16] uint8          */
     size_t hb[16], t1[16], du[16];  /* base_transform stash [B][n_mlp][h] (dtype)                                   */
     size_t wpack;       /* packed weights                                                                          */
     size_t bias;        /* packed biases (fp32)                                                                    */

@@ -127,6 +127,21 @@ __device__ __forceinline__ void store_oct(__bf16* p, f32x4 lo, f32x4 hi) {
     for (int j = 0; j < 4; ++j) { u.e[j] = (__bf16)lo[j]; u.e[4 + j] = (__bf16)hi[j]; }
     *reinterpret_cast<u32x4*>(p) = u.r;
 }
+__device__ __forceinline__ u32x4 pack_oct(f32x4 lo, f32x4 hi) {      // the 16 bytes store_oct(__bf16*) writes
+    union { u32x4 r; __bf16 e[8]; } u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { u.e[j] = (__bf16)lo[j]; u.e[4 + j] = (__bf16)hi[j]; }
+    return u.r;
+}
+// sum over the 16 lanes of a DPP row, result in every lane: rotations by 8, 4, 2, 1 pair the same lanes as the xor butterfly
+// (bit-identical sums) without the LDS round trips of ds_bpermute
+template <int N> __device__ __forceinline__ float dpp_ror(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 + N, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_sum(float x) {
+    x += dpp_ror<8>(x); x += dpp_ror<4>(x); x += dpp_ror<2>(x); x += dpp_ror<1>(x);
+    return x;
+}
 __device__ __forceinline__ f32x4 relu4(f32x4 v) { return f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)}; }
 // value as it will read back after being stored as T (so LDS/global copies and the register copy agree)
 template <typename T> __device__ __forceinline__ f32x4 round_as(f32x4 v) {
@@ -475,21 +490,38 @@ struct LayerArgs {
                            // backward: 16 no stage-1 loads/stores, 32 no base_transform chain, 64 no stage-2 epilogues
 };
 
-// relu bits of one accumulator -> word (n, wn, w) of maskbits[NN][4][B] (bit i <-> feature 32 wn + i; a wave's 16
-// windows are 64 contiguous bytes).  Each lane owns 8 bits (features 8 g + 4 fb + j) of its window; the 4 lanes of a
-// window are OR-combined with two cross-lane shuffles.
+// relu bits: one byte per (node, window, 8-feature group) -- exactly the 8 accumulator elements one lane of the layer / stack
+// kernels owns, so the writer needs no cross-lane exchange: bytes [NN][4 column slices][ceil(B/16) tiles][4 groups][16 windows]
+// (a wave's store is 64 contiguous bytes).  Bit j of the byte of (n, w, f0) <-> feature f0 + j, f0 a multiple of 8.
+__device__ __forceinline__ size_t relu_byte(int n, int B, int w, int f) {
+    return ((((size_t)n * 4 + (f >> 5)) * ((B + 15) >> 4) + (w >> 4)) << 6) + (((f >> 3) & 3) << 4) + (w & 15);
+}
+// relu of one accumulator in place + its 8 relu bits, on the integer pipe: for a float x (no NaNs), max_i32(bits(x), 0) is
+// relu(x) (negative floats and -0 are negative integers), and y > 0 <=> y + 0x7fffffff has its top bit set; v_alignbit
+// shifts that bit into the byte.  2 + 1 instructions per element, no compares / VCC hazards.
+template <typename T>
+__device__ __forceinline__ unsigned relu_with_bits(typename Prec<T>::Acc& acc) {
+    unsigned bits = 0;
+#pragma unroll
+    for (int fb = 1; fb >= 0; --fb)
+#pragma unroll
+        for (int j = 3; j >= 0; --j) {
+            const float xf = acc.c[fb][j];      // (hipcc 7.2 miscompiles __builtin_bit_cast applied directly to a vector element)
+            const int y = max(__float_as_int(xf), 0);
+            acc.c[fb][j] = __int_as_float(y);
+            bits = __builtin_amdgcn_alignbit(bits, (unsigned)y + 0x7fffffffu, 31);
+        }
+    return bits;
+}
 template <typename T>
 __device__ __forceinline__ void store_relu_bits(const typename Prec<T>::Acc& acc, unsigned* maskbits, int NN, int n, int w0, int B, int wn, int lane) {
-    const int g = lane >> 4;
     unsigned bits = 0;
 #pragma unroll
     for (int fb = 0; fb < 2; ++fb)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bits |= (acc.c[fb][j] > 0.f ? 1u : 0u) << (8 * g + 4 * fb + j);
-    bits |= (unsigned)__shfl_xor((int)bits, 16, 64);
-    bits |= (unsigned)__shfl_xor((int)bits, 32, 64);
-    const int w = w0 + c_win(lane);
-    if (g == 0 && w < B) maskbits[((size_t)n * 4 + wn) * B + w] = bits;
+        for (int j = 0; j < 4; ++j) bits |= (acc.c[fb][j] > 0.f ? 1u : 0u) << (4 * fb + j);
+    // rows past the batch inside the last tile land in the buffer's padding (it is sized for whole tiles)
+    reinterpret_cast<uint8_t*>(maskbits)[relu_byte(n, B, w0 + c_win(lane), wn * 32 + c_oct(lane))] = (uint8_t)bits;
 }
 
 // elementwise helpers on one 16-byte chunk of T
@@ -727,7 +759,7 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, Prec<T>::WPS) 
                 v[i] = u32x4{0, 0, 0, 0}; word[i] = 0;
                 if (nk[i] != NK_DEAD && wr < B && !(a.dbg & 16)) {
                     v[i] = *reinterpret_cast<const u32x4*>(gtop + act_idx(wr, n, B) + c * EPC);
-                    if (nk[i] == NK_RELU) word[i] = a.maskbits[((size_t)n * 4 + (c * EPC) / 32) * B + wr];
+                    if (nk[i] == NK_RELU) word[i] = reinterpret_cast<const uint8_t*>(a.maskbits)[relu_byte(n, B, wr, c * EPC)];
                 }
             }
 #pragma unroll
@@ -735,7 +767,7 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, Prec<T>::WPS) 
                 const int n = nb + i * NPB;
                 if (nk[i] == NK_DEAD) continue;
                 if (nk[i] == NK_RELU) {
-                    v[i] = chunk_mask_bits<T>(v[i], word[i] >> ((c * EPC) % 32));   // dH (k_gradw recomputes it the same way)
+                    v[i] = chunk_mask_bits<T>(v[i], word[i] >> ((c * EPC) % 8));   // dH (k_gradw recomputes it the same way)
                 }
                 *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(n, row, c)) = v[i];
             }
@@ -1051,19 +1083,23 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
         FS_STAMP(4 + 4 * l);
         if (a.dbg & 8) continue;
 
+        u32x4 hpk[2] = {}, tpk[2] = {};
         if (nmlp > 0 && !(a.dbg & 64)) {
-            // base_transform: Y = W2 relu(W1 H + b1) + b2 on the first nmlp nodes (hgnn_c2.py:117-121,156); scratch blocks NN + i
-            T* hb = reinterpret_cast<T*>(a.ws + a.hb_off[l]);
-            T* t1 = reinterpret_cast<T*>(a.ws + a.t1_off[l]);
-            typename P::BFrag bf;
+            // base_transform: Y = W2 relu(W1 H + b1) + b2 on the first nmlp nodes (hgnn_c2.py:117-121,156); scratch blocks NN + i.
+            // The H and T1 stashes are kept packed in registers and stored after the chain: a load waited for while stores are in
+            // flight costs a full drain of those stores.
+            static_assert(sizeof(T) == 2, "fused stack kernels are bf16");
+            typename P::BFrag bf, bf2;
             typename P::AFrag af;
             load_bfrag<T>(bf, wpack, fh[FH_W1], wn, lane);
+            load_bfrag<T>(bf2, wpack, fh[FH_W2], wn, lane);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int n = 2 * u + wh;
                 if (n < nmlp) {
-                    lds_store_oct<T>(smem, NN + n, win, col, acc[u].c[0], acc[u].c[1]);
-                    if (train && w_ok) store_oct(hb + act_idx(w, n, B) + col, acc[u].c[0], acc[u].c[1]);
+                    hpk[u] = pack_oct(acc[u].c[0], acc[u].c[1]);
+                    *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(NN + n, win, col / P::EPC)) = hpk[u];
+                    acc_init_bias<T>(acc[u], a.bias + (size_t)fh[FH_B1] * H, wn, lane);
                 }
             }
             __syncthreads();
@@ -1071,20 +1107,18 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
             for (int u = 0; u < 2; ++u) {
                 const int n = 2 * u + wh;
                 if (n < nmlp) {
-                    acc_init_bias<T>(acc[u], a.bias + (size_t)fh[FH_B1] * H, wn, lane);
                     load_afrag<T>(af, smem, NN + n, lane);
                     mac(acc[u], af, bf);
                 }
             }
-            load_bfrag<T>(bf, wpack, fh[FH_W2], wn, lane);
             __syncthreads();   // all reads of H done before T1 overwrites the scratch blocks
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int n = 2 * u + wh;
                 if (n < nmlp) {
-                    const f32x4 t0 = relu4(acc[u].c[0]), t1v = relu4(acc[u].c[1]);
-                    lds_store_oct<T>(smem, NN + n, win, col, t0, t1v);
-                    if (train && w_ok) store_oct(t1 + act_idx(w, n, B) + col, t0, t1v);
+                    tpk[u] = pack_oct(relu4(acc[u].c[0]), relu4(acc[u].c[1]));
+                    *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(NN + n, win, col / P::EPC)) = tpk[u];
+                    acc_init_bias<T>(acc[u], a.bias + (size_t)fh[FH_B2] * H, wn, lane);
                 }
             }
             __syncthreads();
@@ -1092,9 +1126,24 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
             for (int u = 0; u < 2; ++u) {
                 const int n = 2 * u + wh;
                 if (n < nmlp) {
-                    acc_init_bias<T>(acc[u], a.bias + (size_t)fh[FH_B2] * H, wn, lane);
                     load_afrag<T>(af, smem, NN + n, lane);
-                    mac(acc[u], af, bf);
+                    mac(acc[u], af, bf2);
+                }
+            }
+        }
+        FS_STAMP(16 + l);
+        // every load issued so far (chain operands, the next layer's header and program) has landed before the first store of
+        // the epilogue goes out: from here to the next layer's first weight fragment nothing waits on a load
+        __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));
+        if (nmlp > 0 && train && w_ok) {
+            T* hb = reinterpret_cast<T*>(a.ws + a.hb_off[l]);
+            T* t1 = reinterpret_cast<T*>(a.ws + a.t1_off[l]);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int n = 2 * u + wh;
+                if (n < nmlp) {
+                    *reinterpret_cast<u32x4*>(hb + act_idx(w, n, B) + col) = hpk[u];
+                    *reinterpret_cast<u32x4*>(t1 + act_idx(w, n, B) + col) = tpk[u];
                 }
             }
         }
@@ -1118,8 +1167,9 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
                 if (kind != NK_DEAD) {
                     f32x4 y0 = acc[u].c[0], y1 = acc[u].c[1];
                     if (kind == NK_RELU) {
-                        if (train && !(a.dbg & 32)) store_relu_bits<T>(acc[u], maskbits, NN, n, w0, B, wn, lane);
-                        y0 = relu4(y0); y1 = relu4(y1);
+                        const unsigned bits = relu_with_bits<T>(acc[u]);
+                        if (train) reinterpret_cast<uint8_t*>(maskbits)[relu_byte(n, B, w, col)] = (uint8_t)bits;
+                        y0 = acc[u].c[0]; y1 = acc[u].c[1];
                     }
                     if (flags & FF_RESIDUAL) {
                         const u32x4 r = resv[u];
@@ -1152,36 +1202,73 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
 #pragma unroll
                 for (int e = 0; e < 8; ++e) accw[dd][e] = 0.f; }
         }
-        for (int f = tid >> 8; f < a.n_out; f += LAYER_THREADS / 256) {
-            f32x4 x0, x1;
-            lds_load_oct<T>(smem, a.node0 + f, row, c * 8, x0, x1);
-            const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-            float dx[8];
+        // two nodes per pass, every global load of a pass before its first store: a load waited for while stores are in flight
+        // costs a full vmcnt(0) drain (loads and stores retire out of order with respect to each other)
+        // (unconditional loads with clamped indices, so that they are issued back to back and waited for once)
+        float Wv[8][8], bv[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) dx[e] = 0.f;
-            const bool ok = w0 + row < B;
-            const size_t r = (size_t)(w0 + row) * a.n_out + f;
+        for (int dd = 0; dd < 8; ++dd) {
+            const int dc = min(dd, a.dout - 1);
+            const f32x4 wa = *reinterpret_cast<const f32x4*>(W + dc * H + c * 8), wb = *reinterpret_cast<const f32x4*>(W + dc * H + c * 8 + 4);
+            Wv[dd][0] = wa[0]; Wv[dd][1] = wa[1]; Wv[dd][2] = wa[2]; Wv[dd][3] = wa[3];
+            Wv[dd][4] = wb[0]; Wv[dd][5] = wb[1]; Wv[dd][6] = wb[2]; Wv[dd][7] = wb[3];
+            bv[dd] = a.params[a.off_dec_b + dc];
+        }
+        for (int f0 = tid >> 8; f0 < a.n_out; f0 += 2 * (LAYER_THREADS / 256)) {
+            float ov[2][8], dxv[2][8], mk[2][8], yv[2][8];
 #pragma unroll
-            for (int dd = 0; dd < 8; ++dd) {
-                if (dd < a.dout) {
-                    float sum = 0.f;
+            for (int i = 0; i < 2; ++i) {
+                const int f = min(f0 + i * (LAYER_THREADS / 256), a.n_out - 1);
+                const size_t r = (size_t)min(w0 + row, B - 1) * a.n_out + f;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) sum += x[e] * W[dd * H + c * 8 + e];
+                for (int dd = 0; dd < 8; ++dd) {
+                    const int dc = min(dd, a.dout - 1);
+                    mk[i][dd] = a.out_mask[f * a.dout + dc];
+                    yv[i][dd] = fuse ? a.y[r * a.dout + dc] : 0.f;
+                }
+            }
 #pragma unroll
-                    for (int m = 8; m >= 1; m >>= 1) sum += __shfl_xor(sum, m, 64);
-                    const float o = (sum + a.params[a.off_dec_b + dd]) * a.out_mask[f * a.dout + dd];
-                    if (c == 0 && ok) a.out[r * a.dout + dd] = o;
-                    if (fuse && ok) {
-                        const float dlt = o - a.y[r * a.dout + dd];
-                        const float g = 2.0f * dlt * a.inv_n * a.out_mask[f * a.dout + dd];
-                        if (c == 0) lsum += dlt * dlt;
-                        accb[dd] += g;
+            for (int i = 0; i < 2; ++i) {
+                const int f = f0 + i * (LAYER_THREADS / 256);
+                const bool live = f < a.n_out;
+                f32x4 x0, x1;
+                lds_load_oct<T>(smem, a.node0 + (live ? f : f0), row, c * 8, x0, x1);
+                const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) { accw[dd][e] += g * x[e]; dx[e] += g * W[dd * H + c * 8 + e]; }
+                for (int e = 0; e < 8; ++e) dxv[i][e] = 0.f;
+                const bool ok = live && w0 + row < B;
+#pragma unroll
+                for (int dd = 0; dd < 8; ++dd) {
+                    ov[i][dd] = 0.f;
+                    if (dd < a.dout && live) {
+                        float sum = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) sum += x[e] * Wv[dd][e];
+                        sum = row16_sum(sum);
+                        const float o = (sum + bv[dd]) * mk[i][dd];
+                        ov[i][dd] = o;
+                        if (fuse && ok) {
+                            const float dlt = o - yv[i][dd];
+                            const float g = 2.0f * dlt * a.inv_n * mk[i][dd];
+                            if (c == 0) lsum += dlt * dlt;
+                            accb[dd] += g;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) { accw[dd][e] += g * x[e]; dxv[i][e] += g * Wv[dd][e]; }
+                        }
                     }
                 }
             }
-            if (fuse && ok) store8<T>(dxl + act_idx(w0 + row, a.node0 + f, B) + c * 8, dx);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int f = f0 + i * (LAYER_THREADS / 256);
+                const bool ok = f < a.n_out && w0 + row < B;
+                const size_t r = (size_t)(w0 + row) * a.n_out + f;
+                if (c == 0 && ok) {
+#pragma unroll
+                    for (int dd = 0; dd < 8; ++dd) if (dd < a.dout) a.out[r * a.dout + dd] = ov[i][dd];
+                }
+                if (fuse && ok) store8<T>(dxl + act_idx(w0 + row, a.node0 + f, B) + c * 8, dxv[i]);
+            }
         }
         if (fuse) {
             // reduce over the 4 rows of the wave (lanes 16 apart), then over the 8 waves through LDS (the X tile is dead after the barrier)
@@ -1276,7 +1363,7 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
                 const int n = 2 * u + wh;
                 kindv[u] = n < NN ? bh[FH_KIND + n] : NK_DEAD;
                 mword[u] = 0u; rawv[u] = u32x4{0, 0, 0, 0};
-                if (kindv[u] == NK_RELU && w_ok) mword[u] = maskbits[((size_t)n * 4 + wn) * B + w];
+                if (kindv[u] == NK_RELU && w_ok) mword[u] = reinterpret_cast<const uint8_t*>(maskbits)[relu_byte(n, B, w, wn * 32 + g8)];
                 if (kindv[u] != NK_DEAD) rawv[u] = *reinterpret_cast<const u32x4*>(smem + lds_chunk<T>(n, win, col / P::EPC));
             }
 #pragma unroll
@@ -1292,7 +1379,7 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
                                             __builtin_bit_cast(float, raw[3] << 16), __builtin_bit_cast(float, raw[3] & 0xffff0000u)};
                     }
                     if (kindv[u] == NK_RELU)
-                        *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(n, win, col / P::EPC)) = chunk_mask_bits<T>(raw, mword[u] >> g8);
+                        *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(n, win, col / P::EPC)) = chunk_mask_bits<T>(raw, mword[u]);
                 }
             }
         }
@@ -1546,8 +1633,8 @@ __global__ __launch_bounds__(256) void k_gradw_f32(GradwArgs a) {
                 if (w < a.B) {
                     pv[p] = *reinterpret_cast<const f32x4*>(pb + act_idx(w, po, a.B) + c * 4);
                     if (im[9] >= 0) {   // P = dX_{l+1} . relu bits
-                        const unsigned word = reinterpret_cast<const unsigned*>(a.ws + a.buf_off[im[9]])[((size_t)po * 4 + c / 8) * a.B + w];
-                        pv[p] = __builtin_bit_cast(f32x4, chunk_mask_bits<float>(__builtin_bit_cast(u32x4, pv[p]), word >> ((c * 4) % 32)));
+                        const unsigned word = reinterpret_cast<const uint8_t*>(a.ws + a.buf_off[im[9]])[relu_byte(po, a.B, w, c * 4)];
+                        pv[p] = __builtin_bit_cast(f32x4, chunk_mask_bits<float>(__builtin_bit_cast(u32x4, pv[p]), word >> ((c * 4) % 8)));
                     }
                     if (qs >= 0) {
                         qv[p] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const T*>(a.ws + a.buf_off[qbuf]) + act_idx(w, qo, a.B) + c * 4);
@@ -1654,12 +1741,12 @@ __global__ __launch_bounds__(256, GW_WPS) void k_gradw_bf16(GradwArgs a) {
     // the lane's (<= GW_IPL = 2) items are resolved ONCE into per-thread base pointers: no dependent scalar loads
     // inside the streaming loop
     const T* pbase[GW_IPL]; const T* qbase[GW_IPL]; int64_t qstride[GW_IPL]; int qvalid[GW_IPL], qvb[GW_IPL]; u32x4 qsign[GW_IPL];
-    const unsigned* mbase[GW_IPL];   // relu-bit words of the P rows (nullptr: P is used as stored)
+    const uint8_t* mbase[GW_IPL];    // relu-bit bytes of the P rows, at window 0 (nullptr: P is used as stored)
 #pragma unroll
     for (int i = 0; i < GW_IPL; ++i) {
         const int* im = a.items + (it0 + min(i, nit - 1)) * ITEM_INTS;
         pbase[i] = reinterpret_cast<const T*>(a.ws + a.buf_off[im[0]]) + act_idx(0, im[2], a.B) + c * 8;
-        mbase[i] = im[9] >= 0 ? reinterpret_cast<const unsigned*>(a.ws + a.buf_off[im[9]]) + ((size_t)im[2] * 4 + c / 4) * a.B : nullptr;
+        mbase[i] = im[9] >= 0 ? reinterpret_cast<const uint8_t*>(a.ws + a.buf_off[im[9]]) + relu_byte(im[2], a.B, 0, c * 8) : nullptr;
         qsign[i] = u32x4{0, 0, 0, 0};
         if (im[4] >= 0) {
             qbase[i] = reinterpret_cast<const T*>(a.ws + a.buf_off[im[3]]) + act_idx(0, im[5], a.B) + c * 8;
@@ -1688,7 +1775,7 @@ __global__ __launch_bounds__(256, GW_WPS) void k_gradw_bf16(GradwArgs a) {
         const int it = (nit == 2) ? (s & 1) : 0;
         const T* pb = it ? pbase[1] : pbase[0];
         const T* qb = it ? qbase[1] : qbase[0];
-        const unsigned* mb = it ? mbase[1] : mbase[0];
+        const uint8_t* mb = it ? mbase[1] : mbase[0];
         const int64_t qs = it ? qstride[1] : qstride[0];
         const int qn = it ? qvalid[1] : qvalid[0], vb = it ? qvb[1] : qvb[0];
 #pragma unroll
@@ -1697,7 +1784,7 @@ __global__ __launch_bounds__(256, GW_WPS) void k_gradw_bf16(GradwArgs a) {
             st.pv[p] = u32x4{0, 0, 0, 0}; st.qv[p] = u32x4{0, 0, 0, 0}; st.mw[p] = 0xffffffffu;
             if (w < a.B && !(a.dbg & 1)) {
                 st.pv[p] = *reinterpret_cast<const u32x4*>(pb + (size_t)w * H);
-                if (mb) st.mw[p] = mb[w];
+                if (mb) st.mw[p] = mb[((size_t)(w >> 4) << 6) + (w & 15)];
                 if (a.aligned) { if (qn > 0) st.qv[p] = *reinterpret_cast<const u32x4*>(qb + (size_t)w * qs); }   // raw: a use here would serialise the loads
                 else st.qv[p] = load_chunk<T>(qb + (size_t)w * qs, qn, vb);
             }
@@ -1708,7 +1795,7 @@ __global__ __launch_bounds__(256, GW_WPS) void k_gradw_bf16(GradwArgs a) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int row = r0 + 16 * p;
-            const u32x4 pm = chunk_mask_bits<T>(st.pv[p], st.mw[p] >> ((c * 8) % 32));   // dH = dX . relu bits (all-ones when P is stored as is)
+            const u32x4 pm = chunk_mask_bits<T>(st.pv[p], st.mw[p]);   // dH = dX . relu bits (all-ones when P is stored as is)
             *reinterpret_cast<u32x4*>(&Ps[row * GWB_PITCH + c * 8]) = pm;
             *reinterpret_cast<u32x4*>(&Qs[row * GWB_PITCH + c * 8]) = chunk_keep_first<T>(st.qv[p], qn) ^ sx;   // drop pad columns, symmetry sign mask of encoder inputs
             if (bias_flag) {

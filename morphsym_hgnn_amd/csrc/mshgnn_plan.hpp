@@ -812,7 +812,7 @@ inline void layout_workspace(const HostPlan& p, int64_t B, int training, mshgnn_
     const size_t act = (size_t)B * p.NN * H * p.esize, mlp = (size_t)B * std::max(1, p.n_mlp) * H * p.esize;
     auto take = [&](size_t bytes) { size_t r = off; off = align_up(off + bytes, 256); return r; };
     for (int l = 0; l <= p.L; ++l) o->x[l] = take(act);
-    for (int l = 0; l < p.L; ++l) { o->mask[l] = take((size_t)B * p.NN * 4 * 4); o->hb[l] = take(mlp); o->t1[l] = take(mlp); }
+    for (int l = 0; l < p.L; ++l) { o->mask[l] = take((size_t)((B + 15) / 16 * 16) * p.NN * 4 * 4); o->hb[l] = take(mlp); o->t1[l] = take(mlp); }
     if (training) {
         for (int l = 0; l <= p.L; ++l) o->dx[l] = take(act);
         for (int l = 0; l < p.L; ++l) { o->dh[l] = take(act); o->du[l] = take(mlp); }

@@ -19,11 +19,15 @@ t0 = s[:, 0].min()
 names = {0: "start", 1: "tile staged", 30: "end"}
 for l in range(3):
     names.update({2 + 4 * l: f"L{l} MAC start", 3 + 4 * l: f"L{l} MAC end", 4 + 4 * l: f"L{l} barrier", 5 + 4 * l: f"L{l} epilogue end"})
+order = [0, 1]
+for l in range(3): order += [2 + 4 * l, 3 + 4 * l, 4 + 4 * l, 16 + l, 5 + 4 * l]
+order.append(30)
+for l in range(3): names[16 + l] = f"L{l} base MLP end"
 first = np.argsort(s[:, 0])[:256]; second = np.argsort(s[:, 0])[256:]
 for grp, idx in (("first round", first), ("second round", second)):
     print(grp, "start offsets (cycles) min/median/max:", *(int(v) for v in np.percentile(s[idx, 0] - t0, [0, 50, 100])))
     prev = 0
-    for k in sorted(names):
+    for k in order:
         d = np.median(s[idx, k] - s[idx, prev]) if k else 0
         print(f"  {names[k]:18s} +{d:9.0f} cycles (median)   since start {np.median(s[idx, k] - s[idx, 0]):9.0f}")
         prev = k
