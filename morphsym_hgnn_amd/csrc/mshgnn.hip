@@ -1326,6 +1326,7 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
     // their weight-streaming phase at the same time
     { const int sg = a.dbg >> 16; if (sg && blockIdx.x < 256) { const int n = ((blockIdx.x >> 3) & 31) * sg; for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1); } }
 
+    FS_STAMP(0);
     // dX_L tile: only the nodes that are live in the last layer carry a gradient
     {
         const FHdr bh(a.tables + a.prog_off[a.L - 1], lane);
@@ -1339,6 +1340,7 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
         }
     }
     __syncthreads();
+    FS_STAMP(1);
 
     typename P::Acc acc[FS_HS];
     FHdr bhn(a.tables + a.prog_off[a.L - 1], lane);
@@ -1384,6 +1386,7 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
             }
         }
         __syncthreads();
+        FS_STAMP(2 + 5 * (a.L - 1 - l));
 
         if (nmlp > 0) {
             // dT1 = dY W2 ; dU = dT1 . (T1 > 0) ; dH = dU W1     (backward of base_transform, in place on nodes 0..nmlp-1)
@@ -1442,8 +1445,11 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
         }
 
         // phase 2: dX_l[j] = (residual) + dH_j W_rootsum + sum_r sum_{j->i} dH_i W_rel^r
+        FS_STAMP(3 + 5 * (a.L - 1 - l));
         fs_run<T>(wp, acc, smem, wpack, wn, lane);
+        FS_STAMP(4 + 5 * (a.L - 1 - l));
         __syncthreads();   // every wave is done reading dH_l
+        FS_STAMP(5 + 5 * (a.L - 1 - l));
 
         T* dxo = reinterpret_cast<T*>(a.ws + a.dx_off[l]);
         const T* xact = reinterpret_cast<const T*>(a.ws + a.x_off[0]);
@@ -1463,6 +1469,7 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
             }
         }
         __syncthreads();
+        FS_STAMP(6 + 5 * (a.L - 1 - l));
     }
 }
 
@@ -2226,6 +2233,8 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
             for (int l = 0; l < hp.L; ++l) { a.mask_off[l] = lay.mask[l]; a.t1_off[l] = lay.t1[l]; a.dh_off[l] = lay.dh[l]; a.du_off[l] = lay.du[l]; a.prog_off[l] = hp.fs_bwd_off[l]; }
             a.wpack = ws + lay.wpack; a.bias = reinterpret_cast<const float*>(ws + lay.bias); a.tables = p->d_tables;
             a.B = B; a.NN = hp.NN; a.L = hp.L; a.training = 1;
+            { const char* e = getenv("MSHGNN_DBG"); a.dbg = e ? atoi(e) : 0; }
+            { const char* e = getenv("MSHGNN_STAMPS_BWD"); a.stamps = e ? reinterpret_cast<long long*>((uintptr_t)strtoull(e, nullptr, 0)) : nullptr; }
             ProfScope ps(p, hp.ks_stack_bwd, st);
             hipLaunchKernelGGL(k_stack_bwd<T>, dim3(tiles), dim3(LAYER_THREADS), (hp.fs_blk + FS_EXTRA_BLK) * Prec<T>::BLK, st, a);
             fused_done = true;
