@@ -499,6 +499,14 @@ __device__ __forceinline__ size_t relu_byte(int n, int B, int w, int f) {
 // relu of one accumulator in place + its 8 relu bits, on the integer pipe: for a float x (no NaNs), max_i32(bits(x), 0) is
 // relu(x) (negative floats and -0 are negative integers), and y > 0 <=> y + 0x7fffffff has its top bit set; v_alignbit
 // shifts that bit into the byte.  2 + 1 instructions per element, no compares / VCC hazards.
+// base of the 64 relu bytes of (node n, column slice wn) in tile `tile`; the byte of lane (g, w & 15) is at + lane
+__device__ __forceinline__ size_t relu_tile_base(int n, int B, int tile, int wn) { return (((size_t)n * 4 + wn) * ((B + 15) >> 4) + tile) << 6; }
+__device__ __forceinline__ void unpack_oct(u32x4 r, f32x4& lo, f32x4& hi) {     // 8 bf16 -> two f32x4
+    lo = f32x4{__builtin_bit_cast(float, r[0] << 16), __builtin_bit_cast(float, r[0] & 0xffff0000u),
+               __builtin_bit_cast(float, r[1] << 16), __builtin_bit_cast(float, r[1] & 0xffff0000u)};
+    hi = f32x4{__builtin_bit_cast(float, r[2] << 16), __builtin_bit_cast(float, r[2] & 0xffff0000u),
+               __builtin_bit_cast(float, r[3] << 16), __builtin_bit_cast(float, r[3] & 0xffff0000u)};
+}
 template <typename T>
 __device__ __forceinline__ unsigned relu_with_bits(typename Prec<T>::Acc& acc) {
     unsigned bits = 0;
@@ -957,13 +965,13 @@ struct FHdr {
 
 // one segment: walk the accumulators in static order, each with its run-time MAC count; the source blocks come from the
 // program's block stream in execution order, so the fragment of the NEXT MAC is read from LDS under this MAC's MFMAs
-template <typename T>
-__device__ __forceinline__ void fs_walk(const FProg& wp, int sgi, int& pb, typename Prec<T>::AFrag& afn, typename Prec<T>::Acc (&acc)[FS_HS],
+template <typename T, int HS = FS_HS, int CB = 3>      // HS accumulators, CB bits of MAC count per accumulator
+__device__ __forceinline__ void fs_walk(const FProg& wp, int sgi, int& pb, typename Prec<T>::AFrag& afn, typename Prec<T>::Acc (&acc)[HS],
                                         const typename Prec<T>::BFrag& bf, const char* smem, const AOff<T>& lane, int dbg = 0) {
     const int cw = wp.counts(sgi);      // one readlane per segment: 3 bits of MAC count per accumulator
 #pragma unroll
-    for (int u = 0; u < FS_HS; ++u) {
-        const int cnt = (cw >> (3 * u)) & 7;
+    for (int u = 0; u < HS; ++u) {
+        const int cnt = (cw >> (CB * u)) & ((1 << CB) - 1);
         for (int k = 0; k < cnt; ++k) {
             // the MFMAs of this MAC read afn as they issue; the fragment of the NEXT MAC is then read from LDS into the same
             // registers and lands while those MFMAs execute (no second buffer, no register copies)
@@ -990,8 +998,8 @@ __device__ __forceinline__ void fs_walk(const FProg& wp, int sgi, int& pb, typen
 }
 // all segments of a layer.  The next segment's weight fragment streams from L2 while the current one is multiplied
 // (two register buffers).
-template <typename T>
-__device__ __forceinline__ void fs_run(const FProg& wp, typename Prec<T>::Acc (&acc)[FS_HS], const char* smem, const T* wpack, int wn, int lane, int dbg = 0,
+template <typename T, int HS = FS_HS, int CB = 3>
+__device__ __forceinline__ void fs_run(const FProg& wp, typename Prec<T>::Acc (&acc)[HS], const char* smem, const T* wpack, int wn, int lane, int dbg = 0,
                                        long long* segclk = nullptr) {
     const int nseg = wp.at(0);
     int pb = 1;
@@ -1010,8 +1018,8 @@ __device__ __forceinline__ void fs_run(const FProg& wp, typename Prec<T>::Acc (&
     if (dbg & 512) {     // both register buffers filled once, no weight streaming inside the layer (timing only, wrong results)
         load_bfrag<T>(bfb, wpack, wp.pack(0), wn, lane);
         for (int sgi = 0; sgi < nseg; sgi += 2) {
-            fs_walk<T>(wp, sgi, pb, afn, acc, bfa, smem, ao, dbg);
-            if (sgi + 1 < nseg) fs_walk<T>(wp, sgi + 1, pb, afn, acc, bfb, smem, ao, dbg);
+            fs_walk<T, HS, CB>(wp, sgi, pb, afn, acc, bfa, smem, ao, dbg);
+            if (sgi + 1 < nseg) fs_walk<T, HS, CB>(wp, sgi + 1, pb, afn, acc, bfb, smem, ao, dbg);
         }
         return;
     }
@@ -1024,14 +1032,135 @@ __device__ __forceinline__ void fs_run(const FProg& wp, typename Prec<T>::Acc (&
     for (int sgi = 0; sgi < nseg; sgi += 2) {
         load_bfrag<T>(bfb, wpack, wp.pack(min(sgi + 1, nseg - 1)), wn, lane);
         FS_SEGCLK(sgi);
-        fs_walk<T>(wp, sgi, pb, afn, acc, bfa, smem, ao, dbg);
+        fs_walk<T, HS, CB>(wp, sgi, pb, afn, acc, bfa, smem, ao, dbg);
         if (sgi + 1 < nseg) {
             load_bfrag<T>(bfa, wpack, wp.pack(min(sgi + 2, nseg - 1)), wn, lane);
             FS_SEGCLK(sgi + 1);
-            fs_walk<T>(wp, sgi + 1, pb, afn, acc, bfb, smem, ao, dbg);
+            fs_walk<T, HS, CB>(wp, sgi + 1, pb, afn, acc, bfb, smem, ao, dbg);
         }
     }
     FS_SEGCLK(nseg);
+}
+
+// decoder (+ fused wrapper MSE and decoder backward) on the X_L tile in LDS: shared tail of k_stack_fwd / k_slab_fwd
+template <typename T, int THREADS>
+__device__ __forceinline__ void decoder_tail(const StackArgs& a, char* smem, int tid, int lane, int wv, int w0, int B) {
+    // decoder on the out-type rows of X_L (hgnn_c2.py:176-189): thread = (node, row, 8-column chunk).  With y (mshgnn_step_mse) the
+    // same threads also take the wrapper MSE (gnnLightning.py:633-639) and the decoder backward: dX_L rows to global for
+    // k_stack_bwd, and this tile's partial decoder gradients + loss partial into dec_slabs[tile] (summed by k_finalize).
+    {
+        const int c = tid & 15, row = (tid >> 4) & 15;
+        const float* W = a.params + a.off_dec_w;
+        const bool fuse = a.y != nullptr;
+        T* dxl = reinterpret_cast<T*>(a.ws + a.dx_off[a.L]);
+        float accw[8][8], accb[8], lsum = 0.f;
+        if (fuse) {
+#pragma unroll
+            for (int dd = 0; dd < 8; ++dd) { accb[dd] = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) accw[dd][e] = 0.f; }
+        }
+        // two nodes per pass, every global load of a pass before its first store: a load waited for while stores are in flight
+        // costs a full vmcnt(0) drain (loads and stores retire out of order with respect to each other)
+        // (unconditional loads with clamped indices, so that they are issued back to back and waited for once)
+        float Wv[8][8], bv[8];
+#pragma unroll
+        for (int dd = 0; dd < 8; ++dd) {
+            const int dc = min(dd, a.dout - 1);
+            const f32x4 wa = *reinterpret_cast<const f32x4*>(W + dc * H + c * 8), wb = *reinterpret_cast<const f32x4*>(W + dc * H + c * 8 + 4);
+            Wv[dd][0] = wa[0]; Wv[dd][1] = wa[1]; Wv[dd][2] = wa[2]; Wv[dd][3] = wa[3];
+            Wv[dd][4] = wb[0]; Wv[dd][5] = wb[1]; Wv[dd][6] = wb[2]; Wv[dd][7] = wb[3];
+            bv[dd] = a.params[a.off_dec_b + dc];
+        }
+        for (int f0 = tid >> 8; f0 < a.n_out; f0 += 2 * (THREADS / 256)) {
+            float ov[2][8], dxv[2][8], mk[2][8], yv[2][8];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int f = min(f0 + i * (THREADS / 256), a.n_out - 1);
+                const size_t r = (size_t)min(w0 + row, B - 1) * a.n_out + f;
+#pragma unroll
+                for (int dd = 0; dd < 8; ++dd) {
+                    const int dc = min(dd, a.dout - 1);
+                    mk[i][dd] = a.out_mask[f * a.dout + dc];
+                    yv[i][dd] = fuse ? a.y[r * a.dout + dc] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int f = f0 + i * (THREADS / 256);
+                const bool live = f < a.n_out;
+                f32x4 x0, x1;
+                lds_load_oct<T>(smem, a.node0 + (live ? f : f0), row, c * 8, x0, x1);
+                const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dxv[i][e] = 0.f;
+                const bool ok = live && w0 + row < B;
+#pragma unroll
+                for (int dd = 0; dd < 8; ++dd) {
+                    ov[i][dd] = 0.f;
+                    if (dd < a.dout && live) {
+                        float sum = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) sum += x[e] * Wv[dd][e];
+                        sum = row16_sum(sum);
+                        const float o = (sum + bv[dd]) * mk[i][dd];
+                        ov[i][dd] = o;
+                        if (fuse && ok) {
+                            const float dlt = o - yv[i][dd];
+                            const float g = 2.0f * dlt * a.inv_n * mk[i][dd];
+                            if (c == 0) lsum += dlt * dlt;
+                            accb[dd] += g;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) { accw[dd][e] += g * x[e]; dxv[i][e] += g * Wv[dd][e]; }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int f = f0 + i * (THREADS / 256);
+                const bool ok = f < a.n_out && w0 + row < B;
+                const size_t r = (size_t)(w0 + row) * a.n_out + f;
+                if (c == 0 && ok) {
+#pragma unroll
+                    for (int dd = 0; dd < 8; ++dd) if (dd < a.dout) a.out[r * a.dout + dd] = ov[i][dd];
+                }
+                if (fuse && ok) store8<T>(dxl + act_idx(w0 + row, a.node0 + f, B) + c * 8, dxv[i]);
+            }
+        }
+        if (fuse) {
+            // reduce over the 4 rows of the wave (lanes 16 apart), then over the 8 waves through LDS (the X tile is dead after the barrier)
+#pragma unroll
+            for (int dd = 0; dd < 8; ++dd) {
+                if (dd < a.dout) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { accw[dd][e] += __shfl_xor(accw[dd][e], 16, 64); accw[dd][e] += __shfl_xor(accw[dd][e], 32, 64); }
+                    accb[dd] += __shfl_xor(accb[dd], 16, 64); accb[dd] += __shfl_xor(accb[dd], 32, 64);
+                }
+            }
+            lsum += __shfl_xor(lsum, 16, 64); lsum += __shfl_xor(lsum, 32, 64);
+            __syncthreads();
+            float* red = reinterpret_cast<float*>(smem);          // [8 waves][8 H + 16]
+            if (lane < 16) {
+#pragma unroll
+                for (int dd = 0; dd < 8; ++dd) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) red[wv * DEC_SLAB_FLOATS + dd * H + lane * 8 + e] = accw[dd][e];
+                    if (lane == 0) red[wv * DEC_SLAB_FLOATS + 8 * H + dd] = accb[dd];
+                }
+                if (lane == 0) red[wv * DEC_SLAB_FLOATS + 8 * H + 8] = lsum;
+            }
+            __syncthreads();
+            float* slab = a.dec_slabs + (size_t)blockIdx.x * DEC_SLAB_FLOATS;
+            for (int i = tid; i < 8 * H + 9; i += THREADS) {
+                if (i >= a.dout * H && i < 8 * H) continue;       // rows of unused output channels (k_finalize reads dout rows only)
+                float s2 = 0.f;
+#pragma unroll
+                for (int k = 0; k < THREADS / 64; ++k) s2 += red[k * DEC_SLAB_FLOATS + i];
+                slab[i] = s2;
+            }
+        }
+    }
 }
 
 template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_fwd(StackArgs a) {
@@ -1187,122 +1316,7 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
         FS_STAMP(5 + 4 * l);
     }
 
-    // decoder on the out-type rows of X_L (hgnn_c2.py:176-189): thread = (node, row, 8-column chunk).  With y (mshgnn_step_mse) the
-    // same threads also take the wrapper MSE (gnnLightning.py:633-639) and the decoder backward: dX_L rows to global for
-    // k_stack_bwd, and this tile's partial decoder gradients + loss partial into dec_slabs[tile] (summed by k_finalize).
-    {
-        const int c = tid & 15, row = (tid >> 4) & 15;
-        const float* W = a.params + a.off_dec_w;
-        const bool fuse = a.y != nullptr;
-        T* dxl = reinterpret_cast<T*>(a.ws + a.dx_off[a.L]);
-        float accw[8][8], accb[8], lsum = 0.f;
-        if (fuse) {
-#pragma unroll
-            for (int dd = 0; dd < 8; ++dd) { accb[dd] = 0.f;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) accw[dd][e] = 0.f; }
-        }
-        // two nodes per pass, every global load of a pass before its first store: a load waited for while stores are in flight
-        // costs a full vmcnt(0) drain (loads and stores retire out of order with respect to each other)
-        // (unconditional loads with clamped indices, so that they are issued back to back and waited for once)
-        float Wv[8][8], bv[8];
-#pragma unroll
-        for (int dd = 0; dd < 8; ++dd) {
-            const int dc = min(dd, a.dout - 1);
-            const f32x4 wa = *reinterpret_cast<const f32x4*>(W + dc * H + c * 8), wb = *reinterpret_cast<const f32x4*>(W + dc * H + c * 8 + 4);
-            Wv[dd][0] = wa[0]; Wv[dd][1] = wa[1]; Wv[dd][2] = wa[2]; Wv[dd][3] = wa[3];
-            Wv[dd][4] = wb[0]; Wv[dd][5] = wb[1]; Wv[dd][6] = wb[2]; Wv[dd][7] = wb[3];
-            bv[dd] = a.params[a.off_dec_b + dc];
-        }
-        for (int f0 = tid >> 8; f0 < a.n_out; f0 += 2 * (LAYER_THREADS / 256)) {
-            float ov[2][8], dxv[2][8], mk[2][8], yv[2][8];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int f = min(f0 + i * (LAYER_THREADS / 256), a.n_out - 1);
-                const size_t r = (size_t)min(w0 + row, B - 1) * a.n_out + f;
-#pragma unroll
-                for (int dd = 0; dd < 8; ++dd) {
-                    const int dc = min(dd, a.dout - 1);
-                    mk[i][dd] = a.out_mask[f * a.dout + dc];
-                    yv[i][dd] = fuse ? a.y[r * a.dout + dc] : 0.f;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int f = f0 + i * (LAYER_THREADS / 256);
-                const bool live = f < a.n_out;
-                f32x4 x0, x1;
-                lds_load_oct<T>(smem, a.node0 + (live ? f : f0), row, c * 8, x0, x1);
-                const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-#pragma unroll
-                for (int e = 0; e < 8; ++e) dxv[i][e] = 0.f;
-                const bool ok = live && w0 + row < B;
-#pragma unroll
-                for (int dd = 0; dd < 8; ++dd) {
-                    ov[i][dd] = 0.f;
-                    if (dd < a.dout && live) {
-                        float sum = 0.f;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) sum += x[e] * Wv[dd][e];
-                        sum = row16_sum(sum);
-                        const float o = (sum + bv[dd]) * mk[i][dd];
-                        ov[i][dd] = o;
-                        if (fuse && ok) {
-                            const float dlt = o - yv[i][dd];
-                            const float g = 2.0f * dlt * a.inv_n * mk[i][dd];
-                            if (c == 0) lsum += dlt * dlt;
-                            accb[dd] += g;
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) { accw[dd][e] += g * x[e]; dxv[i][e] += g * Wv[dd][e]; }
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int f = f0 + i * (LAYER_THREADS / 256);
-                const bool ok = f < a.n_out && w0 + row < B;
-                const size_t r = (size_t)(w0 + row) * a.n_out + f;
-                if (c == 0 && ok) {
-#pragma unroll
-                    for (int dd = 0; dd < 8; ++dd) if (dd < a.dout) a.out[r * a.dout + dd] = ov[i][dd];
-                }
-                if (fuse && ok) store8<T>(dxl + act_idx(w0 + row, a.node0 + f, B) + c * 8, dxv[i]);
-            }
-        }
-        if (fuse) {
-            // reduce over the 4 rows of the wave (lanes 16 apart), then over the 8 waves through LDS (the X tile is dead after the barrier)
-#pragma unroll
-            for (int dd = 0; dd < 8; ++dd) {
-                if (dd < a.dout) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) { accw[dd][e] += __shfl_xor(accw[dd][e], 16, 64); accw[dd][e] += __shfl_xor(accw[dd][e], 32, 64); }
-                    accb[dd] += __shfl_xor(accb[dd], 16, 64); accb[dd] += __shfl_xor(accb[dd], 32, 64);
-                }
-            }
-            lsum += __shfl_xor(lsum, 16, 64); lsum += __shfl_xor(lsum, 32, 64);
-            __syncthreads();
-            float* red = reinterpret_cast<float*>(smem);          // [8 waves][8 H + 16]
-            if (lane < 16) {
-#pragma unroll
-                for (int dd = 0; dd < 8; ++dd) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) red[wv * DEC_SLAB_FLOATS + dd * H + lane * 8 + e] = accw[dd][e];
-                    if (lane == 0) red[wv * DEC_SLAB_FLOATS + 8 * H + dd] = accb[dd];
-                }
-                if (lane == 0) red[wv * DEC_SLAB_FLOATS + 8 * H + 8] = lsum;
-            }
-            __syncthreads();
-            float* slab = a.dec_slabs + (size_t)blockIdx.x * DEC_SLAB_FLOATS;
-            for (int i = tid; i < 8 * H + 9; i += LAYER_THREADS) {
-                if (i >= a.dout * H && i < 8 * H) continue;       // rows of unused output channels (k_finalize reads dout rows only)
-                float s2 = 0.f;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) s2 += red[k * DEC_SLAB_FLOATS + i];
-                slab[i] = s2;
-            }
-        }
-    }
+    decoder_tail<T, LAYER_THREADS>(a, smem, tid, lane, wv, w0, B);
     FS_STAMP(30);
 #ifdef MSHGNN_SEG_STAMPS
     if (a.stamps) {
@@ -1311,6 +1325,168 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
         if (tid < 3 * 8 * 16) a.stamps[(size_t)gridDim.x * 32 + (size_t)blockIdx.x * 384 + tid] = sc[tid];
     }
 #endif
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Slab variant of the forward stack kernel: 4 waves per workgroup, two workgroups per CU.  Wave wn owns columns
+// [32 wn, 32 wn + 32) of EVERY node, so each weight pack is pulled through the CU's vector L1 once per tile (the 8-wave
+// kernel pulls it once per wave half, and its MAC phase is bound by that path), and the second workgroup's epilogues run
+// under this one's MAC phases.  The destination nodes are processed in two groups (mshgnn_plan.hpp, SL_HA / SL_HB) so that
+// the accumulators stay in registers; group A's new activations wait, packed, while group B is multiplied.
+// ------------------------------------------------------------------------------------------------------
+template <typename T, int HS, int Q0>     // one group: slots q = Q0 + u of the slab header
+__device__ __forceinline__ void slab_group_fwd(const StackArgs& a, const FHdr& fh, const FProg& wp, char* smem, const T* wpack, int wn, int lane,
+                                               int slot_base, int nmlp, bool residual, u32x4 (&keep)[HS], unsigned (&bits)[(HS + 3) / 4]) {
+    using P = Prec<T>;
+    const int win = c_win(lane), col = wn * 32 + c_oct(lane);
+    typename P::Acc acc[HS];
+#pragma unroll
+    for (int u = 0; u < HS; ++u) {
+        if (fh[FH_KIND + Q0 + u] != NK_DEAD) acc_init_bias<T>(acc[u], a.bias + (size_t)fh[FH_BIAS + Q0 + u] * H, wn, lane);
+        else acc_fill(acc[u], 0.f);
+    }
+    fs_run<T, HS, 2>(wp, acc, smem, wpack, wn, lane);
+    if constexpr (Q0 > 0) if (nmlp > 0) {
+        // base_transform: Y = W2 relu(W1 H + b1) + b2 on the first nmlp slots of this group (hgnn_c2.py:117-121,156); scratch
+        // blocks NN + u.  The H / T1 stashes go out packed, behind the chain's last load.
+        static_assert(sizeof(T) == 2, "fused stack kernels are bf16");
+        typename P::BFrag bf, bf2;
+        typename P::AFrag af;
+        u32x4 hpk[4], tpk[4];
+        load_bfrag<T>(bf, wpack, fh[FH_W1], wn, lane);
+        load_bfrag<T>(bf2, wpack, fh[FH_W2], wn, lane);
+#pragma unroll
+        for (int u = 0; u < 4 && u < HS; ++u) {
+            if (u < nmlp) {
+                hpk[u] = pack_oct(acc[u].c[0], acc[u].c[1]);
+                *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(a.NN + u, win, col / P::EPC)) = hpk[u];
+                acc_init_bias<T>(acc[u], a.bias + (size_t)fh[FH_B1] * H, wn, lane);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4 && u < HS; ++u) {
+            if (u < nmlp) { load_afrag<T>(af, smem, a.NN + u, lane); mac(acc[u], af, bf); }
+        }
+        __syncthreads();   // all reads of H done before T1 overwrites the scratch blocks
+#pragma unroll
+        for (int u = 0; u < 4 && u < HS; ++u) {
+            if (u < nmlp) {
+                tpk[u] = pack_oct(relu4(acc[u].c[0]), relu4(acc[u].c[1]));
+                *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(a.NN + u, win, col / P::EPC)) = tpk[u];
+                acc_init_bias<T>(acc[u], a.bias + (size_t)fh[FH_B2] * H, wn, lane);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4 && u < HS; ++u) {
+            if (u < nmlp) { load_afrag<T>(af, smem, a.NN + u, lane); mac(acc[u], af, bf2); }
+        }
+        __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));      // every load has landed before the first store
+        if (a.training) {
+            const int w = blockIdx.x * P::ROWS + win;
+            if (w < a.B) {
+                T* hb = reinterpret_cast<T*>(a.ws + a.hb_off[slot_base >> 8]);
+                T* t1 = reinterpret_cast<T*>(a.ws + a.t1_off[slot_base >> 8]);
+#pragma unroll
+                for (int u = 0; u < 4 && u < HS; ++u) {
+                    if (u < nmlp) {
+                        *reinterpret_cast<u32x4*>(hb + act_idx(w, u, a.B) + col) = hpk[u];
+                        *reinterpret_cast<u32x4*>(t1 + act_idx(w, u, a.B) + col) = tpk[u];
+                    }
+                }
+            }
+        }
+    }
+    // X_{l+1}[n] = f(H[n]) (+ X_l[n]), kept packed in registers (X_l is still being read by the other waves)
+#pragma unroll
+    for (int i = 0; i < (HS + 3) / 4; ++i) bits[i] = 0;
+#pragma unroll
+    for (int u = 0; u < HS; ++u) {
+        keep[u] = u32x4{0, 0, 0, 0};
+        const int kind = fh[FH_KIND + Q0 + u];
+        if (kind != NK_DEAD) {
+            const int n = fh[(slot_base & 255) + u];
+            if (kind == NK_RELU) bits[u >> 2] |= relu_with_bits<T>(acc[u]) << (8 * (u & 3));
+            f32x4 y0 = acc[u].c[0], y1 = acc[u].c[1];
+            if (residual) {
+                const u32x4 r = *reinterpret_cast<const u32x4*>(smem + lds_chunk<T>(n, win, col / P::EPC));
+                f32x4 r0, r1; unpack_oct(r, r0, r1);
+                y0 += r0; y1 += r1;
+            }
+            keep[u] = pack_oct(y0, y1);
+        }
+    }
+}
+// write one group's new activations: LDS block, stash, relu bytes
+template <typename T, int HS, int Q0>
+__device__ __forceinline__ void slab_group_store(const StackArgs& a, const FHdr& fh, char* smem, int wn, int lane, int slot_arr, int l,
+                                                 const u32x4 (&keep)[HS], const unsigned (&bits)[(HS + 3) / 4]) {
+    using P = Prec<T>;
+    const int win = c_win(lane), col = wn * 32 + c_oct(lane), w = blockIdx.x * P::ROWS + win;
+    T* xo = reinterpret_cast<T*>(a.ws + a.x_off[l + 1]);
+    uint8_t* maskbytes = reinterpret_cast<uint8_t*>(a.ws + a.mask_off[l]);
+#pragma unroll
+    for (int u = 0; u < HS; ++u) {
+        const int kind = fh[FH_KIND + Q0 + u];
+        if (kind != NK_DEAD) {
+            const int n = fh[slot_arr + u];
+            *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(n, win, col / P::EPC)) = keep[u];
+            if (a.training) {
+                if (kind == NK_RELU) maskbytes[relu_tile_base(n, a.B, blockIdx.x, wn) + lane] = (uint8_t)(bits[u >> 2] >> (8 * (u & 3)));
+                if (w < a.B) *reinterpret_cast<u32x4*>(xo + act_idx(w, n, a.B) + col) = keep[u];
+            }
+        }
+    }
+}
+
+template <typename T> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_fwd(StackArgs a) {
+    using P = Prec<T>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w0 = blockIdx.x * P::ROWS, B = a.B, NN = a.NN;
+    const T* wpack = reinterpret_cast<const T*>(a.wpack);
+
+    {   // X_0 tile -> LDS: thread = (row, 16-byte chunk), one node per pass, 6 loads in flight
+        const T* src = reinterpret_cast<const T*>(a.tile_in);
+        const int row = tid >> 4, c = tid & 15;
+        constexpr int BATCH = 6;
+        for (int nb = 0; nb < NN; nb += BATCH) {
+            u32x4 v[BATCH];
+#pragma unroll
+            for (int i = 0; i < BATCH; ++i) {
+                v[i] = u32x4{0, 0, 0, 0};
+                if (nb + i < NN && w0 + row < B) v[i] = *reinterpret_cast<const u32x4*>(src + act_idx(w0 + row, nb + i, B) + c * P::EPC);
+            }
+#pragma unroll
+            for (int i = 0; i < BATCH; ++i)
+                if (nb + i < NN) *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(nb + i, row, c)) = v[i];
+        }
+    }
+    __syncthreads();
+
+    FHdr fhn(a.tables + a.prog_off[0], lane);
+    FProg wan(a.tables + a.prog_off[0] + FH_SIZE, lane), wbn(a.tables + a.prog_off[0] + FH_SIZE + FPROG_LEN, lane);
+    for (int l = 0; l < a.L; ++l) {
+        const FHdr fh = fhn;
+        const FProg wa = wan, wb = wbn;
+        if (l + 1 < a.L) {    // the next layer's header and wave programs stream in under this layer's MACs
+            fhn = FHdr(a.tables + a.prog_off[l + 1], lane);
+            wan = FProg(a.tables + a.prog_off[l + 1] + FH_SIZE, lane);
+            wbn = FProg(a.tables + a.prog_off[l + 1] + FH_SIZE + FPROG_LEN, lane);
+        }
+        const int nmlp = fh[FH_NMLP];
+        const bool residual = (fh[FH_FLAGS] & FF_RESIDUAL) != 0;
+        u32x4 keepA[SL_HA], keepB[SL_HB]; unsigned bitsA[(SL_HA + 3) / 4], bitsB[(SL_HB + 3) / 4];
+        slab_group_fwd<T, SL_HA, 0>(a, fh, wa, smem, wpack, wn, lane, FH_SLOTA | (l << 8), 0, residual, keepA, bitsA);
+        slab_group_fwd<T, SL_HB, SL_HA>(a, fh, wb, smem, wpack, wn, lane, FH_SLOTB | (l << 8), nmlp, residual, keepB, bitsB);
+        __syncthreads();   // every wave is done reading X_l: the node blocks may be overwritten
+        __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));      // loads (next header / programs) landed before the stores go out
+        slab_group_store<T, SL_HA, 0>(a, fh, smem, wn, lane, FH_SLOTA, l, keepA, bitsA);
+        slab_group_store<T, SL_HB, SL_HA>(a, fh, smem, wn, lane, FH_SLOTB, l, keepB, bitsB);
+        __syncthreads();
+    }
+    decoder_tail<T, SL_THREADS>(a, smem, tid, lane, wn, w0, B);
 }
 
 template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_bwd(StackArgs a) {
@@ -1991,6 +2167,7 @@ struct mshgnn_plan {
     PackDesc* d_packs = nullptr; BiasDesc* d_biases = nullptr;
     bool attr_set = false;
     bool use_fused = false;             // bf16 plan: fused stack kernels (MSHGNN_FUSED=0 selects the per-layer kernels)
+    bool use_slab = false;              // slab variant of the stack kernels (MSHGNN_SLAB=1)
 };
 
 // bracket one kernel launch with events when profiling
@@ -2050,6 +2227,9 @@ extern "C" int mshgnn_plan_create(const mshgnn_desc* desc, mshgnn_plan** out) {
         if (p->use_fused) {
             const int flds = (hp.fs_blk + FS_EXTRA_BLK) * Prec<__bf16>::BLK;
             if ((rc = set_lds_attr(k_stack_fwd<__bf16>, flds)) || (rc = set_lds_attr(k_stack_bwd<__bf16>, flds))) { mshgnn_plan_destroy(p); return rc; }
+            const char* es = getenv("MSHGNN_SLAB");
+            p->use_slab = hp.slab && es && atoi(es) != 0;
+            if (p->use_slab && (rc = set_lds_attr(k_slab_fwd<__bf16>, flds))) { mshgnn_plan_destroy(p); return rc; }
         }
     }
     *out = p;
@@ -2172,6 +2352,10 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
             }
             { const char* e = getenv("MSHGNN_STAMPS"); a.stamps = e ? reinterpret_cast<long long*>((uintptr_t)strtoull(e, nullptr, 0)) : nullptr; }
             ProfScope ps(p, hp.ks_stack_fwd, st);
+            if (p->use_slab) {
+                for (int l = 0; l < hp.L; ++l) a.prog_off[l] = hp.sl_fwd_off[l];
+                hipLaunchKernelGGL(k_slab_fwd<T>, dim3(tiles), dim3(SL_THREADS), (hp.fs_blk + FS_EXTRA_BLK) * Prec<T>::BLK, st, a);
+            } else
             hipLaunchKernelGGL(k_stack_fwd<T>, dim3(tiles), dim3(LAYER_THREADS), (hp.fs_blk + FS_EXTRA_BLK) * Prec<T>::BLK, st, a);
             HIPCHK(hipGetLastError());
             return MSHGNN_OK;

@@ -68,7 +68,15 @@ enum { FH_NSEG = 0, FH_NMLP, FH_W1, FH_W2, FH_B1, FH_B2, FH_FLAGS, FH_MLP0,   //
        FH_BIAS = 8 + FS_MAXN,            // fwd: bias row of node n
        FH_OUT = 8 + 2 * FS_MAXN,         // bwd: dX_l[n] is produced
        FH_RES = 8 + 3 * FS_MAXN,         // bwd: dX_{l+1}[n] flows into dX_l[n] through the residual
-       FH_SIZE = 8 + 4 * FS_MAXN };
+       FH_SLOTA = 8 + 4 * FS_MAXN,       // slab kernels: node of accumulator slot u of group A / group B (-1: unused)
+       FH_SLOTB = FH_SLOTA + 16,
+       FH_SIZE = FH_SLOTB + 16 };
+// Slab variant of the stack kernels (4-wave workgroups, two per CU): wave wn owns columns [32 wn, 32 wn + 32) of EVERY node, so
+// a weight pack goes through the CU's vector L1 once per tile instead of once per wave half (the stack kernels' MAC phase is
+// bound by that path: DESIGN.md section 6).  To keep the accumulators in registers the destination nodes are processed in two
+// groups, one after the other: A = the node type with the most nodes (<= SL_HA), B = all other nodes (<= SL_HB); group A's
+// results wait, packed, while group B is multiplied.  Wave programs as above with 2 bits of MAC count per slot.
+constexpr int SL_HA = 12, SL_HB = 6, SL_THREADS = 256;
 enum { FF_RESIDUAL = 1, FF_ENC_MASK = 2 };
 
 // buffer ids used by weight-gradient items
@@ -123,6 +131,8 @@ struct HostPlan {
     int fwd_prog_off[MAX_L]{}, bwd_prog_off[MAX_L]{};
     bool fused = false;                           // fused stack kernels available (bf16, <= FS_MAXN nodes, programs fit)
     int fs_fwd_off[MAX_L]{}, fs_bwd_off[MAX_L]{};
+    bool slab = false;                            // slab variant available (two 4-wave workgroups per CU fit, groups fit)
+    int sl_fwd_off[MAX_L]{}, sl_bwd_off[MAX_L]{}, sl_ta = -1;
     int fs_blk = 0;                               // LDS blocks of the fused kernels (NN + base_transform scratch)
     int ks_stack_fwd = -1, ks_stack_bwd = -1;
     int item_off = 0, n_items = 0, tgt_off = 0, n_targets = 0, lane_off = 0, n_lanes = 0, n_parts = 1, n_wg_gradw = 0;
@@ -468,6 +478,50 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
                 for (int i = 0; i < 64; ++i) T.push_back(w[4 * i] | (w[4 * i + 1] << 8) | (w[4 * i + 2] << 16) | (w[4 * i + 3] << 24));
             }
         };
+        // slab programs: group A = the largest node type, group B = every other node in node order
+        int tA = 0; for (int t = 1; t < NT; ++t) if (d.type_nodes[t] > d.type_nodes[tA]) tA = t;
+        std::vector<int> slotA, slotB;
+        for (int n = 0; n < p.NN; ++n) (p.node_type[n] == tA ? slotA : slotB).push_back(n);
+        p.sl_ta = tA;
+        p.slab = 2 * (int64_t)p.fs_blk * p.blk_bytes <= LDS_LIMIT && (int)slotA.size() <= SL_HA && (int)slotB.size() <= SL_HB &&
+                 (!has_mlp || (d.mlp_type != tA && p.n_mlp <= (int)slotB.size()));     // base_transform nodes = the first slots of group B
+        if (has_mlp) for (int u = 0; u < p.n_mlp && p.slab; ++u) if (slotB[u] != p.type_base[d.mlp_type] + u) p.slab = false;
+        auto emit_slab = [&](const std::vector<Seg>& segs, int hdr_src) {
+            const int h = (int)T.size(); T.resize(T.size() + FH_SIZE, 0);
+            for (int i = 0; i < FH_SLOTA; ++i) T[h + i] = T[hdr_src + i];
+            for (int u = 0; u < 16; ++u) { T[h + FH_SLOTA + u] = u < (int)slotA.size() ? slotA[u] : -1; T[h + FH_SLOTB + u] = u < (int)slotB.size() ? slotB[u] : -1; }
+            // per-node arrays re-indexed by slot q (group A: q = u, group B: q = SL_HA + u) so that the kernel reads them with constant lanes
+            static_assert(SL_HA + SL_HB <= FS_MAXN, "slot arrays share the per-node header arrays");
+            for (int q = 0; q < FS_MAXN; ++q) {
+                const int n = q < SL_HA ? (q < (int)slotA.size() ? slotA[q] : -1) : (q - SL_HA < (int)slotB.size() ? slotB[q - SL_HA] : -1);
+                for (int arr : {FH_KIND, FH_BIAS, FH_OUT, FH_RES}) T[h + arr + q] = n >= 0 ? T[hdr_src + arr + n] : 0;
+            }
+            for (int phase = 0; phase < 2 && p.slab; ++phase) {
+                const std::vector<int>& slots = phase == 0 ? slotA : slotB;
+                std::vector<int> w, blocks, counts, packs;
+                bool ok = true;
+                for (const Seg& sg : segs) {
+                    if (sg.macs.empty() || (p.node_type[sg.macs[0].first] == tA) != (phase == 0)) continue;
+                    int cw = 0;
+                    for (size_t u = 0; u < slots.size(); ++u) {
+                        int c = 0;
+                        for (auto& m : sg.macs) if (m.first == slots[u]) { blocks.push_back(m.second); ++c; }
+                        if (c > 3) ok = false;
+                        cw |= (c & 3) << (2 * u);
+                    }
+                    counts.push_back(cw); packs.push_back(sg.pack);
+                }
+                w.push_back((int)packs.size());
+                blocks.push_back(blocks.empty() ? 0 : blocks.back());
+                for (int b : blocks) w.push_back(b);
+                if (!ok || w.size() > 256 || packs.size() > 64) { p.slab = false; break; }
+                w.resize(256, 0); counts.resize(64, 0); packs.resize(64, 0);
+                for (int i = 0; i < 64; ++i) T.push_back(packs[i]);
+                for (int i = 0; i < 64; ++i) T.push_back(counts[i]);
+                for (int i = 0; i < 64; ++i) T.push_back(w[4 * i] | (w[4 * i + 1] << 8) | (w[4 * i + 2] << 16) | (w[4 * i + 3] << 24));
+            }
+            return h;
+        };
         for (int l = 0; l < L && p.fused; ++l) {
             const bool mlp_live = has_mlp && p.live[l][d.mlp_type];
             // forward
@@ -498,6 +552,7 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
                 }
                 T[fh + FH_NSEG] = (int)segs.size();
                 emit_fused(segs);
+                if (p.fused && p.slab) p.sl_fwd_off[l] = emit_slab(segs, fh);
             }
             if (!p.fused) break;
             // backward
@@ -532,8 +587,10 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
                 }
                 T[bh2 + FH_NSEG] = (int)segs.size();
                 emit_fused(segs);
+                if (p.fused && p.slab) p.sl_bwd_off[l] = emit_slab(segs, bh2);
             }
         }
+        if (!p.fused) p.slab = false;
     }
     // algorithmic dX work: one node-linear per (relation, src node with >=1 out-edge into a live dst) -- count below
     for (int l = 0; l < L; ++l)
