@@ -1650,6 +1650,193 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Slab variant of the backward stack kernel (see k_slab_fwd): wave wn owns columns [32 wn, 32 wn + 32) of every node; the
+// nodes whose dX_l is produced are processed in two groups.  A group's accumulators start at the residual term, re-read
+// from the dX_{l+1} stash (written by this wave one layer earlier, or by the decoder backward) when its turn comes, so
+// that they occupy no registers during the base_transform chain or the other group's MACs.
+// ------------------------------------------------------------------------------------------------------
+template <typename T, int HS, int Q0>
+__device__ __forceinline__ void slab_group_bwd(const StackArgs& a, const FHdr& bh, const FProg& wp, char* smem, const T* wpack, int wn, int lane,
+                                               int slot_arr, const T* gsrc, const T* xact, bool enc_mask, u32x4 (&keep)[HS]) {
+    using P = Prec<T>;
+    const int win = c_win(lane), col = wn * 32 + c_oct(lane), w = min(blockIdx.x * P::ROWS + win, a.B - 1);
+    // the accumulators start at the residual term G_{l+1}[n], re-read from the dX_{l+1} stash (written by this wave one layer
+    // earlier, or by the decoder backward).  A drain first: stores of the chain / of the previous layer may still be in flight.
+    typename P::Acc acc[HS];
+    __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));
+    {
+        u32x4 graw[HS];
+#pragma unroll
+        for (int u = 0; u < HS; ++u) {
+            graw[u] = u32x4{0, 0, 0, 0};
+            if (bh[FH_KIND + Q0 + u] != NK_DEAD && bh[FH_RES + Q0 + u]) graw[u] = *reinterpret_cast<const u32x4*>(gsrc + act_idx(w, bh[slot_arr + u], a.B) + col);
+        }
+#pragma unroll
+        for (int u = 0; u < HS; ++u) unpack_oct(graw[u], acc[u].c[0], acc[u].c[1]);
+    }
+    fs_run<T, HS, 2>(wp, acc, smem, wpack, wn, lane);
+    // layer 0: x relu'(X_0) (encoder activation): the X_0 octets of the group are requested back to back (no store is pending here)
+    u32x4 xraw[HS];
+    if (enc_mask) {
+#pragma unroll
+        for (int u = 0; u < HS; ++u) {
+            xraw[u] = u32x4{0, 0, 0, 0};
+            if (bh[FH_OUT + Q0 + u]) xraw[u] = *reinterpret_cast<const u32x4*>(xact + act_idx(w, bh[slot_arr + u], a.B) + col);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < HS; ++u) {
+        keep[u] = u32x4{0, 0, 0, 0};
+        if (bh[FH_OUT + Q0 + u]) {
+            f32x4 y0 = acc[u].c[0], y1 = acc[u].c[1];
+            if (enc_mask) {
+                // bf16 x > 0  <=>  its 16-bit pattern, as a signed integer, is > 0
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const unsigned r = xraw[u][j], r2 = xraw[u][2 + j];
+                    y0[2 * j] = (int)(r << 16) > 0 ? y0[2 * j] : 0.f;  y0[2 * j + 1] = (int)(r & 0xffff0000u) > 0 ? y0[2 * j + 1] : 0.f;
+                    y1[2 * j] = (int)(r2 << 16) > 0 ? y1[2 * j] : 0.f; y1[2 * j + 1] = (int)(r2 & 0xffff0000u) > 0 ? y1[2 * j + 1] : 0.f;
+                }
+            }
+            keep[u] = pack_oct(y0, y1);
+        }
+    }
+}
+
+template <typename T> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_bwd(StackArgs a) {
+    using P = Prec<T>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w0 = blockIdx.x * P::ROWS, B = a.B, NN = a.NN;
+    const T* wpack = reinterpret_cast<const T*>(a.wpack);
+    const int win = c_win(lane), w = w0 + win, col = wn * 32 + c_oct(lane), wc = min(w, B - 1);
+    const bool w_ok = w < B;
+    static_assert(sizeof(T) == 2, "fused stack kernels are bf16");
+
+    // dX_L tile: only the nodes that are live in the last layer carry a gradient
+    {
+        const FHdr bh(a.tables + a.prog_off[a.L - 1], lane);
+        const T* src = reinterpret_cast<const T*>(a.tile_in);
+        const int row = tid >> 4, c = tid & 15;
+        for (int q = 0; q < SL_HA + SL_HB; ++q) {
+            const int n = bh[(q < SL_HA ? FH_SLOTA : FH_SLOTB - SL_HA) + q];
+            if (n < 0 || bh[FH_KIND + q] == NK_DEAD) continue;
+            u32x4 v = u32x4{0, 0, 0, 0};
+            if (w0 + row < B) v = *reinterpret_cast<const u32x4*>(src + act_idx(w0 + row, n, B) + c * P::EPC);
+            *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(n, row, c)) = v;
+        }
+    }
+    __syncthreads();
+
+    FHdr bhn(a.tables + a.prog_off[a.L - 1], lane);
+    FProg wan(a.tables + a.prog_off[a.L - 1] + FH_SIZE, lane), wbn(a.tables + a.prog_off[a.L - 1] + FH_SIZE + FPROG_LEN, lane);
+    for (int l = a.L - 1; l >= 0; --l) {
+        const FHdr bh = bhn;
+        const FProg wa = wan, wb = wbn;
+        if (l > 0) {
+            bhn = FHdr(a.tables + a.prog_off[l - 1], lane);
+            wan = FProg(a.tables + a.prog_off[l - 1] + FH_SIZE, lane);
+            wbn = FProg(a.tables + a.prog_off[l - 1] + FH_SIZE + FPROG_LEN, lane);
+        }
+        const int nmlp = bh[FH_NMLP], flags = bh[FH_FLAGS];
+        const uint8_t* maskbytes = reinterpret_cast<const uint8_t*>(a.ws + a.mask_off[l]);
+
+        // mask phase (each lane on the octets it owns): relu nodes are masked in place -> dH_l[n]; group A's accumulators start
+        // at the residual term G_{l+1}[n].  Every relu byte and every LDS read is issued before the first use.
+        {
+            unsigned mb[SL_HA + SL_HB]; u32x4 rawv[SL_HA + SL_HB]; int kindv[SL_HA + SL_HB], nodev[SL_HA + SL_HB];
+#pragma unroll
+            for (int q = 0; q < SL_HA + SL_HB; ++q) {
+                kindv[q] = bh[FH_KIND + q]; nodev[q] = bh[(q < SL_HA ? FH_SLOTA : FH_SLOTB - SL_HA) + q];
+                mb[q] = 0xffu; rawv[q] = u32x4{0, 0, 0, 0};
+                if (kindv[q] == NK_RELU) mb[q] = maskbytes[relu_tile_base(nodev[q], B, blockIdx.x, wn) + lane];
+                if (kindv[q] != NK_DEAD) rawv[q] = *reinterpret_cast<const u32x4*>(smem + lds_chunk<T>(nodev[q], win, col / P::EPC));
+            }
+#pragma unroll
+            for (int q = 0; q < SL_HA + SL_HB; ++q) {
+                if (kindv[q] == NK_RELU)
+                    *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(nodev[q], win, col / P::EPC)) = chunk_mask_bits<T>(rawv[q], mb[q]);
+            }
+        }
+        __syncthreads();
+
+        if (nmlp > 0) {
+            // dT1 = dY W2 ; dU = dT1 . (T1 > 0) ; dH = dU W1     (backward of base_transform, in place on nodes 0..nmlp-1 = the
+            // first slots of group B); the dU / dH stashes go out behind the chain's last load
+            const T* t1 = reinterpret_cast<const T*>(a.ws + a.t1_off[l]);
+            T* du = reinterpret_cast<T*>(a.ws + a.du_off[l]);
+            T* dh = reinterpret_cast<T*>(a.ws + a.dh_off[l]);
+            typename P::BFrag bf, bf1;
+            typename P::AFrag af;
+            typename P::Acc tm[4];
+            u32x4 traw[4], dupk[4];
+            load_bfrag<T>(bf, wpack, bh[FH_W2], wn, lane);
+            load_bfrag<T>(bf1, wpack, bh[FH_W1], wn, lane);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                traw[u] = u32x4{0, 0, 0, 0};
+                if (u < nmlp) {
+                    traw[u] = *reinterpret_cast<const u32x4*>(t1 + act_idx(wc, u, B) + col);
+                    acc_fill(tm[u], 0.f);
+                    load_afrag<T>(af, smem, u, lane);
+                    mac(tm[u], af, bf);
+                }
+            }
+            __syncthreads();   // all reads of the dY blocks done
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (u < nmlp) {
+                    f32x4 t0, t1v, r0, r1; unpack_oct(traw[u], t0, t1v);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { r0[j] = t0[j] > 0.f ? tm[u].c[0][j] : 0.f; r1[j] = t1v[j] > 0.f ? tm[u].c[1][j] : 0.f; }
+                    dupk[u] = pack_oct(r0, r1);
+                    *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(u, win, col / P::EPC)) = dupk[u];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (u < nmlp) { acc_fill(tm[u], 0.f); load_afrag<T>(af, smem, u, lane); mac(tm[u], af, bf1); }
+            }
+            __syncthreads();   // all reads of the dU blocks done
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (u < nmlp) {
+                    const u32x4 hp = pack_oct(tm[u].c[0], tm[u].c[1]);
+                    *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(u, win, col / P::EPC)) = hp;
+                    if (w_ok) {
+                        *reinterpret_cast<u32x4*>(du + act_idx(w, u, B) + col) = dupk[u];
+                        *reinterpret_cast<u32x4*>(dh + act_idx(w, u, B) + col) = hp;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+
+        // dX_l[j] = (residual) + dH_j W_rootsum + sum_r sum_{j->i} dH_i W_rel^r, group A then group B
+        const T* xact = reinterpret_cast<const T*>(a.ws + a.x_off[0]);
+        const bool enc_mask = (flags & FF_ENC_MASK) != 0;
+        u32x4 keepA[SL_HA], keepB[SL_HB];
+        const T* gsrc = reinterpret_cast<const T*>(a.ws + a.dx_off[l + 1]);
+        slab_group_bwd<T, SL_HA, 0>(a, bh, wa, smem, wpack, wn, lane, FH_SLOTA, gsrc, xact, enc_mask, keepA);
+        slab_group_bwd<T, SL_HB, SL_HA>(a, bh, wb, smem, wpack, wn, lane, FH_SLOTB, gsrc, xact, enc_mask, keepB);
+        __syncthreads();   // every wave is done reading dH_l
+        __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));
+        T* dxo = reinterpret_cast<T*>(a.ws + a.dx_off[l]);
+#pragma unroll
+        for (int q = 0; q < SL_HA + SL_HB; ++q) {
+            if (bh[FH_OUT + q]) {
+                const int n = bh[(q < SL_HA ? FH_SLOTA : FH_SLOTB - SL_HA) + q];
+                const u32x4 v = q < SL_HA ? keepA[q < SL_HA ? q : 0] : keepB[q < SL_HA ? 0 : q - SL_HA];
+                if (l > 0) *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(n, win, col / P::EPC)) = v;
+                if (w_ok) *reinterpret_cast<u32x4*>(dxo + act_idx(w, n, B) + col) = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // decoder forward / backward (hgnn_c2.py:176-189) and the wrapper's MSE (gnnLightning.py:633-639)
 // ------------------------------------------------------------------------------------------------------
 struct DecArgs {
@@ -2167,7 +2354,7 @@ struct mshgnn_plan {
     PackDesc* d_packs = nullptr; BiasDesc* d_biases = nullptr;
     bool attr_set = false;
     bool use_fused = false;             // bf16 plan: fused stack kernels (MSHGNN_FUSED=0 selects the per-layer kernels)
-    bool use_slab = false;              // slab variant of the stack kernels (MSHGNN_SLAB=1)
+    bool use_slab = false;              // slab variant of the stack kernels (MSHGNN_SLAB=0 selects the 8-wave ones)
 };
 
 // bracket one kernel launch with events when profiling
@@ -2228,8 +2415,8 @@ extern "C" int mshgnn_plan_create(const mshgnn_desc* desc, mshgnn_plan** out) {
             const int flds = (hp.fs_blk + FS_EXTRA_BLK) * Prec<__bf16>::BLK;
             if ((rc = set_lds_attr(k_stack_fwd<__bf16>, flds)) || (rc = set_lds_attr(k_stack_bwd<__bf16>, flds))) { mshgnn_plan_destroy(p); return rc; }
             const char* es = getenv("MSHGNN_SLAB");
-            p->use_slab = hp.slab && es && atoi(es) != 0;
-            if (p->use_slab && (rc = set_lds_attr(k_slab_fwd<__bf16>, flds))) { mshgnn_plan_destroy(p); return rc; }
+            p->use_slab = hp.slab && !(es && atoi(es) == 0);       // default on where the plan allows it; MSHGNN_SLAB=0 selects the 8-wave kernels
+            if (p->use_slab && ((rc = set_lds_attr(k_slab_fwd<__bf16>, flds)) || (rc = set_lds_attr(k_slab_bwd<__bf16>, flds)))) { mshgnn_plan_destroy(p); return rc; }
         }
     }
     *out = p;
@@ -2420,6 +2607,10 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
             { const char* e = getenv("MSHGNN_DBG"); a.dbg = e ? atoi(e) : 0; }
             { const char* e = getenv("MSHGNN_STAMPS_BWD"); a.stamps = e ? reinterpret_cast<long long*>((uintptr_t)strtoull(e, nullptr, 0)) : nullptr; }
             ProfScope ps(p, hp.ks_stack_bwd, st);
+            if (p->use_slab) {
+                for (int l = 0; l < hp.L; ++l) a.prog_off[l] = hp.sl_bwd_off[l];
+                hipLaunchKernelGGL(k_slab_bwd<T>, dim3(tiles), dim3(SL_THREADS), (hp.fs_blk + FS_EXTRA_BLK) * Prec<T>::BLK, st, a);
+            } else
             hipLaunchKernelGGL(k_stack_bwd<T>, dim3(tiles), dim3(LAYER_THREADS), (hp.fs_blk + FS_EXTRA_BLK) * Prec<T>::BLK, st, a);
             fused_done = true;
         }
