@@ -23,17 +23,19 @@ def test_emulation_without_rounding_is_the_oracle(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fused", ["1", "0"])
+@pytest.mark.parametrize("fused", ["slab", "stack", "layers"])
 @pytest.mark.parametrize("name", ["a1c2_h128_L2_d3_B37", "a1c2_h128_L3_d3_B3", "mck4_reg_h128_L1_B2", "mi_h128_L2_d1_B3",
                                   "solok4com_h128_L3_B5", "soloc2com_h128_L2_B4", "solos4com_h128_L2_B3", "a1c2_h128_L8_d3_B2"])
 def test_bf16_plan_matches_rounding_point_emulation(name, fused, monkeypatch):
     """bf16 plan vs the fp64 model with bf16 rounding at the engine's storage points.  Remaining differences: fp32
     accumulation and rare 1-ulp bf16 re-roundings (2^-8 relative on single elements), hence norm-wise tolerances:
-    outputs 4e-3 (max-abs relative), gradients 1.5e-2 (L2 relative).  Both kernel sets of the bf16 plan are covered:
-    the fused stack kernels (default) and the per-layer kernels (MSHGNN_FUSED=0, read when the plan is created)."""
+    outputs 4e-3 (max-abs relative), gradients 1.5e-2 (L2 relative).  All three kernel sets of the bf16 plan are covered
+    (the switches are read when the plan is created): the slab stack kernels (default where the plan allows them: two 4-wave
+    workgroups per CU), the 8-wave stack kernels (MSHGNN_SLAB=0) and the per-layer kernels (MSHGNN_FUSED=0)."""
     assert torch.cuda.is_available()
     from morphsym_hgnn_amd import engine as eng
-    monkeypatch.setenv("MSHGNN_FUSED", fused)
+    monkeypatch.setenv("MSHGNN_FUSED", "0" if fused == "layers" else "1")
+    monkeypatch.setenv("MSHGNN_SLAB", "1" if fused == "slab" else "0")
     case, spec, fx, x_dict, y, params, ei = helpers.load_case(name)
     B = case["B"]
     e = eng.Engine(spec, "bf16")
