@@ -2355,6 +2355,9 @@ struct mshgnn_plan {
     bool attr_set = false;
     bool use_fused = false;             // bf16 plan: fused stack kernels (MSHGNN_FUSED=0 selects the per-layer kernels)
     bool use_slab = false;              // slab variant of the stack kernels (MSHGNN_SLAB=0 selects the 8-wave ones)
+    bool slab_force = false; int n_cu = 256;
+    // a slab workgroup has 4 waves for a whole tile: it pays off once there are enough tiles for two workgroups per CU
+    bool slab_for(int tiles) const { return use_slab && (slab_force || tiles >= 2 * n_cu * 3 / 4); }
 };
 
 // bracket one kernel launch with events when profiling
@@ -2416,6 +2419,8 @@ extern "C" int mshgnn_plan_create(const mshgnn_desc* desc, mshgnn_plan** out) {
             if ((rc = set_lds_attr(k_stack_fwd<__bf16>, flds)) || (rc = set_lds_attr(k_stack_bwd<__bf16>, flds))) { mshgnn_plan_destroy(p); return rc; }
             const char* es = getenv("MSHGNN_SLAB");
             p->use_slab = hp.slab && !(es && atoi(es) == 0);       // default on where the plan allows it; MSHGNN_SLAB=0 selects the 8-wave kernels
+            p->slab_force = es && atoi(es) == 2;                   // MSHGNN_SLAB=2: also for batches that do not fill the chip
+            { int dev = 0, cus = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); p->n_cu = cus > 0 ? cus : 256; }
             if (p->use_slab && ((rc = set_lds_attr(k_slab_fwd<__bf16>, flds)) || (rc = set_lds_attr(k_slab_bwd<__bf16>, flds)))) { mshgnn_plan_destroy(p); return rc; }
         }
     }
@@ -2539,7 +2544,7 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
             }
             { const char* e = getenv("MSHGNN_STAMPS"); a.stamps = e ? reinterpret_cast<long long*>((uintptr_t)strtoull(e, nullptr, 0)) : nullptr; }
             ProfScope ps(p, hp.ks_stack_fwd, st);
-            if (p->use_slab) {
+            if (p->slab_for(tiles)) {
                 for (int l = 0; l < hp.L; ++l) a.prog_off[l] = hp.sl_fwd_off[l];
                 hipLaunchKernelGGL(k_slab_fwd<T>, dim3(tiles), dim3(SL_THREADS), (hp.fs_blk + FS_EXTRA_BLK) * Prec<T>::BLK, st, a);
             } else
@@ -2607,7 +2612,7 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
             { const char* e = getenv("MSHGNN_DBG"); a.dbg = e ? atoi(e) : 0; }
             { const char* e = getenv("MSHGNN_STAMPS_BWD"); a.stamps = e ? reinterpret_cast<long long*>((uintptr_t)strtoull(e, nullptr, 0)) : nullptr; }
             ProfScope ps(p, hp.ks_stack_bwd, st);
-            if (p->use_slab) {
+            if (p->slab_for(tiles)) {
                 for (int l = 0; l < hp.L; ++l) a.prog_off[l] = hp.sl_bwd_off[l];
                 hipLaunchKernelGGL(k_slab_bwd<T>, dim3(tiles), dim3(SL_THREADS), (hp.fs_blk + FS_EXTRA_BLK) * Prec<T>::BLK, st, a);
             } else

@@ -269,3 +269,34 @@ def test_step_is_hip_graph_capturable():
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(gflat, ref) and float(loss) == ref_loss
+
+
+@pytest.mark.parametrize("kind,topo,cfg,B", [("c2", "a1-c2", "a1-c2", 8192), ("c2", "a1-c2", "a1-c2", 1000), ("mi", "quadruped-mi", "", 530)])
+def test_slab_and_eight_wave_stack_kernels_agree_bit_for_bit(kind, topo, cfg, B, monkeypatch):
+    """The slab stack kernels (two 4-wave workgroups per CU, destination nodes in two groups) accumulate every node in the same
+    order as the 8-wave stack kernels: outputs and every gradient but the decoder's (whose per-tile partials are summed over 4
+    instead of 8 waves) are identical bits, for full-size and ragged batches."""
+    _require_gpu()
+    from morphsym_hgnn_amd import engine as eng, synth
+    spec = helpers.make_spec(kind, topo, cfg, 128, 3, grf=3 if kind == "c2" else 1)
+    n_y = spec.out_channels * spec.num_nodes[spec.out_type]
+    x_dict, y = synth.make_windows(5, B, spec.num_nodes, spec.widths, n_y)
+    params = synth.make_params(5, spec.param_shapes())
+    res = {}
+    for mode in ("2", "0"):
+        monkeypatch.setenv("MSHGNN_SLAB", mode)       # read when the plan is created
+        e = eng.Engine(spec, "bf16")
+        xs = e.cast_inputs(x_dict)
+        yd = y.reshape(-1).to(e.device, torch.float32)
+        flat = eng.flatten_params(spec, params, e.device)
+        out, loss, g = e.step_mse(xs, flat, yd, B)
+        torch.cuda.synchronize()
+        res[mode] = (out.clone(), loss.clone(), g.clone())
+    assert torch.equal(res["2"][0], res["0"][0])
+    ga, gb = eng.unflatten(spec, res["2"][2]), eng.unflatten(spec, res["0"][2])
+    for k in ga:
+        if k.startswith("decoder"):     # summed over 4 instead of 8 per-wave partials per tile: fp32 summation order
+            assert float((ga[k] - gb[k]).abs().max()) <= 2e-6 * float(gb[k].abs().max()), k
+        else:
+            assert torch.equal(ga[k], gb[k]), k
+    assert abs(float(res["2"][1]) - float(res["0"][1])) <= 1e-6 * abs(float(res["0"][1]))
