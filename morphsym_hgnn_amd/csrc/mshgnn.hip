@@ -1659,7 +1659,8 @@ template <typename T, int HS, int Q0>
 __device__ __forceinline__ void slab_group_bwd(const StackArgs& a, const FHdr& bh, const FProg& wp, char* smem, const T* wpack, int wn, int lane,
                                                int slot_arr, const T* gsrc, const T* xact, bool enc_mask, u32x4 (&keep)[HS]) {
     using P = Prec<T>;
-    const int win = c_win(lane), col = wn * 32 + c_oct(lane), w = min(blockIdx.x * P::ROWS + win, a.B - 1);
+    const int lq = opaque(lane);      // per-node global addresses are rebuilt per call: hoisted out of the layer loop they cost ~40 VGPRs and spill
+    const int win = c_win(lq), col = wn * 32 + c_oct(lq), w = min(blockIdx.x * P::ROWS + win, a.B - 1);
     // the accumulators start at the residual term G_{l+1}[n], re-read from the dX_{l+1} stash (written by this wave one layer
     // earlier, or by the decoder backward).  A drain first: stores of the chain / of the previous layer may still be in flight.
     typename P::Acc acc[HS];
@@ -1709,8 +1710,6 @@ template <typename T> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_bw
     const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int w0 = blockIdx.x * P::ROWS, B = a.B, NN = a.NN;
     const T* wpack = reinterpret_cast<const T*>(a.wpack);
-    const int win = c_win(lane), w = w0 + win, col = wn * 32 + c_oct(lane), wc = min(w, B - 1);
-    const bool w_ok = w < B;
     static_assert(sizeof(T) == 2, "fused stack kernels are bf16");
 
     // dX_L tile: only the nodes that are live in the last layer carry a gradient
@@ -1740,6 +1739,11 @@ template <typename T> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_bw
         }
         const int nmlp = bh[FH_NMLP], flags = bh[FH_FLAGS];
         const uint8_t* maskbytes = reinterpret_cast<const uint8_t*>(a.ws + a.mask_off[l]);
+        // lane constants rebuilt per layer from an opaque copy of the lane id: the per-node global addresses derived from them
+        // would otherwise be hoisted out of the layer loop (dozens of VGPRs, spilled)
+        const int lq = opaque(lane);
+        const int win = c_win(lq), w = w0 + win, col = wn * 32 + c_oct(lq), wc = min(w, B - 1);
+        const bool w_ok = w < B;
 
         // mask phase (each lane on the octets it owns): relu nodes are masked in place -> dH_l[n]; group A's accumulators start
         // at the residual term G_{l+1}[n].  Every relu byte and every LDS read is issued before the first use.
