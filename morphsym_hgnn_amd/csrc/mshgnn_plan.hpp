@@ -33,7 +33,9 @@ constexpr int NWG_DEC = 512;             // workgroups of the decoder backward (
 constexpr int DEC_SLAB_FLOATS = 8 * H + 16; // decoder partial: [out_channels<=8][128] + bias[8] + loss partial (+pad)
 constexpr int GW_IPL = 2;                // items per weight-gradient lane (all workgroups advance at the same pace)
 #ifndef GW_TARGET_WGS
-#define GW_TARGET_WGS 1024.0             // workgroups of the weight-gradient kernel (lanes x window parts)
+#define GW_TARGET_WGS 768.0              // workgroups of the weight-gradient kernel (lanes x window parts): 3 resident per CU x 256 CUs, so
+                                         // that the whole grid runs as ONE wave of workgroups (1024: a third of them ran in a second,
+                                         // mostly empty wave: 128 vs 112 us, and more slabs for k_finalize)
 #endif
 
 enum { OP_LOADW = 0, OP_MAC = 1 };
@@ -695,7 +697,7 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
         tgt_lane_end[g] = (int)lanes.size();
     }
     p.n_lanes = (int)lanes.size();
-    p.n_parts = std::max(1, std::min(16, (int)std::lround(GW_TARGET_WGS / std::max(1, p.n_lanes))));   // ~2 per CU: more parts only add slabs (measured)
+    p.n_parts = std::max(1, std::min(16, (int)std::floor(GW_TARGET_WGS / std::max(1, p.n_lanes))));    // never more workgroups than are resident at once
     // XCD placement: cluster -> least-loaded XCD queue (largest clusters first); block b runs queue[b % 8][b / 8]
     std::vector<int> lane_cluster(p.n_lanes), flat_item_cluster;
     for (size_t g = 0; g < tgts.size(); ++g) for (int it : tgts[g].items) flat_item_cluster.push_back(item_cluster[it]);
