@@ -214,11 +214,7 @@ template <typename T> __device__ __forceinline__ void load_bfrag(typename Prec<T
     constexpr int NBV = Prec<T>::NBV;
     const u32x4* base = reinterpret_cast<const u32x4*>(wpack + (size_t)pack * H * H) + (size_t)wv * NBV * 64 + lane;
 #pragma unroll
-#ifdef MSHGNN_HALF_W
-    for (int v = 0; v < NBV / 2; ++v) {      // timing experiment: half the fragment bytes (wrong results)
-#else
     for (int v = 0; v < NBV; ++v) {
-#endif
         const u32x4 x = base[v * 64];
         b.v[v] = __builtin_bit_cast(typename Prec<T>::Vec, x);
     }
@@ -1173,9 +1169,6 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
     const int win = c_win(lane), w = w0 + win, col = wn * 32 + c_oct(lane);
     const bool w_ok = w < B, train = a.training != 0;
 
-    // experiment (MSHGNN_DBG >> 16): stagger the first round of workgroups within an XCD so that the CUs of one L2 are not all in
-    // their weight-streaming phase at the same time
-    { const int sg = a.dbg >> 16; if (sg && blockIdx.x < 256) { const int n = ((blockIdx.x >> 3) & 31) * sg; for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1); } }
     FS_STAMP(0);
     stage_nodes<T>(smem, reinterpret_cast<const T*>(a.tile_in), NN, w0, B, tid);
     __syncthreads();
@@ -1498,9 +1491,6 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
     const T* wpack = reinterpret_cast<const T*>(a.wpack);
     const int win = c_win(lane), w = w0 + win, col = wn * 32 + c_oct(lane), g8 = (lane >> 4) << 3;
     const bool w_ok = w < B;
-    // experiment (MSHGNN_DBG >> 16): stagger the first round of workgroups within an XCD so that the CUs of one L2 are not all in
-    // their weight-streaming phase at the same time
-    { const int sg = a.dbg >> 16; if (sg && blockIdx.x < 256) { const int n = ((blockIdx.x >> 3) & 31) * sg; for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1); } }
 
     FS_STAMP(0);
     // dX_L tile: only the nodes that are live in the last layer carry a gradient
