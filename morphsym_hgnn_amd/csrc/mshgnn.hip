@@ -1651,11 +1651,19 @@ __device__ __forceinline__ void slab_group_bwd(const StackArgs& a, const FHdr& b
     using P = Prec<T>;
     const int lq = opaque(lane);      // per-node global addresses are rebuilt per call: hoisted out of the layer loop they cost ~40 VGPRs and spill
     const int win = c_win(lq), col = wn * 32 + c_oct(lq), w = min(blockIdx.x * P::ROWS + win, a.B - 1);
-    // the accumulators start at the residual term G_{l+1}[n], re-read from the dX_{l+1} stash (written by this wave one layer
-    // earlier, or by the decoder backward).  A drain first: stores of the chain / of the previous layer may still be in flight.
+    // The accumulators start at the residual term G_{l+1}[n].  gsrc == nullptr: `keep` holds it on entry (the packed dX_{l+1} rows
+    // this wave produced one layer earlier, carried in registers).  Otherwise it is re-read from the dX_{l+1} stash, so that it
+    // occupies no registers during the other group's MACs -- a drain first: stores of the chain / of the previous layer may still
+    // be in flight.
     typename P::Acc acc[HS];
-    __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));
-    {
+    if (!gsrc) {
+#pragma unroll
+        for (int u = 0; u < HS; ++u) {
+            if (bh[FH_KIND + Q0 + u] != NK_DEAD && bh[FH_RES + Q0 + u]) unpack_oct(keep[u], acc[u].c[0], acc[u].c[1]);
+            else acc_fill(acc[u], 0.f);
+        }
+    } else {
+        __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));
         u32x4 graw[HS];
 #pragma unroll
         for (int u = 0; u < HS; ++u) {
@@ -1719,6 +1727,19 @@ template <typename T> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_bw
 
     FHdr bhn(a.tables + a.prog_off[a.L - 1], lane);
     FProg wan(a.tables + a.prog_off[a.L - 1] + FH_SIZE, lane), wbn(a.tables + a.prog_off[a.L - 1] + FH_SIZE + FPROG_LEN, lane);
+    // group A's residual term travels from layer to layer in registers (the packed dX rows of the previous epilogue); for the
+    // last layer it is the decoder backward's dX_L
+    u32x4 keepA[SL_HA];
+    {
+        const T* src = reinterpret_cast<const T*>(a.tile_in);
+        const int wq = min(w0 + c_win(lane), B - 1), colq = wn * 32 + c_oct(lane);
+#pragma unroll
+        for (int u = 0; u < SL_HA; ++u) {
+            keepA[u] = u32x4{0, 0, 0, 0};
+            const int n = bhn[FH_SLOTA + u];
+            if (n >= 0 && bhn[FH_KIND + u] != NK_DEAD) keepA[u] = *reinterpret_cast<const u32x4*>(src + act_idx(wq, n, B) + colq);
+        }
+    }
     for (int l = a.L - 1; l >= 0; --l) {
         const FHdr bh = bhn;
         const FProg wa = wan, wb = wbn;
@@ -1810,9 +1831,9 @@ template <typename T> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_bw
         // dX_l[j] = (residual) + dH_j W_rootsum + sum_r sum_{j->i} dH_i W_rel^r, group A then group B
         const T* xact = reinterpret_cast<const T*>(a.ws + a.x_off[0]);
         const bool enc_mask = (flags & FF_ENC_MASK) != 0;
-        u32x4 keepA[SL_HA], keepB[SL_HB];
+        u32x4 keepB[SL_HB];
         const T* gsrc = reinterpret_cast<const T*>(a.ws + a.dx_off[l + 1]);
-        slab_group_bwd<T, SL_HA, 0>(a, bh, wa, smem, wpack, wn, lane, FH_SLOTA, gsrc, xact, enc_mask, keepA);
+        slab_group_bwd<T, SL_HA, 0>(a, bh, wa, smem, wpack, wn, lane, FH_SLOTA, nullptr, xact, enc_mask, keepA);
         slab_group_bwd<T, SL_HB, SL_HA>(a, bh, wb, smem, wpack, wn, lane, FH_SLOTB, gsrc, xact, enc_mask, keepB);
         __syncthreads();   // every wave is done reading dH_l
         __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));
