@@ -1641,37 +1641,24 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
 
 // ------------------------------------------------------------------------------------------------------
 // Slab variant of the backward stack kernel (see k_slab_fwd): wave wn owns columns [32 wn, 32 wn + 32) of every node; the
-// nodes whose dX_l is produced are processed in two groups.  A group's accumulators start at the residual term, re-read
-// from the dX_{l+1} stash (written by this wave one layer earlier, or by the decoder backward) when its turn comes, so
-// that they occupy no registers during the base_transform chain or the other group's MACs.
+// nodes whose dX_l is produced are processed in two groups.  A group's accumulators start at the residual term, which is the
+// packed dX_{l+1} row this wave produced one layer earlier and kept in registers (for the last layer: the decoder
+// backward's dX_L, read once before the loop).
 // ------------------------------------------------------------------------------------------------------
 template <typename T, int HS, int Q0>
 __device__ __forceinline__ void slab_group_bwd(const StackArgs& a, const FHdr& bh, const FProg& wp, char* smem, const T* wpack, int wn, int lane,
-                                               int slot_arr, const T* gsrc, const T* xact, bool enc_mask, u32x4 (&keep)[HS]) {
+                                               int slot_arr, const T* xact, bool enc_mask, u32x4 (&keep)[HS]) {
     using P = Prec<T>;
     const int lq = opaque(lane);      // per-node global addresses are rebuilt per call: hoisted out of the layer loop they cost ~40 VGPRs and spill
     const int win = c_win(lq), col = wn * 32 + c_oct(lq), w = min(blockIdx.x * P::ROWS + win, a.B - 1);
-    // The accumulators start at the residual term G_{l+1}[n].  gsrc == nullptr: `keep` holds it on entry (the packed dX_{l+1} rows
-    // this wave produced one layer earlier, carried in registers).  Otherwise it is re-read from the dX_{l+1} stash, so that it
-    // occupies no registers during the other group's MACs -- a drain first: stores of the chain / of the previous layer may still
-    // be in flight.
+    // The accumulators start at the residual term G_{l+1}[n]: `keep` holds it on entry -- the packed dX_{l+1} rows this wave
+    // produced one layer earlier (or the decoder backward's dX_L), carried in registers from layer to layer.  (Re-reading them
+    // from the stash instead cost 12 us per launch: 70 MB of fabric traffic and an exposed latency per group.)
     typename P::Acc acc[HS];
-    if (!gsrc) {
 #pragma unroll
-        for (int u = 0; u < HS; ++u) {
-            if (bh[FH_KIND + Q0 + u] != NK_DEAD && bh[FH_RES + Q0 + u]) unpack_oct(keep[u], acc[u].c[0], acc[u].c[1]);
-            else acc_fill(acc[u], 0.f);
-        }
-    } else {
-        __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));
-        u32x4 graw[HS];
-#pragma unroll
-        for (int u = 0; u < HS; ++u) {
-            graw[u] = u32x4{0, 0, 0, 0};
-            if (bh[FH_KIND + Q0 + u] != NK_DEAD && bh[FH_RES + Q0 + u]) graw[u] = *reinterpret_cast<const u32x4*>(gsrc + act_idx(w, bh[slot_arr + u], a.B) + col);
-        }
-#pragma unroll
-        for (int u = 0; u < HS; ++u) unpack_oct(graw[u], acc[u].c[0], acc[u].c[1]);
+    for (int u = 0; u < HS; ++u) {
+        if (bh[FH_KIND + Q0 + u] != NK_DEAD && bh[FH_RES + Q0 + u]) unpack_oct(keep[u], acc[u].c[0], acc[u].c[1]);
+        else acc_fill(acc[u], 0.f);
     }
     fs_run<T, HS, 2>(wp, acc, smem, wpack, wn, lane);
     // layer 0: x relu'(X_0) (encoder activation): the X_0 octets of the group are requested back to back (no store is pending here)
@@ -1729,7 +1716,7 @@ template <typename T> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_bw
     FProg wan(a.tables + a.prog_off[a.L - 1] + FH_SIZE, lane), wbn(a.tables + a.prog_off[a.L - 1] + FH_SIZE + FPROG_LEN, lane);
     // group A's residual term travels from layer to layer in registers (the packed dX rows of the previous epilogue); for the
     // last layer it is the decoder backward's dX_L
-    u32x4 keepA[SL_HA];
+    u32x4 keepA[SL_HA], keepB[SL_HB];
     {
         const T* src = reinterpret_cast<const T*>(a.tile_in);
         const int wq = min(w0 + c_win(lane), B - 1), colq = wn * 32 + c_oct(lane);
@@ -1738,6 +1725,12 @@ template <typename T> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_bw
             keepA[u] = u32x4{0, 0, 0, 0};
             const int n = bhn[FH_SLOTA + u];
             if (n >= 0 && bhn[FH_KIND + u] != NK_DEAD) keepA[u] = *reinterpret_cast<const u32x4*>(src + act_idx(wq, n, B) + colq);
+        }
+#pragma unroll
+        for (int u = 0; u < SL_HB; ++u) {
+            keepB[u] = u32x4{0, 0, 0, 0};
+            const int n = bhn[FH_SLOTB + u];
+            if (n >= 0 && bhn[FH_KIND + SL_HA + u] != NK_DEAD) keepB[u] = *reinterpret_cast<const u32x4*>(src + act_idx(wq, n, B) + colq);
         }
     }
     for (int l = a.L - 1; l >= 0; --l) {
@@ -1781,12 +1774,11 @@ template <typename T> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_bw
             const T* t1 = reinterpret_cast<const T*>(a.ws + a.t1_off[l]);
             T* du = reinterpret_cast<T*>(a.ws + a.du_off[l]);
             T* dh = reinterpret_cast<T*>(a.ws + a.dh_off[l]);
-            typename P::BFrag bf, bf1;
+            typename P::BFrag bf;      // one buffer for both weights: a carried residual (72 VGPRs) lives through this chain
             typename P::AFrag af;
             typename P::Acc tm[4];
             u32x4 traw[4], dupk[4];
             load_bfrag<T>(bf, wpack, bh[FH_W2], wn, lane);
-            load_bfrag<T>(bf1, wpack, bh[FH_W1], wn, lane);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 traw[u] = u32x4{0, 0, 0, 0};
@@ -1797,6 +1789,7 @@ template <typename T> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_bw
                     mac(tm[u], af, bf);
                 }
             }
+            load_bfrag<T>(bf, wpack, bh[FH_W1], wn, lane);
             __syncthreads();   // all reads of the dY blocks done
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -1811,7 +1804,7 @@ template <typename T> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_bw
             __syncthreads();
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                if (u < nmlp) { acc_fill(tm[u], 0.f); load_afrag<T>(af, smem, u, lane); mac(tm[u], af, bf1); }
+                if (u < nmlp) { acc_fill(tm[u], 0.f); load_afrag<T>(af, smem, u, lane); mac(tm[u], af, bf); }
             }
             __syncthreads();   // all reads of the dU blocks done
 #pragma unroll
@@ -1831,10 +1824,8 @@ template <typename T> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_bw
         // dX_l[j] = (residual) + dH_j W_rootsum + sum_r sum_{j->i} dH_i W_rel^r, group A then group B
         const T* xact = reinterpret_cast<const T*>(a.ws + a.x_off[0]);
         const bool enc_mask = (flags & FF_ENC_MASK) != 0;
-        u32x4 keepB[SL_HB];
-        const T* gsrc = reinterpret_cast<const T*>(a.ws + a.dx_off[l + 1]);
-        slab_group_bwd<T, SL_HA, 0>(a, bh, wa, smem, wpack, wn, lane, FH_SLOTA, nullptr, xact, enc_mask, keepA);
-        slab_group_bwd<T, SL_HB, SL_HA>(a, bh, wb, smem, wpack, wn, lane, FH_SLOTB, gsrc, xact, enc_mask, keepB);
+        slab_group_bwd<T, SL_HA, 0>(a, bh, wa, smem, wpack, wn, lane, FH_SLOTA, xact, enc_mask, keepA);
+        slab_group_bwd<T, SL_HB, SL_HA>(a, bh, wb, smem, wpack, wn, lane, FH_SLOTB, xact, enc_mask, keepB);
         __syncthreads();   // every wave is done reading dH_l
         __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));
         T* dxo = reinterpret_cast<T*>(a.ws + a.dx_off[l]);
