@@ -1439,6 +1439,7 @@ template <typename T> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_fw
     const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int w0 = blockIdx.x * P::ROWS, B = a.B, NN = a.NN;
     const T* wpack = reinterpret_cast<const T*>(a.wpack);
+    FS_STAMP(0);
 
     {   // X_0 tile -> LDS: thread = (row, 16-byte chunk), one node per pass, 6 loads in flight
         const T* src = reinterpret_cast<const T*>(a.tile_in);
@@ -1457,6 +1458,7 @@ template <typename T> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_fw
         }
     }
     __syncthreads();
+    FS_STAMP(1);
 
     FHdr fhn(a.tables + a.prog_off[0], lane);
     FProg wan(a.tables + a.prog_off[0] + FH_SIZE, lane), wbn(a.tables + a.prog_off[0] + FH_SIZE + FPROG_LEN, lane);
@@ -1472,14 +1474,19 @@ template <typename T> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_fw
         const bool residual = (fh[FH_FLAGS] & FF_RESIDUAL) != 0;
         u32x4 keepA[SL_HA], keepB[SL_HB]; unsigned bitsA[(SL_HA + 3) / 4], bitsB[(SL_HB + 3) / 4];
         slab_group_fwd<T, SL_HA, 0>(a, fh, wa, smem, wpack, wn, lane, FH_SLOTA | (l << 8), 0, residual, keepA, bitsA);
+        FS_STAMP(2 + 4 * l);
         slab_group_fwd<T, SL_HB, SL_HA>(a, fh, wb, smem, wpack, wn, lane, FH_SLOTB | (l << 8), nmlp, residual, keepB, bitsB);
+        FS_STAMP(3 + 4 * l);
         __syncthreads();   // every wave is done reading X_l: the node blocks may be overwritten
+        FS_STAMP(4 + 4 * l);
         __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));      // loads (next header / programs) landed before the stores go out
         slab_group_store<T, SL_HA, 0>(a, fh, smem, wn, lane, FH_SLOTA, l, keepA, bitsA);
         slab_group_store<T, SL_HB, SL_HA>(a, fh, smem, wn, lane, FH_SLOTB, l, keepB, bitsB);
         __syncthreads();
+        FS_STAMP(5 + 4 * l);
     }
     decoder_tail<T, SL_THREADS>(a, smem, tid, lane, wn, w0, B);
+    FS_STAMP(30);
 }
 
 template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_bwd(StackArgs a) {
