@@ -2108,7 +2108,9 @@ __global__ __launch_bounds__(256, GW_WPS) void k_gradw_bf16(GradwArgs a) {
 #endif
     __shared__ __attribute__((aligned(16))) __bf16 Pbuf[1 + GW_DEEP][GWB_KW * GWB_PITCH];
     __shared__ __attribute__((aligned(16))) __bf16 Qbuf[1 + GW_DEEP][GWB_KW * GWB_PITCH];
+    __shared__ __attribute__((aligned(16))) u32x4 mlut[256];       // relu byte -> AND mask of 8 bf16
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    mlut[tid] = chunk_mask_bits<__bf16>(u32x4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, (unsigned)tid);   // (256 threads; visible after the first barrier)
     const int wr = wv >> 1, wc = wv & 1;
     // blocks b and b+8 share an XCD (round-robin dispatch; speed only): lane_order puts the lanes that read the same
     // dH / X rows on one XCD so they share its L2
@@ -2173,14 +2175,22 @@ __global__ __launch_bounds__(256, GW_WPS) void k_gradw_bf16(GradwArgs a) {
             }
         }
     };
+    // Lane-uniform kinds (the items of a lane belong to one target): P needs the relu mask only for items that carry one, Q needs
+    // pad-column clearing and the symmetry sign only when it is an encoder input.  The staging path is VALU-bound next to the
+    // loads (SQ counters: 29 M VALU instructions per launch against 1.4 M MFMAs), so the generic transforms are skipped where
+    // they are the identity, and the 8 relu bits expand to a 16-byte AND mask through a 256-entry table in LDS.
+    const bool p_masked = mbase[0] != nullptr, q_raw_input = qvb[0] != 16 || qvalid[0] != 8 || (qsign[0][0] | qsign[0][1] | qsign[0][2] | qsign[0][3] | qsign[nit == 2][0] | qsign[nit == 2][1] | qsign[nit == 2][2] | qsign[nit == 2][3]) != 0 || qvalid[nit == 2] != 8;
     auto stage_to_lds = [&](const Stage& st, const u32x4 sx, const int qn, __bf16* Ps, __bf16* Qs) {
         if (a.dbg & 2) { asm volatile("" :: "v"(st.pv[0][0]), "v"(st.qv[3][3])); return; }
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int row = r0 + 16 * p;
-            const u32x4 pm = chunk_mask_bits<T>(st.pv[p], st.mw[p]);   // dH = dX . relu bits (all-ones when P is stored as is)
+            u32x4 pm = st.pv[p];
+            if (p_masked) pm &= mlut[st.mw[p] & 0xffu];                 // dH = dX . relu bits
             *reinterpret_cast<u32x4*>(&Ps[row * GWB_PITCH + c * 8]) = pm;
-            *reinterpret_cast<u32x4*>(&Qs[row * GWB_PITCH + c * 8]) = chunk_keep_first<T>(st.qv[p], qn) ^ sx;   // drop pad columns, symmetry sign mask of encoder inputs
+            u32x4 qm = st.qv[p];
+            if (q_raw_input) qm = chunk_keep_first<T>(qm, qn) ^ sx;     // drop pad columns, symmetry sign mask of encoder inputs
+            *reinterpret_cast<u32x4*>(&Qs[row * GWB_PITCH + c * 8]) = qm;
             if (bias_flag) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
