@@ -423,6 +423,7 @@ template <typename T> __global__ __launch_bounds__(256) void k_enc_fwd(EncArgs a
     const int c = tid % P::CPR, r0 = (tid % VPB) / P::CPR, sub = tid / VPB;   // sub is 0 for fp32
     typename P::BFrag bf;
     typename P::AFrag af;
+    const AOff<T> ao(lane);      // fragment offsets once per kernel (the generic load_afrag rebuilds them per call: 14 VALU instructions)
     u32x4 v[MB / BPP][NIT];
     auto fetch = [&](int kc) {
         const int k0 = kc * H + c * P::EPC;
@@ -449,14 +450,15 @@ template <typename T> __global__ __launch_bounds__(256) void k_enc_fwd(EncArgs a
         for (int mi = 0; mi < MB / BPP; ++mi)
 #pragma unroll
             for (int it = 0; it < NIT; ++it)
-                *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(mi * BPP + sub, r0 + it * (256 / P::CPR), c)) = chunk_keep_first<T>(v[mi][it], nv) ^ sx;
+                *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(mi * BPP + sub, r0 + it * (256 / P::CPR), c)) =
+                    (kc + 1 == nkc ? chunk_keep_first<T>(v[mi][it], nv) : v[mi][it]) ^ sx;      // only the last K chunk has pad columns
         __syncthreads();
         load_bfrag<T>(bf, wpack, a.pack0[t] + kc, wv, lane);   // before the prefetch: vmcnt retires in order
         if (kc + 1 < nkc) fetch(kc + 1);   // the next K chunk streams from HBM under this chunk's MFMAs
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
             if (w0 + m * P::ROWS < a.B) {   // uniform
-                load_afrag<T>(af, smem, m, lane);
+                load_afrag<T>(af, smem, m, ao);
                 mac(acc[m], af, bf);
             }
         }
