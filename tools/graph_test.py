@@ -14,8 +14,7 @@ y = torch.randn(B * 12, generator=g).to(dev)
 flat = eng.flatten_params(spec, synth.make_params(0, spec.param_shapes()), dev)
 gflat = torch.empty_like(flat); out = torch.empty(B * 4, 3, dtype=torch.float32, device=dev); loss = torch.empty(1, device=dev)
 def step():
-    e.forward(xs, flat, B, training=True, out=out)
-    e.backward_mse(xs, flat, out, y, B, grad_flat=gflat, loss=loss)
+    e.step_mse(xs, flat, y, B, out=out, grad_flat=gflat, loss=loss)
 for _ in range(5): step()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
