@@ -1041,8 +1041,8 @@ __device__ __forceinline__ void fs_run(const FProg& wp, typename Prec<T>::Acc (&
 }
 
 // decoder (+ fused wrapper MSE and decoder backward) on the X_L tile in LDS: shared tail of k_stack_fwd / k_slab_fwd
-template <typename T, int THREADS>
-__device__ __forceinline__ void decoder_tail(const StackArgs& a, char* smem, int tid, int lane, int wv, int w0, int B) {
+template <typename T, int THREADS, int DMAX>      // DMAX: compile-time bound on the output channels (4 or 8): loops, loads and registers scale with it
+__device__ __forceinline__ void decoder_tail_impl(const StackArgs& a, char* smem, int tid, int lane, int wv, int w0, int B) {
     // decoder on the out-type rows of X_L (hgnn_c2.py:176-189): thread = (node, row, 8-column chunk).  With y (mshgnn_step_mse) the
     // same threads also take the wrapper MSE (gnnLightning.py:633-639) and the decoder backward: dX_L rows to global for
     // k_stack_bwd, and this tile's partial decoder gradients + loss partial into dec_slabs[tile] (summed by k_finalize).
@@ -1051,19 +1051,19 @@ __device__ __forceinline__ void decoder_tail(const StackArgs& a, char* smem, int
         const float* W = a.params + a.off_dec_w;
         const bool fuse = a.y != nullptr;
         T* dxl = reinterpret_cast<T*>(a.ws + a.dx_off[a.L]);
-        float accw[8][8], accb[8], lsum = 0.f;
+        float accw[DMAX][8], accb[DMAX], lsum = 0.f;
         if (fuse) {
 #pragma unroll
-            for (int dd = 0; dd < 8; ++dd) { accb[dd] = 0.f;
+            for (int dd = 0; dd < DMAX; ++dd) { accb[dd] = 0.f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) accw[dd][e] = 0.f; }
         }
         // two nodes per pass, every global load of a pass before its first store: a load waited for while stores are in flight
         // costs a full vmcnt(0) drain (loads and stores retire out of order with respect to each other)
         // (unconditional loads with clamped indices, so that they are issued back to back and waited for once)
-        float Wv[8][8], bv[8];
+        float Wv[DMAX][8], bv[DMAX];
 #pragma unroll
-        for (int dd = 0; dd < 8; ++dd) {
+        for (int dd = 0; dd < DMAX; ++dd) {
             const int dc = min(dd, a.dout - 1);
             const f32x4 wa = *reinterpret_cast<const f32x4*>(W + dc * H + c * 8), wb = *reinterpret_cast<const f32x4*>(W + dc * H + c * 8 + 4);
             Wv[dd][0] = wa[0]; Wv[dd][1] = wa[1]; Wv[dd][2] = wa[2]; Wv[dd][3] = wa[3];
@@ -1071,13 +1071,13 @@ __device__ __forceinline__ void decoder_tail(const StackArgs& a, char* smem, int
             bv[dd] = a.params[a.off_dec_b + dc];
         }
         for (int f0 = tid >> 8; f0 < a.n_out; f0 += 2 * (THREADS / 256)) {
-            float ov[2][8], dxv[2][8], mk[2][8], yv[2][8];
+            float ov[2][DMAX], dxv[2][8], mk[2][DMAX], yv[2][DMAX];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int f = min(f0 + i * (THREADS / 256), a.n_out - 1);
                 const size_t r = (size_t)min(w0 + row, B - 1) * a.n_out + f;
 #pragma unroll
-                for (int dd = 0; dd < 8; ++dd) {
+                for (int dd = 0; dd < DMAX; ++dd) {
                     const int dc = min(dd, a.dout - 1);
                     mk[i][dd] = a.out_mask[f * a.dout + dc];
                     yv[i][dd] = fuse ? a.y[r * a.dout + dc] : 0.f;
@@ -1094,7 +1094,7 @@ __device__ __forceinline__ void decoder_tail(const StackArgs& a, char* smem, int
                 for (int e = 0; e < 8; ++e) dxv[i][e] = 0.f;
                 const bool ok = live && w0 + row < B;
 #pragma unroll
-                for (int dd = 0; dd < 8; ++dd) {
+                for (int dd = 0; dd < DMAX; ++dd) {
                     ov[i][dd] = 0.f;
                     if (dd < a.dout && live) {
                         float sum = 0.f;
@@ -1121,7 +1121,7 @@ __device__ __forceinline__ void decoder_tail(const StackArgs& a, char* smem, int
                 const size_t r = (size_t)(w0 + row) * a.n_out + f;
                 if (c == 0 && ok) {
 #pragma unroll
-                    for (int dd = 0; dd < 8; ++dd) if (dd < a.dout) a.out[r * a.dout + dd] = ov[i][dd];
+                    for (int dd = 0; dd < DMAX; ++dd) if (dd < a.dout) a.out[r * a.dout + dd] = ov[i][dd];
                 }
                 if (fuse && ok) store8<T>(dxl + act_idx(w0 + row, a.node0 + f, B) + c * 8, dxv[i]);
             }
@@ -1129,7 +1129,7 @@ __device__ __forceinline__ void decoder_tail(const StackArgs& a, char* smem, int
         if (fuse) {
             // reduce over the 4 rows of the wave (lanes 16 apart), then over the 8 waves through LDS (the X tile is dead after the barrier)
 #pragma unroll
-            for (int dd = 0; dd < 8; ++dd) {
+            for (int dd = 0; dd < DMAX; ++dd) {
                 if (dd < a.dout) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { accw[dd][e] += __shfl_xor(accw[dd][e], 16, 64); accw[dd][e] += __shfl_xor(accw[dd][e], 32, 64); }
@@ -1141,7 +1141,7 @@ __device__ __forceinline__ void decoder_tail(const StackArgs& a, char* smem, int
             float* red = reinterpret_cast<float*>(smem);          // [8 waves][8 H + 16]
             if (lane < 16) {
 #pragma unroll
-                for (int dd = 0; dd < 8; ++dd) {
+                for (int dd = 0; dd < DMAX; ++dd) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) red[wv * DEC_SLAB_FLOATS + dd * H + lane * 8 + e] = accw[dd][e];
                     if (lane == 0) red[wv * DEC_SLAB_FLOATS + 8 * H + dd] = accb[dd];
@@ -1159,6 +1159,12 @@ __device__ __forceinline__ void decoder_tail(const StackArgs& a, char* smem, int
             }
         }
     }
+}
+
+template <typename T, int THREADS>
+__device__ __forceinline__ void decoder_tail(const StackArgs& a, char* smem, int tid, int lane, int wv, int w0, int B) {
+    if (a.dout <= 4) decoder_tail_impl<T, THREADS, 4>(a, smem, tid, lane, wv, w0, B);
+    else decoder_tail_impl<T, THREADS, 8>(a, smem, tid, lane, wv, w0, B);
 }
 
 template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_fwd(StackArgs a) {
