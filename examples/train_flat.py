@@ -51,16 +51,17 @@ def train(steps=200, batch=8192, dtype="bf16", layers=3, lr=1e-3, rows=100_000, 
     metrics = StepMetrics(regression=True, device=dev)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     losses = []
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for step in range(1, steps + 1):
+    warm = 5       # untimed: code-object load, workspace allocation, RCCL channel set-up
+    for step in range(1, steps + warm + 1):
+        if step == warm + 1:
+            torch.cuda.synchronize(); t0 = time.perf_counter()
         starts = torch.randint(0, len(store), (batch,), generator=gen, device=dev)
         xs, y, _ = store.assemble(starts, reuse_buffers=True)
-        e.forward(xs, flat, batch, training=True, out=out)
-        e.backward_mse(xs, flat, out, y.view(-1), batch, grad_flat=gflat, loss=loss)
+        e.step_mse(xs, flat, y.view(-1), batch, out=out, grad_flat=gflat, loss=loss)     # forward + MSE + backward in one call
         if dist is not None:
             dist.all_reduce(gflat)
         e.adam_step(flat, gflat, m, v, step, lr, grad_scale=1.0 / world)
-        if step % log_every == 0 or step == 1 or step == steps:
+        if step % log_every == 0 or step == 1 or step == steps + warm:
             metrics.calculate_losses_step(y, out.view(batch, 12))
             losses.append((step, float(loss.item()), float(metrics.rmse_loss.item())))
             if rank == 0 and not quiet:

@@ -94,6 +94,8 @@ typedef struct mshgnn_info {
     double bytes_in;              /* input bytes / window at the plan dtype                            */
     int32_t n_gradw_workgroups;   /* split-K workgroups of the weight-gradient kernel                  */
     int32_t n_launches_fwd, n_launches_bwd;
+    int32_t kernel_sets;          /* bit 0: fused stack kernels (bf16 plan), bit 1: slab stack kernels (two 4-wave workgroups per
+                                     CU; used for batches of >= 1.5 tiles per CU) -- what the plan allows, before env overrides    */
     int64_t grad_split;           /* two-phase step (mshgnn_step_mse_phase): gradients [grad_split, n_flat) are final after
                                      phase 0, [0, grad_split) (the encoder's) after phase 1; -1: the plan has no split       */
 } mshgnn_info;

@@ -77,8 +77,9 @@ enum { FH_NSEG = 0, FH_NMLP, FH_W1, FH_W2, FH_B1, FH_B2, FH_FLAGS, FH_MLP0,   //
 // a weight pack goes through the CU's vector L1 once per tile instead of once per wave half (the stack kernels' MAC phase is
 // bound by that path: DESIGN.md section 6).  To keep the accumulators in registers the destination nodes are processed in two
 // groups, one after the other: A = the node type with the most nodes (<= SL_HA), B = all other nodes (<= SL_HB); group A's
-// results wait, packed, while group B is multiplied.  Wave programs as above with 2 bits of MAC count per slot.
+// results wait, packed, while group B is multiplied.  Wave programs as above with 2 (group A) / 3 (group B) bits of MAC count per slot.
 constexpr int SL_HA = 12, SL_HB = 6, SL_THREADS = 256;
+constexpr int SL_CBA = 2, SL_CBB = 3;    // bits of MAC count per slot and segment in group A / B programs (12 x 2, 6 x 3 bits)
 enum { FF_RESIDUAL = 1, FF_ENC_MASK = 2 };
 
 // buffer ids used by weight-gradient items
@@ -508,8 +509,9 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
                     for (size_t u = 0; u < slots.size(); ++u) {
                         int c = 0;
                         for (auto& m : sg.macs) if (m.first == slots[u]) { blocks.push_back(m.second); ++c; }
-                        if (c > 3) ok = false;
-                        cw |= (c & 3) << (2 * u);
+                        const int cb = phase == 0 ? SL_CBA : SL_CBB;     // bits of MAC count per slot
+                        if (c >= (1 << cb)) ok = false;
+                        cw |= c << (cb * (int)u);
                     }
                     counts.push_back(cw); packs.push_back(sg.pack);
                 }
@@ -820,6 +822,7 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
     p.info.bytes_in = bytes; p.info.n_gradw_workgroups = p.n_wg_gradw;
     p.info.n_launches_fwd = 3 + L; p.info.n_launches_bwd = 3 + L;
     p.info.grad_split = p.grad_split;
+    p.info.kernel_sets = (p.fused ? 1 : 0) | (p.slab ? 2 : 0);
 
     // ---- per-kernel work table (launch order of one fwd+bwd step) -----------------------------------------
     {

@@ -33,6 +33,25 @@ def test_plan_compiler_work_counts():
     assert k4.total_nodes == 20 and k4.lds_bytes == 160 * 1024   # fp32: no spare LDS, base_transform re-uses its own blocks
 
 
+def test_plan_compiler_kernel_sets():
+    """Which stack-kernel variants a plan allows: fp32 plans use the per-layer kernels; bf16 plans the fused stack kernels, and the
+    slab variant (two 4-wave workgroups of <= 80 KB LDS per CU, <= 12 + 6 accumulator slots) where the topology fits."""
+    c2 = helpers.make_spec("c2", "a1-c2", "a1-c2", 128, 3)
+    assert engine.compile_plan_host(c2, "f32").kernel_sets == 0
+    assert engine.compile_plan_host(c2, "bf16").kernel_sets == 3
+    assert engine.compile_plan_host(helpers.make_spec("c2", "a1-c2", "a1-c2", 128, 8), "bf16").kernel_sets == 3
+    mi = helpers.make_spec("mi", "quadruped-mi", "", 128, 2, grf=1)
+    assert engine.compile_plan_host(mi, "bf16").kernel_sets == 3
+    k4 = helpers.make_spec("k4", "mini_cheetah-k4", "mini_cheetah-k4", 128, 8, regression=False)
+    assert engine.compile_plan_host(k4, "bf16").kernel_sets == 1        # 20 nodes + 4 scratch blocks = 96 KB: one workgroup per CU only
+    for kind, topo, cfg in (("k4_com", "solo-k4-com", "solo-k4-com"), ("c2_com", "solo-c2-com", "solo-c2-com")):
+        try:
+            spec = helpers.make_spec(kind, topo, cfg, 128, 2)
+        except Exception:
+            continue
+        assert engine.compile_plan_host(spec, "bf16").kernel_sets & 1
+
+
 def test_plan_compiler_rejects_bad_descriptors():
     spec = helpers.make_spec("c2", "a1-c2", "a1-c2", 64, 2)   # hidden != 128
     with pytest.raises(engine.MshgnnError, match="128"):
