@@ -344,6 +344,37 @@ template <typename T> __global__ void k_prep(PrepArgs a) {
 // k_enc_fwd: X_0[node] = relu((mask . x) W_enc^T + b)      (hgnn_c2.py:143-147)
 // one workgroup = MB row blocks (MB*ROWS windows) of ONE node; K streamed in chunks of 128 through LDS
 // ------------------------------------------------------------------------------------------------------
+// relu bits: one byte per (node, window, 8-feature group) -- exactly the 8 accumulator elements one lane of the layer / stack
+// kernels owns, so the writer needs no cross-lane exchange: bytes [NN][4 column slices][ceil(B/16) tiles][4 groups][16 windows]
+// (a wave's store is 64 contiguous bytes).  Bit j of the byte of (n, w, f0) <-> feature f0 + j, f0 a multiple of 8.
+__device__ __forceinline__ size_t relu_byte(int n, int B, int w, int f) {
+    return ((((size_t)n * 4 + (f >> 5)) * ((B + 15) >> 4) + (w >> 4)) << 6) + (((f >> 3) & 3) << 4) + (w & 15);
+}
+// relu of one accumulator in place + its 8 relu bits, on the integer pipe: for a float x (no NaNs), max_i32(bits(x), 0) is
+// relu(x) (negative floats and -0 are negative integers), and y > 0 <=> y + 0x7fffffff has its top bit set; v_alignbit
+// shifts that bit into the byte.  2 + 1 instructions per element, no compares / VCC hazards.
+// base of the 64 relu bytes of (node n, column slice wn) in tile `tile`; the byte of lane (g, w & 15) is at + lane
+__device__ __forceinline__ size_t relu_tile_base(int n, int B, int tile, int wn) { return (((size_t)n * 4 + wn) * ((B + 15) >> 4) + tile) << 6; }
+__device__ __forceinline__ void unpack_oct(u32x4 r, f32x4& lo, f32x4& hi) {     // 8 bf16 -> two f32x4
+    lo = f32x4{__builtin_bit_cast(float, r[0] << 16), __builtin_bit_cast(float, r[0] & 0xffff0000u),
+               __builtin_bit_cast(float, r[1] << 16), __builtin_bit_cast(float, r[1] & 0xffff0000u)};
+    hi = f32x4{__builtin_bit_cast(float, r[2] << 16), __builtin_bit_cast(float, r[2] & 0xffff0000u),
+               __builtin_bit_cast(float, r[3] << 16), __builtin_bit_cast(float, r[3] & 0xffff0000u)};
+}
+template <typename T>
+__device__ __forceinline__ unsigned relu_with_bits(typename Prec<T>::Acc& acc) {
+    unsigned bits = 0;
+#pragma unroll
+    for (int fb = 1; fb >= 0; --fb)
+#pragma unroll
+        for (int j = 3; j >= 0; --j) {
+            const float xf = acc.c[fb][j];      // (hipcc 7.2 miscompiles __builtin_bit_cast applied directly to a vector element)
+            const int y = max(__float_as_int(xf), 0);
+            acc.c[fb][j] = __int_as_float(y);
+            bits = __builtin_amdgcn_alignbit(bits, (unsigned)y + 0x7fffffffu, 31);
+        }
+    return bits;
+}
 struct EncArgs {
     const void* x[MSHGNN_MAX_TYPES]; int64_t pitch[MSHGNN_MAX_TYPES]; int vb[MSHGNN_MAX_TYPES];
     int width[MSHGNN_MAX_TYPES], nodes[MSHGNN_MAX_TYPES], tbase[MSHGNN_MAX_TYPES], nkc[MSHGNN_MAX_TYPES];
@@ -351,6 +382,7 @@ struct EncArgs {
     int n_types, tiles, B, NN;
     int aligned;   // every input row starts 16-byte aligned and its pitch is a whole number of 16-byte chunks
     const void* wpack; const float* bias; const uint8_t* signs; void* x0;
+    uint8_t* mask0;   // training: relu bytes of X_0 (one byte per lane, as the layer masks), read by the backward stack kernels at layer 0
 };
 
 // load up to EPC elements starting at p with the widest vector the alignment `vb` (bytes) allows
@@ -468,7 +500,11 @@ template <typename T> __global__ __launch_bounds__(256) void k_enc_fwd(EncArgs a
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
         const int w = w0 + m * P::ROWS + c_win(lane);
-        if (w < a.B) store_oct(x0 + act_idx(w, gnode, a.B) + wv * 32 + c_oct(lane), relu4(acc[m].c[0]), relu4(acc[m].c[1]));
+        if (w0 + m * P::ROWS < a.B) {     // uniform: the 16-window block exists (rows past the batch land in the mask buffer's padding)
+            const unsigned bits = relu_with_bits<T>(acc[m]);
+            if (a.mask0) a.mask0[relu_tile_base(gnode, a.B, (w0 + m * P::ROWS) >> 4, wv) + lane] = (uint8_t)bits;
+        }
+        if (w < a.B) store_oct(x0 + act_idx(w, gnode, a.B) + wv * 32 + c_oct(lane), acc[m].c[0], acc[m].c[1]);
     }
 }
 
@@ -488,37 +524,6 @@ struct LayerArgs {
                            // backward: 16 no stage-1 loads/stores, 32 no base_transform chain, 64 no stage-2 epilogues
 };
 
-// relu bits: one byte per (node, window, 8-feature group) -- exactly the 8 accumulator elements one lane of the layer / stack
-// kernels owns, so the writer needs no cross-lane exchange: bytes [NN][4 column slices][ceil(B/16) tiles][4 groups][16 windows]
-// (a wave's store is 64 contiguous bytes).  Bit j of the byte of (n, w, f0) <-> feature f0 + j, f0 a multiple of 8.
-__device__ __forceinline__ size_t relu_byte(int n, int B, int w, int f) {
-    return ((((size_t)n * 4 + (f >> 5)) * ((B + 15) >> 4) + (w >> 4)) << 6) + (((f >> 3) & 3) << 4) + (w & 15);
-}
-// relu of one accumulator in place + its 8 relu bits, on the integer pipe: for a float x (no NaNs), max_i32(bits(x), 0) is
-// relu(x) (negative floats and -0 are negative integers), and y > 0 <=> y + 0x7fffffff has its top bit set; v_alignbit
-// shifts that bit into the byte.  2 + 1 instructions per element, no compares / VCC hazards.
-// base of the 64 relu bytes of (node n, column slice wn) in tile `tile`; the byte of lane (g, w & 15) is at + lane
-__device__ __forceinline__ size_t relu_tile_base(int n, int B, int tile, int wn) { return (((size_t)n * 4 + wn) * ((B + 15) >> 4) + tile) << 6; }
-__device__ __forceinline__ void unpack_oct(u32x4 r, f32x4& lo, f32x4& hi) {     // 8 bf16 -> two f32x4
-    lo = f32x4{__builtin_bit_cast(float, r[0] << 16), __builtin_bit_cast(float, r[0] & 0xffff0000u),
-               __builtin_bit_cast(float, r[1] << 16), __builtin_bit_cast(float, r[1] & 0xffff0000u)};
-    hi = f32x4{__builtin_bit_cast(float, r[2] << 16), __builtin_bit_cast(float, r[2] & 0xffff0000u),
-               __builtin_bit_cast(float, r[3] << 16), __builtin_bit_cast(float, r[3] & 0xffff0000u)};
-}
-template <typename T>
-__device__ __forceinline__ unsigned relu_with_bits(typename Prec<T>::Acc& acc) {
-    unsigned bits = 0;
-#pragma unroll
-    for (int fb = 1; fb >= 0; --fb)
-#pragma unroll
-        for (int j = 3; j >= 0; --j) {
-            const float xf = acc.c[fb][j];      // (hipcc 7.2 miscompiles __builtin_bit_cast applied directly to a vector element)
-            const int y = max(__float_as_int(xf), 0);
-            acc.c[fb][j] = __int_as_float(y);
-            bits = __builtin_amdgcn_alignbit(bits, (unsigned)y + 0x7fffffffu, 31);
-        }
-    return bits;
-}
 template <typename T>
 __device__ __forceinline__ void store_relu_bits(const typename Prec<T>::Acc& acc, unsigned* maskbits, int NN, int n, int w0, int B, int wn, int lane) {
     unsigned bits = 0;
@@ -929,6 +934,7 @@ struct StackArgs {
     const float* params; const float* out_mask; float* out; int64_t off_dec_w, off_dec_b; int node0, n_out, dout;   // fused decoder (fwd)
     // mshgnn_step_mse: the forward also takes the wrapper MSE and the decoder backward (dX_L rows, decoder partial gradients, loss partial)
     const float* y; float* dec_slabs; float inv_n;
+    size_t mask0_off;    // bwd: relu bytes of the encoder activation X_0 in the workspace (0: not available, X_0 rows are read)
     long long* stamps;   // timing experiments (MSHGNN_STAMPS): wave 0 of every workgroup records clock64() at phase boundaries
 };
 #ifdef MSHGNN_SEG_STAMPS
@@ -1640,10 +1646,16 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
             if (n < NN && bh[FH_OUT + n]) {
                 f32x4 y0 = acc[u].c[0], y1 = acc[u].c[1];
                 if ((flags & FF_ENC_MASK) && w_ok) {   // layer 0: x relu'(X_0)  (encoder activation)
-                    f32x4 x0, x1;
-                    load_oct(xact + act_idx(w, n, B) + col, x0, x1);
+                    if (a.mask0_off) {      // the encoder's relu byte of this lane
+                        const unsigned xb = reinterpret_cast<const uint8_t*>(a.ws + a.mask0_off)[relu_byte(n, B, w, wn * 32 + g8)];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { y0[j] = x0[j] > 0.f ? y0[j] : 0.f; y1[j] = x1[j] > 0.f ? y1[j] : 0.f; }
+                        for (int j = 0; j < 4; ++j) { y0[j] = ((xb >> j) & 1u) ? y0[j] : 0.f; y1[j] = ((xb >> (4 + j)) & 1u) ? y1[j] : 0.f; }
+                    } else {
+                        f32x4 x0, x1;
+                        load_oct(xact + act_idx(w, n, B) + col, x0, x1);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { y0[j] = x0[j] > 0.f ? y0[j] : 0.f; y1[j] = x1[j] > 0.f ? y1[j] : 0.f; }
+                    }
                 }
                 if (l > 0) lds_store_oct<T>(smem, n, win, col, y0, y1);
                 if (w_ok) store_oct(dxo + act_idx(w, n, B) + col, y0, y1);
@@ -1676,30 +1688,23 @@ __device__ __forceinline__ void slab_group_bwd(const StackArgs& a, const FHdr& b
         else acc_fill(acc[u], 0.f);
     }
     fs_run<T, HS, (Q0 == 0 ? SL_CBA : SL_CBB)>(wp, acc, smem, wpack, wn, lane);
-    // layer 0: x relu'(X_0) (encoder activation): the X_0 octets of the group are requested back to back (no store is pending here)
-    u32x4 xraw[HS];
+    // layer 0: x relu'(X_0) (encoder activation) from the encoder's relu bytes (one per lane, written by k_enc_fwd): a byte per
+    // node instead of the 16-byte X_0 octet (38 MB per launch, 4 VGPRs per node), all requested back to back
+    const uint8_t* m0 = reinterpret_cast<const uint8_t*>(a.ws + a.mask0_off);
+    unsigned xb[HS];
     if (enc_mask) {
 #pragma unroll
         for (int u = 0; u < HS; ++u) {
-            xraw[u] = u32x4{0, 0, 0, 0};
-            if (bh[FH_OUT + Q0 + u]) xraw[u] = *reinterpret_cast<const u32x4*>(xact + act_idx(w, bh[slot_arr + u], a.B) + col);
+            xb[u] = 0;
+            if (bh[FH_OUT + Q0 + u]) xb[u] = m0[relu_tile_base(bh[slot_arr + u], a.B, blockIdx.x, wn) + lq];
         }
     }
 #pragma unroll
     for (int u = 0; u < HS; ++u) {
         keep[u] = u32x4{0, 0, 0, 0};
         if (bh[FH_OUT + Q0 + u]) {
-            f32x4 y0 = acc[u].c[0], y1 = acc[u].c[1];
-            if (enc_mask) {
-                // bf16 x > 0  <=>  its 16-bit pattern, as a signed integer, is > 0
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const unsigned r = xraw[u][j], r2 = xraw[u][2 + j];
-                    y0[2 * j] = (int)(r << 16) > 0 ? y0[2 * j] : 0.f;  y0[2 * j + 1] = (int)(r & 0xffff0000u) > 0 ? y0[2 * j + 1] : 0.f;
-                    y1[2 * j] = (int)(r2 << 16) > 0 ? y1[2 * j] : 0.f; y1[2 * j + 1] = (int)(r2 & 0xffff0000u) > 0 ? y1[2 * j + 1] : 0.f;
-                }
-            }
-            keep[u] = pack_oct(y0, y1);
+            const u32x4 pk = pack_oct(acc[u].c[0], acc[u].c[1]);
+            keep[u] = enc_mask ? chunk_mask_bits<T>(pk, xb[u]) : pk;
         }
     }
 }
@@ -2553,6 +2558,7 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
             a.wg_prefix[t + 1] = a.wg_prefix[t] + d.type_nodes[t] * a.tiles;
         }
         a.wpack = ws + lay.wpack; a.bias = reinterpret_cast<const float*>(ws + lay.bias); a.signs = p->d_signs; a.x0 = ws + lay.x[0];
+        a.mask0 = (training && lay.dd[0]) ? reinterpret_cast<uint8_t*>(ws + lay.dd[0]) : nullptr;
         ProfScope ps(p, hp.ks_enc, st);
         hipLaunchKernelGGL(k_enc_fwd<T>, dim3(a.wg_prefix[hp.NT]), dim3(256), Prec<T>::ENC_MB * Prec<T>::BLK, st, a);
     }
@@ -2640,6 +2646,7 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
             for (int l = 0; l < hp.L; ++l) { a.mask_off[l] = lay.mask[l]; a.t1_off[l] = lay.t1[l]; a.dh_off[l] = lay.dh[l]; a.du_off[l] = lay.du[l]; a.prog_off[l] = hp.fs_bwd_off[l]; }
             a.wpack = ws + lay.wpack; a.bias = reinterpret_cast<const float*>(ws + lay.bias); a.tables = p->d_tables;
             a.B = B; a.NN = hp.NN; a.L = hp.L; a.training = 1;
+            a.mask0_off = lay.dd[0];
             { const char* e = getenv("MSHGNN_DBG"); a.dbg = e ? atoi(e) : 0; }
             { const char* e = getenv("MSHGNN_STAMPS_BWD"); a.stamps = e ? reinterpret_cast<long long*>((uintptr_t)strtoull(e, nullptr, 0)) : nullptr; }
             ProfScope ps(p, hp.ks_stack_bwd, st);

@@ -876,6 +876,7 @@ inline void layout_workspace(const HostPlan& p, int64_t B, int training, mshgnn_
     for (int l = 0; l <= p.L; ++l) o->x[l] = take(act);
     for (int l = 0; l < p.L; ++l) { o->mask[l] = take((size_t)((B + 15) / 16 * 16) * p.NN * 4 * 4); o->hb[l] = take(mlp); o->t1[l] = take(mlp); }
     if (training) {
+        o->dd[0] = take((size_t)((B + 15) / 16 * 16) * p.NN * 4 * 4);     // relu bytes of the encoder activation X_0 (layout as mask[l])
         for (int l = 0; l <= p.L; ++l) o->dx[l] = take(act);
         for (int l = 0; l < p.L; ++l) { o->dh[l] = take(act); o->du[l] = take(mlp); }
         o->slabs = take((size_t)p.n_slabs * SLAB_FLOATS * 4);
