@@ -300,3 +300,31 @@ def test_slab_and_eight_wave_stack_kernels_agree_bit_for_bit(kind, topo, cfg, B,
         else:
             assert torch.equal(ga[k], gb[k]), k
     assert abs(float(res["2"][1]) - float(res["0"][1])) <= 1e-6 * abs(float(res["0"][1]))
+
+
+def test_full_size_batch_properties_bf16():
+    """The same size-independent properties on the throughput plan (bf16, B=8192: slab stack kernels; the two halves of the
+    batch run on the 8-wave stack kernels): every window's output is independent of its batch -- identical bits -- and the
+    gradient of the halves adds up to the gradient of the whole (fp32 summation order only)."""
+    _require_gpu()
+    from morphsym_hgnn_amd import engine as eng, synth
+    spec = helpers.make_spec("c2", "a1-c2", "a1-c2", 128, 3)
+    B = 8192
+    e = eng.Engine(spec, "bf16")
+    x_dict, y = synth.make_windows(9, B, spec.num_nodes, spec.widths, 12)
+    xs = e.cast_inputs(x_dict)
+    yd = y.reshape(-1).to(e.device, torch.float32)
+    flat = eng.flatten_params(spec, synth.make_params(9, spec.param_shapes()), e.device)
+    out, loss, g = e.step_mse(xs, flat, yd, B)
+    out, loss, g = out.clone(), loss.clone(), g.clone()
+    h = B // 2
+    res = []
+    for lo in (0, h):
+        xh = [x.view(B, -1)[lo:lo + h].reshape(h * spec.num_nodes[t], -1).contiguous() for x, t in zip(xs, spec.node_types)]
+        oh, lh, gh = e.step_mse(xh, flat, yd.view(B, -1)[lo:lo + h].reshape(-1).contiguous(), h)
+        res.append((oh.clone(), lh.clone(), gh.clone()))
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat([res[0][0], res[1][0]]), out)
+    # each half's loss / gradient is a mean over h windows: the whole batch is their average
+    assert abs(0.5 * (float(res[0][1]) + float(res[1][1])) - float(loss)) <= 1e-5 * abs(float(loss))
+    assert float((0.5 * (res[0][2] + res[1][2]) - g).abs().max() / g.abs().max()) < 1e-4
