@@ -430,7 +430,9 @@ template <typename T> __device__ __forceinline__ u32x4 sign_xor(const uint8_t* s
     }
 }
 
-template <typename T> __global__ __launch_bounds__(256) void k_enc_fwd(EncArgs a) {
+// ALIGNED: every input row starts 16-byte aligned with a pitch of whole 16-byte chunks (the engine's own input layout): raw
+// 16-byte loads only -- the general element-wise path is compiled out of this instantiation (a third of the kernel's code)
+template <typename T, bool ALIGNED> __global__ __launch_bounds__(256) void k_enc_fwd(EncArgs a) {
     using P = Prec<T>;
     constexpr int MB = P::ENC_MB;                       // row blocks (of 16 windows) per workgroup
     constexpr int VPB = P::ROWS * P::CPR, NIT = VPB / 256 > 0 ? VPB / 256 : 1, BPP = 256 / VPB > 0 ? 256 / VPB : 1;
@@ -465,11 +467,14 @@ template <typename T> __global__ __launch_bounds__(256) void k_enc_fwd(EncArgs a
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int m = mi * BPP + sub, row = r0 + it * (256 / P::CPR), w = w0 + m * P::ROWS + row;
-                v[mi][it] = u32x4{0, 0, 0, 0};
-                if (w < a.B) {
-                    const T* src = x + ((size_t)w * nt + node) * pitch + k0;
-                    if (a.aligned) { if (nvalid > 0) v[mi][it] = *reinterpret_cast<const u32x4*>(src); }   // raw 16-byte load, nothing uses it here
-                    else v[mi][it] = load_chunk<T>(src, nvalid, vb);
+                if constexpr (ALIGNED) {
+                    // unconditional raw 16-byte load (nothing uses it here): rows past the batch re-read the last row, chunks past the
+                    // row's end re-read the K chunk's first one -- the staging pass zeroes both
+                    const T* src = x + ((size_t)min(w, a.B - 1) * nt + node) * pitch + (nvalid > 0 ? k0 : kc * H);
+                    v[mi][it] = *reinterpret_cast<const u32x4*>(src);
+                } else {
+                    v[mi][it] = u32x4{0, 0, 0, 0};
+                    if (w < a.B) v[mi][it] = load_chunk<T>(x + ((size_t)w * nt + node) * pitch + k0, nvalid, vb);
                 }
             }
     };
@@ -2444,10 +2449,10 @@ extern "C" int mshgnn_plan_create(const mshgnn_desc* desc, mshgnn_plan** out) {
     const int lds = hp.n_blk * hp.blk_bytes;
     if (hp.d.dtype == MSHGNN_F32) {
         if ((rc = set_lds_attr(k_layer_fwd<float>, lds)) || (rc = set_lds_attr(k_layer_bwd<float>, lds)) ||
-            (rc = set_lds_attr(k_enc_fwd<float>, Prec<float>::ENC_MB * Prec<float>::BLK))) { mshgnn_plan_destroy(p); return rc; }
+            (rc = set_lds_attr(k_enc_fwd<float, true>, Prec<float>::ENC_MB * Prec<float>::BLK)) || (rc = set_lds_attr(k_enc_fwd<float, false>, Prec<float>::ENC_MB * Prec<float>::BLK))) { mshgnn_plan_destroy(p); return rc; }
     } else {
         if ((rc = set_lds_attr(k_layer_fwd<__bf16>, lds)) || (rc = set_lds_attr(k_layer_bwd<__bf16>, lds)) ||
-            (rc = set_lds_attr(k_enc_fwd<__bf16>, Prec<__bf16>::ENC_MB * Prec<__bf16>::BLK))) { mshgnn_plan_destroy(p); return rc; }
+            (rc = set_lds_attr(k_enc_fwd<__bf16, true>, Prec<__bf16>::ENC_MB * Prec<__bf16>::BLK)) || (rc = set_lds_attr(k_enc_fwd<__bf16, false>, Prec<__bf16>::ENC_MB * Prec<__bf16>::BLK))) { mshgnn_plan_destroy(p); return rc; }
         const char* e = getenv("MSHGNN_FUSED");
         p->use_fused = hp.fused && !(e && atoi(e) == 0);
         if (p->use_fused) {
@@ -2560,7 +2565,8 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
         a.wpack = ws + lay.wpack; a.bias = reinterpret_cast<const float*>(ws + lay.bias); a.signs = p->d_signs; a.x0 = ws + lay.x[0];
         a.mask0 = (training && lay.dd[0]) ? reinterpret_cast<uint8_t*>(ws + lay.dd[0]) : nullptr;
         ProfScope ps(p, hp.ks_enc, st);
-        hipLaunchKernelGGL(k_enc_fwd<T>, dim3(a.wg_prefix[hp.NT]), dim3(256), Prec<T>::ENC_MB * Prec<T>::BLK, st, a);
+        if (a.aligned) hipLaunchKernelGGL((k_enc_fwd<T, true>), dim3(a.wg_prefix[hp.NT]), dim3(256), Prec<T>::ENC_MB * Prec<T>::BLK, st, a);
+        else hipLaunchKernelGGL((k_enc_fwd<T, false>), dim3(a.wg_prefix[hp.NT]), dim3(256), Prec<T>::ENC_MB * Prec<T>::BLK, st, a);
     }
     // 3. layers (+ decoder): one fused launch on the bf16 plan, else one kernel per layer and the decoder kernel
     const int tiles = (B + Prec<T>::ROWS - 1) / Prec<T>::ROWS;
