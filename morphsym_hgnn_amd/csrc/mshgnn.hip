@@ -2117,8 +2117,9 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16* tile, int w_base, int co
 #ifndef GW_WPS
 #define GW_WPS 3
 #endif
-__global__ __launch_bounds__(256, GW_WPS) void k_gradw_bf16(GradwArgs a) {
+template <int IPL> __global__ __launch_bounds__(256, GW_WPS) void k_gradw_bf16(GradwArgs a) {
     using T = __bf16;
+    constexpr int I1 = IPL - 1;       // index of a lane's second item (== 0 with one item per lane)
     // two LDS stages: the staging writes of step s+1 go to the other stage while step s's MFMAs read this one -> one
     // barrier per step and LDS writes overlap the MFMAs
 #ifndef GW_DEEP
@@ -2141,12 +2142,12 @@ __global__ __launch_bounds__(256, GW_WPS) void k_gradw_bf16(GradwArgs a) {
     const int nsteps = (ch1 - ch0) * nit;    // step s -> chunk ch0 + s / nit, item s % nit
     const int c = tid & 15, r0 = tid >> 4;   // staging: 16 chunks of 8 bf16 per row, 16 rows per pass
 
-    // the lane's (<= GW_IPL = 2) items are resolved ONCE into per-thread base pointers: no dependent scalar loads
+    // the lane's (<= IPL) items are resolved ONCE into per-thread base pointers: no dependent scalar loads
     // inside the streaming loop
-    const T* pbase[GW_IPL]; const T* qbase[GW_IPL]; int64_t qstride[GW_IPL]; int qvalid[GW_IPL], qvb[GW_IPL]; u32x4 qsign[GW_IPL];
-    const uint8_t* mbase[GW_IPL];    // relu-bit bytes of the P rows, at window 0 (nullptr: P is used as stored)
+    const T* pbase[IPL]; const T* qbase[IPL]; int64_t qstride[IPL]; int qvalid[IPL], qvb[IPL]; u32x4 qsign[IPL];
+    const uint8_t* mbase[IPL];    // relu-bit bytes of the P rows, at window 0 (nullptr: P is used as stored)
 #pragma unroll
-    for (int i = 0; i < GW_IPL; ++i) {
+    for (int i = 0; i < IPL; ++i) {
         const int* im = a.items + (it0 + min(i, nit - 1)) * ITEM_INTS;
         pbase[i] = reinterpret_cast<const T*>(a.ws + a.buf_off[im[0]]) + act_idx(0, im[2], a.B) + c * 8;
         mbase[i] = im[9] >= 0 ? reinterpret_cast<const uint8_t*>(a.ws + a.buf_off[im[9]]) + relu_byte(im[2], a.B, 0, c * 8) : nullptr;
@@ -2176,11 +2177,11 @@ __global__ __launch_bounds__(256, GW_WPS) void k_gradw_bf16(GradwArgs a) {
     auto fetch = [&](Stage& st, int s) {
         const int w0 = (ch0 + (nit == 2 ? s >> 1 : s)) * GWB_KW;
         const int it = (nit == 2) ? (s & 1) : 0;
-        const T* pb = it ? pbase[1] : pbase[0];
-        const T* qb = it ? qbase[1] : qbase[0];
-        const uint8_t* mb = it ? mbase[1] : mbase[0];
-        const int64_t qs = it ? qstride[1] : qstride[0];
-        const int qn = it ? qvalid[1] : qvalid[0], vb = it ? qvb[1] : qvb[0];
+        const T* pb = it ? pbase[I1] : pbase[0];
+        const T* qb = it ? qbase[I1] : qbase[0];
+        const uint8_t* mb = it ? mbase[I1] : mbase[0];
+        const int64_t qs = it ? qstride[I1] : qstride[0];
+        const int qn = it ? qvalid[I1] : qvalid[0], vb = it ? qvb[I1] : qvb[0];
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int w = w0 + r0 + 16 * p;
@@ -2197,7 +2198,7 @@ __global__ __launch_bounds__(256, GW_WPS) void k_gradw_bf16(GradwArgs a) {
     // pad-column clearing and the symmetry sign only when it is an encoder input.  The staging path is VALU-bound next to the
     // loads (SQ counters: 29 M VALU instructions per launch against 1.4 M MFMAs), so the generic transforms are skipped where
     // they are the identity, and the 8 relu bits expand to a 16-byte AND mask through a 256-entry table in LDS.
-    const bool p_masked = mbase[0] != nullptr, q_raw_input = qvb[0] != 16 || qvalid[0] != 8 || (qsign[0][0] | qsign[0][1] | qsign[0][2] | qsign[0][3] | qsign[nit == 2][0] | qsign[nit == 2][1] | qsign[nit == 2][2] | qsign[nit == 2][3]) != 0 || qvalid[nit == 2] != 8;
+    const bool p_masked = mbase[0] != nullptr, q_raw_input = qvb[0] != 16 || qvalid[0] != 8 || (qsign[0][0] | qsign[0][1] | qsign[0][2] | qsign[0][3] | qsign[nit == 2 ? I1 : 0][0] | qsign[nit == 2 ? I1 : 0][1] | qsign[nit == 2 ? I1 : 0][2] | qsign[nit == 2 ? I1 : 0][3]) != 0 || qvalid[nit == 2 ? I1 : 0] != 8;
     auto stage_to_lds = [&](const Stage& st, const u32x4 sx, const int qn, __bf16* Ps, __bf16* Qs) {
         if (a.dbg & 2) { asm volatile("" :: "v"(st.pv[0][0]), "v"(st.qv[3][3])); return; }
 #pragma unroll
@@ -2237,8 +2238,8 @@ __global__ __launch_bounds__(256, GW_WPS) void k_gradw_bf16(GradwArgs a) {
     // register stages sa / sb hold the global loads of steps s+1, s+2 (in flight under the MFMAs); even steps use LDS
     // stage 0, odd steps LDS stage 1.  Loop invariant at the top of step s: LDS[s&1] holds step s, registers hold s+1 (and
     // s+2 is being fetched).
-    const u32x4 sx1 = nit == 2 ? qsign[1] : qsign[0];
-    const int qn1 = nit == 2 ? qvalid[1] : qvalid[0];
+    const u32x4 sx1 = nit == 2 ? qsign[I1] : qsign[0];
+    const int qn1 = nit == 2 ? qvalid[I1] : qvalid[0];
 #if GW_DEEP
     Stage sa, sb;
     if (nsteps > 0) fetch(sa, 0);
@@ -2277,7 +2278,7 @@ __global__ __launch_bounds__(256, GW_WPS) void k_gradw_bf16(GradwArgs a) {
     for (int s = 0; s < nsteps; ++s) {
         __syncthreads();
         lap(0);      // waited for the previous MFMA phase of every wave
-        stage_to_lds(sa, (nit == 2 && (s & 1)) ? qsign[1] : qsign[0], (nit == 2 && (s & 1)) ? qvalid[1] : qvalid[0], Pbuf[0], Qbuf[0]);
+        stage_to_lds(sa, (nit == 2 && (s & 1)) ? qsign[I1] : qsign[0], (nit == 2 && (s & 1)) ? qvalid[I1] : qvalid[0], Pbuf[0], Qbuf[0]);
         lap(1);      // global loads landed + LDS written
         __syncthreads();
         lap(2);
@@ -2694,7 +2695,8 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
         ProfScope ps(p, hp.ks_gradw, st);
         if (a.n_pad > 0) {
             if constexpr (sizeof(T) == 4) hipLaunchKernelGGL(k_gradw_f32, dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL(k_gradw_bf16, dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a);
+            else if (hp.gw_ipl == 1) hipLaunchKernelGGL(k_gradw_bf16<1>, dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL(k_gradw_bf16<2>, dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a);
         }
     }
     {
