@@ -2099,14 +2099,16 @@ __global__ __launch_bounds__(256) void k_gradw_f32(GradwArgs a) {
 // disjoint 16-bank ranges) and read as MFMA operands with the hardware-transposing ds_read_b64_tr_b16 (guide T10):
 // both operands are K(=window)-strided in memory.  32x32x16 bf16 MFMA, wave = 64x64 of the 128x128 tile.
 constexpr int GWB_KW = 64;
-constexpr int GWB_PITCH = 160;
+constexpr int GWB_PITCH = 128;           // no row padding: 16-byte chunk c of row r lives at chunk slot c ^ 4 (r & 3) instead (the four rows a
+                                         // transposed read touches land in four different 64-byte bank windows, as they did with a 320-byte pitch)
+__device__ __forceinline__ int gwb_elem(int row, int col) { return row * GWB_PITCH + ((((col >> 3) ^ ((row & 3) << 2)) << 3) | (col & 7)); }
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ bf16x8 tr_frag(const __bf16* tile, int w_base, int col_base, int lane) {
     // lane = 16 g + 4 q + p: supplies the address of row q, columns 4p..4p+3 of its group's 4x16 block;
     // receives column (lane & 15) of the 4 rows.  g&1 selects the 16-column half, g>>1 the K half (8 windows).
     const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
-    const __bf16* p0 = tile + (w_base + 8 * (g >> 1) + q) * GWB_PITCH + col_base + 16 * (g & 1) + 4 * pp;
+    const __bf16* p0 = tile + gwb_elem(w_base + 8 * (g >> 1) + q, col_base + 16 * (g & 1) + 4 * pp);     // (row + 4 has the same swizzle)
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0 + 4 * GWB_PITCH));
     typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -2206,10 +2208,10 @@ template <int IPL> __global__ __launch_bounds__(256, GW_WPS) void k_gradw_bf16(G
             const int row = r0 + 16 * p;
             u32x4 pm = st.pv[p];
             if (p_masked) pm &= mlut[st.mw[p] & 0xffu];                 // dH = dX . relu bits
-            *reinterpret_cast<u32x4*>(&Ps[row * GWB_PITCH + c * 8]) = pm;
+            *reinterpret_cast<u32x4*>(&Ps[gwb_elem(row, c * 8)]) = pm;
             u32x4 qm = st.qv[p];
             if (q_raw_input) qm = chunk_keep_first<T>(qm, qn) ^ sx;     // drop pad columns, symmetry sign mask of encoder inputs
-            *reinterpret_cast<u32x4*>(&Qs[row * GWB_PITCH + c * 8]) = qm;
+            *reinterpret_cast<u32x4*>(&Qs[gwb_elem(row, c * 8)]) = qm;
             if (bias_flag) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
