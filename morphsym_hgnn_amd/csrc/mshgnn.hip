@@ -48,6 +48,19 @@ static int set_err(int code, const std::string& m) { g_err = m; return code; }
 extern "C" const char* mshgnn_last_error(void) { return g_err.c_str(); }
 extern "C" const char* mshgnn_version(void) { return "mshgnn 0.1 (gfx950)"; }
 
+// Timing ablations and in-kernel stamps exist only in instrumented builds (make EXTRA=-DMSHGNN_ABLATE, -DMSHGNN_FS_STAMPS, ...):
+// in the product build every ABL() test is the constant false, so the branches fold away and no environment variable can
+// change what the kernels compute.
+#if defined(MSHGNN_GW_STAMPS) && MSHGNN_GW_STAMPS
+#define MSHGNN_GW_STAMPS_BUILD 1
+#else
+#define MSHGNN_GW_STAMPS_BUILD 0
+#endif
+#ifdef MSHGNN_ABLATE
+#define ABL(x) ((x) != 0)
+#else
+#define ABL(x) (false)
+#endif
 // ------------------------------------------------------------------------------------------------------
 // precision traits
 // ------------------------------------------------------------------------------------------------------
@@ -593,13 +606,13 @@ __device__ __forceinline__ void run_segments(WaveProg& wp, int pc0, typename Pre
     typename P::AFrag af;
     for (int s = 0; s < nseg; ++s) {
         const int pack = wp.next();
-        if (!(dbg & 4) || s == 0) load_bfrag<T>(bf, wpack, pack, wn, lane);
+        if (!ABL(dbg & 4) || s == 0) load_bfrag<T>(bf, wpack, pack, wn, lane);
 #pragma unroll
         for (int u = 0; u < P::HS; ++u) {
             const int cnt = wp.next();
             for (int k = 0; k < cnt; ++k) {
                 const int blk = wp.next();
-                if (!(dbg & 2)) {
+                if (!ABL(dbg & 2)) {
                     load_afrag<T>(af, smem, blk, lane);
                     mac(acc[u], af, bf);
                 }
@@ -642,7 +655,7 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, Prec<T>::WPS) 
     const int* pg = a.prog;
     const int ngroups = pg[0];
     WaveProg wp(pg + 1 + ngroups * GH_SIZE + wh * WPROG_LEN, lane);   // the whole layer's MAC program of this wave, loaded once
-    if (!(a.dbg & 1)) stage_nodes<T>(smem, xin, NN, w0, B, tid);
+    if (!ABL(a.dbg & 1)) stage_nodes<T>(smem, xin, NN, w0, B, tid);
     __syncthreads();
 
     typename P::Acc acc[P::HS];
@@ -653,7 +666,7 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, Prec<T>::WPS) 
 #pragma unroll
         for (int u = 0; u < P::HS; ++u) acc_fill(acc[u], 0.f);
         run_segments<T>(wp, gh[GH_PC0 + wh], acc, smem, wpack, wn, lane, a.dbg);
-        if (a.dbg & 8) continue;
+        if ABL(a.dbg & 8) continue;
 #pragma unroll
         for (int u = 0; u < P::HS; ++u) { acc[u].c[0] += bq.b[0]; acc[u].c[1] += bq.b[1]; }
         if (kind == KIND_RELU) {
@@ -773,7 +786,7 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, Prec<T>::WPS) 
                 const int n = nb + i * NPB;
                 nk[i] = n < NN ? node_kind[n] : NK_DEAD;
                 v[i] = u32x4{0, 0, 0, 0}; word[i] = 0;
-                if (nk[i] != NK_DEAD && wr < B && !(a.dbg & 16)) {
+                if (nk[i] != NK_DEAD && wr < B && !ABL(a.dbg & 16)) {
                     v[i] = *reinterpret_cast<const u32x4*>(gtop + act_idx(wr, n, B) + c * EPC);
                     if (nk[i] == NK_RELU) word[i] = reinterpret_cast<const uint8_t*>(a.maskbits)[relu_byte(n, B, wr, c * EPC)];
                 }
@@ -793,7 +806,7 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, Prec<T>::WPS) 
 
     typename P::Acc acc[P::HS];
 
-    if (nmlp > 0 && !(a.dbg & 32)) {
+    if (nmlp > 0 && !ABL(a.dbg & 32)) {
         // dT1 = dY W2 ; dU = dT1 . (T1 > 0) ; dH = dU W1     (backward of base_transform; re-uses the base blocks)
         const T* t1 = reinterpret_cast<const T*>(a.t1);
         T* du = reinterpret_cast<T*>(a.du);
@@ -837,7 +850,7 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, Prec<T>::WPS) 
 #pragma unroll
         for (int u = 0; u < P::HS; ++u) acc_fill(acc[u], 0.f);
         run_segments<T>(wp, gh[GH_PC0 + wh], acc, smem, wpack, wn, lane, a.dbg);
-        if (a.dbg & 64) continue;
+        if ABL(a.dbg & 64) continue;
         if (flags & GF_LDS_EPI) {
             __syncthreads();   // last group: all dH blocks are dead -> stage D through LDS, store whole rows
 #pragma unroll
@@ -985,8 +998,8 @@ __device__ __forceinline__ void fs_walk(const FProg& wp, int sgi, int& pb, typen
             // the MFMAs of this MAC read afn as they issue; the fragment of the NEXT MAC is then read from LDS into the same
             // registers and lands while those MFMAs execute (no second buffer, no register copies)
 #ifdef MSHGNN_ABLATE
-            if (!(dbg & 128)) mac(acc[u], afn, bf);
-            if (!(dbg & 256)) load_afrag<T>(afn, smem, wp.at(++pb), lane);
+            if (!ABL(dbg & 128)) mac(acc[u], afn, bf);
+            if (!ABL(dbg & 256)) load_afrag<T>(afn, smem, wp.at(++pb), lane);
 #else
             mac(acc[u], afn, bf);
             load_afrag<T>(afn, smem, wp.at(++pb), lane);
@@ -1024,7 +1037,7 @@ __device__ __forceinline__ void fs_run(const FProg& wp, typename Prec<T>::Acc (&
     // every path then has the same number of younger loads outstanding, so the compiler's in-order vmcnt waits inside
     // the MAC loops never have to drain the prefetch
 #ifdef MSHGNN_ABLATE
-    if (dbg & 512) {     // both register buffers filled once, no weight streaming inside the layer (timing only, wrong results)
+    if ABL(dbg & 512) {     // both register buffers filled once, no weight streaming inside the layer (timing only, wrong results)
         load_bfrag<T>(bfb, wpack, wp.pack(0), wn, lane);
         for (int sgi = 0; sgi < nseg; sgi += 2) {
             fs_walk<T, HS, CB>(wp, sgi, pb, afn, acc, bfa, smem, ao, dbg);
@@ -1217,15 +1230,15 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
         long long* segclk = a.stamps ? reinterpret_cast<long long*>(smem + (NN + 4) * P::BLK) + (l * 8 + wv) * 16 : nullptr;
         fs_run<T>(wp, acc, smem, wpack, wn, lane, a.dbg, segclk);
 #else
-        if (!(a.dbg & 2)) fs_run<T>(wp, acc, smem, wpack, wn, lane, a.dbg);
+        if (!ABL(a.dbg & 2)) fs_run<T>(wp, acc, smem, wpack, wn, lane, a.dbg);
 #endif
         FS_STAMP(3 + 4 * l);
         __syncthreads();   // every wave is done reading X_l: the node blocks may be overwritten
         FS_STAMP(4 + 4 * l);
-        if (a.dbg & 8) continue;
+        if ABL(a.dbg & 8) continue;
 
         u32x4 hpk[2] = {}, tpk[2] = {};
-        if (nmlp > 0 && !(a.dbg & 64)) {
+        if (nmlp > 0 && !ABL(a.dbg & 64)) {
             // base_transform: Y = W2 relu(W1 H + b1) + b2 on the first nmlp nodes (hgnn_c2.py:117-121,156); scratch blocks NN + i.
             // The H and T1 stashes are kept packed in registers and stored after the chain: a load waited for while stores are in
             // flight costs a full drain of those stores.
@@ -1320,7 +1333,7 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
                                     __builtin_bit_cast(float, r[3] << 16), __builtin_bit_cast(float, r[3] & 0xffff0000u)};
                     }
                     lds_store_oct<T>(smem, n, win, col, y0, y1);
-                    if (train && w_ok && !(a.dbg & 16)) store_oct(xo + act_idx(w, n, B) + col, y0, y1);
+                    if (train && w_ok && !ABL(a.dbg & 16)) store_oct(xo + act_idx(w, n, B) + col, y0, y1);
                 }
             }
         }
@@ -2188,7 +2201,7 @@ template <int IPL> __global__ __launch_bounds__(256, GW_WPS) void k_gradw_bf16(G
         for (int p = 0; p < 4; ++p) {
             const int w = w0 + r0 + 16 * p;
             st.pv[p] = u32x4{0, 0, 0, 0}; st.qv[p] = u32x4{0, 0, 0, 0}; st.mw[p] = 0xffffffffu;
-            if (w < a.B && !(a.dbg & 1)) {
+            if (w < a.B && !ABL(a.dbg & 1)) {
                 st.pv[p] = *reinterpret_cast<const u32x4*>(pb + (size_t)w * H);
                 if (mb) st.mw[p] = mb[((size_t)(w >> 4) << 6) + (w & 15)];
                 if (a.aligned) { if (qn > 0) st.qv[p] = *reinterpret_cast<const u32x4*>(qb + (size_t)w * qs); }   // raw: a use here would serialise the loads
@@ -2202,7 +2215,7 @@ template <int IPL> __global__ __launch_bounds__(256, GW_WPS) void k_gradw_bf16(G
     // they are the identity, and the 8 relu bits expand to a 16-byte AND mask through a 256-entry table in LDS.
     const bool p_masked = mbase[0] != nullptr, q_raw_input = qvb[0] != 16 || qvalid[0] != 8 || (qsign[0][0] | qsign[0][1] | qsign[0][2] | qsign[0][3] | qsign[nit == 2 ? I1 : 0][0] | qsign[nit == 2 ? I1 : 0][1] | qsign[nit == 2 ? I1 : 0][2] | qsign[nit == 2 ? I1 : 0][3]) != 0 || qvalid[nit == 2 ? I1 : 0] != 8;
     auto stage_to_lds = [&](const Stage& st, const u32x4 sx, const int qn, __bf16* Ps, __bf16* Qs) {
-        if (a.dbg & 2) { asm volatile("" :: "v"(st.pv[0][0]), "v"(st.qv[3][3])); return; }
+        if ABL(a.dbg & 2) { asm volatile("" :: "v"(st.pv[0][0]), "v"(st.qv[3][3])); return; }
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int row = r0 + 16 * p;
@@ -2222,7 +2235,7 @@ template <int IPL> __global__ __launch_bounds__(256, GW_WPS) void k_gradw_bf16(G
         }
     };
     auto mfmas = [&](const __bf16* Ps, const __bf16* Qs) {
-        if (a.dbg & 4) return;
+        if ABL(a.dbg & 4) return;
 #pragma unroll
         for (int ks = 0; ks < GWB_KW / 16; ++ks) {
             bf16x8 af[2], bq[2];
@@ -2295,7 +2308,7 @@ template <int IPL> __global__ __launch_bounds__(256, GW_WPS) void k_gradw_bf16(G
     (void)sx1; (void)qn1;
 #endif
     float* slab = a.slabs + (size_t)(part * a.n_lanes + ln) * SLAB_FLOATS;
-    if (!(a.dbg & 8))
+    if (!ABL(a.dbg & 8))
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -2400,9 +2413,20 @@ struct mshgnn_plan {
     bool use_fused = false;             // bf16 plan: fused stack kernels (MSHGNN_FUSED=0 selects the per-layer kernels)
     bool use_slab = false;              // slab variant of the stack kernels (MSHGNN_SLAB=0 selects the 8-wave ones)
     bool slab_force = false; int n_cu = 256;
+    int dbg = 0, dbg_gw = 0;            // timing ablations (instrumented builds only: read once from MSHGNN_DBG / MSHGNN_DBG_GW at plan creation)
     // a slab workgroup has 4 waves for a whole tile: it pays off once there are enough tiles for two workgroups per CU
     bool slab_for(int tiles) const { return use_slab && (slab_force || tiles >= 2 * n_cu * 3 / 4); }
 };
+
+// in-kernel stamp buffers of the instrumented builds (tools/stamps_*.py pass a device pointer through the environment)
+static long long* stamp_ptr(const char* name) {
+#if defined(MSHGNN_FS_STAMPS) || defined(MSHGNN_SEG_STAMPS) || MSHGNN_GW_STAMPS_BUILD
+    const char* e = getenv(name);
+    return e ? reinterpret_cast<long long*>((uintptr_t)strtoull(e, nullptr, 0)) : nullptr;
+#else
+    (void)name; return nullptr;
+#endif
+}
 
 // bracket one kernel launch with events when profiling
 struct ProfScope {
@@ -2435,6 +2459,9 @@ extern "C" int mshgnn_plan_create(const mshgnn_desc* desc, mshgnn_plan** out) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
         delete p; return set_err(MSHGNN_EHIP, "no HIP device: the MS-HGNN engine has no CPU fallback");
     }
+#ifdef MSHGNN_ABLATE
+    { const char* e = getenv("MSHGNN_DBG"); p->dbg = e ? atoi(e) : 0; e = getenv("MSHGNN_DBG_GW"); p->dbg_gw = e ? atoi(e) : 0; }
+#endif
     HostPlan& hp = p->hp;
     auto up = [&](void** dptr, const void* src, size_t bytes) -> int {
         HIPCHK(hipMalloc(dptr, std::max<size_t>(bytes, 16)));
@@ -2581,14 +2608,14 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
             for (int l = 0; l < hp.L; ++l) { a.mask_off[l] = lay.mask[l]; a.hb_off[l] = lay.hb[l]; a.t1_off[l] = lay.t1[l]; a.prog_off[l] = hp.fs_fwd_off[l]; }
             a.wpack = ws + lay.wpack; a.bias = reinterpret_cast<const float*>(ws + lay.bias); a.tables = p->d_tables;
             a.B = B; a.NN = hp.NN; a.L = hp.L; a.training = training;
-            { const char* e = getenv("MSHGNN_DBG"); a.dbg = e ? atoi(e) : 0; }
+            a.dbg = p->dbg;
             a.params = params; a.out_mask = p->d_out_mask; a.out = out; a.off_dec_w = d.off_dec_w; a.off_dec_b = d.off_dec_b;
             a.node0 = hp.type_base[d.out_type]; a.n_out = d.type_nodes[d.out_type]; a.dout = d.out_channels;
             if (y_fused) {
                 a.y = y_fused; a.dec_slabs = reinterpret_cast<float*>(ws + lay.dec_slabs); a.dx_off[hp.L] = lay.dx[hp.L];
                 a.inv_n = 1.0f / (float)((int64_t)B * a.n_out * a.dout);
             }
-            { const char* e = getenv("MSHGNN_STAMPS"); a.stamps = e ? reinterpret_cast<long long*>((uintptr_t)strtoull(e, nullptr, 0)) : nullptr; }
+            a.stamps = stamp_ptr("MSHGNN_STAMPS");
             ProfScope ps(p, hp.ks_stack_fwd, st);
             if (p->slab_for(tiles)) {
                 for (int l = 0; l < hp.L; ++l) a.prog_off[l] = hp.sl_fwd_off[l];
@@ -2604,7 +2631,7 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
         a.x_in = ws + lay.x[l]; a.x_out = ws + lay.x[l + 1]; a.maskbits = reinterpret_cast<unsigned*>(ws + lay.mask[l]);
         a.hb = ws + lay.hb[l]; a.t1 = ws + lay.t1[l]; a.wpack = ws + lay.wpack; a.bias = reinterpret_cast<const float*>(ws + lay.bias);
         a.prog = p->d_tables + hp.fwd_prog_off[l]; a.B = B; a.NN = hp.NN; a.n_mlp = std::max(1, hp.n_mlp);
-        { const char* e = getenv("MSHGNN_DBG"); a.dbg = e ? atoi(e) : 0; }
+        a.dbg = p->dbg;
         ProfScope ps(p, hp.ks_layer_fwd0 + l, st);
         hipLaunchKernelGGL(k_layer_fwd<T>, dim3(tiles), dim3(LAYER_THREADS), hp.n_blk * Prec<T>::BLK, st, a);
     }
@@ -2656,8 +2683,8 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
             a.wpack = ws + lay.wpack; a.bias = reinterpret_cast<const float*>(ws + lay.bias); a.tables = p->d_tables;
             a.B = B; a.NN = hp.NN; a.L = hp.L; a.training = 1;
             a.mask0_off = lay.dd[0];
-            { const char* e = getenv("MSHGNN_DBG"); a.dbg = e ? atoi(e) : 0; }
-            { const char* e = getenv("MSHGNN_STAMPS_BWD"); a.stamps = e ? reinterpret_cast<long long*>((uintptr_t)strtoull(e, nullptr, 0)) : nullptr; }
+            a.dbg = p->dbg;
+            a.stamps = stamp_ptr("MSHGNN_STAMPS_BWD");
             ProfScope ps(p, hp.ks_stack_bwd, st);
             if (p->slab_for(tiles)) {
                 for (int l = 0; l < hp.L; ++l) a.prog_off[l] = hp.sl_bwd_off[l];
@@ -2673,7 +2700,7 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
         a.hb = ws + lay.hb[l]; a.t1 = ws + lay.t1[l]; a.dh = ws + lay.dh[l]; a.du = ws + lay.du[l]; a.x_act = ws + lay.x[0];
         a.wpack = ws + lay.wpack; a.bias = reinterpret_cast<const float*>(ws + lay.bias);
         a.prog = p->d_tables + hp.bwd_prog_off[l]; a.B = B; a.NN = hp.NN; a.n_mlp = std::max(1, hp.n_mlp);
-        { const char* e = getenv("MSHGNN_DBG"); a.dbg = e ? atoi(e) : 0; }
+        a.dbg = p->dbg;
         ProfScope ps(p, hp.ks_layer_bwd0 + (hp.L - 1 - l), st);
         hipLaunchKernelGGL(k_layer_bwd<T>, dim3(tiles), dim3(LAYER_THREADS), hp.n_blk * Prec<T>::BLK, st, a);
     }
@@ -2692,8 +2719,8 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
         a.items = p->d_tables + hp.item_off; a.lanes = p->d_tables + hp.lane_off; a.lane_order = p->d_tables + hp.lane_order_off; a.n_pad = hp.n_lanes_pad;
         if (gw_phase >= 0) { a.lane_order = p->d_tables + hp.order_ph_off[gw_phase]; a.n_pad = hp.npad_ph[gw_phase]; }
         a.signs = p->d_signs; a.slabs = reinterpret_cast<float*>(ws + lay.slabs); a.B = B; a.n_lanes = hp.n_lanes; a.n_parts = hp.n_parts;
-        { const char* e = getenv("MSHGNN_DBG_GW"); a.dbg = e ? atoi(e) : 0; }
-        { const char* e = getenv("MSHGNN_STAMPS_GW"); a.stamps = e ? reinterpret_cast<long long*>((uintptr_t)strtoull(e, nullptr, 0)) : nullptr; }
+        a.dbg = p->dbg_gw;
+        a.stamps = stamp_ptr("MSHGNN_STAMPS_GW");
         ProfScope ps(p, hp.ks_gradw, st);
         if (a.n_pad > 0) {
             if constexpr (sizeof(T) == 4) hipLaunchKernelGGL(k_gradw_f32, dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a);
