@@ -14,6 +14,10 @@ from typing import Dict, Optional
 import torch
 from torch import nn
 
+import builtins
+import io
+import pickle
+
 from . import models
 
 MODEL_CLASSES = {
@@ -22,6 +26,65 @@ MODEL_CLASSES = {
     "heterogeneous_gnn_k4_com": models.COM_HGNN_K4, "heterogeneous_gnn_c2_com": models.COM_HGNN_C2,
     "heterogeneous_gnn_s4_com": models.COM_HGNN_S4,
 }
+
+
+# ---- reading a Lightning .ckpt without Lightning / torch_geometric ---------------------------------------------------
+# The reference wrappers call save_hyperparameters() with no ignore list (gnnLightning.py:444,494,543,596), so
+# ckpt["hyper_parameters"] holds `dummy_batch` (a torch_geometric HeteroData batch) and `activation_fn`.  A plain
+# torch.load(weights_only=False) then needs torch_geometric importable (it is not part of this stack) and runs arbitrary
+# pickle code of a third-party file.  Only `state_dict` and the scalar hyper-parameters are needed here, so the file is
+# read with weights_only=True first and, failing that, with an unpickler that resolves nothing outside an allow-list:
+# every other global (torch_geometric.*, lightning.*, anything else) becomes an inert placeholder object.
+_SAFE_MODULE_PREFIXES = ("torch", "collections", "numpy", "_codecs", "copyreg", "pathlib", "argparse", "typing", "datetime")
+_SAFE_BUILTINS = {"set", "frozenset", "dict", "list", "tuple", "int", "float", "bool", "str", "bytes", "bytearray", "complex",
+                  "slice", "range", "object"}
+
+
+class OpaqueObject:
+    """Stand-in for a pickled object whose class is not on the allow-list (e.g. the wrapper's `dummy_batch`)."""
+
+    def __init__(self, *args, **kwargs):
+        pass
+
+    def __setstate__(self, state):      # the state of a foreign object is dropped, never interpreted
+        pass
+
+    def __call__(self, *args, **kwargs):
+        return OpaqueObject()
+
+    def __repr__(self):
+        return "<OpaqueObject (class not importable / not allow-listed when the checkpoint was read)>"
+
+
+class _RestrictedUnpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        top = module.split(".")[0]
+        if module == "builtins":
+            if name in _SAFE_BUILTINS:
+                return getattr(builtins, name)
+            return OpaqueObject
+        if top in _SAFE_MODULE_PREFIXES:
+            try:
+                return super().find_class(module, name)
+            except (ImportError, AttributeError):
+                return OpaqueObject
+        return OpaqueObject
+
+
+class _restricted_pickle:
+    """`pickle_module` for torch.load: torch subclasses `Unpickler` (storage handling) and calls up into find_class above."""
+    __name__ = "morphsym_hgnn_amd.checkpoint._restricted_pickle"
+    Unpickler = _RestrictedUnpickler
+    load = staticmethod(lambda f, **kw: _RestrictedUnpickler(f, **kw).load())
+    loads = staticmethod(lambda b, **kw: _RestrictedUnpickler(io.BytesIO(b), **kw).load())
+
+
+def read_checkpoint(path) -> dict:
+    """Load a Lightning `.ckpt` (or a bare state_dict file) onto the host without importing what it pickled."""
+    try:
+        return torch.load(path, map_location="cpu", weights_only=True)
+    except Exception:  # noqa: BLE001  (hyper_parameters hold non-tensor objects: fall through to the restricted reader)
+        return torch.load(path, map_location="cpu", weights_only=False, pickle_module=_restricted_pickle)
 
 
 def model_state_dict(ckpt: dict, prefix: str = "model.") -> Dict[str, torch.Tensor]:
@@ -37,7 +100,7 @@ def load_into(model: nn.Module, ckpt, strict: bool = True):
     """Load a checkpoint (path or dict) into one of the drop-in modules: the lazy encoder is materialised from the
     checkpoint's weight shapes first (the reference does this with a dummy forward, gnnLightning.py:593-595)."""
     if not isinstance(ckpt, dict):
-        ckpt = torch.load(ckpt, map_location="cpu", weights_only=False)
+        ckpt = read_checkpoint(ckpt)
     sd = model_state_dict(ckpt)
     for t, lin in model.encoder.lins.items():
         w = sd.get(f"encoder.lins.{t}.weight")
@@ -53,7 +116,7 @@ def model_from_checkpoint(ckpt, model_type: str, data_metadata=None, **overrides
     load its weights.  `overrides` take precedence, exactly like the keyword arguments of `load_from_checkpoint`
     (`symmetry_mode`, `group_operator_path`, `grf_dimension`, ... -- gnnLightning.py:962-990)."""
     if not isinstance(ckpt, dict):
-        ckpt = torch.load(ckpt, map_location="cpu", weights_only=False)
+        ckpt = read_checkpoint(ckpt)
     if model_type not in MODEL_CLASSES:
         raise ValueError(f"unknown model_type {model_type!r}")
     hp = dict(ckpt.get("hyper_parameters", {}))
@@ -74,6 +137,8 @@ def model_from_checkpoint(ckpt, model_type: str, data_metadata=None, **overrides
 
 
 def to_lightning_checkpoint(model: nn.Module, hyper_parameters: Optional[dict] = None, prefix: str = "model.") -> dict:
-    """The inverse: a dict in Lightning's layout that the reference's `load_from_checkpoint` accepts for the weights."""
+    """The inverse: a dict in Lightning's layout whose `state_dict` the reference's wrappers load by name.  The reference's
+    constructors need `dummy_batch` (gnnLightning.py:564-596), which is not stored here: pass it to `load_from_checkpoint`
+    as a keyword argument next to the path, as `evaluate_model` passes its other overrides."""
     return {"state_dict": {prefix + k: v.detach().cpu() for k, v in model.state_dict().items()},
             "hyper_parameters": dict(hyper_parameters or {}), "pytorch-lightning_version": "2.1.0", "epoch": 0, "global_step": 0}

@@ -82,6 +82,14 @@ class _MSHGNNBase(nn.Module):
         self._precision = os.environ.get("MSHGNN_DTYPE", "f32")
         self._group = None
 
+    # ---- copy / pickle: compiled plans (ctypes handles) and device scratch never travel; they are rebuilt lazily ----
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_engines"] = {}
+        state["_flat"] = None
+        state["_checked_batches"] = set()
+        return state
+
     # ---- construction helpers ---------------------------------------------------------------------
     def _build_convs(self, mean_rels):
         self.encoder = pnn.HeteroDictLinear(-1, self.hidden_channels, self._node_types)

@@ -7,8 +7,8 @@ What it does, per case:
      the reference module, runs forward + wrapper reshape + MSE/CE + backward in float64;
   3. runs oracle/ms_hgnn_oracle.py on the same inputs and asserts agreement <= 1e-12 (relative to the
      tensor's max-abs) on the output, the loss and EVERY parameter gradient, plus the exact parameter count;
-  4. writes a small fixture: case config, seed, full output, loss, and for each gradient its L2 norm, sum
-     and 64 sampled entries (indices are a deterministic function of the name).  Inputs and weights are not
+  4. writes a small fixture: case config, seed, full output, loss, and for each gradient its L2 norm, sum,
+     four +-1 random projections and 64 sampled entries (indices are a deterministic function of the name).  Inputs and weights are not
      stored -- tests regenerate them bit-identically from the seed.
 
 Nothing from /root/reference is copied: fixtures hold numbers only.
@@ -71,6 +71,12 @@ def load_reference_module(fname: str):
 def sample_indices(name: str, numel: int, k: int = 64) -> np.ndarray:
     u = synth.det_uniform(7, "idx:" + name, (k,), 0.0, 1.0).numpy()
     return np.minimum((u * numel).astype(np.int64), numel - 1)
+
+
+def projection_signs(name: str, numel: int, k: int = 4) -> np.ndarray:
+    import zlib
+    rng = np.random.Generator(np.random.PCG64(zlib.crc32(("proj:" + name).encode())))
+    return rng.integers(0, 2, size=(k, numel)).astype(np.float64) * 2.0 - 1.0
 
 
 def build_case(case):
@@ -182,6 +188,7 @@ def main():
             fx["gnorm:" + k] = np.array(np.sqrt((flat ** 2).sum()))
             fx["gsum:" + k] = np.array(flat.sum())
             fx["gsample:" + k] = flat[idx]
+            fx["gproj:" + k] = projection_signs(k, flat.size) @ flat      # four +-1 projections (tests/helpers.py draws the same signs)
         np.savez_compressed(os.path.join(ROOT, "tests", "golden", case["name"] + ".npz"), **fx)
         summary[case["name"]] = {"n_params": n_params, "oracle_vs_reference_max_rel_err": worst,
                                  "loss": float(ref_loss)}

@@ -53,6 +53,13 @@ def sample_indices(name, numel, k=64):
     return np.minimum((u * numel).astype(np.int64), numel - 1)
 
 
+def projection_signs(name, numel, k=4):
+    """k deterministic +-1 vectors per tensor (numpy PCG64 seeded from the tensor name): fixture and check draw the same ones."""
+    import zlib
+    rng = np.random.Generator(np.random.PCG64(zlib.crc32(("proj:" + name).encode())))
+    return rng.integers(0, 2, size=(k, numel)).astype(np.float64) * 2.0 - 1.0
+
+
 def oracle_config(spec):
     from oracle import ms_hgnn_oracle as orc
     return orc.OracleConfig(kind=spec.kind, num_layers=spec.num_layers, edge_types=spec.edge_types,
@@ -88,6 +95,13 @@ def check_against_fixture(fx, out, loss, grads, rtol, what=""):
         if e > worst[0]:
             worst = (e, name)
         assert e2 <= rtol, f"{what} grad-norm {name} rel err {e2:.3e} > {rtol}"
+        # sum of all entries (|sum of errors| <= sqrt(N) * L2 error) and, when the fixture has them, four +-1 random projections:
+        # a localized error that the 64 samples miss still moves these
+        e3 = abs(float(g.sum()) - float(fx["gsum:" + name])) / (gn * np.sqrt(g.size))
+        assert e3 <= rtol, f"{what} grad-sum {name} err {e3:.3e} > {rtol}"
+        if "gproj:" + name in fx.files:
+            e4 = float(np.abs(projection_signs(name, g.size) @ g - fx["gproj:" + name]).max()) / gn
+            assert e4 <= 4 * rtol, f"{what} grad-projection {name} err {e4:.3e} > {4 * rtol}"
         assert e1 <= 30 * rtol, f"{what} grad samples {name} err/rms {e1:.3e} > {30 * rtol}"
     return err, worst
 

@@ -27,3 +27,64 @@ def test_lightning_layout_round_trip(tmp_path):
     back = ck.to_lightning_checkpoint(m2, ckpt["hyper_parameters"])
     assert all(torch.equal(back["state_dict"]["model." + k], params[k]) for k in params)
     assert ck.model_state_dict(params).keys() == params.keys()       # bare state_dicts pass through
+
+
+def test_checkpoint_with_foreign_objects_loads_without_importing_them(tmp_path):
+    """The reference's save_hyperparameters() stores `dummy_batch` (a torch_geometric object) and `activation_fn` in the
+    checkpoint; reading it must neither need those modules nor run their pickle code."""
+    import sys
+    import types
+    torch.set_default_dtype(torch.float64)
+    case, spec, fx, x_dict, y, params, ei = helpers.load_case("a1c2_h128_L3_d3_B3")
+    _, cfg = helpers.load_group(case["cfg"])
+    mod = types.ModuleType("torch_geometric_standin_hetero_data")
+
+    class HeteroDataBatch:      # what torch.save pickles by reference to its module
+        def __init__(self):
+            self.payload = {"x": torch.ones(3)}
+    HeteroDataBatch.__module__ = mod.__name__
+    HeteroDataBatch.__qualname__ = "HeteroDataBatch"
+    mod.HeteroDataBatch = HeteroDataBatch
+    sys.modules[mod.__name__] = mod
+    try:
+        ckpt = {"state_dict": {"model." + k: v for k, v in params.items()},
+                "hyper_parameters": {"hidden_channels": 128, "num_layers": 3, "data_metadata": spec.topology.metadata(), "regression": True,
+                                     "activation_fn": torch.nn.ReLU(), "dummy_batch": HeteroDataBatch(), "symmetry_mode": "MorphSym",
+                                     "group_operator_path": cfg, "grf_dimension": 3}}
+        path = tmp_path / "with_dummy_batch.ckpt"
+        torch.save(ckpt, path)
+    finally:
+        del sys.modules[mod.__name__]
+    loaded = ck.read_checkpoint(str(path))
+    assert isinstance(loaded["hyper_parameters"]["dummy_batch"], ck.OpaqueObject)
+    assert isinstance(loaded["hyper_parameters"]["activation_fn"], torch.nn.ReLU)
+    m = ck.model_from_checkpoint(str(path), "heterogeneous_gnn_c2")
+    sd = m.state_dict()
+    assert all(torch.equal(sd[k], params[k]) for k in params)
+
+
+def test_models_deepcopy_and_pickle_after_the_plan_exists():
+    """copy.deepcopy / pickle / torch.save(model) work after the first forward compiled a plan (the reference modules support all
+    three; Lightning's ddp_spawn pickles the module): engine handles and device scratch are dropped and rebuilt lazily."""
+    import copy
+    import ctypes
+    import pickle
+    torch.set_default_dtype(torch.float64)
+    case, spec, fx, x_dict, y, params, ei = helpers.load_case("a1c2_h128_L3_d3_B3")
+    _, cfg = helpers.load_group(case["cfg"])
+    m = models.GRF_HGNN_C2(128, 3, spec.topology.metadata(), symmetry_mode="MorphSym", group_operator_path=cfg)
+    ck.load_into(m, {"state_dict": {"model." + k: v for k, v in params.items()}})
+    m._spec = spec                                           # what the first forward leaves behind ...
+
+    class FakeEngine:                                        # ... next to an engine holding ctypes handles
+        def __init__(self):
+            self.plan = ctypes.c_void_p(1234)
+            self.lib = ctypes.pointer(ctypes.c_int(0))
+    m._engines[("f32", "cuda:0")] = FakeEngine()
+    m._checked_batches.add(3)
+    for clone in (copy.deepcopy(m), pickle.loads(pickle.dumps(m))):
+        assert clone._engines == {} and clone._flat is None and clone._checked_batches == set()
+        assert clone._spec.flat_size() == spec.flat_size()
+        sd = clone.state_dict()
+        assert all(torch.equal(sd[k], params[k]) for k in params)
+    assert len(m._engines) == 1      # the original keeps its plan
