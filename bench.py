@@ -1,33 +1,44 @@
 #!/usr/bin/env python3
-"""bench.py -- graph-windows/sec, fwd + MSE loss + bwd, A1-C2 GRF regression (BASELINE.json metric).
+"""bench.py -- graph-windows/sec, fwd + loss + bwd of the MS-HGNN hot path (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank/GPU)
+  python bench.py --gpus N --steps K --warmup W [--config a1c2|mck4|synth32] [--dtype bf16|x3|f32] [--surface flat|module]
 
-A "step" is one pass of the hot path over one minibatch of synthetic A1-shaped windows that is already
-resident in HBM: forward (encoder, L message-passing layers, decoder) + MSE loss + backward with every
-parameter gradient materialised (mshgnn_step_mse; + the RCCL gradient all-reduce when N > 1).  Prints ONE JSON line on rank 0.
+A "step" is one pass of the hot path over one minibatch of synthetic windows that is already resident in HBM:
+forward (encoder, L message-passing layers, decoder) + wrapper loss + backward with every parameter gradient
+materialised (mshgnn_step_mse / mshgnn_forward + mshgnn_backward_ce), + the RCCL gradient all-reduce (mean over
+ranks) when N > 1.  Prints ONE JSON line on rank 0.
 
-The workload is BASELINE.json configs[1]: A1 C2 GRF regression, h=128, L=3, grf_dimension=3, batch 8192
-time-windows per GPU (weak scaling).  `roofline` is computed for the kernel with the largest share of the
-step, from HIP events recorded around every kernel by the C-ABI (mshgnn_profile_*), in a second pass over
-the same K steps (so the events do not perturb `value`).  `cpu_baseline` times the fp64 oracle (a port of
-the reference's CPU path, oracle/ms_hgnn_oracle.py) on the host cores on a bounded sample (rank 0, N=1).
+Default workload = BASELINE.json configs[1]: A1 C2 GRF regression, bf16, h=128, L=3, grf_dimension=3, 8192
+time-windows per GPU (weak scaling).  `--gpus N` with WORLD_SIZE unset starts the N rank processes itself (fresh
+children, before this process makes any GPU call); under torch.distributed.run it uses the ranks it is given.
+
+Timing: W warm-up steps, then blocks of EXACTLY K steps bracketed by barrier + synchronize on both sides, MAX over
+ranks per block; blocks are repeated until >= 0.5 s have been timed and the MEDIAN block is reported (`timing` holds
+the spread).  `roofline` is computed for the kernel with the largest share of the step from HIP events recorded
+around every kernel by the C-ABI (mshgnn_profile_*) in a separate pass; `roofline.step` prices the WHOLE step against
+SURVEY.md 8(d)'s algorithmic bytes / FLOPs.  `parity_plan` is the same workload on the parity-grade plan (<= 1e-4 of
+the fp64 oracle, checked here on a small batch).  `cpu_baseline` times the fp64 oracle (a port of the reference's CPU
+path, oracle/ms_hgnn_oracle.py) on the host cores on bounded samples (rank 0, N = 1).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK = {  # /opt/skills/guides/MI355X_MICROARCH.md: chip-level parameters
     "hbm_GBs": 8000.0,
-    "mfma_TFLOPs": {"f32": 157.3, "bf16": 2500.0},
+    "mfma_TFLOPs": {"f32": 157.3, "bf16": 2500.0, "x3": 2500.0},
 }
+# algorithmic minimum per A1-C2 window (h=128, T=150, d=3): inputs read once forward and once for the
+# encoder's weight gradients, at the storage precision of the plan; FLOPs with dead nodes counted (the survey's figure)
+SURVEY_8D = {"bytes_in_bf16": 14408.0, "flops_L3": 19.0e6, "flops_L8": 44.6e6}
+PARITY_DTYPE = "x3"           # parity-grade plan reported next to the headline (falls back to f32 where x3 cannot run)
 
 
 def parse():
@@ -35,32 +46,112 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=8192, help="windows per GPU")
-    ap.add_argument("--layers", type=int, default=3)
-    ap.add_argument("--dtype", default=os.environ.get("MSHGNN_BENCH_DTYPE", "bf16"), choices=["f32", "bf16"])
+    ap.add_argument("--config", default="a1c2", choices=["a1c2", "mck4", "synth32"])
+    ap.add_argument("--batch", type=int, default=0, help="windows per GPU (default: 8192 a1c2, 8192 mck4, 1024 synth32)")
+    ap.add_argument("--layers", type=int, default=0, help="message-passing layers (default: 3 a1c2, 8 mck4, 6 synth32)")
+    ap.add_argument("--hidden", type=int, default=0, help="hidden channels (default 128; 512 for synth32)")
+    ap.add_argument("--dtype", default=os.environ.get("MSHGNN_BENCH_DTYPE", "bf16"), choices=["f32", "bf16", "x3"])
+    ap.add_argument("--surface", default="flat", choices=["flat", "module"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the parity-plan / L=8 / module-surface side measurements")
     ap.add_argument("--cpu-batch", type=int, default=1024)
+    ap.add_argument("--min-time", type=float, default=0.5, help="seconds of timed blocks to accumulate")
+    ap.add_argument("--overlap", default=os.environ.get("MSHGNN_BENCH_OVERLAP", "auto"), choices=["auto", "0", "1"])
     return ap.parse_args()
 
 
-def build_spec(layers):
+# ------------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` starts its own ranks (never from a process that has touched the GPU)
+# ------------------------------------------------------------------------------------------------------------------
+def free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n: int, argv, env_extra=None, script=None) -> int:
+    """Start n fresh rank processes of `script` (this file) with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, wait for
+    all of them, relay rank 0's stdout.  Returns the largest exit code."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        env.update(env_extra or {})
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = max(rc, p.wait())
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# workloads
+# ------------------------------------------------------------------------------------------------------------------
+def build_spec(layers=3, config="a1c2", hidden=128):
     import yaml
     from morphsym_hgnn_amd import synth, topology
     from morphsym_hgnn_amd.spec import ModelSpec
-    with open(os.path.join(ROOT, "morphsym_hgnn_amd", "cfg", "a1-c2.yaml")) as f:
-        group = yaml.safe_load(f)
-    return ModelSpec(kind="c2", topology=topology.a1_c2(), hidden=128, num_layers=layers,
-                     widths=synth.feature_widths("c2", True), regression=True, grf_dimension=3, group=group)
+    cfgdir = os.path.join(ROOT, "morphsym_hgnn_amd", "cfg")
+    if config == "a1c2":
+        with open(os.path.join(cfgdir, "a1-c2.yaml")) as f:
+            group = yaml.safe_load(f)
+        return ModelSpec(kind="c2", topology=topology.a1_c2(), hidden=hidden, num_layers=layers,
+                         widths=synth.feature_widths("c2", True), regression=True, grf_dimension=3, group=group)
+    if config == "mck4":      # BASELINE configs[2]: MiniCheetah K4 contact-state classification (train_classification_msgn.py)
+        with open(os.path.join(cfgdir, "mini_cheetah-k4.yaml")) as f:
+            group = yaml.safe_load(f)
+        return ModelSpec(kind="k4", topology=topology.TOPOLOGIES["mini_cheetah-k4"](), hidden=hidden, num_layers=layers,
+                         widths=synth.feature_widths("k4", False), regression=False, grf_dimension=3, group=group)
+    if config == "synth32":   # BASELINE configs[4]: synthetic 32-limb robot, MI-HGNN model (hgnn.py:GRF_HGNN)
+        return ModelSpec(kind="mi", topology=topology.synthetic_limbs(32), hidden=hidden, num_layers=layers,
+                         widths=synth.feature_widths("mi", True), regression=True, grf_dimension=3, group=None)
+    raise ValueError(config)
 
 
-def cpu_baseline(spec, batch, budget_s=24.0):
-    """Oracle (port of the reference CPU path, fp64) timed on the host cores: fwd + MSE + bwd.  The thread count
+def defaults(args):
+    d = {"a1c2": (8192, 3, 128), "mck4": (8192, 8, 128), "synth32": (1024, 6, 512)}[args.config]
+    return (args.batch or d[0], args.layers or d[1], args.hidden or d[2])
+
+
+def oracle_cfg(spec):
+    from oracle import ms_hgnn_oracle as orc
+    return orc.OracleConfig(kind=spec.kind, num_layers=spec.num_layers, edge_types=spec.edge_types, regression=spec.regression,
+                            grf_dimension=spec.grf_dimension, group=spec.group, num_timesteps=spec.num_timesteps)
+
+
+def make_batch(spec, B, seed):
+    """Synthetic windows in the reference's calling convention: one IMU window tiled to every base node,
+    joints ~N(0,1), foot ones (regression) / ~N(0,1) (classification inputs), labels ~N(0,1) or {0,1}."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    nn_, w = spec.num_nodes, spec.widths
+    imu = torch.randn(B, 1, w["base"], generator=g)
+    x = {"base": imu.expand(B, nn_["base"], w["base"]).reshape(B * nn_["base"], w["base"]),
+         "joint": torch.randn(B * nn_["joint"], w["joint"], generator=g)}
+    if "foot" in nn_:
+        x["foot"] = torch.ones(B * nn_["foot"], 1) if w["foot"] == 1 else torch.randn(B * nn_["foot"], w["foot"], generator=g)
+    n_out = nn_[spec.out_type]
+    if spec.regression:
+        y = torch.randn(B * n_out * spec.out_channels, generator=g)
+    else:
+        y = (torch.rand(B, n_out, generator=g) > 0.5).to(torch.int32)
+    return x, y
+
+
+def cpu_baseline(spec, batch, budget_s=20.0, scan=True):
+    """Oracle (port of the reference CPU path, fp64) timed on the host cores: fwd + loss + bwd.  The thread count
     is picked from a short scan (small-matrix torch code does not scale to every core of the host)."""
+    import torch
     from morphsym_hgnn_amd import synth
     from oracle import ms_hgnn_oracle as orc
-    cfg = orc.OracleConfig(kind="c2", num_layers=spec.num_layers, edge_types=spec.edge_types, regression=True,
-                           grf_dimension=3, group=spec.group)
-    x_dict, y = synth.make_windows(1, batch, spec.num_nodes, spec.widths, 12)
+    cfg = oracle_cfg(spec)
+    n_y = spec.out_channels * spec.num_nodes[spec.out_type] if spec.regression else spec.num_nodes[spec.out_type]
+    x_dict, y = synth.make_windows(1, batch, spec.num_nodes, spec.widths, n_y, classification=not spec.regression)
     params = synth.make_params(1, spec.param_shapes())
     ei = spec.topology.edge_index_dict(batch)
 
@@ -72,7 +163,7 @@ def cpu_baseline(spec, batch, budget_s=24.0):
     default_threads = torch.get_num_threads()
     best = (float("inf"), default_threads)
     t_start = time.perf_counter()
-    for n in sorted({8, 16, 32, 64, default_threads}):
+    for n in sorted({8, 16, 32, 64, default_threads}) if scan else [default_threads]:
         if n > default_threads or time.perf_counter() - t_start > budget_s / 2:
             continue
         torch.set_num_threads(n)
@@ -88,104 +179,186 @@ def cpu_baseline(spec, batch, budget_s=24.0):
     times.sort()
     med = times[len(times) // 2]
     return {"value": batch / med, "unit": "windows/s", "cores": best[1], "kind": "port",
-            "sample": f"oracle fp64 fwd+MSE+bwd, A1-C2 h128 L{spec.num_layers}, B={batch}, median of {len(times)} steps, "
+            "sample": f"oracle fp64 fwd+loss+bwd, {spec.kind} h{spec.hidden} L{spec.num_layers}, B={batch}, median of {len(times)} steps, "
                       f"{best[1]} threads (best of a scan; host has {os.cpu_count()} cpus)"}
+
+
+class Workload:
+    """One (spec, plan dtype, batch) on one device: resident inputs + the step closure."""
+
+    def __init__(self, spec, dtype, B, device, seed, dist=None, overlap="auto"):
+        import torch
+        from morphsym_hgnn_amd import engine as eng, synth
+        self.torch, self.dist, self.spec, self.B = torch, dist, spec, B
+        self.e = eng.Engine(spec, dtype=dtype, device=device)
+        x, y = make_batch(spec, B, seed)
+        self.xs = self.e.cast_inputs(x)
+        self.y = y.to(device)
+        self.flat = eng.flatten_params(spec, synth.make_params(0, spec.param_shapes()), device)
+        self.gflat = torch.empty_like(self.flat)
+        self.out = torch.empty(B * spec.num_nodes[spec.out_type], spec.out_channels, dtype=torch.float32, device=device)
+        self.loss = torch.empty(1, dtype=torch.float32, device=device)
+        split = int(self.e.info.grad_split)
+        world = dist.get_world_size() if dist is not None else 1
+        # two-phase step with the all-reduce of everything but the encoder's gradients under the encoder's weight-gradient
+        # launch: "auto" turns it on from 4 ranks (below that the wire time of a 4 MB all-reduce is less than the split costs)
+        self.overlap = dist is not None and split > 0 and spec.regression and (overlap == "1" or (overlap == "auto" and world >= 4))
+        self.split = split
+
+    def step(self):
+        e, dist = self.e, self.dist
+        if not self.spec.regression:      # classification wrapper: forward + fused cross entropy backward
+            e.forward(self.xs, self.flat, self.B, training=True, out=self.out)
+            e.backward_ce(self.xs, self.flat, self.out, self.y, self.B, grad_flat=self.gflat, loss=self.loss)
+            if dist is not None:
+                dist.all_reduce(self.gflat, op=dist.ReduceOp.AVG)
+            return self.loss
+        if not self.overlap:
+            e.step_mse(self.xs, self.flat, self.y, self.B, out=self.out, grad_flat=self.gflat, loss=self.loss)
+            if dist is not None:
+                dist.all_reduce(self.gflat, op=dist.ReduceOp.AVG)     # DDP semantics: mean over ranks (gnnLightning.py:1396-1400)
+            return self.loss
+        # N > 1: the same step in two calls; the all-reduce of everything but the encoder's gradients (83 % of the buffer) runs on
+        # RCCL's stream while this stream computes the encoder's weight gradients, then the encoder's slice follows.  Both
+        # collectives complete inside the step (wait() makes this stream wait for them).
+        e.step_mse_phase(0, self.xs, self.flat, self.y, self.B, self.out, self.gflat, self.loss)
+        w1 = dist.all_reduce(self.gflat[self.split:], op=dist.ReduceOp.AVG, async_op=True)
+        e.step_mse_phase(1, self.xs, self.flat, self.y, self.B, self.out, self.gflat, self.loss)
+        w2 = dist.all_reduce(self.gflat[:self.split], op=dist.ReduceOp.AVG, async_op=True)
+        w1.wait(); w2.wait()
+        return self.loss
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def time_blocks(self, steps, warmup, min_time, max_blocks=200):
+        """-> (median seconds per K-step block, list of all block times), MAX over ranks per block."""
+        torch, dist = self.torch, self.dist
+        for _ in range(warmup):
+            self.step()
+        blocks, total = [], 0.0
+        while len(blocks) < max_blocks and (not blocks or total < min_time):
+            torch.cuda.synchronize(); self.barrier(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.step()
+            torch.cuda.synchronize(); self.barrier(); torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            if dist is not None:
+                t = torch.tensor([dt, total + dt], dtype=torch.float64, device=self.e.device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt, total = float(t[0]), float(t[1])      # every rank sees the same times -> the same number of blocks
+            else:
+                total += dt
+            blocks.append(dt)
+        srt = sorted(blocks)
+        return srt[len(srt) // 2], blocks
+
+    def kernel_stats(self, steps):
+        e = self.e
+        e.profile(True)
+        for _ in range(steps):
+            self.step()
+        self.torch.cuda.synchronize()
+        stats = [s for s in e.profile_read() if s["launches"] > 0]
+        e.profile(False)
+        return stats
+
+
+def parity_error(spec, dtype, device, B=48):
+    """max-abs error / max-abs reference of the output, the loss and every parameter gradient of plan `dtype` against the
+    fp64 oracle on B seeded windows (the GPU tests do this per golden case; this is the in-line evidence for the bench)."""
+    import torch
+    from morphsym_hgnn_amd import engine as eng, synth
+    from oracle import ms_hgnn_oracle as orc
+    n_y = spec.out_channels * spec.num_nodes[spec.out_type]
+    x_dict, y = synth.make_windows(77, B, spec.num_nodes, spec.widths, n_y)
+    params = synth.make_params(77, spec.param_shapes())
+    o_out, o_loss, o_grads = orc.step(oracle_cfg(spec), params, x_dict, spec.topology.edge_index_dict(B), y, B)
+    e = eng.Engine(spec, dtype=dtype, device=device)
+    out, loss, g = e.step_mse(e.cast_inputs(x_dict), eng.flatten_params(spec, params, device), y.reshape(-1).to(device, torch.float32), B)
+    torch.cuda.synchronize()
+    worst = float((out.double().cpu().reshape(-1) - o_out.reshape(-1)).abs().max() / o_out.abs().max())
+    worst = max(worst, abs(float(loss) - float(o_loss)) / abs(float(o_loss)))
+    for k, v in eng.unflatten(spec, g.cpu()).items():
+        m = float(o_grads[k].abs().max())
+        if m > 0:
+            worst = max(worst, float((v.double() - o_grads[k]).abs().max()) / m)
+    return worst
+
+
+def module_surface(spec, B, device, steps, warmup, precision):
+    """The nn.Module surface the reference's Lightning wrappers call (gnnLightning.py:680-722): fp64 x_dict resident on
+    the device -> GRF_HGNN_C2.forward -> MSE -> loss.backward(), parameters as nn.Parameters."""
+    import torch
+    from morphsym_hgnn_amd import models, synth
+    from morphsym_hgnn_amd.checkpoint import load_into
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)      # the reference does (gnnLightning.py:1183)
+    try:
+        cfg = os.path.join(ROOT, "morphsym_hgnn_amd", "cfg", "a1-c2.yaml")
+        m = models.GRF_HGNN_C2(spec.hidden, spec.num_layers, spec.topology.metadata(), symmetry_mode="MorphSym", group_operator_path=cfg)
+        load_into(m, {"state_dict": {"model." + k: v for k, v in synth.make_params(0, spec.param_shapes()).items()}})
+        m.set_precision(precision).to(device)
+        x, y = make_batch(spec, B, 99)
+        x = {k: v.to(device, torch.float64) for k, v in x.items()}
+        y = y.to(device, torch.float64).view(B, -1)
+        ei = spec.topology.edge_index_dict(B, device=device)
+
+        def step():
+            m.zero_grad(set_to_none=True)
+            out = m(dict(x), ei)
+            loss = ((out.flatten() - y.flatten()) ** 2).mean()
+            loss.backward()
+            return loss
+
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+    finally:
+        torch.set_default_dtype(prev)
+    return {"ms_per_step": dt * 1e3, "value": B / dt, "precision": precision,
+            "what": "GRF_HGNN_C2.forward(x_dict fp64 on device, edge_index_dict) + MSE + loss.backward(), nn.Parameter weights"}
 
 
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # not under torch.distributed.run: start the ranks ourselves, as fresh children, BEFORE anything here touches the GPU
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+    rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched through torch.distributed.run (one rank per GPU)")
+    import torch
     dist = None
     if world > 1 or os.environ.get("MSHGNN_BENCH_FORCE_DIST") == "1":   # (FORCE_DIST: a 1-rank RCCL group, to exercise the N > 1 code path on one GPU)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local))
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
 
-    from morphsym_hgnn_amd import engine as eng, synth
-    spec = build_spec(args.layers)
-    e = eng.Engine(spec, dtype=args.dtype, device=device)
-    B = args.batch
-    g = torch.Generator().manual_seed(1234 + rank)
-    # synthetic A1-shaped windows: one IMU window tiled to both base nodes, joints ~N(0,1), foot ones
-    imu = torch.randn(B, 1, 900, generator=g)
-    x = {"base": imu.expand(B, 2, 900).reshape(B * 2, 900), "joint": torch.randn(B * 12, 450, generator=g),
-         "foot": torch.ones(B * 4, 1)}
-    xs = e.cast_inputs(x)
-    y = torch.randn(B * 12, generator=g).to(device)
-    flat = eng.flatten_params(spec, synth.make_params(0, spec.param_shapes()), device)
-    gflat = torch.empty_like(flat)
-    out = torch.empty(B * 4, 3, dtype=torch.float32, device=device)
+    B, L, hidden = defaults(args)
+    spec = build_spec(L, args.config, hidden)
+    wl = Workload(spec, args.dtype, B, device, 1234 + rank, dist, args.overlap)
+    med, blocks = wl.time_blocks(args.steps, args.warmup, args.min_time)
+    value = world * B * args.steps / med
+    loss = float(wl.loss.item())
 
-    loss_buf = torch.empty(1, dtype=torch.float32, device=device)
-
-    split = int(e.info.grad_split)
-    # two-phase step + interleaved all-reduce: OFF by default.  Measured with a 1-rank RCCL group (no wire time): the split
-    # launches and the extra stream hand-offs cost +51 us per step, about what an 8-GPU all-reduce of 3.3 MB could hide, and
-    # more than a 2- or 4-GPU one could -- the plain sequence is at least as fast at this gradient size (4 MB).
-    overlap = dist is not None and split > 0 and os.environ.get("MSHGNN_BENCH_OVERLAP", "0") == "1"
-
-    def step():
-        # forward + MSE + backward through the C-ABI (on the bf16 plan the decoder, the loss and the decoder backward run inside
-        # the fused forward kernel; == mshgnn_forward + mshgnn_backward_mse, checked by tests/test_engine_gpu.py)
-        if not overlap:
-            _, loss, _ = e.step_mse(xs, flat, y, B, out=out, grad_flat=gflat, loss=loss_buf)
-            if dist is not None:
-                dist.all_reduce(gflat)   # RCCL sum over ranks (DDP semantics: mean = sum / world, folded into lr)
-            return loss
-        # N > 1: the same step in two calls; the all-reduce of everything but the encoder's gradients (83 % of the buffer) runs on
-        # RCCL's stream while this stream computes the encoder's weight gradients, then the encoder's slice follows.  Both
-        # collectives complete inside the step (wait() makes this stream wait for them).
-        e.step_mse_phase(0, xs, flat, y, B, out, gflat, loss_buf)
-        w1 = dist.all_reduce(gflat[split:], async_op=True)
-        e.step_mse_phase(1, xs, flat, y, B, out, gflat, loss_buf)
-        w2 = dist.all_reduce(gflat[:split], async_op=True)
-        w1.wait(); w2.wait()
-        return loss_buf
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    value = world * B * args.steps / dt
-
-    # second pass with per-kernel HIP events -> roofline of the dominant kernel
-    e.profile(True)
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    stats = [s for s in e.profile_read() if s["launches"] > 0]
-    e.profile(False)
+    # per-kernel HIP events (separate pass) -> roofline of the dominant kernel
+    stats = wl.kernel_stats(args.steps)
     total_ms = sum(s["total_ms"] for s in stats)
     dom = max(stats, key=lambda s: s["total_ms"])
     avg_s = dom["total_ms"] / dom["launches"] * 1e-3
-    # the two-phase step (N > 1) launches the weight-gradient kernel twice per step: per-launch work = per-step work / launches
-    per_step = max(1, round(dom["launches"] / args.steps))
+    per_step = max(1, round(dom["launches"] / args.steps))      # the two-phase step launches the weight-gradient kernel twice
     dom = dict(dom, flops_per_window=dom["flops_per_window"] / per_step, bytes_per_window=dom["bytes_per_window"] / per_step)
     if dom["bound"] == "mfma":
         achieved = dom["flops_per_window"] * B / avg_s / 1e12
@@ -199,35 +372,80 @@ def main():
     try:
         import glob
         files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
-        if files and args.dtype == "bf16" and B == 8192 and args.layers == 3:
+        if files and args.dtype == "bf16" and args.config == "a1c2" and B == 8192 and L == 3:
             pm = json.load(open(files[-1]))["kernels"]
             key = dom["name"].rstrip("0123456789")
             if key in pm:
-                roof["traffic"] = pm[key]["hbm_bytes"]
+                roof["traffic"] = pm[key]["hbm_bytes"] / per_step
                 roof["traffic_source"] = os.path.basename(files[-1])
     except Exception:  # noqa: BLE001
         pass
-    if roof.get("traffic") is not None:
-        roof["traffic"] = roof["traffic"] / per_step
     roof["kernel"] = dom["name"]
     roof["launches_per_step"] = per_step
     roof["avg_us"] = avg_s * 1e6
     roof["share_of_step"] = dom["total_ms"] / max(total_ms, 1e-9)
+    roof["bytes_per_window_counted"] = dom["bytes_per_window"]
+    step_s = med / args.steps
+    if args.config == "a1c2" and L in (3, 8) and hidden == 128:
+        # the WHOLE step against SURVEY.md 8(d): inputs read once forward + once for the encoder's weight gradients
+        es = {"bf16": 1.0, "x3": 2.0, "f32": 2.0}[args.dtype]
+        sb = 2.0 * SURVEY_8D["bytes_in_bf16"] * es * B
+        sf = SURVEY_8D["flops_L3" if L == 3 else "flops_L8"] * B
+        roof["step"] = {"algorithmic_bytes": sb, "hbm_frac": sb / step_s / 1e9 / PEAK["hbm_GBs"],
+                        "algorithmic_flops": sf, "mfma_frac": sf / step_s / 1e12 / PEAK["mfma_TFLOPs"][args.dtype],
+                        "note": "SURVEY 8(d) per-window figures x windows / measured step time; the per-kernel `frac` above counts that kernel's "
+                                "own operands (stashed activations included), it is not the step-level fraction"}
     kernels = {s["name"]: round(s["total_ms"] / s["launches"] * 1e3, 2) for s in stats}
 
+    names = {"a1c2": "A1-C2 GRF regression (3-D)", "mck4": "MiniCheetah-K4 contact classification", "synth32": "synthetic 32-limb MI-HGNN GRF regression"}
     res = {
-        "metric": "graph-windows/sec fwd+bwd, A1-C2 GRF regression", "value": value, "unit": "windows/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "metric": "graph-windows/sec fwd+bwd, A1-C2 GRF regression" if args.config == "a1c2" else f"graph-windows/sec fwd+bwd, {names[args.config]}",
+        "value": value, "unit": "windows/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"A1-C2 GRF regression (3-D), h=128, L={args.layers}, T=150, {B} windows/GPU, "
-                               f"fwd+MSE+bwd, all parameter gradients" + (", RCCL all-reduce" if world > 1 else ""),
-                   "global_batch": B * world, "parallelism": f"dp{world}"},
+        "config": {"workload": f"{names[args.config]}, h={hidden}, L={L}, T={spec.num_timesteps}, {B} windows/GPU, "
+                               f"fwd+{'MSE' if spec.regression else 'CE'}+bwd, all parameter gradients"
+                               + (f", RCCL all-reduce (mean over {world} ranks{', overlapped two-phase' if wl.overlap else ''})" if dist is not None else ""),
+                   "global_batch": B * world, "parallelism": f"dp{world}", "rccl_ranks": (dist.get_world_size() if dist is not None else 0)},
+        "timing": {"blocks": len(blocks), "block_steps": args.steps, "median_ms": med * 1e3, "min_ms": min(blocks) * 1e3, "max_ms": max(blocks) * 1e3,
+                   "timed_s": sum(blocks)},
         "roofline": roof, "kernel_us": kernels,
-        "algorithmic_flops_per_window": e.info.flops_fwd + e.info.flops_bwd,
-        "loss": float(loss.item()),
+        "algorithmic_flops_per_window": wl.e.info.flops_fwd + wl.e.info.flops_bwd,
+        "loss": loss,
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    extras = rank == 0 and world == 1 and not args.no_extras and args.config == "a1c2" and args.surface == "flat" and hidden == 128
+    if extras:
+        del wl      # free the 0.6 GB workspace before the side measurements
+        torch.cuda.empty_cache()
+        # the same workload on the parity-grade plan (north_star tolerance 1e-4), driver-visible
+        if args.dtype != PARITY_DTYPE:
+            pd = PARITY_DTYPE
+            try:
+                wp = Workload(spec, pd, B, device, 1234)
+            except Exception:  # noqa: BLE001  (plan not available for this topology)
+                pd = "f32"
+                wp = Workload(spec, pd, B, device, 1234)
+            pm, pb = wp.time_blocks(args.steps, args.warmup, args.min_time / 2)
+            pk = {s["name"]: round(s["total_ms"] / s["launches"] * 1e3, 2) for s in wp.kernel_stats(args.steps)}
+            del wp
+            torch.cuda.empty_cache()
+            res["parity_plan"] = {"dtype": pd, "ms_per_step": pm / args.steps * 1e3, "value": B * args.steps / pm,
+                                  "max_rel_err_vs_oracle": parity_error(build_spec(L, args.config, hidden), pd, device),
+                                  "tolerance": 1e-4, "kernel_us": pk,
+                                  "what": "same workload, parity-grade plan: max-abs error / max-abs reference over output, loss and every "
+                                          "parameter gradient against the fp64 oracle on 48 seeded windows"}
+        if L != 8:      # the paper's depth (train_regression-grf_msgn.py:94)
+            w8 = Workload(build_spec(8, args.config, hidden), args.dtype, B, device, 1234)
+            m8, _ = w8.time_blocks(args.steps, args.warmup, args.min_time / 2)
+            del w8
+            torch.cuda.empty_cache()
+            res["L8"] = {"ms_per_step": m8 / args.steps * 1e3, "value": B * args.steps / m8, "dtype": args.dtype}
+        res["module_surface"] = module_surface(spec, B, device, args.steps, args.warmup, args.dtype if args.dtype != "x3" else "x3")
+    if args.surface == "module" and rank == 0 and world == 1:
+        res["module_surface"] = module_surface(spec, B, device, args.steps, args.warmup, args.dtype)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config != "synth32":
         res["cpu_baseline"] = cpu_baseline(spec, args.cpu_batch)
+        res["cpu_baseline_B32"] = cpu_baseline(spec, 32, budget_s=4.0, scan=False)     # the reference's own CPU-runnable case
     if rank == 0:
         print(json.dumps(res))
     if dist is not None:

@@ -24,11 +24,14 @@ from morphsym_hgnn_amd.windows import SequenceStore, quadsdk_a1_c2_recipe  # noq
 
 
 def synthetic_sequence(n_rows: int, seed: int = 0):
+    """A smooth random sequence; `seed` varies the DATA only -- the torque -> GRF map every rank regresses is drawn from a
+    fixed generator, so that all ranks of a data-parallel run fit the same target function."""
     rng = np.random.default_rng(seed)
+    label_rng = np.random.default_rng(20240131)
     smooth = lambda c: np.cumsum(rng.normal(size=(n_rows, c)), axis=0) / np.sqrt(np.arange(1, n_rows + 1))[:, None]
     seq = {"imu_acc": smooth(3), "imu_omega": smooth(3), "q": smooth(12), "qd": smooth(12), "tau": smooth(12),
            "r_o": np.tile([0.0, 0.0, 0.0, 1.0], (n_rows, 1))}
-    seq["F"] = seq["tau"] @ rng.normal(size=(12, 12)) * 0.5 + 0.1 * seq["q"]
+    seq["F"] = seq["tau"] @ label_rng.normal(size=(12, 12)) * 0.5 + 0.1 * seq["q"]
     return seq
 
 
@@ -59,8 +62,8 @@ def train(steps=200, batch=8192, dtype="bf16", layers=3, lr=1e-3, rows=100_000, 
         xs, y, _ = store.assemble(starts, reuse_buffers=True)
         e.step_mse(xs, flat, y.view(-1), batch, out=out, grad_flat=gflat, loss=loss)     # forward + MSE + backward in one call
         if dist is not None:
-            dist.all_reduce(gflat)
-        e.adam_step(flat, gflat, m, v, step, lr, grad_scale=1.0 / world)
+            dist.all_reduce(gflat, op=dist.ReduceOp.AVG)      # DDP semantics: mean over ranks
+        e.adam_step(flat, gflat, m, v, step, lr)
         if step % log_every == 0 or step == 1 or step == steps + warm:
             metrics.calculate_losses_step(y, out.view(batch, 12))
             losses.append((step, float(loss.item()), float(metrics.rmse_loss.item())))

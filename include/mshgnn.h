@@ -15,7 +15,9 @@
  * All device buffers are caller-allocated (e.g. by the torch caching allocator); no ownership transfer.
  * forward/backward are asynchronous on the caller's HIP stream (passed as void* = hipStream_t).  A plan is
  * immutable after creation, so forward/backward are re-entrant from autograd worker threads as long as each
- * call uses its own workspace.
+ * call uses its own workspace.  A workspace carries the activation stash from a forward to its backward: use one
+ * workspace per stream, with the device that owns it current (hipSetDevice) when the entry point is called -- two
+ * forwards on one workspace overwrite each other's stash, whatever streams they run on.
  *
  * Data layout ("dense window-major"): every window graph of a minibatch has the same tiny topology, so the
  * PyG-batched [B*n_type, F] tensors the reference passes are already [B, n_type, F] contiguous; they are

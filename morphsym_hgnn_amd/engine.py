@@ -338,7 +338,8 @@ class Engine:
         if training:
             self._tickets[B] = self._tickets.get(B, 0) + 1
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        _check(self.lib, self.lib.mshgnn_forward(self._plan, ptrs, pitch, params_flat.data_ptr(), out.data_ptr(),
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.mshgnn_forward(self._plan, ptrs, pitch, params_flat.data_ptr(), out.data_ptr(),
                                                  ws.data_ptr(), B, int(training), stream), "mshgnn_forward")
         return out
 
@@ -354,7 +355,8 @@ class Engine:
             self._check_flat(grad_flat, "grad_flat")
         ws = self.workspace(B, True)
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        _check(self.lib, self.lib.mshgnn_backward(self._plan, ptrs, pitch, params_flat.data_ptr(), grad_out.data_ptr(),
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.mshgnn_backward(self._plan, ptrs, pitch, params_flat.data_ptr(), grad_out.data_ptr(),
                                                   grad_flat.data_ptr(), ws.data_ptr(), B, stream), "mshgnn_backward")
         return grad_flat
 
@@ -372,7 +374,8 @@ class Engine:
             loss = torch.empty(1, dtype=torch.float32, device=self.device)
         ws = self.workspace(B, True)
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        _check(self.lib, self.lib.mshgnn_backward_mse(self._plan, ptrs, pitch, params_flat.data_ptr(), out.data_ptr(), y.data_ptr(),
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.mshgnn_backward_mse(self._plan, ptrs, pitch, params_flat.data_ptr(), out.data_ptr(), y.data_ptr(),
                                                       loss.data_ptr(), grad_flat.data_ptr(), ws.data_ptr(), B, stream), "mshgnn_backward_mse")
         return loss, grad_flat
 
@@ -394,7 +397,8 @@ class Engine:
         ws = self.workspace(B, True)
         self._tickets[B] = self._tickets.get(B, 0) + 1      # the activation stash of this batch size is overwritten
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        _check(self.lib, self.lib.mshgnn_step_mse(self._plan, ptrs, pitch, params_flat.data_ptr(), y.data_ptr(), out.data_ptr(), loss.data_ptr(),
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.mshgnn_step_mse(self._plan, ptrs, pitch, params_flat.data_ptr(), y.data_ptr(), out.data_ptr(), loss.data_ptr(),
                                                   grad_flat.data_ptr(), ws.data_ptr(), B, stream), "mshgnn_step_mse")
         return out, loss, grad_flat
 
@@ -408,7 +412,8 @@ class Engine:
         if phase == 0:
             self._tickets[B] = self._tickets.get(B, 0) + 1
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        _check(self.lib, self.lib.mshgnn_step_mse_phase(self._plan, ptrs, pitch, params_flat.data_ptr(), y.data_ptr(), out.data_ptr(),
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.mshgnn_step_mse_phase(self._plan, ptrs, pitch, params_flat.data_ptr(), y.data_ptr(), out.data_ptr(),
                                                         loss.data_ptr(), grad_flat.data_ptr(), ws.data_ptr(), B, phase, stream), "mshgnn_step_mse_phase")
 
     def backward_ce(self, xs: Sequence[torch.Tensor], params_flat: torch.Tensor, out: torch.Tensor, labels: torch.Tensor, B: int,
@@ -425,7 +430,8 @@ class Engine:
             loss = torch.empty(1, dtype=torch.float32, device=self.device)
         ws = self.workspace(B, True)
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        _check(self.lib, self.lib.mshgnn_backward_ce(self._plan, ptrs, pitch, params_flat.data_ptr(), out.data_ptr(), labels.data_ptr(),
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.mshgnn_backward_ce(self._plan, ptrs, pitch, params_flat.data_ptr(), out.data_ptr(), labels.data_ptr(),
                                                      loss.data_ptr(), grad_flat.data_ptr(), ws.data_ptr(), B, stream), "mshgnn_backward_ce")
         return loss, grad_flat
 
@@ -435,7 +441,8 @@ class Engine:
         for t, n in ((params_flat, "params"), (grad_flat, "grads"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
             self._check_flat(t, n)
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        _check(self.lib, self.lib.mshgnn_adam_step(params_flat.data_ptr(), grad_flat.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.mshgnn_adam_step(params_flat.data_ptr(), grad_flat.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
                                                    params_flat.numel(), step, lr, betas[0], betas[1], eps, grad_scale, stream), "mshgnn_adam_step")
 
     def mse_loss(self, out: torch.Tensor, y: torch.Tensor, want_grad: bool = True):
@@ -446,7 +453,8 @@ class Engine:
         loss = torch.empty(1, dtype=torch.float32, device=self.device)
         g = torch.empty_like(out) if want_grad else None
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        _check(self.lib, self.lib.mshgnn_mse_loss(out.data_ptr(), y.data_ptr(), n, loss.data_ptr(),
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.mshgnn_mse_loss(out.data_ptr(), y.data_ptr(), n, loss.data_ptr(),
                                                   g.data_ptr() if g is not None else None, stream), "mshgnn_mse_loss")
         return loss, g
 
