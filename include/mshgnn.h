@@ -24,6 +24,7 @@
  * consumed as-is.  dtype selects storage/operand precision of inputs and activations:
  *   MSHGNN_F32  : fp32 storage, exact-fp32 MFMA (v_mfma_f32_16x16x4_f32)           -- parity mode (1e-4 rel)
  *   MSHGNN_BF16 : bf16 storage + bf16 MFMA operands, fp32 accumulate, fp32 weights  -- throughput mode
+ *   MSHGNN_BF16X3: fp32 inputs, hi/lo bf16 planes, three bf16 MFMA products per term -- parity mode at bf16-MFMA speed
  * Parameters and parameter gradients are always one flat fp32 buffer (offsets given in the descriptor).
  */
 #ifndef MSHGNN_H
@@ -39,6 +40,10 @@ extern "C" {
 #define MSHGNN_MAX_TYPES 4
 #define MSHGNN_F32 0
 #define MSHGNN_BF16 1
+#define MSHGNN_BF16X3 2   /* split-bf16 parity plan: fp32 inputs; every activation stored as two bf16 planes (hi + lo, 16 mantissa
+                             bits); products on the bf16 MFMA as hi*hi + hi*lo + lo*hi, fp32 accumulate -- 1e-4 relative like
+                             MSHGNN_F32 at a multiple of its speed.  Topologies with <= 20 nodes and 2 (nodes + base_transform
+                             nodes) <= 40 (every A1 / Solo graph; MiniCheetah-K4 has 48: use MSHGNN_F32)                         */
 
 #define MSHGNN_OK 0
 #define MSHGNN_EINVAL (-1)      /* bad descriptor / argument */

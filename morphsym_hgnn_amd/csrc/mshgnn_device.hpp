@@ -1,0 +1,815 @@
+// Shared device helpers, argument structs and the plan object of libmshgnn (included by every .hip translation unit of the
+// library: mshgnn.hip = fp32 / bf16 plans + C-ABI, mshgnn_x3.hip = split-bf16 parity plan, mshgnn_gen.hip = generic-width engine).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mshgnn_plan.hpp"
+
+using namespace mshgnn;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// ------------------------------------------------------------------------------------------------------
+// error handling
+// ------------------------------------------------------------------------------------------------------
+inline thread_local std::string g_err;      // one per thread, shared by every translation unit of the library
+inline int set_err(int code, const std::string& m) { g_err = m; return code; }
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return set_err(MSHGNN_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));       \
+    } while (0)
+
+
+
+// Timing ablations and in-kernel stamps exist only in instrumented builds (make EXTRA=-DMSHGNN_ABLATE, -DMSHGNN_FS_STAMPS, ...):
+// in the product build every ABL() test is the constant false, so the branches fold away and no environment variable can
+// change what the kernels compute.
+#if defined(MSHGNN_GW_STAMPS) && MSHGNN_GW_STAMPS
+#define MSHGNN_GW_STAMPS_BUILD 1
+#else
+#define MSHGNN_GW_STAMPS_BUILD 0
+#endif
+#ifdef MSHGNN_ABLATE
+#define ABL(x) ((x) != 0)
+#else
+#define ABL(x) (false)
+#endif
+// ------------------------------------------------------------------------------------------------------
+// precision traits
+// ------------------------------------------------------------------------------------------------------
+template <typename T> struct Prec;
+// Both precisions use window tiles of 16 rows and 16-wide MFMA column blocks; a wave owns 2 column blocks (32 cols).
+//   fp32: v_mfma_f32_16x16x4_f32   (lane group g = lane>>4 owns K range [32g, 32g+32): 8 chunks of 4 floats)
+//   bf16: v_mfma_f32_16x16x32_bf16 (lane group g owns K range [32g, 32g+32): 4 chunks of 8 bf16)
+template <> struct Prec<float> {
+    static constexpr int ROWS = 16, EPC = 4, CPR = 32, RB = 512, NREG = 8, NBV = 16, NAV = 8, HS = 6, BLK = 8192, ENC_MB = 4, WPS = 2;   // WPS: waves/SIMD the layer kernels are built for
+    using Vec = f32x4;
+    struct Acc { f32x4 c[2]; };
+    struct AFrag { f32x4 v[8]; };
+    struct BFrag { f32x4 v[16]; };
+};
+template <> struct Prec<__bf16> {
+    static constexpr int ROWS = 16, EPC = 8, CPR = 16, RB = 256, NREG = 8, NBV = 8, NAV = 4, HS = 4, BLK = 4096, ENC_MB = 4, WPS = 4;   // 2 workgroups of 8 waves per CU (80 KB LDS each)
+    using Vec = bf16x8;
+    struct Acc { f32x4 c[2]; };
+    struct AFrag { bf16x8 v[4]; };
+    struct BFrag { bf16x8 v[8]; };
+};
+
+// Make a lane-dependent value opaque so the compiler cannot hoist the address math derived from it out of the
+// group loop (hoisted per-register epilogue addresses were being spilled to scratch -- guide, Appendix B pitfalls).
+__device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); return x; }
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(__bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ __bf16 from_f32<__bf16>(float v) { return (__bf16)v; }
+
+// Accumulator layout.  The MFMAs are issued as  D^T = W_frag (A operand) x X_frag (B operand), so in the 16x16 C/D map
+// (col = lane&15, row = 4*(lane>>4)+j -- cdna_hip_programming.md section 3) the COLUMN is the window and the ROWS are
+// output features.  k_prep permutes the weight rows of the wave's two 16-row blocks so that MFMA row 4g+j of block fb is
+// feature 8 g + 4 fb + j: lane (w = lane&15, g = lane>>4) then holds the 8 CONSECUTIVE features 8g..8g+7 of window w
+// (c[0] = first four, c[1] = next four), the 4 lane groups of a window cover 32 contiguous features, and epilogue
+// traffic is one 16-byte (bf16) / 32-byte (fp32) vector per lane and accumulator.
+__device__ __forceinline__ int c_win(int lane) { return lane & 15; }
+__device__ __forceinline__ int c_oct(int lane) { return (lane >> 4) << 3; }                            // within the wave's 32 columns
+__device__ __forceinline__ int c_feat(int fb, int lane) { return c_oct(lane) + (fb << 2); }
+
+template <typename A> __device__ __forceinline__ void acc_fill(A& a, float v) {
+    a.c[0] = f32x4{v, v, v, v}; a.c[1] = f32x4{v, v, v, v};
+}
+
+// 4 consecutive elements of T <-> f32x4 (global or LDS; 16-byte aligned for fp32, 8-byte for bf16)
+__device__ __forceinline__ f32x4 load_quad(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 load_quad(const __bf16* p) {
+    const u32x2 r = *reinterpret_cast<const u32x2*>(p);
+    return f32x4{__builtin_bit_cast(float, r[0] << 16), __builtin_bit_cast(float, r[0] & 0xffff0000u),
+                 __builtin_bit_cast(float, r[1] << 16), __builtin_bit_cast(float, r[1] & 0xffff0000u)};
+}
+__device__ __forceinline__ void store_quad(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void store_quad(__bf16* p, f32x4 v) {
+    union { u32x2 r; __bf16 e[4]; } u;
+    u.e[0] = (__bf16)v[0]; u.e[1] = (__bf16)v[1]; u.e[2] = (__bf16)v[2]; u.e[3] = (__bf16)v[3];
+    *reinterpret_cast<u32x2*>(p) = u.r;
+}
+// 8 consecutive elements of T <-> two f32x4 (global: 16-byte aligned for bf16, 32-byte for fp32)
+__device__ __forceinline__ void load_oct(const float* p, f32x4& lo, f32x4& hi) {
+    lo = reinterpret_cast<const f32x4*>(p)[0]; hi = reinterpret_cast<const f32x4*>(p)[1];
+}
+__device__ __forceinline__ void load_oct(const __bf16* p, f32x4& lo, f32x4& hi) {
+    const u32x4 r = *reinterpret_cast<const u32x4*>(p);
+    lo = f32x4{__builtin_bit_cast(float, r[0] << 16), __builtin_bit_cast(float, r[0] & 0xffff0000u),
+               __builtin_bit_cast(float, r[1] << 16), __builtin_bit_cast(float, r[1] & 0xffff0000u)};
+    hi = f32x4{__builtin_bit_cast(float, r[2] << 16), __builtin_bit_cast(float, r[2] & 0xffff0000u),
+               __builtin_bit_cast(float, r[3] << 16), __builtin_bit_cast(float, r[3] & 0xffff0000u)};
+}
+__device__ __forceinline__ void store_oct(float* p, f32x4 lo, f32x4 hi) {
+    reinterpret_cast<f32x4*>(p)[0] = lo; reinterpret_cast<f32x4*>(p)[1] = hi;
+}
+__device__ __forceinline__ void store_oct(__bf16* p, f32x4 lo, f32x4 hi) {
+    union { u32x4 r; __bf16 e[8]; } u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { u.e[j] = (__bf16)lo[j]; u.e[4 + j] = (__bf16)hi[j]; }
+    *reinterpret_cast<u32x4*>(p) = u.r;
+}
+__device__ __forceinline__ u32x4 pack_oct(f32x4 lo, f32x4 hi) {      // the 16 bytes store_oct(__bf16*) writes
+    union { u32x4 r; __bf16 e[8]; } u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { u.e[j] = (__bf16)lo[j]; u.e[4 + j] = (__bf16)hi[j]; }
+    return u.r;
+}
+// sum over the 16 lanes of a DPP row, result in every lane: rotations by 8, 4, 2, 1 pair the same lanes as the xor butterfly
+// (bit-identical sums) without the LDS round trips of ds_bpermute
+template <int N> __device__ __forceinline__ float dpp_ror(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 + N, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_sum(float x) {
+    x += dpp_ror<8>(x); x += dpp_ror<4>(x); x += dpp_ror<2>(x); x += dpp_ror<1>(x);
+    return x;
+}
+__device__ __forceinline__ f32x4 relu4(f32x4 v) { return f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)}; }
+// value as it will read back after being stored as T (so LDS/global copies and the register copy agree)
+template <typename T> __device__ __forceinline__ f32x4 round_as(f32x4 v) {
+    if constexpr (sizeof(T) == 4) return v;
+    else return f32x4{(float)(__bf16)v[0], (float)(__bf16)v[1], (float)(__bf16)v[2], (float)(__bf16)v[3]};
+}
+
+// Activation tensors (X_l, dX_l, dH_l, D_l, base_transform stash) are NODE-major in HBM: [node][window][128], so the
+// streams of the encoder epilogue and of the weight-gradient kernel (one node, many windows) are contiguous and a layer
+// tile reads one 16 x 128 block per node.
+__device__ __forceinline__ size_t act_idx(int w, int node, int B) { return ((size_t)node * B + w) * H; }
+
+// LDS node-block addressing: block = ROWS rows x 128 elements; 16-byte chunk c of row r lives at chunk slot
+// c ^ swz(r), swz(r) = (r & 15) ^ ((r & 4) << 1).  The plain c ^ (r & 15) of guide T2 is 2-way on the 16x16x32 operand
+// read (lane = row + 16 g reads chunk 4 g + t): ds_read_b128 is served in the lane groups {0-3,12-15,20-27}, ..., and rows
+// 0-3 of g collide with rows 4-7 of g + 1.  Folding row bit 2 into bit 3 makes those reads AND the 8-lane ds_write_b128
+// groups of the octet stores conflict-free (exhaustive check over the GF(2)-linear maps: tools/lds_swizzle_search.py).
+__device__ __forceinline__ int lds_swz(int row) { return (row & 15) ^ ((row & 4) << 1); }
+template <typename T> __device__ __forceinline__ int lds_chunk(int blk, int row, int c) {
+    return blk * Prec<T>::BLK + row * Prec<T>::RB + ((c ^ lds_swz(row)) << 4);
+}
+template <typename T> __device__ __forceinline__ int lds_elem(int blk, int row, int col) {
+    return lds_chunk<T>(blk, row, col / Prec<T>::EPC) + (col % Prec<T>::EPC) * (int)sizeof(T);
+}
+
+// 8 consecutive features (col % 8 == 0) of one row of an LDS node block: one swizzled chunk (bf16) or two (fp32)
+template <typename T> __device__ __forceinline__ void lds_load_oct(const char* smem, int blk, int row, int col, f32x4& lo, f32x4& hi) {
+    if constexpr (sizeof(T) == 4) {
+        lo = *reinterpret_cast<const f32x4*>(smem + lds_chunk<T>(blk, row, col / 4));
+        hi = *reinterpret_cast<const f32x4*>(smem + lds_chunk<T>(blk, row, col / 4 + 1));
+    } else load_oct(reinterpret_cast<const T*>(smem + lds_chunk<T>(blk, row, col / 8)), lo, hi);
+}
+template <typename T> __device__ __forceinline__ void lds_store_oct(char* smem, int blk, int row, int col, f32x4 lo, f32x4 hi) {
+    if constexpr (sizeof(T) == 4) {
+        *reinterpret_cast<f32x4*>(smem + lds_chunk<T>(blk, row, col / 4)) = lo;
+        *reinterpret_cast<f32x4*>(smem + lds_chunk<T>(blk, row, col / 4 + 1)) = hi;
+    } else store_oct(reinterpret_cast<T*>(smem + lds_chunk<T>(blk, row, col / 8)), lo, hi);
+}
+
+// A fragment: lane (row = lane % ROWS, group g = lane / ROWS) reads 8 consecutive chunks = its contiguous K range.
+template <typename T> __device__ __forceinline__ void load_afrag(typename Prec<T>::AFrag& a, const char* smem, int blk, int lane_) {
+    const int lane = opaque(lane_);
+    const int row = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < Prec<T>::NAV; ++t) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(smem + lds_chunk<T>(blk, row, g * Prec<T>::NAV + t));
+        a.v[t] = __builtin_bit_cast(typename Prec<T>::Vec, v);
+    }
+}
+// The same read with this lane's NAV chunk offsets computed once per kernel (stack kernels): per MAC only the block base
+// is added, on address registers of their own, so each K-step's read can issue right behind the MFMAs that consumed it.
+template <typename T> struct AOff {
+    int o[Prec<T>::NAV];
+    __device__ __forceinline__ explicit AOff(int lane) {
+        const int row = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int t = 0; t < Prec<T>::NAV; ++t) o[t] = opaque(lds_chunk<T>(0, row, g * Prec<T>::NAV + t));
+    }
+};
+template <typename T> __device__ __forceinline__ void load_afrag(typename Prec<T>::AFrag& a, const char* smem, int blk, const AOff<T>& ao) {
+    const int base = blk * Prec<T>::BLK;
+#pragma unroll
+    for (int t = 0; t < Prec<T>::NAV; ++t) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(smem + base + ao.o[t]);
+        a.v[t] = __builtin_bit_cast(typename Prec<T>::Vec, v);
+    }
+}
+// B fragment: packed by k_prep so that vector (wave, v, lane) is one contiguous 16-byte load.
+template <typename T> __device__ __forceinline__ void load_bfrag(typename Prec<T>::BFrag& b, const T* wpack, int pack, int wv, int lane) {
+    constexpr int NBV = Prec<T>::NBV;
+    const u32x4* base = reinterpret_cast<const u32x4*>(wpack + (size_t)pack * H * H) + (size_t)wv * NBV * 64 + lane;
+#pragma unroll
+    for (int v = 0; v < NBV; ++v) {
+        const u32x4 x = base[v * 64];
+        b.v[v] = __builtin_bit_cast(typename Prec<T>::Vec, x);
+    }
+}
+
+// acc^T += W_frag . X_frag  (A operand = packed weights, B operand = the window tile)
+__device__ __forceinline__ void mac(Prec<float>::Acc& acc, const Prec<float>::AFrag& x, const Prec<float>::BFrag& w) {
+#pragma unroll
+    for (int t4 = 0; t4 < 8; ++t4)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc.c[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.v[t4][e], x.v[t4][e], acc.c[0], 0, 0, 0);
+            acc.c[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.v[8 + t4][e], x.v[t4][e], acc.c[1], 0, 0, 0);
+        }
+}
+__device__ __forceinline__ void mac(Prec<__bf16>::Acc& acc, const Prec<__bf16>::AFrag& x, const Prec<__bf16>::BFrag& w) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        acc.c[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.v[t], x.v[t], acc.c[0], 0, 0, 0);
+        acc.c[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.v[4 + t], x.v[t], acc.c[1], 0, 0, 0);
+    }
+}
+
+// bias as the accumulator's initial value: this lane's 4 consecutive features of each 16-feature block
+template <typename T> __device__ __forceinline__ void acc_init_bias(typename Prec<T>::Acc& a, const float* bias, int wv, int lane) {
+    if (bias == nullptr) { acc_fill(a, 0.f); return; }
+    a.c[0] = *reinterpret_cast<const f32x4*>(bias + wv * 32 + c_feat(0, lane));
+    a.c[1] = *reinterpret_cast<const f32x4*>(bias + wv * 32 + c_feat(1, lane));
+}
+// this lane's bias values, fetched at group start and ADDED in the epilogue so the load's latency hides under the MACs
+struct BiasQ { f32x4 b[2]; };
+__device__ __forceinline__ BiasQ load_bias(const float* bias, int wv, int lane) {
+    BiasQ q;
+    q.b[0] = *reinterpret_cast<const f32x4*>(bias + wv * 32 + c_feat(0, lane));
+    q.b[1] = *reinterpret_cast<const f32x4*>(bias + wv * 32 + c_feat(1, lane));
+    return q;
+}
+
+// layer kernels: 8 waves = 4 column slices (wn) x 2 slot halves (wh); wave (wn, wh) owns output columns
+// [32 wn, 32 wn + 32) of the destination slots u with (u & 1) == wh  ->  HS = GMAX/2 accumulators per wave.
+constexpr int LAYER_THREADS = 512;
+
+// row-major work split of the 512 layer-kernel threads over node blocks: a block has VPB = ROWS*CPR 16-byte chunks
+// (512 fp32 / 256 bf16), so NPB = 512/VPB blocks are covered per pass; thread -> (sub-block, row, chunk)
+template <typename T> struct RowMap {
+    static constexpr int VPB = Prec<T>::ROWS * Prec<T>::CPR, NPB = LAYER_THREADS / VPB;
+    int sub, row, c;
+    __device__ __forceinline__ explicit RowMap(int tid) : sub(tid / VPB), row((tid % VPB) / Prec<T>::CPR), c(tid % Prec<T>::CPR) {}
+};
+
+// stage node blocks [0, NN) of an activation tensor [B][NN][128] into LDS (zero rows beyond the batch)
+template <typename T>
+__device__ __forceinline__ void stage_nodes(char* smem, const T* src, int NN, int w0, int B, int tid) {
+    constexpr int EPC = Prec<T>::EPC, NPB = RowMap<T>::NPB, BATCH = 6;
+    const RowMap<T> m(tid);
+    for (int nb = m.sub; nb < NN; nb += NPB * BATCH) {
+        u32x4 v[BATCH];
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i) {
+            const int n = nb + i * NPB;
+            v[i] = u32x4{0, 0, 0, 0};
+            if (n < NN && w0 + m.row < B) v[i] = *reinterpret_cast<const u32x4*>(src + act_idx(w0 + m.row, n, B) + m.c * EPC);
+        }
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i) {
+            const int n = nb + i * NPB;
+            if (n < NN) *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(n, m.row, m.c)) = v[i];
+        }
+    }
+}
+
+// relu bits: one byte per (node, window, 8-feature group) -- exactly the 8 accumulator elements one lane of the layer / stack
+// kernels owns, so the writer needs no cross-lane exchange: bytes [NN][4 column slices][ceil(B/16) tiles][4 groups][16 windows]
+// (a wave's store is 64 contiguous bytes).  Bit j of the byte of (n, w, f0) <-> feature f0 + j, f0 a multiple of 8.
+__device__ __forceinline__ size_t relu_byte(int n, int B, int w, int f) {
+    return ((((size_t)n * 4 + (f >> 5)) * ((B + 15) >> 4) + (w >> 4)) << 6) + (((f >> 3) & 3) << 4) + (w & 15);
+}
+// relu of one accumulator in place + its 8 relu bits, on the integer pipe: for a float x (no NaNs), max_i32(bits(x), 0) is
+// relu(x) (negative floats and -0 are negative integers), and y > 0 <=> y + 0x7fffffff has its top bit set; v_alignbit
+// shifts that bit into the byte.  2 + 1 instructions per element, no compares / VCC hazards.
+// base of the 64 relu bytes of (node n, column slice wn) in tile `tile`; the byte of lane (g, w & 15) is at + lane
+__device__ __forceinline__ size_t relu_tile_base(int n, int B, int tile, int wn) { return (((size_t)n * 4 + wn) * ((B + 15) >> 4) + tile) << 6; }
+__device__ __forceinline__ void unpack_oct(u32x4 r, f32x4& lo, f32x4& hi) {     // 8 bf16 -> two f32x4
+    lo = f32x4{__builtin_bit_cast(float, r[0] << 16), __builtin_bit_cast(float, r[0] & 0xffff0000u),
+               __builtin_bit_cast(float, r[1] << 16), __builtin_bit_cast(float, r[1] & 0xffff0000u)};
+    hi = f32x4{__builtin_bit_cast(float, r[2] << 16), __builtin_bit_cast(float, r[2] & 0xffff0000u),
+               __builtin_bit_cast(float, r[3] << 16), __builtin_bit_cast(float, r[3] & 0xffff0000u)};
+}
+template <typename T>
+__device__ __forceinline__ unsigned relu_with_bits(typename Prec<T>::Acc& acc) {
+    unsigned bits = 0;
+#pragma unroll
+    for (int fb = 1; fb >= 0; --fb)
+#pragma unroll
+        for (int j = 3; j >= 0; --j) {
+            const float xf = acc.c[fb][j];      // (hipcc 7.2 miscompiles __builtin_bit_cast applied directly to a vector element)
+            const int y = max(__float_as_int(xf), 0);
+            acc.c[fb][j] = __int_as_float(y);
+            bits = __builtin_amdgcn_alignbit(bits, (unsigned)y + 0x7fffffffu, 31);
+        }
+    return bits;
+}
+struct EncArgs {
+    const void* x[MSHGNN_MAX_TYPES]; int64_t pitch[MSHGNN_MAX_TYPES]; int vb[MSHGNN_MAX_TYPES];
+    int width[MSHGNN_MAX_TYPES], nodes[MSHGNN_MAX_TYPES], tbase[MSHGNN_MAX_TYPES], nkc[MSHGNN_MAX_TYPES];
+    int pack0[MSHGNN_MAX_TYPES], bias_idx[MSHGNN_MAX_TYPES], sign_off[MSHGNN_MAX_TYPES], wg_prefix[MSHGNN_MAX_TYPES + 1];
+    int n_types, tiles, B, NN;
+    int aligned;   // every input row starts 16-byte aligned and its pitch is a whole number of 16-byte chunks
+    const void* wpack; const float* bias; const uint8_t* signs; void* x0;
+    uint8_t* mask0;   // training: relu bytes of X_0 (one byte per lane, as the layer masks), read by the backward stack kernels at layer 0
+};
+
+// load up to EPC elements starting at p with the widest vector the alignment `vb` (bytes) allows
+template <typename T> __device__ __forceinline__ u32x4 load_chunk(const T* p, int nvalid, int vb) {
+    constexpr int EPC = Prec<T>::EPC;
+    u32x4 r = u32x4{0, 0, 0, 0};
+    if (nvalid <= 0) return r;
+    if (nvalid >= EPC && vb >= 16) return *reinterpret_cast<const u32x4*>(p);
+    if (nvalid >= EPC && vb == 8) {
+        const u32x2 a = reinterpret_cast<const u32x2*>(p)[0], b = reinterpret_cast<const u32x2*>(p)[1];
+        return u32x4{a[0], a[1], b[0], b[1]};
+    }
+    if (nvalid >= EPC && vb == 4) {
+        const unsigned* q = reinterpret_cast<const unsigned*>(p);
+        return u32x4{q[0], q[1], q[2], q[3]};
+    }
+    union { T e[EPC]; u32x4 v; } tmp;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) tmp.e[e] = e < nvalid ? p[e] : from_f32<T>(0.f);
+    return tmp.v;
+}
+// zero every element of a 16-byte chunk beyond the first nv (nv >= EPC keeps all)
+template <typename T> __device__ __forceinline__ u32x4 chunk_keep_first(u32x4 v, int nv) {
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (e >= nv) v[e] = 0u;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned m = (2 * e < nv ? 0x0000ffffu : 0u) | (2 * e + 1 < nv ? 0xffff0000u : 0u);
+            v[e] &= m;
+        }
+    }
+    return v;
+}
+// XOR sign bits from EPC sign bytes (0/1) starting at s
+template <typename T> __device__ __forceinline__ u32x4 sign_xor(const uint8_t* s) {
+    if constexpr (sizeof(T) == 4) {
+        const unsigned w = *reinterpret_cast<const unsigned*>(s);
+        return u32x4{(w & 1u) << 31, ((w >> 8) & 1u) << 31, ((w >> 16) & 1u) << 31, ((w >> 24) & 1u) << 31};
+    } else {
+        const unsigned w0 = reinterpret_cast<const unsigned*>(s)[0], w1 = reinterpret_cast<const unsigned*>(s)[1];
+        return u32x4{((w0 & 1u) << 15) | (((w0 >> 8) & 1u) << 31), (((w0 >> 16) & 1u) << 15) | (((w0 >> 24) & 1u) << 31),
+                     ((w1 & 1u) << 15) | (((w1 >> 8) & 1u) << 31), (((w1 >> 16) & 1u) << 15) | (((w1 >> 24) & 1u) << 31)};
+    }
+}
+
+// elementwise helpers on one 16-byte chunk of T
+template <typename T> __device__ __forceinline__ u32x4 chunk_add(u32x4 a, u32x4 b) {
+    union U { u32x4 v; T e[Prec<T>::EPC]; } x, y, r;
+    x.v = a; y.v = b;
+#pragma unroll
+    for (int e = 0; e < Prec<T>::EPC; ++e) r.e[e] = from_f32<T>(to_f32(x.e[e]) + to_f32(y.e[e]));
+    return r.v;
+}
+template <typename T> __device__ __forceinline__ u32x4 chunk_mask_pos(u32x4 v, u32x4 act) {   // keep v where act > 0
+    union U { u32x4 v; T e[Prec<T>::EPC]; } x, y;
+    x.v = v; y.v = act;
+#pragma unroll
+    for (int e = 0; e < Prec<T>::EPC; ++e) if (!(to_f32(y.e[e]) > 0.f)) x.e[e] = from_f32<T>(0.f);
+    return x.v;
+}
+template <typename T> __device__ __forceinline__ u32x4 chunk_mask_bits(u32x4 v, unsigned bits) {   // EPC relu bits, LSB first
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (!((bits >> e) & 1u)) v[e] = 0u;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            unsigned m = 0;
+            if ((bits >> (2 * e)) & 1u) m |= 0x0000ffffu;
+            if ((bits >> (2 * e + 1)) & 1u) m |= 0xffff0000u;
+            v[e] &= m;
+        }
+    }
+    return v;
+}
+
+
+// ------------------------------------------------------------------------------------------------------
+// thread = (row, 8-column chunk): 16 lanes share a row, one wave covers 4 rows; whole rows are read / written coalesced
+template <typename T> __device__ __forceinline__ void load8(const T* p, float (&v)[8]) {
+    if constexpr (sizeof(T) == 4) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(p)[0], b = reinterpret_cast<const f32x4*>(p)[1];
+        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    } else {
+        const u32x4 r = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[2 * e] = __builtin_bit_cast(float, r[e] << 16); v[2 * e + 1] = __builtin_bit_cast(float, r[e] & 0xffff0000u); }
+    }
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float (&v)[8]) {
+    if constexpr (sizeof(T) == 4) {
+        reinterpret_cast<f32x4*>(p)[0] = f32x4{v[0], v[1], v[2], v[3]};
+        reinterpret_cast<f32x4*>(p)[1] = f32x4{v[4], v[5], v[6], v[7]};
+    } else {
+        union { u32x4 r; __bf16 e[8]; } u;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) u.e[e] = (__bf16)v[e];
+        *reinterpret_cast<u32x4*>(p) = u.r;
+    }
+}
+
+struct PrepArgs {
+    const float* params; void* wpack; float* bias; const PackDesc* packs; const BiasDesc* biases; int n_packs; int n_biases;
+};
+
+// split plan (MSHGNN_BF16X3): an fp32 value travels as two bf16 values, hi = bf16(x) and lo = bf16(x - hi): x = hi + lo to 16 mantissa
+// bits (2^-17 relative), and a product is taken as hi*hi + hi*lo + lo*hi on the bf16 MFMA with fp32 accumulation
+__device__ __forceinline__ void split_oct(f32x4 a, f32x4 b, u32x4& hi, u32x4& lo) {
+    hi = pack_oct(a, b);
+    f32x4 ha, hb; unpack_oct(hi, ha, hb);
+    lo = pack_oct(a - ha, b - hb);
+}
+__device__ __forceinline__ void join_oct(u32x4 hi, u32x4 lo, f32x4& a, f32x4& b) {
+    f32x4 la, lb; unpack_oct(hi, a, b); unpack_oct(lo, la, lb);
+    a += la; b += lb;
+}
+
+struct StackArgs {
+    const void* tile_in;                          // fwd: X_0                       bwd: dX_L
+    char* ws;
+    size_t x_off[MAX_L + 1], dx_off[MAX_L + 1];   // X_l stashes (fwd: written for l >= 1; bwd: X_0 read for the encoder mask), dX_l (bwd: written)
+    size_t mask_off[MAX_L], hb_off[MAX_L], t1_off[MAX_L], dh_off[MAX_L], du_off[MAX_L];
+    const void* wpack; const float* bias; const int* tables; int prog_off[MAX_L];
+    int B, NN, L, training, dbg;
+    const float* params; const float* out_mask; float* out; int64_t off_dec_w, off_dec_b; int node0, n_out, dout;   // fused decoder (fwd)
+    // mshgnn_step_mse: the forward also takes the wrapper MSE and the decoder backward (dX_L rows, decoder partial gradients, loss partial)
+    const float* y; float* dec_slabs; float inv_n;
+    size_t mask0_off;    // bwd: relu bytes of the encoder activation X_0 in the workspace (0: not available, X_0 rows are read)
+    long long* stamps;   // timing experiments (MSHGNN_STAMPS): wave 0 of every workgroup records clock64() at phase boundaries
+    // split plan: LDS block of the lo plane of node n = lo_blk + n; element offsets of the lo plane of the activation / base_transform
+    // stashes; the lo image of pack i is pack n_img + i
+    int lo_blk, n_img; size_t act_plane, mlp_plane;
+};
+#ifdef MSHGNN_SEG_STAMPS
+constexpr int FS_EXTRA_BLK = 6;     // LDS room for the per-segment clocks
+#else
+constexpr int FS_EXTRA_BLK = 0;
+#endif
+#if defined(MSHGNN_FS_STAMPS) || defined(MSHGNN_SEG_STAMPS)
+#define FS_STAMP(k) do { if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 32 + (k)] = clock64(); } while (0)
+#else
+#define FS_STAMP(k) do { } while (0)     // the stamp stores are compiled out of the product build (they cost waits at phase boundaries)
+#endif
+
+// wave program in three VGPRs, fetched with v_readlane: pk = pack id of segment `lane`; pcnt = its MAC counts (3 bits per
+// accumulator); pb = 256 byte entries, 4 per lane (entry 0 = number of segments, then the block stream)
+struct FProg {
+    int pk, pcnt, pb;
+    __device__ __forceinline__ FProg(const int* prog, int lane) : pk(prog[lane]), pcnt(prog[64 + lane]), pb(prog[128 + lane]) {}
+    __device__ __forceinline__ int pack(int sgi) const { return __builtin_amdgcn_readlane(pk, sgi); }
+    __device__ __forceinline__ int counts(int sgi) const { return __builtin_amdgcn_readlane(pcnt, sgi); }
+    __device__ __forceinline__ int at(int i) const { return (__builtin_amdgcn_readlane(pb, i >> 2) >> ((i & 3) << 3)) & 0xff; }
+};
+
+// a layer header (FH_SIZE = 88 ints) held in two VGPRs and read with v_readlane: per-node flags cost no scalar-memory round
+// trip (measured with in-kernel stamps: ~40 dependent s_loads of the header were 6.6k cycles before the first MAC of a layer)
+struct FHdr {
+    int h0, h1;
+    __device__ __forceinline__ FHdr() : h0(0), h1(0) {}
+    __device__ __forceinline__ FHdr(const int* hdr, int lane) : h0(hdr[lane]), h1(lane < FH_SIZE - 64 ? hdr[64 + lane] : 0) {}
+    __device__ __forceinline__ int operator[](int i) const { return i < 64 ? __builtin_amdgcn_readlane(h0, i & 63) : __builtin_amdgcn_readlane(h1, i & 63); }
+};
+
+// one segment: walk the accumulators in static order, each with its run-time MAC count; the source blocks come from the
+// program's block stream in execution order, so the fragment of the NEXT MAC is read from LDS under this MAC's MFMAs
+template <typename T, int HS = FS_HS, int CB = 3>      // HS accumulators, CB bits of MAC count per accumulator
+__device__ __forceinline__ void fs_walk(const FProg& wp, int sgi, int& pb, typename Prec<T>::AFrag& afn, typename Prec<T>::Acc (&acc)[HS],
+                                        const typename Prec<T>::BFrag& bf, const char* smem, const AOff<T>& lane, int dbg = 0) {
+    const int cw = wp.counts(sgi);      // one readlane per segment: 3 bits of MAC count per accumulator
+#pragma unroll
+    for (int u = 0; u < HS; ++u) {
+        const int cnt = (cw >> (CB * u)) & ((1 << CB) - 1);
+        for (int k = 0; k < cnt; ++k) {
+            // the MFMAs of this MAC read afn as they issue; the fragment of the NEXT MAC is then read from LDS into the same
+            // registers and lands while those MFMAs execute (no second buffer, no register copies)
+#ifdef MSHGNN_ABLATE
+            if (!ABL(dbg & 128)) mac(acc[u], afn, bf);
+            if (!ABL(dbg & 256)) load_afrag<T>(afn, smem, wp.at(++pb), lane);
+#else
+            mac(acc[u], afn, bf);
+            load_afrag<T>(afn, smem, wp.at(++pb), lane);
+#endif
+            if constexpr (sizeof(T) == 4) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 8 * Prec<T>::NAV, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, Prec<T>::NAV, 0);
+            } else {
+                // K-step t's two MFMAs, then the read that refills x.v[t]: every read gets the rest of the MAC as cover
+#pragma unroll
+                for (int t = 0; t < Prec<T>::NAV; ++t) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            }
+        }
+    }
+}
+// all segments of a layer.  The next segment's weight fragment streams from L2 while the current one is multiplied
+// (two register buffers).
+template <typename T, int HS = FS_HS, int CB = 3>
+__device__ __forceinline__ void fs_run(const FProg& wp, typename Prec<T>::Acc (&acc)[HS], const char* smem, const T* wpack, int wn, int lane, int dbg = 0,
+                                       long long* segclk = nullptr) {
+    const int nseg = wp.at(0);
+    int pb = 1;
+    typename Prec<T>::BFrag bfa, bfb;
+    typename Prec<T>::AFrag afn;
+    const AOff<T> ao(lane);
+    // drain the previous epilogue's memory operations first: with loads AND stores pending the compiler must assume
+    // out-of-order completion and waits vmcnt(0) before every MAC, which would expose each prefetch
+    __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));
+    if (nseg > 0) load_bfrag<T>(bfa, wpack, wp.pack(0), wn, lane);
+    load_afrag<T>(afn, smem, wp.at(pb), ao);
+    // a fragment load is ALWAYS in flight behind the one being multiplied (the last segment re-requests its own pack):
+    // every path then has the same number of younger loads outstanding, so the compiler's in-order vmcnt waits inside
+    // the MAC loops never have to drain the prefetch
+#ifdef MSHGNN_ABLATE
+    if ABL(dbg & 512) {     // both register buffers filled once, no weight streaming inside the layer (timing only, wrong results)
+        load_bfrag<T>(bfb, wpack, wp.pack(0), wn, lane);
+        for (int sgi = 0; sgi < nseg; sgi += 2) {
+            fs_walk<T, HS, CB>(wp, sgi, pb, afn, acc, bfa, smem, ao, dbg);
+            if (sgi + 1 < nseg) fs_walk<T, HS, CB>(wp, sgi + 1, pb, afn, acc, bfb, smem, ao, dbg);
+        }
+        return;
+    }
+#endif
+#ifdef MSHGNN_SEG_STAMPS
+#define FS_SEGCLK(i) do { if (segclk && lane == 0) segclk[i] = clock64(); } while (0)
+#else
+#define FS_SEGCLK(i) do { } while (0)
+#endif
+    for (int sgi = 0; sgi < nseg; sgi += 2) {
+        load_bfrag<T>(bfb, wpack, wp.pack(min(sgi + 1, nseg - 1)), wn, lane);
+        FS_SEGCLK(sgi);
+        fs_walk<T, HS, CB>(wp, sgi, pb, afn, acc, bfa, smem, ao, dbg);
+        if (sgi + 1 < nseg) {
+            load_bfrag<T>(bfa, wpack, wp.pack(min(sgi + 2, nseg - 1)), wn, lane);
+            FS_SEGCLK(sgi + 1);
+            fs_walk<T, HS, CB>(wp, sgi + 1, pb, afn, acc, bfb, smem, ao, dbg);
+        }
+    }
+    FS_SEGCLK(nseg);
+}
+
+// decoder (+ fused wrapper MSE and decoder backward) on the X_L tile in LDS: shared tail of k_stack_fwd / k_slab_fwd
+template <typename T, int THREADS, int DMAX, bool SPLIT = false>      // DMAX: compile-time bound on the output channels (4 or 8): loops, loads and registers scale with it
+__device__ __forceinline__ void decoder_tail_impl(const StackArgs& a, char* smem, int tid, int lane, int wv, int w0, int B) {
+    // decoder on the out-type rows of X_L (hgnn_c2.py:176-189): thread = (node, row, 8-column chunk).  With y (mshgnn_step_mse) the
+    // same threads also take the wrapper MSE (gnnLightning.py:633-639) and the decoder backward: dX_L rows to global for
+    // k_stack_bwd, and this tile's partial decoder gradients + loss partial into dec_slabs[tile] (summed by k_finalize).
+    {
+        const int c = tid & 15, row = (tid >> 4) & 15;
+        const float* W = a.params + a.off_dec_w;
+        const bool fuse = a.y != nullptr;
+        T* dxl = reinterpret_cast<T*>(a.ws + a.dx_off[a.L]);
+        float accw[DMAX][8], accb[DMAX], lsum = 0.f;
+        if (fuse) {
+#pragma unroll
+            for (int dd = 0; dd < DMAX; ++dd) { accb[dd] = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) accw[dd][e] = 0.f; }
+        }
+        // two nodes per pass, every global load of a pass before its first store: a load waited for while stores are in flight
+        // costs a full vmcnt(0) drain (loads and stores retire out of order with respect to each other)
+        // (unconditional loads with clamped indices, so that they are issued back to back and waited for once)
+        float Wv[DMAX][8], bv[DMAX];
+#pragma unroll
+        for (int dd = 0; dd < DMAX; ++dd) {
+            const int dc = min(dd, a.dout - 1);
+            const f32x4 wa = *reinterpret_cast<const f32x4*>(W + dc * H + c * 8), wb = *reinterpret_cast<const f32x4*>(W + dc * H + c * 8 + 4);
+            Wv[dd][0] = wa[0]; Wv[dd][1] = wa[1]; Wv[dd][2] = wa[2]; Wv[dd][3] = wa[3];
+            Wv[dd][4] = wb[0]; Wv[dd][5] = wb[1]; Wv[dd][6] = wb[2]; Wv[dd][7] = wb[3];
+            bv[dd] = a.params[a.off_dec_b + dc];
+        }
+        for (int f0 = tid >> 8; f0 < a.n_out; f0 += 2 * (THREADS / 256)) {
+            float ov[2][DMAX], dxv[2][8], mk[2][DMAX], yv[2][DMAX];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int f = min(f0 + i * (THREADS / 256), a.n_out - 1);
+                const size_t r = (size_t)min(w0 + row, B - 1) * a.n_out + f;
+#pragma unroll
+                for (int dd = 0; dd < DMAX; ++dd) {
+                    const int dc = min(dd, a.dout - 1);
+                    mk[i][dd] = a.out_mask[f * a.dout + dc];
+                    yv[i][dd] = fuse ? a.y[r * a.dout + dc] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int f = f0 + i * (THREADS / 256);
+                const bool live = f < a.n_out;
+                f32x4 x0, x1;
+                lds_load_oct<T>(smem, a.node0 + (live ? f : f0), row, c * 8, x0, x1);
+                if constexpr (SPLIT) {      // X_L = hi + lo
+                    f32x4 l0, l1;
+                    lds_load_oct<T>(smem, a.lo_blk + a.node0 + (live ? f : f0), row, c * 8, l0, l1);
+                    x0 += l0; x1 += l1;
+                }
+                const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dxv[i][e] = 0.f;
+                const bool ok = live && w0 + row < B;
+#pragma unroll
+                for (int dd = 0; dd < DMAX; ++dd) {
+                    ov[i][dd] = 0.f;
+                    if (dd < a.dout && live) {
+                        float sum = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) sum += x[e] * Wv[dd][e];
+                        sum = row16_sum(sum);
+                        const float o = (sum + bv[dd]) * mk[i][dd];
+                        ov[i][dd] = o;
+                        if (fuse && ok) {
+                            const float dlt = o - yv[i][dd];
+                            const float g = 2.0f * dlt * a.inv_n * mk[i][dd];
+                            if (c == 0) lsum += dlt * dlt;
+                            accb[dd] += g;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) { accw[dd][e] += g * x[e]; dxv[i][e] += g * Wv[dd][e]; }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int f = f0 + i * (THREADS / 256);
+                const bool ok = f < a.n_out && w0 + row < B;
+                const size_t r = (size_t)(w0 + row) * a.n_out + f;
+                if (c == 0 && ok) {
+#pragma unroll
+                    for (int dd = 0; dd < DMAX; ++dd) if (dd < a.dout) a.out[r * a.dout + dd] = ov[i][dd];
+                }
+                if (fuse && ok) {
+                    if constexpr (SPLIT) {
+                        u32x4 hi, lo;
+                        split_oct(f32x4{dxv[i][0], dxv[i][1], dxv[i][2], dxv[i][3]}, f32x4{dxv[i][4], dxv[i][5], dxv[i][6], dxv[i][7]}, hi, lo);
+                        T* q = dxl + act_idx(w0 + row, a.node0 + f, B) + c * 8;
+                        *reinterpret_cast<u32x4*>(q) = hi; *reinterpret_cast<u32x4*>(q + a.act_plane) = lo;
+                    } else store8<T>(dxl + act_idx(w0 + row, a.node0 + f, B) + c * 8, dxv[i]);
+                }
+            }
+        }
+        if (fuse) {
+            // reduce over the 4 rows of the wave (lanes 16 apart), then over the 8 waves through LDS (the X tile is dead after the barrier)
+#pragma unroll
+            for (int dd = 0; dd < DMAX; ++dd) {
+                if (dd < a.dout) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { accw[dd][e] += __shfl_xor(accw[dd][e], 16, 64); accw[dd][e] += __shfl_xor(accw[dd][e], 32, 64); }
+                    accb[dd] += __shfl_xor(accb[dd], 16, 64); accb[dd] += __shfl_xor(accb[dd], 32, 64);
+                }
+            }
+            lsum += __shfl_xor(lsum, 16, 64); lsum += __shfl_xor(lsum, 32, 64);
+            __syncthreads();
+            float* red = reinterpret_cast<float*>(smem);          // [8 waves][8 H + 16]
+            if (lane < 16) {
+#pragma unroll
+                for (int dd = 0; dd < DMAX; ++dd) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) red[wv * DEC_SLAB_FLOATS + dd * H + lane * 8 + e] = accw[dd][e];
+                    if (lane == 0) red[wv * DEC_SLAB_FLOATS + 8 * H + dd] = accb[dd];
+                }
+                if (lane == 0) red[wv * DEC_SLAB_FLOATS + 8 * H + 8] = lsum;
+            }
+            __syncthreads();
+            float* slab = a.dec_slabs + (size_t)blockIdx.x * DEC_SLAB_FLOATS;
+            for (int i = tid; i < 8 * H + 9; i += THREADS) {
+                if (i >= a.dout * H && i < 8 * H) continue;       // rows of unused output channels (k_finalize reads dout rows only)
+                float s2 = 0.f;
+#pragma unroll
+                for (int k = 0; k < THREADS / 64; ++k) s2 += red[k * DEC_SLAB_FLOATS + i];
+                slab[i] = s2;
+            }
+        }
+    }
+}
+
+template <typename T, int THREADS, bool SPLIT = false>
+__device__ __forceinline__ void decoder_tail(const StackArgs& a, char* smem, int tid, int lane, int wv, int w0, int B) {
+    if (a.dout <= 4) decoder_tail_impl<T, THREADS, 4, SPLIT>(a, smem, tid, lane, wv, w0, B);
+    else decoder_tail_impl<T, THREADS, 8, SPLIT>(a, smem, tid, lane, wv, w0, B);
+}
+
+struct DecArgs {
+    const void* xl; void* dxl; const float* params; const float* out_mask; float* out; const float* gout; float* slabs;
+    int64_t off_w, off_b; int B, NN, node0, n_out, dout, slab0;
+    const float* y; float* loss; float inv_n;   // fused MSE: gout = 2 (out - y) / n computed on the fly, loss accumulated
+    const int32_t* labels;                      // fused cross entropy (dout == 2): gout = (softmax(out) - onehot) / rows
+};
+
+
+struct GradwArgs {
+    const char* ws; size_t buf_off[BUF_COUNT];
+    const void* x[MSHGNN_MAX_TYPES]; int64_t pitch[MSHGNN_MAX_TYPES]; int nodes[MSHGNN_MAX_TYPES]; int vb[MSHGNN_MAX_TYPES];
+    const int* items; const int* lanes; const int* lane_order; const uint8_t* signs; float* slabs; int B, n_lanes, n_parts, n_pad;
+    int aligned;   // all raw-input rows 16-byte aligned with whole-chunk pitch
+    int dbg;   // timing ablations (MSHGNN_DBG_GW): 1 no global loads, 2 no LDS staging, 4 no MFMA phase, 8 no slab store
+    long long* stamps;   // MSHGNN_STAMPS_GW: thread 0 of every workgroup accumulates clock64() deltas of the step phases
+};
+
+// bf16: P/Q staged row-major ([window][feature], pitch 160 elements = 320 B: 4 consecutive windows land on
+// disjoint 16-bank ranges) and read as MFMA operands with the hardware-transposing ds_read_b64_tr_b16 (guide T10):
+// both operands are K(=window)-strided in memory.  32x32x16 bf16 MFMA, wave = 64x64 of the 128x128 tile.
+constexpr int GWB_KW = 64;
+constexpr int GWB_PITCH = 128;           // no row padding: 16-byte chunk c of row r lives at chunk slot c ^ 4 (r & 3) instead (the four rows a
+                                         // transposed read touches land in four different 64-byte bank windows, as they did with a 320-byte pitch)
+__device__ __forceinline__ int gwb_elem(int row, int col) { return row * GWB_PITCH + ((((col >> 3) ^ ((row & 3) << 2)) << 3) | (col & 7)); }
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x8 tr_frag(const __bf16* tile, int w_base, int col_base, int lane) {
+    // lane = 16 g + 4 q + p: supplies the address of row q, columns 4p..4p+3 of its group's 4x16 block;
+    // receives column (lane & 15) of the 4 rows.  g&1 selects the 16-column half, g>>1 the K half (8 windows).
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const __bf16* p0 = tile + gwb_elem(w_base + 8 * (g >> 1) + q, col_base + 16 * (g & 1) + 4 * pp);     // (row + 4 has the same swizzle)
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0 + 4 * GWB_PITCH));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+
+struct FinArgs { const int* fin; const int* targets; const float* slabs; const float* dec_slabs; float* grad; int n_lanes, n_parts; float* loss; float inv_n;
+                 int n_dec; };   // decoder partial slabs: NWG_DEC (k_dec_bwd) or one per tile (fused forward)
+
+struct ProfRec { int slot; hipEvent_t a, b; };
+struct mshgnn_plan {
+    HostPlan hp;
+    bool prof = false;
+    std::vector<ProfRec> recs;          // recorded, not yet read
+    std::vector<hipEvent_t> free_events;
+    int* d_tables = nullptr; uint8_t* d_signs = nullptr; float* d_out_mask = nullptr;
+    PackDesc* d_packs = nullptr; BiasDesc* d_biases = nullptr;
+    bool attr_set = false;
+    bool use_fused = false;             // bf16 plan: fused stack kernels (MSHGNN_FUSED=0 selects the per-layer kernels)
+    bool use_slab = false;              // slab variant of the stack kernels (MSHGNN_SLAB=0 selects the 8-wave ones)
+    bool slab_force = false; int n_cu = 256;
+    int dbg = 0, dbg_gw = 0;            // timing ablations (instrumented builds only: read once from MSHGNN_DBG / MSHGNN_DBG_GW at plan creation)
+    // a slab workgroup has 4 waves for a whole tile: it pays off once there are enough tiles for two workgroups per CU
+    bool slab_for(int tiles) const { return use_slab && (slab_force || tiles >= 2 * n_cu * 3 / 4); }
+};
+
+// in-kernel stamp buffers of the instrumented builds (tools/stamps_*.py pass a device pointer through the environment)
+inline long long* stamp_ptr(const char* name) {
+#if defined(MSHGNN_FS_STAMPS) || defined(MSHGNN_SEG_STAMPS) || MSHGNN_GW_STAMPS_BUILD
+    const char* e = getenv(name);
+    return e ? reinterpret_cast<long long*>((uintptr_t)strtoull(e, nullptr, 0)) : nullptr;
+#else
+    (void)name; return nullptr;
+#endif
+}
+
+// bracket one kernel launch with events when profiling
+struct ProfScope {
+    mshgnn_plan* p; hipStream_t st; ProfRec r{}; bool on;
+    ProfScope(const mshgnn_plan* pc, int slot, hipStream_t s) : p(const_cast<mshgnn_plan*>(pc)), st(s), on(pc->prof) {
+        if (!on) return;
+        auto get = [&]() { hipEvent_t e; if (!p->free_events.empty()) { e = p->free_events.back(); p->free_events.pop_back(); } else (void)hipEventCreate(&e); return e; };
+        r.slot = slot; r.a = get(); r.b = get();
+        (void)hipEventRecord(r.a, st);
+    }
+    ~ProfScope() { if (on) { (void)hipEventRecord(r.b, st); p->recs.push_back(r); } }
+};
+
+template <typename K> inline int set_lds_attr(K kernel, int bytes) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    return MSHGNN_OK;
+}
+
+inline int vec_bytes(const void* base, int64_t pitch_elems, int esize) {
+    const uint64_t a = (uint64_t)(uintptr_t)base | (uint64_t)(pitch_elems * esize);
+    if ((a & 15) == 0) return 16;
+    if ((a & 7) == 0) return 8;
+    if ((a & 3) == 0) return 4;
+    return esize;
+}
+
+
+
+// k_finalize launch of a step (mshgnn.hip): fixed-order slab sums -> flat gradient (+ fused loss)
+int run_finalize(const mshgnn_plan* p, const mshgnn_ws_layout& lay, char* ws, float* gparams, int B, float* loss, bool is_ce, bool dec_done,
+                 int gw_phase, hipStream_t st);
+// split-bf16 parity plan (mshgnn_x3.hip)
+int x3_set_attrs(mshgnn_plan* p);
+int x3_forward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, float* out, char* ws, int64_t batch,
+               int training, hipStream_t st, const float* y_fused);
+int x3_backward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, const float* gout, float* gparams, char* ws,
+                int64_t batch, hipStream_t st, const float* out, const float* y, float* loss, const int32_t* labels, bool dec_done, int gw_phase);

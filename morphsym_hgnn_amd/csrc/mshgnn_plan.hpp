@@ -119,6 +119,11 @@ struct HostPlan {
     int blk_bytes = 8192;          // one LDS node block
     int gmax = GMAX;               // destination slots per group (12 fp32, 8 bf16: accumulator registers)
     int esize = 4;                 // bytes per stored element
+    bool split = false;            // MSHGNN_BF16X3: every activation is two bf16 planes (hi, lo); packs [0, n_img) = hi images, [n_img, 2 n_img) = lo
+    int planes = 1;                // stored planes per activation tensor (2 on the split plan: plane 1 at + one plane's bytes)
+    int n_img = 0;                 // weight images per plane (== packs.size())
+    int lo_blk = 0;                // split plan: LDS block of the lo plane of node n is lo_blk + n
+    int gw_target = (int)GW_TARGET_WGS;
     bool live[MAX_L][MSHGNN_MAX_TYPES]{};     // layer output of type t reaches the decoder
     bool need_dx[MAX_L][MSHGNN_MAX_TYPES]{};  // dX_l[t] must be produced
     // packed operands
@@ -176,7 +181,7 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
     if (d.hidden != H) return fail(p, "this build supports hidden_channels == 128 only");
     if (d.num_layers < 1 || d.num_layers > MAX_L) return fail(p, "num_layers must be 1..16");
     if (d.n_rel < 1 || d.n_rel > 64) return fail(p, "n_rel must be 1..64");
-    if (d.dtype != MSHGNN_F32 && d.dtype != MSHGNN_BF16) return fail(p, "dtype must be MSHGNN_F32 or MSHGNN_BF16");
+    if (d.dtype != MSHGNN_F32 && d.dtype != MSHGNN_BF16 && d.dtype != MSHGNN_BF16X3) return fail(p, "dtype must be MSHGNN_F32, MSHGNN_BF16 or MSHGNN_BF16X3");
     if (d.out_type < 0 || d.out_type >= d.n_types) return fail(p, "out_type out of range");
     if (d.out_channels < 1 || d.out_channels > 8) return fail(p, "out_channels must be 1..8");
     if (!d.rel_src || !d.rel_dst || !d.rel_mean || !d.rel_edge_off || !d.edges) return fail(p, "null relation arrays");
@@ -195,8 +200,10 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
     }
     p.NN = p.type_base[NT];
     p.esize = d.dtype == MSHGNN_F32 ? 4 : 2;
+    p.split = d.dtype == MSHGNN_BF16X3; p.planes = p.split ? 2 : 1;
+    p.gw_target = p.split ? 512 : (int)GW_TARGET_WGS;     // split plan: the weight-gradient kernel stages four tiles (64 KB) -> two workgroups per CU
     p.blk_bytes = TILE_ROWS * H * p.esize;
-    if ((int64_t)p.NN * p.blk_bytes > LDS_LIMIT)
+    if (!p.split && (int64_t)p.NN * p.blk_bytes > LDS_LIMIT)
         return fail(p, "topology has too many nodes per window for the LDS-resident layer kernel (max 20 fp32 / 40 bf16)");
     p.rows = TILE_ROWS;
     p.gmax = d.dtype == MSHGNN_F32 ? GMAX : 8;   // bf16: 4 accumulators per wave keep the layer kernels at 128 VGPRs (2 workgroups / CU)
@@ -455,11 +462,34 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
     if (prog_overflow) return fail(p, "a layer's MAC program exceeds 128 entries per wave (too many relations/edges for this build)");
 
     // ---- fused stack programs (bf16 plan) ---------------------------------------------------------------
-    p.fused = d.dtype == MSHGNN_BF16 && p.NN <= FS_MAXN && (int64_t)(p.NN + p.n_mlp) * p.blk_bytes <= LDS_LIMIT &&
+    p.fused = d.dtype != MSHGNN_F32 && p.NN <= FS_MAXN && (int64_t)p.planes * (p.NN + p.n_mlp) * p.blk_bytes <= LDS_LIMIT &&
               (!has_mlp || (p.type_base[d.mlp_type] == 0 && p.n_mlp <= 4));   // base_transform nodes are accumulators 0..1 of each wave half
     p.fs_blk = p.NN + p.n_mlp;
+    p.lo_blk = p.fs_blk; p.n_img = (int)p.packs.size();
+    if (p.split && !p.fused)
+        return fail(p, "the split-bf16 parity plan is not supported for this topology (its LDS-resident tile holds 2 x (nodes + base_transform "
+                       "nodes) <= 40 blocks and <= 20 nodes); use MSHGNN_F32");
+    // split plan: X W = X_hi W_hi + X_lo W_hi + X_hi W_lo (the lo x lo term is below fp32 resolution).  The MAC loop of the stack kernels
+    // is unchanged: every segment becomes two -- the hi image with the hi and the lo block of each source, the lo image with the hi block
+    auto split_segs = [&](const std::vector<Seg>& in) {
+        if (!p.split) return in;
+        std::vector<Seg> out;
+        for (const Seg& sg : in) {
+            // at most 3 source blocks per accumulator and segment (the hi-image segment holds twice as many MACs, 3 count bits)
+            std::vector<std::pair<int, int>> rest = sg.macs;
+            while (!rest.empty()) {
+                std::vector<std::pair<int, int>> take, keep; std::vector<int> cnt(64, 0);
+                for (auto& m : rest) { if (cnt[m.first] < 3) { take.push_back(m); cnt[m.first]++; } else keep.push_back(m); }
+                Seg a; a.pack = sg.pack; Seg b; b.pack = sg.pack + p.n_img;
+                for (auto& m : take) { a.macs.push_back(m); a.macs.push_back({m.first, m.second + p.lo_blk}); b.macs.push_back(m); }
+                out.push_back(a); out.push_back(b);
+                rest.swap(keep);
+            }
+        }
+        return out; };
     if (p.fused) {
-        auto emit_fused = [&](const std::vector<Seg>& segs) {   // Seg.macs = (node, source block)
+        auto emit_fused = [&](const std::vector<Seg>& segs_in) {   // Seg.macs = (node, source block)
+            const std::vector<Seg> segs = split_segs(segs_in);
             for (int half = 0; half < 2 && p.fused; ++half) {
                 std::vector<int> w, blocks, counts;    // byte entries; packed per-segment counts
                 w.push_back((int)segs.size());
@@ -488,7 +518,7 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
         std::vector<int> slotA, slotB;
         for (int n = 0; n < p.NN; ++n) (p.node_type[n] == tA ? slotA : slotB).push_back(n);
         p.sl_ta = tA;
-        p.slab = 2 * (int64_t)p.fs_blk * p.blk_bytes <= LDS_LIMIT && (int)slotA.size() <= SL_HA && (int)slotB.size() <= SL_HB &&
+        p.slab = !p.split && 2 * (int64_t)p.fs_blk * p.blk_bytes <= LDS_LIMIT && (int)slotA.size() <= SL_HA && (int)slotB.size() <= SL_HB &&
                  (!has_mlp || (d.mlp_type != tA && p.n_mlp <= (int)slotB.size()));     // base_transform nodes = the first slots of group B
         if (has_mlp) for (int u = 0; u < p.n_mlp && p.slab; ++u) if (slotB[u] != p.type_base[d.mlp_type] + u) p.slab = false;
         auto emit_slab = [&](const std::vector<Seg>& segs, int hdr_src) {
@@ -598,6 +628,8 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
         }
         if (!p.fused) p.slab = false;
     }
+    if (p.split && !p.fused) return fail(p, "the split-bf16 parity plan is not supported for this topology (a layer's MAC program exceeds the "
+                                            "stack kernels' program registers); use MSHGNN_F32");
     // algorithmic dX work: one node-linear per (relation, src node with >=1 out-edge into a live dst) -- count below
     for (int l = 0; l < L; ++l)
         for (int r = 0; r < NR; ++r) {
@@ -692,9 +724,9 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
     p.item_off = (int)T.size(); p.n_items = 0;
     {
         double best = -1;
-        for (int ipl = 1; ipl <= GW_IPL; ++ipl) {
+        for (int ipl = 1; ipl <= (p.split ? 1 : GW_IPL); ++ipl) {
             int nl = 0; for (auto& tg : tgts) nl += ((int)tg.items.size() + ipl - 1) / ipl;
-            const double fill = (double)nl * std::max(1, std::min(16, (int)std::floor(GW_TARGET_WGS / std::max(1, nl))));
+            const double fill = (double)nl * std::max(1, std::min(16, p.gw_target / std::max(1, nl)));
             if (fill > best) { best = fill; p.gw_ipl = ipl; }
         }
     }
@@ -709,7 +741,7 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
         tgt_lane_end[g] = (int)lanes.size();
     }
     p.n_lanes = (int)lanes.size();
-    p.n_parts = std::max(1, std::min(16, (int)std::floor(GW_TARGET_WGS / std::max(1, p.n_lanes))));    // never more workgroups than are resident at once
+    p.n_parts = std::max(1, std::min(16, p.gw_target / std::max(1, p.n_lanes)));    // never more workgroups than are resident at once
     // XCD placement: cluster -> least-loaded XCD queue (largest clusters first); block b runs queue[b % 8][b / 8]
     std::vector<int> lane_cluster(p.n_lanes), flat_item_cluster;
     for (size_t g = 0; g < tgts.size(); ++g) for (int it : tgts[g].items) flat_item_cluster.push_back(item_cluster[it]);
@@ -828,7 +860,7 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
     // ---- info ---------------------------------------------------------------------------------------
     p.info.rows_per_tile = p.rows; p.info.total_nodes = p.NN; p.info.lds_bytes = (int64_t)p.n_blk * p.blk_bytes;
     p.info.flops_fwd = alg_fwd; p.info.flops_bwd = alg_bwd; p.info.flops_exec_fwd = exec_fwd; p.info.flops_exec_bwd = exec_bwd;
-    double bytes = 0; for (int t = 0; t < NT; ++t) bytes += (double)d.type_nodes[t] * d.type_width[t] * p.esize;
+    double bytes = 0; for (int t = 0; t < NT; ++t) bytes += (double)d.type_nodes[t] * d.type_width[t] * (p.split ? 4 : p.esize);     // split plan: fp32 inputs
     p.info.bytes_in = bytes; p.info.n_gradw_workgroups = p.n_wg_gradw;
     p.info.n_launches_fwd = 3 + L; p.info.n_launches_bwd = 3 + L;
     p.info.grad_split = p.grad_split;
@@ -836,7 +868,7 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
 
     // ---- per-kernel work table (launch order of one fwd+bwd step) -----------------------------------------
     {
-        const double es = p.esize, act = (double)p.NN * H * es;
+        const double es = p.esize * p.planes, act = (double)p.NN * H * es;
         auto add = [&](const std::string& name, int bound, double fa, double fe, double by) {
             mshgnn_kernel_stat k{}; std::snprintf(k.name, sizeof(k.name), "%s", name.c_str());
             k.bound = bound; k.flops_per_window = fa; k.flops_exec_per_window = fe; k.bytes_per_window = by;
@@ -881,7 +913,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline void layout_workspace(const HostPlan& p, int64_t B, int training, mshgnn_ws_layout* o) {
     std::memset(o, 0, sizeof(*o));
     size_t off = 0;
-    const size_t act = (size_t)B * p.NN * H * p.esize, mlp = (size_t)B * std::max(1, p.n_mlp) * H * p.esize;
+    const size_t act = (size_t)B * p.NN * H * p.esize * p.planes, mlp = (size_t)B * std::max(1, p.n_mlp) * H * p.esize * p.planes;     // split plan: hi plane, then lo plane
     auto take = [&](size_t bytes) { size_t r = off; off = align_up(off + bytes, 256); return r; };
     for (int l = 0; l <= p.L; ++l) o->x[l] = take(act);
     for (int l = 0; l < p.L; ++l) { o->mask[l] = take((size_t)((B + 15) / 16 * 16) * p.NN * 4 * 4); o->hb[l] = take(mlp); o->t1[l] = take(mlp); }
@@ -893,7 +925,7 @@ inline void layout_workspace(const HostPlan& p, int64_t B, int training, mshgnn_
         // decoder partials: NWG_DEC from k_dec_bwd, or one per 16-window tile when the fused forward produces them (mshgnn_step_mse)
         o->dec_slabs = take((size_t)std::max<int64_t>(NWG_DEC, (B + TILE_ROWS - 1) / TILE_ROWS) * DEC_SLAB_FLOATS * 4);
     }
-    o->wpack = take(p.packs.size() * (size_t)H * H * p.esize);
+    o->wpack = take(p.packs.size() * (size_t)H * H * p.esize * p.planes);
     o->bias = take(p.biases.size() * (size_t)H * 4);
     o->loss = take(64);
     o->total = off;

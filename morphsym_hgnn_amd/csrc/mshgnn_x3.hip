@@ -1,0 +1,847 @@
+// Split-bf16 parity plan (MSHGNN_BF16X3) of the MS-HGNN engine: the same path as the bf16 plan of mshgnn.hip
+// (GRF_HGNN_C2.forward hgnn_c2.py:133-182 and its autograd backward, lowered as DESIGN.md section 2 describes) at the
+// north_star's tolerance (1e-4 relative) on the bf16 matrix cores.
+//
+// Every fp32 quantity x that feeds a product -- inputs, weights, activations, activation gradients -- travels as two bf16
+// values, hi = bf16(x) and lo = bf16(x - hi): x = hi + lo to 16 mantissa bits.  A product is taken as
+//     x w  =  x_hi w_hi + x_lo w_hi + x_hi w_lo          (the lo x lo term is 2^-18 relative: below fp32 resolution)
+// with fp32 accumulation, i.e. three bf16 MFMAs per term instead of one fp32 MFMA at 1/16 of the rate.  Layout:
+//   * inputs x[t]: fp32 in HBM (as the MSHGNN_F32 plan takes them); split in registers while they are staged;
+//   * every activation tensor in the workspace: two bf16 planes, hi then lo ([NN][B][128] each) -- what the bf16 kernels
+//     read and write, twice; the weight-gradient kernel streams both planes of both operands;
+//   * LDS tile of the stack kernels: block n = hi plane of node n, block lo_blk + n = its lo plane (A1-C2: 40 blocks = 160 KB,
+//     one 8-wave workgroup per CU); k_prep writes a hi and a lo image of every weight pack;
+//   * the MAC loop of the stack kernels is the bf16 plan's: the plan compiler (split_segs, mshgnn_plan.hpp) turns each
+//     segment into two -- the hi image with the hi and lo block of every source, the lo image with the hi block.
+#include "mshgnn_device.hpp"
+
+using T16 = __bf16;
+using P16 = Prec<__bf16>;
+
+// ------------------------------------------------------------------------------------------------------
+// k_prep_x3: hi and lo MFMA B-fragment images of every weight pack (root-sum, transpose) + bias sums
+// ------------------------------------------------------------------------------------------------------
+__global__ void k_prep_x3(PrepArgs a) {
+    constexpr int EPC = 8, NBV = 8;
+    const int vec_per_pack = H * H / EPC;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = a.n_packs * vec_per_pack;
+    if (gid < total) {
+        const int pack = gid / vec_per_pack, r = gid % vec_per_pack;
+        const int lane = r % 64, v = (r / 64) % NBV, wv = r / (64 * NBV);
+        const PackDesc pd = a.packs[pack];
+        float g[8][EPC];     // up to 8 source matrices (root-sum), every gather issued before the first add
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int x = 0; x < EPC; ++x) {
+                // same element map as k_prep<__bf16>: MFMA row i = lane & 15 of the wave's 16-row block fb carries output feature 8 (i / 4) + 4 fb + i % 4
+                const int i16 = lane & 15;
+                const int k = 32 * (lane >> 4) + 8 * (v & 3) + x, col = wv * 32 + 8 * (i16 >> 2) + 4 * (v >> 2) + (i16 & 3);
+                g[i][x] = 0.f;
+                if (i < pd.n_src) {
+                    if (pd.orient == 0) { if (k < pd.ncols) g[i][x] = a.params[pd.src[i] + (int64_t)col * pd.ld + pd.col0 + k]; }
+                    else g[i][x] = a.params[pd.src[i] + (int64_t)k * pd.ld + col];
+                }
+            }
+        float sum[EPC];
+#pragma unroll
+        for (int x = 0; x < EPC; ++x) {
+            sum[x] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sum[x] += g[i][x];     // fixed order: same value every step
+        }
+        u32x4 hi, lo;
+        split_oct(f32x4{sum[0], sum[1], sum[2], sum[3]}, f32x4{sum[4], sum[5], sum[6], sum[7]}, hi, lo);
+        u32x4* dst = reinterpret_cast<u32x4*>(a.wpack);
+        dst[gid] = hi;
+        dst[(size_t)total + gid] = lo;
+    } else {
+        const int b = gid - total;
+        if (b < a.n_biases * H) {
+            const BiasDesc bd = a.biases[b / H];
+            float s = 0.f;
+            for (int i = 0; i < bd.n_src; ++i) s += a.params[bd.src[i] + (b % H)];
+            a.bias[b] = s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// k_enc_x3: X_0[node] = relu((mask . x) W_enc^T + b) from fp32 inputs (hgnn_c2.py:143-147); one workgroup = 64 windows of ONE
+// node, K streamed in chunks of 128 through LDS (hi blocks [0, 4), lo blocks [4, 8)), the next chunk prefetched in registers
+// ------------------------------------------------------------------------------------------------------
+template <bool ALIGNED> __global__ __launch_bounds__(256) void k_enc_x3(EncArgs a, size_t act_plane, int n_img) {
+    using P = P16;
+    constexpr int MB = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int t = 0;
+    while (t + 1 < a.n_types && (int)blockIdx.x >= a.wg_prefix[t + 1]) ++t;
+    const int local = blockIdx.x - a.wg_prefix[t];
+    const int node = local / a.tiles, tile = local % a.tiles;
+    const int w0 = tile * MB * P::ROWS;
+    const float* x = reinterpret_cast<const float*>(a.x[t]);
+    const int64_t pitch = a.pitch[t];
+    const int F = a.width[t], nt = a.nodes[t], nkc = a.nkc[t], vb = a.vb[t];
+    const uint8_t* sg = a.signs + a.sign_off[t] + (size_t)node * nkc * H;
+    const T16* wpack = reinterpret_cast<const T16*>(a.wpack);
+    const float* bias = a.bias + (size_t)a.bias_idx[t] * H;
+
+    P::Acc acc[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) acc_init_bias<T16>(acc[m], bias, wv, lane);
+    const int c = tid & 15, r0 = tid >> 4;      // staging: thread = (row, 8-element chunk) of each of the MB row blocks
+    P::BFrag bfh, bfl;
+    P::AFrag af;
+    const AOff<T16> ao(lane);
+    u32x4 v[MB][2];                             // the 8 fp32 elements of the chunk (two 16-byte loads)
+    auto fetch = [&](int kc) {
+        const int k0 = kc * H + c * 8;
+        const int nv = F - k0;
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            const int w = w0 + m * P::ROWS + r0;
+            if constexpr (ALIGNED) {
+                // unconditional raw loads (nothing uses them here): rows past the batch re-read the last row, halves past the row's end
+                // re-read the K chunk's first elements -- the staging pass zeroes the latter, the former are never stored
+                const float* src = x + ((size_t)min(w, a.B - 1) * nt + node) * pitch;
+                v[m][0] = *reinterpret_cast<const u32x4*>(src + (nv > 0 ? k0 : kc * H));
+                v[m][1] = *reinterpret_cast<const u32x4*>(src + (nv > 4 ? k0 + 4 : kc * H));
+            } else {
+                v[m][0] = u32x4{0, 0, 0, 0}; v[m][1] = u32x4{0, 0, 0, 0};
+                if (w < a.B) {
+                    const float* src = x + ((size_t)w * nt + node) * pitch + k0;
+                    v[m][0] = load_chunk<float>(src, nv, vb);
+                    v[m][1] = load_chunk<float>(src + 4, nv - 4, vb);
+                }
+            }
+        }
+    };
+    fetch(0);
+    for (int kc = 0; kc < nkc; ++kc) {
+        const u32x4 sxa = sign_xor<float>(sg + kc * H + c * 8), sxb = sign_xor<float>(sg + kc * H + c * 8 + 4);   // apply_symmetry: +-1 mask as a sign-bit XOR
+        const int nv = F - (kc * H + c * 8);
+        __syncthreads();   // previous chunk's MFMAs are done reading LDS
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            u32x4 fa = v[m][0], fb = v[m][1];
+            if (kc + 1 == nkc) { fa = chunk_keep_first<float>(fa, nv); fb = chunk_keep_first<float>(fb, nv - 4); }     // only the last K chunk has pad columns
+            fa ^= sxa; fb ^= sxb;
+            u32x4 hi, lo;
+            split_oct(__builtin_bit_cast(f32x4, fa), __builtin_bit_cast(f32x4, fb), hi, lo);
+            *reinterpret_cast<u32x4*>(smem + lds_chunk<T16>(m, r0, c)) = hi;
+            *reinterpret_cast<u32x4*>(smem + lds_chunk<T16>(MB + m, r0, c)) = lo;
+        }
+        __syncthreads();
+        load_bfrag<T16>(bfh, wpack, a.pack0[t] + kc, wv, lane);              // before the prefetch: vmcnt retires in order
+        load_bfrag<T16>(bfl, wpack, n_img + a.pack0[t] + kc, wv, lane);
+        if (kc + 1 < nkc) fetch(kc + 1);   // the next K chunk streams from HBM under this chunk's MFMAs
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            if (w0 + m * P::ROWS < a.B) {   // uniform
+                load_afrag<T16>(af, smem, m, ao);
+                mac(acc[m], af, bfh);
+                mac(acc[m], af, bfl);
+                load_afrag<T16>(af, smem, MB + m, ao);
+                mac(acc[m], af, bfh);
+            }
+        }
+    }
+    T16* x0 = reinterpret_cast<T16*>(a.x0);
+    const int gnode = a.tbase[t] + node;
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+        const int w = w0 + m * P::ROWS + c_win(lane);
+        if (w0 + m * P::ROWS < a.B) {     // uniform: the 16-window block exists (rows past the batch land in the mask buffer's padding)
+            const unsigned bits = relu_with_bits<T16>(acc[m]);
+            if (a.mask0) a.mask0[relu_tile_base(gnode, a.B, (w0 + m * P::ROWS) >> 4, wv) + lane] = (uint8_t)bits;
+        }
+        if (w < a.B) {
+            u32x4 hi, lo;
+            split_oct(acc[m].c[0], acc[m].c[1], hi, lo);
+            T16* q = x0 + act_idx(w, gnode, a.B) + wv * 32 + c_oct(lane);
+            *reinterpret_cast<u32x4*>(q) = hi;
+            *reinterpret_cast<u32x4*>(q + act_plane) = lo;
+        }
+    }
+}
+
+// three-product block GEMM of the base_transform chain on this wave's <= 2 accumulators: acc[u] += LDS[blk] (hi + lo) . W (hi + lo)
+template <int N> __device__ __forceinline__ void mlp_mac3(P16::Acc (&acc)[N], const char* smem, int blk0, int lo_blk, int nmlp, int wh, const P16::BFrag& wh_, const P16::BFrag& wl_, int lane) {
+    P16::AFrag af;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int n = 2 * u + wh;
+        if (n < nmlp) {
+            load_afrag<T16>(af, smem, blk0 + n, lane);
+            mac(acc[u], af, wh_);
+            mac(acc[u], af, wl_);
+            load_afrag<T16>(af, smem, lo_blk + blk0 + n, lane);
+            mac(acc[u], af, wh_);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// k_stack_fwd_x3: the whole message-passing stack (+ decoder, + wrapper MSE and decoder backward under mshgnn_step_mse) of one
+// 16-window tile in one 8-wave workgroup -- k_stack_fwd of the bf16 plan on hi/lo planes
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_fwd_x3(StackArgs a) {
+    using T = T16; using P = P16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wv & 3, wh = wv >> 2;
+    const int w0 = blockIdx.x * P::ROWS, B = a.B, NN = a.NN, LO = a.lo_blk;
+    const T* wpack = reinterpret_cast<const T*>(a.wpack);
+    const int win = c_win(lane), w = w0 + win, col = wn * 32 + c_oct(lane);
+    const bool w_ok = w < B, train = a.training != 0;
+
+    stage_nodes<T>(smem, reinterpret_cast<const T*>(a.tile_in), NN, w0, B, tid);
+    stage_nodes<T>(smem + LO * P::BLK, reinterpret_cast<const T*>(a.tile_in) + a.act_plane, NN, w0, B, tid);
+    __syncthreads();
+
+    P::Acc acc[FS_HS];
+    FHdr fhn(a.tables + a.prog_off[0], lane);
+    FProg wpn(a.tables + a.prog_off[0] + FH_SIZE + wh * FPROG_LEN, lane);
+    for (int l = 0; l < a.L; ++l) {
+        const FHdr fh = fhn;
+        const FProg wp = wpn;
+        if (l + 1 < a.L) {    // the next layer's header and wave program stream in under this layer's MACs
+            fhn = FHdr(a.tables + a.prog_off[l + 1], lane);
+            wpn = FProg(a.tables + a.prog_off[l + 1] + FH_SIZE + wh * FPROG_LEN, lane);
+        }
+        const int nmlp = fh[FH_NMLP], flags = fh[FH_FLAGS];
+#pragma unroll
+        for (int u = 0; u < FS_HS; ++u) {
+            const int n = 2 * u + wh;
+            if (n < NN && fh[FH_KIND + n] != NK_DEAD) acc_init_bias<T>(acc[u], a.bias + (size_t)fh[FH_BIAS + n] * H, wn, lane);
+            else acc_fill(acc[u], 0.f);
+        }
+        fs_run<T>(wp, acc, smem, wpack, wn, lane);
+        __syncthreads();   // every wave is done reading X_l: the node blocks may be overwritten
+
+        u32x4 hph[2] = {}, hpl[2] = {}, tph[2] = {}, tpl[2] = {};
+        if (nmlp > 0) {
+            // base_transform: Y = W2 relu(W1 H + b1) + b2 on the first nmlp nodes (hgnn_c2.py:117-121,156); scratch blocks NN + i (hi),
+            // LO + NN + i (lo).  The H and T1 stashes are kept packed in registers and stored after the chain.
+            P::BFrag bfh, bfl;
+            load_bfrag<T>(bfh, wpack, fh[FH_W1], wn, lane);
+            load_bfrag<T>(bfl, wpack, a.n_img + fh[FH_W1], wn, lane);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int n = 2 * u + wh;
+                if (n < nmlp) {
+                    split_oct(acc[u].c[0], acc[u].c[1], hph[u], hpl[u]);
+                    *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(NN + n, win, col / P::EPC)) = hph[u];
+                    *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(LO + NN + n, win, col / P::EPC)) = hpl[u];
+                    acc_init_bias<T>(acc[u], a.bias + (size_t)fh[FH_B1] * H, wn, lane);
+                }
+            }
+            __syncthreads();
+            mlp_mac3(acc, smem, NN, LO, nmlp, wh, bfh, bfl, lane);      // accumulators 0..1 = nodes 0..3
+            load_bfrag<T>(bfh, wpack, fh[FH_W2], wn, lane);
+            load_bfrag<T>(bfl, wpack, a.n_img + fh[FH_W2], wn, lane);
+            __syncthreads();   // all reads of H done before T1 overwrites the scratch blocks
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int n = 2 * u + wh;
+                if (n < nmlp) {
+                    split_oct(relu4(acc[u].c[0]), relu4(acc[u].c[1]), tph[u], tpl[u]);
+                    *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(NN + n, win, col / P::EPC)) = tph[u];
+                    *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(LO + NN + n, win, col / P::EPC)) = tpl[u];
+                    acc_init_bias<T>(acc[u], a.bias + (size_t)fh[FH_B2] * H, wn, lane);
+                }
+            }
+            __syncthreads();
+            mlp_mac3(acc, smem, NN, LO, nmlp, wh, bfh, bfl, lane);      // accumulators 0..1 = nodes 0..3
+        }
+        // every load issued so far has landed before the first store of the epilogue goes out
+        __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));
+        if (nmlp > 0 && train && w_ok) {
+            T* hb = reinterpret_cast<T*>(a.ws + a.hb_off[l]);
+            T* t1 = reinterpret_cast<T*>(a.ws + a.t1_off[l]);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int n = 2 * u + wh;
+                if (n < nmlp) {
+                    *reinterpret_cast<u32x4*>(hb + act_idx(w, n, B) + col) = hph[u];
+                    *reinterpret_cast<u32x4*>(hb + a.mlp_plane + act_idx(w, n, B) + col) = hpl[u];
+                    *reinterpret_cast<u32x4*>(t1 + act_idx(w, n, B) + col) = tph[u];
+                    *reinterpret_cast<u32x4*>(t1 + a.mlp_plane + act_idx(w, n, B) + col) = tpl[u];
+                }
+            }
+        }
+
+        // X_{l+1}[n] = f(H[n]) (+ X_l[n]) for every live node, in place; stash + relu bits on the side
+        T* xo = reinterpret_cast<T*>(a.ws + a.x_off[l + 1]);
+        uint8_t* maskbytes = reinterpret_cast<uint8_t*>(a.ws + a.mask_off[l]);
+        u32x4 resh[FS_HS], resl[FS_HS]; int kindv[FS_HS];     // the residual octets of every node, all LDS reads in flight together
+#pragma unroll
+        for (int u = 0; u < FS_HS; ++u) {
+            const int n = 2 * u + wh;
+            kindv[u] = n < NN ? fh[FH_KIND + n] : NK_DEAD;
+            resh[u] = u32x4{0, 0, 0, 0}; resl[u] = u32x4{0, 0, 0, 0};
+            if (kindv[u] != NK_DEAD && (flags & FF_RESIDUAL)) {
+                resh[u] = *reinterpret_cast<const u32x4*>(smem + lds_chunk<T>(n, win, col / P::EPC));
+                resl[u] = *reinterpret_cast<const u32x4*>(smem + lds_chunk<T>(LO + n, win, col / P::EPC));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < FS_HS; ++u) {
+            const int n = 2 * u + wh;
+            if (n < NN) {
+                const int kind = kindv[u];
+                if (kind != NK_DEAD) {
+                    if (kind == NK_RELU) {
+                        const unsigned bits = relu_with_bits<T>(acc[u]);
+                        if (train) maskbytes[relu_byte(n, B, w, col)] = (uint8_t)bits;
+                    }
+                    f32x4 y0 = acc[u].c[0], y1 = acc[u].c[1];
+                    if (flags & FF_RESIDUAL) {
+                        f32x4 r0, r1;
+                        join_oct(resh[u], resl[u], r0, r1);
+                        y0 += r0; y1 += r1;
+                    }
+                    u32x4 hi, lo;
+                    split_oct(y0, y1, hi, lo);
+                    *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(n, win, col / P::EPC)) = hi;
+                    *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(LO + n, win, col / P::EPC)) = lo;
+                    if (train && w_ok) {
+                        T* q = xo + act_idx(w, n, B) + col;
+                        *reinterpret_cast<u32x4*>(q) = hi;
+                        *reinterpret_cast<u32x4*>(q + a.act_plane) = lo;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    decoder_tail<T, LAYER_THREADS, true>(a, smem, tid, lane, wv, w0, B);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// k_stack_bwd_x3: the L backward layers of a tile -- k_stack_bwd of the bf16 plan on hi/lo planes
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_bwd_x3(StackArgs a) {
+    using T = T16; using P = P16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wv & 3, wh = wv >> 2;
+    const int w0 = blockIdx.x * P::ROWS, B = a.B, NN = a.NN, LO = a.lo_blk;
+    const T* wpack = reinterpret_cast<const T*>(a.wpack);
+    const int win = c_win(lane), w = w0 + win, col = wn * 32 + c_oct(lane), g8 = (lane >> 4) << 3;
+    const bool w_ok = w < B;
+
+    // dX_L tile: only the nodes that are live in the last layer carry a gradient
+    {
+        const FHdr bh(a.tables + a.prog_off[a.L - 1], lane);
+        const T* src = reinterpret_cast<const T*>(a.tile_in);
+        const RowMap<T> m(tid);
+        for (int n = m.sub; n < NN; n += RowMap<T>::NPB) {
+            if (bh[FH_KIND + n] == NK_DEAD) continue;
+            u32x4 vh = u32x4{0, 0, 0, 0}, vl = u32x4{0, 0, 0, 0};
+            if (w0 + m.row < B) {
+                const T* q = src + act_idx(w0 + m.row, n, B) + m.c * P::EPC;
+                vh = *reinterpret_cast<const u32x4*>(q); vl = *reinterpret_cast<const u32x4*>(q + a.act_plane);
+            }
+            *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(n, m.row, m.c)) = vh;
+            *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(LO + n, m.row, m.c)) = vl;
+        }
+    }
+    __syncthreads();
+
+    P::Acc acc[FS_HS];
+    FHdr bhn(a.tables + a.prog_off[a.L - 1], lane);
+    FProg wpn(a.tables + a.prog_off[a.L - 1] + FH_SIZE + wh * FPROG_LEN, lane);
+    for (int l = a.L - 1; l >= 0; --l) {
+        const FHdr bh = bhn;
+        const FProg wp = wpn;
+        if (l > 0) {          // the next layer's header and wave program stream in under this layer's MACs
+            bhn = FHdr(a.tables + a.prog_off[l - 1], lane);
+            wpn = FProg(a.tables + a.prog_off[l - 1] + FH_SIZE + wh * FPROG_LEN, lane);
+        }
+        const int nmlp = bh[FH_NMLP], flags = bh[FH_FLAGS];
+        const uint8_t* maskbytes = reinterpret_cast<const uint8_t*>(a.ws + a.mask_off[l]);
+
+        // phase 1 (each lane on the octets it owns): the accumulator of node n starts at its residual term G_{l+1}[n]; relu nodes are
+        // then masked in place (both planes) -> dH_l[n]
+        {
+            unsigned mword[FS_HS]; u32x4 rawh[FS_HS], rawl[FS_HS]; int kindv[FS_HS];
+#pragma unroll
+            for (int u = 0; u < FS_HS; ++u) {
+                const int n = 2 * u + wh;
+                kindv[u] = n < NN ? bh[FH_KIND + n] : NK_DEAD;
+                mword[u] = 0u; rawh[u] = u32x4{0, 0, 0, 0}; rawl[u] = u32x4{0, 0, 0, 0};
+                if (kindv[u] == NK_RELU && w_ok) mword[u] = maskbytes[relu_byte(n, B, w, wn * 32 + g8)];
+                if (kindv[u] != NK_DEAD) {
+                    rawh[u] = *reinterpret_cast<const u32x4*>(smem + lds_chunk<T>(n, win, col / P::EPC));
+                    rawl[u] = *reinterpret_cast<const u32x4*>(smem + lds_chunk<T>(LO + n, win, col / P::EPC));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < FS_HS; ++u) {
+                const int n = 2 * u + wh;
+                acc_fill(acc[u], 0.f);
+                if (kindv[u] != NK_DEAD) {
+                    if (bh[FH_RES + n]) join_oct(rawh[u], rawl[u], acc[u].c[0], acc[u].c[1]);
+                    if (kindv[u] == NK_RELU) {
+                        *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(n, win, col / P::EPC)) = chunk_mask_bits<T>(rawh[u], mword[u]);
+                        *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(LO + n, win, col / P::EPC)) = chunk_mask_bits<T>(rawl[u], mword[u]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        if (nmlp > 0) {
+            // dT1 = dY W2 ; dU = dT1 . (T1 > 0) ; dH = dU W1     (backward of base_transform, in place on nodes 0..nmlp-1)
+            const T* t1 = reinterpret_cast<const T*>(a.ws + a.t1_off[l]);
+            T* du = reinterpret_cast<T*>(a.ws + a.du_off[l]);
+            T* dh = reinterpret_cast<T*>(a.ws + a.dh_off[l]);
+            P::BFrag bfh, bfl;
+            P::Acc tm[2];
+            u32x4 traw[2];
+            load_bfrag<T>(bfh, wpack, bh[FH_W2], wn, lane);
+            load_bfrag<T>(bfl, wpack, a.n_img + bh[FH_W2], wn, lane);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int n = 2 * u + wh;
+                traw[u] = u32x4{0, 0, 0, 0};
+                acc_fill(tm[u], 0.f);
+                if (n < nmlp && w_ok) traw[u] = *reinterpret_cast<const u32x4*>(t1 + act_idx(w, n, B) + col);     // the hi plane carries the sign of T1
+            }
+            mlp_mac3(tm, smem, 0, LO, nmlp, wh, bfh, bfl, lane);
+            load_bfrag<T>(bfh, wpack, bh[FH_W1], wn, lane);
+            load_bfrag<T>(bfl, wpack, a.n_img + bh[FH_W1], wn, lane);
+            __syncthreads();   // all reads of the dY blocks done
+            u32x4 duh[2] = {}, dul[2] = {};
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int n = 2 * u + wh;
+                if (n < nmlp) {
+                    f32x4 t0, t1v, r0, r1; unpack_oct(traw[u], t0, t1v);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { r0[j] = t0[j] > 0.f ? tm[u].c[0][j] : 0.f; r1[j] = t1v[j] > 0.f ? tm[u].c[1][j] : 0.f; }
+                    split_oct(r0, r1, duh[u], dul[u]);
+                    *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(n, win, col / P::EPC)) = duh[u];
+                    *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(LO + n, win, col / P::EPC)) = dul[u];
+                    acc_fill(tm[u], 0.f);
+                }
+            }
+            __syncthreads();
+            mlp_mac3(tm, smem, 0, LO, nmlp, wh, bfh, bfl, lane);
+            __syncthreads();   // all reads of the dU blocks done
+            __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int n = 2 * u + wh;
+                if (n < nmlp) {
+                    u32x4 hh, hl;
+                    split_oct(tm[u].c[0], tm[u].c[1], hh, hl);
+                    *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(n, win, col / P::EPC)) = hh;
+                    *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(LO + n, win, col / P::EPC)) = hl;
+                    if (w_ok) {
+                        *reinterpret_cast<u32x4*>(du + act_idx(w, n, B) + col) = duh[u];
+                        *reinterpret_cast<u32x4*>(du + a.mlp_plane + act_idx(w, n, B) + col) = dul[u];
+                        *reinterpret_cast<u32x4*>(dh + act_idx(w, n, B) + col) = hh;
+                        *reinterpret_cast<u32x4*>(dh + a.act_plane + act_idx(w, n, B) + col) = hl;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+
+        // phase 2: dX_l[j] = (residual) + dH_j W_rootsum + sum_r sum_{j->i} dH_i W_rel^r
+        fs_run<T>(wp, acc, smem, wpack, wn, lane);
+        __syncthreads();   // every wave is done reading dH_l
+
+        T* dxo = reinterpret_cast<T*>(a.ws + a.dx_off[l]);
+        const uint8_t* m0 = reinterpret_cast<const uint8_t*>(a.ws + a.mask0_off);
+#pragma unroll
+        for (int u = 0; u < FS_HS; ++u) {
+            const int n = 2 * u + wh;
+            if (n < NN && bh[FH_OUT + n]) {
+                f32x4 y0 = acc[u].c[0], y1 = acc[u].c[1];
+                if ((flags & FF_ENC_MASK) && w_ok) {   // layer 0: x relu'(X_0): the encoder's relu byte of this lane
+                    const unsigned xb = m0[relu_byte(n, B, w, wn * 32 + g8)];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { y0[j] = ((xb >> j) & 1u) ? y0[j] : 0.f; y1[j] = ((xb >> (4 + j)) & 1u) ? y1[j] : 0.f; }
+                }
+                u32x4 hi, lo;
+                split_oct(y0, y1, hi, lo);
+                if (l > 0) {
+                    *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(n, win, col / P::EPC)) = hi;
+                    *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(LO + n, win, col / P::EPC)) = lo;
+                }
+                if (w_ok) {
+                    T* q = dxo + act_idx(w, n, B) + col;
+                    *reinterpret_cast<u32x4*>(q) = hi;
+                    *reinterpret_cast<u32x4*>(q + a.act_plane) = lo;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// k_dec_bwd_x3: decoder backward (+ fused wrapper MSE / cross entropy) on the hi/lo planes of X_L -> dX_L planes
+// (k_dec_bwd of mshgnn.hip; used by mshgnn_backward / _mse / _ce -- mshgnn_step_mse takes the fused tail of k_stack_fwd_x3)
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dec_bwd_x3(DecArgs a, size_t act_plane) {
+    using T = T16;
+    __shared__ float red[16][DEC_SLAB_FLOATS];
+    const int c = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int64_t rows = (int64_t)a.B * a.n_out;
+    const int64_t per = ((rows + gridDim.x - 1) / gridDim.x + 15) / 16 * 16;
+    const int64_t r_begin = (int64_t)blockIdx.x * per, r_end = min(rows, r_begin + per);
+    const T* xl = reinterpret_cast<const T*>(a.xl);
+    T* dxl = reinterpret_cast<T*>(a.dxl);
+    const float* W = a.params + a.off_w;
+    float accw[8][8], accb[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) { accb[d] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) accw[d][e] = 0.f; }
+    float lsum = 0.f;
+    for (int64_t r = r_begin + rg; r < r_end; r += 16) {
+        const int w = (int)(r / a.n_out), f = (int)(r % a.n_out);
+        const size_t idx = act_idx(w, a.node0 + f, a.B) + c * 8;
+        float x[8], xlo[8], dx[8];
+        load8<T>(xl + idx, x);
+        load8<T>(xl + act_plane + idx, xlo);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { x[e] += xlo[e]; dx[e] = 0.f; }
+        float ce_g[2] = {0.f, 0.f};
+        if (a.labels) {   // wrapper cross entropy fused (gnnLightning.py:640-648, mean over the batch * 4 feet): dL/dlogit = (p - onehot) / rows
+            const float l0 = a.out[r * 2], l1 = a.out[r * 2 + 1];
+            const float m = fmaxf(l0, l1), e0 = expf(l0 - m), e1 = expf(l1 - m), se = e0 + e1;
+            const int lab = a.labels[r] != 0;
+            ce_g[0] = (e0 / se - (lab ? 0.f : 1.f)) * a.inv_n; ce_g[1] = (e1 / se - (lab ? 1.f : 0.f)) * a.inv_n;
+            if (c == 0) lsum += (m + logf(se)) - (lab ? l1 : l0);
+        }
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            if (d < a.dout) {
+                float go;
+                if (a.labels) go = ce_g[d & 1];
+                else if (a.y) {   // wrapper MSE fused (gnnLightning.py:633-639): dL/dout = 2 (out - y) / n
+                    const float dlt = a.out[r * a.dout + d] - a.y[r * a.dout + d];
+                    go = 2.0f * dlt * a.inv_n;
+                    if (c == 0) lsum += dlt * dlt;
+                } else go = a.gout[r * a.dout + d];
+                const float g = go * a.out_mask[f * a.dout + d];
+                accb[d] += g;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { accw[d][e] += g * x[e]; dx[e] += g * W[d * H + c * 8 + e]; }
+            }
+        }
+        u32x4 hi, lo;
+        split_oct(f32x4{dx[0], dx[1], dx[2], dx[3]}, f32x4{dx[4], dx[5], dx[6], dx[7]}, hi, lo);
+        *reinterpret_cast<u32x4*>(dxl + idx) = hi;
+        *reinterpret_cast<u32x4*>(dxl + act_plane + idx) = lo;
+    }
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[rg][d * H + c * 8 + e] = accw[d][e];
+        if (c == 0) red[rg][8 * H + d] = accb[d];
+    }
+    __syncthreads();
+    float* slab = a.slabs + (size_t)blockIdx.x * DEC_SLAB_FLOATS;
+    {   // per-block loss partial rides in the slab (summed in fixed order by k_finalize: no atomics, deterministic)
+        __shared__ float lred[4];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) lsum += __shfl_xor(lsum, m, 64);
+        if ((threadIdx.x & 63) == 0) lred[threadIdx.x >> 6] = lsum;
+        __syncthreads();
+        if (threadIdx.x == 0) slab[8 * H + 8] = (lred[0] + lred[1]) + (lred[2] + lred[3]);
+    }
+    for (int i = threadIdx.x; i < 8 * H + 8; i += 256) {
+        float s2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s2 += red[r][i];
+        slab[i] = s2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// k_gradw_x3: all weight gradients of the step as one split-K MFMA launch, dW[o][k] = sum_w P[w][o] Q[w][k] with
+// P = P_hi + P_lo, Q = Q_hi + Q_lo: four staged tiles per 64-window step, P_hi Q_hi + P_hi Q_lo + P_lo Q_hi on the 32x32x16 bf16
+// MFMA.  Workgroup = (lane = one item, window part); raw encoder inputs (fp32) are split while they are staged.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_gradw_x3(GradwArgs a, size_t act_plane, size_t mlp_plane) {
+    using T = T16;
+    __shared__ __attribute__((aligned(16))) __bf16 Ph[GWB_KW * GWB_PITCH];
+    __shared__ __attribute__((aligned(16))) __bf16 Pl[GWB_KW * GWB_PITCH];
+    __shared__ __attribute__((aligned(16))) __bf16 Qh[GWB_KW * GWB_PITCH];
+    __shared__ __attribute__((aligned(16))) __bf16 Ql[GWB_KW * GWB_PITCH];
+    __shared__ __attribute__((aligned(16))) u32x4 mlut[256];       // relu byte -> AND mask of 8 bf16
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    mlut[tid] = chunk_mask_bits<__bf16>(u32x4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, (unsigned)tid);   // (visible after the first barrier)
+    const int wr = wv >> 1, wc = wv & 1;
+    const int ln = a.lane_order[blockIdx.x % a.n_pad], part = blockIdx.x / a.n_pad;
+    if (ln < 0) return;
+    const int* lh = a.lanes + ln * LANE_INTS;
+    const int bias_flag = lh[3];
+    const int nchunks = (a.B + GWB_KW - 1) / GWB_KW;
+    const int ch0 = (int)((int64_t)part * nchunks / a.n_parts), ch1 = (int)((int64_t)(part + 1) * nchunks / a.n_parts);
+    const int nsteps = ch1 - ch0;            // one item per lane on the split plan
+    const int c = tid & 15, r0 = tid >> 4;   // staging: 16 chunks of 8 elements per row, 16 rows per pass
+
+    const int* im = a.items + lh[0] * ITEM_INTS;
+    auto plane_of = [&](int buf) { return (buf >= BUF_HB && buf < BUF_IN) ? mlp_plane : act_plane; };     // elements
+    const T* p_hi = reinterpret_cast<const T*>(a.ws + a.buf_off[im[0]]) + act_idx(0, im[2], a.B) + c * 8;
+    const T* p_lo = p_hi + plane_of(im[0]);
+    const uint8_t* mb = im[9] >= 0 ? reinterpret_cast<const uint8_t*>(a.ws + a.buf_off[im[9]]) + relu_byte(im[2], a.B, 0, c * 8) : nullptr;
+    const bool q_act = im[4] >= 0;           // Q is an activation stash (two bf16 planes) / a raw fp32 input
+    const T* q_hi = nullptr; const T* q_lo = nullptr; const float* qf = nullptr;
+    int64_t qstride = H; int qvalid = 8, qvb = 16;
+    u32x4 sxa = u32x4{0, 0, 0, 0}, sxb = u32x4{0, 0, 0, 0};
+    if (q_act) {
+        q_hi = reinterpret_cast<const T*>(a.ws + a.buf_off[im[3]]) + act_idx(0, im[5], a.B) + c * 8;
+        q_lo = q_hi + plane_of(im[3]);
+    } else {
+        const int t = im[3] - BUF_IN;
+        qf = reinterpret_cast<const float*>(a.x[t]) + (size_t)im[5] * a.pitch[t] + im[6] + c * 8;
+        qstride = (int64_t)a.nodes[t] * a.pitch[t]; qvalid = im[7] - c * 8; qvb = a.vb[t];
+        sxa = sign_xor<float>(a.signs + im[8] + c * 8); sxb = sign_xor<float>(a.signs + im[8] + c * 8 + 4);
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+    float bsum[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
+
+    struct Stage { u32x4 ph[4], pl[4], qa[4], qb[4]; unsigned mw[4]; };     // qa / qb: the hi / lo plane rows, or the two fp32 halves of a raw row
+    auto fetch = [&](Stage& st, int s) {
+        const int w0 = (ch0 + s) * GWB_KW;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int w = w0 + r0 + 16 * p;
+            st.ph[p] = u32x4{0, 0, 0, 0}; st.pl[p] = u32x4{0, 0, 0, 0}; st.qa[p] = u32x4{0, 0, 0, 0}; st.qb[p] = u32x4{0, 0, 0, 0}; st.mw[p] = 0xffffffffu;
+            if (w < a.B) {
+                st.ph[p] = *reinterpret_cast<const u32x4*>(p_hi + (size_t)w * H);
+                st.pl[p] = *reinterpret_cast<const u32x4*>(p_lo + (size_t)w * H);
+                if (mb) st.mw[p] = mb[((size_t)(w >> 4) << 6) + (w & 15)];
+                if (q_act) {
+                    st.qa[p] = *reinterpret_cast<const u32x4*>(q_hi + (size_t)w * H);
+                    st.qb[p] = *reinterpret_cast<const u32x4*>(q_lo + (size_t)w * H);
+                } else if (a.aligned) {      // raw: a use here would serialise the loads
+                    if (qvalid > 0) st.qa[p] = *reinterpret_cast<const u32x4*>(qf + (size_t)w * qstride);
+                    if (qvalid > 4) st.qb[p] = *reinterpret_cast<const u32x4*>(qf + (size_t)w * qstride + 4);
+                } else {
+                    st.qa[p] = load_chunk<float>(qf + (size_t)w * qstride, qvalid, qvb);
+                    st.qb[p] = load_chunk<float>(qf + (size_t)w * qstride + 4, qvalid - 4, qvb);
+                }
+            }
+        }
+    };
+    const bool p_masked = mb != nullptr;
+    auto stage_to_lds = [&](const Stage& st) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int row = r0 + 16 * p;
+            u32x4 ph = st.ph[p], pl = st.pl[p];
+            if (p_masked) { const u32x4 m = mlut[st.mw[p] & 0xffu]; ph &= m; pl &= m; }     // dH = dX . relu bits
+            *reinterpret_cast<u32x4*>(&Ph[gwb_elem(row, c * 8)]) = ph;
+            *reinterpret_cast<u32x4*>(&Pl[gwb_elem(row, c * 8)]) = pl;
+            u32x4 qh = st.qa[p], ql = st.qb[p];
+            if (!q_act) {      // drop pad columns, symmetry sign mask, fp32 -> hi / lo
+                const u32x4 fa = chunk_keep_first<float>(st.qa[p], qvalid) ^ sxa, fb = chunk_keep_first<float>(st.qb[p], qvalid - 4) ^ sxb;
+                split_oct(__builtin_bit_cast(f32x4, fa), __builtin_bit_cast(f32x4, fb), qh, ql);
+            }
+            *reinterpret_cast<u32x4*>(&Qh[gwb_elem(row, c * 8)]) = qh;
+            *reinterpret_cast<u32x4*>(&Ql[gwb_elem(row, c * 8)]) = ql;
+            if (bias_flag) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bsum[2 * e] += __builtin_bit_cast(float, ph[e] << 16) + __builtin_bit_cast(float, pl[e] << 16);
+                    bsum[2 * e + 1] += __builtin_bit_cast(float, ph[e] & 0xffff0000u) + __builtin_bit_cast(float, pl[e] & 0xffff0000u);
+                }
+            }
+        }
+    };
+    auto mfmas = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < GWB_KW / 16; ++ks) {
+            bf16x8 afh[2], afl[2], bqh[2], bql[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                afh[i] = tr_frag(Ph, ks * 16, wr * 64 + i * 32, lane);
+                afl[i] = tr_frag(Pl, ks * 16, wr * 64 + i * 32, lane);
+                bqh[i] = tr_frag(Qh, ks * 16, wc * 64 + i * 32, lane);
+                bql[i] = tr_frag(Ql, ks * 16, wc * 64 + i * 32, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afh[i], bqh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afh[i], bql[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afl[i], bqh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+    Stage sa;
+    if (nsteps > 0) fetch(sa, 0);
+    for (int s = 0; s < nsteps; ++s) {
+        __syncthreads();      // the previous MFMA phase of every wave is done reading the tiles
+        stage_to_lds(sa);
+        __syncthreads();
+        if (s + 1 < nsteps) fetch(sa, s + 1);
+        mfmas();
+    }
+    float* slab = a.slabs + (size_t)(part * a.n_lanes + ln) * SLAB_FLOATS;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int o = wr * 64 + i * 32 + (q & 3) + ((q >> 2) << 3) + ((lane >> 5) << 2), k = wc * 64 + j * 32 + (lane & 31);
+                slab[o * H + k] = acc[i][j][q];
+            }
+    if (bias_flag) {
+        float* red = reinterpret_cast<float*>(Ph);   // 16 x 128 floats = 8 KB <= one tile
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[r0 * H + c * 8 + e] = bsum[e];
+        __syncthreads();
+        if (tid < H) {
+            float s2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s2 += red[r * H + tid];
+            slab[H * H + tid] = s2;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// launch sequences (mirrors of forward_impl / backward_impl in mshgnn.hip)
+// ------------------------------------------------------------------------------------------------------
+static int x3_lds_stack(const HostPlan& hp) { return 2 * hp.fs_blk * P16::BLK; }
+
+int x3_set_attrs(mshgnn_plan* p) {
+    int rc;
+    const int flds = x3_lds_stack(p->hp);
+    if ((rc = set_lds_attr(k_stack_fwd_x3, flds)) || (rc = set_lds_attr(k_stack_bwd_x3, flds)) ||
+        (rc = set_lds_attr(k_enc_x3<true>, 8 * P16::BLK)) || (rc = set_lds_attr(k_enc_x3<false>, 8 * P16::BLK))) return rc;
+    return MSHGNN_OK;
+}
+
+static void x3_stack_args(const mshgnn_plan* p, const mshgnn_ws_layout& lay, char* ws, int B, StackArgs& a) {
+    const HostPlan& hp = p->hp;
+    a.ws = ws;
+    for (int l = 0; l <= hp.L; ++l) { a.x_off[l] = lay.x[l]; a.dx_off[l] = lay.dx[l]; }
+    for (int l = 0; l < hp.L; ++l) { a.mask_off[l] = lay.mask[l]; a.hb_off[l] = lay.hb[l]; a.t1_off[l] = lay.t1[l]; a.dh_off[l] = lay.dh[l]; a.du_off[l] = lay.du[l]; }
+    a.wpack = ws + lay.wpack; a.bias = reinterpret_cast<const float*>(ws + lay.bias); a.tables = p->d_tables;
+    a.B = B; a.NN = hp.NN; a.L = hp.L;
+    a.lo_blk = hp.lo_blk; a.n_img = hp.n_img;
+    a.act_plane = (size_t)B * hp.NN * H; a.mlp_plane = (size_t)B * std::max(1, hp.n_mlp) * H;
+}
+
+int x3_forward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, float* out, char* ws, int64_t batch,
+               int training, hipStream_t st, const float* y_fused) {
+    const HostPlan& hp = p->hp;
+    const mshgnn_desc& d = hp.d;
+    mshgnn_ws_layout lay; layout_workspace(hp, batch, training, &lay);
+    const int B = (int)batch;
+    const size_t act_plane = (size_t)B * hp.NN * H;
+    {   // 1. hi / lo weight images
+        PrepArgs a{params, ws + lay.wpack, reinterpret_cast<float*>(ws + lay.bias), p->d_packs, p->d_biases, hp.n_img, (int)hp.biases.size()};
+        const int64_t total = (int64_t)hp.n_img * (H * H / 8) + (int64_t)hp.biases.size() * H;
+        ProfScope ps(p, hp.ks_prep, st);
+        hipLaunchKernelGGL(k_prep_x3, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
+    }
+    {   // 2. encoder (fp32 inputs)
+        EncArgs a{};
+        a.n_types = hp.NT; a.B = B; a.NN = hp.NN; a.tiles = (B + 63) / 64;
+        a.wg_prefix[0] = 0;
+        for (int t = 0; t < hp.NT; ++t) {
+            a.x[t] = x[t]; a.pitch[t] = x_pitch ? x_pitch[t] : d.type_width[t];
+            if (a.pitch[t] < d.type_width[t]) return set_err(MSHGNN_EINVAL, "x_pitch smaller than the feature width");
+            a.vb[t] = vec_bytes(x[t], a.pitch[t], 4);
+            if (t == 0) a.aligned = 1;
+            if (a.vb[t] != 16 || a.pitch[t] % 4) a.aligned = 0;
+            a.width[t] = d.type_width[t]; a.nodes[t] = d.type_nodes[t]; a.tbase[t] = hp.type_base[t]; a.nkc[t] = hp.enc_nkc[t];
+            a.pack0[t] = hp.pack_enc_base[t]; a.bias_idx[t] = hp.bias_enc[t]; a.sign_off[t] = hp.sign_off[t];
+            a.wg_prefix[t + 1] = a.wg_prefix[t] + d.type_nodes[t] * a.tiles;
+        }
+        a.wpack = ws + lay.wpack; a.bias = reinterpret_cast<const float*>(ws + lay.bias); a.signs = p->d_signs; a.x0 = ws + lay.x[0];
+        a.mask0 = (training && lay.dd[0]) ? reinterpret_cast<uint8_t*>(ws + lay.dd[0]) : nullptr;
+        ProfScope ps(p, hp.ks_enc, st);
+        if (a.aligned) hipLaunchKernelGGL(k_enc_x3<true>, dim3(a.wg_prefix[hp.NT]), dim3(256), 8 * P16::BLK, st, a, act_plane, hp.n_img);
+        else hipLaunchKernelGGL(k_enc_x3<false>, dim3(a.wg_prefix[hp.NT]), dim3(256), 8 * P16::BLK, st, a, act_plane, hp.n_img);
+    }
+    {   // 3. all layers + decoder (+ MSE and decoder backward when y_fused)
+        StackArgs a{};
+        x3_stack_args(p, lay, ws, B, a);
+        a.tile_in = ws + lay.x[0]; a.training = training;
+        for (int l = 0; l < hp.L; ++l) a.prog_off[l] = hp.fs_fwd_off[l];
+        a.params = params; a.out_mask = p->d_out_mask; a.out = out; a.off_dec_w = d.off_dec_w; a.off_dec_b = d.off_dec_b;
+        a.node0 = hp.type_base[d.out_type]; a.n_out = d.type_nodes[d.out_type]; a.dout = d.out_channels;
+        if (y_fused) {
+            a.y = y_fused; a.dec_slabs = reinterpret_cast<float*>(ws + lay.dec_slabs);
+            a.inv_n = 1.0f / (float)((int64_t)B * a.n_out * a.dout);
+        }
+        const int tiles = (B + P16::ROWS - 1) / P16::ROWS;
+        ProfScope ps(p, hp.ks_stack_fwd, st);
+        hipLaunchKernelGGL(k_stack_fwd_x3, dim3(tiles), dim3(LAYER_THREADS), x3_lds_stack(hp), st, a);
+    }
+    HIPCHK(hipGetLastError());
+    return MSHGNN_OK;
+}
+
+int x3_backward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, const float* gout, float* gparams, char* ws,
+                int64_t batch, hipStream_t st, const float* out, const float* y, float* loss, const int32_t* labels, bool dec_done, int gw_phase) {
+    const HostPlan& hp = p->hp;
+    const mshgnn_desc& d = hp.d;
+    mshgnn_ws_layout lay; layout_workspace(hp, batch, 1, &lay);
+    const int B = (int)batch;
+    const size_t act_plane = (size_t)B * hp.NN * H, mlp_plane = (size_t)B * std::max(1, hp.n_mlp) * H;
+    if (!dec_done && gw_phase != 1) {
+        DecArgs a{};
+        a.xl = ws + lay.x[hp.L]; a.dxl = ws + lay.dx[hp.L]; a.params = params; a.out_mask = p->d_out_mask; a.gout = gout;
+        a.slabs = reinterpret_cast<float*>(ws + lay.dec_slabs); a.off_w = d.off_dec_w; a.off_b = d.off_dec_b;
+        a.B = B; a.NN = hp.NN; a.node0 = hp.type_base[d.out_type]; a.n_out = d.type_nodes[d.out_type]; a.dout = d.out_channels; a.slab0 = 0;
+        if (y) { a.y = y; a.out = const_cast<float*>(out); a.loss = loss; a.inv_n = 1.0f / (float)((int64_t)B * a.n_out * a.dout); }
+        if (labels) { a.labels = labels; a.out = const_cast<float*>(out); a.loss = loss; a.inv_n = 1.0f / (float)((int64_t)B * a.n_out); }
+        ProfScope ps(p, hp.ks_dec_bwd, st);
+        hipLaunchKernelGGL(k_dec_bwd_x3, dim3(NWG_DEC), dim3(256), 0, st, a, act_plane);
+    }
+    if (gw_phase != 1) {
+        StackArgs a{};
+        x3_stack_args(p, lay, ws, B, a);
+        a.tile_in = ws + lay.dx[hp.L]; a.training = 1; a.mask0_off = lay.dd[0];
+        for (int l = 0; l < hp.L; ++l) a.prog_off[l] = hp.fs_bwd_off[l];
+        const int tiles = (B + P16::ROWS - 1) / P16::ROWS;
+        ProfScope ps(p, hp.ks_stack_bwd, st);
+        hipLaunchKernelGGL(k_stack_bwd_x3, dim3(tiles), dim3(LAYER_THREADS), x3_lds_stack(hp), st, a);
+    }
+    {
+        GradwArgs a{};
+        a.ws = ws;
+        for (int l = 0; l <= hp.L; ++l) { a.buf_off[BUF_X + l] = lay.x[l]; a.buf_off[BUF_DX + l] = lay.dx[l]; }
+        for (int l = 0; l < hp.L; ++l) a.buf_off[BUF_MASK + l] = lay.mask[l];
+        for (int l = 0; l < hp.L; ++l) { a.buf_off[BUF_DH + l] = lay.dh[l]; a.buf_off[BUF_HB + l] = lay.hb[l]; a.buf_off[BUF_T1 + l] = lay.t1[l]; a.buf_off[BUF_DU + l] = lay.du[l]; }
+        for (int t = 0; t < hp.NT; ++t) {
+            a.x[t] = x[t]; a.pitch[t] = x_pitch ? x_pitch[t] : d.type_width[t]; a.nodes[t] = d.type_nodes[t];
+            a.vb[t] = vec_bytes(x[t], a.pitch[t], 4);
+            if (t == 0) a.aligned = 1;
+            if (a.vb[t] != 16 || a.pitch[t] % 4) a.aligned = 0;
+        }
+        a.items = p->d_tables + hp.item_off; a.lanes = p->d_tables + hp.lane_off; a.lane_order = p->d_tables + hp.lane_order_off; a.n_pad = hp.n_lanes_pad;
+        if (gw_phase >= 0) { a.lane_order = p->d_tables + hp.order_ph_off[gw_phase]; a.n_pad = hp.npad_ph[gw_phase]; }
+        a.signs = p->d_signs; a.slabs = reinterpret_cast<float*>(ws + lay.slabs); a.B = B; a.n_lanes = hp.n_lanes; a.n_parts = hp.n_parts;
+        ProfScope ps(p, hp.ks_gradw, st);
+        if (a.n_pad > 0) hipLaunchKernelGGL(k_gradw_x3, dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a, act_plane, mlp_plane);
+    }
+    return run_finalize(p, lay, ws, gparams, B, (y || labels) ? loss : nullptr, labels != nullptr, dec_done, gw_phase, st);
+}

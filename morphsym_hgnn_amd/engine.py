@@ -20,7 +20,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmshgnn.so")
 
 MAX_TYPES = 4
-F32, BF16 = 0, 1
+F32, BF16, BF16X3 = 0, 1, 2
+DTYPE_CODES = {"f32": F32, "bf16": BF16, "x3": BF16X3}      # "x3": split-bf16 parity plan (include/mshgnn.h, MSHGNN_BF16X3)
 FLAG_RESIDUAL, FLAG_BASE_MLP = 1, 2
 
 
@@ -218,7 +219,7 @@ class _DescHolder:
 def compile_plan_host(spec: ModelSpec, dtype: str = "f32") -> MshgnnInfo:
     """Run the plan compiler only (no GPU needed) and return its work/traffic summary."""
     lib = load_library()
-    h = _DescHolder(spec, F32 if dtype == "f32" else BF16)
+    h = _DescHolder(spec, DTYPE_CODES[dtype])
     info = MshgnnInfo()
     n = C.c_int32(0)
     _check(lib, lib.mshgnn_plan_compile_host(C.byref(h.desc), C.byref(info), C.byref(n)), "mshgnn_plan_compile_host")
@@ -243,16 +244,16 @@ class Engine:
     """One compiled plan (topology x model dims x precision) on one GPU."""
 
     def __init__(self, spec: ModelSpec, dtype: str = "f32", device: Optional[torch.device] = None):
-        if dtype not in ("f32", "bf16"):
-            raise ValueError("dtype must be 'f32' or 'bf16'")
+        if dtype not in DTYPE_CODES:
+            raise ValueError("dtype must be 'f32' (exact fp32 MFMA), 'bf16' (throughput) or 'x3' (split-bf16 parity plan)")
         if not torch.cuda.is_available():
             raise RuntimeError("the MS-HGNN engine needs a HIP device; there is no CPU fallback")
         self.lib = load_library()
         self.spec = spec
         self.dtype = dtype
-        self.torch_dtype = torch.float32 if dtype == "f32" else torch.bfloat16
+        self.torch_dtype = torch.bfloat16 if dtype == "bf16" else torch.float32      # dtype of the INPUT tensors (x3 takes fp32)
         self.device = torch.device(device if device is not None else "cuda:0")
-        self._holder = _DescHolder(spec, F32 if dtype == "f32" else BF16)
+        self._holder = _DescHolder(spec, DTYPE_CODES[dtype])
         self._plan = C.c_void_p()
         with torch.cuda.device(self.device):
             _check(self.lib, self.lib.mshgnn_plan_create(C.byref(self._holder.desc), C.byref(self._plan)), "mshgnn_plan_create")
@@ -290,7 +291,7 @@ class Engine:
 
     def padded_width(self, t: str) -> int:
         """Row pitch (elements) of input type t in engine layout: F_t rounded up so every row starts 16-byte aligned."""
-        q = 4 if self.dtype == "f32" else 8
+        q = 8 if self.dtype == "bf16" else 4
         return (self.spec.widths[t] + q - 1) // q * q
 
     def cast_inputs(self, x_dict: Dict[str, torch.Tensor], pad: bool = True) -> List[torch.Tensor]:
@@ -480,19 +481,21 @@ class Engine:
         return out
 
     # ---- introspection (tests) -----------------------------------------------------------------
-    def hidden_state(self, B: int, layer: int) -> torch.Tensor:
-        """X_layer as [B, NN, hidden] (permuted view of the node-major [NN, B, hidden] workspace buffer)."""
-        lay = self.layout(B, True)
+    def _act_tensor(self, off: int, B: int) -> torch.Tensor:
+        """An activation tensor of the workspace as [B, NN, hidden] (node-major [NN, B, hidden] in memory; the split plan stores a
+        hi and a lo bf16 plane, returned as their fp32 sum)."""
         ws = self.workspace(B, True)
         nn_ = self.info.total_nodes
         n = B * nn_ * self.spec.hidden
+        if self.dtype == "x3":
+            planes = ws[off:off + 4 * n].view(torch.bfloat16).view(2, nn_, B, self.spec.hidden).float()
+            return (planes[0] + planes[1]).permute(1, 0, 2)
         es = 4 if self.dtype == "f32" else 2
-        return ws[lay.x[layer]:lay.x[layer] + n * es].view(self.torch_dtype).view(nn_, B, self.spec.hidden).permute(1, 0, 2)
+        return ws[off:off + n * es].view(self.torch_dtype).view(nn_, B, self.spec.hidden).permute(1, 0, 2)
+
+    def hidden_state(self, B: int, layer: int) -> torch.Tensor:
+        """X_layer as [B, NN, hidden]."""
+        return self._act_tensor(self.layout(B, True).x[layer], B)
 
     def grad_hidden(self, B: int, layer: int) -> torch.Tensor:
-        lay = self.layout(B, True)
-        ws = self.workspace(B, True)
-        nn_ = self.info.total_nodes
-        n = B * nn_ * self.spec.hidden
-        es = 4 if self.dtype == "f32" else 2
-        return ws[lay.dx[layer]:lay.dx[layer] + n * es].view(self.torch_dtype).view(nn_, B, self.spec.hidden).permute(1, 0, 2)
+        return self._act_tensor(self.layout(B, True).dx[layer], B)

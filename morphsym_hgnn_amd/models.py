@@ -102,8 +102,8 @@ class _MSHGNNBase(nn.Module):
             self.convs.append(pnn.HeteroConv(conv_dict, aggr="sum"))
 
     def set_precision(self, dtype: str):
-        if dtype not in ("f32", "bf16"):
-            raise ValueError("precision must be 'f32' or 'bf16'")
+        if dtype not in ("f32", "bf16", "x3"):
+            raise ValueError("precision must be 'f32', 'bf16' or 'x3'")
         self._precision = dtype
         return self
 

@@ -96,7 +96,7 @@ class SequenceStore:
         self.lib = eng.load_library()
         self.recipe = recipe
         self.dtype = dtype
-        self.torch_dtype = torch.float32 if dtype == "f32" else torch.bfloat16
+        self.torch_dtype = torch.bfloat16 if dtype == "bf16" else torch.float32      # the split plan ("x3") takes fp32 inputs
         self.names = recipe.series()
         self.series = []
         n_rows = None
@@ -131,7 +131,7 @@ class SequenceStore:
         self.rows = torch.tensor(rows, dtype=torch.int32, device=self.device)
         self.label_cols = torch.tensor(recipe.label_cols or [0], dtype=torch.int32, device=self.device)
         d = eng.MshgnnWindowDesc()
-        d.n_types = len(recipe.node_types); d.dtype = 0 if dtype == "f32" else 1; d.history = recipe.history
+        d.n_types = len(recipe.node_types); d.dtype = {"f32": 0, "bf16": 1, "x3": 2}[dtype]; d.history = recipe.history
         d.normalize = int(recipe.normalize)
         for i, t in enumerate(recipe.node_types):
             d.type_nodes[i] = recipe.num_nodes[t]; d.type_width[i] = recipe.width(t)
@@ -151,7 +151,7 @@ class SequenceStore:
         return self.n_rows - self.recipe.history + 1
 
     def padded_width(self, t: str) -> int:
-        epc = 4 if self.dtype == "f32" else 8
+        epc = 8 if self.dtype == "bf16" else 4
         return (self.recipe.width(t) + epc - 1) // epc * epc
 
     def _buffers(self, B: int):

@@ -200,24 +200,29 @@ def hetero_conv(cfg: OracleConfig, params, layer: int, x_dict, edge_index_dict):
 # Whole-model forward
 # ----------------------------------------------------------------------------------------------
 def forward(cfg: OracleConfig, params: Dict[str, torch.Tensor], x_dict, edge_index_dict,
-            return_hidden: bool = False):
-    """hgnn_c2.py:133-182 / hgnn_k4.py:146-196 / hgnn.py:57-62."""
+            return_hidden: bool = False, relu_fn=None):
+    """hgnn_c2.py:133-182 / hgnn_k4.py:146-196 / hgnn.py:57-62.
+
+    relu_fn(key, h) (tests only) replaces torch.relu at the site `key` = ("enc", type) | ("layer", l, type) | ("t1", l): the GPU
+    parity harness passes h * (the engine's own relu decisions), so that a pre-activation within rounding error of zero, whose
+    decision may legitimately differ from the exact one, does not turn into a spurious gradient mismatch (tests/helpers.py)."""
+    relu = (lambda key, h: torch.relu(h)) if relu_fn is None else relu_fn
     x = apply_symmetry(cfg, x_dict)                                    # :143
-    x = {k: torch.relu(v @ params[f"encoder.lins.{k}.weight"].t() + params[f"encoder.lins.{k}.bias"])
+    x = {k: relu(("enc", k), v @ params[f"encoder.lins.{k}.weight"].t() + params[f"encoder.lins.{k}.bias"])
          for k, v in x.items()}                                         # :146-147
     hidden = [x]
     for layer in range(cfg.num_layers):                                 # :150
         h = hetero_conv(cfg, params, layer, x, edge_index_dict)         # :152
         if cfg.kind in ("mi", "s4_com"):
-            x = {k: torch.relu(v) for k, v in h.items()}                # hgnn.py:60-61 / hgnn_s4_com.py:67-69
+            x = {k: relu(("layer", layer, k), v) for k, v in h.items()}     # hgnn.py:60-61 / hgnn_s4_com.py:67-69
         else:
             new = {}
             for k, v in h.items():
                 if k == "base":                                          # :155-158 (base_transform shared across layers)
-                    t1 = torch.relu(v @ params["base_transform.0.weight"].t() + params["base_transform.0.bias"])
+                    t1 = relu(("t1", layer), v @ params["base_transform.0.weight"].t() + params["base_transform.0.bias"])
                     new[k] = t1 @ params["base_transform.2.weight"].t() + params["base_transform.2.bias"]
                 else:
-                    new[k] = torch.relu(v)
+                    new[k] = relu(("layer", layer, k), v)
             x = {k: new[k] + x[k] if (k in x and x[k].shape == new[k].shape) else new[k] for k in new}  # :161-166
         hidden.append(x)
     if cfg.kind.endswith("_com"):

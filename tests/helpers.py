@@ -123,26 +123,79 @@ def node_slices(spec):
     return out
 
 
-def run_engine_case(spec, x_dict, y, params, ei, B, dtype="f32", device="cuda:0"):
+def engine_relu_decisions(e, spec, B):
+    """The relu decisions the engine took in its last training forward of batch size B, read back from its workspace:
+    {("enc", type) | ("layer", l, type): bool [B*n_type, hidden]} from the relu bytes (one byte per (node, window, 8 features):
+    [NN][4 column slices][ceil(B/16) tiles][4 groups][16 windows], bit j <-> feature 32 slice + 8 group + j) and
+    {("t1", l): bool [B*n_base, hidden]} from the stashed base_transform activation T1 (its backward masks with T1 > 0)."""
+    lay, ws = e.layout(B, True), e.workspace(B, True)
+    nn_, h, tiles = e.info.total_nodes, spec.hidden, (B + 15) // 16
+    sl = node_slices(spec)
+
+    def from_bytes(off):
+        raw = ws[off:off + nn_ * 4 * tiles * 64].view(nn_, 4, tiles, 4, 16).cpu()
+        bits = (raw.unsqueeze(-1) >> torch.arange(8, dtype=torch.uint8)) & 1            # [NN, slice, tile, group, win, bit]
+        return bits.permute(2, 4, 0, 1, 3, 5).reshape(tiles * 16, nn_, h)[:B].bool()  # [B, NN, 128]
+
+    out = {}
+    m0 = from_bytes(lay.dd[0])
+    for t in spec.node_types:
+        out[("enc", t)] = m0[:, sl[t]].reshape(-1, h)
+    for l in range(spec.num_layers):
+        ml = from_bytes(lay.mask[l])
+        for t in spec.live_types(l):
+            if not (spec.has_base_transform and t == "base"):
+                out[("layer", l, t)] = ml[:, sl[t]].reshape(-1, h)
+        if spec.has_base_transform and "base" in spec.live_types(l):
+            nb = spec.num_nodes["base"]
+            n = nb * B * h
+            if e.dtype == "x3":
+                t1 = ws[lay.t1[l]:lay.t1[l] + 2 * n].view(torch.bfloat16)      # hi plane carries the sign
+            else:
+                t1 = ws[lay.t1[l]:lay.t1[l] + n * (4 if e.dtype == "f32" else 2)].view(e.torch_dtype)
+            out[("t1", l)] = (t1.view(nb, B, h).permute(1, 0, 2).reshape(-1, h).float() > 0).cpu()
+    return out
+
+
+def run_engine_case(spec, x_dict, y, params, ei, B, dtype="f32", device="cuda:0", decision_tol=1e-4):
     """Run fwd + MSE/CE + bwd through the C-ABI and through the oracle; return dict of relative errors
-    (max-abs error / max-abs reference) per stage, plus the raw engine results."""
+    (max-abs error / max-abs reference) per stage, plus the raw engine results.
+
+    The oracle is evaluated WITH THE ENGINE'S relu decisions: a pre-activation within rounding error of zero may land on the other
+    side in finite precision, and the gradient is discontinuous there (one flipped decision moves a tiny-batch weight gradient by
+    1e-3..1e-2 of its scale on ANY plan, fp32 included).  Every decision that differs from the exact one must belong to a
+    pre-activation within `decision_tol` x (max-abs of its tensor) of zero -- counted in errs["relu_decisions_outside_tolerance"],
+    which must be 0 -- and given the same decisions every hidden state, the output, the loss and every gradient must match."""
     from morphsym_hgnn_amd import engine as eng
     from oracle import ms_hgnn_oracle as orc
     cfg = oracle_config(spec)
+    e = eng.Engine(spec, dtype=dtype, device=device)
+    xs = e.cast_inputs(x_dict)
+    flat = eng.flatten_params(spec, params, device=e.device)
+    out = e.forward(xs, flat, B, training=True)
+    torch.cuda.synchronize()
+    decisions = engine_relu_decisions(e, spec, B)
+    stats = {"differ": 0, "outside": 0}
+
+    def relu_fn(key, h):
+        if key not in decisions:
+            return torch.relu(h)
+        m = decisions[key]
+        diff = m != (h.detach() > 0)
+        if bool(diff.any()):
+            stats["differ"] += int(diff.sum())
+            stats["outside"] += int((h.detach().abs()[diff] > decision_tol * float(h.detach().abs().max())).sum())
+        return h * m.to(h.dtype)
+
     # oracle (fp64, CPU)
     leaves = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
-    o_out, o_hidden = orc.forward(cfg, leaves, {k: v.clone() for k, v in x_dict.items()}, ei, return_hidden=True)
+    o_out, o_hidden = orc.forward(cfg, leaves, {k: v.clone() for k, v in x_dict.items()}, ei, return_hidden=True, relu_fn=relu_fn)
     yy, yp = orc.wrapper_outputs(cfg, o_out, y, B)
     o_loss = orc.mse_loss(yy, yp) if spec.regression else orc.cross_entropy_loss(yy, yp, B)
     gout_ref = torch.autograd.grad(o_loss, o_out, retain_graph=True)[0]
     o_loss.backward()
     o_grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaves.items()}
-
-    e = eng.Engine(spec, dtype=dtype, device=device)
-    xs = e.cast_inputs(x_dict)
-    flat = eng.flatten_params(spec, params, device=e.device)
-    out = e.forward(xs, flat, B, training=True)
-    errs = {}
+    errs = {"relu_decisions_outside_tolerance": float(stats["outside"])}
 
     def rel(a, b):
         a = a.detach().double().cpu(); b = b.detach().double().cpu()
@@ -174,4 +227,5 @@ def run_engine_case(spec, x_dict, y, params, ei, B, dtype="f32", device="cuda:0"
             errs["grad:" + k] = float(grads[k].abs().max())   # must be exactly zero
         else:
             errs["grad:" + k] = rel(grads[k], g)
+    run_engine_case.last_decisions_differing = stats["differ"]
     return errs, out.detach().cpu(), (loss.detach().cpu() if loss is not None else o_loss.detach()), grads

@@ -1,0 +1,143 @@
+"""GPU parity tests of the split-bf16 parity plan (MSHGNN_BF16X3, "x3"): bf16 MFMA with hi/lo operands at the north_star's
+1e-4 relative tolerance -- same harness and tolerance as the fp32 plan (tests/test_engine_gpu.py)."""
+import pytest
+import torch
+
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+# every golden topology whose LDS tile fits the split plan (2 x (nodes + base_transform nodes) <= 40 blocks): MiniCheetah-K4 (48) does not
+X3_CASES = [c for c in helpers.GOLDEN_CASES if not c.startswith("mck4")]
+
+
+@pytest.mark.parametrize("name", X3_CASES)
+def test_x3_plan_matches_oracle_and_golden(name):
+    assert torch.cuda.is_available()
+    case, spec, fx, x_dict, y, params, ei = helpers.load_case(name)
+    errs, out, loss, grads = helpers.run_engine_case(spec, x_dict, y, params, ei, case["B"], dtype="x3")
+    bad = {k: v for k, v in errs.items() if v > RTOL}
+    assert not bad, f"{name}: stages above {RTOL}: {bad}"
+    helpers.check_against_fixture(fx, out, loss if spec.regression else None, grads, rtol=RTOL, what=name)
+
+
+def test_x3_plan_is_rejected_where_the_tile_does_not_fit():
+    from morphsym_hgnn_amd import engine as eng
+    case, spec, *_ = helpers.load_case("mck4_cls_h128_L2_B3")
+    with pytest.raises(eng.MshgnnError, match="not supported"):
+        eng.Engine(spec, "x3")
+
+
+@pytest.mark.parametrize("B", [1, 15, 16, 17, 33, 65, 333])
+def test_x3_ragged_batches(B):
+    """Batch sizes around the 16-window tile and the 64-window encoder / weight-gradient steps, against the oracle (evaluated with the
+    engine's relu decisions, helpers.run_engine_case: a pre-activation within rounding error of zero may be decided either way)."""
+    from morphsym_hgnn_amd import synth
+    spec = helpers.make_spec("c2", "a1-c2", "a1-c2", 128, 3)
+    params = synth.make_params(5, spec.param_shapes())
+    x_dict, y = synth.make_windows(100 + B, B, spec.num_nodes, spec.widths, 12)
+    errs, *_ = helpers.run_engine_case(spec, x_dict, y, params, spec.topology.edge_index_dict(B), B, dtype="x3")
+    bad = {k: v for k, v in errs.items() if v > RTOL}
+    assert not bad, (B, bad)
+
+
+def test_x3_one_call_step_equals_forward_plus_backward_and_repeats():
+    """mshgnn_step_mse on the split plan (decoder + MSE + decoder backward in the tail of its fused forward kernel) == forward followed
+    by backward_mse: same output bits, loss and gradients up to fp32 summation order; two runs are bit-identical."""
+    from morphsym_hgnn_amd import engine as eng, synth
+    spec = helpers.make_spec("c2", "a1-c2", "a1-c2", 128, 3)
+    for B in (37, 1000):
+        e = eng.Engine(spec, "x3")
+        x_dict, y = synth.make_windows(21, B, spec.num_nodes, spec.widths, 12)
+        xs = e.cast_inputs(x_dict)
+        yd = y.reshape(-1).to(e.device, torch.float32)
+        flat = eng.flatten_params(spec, synth.make_params(21, spec.param_shapes()), e.device)
+        out_a = e.forward(xs, flat, B).clone()
+        loss_a, g_a = e.backward_mse(xs, flat, out_a, yd, B)
+        loss_a, g_a = loss_a.clone(), g_a.clone()
+        out_b, loss_b, g_b = e.step_mse(xs, flat, yd, B)
+        out_b, loss_b, g_b = out_b.clone(), loss_b.clone(), g_b.clone()
+        out_c, loss_c, g_c = e.step_mse(xs, flat, yd, B)
+        torch.cuda.synchronize()
+        assert torch.equal(out_a, out_b) and torch.equal(out_b, out_c) and torch.equal(g_b, g_c) and torch.equal(loss_b, loss_c)
+        assert abs(float(loss_a) - float(loss_b)) <= 1e-5 * abs(float(loss_a))
+        assert float((g_a - g_b).abs().max() / g_a.abs().max()) < 2e-5
+
+
+def test_x3_unaligned_inputs_take_the_general_loader():
+    """Dense (unpadded) fp32 inputs: joint rows of 450 floats start 8-byte aligned only -> the element-wise loaders of the encoder and
+    the weight-gradient kernel; same results as the padded layout."""
+    from morphsym_hgnn_amd import engine as eng, synth
+    spec = helpers.make_spec("c2", "a1-c2", "a1-c2", 128, 2)
+    B = 21
+    e = eng.Engine(spec, "x3")
+    x_dict, y = synth.make_windows(3, B, spec.num_nodes, spec.widths, 12)
+    flat = eng.flatten_params(spec, synth.make_params(3, spec.param_shapes()), e.device)
+    yd = y.reshape(-1).to(e.device, torch.float32)
+    o1, l1, g1 = e.step_mse(e.cast_inputs(x_dict, pad=True), flat, yd, B)
+    o1, l1, g1 = o1.clone(), l1.clone(), g1.clone()
+    o2, l2, g2 = e.step_mse(e.cast_inputs(x_dict, pad=False), flat, yd, B)
+    torch.cuda.synchronize()
+    assert torch.equal(o1, o2) and torch.equal(g1, g2)
+
+
+def test_x3_two_phase_step_is_bit_identical():
+    from morphsym_hgnn_amd import engine as eng, synth
+    spec = helpers.make_spec("c2", "a1-c2", "a1-c2", 128, 3)
+    B = 333
+    e = eng.Engine(spec, "x3")
+    x_dict, y = synth.make_windows(5, B, spec.num_nodes, spec.widths, 12)
+    xs = e.cast_inputs(x_dict)
+    yd = y.reshape(-1).to(e.device, torch.float32)
+    flat = eng.flatten_params(spec, synth.make_params(5, spec.param_shapes()), e.device)
+    out_a, loss_a, g_a = e.step_mse(xs, flat, yd, B)
+    out_a, loss_a, g_a = out_a.clone(), loss_a.clone(), g_a.clone()
+    split = int(e.info.grad_split)
+    out_b = torch.empty_like(out_a); loss_b = torch.empty(1, device=e.device); g_b = torch.full_like(g_a, float("nan"))
+    e.step_mse_phase(0, xs, flat, yd, B, out_b, g_b, loss_b)
+    torch.cuda.synchronize()
+    assert torch.equal(g_b[split:], g_a[split:]) and torch.equal(loss_b, loss_a) and torch.equal(out_b, out_a)
+    e.step_mse_phase(1, xs, flat, yd, B, out_b, g_b, loss_b)
+    torch.cuda.synchronize()
+    assert torch.equal(g_b, g_a)
+
+
+def test_x3_full_size_batch_properties():
+    """BASELINE config size (B=8192): every window's output is independent of its batch (identical bits) and the gradient of the two
+    halves adds up to the gradient of the whole (fp32 summation order only)."""
+    from morphsym_hgnn_amd import engine as eng, synth
+    spec = helpers.make_spec("c2", "a1-c2", "a1-c2", 128, 3)
+    B = 8192
+    e = eng.Engine(spec, "x3")
+    x_dict, y = synth.make_windows(9, B, spec.num_nodes, spec.widths, 12)
+    xs = e.cast_inputs(x_dict)
+    yd = y.reshape(-1).to(e.device, torch.float32)
+    flat = eng.flatten_params(spec, synth.make_params(9, spec.param_shapes()), e.device)
+    out, loss, g = e.step_mse(xs, flat, yd, B)
+    out, loss, g = out.clone(), loss.clone(), g.clone()
+    h = B // 2
+    res = []
+    for lo in (0, h):
+        xh = [x.view(B, -1)[lo:lo + h].reshape(h * spec.num_nodes[t], -1).contiguous() for x, t in zip(xs, spec.node_types)]
+        oh, lh, gh = e.step_mse(xh, flat, yd.view(B, -1)[lo:lo + h].reshape(-1).contiguous(), h)
+        res.append((oh.clone(), lh.clone(), gh.clone()))
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat([res[0][0], res[1][0]]), out)
+    assert abs(0.5 * (float(res[0][1]) + float(res[1][1])) - float(loss)) <= 1e-5 * abs(float(loss))
+    assert float((0.5 * (res[0][2] + res[1][2]) - g).abs().max() / g.abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("name", ["mcc2_cls_h128_L2_B3"])
+def test_x3_fused_cross_entropy_backward_matches_golden(name):
+    from morphsym_hgnn_amd import engine as eng
+    case, spec, fx, x_dict, y, params, ei = helpers.load_case(name)
+    B = case["B"]
+    e = eng.Engine(spec, "x3")
+    xs = e.cast_inputs(x_dict)
+    flat = eng.flatten_params(spec, params, e.device)
+    out = e.forward(xs, flat, B, training=True)
+    loss, gflat = e.backward_ce(xs, flat, out, y.reshape(B, 4).to(e.device, torch.int32).contiguous(), B)
+    torch.cuda.synchronize()
+    grads = {k: v.detach().cpu() for k, v in eng.unflatten(spec, gflat).items()}
+    helpers.check_against_fixture(fx, out.detach().cpu(), loss.detach().cpu(), grads, rtol=RTOL, what=name)
