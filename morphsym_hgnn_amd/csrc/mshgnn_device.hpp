@@ -456,9 +456,8 @@ struct StackArgs {
     const float* y; float* dec_slabs; float inv_n;
     size_t mask0_off;    // bwd: relu bytes of the encoder activation X_0 in the workspace (0: not available, X_0 rows are read)
     long long* stamps;   // timing experiments (MSHGNN_STAMPS): wave 0 of every workgroup records clock64() at phase boundaries
-    // split plan: LDS block of the lo plane of node n = lo_blk + n; element offsets of the lo plane of the activation / base_transform
-    // stashes; the lo image of pack i is pack n_img + i
-    int lo_blk, n_img; size_t act_plane, mlp_plane;
+    // split plan: LDS block of the lo half of node n = lo_blk + n; the lo image of pack i is pack n_img + i
+    int lo_blk, n_img;
 };
 #ifdef MSHGNN_SEG_STAMPS
 constexpr int FS_EXTRA_BLK = 6;     // LDS room for the per-segment clocks
@@ -661,8 +660,8 @@ __device__ __forceinline__ void decoder_tail_impl(const StackArgs& a, char* smem
                     if constexpr (SPLIT) {
                         u32x4 hi, lo;
                         split_oct(f32x4{dxv[i][0], dxv[i][1], dxv[i][2], dxv[i][3]}, f32x4{dxv[i][4], dxv[i][5], dxv[i][6], dxv[i][7]}, hi, lo);
-                        T* q = dxl + act_idx(w0 + row, a.node0 + f, B) + c * 8;
-                        *reinterpret_cast<u32x4*>(q) = hi; *reinterpret_cast<u32x4*>(q + a.act_plane) = lo;
+                        T* q = dxl + 2 * act_idx(w0 + row, a.node0 + f, B) + c * 8;      // split plan rows: [hi 128 | lo 128]
+                        *reinterpret_cast<u32x4*>(q) = hi; *reinterpret_cast<u32x4*>(q + H) = lo;
                     } else store8<T>(dxl + act_idx(w0 + row, a.node0 + f, B) + c * 8, dxv[i]);
                 }
             }

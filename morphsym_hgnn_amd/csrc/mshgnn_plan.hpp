@@ -119,8 +119,8 @@ struct HostPlan {
     int blk_bytes = 8192;          // one LDS node block
     int gmax = GMAX;               // destination slots per group (12 fp32, 8 bf16: accumulator registers)
     int esize = 4;                 // bytes per stored element
-    bool split = false;            // MSHGNN_BF16X3: every activation is two bf16 planes (hi, lo); packs [0, n_img) = hi images, [n_img, 2 n_img) = lo
-    int planes = 1;                // stored planes per activation tensor (2 on the split plan: plane 1 at + one plane's bytes)
+    bool split = false;            // MSHGNN_BF16X3: every activation is stored as hi and lo bf16 halves; packs [0, n_img) = hi images, [n_img, 2 n_img) = lo
+    int planes = 1;                // bf16 halves per stored value (2 on the split plan: rows of [hi 128 | lo 128])
     int n_img = 0;                 // weight images per plane (== packs.size())
     int lo_blk = 0;                // split plan: LDS block of the lo plane of node n is lo_blk + n
     int gw_target = (int)GW_TARGET_WGS;
@@ -201,7 +201,10 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
     p.NN = p.type_base[NT];
     p.esize = d.dtype == MSHGNN_F32 ? 4 : 2;
     p.split = d.dtype == MSHGNN_BF16X3; p.planes = p.split ? 2 : 1;
-    p.gw_target = p.split ? 512 : (int)GW_TARGET_WGS;     // split plan: the weight-gradient kernel stages four tiles (64 KB) -> two workgroups per CU
+#ifndef GWX3_TARGET_WGS
+#define GWX3_TARGET_WGS 768
+#endif
+    p.gw_target = p.split ? GWX3_TARGET_WGS : (int)GW_TARGET_WGS;     // split plan: three resident workgroups per CU of its weight-gradient kernel (four 8 KB tiles per 32-window step)
     p.blk_bytes = TILE_ROWS * H * p.esize;
     if (!p.split && (int64_t)p.NN * p.blk_bytes > LDS_LIMIT)
         return fail(p, "topology has too many nodes per window for the LDS-resident layer kernel (max 20 fp32 / 40 bf16)");
@@ -913,7 +916,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline void layout_workspace(const HostPlan& p, int64_t B, int training, mshgnn_ws_layout* o) {
     std::memset(o, 0, sizeof(*o));
     size_t off = 0;
-    const size_t act = (size_t)B * p.NN * H * p.esize * p.planes, mlp = (size_t)B * std::max(1, p.n_mlp) * H * p.esize * p.planes;     // split plan: hi plane, then lo plane
+    const size_t act = (size_t)B * p.NN * H * p.esize * p.planes, mlp = (size_t)B * std::max(1, p.n_mlp) * H * p.esize * p.planes;     // split plan: rows of [hi 128 | lo 128]
     auto take = [&](size_t bytes) { size_t r = off; off = align_up(off + bytes, 256); return r; };
     for (int l = 0; l <= p.L; ++l) o->x[l] = take(act);
     for (int l = 0; l < p.L; ++l) { o->mask[l] = take((size_t)((B + 15) / 16 * 16) * p.NN * 4 * 4); o->hb[l] = take(mlp); o->t1[l] = take(mlp); }

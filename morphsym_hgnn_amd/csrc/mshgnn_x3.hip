@@ -7,8 +7,8 @@
 //     x w  =  x_hi w_hi + x_lo w_hi + x_hi w_lo          (the lo x lo term is 2^-18 relative: below fp32 resolution)
 // with fp32 accumulation, i.e. three bf16 MFMAs per term instead of one fp32 MFMA at 1/16 of the rate.  Layout:
 //   * inputs x[t]: fp32 in HBM (as the MSHGNN_F32 plan takes them); split in registers while they are staged;
-//   * every activation tensor in the workspace: two bf16 planes, hi then lo ([NN][B][128] each) -- what the bf16 kernels
-//     read and write, twice; the weight-gradient kernel streams both planes of both operands;
+//   * every activation tensor in the workspace: rows of 256 bf16, [hi 128 | lo 128] ([NN][B][2][128]): a window's hi and lo halves are
+//     one contiguous 512-byte piece for every stream (stash writes, tile loads, the weight-gradient kernel's operand rows);
 //   * LDS tile of the stack kernels: block n = hi plane of node n, block lo_blk + n = its lo plane (A1-C2: 40 blocks = 160 KB,
 //     one 8-wave workgroup per CU); k_prep writes a hi and a lo image of every weight pack;
 //   * the MAC loop of the stack kernels is the bf16 plan's: the plan compiler (split_segs, mshgnn_plan.hpp) turns each
@@ -17,6 +17,9 @@
 
 using T16 = __bf16;
 using P16 = Prec<__bf16>;
+
+// element index of the hi half of (window w, node) in a split-plan activation tensor; the lo half follows at + H
+__device__ __forceinline__ size_t x3_idx(int w, int node, int B) { return ((size_t)node * B + w) * (2 * H); }
 
 // ------------------------------------------------------------------------------------------------------
 // k_prep_x3: hi and lo MFMA B-fragment images of every weight pack (root-sum, transpose) + bias sums
@@ -71,7 +74,7 @@ __global__ void k_prep_x3(PrepArgs a) {
 // k_enc_x3: X_0[node] = relu((mask . x) W_enc^T + b) from fp32 inputs (hgnn_c2.py:143-147); one workgroup = 64 windows of ONE
 // node, K streamed in chunks of 128 through LDS (hi blocks [0, 4), lo blocks [4, 8)), the next chunk prefetched in registers
 // ------------------------------------------------------------------------------------------------------
-template <bool ALIGNED> __global__ __launch_bounds__(256) void k_enc_x3(EncArgs a, size_t act_plane, int n_img) {
+template <bool ALIGNED> __global__ __launch_bounds__(256) void k_enc_x3(EncArgs a, int n_img) {
     using P = P16;
     constexpr int MB = 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -160,10 +163,29 @@ template <bool ALIGNED> __global__ __launch_bounds__(256) void k_enc_x3(EncArgs 
         if (w < a.B) {
             u32x4 hi, lo;
             split_oct(acc[m].c[0], acc[m].c[1], hi, lo);
-            T16* q = x0 + act_idx(w, gnode, a.B) + wv * 32 + c_oct(lane);
+            T16* q = x0 + x3_idx(w, gnode, a.B) + wv * 32 + c_oct(lane);
             *reinterpret_cast<u32x4*>(q) = hi;
-            *reinterpret_cast<u32x4*>(q + act_plane) = lo;
+            *reinterpret_cast<u32x4*>(q + H) = lo;
         }
+    }
+}
+
+// stage the [hi | lo] rows of every node for which keep(n) into LDS: 512 threads = 16 rows x 32 chunks, one node per pass, 4 in flight
+template <typename Keep>
+__device__ __forceinline__ void stage_tile_x3(char* smem, const T16* src, int NN, int LO, int w0, int B, int tid, Keep keep) {
+    const int row = tid >> 5, c = tid & 31;      // chunk c < 16: hi half, else lo half
+    const int blk_off = c < 16 ? 0 : LO, cc = c & 15;
+    constexpr int BATCH = 4;
+    for (int nb = 0; nb < NN; nb += BATCH) {
+        u32x4 v[BATCH];
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i) {
+            v[i] = u32x4{0, 0, 0, 0};
+            if (nb + i < NN && keep(nb + i) && w0 + row < B) v[i] = *reinterpret_cast<const u32x4*>(src + x3_idx(w0 + row, nb + i, B) + c * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i)
+            if (nb + i < NN && keep(nb + i)) *reinterpret_cast<u32x4*>(smem + lds_chunk<T16>(blk_off + nb + i, row, cc)) = v[i];
     }
 }
 
@@ -197,8 +219,7 @@ __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_fwd_x3(StackArgs a) 
     const int win = c_win(lane), w = w0 + win, col = wn * 32 + c_oct(lane);
     const bool w_ok = w < B, train = a.training != 0;
 
-    stage_nodes<T>(smem, reinterpret_cast<const T*>(a.tile_in), NN, w0, B, tid);
-    stage_nodes<T>(smem + LO * P::BLK, reinterpret_cast<const T*>(a.tile_in) + a.act_plane, NN, w0, B, tid);
+    stage_tile_x3(smem, reinterpret_cast<const T*>(a.tile_in), NN, LO, w0, B, tid, [](int) { return true; });
     __syncthreads();
 
     P::Acc acc[FS_HS];
@@ -265,10 +286,10 @@ __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_fwd_x3(StackArgs a) 
             for (int u = 0; u < 2; ++u) {
                 const int n = 2 * u + wh;
                 if (n < nmlp) {
-                    *reinterpret_cast<u32x4*>(hb + act_idx(w, n, B) + col) = hph[u];
-                    *reinterpret_cast<u32x4*>(hb + a.mlp_plane + act_idx(w, n, B) + col) = hpl[u];
-                    *reinterpret_cast<u32x4*>(t1 + act_idx(w, n, B) + col) = tph[u];
-                    *reinterpret_cast<u32x4*>(t1 + a.mlp_plane + act_idx(w, n, B) + col) = tpl[u];
+                    *reinterpret_cast<u32x4*>(hb + x3_idx(w, n, B) + col) = hph[u];
+                    *reinterpret_cast<u32x4*>(hb + x3_idx(w, n, B) + H + col) = hpl[u];
+                    *reinterpret_cast<u32x4*>(t1 + x3_idx(w, n, B) + col) = tph[u];
+                    *reinterpret_cast<u32x4*>(t1 + x3_idx(w, n, B) + H + col) = tpl[u];
                 }
             }
         }
@@ -308,9 +329,9 @@ __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_fwd_x3(StackArgs a) 
                     *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(n, win, col / P::EPC)) = hi;
                     *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(LO + n, win, col / P::EPC)) = lo;
                     if (train && w_ok) {
-                        T* q = xo + act_idx(w, n, B) + col;
+                        T* q = xo + x3_idx(w, n, B) + col;
                         *reinterpret_cast<u32x4*>(q) = hi;
-                        *reinterpret_cast<u32x4*>(q + a.act_plane) = lo;
+                        *reinterpret_cast<u32x4*>(q + H) = lo;
                     }
                 }
             }
@@ -336,18 +357,7 @@ __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_bwd_x3(StackArgs a) 
     // dX_L tile: only the nodes that are live in the last layer carry a gradient
     {
         const FHdr bh(a.tables + a.prog_off[a.L - 1], lane);
-        const T* src = reinterpret_cast<const T*>(a.tile_in);
-        const RowMap<T> m(tid);
-        for (int n = m.sub; n < NN; n += RowMap<T>::NPB) {
-            if (bh[FH_KIND + n] == NK_DEAD) continue;
-            u32x4 vh = u32x4{0, 0, 0, 0}, vl = u32x4{0, 0, 0, 0};
-            if (w0 + m.row < B) {
-                const T* q = src + act_idx(w0 + m.row, n, B) + m.c * P::EPC;
-                vh = *reinterpret_cast<const u32x4*>(q); vl = *reinterpret_cast<const u32x4*>(q + a.act_plane);
-            }
-            *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(n, m.row, m.c)) = vh;
-            *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(LO + n, m.row, m.c)) = vl;
-        }
+        stage_tile_x3(smem, reinterpret_cast<const T*>(a.tile_in), NN, LO, w0, B, tid, [&](int n) { return bh[FH_KIND + n] != NK_DEAD; });
     }
     __syncthreads();
 
@@ -409,7 +419,7 @@ __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_bwd_x3(StackArgs a) 
                 const int n = 2 * u + wh;
                 traw[u] = u32x4{0, 0, 0, 0};
                 acc_fill(tm[u], 0.f);
-                if (n < nmlp && w_ok) traw[u] = *reinterpret_cast<const u32x4*>(t1 + act_idx(w, n, B) + col);     // the hi plane carries the sign of T1
+                if (n < nmlp && w_ok) traw[u] = *reinterpret_cast<const u32x4*>(t1 + x3_idx(w, n, B) + col);     // the hi half carries the sign of T1
             }
             mlp_mac3(tm, smem, 0, LO, nmlp, wh, bfh, bfl, lane);
             load_bfrag<T>(bfh, wpack, bh[FH_W1], wn, lane);
@@ -442,10 +452,10 @@ __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_bwd_x3(StackArgs a) 
                     *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(n, win, col / P::EPC)) = hh;
                     *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(LO + n, win, col / P::EPC)) = hl;
                     if (w_ok) {
-                        *reinterpret_cast<u32x4*>(du + act_idx(w, n, B) + col) = duh[u];
-                        *reinterpret_cast<u32x4*>(du + a.mlp_plane + act_idx(w, n, B) + col) = dul[u];
-                        *reinterpret_cast<u32x4*>(dh + act_idx(w, n, B) + col) = hh;
-                        *reinterpret_cast<u32x4*>(dh + a.act_plane + act_idx(w, n, B) + col) = hl;
+                        *reinterpret_cast<u32x4*>(du + x3_idx(w, n, B) + col) = duh[u];
+                        *reinterpret_cast<u32x4*>(du + x3_idx(w, n, B) + H + col) = dul[u];
+                        *reinterpret_cast<u32x4*>(dh + x3_idx(w, n, B) + col) = hh;
+                        *reinterpret_cast<u32x4*>(dh + x3_idx(w, n, B) + H + col) = hl;
                     }
                 }
             }
@@ -475,9 +485,9 @@ __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_bwd_x3(StackArgs a) 
                     *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(LO + n, win, col / P::EPC)) = lo;
                 }
                 if (w_ok) {
-                    T* q = dxo + act_idx(w, n, B) + col;
+                    T* q = dxo + x3_idx(w, n, B) + col;
                     *reinterpret_cast<u32x4*>(q) = hi;
-                    *reinterpret_cast<u32x4*>(q + a.act_plane) = lo;
+                    *reinterpret_cast<u32x4*>(q + H) = lo;
                 }
             }
         }
@@ -489,7 +499,7 @@ __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_bwd_x3(StackArgs a) 
 // k_dec_bwd_x3: decoder backward (+ fused wrapper MSE / cross entropy) on the hi/lo planes of X_L -> dX_L planes
 // (k_dec_bwd of mshgnn.hip; used by mshgnn_backward / _mse / _ce -- mshgnn_step_mse takes the fused tail of k_stack_fwd_x3)
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_dec_bwd_x3(DecArgs a, size_t act_plane) {
+__global__ __launch_bounds__(256) void k_dec_bwd_x3(DecArgs a) {
     using T = T16;
     __shared__ float red[16][DEC_SLAB_FLOATS];
     const int c = threadIdx.x & 15, rg = threadIdx.x >> 4;
@@ -507,10 +517,10 @@ __global__ __launch_bounds__(256) void k_dec_bwd_x3(DecArgs a, size_t act_plane)
     float lsum = 0.f;
     for (int64_t r = r_begin + rg; r < r_end; r += 16) {
         const int w = (int)(r / a.n_out), f = (int)(r % a.n_out);
-        const size_t idx = act_idx(w, a.node0 + f, a.B) + c * 8;
+        const size_t idx = x3_idx(w, a.node0 + f, a.B) + c * 8;
         float x[8], xlo[8], dx[8];
         load8<T>(xl + idx, x);
-        load8<T>(xl + act_plane + idx, xlo);
+        load8<T>(xl + idx + H, xlo);
 #pragma unroll
         for (int e = 0; e < 8; ++e) { x[e] += xlo[e]; dx[e] = 0.f; }
         float ce_g[2] = {0.f, 0.f};
@@ -540,7 +550,7 @@ __global__ __launch_bounds__(256) void k_dec_bwd_x3(DecArgs a, size_t act_plane)
         u32x4 hi, lo;
         split_oct(f32x4{dx[0], dx[1], dx[2], dx[3]}, f32x4{dx[4], dx[5], dx[6], dx[7]}, hi, lo);
         *reinterpret_cast<u32x4*>(dxl + idx) = hi;
-        *reinterpret_cast<u32x4*>(dxl + act_plane + idx) = lo;
+        *reinterpret_cast<u32x4*>(dxl + idx + H) = lo;
     }
 #pragma unroll
     for (int d = 0; d < 8; ++d) {
@@ -571,12 +581,22 @@ __global__ __launch_bounds__(256) void k_dec_bwd_x3(DecArgs a, size_t act_plane)
 // P = P_hi + P_lo, Q = Q_hi + Q_lo: four staged tiles per 64-window step, P_hi Q_hi + P_hi Q_lo + P_lo Q_hi on the 32x32x16 bf16
 // MFMA.  Workgroup = (lane = one item, window part); raw encoder inputs (fp32) are split while they are staged.
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void k_gradw_x3(GradwArgs a, size_t act_plane, size_t mlp_plane) {
+#ifndef GWX3_KW
+#define GWX3_KW 32          // windows per staged step: 32 KB of tiles and three workgroups per CU (64-window steps at two per CU: 339 vs 301 us)
+#endif
+#ifndef GWX3_WPS
+#define GWX3_WPS 3
+#endif
+#ifndef GWX3_NST
+#define GWX3_NST 1          // register stages: global loads run NST steps ahead of the LDS writes
+#endif
+__global__ __launch_bounds__(256, GWX3_WPS) void k_gradw_x3(GradwArgs a) {
     using T = T16;
-    __shared__ __attribute__((aligned(16))) __bf16 Ph[GWB_KW * GWB_PITCH];
-    __shared__ __attribute__((aligned(16))) __bf16 Pl[GWB_KW * GWB_PITCH];
-    __shared__ __attribute__((aligned(16))) __bf16 Qh[GWB_KW * GWB_PITCH];
-    __shared__ __attribute__((aligned(16))) __bf16 Ql[GWB_KW * GWB_PITCH];
+    constexpr int KW = GWX3_KW, NP = KW / 16, NST = GWX3_NST;      // NP: staging passes (16 rows each)
+    __shared__ __attribute__((aligned(16))) __bf16 Ph[KW * GWB_PITCH];
+    __shared__ __attribute__((aligned(16))) __bf16 Pl[KW * GWB_PITCH];
+    __shared__ __attribute__((aligned(16))) __bf16 Qh[KW * GWB_PITCH];
+    __shared__ __attribute__((aligned(16))) __bf16 Ql[KW * GWB_PITCH];
     __shared__ __attribute__((aligned(16))) u32x4 mlut[256];       // relu byte -> AND mask of 8 bf16
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     mlut[tid] = chunk_mask_bits<__bf16>(u32x4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, (unsigned)tid);   // (visible after the first barrier)
@@ -585,29 +605,34 @@ __global__ __launch_bounds__(256, 2) void k_gradw_x3(GradwArgs a, size_t act_pla
     if (ln < 0) return;
     const int* lh = a.lanes + ln * LANE_INTS;
     const int bias_flag = lh[3];
-    const int nchunks = (a.B + GWB_KW - 1) / GWB_KW;
+    const int nchunks = (a.B + KW - 1) / KW;
     const int ch0 = (int)((int64_t)part * nchunks / a.n_parts), ch1 = (int)((int64_t)(part + 1) * nchunks / a.n_parts);
     const int nsteps = ch1 - ch0;            // one item per lane on the split plan
     const int c = tid & 15, r0 = tid >> 4;   // staging: 16 chunks of 8 elements per row, 16 rows per pass
 
+    // Every operand address is a workgroup-uniform base (scalar registers, from the item table) + one small per-thread offset: the
+    // six 64-bit per-thread pointers this replaces were what pushed the kernel over its register budget.
     const int* im = a.items + lh[0] * ITEM_INTS;
-    auto plane_of = [&](int buf) { return (buf >= BUF_HB && buf < BUF_IN) ? mlp_plane : act_plane; };     // elements
-    const T* p_hi = reinterpret_cast<const T*>(a.ws + a.buf_off[im[0]]) + act_idx(0, im[2], a.B) + c * 8;
-    const T* p_lo = p_hi + plane_of(im[0]);
-    const uint8_t* mb = im[9] >= 0 ? reinterpret_cast<const uint8_t*>(a.ws + a.buf_off[im[9]]) + relu_byte(im[2], a.B, 0, c * 8) : nullptr;
+    const T* p_hi = reinterpret_cast<const T*>(a.ws + a.buf_off[im[0]]) + x3_idx(0, im[2], a.B);      // rows of [hi 128 | lo 128]
+    const T* p_lo = p_hi + H;
+    const bool p_masked = im[9] >= 0;
+    const uint8_t* mb = p_masked ? reinterpret_cast<const uint8_t*>(a.ws + a.buf_off[im[9]]) + (((size_t)im[2] * 4) * ((a.B + 15) >> 4) << 6) : nullptr;
+    const int moff = (int)((((size_t)(c >> 2)) * ((a.B + 15) >> 4)) << 6) + ((c & 3) << 4) + r0;      // relu_byte(node, B, w, 8 c) = node base + moff + 64 (w >> 4)   (w & 15 == r0)
     const bool q_act = im[4] >= 0;           // Q is an activation stash (two bf16 planes) / a raw fp32 input
     const T* q_hi = nullptr; const T* q_lo = nullptr; const float* qf = nullptr;
     int64_t qstride = H; int qvalid = 8, qvb = 16;
     u32x4 sxa = u32x4{0, 0, 0, 0}, sxb = u32x4{0, 0, 0, 0};
     if (q_act) {
-        q_hi = reinterpret_cast<const T*>(a.ws + a.buf_off[im[3]]) + act_idx(0, im[5], a.B) + c * 8;
-        q_lo = q_hi + plane_of(im[3]);
+        q_hi = reinterpret_cast<const T*>(a.ws + a.buf_off[im[3]]) + x3_idx(0, im[5], a.B);
+        q_lo = q_hi + H;
     } else {
         const int t = im[3] - BUF_IN;
-        qf = reinterpret_cast<const float*>(a.x[t]) + (size_t)im[5] * a.pitch[t] + im[6] + c * 8;
+        qf = reinterpret_cast<const float*>(a.x[t]) + (size_t)im[5] * a.pitch[t] + im[6];
         qstride = (int64_t)a.nodes[t] * a.pitch[t]; qvalid = im[7] - c * 8; qvb = a.vb[t];
         sxa = sign_xor<float>(a.signs + im[8] + c * 8); sxb = sign_xor<float>(a.signs + im[8] + c * 8 + 4);
     }
+    const int loff = r0 * 2 * H + c * 8;                 // element offset of this thread inside a 16-row pass of an activation tensor
+    const int64_t qoff = (int64_t)r0 * qstride + c * 8;  // same for a raw input (floats)
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -619,34 +644,35 @@ __global__ __launch_bounds__(256, 2) void k_gradw_x3(GradwArgs a, size_t act_pla
 #pragma unroll
     for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
 
-    struct Stage { u32x4 ph[4], pl[4], qa[4], qb[4]; unsigned mw[4]; };     // qa / qb: the hi / lo plane rows, or the two fp32 halves of a raw row
+    struct Stage { u32x4 ph[NP], pl[NP], qa[NP], qb[NP]; unsigned mw[NP]; };     // qa / qb: the hi / lo plane rows, or the two fp32 halves of a raw row
     auto fetch = [&](Stage& st, int s) {
-        const int w0 = (ch0 + s) * GWB_KW;
+        const int w0 = (ch0 + s) * KW;       // uniform
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int w = w0 + r0 + 16 * p;
+        for (int p = 0; p < NP; ++p) {
+            const int wb = w0 + 16 * p, w = wb + r0;
             st.ph[p] = u32x4{0, 0, 0, 0}; st.pl[p] = u32x4{0, 0, 0, 0}; st.qa[p] = u32x4{0, 0, 0, 0}; st.qb[p] = u32x4{0, 0, 0, 0}; st.mw[p] = 0xffffffffu;
             if (w < a.B) {
-                st.ph[p] = *reinterpret_cast<const u32x4*>(p_hi + (size_t)w * H);
-                st.pl[p] = *reinterpret_cast<const u32x4*>(p_lo + (size_t)w * H);
-                if (mb) st.mw[p] = mb[((size_t)(w >> 4) << 6) + (w & 15)];
+                st.ph[p] = *reinterpret_cast<const u32x4*>(p_hi + (size_t)wb * 2 * H + loff);
+                st.pl[p] = *reinterpret_cast<const u32x4*>(p_lo + (size_t)wb * 2 * H + loff);
+                if (p_masked) st.mw[p] = (mb + ((size_t)(wb >> 4) << 6))[moff];
                 if (q_act) {
-                    st.qa[p] = *reinterpret_cast<const u32x4*>(q_hi + (size_t)w * H);
-                    st.qb[p] = *reinterpret_cast<const u32x4*>(q_lo + (size_t)w * H);
+                    st.qa[p] = *reinterpret_cast<const u32x4*>(q_hi + (size_t)wb * 2 * H + loff);
+                    st.qb[p] = *reinterpret_cast<const u32x4*>(q_lo + (size_t)wb * 2 * H + loff);
                 } else if (a.aligned) {      // raw: a use here would serialise the loads
-                    if (qvalid > 0) st.qa[p] = *reinterpret_cast<const u32x4*>(qf + (size_t)w * qstride);
-                    if (qvalid > 4) st.qb[p] = *reinterpret_cast<const u32x4*>(qf + (size_t)w * qstride + 4);
+                    const float* q = qf + (size_t)wb * qstride + qoff;
+                    if (qvalid > 0) st.qa[p] = *reinterpret_cast<const u32x4*>(q);
+                    if (qvalid > 4) st.qb[p] = *reinterpret_cast<const u32x4*>(q + 4);
                 } else {
-                    st.qa[p] = load_chunk<float>(qf + (size_t)w * qstride, qvalid, qvb);
-                    st.qb[p] = load_chunk<float>(qf + (size_t)w * qstride + 4, qvalid - 4, qvb);
+                    const float* q = qf + (size_t)wb * qstride + qoff;
+                    st.qa[p] = load_chunk<float>(q, qvalid, qvb);
+                    st.qb[p] = load_chunk<float>(q + 4, qvalid - 4, qvb);
                 }
             }
         }
     };
-    const bool p_masked = mb != nullptr;
     auto stage_to_lds = [&](const Stage& st) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < NP; ++p) {
             const int row = r0 + 16 * p;
             u32x4 ph = st.ph[p], pl = st.pl[p];
             if (p_masked) { const u32x4 m = mlut[st.mw[p] & 0xffu]; ph &= m; pl &= m; }     // dH = dX . relu bits
@@ -670,7 +696,7 @@ __global__ __launch_bounds__(256, 2) void k_gradw_x3(GradwArgs a, size_t act_pla
     };
     auto mfmas = [&]() {
 #pragma unroll
-        for (int ks = 0; ks < GWB_KW / 16; ++ks) {
+        for (int ks = 0; ks < KW / 16; ++ks) {
             bf16x8 afh[2], afl[2], bqh[2], bql[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -689,14 +715,35 @@ __global__ __launch_bounds__(256, 2) void k_gradw_x3(GradwArgs a, size_t act_pla
                 }
         }
     };
-    Stage sa;
-    if (nsteps > 0) fetch(sa, 0);
-    for (int s = 0; s < nsteps; ++s) {
-        __syncthreads();      // the previous MFMA phase of every wave is done reading the tiles
-        stage_to_lds(sa);
-        __syncthreads();
-        if (s + 1 < nsteps) fetch(sa, s + 1);
-        mfmas();
+    if constexpr (NST == 1) {
+        Stage sa;
+        if (nsteps > 0) fetch(sa, 0);
+        for (int s = 0; s < nsteps; ++s) {
+            __syncthreads();      // the previous MFMA phase of every wave is done reading the tiles
+            stage_to_lds(sa);
+            __syncthreads();
+            if (s + 1 < nsteps) fetch(sa, s + 1);
+            mfmas();
+        }
+    } else {
+        // two register stages: the loads of steps s + 1 and s + 2 are in flight while step s is multiplied
+        Stage sa, sb;
+        if (nsteps > 0) fetch(sa, 0);
+        if (nsteps > 1) fetch(sb, 1);
+        for (int s = 0; s < nsteps; s += 2) {
+            __syncthreads();
+            stage_to_lds(sa);
+            __syncthreads();
+            if (s + 2 < nsteps) fetch(sa, s + 2);
+            mfmas();
+            if (s + 1 < nsteps) {
+                __syncthreads();
+                stage_to_lds(sb);
+                __syncthreads();
+                if (s + 3 < nsteps) fetch(sb, s + 3);
+                mfmas();
+            }
+        }
     }
     float* slab = a.slabs + (size_t)(part * a.n_lanes + ln) * SLAB_FLOATS;
 #pragma unroll
@@ -744,7 +791,6 @@ static void x3_stack_args(const mshgnn_plan* p, const mshgnn_ws_layout& lay, cha
     a.wpack = ws + lay.wpack; a.bias = reinterpret_cast<const float*>(ws + lay.bias); a.tables = p->d_tables;
     a.B = B; a.NN = hp.NN; a.L = hp.L;
     a.lo_blk = hp.lo_blk; a.n_img = hp.n_img;
-    a.act_plane = (size_t)B * hp.NN * H; a.mlp_plane = (size_t)B * std::max(1, hp.n_mlp) * H;
 }
 
 int x3_forward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, float* out, char* ws, int64_t batch,
@@ -753,7 +799,6 @@ int x3_forward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitc
     const mshgnn_desc& d = hp.d;
     mshgnn_ws_layout lay; layout_workspace(hp, batch, training, &lay);
     const int B = (int)batch;
-    const size_t act_plane = (size_t)B * hp.NN * H;
     {   // 1. hi / lo weight images
         PrepArgs a{params, ws + lay.wpack, reinterpret_cast<float*>(ws + lay.bias), p->d_packs, p->d_biases, hp.n_img, (int)hp.biases.size()};
         const int64_t total = (int64_t)hp.n_img * (H * H / 8) + (int64_t)hp.biases.size() * H;
@@ -777,8 +822,8 @@ int x3_forward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitc
         a.wpack = ws + lay.wpack; a.bias = reinterpret_cast<const float*>(ws + lay.bias); a.signs = p->d_signs; a.x0 = ws + lay.x[0];
         a.mask0 = (training && lay.dd[0]) ? reinterpret_cast<uint8_t*>(ws + lay.dd[0]) : nullptr;
         ProfScope ps(p, hp.ks_enc, st);
-        if (a.aligned) hipLaunchKernelGGL(k_enc_x3<true>, dim3(a.wg_prefix[hp.NT]), dim3(256), 8 * P16::BLK, st, a, act_plane, hp.n_img);
-        else hipLaunchKernelGGL(k_enc_x3<false>, dim3(a.wg_prefix[hp.NT]), dim3(256), 8 * P16::BLK, st, a, act_plane, hp.n_img);
+        if (a.aligned) hipLaunchKernelGGL(k_enc_x3<true>, dim3(a.wg_prefix[hp.NT]), dim3(256), 8 * P16::BLK, st, a, hp.n_img);
+        else hipLaunchKernelGGL(k_enc_x3<false>, dim3(a.wg_prefix[hp.NT]), dim3(256), 8 * P16::BLK, st, a, hp.n_img);
     }
     {   // 3. all layers + decoder (+ MSE and decoder backward when y_fused)
         StackArgs a{};
@@ -805,7 +850,6 @@ int x3_backward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pit
     const mshgnn_desc& d = hp.d;
     mshgnn_ws_layout lay; layout_workspace(hp, batch, 1, &lay);
     const int B = (int)batch;
-    const size_t act_plane = (size_t)B * hp.NN * H, mlp_plane = (size_t)B * std::max(1, hp.n_mlp) * H;
     if (!dec_done && gw_phase != 1) {
         DecArgs a{};
         a.xl = ws + lay.x[hp.L]; a.dxl = ws + lay.dx[hp.L]; a.params = params; a.out_mask = p->d_out_mask; a.gout = gout;
@@ -814,7 +858,7 @@ int x3_backward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pit
         if (y) { a.y = y; a.out = const_cast<float*>(out); a.loss = loss; a.inv_n = 1.0f / (float)((int64_t)B * a.n_out * a.dout); }
         if (labels) { a.labels = labels; a.out = const_cast<float*>(out); a.loss = loss; a.inv_n = 1.0f / (float)((int64_t)B * a.n_out); }
         ProfScope ps(p, hp.ks_dec_bwd, st);
-        hipLaunchKernelGGL(k_dec_bwd_x3, dim3(NWG_DEC), dim3(256), 0, st, a, act_plane);
+        hipLaunchKernelGGL(k_dec_bwd_x3, dim3(NWG_DEC), dim3(256), 0, st, a);
     }
     if (gw_phase != 1) {
         StackArgs a{};
@@ -841,7 +885,7 @@ int x3_backward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pit
         if (gw_phase >= 0) { a.lane_order = p->d_tables + hp.order_ph_off[gw_phase]; a.n_pad = hp.npad_ph[gw_phase]; }
         a.signs = p->d_signs; a.slabs = reinterpret_cast<float*>(ws + lay.slabs); a.B = B; a.n_lanes = hp.n_lanes; a.n_parts = hp.n_parts;
         ProfScope ps(p, hp.ks_gradw, st);
-        if (a.n_pad > 0) hipLaunchKernelGGL(k_gradw_x3, dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a, act_plane, mlp_plane);
+        if (a.n_pad > 0) hipLaunchKernelGGL(k_gradw_x3, dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a);
     }
     return run_finalize(p, lay, ws, gparams, B, (y || labels) ? loss : nullptr, labels != nullptr, dec_done, gw_phase, st);
 }

@@ -17,7 +17,7 @@ import torch
 from .spec import ModelSpec, relation_aggr
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmshgnn.so")
+LIB_PATH = os.environ.get("MSHGNN_LIB") or os.path.join(_HERE, "libmshgnn.so")      # MSHGNN_LIB: an alternative build of the same library (kernel experiments)
 
 MAX_TYPES = 4
 F32, BF16, BF16X3 = 0, 1, 2
@@ -482,14 +482,14 @@ class Engine:
 
     # ---- introspection (tests) -----------------------------------------------------------------
     def _act_tensor(self, off: int, B: int) -> torch.Tensor:
-        """An activation tensor of the workspace as [B, NN, hidden] (node-major [NN, B, hidden] in memory; the split plan stores a
-        hi and a lo bf16 plane, returned as their fp32 sum)."""
+        """An activation tensor of the workspace as [B, NN, hidden] (node-major [NN, B, hidden] in memory; the split plan stores rows
+        of [hi | lo] bf16 halves, returned as their fp32 sum)."""
         ws = self.workspace(B, True)
         nn_ = self.info.total_nodes
         n = B * nn_ * self.spec.hidden
         if self.dtype == "x3":
-            planes = ws[off:off + 4 * n].view(torch.bfloat16).view(2, nn_, B, self.spec.hidden).float()
-            return (planes[0] + planes[1]).permute(1, 0, 2)
+            halves = ws[off:off + 4 * n].view(torch.bfloat16).view(nn_, B, 2, self.spec.hidden).float()
+            return (halves[:, :, 0] + halves[:, :, 1]).permute(1, 0, 2)
         es = 4 if self.dtype == "f32" else 2
         return ws[off:off + n * es].view(self.torch_dtype).view(nn_, B, self.spec.hidden).permute(1, 0, 2)
 

@@ -150,10 +150,10 @@ def engine_relu_decisions(e, spec, B):
             nb = spec.num_nodes["base"]
             n = nb * B * h
             if e.dtype == "x3":
-                t1 = ws[lay.t1[l]:lay.t1[l] + 2 * n].view(torch.bfloat16)      # hi plane carries the sign
+                t1 = ws[lay.t1[l]:lay.t1[l] + 4 * n].view(torch.bfloat16).view(nb, B, 2, h)[:, :, 0]      # rows of [hi | lo]: hi carries the sign
             else:
-                t1 = ws[lay.t1[l]:lay.t1[l] + n * (4 if e.dtype == "f32" else 2)].view(e.torch_dtype)
-            out[("t1", l)] = (t1.view(nb, B, h).permute(1, 0, 2).reshape(-1, h).float() > 0).cpu()
+                t1 = ws[lay.t1[l]:lay.t1[l] + n * (4 if e.dtype == "f32" else 2)].view(e.torch_dtype).view(nb, B, h)
+            out[("t1", l)] = (t1.permute(1, 0, 2).reshape(-1, h).float() > 0).cpu()
     return out
 
 
