@@ -1696,10 +1696,32 @@ extern "C" int mshgnn_plan_create(const mshgnn_desc* desc, mshgnn_plan** out) {
     *out = nullptr;
     mshgnn_plan* p = new (std::nothrow) mshgnn_plan();
     if (!p) return set_err(MSHGNN_ENOMEM, "out of host memory");
-    if (!compile_plan(desc, p->hp)) {
-        const std::string m = p->hp.err; delete p;
-        const bool unsup = m.find("supports") != std::string::npos || m.find("not supported") != std::string::npos || m.find("too many") != std::string::npos;
-        return set_err(unsup ? MSHGNN_EUNSUPPORTED : MSHGNN_EINVAL, m);
+    if (!desc) { delete p; return set_err(MSHGNN_EINVAL, "null descriptor"); }
+    p->n_types = desc->n_types;
+    // Engine choice: the LDS-resident kernels (hidden == 128, <= 20 nodes, in-degree 1 on mean relations) where they apply, else the
+    // generic-width engine of mshgnn_gen.hip.  MSHGNN_ENGINE=generic forces the latter (the GPU tests run the golden cases through both).
+    const char* eng_env = getenv("MSHGNN_ENGINE");
+    bool want_gen = eng_env && std::string(eng_env) == "generic";
+    std::string why;
+    if (!want_gen && !compile_plan(desc, p->hp)) {
+        why = p->hp.err;
+        const bool unsup = why.find("supports") != std::string::npos || why.find("not supported") != std::string::npos || why.find("too many") != std::string::npos;
+        if (!unsup) { delete p; return set_err(MSHGNN_EINVAL, why); }
+        want_gen = true;
+    }
+    if (want_gen) {
+        int ndev0 = 0;
+        if (hipGetDeviceCount(&ndev0) != hipSuccess || ndev0 == 0) { delete p; return set_err(MSHGNN_EHIP, "no HIP device: the MS-HGNN engine has no CPU fallback"); }
+        const int rc = gen_create(p, desc);
+        if (rc) {
+            const std::string m = g_err; gen_destroy(p); delete p;
+            return set_err(rc, why.empty() ? m : why + "; generic-width engine: " + m);
+        }
+#ifdef MSHGNN_ABLATE
+        { const char* e = getenv("MSHGNN_DBG"); p->dbg = e ? atoi(e) : 0; }
+#endif
+        *out = p;
+        return MSHGNN_OK;
     }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
@@ -1750,6 +1772,7 @@ extern "C" int mshgnn_plan_create(const mshgnn_desc* desc, mshgnn_plan** out) {
 
 extern "C" void mshgnn_plan_destroy(mshgnn_plan* p) {
     if (!p) return;
+    gen_destroy(p);
     if (p->d_tables) (void)hipFree(p->d_tables);
     if (p->d_signs) (void)hipFree(p->d_signs);
     if (p->d_out_mask) (void)hipFree(p->d_out_mask);
@@ -1768,7 +1791,7 @@ extern "C" int mshgnn_profile_enable(mshgnn_plan* p, int on) {
 
 extern "C" int mshgnn_profile_read(mshgnn_plan* p, mshgnn_kernel_stat* stats, int32_t* n_inout) {
     if (!p || !stats || !n_inout) return set_err(MSHGNN_EINVAL, "null argument");
-    std::vector<mshgnn_kernel_stat> ks = p->hp.kstats;
+    std::vector<mshgnn_kernel_stat> ks = p->gen ? *gen_kstats(p) : p->hp.kstats;
     for (const ProfRec& r : p->recs) {
         HIPCHK(hipEventSynchronize(r.b));
         float ms = 0.f;
@@ -1785,14 +1808,19 @@ extern "C" int mshgnn_profile_read(mshgnn_plan* p, mshgnn_kernel_stat* stats, in
 
 extern "C" int mshgnn_plan_info(const mshgnn_plan* p, mshgnn_info* info) {
     if (!p || !info) return set_err(MSHGNN_EINVAL, "null argument");
-    *info = p->hp.info;
+    *info = p->gen ? *gen_info(p) : p->hp.info;
     return MSHGNN_OK;
 }
 
 // host-only plan compilation (no GPU needed): used by the CPU test-suite to check the plan compiler
 extern "C" int mshgnn_plan_compile_host(const mshgnn_desc* desc, mshgnn_info* info, int32_t* n_tables_out) {
     HostPlan hp;
-    if (!compile_plan(desc, hp)) return set_err(MSHGNN_EINVAL, hp.err);
+    const char* eng_env = getenv("MSHGNN_ENGINE");
+    if ((eng_env && std::string(eng_env) == "generic") || !compile_plan(desc, hp)) {
+        const std::string why = hp.err;
+        if (gen_host_compile(desc, info, n_tables_out) == MSHGNN_OK) return MSHGNN_OK;
+        return set_err(MSHGNN_EINVAL, why.empty() ? g_err : why + "; generic-width engine: " + g_err);
+    }
     if (info) *info = hp.info;
     if (n_tables_out) *n_tables_out = (int32_t)hp.tables.size();
     return MSHGNN_OK;
@@ -1800,7 +1828,14 @@ extern "C" int mshgnn_plan_compile_host(const mshgnn_desc* desc, mshgnn_info* in
 
 extern "C" int mshgnn_workspace_layout(const mshgnn_plan* p, int64_t batch, int training, mshgnn_ws_layout* out) {
     if (!p || !out || batch < 1) return set_err(MSHGNN_EINVAL, "bad argument to mshgnn_workspace_layout");
-    layout_workspace(p->hp, batch, training, out);
+    if (p->gen) gen_layout(p, batch, training, out); else layout_workspace(p->hp, batch, training, out);
+    return MSHGNN_OK;
+}
+
+int launch_prep(const PrepArgs& a, bool split, hipStream_t st) {
+    if (split) return x3_launch_prep(a, st);
+    const int64_t total = (int64_t)a.n_packs * (H * H / Prec<__bf16>::EPC) + (int64_t)a.n_biases * H;
+    hipLaunchKernelGGL(k_prep<__bf16>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
     return MSHGNN_OK;
 }
 
@@ -1994,7 +2029,8 @@ extern "C" int mshgnn_forward(const mshgnn_plan* p, const void* const* x, const 
                               void* workspace, int64_t batch, int training, void* stream) {
     if (!p || !x || !params || !out || !workspace) return set_err(MSHGNN_EINVAL, "null argument to mshgnn_forward");
     if (batch < 1 || batch > (1 << 24)) return set_err(MSHGNN_EINVAL, "batch must be in [1, 2^24]");
-    for (int t = 0; t < p->hp.NT; ++t) if (!x[t]) return set_err(MSHGNN_EINVAL, "null input tensor");
+    for (int t = 0; t < p->n_types; ++t) if (!x[t]) return set_err(MSHGNN_EINVAL, "null input tensor");
+    if (p->gen) return gen_forward(p, x, x_pitch, params, out, (char*)workspace, batch, training, (hipStream_t)stream);
     if (p->hp.d.dtype == MSHGNN_BF16X3) return x3_forward(p, x, x_pitch, params, out, (char*)workspace, batch, training, (hipStream_t)stream, nullptr);
     if (p->hp.d.dtype == MSHGNN_F32) return forward_impl<float>(p, x, x_pitch, params, out, (char*)workspace, batch, training, (hipStream_t)stream);
     return forward_impl<__bf16>(p, x, x_pitch, params, out, (char*)workspace, batch, training, (hipStream_t)stream);
@@ -2004,6 +2040,7 @@ extern "C" int mshgnn_backward(const mshgnn_plan* p, const void* const* x, const
                                float* grad_params, void* workspace, int64_t batch, void* stream) {
     if (!p || !x || !params || !grad_out || !grad_params || !workspace) return set_err(MSHGNN_EINVAL, "null argument to mshgnn_backward");
     if (batch < 1 || batch > (1 << 24)) return set_err(MSHGNN_EINVAL, "batch must be in [1, 2^24]");
+    if (p->gen) return gen_backward(p, x, x_pitch, params, grad_out, grad_params, (char*)workspace, batch, (hipStream_t)stream, nullptr, nullptr, nullptr, nullptr);
     if (p->hp.d.dtype == MSHGNN_BF16X3) return x3_backward(p, x, x_pitch, params, grad_out, grad_params, (char*)workspace, batch, (hipStream_t)stream, nullptr, nullptr, nullptr, nullptr, false, -1);
     if (p->hp.d.dtype == MSHGNN_F32) return backward_impl<float>(p, x, x_pitch, params, grad_out, grad_params, (char*)workspace, batch, (hipStream_t)stream);
     return backward_impl<__bf16>(p, x, x_pitch, params, grad_out, grad_params, (char*)workspace, batch, (hipStream_t)stream);
@@ -2013,6 +2050,7 @@ extern "C" int mshgnn_backward_mse(const mshgnn_plan* p, const void* const* x, c
                                    const float* y, float* loss_out, float* grad_params, void* workspace, int64_t batch, void* stream) {
     if (!p || !x || !params || !out || !y || !loss_out || !grad_params || !workspace) return set_err(MSHGNN_EINVAL, "null argument to mshgnn_backward_mse");
     if (batch < 1 || batch > (1 << 24)) return set_err(MSHGNN_EINVAL, "batch must be in [1, 2^24]");
+    if (p->gen) return gen_backward(p, x, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, (hipStream_t)stream, out, y, loss_out, nullptr);
     if (p->hp.d.dtype == MSHGNN_BF16X3) return x3_backward(p, x, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, (hipStream_t)stream, out, y, loss_out, nullptr, false, -1);
     if (p->hp.d.dtype == MSHGNN_F32) return backward_impl<float>(p, x, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, (hipStream_t)stream, out, y, loss_out);
     return backward_impl<__bf16>(p, x, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, (hipStream_t)stream, out, y, loss_out);
@@ -2022,8 +2060,13 @@ extern "C" int mshgnn_step_mse(const mshgnn_plan* p, const void* const* x, const
                                float* out, float* loss_out, float* grad_params, void* workspace, int64_t batch, void* stream) {
     if (!p || !x || !params || !y || !out || !loss_out || !grad_params || !workspace) return set_err(MSHGNN_EINVAL, "null argument to mshgnn_step_mse");
     if (batch < 1 || batch > (1 << 24)) return set_err(MSHGNN_EINVAL, "batch must be in [1, 2^24]");
-    for (int t = 0; t < p->hp.NT; ++t) if (!x[t]) return set_err(MSHGNN_EINVAL, "null input tensor");
+    for (int t = 0; t < p->n_types; ++t) if (!x[t]) return set_err(MSHGNN_EINVAL, "null input tensor");
     hipStream_t st = (hipStream_t)stream;
+    if (p->gen) {      // generic-width engine: the two-call sequence
+        const int rc = gen_forward(p, x, x_pitch, params, out, (char*)workspace, batch, 1, st);
+        if (rc) return rc;
+        return gen_backward(p, x, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, st, out, y, loss_out, nullptr);
+    }
     if (p->hp.d.dtype == MSHGNN_BF16X3) {      // split plan: decoder, loss and decoder backward in the tail of its fused forward kernel as well
         int rc = x3_forward(p, x, x_pitch, params, out, (char*)workspace, batch, 1, st, y);
         if (rc) return rc;
@@ -2046,8 +2089,8 @@ extern "C" int mshgnn_step_mse_phase(const mshgnn_plan* p, const void* const* x,
     if (!p || !x || !params || !y || !out || !loss_out || !grad_params || !workspace) return set_err(MSHGNN_EINVAL, "null argument to mshgnn_step_mse_phase");
     if (batch < 1 || batch > (1 << 24)) return set_err(MSHGNN_EINVAL, "batch must be in [1, 2^24]");
     if (phase != 0 && phase != 1) return set_err(MSHGNN_EINVAL, "phase must be 0 or 1");
-    if (p->hp.grad_split < 0) return set_err(MSHGNN_EUNSUPPORTED, "this plan has no two-phase gradient split");
-    for (int t = 0; t < p->hp.NT; ++t) if (!x[t]) return set_err(MSHGNN_EINVAL, "null input tensor");
+    if (p->gen || p->hp.grad_split < 0) return set_err(MSHGNN_EUNSUPPORTED, "this plan has no two-phase gradient split");
+    for (int t = 0; t < p->n_types; ++t) if (!x[t]) return set_err(MSHGNN_EINVAL, "null input tensor");
     hipStream_t st = (hipStream_t)stream;
     if (p->hp.d.dtype == MSHGNN_BF16X3) {
         if (phase == 0) { int rc = x3_forward(p, x, x_pitch, params, out, (char*)workspace, batch, 1, st, y); if (rc) return rc; }
@@ -2068,6 +2111,7 @@ extern "C" int mshgnn_backward_ce(const mshgnn_plan* p, const void* const* x, co
     if (!p || !x || !params || !out || !labels || !loss_out || !grad_params || !workspace) return set_err(MSHGNN_EINVAL, "null argument to mshgnn_backward_ce");
     if (batch < 1 || batch > (1 << 24)) return set_err(MSHGNN_EINVAL, "batch must be in [1, 2^24]");
     if (p->hp.d.out_channels != 2) return set_err(MSHGNN_EINVAL, "mshgnn_backward_ce needs a 2-logit (contact classification) plan");
+    if (p->gen) return gen_backward(p, x, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, (hipStream_t)stream, out, nullptr, loss_out, labels);
     if (p->hp.d.dtype == MSHGNN_BF16X3) return x3_backward(p, x, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, (hipStream_t)stream, out, nullptr, loss_out, labels, false, -1);
     if (p->hp.d.dtype == MSHGNN_F32) return backward_impl<float>(p, x, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, (hipStream_t)stream, out, nullptr, loss_out, labels);
     return backward_impl<__bf16>(p, x, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, (hipStream_t)stream, out, nullptr, loss_out, labels);

@@ -749,6 +749,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16* tile, int w_base, int co
 struct FinArgs { const int* fin; const int* targets; const float* slabs; const float* dec_slabs; float* grad; int n_lanes, n_parts; float* loss; float inv_n;
                  int n_dec; };   // decoder partial slabs: NWG_DEC (k_dec_bwd) or one per tile (fused forward)
 
+struct mshgnn_gen_state;      // generic-width engine (mshgnn_gen.hip)
 struct ProfRec { int slot; hipEvent_t a, b; };
 struct mshgnn_plan {
     HostPlan hp;
@@ -761,6 +762,8 @@ struct mshgnn_plan {
     bool use_fused = false;             // bf16 plan: fused stack kernels (MSHGNN_FUSED=0 selects the per-layer kernels)
     bool use_slab = false;              // slab variant of the stack kernels (MSHGNN_SLAB=0 selects the 8-wave ones)
     bool slab_force = false; int n_cu = 256;
+    int n_types = 0;
+    mshgnn_gen_state* gen = nullptr;    // set: this plan runs on the generic-width engine (hidden != 128, many nodes, ...), hp is unused
     int dbg = 0, dbg_gw = 0;            // timing ablations (instrumented builds only: read once from MSHGNN_DBG / MSHGNN_DBG_GW at plan creation)
     // a slab workgroup has 4 waves for a whole tile: it pays off once there are enough tiles for two workgroups per CU
     bool slab_for(int tiles) const { return use_slab && (slab_force || tiles >= 2 * n_cu * 3 / 4); }
@@ -812,3 +815,17 @@ int x3_forward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitc
                int training, hipStream_t st, const float* y_fused);
 int x3_backward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, const float* gout, float* gparams, char* ws,
                 int64_t batch, hipStream_t st, const float* out, const float* y, float* loss, const int32_t* labels, bool dec_done, int gw_phase);
+int x3_launch_prep(const PrepArgs& a, hipStream_t st);
+// weight-image packing for the other engines (mshgnn.hip): k_prep<__bf16> or the hi / lo images of k_prep_x3
+int launch_prep(const PrepArgs& a, bool split, hipStream_t st);
+// generic-width engine (mshgnn_gen.hip)
+int gen_create(mshgnn_plan* p, const mshgnn_desc* desc);
+void gen_destroy(mshgnn_plan* p);
+const mshgnn_info* gen_info(const mshgnn_plan* p);
+const std::vector<mshgnn_kernel_stat>* gen_kstats(const mshgnn_plan* p);
+void gen_layout(const mshgnn_plan* p, int64_t batch, int training, mshgnn_ws_layout* out);
+int gen_host_compile(const mshgnn_desc* desc, mshgnn_info* info, int32_t* n_tables);
+int gen_forward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, float* out, char* ws, int64_t batch,
+                int training, hipStream_t st);
+int gen_backward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, const float* gout, float* gparams, char* ws,
+                 int64_t batch, hipStream_t st, const float* out, const float* y, float* loss, const int32_t* labels);

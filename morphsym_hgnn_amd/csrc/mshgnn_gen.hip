@@ -1,0 +1,639 @@
+// Generic-width MS-HGNN engine (any hidden multiple of 128, any node count / in-degree, 'add' and 'mean' aggregation): the path of
+// mshgnn.hip (GRF_HGNN.forward hgnn.py:57-62, GRF_HGNN_C2.forward hgnn_c2.py:133-182, GRF_HGNN_K4.forward hgnn_k4.py:146-196 and
+// their autograd backward) lowered to grouped block GEMMs by mshgnn_gen_plan.hpp, for the topologies / widths the LDS-resident
+// stack kernels cannot hold -- BASELINE.json configs[4]: synthetic 32-limb robot, h = 512, 6 layers.
+//
+//   k_gstep    one JOB = (destination row, 64-window tile, 128-column tile): K loop over the job's TERMS; a term's A tile
+//              [64 windows x 128] is the fp32 sum (mean: scaled) of its source rows, masked by relu bytes where the source is a
+//              dH = dX . relu bits, staged into LDS; B = a packed 128x128 weight image straight from L2 into registers; bf16 MFMA
+//              16x16x32, fp32 accumulate; bias / relu / relu-byte stash / residual / gating fused in the epilogue.  The encoder
+//              (raw fp32 or bf16 input rows, symmetry sign XOR), every HeteroConv layer, the base_transform MLP and every backward
+//              layer are launches of this one kernel with different job tables.
+//   k_ggradw   split-K weight gradients, one 128x128 tile of one target per workgroup over a chunk of the target's items and a
+//              part of the batch: dW = P^T Q with Q aggregated like a term's A tile; deterministic slab sums in k_gfinalize.
+//   SPLIT      the split-bf16 parity arithmetic of mshgnn_x3.hip (hi + lo bf16 halves, three MFMA products per term, fp32
+//              inputs, activation rows stored [hi Hd | lo Hd]): 1e-4 relative; the non-split instantiation is the bf16 plan.
+#include "mshgnn_device.hpp"
+#include "mshgnn_gen_plan.hpp"
+
+using namespace mshgnn::gen;
+using T16 = __bf16;
+using P16 = Prec<__bf16>;
+
+struct mshgnn_gen_state {      // device side of a generic plan
+    GenPlan gp;
+    int* d_tables = nullptr; uint8_t* d_signs = nullptr; float* d_out_mask = nullptr; PackDesc* d_packs = nullptr; BiasDesc* d_biases = nullptr;
+};
+
+struct GArgs {
+    char* ws; size_t buf_off[GBUF_COUNT];
+    const void* x[MSHGNN_MAX_TYPES]; int64_t pitch[MSHGNN_MAX_TYPES]; int nodes[MSHGNN_MAX_TYPES]; int vb[MSHGNN_MAX_TYPES]; int aligned;
+    const int* jobs; const int* terms; const int* srcs; const int* units; const int* items;
+    const void* wpack; const float* bias; const uint8_t* signs; float* slabs;
+    int n_img, B, Hd, NCT, tiles, training, job0, n_units, n_parts;
+};
+
+// element index of (window w, node, column 0) in an activation tensor: rows are Hd wide, or [hi Hd | lo Hd] on the split plan
+template <bool SPLIT> __device__ __forceinline__ size_t g_row(int w, int node, int B, int Hd) { return ((size_t)node * B + w) * (SPLIT ? 2 * Hd : Hd); }
+// relu bytes: one per (node, window, 8 features): [NN][Hd/32 column slices][ceil(B/16) tiles][4 groups][16 windows] (relu_byte of mshgnn_device.hpp at Hd = 128)
+__device__ __forceinline__ size_t g_relu_byte(int n, int B, int Hd, int w, int f) {
+    return ((((size_t)n * (Hd >> 5) + (f >> 5)) * ((B + 15) >> 4) + (w >> 4)) << 6) + (((f >> 3) & 3) << 4) + (w & 15);
+}
+__device__ __forceinline__ void acc8(float (&s)[8], u32x4 v, float scale) {      // s += scale * (8 bf16 of v)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        s[2 * e] += scale * __builtin_bit_cast(float, v[e] << 16);
+        s[2 * e + 1] += scale * __builtin_bit_cast(float, v[e] & 0xffff0000u);
+    }
+}
+
+// the 8 elements [col, col + 8) of the aggregated source row of window w (fp32): sum_s scale_s . mask_s . X_s[w]
+template <bool SPLIT>
+__device__ __forceinline__ void gather8(const GArgs& a, const int* src, int n_src, int w, int col, float (&s)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.f;
+    for (int k = 0; k < n_src; ++k, src += SRC_INTS) {
+        const T16* base = reinterpret_cast<const T16*>(a.ws + a.buf_off[src[S_BUF]]) + g_row<SPLIT>(w, src[S_NODE], a.B, a.Hd) + col;
+        u32x4 vh = *reinterpret_cast<const u32x4*>(base), vl = u32x4{0, 0, 0, 0};
+        if constexpr (SPLIT) vl = *reinterpret_cast<const u32x4*>(base + a.Hd);
+        if (src[S_MASK] >= 0) {      // dH = dX . relu bits
+            const unsigned byte = reinterpret_cast<const uint8_t*>(a.ws + a.buf_off[src[S_MASK]])[g_relu_byte(src[S_NODE], a.B, a.Hd, w, col)];
+            vh = chunk_mask_bits<T16>(vh, byte);
+            if constexpr (SPLIT) vl = chunk_mask_bits<T16>(vl, byte);
+        }
+        const float sc = __int_as_float(src[S_SCALE]);
+        acc8(s, vh, sc);
+        if constexpr (SPLIT) acc8(s, vl, sc);
+    }
+}
+// the same for a raw input row (type t, node): fp32 (split plan) or bf16 elements [k0, k0 + 8) with pad columns zeroed and the symmetry sign applied
+template <bool SPLIT>
+__device__ __forceinline__ void raw8(const GArgs& a, int t, int node, int w, int k0, int F, const uint8_t* sg, float (&s)[8]) {
+    const int nv = F - k0;
+    if constexpr (SPLIT) {
+        const float* p = reinterpret_cast<const float*>(a.x[t]) + ((size_t)w * a.nodes[t] + node) * a.pitch[t] + k0;
+        const u32x4 fa = chunk_keep_first<float>(load_chunk<float>(p, nv, a.vb[t]), nv) ^ sign_xor<float>(sg);
+        const u32x4 fb = chunk_keep_first<float>(load_chunk<float>(p + 4, nv - 4, a.vb[t]), nv - 4) ^ sign_xor<float>(sg + 4);
+        const f32x4 va = __builtin_bit_cast(f32x4, fa), vb4 = __builtin_bit_cast(f32x4, fb);      // (whole-vector casts: hipcc 7.2 miscompiles __builtin_bit_cast of a single vector element)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s[e] = va[e]; s[4 + e] = vb4[e]; }
+    } else {
+        const T16* p = reinterpret_cast<const T16*>(a.x[t]) + ((size_t)w * a.nodes[t] + node) * a.pitch[t] + k0;
+        const u32x4 v = chunk_keep_first<T16>(load_chunk<T16>(p, nv, a.vb[t]), nv) ^ sign_xor<T16>(sg);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] = 0.f;
+        acc8(s, v, 1.0f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// k_gstep
+// ------------------------------------------------------------------------------------------------------
+template <bool SPLIT> __global__ __launch_bounds__(256) void k_gstep(GArgs a) {
+    using P = P16;
+    constexpr int MB = 4;                               // 16-window row blocks per workgroup
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // blocks [0, MB): (hi) A tile; [MB, 2 MB): lo halves (split plan)
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ct = blockIdx.x % a.NCT, tile = (blockIdx.x / a.NCT) % a.tiles;
+    const int* job = a.jobs + (size_t)(a.job0 + blockIdx.x / (a.NCT * a.tiles)) * JOB_INTS;
+    const int w0 = tile * MB * P::ROWS, B = a.B, Hd = a.Hd;
+    const int flags = job[J_FLAGS];
+    const T16* wpack = reinterpret_cast<const T16*>(a.wpack);
+
+    P::Acc acc[MB];
+    {
+        const float* bias = (flags & JF_BIAS) ? a.bias + ((size_t)job[J_BIAS] + ct) * TW : nullptr;
+#pragma unroll
+        for (int m = 0; m < MB; ++m) acc_init_bias<T16>(acc[m], bias, wv, lane);
+    }
+    const int c = tid & 15, r0 = tid >> 4;              // staging: thread = (row, 8-element chunk) of each row block
+    const AOff<T16> ao(lane);
+    P::BFrag bfh, bfl;
+    P::AFrag af;
+    const int* term = a.terms + (size_t)job[J_TERM0] * TERM_INTS;
+    for (int ti = 0; ti < job[J_NTERMS]; ++ti, term += TERM_INTS) {
+        const int nkc = term[T_NKC], kind = term[T_KIND], n_src = term[T_NSRC], F = term[T_WIDTH];
+        const int* src = a.srcs + (size_t)term[T_SRC0] * SRC_INTS;
+        for (int kc = 0; kc < nkc; ++kc) {
+            float s[MB][8];
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+                const int w = min(w0 + m * P::ROWS + r0, B - 1);      // rows past the batch re-read the last window; they are never stored
+                if (kind == 0) gather8<SPLIT>(a, src, n_src, w, kc * TW + c * 8, s[m]);
+                else raw8<SPLIT>(a, src[S_BUF], src[S_NODE], w, kc * TW + c * 8, F, a.signs + term[T_SIGN] + kc * TW + c * 8, s[m]);
+            }
+            __syncthreads();   // the previous chunk's MFMAs are done reading LDS
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+                const f32x4 lo4 = f32x4{s[m][0], s[m][1], s[m][2], s[m][3]}, hi4 = f32x4{s[m][4], s[m][5], s[m][6], s[m][7]};
+                if constexpr (SPLIT) {
+                    u32x4 hi, lo;
+                    split_oct(lo4, hi4, hi, lo);
+                    *reinterpret_cast<u32x4*>(smem + lds_chunk<T16>(m, r0, c)) = hi;
+                    *reinterpret_cast<u32x4*>(smem + lds_chunk<T16>(MB + m, r0, c)) = lo;
+                } else *reinterpret_cast<u32x4*>(smem + lds_chunk<T16>(m, r0, c)) = pack_oct(lo4, hi4);
+            }
+            __syncthreads();
+            const int pack = term[T_PACK] + kc * a.NCT + ct;
+            load_bfrag<T16>(bfh, wpack, pack, wv, lane);
+            if constexpr (SPLIT) load_bfrag<T16>(bfl, wpack, a.n_img + pack, wv, lane);
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+                if (w0 + m * P::ROWS < B) {   // uniform
+                    load_afrag<T16>(af, smem, m, ao);
+                    mac(acc[m], af, bfh);
+                    if constexpr (SPLIT) {
+                        mac(acc[m], af, bfl);
+                        load_afrag<T16>(af, smem, MB + m, ao);
+                        mac(acc[m], af, bfh);
+                    }
+                }
+            }
+        }
+    }
+    // epilogue: this lane owns 8 consecutive output features of one window per row block
+    const int col = ct * TW + wv * 32 + c_oct(lane);
+    T16* out = reinterpret_cast<T16*>(a.ws + a.buf_off[job[J_OUT_BUF]]);
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+        const int wb = w0 + m * P::ROWS, w = wb + c_win(lane);
+        if (wb >= B) continue;
+        const int wc = min(w, B - 1);
+        if (flags & JF_GATE_POS) {      // dU = dT1 . (T1 > 0): the hi half carries the sign
+            f32x4 g0, g1;
+            load_oct(reinterpret_cast<const T16*>(a.ws + a.buf_off[job[J_GATE_BUF]]) + g_row<SPLIT>(wc, job[J_GATE_NODE], B, Hd) + col, g0, g1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { acc[m].c[0][j] = g0[j] > 0.f ? acc[m].c[0][j] : 0.f; acc[m].c[1][j] = g1[j] > 0.f ? acc[m].c[1][j] : 0.f; }
+        }
+        if (flags & JF_RELU) {
+            const unsigned bits = relu_with_bits<T16>(acc[m]);
+            if ((flags & JF_BITS_OUT) && a.training)      // (rows past the batch inside the last 16-window block land in the buffer's padding)
+                reinterpret_cast<uint8_t*>(a.ws + a.buf_off[job[J_BITS_BUF]])[g_relu_byte(job[J_OUT_NODE], B, Hd, w, col)] = (uint8_t)bits;
+        }
+        f32x4 y0 = acc[m].c[0], y1 = acc[m].c[1];
+        if (flags & JF_RES) {
+            const T16* r = reinterpret_cast<const T16*>(a.ws + a.buf_off[job[J_RES_BUF]]) + g_row<SPLIT>(wc, job[J_RES_NODE], B, Hd) + col;
+            f32x4 r0v, r1v;
+            if constexpr (SPLIT) join_oct(*reinterpret_cast<const u32x4*>(r), *reinterpret_cast<const u32x4*>(r + Hd), r0v, r1v);
+            else load_oct(r, r0v, r1v);
+            y0 += r0v; y1 += r1v;
+        }
+        if (flags & JF_GATE_BITS) {     // layer 0 of the backward pass: x relu'(X_0) from the encoder's relu bytes
+            const unsigned xb = reinterpret_cast<const uint8_t*>(a.ws + a.buf_off[job[J_GATE_BUF]])[g_relu_byte(job[J_GATE_NODE], B, Hd, wc, col)];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { y0[j] = ((xb >> j) & 1u) ? y0[j] : 0.f; y1[j] = ((xb >> (4 + j)) & 1u) ? y1[j] : 0.f; }
+        }
+        if (w < B) {
+            T16* q = out + g_row<SPLIT>(w, job[J_OUT_NODE], B, Hd) + col;
+            if constexpr (SPLIT) {
+                u32x4 hi, lo;
+                split_oct(y0, y1, hi, lo);
+                *reinterpret_cast<u32x4*>(q) = hi;
+                *reinterpret_cast<u32x4*>(q + Hd) = lo;
+            } else store_oct(q, y0, y1);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// decoder forward / backward on the rows of the out type (hgnn_c2.py:176-189) + fused wrapper MSE / cross entropy
+// thread = (row, 8-column chunk c of 16), looping over the Hd / 128 column groups
+// ------------------------------------------------------------------------------------------------------
+struct GDecArgs {
+    const void* xl; void* dxl; const float* params; const float* out_mask; float* out; const float* gout; float* slabs;
+    int64_t off_w, off_b; int B, Hd, node0, n_out, dout;
+    const float* y; const int32_t* labels; float inv_n;
+};
+template <bool SPLIT> __device__ __forceinline__ void g_load8(const T16* p, int Hd, float (&v)[8]) {
+    load8<T16>(p, v);
+    if constexpr (SPLIT) { float l[8]; load8<T16>(p + Hd, l);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += l[e]; }
+}
+template <bool SPLIT> __global__ __launch_bounds__(256) void k_gdec_fwd(GDecArgs a) {
+    const int c = threadIdx.x & 15;
+    const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4), rows = (int64_t)a.B * a.n_out;
+    const bool ok = row < rows;
+    const int w = ok ? (int)(row / a.n_out) : 0, f = ok ? (int)(row % a.n_out) : 0;
+    const T16* xr = reinterpret_cast<const T16*>(a.xl) + g_row<SPLIT>(w, a.node0 + f, a.B, a.Hd);
+    const float* W = a.params + a.off_w;
+    float s[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) s[d] = 0.f;
+    for (int cg = 0; cg < a.Hd; cg += TW) {
+        float x[8];
+        g_load8<SPLIT>(xr + cg + c * 8, a.Hd, x);
+#pragma unroll
+        for (int d = 0; d < 8; ++d)
+            if (d < a.dout) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s[d] += x[e] * W[(size_t)d * a.Hd + cg + c * 8 + e];
+            }
+    }
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        if (d < a.dout) {
+            float v = s[d];
+#pragma unroll
+            for (int m = 8; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+            if (c == 0 && ok) a.out[row * a.dout + d] = (v + a.params[a.off_b + d]) * a.out_mask[f * a.dout + d];
+        }
+    }
+}
+template <bool SPLIT> __global__ __launch_bounds__(256) void k_gdec_bwd(GDecArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float gred[];      // [16 row groups][8 x 128]: one column group at a time
+    __shared__ float bred[16][8];
+    const int SF = 8 * a.Hd + 16;
+    const int c = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int64_t rows = (int64_t)a.B * a.n_out;
+    const int64_t per = ((rows + gridDim.x - 1) / gridDim.x + 15) / 16 * 16;
+    const int64_t r_begin = (int64_t)blockIdx.x * per, r_end = min(rows, r_begin + per);
+    const float* W = a.params + a.off_w;
+    float* slab = a.slabs + (size_t)blockIdx.x * SF;
+    float accb[8], lsum = 0.f;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) accb[d] = 0.f;
+    // column group by column group: the decoder weight gradient accumulates in registers over this block's rows (fixed order)
+    for (int cg = 0; cg < a.Hd; cg += TW) {
+        float accw[8][8];
+#pragma unroll
+        for (int d = 0; d < 8; ++d)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) accw[d][e] = 0.f;
+        for (int64_t r = r_begin + rg; r < r_end; r += 16) {
+            const int w = (int)(r / a.n_out), f = (int)(r % a.n_out);
+            const size_t idx = g_row<SPLIT>(w, a.node0 + f, a.B, a.Hd) + cg + c * 8;
+            float x[8], dx[8];
+            g_load8<SPLIT>(reinterpret_cast<const T16*>(a.xl) + idx, a.Hd, x);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dx[e] = 0.f;
+            float ce_g[2] = {0.f, 0.f};
+            if (a.labels) {   // wrapper cross entropy (gnnLightning.py:640-648, mean over batch * feet): dL/dlogit = (p - onehot) / rows
+                const float l0 = a.out[r * 2], l1 = a.out[r * 2 + 1];
+                const float m = fmaxf(l0, l1), e0 = expf(l0 - m), e1 = expf(l1 - m), se = e0 + e1;
+                const int lab = a.labels[r] != 0;
+                ce_g[0] = (e0 / se - (lab ? 0.f : 1.f)) * a.inv_n; ce_g[1] = (e1 / se - (lab ? 1.f : 0.f)) * a.inv_n;
+                if (c == 0 && cg == 0) lsum += (m + logf(se)) - (lab ? l1 : l0);
+            }
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                if (d < a.dout) {
+                    float go;
+                    if (a.labels) go = ce_g[d & 1];
+                    else if (a.y) {   // wrapper MSE (gnnLightning.py:633-639): dL/dout = 2 (out - y) / n
+                        const float dlt = a.out[r * a.dout + d] - a.y[r * a.dout + d];
+                        go = 2.0f * dlt * a.inv_n;
+                        if (c == 0 && cg == 0) lsum += dlt * dlt;
+                    } else go = a.gout[r * a.dout + d];
+                    const float g = go * a.out_mask[f * a.dout + d];
+                    if (cg == 0) accb[d] += g;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { accw[d][e] += g * x[e]; dx[e] += g * W[(size_t)d * a.Hd + cg + c * 8 + e]; }
+                }
+            }
+            T16* q = reinterpret_cast<T16*>(a.dxl) + idx;
+            if constexpr (SPLIT) {
+                u32x4 hi, lo;
+                split_oct(f32x4{dx[0], dx[1], dx[2], dx[3]}, f32x4{dx[4], dx[5], dx[6], dx[7]}, hi, lo);
+                *reinterpret_cast<u32x4*>(q) = hi; *reinterpret_cast<u32x4*>(q + a.Hd) = lo;
+            } else store8<T16>(q, dx);
+        }
+        __syncthreads();      // the previous column group's sums have been read
+#pragma unroll
+        for (int d = 0; d < 8; ++d)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gred[rg * (8 * TW) + d * TW + c * 8 + e] = accw[d][e];
+        __syncthreads();
+        for (int i = threadIdx.x; i < 8 * TW; i += 256) {
+            float s2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s2 += gred[r * (8 * TW) + i];
+            slab[(i / TW) * a.Hd + cg + (i % TW)] = s2;
+        }
+    }
+    if (c == 0) {
+#pragma unroll
+        for (int d = 0; d < 8; ++d) bred[rg][d] = accb[d];
+    }
+    {   // per-block loss partial rides in the slab (summed in fixed order by k_gfinalize: no atomics, deterministic)
+        __shared__ float lred[4];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) lsum += __shfl_xor(lsum, m, 64);
+        if ((threadIdx.x & 63) == 0) lred[threadIdx.x >> 6] = lsum;
+        __syncthreads();
+        if (threadIdx.x == 0) slab[8 * a.Hd + 8] = (lred[0] + lred[1]) + (lred[2] + lred[3]);
+        if (threadIdx.x < 8) {
+            float s2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s2 += bred[r][threadIdx.x];
+            slab[8 * a.Hd + threadIdx.x] = s2;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// k_ggradw: dW tile [128 x 128] = sum over the unit's items and its part of the batch of P^T Q
+// ------------------------------------------------------------------------------------------------------
+template <bool SPLIT> __global__ __launch_bounds__(256, 2) void k_ggradw(GArgs a) {
+    constexpr int KW = SPLIT ? 32 : 64, NP = KW / 16;
+    __shared__ __attribute__((aligned(16))) __bf16 Ph[KW * GWB_PITCH];
+    __shared__ __attribute__((aligned(16))) __bf16 Qh[KW * GWB_PITCH];
+    __shared__ __attribute__((aligned(16))) __bf16 Pl[SPLIT ? KW * GWB_PITCH : 8];
+    __shared__ __attribute__((aligned(16))) __bf16 Ql[SPLIT ? KW * GWB_PITCH : 8];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wv >> 1, wc = wv & 1;
+    const int un = blockIdx.x % a.n_units, part = blockIdx.x / a.n_units;
+    const int* u = a.units + (size_t)un * UNIT_INTS;
+    const int pcol = u[U_PCOL], qcol = u[U_QCOL], qn = u[U_QN], bias_flag = u[U_BIAS];
+    const int nchunks = (a.B + KW - 1) / KW;
+    const int ch0 = (int)((int64_t)part * nchunks / a.n_parts), ch1 = (int)((int64_t)(part + 1) * nchunks / a.n_parts);
+    const int c = tid & 15, r0 = tid >> 4;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+    float bsum[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
+    for (int it = u[U_ITEM0]; it < u[U_ITEM1]; ++it) {
+        const int* im = a.items + (size_t)it * GITEM_INTS;
+        const int* src = a.srcs + (size_t)im[I_SRC0] * SRC_INTS;
+        const int psrc[SRC_INTS] = {im[I_PBUF], im[I_PNODE], im[I_PMASK], __float_as_int(1.0f)};
+        for (int ch = ch0; ch < ch1; ++ch) {
+            float ps[NP][8], qs[NP][8];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int w = ch * KW + r0 + 16 * p;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { ps[p][e] = 0.f; qs[p][e] = 0.f; }
+                if (w < a.B) {
+                    gather8<SPLIT>(a, psrc, 1, w, pcol + c * 8, ps[p]);
+                    if (im[I_KIND] == 0) { if (c * 8 < qn) gather8<SPLIT>(a, src, im[I_NSRC], w, qcol + c * 8, qs[p]); }
+                    else raw8<SPLIT>(a, src[S_BUF], src[S_NODE], w, qcol + c * 8, qcol + qn, a.signs + src[S_MASK] + qcol + c * 8, qs[p]);
+                }
+            }
+            __syncthreads();   // the previous MFMA phase is done reading the tiles
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int row = r0 + 16 * p;
+                const f32x4 p0 = f32x4{ps[p][0], ps[p][1], ps[p][2], ps[p][3]}, p1 = f32x4{ps[p][4], ps[p][5], ps[p][6], ps[p][7]};
+                const f32x4 q0 = f32x4{qs[p][0], qs[p][1], qs[p][2], qs[p][3]}, q1 = f32x4{qs[p][4], qs[p][5], qs[p][6], qs[p][7]};
+                if constexpr (SPLIT) {
+                    u32x4 hi, lo;
+                    split_oct(p0, p1, hi, lo);
+                    *reinterpret_cast<u32x4*>(&Ph[gwb_elem(row, c * 8)]) = hi; *reinterpret_cast<u32x4*>(&Pl[gwb_elem(row, c * 8)]) = lo;
+                    split_oct(q0, q1, hi, lo);
+                    *reinterpret_cast<u32x4*>(&Qh[gwb_elem(row, c * 8)]) = hi; *reinterpret_cast<u32x4*>(&Ql[gwb_elem(row, c * 8)]) = lo;
+                } else {
+                    *reinterpret_cast<u32x4*>(&Ph[gwb_elem(row, c * 8)]) = pack_oct(p0, p1);
+                    *reinterpret_cast<u32x4*>(&Qh[gwb_elem(row, c * 8)]) = pack_oct(q0, q1);
+                }
+                if (bias_flag) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bsum[e] += ps[p][e];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int ks = 0; ks < KW / 16; ++ks) {
+                bf16x8 afh[2], bqh[2], afl[2], bql[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    afh[i] = tr_frag(Ph, ks * 16, wr * 64 + i * 32, lane);
+                    bqh[i] = tr_frag(Qh, ks * 16, wc * 64 + i * 32, lane);
+                    if constexpr (SPLIT) { afl[i] = tr_frag(Pl, ks * 16, wr * 64 + i * 32, lane); bql[i] = tr_frag(Ql, ks * 16, wc * 64 + i * 32, lane); }
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afh[i], bqh[j], acc[i][j], 0, 0, 0);
+                        if constexpr (SPLIT) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afh[i], bql[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afl[i], bqh[j], acc[i][j], 0, 0, 0);
+                        }
+                    }
+            }
+        }
+    }
+    float* slab = a.slabs + ((size_t)part * a.n_units + un) * SLAB_FLOATS;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int o = wr * 64 + i * 32 + (q & 3) + ((q >> 2) << 3) + ((lane >> 5) << 2), k = wc * 64 + j * 32 + (lane & 31);
+                slab[o * H + k] = acc[i][j][q];
+            }
+    if (bias_flag) {
+        float* red = reinterpret_cast<float*>(Ph);   // 16 x 128 floats = 8 KB <= one tile
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[r0 * H + c * 8 + e] = bsum[e];
+        __syncthreads();
+        if (tid < H) {
+            float s2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s2 += red[r * H + tid];
+            slab[H * H + tid] = s2;
+        }
+    }
+}
+
+// k_gfinalize: fixed-order sums of the slabs of every destination tile -> flat gradient (every parameter written exactly once)
+struct GFinArgs { const int* fin; const float* slabs; const float* dec_slabs; float* grad; int n_units, n_parts, Hd; float* loss; float inv_n; };
+__global__ __launch_bounds__(256) void k_gfinalize(GFinArgs a) {
+    const int* f = a.fin + (size_t)blockIdx.x * GFIN_INTS;
+    const int64_t dst = (int64_t)(unsigned)f[GF_DST_LO] | ((int64_t)f[GF_DST_HI] << 32);
+    const int rows = f[GF_ROWS], cols = f[GF_COLS], ld = f[GF_LD], kind = f[GF_KIND], u0 = f[GF_UNIT0], nu = f[GF_NUNITS];
+    const int SF = 8 * a.Hd + 16;
+    if (a.loss && blockIdx.x == 0 && threadIdx.x < 64) {   // fused loss: sum the per-block partials of the decoder backward
+        float l = 0.f;
+        for (int b = threadIdx.x; b < NWG_DEC; b += 64) l += a.dec_slabs[(size_t)b * SF + 8 * a.Hd + 8];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) l += __shfl_xor(l, m, 64);
+        if (threadIdx.x == 0) *a.loss = l * a.inv_n;
+    }
+    if (kind == FIN_DEC_W || kind == FIN_DEC_B) {      // one decoder row piece: f[8] = its offset inside a decoder slab
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        for (int e = wave; e < rows * cols; e += 4) {
+            const int r = e / cols, cidx = e % cols;
+            const int src = f[8] + cidx;
+            float sum = 0.f;
+            for (int b = lane; b < NWG_DEC; b += 64) sum += a.dec_slabs[(size_t)b * SF + src];
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) sum += __shfl_xor(sum, m, 64);
+            if (lane == 0) a.grad[dst + (int64_t)r * ld + cidx] = sum;
+        }
+        return;
+    }
+    for (int i = threadIdx.x; i < rows * cols; i += 256) {
+        const int r = i / cols, cidx = i % cols;
+        float s = 0.f;
+        if (kind == FIN_MATRIX || kind == FIN_BIAS) {
+            const int src = kind == FIN_MATRIX ? r * H + cidx : H * H + cidx;
+            for (int part = 0; part < a.n_parts; ++part)
+                for (int k = 0; k < nu; ++k) s += a.slabs[((size_t)part * a.n_units + u0 + k) * SLAB_FLOATS + src];
+        }
+        a.grad[dst + (int64_t)r * ld + cidx] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------
+int gen_create(mshgnn_plan* p, const mshgnn_desc* desc) {
+    mshgnn_gen_state* g = new (std::nothrow) mshgnn_gen_state();
+    if (!g) return set_err(MSHGNN_ENOMEM, "out of host memory");
+    if (!compile_gen_plan(desc, g->gp)) {
+        const std::string m = g->gp.err; delete g;
+        return set_err(m.find("not supported") != std::string::npos ? MSHGNN_EUNSUPPORTED : MSHGNN_EINVAL, m);
+    }
+    p->gen = g;
+    GenPlan& gp = g->gp;
+    auto up = [&](void** dptr, const void* src, size_t bytes) -> int {
+        HIPCHK(hipMalloc(dptr, std::max<size_t>(bytes, 16)));
+        if (bytes) HIPCHK(hipMemcpy(*dptr, src, bytes, hipMemcpyHostToDevice));
+        return MSHGNN_OK;
+    };
+    int rc;
+    if ((rc = up((void**)&g->d_tables, gp.tables.data(), gp.tables.size() * 4)) != 0 ||
+        (rc = up((void**)&g->d_signs, gp.signs.data(), gp.signs.size())) != 0 ||
+        (rc = up((void**)&g->d_out_mask, gp.out_mask_f.data(), gp.out_mask_f.size() * 4)) != 0 ||
+        (rc = up((void**)&g->d_packs, gp.packs.data(), gp.packs.size() * sizeof(PackDesc))) != 0 ||
+        (rc = up((void**)&g->d_biases, gp.biases.data(), gp.biases.size() * sizeof(BiasDesc))) != 0) return rc;
+    const int dec_lds = 16 * 8 * TW * 4;
+    if ((rc = set_lds_attr(k_gdec_bwd<false>, dec_lds)) || (rc = set_lds_attr(k_gdec_bwd<true>, dec_lds))) return rc;
+    return MSHGNN_OK;
+}
+
+void gen_destroy(mshgnn_plan* p) {
+    mshgnn_gen_state* g = p->gen;
+    if (!g) return;
+    if (g->d_tables) (void)hipFree(g->d_tables);
+    if (g->d_signs) (void)hipFree(g->d_signs);
+    if (g->d_out_mask) (void)hipFree(g->d_out_mask);
+    if (g->d_packs) (void)hipFree(g->d_packs);
+    if (g->d_biases) (void)hipFree(g->d_biases);
+    delete g;
+    p->gen = nullptr;
+}
+
+const mshgnn_info* gen_info(const mshgnn_plan* p) { return &p->gen->gp.info; }
+const std::vector<mshgnn_kernel_stat>* gen_kstats(const mshgnn_plan* p) { return &p->gen->gp.kstats; }
+void gen_layout(const mshgnn_plan* p, int64_t batch, int training, mshgnn_ws_layout* out) { layout_gen_workspace(p->gen->gp, batch, training, out); }
+int gen_host_compile(const mshgnn_desc* desc, mshgnn_info* info, int32_t* n_tables) {
+    GenPlan gp;
+    if (!compile_gen_plan(desc, gp)) return set_err(MSHGNN_EINVAL, gp.err);
+    if (info) *info = gp.info;
+    if (n_tables) *n_tables = (int32_t)gp.tables.size();
+    return MSHGNN_OK;
+}
+
+static int g_fill(const mshgnn_plan* p, const mshgnn_ws_layout& lay, const void* const* x, const int64_t* x_pitch, char* ws, int B, int training, GArgs& a) {
+    const mshgnn_gen_state* g = p->gen;
+    const GenPlan& gp = g->gp;
+    const mshgnn_desc& d = gp.d;
+    a.ws = ws;
+    for (int l = 0; l <= gp.L; ++l) { a.buf_off[BUF_X + l] = lay.x[l]; a.buf_off[BUF_DX + l] = lay.dx[l]; }
+    for (int l = 0; l < gp.L; ++l) {
+        a.buf_off[BUF_MASK + l] = lay.mask[l]; a.buf_off[BUF_DH + l] = lay.dh[l]; a.buf_off[BUF_HB + l] = lay.hb[l];
+        a.buf_off[BUF_T1 + l] = lay.t1[l]; a.buf_off[BUF_DU + l] = lay.du[l];
+    }
+    a.buf_off[GBUF_MASK0] = lay.dd[0];
+    const int in_es = gp.split ? 4 : 2;
+    for (int t = 0; t < gp.NT; ++t) {
+        a.x[t] = x[t]; a.pitch[t] = x_pitch ? x_pitch[t] : d.type_width[t]; a.nodes[t] = d.type_nodes[t];
+        if (a.pitch[t] < d.type_width[t]) return set_err(MSHGNN_EINVAL, "x_pitch smaller than the feature width");
+        a.vb[t] = vec_bytes(x[t], a.pitch[t], in_es);
+    }
+    a.jobs = g->d_tables + gp.job_off; a.terms = g->d_tables + gp.term_off; a.srcs = g->d_tables + gp.src_off;
+    a.units = g->d_tables + gp.unit_off; a.items = g->d_tables + gp.item_off;
+    a.wpack = ws + lay.wpack; a.bias = reinterpret_cast<const float*>(ws + lay.bias); a.signs = g->d_signs;
+    a.slabs = reinterpret_cast<float*>(ws + lay.slabs);
+    a.n_img = gp.n_img; a.B = B; a.Hd = gp.Hd; a.NCT = gp.NCT; a.tiles = (B + 63) / 64; a.training = training;
+    a.n_units = gp.n_units; a.n_parts = gp.n_parts;
+    return MSHGNN_OK;
+}
+
+static void g_launch_jobs(const mshgnn_plan* p, const Launch& ln, GArgs a, hipStream_t st) {
+    const GenPlan& gp = p->gen->gp;
+    a.job0 = ln.job0;
+    const unsigned grid = (unsigned)ln.n_jobs * a.tiles * a.NCT;
+    ProfScope ps(p, ln.ks, st);
+    if (gp.split) hipLaunchKernelGGL(k_gstep<true>, dim3(grid), dim3(256), 8 * P16::BLK, st, a);
+    else hipLaunchKernelGGL(k_gstep<false>, dim3(grid), dim3(256), 4 * P16::BLK, st, a);
+}
+
+int gen_forward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, float* out, char* ws, int64_t batch,
+                int training, hipStream_t st) {
+    const mshgnn_gen_state* g = p->gen;
+    const GenPlan& gp = g->gp;
+    const mshgnn_desc& d = gp.d;
+    mshgnn_ws_layout lay; layout_gen_workspace(gp, batch, training, &lay);
+    const int B = (int)batch;
+    {
+        PrepArgs a{params, ws + lay.wpack, reinterpret_cast<float*>(ws + lay.bias), g->d_packs, g->d_biases, gp.n_img, (int)gp.biases.size()};
+        ProfScope ps(p, gp.ks_prep, st);
+        launch_prep(a, gp.split, st);
+    }
+    GArgs a{};
+    int rc = g_fill(p, lay, x, x_pitch, ws, B, training, a);
+    if (rc) return rc;
+    for (const Launch& ln : gp.fwd) g_launch_jobs(p, ln, a, st);
+    {
+        GDecArgs da{};
+        da.xl = ws + lay.x[gp.L]; da.params = params; da.out_mask = g->d_out_mask; da.out = out; da.off_w = d.off_dec_w; da.off_b = d.off_dec_b;
+        da.B = B; da.Hd = gp.Hd; da.node0 = gp.type_base[d.out_type]; da.n_out = d.type_nodes[d.out_type]; da.dout = d.out_channels;
+        const int64_t rows = (int64_t)B * da.n_out;
+        ProfScope ps(p, gp.ks_dec_fwd, st);
+        if (gp.split) hipLaunchKernelGGL(k_gdec_fwd<true>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, da);
+        else hipLaunchKernelGGL(k_gdec_fwd<false>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, da);
+    }
+    HIPCHK(hipGetLastError());
+    return MSHGNN_OK;
+}
+
+int gen_backward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, const float* gout, float* gparams, char* ws,
+                 int64_t batch, hipStream_t st, const float* out, const float* y, float* loss, const int32_t* labels) {
+    const mshgnn_gen_state* g = p->gen;
+    const GenPlan& gp = g->gp;
+    const mshgnn_desc& d = gp.d;
+    mshgnn_ws_layout lay; layout_gen_workspace(gp, batch, 1, &lay);
+    const int B = (int)batch;
+    const int n_out = d.type_nodes[d.out_type];
+    {
+        GDecArgs da{};
+        da.xl = ws + lay.x[gp.L]; da.dxl = ws + lay.dx[gp.L]; da.params = params; da.out_mask = g->d_out_mask; da.gout = gout;
+        da.slabs = reinterpret_cast<float*>(ws + lay.dec_slabs); da.off_w = d.off_dec_w; da.off_b = d.off_dec_b;
+        da.B = B; da.Hd = gp.Hd; da.node0 = gp.type_base[d.out_type]; da.n_out = n_out; da.dout = d.out_channels;
+        if (y) { da.y = y; da.out = const_cast<float*>(out); da.inv_n = 1.0f / (float)((int64_t)B * n_out * d.out_channels); }
+        if (labels) { da.labels = labels; da.out = const_cast<float*>(out); da.inv_n = 1.0f / (float)((int64_t)B * n_out); }
+        const int dec_lds = 16 * 8 * TW * 4;
+        ProfScope ps(p, gp.ks_dec_bwd, st);
+        if (gp.split) hipLaunchKernelGGL(k_gdec_bwd<true>, dim3(NWG_DEC), dim3(256), dec_lds, st, da);
+        else hipLaunchKernelGGL(k_gdec_bwd<false>, dim3(NWG_DEC), dim3(256), dec_lds, st, da);
+    }
+    GArgs a{};
+    int rc = g_fill(p, lay, x, x_pitch, ws, B, 1, a);
+    if (rc) return rc;
+    for (const Launch& ln : gp.bwd) g_launch_jobs(p, ln, a, st);
+    {
+        ProfScope ps(p, gp.ks_gradw, st);
+        const unsigned grid = (unsigned)gp.n_units * gp.n_parts;
+        if (gp.split) hipLaunchKernelGGL(k_ggradw<true>, dim3(grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(k_ggradw<false>, dim3(grid), dim3(256), 0, st, a);
+    }
+    {
+        GFinArgs fa{g->d_tables + gp.fin_off, reinterpret_cast<const float*>(ws + lay.slabs), reinterpret_cast<const float*>(ws + lay.dec_slabs), gparams,
+                    gp.n_units, gp.n_parts, gp.Hd, (y || labels) ? loss : nullptr, 1.0f / (float)((int64_t)B * n_out * (labels ? 1 : d.out_channels))};
+        ProfScope ps(p, gp.ks_fin, st);
+        hipLaunchKernelGGL(k_gfinalize, dim3(gp.n_fin), dim3(256), 0, st, fa);
+    }
+    HIPCHK(hipGetLastError());
+    return MSHGNN_OK;
+}

@@ -1,0 +1,476 @@
+// Host-side plan compiler of the GENERIC-WIDTH MS-HGNN engine (mshgnn_gen.hip): any hidden width that is a multiple of 128, any
+// number of nodes per window, any in-degree, 'add' and 'mean' aggregation -- what the LDS-resident stack kernels of mshgnn.hip
+// (hidden == 128, <= 20 nodes) cannot hold, e.g. BASELINE.json configs[4] (synthetic 32-limb robot, h = 512, 6 layers).
+//
+// Same path and the same algebra as mshgnn_plan.hpp (GRF_HGNN.forward hgnn.py:57-62, GRF_HGNN_C2.forward hgnn_c2.py:133-182,
+// GRF_HGNN_K4.forward hgnn_k4.py:146-196; PyG-2.5.0 HeteroConv / GraphConv semantics):
+//     H_d[i] = (sum_r W_root^r) X_d[i] + sum_r b_rel^r + sum_r W_rel^r Agg_r({X_s[j] : j -> i in r})
+// but lowered to a grouped GEMM instead of an LDS-resident tile: every (destination row, 64-window tile, 128-column tile) is a JOB whose
+// K loop runs over TERMS = (weight pack, sources to aggregate).  Aggregation happens while a term's A tile is staged (sum / mean of
+// the source rows in fp32 -- the reference's own order: aggregate, then lin_rel), so a node with in-degree 32 costs one block GEMM
+// per relation, not 32.  The backward pass is the same job machinery on the transposed graph; weight gradients are split-K
+// 128x128 tiles dW = P^T Q with Q aggregated the same way.  No HIP calls in this file.
+#pragma once
+#include "mshgnn_plan.hpp"
+
+namespace mshgnn {
+namespace gen {
+
+constexpr int TW = 128;                 // tile width: output-column tile of a job, K chunk of a term
+constexpr int G_MAX_L = 16;
+enum { JF_BIAS = 1, JF_RELU = 2, JF_RES = 4, JF_BITS_OUT = 8, JF_GATE_BITS = 16, JF_GATE_POS = 32 };
+// job:  out_buf out_node flags bias_idx | res_buf res_node bits_buf gate_buf | gate_node term_begin n_terms pad...
+enum { J_OUT_BUF = 0, J_OUT_NODE, J_FLAGS, J_BIAS, J_RES_BUF, J_RES_NODE, J_BITS_BUF, J_GATE_BUF, J_GATE_NODE, J_TERM0, J_NTERMS, JOB_INTS = 12 };
+// term: pack_base nkc kind(0 activation, 1 raw input) src_begin | n_src width sign_off pad     pack of (kc, ct) = pack_base + kc * NCT + ct
+enum { T_PACK = 0, T_NKC, T_KIND, T_SRC0, T_NSRC, T_WIDTH, T_SIGN, TERM_INTS = 8 };
+// source: buf (raw: node type) node mask_buf(-1: none) scale(float bits)
+enum { S_BUF = 0, S_NODE, S_MASK, S_SCALE, SRC_INTS = 4 };
+// weight-gradient unit = one 128x128 tile of one target over a chunk of its items: item_begin item_end p_col0 q_col0 | q_ncols bias_flag pad pad
+enum { U_ITEM0 = 0, U_ITEM1, U_PCOL, U_QCOL, U_QN, U_BIAS, UNIT_INTS = 8 };
+// item: p_buf p_node p_mask_buf kind(0 activation sources, 1 raw input) | src_begin n_src pad pad
+enum { I_PBUF = 0, I_PNODE, I_PMASK, I_KIND, I_SRC0, I_NSRC, GITEM_INTS = 8 };
+// finalize op: dst_lo dst_hi rows cols | ld kind unit_begin n_units | src_row0 pad pad pad     (units of one target tile are consecutive)
+enum { GF_DST_LO = 0, GF_DST_HI, GF_ROWS, GF_COLS, GF_LD, GF_KIND, GF_UNIT0, GF_NUNITS, GFIN_INTS = 12 };
+constexpr int GBUF_MASK0 = BUF_COUNT;   // relu bytes of the encoder activation X_0 (workspace dd[0]); BUF_* ids as in mshgnn_plan.hpp
+constexpr int GBUF_COUNT = BUF_COUNT + 1;
+constexpr int G_ITEMS_PER_UNIT = 8;     // items one weight-gradient workgroup sweeps (more units = more parallelism, more slabs to sum)
+
+struct Launch { int job0, n_jobs, ks; };
+
+struct GenPlan {
+    mshgnn_desc d{};
+    std::vector<int32_t> rel_src, rel_dst, rel_mean, rel_edge_off, edges;
+    std::vector<float> out_mask_f;
+    std::vector<int64_t> off_enc_w, off_enc_b, off_rel_w, off_rel_b, off_root_w;
+    int L = 0, NT = 0, NR = 0, NN = 0, Hd = 0, NCT = 0, n_mlp = 0;
+    bool split = false; int esize = 2, planes = 1;
+    int type_base[MSHGNN_MAX_TYPES + 1]{};
+    std::vector<int> node_type;
+    bool live[G_MAX_L][MSHGNN_MAX_TYPES]{}, need_dx[G_MAX_L][MSHGNN_MAX_TYPES]{};
+    std::vector<PackDesc> packs; int n_img = 0;
+    std::vector<BiasDesc> biases;
+    std::vector<uint8_t> signs; std::vector<int> sign_off, enc_nkc;
+    std::vector<int32_t> tables;            // jobs | terms | srcs | units | items | fins
+    int job_off = 0, term_off = 0, src_off = 0, unit_off = 0, item_off = 0, fin_off = 0, n_units = 0, n_parts = 1, n_fin = 0;
+    std::vector<Launch> fwd, bwd;           // job launches in order
+    int ks_prep = 0, ks_dec_fwd = 0, ks_dec_bwd = 0, ks_gradw = 0, ks_fin = 0;
+    std::vector<mshgnn_kernel_stat> kstats;
+    mshgnn_info info{};
+    std::string err;
+};
+
+inline bool gfail(GenPlan& p, const std::string& m) { p.err = m; return false; }
+
+inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
+    if (!din) return gfail(p, "null descriptor");
+    p.d = *din;
+    const mshgnn_desc& d = p.d;
+    if (d.n_types < 1 || d.n_types > MSHGNN_MAX_TYPES) return gfail(p, "n_types must be 1..4");
+    if (d.hidden < TW || d.hidden % TW || d.hidden > 2048) return gfail(p, "hidden_channels must be a multiple of 128 (128..2048): not supported by this build");
+    if (d.num_layers < 1 || d.num_layers > G_MAX_L) return gfail(p, "num_layers must be 1..16");
+    if (d.n_rel < 1 || d.n_rel > 64) return gfail(p, "n_rel must be 1..64");
+    if (d.dtype != MSHGNN_BF16 && d.dtype != MSHGNN_BF16X3 && d.dtype != MSHGNN_F32)
+        return gfail(p, "dtype must be MSHGNN_F32, MSHGNN_BF16 or MSHGNN_BF16X3");
+    if (d.out_type < 0 || d.out_type >= d.n_types) return gfail(p, "out_type out of range");
+    if (d.out_channels < 1 || d.out_channels > 8) return gfail(p, "out_channels must be 1..8");
+    if (!d.rel_src || !d.rel_dst || !d.rel_mean || !d.rel_edge_off || !d.edges) return gfail(p, "null relation arrays");
+    if (!d.off_enc_w || !d.off_enc_b || !d.off_rel_w || !d.off_rel_b || !d.off_root_w) return gfail(p, "null offset arrays");
+    // the generic engine has two arithmetic modes: bf16, and the split-bf16 parity mode.  MSHGNN_F32 asks for parity: it is served by
+    // the split mode (1e-4 relative) -- there is no fp32-MFMA variant of these kernels.
+    p.split = d.dtype != MSHGNN_BF16; p.planes = p.split ? 2 : 1; p.esize = 2;
+    p.L = d.num_layers; p.NT = d.n_types; p.NR = d.n_rel; p.Hd = d.hidden; p.NCT = d.hidden / TW;
+    const int L = p.L, NT = p.NT, NR = p.NR, Hd = p.Hd, NCT = p.NCT;
+    const bool has_mlp = (d.flags & MSHGNN_FLAG_BASE_MLP) != 0, residual = (d.flags & MSHGNN_FLAG_RESIDUAL) != 0;
+    if (has_mlp && (d.mlp_type < 0 || d.mlp_type >= NT)) return gfail(p, "mlp_type out of range");
+    p.type_base[0] = 0;
+    for (int t = 0; t < NT; ++t) {
+        if (d.type_nodes[t] < 1 || d.type_width[t] < 1) return gfail(p, "every node type needs >= 1 node and input width >= 1");
+        p.type_base[t + 1] = p.type_base[t] + d.type_nodes[t];
+        for (int i = 0; i < d.type_nodes[t]; ++i) p.node_type.push_back(t);
+    }
+    p.NN = p.type_base[NT];
+    if (p.NN > 4096) return gfail(p, "more than 4096 nodes per window: not supported by this build");
+    p.n_mlp = has_mlp ? d.type_nodes[d.mlp_type] : 0;
+    p.rel_src.assign(d.rel_src, d.rel_src + NR); p.rel_dst.assign(d.rel_dst, d.rel_dst + NR);
+    p.rel_mean.assign(d.rel_mean, d.rel_mean + NR); p.rel_edge_off.assign(d.rel_edge_off, d.rel_edge_off + NR + 1);
+    const int E = p.rel_edge_off[NR];
+    if (p.rel_edge_off[0] != 0 || E < 0) return gfail(p, "bad rel_edge_off");
+    p.edges.assign(d.edges, d.edges + 2 * (size_t)E);
+    p.off_enc_w.assign(d.off_enc_w, d.off_enc_w + NT); p.off_enc_b.assign(d.off_enc_b, d.off_enc_b + NT);
+    p.off_rel_w.assign(d.off_rel_w, d.off_rel_w + (size_t)L * NR); p.off_rel_b.assign(d.off_rel_b, d.off_rel_b + (size_t)L * NR);
+    p.off_root_w.assign(d.off_root_w, d.off_root_w + (size_t)L * NR);
+    std::vector<bool> has_in(NT, false);
+    // in-edges per (relation, dst node) and out-edges per (relation, src node); mean scale = 1 / in-degree of the dst node
+    std::vector<std::vector<std::vector<int>>> in_src(NR), out_dst(NR);
+    for (int r = 0; r < NR; ++r) {
+        const int s = p.rel_src[r], t = p.rel_dst[r];
+        if (s < 0 || s >= NT || t < 0 || t >= NT) return gfail(p, "relation type index out of range");
+        if (p.rel_edge_off[r + 1] < p.rel_edge_off[r]) return gfail(p, "rel_edge_off must be non-decreasing");
+        has_in[t] = true;
+        in_src[r].assign(d.type_nodes[t], {}); out_dst[r].assign(d.type_nodes[s], {});
+        for (int e = p.rel_edge_off[r]; e < p.rel_edge_off[r + 1]; ++e) {
+            const int j = p.edges[2 * e], i = p.edges[2 * e + 1];
+            if (j < 0 || j >= d.type_nodes[s] || i < 0 || i >= d.type_nodes[t]) return gfail(p, "edge endpoint out of range");
+            in_src[r][i].push_back(j); out_dst[r][j].push_back(i);
+        }
+    }
+    for (int t = 0; t < NT; ++t)
+        if (!has_in[t]) return gfail(p, "every node type must be the destination of at least one relation (HeteroConv drops types without incoming relations)");
+    auto scale_of = [&](int r, int i) { return p.rel_mean[r] ? 1.0f / (float)std::max<size_t>(1, in_src[r][i].size()) : 1.0f; };
+    auto fbits = [](float f) { int32_t b; std::memcpy(&b, &f, 4); return b; };
+
+    // symmetry masks (+-1) -> sign bytes per (node, K chunk)
+    p.sign_off.assign(NT, 0); p.enc_nkc.assign(NT, 0);
+    for (int t = 0; t < NT; ++t) {
+        const int F = d.type_width[t], n = d.type_nodes[t];
+        const int nkc = (F + TW - 1) / TW; p.enc_nkc[t] = nkc;
+        p.sign_off[t] = (int)p.signs.size();
+        p.signs.resize(p.signs.size() + (size_t)n * nkc * TW, 0);
+        if (d.in_mask[t])
+            for (int i = 0; i < n; ++i) for (int k = 0; k < F; ++k) {
+                const float m = d.in_mask[t][(size_t)i * F + k];
+                if (m != 1.0f && m != -1.0f) return gfail(p, "symmetry masks must be +1 or -1");
+                p.signs[p.sign_off[t] + (size_t)i * nkc * TW + k] = m < 0 ? 1 : 0;
+            }
+    }
+    const int n_out = d.type_nodes[d.out_type];
+    p.out_mask_f.assign((size_t)n_out * d.out_channels, 1.0f);
+    if (d.out_mask) for (size_t i = 0; i < p.out_mask_f.size(); ++i) {
+        if (d.out_mask[i] != 1.0f && d.out_mask[i] != -1.0f) return gfail(p, "output mask must be +1 or -1");
+        p.out_mask_f[i] = d.out_mask[i];
+    }
+
+    // ---- liveness (as mshgnn_plan.hpp: outputs of the last layer are read on the decoder's type only) -------------------------
+    for (int t = 0; t < NT; ++t) p.live[L - 1][t] = (t == d.out_type);
+    for (int l = L - 2; l >= 0; --l)
+        for (int t = 0; t < NT; ++t) {
+            bool v = p.live[l + 1][t];
+            for (int r = 0; r < NR; ++r) if (p.rel_src[r] == t && p.live[l + 1][p.rel_dst[r]]) v = true;
+            p.live[l][t] = v;
+        }
+    for (int l = 0; l < L; ++l)
+        for (int t = 0; t < NT; ++t) {
+            if (l >= 1) { p.need_dx[l][t] = p.live[l - 1][t]; continue; }
+            bool v = p.live[0][t];
+            for (int r = 0; r < NR; ++r) if (p.rel_src[r] == t && p.live[0][p.rel_dst[r]]) v = true;
+            p.need_dx[0][t] = v;
+        }
+
+    // ---- packs: a [rows x K] weight becomes ceil(K/128) x NCT(rows) images of 128x128, pack(kc, ct) = base + kc * nct + ct ------------
+    // orient 0 (forward, out = A W^T):   B[k][c] = W[ct*128 + c][kc*128 + k]     orient 1 (backward, dA = dH W):   B[k][c] = W[kc*128 + k][ct*128 + c]
+    auto add_packs = [&](int orient, const std::vector<int64_t>& src, int rows, int K) {
+        const int nkc = orient == 0 ? (K + TW - 1) / TW : rows / TW, nct = orient == 0 ? rows / TW : (K + TW - 1) / TW;
+        const int base = (int)p.packs.size();
+        for (int kc = 0; kc < nkc; ++kc)
+            for (int ct = 0; ct < nct; ++ct) {
+                PackDesc q{}; q.orient = orient; q.n_src = (int)src.size(); q.ld = K;
+                if (orient == 0) { q.col0 = kc * TW; q.ncols = std::min(TW, K - kc * TW); for (size_t i = 0; i < src.size(); ++i) q.src[i] = src[i] + (int64_t)ct * TW * K; }
+                else { q.col0 = 0; q.ncols = TW; for (size_t i = 0; i < src.size(); ++i) q.src[i] = src[i] + (int64_t)kc * TW * K + (int64_t)ct * TW; }
+                p.packs.push_back(q);
+            }
+        return base; };
+    auto add_bias = [&](const std::vector<int64_t>& src) {      // an Hd-wide bias = NCT consecutive 128-wide bias rows
+        const int base = (int)p.biases.size();
+        for (int ct = 0; ct < NCT; ++ct) { BiasDesc b{}; b.n_src = (int)src.size(); for (size_t i = 0; i < src.size(); ++i) b.src[i] = src[i] + ct * TW; p.biases.push_back(b); }
+        return base; };
+    std::vector<int> pack_root[2], pack_rel[2], bias_layer((size_t)L * NT, -1), pack_enc(NT, -1), bias_enc(NT, -1);
+    for (int o = 0; o < 2; ++o) { pack_root[o].assign((size_t)L * NT, -1); pack_rel[o].assign((size_t)L * NR, -1); }
+    int pack_mlp[2][2] = {{-1, -1}, {-1, -1}}, bias_mlp[2] = {-1, -1};
+    for (int l = 0; l < L; ++l) {
+        for (int t = 0; t < NT; ++t) {
+            if (!p.live[l][t]) continue;
+            std::vector<int64_t> ws, bs;
+            for (int r = 0; r < NR; ++r) if (p.rel_dst[r] == t) { ws.push_back(p.off_root_w[l * NR + r]); bs.push_back(p.off_rel_b[l * NR + r]); }
+            if (ws.size() > 8) return gfail(p, "more than 8 relations into one node type");
+            pack_root[0][l * NT + t] = add_packs(0, ws, Hd, Hd);
+            pack_root[1][l * NT + t] = add_packs(1, ws, Hd, Hd);
+            bias_layer[l * NT + t] = add_bias(bs);
+        }
+        for (int r = 0; r < NR; ++r) {
+            if (!p.live[l][p.rel_dst[r]] || p.rel_edge_off[r + 1] == p.rel_edge_off[r]) continue;
+            pack_rel[0][l * NR + r] = add_packs(0, {p.off_rel_w[l * NR + r]}, Hd, Hd);
+            pack_rel[1][l * NR + r] = add_packs(1, {p.off_rel_w[l * NR + r]}, Hd, Hd);
+        }
+    }
+    if (has_mlp) {
+        for (int o = 0; o < 2; ++o) { pack_mlp[o][0] = add_packs(o, {d.off_mlp[0]}, Hd, Hd); pack_mlp[o][1] = add_packs(o, {d.off_mlp[2]}, Hd, Hd); }
+        bias_mlp[0] = add_bias({d.off_mlp[1]}); bias_mlp[1] = add_bias({d.off_mlp[3]});
+    }
+    for (int t = 0; t < NT; ++t) { pack_enc[t] = add_packs(0, {p.off_enc_w[t]}, Hd, d.type_width[t]); bias_enc[t] = add_bias({p.off_enc_b[t]}); }
+    p.n_img = (int)p.packs.size();
+
+    // ---- job tables ---------------------------------------------------------------------------------------------------
+    std::vector<int32_t> jobs, terms, srcs;
+    auto add_src = [&](int buf, int node, int mask, float scale) { srcs.insert(srcs.end(), {buf, node, mask, fbits(scale)}); return (int)(srcs.size() / SRC_INTS) - 1; };
+    struct TermDef { int pack, nkc, kind, width, sign; std::vector<std::array<int, 4>> s; };
+    auto add_job = [&](int out_buf, int out_node, int flags, int bias, int res_buf, int res_node, int bits_buf, int gate_buf, int gate_node,
+                       const std::vector<TermDef>& tds) {
+        const int t0 = (int)(terms.size() / TERM_INTS);
+        for (const TermDef& td : tds) {
+            const int s0 = (int)(srcs.size() / SRC_INTS);
+            for (auto& s : td.s) srcs.insert(srcs.end(), {s[0], s[1], s[2], s[3]});
+            terms.insert(terms.end(), {td.pack, td.nkc, td.kind, s0, (int)td.s.size(), td.width, td.sign, 0});
+        }
+        jobs.insert(jobs.end(), {out_buf, out_node, flags, bias, res_buf, res_node, bits_buf, gate_buf, gate_node, t0, (int)tds.size(), 0});
+        return (int)(jobs.size() / JOB_INTS) - 1; };
+    auto one = [&](int buf, int node, int mask = -1, float scale = 1.0f) { return std::array<int, 4>{buf, node, mask, fbits(scale)}; };
+    double alg_fwd = 0, alg_bwd = 0, exec_fwd = 0, exec_bwd = 0;
+    const double NL = 2.0 * Hd * Hd;
+    auto stat = [&](const std::string& name, int bound, double fa, double by) {
+        mshgnn_kernel_stat k{}; std::snprintf(k.name, sizeof(k.name), "%s", name.c_str());
+        k.bound = bound; k.flops_per_window = fa; k.flops_exec_per_window = fa; k.bytes_per_window = by;
+        p.kstats.push_back(k); return (int)p.kstats.size() - 1; };
+    const double es = (double)p.esize * p.planes, in_es = p.split ? 4.0 : 2.0;
+    double bytes_in = 0; for (int t = 0; t < NT; ++t) bytes_in += (double)d.type_nodes[t] * d.type_width[t] * in_es;
+    p.ks_prep = stat("prep", MSHGNN_BOUND_HBM, 0, 0);
+    auto launch = [&](std::vector<Launch>& v, int j0, const std::string& name, double flops, double bytes) {
+        const int n = (int)(jobs.size() / JOB_INTS) - j0;
+        if (n > 0) v.push_back({j0, n, stat(name, MSHGNN_BOUND_MFMA, flops, bytes)}); };
+
+    {   // encoder: X_0[n] = relu((mask . x) W_enc^T + b)      (hgnn_c2.py:143-147)
+        const int j0 = (int)(jobs.size() / JOB_INTS); double fl = 0;
+        for (int t = 0; t < NT; ++t)
+            for (int i = 0; i < d.type_nodes[t]; ++i) {
+                TermDef td{pack_enc[t], p.enc_nkc[t], 1, d.type_width[t], p.sign_off[t] + i * p.enc_nkc[t] * TW, {std::array<int, 4>{t, i, -1, fbits(1.0f)}}};
+                add_job(BUF_X + 0, p.type_base[t] + i, JF_BIAS | JF_RELU | JF_BITS_OUT, bias_enc[t], -1, 0, GBUF_MASK0, -1, 0, {td});
+                fl += 2.0 * Hd * d.type_width[t];
+            }
+        alg_fwd += fl; exec_fwd += fl;
+        launch(p.fwd, j0, "enc_fwd", fl, bytes_in + (double)p.NN * Hd * es);
+    }
+    for (int l = 0; l < L; ++l) {
+        // HeteroConv layer l: one job per live destination node (hgnn_c2.py:150-166)
+        int j0 = (int)(jobs.size() / JOB_INTS); double fl = 0;
+        const bool mlp_live = has_mlp && p.live[l][d.mlp_type];
+        for (int t = 0; t < NT; ++t) {
+            if (!p.live[l][t]) continue;
+            const bool mlp = has_mlp && t == d.mlp_type;
+            for (int i = 0; i < d.type_nodes[t]; ++i) {
+                const int n = p.type_base[t] + i;
+                std::vector<TermDef> tds;
+                tds.push_back({pack_root[0][l * NT + t], NCT, 0, Hd, 0, {one(BUF_X + l, n)}});
+                for (int r = 0; r < NR; ++r) {
+                    if (p.rel_dst[r] != t || in_src[r][i].empty()) continue;
+                    TermDef td{pack_rel[0][l * NR + r], NCT, 0, Hd, 0, {}};
+                    for (int j : in_src[r][i]) td.s.push_back(one(BUF_X + l, p.type_base[p.rel_src[r]] + j, -1, scale_of(r, i)));
+                    tds.push_back(td);
+                }
+                fl += NL * tds.size();
+                if (mlp) add_job(BUF_HB + l, i, JF_BIAS, bias_layer[l * NT + t], -1, 0, -1, -1, 0, tds);      // H -> base_transform
+                else add_job(BUF_X + l + 1, n, JF_BIAS | JF_RELU | JF_BITS_OUT | (residual ? JF_RES : 0), bias_layer[l * NT + t], BUF_X + l, n, BUF_MASK + l, -1, 0, tds);
+            }
+        }
+        alg_fwd += fl; exec_fwd += fl;
+        launch(p.fwd, j0, "layer_fwd" + std::to_string(l), fl, 2.0 * p.NN * Hd * es);
+        if (mlp_live) {   // base_transform: Y = W2 relu(W1 H + b1) + b2, X <- Y + X    (hgnn_c2.py:117-121,156,161-166)
+            j0 = (int)(jobs.size() / JOB_INTS);
+            for (int u = 0; u < p.n_mlp; ++u)
+                add_job(BUF_T1 + l, u, JF_BIAS | JF_RELU, bias_mlp[0], -1, 0, -1, -1, 0, {TermDef{pack_mlp[0][0], NCT, 0, Hd, 0, {one(BUF_HB + l, u)}}});
+            launch(p.fwd, j0, "mlp1_fwd" + std::to_string(l), NL * p.n_mlp, 2.0 * p.n_mlp * Hd * es);
+            j0 = (int)(jobs.size() / JOB_INTS);
+            for (int u = 0; u < p.n_mlp; ++u) {
+                const int n = p.type_base[d.mlp_type] + u;
+                add_job(BUF_X + l + 1, n, JF_BIAS | (residual ? JF_RES : 0), bias_mlp[1], BUF_X + l, n, -1, -1, 0, {TermDef{pack_mlp[0][1], NCT, 0, Hd, 0, {one(BUF_T1 + l, u)}}});
+            }
+            launch(p.fwd, j0, "mlp2_fwd" + std::to_string(l), NL * p.n_mlp, 3.0 * p.n_mlp * Hd * es);
+            alg_fwd += 2 * NL * p.n_mlp; exec_fwd += 2 * NL * p.n_mlp;
+        }
+    }
+    p.ks_dec_fwd = stat("dec_fwd", MSHGNN_BOUND_HBM, 2.0 * n_out * d.out_channels * Hd, n_out * (double)Hd * es);
+    p.ks_dec_bwd = stat("dec_bwd", MSHGNN_BOUND_HBM, 4.0 * n_out * d.out_channels * Hd, 2.0 * n_out * (double)Hd * es);
+    alg_fwd += 2.0 * n_out * d.out_channels * Hd; exec_fwd += 2.0 * n_out * d.out_channels * Hd;
+    alg_bwd += 4.0 * n_out * d.out_channels * Hd; exec_bwd += 4.0 * n_out * d.out_channels * Hd;
+    // dH of node n in layer l as a staging source: relu types = dX_{l+1}[n] . relu bits of layer l; base_transform type = the dH stash
+    auto dh_src = [&](int l, int n, float scale = 1.0f) {
+        const int t = p.node_type[n];
+        if (has_mlp && t == d.mlp_type) return one(BUF_DH + l, n, -1, scale);
+        return one(BUF_DX + l + 1, n, BUF_MASK + l, scale); };
+    for (int l = L - 1; l >= 0; --l) {
+        const bool mlp_live = has_mlp && p.live[l][d.mlp_type];
+        if (mlp_live) {   // dT1 = dY W2 ; dU = dT1 . (T1 > 0) ; dH = dU W1
+            int j0 = (int)(jobs.size() / JOB_INTS);
+            for (int u = 0; u < p.n_mlp; ++u)
+                add_job(BUF_DU + l, u, JF_GATE_POS, 0, -1, 0, -1, BUF_T1 + l, u, {TermDef{pack_mlp[1][1], NCT, 0, Hd, 0, {one(BUF_DX + l + 1, p.type_base[d.mlp_type] + u)}}});
+            launch(p.bwd, j0, "mlp2_bwd" + std::to_string(l), NL * p.n_mlp, 3.0 * p.n_mlp * Hd * es);
+            j0 = (int)(jobs.size() / JOB_INTS);
+            for (int u = 0; u < p.n_mlp; ++u)
+                add_job(BUF_DH + l, p.type_base[d.mlp_type] + u, 0, 0, -1, 0, -1, -1, 0, {TermDef{pack_mlp[1][0], NCT, 0, Hd, 0, {one(BUF_DU + l, u)}}});
+            launch(p.bwd, j0, "mlp1_bwd" + std::to_string(l), NL * p.n_mlp, 2.0 * p.n_mlp * Hd * es);
+            alg_bwd += 2 * NL * p.n_mlp; exec_bwd += 2 * NL * p.n_mlp;
+        }
+        // dX_l[j] = (residual) + dH_j W_rootsum + sum_r W_rel^r-transposed Agg of dH over the out-edges of j; layer 0 also applies relu'(X_0)
+        const int j0 = (int)(jobs.size() / JOB_INTS); double fl = 0;
+        for (int s = 0; s < NT; ++s) {
+            if (!p.need_dx[l][s]) continue;
+            for (int j = 0; j < d.type_nodes[s]; ++j) {
+                const int n = p.type_base[s] + j;
+                std::vector<TermDef> tds;
+                if (p.live[l][s]) tds.push_back({pack_root[1][l * NT + s], NCT, 0, Hd, 0, {dh_src(l, n)}});
+                for (int r = 0; r < NR; ++r) {
+                    if (p.rel_src[r] != s || !p.live[l][p.rel_dst[r]] || out_dst[r][j].empty()) continue;
+                    TermDef td{pack_rel[1][l * NR + r], NCT, 0, Hd, 0, {}};
+                    for (int i : out_dst[r][j]) td.s.push_back(dh_src(l, p.type_base[p.rel_dst[r]] + i, scale_of(r, i)));
+                    tds.push_back(td);
+                }
+                fl += NL * tds.size();
+                const bool res = residual && p.live[l][s];
+                add_job(BUF_DX + l, n, (res ? JF_RES : 0) | (l == 0 ? JF_GATE_BITS : 0), 0, BUF_DX + l + 1, n, -1, GBUF_MASK0, n, tds);
+            }
+        }
+        alg_bwd += fl; exec_bwd += fl;
+        launch(p.bwd, j0, "layer_bwd" + std::to_string(l), fl, 3.0 * p.NN * Hd * es);
+    }
+
+    // ---- weight-gradient targets / items / units / finalize ops -----------------------------------------------------------
+    std::vector<int32_t> units, items, fins;
+    struct Tgt { int rows, K; std::vector<std::array<int, 6>> items; bool bias; int unit0 = 0, chunks = 0; };     // item: p_buf p_node p_mask kind src0 nsrc
+    std::vector<Tgt> tgts;
+    auto new_item = [&](Tgt& g, std::array<int, 4> psrc, int kind, const std::vector<std::array<int, 4>>& qs) {
+        const int s0 = (int)(srcs.size() / SRC_INTS);
+        for (auto& s : qs) srcs.insert(srcs.end(), {s[0], s[1], s[2], s[3]});
+        g.items.push_back({psrc[0], psrc[1], psrc[2], kind, s0, (int)qs.size()}); };
+    std::vector<int> tgt_root((size_t)L * NT, -1), tgt_rel((size_t)L * NR, -1), tgt_enc(NT, -1);
+    int tgt_mlp[2] = {-1, -1};
+    double gw_fl = 0;
+    for (int l = 0; l < L; ++l) {
+        for (int t = 0; t < NT; ++t) {
+            if (!p.live[l][t]) continue;
+            Tgt g{Hd, Hd, {}, true};
+            for (int i = 0; i < d.type_nodes[t]; ++i) { const int n = p.type_base[t] + i; new_item(g, dh_src(l, n), 0, {one(BUF_X + l, n)}); gw_fl += NL; }
+            tgt_root[l * NT + t] = (int)tgts.size(); tgts.push_back(g);
+        }
+        for (int r = 0; r < NR; ++r) {
+            if (pack_rel[0][l * NR + r] < 0) continue;
+            Tgt g{Hd, Hd, {}, false};
+            const int t = p.rel_dst[r];
+            for (int i = 0; i < d.type_nodes[t]; ++i) {
+                if (in_src[r][i].empty()) continue;
+                std::vector<std::array<int, 4>> qs;
+                for (int j : in_src[r][i]) qs.push_back(one(BUF_X + l, p.type_base[p.rel_src[r]] + j, -1, scale_of(r, i)));
+                new_item(g, dh_src(l, p.type_base[t] + i), 0, qs); gw_fl += NL;
+            }
+            tgt_rel[l * NR + r] = (int)tgts.size(); tgts.push_back(g);
+        }
+    }
+    if (has_mlp) {
+        Tgt g1{Hd, Hd, {}, true}, g2{Hd, Hd, {}, true};
+        for (int l = 0; l < L; ++l) {
+            if (!p.live[l][d.mlp_type]) continue;
+            for (int u = 0; u < p.n_mlp; ++u) {
+                new_item(g1, one(BUF_DU + l, u), 0, {one(BUF_HB + l, u)});
+                new_item(g2, one(BUF_DX + l + 1, p.type_base[d.mlp_type] + u), 0, {one(BUF_T1 + l, u)});
+                gw_fl += 2 * NL;
+            }
+        }
+        if (!g1.items.empty()) { tgt_mlp[0] = (int)tgts.size(); tgts.push_back(g1); tgt_mlp[1] = (int)tgts.size(); tgts.push_back(g2); }
+    }
+    for (int t = 0; t < NT; ++t) {
+        if (!p.need_dx[0][t]) continue;
+        Tgt g{Hd, d.type_width[t], {}, true};
+        for (int i = 0; i < d.type_nodes[t]; ++i) {
+            new_item(g, one(BUF_DX + 0, p.type_base[t] + i), 1, {std::array<int, 4>{t, i, p.sign_off[t] + i * p.enc_nkc[t] * TW, 0}});
+            gw_fl += 2.0 * Hd * d.type_width[t];
+        }
+        tgt_enc[t] = (int)tgts.size(); tgts.push_back(g);
+    }
+    alg_bwd += gw_fl; exec_bwd += gw_fl;
+    // units: for every target tile (ot, kt) one unit per chunk of <= G_ITEMS_PER_UNIT items; the units of one tile are consecutive
+    for (Tgt& g : tgts) {
+        g.unit0 = (int)(units.size() / UNIT_INTS);
+        const int i0 = (int)(items.size() / GITEM_INTS);
+        for (auto& it : g.items) items.insert(items.end(), {it[0], it[1], it[2], it[3], it[4], it[5], 0, 0});
+        const int n = (int)g.items.size();
+        g.chunks = (n + G_ITEMS_PER_UNIT - 1) / G_ITEMS_PER_UNIT;
+        const int nkt = (g.K + TW - 1) / TW;
+        for (int ot = 0; ot < g.rows / TW; ++ot)
+            for (int kt = 0; kt < nkt; ++kt)
+                for (int c = 0; c < g.chunks; ++c)
+                    units.insert(units.end(), {i0 + c * G_ITEMS_PER_UNIT, i0 + std::min(n, (c + 1) * G_ITEMS_PER_UNIT), ot * TW, kt * TW, std::min(TW, g.K - kt * TW),
+                                               (g.bias && kt == 0) ? 1 : 0, 0, 0});
+    }
+    p.n_units = (int)(units.size() / UNIT_INTS);
+    p.n_parts = std::max(1, std::min(16, 1536 / std::max(1, p.n_units)));
+    auto add_fin = [&](int64_t dst, int rows, int cols, int ld, int kind, int unit0, int nunits, int row0) {
+        fins.insert(fins.end(), {(int32_t)(dst & 0xffffffff), (int32_t)(dst >> 32), rows, cols, ld, kind, unit0, nunits, row0, 0, 0, 0}); };
+    auto fin_matrix = [&](int64_t dst, int tg, int K) {      // one op per 128x128 tile of the destination matrix [Hd x K]
+        const int nkt = (K + TW - 1) / TW;
+        for (int ot = 0; ot < NCT; ++ot)
+            for (int kt = 0; kt < nkt; ++kt) {
+                const int cols = std::min(TW, K - kt * TW);
+                if (tg < 0) add_fin(dst + (int64_t)ot * TW * K + kt * TW, TW, cols, K, FIN_ZERO, 0, 0, 0);
+                else add_fin(dst + (int64_t)ot * TW * K + kt * TW, TW, cols, K, FIN_MATRIX, tgts[tg].unit0 + (ot * nkt + kt) * tgts[tg].chunks, tgts[tg].chunks, 0);
+            } };
+    auto fin_bias = [&](int64_t dst, int tg, int K) {        // bias sums ride in the slabs of the kt == 0 units
+        const int nkt = (K + TW - 1) / TW;
+        for (int ot = 0; ot < NCT; ++ot) {
+            if (tg < 0) add_fin(dst + ot * TW, 1, TW, TW, FIN_ZERO, 0, 0, 0);
+            else add_fin(dst + ot * TW, 1, TW, TW, FIN_BIAS, tgts[tg].unit0 + (ot * nkt) * tgts[tg].chunks, tgts[tg].chunks, 0);
+        } };
+    for (int t = 0; t < NT; ++t) { fin_matrix(p.off_enc_w[t], tgt_enc[t], d.type_width[t]); fin_bias(p.off_enc_b[t], tgt_enc[t], d.type_width[t]); }
+    for (int l = 0; l < L; ++l)
+        for (int r = 0; r < NR; ++r) {
+            const int tr = tgt_rel[l * NR + r], to = tgt_root[l * NT + p.rel_dst[r]];
+            fin_matrix(p.off_rel_w[l * NR + r], tr, Hd); fin_bias(p.off_rel_b[l * NR + r], to, Hd); fin_matrix(p.off_root_w[l * NR + r], to, Hd);
+        }
+    if (has_mlp) for (int k = 0; k < 2; ++k) { fin_matrix(d.off_mlp[2 * k], tgt_mlp[k], Hd); fin_bias(d.off_mlp[2 * k + 1], tgt_mlp[k], Hd); }
+    for (int dd = 0; dd < d.out_channels; ++dd)      // decoder partials live in their own slabs ([8][Hd] + bias[8] + loss): one op per 128-column piece
+        for (int cg = 0; cg < Hd; cg += TW) add_fin(d.off_dec_w + (int64_t)dd * Hd + cg, 1, TW, TW, FIN_DEC_W, 0, 0, dd * Hd + cg);
+    add_fin(d.off_dec_b, 1, d.out_channels, d.out_channels, FIN_DEC_B, 0, 0, 8 * Hd);
+    {   // alignment gaps of the flat buffer are zeroed, so grad_params really is fully overwritten
+        std::vector<std::pair<int64_t, int64_t>> spans;
+        for (int t = 0; t < NT; ++t) { spans.push_back({p.off_enc_w[t], (int64_t)Hd * d.type_width[t]}); spans.push_back({p.off_enc_b[t], Hd}); }
+        for (int i = 0; i < L * NR; ++i) { spans.push_back({p.off_rel_w[i], (int64_t)Hd * Hd}); spans.push_back({p.off_rel_b[i], Hd}); spans.push_back({p.off_root_w[i], (int64_t)Hd * Hd}); }
+        if (has_mlp) for (int k = 0; k < 2; ++k) { spans.push_back({d.off_mlp[2 * k], (int64_t)Hd * Hd}); spans.push_back({d.off_mlp[2 * k + 1], Hd}); }
+        spans.push_back({d.off_dec_w, (int64_t)d.out_channels * Hd}); spans.push_back({d.off_dec_b, d.out_channels});
+        std::sort(spans.begin(), spans.end());
+        int64_t pos = 0;
+        for (auto& sp : spans) {
+            if (sp.first > pos && sp.first - pos < 4096) add_fin(pos, 1, (int)(sp.first - pos), (int)(sp.first - pos), FIN_ZERO, 0, 0, 0);
+            pos = std::max(pos, sp.first + sp.second);
+        }
+        if (d.n_flat > pos && d.n_flat - pos < 4096) add_fin(pos, 1, (int)(d.n_flat - pos), (int)(d.n_flat - pos), FIN_ZERO, 0, 0, 0);
+    }
+    p.n_fin = (int)(fins.size() / GFIN_INTS);
+    p.ks_gradw = stat("gradw", MSHGNN_BOUND_MFMA, gw_fl, bytes_in + (2.0 * L + 1) * p.NN * Hd * es);
+    p.ks_fin = stat("finalize", MSHGNN_BOUND_HBM, 0, 0);
+
+    std::vector<int32_t>& T = p.tables;
+    p.job_off = 0; T.insert(T.end(), jobs.begin(), jobs.end());
+    p.term_off = (int)T.size(); T.insert(T.end(), terms.begin(), terms.end());
+    p.src_off = (int)T.size(); T.insert(T.end(), srcs.begin(), srcs.end());
+    p.unit_off = (int)T.size(); T.insert(T.end(), units.begin(), units.end());
+    p.item_off = (int)T.size(); T.insert(T.end(), items.begin(), items.end());
+    p.fin_off = (int)T.size(); T.insert(T.end(), fins.begin(), fins.end());
+
+    p.info.rows_per_tile = 64; p.info.total_nodes = p.NN; p.info.lds_bytes = 4 * 4096 * p.planes;
+    p.info.flops_fwd = alg_fwd; p.info.flops_bwd = alg_bwd; p.info.flops_exec_fwd = exec_fwd; p.info.flops_exec_bwd = exec_bwd;
+    p.info.bytes_in = bytes_in; p.info.n_gradw_workgroups = p.n_units * p.n_parts;
+    p.info.n_launches_fwd = 2 + (int)p.fwd.size(); p.info.n_launches_bwd = 3 + (int)p.bwd.size();
+    p.info.kernel_sets = 4;      // bit 2: generic-width engine
+    p.info.grad_split = -1;
+    return true;
+}
+
+inline void layout_gen_workspace(const GenPlan& p, int64_t B, int training, mshgnn_ws_layout* o) {
+    std::memset(o, 0, sizeof(*o));
+    size_t off = 0;
+    const size_t act = (size_t)B * p.NN * p.Hd * p.esize * p.planes, mlp = (size_t)B * std::max(1, p.n_mlp) * p.Hd * p.esize * p.planes;
+    const size_t maskb = (size_t)((B + 15) / 16 * 16) * p.NN * (p.Hd / 32) * 4;      // one byte per (node, window, 8 features)
+    auto take = [&](size_t bytes) { size_t r = off; off = align_up(off + bytes, 256); return r; };
+    for (int l = 0; l <= p.L; ++l) o->x[l] = take(act);
+    for (int l = 0; l < p.L; ++l) { o->mask[l] = take(maskb); o->hb[l] = take(mlp); o->t1[l] = take(mlp); }
+    o->dd[0] = take(maskb);
+    if (training) {
+        for (int l = 0; l <= p.L; ++l) o->dx[l] = take(act);
+        for (int l = 0; l < p.L; ++l) { o->dh[l] = take(act); o->du[l] = take(mlp); }
+        o->slabs = take((size_t)p.n_units * p.n_parts * SLAB_FLOATS * 4);
+        o->dec_slabs = take((size_t)NWG_DEC * (8 * p.Hd + 16) * 4);
+    }
+    o->wpack = take(p.packs.size() * (size_t)TW * TW * p.esize * p.planes);
+    o->bias = take(p.biases.size() * (size_t)TW * 4);
+    o->loss = take(64);
+    o->total = off;
+}
+
+}  // namespace gen
+}  // namespace mshgnn

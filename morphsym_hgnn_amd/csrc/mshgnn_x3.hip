@@ -773,6 +773,12 @@ __global__ __launch_bounds__(256, GWX3_WPS) void k_gradw_x3(GradwArgs a) {
 // ------------------------------------------------------------------------------------------------------
 // launch sequences (mirrors of forward_impl / backward_impl in mshgnn.hip)
 // ------------------------------------------------------------------------------------------------------
+int x3_launch_prep(const PrepArgs& a, hipStream_t st) {
+    const int64_t total = (int64_t)a.n_packs * (H * H / 8) + (int64_t)a.n_biases * H;
+    hipLaunchKernelGGL(k_prep_x3, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
+    return MSHGNN_OK;
+}
+
 static int x3_lds_stack(const HostPlan& hp) { return 2 * hp.fs_blk * P16::BLK; }
 
 int x3_set_attrs(mshgnn_plan* p) {

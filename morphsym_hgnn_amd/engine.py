@@ -259,6 +259,10 @@ class Engine:
             _check(self.lib, self.lib.mshgnn_plan_create(C.byref(self._holder.desc), C.byref(self._plan)), "mshgnn_plan_create")
         self.info = MshgnnInfo()
         _check(self.lib, self.lib.mshgnn_plan_info(self._plan, C.byref(self.info)), "mshgnn_plan_info")
+        # generic-width engine (hidden != 128, many nodes, ...: kernel_sets bit 2) and how activations are stored: "x3" = rows of
+        # [hi | lo] bf16 halves (the split plan, and MSHGNN_F32 requests served by the generic engine's split arithmetic)
+        self.generic = bool(self.info.kernel_sets & 4)
+        self.storage = "x3" if (dtype == "x3" or (self.generic and dtype == "f32")) else dtype
         self._ws: Dict[Tuple[int, int], torch.Tensor] = {}
         self._tickets: Dict[int, int] = {}
         self._lay: Dict[Tuple[int, int], MshgnnWsLayout] = {}
@@ -487,11 +491,11 @@ class Engine:
         ws = self.workspace(B, True)
         nn_ = self.info.total_nodes
         n = B * nn_ * self.spec.hidden
-        if self.dtype == "x3":
+        if self.storage == "x3":
             halves = ws[off:off + 4 * n].view(torch.bfloat16).view(nn_, B, 2, self.spec.hidden).float()
             return (halves[:, :, 0] + halves[:, :, 1]).permute(1, 0, 2)
-        es = 4 if self.dtype == "f32" else 2
-        return ws[off:off + n * es].view(self.torch_dtype).view(nn_, B, self.spec.hidden).permute(1, 0, 2)
+        es = 4 if self.storage == "f32" else 2
+        return ws[off:off + n * es].view(torch.float32 if self.storage == "f32" else torch.bfloat16).view(nn_, B, self.spec.hidden).permute(1, 0, 2)
 
     def hidden_state(self, B: int, layer: int) -> torch.Tensor:
         """X_layer as [B, NN, hidden]."""

@@ -205,6 +205,15 @@ def solo_s4_com() -> RobotTopology:
     )
 
 
+def synthetic_limbs(num_limbs: int = 32, joints_per_limb: int = 3) -> RobotTopology:
+    """MI-HGNN graph of the synthetic many-limb robot (BASELINE.json configs[4] / SURVEY.md 8(d) config 5): 1 base,
+    num_limbs x joints_per_limb joints, num_limbs feet, the 5 relations of the quadruped graph -- compiled from the
+    generated URDF skeleton by the same parser rules as every other robot (urdf_topology.compile_topology; at 4 limbs
+    it reproduces quadruped_mi() exactly)."""
+    from . import urdf_topology as ut      # (imports this module)
+    return ut.compile_topology(ut.synthetic_limb_robot(num_limbs, joints_per_limb), "mi", name=f"synth{num_limbs}-mi")
+
+
 TOPOLOGIES = {
     "a1-c2": a1_c2,
     "mini_cheetah-c2": mini_cheetah_c2,
@@ -213,6 +222,8 @@ TOPOLOGIES = {
     "solo-k4-com": solo_k4_com,
     "solo-c2-com": solo_c2_com,
     "solo-s4-com": solo_s4_com,
+    "synth32-mi": lambda: synthetic_limbs(32),
+    "synth8-mi": lambda: synthetic_limbs(8),
 }
 
 

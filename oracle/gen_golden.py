@@ -55,6 +55,11 @@ CASES = [
     dict(name="soloc2com_h128_L2_B4", kind="c2_com", topo="solo-c2-com", cfg="solo-c2", hidden=128, layers=2, B=4, regression=True, grf=3),
     dict(name="solos4com_h128_L2_B3", kind="s4_com", topo="solo-s4-com", cfg=None, hidden=128, layers=2, B=3, regression=True, grf=3),
     dict(name="com_hgnn_h128_L2_B3", kind="s4_com", topo="solo-s4-com", cfg=None, hidden=128, layers=2, B=3, regression=True, grf=3, ref="COM_HGNN"),
+    # BASELINE.json configs[4] / SURVEY.md 8(d) config 5: synthetic 32-limb robot, MI-HGNN (hgnn.py:GRF_HGNN) at h=512, 6 layers; plus
+    # other widths (the reference's --hidden_size flag, research/train_regression-grf_msgn.py:95) on the 8-limb and the A1-C2 graphs
+    dict(name="synth32_mi_h512_L6_B2", kind="mi", topo="synth32-mi", cfg=None, hidden=512, layers=6, B=2, regression=True, grf=3),
+    dict(name="synth8_mi_h256_L3_B3", kind="mi", topo="synth8-mi", cfg=None, hidden=256, layers=3, B=3, regression=True, grf=1),
+    dict(name="a1c2_h256_L2_d3_B3", kind="c2", topo="a1-c2", cfg="a1-c2", hidden=256, layers=2, B=3, regression=True, grf=3),
 ]
 
 
@@ -134,8 +139,10 @@ def run_reference(case, topo, spec, cfg_path, params, x_dict, ei, y):
         loss.backward()
         grads = {k: (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p)) for k, p in m.named_parameters()}
         return out.detach(), loss.detach(), grads, n_params
-    w = m.out_channels_per_foot * 4
-    y_pred = torch.reshape(out.squeeze(), (B, w))  # gnnLightning.py:691
+    # gnnLightning.py:691 reshapes to (B, out_channels_per_foot * 4): the wrapper hard-codes a quadruped's 4 feet.  The MSE that follows is
+    # taken over the FLATTENED tensors (:633-639), so for the many-limb synthetic robot the same expression is evaluated on all n_foot rows.
+    w = m.out_channels_per_foot * topo.num_nodes.get("foot", 4)
+    y_pred = torch.reshape(out.squeeze(), (B, w))
     yy = torch.reshape(y, (B, w if case["regression"] else 4))  # gnnLightning.py:694 / :512
     if case["regression"]:
         loss = ((y_pred.flatten() - yy.flatten()) ** 2).mean()

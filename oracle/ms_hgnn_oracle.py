@@ -250,6 +250,8 @@ def wrapper_outputs(cfg: OracleConfig, out_raw: torch.Tensor, y: torch.Tensor, b
     if cfg.kind.endswith("_com"):   # COM wrappers compare the [B, n_base*6] prediction with same-shape labels
         return y.reshape(batch_size, -1), out_raw.reshape(batch_size, -1)
     w = cfg.out_channels_per_foot * 4
+    if out_raw.numel() != batch_size * w:      # not a quadruped (synthetic many-limb robot): the MSE is over the flattened tensors either way
+        w = out_raw.numel() // batch_size
     return y.reshape(batch_size, w if cfg.regression else 4), out_raw.squeeze().reshape(batch_size, w)
 
 

@@ -126,14 +126,15 @@ def node_slices(spec):
 def engine_relu_decisions(e, spec, B):
     """The relu decisions the engine took in its last training forward of batch size B, read back from its workspace:
     {("enc", type) | ("layer", l, type): bool [B*n_type, hidden]} from the relu bytes (one byte per (node, window, 8 features):
-    [NN][4 column slices][ceil(B/16) tiles][4 groups][16 windows], bit j <-> feature 32 slice + 8 group + j) and
+    [NN][hidden/32 column slices][ceil(B/16) tiles][4 groups][16 windows], bit j <-> feature 32 slice + 8 group + j) and
     {("t1", l): bool [B*n_base, hidden]} from the stashed base_transform activation T1 (its backward masks with T1 > 0)."""
     lay, ws = e.layout(B, True), e.workspace(B, True)
     nn_, h, tiles = e.info.total_nodes, spec.hidden, (B + 15) // 16
     sl = node_slices(spec)
 
     def from_bytes(off):
-        raw = ws[off:off + nn_ * 4 * tiles * 64].view(nn_, 4, tiles, 4, 16).cpu()
+        ns = h // 32                                                                    # column slices of 32 features
+        raw = ws[off:off + nn_ * ns * tiles * 64].view(nn_, ns, tiles, 4, 16).cpu()
         bits = (raw.unsqueeze(-1) >> torch.arange(8, dtype=torch.uint8)) & 1            # [NN, slice, tile, group, win, bit]
         return bits.permute(2, 4, 0, 1, 3, 5).reshape(tiles * 16, nn_, h)[:B].bool()  # [B, NN, 128]
 
@@ -149,10 +150,10 @@ def engine_relu_decisions(e, spec, B):
         if spec.has_base_transform and "base" in spec.live_types(l):
             nb = spec.num_nodes["base"]
             n = nb * B * h
-            if e.dtype == "x3":
+            if e.storage == "x3":
                 t1 = ws[lay.t1[l]:lay.t1[l] + 4 * n].view(torch.bfloat16).view(nb, B, 2, h)[:, :, 0]      # rows of [hi | lo]: hi carries the sign
             else:
-                t1 = ws[lay.t1[l]:lay.t1[l] + n * (4 if e.dtype == "f32" else 2)].view(e.torch_dtype).view(nb, B, h)
+                t1 = ws[lay.t1[l]:lay.t1[l] + n * (4 if e.storage == "f32" else 2)].view(torch.float32 if e.storage == "f32" else torch.bfloat16).view(nb, B, h)
             out[("t1", l)] = (t1.permute(1, 0, 2).reshape(-1, h).float() > 0).cpu()
     return out
 

@@ -1,0 +1,97 @@
+"""GPU parity tests of the generic-width engine (mshgnn_gen.hip): any hidden multiple of 128, any node count / in-degree -- BASELINE
+configs[4] (synthetic 32-limb robot, h=512, 6 layers) and the reference's --hidden_size flag (train_regression-grf_msgn.py:95).
+Golden vectors come from the reference's own model files (oracle/gen_golden.py); tolerance 1e-4 relative as for every parity plan."""
+import pytest
+import torch
+
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+WIDE_CASES = ["synth32_mi_h512_L6_B2", "synth8_mi_h256_L3_B3", "a1c2_h256_L2_d3_B3"]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "x3"])
+@pytest.mark.parametrize("name", WIDE_CASES)
+def test_wide_models_match_oracle_and_golden(name, dtype):
+    """hidden != 128 / many nodes: plan creation picks the generic engine by itself; a parity request (f32 or x3) runs its split-bf16
+    arithmetic."""
+    from morphsym_hgnn_amd import engine as eng
+    assert torch.cuda.is_available()
+    case, spec, fx, x_dict, y, params, ei = helpers.load_case(name)
+    assert eng.compile_plan_host(spec, dtype).kernel_sets == 4
+    errs, out, loss, grads = helpers.run_engine_case(spec, x_dict, y, params, ei, case["B"], dtype=dtype)
+    bad = {k: v for k, v in errs.items() if v > RTOL}
+    assert not bad, f"{name}: stages above {RTOL}: {bad}"
+    helpers.check_against_fixture(fx, out, loss, grads, rtol=RTOL, what=name)
+
+
+@pytest.mark.parametrize("name", [c for c in helpers.GOLDEN_CASES if "_h128_" in c])
+def test_every_h128_golden_case_through_the_generic_engine(name, monkeypatch):
+    """MSHGNN_ENGINE=generic forces the generic engine for topologies the LDS-resident kernels also cover: every model family (C2, K4,
+    MI, the Solo COM variants; regression and classification; base_transform, residual, mean aggregation) at 1e-4."""
+    monkeypatch.setenv("MSHGNN_ENGINE", "generic")
+    case, spec, fx, x_dict, y, params, ei = helpers.load_case(name)
+    errs, out, loss, grads = helpers.run_engine_case(spec, x_dict, y, params, ei, case["B"], dtype="x3")
+    bad = {k: v for k, v in errs.items() if v > RTOL}
+    assert not bad, f"{name}: stages above {RTOL}: {bad}"
+    helpers.check_against_fixture(fx, out, loss if spec.regression else None, grads, rtol=RTOL, what=name)
+
+
+def test_mean_aggregation_with_in_degree_above_one():
+    """'mean' relations whose destination nodes have several in-edges (rejected by the LDS-resident kernels; every reference topology has
+    degree 1 there): the generic engine scales the aggregated row by 1 / in-degree, as PyG's GraphConv(aggr='mean') does."""
+    from morphsym_hgnn_amd import engine as eng, synth, topology
+    from morphsym_hgnn_amd.spec import ModelSpec
+    topo = topology.mini_cheetah_k4()
+    rel = dict(topo.relations)
+    rel[("base", "gt", "base")] = [[0, 1], [2, 1], [3, 1], [1, 0], [2, 0], [0, 3], [1, 2]]      # in-degrees 2, 3, 1, 1
+    topo.relations = [(k, rel[k]) for k, _ in topo.relations]
+    group, _ = helpers.load_group("mini_cheetah-k4")
+    spec = ModelSpec(kind="k4", topology=topo, hidden=128, num_layers=3, widths=synth.feature_widths("k4", True), regression=True, group=group)
+    B = 5
+    x_dict, y = synth.make_windows(8, B, spec.num_nodes, spec.widths, 4)
+    params = synth.make_params(8, spec.param_shapes())
+    assert eng.compile_plan_host(spec, "x3").kernel_sets == 4      # the specialised plan rejects it, the generic one takes it
+    errs, *_ = helpers.run_engine_case(spec, x_dict, y, params, topo.edge_index_dict(B), B, dtype="x3")
+    bad = {k: v for k, v in errs.items() if v > RTOL}
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("name", ["synth8_mi_h256_L3_B3", "a1c2_h256_L2_d3_B3"])
+def test_generic_bf16_arithmetic_is_within_bf16_distance_of_the_oracle(name):
+    """The throughput arithmetic of the generic engine (bf16 storage / operands, fp32 accumulate) against the oracle evaluated with the
+    engine's relu decisions: every stage within 3e-2 (max-abs relative; bf16 has 8 mantissa bits and the model is 3 layers deep), every
+    decision that differs from the exact one within 3e-2 of zero; inference == training forward."""
+    from morphsym_hgnn_amd import engine as eng
+    case, spec, fx, x_dict, y, params, ei = helpers.load_case(name)
+    B = case["B"]
+    errs, out, *_ = helpers.run_engine_case(spec, x_dict, y, params, ei, B, dtype="bf16", decision_tol=3e-2)
+    bad = {k: v for k, v in errs.items() if v > 3e-2}
+    assert not bad, bad
+    e = eng.Engine(spec, "bf16")
+    assert e.generic
+    out_inf = e.forward(e.cast_inputs(x_dict), eng.flatten_params(spec, params, e.device), B, training=False)
+    assert torch.equal(out_inf.cpu(), out)
+
+
+def test_generic_ragged_batches_and_step_equals_two_call_sequence():
+    from morphsym_hgnn_amd import engine as eng, synth
+    case, spec, *_ = helpers.load_case("synth8_mi_h256_L3_B3")
+    params = synth.make_params(5, spec.param_shapes())
+    for B in (1, 17, 65, 130):
+        x_dict, y = synth.make_windows(300 + B, B, spec.num_nodes, spec.widths, spec.num_nodes["foot"])
+        errs, *_ = helpers.run_engine_case(spec, x_dict, y, params, spec.topology.edge_index_dict(B), B, dtype="x3")
+        bad = {k: v for k, v in errs.items() if v > RTOL}
+        assert not bad, (B, bad)
+    e = eng.Engine(spec, "x3")
+    B = 130
+    x_dict, y = synth.make_windows(9, B, spec.num_nodes, spec.widths, spec.num_nodes["foot"])
+    xs = e.cast_inputs(x_dict); yd = y.reshape(-1).to(e.device, torch.float32)
+    flat = eng.flatten_params(spec, params, e.device)
+    out_a = e.forward(xs, flat, B).clone()
+    loss_a, g_a = e.backward_mse(xs, flat, out_a, yd, B)
+    loss_a, g_a = loss_a.clone(), g_a.clone()
+    out_b, loss_b, g_b = e.step_mse(xs, flat, yd, B)
+    torch.cuda.synchronize()
+    assert torch.equal(out_a, out_b) and torch.equal(g_a, g_b) and torch.equal(loss_a, loss_b)      # deterministic: fixed-order slab sums

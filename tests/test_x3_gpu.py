@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-4
 
 # every golden topology whose LDS tile fits the split plan (2 x (nodes + base_transform nodes) <= 40 blocks): MiniCheetah-K4 (48) does not
-X3_CASES = [c for c in helpers.GOLDEN_CASES if not c.startswith("mck4")]
+X3_CASES = [c for c in helpers.GOLDEN_CASES if not c.startswith("mck4") and "_h128_" in c]
 
 
 @pytest.mark.parametrize("name", X3_CASES)
@@ -22,11 +22,13 @@ def test_x3_plan_matches_oracle_and_golden(name):
     helpers.check_against_fixture(fx, out, loss if spec.regression else None, grads, rtol=RTOL, what=name)
 
 
-def test_x3_plan_is_rejected_where_the_tile_does_not_fit():
+def test_x3_request_falls_to_the_generic_engine_where_the_tile_does_not_fit():
+    """MiniCheetah-K4 (24 LDS blocks x 2 halves) does not fit the fused split kernels: the same request runs on the generic-width
+    engine's split arithmetic (tests/test_generic_gpu.py checks its parity)."""
     from morphsym_hgnn_amd import engine as eng
     case, spec, *_ = helpers.load_case("mck4_cls_h128_L2_B3")
-    with pytest.raises(eng.MshgnnError, match="not supported"):
-        eng.Engine(spec, "x3")
+    e = eng.Engine(spec, "x3")
+    assert e.generic and e.storage == "x3"
 
 
 @pytest.mark.parametrize("B", [1, 15, 16, 17, 33, 65, 333])
