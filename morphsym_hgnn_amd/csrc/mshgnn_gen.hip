@@ -89,9 +89,8 @@ __device__ __forceinline__ void raw8(const GArgs& a, int t, int node, int w, int
 // ------------------------------------------------------------------------------------------------------
 // k_gstep
 // ------------------------------------------------------------------------------------------------------
-template <bool SPLIT> __global__ __launch_bounds__(256) void k_gstep(GArgs a) {
+template <bool SPLIT, int MB> __global__ __launch_bounds__(256) void k_gstep(GArgs a) {      // MB: 16-window row blocks per workgroup
     using P = P16;
-    constexpr int MB = 4;                               // 16-window row blocks per workgroup
     extern __shared__ __attribute__((aligned(16))) char smem[];      // blocks [0, MB): (hi) A tile; [MB, 2 MB): lo halves (split plan)
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ct = blockIdx.x % a.NCT, tile = (blockIdx.x / a.NCT) % a.tiles;
@@ -115,23 +114,27 @@ template <bool SPLIT> __global__ __launch_bounds__(256) void k_gstep(GArgs a) {
         const int nkc = term[T_NKC], kind = term[T_KIND], n_src = term[T_NSRC], F = term[T_WIDTH];
         const int* src = a.srcs + (size_t)term[T_SRC0] * SRC_INTS;
         for (int kc = 0; kc < nkc; ++kc) {
-            float s[MB][8];
-#pragma unroll
-            for (int m = 0; m < MB; ++m) {
-                const int w = min(w0 + m * P::ROWS + r0, B - 1);      // rows past the batch re-read the last window; they are never stored
-                if (kind == 0) gather8<SPLIT>(a, src, n_src, w, kc * TW + c * 8, s[m]);
-                else raw8<SPLIT>(a, src[S_BUF], src[S_NODE], w, kc * TW + c * 8, F, a.signs + term[T_SIGN] + kc * TW + c * 8, s[m]);
-            }
             __syncthreads();   // the previous chunk's MFMAs are done reading LDS
 #pragma unroll
-            for (int m = 0; m < MB; ++m) {
-                const f32x4 lo4 = f32x4{s[m][0], s[m][1], s[m][2], s[m][3]}, hi4 = f32x4{s[m][4], s[m][5], s[m][6], s[m][7]};
-                if constexpr (SPLIT) {
-                    u32x4 hi, lo;
-                    split_oct(lo4, hi4, hi, lo);
-                    *reinterpret_cast<u32x4*>(smem + lds_chunk<T16>(m, r0, c)) = hi;
-                    *reinterpret_cast<u32x4*>(smem + lds_chunk<T16>(MB + m, r0, c)) = lo;
-                } else *reinterpret_cast<u32x4*>(smem + lds_chunk<T16>(m, r0, c)) = pack_oct(lo4, hi4);
+            for (int m0 = 0; m0 < MB; m0 += 4) {      // four row blocks at a time: their loads are in flight together
+                float s[4][8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int w = min(w0 + (m0 + i) * P::ROWS + r0, B - 1);      // rows past the batch re-read the last window; they are never stored
+                    if (kind == 0) gather8<SPLIT>(a, src, n_src, w, kc * TW + c * 8, s[i]);
+                    else raw8<SPLIT>(a, src[S_BUF], src[S_NODE], w, kc * TW + c * 8, F, a.signs + term[T_SIGN] + kc * TW + c * 8, s[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int m = m0 + i;
+                    const f32x4 lo4 = f32x4{s[i][0], s[i][1], s[i][2], s[i][3]}, hi4 = f32x4{s[i][4], s[i][5], s[i][6], s[i][7]};
+                    if constexpr (SPLIT) {
+                        u32x4 hi, lo;
+                        split_oct(lo4, hi4, hi, lo);
+                        *reinterpret_cast<u32x4*>(smem + lds_chunk<T16>(m, r0, c)) = hi;
+                        *reinterpret_cast<u32x4*>(smem + lds_chunk<T16>(MB + m, r0, c)) = lo;
+                    } else *reinterpret_cast<u32x4*>(smem + lds_chunk<T16>(m, r0, c)) = pack_oct(lo4, hi4);
+                }
             }
             __syncthreads();
             const int pack = term[T_PACK] + kc * a.NCT + ct;
@@ -507,7 +510,9 @@ int gen_create(mshgnn_plan* p, const mshgnn_desc* desc) {
         (rc = up((void**)&g->d_packs, gp.packs.data(), gp.packs.size() * sizeof(PackDesc))) != 0 ||
         (rc = up((void**)&g->d_biases, gp.biases.data(), gp.biases.size() * sizeof(BiasDesc))) != 0) return rc;
     const int dec_lds = 16 * 8 * TW * 4;
-    if ((rc = set_lds_attr(k_gdec_bwd<false>, dec_lds)) || (rc = set_lds_attr(k_gdec_bwd<true>, dec_lds))) return rc;
+    if ((rc = set_lds_attr(k_gdec_bwd<false>, dec_lds)) || (rc = set_lds_attr(k_gdec_bwd<true>, dec_lds)) ||
+        (rc = set_lds_attr(k_gstep<true, 16>, 32 * P16::BLK)) || (rc = set_lds_attr(k_gstep<false, 16>, 16 * P16::BLK)) ||
+        (rc = set_lds_attr(k_gstep<true, 8>, 16 * P16::BLK))) return rc;
     return MSHGNN_OK;
 }
 
@@ -560,13 +565,32 @@ static int g_fill(const mshgnn_plan* p, const mshgnn_ws_layout& lay, const void*
     return MSHGNN_OK;
 }
 
+static int g_tile_blocks(int B) {
+    static const int forced = [] { const char* e = getenv("MSHGNN_GEN_MB"); return e ? atoi(e) : 0; }();      // (kernel experiments)
+    if (forced == 4 || forced == 8 || forced == 16) return forced;
+    // measured (synthetic 32-limb, h=512, B=1024, bf16): layer_fwd 518 / 756 / 1217 us at 4 / 8 / 16 row blocks -- the kernel is bound by the
+    // exposed latency of the staging loads, so more, smaller workgroups win until the staging is software-pipelined
+    (void)B; return 4;
+}
+
 static void g_launch_jobs(const mshgnn_plan* p, const Launch& ln, GArgs a, hipStream_t st) {
     const GenPlan& gp = p->gen->gp;
     a.job0 = ln.job0;
+    // windows per workgroup: a packed weight fragment (8 KB per wave and K chunk, from L2) is reused for every 16-window row block of the tile
+    const int mb = g_tile_blocks(a.B);
+    a.tiles = (a.B + mb * 16 - 1) / (mb * 16);
     const unsigned grid = (unsigned)ln.n_jobs * a.tiles * a.NCT;
+    const int lds = mb * P16::BLK * (gp.split ? 2 : 1);
     ProfScope ps(p, ln.ks, st);
-    if (gp.split) hipLaunchKernelGGL(k_gstep<true>, dim3(grid), dim3(256), 8 * P16::BLK, st, a);
-    else hipLaunchKernelGGL(k_gstep<false>, dim3(grid), dim3(256), 4 * P16::BLK, st, a);
+    if (gp.split) {
+        if (mb == 16) hipLaunchKernelGGL((k_gstep<true, 16>), dim3(grid), dim3(256), lds, st, a);
+        else if (mb == 8) hipLaunchKernelGGL((k_gstep<true, 8>), dim3(grid), dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((k_gstep<true, 4>), dim3(grid), dim3(256), lds, st, a);
+    } else {
+        if (mb == 16) hipLaunchKernelGGL((k_gstep<false, 16>), dim3(grid), dim3(256), lds, st, a);
+        else if (mb == 8) hipLaunchKernelGGL((k_gstep<false, 8>), dim3(grid), dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((k_gstep<false, 4>), dim3(grid), dim3(256), lds, st, a);
+    }
 }
 
 int gen_forward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, float* out, char* ws, int64_t batch,
