@@ -163,7 +163,7 @@ def cpu_baseline(spec, batch, budget_s=20.0, scan=True):
     default_threads = torch.get_num_threads()
     best = (float("inf"), default_threads)
     t_start = time.perf_counter()
-    for n in sorted({8, 16, 32, 64, default_threads}) if scan else [default_threads]:
+    for n in sorted({8, 16, 32, 64, default_threads}) if scan else sorted({1, 2, 4, 8, 16}):
         if n > default_threads or time.perf_counter() - t_start > budget_s / 2:
             continue
         torch.set_num_threads(n)
@@ -267,64 +267,64 @@ class Workload:
 
 
 def parity_error(spec, dtype, device, B=48):
-    """max-abs error / max-abs reference of the output, the loss and every parameter gradient of plan `dtype` against the
-    fp64 oracle on B seeded windows (the GPU tests do this per golden case; this is the in-line evidence for the bench)."""
-    import torch
-    from morphsym_hgnn_amd import engine as eng, synth
-    from oracle import ms_hgnn_oracle as orc
+    """Worst max-abs error / max-abs reference over every hidden state, the output, the loss and every parameter gradient of plan
+    `dtype` against the fp64 oracle on B seeded windows -- the GPU tests' own harness (tests/helpers.run_engine_case: the oracle is
+    evaluated with the engine's relu decisions, each of which must lie within 1e-4 of the exact one's zero crossing)."""
+    from morphsym_hgnn_amd import synth
+    from tests import helpers
     n_y = spec.out_channels * spec.num_nodes[spec.out_type]
     x_dict, y = synth.make_windows(77, B, spec.num_nodes, spec.widths, n_y)
     params = synth.make_params(77, spec.param_shapes())
-    o_out, o_loss, o_grads = orc.step(oracle_cfg(spec), params, x_dict, spec.topology.edge_index_dict(B), y, B)
-    e = eng.Engine(spec, dtype=dtype, device=device)
-    out, loss, g = e.step_mse(e.cast_inputs(x_dict), eng.flatten_params(spec, params, device), y.reshape(-1).to(device, torch.float32), B)
-    torch.cuda.synchronize()
-    worst = float((out.double().cpu().reshape(-1) - o_out.reshape(-1)).abs().max() / o_out.abs().max())
-    worst = max(worst, abs(float(loss) - float(o_loss)) / abs(float(o_loss)))
-    for k, v in eng.unflatten(spec, g.cpu()).items():
-        m = float(o_grads[k].abs().max())
-        if m > 0:
-            worst = max(worst, float((v.double() - o_grads[k]).abs().max()) / m)
-    return worst
+    errs, *_ = helpers.run_engine_case(spec, x_dict, y, params, spec.topology.edge_index_dict(B), B, dtype=dtype, device=str(device))
+    return max(errs.values())
 
 
 def module_surface(spec, B, device, steps, warmup, precision):
-    """The nn.Module surface the reference's Lightning wrappers call (gnnLightning.py:680-722): fp64 x_dict resident on
-    the device -> GRF_HGNN_C2.forward -> MSE -> loss.backward(), parameters as nn.Parameters."""
+    """The nn.Module surface the reference's Lightning wrappers call (gnnLightning.py:680-722): x_dict resident on the device ->
+    GRF_HGNN_C2.forward -> MSE -> loss.backward(), parameters as nn.Parameters.  Two input conventions: fp64 as the reference's datasets
+    produce them (the fp64 -> plan-dtype cast of 59 M elements is then part of every step), and tensors already at the plan's input
+    dtype and pitch (what the on-device window assembly hands over: no cast)."""
     import torch
     from morphsym_hgnn_amd import models, synth
     from morphsym_hgnn_amd.checkpoint import load_into
     prev = torch.get_default_dtype()
     torch.set_default_dtype(torch.float64)      # the reference does (gnnLightning.py:1183)
+    res = {"precision": precision, "what": "GRF_HGNN_C2.forward(x_dict on device, edge_index_dict) + MSE + loss.backward(), nn.Parameter weights"}
     try:
         cfg = os.path.join(ROOT, "morphsym_hgnn_amd", "cfg", "a1-c2.yaml")
         m = models.GRF_HGNN_C2(spec.hidden, spec.num_layers, spec.topology.metadata(), symmetry_mode="MorphSym", group_operator_path=cfg)
         load_into(m, {"state_dict": {"model." + k: v for k, v in synth.make_params(0, spec.param_shapes()).items()}})
         m.set_precision(precision).to(device)
         x, y = make_batch(spec, B, 99)
-        x = {k: v.to(device, torch.float64) for k, v in x.items()}
+        x64 = {k: v.to(device, torch.float64) for k, v in x.items()}
         y = y.to(device, torch.float64).view(B, -1)
         ei = spec.topology.edge_index_dict(B, device=device)
+        with torch.no_grad():
+            m(dict(x64), ei)
+        e = next(iter(m._engines.values()))
+        xplan = dict(zip(e.types, e.cast_inputs(x64)))
 
-        def step():
-            m.zero_grad(set_to_none=True)
-            out = m(dict(x), ei)
-            loss = ((out.flatten() - y.flatten()) ** 2).mean()
-            loss.backward()
-            return loss
+        def run(xin):
+            def step():
+                m.zero_grad(set_to_none=True)
+                out = m(dict(xin), ei)
+                loss = ((out.flatten() - y.flatten()) ** 2).mean()
+                loss.backward()
+            for _ in range(warmup):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / steps
 
-        for _ in range(warmup):
-            step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps
+        dt64, dtp = run(x64), run(xplan)
+        res.update({"ms_per_step": dt64 * 1e3, "value": B / dt64, "inputs": "fp64 on device (reference convention; cast every step)",
+                    "plan_dtype_inputs": {"ms_per_step": dtp * 1e3, "value": B / dtp, "inputs": "already at the plan's input dtype and pitch (no cast)"}})
     finally:
         torch.set_default_dtype(prev)
-    return {"ms_per_step": dt * 1e3, "value": B / dt, "precision": precision,
-            "what": "GRF_HGNN_C2.forward(x_dict fp64 on device, edge_index_dict) + MSE + loss.backward(), nn.Parameter weights"}
+    return res
 
 
 def main():
@@ -445,7 +445,7 @@ def main():
         res["module_surface"] = module_surface(spec, B, device, args.steps, args.warmup, args.dtype)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config != "synth32":
         res["cpu_baseline"] = cpu_baseline(spec, args.cpu_batch)
-        res["cpu_baseline_B32"] = cpu_baseline(spec, 32, budget_s=4.0, scan=False)     # the reference's own CPU-runnable case
+        res["cpu_baseline_B32"] = cpu_baseline(spec, 32, budget_s=6.0, scan=False)     # the reference's own CPU-runnable case
     if rank == 0:
         print(json.dumps(res))
     if dist is not None:

@@ -62,6 +62,70 @@ class _EngineFn(torch.autograd.Function):
         return (gflat, None, None, None, *([None] * len(ctx.xs)))
 
 
+class _EngineFnP(torch.autograd.Function):
+    """The hot path for parameters that already live as views of the engine's flat fp32 buffer (`_MSHGNNBase._flat_params`): nothing
+    is copied on the way in, and backward hands every parameter a VIEW of the fresh flat gradient buffer the C-ABI fills -- no
+    per-parameter cast or copy kernels (the parameters are autograd inputs only so that their .grad gets populated)."""
+
+    @staticmethod
+    def forward(ctx, engine, B, flat, offsets, n_x, *args):
+        xs = args[:n_x]
+        out = engine.forward(xs, flat, B, training=True)
+        ctx.engine, ctx.B, ctx.xs, ctx.flat, ctx.offsets, ctx.n_x = engine, B, xs, flat, offsets, n_x
+        ctx.shapes = [p.shape for p in args[n_x:]]
+        ctx.ticket = engine.stash_ticket(B)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        e = ctx.engine
+        if e.stash_ticket(ctx.B) != ctx.ticket:
+            raise RuntimeError("the activation stash of this forward was overwritten by a later forward of the same "
+                               "batch size on the same engine; call backward before the next forward")
+        gflat = e.backward(ctx.xs, ctx.flat, gout.contiguous().to(torch.float32), ctx.B)      # a fresh buffer per backward: .grad views never alias
+        grads = [gflat[o:o + n].view(shape) for (o, n), shape in zip(ctx.offsets, ctx.shapes)]
+        return (None, None, None, None, None, *([None] * ctx.n_x), *grads)
+
+
+class _EngineFnFast(torch.autograd.Function):
+    """Single-process fast path: like _EngineFnP, but the parameter gradients do not travel through autograd at all -- 50 AccumulateGrad
+    nodes and 50 freshly sliced views per step cost more host time than the whole step takes on the GPU.  The C-ABI writes the flat
+    gradient into a persistent buffer whose per-parameter views are cached; backward assigns them to .grad when the gradients were
+    cleared (zero_grad(set_to_none=True), the first step) and ADDS a fresh gradient in place otherwise (accumulation, or gradients
+    zeroed in place), which is what autograd's accumulation would have produced.  Not used under torch.distributed (DDP needs the
+    per-parameter autograd hooks: _EngineFnP)."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, engine, B, *xs):
+        out = engine.forward(xs, model._flat, B, training=True)
+        ctx.model, ctx.engine, ctx.B, ctx.xs, ctx.flat = model, engine, B, xs, model._flat
+        ctx.ticket = engine.stash_ticket(B)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        e, m = ctx.engine, ctx.model
+        if e.stash_ticket(ctx.B) != ctx.ticket:
+            raise RuntimeError("the activation stash of this forward was overwritten by a later forward of the same "
+                               "batch size on the same engine; call backward before the next forward")
+        g32 = gout.contiguous().to(torch.float32)
+        params = m._param_list
+        if m._gflat is None or m._gflat.device != ctx.flat.device:
+            m._gflat = torch.zeros_like(ctx.flat)
+            m._gviews = [m._gflat[o:o + n].view(p.shape) for (o, n), p in zip(m._spec.param_offsets().values(), params)]
+        if all(p.grad is None for p in params[:2]):
+            e.backward(ctx.xs, ctx.flat, g32, ctx.B, grad_flat=m._gflat)
+            for p, v in zip(params, m._gviews):
+                if p.requires_grad:
+                    p.grad = v
+        else:
+            m._gflat.add_(e.backward(ctx.xs, ctx.flat, g32, ctx.B))
+            for p, v in zip(params, m._gviews):      # (a parameter whose .grad was cleared individually)
+                if p.requires_grad and p.grad is None:
+                    p.grad = v
+        return (None, None, None, None, *([None] * len(ctx.xs)))
+
+
 class _MSHGNNBase(nn.Module):
     kind = "c2"
     num_bases = 2
@@ -78,6 +142,11 @@ class _MSHGNNBase(nn.Module):
         self._engines: Dict[Tuple[str, str], object] = {}
         self._spec: Optional[ModelSpec] = None
         self._flat: Optional[torch.Tensor] = None
+        self._flat_ok = False            # parameters are fp32 views into self._flat (device-resident fast path)
+        self._param_list = None
+        self._gflat = None               # persistent flat gradient + its cached per-parameter views (_EngineFnFast)
+        self._gviews = None
+        self._anchor = None
         self._checked_batches = set()
         self._precision = os.environ.get("MSHGNN_DTYPE", "f32")
         self._group = None
@@ -87,8 +156,53 @@ class _MSHGNNBase(nn.Module):
         state = self.__dict__.copy()
         state["_engines"] = {}
         state["_flat"] = None
+        state["_flat_ok"] = False
+        state["_gflat"] = state["_gviews"] = state["_anchor"] = None
+        state["_param_list"] = None
         state["_checked_batches"] = set()
         return state
+
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        """nn.Module.zero_grad walks the whole module tree (~0.3 ms of host time for these ~80 sub-modules: as long as the GPU step);
+        same semantics over the cached parameter list."""
+        if self._spec is None:
+            return super().zero_grad(set_to_none)
+        for p in self._params_in_flat_order():
+            if p.grad is not None:
+                if set_to_none:
+                    p.grad = None
+                else:
+                    p.grad.detach_().zero_()
+
+    def _apply(self, fn, *args, **kwargs):
+        # .to() / .cuda() / .double() / .float() replace the parameter tensors: the flat-buffer views are re-established by the next forward
+        self._flat_ok = False
+        return super()._apply(fn, *args, **kwargs)
+
+    def _flat_params(self, pdev):
+        """Device-resident fast path: every parameter's storage IS a slice of one flat fp32 buffer in state_dict order (the layout the
+        C-ABI takes), so a forward copies nothing.  Parameters therefore live in fp32 on the device whatever the default dtype is (the
+        engine's master weights are fp32; optimizers update the views in place; load_state_dict copies into them).  A later
+        .to() / .double() un-does this; the next forward re-establishes it."""
+        if self._flat_ok and self._flat is not None and self._flat.device == pdev:
+            return self._flat
+        params = self._params_in_flat_order()
+        flat = torch.zeros(self._spec.flat_size(), dtype=torch.float32, device=pdev)
+        with torch.no_grad():
+            for (o, n), p in zip(self._spec.param_offsets().values(), params):
+                v = flat[o:o + n].view(p.shape)
+                v.copy_(p.detach())
+                p.data = v
+        self._flat, self._flat_ok = flat, True
+        self._gflat = self._gviews = None
+        self._anchor = torch.zeros((), device=pdev, requires_grad=True)
+        return flat
+
+    def _params_in_flat_order(self):
+        if self._param_list is None:
+            sd = dict(self.named_parameters())
+            self._param_list = [sd[k] for k in self._spec.param_offsets().keys()]
+        return self._param_list
 
     # ---- construction helpers ---------------------------------------------------------------------
     def _build_convs(self, mean_rels):
@@ -145,10 +259,6 @@ class _MSHGNNBase(nn.Module):
                          group=self._group, num_timesteps=getattr(self, "num_timesteps", 150),
                          com_dimension=getattr(self, "num_dimensions_per_base", 6) if self.kind == "s4_com" else 6)
 
-    def _named_in_flat_order(self):
-        sd = dict(self.named_parameters())
-        return [sd[k] for k in self._spec.param_offsets().keys()]
-
     def _engine(self, device):
         from .engine import Engine
         key = (self._precision, str(device))
@@ -175,8 +285,11 @@ class _MSHGNNBase(nn.Module):
                 raise RuntimeError(f"parameter layout mismatch: {set(expect) ^ set(have)}")
         spec = self._spec
         B, nn_ = self._num_nodes(x_dict)
+        def _pitch_ok(x, F):     # the reference's width, or rows already at the engine's 16-byte-aligned pitch (on-device window assembly)
+            q = {torch.bfloat16: 8, torch.float32: 4}.get(x.dtype)
+            return x.shape[1] == F or (q is not None and x.shape[1] == (F + q - 1) // q * q)
         for t in self._node_types:
-            if nn_[t] != spec.num_nodes[t] or x_dict[t].shape[1] != spec.widths[t]:
+            if nn_[t] != spec.num_nodes[t] or not _pitch_ok(x_dict[t], spec.widths[t]):
                 raise ValueError(f"x_dict['{t}'] does not match the compiled topology "
                                  f"({nn_[t]} nodes x {x_dict[t].shape[1]} vs {spec.num_nodes[t]} x {spec.widths[t]})")
         if B not in self._checked_batches:   # one host-side check per batch size: B copies of the compiled graph
@@ -196,20 +309,34 @@ class _MSHGNNBase(nn.Module):
         e = self._engine(pdev)
         in_dev, in_dtype = x_dict[self._node_types[0]].device, x_dict[self._node_types[0]].dtype
         xs = e.cast_inputs(x_dict)
-        if self._flat is None or self._flat.device != pdev:
-            self._flat = torch.zeros(spec.flat_size(), dtype=torch.float32, device=pdev)
-        params = self._named_in_flat_order()
+        params = self._params_in_flat_order()
         offsets = list(spec.param_offsets().values())
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
-        if need_grad:
-            flat = _Flatten.apply(spec.flat_size(), pdev, offsets, *params)
-            out = _EngineFn.apply(flat, e, B, True, *xs)
+        if params[0].device.type == "cuda":
+            # parameters on the device: they are (made) views of the flat fp32 buffer -- no copy in, no copy out
+            flat = self._flat_params(pdev)
+            if need_grad:
+                import torch.distributed as dist
+                if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                    out = _EngineFnP.apply(e, B, flat, offsets, len(xs), *xs, *params)      # gradients through autograd: DDP's hooks see them
+                else:
+                    out = _EngineFnFast.apply(self._anchor, self, e, B, *xs)
+            else:
+                with torch.no_grad():
+                    out = e.forward(xs, flat, B, training=False)
         else:
-            with torch.no_grad():
-                views = [self._flat[o:o + n].view(p.shape) for (o, n), p in zip(offsets, params)]
-                torch._foreach_copy_(views, [p.detach() for p in params])
-                out = e.forward(xs, self._flat, B, training=False)
-        out = out.to(device=in_dev, dtype=in_dtype if in_dtype.is_floating_point else torch.float32)
+            # parameters on the host: a device copy per forward (the slow path: lazy-init call, CPU-pinned evaluation)
+            if self._flat is None or self._flat.device != pdev or self._flat_ok:
+                self._flat, self._flat_ok = torch.zeros(spec.flat_size(), dtype=torch.float32, device=pdev), False
+            if need_grad:
+                flat = _Flatten.apply(spec.flat_size(), pdev, offsets, *params)
+                out = _EngineFn.apply(flat, e, B, True, *xs)
+            else:
+                with torch.no_grad():
+                    views = [self._flat[o:o + n].view(p.shape) for (o, n), p in zip(offsets, params)]
+                    torch._foreach_copy_(views, [p.detach() for p in params])
+                    out = e.forward(xs, self._flat, B, training=False)
+        out = out.to(device=in_dev, dtype=in_dtype if in_dtype in (torch.float64, torch.float32) else torch.float32)
         if spec.output_is_window_major:
             return out.view(B, -1)      # ms_foot_decoder: [B, 4*3]   (hgnn_c2.py:184-189)
         if spec.kind in ("k4_com", "c2_com"):

@@ -160,6 +160,9 @@ class ModelSpec:
 
     def param_offsets(self) -> "OrderedDict[str, Tuple[int, int]]":
         """name -> (offset, numel) in the flat fp32 parameter / gradient buffer (16-element aligned)."""
+        cached = self.__dict__.get("_param_offsets")      # the spec is immutable after construction; this is on every call path
+        if cached is not None:
+            return cached
         off = 0
         out: "OrderedDict[str, Tuple[int, int]]" = OrderedDict()
         for k, s in self.param_shapes().items():
@@ -168,6 +171,7 @@ class ModelSpec:
                 n *= v
             out[k] = (off, n)
             off += (n + 15) // 16 * 16
+        self.__dict__["_param_offsets"] = out
         return out
 
     def num_params(self) -> int:

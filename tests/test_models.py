@@ -115,3 +115,47 @@ def test_module_forward_backward_matches_golden(name, param_dev):
         with pytest.raises(ValueError):
             m._checked_batches.clear()
             m(x_dict=xd, edge_index_dict=bad)
+
+
+@pytest.mark.gpu
+def test_device_parameters_are_views_of_the_flat_buffer_and_behave_like_ordinary_parameters():
+    """Fast path of the module surface: with the module on the GPU every parameter is an fp32 view into the engine's flat buffer (nothing
+    is copied per forward), .grad tensors are views of the flat gradient.  What a training loop relies on must keep working:
+    gradient accumulation over two backwards, an in-place optimizer step seen by the next forward, load_state_dict, and
+    .double() / .to() followed by another forward."""
+    assert torch.cuda.is_available()
+    torch.set_default_dtype(torch.float64)
+    case, spec, fx, x_dict, y, params, ei = helpers.load_case("a1c2_h128_L3_d3_B3")
+    B = case["B"]
+    m = _build(case, spec).cuda()
+    xd = {k: v.cuda() for k, v in x_dict.items()}
+    eid = {k: v.cuda() for k, v in ei.items()}
+    with torch.no_grad():
+        m(x_dict=dict(xd), edge_index_dict=eid)
+    m.load_state_dict(params)
+    flat = m._flat
+    assert all(p.dtype == torch.float32 and p.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() for p in m.parameters())
+
+    def loss_of(model):
+        out = model(x_dict=dict(xd), edge_index_dict=eid)
+        return ((out.flatten() - y.cuda().flatten()) ** 2).mean()
+
+    loss_of(m).backward()
+    g1 = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    helpers.check_against_fixture(fx, m(x_dict=dict(xd), edge_index_dict=eid).detach().cpu(), None, {k: v.cpu() for k, v in g1.items()} | {
+        k: torch.zeros_like(p).cpu() for k, p in m.named_parameters() if p.grad is None}, rtol=1e-4, what="module fast path")
+    loss_of(m).backward()                                    # accumulation: .grad == 2 x the single-step gradient
+    for k, p in m.named_parameters():
+        if k in g1:
+            assert torch.allclose(p.grad, 2 * g1[k], rtol=1e-6, atol=0), k
+    m.zero_grad(set_to_none=True)
+    l0 = loss_of(m)
+    l0.backward()
+    l0 = float(l0)
+    opt = torch.optim.SGD(m.parameters(), lr=1e-3)
+    opt.step()                                               # in place on the views -> the flat buffer the kernels read
+    assert m._flat is flat and float(loss_of(m)) < l0
+    m.double()                                               # replaces the parameter tensors ...
+    assert not m._flat_ok
+    l1 = float(loss_of(m))                                   # ... the next forward re-establishes the fp32 views
+    assert m._flat_ok and all(p.dtype == torch.float32 for p in m.parameters()) and abs(l1 - float(loss_of(m))) < 1e-12
