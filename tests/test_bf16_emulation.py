@@ -63,3 +63,35 @@ def test_bf16_plan_matches_rounding_point_emulation(name, fused, monkeypatch):
     # and a sanity bound against the exact (un-rounded) oracle: bf16 forward within 2e-2 of fp64
     o_out, _, _ = orc.step(helpers.oracle_config(spec), params, x_dict, ei, y, B)
     assert float((out.cpu().double().reshape(-1) - o_out.reshape(-1)).abs().max() / o_out.abs().max()) < 2e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", ["default", "layers"])
+@pytest.mark.parametrize("name", ["mck4_cls_h128_L2_B3", "mcc2_cls_h128_L2_B3", "mck4_cls_h128_L8_B2"])
+def test_bf16_plan_classification_through_the_fused_cross_entropy(name, fused, monkeypatch):
+    """The classification wrappers on the bf16 plan: logits, then mshgnn_backward_ce (cross entropy fused into the decoder backward),
+    against the rounding-point emulation with the same loss -- MiniCheetah K4 (per-layer kernels: 24 LDS blocks do not fit the stack
+    kernels' slab variant) and C2, at the paper's depth too."""
+    assert torch.cuda.is_available()
+    from morphsym_hgnn_amd import engine as eng
+    monkeypatch.setenv("MSHGNN_FUSED", "0" if fused == "layers" else "1")
+    case, spec, fx, x_dict, y, params, ei = helpers.load_case(name)
+    B = case["B"]
+    e = eng.Engine(spec, "bf16")
+    xs = e.cast_inputs(x_dict)
+    flat = eng.flatten_params(spec, params, e.device)
+    out = e.forward(xs, flat, B)
+    loss, gflat = e.backward_ce(xs, flat, out, y.reshape(B, 4).to(e.device, torch.int32).contiguous(), B)
+    torch.cuda.synchronize()
+    grads = {k: v.cpu().double() for k, v in eng.unflatten(spec, gflat).items()}
+    r_out, r_loss, r_grads = emulate_step(spec, params, x_dict, y, B, quant=True)
+    assert float((out.cpu().double().reshape(-1) - r_out.reshape(-1)).abs().max() / r_out.abs().max()) < 4e-3
+    assert abs(float(loss) - float(r_loss)) / abs(float(r_loss)) < 4e-3
+    bad = {}
+    for k, ref in r_grads.items():
+        n = float(ref.norm())
+        if n == 0:
+            assert float(grads[k].abs().max()) == 0.0, k
+        elif float((grads[k] - ref).norm()) / n > 1.5e-2:
+            bad[k] = float((grads[k] - ref).norm()) / n
+    assert not bad, bad

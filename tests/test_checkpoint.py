@@ -88,3 +88,37 @@ def test_models_deepcopy_and_pickle_after_the_plan_exists():
         sd = clone.state_dict()
         assert all(torch.equal(sd[k], params[k]) for k in params)
     assert len(m._engines) == 1      # the original keeps its plan
+
+
+import pytest
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,model_type", [("a1c2_h128_L3_d3_B3", "heterogeneous_gnn_c2"), ("mck4_cls_h128_L2_B3", "heterogeneous_gnn_k4"),
+                                             ("mi_h128_L2_d3_B2", "heterogeneous_gnn")])
+def test_checkpoint_to_engine_matches_golden(name, model_type, tmp_path):
+    """A Lightning-layout .ckpt (written the way the reference's ModelCheckpoint does, incl. a foreign `dummy_batch`) -> model_from_checkpoint
+    -> forward + loss + backward on the GPU engine == the golden vectors of the reference run with those weights."""
+    assert torch.cuda.is_available()
+    torch.set_default_dtype(torch.float64)
+    case, spec, fx, x_dict, y, params, ei = helpers.load_case(name)
+    _, cfg = helpers.load_group(case["cfg"])
+    B = case["B"]
+    hp = {"hidden_channels": 128, "num_layers": case["layers"], "data_metadata": spec.topology.metadata(), "regression": case["regression"],
+          "activation_fn": torch.nn.ReLU(), "dummy_batch": ck.OpaqueObject(), "symmetry_mode": "MorphSym" if cfg else None,
+          "group_operator_path": cfg, "grf_dimension": case["grf"]}
+    path = tmp_path / "epoch=9.ckpt"
+    torch.save({"state_dict": {**{"model." + k: v for k, v in params.items()}, "metric_mse.total": torch.tensor(0)}, "hyper_parameters": hp}, path)
+    m = ck.model_from_checkpoint(str(path), model_type).cuda()
+    xd = {k: v.cuda() for k, v in x_dict.items()}
+    eid = {k: v.cuda() for k, v in ei.items()}
+    out = m(x_dict=xd, edge_index_dict=eid)
+    w = m.out_channels_per_foot * 4
+    y_pred = torch.reshape(out.squeeze(), (B, w))
+    if case["regression"]:
+        loss = ((y_pred.flatten() - y.cuda().reshape(B, w).flatten()) ** 2).mean()
+    else:
+        loss = torch.nn.functional.cross_entropy(y_pred.reshape(B * 4, 2), y.cuda().reshape(B, 4).long().flatten())
+    loss.backward()
+    grads = {k: (p.grad.detach().cpu() if p.grad is not None else torch.zeros_like(p).cpu()) for k, p in m.named_parameters()}
+    helpers.check_against_fixture(fx, out.detach().cpu(), loss.detach().cpu(), grads, rtol=1e-4, what=name)

@@ -328,3 +328,35 @@ def test_full_size_batch_properties_bf16():
     # each half's loss / gradient is a mean over h windows: the whole batch is their average
     assert abs(0.5 * (float(res[0][1]) + float(res[1][1])) - float(loss)) <= 1e-5 * abs(float(loss))
     assert float((0.5 * (res[0][2] + res[1][2]) - g).abs().max() / g.abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "x3"])
+@pytest.mark.parametrize("kind,topo,cfg,regression", [("k4", "mini_cheetah-k4", "mini_cheetah-k4", False), ("k4_com", "solo-k4-com", "solo-k4", True),
+                                                       ("c2_com", "solo-c2-com", "solo-c2", True)])
+def test_k4_and_com_batches_of_a_thousand_windows_are_additive(kind, topo, cfg, regression, dtype):
+    """MiniCheetah-K4 classification (BASELINE configs[2]) and the Solo COM graphs (configs[3]) at B = 1000, past the sizes the oracle
+    covers: every window's output is independent of its batch (identical bits) and the gradient w.r.t. a fixed dL/dout of the two halves
+    adds up to the gradient of the whole -- on the fp32 plan, the bf16 plan and the split plan (MiniCheetah-K4 at 'x3': generic engine)."""
+    _require_gpu()
+    from morphsym_hgnn_amd import engine as eng, synth
+    spec = helpers.make_spec(kind, topo, cfg, 128, 3, regression=regression)
+    B = 1000
+    n_out, d_out = spec.num_nodes[spec.out_type], spec.out_channels
+    e = eng.Engine(spec, dtype)
+    x_dict, _ = synth.make_windows(13, B, spec.num_nodes, spec.widths, n_out * d_out)
+    xs = e.cast_inputs(x_dict)
+    flat = eng.flatten_params(spec, synth.make_params(13, spec.param_shapes()), e.device)
+    g = torch.Generator().manual_seed(5)
+    go = torch.randn(B * n_out, d_out, generator=g).to(e.device)
+    out = e.forward(xs, flat, B).clone()
+    g_all = e.backward(xs, flat, go, B).clone()
+    h = B // 2
+    parts = []
+    for lo in (0, h):
+        xh = [x.view(B, -1)[lo:lo + h].reshape(h * spec.num_nodes[t], -1).contiguous() for x, t in zip(xs, spec.node_types)]
+        oh = e.forward(xh, flat, h).clone()
+        gh = e.backward(xh, flat, go[lo * n_out:(lo + h) * n_out].contiguous(), h).clone()
+        parts.append((oh, gh))
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat([parts[0][0], parts[1][0]]), out)
+    assert float((parts[0][1] + parts[1][1] - g_all).abs().max() / g_all.abs().max()) < (2e-3 if dtype == "bf16" else 1e-4)
