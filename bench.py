@@ -200,9 +200,13 @@ class Workload:
         self.loss = torch.empty(1, dtype=torch.float32, device=device)
         split = int(self.e.info.grad_split)
         world = dist.get_world_size() if dist is not None else 1
-        # two-phase step with the all-reduce of everything but the encoder's gradients under the encoder's weight-gradient
-        # launch: "auto" turns it on from 4 ranks (below that the wire time of a 4 MB all-reduce is less than the split costs)
-        self.overlap = dist is not None and split > 0 and spec.regression and (overlap == "1" or (overlap == "auto" and world >= 4))
+        # Two-phase step (--overlap 1): the all-reduce of everything but the encoder's gradients (83 % of the buffer) runs under the
+        # encoder's weight-gradient launch.  OFF unless asked for: measured on one GPU with a 1-rank RCCL group (no wire time) the split
+        # costs +51 us per step (two weight-gradient launches that each fill the chip less well, two finalize launches, two stream
+        # hand-offs; +126 us when each phase gets its own window-part count: more slabs to write and sum), while an 8-GPU all-reduce of
+        # 3.3 MB is ~60-90 us of which at most the ~45 us of the encoder's weight gradients can be hidden -- the plain sequence
+        # "step, then one mean all-reduce of the 4 MB flat gradient" is at least as fast at this gradient size.
+        self.overlap = dist is not None and split > 0 and spec.regression and overlap == "1"
         self.split = split
 
     def step(self):
