@@ -170,12 +170,13 @@ template <bool ALIGNED> __global__ __launch_bounds__(256) void k_enc_x3(EncArgs 
     }
 }
 
-// stage the [hi | lo] rows of every node for which keep(n) into LDS: 512 threads = 16 rows x 32 chunks, one node per pass, 4 in flight
+// stage the [hi | lo] rows of every node for which keep(n) into LDS: 512 threads = 16 rows x 32 chunks, one node per load, 10 in flight
+// (an 18-node tile in two round trips to HBM: with one workgroup per CU nothing else hides them)
 template <typename Keep>
 __device__ __forceinline__ void stage_tile_x3(char* smem, const T16* src, int NN, int LO, int w0, int B, int tid, Keep keep) {
     const int row = tid >> 5, c = tid & 31;      // chunk c < 16: hi half, else lo half
     const int blk_off = c < 16 ? 0 : LO, cc = c & 15;
-    constexpr int BATCH = 4;
+    constexpr int BATCH = 10;
     for (int nb = 0; nb < NN; nb += BATCH) {
         u32x4 v[BATCH];
 #pragma unroll
@@ -219,8 +220,10 @@ __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_fwd_x3(StackArgs a) 
     const int win = c_win(lane), w = w0 + win, col = wn * 32 + c_oct(lane);
     const bool w_ok = w < B, train = a.training != 0;
 
+    FS_STAMP(0);
     stage_tile_x3(smem, reinterpret_cast<const T*>(a.tile_in), NN, LO, w0, B, tid, [](int) { return true; });
     __syncthreads();
+    FS_STAMP(1);
 
     P::Acc acc[FS_HS];
     FHdr fhn(a.tables + a.prog_off[0], lane);
@@ -239,8 +242,11 @@ __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_fwd_x3(StackArgs a) 
             if (n < NN && fh[FH_KIND + n] != NK_DEAD) acc_init_bias<T>(acc[u], a.bias + (size_t)fh[FH_BIAS + n] * H, wn, lane);
             else acc_fill(acc[u], 0.f);
         }
+        FS_STAMP(2 + 4 * l);
         fs_run<T>(wp, acc, smem, wpack, wn, lane);
+        FS_STAMP(3 + 4 * l);
         __syncthreads();   // every wave is done reading X_l: the node blocks may be overwritten
+        FS_STAMP(4 + 4 * l);
 
         u32x4 hph[2] = {}, hpl[2] = {}, tph[2] = {}, tpl[2] = {};
         if (nmlp > 0) {
@@ -277,6 +283,7 @@ __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_fwd_x3(StackArgs a) 
             __syncthreads();
             mlp_mac3(acc, smem, NN, LO, nmlp, wh, bfh, bfl, lane);      // accumulators 0..1 = nodes 0..3
         }
+        FS_STAMP(16 + l);
         // every load issued so far has landed before the first store of the epilogue goes out
         __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));
         if (nmlp > 0 && train && w_ok) {
@@ -337,8 +344,10 @@ __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_fwd_x3(StackArgs a) 
             }
         }
         __syncthreads();
+        FS_STAMP(5 + 4 * l);
     }
     decoder_tail<T, LAYER_THREADS, true>(a, smem, tid, lane, wv, w0, B);
+    FS_STAMP(30);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -843,6 +852,7 @@ int x3_forward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitc
             a.inv_n = 1.0f / (float)((int64_t)B * a.n_out * a.dout);
         }
         const int tiles = (B + P16::ROWS - 1) / P16::ROWS;
+        a.stamps = stamp_ptr("MSHGNN_STAMPS");
         ProfScope ps(p, hp.ks_stack_fwd, st);
         hipLaunchKernelGGL(k_stack_fwd_x3, dim3(tiles), dim3(LAYER_THREADS), x3_lds_stack(hp), st, a);
     }

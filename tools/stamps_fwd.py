@@ -7,7 +7,7 @@ dev = torch.device("cuda", 0)
 spec = bench.build_spec(3); B = 8192
 stamps = torch.zeros(512 * 32, dtype=torch.int64, device=dev)
 os.environ["MSHGNN_STAMPS"] = hex(stamps.data_ptr())
-e = eng.Engine(spec, "bf16", device=dev)
+e = eng.Engine(spec, sys.argv[1] if len(sys.argv) > 1 else "bf16", device=dev)      # needs a build with EXTRA=-DMSHGNN_FS_STAMPS (MSHGNN_LIB=...)
 g = torch.Generator().manual_seed(0)
 imu = torch.randn(B, 1, 900, generator=g)
 x = {"base": imu.expand(B, 2, 900).reshape(B * 2, 900), "joint": torch.randn(B * 12, 450, generator=g), "foot": torch.ones(B * 4, 1)}
