@@ -19,6 +19,10 @@
  * workspace per stream, with the device that owns it current (hipSetDevice) when the entry point is called -- two
  * forwards on one workspace overwrite each other's stash, whatever streams they run on.
  *
+ * Engines: plan creation picks the LDS-resident kernels (hidden == 128, <= 20 nodes per window, in-degree 1 on 'mean' relations) where
+ * they apply, else the generic-width engine (any hidden multiple of 128 up to 2048, any node count / in-degree; bf16 or split-bf16
+ * arithmetic -- an MSHGNN_F32 request is served by the latter at the same tolerance).  mshgnn_info.kernel_sets bit 2 tells which.
+ *
  * Data layout ("dense window-major"): every window graph of a minibatch has the same tiny topology, so the
  * PyG-batched [B*n_type, F] tensors the reference passes are already [B, n_type, F] contiguous; they are
  * consumed as-is.  dtype selects storage/operand precision of inputs and activations:
@@ -47,7 +51,7 @@ extern "C" {
 
 #define MSHGNN_OK 0
 #define MSHGNN_EINVAL (-1)      /* bad descriptor / argument */
-#define MSHGNN_EUNSUPPORTED (-2) /* valid request the engine cannot run (e.g. hidden != 128) */
+#define MSHGNN_EUNSUPPORTED (-2) /* valid request the engine cannot run (e.g. hidden not a multiple of 128) */
 #define MSHGNN_EHIP (-3)        /* HIP runtime error */
 #define MSHGNN_ENOMEM (-4)
 
@@ -61,7 +65,7 @@ typedef struct mshgnn_plan mshgnn_plan;
  * All offsets are element offsets into the flat fp32 parameter buffer.                              */
 typedef struct mshgnn_desc {
     int32_t n_types;                              /* node types, in data_metadata[0] order            */
-    int32_t hidden;                               /* hidden_channels (engine: must be 128)            */
+    int32_t hidden;                               /* hidden_channels: a multiple of 128 (128: LDS-resident kernels; else generic-width engine) */
     int32_t num_layers;                           /* message-passing layers                           */
     int32_t n_rel;                                /* relations, in data_metadata[1] order             */
     int32_t out_type;                             /* node type the decoder reads ('foot')             */

@@ -53,9 +53,25 @@ def test_plan_compiler_kernel_sets():
 
 
 def test_plan_compiler_rejects_bad_descriptors():
-    spec = helpers.make_spec("c2", "a1-c2", "a1-c2", 64, 2)   # hidden != 128
+    spec = helpers.make_spec("c2", "a1-c2", "a1-c2", 64, 2)   # hidden not a multiple of 128: neither engine takes it
     with pytest.raises(engine.MshgnnError, match="128"):
         engine.compile_plan_host(spec, "f32")
+
+
+def test_wide_and_many_node_models_compile_on_the_generic_engine():
+    """hidden = 256 / 512, 129 nodes per window (BASELINE configs[4]): the specialised plan declines, the generic-width engine's compiler
+    takes the descriptor (kernel_sets bit 2) for every arithmetic mode."""
+    from morphsym_hgnn_amd import synth, topology
+    from morphsym_hgnn_amd.spec import ModelSpec
+    synth32 = ModelSpec(kind="mi", topology=topology.synthetic_limbs(32), hidden=512, num_layers=6, widths=synth.feature_widths("mi", True),
+                        regression=True, grf_dimension=3)
+    assert synth32.num_params() == 16438787
+    for dt in ("bf16", "x3", "f32"):
+        info = engine.compile_plan_host(synth32, dt)
+        assert info.kernel_sets == 4 and info.total_nodes == 129
+        assert engine.compile_plan_host(helpers.make_spec("c2", "a1-c2", "a1-c2", 256, 3), dt).kernel_sets == 4
+    # algorithmic work of configs[4]: 2.70 GFLOP per window forward + backward
+    assert abs((info.flops_fwd + info.flops_bwd) / 1e9 - 2.70) < 0.05
 
 
 def test_engine_fails_loudly_without_gpu():
