@@ -28,7 +28,7 @@ struct mshgnn_gen_state {      // device side of a generic plan
 struct GArgs {
     char* ws; size_t buf_off[GBUF_COUNT];
     const void* x[MSHGNN_MAX_TYPES]; int64_t pitch[MSHGNN_MAX_TYPES]; int nodes[MSHGNN_MAX_TYPES]; int vb[MSHGNN_MAX_TYPES]; int aligned;
-    const int* jobs; const int* terms; const int* srcs; const int* units; const int* items;
+    const int* jobs; const int* terms; const int* srcs; const int* units; const int* items; const int* unit_order;
     const void* wpack; const float* bias; const uint8_t* signs; float* slabs;
     int n_img, B, Hd, NCT, tiles, training, job0, n_units, n_parts;
 };
@@ -336,21 +336,25 @@ template <bool SPLIT> __global__ __launch_bounds__(256) void k_gdec_bwd(GDecArgs
 
 // ------------------------------------------------------------------------------------------------------
 // k_ggradw: dW tile [128 x 128] = sum over the unit's items and its part of the batch of P^T Q
+// Steps = (item, 32-window chunk) pairs; the global loads of step s + NST run in registers, untouched, while step s is multiplied (P rows always;
+// Q rows when the item has one source -- raw input or a single activation row; aggregated Q rows are gathered at staging time).
 // ------------------------------------------------------------------------------------------------------
-template <bool SPLIT> __global__ __launch_bounds__(256, 2) void k_ggradw(GArgs a) {
-    constexpr int KW = SPLIT ? 32 : 64, NP = KW / 16;
+template <bool SPLIT> __global__ __launch_bounds__(256, SPLIT ? 2 : 3) void k_ggradw(GArgs a) {
+    constexpr int KW = 32, NP = KW / 16, NST = 2;
     __shared__ __attribute__((aligned(16))) __bf16 Ph[KW * GWB_PITCH];
     __shared__ __attribute__((aligned(16))) __bf16 Qh[KW * GWB_PITCH];
     __shared__ __attribute__((aligned(16))) __bf16 Pl[SPLIT ? KW * GWB_PITCH : 8];
     __shared__ __attribute__((aligned(16))) __bf16 Ql[SPLIT ? KW * GWB_PITCH : 8];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wv >> 1, wc = wv & 1;
-    const int un = blockIdx.x % a.n_units, part = blockIdx.x / a.n_units;
+    const int un = a.unit_order[blockIdx.x % a.n_units], part = blockIdx.x / a.n_units;
     const int* u = a.units + (size_t)un * UNIT_INTS;
-    const int pcol = u[U_PCOL], qcol = u[U_QCOL], qn = u[U_QN], bias_flag = u[U_BIAS];
+    const int it0 = u[U_ITEM0], pcol = u[U_PCOL], qcol = u[U_QCOL], qn = u[U_QN], bias_flag = u[U_BIAS];
     const int nchunks = (a.B + KW - 1) / KW;
     const int ch0 = (int)((int64_t)part * nchunks / a.n_parts), ch1 = (int)((int64_t)(part + 1) * nchunks / a.n_parts);
-    const int c = tid & 15, r0 = tid >> 4;
+    const int nch = ch1 - ch0, nsteps = (u[U_ITEM1] - it0) * nch;
+    const int c = tid & 15, r0 = tid >> 4, B = a.B, Hd = a.Hd;
+    const int one_bits = __float_as_int(1.0f);
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -361,65 +365,123 @@ template <bool SPLIT> __global__ __launch_bounds__(256, 2) void k_ggradw(GArgs a
     float bsum[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
-    for (int it = u[U_ITEM0]; it < u[U_ITEM1]; ++it) {
-        const int* im = a.items + (size_t)it * GITEM_INTS;
+
+    struct Stage { u32x4 pa[NP], pb[NP], qa[NP], qb[NP]; unsigned mw[NP]; };      // a: bf16 chunk / hi half / first four fp32; b: lo half / next four fp32
+    // Q kind of an item: 1 raw input, 0 single activation source, 2 aggregate
+    auto q_kind = [&](const int* im) {
+        if (im[I_KIND] == 1) return 1;
         const int* src = a.srcs + (size_t)im[I_SRC0] * SRC_INTS;
-        const int psrc[SRC_INTS] = {im[I_PBUF], im[I_PNODE], im[I_PMASK], __float_as_int(1.0f)};
-        for (int ch = ch0; ch < ch1; ++ch) {
-            float ps[NP][8], qs[NP][8];
+        return (im[I_NSRC] == 1 && src[S_SCALE] == one_bits) ? 0 : 2; };
+    auto fetch = [&](Stage& st, int s) {
+        const int* im = a.items + (size_t)(it0 + s / nch) * GITEM_INTS;
+        const int* src = a.srcs + (size_t)im[I_SRC0] * SRC_INTS;
+        const int w0 = (ch0 + s % nch) * KW, qk = q_kind(im);
+        const T16* pbase = reinterpret_cast<const T16*>(a.ws + a.buf_off[im[I_PBUF]]) + pcol + c * 8;
+        const uint8_t* mb = im[I_PMASK] >= 0 ? reinterpret_cast<const uint8_t*>(a.ws + a.buf_off[im[I_PMASK]]) : nullptr;
 #pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                const int w = ch * KW + r0 + 16 * p;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { ps[p][e] = 0.f; qs[p][e] = 0.f; }
-                if (w < a.B) {
-                    gather8<SPLIT>(a, psrc, 1, w, pcol + c * 8, ps[p]);
-                    if (im[I_KIND] == 0) { if (c * 8 < qn) gather8<SPLIT>(a, src, im[I_NSRC], w, qcol + c * 8, qs[p]); }
-                    else raw8<SPLIT>(a, src[S_BUF], src[S_NODE], w, qcol + c * 8, qcol + qn, a.signs + src[S_MASK] + qcol + c * 8, qs[p]);
-                }
-            }
-            __syncthreads();   // the previous MFMA phase is done reading the tiles
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                const int row = r0 + 16 * p;
-                const f32x4 p0 = f32x4{ps[p][0], ps[p][1], ps[p][2], ps[p][3]}, p1 = f32x4{ps[p][4], ps[p][5], ps[p][6], ps[p][7]};
-                const f32x4 q0 = f32x4{qs[p][0], qs[p][1], qs[p][2], qs[p][3]}, q1 = f32x4{qs[p][4], qs[p][5], qs[p][6], qs[p][7]};
-                if constexpr (SPLIT) {
-                    u32x4 hi, lo;
-                    split_oct(p0, p1, hi, lo);
-                    *reinterpret_cast<u32x4*>(&Ph[gwb_elem(row, c * 8)]) = hi; *reinterpret_cast<u32x4*>(&Pl[gwb_elem(row, c * 8)]) = lo;
-                    split_oct(q0, q1, hi, lo);
-                    *reinterpret_cast<u32x4*>(&Qh[gwb_elem(row, c * 8)]) = hi; *reinterpret_cast<u32x4*>(&Ql[gwb_elem(row, c * 8)]) = lo;
-                } else {
-                    *reinterpret_cast<u32x4*>(&Ph[gwb_elem(row, c * 8)]) = pack_oct(p0, p1);
-                    *reinterpret_cast<u32x4*>(&Qh[gwb_elem(row, c * 8)]) = pack_oct(q0, q1);
-                }
-                if (bias_flag) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) bsum[e] += ps[p][e];
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int ks = 0; ks < KW / 16; ++ks) {
-                bf16x8 afh[2], bqh[2], afl[2], bql[2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    afh[i] = tr_frag(Ph, ks * 16, wr * 64 + i * 32, lane);
-                    bqh[i] = tr_frag(Qh, ks * 16, wc * 64 + i * 32, lane);
-                    if constexpr (SPLIT) { afl[i] = tr_frag(Pl, ks * 16, wr * 64 + i * 32, lane); bql[i] = tr_frag(Ql, ks * 16, wc * 64 + i * 32, lane); }
-                }
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afh[i], bqh[j], acc[i][j], 0, 0, 0);
-                        if constexpr (SPLIT) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afh[i], bql[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afl[i], bqh[j], acc[i][j], 0, 0, 0);
-                        }
+        for (int p = 0; p < NP; ++p) {
+            const int w = w0 + r0 + 16 * p;
+            st.pa[p] = u32x4{0, 0, 0, 0}; st.pb[p] = u32x4{0, 0, 0, 0}; st.qa[p] = u32x4{0, 0, 0, 0}; st.qb[p] = u32x4{0, 0, 0, 0}; st.mw[p] = 0xffu;
+            if (w < B) {
+                const T16* pr = pbase + g_row<SPLIT>(w, im[I_PNODE], B, Hd);
+                st.pa[p] = *reinterpret_cast<const u32x4*>(pr);
+                if constexpr (SPLIT) st.pb[p] = *reinterpret_cast<const u32x4*>(pr + Hd);
+                if (mb) st.mw[p] = mb[g_relu_byte(im[I_PNODE], B, Hd, w, pcol + c * 8)];
+                if (qk == 0) {
+                    const T16* qr = reinterpret_cast<const T16*>(a.ws + a.buf_off[src[S_BUF]]) + g_row<SPLIT>(w, src[S_NODE], B, Hd) + qcol + c * 8;
+                    st.qa[p] = *reinterpret_cast<const u32x4*>(qr);
+                    if constexpr (SPLIT) st.qb[p] = *reinterpret_cast<const u32x4*>(qr + Hd);
+                } else if (qk == 1) {
+                    const int t = src[S_BUF], nv = qn - c * 8;
+                    if constexpr (SPLIT) {
+                        const float* qr = reinterpret_cast<const float*>(a.x[t]) + ((size_t)w * a.nodes[t] + src[S_NODE]) * a.pitch[t] + qcol + c * 8;
+                        st.qa[p] = load_chunk<float>(qr, nv, a.vb[t]);
+                        st.qb[p] = load_chunk<float>(qr + 4, nv - 4, a.vb[t]);
+                    } else {
+                        const T16* qr = reinterpret_cast<const T16*>(a.x[t]) + ((size_t)w * a.nodes[t] + src[S_NODE]) * a.pitch[t] + qcol + c * 8;
+                        st.qa[p] = load_chunk<T16>(qr, nv, a.vb[t]);
                     }
+                }
             }
+        }
+    };
+    auto stage_to_lds = [&](const Stage& st, int s) {
+        const int* im = a.items + (size_t)(it0 + s / nch) * GITEM_INTS;
+        const int* src = a.srcs + (size_t)im[I_SRC0] * SRC_INTS;
+        const int w0 = (ch0 + s % nch) * KW, qk = q_kind(im);
+        const bool masked = im[I_PMASK] >= 0;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int row = r0 + 16 * p, w = w0 + row;
+            u32x4 ph = st.pa[p], pl = st.pb[p];
+            if (masked) { ph = chunk_mask_bits<T16>(ph, st.mw[p]); if constexpr (SPLIT) pl = chunk_mask_bits<T16>(pl, st.mw[p]); }     // dH = dX . relu bits
+            *reinterpret_cast<u32x4*>(&Ph[gwb_elem(row, c * 8)]) = ph;
+            if constexpr (SPLIT) *reinterpret_cast<u32x4*>(&Pl[gwb_elem(row, c * 8)]) = pl;
+            u32x4 qh = st.qa[p], ql = st.qb[p];
+            if (qk == 1) {          // raw input: pad columns dropped, symmetry sign, (split plan) fp32 -> hi / lo
+                const int nv = qn - c * 8;
+                const uint8_t* sg = a.signs + src[S_MASK] + qcol + c * 8;
+                if constexpr (SPLIT) {
+                    const u32x4 fa = chunk_keep_first<float>(st.qa[p], nv) ^ sign_xor<float>(sg), fb = chunk_keep_first<float>(st.qb[p], nv - 4) ^ sign_xor<float>(sg + 4);
+                    split_oct(__builtin_bit_cast(f32x4, fa), __builtin_bit_cast(f32x4, fb), qh, ql);
+                } else qh = chunk_keep_first<T16>(st.qa[p], nv) ^ sign_xor<T16>(sg);
+            } else if (qk == 2) {   // aggregate: fp32 sum (mean: scaled) of the source rows, gathered now
+                float qs[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) qs[e] = 0.f;
+                if (w < B) gather8<SPLIT>(a, src, im[I_NSRC], w, qcol + c * 8, qs);
+                const f32x4 q0 = f32x4{qs[0], qs[1], qs[2], qs[3]}, q1 = f32x4{qs[4], qs[5], qs[6], qs[7]};
+                if constexpr (SPLIT) split_oct(q0, q1, qh, ql); else qh = pack_oct(q0, q1);
+            }
+            *reinterpret_cast<u32x4*>(&Qh[gwb_elem(row, c * 8)]) = qh;
+            if constexpr (SPLIT) *reinterpret_cast<u32x4*>(&Ql[gwb_elem(row, c * 8)]) = ql;
+            if (bias_flag) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bsum[2 * e] += __builtin_bit_cast(float, ph[e] << 16) + (SPLIT ? __builtin_bit_cast(float, pl[e] << 16) : 0.f);
+                    bsum[2 * e + 1] += __builtin_bit_cast(float, ph[e] & 0xffff0000u) + (SPLIT ? __builtin_bit_cast(float, pl[e] & 0xffff0000u) : 0.f);
+                }
+            }
+        }
+    };
+    auto mfmas = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < KW / 16; ++ks) {
+            bf16x8 afh[2], bqh[2], afl[2], bql[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                afh[i] = tr_frag(Ph, ks * 16, wr * 64 + i * 32, lane);
+                bqh[i] = tr_frag(Qh, ks * 16, wc * 64 + i * 32, lane);
+                if constexpr (SPLIT) { afl[i] = tr_frag(Pl, ks * 16, wr * 64 + i * 32, lane); bql[i] = tr_frag(Ql, ks * 16, wc * 64 + i * 32, lane); }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afh[i], bqh[j], acc[i][j], 0, 0, 0);
+                    if constexpr (SPLIT) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afh[i], bql[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afl[i], bqh[j], acc[i][j], 0, 0, 0);
+                    }
+                }
+        }
+    };
+    static_assert(NST == 2, "two register stages");
+    Stage sa, sb;
+    if (nsteps > 0) fetch(sa, 0);
+    if (nsteps > 1) fetch(sb, 1);
+    for (int s = 0; s < nsteps; s += 2) {
+        __syncthreads();      // the previous MFMA phase is done reading the tiles
+        stage_to_lds(sa, s);
+        __syncthreads();
+        if (s + 2 < nsteps) fetch(sa, s + 2);
+        mfmas();
+        if (s + 1 < nsteps) {
+            __syncthreads();
+            stage_to_lds(sb, s + 1);
+            __syncthreads();
+            if (s + 3 < nsteps) fetch(sb, s + 3);
+            mfmas();
         }
     }
     float* slab = a.slabs + ((size_t)part * a.n_units + un) * SLAB_FLOATS;
@@ -433,7 +495,7 @@ template <bool SPLIT> __global__ __launch_bounds__(256, 2) void k_ggradw(GArgs a
                 slab[o * H + k] = acc[i][j][q];
             }
     if (bias_flag) {
-        float* red = reinterpret_cast<float*>(Ph);   // 16 x 128 floats = 8 KB <= one tile
+        float* red = reinterpret_cast<float*>(Ph);   // 16 x 128 floats = 8 KB = one tile
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < 8; ++e) red[r0 * H + c * 8 + e] = bsum[e];
@@ -557,7 +619,7 @@ static int g_fill(const mshgnn_plan* p, const mshgnn_ws_layout& lay, const void*
         a.vb[t] = vec_bytes(x[t], a.pitch[t], in_es);
     }
     a.jobs = g->d_tables + gp.job_off; a.terms = g->d_tables + gp.term_off; a.srcs = g->d_tables + gp.src_off;
-    a.units = g->d_tables + gp.unit_off; a.items = g->d_tables + gp.item_off;
+    a.units = g->d_tables + gp.unit_off; a.items = g->d_tables + gp.item_off; a.unit_order = g->d_tables + gp.order_off;
     a.wpack = ws + lay.wpack; a.bias = reinterpret_cast<const float*>(ws + lay.bias); a.signs = g->d_signs;
     a.slabs = reinterpret_cast<float*>(ws + lay.slabs);
     a.n_img = gp.n_img; a.B = B; a.Hd = gp.Hd; a.NCT = gp.NCT; a.tiles = (B + 63) / 64; a.training = training;

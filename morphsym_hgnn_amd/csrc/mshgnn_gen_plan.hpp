@@ -51,7 +51,7 @@ struct GenPlan {
     std::vector<BiasDesc> biases;
     std::vector<uint8_t> signs; std::vector<int> sign_off, enc_nkc;
     std::vector<int32_t> tables;            // jobs | terms | srcs | units | items | fins
-    int job_off = 0, term_off = 0, src_off = 0, unit_off = 0, item_off = 0, fin_off = 0, n_units = 0, n_parts = 1, n_fin = 0;
+    int job_off = 0, term_off = 0, src_off = 0, unit_off = 0, order_off = 0, item_off = 0, fin_off = 0, n_units = 0, n_parts = 1, n_fin = 0;
     std::vector<Launch> fwd, bwd;           // job launches in order
     int ks_prep = 0, ks_dec_fwd = 0, ks_dec_bwd = 0, ks_gradw = 0, ks_fin = 0;
     std::vector<mshgnn_kernel_stat> kstats;
@@ -390,6 +390,30 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
     }
     p.n_units = (int)(units.size() / UNIT_INTS);
     p.n_parts = std::max(1, std::min(16, 1536 / std::max(1, p.n_units)));
+    // launch order: the tiles of ONE item chunk read the same P rows (shared by its k tiles) and Q rows (shared by its o tiles); workgroups b and
+    // b + 8 run on the same XCD (round-robin dispatch), so a chunk's tiles are placed 8 apart on one XCD, back to back: the re-reads hit that
+    // XCD's L2 instead of the Infinity Cache (speed only)
+    std::vector<int32_t> order(p.n_units, 0);
+    {
+        std::vector<std::vector<int>> groups;      // units of one (target, item chunk)
+        for (Tgt& g : tgts) {
+            const int ntiles = (g.rows / TW) * ((g.K + TW - 1) / TW);
+            for (int c = 0; c < g.chunks; ++c) { std::vector<int> v; for (int t = 0; t < ntiles; ++t) v.push_back(g.unit0 + t * g.chunks + c); groups.push_back(v); }
+        }
+        std::vector<std::vector<int>> xq(8);
+        for (auto& v : groups) {      // to the XCD queue that is shortest so far
+            int best = 0; for (int x = 1; x < 8; ++x) if (xq[x].size() < xq[best].size()) best = x;
+            for (int un : v) xq[best].push_back(un);
+        }
+        std::vector<size_t> pos(8, 0);
+        int b = 0;
+        while (b < p.n_units) {       // block b -> queue b % 8; an exhausted queue borrows from the longest remaining one
+            const int x = b % 8;
+            int q = x;
+            if (pos[q] >= xq[q].size()) { q = 0; for (int y = 1; y < 8; ++y) if (xq[y].size() - pos[y] > xq[q].size() - pos[q]) q = y; }
+            order[b++] = xq[q][pos[q]++];
+        }
+    }
     auto add_fin = [&](int64_t dst, int rows, int cols, int ld, int kind, int unit0, int nunits, int row0) {
         fins.insert(fins.end(), {(int32_t)(dst & 0xffffffff), (int32_t)(dst >> 32), rows, cols, ld, kind, unit0, nunits, row0, 0, 0, 0}); };
     auto fin_matrix = [&](int64_t dst, int tg, int K) {      // one op per 128x128 tile of the destination matrix [Hd x K]
@@ -439,6 +463,7 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
     p.term_off = (int)T.size(); T.insert(T.end(), terms.begin(), terms.end());
     p.src_off = (int)T.size(); T.insert(T.end(), srcs.begin(), srcs.end());
     p.unit_off = (int)T.size(); T.insert(T.end(), units.begin(), units.end());
+    p.order_off = (int)T.size(); T.insert(T.end(), order.begin(), order.end());
     p.item_off = (int)T.size(); T.insert(T.end(), items.begin(), items.end());
     p.fin_off = (int)T.size(); T.insert(T.end(), fins.begin(), fins.end());
 
