@@ -89,12 +89,16 @@ __device__ __forceinline__ void raw8(const GArgs& a, int t, int node, int w, int
 // ------------------------------------------------------------------------------------------------------
 // k_gstep
 // ------------------------------------------------------------------------------------------------------
-template <bool SPLIT, int MB> __global__ __launch_bounds__(256) void k_gstep(GArgs a) {      // MB: 16-window row blocks per workgroup
+// MB: 16-window row blocks per workgroup; NW: waves -- wave wv owns the 32-column slice (wv & 3) of the 128-column pack tile ctg * (NW / 4) + (wv >> 2),
+// so a workgroup's output tile is MB * 16 windows x NW * 32 columns and the staged A tile is shared by all NW waves
+template <bool SPLIT, int MB, int NW> __global__ __launch_bounds__(64 * NW) void k_gstep(GArgs a) {
     using P = P16;
+    constexpr int CPW = NW / 4;                          // 128-column pack tiles per workgroup
     extern __shared__ __attribute__((aligned(16))) char smem[];      // blocks [0, MB): (hi) A tile; [MB, 2 MB): lo halves (split plan)
-    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ct = blockIdx.x % a.NCT, tile = (blockIdx.x / a.NCT) % a.tiles;
-    const int* job = a.jobs + (size_t)(a.job0 + blockIdx.x / (a.NCT * a.tiles)) * JOB_INTS;
+    const int tid = threadIdx.x, lane = tid & 63, wq = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nctg = a.NCT / CPW;
+    const int ct = (blockIdx.x % nctg) * CPW + (wq >> 2), wv = wq & 3, tile = (blockIdx.x / nctg) % a.tiles;
+    const int* job = a.jobs + (size_t)(a.job0 + blockIdx.x / (nctg * a.tiles)) * JOB_INTS;
     const int w0 = tile * MB * P::ROWS, B = a.B, Hd = a.Hd;
     const int flags = job[J_FLAGS];
     const T16* wpack = reinterpret_cast<const T16*>(a.wpack);
@@ -105,7 +109,9 @@ template <bool SPLIT, int MB> __global__ __launch_bounds__(256) void k_gstep(GAr
 #pragma unroll
         for (int m = 0; m < MB; ++m) acc_init_bias<T16>(acc[m], bias, wv, lane);
     }
-    const int c = tid & 15, r0 = tid >> 4;              // staging: thread = (row, 8-element chunk) of each row block
+    const int c = tid & 15, rr = tid >> 4;              // staging: thread = (row rr + 4 NW i of the tile, 8-element chunk c), i = 0 .. NPASS - 1
+    constexpr int NPASS = MB * 16 / (4 * NW);
+    static_assert(NPASS >= 1 && NPASS * 4 * NW == MB * 16, "row blocks must cover whole staging passes");
     const AOff<T16> ao(lane);
     P::BFrag bfh, bfl;
     P::AFrag af;
@@ -116,17 +122,18 @@ template <bool SPLIT, int MB> __global__ __launch_bounds__(256) void k_gstep(GAr
         for (int kc = 0; kc < nkc; ++kc) {
             __syncthreads();   // the previous chunk's MFMAs are done reading LDS
 #pragma unroll
-            for (int m0 = 0; m0 < MB; m0 += 4) {      // four row blocks at a time: their loads are in flight together
-                float s[4][8];
+            for (int i0 = 0; i0 < NPASS; i0 += 4) {      // four rows at a time: their loads are in flight together
+                constexpr int NB = NPASS < 4 ? NPASS : 4;
+                float s[NB][8];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int w = min(w0 + (m0 + i) * P::ROWS + r0, B - 1);      // rows past the batch re-read the last window; they are never stored
+                for (int i = 0; i < NB; ++i) {
+                    const int w = min(w0 + (i0 + i) * (4 * NW) + rr, B - 1);      // rows past the batch re-read the last window; they are never stored
                     if (kind == 0) gather8<SPLIT>(a, src, n_src, w, kc * TW + c * 8, s[i]);
                     else raw8<SPLIT>(a, src[S_BUF], src[S_NODE], w, kc * TW + c * 8, F, a.signs + term[T_SIGN] + kc * TW + c * 8, s[i]);
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int m = m0 + i;
+                for (int i = 0; i < NB; ++i) {
+                    const int grow = (i0 + i) * (4 * NW) + rr, m = grow >> 4, r0 = grow & 15;
                     const f32x4 lo4 = f32x4{s[i][0], s[i][1], s[i][2], s[i][3]}, hi4 = f32x4{s[i][4], s[i][5], s[i][6], s[i][7]};
                     if constexpr (SPLIT) {
                         u32x4 hi, lo;
@@ -573,8 +580,7 @@ int gen_create(mshgnn_plan* p, const mshgnn_desc* desc) {
         (rc = up((void**)&g->d_biases, gp.biases.data(), gp.biases.size() * sizeof(BiasDesc))) != 0) return rc;
     const int dec_lds = 16 * 8 * TW * 4;
     if ((rc = set_lds_attr(k_gdec_bwd<false>, dec_lds)) || (rc = set_lds_attr(k_gdec_bwd<true>, dec_lds)) ||
-        (rc = set_lds_attr(k_gstep<true, 16>, 32 * P16::BLK)) || (rc = set_lds_attr(k_gstep<false, 16>, 16 * P16::BLK)) ||
-        (rc = set_lds_attr(k_gstep<true, 8>, 16 * P16::BLK))) return rc;
+        (rc = set_lds_attr(k_gstep<true, 8, 8>, 16 * P16::BLK))) return rc;
     return MSHGNN_OK;
 }
 
@@ -627,31 +633,39 @@ static int g_fill(const mshgnn_plan* p, const mshgnn_ws_layout& lay, const void*
     return MSHGNN_OK;
 }
 
-static int g_tile_blocks(int B) {
-    static const int forced = [] { const char* e = getenv("MSHGNN_GEN_MB"); return e ? atoi(e) : 0; }();      // (kernel experiments)
-    if (forced == 4 || forced == 8 || forced == 16) return forced;
-    // measured (synthetic 32-limb, h=512, B=1024, bf16): layer_fwd 518 / 756 / 1217 us at 4 / 8 / 16 row blocks -- the kernel is bound by the
-    // exposed latency of the staging loads, so more, smaller workgroups win until the staging is software-pipelined
-    (void)B; return 4;
+static int g_tile_blocks(int B, bool split) {
+    static const int forced = [] { const char* e = getenv("MSHGNN_GEN_TILE"); return e ? atoi(e) : -1; }();      // (kernel experiments)
+    if (forced >= 0 && forced <= 3) return forced;
+    (void)B; return split ? 2 : 3;      // the widest column tile the hidden width and the registers allow (16 waves of the split kernel spill)
 }
 
 static void g_launch_jobs(const mshgnn_plan* p, const Launch& ln, GArgs a, hipStream_t st) {
     const GenPlan& gp = p->gen->gp;
     a.job0 = ln.job0;
     // windows per workgroup: a packed weight fragment (8 KB per wave and K chunk, from L2) is reused for every 16-window row block of the tile
-    const int mb = g_tile_blocks(a.B);
+    // output tile of a workgroup: 64 windows x (32 NW) columns.  The staged A tile is shared by all NW waves, so wider tiles re-read the
+    // activations fewer times (hidden / (32 NW) column groups per row of jobs): measured at h=512, B=1024: layer_fwd bf16 515 / 354 / 296 us at
+    // 4 / 8 / 16 waves, split 870 / 799 / 1012 us (16 waves: 128 VGPRs, spills); 128-window tiles lose (fewer resident workgroups hide less
+    // of the staging latency: 495 us at 8 waves)
+    const int mode = g_tile_blocks(a.B, gp.split);      // 0: 4 waves; 1: 8 waves, 128 windows; 2: 8 waves; 3: 16 waves
+    int nw = 4;
+    if ((mode == 1 || mode == 2) && gp.NCT % 2 == 0) nw = 8;
+    if (mode == 3) nw = gp.NCT % 4 == 0 ? 16 : (gp.NCT % 2 == 0 ? 8 : 4);
+    const int mb = (nw == 8 && mode == 1) ? 8 : 4;
     a.tiles = (a.B + mb * 16 - 1) / (mb * 16);
-    const unsigned grid = (unsigned)ln.n_jobs * a.tiles * a.NCT;
+    const unsigned grid = (unsigned)ln.n_jobs * a.tiles * (a.NCT / (nw / 4));
     const int lds = mb * P16::BLK * (gp.split ? 2 : 1);
     ProfScope ps(p, ln.ks, st);
     if (gp.split) {
-        if (mb == 16) hipLaunchKernelGGL((k_gstep<true, 16>), dim3(grid), dim3(256), lds, st, a);
-        else if (mb == 8) hipLaunchKernelGGL((k_gstep<true, 8>), dim3(grid), dim3(256), lds, st, a);
-        else hipLaunchKernelGGL((k_gstep<true, 4>), dim3(grid), dim3(256), lds, st, a);
+        if (nw == 16) hipLaunchKernelGGL((k_gstep<true, 4, 16>), dim3(grid), dim3(1024), lds, st, a);
+        else if (nw == 8 && mb == 8) hipLaunchKernelGGL((k_gstep<true, 8, 8>), dim3(grid), dim3(512), lds, st, a);
+        else if (nw == 8) hipLaunchKernelGGL((k_gstep<true, 4, 8>), dim3(grid), dim3(512), lds, st, a);
+        else hipLaunchKernelGGL((k_gstep<true, 4, 4>), dim3(grid), dim3(256), lds, st, a);
     } else {
-        if (mb == 16) hipLaunchKernelGGL((k_gstep<false, 16>), dim3(grid), dim3(256), lds, st, a);
-        else if (mb == 8) hipLaunchKernelGGL((k_gstep<false, 8>), dim3(grid), dim3(256), lds, st, a);
-        else hipLaunchKernelGGL((k_gstep<false, 4>), dim3(grid), dim3(256), lds, st, a);
+        if (nw == 16) hipLaunchKernelGGL((k_gstep<false, 4, 16>), dim3(grid), dim3(1024), lds, st, a);
+        else if (nw == 8 && mb == 8) hipLaunchKernelGGL((k_gstep<false, 8, 8>), dim3(grid), dim3(512), lds, st, a);
+        else if (nw == 8) hipLaunchKernelGGL((k_gstep<false, 4, 8>), dim3(grid), dim3(512), lds, st, a);
+        else hipLaunchKernelGGL((k_gstep<false, 4, 4>), dim3(grid), dim3(256), lds, st, a);
     }
 }
 
