@@ -28,9 +28,9 @@ struct mshgnn_gen_state {      // device side of a generic plan
 struct GArgs {
     char* ws; size_t buf_off[GBUF_COUNT];
     const void* x[MSHGNN_MAX_TYPES]; int64_t pitch[MSHGNN_MAX_TYPES]; int nodes[MSHGNN_MAX_TYPES]; int vb[MSHGNN_MAX_TYPES]; int aligned;
-    const int* jobs; const int* terms; const int* srcs; const int* units; const int* items; const int* unit_order;
+    const int* jobs; const int* terms; const int* srcs; const int* units; const int* items; const int* sunits;
     const void* wpack; const float* bias; const uint8_t* signs; float* slabs;
-    int n_img, B, Hd, NCT, tiles, training, job0, n_units, n_parts;
+    int n_img, B, Hd, NCT, tiles, training, job0, n_units, n_parts, n_sunits;
 };
 
 // element index of (window w, node, column 0) in an activation tensor: rows are Hd wide, or [hi Hd | lo Hd] on the split plan
@@ -342,25 +342,39 @@ template <bool SPLIT> __global__ __launch_bounds__(256) void k_gdec_bwd(GDecArgs
 }
 
 // ------------------------------------------------------------------------------------------------------
-// k_ggradw: dW tile [128 x 128] = sum over the unit's items and its part of the batch of P^T Q
-// Steps = (item, 32-window chunk) pairs; the global loads of step s + NST run in registers, untouched, while step s is multiplied (P rows always;
-// Q rows when the item has one source -- raw input or a single activation row; aggregated Q rows are gathered at staging time).
+// k_ggradw: one SUPER-UNIT per workgroup = OS x 2 adjacent 128x128 tiles of one target's weight gradient, dW = P^T Q summed over a chunk of
+// the target's items and a part of the batch.  4 OS x 4 waves, each a 64x64 piece; the P rows [32 windows x 128 OS] and the Q rows [32 x 256]
+// of a step are staged ONCE for all of them.  Steps = (item, 32-window chunk) pairs; the global loads of the next step(s) run in registers,
+// untouched, while a step is multiplied (P rows always; Q rows when the item has one source; aggregated Q rows are gathered at staging time).
 // ------------------------------------------------------------------------------------------------------
-template <bool SPLIT> __global__ __launch_bounds__(256, SPLIT ? 2 : 3) void k_ggradw(GArgs a) {
-    constexpr int KW = 32, NP = KW / 16, NST = 2;
-    __shared__ __attribute__((aligned(16))) __bf16 Ph[KW * GWB_PITCH];
-    __shared__ __attribute__((aligned(16))) __bf16 Qh[KW * GWB_PITCH];
-    __shared__ __attribute__((aligned(16))) __bf16 Pl[SPLIT ? KW * GWB_PITCH : 8];
-    __shared__ __attribute__((aligned(16))) __bf16 Ql[SPLIT ? KW * GWB_PITCH : 8];
+template <bool SPLIT, int OS> __global__ __launch_bounds__(512 * OS) void k_ggradw(GArgs a) {
+    constexpr int KW = 32, NT = 512 * OS, PC = 16 * OS;      // PC: 16-byte chunks per staged P row
+    constexpr int NQ = KW * 32 / NT;                         // Q chunks per thread (1 with 1024 threads, 2 with 512); P: one chunk per thread
+#ifndef GGW_NST_SPLIT
+#define GGW_NST_SPLIT 2
+#endif
+#ifndef GGW_NST_BF16
+#define GGW_NST_BF16 1      // (two stages at 16 waves: 128 VGPRs with 60 B of scratch, 3.29 ms against 2.27 ms at h=512)
+#endif
+    constexpr int NST = OS == 2 ? 1 : (SPLIT ? GGW_NST_SPLIT : GGW_NST_BF16);      // register stages (16 waves: 128 VGPRs, one stage)
+    constexpr int TSZ = KW * GWB_PITCH;                      // one staged 32 x 128 tile
+    __shared__ __attribute__((aligned(16))) __bf16 tiles_h[(OS + 2) * TSZ];      // P sub-tiles [0, OS), Q sub-tiles [OS, OS + 2) (one buffer: the bias reduction reuses it)
+    __shared__ __attribute__((aligned(16))) __bf16 tiles_l[SPLIT ? (OS + 2) * TSZ : 8];
+    auto Ph = [&](int t) { return tiles_h + t * TSZ; };
+    auto Qh = [&](int t) { return tiles_h + (OS + t) * TSZ; };
+    auto Pl = [&](int t) { return tiles_l + (SPLIT ? t * TSZ : 0); };
+    auto Ql = [&](int t) { return tiles_l + (SPLIT ? (OS + t) * TSZ : 0); };
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wv >> 1, wc = wv & 1;
-    const int un = a.unit_order[blockIdx.x % a.n_units], part = blockIdx.x / a.n_units;
-    const int* u = a.units + (size_t)un * UNIT_INTS;
-    const int it0 = u[U_ITEM0], pcol = u[U_PCOL], qcol = u[U_QCOL], qn = u[U_QN], bias_flag = u[U_BIAS];
+    const int wr = wv >> 2, wc = wv & 3;                     // wave (wr, wc): rows [64 wr, +64) of the o range, columns [64 wc, +64) of the k range
+    const int su_i = blockIdx.x % a.n_sunits, part = blockIdx.x / a.n_sunits;
+    const int* su = a.sunits + (size_t)su_i * SUNIT_INTS;
+    const int it0 = su[SU_ITEM0], pcol = su[SU_PCOL], qcol = su[SU_QCOL], qn = su[SU_QN];
     const int nchunks = (a.B + KW - 1) / KW;
     const int ch0 = (int)((int64_t)part * nchunks / a.n_parts), ch1 = (int)((int64_t)(part + 1) * nchunks / a.n_parts);
-    const int nch = ch1 - ch0, nsteps = (u[U_ITEM1] - it0) * nch;
-    const int c = tid & 15, r0 = tid >> 4, B = a.B, Hd = a.Hd;
+    const int nch = ch1 - ch0, nsteps = (su[SU_ITEM1] - it0) * nch;
+    const int B = a.B, Hd = a.Hd;
+    const int cp = tid % PC, rp = tid / PC;                  // P staging: (row rp < 32, chunk cp)
+    const int cq = tid & 31, rq = tid >> 5;                  // Q staging: (row rq + (NT / 32) i, chunk cq), i < NQ
     const int one_bits = __float_as_int(1.0f);
     f32x16 acc[2][2];
 #pragma unroll
@@ -373,9 +387,8 @@ template <bool SPLIT> __global__ __launch_bounds__(256, SPLIT ? 2 : 3) void k_gg
 #pragma unroll
     for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
 
-    struct Stage { u32x4 pa[NP], pb[NP], qa[NP], qb[NP]; unsigned mw[NP]; };      // a: bf16 chunk / hi half / first four fp32; b: lo half / next four fp32
-    // Q kind of an item: 1 raw input, 0 single activation source, 2 aggregate
-    auto q_kind = [&](const int* im) {
+    struct Stage { u32x4 pa, pb, qa[NQ], qb[NQ]; unsigned mw; };      // a: bf16 chunk / hi half / first four fp32; b: lo half / next four fp32
+    auto q_kind = [&](const int* im) {      // 1 raw input, 0 single activation source, 2 aggregate
         if (im[I_KIND] == 1) return 1;
         const int* src = a.srcs + (size_t)im[I_SRC0] * SRC_INTS;
         return (im[I_NSRC] == 1 && src[S_SCALE] == one_bits) ? 0 : 2; };
@@ -383,30 +396,34 @@ template <bool SPLIT> __global__ __launch_bounds__(256, SPLIT ? 2 : 3) void k_gg
         const int* im = a.items + (size_t)(it0 + s / nch) * GITEM_INTS;
         const int* src = a.srcs + (size_t)im[I_SRC0] * SRC_INTS;
         const int w0 = (ch0 + s % nch) * KW, qk = q_kind(im);
-        const T16* pbase = reinterpret_cast<const T16*>(a.ws + a.buf_off[im[I_PBUF]]) + pcol + c * 8;
-        const uint8_t* mb = im[I_PMASK] >= 0 ? reinterpret_cast<const uint8_t*>(a.ws + a.buf_off[im[I_PMASK]]) : nullptr;
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            const int w = w0 + r0 + 16 * p;
-            st.pa[p] = u32x4{0, 0, 0, 0}; st.pb[p] = u32x4{0, 0, 0, 0}; st.qa[p] = u32x4{0, 0, 0, 0}; st.qb[p] = u32x4{0, 0, 0, 0}; st.mw[p] = 0xffu;
+        st.pa = u32x4{0, 0, 0, 0}; st.pb = u32x4{0, 0, 0, 0}; st.mw = 0xffu;
+        {
+            const int w = w0 + rp;
             if (w < B) {
-                const T16* pr = pbase + g_row<SPLIT>(w, im[I_PNODE], B, Hd);
-                st.pa[p] = *reinterpret_cast<const u32x4*>(pr);
-                if constexpr (SPLIT) st.pb[p] = *reinterpret_cast<const u32x4*>(pr + Hd);
-                if (mb) st.mw[p] = mb[g_relu_byte(im[I_PNODE], B, Hd, w, pcol + c * 8)];
+                const T16* pr = reinterpret_cast<const T16*>(a.ws + a.buf_off[im[I_PBUF]]) + g_row<SPLIT>(w, im[I_PNODE], B, Hd) + pcol + cp * 8;
+                st.pa = *reinterpret_cast<const u32x4*>(pr);
+                if constexpr (SPLIT) st.pb = *reinterpret_cast<const u32x4*>(pr + Hd);
+                if (im[I_PMASK] >= 0) st.mw = reinterpret_cast<const uint8_t*>(a.ws + a.buf_off[im[I_PMASK]])[g_relu_byte(im[I_PNODE], B, Hd, w, pcol + cp * 8)];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int w = w0 + rq + (NT / 32) * i;
+            st.qa[i] = u32x4{0, 0, 0, 0}; st.qb[i] = u32x4{0, 0, 0, 0};
+            if (w < B && cq * 8 < qn) {
                 if (qk == 0) {
-                    const T16* qr = reinterpret_cast<const T16*>(a.ws + a.buf_off[src[S_BUF]]) + g_row<SPLIT>(w, src[S_NODE], B, Hd) + qcol + c * 8;
-                    st.qa[p] = *reinterpret_cast<const u32x4*>(qr);
-                    if constexpr (SPLIT) st.qb[p] = *reinterpret_cast<const u32x4*>(qr + Hd);
+                    const T16* qr = reinterpret_cast<const T16*>(a.ws + a.buf_off[src[S_BUF]]) + g_row<SPLIT>(w, src[S_NODE], B, Hd) + qcol + cq * 8;
+                    st.qa[i] = *reinterpret_cast<const u32x4*>(qr);
+                    if constexpr (SPLIT) st.qb[i] = *reinterpret_cast<const u32x4*>(qr + Hd);
                 } else if (qk == 1) {
-                    const int t = src[S_BUF], nv = qn - c * 8;
+                    const int t = src[S_BUF], nv = qn - cq * 8;
                     if constexpr (SPLIT) {
-                        const float* qr = reinterpret_cast<const float*>(a.x[t]) + ((size_t)w * a.nodes[t] + src[S_NODE]) * a.pitch[t] + qcol + c * 8;
-                        st.qa[p] = load_chunk<float>(qr, nv, a.vb[t]);
-                        st.qb[p] = load_chunk<float>(qr + 4, nv - 4, a.vb[t]);
+                        const float* qr = reinterpret_cast<const float*>(a.x[t]) + ((size_t)w * a.nodes[t] + src[S_NODE]) * a.pitch[t] + qcol + cq * 8;
+                        st.qa[i] = load_chunk<float>(qr, nv, a.vb[t]);
+                        st.qb[i] = load_chunk<float>(qr + 4, nv - 4, a.vb[t]);
                     } else {
-                        const T16* qr = reinterpret_cast<const T16*>(a.x[t]) + ((size_t)w * a.nodes[t] + src[S_NODE]) * a.pitch[t] + qcol + c * 8;
-                        st.qa[p] = load_chunk<T16>(qr, nv, a.vb[t]);
+                        const T16* qr = reinterpret_cast<const T16*>(a.x[t]) + ((size_t)w * a.nodes[t] + src[S_NODE]) * a.pitch[t] + qcol + cq * 8;
+                        st.qa[i] = load_chunk<T16>(qr, nv, a.vb[t]);
                     }
                 }
             }
@@ -416,102 +433,131 @@ template <bool SPLIT> __global__ __launch_bounds__(256, SPLIT ? 2 : 3) void k_gg
         const int* im = a.items + (size_t)(it0 + s / nch) * GITEM_INTS;
         const int* src = a.srcs + (size_t)im[I_SRC0] * SRC_INTS;
         const int w0 = (ch0 + s % nch) * KW, qk = q_kind(im);
-        const bool masked = im[I_PMASK] >= 0;
+        {
+            u32x4 ph = st.pa, pl = st.pb;
+            if (im[I_PMASK] >= 0) { ph = chunk_mask_bits<T16>(ph, st.mw); if constexpr (SPLIT) pl = chunk_mask_bits<T16>(pl, st.mw); }     // dH = dX . relu bits
+            *reinterpret_cast<u32x4*>(Ph(cp >> 4) + gwb_elem(rp, (cp & 15) * 8)) = ph;
+            if constexpr (SPLIT) *reinterpret_cast<u32x4*>(Pl(cp >> 4) + gwb_elem(rp, (cp & 15) * 8)) = pl;
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            const int row = r0 + 16 * p, w = w0 + row;
-            u32x4 ph = st.pa[p], pl = st.pb[p];
-            if (masked) { ph = chunk_mask_bits<T16>(ph, st.mw[p]); if constexpr (SPLIT) pl = chunk_mask_bits<T16>(pl, st.mw[p]); }     // dH = dX . relu bits
-            *reinterpret_cast<u32x4*>(&Ph[gwb_elem(row, c * 8)]) = ph;
-            if constexpr (SPLIT) *reinterpret_cast<u32x4*>(&Pl[gwb_elem(row, c * 8)]) = pl;
-            u32x4 qh = st.qa[p], ql = st.qb[p];
+            for (int e = 0; e < 4; ++e) {      // column sums of P (bias gradients of the kt == 0 units; cheap enough to keep unconditional)
+                bsum[2 * e] += __builtin_bit_cast(float, ph[e] << 16) + (SPLIT ? __builtin_bit_cast(float, pl[e] << 16) : 0.f);
+                bsum[2 * e + 1] += __builtin_bit_cast(float, ph[e] & 0xffff0000u) + (SPLIT ? __builtin_bit_cast(float, pl[e] & 0xffff0000u) : 0.f);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int row = rq + (NT / 32) * i, w = w0 + row;
+            u32x4 qh = st.qa[i], ql = st.qb[i];
             if (qk == 1) {          // raw input: pad columns dropped, symmetry sign, (split plan) fp32 -> hi / lo
-                const int nv = qn - c * 8;
-                const uint8_t* sg = a.signs + src[S_MASK] + qcol + c * 8;
-                if constexpr (SPLIT) {
-                    const u32x4 fa = chunk_keep_first<float>(st.qa[p], nv) ^ sign_xor<float>(sg), fb = chunk_keep_first<float>(st.qb[p], nv - 4) ^ sign_xor<float>(sg + 4);
-                    split_oct(__builtin_bit_cast(f32x4, fa), __builtin_bit_cast(f32x4, fb), qh, ql);
-                } else qh = chunk_keep_first<T16>(st.qa[p], nv) ^ sign_xor<T16>(sg);
+                const int nv = qn - cq * 8;
+                const uint8_t* sg = a.signs + src[S_MASK] + qcol + cq * 8;
+                if (nv > 0) {
+                    if constexpr (SPLIT) {
+                        const u32x4 fa = chunk_keep_first<float>(st.qa[i], nv) ^ sign_xor<float>(sg), fb = chunk_keep_first<float>(st.qb[i], nv - 4) ^ sign_xor<float>(sg + 4);
+                        split_oct(__builtin_bit_cast(f32x4, fa), __builtin_bit_cast(f32x4, fb), qh, ql);
+                    } else qh = chunk_keep_first<T16>(st.qa[i], nv) ^ sign_xor<T16>(sg);
+                }
             } else if (qk == 2) {   // aggregate: fp32 sum (mean: scaled) of the source rows, gathered now
                 float qs[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) qs[e] = 0.f;
-                if (w < B) gather8<SPLIT>(a, src, im[I_NSRC], w, qcol + c * 8, qs);
+                if (w < B && cq * 8 < qn) gather8<SPLIT>(a, src, im[I_NSRC], w, qcol + cq * 8, qs);
                 const f32x4 q0 = f32x4{qs[0], qs[1], qs[2], qs[3]}, q1 = f32x4{qs[4], qs[5], qs[6], qs[7]};
                 if constexpr (SPLIT) split_oct(q0, q1, qh, ql); else qh = pack_oct(q0, q1);
             }
-            *reinterpret_cast<u32x4*>(&Qh[gwb_elem(row, c * 8)]) = qh;
-            if constexpr (SPLIT) *reinterpret_cast<u32x4*>(&Ql[gwb_elem(row, c * 8)]) = ql;
-            if (bias_flag) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    bsum[2 * e] += __builtin_bit_cast(float, ph[e] << 16) + (SPLIT ? __builtin_bit_cast(float, pl[e] << 16) : 0.f);
-                    bsum[2 * e + 1] += __builtin_bit_cast(float, ph[e] & 0xffff0000u) + (SPLIT ? __builtin_bit_cast(float, pl[e] & 0xffff0000u) : 0.f);
-                }
-            }
+            *reinterpret_cast<u32x4*>(Qh(cq >> 4) + gwb_elem(row, (cq & 15) * 8)) = qh;
+            if constexpr (SPLIT) *reinterpret_cast<u32x4*>(Ql(cq >> 4) + gwb_elem(row, (cq & 15) * 8)) = ql;
         }
     };
+    const __bf16* Pt = Ph(wr >> 1); const __bf16* Qt = Qh(wc >> 1);
+    const __bf16* Plt = Pl(wr >> 1); const __bf16* Qlt = Ql(wc >> 1);
+    const int my_unit = su[SU_UNIT + (wr >> 1) * 2 + (wc >> 1)];      // the 128x128 sub-tile this wave belongs to (-1: beyond the matrix edge)
     auto mfmas = [&]() {
+        if (my_unit < 0) return;      // (wave-uniform)
 #pragma unroll
         for (int ks = 0; ks < KW / 16; ++ks) {
-            bf16x8 afh[2], bqh[2], afl[2], bql[2];
+            if constexpr (SPLIT) {      // Q fragments one column block at a time: 24 fragment registers live instead of 32
+                bf16x8 afh[2], afl[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                afh[i] = tr_frag(Ph, ks * 16, wr * 64 + i * 32, lane);
-                bqh[i] = tr_frag(Qh, ks * 16, wc * 64 + i * 32, lane);
-                if constexpr (SPLIT) { afl[i] = tr_frag(Pl, ks * 16, wr * 64 + i * 32, lane); bql[i] = tr_frag(Ql, ks * 16, wc * 64 + i * 32, lane); }
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i) { afh[i] = tr_frag(Pt, ks * 16, (wr & 1) * 64 + i * 32, lane); afl[i] = tr_frag(Plt, ks * 16, (wr & 1) * 64 + i * 32, lane); }
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afh[i], bqh[j], acc[i][j], 0, 0, 0);
-                    if constexpr (SPLIT) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afh[i], bql[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afl[i], bqh[j], acc[i][j], 0, 0, 0);
+                    const bf16x8 bqh = tr_frag(Qt, ks * 16, (wc & 1) * 64 + j * 32, lane), bql = tr_frag(Qlt, ks * 16, (wc & 1) * 64 + j * 32, lane);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afh[i], bqh, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afh[i], bql, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afl[i], bqh, acc[i][j], 0, 0, 0);
                     }
                 }
+            } else {
+                bf16x8 afh[2], bqh[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) { afh[i] = tr_frag(Pt, ks * 16, (wr & 1) * 64 + i * 32, lane); bqh[i] = tr_frag(Qt, ks * 16, (wc & 1) * 64 + i * 32, lane); }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afh[i], bqh[j], acc[i][j], 0, 0, 0);
+            }
         }
     };
-    static_assert(NST == 2, "two register stages");
-    Stage sa, sb;
-    if (nsteps > 0) fetch(sa, 0);
-    if (nsteps > 1) fetch(sb, 1);
-    for (int s = 0; s < nsteps; s += 2) {
-        __syncthreads();      // the previous MFMA phase is done reading the tiles
-        stage_to_lds(sa, s);
-        __syncthreads();
-        if (s + 2 < nsteps) fetch(sa, s + 2);
-        mfmas();
-        if (s + 1 < nsteps) {
+    if constexpr (NST == 2) {
+        Stage sa, sb;
+        if (nsteps > 0) fetch(sa, 0);
+        if (nsteps > 1) fetch(sb, 1);
+        for (int s = 0; s < nsteps; s += 2) {
+            __syncthreads();      // the previous MFMA phase is done reading the tiles
+            stage_to_lds(sa, s);
             __syncthreads();
-            stage_to_lds(sb, s + 1);
+            if (s + 2 < nsteps) fetch(sa, s + 2);
+            mfmas();
+            if (s + 1 < nsteps) {
+                __syncthreads();
+                stage_to_lds(sb, s + 1);
+                __syncthreads();
+                if (s + 3 < nsteps) fetch(sb, s + 3);
+                mfmas();
+            }
+        }
+    } else {
+        Stage sa;
+        if (nsteps > 0) fetch(sa, 0);
+        for (int s = 0; s < nsteps; ++s) {
             __syncthreads();
-            if (s + 3 < nsteps) fetch(sb, s + 3);
+            stage_to_lds(sa, s);
+            __syncthreads();
+            if (s + 1 < nsteps) fetch(sa, s + 1);
             mfmas();
         }
     }
-    float* slab = a.slabs + ((size_t)part * a.n_units + un) * SLAB_FLOATS;
+    if (my_unit >= 0) {
+        float* slab = a.slabs + ((size_t)part * a.n_units + my_unit) * SLAB_FLOATS;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int o = wr * 64 + i * 32 + (q & 3) + ((q >> 2) << 3) + ((lane >> 5) << 2), k = wc * 64 + j * 32 + (lane & 31);
-                slab[o * H + k] = acc[i][j][q];
+                for (int q = 0; q < 16; ++q) {
+                    const int o = (wr & 1) * 64 + i * 32 + (q & 3) + ((q >> 2) << 3) + ((lane >> 5) << 2), k = (wc & 1) * 64 + j * 32 + (lane & 31);
+                    slab[o * H + k] = acc[i][j][q];
+                }
+    }
+    // bias gradients: column sums of the staged P rows, into the slab of the k-tile-0 unit of each o sub-tile (the only ones the finalize reads)
+    if (qcol == 0) {      // (uniform: super-units that hold k tile 0)
+        float* red = reinterpret_cast<float*>(tiles_h);      // [32 rows][128 OS] floats
+        static_assert(sizeof(float) * 32 * 128 * OS <= sizeof(__bf16) * (OS + 2) * TSZ, "bias reduction buffer fits the P and Q tiles");
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[rp * (128 * OS) + cp * 8 + e] = bsum[e];
+        __syncthreads();
+        if (tid < 128 * OS) {
+            const int un = su[SU_UNIT + (tid >> 7) * 2];
+            if (un >= 0) {
+                float s2 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 32; ++r) s2 += red[r * (128 * OS) + tid];
+                a.slabs[((size_t)part * a.n_units + un) * SLAB_FLOATS + H * H + (tid & 127)] = s2;
             }
-    if (bias_flag) {
-        float* red = reinterpret_cast<float*>(Ph);   // 16 x 128 floats = 8 KB = one tile
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < 8; ++e) red[r0 * H + c * 8 + e] = bsum[e];
-        __syncthreads();
-        if (tid < H) {
-            float s2 = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s2 += red[r * H + tid];
-            slab[H * H + tid] = s2;
         }
     }
 }
@@ -523,7 +569,7 @@ __global__ __launch_bounds__(256) void k_gfinalize(GFinArgs a) {
     const int64_t dst = (int64_t)(unsigned)f[GF_DST_LO] | ((int64_t)f[GF_DST_HI] << 32);
     const int rows = f[GF_ROWS], cols = f[GF_COLS], ld = f[GF_LD], kind = f[GF_KIND], u0 = f[GF_UNIT0], nu = f[GF_NUNITS];
     const int SF = 8 * a.Hd + 16;
-    if (a.loss && blockIdx.x == 0 && threadIdx.x < 64) {   // fused loss: sum the per-block partials of the decoder backward
+    if (a.loss && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) {   // fused loss: sum the per-block partials of the decoder backward
         float l = 0.f;
         for (int b = threadIdx.x; b < NWG_DEC; b += 64) l += a.dec_slabs[(size_t)b * SF + 8 * a.Hd + 8];
 #pragma unroll
@@ -531,6 +577,7 @@ __global__ __launch_bounds__(256) void k_gfinalize(GFinArgs a) {
         if (threadIdx.x == 0) *a.loss = l * a.inv_n;
     }
     if (kind == FIN_DEC_W || kind == FIN_DEC_B) {      // one decoder row piece: f[8] = its offset inside a decoder slab
+        if (blockIdx.y != 0) return;
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         for (int e = wave; e < rows * cols; e += 4) {
             const int r = e / cols, cidx = e % cols;
@@ -543,13 +590,23 @@ __global__ __launch_bounds__(256) void k_gfinalize(GFinArgs a) {
         }
         return;
     }
-    for (int i = threadIdx.x; i < rows * cols; i += 256) {
-        const int r = i / cols, cidx = i % cols;
+    // rows of the op are dealt to the gridDim.y workgroups of this op; per element a fixed-order sum over the (part, unit) slabs, 4 in flight
+    const int rpb = (rows + gridDim.y - 1) / gridDim.y, r_lo = blockIdx.y * rpb, r_hi = min(rows, r_lo + rpb);
+    for (int i = threadIdx.x; i < (r_hi - r_lo) * cols; i += 256) {
+        const int r = r_lo + i / cols, cidx = i % cols;
         float s = 0.f;
         if (kind == FIN_MATRIX || kind == FIN_BIAS) {
             const int src = kind == FIN_MATRIX ? r * H + cidx : H * H + cidx;
-            for (int part = 0; part < a.n_parts; ++part)
-                for (int k = 0; k < nu; ++k) s += a.slabs[((size_t)part * a.n_units + u0 + k) * SLAB_FLOATS + src];
+            const int total = a.n_parts * nu;      // slab t = part (t / nu), unit u0 + t % nu
+            for (int t0 = 0; t0 < total; t0 += 4) {
+                float v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int t = t0 + q;
+                    v[q] = t < total ? a.slabs[((size_t)(t / nu) * a.n_units + u0 + t % nu) * SLAB_FLOATS + src] : 0.f;
+                }
+                s += (v[0] + v[1]) + (v[2] + v[3]);
+            }
         }
         a.grad[dst + (int64_t)r * ld + cidx] = s;
     }
@@ -625,11 +682,11 @@ static int g_fill(const mshgnn_plan* p, const mshgnn_ws_layout& lay, const void*
         a.vb[t] = vec_bytes(x[t], a.pitch[t], in_es);
     }
     a.jobs = g->d_tables + gp.job_off; a.terms = g->d_tables + gp.term_off; a.srcs = g->d_tables + gp.src_off;
-    a.units = g->d_tables + gp.unit_off; a.items = g->d_tables + gp.item_off; a.unit_order = g->d_tables + gp.order_off;
+    a.units = g->d_tables + gp.unit_off; a.items = g->d_tables + gp.item_off; a.sunits = g->d_tables + gp.sunit_off;
     a.wpack = ws + lay.wpack; a.bias = reinterpret_cast<const float*>(ws + lay.bias); a.signs = g->d_signs;
     a.slabs = reinterpret_cast<float*>(ws + lay.slabs);
     a.n_img = gp.n_img; a.B = B; a.Hd = gp.Hd; a.NCT = gp.NCT; a.tiles = (B + 63) / 64; a.training = training;
-    a.n_units = gp.n_units; a.n_parts = gp.n_parts;
+    a.n_units = gp.n_units; a.n_parts = gp.n_parts; a.n_sunits = gp.n_sunits;
     return MSHGNN_OK;
 }
 
@@ -724,15 +781,17 @@ int gen_backward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pi
     for (const Launch& ln : gp.bwd) g_launch_jobs(p, ln, a, st);
     {
         ProfScope ps(p, gp.ks_gradw, st);
-        const unsigned grid = (unsigned)gp.n_units * gp.n_parts;
-        if (gp.split) hipLaunchKernelGGL(k_ggradw<true>, dim3(grid), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(k_ggradw<false>, dim3(grid), dim3(256), 0, st, a);
+        const unsigned grid = (unsigned)gp.n_sunits * gp.n_parts;
+        if (gp.split && gp.su_os == 2) hipLaunchKernelGGL((k_ggradw<true, 2>), dim3(grid), dim3(1024), 0, st, a);
+        else if (gp.split) hipLaunchKernelGGL((k_ggradw<true, 1>), dim3(grid), dim3(512), 0, st, a);
+        else if (gp.su_os == 2) hipLaunchKernelGGL((k_ggradw<false, 2>), dim3(grid), dim3(1024), 0, st, a);
+        else hipLaunchKernelGGL((k_ggradw<false, 1>), dim3(grid), dim3(512), 0, st, a);
     }
     {
         GFinArgs fa{g->d_tables + gp.fin_off, reinterpret_cast<const float*>(ws + lay.slabs), reinterpret_cast<const float*>(ws + lay.dec_slabs), gparams,
                     gp.n_units, gp.n_parts, gp.Hd, (y || labels) ? loss : nullptr, 1.0f / (float)((int64_t)B * n_out * (labels ? 1 : d.out_channels))};
         ProfScope ps(p, gp.ks_fin, st);
-        hipLaunchKernelGGL(k_gfinalize, dim3(gp.n_fin), dim3(256), 0, st, fa);
+        hipLaunchKernelGGL(k_gfinalize, dim3(gp.n_fin, 8), dim3(256), 0, st, fa);
     }
     HIPCHK(hipGetLastError());
     return MSHGNN_OK;

@@ -27,6 +27,7 @@ enum { T_PACK = 0, T_NKC, T_KIND, T_SRC0, T_NSRC, T_WIDTH, T_SIGN, TERM_INTS = 8
 enum { S_BUF = 0, S_NODE, S_MASK, S_SCALE, SRC_INTS = 4 };
 // weight-gradient unit = one 128x128 tile of one target over a chunk of its items: item_begin item_end p_col0 q_col0 | q_ncols bias_flag pad pad
 enum { U_ITEM0 = 0, U_ITEM1, U_PCOL, U_QCOL, U_QN, U_BIAS, UNIT_INTS = 8 };
+enum { SU_UNIT = 0, SU_ITEM0 = 4, SU_ITEM1, SU_PCOL, SU_QCOL, SU_QN, SUNIT_INTS = 12 };
 // item: p_buf p_node p_mask_buf kind(0 activation sources, 1 raw input) | src_begin n_src pad pad
 enum { I_PBUF = 0, I_PNODE, I_PMASK, I_KIND, I_SRC0, I_NSRC, GITEM_INTS = 8 };
 // finalize op: dst_lo dst_hi rows cols | ld kind unit_begin n_units | src_row0 pad pad pad     (units of one target tile are consecutive)
@@ -51,7 +52,7 @@ struct GenPlan {
     std::vector<BiasDesc> biases;
     std::vector<uint8_t> signs; std::vector<int> sign_off, enc_nkc;
     std::vector<int32_t> tables;            // jobs | terms | srcs | units | items | fins
-    int job_off = 0, term_off = 0, src_off = 0, unit_off = 0, order_off = 0, item_off = 0, fin_off = 0, n_units = 0, n_parts = 1, n_fin = 0;
+    int job_off = 0, term_off = 0, src_off = 0, unit_off = 0, sunit_off = 0, n_sunits = 0, su_os = 1, item_off = 0, fin_off = 0, n_units = 0, n_parts = 1, n_fin = 0;
     std::vector<Launch> fwd, bwd;           // job launches in order
     int ks_prep = 0, ks_dec_fwd = 0, ks_dec_bwd = 0, ks_gradw = 0, ks_fin = 0;
     std::vector<mshgnn_kernel_stat> kstats;
@@ -389,31 +390,29 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
                                                (g.bias && kt == 0) ? 1 : 0, 0, 0});
     }
     p.n_units = (int)(units.size() / UNIT_INTS);
-    p.n_parts = std::max(1, std::min(16, 1536 / std::max(1, p.n_units)));
-    // launch order: the tiles of ONE item chunk read the same P rows (shared by its k tiles) and Q rows (shared by its o tiles); workgroups b and
-    // b + 8 run on the same XCD (round-robin dispatch), so a chunk's tiles are placed 8 apart on one XCD, back to back: the re-reads hit that
-    // XCD's L2 instead of the Infinity Cache (speed only)
-    std::vector<int32_t> order(p.n_units, 0);
-    {
-        std::vector<std::vector<int>> groups;      // units of one (target, item chunk)
-        for (Tgt& g : tgts) {
-            const int ntiles = (g.rows / TW) * ((g.K + TW - 1) / TW);
-            for (int c = 0; c < g.chunks; ++c) { std::vector<int> v; for (int t = 0; t < ntiles; ++t) v.push_back(g.unit0 + t * g.chunks + c); groups.push_back(v); }
-        }
-        std::vector<std::vector<int>> xq(8);
-        for (auto& v : groups) {      // to the XCD queue that is shortest so far
-            int best = 0; for (int x = 1; x < 8; ++x) if (xq[x].size() < xq[best].size()) best = x;
-            for (int un : v) xq[best].push_back(un);
-        }
-        std::vector<size_t> pos(8, 0);
-        int b = 0;
-        while (b < p.n_units) {       // block b -> queue b % 8; an exhausted queue borrows from the longest remaining one
-            const int x = b % 8;
-            int q = x;
-            if (pos[q] >= xq[q].size()) { q = 0; for (int y = 1; y < 8; ++y) if (xq[y].size() - pos[y] > xq[q].size() - pos[q]) q = y; }
-            order[b++] = xq[q][pos[q]++];
-        }
+    // SUPER-UNITS = what one weight-gradient workgroup computes: OS x 2 adjacent 128x128 tiles of a target over one chunk of its items (OS = 2
+    // o-tiles with 16 waves on the bf16 plan, 1 with 8 waves on the split plan).  The P rows are staged once for the 2 k-tiles and the Q rows
+    // once for the OS o-tiles (a quarter / three eighths of the operand traffic of one workgroup per tile); every 128x128 sub-tile keeps its own
+    // slab (the unit's), so the finalize tables do not change.  super-unit: unit[o][k] x4 (-1: absent) | item_begin item_end p_col0 q_col0 | q_ncols pad..
+    std::vector<int32_t> sunits;
+#ifndef GGW_SPLIT_OS2
+#define GGW_SPLIT_OS2 0      // (16 waves of the split kernel: 128 VGPRs with 164 B of scratch, 10.1 ms against 5.8 ms at h=512)
+#endif
+    p.su_os = ((!p.split || GGW_SPLIT_OS2) && NCT % 2 == 0) ? 2 : 1;
+    for (Tgt& g : tgts) {
+        const int n = (int)g.items.size(), nkt = (g.K + TW - 1) / TW, not_ = g.rows / TW, i0 = units[(size_t)g.unit0 * UNIT_INTS + U_ITEM0];
+        for (int c = 0; c < g.chunks; ++c)
+            for (int ot = 0; ot < not_; ot += p.su_os)
+                for (int kt = 0; kt < nkt; kt += 2) {
+                    int u[4] = {-1, -1, -1, -1};
+                    for (int a = 0; a < p.su_os; ++a) for (int b = 0; b < 2; ++b)
+                        if (ot + a < not_ && kt + b < nkt) u[a * 2 + b] = g.unit0 + ((ot + a) * nkt + kt + b) * g.chunks + c;
+                    sunits.insert(sunits.end(), {u[0], u[1], u[2], u[3], i0 + c * G_ITEMS_PER_UNIT, i0 + std::min(n, (c + 1) * G_ITEMS_PER_UNIT), ot * TW, kt * TW,
+                                                 std::min(2 * TW, g.K - kt * TW), 0, 0, 0});
+                }
     }
+    p.n_sunits = (int)(sunits.size() / SUNIT_INTS);
+    p.n_parts = std::max(1, std::min(16, 768 / std::max(1, p.n_sunits)));
     auto add_fin = [&](int64_t dst, int rows, int cols, int ld, int kind, int unit0, int nunits, int row0) {
         fins.insert(fins.end(), {(int32_t)(dst & 0xffffffff), (int32_t)(dst >> 32), rows, cols, ld, kind, unit0, nunits, row0, 0, 0, 0}); };
     auto fin_matrix = [&](int64_t dst, int tg, int K) {      // one op per 128x128 tile of the destination matrix [Hd x K]
@@ -463,13 +462,13 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
     p.term_off = (int)T.size(); T.insert(T.end(), terms.begin(), terms.end());
     p.src_off = (int)T.size(); T.insert(T.end(), srcs.begin(), srcs.end());
     p.unit_off = (int)T.size(); T.insert(T.end(), units.begin(), units.end());
-    p.order_off = (int)T.size(); T.insert(T.end(), order.begin(), order.end());
+    p.sunit_off = (int)T.size(); T.insert(T.end(), sunits.begin(), sunits.end());
     p.item_off = (int)T.size(); T.insert(T.end(), items.begin(), items.end());
     p.fin_off = (int)T.size(); T.insert(T.end(), fins.begin(), fins.end());
 
     p.info.rows_per_tile = 64; p.info.total_nodes = p.NN; p.info.lds_bytes = 4 * 4096 * p.planes;
     p.info.flops_fwd = alg_fwd; p.info.flops_bwd = alg_bwd; p.info.flops_exec_fwd = exec_fwd; p.info.flops_exec_bwd = exec_bwd;
-    p.info.bytes_in = bytes_in; p.info.n_gradw_workgroups = p.n_units * p.n_parts;
+    p.info.bytes_in = bytes_in; p.info.n_gradw_workgroups = p.n_sunits * p.n_parts;
     p.info.n_launches_fwd = 2 + (int)p.fwd.size(); p.info.n_launches_bwd = 3 + (int)p.bwd.size();
     p.info.kernel_sets = 4;      // bit 2: generic-width engine
     p.info.grad_split = -1;
