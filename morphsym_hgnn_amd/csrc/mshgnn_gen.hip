@@ -28,7 +28,7 @@ struct mshgnn_gen_state {      // device side of a generic plan
 struct GArgs {
     char* ws; size_t buf_off[GBUF_COUNT];
     const void* x[MSHGNN_MAX_TYPES]; int64_t pitch[MSHGNN_MAX_TYPES]; int nodes[MSHGNN_MAX_TYPES]; int vb[MSHGNN_MAX_TYPES]; int aligned;
-    const int* jobs; const int* terms; const int* srcs; const int* units; const int* items; const int* sunits;
+    const int* jobs; const int* terms; const int* srcs; const int* units; const int* items; const int* sunits; const int* su_order;
     const void* wpack; const float* bias; const uint8_t* signs; float* slabs;
     int n_img, B, Hd, NCT, tiles, training, job0, n_units, n_parts, n_sunits;
 };
@@ -366,7 +366,7 @@ template <bool SPLIT, int OS> __global__ __launch_bounds__(512 * OS) void k_ggra
     auto Ql = [&](int t) { return tiles_l + (SPLIT ? (OS + t) * TSZ : 0); };
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wv >> 2, wc = wv & 3;                     // wave (wr, wc): rows [64 wr, +64) of the o range, columns [64 wc, +64) of the k range
-    const int su_i = blockIdx.x % a.n_sunits, part = blockIdx.x / a.n_sunits;
+    const int su_i = a.su_order[blockIdx.x % a.n_sunits], part = blockIdx.x / a.n_sunits;
     const int* su = a.sunits + (size_t)su_i * SUNIT_INTS;
     const int it0 = su[SU_ITEM0], pcol = su[SU_PCOL], qcol = su[SU_QCOL], qn = su[SU_QN];
     const int nchunks = (a.B + KW - 1) / KW;
@@ -682,7 +682,7 @@ static int g_fill(const mshgnn_plan* p, const mshgnn_ws_layout& lay, const void*
         a.vb[t] = vec_bytes(x[t], a.pitch[t], in_es);
     }
     a.jobs = g->d_tables + gp.job_off; a.terms = g->d_tables + gp.term_off; a.srcs = g->d_tables + gp.src_off;
-    a.units = g->d_tables + gp.unit_off; a.items = g->d_tables + gp.item_off; a.sunits = g->d_tables + gp.sunit_off;
+    a.units = g->d_tables + gp.unit_off; a.items = g->d_tables + gp.item_off; a.sunits = g->d_tables + gp.sunit_off; a.su_order = g->d_tables + gp.su_order_off;
     a.wpack = ws + lay.wpack; a.bias = reinterpret_cast<const float*>(ws + lay.bias); a.signs = g->d_signs;
     a.slabs = reinterpret_cast<float*>(ws + lay.slabs);
     a.n_img = gp.n_img; a.B = B; a.Hd = gp.Hd; a.NCT = gp.NCT; a.tiles = (B + 63) / 64; a.training = training;

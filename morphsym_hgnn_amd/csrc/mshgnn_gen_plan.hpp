@@ -52,7 +52,7 @@ struct GenPlan {
     std::vector<BiasDesc> biases;
     std::vector<uint8_t> signs; std::vector<int> sign_off, enc_nkc;
     std::vector<int32_t> tables;            // jobs | terms | srcs | units | items | fins
-    int job_off = 0, term_off = 0, src_off = 0, unit_off = 0, sunit_off = 0, n_sunits = 0, su_os = 1, item_off = 0, fin_off = 0, n_units = 0, n_parts = 1, n_fin = 0;
+    int job_off = 0, term_off = 0, src_off = 0, unit_off = 0, sunit_off = 0, su_order_off = 0, n_sunits = 0, su_os = 1, item_off = 0, fin_off = 0, n_units = 0, n_parts = 1, n_fin = 0;
     std::vector<Launch> fwd, bwd;           // job launches in order
     int ks_prep = 0, ks_dec_fwd = 0, ks_dec_bwd = 0, ks_gradw = 0, ks_fin = 0;
     std::vector<mshgnn_kernel_stat> kstats;
@@ -413,6 +413,29 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
     }
     p.n_sunits = (int)(sunits.size() / SUNIT_INTS);
     p.n_parts = std::max(1, std::min(16, 768 / std::max(1, p.n_sunits)));
+    // launch order: the super-units of ONE (target, item chunk) read the same P and Q rows (each half of them twice at hidden = 512).  Workgroups b
+    // and b + 8 run on the same XCD (round-robin dispatch), so they are placed 8 apart on one XCD, back to back, and the second reader hits that
+    // XCD's L2 (speed only).  Super-units were emitted (target, chunk)-major, so a group is a run of consecutive indices.
+    std::vector<int32_t> su_order(p.n_sunits, 0);
+    {
+        std::vector<std::pair<int, int>> groups;      // (first super-unit, count)
+        int pos = 0;
+        for (Tgt& g : tgts) {
+            const int per = ((g.rows / TW + p.su_os - 1) / p.su_os) * (((g.K + TW - 1) / TW + 1) / 2);
+            for (int c = 0; c < g.chunks; ++c) { groups.push_back({pos, per}); pos += per; }
+        }
+        std::vector<std::vector<int>> xq(8);
+        for (auto& gr : groups) {      // to the XCD queue that is shortest so far
+            int best = 0; for (int x = 1; x < 8; ++x) if (xq[x].size() < xq[best].size()) best = x;
+            for (int k = 0; k < gr.second; ++k) xq[best].push_back(gr.first + k);
+        }
+        std::vector<size_t> qpos(8, 0);
+        for (int b = 0; b < p.n_sunits; ++b) {      // block b -> queue b % 8; an exhausted queue borrows from the longest remaining one
+            int q = b % 8;
+            if (qpos[q] >= xq[q].size()) { q = 0; for (int y = 1; y < 8; ++y) if (xq[y].size() - qpos[y] > xq[q].size() - qpos[q]) q = y; }
+            su_order[b] = xq[q][qpos[q]++];
+        }
+    }
     auto add_fin = [&](int64_t dst, int rows, int cols, int ld, int kind, int unit0, int nunits, int row0) {
         fins.insert(fins.end(), {(int32_t)(dst & 0xffffffff), (int32_t)(dst >> 32), rows, cols, ld, kind, unit0, nunits, row0, 0, 0, 0}); };
     auto fin_matrix = [&](int64_t dst, int tg, int K) {      // one op per 128x128 tile of the destination matrix [Hd x K]
@@ -463,6 +486,7 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
     p.src_off = (int)T.size(); T.insert(T.end(), srcs.begin(), srcs.end());
     p.unit_off = (int)T.size(); T.insert(T.end(), units.begin(), units.end());
     p.sunit_off = (int)T.size(); T.insert(T.end(), sunits.begin(), sunits.end());
+    p.su_order_off = (int)T.size(); T.insert(T.end(), su_order.begin(), su_order.end());
     p.item_off = (int)T.size(); T.insert(T.end(), items.begin(), items.end());
     p.fin_off = (int)T.size(); T.insert(T.end(), fins.begin(), fins.end());
 

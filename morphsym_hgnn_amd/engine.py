@@ -286,12 +286,24 @@ class Engine:
             self._lay[key] = lay
         return self._lay[key]
 
+    MAX_WORKSPACES = 4      # distinct (batch size, training) workspaces kept alive; least recently used beyond that are released
+
     def workspace(self, B: int, training: bool = True) -> torch.Tensor:
+        """The caller-owned activation stash of the C-ABI for batch size B (0.6 GB at B = 8192 on the bf16 plan).  One per (B, training),
+        at most MAX_WORKSPACES of them: a training loop has one or two batch sizes (the last, ragged batch; validation), a sweep over
+        batch sizes must not pin them all.  Evicting a workspace invalidates a forward whose backward has not run yet: its stash
+        ticket is bumped, so that backward raises instead of reading freed memory."""
         key = (B, int(training))
-        if key not in self._ws:
+        ws = self._ws.pop(key, None)
+        if ws is None:
             lay = self.layout(B, training)
-            self._ws[key] = torch.empty(lay.total, dtype=torch.uint8, device=self.device)
-        return self._ws[key]
+            ws = torch.empty(lay.total, dtype=torch.uint8, device=self.device)
+            while len(self._ws) >= self.MAX_WORKSPACES:
+                old_key = next(iter(self._ws))
+                del self._ws[old_key]
+                self._tickets[old_key[0]] = self._tickets.get(old_key[0], 0) + 1
+        self._ws[key] = ws           # (re-inserted last: dict order = recency)
+        return ws
 
     def padded_width(self, t: str) -> int:
         """Row pitch (elements) of input type t in engine layout: F_t rounded up so every row starts 16-byte aligned."""

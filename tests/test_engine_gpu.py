@@ -360,3 +360,22 @@ def test_k4_and_com_batches_of_a_thousand_windows_are_additive(kind, topo, cfg, 
     torch.cuda.synchronize()
     assert torch.equal(torch.cat([parts[0][0], parts[1][0]]), out)
     assert float((parts[0][1] + parts[1][1] - g_all).abs().max() / g_all.abs().max()) < (2e-3 if dtype == "bf16" else 1e-4)
+
+
+def test_engine_keeps_a_bounded_number_of_workspaces():
+    """A sweep over batch sizes must not pin one workspace per size forever (0.6 GB each at B = 8192): least recently used ones are released,
+    and a forward whose workspace was released can no longer be backpropagated (its ticket changes) instead of reading freed memory."""
+    _require_gpu()
+    from morphsym_hgnn_amd import engine as eng, synth
+    spec = helpers.make_spec("c2", "a1-c2", "a1-c2", 128, 2)
+    e = eng.Engine(spec, "bf16")
+    flat = eng.flatten_params(spec, synth.make_params(1, spec.param_shapes()), e.device)
+    t0 = None
+    for B in (3, 5, 7, 9, 11, 13):
+        x_dict, _ = synth.make_windows(B, B, spec.num_nodes, spec.widths, 12)
+        e.forward(e.cast_inputs(x_dict), flat, B)
+        if B == 3:
+            t0 = e.stash_ticket(3)
+    torch.cuda.synchronize()
+    assert len(e._ws) <= e.MAX_WORKSPACES and (13, 1) in e._ws and (3, 1) not in e._ws
+    assert e.stash_ticket(3) != t0
