@@ -392,10 +392,13 @@ template <bool SPLIT, int OS> __global__ __launch_bounds__(512 * OS) void k_ggra
         if (im[I_KIND] == 1) return 1;
         const int* src = a.srcs + (size_t)im[I_SRC0] * SRC_INTS;
         return (im[I_NSRC] == 1 && src[S_SCALE] == one_bits) ? 0 : 2; };
-    auto fetch = [&](Stage& st, int s) {
-        const int* im = a.items + (size_t)(it0 + s / nch) * GITEM_INTS;
+    // step cursors (item, chunk) of the fetch and of the staging stream: advanced by one step per call (no division per step)
+    int f_it = it0, f_ch = ch0, s_it = it0, s_ch = ch0;
+    auto fetch = [&](Stage& st) {
+        const int* im = a.items + (size_t)f_it * GITEM_INTS;
         const int* src = a.srcs + (size_t)im[I_SRC0] * SRC_INTS;
-        const int w0 = (ch0 + s % nch) * KW, qk = q_kind(im);
+        const int w0 = f_ch * KW, qk = q_kind(im);
+        if (++f_ch == ch1) { f_ch = ch0; ++f_it; }
         st.pa = u32x4{0, 0, 0, 0}; st.pb = u32x4{0, 0, 0, 0}; st.mw = 0xffu;
         {
             const int w = w0 + rp;
@@ -429,10 +432,11 @@ template <bool SPLIT, int OS> __global__ __launch_bounds__(512 * OS) void k_ggra
             }
         }
     };
-    auto stage_to_lds = [&](const Stage& st, int s) {
-        const int* im = a.items + (size_t)(it0 + s / nch) * GITEM_INTS;
+    auto stage_to_lds = [&](const Stage& st) {
+        const int* im = a.items + (size_t)s_it * GITEM_INTS;
         const int* src = a.srcs + (size_t)im[I_SRC0] * SRC_INTS;
-        const int w0 = (ch0 + s % nch) * KW, qk = q_kind(im);
+        const int w0 = s_ch * KW, qk = q_kind(im);
+        if (++s_ch == ch1) { s_ch = ch0; ++s_it; }
         {
             u32x4 ph = st.pa, pl = st.pb;
             if (im[I_PMASK] >= 0) { ph = chunk_mask_bits<T16>(ph, st.mw); if constexpr (SPLIT) pl = chunk_mask_bits<T16>(pl, st.mw); }     // dH = dX . relu bits
@@ -503,30 +507,30 @@ template <bool SPLIT, int OS> __global__ __launch_bounds__(512 * OS) void k_ggra
     };
     if constexpr (NST == 2) {
         Stage sa, sb;
-        if (nsteps > 0) fetch(sa, 0);
-        if (nsteps > 1) fetch(sb, 1);
+        if (nsteps > 0) fetch(sa);
+        if (nsteps > 1) fetch(sb);
         for (int s = 0; s < nsteps; s += 2) {
             __syncthreads();      // the previous MFMA phase is done reading the tiles
-            stage_to_lds(sa, s);
+            stage_to_lds(sa);
             __syncthreads();
-            if (s + 2 < nsteps) fetch(sa, s + 2);
+            if (s + 2 < nsteps) fetch(sa);
             mfmas();
             if (s + 1 < nsteps) {
                 __syncthreads();
-                stage_to_lds(sb, s + 1);
+                stage_to_lds(sb);
                 __syncthreads();
-                if (s + 3 < nsteps) fetch(sb, s + 3);
+                if (s + 3 < nsteps) fetch(sb);
                 mfmas();
             }
         }
     } else {
         Stage sa;
-        if (nsteps > 0) fetch(sa, 0);
+        if (nsteps > 0) fetch(sa);
         for (int s = 0; s < nsteps; ++s) {
             __syncthreads();
-            stage_to_lds(sa, s);
+            stage_to_lds(sa);
             __syncthreads();
-            if (s + 1 < nsteps) fetch(sa, s + 1);
+            if (s + 1 < nsteps) fetch(sa);
             mfmas();
         }
     }
