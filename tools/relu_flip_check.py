@@ -1,4 +1,5 @@
-"""Are the gradient outliers of the split plan on tiny batches relu decisions that flip within the arithmetic error?"""
+"""Are the gradient outliers of a plan on tiny batches relu decisions that flip within the arithmetic error?  usage: python tools/relu_flip_check.py x3|f32
+(finding, round 2: yes -- every outlier coincides with a decision whose pre-activation lies within 1e-4 of zero)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
