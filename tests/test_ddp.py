@@ -52,3 +52,39 @@ def test_two_rank_gradient_allreduce_matches_global_batch():
     port = 29000 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(world, port, B, ret), nprocs=world, join=True)
     assert ret["err"] < 1e-6   # fp32 flat buffer round-trip of fp64 oracle gradients
+
+
+def _gpu_worker(rank, world, port, B, dtype, ret):
+    """One rank of a data-parallel step on the REAL engine: both ranks share cuda:0 (the only GPU of the test box), so the exchange goes
+    through gloo on host copies -- everything else (sharding, per-rank engine step through the C-ABI, mean semantics) is what bench.py does
+    with RCCL on N GPUs."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from morphsym_hgnn_amd import engine as eng
+    spec = helpers.make_spec("c2", "a1-c2", "a1-c2", 128, 3)
+    x_dict, y = synth.make_windows(31, B, spec.num_nodes, spec.widths, 12)
+    params = synth.make_params(31, spec.param_shapes())
+    e = eng.Engine(spec, dtype, device="cuda:0")
+    flat = eng.flatten_params(spec, params, e.device)
+    xs, (b, en) = ddp.shard_x_dict(x_dict, spec.num_nodes, B, rank, world)
+    n = en - b
+    _, _, g = e.step_mse(e.cast_inputs(xs), flat, y[b:en].reshape(-1).to(e.device, torch.float32), n)
+    g = g.cpu()
+    ddp.allreduce_gradients_(g, n, B)          # local-mean gradients -> gradient of the global mean loss
+    if rank == 0:
+        _, _, g_full = e.step_mse(e.cast_inputs(x_dict), flat, y.reshape(-1).to(e.device, torch.float32), B)
+        ret["err"] = float((g - g_full.cpu()).abs().max() / g_full.abs().max())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f32", "x3"])
+def test_two_engine_ranks_reproduce_the_global_batch_gradient(dtype):
+    world, B = 2, 333   # ragged split: 167 + 166 windows
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 31000 + (os.getpid() % 2000)
+    mp.spawn(_gpu_worker, args=(world, port, B, dtype, ret), nprocs=world, join=True)
+    assert ret["err"] < 1e-5    # same arithmetic, different summation order over the windows
