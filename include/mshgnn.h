@@ -72,7 +72,7 @@ typedef struct mshgnn_desc {
     int32_t out_channels;                         /* out_channels_per_foot                            */
     int32_t mlp_type;                             /* type with the base_transform epilogue, or -1     */
     uint32_t flags;                               /* MSHGNN_FLAG_*                                    */
-    int32_t dtype;                                /* MSHGNN_F32 | MSHGNN_BF16                         */
+    int32_t dtype;                                /* MSHGNN_F32 | MSHGNN_BF16 | MSHGNN_BF16X3          */
     int32_t type_nodes[MSHGNN_MAX_TYPES];         /* nodes of each type per window                    */
     int32_t type_width[MSHGNN_MAX_TYPES];         /* input feature width F_type                       */
     const int32_t* rel_src;                       /* [n_rel] source type                              */

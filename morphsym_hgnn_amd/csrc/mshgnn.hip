@@ -1720,6 +1720,9 @@ extern "C" int mshgnn_plan_create(const mshgnn_desc* desc, mshgnn_plan** out) {
 #ifdef MSHGNN_ABLATE
         { const char* e = getenv("MSHGNN_DBG"); p->dbg = e ? atoi(e) : 0; }
 #endif
+        if (!p->hp.d.n_types) {      // forced generic engine: the specialised compiler never ran; entry points read the scalar fields from here
+            p->hp.d = *desc;         // (its host pointers belong to the caller and are not read again)
+        }
         *out = p;
         return MSHGNN_OK;
     }
