@@ -1624,6 +1624,162 @@ template <int IPL> __global__ __launch_bounds__(256, GW_WPS) void k_gradw_bf16(G
     }
 }
 
+// k_gradw_bf16_lean: the same split-K step loop with a hot path that issues almost nothing but loads, LDS traffic and MFMAs.  The general kernel above
+// spends ~300 VALU instructions per wave and 64-window step on 64-bit row addresses, bound checks and per-row mask bytes (SQ counters: 29 M VALU
+// instructions per launch against 1.4 M MFMAs).  Here a thread owns FOUR CONSECUTIVE windows of one 16-byte column chunk, so that
+//   * every global address is  wave-uniform stream pointer (SGPRs, advanced by scalar adds)  +  per-thread 32-bit offset  +  immediate (256 p),
+//   * the relu bytes of its four rows are ONE aligned 32-bit load (the byte layout keeps 16 consecutive windows together),
+//   * full chunks (all but the last one of the batch) carry no bound checks.
+// One item per lane, raw inputs 16-byte aligned (the launcher falls back to the general kernel otherwise).  Same step order, same MFMA
+// sequence: the matrix slabs are bit-identical to the general kernel's; the bias partial sums add the same values in another order.
+__global__ __launch_bounds__(256, GW_WPS) void k_gradw_bf16_lean(GradwArgs a) {
+    using T = __bf16;
+    __shared__ __attribute__((aligned(16))) __bf16 Ps[GWB_KW * GWB_PITCH];
+    __shared__ __attribute__((aligned(16))) __bf16 Qs[GWB_KW * GWB_PITCH];
+    __shared__ __attribute__((aligned(16))) u32x4 mlut[256];       // relu byte -> AND mask of 8 bf16
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    mlut[tid] = chunk_mask_bits<__bf16>(u32x4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, (unsigned)tid);   // (visible after the first barrier)
+    const int wr = wv >> 1, wc = wv & 1;
+    const int ln = a.lane_order[blockIdx.x % a.n_pad], part = blockIdx.x / a.n_pad;
+    if (ln < 0) return;
+    const int* lh = a.lanes + ln * LANE_INTS;
+    const int bias_flag = lh[3];
+    const int* im = a.items + lh[0] * ITEM_INTS;
+    const int nchunks = (a.B + GWB_KW - 1) / GWB_KW;
+    const int ch0 = (int)((int64_t)part * nchunks / a.n_parts), ch1 = (int)((int64_t)(part + 1) * nchunks / a.n_parts);
+    const int nsteps = ch1 - ch0;
+    const int c = tid & 15, r4 = (tid >> 4) * 4;      // rows r4 .. r4 + 3 of the 64-window step, columns [8c, 8c + 8)
+
+    // wave-uniform stream pointers at the part's first window; per-thread byte offsets
+    const char* pS = a.ws + a.buf_off[im[0]] + (act_idx(0, im[2], a.B) + (size_t)ch0 * GWB_KW * H) * sizeof(T);
+    const bool p_masked = im[9] >= 0;
+    const int ntile = (a.B + 15) >> 4;
+    const char* mS = p_masked ? a.ws + a.buf_off[im[9]] + relu_byte(im[2], a.B, 0, 0) + (size_t)ch0 * (GWB_KW / 16) * 64 : a.ws;
+    const unsigned voffP = (unsigned)(r4 * H + c * 8) * (unsigned)sizeof(T);
+    const unsigned voffM = (unsigned)(((c >> 2) * ntile + (r4 >> 4)) * 64 + (c & 3) * 16 + (r4 & 15));
+    const bool q_raw = im[4] < 0;
+    const char* qS; unsigned qsb; int qn = 8; u32x4 qsx = u32x4{0, 0, 0, 0};
+    if (!q_raw) {
+        qS = a.ws + a.buf_off[im[3]] + (act_idx(0, im[5], a.B) + (size_t)ch0 * GWB_KW * H) * sizeof(T);
+        qsb = H * sizeof(T);
+    } else {
+        const int t = im[3] - BUF_IN;
+        qsb = (unsigned)(a.nodes[t] * a.pitch[t]) * (unsigned)sizeof(T);
+        qS = reinterpret_cast<const char*>(a.x[t]) + ((size_t)im[5] * a.pitch[t] + im[6]) * sizeof(T) + (size_t)ch0 * GWB_KW * qsb;
+        qn = im[7] - c * 8;
+        qsx = sign_xor<T>(a.signs + im[8] + c * 8);
+    }
+    const u32x4 qkeep = chunk_keep_first<T>(u32x4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, qn);
+    unsigned voffQ[4], ldsw[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        voffQ[p] = (unsigned)(r4 + p) * qsb + (unsigned)c * 16u;
+        ldsw[p] = (unsigned)gwb_elem(r4 + p, c * 8);
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+    float bsum[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
+
+    u32x4 pv[4], qv[4]; unsigned mw = 0xffffffffu;
+    auto fetch = [&](int s) {      // loads of step s (chunk ch0 + s); pS / qS / mS already point at it
+        const int w0 = (ch0 + s) * GWB_KW;
+        if (w0 + GWB_KW <= a.B) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                pv[p] = *reinterpret_cast<const u32x4*>(pS + voffP + p * (int)(H * sizeof(T)));
+                qv[p] = u32x4{0, 0, 0, 0};
+                if (qn > 0) qv[p] = *reinterpret_cast<const u32x4*>(qS + voffQ[p]);
+            }
+            if (p_masked) mw = *reinterpret_cast<const unsigned*>(mS + voffM);
+        } else {                   // last chunk of the batch: rows beyond B are zero
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                pv[p] = u32x4{0, 0, 0, 0}; qv[p] = u32x4{0, 0, 0, 0};
+                if (w0 + r4 + p < a.B) {
+                    pv[p] = *reinterpret_cast<const u32x4*>(pS + voffP + p * (int)(H * sizeof(T)));
+                    if (qn > 0) qv[p] = *reinterpret_cast<const u32x4*>(qS + voffQ[p]);
+                }
+            }
+            mw = 0xffffffffu;
+            if (p_masked && w0 + r4 < a.B) mw = *reinterpret_cast<const unsigned*>(mS + voffM);     // (the 16-window tile of row r4 exists)
+        }
+        pS += (size_t)GWB_KW * H * sizeof(T); qS += (size_t)GWB_KW * qsb; mS += (GWB_KW / 16) * 64;
+    };
+    auto stage_to_lds = [&]() {
+        u32x4 mk[4];
+        if (p_masked) {              // the four table reads go out together (one LDS round trip, not four)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) mk[p] = mlut[(mw >> (8 * p)) & 0xffu];
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            u32x4 pm = pv[p];
+            if (p_masked) pm &= mk[p];                                   // dH = dX . relu bits
+            *reinterpret_cast<u32x4*>(&Ps[ldsw[p]]) = pm;
+            u32x4 qm = qv[p];
+            if (q_raw) qm = (qm & qkeep) ^ qsx;                          // drop pad columns, symmetry sign mask of encoder inputs
+            *reinterpret_cast<u32x4*>(&Qs[ldsw[p]]) = qm;
+            if (bias_flag) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bsum[2 * e] += __builtin_bit_cast(float, pm[e] << 16);
+                    bsum[2 * e + 1] += __builtin_bit_cast(float, pm[e] & 0xffff0000u);
+                }
+            }
+        }
+    };
+    if (nsteps > 0) fetch(0);
+    for (int s = 0; s < nsteps; ++s) {
+        __syncthreads();             // every wave is done with the previous step's tiles
+        stage_to_lds();
+        __syncthreads();
+        if (s + 1 < nsteps) fetch(s + 1);
+#pragma unroll
+        for (int ks = 0; ks < GWB_KW / 16; ++ks) {
+            bf16x8 af[2], bq[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i] = tr_frag(Ps, ks * 16, wr * 64 + i * 32, lane);
+                bq[i] = tr_frag(Qs, ks * 16, wc * 64 + i * 32, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bq[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    float* slab = a.slabs + (size_t)(part * a.n_lanes + ln) * SLAB_FLOATS;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int o = wr * 64 + i * 32 + (q & 3) + ((q >> 2) << 3) + ((lane >> 5) << 2), k = wc * 64 + j * 32 + (lane & 31);
+                slab[o * H + k] = acc[i][j][q];
+            }
+    if (bias_flag) {
+        float* red = reinterpret_cast<float*>(Ps);   // 16 x 128 floats = 8 KB <= one tile
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[(r4 >> 2) * H + c * 8 + e] = bsum[e];
+        __syncthreads();
+        if (tid < H) {
+            float s2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s2 += red[r * H + tid];
+            slab[H * H + tid] = s2;
+        }
+    }
+}
+
 // k_finalize: sum split-K slabs in fixed order into the flat gradient buffer (every parameter written once)
 
 __global__ __launch_bounds__(256) void k_finalize(FinArgs a) {
@@ -2020,7 +2176,9 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
         a.stamps = stamp_ptr("MSHGNN_STAMPS_GW");
         ProfScope ps(p, hp.ks_gradw, st);
         if (a.n_pad > 0) {
+            static const bool gw_general = getenv("MSHGNN_GRADW") && std::string(getenv("MSHGNN_GRADW")) == "general";   // read once: the general kernel also where the lean one applies (A/B runs)
             if constexpr (sizeof(T) == 4) hipLaunchKernelGGL(k_gradw_f32, dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a);
+            else if (hp.gw_ipl == 1 && a.aligned && !gw_general) hipLaunchKernelGGL(k_gradw_bf16_lean, dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a);
             else if (hp.gw_ipl == 1) hipLaunchKernelGGL(k_gradw_bf16<1>, dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a);
             else hipLaunchKernelGGL(k_gradw_bf16<2>, dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a);
         }

@@ -40,6 +40,10 @@ constexpr int GW_IPL = 2;                // most items per weight-gradient lane;
                                          // mostly empty wave: 128 vs 112 us, and more slabs for k_finalize)
 #endif
 
+#ifndef GW_XCD_SLACK
+#define GW_XCD_SLACK 1                   // lanes an XCD queue of the weight-gradient kernel may exceed the balanced length by (placement by operand sharing)
+#endif
+
 enum { OP_LOADW = 0, OP_MAC = 1 };
 enum { KIND_RELU = 0, KIND_MLP = 1 };
 enum { NK_DEAD = 0, NK_RELU = 1, NK_MLP = 2 };
@@ -753,6 +757,74 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
     std::vector<std::pair<int, int>> cl_size;   // (-size, id)
     for (int c : cl_ids) cl_size.push_back({-(int)std::count(lane_cluster.begin(), lane_cluster.end(), c), c});
     std::sort(cl_size.begin(), cl_size.end());
+    // Operand streams of a lane: (buffer, node[, input column chunk]) of its P and Q rows, with their bytes per window.  Lanes on one XCD
+    // that share a stream fetch it through that XCD's L2 once, so the placement minimises  sum over XCDs of the distinct stream bytes
+    // (tools/gradw_sharing.py prints that sum next to the unique bytes) by local search from the cluster placement: single-lane moves and
+    // pair swaps, queue lengths kept within GW_XCD_SLACK of the balanced length.  Deterministic (no randomness).
+    std::vector<std::vector<std::pair<int, int>>> lane_streams(p.n_lanes);    // (stream id, bytes)
+    int n_streams = 0;
+    {
+        std::vector<std::array<int, 4>> keys;
+        auto sid = [&](std::array<int, 4> k) { for (size_t i = 0; i < keys.size(); ++i) if (keys[i] == k) return (int)i; keys.push_back(k); return (int)keys.size() - 1; };
+        for (int ln = 0; ln < p.n_lanes; ++ln)
+            for (int it = lanes[ln][0]; it < lanes[ln][1]; ++it) {
+                const int32_t* im = &T[p.item_off + (size_t)it * ITEM_INTS];
+                const int es = p.esize * p.planes;
+                lane_streams[ln].push_back({sid({0, im[0], im[2], 0}), H * es + (im[9] >= 0 ? 16 : 0)});
+                if (im[4] >= 0) lane_streams[ln].push_back({sid({1, im[3], im[5], 0}), H * es});
+                else lane_streams[ln].push_back({sid({1, im[3], im[5], im[6]}), std::min(H, im[7]) * (p.split ? 4 : p.esize)});
+            }
+        n_streams = (int)keys.size();
+    }
+    auto refine_queues = [&](std::vector<std::vector<int>>& xq) {
+        int n = 0; for (auto& q : xq) n += (int)q.size();
+        if (n < 16) return;
+        const int cap = (n + 7) / 8 + GW_XCD_SLACK;
+        std::vector<int> where(p.n_lanes, -1), qsz(8, 0);
+        std::vector<std::vector<int>> cnt(8, std::vector<int>(n_streams, 0));
+        for (int x = 0; x < 8; ++x) for (int ln : xq[x]) { where[ln] = x; ++qsz[x]; for (auto& s : lane_streams[ln]) ++cnt[x][s.first]; }
+        auto remove_gain = [&](int ln, int x) { int g = 0; for (auto& s : lane_streams[ln]) if (cnt[x][s.first] == 1) g += s.second; return g; };
+        auto add_cost = [&](int ln, int x) { int c = 0; for (auto& s : lane_streams[ln]) if (cnt[x][s.first] == 0) c += s.second; return c; };
+        auto take_out = [&](int ln, int x) { for (auto& s : lane_streams[ln]) --cnt[x][s.first]; --qsz[x]; };
+        auto put_in = [&](int ln, int x) { for (auto& s : lane_streams[ln]) ++cnt[x][s.first]; ++qsz[x]; where[ln] = x; };
+        for (int sweep = 0; sweep < 64; ++sweep) {
+            bool improved = false;
+            for (int a = 0; a < p.n_lanes; ++a) {
+                if (where[a] < 0) continue;
+                const int xa = where[a];
+                // best single move
+                int best_y = -1, best_d = 0;
+                const int ga = remove_gain(a, xa);
+                for (int y = 0; y < 8; ++y) {
+                    if (y == xa || qsz[y] >= cap) continue;
+                    const int dlt = add_cost(a, y) - ga;
+                    if (dlt < best_d) { best_d = dlt; best_y = y; }
+                }
+                if (best_y >= 0) { take_out(a, xa); put_in(a, best_y); improved = true; continue; }
+                // best swap with a lane of another queue
+                int best_b = -1; best_d = 0;
+                for (int b = a + 1; b < p.n_lanes; ++b) {
+                    const int xb = where[b];
+                    if (xb < 0 || xb == xa) continue;
+                    take_out(a, xa); take_out(b, xb);
+                    const int before_a = add_cost(a, xa), before_b = add_cost(b, xb);   // what the two lanes cost where they were
+                    const int after = [&] { int c = add_cost(a, xb); put_in(a, xb); const int c2 = add_cost(b, xa); take_out(a, xb); return c + c2; }();
+                    const int before = [&] { put_in(a, xa); const int c2 = add_cost(b, xb); take_out(a, xa); return before_a + c2; }();
+                    (void)before_b;
+                    put_in(a, xa); put_in(b, xb);
+                    if (after - before < best_d) { best_d = after - before; best_b = b; }
+                }
+                if (best_b >= 0) { const int xb = where[best_b]; take_out(a, xa); take_out(best_b, xb); put_in(a, xb); put_in(best_b, xa); improved = true; }
+            }
+            if (!improved) break;
+        }
+        for (auto& q : xq) q.clear();
+        for (int ln = 0; ln < p.n_lanes; ++ln) if (where[ln] >= 0) xq[where[ln]].push_back(ln);
+    };
+    auto queue_cost = [&](const std::vector<std::vector<int>>& xq) {
+        long c = 0;
+        for (auto& q : xq) { std::vector<char> seen(n_streams, 0); for (int ln : q) for (auto& s2 : lane_streams[ln]) if (!seen[s2.first]) { seen[s2.first] = 1; c += s2.second; } }
+        return c; };
     auto build_queues = [&](const std::vector<bool>& take, std::vector<std::vector<int>>& xq) {
         xq.assign(8, {});
         for (auto& cs : cl_size) {
@@ -764,6 +836,32 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
             int lo = 0, hi = 0; for (int x = 1; x < 8; ++x) { if (xq[x].size() < xq[lo].size()) lo = x; if (xq[x].size() > xq[hi].size()) hi = x; }
             if (xq[hi].size() <= xq[lo].size() + 1) break;
             xq[lo].push_back(xq[hi].back()); xq[hi].pop_back();
+        }
+        refine_queues(xq);
+        {   // alternative start: grow each queue along shared streams (seed, then always the lane that adds the fewest new bytes); keep the cheaper result
+            std::vector<std::vector<int>> gq(8);
+            std::vector<int> todo; for (int ln = 0; ln < p.n_lanes; ++ln) if (take[ln]) todo.push_back(ln);
+            const int n = (int)todo.size();
+            std::vector<bool> used(p.n_lanes, false);
+            int left = n;
+            for (int x = 0; x < 8 && left > 0; ++x) {
+                const int want = (left + (8 - x) - 1) / (8 - x);
+                std::vector<int> cnt(n_streams, 0);
+                for (int k = 0; k < want; ++k) {
+                    int best = -1, best_add = 0, best_share = 0;
+                    for (int ln : todo) {
+                        if (used[ln]) continue;
+                        int add = 0, share = 0;
+                        for (auto& s2 : lane_streams[ln]) { if (cnt[s2.first]) share += s2.second; else add += s2.second; }
+                        if (best < 0 || (k > 0 && (add < best_add || (add == best_add && share > best_share)))) { best = ln; best_add = add; best_share = share; }
+                        if (k == 0) break;      // seed: the first unplaced lane (target order)
+                    }
+                    used[best] = true; gq[x].push_back(best); --left;
+                    for (auto& s2 : lane_streams[best]) ++cnt[s2.first];
+                }
+            }
+            refine_queues(gq);
+            if (queue_cost(gq) < queue_cost(xq)) xq = gq;
         }
         size_t m = 0; for (auto& q : xq) m = std::max(m, q.size());
         return m; };
