@@ -84,7 +84,7 @@ template <typename T, bool ALIGNED> __global__ __launch_bounds__(256) void k_enc
     int t = 0;
     while (t + 1 < a.n_types && (int)blockIdx.x >= a.wg_prefix[t + 1]) ++t;
     const int local = blockIdx.x - a.wg_prefix[t];
-    const int node = local / a.tiles, tile = local % a.tiles;
+    const int node = ENC_ORDER ? local % a.nodes[t] : local / a.tiles, tile = ENC_ORDER ? local / a.nodes[t] : local % a.tiles;
     const int w0 = tile * MB * P::ROWS;
     const T* x = reinterpret_cast<const T*>(a.x[t]);
     const int64_t pitch = a.pitch[t];
@@ -101,8 +101,8 @@ template <typename T, bool ALIGNED> __global__ __launch_bounds__(256) void k_enc
     typename P::BFrag bf;
     typename P::AFrag af;
     const AOff<T> ao(lane);      // fragment offsets once per kernel (the generic load_afrag rebuilds them per call: 14 VALU instructions)
-    u32x4 v[MB / BPP][NIT];
-    auto fetch = [&](int kc) {
+    using VBuf = u32x4[MB / BPP][NIT];
+    auto fetch = [&](VBuf& v, int kc) {
         const int k0 = kc * H + c * P::EPC;
         const int nvalid = min(P::EPC, F - k0);
 #pragma unroll
@@ -114,15 +114,15 @@ template <typename T, bool ALIGNED> __global__ __launch_bounds__(256) void k_enc
                     // unconditional raw 16-byte load (nothing uses it here): rows past the batch re-read the last row, chunks past the
                     // row's end re-read the K chunk's first one -- the staging pass zeroes both
                     const T* src = x + ((size_t)min(w, a.B - 1) * nt + node) * pitch + (nvalid > 0 ? k0 : kc * H);
-                    v[mi][it] = *reinterpret_cast<const u32x4*>(src);
+                    v[mi][it] = ld16<ENC_NT>(src);
                 } else {
                     v[mi][it] = u32x4{0, 0, 0, 0};
                     if (w < a.B) v[mi][it] = load_chunk<T>(x + ((size_t)w * nt + node) * pitch + k0, nvalid, vb);
                 }
             }
     };
-    fetch(0);
-    for (int kc = 0; kc < nkc; ++kc) {
+    // one K chunk: registers -> LDS (sign XOR, pad columns), weight fragment, the chunk `ahead` steps on starts streaming, MACs
+    auto chunk = [&](VBuf& v, int kc, int ahead) {
         const u32x4 sx = sign_xor<T>(sg + kc * H + c * P::EPC);   // apply_symmetry: +-1 mask as a sign-bit XOR
         const int nv = F - (kc * H + c * P::EPC);                  // valid elements of this thread's chunk (pad columns dropped)
         __syncthreads();   // previous chunk's MFMAs are done reading LDS
@@ -134,7 +134,7 @@ template <typename T, bool ALIGNED> __global__ __launch_bounds__(256) void k_enc
                     (kc + 1 == nkc ? chunk_keep_first<T>(v[mi][it], nv) : v[mi][it]) ^ sx;      // only the last K chunk has pad columns
         __syncthreads();
         load_bfrag<T>(bf, wpack, a.pack0[t] + kc, wv, lane);   // before the prefetch: vmcnt retires in order
-        if (kc + 1 < nkc) fetch(kc + 1);   // the next K chunk streams from HBM under this chunk's MFMAs
+        if (kc + ahead < nkc) fetch(v, kc + ahead);   // a later K chunk streams from HBM under this chunk's MFMAs
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
             if (w0 + m * P::ROWS < a.B) {   // uniform
@@ -142,6 +142,22 @@ template <typename T, bool ALIGNED> __global__ __launch_bounds__(256) void k_enc
                 mac(acc[m], af, bf);
             }
         }
+    };
+#ifndef ENC_DEEP
+#define ENC_DEEP 0      // 1: two K chunks in flight per thread (experiment)
+#endif
+    if constexpr (ENC_DEEP && sizeof(T) == 2) {
+        VBuf va, vb2;
+        fetch(va, 0);
+        if (nkc > 1) fetch(vb2, 1);
+        for (int kc = 0; kc < nkc; kc += 2) {
+            chunk(va, kc, 2);
+            if (kc + 1 < nkc) chunk(vb2, kc + 1, 2);
+        }
+    } else {
+        VBuf v;
+        fetch(v, 0);
+        for (int kc = 0; kc < nkc; ++kc) chunk(v, kc, 1);
     }
     T* x0 = reinterpret_cast<T*>(a.x0);
     const int gnode = a.tbase[t] + node;
@@ -686,7 +702,7 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
 // under this one's MAC phases.  The destination nodes are processed in two groups (mshgnn_plan.hpp, SL_HA / SL_HB) so that
 // the accumulators stay in registers; group A's new activations wait, packed, while group B is multiplied.
 // ------------------------------------------------------------------------------------------------------
-template <typename T, int HS, int Q0>     // one group: slots q = Q0 + u of the slab header
+template <typename T, int HS, int Q0, int NM = 4>     // one group: slots q = Q0 + u of the slab header; NM: compile-time bound on the base_transform nodes
 __device__ __forceinline__ void slab_group_fwd(const StackArgs& a, const FHdr& fh, const FProg& wp, char* smem, const T* wpack, int wn, int lane,
                                                int slot_base, int nmlp, bool residual, u32x4 (&keep)[HS], unsigned (&bits)[(HS + 3) / 4]) {
     using P = Prec<T>;
@@ -704,11 +720,11 @@ __device__ __forceinline__ void slab_group_fwd(const StackArgs& a, const FHdr& f
         static_assert(sizeof(T) == 2, "fused stack kernels are bf16");
         typename P::BFrag bf, bf2;
         typename P::AFrag af;
-        u32x4 hpk[4], tpk[4];
+        u32x4 hpk[NM], tpk[NM];
         load_bfrag<T>(bf, wpack, fh[FH_W1], wn, lane);
         load_bfrag<T>(bf2, wpack, fh[FH_W2], wn, lane);
 #pragma unroll
-        for (int u = 0; u < 4 && u < HS; ++u) {
+        for (int u = 0; u < NM && u < HS; ++u) {
             if (u < nmlp) {
                 hpk[u] = pack_oct(acc[u].c[0], acc[u].c[1]);
                 *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(a.NN + u, win, col / P::EPC)) = hpk[u];
@@ -717,12 +733,12 @@ __device__ __forceinline__ void slab_group_fwd(const StackArgs& a, const FHdr& f
         }
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < 4 && u < HS; ++u) {
+        for (int u = 0; u < NM && u < HS; ++u) {
             if (u < nmlp) { load_afrag<T>(af, smem, a.NN + u, lane); mac(acc[u], af, bf); }
         }
         __syncthreads();   // all reads of H done before T1 overwrites the scratch blocks
 #pragma unroll
-        for (int u = 0; u < 4 && u < HS; ++u) {
+        for (int u = 0; u < NM && u < HS; ++u) {
             if (u < nmlp) {
                 tpk[u] = pack_oct(relu4(acc[u].c[0]), relu4(acc[u].c[1]));
                 *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(a.NN + u, win, col / P::EPC)) = tpk[u];
@@ -731,7 +747,7 @@ __device__ __forceinline__ void slab_group_fwd(const StackArgs& a, const FHdr& f
         }
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < 4 && u < HS; ++u) {
+        for (int u = 0; u < NM && u < HS; ++u) {
             if (u < nmlp) { load_afrag<T>(af, smem, a.NN + u, lane); mac(acc[u], af, bf2); }
         }
         __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));      // every load has landed before the first store
@@ -741,7 +757,7 @@ __device__ __forceinline__ void slab_group_fwd(const StackArgs& a, const FHdr& f
                 T* hb = reinterpret_cast<T*>(a.ws + a.hb_off[slot_base >> 8]);
                 T* t1 = reinterpret_cast<T*>(a.ws + a.t1_off[slot_base >> 8]);
 #pragma unroll
-                for (int u = 0; u < 4 && u < HS; ++u) {
+                for (int u = 0; u < NM && u < HS; ++u) {
                     if (u < nmlp) {
                         *reinterpret_cast<u32x4*>(hb + act_idx(w, u, a.B) + col) = hpk[u];
                         *reinterpret_cast<u32x4*>(t1 + act_idx(w, u, a.B) + col) = tpk[u];
@@ -792,7 +808,7 @@ __device__ __forceinline__ void slab_group_store(const StackArgs& a, const FHdr&
     }
 }
 
-template <typename T> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_fwd(StackArgs a) {
+template <typename T, int NM> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_fwd(StackArgs a) {
     using P = Prec<T>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -834,7 +850,7 @@ template <typename T> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_fw
         u32x4 keepA[SL_HA], keepB[SL_HB]; unsigned bitsA[(SL_HA + 3) / 4], bitsB[(SL_HB + 3) / 4];
         slab_group_fwd<T, SL_HA, 0>(a, fh, wa, smem, wpack, wn, lane, FH_SLOTA | (l << 8), 0, residual, keepA, bitsA);
         FS_STAMP(2 + 4 * l);
-        slab_group_fwd<T, SL_HB, SL_HA>(a, fh, wb, smem, wpack, wn, lane, FH_SLOTB | (l << 8), nmlp, residual, keepB, bitsB);
+        slab_group_fwd<T, SL_HB, SL_HA, NM>(a, fh, wb, smem, wpack, wn, lane, FH_SLOTB | (l << 8), nmlp, residual, keepB, bitsB);
         FS_STAMP(3 + 4 * l);
         __syncthreads();   // every wave is done reading X_l: the node blocks may be overwritten
         FS_STAMP(4 + 4 * l);
@@ -1054,7 +1070,7 @@ __device__ __forceinline__ void slab_group_bwd(const StackArgs& a, const FHdr& b
     }
 }
 
-template <typename T> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_bwd(StackArgs a) {
+template <typename T, int NM> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_bwd(StackArgs a) {
     using P = Prec<T>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1117,18 +1133,19 @@ template <typename T> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_bw
         // mask phase (each lane on the octets it owns): relu nodes are masked in place -> dH_l[n]; group A's accumulators start
         // at the residual term G_{l+1}[n].  Every relu byte and every LDS read is issued before the first use.
         {
-            unsigned mb[SL_HA + SL_HB]; u32x4 rawv[SL_HA + SL_HB]; int kindv[SL_HA + SL_HB], nodev[SL_HA + SL_HB];
+            // (the unmasked rows are the carried `keep` registers: the packed dX_{l+1} this wave wrote into the blocks itself)
+            unsigned mb[SL_HA + SL_HB];
 #pragma unroll
             for (int q = 0; q < SL_HA + SL_HB; ++q) {
-                kindv[q] = bh[FH_KIND + q]; nodev[q] = bh[(q < SL_HA ? FH_SLOTA : FH_SLOTB - SL_HA) + q];
-                mb[q] = 0xffu; rawv[q] = u32x4{0, 0, 0, 0};
-                if (kindv[q] == NK_RELU) mb[q] = maskbytes[relu_tile_base(nodev[q], B, blockIdx.x, wn) + lane];
-                if (kindv[q] != NK_DEAD) rawv[q] = *reinterpret_cast<const u32x4*>(smem + lds_chunk<T>(nodev[q], win, col / P::EPC));
+                mb[q] = 0xffu;
+                if (bh[FH_KIND + q] == NK_RELU) mb[q] = maskbytes[relu_tile_base(bh[(q < SL_HA ? FH_SLOTA : FH_SLOTB - SL_HA) + q], B, blockIdx.x, wn) + lane];
             }
 #pragma unroll
             for (int q = 0; q < SL_HA + SL_HB; ++q) {
-                if (kindv[q] == NK_RELU)
-                    *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(nodev[q], win, col / P::EPC)) = chunk_mask_bits<T>(rawv[q], mb[q]);
+                if (bh[FH_KIND + q] == NK_RELU) {
+                    const u32x4 raw = q < SL_HA ? keepA[q < SL_HA ? q : 0] : keepB[q < SL_HA ? 0 : q - SL_HA];
+                    *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(bh[(q < SL_HA ? FH_SLOTA : FH_SLOTB - SL_HA) + q], win, col / P::EPC)) = chunk_mask_bits<T>(raw, mb[q]);
+                }
             }
         }
         __syncthreads();
@@ -1141,11 +1158,11 @@ template <typename T> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_bw
             T* dh = reinterpret_cast<T*>(a.ws + a.dh_off[l]);
             typename P::BFrag bf;      // one buffer for both weights: a carried residual (72 VGPRs) lives through this chain
             typename P::AFrag af;
-            typename P::Acc tm[4];
-            u32x4 traw[4], dupk[4];
+            typename P::Acc tm[NM];
+            u32x4 traw[NM], dupk[NM];
             load_bfrag<T>(bf, wpack, bh[FH_W2], wn, lane);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NM; ++u) {
                 traw[u] = u32x4{0, 0, 0, 0};
                 if (u < nmlp) {
                     traw[u] = *reinterpret_cast<const u32x4*>(t1 + act_idx(wc, u, B) + col);
@@ -1157,7 +1174,7 @@ template <typename T> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_bw
             load_bfrag<T>(bf, wpack, bh[FH_W1], wn, lane);
             __syncthreads();   // all reads of the dY blocks done
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NM; ++u) {
                 if (u < nmlp) {
                     f32x4 t0, t1v, r0, r1; unpack_oct(traw[u], t0, t1v);
 #pragma unroll
@@ -1168,12 +1185,12 @@ template <typename T> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_bw
             }
             __syncthreads();
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NM; ++u) {
                 if (u < nmlp) { acc_fill(tm[u], 0.f); load_afrag<T>(af, smem, u, lane); mac(tm[u], af, bf); }
             }
             __syncthreads();   // all reads of the dU blocks done
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NM; ++u) {
                 if (u < nmlp) {
                     const u32x4 hp = pack_oct(tm[u].c[0], tm[u].c[1]);
                     *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(u, win, col / P::EPC)) = hp;
@@ -1693,9 +1710,9 @@ __global__ __launch_bounds__(256, GW_WPS) void k_gradw_bf16_lean(GradwArgs a) {
         if (w0 + GWB_KW <= a.B) {
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                pv[p] = *reinterpret_cast<const u32x4*>(pS + voffP + p * (int)(H * sizeof(T)));
+                pv[p] = ld16<(GW_NT > 1)>(pS + voffP + p * (int)(H * sizeof(T)));
                 qv[p] = u32x4{0, 0, 0, 0};
-                if (qn > 0) qv[p] = *reinterpret_cast<const u32x4*>(qS + voffQ[p]);
+                if (qn > 0) qv[p] = (GW_NT == 1 && q_raw) ? ld16<1>(qS + voffQ[p]) : ld16<(GW_NT > 1)>(qS + voffQ[p]);
             }
             if (p_masked) mw = *reinterpret_cast<const unsigned*>(mS + voffM);
         } else {                   // last chunk of the batch: rows beyond B are zero
@@ -1922,7 +1939,8 @@ extern "C" int mshgnn_plan_create(const mshgnn_desc* desc, mshgnn_plan** out) {
             p->use_slab = hp.slab && !(es && atoi(es) == 0);       // default on where the plan allows it; MSHGNN_SLAB=0 selects the 8-wave kernels
             p->slab_force = es && atoi(es) == 2;                   // MSHGNN_SLAB=2: also for batches that do not fill the chip
             { int dev = 0, cus = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); p->n_cu = cus > 0 ? cus : 256; }
-            if (p->use_slab && ((rc = set_lds_attr(k_slab_fwd<__bf16>, flds)) || (rc = set_lds_attr(k_slab_bwd<__bf16>, flds)))) { mshgnn_plan_destroy(p); return rc; }
+            if (p->use_slab && ((rc = set_lds_attr(k_slab_fwd<__bf16, 2>, flds)) || (rc = set_lds_attr(k_slab_bwd<__bf16, 2>, flds)) ||
+                                (rc = set_lds_attr(k_slab_fwd<__bf16, 4>, flds)) || (rc = set_lds_attr(k_slab_bwd<__bf16, 4>, flds)))) { mshgnn_plan_destroy(p); return rc; }
         }
     }
     *out = p;
@@ -2072,7 +2090,7 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
             ProfScope ps(p, hp.ks_stack_fwd, st);
             if (p->slab_for(tiles)) {
                 for (int l = 0; l < hp.L; ++l) a.prog_off[l] = hp.sl_fwd_off[l];
-                hipLaunchKernelGGL(k_slab_fwd<T>, dim3(tiles), dim3(SL_THREADS), (hp.fs_blk + FS_EXTRA_BLK) * Prec<T>::BLK, st, a);
+                hipLaunchKernelGGL((hp.n_mlp <= 2 ? k_slab_fwd<T, 2> : k_slab_fwd<T, 4>), dim3(tiles), dim3(SL_THREADS), (hp.fs_blk + FS_EXTRA_BLK) * Prec<T>::BLK, st, a);
             } else
             hipLaunchKernelGGL(k_stack_fwd<T>, dim3(tiles), dim3(LAYER_THREADS), (hp.fs_blk + FS_EXTRA_BLK) * Prec<T>::BLK, st, a);
             HIPCHK(hipGetLastError());
@@ -2141,7 +2159,7 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
             ProfScope ps(p, hp.ks_stack_bwd, st);
             if (p->slab_for(tiles)) {
                 for (int l = 0; l < hp.L; ++l) a.prog_off[l] = hp.sl_bwd_off[l];
-                hipLaunchKernelGGL(k_slab_bwd<T>, dim3(tiles), dim3(SL_THREADS), (hp.fs_blk + FS_EXTRA_BLK) * Prec<T>::BLK, st, a);
+                hipLaunchKernelGGL((hp.n_mlp <= 2 ? k_slab_bwd<T, 2> : k_slab_bwd<T, 4>), dim3(tiles), dim3(SL_THREADS), (hp.fs_blk + FS_EXTRA_BLK) * Prec<T>::BLK, st, a);
             } else
             hipLaunchKernelGGL(k_stack_bwd<T>, dim3(tiles), dim3(LAYER_THREADS), (hp.fs_blk + FS_EXTRA_BLK) * Prec<T>::BLK, st, a);
             fused_done = true;

@@ -21,6 +21,21 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
+// once-read streams (raw inputs): optional non-temporal loads, a build-time experiment switch (EXTRA=-DENC_NT=1 / -DGW_NT=1|2)
+#ifndef ENC_NT
+#define ENC_NT 0
+#endif
+#ifndef GW_NT
+#define GW_NT 0
+#endif
+#ifndef ENC_ORDER
+#define ENC_ORDER 0      // 1: encoder workgroups tile-major inside a type (all nodes of 64 windows run together)
+#endif
+template <int NT> __device__ __forceinline__ u32x4 ld16(const void* p) {
+    if constexpr (NT != 0) return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    else return *reinterpret_cast<const u32x4*>(p);
+}
+
 // ------------------------------------------------------------------------------------------------------
 // error handling
 // ------------------------------------------------------------------------------------------------------

@@ -82,7 +82,7 @@ template <bool ALIGNED> __global__ __launch_bounds__(256) void k_enc_x3(EncArgs 
     int t = 0;
     while (t + 1 < a.n_types && (int)blockIdx.x >= a.wg_prefix[t + 1]) ++t;
     const int local = blockIdx.x - a.wg_prefix[t];
-    const int node = local / a.tiles, tile = local % a.tiles;
+    const int node = ENC_ORDER ? local % a.nodes[t] : local / a.tiles, tile = ENC_ORDER ? local / a.nodes[t] : local % a.tiles;
     const int w0 = tile * MB * P::ROWS;
     const float* x = reinterpret_cast<const float*>(a.x[t]);
     const int64_t pitch = a.pitch[t];
@@ -109,8 +109,8 @@ template <bool ALIGNED> __global__ __launch_bounds__(256) void k_enc_x3(EncArgs 
                 // unconditional raw loads (nothing uses them here): rows past the batch re-read the last row, halves past the row's end
                 // re-read the K chunk's first elements -- the staging pass zeroes the latter, the former are never stored
                 const float* src = x + ((size_t)min(w, a.B - 1) * nt + node) * pitch;
-                v[m][0] = *reinterpret_cast<const u32x4*>(src + (nv > 0 ? k0 : kc * H));
-                v[m][1] = *reinterpret_cast<const u32x4*>(src + (nv > 4 ? k0 + 4 : kc * H));
+                v[m][0] = ld16<ENC_NT>(src + (nv > 0 ? k0 : kc * H));
+                v[m][1] = ld16<ENC_NT>(src + (nv > 4 ? k0 + 4 : kc * H));
             } else {
                 v[m][0] = u32x4{0, 0, 0, 0}; v[m][1] = u32x4{0, 0, 0, 0};
                 if (w < a.B) {
@@ -661,16 +661,16 @@ __global__ __launch_bounds__(256, GWX3_WPS) void k_gradw_x3(GradwArgs a) {
             const int wb = w0 + 16 * p, w = wb + r0;
             st.ph[p] = u32x4{0, 0, 0, 0}; st.pl[p] = u32x4{0, 0, 0, 0}; st.qa[p] = u32x4{0, 0, 0, 0}; st.qb[p] = u32x4{0, 0, 0, 0}; st.mw[p] = 0xffffffffu;
             if (w < a.B) {
-                st.ph[p] = *reinterpret_cast<const u32x4*>(p_hi + (size_t)wb * 2 * H + loff);
-                st.pl[p] = *reinterpret_cast<const u32x4*>(p_lo + (size_t)wb * 2 * H + loff);
+                st.ph[p] = ld16<(GW_NT > 1)>(p_hi + (size_t)wb * 2 * H + loff);
+                st.pl[p] = ld16<(GW_NT > 1)>(p_lo + (size_t)wb * 2 * H + loff);
                 if (p_masked) st.mw[p] = (mb + ((size_t)(wb >> 4) << 6))[moff];
                 if (q_act) {
-                    st.qa[p] = *reinterpret_cast<const u32x4*>(q_hi + (size_t)wb * 2 * H + loff);
-                    st.qb[p] = *reinterpret_cast<const u32x4*>(q_lo + (size_t)wb * 2 * H + loff);
+                    st.qa[p] = ld16<(GW_NT > 1)>(q_hi + (size_t)wb * 2 * H + loff);
+                    st.qb[p] = ld16<(GW_NT > 1)>(q_lo + (size_t)wb * 2 * H + loff);
                 } else if (a.aligned) {      // raw: a use here would serialise the loads
                     const float* q = qf + (size_t)wb * qstride + qoff;
-                    if (qvalid > 0) st.qa[p] = *reinterpret_cast<const u32x4*>(q);
-                    if (qvalid > 4) st.qb[p] = *reinterpret_cast<const u32x4*>(q + 4);
+                    if (qvalid > 0) st.qa[p] = ld16<(GW_NT > 0)>(q);
+                    if (qvalid > 4) st.qb[p] = ld16<(GW_NT > 0)>(q + 4);
                 } else {
                     const float* q = qf + (size_t)wb * qstride + qoff;
                     st.qa[p] = load_chunk<float>(q, qvalid, qvb);
@@ -769,6 +769,182 @@ __global__ __launch_bounds__(256, GWX3_WPS) void k_gradw_x3(GradwArgs a) {
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < 8; ++e) red[r0 * H + c * 8 + e] = bsum[e];
+        __syncthreads();
+        if (tid < H) {
+            float s2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s2 += red[r * H + tid];
+            slab[H * H + tid] = s2;
+        }
+    }
+}
+
+// k_gradw_x3_lean: the same 32-window step loop with the addressing of k_gradw_bf16_lean (mshgnn.hip): a thread owns TWO CONSECUTIVE windows of
+// one 16-byte column chunk, so every global address is  workgroup-uniform stream pointer (scalar registers, advanced by scalar adds)  +  ONE
+// per-thread 32-bit offset  +  an immediate (the [hi | lo] row layout puts the four loads of an operand at +0 / +256 / +512 / +768), the relu
+// bytes of its two rows are one aligned 16-bit load, and full chunks carry no bound checks.  The general kernel above keeps six 64-bit
+// per-thread pointers alive and spills three of them (28 B of scratch per lane, reloaded inside the step loop in front of the loads that
+// need them).  Same step order and MFMA sequence: the matrix slabs are bit-identical to the general kernel's; the bias partial sums add the
+// same values in another order.  Needs 16-byte aligned raw inputs (the launcher falls back to the general kernel otherwise).
+__global__ __launch_bounds__(256, GWX3_WPS) void k_gradw_x3_lean(GradwArgs a) {
+    using T = T16;
+    constexpr int KW = 32;
+    __shared__ __attribute__((aligned(16))) __bf16 Ph[KW * GWB_PITCH];
+    __shared__ __attribute__((aligned(16))) __bf16 Pl[KW * GWB_PITCH];
+    __shared__ __attribute__((aligned(16))) __bf16 Qh[KW * GWB_PITCH];
+    __shared__ __attribute__((aligned(16))) __bf16 Ql[KW * GWB_PITCH];
+    __shared__ __attribute__((aligned(16))) u32x4 mlut[256];       // relu byte -> AND mask of 8 bf16
+    __shared__ __attribute__((aligned(16))) u32x4 qfix[16][4];     // raw-input items: per column chunk c the keep masks and sign XORs of its two fp32 halves
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    mlut[tid] = chunk_mask_bits<__bf16>(u32x4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, (unsigned)tid);   // (visible after the first barrier)
+    const int wr = wv >> 1, wc = wv & 1;
+    const int ln = a.lane_order[blockIdx.x % a.n_pad], part = blockIdx.x / a.n_pad;
+    if (ln < 0) return;
+    const int* lh = a.lanes + ln * LANE_INTS;
+    const int bias_flag = lh[3];
+    const int* im = a.items + lh[0] * ITEM_INTS;
+    const int nchunks = (a.B + KW - 1) / KW;
+    const int ch0 = (int)((int64_t)part * nchunks / a.n_parts), ch1 = (int)((int64_t)(part + 1) * nchunks / a.n_parts);
+    const int nsteps = ch1 - ch0;
+    const int c = tid & 15, r2 = (tid >> 4) * 2;      // rows r2, r2 + 1 of the 32-window step, columns [8c, 8c + 8)
+    constexpr int ROWB = 2 * H * (int)sizeof(T);      // bytes of one [hi | lo] row
+
+    const char* pS = a.ws + a.buf_off[im[0]] + (x3_idx(0, im[2], a.B) + (size_t)ch0 * KW * 2 * H) * sizeof(T);
+    const bool p_masked = im[9] >= 0;
+    const int ntile = (a.B + 15) >> 4;
+    const char* mS = p_masked ? a.ws + a.buf_off[im[9]] + relu_byte(im[2], a.B, 0, 0) + (size_t)ch0 * (KW / 16) * 64 : a.ws;
+    const unsigned voffP = (unsigned)(r2 * ROWB + c * 16);
+    const unsigned voffM = (unsigned)(((c >> 2) * ntile + (r2 >> 4)) * 64 + (c & 3) * 16 + (r2 & 15));
+    const bool q_act = im[4] >= 0;
+    const char* qS; unsigned qsb; int qn = 8;
+    if (q_act) {
+        qS = a.ws + a.buf_off[im[3]] + (x3_idx(0, im[5], a.B) + (size_t)ch0 * KW * 2 * H) * sizeof(T);
+        qsb = ROWB;
+    } else {
+        const int t = im[3] - BUF_IN;
+        qsb = (unsigned)(a.nodes[t] * a.pitch[t]) * 4u;
+        qS = reinterpret_cast<const char*>(a.x[t]) + ((size_t)im[5] * a.pitch[t] + im[6]) * 4 + (size_t)ch0 * KW * qsb;
+        qn = im[7] - c * 8;
+        if (tid < 16) {      // (these constants would cost 16 VGPRs per lane: over the budget of three workgroups per CU)
+            const u32x4 ones = u32x4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+            qfix[tid][0] = chunk_keep_first<float>(ones, qn); qfix[tid][1] = chunk_keep_first<float>(ones, qn - 4);
+            qfix[tid][2] = sign_xor<float>(a.signs + im[8] + c * 8); qfix[tid][3] = sign_xor<float>(a.signs + im[8] + c * 8 + 4);
+        }
+    }
+    // raw rows: two 16-byte halves of 8 floats; halves past the row's end re-read the chunk's first bytes (never used: keepa / keepb are 0)
+    const unsigned voffQ0 = q_act ? voffP : (unsigned)r2 * qsb + (qn > 0 ? (unsigned)c * 32u : 0u);
+    const unsigned qhalf = q_act ? 256u : (qn > 4 ? 16u : 0u);
+    unsigned ldsw[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) ldsw[p] = (unsigned)gwb_elem(r2 + p, c * 8);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+    float bsum[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
+
+    u32x4 ph[2], pl[2], qa[2], qb[2]; unsigned mw = 0xffffu;
+    auto fetch = [&](int s) {      // loads of step s (chunk ch0 + s); pS / qS / mS already point at it
+        const int w0 = (ch0 + s) * KW;
+        if (w0 + KW <= a.B) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                ph[p] = *reinterpret_cast<const u32x4*>(pS + voffP + p * ROWB);
+                pl[p] = *reinterpret_cast<const u32x4*>(pS + voffP + p * ROWB + 256);
+                qa[p] = *reinterpret_cast<const u32x4*>(qS + voffQ0 + p * qsb);
+                qb[p] = *reinterpret_cast<const u32x4*>(qS + voffQ0 + p * qsb + qhalf);
+            }
+            if (p_masked) mw = *reinterpret_cast<const unsigned short*>(mS + voffM);
+        } else {                   // last chunk of the batch: rows beyond B are zero
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                ph[p] = u32x4{0, 0, 0, 0}; pl[p] = u32x4{0, 0, 0, 0}; qa[p] = u32x4{0, 0, 0, 0}; qb[p] = u32x4{0, 0, 0, 0};
+                if (w0 + r2 + p < a.B) {
+                    ph[p] = *reinterpret_cast<const u32x4*>(pS + voffP + p * ROWB);
+                    pl[p] = *reinterpret_cast<const u32x4*>(pS + voffP + p * ROWB + 256);
+                    qa[p] = *reinterpret_cast<const u32x4*>(qS + voffQ0 + p * qsb);
+                    qb[p] = *reinterpret_cast<const u32x4*>(qS + voffQ0 + p * qsb + qhalf);
+                }
+            }
+            mw = 0xffffu;
+            if (p_masked && w0 + r2 < a.B) mw = *reinterpret_cast<const unsigned short*>(mS + voffM);     // (the 16-window tile of row r2 exists)
+        }
+        pS += (size_t)KW * ROWB; qS += (size_t)KW * qsb; mS += (KW / 16) * 64;
+    };
+    auto stage_to_lds = [&]() {
+        u32x4 mk[2];
+        if (p_masked) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) mk[p] = mlut[(mw >> (8 * p)) & 0xffu];
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            u32x4 h = ph[p], l = pl[p];
+            if (p_masked) { h &= mk[p]; l &= mk[p]; }                   // dH = dX . relu bits
+            *reinterpret_cast<u32x4*>(&Ph[ldsw[p]]) = h;
+            *reinterpret_cast<u32x4*>(&Pl[ldsw[p]]) = l;
+            u32x4 qh = qa[p], ql = qb[p];
+            if (!q_act) {      // drop pad columns, symmetry sign mask, fp32 -> hi / lo
+                const u32x4 fa = (qa[p] & qfix[c][0]) ^ qfix[c][2], fb = (qb[p] & qfix[c][1]) ^ qfix[c][3];
+                split_oct(__builtin_bit_cast(f32x4, fa), __builtin_bit_cast(f32x4, fb), qh, ql);
+            }
+            *reinterpret_cast<u32x4*>(&Qh[ldsw[p]]) = qh;
+            *reinterpret_cast<u32x4*>(&Ql[ldsw[p]]) = ql;
+            if (bias_flag) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bsum[2 * e] += __builtin_bit_cast(float, h[e] << 16) + __builtin_bit_cast(float, l[e] << 16);
+                    bsum[2 * e + 1] += __builtin_bit_cast(float, h[e] & 0xffff0000u) + __builtin_bit_cast(float, l[e] & 0xffff0000u);
+                }
+            }
+        }
+    };
+    if (nsteps > 0) fetch(0);
+    for (int s = 0; s < nsteps; ++s) {
+        __syncthreads();      // the previous MFMA phase of every wave is done reading the tiles
+        stage_to_lds();
+        __syncthreads();
+        if (s + 1 < nsteps) fetch(s + 1);
+#pragma unroll
+        for (int ks = 0; ks < KW / 16; ++ks) {
+            bf16x8 afh[2], afl[2], bqh[2], bql[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                afh[i] = tr_frag(Ph, ks * 16, wr * 64 + i * 32, lane);
+                afl[i] = tr_frag(Pl, ks * 16, wr * 64 + i * 32, lane);
+                bqh[i] = tr_frag(Qh, ks * 16, wc * 64 + i * 32, lane);
+                bql[i] = tr_frag(Ql, ks * 16, wc * 64 + i * 32, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afh[i], bqh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afh[i], bql[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afl[i], bqh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+    float* slab = a.slabs + (size_t)(part * a.n_lanes + ln) * SLAB_FLOATS;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int o = wr * 64 + i * 32 + (q & 3) + ((q >> 2) << 3) + ((lane >> 5) << 2), k = wc * 64 + j * 32 + (lane & 31);
+                slab[o * H + k] = acc[i][j][q];
+            }
+    if (bias_flag) {
+        float* red = reinterpret_cast<float*>(Ph);   // 16 x 128 floats = 8 KB <= one tile
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[(tid >> 4) * H + c * 8 + e] = bsum[e];
         __syncthreads();
         if (tid < H) {
             float s2 = 0.f;
@@ -901,7 +1077,11 @@ int x3_backward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pit
         if (gw_phase >= 0) { a.lane_order = p->d_tables + hp.order_ph_off[gw_phase]; a.n_pad = hp.npad_ph[gw_phase]; }
         a.signs = p->d_signs; a.slabs = reinterpret_cast<float*>(ws + lay.slabs); a.B = B; a.n_lanes = hp.n_lanes; a.n_parts = hp.n_parts;
         ProfScope ps(p, hp.ks_gradw, st);
-        if (a.n_pad > 0) hipLaunchKernelGGL(k_gradw_x3, dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a);
+        static const bool gw_general = getenv("MSHGNN_GRADW") && std::string(getenv("MSHGNN_GRADW")) == "general";   // read once: the general kernel also where the lean one applies (A/B runs)
+        if (a.n_pad > 0) {
+            if (a.aligned && GWX3_KW == 32 && !gw_general) hipLaunchKernelGGL(k_gradw_x3_lean, dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL(k_gradw_x3, dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a);
+        }
     }
     return run_finalize(p, lay, ws, gparams, B, (y || labels) ? loss : nullptr, labels != nullptr, dec_done, gw_phase, st);
 }
