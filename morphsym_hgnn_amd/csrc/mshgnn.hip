@@ -721,34 +721,41 @@ __device__ __forceinline__ void slab_group_fwd(const StackArgs& a, const FHdr& f
         typename P::BFrag bf, bf2;
         typename P::AFrag af;
         u32x4 hpk[NM], tpk[NM];
+        // scratch blocks: behind the tile, or (FF_SCR_ALIAS) the blocks of the first group-A nodes -- every wave must then be done with ALL
+        // its MACs (and group A's residual reads) before H lands in them
+        const bool alias = (fh[FH_FLAGS] & FF_SCR_ALIAS) != 0;
+        int scr[NM];
+#pragma unroll
+        for (int u = 0; u < NM; ++u) scr[u] = alias ? fh[FH_SLOTA + u] : a.NN + u;
+        if (alias) __syncthreads();
         load_bfrag<T>(bf, wpack, fh[FH_W1], wn, lane);
         load_bfrag<T>(bf2, wpack, fh[FH_W2], wn, lane);
 #pragma unroll
         for (int u = 0; u < NM && u < HS; ++u) {
             if (u < nmlp) {
                 hpk[u] = pack_oct(acc[u].c[0], acc[u].c[1]);
-                *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(a.NN + u, win, col / P::EPC)) = hpk[u];
+                *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(scr[u], win, col / P::EPC)) = hpk[u];
                 acc_init_bias<T>(acc[u], a.bias + (size_t)fh[FH_B1] * H, wn, lane);
             }
         }
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < NM && u < HS; ++u) {
-            if (u < nmlp) { load_afrag<T>(af, smem, a.NN + u, lane); mac(acc[u], af, bf); }
+            if (u < nmlp) { load_afrag<T>(af, smem, scr[u], lane); mac(acc[u], af, bf); }
         }
         __syncthreads();   // all reads of H done before T1 overwrites the scratch blocks
 #pragma unroll
         for (int u = 0; u < NM && u < HS; ++u) {
             if (u < nmlp) {
                 tpk[u] = pack_oct(relu4(acc[u].c[0]), relu4(acc[u].c[1]));
-                *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(a.NN + u, win, col / P::EPC)) = tpk[u];
+                *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(scr[u], win, col / P::EPC)) = tpk[u];
                 acc_init_bias<T>(acc[u], a.bias + (size_t)fh[FH_B2] * H, wn, lane);
             }
         }
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < NM && u < HS; ++u) {
-            if (u < nmlp) { load_afrag<T>(af, smem, a.NN + u, lane); mac(acc[u], af, bf2); }
+            if (u < nmlp) { load_afrag<T>(af, smem, scr[u], lane); mac(acc[u], af, bf2); }
         }
         __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));      // every load has landed before the first store
         if (a.training) {
@@ -808,7 +815,7 @@ __device__ __forceinline__ void slab_group_store(const StackArgs& a, const FHdr&
     }
 }
 
-template <typename T, int NM> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_fwd(StackArgs a) {
+template <typename T, int NM, int HB> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_fwd(StackArgs a) {
     using P = Prec<T>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -847,16 +854,16 @@ template <typename T, int NM> __global__ __launch_bounds__(SL_THREADS, 2) void k
         }
         const int nmlp = fh[FH_NMLP];
         const bool residual = (fh[FH_FLAGS] & FF_RESIDUAL) != 0;
-        u32x4 keepA[SL_HA], keepB[SL_HB]; unsigned bitsA[(SL_HA + 3) / 4], bitsB[(SL_HB + 3) / 4];
+        u32x4 keepA[SL_HA], keepB[HB]; unsigned bitsA[(SL_HA + 3) / 4], bitsB[(HB + 3) / 4];
         slab_group_fwd<T, SL_HA, 0>(a, fh, wa, smem, wpack, wn, lane, FH_SLOTA | (l << 8), 0, residual, keepA, bitsA);
         FS_STAMP(2 + 4 * l);
-        slab_group_fwd<T, SL_HB, SL_HA, NM>(a, fh, wb, smem, wpack, wn, lane, FH_SLOTB | (l << 8), nmlp, residual, keepB, bitsB);
+        slab_group_fwd<T, HB, SL_HA, NM>(a, fh, wb, smem, wpack, wn, lane, FH_SLOTB | (l << 8), nmlp, residual, keepB, bitsB);
         FS_STAMP(3 + 4 * l);
         __syncthreads();   // every wave is done reading X_l: the node blocks may be overwritten
         FS_STAMP(4 + 4 * l);
         __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));      // loads (next header / programs) landed before the stores go out
         slab_group_store<T, SL_HA, 0>(a, fh, smem, wn, lane, FH_SLOTA, l, keepA, bitsA);
-        slab_group_store<T, SL_HB, SL_HA>(a, fh, smem, wn, lane, FH_SLOTB, l, keepB, bitsB);
+        slab_group_store<T, HB, SL_HA>(a, fh, smem, wn, lane, FH_SLOTB, l, keepB, bitsB);
         __syncthreads();
         FS_STAMP(5 + 4 * l);
     }
@@ -1070,7 +1077,7 @@ __device__ __forceinline__ void slab_group_bwd(const StackArgs& a, const FHdr& b
     }
 }
 
-template <typename T, int NM> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_bwd(StackArgs a) {
+template <typename T, int NM, int HB> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_bwd(StackArgs a) {
     using P = Prec<T>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1083,7 +1090,7 @@ template <typename T, int NM> __global__ __launch_bounds__(SL_THREADS, 2) void k
         const FHdr bh(a.tables + a.prog_off[a.L - 1], lane);
         const T* src = reinterpret_cast<const T*>(a.tile_in);
         const int row = tid >> 4, c = tid & 15;
-        for (int q = 0; q < SL_HA + SL_HB; ++q) {
+        for (int q = 0; q < SL_HA + HB; ++q) {
             const int n = bh[(q < SL_HA ? FH_SLOTA : FH_SLOTB - SL_HA) + q];
             if (n < 0 || bh[FH_KIND + q] == NK_DEAD) continue;
             u32x4 v = u32x4{0, 0, 0, 0};
@@ -1097,7 +1104,7 @@ template <typename T, int NM> __global__ __launch_bounds__(SL_THREADS, 2) void k
     FProg wan(a.tables + a.prog_off[a.L - 1] + FH_SIZE, lane), wbn(a.tables + a.prog_off[a.L - 1] + FH_SIZE + FPROG_LEN, lane);
     // group A's residual term travels from layer to layer in registers (the packed dX rows of the previous epilogue); for the
     // last layer it is the decoder backward's dX_L
-    u32x4 keepA[SL_HA], keepB[SL_HB];
+    u32x4 keepA[SL_HA], keepB[HB];
     {
         const T* src = reinterpret_cast<const T*>(a.tile_in);
         const int wq = min(w0 + c_win(lane), B - 1), colq = wn * 32 + c_oct(lane);
@@ -1108,7 +1115,7 @@ template <typename T, int NM> __global__ __launch_bounds__(SL_THREADS, 2) void k
             if (n >= 0 && bhn[FH_KIND + u] != NK_DEAD) keepA[u] = *reinterpret_cast<const u32x4*>(src + act_idx(wq, n, B) + colq);
         }
 #pragma unroll
-        for (int u = 0; u < SL_HB; ++u) {
+        for (int u = 0; u < HB; ++u) {
             keepB[u] = u32x4{0, 0, 0, 0};
             const int n = bhn[FH_SLOTB + u];
             if (n >= 0 && bhn[FH_KIND + SL_HA + u] != NK_DEAD) keepB[u] = *reinterpret_cast<const u32x4*>(src + act_idx(wq, n, B) + colq);
@@ -1134,14 +1141,14 @@ template <typename T, int NM> __global__ __launch_bounds__(SL_THREADS, 2) void k
         // at the residual term G_{l+1}[n].  Every relu byte and every LDS read is issued before the first use.
         {
             // (the unmasked rows are the carried `keep` registers: the packed dX_{l+1} this wave wrote into the blocks itself)
-            unsigned mb[SL_HA + SL_HB];
+            unsigned mb[SL_HA + HB];
 #pragma unroll
-            for (int q = 0; q < SL_HA + SL_HB; ++q) {
+            for (int q = 0; q < SL_HA + HB; ++q) {
                 mb[q] = 0xffu;
                 if (bh[FH_KIND + q] == NK_RELU) mb[q] = maskbytes[relu_tile_base(bh[(q < SL_HA ? FH_SLOTA : FH_SLOTB - SL_HA) + q], B, blockIdx.x, wn) + lane];
             }
 #pragma unroll
-            for (int q = 0; q < SL_HA + SL_HB; ++q) {
+            for (int q = 0; q < SL_HA + HB; ++q) {
                 if (bh[FH_KIND + q] == NK_RELU) {
                     const u32x4 raw = q < SL_HA ? keepA[q < SL_HA ? q : 0] : keepB[q < SL_HA ? 0 : q - SL_HA];
                     *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(bh[(q < SL_HA ? FH_SLOTA : FH_SLOTB - SL_HA) + q], win, col / P::EPC)) = chunk_mask_bits<T>(raw, mb[q]);
@@ -1181,6 +1188,9 @@ template <typename T, int NM> __global__ __launch_bounds__(SL_THREADS, 2) void k
                     for (int j = 0; j < 4; ++j) { r0[j] = t0[j] > 0.f ? tm[u].c[0][j] : 0.f; r1[j] = t1v[j] > 0.f ? tm[u].c[1][j] : 0.f; }
                     dupk[u] = pack_oct(r0, r1);
                     *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(u, win, col / P::EPC)) = dupk[u];
+                    // four base_transform nodes (K4): the dU rows go out at once -- holding them to the end of the chain costs 16 VGPRs the
+                    // kernel does not have (no global load follows inside the chain; the MAC phase drains the stores before its first fragment)
+                    if constexpr (NM > 2) { if (w_ok) *reinterpret_cast<u32x4*>(du + act_idx(w, u, B) + col) = dupk[u]; }
                 }
             }
             __syncthreads();
@@ -1195,7 +1205,7 @@ template <typename T, int NM> __global__ __launch_bounds__(SL_THREADS, 2) void k
                     const u32x4 hp = pack_oct(tm[u].c[0], tm[u].c[1]);
                     *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(u, win, col / P::EPC)) = hp;
                     if (w_ok) {
-                        *reinterpret_cast<u32x4*>(du + act_idx(w, u, B) + col) = dupk[u];
+                        if constexpr (NM <= 2) *reinterpret_cast<u32x4*>(du + act_idx(w, u, B) + col) = dupk[u];
                         *reinterpret_cast<u32x4*>(dh + act_idx(w, u, B) + col) = hp;
                     }
                 }
@@ -1207,12 +1217,12 @@ template <typename T, int NM> __global__ __launch_bounds__(SL_THREADS, 2) void k
         const T* xact = reinterpret_cast<const T*>(a.ws + a.x_off[0]);
         const bool enc_mask = (flags & FF_ENC_MASK) != 0;
         slab_group_bwd<T, SL_HA, 0>(a, bh, wa, smem, wpack, wn, lane, FH_SLOTA, xact, enc_mask, keepA);
-        slab_group_bwd<T, SL_HB, SL_HA>(a, bh, wb, smem, wpack, wn, lane, FH_SLOTB, xact, enc_mask, keepB);
+        slab_group_bwd<T, HB, SL_HA>(a, bh, wb, smem, wpack, wn, lane, FH_SLOTB, xact, enc_mask, keepB);
         __syncthreads();   // every wave is done reading dH_l
         __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));
         T* dxo = reinterpret_cast<T*>(a.ws + a.dx_off[l]);
 #pragma unroll
-        for (int q = 0; q < SL_HA + SL_HB; ++q) {
+        for (int q = 0; q < SL_HA + HB; ++q) {
             if (bh[FH_OUT + q]) {
                 const int n = bh[(q < SL_HA ? FH_SLOTA : FH_SLOTB - SL_HA) + q];
                 const u32x4 v = q < SL_HA ? keepA[q < SL_HA ? q : 0] : keepB[q < SL_HA ? 0 : q - SL_HA];
@@ -1222,6 +1232,17 @@ template <typename T, int NM> __global__ __launch_bounds__(SL_THREADS, 2) void k
         }
         __syncthreads();
     }
+}
+
+// the slab instantiation of a plan: NM = bound on the base_transform nodes (2 / 4), HB = group-B slots (6 / 8)
+using StackKernel = void (*)(StackArgs);
+static StackKernel slab_fwd_kernel(const HostPlan& hp) {
+    if (hp.sl_hb <= SL_HB) return hp.n_mlp <= 2 ? k_slab_fwd<__bf16, 2, SL_HB> : k_slab_fwd<__bf16, 4, SL_HB>;
+    return hp.n_mlp <= 2 ? k_slab_fwd<__bf16, 2, SL_HB_MAX> : k_slab_fwd<__bf16, 4, SL_HB_MAX>;
+}
+static StackKernel slab_bwd_kernel(const HostPlan& hp) {
+    if (hp.sl_hb <= SL_HB) return hp.n_mlp <= 2 ? k_slab_bwd<__bf16, 2, SL_HB> : k_slab_bwd<__bf16, 4, SL_HB>;
+    return hp.n_mlp <= 2 ? k_slab_bwd<__bf16, 2, SL_HB_MAX> : k_slab_bwd<__bf16, 4, SL_HB_MAX>;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1939,8 +1960,7 @@ extern "C" int mshgnn_plan_create(const mshgnn_desc* desc, mshgnn_plan** out) {
             p->use_slab = hp.slab && !(es && atoi(es) == 0);       // default on where the plan allows it; MSHGNN_SLAB=0 selects the 8-wave kernels
             p->slab_force = es && atoi(es) == 2;                   // MSHGNN_SLAB=2: also for batches that do not fill the chip
             { int dev = 0, cus = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); p->n_cu = cus > 0 ? cus : 256; }
-            if (p->use_slab && ((rc = set_lds_attr(k_slab_fwd<__bf16, 2>, flds)) || (rc = set_lds_attr(k_slab_bwd<__bf16, 2>, flds)) ||
-                                (rc = set_lds_attr(k_slab_fwd<__bf16, 4>, flds)) || (rc = set_lds_attr(k_slab_bwd<__bf16, 4>, flds)))) { mshgnn_plan_destroy(p); return rc; }
+            if (p->use_slab && ((rc = set_lds_attr(slab_fwd_kernel(hp), flds)) || (rc = set_lds_attr(slab_bwd_kernel(hp), flds)))) { mshgnn_plan_destroy(p); return rc; }
         }
     }
     *out = p;
@@ -2090,7 +2110,7 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
             ProfScope ps(p, hp.ks_stack_fwd, st);
             if (p->slab_for(tiles)) {
                 for (int l = 0; l < hp.L; ++l) a.prog_off[l] = hp.sl_fwd_off[l];
-                hipLaunchKernelGGL((hp.n_mlp <= 2 ? k_slab_fwd<T, 2> : k_slab_fwd<T, 4>), dim3(tiles), dim3(SL_THREADS), (hp.fs_blk + FS_EXTRA_BLK) * Prec<T>::BLK, st, a);
+                hipLaunchKernelGGL(slab_fwd_kernel(hp), dim3(tiles), dim3(SL_THREADS), (hp.sl_blk + FS_EXTRA_BLK) * Prec<T>::BLK, st, a);
             } else
             hipLaunchKernelGGL(k_stack_fwd<T>, dim3(tiles), dim3(LAYER_THREADS), (hp.fs_blk + FS_EXTRA_BLK) * Prec<T>::BLK, st, a);
             HIPCHK(hipGetLastError());
@@ -2159,7 +2179,7 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
             ProfScope ps(p, hp.ks_stack_bwd, st);
             if (p->slab_for(tiles)) {
                 for (int l = 0; l < hp.L; ++l) a.prog_off[l] = hp.sl_bwd_off[l];
-                hipLaunchKernelGGL((hp.n_mlp <= 2 ? k_slab_bwd<T, 2> : k_slab_bwd<T, 4>), dim3(tiles), dim3(SL_THREADS), (hp.fs_blk + FS_EXTRA_BLK) * Prec<T>::BLK, st, a);
+                hipLaunchKernelGGL(slab_bwd_kernel(hp), dim3(tiles), dim3(SL_THREADS), (hp.sl_blk + FS_EXTRA_BLK) * Prec<T>::BLK, st, a);
             } else
             hipLaunchKernelGGL(k_stack_bwd<T>, dim3(tiles), dim3(LAYER_THREADS), (hp.fs_blk + FS_EXTRA_BLK) * Prec<T>::BLK, st, a);
             fused_done = true;

@@ -84,9 +84,13 @@ enum { FH_NSEG = 0, FH_NMLP, FH_W1, FH_W2, FH_B1, FH_B2, FH_FLAGS, FH_MLP0,   //
 // bound by that path: DESIGN.md section 6).  To keep the accumulators in registers the destination nodes are processed in two
 // groups, one after the other: A = the node type with the most nodes (<= SL_HA), B = all other nodes (<= SL_HB); group A's
 // results wait, packed, while group B is multiplied.  Wave programs as above with 2 (group A) / 3 (group B) bits of MAC count per slot.
-constexpr int SL_HA = 12, SL_HB = 6, SL_THREADS = 256;
-constexpr int SL_CBA = 2, SL_CBB = 3;    // bits of MAC count per slot and segment in group A / B programs (12 x 2, 6 x 3 bits)
-enum { FF_RESIDUAL = 1, FF_ENC_MASK = 2 };
+// Group B holds 6 slots (A1-C2, the MI graph, the COM graphs) or 8 (MiniCheetah-K4: 4 base + 4 foot nodes): the kernels are instantiated for both
+// (template parameter HB), the plan says which (sl_hb).  Where the tile + base_transform scratch blocks do not fit twice into a CU's LDS but
+// the tile alone does (K4: 20 + 4 blocks), the scratch blocks ALIAS the first group-A nodes (FF_SCR_ALIAS: one more barrier per layer with a
+// live base_transform; group A's residual reads are over by then and its new rows wait in registers).
+constexpr int SL_HA = 12, SL_HB = 6, SL_HB_MAX = 8, SL_THREADS = 256;
+constexpr int SL_CBA = 2, SL_CBB = 3;    // bits of MAC count per slot and segment in group A / B programs (12 x 2, 6..8 x 3 bits)
+enum { FF_RESIDUAL = 1, FF_ENC_MASK = 2, FF_SCR_ALIAS = 4 };
 
 // buffer ids used by weight-gradient items
 enum { BUF_X = 0, BUF_DX = 17, BUF_DH = 34, BUF_HB = 50, BUF_T1 = 66, BUF_DU = 82, BUF_IN = 98, BUF_MASK = 102, BUF_COUNT = 118 };
@@ -146,7 +150,8 @@ struct HostPlan {
     bool fused = false;                           // fused stack kernels available (bf16, <= FS_MAXN nodes, programs fit)
     int fs_fwd_off[MAX_L]{}, fs_bwd_off[MAX_L]{};
     bool slab = false;                            // slab variant available (two 4-wave workgroups per CU fit, groups fit)
-    int sl_fwd_off[MAX_L]{}, sl_bwd_off[MAX_L]{}, sl_ta = -1;
+    int sl_fwd_off[MAX_L]{}, sl_bwd_off[MAX_L]{}, sl_ta = -1, sl_hb = SL_HB, sl_blk = 0;      // sl_hb: group-B slots (6 / 8); sl_blk: LDS blocks of a slab workgroup
+    bool sl_alias = false;                        // base_transform scratch aliases group-A node blocks
     int fs_blk = 0;                               // LDS blocks of the fused kernels (NN + base_transform scratch)
     int ks_stack_fwd = -1, ks_stack_bwd = -1;
     int item_off = 0, n_items = 0, tgt_off = 0, n_targets = 0, lane_off = 0, n_lanes = 0, n_parts = 1, n_wg_gradw = 0;
@@ -525,7 +530,10 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
         std::vector<int> slotA, slotB;
         for (int n = 0; n < p.NN; ++n) (p.node_type[n] == tA ? slotA : slotB).push_back(n);
         p.sl_ta = tA;
-        p.slab = !p.split && 2 * (int64_t)p.fs_blk * p.blk_bytes <= LDS_LIMIT && (int)slotA.size() <= SL_HA && (int)slotB.size() <= SL_HB &&
+        p.sl_hb = (int)slotB.size() <= SL_HB ? SL_HB : SL_HB_MAX;
+        p.sl_alias = 2 * (int64_t)p.fs_blk * p.blk_bytes > LDS_LIMIT && p.n_mlp <= (int)slotA.size();
+        p.sl_blk = p.sl_alias ? p.NN : p.fs_blk;
+        p.slab = !p.split && 2 * (int64_t)p.sl_blk * p.blk_bytes <= LDS_LIMIT && (int)slotA.size() <= SL_HA && (int)slotB.size() <= SL_HB_MAX &&
                  (!has_mlp || (d.mlp_type != tA && p.n_mlp <= (int)slotB.size()));     // base_transform nodes = the first slots of group B
         if (has_mlp) for (int u = 0; u < p.n_mlp && p.slab; ++u) if (slotB[u] != p.type_base[d.mlp_type] + u) p.slab = false;
         auto emit_slab = [&](const std::vector<Seg>& segs, int hdr_src) {
@@ -533,7 +541,8 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
             for (int i = 0; i < FH_SLOTA; ++i) T[h + i] = T[hdr_src + i];
             for (int u = 0; u < 16; ++u) { T[h + FH_SLOTA + u] = u < (int)slotA.size() ? slotA[u] : -1; T[h + FH_SLOTB + u] = u < (int)slotB.size() ? slotB[u] : -1; }
             // per-node arrays re-indexed by slot q (group A: q = u, group B: q = SL_HA + u) so that the kernel reads them with constant lanes
-            static_assert(SL_HA + SL_HB <= FS_MAXN, "slot arrays share the per-node header arrays");
+            static_assert(SL_HA + SL_HB_MAX <= FS_MAXN, "slot arrays share the per-node header arrays");
+            if (p.sl_alias) T[h + FH_FLAGS] |= FF_SCR_ALIAS;
             for (int q = 0; q < FS_MAXN; ++q) {
                 const int n = q < SL_HA ? (q < (int)slotA.size() ? slotA[q] : -1) : (q - SL_HA < (int)slotB.size() ? slotB[q - SL_HA] : -1);
                 for (int arr : {FH_KIND, FH_BIAS, FH_OUT, FH_RES}) T[h + arr + q] = n >= 0 ? T[hdr_src + arr + n] : 0;

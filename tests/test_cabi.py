@@ -43,7 +43,7 @@ def test_plan_compiler_kernel_sets():
     mi = helpers.make_spec("mi", "quadruped-mi", "", 128, 2, grf=1)
     assert engine.compile_plan_host(mi, "bf16").kernel_sets == 3
     k4 = helpers.make_spec("k4", "mini_cheetah-k4", "mini_cheetah-k4", 128, 8, regression=False)
-    assert engine.compile_plan_host(k4, "bf16").kernel_sets == 1        # 20 nodes + 4 scratch blocks = 96 KB: one workgroup per CU only
+    assert engine.compile_plan_host(k4, "bf16").kernel_sets == 3        # 20 nodes: the base_transform scratch aliases four joint blocks (80 KB, two workgroups per CU), group B of 8 slots
     for kind, topo, cfg in (("k4_com", "solo-k4-com", "solo-k4-com"), ("c2_com", "solo-c2-com", "solo-c2-com")):
         try:
             spec = helpers.make_spec(kind, topo, cfg, 128, 2)
