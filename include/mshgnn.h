@@ -253,6 +253,28 @@ int mshgnn_assemble_windows(const mshgnn_window_desc* desc, const float* const* 
                             const int64_t* src_rows, const int64_t* starts /* device int64[batch] */, int64_t batch,
                             void* const* x_out, const int64_t* x_pitch, float* y_out, float* quat_out, void* stream);
 
+/* ---- stand-alone operators behind the four torch_geometric.nn names ----------------------------------
+ * For a maintainer who swaps only the PyG import (hgnn_c2.py:3): Linear / HeteroDictLinear (hgnn_c2.py:88,131), GraphConv
+ * (hgnn_c2.py:100-112) and their autograd backward on arbitrary graphs and widths, fp32 operands, fp32 MFMA, no float atomics.
+ *
+ * mshgnn_op_gemm: C[m ldc + n] (+)= sum_k A[m sAm + k sAk] B[n sBn + k sBk] (+ bias[n]) -- element strides, so the three products
+ * of a Linear are one entry point: y = x W^T + b (A = x, B = W), dx = dy W (B = W with sBn = 1, sBk = in), dW = dy^T x (A = dy with
+ * sAm = 1, sAk = out; B = x with sBn = 1, sBk = in: reduction over the rows, split-K with a fixed-order sum).
+ * mshgnn_op_gemm_workspace: bytes of device workspace that shape needs (0: none).  accumulate != 0 adds into C.               */
+int64_t mshgnn_op_gemm_workspace(int64_t M, int64_t N, int64_t K, int32_t* splits_out);
+int mshgnn_op_gemm(const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBn, int64_t sBk, const float* bias,
+                   float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int accumulate, void* workspace, void* stream);
+
+/* GraphConv's aggregation (PyG: propagate with aggr 'add' / 'mean', before lin_rel): out[r][:] = sum over the CSR row r of
+ * edge_scale[e] x[col[e]][:] (edge_scale null: 1; 'mean': 1 / max(in-degree, 1) of the edge's destination).  The backward is the
+ * same call on the CSR of the transposed graph.  rowptr: int32[n_rows + 1], col / edge_scale: [n_edges], all on the device.   */
+int mshgnn_op_aggregate(const float* x, int64_t ldx, const int32_t* rowptr, const int32_t* col, const float* edge_scale,
+                        float* out, int64_t ldo, int64_t n_rows, int64_t width, void* stream);
+
+/* bias gradient: out[n] = sum_m X[m ldx + n], two fixed-order stages; workspace bytes from mshgnn_op_colsum_workspace.      */
+int64_t mshgnn_op_colsum_workspace(int64_t M, int64_t N);
+int mshgnn_op_colsum(const float* X, int64_t ldx, float* out, int64_t M, int64_t N, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

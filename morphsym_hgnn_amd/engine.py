@@ -80,6 +80,7 @@ EXPORTS = [
     "mshgnn_profile_enable", "mshgnn_profile_read", "mshgnn_backward_mse", "mshgnn_adam_step",
     "mshgnn_metrics_regression", "mshgnn_metrics_classification", "mshgnn_grf_body_to_world", "mshgnn_assemble_windows",
     "mshgnn_backward_ce", "mshgnn_step_mse", "mshgnn_step_mse_phase",
+    "mshgnn_op_gemm", "mshgnn_op_gemm_workspace", "mshgnn_op_aggregate", "mshgnn_op_colsum", "mshgnn_op_colsum_workspace",
 ]
 
 _lib = None
@@ -134,6 +135,15 @@ def load_library():
     lib.mshgnn_assemble_windows.argtypes = [C.POINTER(MshgnnWindowDesc), C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                             C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p, C.c_void_p,
                                             C.c_void_p]
+    lib.mshgnn_op_gemm_workspace.restype = C.c_int64
+    lib.mshgnn_op_gemm_workspace.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int32)]
+    lib.mshgnn_op_gemm.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
+                                   C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
+    lib.mshgnn_op_aggregate.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
+                                        C.c_void_p]
+    lib.mshgnn_op_colsum_workspace.restype = C.c_int64
+    lib.mshgnn_op_colsum_workspace.argtypes = [C.c_int64, C.c_int64]
+    lib.mshgnn_op_colsum.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
     _lib = lib
     return lib
 

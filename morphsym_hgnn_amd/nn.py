@@ -7,9 +7,11 @@ the same constructor signatures, attribute names and state_dict keys (PyG 2.5.0)
     decoder.{weight,bias}
 
 so reference checkpoints load unchanged and `model.convs[i].convs[edge_type].lin_rel.weight`
-(hgnn_c2.py:295-306) keeps working.  Their arithmetic does NOT live here: the model classes in models.py hand
-all parameters to the fused HIP engine.  Calling one of these modules on its own raises, loudly -- there is
-no eager / CPU implementation of the path in this package.
+(hgnn_c2.py:295-306) keeps working.  The model classes in models.py hand all parameters to the fused HIP engine and
+never call these forwards.  Called on their own (a maintainer who swaps only the PyG import) they run PyG 2.5.0's
+semantics -- `forward(x)`, `forward(x_dict)`, `forward(x | (x_src, x_dst), edge_index)`, `forward(x_dict,
+edge_index_dict)` -- on the stand-alone HIP operators of ops.py (fp32 MFMA, autograd), for any graph and width.  There
+is no eager / CPU implementation: tensors off the HIP device raise.
 """
 from __future__ import annotations
 
@@ -21,8 +23,7 @@ from torch import nn
 
 EdgeType = Tuple[str, str, str]
 
-_STANDALONE = ("{} is a parameter container of the fused MI355X MS-HGNN engine; run it through "
-               "GRF_HGNN_C2 / GRF_HGNN_K4 / GRF_HGNN (morphsym_hgnn_amd.models). There is no eager fallback.")
+from . import ops
 
 
 class Linear(nn.Module):
@@ -59,7 +60,9 @@ class Linear(nn.Module):
                 self.bias.uniform_(-bound, bound)
 
     def forward(self, x):
-        raise NotImplementedError(_STANDALONE.format("Linear"))
+        """y = x W^T + b; a lazy weight (`in_channels=-1`) is materialised from x on the first call, like PyG's."""
+        self.materialize(x.shape[-1])
+        return ops.linear(x, self.weight, self.bias)
 
 
 class HeteroDictLinear(nn.Module):
@@ -78,7 +81,8 @@ class HeteroDictLinear(nn.Module):
             lin.reset_parameters()
 
     def forward(self, x_dict):
-        raise NotImplementedError(_STANDALONE.format("HeteroDictLinear"))
+        """One Linear per node type present in x_dict (PyG HeteroDictLinear.forward)."""
+        return {k: self.lins[k](x) for k, x in x_dict.items() if k in self.lins}
 
 
 class GraphConv(nn.Module):
@@ -98,7 +102,10 @@ class GraphConv(nn.Module):
         self.lin_root.reset_parameters()
 
     def forward(self, x, edge_index, edge_weight=None, size=None):
-        raise NotImplementedError(_STANDALONE.format("GraphConv"))
+        """out_i = lin_rel(aggr_{j->i} x_src[j]) + lin_root(x_dst[i]); x is a tensor or an (x_src, x_dst) pair."""
+        if edge_weight is not None:
+            raise NotImplementedError("GraphConv(edge_weight=...) is not on the MS-HGNN path (hgnn_c2.py never passes one)")
+        return ops.graph_conv(x, edge_index, self.lin_rel.weight, self.lin_rel.bias, self.lin_root.weight, self.aggr)
 
 
 def internal_key(edge_type) -> str:
@@ -137,4 +144,20 @@ class HeteroConv(nn.Module):
             c.reset_parameters()
 
     def forward(self, x_dict, edge_index_dict):
-        raise NotImplementedError(_STANDALONE.format("HeteroConv"))
+        """PyG HeteroConv.forward: relations in constructor order, those without edges or features skipped, results summed per
+        destination type (`torch.stack(xs).sum(0)`: left to right)."""
+        outs: Dict[str, list] = {}
+        for et in self.edge_types:
+            if et not in edge_index_dict:
+                continue
+            src, _, dst = et
+            if src not in x_dict or dst not in x_dict:
+                continue
+            outs.setdefault(dst, []).append(self.convs[et]((x_dict[src], x_dict[dst]), edge_index_dict[et]))
+        res = {}
+        for dst, xs in outs.items():
+            acc = xs[0]
+            for t in xs[1:]:
+                acc = acc + t
+            res[dst] = acc
+        return res

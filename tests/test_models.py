@@ -63,9 +63,12 @@ def test_state_dict_layout_matches_reference_names(name):
         assert torch.equal(m.joints_linear_weights, c[0]) and torch.equal(m.feet_linear_weights, c[1])
 
 
-def test_operator_containers_have_no_eager_path():
-    with pytest.raises(NotImplementedError):
+def test_operators_have_no_cpu_path():
+    """Called on their own the four operator modules run on the HIP operators of ops.py; host tensors raise (no eager fallback)."""
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
         pnn.GraphConv(8, 8)(torch.zeros(2, 8), torch.zeros(2, 0, dtype=torch.long))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        pnn.Linear(8, 4)(torch.zeros(2, 8))
     with pytest.raises(NotImplementedError):
         models.GRF_HGNN_C2(128, 1, (["base", "joint", "foot"], [("base", "x", "joint")]), activation_fn=nn.Tanh())
 
