@@ -86,6 +86,26 @@ def minicheetah_k4_recipe(joint_perm: Sequence[int], foot_perm: Sequence[int], h
         label_series="contacts", label_cols=[int(i) for i in foot_perm], normalize=normalize)
 
 
+def solo_com_recipe(kind: str, joint_perm: Sequence[int], history: int = 1) -> WindowRecipe:
+    """The Solo-12 centroidal-momentum dataset (BASELINE configs[3] data format) on the K4 / C2 / S4 graphs: joint = (q, qd) in graph
+    order, base = the (all-zero) IMU series tiled to the base nodes, labels = the 6-D base velocity of the window's last row, once per
+    base node as [lin(3) | ang(3)] (soloDataset.py:235-300, 382-400, 546-717).  Series: `solo_com_arrays(X, Y)`."""
+    nb = {"k4_com": 4, "c2_com": 2, "s4_com": 1}[kind]
+    return WindowRecipe(
+        node_types=["base", "joint"], num_nodes={"base": nb, "joint": len(joint_perm)}, history=history,
+        variables={"base": [("base_lin", [[0, 1, 2]] * nb), ("base_ang", [[0, 1, 2]] * nb)],
+                   "joint": [(s, [[int(j)] for j in joint_perm]) for s in ("q", "qd")]},
+        label_series="Y", label_cols=[0, 1, 2, 3, 4, 5] * nb)
+
+
+def solo_com_arrays(X: np.ndarray, Y: np.ndarray) -> Dict[str, np.ndarray]:
+    """The raw series `solo_com_recipe` names, from the dataset's X [N, 24] (q | qd) and Y [N, 6] (soloDataset.py:382-400: the base
+    IMU inputs of this task are zeros)."""
+    X, Y = np.asarray(X), np.asarray(Y)
+    z = np.zeros((X.shape[0], 3), dtype=np.float32)
+    return {"q": X[:, :12], "qd": X[:, 12:], "base_lin": z, "base_ang": z, "Y": Y}
+
+
 class SequenceStore:
     """The raw series of one recorded sequence on the GPU + the recipe that turns window indices into engine inputs."""
 

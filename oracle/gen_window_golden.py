@@ -45,6 +45,16 @@ def minicheetah_sequence(seed, N):
             "contacts": rng.integers(0, 2, size=(N, 4)).astype(np.float64)}
 
 
+def solo_sequence(seed, N):
+    rng = np.random.default_rng(seed)
+    f = lambda *s: rng.integers(-2000, 2000, size=s).astype(np.float64) / 64.0
+    return {"X": f(N, 24), "Y": f(N, 6)}
+
+
+SOLO_KINDS = {"k4_com": ("heterogeneous_gnn_k4_com", 4, "load_data_sorted_k4"), "c2_com": ("heterogeneous_gnn_c2_com", 2, "load_data_sorted_c2"),
+              "s4_com": ("heterogeneous_gnn_s4_com", 1, "load_data_sorted")}
+
+
 def reference_module():
     pk = types.ModuleType("ms_hgnn"); pk.__path__ = [REF]; sys.modules["ms_hgnn"] = pk
     dp = types.ModuleType("ms_hgnn.datasets_py"); dp.__path__ = [REF + "/datasets_py"]; sys.modules["ms_hgnn.datasets_py"] = dp
@@ -141,6 +151,38 @@ def main():
         fx4[f"k4:{st}:joint"] = data["joint"].x.numpy()[:, ::11].copy(); fx4[f"k4:{st}:foot"] = data["foot"].x.numpy()[:, ::13].copy()
     print("k4 oracle == reference on", len(starts), "windows")
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "windows_mck4.npz"), **fx4)
+
+    # Solo-12 centroidal-momentum task (soloDataset.py), K4 / C2 / S4 graphs, history 1 (the COM models' setting) and 5
+    sm = importlib.import_module("ms_hgnn.datasets_py.soloDataset")
+    scls = next(getattr(sm, n) for n in dir(sm) if isinstance(getattr(sm, n), type) and hasattr(getattr(sm, n), "load_data_sorted_k4"))
+    flex = importlib.import_module("ms_hgnn.datasets_py.flexibleDataset").FlexibleDataset
+    sq = solo_sequence(seed + 2, N)
+    fxs = {"seed": np.array(seed + 2), "N": np.array(N), "starts": np.array(starts), "joint_perm": JOINT_PERM.astype(np.int64)}
+    for kind, (model_type, nb, loader) in SOLO_KINDS.items():
+        for Th in (1, 5):
+            ss = types.SimpleNamespace()
+            ss.X, ss.Y, ss.history_length, ss.model_type = sq["X"], sq["Y"], Th, model_type
+            ss.symmetry_operator = None; ss.swap_legs = None; ss.normalize = False
+            ss.joint_node_indices_sorted = JOINT_PERM; ss.foot_node_indices_sorted = FOOT_PERM
+            ss.hgnn_number_nodes = (nb, 12, 0); ss.base_width = 6 * Th; ss.joint_width = 2 * Th
+            ss.urdf_name_to_graph_index_joint = {str(i): i for i in range(12)}
+            z = torch.zeros(2, 0, dtype=torch.long)
+            for k in ("bj", "jb", "jj", "gt", "gs", "bj_front", "jb_front", "bj_back", "jb_back", "bb"):
+                setattr(ss, k, z)
+            ss.load_data_at_dataset_seq = types.MethodType(scls.load_data_at_dataset_seq, ss)
+            ss.load_data_sorted = types.MethodType(scls.load_data_sorted, ss)
+            ss.load_data_sorted_k4 = types.MethodType(scls.load_data_sorted_k4, ss)
+            ss.load_data_sorted_c2 = types.MethodType(scls.load_data_sorted_c2, ss)
+            ss.find_variables_to_use = types.MethodType(flex.find_variables_to_use, ss)
+            ss.get = types.MethodType(scls.get_helper_heterogeneous_gnn, ss)
+            for st in starts:
+                data = ss.get(st)
+                ob, oj, oy = wo.solo_com_window(sq["X"], sq["Y"], st, Th, JOINT_PERM.astype(int), nb)
+                for a, b, what in ((data["base"].x.numpy(), ob, "base"), (data["joint"].x.numpy(), oj, "joint"), (data.y.numpy(), oy, "y")):
+                    assert a.shape == b.shape and np.abs(a - b).max() == 0.0, (kind, Th, st, what)
+                fxs[f"{kind}:{Th}:{st}:y"] = data.y.numpy(); fxs[f"{kind}:{Th}:{st}:joint"] = data["joint"].x.numpy()
+        print(kind, "oracle == reference on", 2 * len(starts), "windows")
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "windows_solo.npz"), **fxs)
 
 
 if __name__ == "__main__":

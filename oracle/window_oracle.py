@@ -61,3 +61,18 @@ def minicheetah_k4_window(seq, start, T, joint_perm, foot_perm, normalize=False,
     foot = np.stack([np.concatenate([v[:, 3 * i:3 * i + 3].flatten("F") for v in (fp, fv)]) for i in range(len(foot_perm))])
     return base, joint, foot, labels.astype(np.float64)
 
+
+
+def solo_com_window(X, Y, start, T, joint_perm, n_base):
+    """Solo-12 centroidal-momentum task -- soloDataset.py:382-400 (`load_data_at_dataset_seq`: q / qd = the two halves of X, label = Y of
+    the window's last row, base IMU = zeros), :332-380 / :546-632 / :634-717 (`load_data_sorted[_k4|_c2]`: base series and labels tiled
+    to the n_base base nodes, joints re-ordered; labels re-ordered to [lin(3) | ang(3)] per base node) and :235-300
+    (`get_helper_heterogeneous_gnn`: flatten('F') per variable).  X: [N, 24], Y: [N, 6].  Returns base [n_base, 6T] (zeros),
+    joint [12, 2T], y [n_base * 6]."""
+    sl = slice(start, start + T)
+    jp, jv = X[sl, :12][:, joint_perm], X[sl, 12:][:, joint_perm]
+    lab = np.concatenate([Y[sl, :3][-1], Y[sl, 3:][-1]])
+    base = np.zeros((n_base, 6 * T))
+    joint = np.stack([np.concatenate([v[:, i] for v in (jp, jv)]) for i in range(len(joint_perm))])
+    y = np.concatenate([np.concatenate([lab[:3], lab[3:]]) for _ in range(n_base)])
+    return base, joint, y

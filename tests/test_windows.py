@@ -110,3 +110,50 @@ def test_k4_device_assembly_matches_oracle(normalize):
         assert np.abs(got - ref).max() <= (0.0 if not normalize else 2e-7 * np.abs(ref).max())
     assert np.array_equal(y.cpu().numpy(), np.stack([w[3] for w in want])) and q is None
 
+
+
+# --- Solo-12 centroidal-momentum task (SURVEY.md 8(d) config 4 data format; soloDataset.py) ------------------------------------------
+from oracle.gen_window_golden import solo_sequence, SOLO_KINDS   # noqa: E402
+
+FXS = np.load(os.path.join(os.path.dirname(__file__), "golden", "windows_solo.npz"))
+SEQS = solo_sequence(int(FXS["seed"]), int(FXS["N"]))
+
+
+@pytest.mark.parametrize("kind", list(SOLO_KINDS))
+def test_solo_oracle_matches_reference_fixture(kind):
+    nb = SOLO_KINDS[kind][1]
+    for Th in (1, 5):
+        for st in FXS["starts"]:
+            b, j, y = wo.solo_com_window(SEQS["X"], SEQS["Y"], int(st), Th, JP, nb)
+            k = f"{kind}:{Th}:{int(st)}"
+            assert np.array_equal(y, FXS[k + ":y"]) and np.array_equal(j, FXS[k + ":joint"])
+            assert b.shape == (nb, 6 * Th) and not b.any() and j.shape == (12, 2 * Th) and y.shape == (6 * nb,)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("history", [1, 5])
+@pytest.mark.parametrize("kind", list(SOLO_KINDS))
+def test_solo_device_assembly_matches_oracle_and_feeds_the_engine(kind, history):
+    from morphsym_hgnn_amd.windows import SequenceStore, solo_com_recipe, solo_com_arrays
+    nb = SOLO_KINDS[kind][1]
+    store = SequenceStore(solo_com_arrays(SEQS["X"], SEQS["Y"]), solo_com_recipe(kind, JP, history), dtype="f32")
+    N4 = int(FXS["N"])
+    starts = [0, N4 - history, 17, 17, 3]
+    xs, y, q = store.assemble(starts)
+    want = [wo.solo_com_window(SEQS["X"], SEQS["Y"], s, history, JP, nb) for s in starts]
+    for ti, n in enumerate((nb, 12)):
+        ref = np.stack([w[ti] for w in want]).reshape(len(starts) * n, -1)
+        got = xs[ti].cpu().numpy().astype(np.float64)
+        assert np.array_equal(got[:, :ref.shape[1]], ref) and not got[:, ref.shape[1]:].any()
+    assert np.array_equal(y.cpu().numpy(), np.stack([w[2] for w in want])) and q is None
+    if history == 1 and kind != "s4_com":      # the COM models' setting: the assembled batch goes straight into the engine
+        from morphsym_hgnn_amd import engine as eng, synth
+        from tests import helpers
+        topo, cfg = {"k4_com": ("solo-k4-com", "solo-k4"), "c2_com": ("solo-c2-com", "solo-c2")}[kind]
+        spec = helpers.make_spec(kind, topo, cfg, 128, 2)
+        e = eng.Engine(spec, "f32")
+        flat = eng.flatten_params(spec, synth.make_params(4, spec.param_shapes()), e.device)
+        B = len(starts)
+        out_dev = e.forward(xs, flat, B, training=False).clone()
+        x_dict = {t: torch.from_numpy(np.stack([w[i] for w in want]).reshape(B * n, -1)) for i, (t, n) in enumerate((("base", nb), ("joint", 12)))}
+        assert torch.equal(out_dev, e.forward(e.cast_inputs(x_dict), flat, B, training=False))
