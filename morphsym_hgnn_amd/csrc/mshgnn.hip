@@ -1668,52 +1668,64 @@ template <int IPL> __global__ __launch_bounds__(256, GW_WPS) void k_gradw_bf16(G
 //   * every global address is  wave-uniform stream pointer (SGPRs, advanced by scalar adds)  +  per-thread 32-bit offset  +  immediate (256 p),
 //   * the relu bytes of its four rows are ONE aligned 32-bit load (the byte layout keeps 16 consecutive windows together),
 //   * full chunks (all but the last one of the batch) carry no bound checks.
-// One item per lane, raw inputs 16-byte aligned (the launcher falls back to the general kernel otherwise).  Same step order, same MFMA
-// sequence: the matrix slabs are bit-identical to the general kernel's; the bias partial sums add the same values in another order.
-__global__ __launch_bounds__(256, GW_WPS) void k_gradw_bf16_lean(GradwArgs a) {
+// A lane holds up to GW_IPL items (all of one target: same operand kinds, same input column chunk), interleaved chunk by chunk into the same
+// accumulators -- chunk-major, so that every workgroup of the launch sweeps the batch at the same pace and rows shared between lanes still meet in
+// L2 (item-major order was measured: 109 -> 160 us, the sharing is lost; more than two items per lane lose it too, see GW_IPL_MAX).  The items'
+// stream bases and sign masks sit in a small LDS table; a step reads its three 64-bit bases from it (broadcast reads, moved to scalar
+// registers).  ALIGNED: raw inputs in the engine's own 16-byte-aligned layout; the other instantiation reads them element-wise.  Same MFMA
+// sequence as the general kernel.
+template <bool ALIGNED> __global__ __launch_bounds__(256, GW_WPS) void k_gradw_bf16_lean(GradwArgs a) {
     using T = __bf16;
     __shared__ __attribute__((aligned(16))) __bf16 Ps[GWB_KW * GWB_PITCH];
     __shared__ __attribute__((aligned(16))) __bf16 Qs[GWB_KW * GWB_PITCH];
     __shared__ __attribute__((aligned(16))) u32x4 mlut[256];       // relu byte -> AND mask of 8 bf16
+    __shared__ __attribute__((aligned(16))) u32x4 qkeep_t[16];            // raw Q: keep mask (pad columns) of column chunk c (registers are short)
+    __shared__ __attribute__((aligned(16))) u32x4 qsign_t[GW_IPL][16];    // raw Q: symmetry sign XOR of (item, column chunk)
+    __shared__ unsigned long long sbase[GW_IPL][4];                       // per item: stream bases of P, relu bytes, Q at the part's first window
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     mlut[tid] = chunk_mask_bits<__bf16>(u32x4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, (unsigned)tid);   // (visible after the first barrier)
     const int wr = wv >> 1, wc = wv & 1;
     const int ln = a.lane_order[blockIdx.x % a.n_pad], part = blockIdx.x / a.n_pad;
     if (ln < 0) return;
     const int* lh = a.lanes + ln * LANE_INTS;
-    const int bias_flag = lh[3];
-    const int* im = a.items + lh[0] * ITEM_INTS;
+    const int it0 = lh[0], nit = lh[1] - lh[0], bias_flag = lh[3];
+    const int* im0 = a.items + it0 * ITEM_INTS;
     const int nchunks = (a.B + GWB_KW - 1) / GWB_KW;
     const int ch0 = (int)((int64_t)part * nchunks / a.n_parts), ch1 = (int)((int64_t)(part + 1) * nchunks / a.n_parts);
-    const int nsteps = ch1 - ch0;
+    const int nsteps = ch1 - ch0, total = nsteps * nit;
     const int c = tid & 15, r4 = (tid >> 4) * 4;      // rows r4 .. r4 + 3 of the 64-window step, columns [8c, 8c + 8)
 
-    // wave-uniform stream pointers at the part's first window; per-thread byte offsets
-    const char* pS = a.ws + a.buf_off[im[0]] + (act_idx(0, im[2], a.B) + (size_t)ch0 * GWB_KW * H) * sizeof(T);
-    const bool p_masked = im[9] >= 0;
+    // what every item of the lane shares (one target): operand kinds, the input type and column chunk of a raw Q
+    const bool p_masked = im0[9] >= 0, q_raw = im0[4] < 0;
     const int ntile = (a.B + 15) >> 4;
-    const char* mS = p_masked ? a.ws + a.buf_off[im[9]] + relu_byte(im[2], a.B, 0, 0) + (size_t)ch0 * (GWB_KW / 16) * 64 : a.ws;
     const unsigned voffP = (unsigned)(r4 * H + c * 8) * (unsigned)sizeof(T);
     const unsigned voffM = (unsigned)(((c >> 2) * ntile + (r4 >> 4)) * 64 + (c & 3) * 16 + (r4 & 15));
-    const bool q_raw = im[4] < 0;
-    const char* qS; unsigned qsb; int qn = 8; u32x4 qsx = u32x4{0, 0, 0, 0};
-    if (!q_raw) {
-        qS = a.ws + a.buf_off[im[3]] + (act_idx(0, im[5], a.B) + (size_t)ch0 * GWB_KW * H) * sizeof(T);
-        qsb = H * sizeof(T);
-    } else {
-        const int t = im[3] - BUF_IN;
-        qsb = (unsigned)(a.nodes[t] * a.pitch[t]) * (unsigned)sizeof(T);
-        qS = reinterpret_cast<const char*>(a.x[t]) + ((size_t)im[5] * a.pitch[t] + im[6]) * sizeof(T) + (size_t)ch0 * GWB_KW * qsb;
-        qn = im[7] - c * 8;
-        qsx = sign_xor<T>(a.signs + im[8] + c * 8);
-    }
-    const u32x4 qkeep = chunk_keep_first<T>(u32x4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, qn);
-    unsigned voffQ[4], ldsw[4];
+    const int qt = q_raw ? im0[3] - BUF_IN : 0;
+    const unsigned qsb = q_raw ? (unsigned)(a.nodes[qt] * a.pitch[qt]) * (unsigned)sizeof(T) : (unsigned)(H * sizeof(T));
+    const int qn = q_raw ? im0[7] - c * 8 : 8, qvb = q_raw ? a.vb[qt] : 16;
+    const unsigned voffQ0 = (unsigned)r4 * qsb + (unsigned)c * 16u;
+    unsigned ldsw[4];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        voffQ[p] = (unsigned)(r4 + p) * qsb + (unsigned)c * 16u;
-        ldsw[p] = (unsigned)gwb_elem(r4 + p, c * 8);
+    for (int p = 0; p < 4; ++p) ldsw[p] = (unsigned)gwb_elem(r4 + p, c * 8);
+    if (tid < 16) qkeep_t[tid] = chunk_keep_first<T>(u32x4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, qn);      // (tid == c)
+    if (tid < nit) {     // thread k resolves item k's stream bases (at the part's first window)
+        const int* im = a.items + (it0 + tid) * ITEM_INTS;
+        sbase[tid][0] = (unsigned long long)(a.ws + a.buf_off[im[0]] + (act_idx(0, im[2], a.B) + (size_t)ch0 * GWB_KW * H) * sizeof(T));
+        sbase[tid][1] = p_masked ? (unsigned long long)(a.ws + a.buf_off[im[9]] + relu_byte(im[2], a.B, 0, 0) + (size_t)ch0 * (GWB_KW / 16) * 64) : 0ull;
+        sbase[tid][2] = q_raw ? (unsigned long long)(reinterpret_cast<const char*>(a.x[qt]) + ((size_t)im[5] * a.pitch[qt] + im[6]) * sizeof(T) + (size_t)ch0 * GWB_KW * qsb)
+                              : (unsigned long long)(a.ws + a.buf_off[im[3]] + (act_idx(0, im[5], a.B) + (size_t)ch0 * GWB_KW * H) * sizeof(T));
     }
+    if (q_raw && tid < nit * 16) {
+        const int* im = a.items + (it0 + (tid >> 4)) * ITEM_INTS;
+        qsign_t[tid >> 4][c] = sign_xor<T>(a.signs + im[8] + c * 8);
+    }
+    __syncthreads();
+    const char* pS = a.ws; const char* mS = a.ws; const char* qS = a.ws;
+    auto ubase = [&](int k, int j, size_t off) -> const char* {      // wave-uniform 64-bit pointer out of the LDS table
+        const unsigned long long v = sbase[k][j] + off;
+        return reinterpret_cast<const char*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+                                             (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v));
+    };
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -1726,14 +1738,22 @@ __global__ __launch_bounds__(256, GW_WPS) void k_gradw_bf16_lean(GradwArgs a) {
     for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
 
     u32x4 pv[4], qv[4]; unsigned mw = 0xffffffffu;
-    auto fetch = [&](int s) {      // loads of step s (chunk ch0 + s); pS / qS / mS already point at it
-        const int w0 = (ch0 + s) * GWB_KW;
+    auto load_q = [&](int p) -> u32x4 {
+        if constexpr (ALIGNED) return *reinterpret_cast<const u32x4*>(qS + voffQ0 + p * qsb);
+        else return q_raw ? load_chunk<T>(reinterpret_cast<const T*>(qS + voffQ0 + p * qsb), qn, qvb) : *reinterpret_cast<const u32x4*>(qS + voffQ0 + p * qsb);
+    };
+    int nk = 0, nc = 0;            // (item, chunk of the part) of the next fetch: items interleaved chunk by chunk
+    auto fetch = [&]() {
+        pS = ubase(nk, 0, (size_t)nc * GWB_KW * H * sizeof(T));
+        if (p_masked) mS = ubase(nk, 1, (size_t)nc * (GWB_KW / 16) * 64);
+        qS = ubase(nk, 2, (size_t)nc * GWB_KW * qsb);
+        const int w0 = (ch0 + nc) * GWB_KW;
         if (w0 + GWB_KW <= a.B) {
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                pv[p] = ld16<(GW_NT > 1)>(pS + voffP + p * (int)(H * sizeof(T)));
+                pv[p] = *reinterpret_cast<const u32x4*>(pS + voffP + p * (int)(H * sizeof(T)));
                 qv[p] = u32x4{0, 0, 0, 0};
-                if (qn > 0) qv[p] = (GW_NT == 1 && q_raw) ? ld16<1>(qS + voffQ[p]) : ld16<(GW_NT > 1)>(qS + voffQ[p]);
+                if (qn > 0) qv[p] = load_q(p);
             }
             if (p_masked) mw = *reinterpret_cast<const unsigned*>(mS + voffM);
         } else {                   // last chunk of the batch: rows beyond B are zero
@@ -1742,16 +1762,19 @@ __global__ __launch_bounds__(256, GW_WPS) void k_gradw_bf16_lean(GradwArgs a) {
                 pv[p] = u32x4{0, 0, 0, 0}; qv[p] = u32x4{0, 0, 0, 0};
                 if (w0 + r4 + p < a.B) {
                     pv[p] = *reinterpret_cast<const u32x4*>(pS + voffP + p * (int)(H * sizeof(T)));
-                    if (qn > 0) qv[p] = *reinterpret_cast<const u32x4*>(qS + voffQ[p]);
+                    if (qn > 0) qv[p] = load_q(p);
                 }
             }
             mw = 0xffffffffu;
             if (p_masked && w0 + r4 < a.B) mw = *reinterpret_cast<const unsigned*>(mS + voffM);     // (the 16-window tile of row r4 exists)
         }
-        pS += (size_t)GWB_KW * H * sizeof(T); qS += (size_t)GWB_KW * qsb; mS += (GWB_KW / 16) * 64;
+        if (++nk == nit) { nk = 0; ++nc; }
     };
+    int sk = 0;                    // item of the step being staged
     auto stage_to_lds = [&]() {
-        u32x4 mk[4];
+        u32x4 mk[4], qkeep, sx;
+        if (q_raw) { qkeep = qkeep_t[c]; sx = qsign_t[sk][c]; }
+        if (++sk == nit) sk = 0;
         if (p_masked) {              // the four table reads go out together (one LDS round trip, not four)
 #pragma unroll
             for (int p = 0; p < 4; ++p) mk[p] = mlut[(mw >> (8 * p)) & 0xffu];
@@ -1762,7 +1785,7 @@ __global__ __launch_bounds__(256, GW_WPS) void k_gradw_bf16_lean(GradwArgs a) {
             if (p_masked) pm &= mk[p];                                   // dH = dX . relu bits
             *reinterpret_cast<u32x4*>(&Ps[ldsw[p]]) = pm;
             u32x4 qm = qv[p];
-            if (q_raw) qm = (qm & qkeep) ^ qsx;                          // drop pad columns, symmetry sign mask of encoder inputs
+            if (q_raw) qm = (qm & qkeep) ^ sx;                           // drop pad columns, symmetry sign mask of encoder inputs
             *reinterpret_cast<u32x4*>(&Qs[ldsw[p]]) = qm;
             if (bias_flag) {
 #pragma unroll
@@ -1773,12 +1796,12 @@ __global__ __launch_bounds__(256, GW_WPS) void k_gradw_bf16_lean(GradwArgs a) {
             }
         }
     };
-    if (nsteps > 0) fetch(0);
-    for (int s = 0; s < nsteps; ++s) {
+    if (total > 0) fetch();
+    for (int s = 0; s < total; ++s) {
         __syncthreads();             // every wave is done with the previous step's tiles
         stage_to_lds();
         __syncthreads();
-        if (s + 1 < nsteps) fetch(s + 1);
+        if (s + 1 < total) fetch();
 #pragma unroll
         for (int ks = 0; ks < GWB_KW / 16; ++ks) {
             bf16x8 af[2], bq[2];
@@ -2216,9 +2239,10 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
         if (a.n_pad > 0) {
             static const bool gw_general = getenv("MSHGNN_GRADW") && std::string(getenv("MSHGNN_GRADW")) == "general";   // read once: the general kernel also where the lean one applies (A/B runs)
             if constexpr (sizeof(T) == 4) hipLaunchKernelGGL(k_gradw_f32, dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a);
-            else if (hp.gw_ipl == 1 && a.aligned && !gw_general) hipLaunchKernelGGL(k_gradw_bf16_lean, dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a);
-            else if (hp.gw_ipl == 1) hipLaunchKernelGGL(k_gradw_bf16<1>, dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL(k_gradw_bf16<2>, dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a);
+            else if (gw_general && hp.gw_ipl == 1) hipLaunchKernelGGL(k_gradw_bf16<1>, dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a);
+            else if (gw_general && hp.gw_ipl == 2) hipLaunchKernelGGL(k_gradw_bf16<2>, dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a);
+            else if (a.aligned) hipLaunchKernelGGL(k_gradw_bf16_lean<true>, dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL(k_gradw_bf16_lean<false>, dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a);
         }
     }
     return run_finalize(p, lay, ws, gparams, B, (y || labels) ? loss : nullptr, labels != nullptr, dec_done, gw_phase, st);

@@ -707,7 +707,7 @@ static void g_launch_jobs(const mshgnn_plan* p, const Launch& ln, GArgs a, hipSt
     // output tile of a workgroup: 64 windows x (32 NW) columns.  The staged A tile is shared by all NW waves, so wider tiles re-read the
     // activations fewer times (hidden / (32 NW) column groups per row of jobs): measured at h=512, B=1024: layer_fwd bf16 515 / 354 / 296 us at
     // 4 / 8 / 16 waves, split 870 / 799 / 1012 us (16 waves: 128 VGPRs, spills); 128-window tiles lose (fewer resident workgroups hide less
-    // of the staging latency: 495 us at 8 waves)
+    // of the staging latency: 495 us at 8 waves, 389 us at 16 waves with 56 B of scratch)
     const int mode = g_tile_blocks(a.B, gp.split);      // 0: 4 waves; 1: 8 waves, 128 windows; 2: 8 waves; 3: 16 waves
     int nw = 4;
     if ((mode == 1 || mode == 2) && gp.NCT % 2 == 0) nw = 8;

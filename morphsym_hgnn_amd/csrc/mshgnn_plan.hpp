@@ -31,9 +31,13 @@ constexpr int LDS_LIMIT = 160 * 1024;
 constexpr int SLAB_FLOATS = H * H + H;   // one split-K partial: 128x128 matrix + 128 column sums
 constexpr int NWG_DEC = 512;             // workgroups of the decoder backward (each writes one small slab)
 constexpr int DEC_SLAB_FLOATS = 8 * H + 16; // decoder partial: [out_channels<=8][128] + bias[8] + loss partial (+pad)
-constexpr int GW_IPL = 2;                // most items per weight-gradient lane; the plan picks 1 or 2 (gw_ipl): whichever fills more of
-                                         // the GW_TARGET_WGS resident workgroups (lanes x window parts), 1 on a tie -- with one item per
-                                         // lane the kernel has no per-step item selection and 12 fewer VGPRs (111 -> 106.5 us at L=3)
+#ifndef GW_IPL_MAX
+#define GW_IPL_MAX 2                     // measured with 4 and 8 (EXTRA=-DGW_IPL_MAX=..): the grid fills better (A1-C2 L=3: 704 -> 742 of 768 workgroups,
+#endif                                   // MiniCheetah-K4 L=8: 560 -> 714) and the kernel gets SLOWER (110 -> 152 us, 333 -> 372 us): lanes of 3-4 interleaved items
+                                         // reach a shared P / Q stream steps apart, and a stream survives in an XCD's L2 for about one step
+constexpr int GW_IPL = GW_IPL_MAX;       // most items per weight-gradient lane; the plan picks gw_ipl in 1 .. GW_IPL: whichever fills most of
+                                         // the GW_TARGET_WGS resident workgroups (lanes x window parts), the smallest on a tie.  The lean kernels
+                                         // interleave a lane's items chunk by chunk (any number); the general bf16 kernel (MSHGNN_GRADW=general) at most two
 #ifndef GW_TARGET_WGS
 #define GW_TARGET_WGS 768.0              // workgroups of the weight-gradient kernel (lanes x window parts): 3 resident per CU x 256 CUs, so
                                          // that the whole grid runs as ONE wave of workgroups (1024: a third of them ran in a second,

@@ -784,9 +784,10 @@ __global__ __launch_bounds__(256, GWX3_WPS) void k_gradw_x3(GradwArgs a) {
 // per-thread 32-bit offset  +  an immediate (the [hi | lo] row layout puts the four loads of an operand at +0 / +256 / +512 / +768), the relu
 // bytes of its two rows are one aligned 16-bit load, and full chunks carry no bound checks.  The general kernel above keeps six 64-bit
 // per-thread pointers alive and spills three of them (28 B of scratch per lane, reloaded inside the step loop in front of the loads that
-// need them).  Same step order and MFMA sequence: the matrix slabs are bit-identical to the general kernel's; the bias partial sums add the
-// same values in another order.  Needs 16-byte aligned raw inputs (the launcher falls back to the general kernel otherwise).
-__global__ __launch_bounds__(256, GWX3_WPS) void k_gradw_x3_lean(GradwArgs a) {
+// need them).  A lane's items (all of one target) are swept one after the other over the lane's window part into the same accumulators (any
+// number of items per lane: the plan picks the items-per-lane x window-parts split that fills the chip best).  ALIGNED: raw inputs in the
+// engine's own 16-byte-aligned layout; the other instantiation reads them element-wise.
+template <bool ALIGNED> __global__ __launch_bounds__(256, GWX3_WPS) void k_gradw_x3_lean(GradwArgs a) {
     using T = T16;
     constexpr int KW = 32;
     __shared__ __attribute__((aligned(16))) __bf16 Ph[KW * GWB_PITCH];
@@ -794,46 +795,56 @@ __global__ __launch_bounds__(256, GWX3_WPS) void k_gradw_x3_lean(GradwArgs a) {
     __shared__ __attribute__((aligned(16))) __bf16 Qh[KW * GWB_PITCH];
     __shared__ __attribute__((aligned(16))) __bf16 Ql[KW * GWB_PITCH];
     __shared__ __attribute__((aligned(16))) u32x4 mlut[256];       // relu byte -> AND mask of 8 bf16
-    __shared__ __attribute__((aligned(16))) u32x4 qfix[16][4];     // raw-input items: per column chunk c the keep masks and sign XORs of its two fp32 halves
+    __shared__ __attribute__((aligned(16))) u32x4 qfix[16][2];            // raw-input items: per column chunk c the keep masks of its two fp32 halves
+    __shared__ __attribute__((aligned(16))) u32x4 qsign_t[GW_IPL][16][2]; // ... and per (item, column chunk) the symmetry sign XORs
+    __shared__ unsigned long long sbase[GW_IPL][4];                       // per item: stream bases of P, relu bytes, Q at the part's first window
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     mlut[tid] = chunk_mask_bits<__bf16>(u32x4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, (unsigned)tid);   // (visible after the first barrier)
     const int wr = wv >> 1, wc = wv & 1;
     const int ln = a.lane_order[blockIdx.x % a.n_pad], part = blockIdx.x / a.n_pad;
     if (ln < 0) return;
     const int* lh = a.lanes + ln * LANE_INTS;
-    const int bias_flag = lh[3];
-    const int* im = a.items + lh[0] * ITEM_INTS;
+    const int it0 = lh[0], nit = lh[1] - lh[0], bias_flag = lh[3];
+    const int* im0 = a.items + it0 * ITEM_INTS;
     const int nchunks = (a.B + KW - 1) / KW;
     const int ch0 = (int)((int64_t)part * nchunks / a.n_parts), ch1 = (int)((int64_t)(part + 1) * nchunks / a.n_parts);
-    const int nsteps = ch1 - ch0;
+    const int nsteps = ch1 - ch0, total = nsteps * nit;      // the lane's items interleaved chunk by chunk (every workgroup sweeps the batch at the same pace), into the same accumulators
     const int c = tid & 15, r2 = (tid >> 4) * 2;      // rows r2, r2 + 1 of the 32-window step, columns [8c, 8c + 8)
     constexpr int ROWB = 2 * H * (int)sizeof(T);      // bytes of one [hi | lo] row
 
-    const char* pS = a.ws + a.buf_off[im[0]] + (x3_idx(0, im[2], a.B) + (size_t)ch0 * KW * 2 * H) * sizeof(T);
-    const bool p_masked = im[9] >= 0;
+    // what every item of the lane shares (one target): operand kinds, the input type and column chunk of a raw Q
+    const bool p_masked = im0[9] >= 0, q_act = im0[4] >= 0;
     const int ntile = (a.B + 15) >> 4;
-    const char* mS = p_masked ? a.ws + a.buf_off[im[9]] + relu_byte(im[2], a.B, 0, 0) + (size_t)ch0 * (KW / 16) * 64 : a.ws;
     const unsigned voffP = (unsigned)(r2 * ROWB + c * 16);
     const unsigned voffM = (unsigned)(((c >> 2) * ntile + (r2 >> 4)) * 64 + (c & 3) * 16 + (r2 & 15));
-    const bool q_act = im[4] >= 0;
-    const char* qS; unsigned qsb; int qn = 8;
-    if (q_act) {
-        qS = a.ws + a.buf_off[im[3]] + (x3_idx(0, im[5], a.B) + (size_t)ch0 * KW * 2 * H) * sizeof(T);
-        qsb = ROWB;
-    } else {
-        const int t = im[3] - BUF_IN;
-        qsb = (unsigned)(a.nodes[t] * a.pitch[t]) * 4u;
-        qS = reinterpret_cast<const char*>(a.x[t]) + ((size_t)im[5] * a.pitch[t] + im[6]) * 4 + (size_t)ch0 * KW * qsb;
-        qn = im[7] - c * 8;
-        if (tid < 16) {      // (these constants would cost 16 VGPRs per lane: over the budget of three workgroups per CU)
-            const u32x4 ones = u32x4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-            qfix[tid][0] = chunk_keep_first<float>(ones, qn); qfix[tid][1] = chunk_keep_first<float>(ones, qn - 4);
-            qfix[tid][2] = sign_xor<float>(a.signs + im[8] + c * 8); qfix[tid][3] = sign_xor<float>(a.signs + im[8] + c * 8 + 4);
-        }
+    const int qt = q_act ? 0 : im0[3] - BUF_IN;
+    const unsigned qsb = q_act ? (unsigned)ROWB : (unsigned)(a.nodes[qt] * a.pitch[qt]) * 4u;
+    const int qn = q_act ? 8 : im0[7] - c * 8, qvb = q_act ? 16 : a.vb[qt];
+    if (!q_act && tid < 16) {      // (these constants would cost 16 VGPRs per lane: over the budget of three workgroups per CU)
+        const u32x4 ones = u32x4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+        qfix[tid][0] = chunk_keep_first<float>(ones, qn); qfix[tid][1] = chunk_keep_first<float>(ones, qn - 4);
     }
-    // raw rows: two 16-byte halves of 8 floats; halves past the row's end re-read the chunk's first bytes (never used: keepa / keepb are 0)
+    // raw rows: two 16-byte halves of 8 floats; halves past the row's end re-read the chunk's first bytes (never used: the keep masks are 0)
     const unsigned voffQ0 = q_act ? voffP : (unsigned)r2 * qsb + (qn > 0 ? (unsigned)c * 32u : 0u);
     const unsigned qhalf = q_act ? 256u : (qn > 4 ? 16u : 0u);
+    if (tid < nit) {     // thread k resolves item k's stream bases (at the part's first window)
+        const int* im = a.items + (it0 + tid) * ITEM_INTS;
+        sbase[tid][0] = (unsigned long long)(a.ws + a.buf_off[im[0]] + (x3_idx(0, im[2], a.B) + (size_t)ch0 * KW * 2 * H) * sizeof(T));
+        sbase[tid][1] = p_masked ? (unsigned long long)(a.ws + a.buf_off[im[9]] + relu_byte(im[2], a.B, 0, 0) + (size_t)ch0 * (KW / 16) * 64) : 0ull;
+        sbase[tid][2] = q_act ? (unsigned long long)(a.ws + a.buf_off[im[3]] + (x3_idx(0, im[5], a.B) + (size_t)ch0 * KW * 2 * H) * sizeof(T))
+                              : (unsigned long long)(reinterpret_cast<const char*>(a.x[qt]) + ((size_t)im[5] * a.pitch[qt] + im[6]) * 4 + (size_t)ch0 * KW * qsb);
+    }
+    if (!q_act && tid < nit * 16) {
+        const int* im = a.items + (it0 + (tid >> 4)) * ITEM_INTS;
+        qsign_t[tid >> 4][c][0] = sign_xor<float>(a.signs + im[8] + c * 8); qsign_t[tid >> 4][c][1] = sign_xor<float>(a.signs + im[8] + c * 8 + 4);
+    }
+    __syncthreads();
+    const char* pS = a.ws; const char* mS = a.ws; const char* qS = a.ws;
+    auto ubase = [&](int k, int j, size_t off) -> const char* {      // workgroup-uniform 64-bit pointer out of the LDS table
+        const unsigned long long v = sbase[k][j] + off;
+        return reinterpret_cast<const char*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+                                             (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v));
+    };
     unsigned ldsw[2];
 #pragma unroll
     for (int p = 0; p < 2; ++p) ldsw[p] = (unsigned)gwb_elem(r2 + p, c * 8);
@@ -849,15 +860,27 @@ __global__ __launch_bounds__(256, GWX3_WPS) void k_gradw_x3_lean(GradwArgs a) {
     for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
 
     u32x4 ph[2], pl[2], qa[2], qb[2]; unsigned mw = 0xffffu;
-    auto fetch = [&](int s) {      // loads of step s (chunk ch0 + s); pS / qS / mS already point at it
-        const int w0 = (ch0 + s) * KW;
+    auto load_qa = [&](int p) -> u32x4 {
+        if constexpr (ALIGNED) return *reinterpret_cast<const u32x4*>(qS + voffQ0 + p * qsb);
+        else return q_act ? *reinterpret_cast<const u32x4*>(qS + voffQ0 + p * qsb) : load_chunk<float>(reinterpret_cast<const float*>(qS + (unsigned)(r2 + p) * qsb + (unsigned)c * 32u), qn, qvb);
+    };
+    auto load_qb = [&](int p) -> u32x4 {
+        if constexpr (ALIGNED) return *reinterpret_cast<const u32x4*>(qS + voffQ0 + p * qsb + qhalf);
+        else return q_act ? *reinterpret_cast<const u32x4*>(qS + voffQ0 + p * qsb + qhalf) : load_chunk<float>(reinterpret_cast<const float*>(qS + (unsigned)(r2 + p) * qsb + (unsigned)c * 32u) + 4, qn - 4, qvb);
+    };
+    int nk = 0, nc = 0;            // (item, chunk of the part) of the next fetch: items interleaved chunk by chunk
+    auto fetch = [&]() {
+        pS = ubase(nk, 0, (size_t)nc * KW * ROWB);
+        if (p_masked) mS = ubase(nk, 1, (size_t)nc * (KW / 16) * 64);
+        qS = ubase(nk, 2, (size_t)nc * KW * qsb);
+        const int w0 = (ch0 + nc) * KW;
         if (w0 + KW <= a.B) {
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 ph[p] = *reinterpret_cast<const u32x4*>(pS + voffP + p * ROWB);
                 pl[p] = *reinterpret_cast<const u32x4*>(pS + voffP + p * ROWB + 256);
-                qa[p] = *reinterpret_cast<const u32x4*>(qS + voffQ0 + p * qsb);
-                qb[p] = *reinterpret_cast<const u32x4*>(qS + voffQ0 + p * qsb + qhalf);
+                qa[p] = load_qa(p);
+                qb[p] = load_qb(p);
             }
             if (p_masked) mw = *reinterpret_cast<const unsigned short*>(mS + voffM);
         } else {                   // last chunk of the batch: rows beyond B are zero
@@ -867,16 +890,19 @@ __global__ __launch_bounds__(256, GWX3_WPS) void k_gradw_x3_lean(GradwArgs a) {
                 if (w0 + r2 + p < a.B) {
                     ph[p] = *reinterpret_cast<const u32x4*>(pS + voffP + p * ROWB);
                     pl[p] = *reinterpret_cast<const u32x4*>(pS + voffP + p * ROWB + 256);
-                    qa[p] = *reinterpret_cast<const u32x4*>(qS + voffQ0 + p * qsb);
-                    qb[p] = *reinterpret_cast<const u32x4*>(qS + voffQ0 + p * qsb + qhalf);
+                    qa[p] = load_qa(p);
+                    qb[p] = load_qb(p);
                 }
             }
             mw = 0xffffu;
             if (p_masked && w0 + r2 < a.B) mw = *reinterpret_cast<const unsigned short*>(mS + voffM);     // (the 16-window tile of row r2 exists)
         }
-        pS += (size_t)KW * ROWB; qS += (size_t)KW * qsb; mS += (KW / 16) * 64;
+        if (++nk == nit) { nk = 0; ++nc; }
     };
+    int sk = 0;                    // item of the step being staged
     auto stage_to_lds = [&]() {
+        const int ks = sk;
+        if (++sk == nit) sk = 0;
         u32x4 mk[2];
         if (p_masked) {
 #pragma unroll
@@ -890,7 +916,7 @@ __global__ __launch_bounds__(256, GWX3_WPS) void k_gradw_x3_lean(GradwArgs a) {
             *reinterpret_cast<u32x4*>(&Pl[ldsw[p]]) = l;
             u32x4 qh = qa[p], ql = qb[p];
             if (!q_act) {      // drop pad columns, symmetry sign mask, fp32 -> hi / lo
-                const u32x4 fa = (qa[p] & qfix[c][0]) ^ qfix[c][2], fb = (qb[p] & qfix[c][1]) ^ qfix[c][3];
+                const u32x4 fa = (qa[p] & qfix[c][0]) ^ qsign_t[ks][c][0], fb = (qb[p] & qfix[c][1]) ^ qsign_t[ks][c][1];
                 split_oct(__builtin_bit_cast(f32x4, fa), __builtin_bit_cast(f32x4, fb), qh, ql);
             }
             *reinterpret_cast<u32x4*>(&Qh[ldsw[p]]) = qh;
@@ -904,12 +930,12 @@ __global__ __launch_bounds__(256, GWX3_WPS) void k_gradw_x3_lean(GradwArgs a) {
             }
         }
     };
-    if (nsteps > 0) fetch(0);
-    for (int s = 0; s < nsteps; ++s) {
+    if (total > 0) fetch();
+    for (int s = 0; s < total; ++s) {
         __syncthreads();      // the previous MFMA phase of every wave is done reading the tiles
         stage_to_lds();
         __syncthreads();
-        if (s + 1 < nsteps) fetch(s + 1);
+        if (s + 1 < total) fetch();
 #pragma unroll
         for (int ks = 0; ks < KW / 16; ++ks) {
             bf16x8 afh[2], afl[2], bqh[2], bql[2];
@@ -1079,8 +1105,9 @@ int x3_backward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pit
         ProfScope ps(p, hp.ks_gradw, st);
         static const bool gw_general = getenv("MSHGNN_GRADW") && std::string(getenv("MSHGNN_GRADW")) == "general";   // read once: the general kernel also where the lean one applies (A/B runs)
         if (a.n_pad > 0) {
-            if (a.aligned && GWX3_KW == 32 && !gw_general) hipLaunchKernelGGL(k_gradw_x3_lean, dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL(k_gradw_x3, dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a);
+            if (gw_general && hp.gw_ipl == 1) hipLaunchKernelGGL(k_gradw_x3, dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a);
+            else if (a.aligned) hipLaunchKernelGGL(k_gradw_x3_lean<true>, dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL(k_gradw_x3_lean<false>, dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a);
         }
     }
     return run_finalize(p, lay, ws, gparams, B, (y || labels) ? loss : nullptr, labels != nullptr, dec_done, gw_phase, st);

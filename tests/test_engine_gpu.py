@@ -388,3 +388,23 @@ def test_engine_keeps_a_bounded_number_of_workspaces():
     torch.cuda.synchronize()
     assert len(e._ws) <= e.MAX_WORKSPACES and (13, 1) in e._ws and (3, 1) not in e._ws
     assert e.stash_ticket(3) != t0
+
+
+@pytest.mark.parametrize("kind,topo,cfg,L", [("c2", "a1-c2", "a1-c2", 2), ("k4", "mini_cheetah-k4", "mini_cheetah-k4", 8)])
+def test_bf16_unaligned_inputs_take_the_element_wise_loaders(kind, topo, cfg, L):
+    """Dense (unpadded) bf16 inputs: joint rows of 450 / 300 elements start 4-byte aligned only -> the element-wise loaders of the encoder and
+    of the weight-gradient kernel (k_gradw_bf16_lean<false>, several items per lane on the K4 plan); same results as the padded layout."""
+    _require_gpu()
+    from morphsym_hgnn_amd import engine as eng, synth
+    spec = helpers.make_spec(kind, topo, cfg, 128, L, grf=3 if kind == "c2" else 1)
+    B = 21
+    e = eng.Engine(spec, "bf16")
+    n_y = spec.out_channels * spec.num_nodes[spec.out_type]
+    x_dict, y = synth.make_windows(3, B, spec.num_nodes, spec.widths, n_y)
+    flat = eng.flatten_params(spec, synth.make_params(3, spec.param_shapes()), e.device)
+    yd = y.reshape(-1).to(e.device, torch.float32)
+    o1, l1, g1 = e.step_mse(e.cast_inputs(x_dict, pad=True), flat, yd, B)
+    o1, l1, g1 = o1.clone(), l1.clone(), g1.clone()
+    o2, l2, g2 = e.step_mse(e.cast_inputs(x_dict, pad=False), flat, yd, B)
+    torch.cuda.synchronize()
+    assert torch.equal(o1, o2) and torch.equal(g1, g2)
