@@ -242,7 +242,10 @@ int mshgnn_grf_body_to_world(const float* quat, const float* grf_body, float* gr
 typedef struct mshgnn_window_desc {
     int32_t n_types, dtype, history, normalize;
     int32_t type_nodes[MSHGNN_MAX_TYPES], type_width[MSHGNN_MAX_TYPES];
-    int32_t n_src, n_runs, n_rows, _pad;
+    int32_t n_src, n_runs, n_rows;
+    int32_t fast_layout;      /* != 0: the caller states that the runs of every node row all have one length and follow each other from the row's first run's
+                               * feature on (what a recipe of T-long variables gives): with 16-byte aligned output rows and no standardisation the
+                               * gather then runs as one 16-byte store per output chunk (k_assemble_windows_fast)                              */
     const int32_t* runs;
     const int32_t* rows;
     int32_t n_label, label_src, label_rotate, quat_src;      /* quat_src = -1: none */

@@ -2623,6 +2623,71 @@ template <typename T, int NSET> __global__ __launch_bounds__(256) void k_assembl
     }
 }
 
+// Fast path of the same gather (no standardisation, 16-byte aligned output rows whose runs all have one length -- what SequenceStore builds):
+// a thread owns one 16-BYTE CHUNK of one node row -- EPC consecutive features, which live in at most two runs of that length -- gathers them
+// with EPC scalar loads (consecutive lanes read consecutive elements of a column-major series) and writes ONE 16-byte store; all chunks of a
+// window are independent, so every load of the window is in flight at once.  The general kernel above writes 4 bytes per lane and walks a row's
+// runs in turn: 0.12 ms for 8192 A1 windows against 0.03-0.04 ms here.  Pad columns inside a row's last chunk are written as zeros.
+constexpr int WIN_MAX_ROWS = 64, WIN_MAX_RUNS = 128;
+template <typename T> __global__ __launch_bounds__(256) void k_assemble_windows_fast(WindowArgs a) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    __shared__ unsigned long long s_src[WIN_MAX_RUNS];                    // source pointer of run r at this window's first step (0: the constant 1)
+    __shared__ int s_first[WIN_MAX_ROWS + 1];                             // chunk prefix per node row
+    __shared__ int s_run0[WIN_MAX_ROWS], s_len[WIN_MAX_ROWS], s_width[WIN_MAX_ROWS];
+    __shared__ unsigned long long s_dst[WIN_MAX_ROWS];                    // destination of the row's first element
+    const int tid = threadIdx.x;
+    const int64_t b = blockIdx.x, start = a.starts[b];
+    if (tid < a.n_runs) {
+        const int sc = a.runs[(size_t)tid * 5 + 3];
+        const float* sp = nullptr;
+#pragma unroll
+        for (int k = 0; k < WIN_MAX_SRC; ++k) if (sc >= 0 && (sc >> 8) == k) sp = a.src[k] + (size_t)(sc & 0xff) * a.src_cstride[k] + start;
+        s_src[tid] = (unsigned long long)sp;
+    }
+    if (tid < a.n_rows) {
+        const int r0 = a.rows[2 * tid], r1 = a.rows[2 * tid + 1];
+        const int* run = a.runs + (size_t)r0 * 5;
+        const int t = run[0], node = run[1], len = run[4];
+        int nodes = 0; int64_t pitch = 0; char* xb = nullptr;
+#pragma unroll
+        for (int k = 0; k < MSHGNN_MAX_TYPES; ++k) if (t == k) { nodes = a.nodes[k]; pitch = a.x_pitch[k]; xb = reinterpret_cast<char*>(a.x[k]); }
+        s_run0[tid] = r0; s_len[tid] = len; s_width[tid] = (r1 - r0) * len;
+        s_dst[tid] = (unsigned long long)(xb + (((size_t)b * nodes + node) * pitch + run[2]) * sizeof(T));
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        for (int r = 0; r < a.n_rows; ++r) { s_first[r] = acc; acc += (s_width[r] + EPC - 1) / EPC; }
+        s_first[a.n_rows] = acc;
+    }
+    __syncthreads();
+    const int total = s_first[a.n_rows];
+    int row = 0;
+    for (int task = tid; task < total; task += 256) {
+        while (task >= s_first[row + 1]) ++row;                            // (tasks of a thread ascend)
+        const int j = task - s_first[row], len = s_len[row], width = s_width[row];
+        const int k0 = j * EPC;
+        int run = s_run0[row] + k0 / len, off = k0 % len;
+        float v[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            v[e] = 0.f;
+            if (k0 + e < width) {
+                const float* sp = reinterpret_cast<const float*>(s_src[run]);
+                v[e] = sp ? sp[off] : 1.0f;
+            }
+            if (++off == len) { off = 0; ++run; }
+        }
+        T* dst = reinterpret_cast<T*>(s_dst[row]) + k0;
+        if constexpr (sizeof(T) == 2) {
+            union { u32x4 u; __bf16 e[8]; } pk;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pk.e[e] = (__bf16)v[e];
+            *reinterpret_cast<u32x4*>(dst) = pk.u;
+        } else *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+    }
+}
+
 // labels of a window = the label row of its LAST time step (quadSDKDataset.py: grfs[-1]); with label_rotate the world-frame
 // GRFs are taken into the body frame with the world->body quaternion of that step, R f per foot (the as_matrix() @ grfs_T
 // branch of load_data_at_dataset_seq_3d); quat out = that quaternion (data.r_o, quadSDKDataset_Morph.py:365-367)
@@ -2682,7 +2747,17 @@ extern "C" int mshgnn_assemble_windows(const mshgnn_window_desc* d, const float*
     a.y = y_out; a.quat = quat_out;
     hipStream_t st = (hipStream_t)stream;
     if (d->n_runs > 128) return set_err(MSHGNN_EUNSUPPORTED, "more than 128 feature runs per window are not supported by this build");
-    if (d->dtype == MSHGNN_F32 || d->dtype == MSHGNN_BF16X3) {      // the split plan takes fp32 inputs
+    // fast path: no standardisation, every row's runs of one length starting at the row's first feature 0, 16-byte aligned rows whose pitch covers whole chunks
+    const bool f32 = d->dtype == MSHGNN_F32 || d->dtype == MSHGNN_BF16X3;      // the split plan takes fp32 inputs
+    bool fast = !d->normalize && d->n_rows <= WIN_MAX_ROWS && d->n_runs <= WIN_MAX_RUNS && d->fast_layout != 0;
+    for (int t = 0; t < d->n_types && fast; ++t) {
+        const int epc = f32 ? 4 : 8;
+        if (((uintptr_t)x_out[t] & 15) || x_pitch[t] % epc || x_pitch[t] < (d->type_width[t] + epc - 1) / epc * epc) fast = false;
+    }
+    if (fast) {
+        if (f32) hipLaunchKernelGGL(k_assemble_windows_fast<float>, dim3((unsigned)batch), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(k_assemble_windows_fast<__bf16>, dim3((unsigned)batch), dim3(256), 0, st, a);
+    } else if (f32) {
         if (d->n_runs <= 64) hipLaunchKernelGGL((k_assemble_windows<float, 1>), dim3((unsigned)batch), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((k_assemble_windows<float, 2>), dim3((unsigned)batch), dim3(256), 0, st, a);
     } else {

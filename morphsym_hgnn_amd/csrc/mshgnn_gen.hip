@@ -86,82 +86,11 @@ __device__ __forceinline__ void raw8(const GArgs& a, int t, int node, int w, int
     }
 }
 
-// ------------------------------------------------------------------------------------------------------
-// k_gstep
-// ------------------------------------------------------------------------------------------------------
-// MB: 16-window row blocks per workgroup; NW: waves -- wave wv owns the 32-column slice (wv & 3) of the 128-column pack tile ctg * (NW / 4) + (wv >> 2),
-// so a workgroup's output tile is MB * 16 windows x NW * 32 columns and the staged A tile is shared by all NW waves
-template <bool SPLIT, int MB, int NW> __global__ __launch_bounds__(64 * NW) void k_gstep(GArgs a) {
+// epilogue of a job tile: this lane owns 8 consecutive output features of one window per row block (bias already in the accumulators)
+template <bool SPLIT, int MB>
+__device__ __forceinline__ void gstep_epilogue(const GArgs& a, const int* job, P16::Acc (&acc)[MB], int ct, int wv, int lane, int w0) {
     using P = P16;
-    constexpr int CPW = NW / 4;                          // 128-column pack tiles per workgroup
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // blocks [0, MB): (hi) A tile; [MB, 2 MB): lo halves (split plan)
-    const int tid = threadIdx.x, lane = tid & 63, wq = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nctg = a.NCT / CPW;
-    const int ct = (blockIdx.x % nctg) * CPW + (wq >> 2), wv = wq & 3, tile = (blockIdx.x / nctg) % a.tiles;
-    const int* job = a.jobs + (size_t)(a.job0 + blockIdx.x / (nctg * a.tiles)) * JOB_INTS;
-    const int w0 = tile * MB * P::ROWS, B = a.B, Hd = a.Hd;
-    const int flags = job[J_FLAGS];
-    const T16* wpack = reinterpret_cast<const T16*>(a.wpack);
-
-    P::Acc acc[MB];
-    {
-        const float* bias = (flags & JF_BIAS) ? a.bias + ((size_t)job[J_BIAS] + ct) * TW : nullptr;
-#pragma unroll
-        for (int m = 0; m < MB; ++m) acc_init_bias<T16>(acc[m], bias, wv, lane);
-    }
-    const int c = tid & 15, rr = tid >> 4;              // staging: thread = (row rr + 4 NW i of the tile, 8-element chunk c), i = 0 .. NPASS - 1
-    constexpr int NPASS = MB * 16 / (4 * NW);
-    static_assert(NPASS >= 1 && NPASS * 4 * NW == MB * 16, "row blocks must cover whole staging passes");
-    const AOff<T16> ao(lane);
-    P::BFrag bfh, bfl;
-    P::AFrag af;
-    const int* term = a.terms + (size_t)job[J_TERM0] * TERM_INTS;
-    for (int ti = 0; ti < job[J_NTERMS]; ++ti, term += TERM_INTS) {
-        const int nkc = term[T_NKC], kind = term[T_KIND], n_src = term[T_NSRC], F = term[T_WIDTH];
-        const int* src = a.srcs + (size_t)term[T_SRC0] * SRC_INTS;
-        for (int kc = 0; kc < nkc; ++kc) {
-            __syncthreads();   // the previous chunk's MFMAs are done reading LDS
-#pragma unroll
-            for (int i0 = 0; i0 < NPASS; i0 += 4) {      // four rows at a time: their loads are in flight together
-                constexpr int NB = NPASS < 4 ? NPASS : 4;
-                float s[NB][8];
-#pragma unroll
-                for (int i = 0; i < NB; ++i) {
-                    const int w = min(w0 + (i0 + i) * (4 * NW) + rr, B - 1);      // rows past the batch re-read the last window; they are never stored
-                    if (kind == 0) gather8<SPLIT>(a, src, n_src, w, kc * TW + c * 8, s[i]);
-                    else raw8<SPLIT>(a, src[S_BUF], src[S_NODE], w, kc * TW + c * 8, F, a.signs + term[T_SIGN] + kc * TW + c * 8, s[i]);
-                }
-#pragma unroll
-                for (int i = 0; i < NB; ++i) {
-                    const int grow = (i0 + i) * (4 * NW) + rr, m = grow >> 4, r0 = grow & 15;
-                    const f32x4 lo4 = f32x4{s[i][0], s[i][1], s[i][2], s[i][3]}, hi4 = f32x4{s[i][4], s[i][5], s[i][6], s[i][7]};
-                    if constexpr (SPLIT) {
-                        u32x4 hi, lo;
-                        split_oct(lo4, hi4, hi, lo);
-                        *reinterpret_cast<u32x4*>(smem + lds_chunk<T16>(m, r0, c)) = hi;
-                        *reinterpret_cast<u32x4*>(smem + lds_chunk<T16>(MB + m, r0, c)) = lo;
-                    } else *reinterpret_cast<u32x4*>(smem + lds_chunk<T16>(m, r0, c)) = pack_oct(lo4, hi4);
-                }
-            }
-            __syncthreads();
-            const int pack = term[T_PACK] + kc * a.NCT + ct;
-            load_bfrag<T16>(bfh, wpack, pack, wv, lane);
-            if constexpr (SPLIT) load_bfrag<T16>(bfl, wpack, a.n_img + pack, wv, lane);
-#pragma unroll
-            for (int m = 0; m < MB; ++m) {
-                if (w0 + m * P::ROWS < B) {   // uniform
-                    load_afrag<T16>(af, smem, m, ao);
-                    mac(acc[m], af, bfh);
-                    if constexpr (SPLIT) {
-                        mac(acc[m], af, bfl);
-                        load_afrag<T16>(af, smem, MB + m, ao);
-                        mac(acc[m], af, bfh);
-                    }
-                }
-            }
-        }
-    }
-    // epilogue: this lane owns 8 consecutive output features of one window per row block
+    const int B = a.B, Hd = a.Hd, flags = job[J_FLAGS];
     const int col = ct * TW + wv * 32 + c_oct(lane);
     T16* out = reinterpret_cast<T16*>(a.ws + a.buf_off[job[J_OUT_BUF]]);
 #pragma unroll
@@ -203,6 +132,100 @@ template <bool SPLIT, int MB, int NW> __global__ __launch_bounds__(64 * NW) void
             } else store_oct(q, y0, y1);
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// k_gstep
+// ------------------------------------------------------------------------------------------------------
+// MB: 16-window row blocks per workgroup; NW: waves -- wave wv owns the 32-column slice (wv & 3) of the 128-column pack tile ctg * (NW / 4) + (wv >> 2),
+// so a workgroup's output tile is MB * 16 windows x NW * 32 columns and the staged A tile is shared by all NW waves
+// Measured and left off (round 2, h = 512, B = 1024, us per layer launch):  GSTEP_W_EARLY=1 (the chunk's weight fragment requested before its A rows
+// are gathered instead of after the barrier) 297 vs 286 bf16, 829 vs 814 split;  a software-pipelined variant of this kernel (8 waves at two per SIMD
+// and up to 256 VGPRs, two A buffers in LDS, the next chunk's weight fragment and source rows in flight under the MFMAs, one barrier per chunk;
+// bit-identical results) 399 (128-window tiles) / 470 us bf16 against 287 for the 16-wave kernel below, 795 against 810 us split: with two waves per
+// SIMD one MFMA phase (~0.45 us) is too short a prefetch distance for the L2 / HBM latency of the rows, and the occupancy it costs hid more.
+#ifndef GSTEP_W_EARLY
+#define GSTEP_W_EARLY 0
+#endif
+template <bool SPLIT, int MB, int NW> __global__ __launch_bounds__(64 * NW) void k_gstep(GArgs a) {
+    using P = P16;
+    constexpr int CPW = NW / 4;                          // 128-column pack tiles per workgroup
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // blocks [0, MB): (hi) A tile; [MB, 2 MB): lo halves (split plan)
+    const int tid = threadIdx.x, lane = tid & 63, wq = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nctg = a.NCT / CPW;
+    const int ct = (blockIdx.x % nctg) * CPW + (wq >> 2), wv = wq & 3, tile = (blockIdx.x / nctg) % a.tiles;
+    const int* job = a.jobs + (size_t)(a.job0 + blockIdx.x / (nctg * a.tiles)) * JOB_INTS;
+    const int w0 = tile * MB * P::ROWS, B = a.B, Hd = a.Hd;
+    const int flags = job[J_FLAGS];
+    const T16* wpack = reinterpret_cast<const T16*>(a.wpack);
+
+    P::Acc acc[MB];
+    {
+        const float* bias = (flags & JF_BIAS) ? a.bias + ((size_t)job[J_BIAS] + ct) * TW : nullptr;
+#pragma unroll
+        for (int m = 0; m < MB; ++m) acc_init_bias<T16>(acc[m], bias, wv, lane);
+    }
+    const int c = tid & 15, rr = tid >> 4;              // staging: thread = (row rr + 4 NW i of the tile, 8-element chunk c), i = 0 .. NPASS - 1
+    constexpr int NPASS = MB * 16 / (4 * NW);
+    static_assert(NPASS >= 1 && NPASS * 4 * NW == MB * 16, "row blocks must cover whole staging passes");
+    const AOff<T16> ao(lane);
+    P::BFrag bfh, bfl;
+    P::AFrag af;
+    const int* term = a.terms + (size_t)job[J_TERM0] * TERM_INTS;
+    for (int ti = 0; ti < job[J_NTERMS]; ++ti, term += TERM_INTS) {
+        const int nkc = term[T_NKC], kind = term[T_KIND], n_src = term[T_NSRC], F = term[T_WIDTH];
+        const int* src = a.srcs + (size_t)term[T_SRC0] * SRC_INTS;
+        for (int kc = 0; kc < nkc; ++kc) {
+#if GSTEP_W_EARLY
+            // the chunk's weight fragment first: it needs no LDS, and its L2 latency then runs under the A rows' instead of after them
+            const int pack = term[T_PACK] + kc * a.NCT + ct;
+            load_bfrag<T16>(bfh, wpack, pack, wv, lane);
+            if constexpr (SPLIT) load_bfrag<T16>(bfl, wpack, a.n_img + pack, wv, lane);
+#endif
+            __syncthreads();   // the previous chunk's MFMAs are done reading LDS
+#pragma unroll
+            for (int i0 = 0; i0 < NPASS; i0 += 4) {      // four rows at a time: their loads are in flight together
+                constexpr int NB = NPASS < 4 ? NPASS : 4;
+                float s[NB][8];
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    const int w = min(w0 + (i0 + i) * (4 * NW) + rr, B - 1);      // rows past the batch re-read the last window; they are never stored
+                    if (kind == 0) gather8<SPLIT>(a, src, n_src, w, kc * TW + c * 8, s[i]);
+                    else raw8<SPLIT>(a, src[S_BUF], src[S_NODE], w, kc * TW + c * 8, F, a.signs + term[T_SIGN] + kc * TW + c * 8, s[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    const int grow = (i0 + i) * (4 * NW) + rr, m = grow >> 4, r0 = grow & 15;
+                    const f32x4 lo4 = f32x4{s[i][0], s[i][1], s[i][2], s[i][3]}, hi4 = f32x4{s[i][4], s[i][5], s[i][6], s[i][7]};
+                    if constexpr (SPLIT) {
+                        u32x4 hi, lo;
+                        split_oct(lo4, hi4, hi, lo);
+                        *reinterpret_cast<u32x4*>(smem + lds_chunk<T16>(m, r0, c)) = hi;
+                        *reinterpret_cast<u32x4*>(smem + lds_chunk<T16>(MB + m, r0, c)) = lo;
+                    } else *reinterpret_cast<u32x4*>(smem + lds_chunk<T16>(m, r0, c)) = pack_oct(lo4, hi4);
+                }
+            }
+            __syncthreads();
+#if !GSTEP_W_EARLY
+            const int pack = term[T_PACK] + kc * a.NCT + ct;
+            load_bfrag<T16>(bfh, wpack, pack, wv, lane);
+            if constexpr (SPLIT) load_bfrag<T16>(bfl, wpack, a.n_img + pack, wv, lane);
+#endif
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+                if (w0 + m * P::ROWS < B) {   // uniform
+                    load_afrag<T16>(af, smem, m, ao);
+                    mac(acc[m], af, bfh);
+                    if constexpr (SPLIT) {
+                        mac(acc[m], af, bfl);
+                        load_afrag<T16>(af, smem, MB + m, ao);
+                        mac(acc[m], af, bfh);
+                    }
+                }
+            }
+        }
+    }
+    gstep_epilogue<SPLIT, MB>(a, job, acc, ct, wv, lane, w0);
 }
 
 // ------------------------------------------------------------------------------------------------------

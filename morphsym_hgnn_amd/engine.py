@@ -61,7 +61,7 @@ class MshgnnWindowDesc(C.Structure):
     _fields_ = [
         ("n_types", C.c_int32), ("dtype", C.c_int32), ("history", C.c_int32), ("normalize", C.c_int32),
         ("type_nodes", C.c_int32 * 4), ("type_width", C.c_int32 * 4),
-        ("n_src", C.c_int32), ("n_runs", C.c_int32), ("n_rows", C.c_int32), ("_pad", C.c_int32), ("runs", C.c_void_p), ("rows", C.c_void_p),
+        ("n_src", C.c_int32), ("n_runs", C.c_int32), ("n_rows", C.c_int32), ("fast_layout", C.c_int32), ("runs", C.c_void_p), ("rows", C.c_void_p),
         ("n_label", C.c_int32), ("label_src", C.c_int32), ("label_rotate", C.c_int32), ("quat_src", C.c_int32),
         ("label_cols", C.c_void_p),
     ]

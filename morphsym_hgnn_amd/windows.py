@@ -109,7 +109,7 @@ def solo_com_arrays(X: np.ndarray, Y: np.ndarray) -> Dict[str, np.ndarray]:
 class SequenceStore:
     """The raw series of one recorded sequence on the GPU + the recipe that turns window indices into engine inputs."""
 
-    def __init__(self, arrays: Dict[str, np.ndarray], recipe: WindowRecipe, dtype: str = "bf16", device=None):
+    def __init__(self, arrays: Dict[str, np.ndarray], recipe: WindowRecipe, dtype: str = "bf16", device=None, fast: bool = True):
         if not torch.cuda.is_available():
             raise RuntimeError("window assembly runs on a HIP device; there is no CPU fallback")
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -156,6 +156,8 @@ class SequenceStore:
         for i, t in enumerate(recipe.node_types):
             d.type_nodes[i] = recipe.num_nodes[t]; d.type_width[i] = recipe.width(t)
         d.n_src = len(self.series); d.n_runs = len(runs); d.runs = self.runs.data_ptr()
+        d.fast_layout = int(fast)      # every row's runs are `history` long (or the single constant-1 run) and follow each other from feature 0
+                                       # (fast=False: the general run-by-run gather kernel, kept for descriptors that do not promise this)
         d.n_rows = len(rows); d.rows = self.rows.data_ptr()
         d.n_label = len(recipe.label_cols); d.label_src = sidx[recipe.label_series] if recipe.label_series else 0
         d.label_rotate = int(recipe.label_rotate); d.quat_src = sidx[recipe.quat_series] if recipe.quat_series else -1

@@ -27,14 +27,15 @@ def test_oracle_matches_reference_fixture(case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fast", [True, False], ids=["chunk-gather", "run-gather"])
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
-def test_device_assembly_matches_oracle(case, dtype):
+def test_device_assembly_matches_oracle(case, dtype, fast):
     from morphsym_hgnn_amd.windows import SequenceStore, quadsdk_a1_c2_recipe
     if case["grf"] == 1 and case["body"]:
         pytest.skip("not a reference configuration")
     recipe = quadsdk_a1_c2_recipe(JP, FP, T, case["grf"], case["body"], case["norm"])
-    store = SequenceStore(SEQ, recipe, dtype=dtype)
+    store = SequenceStore(SEQ, recipe, dtype=dtype, fast=fast)      # (both gather kernels; standardised recipes always take the run-by-run one)
     assert len(store) == N - T + 1
     starts = [0, 1, 37, 249, 250, 17, 17, 250, 3]            # repeats and the last valid window
     xs, y, q = store.assemble(starts)

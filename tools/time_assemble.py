@@ -1,0 +1,19 @@
+"""Time mshgnn_assemble_windows (8192 A1 windows out of a 200 000-step sequence) with both gather kernels, and the end-to-end loop of
+examples/train_flat.py's shape: assembly + step + Adam."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from morphsym_hgnn_amd.windows import SequenceStore, quadsdk_a1_c2_recipe
+N, B, T = 200000, 8192, 150
+rng = np.random.default_rng(0)
+seq = {k: rng.standard_normal((N, c)).astype(np.float32) for k, c in (("imu_acc", 3), ("imu_omega", 3), ("q", 12), ("qd", 12), ("tau", 12), ("F", 12), ("r_o", 4))}
+jp, fp = list(range(12)), list(range(4))
+starts = torch.from_numpy(rng.integers(0, N - T, size=B)).cuda()
+for dtype in ("bf16", "f32"):
+    for fast in (True, False):
+        st = SequenceStore(seq, quadsdk_a1_c2_recipe(jp, fp, T, 3), dtype=dtype, fast=fast)
+        for _ in range(5): st.assemble(starts, reuse_buffers=True)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(50): st.assemble(starts, reuse_buffers=True)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 50
+        print(f"assemble {dtype} {'chunk-gather' if fast else 'run-gather'}: {dt * 1e3:.4f} ms  ({B / dt / 1e6:.1f} M windows/s)")
