@@ -473,6 +473,7 @@ struct StackArgs {
     long long* stamps;   // timing experiments (MSHGNN_STAMPS): wave 0 of every workgroup records clock64() at phase boundaries
     // split plan: LDS block of the lo half of node n = lo_blk + n; the lo image of pack i is pack n_img + i
     int lo_blk, n_img;
+    int scr0;            // split plan: first base_transform scratch block (NN, or NN - n_mlp when the scratch aliases the last nodes' blocks)
 };
 #ifdef MSHGNN_SEG_STAMPS
 constexpr int FS_EXTRA_BLK = 6;     // LDS room for the per-segment clocks

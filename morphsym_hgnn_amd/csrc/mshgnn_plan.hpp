@@ -27,7 +27,10 @@ constexpr int H = 128;            // hidden width the kernels are built for
 constexpr int GMAX = 12;          // accumulator slots (dst nodes) a workgroup keeps live at once
 constexpr int TILE_ROWS = 16;      // windows per layer-kernel tile (one LDS node block = 16 x 128 elements)
 constexpr int MAX_L = 16;
-constexpr int LDS_LIMIT = 160 * 1024;
+#ifndef LDS_LIMIT_KB
+#define LDS_LIMIT_KB 160
+#endif
+constexpr int LDS_LIMIT = LDS_LIMIT_KB * 1024;
 constexpr int SLAB_FLOATS = H * H + H;   // one split-K partial: 128x128 matrix + 128 column sums
 constexpr int NWG_DEC = 512;             // workgroups of the decoder backward (each writes one small slab)
 constexpr int DEC_SLAB_FLOATS = 8 * H + 16; // decoder partial: [out_channels<=8][128] + bias[8] + loss partial (+pad)
@@ -157,6 +160,7 @@ struct HostPlan {
     int sl_fwd_off[MAX_L]{}, sl_bwd_off[MAX_L]{}, sl_ta = -1, sl_hb = SL_HB, sl_blk = 0;      // sl_hb: group-B slots (6 / 8); sl_blk: LDS blocks of a slab workgroup
     bool sl_alias = false;                        // base_transform scratch aliases group-A node blocks
     int fs_blk = 0;                               // LDS blocks of the fused kernels (NN + base_transform scratch)
+    bool x3_alias = false;                        // split plan: the base_transform scratch aliases the last n_mlp node blocks
     int ks_stack_fwd = -1, ks_stack_bwd = -1;
     int item_off = 0, n_items = 0, tgt_off = 0, n_targets = 0, lane_off = 0, n_lanes = 0, n_parts = 1, n_wg_gradw = 0;
     int lane_order_off = 0, n_lanes_pad = 0, gw_ipl = 1;
@@ -478,9 +482,15 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
     if (prog_overflow) return fail(p, "a layer's MAC program exceeds 128 entries per wave (too many relations/edges for this build)");
 
     // ---- fused stack programs (bf16 plan) ---------------------------------------------------------------
-    p.fused = d.dtype != MSHGNN_F32 && p.NN <= FS_MAXN && (int64_t)p.planes * (p.NN + p.n_mlp) * p.blk_bytes <= LDS_LIMIT &&
+    // split plan: where the doubled tile + base_transform scratch does not fit (MiniCheetah-K4: 2 x 24 blocks) but the doubled tile alone does
+    // (2 x 20 = 160 KB), the scratch blocks ALIAS the last n_mlp nodes' blocks: their owners read those nodes' residual octets before the chain
+    // (x3_alias; needs an even first victim so that scratch block i and victim i belong to the same wave, and victims that are not
+    // base_transform nodes themselves)
+    p.x3_alias = p.split && has_mlp && (int64_t)p.planes * (p.NN + p.n_mlp) * p.blk_bytes > LDS_LIMIT && (int64_t)p.planes * p.NN * p.blk_bytes <= LDS_LIMIT &&
+                 p.NN >= 2 * p.n_mlp && (p.NN - p.n_mlp) % 2 == 0;
+    p.fs_blk = p.NN + (p.x3_alias ? 0 : p.n_mlp);
+    p.fused = d.dtype != MSHGNN_F32 && p.NN <= FS_MAXN && (int64_t)p.planes * p.fs_blk * p.blk_bytes <= LDS_LIMIT &&
               (!has_mlp || (p.type_base[d.mlp_type] == 0 && p.n_mlp <= 4));   // base_transform nodes are accumulators 0..1 of each wave half
-    p.fs_blk = p.NN + p.n_mlp;
     p.lo_blk = p.fs_blk; p.n_img = (int)p.packs.size();
     if (p.split && !p.fused)
         return fail(p, "the split-bf16 parity plan is not supported for this topology (its LDS-resident tile holds 2 x (nodes + base_transform "

@@ -210,12 +210,13 @@ template <int N> __device__ __forceinline__ void mlp_mac3(P16::Acc (&acc)[N], co
 // k_stack_fwd_x3: the whole message-passing stack (+ decoder, + wrapper MSE and decoder backward under mshgnn_step_mse) of one
 // 16-window tile in one 8-wave workgroup -- k_stack_fwd of the bf16 plan on hi/lo planes
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_fwd_x3(StackArgs a) {
+// ALIAS: the base_transform scratch blocks are the blocks of the last nodes (topologies whose doubled tile leaves no room: MiniCheetah-K4)
+template <bool ALIAS> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_fwd_x3(StackArgs a) {
     using T = T16; using P = P16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wv & 3, wh = wv >> 2;
-    const int w0 = blockIdx.x * P::ROWS, B = a.B, NN = a.NN, LO = a.lo_blk;
+    const int w0 = blockIdx.x * P::ROWS, B = a.B, NN = a.NN, LO = a.lo_blk, SCR = a.scr0;
     const T* wpack = reinterpret_cast<const T*>(a.wpack);
     const int win = c_win(lane), w = w0 + win, col = wn * 32 + c_oct(lane);
     const bool w_ok = w < B, train = a.training != 0;
@@ -249,6 +250,19 @@ __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_fwd_x3(StackArgs a) 
         FS_STAMP(4 + 4 * l);
 
         u32x4 hph[2] = {}, hpl[2] = {}, tph[2] = {}, tpl[2] = {};
+        u32x4 vrh[2] = {}, vrl[2] = {};      // ALIAS: residual octets of the victim nodes SCR + wh + 2 j this wave owns, read before the chain overwrites their blocks
+        if constexpr (ALIAS) {
+            if (nmlp > 0 && (flags & FF_RESIDUAL)) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int v = SCR + wh + 2 * j;
+                    if (v < SCR + nmlp && fh[FH_KIND + v] != NK_DEAD) {
+                        vrh[j] = *reinterpret_cast<const u32x4*>(smem + lds_chunk<T>(v, win, col / P::EPC));
+                        vrl[j] = *reinterpret_cast<const u32x4*>(smem + lds_chunk<T>(LO + v, win, col / P::EPC));
+                    }
+                }
+            }
+        }
         if (nmlp > 0) {
             // base_transform: Y = W2 relu(W1 H + b1) + b2 on the first nmlp nodes (hgnn_c2.py:117-121,156); scratch blocks NN + i (hi),
             // LO + NN + i (lo).  The H and T1 stashes are kept packed in registers and stored after the chain.
@@ -260,13 +274,13 @@ __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_fwd_x3(StackArgs a) 
                 const int n = 2 * u + wh;
                 if (n < nmlp) {
                     split_oct(acc[u].c[0], acc[u].c[1], hph[u], hpl[u]);
-                    *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(NN + n, win, col / P::EPC)) = hph[u];
-                    *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(LO + NN + n, win, col / P::EPC)) = hpl[u];
+                    *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(SCR + n, win, col / P::EPC)) = hph[u];
+                    *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(LO + SCR + n, win, col / P::EPC)) = hpl[u];
                     acc_init_bias<T>(acc[u], a.bias + (size_t)fh[FH_B1] * H, wn, lane);
                 }
             }
             __syncthreads();
-            mlp_mac3(acc, smem, NN, LO, nmlp, wh, bfh, bfl, lane);      // accumulators 0..1 = nodes 0..3
+            mlp_mac3(acc, smem, SCR, LO, nmlp, wh, bfh, bfl, lane);      // accumulators 0..1 = nodes 0..3
             load_bfrag<T>(bfh, wpack, fh[FH_W2], wn, lane);
             load_bfrag<T>(bfl, wpack, a.n_img + fh[FH_W2], wn, lane);
             __syncthreads();   // all reads of H done before T1 overwrites the scratch blocks
@@ -275,13 +289,13 @@ __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_fwd_x3(StackArgs a) 
                 const int n = 2 * u + wh;
                 if (n < nmlp) {
                     split_oct(relu4(acc[u].c[0]), relu4(acc[u].c[1]), tph[u], tpl[u]);
-                    *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(NN + n, win, col / P::EPC)) = tph[u];
-                    *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(LO + NN + n, win, col / P::EPC)) = tpl[u];
+                    *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(SCR + n, win, col / P::EPC)) = tph[u];
+                    *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(LO + SCR + n, win, col / P::EPC)) = tpl[u];
                     acc_init_bias<T>(acc[u], a.bias + (size_t)fh[FH_B2] * H, wn, lane);
                 }
             }
             __syncthreads();
-            mlp_mac3(acc, smem, NN, LO, nmlp, wh, bfh, bfl, lane);      // accumulators 0..1 = nodes 0..3
+            mlp_mac3(acc, smem, SCR, LO, nmlp, wh, bfh, bfl, lane);      // accumulators 0..1 = nodes 0..3
         }
         FS_STAMP(16 + l);
         // every load issued so far has landed before the first store of the epilogue goes out
@@ -311,8 +325,12 @@ __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_fwd_x3(StackArgs a) 
             kindv[u] = n < NN ? fh[FH_KIND + n] : NK_DEAD;
             resh[u] = u32x4{0, 0, 0, 0}; resl[u] = u32x4{0, 0, 0, 0};
             if (kindv[u] != NK_DEAD && (flags & FF_RESIDUAL)) {
-                resh[u] = *reinterpret_cast<const u32x4*>(smem + lds_chunk<T>(n, win, col / P::EPC));
-                resl[u] = *reinterpret_cast<const u32x4*>(smem + lds_chunk<T>(LO + n, win, col / P::EPC));
+                if (ALIAS && nmlp > 0 && n >= SCR && n < SCR + nmlp) {      // a victim: its block holds T1 by now
+                    resh[u] = ((n - SCR) >> 1) == 0 ? vrh[0] : vrh[1]; resl[u] = ((n - SCR) >> 1) == 0 ? vrl[0] : vrl[1];
+                } else {
+                    resh[u] = *reinterpret_cast<const u32x4*>(smem + lds_chunk<T>(n, win, col / P::EPC));
+                    resl[u] = *reinterpret_cast<const u32x4*>(smem + lds_chunk<T>(LO + n, win, col / P::EPC));
+                }
             }
         }
 #pragma unroll
@@ -995,7 +1013,7 @@ static int x3_lds_stack(const HostPlan& hp) { return 2 * hp.fs_blk * P16::BLK; }
 int x3_set_attrs(mshgnn_plan* p) {
     int rc;
     const int flds = x3_lds_stack(p->hp);
-    if ((rc = set_lds_attr(k_stack_fwd_x3, flds)) || (rc = set_lds_attr(k_stack_bwd_x3, flds)) ||
+    if ((rc = set_lds_attr(k_stack_fwd_x3<false>, flds)) || (rc = set_lds_attr(k_stack_fwd_x3<true>, flds)) || (rc = set_lds_attr(k_stack_bwd_x3, flds)) ||
         (rc = set_lds_attr(k_enc_x3<true>, 8 * P16::BLK)) || (rc = set_lds_attr(k_enc_x3<false>, 8 * P16::BLK))) return rc;
     return MSHGNN_OK;
 }
@@ -1007,7 +1025,7 @@ static void x3_stack_args(const mshgnn_plan* p, const mshgnn_ws_layout& lay, cha
     for (int l = 0; l < hp.L; ++l) { a.mask_off[l] = lay.mask[l]; a.hb_off[l] = lay.hb[l]; a.t1_off[l] = lay.t1[l]; a.dh_off[l] = lay.dh[l]; a.du_off[l] = lay.du[l]; }
     a.wpack = ws + lay.wpack; a.bias = reinterpret_cast<const float*>(ws + lay.bias); a.tables = p->d_tables;
     a.B = B; a.NN = hp.NN; a.L = hp.L;
-    a.lo_blk = hp.lo_blk; a.n_img = hp.n_img;
+    a.lo_blk = hp.lo_blk; a.n_img = hp.n_img; a.scr0 = hp.x3_alias ? hp.NN - hp.n_mlp : hp.NN;
 }
 
 int x3_forward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, float* out, char* ws, int64_t batch,
@@ -1056,7 +1074,8 @@ int x3_forward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitc
         const int tiles = (B + P16::ROWS - 1) / P16::ROWS;
         a.stamps = stamp_ptr("MSHGNN_STAMPS");
         ProfScope ps(p, hp.ks_stack_fwd, st);
-        hipLaunchKernelGGL(k_stack_fwd_x3, dim3(tiles), dim3(LAYER_THREADS), x3_lds_stack(hp), st, a);
+        if (hp.x3_alias) hipLaunchKernelGGL(k_stack_fwd_x3<true>, dim3(tiles), dim3(LAYER_THREADS), x3_lds_stack(hp), st, a);
+        else hipLaunchKernelGGL(k_stack_fwd_x3<false>, dim3(tiles), dim3(LAYER_THREADS), x3_lds_stack(hp), st, a);
     }
     HIPCHK(hipGetLastError());
     return MSHGNN_OK;
