@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- graph-windows/sec, fwd + loss + bwd of the MS-HGNN hot path (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W [--config a1c2|mck4|synth32] [--dtype bf16|x3|f32] [--surface flat|module]
+  python bench.py --gpus N --steps K --warmup W [--config a1c2|mck4|solo|synth32] [--dtype bf16|x3|f32] [--surface flat|module]
 
 A "step" is one pass of the hot path over one minibatch of synthetic windows that is already resident in HBM:
 forward (encoder, L message-passing layers, decoder) + wrapper loss + backward with every parameter gradient
@@ -46,9 +46,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="a1c2", choices=["a1c2", "mck4", "synth32"])
-    ap.add_argument("--batch", type=int, default=0, help="windows per GPU (default: 8192 a1c2, 8192 mck4, 1024 synth32)")
-    ap.add_argument("--layers", type=int, default=0, help="message-passing layers (default: 3 a1c2, 8 mck4, 6 synth32)")
+    ap.add_argument("--config", default="a1c2", choices=["a1c2", "mck4", "solo", "synth32"])
+    ap.add_argument("--batch", type=int, default=0, help="windows per GPU (default: 8192 a1c2, 8192 mck4, 65536 solo, 1024 synth32)")
+    ap.add_argument("--layers", type=int, default=0, help="message-passing layers (default: 3 a1c2, 8 mck4, 8 solo, 6 synth32)")
     ap.add_argument("--hidden", type=int, default=0, help="hidden channels (default 128; 512 for synth32)")
     ap.add_argument("--dtype", default=os.environ.get("MSHGNN_BENCH_DTYPE", "bf16"), choices=["f32", "bf16", "x3"])
     ap.add_argument("--surface", default="flat", choices=["flat", "module"])
@@ -107,6 +107,11 @@ def build_spec(layers=3, config="a1c2", hidden=128):
             group = yaml.safe_load(f)
         return ModelSpec(kind="k4", topology=topology.TOPOLOGIES["mini_cheetah-k4"](), hidden=hidden, num_layers=layers,
                          widths=synth.feature_widths("k4", False), regression=False, grf_dimension=3, group=group)
+    if config == "solo":      # BASELINE configs[3]: Solo-12 K4 regression = the centroidal-momentum model COM_HGNN_K4 (train_regression-com_msgn.py:
+        with open(os.path.join(cfgdir, "solo-k4.yaml")) as f:      # history_length 1, num_layers 8, hidden 128)
+            group = yaml.safe_load(f)
+        return ModelSpec(kind="k4_com", topology=topology.TOPOLOGIES["solo-k4-com"](), hidden=hidden, num_layers=layers,
+                         widths=synth.feature_widths("k4_com", True), regression=True, grf_dimension=3, group=group)
     if config == "synth32":   # BASELINE configs[4]: synthetic 32-limb robot, MI-HGNN model (hgnn.py:GRF_HGNN)
         return ModelSpec(kind="mi", topology=topology.synthetic_limbs(32), hidden=hidden, num_layers=layers,
                          widths=synth.feature_widths("mi", True), regression=True, grf_dimension=3, group=None)
@@ -114,7 +119,7 @@ def build_spec(layers=3, config="a1c2", hidden=128):
 
 
 def defaults(args):
-    d = {"a1c2": (8192, 3, 128), "mck4": (8192, 8, 128), "synth32": (1024, 6, 512)}[args.config]
+    d = {"a1c2": (8192, 3, 128), "mck4": (8192, 8, 128), "solo": (65536, 8, 128), "synth32": (1024, 6, 512)}[args.config]
     return (args.batch or d[0], args.layers or d[1], args.hidden or d[2])
 
 
@@ -410,7 +415,8 @@ def main():
                                 "own operands (stashed activations included), it is not the step-level fraction"}
     kernels = {s["name"]: round(s["total_ms"] / s["launches"] * 1e3, 2) for s in stats}
 
-    names = {"a1c2": "A1-C2 GRF regression (3-D)", "mck4": "MiniCheetah-K4 contact classification", "synth32": "synthetic 32-limb MI-HGNN GRF regression"}
+    names = {"a1c2": "A1-C2 GRF regression (3-D)", "mck4": "MiniCheetah-K4 contact classification", "solo": "Solo-12 K4 centroidal-momentum regression (COM_HGNN_K4)",
+             "synth32": "synthetic 32-limb MI-HGNN GRF regression"}
     res = {
         "metric": "graph-windows/sec fwd+bwd, A1-C2 GRF regression" if args.config == "a1c2" else f"graph-windows/sec fwd+bwd, {names[args.config]}",
         "value": value, "unit": "windows/s",
