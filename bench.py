@@ -336,6 +336,43 @@ def module_surface(spec, B, device, steps, warmup, precision):
     return res
 
 
+def end_to_end(spec, B, device, steps, warmup):
+    """Training throughput INCLUDING the data path (never `value`): random window starts -> gather from a resident synthetic sequence ->
+    step -> Adam on the flat buffers, all on the device (examples/train_flat.py).  Two routes with identical bits: mshgnn_assemble_windows +
+    mshgnn_step_mse, and mshgnn_step_mse_series (the gather fused into the encoder)."""
+    import numpy as np
+    import torch
+    from morphsym_hgnn_amd import engine as eng, synth
+    from morphsym_hgnn_amd.windows import SequenceStore, quadsdk_a1_c2_recipe
+    rows, T = 200_000, 150
+    rng = np.random.default_rng(0)
+    seq = {k: rng.standard_normal((rows, c)).astype(np.float32) for k, c in (("imu_acc", 3), ("imu_omega", 3), ("q", 12), ("qd", 12), ("tau", 12), ("F", 12), ("r_o", 4))}
+    store = SequenceStore(seq, quadsdk_a1_c2_recipe(range(12), range(4), T, 3), dtype="bf16", device=device)
+    e = eng.Engine(spec, dtype="bf16", device=device)
+    flat = eng.flatten_params(spec, synth.make_params(0, spec.param_shapes()), device)
+    gflat, m, v = torch.empty_like(flat), torch.zeros_like(flat), torch.zeros_like(flat)
+    out = torch.empty(B * 4, 3, dtype=torch.float32, device=device); loss = torch.empty(1, dtype=torch.float32, device=device)
+    gen = torch.Generator(device=device).manual_seed(7)
+    res = {"what": f"random starts -> window gather from a resident {rows}-step sequence -> fwd + MSE + bwd -> Adam, {B} windows/step, bf16 plan"}
+    for name, fused in (("assemble_then_step", False), ("fused_gather", True)):
+        def step(i):
+            starts = torch.randint(0, len(store), (B,), generator=gen, device=device)
+            if fused:
+                e.step_mse_series(store, starts, flat, out=out, grad_flat=gflat, loss=loss)
+            else:
+                xs, y, _ = store.assemble(starts, reuse_buffers=True)
+                e.step_mse(xs, flat, y.view(-1), B, out=out, grad_flat=gflat, loss=loss)
+            e.adam_step(flat, gflat, m, v, i + 1, 1e-4)
+        for i in range(warmup):
+            step(i)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(steps):
+            step(warmup + i)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+        res[name] = {"ms_per_step": dt * 1e3, "value": B / dt}
+    return res
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -455,6 +492,9 @@ def main():
                                   "tolerance": 1e-4, "kernel_us": pk,
                                   "what": "same workload, parity-grade plan: max-abs error / max-abs reference over output, loss and every "
                                           "parameter gradient against the fp64 oracle on 48 seeded windows"}
+        if args.dtype == "bf16" and L == 3:
+            res["end_to_end"] = end_to_end(spec, B, device, args.steps, args.warmup)
+            torch.cuda.empty_cache()
         if L != 8:      # the paper's depth (train_regression-grf_msgn.py:94)
             w8 = Workload(build_spec(8, args.config, hidden), args.dtype, B, device, 1234)
             m8, _ = w8.time_blocks(args.steps, args.warmup, args.min_time / 2)

@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """End-to-end training loop on the flat C-ABI interface, everything on the MI355X:
 
-    window indices --(mshgnn_assemble_windows)--> engine inputs --(forward, fused MSE backward)--> flat gradient
+    window indices --(mshgnn_step_mse_series: the window gather fused into the encoder, forward, fused MSE backward)--> flat gradient
     --(RCCL all-reduce when launched with torchrun)--> Adam on the flat buffers, step metrics on device.
+(`--two-call`: mshgnn_assemble_windows, then mshgnn_step_mse -- the same bits, one more pass over the batch's windows; the only route of the
+fp32 plan.)
 
 It is what `train_model` (gnnLightning.py:1230-1400) does through Lightning + PyG's DataLoader, reduced to the hot path;
 data are synthetic (a smooth random sequence whose GRFs are a fixed linear function of the joint torques, so the loss has
@@ -35,7 +37,7 @@ def synthetic_sequence(n_rows: int, seed: int = 0):
     return seq
 
 
-def train(steps=200, batch=8192, dtype="bf16", layers=3, lr=1e-3, rows=100_000, log_every=50, quiet=False):
+def train(steps=200, batch=8192, dtype="bf16", layers=3, lr=1e-3, rows=100_000, log_every=50, quiet=False, fused_gather=None):
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     dist = None
     if world > 1:
@@ -54,13 +56,17 @@ def train(steps=200, batch=8192, dtype="bf16", layers=3, lr=1e-3, rows=100_000, 
     metrics = StepMetrics(regression=True, device=dev)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     losses = []
+    fused_gather = (dtype == "bf16") if fused_gather is None else fused_gather
     warm = 5       # untimed: code-object load, workspace allocation, RCCL channel set-up
     for step in range(1, steps + warm + 1):
         if step == warm + 1:
             torch.cuda.synchronize(); t0 = time.perf_counter()
         starts = torch.randint(0, len(store), (batch,), generator=gen, device=dev)
-        xs, y, _ = store.assemble(starts, reuse_buffers=True)
-        e.step_mse(xs, flat, y.view(-1), batch, out=out, grad_flat=gflat, loss=loss)     # forward + MSE + backward in one call
+        if fused_gather:     # the encoder gathers its inputs from the resident series; forward + MSE + backward in the same call
+            xs, y, *_ = e.step_mse_series(store, starts, flat, out=out, grad_flat=gflat, loss=loss)
+        else:
+            xs, y, _ = store.assemble(starts, reuse_buffers=True)
+            e.step_mse(xs, flat, y.view(-1), batch, out=out, grad_flat=gflat, loss=loss)     # forward + MSE + backward in one call
         if dist is not None:
             dist.all_reduce(gflat, op=dist.ReduceOp.AVG)      # DDP semantics: mean over ranks
         e.adam_step(flat, gflat, m, v, step, lr)
@@ -82,6 +88,6 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=200); ap.add_argument("--batch", type=int, default=8192)
     ap.add_argument("--dtype", default="bf16", choices=["f32", "bf16"]); ap.add_argument("--layers", type=int, default=3)
-    ap.add_argument("--lr", type=float, default=1e-3)
+    ap.add_argument("--lr", type=float, default=1e-3); ap.add_argument("--two-call", action="store_true")
     a = ap.parse_args()
-    train(a.steps, a.batch, a.dtype, a.layers, a.lr)
+    train(a.steps, a.batch, a.dtype, a.layers, a.lr, fused_gather=False if a.two_call else None)

@@ -256,6 +256,18 @@ int mshgnn_assemble_windows(const mshgnn_window_desc* desc, const float* const* 
                             const int64_t* src_rows, const int64_t* starts /* device int64[batch] */, int64_t batch,
                             void* const* x_out, const int64_t* x_pitch, float* y_out, float* quat_out, void* stream);
 
+/* One training step straight from a sequence's resident raw series: mshgnn_assemble_windows + mshgnn_step_mse with the window gather FUSED INTO THE
+ * ENCODER (no separate pass that writes and re-reads the batch's windows): the encoder kernel gathers its K chunks from bf16 copies of the series
+ * (src_bf16: same shapes / column strides as src, every column followed by >= 8 elements of slack: src_cstride >= src_rows + 8), and writes the
+ * materialised windows x_out (bf16, 16-byte aligned rows, pitch a multiple of 8) for the weight-gradient pass and for the caller; labels / quaternions come
+ * from the fp32 series as in mshgnn_assemble_windows.  The descriptor must be a bf16, fast_layout, unstandardised recipe whose node types match the
+ * plan's; bf16 plan with the fused stack kernels (else MSHGNN_EUNSUPPORTED: assemble, then mshgnn_step_mse).  run_ptrs: device scratch, 8 bytes per run.
+ * Results are bit-identical to mshgnn_assemble_windows followed by mshgnn_step_mse.                                                              */
+int mshgnn_step_mse_series(const mshgnn_plan* plan, const mshgnn_window_desc* desc, const float* const* src, const void* const* src_bf16,
+                           const int64_t* src_cstride, const int64_t* src_rows, const int64_t* starts /* device int64[batch] */, int64_t batch,
+                           void* const* x_out, const int64_t* x_pitch, float* y_out, float* quat_out, void* run_ptrs,
+                           const float* params, float* out, float* loss_out, float* grad_params, void* workspace, void* stream);
+
 /* ---- stand-alone operators behind the four torch_geometric.nn names ----------------------------------
  * For a maintainer who swaps only the PyG import (hgnn_c2.py:3): Linear / HeteroDictLinear (hgnn_c2.py:88,131), GraphConv
  * (hgnn_c2.py:100-112) and their autograd backward on arbitrary graphs and widths, fp32 operands, fp32 MFMA, no float atomics.

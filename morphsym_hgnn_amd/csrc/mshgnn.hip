@@ -75,8 +75,19 @@ template <typename T> __global__ void k_prep(PrepArgs a) {
 
 // ALIGNED: every input row starts 16-byte aligned with a pitch of whole 16-byte chunks (the engine's own input layout): raw
 // 16-byte loads only -- the general element-wise path is compiled out of this instantiation (a third of the kernel's code)
-template <typename T, bool ALIGNED> __global__ __launch_bounds__(256) void k_enc_fwd(EncArgs a) {
+// SERIES (bf16, ALIGNED): the rows come out of the sequence's raw series (SeriesSrc) and are ALSO written to a.x as materialised windows (the
+// weight-gradient kernel reads them later): window assembly fused into the encoder -- one unaligned 16-byte load per chunk (two where the chunk
+// straddles two runs), no separate gather pass over 118 MB.
+__device__ __forceinline__ u32x4 splice8(u32x4 A, u32x4 B, int n0) {      // bf16 elements A[0 .. n0) ++ B[0 .. 8 - n0), 0 < n0 < 8
+    const unsigned __int128 a = ((unsigned __int128)(((unsigned long long)A[3] << 32) | A[2]) << 64) | (((unsigned long long)A[1] << 32) | A[0]);
+    const unsigned __int128 b = ((unsigned __int128)(((unsigned long long)B[3] << 32) | B[2]) << 64) | (((unsigned long long)B[1] << 32) | B[0]);
+    const int sh = 16 * n0;
+    const unsigned __int128 r = (a & ((((unsigned __int128)1) << sh) - 1)) | (b << sh);
+    return u32x4{(unsigned)r, (unsigned)(r >> 32), (unsigned)(r >> 64), (unsigned)(r >> 96)};
+}
+template <typename T, bool ALIGNED, bool SERIES = false> __global__ __launch_bounds__(256) void k_enc_fwd(EncArgs a, SeriesSrc ser) {
     using P = Prec<T>;
+    static_assert(!SERIES || (sizeof(T) == 2 && ALIGNED), "the series gather is a bf16 path");
     constexpr int MB = P::ENC_MB;                       // row blocks (of 16 windows) per workgroup
     constexpr int VPB = P::ROWS * P::CPR, NIT = VPB / 256 > 0 ? VPB / 256 : 1, BPP = 256 / VPB > 0 ? 256 / VPB : 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -102,9 +113,35 @@ template <typename T, bool ALIGNED> __global__ __launch_bounds__(256) void k_enc
     typename P::AFrag af;
     const AOff<T> ao(lane);      // fragment offsets once per kernel (the generic load_afrag rebuilds them per call: 14 VALU instructions)
     using VBuf = u32x4[MB / BPP][NIT];
+    // SERIES: first series row of this thread's window rows, the node row's first run
+    int srow[SERIES ? MB / BPP : 1]; int rfirst = 0;
+    if constexpr (SERIES) {
+#pragma unroll
+        for (int mi = 0; mi < MB / BPP; ++mi) srow[mi] = (int)ser.starts[min(w0 + (mi * BPP + sub) * P::ROWS + r0, a.B - 1)];
+        rfirst = ser.rows[2 * (ser.row0[t] + node)];
+    }
     auto fetch = [&](VBuf& v, int kc) {
         const int k0 = kc * H + c * P::EPC;
         const int nvalid = min(P::EPC, F - k0);
+        if constexpr (SERIES) {
+            // elements [k0, k0 + 8) of the row: n0 of them from run j at time offset off, the rest from run j + 1 at offset 0
+            const int j = k0 / ser.T, off = k0 - j * ser.T, n0 = min(P::EPC, ser.T - off);
+            const bool second = nvalid > n0;
+            const unsigned long long pa = nvalid > 0 ? ser.run_ptr[rfirst + j] : 0ull, pb = second ? ser.run_ptr[rfirst + j + 1] : 0ull;
+            const u32x4 ones = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};      // the constant-1 run (bf16 1.0)
+#pragma unroll
+            for (int mi = 0; mi < MB / BPP; ++mi) {
+                u32x4 va = nvalid > 0 ? ones : u32x4{0, 0, 0, 0};
+                if (pa) va = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(pa) + srow[mi] + off);       // 2-byte aligned: served at full rate
+                if (second) {
+                    u32x4 vb2 = ones;
+                    if (pb) vb2 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(pb) + srow[mi]);
+                    va = splice8(va, vb2, n0);
+                }
+                v[mi][0] = va;
+            }
+            return;
+        }
 #pragma unroll
         for (int mi = 0; mi < MB / BPP; ++mi)
 #pragma unroll
@@ -129,9 +166,14 @@ template <typename T, bool ALIGNED> __global__ __launch_bounds__(256) void k_enc
 #pragma unroll
         for (int mi = 0; mi < MB / BPP; ++mi)
 #pragma unroll
-            for (int it = 0; it < NIT; ++it)
-                *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(mi * BPP + sub, r0 + it * (256 / P::CPR), c)) =
-                    (kc + 1 == nkc ? chunk_keep_first<T>(v[mi][it], nv) : v[mi][it]) ^ sx;      // only the last K chunk has pad columns
+            for (int it = 0; it < NIT; ++it) {
+                const u32x4 raw = kc + 1 == nkc ? chunk_keep_first<T>(v[mi][it], nv) : v[mi][it];      // only the last K chunk has pad columns
+                *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(mi * BPP + sub, r0 + it * (256 / P::CPR), c)) = raw ^ sx;
+                if constexpr (SERIES) {      // the materialised window row (raw values: the sign mask is applied by whoever reads it)
+                    const int w = w0 + (mi * BPP + sub) * P::ROWS + r0 + it * (256 / P::CPR), k0 = kc * H + c * P::EPC;
+                    if (w < a.B && k0 < (int)pitch) *reinterpret_cast<u32x4*>(const_cast<T*>(x) + ((size_t)w * nt + node) * pitch + k0) = raw;
+                }
+            }
         __syncthreads();
         load_bfrag<T>(bf, wpack, a.pack0[t] + kc, wv, lane);   // before the prefetch: vmcnt retires in order
         if (kc + ahead < nkc) fetch(v, kc + ahead);   // a later K chunk streams from HBM under this chunk's MFMAs
@@ -1973,7 +2015,7 @@ extern "C" int mshgnn_plan_create(const mshgnn_desc* desc, mshgnn_plan** out) {
             (rc = set_lds_attr(k_enc_fwd<float, true>, Prec<float>::ENC_MB * Prec<float>::BLK)) || (rc = set_lds_attr(k_enc_fwd<float, false>, Prec<float>::ENC_MB * Prec<float>::BLK))) { mshgnn_plan_destroy(p); return rc; }
     } else {
         if ((rc = set_lds_attr(k_layer_fwd<__bf16>, lds)) || (rc = set_lds_attr(k_layer_bwd<__bf16>, lds)) ||
-            (rc = set_lds_attr(k_enc_fwd<__bf16, true>, Prec<__bf16>::ENC_MB * Prec<__bf16>::BLK)) || (rc = set_lds_attr(k_enc_fwd<__bf16, false>, Prec<__bf16>::ENC_MB * Prec<__bf16>::BLK))) { mshgnn_plan_destroy(p); return rc; }
+            (rc = set_lds_attr(k_enc_fwd<__bf16, true>, Prec<__bf16>::ENC_MB * Prec<__bf16>::BLK)) || (rc = set_lds_attr(k_enc_fwd<__bf16, true, true>, Prec<__bf16>::ENC_MB * Prec<__bf16>::BLK)) || (rc = set_lds_attr(k_enc_fwd<__bf16, false>, Prec<__bf16>::ENC_MB * Prec<__bf16>::BLK))) { mshgnn_plan_destroy(p); return rc; }
         const char* e = getenv("MSHGNN_FUSED");
         p->use_fused = hp.fused && !(e && atoi(e) == 0);
         if (p->use_fused) {
@@ -2079,7 +2121,7 @@ int run_finalize(const mshgnn_plan* p, const mshgnn_ws_layout& lay, char* ws, fl
 
 template <typename T>
 static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, float* out,
-                        char* ws, int64_t batch, int training, hipStream_t st, const float* y_fused = nullptr) {
+                        char* ws, int64_t batch, int training, hipStream_t st, const float* y_fused = nullptr, const SeriesSrc* series = nullptr) {
     const HostPlan& hp = p->hp;
     const mshgnn_desc& d = hp.d;
     mshgnn_ws_layout lay; layout_workspace(hp, batch, training, &lay);
@@ -2109,8 +2151,16 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
         a.wpack = ws + lay.wpack; a.bias = reinterpret_cast<const float*>(ws + lay.bias); a.signs = p->d_signs; a.x0 = ws + lay.x[0];
         a.mask0 = (training && lay.dd[0]) ? reinterpret_cast<uint8_t*>(ws + lay.dd[0]) : nullptr;
         ProfScope ps(p, hp.ks_enc, st);
-        if (a.aligned) hipLaunchKernelGGL((k_enc_fwd<T, true>), dim3(a.wg_prefix[hp.NT]), dim3(256), Prec<T>::ENC_MB * Prec<T>::BLK, st, a);
-        else hipLaunchKernelGGL((k_enc_fwd<T, false>), dim3(a.wg_prefix[hp.NT]), dim3(256), Prec<T>::ENC_MB * Prec<T>::BLK, st, a);
+        if constexpr (sizeof(T) == 2) {
+            if (series) {
+                if (!a.aligned) return set_err(MSHGNN_EINVAL, "the fused window assembly needs 16-byte aligned window rows (pitch a multiple of 8)");
+                hipLaunchKernelGGL((k_enc_fwd<T, true, true>), dim3(a.wg_prefix[hp.NT]), dim3(256), Prec<T>::ENC_MB * Prec<T>::BLK, st, a, *series);
+            } else if (a.aligned) hipLaunchKernelGGL((k_enc_fwd<T, true>), dim3(a.wg_prefix[hp.NT]), dim3(256), Prec<T>::ENC_MB * Prec<T>::BLK, st, a, SeriesSrc{});
+            else hipLaunchKernelGGL((k_enc_fwd<T, false>), dim3(a.wg_prefix[hp.NT]), dim3(256), Prec<T>::ENC_MB * Prec<T>::BLK, st, a, SeriesSrc{});
+        } else {
+            if (a.aligned) hipLaunchKernelGGL((k_enc_fwd<T, true>), dim3(a.wg_prefix[hp.NT]), dim3(256), Prec<T>::ENC_MB * Prec<T>::BLK, st, a, SeriesSrc{});
+            else hipLaunchKernelGGL((k_enc_fwd<T, false>), dim3(a.wg_prefix[hp.NT]), dim3(256), Prec<T>::ENC_MB * Prec<T>::BLK, st, a, SeriesSrc{});
+        }
     }
     // 3. layers (+ decoder): one fused launch on the bf16 plan, else one kernel per layer and the decoder kernel
     const int tiles = (B + Prec<T>::ROWS - 1) / Prec<T>::ROWS;
@@ -2770,3 +2820,61 @@ extern "C" int mshgnn_assemble_windows(const mshgnn_window_desc* d, const float*
     return MSHGNN_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// mshgnn_step_mse_series: one training step straight from a sequence's resident raw series -- the window gather of mshgnn_assemble_windows
+// fused into the encoder (k_enc_fwd<.., SERIES>), which also writes the materialised windows for the weight-gradient kernel; labels by
+// k_window_labels.  bf16 plan with the fused stack kernels; everything after the encoder is mshgnn_step_mse.
+// ------------------------------------------------------------------------------------------------------
+__global__ void k_series_run_ptrs(const int* runs, int n_runs, WindowArgs a, unsigned long long* out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_runs) return;
+    const int sc = runs[(size_t)r * 5 + 3];
+    unsigned long long p = 0ull;
+#pragma unroll
+    for (int k = 0; k < WIN_MAX_SRC; ++k) if (sc >= 0 && (sc >> 8) == k) p = (unsigned long long)(reinterpret_cast<const __bf16*>(a.src[k]) + (size_t)(sc & 0xff) * a.src_cstride[k]);
+    out[r] = p;
+}
+
+extern "C" int mshgnn_step_mse_series(const mshgnn_plan* p, const mshgnn_window_desc* d, const float* const* src, const void* const* src_bf16,
+                                      const int64_t* src_cstride, const int64_t* src_rows, const int64_t* starts, int64_t batch,
+                                      void* const* x_out, const int64_t* x_pitch, float* y_out, float* quat_out, void* run_ptrs,
+                                      const float* params, float* out, float* loss_out, float* grad_params, void* workspace, void* stream) {
+    if (!p || !d || !src || !src_bf16 || !src_cstride || !src_rows || !starts || !x_out || !x_pitch || !y_out || !run_ptrs || !params || !out || !loss_out ||
+        !grad_params || !workspace) return set_err(MSHGNN_EINVAL, "null argument to mshgnn_step_mse_series");
+    if (batch < 1 || batch > (1 << 24)) return set_err(MSHGNN_EINVAL, "batch must be in [1, 2^24]");
+    if (p->gen || p->hp.d.dtype != MSHGNN_BF16 || !p->use_fused)
+        return set_err(MSHGNN_EUNSUPPORTED, "mshgnn_step_mse_series runs on the bf16 plan with the fused stack kernels; use mshgnn_assemble_windows + mshgnn_step_mse");
+    const mshgnn_desc& md = p->hp.d;
+    if (d->n_types != md.n_types || d->dtype != MSHGNN_BF16 || d->normalize || !d->fast_layout || d->n_src < 1 || d->n_src > WIN_MAX_SRC || d->n_runs < 1 ||
+        d->n_runs > WIN_MAX_RUNS || !d->runs || !d->rows || d->history < 1 || d->n_label < 1 || !d->label_cols || d->label_src < 0 || d->label_src >= d->n_src)
+        return set_err(MSHGNN_EINVAL, "mshgnn_step_mse_series: the window descriptor must be a bf16, fast_layout, unstandardised recipe with labels");
+    int n_rows = 0;
+    for (int t = 0; t < d->n_types; ++t) {
+        if (d->type_nodes[t] != md.type_nodes[t] || d->type_width[t] != md.type_width[t]) return set_err(MSHGNN_EINVAL, "window recipe and plan disagree on a node type");
+        if (!x_out[t] || ((uintptr_t)x_out[t] & 15) || x_pitch[t] % 8 || x_pitch[t] < (d->type_width[t] + 7) / 8 * 8) return set_err(MSHGNN_EINVAL, "bad window buffer");
+        n_rows += d->type_nodes[t];
+    }
+    if (n_rows != d->n_rows) return set_err(MSHGNN_EINVAL, "window recipe: one node row per node expected");
+    if (d->n_label != md.type_nodes[md.out_type] * md.out_channels) return set_err(MSHGNN_EINVAL, "window recipe: label count differs from the model's outputs");
+    WindowArgs wa{};
+    for (int i = 0; i < d->n_src; ++i) {
+        // (the bf16 copies need 8 elements of slack behind every column: a chunk's 16-byte load may run past the window's last step)
+        if (!src[i] || !src_bf16[i] || src_rows[i] < d->history || src_cstride[i] < src_rows[i] + 8 || src_rows[i] >= (1ll << 31)) return set_err(MSHGNN_EINVAL, "bad source array (bf16 copies need cstride >= rows + 8)");
+        wa.src[i] = reinterpret_cast<const float*>(src_bf16[i]); wa.src_cstride[i] = src_cstride[i];
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_series_run_ptrs, dim3(1), dim3(WIN_MAX_RUNS), 0, st, d->runs, d->n_runs, wa, reinterpret_cast<unsigned long long*>(run_ptrs));
+    // labels (fp32 series)
+    WindowArgs la{};
+    for (int i = 0; i < d->n_src; ++i) { la.src[i] = src[i]; la.src_cstride[i] = src_cstride[i]; }
+    la.starts = starts; la.B = batch; la.T = d->history; la.label_cols = d->label_cols; la.n_label = d->n_label; la.label_src = d->label_src;
+    la.label_rotate = d->label_rotate; la.quat_src = d->quat_src; la.y = y_out; la.quat = quat_out;
+    if (d->label_rotate && (d->n_label % 3 != 0 || d->quat_src < 0)) return set_err(MSHGNN_EINVAL, "label rotation needs 3-D labels and a quaternion source");
+    hipLaunchKernelGGL(k_window_labels, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, la);
+    SeriesSrc ser{};
+    ser.run_ptr = reinterpret_cast<const unsigned long long*>(run_ptrs); ser.rows = d->rows; ser.starts = starts; ser.T = d->history;
+    { int r0 = 0; for (int t = 0; t < d->n_types; ++t) { ser.row0[t] = r0; r0 += d->type_nodes[t]; } }
+    int rc = forward_impl<__bf16>(p, x_out, x_pitch, params, out, (char*)workspace, batch, 1, st, y_out, &ser);
+    if (rc) return rc;
+    return backward_impl<__bf16>(p, x_out, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, st, out, y_out, loss_out, nullptr, true);
+}

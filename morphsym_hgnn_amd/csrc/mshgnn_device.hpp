@@ -342,6 +342,17 @@ struct EncArgs {
     uint8_t* mask0;   // training: relu bytes of X_0 (one byte per lane, as the layer masks), read by the backward stack kernels at layer 0
 };
 
+// The encoder's inputs gathered straight from a sequence's resident raw series (bf16 copies, column-major) instead of materialised windows --
+// the fused window assembly of mshgnn_step_mse_series: feature k of node row (t, node) of window w is element starts[w] + k % T of the row's
+// run k / T (runs of one length T, or the single constant-1 run; mshgnn_window_desc.fast_layout).
+struct SeriesSrc {
+    const unsigned long long* run_ptr;   // device: per run of the window descriptor, the address of its column's element 0 (0: the constant 1)
+    const int* rows;                     // device: per node row, [first run, end run)
+    const int64_t* starts;               // device: first series row of every window
+    int row0[MSHGNN_MAX_TYPES];          // first node row of each type
+    int T;
+};
+
 // load up to EPC elements starting at p with the widest vector the alignment `vb` (bytes) allows
 template <typename T> __device__ __forceinline__ u32x4 load_chunk(const T* p, int nvalid, int vb) {
     constexpr int EPC = Prec<T>::EPC;

@@ -80,7 +80,7 @@ EXPORTS = [
     "mshgnn_profile_enable", "mshgnn_profile_read", "mshgnn_backward_mse", "mshgnn_adam_step",
     "mshgnn_metrics_regression", "mshgnn_metrics_classification", "mshgnn_grf_body_to_world", "mshgnn_assemble_windows",
     "mshgnn_backward_ce", "mshgnn_step_mse", "mshgnn_step_mse_phase",
-    "mshgnn_op_gemm", "mshgnn_op_gemm_workspace", "mshgnn_op_aggregate", "mshgnn_op_colsum", "mshgnn_op_colsum_workspace",
+    "mshgnn_step_mse_series", "mshgnn_op_gemm", "mshgnn_op_gemm_workspace", "mshgnn_op_aggregate", "mshgnn_op_colsum", "mshgnn_op_colsum_workspace",
 ]
 
 _lib = None
@@ -135,6 +135,9 @@ def load_library():
     lib.mshgnn_assemble_windows.argtypes = [C.POINTER(MshgnnWindowDesc), C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                             C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p, C.c_void_p,
                                             C.c_void_p]
+    lib.mshgnn_step_mse_series.argtypes = [C.c_void_p, C.POINTER(MshgnnWindowDesc), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+                                           C.POINTER(C.c_int64), C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.mshgnn_op_gemm_workspace.restype = C.c_int64
     lib.mshgnn_op_gemm_workspace.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int32)]
     lib.mshgnn_op_gemm.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
@@ -430,6 +433,38 @@ class Engine:
             _check(self.lib, self.lib.mshgnn_step_mse(self._plan, ptrs, pitch, params_flat.data_ptr(), y.data_ptr(), out.data_ptr(), loss.data_ptr(),
                                                   grad_flat.data_ptr(), ws.data_ptr(), B, stream), "mshgnn_step_mse")
         return out, loss, grad_flat
+
+    def step_mse_series(self, store, starts: torch.Tensor, params_flat: torch.Tensor, out: Optional[torch.Tensor] = None,
+                        grad_flat: Optional[torch.Tensor] = None, loss: Optional[torch.Tensor] = None):
+        """One training step straight from a `windows.SequenceStore` (mshgnn_step_mse_series): the window gather is fused into the encoder,
+        which also materialises the windows.  starts: device int64 window start rows.  Returns (xs, y, out, loss[1], grad_flat) -- bit-identical
+        to `store.assemble(starts)` followed by `step_mse`.  bf16 plan with the fused stack kernels."""
+        self._check_flat(params_flat, "params_flat")
+        if not starts.is_cuda or starts.dtype != torch.int64:
+            raise ValueError("starts must be a device int64 tensor")
+        B = int(starts.numel())
+        r = store.recipe
+        xs, y, q = store._buffers(B)
+        if y is None:
+            raise ValueError("the recipe has no labels")
+        if out is None:
+            out = torch.empty(B * self.n_out, self.spec.out_channels, dtype=torch.float32, device=self.device)
+        if grad_flat is None:
+            grad_flat = torch.empty(self.spec.flat_size(), dtype=torch.float32, device=self.device)
+        if loss is None:
+            loss = torch.empty(1, dtype=torch.float32, device=self.device)
+        src16, run_ptrs = store.series_step_args()
+        xp = (C.c_void_p * len(xs))(*[x.data_ptr() for x in xs])
+        pitch = (C.c_int64 * len(xs))(*[x.shape[1] for x in xs])
+        ws = self.workspace(B, True)
+        self._tickets[B] = self._tickets.get(B, 0) + 1
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.mshgnn_step_mse_series(self._plan, C.byref(store.desc), store._src, src16, store._pitch, store._rows, starts.data_ptr(), B,
+                                                         xp, pitch, y.data_ptr(), q.data_ptr() if q is not None else None, run_ptrs.data_ptr(),
+                                                         params_flat.data_ptr(), out.data_ptr(), loss.data_ptr(), grad_flat.data_ptr(), ws.data_ptr(), stream),
+                   "mshgnn_step_mse_series")
+        return xs, y, out, loss, grad_flat
 
     def step_mse_phase(self, phase: int, xs: Sequence[torch.Tensor], params_flat: torch.Tensor, y: torch.Tensor, B: int, out: torch.Tensor,
                        grad_flat: torch.Tensor, loss: torch.Tensor):

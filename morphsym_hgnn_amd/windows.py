@@ -120,11 +120,14 @@ class SequenceStore:
         self.names = recipe.series()
         self.series = []
         n_rows = None
+        self.series16 = []       # bf16 copies for the fused gather of Engine.step_mse_series (made on first use)
         for s in self.names:
             a = torch.as_tensor(np.asarray(arrays[s])).to(self.device, torch.float32)
-            a = a.reshape(a.shape[0], -1).t().contiguous()          # column-major: one window of one column is contiguous
+            a = a.reshape(a.shape[0], -1).t()                       # column-major: one window of one column is contiguous
             n_rows = a.shape[1] if n_rows is None else min(n_rows, a.shape[1])
-            self.series.append(a)
+            pad = torch.zeros(a.shape[0], a.shape[1] + 8, dtype=torch.float32, device=self.device)     # 8 elements of slack behind every column
+            pad[:, :a.shape[1]] = a                                 # (a 16-byte load of the fused gather may run past a window's last step)
+            self.series.append(pad)
         self.n_rows = int(n_rows)
         if self.n_rows < recipe.history:
             raise ValueError("sequence shorter than one window")
@@ -165,8 +168,9 @@ class SequenceStore:
         self.desc = d
         self._cache = {}
         self._src = (C.c_void_p * len(self.series))(*[a.data_ptr() for a in self.series])
-        self._pitch = (C.c_int64 * len(self.series))(*[a.shape[1] for a in self.series])     # column stride
-        self._rows = (C.c_int64 * len(self.series))(*[a.shape[1] for a in self.series])
+        self._pitch = (C.c_int64 * len(self.series))(*[a.shape[1] for a in self.series])     # column stride (rows + slack)
+        self._rows = (C.c_int64 * len(self.series))(*[a.shape[1] - 8 for a in self.series])
+        self._src16 = None; self._run_ptrs = None
 
     def __len__(self) -> int:
         """Number of windows (the reference's dataset length: rows - history + 1)."""
@@ -216,3 +220,11 @@ class SequenceStore:
                                               y.data_ptr() if y is not None else None, q.data_ptr() if q is not None else None, stream)
         eng._check(self.lib, rc, "mshgnn_assemble_windows")
         return xs, y, q
+
+    def series_step_args(self):
+        """What Engine.step_mse_series hands to mshgnn_step_mse_series: bf16 copies of the series (same strides) and the run-pointer scratch."""
+        if self._src16 is None:
+            self.series16 = [a.to(torch.bfloat16) for a in self.series]
+            self._src16 = (C.c_void_p * len(self.series16))(*[a.data_ptr() for a in self.series16])
+            self._run_ptrs = torch.zeros(max(1, int(self.desc.n_runs)), dtype=torch.int64, device=self.device)
+        return self._src16, self._run_ptrs

@@ -158,3 +158,40 @@ def test_solo_device_assembly_matches_oracle_and_feeds_the_engine(kind, history)
         out_dev = e.forward(xs, flat, B, training=False).clone()
         x_dict = {t: torch.from_numpy(np.stack([w[i] for w in want]).reshape(B * n, -1)) for i, (t, n) in enumerate((("base", nb), ("joint", 12)))}
         assert torch.equal(out_dev, e.forward(e.cast_inputs(x_dict), flat, B, training=False))
+
+
+# --- fused window assembly: the encoder gathers its inputs from the resident series (mshgnn_step_mse_series) -------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("recipe_name,B", [("a1c2", 37), ("a1c2", 1000), ("a1c2_body", 64), ("mck4", 130)])
+def test_series_step_is_bit_identical_to_assemble_then_step(recipe_name, B):
+    """One training step straight from the sequence (window gather fused into the encoder) == mshgnn_assemble_windows + mshgnn_step_mse: the
+    materialised windows, labels, outputs, loss and every gradient are the same bits (random starts incl. the first and the last window)."""
+    from morphsym_hgnn_amd import engine as eng, synth
+    from morphsym_hgnn_amd.windows import SequenceStore, quadsdk_a1_c2_recipe, minicheetah_k4_recipe
+    from tests import helpers
+    if recipe_name.startswith("a1c2"):
+        seq, n = SEQ, N
+        recipe = quadsdk_a1_c2_recipe(JP, FP, T, 3, body_frame_labels=recipe_name.endswith("body"))
+        spec = helpers.make_spec("c2", "a1-c2", "a1-c2", 128, 3)
+    else:
+        seq, n = dict(SEQ4), int(FX4["N"])
+        seq["F"] = SEQ["F"][:n, :4]                         # a regression label series for the K4 graph (4 feet x 1)
+        recipe = minicheetah_k4_recipe(JP, FP, T)
+        recipe.label_series, recipe.label_cols = "F", [0, 1, 2, 3]
+        spec = helpers.make_spec("k4", "mini_cheetah-k4", "mini_cheetah-k4", 128, 3, grf=1)
+    store = SequenceStore(seq, recipe, dtype="bf16")
+    e = eng.Engine(spec, "bf16")
+    g = torch.Generator().manual_seed(B)
+    starts = torch.randint(0, n - T + 1, (B,), generator=g)
+    starts[0], starts[-1] = 0, n - T
+    starts = starts.cuda()
+    flat = eng.flatten_params(spec, synth.make_params(8, spec.param_shapes()), e.device)
+    xs, y, _ = store.assemble(starts)
+    xs = [x.clone() for x in xs]; y = y.clone()
+    out_a, loss_a, g_a = e.step_mse(xs, flat, y.reshape(-1), B)
+    out_a, loss_a, g_a = out_a.clone(), loss_a.clone(), g_a.clone()
+    xs2, y2, out_b, loss_b, g_b = e.step_mse_series(store, starts, flat)
+    torch.cuda.synchronize()
+    for a, b in zip(xs, xs2):
+        assert torch.equal(a, b)
+    assert torch.equal(y, y2) and torch.equal(out_a, out_b) and torch.equal(loss_a, loss_b) and torch.equal(g_a, g_b)

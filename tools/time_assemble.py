@@ -17,3 +17,27 @@ for dtype in ("bf16", "f32"):
         for _ in range(50): st.assemble(starts, reuse_buffers=True)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 50
         print(f"assemble {dtype} {'chunk-gather' if fast else 'run-gather'}: {dt * 1e3:.4f} ms  ({B / dt / 1e6:.1f} M windows/s)")
+
+# end to end: assembly + step (+ the same fused into the encoder), bf16 plan, A1-C2 L=3
+import bench
+from morphsym_hgnn_amd import engine as eng, synth as _synth
+spec = bench.build_spec(3)
+e = eng.Engine(spec, "bf16")
+flat = eng.flatten_params(spec, _synth.make_params(0, spec.param_shapes()), e.device)
+st = SequenceStore(seq, quadsdk_a1_c2_recipe(jp, fp, T, 3), dtype="bf16")
+out = torch.empty(B * 4, 3, device="cuda"); gfl = torch.empty_like(flat); loss = torch.empty(1, device="cuda")
+def two():
+    xs, y, _ = st.assemble(starts, reuse_buffers=True)
+    e.step_mse(xs, flat, y.reshape(-1), B, out=out, grad_flat=gfl, loss=loss)
+def fused():
+    e.step_mse_series(st, starts, flat, out=out, grad_flat=gfl, loss=loss)
+for name, fn in (("assemble + step_mse", two), ("step_mse_series (gather fused into the encoder)", fused)):
+    for _ in range(5): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(50): fn()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 50
+    print(f"{name}: {dt * 1e3:.4f} ms/step  ({B / dt / 1e6:.1f} M windows/s)")
+e.profile(True)
+for _ in range(20): fused()
+torch.cuda.synchronize()
+print({s["name"]: round(s["total_ms"] / s["launches"] * 1e3, 1) for s in e.profile_read() if s["launches"]})
