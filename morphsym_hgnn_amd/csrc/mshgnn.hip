@@ -171,7 +171,7 @@ template <typename T, bool ALIGNED, bool SERIES = false> __global__ __launch_bou
                 *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(mi * BPP + sub, r0 + it * (256 / P::CPR), c)) = raw ^ sx;
                 if constexpr (SERIES) {      // the materialised window row (raw values: the sign mask is applied by whoever reads it)
                     const int w = w0 + (mi * BPP + sub) * P::ROWS + r0 + it * (256 / P::CPR), k0 = kc * H + c * P::EPC;
-                    if (w < a.B && k0 < (int)pitch) *reinterpret_cast<u32x4*>(const_cast<T*>(x) + ((size_t)w * nt + node) * pitch + k0) = raw;
+                    if (x != nullptr && w < a.B && k0 < (int)pitch) *reinterpret_cast<u32x4*>(const_cast<T*>(x) + ((size_t)w * nt + node) * pitch + k0) = raw;
                 }
             }
         __syncthreads();
@@ -1716,7 +1716,11 @@ template <int IPL> __global__ __launch_bounds__(256, GW_WPS) void k_gradw_bf16(G
 // stream bases and sign masks sit in a small LDS table; a step reads its three 64-bit bases from it (broadcast reads, moved to scalar
 // registers).  ALIGNED: raw inputs in the engine's own 16-byte-aligned layout; the other instantiation reads them element-wise.  Same MFMA
 // sequence as the general kernel.
-template <bool ALIGNED> __global__ __launch_bounds__(256, GW_WPS) void k_gradw_bf16_lean(GradwArgs a) {
+// SERIES (with ALIGNED): a raw Q operand is gathered from the sequence's series like the encoder's input (k_enc_fwd<.., SERIES>): element k of a
+// node row = element starts[w] + k % T of run k / T -- one unaligned 16-byte load per (window, chunk), two and a splice where the chunk straddles
+// two runs; the four window starts of a thread are fetched one step ahead.  No materialised windows are read.
+template <bool ALIGNED, bool SERIES = false> __global__ __launch_bounds__(256, GW_WPS) void k_gradw_bf16_lean(GradwArgs a) {
+    static_assert(!SERIES || ALIGNED, "the series gather replaces the aligned raw loads");
     using T = __bf16;
     __shared__ __attribute__((aligned(16))) __bf16 Ps[GWB_KW * GWB_PITCH];
     __shared__ __attribute__((aligned(16))) __bf16 Qs[GWB_KW * GWB_PITCH];
@@ -1724,6 +1728,7 @@ template <bool ALIGNED> __global__ __launch_bounds__(256, GW_WPS) void k_gradw_b
     __shared__ __attribute__((aligned(16))) u32x4 qkeep_t[16];            // raw Q: keep mask (pad columns) of column chunk c (registers are short)
     __shared__ __attribute__((aligned(16))) u32x4 qsign_t[GW_IPL][16];    // raw Q: symmetry sign XOR of (item, column chunk)
     __shared__ unsigned long long sbase[GW_IPL][4];                       // per item: stream bases of P, relu bytes, Q at the part's first window
+    __shared__ unsigned long long sser[SERIES ? GW_IPL : 1][16][2];       // SERIES, raw Q: per (item, column chunk) the run pointers (at the chunk's time offset) of its two pieces
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     mlut[tid] = chunk_mask_bits<__bf16>(u32x4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, (unsigned)tid);   // (visible after the first barrier)
     const int wr = wv >> 1, wc = wv & 1;
@@ -1760,7 +1765,16 @@ template <bool ALIGNED> __global__ __launch_bounds__(256, GW_WPS) void k_gradw_b
     if (q_raw && tid < nit * 16) {
         const int* im = a.items + (it0 + (tid >> 4)) * ITEM_INTS;
         qsign_t[tid >> 4][c] = sign_xor<T>(a.signs + im[8] + c * 8);
+        if constexpr (SERIES) {      // elements [k0, k0 + 8) of the node row: n0 from run j at time offset off, the rest from run j + 1 at offset 0
+            const int k0 = im[6] + c * 8, j = k0 / a.ser.T, off = k0 - j * a.ser.T, n0 = min(8, a.ser.T - off);
+            const int rfirst = a.ser.rows[2 * (a.ser.row0[qt] + im[5])];
+            const unsigned long long pa = qn > 0 ? a.ser.run_ptr[rfirst + j] : 0ull, pb = min(qn, 8) > n0 ? a.ser.run_ptr[rfirst + j + 1] : 0ull;
+            sser[tid >> 4][c][0] = pa ? pa + (unsigned long long)off * sizeof(T) : 0ull;
+            sser[tid >> 4][c][1] = pb;
+        }
     }
+    int s_n0 = 8; bool s_two = false;      // SERIES: this thread's chunk takes n0 elements from its first run; a second piece exists
+    if constexpr (SERIES) { if (q_raw) { const int k0 = im0[6] + c * 8, off = k0 % a.ser.T; s_n0 = min(8, a.ser.T - off); s_two = min(qn, 8) > s_n0; } }
     __syncthreads();
     const char* pS = a.ws; const char* mS = a.ws; const char* qS = a.ws;
     auto ubase = [&](int k, int j, size_t off) -> const char* {      // wave-uniform 64-bit pointer out of the LDS table
@@ -1780,11 +1794,35 @@ template <bool ALIGNED> __global__ __launch_bounds__(256, GW_WPS) void k_gradw_b
     for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
 
     u32x4 pv[4], qv[4]; unsigned mw = 0xffffffffu;
+    int nk = 0, nc = 0;            // (item, chunk of the part) of the next fetch: items interleaved chunk by chunk
+    int wst[SERIES ? 4 : 1];      // SERIES: first series row of the four windows of the NEXT fetch (loaded one step ahead)
+    auto load_starts = [&](int chunk) {
+        if constexpr (SERIES) {
+            if (q_raw) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) wst[p] = (int)a.ser.starts[min((ch0 + chunk) * GWB_KW + r4 + p, a.B - 1)];
+            }
+        }
+    };
     auto load_q = [&](int p) -> u32x4 {
+        if constexpr (SERIES) {
+            if (q_raw) {
+                const u32x4 ones = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};      // the constant-1 run (bf16 1.0)
+                const unsigned long long pa = sser[nk][c][0];
+                u32x4 va = ones;
+                if (pa) va = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(pa) + wst[p]);
+                if (s_two) {
+                    const unsigned long long pb = sser[nk][c][1];
+                    u32x4 vb2 = ones;
+                    if (pb) vb2 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(pb) + wst[p]);
+                    va = splice8(va, vb2, s_n0);
+                }
+                return va;
+            }
+        }
         if constexpr (ALIGNED) return *reinterpret_cast<const u32x4*>(qS + voffQ0 + p * qsb);
         else return q_raw ? load_chunk<T>(reinterpret_cast<const T*>(qS + voffQ0 + p * qsb), qn, qvb) : *reinterpret_cast<const u32x4*>(qS + voffQ0 + p * qsb);
     };
-    int nk = 0, nc = 0;            // (item, chunk of the part) of the next fetch: items interleaved chunk by chunk
     auto fetch = [&]() {
         pS = ubase(nk, 0, (size_t)nc * GWB_KW * H * sizeof(T));
         if (p_masked) mS = ubase(nk, 1, (size_t)nc * (GWB_KW / 16) * 64);
@@ -1810,7 +1848,7 @@ template <bool ALIGNED> __global__ __launch_bounds__(256, GW_WPS) void k_gradw_b
             mw = 0xffffffffu;
             if (p_masked && w0 + r4 < a.B) mw = *reinterpret_cast<const unsigned*>(mS + voffM);     // (the 16-window tile of row r4 exists)
         }
-        if (++nk == nit) { nk = 0; ++nc; }
+        if (++nk == nit) { nk = 0; ++nc; if (nc < nsteps) load_starts(nc); }      // (the next chunk's window starts: used by the fetch after this one)
     };
     int sk = 0;                    // item of the step being staged
     auto stage_to_lds = [&]() {
@@ -1838,7 +1876,7 @@ template <bool ALIGNED> __global__ __launch_bounds__(256, GW_WPS) void k_gradw_b
             }
         }
     };
-    if (total > 0) fetch();
+    if (total > 0) { load_starts(0); fetch(); }
     for (int s = 0; s < total; ++s) {
         __syncthreads();             // every wave is done with the previous step's tiles
         stage_to_lds();
@@ -2139,9 +2177,9 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
         a.n_types = hp.NT; a.B = B; a.NN = hp.NN; a.tiles = (B + Prec<T>::ENC_MB * Prec<T>::ROWS - 1) / (Prec<T>::ENC_MB * Prec<T>::ROWS);
         a.wg_prefix[0] = 0;
         for (int t = 0; t < hp.NT; ++t) {
-            a.x[t] = x[t]; a.pitch[t] = x_pitch ? x_pitch[t] : d.type_width[t];
+            a.x[t] = x ? x[t] : nullptr; a.pitch[t] = x_pitch ? x_pitch[t] : d.type_width[t];
             if (a.pitch[t] < d.type_width[t]) return set_err(MSHGNN_EINVAL, "x_pitch smaller than the feature width");
-            a.vb[t] = vec_bytes(x[t], a.pitch[t], (int)sizeof(T));
+            a.vb[t] = vec_bytes(a.x[t], a.pitch[t], (int)sizeof(T));
             if (t == 0) a.aligned = 1;
             if (a.vb[t] != 16 || a.pitch[t] % Prec<T>::EPC) a.aligned = 0;
             a.width[t] = d.type_width[t]; a.nodes[t] = d.type_nodes[t]; a.tbase[t] = hp.type_base[t]; a.nkc[t] = hp.enc_nkc[t];
@@ -2153,7 +2191,7 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
         ProfScope ps(p, hp.ks_enc, st);
         if constexpr (sizeof(T) == 2) {
             if (series) {
-                if (!a.aligned) return set_err(MSHGNN_EINVAL, "the fused window assembly needs 16-byte aligned window rows (pitch a multiple of 8)");
+                if (x && !a.aligned) return set_err(MSHGNN_EINVAL, "the fused window assembly needs 16-byte aligned window rows (pitch a multiple of 8)");
                 hipLaunchKernelGGL((k_enc_fwd<T, true, true>), dim3(a.wg_prefix[hp.NT]), dim3(256), Prec<T>::ENC_MB * Prec<T>::BLK, st, a, *series);
             } else if (a.aligned) hipLaunchKernelGGL((k_enc_fwd<T, true>), dim3(a.wg_prefix[hp.NT]), dim3(256), Prec<T>::ENC_MB * Prec<T>::BLK, st, a, SeriesSrc{});
             else hipLaunchKernelGGL((k_enc_fwd<T, false>), dim3(a.wg_prefix[hp.NT]), dim3(256), Prec<T>::ENC_MB * Prec<T>::BLK, st, a, SeriesSrc{});
@@ -2215,7 +2253,7 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
 template <typename T>
 static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, const float* gout,
                          float* gparams, char* ws, int64_t batch, hipStream_t st, const float* out = nullptr, const float* y = nullptr,
-                         float* loss = nullptr, const int32_t* labels = nullptr, bool dec_done = false, int gw_phase = -1) {
+                         float* loss = nullptr, const int32_t* labels = nullptr, bool dec_done = false, int gw_phase = -1, const SeriesSrc* series = nullptr) {
     // gw_phase: -1 = everything; 0 = backward sweep + the weight gradients of every parameter but the encoder's; 1 = only the
     // encoder's weight gradients (the sweep of phase 0 left dX_0 in the workspace)
     const HostPlan& hp = p->hp;
@@ -2275,11 +2313,12 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
         for (int l = 0; l < hp.L; ++l) a.buf_off[BUF_MASK + l] = lay.mask[l];
         for (int l = 0; l < hp.L; ++l) { a.buf_off[BUF_DH + l] = lay.dh[l]; a.buf_off[BUF_HB + l] = lay.hb[l]; a.buf_off[BUF_T1 + l] = lay.t1[l]; a.buf_off[BUF_DU + l] = lay.du[l]; }
         for (int t = 0; t < hp.NT; ++t) {
-            a.x[t] = x[t]; a.pitch[t] = x_pitch ? x_pitch[t] : d.type_width[t]; a.nodes[t] = d.type_nodes[t];
-            a.vb[t] = vec_bytes(x[t], a.pitch[t], (int)sizeof(T));
+            a.x[t] = x ? x[t] : nullptr; a.pitch[t] = x_pitch ? x_pitch[t] : d.type_width[t]; a.nodes[t] = d.type_nodes[t];
+            a.vb[t] = vec_bytes(a.x[t], a.pitch[t], (int)sizeof(T));
             if (t == 0) a.aligned = 1;
             if (a.vb[t] != 16 || a.pitch[t] % Prec<T>::EPC) a.aligned = 0;
         }
+        if (series) a.ser = *series;
         a.items = p->d_tables + hp.item_off; a.lanes = p->d_tables + hp.lane_off; a.lane_order = p->d_tables + hp.lane_order_off; a.n_pad = hp.n_lanes_pad;
         if (gw_phase >= 0) { a.lane_order = p->d_tables + hp.order_ph_off[gw_phase]; a.n_pad = hp.npad_ph[gw_phase]; }
         a.signs = p->d_signs; a.slabs = reinterpret_cast<float*>(ws + lay.slabs); a.B = B; a.n_lanes = hp.n_lanes; a.n_parts = hp.n_parts;
@@ -2291,6 +2330,7 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
             if constexpr (sizeof(T) == 4) hipLaunchKernelGGL(k_gradw_f32, dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a);
             else if (gw_general && hp.gw_ipl == 1) hipLaunchKernelGGL(k_gradw_bf16<1>, dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a);
             else if (gw_general && hp.gw_ipl == 2) hipLaunchKernelGGL(k_gradw_bf16<2>, dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a);
+            else if (series) hipLaunchKernelGGL((k_gradw_bf16_lean<true, true>), dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a);      // raw operands from the series
             else if (a.aligned) hipLaunchKernelGGL(k_gradw_bf16_lean<true>, dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a);
             else hipLaunchKernelGGL(k_gradw_bf16_lean<false>, dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a);
         }
@@ -2839,8 +2879,8 @@ extern "C" int mshgnn_step_mse_series(const mshgnn_plan* p, const mshgnn_window_
                                       const int64_t* src_cstride, const int64_t* src_rows, const int64_t* starts, int64_t batch,
                                       void* const* x_out, const int64_t* x_pitch, float* y_out, float* quat_out, void* run_ptrs,
                                       const float* params, float* out, float* loss_out, float* grad_params, void* workspace, void* stream) {
-    if (!p || !d || !src || !src_bf16 || !src_cstride || !src_rows || !starts || !x_out || !x_pitch || !y_out || !run_ptrs || !params || !out || !loss_out ||
-        !grad_params || !workspace) return set_err(MSHGNN_EINVAL, "null argument to mshgnn_step_mse_series");
+    if (!p || !d || !src || !src_bf16 || !src_cstride || !src_rows || !starts || !y_out || !run_ptrs || !params || !out || !loss_out ||
+        !grad_params || !workspace || (x_out && !x_pitch)) return set_err(MSHGNN_EINVAL, "null argument to mshgnn_step_mse_series");
     if (batch < 1 || batch > (1 << 24)) return set_err(MSHGNN_EINVAL, "batch must be in [1, 2^24]");
     if (p->gen || p->hp.d.dtype != MSHGNN_BF16 || !p->use_fused)
         return set_err(MSHGNN_EUNSUPPORTED, "mshgnn_step_mse_series runs on the bf16 plan with the fused stack kernels; use mshgnn_assemble_windows + mshgnn_step_mse");
@@ -2851,7 +2891,7 @@ extern "C" int mshgnn_step_mse_series(const mshgnn_plan* p, const mshgnn_window_
     int n_rows = 0;
     for (int t = 0; t < d->n_types; ++t) {
         if (d->type_nodes[t] != md.type_nodes[t] || d->type_width[t] != md.type_width[t]) return set_err(MSHGNN_EINVAL, "window recipe and plan disagree on a node type");
-        if (!x_out[t] || ((uintptr_t)x_out[t] & 15) || x_pitch[t] % 8 || x_pitch[t] < (d->type_width[t] + 7) / 8 * 8) return set_err(MSHGNN_EINVAL, "bad window buffer");
+        if (x_out && (!x_out[t] || ((uintptr_t)x_out[t] & 15) || x_pitch[t] % 8 || x_pitch[t] < (d->type_width[t] + 7) / 8 * 8)) return set_err(MSHGNN_EINVAL, "bad window buffer");
         n_rows += d->type_nodes[t];
     }
     if (n_rows != d->n_rows) return set_err(MSHGNN_EINVAL, "window recipe: one node row per node expected");
@@ -2876,5 +2916,7 @@ extern "C" int mshgnn_step_mse_series(const mshgnn_plan* p, const mshgnn_window_
     { int r0 = 0; for (int t = 0; t < d->n_types; ++t) { ser.row0[t] = r0; r0 += d->type_nodes[t]; } }
     int rc = forward_impl<__bf16>(p, x_out, x_pitch, params, out, (char*)workspace, batch, 1, st, y_out, &ser);
     if (rc) return rc;
-    return backward_impl<__bf16>(p, x_out, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, st, out, y_out, loss_out, nullptr, true);
+    // x_out == NULL: no materialised windows at all -- the weight-gradient kernel gathers its raw-input operands from the series as well
+    return backward_impl<__bf16>(p, x_out, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, st, out, y_out, loss_out, nullptr, true, -1,
+                                 x_out ? nullptr : &ser);
 }

@@ -749,6 +749,7 @@ struct GradwArgs {
     int aligned;   // all raw-input rows 16-byte aligned with whole-chunk pitch
     int dbg;   // timing ablations (MSHGNN_DBG_GW): 1 no global loads, 2 no LDS staging, 4 no MFMA phase, 8 no slab store
     long long* stamps;   // MSHGNN_STAMPS_GW: thread 0 of every workgroup accumulates clock64() deltas of the step phases
+    SeriesSrc ser;       // raw-input operands gathered from the sequence's series (mshgnn_step_mse_series without materialised windows)
 };
 
 // bf16: P/Q staged row-major ([window][feature], pitch 160 elements = 320 B: 4 consecutive windows land on

@@ -435,10 +435,13 @@ class Engine:
         return out, loss, grad_flat
 
     def step_mse_series(self, store, starts: torch.Tensor, params_flat: torch.Tensor, out: Optional[torch.Tensor] = None,
-                        grad_flat: Optional[torch.Tensor] = None, loss: Optional[torch.Tensor] = None):
-        """One training step straight from a `windows.SequenceStore` (mshgnn_step_mse_series): the window gather is fused into the encoder,
-        which also materialises the windows.  starts: device int64 window start rows.  Returns (xs, y, out, loss[1], grad_flat) -- bit-identical
-        to `store.assemble(starts)` followed by `step_mse`.  bf16 plan with the fused stack kernels."""
+                        grad_flat: Optional[torch.Tensor] = None, loss: Optional[torch.Tensor] = None, materialize: bool = True):
+        """One training step straight from a `windows.SequenceStore` (mshgnn_step_mse_series): the encoder gathers its raw inputs from the
+        sequence's resident series and (materialize=True, the fast route) writes the batch's windows on the side for the weight-gradient pass;
+        materialize=False keeps no windows at all -- the weight-gradient kernel gathers from the series too (same bits, no 118 MB buffer, but
+        measured slower: its random 256-byte gathers stretch the raw-input lanes' steps, 0.385 vs 0.557 ms/step).  starts: device int64 window
+        start rows.  Returns (xs | None, y, out, loss[1], grad_flat) -- bit-identical to `store.assemble(starts)` followed by `step_mse`.
+        bf16 plan with the fused stack kernels."""
         self._check_flat(params_flat, "params_flat")
         if not starts.is_cuda or starts.dtype != torch.int64:
             raise ValueError("starts must be a device int64 tensor")
@@ -454,8 +457,10 @@ class Engine:
         if loss is None:
             loss = torch.empty(1, dtype=torch.float32, device=self.device)
         src16, run_ptrs = store.series_step_args()
-        xp = (C.c_void_p * len(xs))(*[x.data_ptr() for x in xs])
-        pitch = (C.c_int64 * len(xs))(*[x.shape[1] for x in xs])
+        xp = (C.c_void_p * len(xs))(*[x.data_ptr() for x in xs]) if materialize else None
+        pitch = (C.c_int64 * len(xs))(*[x.shape[1] for x in xs]) if materialize else None
+        if not materialize:
+            xs = None
         ws = self.workspace(B, True)
         self._tickets[B] = self._tickets.get(B, 0) + 1
         stream = torch.cuda.current_stream(self.device).cuda_stream

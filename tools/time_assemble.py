@@ -30,14 +30,16 @@ def two():
     xs, y, _ = st.assemble(starts, reuse_buffers=True)
     e.step_mse(xs, flat, y.reshape(-1), B, out=out, grad_flat=gfl, loss=loss)
 def fused():
-    e.step_mse_series(st, starts, flat, out=out, grad_flat=gfl, loss=loss)
-for name, fn in (("assemble + step_mse", two), ("step_mse_series (gather fused into the encoder)", fused)):
+    e.step_mse_series(st, starts, flat, out=out, grad_flat=gfl, loss=loss, materialize=True)
+def fused2():
+    e.step_mse_series(st, starts, flat, out=out, grad_flat=gfl, loss=loss, materialize=False)
+for name, fn in (("assemble + step_mse", two), ("step_mse_series, windows materialised by the encoder", fused), ("step_mse_series, no materialised windows", fused2)):
     for _ in range(5): fn()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(50): fn()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 50
     print(f"{name}: {dt * 1e3:.4f} ms/step  ({B / dt / 1e6:.1f} M windows/s)")
 e.profile(True)
-for _ in range(20): fused()
+for _ in range(20): fused2()
 torch.cuda.synchronize()
 print({s["name"]: round(s["total_ms"] / s["launches"] * 1e3, 1) for s in e.profile_read() if s["launches"]})
