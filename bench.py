@@ -205,14 +205,17 @@ class Workload:
         self.loss = torch.empty(1, dtype=torch.float32, device=device)
         split = int(self.e.info.grad_split)
         world = dist.get_world_size() if dist is not None else 1
-        # Two-phase step (--overlap 1): the all-reduce of everything but the encoder's gradients (83 % of the buffer) runs under the
-        # encoder's weight-gradient launch.  OFF unless asked for: measured on one GPU with a 1-rank RCCL group (no wire time) the split
+        # Two-phase step (--overlap 1; --overlap auto, the default, measures both on the machine it runs on when there is more than one rank and
+        # keeps the faster: calibrate_overlap): the all-reduce of everything but the encoder's gradients (83 % of the buffer) runs under the
+        # encoder's weight-gradient launch.  Measured on one GPU with a 1-rank RCCL group (no wire time) the split
         # costs +51 us per step (two weight-gradient launches that each fill the chip less well, two finalize launches, two stream
         # hand-offs; +126 us when each phase gets its own window-part count: more slabs to write and sum), while an 8-GPU all-reduce of
         # 3.3 MB is ~60-90 us of which at most the ~45 us of the encoder's weight gradients can be hidden -- the plain sequence
         # "step, then one mean all-reduce of the 4 MB flat gradient" is at least as fast at this gradient size.
-        self.overlap = dist is not None and split > 0 and spec.regression and overlap == "1"
+        self.can_overlap = dist is not None and split > 0 and spec.regression
+        self.overlap = self.can_overlap and overlap == "1"
         self.split = split
+        self.overlap_choice = None
 
     def step(self):
         e, dist = self.e, self.dist
@@ -240,6 +243,27 @@ class Workload:
     def barrier(self):
         if self.dist is not None:
             self.dist.barrier()
+
+    def calibrate_overlap(self, steps=20, warmup=3):
+        """--overlap auto with more than one rank: time the plain sequence (step, then ONE all-reduce of the flat gradient) and the two-phase step
+        (all-reduce of everything but the encoder's gradients under the encoder's weight-gradient launch) on THIS machine -- MAX over ranks, so every
+        rank takes the same decision -- and keep the faster.  What an 8-GPU node's all-reduce costs is not something a 1-GPU box can tell."""
+        torch, dist = self.torch, self.dist
+        ms = {}
+        for mode in (False, True):
+            self.overlap = mode
+            for _ in range(warmup):
+                self.step()
+            torch.cuda.synchronize(); self.barrier(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.step()
+            torch.cuda.synchronize(); self.barrier(); torch.cuda.synchronize()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=self.e.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ms[mode] = float(t[0]) / steps * 1e3
+        self.overlap = ms[True] < ms[False]
+        self.overlap_choice = {"mode": "auto", "two_phase": bool(self.overlap), "ms_plain": ms[False], "ms_two_phase": ms[True]}
 
     def time_blocks(self, steps, warmup, min_time, max_blocks=200):
         """-> (median seconds per K-step block, list of all block times), MAX over ranks per block."""
@@ -395,6 +419,8 @@ def main():
     B, L, hidden = defaults(args)
     spec = build_spec(L, args.config, hidden)
     wl = Workload(spec, args.dtype, B, device, 1234 + rank, dist, args.overlap)
+    if args.overlap == "auto" and wl.can_overlap and (world > 1 or os.environ.get("MSHGNN_BENCH_FORCE_DIST") == "1"):
+        wl.calibrate_overlap()
     med, blocks = wl.time_blocks(args.steps, args.warmup, args.min_time)
     value = world * B * args.steps / med
     loss = float(wl.loss.item())
@@ -465,6 +491,7 @@ def main():
                    "global_batch": B * world, "parallelism": f"dp{world}", "rccl_ranks": (dist.get_world_size() if dist is not None else 0)},
         "timing": {"blocks": len(blocks), "block_steps": args.steps, "median_ms": med * 1e3, "min_ms": min(blocks) * 1e3, "max_ms": max(blocks) * 1e3,
                    "timed_s": sum(blocks)},
+        "overlap": wl.overlap_choice or {"mode": args.overlap, "two_phase": bool(wl.overlap)},
         "roofline": roof, "kernel_us": kernels,
         "algorithmic_flops_per_window": wl.e.info.flops_fwd + wl.e.info.flops_bwd,
         "loss": loss,

@@ -39,6 +39,15 @@ for name, fn in (("assemble + step_mse", two), ("step_mse_series, windows materi
     for _ in range(50): fn()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 50
     print(f"{name}: {dt * 1e3:.4f} ms/step  ({B / dt / 1e6:.1f} M windows/s)")
+# the same with the batch's window starts SORTED (an SGD minibatch is a set: the caller may order it): neighbouring windows overlap, so the gathers
+# of neighbouring rows walk the same cache lines
+starts = torch.sort(starts).values
+for name, fn in (("sorted starts: assemble + step_mse", two), ("sorted starts: step_mse_series, windows materialised", fused), ("sorted starts: step_mse_series, no materialised windows", fused2)):
+    for _ in range(5): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(50): fn()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 50
+    print(f"{name}: {dt * 1e3:.4f} ms/step  ({B / dt / 1e6:.1f} M windows/s)")
 e.profile(True)
 for _ in range(20): fused2()
 torch.cuda.synchronize()
