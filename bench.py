@@ -219,9 +219,8 @@ class Workload:
 
     def step(self):
         e, dist = self.e, self.dist
-        if not self.spec.regression:      # classification wrapper: forward + fused cross entropy backward
-            e.forward(self.xs, self.flat, self.B, training=True, out=self.out)
-            e.backward_ce(self.xs, self.flat, self.out, self.y, self.B, grad_flat=self.gflat, loss=self.loss)
+        if not self.spec.regression:      # classification wrapper: forward + cross entropy + backward in one call (mshgnn_step_ce)
+            e.step_ce(self.xs, self.flat, self.y, self.B, out=self.out, grad_flat=self.gflat, loss=self.loss)
             if dist is not None:
                 dist.all_reduce(self.gflat, op=dist.ReduceOp.AVG)
             return self.loss

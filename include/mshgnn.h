@@ -182,6 +182,12 @@ int mshgnn_backward_mse(const mshgnn_plan* plan, const void* const* x, const int
 int mshgnn_step_mse(const mshgnn_plan* plan, const void* const* x, const int64_t* x_pitch, const float* params, const float* y,
                     float* out, float* loss_out, float* grad_params, void* workspace, int64_t batch, void* stream);
 
+/* One whole training_step of the classification wrappers (forward + CrossEntropyLoss over the per-foot logit pairs + loss.backward(),
+ * gnnLightning.py:640-648, 680-722) in one call: on the bf16 plan the decoder, the cross entropy and the decoder backward run in the tail of the
+ * fused forward kernel (== mshgnn_forward followed by mshgnn_backward_ce, which the other plans run).  labels: device int32 [batch][n_out] in {0, 1}. */
+int mshgnn_step_ce(const mshgnn_plan* plan, const void* const* x, const int64_t* x_pitch, const float* params, const int32_t* labels,
+                   float* out, float* loss_out, float* grad_params, void* workspace, int64_t batch, void* stream);
+
 /* The same step in two calls, for overlapping the gradient all-reduce with compute on several GPUs: phase 0 runs the forward,
  * the loss, the backward sweep and every weight gradient except the encoder's -- grad_params[grad_split, n_flat) and
  * loss_out are final when it completes; phase 1 finishes the encoder's gradients, grad_params[0, grad_split).  A caller

@@ -2159,7 +2159,8 @@ int run_finalize(const mshgnn_plan* p, const mshgnn_ws_layout& lay, char* ws, fl
 
 template <typename T>
 static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, float* out,
-                        char* ws, int64_t batch, int training, hipStream_t st, const float* y_fused = nullptr, const SeriesSrc* series = nullptr) {
+                        char* ws, int64_t batch, int training, hipStream_t st, const float* y_fused = nullptr, const SeriesSrc* series = nullptr,
+                        const int32_t* labels_fused = nullptr) {
     const HostPlan& hp = p->hp;
     const mshgnn_desc& d = hp.d;
     mshgnn_ws_layout lay; layout_workspace(hp, batch, training, &lay);
@@ -2216,6 +2217,9 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
             if (y_fused) {
                 a.y = y_fused; a.dec_slabs = reinterpret_cast<float*>(ws + lay.dec_slabs); a.dx_off[hp.L] = lay.dx[hp.L];
                 a.inv_n = 1.0f / (float)((int64_t)B * a.n_out * a.dout);
+            } else if (labels_fused) {      // mshgnn_step_ce: cross entropy over the per-foot logit pairs, mean over B * n_out rows
+                a.labels = labels_fused; a.dec_slabs = reinterpret_cast<float*>(ws + lay.dec_slabs); a.dx_off[hp.L] = lay.dx[hp.L];
+                a.inv_n = 1.0f / (float)((int64_t)B * a.n_out);
             }
             a.stamps = stamp_ptr("MSHGNN_STAMPS");
             ProfScope ps(p, hp.ks_stack_fwd, st);
@@ -2395,6 +2399,25 @@ extern "C" int mshgnn_step_mse(const mshgnn_plan* p, const void* const* x, const
     int rc = forward_impl<__bf16>(p, x, x_pitch, params, out, (char*)workspace, batch, 1, st, y);
     if (rc) return rc;
     return backward_impl<__bf16>(p, x, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, st, out, y, loss_out, nullptr, true);
+}
+
+extern "C" int mshgnn_step_ce(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, const int32_t* labels,
+                              float* out, float* loss_out, float* grad_params, void* workspace, int64_t batch, void* stream) {
+    if (!p || !x || !params || !labels || !out || !loss_out || !grad_params || !workspace) return set_err(MSHGNN_EINVAL, "null argument to mshgnn_step_ce");
+    if (batch < 1 || batch > (1 << 24)) return set_err(MSHGNN_EINVAL, "batch must be in [1, 2^24]");
+    for (int t = 0; t < p->n_types; ++t) if (!x[t]) return set_err(MSHGNN_EINVAL, "null input tensor");
+    if (p->hp.d.out_channels != 2) return set_err(MSHGNN_EINVAL, "mshgnn_step_ce: the classification wrappers have two logits per foot");
+    hipStream_t st = (hipStream_t)stream;
+    // bf16 plan with the fused stack kernels: decoder, cross entropy and decoder backward in the tail of the forward kernel; every other plan: the
+    // two-call sequence (mshgnn_forward + mshgnn_backward_ce)
+    if (!p->gen && p->hp.d.dtype == MSHGNN_BF16 && p->use_fused) {
+        int rc = forward_impl<__bf16>(p, x, x_pitch, params, out, (char*)workspace, batch, 1, st, nullptr, nullptr, labels);
+        if (rc) return rc;
+        return backward_impl<__bf16>(p, x, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, st, out, nullptr, loss_out, labels, true);
+    }
+    int rc = mshgnn_forward(p, x, x_pitch, params, out, workspace, batch, 1, stream);
+    if (rc) return rc;
+    return mshgnn_backward_ce(p, x, x_pitch, params, out, labels, loss_out, grad_params, workspace, batch, stream);
 }
 
 extern "C" int mshgnn_step_mse_phase(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, const float* y,

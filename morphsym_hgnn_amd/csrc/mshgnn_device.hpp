@@ -480,6 +480,7 @@ struct StackArgs {
     const float* params; const float* out_mask; float* out; int64_t off_dec_w, off_dec_b; int node0, n_out, dout;   // fused decoder (fwd)
     // mshgnn_step_mse: the forward also takes the wrapper MSE and the decoder backward (dX_L rows, decoder partial gradients, loss partial)
     const float* y; float* dec_slabs; float inv_n;
+    const int32_t* labels;   // mshgnn_step_ce: the classification wrappers' cross entropy instead of the MSE (labels [B][n_out] in {0, 1}, two logits per foot)
     size_t mask0_off;    // bwd: relu bytes of the encoder activation X_0 in the workspace (0: not available, X_0 rows are read)
     long long* stamps;   // timing experiments (MSHGNN_STAMPS): wave 0 of every workgroup records clock64() at phase boundaries
     // split plan: LDS block of the lo half of node n = lo_blk + n; the lo image of pack i is pack n_img + i
@@ -604,7 +605,7 @@ __device__ __forceinline__ void decoder_tail_impl(const StackArgs& a, char* smem
     {
         const int c = tid & 15, row = (tid >> 4) & 15;
         const float* W = a.params + a.off_dec_w;
-        const bool fuse = a.y != nullptr;
+        const bool ce = a.labels != nullptr, fuse = a.y != nullptr || ce;      // ce: cross entropy over the two logits of a foot (gnnLightning.py:640-648)
         T* dxl = reinterpret_cast<T*>(a.ws + a.dx_off[a.L]);
         float accw[DMAX][8], accb[DMAX], lsum = 0.f;
         if (fuse) {
@@ -626,16 +627,17 @@ __device__ __forceinline__ void decoder_tail_impl(const StackArgs& a, char* smem
             bv[dd] = a.params[a.off_dec_b + dc];
         }
         for (int f0 = tid >> 8; f0 < a.n_out; f0 += 2 * (THREADS / 256)) {
-            float ov[2][DMAX], dxv[2][8], mk[2][DMAX], yv[2][DMAX];
+            float ov[2][DMAX], dxv[2][8], mk[2][DMAX], yv[2][DMAX]; int labv[2] = {0, 0};
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int f = min(f0 + i * (THREADS / 256), a.n_out - 1);
                 const size_t r = (size_t)min(w0 + row, B - 1) * a.n_out + f;
+                if (ce) labv[i] = a.labels[r] != 0;
 #pragma unroll
                 for (int dd = 0; dd < DMAX; ++dd) {
                     const int dc = min(dd, a.dout - 1);
                     mk[i][dd] = a.out_mask[f * a.dout + dc];
-                    yv[i][dd] = fuse ? a.y[r * a.dout + dc] : 0.f;
+                    yv[i][dd] = a.y ? a.y[r * a.dout + dc] : 0.f;
                 }
             }
 #pragma unroll
@@ -661,12 +663,27 @@ __device__ __forceinline__ void decoder_tail_impl(const StackArgs& a, char* smem
 #pragma unroll
                         for (int e = 0; e < 8; ++e) sum += x[e] * Wv[dd][e];
                         sum = row16_sum(sum);
-                        const float o = (sum + bv[dd]) * mk[i][dd];
-                        ov[i][dd] = o;
-                        if (fuse && ok) {
-                            const float dlt = o - yv[i][dd];
-                            const float g = 2.0f * dlt * a.inv_n * mk[i][dd];
-                            if (c == 0) lsum += dlt * dlt;
+                        ov[i][dd] = (sum + bv[dd]) * mk[i][dd];
+                    }
+                }
+                if (fuse && ok) {
+                    float ce_g[2] = {0.f, 0.f};
+                    if (ce) {      // dL/dlogit = (softmax - onehot) / rows, the arithmetic of k_dec_bwd
+                        const float l0 = ov[i][0], l1 = ov[i][1];
+                        const float m = fmaxf(l0, l1), e0 = expf(l0 - m), e1 = expf(l1 - m), se = e0 + e1;
+                        ce_g[0] = (e0 / se - (labv[i] ? 0.f : 1.f)) * a.inv_n; ce_g[1] = (e1 / se - (labv[i] ? 1.f : 0.f)) * a.inv_n;
+                        if (c == 0) lsum += (m + logf(se)) - (labv[i] ? l1 : l0);
+                    }
+#pragma unroll
+                    for (int dd = 0; dd < DMAX; ++dd) {
+                        if (dd < a.dout) {
+                            float g;
+                            if (ce) g = ce_g[dd & 1] * mk[i][dd];
+                            else {
+                                const float dlt = ov[i][dd] - yv[i][dd];
+                                g = 2.0f * dlt * a.inv_n * mk[i][dd];
+                                if (c == 0) lsum += dlt * dlt;
+                            }
                             accb[dd] += g;
 #pragma unroll
                             for (int e = 0; e < 8; ++e) { accw[dd][e] += g * x[e]; dxv[i][e] += g * Wv[dd][e]; }

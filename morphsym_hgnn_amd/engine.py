@@ -80,7 +80,7 @@ EXPORTS = [
     "mshgnn_profile_enable", "mshgnn_profile_read", "mshgnn_backward_mse", "mshgnn_adam_step",
     "mshgnn_metrics_regression", "mshgnn_metrics_classification", "mshgnn_grf_body_to_world", "mshgnn_assemble_windows",
     "mshgnn_backward_ce", "mshgnn_step_mse", "mshgnn_step_mse_phase",
-    "mshgnn_step_mse_series", "mshgnn_op_gemm", "mshgnn_op_gemm_workspace", "mshgnn_op_aggregate", "mshgnn_op_colsum", "mshgnn_op_colsum_workspace",
+    "mshgnn_step_mse_series", "mshgnn_step_ce", "mshgnn_op_gemm", "mshgnn_op_gemm_workspace", "mshgnn_op_aggregate", "mshgnn_op_colsum", "mshgnn_op_colsum_workspace",
 ]
 
 _lib = None
@@ -122,6 +122,8 @@ def load_library():
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.mshgnn_step_mse.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.mshgnn_step_ce.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.mshgnn_step_mse_phase.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
     lib.mshgnn_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_float, C.c_float,
@@ -432,6 +434,28 @@ class Engine:
         with torch.cuda.device(self.device):
             _check(self.lib, self.lib.mshgnn_step_mse(self._plan, ptrs, pitch, params_flat.data_ptr(), y.data_ptr(), out.data_ptr(), loss.data_ptr(),
                                                   grad_flat.data_ptr(), ws.data_ptr(), B, stream), "mshgnn_step_mse")
+        return out, loss, grad_flat
+
+    def step_ce(self, xs: Sequence[torch.Tensor], params_flat: torch.Tensor, labels: torch.Tensor, B: int, out: Optional[torch.Tensor] = None,
+                grad_flat: Optional[torch.Tensor] = None, loss: Optional[torch.Tensor] = None):
+        """One training step of the classification wrappers in one call (forward + cross entropy + backward, mshgnn_step_ce):
+        returns (out, loss[1], grad_flat).  labels: int32 [B, n_out] in {0, 1}."""
+        self._check_flat(params_flat, "params_flat")
+        ptrs, pitch = self._xptrs(xs, B)
+        if labels.dtype != torch.int32 or labels.numel() != B * self.n_out or not labels.is_contiguous():
+            raise ValueError("labels must be contiguous int32 with B*n_out elements")
+        if out is None:
+            out = torch.empty(B * self.n_out, self.spec.out_channels, dtype=torch.float32, device=self.device)
+        if grad_flat is None:
+            grad_flat = torch.empty(self.spec.flat_size(), dtype=torch.float32, device=self.device)
+        if loss is None:
+            loss = torch.empty(1, dtype=torch.float32, device=self.device)
+        ws = self.workspace(B, True)
+        self._tickets[B] = self._tickets.get(B, 0) + 1
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.mshgnn_step_ce(self._plan, ptrs, pitch, params_flat.data_ptr(), labels.data_ptr(), out.data_ptr(), loss.data_ptr(),
+                                                 grad_flat.data_ptr(), ws.data_ptr(), B, stream), "mshgnn_step_ce")
         return out, loss, grad_flat
 
     def step_mse_series(self, store, starts: torch.Tensor, params_flat: torch.Tensor, out: Optional[torch.Tensor] = None,

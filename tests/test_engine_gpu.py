@@ -408,3 +408,29 @@ def test_bf16_unaligned_inputs_take_the_element_wise_loaders(kind, topo, cfg, L)
     o2, l2, g2 = e.step_mse(e.cast_inputs(x_dict, pad=False), flat, yd, B)
     torch.cuda.synchronize()
     assert torch.equal(o1, o2) and torch.equal(g1, g2)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "x3", "f32"])
+@pytest.mark.parametrize("kind,topo,cfg,B", [("k4", "mini_cheetah-k4", "mini_cheetah-k4", 8192), ("k4", "mini_cheetah-k4", "mini_cheetah-k4", 333),
+                                             ("c2", "mini_cheetah-c2", "mini_cheetah-c2", 77)])
+def test_one_call_classification_step_equals_forward_plus_backward_ce(kind, topo, cfg, B, dtype):
+    """mshgnn_step_ce (bf16 plan: decoder + cross entropy + decoder backward in the tail of the fused forward kernel) == mshgnn_forward
+    followed by mshgnn_backward_ce: same logits bits, loss and gradients up to fp32 summation order."""
+    _require_gpu()
+    from morphsym_hgnn_amd import engine as eng, synth
+    if dtype != "bf16" and B > 1000:
+        pytest.skip("the full-size batch exercises the slab kernels of the bf16 plan")
+    spec = helpers.make_spec(kind, topo, cfg, 128, 3, regression=False)
+    e = eng.Engine(spec, dtype)
+    x_dict, y = synth.make_windows(31, B, spec.num_nodes, spec.widths, 4, classification=True)
+    xs = e.cast_inputs(x_dict)
+    lab = y.reshape(B, -1).to(e.device, torch.int32).contiguous()
+    flat = eng.flatten_params(spec, synth.make_params(31, spec.param_shapes()), e.device)
+    out_a = e.forward(xs, flat, B).clone()
+    loss_a, g_a = e.backward_ce(xs, flat, out_a, lab, B)
+    loss_a, g_a = loss_a.clone(), g_a.clone()
+    out_b, loss_b, g_b = e.step_ce(xs, flat, lab, B)
+    torch.cuda.synchronize()
+    assert torch.equal(out_a, out_b)
+    assert abs(float(loss_a) - float(loss_b)) <= 1e-6 * abs(float(loss_a))
+    assert float((g_a - g_b).abs().max()) <= 2e-6 * float(g_a.abs().max())
