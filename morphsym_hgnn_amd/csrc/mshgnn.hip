@@ -112,7 +112,7 @@ template <typename T, bool ALIGNED, bool SERIES = false> __global__ __launch_bou
     typename P::BFrag bf;
     typename P::AFrag af;
     const AOff<T> ao(lane);      // fragment offsets once per kernel (the generic load_afrag rebuilds them per call: 14 VALU instructions)
-    using VBuf = u32x4[MB / BPP][NIT];
+    u32x4 v[MB / BPP][NIT];
     // SERIES: first series row of this thread's window rows, the node row's first run
     int srow[SERIES ? MB / BPP : 1]; int rfirst = 0;
     if constexpr (SERIES) {
@@ -120,7 +120,7 @@ template <typename T, bool ALIGNED, bool SERIES = false> __global__ __launch_bou
         for (int mi = 0; mi < MB / BPP; ++mi) srow[mi] = (int)ser.starts[min(w0 + (mi * BPP + sub) * P::ROWS + r0, a.B - 1)];
         rfirst = ser.rows[2 * (ser.row0[t] + node)];
     }
-    auto fetch = [&](VBuf& v, int kc) {
+    auto fetch = [&](int kc) {
         const int k0 = kc * H + c * P::EPC;
         const int nvalid = min(P::EPC, F - k0);
         if constexpr (SERIES) {
@@ -158,8 +158,9 @@ template <typename T, bool ALIGNED, bool SERIES = false> __global__ __launch_bou
                 }
             }
     };
-    // one K chunk: registers -> LDS (sign XOR, pad columns), weight fragment, the chunk `ahead` steps on starts streaming, MACs
-    auto chunk = [&](VBuf& v, int kc, int ahead) {
+    // (two K chunks in flight per thread were measured: no gain, ENC_DEEP of round 2; the plain loop keeps the kernel at 82 VGPRs = five workgroups per CU)
+    fetch(0);
+    for (int kc = 0; kc < nkc; ++kc) {
         const u32x4 sx = sign_xor<T>(sg + kc * H + c * P::EPC);   // apply_symmetry: +-1 mask as a sign-bit XOR
         const int nv = F - (kc * H + c * P::EPC);                  // valid elements of this thread's chunk (pad columns dropped)
         __syncthreads();   // previous chunk's MFMAs are done reading LDS
@@ -176,7 +177,7 @@ template <typename T, bool ALIGNED, bool SERIES = false> __global__ __launch_bou
             }
         __syncthreads();
         load_bfrag<T>(bf, wpack, a.pack0[t] + kc, wv, lane);   // before the prefetch: vmcnt retires in order
-        if (kc + ahead < nkc) fetch(v, kc + ahead);   // a later K chunk streams from HBM under this chunk's MFMAs
+        if (kc + 1 < nkc) fetch(kc + 1);   // the next K chunk streams from HBM under this chunk's MFMAs
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
             if (w0 + m * P::ROWS < a.B) {   // uniform
@@ -184,22 +185,6 @@ template <typename T, bool ALIGNED, bool SERIES = false> __global__ __launch_bou
                 mac(acc[m], af, bf);
             }
         }
-    };
-#ifndef ENC_DEEP
-#define ENC_DEEP 0      // 1: two K chunks in flight per thread (experiment)
-#endif
-    if constexpr (ENC_DEEP && sizeof(T) == 2) {
-        VBuf va, vb2;
-        fetch(va, 0);
-        if (nkc > 1) fetch(vb2, 1);
-        for (int kc = 0; kc < nkc; kc += 2) {
-            chunk(va, kc, 2);
-            if (kc + 1 < nkc) chunk(vb2, kc + 1, 2);
-        }
-    } else {
-        VBuf v;
-        fetch(v, 0);
-        for (int kc = 0; kc < nkc; ++kc) chunk(v, kc, 1);
     }
     T* x0 = reinterpret_cast<T*>(a.x0);
     const int gnode = a.tbase[t] + node;
