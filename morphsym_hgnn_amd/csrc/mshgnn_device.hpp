@@ -470,6 +470,96 @@ __device__ __forceinline__ void join_oct(u32x4 hi, u32x4 lo, f32x4& a, f32x4& b)
     a += la; b += lb;
 }
 
+// k_prep, tiled: one workgroup = one HALF (64 output columns) of one weight pack.  The source matrices are read row by row with 16-byte loads
+// (root-sum of up to 8 matrices in registers, in source order), the summed tile goes through LDS, and every thread then assembles its MFMA
+// B-fragment vectors from LDS -- the first version gathered every element with a scalar load from global memory (64 scattered 32-byte sectors per
+// wave instruction).  Same sums in the same order: identical images.  It wins where there are many packs (>= PREP_TILED_MIN); with ~100 packs the
+// per-thread kernel has more workgroups in flight and one memory round trip fewer.
+//   orient 0 (forward images, B[k][c] = W[c][col0 + k], zero for k >= ncols): tile[a = c - 64 h][b = k], 64 x 128
+//   orient 1 (backward images, B[k][c] = W[k][c]):                            tile[a = k][b = c - 64 h], 128 x 64
+constexpr int PREP_PITCH0 = 132, PREP_PITCH1 = 68, PREP_TILE_FLOATS = 64 * PREP_PITCH0 > 128 * PREP_PITCH1 ? 64 * PREP_PITCH0 : 128 * PREP_PITCH1;
+template <typename T, bool SPLIT_OUT>      // T: element type of the images (float / __bf16); SPLIT_OUT: hi image at wpack, lo image n_packs images further (split plan)
+__device__ __forceinline__ void prep_pack_half(const PrepArgs& a, int pack, int h, float* tile, int tid) {
+    constexpr int EPC = Prec<T>::EPC, NBV = Prec<T>::NBV;
+    const PackDesc pd = a.packs[pack];
+    const bool o0 = pd.orient == 0;
+    const int pitch = o0 ? PREP_PITCH0 : PREP_PITCH1;
+    // ---- summed source tile -> LDS
+    {
+        const int nb4 = o0 ? 32 : 16;                        // float4 columns of a tile row
+        const int b4 = (tid % nb4) * 4, a0 = tid / nb4, apass = 256 / nb4, npass = (o0 ? 64 : 128) / apass;      // 8 passes either way
+        f32x4 sum[8];
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) sum[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < pd.n_src; ++i) {
+            const float* base = a.params + pd.src[i];
+            const bool al = ((pd.src[i] + (o0 ? pd.col0 : 0)) % 4 == 0) && pd.ld % 4 == 0;
+            f32x4 g[8];
+#pragma unroll
+            for (int ps = 0; ps < 8; ++ps) {
+                const int ar = a0 + ps * apass;
+                const float* q = o0 ? base + (int64_t)(64 * h + ar) * pd.ld + pd.col0 + b4 : base + (int64_t)ar * pd.ld + 64 * h + b4;
+                const int nvalid = o0 ? pd.ncols - b4 : 4;
+                g[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (ps < npass) {
+                    if (al && nvalid >= 4) g[ps] = *reinterpret_cast<const f32x4*>(q);
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (e < nvalid) g[ps][e] = q[e];
+                    }
+                }
+            }
+#pragma unroll
+            for (int ps = 0; ps < 8; ++ps) sum[ps] += g[ps];      // source order: the same value every step
+        }
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) if (ps < npass) *reinterpret_cast<f32x4*>(&tile[(a0 + ps * apass) * pitch + b4]) = sum[ps];
+    }
+    __syncthreads();
+    // ---- fragment vectors of the two 32-column wave slices of this half
+    constexpr int VPH = 2 * NBV * 64;          // vectors per half
+    const size_t vec0 = (size_t)pack * (H * H / EPC) + (size_t)(2 * h) * NBV * 64;
+    for (int r = tid; r < VPH; r += 256) {
+        const int lane = r % 64, v = (r / 64) % NBV, wl = r / (64 * NBV);      // wl: wave slice inside the half
+        const int i16 = lane & 15;
+        int k, cl;                               // cl: column inside the half
+        if constexpr (sizeof(T) == 4) { k = 32 * (lane >> 4) + 4 * (v & 7); cl = wl * 32 + 8 * (i16 >> 2) + 4 * (v >> 3) + (i16 & 3); }
+        else { k = 32 * (lane >> 4) + 8 * (v & 3); cl = wl * 32 + 8 * (i16 >> 2) + 4 * (v >> 2) + (i16 & 3); }
+        float s[EPC];
+#pragma unroll
+        for (int x = 0; x < EPC; ++x) s[x] = o0 ? tile[cl * PREP_PITCH0 + k + x] : tile[(k + x) * PREP_PITCH1 + cl];
+        if constexpr (SPLIT_OUT) {
+            u32x4 hi, lo;
+            split_oct(f32x4{s[0], s[1], s[2], s[3]}, f32x4{s[4], s[5], s[6], s[7]}, hi, lo);
+            u32x4* dst = reinterpret_cast<u32x4*>(a.wpack);
+            dst[vec0 + r] = hi;
+            dst[(size_t)a.n_packs * (H * H / EPC) + vec0 + r] = lo;
+        } else {
+            T* dst = reinterpret_cast<T*>(a.wpack) + (vec0 + r) * EPC;
+            if constexpr (sizeof(T) == 4) *reinterpret_cast<f32x4*>(dst) = f32x4{s[0], s[1], s[2], s[3]};
+            else *reinterpret_cast<u32x4*>(dst) = pack_oct(f32x4{s[0], s[1], s[2], s[3]}, f32x4{s[4], s[5], s[6], s[7]});
+        }
+    }
+}
+template <typename T, bool SPLIT_OUT> __global__ __launch_bounds__(256) void k_prep_tiled(PrepArgs a) {
+    __shared__ __attribute__((aligned(16))) float tile[PREP_TILE_FLOATS];
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x < 2 * a.n_packs) { prep_pack_half<T, SPLIT_OUT>(a, blockIdx.x >> 1, blockIdx.x & 1, tile, tid); return; }
+    const int b = ((int)blockIdx.x - 2 * a.n_packs) * 256 + tid;
+    if (b < a.n_biases * H) {
+        const BiasDesc bd = a.biases[b / H];
+        float s = 0.f;
+        for (int i = 0; i < bd.n_src; ++i) s += a.params[bd.src[i] + (b % H)];
+        a.bias[b] = s;
+    }
+}
+constexpr int PREP_TILED_MIN = 200;       // packs from which the tiled kernel wins
+inline bool prep_use_tiled(int n_packs) {      // MSHGNN_PREP_TILED=0 / 1 forces either kernel (A/B runs)
+    static const int forced = [] { const char* e = getenv("MSHGNN_PREP_TILED"); return e ? atoi(e) : -1; }();
+    return forced >= 0 ? forced != 0 : n_packs >= PREP_TILED_MIN;
+}
+inline unsigned prep_tiled_grid(int n_packs, int n_biases) { return (unsigned)(2 * n_packs + (n_biases * H + 255) / 256); }
+
 struct StackArgs {
     const void* tile_in;                          // fwd: X_0                       bwd: dX_L
     char* ws;

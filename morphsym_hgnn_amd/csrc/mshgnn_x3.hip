@@ -24,6 +24,7 @@ __device__ __forceinline__ size_t x3_idx(int w, int node, int B) { return ((size
 // ------------------------------------------------------------------------------------------------------
 // k_prep_x3: hi and lo MFMA B-fragment images of every weight pack (root-sum, transpose) + bias sums
 // ------------------------------------------------------------------------------------------------------
+// (many packs: k_prep_tiled<__bf16, true>, mshgnn_device.hpp)
 __global__ void k_prep_x3(PrepArgs a) {
     constexpr int EPC = 8, NBV = 8;
     const int vec_per_pack = H * H / EPC;
@@ -1004,7 +1005,8 @@ template <bool ALIGNED> __global__ __launch_bounds__(256, GWX3_WPS) void k_gradw
 // ------------------------------------------------------------------------------------------------------
 int x3_launch_prep(const PrepArgs& a, hipStream_t st) {
     const int64_t total = (int64_t)a.n_packs * (H * H / 8) + (int64_t)a.n_biases * H;
-    hipLaunchKernelGGL(k_prep_x3, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
+    if (prep_use_tiled(a.n_packs)) hipLaunchKernelGGL((k_prep_tiled<__bf16, true>), dim3(prep_tiled_grid(a.n_packs, a.n_biases)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_prep_x3, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
     return MSHGNN_OK;
 }
 
@@ -1038,7 +1040,8 @@ int x3_forward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitc
         PrepArgs a{params, ws + lay.wpack, reinterpret_cast<float*>(ws + lay.bias), p->d_packs, p->d_biases, hp.n_img, (int)hp.biases.size()};
         const int64_t total = (int64_t)hp.n_img * (H * H / 8) + (int64_t)hp.biases.size() * H;
         ProfScope ps(p, hp.ks_prep, st);
-        hipLaunchKernelGGL(k_prep_x3, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
+        if (prep_use_tiled(a.n_packs)) hipLaunchKernelGGL((k_prep_tiled<__bf16, true>), dim3(prep_tiled_grid(a.n_packs, a.n_biases)), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(k_prep_x3, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
     }
     {   // 2. encoder (fp32 inputs)
         EncArgs a{};
