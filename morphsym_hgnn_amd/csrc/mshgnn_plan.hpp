@@ -754,7 +754,7 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
     p.item_off = (int)T.size(); p.n_items = 0;
     {
         double best = -1;
-        for (int ipl = 1; ipl <= (p.split ? 1 : GW_IPL); ++ipl) {
+        for (int ipl = 1; ipl <= GW_IPL; ++ipl) {
             int nl = 0; for (auto& tg : tgts) nl += ((int)tg.items.size() + ipl - 1) / ipl;
             const double fill = (double)nl * std::max(1, std::min(16, p.gw_target / std::max(1, nl)));
             if (fill > best) { best = fill; p.gw_ipl = ipl; }
