@@ -24,13 +24,15 @@ extern "C" const char* mshgnn_version(void) { return "mshgnn 0.1 (gfx950)"; }
 // Few packs (A1-C2 at L = 3: ~100): one thread per output vector, gathers straight from global memory -- more workgroups than packs, two memory
 // round trips.  Many packs (K4 at L = 8, the generic-width engine): k_prep_tiled (mshgnn_device.hpp), one workgroup per half pack through LDS
 // (measured: A1-C2 L=3 10.7 vs 17.1 us, K4 L=8 18.5 vs 16.2, synthetic 32-limb h=512 97 vs 52).
-template <typename T> __global__ void k_prep(PrepArgs a) {
+// output vector `idx` of this launch's pack range, or (idx past the packs) one bias sum
+template <typename T> __device__ __forceinline__ void prep_one(const PrepArgs& a, int idx, bool with_bias) {
     constexpr int EPC = Prec<T>::EPC, NBV = Prec<T>::NBV;
     const int vec_per_pack = H * H / EPC;
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int total = a.n_packs * vec_per_pack;
-    if (gid < total) {
-        const int pack = gid / vec_per_pack, r = gid % vec_per_pack;
+    const int npk = a.pack_n < 0 ? a.n_packs : a.pack_n;
+    const int total = npk * vec_per_pack;
+    if (idx < total) {
+        const int pack = a.pack0 + idx / vec_per_pack, r = idx % vec_per_pack;
+        const int gid = pack * vec_per_pack + r;
         const int lane = r % 64, v = (r / 64) % NBV, wv = r / (64 * NBV);
         const PackDesc pd = a.packs[pack];
         T out[EPC];
@@ -60,8 +62,8 @@ template <typename T> __global__ void k_prep(PrepArgs a) {
         T* dst = reinterpret_cast<T*>(a.wpack) + (size_t)gid * EPC;
 #pragma unroll
         for (int x = 0; x < EPC; ++x) dst[x] = out[x];
-    } else {
-        const int b = gid - total;
+    } else if (with_bias) {
+        const int b = idx - total;
         if (b < a.n_biases * H) {
             const BiasDesc bd = a.biases[b / H];
             float s = 0.f;
@@ -70,6 +72,7 @@ template <typename T> __global__ void k_prep(PrepArgs a) {
         }
     }
 }
+template <typename T> __global__ void k_prep(PrepArgs a) { prep_one<T>(a, blockIdx.x * blockDim.x + threadIdx.x, true); }
 
 // ------------------------------------------------------------------------------------------------------
 // k_enc_fwd: X_0[node] = relu((mask . x) W_enc^T + b)      (hgnn_c2.py:143-147)
@@ -95,6 +98,10 @@ template <typename T, bool ALIGNED, bool SERIES = false> __global__ __launch_bou
     constexpr int VPB = P::ROWS * P::CPR, NIT = VPB / 256 > 0 ? VPB / 256 : 1, BPP = 256 / VPB > 0 ? 256 / VPB : 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if ((int)blockIdx.x >= a.wg_prefix[a.n_types]) {      // a workgroup of the embedded layer-pack prep (bf16 plan; see EncArgs.prep)
+        if constexpr (sizeof(T) == 2 && ALIGNED && !SERIES) prep_one<T>(a.prep, ((int)blockIdx.x - a.wg_prefix[a.n_types]) * 256 + tid, false);
+        return;
+    }
     int t = 0;
     while (t + 1 < a.n_types && (int)blockIdx.x >= a.wg_prefix[t + 1]) ++t;
     const int local = blockIdx.x - a.wg_prefix[t];
@@ -2154,10 +2161,17 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
     const mshgnn_desc& d = hp.d;
     mshgnn_ws_layout lay; layout_workspace(hp, batch, training, &lay);
     const int B = (int)batch;
-    // 1. weight images
+    // 1. weight images.  bf16 plan with few packs: only the encoder's packs (the last ones of the list) + the biases here; the layer packs are packed
+    //    by extra workgroups of the encoder launch, under its tail (EncArgs.prep) -- the whole-list launch in front of the encoder cost 10.9 us
+    PrepArgs pa{params, ws + lay.wpack, reinterpret_cast<float*>(ws + lay.bias), p->d_packs, p->d_biases, (int)hp.packs.size(), (int)hp.biases.size()};
+    int enc_pack0 = (int)hp.packs.size();
+    for (int t = 0; t < hp.NT; ++t) if (hp.pack_enc_base[t] >= 0) enc_pack0 = std::min(enc_pack0, hp.pack_enc_base[t]);
+    static const bool embed_off = getenv("MSHGNN_PREP_EMBED") && atoi(getenv("MSHGNN_PREP_EMBED")) == 0;      // (A/B runs)
+    const bool embed = sizeof(T) == 2 && !series && !prep_use_tiled(pa.n_packs) && enc_pack0 > 0 && !embed_off;
     {
-        PrepArgs a{params, ws + lay.wpack, reinterpret_cast<float*>(ws + lay.bias), p->d_packs, p->d_biases, (int)hp.packs.size(), (int)hp.biases.size()};
-        const int64_t total = (int64_t)hp.packs.size() * (H * H / Prec<T>::EPC) + (int64_t)hp.biases.size() * H;
+        PrepArgs a = pa;
+        if (embed) { a.pack0 = enc_pack0; a.pack_n = pa.n_packs - enc_pack0; }
+        const int64_t total = (int64_t)(embed ? a.pack_n : a.n_packs) * (H * H / Prec<T>::EPC) + (int64_t)hp.biases.size() * H;
         ProfScope ps(p, hp.ks_prep, st);
         if (prep_use_tiled(a.n_packs)) hipLaunchKernelGGL((k_prep_tiled<T, false>), dim3(prep_tiled_grid(a.n_packs, a.n_biases)), dim3(256), 0, st, a);
         else hipLaunchKernelGGL(k_prep<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
@@ -2179,16 +2193,25 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
         }
         a.wpack = ws + lay.wpack; a.bias = reinterpret_cast<const float*>(ws + lay.bias); a.signs = p->d_signs; a.x0 = ws + lay.x[0];
         a.mask0 = (training && lay.dd[0]) ? reinterpret_cast<uint8_t*>(ws + lay.dd[0]) : nullptr;
+        unsigned enc_grid = (unsigned)a.wg_prefix[hp.NT];
+        if (embed) {
+            PrepArgs lp = pa; lp.pack0 = 0; lp.pack_n = enc_pack0;
+            if (a.aligned) { a.prep = lp; a.prep_vecs = enc_pack0 * (H * H / Prec<T>::EPC); enc_grid += (unsigned)((a.prep_vecs + 255) / 256); }
+            else {      // the element-wise encoder has no embedded prep: pack the layer images in front of it after all
+                ProfScope ps(p, hp.ks_prep, st);
+                hipLaunchKernelGGL(k_prep<T>, dim3((unsigned)(((int64_t)enc_pack0 * (H * H / Prec<T>::EPC) + 255) / 256)), dim3(256), 0, st, lp);
+            }
+        }
         ProfScope ps(p, hp.ks_enc, st);
         if constexpr (sizeof(T) == 2) {
             if (series) {
                 if (x && !a.aligned) return set_err(MSHGNN_EINVAL, "the fused window assembly needs 16-byte aligned window rows (pitch a multiple of 8)");
-                hipLaunchKernelGGL((k_enc_fwd<T, true, true>), dim3(a.wg_prefix[hp.NT]), dim3(256), Prec<T>::ENC_MB * Prec<T>::BLK, st, a, *series);
-            } else if (a.aligned) hipLaunchKernelGGL((k_enc_fwd<T, true>), dim3(a.wg_prefix[hp.NT]), dim3(256), Prec<T>::ENC_MB * Prec<T>::BLK, st, a, SeriesSrc{});
-            else hipLaunchKernelGGL((k_enc_fwd<T, false>), dim3(a.wg_prefix[hp.NT]), dim3(256), Prec<T>::ENC_MB * Prec<T>::BLK, st, a, SeriesSrc{});
+                hipLaunchKernelGGL((k_enc_fwd<T, true, true>), dim3(enc_grid), dim3(256), Prec<T>::ENC_MB * Prec<T>::BLK, st, a, *series);
+            } else if (a.aligned) hipLaunchKernelGGL((k_enc_fwd<T, true>), dim3(enc_grid), dim3(256), Prec<T>::ENC_MB * Prec<T>::BLK, st, a, SeriesSrc{});
+            else hipLaunchKernelGGL((k_enc_fwd<T, false>), dim3(enc_grid), dim3(256), Prec<T>::ENC_MB * Prec<T>::BLK, st, a, SeriesSrc{});
         } else {
-            if (a.aligned) hipLaunchKernelGGL((k_enc_fwd<T, true>), dim3(a.wg_prefix[hp.NT]), dim3(256), Prec<T>::ENC_MB * Prec<T>::BLK, st, a, SeriesSrc{});
-            else hipLaunchKernelGGL((k_enc_fwd<T, false>), dim3(a.wg_prefix[hp.NT]), dim3(256), Prec<T>::ENC_MB * Prec<T>::BLK, st, a, SeriesSrc{});
+            if (a.aligned) hipLaunchKernelGGL((k_enc_fwd<T, true>), dim3(enc_grid), dim3(256), Prec<T>::ENC_MB * Prec<T>::BLK, st, a, SeriesSrc{});
+            else hipLaunchKernelGGL((k_enc_fwd<T, false>), dim3(enc_grid), dim3(256), Prec<T>::ENC_MB * Prec<T>::BLK, st, a, SeriesSrc{});
         }
     }
     // 3. layers (+ decoder): one fused launch on the bf16 plan, else one kernel per layer and the decoder kernel

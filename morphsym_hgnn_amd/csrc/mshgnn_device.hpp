@@ -332,6 +332,11 @@ __device__ __forceinline__ unsigned relu_with_bits(typename Prec<T>::Acc& acc) {
         }
     return bits;
 }
+struct PrepArgs {
+    const float* params; void* wpack; float* bias; const PackDesc* packs; const BiasDesc* biases; int n_packs; int n_biases;
+    int pack0 = 0, pack_n = -1;      // per-thread kernel: the packs [pack0, pack0 + pack_n) of this launch (-1: all of them)
+};
+
 struct EncArgs {
     const void* x[MSHGNN_MAX_TYPES]; int64_t pitch[MSHGNN_MAX_TYPES]; int vb[MSHGNN_MAX_TYPES];
     int width[MSHGNN_MAX_TYPES], nodes[MSHGNN_MAX_TYPES], tbase[MSHGNN_MAX_TYPES], nkc[MSHGNN_MAX_TYPES];
@@ -340,6 +345,9 @@ struct EncArgs {
     int aligned;   // every input row starts 16-byte aligned and its pitch is a whole number of 16-byte chunks
     const void* wpack; const float* bias; const uint8_t* signs; void* x0;
     uint8_t* mask0;   // training: relu bytes of X_0 (one byte per lane, as the layer masks), read by the backward stack kernels at layer 0
+    // bf16 plan, small plans: the LAYER weight packs are packed by extra workgroups behind the encoder's own (blockIdx >= wg_prefix[n_types]): they
+    // run under the encoder's tail instead of in front of it (the encoder's own packs + the biases were packed by a short launch before)
+    PrepArgs prep; int prep_vecs;      // prep_vecs: output vectors of those packs (0: none)
 };
 
 // The encoder's inputs gathered straight from a sequence's resident raw series (bf16 copies, column-major) instead of materialised windows --
@@ -454,9 +462,6 @@ template <typename T> __device__ __forceinline__ void store8(T* p, const float (
     }
 }
 
-struct PrepArgs {
-    const float* params; void* wpack; float* bias; const PackDesc* packs; const BiasDesc* biases; int n_packs; int n_biases;
-};
 
 // split plan (MSHGNN_BF16X3): an fp32 value travels as two bf16 values, hi = bf16(x) and lo = bf16(x - hi): x = hi + lo to 16 mantissa
 // bits (2^-17 relative), and a product is taken as hi*hi + hi*lo + lo*hi on the bf16 MFMA with fp32 accumulation
