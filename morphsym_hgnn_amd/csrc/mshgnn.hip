@@ -1918,6 +1918,10 @@ template <bool ALIGNED, bool SERIES = false> __global__ __launch_bounds__(256, G
 
 // k_finalize: sum split-K slabs in fixed order into the flat gradient buffer (every parameter written once)
 
+#ifndef FIN_LB
+#define FIN_LB 4       // lanes per load batch of k_finalize (x 4 parts = 16 slab loads in flight per thread; 8 / 16 lanes measured: A1-C2 18.7 -> 18.6 / 17.9 us,
+                       // MiniCheetah-K4 L=8 19.3 -> 20.5 / 23.6 us)
+#endif
 __global__ __launch_bounds__(256) void k_finalize(FinArgs a) {
     const int* f = a.fin + blockIdx.x * FIN_INTS;
     const int64_t dst = (int64_t)(unsigned)f[0] | ((int64_t)f[1] << 32);
@@ -1963,16 +1967,16 @@ __global__ __launch_bounds__(256) void k_finalize(FinArgs a) {
             // slab(part, j) = part * n_lanes + l0 + j; summed lane-major in batches of 16 loads -- fixed summation order
             const float* sp = a.slabs + (size_t)l0 * SLAB_FLOATS + src;
             const size_t pstride = (size_t)a.n_lanes * SLAB_FLOATS;
-            for (int j0 = 0; j0 < nl; j0 += 4)
+            for (int j0 = 0; j0 < nl; j0 += FIN_LB)
                 for (int p0 = 0; p0 < a.n_parts; p0 += 4) {
-                    float v[4][4];
+                    float v[FIN_LB][4];
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj)
+                    for (int jj = 0; jj < FIN_LB; ++jj)
 #pragma unroll
                         for (int pp = 0; pp < 4; ++pp)
                             v[jj][pp] = (j0 + jj < nl && p0 + pp < a.n_parts) ? sp[(size_t)(j0 + jj) * SLAB_FLOATS + (size_t)(p0 + pp) * pstride] : 0.f;
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) s += (v[jj][0] + v[jj][1]) + (v[jj][2] + v[jj][3]);
+                    for (int jj = 0; jj < FIN_LB; ++jj) s += (v[jj][0] + v[jj][1]) + (v[jj][2] + v[jj][3]);
                 }
         }
         a.grad[dst + (int64_t)r * ld + cidx] = s;
