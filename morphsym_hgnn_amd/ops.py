@@ -177,14 +177,16 @@ _csr_cache: dict = {}
 
 
 def csr_of(edge_index: torch.Tensor, n_src: int, n_dst: int, mean: bool) -> Csr:
-    """CSR views of an edge_index, cached on the tensor's identity and version (a training loop presents the same graph every step)."""
-    key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), n_src, n_dst, mean, str(edge_index.device))
-    c = _csr_cache.get(key)
-    if c is None:
+    """CSR views of an edge_index, cached on the tensor's storage address, version and shape (a training loop presents the same graph every
+    step).  The cache entry keeps a reference to the tensor, so its storage cannot be freed and handed to ANOTHER edge_index while the entry is
+    alive -- an address match therefore means the same data (in-place edits bump the version)."""
+    key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), tuple(edge_index.stride()), n_src, n_dst, mean, str(edge_index.device))
+    hit = _csr_cache.get(key)
+    if hit is None:
         if len(_csr_cache) >= 64:
             _csr_cache.clear()
-        c = _csr_cache[key] = Csr(edge_index, n_src, n_dst, mean)
-    return c
+        hit = _csr_cache[key] = (edge_index, Csr(edge_index, n_src, n_dst, mean))
+    return hit[1]
 
 
 def graph_conv(x: "torch.Tensor | Tuple[torch.Tensor, torch.Tensor]", edge_index: torch.Tensor, w_rel: torch.Tensor,

@@ -140,3 +140,22 @@ def test_hetero_stack_matches_reference_on_the_a1_graph():
             assert pd.grad is None or float(pd.grad.abs().max()) == 0.0, kd
         else:
             assert _rel(pd.grad, ps.grad) < RTOL, kd
+
+
+def test_csr_cache_never_serves_another_graph():
+    """Fresh edge_index tensors every call (what PyG's collate produces): the cached CSR views are keyed on storage the cache keeps alive, so a new
+    graph that happens to reuse a freed address cannot hit a stale entry."""
+    _require_gpu()
+    from morphsym_hgnn_amd import nn as pnn
+    ref = _ref_nn()
+    r = ref.GraphConv((8, 8), 8, aggr="add").double()
+    m = pnn.GraphConv((8, 8), 8, aggr="add").double().cuda()
+    _copy_params(m, r)
+    g = torch.Generator().manual_seed(0)
+    xs, xd = torch.randn(30, 8, dtype=torch.float64, generator=g), torch.randn(20, 8, dtype=torch.float64, generator=g)
+    for it in range(40):
+        ei = torch.stack([torch.randint(0, 30, (50,), generator=g), torch.randint(0, 20, (50,), generator=g)])
+        eg = ei.cuda()                       # a new device tensor per iteration; the previous one is dropped
+        y = m((xs.cuda(), xd.cuda()), eg)
+        assert _rel(y, r((xs, xd), ei)) < RTOL, it
+        del eg
