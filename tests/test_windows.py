@@ -200,3 +200,23 @@ def test_series_step_is_bit_identical_to_assemble_then_step(recipe_name, B):
     xs3, y3, out_c, loss_c, g_c = e.step_mse_series(store, starts, flat, materialize=False)
     torch.cuda.synchronize()
     assert xs3 is None and torch.equal(y, y3) and torch.equal(out_a, out_c) and torch.equal(loss_a, loss_c) and torch.equal(g_a, g_c)
+
+
+@pytest.mark.gpu
+def test_series_step_refuses_what_it_cannot_run():
+    """mshgnn_step_mse_series is a bf16-plan route: other plans, standardised recipes and recipes whose node types differ from the plan's are
+    refused with an error (the caller assembles windows and calls mshgnn_step_mse instead) -- never a silent fallback."""
+    from morphsym_hgnn_amd import engine as eng, synth
+    from morphsym_hgnn_amd.windows import SequenceStore, quadsdk_a1_c2_recipe, minicheetah_k4_recipe
+    from tests import helpers
+    spec = helpers.make_spec("c2", "a1-c2", "a1-c2", 128, 2)
+    starts = torch.tensor([0, 5, 9], dtype=torch.int64).cuda()
+    flat32 = None
+    for dtype, recipe, match in (("x3", quadsdk_a1_c2_recipe(JP, FP, T, 3), "bf16 plan"),
+                                 ("bf16", quadsdk_a1_c2_recipe(JP, FP, T, 3, normalize=True), "unstandardised"),
+                                 ("bf16", quadsdk_a1_c2_recipe(JP, FP, T, 1), "label count")):
+        e = eng.Engine(spec, dtype)
+        store = SequenceStore(SEQ, recipe, dtype="bf16" if dtype == "bf16" else "f32")
+        flat = eng.flatten_params(spec, synth.make_params(1, spec.param_shapes()), e.device)
+        with pytest.raises(eng.MshgnnError, match=match):
+            e.step_mse_series(store, starts, flat)
