@@ -131,8 +131,10 @@ class _MSHGNNBase(nn.Module):
     num_bases = 2
 
     def _init_common(self, hidden_channels, num_layers, data_metadata, regression, activation_fn):
-        if not isinstance(activation_fn, nn.ReLU):
-            raise NotImplementedError("the MI355X MS-HGNN engine fuses ReLU; other activation_fn are not supported")
+        # The fused engine implements the reference's default, nn.ReLU().  Any other activation module (the constructors accept one,
+        # hgnn_c2.py:10-12) runs the same forward operator by operator on the stand-alone HIP operators of ops.py (_forward_operators): PyG-style
+        # launches instead of the fused kernels -- slower, same numerics, still no CPU path.
+        self._fused_activation = isinstance(activation_fn, nn.ReLU)
         self.regression = regression
         self.activation = activation_fn
         self.hidden_channels = hidden_channels
@@ -298,6 +300,8 @@ class _MSHGNNBase(nn.Module):
                 if infer_window_edges(edge_index_dict[et], nn_[s], nn_[d], B) != spec.topology.edges(et):
                     raise ValueError(f"edge_index_dict[{et}] differs from the topology this model was compiled for")
             self._checked_batches.add(B)
+        if not self._fused_activation:
+            return self._forward_operators(x_dict, edge_index_dict, B)
         pdev = self.decoder.weight.device
         if pdev.type != "cuda":
             # parameters still on the host (e.g. the wrapper's lazy-init call, gnnLightning.py:593-595, or
@@ -342,6 +346,47 @@ class _MSHGNNBase(nn.Module):
         if spec.kind in ("k4_com", "c2_com"):
             return out.view(B, spec.num_nodes["base"], spec.out_channels)   # morphological_symmetry_decoder, hgnn_k4_com.py:157-165
         return out                      # [B*4, out_channels_per_foot]  (COM S4 / COM_HGNN: [B, com_dimension])
+
+    def _forward_operators(self, x_dict, edge_index_dict, B):
+        """The reference's forward (hgnn_c2.py:133-182, hgnn_k4.py:146-196, hgnn.py:57-62, hgnn_*_com.py) operator by operator, for models built with
+        an activation_fn other than nn.ReLU(): every Linear / GraphConv runs on the HIP operators of ops.py with autograd, the activation itself
+        is the caller's module.  Inputs and parameters must be on the device."""
+        from . import ops
+        spec, act = self._spec, self.activation
+        dev = x_dict[self._node_types[0]].device
+        if dev.type != "cuda":
+            raise RuntimeError("the operator path of a non-ReLU model runs on a HIP device (inputs are on the host); there is no CPU fallback")
+        if self.decoder.weight.device != dev:
+            raise RuntimeError("move the model to the inputs' device first (model.to(device))")
+        x = {}
+        for t, m in spec.input_masks().items():                # apply_symmetry (hgnn_c2.py:191-284) as its net +-1 masks
+            v = x_dict[t]
+            if v.shape[1] != spec.widths[t]:
+                raise ValueError(f"x_dict['{t}'] must have the reference's width {spec.widths[t]} on the operator path")
+            n = m.shape[0]
+            x[t] = (v.view(-1, n, v.shape[1]) * m.to(v.device, v.dtype).unsqueeze(0)).reshape(v.shape)
+        x = {k: act(v) for k, v in self.encoder(x).items()}
+        bt = getattr(self, "base_transform", None)
+        for conv in self.convs:
+            h = conv(x, edge_index_dict)
+            if spec.kind in ("mi", "s4_com") or bt is None:
+                x = {k: act(v) for k, v in h.items()}
+                continue
+            new = {}
+            for k, v in h.items():
+                if k == "base":                                   # base_transform: Linear, nn.ReLU() (fixed in the reference), Linear
+                    new[k] = ops.linear(torch.relu(ops.linear(v, bt[0].weight, bt[0].bias)), bt[2].weight, bt[2].bias)
+                else:
+                    new[k] = act(v)
+            x = {k: new[k] + x[k] if (k in x and x[k].shape == new[k].shape) else new[k] for k in new}
+        out = self.decoder(x[spec.out_type])
+        n_out = spec.num_nodes[spec.out_type]
+        out = (out.view(B, n_out, -1) * spec.output_mask().to(out.device, out.dtype).unsqueeze(0)).reshape(B * n_out, -1)
+        if spec.output_is_window_major:
+            return out.view(B, -1)
+        if spec.kind in ("k4_com", "c2_com"):
+            return out.view(B, spec.num_nodes["base"], spec.out_channels)
+        return out
 
     # ---- reference helper kept for API compatibility ------------------------------------------------------
     def apply_symmetry(self, x_dict):

@@ -10,25 +10,25 @@ from morphsym_hgnn_amd import models, nn as pnn
 from tests import helpers
 
 
-def _build(case, spec):
+def _build(case, spec, **extra):      # extra: e.g. activation_fn
     _, cfg_path = helpers.load_group(case["cfg"])
     meta = spec.topology.metadata()
     if case["kind"] == "c2":
         return models.GRF_HGNN_C2(case["hidden"], case["layers"], meta, regression=case["regression"],
                                   symmetry_mode="MorphSym" if cfg_path else None, group_operator_path=cfg_path,
-                                  grf_dimension=case["grf"])
+                                  grf_dimension=case["grf"], **extra)
     if case["kind"] == "k4":
         return models.GRF_HGNN_K4(case["hidden"], case["layers"], meta, regression=case["regression"],
-                                  symmetry_mode="MorphSym" if cfg_path else None, group_operator_path=cfg_path)
+                                  symmetry_mode="MorphSym" if cfg_path else None, group_operator_path=cfg_path, **extra)
     if case["kind"] in ("k4_com", "c2_com"):
         cls = models.COM_HGNN_K4 if case["kind"] == "k4_com" else models.COM_HGNN_C2
         return cls(case["hidden"], case["layers"], meta, symmetry_mode="MorphSym" if cfg_path else None,
-                   group_operator_path=cfg_path)
+                   group_operator_path=cfg_path, **extra)
     if case["kind"] == "s4_com":
         if case.get("ref") == "COM_HGNN":
-            return models.COM_HGNN(case["hidden"], case["layers"], meta, com_dimension=6)
-        return models.COM_HGNN_S4(case["hidden"], case["layers"], meta)
-    return models.GRF_HGNN(case["hidden"], case["layers"], meta, regression=case["regression"], grf_dimension=case["grf"])
+            return models.COM_HGNN(case["hidden"], case["layers"], meta, com_dimension=6, **extra)
+        return models.COM_HGNN_S4(case["hidden"], case["layers"], meta, **extra)
+    return models.GRF_HGNN(case["hidden"], case["layers"], meta, regression=case["regression"], grf_dimension=case["grf"], **extra)
 
 
 def _is_com(case):
@@ -69,8 +69,8 @@ def test_operators_have_no_cpu_path():
         pnn.GraphConv(8, 8)(torch.zeros(2, 8), torch.zeros(2, 0, dtype=torch.long))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         pnn.Linear(8, 4)(torch.zeros(2, 8))
-    with pytest.raises(NotImplementedError):
-        models.GRF_HGNN_C2(128, 1, (["base", "joint", "foot"], [("base", "x", "joint")]), activation_fn=nn.Tanh())
+    m = models.GRF_HGNN_C2(128, 1, (["base", "joint", "foot"], [("base", "x", "joint")]), activation_fn=nn.Tanh())      # accepted: runs operator by operator
+    assert not m._fused_activation
 
 
 @pytest.mark.gpu
@@ -162,3 +162,44 @@ def test_device_parameters_are_views_of_the_flat_buffer_and_behave_like_ordinary
     assert not m._flat_ok
     l1 = float(loss_of(m))                                   # ... the next forward re-establishes the fp32 views
     assert m._flat_ok and all(p.dtype == torch.float32 for p in m.parameters()) and abs(l1 - float(loss_of(m))) < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["a1c2_h128_L3_d3_B3", "mck4_cls_h128_L2_B3", "mi_h128_L2_d3_B2", "solok4com_h128_L3_B5", "solos4com_h128_L2_B3"])
+def test_non_relu_activation_runs_operator_by_operator(name):
+    """activation_fn other than nn.ReLU() (the reference's constructors take any module): the same forward on the stand-alone HIP operators;
+    outputs, loss and every parameter gradient within 1e-4 of the oracle evaluated with that activation (base_transform keeps its own nn.ReLU,
+    hgnn_c2.py:117-121)."""
+    from oracle import ms_hgnn_oracle as orc
+    assert torch.cuda.is_available()
+    torch.set_default_dtype(torch.float64)
+    case, spec, fx, x_dict, y, params, ei = helpers.load_case(name)
+    B = case["B"]
+    m = _build(case, spec, activation_fn=nn.Tanh()).cuda()
+    dev = torch.device("cuda")
+    xd = {k: v.to(dev) for k, v in x_dict.items()}
+    eid = {k: v.to(dev) for k, v in ei.items()}
+    with torch.no_grad():
+        m(x_dict={k: v.clone() for k, v in xd.items()}, edge_index_dict=eid)      # lazy encoder, spec
+    m.load_state_dict(params)
+    out = m(x_dict=xd, edge_index_dict=eid)
+    # oracle with tanh at the encoder / layer sites and relu inside base_transform
+    cfg = helpers.oracle_config(spec)
+    act = lambda key, h: torch.relu(h) if key[0] == "t1" else torch.tanh(h)
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+    o_ref = orc.forward(cfg, leaves, {k: v.clone() for k, v in x_dict.items()}, ei, relu_fn=act)
+    yy, yp = orc.wrapper_outputs(cfg, o_ref, y, B)
+    l_ref = orc.mse_loss(yy, yp) if cfg.regression else orc.cross_entropy_loss(yy, yp, B)
+    l_ref.backward()
+    yy2, yp2 = orc.wrapper_outputs(cfg, out.cpu(), y, B)
+    assert float((yp2 - yp.detach()).abs().max() / yp.detach().abs().max()) < 1e-4
+    loss = (orc.mse_loss(yy.to(dev), orc.wrapper_outputs(cfg, out, y.to(dev), B)[1]) if cfg.regression
+            else orc.cross_entropy_loss(yy.to(dev), orc.wrapper_outputs(cfg, out, y.to(dev), B)[1], B))
+    loss.backward()
+    assert abs(float(loss) - float(l_ref)) <= 1e-4 * abs(float(l_ref))
+    for k, p in m.named_parameters():
+        ref = leaves[k].grad
+        if ref is None or float(ref.abs().max()) == 0.0:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+        else:
+            assert float((p.grad.cpu().double() - ref).abs().max() / ref.abs().max()) < 1e-4, k
