@@ -131,10 +131,11 @@ class _MSHGNNBase(nn.Module):
     num_bases = 2
 
     def _init_common(self, hidden_channels, num_layers, data_metadata, regression, activation_fn):
-        # The fused engine implements the reference's default, nn.ReLU().  Any other activation module (the constructors accept one,
-        # hgnn_c2.py:10-12) runs the same forward operator by operator on the stand-alone HIP operators of ops.py (_forward_operators): PyG-style
-        # launches instead of the fused kernels -- slower, same numerics, still no CPU path.
-        self._fused_activation = isinstance(activation_fn, nn.ReLU)
+        # The fused engines implement the reference's default, nn.ReLU(), at hidden widths that are multiples of 128.  Any other activation module
+        # (the constructors accept one, hgnn_c2.py:10-12) or width runs the same forward operator by operator on the stand-alone HIP operators
+        # of ops.py (_forward_operators): PyG-style launches instead of the fused kernels -- slower, same numerics, still no CPU path.
+        self._fused_activation = isinstance(activation_fn, nn.ReLU) and hidden_channels % 128 == 0      # (the engines' widths are multiples of 128: any
+                                                                                                      # other hidden_channels runs on the operators too)
         self.regression = regression
         self.activation = activation_fn
         self.hidden_channels = hidden_channels

@@ -203,3 +203,37 @@ def test_non_relu_activation_runs_operator_by_operator(name):
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
         else:
             assert float((p.grad.cpu().double() - ref).abs().max() / ref.abs().max()) < 1e-4, k
+
+
+@pytest.mark.gpu
+def test_hidden_width_off_the_engines_grid_runs_operator_by_operator():
+    """hidden_channels = 96 (the reference takes any width; the fused engines take multiples of 128): the operator path, against the oracle."""
+    from oracle import ms_hgnn_oracle as orc
+    from morphsym_hgnn_amd import synth
+    assert torch.cuda.is_available()
+    torch.set_default_dtype(torch.float64)
+    spec = helpers.make_spec("c2", "a1-c2", "a1-c2", 96, 2)
+    B = 3
+    _, cfg_path = helpers.load_group("a1-c2")
+    m = models.GRF_HGNN_C2(96, 2, spec.topology.metadata(), symmetry_mode="MorphSym", group_operator_path=cfg_path, grf_dimension=3).cuda()
+    assert not m._fused_activation
+    x_dict, y = synth.make_windows(4, B, spec.num_nodes, spec.widths, 12)
+    params = synth.make_params(4, spec.param_shapes())
+    ei = spec.topology.edge_index_dict(B)
+    xd = {k: v.double().cuda() for k, v in x_dict.items()}
+    eid = {k: v.cuda() for k, v in ei.items()}
+    with torch.no_grad():
+        m(x_dict={k: v.clone() for k, v in xd.items()}, edge_index_dict=eid)
+    m.load_state_dict(params)
+    out = m(x_dict=xd, edge_index_dict=eid)
+    o_ref, l_ref, g_ref = orc.step(helpers.oracle_config(spec), params, {k: v.double() for k, v in x_dict.items()}, ei, y.double(), B)
+    assert float((out.cpu().reshape(-1) - o_ref.reshape(-1)).abs().max() / o_ref.abs().max()) < 1e-4
+    loss = ((out.flatten() - y.double().cuda().flatten()) ** 2).mean()
+    loss.backward()
+    assert abs(float(loss) - float(l_ref)) <= 1e-4 * abs(float(l_ref))
+    for k, p in m.named_parameters():
+        ref = g_ref[k]
+        if float(ref.abs().max()) == 0.0:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+        else:
+            assert float((p.grad.cpu().double() - ref).abs().max() / ref.abs().max()) < 1e-4, k
