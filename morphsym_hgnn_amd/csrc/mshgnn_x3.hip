@@ -25,13 +25,15 @@ __device__ __forceinline__ size_t x3_idx(int w, int node, int B) { return ((size
 // k_prep_x3: hi and lo MFMA B-fragment images of every weight pack (root-sum, transpose) + bias sums
 // ------------------------------------------------------------------------------------------------------
 // (many packs: k_prep_tiled<__bf16, true>, mshgnn_device.hpp)
-__global__ void k_prep_x3(PrepArgs a) {
+// output vector `idx` of this launch's pack range (hi and lo images), or (idx past the packs) one bias sum
+__device__ __forceinline__ void prep_one_x3(const PrepArgs& a, int idx, bool with_bias) {
     constexpr int EPC = 8, NBV = 8;
     const int vec_per_pack = H * H / EPC;
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int total = a.n_packs * vec_per_pack;
-    if (gid < total) {
-        const int pack = gid / vec_per_pack, r = gid % vec_per_pack;
+    const int npk = a.pack_n < 0 ? a.n_packs : a.pack_n;
+    const int total = npk * vec_per_pack;
+    if (idx < total) {
+        const int pack = a.pack0 + idx / vec_per_pack, r = idx % vec_per_pack;
+        const int gid = pack * vec_per_pack + r;
         const int lane = r % 64, v = (r / 64) % NBV, wv = r / (64 * NBV);
         const PackDesc pd = a.packs[pack];
         float g[8][EPC];     // up to 8 source matrices (root-sum), every gather issued before the first add
@@ -59,9 +61,9 @@ __global__ void k_prep_x3(PrepArgs a) {
         split_oct(f32x4{sum[0], sum[1], sum[2], sum[3]}, f32x4{sum[4], sum[5], sum[6], sum[7]}, hi, lo);
         u32x4* dst = reinterpret_cast<u32x4*>(a.wpack);
         dst[gid] = hi;
-        dst[(size_t)total + gid] = lo;
-    } else {
-        const int b = gid - total;
+        dst[(size_t)a.n_packs * vec_per_pack + gid] = lo;
+    } else if (with_bias) {
+        const int b = idx - total;
         if (b < a.n_biases * H) {
             const BiasDesc bd = a.biases[b / H];
             float s = 0.f;
@@ -70,6 +72,7 @@ __global__ void k_prep_x3(PrepArgs a) {
         }
     }
 }
+__global__ void k_prep_x3(PrepArgs a) { prep_one_x3(a, blockIdx.x * blockDim.x + threadIdx.x, true); }
 
 // ------------------------------------------------------------------------------------------------------
 // k_enc_x3: X_0[node] = relu((mask . x) W_enc^T + b) from fp32 inputs (hgnn_c2.py:143-147); one workgroup = 64 windows of ONE
@@ -80,6 +83,10 @@ template <bool ALIGNED> __global__ __launch_bounds__(256) void k_enc_x3(EncArgs 
     constexpr int MB = 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if ((int)blockIdx.x >= a.wg_prefix[a.n_types]) {      // a workgroup of the embedded layer-pack prep (EncArgs.prep)
+        if constexpr (ALIGNED) prep_one_x3(a.prep, ((int)blockIdx.x - a.wg_prefix[a.n_types]) * 256 + tid, false);
+        return;
+    }
     int t = 0;
     while (t + 1 < a.n_types && (int)blockIdx.x >= a.wg_prefix[t + 1]) ++t;
     const int local = blockIdx.x - a.wg_prefix[t];
@@ -1036,9 +1043,16 @@ int x3_forward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitc
     const mshgnn_desc& d = hp.d;
     mshgnn_ws_layout lay; layout_workspace(hp, batch, training, &lay);
     const int B = (int)batch;
-    {   // 1. hi / lo weight images
-        PrepArgs a{params, ws + lay.wpack, reinterpret_cast<float*>(ws + lay.bias), p->d_packs, p->d_biases, hp.n_img, (int)hp.biases.size()};
-        const int64_t total = (int64_t)hp.n_img * (H * H / 8) + (int64_t)hp.biases.size() * H;
+    // 1. hi / lo weight images; few packs: only the encoder's packs + biases here, the layer packs under the encoder's tail (as forward_impl of mshgnn.hip)
+    PrepArgs pa{params, ws + lay.wpack, reinterpret_cast<float*>(ws + lay.bias), p->d_packs, p->d_biases, hp.n_img, (int)hp.biases.size()};
+    int enc_pack0 = hp.n_img;
+    for (int t = 0; t < hp.NT; ++t) if (hp.pack_enc_base[t] >= 0) enc_pack0 = std::min(enc_pack0, hp.pack_enc_base[t]);
+    static const bool embed_off = getenv("MSHGNN_PREP_EMBED") && atoi(getenv("MSHGNN_PREP_EMBED")) == 0;
+    const bool embed = !prep_use_tiled(pa.n_packs) && enc_pack0 > 0 && !embed_off;
+    {
+        PrepArgs a = pa;
+        if (embed) { a.pack0 = enc_pack0; a.pack_n = pa.n_packs - enc_pack0; }
+        const int64_t total = (int64_t)(embed ? a.pack_n : a.n_packs) * (H * H / 8) + (int64_t)hp.biases.size() * H;
         ProfScope ps(p, hp.ks_prep, st);
         if (prep_use_tiled(a.n_packs)) hipLaunchKernelGGL((k_prep_tiled<__bf16, true>), dim3(prep_tiled_grid(a.n_packs, a.n_biases)), dim3(256), 0, st, a);
         else hipLaunchKernelGGL(k_prep_x3, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
@@ -1059,9 +1073,18 @@ int x3_forward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitc
         }
         a.wpack = ws + lay.wpack; a.bias = reinterpret_cast<const float*>(ws + lay.bias); a.signs = p->d_signs; a.x0 = ws + lay.x[0];
         a.mask0 = (training && lay.dd[0]) ? reinterpret_cast<uint8_t*>(ws + lay.dd[0]) : nullptr;
+        unsigned enc_grid = (unsigned)a.wg_prefix[hp.NT];
+        if (embed) {
+            PrepArgs lp = pa; lp.pack0 = 0; lp.pack_n = enc_pack0;
+            if (a.aligned) { a.prep = lp; a.prep_vecs = enc_pack0 * (H * H / 8); enc_grid += (unsigned)((a.prep_vecs + 255) / 256); }
+            else {
+                ProfScope ps(p, hp.ks_prep, st);
+                hipLaunchKernelGGL(k_prep_x3, dim3((unsigned)(((int64_t)enc_pack0 * (H * H / 8) + 255) / 256)), dim3(256), 0, st, lp);
+            }
+        }
         ProfScope ps(p, hp.ks_enc, st);
-        if (a.aligned) hipLaunchKernelGGL(k_enc_x3<true>, dim3(a.wg_prefix[hp.NT]), dim3(256), 8 * P16::BLK, st, a, hp.n_img);
-        else hipLaunchKernelGGL(k_enc_x3<false>, dim3(a.wg_prefix[hp.NT]), dim3(256), 8 * P16::BLK, st, a, hp.n_img);
+        if (a.aligned) hipLaunchKernelGGL(k_enc_x3<true>, dim3(enc_grid), dim3(256), 8 * P16::BLK, st, a, hp.n_img);
+        else hipLaunchKernelGGL(k_enc_x3<false>, dim3(enc_grid), dim3(256), 8 * P16::BLK, st, a, hp.n_img);
     }
     {   // 3. all layers + decoder (+ MSE and decoder backward when y_fused)
         StackArgs a{};
