@@ -359,32 +359,43 @@ def module_surface(spec, B, device, steps, warmup, precision):
     return res
 
 
-def end_to_end(spec, B, device, steps, warmup):
+def end_to_end(spec, B, device, steps, warmup, config="a1c2"):
     """Training throughput INCLUDING the data path (never `value`): random window starts -> gather from a resident synthetic sequence ->
     step -> Adam on the flat buffers, all on the device (examples/train_flat.py).  Two routes with identical bits: mshgnn_assemble_windows +
-    mshgnn_step_mse, and mshgnn_step_mse_series (the gather fused into the encoder)."""
+    mshgnn_step_mse / mshgnn_step_ce, and mshgnn_step_mse_series / mshgnn_step_ce_series (the gather fused into the encoder)."""
     import numpy as np
     import torch
     from morphsym_hgnn_amd import engine as eng, synth
-    from morphsym_hgnn_amd.windows import SequenceStore, quadsdk_a1_c2_recipe
+    from morphsym_hgnn_amd.windows import SequenceStore, quadsdk_a1_c2_recipe, minicheetah_k4_recipe
     rows, T = 200_000, 150
     rng = np.random.default_rng(0)
-    seq = {k: rng.standard_normal((rows, c)).astype(np.float32) for k, c in (("imu_acc", 3), ("imu_omega", 3), ("q", 12), ("qd", 12), ("tau", 12), ("F", 12), ("r_o", 4))}
-    store = SequenceStore(seq, quadsdk_a1_c2_recipe(range(12), range(4), T, 3), dtype="bf16", device=device)
+    ce = config == "mck4"
+    if ce:      # MiniCheetah contact data format: labels = the contact flags of the window's last step
+        seq = {k: rng.standard_normal((rows, c)).astype(np.float32) for k, c in (("imu_acc", 3), ("imu_omega", 3), ("q", 12), ("qd", 12), ("p", 12), ("v", 12))}
+        seq["contacts"] = (rng.random((rows, 4)) < 0.5).astype(np.float32)
+        recipe = minicheetah_k4_recipe(range(12), range(4), T)
+    else:
+        seq = {k: rng.standard_normal((rows, c)).astype(np.float32) for k, c in (("imu_acc", 3), ("imu_omega", 3), ("q", 12), ("qd", 12), ("tau", 12), ("F", 12), ("r_o", 4))}
+        recipe = quadsdk_a1_c2_recipe(range(12), range(4), T, 3)
+    store = SequenceStore(seq, recipe, dtype="bf16", device=device)
     e = eng.Engine(spec, dtype="bf16", device=device)
     flat = eng.flatten_params(spec, synth.make_params(0, spec.param_shapes()), device)
     gflat, m, v = torch.empty_like(flat), torch.zeros_like(flat), torch.zeros_like(flat)
-    out = torch.empty(B * 4, 3, dtype=torch.float32, device=device); loss = torch.empty(1, dtype=torch.float32, device=device)
+    out = torch.empty(B * 4, spec.out_channels, dtype=torch.float32, device=device); loss = torch.empty(1, dtype=torch.float32, device=device)
     gen = torch.Generator(device=device).manual_seed(7)
-    res = {"what": f"random starts -> window gather from a resident {rows}-step sequence -> fwd + MSE + bwd -> Adam, {B} windows/step, bf16 plan"}
+    res = {"what": f"random starts -> window gather from a resident {rows}-step sequence -> fwd + {'cross entropy' if ce else 'MSE'} + bwd -> Adam, "
+                   f"{B} windows/step, bf16 plan"}
     for name, fused in (("assemble_then_step", False), ("fused_gather", True)):
         def step(i):
             starts = torch.randint(0, len(store), (B,), generator=gen, device=device)
             if fused:
-                e.step_mse_series(store, starts, flat, out=out, grad_flat=gflat, loss=loss)
+                (e.step_ce_series if ce else e.step_mse_series)(store, starts, flat, out=out, grad_flat=gflat, loss=loss)
             else:
                 xs, y, _ = store.assemble(starts, reuse_buffers=True)
-                e.step_mse(xs, flat, y.view(-1), B, out=out, grad_flat=gflat, loss=loss)
+                if ce:
+                    e.step_ce(xs, flat, (y != 0).to(torch.int32).view(B, -1), B, out=out, grad_flat=gflat, loss=loss)
+                else:
+                    e.step_mse(xs, flat, y.view(-1), B, out=out, grad_flat=gflat, loss=loss)
             e.adam_step(flat, gflat, m, v, i + 1, 1e-4)
         for i in range(warmup):
             step(i)
@@ -496,6 +507,10 @@ def main():
         "loss": loss,
     }
     extras = rank == 0 and world == 1 and not args.no_extras and args.config == "a1c2" and args.surface == "flat" and hidden == 128
+    if rank == 0 and world == 1 and not args.no_extras and args.config == "mck4" and args.dtype == "bf16" and args.surface == "flat" and hidden == 128:
+        del wl
+        torch.cuda.empty_cache()
+        res["end_to_end"] = end_to_end(spec, B, device, args.steps, args.warmup, "mck4")
     if extras:
         del wl      # free the 0.6 GB workspace before the side measurements
         torch.cuda.empty_cache()

@@ -275,6 +275,13 @@ int mshgnn_step_mse_series(const mshgnn_plan* plan, const mshgnn_window_desc* de
                            void* const* x_out, const int64_t* x_pitch, float* y_out, float* quat_out, void* run_ptrs,
                            const float* params, float* out, float* loss_out, float* grad_params, void* workspace, void* stream);
 
+/* The same for the classification wrappers (mshgnn_step_ce): labels_out (device int32 [batch][n_out]) receives the window labels != 0 (the
+ * contact flags of the window's last step), y_out the float label rows.                                                                         */
+int mshgnn_step_ce_series(const mshgnn_plan* plan, const mshgnn_window_desc* desc, const float* const* src, const void* const* src_bf16,
+                          const int64_t* src_cstride, const int64_t* src_rows, const int64_t* starts, int64_t batch,
+                          void* const* x_out, const int64_t* x_pitch, float* y_out, int32_t* labels_out, void* run_ptrs,
+                          const float* params, float* out, float* loss_out, float* grad_params, void* workspace, void* stream);
+
 /* ---- stand-alone operators behind the four torch_geometric.nn names ----------------------------------
  * For a maintainer who swaps only the PyG import (hgnn_c2.py:3): Linear / HeteroDictLinear (hgnn_c2.py:88,131), GraphConv
  * (hgnn_c2.py:100-112) and their autograd backward on arbitrary graphs and widths, fp32 operands, fp32 MFMA, no float atomics.

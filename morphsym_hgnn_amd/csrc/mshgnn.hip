@@ -2915,12 +2915,18 @@ __global__ void k_series_run_ptrs(const int* runs, int n_runs, WindowArgs a, uns
     out[r] = p;
 }
 
-extern "C" int mshgnn_step_mse_series(const mshgnn_plan* p, const mshgnn_window_desc* d, const float* const* src, const void* const* src_bf16,
-                                      const int64_t* src_cstride, const int64_t* src_rows, const int64_t* starts, int64_t batch,
-                                      void* const* x_out, const int64_t* x_pitch, float* y_out, float* quat_out, void* run_ptrs,
-                                      const float* params, float* out, float* loss_out, float* grad_params, void* workspace, void* stream) {
+__global__ void k_labels_to_int(const float* y, int32_t* lab, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) lab[i] = y[i] != 0.f;
+}
+
+static int step_series(const mshgnn_plan* p, const mshgnn_window_desc* d, const float* const* src, const void* const* src_bf16,
+                       const int64_t* src_cstride, const int64_t* src_rows, const int64_t* starts, int64_t batch,
+                       void* const* x_out, const int64_t* x_pitch, float* y_out, float* quat_out, void* run_ptrs,
+                       const float* params, float* out, float* loss_out, float* grad_params, void* workspace, void* stream, int32_t* labels_out) {
+    const bool ce = labels_out != nullptr;      // classification wrappers: cross entropy over the per-foot logit pairs, labels = the window labels != 0
     if (!p || !d || !src || !src_bf16 || !src_cstride || !src_rows || !starts || !y_out || !run_ptrs || !params || !out || !loss_out ||
-        !grad_params || !workspace || (x_out && !x_pitch)) return set_err(MSHGNN_EINVAL, "null argument to mshgnn_step_mse_series");
+        !grad_params || !workspace || (x_out && !x_pitch)) return set_err(MSHGNN_EINVAL, "null argument to mshgnn_step_mse_series / mshgnn_step_ce_series");
     if (batch < 1 || batch > (1 << 24)) return set_err(MSHGNN_EINVAL, "batch must be in [1, 2^24]");
     if (p->gen || p->hp.d.dtype != MSHGNN_BF16 || !p->use_fused)
         return set_err(MSHGNN_EUNSUPPORTED, "mshgnn_step_mse_series runs on the bf16 plan with the fused stack kernels; use mshgnn_assemble_windows + mshgnn_step_mse");
@@ -2935,7 +2941,8 @@ extern "C" int mshgnn_step_mse_series(const mshgnn_plan* p, const mshgnn_window_
         n_rows += d->type_nodes[t];
     }
     if (n_rows != d->n_rows) return set_err(MSHGNN_EINVAL, "window recipe: one node row per node expected");
-    if (d->n_label != md.type_nodes[md.out_type] * md.out_channels) return set_err(MSHGNN_EINVAL, "window recipe: label count differs from the model's outputs");
+    if (d->n_label != md.type_nodes[md.out_type] * (ce ? 1 : md.out_channels)) return set_err(MSHGNN_EINVAL, "window recipe: label count differs from the model's outputs");
+    if (ce && md.out_channels != 2) return set_err(MSHGNN_EINVAL, "mshgnn_step_ce_series: the classification wrappers have two logits per foot");
     WindowArgs wa{};
     for (int i = 0; i < d->n_src; ++i) {
         // (the bf16 copies need 8 elements of slack behind every column: a chunk's 16-byte load may run past the window's last step)
@@ -2954,9 +2961,27 @@ extern "C" int mshgnn_step_mse_series(const mshgnn_plan* p, const mshgnn_window_
     SeriesSrc ser{};
     ser.run_ptr = reinterpret_cast<const unsigned long long*>(run_ptrs); ser.rows = d->rows; ser.starts = starts; ser.T = d->history;
     { int r0 = 0; for (int t = 0; t < d->n_types; ++t) { ser.row0[t] = r0; r0 += d->type_nodes[t]; } }
-    int rc = forward_impl<__bf16>(p, x_out, x_pitch, params, out, (char*)workspace, batch, 1, st, y_out, &ser);
+    if (ce) hipLaunchKernelGGL(k_labels_to_int, dim3((unsigned)((batch * d->n_label + 255) / 256)), dim3(256), 0, st, y_out, labels_out, batch * d->n_label);
+    int rc = forward_impl<__bf16>(p, x_out, x_pitch, params, out, (char*)workspace, batch, 1, st, ce ? nullptr : y_out, &ser, ce ? labels_out : nullptr);
     if (rc) return rc;
     // x_out == NULL: no materialised windows at all -- the weight-gradient kernel gathers its raw-input operands from the series as well
-    return backward_impl<__bf16>(p, x_out, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, st, out, y_out, loss_out, nullptr, true, -1,
-                                 x_out ? nullptr : &ser);
+    return backward_impl<__bf16>(p, x_out, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, st, out, ce ? nullptr : y_out, loss_out,
+                                 ce ? labels_out : nullptr, true, -1, x_out ? nullptr : &ser);
+}
+
+extern "C" int mshgnn_step_mse_series(const mshgnn_plan* p, const mshgnn_window_desc* d, const float* const* src, const void* const* src_bf16,
+                                      const int64_t* src_cstride, const int64_t* src_rows, const int64_t* starts, int64_t batch,
+                                      void* const* x_out, const int64_t* x_pitch, float* y_out, float* quat_out, void* run_ptrs,
+                                      const float* params, float* out, float* loss_out, float* grad_params, void* workspace, void* stream) {
+    return step_series(p, d, src, src_bf16, src_cstride, src_rows, starts, batch, x_out, x_pitch, y_out, quat_out, run_ptrs, params, out, loss_out, grad_params,
+                       workspace, stream, nullptr);
+}
+
+extern "C" int mshgnn_step_ce_series(const mshgnn_plan* p, const mshgnn_window_desc* d, const float* const* src, const void* const* src_bf16,
+                                     const int64_t* src_cstride, const int64_t* src_rows, const int64_t* starts, int64_t batch,
+                                     void* const* x_out, const int64_t* x_pitch, float* y_out, int32_t* labels_out, void* run_ptrs,
+                                     const float* params, float* out, float* loss_out, float* grad_params, void* workspace, void* stream) {
+    if (!labels_out) return set_err(MSHGNN_EINVAL, "null argument to mshgnn_step_ce_series");
+    return step_series(p, d, src, src_bf16, src_cstride, src_rows, starts, batch, x_out, x_pitch, y_out, nullptr, run_ptrs, params, out, loss_out, grad_params,
+                       workspace, stream, labels_out);
 }

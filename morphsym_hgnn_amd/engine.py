@@ -80,7 +80,7 @@ EXPORTS = [
     "mshgnn_profile_enable", "mshgnn_profile_read", "mshgnn_backward_mse", "mshgnn_adam_step",
     "mshgnn_metrics_regression", "mshgnn_metrics_classification", "mshgnn_grf_body_to_world", "mshgnn_assemble_windows",
     "mshgnn_backward_ce", "mshgnn_step_mse", "mshgnn_step_mse_phase",
-    "mshgnn_step_mse_series", "mshgnn_step_ce", "mshgnn_op_gemm", "mshgnn_op_gemm_workspace", "mshgnn_op_aggregate", "mshgnn_op_colsum", "mshgnn_op_colsum_workspace",
+    "mshgnn_step_mse_series", "mshgnn_step_ce_series", "mshgnn_step_ce", "mshgnn_op_gemm", "mshgnn_op_gemm_workspace", "mshgnn_op_aggregate", "mshgnn_op_colsum", "mshgnn_op_colsum_workspace",
 ]
 
 _lib = None
@@ -140,6 +140,7 @@ def load_library():
     lib.mshgnn_step_mse_series.argtypes = [C.c_void_p, C.POINTER(MshgnnWindowDesc), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
                                            C.POINTER(C.c_int64), C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.mshgnn_step_ce_series.argtypes = list(lib.mshgnn_step_mse_series.argtypes)
     lib.mshgnn_op_gemm_workspace.restype = C.c_int64
     lib.mshgnn_op_gemm_workspace.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int32)]
     lib.mshgnn_op_gemm.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
@@ -458,6 +459,13 @@ class Engine:
                                                  grad_flat.data_ptr(), ws.data_ptr(), B, stream), "mshgnn_step_ce")
         return out, loss, grad_flat
 
+    def step_ce_series(self, store, starts: torch.Tensor, params_flat: torch.Tensor, out: Optional[torch.Tensor] = None,
+                       grad_flat: Optional[torch.Tensor] = None, loss: Optional[torch.Tensor] = None, materialize: bool = True):
+        """`step_mse_series` for the classification wrappers (mshgnn_step_ce_series): the labels are the contact flags of each window's last
+        step, cross entropy over the per-foot logit pairs.  Returns (xs | None, labels int32 [B, n_out], out, loss[1], grad_flat) -- bit-identical
+        to `store.assemble(starts)` followed by `step_ce`."""
+        return self._step_series(True, store, starts, params_flat, out, grad_flat, loss, materialize)
+
     def step_mse_series(self, store, starts: torch.Tensor, params_flat: torch.Tensor, out: Optional[torch.Tensor] = None,
                         grad_flat: Optional[torch.Tensor] = None, loss: Optional[torch.Tensor] = None, materialize: bool = True):
         """One training step straight from a `windows.SequenceStore` (mshgnn_step_mse_series): the encoder gathers its raw inputs from the
@@ -466,6 +474,9 @@ class Engine:
         measured slower: its random 256-byte gathers stretch the raw-input lanes' steps, 0.385 vs 0.557 ms/step).  starts: device int64 window
         start rows.  Returns (xs | None, y, out, loss[1], grad_flat) -- bit-identical to `store.assemble(starts)` followed by `step_mse`.
         bf16 plan with the fused stack kernels."""
+        return self._step_series(False, store, starts, params_flat, out, grad_flat, loss, materialize)
+
+    def _step_series(self, ce: bool, store, starts, params_flat, out, grad_flat, loss, materialize):
         self._check_flat(params_flat, "params_flat")
         if not starts.is_cuda or starts.dtype != torch.int64:
             raise ValueError("starts must be a device int64 tensor")
@@ -489,6 +500,13 @@ class Engine:
         self._tickets[B] = self._tickets.get(B, 0) + 1
         stream = torch.cuda.current_stream(self.device).cuda_stream
         with torch.cuda.device(self.device):
+            if ce:
+                labels = torch.empty(B, self.n_out, dtype=torch.int32, device=self.device)
+                _check(self.lib, self.lib.mshgnn_step_ce_series(self._plan, C.byref(store.desc), store._src, src16, store._pitch, store._rows, starts.data_ptr(), B,
+                                                            xp, pitch, y.data_ptr(), labels.data_ptr(), run_ptrs.data_ptr(),
+                                                            params_flat.data_ptr(), out.data_ptr(), loss.data_ptr(), grad_flat.data_ptr(), ws.data_ptr(), stream),
+                       "mshgnn_step_ce_series")
+                return xs, labels, out, loss, grad_flat
             _check(self.lib, self.lib.mshgnn_step_mse_series(self._plan, C.byref(store.desc), store._src, src16, store._pitch, store._rows, starts.data_ptr(), B,
                                                          xp, pitch, y.data_ptr(), q.data_ptr() if q is not None else None, run_ptrs.data_ptr(),
                                                          params_flat.data_ptr(), out.data_ptr(), loss.data_ptr(), grad_flat.data_ptr(), ws.data_ptr(), stream),

@@ -203,6 +203,40 @@ def test_series_step_is_bit_identical_to_assemble_then_step(recipe_name, B):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B", [3, 130, 1000])
+def test_classification_series_step_is_bit_identical_to_assemble_then_step_ce(B):
+    """MiniCheetah-K4 contact classification straight from the sequence (mshgnn_step_ce_series): labels = the contact flags of each window's
+    last step; same bits as mshgnn_assemble_windows + mshgnn_step_ce, with and without materialised windows."""
+    from morphsym_hgnn_amd import engine as eng, synth
+    from morphsym_hgnn_amd.windows import SequenceStore, minicheetah_k4_recipe
+    from tests import helpers
+    seq, n = dict(SEQ4), int(FX4["N"])
+    recipe = minicheetah_k4_recipe(JP, FP, T)
+    spec = helpers.make_spec("k4", "mini_cheetah-k4", "mini_cheetah-k4", 128, 3, regression=False)
+    store = SequenceStore(seq, recipe, dtype="bf16")
+    e = eng.Engine(spec, "bf16")
+    starts = torch.randint(0, n - T + 1, (B,), generator=torch.Generator().manual_seed(B))
+    starts[0], starts[-1] = 0, n - T
+    starts = starts.cuda()
+    flat = eng.flatten_params(spec, synth.make_params(8, spec.param_shapes()), e.device)
+    xs, y, _ = store.assemble(starts)
+    xs = [x.clone() for x in xs]
+    lab = (y != 0).to(torch.int32).reshape(B, 4).contiguous()
+    assert 0 < int(lab.sum()) < lab.numel()
+    out_a, loss_a, g_a = e.step_ce(xs, flat, lab, B)
+    out_a, loss_a, g_a = out_a.clone(), loss_a.clone(), g_a.clone()
+    for mat in (True, False):
+        xs2, lab2, out_b, loss_b, g_b = e.step_ce_series(store, starts, flat, materialize=mat)
+        torch.cuda.synchronize()
+        if mat:
+            assert all(torch.equal(a, b) for a, b in zip(xs, xs2))
+        assert torch.equal(lab, lab2) and torch.equal(out_a, out_b) and torch.equal(loss_a, loss_b) and torch.equal(g_a, g_b)
+    # a regression plan refuses the classification entry point and the other way round
+    with pytest.raises(eng.MshgnnError):
+        e.step_mse_series(store, starts, flat)
+
+
+@pytest.mark.gpu
 def test_series_step_refuses_what_it_cannot_run():
     """mshgnn_step_mse_series is a bf16-plan route: other plans, standardised recipes and recipes whose node types differ from the plan's are
     refused with an error (the caller assembles windows and calls mshgnn_step_mse instead) -- never a silent fallback."""
