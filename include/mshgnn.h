@@ -214,10 +214,15 @@ int mshgnn_adam_step(float* params, const float* grads, float* exp_avg, float* e
  * grad_out = 2 (out - y) / n.  loss_out: device float[1].                                               */
 int mshgnn_mse_loss(const float* out, const float* y, int64_t n, float* loss_out, float* grad_out, void* stream);
 
+/* Loss of the classification wrappers (gnnLightning.py:640-648, customMetrics.py:6-25): mean cross entropy over `rows` per-foot logit
+ * pairs (logits [rows][2], labels int32 [rows], nonzero = stable contact) and grad_out [rows][2] = (softmax - onehot) / rows
+ * (NULL: loss only).  loss_out: device float[1].                                                                                  */
+int mshgnn_ce_loss(const float* logits, const int32_t* labels, int64_t rows, float* loss_out, float* grad_out, void* stream);
+
 /* ---- step metrics of the Lightning wrappers ------------------------------------------
  * The reference's torchmetrics states are plain sums across steps (gnnLightning.py:52-63, customMetrics.py:11-54); each
  * call ADDS one step's sums into caller-owned device state (zero it to start an epoch / to get step values).  Math in
- * fp64, one workgroup with a fixed reduction order (bit-reproducible).
+ * fp64, a fixed reduction order (bit-reproducible).
  *
  * regression (calculate_losses_step, gnnLightning.py:124-130 / :633-639): state double[3]:
  *   [0] += sum (y_pred - y)^2   [1] += sum |y_pred - y|   [2] += n        => MSE = [0]/[2], RMSE = sqrt(MSE), L1 = [1]/[2] */
@@ -229,6 +234,19 @@ int mshgnn_metrics_regression(const float* y_pred, const float* y, int64_t n, do
  *   state 8 y0 + 4 y1 + 2 y2 + y3, [2 + 4k .. 5 + 4k] += tp, fp, fn, tn of leg k (BinaryF1Score, customMetrics.py:26-54). */
 int mshgnn_metrics_classification(const float* logits, const int32_t* y, int64_t batch, double* ce_state, int64_t* counts,
                                   void* stream);
+
+/* The same sums for one training / validation step in ONE multi-workgroup launch (what a wrapper's calculate_losses_step needs every step):
+ * batch_* (nullable as a pair) receive this step's sums (overwritten -- no zeroing; batch_state / batch_ce are double[4]: the sums
+ * followed by the step's loss itself, batch_state[3] = MSE, batch_ce[2] = cross entropy), epoch_* (nullable as a pair) have them added, and grad_out (nullable) receives the gradient of the step's loss with respect to the predictions -- what
+ * `training_step` returns for backward (gnnLightning.py:709-722): regression d MSE / d y_pred = 2 (y_pred - y) / n, fp32 [n];
+ * classification d CE / d logits = (softmax - onehot) / (4 batch), fp32 [batch*4][2].  scratch: MSHGNN_METRICS_SCRATCH_BYTES of device
+ * memory, 8-byte aligned, zeroed ONCE by the caller and then owned by these calls (per-workgroup partials + a ticket the kernel resets;
+ * the partials are added in workgroup order: bit-reproducible); one scratch per stream.                                                  */
+#define MSHGNN_METRICS_SCRATCH_BYTES 16384
+int mshgnn_metrics_regression_step(const float* y_pred, const float* y, int64_t n, double* batch_state, double* epoch_state,
+                                   float* grad_out, void* scratch, void* stream);
+int mshgnn_metrics_classification_step(const float* logits, const int32_t* y, int64_t batch, double* batch_ce, int64_t* batch_counts,
+                                       double* epoch_ce, int64_t* epoch_counts, float* grad_out, void* scratch, void* stream);
 
 /* body_frame_to_world_frame (gnnLightning.py:663-676) without the per-step CPU/scipy round trip: quat fp32 [batch][4] is
  * the world->body rotation, scalar-last (x, y, z, w) as scipy.Rotation.from_quat takes it; grf fp32 [batch][4][3].       */

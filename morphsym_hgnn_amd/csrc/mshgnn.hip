@@ -2517,6 +2517,40 @@ extern "C" int mshgnn_mse_loss(const float* out, const float* y, int64_t n, floa
     return MSHGNN_OK;
 }
 
+// Stand-alone contact cross entropy of the classification wrappers (gnnLightning.py:640-648, customMetrics.py:6-25: CrossEntropyLoss over
+// the [rows, 2] per-foot logits, batch value = sum / rows) with its gradient (softmax - onehot) / rows.  One thread per row.
+__global__ void k_ce(const float* logits, const int32_t* labels, int64_t rows, float* loss, float* gout) {
+    __shared__ float red[4];
+    float s = 0.f;
+    const float inv = 1.0f / (float)rows;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
+        const float l0 = logits[2 * r], l1 = logits[2 * r + 1];
+        const float m = fmaxf(l0, l1);
+        const float e0 = expf(l0 - m), e1 = expf(l1 - m), z = e0 + e1;
+        const int lab = labels[r] != 0;
+        s += logf(z) + m - (lab ? l1 : l0);
+        if (gout) {
+            gout[2 * r] = (e0 / z - (lab ? 0.f : 1.f)) * inv;
+            gout[2 * r + 1] = (e1 / z - (lab ? 1.f : 0.f)) * inv;
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv);
+}
+
+extern "C" int mshgnn_ce_loss(const float* logits, const int32_t* labels, int64_t rows, float* loss_out, float* grad_out, void* stream) {
+    if (!logits || !labels || !loss_out || rows < 1) return set_err(MSHGNN_EINVAL, "bad argument to mshgnn_ce_loss");
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipMemsetAsync(loss_out, 0, sizeof(float), st));
+    const int blocks = (int)std::min<int64_t>((rows + 255) / 256, 1024);
+    hipLaunchKernelGGL(k_ce, dim3(blocks), dim3(256), 0, st, logits, labels, rows, loss_out, grad_out);
+    HIPCHK(hipGetLastError());
+    return MSHGNN_OK;
+}
+
 // ------------------------------------------------------------------------------------------------------
 // Step metrics of the Lightning wrappers, on device.  The reference keeps
 // torchmetrics states that are plain sums across steps (gnnLightning.py:52-63, customMetrics.py:11-54); these kernels
@@ -2533,21 +2567,69 @@ __device__ __forceinline__ long long wave_sum(long long v) {
     return v;
 }
 
-// regression (calculate_losses_step, gnnLightning.py:124-130): state[0] += sum (pred - y)^2, state[1] += sum |pred - y|, state[2] += n
-__global__ __launch_bounds__(1024) void k_metrics_reg(const float* pred, const float* y, int64_t n, double* state) {
-    __shared__ double r0[16], r1[16];
+// Both kernels run on up to MET_BLOCKS workgroups: every workgroup leaves its partial sums in the caller's scratch, takes a ticket, and the
+// workgroup that draws the last ticket adds the partials IN INDEX ORDER (bit-reproducible whatever the arrival order) and resets the
+// ticket.  The one-workgroup entry points (mshgnn_metrics_regression / _classification, no scratch) run the same kernels with one block.
+constexpr int MET_COUNTS = 18, MET_BLOCKS = 64, MET_THREADS = 256;
+struct MetScratch {
+    unsigned int ticket, pad;
+    double f[MET_BLOCKS][2];
+    long long c[MET_BLOCKS][MET_COUNTS];
+};
+static_assert(sizeof(MetScratch) <= MSHGNN_METRICS_SCRATCH_BYTES, "include/mshgnn.h promises this scratch size");
+
+__device__ __forceinline__ void met_store(double* p, double v) { __hip_atomic_store(reinterpret_cast<long long*>(p), __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double met_load(const double* p) { return __longlong_as_double(__hip_atomic_load(reinterpret_cast<const long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+__device__ __forceinline__ void met_store(long long* p, long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ long long met_load(const long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// thread 0 of every workgroup, after its partials are stored: true in the workgroup that arrives last (sc == nullptr: a one-block launch)
+__device__ __forceinline__ bool met_last_block(MetScratch* sc) {
+    if (!sc) return true;
+    __atomic_thread_fence(__ATOMIC_RELEASE);        // (agent scope: the partials reach memory every XCD's L2 sees)
+    const unsigned int t = __hip_atomic_fetch_add(&sc->ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (t != gridDim.x - 1) return false;
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return true;
+}
+
+// regression (calculate_losses_step, gnnLightning.py:124-130): sums of (pred - y)^2, |pred - y| and n; `batch` (nullable) receives this
+// step's sums (overwritten), `epoch` (nullable) has them added; gout (nullable) = d mean((pred - y)^2) / d pred = 2 (pred - y) / n
+__global__ __launch_bounds__(MET_THREADS) void k_metrics_reg(const float* pred, const float* y, int64_t n, double* batch, double* epoch, float* gout,
+                                                             MetScratch* sc) {
+    __shared__ double r0[MET_THREADS / 64], r1[MET_THREADS / 64], pf[MET_BLOCKS][2];
+    __shared__ int s_last;
     double s = 0.0, a = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    const double inv2 = 2.0 / (double)n;
+    for (int64_t i = (int64_t)blockIdx.x * MET_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * MET_THREADS) {
         const double dlt = (double)pred[i] - (double)y[i];
         s += dlt * dlt; a += fabs(dlt);
+        if (gout) gout[i] = (float)(dlt * inv2);
     }
     s = wave_sum(s); a = wave_sum(a);
     if ((threadIdx.x & 63) == 0) { r0[threadIdx.x >> 6] = s; r1[threadIdx.x >> 6] = a; }
     __syncthreads();
+    double ts = 0.0, ta = 0.0;
     if (threadIdx.x == 0) {
-        double ts = 0.0, ta = 0.0;
-        for (int k = 0; k < 16; ++k) { ts += r0[k]; ta += r1[k]; }
-        state[0] += ts; state[1] += ta; state[2] += (double)n;
+        for (int k = 0; k < MET_THREADS / 64; ++k) { ts += r0[k]; ta += r1[k]; }
+        if (sc) { met_store(&sc->f[blockIdx.x][0], ts); met_store(&sc->f[blockIdx.x][1], ta); }
+        s_last = met_last_block(sc) ? 1 : 0;
+    }
+    if (sc) {
+        __syncthreads();
+        if (!s_last) return;
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        // the last workgroup: one partial per thread (all loads in flight at once), then thread 0 adds them in workgroup order
+        if (threadIdx.x < gridDim.x) { pf[threadIdx.x][0] = met_load(&sc->f[threadIdx.x][0]); pf[threadIdx.x][1] = met_load(&sc->f[threadIdx.x][1]); }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            ts = ta = 0.0;
+            for (unsigned b = 0; b < gridDim.x; ++b) { ts += pf[b][0]; ta += pf[b][1]; }
+            __hip_atomic_store(&sc->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (threadIdx.x == 0) {
+        if (batch) { batch[0] = ts; batch[1] = ta; batch[2] = (double)n; batch[3] = ts / (double)n; }      // [3]: this step's MSE
+        if (epoch) { epoch[0] += ts; epoch[1] += ta; epoch[2] += (double)n; }
     }
 }
 
@@ -2556,15 +2638,19 @@ __global__ __launch_bounds__(1024) void k_metrics_reg(const float* pred, const f
 //   counts[0] += B, counts[1] += windows whose 16-class argmax equals the label state       (Accuracy, 16 classes)
 //   counts[2 + 4 k + {0,1,2,3}] += tp, fp, fn, tn of leg k                                   (BinaryF1Score)
 // The 16-class probabilities are the reference's products (p or 1 - p per foot, ((f0 f1)(f2 f3)), first maximum wins).
-constexpr int MET_COUNTS = 18;
-__global__ __launch_bounds__(1024) void k_metrics_cls(const float* logits, const int32_t* y, int64_t B, double* ce_state, long long* counts) {
-    __shared__ double rce[16];
-    __shared__ long long rc[16][MET_COUNTS];
+// ce_b / counts_b (nullable): this step's sums, overwritten; ce_state / counts (nullable): added into; gout (nullable) [B*4][2] = d ce / d logits
+// = (softmax - onehot) / (4 B)
+__global__ __launch_bounds__(MET_THREADS) void k_metrics_cls(const float* logits, const int32_t* y, int64_t B, double* ce_b, long long* counts_b,
+                                                             double* ce_state, long long* counts, float* gout, MetScratch* sc) {
+    __shared__ double rce[MET_THREADS / 64];
+    __shared__ long long rc[MET_THREADS / 64][MET_COUNTS], pc[MET_BLOCKS][MET_COUNTS];
+    __shared__ double pce[MET_BLOCKS];
+    __shared__ int s_last;
     double ce = 0.0;
     long long c[MET_COUNTS];
 #pragma unroll
     for (int k = 0; k < MET_COUNTS; ++k) c[k] = 0;
-    for (int64_t w = threadIdx.x; w < B; w += 1024) {
+    for (int64_t w = (int64_t)blockIdx.x * MET_THREADS + threadIdx.x; w < B; w += (int64_t)gridDim.x * MET_THREADS) {
         double p1[4];
         int state = 0;
 #pragma unroll
@@ -2574,6 +2660,11 @@ __global__ __launch_bounds__(1024) void k_metrics_cls(const float* logits, const
             const int lab = y[w * 4 + k] != 0;
             ce += (m + log(se)) - (lab ? l1 : l0);
             const double p0 = e0 / se; p1[k] = e1 / se;
+            if (gout) {
+                const double inv = 1.0 / (double)(4 * B);
+                gout[(w * 4 + k) * 2] = (float)((p0 - (lab ? 0.0 : 1.0)) * inv);
+                gout[(w * 4 + k) * 2 + 1] = (float)((p1[k] - (lab ? 1.0 : 0.0)) * inv);
+            }
             const int pred = p1[k] > p0 ? 1 : 0;             // argmax over (p0, p1): the first maximum wins
             c[2 + 4 * k + (pred ? (lab ? 0 : 1) : (lab ? 2 : 3))] += 1;
             state = state * 2 + lab;
@@ -2597,15 +2688,37 @@ __global__ __launch_bounds__(1024) void k_metrics_cls(const float* logits, const
         for (int k = 0; k < MET_COUNTS; ++k) rc[threadIdx.x >> 6][k] = c[k];
     }
     __syncthreads();
+    // this workgroup's sums: thread 0 the cross entropy, threads 0..17 one count each
+    double tce = 0.0; long long tc = 0;
+    if (threadIdx.x == 0) for (int k = 0; k < MET_THREADS / 64; ++k) tce += rce[k];
+    if (threadIdx.x < MET_COUNTS) for (int k = 0; k < MET_THREADS / 64; ++k) tc += rc[k][threadIdx.x];
+    if (sc) {
+        if (threadIdx.x == 0) met_store(&sc->f[blockIdx.x][0], tce);
+        if (threadIdx.x < MET_COUNTS) met_store(&sc->c[blockIdx.x][threadIdx.x], tc);
+        __syncthreads();                                    // every partial of this workgroup is stored before thread 0 takes the ticket
+        if (threadIdx.x == 0) s_last = met_last_block(sc) ? 1 : 0;
+        __syncthreads();
+        if (!s_last) return;
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        // the last workgroup: thread b fetches workgroup b's partials (all loads in flight at once), then one thread per sum adds them in workgroup order
+        if (threadIdx.x < gridDim.x) {
+            pce[threadIdx.x] = met_load(&sc->f[threadIdx.x][0]);
+#pragma unroll
+            for (int k = 0; k < MET_COUNTS; ++k) pc[threadIdx.x][k] = met_load(&sc->c[threadIdx.x][k]);
+        }
+        __syncthreads();
+        tce = 0.0; tc = 0;
+        if (threadIdx.x == 0) for (unsigned b = 0; b < gridDim.x; ++b) tce += pce[b];
+        if (threadIdx.x < MET_COUNTS) for (unsigned b = 0; b < gridDim.x; ++b) tc += pc[b][threadIdx.x];
+        if (threadIdx.x == 0) __hip_atomic_store(&sc->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int k = 0; k < 16; ++k) t += rce[k];
-        ce_state[0] += t; ce_state[1] += (double)(4 * B);
+        if (ce_b) { ce_b[0] = tce; ce_b[1] = (double)(4 * B); ce_b[2] = (double)(float)tce / (double)(4 * B); ce_b[3] = 0.0; }      // [2]: this step's CE, `summed_loss.float() / total_num` (customMetrics.py:24)
+        if (ce_state) { ce_state[0] += tce; ce_state[1] += (double)(4 * B); }
     }
     if (threadIdx.x < MET_COUNTS) {
-        long long t = 0;
-        for (int k = 0; k < 16; ++k) t += rc[k][threadIdx.x];
-        counts[threadIdx.x] += t;
+        if (counts_b) counts_b[threadIdx.x] = tc;
+        if (counts) counts[threadIdx.x] += tc;
     }
 }
 
@@ -2628,16 +2741,41 @@ __global__ void k_grf_to_world(const float* quat, const float* body, float* worl
     }
 }
 
+static int met_blocks(int64_t items, int per_thread) {
+    return (int)std::max<int64_t>(1, std::min<int64_t>(MET_BLOCKS, (items + per_thread * MET_THREADS - 1) / (per_thread * MET_THREADS)));
+}
+
 extern "C" int mshgnn_metrics_regression(const float* y_pred, const float* y, int64_t n, double* state, void* stream) {
     if (!y_pred || !y || !state || n < 1) return set_err(MSHGNN_EINVAL, "bad argument to mshgnn_metrics_regression");
-    hipLaunchKernelGGL(k_metrics_reg, dim3(1), dim3(1024), 0, (hipStream_t)stream, y_pred, y, n, state);
+    hipLaunchKernelGGL(k_metrics_reg, dim3(1), dim3(MET_THREADS), 0, (hipStream_t)stream, y_pred, y, n, (double*)nullptr, state, (float*)nullptr, (MetScratch*)nullptr);
+    HIPCHK(hipGetLastError());
+    return MSHGNN_OK;
+}
+
+extern "C" int mshgnn_metrics_regression_step(const float* y_pred, const float* y, int64_t n, double* batch_state, double* epoch_state, float* grad_out,
+                                              void* scratch, void* stream) {
+    if (!y_pred || !y || (!batch_state && !epoch_state) || !scratch || n < 1) return set_err(MSHGNN_EINVAL, "bad argument to mshgnn_metrics_regression_step");
+    hipLaunchKernelGGL(k_metrics_reg, dim3(met_blocks(n, 16)), dim3(MET_THREADS), 0, (hipStream_t)stream, y_pred, y, n, batch_state, epoch_state, grad_out,
+                       reinterpret_cast<MetScratch*>(scratch));
     HIPCHK(hipGetLastError());
     return MSHGNN_OK;
 }
 
 extern "C" int mshgnn_metrics_classification(const float* logits, const int32_t* y, int64_t batch, double* ce_state, int64_t* counts, void* stream) {
     if (!logits || !y || !ce_state || !counts || batch < 1) return set_err(MSHGNN_EINVAL, "bad argument to mshgnn_metrics_classification");
-    hipLaunchKernelGGL(k_metrics_cls, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, y, batch, ce_state, reinterpret_cast<long long*>(counts));
+    hipLaunchKernelGGL(k_metrics_cls, dim3(1), dim3(MET_THREADS), 0, (hipStream_t)stream, logits, y, batch, (double*)nullptr, (long long*)nullptr, ce_state,
+                       reinterpret_cast<long long*>(counts), (float*)nullptr, (MetScratch*)nullptr);
+    HIPCHK(hipGetLastError());
+    return MSHGNN_OK;
+}
+
+extern "C" int mshgnn_metrics_classification_step(const float* logits, const int32_t* y, int64_t batch, double* batch_ce, int64_t* batch_counts,
+                                                  double* epoch_ce, int64_t* epoch_counts, float* grad_out, void* scratch, void* stream) {
+    if (!logits || !y || batch < 1 || !scratch || (!batch_ce != !batch_counts) || (!epoch_ce != !epoch_counts) || (!batch_ce && !epoch_ce))
+        return set_err(MSHGNN_EINVAL, "bad argument to mshgnn_metrics_classification_step");
+    hipLaunchKernelGGL(k_metrics_cls, dim3(met_blocks(batch, 1)), dim3(MET_THREADS), 0, (hipStream_t)stream, logits, y, batch, batch_ce,
+                       reinterpret_cast<long long*>(batch_counts), epoch_ce, reinterpret_cast<long long*>(epoch_counts), grad_out,
+                       reinterpret_cast<MetScratch*>(scratch));
     HIPCHK(hipGetLastError());
     return MSHGNN_OK;
 }
@@ -2821,9 +2959,7 @@ template <typename T> __global__ __launch_bounds__(256) void k_assemble_windows_
 // labels of a window = the label row of its LAST time step (quadSDKDataset.py: grfs[-1]); with label_rotate the world-frame
 // GRFs are taken into the body frame with the world->body quaternion of that step, R f per foot (the as_matrix() @ grfs_T
 // branch of load_data_at_dataset_seq_3d); quat out = that quaternion (data.r_o, quadSDKDataset_Morph.py:365-367)
-__global__ void k_window_labels(WindowArgs a) {
-    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= a.B) return;
+__device__ __forceinline__ void window_labels_one(const WindowArgs& a, int64_t b, int32_t* labels_int) {
     const int64_t row = a.starts[b] + a.T - 1;
     const float* lab = a.src[a.label_src] + row;                  // column-major: element c at lab[c * cstride]
     const int64_t lcs = a.src_cstride[a.label_src];
@@ -2847,8 +2983,17 @@ __global__ void k_window_labels(WindowArgs a) {
             for (int i = 0; i < 3; ++i) a.y[b * a.n_label + f + i] = (float)(R[i][0] * v0 + R[i][1] * v1 + R[i][2] * v2);
         }
     } else {
-        for (int k = 0; k < a.n_label; ++k) a.y[b * a.n_label + k] = lab[a.label_cols[k] * lcs];
+        for (int k = 0; k < a.n_label; ++k) {
+            const float v = lab[a.label_cols[k] * lcs];
+            a.y[b * a.n_label + k] = v;
+            if (labels_int) labels_int[b * a.n_label + k] = v != 0.f;      // contact flags for the fused cross entropy (mshgnn_step_ce_series)
+        }
     }
+}
+
+__global__ void k_window_labels(WindowArgs a) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < a.B) window_labels_one(a, b, nullptr);
 }
 
 extern "C" int mshgnn_assemble_windows(const mshgnn_window_desc* d, const float* const* src, const int64_t* src_cstride, const int64_t* src_rows,
@@ -2905,19 +3050,19 @@ extern "C" int mshgnn_assemble_windows(const mshgnn_window_desc* d, const float*
 // fused into the encoder (k_enc_fwd<.., SERIES>), which also writes the materialised windows for the weight-gradient kernel; labels by
 // k_window_labels.  bf16 plan with the fused stack kernels; everything after the encoder is mshgnn_step_mse.
 // ------------------------------------------------------------------------------------------------------
-__global__ void k_series_run_ptrs(const int* runs, int n_runs, WindowArgs a, unsigned long long* out) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_runs) return;
-    const int sc = runs[(size_t)r * 5 + 3];
-    unsigned long long p = 0ull;
+// everything mshgnn_step_*_series needs before its encoder launch, in ONE launch: the windows' labels (k_window_labels' arithmetic, plus
+// the int32 contact flags for the classification step) and, in workgroup 0, the bf16 base pointer of every run's series column
+__global__ void k_series_setup(WindowArgs la, const int* runs, int n_runs, WindowArgs wa, unsigned long long* run_ptr, int32_t* labels_int) {
+    if (blockIdx.x == 0 && (int)threadIdx.x < n_runs) {
+        const int r = threadIdx.x;
+        const int sc = runs[(size_t)r * 5 + 3];
+        unsigned long long p = 0ull;
 #pragma unroll
-    for (int k = 0; k < WIN_MAX_SRC; ++k) if (sc >= 0 && (sc >> 8) == k) p = (unsigned long long)(reinterpret_cast<const __bf16*>(a.src[k]) + (size_t)(sc & 0xff) * a.src_cstride[k]);
-    out[r] = p;
-}
-
-__global__ void k_labels_to_int(const float* y, int32_t* lab, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) lab[i] = y[i] != 0.f;
+        for (int k = 0; k < WIN_MAX_SRC; ++k) if (sc >= 0 && (sc >> 8) == k) p = (unsigned long long)(reinterpret_cast<const __bf16*>(wa.src[k]) + (size_t)(sc & 0xff) * wa.src_cstride[k]);
+        run_ptr[r] = p;
+    }
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < la.B) window_labels_one(la, b, labels_int);
 }
 
 static int step_series(const mshgnn_plan* p, const mshgnn_window_desc* d, const float* const* src, const void* const* src_bf16,
@@ -2950,18 +3095,19 @@ static int step_series(const mshgnn_plan* p, const mshgnn_window_desc* d, const 
         wa.src[i] = reinterpret_cast<const float*>(src_bf16[i]); wa.src_cstride[i] = src_cstride[i];
     }
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_series_run_ptrs, dim3(1), dim3(WIN_MAX_RUNS), 0, st, d->runs, d->n_runs, wa, reinterpret_cast<unsigned long long*>(run_ptrs));
     // labels (fp32 series)
     WindowArgs la{};
     for (int i = 0; i < d->n_src; ++i) { la.src[i] = src[i]; la.src_cstride[i] = src_cstride[i]; }
     la.starts = starts; la.B = batch; la.T = d->history; la.label_cols = d->label_cols; la.n_label = d->n_label; la.label_src = d->label_src;
     la.label_rotate = d->label_rotate; la.quat_src = d->quat_src; la.y = y_out; la.quat = quat_out;
     if (d->label_rotate && (d->n_label % 3 != 0 || d->quat_src < 0)) return set_err(MSHGNN_EINVAL, "label rotation needs 3-D labels and a quaternion source");
-    hipLaunchKernelGGL(k_window_labels, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, la);
+    static_assert(WIN_MAX_RUNS <= 256, "k_series_setup resolves the runs in one 256-thread workgroup");
+    if (ce && d->label_rotate) return set_err(MSHGNN_EINVAL, "mshgnn_step_ce_series: contact labels are not rotated");
+    hipLaunchKernelGGL(k_series_setup, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, la, d->runs, d->n_runs, wa,
+                       reinterpret_cast<unsigned long long*>(run_ptrs), ce ? labels_out : nullptr);
     SeriesSrc ser{};
     ser.run_ptr = reinterpret_cast<const unsigned long long*>(run_ptrs); ser.rows = d->rows; ser.starts = starts; ser.T = d->history;
     { int r0 = 0; for (int t = 0; t < d->n_types; ++t) { ser.row0[t] = r0; r0 += d->type_nodes[t]; } }
-    if (ce) hipLaunchKernelGGL(k_labels_to_int, dim3((unsigned)((batch * d->n_label + 255) / 256)), dim3(256), 0, st, y_out, labels_out, batch * d->n_label);
     int rc = forward_impl<__bf16>(p, x_out, x_pitch, params, out, (char*)workspace, batch, 1, st, ce ? nullptr : y_out, &ser, ce ? labels_out : nullptr);
     if (rc) return rc;
     // x_out == NULL: no materialised windows at all -- the weight-gradient kernel gathers its raw-input operands from the series as well

@@ -6,7 +6,10 @@ Mirrors the metric half of `Base_Lightning` (src/ms_hgnn/lightning_py/gnnLightni
 `body_frame_to_world_frame` (:663-676, which in the reference hops to the CPU and scipy every step).  The reference's
 torchmetrics / customMetrics states are plain sums; here they live in two small device buffers that the kernels
 `mshgnn_metrics_regression` / `mshgnn_metrics_classification` add into (include/mshgnn.h).  Same attribute names as the
-reference (`mse_loss`, `rmse_loss`, `l1_loss`, `ce_loss`, `acc`, `f1_leg0..3`), values are float64 tensors.
+reference (`mse_loss`, `rmse_loss`, `l1_loss`, `ce_loss`, `acc`, `f1_leg0..3`), values are float64 tensors.  As in the reference, the
+loss a `training_step` returns (`mse_loss` / `ce_loss`, gnnLightning.py:709-722) carries autograd when `y_pred` does: its backward is one
+launch of `mshgnn_mse_loss` / `mshgnn_ce_loss` (dL/dy_pred on the device), so a wrapper built on this class trains without torch's
+elementwise loss kernels.
 
 There is no CPU implementation: without a HIP device every method raises.
 """
@@ -37,60 +40,134 @@ def _f1(tp, fp, fn):
     return torch.nan_to_num(2 * (precision * recall) / (precision + recall))
 
 
+class _StepLoss(torch.autograd.Function):
+    """The batch loss of `calculate_losses_step` as an autograd node.  forward: ONE launch -- this step's metric sums, the loss, their accumulation
+    into the epoch state and dL/dy_pred (2 (y_pred - y) / n, or (softmax - onehot) / rows); backward: that gradient times the upstream scalar."""
+
+    @staticmethod
+    def forward(ctx, y_pred, y, metrics):
+        buf, g = metrics._launch(y, y_pred, True)
+        metrics._cur = buf          # (the sums are no autograd outputs: the only output is the loss the kernel left next to them)
+        ctx.g, ctx.meta = g, (y_pred.shape, y_pred.dtype, y_pred.device)
+        return buf[:4].view(torch.float64)[3 if metrics.regression else 2]
+
+    @staticmethod
+    def backward(ctx, gl):
+        shape, dtype, in_dev = ctx.meta
+        g = ctx.g * gl.to(ctx.g.device)           # (a 0-dim factor does not promote the fp32 gradient; out of place: backward may run twice)
+        return g.to(device=in_dev, dtype=dtype).view(shape), None, None
+
+
+_REG_NAMES = ("mse_loss", "rmse_loss", "l1_loss")
+_CLS_NAMES = ("ce_loss", "acc", "f1_leg0", "f1_leg1", "f1_leg2", "f1_leg3")
+
+
 class StepMetrics:
     """Drop-in for the metric bookkeeping of `Base_Lightning` (`regression=True`: GRF / COM regression wrappers,
-    `False`: contact classification)."""
+    `False`: contact classification).  The published values (`mse_loss`, ..., `f1_leg3`) are evaluated from the device sums when they are
+    read, so a step that only needs its loss launches nothing for the others."""
 
     def __init__(self, regression: bool = True, device=None):
         self.regression = regression
         self.device = _device(device)
         self.lib = eng.load_library()
-        self._epoch_f = torch.zeros(4, dtype=torch.float64, device=self.device)    # regression: sq, abs, n | classification: ce, rows
-        self._epoch_i = torch.zeros(18, dtype=torch.int64, device=self.device)
-        self.mse_loss = self.rmse_loss = self.l1_loss = None
-        self.ce_loss = self.acc = self.f1_leg0 = self.f1_leg1 = self.f1_leg2 = self.f1_leg3 = None
+        # state layout (one buffer of 22 eight-byte words): [0:4] float64 -- regression: sq, abs, n | classification: ce, rows; [4:22] int64 counts
+        self._epoch = torch.zeros(22, dtype=torch.int64, device=self.device)
+        self._scratch = torch.zeros(16384 // 8, dtype=torch.int64, device=self.device)      # MSHGNN_METRICS_SCRATCH_BYTES: partials + ticket
+        self._cur = None          # the state the published values are read from: the last step's, or the epoch's
+        self._loss = None         # the last step's loss when it carries autograd
+        self._vals = {}
+        self._from_step = False
+
+    @property
+    def _epoch_f(self):
+        return self._epoch[:4].view(torch.float64)
+
+    @property
+    def _epoch_i(self):
+        return self._epoch[4:]
 
     # ---- values from a state -----------------------------------------------------------------------------------
-    def _publish(self, f, i):
-        if self.regression:
-            self.mse_loss = f[0] / f[2]
-            self.rmse_loss = torch.sqrt(f[0] / f[2])
-            self.l1_loss = f[1] / f[2]
+    def _value(self, name):
+        if name not in (_REG_NAMES if self.regression else _CLS_NAMES):
+            raise AttributeError(f"'{name}' is not a metric of a {'regression' if self.regression else 'classification'} wrapper")
+        if self._cur is None:
+            return None
+        if name in self._vals:
+            return self._vals[name]
+        f, i = self._cur[:4].view(torch.float64), self._cur[4:]
+        if name in ("mse_loss", "ce_loss") and self._loss is not None:
+            v = self._loss
+        elif name in ("mse_loss", "ce_loss") and self._from_step:
+            v = f[3 if self.regression else 2]          # the kernel left the step's loss next to its sums
+        elif name == "mse_loss":
+            v = f[0] / f[2]
+        elif name == "rmse_loss":
+            v = torch.sqrt(f[0] / f[2])
+        elif name == "l1_loss":
+            v = f[1] / f[2]
+        elif name == "ce_loss":
+            v = f[0].float().double() / f[1]            # `summed_loss.float() / total_num`, customMetrics.py:24
+        elif name == "acc":
+            v = i[1].double() / i[0].double()
         else:
-            self.ce_loss = f[0].float().double() / f[1]            # `summed_loss.float() / total_num`, customMetrics.py:24
-            self.acc = i[1].double() / i[0].double()
-            for k in range(4):
-                setattr(self, f"f1_leg{k}", _f1(i[2 + 4 * k], i[3 + 4 * k], i[4 + 4 * k]))
+            k = int(name[-1])
+            v = _f1(i[2 + 4 * k], i[3 + 4 * k], i[4 + 4 * k])
+        self._vals[name] = v
+        return v
+
+    mse_loss = property(lambda self: self._value("mse_loss"))
+    rmse_loss = property(lambda self: self._value("rmse_loss"))
+    l1_loss = property(lambda self: self._value("l1_loss"))
+    ce_loss = property(lambda self: self._value("ce_loss"))
+    acc = property(lambda self: self._value("acc"))
+    f1_leg0 = property(lambda self: self._value("f1_leg0"))
+    f1_leg1 = property(lambda self: self._value("f1_leg1"))
+    f1_leg2 = property(lambda self: self._value("f1_leg2"))
+    f1_leg3 = property(lambda self: self._value("f1_leg3"))
 
     # ---- reference API -----------------------------------------------------------------------------------------
-    def calculate_losses_step(self, y: torch.Tensor, y_pred: torch.Tensor):
-        """Metrics of this batch (published as attributes) and accumulation into the epoch state."""
+    def _launch(self, y: torch.Tensor, y_pred: torch.Tensor, want_grad: bool):
+        """One launch: this batch's sums into a fresh state buffer, added into the epoch state, + dL/dy_pred (fp32) when asked for."""
         dev = self.device
-        f = torch.zeros(4, dtype=torch.float64, device=dev)
-        i = torch.zeros(18, dtype=torch.int64, device=dev)
-        if self.regression:
-            yp = y_pred.detach().to(dev, torch.float32).flatten().contiguous()
-            yy = y.detach().to(dev, torch.float32).flatten().contiguous()
-            if yp.numel() != yy.numel():
-                raise ValueError("y and y_pred must have the same number of elements")
-            eng._check(self.lib, self.lib.mshgnn_metrics_regression(yp.data_ptr(), yy.data_ptr(), yp.numel(), f.data_ptr(), _stream(dev)),
-                       "mshgnn_metrics_regression")
+        buf = torch.empty(22, dtype=torch.int64, device=dev)
+        ep = self._epoch.data_ptr()
+        with torch.cuda.device(dev):
+            if self.regression:
+                yp = y_pred.detach().to(dev, torch.float32).flatten().contiguous()
+                yy = y.detach().to(dev, torch.float32).flatten().contiguous()
+                if yp.numel() != yy.numel():
+                    raise ValueError("y and y_pred must have the same number of elements")
+                g = torch.empty_like(yp) if want_grad else None
+                eng._check(self.lib, self.lib.mshgnn_metrics_regression_step(yp.data_ptr(), yy.data_ptr(), yp.numel(), buf.data_ptr(), ep,
+                                                                             g.data_ptr() if want_grad else None, self._scratch.data_ptr(), _stream(dev)),
+                           "mshgnn_metrics_regression_step")
+            else:
+                batch = y_pred.shape[0]
+                yp = y_pred.detach().to(dev, torch.float32).reshape(batch * 4, 2).contiguous()     # gnnLightning.py:300
+                yy = y.detach().to(dev, torch.int32).reshape(batch * 4).contiguous()
+                g = torch.empty_like(yp) if want_grad else None
+                eng._check(self.lib, self.lib.mshgnn_metrics_classification_step(yp.data_ptr(), yy.data_ptr(), batch, buf.data_ptr(), buf.data_ptr() + 32,
+                                                                                 ep, ep + 32, g.data_ptr() if want_grad else None, self._scratch.data_ptr(),
+                                                                                 _stream(dev)),
+                           "mshgnn_metrics_classification_step")
+        return buf, g
+
+    def calculate_losses_step(self, y: torch.Tensor, y_pred: torch.Tensor):
+        """Metrics of this batch (published as attributes) and accumulation into the epoch state.  When `y_pred` carries autograd, so does
+        the published `mse_loss` / `ce_loss` -- what the reference's `training_step` returns for backward (gnnLightning.py:709-722)."""
+        if torch.is_grad_enabled() and y_pred.requires_grad:
+            self._loss = _StepLoss.apply(y_pred, y, self)
         else:
-            batch = y_pred.shape[0]
-            yp = y_pred.detach().to(dev, torch.float32).reshape(batch * 4, 2).contiguous()     # gnnLightning.py:300
-            yy = y.detach().to(dev, torch.int32).reshape(batch, 4).contiguous()
-            eng._check(self.lib, self.lib.mshgnn_metrics_classification(yp.data_ptr(), yy.data_ptr(), batch, f.data_ptr(), i.data_ptr(),
-                                                                        _stream(dev)), "mshgnn_metrics_classification")
-        self._epoch_f += f
-        self._epoch_i += i
-        self._publish(f, i)
+            self._loss = None
+            self._cur, _ = self._launch(y, y_pred, False)
+        self._vals, self._from_step = {}, True
 
     def calculate_losses_epoch(self) -> None:
-        self._publish(self._epoch_f, self._epoch_i)
+        self._cur, self._loss, self._vals, self._from_step = self._epoch.clone(), None, {}, False
 
     def reset_all_metrics(self) -> None:
-        self._epoch_f.zero_()
-        self._epoch_i.zero_()
+        self._epoch.zero_()
 
     @staticmethod
     def classification_conversion_16_class(y_pred_per_foot_prob_only_1: torch.Tensor, y: torch.Tensor):

@@ -116,3 +116,54 @@ def test_device_body_to_world_matches_oracle():
     got = StepMetrics(True).body_frame_to_world_frame(torch.from_numpy(q), torch.from_numpy(g)).cpu().numpy()
     want = mo.body_frame_to_world_frame(q, g)
     assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_step_loss_carries_autograd_regression(dtype):
+    """The loss `training_step` returns (gnnLightning.py:709-722) is differentiable, as the reference's torchmetrics value is: value and
+    dL/dy_pred against torch's own arithmetic in fp64."""
+    from morphsym_hgnn_amd.metrics import StepMetrics
+    g = torch.Generator().manual_seed(3)
+    B = 517
+    y_pred = (torch.randn(B, 12, generator=g, dtype=torch.float64) * 30).to(dtype).cuda().requires_grad_(True)
+    y = (torch.randn(B, 12, generator=g, dtype=torch.float64) * 30).to(dtype).cuda()
+    m = StepMetrics(regression=True)
+    m.calculate_losses_step(y, y_pred)
+    assert m.mse_loss.requires_grad and not m.rmse_loss.requires_grad
+    (3.0 * m.mse_loss).backward()
+    ref_in = y_pred.detach().double().cpu().requires_grad_(True)
+    ref = ((ref_in.flatten() - y.double().cpu().flatten()) ** 2).mean()
+    (3.0 * ref).backward()
+    assert abs(float(m.mse_loss) - float(ref)) <= 1e-6 * float(ref)
+    assert y_pred.grad.dtype == dtype and y_pred.grad.shape == y_pred.shape
+    assert float((y_pred.grad.double().cpu() - ref_in.grad).abs().max()) <= 2e-6 * float(ref_in.grad.abs().max())
+    # without autograd on the prediction the published values are plain tensors, as before; the multi-workgroup sums are bit-reproducible
+    m.calculate_losses_step(y, y_pred.detach())
+    assert not m.mse_loss.requires_grad
+    first = (m.mse_loss.clone(), m.l1_loss.clone())
+    for _ in range(5):
+        m.calculate_losses_step(y, y_pred.detach())
+        assert torch.equal(m.mse_loss, first[0]) and torch.equal(m.l1_loss, first[1])
+    with torch.no_grad():
+        m.calculate_losses_step(y, y_pred)
+    assert not m.mse_loss.requires_grad
+
+
+@pytest.mark.gpu
+def test_step_loss_carries_autograd_classification():
+    from morphsym_hgnn_amd.metrics import StepMetrics
+    g = torch.Generator().manual_seed(4)
+    B = 333
+    y_pred = (torch.randn(B, 8, generator=g, dtype=torch.float64) * 3).cuda().requires_grad_(True)      # step_helper_function's [B, 2 * 4] logits
+    y = torch.randint(0, 2, (B, 4), generator=g).cuda()
+    m = StepMetrics(regression=False)
+    m.calculate_losses_step(y, y_pred)
+    assert m.ce_loss.requires_grad
+    m.ce_loss.backward()
+    ref_in = y_pred.detach().cpu().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(ref_in.reshape(B * 4, 2), y.cpu().long().flatten(), reduction="sum") / (B * 4)
+    ref.backward()
+    assert abs(float(m.ce_loss) - float(ref)) <= 1e-6 * float(ref)
+    assert float((y_pred.grad.cpu() - ref_in.grad).abs().max()) <= 2e-6 * float(ref_in.grad.abs().max())
+    assert 0.0 <= float(m.acc) <= 1.0
