@@ -2594,13 +2594,13 @@ __device__ __forceinline__ bool met_last_block(MetScratch* sc) {
 
 // regression (calculate_losses_step, gnnLightning.py:124-130): sums of (pred - y)^2, |pred - y| and n; `batch` (nullable) receives this
 // step's sums (overwritten), `epoch` (nullable) has them added; gout (nullable) = d mean((pred - y)^2) / d pred = 2 (pred - y) / n
-__global__ __launch_bounds__(MET_THREADS) void k_metrics_reg(const float* pred, const float* y, int64_t n, double* batch, double* epoch, float* gout,
+template <int NT> __global__ __launch_bounds__(NT) void k_metrics_reg(const float* pred, const float* y, int64_t n, double* batch, double* epoch, float* gout,
                                                              MetScratch* sc) {
-    __shared__ double r0[MET_THREADS / 64], r1[MET_THREADS / 64], pf[MET_BLOCKS][2];
+    __shared__ double r0[NT / 64], r1[NT / 64], pf[MET_BLOCKS][2];
     __shared__ int s_last;
     double s = 0.0, a = 0.0;
     const double inv2 = 2.0 / (double)n;
-    for (int64_t i = (int64_t)blockIdx.x * MET_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * MET_THREADS) {
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
         const double dlt = (double)pred[i] - (double)y[i];
         s += dlt * dlt; a += fabs(dlt);
         if (gout) gout[i] = (float)(dlt * inv2);
@@ -2610,7 +2610,7 @@ __global__ __launch_bounds__(MET_THREADS) void k_metrics_reg(const float* pred, 
     __syncthreads();
     double ts = 0.0, ta = 0.0;
     if (threadIdx.x == 0) {
-        for (int k = 0; k < MET_THREADS / 64; ++k) { ts += r0[k]; ta += r1[k]; }
+        for (int k = 0; k < NT / 64; ++k) { ts += r0[k]; ta += r1[k]; }
         if (sc) { met_store(&sc->f[blockIdx.x][0], ts); met_store(&sc->f[blockIdx.x][1], ta); }
         s_last = met_last_block(sc) ? 1 : 0;
     }
@@ -2640,17 +2640,17 @@ __global__ __launch_bounds__(MET_THREADS) void k_metrics_reg(const float* pred, 
 // The 16-class probabilities are the reference's products (p or 1 - p per foot, ((f0 f1)(f2 f3)), first maximum wins).
 // ce_b / counts_b (nullable): this step's sums, overwritten; ce_state / counts (nullable): added into; gout (nullable) [B*4][2] = d ce / d logits
 // = (softmax - onehot) / (4 B)
-__global__ __launch_bounds__(MET_THREADS) void k_metrics_cls(const float* logits, const int32_t* y, int64_t B, double* ce_b, long long* counts_b,
+template <int NT> __global__ __launch_bounds__(NT) void k_metrics_cls(const float* logits, const int32_t* y, int64_t B, double* ce_b, long long* counts_b,
                                                              double* ce_state, long long* counts, float* gout, MetScratch* sc) {
-    __shared__ double rce[MET_THREADS / 64];
-    __shared__ long long rc[MET_THREADS / 64][MET_COUNTS], pc[MET_BLOCKS][MET_COUNTS];
+    __shared__ double rce[NT / 64];
+    __shared__ long long rc[NT / 64][MET_COUNTS], pc[MET_BLOCKS][MET_COUNTS];
     __shared__ double pce[MET_BLOCKS];
     __shared__ int s_last;
     double ce = 0.0;
     long long c[MET_COUNTS];
 #pragma unroll
     for (int k = 0; k < MET_COUNTS; ++k) c[k] = 0;
-    for (int64_t w = (int64_t)blockIdx.x * MET_THREADS + threadIdx.x; w < B; w += (int64_t)gridDim.x * MET_THREADS) {
+    for (int64_t w = (int64_t)blockIdx.x * NT + threadIdx.x; w < B; w += (int64_t)gridDim.x * NT) {
         double p1[4];
         int state = 0;
 #pragma unroll
@@ -2690,8 +2690,8 @@ __global__ __launch_bounds__(MET_THREADS) void k_metrics_cls(const float* logits
     __syncthreads();
     // this workgroup's sums: thread 0 the cross entropy, threads 0..17 one count each
     double tce = 0.0; long long tc = 0;
-    if (threadIdx.x == 0) for (int k = 0; k < MET_THREADS / 64; ++k) tce += rce[k];
-    if (threadIdx.x < MET_COUNTS) for (int k = 0; k < MET_THREADS / 64; ++k) tc += rc[k][threadIdx.x];
+    if (threadIdx.x == 0) for (int k = 0; k < NT / 64; ++k) tce += rce[k];
+    if (threadIdx.x < MET_COUNTS) for (int k = 0; k < NT / 64; ++k) tc += rc[k][threadIdx.x];
     if (sc) {
         if (threadIdx.x == 0) met_store(&sc->f[blockIdx.x][0], tce);
         if (threadIdx.x < MET_COUNTS) met_store(&sc->c[blockIdx.x][threadIdx.x], tc);
@@ -2747,7 +2747,7 @@ static int met_blocks(int64_t items, int per_thread) {
 
 extern "C" int mshgnn_metrics_regression(const float* y_pred, const float* y, int64_t n, double* state, void* stream) {
     if (!y_pred || !y || !state || n < 1) return set_err(MSHGNN_EINVAL, "bad argument to mshgnn_metrics_regression");
-    hipLaunchKernelGGL(k_metrics_reg, dim3(1), dim3(MET_THREADS), 0, (hipStream_t)stream, y_pred, y, n, (double*)nullptr, state, (float*)nullptr, (MetScratch*)nullptr);
+    hipLaunchKernelGGL(k_metrics_reg<1024>, dim3(1), dim3(1024), 0, (hipStream_t)stream, y_pred, y, n, (double*)nullptr, state, (float*)nullptr, (MetScratch*)nullptr);
     HIPCHK(hipGetLastError());
     return MSHGNN_OK;
 }
@@ -2755,7 +2755,7 @@ extern "C" int mshgnn_metrics_regression(const float* y_pred, const float* y, in
 extern "C" int mshgnn_metrics_regression_step(const float* y_pred, const float* y, int64_t n, double* batch_state, double* epoch_state, float* grad_out,
                                               void* scratch, void* stream) {
     if (!y_pred || !y || (!batch_state && !epoch_state) || !scratch || n < 1) return set_err(MSHGNN_EINVAL, "bad argument to mshgnn_metrics_regression_step");
-    hipLaunchKernelGGL(k_metrics_reg, dim3(met_blocks(n, 16)), dim3(MET_THREADS), 0, (hipStream_t)stream, y_pred, y, n, batch_state, epoch_state, grad_out,
+    hipLaunchKernelGGL(k_metrics_reg<MET_THREADS>, dim3(met_blocks(n, 16)), dim3(MET_THREADS), 0, (hipStream_t)stream, y_pred, y, n, batch_state, epoch_state, grad_out,
                        reinterpret_cast<MetScratch*>(scratch));
     HIPCHK(hipGetLastError());
     return MSHGNN_OK;
@@ -2763,7 +2763,7 @@ extern "C" int mshgnn_metrics_regression_step(const float* y_pred, const float* 
 
 extern "C" int mshgnn_metrics_classification(const float* logits, const int32_t* y, int64_t batch, double* ce_state, int64_t* counts, void* stream) {
     if (!logits || !y || !ce_state || !counts || batch < 1) return set_err(MSHGNN_EINVAL, "bad argument to mshgnn_metrics_classification");
-    hipLaunchKernelGGL(k_metrics_cls, dim3(1), dim3(MET_THREADS), 0, (hipStream_t)stream, logits, y, batch, (double*)nullptr, (long long*)nullptr, ce_state,
+    hipLaunchKernelGGL(k_metrics_cls<1024>, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, y, batch, (double*)nullptr, (long long*)nullptr, ce_state,
                        reinterpret_cast<long long*>(counts), (float*)nullptr, (MetScratch*)nullptr);
     HIPCHK(hipGetLastError());
     return MSHGNN_OK;
@@ -2773,7 +2773,7 @@ extern "C" int mshgnn_metrics_classification_step(const float* logits, const int
                                                   double* epoch_ce, int64_t* epoch_counts, float* grad_out, void* scratch, void* stream) {
     if (!logits || !y || batch < 1 || !scratch || (!batch_ce != !batch_counts) || (!epoch_ce != !epoch_counts) || (!batch_ce && !epoch_ce))
         return set_err(MSHGNN_EINVAL, "bad argument to mshgnn_metrics_classification_step");
-    hipLaunchKernelGGL(k_metrics_cls, dim3(met_blocks(batch, 1)), dim3(MET_THREADS), 0, (hipStream_t)stream, logits, y, batch, batch_ce,
+    hipLaunchKernelGGL(k_metrics_cls<MET_THREADS>, dim3(met_blocks(batch, 1)), dim3(MET_THREADS), 0, (hipStream_t)stream, logits, y, batch, batch_ce,
                        reinterpret_cast<long long*>(batch_counts), epoch_ce, reinterpret_cast<long long*>(epoch_counts), grad_out,
                        reinterpret_cast<MetScratch*>(scratch));
     HIPCHK(hipGetLastError());

@@ -167,3 +167,31 @@ def test_step_loss_carries_autograd_classification():
     assert abs(float(m.ce_loss) - float(ref)) <= 1e-6 * float(ref)
     assert float((y_pred.grad.cpu() - ref_in.grad).abs().max()) <= 2e-6 * float(ref_in.grad.abs().max())
     assert 0.0 <= float(m.acc) <= 1.0
+
+
+@pytest.mark.gpu
+def test_accumulating_entry_points_agree_with_the_step_entry_points():
+    """mshgnn_metrics_regression / _classification (one workgroup, ADD into a caller state) against the one-launch step entry points the
+    StepMetrics class uses: same fp64 sums up to the order of the partial sums; integer counts identical."""
+    import ctypes as C
+    from morphsym_hgnn_amd import engine as eng
+    from morphsym_hgnn_amd.metrics import StepMetrics
+    lib = eng.load_library()
+    g = torch.Generator().manual_seed(9)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p, y = torch.randn(5000, 12, generator=g).cuda(), torch.randn(5000, 12, generator=g).cuda()
+    state = torch.zeros(3, dtype=torch.float64, device="cuda")
+    for _ in range(2):
+        eng._check(lib, lib.mshgnn_metrics_regression(p.data_ptr(), y.data_ptr(), p.numel(), state.data_ptr(), st), "mshgnn_metrics_regression")
+    m = StepMetrics(regression=True)
+    m.calculate_losses_step(y, p); m.calculate_losses_step(y, p)
+    torch.cuda.synchronize()
+    assert torch.allclose(state, m._epoch_f[:3], rtol=1e-13, atol=0) and float(state[2]) == 2 * p.numel()
+    lg = (torch.randn(3000, 8, generator=g) * 3).cuda()
+    yy = (torch.rand(3000, 4, generator=g) > 0.5).int().cuda()
+    ce, cnt = torch.zeros(2, dtype=torch.float64, device="cuda"), torch.zeros(18, dtype=torch.int64, device="cuda")
+    eng._check(lib, lib.mshgnn_metrics_classification(lg.data_ptr(), yy.data_ptr(), 3000, ce.data_ptr(), cnt.data_ptr(), st), "mshgnn_metrics_classification")
+    mc = StepMetrics(regression=False)
+    mc.calculate_losses_step(yy, lg)
+    torch.cuda.synchronize()
+    assert torch.equal(cnt, mc._epoch_i) and torch.allclose(ce, mc._epoch_f[:2], rtol=1e-13, atol=0)
