@@ -88,8 +88,11 @@ class StepMetrics:
         return self._epoch[4:]
 
     # ---- values from a state -----------------------------------------------------------------------------------
+    def _names(self):
+        return _REG_NAMES if self.regression else _CLS_NAMES
+
     def _value(self, name):
-        if name not in (_REG_NAMES if self.regression else _CLS_NAMES):
+        if name not in self._names():
             raise AttributeError(f"'{name}' is not a metric of a {'regression' if self.regression else 'classification'} wrapper")
         if self._cur is None:
             return None

@@ -1,0 +1,313 @@
+"""The training-step wrappers around the MS-HGNN models: host-side mirror of the reference's Lightning modules for the hot path.
+
+Same class names, constructor arguments, method names and return values as `src/ms_hgnn/lightning_py/gnnLightning.py`:
+`Base_Lightning` (:28-348), `Heterogeneous_GNN_Lightning` (:415-462), `HGNN_K4_Lightning` (:464-513), `HGNN_C2_Lightning_Cls`
+(:515-562), `HGNN_C2_Lightning_Reg` (:564-778).  What differs is where the work runs: the model is this package's (HIP engine), the
+metric bookkeeping is `metrics.StepMetrics` (one launch per step, the returned loss carries autograd) and the world-frame rotation of
+the GRFs stays on the device instead of the reference's per-step CPU + scipy hop (:663-676).
+
+`lightning` is not a dependency: with it installed the wrappers ARE `LightningModule`s and a `Trainer` drives them unchanged; without
+it they are plain `nn.Module`s whose `log()` records the values in `self.logged`, and `examples/` / `tests/` drive the same methods
+(`training_step`, `validation_step`, `on_validation_epoch_end`, `configure_optimizers`) by hand.  Datasets, checkpoint callbacks, W&B
+logging and `train_model` / `evaluate_model` are out of scope (control plane).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import nn, optim
+
+from . import models
+from .metrics import StepMetrics
+
+try:  # pragma: no cover - lightning is absent in the build image
+    import lightning as _L
+    _Base = _L.LightningModule
+except Exception:  # noqa: BLE001
+    _L = None
+    _Base = nn.Module
+
+_REG = ("MSE_loss", "mse_loss"), ("RMSE_loss", "rmse_loss"), ("L1_loss", "l1_loss")
+_METRIC_ATTRS = ("mse_loss", "rmse_loss", "l1_loss", "ce_loss", "acc", "f1_leg0", "f1_leg1", "f1_leg2", "f1_leg3")
+
+
+def _metric_property(name):
+    def get(self):
+        m = self.__dict__.get("_metrics")
+        return None if m is None or name not in m._names() else getattr(m, name)
+    return property(get)
+
+
+class Base_Lightning(_Base):
+    """Steps, epoch hooks, logging and the optimizer shared by every wrapper (gnnLightning.py:28-348)."""
+
+    def __init__(self, optimizer: str, lr: float, regression: bool):
+        super().__init__()
+        self.optimizer = optimizer
+        self.lr = lr
+        self.regression = regression
+        self.body_to_world_frame = False
+        self.__dict__["_metrics"] = None            # metrics.StepMetrics, created with the first step (it needs the device)
+        self.__dict__["_metrics_world"] = None
+        self.logged = {}
+
+    # ---- metric state ------------------------------------------------------------------------------------------------
+    def _m(self, world: bool = False) -> StepMetrics:
+        key = "_metrics_world" if world else "_metrics"
+        if self.__dict__[key] is None:
+            self.__dict__[key] = StepMetrics(regression=True if world else self.regression)
+        return self.__dict__[key]
+
+    if _L is None:
+        def log(self, name, value, on_step: bool = False, on_epoch: bool = True, **_):
+            """Stand-in for LightningModule.log: the last value per name (a device tensor; reading it is the caller's sync)."""
+            self.logged[name] = value
+
+    def log_losses(self, step_name: str, on_step: bool):
+        on_epoch = not on_step
+        if self.regression:
+            for label, attr in _REG:
+                self.log(f"{step_name}_{label}", getattr(self, attr), on_step=on_step, on_epoch=on_epoch)
+        else:
+            self.log(step_name + "_CE_loss", self.ce_loss, on_step=on_step, on_epoch=on_epoch)
+            self.log(step_name + "_Accuracy", self.acc, on_step=on_step, on_epoch=on_epoch)
+            f1 = [self.f1_leg0, self.f1_leg1, self.f1_leg2, self.f1_leg3]
+            self.log(step_name + "_F1_Score_Leg_Avg", (f1[0] + f1[1] + f1[2] + f1[3]) / 4.0, on_step=on_step, on_epoch=on_epoch)
+            for k in range(4):
+                self.log(f"{step_name}_F1_Score_Leg_{k}", f1[k], on_step=on_step, on_epoch=on_epoch)
+
+    def calculate_losses_step(self, y: torch.Tensor, y_pred: torch.Tensor):
+        """gnnLightning.py:124-151.  Classification: `y_pred` [batch, 8] logits, `y` [batch, 4] contact flags."""
+        self._m().calculate_losses_step(y, y_pred)
+
+    def calculate_losses_epoch(self) -> None:
+        self._m().calculate_losses_epoch()
+
+    def reset_all_metrics(self) -> None:
+        self._m().reset_all_metrics()
+
+    def _loss(self):
+        return self.mse_loss if self.regression else self.ce_loss
+
+    # ---- steps (gnnLightning.py:179-256) -----------------------------------------------------------------------------
+    def training_step(self, batch, batch_idx):
+        y, y_pred = self.step_helper_function(batch)
+        self.calculate_losses_step(y, y_pred)
+        self.log_losses("train", on_step=True)
+        return self._loss()
+
+    def on_validation_epoch_start(self):
+        self.reset_all_metrics()
+
+    def validation_step(self, batch, batch_idx):
+        y, y_pred = self.step_helper_function(batch)
+        self.calculate_losses_step(y, y_pred)
+        return self._loss()
+
+    def on_validation_epoch_end(self):
+        self.calculate_losses_epoch()
+        self.log_losses("val", on_step=False)
+
+    def on_test_epoch_start(self):
+        self.reset_all_metrics()
+
+    def test_step(self, batch, batch_idx):
+        return self.validation_step(batch, batch_idx)
+
+    def on_test_epoch_end(self):
+        self.calculate_losses_epoch()
+        self.log_losses("test", on_step=False)
+
+    def on_predict_start(self):
+        self.reset_all_metrics()
+
+    def predict_step(self, batch, batch_idx):
+        y, y_pred = self.step_helper_function(batch)
+        self.calculate_losses_step(y, y_pred)
+        if not self.regression:
+            raise NotImplementedError("This prediction method is not fully tested for classification.")
+        return y, y_pred
+
+    def on_predict_end(self):
+        self.calculate_losses_epoch()
+
+    # ---- optimizer (gnnLightning.py:258-265) -------------------------------------------------------------------------
+    def configure_optimizers(self):
+        if self.optimizer == "adam":
+            return optim.Adam(self.parameters(), lr=self.lr)
+        if self.optimizer == "sgd":
+            return optim.SGD(self.parameters(), lr=self.lr)
+        raise ValueError("Invalid optimizer setting")
+
+    # ---- helpers -----------------------------------------------------------------------------------------------------
+    def step_helper_function(self, batch):
+        raise NotImplementedError
+
+    def classification_calculate_useful_values(self, y_pred, batch_size):
+        """Per-foot logits [batch*4, 2], their softmax, and the contact probabilities [batch, 4] (gnnLightning.py:285-304)."""
+        per_foot = torch.reshape(y_pred, (batch_size * 4, 2))
+        prob = torch.nn.functional.softmax(per_foot, dim=1)
+        return per_foot, prob, torch.reshape(prob[:, 1], (batch_size, 4))
+
+    @staticmethod
+    def classification_conversion_16_class(y_pred_per_foot_prob_only_1: torch.Tensor, y: torch.Tensor):
+        return StepMetrics.classification_conversion_16_class(y_pred_per_foot_prob_only_1, y)
+
+
+for _n in _METRIC_ATTRS:
+    setattr(Base_Lightning, _n, _metric_property(_n))
+
+
+class _HGNNWrapper(Base_Lightning):
+    """What the four GRF wrappers share: build the model, run the lazy-initialising dummy forward (:445-447), reshape outputs and labels
+    per window (:449-462, :495-513, :680-695)."""
+
+    _label_width_is_output_width = False      # y: [batch, out_channels_per_foot * 4] (True) or [batch, 4] (False)
+
+    def _finish_init(self, dummy_batch):
+        with torch.no_grad():
+            self.model(x_dict=dummy_batch.x_dict, edge_index_dict=dummy_batch.edge_index_dict)
+        if _L is not None:  # pragma: no cover
+            self.save_hyperparameters(ignore=["dummy_batch", "activation_fn"])
+
+    def step_helper_function(self, batch):
+        out_raw = self.model(x_dict=batch.x_dict, edge_index_dict=batch.edge_index_dict)
+        batch_size = batch.batch_size if hasattr(batch, "batch_size") else 1
+        width = self.model.out_channels_per_foot * 4
+        y_pred = torch.reshape(out_raw.squeeze(), (batch_size, width))
+        y = torch.reshape(batch.y, (batch_size, width if self._label_width_is_output_width else 4))
+        return y, y_pred
+
+
+class Heterogeneous_GNN_Lightning(_HGNNWrapper):
+    """MI-HGNN baseline `GRF_HGNN` (gnnLightning.py:415-462)."""
+    _label_width_is_output_width = True
+
+    def __init__(self, hidden_channels: int, num_layers: int, data_metadata, dummy_batch, optimizer: str = "adam", lr: float = 0.003,
+                 regression: bool = True, activation_fn=nn.ReLU(), grf_dimension: int = 1):
+        super().__init__(optimizer, lr, regression)
+        self.model = models.GRF_HGNN(hidden_channels=hidden_channels, num_layers=num_layers, data_metadata=data_metadata,
+                                     regression=regression, activation_fn=activation_fn, grf_dimension=grf_dimension)
+        self._finish_init(dummy_batch)
+
+
+class HGNN_K4_Lightning(_HGNNWrapper):
+    """`GRF_HGNN_K4` (gnnLightning.py:464-513): labels [batch, 4] (1-D GRFs or contact flags)."""
+
+    def __init__(self, hidden_channels: int, num_layers: int, data_metadata, dummy_batch, optimizer: str = "adam", lr: float = 0.003,
+                 regression: bool = True, activation_fn=nn.ReLU(), symmetry_mode: Optional[str] = None,
+                 group_operator_path: Optional[str] = None):
+        super().__init__(optimizer, lr, regression)
+        self.model = models.GRF_HGNN_K4(hidden_channels=hidden_channels, num_layers=num_layers, data_metadata=data_metadata,
+                                        regression=regression, activation_fn=activation_fn, symmetry_mode=symmetry_mode,
+                                        group_operator_path=group_operator_path)
+        self._finish_init(dummy_batch)
+
+
+class HGNN_C2_Lightning_Cls(_HGNNWrapper):
+    """`GRF_HGNN_C2` for contact classification (gnnLightning.py:515-562)."""
+
+    def __init__(self, hidden_channels: int, num_layers: int, data_metadata, dummy_batch, optimizer: str = "adam", lr: float = 0.003,
+                 regression: bool = True, activation_fn=nn.ReLU(), symmetry_mode: Optional[str] = None,
+                 group_operator_path: Optional[str] = None):
+        super().__init__(optimizer, lr, regression)
+        self.model = models.GRF_HGNN_C2(hidden_channels=hidden_channels, num_layers=num_layers, data_metadata=data_metadata,
+                                        regression=regression, activation_fn=activation_fn, symmetry_mode=symmetry_mode,
+                                        group_operator_path=group_operator_path)
+        self._finish_init(dummy_batch)
+
+
+class HGNN_C2_Lightning_Reg(_HGNNWrapper):
+    """`GRF_HGNN_C2` for GRF regression, optionally with the metrics ALSO evaluated in the world frame (gnnLightning.py:564-778): with
+    `grf_body_to_world_frame` the labels / predictions are rotated by the inverse of `batch.r_o` (world->body quaternions, scalar last)
+    on the device and a second metric state accumulates them; the loss that is returned stays the body-frame MSE (:709-716)."""
+    _label_width_is_output_width = True
+
+    def __init__(self, hidden_channels: int, num_layers: int, data_metadata, dummy_batch, optimizer: str = "adam", lr: float = 0.003,
+                 regression: bool = True, activation_fn=nn.ReLU(), symmetry_mode: Optional[str] = None,
+                 group_operator_path: Optional[str] = None, grf_body_to_world_frame: Optional[bool] = None, grf_dimension: int = 3):
+        super().__init__(optimizer, lr, regression)
+        self.model = models.GRF_HGNN_C2(hidden_channels=hidden_channels, num_layers=num_layers, data_metadata=data_metadata,
+                                        regression=regression, activation_fn=activation_fn, symmetry_mode=symmetry_mode,
+                                        group_operator_path=group_operator_path, grf_dimension=grf_dimension)
+        self._finish_init(dummy_batch)
+        self.body_to_world_frame = bool(grf_body_to_world_frame) if regression else False
+
+    # world-frame values: read from the second metric state
+    mse_loss_worldframe = property(lambda self: None if self.__dict__["_metrics_world"] is None else self._m(True).mse_loss)
+    rmse_loss_worldframe = property(lambda self: None if self.__dict__["_metrics_world"] is None else self._m(True).rmse_loss)
+    l1_loss_worldframe = property(lambda self: None if self.__dict__["_metrics_world"] is None else self._m(True).l1_loss)
+
+    def body_frame_to_world_frame(self, batch_r_quat, grf_bodyFrame):
+        return self._m().body_frame_to_world_frame(batch_r_quat, grf_bodyFrame)
+
+    def calculate_losses_step_original(self, y: torch.Tensor, y_pred: torch.Tensor):
+        Base_Lightning.calculate_losses_step(self, y, y_pred)
+
+    def calculate_losses_step_worldframe(self, y, y_pred, batch_r_quat, test_only_on_z: bool = False):
+        self.calculate_losses_step_original(y, y_pred)
+        y_world = self.body_frame_to_world_frame(batch_r_quat, y.detach())
+        y_pred_world = self.body_frame_to_world_frame(batch_r_quat, y_pred.detach())
+        if test_only_on_z:
+            y_world, y_pred_world = y_world[:, [2, 5, 8, 11]], y_pred_world[:, [2, 5, 8, 11]]
+        self._m(True).calculate_losses_step(y_world, y_pred_world)
+
+    def calculate_losses_step(self, y, y_pred, batch_r_quat=None):
+        if self.body_to_world_frame:
+            if batch_r_quat is None:
+                raise ValueError("grf_body_to_world_frame needs the batch's r_o quaternions")
+            self.calculate_losses_step_worldframe(y, y_pred, batch_r_quat)
+        else:
+            self.calculate_losses_step_original(y, y_pred)
+
+    def log_losses_worldframe(self, step_name: str, on_step: bool):
+        self.log_losses(step_name, on_step)
+        for label, attr in _REG:
+            self.log(f"{step_name}_{label}_WorldFrame", getattr(self, attr + "_worldframe"), on_step=on_step, on_epoch=not on_step)
+
+    def calculate_losses_epoch_worldframe(self) -> None:
+        self.calculate_losses_epoch()
+        self._m(True).calculate_losses_epoch()
+
+    def reset_all_metrics_worldframe(self) -> None:
+        self.reset_all_metrics()
+        self._m(True).reset_all_metrics()
+
+    def _step(self, batch):
+        y, y_pred = self.step_helper_function(batch)
+        if self.body_to_world_frame:
+            self.calculate_losses_step_worldframe(y, y_pred, batch.r_o.view(batch.batch_size, 4))
+        else:
+            self.calculate_losses_step_original(y, y_pred)
+
+    def training_step(self, batch, batch_idx):
+        self._step(batch)
+        (self.log_losses_worldframe if self.body_to_world_frame else self.log_losses)("train", on_step=True)
+        return self._loss()
+
+    def validation_step(self, batch, batch_idx):
+        self._step(batch)
+        return self._loss()
+
+    def on_validation_epoch_start(self):
+        (self.reset_all_metrics_worldframe if self.body_to_world_frame else self.reset_all_metrics)()
+
+    def on_validation_epoch_end(self):
+        if self.body_to_world_frame:
+            self.calculate_losses_epoch_worldframe()
+            self.log_losses_worldframe("val", on_step=False)
+        else:
+            self.calculate_losses_epoch()
+            self.log_losses("val", on_step=False)
+
+    def on_test_epoch_start(self):
+        self.on_validation_epoch_start()
+
+    def on_test_epoch_end(self):
+        if self.body_to_world_frame:
+            self.calculate_losses_epoch_worldframe()
+            self.log_losses_worldframe("test", on_step=False)
+        else:
+            self.calculate_losses_epoch()
+            self.log_losses("test", on_step=False)

@@ -1,0 +1,104 @@
+"""The training-step wrappers (morphsym_hgnn_amd/wrappers.py) against the golden vectors: `training_step` returns the loss the reference's
+Lightning modules return (gnnLightning.py:179-186, 709-722) and `loss.backward()` leaves the golden parameter gradients -- with the loss
+and its gradient coming from the device metric kernels, not from torch's loss arithmetic."""
+import types
+
+import pytest
+import torch
+
+from tests import helpers
+
+
+def _batch(x_dict, ei, y, B, dev, r_o=None):
+    b = types.SimpleNamespace(x_dict={k: v.to(dev) for k, v in x_dict.items()}, edge_index_dict={k: v.to(dev) for k, v in ei.items()},
+                              y=y.to(dev).flatten(), batch_size=B)
+    if r_o is not None:
+        b.r_o = r_o.to(dev).flatten()
+    return b
+
+
+def _wrapper(case, spec, dummy, **kw):
+    from morphsym_hgnn_amd import wrappers
+    _, cfg = helpers.load_group(case["cfg"])
+    meta = spec.topology.metadata()
+    sym = dict(symmetry_mode="MorphSym" if cfg else None, group_operator_path=cfg)
+    if case["kind"] == "c2" and case["regression"]:
+        return wrappers.HGNN_C2_Lightning_Reg(case["hidden"], case["layers"], meta, dummy, lr=1e-4, grf_dimension=case["grf"], **sym, **kw)
+    if case["kind"] == "c2":
+        return wrappers.HGNN_C2_Lightning_Cls(case["hidden"], case["layers"], meta, dummy, lr=1e-4, regression=False, **sym, **kw)
+    if case["kind"] == "k4":
+        return wrappers.HGNN_K4_Lightning(case["hidden"], case["layers"], meta, dummy, lr=1e-4, regression=case["regression"], **sym, **kw)
+    return wrappers.Heterogeneous_GNN_Lightning(case["hidden"], case["layers"], meta, dummy, lr=1e-4, regression=case["regression"],
+                                                grf_dimension=case["grf"], **kw)
+
+
+def test_optimizer_setting_and_missing_helper_raise_like_the_reference():
+    from morphsym_hgnn_amd import wrappers
+    w = wrappers.Base_Lightning("lbfgs", 1e-3, True)
+    w.lin = torch.nn.Linear(2, 2)
+    with pytest.raises(ValueError, match="Invalid optimizer setting"):       # gnnLightning.py:264
+        w.configure_optimizers()
+    w.optimizer = "sgd"
+    assert isinstance(w.configure_optimizers(), torch.optim.SGD)
+    w.optimizer = "adam"
+    opt = w.configure_optimizers()
+    assert isinstance(opt, torch.optim.Adam) and opt.defaults["lr"] == 1e-3
+    with pytest.raises(NotImplementedError):
+        w.step_helper_function(None)
+    assert w.mse_loss is None and w.ce_loss is None          # before the first step, as in the reference's constructor (:65-74)
+    p = torch.tensor([[0.2, -1.0, 3.0, 0.5, 0.1, 0.0, -2.0, 2.0]])
+    per_foot, prob, only1 = w.classification_calculate_useful_values(p, 1)
+    assert per_foot.shape == (4, 2) and torch.allclose(prob.sum(1), torch.ones(4)) and only1.shape == (1, 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["a1c2_h128_L3_d3_B3", "mck4_cls_h128_L2_B3", "mi_h128_L2_d1_B3", "mcc2_cls_h128_L2_B3"])
+def test_training_step_returns_the_golden_loss_and_backward_the_golden_gradients(name):
+    torch.set_default_dtype(torch.float64)
+    case, spec, fx, x_dict, y, params, ei = helpers.load_case(name)
+    B = case["B"]
+    dev = torch.device("cuda")
+    batch = _batch(x_dict, ei, y, B, dev)
+    w = _wrapper(case, spec, batch).to(dev)
+    w.model.load_state_dict(params)
+    loss = w.training_step(batch, 0)
+    assert loss.requires_grad and loss is (w.mse_loss if case["regression"] else w.ce_loss)
+    loss.backward()
+    grads = {k: (p.grad.detach().cpu() if p.grad is not None else torch.zeros_like(p).cpu()) for k, p in w.model.named_parameters()}
+    out = w.model(x_dict=batch.x_dict, edge_index_dict=batch.edge_index_dict)
+    helpers.check_against_fixture(fx, out.detach().cpu(), loss.detach().cpu(), grads, rtol=1e-4, what=name)
+    key = "train_MSE_loss" if case["regression"] else "train_CE_loss"
+    assert torch.equal(w.logged[key], loss)
+    if not case["regression"]:
+        assert 0.0 <= float(w.logged["train_Accuracy"]) <= 1.0 and "train_F1_Score_Leg_3" in w.logged
+    # validation: epoch values are the ratio of the accumulated sums; one optimizer step runs on the view parameters
+    w.on_validation_epoch_start()
+    with torch.no_grad():        # (as a Trainer runs validation)
+        v1 = w.validation_step(batch, 0); v2 = w.validation_step(batch, 1)
+    assert not v1.requires_grad
+    w.on_validation_epoch_end()
+    ep = w.logged["val_MSE_loss" if case["regression"] else "val_CE_loss"]
+    assert abs(float(ep) - 0.5 * (float(v1) + float(v2))) <= 1e-6 * abs(float(ep))
+    opt = w.configure_optimizers()
+    before = w.model.decoder.weight.detach().clone()
+    opt.step()
+    assert not torch.equal(before, w.model.decoder.weight.detach())
+
+
+@pytest.mark.gpu
+def test_world_frame_metrics_follow_the_rotated_forces():
+    """HGNN_C2_Lightning_Reg(grf_body_to_world_frame=True): the returned loss stays the body-frame MSE, the *_WorldFrame values are the
+    metrics of the rotated labels / predictions (gnnLightning.py:621-631, 663-676) -- rotation invariance makes MSE equal in both frames."""
+    torch.set_default_dtype(torch.float64)
+    case, spec, fx, x_dict, y, params, ei = helpers.load_case("a1c2_h128_L3_d3_B3")
+    B = case["B"]
+    dev = torch.device("cuda")
+    q = torch.randn(B, 4, generator=torch.Generator().manual_seed(0))
+    batch = _batch(x_dict, ei, y, B, dev, r_o=q)
+    w = _wrapper(case, spec, batch, grf_body_to_world_frame=True).to(dev)
+    w.model.load_state_dict(params)
+    loss = w.training_step(batch, 0)
+    assert loss.requires_grad
+    assert abs(float(w.mse_loss_worldframe) - float(loss)) <= 1e-5 * float(loss)          # rotations preserve the squared error
+    assert abs(float(w.logged["train_RMSE_loss_WorldFrame"]) - float(loss) ** 0.5) <= 1e-5 * float(loss) ** 0.5
+    assert float(w.l1_loss_worldframe) > 0 and abs(float(w.l1_loss_worldframe) - float(w.l1_loss)) > 0      # L1 is frame dependent
