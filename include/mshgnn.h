@@ -248,6 +248,15 @@ int mshgnn_metrics_regression_step(const float* y_pred, const float* y, int64_t 
 int mshgnn_metrics_classification_step(const float* logits, const int32_t* y, int64_t batch, double* batch_ce, int64_t* batch_counts,
                                        double* epoch_ce, int64_t* epoch_counts, float* grad_out, void* scratch, void* stream);
 
+/* The extra sums of the centroidal-momentum wrappers (COM_Base_Lightning.calculate_losses_step, gnnLightning_com.py:96-121;
+ * CosineSimilarityMetric, customMetrics.py:56-95): y_pred / y fp32 [batch][n_bases][6], each base node (lin(3) | ang(3)), standardised;
+ * y_mean / y_std: HOST double[6] of the dataset's Standarizer (soloDataset.py:12-46).  state double[8] (batch_state overwritten,
+ * epoch_state added into, either nullable):  [0] sum sq err of the lin halves  [1] of the ang halves  [2] = [3] 3 n_bases batch
+ * [4] sum over windows of cos(lin_pred, lin) of base node 0 after un-standardising  [5] the same for ang  [6] batch  [7] 0.
+ * MSE_lin = [0]/[2], MSE_ang = [1]/[3], cos_sim_lin = [4]/[6], cos_sim_ang = [5]/[6].  scratch: as for the two calls above.          */
+int mshgnn_metrics_com_step(const float* y_pred, const float* y, int64_t batch, int n_bases, const double* y_mean, const double* y_std,
+                            double* batch_state, double* epoch_state, void* scratch, void* stream);
+
 /* body_frame_to_world_frame (gnnLightning.py:663-676) without the per-step CPU/scipy round trip: quat fp32 [batch][4] is
  * the world->body rotation, scalar-last (x, y, z, w) as scipy.Rotation.from_quat takes it; grf fp32 [batch][4][3].       */
 int mshgnn_grf_body_to_world(const float* quat, const float* grf_body, float* grf_world, int64_t batch, void* stream);

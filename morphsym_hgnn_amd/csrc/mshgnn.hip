@@ -2722,6 +2722,91 @@ template <int NT> __global__ __launch_bounds__(NT) void k_metrics_cls(const floa
     }
 }
 
+// centroidal-momentum wrappers (gnnLightning_com.py:96-121): y / y_pred [B][nb][6] = per base node (lin(3) | ang(3)), standardised.
+//   state[0] += sum sq err of the lin halves, [1] += of the ang halves, [2] += 3 nb B, [3] += 3 nb B,
+//   [4] += sum over windows of cos(lin_pred, lin) of base node 0 after un-standardising (v * y_std + y_mean), [5] += the same for ang,
+//   [6] += B.  Cosine similarity as torch.nn.CosineSimilarity(dim=1, eps=1e-8): sum (a / max(|a|, eps)) (b / max(|b|, eps))
+//   (customMetrics.py:56-95).  One thread per window; multi-workgroup with the ticket scheme above.
+struct MetScratchCom { unsigned int ticket, pad; double f[MET_BLOCKS][4]; };
+static_assert(sizeof(MetScratchCom) <= MSHGNN_METRICS_SCRATCH_BYTES, "include/mshgnn.h promises this scratch size");
+struct ComStats { double mean[6], std[6]; };
+
+__global__ __launch_bounds__(MET_THREADS) void k_metrics_com(const float* pred, const float* y, int64_t B, int nb, ComStats st, double* batch, double* epoch,
+                                                             MetScratchCom* sc) {
+    __shared__ double r[MET_THREADS / 64][4], pf[MET_BLOCKS][4];
+    __shared__ int s_last;
+    double a[4] = {0.0, 0.0, 0.0, 0.0};      // sq lin, sq ang, cos lin, cos ang
+    for (int64_t w = (int64_t)blockIdx.x * MET_THREADS + threadIdx.x; w < B; w += (int64_t)gridDim.x * MET_THREADS) {
+        for (int b = 0; b < nb; ++b)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const double d = (double)pred[(w * nb + b) * 6 + k] - (double)y[(w * nb + b) * 6 + k];
+                a[k < 3 ? 0 : 1] += d * d;
+            }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            double pp = 0.0, yy = 0.0, py = 0.0, pv[3], yv[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                pv[k] = (double)pred[w * nb * 6 + 3 * h + k] * st.std[3 * h + k] + st.mean[3 * h + k];
+                yv[k] = (double)y[w * nb * 6 + 3 * h + k] * st.std[3 * h + k] + st.mean[3 * h + k];
+                pp += pv[k] * pv[k]; yy += yv[k] * yv[k];
+            }
+            const double pn = fmax(sqrt(pp), 1e-8), yn = fmax(sqrt(yy), 1e-8);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) py += (pv[k] / pn) * (yv[k] / yn);
+            a[2 + h] += py;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] = wave_sum(a[k]);
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[threadIdx.x >> 6][k] = a[k];
+    __syncthreads();
+    double t[4] = {0.0, 0.0, 0.0, 0.0};
+    if (threadIdx.x == 0) {
+        for (int v = 0; v < MET_THREADS / 64; ++v)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[k] += r[v][k];
+        if (sc)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) met_store(&sc->f[blockIdx.x][k], t[k]);
+        s_last = 1;
+        if (sc) {
+            __atomic_thread_fence(__ATOMIC_RELEASE);
+            const unsigned int tk = __hip_atomic_fetch_add(&sc->ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = tk == gridDim.x - 1;
+        }
+    }
+    if (sc) {
+        __syncthreads();
+        if (!s_last) return;
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        if (threadIdx.x < gridDim.x)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pf[threadIdx.x][k] = met_load(&sc->f[threadIdx.x][k]);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[k] = 0.0;
+            for (unsigned b = 0; b < gridDim.x; ++b)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) t[k] += pf[b][k];
+            __hip_atomic_store(&sc->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (threadIdx.x == 0) {
+        const double n3 = 3.0 * (double)nb * (double)B;
+        const double v[8] = {t[0], t[1], n3, n3, t[2], t[3], (double)B, 0.0};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (batch) batch[k] = v[k];
+            if (epoch) epoch[k] += v[k];
+        }
+    }
+}
+
 // GRF body frame -> world frame (gnnLightning.py:663-676): quat = world->body rotation, scalar-last (x, y, z, w) as scipy's
 // Rotation.from_quat takes it (normalised here as scipy does); world = R(quat)^-1 f for each of the 4 feet.
 __global__ void k_grf_to_world(const float* quat, const float* body, float* world, int64_t B) {
@@ -2776,6 +2861,18 @@ extern "C" int mshgnn_metrics_classification_step(const float* logits, const int
     hipLaunchKernelGGL(k_metrics_cls<MET_THREADS>, dim3(met_blocks(batch, 1)), dim3(MET_THREADS), 0, (hipStream_t)stream, logits, y, batch, batch_ce,
                        reinterpret_cast<long long*>(batch_counts), epoch_ce, reinterpret_cast<long long*>(epoch_counts), grad_out,
                        reinterpret_cast<MetScratch*>(scratch));
+    HIPCHK(hipGetLastError());
+    return MSHGNN_OK;
+}
+
+extern "C" int mshgnn_metrics_com_step(const float* y_pred, const float* y, int64_t batch, int n_bases, const double* y_mean, const double* y_std,
+                                       double* batch_state, double* epoch_state, void* scratch, void* stream) {
+    if (!y_pred || !y || !y_mean || !y_std || batch < 1 || n_bases < 1 || !scratch || (!batch_state && !epoch_state))
+        return set_err(MSHGNN_EINVAL, "bad argument to mshgnn_metrics_com_step");
+    ComStats st;
+    for (int k = 0; k < 6; ++k) { st.mean[k] = y_mean[k]; st.std[k] = y_std[k]; }
+    hipLaunchKernelGGL(k_metrics_com, dim3(met_blocks(batch, 1)), dim3(MET_THREADS), 0, (hipStream_t)stream, y_pred, y, batch, n_bases, st, batch_state,
+                       epoch_state, reinterpret_cast<MetScratchCom*>(scratch));
     HIPCHK(hipGetLastError());
     return MSHGNN_OK;
 }

@@ -196,3 +196,55 @@ class StepMetrics:
         eng._check(self.lib, self.lib.mshgnn_grf_body_to_world(q.data_ptr(), g.data_ptr(), out.data_ptr(), n, _stream(dev)),
                    "mshgnn_grf_body_to_world")
         return out.to(grf_body_frame.dtype)
+
+
+class ComStepMetrics(StepMetrics):
+    """Metric bookkeeping of the centroidal-momentum wrappers (`COM_Base_Lightning`, gnnLightning_com.py:28-232): the regression values of
+    `StepMetrics` (`mse_loss` differentiable, `rmse_loss`) plus `mse_loss_lin`, `mse_loss_ang`, `cos_sim_lin`, `cos_sim_ang`, `avg_cos_sim`
+    and `loss` (= `mse_loss`, :121).  `y_mean` / `y_std`: the 6 label statistics of the dataset's `Standarizer` (soloDataset.py:12-46) --
+    the cosine similarities are taken on base node 0 after un-standardising.  Two launches per step."""
+
+    def __init__(self, num_bases: int, y_mean, y_std, device=None):
+        super().__init__(regression=True, device=device)
+        self.num_bases = int(num_bases)
+        mean = [float(v) for v in torch.as_tensor(y_mean, dtype=torch.float64).flatten().tolist()]
+        std = [float(v) for v in torch.as_tensor(y_std, dtype=torch.float64).flatten().tolist()]
+        if len(mean) != 6 or len(std) != 6:
+            raise ValueError("y_mean and y_std must have 6 entries (lin(3) | ang(3))")
+        self._mean, self._std = (C.c_double * 6)(*mean), (C.c_double * 6)(*std)
+        self._com_epoch = torch.zeros(8, dtype=torch.float64, device=self.device)
+        self._com_cur = None
+        self._com_scratch = torch.zeros(16384 // 8, dtype=torch.int64, device=self.device)
+
+    def calculate_losses_step(self, y: torch.Tensor, y_pred: torch.Tensor):
+        super().calculate_losses_step(y, y_pred)
+        dev = self.device
+        yp = y_pred.detach().to(dev, torch.float32).flatten().contiguous()
+        yy = y.detach().to(dev, torch.float32).flatten().contiguous()
+        per = self.num_bases * 6
+        if yp.numel() != yy.numel() or yp.numel() % per:
+            raise ValueError(f"y and y_pred must hold batch x {self.num_bases} x 6 values")
+        cur = torch.empty(8, dtype=torch.float64, device=dev)
+        with torch.cuda.device(dev):
+            eng._check(self.lib, self.lib.mshgnn_metrics_com_step(yp.data_ptr(), yy.data_ptr(), yp.numel() // per, self.num_bases, self._mean, self._std,
+                                                                  cur.data_ptr(), self._com_epoch.data_ptr(), self._com_scratch.data_ptr(), _stream(dev)),
+                       "mshgnn_metrics_com_step")
+        self._com_cur = cur
+
+    def calculate_losses_epoch(self) -> None:
+        super().calculate_losses_epoch()
+        self._com_cur = self._com_epoch.clone()
+
+    def reset_all_metrics(self) -> None:
+        super().reset_all_metrics()
+        self._com_epoch.zero_()
+
+    def _com(self, i, j):
+        return None if self._com_cur is None else self._com_cur[i] / self._com_cur[j]
+
+    mse_loss_lin = property(lambda self: self._com(0, 2))
+    mse_loss_ang = property(lambda self: self._com(1, 3))
+    cos_sim_lin = property(lambda self: self._com(4, 6))
+    cos_sim_ang = property(lambda self: self._com(5, 6))
+    avg_cos_sim = property(lambda self: None if self._com_cur is None else (self.cos_sim_lin + self.cos_sim_ang) / 2)
+    loss = property(lambda self: self.mse_loss)

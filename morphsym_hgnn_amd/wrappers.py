@@ -2,7 +2,8 @@
 
 Same class names, constructor arguments, method names and return values as `src/ms_hgnn/lightning_py/gnnLightning.py`:
 `Base_Lightning` (:28-348), `Heterogeneous_GNN_Lightning` (:415-462), `HGNN_K4_Lightning` (:464-513), `HGNN_C2_Lightning_Cls`
-(:515-562), `HGNN_C2_Lightning_Reg` (:564-778).  What differs is where the work runs: the model is this package's (HIP engine), the
+(:515-562), `HGNN_C2_Lightning_Reg` (:564-778), and of `gnnLightning_com.py`: `COM_Base_Lightning` (:28-232), `COM_HGNN_Lightning`
+(:290-340), `COM_HGNN_SYM_Lightning` (:343-409).  What differs is where the work runs: the model is this package's (HIP engine), the
 metric bookkeeping is `metrics.StepMetrics` (one launch per step, the returned loss carries autograd) and the world-frame rotation of
 the GRFs stays on the device instead of the reference's per-step CPU + scipy hop (:663-676).
 
@@ -311,3 +312,133 @@ class HGNN_C2_Lightning_Reg(_HGNNWrapper):
         else:
             self.calculate_losses_epoch()
             self.log_losses("test", on_step=False)
+
+
+# ---- centroidal-momentum wrappers (src/ms_hgnn/lightning_py/gnnLightning_com.py) ---------------------------------------------------
+_COM_LOGS = (("MSE_loss", "mse_loss"), ("RMSE_loss", "rmse_loss"), ("MSE_loss_lin", "mse_loss_lin"), ("MSE_loss_ang", "mse_loss_ang"),
+             ("cos_sim_lin", "cos_sim_lin"), ("cos_sim_ang", "cos_sim_ang"), ("avg_cos_sim", "avg_cos_sim"), ("loss", "loss"))
+
+
+class COM_Base_Lightning(_Base):
+    """`COM_Base_Lightning` (gnnLightning_com.py:28-232).  `data_path` is the dataset folder whose `processed/rss_stats.npz` holds the
+    label statistics (`y_mean`, `y_std`) the cosine-similarity metrics un-standardise with (:52-58); `stats=(y_mean, y_std)` hands them
+    over directly (synthetic data, tests)."""
+
+    def __init__(self, optimizer: str, lr: float, data_path=None, stats=None):
+        super().__init__()
+        self.optimizer, self.lr, self.data_path = optimizer, lr, data_path
+        self.regression = True
+        if stats is None:
+            import os
+            import numpy as np
+            if data_path is None:
+                raise ValueError("COM wrappers need data_path (processed/rss_stats.npz) or stats=(y_mean, y_std)")
+            st = np.load(os.path.join(str(data_path), "processed", "rss_stats.npz"))
+            stats = (st["y_mean"], st["y_std"])
+        self.__dict__["_stats"] = stats
+        self.__dict__["_metrics"] = None
+        self.logged = {}
+
+    def _m(self):
+        if self.__dict__["_metrics"] is None:
+            from .metrics import ComStepMetrics
+            self.__dict__["_metrics"] = ComStepMetrics(self.model.num_bases, *self.__dict__["_stats"])
+        return self.__dict__["_metrics"]
+
+    if _L is None:
+        def log(self, name, value, on_step: bool = False, on_epoch: bool = True, **_):
+            self.logged[name] = value
+
+    def log_losses(self, step_name: str, on_step: bool):
+        for label, attr in _COM_LOGS:
+            self.log(f"{step_name}_{label}", getattr(self, attr), on_step=on_step, on_epoch=not on_step)
+
+    def calculate_losses_step(self, y: torch.Tensor, y_pred: torch.Tensor):
+        self._m().calculate_losses_step(y, y_pred)
+
+    def calculate_losses_epoch(self) -> None:
+        self._m().calculate_losses_epoch()
+
+    def reset_all_metrics(self) -> None:
+        self._m().reset_all_metrics()
+
+    def training_step(self, batch, batch_idx):
+        y, y_pred = self.step_helper_function(batch)
+        self.calculate_losses_step(y, y_pred)
+        self.log_losses("train", on_step=True)
+        return self.loss
+
+    def on_validation_epoch_start(self):
+        self.reset_all_metrics()
+
+    def validation_step(self, batch, batch_idx):
+        y, y_pred = self.step_helper_function(batch)
+        self.calculate_losses_step(y, y_pred)
+        return self.loss
+
+    def on_validation_epoch_end(self):
+        self.calculate_losses_epoch()
+        self.log_losses("val", on_step=False)
+
+    def on_test_epoch_start(self):
+        self.reset_all_metrics()
+
+    def test_step(self, batch, batch_idx):
+        return self.validation_step(batch, batch_idx)
+
+    def on_test_epoch_end(self):
+        self.calculate_losses_epoch()
+        self.log_losses("test", on_step=False)
+
+    def configure_optimizers(self):
+        return Base_Lightning.configure_optimizers(self)
+
+    def step_helper_function(self, batch):
+        """Outputs and labels per window, [batch, num_bases * 6] (gnnLightning_com.py:324-340, 394-409)."""
+        out_raw = self.model(x_dict=batch.x_dict, edge_index_dict=batch.edge_index_dict)
+        batch_size = batch.batch_size if hasattr(batch, "batch_size") else 1
+        width = self.model.num_bases * self.model.num_dimensions_per_base
+        return torch.reshape(batch.y, (batch_size, width)), torch.reshape(out_raw.squeeze(), (batch_size, width))
+
+    def _finish_init(self, dummy_batch):
+        with torch.no_grad():
+            self.model(x_dict=dummy_batch.x_dict, edge_index_dict=dummy_batch.edge_index_dict)
+        if _L is not None:  # pragma: no cover
+            self.save_hyperparameters(ignore=["dummy_batch", "activation_fn"])
+
+
+for _n in ("mse_loss", "rmse_loss", "mse_loss_lin", "mse_loss_ang", "cos_sim_lin", "cos_sim_ang", "avg_cos_sim", "loss"):
+    setattr(COM_Base_Lightning, _n, property(lambda self, _n=_n: None if self.__dict__.get("_metrics") is None else getattr(self.__dict__["_metrics"], _n)))
+
+
+class COM_HGNN_Lightning(COM_Base_Lightning):
+    """`COM_HGNN` (one base node, no symmetry; gnnLightning_com.py:290-340)."""
+
+    def __init__(self, hidden_channels: int, num_layers: int, data_metadata, dummy_batch, optimizer: str = "adam", lr: float = 0.003,
+                 regression: bool = True, activation_fn=nn.ReLU(), com_dimension: int = 6, data_path=None, stats=None):
+        super().__init__(optimizer, lr, data_path, stats)
+        self.model = models.COM_HGNN(hidden_channels=hidden_channels, num_layers=num_layers, data_metadata=data_metadata, regression=regression,
+                                     activation_fn=activation_fn, com_dimension=com_dimension)
+        self.regression = regression
+        self._finish_init(dummy_batch)
+
+
+class COM_HGNN_SYM_Lightning(COM_Base_Lightning):
+    """`COM_HGNN_K4` / `COM_HGNN_C2` / `COM_HGNN_S4` by `model_type` (gnnLightning_com.py:343-409)."""
+
+    def __init__(self, hidden_channels: int, num_layers: int, data_metadata, dummy_batch, optimizer: str = "adam", lr: float = 0.003,
+                 regression: bool = True, activation_fn=nn.ReLU(), symmetry_mode: Optional[str] = None, group_operator_path: Optional[str] = None,
+                 model_type: str = "heterogeneous_gnn_k4_com", data_path=None, stats=None):
+        super().__init__(optimizer, lr, data_path, stats)
+        common = dict(hidden_channels=hidden_channels, num_layers=num_layers, data_metadata=data_metadata, regression=regression,
+                      activation_fn=activation_fn)
+        if model_type == "heterogeneous_gnn_k4_com":
+            self.model = models.COM_HGNN_K4(symmetry_mode=symmetry_mode, group_operator_path=group_operator_path, **common)
+        elif model_type == "heterogeneous_gnn_c2_com":
+            self.model = models.COM_HGNN_C2(symmetry_mode=symmetry_mode, group_operator_path=group_operator_path, **common)
+        elif model_type == "heterogeneous_gnn_s4_com":
+            self.model = models.COM_HGNN_S4(**common)
+        else:
+            raise ValueError(f"unknown model_type '{model_type}'")
+        self.regression = regression
+        self._finish_init(dummy_batch)

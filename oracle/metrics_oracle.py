@@ -2,7 +2,9 @@
 bookkeeping of the reference's Lightning wrappers, torchmetrics-free.
 
 Restates src/ms_hgnn/lightning_py/gnnLightning.py:124-151 (calculate_losses_step), :285-348 (softmax helper, 16-class
-conversion), :663-676 (body_frame_to_world_frame) and customMetrics.py:5-54 (CrossEntropyLossMetric, BinaryF1Score).
+conversion), :663-676 (body_frame_to_world_frame), customMetrics.py:5-54 (CrossEntropyLossMetric, BinaryF1Score) and, for the
+centroidal-momentum wrappers, gnnLightning_com.py:96-121 with customMetrics.py:56-95 (CosineSimilarityMetric; pinned against
+torch.nn.CosineSimilarity itself in tests/test_metrics.py -- the reference's tests hold no known answer for it).
 torchmetrics 1.x (environment_files/requirements.txt) is absent from this image; its three members used here have
 published closed forms: MeanSquaredError(squared=True/False) = sum sq err / n (sqrt of it), MeanAbsoluteError =
 sum |err| / n, multiclass Accuracy(micro) = correct / total.
@@ -83,3 +85,25 @@ def body_frame_to_world_frame(quat, grf_body):
                   np.stack([2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1)], 1)   # [N, 3, 3]
     f = np.asarray(grf_body, dtype=np.float64).reshape(q.shape[0], 4, 3)
     return np.einsum("nji,nfj->nfi", R, f).reshape(q.shape[0], 12)
+
+
+def com_metrics(y, y_pred, n_bases, y_mean, y_std, eps=1e-8):
+    """COM_Base_Lightning.calculate_losses_step (gnnLightning_com.py:96-121) -> dict(mse, rmse, mse_lin, mse_ang, cos_sim_lin,
+    cos_sim_ang, avg_cos_sim).  y / y_pred: [B, n_bases * 6] standardised; the cosine similarities are taken on base node 0 after
+    un-standardising (soloDataset.py:33-46) with torch.nn.CosineSimilarity(dim=1)'s definition, batch mean (customMetrics.py:56-95)."""
+    y = np.asarray(y, dtype=np.float64).reshape(-1, n_bases, 6)
+    p = np.asarray(y_pred, dtype=np.float64).reshape(-1, n_bases, 6)
+    mse = np.mean(np.square(p - y))
+    out = {"mse": mse, "rmse": np.sqrt(mse), "mse_lin": np.mean(np.square(p[:, :, :3] - y[:, :, :3])),
+           "mse_ang": np.mean(np.square(p[:, :, 3:] - y[:, :, 3:]))}
+    yu = y * np.asarray(y_std, dtype=np.float64) + np.asarray(y_mean, dtype=np.float64)
+    pu = p * np.asarray(y_std, dtype=np.float64) + np.asarray(y_mean, dtype=np.float64)
+
+    def cos(a, b):
+        an = np.maximum(np.linalg.norm(a, axis=1, keepdims=True), eps)
+        bn = np.maximum(np.linalg.norm(b, axis=1, keepdims=True), eps)
+        return np.mean(np.sum((a / an) * (b / bn), axis=1))
+    out["cos_sim_lin"] = cos(pu[:, 0, :3], yu[:, 0, :3])
+    out["cos_sim_ang"] = cos(pu[:, 0, 3:], yu[:, 0, 3:])
+    out["avg_cos_sim"] = (out["cos_sim_lin"] + out["cos_sim_ang"]) / 2
+    return out

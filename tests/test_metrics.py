@@ -195,3 +195,56 @@ def test_accumulating_entry_points_agree_with_the_step_entry_points():
     mc.calculate_losses_step(yy, lg)
     torch.cuda.synchronize()
     assert torch.equal(cnt, mc._epoch_i) and torch.allclose(ce, mc._epoch_f[:2], rtol=1e-13, atol=0)
+
+
+# --- centroidal-momentum wrappers' metrics (gnnLightning_com.py:96-121) ----------------------------------------------------------------
+def _com_case(B=257, nb=4, seed=11):
+    g = torch.Generator().manual_seed(seed)
+    y = torch.randn(B, nb * 6, generator=g, dtype=torch.float64)
+    p = y + 0.3 * torch.randn(B, nb * 6, generator=g, dtype=torch.float64)
+    mean = torch.randn(6, generator=g, dtype=torch.float64)
+    std = torch.rand(6, generator=g, dtype=torch.float64) + 0.5
+    return y, p, mean, std
+
+
+def test_oracle_com_metrics_match_torch_cosine_similarity():
+    """The reference's tests hold no known answer for CosineSimilarityMetric: the oracle is pinned against torch.nn.CosineSimilarity and
+    plain torch arithmetic, following COM_Base_Lightning.calculate_losses_step line by line."""
+    y, p, mean, std = _com_case()
+    nb = 4
+    o = mo.com_metrics(y.numpy(), p.numpy(), nb, mean.numpy(), std.numpy())
+    yv, pv = y.view(-1, nb, 6), p.view(-1, nb, 6)
+    assert abs(o["mse"] - float(((p - y) ** 2).mean())) < 1e-14
+    assert abs(o["mse_lin"] - float(((pv[:, :, :3] - yv[:, :, :3]) ** 2).mean())) < 1e-14
+    assert abs(o["mse_ang"] - float(((pv[:, :, 3:] - yv[:, :, 3:]) ** 2).mean())) < 1e-14
+    yu, pu = yv * std + mean, pv * std + mean
+    cs = torch.nn.CosineSimilarity(dim=1)
+    assert abs(o["cos_sim_lin"] - float(cs(pu[:, 0, :3], yu[:, 0, :3]).sum() / y.shape[0])) < 1e-14
+    assert abs(o["cos_sim_ang"] - float(cs(pu[:, 0, 3:], yu[:, 0, 3:]).sum() / y.shape[0])) < 1e-14
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,nb", [(1, 1), (257, 4), (8192, 2)])
+def test_device_com_metrics_match_oracle_and_accumulate(B, nb):
+    from morphsym_hgnn_amd.metrics import ComStepMetrics
+    y, p, mean, std = _com_case(B, nb)
+    m = ComStepMetrics(nb, mean, std)
+    pr = p.cuda().requires_grad_(True)
+    m.calculate_losses_step(y.cuda(), pr)
+    o = mo.com_metrics(y.float().numpy(), p.float().numpy(), nb, mean.numpy(), std.numpy())        # (the kernels read fp32 copies)
+    for name, key in (("mse_loss", "mse"), ("rmse_loss", "rmse"), ("mse_loss_lin", "mse_lin"), ("mse_loss_ang", "mse_ang"),
+                      ("cos_sim_lin", "cos_sim_lin"), ("cos_sim_ang", "cos_sim_ang"), ("avg_cos_sim", "avg_cos_sim"), ("loss", "mse")):
+        assert abs(float(getattr(m, name)) - o[key]) <= 1e-12 * max(1.0, abs(o[key])), name
+    assert m.loss.requires_grad
+    m.loss.backward()
+    ref = 2 * (p.float().double() - y.float().double()) / p.numel()
+    assert float((pr.grad.cpu() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    # epoch = ratio of accumulated sums; two different batches
+    y2, p2, *_ = _com_case(B, nb, seed=12)
+    m.calculate_losses_step(y2.cuda(), p2.cuda())
+    m.calculate_losses_epoch()
+    oa = mo.com_metrics(torch.cat([y, y2]).float().numpy(), torch.cat([p, p2]).float().numpy(), nb, mean.numpy(), std.numpy())
+    assert abs(float(m.cos_sim_lin) - oa["cos_sim_lin"]) <= 1e-12 and abs(float(m.mse_loss_ang) - oa["mse_ang"]) <= 1e-12 * oa["mse_ang"]
+    m.reset_all_metrics()
+    m.calculate_losses_step(y.cuda(), p.cuda()); m.calculate_losses_epoch()
+    assert abs(float(m.mse_loss_lin) - o["mse_lin"]) <= 1e-12 * o["mse_lin"]
