@@ -323,31 +323,41 @@ def module_surface(spec, B, device, steps, warmup, precision):
     torch.set_default_dtype(torch.float64)      # the reference does (gnnLightning.py:1183)
     res = {"precision": precision, "what": "GRF_HGNN_C2.forward(x_dict on device, edge_index_dict) + MSE + loss.backward(), nn.Parameter weights"}
     try:
+        import types
+        from morphsym_hgnn_amd import wrappers
         cfg = os.path.join(ROOT, "morphsym_hgnn_amd", "cfg", "a1-c2.yaml")
-        m = models.GRF_HGNN_C2(spec.hidden, spec.num_layers, spec.topology.metadata(), symmetry_mode="MorphSym", group_operator_path=cfg)
-        load_into(m, {"state_dict": {"model." + k: v for k, v in synth.make_params(0, spec.param_shapes()).items()}})
-        m.set_precision(precision).to(device)
         x, y = make_batch(spec, B, 99)
         x64 = {k: v.to(device, torch.float64) for k, v in x.items()}
         y = y.to(device, torch.float64).view(B, -1)
         ei = spec.topology.edge_index_dict(B, device=device)
+        prev_env = os.environ.get("MSHGNN_DTYPE")      # (the wrapper builds its model itself: the plan is chosen through MSHGNN_DTYPE)
+        os.environ["MSHGNN_DTYPE"] = precision
+        try:      # the reference's own entry: the wrapper builds the model and runs the lazy-initialising dummy forward (gnnLightning.py:564-595)
+            w = wrappers.HGNN_C2_Lightning_Reg(spec.hidden, spec.num_layers, spec.topology.metadata(),
+                                               types.SimpleNamespace(x_dict=dict(x64), edge_index_dict=ei), lr=1e-4, symmetry_mode="MorphSym",
+                                               group_operator_path=cfg)
+        finally:
+            if prev_env is None:
+                os.environ.pop("MSHGNN_DTYPE", None)
+            else:
+                os.environ["MSHGNN_DTYPE"] = prev_env
+        m = w.model
+        load_into(m, {"state_dict": {"model." + k: v for k, v in synth.make_params(0, spec.param_shapes()).items()}})
+        m.set_precision(precision)
+        w.to(device)
         with torch.no_grad():
             m(dict(x64), ei)
         e = next(iter(m._engines.values()))
         xplan = dict(zip(e.types, e.cast_inputs(x64)))
-
-        from morphsym_hgnn_amd.metrics import StepMetrics
-        sm = StepMetrics(regression=True, device=device)
         y32 = y.float()      # labels as the on-device window assembly hands them over
 
         def run(xin, device_loss=False):
             def step():
                 m.zero_grad(set_to_none=True)
-                out = m(dict(xin), ei)
-                if device_loss:      # the wrapper's metric bookkeeping on the device; its mse_loss carries autograd (metrics.StepMetrics)
-                    sm.calculate_losses_step(y32, out)
-                    loss = sm.mse_loss
+                if device_loss:      # the wrapper's own training_step: model + metric bookkeeping on the device, its mse_loss carries autograd
+                    loss = w.training_step(types.SimpleNamespace(x_dict=dict(xin), edge_index_dict=ei, y=y32, batch_size=B), 0)
                 else:
+                    out = m(dict(xin), ei)
                     loss = ((out.flatten() - y.flatten()) ** 2).mean()
                 loss.backward()
             for _ in range(warmup):
@@ -365,10 +375,10 @@ def module_surface(spec, B, device, steps, warmup, precision):
         dt64, dtp, dtm = run(x64), run(xplan), run(xplan, True)
         res.update({"ms_per_step": dt64 * 1e3, "value": B / dt64, "inputs": "fp64 on device (reference convention; cast every step)",
                     "plan_dtype_inputs": {"ms_per_step": dtp * 1e3, "value": B / dtp, "inputs": "already at the plan's input dtype and pitch (no cast)"},
-                    "plan_dtype_inputs_device_loss": {"ms_per_step": dtm * 1e3, "value": B / dtm,
-                                                      "what": "as plan_dtype_inputs with fp32 labels, the loss and the step metrics (MSE / RMSE / L1 sums, epoch "
-                                                              "accumulation, dL/dy_pred) from metrics.StepMetrics in one launch instead of torch's fp64 elementwise "
-                                                              "loss kernels"}})
+                    "wrapper_training_step": {"ms_per_step": dtm * 1e3, "value": B / dtm,
+                                                      "what": "wrappers.HGNN_C2_Lightning_Reg.training_step(batch) + loss.backward(): as plan_dtype_inputs with fp32 "
+                                                              "labels; the loss, the step metrics (MSE / RMSE / L1 sums, epoch accumulation) and dL/dy_pred come "
+                                                              "from one device launch instead of torch's fp64 elementwise loss kernels"}})
     finally:
         torch.set_default_dtype(prev)
     return res
