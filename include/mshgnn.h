@@ -236,8 +236,9 @@ int mshgnn_metrics_classification(const float* logits, const int32_t* y, int64_t
                                   void* stream);
 
 /* The same sums for one training / validation step in ONE multi-workgroup launch (what a wrapper's calculate_losses_step needs every step):
- * batch_* (nullable as a pair) receive this step's sums (overwritten -- no zeroing; batch_state / batch_ce are double[4]: the sums
- * followed by the step's loss itself, batch_state[3] = MSE, batch_ce[2] = cross entropy), epoch_* (nullable as a pair) have them added, and grad_out (nullable) receives the gradient of the step's loss with respect to the predictions -- what
+ * batch_* (nullable as a pair) receive this step's sums (overwritten -- no zeroing) followed by the step's published values, so that a
+ * wrapper logs them without further launches: batch_state double[8] = sq, abs, n, MSE, RMSE, L1, 0, 0; batch_ce double[8] = ce sum, rows,
+ * CE, 16-class accuracy, F1 of leg 0..3 (customMetrics.py:51-54, 0/0 -> 0); epoch_* (nullable as a pair; double[3] / double[2]) have the sums added, and grad_out (nullable) receives the gradient of the step's loss with respect to the predictions -- what
  * `training_step` returns for backward (gnnLightning.py:709-722): regression d MSE / d y_pred = 2 (y_pred - y) / n, fp32 [n];
  * classification d CE / d logits = (softmax - onehot) / (4 batch), fp32 [batch*4][2].  scratch: MSHGNN_METRICS_SCRATCH_BYTES of device
  * memory, 8-byte aligned, zeroed ONCE by the caller and then owned by these calls (per-workgroup partials + a ticket the kernel resets;

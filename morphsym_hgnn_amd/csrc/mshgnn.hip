@@ -2628,7 +2628,10 @@ template <int NT> __global__ __launch_bounds__(NT) void k_metrics_reg(const floa
         }
     }
     if (threadIdx.x == 0) {
-        if (batch) { batch[0] = ts; batch[1] = ta; batch[2] = (double)n; batch[3] = ts / (double)n; }      // [3]: this step's MSE
+        if (batch) {      // the sums, then the step's published values: MSE, RMSE, L1 (gnnLightning.py:124-130)
+            batch[0] = ts; batch[1] = ta; batch[2] = (double)n; batch[3] = ts / (double)n; batch[4] = sqrt(ts / (double)n); batch[5] = ta / (double)n;
+            batch[6] = batch[7] = 0.0;
+        }
         if (epoch) { epoch[0] += ts; epoch[1] += ta; epoch[2] += (double)n; }
     }
 }
@@ -2713,12 +2716,24 @@ template <int NT> __global__ __launch_bounds__(NT) void k_metrics_cls(const floa
         if (threadIdx.x == 0) __hip_atomic_store(&sc->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (threadIdx.x == 0) {
-        if (ce_b) { ce_b[0] = tce; ce_b[1] = (double)(4 * B); ce_b[2] = (double)(float)tce / (double)(4 * B); ce_b[3] = 0.0; }      // [2]: this step's CE, `summed_loss.float() / total_num` (customMetrics.py:24)
+        if (ce_b) { ce_b[0] = tce; ce_b[1] = (double)(4 * B); ce_b[2] = (double)(float)tce / (double)(4 * B); }      // [2]: this step's CE, `summed_loss.float() / total_num` (customMetrics.py:24)
         if (ce_state) { ce_state[0] += tce; ce_state[1] += (double)(4 * B); }
     }
     if (threadIdx.x < MET_COUNTS) {
         if (counts_b) counts_b[threadIdx.x] = tc;
         if (counts) counts[threadIdx.x] += tc;
+        if (ce_b) pc[0][threadIdx.x] = tc;                  // (pc: free again -- every partial has been added)
+    }
+    if (ce_b) {      // the step's published values next to its sums: [3] 16-class accuracy, [4..7] F1 of leg 0..3 (customMetrics.py:51-54, 0/0 -> 0)
+        __syncthreads();
+        if (threadIdx.x == 0) ce_b[3] = (double)pc[0][1] / (double)pc[0][0];
+        if (threadIdx.x >= 1 && threadIdx.x <= 4) {
+            const int k = threadIdx.x - 1;
+            const double tp = (double)pc[0][2 + 4 * k], fp = (double)pc[0][3 + 4 * k], fn = (double)pc[0][4 + 4 * k];
+            const double precision = tp / (tp + fp), recall = tp / (tp + fn);
+            const double f1 = 2.0 * (precision * recall) / (precision + recall);
+            ce_b[4 + k] = f1 != f1 ? 0.0 : f1;
+        }
     }
 }
 

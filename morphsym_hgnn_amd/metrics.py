@@ -49,7 +49,7 @@ class _StepLoss(torch.autograd.Function):
         buf, g = metrics._launch(y, y_pred, True)
         metrics._cur = buf          # (the sums are no autograd outputs: the only output is the loss the kernel left next to them)
         ctx.g, ctx.meta = g, (y_pred.shape, y_pred.dtype, y_pred.device)
-        return buf[:4].view(torch.float64)[3 if metrics.regression else 2]
+        return buf[:8].view(torch.float64)[3 if metrics.regression else 2]
 
     @staticmethod
     def backward(ctx, gl):
@@ -71,8 +71,9 @@ class StepMetrics:
         self.regression = regression
         self.device = _device(device)
         self.lib = eng.load_library()
-        # state layout (one buffer of 22 eight-byte words): [0:4] float64 -- regression: sq, abs, n | classification: ce, rows; [4:22] int64 counts
-        self._epoch = torch.zeros(22, dtype=torch.int64, device=self.device)
+        # state layout (one buffer of 26 eight-byte words): [0:8] float64 -- regression: sq, abs, n | classification: ce, rows (a step's buffer also
+        # holds the step's published values behind them, include/mshgnn.h); [8:26] int64 counts
+        self._epoch = torch.zeros(26, dtype=torch.int64, device=self.device)
         self._scratch = torch.zeros(16384 // 8, dtype=torch.int64, device=self.device)      # MSHGNN_METRICS_SCRATCH_BYTES: partials + ticket
         self._cur = None          # the state the published values are read from: the last step's, or the epoch's
         self._loss = None         # the last step's loss when it carries autograd
@@ -81,11 +82,11 @@ class StepMetrics:
 
     @property
     def _epoch_f(self):
-        return self._epoch[:4].view(torch.float64)
+        return self._epoch[:8].view(torch.float64)
 
     @property
     def _epoch_i(self):
-        return self._epoch[4:]
+        return self._epoch[8:]
 
     # ---- values from a state -----------------------------------------------------------------------------------
     def _names(self):
@@ -98,11 +99,11 @@ class StepMetrics:
             return None
         if name in self._vals:
             return self._vals[name]
-        f, i = self._cur[:4].view(torch.float64), self._cur[4:]
+        f, i = self._cur[:8].view(torch.float64), self._cur[8:]
         if name in ("mse_loss", "ce_loss") and self._loss is not None:
             v = self._loss
-        elif name in ("mse_loss", "ce_loss") and self._from_step:
-            v = f[3 if self.regression else 2]          # the kernel left the step's loss next to its sums
+        elif self._from_step:                              # the kernel left the step's values next to its sums: no launch
+            v = f[(_REG_NAMES.index(name) + 3) if self.regression else (_CLS_NAMES.index(name) + 2)]
         elif name == "mse_loss":
             v = f[0] / f[2]
         elif name == "rmse_loss":
@@ -133,7 +134,7 @@ class StepMetrics:
     def _launch(self, y: torch.Tensor, y_pred: torch.Tensor, want_grad: bool):
         """One launch: this batch's sums into a fresh state buffer, added into the epoch state, + dL/dy_pred (fp32) when asked for."""
         dev = self.device
-        buf = torch.empty(22, dtype=torch.int64, device=dev)
+        buf = torch.empty(26, dtype=torch.int64, device=dev)
         ep = self._epoch.data_ptr()
         with torch.cuda.device(dev):
             if self.regression:
@@ -150,8 +151,8 @@ class StepMetrics:
                 yp = y_pred.detach().to(dev, torch.float32).reshape(batch * 4, 2).contiguous()     # gnnLightning.py:300
                 yy = y.detach().to(dev, torch.int32).reshape(batch * 4).contiguous()
                 g = torch.empty_like(yp) if want_grad else None
-                eng._check(self.lib, self.lib.mshgnn_metrics_classification_step(yp.data_ptr(), yy.data_ptr(), batch, buf.data_ptr(), buf.data_ptr() + 32,
-                                                                                 ep, ep + 32, g.data_ptr() if want_grad else None, self._scratch.data_ptr(),
+                eng._check(self.lib, self.lib.mshgnn_metrics_classification_step(yp.data_ptr(), yy.data_ptr(), batch, buf.data_ptr(), buf.data_ptr() + 64,
+                                                                                 ep, ep + 64, g.data_ptr() if want_grad else None, self._scratch.data_ptr(),
                                                                                  _stream(dev)),
                            "mshgnn_metrics_classification_step")
         return buf, g
@@ -165,6 +166,11 @@ class StepMetrics:
             self._loss = None
             self._cur, _ = self._launch(y, y_pred, False)
         self._vals, self._from_step = {}, True
+
+    def set_step_loss(self, loss: torch.Tensor) -> None:
+        """Publish `loss` (a differentiable scalar the caller computed for this step, e.g. the fused engine step's) as `mse_loss` / `ce_loss`."""
+        self._loss = loss
+        self._vals.pop("mse_loss" if self.regression else "ce_loss", None)
 
     def calculate_losses_epoch(self) -> None:
         self._cur, self._loss, self._vals, self._from_step = self._epoch.clone(), None, {}, False

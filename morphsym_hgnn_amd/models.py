@@ -109,21 +109,62 @@ class _EngineFnFast(torch.autograd.Function):
             raise RuntimeError("the activation stash of this forward was overwritten by a later forward of the same "
                                "batch size on the same engine; call backward before the next forward")
         g32 = gout.contiguous().to(torch.float32)
-        params = m._param_list
-        if m._gflat is None or m._gflat.device != ctx.flat.device:
-            m._gflat = torch.zeros_like(ctx.flat)
-            m._gviews = [m._gflat[o:o + n].view(p.shape) for (o, n), p in zip(m._spec.param_offsets().values(), params)]
-        if all(p.grad is None for p in params[:2]):
-            e.backward(ctx.xs, ctx.flat, g32, ctx.B, grad_flat=m._gflat)
-            for p, v in zip(params, m._gviews):
-                if p.requires_grad:
-                    p.grad = v
-        else:
-            m._gflat.add_(e.backward(ctx.xs, ctx.flat, g32, ctx.B))
-            for p, v in zip(params, m._gviews):      # (a parameter whose .grad was cleared individually)
-                if p.requires_grad and p.grad is None:
-                    p.grad = v
+        _deliver_gradients(m, ctx.flat, lambda target: e.backward(ctx.xs, ctx.flat, g32, ctx.B, grad_flat=target))
         return (None, None, None, None, *([None] * len(ctx.xs)))
+
+
+def _deliver_gradients(m, flat, fresh, scale=None):
+    """Hand a freshly computed flat gradient to the parameters' .grad (views of the persistent m._gflat): assigned when the gradients were
+    cleared (zero_grad(set_to_none=True), the first step), ADDED in place otherwise -- what autograd's accumulation would have produced.
+    fresh: callable(target | None) -> the flat gradient, written into `target` when given."""
+    params = m._param_list
+    if m._gflat is None or m._gflat.device != flat.device:
+        m._gflat = torch.zeros_like(flat)
+        m._gviews = [m._gflat[o:o + n].view(p.shape) for (o, n), p in zip(m._spec.param_offsets().values(), params)]
+    if all(p.grad is None for p in params[:2]):
+        fresh(m._gflat)
+        if scale is not None:
+            m._gflat.mul_(scale)
+        for p, v in zip(params, m._gviews):
+            if p.requires_grad:
+                p.grad = v
+    else:
+        g = fresh(None)
+        m._gflat.add_(g if scale is None else g * scale)
+        for p, v in zip(params, m._gviews):      # (a parameter whose .grad was cleared individually)
+            if p.requires_grad and p.grad is None:
+                p.grad = v
+
+
+class _FusedStepFn(torch.autograd.Function):
+    """_MSHGNNBase.fused_training_step: the whole step (forward, wrapper loss, backward) runs in forward() as one engine call that leaves the
+    flat gradient in a pending buffer; backward() hands it to the parameters times the upstream factor (Lightning clears the gradients
+    BETWEEN training_step and backward, so nothing may touch .grad before).  target: fp32 labels (regression) or int32 contact flags."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, engine, B, target, *xs):
+        if model._gpend is None or model._gpend.device != model._flat.device:
+            model._gpend = torch.empty_like(model._flat)
+        step = engine.step_mse if model._spec.regression else engine.step_ce
+        out, loss, _ = step(xs, model._flat, target, B, grad_flat=model._gpend)
+        model._gpend_id += 1
+        ctx.model, ctx.flat, ctx.ticket = model, model._flat, model._gpend_id
+        ctx.mark_non_differentiable(out)
+        ctx.set_materialize_grads(False)      # (no zero tensor for the output's absent gradient)
+        return loss[0], out
+
+    @staticmethod
+    def backward(ctx, gl, _gout):
+        m = ctx.model
+        n_in = len(ctx.needs_input_grad)
+        if gl is None:
+            return (None,) * n_in
+        if m._gpend_id != ctx.ticket:
+            raise RuntimeError("the pending gradient of this training step was overwritten by a later fused training step of the same "
+                               "model; call backward before the next step")
+        pend, scale = m._gpend, gl.to(device=m._gpend.device, dtype=torch.float32)
+        _deliver_gradients(m, ctx.flat, lambda target: torch.mul(pend, scale, out=target) if target is not None else pend * scale)
+        return (None,) * n_in
 
 
 class _MSHGNNBase(nn.Module):
@@ -148,6 +189,8 @@ class _MSHGNNBase(nn.Module):
         self._flat_ok = False            # parameters are fp32 views into self._flat (device-resident fast path)
         self._param_list = None
         self._gflat = None               # persistent flat gradient + its cached per-parameter views (_EngineFnFast)
+        self._gpend = None               # the flat gradient a fused training step computed, until its backward() delivers it
+        self._gpend_id = 0
         self._gviews = None
         self._anchor = None
         self._checked_batches = set()
@@ -160,7 +203,7 @@ class _MSHGNNBase(nn.Module):
         state["_engines"] = {}
         state["_flat"] = None
         state["_flat_ok"] = False
-        state["_gflat"] = state["_gviews"] = state["_anchor"] = None
+        state["_gflat"] = state["_gviews"] = state["_anchor"] = state["_gpend"] = None
         state["_param_list"] = None
         state["_checked_batches"] = set()
         return state
@@ -197,7 +240,7 @@ class _MSHGNNBase(nn.Module):
                 v.copy_(p.detach())
                 p.data = v
         self._flat, self._flat_ok = flat, True
-        self._gflat = self._gviews = None
+        self._gflat = self._gviews = self._gpend = None
         self._anchor = torch.zeros((), device=pdev, requires_grad=True)
         return flat
 
@@ -270,7 +313,8 @@ class _MSHGNNBase(nn.Module):
         return self._engines[key]
 
     # ---- forward --------------------------------------------------------------------------------------
-    def forward(self, x_dict, edge_index_dict):
+    def _prepare(self, x_dict, edge_index_dict):
+        """Checks, lazy initialisation and the engine for this call: (spec, B, engine | None, device of the parameters' engine copy)."""
         for t in self._node_types:
             if t not in x_dict:
                 raise KeyError(f"x_dict lacks node type '{t}'")
@@ -302,7 +346,7 @@ class _MSHGNNBase(nn.Module):
                     raise ValueError(f"edge_index_dict[{et}] differs from the topology this model was compiled for")
             self._checked_batches.add(B)
         if not self._fused_activation:
-            return self._forward_operators(x_dict, edge_index_dict, B)
+            return spec, B, None, None
         pdev = self.decoder.weight.device
         if pdev.type != "cuda":
             # parameters still on the host (e.g. the wrapper's lazy-init call, gnnLightning.py:593-595, or
@@ -311,7 +355,45 @@ class _MSHGNNBase(nn.Module):
             if not torch.cuda.is_available():
                 raise RuntimeError("the MS-HGNN engine needs a HIP device; there is no CPU fallback")
             pdev = torch.device("cuda", torch.cuda.current_device())
-        e = self._engine(pdev)
+        return spec, B, self._engine(pdev), pdev
+
+    def _shape_output(self, out, spec, B, in_dev, in_dtype):
+        out = out.to(device=in_dev, dtype=in_dtype if in_dtype in (torch.float64, torch.float32) else torch.float32)
+        if spec.output_is_window_major:
+            return out.view(B, -1)      # ms_foot_decoder: [B, 4*3]   (hgnn_c2.py:184-189)
+        if spec.kind in ("k4_com", "c2_com"):
+            return out.view(B, spec.num_nodes["base"], spec.out_channels)   # morphological_symmetry_decoder, hgnn_k4_com.py:157-165
+        return out                      # [B*4, out_channels_per_foot]  (COM S4 / COM_HGNN: [B, com_dimension])
+
+    def fused_training_step(self, x_dict, edge_index_dict, y):
+        """forward + the wrapper's loss + backward in ONE engine call (mshgnn_step_mse / mshgnn_step_ce: the decoder, the loss and the decoder's
+        backward run in the tail of the fused forward kernel) for a caller that has the labels at forward time -- the training-step wrappers.
+        y: the batch's labels (regression: B * n_out * out_channels values; classification: B * 4 contact flags).  Returns (out, loss):
+        `out` as forward() returns it (no autograd), `loss` a scalar whose backward() delivers the parameter gradients the engine has
+        already computed (times the upstream factor) -- same values as forward() + loss + backward() through autograd.
+        Returns None when this route does not apply (gradients disabled, parameters on the host, the operator-by-operator path, more than
+        one process: DDP needs the per-parameter autograd hooks); the caller then takes the two-call route."""
+        spec, B, e, pdev = self._prepare(x_dict, edge_index_dict)
+        params = self._params_in_flat_order()
+        if e is None or not torch.is_grad_enabled() or params[0].device.type != "cuda" or not all(p.requires_grad for p in params):
+            return None
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return None
+        in_dev, in_dtype = x_dict[self._node_types[0]].device, x_dict[self._node_types[0]].dtype
+        xs = e.cast_inputs(x_dict)
+        self._flat_params(pdev)
+        if spec.regression:
+            target = y.detach().to(pdev, torch.float32).flatten().contiguous()
+        else:
+            target = (y.detach().to(pdev) != 0).to(torch.int32).flatten().contiguous()
+        loss, out = _FusedStepFn.apply(self._anchor, self, e, B, target, *xs)
+        return self._shape_output(out, spec, B, in_dev, in_dtype), loss
+
+    def forward(self, x_dict, edge_index_dict):
+        spec, B, e, pdev = self._prepare(x_dict, edge_index_dict)
+        if e is None:
+            return self._forward_operators(x_dict, edge_index_dict, B)
         in_dev, in_dtype = x_dict[self._node_types[0]].device, x_dict[self._node_types[0]].dtype
         xs = e.cast_inputs(x_dict)
         params = self._params_in_flat_order()
@@ -341,12 +423,7 @@ class _MSHGNNBase(nn.Module):
                     views = [self._flat[o:o + n].view(p.shape) for (o, n), p in zip(offsets, params)]
                     torch._foreach_copy_(views, [p.detach() for p in params])
                     out = e.forward(xs, self._flat, B, training=False)
-        out = out.to(device=in_dev, dtype=in_dtype if in_dtype in (torch.float64, torch.float32) else torch.float32)
-        if spec.output_is_window_major:
-            return out.view(B, -1)      # ms_foot_decoder: [B, 4*3]   (hgnn_c2.py:184-189)
-        if spec.kind in ("k4_com", "c2_com"):
-            return out.view(B, spec.num_nodes["base"], spec.out_channels)   # morphological_symmetry_decoder, hgnn_k4_com.py:157-165
-        return out                      # [B*4, out_channels_per_foot]  (COM S4 / COM_HGNN: [B, com_dimension])
+        return self._shape_output(out, spec, B, in_dev, in_dtype)
 
     def _forward_operators(self, x_dict, edge_index_dict, B):
         """The reference's forward (hgnn_c2.py:133-182, hgnn_k4.py:146-196, hgnn.py:57-62, hgnn_*_com.py) operator by operator, for models built with

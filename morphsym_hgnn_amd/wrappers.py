@@ -14,6 +14,7 @@ logging and `train_model` / `evaluate_model` are out of scope (SURVEY.md section
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -42,6 +43,12 @@ def _metric_property(name):
 
 class Base_Lightning(_Base):
     """Steps, epoch hooks, logging and the optimizer shared by every wrapper (gnnLightning.py:28-348)."""
+
+    # training_step hands the labels to the model, which runs forward + loss + backward as ONE engine call (models.fused_training_step:
+    # the decoder, the loss and the decoder's backward sit in the tail of the fused forward kernel); the returned loss delivers those
+    # gradients when backward() is called on it.  Same loss and gradients as the two-call route, which is taken when this is False
+    # (or MSHGNN_FUSED_TRAINING_STEP=0), under torch.distributed, with host parameters, or without autograd.
+    fused_training_step = os.environ.get("MSHGNN_FUSED_TRAINING_STEP", "1") != "0"
 
     def __init__(self, optimizer: str, lr: float, regression: bool):
         super().__init__()
@@ -172,13 +179,35 @@ class _HGNNWrapper(Base_Lightning):
         if _L is not None:  # pragma: no cover
             self.save_hyperparameters(ignore=["dummy_batch", "activation_fn"])
 
-    def step_helper_function(self, batch):
-        out_raw = self.model(x_dict=batch.x_dict, edge_index_dict=batch.edge_index_dict)
+    def _shape(self, batch, out_raw):
         batch_size = batch.batch_size if hasattr(batch, "batch_size") else 1
         width = self.model.out_channels_per_foot * 4
         y_pred = torch.reshape(out_raw.squeeze(), (batch_size, width))
         y = torch.reshape(batch.y, (batch_size, width if self._label_width_is_output_width else 4))
         return y, y_pred
+
+    def step_helper_function(self, batch):
+        return self._shape(batch, self.model(x_dict=batch.x_dict, edge_index_dict=batch.edge_index_dict))
+
+    def _fused_step(self, batch):
+        """(y, y_pred, loss) from the one-call engine step, or None when that route does not apply."""
+        if not self.fused_training_step:
+            return None
+        r = self.model.fused_training_step(batch.x_dict, batch.edge_index_dict, batch.y)
+        if r is None:
+            return None
+        y, y_pred = self._shape(batch, r[0])
+        return y, y_pred, r[1]
+
+    def training_step(self, batch, batch_idx):
+        r = self._fused_step(batch)
+        if r is None:
+            return super().training_step(batch, batch_idx)
+        y, y_pred, loss = r
+        self.calculate_losses_step(y, y_pred)          # the step's metric sums (y_pred carries no autograd here)
+        self._m().set_step_loss(loss)
+        self.log_losses("train", on_step=True)
+        return loss
 
 
 class Heterogeneous_GNN_Lightning(_HGNNWrapper):
@@ -283,7 +312,16 @@ class HGNN_C2_Lightning_Reg(_HGNNWrapper):
             self.calculate_losses_step_original(y, y_pred)
 
     def training_step(self, batch, batch_idx):
-        self._step(batch)
+        r = self._fused_step(batch)
+        if r is None:
+            self._step(batch)
+        else:
+            y, y_pred, loss = r
+            if self.body_to_world_frame:
+                self.calculate_losses_step_worldframe(y, y_pred, batch.r_o.view(batch.batch_size, 4))
+            else:
+                self.calculate_losses_step_original(y, y_pred)
+            self._m().set_step_loss(loss)
         (self.log_losses_worldframe if self.body_to_world_frame else self.log_losses)("train", on_step=True)
         return self._loss()
 
@@ -362,9 +400,17 @@ class COM_Base_Lightning(_Base):
     def reset_all_metrics(self) -> None:
         self._m().reset_all_metrics()
 
+    fused_training_step = Base_Lightning.fused_training_step
+
     def training_step(self, batch, batch_idx):
-        y, y_pred = self.step_helper_function(batch)
-        self.calculate_losses_step(y, y_pred)
+        r = self.model.fused_training_step(batch.x_dict, batch.edge_index_dict, batch.y) if self.fused_training_step else None
+        if r is None:
+            y, y_pred = self.step_helper_function(batch)
+            self.calculate_losses_step(y, y_pred)
+        else:
+            y, y_pred = self._shape(batch, r[0])
+            self.calculate_losses_step(y, y_pred)
+            self._m().set_step_loss(r[1])
         self.log_losses("train", on_step=True)
         return self.loss
 
@@ -395,7 +441,9 @@ class COM_Base_Lightning(_Base):
 
     def step_helper_function(self, batch):
         """Outputs and labels per window, [batch, num_bases * 6] (gnnLightning_com.py:324-340, 394-409)."""
-        out_raw = self.model(x_dict=batch.x_dict, edge_index_dict=batch.edge_index_dict)
+        return self._shape(batch, self.model(x_dict=batch.x_dict, edge_index_dict=batch.edge_index_dict))
+
+    def _shape(self, batch, out_raw):
         batch_size = batch.batch_size if hasattr(batch, "batch_size") else 1
         width = self.model.num_bases * self.model.num_dimensions_per_base
         return torch.reshape(batch.y, (batch_size, width)), torch.reshape(out_raw.squeeze(), (batch_size, width))

@@ -52,8 +52,11 @@ def test_optimizer_setting_and_missing_helper_raise_like_the_reference():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("name", ["a1c2_h128_L3_d3_B3", "mck4_cls_h128_L2_B3", "mi_h128_L2_d1_B3", "mcc2_cls_h128_L2_B3"])
-def test_training_step_returns_the_golden_loss_and_backward_the_golden_gradients(name):
+def test_training_step_returns_the_golden_loss_and_backward_the_golden_gradients(name, fused):
+    """Both routes of training_step: the one-call engine step (labels handed to the model: forward + loss + backward in one C-ABI call, the
+    returned loss delivers the gradients) and forward -> device metric loss -> autograd."""
     torch.set_default_dtype(torch.float64)
     case, spec, fx, x_dict, y, params, ei = helpers.load_case(name)
     B = case["B"]
@@ -61,12 +64,21 @@ def test_training_step_returns_the_golden_loss_and_backward_the_golden_gradients
     batch = _batch(x_dict, ei, y, B, dev)
     w = _wrapper(case, spec, batch).to(dev)
     w.model.load_state_dict(params)
+    w.fused_training_step = fused
     loss = w.training_step(batch, 0)
+    assert w.model._gpend_id == (1 if fused else 0)            # the route that was asked for is the one that ran
     assert loss.requires_grad and loss is (w.mse_loss if case["regression"] else w.ce_loss)
+    w.model.zero_grad()                                        # (Lightning clears the gradients between training_step and backward)
     loss.backward()
     grads = {k: (p.grad.detach().cpu() if p.grad is not None else torch.zeros_like(p).cpu()) for k, p in w.model.named_parameters()}
     out = w.model(x_dict=batch.x_dict, edge_index_dict=batch.edge_index_dict)
-    helpers.check_against_fixture(fx, out.detach().cpu(), loss.detach().cpu(), grads, rtol=1e-4, what=name)
+    helpers.check_against_fixture(fx, out.detach().cpu(), loss.detach().double().cpu(), grads, rtol=1e-4, what=name)
+    # accumulation and an upstream factor: a second step without clearing adds 0.5 x the same gradient
+    g1 = w.model.decoder.weight.grad.detach().clone()
+    (0.5 * w.training_step(batch, 1)).backward()
+    assert float((w.model.decoder.weight.grad - 1.5 * g1).abs().max()) <= 1e-5 * float(g1.abs().max())
+    w.model.zero_grad()
+    w.training_step(batch, 2).backward()
     key = "train_MSE_loss" if case["regression"] else "train_CE_loss"
     assert torch.equal(w.logged[key], loss)
     if not case["regression"]:
@@ -107,7 +119,8 @@ def test_world_frame_metrics_follow_the_rotated_forces():
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,model_type", [("solok4com_h128_L3_B5", "heterogeneous_gnn_k4_com"), ("soloc2com_h128_L2_B4", "heterogeneous_gnn_c2_com"),
                                              ("solos4com_h128_L2_B3", "heterogeneous_gnn_s4_com"), ("com_hgnn_h128_L2_B3", None)])
-def test_com_training_step_returns_the_golden_loss_and_gradients(name, model_type):
+@pytest.mark.parametrize("fused", [True, False])
+def test_com_training_step_returns_the_golden_loss_and_gradients(name, model_type, fused):
     """COM_HGNN_SYM_Lightning / COM_HGNN_Lightning (gnnLightning_com.py:290-409): loss = MSE over [batch, num_bases * 6], golden gradients;
     the extra metrics (lin / ang MSE, cosine similarities) against the oracle."""
     from morphsym_hgnn_amd import wrappers
@@ -127,12 +140,14 @@ def test_com_training_step_returns_the_golden_loss_and_gradients(name, model_typ
                                             group_operator_path=cfg, model_type=model_type, stats=stats)
     w = w.to(dev)
     w.model.load_state_dict(params)
+    w.fused_training_step = fused
     loss = w.training_step(batch, 0)
+    assert w.model._gpend_id == (1 if fused else 0)
     assert loss.requires_grad and loss is w.loss
     loss.backward()
     grads = {k: (p.grad.detach().cpu() if p.grad is not None else torch.zeros_like(p).cpu()) for k, p in w.model.named_parameters()}
     out = w.model(x_dict=batch.x_dict, edge_index_dict=batch.edge_index_dict)
-    helpers.check_against_fixture(fx, out.detach().cpu(), loss.detach().cpu(), grads, rtol=1e-4, what=name)
+    helpers.check_against_fixture(fx, out.detach().cpu(), loss.detach().double().cpu(), grads, rtol=1e-4, what=name)
     nb = w.model.num_bases
     o = mo.com_metrics(y.reshape(B, -1).float().numpy(), out.detach().reshape(B, -1).float().cpu().numpy(), nb, *stats)
     for key, okey in (("train_MSE_loss_lin", "mse_lin"), ("train_MSE_loss_ang", "mse_ang"), ("train_cos_sim_lin", "cos_sim_lin"),

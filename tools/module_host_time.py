@@ -9,6 +9,7 @@ from morphsym_hgnn_amd.checkpoint import load_into
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 device_loss = len(sys.argv) > 2 and sys.argv[2] == "device-loss"      # loss + metrics from metrics.StepMetrics instead of torch's elementwise kernels
+wrapper = len(sys.argv) > 2 and sys.argv[2] == "wrapper"              # wrappers.HGNN_C2_Lightning_Reg.training_step (one-call engine step) + backward
 dev = torch.device("cuda", 0)
 B = 8192
 spec = bench.build_spec(3, "a1c2", 128)
@@ -32,8 +33,19 @@ sm = StepMetrics(regression=True, device=dev)
 y32 = y.float()
 
 
+if wrapper:
+    import types
+    from morphsym_hgnn_amd import wrappers
+    w = wrappers.Base_Lightning.__new__(wrappers.HGNN_C2_Lightning_Reg)
+    wrappers.Base_Lightning.__init__(w, "adam", 1e-4, True)
+    w.model = m
+
+
 def step():
     m.zero_grad(set_to_none=True)
+    if wrapper:
+        w.training_step(types.SimpleNamespace(x_dict=dict(xin), edge_index_dict=ei, y=y32, batch_size=B), 0).backward()
+        return
     out = m(dict(xin), ei)
     if device_loss:
         sm.calculate_losses_step(y32, out)
