@@ -143,6 +143,10 @@ class Base_Lightning(_Base):
     # ---- optimizer (gnnLightning.py:258-265) -------------------------------------------------------------------------
     def configure_optimizers(self):
         if self.optimizer == "adam":
+            model = getattr(self, "model", None)
+            if isinstance(model, models._MSHGNNBase) and len(list(self.parameters())) == len(list(model.parameters())):
+                from .optim import FlatAdam      # a torch.optim.Adam whose step is one launch on the flat buffers (torch's own step otherwise)
+                return FlatAdam(model, lr=self.lr)
             return optim.Adam(self.parameters(), lr=self.lr)
         if self.optimizer == "sgd":
             return optim.SGD(self.parameters(), lr=self.lr)

@@ -155,3 +155,47 @@ def test_com_training_step_returns_the_golden_loss_and_gradients(name, model_typ
         assert abs(float(w.logged[key]) - o[okey]) <= 1e-9 * max(1.0, abs(o[okey])), key
     with pytest.raises(ValueError):
         wrappers.COM_Base_Lightning("adam", 1e-3)
+
+
+@pytest.mark.gpu
+def test_flat_adam_follows_torch_adam_and_round_trips_its_state():
+    """configure_optimizers returns FlatAdam (a torch.optim.Adam; one mshgnn_adam_step launch per step on the flat buffers): three steps
+    track torch.optim.Adam on a twin model; its state_dict loads into torch's Adam and back, and both continue in step."""
+    from morphsym_hgnn_amd.optim import FlatAdam
+    torch.set_default_dtype(torch.float64)
+    case, spec, fx, x_dict, y, params, ei = helpers.load_case("a1c2_h128_L3_d3_B3")
+    dev = torch.device("cuda")
+    batch = _batch(x_dict, ei, y, case["B"], dev)
+    twins = []
+    for _ in range(2):
+        w = _wrapper(case, spec, batch).to(dev)
+        w.model.load_state_dict(params)
+        w.lr = 1e-3
+        twins.append(w)
+    a, b = twins
+    oa = a.configure_optimizers()
+    ob = torch.optim.Adam(b.parameters(), lr=1e-3)
+    assert isinstance(oa, FlatAdam) and isinstance(oa, torch.optim.Adam)
+
+    def step(w, opt):
+        loss = w.training_step(batch, 0)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+
+    def worst():
+        return max(float((p.detach() - q.detach()).abs().max() / q.detach().abs().max().clamp_min(1e-12))
+                   for p, q in zip(a.model.parameters(), b.model.parameters()))
+    for _ in range(3):
+        step(a, oa); step(b, ob)
+    assert oa._t == 3 and worst() < 5e-5            # (fp32 master weights on both sides; the two Adams differ in rounding only, which the
+                                                    #  next step's gradients amplify a little)
+    # state round trip: FlatAdam -> torch Adam on the twin, torch Adam -> FlatAdam, then one more step each
+    sd_a, sd_b = oa.state_dict(), ob.state_dict()
+    assert int(sd_a["state"][0]["step"]) == 3 and sd_a["state"][0]["exp_avg"].shape == sd_b["state"][0]["exp_avg"].shape
+    ob.load_state_dict(sd_a); oa.load_state_dict(sd_b)
+    step(a, oa); step(b, ob)
+    assert oa._t == 4 and worst() < 5e-5
+    # gradients that are not the flat views (here: cleared) -> torch's own step, nothing breaks
+    oa.zero_grad(set_to_none=True)
+    oa.step()
