@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """The reference's training loop through its own wrapper API, on the MI355X:
 
-    SequenceStore.assemble (windows gathered on the device)  ->  HGNN_C2_Lightning_Reg.training_step(batch)  ->  loss.backward()
+    SequenceStore.batch (window indices; the encoder gathers them from the resident series -- `--assemble`: a separate gather pass first)
+    ->  HGNN_C2_Lightning_Reg.training_step(batch)  ->  loss.backward()
     ->  the optimizer `configure_optimizers()` returns (optim.FlatAdam: a torch.optim.Adam whose step is one launch on the flat buffers)
 
 i.e. what Lightning's Trainer does with the reference's `HGNN_C2_Lightning_Reg` (gnnLightning.py:564-778, train_model :1230-1400), driven
@@ -24,17 +25,19 @@ from morphsym_hgnn_amd import wrappers  # noqa: E402
 from morphsym_hgnn_amd.windows import SequenceStore, quadsdk_a1_c2_recipe  # noqa: E402
 
 
-def train(steps=200, batch=8192, dtype="bf16", layers=3, lr=1e-3, rows=100_000, log_every=50, quiet=False):
+def train(steps=200, batch=8192, dtype="bf16", layers=3, lr=1e-3, rows=100_000, log_every=50, quiet=False, assemble=False):
     dev = torch.device("cuda", torch.cuda.current_device())
     spec = bench.build_spec(layers)
     store = SequenceStore(synthetic_sequence(rows), quadsdk_a1_c2_recipe(range(12), range(4), 150, 3), dtype=dtype, device=dev)
     ei = spec.topology.edge_index_dict(batch, device=dev)
     gen = torch.Generator(device=dev).manual_seed(1234)
 
-    def next_batch():
+    def next_batch():      # a WindowBatch: window indices only -- training_step lets the encoder gather them; `assemble=True`: tensors first
         starts = torch.randint(0, len(store), (batch,), generator=gen, device=dev)
-        xs, y, r_o = store.assemble(starts, reuse_buffers=True)
-        return types.SimpleNamespace(x_dict=dict(zip(store.recipe.node_types, xs)), edge_index_dict=ei, y=y, r_o=r_o, batch_size=batch)
+        wb = store.batch(starts, ei)
+        if assemble:
+            wb.x_dict
+        return wb
 
     os.environ["MSHGNN_DTYPE"] = dtype
     torch.manual_seed(0)
@@ -70,6 +73,6 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=200); ap.add_argument("--batch", type=int, default=8192)
     ap.add_argument("--dtype", default="bf16", choices=["f32", "bf16", "x3"]); ap.add_argument("--layers", type=int, default=3)
-    ap.add_argument("--lr", type=float, default=1e-3)
+    ap.add_argument("--lr", type=float, default=1e-3); ap.add_argument("--assemble", action="store_true")
     a = ap.parse_args()
-    train(a.steps, a.batch, a.dtype, a.layers, a.lr)
+    train(a.steps, a.batch, a.dtype, a.layers, a.lr, assemble=a.assemble)

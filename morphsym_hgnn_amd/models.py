@@ -142,11 +142,11 @@ class _FusedStepFn(torch.autograd.Function):
     BETWEEN training_step and backward, so nothing may touch .grad before).  target: fp32 labels (regression) or int32 contact flags."""
 
     @staticmethod
-    def forward(ctx, anchor, model, engine, B, target, *xs):
+    def forward(ctx, anchor, model, run):
+        """run(grad_flat) -> (out, loss[1]): the engine call (mshgnn_step_mse / _ce or their *_series forms)."""
         if model._gpend is None or model._gpend.device != model._flat.device:
             model._gpend = torch.empty_like(model._flat)
-        step = engine.step_mse if model._spec.regression else engine.step_ce
-        out, loss, _ = step(xs, model._flat, target, B, grad_flat=model._gpend)
+        out, loss = run(model._gpend)
         model._gpend_id += 1
         ctx.model, ctx.flat, ctx.ticket = model, model._flat, model._gpend_id
         ctx.mark_non_differentiable(out)
@@ -387,8 +387,48 @@ class _MSHGNNBase(nn.Module):
             target = y.detach().to(pdev, torch.float32).flatten().contiguous()
         else:
             target = (y.detach().to(pdev) != 0).to(torch.int32).flatten().contiguous()
-        loss, out = _FusedStepFn.apply(self._anchor, self, e, B, target, *xs)
+        step = e.step_mse if spec.regression else e.step_ce
+        loss, out = _FusedStepFn.apply(self._anchor, self, lambda g: step(xs, self._flat, target, B, grad_flat=g)[:2])
         return self._shape_output(out, spec, B, in_dev, in_dtype), loss
+
+    def fused_training_step_windows(self, batch):
+        """`fused_training_step` for a `windows.WindowBatch`: the encoder gathers the batch's inputs straight from the sequence's resident
+        series (mshgnn_step_mse_series / mshgnn_step_ce_series -- no separate assembly pass over the windows); the labels (and the
+        materialised windows) are left on the batch.  Returns (out, loss) or None when this route does not apply: the model has not seen
+        its lazy-initialising forward yet, a plan other than bf16 on the LDS-resident kernels, a store that is not bf16 / fast-layout /
+        unstandardised or whose recipe differs from the model's node types and widths, plus fused_training_step's own conditions."""
+        spec = self._spec
+        store, B = batch.store, batch.batch_size
+        r = store.recipe
+        if spec is None or not self._fused_activation or store.dtype != "bf16" or r.normalize or not store.desc.fast_layout or not r.label_cols:
+            return None
+        if list(r.node_types) != list(spec.node_types) or any(r.num_nodes[t] != spec.num_nodes[t] or r.width(t) != spec.widths[t] for t in r.node_types):
+            return None
+        params = self._params_in_flat_order()
+        if not torch.is_grad_enabled() or params[0].device.type != "cuda" or params[0].device != store.device or not all(p.requires_grad for p in params):
+            return None
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return None
+        e = self._engine(store.device)
+        if e.generic or e.storage != "bf16":
+            return None
+        if B not in self._checked_batches:   # one host-side check per batch size: B copies of the compiled graph
+            for et in self._edge_types:
+                s_, _, d_ = et
+                if infer_window_edges(batch.edge_index_dict[et], spec.num_nodes[s_], spec.num_nodes[d_], B) != spec.topology.edges(et):
+                    raise ValueError(f"edge_index_dict[{et}] differs from the topology this model was compiled for")
+            self._checked_batches.add(B)
+        self._flat_params(store.device)
+        step = e.step_mse_series if spec.regression else e.step_ce_series
+
+        def run(g):
+            xs, y, out, loss, _ = step(store, batch.starts, self._flat, grad_flat=g)
+            _, yf, q = store._buffers(B)
+            batch._labels_from_step(xs, yf, q)
+            return out, loss
+        loss, out = _FusedStepFn.apply(self._anchor, self, run)
+        return self._shape_output(out, spec, B, store.device, torch.float32), loss
 
     def forward(self, x_dict, edge_index_dict):
         spec, B, e, pdev = self._prepare(x_dict, edge_index_dict)

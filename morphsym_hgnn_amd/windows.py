@@ -221,6 +221,10 @@ class SequenceStore:
         eng._check(self.lib, rc, "mshgnn_assemble_windows")
         return xs, y, q
 
+    def batch(self, starts, edge_index_dict) -> "WindowBatch":
+        """A minibatch of window indices shaped like the PyG batch the wrappers take (see WindowBatch)."""
+        return WindowBatch(self, starts, edge_index_dict)
+
     def series_step_args(self):
         """What Engine.step_mse_series hands to mshgnn_step_mse_series: bf16 copies of the series (same strides) and the run-pointer scratch."""
         if self._src16 is None:
@@ -228,3 +232,52 @@ class SequenceStore:
             self._src16 = (C.c_void_p * len(self.series16))(*[a.data_ptr() for a in self.series16])
             self._run_ptrs = torch.zeros(max(1, int(self.desc.n_runs)), dtype=torch.int64, device=self.device)
         return self._src16, self._run_ptrs
+
+
+class WindowBatch:
+    """One minibatch of window indices of a `SequenceStore`, with the attributes the reference's wrappers read off a PyG batch
+    (`x_dict`, `edge_index_dict`, `y`, `r_o`, `batch_size`; gnnLightning.py:680-722).  Nothing is gathered when it is made: a wrapper's
+    `training_step` hands the indices to the engine, whose encoder gathers its inputs from the resident series
+    (`models.fused_training_step_windows` -> `mshgnn_step_mse_series` / `mshgnn_step_ce_series`) and leaves the labels here; any other consumer
+    (validation, the two-call route) gets the windows assembled on first access (`SequenceStore.assemble`, the store's reusable buffers:
+    consume a batch before asking the store for the next one)."""
+
+    def __init__(self, store: SequenceStore, starts, edge_index_dict):
+        st = starts if isinstance(starts, torch.Tensor) else torch.as_tensor(np.asarray(starts), dtype=torch.int64)
+        st = st.flatten().to(torch.int64)
+        if not st.is_cuda:
+            if st.numel() < 1 or int(st.min()) < 0 or int(st.max()) + store.recipe.history > store.n_rows:
+                raise IndexError("window index out of range")
+            st = st.to(store.device)
+        self.store, self.starts, self.edge_index_dict = store, st, edge_index_dict
+        self.batch_size = int(st.numel())
+        self._x = self._y = self._q = None
+
+    def _assemble(self):
+        if self._x is None:
+            xs, y, q = self.store.assemble(self.starts, reuse_buffers=True)
+            self._x = dict(zip(self.store.recipe.node_types, xs))
+            self._y = y if self._y is None else self._y
+            self._q = q if self._q is None else self._q
+
+    def _labels_from_step(self, xs, y, q):
+        """(the fused training step materialised the windows and the labels as a by-product)"""
+        self._x = dict(zip(self.store.recipe.node_types, xs)) if xs is not None else None
+        self._y, self._q = y, q
+
+    @property
+    def x_dict(self):
+        self._assemble()
+        return self._x
+
+    @property
+    def y(self):
+        if self._y is None:
+            self._assemble()
+        return self._y
+
+    @property
+    def r_o(self):
+        if self._q is None:
+            self._assemble()
+        return self._q

@@ -41,6 +41,19 @@ def _metric_property(name):
     return property(get)
 
 
+def _model_fused_step(wrapper, batch):
+    """(out, loss) from the model's one-call training step -- for a `windows.WindowBatch` with the window gather fused into the encoder --
+    or None when the wrapper has to take the two-call route."""
+    if not wrapper.fused_training_step:
+        return None
+    from .windows import WindowBatch
+    if isinstance(batch, WindowBatch):
+        r = wrapper.model.fused_training_step_windows(batch)
+        if r is not None:
+            return r
+    return wrapper.model.fused_training_step(batch.x_dict, batch.edge_index_dict, batch.y)
+
+
 class Base_Lightning(_Base):
     """Steps, epoch hooks, logging and the optimizer shared by every wrapper (gnnLightning.py:28-348)."""
 
@@ -195,9 +208,7 @@ class _HGNNWrapper(Base_Lightning):
 
     def _fused_step(self, batch):
         """(y, y_pred, loss) from the one-call engine step, or None when that route does not apply."""
-        if not self.fused_training_step:
-            return None
-        r = self.model.fused_training_step(batch.x_dict, batch.edge_index_dict, batch.y)
+        r = _model_fused_step(self, batch)
         if r is None:
             return None
         y, y_pred = self._shape(batch, r[0])
@@ -407,7 +418,7 @@ class COM_Base_Lightning(_Base):
     fused_training_step = Base_Lightning.fused_training_step
 
     def training_step(self, batch, batch_idx):
-        r = self.model.fused_training_step(batch.x_dict, batch.edge_index_dict, batch.y) if self.fused_training_step else None
+        r = _model_fused_step(self, batch)
         if r is None:
             y, y_pred = self.step_helper_function(batch)
             self.calculate_losses_step(y, y_pred)

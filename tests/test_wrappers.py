@@ -199,3 +199,60 @@ def test_flat_adam_follows_torch_adam_and_round_trips_its_state():
     # gradients that are not the flat views (here: cleared) -> torch's own step, nothing breaks
     oa.zero_grad(set_to_none=True)
     oa.step()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["a1c2_regression", "mck4_classification"])
+def test_window_batch_training_step_gathers_in_the_encoder_and_matches_the_assembled_batch(kind):
+    """A `windows.WindowBatch` (window indices of a resident sequence) through `training_step`: the encoder gathers its inputs from the
+    series (mshgnn_step_mse_series / _ce_series); loss and every gradient are the bits of the same step on the assembled batch, and the
+    batch still serves `x_dict` / `y` to consumers that want tensors (validation)."""
+    import types
+    from morphsym_hgnn_amd import wrappers
+    from morphsym_hgnn_amd.windows import SequenceStore, WindowBatch, quadsdk_a1_c2_recipe, minicheetah_k4_recipe
+    from tests import test_windows as tw
+    torch.set_default_dtype(torch.float32)
+    dev = torch.device("cuda")
+    if kind.startswith("a1c2"):
+        seq, n, recipe = tw.SEQ, tw.N, quadsdk_a1_c2_recipe(tw.JP, tw.FP, tw.T, 3)
+        spec = helpers.make_spec("c2", "a1-c2", "a1-c2", 128, 2)
+        _, cfg = helpers.load_group("a1-c2")
+        make = lambda dummy: wrappers.HGNN_C2_Lightning_Reg(128, 2, spec.topology.metadata(), dummy, symmetry_mode="MorphSym", group_operator_path=cfg)
+    else:
+        seq, n, recipe = dict(tw.SEQ4), int(tw.FX4["N"]), minicheetah_k4_recipe(tw.JP, tw.FP, tw.T)
+        spec = helpers.make_spec("k4", "mini_cheetah-k4", "mini_cheetah-k4", 128, 2, regression=False)
+        _, cfg = helpers.load_group("mini_cheetah-k4")
+        make = lambda dummy: wrappers.HGNN_K4_Lightning(128, 2, spec.topology.metadata(), dummy, regression=False, symmetry_mode="MorphSym",
+                                                        group_operator_path=cfg)
+    store = SequenceStore(seq, recipe, dtype="bf16")
+    B = 96
+    starts = torch.randint(0, n - tw.T + 1, (B,), generator=torch.Generator().manual_seed(5))
+    ei = spec.topology.edge_index_dict(B, device=dev)
+    xs, y, _ = store.assemble(starts)
+    plain = types.SimpleNamespace(x_dict={t: x.clone() for t, x in zip(recipe.node_types, xs)}, edge_index_dict=ei, y=y.clone(), batch_size=B)
+    dummy = types.SimpleNamespace(edge_index_dict=ei, x_dict={t: x[:, :recipe.width(t)].float().contiguous() for t, x in plain.x_dict.items()})
+    import os
+    prev = os.environ.get("MSHGNN_DTYPE")
+    os.environ["MSHGNN_DTYPE"] = "bf16"
+    try:
+        torch.manual_seed(3)
+        w = make(dummy).to(dev)
+    finally:
+        os.environ.pop("MSHGNN_DTYPE", None) if prev is None else os.environ.__setitem__("MSHGNN_DTYPE", prev)
+    loss_a = w.training_step(plain, 0)
+    loss_a.backward()
+    g_a = w.model._gflat.clone(); la = loss_a.detach().clone()
+    w.model.zero_grad()
+    wb = store.batch(starts, ei)
+    assert isinstance(wb, WindowBatch) and wb._x is None
+    loss_b = w.training_step(wb, 1)
+    assert wb._x is not None and torch.equal(wb.y, y.to(dev))          # the step left the materialised windows and the labels on the batch
+    loss_b.backward()
+    torch.cuda.synchronize()
+    assert torch.equal(la, loss_b.detach()) and torch.equal(g_a, w.model._gflat)
+    for t in recipe.node_types:
+        assert torch.equal(wb.x_dict[t], plain.x_dict[t])
+    # a fresh WindowBatch without the fused route (validation under no_grad): tensors assembled on first access
+    with torch.no_grad():
+        v = w.validation_step(store.batch(starts, ei), 0)
+    assert abs(float(v) - float(la)) <= 1e-5 * abs(float(la))
