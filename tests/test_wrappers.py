@@ -111,6 +111,7 @@ def test_world_frame_metrics_follow_the_rotated_forces():
     w.model.load_state_dict(params)
     loss = w.training_step(batch, 0)
     assert loss.requires_grad
+    loss = loss.detach()
     assert abs(float(w.mse_loss_worldframe) - float(loss)) <= 1e-5 * float(loss)          # rotations preserve the squared error
     assert abs(float(w.logged["train_RMSE_loss_WorldFrame"]) - float(loss) ** 0.5) <= 1e-5 * float(loss) ** 0.5
     assert float(w.l1_loss_worldframe) > 0 and abs(float(w.l1_loss_worldframe) - float(w.l1_loss)) > 0      # L1 is frame dependent
@@ -256,3 +257,24 @@ def test_window_batch_training_step_gathers_in_the_encoder_and_matches_the_assem
     with torch.no_grad():
         v = w.validation_step(store.batch(starts, ei), 0)
     assert abs(float(v) - float(la)) <= 1e-5 * abs(float(la))
+
+
+@pytest.mark.gpu
+def test_wrapper_state_dict_is_the_lightning_checkpoint_layout():
+    """A wrapper's state_dict has the keys of the reference's Lightning checkpoints (`model.<parameter>`, gnnLightning.py:962-984): the
+    `state_dict` of a checkpoint written by `checkpoint.to_lightning_checkpoint` loads into it directly and reproduces the golden output."""
+    from morphsym_hgnn_amd import checkpoint
+    torch.set_default_dtype(torch.float64)
+    case, spec, fx, x_dict, y, params, ei = helpers.load_case("a1c2_h128_L3_d3_B3")
+    dev = torch.device("cuda")
+    batch = _batch(x_dict, ei, y, case["B"], dev)
+    w = _wrapper(case, spec, batch).to(dev)
+    assert list(w.state_dict().keys()) == ["model." + k for k in spec.param_shapes().keys()]
+    src = _wrapper(case, spec, batch)
+    src.model.load_state_dict(params)
+    ckpt = checkpoint.to_lightning_checkpoint(src.model)
+    w.load_state_dict(ckpt["state_dict"])
+    with torch.no_grad():
+        out = w.model(x_dict=batch.x_dict, edge_index_dict=batch.edge_index_dict)
+    ref = torch.from_numpy(fx["out"])
+    assert float((out.double().cpu().reshape(ref.shape) - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
