@@ -51,10 +51,17 @@ def test_optimizer_setting_and_missing_helper_raise_like_the_reference():
     assert per_foot.shape == (4, 2) and torch.allclose(prob.sum(1), torch.ones(4)) and only1.shape == (1, 4)
 
 
+@pytest.fixture(params=["f32", "x3"])
+def parity_plan(request, monkeypatch):
+    """The two parity-grade plans (north_star tolerance 1e-4): exact fp32 MFMA and split-bf16; the wrappers' models read MSHGNN_DTYPE."""
+    monkeypatch.setenv("MSHGNN_DTYPE", request.param)
+    return request.param
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("name", ["a1c2_h128_L3_d3_B3", "mck4_cls_h128_L2_B3", "mi_h128_L2_d1_B3", "mcc2_cls_h128_L2_B3"])
-def test_training_step_returns_the_golden_loss_and_backward_the_golden_gradients(name, fused):
+def test_training_step_returns_the_golden_loss_and_backward_the_golden_gradients(name, fused, parity_plan):
     """Both routes of training_step: the one-call engine step (labels handed to the model: forward + loss + backward in one C-ABI call, the
     returned loss delivers the gradients) and forward -> device metric loss -> autograd."""
     torch.set_default_dtype(torch.float64)
@@ -67,6 +74,7 @@ def test_training_step_returns_the_golden_loss_and_backward_the_golden_gradients
     w.fused_training_step = fused
     loss = w.training_step(batch, 0)
     assert w.model._gpend_id == (1 if fused else 0)            # the route that was asked for is the one that ran
+    assert next(iter(w.model._engines.values())).storage == parity_plan
     assert loss.requires_grad and loss is (w.mse_loss if case["regression"] else w.ce_loss)
     w.model.zero_grad()                                        # (Lightning clears the gradients between training_step and backward)
     loss.backward()
