@@ -402,14 +402,24 @@ def end_to_end(spec, B, device, steps, warmup, config="a1c2"):
     else:
         seq = {k: rng.standard_normal((rows, c)).astype(np.float32) for k, c in (("imu_acc", 3), ("imu_omega", 3), ("q", 12), ("qd", 12), ("tau", 12), ("F", 12), ("r_o", 4))}
         recipe = quadsdk_a1_c2_recipe(range(12), range(4), T, 3)
-    store = SequenceStore(seq, recipe, dtype="bf16", device=device)
-    e = eng.Engine(spec, dtype="bf16", device=device)
-    flat = eng.flatten_params(spec, synth.make_params(0, spec.param_shapes()), device)
-    gflat, m, v = torch.empty_like(flat), torch.zeros_like(flat), torch.zeros_like(flat)
-    out = torch.empty(B * 4, spec.out_channels, dtype=torch.float32, device=device); loss = torch.empty(1, dtype=torch.float32, device=device)
-    gen = torch.Generator(device=device).manual_seed(7)
     res = {"what": f"random starts -> window gather from a resident {rows}-step sequence -> fwd + {'cross entropy' if ce else 'MSE'} + bwd -> Adam, "
-                   f"{B} windows/step, bf16 plan"}
+                   f"{B} windows/step, bf16 plan (parity_plan: the same on the split-bf16 plan, fp32 series and windows)"}
+    for plan in ("bf16", PARITY_DTYPE):
+        res_p = res if plan == "bf16" else res.setdefault("parity_plan", {"dtype": plan})
+        store = SequenceStore(seq, recipe, dtype=plan, device=device)
+        e = eng.Engine(spec, dtype=plan, device=device)
+        flat = eng.flatten_params(spec, synth.make_params(0, spec.param_shapes()), device)
+        gflat, m, v = torch.empty_like(flat), torch.zeros_like(flat), torch.zeros_like(flat)
+        out = torch.empty(B * 4, spec.out_channels, dtype=torch.float32, device=device); loss = torch.empty(1, dtype=torch.float32, device=device)
+        gen = torch.Generator(device=device).manual_seed(7)
+        _end_to_end_routes(res_p, e, store, flat, gflat, m, v, out, loss, gen, B, ce, steps, warmup, device)
+        del store, e
+        torch.cuda.empty_cache()
+    return res
+
+
+def _end_to_end_routes(res, e, store, flat, gflat, m, v, out, loss, gen, B, ce, steps, warmup, device):
+    import torch
     for name, fused in (("assemble_then_step", False), ("fused_gather", True)):
         def step(i):
             starts = torch.randint(0, len(store), (B,), generator=gen, device=device)
@@ -429,7 +439,6 @@ def end_to_end(spec, B, device, steps, warmup, config="a1c2"):
             step(warmup + i)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
         res[name] = {"ms_per_step": dt * 1e3, "value": B / dt}
-    return res
 
 
 def main():

@@ -297,7 +297,9 @@ int mshgnn_assemble_windows(const mshgnn_window_desc* desc, const float* const* 
  * from the fp32 series as in mshgnn_assemble_windows.  The descriptor must be a bf16, fast_layout, unstandardised recipe whose node types match the
  * plan's; bf16 plan with the fused stack kernels (else MSHGNN_EUNSUPPORTED: assemble, then mshgnn_step_mse).  run_ptrs: device scratch, 8 bytes per run.
  * x_out == NULL (x_pitch ignored): NO materialised windows -- the weight-gradient kernel gathers its raw-input operands from the series as well.
- * Results are bit-identical to mshgnn_assemble_windows followed by mshgnn_step_mse either way.                                                   */
+ * Results are bit-identical to mshgnn_assemble_windows followed by mshgnn_step_mse either way.
+ * Split plan (MSHGNN_BF16X3): the encoder gathers from the fp32 series themselves (src; src_bf16 may be NULL; the same 8 elements of slack behind
+ * every column), the descriptor's dtype is MSHGNN_F32 / MSHGNN_BF16X3, x_out (fp32, 16-byte aligned rows, pitch a multiple of 4) is required.     */
 int mshgnn_step_mse_series(const mshgnn_plan* plan, const mshgnn_window_desc* desc, const float* const* src, const void* const* src_bf16,
                            const int64_t* src_cstride, const int64_t* src_rows, const int64_t* starts /* device int64[batch] */, int64_t batch,
                            void* const* x_out, const int64_t* x_pitch, float* y_out, float* quat_out, void* run_ptrs,

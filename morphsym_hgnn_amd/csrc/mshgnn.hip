@@ -3179,13 +3179,14 @@ extern "C" int mshgnn_assemble_windows(const mshgnn_window_desc* d, const float*
 // ------------------------------------------------------------------------------------------------------
 // everything mshgnn_step_*_series needs before its encoder launch, in ONE launch: the windows' labels (k_window_labels' arithmetic, plus
 // the int32 contact flags for the classification step) and, in workgroup 0, the bf16 base pointer of every run's series column
-__global__ void k_series_setup(WindowArgs la, const int* runs, int n_runs, WindowArgs wa, unsigned long long* run_ptr, int32_t* labels_int) {
+__global__ void k_series_setup(WindowArgs la, const int* runs, int n_runs, WindowArgs wa, int elem_bytes, unsigned long long* run_ptr, int32_t* labels_int) {
     if (blockIdx.x == 0 && (int)threadIdx.x < n_runs) {
         const int r = threadIdx.x;
         const int sc = runs[(size_t)r * 5 + 3];
         unsigned long long p = 0ull;
 #pragma unroll
-        for (int k = 0; k < WIN_MAX_SRC; ++k) if (sc >= 0 && (sc >> 8) == k) p = (unsigned long long)(reinterpret_cast<const __bf16*>(wa.src[k]) + (size_t)(sc & 0xff) * wa.src_cstride[k]);
+        for (int k = 0; k < WIN_MAX_SRC; ++k)
+            if (sc >= 0 && (sc >> 8) == k) p = (unsigned long long)(reinterpret_cast<const char*>(wa.src[k]) + (size_t)(sc & 0xff) * wa.src_cstride[k] * elem_bytes);
         run_ptr[r] = p;
     }
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -3197,19 +3198,26 @@ static int step_series(const mshgnn_plan* p, const mshgnn_window_desc* d, const 
                        void* const* x_out, const int64_t* x_pitch, float* y_out, float* quat_out, void* run_ptrs,
                        const float* params, float* out, float* loss_out, float* grad_params, void* workspace, void* stream, int32_t* labels_out) {
     const bool ce = labels_out != nullptr;      // classification wrappers: cross entropy over the per-foot logit pairs, labels = the window labels != 0
-    if (!p || !d || !src || !src_bf16 || !src_cstride || !src_rows || !starts || !y_out || !run_ptrs || !params || !out || !loss_out ||
+    if (!p || !d || !src || !src_cstride || !src_rows || !starts || !y_out || !run_ptrs || !params || !out || !loss_out ||
         !grad_params || !workspace || (x_out && !x_pitch)) return set_err(MSHGNN_EINVAL, "null argument to mshgnn_step_mse_series / mshgnn_step_ce_series");
     if (batch < 1 || batch > (1 << 24)) return set_err(MSHGNN_EINVAL, "batch must be in [1, 2^24]");
-    if (p->gen || p->hp.d.dtype != MSHGNN_BF16 || !p->use_fused)
-        return set_err(MSHGNN_EUNSUPPORTED, "mshgnn_step_mse_series runs on the bf16 plan with the fused stack kernels; use mshgnn_assemble_windows + mshgnn_step_mse");
+    // bf16 plan (fused stack kernels): bf16 copies of the series, optional materialisation.  Split plan (MSHGNN_BF16X3): the fp32 series
+    // themselves, windows always materialised (fp32) for its weight-gradient kernel.
+    const bool x3 = !p->gen && p->hp.d.dtype == MSHGNN_BF16X3;
+    if (p->gen || (!x3 && (p->hp.d.dtype != MSHGNN_BF16 || !p->use_fused)))
+        return set_err(MSHGNN_EUNSUPPORTED, "mshgnn_step_mse_series runs on the bf16 plan with the fused stack kernels or on the split plan; use mshgnn_assemble_windows + mshgnn_step_mse");
+    if (!x3 && !src_bf16) return set_err(MSHGNN_EINVAL, "null argument to mshgnn_step_mse_series / mshgnn_step_ce_series");
+    if (x3 && !x_out) return set_err(MSHGNN_EUNSUPPORTED, "the split plan's weight-gradient kernel reads materialised windows: x_out must be given");
     const mshgnn_desc& md = p->hp.d;
-    if (d->n_types != md.n_types || d->dtype != MSHGNN_BF16 || d->normalize || !d->fast_layout || d->n_src < 1 || d->n_src > WIN_MAX_SRC || d->n_runs < 1 ||
+    const bool dtype_ok = x3 ? (d->dtype == MSHGNN_F32 || d->dtype == MSHGNN_BF16X3) : d->dtype == MSHGNN_BF16;
+    if (d->n_types != md.n_types || !dtype_ok || d->normalize || !d->fast_layout || d->n_src < 1 || d->n_src > WIN_MAX_SRC || d->n_runs < 1 ||
         d->n_runs > WIN_MAX_RUNS || !d->runs || !d->rows || d->history < 1 || d->n_label < 1 || !d->label_cols || d->label_src < 0 || d->label_src >= d->n_src)
-        return set_err(MSHGNN_EINVAL, "mshgnn_step_mse_series: the window descriptor must be a bf16, fast_layout, unstandardised recipe with labels");
+        return set_err(MSHGNN_EINVAL, "mshgnn_step_mse_series: the window descriptor must be a fast_layout, unstandardised recipe with labels at the plan's input dtype (bf16; split plan: fp32)");
+    const int epc = x3 ? 4 : 8;      // elements per 16 bytes of the window buffers
     int n_rows = 0;
     for (int t = 0; t < d->n_types; ++t) {
         if (d->type_nodes[t] != md.type_nodes[t] || d->type_width[t] != md.type_width[t]) return set_err(MSHGNN_EINVAL, "window recipe and plan disagree on a node type");
-        if (x_out && (!x_out[t] || ((uintptr_t)x_out[t] & 15) || x_pitch[t] % 8 || x_pitch[t] < (d->type_width[t] + 7) / 8 * 8)) return set_err(MSHGNN_EINVAL, "bad window buffer");
+        if (x_out && (!x_out[t] || ((uintptr_t)x_out[t] & 15) || x_pitch[t] % epc || x_pitch[t] < (d->type_width[t] + epc - 1) / epc * epc)) return set_err(MSHGNN_EINVAL, "bad window buffer");
         n_rows += d->type_nodes[t];
     }
     if (n_rows != d->n_rows) return set_err(MSHGNN_EINVAL, "window recipe: one node row per node expected");
@@ -3218,8 +3226,8 @@ static int step_series(const mshgnn_plan* p, const mshgnn_window_desc* d, const 
     WindowArgs wa{};
     for (int i = 0; i < d->n_src; ++i) {
         // (the bf16 copies need 8 elements of slack behind every column: a chunk's 16-byte load may run past the window's last step)
-        if (!src[i] || !src_bf16[i] || src_rows[i] < d->history || src_cstride[i] < src_rows[i] + 8 || src_rows[i] >= (1ll << 31)) return set_err(MSHGNN_EINVAL, "bad source array (bf16 copies need cstride >= rows + 8)");
-        wa.src[i] = reinterpret_cast<const float*>(src_bf16[i]); wa.src_cstride[i] = src_cstride[i];
+        if (!src[i] || (!x3 && !src_bf16[i]) || src_rows[i] < d->history || src_cstride[i] < src_rows[i] + 8 || src_rows[i] >= (1ll << 31)) return set_err(MSHGNN_EINVAL, "bad source array (the gather needs cstride >= rows + 8)");
+        wa.src[i] = x3 ? src[i] : reinterpret_cast<const float*>(src_bf16[i]); wa.src_cstride[i] = src_cstride[i];
     }
     hipStream_t st = (hipStream_t)stream;
     // labels (fp32 series)
@@ -3230,11 +3238,17 @@ static int step_series(const mshgnn_plan* p, const mshgnn_window_desc* d, const 
     if (d->label_rotate && (d->n_label % 3 != 0 || d->quat_src < 0)) return set_err(MSHGNN_EINVAL, "label rotation needs 3-D labels and a quaternion source");
     static_assert(WIN_MAX_RUNS <= 256, "k_series_setup resolves the runs in one 256-thread workgroup");
     if (ce && d->label_rotate) return set_err(MSHGNN_EINVAL, "mshgnn_step_ce_series: contact labels are not rotated");
-    hipLaunchKernelGGL(k_series_setup, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, la, d->runs, d->n_runs, wa,
+    hipLaunchKernelGGL(k_series_setup, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, la, d->runs, d->n_runs, wa, x3 ? 4 : 2,
                        reinterpret_cast<unsigned long long*>(run_ptrs), ce ? labels_out : nullptr);
     SeriesSrc ser{};
     ser.run_ptr = reinterpret_cast<const unsigned long long*>(run_ptrs); ser.rows = d->rows; ser.starts = starts; ser.T = d->history;
     { int r0 = 0; for (int t = 0; t < d->n_types; ++t) { ser.row0[t] = r0; r0 += d->type_nodes[t]; } }
+    if (x3) {      // (the split plan fuses the MSE into its forward kernel's tail; cross entropy: forward, then the fused-loss backward)
+        int rc = x3_forward(p, x_out, x_pitch, params, out, (char*)workspace, batch, 1, st, ce ? nullptr : y_out, &ser);
+        if (rc) return rc;
+        return x3_backward(p, x_out, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, st, out, ce ? nullptr : y_out, loss_out,
+                           ce ? labels_out : nullptr, !ce, -1);
+    }
     int rc = forward_impl<__bf16>(p, x_out, x_pitch, params, out, (char*)workspace, batch, 1, st, ce ? nullptr : y_out, &ser, ce ? labels_out : nullptr);
     if (rc) return rc;
     // x_out == NULL: no materialised windows at all -- the weight-gradient kernel gathers its raw-input operands from the series as well

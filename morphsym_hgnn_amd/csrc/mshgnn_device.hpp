@@ -952,7 +952,7 @@ int run_finalize(const mshgnn_plan* p, const mshgnn_ws_layout& lay, char* ws, fl
 // split-bf16 parity plan (mshgnn_x3.hip)
 int x3_set_attrs(mshgnn_plan* p);
 int x3_forward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, float* out, char* ws, int64_t batch,
-               int training, hipStream_t st, const float* y_fused);
+               int training, hipStream_t st, const float* y_fused, const SeriesSrc* series = nullptr);
 int x3_backward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, const float* gout, float* gparams, char* ws,
                 int64_t batch, hipStream_t st, const float* out, const float* y, float* loss, const int32_t* labels, bool dec_done, int gw_phase);
 int x3_launch_prep(const PrepArgs& a, hipStream_t st);

@@ -78,13 +78,40 @@ __global__ void k_prep_x3(PrepArgs a) { prep_one_x3(a, blockIdx.x * blockDim.x +
 // k_enc_x3: X_0[node] = relu((mask . x) W_enc^T + b) from fp32 inputs (hgnn_c2.py:143-147); one workgroup = 64 windows of ONE
 // node, K streamed in chunks of 128 through LDS (hi blocks [0, 4), lo blocks [4, 8)), the next chunk prefetched in registers
 // ------------------------------------------------------------------------------------------------------
-template <bool ALIGNED> __global__ __launch_bounds__(256) void k_enc_x3(EncArgs a, int n_img) {
+// out[e] = e < n0 ? a[e] : b[e - n0] over the 8 fp32 elements (a0 | a1), (b0 | b1): the second piece of a chunk that straddles two runs of a
+// window row (k_enc_x3<.., SERIES>); b is moved up by n0 elements in three conditional stages (4, 2, 1), n0 in [1, 7] is per thread
+__device__ __forceinline__ void splice8f(u32x4& a0, u32x4& a1, const u32x4 b0, const u32x4 b1, int n0) {
+    unsigned sft[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+    if (n0 & 4) {
+#pragma unroll
+        for (int e = 7; e >= 4; --e) sft[e] = sft[e - 4];
+    }
+    if (n0 & 2) {
+#pragma unroll
+        for (int e = 7; e >= 2; --e) sft[e] = sft[e - 2];
+    }
+    if (n0 & 1) {
+#pragma unroll
+        for (int e = 7; e >= 1; --e) sft[e] = sft[e - 1];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        a0[e] = e < n0 ? a0[e] : sft[e];
+        a1[e] = e + 4 < n0 ? a1[e] : sft[e + 4];
+    }
+}
+
+// SERIES (with ALIGNED): the fp32 inputs are gathered from the sequence's resident series like the bf16 encoder's (k_enc_fwd<.., SERIES>): element k
+// of a node row = element starts[w] + k % T of run k / T -- two 4-byte-aligned 16-byte loads per (window, chunk), four and a splice where the chunk
+// straddles two runs -- and the materialised window rows are written on the side for the weight-gradient pass (a.x: the window buffers).
+template <bool ALIGNED, bool SERIES = false> __global__ __launch_bounds__(256) void k_enc_x3(EncArgs a, int n_img, SeriesSrc ser) {
+    static_assert(!SERIES || ALIGNED, "the series gather writes aligned window buffers");
     using P = P16;
     constexpr int MB = 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     if ((int)blockIdx.x >= a.wg_prefix[a.n_types]) {      // a workgroup of the embedded layer-pack prep (EncArgs.prep)
-        if constexpr (ALIGNED) prep_one_x3(a.prep, ((int)blockIdx.x - a.wg_prefix[a.n_types]) * 256 + tid, false);
+        if constexpr (ALIGNED && !SERIES) prep_one_x3(a.prep, ((int)blockIdx.x - a.wg_prefix[a.n_types]) * 256 + tid, false);
         return;
     }
     int t = 0;
@@ -107,9 +134,40 @@ template <bool ALIGNED> __global__ __launch_bounds__(256) void k_enc_x3(EncArgs 
     P::AFrag af;
     const AOff<T16> ao(lane);
     u32x4 v[MB][2];                             // the 8 fp32 elements of the chunk (two 16-byte loads)
+    int srow[SERIES ? MB : 1]; int rfirst = 0;  // SERIES: first series row of this thread's window rows, the node row's first run
+    if constexpr (SERIES) {
+#pragma unroll
+        for (int m = 0; m < MB; ++m) srow[m] = (int)ser.starts[min(w0 + m * P::ROWS + r0, a.B - 1)];
+        rfirst = ser.rows[2 * (ser.row0[t] + node)];
+    }
     auto fetch = [&](int kc) {
         const int k0 = kc * H + c * 8;
         const int nv = F - k0;
+        if constexpr (SERIES) {
+            // elements [k0, k0 + 8) of the row: n0 of them from run j at time offset off, the rest from run j + 1 at offset 0
+            const int j = k0 / ser.T, off = k0 - j * ser.T, n0 = min(8, ser.T - off);
+            const bool second = min(nv, 8) > n0;
+            const unsigned long long pa = nv > 0 ? ser.run_ptr[rfirst + j] : 0ull, pb = second ? ser.run_ptr[rfirst + j + 1] : 0ull;
+            const u32x4 ones = u32x4{0x3f800000u, 0x3f800000u, 0x3f800000u, 0x3f800000u};      // the constant-1 run
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+                u32x4 a0 = nv > 0 ? ones : u32x4{0, 0, 0, 0}, a1 = a0;
+                if (pa) {      // (4-byte aligned; the second load may run up to 7 elements past the window's last step: the columns' slack)
+                    const float* sp = reinterpret_cast<const float*>(pa) + srow[m] + off;
+                    a0 = *reinterpret_cast<const u32x4*>(sp); a1 = *reinterpret_cast<const u32x4*>(sp + 4);
+                }
+                if (second) {
+                    u32x4 b0 = ones, b1 = ones;
+                    if (pb) {
+                        const float* sp = reinterpret_cast<const float*>(pb) + srow[m];
+                        b0 = *reinterpret_cast<const u32x4*>(sp); b1 = *reinterpret_cast<const u32x4*>(sp + 4);
+                    }
+                    splice8f(a0, a1, b0, b1, n0);
+                }
+                v[m][0] = a0; v[m][1] = a1;
+            }
+            return;
+        }
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
             const int w = w0 + m * P::ROWS + r0;
@@ -138,6 +196,14 @@ template <bool ALIGNED> __global__ __launch_bounds__(256) void k_enc_x3(EncArgs 
         for (int m = 0; m < MB; ++m) {
             u32x4 fa = v[m][0], fb = v[m][1];
             if (kc + 1 == nkc) { fa = chunk_keep_first<float>(fa, nv); fb = chunk_keep_first<float>(fb, nv - 4); }     // only the last K chunk has pad columns
+            if constexpr (SERIES) {      // the materialised window row (raw values: the sign mask is applied by whoever reads it)
+                const int w = w0 + m * P::ROWS + r0, k0 = kc * H + c * 8;
+                if (x != nullptr && w < a.B) {
+                    float* dst = const_cast<float*>(x) + ((size_t)w * nt + node) * pitch + k0;
+                    if (k0 < (int)pitch) *reinterpret_cast<u32x4*>(dst) = fa;
+                    if (k0 + 4 < (int)pitch) *reinterpret_cast<u32x4*>(dst + 4) = fb;
+                }
+            }
             fa ^= sxa; fb ^= sxb;
             u32x4 hi, lo;
             split_oct(__builtin_bit_cast(f32x4, fa), __builtin_bit_cast(f32x4, fb), hi, lo);
@@ -1023,7 +1089,8 @@ int x3_set_attrs(mshgnn_plan* p) {
     int rc;
     const int flds = x3_lds_stack(p->hp);
     if ((rc = set_lds_attr(k_stack_fwd_x3<false>, flds)) || (rc = set_lds_attr(k_stack_fwd_x3<true>, flds)) || (rc = set_lds_attr(k_stack_bwd_x3, flds)) ||
-        (rc = set_lds_attr(k_enc_x3<true>, 8 * P16::BLK)) || (rc = set_lds_attr(k_enc_x3<false>, 8 * P16::BLK))) return rc;
+        (rc = set_lds_attr(k_enc_x3<true>, 8 * P16::BLK)) || (rc = set_lds_attr(k_enc_x3<false>, 8 * P16::BLK)) ||
+        (rc = set_lds_attr(k_enc_x3<true, true>, 8 * P16::BLK))) return rc;
     return MSHGNN_OK;
 }
 
@@ -1038,7 +1105,7 @@ static void x3_stack_args(const mshgnn_plan* p, const mshgnn_ws_layout& lay, cha
 }
 
 int x3_forward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, float* out, char* ws, int64_t batch,
-               int training, hipStream_t st, const float* y_fused) {
+               int training, hipStream_t st, const float* y_fused, const SeriesSrc* series) {
     const HostPlan& hp = p->hp;
     const mshgnn_desc& d = hp.d;
     mshgnn_ws_layout lay; layout_workspace(hp, batch, training, &lay);
@@ -1048,7 +1115,7 @@ int x3_forward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitc
     int enc_pack0 = hp.n_img;
     for (int t = 0; t < hp.NT; ++t) if (hp.pack_enc_base[t] >= 0) enc_pack0 = std::min(enc_pack0, hp.pack_enc_base[t]);
     static const bool embed_off = getenv("MSHGNN_PREP_EMBED") && atoi(getenv("MSHGNN_PREP_EMBED")) == 0;
-    const bool embed = !prep_use_tiled(pa.n_packs) && enc_pack0 > 0 && !embed_off;
+    const bool embed = !prep_use_tiled(pa.n_packs) && enc_pack0 > 0 && !embed_off && !series;
     {
         PrepArgs a = pa;
         if (embed) { a.pack0 = enc_pack0; a.pack_n = pa.n_packs - enc_pack0; }
@@ -1083,8 +1150,12 @@ int x3_forward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitc
             }
         }
         ProfScope ps(p, hp.ks_enc, st);
-        if (a.aligned) hipLaunchKernelGGL(k_enc_x3<true>, dim3(enc_grid), dim3(256), 8 * P16::BLK, st, a, hp.n_img);
-        else hipLaunchKernelGGL(k_enc_x3<false>, dim3(enc_grid), dim3(256), 8 * P16::BLK, st, a, hp.n_img);
+        if (series) {      // inputs gathered from the sequence's series; x = the window buffers the rows are materialised into
+            if (!a.aligned) return set_err(MSHGNN_EINVAL, "the series gather writes 16-byte-aligned window buffers whose pitch is a multiple of 4");
+            hipLaunchKernelGGL((k_enc_x3<true, true>), dim3(enc_grid), dim3(256), 8 * P16::BLK, st, a, hp.n_img, *series);
+        }
+        else if (a.aligned) hipLaunchKernelGGL(k_enc_x3<true>, dim3(enc_grid), dim3(256), 8 * P16::BLK, st, a, hp.n_img, SeriesSrc{});
+        else hipLaunchKernelGGL(k_enc_x3<false>, dim3(enc_grid), dim3(256), 8 * P16::BLK, st, a, hp.n_img, SeriesSrc{});
     }
     {   // 3. all layers + decoder (+ MSE and decoder backward when y_fused)
         StackArgs a{};

@@ -479,7 +479,8 @@ class Engine:
         materialize=False keeps no windows at all -- the weight-gradient kernel gathers from the series too (same bits, no 118 MB buffer, but
         measured slower: its random 256-byte gathers stretch the raw-input lanes' steps, 0.385 vs 0.557 ms/step).  starts: device int64 window
         start rows.  Returns (xs | None, y, out, loss[1], grad_flat) -- bit-identical to `store.assemble(starts)` followed by `step_mse`.
-        bf16 plan with the fused stack kernels."""
+        bf16 plan with the fused stack kernels (a bf16 store), or the split plan "x3" (an fp32 store: `SequenceStore(..., dtype="x3")`; its
+        encoder gathers from the fp32 series and always materialises the windows)."""
         return self._step_series(False, store, starts, params_flat, out, grad_flat, loss, materialize)
 
     def _step_series(self, ce: bool, store, starts, params_flat, out, grad_flat, loss, materialize):
@@ -497,7 +498,9 @@ class Engine:
             grad_flat = torch.empty(self.spec.flat_size(), dtype=torch.float32, device=self.device)
         if loss is None:
             loss = torch.empty(1, dtype=torch.float32, device=self.device)
-        src16, run_ptrs = store.series_step_args()
+        src16, run_ptrs = store.series_step_args(bf16=self.storage != "x3")
+        if self.storage == "x3" and not materialize:
+            raise ValueError("the split plan's weight-gradient kernel reads materialised windows: materialize=False is a bf16-plan option")
         xp = (C.c_void_p * len(xs))(*[x.data_ptr() for x in xs]) if materialize else None
         pitch = (C.c_int64 * len(xs))(*[x.shape[1] for x in xs]) if materialize else None
         if not materialize:

@@ -395,12 +395,12 @@ class _MSHGNNBase(nn.Module):
         """`fused_training_step` for a `windows.WindowBatch`: the encoder gathers the batch's inputs straight from the sequence's resident
         series (mshgnn_step_mse_series / mshgnn_step_ce_series -- no separate assembly pass over the windows); the labels (and the
         materialised windows) are left on the batch.  Returns (out, loss) or None when this route does not apply: the model has not seen
-        its lazy-initialising forward yet, a plan other than bf16 on the LDS-resident kernels, a store that is not bf16 / fast-layout /
-        unstandardised or whose recipe differs from the model's node types and widths, plus fused_training_step's own conditions."""
+        its lazy-initialising forward yet, a plan other than bf16 / split-bf16 on the LDS-resident kernels, a store whose dtype is not the plan's
+        input dtype or that is not fast-layout / unstandardised, or whose recipe differs from the model's node types and widths, plus fused_training_step's own conditions."""
         spec = self._spec
         store, B = batch.store, batch.batch_size
         r = store.recipe
-        if spec is None or not self._fused_activation or store.dtype != "bf16" or r.normalize or not store.desc.fast_layout or not r.label_cols:
+        if spec is None or not self._fused_activation or store.dtype not in ("bf16", "x3", "f32") or r.normalize or not store.desc.fast_layout or not r.label_cols:
             return None
         if list(r.node_types) != list(spec.node_types) or any(r.num_nodes[t] != spec.num_nodes[t] or r.width(t) != spec.widths[t] for t in r.node_types):
             return None
@@ -411,7 +411,7 @@ class _MSHGNNBase(nn.Module):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             return None
         e = self._engine(store.device)
-        if e.generic or e.storage != "bf16":
+        if e.generic or e.storage not in ("bf16", "x3") or (e.storage == "bf16") != (store.dtype == "bf16"):      # (the split plan gathers fp32 series)
             return None
         if B not in self._checked_batches:   # one host-side check per batch size: B copies of the compiled graph
             for et in self._edge_types:

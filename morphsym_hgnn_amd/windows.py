@@ -225,13 +225,15 @@ class SequenceStore:
         """A minibatch of window indices shaped like the PyG batch the wrappers take (see WindowBatch)."""
         return WindowBatch(self, starts, edge_index_dict)
 
-    def series_step_args(self):
-        """What Engine.step_mse_series hands to mshgnn_step_mse_series: bf16 copies of the series (same strides) and the run-pointer scratch."""
-        if self._src16 is None:
+    def series_step_args(self, bf16: bool = True):
+        """What Engine.step_mse_series hands to mshgnn_step_mse_series: bf16 copies of the series (same strides; bf16=False, the split plan:
+        none -- it gathers from the fp32 series themselves) and the run-pointer scratch."""
+        if self._run_ptrs is None:
+            self._run_ptrs = torch.zeros(max(1, int(self.desc.n_runs)), dtype=torch.int64, device=self.device)
+        if bf16 and self._src16 is None:
             self.series16 = [a.to(torch.bfloat16) for a in self.series]
             self._src16 = (C.c_void_p * len(self.series16))(*[a.data_ptr() for a in self.series16])
-            self._run_ptrs = torch.zeros(max(1, int(self.desc.n_runs)), dtype=torch.int64, device=self.device)
-        return self._src16, self._run_ptrs
+        return (self._src16 if bf16 else None), self._run_ptrs
 
 
 class WindowBatch:

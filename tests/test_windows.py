@@ -162,6 +162,49 @@ def test_solo_device_assembly_matches_oracle_and_feeds_the_engine(kind, history)
 
 # --- fused window assembly: the encoder gathers its inputs from the resident series (mshgnn_step_mse_series) -------------------------------------
 @pytest.mark.gpu
+@pytest.mark.parametrize("recipe_name,B", [("a1c2", 37), ("a1c2", 1000), ("a1c2_body", 64), ("mck4", 130), ("mck4", 1)])
+def test_split_plan_series_step_is_bit_identical_to_assemble_then_step(recipe_name, B):
+    """The same on the split-bf16 parity plan: its encoder gathers fp32 inputs from the fp32 series (two 16-byte loads per chunk, a register
+    splice where a chunk straddles two runs) and materialises fp32 windows; regression (fused MSE) and contact classification."""
+    from morphsym_hgnn_amd import engine as eng, synth
+    from morphsym_hgnn_amd.windows import SequenceStore, quadsdk_a1_c2_recipe, minicheetah_k4_recipe
+    from tests import helpers
+    if recipe_name.startswith("a1c2"):
+        seq, n = SEQ, N
+        recipe = quadsdk_a1_c2_recipe(JP, FP, T, 3, body_frame_labels=recipe_name.endswith("body"))
+        spec = helpers.make_spec("c2", "a1-c2", "a1-c2", 128, 3)
+    else:
+        seq, n = dict(SEQ4), int(FX4["N"])
+        recipe = minicheetah_k4_recipe(JP, FP, T)
+        spec = helpers.make_spec("k4", "mini_cheetah-k4", "mini_cheetah-k4", 128, 3, regression=False)
+    store = SequenceStore(seq, recipe, dtype="x3")
+    e = eng.Engine(spec, "x3")
+    assert not e.generic
+    starts = torch.randint(0, n - T + 1, (B,), generator=torch.Generator().manual_seed(B))
+    starts[0], starts[-1] = 0, n - T
+    starts = starts.cuda()
+    flat = eng.flatten_params(spec, synth.make_params(8, spec.param_shapes()), e.device)
+    xs, y, _ = store.assemble(starts)
+    xs = [x.clone() for x in xs]; y = y.clone()
+    if spec.regression:
+        out_a, loss_a, g_a = e.step_mse(xs, flat, y.reshape(-1), B)
+    else:
+        out_a, loss_a, g_a = e.step_ce(xs, flat, (y != 0).to(torch.int32).reshape(B, 4).contiguous(), B)
+    out_a, loss_a, g_a = out_a.clone(), loss_a.clone(), g_a.clone()
+    for x, t in zip(store._buffers(B)[0], recipe.node_types):
+        x.fill_(float("nan"))                    # the fused step must rewrite every feature column ...
+        x[:, recipe.width(t):] = 0               # ... and leaves the (zero) pad columns alone
+    xs2, y2, out_b, loss_b, g_b = (e.step_mse_series if spec.regression else e.step_ce_series)(store, starts, flat)
+    torch.cuda.synchronize()
+    for a, b in zip(xs, xs2):
+        assert torch.equal(a, b)
+    assert torch.equal(out_a, out_b) and torch.equal(loss_a, loss_b) and torch.equal(g_a, g_b)
+    assert torch.equal(y, store._buffers(B)[1])
+    with pytest.raises(ValueError, match="materialised"):
+        e.step_mse_series(store, starts, flat, materialize=False)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("recipe_name,B", [("a1c2", 37), ("a1c2", 1000), ("a1c2_body", 64), ("mck4", 130)])
 def test_series_step_is_bit_identical_to_assemble_then_step(recipe_name, B):
     """One training step straight from the sequence (window gather fused into the encoder) == mshgnn_assemble_windows + mshgnn_step_mse: the
@@ -238,7 +281,7 @@ def test_classification_series_step_is_bit_identical_to_assemble_then_step_ce(B)
 
 @pytest.mark.gpu
 def test_series_step_refuses_what_it_cannot_run():
-    """mshgnn_step_mse_series is a bf16-plan route: other plans, standardised recipes and recipes whose node types differ from the plan's are
+    """mshgnn_step_mse_series is a route of the bf16 and the split plan: the fp32 plan, standardised recipes and recipes whose node types differ from the plan's are
     refused with an error (the caller assembles windows and calls mshgnn_step_mse instead) -- never a silent fallback."""
     from morphsym_hgnn_amd import engine as eng, synth
     from morphsym_hgnn_amd.windows import SequenceStore, quadsdk_a1_c2_recipe, minicheetah_k4_recipe
@@ -246,7 +289,7 @@ def test_series_step_refuses_what_it_cannot_run():
     spec = helpers.make_spec("c2", "a1-c2", "a1-c2", 128, 2)
     starts = torch.tensor([0, 5, 9], dtype=torch.int64).cuda()
     flat32 = None
-    for dtype, recipe, match in (("x3", quadsdk_a1_c2_recipe(JP, FP, T, 3), "bf16 plan"),
+    for dtype, recipe, match in (("f32", quadsdk_a1_c2_recipe(JP, FP, T, 3), "bf16 plan"),
                                  ("bf16", quadsdk_a1_c2_recipe(JP, FP, T, 3, normalize=True), "unstandardised"),
                                  ("bf16", quadsdk_a1_c2_recipe(JP, FP, T, 1), "label count")):
         e = eng.Engine(spec, dtype)
