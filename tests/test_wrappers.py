@@ -211,8 +211,9 @@ def test_flat_adam_follows_torch_adam_and_round_trips_its_state():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("plan", ["bf16", "x3"])
 @pytest.mark.parametrize("kind", ["a1c2_regression", "mck4_classification"])
-def test_window_batch_training_step_gathers_in_the_encoder_and_matches_the_assembled_batch(kind):
+def test_window_batch_training_step_gathers_in_the_encoder_and_matches_the_assembled_batch(kind, plan):
     """A `windows.WindowBatch` (window indices of a resident sequence) through `training_step`: the encoder gathers its inputs from the
     series (mshgnn_step_mse_series / _ce_series); loss and every gradient are the bits of the same step on the assembled batch, and the
     batch still serves `x_dict` / `y` to consumers that want tensors (validation)."""
@@ -233,7 +234,7 @@ def test_window_batch_training_step_gathers_in_the_encoder_and_matches_the_assem
         _, cfg = helpers.load_group("mini_cheetah-k4")
         make = lambda dummy: wrappers.HGNN_K4_Lightning(128, 2, spec.topology.metadata(), dummy, regression=False, symmetry_mode="MorphSym",
                                                         group_operator_path=cfg)
-    store = SequenceStore(seq, recipe, dtype="bf16")
+    store = SequenceStore(seq, recipe, dtype=plan)
     B = 96
     starts = torch.randint(0, n - tw.T + 1, (B,), generator=torch.Generator().manual_seed(5))
     ei = spec.topology.edge_index_dict(B, device=dev)
@@ -242,7 +243,7 @@ def test_window_batch_training_step_gathers_in_the_encoder_and_matches_the_assem
     dummy = types.SimpleNamespace(edge_index_dict=ei, x_dict={t: x[:, :recipe.width(t)].float().contiguous() for t, x in plain.x_dict.items()})
     import os
     prev = os.environ.get("MSHGNN_DTYPE")
-    os.environ["MSHGNN_DTYPE"] = "bf16"
+    os.environ["MSHGNN_DTYPE"] = plan
     try:
         torch.manual_seed(3)
         w = make(dummy).to(dev)
@@ -253,7 +254,7 @@ def test_window_batch_training_step_gathers_in_the_encoder_and_matches_the_assem
     g_a = w.model._gflat.clone(); la = loss_a.detach().clone()
     w.model.zero_grad()
     wb = store.batch(starts, ei)
-    assert isinstance(wb, WindowBatch) and wb._x is None
+    assert isinstance(wb, WindowBatch) and wb._x is None and next(iter(w.model._engines.values())).storage == plan
     loss_b = w.training_step(wb, 1)
     assert wb._x is not None and torch.equal(wb.y, y.to(dev))          # the step left the materialised windows and the labels on the batch
     loss_b.backward()
