@@ -8,7 +8,7 @@
 i.e. what Lightning's Trainer does with the reference's `HGNN_C2_Lightning_Reg` (gnnLightning.py:564-778, train_model :1230-1400), driven
 by hand because `lightning` is not installed here -- same method calls in the same order (training_step, zero_grad, backward, step).
 Data are synthetic (examples/train_flat.py's sequence: GRFs are a fixed linear function of the joint torques).
-Usage:  python examples/train_wrapper.py [--steps 200] [--batch 8192] [--dtype bf16]
+Usage:  python examples/train_wrapper.py [--steps 200] [--batch 8192] [--dtype bf16]   (under torchrun: one rank per GPU, `ddp.flat_data_parallel`)
 """
 import argparse
 import os
@@ -26,11 +26,18 @@ from morphsym_hgnn_amd.windows import SequenceStore, quadsdk_a1_c2_recipe  # noq
 
 
 def train(steps=200, batch=8192, dtype="bf16", layers=3, lr=1e-3, rows=100_000, log_every=50, quiet=False, assemble=False):
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    dist = None
+    if world > 1:      # one process per GPU (torchrun): every rank trains on its own windows, one all-reduce of the flat gradient per step
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+        dist.init_process_group("nccl")
     dev = torch.device("cuda", torch.cuda.current_device())
     spec = bench.build_spec(layers)
-    store = SequenceStore(synthetic_sequence(rows), quadsdk_a1_c2_recipe(range(12), range(4), 150, 3), dtype=dtype, device=dev)
+    store = SequenceStore(synthetic_sequence(rows, seed=rank), quadsdk_a1_c2_recipe(range(12), range(4), 150, 3), dtype=dtype, device=dev)
     ei = spec.topology.edge_index_dict(batch, device=dev)
-    gen = torch.Generator(device=dev).manual_seed(1234)
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
 
     def next_batch():      # a WindowBatch: window indices only -- training_step lets the encoder gather them; `assemble=True`: tensors first
         starts = torch.randint(0, len(store), (batch,), generator=gen, device=dev)
@@ -48,6 +55,11 @@ def train(steps=200, batch=8192, dtype="bf16", layers=3, lr=1e-3, rows=100_000, 
     dummy = types.SimpleNamespace(edge_index_dict=ei, x_dict={t: x[:, :store.recipe.width(t)].float().contiguous() for t, x in first.x_dict.items()})
     model = wrappers.HGNN_C2_Lightning_Reg(spec.hidden, layers, spec.topology.metadata(), dummy, optimizer="adam", lr=lr,
                                            symmetry_mode="MorphSym", group_operator_path=cfg, grf_body_to_world_frame=False).to(dev)
+    if dist is not None:
+        from morphsym_hgnn_amd import ddp
+        with torch.no_grad():
+            model.model(x_dict=dict(first.x_dict), edge_index_dict=ei)      # parameters become views of the flat buffer
+        ddp.flat_data_parallel(model)                                      # broadcast rank 0's parameters; training_step all-reduces the flat gradient
     opt = model.configure_optimizers()
     losses = []
     warm = 5
@@ -60,13 +72,15 @@ def train(steps=200, batch=8192, dtype="bf16", layers=3, lr=1e-3, rows=100_000, 
         opt.step()
         if step % log_every == 0 or step == 1 or step == steps + warm:
             losses.append((step, float(model.logged["train_MSE_loss"]), float(model.logged["train_RMSE_loss"]), float(model.logged["train_L1_loss"])))
-            if not quiet:
+            if not quiet and rank == 0:
                 print(f"step {step:5d}  mse {losses[-1][1]:.5f}  rmse {losses[-1][2]:.5f}  l1 {losses[-1][3]:.5f}")
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    if not quiet:
-        print(f"{steps} steps of {batch} windows: {batch * steps / dt / 1e6:.2f} M windows/s end to end (window assembly + training_step + backward + "
+    if dist is not None:
+        dist.destroy_process_group()
+    if not quiet and rank == 0:
+        print(f"{steps} steps of {batch} windows x {world} GPU(s): {world * batch * steps / dt / 1e6:.2f} M windows/s end to end (window assembly + training_step + backward + "
               f"{type(opt).__name__}.step), {dt / steps * 1e3:.3f} ms/step")
-    return losses, batch * steps / dt
+    return losses, world * batch * steps / dt
 
 
 if __name__ == "__main__":

@@ -7,7 +7,9 @@ over xGMI on GPUs (`backend="nccl"`), gloo on CPU in the tests.  This is what Li
 reference with devices>1 (gnnLightning.py:1396-1400), with mean semantics (sum / world size).
 
 The nn.Module surface (models.py) needs none of this: its parameters are ordinary nn.Parameters, so
-torch.nn.parallel.DistributedDataParallel / Lightning DDP wrap it unchanged.
+torch.nn.parallel.DistributedDataParallel / Lightning DDP wrap it unchanged (their bucketed all-reduce, per-parameter autograd hooks).
+`flat_data_parallel` is the one-exchange alternative for the training-step wrappers: the one-call training step keeps running under
+torch.distributed and all-reduces its flat gradient buffer once before it hands it to the parameters.
 """
 from __future__ import annotations
 
@@ -39,3 +41,26 @@ def allreduce_gradients_(flat_grad: torch.Tensor, local_windows: int, global_win
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
     return flat_grad
+
+
+def flat_data_parallel(module, group=None):
+    """Data parallelism for a training-step wrapper (wrappers.py) or a model (models.py) WITHOUT torch's DistributedDataParallel: the
+    parameters (views of one flat buffer) are broadcast from rank 0 once, and from then on the fused training step
+    (`training_step` -> `models.fused_training_step[_windows]`) sum-all-reduces its flat gradient in `loss.backward()` and divides by the
+    world size -- the mean over ranks DDP / Lightning-DDP produce (gnnLightning.py:1396-1400), as ONE exchange of 4 MB instead of ~50
+    per-parameter buckets and autograd hooks.  Every rank feeds its own shard of the global batch (equal shard sizes give the global
+    mean loss's gradient).  The model must have seen its lazy-initialising forward and live on the device; do not also wrap it in DDP.
+    Returns `module`."""
+    import torch.distributed as dist
+    model = getattr(module, "model", module)
+    if not (dist.is_available() and dist.is_initialized()):
+        raise RuntimeError("flat_data_parallel needs an initialised torch.distributed process group")
+    if getattr(model, "_spec", None) is None:
+        raise RuntimeError("flat_data_parallel: run the lazy-initialising forward first (the wrappers' constructors do)")
+    p0 = model._params_in_flat_order()[0]
+    if p0.device.type != "cuda":
+        raise RuntimeError("flat_data_parallel: move the model to its GPU first")
+    flat = model._flat_params(p0.device)
+    dist.broadcast(flat, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    model._flat_ddp = True if group is None else group
+    return module

@@ -163,6 +163,11 @@ class _FusedStepFn(torch.autograd.Function):
             raise RuntimeError("the pending gradient of this training step was overwritten by a later fused training step of the same "
                                "model; call backward before the next step")
         pend, scale = m._gpend, gl.to(device=m._gpend.device, dtype=torch.float32)
+        if m._flat_ddp is not None:      # data parallel: ONE sum-all-reduce of the flat gradient, mean over the ranks (DDP semantics)
+            import torch.distributed as dist
+            group = None if m._flat_ddp is True else m._flat_ddp
+            dist.all_reduce(pend, op=dist.ReduceOp.SUM, group=group)
+            scale = scale / dist.get_world_size(group)
         _deliver_gradients(m, ctx.flat, lambda target: torch.mul(pend, scale, out=target) if target is not None else pend * scale)
         return (None,) * n_in
 
@@ -191,6 +196,7 @@ class _MSHGNNBase(nn.Module):
         self._gflat = None               # persistent flat gradient + its cached per-parameter views (_EngineFnFast)
         self._gpend = None               # the flat gradient a fused training step computed, until its backward() delivers it
         self._gpend_id = 0
+        self._flat_ddp = None            # ddp.flat_data_parallel: the process group the fused training step all-reduces its flat gradient over
         self._gviews = None
         self._anchor = None
         self._checked_batches = set()
@@ -203,7 +209,7 @@ class _MSHGNNBase(nn.Module):
         state["_engines"] = {}
         state["_flat"] = None
         state["_flat_ok"] = False
-        state["_gflat"] = state["_gviews"] = state["_anchor"] = state["_gpend"] = None
+        state["_gflat"] = state["_gviews"] = state["_anchor"] = state["_gpend"] = state["_flat_ddp"] = None
         state["_param_list"] = None
         state["_checked_batches"] = set()
         return state
@@ -372,13 +378,13 @@ class _MSHGNNBase(nn.Module):
         `out` as forward() returns it (no autograd), `loss` a scalar whose backward() delivers the parameter gradients the engine has
         already computed (times the upstream factor) -- same values as forward() + loss + backward() through autograd.
         Returns None when this route does not apply (gradients disabled, parameters on the host, the operator-by-operator path, more than
-        one process: DDP needs the per-parameter autograd hooks); the caller then takes the two-call route."""
+        one process without `ddp.flat_data_parallel`: torch's DDP needs the per-parameter autograd hooks); the caller then takes the two-call route."""
         spec, B, e, pdev = self._prepare(x_dict, edge_index_dict)
         params = self._params_in_flat_order()
         if e is None or not torch.is_grad_enabled() or params[0].device.type != "cuda" or not all(p.requires_grad for p in params):
             return None
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and self._flat_ddp is None:
             return None
         in_dev, in_dtype = x_dict[self._node_types[0]].device, x_dict[self._node_types[0]].dtype
         xs = e.cast_inputs(x_dict)
@@ -408,7 +414,7 @@ class _MSHGNNBase(nn.Module):
         if not torch.is_grad_enabled() or params[0].device.type != "cuda" or params[0].device != store.device or not all(p.requires_grad for p in params):
             return None
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and self._flat_ddp is None:
             return None
         e = self._engine(store.device)
         if e.generic or e.storage not in ("bf16", "x3") or (e.storage == "bf16") != (store.dtype == "bf16"):      # (the split plan gathers fp32 series)

@@ -88,3 +88,60 @@ def test_two_engine_ranks_reproduce_the_global_batch_gradient(dtype):
     port = 31000 + (os.getpid() % 2000)
     mp.spawn(_gpu_worker, args=(world, port, B, dtype, ret), nprocs=world, join=True)
     assert ret["err"] < 1e-5    # same arithmetic, different summation order over the windows
+
+
+def _wrapper_worker(rank, world, port, B, ret):
+    """Two wrapper ranks on the one GPU of the test box (gloo: its all-reduce takes device tensors through host copies): flat_data_parallel +
+    training_step + backward on each rank's shard == the single-process step on the whole batch."""
+    import types
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from morphsym_hgnn_amd import wrappers
+    torch.set_default_dtype(torch.float64)
+    dev = torch.device("cuda", 0)
+    spec = helpers.make_spec("c2", "a1-c2", "a1-c2", 128, 2)
+    _, cfg = helpers.load_group("a1-c2")
+    x_dict, y = synth.make_windows(41, B, spec.num_nodes, spec.widths, 12)
+    params = synth.make_params(41 + rank, spec.param_shapes())          # different on every rank: the broadcast must make them rank 0's
+
+    def batch_of(xd, yy, n):
+        return types.SimpleNamespace(x_dict={k: v.to(dev) for k, v in xd.items()}, edge_index_dict=spec.topology.edge_index_dict(n, device=dev),
+                                     y=yy.to(dev).flatten(), batch_size=n)
+    xs, (b, en) = ddp.shard_x_dict(x_dict, spec.num_nodes, B, rank, world)
+    mine = batch_of(xs, y[b:en], en - b)
+    w = wrappers.HGNN_C2_Lightning_Reg(128, 2, spec.topology.metadata(), mine, symmetry_mode="MorphSym", group_operator_path=cfg).to(dev)
+    w.model.load_state_dict(params)
+    with torch.no_grad():
+        w.model(x_dict=dict(mine.x_dict), edge_index_dict=mine.edge_index_dict)      # parameters become views of the flat buffer
+    ddp.flat_data_parallel(w)
+    loss = w.training_step(mine, 0)
+    assert w.model._gpend_id == 1                                      # the one-call step ran under torch.distributed
+    w.model.zero_grad()
+    loss.backward()
+    g = w.model._gflat.clone()
+    if rank == 0:
+        ref = wrappers.HGNN_C2_Lightning_Reg(128, 2, spec.topology.metadata(), mine, symmetry_mode="MorphSym", group_operator_path=cfg).to(dev)
+        ref.model.load_state_dict(synth.make_params(41, spec.param_shapes()))
+        ref.model._flat_ddp = None
+        full = batch_of(x_dict, y, B)
+        ref.fused_training_step = False                                # (single-process reference through autograd)
+        lf = ref.training_step(full, 0)
+        lf.backward()
+        gf = torch.zeros_like(g)                                       # (under torch.distributed the two-call route goes through autograd)
+        for (o, n), q in zip(spec.param_offsets().values(), ref.model._params_in_flat_order()):
+            gf[o:o + n] = q.grad.flatten()
+        ret["err"] = float((g - gf).abs().max() / gf.abs().max())
+        ret["params_equal"] = bool(torch.equal(w.model._flat, ref.model._flat))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_flat_data_parallel_wrappers_reproduce_the_global_batch_gradient():
+    world, B = 2, 64        # equal shards: the mean of the ranks' mean losses is the global mean
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 33000 + (os.getpid() % 2000)
+    mp.spawn(_wrapper_worker, args=(world, port, B, ret), nprocs=world, join=True)
+    assert ret["params_equal"] and ret["err"] < 1e-5
