@@ -525,6 +525,29 @@ class _MSHGNNBase(nn.Module):
         return x_dict
 
 
+class _SymmetryHelpers:
+    """The tensor helpers the reference's C2 / K4 models carry next to `apply_symmetry` (hgnn_c2.py:184-189, 233-284; hgnn_k4.py): the engine needs
+    none of them (the masks are sign-bit XORs inside its encoder, the output mask sits in its decoder tail), they exist for callers that use them."""
+
+    def ms_foot_decoder(self, x):
+        """[B * num_legs, out_channels_per_foot] decoder rows -> [B, num_legs * out_channels_per_foot] times the feet's +-1 mask (hgnn_c2.py:184-189)."""
+        x = x.view(-1, self.num_legs, self.out_channels_per_foot).flatten(start_dim=1)
+        return self.feet_linear_weights.to(x.device) * x
+
+    def unpack_data(self, data, batch_size, num_nodes):
+        """Node rows [batch * nodes, 2 * dims * T] laid out [variable][axis][time] -> the two variables as [batch, T, nodes * dims]
+        (hgnn_c2.py:233-264)."""
+        d, t = self.num_dimensions_per_foot, self.num_timesteps
+        x = data.view(batch_size, num_nodes, 2, d, t).permute(2, 0, 4, 1, 3)           # [variable, batch, time, node, axis]
+        return x[0].reshape(batch_size, t, num_nodes * d), x[1].reshape(batch_size, t, num_nodes * d)
+
+    def pack_data(self, f_p, f_v, batch_size, num_nodes):
+        """The inverse of `unpack_data` (hgnn_c2.py:266-284)."""
+        d, t = self.num_dimensions_per_foot, self.num_timesteps
+        both = torch.stack([f_p.view(batch_size, t, num_nodes, d), f_v.view(batch_size, t, num_nodes, d)])      # [variable, batch, time, node, axis]
+        return both.permute(1, 3, 0, 4, 2).reshape(batch_size * num_nodes, 2 * d * t)
+
+
 def _load_group(symmetry_mode, group_operator_path):
     if symmetry_mode and group_operator_path:
         with open(group_operator_path, "r") as f:
@@ -532,7 +555,7 @@ def _load_group(symmetry_mode, group_operator_path):
     return None
 
 
-class GRF_HGNN_C2(_MSHGNNBase):
+class GRF_HGNN_C2(_SymmetryHelpers, _MSHGNNBase):
     """MS-HGNN for the C2 graph (2 base nodes) -- drop-in for hgnn_c2.py:GRF_HGNN_C2."""
     kind = "c2"
     num_bases = 2
@@ -571,7 +594,7 @@ class GRF_HGNN_C2(_MSHGNNBase):
         return p
 
 
-class GRF_HGNN_K4(_MSHGNNBase):
+class GRF_HGNN_K4(_SymmetryHelpers, _MSHGNNBase):
     """MS-HGNN for the K4 graph (4 base nodes) -- drop-in for hgnn_k4.py:GRF_HGNN_K4."""
     kind = "k4"
     num_bases = 4

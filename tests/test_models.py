@@ -237,3 +237,28 @@ def test_hidden_width_off_the_engines_grid_runs_operator_by_operator():
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
         else:
             assert float((p.grad.cpu().double() - ref).abs().max() / ref.abs().max()) < 1e-4, k
+
+
+def test_pack_helpers_follow_the_reference_layout():
+    """unpack_data / pack_data / ms_foot_decoder (hgnn_c2.py:184-189, 233-284): node rows are [variable][axis][time]; unpacked tensors are
+    [batch, time, node * axis]; the pair is an exact round trip and ms_foot_decoder applies the feet's mask to [B, 12]."""
+    torch.set_default_dtype(torch.float64)
+    case, spec, fx, x_dict, y, params, ei = helpers.load_case("a1c2_h128_L3_d3_B3")
+    m = _build(case, spec)
+    B, n, T, D = 3, 2, m.num_timesteps, 3
+    data = torch.arange(B * n * 2 * D * T, dtype=torch.float64).view(B * n, 2 * D * T)
+    f_p, f_v = m.unpack_data(data, B, n)
+    assert f_p.shape == (B, T, n * D) and f_v.shape == (B, T, n * D)
+    for b, node, axis, t in ((0, 0, 0, 0), (2, 1, 2, 149), (1, 0, 1, 77)):
+        assert f_p[b, t, node * D + axis] == data[b * n + node, axis * T + t]
+        assert f_v[b, t, node * D + axis] == data[b * n + node, D * T + axis * T + t]
+    assert torch.equal(m.pack_data(f_p, f_v, B, n), data)
+    dec = torch.randn(B * 4, 3)
+    assert torch.equal(m.ms_foot_decoder(dec), dec.view(B, 12) * m.feet_linear_weights)
+    # apply_symmetry == unpack, scale, pack for the base rows (hgnn_c2.py:220-229)
+    base = torch.randn(B * 2, 900)
+    lin, ang = m.unpack_data(base, B, 2)
+    ref = m.pack_data(lin * m.base_coefficients_lin.view(1, 1, -1), ang * m.base_coefficients_ang.view(1, 1, -1), B, 2)
+    m._spec = spec
+    got = m.apply_symmetry({"base": base.clone(), "joint": torch.randn(B * 12, 450), "foot": torch.ones(B * 4, 1)})["base"]
+    assert torch.equal(got, ref)
