@@ -39,7 +39,8 @@ constexpr int DEC_SLAB_FLOATS = 8 * H + 16; // decoder partial: [out_channels<=8
 #endif                                   // MiniCheetah-K4 L=8: 560 -> 714) and the kernel gets SLOWER (110 -> 152 us, 333 -> 372 us): lanes of 3-4 interleaved items
                                          // reach a shared P / Q stream steps apart, and a stream survives in an XCD's L2 for about one step
 constexpr int GW_IPL = GW_IPL_MAX;       // most items per weight-gradient lane; the plan picks gw_ipl in 1 .. GW_IPL: whichever fills most of
-                                         // the GW_TARGET_WGS resident workgroups (lanes x window parts), the smallest on a tie.  The lean kernels
+                                         // the GW_TARGET_WGS resident workgroups (lanes x window parts), the smallest on a tie (K4 L=8, 560 workgroups either
+                                         // way: 1 item x 1 part 328 us, 2 items x 2 parts 340 us; split plan 646 vs 712).  The lean kernels
                                          // interleave a lane's items chunk by chunk (any number); the general bf16 kernel (MSHGNN_GRADW=general) at most two
 #ifndef GW_TARGET_WGS
 #define GW_TARGET_WGS 768.0              // workgroups of the weight-gradient kernel (lanes x window parts): 3 resident per CU x 256 CUs, so
