@@ -98,13 +98,24 @@ template <typename T, bool ALIGNED, bool SERIES = false> __global__ __launch_bou
     constexpr int VPB = P::ROWS * P::CPR, NIT = VPB / 256 > 0 ? VPB / 256 : 1, BPP = 256 / VPB > 0 ? 256 / VPB : 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if ((int)blockIdx.x >= a.wg_prefix[a.n_types]) {      // a workgroup of the embedded layer-pack prep (bf16 plan; see EncArgs.prep)
-        if constexpr (sizeof(T) == 2 && ALIGNED && !SERIES) prep_one<T>(a.prep, ((int)blockIdx.x - a.wg_prefix[a.n_types]) * 256 + tid, false);
+    // SERIES: the FIRST workgroups of the launch compute the batch's window labels (SeriesSrc.lab) -- chains of dependent round trips that finish
+    // under the encoder's body (as the last workgroups they stretched its tail instead: measured)
+    const int lab_blocks = SERIES ? (int)((ser.lab.B + 255) / 256) : 0;
+    if constexpr (SERIES) {
+        if ((int)blockIdx.x < lab_blocks) {
+            const int64_t b = (int64_t)blockIdx.x * 256 + tid;
+            if (b < ser.lab.B) window_labels_one(ser.lab, b);
+            return;
+        }
+    }
+    const int bid = (int)blockIdx.x - lab_blocks;
+    if (bid >= a.wg_prefix[a.n_types]) {      // a workgroup of the embedded layer-pack prep (bf16 plan; see EncArgs.prep)
+        if constexpr (sizeof(T) == 2 && ALIGNED && !SERIES) prep_one<T>(a.prep, (bid - a.wg_prefix[a.n_types]) * 256 + tid, false);
         return;
     }
     int t = 0;
-    while (t + 1 < a.n_types && (int)blockIdx.x >= a.wg_prefix[t + 1]) ++t;
-    const int local = blockIdx.x - a.wg_prefix[t];
+    while (t + 1 < a.n_types && bid >= a.wg_prefix[t + 1]) ++t;
+    const int local = bid - a.wg_prefix[t];
     const int node = ENC_ORDER ? local % a.nodes[t] : local / a.tiles, tile = ENC_ORDER ? local / a.nodes[t] : local % a.tiles;
     const int w0 = tile * MB * P::ROWS;
     const T* x = reinterpret_cast<const T*>(a.x[t]);
@@ -2210,6 +2221,7 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
         if constexpr (sizeof(T) == 2) {
             if (series) {
                 if (x && !a.aligned) return set_err(MSHGNN_EINVAL, "the fused window assembly needs 16-byte aligned window rows (pitch a multiple of 8)");
+                enc_grid += (unsigned)((series->lab.B + 255) / 256);      // the label workgroups
                 hipLaunchKernelGGL((k_enc_fwd<T, true, true>), dim3(enc_grid), dim3(256), Prec<T>::ENC_MB * Prec<T>::BLK, st, a, *series);
             } else if (a.aligned) hipLaunchKernelGGL((k_enc_fwd<T, true>), dim3(enc_grid), dim3(256), Prec<T>::ENC_MB * Prec<T>::BLK, st, a, SeriesSrc{});
             else hipLaunchKernelGGL((k_enc_fwd<T, false>), dim3(enc_grid), dim3(256), Prec<T>::ENC_MB * Prec<T>::BLK, st, a, SeriesSrc{});
@@ -3071,56 +3083,19 @@ template <typename T> __global__ __launch_bounds__(256) void k_assemble_windows_
 // labels of a window = the label row of its LAST time step (quadSDKDataset.py: grfs[-1]); with label_rotate the world-frame
 // GRFs are taken into the body frame with the world->body quaternion of that step, R f per foot (the as_matrix() @ grfs_T
 // branch of load_data_at_dataset_seq_3d); quat out = that quaternion (data.r_o, quadSDKDataset_Morph.py:365-367)
-__device__ __forceinline__ void window_labels_one(const WindowArgs& a, int64_t b, int32_t* labels_int) {
-    const int64_t row = a.starts[b] + a.T - 1;
-    const float* lab = a.src[a.label_src] + row;                  // column-major: element c at lab[c * cstride]
-    const int64_t lcs = a.src_cstride[a.label_src];
-    double R[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
-    float qv[4] = {0.f, 0.f, 0.f, 1.f};
-    if (a.quat_src >= 0) {
-        const float* qp = a.src[a.quat_src] + row;
-        const int64_t qcs = a.src_cstride[a.quat_src];
-        const float q0 = qp[0], q1 = qp[qcs], q2 = qp[2 * qcs], q3 = qp[3 * qcs];
-        qv[0] = q0; qv[1] = q1; qv[2] = q2; qv[3] = q3;
-        if (a.label_rotate) {
-            double x = q0, yq = q1, z = q2, s = q3;
-            const double nrm = sqrt(x * x + yq * yq + z * z + s * s);
-            x /= nrm; yq /= nrm; z /= nrm; s /= nrm;
-            R[0][0] = 1 - 2 * (yq * yq + z * z); R[0][1] = 2 * (x * yq - z * s); R[0][2] = 2 * (x * z + yq * s);
-            R[1][0] = 2 * (x * yq + z * s); R[1][1] = 1 - 2 * (x * x + z * z); R[1][2] = 2 * (yq * z - x * s);
-            R[2][0] = 2 * (x * z - yq * s); R[2][1] = 2 * (yq * z + x * s); R[2][2] = 1 - 2 * (x * x + yq * yq);
-        }
-    }
-    // every label of the window is fetched before the first one is stored: the stores may alias the series as far as the compiler knows, and a
-    // load -> store -> load chain costs one memory round trip per label (12 for the A1 GRFs: 18 us for 8192 windows, now 6)
-    constexpr int LMAX = 24;
-    for (int k0 = 0; k0 < a.n_label; k0 += LMAX) {
-        float v[LMAX];
-#pragma unroll
-        for (int j = 0; j < LMAX; ++j) v[j] = k0 + j < a.n_label ? lab[a.label_cols[k0 + j] * lcs] : 0.f;
-        if (a.label_rotate) {
-#pragma unroll
-            for (int j = 0; j + 2 < LMAX; j += 3) {
-                if (k0 + j + 2 >= a.n_label) break;
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-                    a.y[b * a.n_label + k0 + j + i] = (float)(R[i][0] * (double)v[j] + R[i][1] * (double)v[j + 1] + R[i][2] * (double)v[j + 2]);
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < LMAX; ++j) {
-                if (k0 + j >= a.n_label) break;
-                a.y[b * a.n_label + k0 + j] = v[j];
-                if (labels_int) labels_int[b * a.n_label + k0 + j] = v[j] != 0.f;      // contact flags for the fused cross entropy (mshgnn_step_ce_series)
-            }
-        }
-    }
-    if (a.quat_src >= 0 && a.quat) { a.quat[b * 4] = qv[0]; a.quat[b * 4 + 1] = qv[1]; a.quat[b * 4 + 2] = qv[2]; a.quat[b * 4 + 3] = qv[3]; }
+// (window_labels_one itself lives in mshgnn_device.hpp: the fused-gather encoders run it in extra workgroups of their own launch)
+__device__ __forceinline__ LabelArgs label_args_of(const WindowArgs& a, int32_t* labels_int) {
+    LabelArgs l{};
+    l.lab = a.src[a.label_src]; l.lab_cs = a.src_cstride[a.label_src];
+    l.quat_src = a.quat_src >= 0 ? a.src[a.quat_src] : nullptr; l.quat_cs = a.quat_src >= 0 ? a.src_cstride[a.quat_src] : 0;
+    l.starts = a.starts; l.B = a.B; l.T = a.T; l.label_cols = a.label_cols; l.n_label = a.n_label; l.label_rotate = a.label_rotate;
+    l.y = a.y; l.quat = a.quat; l.labels_int = labels_int;
+    return l;
 }
 
 __global__ void k_window_labels(WindowArgs a) {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < a.B) window_labels_one(a, b, nullptr);
+    if (b < a.B) window_labels_one(label_args_of(a, nullptr), b);
 }
 
 extern "C" int mshgnn_assemble_windows(const mshgnn_window_desc* d, const float* const* src, const int64_t* src_cstride, const int64_t* src_rows,
@@ -3177,20 +3152,18 @@ extern "C" int mshgnn_assemble_windows(const mshgnn_window_desc* d, const float*
 // fused into the encoder (k_enc_fwd<.., SERIES>), which also writes the materialised windows for the weight-gradient kernel; labels by
 // k_window_labels.  bf16 plan with the fused stack kernels; everything after the encoder is mshgnn_step_mse.
 // ------------------------------------------------------------------------------------------------------
-// everything mshgnn_step_*_series needs before its encoder launch, in ONE launch: the windows' labels (k_window_labels' arithmetic, plus
-// the int32 contact flags for the classification step) and, in workgroup 0, the bf16 base pointer of every run's series column
-__global__ void k_series_setup(WindowArgs la, const int* runs, int n_runs, WindowArgs wa, int elem_bytes, unsigned long long* run_ptr, int32_t* labels_int) {
-    if (blockIdx.x == 0 && (int)threadIdx.x < n_runs) {
-        const int r = threadIdx.x;
-        const int sc = runs[(size_t)r * 5 + 3];
-        unsigned long long p = 0ull;
+// the one thing mshgnn_step_*_series needs before its encoder launch: the base pointer of every run's series column (one workgroup).  The windows'
+// labels (and the int32 contact flags of the classification step) are computed by extra workgroups of the encoder launch itself (SeriesSrc.lab):
+// a launch of their own cost 13.6 us of dependent round trips in front of the encoder, there they run under its tail.
+__global__ void k_series_run_ptrs(const int* runs, int n_runs, WindowArgs wa, int elem_bytes, unsigned long long* run_ptr) {
+    const int r = threadIdx.x;
+    if (r >= n_runs) return;
+    const int sc = runs[(size_t)r * 5 + 3];
+    unsigned long long p = 0ull;
 #pragma unroll
-        for (int k = 0; k < WIN_MAX_SRC; ++k)
-            if (sc >= 0 && (sc >> 8) == k) p = (unsigned long long)(reinterpret_cast<const char*>(wa.src[k]) + (size_t)(sc & 0xff) * wa.src_cstride[k] * elem_bytes);
-        run_ptr[r] = p;
-    }
-    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < la.B) window_labels_one(la, b, labels_int);
+    for (int k = 0; k < WIN_MAX_SRC; ++k)
+        if (sc >= 0 && (sc >> 8) == k) p = (unsigned long long)(reinterpret_cast<const char*>(wa.src[k]) + (size_t)(sc & 0xff) * wa.src_cstride[k] * elem_bytes);
+    run_ptr[r] = p;
 }
 
 static int step_series(const mshgnn_plan* p, const mshgnn_window_desc* d, const float* const* src, const void* const* src_bf16,
@@ -3236,11 +3209,17 @@ static int step_series(const mshgnn_plan* p, const mshgnn_window_desc* d, const 
     la.starts = starts; la.B = batch; la.T = d->history; la.label_cols = d->label_cols; la.n_label = d->n_label; la.label_src = d->label_src;
     la.label_rotate = d->label_rotate; la.quat_src = d->quat_src; la.y = y_out; la.quat = quat_out;
     if (d->label_rotate && (d->n_label % 3 != 0 || d->quat_src < 0)) return set_err(MSHGNN_EINVAL, "label rotation needs 3-D labels and a quaternion source");
-    static_assert(WIN_MAX_RUNS <= 256, "k_series_setup resolves the runs in one 256-thread workgroup");
+    static_assert(WIN_MAX_RUNS <= 256, "k_series_run_ptrs resolves the runs in one 256-thread workgroup");
     if (ce && d->label_rotate) return set_err(MSHGNN_EINVAL, "mshgnn_step_ce_series: contact labels are not rotated");
-    hipLaunchKernelGGL(k_series_setup, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, la, d->runs, d->n_runs, wa, x3 ? 4 : 2,
-                       reinterpret_cast<unsigned long long*>(run_ptrs), ce ? labels_out : nullptr);
+    hipLaunchKernelGGL(k_series_run_ptrs, dim3(1), dim3(256), 0, st, d->runs, d->n_runs, wa, x3 ? 4 : 2, reinterpret_cast<unsigned long long*>(run_ptrs));
     SeriesSrc ser{};
+    {   // labels: extra workgroups of the encoder launch
+        LabelArgs& l = ser.lab;
+        l.lab = la.src[la.label_src]; l.lab_cs = la.src_cstride[la.label_src];
+        l.quat_src = la.quat_src >= 0 ? la.src[la.quat_src] : nullptr; l.quat_cs = la.quat_src >= 0 ? la.src_cstride[la.quat_src] : 0;
+        l.starts = starts; l.B = batch; l.T = d->history; l.label_cols = d->label_cols; l.n_label = d->n_label; l.label_rotate = d->label_rotate;
+        l.y = y_out; l.quat = quat_out; l.labels_int = ce ? labels_out : nullptr;
+    }
     ser.run_ptr = reinterpret_cast<const unsigned long long*>(run_ptrs); ser.rows = d->rows; ser.starts = starts; ser.T = d->history;
     { int r0 = 0; for (int t = 0; t < d->n_types; ++t) { ser.row0[t] = r0; r0 += d->type_nodes[t]; } }
     if (x3) {      // (the split plan fuses the MSE into its forward kernel's tail; cross entropy: forward, then the fused-loss backward)

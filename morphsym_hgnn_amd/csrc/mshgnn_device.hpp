@@ -353,12 +353,71 @@ struct EncArgs {
 // The encoder's inputs gathered straight from a sequence's resident raw series (bf16 copies, column-major) instead of materialised windows --
 // the fused window assembly of mshgnn_step_mse_series: feature k of node row (t, node) of window w is element starts[w] + k % T of the row's
 // run k / T (runs of one length T, or the single constant-1 run; mshgnn_window_desc.fast_layout).
+// Labels of a batch of windows (mshgnn_assemble_windows / mshgnn_step_*_series): y[b][k] = label series column label_cols[k] at the window's last
+// step; label_rotate: the 3-D world-frame GRFs are taken into the body frame with the world->body quaternion of that step, R f per foot (the
+// as_matrix() @ grfs_T branch of load_data_at_dataset_seq_3d); quat out = that quaternion (data.r_o, quadSDKDataset_Morph.py:365-367).
+struct LabelArgs {
+    const float* lab; int64_t lab_cs;            // the label series (column-major: element (row, c) at c * lab_cs + row)
+    const float* quat_src; int64_t quat_cs;      // the quaternion series or nullptr
+    const int64_t* starts; int64_t B; int T;
+    const int* label_cols; int n_label, label_rotate;
+    float* y; float* quat; int32_t* labels_int;  // labels_int (nullable): contact flags y != 0 for the fused cross entropy (mshgnn_step_ce_series)
+};
+
+__device__ __forceinline__ void window_labels_one(const LabelArgs& a, int64_t b) {
+    const int64_t row = a.starts[b] + a.T - 1;
+    const float* lab = a.lab + row;
+    const int64_t lcs = a.lab_cs;
+    double R[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    float qv[4] = {0.f, 0.f, 0.f, 1.f};
+    if (a.quat_src) {
+        const float* qp = a.quat_src + row;
+        const int64_t qcs = a.quat_cs;
+        const float q0 = qp[0], q1 = qp[qcs], q2 = qp[2 * qcs], q3 = qp[3 * qcs];
+        qv[0] = q0; qv[1] = q1; qv[2] = q2; qv[3] = q3;
+        if (a.label_rotate) {
+            double x = q0, yq = q1, z = q2, s = q3;
+            const double nrm = sqrt(x * x + yq * yq + z * z + s * s);
+            x /= nrm; yq /= nrm; z /= nrm; s /= nrm;
+            R[0][0] = 1 - 2 * (yq * yq + z * z); R[0][1] = 2 * (x * yq - z * s); R[0][2] = 2 * (x * z + yq * s);
+            R[1][0] = 2 * (x * yq + z * s); R[1][1] = 1 - 2 * (x * x + z * z); R[1][2] = 2 * (yq * z - x * s);
+            R[2][0] = 2 * (x * z - yq * s); R[2][1] = 2 * (yq * z + x * s); R[2][2] = 1 - 2 * (x * x + yq * yq);
+        }
+    }
+    // every label of the window is fetched before the first one is stored: the stores may alias the series as far as the compiler knows, and a
+    // load -> store -> load chain costs one memory round trip per label (12 for the A1 GRFs: 18 us for 8192 windows, 13.6 with the loads batched)
+    constexpr int LMAX = 24;
+    for (int k0 = 0; k0 < a.n_label; k0 += LMAX) {
+        float v[LMAX];
+#pragma unroll
+        for (int j = 0; j < LMAX; ++j) v[j] = k0 + j < a.n_label ? lab[a.label_cols[k0 + j] * lcs] : 0.f;
+        if (a.label_rotate) {
+#pragma unroll
+            for (int j = 0; j + 2 < LMAX; j += 3) {
+                if (k0 + j + 2 >= a.n_label) break;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    a.y[b * a.n_label + k0 + j + i] = (float)(R[i][0] * (double)v[j] + R[i][1] * (double)v[j + 1] + R[i][2] * (double)v[j + 2]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < LMAX; ++j) {
+                if (k0 + j >= a.n_label) break;
+                a.y[b * a.n_label + k0 + j] = v[j];
+                if (a.labels_int) a.labels_int[b * a.n_label + k0 + j] = v[j] != 0.f;
+            }
+        }
+    }
+    if (a.quat_src && a.quat) { a.quat[b * 4] = qv[0]; a.quat[b * 4 + 1] = qv[1]; a.quat[b * 4 + 2] = qv[2]; a.quat[b * 4 + 3] = qv[3]; }
+}
+
 struct SeriesSrc {
     const unsigned long long* run_ptr;   // device: per run of the window descriptor, the address of its column's element 0 (0: the constant 1)
     const int* rows;                     // device: per node row, [first run, end run)
     const int64_t* starts;               // device: first series row of every window
     int row0[MSHGNN_MAX_TYPES];          // first node row of each type
     int T;
+    LabelArgs lab;                       // the batch's labels: computed by extra workgroups of the fused-gather encoder launch (lab.B == 0: none)
 };
 
 // load up to EPC elements starting at p with the widest vector the alignment `vb` (bytes) allows

@@ -110,13 +110,22 @@ template <bool ALIGNED, bool SERIES = false> __global__ __launch_bounds__(256) v
     constexpr int MB = 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if ((int)blockIdx.x >= a.wg_prefix[a.n_types]) {      // a workgroup of the embedded layer-pack prep (EncArgs.prep)
-        if constexpr (ALIGNED && !SERIES) prep_one_x3(a.prep, ((int)blockIdx.x - a.wg_prefix[a.n_types]) * 256 + tid, false);
+    const int lab_blocks = SERIES ? (int)((ser.lab.B + 255) / 256) : 0;      // SERIES: the first workgroups compute the batch's window labels (as k_enc_fwd)
+    if constexpr (SERIES) {
+        if ((int)blockIdx.x < lab_blocks) {
+            const int64_t b = (int64_t)blockIdx.x * 256 + tid;
+            if (b < ser.lab.B) window_labels_one(ser.lab, b);
+            return;
+        }
+    }
+    const int bid = (int)blockIdx.x - lab_blocks;
+    if (bid >= a.wg_prefix[a.n_types]) {      // a workgroup of the embedded layer-pack prep (EncArgs.prep)
+        if constexpr (ALIGNED && !SERIES) prep_one_x3(a.prep, (bid - a.wg_prefix[a.n_types]) * 256 + tid, false);
         return;
     }
     int t = 0;
-    while (t + 1 < a.n_types && (int)blockIdx.x >= a.wg_prefix[t + 1]) ++t;
-    const int local = blockIdx.x - a.wg_prefix[t];
+    while (t + 1 < a.n_types && bid >= a.wg_prefix[t + 1]) ++t;
+    const int local = bid - a.wg_prefix[t];
     const int node = ENC_ORDER ? local % a.nodes[t] : local / a.tiles, tile = ENC_ORDER ? local / a.nodes[t] : local % a.tiles;
     const int w0 = tile * MB * P::ROWS;
     const float* x = reinterpret_cast<const float*>(a.x[t]);
@@ -1152,6 +1161,7 @@ int x3_forward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitc
         ProfScope ps(p, hp.ks_enc, st);
         if (series) {      // inputs gathered from the sequence's series; x = the window buffers the rows are materialised into
             if (!a.aligned) return set_err(MSHGNN_EINVAL, "the series gather writes 16-byte-aligned window buffers whose pitch is a multiple of 4");
+            enc_grid += (unsigned)((series->lab.B + 255) / 256);      // the label workgroups
             hipLaunchKernelGGL((k_enc_x3<true, true>), dim3(enc_grid), dim3(256), 8 * P16::BLK, st, a, hp.n_img, *series);
         }
         else if (a.aligned) hipLaunchKernelGGL(k_enc_x3<true>, dim3(enc_grid), dim3(256), 8 * P16::BLK, st, a, hp.n_img, SeriesSrc{});
