@@ -33,11 +33,36 @@ MODEL_CLASSES = {
 # ckpt["hyper_parameters"] holds `dummy_batch` (a torch_geometric HeteroData batch) and `activation_fn`.  A plain
 # torch.load(weights_only=False) then needs torch_geometric importable (it is not part of this stack) and runs arbitrary
 # pickle code of a third-party file.  Only `state_dict` and the scalar hyper-parameters are needed here, so the file is
-# read with weights_only=True first and, failing that, with an unpickler that resolves nothing outside an allow-list:
-# every other global (torch_geometric.*, lightning.*, anything else) becomes an inert placeholder object.
-_SAFE_MODULE_PREFIXES = ("torch", "collections", "numpy", "_codecs", "copyreg", "pathlib", "argparse", "typing", "datetime")
+# read with weights_only=True first and, when that reader rejects a global, with an unpickler that resolves ONLY the exact
+# (module, name) pairs below -- the constructors a tensor / ndarray / plain-container pickle needs.  Every other global
+# (torch_geometric.*, lightning.*, but also torch.utils.*, torch.hub.*, numpy.testing.* ...: a package prefix is not a
+# licence, those hold functions that run commands) becomes an inert placeholder whose REDUCE / BUILD do nothing.
+_SAFE_GLOBALS = {
+    ("collections", "OrderedDict"), ("collections", "defaultdict"),
+    ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"), ("torch._utils", "_rebuild_parameter"),
+    ("torch.nn.parameter", "Parameter"), ("torch._tensor", "_rebuild_from_type_v2"),
+    ("torch.storage", "TypedStorage"), ("torch.storage", "UntypedStorage"), ("torch", "Size"), ("torch", "device"), ("torch", "Tensor"),
+    ("numpy", "ndarray"), ("numpy", "dtype"),
+    ("numpy.core.multiarray", "_reconstruct"), ("numpy.core.multiarray", "scalar"),
+    ("numpy._core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "scalar"),
+    ("_codecs", "encode"), ("copyreg", "_reconstructor"),
+    ("pathlib", "PosixPath"), ("pathlib", "PurePosixPath"), ("pathlib", "Path"), ("argparse", "Namespace"),
+}
+# activation modules a wrapper may have stored as `activation_fn` (parameter-free nn.Modules, rebuilt through copyreg._reconstructor)
+_SAFE_ACTIVATIONS = {"ReLU", "LeakyReLU", "ELU", "GELU", "SiLU", "Tanh", "Sigmoid", "Softplus", "PReLU", "SELU", "CELU", "Mish", "Hardtanh", "ReLU6",
+                     "Identity"}
 _SAFE_BUILTINS = {"set", "frozenset", "dict", "list", "tuple", "int", "float", "bool", "str", "bytes", "bytearray", "complex",
                   "slice", "range", "object"}
+
+
+def _safe_torch_attr(name):
+    """`torch.<name>` for the value kinds a tensor pickle references by name: dtypes and (legacy) storage classes."""
+    obj = getattr(torch, name, None)
+    if isinstance(obj, torch.dtype):
+        return obj
+    if isinstance(obj, type) and issubclass(obj, (torch.storage.TypedStorage, torch.storage.UntypedStorage)):
+        return obj
+    return None
 
 
 class OpaqueObject:
@@ -58,12 +83,13 @@ class OpaqueObject:
 
 class _RestrictedUnpickler(pickle.Unpickler):
     def find_class(self, module, name):
-        top = module.split(".")[0]
         if module == "builtins":
-            if name in _SAFE_BUILTINS:
-                return getattr(builtins, name)
-            return OpaqueObject
-        if top in _SAFE_MODULE_PREFIXES:
+            return getattr(builtins, name) if name in _SAFE_BUILTINS else OpaqueObject
+        if module == "torch" and "." not in name:
+            obj = _safe_torch_attr(name)
+            if obj is not None:
+                return obj
+        if (module, name) in _SAFE_GLOBALS or (module in ("torch.nn.modules.activation", "torch.nn.modules.linear") and name in _SAFE_ACTIVATIONS):
             try:
                 return super().find_class(module, name)
             except (ImportError, AttributeError):
@@ -80,10 +106,10 @@ class _restricted_pickle:
 
 
 def read_checkpoint(path) -> dict:
-    """Load a Lightning `.ckpt` (or a bare state_dict file) onto the host without importing what it pickled."""
+    """Load a Lightning `.ckpt` (or a bare state_dict file) onto the host without importing or calling what it pickled."""
     try:
         return torch.load(path, map_location="cpu", weights_only=True)
-    except Exception:  # noqa: BLE001  (hyper_parameters hold non-tensor objects: fall through to the restricted reader)
+    except pickle.UnpicklingError:      # hyper_parameters hold non-tensor objects the weights_only reader rejects: restricted reader
         return torch.load(path, map_location="cpu", weights_only=False, pickle_module=_restricted_pickle)
 
 
