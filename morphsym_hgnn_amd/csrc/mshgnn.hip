@@ -2074,6 +2074,10 @@ extern "C" int mshgnn_plan_create(const mshgnn_desc* desc, mshgnn_plan** out) {
             p->slab_force = es && atoi(es) == 2;                   // MSHGNN_SLAB=2: also for batches that do not fill the chip
             { int dev = 0, cus = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); p->n_cu = cus > 0 ? cus : 256; }
             if (p->use_slab && ((rc = set_lds_attr(slab_fwd_kernel(hp), flds)) || (rc = set_lds_attr(slab_bwd_kernel(hp), flds)))) { mshgnn_plan_destroy(p); return rc; }
+            const char* ew = getenv("MSHGNN_WIDE");
+            p->use_wide = hp.wide && !(ew && atoi(ew) == 0);       // default on where the plan allows it; MSHGNN_WIDE=0 selects the slab / 8-wave kernels
+            p->wide_force = ew && atoi(ew) == 2;                   // MSHGNN_WIDE=2: also for batches that do not fill the chip
+            if (p->use_wide && (rc = wide_set_attrs(p))) { mshgnn_plan_destroy(p); return rc; }
         }
     }
     *out = p;
@@ -2157,7 +2161,7 @@ int run_finalize(const mshgnn_plan* p, const mshgnn_ws_layout& lay, char* ws, fl
     FinArgs a{p->d_tables + hp.fin_off, p->d_tables + hp.tgt_off, reinterpret_cast<const float*>(ws + lay.slabs),
               reinterpret_cast<const float*>(ws + lay.dec_slabs), gparams, hp.n_lanes, hp.n_parts, loss,
               1.0f / (float)((int64_t)B * d.type_nodes[d.out_type] * (is_ce ? 1 : d.out_channels)),
-              dec_done ? (int)((B + TILE_ROWS - 1) / TILE_ROWS) : NWG_DEC};
+              dec_done ? (int)(p->wide_for(B) ? (B + WD_ROWS - 1) / WD_ROWS : (B + TILE_ROWS - 1) / TILE_ROWS) : NWG_DEC};
     int f0 = 0, nf = hp.n_fin;
     if (gw_phase == 0) nf = hp.n_fin_ph0;
     if (gw_phase == 1) { f0 = hp.n_fin_ph0; nf = hp.n_fin - hp.n_fin_ph0; a.loss = nullptr; }
@@ -2252,7 +2256,10 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
             }
             a.stamps = stamp_ptr("MSHGNN_STAMPS");
             ProfScope ps(p, hp.ks_stack_fwd, st);
-            if (p->slab_for(tiles)) {
+            if (p->wide_for(B)) {
+                for (int l = 0; l < hp.L; ++l) a.prog_off[l] = hp.wd_fwd_off[l];
+                if (int rc = wide_launch(p, a, false, st)) return rc;
+            } else if (p->slab_for(tiles)) {
                 for (int l = 0; l < hp.L; ++l) a.prog_off[l] = hp.sl_fwd_off[l];
                 hipLaunchKernelGGL(slab_fwd_kernel(hp), dim3(tiles), dim3(SL_THREADS), (hp.sl_blk + FS_EXTRA_BLK) * Prec<T>::BLK, st, a);
             } else
@@ -2321,7 +2328,10 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
             a.dbg = p->dbg;
             a.stamps = stamp_ptr("MSHGNN_STAMPS_BWD");
             ProfScope ps(p, hp.ks_stack_bwd, st);
-            if (p->slab_for(tiles)) {
+            if (p->wide_for(B)) {
+                for (int l = 0; l < hp.L; ++l) a.prog_off[l] = hp.wd_bwd_off[l];
+                if (int rc = wide_launch(p, a, true, st)) return rc;
+            } else if (p->slab_for(tiles)) {
                 for (int l = 0; l < hp.L; ++l) a.prog_off[l] = hp.sl_bwd_off[l];
                 hipLaunchKernelGGL(slab_bwd_kernel(hp), dim3(tiles), dim3(SL_THREADS), (hp.sl_blk + FS_EXTRA_BLK) * Prec<T>::BLK, st, a);
             } else

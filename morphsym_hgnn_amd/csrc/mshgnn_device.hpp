@@ -961,11 +961,14 @@ struct mshgnn_plan {
     bool use_fused = false;             // bf16 plan: fused stack kernels (MSHGNN_FUSED=0 selects the per-layer kernels)
     bool use_slab = false;              // slab variant of the stack kernels (MSHGNN_SLAB=0 selects the 8-wave ones)
     bool slab_force = false; int n_cu = 256;
+    bool use_wide = false, wide_force = false;   // wide variant (mshgnn_wide.hip: 32-window tiles, one 4-wave workgroup per CU; MSHGNN_WIDE=0 off, 2 always)
     int n_types = 0;
     mshgnn_gen_state* gen = nullptr;    // set: this plan runs on the generic-width engine (hidden != 128, many nodes, ...), hp is unused
     int dbg = 0, dbg_gw = 0;            // timing ablations (instrumented builds only: read once from MSHGNN_DBG / MSHGNN_DBG_GW at plan creation)
     // a slab workgroup has 4 waves for a whole tile: it pays off once there are enough tiles for two workgroups per CU
     bool slab_for(int tiles) const { return use_slab && (slab_force || tiles >= 2 * n_cu * 3 / 4); }
+    // a wide workgroup owns a CU: it pays off once the batch gives (nearly) every CU a 32-window tile
+    bool wide_for(int64_t B) const { return use_wide && (wide_force || (B + WD_ROWS - 1) / WD_ROWS >= n_cu * 3 / 4); }
 };
 
 // in-kernel stamp buffers of the instrumented builds (tools/stamps_*.py pass a device pointer through the environment)
@@ -1008,6 +1011,9 @@ inline int vec_bytes(const void* base, int64_t pitch_elems, int esize) {
 // k_finalize launch of a step (mshgnn.hip): fixed-order slab sums -> flat gradient (+ fused loss)
 int run_finalize(const mshgnn_plan* p, const mshgnn_ws_layout& lay, char* ws, float* gparams, int B, float* loss, bool is_ce, bool dec_done,
                  int gw_phase, hipStream_t st);
+// wide stack kernels of the bf16 plan (mshgnn_wide.hip)
+int wide_set_attrs(const mshgnn_plan* p);
+int wide_launch(const mshgnn_plan* p, const StackArgs& a, bool bwd, hipStream_t st);
 // split-bf16 parity plan (mshgnn_x3.hip)
 int x3_set_attrs(mshgnn_plan* p);
 int x3_forward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, float* out, char* ws, int64_t batch,

@@ -280,9 +280,10 @@ def test_step_is_hip_graph_capturable():
                                              ("k4", "mini_cheetah-k4", "mini_cheetah-k4", 8192), ("k4", "mini_cheetah-k4", "mini_cheetah-k4", 777),
                                              ("k4_com", "solo-k4-com", "solo-k4", 500), ("c2_com", "solo-c2-com", "solo-c2", 300)])
 def test_slab_and_eight_wave_stack_kernels_agree_bit_for_bit(kind, topo, cfg, B, monkeypatch):
-    """The slab stack kernels (two 4-wave workgroups per CU, destination nodes in two groups) accumulate every node in the same
-    order as the 8-wave stack kernels: outputs and every gradient but the decoder's (whose per-tile partials are summed over 4
-    instead of 8 waves) are identical bits, for full-size and ragged batches."""
+    """The slab stack kernels (two 4-wave workgroups per CU, destination nodes in two groups) and the wide ones (one 4-wave workgroup per CU,
+    32-window tiles, every node's accumulators in registers) accumulate every node in the same order as the 8-wave stack kernels: outputs and
+    every gradient but the decoder's (whose per-tile partials are summed over fewer per-wave partials) are identical bits, for full-size and
+    ragged batches."""
     _require_gpu()
     from morphsym_hgnn_amd import engine as eng, synth
     spec = helpers.make_spec(kind, topo, cfg, 128, 3, grf=3 if kind == "c2" else 1)
@@ -290,25 +291,31 @@ def test_slab_and_eight_wave_stack_kernels_agree_bit_for_bit(kind, topo, cfg, B,
     x_dict, y = synth.make_windows(5, B, spec.num_nodes, spec.widths, n_y)
     params = synth.make_params(5, spec.param_shapes())
     res = {}
-    for mode in ("2", "0"):
-        monkeypatch.setenv("MSHGNN_SLAB", mode)       # read when the plan is created
+    for mode, (wide, slab) in {"wide": ("2", "2"), "slab": ("0", "2"), "8wave": ("0", "0")}.items():
+        monkeypatch.setenv("MSHGNN_WIDE", wide)       # read when the plan is created
+        monkeypatch.setenv("MSHGNN_SLAB", slab)
         e = eng.Engine(spec, "bf16")
-        if not (e.info.kernel_sets & 2):
-            pytest.skip("this topology has no slab plan")
+        if mode == "slab" and not (e.info.kernel_sets & 2):
+            continue
+        assert mode != "wide" or (e.info.kernel_sets & 8), "every fused topology has a wide plan"
         xs = e.cast_inputs(x_dict)
         yd = y.reshape(-1).to(e.device, torch.float32)
         flat = eng.flatten_params(spec, params, e.device)
         out, loss, g = e.step_mse(xs, flat, yd, B)
         torch.cuda.synchronize()
         res[mode] = (out.clone(), loss.clone(), g.clone())
-    assert torch.equal(res["2"][0], res["0"][0])
-    ga, gb = eng.unflatten(spec, res["2"][2]), eng.unflatten(spec, res["0"][2])
-    for k in ga:
-        if k.startswith("decoder"):     # summed over 4 instead of 8 per-wave partials per tile: fp32 summation order
-            assert float((ga[k] - gb[k]).abs().max()) <= 2e-6 * float(gb[k].abs().max()), k
-        else:
-            assert torch.equal(ga[k], gb[k]), k
-    assert abs(float(res["2"][1]) - float(res["0"][1])) <= 1e-6 * abs(float(res["0"][1]))
+    ref = res["8wave"]
+    for mode in res:
+        if mode == "8wave":
+            continue
+        assert torch.equal(res[mode][0], ref[0]), mode
+        ga, gb = eng.unflatten(spec, res[mode][2]), eng.unflatten(spec, ref[2])
+        for k in ga:
+            if k.startswith("decoder"):     # summed over 4 instead of 8 per-wave partials per tile: fp32 summation order
+                assert float((ga[k] - gb[k]).abs().max()) <= 2e-6 * float(gb[k].abs().max()), (mode, k)
+            else:
+                assert torch.equal(ga[k], gb[k]), (mode, k)
+        assert abs(float(res[mode][1]) - float(ref[1])) <= 1e-6 * abs(float(ref[1])), mode
 
 
 def test_full_size_batch_properties_bf16():
