@@ -2075,8 +2075,10 @@ extern "C" int mshgnn_plan_create(const mshgnn_desc* desc, mshgnn_plan** out) {
             { int dev = 0, cus = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); p->n_cu = cus > 0 ? cus : 256; }
             if (p->use_slab && ((rc = set_lds_attr(slab_fwd_kernel(hp), flds)) || (rc = set_lds_attr(slab_bwd_kernel(hp), flds)))) { mshgnn_plan_destroy(p); return rc; }
             const char* ew = getenv("MSHGNN_WIDE");
-            p->use_wide = hp.wide && !(ew && atoi(ew) == 0);       // default on where the plan allows it; MSHGNN_WIDE=0 selects the slab / 8-wave kernels
-            p->wide_force = ew && atoi(ew) == 2;                   // MSHGNN_WIDE=2: also for batches that do not fill the chip
+            // wide variant (mshgnn_wide.hip): opt-in.  Measured on A1-C2, 8192 windows: 81 us against the slab kernel's 65 (inference: 67 / 54) -- with 32 windows
+            // per CU one wave per SIMD exposes every memory and instruction-fetch latency of a kernel whose code runs once.
+            p->use_wide = hp.wide && ew && atoi(ew) >= 1;           // MSHGNN_WIDE=1: where the batch gives 3/4 of the CUs a tile
+            p->wide_force = ew && atoi(ew) == 2;                   // MSHGNN_WIDE=2: for every batch
             if (p->use_wide && (rc = wide_set_attrs(p))) { mshgnn_plan_destroy(p); return rc; }
         }
     }

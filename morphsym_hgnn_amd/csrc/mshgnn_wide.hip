@@ -38,8 +38,8 @@ template <int S, int H, int E> __device__ __forceinline__ float wd_acc_get1(WReg
     float x;
     constexpr int K = S / 2, IDX = S < 16 ? 16 * S + 8 * H + E : 192 + 16 * (S - 16) + 8 * H + E;
 #define WD_X(KK, REG) if constexpr (K == KK) { \
-        if constexpr (S < 16) asm volatile("v_accvgpr_read_b32 %0, a[%c2]" : "=v"(x), "+{" REG "}"(wd_tuple<KK>(r)) : "i"(IDX)); \
-        else asm volatile("v_mov_b32 %0, v[%c2]" : "=v"(x), "+{" REG "}"(wd_tuple<KK>(r)) : "i"(IDX)); }
+        if constexpr (S < 16) asm("v_accvgpr_read_b32 %0, a[%c2]" : "=v"(x) : "{" REG "}"(wd_tuple<KK>(r)), "i"(IDX)); \
+        else asm("v_mov_b32 %0, v[%c2]" : "=v"(x) : "{" REG "}"(wd_tuple<KK>(r)), "i"(IDX)); }
     WD_TUPLES(WD_X)
 #undef WD_X
     return x;
@@ -47,8 +47,8 @@ template <int S, int H, int E> __device__ __forceinline__ float wd_acc_get1(WReg
 template <int S, int H, int E> __device__ __forceinline__ void wd_acc_set1(WRegs& r, float x) {
     constexpr int K = S / 2, IDX = S < 16 ? 16 * S + 8 * H + E : 192 + 16 * (S - 16) + 8 * H + E;
 #define WD_X(KK, REG) if constexpr (K == KK) { \
-        if constexpr (S < 16) asm volatile("v_accvgpr_write_b32 a[%c1], %2" : "+{" REG "}"(wd_tuple<KK>(r)) : "i"(IDX), "v"(x)); \
-        else asm volatile("v_mov_b32 v[%c1], %2" : "+{" REG "}"(wd_tuple<KK>(r)) : "i"(IDX), "v"(x)); }
+        if constexpr (S < 16) asm("v_accvgpr_write_b32 a[%c1], %2" : "+{" REG "}"(wd_tuple<KK>(r)) : "i"(IDX), "v"(x)); \
+        else asm("v_mov_b32 v[%c1], %2" : "+{" REG "}"(wd_tuple<KK>(r)) : "i"(IDX), "v"(x)); }
     WD_TUPLES(WD_X)
 #undef WD_X
 }
@@ -309,17 +309,39 @@ template <int NS, int NM, int DMAX> WD_KERNEL void k_wide_fwd(StackArgs a) {
         }
         const int nmlp = fh[FH_NMLP];
         const bool residual = (fh[FH_FLAGS] & FF_RESIDUAL) != 0;
-        // accumulators start at the bias row of their node's type
-        wd_for<0, NS>([&](auto uc) {
-            constexpr int U = decltype(uc)::value;
-            f32x4 b0 = f32x4{0.f, 0.f, 0.f, 0.f}, b1 = b0;
-            if (U < NN && fh[FH_KIND + U] != NK_DEAD) {
-                const float* bias = a.bias + (size_t)fh[FH_BIAS + U] * H + wn * 32;
-                b0 = *reinterpret_cast<const f32x4*>(bias + c_feat(0, lane)); b1 = *reinterpret_cast<const f32x4*>(bias + c_feat(1, lane));
+        // accumulators start at the bias row of their node's type; the rows of six nodes are requested before the first of their accumulators is
+        // written (three memory round trips per layer instead of one per node; row 0 stands in for dead nodes, whose accumulators start at zero)
+        wd_for<0, (NS + 5) / 6>([&](auto gc) {
+            constexpr int G = decltype(gc)::value;
+            f32x4 bv[6][2];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int u = 6 * G + i;
+                const bool live = u < NN && u < NS && fh[FH_KIND + (u < NS ? u : 0)] != NK_DEAD;
+                const float* bias = a.bias + (size_t)(live ? fh[FH_BIAS + (u < NS ? u : 0)] : 0) * H + wn * 32;
+                bv[i][0] = *reinterpret_cast<const f32x4*>(bias + c_feat(0, lane)); bv[i][1] = *reinterpret_cast<const f32x4*>(bias + c_feat(1, lane));
             }
-            wd_acc_set<U, 0>(R, b0, b1); wd_acc_set<U, 1>(R, b0, b1);
+            wd_for<0, 6>([&](auto ic) {
+                constexpr int I = decltype(ic)::value, U = 6 * G + I;
+                if constexpr (U < NS) {
+                    const bool live = U < NN && fh[FH_KIND + U] != NK_DEAD;
+                    const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f}, b0 = live ? bv[I][0] : z, b1 = live ? bv[I][1] : z;
+                    wd_acc_set<U, 0>(R, b0, b1); wd_acc_set<U, 1>(R, b0, b1);
+                }
+            });
         });
+#ifdef MSHGNN_ABLATE
+        {   // timing experiment (wrong results): the layer's MAC phase executed `reps` times from the SAME code (instruction cache warm after the first)
+            const int reps = 1 + ((a.dbg >> 12) & 3);
+            for (int rep = 0; rep < reps; ++rep) {
+                if (l == 0) FS_STAMP(24 + rep);
+                wd_run<NS>(R, wp, smem, wpack, wn, lane, ao);
+                if (l == 0) FS_STAMP(20 + rep);
+            }
+        }
+#else
         wd_run<NS>(R, wp, smem, wpack, wn, lane, ao);
+#endif
         FS_STAMP(2 + 4 * l);
         __syncthreads();   // every wave is done reading X_l: the node blocks may be overwritten
         FS_STAMP(3 + 4 * l);
@@ -355,29 +377,40 @@ template <int NS, int NM, int DMAX> WD_KERNEL void k_wide_fwd(StackArgs a) {
                 }
             });
         }
-        // X_{l+1}[n] = relu(H[n]) (+ X_l[n]) for the relu nodes, in place; stash + relu bytes on the side
-        wd_for<0, NS>([&](auto uc) {
-            constexpr int U = decltype(uc)::value;
-            if (U < NN && fh[FH_KIND + U] == NK_RELU) {
-                u32x4 r[2] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}};
-                if (residual) {
-                    r[0] = *reinterpret_cast<const u32x4*>(smem + U * WD_BLK + loff);
-                    r[1] = *reinterpret_cast<const u32x4*>(smem + U * WD_BLK + P::BLK + loff);
-                }
-                P::Acc c[2]; wd_acc_get<U, 0>(R, c[0]); wd_acc_get<U, 1>(R, c[1]);
+        // X_{l+1}[n] = relu(H[n]) (+ X_l[n]) for the relu nodes, in place; stash + relu bytes on the side.  Six nodes at a time: their residual octets
+        // are read before the first write of the group (the compiler cannot move an LDS read above an LDS write that may alias it)
+        wd_for<0, (NS + 5) / 6>([&](auto gc) {
+            constexpr int G = decltype(gc)::value;
+            u32x4 rres[6][2];
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const unsigned bits = relu_with_bits<T>(c[h]);
-                    f32x4 r0, r1; unpack_oct(r[h], r0, r1);
-                    const u32x4 pk = pack_oct(c[h].c[0] + r0, c[h].c[1] + r1);
-                    *reinterpret_cast<u32x4*>(smem + U * WD_BLK + h * P::BLK + loff) = pk;
-                    if (train) {
-                        const int w = w0 + 16 * h + win;
-                        if (w0 + 16 * h < B) maskbytes[relu_tile_base(U, B, 2 * blockIdx.x + h, wn) + lane] = (uint8_t)bits;
-                        if (w < B) *reinterpret_cast<u32x4*>(xo + act_idx(w, U, B) + col) = pk;
-                    }
+            for (int i = 0; i < 6; ++i) {
+                const int u = 6 * G + i;
+                rres[i][0] = rres[i][1] = u32x4{0, 0, 0, 0};
+                if (u < NN && u < NS && residual && fh[FH_KIND + (u < NS ? u : 0)] == NK_RELU) {
+                    rres[i][0] = *reinterpret_cast<const u32x4*>(smem + u * WD_BLK + loff);
+                    rres[i][1] = *reinterpret_cast<const u32x4*>(smem + u * WD_BLK + P::BLK + loff);
                 }
             }
+            wd_for<0, 6>([&](auto ic) {
+                constexpr int I = decltype(ic)::value, U = 6 * G + I;
+                if constexpr (U < NS) {
+                    if (U < NN && fh[FH_KIND + U] == NK_RELU) {
+                        P::Acc c[2]; wd_acc_get<U, 0>(R, c[0]); wd_acc_get<U, 1>(R, c[1]);
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const unsigned bits = relu_with_bits<T>(c[h]);
+                            f32x4 r0, r1; unpack_oct(rres[I][h], r0, r1);
+                            const u32x4 pk = pack_oct(c[h].c[0] + r0, c[h].c[1] + r1);
+                            *reinterpret_cast<u32x4*>(smem + U * WD_BLK + h * P::BLK + loff) = pk;
+                            if (train) {
+                                const int w = w0 + 16 * h + win;
+                                if (w0 + 16 * h < B) maskbytes[relu_tile_base(U, B, 2 * blockIdx.x + h, wn) + lane] = (uint8_t)bits;
+                                if (w < B) *reinterpret_cast<u32x4*>(xo + act_idx(w, U, B) + col) = pk;
+                            }
+                        }
+                    }
+                }
+            });
         });
         FS_STAMP(4 + 4 * l);
         if (nmlp > 0) {

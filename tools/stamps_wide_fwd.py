@@ -27,5 +27,5 @@ for k in order:
     print(f"  {names[k]:28s} +{d:9.0f} cycles (median)   since start {np.median(s[:, k] - s[:, 0]):9.0f}")
     prev = k
 for k in (20, 21, 22, 23):
-    if s[:, k].max() > 0: print(f"  L0 MAC rep {k - 20} end: since tile staged {np.median(s[:, k] - s[:, 1]):9.0f}")
+    if s[:, k].max() > 0: print(f"  L0 engine rep {k - 20}: {np.median(s[:, k] - s[:, k + 4]):9.0f} cycles   (start since tile staged {np.median(s[:, k + 4] - s[:, 1]):9.0f})")
 print("start spread (cycles):", int(s[:, 0].max() - s[:, 0].min()), " span:", int(s[:, 30].max() - s[:, 0].min()))
