@@ -26,7 +26,11 @@
  * Data layout ("dense window-major"): every window graph of a minibatch has the same tiny topology, so the
  * PyG-batched [B*n_type, F] tensors the reference passes are already [B, n_type, F] contiguous; they are
  * consumed as-is.  dtype selects storage/operand precision of inputs and activations:
- *   MSHGNN_F32  : fp32 storage, exact-fp32 MFMA (v_mfma_f32_16x16x4_f32)           -- parity mode (1e-4 rel)
+ *   MSHGNN_F32  : fp32 storage, exact-fp32 MFMA (v_mfma_f32_16x16x4_f32)           -- parity mode (1e-4 rel).  ONLY on the LDS-resident
+ *                 kernels: a plan that falls to the generic-width engine (mshgnn_info.kernel_sets & 4: hidden != 128, > 20 nodes, mean
+ *                 aggregation with in-degree > 1) has no fp32-MFMA variant and serves an MSHGNN_F32 request with the split-bf16 arithmetic of
+ *                 MSHGNN_BF16X3 (inputs stay fp32; products x_hi w_hi + x_lo w_hi + x_hi w_lo with fp32 accumulation: measured <= 1.4e-5 of the
+ *                 fp64 reference, tolerance 1e-4) -- NOT a bit-exact fp32 fma chain.
  *   MSHGNN_BF16 : bf16 storage + bf16 MFMA operands, fp32 accumulate, fp32 weights  -- throughput mode
  *   MSHGNN_BF16X3: fp32 inputs, hi/lo bf16 planes, three bf16 MFMA products per term -- parity mode at bf16-MFMA speed
  * Parameters and parameter gradients are always one flat fp32 buffer (offsets given in the descriptor).
@@ -149,6 +153,11 @@ const char* mshgnn_version(void);
 int mshgnn_plan_create(const mshgnn_desc* desc, mshgnn_plan** plan_out);
 void mshgnn_plan_destroy(mshgnn_plan* plan);
 int mshgnn_plan_info(const mshgnn_plan* plan, mshgnn_info* info);
+/* The plan compiler alone, on the host: no HIP device is touched, nothing is allocated.  Fills `info` (work counts, LDS bytes, kernel sets: what
+ * mshgnn_plan_info would report for a plan of this descriptor) and the number of 32-bit table entries the plan would upload; returns the same error
+ * codes / mshgnn_last_error() text as mshgnn_plan_create for a descriptor no engine takes.  Used by the CPU test-suite and by callers that size a
+ * deployment before a GPU is attached (replaces nothing in the reference: its models have no compile step, hgnn_c2.py:10-131).  */
+int mshgnn_plan_compile_host(const mshgnn_desc* desc, mshgnn_info* info, int32_t* n_tables_out);
 
 /* Profiling: while enabled, forward/backward bracket every kernel with HIP events on the stream (not
  * graph-capturable, not thread-safe).  mshgnn_profile_read synchronises the recorded events, fills up to

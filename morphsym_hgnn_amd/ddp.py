@@ -49,14 +49,20 @@ def flat_data_parallel(module, group=None):
     (`training_step` -> `models.fused_training_step[_windows]`) sum-all-reduces its flat gradient in `loss.backward()` and divides by the
     world size -- the mean over ranks DDP / Lightning-DDP produce (gnnLightning.py:1396-1400), as ONE exchange of 4 MB instead of ~50
     per-parameter buckets and autograd hooks.  Every rank feeds its own shard of the global batch (equal shard sizes give the global
-    mean loss's gradient).  The model must have seen its lazy-initialising forward and live on the device; do not also wrap it in DDP.
-    Returns `module`."""
+    mean loss's gradient).  The two-call route (`forward` + `loss.backward()`: `fused_training_step = False`, a frozen parameter, a
+    normalising WindowBatch) makes the same single exchange in the engine's backward.  Only the fused engine has that hook: a model that runs
+    operator by operator (an activation other than ReLU, a hidden width that is not a multiple of 128) is rejected here -- wrap that one in
+    torch's DistributedDataParallel.  The model must have seen its lazy-initialising forward and live on the device; do not also wrap it
+    in DDP.  Returns `module`."""
     import torch.distributed as dist
     model = getattr(module, "model", module)
     if not (dist.is_available() and dist.is_initialized()):
         raise RuntimeError("flat_data_parallel needs an initialised torch.distributed process group")
     if getattr(model, "_spec", None) is None:
         raise RuntimeError("flat_data_parallel: run the lazy-initialising forward first (the wrappers' constructors do)")
+    if not getattr(model, "_fused_activation", True):
+        raise RuntimeError("flat_data_parallel: this model runs operator by operator (activation other than ReLU, or a hidden width that is not a "
+                           "multiple of 128): its gradients never pass the engine's flat buffer -- wrap it in torch.nn.parallel.DistributedDataParallel")
     p0 = model._params_in_flat_order()[0]
     if p0.device.type != "cuda":
         raise RuntimeError("flat_data_parallel: move the model to its GPU first")

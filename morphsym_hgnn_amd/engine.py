@@ -323,7 +323,8 @@ class Engine:
             while len(self._ws) >= self.MAX_WORKSPACES:
                 old_key = next(iter(self._ws))
                 del self._ws[old_key]
-                self._tickets[old_key[0]] = self._tickets.get(old_key[0], 0) + 1
+                if old_key[1] == 1:      # only a TRAINING workspace holds a stash some pending backward may still need
+                    self._tickets[old_key[0]] = self._tickets.get(old_key[0], 0) + 1
         self._ws[key] = ws           # (re-inserted last: dict order = recency)
         return ws
 

@@ -68,10 +68,12 @@ class _EngineFnP(torch.autograd.Function):
     per-parameter cast or copy kernels (the parameters are autograd inputs only so that their .grad gets populated)."""
 
     @staticmethod
-    def forward(ctx, engine, B, flat, offsets, n_x, *args):
+    def forward(ctx, engine, B, flat, offsets, ddp, n_x, *args):
+        """ddp: None, or the process group (True: the default one) of ddp.flat_data_parallel -- the flat gradient is then all-reduced here, since
+        no DistributedDataParallel wrapper hooks the parameters on that route."""
         xs = args[:n_x]
         out = engine.forward(xs, flat, B, training=True)
-        ctx.engine, ctx.B, ctx.xs, ctx.flat, ctx.offsets, ctx.n_x = engine, B, xs, flat, offsets, n_x
+        ctx.engine, ctx.B, ctx.xs, ctx.flat, ctx.offsets, ctx.n_x, ctx.ddp = engine, B, xs, flat, offsets, n_x, ddp
         ctx.shapes = [p.shape for p in args[n_x:]]
         ctx.ticket = engine.stash_ticket(B)
         return out
@@ -83,8 +85,13 @@ class _EngineFnP(torch.autograd.Function):
             raise RuntimeError("the activation stash of this forward was overwritten by a later forward of the same "
                                "batch size on the same engine; call backward before the next forward")
         gflat = e.backward(ctx.xs, ctx.flat, gout.contiguous().to(torch.float32), ctx.B)      # a fresh buffer per backward: .grad views never alias
+        if ctx.ddp is not None:      # ddp.flat_data_parallel on the two-call route: the same single exchange the fused training step makes
+            import torch.distributed as dist
+            group = None if ctx.ddp is True else ctx.ddp
+            dist.all_reduce(gflat, op=dist.ReduceOp.SUM, group=group)
+            gflat.div_(dist.get_world_size(group))
         grads = [gflat[o:o + n].view(shape) for (o, n), shape in zip(ctx.offsets, ctx.shapes)]
-        return (None, None, None, None, None, *([None] * ctx.n_x), *grads)
+        return (None, None, None, None, None, None, *([None] * ctx.n_x), *grads)
 
 
 class _EngineFnFast(torch.autograd.Function):
@@ -115,25 +122,39 @@ class _EngineFnFast(torch.autograd.Function):
 
 def _deliver_gradients(m, flat, fresh, scale=None):
     """Hand a freshly computed flat gradient to the parameters' .grad (views of the persistent m._gflat): assigned when the gradients were
-    cleared (zero_grad(set_to_none=True), the first step), ADDED in place otherwise -- what autograd's accumulation would have produced.
+    cleared (zero_grad(set_to_none=True), the first step), ADDED otherwise -- what autograd's accumulation would have produced.  Decided per
+    TRAINABLE parameter: a frozen parameter's .grad stays None and says nothing; a .grad that is not this buffer's view (left over from
+    before a .to() re-created the flat buffers, or assigned by another route) is accumulated into in place, like autograd would.
     fresh: callable(target | None) -> the flat gradient, written into `target` when given."""
     params = m._param_list
     if m._gflat is None or m._gflat.device != flat.device:
         m._gflat = torch.zeros_like(flat)
         m._gviews = [m._gflat[o:o + n].view(p.shape) for (o, n), p in zip(m._spec.param_offsets().values(), params)]
-    if all(p.grad is None for p in params[:2]):
+    trainable = [(p, v) for p, v in zip(params, m._gviews) if p.requires_grad]
+    if all(p.grad is None for p, _ in trainable):      # every gradient was cleared: the buffer is free to be overwritten
         fresh(m._gflat)
         if scale is not None:
             m._gflat.mul_(scale)
-        for p, v in zip(params, m._gviews):
-            if p.requires_grad:
-                p.grad = v
-    else:
-        g = fresh(None)
-        m._gflat.add_(g if scale is None else g * scale)
-        for p, v in zip(params, m._gviews):      # (a parameter whose .grad was cleared individually)
-            if p.requires_grad and p.grad is None:
-                p.grad = v
+        for p, v in trainable:
+            p.grad = v
+        return
+    g = fresh(None)
+    if scale is not None:
+        g = g * scale
+    if all(p.grad is v for p, v in trainable):         # accumulation into the views of this buffer: one flat add
+        m._gflat.add_(g)
+        return
+    for (p, v), (o, n) in zip(zip(params, m._gviews), m._spec.param_offsets().values()):
+        if not p.requires_grad:
+            continue
+        gp = g[o:o + n].view(p.shape)
+        if p.grad is None:           # cleared individually: takes the view, holding exactly this step's gradient
+            v.copy_(gp)
+            p.grad = v
+        elif p.grad is v:
+            v.add_(gp)
+        else:                        # a foreign gradient tensor (stale view of an earlier buffer, a user-assigned tensor): accumulate in place
+            p.grad.add_(gp.to(p.grad.dtype))
 
 
 class _FusedStepFn(torch.autograd.Function):
@@ -451,7 +472,7 @@ class _MSHGNNBase(nn.Module):
             if need_grad:
                 import torch.distributed as dist
                 if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-                    out = _EngineFnP.apply(e, B, flat, offsets, len(xs), *xs, *params)      # gradients through autograd: DDP's hooks see them
+                    out = _EngineFnP.apply(e, B, flat, offsets, self._flat_ddp, len(xs), *xs, *params)      # gradients through autograd: DDP's hooks see them
                 else:
                     out = _EngineFnFast.apply(self._anchor, self, e, B, *xs)
             else:

@@ -16,6 +16,8 @@ import ctypes as C
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import os
+
 import numpy as np
 import torch
 
@@ -247,7 +249,10 @@ class WindowBatch:
     def __init__(self, store: SequenceStore, starts, edge_index_dict):
         st = starts if isinstance(starts, torch.Tensor) else torch.as_tensor(np.asarray(starts), dtype=torch.int64)
         st = st.flatten().to(torch.int64)
-        if not st.is_cuda:
+        # Contract: every start index i satisfies 0 <= i and i + history <= store.n_rows (the fused-gather kernels read the series at
+        # [i, i + history) without a bound check).  Host indices are checked here; DEVICE indices are taken as they are, because checking them costs a
+        # host synchronisation per batch -- MSHGNN_CHECK_STARTS=1 turns that check on (debugging a sampler).
+        if not st.is_cuda or os.environ.get("MSHGNN_CHECK_STARTS") == "1":
             if st.numel() < 1 or int(st.min()) < 0 or int(st.max()) + store.recipe.history > store.n_rows:
                 raise IndexError("window index out of range")
             st = st.to(store.device)

@@ -120,6 +120,16 @@ def _wrapper_worker(rank, world, port, B, ret):
     w.model.zero_grad()
     loss.backward()
     g = w.model._gflat.clone()
+    # the two-call route (forward + loss.backward()) under flat_data_parallel makes the same exchange in the engine's backward
+    w.fused_training_step = False
+    w.model.zero_grad()
+    l2 = w.training_step(mine, 0)
+    assert w.model._gpend_id == 1                                      # (no second one-call step)
+    l2.backward()
+    g2 = torch.zeros_like(g)
+    for (o, n), q in zip(spec.param_offsets().values(), w.model._params_in_flat_order()):
+        g2[o:o + n] = q.grad.flatten()
+    ret[f"two_call_{rank}"] = float((g2 - g).abs().max() / g.abs().max())
     if rank == 0:
         ref = wrappers.HGNN_C2_Lightning_Reg(128, 2, spec.topology.metadata(), mine, symmetry_mode="MorphSym", group_operator_path=cfg).to(dev)
         ref.model.load_state_dict(synth.make_params(41, spec.param_shapes()))
@@ -145,3 +155,4 @@ def test_flat_data_parallel_wrappers_reproduce_the_global_batch_gradient():
     port = 33000 + (os.getpid() % 2000)
     mp.spawn(_wrapper_worker, args=(world, port, B, ret), nprocs=world, join=True)
     assert ret["params_equal"] and ret["err"] < 1e-5
+    assert ret["two_call_0"] < 1e-5 and ret["two_call_1"] < 1e-5

@@ -165,6 +165,54 @@ def test_device_parameters_are_views_of_the_flat_buffer_and_behave_like_ordinary
 
 
 @pytest.mark.gpu
+def test_gradient_accumulation_with_frozen_parameters_and_after_to():
+    """Gradient delivery decides per TRAINABLE parameter (the first parameters in flat order may be frozen: their .grad is always None), and a
+    .grad tensor that is not a view of the current flat gradient buffer (left over from before .to() re-created the buffers, gradients zeroed
+    in place) is accumulated into instead of being dropped."""
+    assert torch.cuda.is_available()
+    torch.set_default_dtype(torch.float64)
+    case, spec, fx, x_dict, y, params, ei = helpers.load_case("a1c2_h128_L3_d3_B3")
+    xd = {k: v.cuda() for k, v in x_dict.items()}
+    eid = {k: v.cuda() for k, v in ei.items()}
+
+    def loss_of(model):
+        out = model(x_dict=dict(xd), edge_index_dict=eid)
+        return ((out.flatten() - y.cuda().flatten()) ** 2).mean()
+
+    def fresh():
+        m = _build(case, spec).cuda()
+        with torch.no_grad():
+            m(x_dict=dict(xd), edge_index_dict=eid)
+        m.load_state_dict(params)
+        return m
+    ref = fresh()
+    loss_of(ref).backward()
+    g1 = {k: p.grad.clone() for k, p in ref.named_parameters() if p.grad is not None}
+    # (a) frozen encoder, two accumulation steps
+    m = fresh()
+    for k, p in m.named_parameters():
+        if k.startswith("encoder"):
+            p.requires_grad_(False)
+    loss_of(m).backward()
+    loss_of(m).backward()
+    for k, p in m.named_parameters():
+        if k.startswith("encoder"):
+            assert p.grad is None, k
+        elif k in g1:
+            assert torch.allclose(p.grad, 2 * g1[k], rtol=1e-6, atol=0), k
+    # (b) .to() between two steps with the gradients zeroed in place: the old .grad tensors survive and must receive the new gradient
+    m = fresh()
+    loss_of(m).backward()
+    m.zero_grad(set_to_none=False)
+    held = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    m.double()                                     # replaces the parameter tensors (and keeps their .grad), the next forward rebuilds the flat buffers
+    loss_of(m).backward()
+    for k, p in m.named_parameters():
+        if k in g1:
+            assert p.grad is not None and torch.allclose(p.grad.float(), g1[k], rtol=1e-5, atol=0), k
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["a1c2_h128_L3_d3_B3", "mck4_cls_h128_L2_B3", "mi_h128_L2_d3_B2", "solok4com_h128_L3_B5", "solos4com_h128_L2_B3"])
 def test_non_relu_activation_runs_operator_by_operator(name):
     """activation_fn other than nn.ReLU() (the reference's constructors take any module): the same forward on the stand-alone HIP operators;
