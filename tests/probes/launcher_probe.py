@@ -8,6 +8,12 @@ import torch
 import torch.distributed as dist
 
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+if len(sys.argv) > 1 and sys.argv[1] == "--crash-early":      # rank 1 dies before it joins the group: rank 0 would wait in the rendezvous for minutes
+    if rank == 1:
+        sys.stderr.write("probe rank 1: crashing before the rendezvous\n")
+        sys.exit(7)
+    import time
+    time.sleep(600)
 assert int(os.environ["LOCAL_RANK"]) == rank and os.environ["MASTER_ADDR"] == "127.0.0.1"
 dist.init_process_group("gloo", rank=rank, world_size=world)
 t = torch.tensor([float(rank + 1)])

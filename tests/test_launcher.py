@@ -20,6 +20,16 @@ def test_spawn_ranks_reports_a_failing_rank(capfd):
     assert bench.spawn_ranks(2, ["--fail"], script=PROBE) == 3
 
 
+def test_spawn_ranks_terminates_the_survivors_when_a_rank_dies(capfd):
+    """A rank that dies early must not leave its peers hanging in a collective / rendezvous: the launcher watches every child, terminates the rest
+    and returns the failing rank's exit code -- promptly."""
+    import time
+    t0 = time.monotonic()
+    assert bench.spawn_ranks(2, ["--crash-early"], script=PROBE) == 7
+    assert time.monotonic() - t0 < 60.0
+    assert "crashing before the rendezvous" in capfd.readouterr().err      # every rank's stderr is kept
+
+
 def test_gpus_gt_1_without_rank_env_goes_through_the_launcher(monkeypatch):
     calls = {}
     monkeypatch.setattr(bench, "spawn_ranks", lambda n, argv, **kw: calls.setdefault("n", n) and 0)
