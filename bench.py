@@ -552,6 +552,8 @@ def side_config(config, device, steps, warmup, min_time=0.25):
         entry["kernel_us"] = {s["name"]: round(s["total_ms"] / s["launches"] * 1e3, 2) for s in stats}
         r = roofline_of(stats, st, B, plan, w.e, config, L, hidden)
         entry["dominant"] = {k: r[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_us", "share_of_step")}
+        if "operands" in r:      # (HBM-bound kernel: `frac` prices the raw-input bytes only -- SURVEY 8(d); its own operand stream is reported beside it)
+            entry["dominant"]["operands_frac"] = r["operands"]["frac"]
         fl = (w.e.info.flops_fwd + w.e.info.flops_bwd) * B
         entry["step_mfma_frac"] = fl / (med / st) / 1e12 / PEAK["mfma_TFLOPs"][plan]
         res["bf16" if plan == "bf16" else "parity_plan"] = entry

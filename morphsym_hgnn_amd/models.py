@@ -244,8 +244,12 @@ class _MSHGNNBase(nn.Module):
             if p.grad is not None:
                 if set_to_none:
                     p.grad = None
-                else:
-                    p.grad.detach_().zero_()
+                else:      # (torch.optim's zero_grad: .grad tensors here are views of the flat gradient buffer, which detach_() refuses)
+                    if p.grad.grad_fn is not None:
+                        p.grad.detach_()
+                    else:
+                        p.grad.requires_grad_(False)
+                    p.grad.zero_()
 
     def _apply(self, fn, *args, **kwargs):
         # .to() / .cuda() / .double() / .float() replace the parameter tensors: the flat-buffer views are re-established by the next forward
