@@ -318,6 +318,45 @@ def test_slab_and_eight_wave_stack_kernels_agree_bit_for_bit(kind, topo, cfg, B,
         assert abs(float(res[mode][1]) - float(ref[1])) <= 1e-6 * abs(float(ref[1])), mode
 
 
+@pytest.mark.parametrize("kind,topo,cfg,layers,B", [("c2", "a1-c2", "a1-c2", 8, 300), ("k4", "mini_cheetah-k4", "mini_cheetah-k4", 8, 130)])
+def test_wide_stack_kernels_on_every_entry_point(kind, topo, cfg, layers, B, monkeypatch):
+    """The wide stack kernels (opt-in, MSHGNN_WIDE=2) behind every entry point that launches a stack kernel -- inference forward (no stashes), the
+    two-call route (mshgnn_forward + mshgnn_backward_mse: the decoder backward is its own launch) and, for the classification model, the one-call
+    cross-entropy step -- at the paper's depth (L = 8): identical bits to the 8-wave kernels (decoder gradients: summation order)."""
+    _require_gpu()
+    from morphsym_hgnn_amd import engine as eng, synth
+    reg = kind == "c2"
+    spec = helpers.make_spec(kind, topo, cfg, 128, layers, grf=3 if reg else 1, regression=reg)
+    n_y = spec.out_channels * spec.num_nodes[spec.out_type] if reg else spec.num_nodes[spec.out_type]
+    x_dict, y = synth.make_windows(11, B, spec.num_nodes, spec.widths, n_y, classification=not reg)
+    params = synth.make_params(11, spec.param_shapes())
+    res = {}
+    for mode, (wide, slab) in {"wide": ("2", "2"), "8wave": ("0", "0")}.items():
+        monkeypatch.setenv("MSHGNN_WIDE", wide)
+        monkeypatch.setenv("MSHGNN_SLAB", slab)
+        e = eng.Engine(spec, "bf16")
+        xs = e.cast_inputs(x_dict)
+        flat = eng.flatten_params(spec, params, e.device)
+        inf = e.forward(xs, flat, B, training=False).clone()
+        if reg:
+            yd = y.reshape(-1).to(e.device, torch.float32)
+            out = e.forward(xs, flat, B, training=True).clone()
+            g = e.backward_mse(xs, flat, out, yd, B)[1].clone()
+        else:
+            lab = y.reshape(B, -1).to(e.device, torch.int32)
+            out, loss, g = e.step_ce(xs, flat, lab, B)
+            out, g = out.clone(), g.clone()
+        torch.cuda.synchronize()
+        res[mode] = (inf, out, g)
+    assert torch.equal(res["wide"][0], res["8wave"][0]) and torch.equal(res["wide"][1], res["8wave"][1])
+    ga, gb = eng.unflatten(spec, res["wide"][2]), eng.unflatten(spec, res["8wave"][2])
+    for k in ga:
+        if k.startswith("decoder"):
+            assert float((ga[k] - gb[k]).abs().max()) <= 2e-6 * float(gb[k].abs().max()), k
+        else:
+            assert torch.equal(ga[k], gb[k]), k
+
+
 def test_full_size_batch_properties_bf16():
     """The same size-independent properties on the throughput plan (bf16, B=8192: slab stack kernels; the two halves of the
     batch run on the 8-wave stack kernels): every window's output is independent of its batch -- identical bits -- and the
