@@ -12,7 +12,6 @@ template <int X, int N> __device__ __forceinline__ void filler(u32x4& d0, u32x4&
     for (int n = 0; n < N; ++n) {
         if constexpr (X == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(n & 1 ? d1 : d0) : "v"(ad));
         if constexpr (X == 1) asm volatile("v_add_u32 %0, %0, %1" : "+v"(vv) : "v"(ad));
-        if constexpr (X == 2) asm volatile("s_add_u32 %0, %0, 1" : "+s"(ss));
         if constexpr (X == 3) asm volatile("s_waitcnt lgkmcnt(15)");
         if constexpr (X == 4) asm volatile("s_nop 0");
         if constexpr (X == 5) asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(ss) : "v"(vv));
@@ -61,7 +60,6 @@ int main() {
     run<0, 1>("ds_read_b128", in, out, cyc); run<0, 2>("ds_read_b128", in, out, cyc);
     run<6, 1>("ds_read_b64", in, out, cyc); run<6, 2>("ds_read_b64", in, out, cyc);
     run<1, 1>("v_add_u32", in, out, cyc); run<1, 2>("v_add_u32", in, out, cyc); run<1, 4>("v_add_u32", in, out, cyc);
-    run<2, 1>("s_add_u32", in, out, cyc); run<2, 2>("s_add_u32", in, out, cyc); run<2, 4>("s_add_u32", in, out, cyc);
     run<3, 1>("s_waitcnt", in, out, cyc); run<3, 2>("s_waitcnt", in, out, cyc);
     run<4, 1>("s_nop 0", in, out, cyc); run<4, 2>("s_nop 0", in, out, cyc); run<4, 4>("s_nop 0", in, out, cyc);
     run<5, 1>("v_readlane", in, out, cyc); run<5, 2>("v_readlane", in, out, cyc);
