@@ -869,6 +869,7 @@ template <typename T, int NM, int HB> __global__ __launch_bounds__(SL_THREADS, 2
     const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int w0 = blockIdx.x * P::ROWS, B = a.B, NN = a.NN;
     const T* wpack = reinterpret_cast<const T*>(a.wpack);
+    stack_stagger(a);
     FS_STAMP(0);
 
     {   // X_0 tile -> LDS: thread = (row, 16-byte chunk), one node per pass, 6 loads in flight
@@ -1132,6 +1133,7 @@ template <typename T, int NM, int HB> __global__ __launch_bounds__(SL_THREADS, 2
     const int w0 = blockIdx.x * P::ROWS, B = a.B, NN = a.NN;
     const T* wpack = reinterpret_cast<const T*>(a.wpack);
     static_assert(sizeof(T) == 2, "fused stack kernels are bf16");
+    stack_stagger(a);
 
     // dX_L tile: only the nodes that are live in the last layer carry a gradient
     {
@@ -2080,6 +2082,11 @@ extern "C" int mshgnn_plan_create(const mshgnn_desc* desc, mshgnn_plan** out) {
             p->use_wide = hp.wide && ew && atoi(ew) >= 1;           // MSHGNN_WIDE=1: where the batch gives 3/4 of the CUs a tile
             p->wide_force = ew && atoi(ew) == 2;                   // MSHGNN_WIDE=2: for every batch
             if (p->use_wide && (rc = wide_set_attrs(p))) { mshgnn_plan_destroy(p); return rc; }
+            { const char* eg = getenv("MSHGNN_STAGGER"); p->stagger = eg ? atoi(eg) : 0; }
+            const char* e2 = getenv("MSHGNN_SLAB2");
+            p->use_slab2 = hp.slab2 && e2 && atoi(e2) >= 1;        // slab2 variant: the engine-driven kernels on 16-window tiles, two workgroups per CU
+            p->slab2_force = e2 && atoi(e2) == 2;
+            if (p->use_slab2 && (rc = slab2_set_attrs(p))) { mshgnn_plan_destroy(p); return rc; }
         }
     }
     *out = p;
@@ -2257,10 +2264,14 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
                 a.inv_n = 1.0f / (float)((int64_t)B * a.n_out);
             }
             a.stamps = stamp_ptr("MSHGNN_STAMPS");
+            a.stagger = (p->slab2_for(tiles) || p->slab_for(tiles)) && tiles > p->n_cu ? p->stagger : 0;
             ProfScope ps(p, hp.ks_stack_fwd, st);
             if (p->wide_for(B)) {
                 for (int l = 0; l < hp.L; ++l) a.prog_off[l] = hp.wd_fwd_off[l];
                 if (int rc = wide_launch(p, a, false, st)) return rc;
+            } else if (p->slab2_for(tiles)) {
+                for (int l = 0; l < hp.L; ++l) a.prog_off[l] = hp.s2_fwd_off[l];
+                if (int rc = slab2_launch(p, a, false, st)) return rc;
             } else if (p->slab_for(tiles)) {
                 for (int l = 0; l < hp.L; ++l) a.prog_off[l] = hp.sl_fwd_off[l];
                 hipLaunchKernelGGL(slab_fwd_kernel(hp), dim3(tiles), dim3(SL_THREADS), (hp.sl_blk + FS_EXTRA_BLK) * Prec<T>::BLK, st, a);
@@ -2329,10 +2340,14 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
             a.mask0_off = lay.dd[0];
             a.dbg = p->dbg;
             a.stamps = stamp_ptr("MSHGNN_STAMPS_BWD");
+            a.stagger = (p->slab2_for(tiles) || p->slab_for(tiles)) && tiles > p->n_cu ? p->stagger : 0;
             ProfScope ps(p, hp.ks_stack_bwd, st);
             if (p->wide_for(B)) {
                 for (int l = 0; l < hp.L; ++l) a.prog_off[l] = hp.wd_bwd_off[l];
                 if (int rc = wide_launch(p, a, true, st)) return rc;
+            } else if (p->slab2_for(tiles)) {
+                for (int l = 0; l < hp.L; ++l) a.prog_off[l] = hp.s2_bwd_off[l];
+                if (int rc = slab2_launch(p, a, true, st)) return rc;
             } else if (p->slab_for(tiles)) {
                 for (int l = 0; l < hp.L; ++l) a.prog_off[l] = hp.sl_bwd_off[l];
                 hipLaunchKernelGGL(slab_bwd_kernel(hp), dim3(tiles), dim3(SL_THREADS), (hp.sl_blk + FS_EXTRA_BLK) * Prec<T>::BLK, st, a);

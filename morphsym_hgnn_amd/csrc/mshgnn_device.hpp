@@ -640,7 +640,14 @@ struct StackArgs {
     // split plan: LDS block of the lo half of node n = lo_blk + n; the lo image of pack i is pack n_img + i
     int lo_blk, n_img;
     int scr0;            // split plan: first base_transform scratch block (NN, or NN - n_mlp when the scratch aliases the last nodes' blocks)
+    int stagger;         // two workgroups per CU: the second half of the grid starts this many cycles late, so that one workgroup's MAC phases
+                         // (matrix pipe) run beside the other's epilogues (stores) instead of both competing for the same unit (0: off)
 };
+// start-up delay of the workgroups that share a CU with an earlier one (the first gridDim.x / 2 workgroups fill one slot per CU)
+__device__ __forceinline__ void stack_stagger(const StackArgs& a) {
+    if (a.stagger > 0 && blockIdx.x >= (gridDim.x + 1) / 2)
+        for (int i = 0; i < a.stagger; i += 1024) __builtin_amdgcn_s_sleep(16);      // (s_sleep n = 64 n cycles)
+}
 #ifdef MSHGNN_SEG_STAMPS
 constexpr int FS_EXTRA_BLK = 6;     // LDS room for the per-segment clocks
 #else
@@ -962,6 +969,9 @@ struct mshgnn_plan {
     bool use_slab = false;              // slab variant of the stack kernels (MSHGNN_SLAB=0 selects the 8-wave ones)
     bool slab_force = false; int n_cu = 256;
     bool use_wide = false, wide_force = false;   // wide variant (mshgnn_wide.hip: 32-window tiles, one 4-wave workgroup per CU; MSHGNN_WIDE=0 off, 2 always)
+    int stagger = 0;                             // StackArgs.stagger of the two-workgroups-per-CU stack kernels (MSHGNN_STAGGER)
+    bool use_slab2 = false, slab2_force = false; // slab2 variant (mshgnn_wide.hip: the engine-driven kernels on 16-window tiles; MSHGNN_SLAB2=0 off, 2 always)
+    bool slab2_for(int tiles) const { return use_slab2 && (slab2_force || tiles >= 2 * n_cu * 3 / 4); }
     int n_types = 0;
     mshgnn_gen_state* gen = nullptr;    // set: this plan runs on the generic-width engine (hidden != 128, many nodes, ...), hp is unused
     int dbg = 0, dbg_gw = 0;            // timing ablations (instrumented builds only: read once from MSHGNN_DBG / MSHGNN_DBG_GW at plan creation)
@@ -1014,6 +1024,8 @@ int run_finalize(const mshgnn_plan* p, const mshgnn_ws_layout& lay, char* ws, fl
 // wide stack kernels of the bf16 plan (mshgnn_wide.hip)
 int wide_set_attrs(const mshgnn_plan* p);
 int wide_launch(const mshgnn_plan* p, const StackArgs& a, bool bwd, hipStream_t st);
+int slab2_set_attrs(const mshgnn_plan* p);
+int slab2_launch(const mshgnn_plan* p, const StackArgs& a, bool bwd, hipStream_t st);
 // split-bf16 parity plan (mshgnn_x3.hip)
 int x3_set_attrs(mshgnn_plan* p);
 int x3_forward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, float* out, char* ws, int64_t batch,

@@ -1,21 +1,17 @@
-// WIDE stack kernels of the bf16 plan (hgnn_c2.py:150-166, the L x HeteroConv loop, + base_transform, residual, decoder): one 4-wave workgroup
-// per CU owns a tile of 32 windows for every layer.
-//
-// Why: the slab kernels (mshgnn.hip) are bound by weight-fragment supply and per-tile skeleton, not by MFMA issue -- a 16-window tile pulls every
-// 32 KB weight pack of a layer through the CU's vector L1 for 16 windows' worth of MFMAs, twice per CU (two workgroups), and interprets the layer
-// program / headers / barriers once per 16 windows.  Here one wave per SIMD owns the whole 512-entry register file: wave wn keeps the accumulators
-// of its 32 output columns of EVERY node for BOTH 16-window halves of the tile (18 nodes x 2 halves x 8 registers), so
-//   * a weight fragment (8 KB per wave and pack) is multiplied into 32 windows: half the L2 -> CU fragment bytes per window, and there are registers
-//     for three fragment buffers (two segments of prefetch);
-//   * a layer is ONE group: no packed results parked in registers while a second group is multiplied, the epilogue converts the accumulators in place;
-//   * program interpretation, header reads, barriers and pipeline drains are paid once per 32 windows.
-// One wave per SIMD issues strictly in order, so the MAC phase is a generated, hand-scheduled asm statement (mshgnn_wide_engine.inc,
-// tools/gen_wide_engine.py: threaded code over a jump table of per-slot bodies); the accumulators live in LITERAL registers for the whole kernel
-// (slots 0..15: a[16 s ..], slots 16..19: v[192 + 16 (s - 16) ..]): the compiler tracks them as ten 32-register values pinned to those registers in
-// every statement that touches them (WRegs), so it allocates nothing else there, and C++ code reads / writes them through the wd_acc_* accessors
-// (tools/audit_wide_isa.py checks the ISA: no compiler-generated instruction names an accumulator register).
-// LDS: node block n = two 4 KB halves (rows 0-15 / 16-31 of the tile) in the slab kernels' swizzled layout -> 8 KB per node, 144 KB for A1-C2,
-// 160 KB for MiniCheetah-K4; the base_transform chain runs IN PLACE on the base nodes' own blocks (their residual rows wait in registers).
+// ENGINE-DRIVEN stack kernels of the bf16 plan (hgnn_c2.py:150-166, the L x HeteroConv loop, + base_transform, residual, decoder): the MAC phase of
+// a layer is a generated, hand-scheduled asm statement (mshgnn_wide_engine.inc, tools/gen_wide_engine.py: threaded code over a jump table of per-slot
+// bodies, weight fragments in rotating register buffers), every node's accumulators stay in FIXED registers for the whole kernel, and a layer is ONE
+// group: no packed results parked in registers while a second group is multiplied, the epilogue converts the accumulators in place.  Two geometries
+// (template parameter NH = 16-window halves per tile):
+//   * slab2 (NH = 1): 16-window tiles, two 4-wave workgroups per CU like the slab kernels of mshgnn.hip -- 128 accumulator registers (slots 0..15)
+//     + 128 vector registers per wave: v0..v31 for the compiler, two weight buffers, the window fragment, slots 16 / 17.  LDS: 4 KB per node, 72 KB for
+//     A1-C2 (the base_transform chain runs IN PLACE on the base nodes' own blocks: no scratch blocks), two workgroups per CU.
+//   * wide  (NH = 2): 32-window tiles, ONE 4-wave workgroup per CU with the whole 512-entry register file per wave (three weight buffers): half the
+//     weight-fragment bytes per window -- and every memory / instruction-fetch latency exposed, since nothing else runs on the SIMD.  Measured slower
+//     than the slab kernels at 32 windows per CU; kept as an opt-in.
+// The accumulators (slot s < 16: a[8 NH s ..], slots 16..: v[VACC + 8 NH (s - 16) ..]) are tracked by the compiler as values of 16 NH registers pinned to
+// those registers in every statement that touches them (WRegs), so it allocates nothing else there, and C++ code reads / writes them through the
+// wd_acc_* accessors (tools/audit_wide_isa.py lists compiler-generated instructions on accumulator registers).
 // Arithmetic: the same v_mfma_f32_16x16x32_bf16 per (16 windows, 16 features, 32 K) in the same order as the slab / 8-wave kernels -> activations,
 // stashes, relu bytes and dX rows are bit-identical to theirs (tests/test_engine_gpu.py).
 #include "mshgnn_device.hpp"
@@ -25,46 +21,60 @@ namespace {
 
 using T = __bf16;
 using P = Prec<__bf16>;
-constexpr int WD_BLK = 2 * P::BLK;      // LDS bytes of one node: two 16-window halves
-#define WD_KERNEL __global__ __launch_bounds__(WD_THREADS, 1)
+template <int NH> constexpr int WD_BLKB = NH * P::BLK;      // LDS bytes of one node: NH 16-window halves
+#define WD_KERNEL(NH) __global__ __launch_bounds__(WD_THREADS, (NH) == 2 ? 1 : 2)
 
-// ---- accumulator accessors: register (slot S, half H, element E of 8).  Every statement names the 32-register value that holds the slot as an
-// operand pinned to its registers (the compiler then knows the registers are occupied and what each statement reads / writes); the instruction
-// text addresses the single register literally.
-#define WD_TUPLES(X) X(0, "a[0:31]") X(1, "a[32:63]") X(2, "a[64:95]") X(3, "a[96:127]") X(4, "a[128:159]") X(5, "a[160:191]") X(6, "a[192:223]") \
-                     X(7, "a[224:255]") X(8, "v[192:223]") X(9, "v[224:255]")
-template <int K> __device__ __forceinline__ wd_f32x32& wd_tuple(WRegs& r) { if constexpr (K < 8) return r.a[K]; else return r.v[K - 8]; }
-template <int S, int H, int E> __device__ __forceinline__ float wd_acc_get1(WRegs& r) {
+// ---- accumulator accessors: register (slot S, half H, element E of 8).  Every statement names the value that holds the slot as an operand pinned to
+// its registers (the compiler then knows the registers are occupied and what each statement reads / writes); the instruction text addresses the single
+// register literally.
+#define WD_TUPLES2(X) X(0, "a[0:31]") X(1, "a[32:63]") X(2, "a[64:95]") X(3, "a[96:127]") X(4, "a[128:159]") X(5, "a[160:191]") X(6, "a[192:223]") \
+                      X(7, "a[224:255]") X(8, "v[192:223]") X(9, "v[224:255]")
+#define WD_TUPLES1(X) X(0, "a[0:15]") X(1, "a[16:31]") X(2, "a[32:47]") X(3, "a[48:63]") X(4, "a[64:79]") X(5, "a[80:95]") X(6, "a[96:111]") \
+                      X(7, "a[112:127]") X(8, "v[112:127]")
+template <int NH> constexpr int WD_VACC = NH == 2 ? 192 : 112;
+template <int NH, int K> __device__ __forceinline__ auto& wd_tuple(WRegs<NH>& r) { if constexpr (K < 8) return r.a[K]; else return r.v[K - 8]; }
+template <int NH, int S> constexpr int wd_tuple_of() { return S < 16 ? S / 2 : 8 + (S - 16) / 2; }
+template <int NH, int S, int H, int E> constexpr int wd_reg_of() { return S < 16 ? 8 * NH * S + 8 * H + E : WD_VACC<NH> + 8 * NH * (S - 16) + 8 * H + E; }
+template <int NH, int S, int H, int E> __device__ __forceinline__ float wd_acc_get1(WRegs<NH>& r) {
     float x;
-    constexpr int K = S / 2, IDX = S < 16 ? 16 * S + 8 * H + E : 192 + 16 * (S - 16) + 8 * H + E;
+    constexpr int K = wd_tuple_of<NH, S>(), IDX = wd_reg_of<NH, S, H, E>();
 #define WD_X(KK, REG) if constexpr (K == KK) { \
-        if constexpr (S < 16) asm("v_accvgpr_read_b32 %0, a[%c2]" : "=v"(x) : "{" REG "}"(wd_tuple<KK>(r)), "i"(IDX)); \
-        else asm("v_mov_b32 %0, v[%c2]" : "=v"(x) : "{" REG "}"(wd_tuple<KK>(r)), "i"(IDX)); }
-    WD_TUPLES(WD_X)
+        if constexpr (S < 16) asm("v_accvgpr_read_b32 %0, a[%c2]" : "=v"(x) : "{" REG "}"(wd_tuple<NH, KK>(r)), "i"(IDX)); \
+        else asm("v_mov_b32 %0, v[%c2]" : "=v"(x) : "{" REG "}"(wd_tuple<NH, KK>(r)), "i"(IDX)); }
+    if constexpr (NH == 2) { WD_TUPLES2(WD_X) } else { WD_TUPLES1(WD_X) }
 #undef WD_X
     return x;
 }
-template <int S, int H, int E> __device__ __forceinline__ void wd_acc_set1(WRegs& r, float x) {
-    constexpr int K = S / 2, IDX = S < 16 ? 16 * S + 8 * H + E : 192 + 16 * (S - 16) + 8 * H + E;
+template <int NH, int S, int H, int E> __device__ __forceinline__ void wd_acc_set1(WRegs<NH>& r, float x) {
+    constexpr int K = wd_tuple_of<NH, S>(), IDX = wd_reg_of<NH, S, H, E>();
 #define WD_X(KK, REG) if constexpr (K == KK) { \
-        if constexpr (S < 16) asm("v_accvgpr_write_b32 a[%c1], %2" : "+{" REG "}"(wd_tuple<KK>(r)) : "i"(IDX), "v"(x)); \
-        else asm("v_mov_b32 v[%c1], %2" : "+{" REG "}"(wd_tuple<KK>(r)) : "i"(IDX), "v"(x)); }
-    WD_TUPLES(WD_X)
+        if constexpr (S < 16) asm("v_accvgpr_write_b32 a[%c1], %2" : "+{" REG "}"(wd_tuple<NH, KK>(r)) : "i"(IDX), "v"(x)); \
+        else asm("v_mov_b32 v[%c1], %2" : "+{" REG "}"(wd_tuple<NH, KK>(r)) : "i"(IDX), "v"(x)); }
+    if constexpr (NH == 2) { WD_TUPLES2(WD_X) } else { WD_TUPLES1(WD_X) }
 #undef WD_X
 }
-// first definition of the accumulator values (their registers hold nothing yet)
-__device__ __forceinline__ void wd_regs_init(WRegs& r) {
-#define WD_X(KK, REG) asm volatile("" : "={" REG "}"(wd_tuple<KK>(r)));
-    WD_TUPLES(WD_X)
+// first definition of the accumulator values a kernel with NS slots uses (their registers hold nothing yet)
+template <int NH, int NS> __device__ __forceinline__ void wd_regs_init(WRegs<NH>& r) {
+#define WD_X(KK, REG) if constexpr (KK < 8 ? 2 * KK < (NS < 16 ? NS : 16) : 16 + 2 * (KK - 8) < NS) asm volatile("" : "={" REG "}"(wd_tuple<NH, KK>(r)));
+    if constexpr (NH == 2) { WD_TUPLES2(WD_X) } else { WD_TUPLES1(WD_X) }
 #undef WD_X
 }
-template <int S, int H> __device__ __forceinline__ void wd_acc_get(WRegs& r, P::Acc& a) {
-    a.c[0] = f32x4{wd_acc_get1<S, H, 0>(r), wd_acc_get1<S, H, 1>(r), wd_acc_get1<S, H, 2>(r), wd_acc_get1<S, H, 3>(r)};
-    a.c[1] = f32x4{wd_acc_get1<S, H, 4>(r), wd_acc_get1<S, H, 5>(r), wd_acc_get1<S, H, 6>(r), wd_acc_get1<S, H, 7>(r)};
+template <int NH, int S, int H> __device__ __forceinline__ void wd_acc_get(WRegs<NH>& r, P::Acc& a) {
+    a.c[0] = f32x4{wd_acc_get1<NH, S, H, 0>(r), wd_acc_get1<NH, S, H, 1>(r), wd_acc_get1<NH, S, H, 2>(r), wd_acc_get1<NH, S, H, 3>(r)};
+    a.c[1] = f32x4{wd_acc_get1<NH, S, H, 4>(r), wd_acc_get1<NH, S, H, 5>(r), wd_acc_get1<NH, S, H, 6>(r), wd_acc_get1<NH, S, H, 7>(r)};
 }
-template <int S, int H> __device__ __forceinline__ void wd_acc_set(WRegs& r, f32x4 c0, f32x4 c1) {
-    wd_acc_set1<S, H, 0>(r, c0[0]); wd_acc_set1<S, H, 1>(r, c0[1]); wd_acc_set1<S, H, 2>(r, c0[2]); wd_acc_set1<S, H, 3>(r, c0[3]);
-    wd_acc_set1<S, H, 4>(r, c1[0]); wd_acc_set1<S, H, 5>(r, c1[1]); wd_acc_set1<S, H, 6>(r, c1[2]); wd_acc_set1<S, H, 7>(r, c1[3]);
+template <int NH, int S, int H> __device__ __forceinline__ void wd_acc_set(WRegs<NH>& r, f32x4 c0, f32x4 c1) {
+    wd_acc_set1<NH, S, H, 0>(r, c0[0]); wd_acc_set1<NH, S, H, 1>(r, c0[1]); wd_acc_set1<NH, S, H, 2>(r, c0[2]); wd_acc_set1<NH, S, H, 3>(r, c0[3]);
+    wd_acc_set1<NH, S, H, 4>(r, c1[0]); wd_acc_set1<NH, S, H, 5>(r, c1[1]); wd_acc_set1<NH, S, H, 6>(r, c1[2]); wd_acc_set1<NH, S, H, 7>(r, c1[3]);
+}
+// all halves of a slot at once
+template <int NH, int S> __device__ __forceinline__ void wd_acc_get_all(WRegs<NH>& r, P::Acc (&c)[NH]) {
+    wd_acc_get<NH, S, 0>(r, c[0]);
+    if constexpr (NH == 2) wd_acc_get<NH, S, 1>(r, c[1]);
+}
+template <int NH, int S> __device__ __forceinline__ void wd_acc_set_all(WRegs<NH>& r, const f32x4 (&c0)[NH], const f32x4 (&c1)[NH]) {
+    wd_acc_set<NH, S, 0>(r, c0[0], c1[0]);
+    if constexpr (NH == 2) wd_acc_set<NH, S, 1>(r, c0[1], c1[1]);
 }
 // compile-time loop over the accumulator slots
 template <int U, int N, typename F> __device__ __forceinline__ void wd_for(F&& f) {
@@ -77,23 +87,23 @@ struct WProg {
     __device__ __forceinline__ WProg() : prog(0), pk(0), misc(0) {}
     __device__ __forceinline__ WProg(const int* t, int lane) : prog(t[lane]), pk(t[64 + lane]), misc(t[128 + lane]) {}
 };
-template <int NS> __device__ __forceinline__ void wd_run(WRegs& r, const WProg& wp, const char* smem, const T* wpack, int wn, int lane, const AOff<T>& ao) {
+template <int NH, int NS> __device__ __forceinline__ void wd_run(WRegs<NH>& r, const WProg& wp, const char* smem, const T* wpack, int wn, int lane, const AOff<T>& ao) {
     const int m = __builtin_amdgcn_readlane(wp.misc, 0);
-    wd_engine<NS>(r, wp.prog, wp.pk, lane * 16, ao.o, reinterpret_cast<const char*>(wpack) + wn * (P::NBV * 64 * 16), (m & 0xff) * WD_BLK, ((m >> 8) & 0xff) * WD_BLK,
-                  (m >> 16) & 0xff, (m >> 24) & 0xff);
+    wd_engine<NH, NS>(r, wp.prog, wp.pk, lane * 16, ao.o, reinterpret_cast<const char*>(wpack) + wn * (P::NBV * 64 * 16), (m & 0xff) * WD_BLKB<NH>,
+                      ((m >> 8) & 0xff) * WD_BLKB<NH>, (m >> 16) & 0xff, (m >> 24) & 0xff);
 }
 
-__device__ __forceinline__ int wd_chunk(int node, int h, int row16, int c) { return node * WD_BLK + lds_chunk<T>(h, row16, c); }
+template <int NH> __device__ __forceinline__ int wd_chunk(int node, int h, int row16, int c) { return node * WD_BLKB<NH> + lds_chunk<T>(h, row16, c); }
 
 // window operand of one MAC and the base_transform chain's GEMMs (compiler-scheduled, accumulators in VGPRs)
-struct WAcc { P::Acc h[2]; };
-struct XFrag { bf16x8 v[2][4]; };
-__device__ __forceinline__ void wd_load_x(XFrag& x, const char* smem, int node, const AOff<T>& ao) {
-    const int base = node * WD_BLK;
+template <int NH> struct WAcc { P::Acc h[NH]; };
+template <int NH> struct XFrag { bf16x8 v[NH][4]; };
+template <int NH> __device__ __forceinline__ void wd_load_x(XFrag<NH>& x, const char* smem, int node, const AOff<T>& ao) {
+    const int base = node * WD_BLKB<NH>;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NH; ++h) {
             const u32x4 v = *reinterpret_cast<const u32x4*>(smem + base + h * P::BLK + ao.o[t]);
             x.v[h][t] = __builtin_bit_cast(bf16x8, v);
         }
@@ -101,37 +111,38 @@ __device__ __forceinline__ void wd_load_x(XFrag& x, const char* smem, int node, 
 __device__ __forceinline__ void wd_mfma_v(f32x4& c, const bf16x8& w, const bf16x8& x) {
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(w), "v"(x));
 }
-template <bool PAD> __device__ __forceinline__ void wd_fence_v(WAcc& a) {      // hipcc pads nothing around an asm MFMA (guide 5.7): fresh value -> MFMA, MFMA -> reader
-    if constexpr (PAD) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(a.h[0].c[0]), "+v"(a.h[0].c[1]), "+v"(a.h[1].c[0]), "+v"(a.h[1].c[1]));
-    else asm volatile("" : "+v"(a.h[0].c[0]), "+v"(a.h[0].c[1]), "+v"(a.h[1].c[0]), "+v"(a.h[1].c[1]));
+// hipcc pads nothing around an asm MFMA (guide 5.7): fresh value -> MFMA, MFMA -> reader
+template <int NH> __device__ __forceinline__ void wd_fence_v(WAcc<NH>& a) {
+    if constexpr (NH == 2) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(a.h[0].c[0]), "+v"(a.h[0].c[1]), "+v"(a.h[1].c[0]), "+v"(a.h[1].c[1]));
+    else asm volatile("s_nop 15\n\ts_nop 7" : "+v"(a.h[0].c[0]), "+v"(a.h[0].c[1]));
 }
 // one base_transform GEMM in place: tm[u] += LDS[node u] . W for the first nm nodes (per accumulator the K steps run in the order of mac())
-template <int NM>
-__device__ __forceinline__ void wd_chain_gemm(WAcc (&tm)[NM], int nm, const char* smem, const P::BFrag& bf, const AOff<T>& ao) {
-    XFrag x;
+template <int NH, int NM>
+__device__ __forceinline__ void wd_chain_gemm(WAcc<NH> (&tm)[NM], int nm, const char* smem, const P::BFrag& bf, const AOff<T>& ao) {
+    XFrag<NH> x;
 #pragma unroll
-    for (int u = 0; u < NM; ++u) wd_fence_v<true>(tm[u]);
+    for (int u = 0; u < NM; ++u) wd_fence_v<NH>(tm[u]);
 #pragma unroll
     for (int u = 0; u < NM; ++u)
         if (u < nm) {
-            wd_load_x(x, smem, u, ao);
+            wd_load_x<NH>(x, smem, u, ao);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
+                for (int h = 0; h < NH; ++h) {
                     wd_mfma_v(tm[u].h[h].c[0], bf.v[t], x.v[h][t]);
                     wd_mfma_v(tm[u].h[h].c[1], bf.v[4 + t], x.v[h][t]);
                 }
         }
 #pragma unroll
-    for (int u = 0; u < NM; ++u) wd_fence_v<true>(tm[u]);
+    for (int u = 0; u < NM; ++u) wd_fence_v<NH>(tm[u]);
 }
 
 // ------------------------------------------------------------------------------------------------------
 // decoder (+ fused wrapper loss and decoder backward) on the X_L tile in LDS: the tail of decoder_tail_impl (mshgnn_device.hpp) for a 32-window
-// tile.  thread = (row16, 8-column chunk); a pass takes two out-type nodes x two halves, every global load of the pass before its first store.
+// tile.  thread = (row16, 8-column chunk); a pass takes two out-type nodes x NH halves, every global load of the pass before its first store.
 // ------------------------------------------------------------------------------------------------------
-template <int DMAX>
+template <int NH, int DMAX>
 __device__ __forceinline__ void wd_decoder_tail(const StackArgs& a, char* smem, int tid, int lane, int wv, int w0, int B) {
     const int c = tid & 15, row16 = (tid >> 4) & 15;
     const float* W = a.params + a.off_dec_w;
@@ -154,26 +165,26 @@ __device__ __forceinline__ void wd_decoder_tail(const StackArgs& a, char* smem, 
         bv[dd] = a.params[a.off_dec_b + dc];
     }
     for (int f0 = 0; f0 < a.n_out; f0 += 2) {
-        float ov[4][DMAX], dxv[4][8], mk[2][DMAX], yv[4][DMAX]; int labv[4] = {0, 0, 0, 0};
+        float ov[2 * NH][DMAX], dxv[2 * NH][8], mk[2][DMAX], yv[2 * NH][DMAX]; int labv[2 * NH];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int f = min(f0 + i, a.n_out - 1);
 #pragma unroll
             for (int dd = 0; dd < DMAX; ++dd) mk[i][dd] = a.out_mask[f * a.dout + min(dd, a.dout - 1)];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < NH; ++h) {
                 const size_t r = (size_t)min(w0 + 16 * h + row16, B - 1) * a.n_out + f;
-                if (ce) labv[2 * i + h] = a.labels[r] != 0;
+                labv[NH * i + h] = ce ? a.labels[r] != 0 : 0;
 #pragma unroll
-                for (int dd = 0; dd < DMAX; ++dd) yv[2 * i + h][dd] = a.y ? a.y[r * a.dout + min(dd, a.dout - 1)] : 0.f;
+                for (int dd = 0; dd < DMAX; ++dd) yv[NH * i + h][dd] = a.y ? a.y[r * a.dout + min(dd, a.dout - 1)] : 0.f;
             }
         }
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int i = it >> 1, h = it & 1, f = f0 + i;
+        for (int it = 0; it < 2 * NH; ++it) {
+            const int i = it / NH, h = it % NH, f = f0 + i;
             const bool live = f < a.n_out;
             f32x4 x0, x1;
-            load_oct(reinterpret_cast<const T*>(smem + wd_chunk(a.node0 + (live ? f : f0), h, row16, c)), x0, x1);
+            load_oct(reinterpret_cast<const T*>(smem + wd_chunk<NH>(a.node0 + (live ? f : f0), h, row16, c)), x0, x1);
             const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
 #pragma unroll
             for (int e = 0; e < 8; ++e) dxv[it][e] = 0.f;
@@ -215,8 +226,8 @@ __device__ __forceinline__ void wd_decoder_tail(const StackArgs& a, char* smem, 
             }
         }
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int i = it >> 1, h = it & 1, f = f0 + i, w = w0 + 16 * h + row16;
+        for (int it = 0; it < 2 * NH; ++it) {
+            const int i = it / NH, h = it % NH, f = f0 + i, w = w0 + 16 * h + row16;
             const bool ok = f < a.n_out && w < B;
             const size_t r = (size_t)w * a.n_out + f;
             if (c == 0 && ok) {
@@ -263,28 +274,30 @@ __device__ __forceinline__ void wd_decoder_tail(const StackArgs& a, char* smem, 
 // ------------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------------
-template <int NS, int NM, int DMAX> WD_KERNEL void k_wide_fwd(StackArgs a) {
+template <int NH, int NS, int NM, int DMAX> WD_KERNEL(NH) void k_eng_fwd(StackArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BLKB = WD_BLKB<NH>;
     const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int w0 = blockIdx.x * WD_ROWS, B = a.B, NN = a.NN;
+    const int w0 = blockIdx.x * 16 * NH, B = a.B, NN = a.NN;
     const T* wpack = reinterpret_cast<const T*>(a.wpack);
     const bool train = a.training != 0;
-    WRegs R; wd_regs_init(R);
+    WRegs<NH> R; wd_regs_init<NH, NS>(R);
+    if constexpr (NH == 1) stack_stagger(a);
     FS_STAMP(0);
 
     // layer 0's header and program stream in under the tile load
     FHdr fhn(a.tables + a.prog_off[0], lane);
     WProg wpn(a.tables + a.prog_off[0] + FH_SIZE, lane);
-    {   // X_0 tile -> LDS: thread = (row16, 16-byte chunk), three nodes (six rows) per pass
+    {   // X_0 tile -> LDS: thread = (row16, 16-byte chunk), six rows per pass
         const T* src = reinterpret_cast<const T*>(a.tile_in);
         const int row16 = tid >> 4, c = tid & 15;
-        constexpr int NB = 3;
+        constexpr int NB = 6 / NH;
         for (int n0 = 0; n0 < NN; n0 += NB) {
-            u32x4 v[NB][2];
+            u32x4 v[NB][NH];
 #pragma unroll
             for (int i = 0; i < NB; ++i)
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
+                for (int h = 0; h < NH; ++h) {
                     v[i][h] = u32x4{0, 0, 0, 0};
                     const int w = w0 + 16 * h + row16;
                     if (n0 + i < NN && w < B) v[i][h] = *reinterpret_cast<const u32x4*>(src + act_idx(w, n0 + i, B) + c * P::EPC);
@@ -292,14 +305,13 @@ template <int NS, int NM, int DMAX> WD_KERNEL void k_wide_fwd(StackArgs a) {
 #pragma unroll
             for (int i = 0; i < NB; ++i)
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
-                    if (n0 + i < NN) *reinterpret_cast<u32x4*>(smem + wd_chunk(n0 + i, h, row16, c)) = v[i][h];
+                for (int h = 0; h < NH; ++h)
+                    if (n0 + i < NN) *reinterpret_cast<u32x4*>(smem + wd_chunk<NH>(n0 + i, h, row16, c)) = v[i][h];
         }
     }
     __syncthreads();
     FS_STAMP(1);
 
-    const AOff<T> ao(lane);
     for (int l = 0; l < a.L; ++l) {
         const FHdr fh = fhn;
         const WProg wp = wpn;
@@ -325,23 +337,19 @@ template <int NS, int NM, int DMAX> WD_KERNEL void k_wide_fwd(StackArgs a) {
                 constexpr int I = decltype(ic)::value, U = 6 * G + I;
                 if constexpr (U < NS) {
                     const bool live = U < NN && fh[FH_KIND + U] != NK_DEAD;
-                    const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f}, b0 = live ? bv[I][0] : z, b1 = live ? bv[I][1] : z;
-                    wd_acc_set<U, 0>(R, b0, b1); wd_acc_set<U, 1>(R, b0, b1);
+                    const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+                    f32x4 b0[NH], b1[NH];
+#pragma unroll
+                    for (int h = 0; h < NH; ++h) { b0[h] = live ? bv[I][0] : z; b1[h] = live ? bv[I][1] : z; }
+                    wd_acc_set_all<NH, U>(R, b0, b1);
                 }
             });
         });
-#ifdef MSHGNN_ABLATE
-        {   // timing experiment (wrong results): the layer's MAC phase executed `reps` times from the SAME code (instruction cache warm after the first)
-            const int reps = 1 + ((a.dbg >> 12) & 3);
-            for (int rep = 0; rep < reps; ++rep) {
-                if (l == 0) FS_STAMP(24 + rep);
-                wd_run<NS>(R, wp, smem, wpack, wn, lane, ao);
-                if (l == 0) FS_STAMP(20 + rep);
-            }
+        FS_STAMP(20 + l);
+        {   // (fragment offsets rebuilt where they are used: four registers that would otherwise be carried -- spilled -- across the engine)
+            const AOff<T> ao(opaque(lane));
+            wd_run<NH, NS>(R, wp, smem, wpack, wn, lane, ao);
         }
-#else
-        wd_run<NS>(R, wp, smem, wpack, wn, lane, ao);
-#endif
         FS_STAMP(2 + 4 * l);
         __syncthreads();   // every wave is done reading X_l: the node blocks may be overwritten
         FS_STAMP(3 + 4 * l);
@@ -353,27 +361,27 @@ template <int NS, int NM, int DMAX> WD_KERNEL void k_wide_fwd(StackArgs a) {
         const int loff = lds_chunk<T>(0, win, col / P::EPC);
         T* xo = reinterpret_cast<T*>(a.ws + a.x_off[l + 1]);
         uint8_t* maskbytes = reinterpret_cast<uint8_t*>(a.ws + a.mask_off[l]);
-        P::BFrag bfa, bfb;
-        u32x4 resm[NM][2], hpk[NM][2];
+        u32x4 resm[NM][NH], hpk[NM][NH];
         if (nmlp > 0) {
             // base_transform, in place on the nodes' own blocks: their residual rows wait in registers, H goes into the blocks
-            load_bfrag<T>(bfa, wpack, fh[FH_W1], wn, lane); load_bfrag<T>(bfb, wpack, fh[FH_W2], wn, lane);
             wd_for<0, NM>([&](auto uc) {
                 constexpr int U = decltype(uc)::value;
 #pragma unroll
-                for (int h = 0; h < 2; ++h) resm[U][h] = hpk[U][h] = u32x4{0, 0, 0, 0};
+                for (int h = 0; h < NH; ++h) resm[U][h] = hpk[U][h] = u32x4{0, 0, 0, 0};
                 if (U < nmlp) {
-                    P::Acc c0, c1; wd_acc_get<U, 0>(R, c0); wd_acc_get<U, 1>(R, c1);
-                    resm[U][0] = *reinterpret_cast<const u32x4*>(smem + U * WD_BLK + loff);
-                    resm[U][1] = *reinterpret_cast<const u32x4*>(smem + U * WD_BLK + P::BLK + loff);
-                    hpk[U][0] = pack_oct(c0.c[0], c0.c[1]); hpk[U][1] = pack_oct(c1.c[0], c1.c[1]);
+                    P::Acc c[NH]; wd_acc_get_all<NH, U>(R, c);
+#pragma unroll
+                    for (int h = 0; h < NH; ++h) {
+                        resm[U][h] = *reinterpret_cast<const u32x4*>(smem + U * BLKB + h * P::BLK + loff);
+                        hpk[U][h] = pack_oct(c[h].c[0], c[h].c[1]);
+                    }
                 }
             });
             wd_for<0, NM>([&](auto uc) {
                 constexpr int U = decltype(uc)::value;
                 if (U < nmlp) {
-                    *reinterpret_cast<u32x4*>(smem + U * WD_BLK + loff) = hpk[U][0];
-                    *reinterpret_cast<u32x4*>(smem + U * WD_BLK + P::BLK + loff) = hpk[U][1];
+#pragma unroll
+                    for (int h = 0; h < NH; ++h) *reinterpret_cast<u32x4*>(smem + U * BLKB + h * P::BLK + loff) = hpk[U][h];
                 }
             });
         }
@@ -381,30 +389,31 @@ template <int NS, int NM, int DMAX> WD_KERNEL void k_wide_fwd(StackArgs a) {
         // are read before the first write of the group (the compiler cannot move an LDS read above an LDS write that may alias it)
         wd_for<0, (NS + 5) / 6>([&](auto gc) {
             constexpr int G = decltype(gc)::value;
-            u32x4 rres[6][2];
+            u32x4 rres[6][NH];
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
                 const int u = 6 * G + i;
-                rres[i][0] = rres[i][1] = u32x4{0, 0, 0, 0};
-                if (u < NN && u < NS && residual && fh[FH_KIND + (u < NS ? u : 0)] == NK_RELU) {
-                    rres[i][0] = *reinterpret_cast<const u32x4*>(smem + u * WD_BLK + loff);
-                    rres[i][1] = *reinterpret_cast<const u32x4*>(smem + u * WD_BLK + P::BLK + loff);
+#pragma unroll
+                for (int h = 0; h < NH; ++h) {
+                    rres[i][h] = u32x4{0, 0, 0, 0};
+                    if (u < NN && u < NS && residual && fh[FH_KIND + (u < NS ? u : 0)] == NK_RELU)
+                        rres[i][h] = *reinterpret_cast<const u32x4*>(smem + u * BLKB + h * P::BLK + loff);
                 }
             }
             wd_for<0, 6>([&](auto ic) {
                 constexpr int I = decltype(ic)::value, U = 6 * G + I;
                 if constexpr (U < NS) {
                     if (U < NN && fh[FH_KIND + U] == NK_RELU) {
-                        P::Acc c[2]; wd_acc_get<U, 0>(R, c[0]); wd_acc_get<U, 1>(R, c[1]);
+                        P::Acc c[NH]; wd_acc_get_all<NH, U>(R, c);
 #pragma unroll
-                        for (int h = 0; h < 2; ++h) {
+                        for (int h = 0; h < NH; ++h) {
                             const unsigned bits = relu_with_bits<T>(c[h]);
                             f32x4 r0, r1; unpack_oct(rres[I][h], r0, r1);
                             const u32x4 pk = pack_oct(c[h].c[0] + r0, c[h].c[1] + r1);
-                            *reinterpret_cast<u32x4*>(smem + U * WD_BLK + h * P::BLK + loff) = pk;
+                            *reinterpret_cast<u32x4*>(smem + U * BLKB + h * P::BLK + loff) = pk;
                             if (train) {
                                 const int w = w0 + 16 * h + win;
-                                if (w0 + 16 * h < B) maskbytes[relu_tile_base(U, B, 2 * blockIdx.x + h, wn) + lane] = (uint8_t)bits;
+                                if (w0 + 16 * h < B) maskbytes[relu_tile_base(U, B, NH * blockIdx.x + h, wn) + lane] = (uint8_t)bits;
                                 if (w < B) *reinterpret_cast<u32x4*>(xo + act_idx(w, U, B) + col) = pk;
                             }
                         }
@@ -414,39 +423,50 @@ template <int NS, int NM, int DMAX> WD_KERNEL void k_wide_fwd(StackArgs a) {
         });
         FS_STAMP(4 + 4 * l);
         if (nmlp > 0) {
-            WAcc tm[NM];
-            u32x4 tpk[NM][2];
+            WAcc<NH> tm[NM];
+            u32x4 tpk[NM][NH];
 #pragma unroll
-            for (int u = 0; u < NM; ++u) { acc_init_bias<T>(tm[u].h[0], a.bias + (size_t)fh[FH_B1] * H, wn, lane); tm[u].h[1] = tm[u].h[0]; }
+            for (int u = 0; u < NM; ++u) {
+                acc_init_bias<T>(tm[u].h[0], a.bias + (size_t)fh[FH_B1] * H, wn, lane);
+                if constexpr (NH == 2) tm[u].h[NH - 1] = tm[u].h[0];
+            }
+            const AOff<T> ao(opaque(lane));
+            P::BFrag bf;      // (one fragment at a time, requested right before its GEMM: 64 registers held across the relu epilogue made it spill, and a
+                              //  scratch reload next to pending stores is a full vmcnt(0) drain)
+            load_bfrag<T>(bf, wpack, fh[FH_W1], wn, lane);
             __syncthreads();      // H of every wave is in the blocks
-            wd_chain_gemm<NM>(tm, nmlp, smem, bfa, ao);
+            wd_chain_gemm<NH, NM>(tm, nmlp, smem, bf, ao);
+            load_bfrag<T>(bf, wpack, fh[FH_W2], wn, lane);
             __syncthreads();      // all reads of H done before T1 overwrites the blocks
 #pragma unroll
             for (int u = 0; u < NM; ++u)
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
+                for (int h = 0; h < NH; ++h) {
                     tpk[u][h] = u32x4{0, 0, 0, 0};
                     if (u < nmlp) {
                         tpk[u][h] = pack_oct(relu4(tm[u].h[h].c[0]), relu4(tm[u].h[h].c[1]));
-                        *reinterpret_cast<u32x4*>(smem + u * WD_BLK + h * P::BLK + loff) = tpk[u][h];
+                        *reinterpret_cast<u32x4*>(smem + u * BLKB + h * P::BLK + loff) = tpk[u][h];
                     }
                 }
 #pragma unroll
-            for (int u = 0; u < NM; ++u) { acc_init_bias<T>(tm[u].h[0], a.bias + (size_t)fh[FH_B2] * H, wn, lane); tm[u].h[1] = tm[u].h[0]; }
+            for (int u = 0; u < NM; ++u) {
+                acc_init_bias<T>(tm[u].h[0], a.bias + (size_t)fh[FH_B2] * H, wn, lane);
+                if constexpr (NH == 2) tm[u].h[NH - 1] = tm[u].h[0];
+            }
             __syncthreads();
-            wd_chain_gemm<NM>(tm, nmlp, smem, bfb, ao);
+            wd_chain_gemm<NH, NM>(tm, nmlp, smem, bf, ao);
             __syncthreads();      // all reads of T1 done before X_{l+1} overwrites the blocks
             T* hb = reinterpret_cast<T*>(a.ws + a.hb_off[l]);
             T* t1 = reinterpret_cast<T*>(a.ws + a.t1_off[l]);
 #pragma unroll
             for (int u = 0; u < NM; ++u)
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
+                for (int h = 0; h < NH; ++h) {
                     if (u < nmlp) {
                         f32x4 y0 = tm[u].h[h].c[0], y1 = tm[u].h[h].c[1];
                         if (residual) { f32x4 r0, r1; unpack_oct(resm[u][h], r0, r1); y0 += r0; y1 += r1; }
                         const u32x4 pk = pack_oct(y0, y1);
-                        *reinterpret_cast<u32x4*>(smem + u * WD_BLK + h * P::BLK + loff) = pk;
+                        *reinterpret_cast<u32x4*>(smem + u * BLKB + h * P::BLK + loff) = pk;
                         const int w = w0 + 16 * h + win;
                         if (train && w < B) {
                             *reinterpret_cast<u32x4*>(hb + act_idx(w, u, B) + col) = hpk[u][h];
@@ -459,23 +479,23 @@ template <int NS, int NM, int DMAX> WD_KERNEL void k_wide_fwd(StackArgs a) {
         __syncthreads();
         FS_STAMP(5 + 4 * l);
     }
-    wd_decoder_tail<DMAX>(a, smem, tid, lane, wn, w0, B);
+    wd_decoder_tail<NH, DMAX>(a, smem, tid, lane, wn, w0, B);
     FS_STAMP(30);
 }
 
 // ------------------------------------------------------------------------------------------------------
-// backward: the L backward layers of a 32-window tile.  The accumulators carry the residual term dX_{l+1} from layer to layer (rounded to the
-// stored bf16 value, as the slab kernel's packed rows), and a layer's epilogue writes the NEXT layer's dH straight into LDS: relu nodes masked with
-// the relu bytes of layer l - 1, base_transform nodes unmasked for the chain.
+// backward: the L backward layers of a tile.  The accumulators carry the residual term dX_{l+1} from layer to layer (rounded to the stored bf16
+// value, as the slab kernel's packed rows), and a layer's epilogue writes the NEXT layer's dH straight into LDS: relu nodes masked with the relu
+// bytes of layer l - 1, base_transform nodes unmasked for the chain.
 // ------------------------------------------------------------------------------------------------------
-template <int NS, int NM> WD_KERNEL void k_wide_bwd(StackArgs a) {
+template <int NH, int NS, int NM> WD_KERNEL(NH) void k_eng_bwd(StackArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BLKB = WD_BLKB<NH>;
     const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int w0 = blockIdx.x * WD_ROWS, B = a.B, NN = a.NN;
+    const int w0 = blockIdx.x * 16 * NH, B = a.B, NN = a.NN;
     const T* wpack = reinterpret_cast<const T*>(a.wpack);
-    const AOff<T> ao(lane);
-    const bool h_ok[2] = {w0 < B, w0 + 16 < B};
-    WRegs R; wd_regs_init(R);
+    WRegs<NH> R; wd_regs_init<NH, NS>(R);
+    if constexpr (NH == 1) stack_stagger(a);
 
     FHdr bhn(a.tables + a.prog_off[a.L - 1], lane);
     WProg wpn(a.tables + a.prog_off[a.L - 1] + FH_SIZE, lane);
@@ -487,21 +507,27 @@ template <int NS, int NM> WD_KERNEL void k_wide_bwd(StackArgs a) {
         wd_for<0, NS>([&](auto uc) {
             constexpr int U = decltype(uc)::value;
             const int kind = U < NN ? bhn[FH_KIND + U] : NK_DEAD;
-            u32x4 pk[2] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}}; unsigned mb[2] = {0xffu, 0xffu};
+            u32x4 pk[NH]; unsigned mb[NH];
+#pragma unroll
+            for (int h = 0; h < NH; ++h) { pk[h] = u32x4{0, 0, 0, 0}; mb[h] = 0xffu; }
             if (kind != NK_DEAD) {
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
+                for (int h = 0; h < NH; ++h) {
                     pk[h] = *reinterpret_cast<const u32x4*>(src + act_idx(min(w0 + 16 * h + win, B - 1), U, B) + col);
-                    if (kind == NK_RELU && h_ok[h]) mb[h] = mbytes[relu_tile_base(U, B, 2 * blockIdx.x + h, wn) + lane];
+                    if (kind == NK_RELU && w0 + 16 * h < B) mb[h] = mbytes[relu_tile_base(U, B, NH * blockIdx.x + h, wn) + lane];
                 }
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
-                    *reinterpret_cast<u32x4*>(smem + U * WD_BLK + h * P::BLK + loff) = kind == NK_RELU ? chunk_mask_bits<T>(pk[h], mb[h]) : pk[h];
+                for (int h = 0; h < NH; ++h)
+                    *reinterpret_cast<u32x4*>(smem + U * BLKB + h * P::BLK + loff) = kind == NK_RELU ? chunk_mask_bits<T>(pk[h], mb[h]) : pk[h];
             }
             const bool res = kind != NK_DEAD && bhn[FH_RES + U] != 0;
-            f32x4 c0 = f32x4{0.f, 0.f, 0.f, 0.f}, c1 = c0, d0 = c0, d1 = c0;
-            if (res) { unpack_oct(pk[0], c0, c1); unpack_oct(pk[1], d0, d1); }
-            wd_acc_set<U, 0>(R, c0, c1); wd_acc_set<U, 1>(R, d0, d1);
+            f32x4 c0[NH], c1[NH];
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                c0[h] = c1[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (res) unpack_oct(pk[h], c0[h], c1[h]);
+            }
+            wd_acc_set_all<NH, U>(R, c0, c1);
         });
     }
     __syncthreads();
@@ -523,45 +549,46 @@ template <int NS, int NM> WD_KERNEL void k_wide_bwd(StackArgs a) {
             const T* t1 = reinterpret_cast<const T*>(a.ws + a.t1_off[l]);
             T* du = reinterpret_cast<T*>(a.ws + a.du_off[l]);
             T* dh = reinterpret_cast<T*>(a.ws + a.dh_off[l]);
-            P::BFrag bfa, bfb;
-            WAcc tm[NM];
-            u32x4 traw[NM][2], dupk[NM][2];
-            load_bfrag<T>(bfa, wpack, bh[FH_W2], wn, lane);
-            load_bfrag<T>(bfb, wpack, bh[FH_W1], wn, lane);
+            const AOff<T> ao(opaque(lane));
+            P::BFrag bf;
+            WAcc<NH> tm[NM];
+            u32x4 traw[NM][NH], dupk[NM][NH];
+            load_bfrag<T>(bf, wpack, bh[FH_W2], wn, lane);
 #pragma unroll
             for (int u = 0; u < NM; ++u)
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
+                for (int h = 0; h < NH; ++h) {
                     traw[u][h] = u32x4{0, 0, 0, 0};
                     if (u < nmlp) traw[u][h] = *reinterpret_cast<const u32x4*>(t1 + act_idx(min(w0 + 16 * h + win, B - 1), u, B) + col);
                     acc_fill(tm[u].h[h], 0.f);
                 }
-            wd_chain_gemm<NM>(tm, nmlp, smem, bfa, ao);
+            wd_chain_gemm<NH, NM>(tm, nmlp, smem, bf, ao);
+            load_bfrag<T>(bf, wpack, bh[FH_W1], wn, lane);
             __syncthreads();   // all reads of the dY blocks done
 #pragma unroll
             for (int u = 0; u < NM; ++u)
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
+                for (int h = 0; h < NH; ++h) {
                     dupk[u][h] = u32x4{0, 0, 0, 0};
                     if (u < nmlp) {
                         f32x4 t0, t1v, r0, r1; unpack_oct(traw[u][h], t0, t1v);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) { r0[j] = t0[j] > 0.f ? tm[u].h[h].c[0][j] : 0.f; r1[j] = t1v[j] > 0.f ? tm[u].h[h].c[1][j] : 0.f; }
                         dupk[u][h] = pack_oct(r0, r1);
-                        *reinterpret_cast<u32x4*>(smem + u * WD_BLK + h * P::BLK + loff) = dupk[u][h];
+                        *reinterpret_cast<u32x4*>(smem + u * BLKB + h * P::BLK + loff) = dupk[u][h];
                     }
                     acc_fill(tm[u].h[h], 0.f);
                 }
             __syncthreads();
-            wd_chain_gemm<NM>(tm, nmlp, smem, bfb, ao);
+            wd_chain_gemm<NH, NM>(tm, nmlp, smem, bf, ao);
             __syncthreads();   // all reads of the dU blocks done
 #pragma unroll
             for (int u = 0; u < NM; ++u)
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
+                for (int h = 0; h < NH; ++h) {
                     if (u < nmlp) {
                         const u32x4 hp = pack_oct(tm[u].h[h].c[0], tm[u].h[h].c[1]);
-                        *reinterpret_cast<u32x4*>(smem + u * WD_BLK + h * P::BLK + loff) = hp;
+                        *reinterpret_cast<u32x4*>(smem + u * BLKB + h * P::BLK + loff) = hp;
                         const int w = w0 + 16 * h + win;
                         if (w < B) {
                             *reinterpret_cast<u32x4*>(du + act_idx(w, u, B) + col) = dupk[u][h];
@@ -573,70 +600,92 @@ template <int NS, int NM> WD_KERNEL void k_wide_bwd(StackArgs a) {
         }
 
         // dX_l[j] = (residual) + dH_j W_rootsum + sum_r sum_{j->i} dH_i W_rel^r
-        wd_run<NS>(R, wp, smem, wpack, wn, lane, ao);
+        {
+            const AOff<T> ao(opaque(lane));
+            wd_run<NH, NS>(R, wp, smem, wpack, wn, lane, ao);
+        }
         __syncthreads();   // every wave is done reading dH_l
         lq = opaque(lane); win = c_win(lq); col = wn * 32 + c_oct(lq); loff = lds_chunk<T>(0, win, col / P::EPC);      // (rebuilt: nothing derived from them lives across the MAC phase)
         T* dxo = reinterpret_cast<T*>(a.ws + a.dx_off[l]);
         const uint8_t* mbytes = reinterpret_cast<const uint8_t*>(a.ws + (l > 0 ? a.mask_off[l - 1] : a.mask0_off));
-        wd_for<0, NS>([&](auto uc) {
-            constexpr int U = decltype(uc)::value;
-            const bool outp = U < NN && bh[FH_OUT + U] != 0;
-            const int nkind = (l > 0 && U < NN) ? bhn[FH_KIND + U] : NK_DEAD;
-            const bool nres = l > 0 && U < NN && nkind != NK_DEAD && bhn[FH_RES + U] != 0;
-            f32x4 n0[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, n1[2] = {n0[0], n0[0]};
-            if (outp) {
-                // the relu bytes of the next layer's mask (layer 0: the encoder activation's)
-                unsigned mb[2] = {0xffu, 0xffu};
-                const bool want = l > 0 ? nkind == NK_RELU : enc_mask;
+        // six nodes at a time: the relu bytes of the next layer's mask (layer 0: the encoder activation's) are requested before the group's stores
+        wd_for<0, (NS + 5) / 6>([&](auto gc) {
+            constexpr int G = decltype(gc)::value;
+            unsigned mb[6][NH];
 #pragma unroll
-                for (int h = 0; h < 2; ++h) if (want && h_ok[h]) mb[h] = mbytes[relu_tile_base(U, B, 2 * blockIdx.x + h, wn) + lane];
-                P::Acc c[2]; wd_acc_get<U, 0>(R, c[0]); wd_acc_get<U, 1>(R, c[1]);
+            for (int i = 0; i < 6; ++i) {
+                const int u = 6 * G + i, uc = u < NS ? u : 0;
+                const bool outp = u < NN && u < NS && bh[FH_OUT + uc] != 0;
+                const bool want = outp && (l > 0 ? bhn[FH_KIND + uc] == NK_RELU : enc_mask);
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    u32x4 pk = pack_oct(c[h].c[0], c[h].c[1]);
-                    if (l == 0 && enc_mask) pk = chunk_mask_bits<T>(pk, mb[h]);
-                    const int w = w0 + 16 * h + win;
-                    if (w < B) *reinterpret_cast<u32x4*>(dxo + act_idx(w, U, B) + col) = pk;
-                    if (nkind != NK_DEAD)
-                        *reinterpret_cast<u32x4*>(smem + U * WD_BLK + h * P::BLK + loff) = nkind == NK_RELU ? chunk_mask_bits<T>(pk, mb[h]) : pk;
-                    if (nres) unpack_oct(pk, n0[h], n1[h]);
+                for (int h = 0; h < NH; ++h) {
+                    mb[i][h] = 0xffu;
+                    if (want && w0 + 16 * h < B) mb[i][h] = mbytes[relu_tile_base(u, B, NH * blockIdx.x + h, wn) + lane];
                 }
             }
-            if (l > 0) { wd_acc_set<U, 0>(R, n0[0], n1[0]); wd_acc_set<U, 1>(R, n0[1], n1[1]); }
+            wd_for<0, 6>([&](auto ic) {
+                constexpr int I = decltype(ic)::value, U = 6 * G + I;
+                if constexpr (U < NS) {
+                    const bool outp = U < NN && bh[FH_OUT + U] != 0;
+                    const int nkind = (l > 0 && U < NN) ? bhn[FH_KIND + U] : NK_DEAD;
+                    const bool nres = l > 0 && U < NN && nkind != NK_DEAD && bhn[FH_RES + U] != 0;
+                    f32x4 n0[NH], n1[NH];
+#pragma unroll
+                    for (int h = 0; h < NH; ++h) n0[h] = n1[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (outp) {
+                        P::Acc c[NH]; wd_acc_get_all<NH, U>(R, c);
+#pragma unroll
+                        for (int h = 0; h < NH; ++h) {
+                            u32x4 pk = pack_oct(c[h].c[0], c[h].c[1]);
+                            if (l == 0 && enc_mask) pk = chunk_mask_bits<T>(pk, mb[I][h]);
+                            const int w = w0 + 16 * h + win;
+                            if (w < B) *reinterpret_cast<u32x4*>(dxo + act_idx(w, U, B) + col) = pk;
+                            if (nkind != NK_DEAD)
+                                *reinterpret_cast<u32x4*>(smem + U * BLKB + h * P::BLK + loff) = nkind == NK_RELU ? chunk_mask_bits<T>(pk, mb[I][h]) : pk;
+                            if (nres) unpack_oct(pk, n0[h], n1[h]);
+                        }
+                    }
+                    if (l > 0) wd_acc_set_all<NH, U>(R, n0, n1);
+                }
+            });
         });
         __syncthreads();
     }
 }
 
-template <int NS, int NM, int DMAX> int launch_one(const StackArgs& a, bool bwd, int tiles, int lds, hipStream_t st, bool set_attr) {
+template <int NH, int NS, int NM, int DMAX> int launch_one(const StackArgs& a, bool bwd, int tiles, int lds, hipStream_t st, bool set_attr) {
     if (set_attr) {
         int rc;
-        if ((rc = set_lds_attr(k_wide_fwd<NS, NM, DMAX>, lds)) || (rc = set_lds_attr(k_wide_bwd<NS, NM>, lds))) return rc;
+        if ((rc = set_lds_attr(k_eng_fwd<NH, NS, NM, DMAX>, lds)) || (rc = set_lds_attr(k_eng_bwd<NH, NS, NM>, lds))) return rc;
         return MSHGNN_OK;
     }
-    if (bwd) hipLaunchKernelGGL((k_wide_bwd<NS, NM>), dim3(tiles), dim3(WD_THREADS), lds, st, a);
-    else hipLaunchKernelGGL((k_wide_fwd<NS, NM, DMAX>), dim3(tiles), dim3(WD_THREADS), lds, st, a);
+    if (bwd) hipLaunchKernelGGL((k_eng_bwd<NH, NS, NM>), dim3(tiles), dim3(WD_THREADS), lds, st, a);
+    else hipLaunchKernelGGL((k_eng_fwd<NH, NS, NM, DMAX>), dim3(tiles), dim3(WD_THREADS), lds, st, a);
     return MSHGNN_OK;
 }
-template <int NS, int NM> int launch_pair(const HostPlan& hp, const StackArgs& a, bool bwd, int tiles, int lds, hipStream_t st, bool set_attr) {
-    return hp.d.out_channels <= 4 ? launch_one<NS, NM, 4>(a, bwd, tiles, lds, st, set_attr) : launch_one<NS, NM, 8>(a, bwd, tiles, lds, st, set_attr);
+template <int NH, int NS, int NM> int launch_pair(const HostPlan& hp, const StackArgs& a, bool bwd, int tiles, int lds, hipStream_t st, bool set_attr) {
+    return hp.d.out_channels <= 4 ? launch_one<NH, NS, NM, 4>(a, bwd, tiles, lds, st, set_attr) : launch_one<NH, NS, NM, 8>(a, bwd, tiles, lds, st, set_attr);
 }
-int dispatch(const HostPlan& hp, const StackArgs& a, bool bwd, int tiles, hipStream_t st, bool set_attr) {
-    const int lds = hp.NN * WD_BLK;
+template <int NH> int dispatch(const HostPlan& hp, const StackArgs& a, bool bwd, int tiles, hipStream_t st, bool set_attr) {
+    const int lds = hp.NN * WD_BLKB<NH>;
     const bool nm2 = hp.n_mlp <= 2;
 #ifdef WD_ONLY18
-    return launch_one<18, 2, 4>(a, bwd, tiles, lds, st, set_attr);
+    return launch_one<NH, 18, 2, 4>(a, bwd, tiles, lds, st, set_attr);
 #else
-    if (hp.NN <= 16) return nm2 ? launch_pair<16, 2>(hp, a, bwd, tiles, lds, st, set_attr) : launch_pair<16, 4>(hp, a, bwd, tiles, lds, st, set_attr);
-    if (hp.NN <= 18) return nm2 ? launch_pair<18, 2>(hp, a, bwd, tiles, lds, st, set_attr) : launch_pair<18, 4>(hp, a, bwd, tiles, lds, st, set_attr);
-    return nm2 ? launch_pair<20, 2>(hp, a, bwd, tiles, lds, st, set_attr) : launch_pair<20, 4>(hp, a, bwd, tiles, lds, st, set_attr);
+    if (hp.NN <= 16) return nm2 ? launch_pair<NH, 16, 2>(hp, a, bwd, tiles, lds, st, set_attr) : launch_pair<NH, 16, 4>(hp, a, bwd, tiles, lds, st, set_attr);
+    if (hp.NN <= 18) return nm2 ? launch_pair<NH, 18, 2>(hp, a, bwd, tiles, lds, st, set_attr) : launch_pair<NH, 18, 4>(hp, a, bwd, tiles, lds, st, set_attr);
+    if constexpr (NH == 2) return nm2 ? launch_pair<NH, 20, 2>(hp, a, bwd, tiles, lds, st, set_attr) : launch_pair<NH, 20, 4>(hp, a, bwd, tiles, lds, st, set_attr);
+    return set_err(MSHGNN_EUNSUPPORTED, "the slab2 stack kernels hold at most 18 nodes per window");
 #endif
 }
 
 }  // namespace
 
-int wide_set_attrs(const mshgnn_plan* p) { return dispatch(p->hp, StackArgs{}, false, 0, nullptr, true); }
+int wide_set_attrs(const mshgnn_plan* p) { return dispatch<2>(p->hp, StackArgs{}, false, 0, nullptr, true); }
 int wide_launch(const mshgnn_plan* p, const StackArgs& a, bool bwd, hipStream_t st) {
-    const int tiles = (a.B + WD_ROWS - 1) / WD_ROWS;
-    return dispatch(p->hp, a, bwd, tiles, st, false);
+    return dispatch<2>(p->hp, a, bwd, (a.B + WD_ROWS - 1) / WD_ROWS, st, false);
+}
+int slab2_set_attrs(const mshgnn_plan* p) { return dispatch<1>(p->hp, StackArgs{}, false, 0, nullptr, true); }
+int slab2_launch(const mshgnn_plan* p, const StackArgs& a, bool bwd, hipStream_t st) {
+    return dispatch<1>(p->hp, a, bwd, (a.B + TILE_ROWS - 1) / TILE_ROWS, st, false);
 }

@@ -280,8 +280,9 @@ def test_step_is_hip_graph_capturable():
                                              ("k4", "mini_cheetah-k4", "mini_cheetah-k4", 8192), ("k4", "mini_cheetah-k4", "mini_cheetah-k4", 777),
                                              ("k4_com", "solo-k4-com", "solo-k4", 500), ("c2_com", "solo-c2-com", "solo-c2", 300)])
 def test_slab_and_eight_wave_stack_kernels_agree_bit_for_bit(kind, topo, cfg, B, monkeypatch):
-    """The slab stack kernels (two 4-wave workgroups per CU, destination nodes in two groups) and the wide ones (one 4-wave workgroup per CU,
-    32-window tiles, every node's accumulators in registers) accumulate every node in the same order as the 8-wave stack kernels: outputs and
+    """The slab stack kernels (two 4-wave workgroups per CU, destination nodes in two groups) and the engine-driven ones (asm MAC engine, every node's
+    accumulators in fixed registers: slab2 = 16-window tiles, two workgroups per CU; wide = 32-window tiles, one workgroup per CU) accumulate every
+    node in the same order as the 8-wave stack kernels: outputs and
     every gradient but the decoder's (whose per-tile partials are summed over fewer per-wave partials) are identical bits, for full-size and
     ragged batches."""
     _require_gpu()
@@ -291,11 +292,12 @@ def test_slab_and_eight_wave_stack_kernels_agree_bit_for_bit(kind, topo, cfg, B,
     x_dict, y = synth.make_windows(5, B, spec.num_nodes, spec.widths, n_y)
     params = synth.make_params(5, spec.param_shapes())
     res = {}
-    for mode, (wide, slab) in {"wide": ("2", "2"), "slab": ("0", "2"), "8wave": ("0", "0")}.items():
+    for mode, (wide, slab2, slab) in {"wide": ("2", "0", "2"), "slab2": ("0", "2", "2"), "slab": ("0", "0", "2"), "8wave": ("0", "0", "0")}.items():
         monkeypatch.setenv("MSHGNN_WIDE", wide)       # read when the plan is created
+        monkeypatch.setenv("MSHGNN_SLAB2", slab2)
         monkeypatch.setenv("MSHGNN_SLAB", slab)
         e = eng.Engine(spec, "bf16")
-        if mode == "slab" and not (e.info.kernel_sets & 2):
+        if (mode == "slab" and not (e.info.kernel_sets & 2)) or (mode == "slab2" and not (e.info.kernel_sets & 16)):
             continue
         assert mode != "wide" or (e.info.kernel_sets & 8), "every fused topology has a wide plan"
         xs = e.cast_inputs(x_dict)
@@ -331,10 +333,13 @@ def test_wide_stack_kernels_on_every_entry_point(kind, topo, cfg, layers, B, mon
     x_dict, y = synth.make_windows(11, B, spec.num_nodes, spec.widths, n_y, classification=not reg)
     params = synth.make_params(11, spec.param_shapes())
     res = {}
-    for mode, (wide, slab) in {"wide": ("2", "2"), "8wave": ("0", "0")}.items():
+    for mode, (wide, slab2, slab) in {"wide": ("2", "0", "2"), "slab2": ("0", "2", "2"), "8wave": ("0", "0", "0")}.items():
         monkeypatch.setenv("MSHGNN_WIDE", wide)
+        monkeypatch.setenv("MSHGNN_SLAB2", slab2)
         monkeypatch.setenv("MSHGNN_SLAB", slab)
         e = eng.Engine(spec, "bf16")
+        if mode == "slab2" and not (e.info.kernel_sets & 16):
+            continue
         xs = e.cast_inputs(x_dict)
         flat = eng.flatten_params(spec, params, e.device)
         inf = e.forward(xs, flat, B, training=False).clone()
@@ -348,13 +353,16 @@ def test_wide_stack_kernels_on_every_entry_point(kind, topo, cfg, layers, B, mon
             out, g = out.clone(), g.clone()
         torch.cuda.synchronize()
         res[mode] = (inf, out, g)
-    assert torch.equal(res["wide"][0], res["8wave"][0]) and torch.equal(res["wide"][1], res["8wave"][1])
-    ga, gb = eng.unflatten(spec, res["wide"][2]), eng.unflatten(spec, res["8wave"][2])
-    for k in ga:
-        if k.startswith("decoder"):
-            assert float((ga[k] - gb[k]).abs().max()) <= 2e-6 * float(gb[k].abs().max()), k
-        else:
-            assert torch.equal(ga[k], gb[k]), k
+    for mode in res:
+        if mode == "8wave":
+            continue
+        assert torch.equal(res[mode][0], res["8wave"][0]) and torch.equal(res[mode][1], res["8wave"][1]), mode
+        ga, gb = eng.unflatten(spec, res[mode][2]), eng.unflatten(spec, res["8wave"][2])
+        for k in ga:
+            if k.startswith("decoder"):
+                assert float((ga[k] - gb[k]).abs().max()) <= 2e-6 * float(gb[k].abs().max()), (mode, k)
+            else:
+                assert torch.equal(ga[k], gb[k]), (mode, k)
 
 
 def test_full_size_batch_properties_bf16():

@@ -9,8 +9,9 @@ funcs = re.split(r'\n(?=_ZN12_GLOBAL__N_1\w+:)', s)
 bad_total = 0
 for f in funcs[1:]:
     name = f.split(':')[0]
-    if 'k_wide' not in name: continue
-    ns = int(re.search(r'ILi(\d+)E', name).group(1))      # accumulator slots: 16 -> no VGPR accumulators, 18 -> v[192:223], 20 -> v[192:255]
+    if 'k_wide' not in name and 'k_eng' not in name: continue
+    m = re.search(r'ILi(\d+)ELi(\d+)E', name)
+    nh, ns = int(m.group(1)), int(m.group(2))      # geometry (halves per tile) and accumulator slots: slots 16.. live in v[VACC ..], VACC = 192 (wide) / 112 (slab2)
     inasm = False; bad = []
     for i, l in enumerate(f.split('\n')):
         if ';;#ASMSTART' in l: inasm = True; continue
@@ -18,8 +19,9 @@ for f in funcs[1:]:
         if inasm or l.strip().startswith(';') or l.strip().startswith('.'): continue
         if re.search(r'\ba\[?\d+', l) or 'accvgpr' in l: bad.append((i, l.strip()))
         regs = [int(x) for x in re.findall(r'\bv(\d+)\b', l)] + [int(y) for x in re.findall(r'v\[(\d+):(\d+)\]', l) for y in x]
-        if any(192 <= r < 192 + 32 * ((max(0, ns - 16) + 1) // 2) for r in regs): bad.append((i, l.strip()))
+        vacc = 192 if nh == 2 else 112
+        if any(vacc <= r < vacc + 16 * nh * ((max(0, ns - 16) + 1) // 2) for r in regs): bad.append((i, l.strip()))
     m = re.search(r'; ScratchSize: (\d+)', f); c = re.search(r'; codeLenInByte = (\d+)', f)
-    print(f"{name[19:52]:34s} code {c.group(1) if c else '?':>7s} B  scratch {m.group(1) if m else '?':>4s} B  compiler-generated instructions on accumulator registers: {len(bad)}", bad[:3])
+    print(f"{name[19:56]:38s} code {c.group(1) if c else '?':>7s} B  scratch {m.group(1) if m else '?':>4s} B  compiler-generated instructions on accumulator registers: {len(bad)}", bad[:3])
     bad_total += len(bad)
 sys.exit(0)

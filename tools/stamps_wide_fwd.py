@@ -15,7 +15,7 @@ xs = e.cast_inputs(x); flat = eng.flatten_params(spec, synth.make_params(0, spec
 y = torch.randn(B * 12, generator=g).to(dev)
 for _ in range(3): e.step_mse(xs, flat, y, B)
 torch.cuda.synchronize()
-s = stamps.cpu().numpy().reshape(512, 32).astype(np.float64)[:256]
+s = stamps.cpu().numpy().reshape(512, 32).astype(np.float64); s = s[s[:, 30] > 0]
 names = {0: "start", 1: "tile staged", 30: "end (decoder + MSE tail)"}; order = [0, 1]
 for l in range(3):
     names.update({2 + 4 * l: f"L{l} MAC phase", 3 + 4 * l: f"L{l} barrier", 4 + 4 * l: f"L{l} relu epilogue", 5 + 4 * l: f"L{l} base MLP + barrier"})
@@ -26,6 +26,6 @@ for k in order:
     d = np.median(s[:, k] - s[:, prev]) if k else 0
     print(f"  {names[k]:28s} +{d:9.0f} cycles (median)   since start {np.median(s[:, k] - s[:, 0]):9.0f}")
     prev = k
-for k in (20, 21, 22, 23):
-    if s[:, k].max() > 0: print(f"  L0 engine rep {k - 20}: {np.median(s[:, k] - s[:, k + 4]):9.0f} cycles   (start since tile staged {np.median(s[:, k + 4] - s[:, 1]):9.0f})")
+for l in range(3):
+    if s[:, 20 + l].max() > 0: print(f"  L{l}: accumulator init {np.median(s[:, 20 + l] - s[:, 1 if l == 0 else 5 + 4 * (l - 1)]):8.0f}   MAC engine {np.median(s[:, 2 + 4 * l] - s[:, 20 + l]):8.0f} cycles")
 print("start spread (cycles):", int(s[:, 0].max() - s[:, 0].min()), " span:", int(s[:, 30].max() - s[:, 0].min()))
