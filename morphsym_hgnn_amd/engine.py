@@ -91,7 +91,7 @@ def build_library(force: bool = False) -> str:
     src = os.path.join(_HERE, "csrc")
     if force and os.path.exists(LIB_PATH):
         os.remove(LIB_PATH)
-    subprocess.run(["make", "-C", src], check=True)
+    subprocess.run(["make", "-j", "6", "-C", src], check=True)
     return LIB_PATH
 
 
