@@ -927,8 +927,6 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
     const int wn = wv & 3, wh = wv >> 2;
     const int w0 = blockIdx.x * P::ROWS, B = a.B, NN = a.NN;
     const T* wpack = reinterpret_cast<const T*>(a.wpack);
-    const int win = c_win(lane), w = w0 + win, col = wn * 32 + c_oct(lane), g8 = (lane >> 4) << 3;
-    const bool w_ok = w < B;
 
     FS_STAMP(0);
     // dX_L tile: only the nodes that are live in the last layer carry a gradient
@@ -958,6 +956,11 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
         }
         const int nmlp = bh[FH_NMLP], flags = bh[FH_FLAGS];
         const unsigned* maskbits = reinterpret_cast<const unsigned*>(a.ws + a.mask_off[l]);
+        // lane constants rebuilt per layer from an opaque copy of the lane id: the per-node 64-bit addresses derived from them were hoisted out of the
+        // layer loop and spilled, and a scratch reload next to the epilogue's pending stores is a full vmcnt(0) drain
+        const int lq = opaque(lane);
+        const int win = c_win(lq), w = w0 + win, col = wn * 32 + c_oct(lq), g8 = (lq >> 4) << 3;
+        const bool w_ok = w < B;
 
         // phase 1 (each lane on the octets it owns): the accumulator of node n starts at its residual term
         // G_{l+1}[n]; relu nodes are then masked in place -> dH_l[n].  Every relu-bit word and every LDS read is issued
@@ -1057,6 +1060,16 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
 
         T* dxo = reinterpret_cast<T*>(a.ws + a.dx_off[l]);
         const T* xact = reinterpret_cast<const T*>(a.ws + a.x_off[0]);
+        // layer 0: the encoder's relu bytes of every node are requested before the first store of the epilogue (a load waited for while stores are
+        // in flight drains them all: one round trip instead of one per node)
+        unsigned xbv[FS_HS];
+#pragma unroll
+        for (int u = 0; u < FS_HS; ++u) {
+            const int n = 2 * u + wh;
+            xbv[u] = 0xffu;
+            if ((flags & FF_ENC_MASK) && w_ok && a.mask0_off && n < NN && bh[FH_OUT + n])
+                xbv[u] = reinterpret_cast<const uint8_t*>(a.ws + a.mask0_off)[relu_byte(n, B, w, wn * 32 + g8)];
+        }
 #pragma unroll
         for (int u = 0; u < FS_HS; ++u) {
             const int n = 2 * u + wh;
@@ -1064,7 +1077,7 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
                 f32x4 y0 = acc[u].c[0], y1 = acc[u].c[1];
                 if ((flags & FF_ENC_MASK) && w_ok) {   // layer 0: x relu'(X_0)  (encoder activation)
                     if (a.mask0_off) {      // the encoder's relu byte of this lane
-                        const unsigned xb = reinterpret_cast<const uint8_t*>(a.ws + a.mask0_off)[relu_byte(n, B, w, wn * 32 + g8)];
+                        const unsigned xb = xbv[u];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) { y0[j] = ((xb >> j) & 1u) ? y0[j] : 0.f; y1[j] = ((xb >> (4 + j)) & 1u) ? y1[j] : 0.f; }
                     } else {

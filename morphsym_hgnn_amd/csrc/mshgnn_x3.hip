@@ -301,8 +301,7 @@ template <bool ALIAS> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
     const int wn = wv & 3, wh = wv >> 2;
     const int w0 = blockIdx.x * P::ROWS, B = a.B, NN = a.NN, LO = a.lo_blk, SCR = a.scr0;
     const T* wpack = reinterpret_cast<const T*>(a.wpack);
-    const int win = c_win(lane), w = w0 + win, col = wn * 32 + c_oct(lane);
-    const bool w_ok = w < B, train = a.training != 0;
+    const bool train = a.training != 0;
 
     FS_STAMP(0);
     stage_tile_x3(smem, reinterpret_cast<const T*>(a.tile_in), NN, LO, w0, B, tid, [](int) { return true; });
@@ -328,6 +327,11 @@ template <bool ALIAS> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
         }
         FS_STAMP(2 + 4 * l);
         fs_run<T>(wp, acc, smem, wpack, wn, lane);
+        // lane constants of the epilogue rebuilt per layer from an opaque copy of the lane id (per-node addresses derived from them were hoisted out
+        // of the layer loop and spilled; a scratch reload next to pending stores is a full vmcnt(0) drain)
+        const int lq = opaque(lane);
+        const int win = c_win(lq), w = w0 + win, col = wn * 32 + c_oct(lq);
+        const bool w_ok = w < B;
         FS_STAMP(3 + 4 * l);
         __syncthreads();   // every wave is done reading X_l: the node blocks may be overwritten
         FS_STAMP(4 + 4 * l);
@@ -461,8 +465,6 @@ __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_bwd_x3(StackArgs a) 
     const int wn = wv & 3, wh = wv >> 2;
     const int w0 = blockIdx.x * P::ROWS, B = a.B, NN = a.NN, LO = a.lo_blk;
     const T* wpack = reinterpret_cast<const T*>(a.wpack);
-    const int win = c_win(lane), w = w0 + win, col = wn * 32 + c_oct(lane), g8 = (lane >> 4) << 3;
-    const bool w_ok = w < B;
 
     // dX_L tile: only the nodes that are live in the last layer carry a gradient
     {
@@ -483,6 +485,11 @@ __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_bwd_x3(StackArgs a) 
         }
         const int nmlp = bh[FH_NMLP], flags = bh[FH_FLAGS];
         const uint8_t* maskbytes = reinterpret_cast<const uint8_t*>(a.ws + a.mask_off[l]);
+        // lane constants rebuilt per layer from an opaque copy of the lane id: the per-node 64-bit addresses derived from them were hoisted out of
+        // the layer loop and spilled, and a scratch reload next to the epilogue's pending stores is a full vmcnt(0) drain
+        const int lq = opaque(lane);
+        const int win = c_win(lq), w = w0 + win, col = wn * 32 + c_oct(lq), g8 = (lq >> 4) << 3;
+        const bool w_ok = w < B;
 
         // phase 1 (each lane on the octets it owns): the accumulator of node n starts at its residual term G_{l+1}[n]; relu nodes are
         // then masked in place (both planes) -> dH_l[n]
@@ -578,13 +585,22 @@ __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_bwd_x3(StackArgs a) 
 
         T* dxo = reinterpret_cast<T*>(a.ws + a.dx_off[l]);
         const uint8_t* m0 = reinterpret_cast<const uint8_t*>(a.ws + a.mask0_off);
+        // layer 0: the encoder's relu bytes of every node are requested before the first store of the epilogue (one round trip; a load waited for
+        // while stores are in flight drains them all)
+        unsigned xbv[FS_HS];
+#pragma unroll
+        for (int u = 0; u < FS_HS; ++u) {
+            const int n = 2 * u + wh;
+            xbv[u] = 0xffu;
+            if ((flags & FF_ENC_MASK) && w_ok && n < NN && bh[FH_OUT + n]) xbv[u] = m0[relu_byte(n, B, w, wn * 32 + g8)];
+        }
 #pragma unroll
         for (int u = 0; u < FS_HS; ++u) {
             const int n = 2 * u + wh;
             if (n < NN && bh[FH_OUT + n]) {
                 f32x4 y0 = acc[u].c[0], y1 = acc[u].c[1];
                 if ((flags & FF_ENC_MASK) && w_ok) {   // layer 0: x relu'(X_0): the encoder's relu byte of this lane
-                    const unsigned xb = m0[relu_byte(n, B, w, wn * 32 + g8)];
+                    const unsigned xb = xbv[u];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { y0[j] = ((xb >> j) & 1u) ? y0[j] : 0.f; y1[j] = ((xb >> (4 + j)) & 1u) ? y1[j] : 0.f; }
                 }
