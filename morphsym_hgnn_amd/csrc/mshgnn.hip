@@ -134,12 +134,17 @@ template <typename T, bool ALIGNED, bool SERIES = false> __global__ __launch_bou
     typename P::AFrag af;
     const AOff<T> ao(lane);      // fragment offsets once per kernel (the generic load_afrag rebuilds them per call: 14 VALU instructions)
     u32x4 v[MB / BPP][NIT];
+    u32x4 rawv[SERIES ? MB / BPP : 1][NIT];      // SERIES: the chunk being multiplied, kept until its window rows have been written
     // SERIES: first series row of this thread's window rows, the node row's first run
-    int srow[SERIES ? MB / BPP : 1]; int rfirst = 0;
+    int srow[SERIES ? MB / BPP : 1];
+    __shared__ unsigned long long rp_s[SERIES ? 16 : 1];      // SERIES: the column pointers of this node row's runs (a chunk takes its pieces from runs j, j + 1)
     if constexpr (SERIES) {
 #pragma unroll
         for (int mi = 0; mi < MB / BPP; ++mi) srow[mi] = (int)ser.starts[min(w0 + (mi * BPP + sub) * P::ROWS + r0, a.B - 1)];
-        rfirst = ser.rows[2 * (ser.row0[t] + node)];
+        // one round trip for the row's run pointers instead of a dependent pointer load in front of every chunk's data loads
+        const int rfirst = ser.rows[2 * (ser.row0[t] + node)], rend = ser.rows[2 * (ser.row0[t] + node) + 1];
+        if (tid < 16) rp_s[tid] = rfirst + tid < rend ? ser.run_ptr[rfirst + tid] : 0ull;
+        __syncthreads();
     }
     auto fetch = [&](int kc) {
         const int k0 = kc * H + c * P::EPC;
@@ -148,7 +153,7 @@ template <typename T, bool ALIGNED, bool SERIES = false> __global__ __launch_bou
             // elements [k0, k0 + 8) of the row: n0 of them from run j at time offset off, the rest from run j + 1 at offset 0
             const int j = k0 / ser.T, off = k0 - j * ser.T, n0 = min(P::EPC, ser.T - off);
             const bool second = nvalid > n0;
-            const unsigned long long pa = nvalid > 0 ? ser.run_ptr[rfirst + j] : 0ull, pb = second ? ser.run_ptr[rfirst + j + 1] : 0ull;
+            const unsigned long long pa = nvalid > 0 ? rp_s[min(j, 15)] : 0ull, pb = second ? rp_s[min(j + 1, 15)] : 0ull;
             const u32x4 ones = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};      // the constant-1 run (bf16 1.0)
 #pragma unroll
             for (int mi = 0; mi < MB / BPP; ++mi) {
@@ -191,14 +196,23 @@ template <typename T, bool ALIGNED, bool SERIES = false> __global__ __launch_bou
             for (int it = 0; it < NIT; ++it) {
                 const u32x4 raw = kc + 1 == nkc ? chunk_keep_first<T>(v[mi][it], nv) : v[mi][it];      // only the last K chunk has pad columns
                 *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(mi * BPP + sub, r0 + it * (256 / P::CPR), c)) = raw ^ sx;
-                if constexpr (SERIES) {      // the materialised window row (raw values: the sign mask is applied by whoever reads it)
-                    const int w = w0 + (mi * BPP + sub) * P::ROWS + r0 + it * (256 / P::CPR), k0 = kc * H + c * P::EPC;
-                    if (x != nullptr && w < a.B && k0 < (int)pitch) *reinterpret_cast<u32x4*>(const_cast<T*>(x) + ((size_t)w * nt + node) * pitch + k0) = raw;
-                }
+                if constexpr (SERIES) rawv[mi][it] = raw;
             }
         __syncthreads();
         load_bfrag<T>(bf, wpack, a.pack0[t] + kc, wv, lane);   // before the prefetch: vmcnt retires in order
         if (kc + 1 < nkc) fetch(kc + 1);   // the next K chunk streams from HBM under this chunk's MFMAs
+        if constexpr (SERIES) {
+            // the materialised window rows of THIS chunk (raw values: the sign mask is applied by whoever reads them) go out BEHIND the next chunk's
+            // loads: vmcnt retires in issue order, so a load issued after stores can only be waited for together with them -- with the stores
+            // youngest, the next chunk's wait leaves them in flight
+#pragma unroll
+            for (int mi = 0; mi < MB / BPP; ++mi)
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int w = w0 + (mi * BPP + sub) * P::ROWS + r0 + it * (256 / P::CPR), k0 = kc * H + c * P::EPC;
+                    if (x != nullptr && w < a.B && k0 < (int)pitch) *reinterpret_cast<u32x4*>(const_cast<T*>(x) + ((size_t)w * nt + node) * pitch + k0) = rawv[mi][it];
+                }
+        }
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
             if (w0 + m * P::ROWS < a.B) {   // uniform
@@ -3230,6 +3244,7 @@ static int step_series(const mshgnn_plan* p, const mshgnn_window_desc* d, const 
     int n_rows = 0;
     for (int t = 0; t < d->n_types; ++t) {
         if (d->type_nodes[t] != md.type_nodes[t] || d->type_width[t] != md.type_width[t]) return set_err(MSHGNN_EINVAL, "window recipe and plan disagree on a node type");
+        if (!x3 && (d->type_width[t] + d->history - 1) / d->history > 16) return set_err(MSHGNN_EUNSUPPORTED, "the fused gather holds at most 16 runs per node row (assemble, then mshgnn_step_mse)");
         if (x_out && (!x_out[t] || ((uintptr_t)x_out[t] & 15) || x_pitch[t] % epc || x_pitch[t] < (d->type_width[t] + epc - 1) / epc * epc)) return set_err(MSHGNN_EINVAL, "bad window buffer");
         n_rows += d->type_nodes[t];
     }
