@@ -13,7 +13,10 @@ imu = torch.randn(B, 1, 900, generator=g)
 x = {"base": imu.expand(B, 2, 900).reshape(B * 2, 900), "joint": torch.randn(B * 12, 450, generator=g), "foot": torch.ones(B * 4, 1)}
 xs = e.cast_inputs(x); flat = eng.flatten_params(spec, synth.make_params(0, spec.param_shapes()), dev)
 y = torch.randn(B * 12, generator=g).to(dev)
-for _ in range(3): e.step_mse(xs, flat, y, B)
+infer = os.environ.get("STAMP_INFER") == "1"     # forward without the training stashes
+for _ in range(3):
+    if infer: e.forward(xs, flat, B, training=False)
+    else: e.step_mse(xs, flat, y, B)
 torch.cuda.synchronize()
 s = stamps.cpu().numpy().reshape(512, 32).astype(np.float64); s = s[s[:, 30] > 0]
 names = {0: "start", 1: "tile staged", 30: "end (decoder + MSE tail)"}; order = [0, 1]
