@@ -614,6 +614,7 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
     typename P::Acc acc[FS_HS];
     FHdr fhn(a.tables + a.prog_off[0], lane);
     FProg wpn(a.tables + a.prog_off[0] + FH_SIZE + wh * FPROG_LEN, lane);
+    fhn.settle(); wpn.settle();
     for (int l = 0; l < a.L; ++l) {
         const FHdr fh = fhn;
         const FProg wp = wpn;
@@ -694,6 +695,7 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
         // every load issued so far (chain operands, the next layer's header and program) has landed before the first store of
         // the epilogue goes out: from here to the next layer's first weight fragment nothing waits on a load
         __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));
+        fhn.settle(); wpn.settle();      // (and the compiler stops tracking them as pending: no vmcnt(0) at the top of the next layer, FProg::settle)
         if (nmlp > 0 && train && w_ok) {
             T* hb = reinterpret_cast<T*>(a.ws + a.hb_off[l]);
             T* t1 = reinterpret_cast<T*>(a.ws + a.t1_off[l]);
@@ -907,6 +909,7 @@ template <typename T, int NM, int HB> __global__ __launch_bounds__(SL_THREADS, 2
 
     FHdr fhn(a.tables + a.prog_off[0], lane);
     FProg wan(a.tables + a.prog_off[0] + FH_SIZE, lane), wbn(a.tables + a.prog_off[0] + FH_SIZE + FPROG_LEN, lane);
+    fhn.settle(); wan.settle(); wbn.settle();      // (waited for here, not by a vmcnt(0) at the top of every layer)
     for (int l = 0; l < a.L; ++l) {
         const FHdr fh = fhn;
         const FProg wa = wan, wb = wbn;
@@ -924,7 +927,7 @@ template <typename T, int NM, int HB> __global__ __launch_bounds__(SL_THREADS, 2
         FS_STAMP(3 + 4 * l);
         __syncthreads();   // every wave is done reading X_l: the node blocks may be overwritten
         FS_STAMP(4 + 4 * l);
-        __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));      // loads (next header / programs) landed before the stores go out
+        fhn.settle(); wan.settle(); wbn.settle();      // the next header / programs have landed before the stores go out (no drain at the top of the next layer)
         slab_group_store<T, SL_HA, 0>(a, fh, smem, wn, lane, FH_SLOTA, l, keepA, bitsA);
         slab_group_store<T, HB, SL_HA>(a, fh, smem, wn, lane, FH_SLOTB, l, keepB, bitsB);
         __syncthreads();
@@ -961,6 +964,7 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
     typename P::Acc acc[FS_HS];
     FHdr bhn(a.tables + a.prog_off[a.L - 1], lane);
     FProg wpn(a.tables + a.prog_off[a.L - 1] + FH_SIZE + wh * FPROG_LEN, lane);
+    bhn.settle(); wpn.settle();
     for (int l = a.L - 1; l >= 0; --l) {
         const FHdr bh = bhn;
         const FProg wp = wpn;
@@ -1074,6 +1078,7 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
 
         T* dxo = reinterpret_cast<T*>(a.ws + a.dx_off[l]);
         const T* xact = reinterpret_cast<const T*>(a.ws + a.x_off[0]);
+        bhn.settle(); wpn.settle();      // next header / program landed before the stores go out (FProg::settle)
         // layer 0: the encoder's relu bytes of every node are requested before the first store of the epilogue (a load waited for while stores are
         // in flight drains them all: one round trip instead of one per node)
         unsigned xbv[FS_HS];
@@ -1198,6 +1203,7 @@ template <typename T, int NM, int HB> __global__ __launch_bounds__(SL_THREADS, 2
             if (n >= 0 && bhn[FH_KIND + SL_HA + u] != NK_DEAD) keepB[u] = *reinterpret_cast<const u32x4*>(src + act_idx(wq, n, B) + colq);
         }
     }
+    bhn.settle(); wan.settle(); wbn.settle();
     for (int l = a.L - 1; l >= 0; --l) {
         const FHdr bh = bhn;
         const FProg wa = wan, wb = wbn;
@@ -1296,7 +1302,7 @@ template <typename T, int NM, int HB> __global__ __launch_bounds__(SL_THREADS, 2
         slab_group_bwd<T, SL_HA, 0>(a, bh, wa, smem, wpack, wn, lane, FH_SLOTA, xact, enc_mask, keepA);
         slab_group_bwd<T, HB, SL_HA>(a, bh, wb, smem, wpack, wn, lane, FH_SLOTB, xact, enc_mask, keepB);
         __syncthreads();   // every wave is done reading dH_l
-        __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));
+        bhn.settle(); wan.settle(); wbn.settle();      // next header / programs landed before the stores go out (FProg::settle)
         T* dxo = reinterpret_cast<T*>(a.ws + a.dx_off[l]);
 #pragma unroll
         for (int q = 0; q < SL_HA + HB; ++q) {

@@ -667,6 +667,9 @@ struct FProg {
     __device__ __forceinline__ int pack(int sgi) const { return __builtin_amdgcn_readlane(pk, sgi); }
     __device__ __forceinline__ int counts(int sgi) const { return __builtin_amdgcn_readlane(pcnt, sgi); }
     __device__ __forceinline__ int at(int i) const { return (__builtin_amdgcn_readlane(pb, i >> 2) >> ((i & 3) << 3)) & 0xff; }
+    // the loads have landed from here on (the compiler waits for them HERE, with a counted vmcnt, and no longer tracks them as pending: a wait at the
+    // first use -- the top of the next layer, behind this layer's stores -- would be a full drain)
+    __device__ __forceinline__ void settle() { asm volatile("" : "+v"(pk), "+v"(pcnt), "+v"(pb)); }
 };
 
 // a layer header (FH_SIZE = 88 ints) held in two VGPRs and read with v_readlane: per-node flags cost no scalar-memory round
@@ -676,6 +679,7 @@ struct FHdr {
     __device__ __forceinline__ FHdr() : h0(0), h1(0) {}
     __device__ __forceinline__ FHdr(const int* hdr, int lane) : h0(hdr[lane]), h1(lane < FH_SIZE - 64 ? hdr[64 + lane] : 0) {}
     __device__ __forceinline__ int operator[](int i) const { return i < 64 ? __builtin_amdgcn_readlane(h0, i & 63) : __builtin_amdgcn_readlane(h1, i & 63); }
+    __device__ __forceinline__ void settle() { asm volatile("" : "+v"(h0), "+v"(h1)); }      // see FProg::settle
 };
 
 // one segment: walk the accumulators in static order, each with its run-time MAC count; the source blocks come from the

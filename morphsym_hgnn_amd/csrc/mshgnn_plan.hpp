@@ -86,7 +86,10 @@ enum { FH_NSEG = 0, FH_NMLP, FH_W1, FH_W2, FH_B1, FH_B2, FH_FLAGS, FH_MLP0,   //
        FH_RES = 8 + 3 * FS_MAXN,         // bwd: dX_{l+1}[n] flows into dX_l[n] through the residual
        FH_SLOTA = 8 + 4 * FS_MAXN,       // slab kernels: node of accumulator slot u of group A / group B (-1: unused)
        FH_SLOTB = FH_SLOTA + 16,
-       FH_SIZE = FH_SLOTB + 16 };
+       FH_SIZE = FH_SLOTB + 16,
+       FH_NEXT = FH_SLOTA };             // engine-driven kernels (their header copy has no slot arrays).  bwd: NK_* | residual << 2 of node n in layer l - 1;
+                                         // fwd: [0, 4) bias row of type t in this layer, [4, 8) in the next layer, [8, 28) type of node n
+static_assert(FH_NEXT + 8 + 20 <= FH_SIZE && MSHGNN_MAX_TYPES <= 4, "header: next-layer array");
 // Slab variant of the stack kernels (4-wave workgroups, two per CU): wave wn owns columns [32 wn, 32 wn + 32) of EVERY node, so
 // a weight pack goes through the CU's vector L1 once per tile instead of once per wave half (the stack kernels' MAC phase is
 // bound by that path: DESIGN.md section 6).  To keep the accumulators in registers the destination nodes are processed in two
@@ -610,9 +613,24 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
         // segments << 16 | first body << 24].
         p.wide = !p.split && p.NN <= WD_MAXN && (int64_t)p.NN * 2 * p.blk_bytes <= LDS_LIMIT;
         p.slab2 = !p.split && p.NN <= S2_MAXN && 2 * (int64_t)p.NN * p.blk_bytes <= LDS_LIMIT;
-        auto emit_wide = [&](const std::vector<Seg>& segs_in, int hdr_src, int nbuf, bool& avail) {
+        const int bias_zero = add_bias(p, {});      // a row of zeros: the accumulators of dead nodes start there (no select in the kernel)
+        auto emit_wide = [&](const std::vector<Seg>& segs_in, int hdr_src, int nbuf, bool& avail, int l, bool bwd) {
             const int h = (int)T.size(); T.resize(T.size() + FH_SIZE, 0);
             for (int i = 0; i < FH_SIZE; ++i) T[h + i] = T[hdr_src + i];
+            for (int i = 0; i < 32; ++i) T[h + FH_NEXT + i] = 0;
+            for (int n = 0; n < p.NN && n < WD_MAXN; ++n) {
+                const int t = p.node_type[n];
+                if (!bwd) { if (!p.live[l][t]) T[h + FH_BIAS + n] = bias_zero; T[h + FH_NEXT + 8 + n] = t; }
+                else if (l > 0) {
+                    const int kind = !p.live[l - 1][t] ? NK_DEAD : ((has_mlp && t == d.mlp_type) ? NK_MLP : NK_RELU);
+                    T[h + FH_NEXT + n] = kind | ((residual && p.live[l - 1][t] && p.need_dx[l - 1][t]) ? 4 : 0);
+                }
+            }
+            if (!bwd)      // forward: bias row of every node type in this layer and in the next one (the kernel keeps a layer's rows in LDS), type of node n
+                for (int t = 0; t < 4; ++t) {
+                    T[h + FH_NEXT + t] = (t < NT && p.live[l][t]) ? p.bias_layer[l * NT + t] : bias_zero;
+                    T[h + FH_NEXT + 4 + t] = (t < NT && l + 1 < L && p.live[l + 1][t]) ? p.bias_layer[(l + 1) * NT + t] : bias_zero;
+                }
             const int idx_issue = nbuf * WD_MAXN, idx_noissue = idx_issue + nbuf, idx_last = idx_noissue + 1, idx_exit = idx_last + 1;
             std::vector<Seg> segs;
             for (const Seg& sg : segs_in) if (!sg.macs.empty()) segs.push_back(sg);
@@ -675,8 +693,8 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
                 T[fh + FH_NSEG] = (int)segs.size();
                 emit_fused(segs);
                 if (p.fused && p.slab) p.sl_fwd_off[l] = emit_slab(segs, fh);
-                if (p.fused && p.wide) p.wd_fwd_off[l] = emit_wide(segs, fh, 3, p.wide);
-                if (p.fused && p.slab2) p.s2_fwd_off[l] = emit_wide(segs, fh, 2, p.slab2);
+                if (p.fused && p.wide) p.wd_fwd_off[l] = emit_wide(segs, fh, 3, p.wide, l, false);
+                if (p.fused && p.slab2) p.s2_fwd_off[l] = emit_wide(segs, fh, 2, p.slab2, l, false);
             }
             if (!p.fused) break;
             // backward
@@ -712,8 +730,8 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
                 T[bh2 + FH_NSEG] = (int)segs.size();
                 emit_fused(segs);
                 if (p.fused && p.slab) p.sl_bwd_off[l] = emit_slab(segs, bh2);
-                if (p.fused && p.wide) p.wd_bwd_off[l] = emit_wide(segs, bh2, 3, p.wide);
-                if (p.fused && p.slab2) p.s2_bwd_off[l] = emit_wide(segs, bh2, 2, p.slab2);
+                if (p.fused && p.wide) p.wd_bwd_off[l] = emit_wide(segs, bh2, 3, p.wide, l, true);
+                if (p.fused && p.slab2) p.s2_bwd_off[l] = emit_wide(segs, bh2, 2, p.slab2, l, true);
             }
         }
         if (!p.fused) p.slab = p.wide = p.slab2 = false;

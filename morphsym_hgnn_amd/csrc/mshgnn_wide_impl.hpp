@@ -23,6 +23,9 @@ namespace {
 using T = __bf16;
 using P = Prec<__bf16>;
 template <int NH> constexpr int WD_BLKB = NH * P::BLK;      // LDS bytes of one node: NH 16-window halves
+// <= 18 nodes: a layer's bias rows (one per node type, this wave's 32 columns) wait in LDS behind the node blocks; the accumulators start from there
+// without a global round trip, and the next layer's rows are requested right after the MAC engine, together with its header
+constexpr int WD_LDSBIAS_MAXN = 18, WD_BIAS_LDS = 4 * 4 * 128;
 #define WD_KERNEL(NH) __global__ __launch_bounds__(WD_THREADS, (NH) == 2 ? 1 : 2)
 
 // ---- accumulator accessors: register (slot S, half H, element E of 8).  Every statement names the value that holds the slot as an operand pinned to
@@ -64,9 +67,19 @@ template <int NH, int S, int H> __device__ __forceinline__ void wd_acc_get(WRegs
     a.c[0] = f32x4{wd_acc_get1<NH, S, H, 0>(r), wd_acc_get1<NH, S, H, 1>(r), wd_acc_get1<NH, S, H, 2>(r), wd_acc_get1<NH, S, H, 3>(r)};
     a.c[1] = f32x4{wd_acc_get1<NH, S, H, 4>(r), wd_acc_get1<NH, S, H, 5>(r), wd_acc_get1<NH, S, H, 6>(r), wd_acc_get1<NH, S, H, 7>(r)};
 }
+// (one statement for the eight registers of a (slot, half): element-wise statements leave hipcc's coalescer sixteen tied copies of the same
+//  16 NH-register value per slot pair, and where it gives up it parks whole accumulator tuples in scratch)
 template <int NH, int S, int H> __device__ __forceinline__ void wd_acc_set(WRegs<NH>& r, f32x4 c0, f32x4 c1) {
-    wd_acc_set1<NH, S, H, 0>(r, c0[0]); wd_acc_set1<NH, S, H, 1>(r, c0[1]); wd_acc_set1<NH, S, H, 2>(r, c0[2]); wd_acc_set1<NH, S, H, 3>(r, c0[3]);
-    wd_acc_set1<NH, S, H, 4>(r, c1[0]); wd_acc_set1<NH, S, H, 5>(r, c1[1]); wd_acc_set1<NH, S, H, 6>(r, c1[2]); wd_acc_set1<NH, S, H, 7>(r, c1[3]);
+    constexpr int K = wd_tuple_of<NH, S>(), IDX = wd_reg_of<NH, S, H, 0>();
+#define WD_X(KK, REG) if constexpr (K == KK) { \
+        if constexpr (S < 16) asm("v_accvgpr_write_b32 a[%c1], %2\n v_accvgpr_write_b32 a[%c1+1], %3\n v_accvgpr_write_b32 a[%c1+2], %4\n v_accvgpr_write_b32 a[%c1+3], %5\n" \
+                                  "v_accvgpr_write_b32 a[%c1+4], %6\n v_accvgpr_write_b32 a[%c1+5], %7\n v_accvgpr_write_b32 a[%c1+6], %8\n v_accvgpr_write_b32 a[%c1+7], %9" \
+                                  : "+{" REG "}"(wd_tuple<NH, KK>(r)) : "i"(IDX), "v"(c0[0]), "v"(c0[1]), "v"(c0[2]), "v"(c0[3]), "v"(c1[0]), "v"(c1[1]), "v"(c1[2]), "v"(c1[3])); \
+        else asm("v_mov_b32 v[%c1], %2\n v_mov_b32 v[%c1+1], %3\n v_mov_b32 v[%c1+2], %4\n v_mov_b32 v[%c1+3], %5\n v_mov_b32 v[%c1+4], %6\n v_mov_b32 v[%c1+5], %7\n" \
+                 "v_mov_b32 v[%c1+6], %8\n v_mov_b32 v[%c1+7], %9" \
+                 : "+{" REG "}"(wd_tuple<NH, KK>(r)) : "i"(IDX), "v"(c0[0]), "v"(c0[1]), "v"(c0[2]), "v"(c0[3]), "v"(c1[0]), "v"(c1[1]), "v"(c1[2]), "v"(c1[3])); }
+    if constexpr (NH == 2) { WD_TUPLES2(WD_X) } else { WD_TUPLES1(WD_X) }
+#undef WD_X
 }
 // all halves of a slot at once
 template <int NH, int S> __device__ __forceinline__ void wd_acc_get_all(WRegs<NH>& r, P::Acc (&c)[NH]) {
@@ -87,11 +100,15 @@ struct WProg {
     int prog, pk, misc;
     __device__ __forceinline__ WProg() : prog(0), pk(0), misc(0) {}
     __device__ __forceinline__ WProg(const int* t, int lane) : prog(t[lane]), pk(t[64 + lane]), misc(t[128 + lane]) {}
+    __device__ __forceinline__ void settle() { asm volatile("" : "+v"(prog), "+v"(pk), "+v"(misc)); }      // see FProg::settle
 };
-template <int NH, int NS> __device__ __forceinline__ void wd_run(WRegs<NH>& r, const WProg& wp, const char* smem, const T* wpack, int wn, int lane, const AOff<T>& ao) {
+// hdr1 / bbase / init: forward layers whose bias rows wait in LDS (k_eng_fwd) let the engine start the accumulators from them
+template <int NH, int NS> __device__ __forceinline__ void wd_run(WRegs<NH>& r, const WProg& wp, const char* smem, const T* wpack, int wn, int lane, const AOff<T>& ao,
+                                                                 int hdr1 = 0, int bbase = 0, int init = 0) {
+    static_assert(FH_NEXT + 8 - 64 == 32, "tools/gen_wide_engine.py: HDR_TYPE_LANE");
     const int m = __builtin_amdgcn_readlane(wp.misc, 0);
     wd_engine<NH, NS>(r, wp.prog, wp.pk, lane * 16, ao.o, reinterpret_cast<const char*>(wpack) + wn * (P::NBV * 64 * 16), (m & 0xff) * WD_BLKB<NH>,
-                      ((m >> 8) & 0xff) * WD_BLKB<NH>, (m >> 16) & 0xff, (m >> 24) & 0xff);
+                      ((m >> 8) & 0xff) * WD_BLKB<NH>, (m >> 16) & 0xff, (m >> 24) & 0xff, hdr1, bbase, init);
 }
 
 template <int NH> __device__ __forceinline__ int wd_chunk(int node, int h, int row16, int c) { return node * WD_BLKB<NH> + lds_chunk<T>(h, row16, c); }
@@ -310,47 +327,66 @@ template <int NH, int NS, int NM, int DMAX> WD_KERNEL(NH) void k_eng_fwd(StackAr
                     if (n0 + i < NN) *reinterpret_cast<u32x4*>(smem + wd_chunk<NH>(n0 + i, h, row16, c)) = v[i][h];
         }
     }
+    constexpr bool LB = NS <= WD_LDSBIAS_MAXN;
+    const int bsm = NN * BLKB + wn * 512;      // this wave's bias rows: [type][32 floats]
+    // lanes 0..31: 16-byte chunk (lane & 7) of the row of type (lane >> 3); rows named by four consecutive header entries
+    auto bias_fetch = [&](const FHdr& h, int base) {
+        const int t = (lane >> 3) & 3, r0 = h[base], r1 = h[base + 1], r2 = h[base + 2], r3 = h[base + 3];
+        const int row = t == 0 ? r0 : t == 1 ? r1 : t == 2 ? r2 : r3;
+        return *reinterpret_cast<const f32x4*>(a.bias + (size_t)row * H + wn * 32 + (lane & 7) * 4);
+    };
+    auto bias_put = [&](f32x4 v) { if (lane < 32) *reinterpret_cast<f32x4*>(smem + bsm + (lane >> 3) * 128 + (lane & 7) * 16) = v; };
+    fhn.settle(); wpn.settle();
+    if constexpr (LB) bias_put(bias_fetch(fhn, FH_NEXT));
     __syncthreads();
     FS_STAMP(1);
 
     for (int l = 0; l < a.L; ++l) {
         const FHdr fh = fhn;
         const WProg wp = wpn;
-        if (l + 1 < a.L) {    // the next layer's header and program stream in under this layer's MACs
-            fhn = FHdr(a.tables + a.prog_off[l + 1], lane);
-            wpn = WProg(a.tables + a.prog_off[l + 1] + FH_SIZE, lane);
-        }
         const int nmlp = fh[FH_NMLP];
         const bool residual = (fh[FH_FLAGS] & FF_RESIDUAL) != 0;
+        if constexpr (!LB) {
         // accumulators start at the bias row of their node's type; the rows of six nodes are requested before the first of their accumulators is
-        // written (three memory round trips per layer instead of one per node; row 0 stands in for dead nodes, whose accumulators start at zero)
-        wd_for<0, (NS + 5) / 6>([&](auto gc) {
-            constexpr int G = decltype(gc)::value;
-            f32x4 bv[6][2];
+            // written (three memory round trips per layer instead of one per node; dead nodes: their header entry names the plan's row of zeros, the select
+            // below is kept because the straight-line version makes hipcc park finished accumulator tuples in scratch)
+            wd_for<0, (NS + 5) / 6>([&](auto gc) {
+                constexpr int G = decltype(gc)::value;
+                f32x4 bv[6][2];
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const int u = 6 * G + i;
-                const bool live = u < NN && u < NS && fh[FH_KIND + (u < NS ? u : 0)] != NK_DEAD;
-                const float* bias = a.bias + (size_t)(live ? fh[FH_BIAS + (u < NS ? u : 0)] : 0) * H + wn * 32;
-                bv[i][0] = *reinterpret_cast<const f32x4*>(bias + c_feat(0, lane)); bv[i][1] = *reinterpret_cast<const f32x4*>(bias + c_feat(1, lane));
-            }
-            wd_for<0, 6>([&](auto ic) {
-                constexpr int I = decltype(ic)::value, U = 6 * G + I;
-                if constexpr (U < NS) {
-                    const bool live = U < NN && fh[FH_KIND + U] != NK_DEAD;
-                    const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
-                    f32x4 b0[NH], b1[NH];
-#pragma unroll
-                    for (int h = 0; h < NH; ++h) { b0[h] = live ? bv[I][0] : z; b1[h] = live ? bv[I][1] : z; }
-                    wd_acc_set_all<NH, U>(R, b0, b1);
+                for (int i = 0; i < 6; ++i) {
+                    const int u = 6 * G + i;
+                    const bool live = u < NN && u < NS && fh[FH_KIND + (u < NS ? u : 0)] != NK_DEAD;
+                    const float* bias = a.bias + (size_t)(live ? fh[FH_BIAS + (u < NS ? u : 0)] : 0) * H + wn * 32;
+                    bv[i][0] = *reinterpret_cast<const f32x4*>(bias + c_feat(0, lane)); bv[i][1] = *reinterpret_cast<const f32x4*>(bias + c_feat(1, lane));
                 }
+                wd_for<0, 6>([&](auto ic) {
+                    constexpr int I = decltype(ic)::value, U = 6 * G + I;
+                    if constexpr (U < NS) {
+                        const bool live = U < NN && fh[FH_KIND + U] != NK_DEAD;
+                        const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+                        f32x4 b0[NH], b1[NH];
+#pragma unroll
+                        for (int h = 0; h < NH; ++h) { b0[h] = live ? bv[I][0] : z; b1[h] = live ? bv[I][1] : z; }
+                        wd_acc_set_all<NH, U>(R, b0, b1);
+                    }
+                });
             });
-        });
+        }
         FS_STAMP(20 + l);
         {   // (fragment offsets rebuilt where they are used: four registers that would otherwise be carried -- spilled -- across the engine)
             const AOff<T> ao(opaque(lane));
-            wd_run<NH, NS>(R, wp, smem, wpack, wn, lane, ao);
+            // <= 18 nodes: the engine itself starts the accumulators from this wave's bias rows in LDS (row of type t at bsm + 128 t)
+            if constexpr (LB) wd_run<NH, NS>(R, wp, smem, wpack, wn, lane, ao, fh.h1, bsm + c_oct(opaque(lane)) * 4, 1);      // (the dynamic LDS segment starts at address 0, as for the block offsets)
+            else wd_run<NH, NS>(R, wp, smem, wpack, wn, lane, ao);
         }
+        if (l + 1 < a.L) {    // the next layer's header and program: requested here, so that they do not live (spilled, one serialised round trip each) across the
+                              // MAC engine, and settled before the epilogue's first store
+            fhn = FHdr(a.tables + a.prog_off[l + 1], lane);
+            wpn = WProg(a.tables + a.prog_off[l + 1] + FH_SIZE, lane);
+        }
+        f32x4 brow = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (LB) brow = bias_fetch(fh, FH_NEXT + 4);      // the next layer's bias rows (this wave's copy is read only by this wave: no barrier)
         FS_STAMP(2 + 4 * l);
         __syncthreads();   // every wave is done reading X_l: the node blocks may be overwritten
         FS_STAMP(3 + 4 * l);
@@ -386,6 +422,8 @@ template <int NH, int NS, int NM, int DMAX> WD_KERNEL(NH) void k_eng_fwd(StackAr
                 }
             });
         }
+        fhn.settle(); wpn.settle();
+        if constexpr (LB) bias_put(brow);
         // X_{l+1}[n] = relu(H[n]) (+ X_l[n]) for the relu nodes, in place; stash + relu bytes on the side.  Six nodes at a time: their residual octets
         // are read before the first write of the group (the compiler cannot move an LDS read above an LDS write that may alias it)
         wd_for<0, (NS + 5) / 6>([&](auto gc) {
@@ -532,14 +570,11 @@ template <int NH, int NS, int NM> WD_KERNEL(NH) void k_eng_bwd(StackArgs a) {
         });
     }
     __syncthreads();
+    bhn.settle(); wpn.settle();
 
     for (int l = a.L - 1; l >= 0; --l) {
         const FHdr bh = bhn;
         const WProg wp = wpn;
-        if (l > 0) {
-            bhn = FHdr(a.tables + a.prog_off[l - 1], lane);
-            wpn = WProg(a.tables + a.prog_off[l - 1] + FH_SIZE, lane);
-        }
         const int nmlp = bh[FH_NMLP], flags = bh[FH_FLAGS];
         const bool enc_mask = (flags & FF_ENC_MASK) != 0;
         int lq = opaque(lane);
@@ -605,50 +640,51 @@ template <int NH, int NS, int NM> WD_KERNEL(NH) void k_eng_bwd(StackArgs a) {
             const AOff<T> ao(opaque(lane));
             wd_run<NH, NS>(R, wp, smem, wpack, wn, lane, ao);
         }
+        if (l > 0) {          // the next layer's header and program (not carried across the MAC engine; what this epilogue needs of the next layer is in bh[FH_NEXT])
+            bhn = FHdr(a.tables + a.prog_off[l - 1], lane);
+            wpn = WProg(a.tables + a.prog_off[l - 1] + FH_SIZE, lane);
+        }
         __syncthreads();   // every wave is done reading dH_l
         lq = opaque(lane); win = c_win(lq); col = wn * 32 + c_oct(lq); loff = lds_chunk<T>(0, win, col / P::EPC);      // (rebuilt: nothing derived from them lives across the MAC phase)
         T* dxo = reinterpret_cast<T*>(a.ws + a.dx_off[l]);
         const uint8_t* mbytes = reinterpret_cast<const uint8_t*>(a.ws + (l > 0 ? a.mask_off[l - 1] : a.mask0_off));
-        // six nodes at a time: the relu bytes of the next layer's mask (layer 0: the encoder activation's) are requested before the group's stores
-        wd_for<0, (NS + 5) / 6>([&](auto gc) {
-            constexpr int G = decltype(gc)::value;
-            unsigned mb[6][NH];
+        // the relu bytes of the next layer's mask (layer 0: the encoder activation's) of every node are requested before the first store: one round trip
+        // per layer, which also brings the next header and program in
+        unsigned mb[NS][NH];
+        wd_for<0, NS>([&](auto uc) {
+            constexpr int U = decltype(uc)::value;
+            const bool outp = U < NN && bh[FH_OUT + U] != 0;
+            const bool want = outp && (l > 0 ? (bh[FH_NEXT + U] & 3) == NK_RELU : enc_mask);
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const int u = 6 * G + i, uc = u < NS ? u : 0;
-                const bool outp = u < NN && u < NS && bh[FH_OUT + uc] != 0;
-                const bool want = outp && (l > 0 ? bhn[FH_KIND + uc] == NK_RELU : enc_mask);
+            for (int h = 0; h < NH; ++h) {
+                mb[U][h] = 0xffu;
+                if (want && w0 + 16 * h < B) mb[U][h] = mbytes[relu_tile_base(U, B, NH * blockIdx.x + h, wn) + lane];
+            }
+        });
+        bhn.settle(); wpn.settle();
+        wd_for<0, NS>([&](auto uc) {
+            constexpr int U = decltype(uc)::value;
+            const bool outp = U < NN && bh[FH_OUT + U] != 0;
+            const int nx = (l > 0 && U < NN) ? bh[FH_NEXT + U] : 0;
+            const int nkind = nx & 3;
+            const bool nres = nkind != NK_DEAD && (nx & 4) != 0;
+            f32x4 n0[NH], n1[NH];
+#pragma unroll
+            for (int h = 0; h < NH; ++h) n0[h] = n1[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (outp) {
+                P::Acc c[NH]; wd_acc_get_all<NH, U>(R, c);
 #pragma unroll
                 for (int h = 0; h < NH; ++h) {
-                    mb[i][h] = 0xffu;
-                    if (want && w0 + 16 * h < B) mb[i][h] = mbytes[relu_tile_base(u, B, NH * blockIdx.x + h, wn) + lane];
+                    u32x4 pk = pack_oct(c[h].c[0], c[h].c[1]);
+                    if (l == 0 && enc_mask) pk = chunk_mask_bits<T>(pk, mb[U][h]);
+                    const int w = w0 + 16 * h + win;
+                    if (w < B) *reinterpret_cast<u32x4*>(dxo + act_idx(w, U, B) + col) = pk;
+                    if (nkind != NK_DEAD)
+                        *reinterpret_cast<u32x4*>(smem + U * BLKB + h * P::BLK + loff) = nkind == NK_RELU ? chunk_mask_bits<T>(pk, mb[U][h]) : pk;
+                    if (nres) unpack_oct(pk, n0[h], n1[h]);
                 }
             }
-            wd_for<0, 6>([&](auto ic) {
-                constexpr int I = decltype(ic)::value, U = 6 * G + I;
-                if constexpr (U < NS) {
-                    const bool outp = U < NN && bh[FH_OUT + U] != 0;
-                    const int nkind = (l > 0 && U < NN) ? bhn[FH_KIND + U] : NK_DEAD;
-                    const bool nres = l > 0 && U < NN && nkind != NK_DEAD && bhn[FH_RES + U] != 0;
-                    f32x4 n0[NH], n1[NH];
-#pragma unroll
-                    for (int h = 0; h < NH; ++h) n0[h] = n1[h] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (outp) {
-                        P::Acc c[NH]; wd_acc_get_all<NH, U>(R, c);
-#pragma unroll
-                        for (int h = 0; h < NH; ++h) {
-                            u32x4 pk = pack_oct(c[h].c[0], c[h].c[1]);
-                            if (l == 0 && enc_mask) pk = chunk_mask_bits<T>(pk, mb[I][h]);
-                            const int w = w0 + 16 * h + win;
-                            if (w < B) *reinterpret_cast<u32x4*>(dxo + act_idx(w, U, B) + col) = pk;
-                            if (nkind != NK_DEAD)
-                                *reinterpret_cast<u32x4*>(smem + U * BLKB + h * P::BLK + loff) = nkind == NK_RELU ? chunk_mask_bits<T>(pk, mb[I][h]) : pk;
-                            if (nres) unpack_oct(pk, n0[h], n1[h]);
-                        }
-                    }
-                    if (l > 0) wd_acc_set_all<NH, U>(R, n0, n1);
-                }
-            });
+            if (l > 0) wd_acc_set_all<NH, U>(R, n0, n1);
         });
         __syncthreads();
     }
@@ -670,7 +706,7 @@ template <int NH, int NS, int NM> int launch_pair(const HostPlan& hp, const Stac
 // The instantiations are spread over three translation units (compile time: the asm engines are 8-10 k lines each):
 //   WD_PART 0: wide geometry, <= 18 nodes (+ the wide entry points)   1: wide geometry, 19-20 nodes   2: slab2 geometry (+ its entry points)
 template <int NH, int NSLO, int NSHI> int dispatch(const HostPlan& hp, const StackArgs& a, bool bwd, int tiles, hipStream_t st, bool set_attr) {
-    const int lds = hp.NN * WD_BLKB<NH>;
+    const int lds = hp.NN * WD_BLKB<NH> + (hp.NN <= WD_LDSBIAS_MAXN ? WD_BIAS_LDS : 0);
     const bool nm2 = hp.n_mlp <= 2;
 #ifdef WD_ONLY18
     if constexpr (NSLO <= 18 && NSHI >= 18) return launch_one<NH, 18, 2, 4>(a, bwd, tiles, lds, st, set_attr);

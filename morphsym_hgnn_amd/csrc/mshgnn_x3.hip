@@ -311,6 +311,7 @@ template <bool ALIAS> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
     P::Acc acc[FS_HS];
     FHdr fhn(a.tables + a.prog_off[0], lane);
     FProg wpn(a.tables + a.prog_off[0] + FH_SIZE + wh * FPROG_LEN, lane);
+    fhn.settle(); wpn.settle();
     for (int l = 0; l < a.L; ++l) {
         const FHdr fh = fhn;
         const FProg wp = wpn;
@@ -387,6 +388,7 @@ template <bool ALIAS> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
         FS_STAMP(16 + l);
         // every load issued so far has landed before the first store of the epilogue goes out
         __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));
+        fhn.settle(); wpn.settle();      // (FProg::settle: no vmcnt(0) for them at the top of the next layer)
         if (nmlp > 0 && train && w_ok) {
             T* hb = reinterpret_cast<T*>(a.ws + a.hb_off[l]);
             T* t1 = reinterpret_cast<T*>(a.ws + a.t1_off[l]);
@@ -476,6 +478,7 @@ __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_bwd_x3(StackArgs a) 
     P::Acc acc[FS_HS];
     FHdr bhn(a.tables + a.prog_off[a.L - 1], lane);
     FProg wpn(a.tables + a.prog_off[a.L - 1] + FH_SIZE + wh * FPROG_LEN, lane);
+    bhn.settle(); wpn.settle();
     for (int l = a.L - 1; l >= 0; --l) {
         const FHdr bh = bhn;
         const FProg wp = wpn;
@@ -585,6 +588,7 @@ __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_bwd_x3(StackArgs a) 
 
         T* dxo = reinterpret_cast<T*>(a.ws + a.dx_off[l]);
         const uint8_t* m0 = reinterpret_cast<const uint8_t*>(a.ws + a.mask0_off);
+        bhn.settle(); wpn.settle();      // next header / program landed before the stores go out (FProg::settle)
         // layer 0: the encoder's relu bytes of every node are requested before the first store of the epilogue (one round trip; a load waited for
         // while stores are in flight drains them all)
         unsigned xbv[FS_HS];

@@ -10,8 +10,8 @@ n_y = spec.out_channels * spec.num_nodes[spec.out_type]
 x_dict, y = synth.make_windows(5, B, spec.num_nodes, spec.widths, n_y)
 params = synth.make_params(5, spec.param_shapes())
 res = {}
-for mode, (wide, slab) in {"wide": ("2", "2"), "8wave": ("0", "0")}.items():
-    os.environ["MSHGNN_WIDE"] = wide; os.environ["MSHGNN_SLAB"] = slab
+for mode, (wide, slab2, slab) in {"wide": ("2", "0", "2"), "slab2": ("0", "2", "2"), "8wave": ("0", "0", "0")}.items():
+    os.environ["MSHGNN_WIDE"] = wide; os.environ["MSHGNN_SLAB2"] = slab2; os.environ["MSHGNN_SLAB"] = slab
     e = eng.Engine(spec, "bf16")
     xs = e.cast_inputs(x_dict); yd = y.reshape(-1).to(e.device, torch.float32); flat = eng.flatten_params(spec, params, e.device)
     e.workspace(B).zero_()
@@ -23,10 +23,13 @@ for mode, (wide, slab) in {"wide": ("2", "2"), "8wave": ("0", "0")}.items():
         st[f"dx{l}"] = e.grad_hidden(B, l).clone()
     res[mode] = st
 NN = sum(spec.num_nodes.values())
-for k in res["wide"]:
-    a, b = res["wide"][k].float(), res["8wave"][k].float()
+for mode in ("wide", "slab2"):
+  print("==", mode)
+  for k in res[mode]:
+    a, b = res[mode][k].float(), res["8wave"][k].float()
     if torch.equal(a, b): print(k, "equal"); continue
     d = (a - b).abs()
-    if k in ("out", "g"): print(k, "DIFF max", float(d.max())); continue
+    if k in ("out", "g"): print(k, "DIFF max", float(d.max()), "elements", int((d > 0).sum())); continue
     per_node = d.amax(dim=(0, 2))
-    print(k, "DIFF per node:", [round(float(v), 4) for v in per_node])
+    wins = (d.amax(dim=(1, 2)) > 0).nonzero().flatten()
+    print(k, "DIFF per node:", [round(float(v), 4) for v in per_node], "windows:", wins[:8].tolist(), "...", int(wins.numel()))

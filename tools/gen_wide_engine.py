@@ -24,6 +24,7 @@ accessors of mshgnn_wide.hip.  The engine's own vector registers (weight buffers
 import os
 
 NSLOT_T = 20            # table stride of the slot bodies per weight buffer
+HDR_TYPE_LANE = 32      # FH_NEXT + 8 - 64 (mshgnn_plan.hpp): lane of the header's second register that holds the type of node 0
 BODY = 512              # bytes per table entry
 
 
@@ -150,7 +151,9 @@ def sw_body(g, kind, buf=0):
 def engine_text(g, ns):
     L = []
     a = L.append
-    a("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    # (no vmcnt wait here: the fragment loads below are requested behind whatever the epilogue before this statement still has in flight, and the first
+    #  switch's counted wait covers both -- memory operations retire in order)
+    a("s_waitcnt lgkmcnt(0)")
     a("s_getpc_b64 %[tb]")
     a("L_pc%=:")
     a("s_add_u32 %[tblo], %[tblo], L_table%=-L_pc%=")
@@ -165,6 +168,18 @@ def engine_text(g, ns):
         L += frag_loads(g, s)
     a("L_pre%=:")
     a(f"s_mov_b32 %[seg], {g.nbuf - 1}")
+    # forward layers (init != 0): the accumulators start at the bias row of their node's type, straight from this wave's rows in LDS into the
+    # accumulator registers (lane HDR_TYPE_LANE + slot of the header's second register = type of the node; 128 bytes per type), under the fragment loads
+    a("s_cmp_eq_u32 %[init], 0")
+    a("s_cbranch_scc1 L_noinit%=")
+    for u in range(ns):
+        a(f"v_readlane_b32 %[t0], %[hdr1], {HDR_TYPE_LANE + u}")
+        a("s_lshl_b32 %[t0], %[t0], 7")
+        a("v_add_u32 %[va0], %[t0], %[bbase]")
+        for h in range(g.nh):
+            for fb in range(2):
+                a(f"ds_read_b128 {g.acc(u, h, fb)}, %[va0]" + (" offset:16" if fb else ""))
+    a("L_noinit%=:")
     # window fragment of MAC 0, addresses of MAC 1's
     for t in range(4):
         a(f"v_add_u32 %[va{t}], %[blk0], %[ao{t}]")
@@ -215,7 +230,7 @@ def emit(g, ns):
         text = [t.replace(k, v) for t in text]
     text = [t.replace("%[blksh]", str(12 + (g.nh - 1))) for t in text]      # LDS block of a node: NH x 4 KB
     s = []
-    s.append(f"template <> __device__ __forceinline__ void wd_engine<{g.nh}, {ns}>(WRegs<{g.nh}>& r, int prog, int pk, int lane16, const int (&ao)[4], const void* wfrag, int blk0, int blk1, int nseg, int first) {{")
+    s.append(f"template <> __device__ __forceinline__ void wd_engine<{g.nh}, {ns}>(WRegs<{g.nh}>& r, int prog, int pk, int lane16, const int (&ao)[4], const void* wfrag, int blk0, int blk1, int nseg, int first, int hdr1, int bbase, int init) {{")
     s.append("    int va0, va1, va2, va3;")
     s.append("    const unsigned wlo = (unsigned)(unsigned long long)wfrag, whi = (unsigned)((unsigned long long)wfrag >> 32);")
     s.append("    asm volatile(")
@@ -224,7 +239,7 @@ def emit(g, ns):
     s.append('        : [va0] "=&v"(va0), [va1] "=&v"(va1), [va2] "=&v"(va2), [va3] "=&v"(va3),')
     s.append("          " + ", ".join(f'"+{{{reg}}}"({name})' for name, reg in g.tuples(ns)))
     s.append('        : [prog] "v"(prog), [pk] "v"(pk), [lane16] "v"(lane16), [ao0] "v"(ao[0]), [ao1] "v"(ao[1]), [ao2] "v"(ao[2]), [ao3] "v"(ao[3]), [wlo] "s"(wlo), [whi] "s"(whi),')
-    s.append('          [blk0] "s"(blk0), [blk1] "s"(blk1), [nseg] "s"(nseg), [first] "s"(first)')
+    s.append('          [blk0] "s"(blk0), [blk1] "s"(blk1), [nseg] "s"(nseg), [first] "s"(first), [hdr1] "v"(hdr1), [bbase] "v"(bbase), [init] "s"(init)')
     s.append("        : " + ", ".join(f'"{c}"' for c in clobbers(g)) + ");")
     s.append("}")
     return "\n".join(s)
@@ -239,7 +254,7 @@ typedef float wd_f32x16 __attribute__((ext_vector_type(16)));
 template <int NH> struct WRegs;
 template <> struct WRegs<2> { wd_f32x32 a[8]; wd_f32x32 v[2]; };
 template <> struct WRegs<1> { wd_f32x16 a[8]; wd_f32x16 v[1]; };
-template <int NH, int NS> __device__ __forceinline__ void wd_engine(WRegs<NH>& r, int prog, int pk, int lane16, const int (&ao)[4], const void* wfrag, int blk0, int blk1, int nseg, int first);
+template <int NH, int NS> __device__ __forceinline__ void wd_engine(WRegs<NH>& r, int prog, int pk, int lane16, const int (&ao)[4], const void* wfrag, int blk0, int blk1, int nseg, int first, int hdr1, int bbase, int init);
 '''
 
 
