@@ -888,6 +888,9 @@ template <typename T, int NM, int HB> __global__ __launch_bounds__(SL_THREADS, 2
     stack_stagger(a);
     FS_STAMP(0);
 
+    // layer 0's header and programs stream in under the tile load
+    FHdr fhn(a.tables + a.prog_off[0], lane);
+    FProg wan(a.tables + a.prog_off[0] + FH_SIZE, lane), wbn(a.tables + a.prog_off[0] + FH_SIZE + FPROG_LEN, lane);
     {   // X_0 tile -> LDS: thread = (row, 16-byte chunk), one node per pass, 6 loads in flight
         const T* src = reinterpret_cast<const T*>(a.tile_in);
         const int row = tid >> 4, c = tid & 15;
@@ -907,8 +910,6 @@ template <typename T, int NM, int HB> __global__ __launch_bounds__(SL_THREADS, 2
     __syncthreads();
     FS_STAMP(1);
 
-    FHdr fhn(a.tables + a.prog_off[0], lane);
-    FProg wan(a.tables + a.prog_off[0] + FH_SIZE, lane), wbn(a.tables + a.prog_off[0] + FH_SIZE + FPROG_LEN, lane);
     fhn.settle(); wan.settle(); wbn.settle();      // (waited for here, not by a vmcnt(0) at the top of every layer)
     for (int l = 0; l < a.L; ++l) {
         const FHdr fh = fhn;
@@ -1167,40 +1168,45 @@ template <typename T, int NM, int HB> __global__ __launch_bounds__(SL_THREADS, 2
     static_assert(sizeof(T) == 2, "fused stack kernels are bf16");
     stack_stagger(a);
 
-    // dX_L tile: only the nodes that are live in the last layer carry a gradient
+    // the last layer's header and programs stream in under the tile load
+    FHdr bhn(a.tables + a.prog_off[a.L - 1], lane);
+    FProg wan(a.tables + a.prog_off[a.L - 1] + FH_SIZE, lane), wbn(a.tables + a.prog_off[a.L - 1] + FH_SIZE + FPROG_LEN, lane);
+    // dX_L tile: only the nodes that are live in the last layer carry a gradient -- the output type's [node0, node0 + n_out), known from the arguments, so
+    // the loads do not wait for the header; four nodes per round trip
     {
-        const FHdr bh(a.tables + a.prog_off[a.L - 1], lane);
         const T* src = reinterpret_cast<const T*>(a.tile_in);
         const int row = tid >> 4, c = tid & 15;
-        for (int q = 0; q < SL_HA + HB; ++q) {
-            const int n = bh[(q < SL_HA ? FH_SLOTA : FH_SLOTB - SL_HA) + q];
-            if (n < 0 || bh[FH_KIND + q] == NK_DEAD) continue;
-            u32x4 v = u32x4{0, 0, 0, 0};
-            if (w0 + row < B) v = *reinterpret_cast<const u32x4*>(src + act_idx(w0 + row, n, B) + c * P::EPC);
-            *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(n, row, c)) = v;
+        for (int f0 = 0; f0 < a.n_out; f0 += 4) {
+            u32x4 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i] = u32x4{0, 0, 0, 0};
+                if (f0 + i < a.n_out && w0 + row < B) v[i] = *reinterpret_cast<const u32x4*>(src + act_idx(w0 + row, a.node0 + f0 + i, B) + c * P::EPC);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (f0 + i < a.n_out) *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(a.node0 + f0 + i, row, c)) = v[i];
         }
     }
     __syncthreads();
 
-    FHdr bhn(a.tables + a.prog_off[a.L - 1], lane);
-    FProg wan(a.tables + a.prog_off[a.L - 1] + FH_SIZE, lane), wbn(a.tables + a.prog_off[a.L - 1] + FH_SIZE + FPROG_LEN, lane);
     // group A's residual term travels from layer to layer in registers (the packed dX rows of the previous epilogue); for the
     // last layer it is the decoder backward's dX_L
     u32x4 keepA[SL_HA], keepB[HB];
     {
-        const T* src = reinterpret_cast<const T*>(a.tile_in);
-        const int wq = min(w0 + c_win(lane), B - 1), colq = wn * 32 + c_oct(lane);
+        // (read back from the tile in LDS: rows past the batch are zero there)
+        const int loffq = lds_chunk<T>(0, c_win(lane), (wn * 32 + c_oct(lane)) / P::EPC);
 #pragma unroll
         for (int u = 0; u < SL_HA; ++u) {
             keepA[u] = u32x4{0, 0, 0, 0};
             const int n = bhn[FH_SLOTA + u];
-            if (n >= 0 && bhn[FH_KIND + u] != NK_DEAD) keepA[u] = *reinterpret_cast<const u32x4*>(src + act_idx(wq, n, B) + colq);
+            if (n >= 0 && bhn[FH_KIND + u] != NK_DEAD) keepA[u] = *reinterpret_cast<const u32x4*>(smem + n * P::BLK + loffq);
         }
 #pragma unroll
         for (int u = 0; u < HB; ++u) {
             keepB[u] = u32x4{0, 0, 0, 0};
             const int n = bhn[FH_SLOTB + u];
-            if (n >= 0 && bhn[FH_KIND + SL_HA + u] != NK_DEAD) keepB[u] = *reinterpret_cast<const u32x4*>(src + act_idx(wq, n, B) + colq);
+            if (n >= 0 && bhn[FH_KIND + SL_HA + u] != NK_DEAD) keepB[u] = *reinterpret_cast<const u32x4*>(smem + n * P::BLK + loffq);
         }
     }
     bhn.settle(); wan.settle(); wbn.settle();
@@ -2370,6 +2376,7 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
             for (int l = 0; l < hp.L; ++l) { a.mask_off[l] = lay.mask[l]; a.t1_off[l] = lay.t1[l]; a.dh_off[l] = lay.dh[l]; a.du_off[l] = lay.du[l]; a.prog_off[l] = hp.fs_bwd_off[l]; }
             a.wpack = ws + lay.wpack; a.bias = reinterpret_cast<const float*>(ws + lay.bias); a.tables = p->d_tables;
             a.B = B; a.NN = hp.NN; a.L = hp.L; a.training = 1;
+            a.node0 = hp.type_base[d.out_type]; a.n_out = d.type_nodes[d.out_type];      // the nodes that carry dX_L (the only live type of the last layer)
             a.mask0_off = lay.dd[0];
             a.dbg = p->dbg;
             a.stamps = stamp_ptr("MSHGNN_STAMPS_BWD");

@@ -28,3 +28,16 @@ for k in order:
     print(f"  {names[k]:28s} +{d:9.0f} cycles (median)   since start {np.median(s[:, k] - s[:, 0]):9.0f}")
     prev = k
 print("start spread (cycles):", int(s[:, 0].max() - s[:, 0].min()), " span:", int(s[:, 30].max() - s[:, 0].min()))
+# distribution over the workgroups: the launch lasts as long as its slowest tile, not the median one
+dur = s[:, 30] - s[:, 0]; st = s[:, 0] - s[:, 0].min(); en = s[:, 30] - s[:, 0].min()
+q = lambda a, p: float(np.percentile(a, p))
+print(f"tile duration: min {dur.min():.0f}  median {np.median(dur):.0f}  p90 {q(dur, 90):.0f}  p99 {q(dur, 99):.0f}  max {dur.max():.0f}")
+print(f"tile start   : median {np.median(st):.0f}  p90 {q(st, 90):.0f}  max {st.max():.0f}")
+print(f"tile end     : median {np.median(en):.0f}  p90 {q(en, 90):.0f}  max {en.max():.0f}   (clock64 is per XCD: differences across XCDs include their clock offsets)")
+xcd = np.arange(512) % 8
+for x in range(8):
+    m = xcd == x
+    print(f"  XCD {x}: start {np.median(s[m, 0] - s[m, 0].min()):7.0f}  duration median {np.median(dur[m]):7.0f} max {dur[m].max():7.0f}  last end - first start {s[m, 30].max() - s[m, 0].min():7.0f}")
+for k, nm in ((1, "tile staged"), (5, "L0 end"), (9, "L1 end"), (13, "L2 end")):
+    d = s[:, k] - s[:, 0]
+    print(f"  since start at '{nm}': median {np.median(d):.0f}  p99 {q(d, 99):.0f}  max {d.max():.0f}")
