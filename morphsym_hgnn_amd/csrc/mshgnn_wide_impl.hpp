@@ -378,7 +378,7 @@ template <int NH, int NS, int NM, int DMAX> WD_KERNEL(NH) void k_eng_fwd(StackAr
             const AOff<T> ao(opaque(lane));
             // <= 18 nodes: the engine itself starts the accumulators from this wave's bias rows in LDS (row of type t at bsm + 128 t)
             if constexpr (LB) wd_run<NH, NS>(R, wp, smem, wpack, wn, lane, ao, fh.h1, bsm + c_oct(opaque(lane)) * 4, 1);      // (the dynamic LDS segment starts at address 0, as for the block offsets)
-            else wd_run<NH, NS>(R, wp, smem, wpack, wn, lane, ao);
+            else wd_run<NH, NS>(R, wp, smem, wpack, wn, lane, ao, wp.prog, wp.prog, 0);
         }
         if (l + 1 < a.L) {    // the next layer's header and program: requested here, so that they do not live (spilled, one serialised round trip each) across the
                               // MAC engine, and settled before the epilogue's first store
@@ -535,6 +535,7 @@ template <int NH, int NS, int NM> WD_KERNEL(NH) void k_eng_bwd(StackArgs a) {
     const T* wpack = reinterpret_cast<const T*>(a.wpack);
     WRegs<NH> R; wd_regs_init<NH, NS>(R);
     if constexpr (NH == 1) stack_stagger(a);
+    FS_STAMP(0);
 
     FHdr bhn(a.tables + a.prog_off[a.L - 1], lane);
     WProg wpn(a.tables + a.prog_off[a.L - 1] + FH_SIZE, lane);
@@ -571,10 +572,12 @@ template <int NH, int NS, int NM> WD_KERNEL(NH) void k_eng_bwd(StackArgs a) {
     }
     __syncthreads();
     bhn.settle(); wpn.settle();
+    FS_STAMP(1);
 
     for (int l = a.L - 1; l >= 0; --l) {
         const FHdr bh = bhn;
         const WProg wp = wpn;
+        FS_STAMP(2 + 5 * (a.L - 1 - l));
         const int nmlp = bh[FH_NMLP], flags = bh[FH_FLAGS];
         const bool enc_mask = (flags & FF_ENC_MASK) != 0;
         int lq = opaque(lane);
@@ -636,15 +639,18 @@ template <int NH, int NS, int NM> WD_KERNEL(NH) void k_eng_bwd(StackArgs a) {
         }
 
         // dX_l[j] = (residual) + dH_j W_rootsum + sum_r sum_{j->i} dH_i W_rel^r
+        FS_STAMP(3 + 5 * (a.L - 1 - l));
         {
             const AOff<T> ao(opaque(lane));
-            wd_run<NH, NS>(R, wp, smem, wpack, wn, lane, ao);
+            wd_run<NH, NS>(R, wp, smem, wpack, wn, lane, ao, wp.prog, wp.prog, 0);      // (no bias start: any register serves as the two unused operands)
         }
+        FS_STAMP(4 + 5 * (a.L - 1 - l));
         if (l > 0) {          // the next layer's header and program (not carried across the MAC engine; what this epilogue needs of the next layer is in bh[FH_NEXT])
             bhn = FHdr(a.tables + a.prog_off[l - 1], lane);
             wpn = WProg(a.tables + a.prog_off[l - 1] + FH_SIZE, lane);
         }
         __syncthreads();   // every wave is done reading dH_l
+        FS_STAMP(5 + 5 * (a.L - 1 - l));
         lq = opaque(lane); win = c_win(lq); col = wn * 32 + c_oct(lq); loff = lds_chunk<T>(0, win, col / P::EPC);      // (rebuilt: nothing derived from them lives across the MAC phase)
         T* dxo = reinterpret_cast<T*>(a.ws + a.dx_off[l]);
         const uint8_t* mbytes = reinterpret_cast<const uint8_t*>(a.ws + (l > 0 ? a.mask_off[l - 1] : a.mask0_off));
@@ -687,6 +693,7 @@ template <int NH, int NS, int NM> WD_KERNEL(NH) void k_eng_bwd(StackArgs a) {
             if (l > 0) wd_acc_set_all<NH, U>(R, n0, n1);
         });
         __syncthreads();
+        FS_STAMP(6 + 5 * (a.L - 1 - l));
     }
 }
 
