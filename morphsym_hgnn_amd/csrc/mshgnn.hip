@@ -2125,7 +2125,8 @@ extern "C" int mshgnn_plan_create(const mshgnn_desc* desc, mshgnn_plan** out) {
             const char* e2 = getenv("MSHGNN_SLAB2");
             p->use_slab2 = hp.slab2 && e2 && atoi(e2) >= 1;        // slab2 variant: the engine-driven kernels on 16-window tiles, two workgroups per CU
             p->slab2_force = e2 && atoi(e2) == 2;
-            if (p->use_slab2 && (rc = slab2_set_attrs(p))) { mshgnn_plan_destroy(p); return rc; }
+            p->slab2_infer = hp.slab2 && p->use_slab && !(e2 && atoi(e2) == 0);      // default: the inference forward (see slab2_for)
+            if ((p->use_slab2 || p->slab2_infer) && (rc = slab2_set_attrs(p))) { mshgnn_plan_destroy(p); return rc; }
         }
     }
     *out = p;
@@ -2303,12 +2304,12 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
                 a.inv_n = 1.0f / (float)((int64_t)B * a.n_out);
             }
             a.stamps = stamp_ptr("MSHGNN_STAMPS");
-            a.stagger = (p->slab2_for(tiles) || p->slab_for(tiles)) && tiles > p->n_cu ? p->stagger : 0;
+            a.stagger = (p->slab2_for(tiles, a.training != 0) || p->slab_for(tiles)) && tiles > p->n_cu ? p->stagger : 0;
             ProfScope ps(p, hp.ks_stack_fwd, st);
             if (p->wide_for(B)) {
                 for (int l = 0; l < hp.L; ++l) a.prog_off[l] = hp.wd_fwd_off[l];
                 if (int rc = wide_launch(p, a, false, st)) return rc;
-            } else if (p->slab2_for(tiles)) {
+            } else if (p->slab2_for(tiles, a.training != 0)) {
                 for (int l = 0; l < hp.L; ++l) a.prog_off[l] = hp.s2_fwd_off[l];
                 if (int rc = slab2_launch(p, a, false, st)) return rc;
             } else if (p->slab_for(tiles)) {

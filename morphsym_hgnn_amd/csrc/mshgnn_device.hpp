@@ -974,8 +974,12 @@ struct mshgnn_plan {
     bool slab_force = false; int n_cu = 256;
     bool use_wide = false, wide_force = false;   // wide variant (mshgnn_wide.hip: 32-window tiles, one 4-wave workgroup per CU; MSHGNN_WIDE=0 off, 2 always)
     int stagger = 0;                             // StackArgs.stagger of the two-workgroups-per-CU stack kernels (MSHGNN_STAGGER)
-    bool use_slab2 = false, slab2_force = false; // slab2 variant (mshgnn_wide.hip: the engine-driven kernels on 16-window tiles; MSHGNN_SLAB2=0 off, 2 always)
-    bool slab2_for(int tiles) const { return use_slab2 && (slab2_force || tiles >= 2 * n_cu * 3 / 4); }
+    // slab2 variant (mshgnn_slab2.hip: the engine-driven kernels on 16-window tiles).  Default: the INFERENCE forward only (no stashes: 50.4 against the slab
+    // kernel's 53.9 us on A1-C2, 8192 windows); MSHGNN_SLAB2=1 also the training kernels (on par with the slab kernels), 2 for every batch size, 0 never
+    bool use_slab2 = false, slab2_force = false, slab2_infer = false;
+    bool slab2_for(int tiles, bool training = true) const {
+        return (use_slab2 || (slab2_infer && !training)) && (slab2_force || tiles >= 2 * n_cu * 3 / 4);
+    }
     int n_types = 0;
     mshgnn_gen_state* gen = nullptr;    // set: this plan runs on the generic-width engine (hidden != 128, many nodes, ...), hp is unused
     int dbg = 0, dbg_gw = 0;            // timing ablations (instrumented builds only: read once from MSHGNN_DBG / MSHGNN_DBG_GW at plan creation)

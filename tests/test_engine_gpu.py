@@ -365,6 +365,31 @@ def test_wide_stack_kernels_on_every_entry_point(kind, topo, cfg, layers, B, mon
                 assert torch.equal(ga[k], gb[k]), (mode, k)
 
 
+def test_default_inference_forward_uses_the_engine_kernels_and_matches(monkeypatch):
+    """With no switches set, the inference forward of a full-size batch runs on the slab2 engine kernels (the training entry points stay on the slab
+    kernels): identical bits to the slab kernels' inference forward, and the training step is the slab kernels' either way."""
+    _require_gpu()
+    from morphsym_hgnn_amd import engine as eng, synth
+    spec = helpers.make_spec("c2", "a1-c2", "a1-c2", 128, 3)
+    B = 8192
+    x_dict, y = synth.make_windows(13, B, spec.num_nodes, spec.widths, 12)
+    params = synth.make_params(13, spec.param_shapes())
+    res = {}
+    for mode, env in {"default": None, "slab": "0"}.items():
+        for k in ("MSHGNN_WIDE", "MSHGNN_SLAB"):
+            monkeypatch.delenv(k, raising=False)
+        if env is None: monkeypatch.delenv("MSHGNN_SLAB2", raising=False)
+        else: monkeypatch.setenv("MSHGNN_SLAB2", env)
+        e = eng.Engine(spec, "bf16")
+        xs = e.cast_inputs(x_dict)
+        flat = eng.flatten_params(spec, params, e.device)
+        inf = e.forward(xs, flat, B, training=False).clone()
+        out, loss, g = e.step_mse(xs, flat, y.reshape(-1).to(e.device, torch.float32), B)
+        res[mode] = (inf, out.clone(), g.clone())
+    for i in range(3):
+        assert torch.equal(res["default"][i], res["slab"][i]), i
+
+
 def test_full_size_batch_properties_bf16():
     """The same size-independent properties on the throughput plan (bf16, B=8192: slab stack kernels; the two halves of the
     batch run on the 8-wave stack kernels): every window's output is independent of its batch -- identical bits -- and the
