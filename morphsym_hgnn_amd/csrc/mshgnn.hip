@@ -879,9 +879,9 @@ __device__ __forceinline__ void slab_group_store(const StackArgs& a, const FHdr&
     }
 }
 
-template <typename T, int NM, int HB> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_fwd(StackArgs a) {
+// STEP: part of k_slab_step -- the decoder tail leaves dX_L in the out-type nodes' LDS blocks for the backward sweep that follows in the same launch
+template <typename T, int NM, int HB, bool STEP> __device__ __forceinline__ void slab_fwd_body(const StackArgs& a, char* smem) {
     using P = Prec<T>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int w0 = blockIdx.x * P::ROWS, B = a.B, NN = a.NN;
     const T* wpack = reinterpret_cast<const T*>(a.wpack);
@@ -934,8 +934,12 @@ template <typename T, int NM, int HB> __global__ __launch_bounds__(SL_THREADS, 2
         __syncthreads();
         FS_STAMP(5 + 4 * l);
     }
-    decoder_tail<T, SL_THREADS>(a, smem, tid, lane, wn, w0, B);
+    decoder_tail<T, SL_THREADS, false, STEP>(a, smem, tid, lane, wn, w0, B);
     FS_STAMP(30);
+}
+template <typename T, int NM, int HB> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_fwd(StackArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    slab_fwd_body<T, NM, HB, false>(a, smem);
 }
 
 template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_bwd(StackArgs a) {
@@ -1159,21 +1163,22 @@ __device__ __forceinline__ void slab_group_bwd(const StackArgs& a, const FHdr& b
     }
 }
 
-template <typename T, int NM, int HB> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_bwd(StackArgs a) {
+// STEP: part of k_slab_step -- the forward's decoder tail of the same launch left the dX_L tile in LDS; the layers' programs are a.prog_off_b
+template <typename T, int NM, int HB, bool STEP> __device__ __forceinline__ void slab_bwd_body(const StackArgs& a, char* smem) {
     using P = Prec<T>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int w0 = blockIdx.x * P::ROWS, B = a.B, NN = a.NN;
     const T* wpack = reinterpret_cast<const T*>(a.wpack);
     static_assert(sizeof(T) == 2, "fused stack kernels are bf16");
-    stack_stagger(a);
+    auto prog_of = [&](int l) { return STEP ? a.prog_off_b[l] : a.prog_off[l]; };
+    if constexpr (!STEP) stack_stagger(a);
 
     // the last layer's header and programs stream in under the tile load
-    FHdr bhn(a.tables + a.prog_off[a.L - 1], lane);
-    FProg wan(a.tables + a.prog_off[a.L - 1] + FH_SIZE, lane), wbn(a.tables + a.prog_off[a.L - 1] + FH_SIZE + FPROG_LEN, lane);
+    FHdr bhn(a.tables + prog_of(a.L - 1), lane);
+    FProg wan(a.tables + prog_of(a.L - 1) + FH_SIZE, lane), wbn(a.tables + prog_of(a.L - 1) + FH_SIZE + FPROG_LEN, lane);
     // dX_L tile: only the nodes that are live in the last layer carry a gradient -- the output type's [node0, node0 + n_out), known from the arguments, so
     // the loads do not wait for the header; four nodes per round trip
-    {
+    if constexpr (!STEP) {
         const T* src = reinterpret_cast<const T*>(a.tile_in);
         const int row = tid >> 4, c = tid & 15;
         for (int f0 = 0; f0 < a.n_out; f0 += 4) {
@@ -1214,9 +1219,9 @@ template <typename T, int NM, int HB> __global__ __launch_bounds__(SL_THREADS, 2
         const FHdr bh = bhn;
         const FProg wa = wan, wb = wbn;
         if (l > 0) {
-            bhn = FHdr(a.tables + a.prog_off[l - 1], lane);
-            wan = FProg(a.tables + a.prog_off[l - 1] + FH_SIZE, lane);
-            wbn = FProg(a.tables + a.prog_off[l - 1] + FH_SIZE + FPROG_LEN, lane);
+            bhn = FHdr(a.tables + prog_of(l - 1), lane);
+            wan = FProg(a.tables + prog_of(l - 1) + FH_SIZE, lane);
+            wbn = FProg(a.tables + prog_of(l - 1) + FH_SIZE + FPROG_LEN, lane);
         }
         const int nmlp = bh[FH_NMLP], flags = bh[FH_FLAGS];
         const uint8_t* maskbytes = reinterpret_cast<const uint8_t*>(a.ws + a.mask_off[l]);
@@ -1322,12 +1327,29 @@ template <typename T, int NM, int HB> __global__ __launch_bounds__(SL_THREADS, 2
         __syncthreads();
     }
 }
+template <typename T, int NM, int HB> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_bwd(StackArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    slab_bwd_body<T, NM, HB, false>(a, smem);
+}
+// One-call training step (mshgnn_step_mse / mshgnn_step_ce): the forward layers, decoder + loss + decoder backward and the backward layers of a tile in ONE
+// launch.  The tail leaves dX_L in the node blocks, so the backward sweep starts without a launch boundary, without the header / tile round trips of
+// k_slab_bwd's start and without re-reading dX_L (stamps: 16 k of its 163 k cycles).  Same code, same order of every accumulation: identical bits.
+template <typename T, int NM, int HB> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_step(StackArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    slab_fwd_body<T, NM, HB, true>(a, smem);
+    __syncthreads();      // the tile's dX_L rows are in the out-type blocks, the tail's reduction scratch has been read
+    slab_bwd_body<T, NM, HB, true>(a, smem);
+}
 
 // the slab instantiation of a plan: NM = bound on the base_transform nodes (2 / 4), HB = group-B slots (6 / 8)
 using StackKernel = void (*)(StackArgs);
 static StackKernel slab_fwd_kernel(const HostPlan& hp) {
     if (hp.sl_hb <= SL_HB) return hp.n_mlp <= 2 ? k_slab_fwd<__bf16, 2, SL_HB> : k_slab_fwd<__bf16, 4, SL_HB>;
     return hp.n_mlp <= 2 ? k_slab_fwd<__bf16, 2, SL_HB_MAX> : k_slab_fwd<__bf16, 4, SL_HB_MAX>;
+}
+static StackKernel slab_step_kernel(const HostPlan& hp) {
+    if (hp.sl_hb <= SL_HB) return hp.n_mlp <= 2 ? k_slab_step<__bf16, 2, SL_HB> : k_slab_step<__bf16, 4, SL_HB>;
+    return hp.n_mlp <= 2 ? k_slab_step<__bf16, 2, SL_HB_MAX> : k_slab_step<__bf16, 4, SL_HB_MAX>;
 }
 static StackKernel slab_bwd_kernel(const HostPlan& hp) {
     if (hp.sl_hb <= SL_HB) return hp.n_mlp <= 2 ? k_slab_bwd<__bf16, 2, SL_HB> : k_slab_bwd<__bf16, 4, SL_HB>;
@@ -2114,7 +2136,9 @@ extern "C" int mshgnn_plan_create(const mshgnn_desc* desc, mshgnn_plan** out) {
             p->use_slab = hp.slab && !(es && atoi(es) == 0);       // default on where the plan allows it; MSHGNN_SLAB=0 selects the 8-wave kernels
             p->slab_force = es && atoi(es) == 2;                   // MSHGNN_SLAB=2: also for batches that do not fill the chip
             { int dev = 0, cus = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); p->n_cu = cus > 0 ? cus : 256; }
-            if (p->use_slab && ((rc = set_lds_attr(slab_fwd_kernel(hp), flds)) || (rc = set_lds_attr(slab_bwd_kernel(hp), flds)))) { mshgnn_plan_destroy(p); return rc; }
+            if (p->use_slab && ((rc = set_lds_attr(slab_fwd_kernel(hp), flds)) || (rc = set_lds_attr(slab_bwd_kernel(hp), flds)) ||
+                                (rc = set_lds_attr(slab_step_kernel(hp), flds)))) { mshgnn_plan_destroy(p); return rc; }
+            { const char* et = getenv("MSHGNN_STEP_KERNEL"); p->use_step = p->use_slab && !(et && atoi(et) == 0); }      // one-call steps: forward + backward sweep in one launch
             const char* ew = getenv("MSHGNN_WIDE");
             // wide variant (mshgnn_wide.hip): opt-in.  Measured on A1-C2, 8192 windows: 81 us against the slab kernel's 65 (inference: 67 / 54) -- with 32 windows
             // per CU one wave per SIMD exposes every memory and instruction-fetch latency of a kernel whose code runs once.
@@ -2224,7 +2248,9 @@ int run_finalize(const mshgnn_plan* p, const mshgnn_ws_layout& lay, char* ws, fl
 template <typename T>
 static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, float* out,
                         char* ws, int64_t batch, int training, hipStream_t st, const float* y_fused = nullptr, const SeriesSrc* series = nullptr,
-                        const int32_t* labels_fused = nullptr) {
+                        const int32_t* labels_fused = nullptr, bool* stack_step_done = nullptr) {
+    // stack_step_done (one-call steps): where the slab kernels run and the loss is fused, the backward sweep of the stack runs in the same launch
+    // (k_slab_step) and *stack_step_done tells backward_impl to skip its own
     const HostPlan& hp = p->hp;
     const mshgnn_desc& d = hp.d;
     mshgnn_ws_layout lay; layout_workspace(hp, batch, training, &lay);
@@ -2305,7 +2331,10 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
             }
             a.stamps = stamp_ptr("MSHGNN_STAMPS");
             a.stagger = (p->slab2_for(tiles, a.training != 0) || p->slab_for(tiles)) && tiles > p->n_cu ? p->stagger : 0;
-            ProfScope ps(p, hp.ks_stack_fwd, st);
+            // the tail's reduction scratch (one decoder slab per wave at the start of LDS) must end below the out-type nodes' blocks
+            const bool step = stack_step_done && p->use_step && (y_fused || labels_fused) && !p->wide_for(B) && !p->slab2_for(tiles, true) && p->slab_for(tiles) &&
+                              (size_t)a.node0 * Prec<T>::BLK >= (size_t)(SL_THREADS / 64) * DEC_SLAB_FLOATS * sizeof(float);
+            ProfScope ps(p, step ? hp.ks_stack_step : hp.ks_stack_fwd, st);
             if (p->wide_for(B)) {
                 for (int l = 0; l < hp.L; ++l) a.prog_off[l] = hp.wd_fwd_off[l];
                 if (int rc = wide_launch(p, a, false, st)) return rc;
@@ -2314,6 +2343,13 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
                 if (int rc = slab2_launch(p, a, false, st)) return rc;
             } else if (p->slab_for(tiles)) {
                 for (int l = 0; l < hp.L; ++l) a.prog_off[l] = hp.sl_fwd_off[l];
+                if (step) {
+                    for (int l = 0; l <= hp.L; ++l) a.dx_off[l] = lay.dx[l];
+                    for (int l = 0; l < hp.L; ++l) { a.dh_off[l] = lay.dh[l]; a.du_off[l] = lay.du[l]; a.prog_off_b[l] = hp.sl_bwd_off[l]; }
+                    a.mask0_off = lay.dd[0];
+                    hipLaunchKernelGGL(slab_step_kernel(hp), dim3(tiles), dim3(SL_THREADS), (hp.sl_blk + FS_EXTRA_BLK) * Prec<T>::BLK, st, a);
+                    *stack_step_done = true;
+                } else
                 hipLaunchKernelGGL(slab_fwd_kernel(hp), dim3(tiles), dim3(SL_THREADS), (hp.sl_blk + FS_EXTRA_BLK) * Prec<T>::BLK, st, a);
             } else
             hipLaunchKernelGGL(k_stack_fwd<T>, dim3(tiles), dim3(LAYER_THREADS), (hp.fs_blk + FS_EXTRA_BLK) * Prec<T>::BLK, st, a);
@@ -2346,7 +2382,8 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
 template <typename T>
 static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, const float* gout,
                          float* gparams, char* ws, int64_t batch, hipStream_t st, const float* out = nullptr, const float* y = nullptr,
-                         float* loss = nullptr, const int32_t* labels = nullptr, bool dec_done = false, int gw_phase = -1, const SeriesSrc* series = nullptr) {
+                         float* loss = nullptr, const int32_t* labels = nullptr, bool dec_done = false, int gw_phase = -1, const SeriesSrc* series = nullptr,
+                         bool stack_done = false) {      // stack_done: k_slab_step already ran the backward sweep of the stack (forward_impl)
     // gw_phase: -1 = everything; 0 = backward sweep + the weight gradients of every parameter but the encoder's; 1 = only the
     // encoder's weight gradients (the sweep of phase 0 left dX_0 in the workspace)
     const HostPlan& hp = p->hp;
@@ -2368,9 +2405,9 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
         hipLaunchKernelGGL(k_dec_bwd<T>, dim3(NWG_DEC), dim3(256), 0, st, a);
     }
     const int tiles = (B + Prec<T>::ROWS - 1) / Prec<T>::ROWS;
-    bool fused_done = gw_phase == 1;
+    bool fused_done = gw_phase == 1 || stack_done;
     if constexpr (sizeof(T) == 2) {
-        if (p->use_fused && gw_phase != 1) {
+        if (p->use_fused && gw_phase != 1 && !stack_done) {
             StackArgs a{};
             a.tile_in = ws + lay.dx[hp.L]; a.ws = ws;
             for (int l = 0; l <= hp.L; ++l) { a.x_off[l] = lay.x[l]; a.dx_off[l] = lay.dx[l]; }
@@ -2493,9 +2530,10 @@ extern "C" int mshgnn_step_mse(const mshgnn_plan* p, const void* const* x, const
         return p->hp.d.dtype == MSHGNN_F32 ? backward_impl<float>(p, x, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, st, out, y, loss_out)
                                            : backward_impl<__bf16>(p, x, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, st, out, y, loss_out);
     }
-    int rc = forward_impl<__bf16>(p, x, x_pitch, params, out, (char*)workspace, batch, 1, st, y);
+    bool stack_done = false;
+    int rc = forward_impl<__bf16>(p, x, x_pitch, params, out, (char*)workspace, batch, 1, st, y, nullptr, nullptr, &stack_done);
     if (rc) return rc;
-    return backward_impl<__bf16>(p, x, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, st, out, y, loss_out, nullptr, true);
+    return backward_impl<__bf16>(p, x, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, st, out, y, loss_out, nullptr, true, -1, nullptr, stack_done);
 }
 
 extern "C" int mshgnn_step_ce(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, const int32_t* labels,
@@ -2508,9 +2546,10 @@ extern "C" int mshgnn_step_ce(const mshgnn_plan* p, const void* const* x, const 
     // bf16 plan with the fused stack kernels: decoder, cross entropy and decoder backward in the tail of the forward kernel; every other plan: the
     // two-call sequence (mshgnn_forward + mshgnn_backward_ce)
     if (!p->gen && p->hp.d.dtype == MSHGNN_BF16 && p->use_fused) {
-        int rc = forward_impl<__bf16>(p, x, x_pitch, params, out, (char*)workspace, batch, 1, st, nullptr, nullptr, labels);
+        bool stack_done = false;
+        int rc = forward_impl<__bf16>(p, x, x_pitch, params, out, (char*)workspace, batch, 1, st, nullptr, nullptr, labels, &stack_done);
         if (rc) return rc;
-        return backward_impl<__bf16>(p, x, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, st, out, nullptr, loss_out, labels, true);
+        return backward_impl<__bf16>(p, x, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, st, out, nullptr, loss_out, labels, true, -1, nullptr, stack_done);
     }
     int rc = mshgnn_forward(p, x, x_pitch, params, out, workspace, batch, 1, stream);
     if (rc) return rc;
@@ -3297,11 +3336,12 @@ static int step_series(const mshgnn_plan* p, const mshgnn_window_desc* d, const 
         return x3_backward(p, x_out, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, st, out, ce ? nullptr : y_out, loss_out,
                            ce ? labels_out : nullptr, !ce, -1);
     }
-    int rc = forward_impl<__bf16>(p, x_out, x_pitch, params, out, (char*)workspace, batch, 1, st, ce ? nullptr : y_out, &ser, ce ? labels_out : nullptr);
+    bool stack_done = false;
+    int rc = forward_impl<__bf16>(p, x_out, x_pitch, params, out, (char*)workspace, batch, 1, st, ce ? nullptr : y_out, &ser, ce ? labels_out : nullptr, &stack_done);
     if (rc) return rc;
     // x_out == NULL: no materialised windows at all -- the weight-gradient kernel gathers its raw-input operands from the series as well
     return backward_impl<__bf16>(p, x_out, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, st, out, ce ? nullptr : y_out, loss_out,
-                                 ce ? labels_out : nullptr, true, -1, x_out ? nullptr : &ser);
+                                 ce ? labels_out : nullptr, true, -1, x_out ? nullptr : &ser, stack_done);
 }
 
 extern "C" int mshgnn_step_mse_series(const mshgnn_plan* p, const mshgnn_window_desc* d, const float* const* src, const void* const* src_bf16,

@@ -630,6 +630,7 @@ struct StackArgs {
     size_t x_off[MAX_L + 1], dx_off[MAX_L + 1];   // X_l stashes (fwd: written for l >= 1; bwd: X_0 read for the encoder mask), dX_l (bwd: written)
     size_t mask_off[MAX_L], hb_off[MAX_L], t1_off[MAX_L], dh_off[MAX_L], du_off[MAX_L];
     const void* wpack; const float* bias; const int* tables; int prog_off[MAX_L];
+    int prog_off_b[MAX_L];                        // k_slab_step (forward + backward sweep of a tile in one launch): the backward layers' programs (prog_off: the forward's)
     int B, NN, L, training, dbg;
     const float* params; const float* out_mask; float* out; int64_t off_dec_w, off_dec_b; int node0, n_out, dout;   // fused decoder (fwd)
     // mshgnn_step_mse: the forward also takes the wrapper MSE and the decoder backward (dX_L rows, decoder partial gradients, loss partial)
@@ -762,7 +763,9 @@ __device__ __forceinline__ void fs_run(const FProg& wp, typename Prec<T>::Acc (&
 }
 
 // decoder (+ fused wrapper MSE and decoder backward) on the X_L tile in LDS: shared tail of k_stack_fwd / k_slab_fwd
-template <typename T, int THREADS, int DMAX, bool SPLIT = false>      // DMAX: compile-time bound on the output channels (4 or 8): loops, loads and registers scale with it
+// TOLDS (k_slab_step): the dX_L rows also go into the out-type nodes' LDS blocks (rows past the batch: zeros), where the backward sweep of the same launch
+// picks them up; the reduction scratch at the start of LDS must not reach those blocks (checked on the host)
+template <typename T, int THREADS, int DMAX, bool SPLIT = false, bool TOLDS = false>      // DMAX: compile-time bound on the output channels (4 or 8): loops, loads and registers scale with it
 __device__ __forceinline__ void decoder_tail_impl(const StackArgs& a, char* smem, int tid, int lane, int wv, int w0, int B) {
     // decoder on the out-type rows of X_L (hgnn_c2.py:176-189): thread = (node, row, 8-column chunk).  With y (mshgnn_step_mse) the
     // same threads also take the wrapper MSE (gnnLightning.py:633-639) and the decoder backward: dX_L rows to global for
@@ -873,6 +876,15 @@ __device__ __forceinline__ void decoder_tail_impl(const StackArgs& a, char* smem
                         *reinterpret_cast<u32x4*>(q) = hi; *reinterpret_cast<u32x4*>(q + H) = lo;
                     } else store8<T>(dxl + act_idx(w0 + row, a.node0 + f, B) + c * 8, dxv[i]);
                 }
+                if constexpr (TOLDS) {
+                    if (f < a.n_out) {
+                        if (!ok) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) dxv[i][e] = 0.f;
+                        }
+                        store8<T>(reinterpret_cast<T*>(smem + lds_chunk<T>(a.node0 + f, row, c)), dxv[i]);
+                    }
+                }
             }
         }
         if (fuse) {
@@ -910,10 +922,10 @@ __device__ __forceinline__ void decoder_tail_impl(const StackArgs& a, char* smem
     }
 }
 
-template <typename T, int THREADS, bool SPLIT = false>
+template <typename T, int THREADS, bool SPLIT = false, bool TOLDS = false>
 __device__ __forceinline__ void decoder_tail(const StackArgs& a, char* smem, int tid, int lane, int wv, int w0, int B) {
-    if (a.dout <= 4) decoder_tail_impl<T, THREADS, 4, SPLIT>(a, smem, tid, lane, wv, w0, B);
-    else decoder_tail_impl<T, THREADS, 8, SPLIT>(a, smem, tid, lane, wv, w0, B);
+    if (a.dout <= 4) decoder_tail_impl<T, THREADS, 4, SPLIT, TOLDS>(a, smem, tid, lane, wv, w0, B);
+    else decoder_tail_impl<T, THREADS, 8, SPLIT, TOLDS>(a, smem, tid, lane, wv, w0, B);
 }
 
 struct DecArgs {
@@ -972,6 +984,7 @@ struct mshgnn_plan {
     bool use_fused = false;             // bf16 plan: fused stack kernels (MSHGNN_FUSED=0 selects the per-layer kernels)
     bool use_slab = false;              // slab variant of the stack kernels (MSHGNN_SLAB=0 selects the 8-wave ones)
     bool slab_force = false; int n_cu = 256;
+    bool use_step = false;              // one-call steps on the slab kernels: k_slab_step (MSHGNN_STEP_KERNEL=0: two launches)
     bool use_wide = false, wide_force = false;   // wide variant (mshgnn_wide.hip: 32-window tiles, one 4-wave workgroup per CU; MSHGNN_WIDE=0 off, 2 always)
     int stagger = 0;                             // StackArgs.stagger of the two-workgroups-per-CU stack kernels (MSHGNN_STAGGER)
     // slab2 variant (mshgnn_slab2.hip: the engine-driven kernels on 16-window tiles).  Default: the INFERENCE forward only (no stashes: 50.4 against the slab

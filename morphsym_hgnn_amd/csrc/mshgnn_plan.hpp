@@ -191,7 +191,7 @@ struct HostPlan {
     int n_slabs = 0;
     std::vector<float> out_mask_f;
     std::vector<mshgnn_kernel_stat> kstats;   // one per kernel of a step, in launch order
-    int ks_prep = 0, ks_enc = 0, ks_layer_fwd0 = 0, ks_dec_fwd = 0, ks_dec_bwd = 0, ks_layer_bwd0 = 0, ks_gradw = 0, ks_fin = 0;
+    int ks_prep = 0, ks_enc = 0, ks_layer_fwd0 = 0, ks_dec_fwd = 0, ks_dec_bwd = 0, ks_layer_bwd0 = 0, ks_gradw = 0, ks_fin = 0, ks_stack_step = 0;
     mshgnn_info info{};
     std::string err;
 };
@@ -1104,6 +1104,7 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
             fa += 2.0 * n_out * d.out_channels * H; fe += 2.0 * n_out * d.out_channels * H;
             p.ks_stack_fwd = add("stack_fwd", MSHGNN_BOUND_MFMA, fa, fe, fb);
             p.ks_stack_bwd = add("stack_bwd", MSHGNN_BOUND_MFMA, ba, be, bb);
+            p.ks_stack_step = add("stack_step", MSHGNN_BOUND_MFMA, fa + ba, fe + be, fb + bb);      // one-call steps on the slab kernels: both sweeps in one launch
         }
     }
     return true;
