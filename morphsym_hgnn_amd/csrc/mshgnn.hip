@@ -2519,9 +2519,10 @@ extern "C" int mshgnn_step_mse(const mshgnn_plan* p, const void* const* x, const
         return gen_backward(p, x, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, st, out, y, loss_out, nullptr);
     }
     if (p->hp.d.dtype == MSHGNN_BF16X3) {      // split plan: decoder, loss and decoder backward in the tail of its fused forward kernel as well
-        int rc = x3_forward(p, x, x_pitch, params, out, (char*)workspace, batch, 1, st, y);
+        bool stack_done = false;
+        int rc = x3_forward(p, x, x_pitch, params, out, (char*)workspace, batch, 1, st, y, nullptr, &stack_done);
         if (rc) return rc;
-        return x3_backward(p, x, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, st, out, y, loss_out, nullptr, true, -1);
+        return x3_backward(p, x, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, st, out, y, loss_out, nullptr, true, -1, stack_done);
     }
     if (p->hp.d.dtype == MSHGNN_F32 || !p->use_fused) {      // no fused stack kernels on this plan: the two-call sequence
         int rc = p->hp.d.dtype == MSHGNN_F32 ? forward_impl<float>(p, x, x_pitch, params, out, (char*)workspace, batch, 1, st)
@@ -3331,10 +3332,11 @@ static int step_series(const mshgnn_plan* p, const mshgnn_window_desc* d, const 
     ser.run_ptr = reinterpret_cast<const unsigned long long*>(run_ptrs); ser.rows = d->rows; ser.starts = starts; ser.T = d->history;
     { int r0 = 0; for (int t = 0; t < d->n_types; ++t) { ser.row0[t] = r0; r0 += d->type_nodes[t]; } }
     if (x3) {      // (the split plan fuses the MSE into its forward kernel's tail; cross entropy: forward, then the fused-loss backward)
-        int rc = x3_forward(p, x_out, x_pitch, params, out, (char*)workspace, batch, 1, st, ce ? nullptr : y_out, &ser);
+        bool x3_stack_done = false;
+        int rc = x3_forward(p, x_out, x_pitch, params, out, (char*)workspace, batch, 1, st, ce ? nullptr : y_out, &ser, &x3_stack_done);
         if (rc) return rc;
         return x3_backward(p, x_out, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, st, out, ce ? nullptr : y_out, loss_out,
-                           ce ? labels_out : nullptr, !ce, -1);
+                           ce ? labels_out : nullptr, !ce, -1, x3_stack_done);
     }
     bool stack_done = false;
     int rc = forward_impl<__bf16>(p, x_out, x_pitch, params, out, (char*)workspace, batch, 1, st, ce ? nullptr : y_out, &ser, ce ? labels_out : nullptr, &stack_done);

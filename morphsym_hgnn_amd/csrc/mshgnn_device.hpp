@@ -882,7 +882,12 @@ __device__ __forceinline__ void decoder_tail_impl(const StackArgs& a, char* smem
 #pragma unroll
                             for (int e = 0; e < 8; ++e) dxv[i][e] = 0.f;
                         }
-                        store8<T>(reinterpret_cast<T*>(smem + lds_chunk<T>(a.node0 + f, row, c)), dxv[i]);
+                        if constexpr (SPLIT) {      // hi plane in the node's block, lo plane in block lo_blk + node
+                            u32x4 hi, lo;
+                            split_oct(f32x4{dxv[i][0], dxv[i][1], dxv[i][2], dxv[i][3]}, f32x4{dxv[i][4], dxv[i][5], dxv[i][6], dxv[i][7]}, hi, lo);
+                            *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(a.node0 + f, row, c)) = hi;
+                            *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(a.lo_blk + a.node0 + f, row, c)) = lo;
+                        } else store8<T>(reinterpret_cast<T*>(smem + lds_chunk<T>(a.node0 + f, row, c)), dxv[i]);
                     }
                 }
             }
@@ -1050,9 +1055,9 @@ int slab2_launch(const mshgnn_plan* p, const StackArgs& a, bool bwd, hipStream_t
 // split-bf16 parity plan (mshgnn_x3.hip)
 int x3_set_attrs(mshgnn_plan* p);
 int x3_forward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, float* out, char* ws, int64_t batch,
-               int training, hipStream_t st, const float* y_fused, const SeriesSrc* series = nullptr);
+               int training, hipStream_t st, const float* y_fused, const SeriesSrc* series = nullptr, bool* stack_step_done = nullptr);
 int x3_backward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, const float* gout, float* gparams, char* ws,
-                int64_t batch, hipStream_t st, const float* out, const float* y, float* loss, const int32_t* labels, bool dec_done, int gw_phase);
+                int64_t batch, hipStream_t st, const float* out, const float* y, float* loss, const int32_t* labels, bool dec_done, int gw_phase, bool stack_done = false);
 int x3_launch_prep(const PrepArgs& a, hipStream_t st);
 // weight-image packing for the other engines (mshgnn.hip): k_prep<__bf16> or the hi / lo images of k_prep_x3
 int launch_prep(const PrepArgs& a, bool split, hipStream_t st);

@@ -294,9 +294,9 @@ template <int N> __device__ __forceinline__ void mlp_mac3(P16::Acc (&acc)[N], co
 // 16-window tile in one 8-wave workgroup -- k_stack_fwd of the bf16 plan on hi/lo planes
 // ------------------------------------------------------------------------------------------------------
 // ALIAS: the base_transform scratch blocks are the blocks of the last nodes (topologies whose doubled tile leaves no room: MiniCheetah-K4)
-template <bool ALIAS> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_fwd_x3(StackArgs a) {
+// STEP: part of k_stack_step_x3 -- the decoder tail leaves dX_L (both planes) in the out-type nodes' LDS blocks for the backward sweep of the same launch
+template <bool ALIAS, bool STEP> __device__ __forceinline__ void stack_fwd_x3_body(const StackArgs& a, char* smem) {
     using T = T16; using P = P16;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wv & 3, wh = wv >> 2;
     const int w0 = blockIdx.x * P::ROWS, B = a.B, NN = a.NN, LO = a.lo_blk, SCR = a.scr0;
@@ -453,38 +453,43 @@ template <bool ALIAS> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
         __syncthreads();
         FS_STAMP(5 + 4 * l);
     }
-    decoder_tail<T, LAYER_THREADS, true>(a, smem, tid, lane, wv, w0, B);
+    decoder_tail<T, LAYER_THREADS, true, STEP>(a, smem, tid, lane, wv, w0, B);
     FS_STAMP(30);
+}
+template <bool ALIAS> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_fwd_x3(StackArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    stack_fwd_x3_body<ALIAS, false>(a, smem);
 }
 
 // ------------------------------------------------------------------------------------------------------
 // k_stack_bwd_x3: the L backward layers of a tile -- k_stack_bwd of the bf16 plan on hi/lo planes
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_bwd_x3(StackArgs a) {
+// STEP: part of k_stack_step_x3 -- the forward's decoder tail of the same launch left the dX_L tile in LDS; the layers' programs are a.prog_off_b
+template <bool STEP> __device__ __forceinline__ void stack_bwd_x3_body(const StackArgs& a, char* smem) {
     using T = T16; using P = P16;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wv & 3, wh = wv >> 2;
     const int w0 = blockIdx.x * P::ROWS, B = a.B, NN = a.NN, LO = a.lo_blk;
     const T* wpack = reinterpret_cast<const T*>(a.wpack);
+    auto prog_of = [&](int l) { return STEP ? a.prog_off_b[l] : a.prog_off[l]; };
 
     // dX_L tile: only the nodes that are live in the last layer carry a gradient
-    {
-        const FHdr bh(a.tables + a.prog_off[a.L - 1], lane);
+    if constexpr (!STEP) {
+        const FHdr bh(a.tables + prog_of(a.L - 1), lane);
         stage_tile_x3(smem, reinterpret_cast<const T*>(a.tile_in), NN, LO, w0, B, tid, [&](int n) { return bh[FH_KIND + n] != NK_DEAD; });
     }
     __syncthreads();
 
     P::Acc acc[FS_HS];
-    FHdr bhn(a.tables + a.prog_off[a.L - 1], lane);
-    FProg wpn(a.tables + a.prog_off[a.L - 1] + FH_SIZE + wh * FPROG_LEN, lane);
+    FHdr bhn(a.tables + prog_of(a.L - 1), lane);
+    FProg wpn(a.tables + prog_of(a.L - 1) + FH_SIZE + wh * FPROG_LEN, lane);
     bhn.settle(); wpn.settle();
     for (int l = a.L - 1; l >= 0; --l) {
         const FHdr bh = bhn;
         const FProg wp = wpn;
         if (l > 0) {          // the next layer's header and wave program stream in under this layer's MACs
-            bhn = FHdr(a.tables + a.prog_off[l - 1], lane);
-            wpn = FProg(a.tables + a.prog_off[l - 1] + FH_SIZE + wh * FPROG_LEN, lane);
+            bhn = FHdr(a.tables + prog_of(l - 1), lane);
+            wpn = FProg(a.tables + prog_of(l - 1) + FH_SIZE + wh * FPROG_LEN, lane);
         }
         const int nmlp = bh[FH_NMLP], flags = bh[FH_FLAGS];
         const uint8_t* maskbytes = reinterpret_cast<const uint8_t*>(a.ws + a.mask_off[l]);
@@ -623,6 +628,17 @@ __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_bwd_x3(StackArgs a) 
         }
         __syncthreads();
     }
+}
+__global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_bwd_x3(StackArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    stack_bwd_x3_body<false>(a, smem);
+}
+// mshgnn_step_mse on the split plan: both sweeps of a tile in one launch (k_slab_step of mshgnn.hip: dX_L stays in LDS, no second launch, no tile reload)
+template <bool ALIAS> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_step_x3(StackArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    stack_fwd_x3_body<ALIAS, true>(a, smem);
+    __syncthreads();
+    stack_bwd_x3_body<true>(a, smem);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1118,6 +1134,7 @@ int x3_set_attrs(mshgnn_plan* p) {
     int rc;
     const int flds = x3_lds_stack(p->hp);
     if ((rc = set_lds_attr(k_stack_fwd_x3<false>, flds)) || (rc = set_lds_attr(k_stack_fwd_x3<true>, flds)) || (rc = set_lds_attr(k_stack_bwd_x3, flds)) ||
+        (rc = set_lds_attr(k_stack_step_x3<false>, flds)) || (rc = set_lds_attr(k_stack_step_x3<true>, flds)) ||
         (rc = set_lds_attr(k_enc_x3<true>, 8 * P16::BLK)) || (rc = set_lds_attr(k_enc_x3<false>, 8 * P16::BLK)) ||
         (rc = set_lds_attr(k_enc_x3<true, true>, 8 * P16::BLK))) return rc;
     return MSHGNN_OK;
@@ -1134,7 +1151,7 @@ static void x3_stack_args(const mshgnn_plan* p, const mshgnn_ws_layout& lay, cha
 }
 
 int x3_forward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, float* out, char* ws, int64_t batch,
-               int training, hipStream_t st, const float* y_fused, const SeriesSrc* series) {
+               int training, hipStream_t st, const float* y_fused, const SeriesSrc* series, bool* stack_step_done) {
     const HostPlan& hp = p->hp;
     const mshgnn_desc& d = hp.d;
     mshgnn_ws_layout lay; layout_workspace(hp, batch, training, &lay);
@@ -1200,7 +1217,18 @@ int x3_forward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitc
         }
         const int tiles = (B + P16::ROWS - 1) / P16::ROWS;
         a.stamps = stamp_ptr("MSHGNN_STAMPS");
-        ProfScope ps(p, hp.ks_stack_fwd, st);
+        // one-call step: the backward sweep in the same launch (the tail's reduction scratch, one decoder slab per wave at the start of LDS, must end below the
+        // out-type nodes' blocks)
+        static const bool step_off = getenv("MSHGNN_STEP_KERNEL") && atoi(getenv("MSHGNN_STEP_KERNEL")) == 0;
+        const bool step = stack_step_done && y_fused && !step_off && (size_t)a.node0 * P16::BLK >= (size_t)(LAYER_THREADS / 64) * DEC_SLAB_FLOATS * sizeof(float);
+        ProfScope ps(p, step ? hp.ks_stack_step : hp.ks_stack_fwd, st);
+        if (step) {
+            a.mask0_off = lay.dd[0];
+            for (int l = 0; l < hp.L; ++l) a.prog_off_b[l] = hp.fs_bwd_off[l];
+            if (hp.x3_alias) hipLaunchKernelGGL(k_stack_step_x3<true>, dim3(tiles), dim3(LAYER_THREADS), x3_lds_stack(hp), st, a);
+            else hipLaunchKernelGGL(k_stack_step_x3<false>, dim3(tiles), dim3(LAYER_THREADS), x3_lds_stack(hp), st, a);
+            *stack_step_done = true;
+        } else
         if (hp.x3_alias) hipLaunchKernelGGL(k_stack_fwd_x3<true>, dim3(tiles), dim3(LAYER_THREADS), x3_lds_stack(hp), st, a);
         else hipLaunchKernelGGL(k_stack_fwd_x3<false>, dim3(tiles), dim3(LAYER_THREADS), x3_lds_stack(hp), st, a);
     }
@@ -1209,7 +1237,7 @@ int x3_forward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitc
 }
 
 int x3_backward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, const float* gout, float* gparams, char* ws,
-                int64_t batch, hipStream_t st, const float* out, const float* y, float* loss, const int32_t* labels, bool dec_done, int gw_phase) {
+                int64_t batch, hipStream_t st, const float* out, const float* y, float* loss, const int32_t* labels, bool dec_done, int gw_phase, bool stack_done) {
     const HostPlan& hp = p->hp;
     const mshgnn_desc& d = hp.d;
     mshgnn_ws_layout lay; layout_workspace(hp, batch, 1, &lay);
@@ -1224,7 +1252,7 @@ int x3_backward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pit
         ProfScope ps(p, hp.ks_dec_bwd, st);
         hipLaunchKernelGGL(k_dec_bwd_x3, dim3(NWG_DEC), dim3(256), 0, st, a);
     }
-    if (gw_phase != 1) {
+    if (gw_phase != 1 && !stack_done) {
         StackArgs a{};
         x3_stack_args(p, lay, ws, B, a);
         a.tile_in = ws + lay.dx[hp.L]; a.training = 1; a.mask0_off = lay.dd[0];
