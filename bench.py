@@ -499,7 +499,10 @@ def roofline_of(stats, steps, B, dtype, e, config, L, hidden):
     if dom["bound"] == "mfma":
         achieved = flops_w * B / avg_s / 1e12
         peak = PEAK["mfma_TFLOPs"][dtype]
-        roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None}
+        roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                "algorithmic_flops": flops_w * B,
+                "operands": {"bytes": bytes_w * B, "achieved": bytes_w * B / avg_s / 1e9, "unit": "GB/s", "frac": bytes_w * B / avg_s / 1e9 / PEAK["hbm_GBs"],
+                             "note": "the launch's own operand stream against the HBM peak (tile in, stashes out): the other roof of this kernel"}}
     else:
         b8d = float(e.info.bytes_in) * B + (4.0 * e.spec.flat_size() if dom["name"].startswith("gradw") else 0.0)
         achieved = b8d / avg_s / 1e9
