@@ -240,7 +240,7 @@ template <bool SPLIT, int MB, int NW> __global__ __launch_bounds__(64 * NW) void
 template <int U, int N, typename F> __device__ __forceinline__ void wd_for_g3(F&& f) {
     if constexpr (U < N) { f(std::integral_constant<int, U>{}); wd_for_g3<U + 1, N>(f); }
 }
-constexpr int G3_MB = 8, G3_NW = 4, G3_ROWS = G3_MB * 16, G3_NR = 8;      // NR: rows a thread stages per chunk (rows rr + 16 i)
+constexpr int G3_MB = 8, G3_ROWS = G3_MB * 16;
 constexpr int G3_MAXT = 16, G3_XI = 4, G3_META = G3_MAXT * (TERM_INTS + SRC_INTS + G3_XI) * 4;      // the job's term table, first sources and their resolved addresses, behind the two A tiles in LDS
 struct G3Chunk { const int* src; int n_src, kind, F, sign, kc, pack, nkc; int s_buf, s_node, s_mask, s_scale; bool pre; unsigned long long rbase, mbase; };      // pre: one plain source -> its rows can wait in registers
 __device__ __forceinline__ int g3_u(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -258,37 +258,40 @@ __device__ __forceinline__ G3Chunk g3_chunk(const GArgs& a, const int* meta, int
     q.mbase = ((unsigned long long)(unsigned)g3_u(xi[3]) << 32) | (unsigned)g3_u(xi[2]);
     return q;
 }
-__global__ __launch_bounds__(64 * G3_NW) void k_gstep3(GArgs a) {
+// NS: 32-column slices per wave.  4: four waves per workgroup (one per SIMD, 512 registers each); 2: eight waves (two per SIMD: one wave's memory waits run
+// under the other's MFMAs), 128 accumulator + 128 vector registers each.
+template <int NS> __global__ __launch_bounds__(64 * 16 / NS) void k_gstep3(GArgs a) {
     using P = P16;
-    constexpr int MB = G3_MB, NR = G3_NR;
+    constexpr int MB = G3_MB, NWV = 16 / NS, NT = 64 * NWV, RS = NT / 16, NR = G3_ROWS / RS, TUP = 8 * NS;      // RS: rows between a thread's staging rows; NR of them
     extern __shared__ __attribute__((aligned(16))) char smem[];      // two A tiles of MB blocks, then the job's term table
     const int tid = threadIdx.x, lane = tid & 63, wq = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nctg = a.NCT / 4;
-    const int ct = (blockIdx.x % nctg) * 4 + wq, tile = (blockIdx.x / nctg) % a.tiles;
+    const int ct = (blockIdx.x % nctg) * 4 + wq * NS / 4, wv0 = (wq * NS) & 3, tile = (blockIdx.x / nctg) % a.tiles;      // the wave's slices wv0 .. wv0 + NS - 1 of pack tile ct
     const int* job = a.jobs + (size_t)(a.job0 + blockIdx.x / (nctg * a.tiles)) * JOB_INTS;
     const int w0 = tile * G3_ROWS, B = a.B, Hd = a.Hd;
     const int flags = job[J_FLAGS];
     const T16* wpack = reinterpret_cast<const T16*>(a.wpack);
+    const size_t wsl = (size_t)wv0 * P::NBV * 64 * 8;      // elements from a pack image to this wave's first slice
 
 #ifdef G3_STAMPS
-    long long tk0 = clock64(), tk_asm = 0, tk1 = 0, tk2 = 0, tk_stage = 0, tk_bar = 0, tk_req = 0;
+    long long tk0 = clock64(), tk_asm = 0, tk1 = 0, tk2 = 0, tk_stage = 0, tk_bar = 0;
 #endif
-    GAcc R;
+    GAcc<NS> R;
     {
-        float bv[32];
+        float bv[TUP];
 #pragma unroll
-        for (int k = 0; k < 32; ++k) bv[k] = 0.f;
+        for (int k = 0; k < TUP; ++k) bv[k] = 0.f;
         if (flags & JF_BIAS) {
             const float* bias = a.bias + ((size_t)job[J_BIAS] + ct) * TW;
 #pragma unroll
-            for (int cb = 0; cb < 8; ++cb) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(bias + (cb >> 1) * 32 + c_feat(cb & 1, lane));
+            for (int cb = 0; cb < 2 * NS; ++cb) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(bias + (wv0 + (cb >> 1)) * 32 + c_feat(cb & 1, lane));
                 bv[4 * cb] = v[0]; bv[4 * cb + 1] = v[1]; bv[4 * cb + 2] = v[2]; bv[4 * cb + 3] = v[3];
             }
         }
         g4_init(R, bv);
     }
-    const int c = tid & 15, rr = tid >> 4;              // staging: thread = (rows rr + 16 i, i < NR, 8-element chunk c)
+    const int c = tid & 15, rr = tid >> 4;              // staging: thread = (rows rr + RS i, i < NR, 8-element chunk c)
     const int ao0 = lds_chunk<T16>(0, lane & 15, (lane >> 4) * P::NAV);
     const int nterms = job[J_NTERMS];
     const int* term0 = a.terms + (size_t)job[J_TERM0] * TERM_INTS;
@@ -309,22 +312,21 @@ __global__ __launch_bounds__(64 * G3_NW) void k_gstep3(GArgs a) {
     }
     __syncthreads();
 
-    g4_f32x32 rowsv; g4_u32x8 rmaskv;      // the staged chunk's rows (8 x 16 bytes) and relu bytes: requested by the MFMA block of the chunk before (first chunk: below)
-    // this thread's part of a row / relu-byte address is rebuilt from the row number (two or three VALU per load: sixteen live address registers across the
-    // MFMA block made hipcc spill, and a scratch reload is a vmcnt(0) between the requests); the chunk's part is wave-uniform
+    G4Rows<NS> rowsv; G4Mask<NS> rmaskv;      // the staged chunk's rows (NR x 16 bytes) and relu bytes: requested by the MFMA block of the chunk before (first chunk: below)
+    // this thread's part of a row / relu-byte address (full tiles: row rr + RS i < B); the chunk's part is wave-uniform
     const int tilesB = (B + 15) >> 4;
-    auto toff = [&](int i) { const int w = min(w0 + rr + 16 * i, B - 1); return (unsigned)(((size_t)w * Hd + c * 8) * sizeof(T16)); };
-    auto toffm = [&](int i) { const int w = min(w0 + rr + 16 * i, B - 1); return (unsigned)((((size_t)(c >> 2) * tilesB + (w >> 4)) << 6) + ((c & 3) << 4) + (w & 15)); };
+    auto toff = [&](int i) { const int w = w0 + rr + RS * i; return (unsigned)(((size_t)w * Hd + c * 8) * sizeof(T16)); };
+    auto toffm = [&](int i) { const int w = w0 + rr + RS * i; return (unsigned)((((size_t)(c >> 2) * tilesB + (w >> 4)) << 6) + ((c & 3) << 4) + (w & 15)); };
     // row / relu-byte base of a chunk (a chunk that is gathered at staging time, or has no mask, reads the start of the workspace instead)
     auto row_base = [&](const G3Chunk& q) { return q.pre ? reinterpret_cast<const char*>(q.rbase) + (size_t)q.kc * TW * sizeof(T16) : a.ws; };
     auto mask_base = [&](const G3Chunk& q) { return (q.pre && q.s_mask >= 0) ? reinterpret_cast<const char*>(q.mbase) + (((size_t)q.kc * 4 * tilesB) << 6) : a.ws; };
-    auto request = [&](const G3Chunk& q) {      // (first chunk only; full tiles: row rr + 16 i < B)
+    auto request = [&](const G3Chunk& q) {      // (first chunk only)
         const char* base = row_base(q); const char* mbase = mask_base(q);
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
-            const f32x4 v = __builtin_bit_cast(f32x4, *reinterpret_cast<const u32x4*>(base + toff(i)));
-            rowsv[4 * i] = v[0]; rowsv[4 * i + 1] = v[1]; rowsv[4 * i + 2] = v[2]; rowsv[4 * i + 3] = v[3];
-            rmaskv[i] = *reinterpret_cast<const uint8_t*>(mbase + toffm(i));
+            const f32x4 v = __builtin_bit_cast(f32x4, *reinterpret_cast<const u32x4*>(base + toff(i)));      // (whole-vector cast: hipcc 7.2 miscompiles a bit_cast of one element)
+            rowsv.v[4 * i] = v[0]; rowsv.v[4 * i + 1] = v[1]; rowsv.v[4 * i + 2] = v[2]; rowsv.v[4 * i + 3] = v[3];
+            rmaskv.v[i] = *reinterpret_cast<const uint8_t*>(mbase + toffm(i));
         }
     };
     auto stage = [&](const G3Chunk& q, int buf) {
@@ -334,54 +336,56 @@ __global__ __launch_bounds__(64 * G3_NW) void k_gstep3(GArgs a) {
             const bool msk = q.s_mask >= 0;
 #pragma unroll
             for (int i = 0; i < NR; ++i) {
-                const u32x4 rv = __builtin_bit_cast(u32x4, f32x4{rowsv[4 * i], rowsv[4 * i + 1], rowsv[4 * i + 2], rowsv[4 * i + 3]});
-                u32x4 v = chunk_mask_bits<T16>(rv, msk ? (rmaskv[i] & 0xffu) : 0xffu);
+                const int grow = rr + RS * i;
+                const u32x4 rv = __builtin_bit_cast(u32x4, f32x4{rowsv.v[4 * i], rowsv.v[4 * i + 1], rowsv.v[4 * i + 2], rowsv.v[4 * i + 3]});
+                u32x4 v = chunk_mask_bits<T16>(rv, msk ? (rmaskv.v[i] & 0xffu) : 0xffu);
                 if (sc != 1.0f) { float s8[8] = {0, 0, 0, 0, 0, 0, 0, 0}; acc8(s8, v, sc); v = pack_oct(f32x4{s8[0], s8[1], s8[2], s8[3]}, f32x4{s8[4], s8[5], s8[6], s8[7]}); }
-                *reinterpret_cast<u32x4*>(dst + lds_chunk<T16>(i, rr, c)) = v;
+                *reinterpret_cast<u32x4*>(dst + lds_chunk<T16>(grow >> 4, grow & 15, c)) = v;
             }
         } else {
+            constexpr int NB = NR < 4 ? NR : 4;
 #pragma unroll
-            for (int i0 = 0; i0 < NR; i0 += 4) {
-                float s8[4][8];
+            for (int i0 = 0; i0 < NR; i0 += NB) {
+                float s8[NB][8];
                 if (q.kind == 0) {
-                    // aggregate of several sources (fp32 sum in source order, as gather8): the four rows of a source are in flight together and the next
-                    // source's are requested before this one's are added (the base node of the 32-limb robot sums 32 sources)
+                    // aggregate of several sources (fp32 sum in source order, as gather8): the rows of a source are in flight together and the next source's are
+                    // requested before this one's are added (the base node of the 32-limb robot sums 32 sources)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < NB; ++i)
 #pragma unroll
                         for (int e = 0; e < 8; ++e) s8[i][e] = 0.f;
                     const int col = q.kc * TW + c * 8;
-                    u32x4 cv[4], nv[4]; unsigned cm[4], nm[4];
-                    auto fetch4 = [&](const int* sp, u32x4 (&v)[4], unsigned (&m)[4]) {
+                    u32x4 cv[NB], nv[NB]; unsigned cm[NB], nm[NB];
+                    auto fetchn = [&](const int* sp, u32x4 (&v)[NB], unsigned (&m)[NB]) {
                         const T16* bp = reinterpret_cast<const T16*>(a.ws + a.buf_off[sp[S_BUF]]);
                         const bool mk = sp[S_MASK] >= 0;
                         const uint8_t* mp = reinterpret_cast<const uint8_t*>(a.ws + (mk ? a.buf_off[sp[S_MASK]] : 0));
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int w = min(w0 + rr + 16 * (i0 + i), B - 1);
+                        for (int i = 0; i < NB; ++i) {
+                            const int w = w0 + rr + RS * (i0 + i);
                             v[i] = *reinterpret_cast<const u32x4*>(bp + g_row<false>(w, sp[S_NODE], B, Hd) + col);
                             const unsigned byte = mp[mk ? g_relu_byte(sp[S_NODE], B, Hd, w, col) : (size_t)0];
                             m[i] = mk ? byte : 0xffu;
                         }
                     };
-                    fetch4(q.src, cv, cm);
+                    fetchn(q.src, cv, cm);
                     for (int k = 0; k < q.n_src; ++k) {
                         const int* sp = q.src + (size_t)k * SRC_INTS;
-                        if (k + 1 < q.n_src) fetch4(sp + SRC_INTS, nv, nm);
+                        if (k + 1 < q.n_src) fetchn(sp + SRC_INTS, nv, nm);
                         const float sc = __int_as_float(sp[S_SCALE]);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) { acc8(s8[i], chunk_mask_bits<T16>(cv[i], cm[i]), sc); cv[i] = nv[i]; cm[i] = nm[i]; }
+                        for (int i = 0; i < NB; ++i) { acc8(s8[i], chunk_mask_bits<T16>(cv[i], cm[i]), sc); cv[i] = nv[i]; cm[i] = nm[i]; }
                     }
                 } else {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int w = min(w0 + rr + 16 * (i0 + i), B - 1);
-                        raw8<false>(a, q.src[S_BUF], q.src[S_NODE], w, q.kc * TW + c * 8, q.F, a.signs + q.sign + q.kc * TW + c * 8, s8[i]);
-                    }
+                    for (int i = 0; i < NB; ++i)
+                        raw8<false>(a, q.src[S_BUF], q.src[S_NODE], w0 + rr + RS * (i0 + i), q.kc * TW + c * 8, q.F, a.signs + q.sign + q.kc * TW + c * 8, s8[i]);
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    *reinterpret_cast<u32x4*>(dst + lds_chunk<T16>(i0 + i, rr, c)) = pack_oct(f32x4{s8[i][0], s8[i][1], s8[i][2], s8[i][3]}, f32x4{s8[i][4], s8[i][5], s8[i][6], s8[i][7]});
+                for (int i = 0; i < NB; ++i) {
+                    const int grow = rr + RS * (i0 + i);
+                    *reinterpret_cast<u32x4*>(dst + lds_chunk<T16>(grow >> 4, grow & 15, c)) = pack_oct(f32x4{s8[i][0], s8[i][1], s8[i][2], s8[i][3]}, f32x4{s8[i][4], s8[i][5], s8[i][6], s8[i][7]});
+                }
             }
         }
     };
@@ -393,13 +397,13 @@ __global__ __launch_bounds__(64 * G3_NW) void k_gstep3(GArgs a) {
     G3Chunk cur = g3_chunk(a, meta, 0, 0, ct);
     request(cur);
     // the weight fragments of a chunk's first K step: requested here for the first chunk, by the MFMA block of the chunk before for every other one
-    g4_f32x32 w0f;
+    G4W<NS> w0f;
     {
-        const u32x4* wb = reinterpret_cast<const u32x4*>(wpack + (size_t)cur.pack * H * H) + lane;
+        const u32x4* wb = reinterpret_cast<const u32x4*>(wpack + (size_t)cur.pack * H * H + wsl) + lane;
 #pragma unroll
-        for (int cb = 0; cb < 8; ++cb) {
-            const f32x4 v = __builtin_bit_cast(f32x4, wb[(size_t)((cb >> 1) * P::NBV + 4 * (cb & 1)) * 64]);      // (whole-vector cast: hipcc 7.2 miscompiles a bit_cast of one element)
-            w0f[4 * cb] = v[0]; w0f[4 * cb + 1] = v[1]; w0f[4 * cb + 2] = v[2]; w0f[4 * cb + 3] = v[3];
+        for (int cb = 0; cb < 2 * NS; ++cb) {
+            const f32x4 v = __builtin_bit_cast(f32x4, wb[(size_t)((cb >> 1) * P::NBV + 4 * (cb & 1)) * 64]);
+            w0f.v[4 * cb] = v[0]; w0f.v[4 * cb + 1] = v[1]; w0f.v[4 * cb + 2] = v[2]; w0f.v[4 * cb + 3] = v[3];
         }
     }
     while (true) {
@@ -417,12 +421,9 @@ __global__ __launch_bounds__(64 * G3_NW) void k_gstep3(GArgs a) {
         if (more) nxt = g3_chunk(a, meta, nti, nkc, ct);
         __syncthreads();      // this chunk's A tile is complete; every wave is past the block of the chunk before (the other buffer is free for the next stage)
 #ifdef G3_STAMPS
-        const long long ts2 = clock64(); tk_bar += ts2 - ts1;
+        const long long ta = clock64(); tk_bar += ta - ts1;
 #endif
-#ifdef G3_STAMPS
-        const long long ta = clock64(); tk_req += ta - ts2;
-#endif
-        g4_chunk(R, w0f, rowsv, rmaskv, wpack + (size_t)cur.pack * H * H, wpack + (size_t)nxt.pack * H * H, row_base(nxt), mask_base(nxt), (unsigned)(16 * Hd * sizeof(T16)),
+        g4_chunk(R, w0f, rowsv, rmaskv, wpack + (size_t)cur.pack * H * H + wsl, wpack + (size_t)nxt.pack * H * H + wsl, row_base(nxt), mask_base(nxt), (unsigned)(RS * Hd * sizeof(T16)),
                  (int)toff(0), (int)toffm(0), (unsigned)((it & 1) * (MB * P::BLK)), ao0, lane * 16);
 #ifdef G3_STAMPS
         tk_asm += clock64() - ta;
@@ -433,7 +434,7 @@ __global__ __launch_bounds__(64 * G3_NW) void k_gstep3(GArgs a) {
 #ifdef G3_STAMPS
     tk2 = clock64();
 #endif
-    // epilogue, two row blocks at a time: every gate / residual / relu-byte load of the eight (row block, slice) pieces is requested before the first is used
+    // epilogue, two row blocks at a time: every gate / residual / relu-byte load of the (row block, slice) pieces is requested before the first is used
     // (gstep_epilogue's arithmetic; one memory round trip per pair of row blocks instead of one per piece)
     {
         const int oflags = flags;
@@ -446,16 +447,16 @@ __global__ __launch_bounds__(64 * G3_NW) void k_gstep3(GArgs a) {
         const int gnode = job[J_GATE_NODE], rnode = job[J_RES_NODE];
         wd_for_g3<0, MB / 2>([&](auto mc) {
             constexpr int M2 = decltype(mc)::value;
-            float o[2][32];
+            float o[2][TUP];
             g4_read<2 * M2>(R, o[0]);
             g4_read<2 * M2 + 1>(R, o[1]);
-            u32x4 gv[2][4], rv[2][4]; unsigned xb[2][4];
+            u32x4 gv[2][NS], rv[2][NS]; unsigned xb[2][NS];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int wb = w0 + (2 * M2 + h) * P::ROWS, wc = min(wb + c_win(lane), B - 1);
 #pragma unroll
-                for (int sl = 0; sl < 4; ++sl) {
-                    const int col = ct * TW + sl * 32 + c_oct(lane);
+                for (int sl = 0; sl < NS; ++sl) {
+                    const int col = ct * TW + (wv0 + sl) * 32 + c_oct(lane);
                     gv[h][sl] = u32x4{0, 0, 0, 0}; rv[h][sl] = u32x4{0, 0, 0, 0}; xb[h][sl] = 0xffu;
                     if (gsrc) gv[h][sl] = *reinterpret_cast<const u32x4*>(gsrc + g_row<false>(wc, gnode, B, Hd) + col);
                     if (rsrc) rv[h][sl] = *reinterpret_cast<const u32x4*>(rsrc + g_row<false>(wc, rnode, B, Hd) + col);
@@ -467,8 +468,8 @@ __global__ __launch_bounds__(64 * G3_NW) void k_gstep3(GArgs a) {
                 const int wb = w0 + (2 * M2 + h) * P::ROWS, w = wb + c_win(lane);
                 if (wb >= B) continue;
 #pragma unroll
-                for (int sl = 0; sl < 4; ++sl) {
-                    const int col = ct * TW + sl * 32 + c_oct(lane);
+                for (int sl = 0; sl < NS; ++sl) {
+                    const int col = ct * TW + (wv0 + sl) * 32 + c_oct(lane);
                     P::Acc ac;
                     ac.c[0] = f32x4{o[h][8 * sl], o[h][8 * sl + 1], o[h][8 * sl + 2], o[h][8 * sl + 3]};
                     ac.c[1] = f32x4{o[h][8 * sl + 4], o[h][8 * sl + 5], o[h][8 * sl + 6], o[h][8 * sl + 7]};
@@ -495,8 +496,8 @@ __global__ __launch_bounds__(64 * G3_NW) void k_gstep3(GArgs a) {
     }
 #ifdef G3_STAMPS
     if (a.slabs && tid == 0) {
-        long long* st = reinterpret_cast<long long*>(a.slabs) + (size_t)blockIdx.x * 8; long long* st2 = reinterpret_cast<long long*>(a.slabs) + 4096 * 8 + blockIdx.x; *st2 = tk_req;
-        st[0] = tk1 - tk0; st[1] = tk2 - tk1; st[2] = tk_asm; st[3] = clock64() - tk2; st[4] = it + 1; st[5] = clock64() - tk0; st[6] = tk_stage; st[7] = tk_bar; if (blockIdx.x < 2048) st[8 * 2048 * 0 + 0] = st[0];
+        long long* st = reinterpret_cast<long long*>(a.slabs) + (size_t)blockIdx.x * 8;
+        st[0] = tk1 - tk0; st[1] = tk2 - tk1; st[2] = tk_asm; st[3] = clock64() - tk2; st[4] = it + 1; st[5] = clock64() - tk0; st[6] = tk_stage; st[7] = tk_bar;
     }
 #endif
 }
@@ -993,7 +994,7 @@ static int g_fill(const mshgnn_plan* p, const mshgnn_ws_layout& lay, const void*
 static int g_tile_blocks(int B, bool split) {
     const char* e = getenv("MSHGNN_GEN_TILE");      // (kernel experiments; read per launch so that a test can compare modes in one process)
     const int forced = e ? atoi(e) : -1;
-    if (forced >= 0 && forced <= 4) return forced;
+    if (forced >= 0 && forced <= 5) return forced;
     (void)B; return split ? 2 : 3;      // the widest column tile the hidden width and the registers allow (16 waves of the split kernel spill)
 }
 
@@ -1005,15 +1006,16 @@ static void g_launch_jobs(const mshgnn_plan* p, const Launch& ln, GArgs a, hipSt
     // activations fewer times (hidden / (32 NW) column groups per row of jobs): measured at h=512, B=1024: layer_fwd bf16 515 / 354 / 296 us at
     // 4 / 8 / 16 waves, split 870 / 799 / 1012 us (16 waves: 128 VGPRs, spills); 128-window tiles lose (fewer resident workgroups hide less
     // of the staging latency: 495 us at 8 waves, 389 us at 16 waves with 56 B of scratch)
-    const int mode = g_tile_blocks(a.B, gp.split);      // 0: 4 waves; 1: 8 waves, 128 windows; 2: 8 waves; 3: 16 waves; 4: k_gstep3 (bf16, hidden % 512 == 0)
-    if (mode == 4 && !gp.split && gp.NCT % 4 == 0 && a.B % G3_ROWS == 0) {      // (full 128-window tiles: the block requests the next chunk's rows without a row clamp)
-        a.tiles = (a.B + G3_ROWS - 1) / G3_ROWS;
+    const int mode = g_tile_blocks(a.B, gp.split);      // 0: 4 waves; 1: 8 waves, 128 windows; 2: 8 waves; 3: 16 waves; 4 / 5: k_gstep3 with 4 / 8 waves (bf16, hidden % 512 == 0)
+    if ((mode == 4 || mode == 5) && !gp.split && gp.NCT % 4 == 0 && a.B % G3_ROWS == 0) {      // (full 128-window tiles: the block requests the next chunk's rows without a row clamp)
+        a.tiles = a.B / G3_ROWS;
         const unsigned grid3 = (unsigned)ln.n_jobs * a.tiles * (a.NCT / 4);
 #ifdef G3_STAMPS
         { const char* e = getenv("MSHGNN_G3_STAMPS"); a.slabs = e ? reinterpret_cast<float*>(strtoull(e, nullptr, 16)) : nullptr; }
 #endif
         ProfScope ps(p, ln.ks, st);
-        hipLaunchKernelGGL(k_gstep3, dim3(grid3), dim3(64 * G3_NW), 2 * G3_MB * P16::BLK + G3_META, st, a);
+        if (mode == 4) hipLaunchKernelGGL(k_gstep3<4>, dim3(grid3), dim3(256), 2 * G3_MB * P16::BLK + G3_META, st, a);
+        else hipLaunchKernelGGL(k_gstep3<2>, dim3(grid3), dim3(512), 2 * G3_MB * P16::BLK + G3_META, st, a);
         return;
     }
     int nw = 4;

@@ -5,7 +5,7 @@ sys.path.insert(0, "/root/repo" if os.path.exists("/root/repo/bench.py") else os
 from morphsym_hgnn_amd import engine as eng, synth, topology
 from morphsym_hgnn_amd.spec import ModelSpec
 if sys.argv[1] == "cmp":
-    a = torch.load("gpurun_out/dbg_gen_3.pt"); b = torch.load("gpurun_out/dbg_gen_4.pt")
+    a = torch.load("gpurun_out/dbg_gen_3.pt"); b = torch.load(f"gpurun_out/dbg_gen_{sys.argv[2] if len(sys.argv) > 2 else 4}.pt")
     print("out equal", torch.equal(a["out"], b["out"]), float((a["out"] - b["out"]).abs().max()))
     for l, (x, z) in enumerate(zip(a["hs"], b["hs"])):
         d = (x - z).abs()
