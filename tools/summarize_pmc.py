@@ -12,7 +12,7 @@ def per_kernel(pattern, counter):
     return {k: sum(v) / len(v) for k, v in agg.items()}
 
 def short(name):
-    for key, s in [("k_prep", "prep"), ("k_enc_fwd", "enc_fwd"), ("k_enc_x3", "enc_fwd"), ("k_gstep", "gstep"), ("k_ggradw", "ggradw"), ("k_stack_fwd", "stack_fwd"), ("k_stack_bwd", "stack_bwd"), ("k_slab_step", "stack_step"), ("k_slab_fwd", "stack_fwd"), ("k_slab_bwd", "stack_bwd"), ("k_eng_fwd", "stack_fwd"), ("k_eng_bwd", "stack_bwd"), ("k_wide_fwd", "stack_fwd"), ("k_wide_bwd", "stack_bwd"),
+    for key, s in [("k_prep", "prep"), ("k_enc_fwd", "enc_fwd"), ("k_enc_x3", "enc_fwd"), ("k_gstep", "gstep"), ("k_ggradw", "ggradw"), ("k_stack_fwd", "stack_fwd"), ("k_stack_bwd", "stack_bwd"), ("k_slab_step", "stack_step"), ("k_stack_step", "stack_step"), ("k_slab_fwd", "stack_fwd"), ("k_slab_bwd", "stack_bwd"), ("k_eng_fwd", "stack_fwd"), ("k_eng_bwd", "stack_bwd"), ("k_wide_fwd", "stack_fwd"), ("k_wide_bwd", "stack_bwd"),
                    ("k_layer_fwd", "layer_fwd"), ("k_dec_fwd", "dec_fwd"),
                    ("k_dec_bwd", "dec_bwd"), ("k_layer_bwd", "layer_bwd"), ("k_gradw", "gradw"), ("k_finalize", "finalize"), ("k_mse", "mse")]:
         if key in name:
