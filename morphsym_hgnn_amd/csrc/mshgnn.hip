@@ -1257,50 +1257,57 @@ template <typename T, int NM, int HB, bool STEP> __device__ __forceinline__ void
             const T* t1 = reinterpret_cast<const T*>(a.ws + a.t1_off[l]);
             T* du = reinterpret_cast<T*>(a.ws + a.du_off[l]);
             T* dh = reinterpret_cast<T*>(a.ws + a.dh_off[l]);
+            // Two nodes at a time (K4 has four base_transform nodes: all four at once need 16 accumulator + 16 staging registers the kernel does not have next
+            // to the carried residual rows; each pair pays its own three barriers -- the chain is a few hundred cycles, the spills were round trips)
             typename P::BFrag bf;      // one buffer for both weights: a carried residual (72 VGPRs) lives through this chain
             typename P::AFrag af;
-            typename P::Acc tm[NM];
-            u32x4 traw[NM], dupk[NM];
-            load_bfrag<T>(bf, wpack, bh[FH_W2], wn, lane);
+            for (int u0 = 0; u0 < NM; u0 += 2) {
+                if (u0 >= nmlp) break;      // (uniform)
+                typename P::Acc tm[2];
+                u32x4 traw[2], dupk[2];
+                load_bfrag<T>(bf, wpack, bh[FH_W2], wn, lane);
 #pragma unroll
-            for (int u = 0; u < NM; ++u) {
-                traw[u] = u32x4{0, 0, 0, 0};
-                if (u < nmlp) {
-                    traw[u] = *reinterpret_cast<const u32x4*>(t1 + act_idx(wc, u, B) + col);
-                    acc_fill(tm[u], 0.f);
-                    load_afrag<T>(af, smem, u, lane);
-                    mac(tm[u], af, bf);
+                for (int v = 0; v < 2; ++v) {
+                    const int u = u0 + v;
+                    traw[v] = u32x4{0, 0, 0, 0};
+                    if (u < nmlp) {
+                        traw[v] = *reinterpret_cast<const u32x4*>(t1 + act_idx(wc, u, B) + col);
+                        acc_fill(tm[v], 0.f);
+                        load_afrag<T>(af, smem, u, lane);
+                        mac(tm[v], af, bf);
+                    }
                 }
-            }
-            load_bfrag<T>(bf, wpack, bh[FH_W1], wn, lane);
-            __syncthreads();   // all reads of the dY blocks done
+                load_bfrag<T>(bf, wpack, bh[FH_W1], wn, lane);
+                __syncthreads();   // all reads of the dY blocks done
 #pragma unroll
-            for (int u = 0; u < NM; ++u) {
-                if (u < nmlp) {
-                    f32x4 t0, t1v, r0, r1; unpack_oct(traw[u], t0, t1v);
+                for (int v = 0; v < 2; ++v) {
+                    const int u = u0 + v;
+                    dupk[v] = u32x4{0, 0, 0, 0};
+                    if (u < nmlp) {
+                        f32x4 t0, t1v, r0, r1; unpack_oct(traw[v], t0, t1v);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { r0[j] = t0[j] > 0.f ? tm[u].c[0][j] : 0.f; r1[j] = t1v[j] > 0.f ? tm[u].c[1][j] : 0.f; }
-                    dupk[u] = pack_oct(r0, r1);
-                    *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(u, win, col / P::EPC)) = dupk[u];
-                    // four base_transform nodes (K4): the dU rows go out at once -- holding them to the end of the chain costs 16 VGPRs the
-                    // kernel does not have (no global load follows inside the chain; the MAC phase drains the stores before its first fragment)
-                    if constexpr (NM > 2) { if (w_ok) *reinterpret_cast<u32x4*>(du + act_idx(w, u, B) + col) = dupk[u]; }
+                        for (int j = 0; j < 4; ++j) { r0[j] = t0[j] > 0.f ? tm[v].c[0][j] : 0.f; r1[j] = t1v[j] > 0.f ? tm[v].c[1][j] : 0.f; }
+                        dupk[v] = pack_oct(r0, r1);
+                        *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(u, win, col / P::EPC)) = dupk[v];
+                    }
                 }
-            }
-            __syncthreads();
+                __syncthreads();
 #pragma unroll
-            for (int u = 0; u < NM; ++u) {
-                if (u < nmlp) { acc_fill(tm[u], 0.f); load_afrag<T>(af, smem, u, lane); mac(tm[u], af, bf); }
-            }
-            __syncthreads();   // all reads of the dU blocks done
+                for (int v = 0; v < 2; ++v) {
+                    const int u = u0 + v;
+                    if (u < nmlp) { acc_fill(tm[v], 0.f); load_afrag<T>(af, smem, u, lane); mac(tm[v], af, bf); }
+                }
+                __syncthreads();   // all reads of the dU blocks done
 #pragma unroll
-            for (int u = 0; u < NM; ++u) {
-                if (u < nmlp) {
-                    const u32x4 hp = pack_oct(tm[u].c[0], tm[u].c[1]);
-                    *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(u, win, col / P::EPC)) = hp;
-                    if (w_ok) {
-                        if constexpr (NM <= 2) *reinterpret_cast<u32x4*>(du + act_idx(w, u, B) + col) = dupk[u];
-                        *reinterpret_cast<u32x4*>(dh + act_idx(w, u, B) + col) = hp;
+                for (int v = 0; v < 2; ++v) {
+                    const int u = u0 + v;
+                    if (u < nmlp) {
+                        const u32x4 hp = pack_oct(tm[v].c[0], tm[v].c[1]);
+                        *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(u, win, col / P::EPC)) = hp;
+                        if (w_ok) {
+                            *reinterpret_cast<u32x4*>(du + act_idx(w, u, B) + col) = dupk[v];
+                            *reinterpret_cast<u32x4*>(dh + act_idx(w, u, B) + col) = hp;
+                        }
                     }
                 }
             }
