@@ -19,13 +19,14 @@ def short(name):
             return s
     return None
 
-fetch = per_kernel(sys.argv[1] + "/**/*counter_collection.csv", "FETCH_SIZE")
-write = per_kernel(sys.argv[2] + "/**/*counter_collection.csv", "WRITE_SIZE")
-out = {}
-for k, v in fetch.items():
-    s = short(k)
-    if s:
-        out[s] = {"fetch_bytes": 2.0 * v * 1024.0, "write_bytes": write.get(k, 0.0) * 1024.0}
-        out[s]["hbm_bytes"] = out[s]["fetch_bytes"] + out[s]["write_bytes"]
-json.dump({"note": "per launch, averaged over launches (layer_fwd / layer_bwd: averaged over the L layers); "
-                   "FETCH_SIZE x2 (gfx950), KiB -> bytes", "kernels": out}, sys.stdout, indent=1)
+if __name__ == "__main__":
+    fetch = per_kernel(sys.argv[1] + "/**/*counter_collection.csv", "FETCH_SIZE")
+    write = per_kernel(sys.argv[2] + "/**/*counter_collection.csv", "WRITE_SIZE")
+    out = {}
+    for k, v in fetch.items():
+        s = short(k)
+        if s:
+            out[s] = {"fetch_bytes": 2.0 * v * 1024.0, "write_bytes": write.get(k, 0.0) * 1024.0}
+            out[s]["hbm_bytes"] = out[s]["fetch_bytes"] + out[s]["write_bytes"]
+    json.dump({"note": "per launch, averaged over launches (layer_fwd / layer_bwd: averaged over the L layers); "
+                       "FETCH_SIZE x2 (gfx950), KiB -> bytes", "kernels": out}, sys.stdout, indent=1)
