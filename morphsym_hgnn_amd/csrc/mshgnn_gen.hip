@@ -229,6 +229,94 @@ template <bool SPLIT, int MB, int NW> __global__ __launch_bounds__(64 * NW) void
 }
 
 // ------------------------------------------------------------------------------------------------------
+// k_gstep4 (bf16 arithmetic): k_gstep's 16 waves on 128-window tiles
+// ------------------------------------------------------------------------------------------------------
+// k_gstep is bound by its weight stream (8 KB of fragments per wave and K chunk through L1 / L2: 2.2 GB per layer launch at h = 512, 7.6 TB/s); a weight
+// fragment that feeds 8 row blocks instead of 4 halves it.  Round 2's 128-window variant of k_gstep spilled at the 128 registers 16 waves leave (389 us against
+// 287); this kernel keeps the registers down instead: single-source chunks are staged as raw 16-byte chunks (mask applied on the packed value, no fp32 round trip),
+// other chunks one row at a time, and the window fragments are read per K step (4 registers) instead of per row block (16).
+#ifndef G4_W_EARLY
+#define G4_W_EARLY 0
+#endif
+template <int NW> __global__ __launch_bounds__(64 * NW) void k_gstep4(GArgs a) {
+    using P = P16;
+    constexpr int MB = 8, CPW = NW / 4, NPASS = MB * 16 / (4 * NW);      // staging passes: thread = (row rr + 4 NW i, chunk c)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wq = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nctg = a.NCT / CPW;
+    const int ct = (blockIdx.x % nctg) * CPW + (wq >> 2), wv = wq & 3, tile = (blockIdx.x / nctg) % a.tiles;
+    const int* job = a.jobs + (size_t)(a.job0 + blockIdx.x / (nctg * a.tiles)) * JOB_INTS;
+    const int w0 = tile * MB * P::ROWS, B = a.B, Hd = a.Hd;
+    const int flags = job[J_FLAGS];
+    const T16* wpack = reinterpret_cast<const T16*>(a.wpack);
+
+    P::Acc acc[MB];
+    {
+        const float* bias = (flags & JF_BIAS) ? a.bias + ((size_t)job[J_BIAS] + ct) * TW : nullptr;
+#pragma unroll
+        for (int m = 0; m < MB; ++m) acc_init_bias<T16>(acc[m], bias, wv, lane);
+    }
+    const int c = tid & 15, rr = tid >> 4;
+    const int ao0 = lds_chunk<T16>(0, lane & 15, (lane >> 4) * P::NAV);
+    const int one_bits = __float_as_int(1.0f);
+    P::BFrag bf;
+    const int* term = a.terms + (size_t)job[J_TERM0] * TERM_INTS;
+    for (int ti = 0; ti < job[J_NTERMS]; ++ti, term += TERM_INTS) {
+        const int nkc = term[T_NKC], kind = term[T_KIND], n_src = term[T_NSRC], F = term[T_WIDTH];
+        const int* src = a.srcs + (size_t)term[T_SRC0] * SRC_INTS;
+        const bool plain = kind == 0 && n_src == 1 && src[S_SCALE] == one_bits;
+        for (int kc = 0; kc < nkc; ++kc) {
+#if G4_W_EARLY
+            load_bfrag<T16>(bf, wpack, term[T_PACK] + kc * a.NCT + ct, wv, lane);      // (before the staging: its L2 latency runs under the rows')
+#endif
+            __syncthreads();   // the previous chunk's MFMAs are done reading LDS
+            if (plain) {
+                const T16* base = reinterpret_cast<const T16*>(a.ws + a.buf_off[src[S_BUF]]);
+                const bool msk = src[S_MASK] >= 0;
+                const uint8_t* mb = reinterpret_cast<const uint8_t*>(a.ws + (msk ? a.buf_off[src[S_MASK]] : 0));
+                const int col = kc * TW + c * 8;
+                u32x4 v[NPASS]; unsigned bm[NPASS];
+#pragma unroll
+                for (int i = 0; i < NPASS; ++i) {
+                    const int w = min(w0 + i * (4 * NW) + rr, B - 1);
+                    v[i] = *reinterpret_cast<const u32x4*>(base + g_row<false>(w, src[S_NODE], B, Hd) + col);
+                    bm[i] = msk ? mb[g_relu_byte(src[S_NODE], B, Hd, w, col)] : 0xffu;
+                }
+#pragma unroll
+                for (int i = 0; i < NPASS; ++i) {
+                    const int grow = i * (4 * NW) + rr;
+                    *reinterpret_cast<u32x4*>(smem + lds_chunk<T16>(grow >> 4, grow & 15, c)) = chunk_mask_bits<T16>(v[i], bm[i]);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NPASS; ++i) {
+                    float s8[8];
+                    const int w = min(w0 + i * (4 * NW) + rr, B - 1);
+                    if (kind == 0) gather8<false>(a, src, n_src, w, kc * TW + c * 8, s8);
+                    else raw8<false>(a, src[S_BUF], src[S_NODE], w, kc * TW + c * 8, F, a.signs + term[T_SIGN] + kc * TW + c * 8, s8);
+                    const int grow = i * (4 * NW) + rr;
+                    *reinterpret_cast<u32x4*>(smem + lds_chunk<T16>(grow >> 4, grow & 15, c)) = pack_oct(f32x4{s8[0], s8[1], s8[2], s8[3]}, f32x4{s8[4], s8[5], s8[6], s8[7]});
+                }
+            }
+            __syncthreads();
+#if !G4_W_EARLY
+            load_bfrag<T16>(bf, wpack, term[T_PACK] + kc * a.NCT + ct, wv, lane);
+#endif
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const bf16x8 xf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(smem + m * P::BLK + (ao0 ^ (16 * t))));
+                    acc[m].c[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf.v[t], xf, acc[m].c[0], 0, 0, 0);
+                    acc[m].c[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf.v[4 + t], xf, acc[m].c[1], 0, 0, 0);
+                }
+            }
+        }
+    }
+    gstep_epilogue<false, MB>(a, job, acc, ct, wv, lane, w0);
+}
+
+// ------------------------------------------------------------------------------------------------------
 // k_gstep3 (bf16 arithmetic, hidden a multiple of 512): the same jobs on 128-window x 512-column workgroup tiles, MFMA block in asm
 // ------------------------------------------------------------------------------------------------------
 // 4 waves, one workgroup per CU, the whole register file: wave wq owns 128 windows x the 128 columns of pack tile ctg 4 + wq -- 256 accumulator registers that
@@ -994,8 +1082,10 @@ static int g_fill(const mshgnn_plan* p, const mshgnn_ws_layout& lay, const void*
 static int g_tile_blocks(int B, bool split) {
     const char* e = getenv("MSHGNN_GEN_TILE");      // (kernel experiments; read per launch so that a test can compare modes in one process)
     const int forced = e ? atoi(e) : -1;
-    if (forced >= 0 && forced <= 5) return forced;
-    (void)B; return split ? 2 : 3;      // the widest column tile the hidden width and the registers allow (16 waves of the split kernel spill)
+    if (forced >= 0 && forced <= 6) return forced;
+    // bf16: 16 waves; on 128-window tiles (k_gstep4) once the batch has two of them -- half the weight stream per window, 250-258 / 252-314 us per layer launch
+    // against 285-292 / 303-357 on the 32-limb model; split: 8 waves (16 waves of the split kernel spill)
+    return split ? 2 : (B >= 256 ? 6 : 3);
 }
 
 static void g_launch_jobs(const mshgnn_plan* p, const Launch& ln, GArgs a, hipStream_t st) {
@@ -1006,7 +1096,14 @@ static void g_launch_jobs(const mshgnn_plan* p, const Launch& ln, GArgs a, hipSt
     // activations fewer times (hidden / (32 NW) column groups per row of jobs): measured at h=512, B=1024: layer_fwd bf16 515 / 354 / 296 us at
     // 4 / 8 / 16 waves, split 870 / 799 / 1012 us (16 waves: 128 VGPRs, spills); 128-window tiles lose (fewer resident workgroups hide less
     // of the staging latency: 495 us at 8 waves, 389 us at 16 waves with 56 B of scratch)
-    const int mode = g_tile_blocks(a.B, gp.split);      // 0: 4 waves; 1: 8 waves, 128 windows; 2: 8 waves; 3: 16 waves; 4 / 5: k_gstep3 with 4 / 8 waves (bf16, hidden % 512 == 0)
+    const int mode = g_tile_blocks(a.B, gp.split);      // 0: 4 waves; 1: 8 waves, 128 windows; 2: 8 waves; 3: 16 waves; 4 / 5: k_gstep3 with 4 / 8 waves; 6: k_gstep4 (bf16, hidden % 512 == 0; the default from 256 windows)
+    if (mode == 6 && !gp.split && gp.NCT % 4 == 0) {      // k_gstep4: 16 waves on 128-window tiles (hidden a multiple of 512; other widths: k_gstep below)
+        a.tiles = (a.B + 127) / 128;
+        const unsigned grid4 = (unsigned)ln.n_jobs * a.tiles * (a.NCT / 4);
+        ProfScope ps(p, ln.ks, st);
+        hipLaunchKernelGGL(k_gstep4<16>, dim3(grid4), dim3(1024), 8 * P16::BLK, st, a);
+        return;
+    }
     if ((mode == 4 || mode == 5) && !gp.split && gp.NCT % 4 == 0 && a.B % G3_ROWS == 0) {      // (full 128-window tiles: the block requests the next chunk's rows without a row clamp)
         a.tiles = a.B / G3_ROWS;
         const unsigned grid3 = (unsigned)ln.n_jobs * a.tiles * (a.NCT / 4);
@@ -1020,7 +1117,7 @@ static void g_launch_jobs(const mshgnn_plan* p, const Launch& ln, GArgs a, hipSt
     }
     int nw = 4;
     if ((mode == 1 || mode == 2) && gp.NCT % 2 == 0) nw = 8;
-    if (mode == 3) nw = gp.NCT % 4 == 0 ? 16 : (gp.NCT % 2 == 0 ? 8 : 4);
+    if (mode == 3 || mode >= 4) nw = gp.NCT % 4 == 0 ? 16 : (gp.NCT % 2 == 0 ? 8 : 4);
     const int mb = (nw == 8 && mode == 1) ? 8 : 4;
     a.tiles = (a.B + mb * 16 - 1) / (mb * 16);
     const unsigned grid = (unsigned)ln.n_jobs * a.tiles * (a.NCT / (nw / 4));

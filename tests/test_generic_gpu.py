@@ -97,24 +97,26 @@ def test_generic_ragged_batches_and_step_equals_two_call_sequence():
     assert torch.equal(out_a, out_b) and torch.equal(g_a, g_b) and torch.equal(loss_a, loss_b)      # deterministic: fixed-order slab sums
 
 
-def test_asm_block_job_kernel_matches_the_default_one_bit_for_bit(monkeypatch):
-    """MSHGNN_GEN_TILE=4: the generic engine's job kernel on 128-window x 512-column tiles with its MFMA block in generated asm (k_gstep3, opt-in: measured
-    slower than the 16-wave kernel on most layers) -- same operands in the same order per accumulator, so outputs, loss and every gradient are identical
-    bits on the synthetic 32-limb model (h = 512; full 128-window tiles)."""
+def test_job_kernels_of_the_generic_engine_agree_bit_for_bit(monkeypatch):
+    """The generic engine's job kernels on the synthetic 32-limb model (h = 512): the 16-wave kernel on 64-window tiles (MSHGNN_GEN_TILE=3, small batches), on
+    128-window tiles (k_gstep4: the default from 256 windows), and the opt-in k_gstep3 with its MFMA block in generated asm (4 / 8 waves) -- same operands in
+    the same order per accumulator, so outputs, loss and every gradient are identical bits (full and ragged 128-window tiles)."""
     from morphsym_hgnn_amd import engine as eng, synth
     case, spec, *_ = helpers.load_case("synth32_mi_h512_L6_B2")
-    B = 128
     n_y = spec.out_channels * spec.num_nodes[spec.out_type]
-    x_dict, y = synth.make_windows(21, B, spec.num_nodes, spec.widths, n_y)
     params = synth.make_params(21, spec.param_shapes())
-    res = {}
-    for mode in ("3", "4"):
-        monkeypatch.setenv("MSHGNN_GEN_TILE", mode)
-        e = eng.Engine(spec, "bf16")
-        assert e.generic
-        xs = e.cast_inputs(x_dict); yd = y.reshape(-1).to(e.device, torch.float32); flat = eng.flatten_params(spec, params, e.device)
-        out, loss, g = e.step_mse(xs, flat, yd, B)
-        torch.cuda.synchronize()
-        res[mode] = (out.clone(), loss.clone(), g.clone())
-    for i in range(3):
-        assert torch.equal(res["3"][i], res["4"][i]), i
+    for B, modes in ((256, ("3", "4", "5", "6", None)), (300, ("3", "6", None))):      # (k_gstep3 takes full tiles only)
+        x_dict, y = synth.make_windows(21 + B, B, spec.num_nodes, spec.widths, n_y)
+        res = {}
+        for mode in modes:
+            if mode is None: monkeypatch.delenv("MSHGNN_GEN_TILE", raising=False)
+            else: monkeypatch.setenv("MSHGNN_GEN_TILE", mode)
+            e = eng.Engine(spec, "bf16")
+            assert e.generic
+            xs = e.cast_inputs(x_dict); yd = y.reshape(-1).to(e.device, torch.float32); flat = eng.flatten_params(spec, params, e.device)
+            out, loss, g = e.step_mse(xs, flat, yd, B)
+            torch.cuda.synchronize()
+            res[mode] = (out.clone(), loss.clone(), g.clone())
+        for mode in modes[1:]:
+            for i in range(3):
+                assert torch.equal(res["3"][i], res[mode][i]), (B, mode, i)
