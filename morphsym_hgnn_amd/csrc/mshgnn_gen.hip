@@ -235,13 +235,13 @@ template <bool SPLIT, int MB, int NW> __global__ __launch_bounds__(64 * NW) void
 // fragment that feeds 8 row blocks instead of 4 halves it.  Round 2's 128-window variant of k_gstep spilled at the 128 registers 16 waves leave (389 us against
 // 287); this kernel keeps the registers down instead: single-source chunks are staged as raw 16-byte chunks (mask applied on the packed value, no fp32 round trip),
 // other chunks one row at a time, and the window fragments are read per K step (4 registers) instead of per row block (16).
-#ifndef G4_W_EARLY
-#define G4_W_EARLY 0
-#endif
-template <int NW> __global__ __launch_bounds__(64 * NW) void k_gstep4(GArgs a) {
+// SPLIT (the split-bf16 arithmetic of section 4b: rows [hi Hd | lo Hd], three products per term) runs it on 64-window tiles (MB = 4): with the same register diet
+// its 16-wave form fits the 128 registers that k_gstep<true, 4, 16> overflowed, so the A tile is staged once for 512 columns instead of twice.
+template <bool SPLIT, int MB, int NW> __global__ __launch_bounds__(64 * NW) void k_gstep4(GArgs a) {
     using P = P16;
-    constexpr int MB = 8, CPW = NW / 4, NPASS = MB * 16 / (4 * NW);      // staging passes: thread = (row rr + 4 NW i, chunk c)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int CPW = NW / 4, NPASS = MB * 16 / (4 * NW);      // staging passes: thread = (row rr + 4 NW i, chunk c)
+    static_assert(NPASS >= 1 && NPASS * 4 * NW == MB * 16, "row blocks must cover whole staging passes");
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // blocks [0, MB): (hi) A tile; [MB, 2 MB): lo halves (split arithmetic)
     const int tid = threadIdx.x, lane = tid & 63, wq = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nctg = a.NCT / CPW;
     const int ct = (blockIdx.x % nctg) * CPW + (wq >> 2), wv = wq & 3, tile = (blockIdx.x / nctg) % a.tiles;
@@ -259,61 +259,82 @@ template <int NW> __global__ __launch_bounds__(64 * NW) void k_gstep4(GArgs a) {
     const int c = tid & 15, rr = tid >> 4;
     const int ao0 = lds_chunk<T16>(0, lane & 15, (lane >> 4) * P::NAV);
     const int one_bits = __float_as_int(1.0f);
-    P::BFrag bf;
+    P::BFrag bfh, bfl;
     const int* term = a.terms + (size_t)job[J_TERM0] * TERM_INTS;
     for (int ti = 0; ti < job[J_NTERMS]; ++ti, term += TERM_INTS) {
         const int nkc = term[T_NKC], kind = term[T_KIND], n_src = term[T_NSRC], F = term[T_WIDTH];
         const int* src = a.srcs + (size_t)term[T_SRC0] * SRC_INTS;
         const bool plain = kind == 0 && n_src == 1 && src[S_SCALE] == one_bits;
         for (int kc = 0; kc < nkc; ++kc) {
-#if G4_W_EARLY
-            load_bfrag<T16>(bf, wpack, term[T_PACK] + kc * a.NCT + ct, wv, lane);      // (before the staging: its L2 latency runs under the rows')
-#endif
             __syncthreads();   // the previous chunk's MFMAs are done reading LDS
             if (plain) {
                 const T16* base = reinterpret_cast<const T16*>(a.ws + a.buf_off[src[S_BUF]]);
                 const bool msk = src[S_MASK] >= 0;
                 const uint8_t* mb = reinterpret_cast<const uint8_t*>(a.ws + (msk ? a.buf_off[src[S_MASK]] : 0));
                 const int col = kc * TW + c * 8;
-                u32x4 v[NPASS]; unsigned bm[NPASS];
+                u32x4 v[NPASS], vl[SPLIT ? NPASS : 1]; unsigned bm[NPASS];
 #pragma unroll
                 for (int i = 0; i < NPASS; ++i) {
                     const int w = min(w0 + i * (4 * NW) + rr, B - 1);
-                    v[i] = *reinterpret_cast<const u32x4*>(base + g_row<false>(w, src[S_NODE], B, Hd) + col);
+                    const T16* rp = base + g_row<SPLIT>(w, src[S_NODE], B, Hd) + col;
+                    v[i] = *reinterpret_cast<const u32x4*>(rp);
+                    if constexpr (SPLIT) vl[i] = *reinterpret_cast<const u32x4*>(rp + Hd);
                     bm[i] = msk ? mb[g_relu_byte(src[S_NODE], B, Hd, w, col)] : 0xffu;
                 }
 #pragma unroll
                 for (int i = 0; i < NPASS; ++i) {
                     const int grow = i * (4 * NW) + rr;
                     *reinterpret_cast<u32x4*>(smem + lds_chunk<T16>(grow >> 4, grow & 15, c)) = chunk_mask_bits<T16>(v[i], bm[i]);
+                    if constexpr (SPLIT) *reinterpret_cast<u32x4*>(smem + lds_chunk<T16>(MB + (grow >> 4), grow & 15, c)) = chunk_mask_bits<T16>(vl[i], bm[i]);
                 }
             } else {
 #pragma unroll
                 for (int i = 0; i < NPASS; ++i) {
                     float s8[8];
                     const int w = min(w0 + i * (4 * NW) + rr, B - 1);
-                    if (kind == 0) gather8<false>(a, src, n_src, w, kc * TW + c * 8, s8);
-                    else raw8<false>(a, src[S_BUF], src[S_NODE], w, kc * TW + c * 8, F, a.signs + term[T_SIGN] + kc * TW + c * 8, s8);
+                    if (kind == 0) gather8<SPLIT>(a, src, n_src, w, kc * TW + c * 8, s8);
+                    else raw8<SPLIT>(a, src[S_BUF], src[S_NODE], w, kc * TW + c * 8, F, a.signs + term[T_SIGN] + kc * TW + c * 8, s8);
                     const int grow = i * (4 * NW) + rr;
-                    *reinterpret_cast<u32x4*>(smem + lds_chunk<T16>(grow >> 4, grow & 15, c)) = pack_oct(f32x4{s8[0], s8[1], s8[2], s8[3]}, f32x4{s8[4], s8[5], s8[6], s8[7]});
+                    const f32x4 lo4 = f32x4{s8[0], s8[1], s8[2], s8[3]}, hi4 = f32x4{s8[4], s8[5], s8[6], s8[7]};
+                    if constexpr (SPLIT) {
+                        u32x4 hi, lo;
+                        split_oct(lo4, hi4, hi, lo);
+                        *reinterpret_cast<u32x4*>(smem + lds_chunk<T16>(grow >> 4, grow & 15, c)) = hi;
+                        *reinterpret_cast<u32x4*>(smem + lds_chunk<T16>(MB + (grow >> 4), grow & 15, c)) = lo;
+                    } else *reinterpret_cast<u32x4*>(smem + lds_chunk<T16>(grow >> 4, grow & 15, c)) = pack_oct(lo4, hi4);
                 }
             }
             __syncthreads();
-#if !G4_W_EARLY
-            load_bfrag<T16>(bf, wpack, term[T_PACK] + kc * a.NCT + ct, wv, lane);
-#endif
+            const int pack = term[T_PACK] + kc * a.NCT + ct;
+            load_bfrag<T16>(bfh, wpack, pack, wv, lane);
+            if constexpr (SPLIT) load_bfrag<T16>(bfl, wpack, a.n_img + pack, wv, lane);
 #pragma unroll
             for (int m = 0; m < MB; ++m) {
+                // (the order of mac() in k_gstep: hi x hi over the four K steps, then hi x lo-weights, then lo x hi)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const bf16x8 xf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(smem + m * P::BLK + (ao0 ^ (16 * t))));
-                    acc[m].c[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf.v[t], xf, acc[m].c[0], 0, 0, 0);
-                    acc[m].c[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf.v[4 + t], xf, acc[m].c[1], 0, 0, 0);
+                    acc[m].c[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfh.v[t], xf, acc[m].c[0], 0, 0, 0);
+                    acc[m].c[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfh.v[4 + t], xf, acc[m].c[1], 0, 0, 0);
+                }
+                if constexpr (SPLIT) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const bf16x8 xf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(smem + m * P::BLK + (ao0 ^ (16 * t))));
+                        acc[m].c[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfl.v[t], xf, acc[m].c[0], 0, 0, 0);
+                        acc[m].c[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfl.v[4 + t], xf, acc[m].c[1], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const bf16x8 xf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(smem + (MB + m) * P::BLK + (ao0 ^ (16 * t))));
+                        acc[m].c[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfh.v[t], xf, acc[m].c[0], 0, 0, 0);
+                        acc[m].c[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfh.v[4 + t], xf, acc[m].c[1], 0, 0, 0);
+                    }
                 }
             }
         }
     }
-    gstep_epilogue<false, MB>(a, job, acc, ct, wv, lane, w0);
+    gstep_epilogue<SPLIT, MB>(a, job, acc, ct, wv, lane, w0);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1084,8 +1105,9 @@ static int g_tile_blocks(int B, bool split) {
     const int forced = e ? atoi(e) : -1;
     if (forced >= 0 && forced <= 6) return forced;
     // bf16: 16 waves; on 128-window tiles (k_gstep4) once the batch has two of them -- half the weight stream per window, 250-258 / 252-314 us per layer launch
-    // against 285-292 / 303-357 on the 32-limb model; split: 8 waves (16 waves of the split kernel spill)
-    return split ? 2 : (B >= 256 ? 6 : 3);
+    // against 285-292 / 303-357 on the 32-limb model; split arithmetic: k_gstep4 at 16 waves on 64-window tiles (720-740 / 673-766 us against 803-813 / 814-925
+    // for k_gstep at 8 waves, whose 16-wave form spills)
+    return split ? 6 : (B >= 256 ? 6 : 3);      // (split, hidden % 512 != 0: the dispatch falls back to k_gstep at 8 / 4 waves)
 }
 
 static void g_launch_jobs(const mshgnn_plan* p, const Launch& ln, GArgs a, hipStream_t st) {
@@ -1101,7 +1123,14 @@ static void g_launch_jobs(const mshgnn_plan* p, const Launch& ln, GArgs a, hipSt
         a.tiles = (a.B + 127) / 128;
         const unsigned grid4 = (unsigned)ln.n_jobs * a.tiles * (a.NCT / 4);
         ProfScope ps(p, ln.ks, st);
-        hipLaunchKernelGGL(k_gstep4<16>, dim3(grid4), dim3(1024), 8 * P16::BLK, st, a);
+        hipLaunchKernelGGL((k_gstep4<false, 8, 16>), dim3(grid4), dim3(1024), 8 * P16::BLK, st, a);
+        return;
+    }
+    if (mode == 6 && gp.split && gp.NCT % 4 == 0) {       // the split arithmetic: the same kernel at 16 waves on 64-window tiles
+        a.tiles = (a.B + 63) / 64;
+        const unsigned grid4 = (unsigned)ln.n_jobs * a.tiles * (a.NCT / 4);
+        ProfScope ps(p, ln.ks, st);
+        hipLaunchKernelGGL((k_gstep4<true, 4, 16>), dim3(grid4), dim3(1024), 2 * 4 * P16::BLK, st, a);
         return;
     }
     if ((mode == 4 || mode == 5) && !gp.split && gp.NCT % 4 == 0 && a.B % G3_ROWS == 0) {      // (full 128-window tiles: the block requests the next chunk's rows without a row clamp)

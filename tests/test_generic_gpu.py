@@ -120,3 +120,14 @@ def test_job_kernels_of_the_generic_engine_agree_bit_for_bit(monkeypatch):
         for mode in modes[1:]:
             for i in range(3):
                 assert torch.equal(res["3"][i], res[mode][i]), (B, mode, i)
+    # split arithmetic: k_gstep at 8 waves (mode 2) and k_gstep4 at 16 waves (the default) against the oracle.  (Not against each other: k_gstep4 stages a single
+    # source's hi / lo halves as they are, k_gstep adds them and splits the sum again -- a half-ulp lo half may land on the other side of the hi half's rounding
+    # tie, and a 2^-16 perturbation flips relu decisions of pre-activations near zero; each run is compared with the oracle under its own decisions.)
+    B = 70
+    x_dict, y = synth.make_windows(77, B, spec.num_nodes, spec.widths, n_y)
+    for mode in ("2", None):
+        if mode is None: monkeypatch.delenv("MSHGNN_GEN_TILE", raising=False)
+        else: monkeypatch.setenv("MSHGNN_GEN_TILE", mode)
+        errs, *_ = helpers.run_engine_case(spec, x_dict, y, params, spec.topology.edge_index_dict(B), B, dtype="x3")
+        bad = {k: v for k, v in errs.items() if v > RTOL}
+        assert not bad, (mode, bad)

@@ -17,7 +17,7 @@ params = synth.make_params(3, spec.param_shapes())
 res = {}
 for mode in sys.argv[2:] or ["3"]:
     os.environ["MSHGNN_GEN_TILE"] = mode
-    e = eng.Engine(spec, "bf16")
+    e = eng.Engine(spec, os.environ.get("DT", "bf16"))
     xs = e.cast_inputs(x_dict); yd = y.reshape(-1).to(e.device, torch.float32); flat = eng.flatten_params(spec, params, e.device)
     for _ in range(2): out, loss, g = e.step_mse(xs, flat, yd, B)
     e.profile(True)
