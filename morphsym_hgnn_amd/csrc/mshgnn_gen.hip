@@ -800,19 +800,35 @@ template <bool SPLIT, int OS> __global__ __launch_bounds__(512 * OS) void k_ggra
         return (im[I_NSRC] == 1 && src[S_SCALE] == one_bits) ? 0 : 2; };
     // step cursors (item, chunk) of the fetch and of the staging stream: advanced by one step per call (no division per step)
     int f_it = it0, f_ch = ch0, s_it = it0, s_ch = ch0;
+    // An item's descriptor, resolved ONCE per item and stream (not per step): item -> source -> buffer offset is a chain of five dependent scalar loads, ~1.5 k
+    // cycles that every wave of the workgroup paid at the same moment in front of each step's row requests (a step's MFMAs are 256 cycles per wave).
+    struct ItemC { const int* src; int n_src, qk, pmask, qt, qnode, sign; const T16* prow; const uint8_t* pmb; const T16* qrow; };
+    auto resolve = [&](int it) {
+        ItemC q;
+        const int* im = a.items + (size_t)it * GITEM_INTS;
+        q.src = a.srcs + (size_t)im[I_SRC0] * SRC_INTS; q.n_src = im[I_NSRC]; q.qk = q_kind(im); q.pmask = im[I_PMASK];
+        const int pnode = im[I_PNODE];
+        q.prow = reinterpret_cast<const T16*>(a.ws + a.buf_off[im[I_PBUF]]) + g_row<SPLIT>(0, pnode, B, Hd) + pcol;      // row 0 of the P operand, first column of this super-unit
+        q.pmb = q.pmask >= 0 ? reinterpret_cast<const uint8_t*>(a.ws + a.buf_off[q.pmask]) + g_relu_byte(pnode, B, Hd, 0, 0) : nullptr;
+        q.qt = q.src[S_BUF]; q.qnode = q.src[S_NODE]; q.sign = q.src[S_MASK];
+        q.qrow = q.qk == 0 ? reinterpret_cast<const T16*>(a.ws + a.buf_off[q.qt]) + g_row<SPLIT>(0, q.qnode, B, Hd) + qcol : nullptr;
+        return q;
+    };
+    ItemC fi = resolve(min(it0, su[SU_ITEM1] - 1)), si = fi;
+    // relu byte of (window w, column col) relative to the node's first byte (g_relu_byte without the node term)
+    auto mask_off = [&](int w, int col) { return ((((size_t)(col >> 5)) * ((B + 15) >> 4) + (w >> 4)) << 6) + (((col >> 3) & 3) << 4) + (w & 15); };
     auto fetch = [&](Stage& st) {
-        const int* im = a.items + (size_t)f_it * GITEM_INTS;
-        const int* src = a.srcs + (size_t)im[I_SRC0] * SRC_INTS;
-        const int w0 = f_ch * KW, qk = q_kind(im);
-        if (++f_ch == ch1) { f_ch = ch0; ++f_it; }
+        const int w0 = f_ch * KW, qk = fi.qk;
+        const ItemC q = fi;
+        if (++f_ch == ch1) { f_ch = ch0; ++f_it; if (f_it < su[SU_ITEM1]) fi = resolve(f_it); }
         st.pa = u32x4{0, 0, 0, 0}; st.pb = u32x4{0, 0, 0, 0}; st.mw = 0xffu;
         {
             const int w = w0 + rp;
             if (w < B) {
-                const T16* pr = reinterpret_cast<const T16*>(a.ws + a.buf_off[im[I_PBUF]]) + g_row<SPLIT>(w, im[I_PNODE], B, Hd) + pcol + cp * 8;
+                const T16* pr = q.prow + (size_t)w * (SPLIT ? 2 * Hd : Hd) + cp * 8;
                 st.pa = *reinterpret_cast<const u32x4*>(pr);
                 if constexpr (SPLIT) st.pb = *reinterpret_cast<const u32x4*>(pr + Hd);
-                if (im[I_PMASK] >= 0) st.mw = reinterpret_cast<const uint8_t*>(a.ws + a.buf_off[im[I_PMASK]])[g_relu_byte(im[I_PNODE], B, Hd, w, pcol + cp * 8)];
+                if (q.pmask >= 0) st.mw = q.pmb[mask_off(w, pcol + cp * 8)];
             }
         }
 #pragma unroll
@@ -821,17 +837,17 @@ template <bool SPLIT, int OS> __global__ __launch_bounds__(512 * OS) void k_ggra
             st.qa[i] = u32x4{0, 0, 0, 0}; st.qb[i] = u32x4{0, 0, 0, 0};
             if (w < B && cq * 8 < qn) {
                 if (qk == 0) {
-                    const T16* qr = reinterpret_cast<const T16*>(a.ws + a.buf_off[src[S_BUF]]) + g_row<SPLIT>(w, src[S_NODE], B, Hd) + qcol + cq * 8;
+                    const T16* qr = q.qrow + (size_t)w * (SPLIT ? 2 * Hd : Hd) + cq * 8;
                     st.qa[i] = *reinterpret_cast<const u32x4*>(qr);
                     if constexpr (SPLIT) st.qb[i] = *reinterpret_cast<const u32x4*>(qr + Hd);
                 } else if (qk == 1) {
-                    const int t = src[S_BUF], nv = qn - cq * 8;
+                    const int t = q.qt, nv = qn - cq * 8;
                     if constexpr (SPLIT) {
-                        const float* qr = reinterpret_cast<const float*>(a.x[t]) + ((size_t)w * a.nodes[t] + src[S_NODE]) * a.pitch[t] + qcol + cq * 8;
+                        const float* qr = reinterpret_cast<const float*>(a.x[t]) + ((size_t)w * a.nodes[t] + q.qnode) * a.pitch[t] + qcol + cq * 8;
                         st.qa[i] = load_chunk<float>(qr, nv, a.vb[t]);
                         st.qb[i] = load_chunk<float>(qr + 4, nv - 4, a.vb[t]);
                     } else {
-                        const T16* qr = reinterpret_cast<const T16*>(a.x[t]) + ((size_t)w * a.nodes[t] + src[S_NODE]) * a.pitch[t] + qcol + cq * 8;
+                        const T16* qr = reinterpret_cast<const T16*>(a.x[t]) + ((size_t)w * a.nodes[t] + q.qnode) * a.pitch[t] + qcol + cq * 8;
                         st.qa[i] = load_chunk<T16>(qr, nv, a.vb[t]);
                     }
                 }
@@ -839,10 +855,12 @@ template <bool SPLIT, int OS> __global__ __launch_bounds__(512 * OS) void k_ggra
         }
     };
     auto stage_to_lds = [&](const Stage& st) {
-        const int* im = a.items + (size_t)s_it * GITEM_INTS;
-        const int* src = a.srcs + (size_t)im[I_SRC0] * SRC_INTS;
-        const int w0 = s_ch * KW, qk = q_kind(im);
-        if (++s_ch == ch1) { s_ch = ch0; ++s_it; }
+        const ItemC q = si;
+        const int* src = q.src;
+        const int w0 = s_ch * KW, qk = q.qk;
+        int im[GITEM_INTS];      // (the fields the staging reads)
+        im[I_PMASK] = q.pmask; im[I_NSRC] = q.n_src;
+        if (++s_ch == ch1) { s_ch = ch0; ++s_it; if (s_it < su[SU_ITEM1]) si = resolve(s_it); }
         {
             u32x4 ph = st.pa, pl = st.pb;
             if (im[I_PMASK] >= 0) { ph = chunk_mask_bits<T16>(ph, st.mw); if constexpr (SPLIT) pl = chunk_mask_bits<T16>(pl, st.mw); }     // dH = dX . relu bits
@@ -860,7 +878,7 @@ template <bool SPLIT, int OS> __global__ __launch_bounds__(512 * OS) void k_ggra
             u32x4 qh = st.qa[i], ql = st.qb[i];
             if (qk == 1) {          // raw input: pad columns dropped, symmetry sign, (split plan) fp32 -> hi / lo
                 const int nv = qn - cq * 8;
-                const uint8_t* sg = a.signs + src[S_MASK] + qcol + cq * 8;
+                const uint8_t* sg = a.signs + q.sign + qcol + cq * 8;
                 if (nv > 0) {
                     if constexpr (SPLIT) {
                         const u32x4 fa = chunk_keep_first<float>(st.qa[i], nv) ^ sign_xor<float>(sg), fb = chunk_keep_first<float>(st.qb[i], nv - 4) ^ sign_xor<float>(sg + 4);
