@@ -1137,13 +1137,14 @@ static void g_launch_jobs(const mshgnn_plan* p, const Launch& ln, GArgs a, hipSt
     // 4 / 8 / 16 waves, split 870 / 799 / 1012 us (16 waves: 128 VGPRs, spills); 128-window tiles lose (fewer resident workgroups hide less
     // of the staging latency: 495 us at 8 waves, 389 us at 16 waves with 56 B of scratch)
     const int mode = g_tile_blocks(a.B, gp.split);      // 0: 4 waves; 1: 8 waves, 128 windows; 2: 8 waves; 3: 16 waves; 4 / 5: k_gstep3 with 4 / 8 waves; 6: k_gstep4 (bf16, hidden % 512 == 0; the default from 256 windows)
-    if (mode == 6 && !gp.split && gp.NCT % 4 == 0) {      // k_gstep4: 16 waves on 128-window tiles (hidden a multiple of 512; other widths: k_gstep below)
+    if (mode == 6 && !gp.split && gp.NCT % 4 == 0) {      // k_gstep4: 16 waves on 128-window tiles (hidden a multiple of 512)
         a.tiles = (a.B + 127) / 128;
         const unsigned grid4 = (unsigned)ln.n_jobs * a.tiles * (a.NCT / 4);
         ProfScope ps(p, ln.ks, st);
         hipLaunchKernelGGL((k_gstep4<false, 8, 16>), dim3(grid4), dim3(1024), 8 * P16::BLK, st, a);
         return;
     }
+    // (hidden = 256: the 8-wave form of k_gstep4 measured 1.51 against 1.47 ms/step for k_gstep on A1-C2, 8192 windows -- tools/time_h256.py; not dispatched)
     if (mode == 6 && gp.split && gp.NCT % 4 == 0) {       // the split arithmetic: the same kernel at 16 waves on 64-window tiles
         a.tiles = (a.B + 63) / 64;
         const unsigned grid4 = (unsigned)ln.n_jobs * a.tiles * (a.NCT / 4);
