@@ -596,9 +596,9 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, Prec<T>::WPS) 
 // place; the stashes the backward pass / k_gradw need are written on the side and never read back by this kernel.
 // One workgroup of 8 waves per CU (<= 256 VGPRs per wave): all accumulators live + double-buffered weight fragments.
 
-template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_fwd(StackArgs a) {
+// STEP: part of k_stack_step -- the decoder tail leaves dX_L in the out-type nodes' LDS blocks for the backward sweep that follows in the same launch
+template <typename T, bool STEP> __device__ __forceinline__ void stack_fwd_body(const StackArgs& a, char* smem) {
     using P = Prec<T>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wv & 3, wh = wv >> 2;
     const int w0 = blockIdx.x * P::ROWS, B = a.B, NN = a.NN;
@@ -748,7 +748,7 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
         FS_STAMP(5 + 4 * l);
     }
 
-    decoder_tail<T, LAYER_THREADS>(a, smem, tid, lane, wv, w0, B);
+    decoder_tail<T, LAYER_THREADS, false, STEP>(a, smem, tid, lane, wv, w0, B);
     FS_STAMP(30);
 #ifdef MSHGNN_SEG_STAMPS
     if (a.stamps) {
@@ -757,6 +757,10 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
         if (tid < 3 * 8 * 16) a.stamps[(size_t)gridDim.x * 32 + (size_t)blockIdx.x * 384 + tid] = sc[tid];
     }
 #endif
+}
+template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_fwd(StackArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    stack_fwd_body<T, false>(a, smem);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -942,18 +946,19 @@ template <typename T, int NM, int HB> __global__ __launch_bounds__(SL_THREADS, 2
     slab_fwd_body<T, NM, HB, false>(a, smem);
 }
 
-template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_bwd(StackArgs a) {
+// STEP: part of k_stack_step -- the forward's decoder tail of the same launch left the dX_L tile in LDS; the layers' programs are a.prog_off_b
+template <typename T, bool STEP> __device__ __forceinline__ void stack_bwd_body(const StackArgs& a, char* smem) {
     using P = Prec<T>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wv & 3, wh = wv >> 2;
     const int w0 = blockIdx.x * P::ROWS, B = a.B, NN = a.NN;
     const T* wpack = reinterpret_cast<const T*>(a.wpack);
+    auto prog_of = [&](int l) { return STEP ? a.prog_off_b[l] : a.prog_off[l]; };
 
     FS_STAMP(0);
     // dX_L tile: only the nodes that are live in the last layer carry a gradient
-    {
-        const FHdr bh(a.tables + a.prog_off[a.L - 1], lane);
+    if constexpr (!STEP) {
+        const FHdr bh(a.tables + prog_of(a.L - 1), lane);
         const T* src = reinterpret_cast<const T*>(a.tile_in);
         const RowMap<T> m(tid);
         for (int n = m.sub; n < NN; n += RowMap<T>::NPB) {
@@ -967,15 +972,15 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
     FS_STAMP(1);
 
     typename P::Acc acc[FS_HS];
-    FHdr bhn(a.tables + a.prog_off[a.L - 1], lane);
-    FProg wpn(a.tables + a.prog_off[a.L - 1] + FH_SIZE + wh * FPROG_LEN, lane);
+    FHdr bhn(a.tables + prog_of(a.L - 1), lane);
+    FProg wpn(a.tables + prog_of(a.L - 1) + FH_SIZE + wh * FPROG_LEN, lane);
     bhn.settle(); wpn.settle();
     for (int l = a.L - 1; l >= 0; --l) {
         const FHdr bh = bhn;
         const FProg wp = wpn;
         if (l > 0) {          // the next layer's header and wave program stream in under this layer's MACs
-            bhn = FHdr(a.tables + a.prog_off[l - 1], lane);
-            wpn = FProg(a.tables + a.prog_off[l - 1] + FH_SIZE + wh * FPROG_LEN, lane);
+            bhn = FHdr(a.tables + prog_of(l - 1), lane);
+            wpn = FProg(a.tables + prog_of(l - 1) + FH_SIZE + wh * FPROG_LEN, lane);
         }
         const int nmlp = bh[FH_NMLP], flags = bh[FH_FLAGS];
         const unsigned* maskbits = reinterpret_cast<const unsigned*>(a.ws + a.mask_off[l]);
@@ -1118,6 +1123,17 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
         __syncthreads();
         FS_STAMP(6 + 5 * (a.L - 1 - l));
     }
+}
+template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_bwd(StackArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    stack_bwd_body<T, false>(a, smem);
+}
+// the one-call steps below the slab kernels' batch size: both sweeps of a tile in one launch (k_slab_step's scheme on the 8-wave kernels)
+template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_step(StackArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    stack_fwd_body<T, true>(a, smem);
+    __syncthreads();
+    stack_bwd_body<T, true>(a, smem);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -2138,14 +2154,14 @@ extern "C" int mshgnn_plan_create(const mshgnn_desc* desc, mshgnn_plan** out) {
         p->use_fused = hp.fused && !(e && atoi(e) == 0);
         if (p->use_fused) {
             const int flds = (hp.fs_blk + FS_EXTRA_BLK) * Prec<__bf16>::BLK;
-            if ((rc = set_lds_attr(k_stack_fwd<__bf16>, flds)) || (rc = set_lds_attr(k_stack_bwd<__bf16>, flds))) { mshgnn_plan_destroy(p); return rc; }
+            if ((rc = set_lds_attr(k_stack_fwd<__bf16>, flds)) || (rc = set_lds_attr(k_stack_bwd<__bf16>, flds)) || (rc = set_lds_attr(k_stack_step<__bf16>, flds))) { mshgnn_plan_destroy(p); return rc; }
             const char* es = getenv("MSHGNN_SLAB");
             p->use_slab = hp.slab && !(es && atoi(es) == 0);       // default on where the plan allows it; MSHGNN_SLAB=0 selects the 8-wave kernels
             p->slab_force = es && atoi(es) == 2;                   // MSHGNN_SLAB=2: also for batches that do not fill the chip
             { int dev = 0, cus = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); p->n_cu = cus > 0 ? cus : 256; }
             if (p->use_slab && ((rc = set_lds_attr(slab_fwd_kernel(hp), flds)) || (rc = set_lds_attr(slab_bwd_kernel(hp), flds)) ||
                                 (rc = set_lds_attr(slab_step_kernel(hp), flds)))) { mshgnn_plan_destroy(p); return rc; }
-            { const char* et = getenv("MSHGNN_STEP_KERNEL"); p->use_step = p->use_slab && !(et && atoi(et) == 0); }      // one-call steps: forward + backward sweep in one launch
+            { const char* et = getenv("MSHGNN_STEP_KERNEL"); p->use_step = !(et && atoi(et) == 0); }      // one-call steps: forward + backward sweep in one launch
             const char* ew = getenv("MSHGNN_WIDE");
             // wide variant (mshgnn_wide.hip): opt-in.  Measured on A1-C2, 8192 windows: 81 us against the slab kernel's 65 (inference: 67 / 54) -- with 32 windows
             // per CU one wave per SIMD exposes every memory and instruction-fetch latency of a kernel whose code runs once.
@@ -2339,8 +2355,8 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
             a.stamps = stamp_ptr("MSHGNN_STAMPS");
             a.stagger = (p->slab2_for(tiles, a.training != 0) || p->slab_for(tiles)) && tiles > p->n_cu ? p->stagger : 0;
             // the tail's reduction scratch (one decoder slab per wave at the start of LDS) must end below the out-type nodes' blocks
-            const bool step = stack_step_done && p->use_step && (y_fused || labels_fused) && !p->wide_for(B) && !p->slab2_for(tiles, true) && p->slab_for(tiles) &&
-                              (size_t)a.node0 * Prec<T>::BLK >= (size_t)(SL_THREADS / 64) * DEC_SLAB_FLOATS * sizeof(float);
+            const bool step = stack_step_done && p->use_step && (y_fused || labels_fused) && !p->wide_for(B) && !p->slab2_for(tiles, true) &&
+                              (size_t)a.node0 * Prec<T>::BLK >= (size_t)((p->slab_for(tiles) ? SL_THREADS : LAYER_THREADS) / 64) * DEC_SLAB_FLOATS * sizeof(float);
             ProfScope ps(p, step ? hp.ks_stack_step : hp.ks_stack_fwd, st);
             if (p->wide_for(B)) {
                 for (int l = 0; l < hp.L; ++l) a.prog_off[l] = hp.wd_fwd_off[l];
@@ -2358,6 +2374,12 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
                     *stack_step_done = true;
                 } else
                 hipLaunchKernelGGL(slab_fwd_kernel(hp), dim3(tiles), dim3(SL_THREADS), (hp.sl_blk + FS_EXTRA_BLK) * Prec<T>::BLK, st, a);
+            } else if (step) {
+                for (int l = 0; l <= hp.L; ++l) a.dx_off[l] = lay.dx[l];
+                for (int l = 0; l < hp.L; ++l) { a.dh_off[l] = lay.dh[l]; a.du_off[l] = lay.du[l]; a.prog_off_b[l] = hp.fs_bwd_off[l]; }
+                a.mask0_off = lay.dd[0];
+                hipLaunchKernelGGL(k_stack_step<T>, dim3(tiles), dim3(LAYER_THREADS), (hp.fs_blk + FS_EXTRA_BLK) * Prec<T>::BLK, st, a);
+                *stack_step_done = true;
             } else
             hipLaunchKernelGGL(k_stack_fwd<T>, dim3(tiles), dim3(LAYER_THREADS), (hp.fs_blk + FS_EXTRA_BLK) * Prec<T>::BLK, st, a);
             HIPCHK(hipGetLastError());

@@ -292,12 +292,16 @@ def test_slab_and_eight_wave_stack_kernels_agree_bit_for_bit(kind, topo, cfg, B,
     x_dict, y = synth.make_windows(5, B, spec.num_nodes, spec.widths, n_y)
     params = synth.make_params(5, spec.param_shapes())
     res = {}
-    for mode, (wide, slab2, slab) in {"wide": ("2", "0", "2"), "slab2": ("0", "2", "2"), "slab": ("0", "0", "2"), "8wave": ("0", "0", "0")}.items():
+    # "8wave": the two launches per step of the 8-wave kernels; "8wave-step" and "slab" run both sweeps in one launch (k_stack_step / k_slab_step)
+    modes = {"wide": ("2", "0", "2", "1"), "slab2": ("0", "2", "2", "1"), "slab": ("0", "0", "2", "1"), "slab-2launch": ("0", "0", "2", "0"),
+             "8wave-step": ("0", "0", "0", "1"), "8wave": ("0", "0", "0", "0")}
+    for mode, (wide, slab2, slab, step) in modes.items():
         monkeypatch.setenv("MSHGNN_WIDE", wide)       # read when the plan is created
         monkeypatch.setenv("MSHGNN_SLAB2", slab2)
         monkeypatch.setenv("MSHGNN_SLAB", slab)
+        monkeypatch.setenv("MSHGNN_STEP_KERNEL", step)
         e = eng.Engine(spec, "bf16")
-        if (mode == "slab" and not (e.info.kernel_sets & 2)) or (mode == "slab2" and not (e.info.kernel_sets & 16)):
+        if (mode.startswith("slab") and mode != "slab2" and not (e.info.kernel_sets & 2)) or (mode == "slab2" and not (e.info.kernel_sets & 16)):
             continue
         assert mode != "wide" or (e.info.kernel_sets & 8), "every fused topology has a wide plan"
         xs = e.cast_inputs(x_dict)
@@ -313,7 +317,7 @@ def test_slab_and_eight_wave_stack_kernels_agree_bit_for_bit(kind, topo, cfg, B,
         assert torch.equal(res[mode][0], ref[0]), mode
         ga, gb = eng.unflatten(spec, res[mode][2]), eng.unflatten(spec, ref[2])
         for k in ga:
-            if k.startswith("decoder"):     # summed over 4 instead of 8 per-wave partials per tile: fp32 summation order
+            if k.startswith("decoder") and mode != "8wave-step":     # summed over 4 instead of 8 per-wave partials per tile: fp32 summation order
                 assert float((ga[k] - gb[k]).abs().max()) <= 2e-6 * float(gb[k].abs().max()), (mode, k)
             else:
                 assert torch.equal(ga[k], gb[k]), (mode, k)
