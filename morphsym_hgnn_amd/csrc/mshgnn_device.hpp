@@ -486,11 +486,9 @@ template <typename T> __device__ __forceinline__ u32x4 chunk_mask_bits(u32x4 v, 
         for (int e = 0; e < 4; ++e) if (!((bits >> e) & 1u)) v[e] = 0u;
     } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            unsigned m = 0;
-            if ((bits >> (2 * e)) & 1u) m |= 0x0000ffffu;
-            if ((bits >> (2 * e + 1)) & 1u) m |= 0xffff0000u;
-            v[e] &= m;
+        for (int e = 0; e < 4; ++e) {      // two sign-extending bit-field extracts + one bit-field insert per pair (the compare / select form costs 7 VALU per pair)
+            const int lo = __builtin_amdgcn_sbfe((int)bits, 2 * e, 1), hi = __builtin_amdgcn_sbfe((int)bits, 2 * e + 1, 1);
+            v[e] &= (unsigned)((lo & 0xffff) | (hi & (int)0xffff0000));
         }
     }
     return v;

@@ -753,9 +753,13 @@ template <bool SPLIT> __global__ __launch_bounds__(256) void k_gdec_bwd(GDecArgs
 // of a step are staged ONCE for all of them.  Steps = (item, 32-window chunk) pairs; the global loads of the next step(s) run in registers,
 // untouched, while a step is multiplied (P rows always; Q rows when the item has one source; aggregated Q rows are gathered at staging time).
 // ------------------------------------------------------------------------------------------------------
-template <bool SPLIT, int OS> __global__ __launch_bounds__(512 * OS) void k_ggradw(GArgs a) {
-    constexpr int KW = 32, NT = 512 * OS, PC = 16 * OS;      // PC: 16-byte chunks per staged P row
-    constexpr int NQ = KW * 32 / NT;                         // Q chunks per thread (1 with 1024 threads, 2 with 512); P: one chunk per thread
+// NWV waves: 4 wave columns of 64 k each x NWV / 4 wave rows of 32 RI o each (RI = 2: 64x64 per wave; OS = 2 on 8 waves: 128x64 per wave, 128 accumulator
+// registers at two waves per SIMD -- room for two register stages of loads where the 16-wave form has 128 registers and one).
+template <bool SPLIT, int OS, int NWV = 8 * OS> __global__ __launch_bounds__(64 * NWV) void k_ggradw(GArgs a) {
+    constexpr int KW = 32, NT = 64 * NWV, PC = 16 * OS;      // PC: 16-byte chunks per staged P row
+    constexpr int NQ = KW * 32 / NT;                         // Q chunks per thread (1 with 1024 threads, 2 with 512)
+    constexpr int NP = KW * PC / NT, PR = NT / PC;           // P chunks per thread; P rows per staging pass
+    constexpr int RI = (128 * OS) / (NWV / 4) / 32;          // 32-row blocks of the o range per wave
 #ifndef GGW_NST_SPLIT
 #define GGW_NST_SPLIT 2
 #endif
@@ -764,14 +768,16 @@ template <bool SPLIT, int OS> __global__ __launch_bounds__(512 * OS) void k_ggra
 #endif
     constexpr int NST = OS == 2 ? 1 : (SPLIT ? GGW_NST_SPLIT : GGW_NST_BF16);      // register stages (16 waves: 128 VGPRs, one stage)
     constexpr int TSZ = KW * GWB_PITCH;                      // one staged 32 x 128 tile
-    __shared__ __attribute__((aligned(16))) __bf16 tiles_h[(OS + 2) * TSZ];      // P sub-tiles [0, OS), Q sub-tiles [OS, OS + 2) (one buffer: the bias reduction reuses it)
-    __shared__ __attribute__((aligned(16))) __bf16 tiles_l[SPLIT ? (OS + 2) * TSZ : 8];
+    constexpr int BUFSZ = (OS + 2) * TSZ;
+    __shared__ __attribute__((aligned(16))) __bf16 tiles_h[BUFSZ];      // P sub-tiles [0, OS), Q sub-tiles [OS, OS + 2) (the bias reduction reuses it)
+    __shared__ __attribute__((aligned(16))) __bf16 tiles_l[SPLIT ? BUFSZ : 8];
     auto Ph = [&](int t) { return tiles_h + t * TSZ; };
     auto Qh = [&](int t) { return tiles_h + (OS + t) * TSZ; };
     auto Pl = [&](int t) { return tiles_l + (SPLIT ? t * TSZ : 0); };
     auto Ql = [&](int t) { return tiles_l + (SPLIT ? (OS + t) * TSZ : 0); };
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wv >> 2, wc = wv & 3;                     // wave (wr, wc): rows [64 wr, +64) of the o range, columns [64 wc, +64) of the k range
+    const int wr = wv >> 2, wc = wv & 3;                     // wave (wr, wc): rows [32 RI wr, +32 RI) of the o range, columns [64 wc, +64) of the k range
+    const int row0 = 32 * RI * wr;
     const int su_i = a.su_order[blockIdx.x % a.n_sunits], part = blockIdx.x / a.n_sunits;
     const int* su = a.sunits + (size_t)su_i * SUNIT_INTS;
     const int it0 = su[SU_ITEM0], pcol = su[SU_PCOL], qcol = su[SU_QCOL], qn = su[SU_QN];
@@ -782,9 +788,9 @@ template <bool SPLIT, int OS> __global__ __launch_bounds__(512 * OS) void k_ggra
     const int cp = tid % PC, rp = tid / PC;                  // P staging: (row rp < 32, chunk cp)
     const int cq = tid & 31, rq = tid >> 5;                  // Q staging: (row rq + (NT / 32) i, chunk cq), i < NQ
     const int one_bits = __float_as_int(1.0f);
-    f32x16 acc[2][2];
+    f32x16 acc[RI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -793,7 +799,7 @@ template <bool SPLIT, int OS> __global__ __launch_bounds__(512 * OS) void k_ggra
 #pragma unroll
     for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
 
-    struct Stage { u32x4 pa, pb, qa[NQ], qb[NQ]; unsigned mw; };      // a: bf16 chunk / hi half / first four fp32; b: lo half / next four fp32
+    struct Stage { u32x4 pa[NP], pb[NP], qa[NQ], qb[NQ]; unsigned mw[NP]; };      // a: bf16 chunk / hi half / first four fp32; b: lo half / next four fp32
     auto q_kind = [&](const int* im) {      // 1 raw input, 0 single activation source, 2 aggregate
         if (im[I_KIND] == 1) return 1;
         const int* src = a.srcs + (size_t)im[I_SRC0] * SRC_INTS;
@@ -821,14 +827,15 @@ template <bool SPLIT, int OS> __global__ __launch_bounds__(512 * OS) void k_ggra
         const int w0 = f_ch * KW, qk = fi.qk;
         const ItemC q = fi;
         if (++f_ch == ch1) { f_ch = ch0; ++f_it; if (f_it < su[SU_ITEM1]) fi = resolve(f_it); }
-        st.pa = u32x4{0, 0, 0, 0}; st.pb = u32x4{0, 0, 0, 0}; st.mw = 0xffu;
-        {
-            const int w = w0 + rp;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            st.pa[i] = u32x4{0, 0, 0, 0}; st.pb[i] = u32x4{0, 0, 0, 0}; st.mw[i] = 0xffu;
+            const int w = w0 + rp + PR * i;
             if (w < B) {
                 const T16* pr = q.prow + (size_t)w * (SPLIT ? 2 * Hd : Hd) + cp * 8;
-                st.pa = *reinterpret_cast<const u32x4*>(pr);
-                if constexpr (SPLIT) st.pb = *reinterpret_cast<const u32x4*>(pr + Hd);
-                if (q.pmask >= 0) st.mw = q.pmb[mask_off(w, pcol + cp * 8)];
+                st.pa[i] = *reinterpret_cast<const u32x4*>(pr);
+                if constexpr (SPLIT) st.pb[i] = *reinterpret_cast<const u32x4*>(pr + Hd);
+                if (q.pmask >= 0) st.mw[i] = q.pmb[mask_off(w, pcol + cp * 8)];
             }
         }
 #pragma unroll
@@ -861,11 +868,12 @@ template <bool SPLIT, int OS> __global__ __launch_bounds__(512 * OS) void k_ggra
         int im[GITEM_INTS];      // (the fields the staging reads)
         im[I_PMASK] = q.pmask; im[I_NSRC] = q.n_src;
         if (++s_ch == ch1) { s_ch = ch0; ++s_it; if (s_it < su[SU_ITEM1]) si = resolve(s_it); }
-        {
-            u32x4 ph = st.pa, pl = st.pb;
-            if (im[I_PMASK] >= 0) { ph = chunk_mask_bits<T16>(ph, st.mw); if constexpr (SPLIT) pl = chunk_mask_bits<T16>(pl, st.mw); }     // dH = dX . relu bits
-            *reinterpret_cast<u32x4*>(Ph(cp >> 4) + gwb_elem(rp, (cp & 15) * 8)) = ph;
-            if constexpr (SPLIT) *reinterpret_cast<u32x4*>(Pl(cp >> 4) + gwb_elem(rp, (cp & 15) * 8)) = pl;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            u32x4 ph = st.pa[i], pl = st.pb[i];
+            if (im[I_PMASK] >= 0) { ph = chunk_mask_bits<T16>(ph, st.mw[i]); if constexpr (SPLIT) pl = chunk_mask_bits<T16>(pl, st.mw[i]); }     // dH = dX . relu bits
+            *reinterpret_cast<u32x4*>(Ph(cp >> 4) + gwb_elem(rp + PR * i, (cp & 15) * 8)) = ph;
+            if constexpr (SPLIT) *reinterpret_cast<u32x4*>(Pl(cp >> 4) + gwb_elem(rp + PR * i, (cp & 15) * 8)) = pl;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {      // column sums of P (bias gradients of the kt == 0 units; cheap enough to keep unconditional)
                 bsum[2 * e] += __builtin_bit_cast(float, ph[e] << 16) + (SPLIT ? __builtin_bit_cast(float, pl[e] << 16) : 0.f);
@@ -897,83 +905,157 @@ template <bool SPLIT, int OS> __global__ __launch_bounds__(512 * OS) void k_ggra
             if constexpr (SPLIT) *reinterpret_cast<u32x4*>(Ql(cq >> 4) + gwb_elem(row, (cq & 15) * 8)) = ql;
         }
     };
-    const __bf16* Pt = Ph(wr >> 1); const __bf16* Qt = Qh(wc >> 1);
-    const __bf16* Plt = Pl(wr >> 1); const __bf16* Qlt = Ql(wc >> 1);
-    const int my_unit = su[SU_UNIT + (wr >> 1) * 2 + (wc >> 1)];      // the 128x128 sub-tile this wave belongs to (-1: beyond the matrix edge)
+    // LEAN streams (super-units whose items all have ONE plain activation source at scale 1, SU_FLAGS bit 0 -- the plan sorts those items to the front of
+    // their target): what changes per step is a uniform base address per operand (SGPRs, advanced by one 32-window chunk) -- the per-thread offsets are
+    // constants of the launch, the item descriptor is read at item boundaries only, column sums of P are kept only where a bias gradient is read (bit 1).
+    // The general streams above spend ~0.9 ms of a 2.0 ms launch at h = 512 on their own bookkeeping (timed with the loads and MFMAs compiled out).
+    const int rowb = (SPLIT ? 2 * Hd : Hd) * 2;      // bytes per activation row
+    const unsigned poff = (unsigned)rp * rowb + cp * 16, qoff = (unsigned)rq * rowb + cq * 16;
+    const unsigned moff = (unsigned)mask_off(rp, pcol + cp * 8);
+    const bool need_bias = (su[SU_FLAGS] & 2) != 0;
+    struct LeanF { const char* pb; const uint8_t* mb; const char* qb; int it, left, ch; bool msk; } LF{nullptr, nullptr, nullptr, it0, 0, 0, false};
+    struct LeanS { int it, left; bool msk; } LS{it0, 0, false};
+    auto fetch_lean = [&](Stage& st) {
+        if (LF.left == 0) {      // next item of the fetch stream
+            const int* im = a.items + (size_t)LF.it * GITEM_INTS;
+            const int* src = a.srcs + (size_t)im[I_SRC0] * SRC_INTS;
+            const int pnode = im[I_PNODE], pm = im[I_PMASK];
+            LF.ch = ch0;
+            LF.pb = a.ws + a.buf_off[im[I_PBUF]] + (g_row<SPLIT>(LF.ch * KW, pnode, B, Hd) + pcol) * 2;
+            LF.msk = pm >= 0;
+            LF.mb = reinterpret_cast<const uint8_t*>(a.ws + a.buf_off[pm >= 0 ? pm : 0]) + g_relu_byte(pnode, B, Hd, 0, 0) + ((size_t)((LF.ch * KW) >> 4) << 6);
+            LF.qb = a.ws + a.buf_off[src[S_BUF]] + (g_row<SPLIT>(LF.ch * KW, src[S_NODE], B, Hd) + qcol) * 2;
+            LF.left = nch; ++LF.it;
+        }
+        const int nrow = B - LF.ch * KW;      // rows of this chunk inside the batch
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            st.pa[i] = u32x4{0, 0, 0, 0}; st.pb[i] = u32x4{0, 0, 0, 0}; st.mw[i] = 0xffu;
+            if (rp + PR * i < nrow) {
+                const char* pr = LF.pb + (poff + (unsigned)(i * PR) * rowb);
+                st.pa[i] = *reinterpret_cast<const u32x4*>(pr);
+                if constexpr (SPLIT) st.pb[i] = *reinterpret_cast<const u32x4*>(pr + 2 * Hd);
+                if (LF.msk) st.mw[i] = LF.mb[moff + (unsigned)(i * (PR >> 4) * 64)];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            st.qa[i] = u32x4{0, 0, 0, 0}; st.qb[i] = u32x4{0, 0, 0, 0};
+            if (rq + (NT / 32) * i < nrow && cq * 8 < qn) {
+                const char* qr = LF.qb + (qoff + (unsigned)(i * (NT / 32)) * rowb);
+                st.qa[i] = *reinterpret_cast<const u32x4*>(qr);
+                if constexpr (SPLIT) st.qb[i] = *reinterpret_cast<const u32x4*>(qr + 2 * Hd);
+            }
+        }
+        LF.pb += (size_t)KW * rowb; LF.mb += (KW >> 4) << 6; LF.qb += (size_t)KW * rowb; ++LF.ch; --LF.left;
+    };
+    auto stage_lean = [&](const Stage& st) {
+        if (LS.left == 0) { LS.msk = a.items[(size_t)LS.it * GITEM_INTS + I_PMASK] >= 0; LS.left = nch; ++LS.it; }
+        --LS.left;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            u32x4 ph = st.pa[i], pl = st.pb[i];
+            if (LS.msk) { ph = chunk_mask_bits<T16>(ph, st.mw[i]); if constexpr (SPLIT) pl = chunk_mask_bits<T16>(pl, st.mw[i]); }     // dH = dX . relu bits
+            *reinterpret_cast<u32x4*>(Ph(cp >> 4) + gwb_elem(rp + PR * i, (cp & 15) * 8)) = ph;
+            if constexpr (SPLIT) *reinterpret_cast<u32x4*>(Pl(cp >> 4) + gwb_elem(rp + PR * i, (cp & 15) * 8)) = pl;
+            if (need_bias) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bsum[2 * e] += __builtin_bit_cast(float, ph[e] << 16) + (SPLIT ? __builtin_bit_cast(float, pl[e] << 16) : 0.f);
+                    bsum[2 * e + 1] += __builtin_bit_cast(float, ph[e] & 0xffff0000u) + (SPLIT ? __builtin_bit_cast(float, pl[e] & 0xffff0000u) : 0.f);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int row = rq + (NT / 32) * i;
+            *reinterpret_cast<u32x4*>(Qh(cq >> 4) + gwb_elem(row, (cq & 15) * 8)) = st.qa[i];
+            if constexpr (SPLIT) *reinterpret_cast<u32x4*>(Ql(cq >> 4) + gwb_elem(row, (cq & 15) * 8)) = st.qb[i];
+        }
+    };
+    const __bf16* Pt0 = tiles_h + (row0 >> 7) * TSZ; const __bf16* Qt0 = tiles_h + (OS + (wc >> 1)) * TSZ;
+    const __bf16* Plt = Pl(row0 >> 7); const __bf16* Qlt = Ql(wc >> 1);
+    const int my_unit = su[SU_UNIT + (row0 >> 7) * 2 + (wc >> 1)];      // the 128x128 sub-tile this wave belongs to (-1: beyond the matrix edge)
     auto mfmas = [&]() {
         if (my_unit < 0) return;      // (wave-uniform)
+        const __bf16* Pt = Pt0; const __bf16* Qt = Qt0;
 #pragma unroll
         for (int ks = 0; ks < KW / 16; ++ks) {
             if constexpr (SPLIT) {      // Q fragments one column block at a time: 24 fragment registers live instead of 32
-                bf16x8 afh[2], afl[2];
+                bf16x8 afh[RI], afl[RI];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) { afh[i] = tr_frag(Pt, ks * 16, (wr & 1) * 64 + i * 32, lane); afl[i] = tr_frag(Plt, ks * 16, (wr & 1) * 64 + i * 32, lane); }
+                for (int i = 0; i < RI; ++i) { afh[i] = tr_frag(Pt, ks * 16, (row0 & 127) + i * 32, lane); afl[i] = tr_frag(Plt, ks * 16, (row0 & 127) + i * 32, lane); }
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const bf16x8 bqh = tr_frag(Qt, ks * 16, (wc & 1) * 64 + j * 32, lane), bql = tr_frag(Qlt, ks * 16, (wc & 1) * 64 + j * 32, lane);
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) {
+                    for (int i = 0; i < RI; ++i) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afh[i], bqh, acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afh[i], bql, acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afl[i], bqh, acc[i][j], 0, 0, 0);
                     }
                 }
             } else {
-                bf16x8 afh[2], bqh[2];
+                bf16x8 afh[RI], bqh[2];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) { afh[i] = tr_frag(Pt, ks * 16, (wr & 1) * 64 + i * 32, lane); bqh[i] = tr_frag(Qt, ks * 16, (wc & 1) * 64 + i * 32, lane); }
+                for (int i = 0; i < RI; ++i) afh[i] = tr_frag(Pt, ks * 16, (row0 & 127) + i * 32, lane);
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i) bqh[i] = tr_frag(Qt, ks * 16, (wc & 1) * 64 + i * 32, lane);
+#pragma unroll
+                for (int i = 0; i < RI; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afh[i], bqh[j], acc[i][j], 0, 0, 0);
             }
         }
     };
-    if constexpr (NST == 2) {
-        Stage sa, sb;
-        if (nsteps > 0) fetch(sa);
-        if (nsteps > 1) fetch(sb);
-        for (int s = 0; s < nsteps; s += 2) {
-            __syncthreads();      // the previous MFMA phase is done reading the tiles
-            stage_to_lds(sa);
-            __syncthreads();
-            if (s + 2 < nsteps) fetch(sa);
-            mfmas();
-            if (s + 1 < nsteps) {
+    auto run = [&](auto& fetchf, auto& stagef) {
+        if constexpr (NST == 2) {
+            Stage sa, sb;
+            if (nsteps > 0) fetchf(sa);
+            if (nsteps > 1) fetchf(sb);
+            for (int s = 0; s < nsteps; s += 2) {
+                __syncthreads();      // the previous MFMA phase is done reading the tiles
+                stagef(sa);
                 __syncthreads();
-                stage_to_lds(sb);
+                if (s + 2 < nsteps) fetchf(sa);
+                mfmas();
+                if (s + 1 < nsteps) {
+                    __syncthreads();
+                    stagef(sb);
+                    __syncthreads();
+                    if (s + 3 < nsteps) fetchf(sb);
+                    mfmas();
+                }
+            }
+        } else {
+            Stage sa;
+            if (nsteps > 0) fetchf(sa);
+            for (int s = 0; s < nsteps; ++s) {
                 __syncthreads();
-                if (s + 3 < nsteps) fetch(sb);
+                stagef(sa);
+                __syncthreads();
+                if (s + 1 < nsteps) fetchf(sa);
                 mfmas();
             }
         }
-    } else {
-        Stage sa;
-        if (nsteps > 0) fetch(sa);
-        for (int s = 0; s < nsteps; ++s) {
-            __syncthreads();
-            stage_to_lds(sa);
-            __syncthreads();
-            if (s + 1 < nsteps) fetch(sa);
-            mfmas();
-        }
-    }
+    };
+    if (su[SU_FLAGS] & 1) run(fetch_lean, stage_lean); else run(fetch, stage_to_lds);
     if (my_unit >= 0) {
         float* slab = a.slabs + ((size_t)part * a.n_units + my_unit) * SLAB_FLOATS;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < RI; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
-                    const int o = (wr & 1) * 64 + i * 32 + (q & 3) + ((q >> 2) << 3) + ((lane >> 5) << 2), k = (wc & 1) * 64 + j * 32 + (lane & 31);
+                    const int o = (row0 & 127) + i * 32 + (q & 3) + ((q >> 2) << 3) + ((lane >> 5) << 2), k = (wc & 1) * 64 + j * 32 + (lane & 31);
                     slab[o * H + k] = acc[i][j][q];
                 }
     }
     // bias gradients: column sums of the staged P rows, into the slab of the k-tile-0 unit of each o sub-tile (the only ones the finalize reads)
     if (qcol == 0) {      // (uniform: super-units that hold k tile 0)
-        float* red = reinterpret_cast<float*>(tiles_h);      // [32 rows][128 OS] floats
-        static_assert(sizeof(float) * 32 * 128 * OS <= sizeof(__bf16) * (OS + 2) * TSZ, "bias reduction buffer fits the P and Q tiles");
+        float* red = reinterpret_cast<float*>(tiles_h);      // [PR rows][128 OS] floats
+        static_assert(sizeof(float) * PR * 128 * OS <= sizeof(__bf16) * (OS + 2) * TSZ, "bias reduction buffer fits the P and Q tiles");
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < 8; ++e) red[rp * (128 * OS) + cp * 8 + e] = bsum[e];
@@ -983,7 +1065,7 @@ template <bool SPLIT, int OS> __global__ __launch_bounds__(512 * OS) void k_ggra
             if (un >= 0) {
                 float s2 = 0.f;
 #pragma unroll
-                for (int r = 0; r < 32; ++r) s2 += red[r * (128 * OS) + tid];
+                for (int r = 0; r < PR; ++r) s2 += red[r * (128 * OS) + tid];
                 a.slabs[((size_t)part * a.n_units + un) * SLAB_FLOATS + H * H + (tid & 127)] = s2;
             }
         }

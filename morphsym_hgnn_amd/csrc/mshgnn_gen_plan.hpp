@@ -27,7 +27,7 @@ enum { T_PACK = 0, T_NKC, T_KIND, T_SRC0, T_NSRC, T_WIDTH, T_SIGN, TERM_INTS = 8
 enum { S_BUF = 0, S_NODE, S_MASK, S_SCALE, SRC_INTS = 4 };
 // weight-gradient unit = one 128x128 tile of one target over a chunk of its items: item_begin item_end p_col0 q_col0 | q_ncols bias_flag pad pad
 enum { U_ITEM0 = 0, U_ITEM1, U_PCOL, U_QCOL, U_QN, U_BIAS, UNIT_INTS = 8 };
-enum { SU_UNIT = 0, SU_ITEM0 = 4, SU_ITEM1, SU_PCOL, SU_QCOL, SU_QN, SUNIT_INTS = 12 };
+enum { SU_UNIT = 0, SU_ITEM0 = 4, SU_ITEM1, SU_PCOL, SU_QCOL, SU_QN, SU_FLAGS, SUNIT_INTS = 12 };      // SU_FLAGS: 1 every item has one plain source (lean streams), 2 bias sums read
 // item: p_buf p_node p_mask_buf kind(0 activation sources, 1 raw input) | src_begin n_src pad pad
 enum { I_PBUF = 0, I_PNODE, I_PMASK, I_KIND, I_SRC0, I_NSRC, GITEM_INTS = 8 };
 // finalize op: dst_lo dst_hi rows cols | ld kind unit_begin n_units | src_row0 pad pad pad     (units of one target tile are consecutive)
@@ -375,10 +375,14 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
         tgt_enc[t] = (int)tgts.size(); tgts.push_back(g);
     }
     alg_bwd += gw_fl; exec_bwd += gw_fl;
+    auto item_plain = [&](const std::array<int, 6>& it) { return it[3] == 0 && it[5] == 1 && srcs[(size_t)it[4] * SRC_INTS + S_SCALE] == fbits(1.0f); };
     // units: for every target tile (ot, kt) one unit per chunk of <= G_ITEMS_PER_UNIT items; the units of one tile are consecutive
     for (Tgt& g : tgts) {
         g.unit0 = (int)(units.size() / UNIT_INTS);
         const int i0 = (int)(items.size() / GITEM_INTS);
+        // items with one plain activation source at scale 1 first: the weight-gradient kernel walks super-units that hold only such items with its lean
+        // streams (a fixed order either way: the sums stay deterministic)
+        std::stable_sort(g.items.begin(), g.items.end(), [&](const std::array<int, 6>& x, const std::array<int, 6>& y) { return item_plain(x) > item_plain(y); });
         for (auto& it : g.items) items.insert(items.end(), {it[0], it[1], it[2], it[3], it[4], it[5], 0, 0});
         const int n = (int)g.items.size();
         g.chunks = (n + G_ITEMS_PER_UNIT - 1) / G_ITEMS_PER_UNIT;
@@ -407,8 +411,11 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
                     int u[4] = {-1, -1, -1, -1};
                     for (int a = 0; a < p.su_os; ++a) for (int b = 0; b < 2; ++b)
                         if (ot + a < not_ && kt + b < nkt) u[a * 2 + b] = g.unit0 + ((ot + a) * nkt + kt + b) * g.chunks + c;
+                    int flags = 1;
+                    for (int i = c * G_ITEMS_PER_UNIT; i < std::min(n, (c + 1) * G_ITEMS_PER_UNIT); ++i) if (!item_plain(g.items[i])) flags = 0;
+                    if (g.bias && kt == 0) flags |= 2;
                     sunits.insert(sunits.end(), {u[0], u[1], u[2], u[3], i0 + c * G_ITEMS_PER_UNIT, i0 + std::min(n, (c + 1) * G_ITEMS_PER_UNIT), ot * TW, kt * TW,
-                                                 std::min(2 * TW, g.K - kt * TW), 0, 0, 0});
+                                                 std::min(2 * TW, g.K - kt * TW), flags, 0, 0});
                 }
     }
     p.n_sunits = (int)(sunits.size() / SUNIT_INTS);
