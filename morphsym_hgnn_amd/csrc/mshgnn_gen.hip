@@ -31,6 +31,9 @@ struct GArgs {
     const int* jobs; const int* terms; const int* srcs; const int* units; const int* items; const int* sunits; const int* su_order;
     const void* wpack; const float* bias; const uint8_t* signs; float* slabs;
     int n_img, B, Hd, NCT, tiles, training, job0, n_units, n_parts, n_sunits;
+#ifdef GGW_STAMPS
+    long long* stamps;      // (phase clocks of k_ggradw, tools/stamps_ggradw.py)
+#endif
 };
 
 // element index of (window w, node, column 0) in an activation tensor: rows are Hd wide, or [hi Hd | lo Hd] on the split plan
@@ -753,13 +756,16 @@ template <bool SPLIT> __global__ __launch_bounds__(256) void k_gdec_bwd(GDecArgs
 // of a step are staged ONCE for all of them.  Steps = (item, 32-window chunk) pairs; the global loads of the next step(s) run in registers,
 // untouched, while a step is multiplied (P rows always; Q rows when the item has one source; aggregated Q rows are gathered at staging time).
 // ------------------------------------------------------------------------------------------------------
-// NWV waves: 4 wave columns of 64 k each x NWV / 4 wave rows of 32 RI o each (RI = 2: 64x64 per wave; OS = 2 on 8 waves: 128x64 per wave, 128 accumulator
-// registers at two waves per SIMD -- room for two register stages of loads where the 16-wave form has 128 registers and one).
+// The wave grid is a parameter (NWV / 4 wave rows x 4 wave columns) because other shapes were measured on the bf16 plan -- 8 waves of 128x64 with double-buffered
+// tiles: 12 % faster on the lean super-units, but a different block size than the general ones need, i.e. a second launch; 4 waves of 128x128 with the
+// accumulators in the AGPRs: hipcc spills 0.7-1.5 KB per lane whichever way the accumulators are pinned -- the launches use NWV = 8 OS.
 template <bool SPLIT, int OS, int NWV = 8 * OS> __global__ __launch_bounds__(64 * NWV) void k_ggradw(GArgs a) {
     constexpr int KW = 32, NT = 64 * NWV, PC = 16 * OS;      // PC: 16-byte chunks per staged P row
     constexpr int NQ = KW * 32 / NT;                         // Q chunks per thread (1 with 1024 threads, 2 with 512)
     constexpr int NP = KW * PC / NT, PR = NT / PC;           // P chunks per thread; P rows per staging pass
-    constexpr int RI = (128 * OS) / (NWV / 4) / 32;          // 32-row blocks of the o range per wave
+    constexpr int WCOLS = 4;                                 // wave grid: NWV / WCOLS rows x WCOLS columns
+    constexpr int RI = (128 * OS) / (NWV / WCOLS) / 32;      // 32-row blocks of the o range per wave
+    constexpr int CJ = 256 / WCOLS / 32;                     // 32-column blocks of the k range per wave
 #ifndef GGW_NST_SPLIT
 #define GGW_NST_SPLIT 2
 #endif
@@ -776,8 +782,8 @@ template <bool SPLIT, int OS, int NWV = 8 * OS> __global__ __launch_bounds__(64 
     auto Pl = [&](int t) { return tiles_l + (SPLIT ? t * TSZ : 0); };
     auto Ql = [&](int t) { return tiles_l + (SPLIT ? (OS + t) * TSZ : 0); };
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wv >> 2, wc = wv & 3;                     // wave (wr, wc): rows [32 RI wr, +32 RI) of the o range, columns [64 wc, +64) of the k range
-    const int row0 = 32 * RI * wr;
+    const int wr = wv / WCOLS, wc = wv % WCOLS;              // wave (wr, wc): rows [32 RI wr, +32 RI) of the o range, columns [32 CJ wc, +32 CJ) of the k range
+    const int row0 = 32 * RI * wr, col0 = 32 * CJ * wc;
     const int su_i = a.su_order[blockIdx.x % a.n_sunits], part = blockIdx.x / a.n_sunits;
     const int* su = a.sunits + (size_t)su_i * SUNIT_INTS;
     const int it0 = su[SU_ITEM0], pcol = su[SU_PCOL], qcol = su[SU_QCOL], qn = su[SU_QN];
@@ -788,18 +794,18 @@ template <bool SPLIT, int OS, int NWV = 8 * OS> __global__ __launch_bounds__(64 
     const int cp = tid % PC, rp = tid / PC;                  // P staging: (row rp < 32, chunk cp)
     const int cq = tid & 31, rq = tid >> 5;                  // Q staging: (row rq + (NT / 32) i, chunk cq), i < NQ
     const int one_bits = __float_as_int(1.0f);
-    f32x16 acc[RI][2];
+    f32x16 acc[RI][CJ];
 #pragma unroll
     for (int i = 0; i < RI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < CJ; ++j)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
     float bsum[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
 
-    struct Stage { u32x4 pa[NP], pb[NP], qa[NQ], qb[NQ]; unsigned mw[NP]; };      // a: bf16 chunk / hi half / first four fp32; b: lo half / next four fp32
+    struct Stage { u32x4 pa[NP], pb[NP], qa[NQ], qb[NQ], qc[SPLIT ? 1 : NQ]; unsigned mw[NP]; };      // qc: second source of a two-source sum (lean streams, bf16)      // a: bf16 chunk / hi half / first four fp32; b: lo half / next four fp32
     auto q_kind = [&](const int* im) {      // 1 raw input, 0 single activation source, 2 aggregate
         if (im[I_KIND] == 1) return 1;
         const int* src = a.srcs + (size_t)im[I_SRC0] * SRC_INTS;
@@ -905,7 +911,7 @@ template <bool SPLIT, int OS, int NWV = 8 * OS> __global__ __launch_bounds__(64 
             if constexpr (SPLIT) *reinterpret_cast<u32x4*>(Ql(cq >> 4) + gwb_elem(row, (cq & 15) * 8)) = ql;
         }
     };
-    // LEAN streams (super-units whose items all have ONE plain activation source at scale 1, SU_FLAGS bit 0 -- the plan sorts those items to the front of
+    // LEAN streams (super-units whose items all have ONE plain activation source at scale 1 -- or, on the bf16 plan, the sum of two --, SU_FLAGS bit 0 -- the plan sorts those items to the front of
     // their target): what changes per step is a uniform base address per operand (SGPRs, advanced by one 32-window chunk) -- the per-thread offsets are
     // constants of the launch, the item descriptor is read at item boundaries only, column sums of P are kept only where a bias gradient is read (bit 1).
     // The general streams above spend ~0.9 ms of a 2.0 ms launch at h = 512 on their own bookkeeping (timed with the loads and MFMAs compiled out).
@@ -913,8 +919,8 @@ template <bool SPLIT, int OS, int NWV = 8 * OS> __global__ __launch_bounds__(64 
     const unsigned poff = (unsigned)rp * rowb + cp * 16, qoff = (unsigned)rq * rowb + cq * 16;
     const unsigned moff = (unsigned)mask_off(rp, pcol + cp * 8);
     const bool need_bias = (su[SU_FLAGS] & 2) != 0;
-    struct LeanF { const char* pb; const uint8_t* mb; const char* qb; int it, left, ch; bool msk; } LF{nullptr, nullptr, nullptr, it0, 0, 0, false};
-    struct LeanS { int it, left; bool msk; } LS{it0, 0, false};
+    struct LeanF { const char* pb; const uint8_t* mb; const char* qb; const char* qb2; int it, left, ch; bool msk, two; } LF{nullptr, nullptr, nullptr, nullptr, it0, 0, 0, false, false};
+    struct LeanS { int it, left; bool msk, two; } LS{it0, 0, false, false};
     auto fetch_lean = [&](Stage& st) {
         if (LF.left == 0) {      // next item of the fetch stream
             const int* im = a.items + (size_t)LF.it * GITEM_INTS;
@@ -925,6 +931,8 @@ template <bool SPLIT, int OS, int NWV = 8 * OS> __global__ __launch_bounds__(64 
             LF.msk = pm >= 0;
             LF.mb = reinterpret_cast<const uint8_t*>(a.ws + a.buf_off[pm >= 0 ? pm : 0]) + g_relu_byte(pnode, B, Hd, 0, 0) + ((size_t)((LF.ch * KW) >> 4) << 6);
             LF.qb = a.ws + a.buf_off[src[S_BUF]] + (g_row<SPLIT>(LF.ch * KW, src[S_NODE], B, Hd) + qcol) * 2;
+            LF.two = !SPLIT && im[I_NSRC] == 2;      // Q = the sum of two plain rows (bf16 plan)
+            if (LF.two) LF.qb2 = a.ws + a.buf_off[src[SRC_INTS + S_BUF]] + (g_row<SPLIT>(LF.ch * KW, src[SRC_INTS + S_NODE], B, Hd) + qcol) * 2;
             LF.left = nch; ++LF.it;
         }
         const int nrow = B - LF.ch * KW;      // rows of this chunk inside the batch
@@ -935,22 +943,27 @@ template <bool SPLIT, int OS, int NWV = 8 * OS> __global__ __launch_bounds__(64 
                 const char* pr = LF.pb + (poff + (unsigned)(i * PR) * rowb);
                 st.pa[i] = *reinterpret_cast<const u32x4*>(pr);
                 if constexpr (SPLIT) st.pb[i] = *reinterpret_cast<const u32x4*>(pr + 2 * Hd);
-                if (LF.msk) st.mw[i] = LF.mb[moff + (unsigned)(i * (PR >> 4) * 64)];
+                if (LF.msk) st.mw[i] = LF.mb[moff + (unsigned)((((PR * i) >> 4) << 6) + ((PR * i) & 15))];      // (rp < PR <= 16, or one pass)
             }
         }
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
             st.qa[i] = u32x4{0, 0, 0, 0}; st.qb[i] = u32x4{0, 0, 0, 0};
+            if constexpr (!SPLIT) st.qc[i] = u32x4{0, 0, 0, 0};
             if (rq + (NT / 32) * i < nrow && cq * 8 < qn) {
                 const char* qr = LF.qb + (qoff + (unsigned)(i * (NT / 32)) * rowb);
                 st.qa[i] = *reinterpret_cast<const u32x4*>(qr);
                 if constexpr (SPLIT) st.qb[i] = *reinterpret_cast<const u32x4*>(qr + 2 * Hd);
+                else if (LF.two) st.qc[i] = *reinterpret_cast<const u32x4*>(LF.qb2 + (qoff + (unsigned)(i * (NT / 32)) * rowb));
             }
         }
-        LF.pb += (size_t)KW * rowb; LF.mb += (KW >> 4) << 6; LF.qb += (size_t)KW * rowb; ++LF.ch; --LF.left;
+        LF.pb += (size_t)KW * rowb; LF.mb += (KW >> 4) << 6; LF.qb += (size_t)KW * rowb; LF.qb2 += (size_t)KW * rowb; ++LF.ch; --LF.left;
     };
     auto stage_lean = [&](const Stage& st) {
-        if (LS.left == 0) { LS.msk = a.items[(size_t)LS.it * GITEM_INTS + I_PMASK] >= 0; LS.left = nch; ++LS.it; }
+        if (LS.left == 0) {
+            const int* im = a.items + (size_t)LS.it * GITEM_INTS;
+            LS.msk = im[I_PMASK] >= 0; LS.two = !SPLIT && im[I_NSRC] == 2; LS.left = nch; ++LS.it;
+        }
         --LS.left;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
@@ -969,13 +982,21 @@ template <bool SPLIT, int OS, int NWV = 8 * OS> __global__ __launch_bounds__(64 
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
             const int row = rq + (NT / 32) * i;
-            *reinterpret_cast<u32x4*>(Qh(cq >> 4) + gwb_elem(row, (cq & 15) * 8)) = st.qa[i];
+            u32x4 qh = st.qa[i];
+            if constexpr (!SPLIT) {
+                if (LS.two) {      // fp32 sum of the two rows, rounded once: what the general stream's gather computes
+                    f32x4 a0, a1, b0, b1;
+                    unpack_oct(st.qa[i], a0, a1); unpack_oct(st.qc[i], b0, b1);
+                    qh = pack_oct(a0 + b0, a1 + b1);
+                }
+            }
+            *reinterpret_cast<u32x4*>(Qh(cq >> 4) + gwb_elem(row, (cq & 15) * 8)) = qh;
             if constexpr (SPLIT) *reinterpret_cast<u32x4*>(Ql(cq >> 4) + gwb_elem(row, (cq & 15) * 8)) = st.qb[i];
         }
     };
-    const __bf16* Pt0 = tiles_h + (row0 >> 7) * TSZ; const __bf16* Qt0 = tiles_h + (OS + (wc >> 1)) * TSZ;
-    const __bf16* Plt = Pl(row0 >> 7); const __bf16* Qlt = Ql(wc >> 1);
-    const int my_unit = su[SU_UNIT + (row0 >> 7) * 2 + (wc >> 1)];      // the 128x128 sub-tile this wave belongs to (-1: beyond the matrix edge)
+    const __bf16* Pt0 = tiles_h + (row0 >> 7) * TSZ; const __bf16* Qt0 = tiles_h + (OS + (col0 >> 7)) * TSZ;
+    const __bf16* Plt = Pl(row0 >> 7); const __bf16* Qlt = Ql(col0 >> 7);
+    const int my_unit = su[SU_UNIT + (row0 >> 7) * 2 + (col0 >> 7)];      // the 128x128 sub-tile this wave belongs to (-1: beyond the matrix edge)
     auto mfmas = [&]() {
         if (my_unit < 0) return;      // (wave-uniform)
         const __bf16* Pt = Pt0; const __bf16* Qt = Qt0;
@@ -987,7 +1008,7 @@ template <bool SPLIT, int OS, int NWV = 8 * OS> __global__ __launch_bounds__(64 
                 for (int i = 0; i < RI; ++i) { afh[i] = tr_frag(Pt, ks * 16, (row0 & 127) + i * 32, lane); afl[i] = tr_frag(Plt, ks * 16, (row0 & 127) + i * 32, lane); }
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const bf16x8 bqh = tr_frag(Qt, ks * 16, (wc & 1) * 64 + j * 32, lane), bql = tr_frag(Qlt, ks * 16, (wc & 1) * 64 + j * 32, lane);
+                    const bf16x8 bqh = tr_frag(Qt, ks * 16, (col0 & 127) + j * 32, lane), bql = tr_frag(Qlt, ks * 16, (col0 & 127) + j * 32, lane);
 #pragma unroll
                     for (int i = 0; i < RI; ++i) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afh[i], bqh, acc[i][j], 0, 0, 0);
@@ -996,15 +1017,15 @@ template <bool SPLIT, int OS, int NWV = 8 * OS> __global__ __launch_bounds__(64 
                     }
                 }
             } else {
-                bf16x8 afh[RI], bqh[2];
+                bf16x8 afh[RI], bqh[CJ];
 #pragma unroll
                 for (int i = 0; i < RI; ++i) afh[i] = tr_frag(Pt, ks * 16, (row0 & 127) + i * 32, lane);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) bqh[i] = tr_frag(Qt, ks * 16, (wc & 1) * 64 + i * 32, lane);
+                for (int i = 0; i < CJ; ++i) bqh[i] = tr_frag(Qt, ks * 16, (col0 & 127) + i * 32, lane);
 #pragma unroll
                 for (int i = 0; i < RI; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afh[i], bqh[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < CJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afh[i], bqh[j], acc[i][j], 0, 0, 0);
             }
         }
     };
@@ -1030,13 +1051,33 @@ template <bool SPLIT, int OS, int NWV = 8 * OS> __global__ __launch_bounds__(64 
         } else {
             Stage sa;
             if (nsteps > 0) fetchf(sa);
+#ifdef GGW_STAMPS
+            long long tk[6] = {0, 0, 0, 0, 0, 0}, t0 = clock64();
+#define GGW_T(k) { const long long t1 = clock64(); tk[k] += t1 - t0; t0 = t1; }
+#else
+#define GGW_T(k)
+#endif
             for (int s = 0; s < nsteps; ++s) {
                 __syncthreads();
+                GGW_T(0)
+#ifdef GGW_STAMPS
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                GGW_T(1)
+#endif
                 stagef(sa);
+                GGW_T(2)
                 __syncthreads();
+                GGW_T(3)
                 if (s + 1 < nsteps) fetchf(sa);
                 mfmas();
+#ifdef GGW_STAMPS
+                { float d; asm volatile("v_mov_b32 %0, %1" : "=v"(d) : "v"(acc[1][1][15])); asm volatile("" :: "v"(d)); }
+#endif
+                GGW_T(4)
             }
+#ifdef GGW_STAMPS
+            if (a.stamps && tid == 0) { for (int k = 0; k < 5; ++k) a.stamps[(size_t)blockIdx.x * 8 + k] = tk[k]; a.stamps[(size_t)blockIdx.x * 8 + 5] = nsteps; a.stamps[(size_t)blockIdx.x * 8 + 6] = su[SU_FLAGS]; }
+#endif
         }
     };
     if (su[SU_FLAGS] & 1) run(fetch_lean, stage_lean); else run(fetch, stage_to_lds);
@@ -1045,10 +1086,10 @@ template <bool SPLIT, int OS, int NWV = 8 * OS> __global__ __launch_bounds__(64 
 #pragma unroll
         for (int i = 0; i < RI; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < CJ; ++j)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
-                    const int o = (row0 & 127) + i * 32 + (q & 3) + ((q >> 2) << 3) + ((lane >> 5) << 2), k = (wc & 1) * 64 + j * 32 + (lane & 31);
+                    const int o = (row0 & 127) + i * 32 + (q & 3) + ((q >> 2) << 3) + ((lane >> 5) << 2), k = (col0 & 127) + j * 32 + (lane & 31);
                     slab[o * H + k] = acc[i][j][q];
                 }
     }
@@ -1322,6 +1363,9 @@ int gen_backward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pi
     {
         ProfScope ps(p, gp.ks_gradw, st);
         const unsigned grid = (unsigned)gp.n_sunits * gp.n_parts;
+#ifdef GGW_STAMPS
+        { const char* e = getenv("MSHGNN_GGW_STAMPS"); a.stamps = e ? reinterpret_cast<long long*>(strtoull(e, nullptr, 16)) : nullptr; }
+#endif
         if (gp.split && gp.su_os == 2) hipLaunchKernelGGL((k_ggradw<true, 2>), dim3(grid), dim3(1024), 0, st, a);
         else if (gp.split) hipLaunchKernelGGL((k_ggradw<true, 1>), dim3(grid), dim3(512), 0, st, a);
         else if (gp.su_os == 2) hipLaunchKernelGGL((k_ggradw<false, 2>), dim3(grid), dim3(1024), 0, st, a);

@@ -375,7 +375,13 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
         tgt_enc[t] = (int)tgts.size(); tgts.push_back(g);
     }
     alg_bwd += gw_fl; exec_bwd += gw_fl;
-    auto item_plain = [&](const std::array<int, 6>& it) { return it[3] == 0 && it[5] == 1 && srcs[(size_t)it[4] * SRC_INTS + S_SCALE] == fbits(1.0f); };
+    auto item_plain = [&](const std::array<int, 6>& it) {      // one plain activation row at scale 1, or (bf16 arithmetic) the sum of two such rows
+        if (it[3] != 0 || it[5] > (p.split ? 1 : 2)) return false;
+        for (int k = 0; k < it[5]; ++k) {
+            const int32_t* sp = &srcs[(size_t)(it[4] + k) * SRC_INTS];
+            if (sp[S_SCALE] != fbits(1.0f) || sp[S_MASK] >= 0) return false;
+        }
+        return true; };
     // units: for every target tile (ot, kt) one unit per chunk of <= G_ITEMS_PER_UNIT items; the units of one tile are consecutive
     for (Tgt& g : tgts) {
         g.unit0 = (int)(units.size() / UNIT_INTS);
@@ -423,24 +429,28 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
     // launch order: the super-units of ONE (target, item chunk) read the same P and Q rows (each half of them twice at hidden = 512).  Workgroups b
     // and b + 8 run on the same XCD (round-robin dispatch), so they are placed 8 apart on one XCD, back to back, and the second reader hits that
     // XCD's L2 (speed only).  Super-units were emitted (target, chunk)-major, so a group is a run of consecutive indices.
-    std::vector<int32_t> su_order(p.n_sunits, 0);
-    {
+    // The super-units on the general streams (aggregates of many rows, raw inputs: SU_FLAGS bit 0 clear) take about twice as long per step as the lean ones:
+    // they are dispatched first, so that they do not form the tail of the launch.
+    std::vector<int32_t> su_order;
+    for (int cls = 0; cls <= 1; ++cls) {
         std::vector<std::pair<int, int>> groups;      // (first super-unit, count)
         int pos = 0;
         for (Tgt& g : tgts) {
             const int per = ((g.rows / TW + p.su_os - 1) / p.su_os) * (((g.K + TW - 1) / TW + 1) / 2);
-            for (int c = 0; c < g.chunks; ++c) { groups.push_back({pos, per}); pos += per; }
+            for (int c = 0; c < g.chunks; ++c) { if ((sunits[(size_t)pos * SUNIT_INTS + SU_FLAGS] & 1) == cls) groups.push_back({pos, per}); pos += per; }
         }
         std::vector<std::vector<int>> xq(8);
+        int total = 0;
         for (auto& gr : groups) {      // to the XCD queue that is shortest so far
             int best = 0; for (int x = 1; x < 8; ++x) if (xq[x].size() < xq[best].size()) best = x;
             for (int k = 0; k < gr.second; ++k) xq[best].push_back(gr.first + k);
+            total += gr.second;
         }
         std::vector<size_t> qpos(8, 0);
-        for (int b = 0; b < p.n_sunits; ++b) {      // block b -> queue b % 8; an exhausted queue borrows from the longest remaining one
+        for (int b = 0; b < total; ++b) {      // block b -> queue b % 8; an exhausted queue borrows from the longest remaining one
             int q = b % 8;
             if (qpos[q] >= xq[q].size()) { q = 0; for (int y = 1; y < 8; ++y) if (xq[y].size() - qpos[y] > xq[q].size() - qpos[q]) q = y; }
-            su_order[b] = xq[q][qpos[q]++];
+            su_order.push_back(xq[q][qpos[q]++]);
         }
     }
     auto add_fin = [&](int64_t dst, int rows, int cols, int ld, int kind, int unit0, int nunits, int row0) {
