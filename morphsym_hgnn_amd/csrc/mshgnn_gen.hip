@@ -28,13 +28,21 @@ struct mshgnn_gen_state {      // device side of a generic plan
 struct GArgs {
     char* ws; size_t buf_off[GBUF_COUNT];
     const void* x[MSHGNN_MAX_TYPES]; int64_t pitch[MSHGNN_MAX_TYPES]; int nodes[MSHGNN_MAX_TYPES]; int vb[MSHGNN_MAX_TYPES]; int aligned;
-    const int* jobs; const int* terms; const int* srcs; const int* units; const int* items; const int* sunits; const int* su_order;
+    const int* jobs; const int* terms; const int* srcs; const int* units; const int* items; const int* sunits; const int* su_order; const int* aggs;
     const void* wpack; const float* bias; const uint8_t* signs; float* slabs;
     int n_img, B, Hd, NCT, tiles, training, job0, n_units, n_parts, n_sunits;
 #ifdef GGW_STAMPS
     long long* stamps;      // (phase clocks of k_ggradw, tools/stamps_ggradw.py)
 #endif
+#ifdef GEN_TIMELINE
+    long long* tl;          // (start / end wall clock and hardware id of every workgroup of a job or weight-gradient launch, tools/timeline_gen.py)
+#endif
 };
+#ifdef GEN_TIMELINE
+#define GEN_TL(k) do { if (a.tl && threadIdx.x == 0) { a.tl[(size_t)blockIdx.x * 4 + (k)] = wall_clock64(); if ((k) == 0) { unsigned id; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id)); a.tl[(size_t)blockIdx.x * 4 + 2] = id; unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); a.tl[(size_t)blockIdx.x * 4 + 3] = xcc; } } } while (0)
+#else
+#define GEN_TL(k) do { } while (0)
+#endif
 
 // element index of (window w, node, column 0) in an activation tensor: rows are Hd wide, or [hi Hd | lo Hd] on the split plan
 template <bool SPLIT> __device__ __forceinline__ size_t g_row(int w, int node, int B, int Hd) { return ((size_t)node * B + w) * (SPLIT ? 2 * Hd : Hd); }
@@ -252,6 +260,7 @@ template <bool SPLIT, int MB, int NW> __global__ __launch_bounds__(64 * NW) void
     const int w0 = tile * MB * P::ROWS, B = a.B, Hd = a.Hd;
     const int flags = job[J_FLAGS];
     const T16* wpack = reinterpret_cast<const T16*>(a.wpack);
+    GEN_TL(0);
 
     P::Acc acc[MB];
     {
@@ -338,6 +347,7 @@ template <bool SPLIT, int MB, int NW> __global__ __launch_bounds__(64 * NW) void
         }
     }
     gstep_epilogue<SPLIT, MB>(a, job, acc, ct, wv, lane, w0);
+    GEN_TL(1);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -784,6 +794,7 @@ template <bool SPLIT, int OS, int NWV = 8 * OS> __global__ __launch_bounds__(64 
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wv / WCOLS, wc = wv % WCOLS;              // wave (wr, wc): rows [32 RI wr, +32 RI) of the o range, columns [32 CJ wc, +32 CJ) of the k range
     const int row0 = 32 * RI * wr, col0 = 32 * CJ * wc;
+    GEN_TL(0);
     const int su_i = a.su_order[blockIdx.x % a.n_sunits], part = blockIdx.x / a.n_sunits;
     const int* su = a.sunits + (size_t)su_i * SUNIT_INTS;
     const int it0 = su[SU_ITEM0], pcol = su[SU_PCOL], qcol = su[SU_QCOL], qn = su[SU_QN];
@@ -1093,6 +1104,7 @@ template <bool SPLIT, int OS, int NWV = 8 * OS> __global__ __launch_bounds__(64 
                     slab[o * H + k] = acc[i][j][q];
                 }
     }
+    GEN_TL(1);
     // bias gradients: column sums of the staged P rows, into the slab of the k-tile-0 unit of each o sub-tile (the only ones the finalize reads)
     if (qcol == 0) {      // (uniform: super-units that hold k tile 0)
         float* red = reinterpret_cast<float*>(tiles_h);      // [PR rows][128 OS] floats
@@ -1215,6 +1227,74 @@ int gen_host_compile(const mshgnn_desc* desc, mshgnn_info* info, int32_t* n_tabl
     return MSHGNN_OK;
 }
 
+// k_gagg: the aggregates of many rows of one launch (mshgnn_gen_plan.hpp, G_MANY): out[w] = round(sum_s scale_s . mask_s . X_s[w]) -- the fp32 sums of gather8 in the
+// same order, rounded (or split) once, i.e. exactly the A-tile rows the job kernels staged for such a term.  A thread owns 16-byte chunks of the workgroup's GA_ROWS
+// rows; GA_U sources are in flight per thread.
+constexpr int GA_ROWS = 8, GA_U = 16, GA_THREADS = 512, GA_TAB = 64;
+template <bool SPLIT> __global__ __launch_bounds__(GA_THREADS) void k_gagg(GArgs a, int agg0, int row_blocks) {
+    // the sources' row / relu-byte addresses and scales, resolved by one thread each (source -> buffer -> offset is a chain of dependent loads: walked per source
+    // by every thread through scalar loads it made the kernel 24 us for 32 MB)
+    __shared__ unsigned long long t_row[GA_TAB], t_mask[GA_TAB];
+    __shared__ float t_scale[GA_TAB];
+    const int* op = a.aggs + (size_t)(agg0 + blockIdx.x / row_blocks) * AGG_INTS;
+    const int w0 = (blockIdx.x % row_blocks) * GA_ROWS, B = a.B, Hd = a.Hd, chunks = Hd >> 3, n_src = op[AG_NSRC];
+    const int* src0 = a.srcs + (size_t)op[AG_SRC0] * SRC_INTS;
+    T16* out = reinterpret_cast<T16*>(a.ws + a.buf_off[op[AG_OUT_BUF]]);
+    const int n_it = (GA_ROWS * chunks + GA_THREADS - 1) / GA_THREADS;
+    for (int it = 0; it < n_it; ++it) {      // (uniform trip count: the table barriers are inside)
+        const int idx = it * GA_THREADS + threadIdx.x;
+        const bool live = idx < GA_ROWS * chunks && w0 + idx / chunks < B;
+        const int w = min(w0 + idx / chunks, B - 1), col = (idx % chunks) * 8;
+        const size_t roff = (size_t)w * (SPLIT ? 2 * Hd : Hd) + col;
+        const int moff = (int)g_relu_byte(0, B, Hd, w, col);
+        float s[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] = 0.f;
+        for (int k0 = 0; k0 < n_src; k0 += GA_TAB) {
+            const int nt = min(GA_TAB, n_src - k0);
+            __syncthreads();
+            if ((int)threadIdx.x < nt) {
+                const int* sp = src0 + (size_t)(k0 + threadIdx.x) * SRC_INTS;
+                const int node = sp[S_NODE], mb = sp[S_MASK];
+                t_row[threadIdx.x] = reinterpret_cast<unsigned long long>(reinterpret_cast<const T16*>(a.ws + a.buf_off[sp[S_BUF]]) + g_row<SPLIT>(0, node, B, Hd));
+                t_mask[threadIdx.x] = mb >= 0 ? reinterpret_cast<unsigned long long>(reinterpret_cast<const uint8_t*>(a.ws + a.buf_off[mb]) + g_relu_byte(node, B, Hd, 0, 0)) : 0ull;
+                t_scale[threadIdx.x] = __int_as_float(sp[S_SCALE]);
+            }
+            __syncthreads();
+            for (int k = 0; k < nt; k += GA_U) {
+                u32x4 vh[GA_U], vl[SPLIT ? GA_U : 1]; unsigned bm[GA_U]; float sc[GA_U];
+#pragma unroll
+                for (int u = 0; u < GA_U; ++u) {
+                    if (k + u < nt) {      // (uniform)
+                        const T16* rp = reinterpret_cast<const T16*>(t_row[k + u]) + roff;
+                        const unsigned long long mk = t_mask[k + u];
+                        vh[u] = *reinterpret_cast<const u32x4*>(rp);
+                        if constexpr (SPLIT) vl[u] = *reinterpret_cast<const u32x4*>(rp + Hd);
+                        bm[u] = mk ? reinterpret_cast<const uint8_t*>(mk)[moff] : 0xffu;
+                        sc[u] = t_scale[k + u];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < GA_U; ++u) {
+                    if (k + u < nt) {
+                        acc8(s, chunk_mask_bits<T16>(vh[u], bm[u]), sc[u]);
+                        if constexpr (SPLIT) acc8(s, chunk_mask_bits<T16>(vl[u], bm[u]), sc[u]);
+                    }
+                }
+            }
+        }
+        if (live) {
+            const f32x4 lo4 = f32x4{s[0], s[1], s[2], s[3]}, hi4 = f32x4{s[4], s[5], s[6], s[7]};
+            T16* q = out + g_row<SPLIT>(w, op[AG_OUT_NODE], B, Hd) + col;
+            if constexpr (SPLIT) {
+                u32x4 hi, lo;
+                split_oct(lo4, hi4, hi, lo);
+                *reinterpret_cast<u32x4*>(q) = hi; *reinterpret_cast<u32x4*>(q + Hd) = lo;
+            } else *reinterpret_cast<u32x4*>(q) = pack_oct(lo4, hi4);
+        }
+    }
+}
+
 static int g_fill(const mshgnn_plan* p, const mshgnn_ws_layout& lay, const void* const* x, const int64_t* x_pitch, char* ws, int B, int training, GArgs& a) {
     const mshgnn_gen_state* g = p->gen;
     const GenPlan& gp = g->gp;
@@ -1226,6 +1306,11 @@ static int g_fill(const mshgnn_plan* p, const mshgnn_ws_layout& lay, const void*
         a.buf_off[BUF_T1 + l] = lay.t1[l]; a.buf_off[BUF_DU + l] = lay.du[l];
     }
     a.buf_off[GBUF_MASK0] = lay.dd[0];
+    {
+        const size_t aggsz = align_up((size_t)B * gp.n_aggbuf * gp.Hd * gp.esize * gp.planes, 256);
+        for (int l = 0; l < gp.L; ++l) { a.buf_off[GBUF_AGGF + l] = lay.dd[1] + l * aggsz; a.buf_off[GBUF_AGGB + l] = lay.dd[2] + l * aggsz; }
+    }
+    a.aggs = g->d_tables + gp.agg_off;
     const int in_es = gp.split ? 4 : 2;
     for (int t = 0; t < gp.NT; ++t) {
         a.x[t] = x[t]; a.pitch[t] = x_pitch ? x_pitch[t] : d.type_width[t]; a.nodes[t] = d.type_nodes[t];
@@ -1251,9 +1336,27 @@ static int g_tile_blocks(int B, bool split) {
     return split ? 6 : (B >= 256 ? 6 : 3);      // (split, hidden % 512 != 0: the dispatch falls back to k_gstep at 8 / 4 waves)
 }
 
+#ifdef GEN_TIMELINE
+static long long* gen_tl(const char* which) {      // MSHGNN_GEN_TL = "<launch name>:<hex device address>"
+    const char* e = getenv("MSHGNN_GEN_TL");
+    if (!e) return nullptr;
+    const char* c = strchr(e, ':');
+    if (!c || strncmp(e, which, (size_t)(c - e)) != 0 || strlen(which) != (size_t)(c - e)) return nullptr;
+    return reinterpret_cast<long long*>(strtoull(c + 1, nullptr, 16));
+}
+#endif
 static void g_launch_jobs(const mshgnn_plan* p, const Launch& ln, GArgs a, hipStream_t st) {
     const GenPlan& gp = p->gen->gp;
     a.job0 = ln.job0;
+    if (ln.n_agg > 0) {      // the launch's aggregates of many rows
+        ProfScope ps(p, gp.ks_agg, st);
+        const int row_blocks = (a.B + GA_ROWS - 1) / GA_ROWS;
+        if (gp.split) hipLaunchKernelGGL(k_gagg<true>, dim3((unsigned)ln.n_agg * row_blocks), dim3(GA_THREADS), 0, st, a, ln.agg0, row_blocks);
+        else hipLaunchKernelGGL(k_gagg<false>, dim3((unsigned)ln.n_agg * row_blocks), dim3(GA_THREADS), 0, st, a, ln.agg0, row_blocks);
+    }
+#ifdef GEN_TIMELINE
+    a.tl = gen_tl(gp.kstats[ln.ks].name);
+#endif
     // windows per workgroup: a packed weight fragment (8 KB per wave and K chunk, from L2) is reused for every 16-window row block of the tile
     // output tile of a workgroup: 64 windows x (32 NW) columns.  The staged A tile is shared by all NW waves, so wider tiles re-read the
     // activations fewer times (hidden / (32 NW) column groups per row of jobs): measured at h=512, B=1024: layer_fwd bf16 515 / 354 / 296 us at
@@ -1365,6 +1468,9 @@ int gen_backward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pi
         const unsigned grid = (unsigned)gp.n_sunits * gp.n_parts;
 #ifdef GGW_STAMPS
         { const char* e = getenv("MSHGNN_GGW_STAMPS"); a.stamps = e ? reinterpret_cast<long long*>(strtoull(e, nullptr, 16)) : nullptr; }
+#endif
+#ifdef GEN_TIMELINE
+        a.tl = gen_tl("gradw");
 #endif
         if (gp.split && gp.su_os == 2) hipLaunchKernelGGL((k_ggradw<true, 2>), dim3(grid), dim3(1024), 0, st, a);
         else if (gp.split) hipLaunchKernelGGL((k_ggradw<true, 1>), dim3(grid), dim3(512), 0, st, a);

@@ -12,6 +12,7 @@
 // 128x128 tiles dW = P^T Q with Q aggregated the same way.  No HIP calls in this file.
 #pragma once
 #include "mshgnn_plan.hpp"
+#include <map>
 
 namespace mshgnn {
 namespace gen {
@@ -33,10 +34,19 @@ enum { I_PBUF = 0, I_PNODE, I_PMASK, I_KIND, I_SRC0, I_NSRC, GITEM_INTS = 8 };
 // finalize op: dst_lo dst_hi rows cols | ld kind unit_begin n_units | src_row0 pad pad pad     (units of one target tile are consecutive)
 enum { GF_DST_LO = 0, GF_DST_HI, GF_ROWS, GF_COLS, GF_LD, GF_KIND, GF_UNIT0, GF_NUNITS, GFIN_INTS = 12 };
 constexpr int GBUF_MASK0 = BUF_COUNT;   // relu bytes of the encoder activation X_0 (workspace dd[0]); BUF_* ids as in mshgnn_plan.hpp
-constexpr int GBUF_COUNT = BUF_COUNT + 1;
+// Aggregates of MANY rows (more than G_MANY sources: the base node of an N-limb model sums N rows) are computed ONCE per layer and direction by their own small
+// launch (k_gagg) into one-node-per-aggregate buffers, and the job / weight-gradient item that consumes them sees one plain row.  Gathered inside the job kernel
+// they are one dependent round trip per source and staged row: at 32 sources the base node's workgroups run 263-347 us, as long as the whole layer launch
+// (tools/timeline_gen.py), and pipelining that gather in place cost the plain path its registers (+50 us on every launch).  The crossover was measured on the
+// 32-limb model: with the aggregate launches its layer launches take 250 -> 241 / 270 -> 252 us and the weight gradients lose their slowest super-units, but
+// k_gagg itself takes 23 us per launch (32 MB gathered from 32 strided regions at 1.4 TB/s), a wash at 32 rows -- so the threshold sits above it.
+constexpr int GBUF_AGGF = BUF_COUNT + 1, GBUF_AGGB = GBUF_AGGF + G_MAX_L;      // forward (sums of X_l rows) / backward (sums of masked dX_{l+1} rows) aggregates of layer l
+constexpr int GBUF_COUNT = GBUF_AGGB + G_MAX_L;
+constexpr int G_MANY = 32;
+enum { AG_OUT_BUF = 0, AG_OUT_NODE, AG_SRC0, AG_NSRC, AGG_INTS = 4 };
 constexpr int G_ITEMS_PER_UNIT = 8;     // items one weight-gradient workgroup sweeps (more units = more parallelism, more slabs to sum)
 
-struct Launch { int job0, n_jobs, ks; };
+struct Launch { int job0, n_jobs, ks; int agg0 = 0, n_agg = 0; };      // agg0 / n_agg: the aggregates computed in front of the launch
 
 struct GenPlan {
     mshgnn_desc d{};
@@ -52,9 +62,10 @@ struct GenPlan {
     std::vector<BiasDesc> biases;
     std::vector<uint8_t> signs; std::vector<int> sign_off, enc_nkc;
     std::vector<int32_t> tables;            // jobs | terms | srcs | units | items | fins
+    int agg_off = 0, n_aggbuf = 0;      // aggregate ops (AGG_INTS each); nodes per aggregate buffer
     int job_off = 0, term_off = 0, src_off = 0, unit_off = 0, sunit_off = 0, su_order_off = 0, n_sunits = 0, su_os = 1, item_off = 0, fin_off = 0, n_units = 0, n_parts = 1, n_fin = 0;
     std::vector<Launch> fwd, bwd;           // job launches in order
-    int ks_prep = 0, ks_dec_fwd = 0, ks_dec_bwd = 0, ks_gradw = 0, ks_fin = 0;
+    int ks_prep = 0, ks_dec_fwd = 0, ks_dec_bwd = 0, ks_gradw = 0, ks_fin = 0, ks_agg = -1;
     std::vector<mshgnn_kernel_stat> kstats;
     mshgnn_info info{};
     std::string err;
@@ -224,9 +235,28 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
     const double es = (double)p.esize * p.planes, in_es = p.split ? 4.0 : 2.0;
     double bytes_in = 0; for (int t = 0; t < NT; ++t) bytes_in += (double)d.type_nodes[t] * d.type_width[t] * in_es;
     p.ks_prep = stat("prep", MSHGNN_BOUND_HBM, 0, 0);
+    std::vector<int32_t> aggs;
+    int agg_mark = 0;      // first aggregate op of the launch being built
     auto launch = [&](std::vector<Launch>& v, int j0, const std::string& name, double flops, double bytes) {
-        const int n = (int)(jobs.size() / JOB_INTS) - j0;
-        if (n > 0) v.push_back({j0, n, stat(name, MSHGNN_BOUND_MFMA, flops, bytes)}); };
+        const int n = (int)(jobs.size() / JOB_INTS) - j0, na = (int)(aggs.size() / AGG_INTS);
+        if (n > 0) { Launch ln{j0, n, stat(name, MSHGNN_BOUND_MFMA, flops, bytes)}; ln.agg0 = agg_mark; ln.n_agg = na - agg_mark; v.push_back(ln); }
+        agg_mark = na; };
+    // a term's / item's source list -> itself, or (more than G_MANY rows) one plain row of the layer's aggregate buffer + the op that fills it
+    std::map<std::vector<std::array<int, 4>>, std::array<int, 4>> agg_known;      // (forward aggregates are looked up again by the weight-gradient items)
+    int agg_count[2][G_MAX_L] = {};
+    auto many = [&](const std::vector<std::array<int, 4>>& srcl, int dir, int l, bool create) -> std::vector<std::array<int, 4>> {
+        if ((int)srcl.size() <= G_MANY) return srcl;
+        auto it = agg_known.find(srcl);
+        if (it != agg_known.end()) return {it->second};
+        if (!create) return srcl;
+        const int node = agg_count[dir][l]++;
+        p.n_aggbuf = std::max(p.n_aggbuf, node + 1);
+        const int s0 = (int)(srcs.size() / SRC_INTS);
+        for (auto& q : srcl) srcs.insert(srcs.end(), {q[0], q[1], q[2], q[3]});
+        aggs.insert(aggs.end(), {(dir ? GBUF_AGGB : GBUF_AGGF) + l, node, s0, (int)srcl.size()});
+        const std::array<int, 4> row{(dir ? GBUF_AGGB : GBUF_AGGF) + l, node, -1, fbits(1.0f)};
+        agg_known[srcl] = row;
+        return {row}; };
 
     {   // encoder: X_0[n] = relu((mask . x) W_enc^T + b)      (hgnn_c2.py:143-147)
         const int j0 = (int)(jobs.size() / JOB_INTS); double fl = 0;
@@ -254,6 +284,7 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
                     if (p.rel_dst[r] != t || in_src[r][i].empty()) continue;
                     TermDef td{pack_rel[0][l * NR + r], NCT, 0, Hd, 0, {}};
                     for (int j : in_src[r][i]) td.s.push_back(one(BUF_X + l, p.type_base[p.rel_src[r]] + j, -1, scale_of(r, i)));
+                    td.s = many(td.s, 0, l, true);
                     tds.push_back(td);
                 }
                 fl += NL * tds.size();
@@ -311,6 +342,7 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
                     if (p.rel_src[r] != s || !p.live[l][p.rel_dst[r]] || out_dst[r][j].empty()) continue;
                     TermDef td{pack_rel[1][l * NR + r], NCT, 0, Hd, 0, {}};
                     for (int i : out_dst[r][j]) td.s.push_back(dh_src(l, p.type_base[p.rel_dst[r]] + i, scale_of(r, i)));
+                    td.s = many(td.s, 1, l, true);
                     tds.push_back(td);
                 }
                 fl += NL * tds.size();
@@ -348,7 +380,7 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
                 if (in_src[r][i].empty()) continue;
                 std::vector<std::array<int, 4>> qs;
                 for (int j : in_src[r][i]) qs.push_back(one(BUF_X + l, p.type_base[p.rel_src[r]] + j, -1, scale_of(r, i)));
-                new_item(g, dh_src(l, p.type_base[t] + i), 0, qs); gw_fl += NL;
+                new_item(g, dh_src(l, p.type_base[t] + i), 0, many(qs, 0, l, false)); gw_fl += NL;      // (the forward pass left the sum of many rows in its aggregate buffer)
             }
             tgt_rel[l * NR + r] = (int)tgts.size(); tgts.push_back(g);
         }
@@ -496,6 +528,7 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
     p.n_fin = (int)(fins.size() / GFIN_INTS);
     p.ks_gradw = stat("gradw", MSHGNN_BOUND_MFMA, gw_fl, bytes_in + (2.0 * L + 1) * p.NN * Hd * es);
     p.ks_fin = stat("finalize", MSHGNN_BOUND_HBM, 0, 0);
+    if (!aggs.empty()) p.ks_agg = stat("aggregate", MSHGNN_BOUND_HBM, 0, 0);      // (k_gagg, in front of the launches that consume aggregates of many rows)
 
     std::vector<int32_t>& T = p.tables;
     p.job_off = 0; T.insert(T.end(), jobs.begin(), jobs.end());
@@ -506,6 +539,7 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
     p.su_order_off = (int)T.size(); T.insert(T.end(), su_order.begin(), su_order.end());
     p.item_off = (int)T.size(); T.insert(T.end(), items.begin(), items.end());
     p.fin_off = (int)T.size(); T.insert(T.end(), fins.begin(), fins.end());
+    p.agg_off = (int)T.size(); T.insert(T.end(), aggs.begin(), aggs.end());
 
     p.info.rows_per_tile = 64; p.info.total_nodes = p.NN; p.info.lds_bytes = 4 * 4096 * p.planes;
     p.info.flops_fwd = alg_fwd; p.info.flops_bwd = alg_bwd; p.info.flops_exec_fwd = exec_fwd; p.info.flops_exec_bwd = exec_bwd;
@@ -525,9 +559,12 @@ inline void layout_gen_workspace(const GenPlan& p, int64_t B, int training, mshg
     for (int l = 0; l <= p.L; ++l) o->x[l] = take(act);
     for (int l = 0; l < p.L; ++l) { o->mask[l] = take(maskb); o->hb[l] = take(mlp); o->t1[l] = take(mlp); }
     o->dd[0] = take(maskb);
+    const size_t aggsz = align_up((size_t)B * p.n_aggbuf * p.Hd * p.esize * p.planes, 256);      // one aggregate buffer (a layer's, one direction)
+    if (p.n_aggbuf) o->dd[1] = take(aggsz * p.L);      // dd[1] / dd[2]: forward / backward aggregates of many rows, L buffers of [n_aggbuf][B][h] each
     if (training) {
         for (int l = 0; l <= p.L; ++l) o->dx[l] = take(act);
         for (int l = 0; l < p.L; ++l) { o->dh[l] = take(act); o->du[l] = take(mlp); }
+        if (p.n_aggbuf) o->dd[2] = take(aggsz * p.L);
         o->slabs = take((size_t)p.n_units * p.n_parts * SLAB_FLOATS * 4);
         o->dec_slabs = take((size_t)NWG_DEC * (8 * p.Hd + 16) * 4);
     }

@@ -227,6 +227,11 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
     const bool residual = (d.flags & MSHGNN_FLAG_RESIDUAL) != 0;
     if (has_mlp && (d.mlp_type < 0 || d.mlp_type >= NT)) return fail(p, "mlp_type out of range");
     p.type_base[0] = 0;
+    {   // (before node_type[] is filled: a 129-node topology at hidden = 128 used to run past its 64 entries here instead of being handed to the generic engine)
+        int64_t total = 0;
+        for (int t = 0; t < NT; ++t) total += std::max(0, d.type_nodes[t]);
+        if (total > 64) return fail(p, "topology has too many nodes per window for the LDS-resident layer kernel (max 20 fp32 / 40 bf16)");
+    }
     for (int t = 0; t < NT; ++t) {
         if (d.type_nodes[t] < 1) return fail(p, "every node type needs >= 1 node");
         if (d.type_width[t] < 1) return fail(p, "every node type needs input width >= 1");

@@ -73,6 +73,14 @@ def test_wide_and_many_node_models_compile_on_the_generic_engine():
         assert engine.compile_plan_host(helpers.make_spec("c2", "a1-c2", "a1-c2", 256, 3), dt).kernel_sets == 4
     # algorithmic work of configs[4]: 2.70 GFLOP per window forward + backward
     assert abs((info.flops_fwd + info.flops_bwd) / 1e9 - 2.70) < 0.05
+    # the same many-node topologies at hidden = 128, where the specialised plan is tried first: it declines (its node tables hold 64 entries) instead of
+    # writing past them, and the generic engine takes over
+    for limbs in (32, 40, 70):
+        many = ModelSpec(kind="mi", topology=topology.synthetic_limbs(limbs), hidden=128, num_layers=3, widths=synth.feature_widths("mi", True),
+                         regression=True, grf_dimension=1)
+        for dt in ("bf16", "x3"):
+            info = engine.compile_plan_host(many, dt)
+            assert info.kernel_sets == 4 and info.total_nodes == 1 + 4 * limbs
 
 
 def test_engine_fails_loudly_without_gpu():

@@ -58,6 +58,31 @@ def test_mean_aggregation_with_in_degree_above_one():
     assert not bad, bad
 
 
+@pytest.mark.parametrize("dtype", ["x3", "bf16"])
+def test_base_node_of_many_limbs_goes_through_the_aggregate_launch(dtype):
+    """More than 32 rows into one destination (the base node of a 40-limb robot: 40 hip joints, forward; their 40 gradients, backward): the sums are
+    computed by their own launch (k_gagg) per layer and direction, and the forward ones feed the weight-gradient item of that relation as well."""
+    from morphsym_hgnn_amd import engine as eng, synth, topology
+    from morphsym_hgnn_amd.spec import ModelSpec
+    topo = topology.synthetic_limbs(40)
+    spec = ModelSpec(kind="mi", topology=topo, hidden=128, num_layers=3, widths=synth.feature_widths("mi", True), regression=True, grf_dimension=1)
+    B = 19
+    n_y = spec.out_channels * spec.num_nodes[spec.out_type]
+    x_dict, y = synth.make_windows(21, B, spec.num_nodes, spec.widths, n_y)
+    params = synth.make_params(21, spec.param_shapes())
+    assert eng.compile_plan_host(spec, dtype).kernel_sets == 4
+    tol = RTOL if dtype == "x3" else 3e-2
+    errs, *_ = helpers.run_engine_case(spec, x_dict, y, params, topo.edge_index_dict(B), B, dtype=dtype, **({} if dtype == "x3" else {"decision_tol": 3e-2}))
+    bad = {k: v for k, v in errs.items() if v > tol}
+    assert not bad, bad
+    e = eng.Engine(spec, dtype)
+    xs = e.cast_inputs(x_dict); flat = eng.flatten_params(spec, params, e.device)
+    e.profile(True)
+    e.step_mse(xs, flat, y.reshape(-1).to(e.device, torch.float32), B)
+    torch.cuda.synchronize()
+    assert any(r["name"] == "aggregate" and r["launches"] > 0 for r in e.profile_read()), "the aggregate launch ran"
+
+
 @pytest.mark.parametrize("name", ["synth8_mi_h256_L3_B3", "a1c2_h256_L2_d3_B3"])
 def test_generic_bf16_arithmetic_is_within_bf16_distance_of_the_oracle(name):
     """The throughput arithmetic of the generic engine (bf16 storage / operands, fp32 accumulate) against the oracle evaluated with the
