@@ -124,7 +124,8 @@ typedef struct mshgnn_ws_layout {
     size_t x[17];       /* X_l      [B][NN][h]  l = 0..L   (dtype)      hidden state after the encoder / layer l-1 */
     size_t dx[17];      /* dX_l     [B][NN][h]  l = 0..L   (dtype)                                                  */
     size_t dh[16];      /* dH_l     [B][NN][h]  l = 0..L-1 (dtype)      gradient w.r.t. the HeteroConv output       */
-    size_t dd[16];      /* dd[0]: relu bytes of the encoder activation X_0 (layout as mask[l], training only); rest 0 */
+    size_t dd[16];      /* dd[0]: relu bytes of the encoder activation X_0 (layout as mask[l], training only); generic engine: dd[1] / dd[2] =
+                           forward / backward sums of more than 32 rows into one node, L buffers of [aggregates][B][h] each (0: none); rest 0 */
     size_t mask[16];    /* relu bits, one byte per (node, window, 8 features): [NN][4][ceil(B/16)][4][16] uint8          */
     size_t hb[16], t1[16], du[16];  /* base_transform stash [B][n_mlp][h] (dtype)                                   */
     size_t wpack;       /* packed weights                                                                          */
