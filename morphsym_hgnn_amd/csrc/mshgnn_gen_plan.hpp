@@ -244,8 +244,9 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
     // a term's / item's source list -> itself, or (more than G_MANY rows) one plain row of the layer's aggregate buffer + the op that fills it
     std::map<std::vector<std::array<int, 4>>, std::array<int, 4>> agg_known;      // (forward aggregates are looked up again by the weight-gradient items)
     int agg_count[2][G_MAX_L] = {};
+    const int g_many = []() { const char* e = std::getenv("MSHGNN_GEN_MANY"); return e ? std::max(2, std::atoi(e)) : G_MANY; }();      // (threshold override, read when the plan is compiled: tests, measurements)
     auto many = [&](const std::vector<std::array<int, 4>>& srcl, int dir, int l, bool create) -> std::vector<std::array<int, 4>> {
-        if ((int)srcl.size() <= G_MANY) return srcl;
+        if ((int)srcl.size() <= g_many) return srcl;
         auto it = agg_known.find(srcl);
         if (it != agg_known.end()) return {it->second};
         if (!create) return srcl;

@@ -58,6 +58,17 @@ def test_mean_aggregation_with_in_degree_above_one():
     assert not bad, bad
 
 
+def test_aggregate_launch_on_the_32_limb_golden_case(monkeypatch):
+    """The aggregate launches forced onto BASELINE configs[4]'s topology (threshold 4 instead of 32 rows, MSHGNN_GEN_MANY, read when the plan is compiled):
+    same golden vectors, same tolerance."""
+    monkeypatch.setenv("MSHGNN_GEN_MANY", "4")
+    case, spec, fx, x_dict, y, params, ei = helpers.load_case("synth32_mi_h512_L6_B2")
+    errs, out, loss, grads = helpers.run_engine_case(spec, x_dict, y, params, ei, case["B"], dtype="x3")
+    bad = {k: v for k, v in errs.items() if v > RTOL}
+    assert not bad, bad
+    helpers.check_against_fixture(fx, out, loss, grads, rtol=RTOL, what="synth32 with aggregate launches")
+
+
 @pytest.mark.parametrize("dtype", ["x3", "bf16"])
 def test_base_node_of_many_limbs_goes_through_the_aggregate_launch(dtype):
     """More than 32 rows into one destination (the base node of a 40-limb robot: 40 hip joints, forward; their 40 gradients, backward): the sums are
