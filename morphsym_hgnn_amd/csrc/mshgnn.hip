@@ -2354,9 +2354,14 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
             }
             a.stamps = stamp_ptr("MSHGNN_STAMPS");
             a.stagger = (p->slab2_for(tiles, a.training != 0) || p->slab_for(tiles)) && tiles > p->n_cu ? p->stagger : 0;
-            // the tail's reduction scratch (one decoder slab per wave at the start of LDS) must end below the out-type nodes' blocks
-            const bool step = stack_step_done && p->use_step && (y_fused || labels_fused) && !p->wide_for(B) && !p->slab2_for(tiles, true) &&
-                              (size_t)a.node0 * Prec<T>::BLK >= (size_t)((p->slab_for(tiles) ? SL_THREADS : LAYER_THREADS) / 64) * DEC_SLAB_FLOATS * sizeof(float);
+            // the tail's reduction scratch (one decoder slab per wave) must not touch the out-type nodes' blocks, which receive dX_L for the backward sweep: it sits
+            // in the blocks in front of them, or (models whose out type comes first: the centroidal-momentum ones) in the blocks behind them
+            const bool step_slab = p->slab_for(tiles);
+            const size_t red_need = (size_t)((step_slab ? SL_THREADS : LAYER_THREADS) / 64) * DEC_SLAB_FLOATS * sizeof(float);
+            const size_t lds_launch = (size_t)((step_slab ? hp.sl_blk : hp.fs_blk) + FS_EXTRA_BLK) * Prec<T>::BLK, red_back = (size_t)(a.node0 + a.n_out) * Prec<T>::BLK;
+            const bool red_front_ok = (size_t)a.node0 * Prec<T>::BLK >= red_need, red_back_ok = red_back + red_need <= lds_launch;
+            const bool step = stack_step_done && p->use_step && (y_fused || labels_fused) && !p->wide_for(B) && !p->slab2_for(tiles, true) && (red_front_ok || red_back_ok);
+            if (step && !red_front_ok) a.red_off = (int)red_back;
             ProfScope ps(p, step ? hp.ks_stack_step : hp.ks_stack_fwd, st);
             if (p->wide_for(B)) {
                 for (int l = 0; l < hp.L; ++l) a.prog_off[l] = hp.wd_fwd_off[l];

@@ -639,6 +639,7 @@ struct StackArgs {
     // split plan: LDS block of the lo half of node n = lo_blk + n; the lo image of pack i is pack n_img + i
     int lo_blk, n_img;
     int scr0;            // split plan: first base_transform scratch block (NN, or NN - n_mlp when the scratch aliases the last nodes' blocks)
+    int red_off;         // byte offset in LDS of the decoder tail's reduction scratch (0: the first blocks; one-launch steps whose out-type nodes come first: the blocks behind them)
     int stagger;         // two workgroups per CU: the second half of the grid starts this many cycles late, so that one workgroup's MAC phases
                          // (matrix pipe) run beside the other's epilogues (stores) instead of both competing for the same unit (0: off)
 };
@@ -902,7 +903,7 @@ __device__ __forceinline__ void decoder_tail_impl(const StackArgs& a, char* smem
             }
             lsum += __shfl_xor(lsum, 16, 64); lsum += __shfl_xor(lsum, 32, 64);
             __syncthreads();
-            float* red = reinterpret_cast<float*>(smem);          // [8 waves][8 H + 16]
+            float* red = reinterpret_cast<float*>(smem + a.red_off);          // [waves][8 H + 16]
             if (lane < 16) {
 #pragma unroll
                 for (int dd = 0; dd < DMAX; ++dd) {
