@@ -785,10 +785,15 @@ template <bool SPLIT, int OS, int NWV = 8 * OS> __global__ __launch_bounds__(64 
     constexpr int NST = OS == 2 ? 1 : (SPLIT ? GGW_NST_SPLIT : GGW_NST_BF16);      // register stages (16 waves: 128 VGPRs, one stage)
     constexpr int TSZ = KW * GWB_PITCH;                      // one staged 32 x 128 tile
     constexpr int BUFSZ = (OS + 2) * TSZ;
-    __shared__ __attribute__((aligned(16))) __bf16 tiles_h[BUFSZ];      // P sub-tiles [0, OS), Q sub-tiles [OS, OS + 2) (the bias reduction reuses it)
+    // DB (the bf16 plan): two tile sets -- step s + 1 is staged into one while step s is multiplied from the other, ONE barrier per step instead
+    // of two (the phase clocks showed 640 of a step's 3 360 clocks at the second barrier: the waves wait for the slowest stager, then again for the slowest
+    // multiplier; with one barrier a wave that has staged goes straight on to its MFMAs)
+    constexpr bool DB = !SPLIT;
+    __shared__ __attribute__((aligned(16))) __bf16 tiles_h[(DB ? 2 : 1) * BUFSZ];      // P sub-tiles [0, OS), Q sub-tiles [OS, OS + 2) (the bias reduction reuses it)
     __shared__ __attribute__((aligned(16))) __bf16 tiles_l[SPLIT ? BUFSZ : 8];
-    auto Ph = [&](int t) { return tiles_h + t * TSZ; };
-    auto Qh = [&](int t) { return tiles_h + (OS + t) * TSZ; };
+    int sbuf = 0, mbuf = 0;      // (DB) tile set the staging writes / the MFMAs read
+    auto Ph = [&](int t) { return tiles_h + (DB ? sbuf * BUFSZ : 0) + t * TSZ; };
+    auto Qh = [&](int t) { return tiles_h + (DB ? sbuf * BUFSZ : 0) + (OS + t) * TSZ; };
     auto Pl = [&](int t) { return tiles_l + (SPLIT ? t * TSZ : 0); };
     auto Ql = [&](int t) { return tiles_l + (SPLIT ? (OS + t) * TSZ : 0); };
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1010,7 +1015,7 @@ template <bool SPLIT, int OS, int NWV = 8 * OS> __global__ __launch_bounds__(64 
     const int my_unit = su[SU_UNIT + (row0 >> 7) * 2 + (col0 >> 7)];      // the 128x128 sub-tile this wave belongs to (-1: beyond the matrix edge)
     auto mfmas = [&]() {
         if (my_unit < 0) return;      // (wave-uniform)
-        const __bf16* Pt = Pt0; const __bf16* Qt = Qt0;
+        const __bf16* Pt = Pt0 + (DB ? mbuf * BUFSZ : 0); const __bf16* Qt = Qt0 + (DB ? mbuf * BUFSZ : 0);
 #pragma unroll
         for (int ks = 0; ks < KW / 16; ++ks) {
             if constexpr (SPLIT) {      // Q fragments one column block at a time: 24 fragment registers live instead of 32
@@ -1041,7 +1046,39 @@ template <bool SPLIT, int OS, int NWV = 8 * OS> __global__ __launch_bounds__(64 
         }
     };
     auto run = [&](auto& fetchf, auto& stagef) {
-        if constexpr (NST == 2) {
+        if constexpr (DB) {
+            Stage sa;      // tile set s & 1 = step s; `sa` = step s + 1, requested under the MFMAs of step s - 1
+            if (nsteps > 0) { fetchf(sa); sbuf = 0; stagef(sa); }
+            if (nsteps > 1) fetchf(sa);
+            __syncthreads();
+#ifdef GGW_STAMPS
+            long long tk[6] = {0, 0, 0, 0, 0, 0}, t0 = clock64();
+#define GGW_TD(k) { const long long t1 = clock64(); tk[k] += t1 - t0; t0 = t1; }
+#else
+#define GGW_TD(k)
+#endif
+            for (int s = 0; s < nsteps; ++s) {
+                sbuf = (s + 1) & 1; mbuf = s & 1;
+#ifdef GGW_STAMPS
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                GGW_TD(1)
+#endif
+                if (s + 1 < nsteps) stagef(sa);
+                GGW_TD(2)
+                if (s + 2 < nsteps) fetchf(sa);
+                mfmas();
+#ifdef GGW_STAMPS
+                { float d; asm volatile("v_mov_b32 %0, %1" : "=v"(d) : "v"(acc[1][1][15])); asm volatile("" :: "v"(d)); }
+#endif
+                GGW_TD(4)
+                __syncthreads();
+                GGW_TD(0)
+            }
+            sbuf = 0;
+#ifdef GGW_STAMPS
+            if (a.stamps && tid == 0) { for (int k = 0; k < 5; ++k) a.stamps[(size_t)blockIdx.x * 8 + k] = tk[k]; a.stamps[(size_t)blockIdx.x * 8 + 5] = nsteps; a.stamps[(size_t)blockIdx.x * 8 + 6] = su[SU_FLAGS]; }
+#endif
+        } else if constexpr (NST == 2) {
             Stage sa, sb;
             if (nsteps > 0) fetchf(sa);
             if (nsteps > 1) fetchf(sb);

@@ -1,5 +1,6 @@
 """Phase clocks of k_ggradw's step loop (build with EXTRA=-DGGW_STAMPS into another library and pass it as MSHGNN_LIB): per workgroup, summed over its steps,
-wave 0's clocks [at the first barrier, waiting for the step's loads, staging, at the second barrier, requests + MFMAs]."""
+wave 0's clocks [at the step's barrier, waiting for the next step's loads, staging it, (second barrier: the two-barrier loop of the split plan only),
+requests + MFMAs]."""
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from morphsym_hgnn_amd import engine as eng, synth, topology
@@ -20,6 +21,6 @@ for name, sel in (("lean super-units", (s[:, 6].astype(int) & 1) == 1), ("genera
     if not len(q): continue
     per = q[:, :5] / q[:, 5:6]
     print(f"{name}: {len(q)} workgroups, steps per workgroup median {np.median(q[:, 5]):.0f}; clocks per step (median over workgroups):")
-    for k, nm in enumerate(["barrier 1", "wait for loads", "stage", "barrier 2", "requests + MFMAs"]):
+    for k, nm in enumerate(["barrier", "wait for loads", "stage", "(barrier 2)", "requests + MFMAs"]):
         print(f"  {nm:18s} {np.median(per[:, k]):8.1f}   p90 {np.percentile(per[:, k], 90):8.1f}")
     print(f"  {'sum':18s} {np.median(per.sum(1)):8.1f}")
