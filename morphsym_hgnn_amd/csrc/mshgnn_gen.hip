@@ -769,6 +769,7 @@ template <bool SPLIT> __global__ __launch_bounds__(256) void k_gdec_bwd(GDecArgs
 // The wave grid is a parameter (NWV / 4 wave rows x 4 wave columns) because other shapes were measured on the bf16 plan -- 8 waves of 128x64 with double-buffered
 // tiles: 12 % faster on the lean super-units, but a different block size than the general ones need, i.e. a second launch; 4 waves of 128x128 with the
 // accumulators in the AGPRs: hipcc spills 0.7-1.5 KB per lane whichever way the accumulators are pinned -- the launches use NWV = 8 OS.
+constexpr int ggw_lds_bytes(bool split, int os) { return 2 * (split ? 2 : 1) * (os + 2) * 32 * GWB_PITCH * 2; }      // k_ggradw's dynamic LDS: two tile sets per plane
 template <bool SPLIT, int OS, int NWV = 8 * OS> __global__ __launch_bounds__(64 * NWV) void k_ggradw(GArgs a) {
     constexpr int KW = 32, NT = 64 * NWV, PC = 16 * OS;      // PC: 16-byte chunks per staged P row
     constexpr int NQ = KW * 32 / NT;                         // Q chunks per thread (1 with 1024 threads, 2 with 512)
@@ -785,17 +786,18 @@ template <bool SPLIT, int OS, int NWV = 8 * OS> __global__ __launch_bounds__(64 
     constexpr int NST = OS == 2 ? 1 : (SPLIT ? GGW_NST_SPLIT : GGW_NST_BF16);      // register stages (16 waves: 128 VGPRs, one stage)
     constexpr int TSZ = KW * GWB_PITCH;                      // one staged 32 x 128 tile
     constexpr int BUFSZ = (OS + 2) * TSZ;
-    // DB (the bf16 plan): two tile sets -- step s + 1 is staged into one while step s is multiplied from the other, ONE barrier per step instead
+    // DB: two tile sets -- step s + 1 is staged into one while step s is multiplied from the other, ONE barrier per step instead
     // of two (the phase clocks showed 640 of a step's 3 360 clocks at the second barrier: the waves wait for the slowest stager, then again for the slowest
     // multiplier; with one barrier a wave that has staged goes straight on to its MFMAs)
-    constexpr bool DB = !SPLIT;
-    __shared__ __attribute__((aligned(16))) __bf16 tiles_h[(DB ? 2 : 1) * BUFSZ];      // P sub-tiles [0, OS), Q sub-tiles [OS, OS + 2) (the bias reduction reuses it)
-    __shared__ __attribute__((aligned(16))) __bf16 tiles_l[SPLIT ? BUFSZ : 8];
-    int sbuf = 0, mbuf = 0;      // (DB) tile set the staging writes / the MFMAs read
-    auto Ph = [&](int t) { return tiles_h + (DB ? sbuf * BUFSZ : 0) + t * TSZ; };
-    auto Qh = [&](int t) { return tiles_h + (DB ? sbuf * BUFSZ : 0) + (OS + t) * TSZ; };
-    auto Pl = [&](int t) { return tiles_l + (SPLIT ? t * TSZ : 0); };
-    auto Ql = [&](int t) { return tiles_l + (SPLIT ? (OS + t) * TSZ : 0); };
+    constexpr bool DB = true;
+    extern __shared__ __attribute__((aligned(16))) char ggw_smem[];      // ggw_lds_bytes<SPLIT, OS>(): two tile sets of the hi plane, then (split arithmetic) two of the lo plane
+    __bf16* tiles_h = reinterpret_cast<__bf16*>(ggw_smem);               // P sub-tiles [0, OS), Q sub-tiles [OS, OS + 2) of each set (the bias reduction reuses the first one)
+    __bf16* tiles_l = tiles_h + (SPLIT ? 2 * BUFSZ : 0);
+    int sbuf = 0, mbuf = 0;      // tile set the staging writes / the MFMAs read
+    auto Ph = [&](int t) { return tiles_h + sbuf * BUFSZ + t * TSZ; };
+    auto Qh = [&](int t) { return tiles_h + sbuf * BUFSZ + (OS + t) * TSZ; };
+    auto Pl = [&](int t) { return tiles_l + sbuf * BUFSZ + t * TSZ; };
+    auto Ql = [&](int t) { return tiles_l + sbuf * BUFSZ + (OS + t) * TSZ; };
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wv / WCOLS, wc = wv % WCOLS;              // wave (wr, wc): rows [32 RI wr, +32 RI) of the o range, columns [32 CJ wc, +32 CJ) of the k range
     const int row0 = 32 * RI * wr, col0 = 32 * CJ * wc;
@@ -1011,11 +1013,12 @@ template <bool SPLIT, int OS, int NWV = 8 * OS> __global__ __launch_bounds__(64 
         }
     };
     const __bf16* Pt0 = tiles_h + (row0 >> 7) * TSZ; const __bf16* Qt0 = tiles_h + (OS + (col0 >> 7)) * TSZ;
-    const __bf16* Plt = Pl(row0 >> 7); const __bf16* Qlt = Ql(col0 >> 7);
+    const __bf16* Plt0 = tiles_l + (row0 >> 7) * TSZ; const __bf16* Qlt0 = tiles_l + (OS + (col0 >> 7)) * TSZ;
     const int my_unit = su[SU_UNIT + (row0 >> 7) * 2 + (col0 >> 7)];      // the 128x128 sub-tile this wave belongs to (-1: beyond the matrix edge)
     auto mfmas = [&]() {
         if (my_unit < 0) return;      // (wave-uniform)
-        const __bf16* Pt = Pt0 + (DB ? mbuf * BUFSZ : 0); const __bf16* Qt = Qt0 + (DB ? mbuf * BUFSZ : 0);
+        const __bf16* Pt = Pt0 + mbuf * BUFSZ; const __bf16* Qt = Qt0 + mbuf * BUFSZ;
+        const __bf16* Plt = Plt0 + mbuf * BUFSZ; const __bf16* Qlt = Qlt0 + mbuf * BUFSZ;
 #pragma unroll
         for (int ks = 0; ks < KW / 16; ++ks) {
             if constexpr (SPLIT) {      // Q fragments one column block at a time: 24 fragment registers live instead of 32
@@ -1145,7 +1148,7 @@ template <bool SPLIT, int OS, int NWV = 8 * OS> __global__ __launch_bounds__(64 
     // bias gradients: column sums of the staged P rows, into the slab of the k-tile-0 unit of each o sub-tile (the only ones the finalize reads)
     if (qcol == 0) {      // (uniform: super-units that hold k tile 0)
         float* red = reinterpret_cast<float*>(tiles_h);      // [PR rows][128 OS] floats
-        static_assert(sizeof(float) * PR * 128 * OS <= sizeof(__bf16) * (OS + 2) * TSZ, "bias reduction buffer fits the P and Q tiles");
+        static_assert(sizeof(float) * PR * 128 * OS <= sizeof(__bf16) * 2 * (OS + 2) * TSZ, "bias reduction buffer fits the two tile sets");
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < 8; ++e) red[rp * (128 * OS) + cp * 8 + e] = bsum[e];
@@ -1237,7 +1240,8 @@ int gen_create(mshgnn_plan* p, const mshgnn_desc* desc) {
         (rc = up((void**)&g->d_biases, gp.biases.data(), gp.biases.size() * sizeof(BiasDesc))) != 0) return rc;
     const int dec_lds = 16 * 8 * TW * 4;
     if ((rc = set_lds_attr(k_gdec_bwd<false>, dec_lds)) || (rc = set_lds_attr(k_gdec_bwd<true>, dec_lds)) ||
-        (rc = set_lds_attr(k_gstep<true, 8, 8>, 16 * P16::BLK))) return rc;
+        (rc = set_lds_attr(k_gstep<true, 8, 8>, 16 * P16::BLK)) || (rc = set_lds_attr(k_ggradw<true, 1>, ggw_lds_bytes(true, 1))) ||
+        (rc = set_lds_attr(k_ggradw<true, 2>, ggw_lds_bytes(true, 2)))) return rc;
     return MSHGNN_OK;
 }
 
@@ -1509,10 +1513,10 @@ int gen_backward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pi
 #ifdef GEN_TIMELINE
         a.tl = gen_tl("gradw");
 #endif
-        if (gp.split && gp.su_os == 2) hipLaunchKernelGGL((k_ggradw<true, 2>), dim3(grid), dim3(1024), 0, st, a);
-        else if (gp.split) hipLaunchKernelGGL((k_ggradw<true, 1>), dim3(grid), dim3(512), 0, st, a);
-        else if (gp.su_os == 2) hipLaunchKernelGGL((k_ggradw<false, 2>), dim3(grid), dim3(1024), 0, st, a);
-        else hipLaunchKernelGGL((k_ggradw<false, 1>), dim3(grid), dim3(512), 0, st, a);
+        if (gp.split && gp.su_os == 2) hipLaunchKernelGGL((k_ggradw<true, 2>), dim3(grid), dim3(1024), ggw_lds_bytes(true, 2), st, a);
+        else if (gp.split) hipLaunchKernelGGL((k_ggradw<true, 1>), dim3(grid), dim3(512), ggw_lds_bytes(true, 1), st, a);
+        else if (gp.su_os == 2) hipLaunchKernelGGL((k_ggradw<false, 2>), dim3(grid), dim3(1024), ggw_lds_bytes(false, 2), st, a);
+        else hipLaunchKernelGGL((k_ggradw<false, 1>), dim3(grid), dim3(512), ggw_lds_bytes(false, 1), st, a);
     }
     {
         GFinArgs fa{g->d_tables + gp.fin_off, reinterpret_cast<const float*>(ws + lay.slabs), reinterpret_cast<const float*>(ws + lay.dec_slabs), gparams,
