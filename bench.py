@@ -507,9 +507,15 @@ def roofline_of(stats, steps, B, dtype, e, config, L, hidden):
         b8d = float(e.info.bytes_in) * B + (4.0 * e.spec.flat_size() if dom["name"].startswith("gradw") else 0.0)
         achieved = b8d / avg_s / 1e9
         roof = {"bound": "hbm", "achieved": achieved, "peak": PEAK["hbm_GBs"], "unit": "GB/s", "frac": achieved / PEAK["hbm_GBs"], "traffic": None,
-                "algorithmic_bytes": b8d,
+                "algorithmic_bytes": b8d, "priced_by": "SURVEY 8(d) raw-input bytes",
                 "operands": {"bytes": bytes_w * B, "achieved": bytes_w * B / avg_s / 1e9, "frac": bytes_w * B / avg_s / 1e9 / PEAK["hbm_GBs"],
                              "note": "every operand of the launch counted once, stashed activations included (the kernel's own operand floor)"}}
+        if bytes_w * B > 20.0 * b8d:
+            # a workload whose raw inputs are tiny next to its hidden state (Solo-12 COM: T = 1, 36 input values against 16 x 128 hidden per layer): the
+            # raw-input figure says nothing about the launch (it read 0.0005 on that config) -- price it by its own operand stream, keep 8(d) beside it
+            roof["survey_8d"] = {"algorithmic_bytes": b8d, "achieved": achieved, "frac": achieved / PEAK["hbm_GBs"]}
+            roof["achieved"], roof["frac"], roof["algorithmic_bytes"] = roof["operands"]["achieved"], roof["operands"]["frac"], bytes_w * B
+            roof["priced_by"] = "the launch's own operand stream (raw inputs are < 5 % of it)"
     # HBM-side traffic per launch of that kernel, from the committed rocprofv3 PMC passes (separate FETCH_SIZE /
     # WRITE_SIZE runs of this same command, gfx950 corrections applied -- tools/summarize_pmc.py); null if absent
     try:
@@ -521,7 +527,8 @@ def roofline_of(stats, steps, B, dtype, e, config, L, hidden):
             key = dom["name"].rstrip("0123456789")
             if key in pm:
                 roof["traffic"] = pm[key]["hbm_bytes"] / per_step
-                roof["traffic_source"] = os.path.basename(files[-1])
+                meta = json.load(open(files[-1]))
+                roof["traffic_source"] = os.path.basename(files[-1]) + (f" (commit {meta['commit']})" if "commit" in meta else "")
     except Exception:  # noqa: BLE001
         pass
     roof["kernel"] = dom["name"]
@@ -555,6 +562,8 @@ def side_config(config, device, steps, warmup, min_time=0.25):
         entry["kernel_us"] = {s["name"]: round(s["total_ms"] / s["launches"] * 1e3, 2) for s in stats}
         r = roofline_of(stats, st, B, plan, w.e, config, L, hidden)
         entry["dominant"] = {k: r[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_us", "share_of_step")}
+        if "priced_by" in r:
+            entry["dominant"]["priced_by"] = r["priced_by"]
         if "operands" in r:      # (HBM-bound kernel: `frac` prices the raw-input bytes only -- SURVEY 8(d); its own operand stream is reported beside it)
             entry["dominant"]["operands_frac"] = r["operands"]["frac"]
         fl = (w.e.info.flops_fwd + w.e.info.flops_bwd) * B
@@ -672,6 +681,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config != "synth32":
         res["cpu_baseline"] = cpu_baseline(spec, args.cpu_batch)
         res["cpu_baseline_B32"] = cpu_baseline(spec, 32, budget_s=6.0, scan=False)     # the reference's own CPU-runnable case
+    cfile = os.path.join(ROOT, ".build_commit")      # (tools/profile_round.sh runs: the commit the snapshot was taken at)
+    if os.path.exists(cfile):
+        res["commit"] = open(cfile).read().strip()
     if rank == 0:
         print(json.dumps(res))
     if dist is not None:

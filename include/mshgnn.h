@@ -110,10 +110,7 @@ typedef struct mshgnn_info {
     int32_t n_gradw_workgroups;   /* split-K workgroups of the weight-gradient kernel                  */
     int32_t n_launches_fwd, n_launches_bwd;
     int32_t kernel_sets;          /* bit 0: fused stack kernels (bf16 plan), bit 1: slab stack kernels (two 4-wave workgroups per
-                                     CU; used for batches of >= 1.5 tiles per CU), bit 2: generic-width engine, bit 3: wide stack kernels
-                                     (one 4-wave workgroup per CU on 32-window tiles; opt-in, environment MSHGNN_WIDE=1 / 2), bit 4: slab2
-                                     stack kernels (the same generated MAC engine on 16-window tiles, two workgroups per CU, <= 18 nodes;
-                                     default for the inference forward, MSHGNN_SLAB2=1 / 2 for training too) -- what the plan allows                    */
+                                     CU; used for batches of >= 1.5 tiles per CU), bit 2: generic-width engine -- what the plan allows  */
     int64_t grad_split;           /* two-phase step (mshgnn_step_mse_phase): gradients [grad_split, n_flat) are final after
                                      phase 0, [0, grad_split) (the encoder's) after phase 1; -1: the plan has no split       */
 } mshgnn_info;

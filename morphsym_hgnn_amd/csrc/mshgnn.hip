@@ -137,12 +137,13 @@ template <typename T, bool ALIGNED, bool SERIES = false> __global__ __launch_bou
     u32x4 rawv[SERIES ? MB / BPP : 1][NIT];      // SERIES: the chunk being multiplied, kept until its window rows have been written
     // SERIES: first series row of this thread's window rows, the node row's first run
     int srow[SERIES ? MB / BPP : 1];
-    __shared__ unsigned long long rp_s[SERIES ? 16 : 1];      // SERIES: the column pointers of this node row's runs (a chunk takes its pieces from runs j, j + 1)
+    __shared__ unsigned long long rp_s[SERIES ? 16 : 1];      // SERIES: the column pointers of this node row's first 16 runs (a chunk takes its pieces from runs j, j + 1)
+    int rfirst = 0, rend = 0;
     if constexpr (SERIES) {
 #pragma unroll
         for (int mi = 0; mi < MB / BPP; ++mi) srow[mi] = (int)ser.starts[min(w0 + (mi * BPP + sub) * P::ROWS + r0, a.B - 1)];
         // one round trip for the row's run pointers instead of a dependent pointer load in front of every chunk's data loads
-        const int rfirst = ser.rows[2 * (ser.row0[t] + node)], rend = ser.rows[2 * (ser.row0[t] + node) + 1];
+        rfirst = ser.rows[2 * (ser.row0[t] + node)]; rend = ser.rows[2 * (ser.row0[t] + node) + 1];
         if (tid < 16) rp_s[tid] = rfirst + tid < rend ? ser.run_ptr[rfirst + tid] : 0ull;
         __syncthreads();
     }
@@ -153,7 +154,9 @@ template <typename T, bool ALIGNED, bool SERIES = false> __global__ __launch_bou
             // elements [k0, k0 + 8) of the row: n0 of them from run j at time offset off, the rest from run j + 1 at offset 0
             const int j = k0 / ser.T, off = k0 - j * ser.T, n0 = min(P::EPC, ser.T - off);
             const bool second = nvalid > n0;
-            const unsigned long long pa = nvalid > 0 ? rp_s[min(j, 15)] : 0ull, pb = second ? rp_s[min(j + 1, 15)] : 0ull;
+            // (runs past the 16th -- a node row of more than 16 T-long variables -- come from the global table: a dependent load, rare recipes only)
+            auto run_ptr_of = [&](int jj) -> unsigned long long { return jj < 16 ? rp_s[jj] : (rfirst + jj < rend ? ser.run_ptr[rfirst + jj] : 0ull); };
+            const unsigned long long pa = nvalid > 0 ? run_ptr_of(j) : 0ull, pb = second ? run_ptr_of(j + 1) : 0ull;
             const u32x4 ones = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};      // the constant-1 run (bf16 1.0)
 #pragma unroll
             for (int mi = 0; mi < MB / BPP; ++mi) {
@@ -2143,6 +2146,7 @@ extern "C" int mshgnn_plan_create(const mshgnn_desc* desc, mshgnn_plan** out) {
     const int lds = hp.n_blk * hp.blk_bytes;
     if (hp.d.dtype == MSHGNN_BF16X3) {
         p->use_fused = true;      // the split plan has only the fused 8-wave stack kernels (mshgnn_x3.hip)
+        { const char* et = getenv("MSHGNN_STEP_KERNEL"); p->use_step = !(et && atoi(et) == 0); }      // read per plan, as on the bf16 plan
         if ((rc = x3_set_attrs(p))) { mshgnn_plan_destroy(p); return rc; }
     } else if (hp.d.dtype == MSHGNN_F32) {
         if ((rc = set_lds_attr(k_layer_fwd<float>, lds)) || (rc = set_lds_attr(k_layer_bwd<float>, lds)) ||
@@ -2162,18 +2166,7 @@ extern "C" int mshgnn_plan_create(const mshgnn_desc* desc, mshgnn_plan** out) {
             if (p->use_slab && ((rc = set_lds_attr(slab_fwd_kernel(hp), flds)) || (rc = set_lds_attr(slab_bwd_kernel(hp), flds)) ||
                                 (rc = set_lds_attr(slab_step_kernel(hp), flds)))) { mshgnn_plan_destroy(p); return rc; }
             { const char* et = getenv("MSHGNN_STEP_KERNEL"); p->use_step = !(et && atoi(et) == 0); }      // one-call steps: forward + backward sweep in one launch
-            const char* ew = getenv("MSHGNN_WIDE");
-            // wide variant (mshgnn_wide.hip): opt-in.  Measured on A1-C2, 8192 windows: 81 us against the slab kernel's 65 (inference: 67 / 54) -- with 32 windows
-            // per CU one wave per SIMD exposes every memory and instruction-fetch latency of a kernel whose code runs once.
-            p->use_wide = hp.wide && ew && atoi(ew) >= 1;           // MSHGNN_WIDE=1: where the batch gives 3/4 of the CUs a tile
-            p->wide_force = ew && atoi(ew) == 2;                   // MSHGNN_WIDE=2: for every batch
-            if (p->use_wide && (rc = wide_set_attrs(p))) { mshgnn_plan_destroy(p); return rc; }
             { const char* eg = getenv("MSHGNN_STAGGER"); p->stagger = eg ? atoi(eg) : 0; }
-            const char* e2 = getenv("MSHGNN_SLAB2");
-            p->use_slab2 = hp.slab2 && e2 && atoi(e2) >= 1;        // slab2 variant: the engine-driven kernels on 16-window tiles, two workgroups per CU
-            p->slab2_force = e2 && atoi(e2) == 2;
-            p->slab2_infer = hp.slab2 && p->use_slab && !(e2 && atoi(e2) == 0);      // default: the inference forward (see slab2_for)
-            if ((p->use_slab2 || p->slab2_infer) && (rc = slab2_set_attrs(p))) { mshgnn_plan_destroy(p); return rc; }
         }
     }
     *out = p;
@@ -2257,7 +2250,7 @@ int run_finalize(const mshgnn_plan* p, const mshgnn_ws_layout& lay, char* ws, fl
     FinArgs a{p->d_tables + hp.fin_off, p->d_tables + hp.tgt_off, reinterpret_cast<const float*>(ws + lay.slabs),
               reinterpret_cast<const float*>(ws + lay.dec_slabs), gparams, hp.n_lanes, hp.n_parts, loss,
               1.0f / (float)((int64_t)B * d.type_nodes[d.out_type] * (is_ce ? 1 : d.out_channels)),
-              dec_done ? (int)(p->wide_for(B) ? (B + WD_ROWS - 1) / WD_ROWS : (B + TILE_ROWS - 1) / TILE_ROWS) : NWG_DEC};
+              dec_done ? (int)((B + TILE_ROWS - 1) / TILE_ROWS) : NWG_DEC};
     int f0 = 0, nf = hp.n_fin;
     if (gw_phase == 0) nf = hp.n_fin_ph0;
     if (gw_phase == 1) { f0 = hp.n_fin_ph0; nf = hp.n_fin - hp.n_fin_ph0; a.loss = nullptr; }
@@ -2353,23 +2346,17 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
                 a.inv_n = 1.0f / (float)((int64_t)B * a.n_out);
             }
             a.stamps = stamp_ptr("MSHGNN_STAMPS");
-            a.stagger = (p->slab2_for(tiles, a.training != 0) || p->slab_for(tiles)) && tiles > p->n_cu ? p->stagger : 0;
+            a.stagger = p->slab_for(tiles) && tiles > p->n_cu ? p->stagger : 0;
             // the tail's reduction scratch (one decoder slab per wave) must not touch the out-type nodes' blocks, which receive dX_L for the backward sweep: it sits
             // in the blocks in front of them, or (models whose out type comes first: the centroidal-momentum ones) in the blocks behind them
             const bool step_slab = p->slab_for(tiles);
             const size_t red_need = (size_t)((step_slab ? SL_THREADS : LAYER_THREADS) / 64) * DEC_SLAB_FLOATS * sizeof(float);
             const size_t lds_launch = (size_t)((step_slab ? hp.sl_blk : hp.fs_blk) + FS_EXTRA_BLK) * Prec<T>::BLK, red_back = (size_t)(a.node0 + a.n_out) * Prec<T>::BLK;
             const bool red_front_ok = (size_t)a.node0 * Prec<T>::BLK >= red_need, red_back_ok = red_back + red_need <= lds_launch;
-            const bool step = stack_step_done && p->use_step && (y_fused || labels_fused) && !p->wide_for(B) && !p->slab2_for(tiles, true) && (red_front_ok || red_back_ok);
+            const bool step = stack_step_done && p->use_step && (y_fused || labels_fused) && (red_front_ok || red_back_ok);
             if (step && !red_front_ok) a.red_off = (int)red_back;
             ProfScope ps(p, step ? hp.ks_stack_step : hp.ks_stack_fwd, st);
-            if (p->wide_for(B)) {
-                for (int l = 0; l < hp.L; ++l) a.prog_off[l] = hp.wd_fwd_off[l];
-                if (int rc = wide_launch(p, a, false, st)) return rc;
-            } else if (p->slab2_for(tiles, a.training != 0)) {
-                for (int l = 0; l < hp.L; ++l) a.prog_off[l] = hp.s2_fwd_off[l];
-                if (int rc = slab2_launch(p, a, false, st)) return rc;
-            } else if (p->slab_for(tiles)) {
+            if (p->slab_for(tiles)) {
                 for (int l = 0; l < hp.L; ++l) a.prog_off[l] = hp.sl_fwd_off[l];
                 if (step) {
                     for (int l = 0; l <= hp.L; ++l) a.dx_off[l] = lay.dx[l];
@@ -2452,15 +2439,9 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
             a.mask0_off = lay.dd[0];
             a.dbg = p->dbg;
             a.stamps = stamp_ptr("MSHGNN_STAMPS_BWD");
-            a.stagger = (p->slab2_for(tiles) || p->slab_for(tiles)) && tiles > p->n_cu ? p->stagger : 0;
+            a.stagger = p->slab_for(tiles) && tiles > p->n_cu ? p->stagger : 0;
             ProfScope ps(p, hp.ks_stack_bwd, st);
-            if (p->wide_for(B)) {
-                for (int l = 0; l < hp.L; ++l) a.prog_off[l] = hp.wd_bwd_off[l];
-                if (int rc = wide_launch(p, a, true, st)) return rc;
-            } else if (p->slab2_for(tiles)) {
-                for (int l = 0; l < hp.L; ++l) a.prog_off[l] = hp.s2_bwd_off[l];
-                if (int rc = slab2_launch(p, a, true, st)) return rc;
-            } else if (p->slab_for(tiles)) {
+            if (p->slab_for(tiles)) {
                 for (int l = 0; l < hp.L; ++l) a.prog_off[l] = hp.sl_bwd_off[l];
                 hipLaunchKernelGGL(slab_bwd_kernel(hp), dim3(tiles), dim3(SL_THREADS), (hp.sl_blk + FS_EXTRA_BLK) * Prec<T>::BLK, st, a);
             } else
@@ -3332,7 +3313,6 @@ static int step_series(const mshgnn_plan* p, const mshgnn_window_desc* d, const 
     int n_rows = 0;
     for (int t = 0; t < d->n_types; ++t) {
         if (d->type_nodes[t] != md.type_nodes[t] || d->type_width[t] != md.type_width[t]) return set_err(MSHGNN_EINVAL, "window recipe and plan disagree on a node type");
-        if (!x3 && (d->type_width[t] + d->history - 1) / d->history > 16) return set_err(MSHGNN_EUNSUPPORTED, "the fused gather holds at most 16 runs per node row (assemble, then mshgnn_step_mse)");
         if (x_out && (!x_out[t] || ((uintptr_t)x_out[t] & 15) || x_pitch[t] % epc || x_pitch[t] < (d->type_width[t] + epc - 1) / epc * epc)) return set_err(MSHGNN_EINVAL, "bad window buffer");
         n_rows += d->type_nodes[t];
     }

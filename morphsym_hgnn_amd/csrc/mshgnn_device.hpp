@@ -989,21 +989,12 @@ struct mshgnn_plan {
     bool use_slab = false;              // slab variant of the stack kernels (MSHGNN_SLAB=0 selects the 8-wave ones)
     bool slab_force = false; int n_cu = 256;
     bool use_step = false;              // one-call steps on the slab kernels: k_slab_step (MSHGNN_STEP_KERNEL=0: two launches)
-    bool use_wide = false, wide_force = false;   // wide variant (mshgnn_wide.hip: 32-window tiles, one 4-wave workgroup per CU; MSHGNN_WIDE=0 off, 2 always)
     int stagger = 0;                             // StackArgs.stagger of the two-workgroups-per-CU stack kernels (MSHGNN_STAGGER)
-    // slab2 variant (mshgnn_slab2.hip: the engine-driven kernels on 16-window tiles).  Default: the INFERENCE forward only (no stashes: 50.4 against the slab
-    // kernel's 53.9 us on A1-C2, 8192 windows); MSHGNN_SLAB2=1 also the training kernels (on par with the slab kernels), 2 for every batch size, 0 never
-    bool use_slab2 = false, slab2_force = false, slab2_infer = false;
-    bool slab2_for(int tiles, bool training = true) const {
-        return (use_slab2 || (slab2_infer && !training)) && (slab2_force || tiles >= 2 * n_cu * 3 / 4);
-    }
     int n_types = 0;
     mshgnn_gen_state* gen = nullptr;    // set: this plan runs on the generic-width engine (hidden != 128, many nodes, ...), hp is unused
     int dbg = 0, dbg_gw = 0;            // timing ablations (instrumented builds only: read once from MSHGNN_DBG / MSHGNN_DBG_GW at plan creation)
     // a slab workgroup has 4 waves for a whole tile: it pays off once there are enough tiles for two workgroups per CU
     bool slab_for(int tiles) const { return use_slab && (slab_force || tiles >= 2 * n_cu * 3 / 4); }
-    // a wide workgroup owns a CU: it pays off once the batch gives (nearly) every CU a 32-window tile
-    bool wide_for(int64_t B) const { return use_wide && (wide_force || (B + WD_ROWS - 1) / WD_ROWS >= n_cu * 3 / 4); }
 };
 
 // in-kernel stamp buffers of the instrumented builds (tools/stamps_*.py pass a device pointer through the environment)
@@ -1046,11 +1037,6 @@ inline int vec_bytes(const void* base, int64_t pitch_elems, int esize) {
 // k_finalize launch of a step (mshgnn.hip): fixed-order slab sums -> flat gradient (+ fused loss)
 int run_finalize(const mshgnn_plan* p, const mshgnn_ws_layout& lay, char* ws, float* gparams, int B, float* loss, bool is_ce, bool dec_done,
                  int gw_phase, hipStream_t st);
-// wide stack kernels of the bf16 plan (mshgnn_wide.hip)
-int wide_set_attrs(const mshgnn_plan* p);
-int wide_launch(const mshgnn_plan* p, const StackArgs& a, bool bwd, hipStream_t st);
-int slab2_set_attrs(const mshgnn_plan* p);
-int slab2_launch(const mshgnn_plan* p, const StackArgs& a, bool bwd, hipStream_t st);
 // split-bf16 parity plan (mshgnn_x3.hip)
 int x3_set_attrs(mshgnn_plan* p);
 int x3_forward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, float* out, char* ws, int64_t batch,

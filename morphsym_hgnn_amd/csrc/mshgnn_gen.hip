@@ -351,280 +351,6 @@ template <bool SPLIT, int MB, int NW> __global__ __launch_bounds__(64 * NW) void
 }
 
 // ------------------------------------------------------------------------------------------------------
-// k_gstep3 (bf16 arithmetic, hidden a multiple of 512): the same jobs on 128-window x 512-column workgroup tiles, MFMA block in asm
-// ------------------------------------------------------------------------------------------------------
-// 4 waves, one workgroup per CU, the whole register file: wave wq owns 128 windows x the 128 columns of pack tile ctg 4 + wq -- 256 accumulator registers that
-// stay in a[0:255] (mshgnn_gemm_block.inc, tools/gen_gemm_block.py).  Every weight byte feeds 8 row blocks (k_gstep: 4), every staged window fragment 8 MFMAs.
-// Per 128-wide K chunk: the chunk's A tile is written into one of two LDS buffers (from rows requested one chunk earlier into registers, or gathered here when
-// the chunk is an aggregate / raw input), the weight fragments of its first K step are requested, ONE barrier, the next chunk's rows are requested, then the asm
-// block: 256 MFMAs with the next K step's weight and window fragments in flight.  Same operands in the same order per accumulator as k_gstep: identical bits.
-#include "mshgnn_gemm_block.inc"
-template <int U, int N, typename F> __device__ __forceinline__ void wd_for_g3(F&& f) {
-    if constexpr (U < N) { f(std::integral_constant<int, U>{}); wd_for_g3<U + 1, N>(f); }
-}
-constexpr int G3_MB = 8, G3_ROWS = G3_MB * 16;
-constexpr int G3_MAXT = 16, G3_XI = 4, G3_META = G3_MAXT * (TERM_INTS + SRC_INTS + G3_XI) * 4;      // the job's term table, first sources and their resolved addresses, behind the two A tiles in LDS
-struct G3Chunk { const int* src; int n_src, kind, F, sign, kc, pack, nkc; int s_buf, s_node, s_mask, s_scale; bool pre; unsigned long long rbase, mbase; };      // pre: one plain source -> its rows can wait in registers
-__device__ __forceinline__ int g3_u(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ G3Chunk g3_chunk(const GArgs& a, const int* meta, int ti, int kc, int ct) {
-    const int* term = meta + ti * TERM_INTS;
-    const int* s0 = meta + G3_MAXT * TERM_INTS + ti * SRC_INTS;
-    G3Chunk q;
-    q.src = a.srcs + (size_t)g3_u(term[T_SRC0]) * SRC_INTS; q.n_src = g3_u(term[T_NSRC]); q.kind = g3_u(term[T_KIND]); q.F = g3_u(term[T_WIDTH]); q.sign = g3_u(term[T_SIGN]);
-    q.kc = kc; q.nkc = g3_u(term[T_NKC]);
-    q.pack = g3_u(term[T_PACK]) + kc * a.NCT + ct;
-    q.s_buf = g3_u(s0[S_BUF]); q.s_node = g3_u(s0[S_NODE]); q.s_mask = g3_u(s0[S_MASK]); q.s_scale = g3_u(s0[S_SCALE]);
-    q.pre = q.kind == 0 && q.n_src == 1;
-    const int* xi = meta + G3_MAXT * (TERM_INTS + SRC_INTS) + ti * G3_XI;      // row / relu-byte address of (source node, column 0 / column slice 0), resolved once per workgroup
-    q.rbase = ((unsigned long long)(unsigned)g3_u(xi[1]) << 32) | (unsigned)g3_u(xi[0]);
-    q.mbase = ((unsigned long long)(unsigned)g3_u(xi[3]) << 32) | (unsigned)g3_u(xi[2]);
-    return q;
-}
-// NS: 32-column slices per wave.  4: four waves per workgroup (one per SIMD, 512 registers each); 2: eight waves (two per SIMD: one wave's memory waits run
-// under the other's MFMAs), 128 accumulator + 128 vector registers each.
-template <int NS> __global__ __launch_bounds__(64 * 16 / NS) void k_gstep3(GArgs a) {
-    using P = P16;
-    constexpr int MB = G3_MB, NWV = 16 / NS, NT = 64 * NWV, RS = NT / 16, NR = G3_ROWS / RS, TUP = 8 * NS;      // RS: rows between a thread's staging rows; NR of them
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // two A tiles of MB blocks, then the job's term table
-    const int tid = threadIdx.x, lane = tid & 63, wq = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nctg = a.NCT / 4;
-    const int ct = (blockIdx.x % nctg) * 4 + wq * NS / 4, wv0 = (wq * NS) & 3, tile = (blockIdx.x / nctg) % a.tiles;      // the wave's slices wv0 .. wv0 + NS - 1 of pack tile ct
-    const int* job = a.jobs + (size_t)(a.job0 + blockIdx.x / (nctg * a.tiles)) * JOB_INTS;
-    const int w0 = tile * G3_ROWS, B = a.B, Hd = a.Hd;
-    const int flags = job[J_FLAGS];
-    const T16* wpack = reinterpret_cast<const T16*>(a.wpack);
-    const size_t wsl = (size_t)wv0 * P::NBV * 64 * 8;      // elements from a pack image to this wave's first slice
-
-#ifdef G3_STAMPS
-    long long tk0 = clock64(), tk_asm = 0, tk1 = 0, tk2 = 0, tk_stage = 0, tk_bar = 0;
-#endif
-    GAcc<NS> R;
-    {
-        float bv[TUP];
-#pragma unroll
-        for (int k = 0; k < TUP; ++k) bv[k] = 0.f;
-        if (flags & JF_BIAS) {
-            const float* bias = a.bias + ((size_t)job[J_BIAS] + ct) * TW;
-#pragma unroll
-            for (int cb = 0; cb < 2 * NS; ++cb) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(bias + (wv0 + (cb >> 1)) * 32 + c_feat(cb & 1, lane));
-                bv[4 * cb] = v[0]; bv[4 * cb + 1] = v[1]; bv[4 * cb + 2] = v[2]; bv[4 * cb + 3] = v[3];
-            }
-        }
-        g4_init(R, bv);
-    }
-    const int c = tid & 15, rr = tid >> 4;              // staging: thread = (rows rr + RS i, i < NR, 8-element chunk c)
-    const int ao0 = lds_chunk<T16>(0, lane & 15, (lane >> 4) * P::NAV);
-    const int nterms = job[J_NTERMS];
-    const int* term0 = a.terms + (size_t)job[J_TERM0] * TERM_INTS;
-    int* meta = reinterpret_cast<int*>(smem + 2 * MB * P::BLK);
-    if (tid < nterms * TERM_INTS) meta[tid] = term0[tid];
-    if (tid >= 128 && tid - 128 < nterms * SRC_INTS) {
-        const int ti = (tid - 128) / SRC_INTS, e = (tid - 128) % SRC_INTS;
-        meta[G3_MAXT * TERM_INTS + tid - 128] = a.srcs[(size_t)term0[ti * TERM_INTS + T_SRC0] * SRC_INTS + e];
-    }
-    if (tid >= 192 && tid - 192 < nterms) {      // (scalar loads of buf_off[] inside the chunk loop are a round trip each)
-        const int ti = tid - 192;
-        const int* sr = a.srcs + (size_t)term0[ti * TERM_INTS + T_SRC0] * SRC_INTS;
-        const bool act = term0[ti * TERM_INTS + T_KIND] == 0;
-        const unsigned long long rb = act ? (unsigned long long)(a.ws + a.buf_off[sr[S_BUF]]) + (size_t)sr[S_NODE] * B * Hd * sizeof(T16) : (unsigned long long)a.ws;
-        const unsigned long long mb = (act && sr[S_MASK] >= 0) ? (unsigned long long)(a.ws + a.buf_off[sr[S_MASK]]) + ((((size_t)sr[S_NODE] * (Hd >> 5)) * ((B + 15) >> 4)) << 6) : (unsigned long long)a.ws;
-        int* xi = meta + G3_MAXT * (TERM_INTS + SRC_INTS) + ti * G3_XI;
-        xi[0] = (int)(unsigned)rb; xi[1] = (int)(unsigned)(rb >> 32); xi[2] = (int)(unsigned)mb; xi[3] = (int)(unsigned)(mb >> 32);
-    }
-    __syncthreads();
-
-    G4Rows<NS> rowsv; G4Mask<NS> rmaskv;      // the staged chunk's rows (NR x 16 bytes) and relu bytes: requested by the MFMA block of the chunk before (first chunk: below)
-    // this thread's part of a row / relu-byte address (full tiles: row rr + RS i < B); the chunk's part is wave-uniform
-    const int tilesB = (B + 15) >> 4;
-    auto toff = [&](int i) { const int w = w0 + rr + RS * i; return (unsigned)(((size_t)w * Hd + c * 8) * sizeof(T16)); };
-    auto toffm = [&](int i) { const int w = w0 + rr + RS * i; return (unsigned)((((size_t)(c >> 2) * tilesB + (w >> 4)) << 6) + ((c & 3) << 4) + (w & 15)); };
-    // row / relu-byte base of a chunk (a chunk that is gathered at staging time, or has no mask, reads the start of the workspace instead)
-    auto row_base = [&](const G3Chunk& q) { return q.pre ? reinterpret_cast<const char*>(q.rbase) + (size_t)q.kc * TW * sizeof(T16) : a.ws; };
-    auto mask_base = [&](const G3Chunk& q) { return (q.pre && q.s_mask >= 0) ? reinterpret_cast<const char*>(q.mbase) + (((size_t)q.kc * 4 * tilesB) << 6) : a.ws; };
-    auto request = [&](const G3Chunk& q) {      // (first chunk only)
-        const char* base = row_base(q); const char* mbase = mask_base(q);
-#pragma unroll
-        for (int i = 0; i < NR; ++i) {
-            const f32x4 v = __builtin_bit_cast(f32x4, *reinterpret_cast<const u32x4*>(base + toff(i)));      // (whole-vector cast: hipcc 7.2 miscompiles a bit_cast of one element)
-            rowsv.v[4 * i] = v[0]; rowsv.v[4 * i + 1] = v[1]; rowsv.v[4 * i + 2] = v[2]; rowsv.v[4 * i + 3] = v[3];
-            rmaskv.v[i] = *reinterpret_cast<const uint8_t*>(mbase + toffm(i));
-        }
-    };
-    auto stage = [&](const G3Chunk& q, int buf) {
-        char* dst = smem + buf * (MB * P::BLK);
-        if (q.pre) {
-            const float sc = __int_as_float(q.s_scale);
-            const bool msk = q.s_mask >= 0;
-#pragma unroll
-            for (int i = 0; i < NR; ++i) {
-                const int grow = rr + RS * i;
-                const u32x4 rv = __builtin_bit_cast(u32x4, f32x4{rowsv.v[4 * i], rowsv.v[4 * i + 1], rowsv.v[4 * i + 2], rowsv.v[4 * i + 3]});
-                u32x4 v = chunk_mask_bits<T16>(rv, msk ? (rmaskv.v[i] & 0xffu) : 0xffu);
-                if (sc != 1.0f) { float s8[8] = {0, 0, 0, 0, 0, 0, 0, 0}; acc8(s8, v, sc); v = pack_oct(f32x4{s8[0], s8[1], s8[2], s8[3]}, f32x4{s8[4], s8[5], s8[6], s8[7]}); }
-                *reinterpret_cast<u32x4*>(dst + lds_chunk<T16>(grow >> 4, grow & 15, c)) = v;
-            }
-        } else {
-            constexpr int NB = NR < 4 ? NR : 4;
-#pragma unroll
-            for (int i0 = 0; i0 < NR; i0 += NB) {
-                float s8[NB][8];
-                if (q.kind == 0) {
-                    // aggregate of several sources (fp32 sum in source order, as gather8): the rows of a source are in flight together and the next source's are
-                    // requested before this one's are added (the base node of the 32-limb robot sums 32 sources)
-#pragma unroll
-                    for (int i = 0; i < NB; ++i)
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) s8[i][e] = 0.f;
-                    const int col = q.kc * TW + c * 8;
-                    u32x4 cv[NB], nv[NB]; unsigned cm[NB], nm[NB];
-                    auto fetchn = [&](const int* sp, u32x4 (&v)[NB], unsigned (&m)[NB]) {
-                        const T16* bp = reinterpret_cast<const T16*>(a.ws + a.buf_off[sp[S_BUF]]);
-                        const bool mk = sp[S_MASK] >= 0;
-                        const uint8_t* mp = reinterpret_cast<const uint8_t*>(a.ws + (mk ? a.buf_off[sp[S_MASK]] : 0));
-#pragma unroll
-                        for (int i = 0; i < NB; ++i) {
-                            const int w = w0 + rr + RS * (i0 + i);
-                            v[i] = *reinterpret_cast<const u32x4*>(bp + g_row<false>(w, sp[S_NODE], B, Hd) + col);
-                            const unsigned byte = mp[mk ? g_relu_byte(sp[S_NODE], B, Hd, w, col) : (size_t)0];
-                            m[i] = mk ? byte : 0xffu;
-                        }
-                    };
-                    fetchn(q.src, cv, cm);
-                    for (int k = 0; k < q.n_src; ++k) {
-                        const int* sp = q.src + (size_t)k * SRC_INTS;
-                        if (k + 1 < q.n_src) fetchn(sp + SRC_INTS, nv, nm);
-                        const float sc = __int_as_float(sp[S_SCALE]);
-#pragma unroll
-                        for (int i = 0; i < NB; ++i) { acc8(s8[i], chunk_mask_bits<T16>(cv[i], cm[i]), sc); cv[i] = nv[i]; cm[i] = nm[i]; }
-                    }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < NB; ++i)
-                        raw8<false>(a, q.src[S_BUF], q.src[S_NODE], w0 + rr + RS * (i0 + i), q.kc * TW + c * 8, q.F, a.signs + q.sign + q.kc * TW + c * 8, s8[i]);
-                }
-#pragma unroll
-                for (int i = 0; i < NB; ++i) {
-                    const int grow = rr + RS * (i0 + i);
-                    *reinterpret_cast<u32x4*>(dst + lds_chunk<T16>(grow >> 4, grow & 15, c)) = pack_oct(f32x4{s8[i][0], s8[i][1], s8[i][2], s8[i][3]}, f32x4{s8[i][4], s8[i][5], s8[i][6], s8[i][7]});
-                }
-            }
-        }
-    };
-
-#ifdef G3_STAMPS
-    tk1 = clock64();
-#endif
-    int ti = 0, kc = 0, it = 0;
-    G3Chunk cur = g3_chunk(a, meta, 0, 0, ct);
-    request(cur);
-    // the weight fragments of a chunk's first K step: requested here for the first chunk, by the MFMA block of the chunk before for every other one
-    G4W<NS> w0f;
-    {
-        const u32x4* wb = reinterpret_cast<const u32x4*>(wpack + (size_t)cur.pack * H * H + wsl) + lane;
-#pragma unroll
-        for (int cb = 0; cb < 2 * NS; ++cb) {
-            const f32x4 v = __builtin_bit_cast(f32x4, wb[(size_t)((cb >> 1) * P::NBV + 4 * (cb & 1)) * 64]);
-            w0f.v[4 * cb] = v[0]; w0f.v[4 * cb + 1] = v[1]; w0f.v[4 * cb + 2] = v[2]; w0f.v[4 * cb + 3] = v[3];
-        }
-    }
-    while (true) {
-#ifdef G3_STAMPS
-        const long long ts0 = clock64();
-#endif
-        stage(cur, it & 1);
-#ifdef G3_STAMPS
-        const long long ts1 = clock64(); tk_stage += ts1 - ts0;
-#endif
-        int nti = ti, nkc = kc + 1;
-        if (nkc >= cur.nkc) { nti = ti + 1; nkc = 0; }
-        const bool more = nti < nterms;
-        G3Chunk nxt = cur;
-        if (more) nxt = g3_chunk(a, meta, nti, nkc, ct);
-        __syncthreads();      // this chunk's A tile is complete; every wave is past the block of the chunk before (the other buffer is free for the next stage)
-#ifdef G3_STAMPS
-        const long long ta = clock64(); tk_bar += ta - ts1;
-#endif
-        g4_chunk(R, w0f, rowsv, rmaskv, wpack + (size_t)cur.pack * H * H + wsl, wpack + (size_t)nxt.pack * H * H + wsl, row_base(nxt), mask_base(nxt), (unsigned)(RS * Hd * sizeof(T16)),
-                 (int)toff(0), (int)toffm(0), (unsigned)((it & 1) * (MB * P::BLK)), ao0, lane * 16);
-#ifdef G3_STAMPS
-        tk_asm += clock64() - ta;
-#endif
-        if (!more) break;
-        cur = nxt; ti = nti; kc = nkc; ++it;
-    }
-#ifdef G3_STAMPS
-    tk2 = clock64();
-#endif
-    // epilogue, two row blocks at a time: every gate / residual / relu-byte load of the (row block, slice) pieces is requested before the first is used
-    // (gstep_epilogue's arithmetic; one memory round trip per pair of row blocks instead of one per piece)
-    {
-        const int oflags = flags;
-        T16* outp = reinterpret_cast<T16*>(a.ws + a.buf_off[job[J_OUT_BUF]]);
-        const int onode = job[J_OUT_NODE];
-        const T16* gsrc = (oflags & JF_GATE_POS) ? reinterpret_cast<const T16*>(a.ws + a.buf_off[job[J_GATE_BUF]]) : nullptr;
-        const uint8_t* gbits = (oflags & JF_GATE_BITS) ? reinterpret_cast<const uint8_t*>(a.ws + a.buf_off[job[J_GATE_BUF]]) : nullptr;
-        const T16* rsrc = (oflags & JF_RES) ? reinterpret_cast<const T16*>(a.ws + a.buf_off[job[J_RES_BUF]]) : nullptr;
-        uint8_t* bout = ((oflags & JF_RELU) && (oflags & JF_BITS_OUT) && a.training) ? reinterpret_cast<uint8_t*>(a.ws + a.buf_off[job[J_BITS_BUF]]) : nullptr;
-        const int gnode = job[J_GATE_NODE], rnode = job[J_RES_NODE];
-        wd_for_g3<0, MB / 2>([&](auto mc) {
-            constexpr int M2 = decltype(mc)::value;
-            float o[2][TUP];
-            g4_read<2 * M2>(R, o[0]);
-            g4_read<2 * M2 + 1>(R, o[1]);
-            u32x4 gv[2][NS], rv[2][NS]; unsigned xb[2][NS];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int wb = w0 + (2 * M2 + h) * P::ROWS, wc = min(wb + c_win(lane), B - 1);
-#pragma unroll
-                for (int sl = 0; sl < NS; ++sl) {
-                    const int col = ct * TW + (wv0 + sl) * 32 + c_oct(lane);
-                    gv[h][sl] = u32x4{0, 0, 0, 0}; rv[h][sl] = u32x4{0, 0, 0, 0}; xb[h][sl] = 0xffu;
-                    if (gsrc) gv[h][sl] = *reinterpret_cast<const u32x4*>(gsrc + g_row<false>(wc, gnode, B, Hd) + col);
-                    if (rsrc) rv[h][sl] = *reinterpret_cast<const u32x4*>(rsrc + g_row<false>(wc, rnode, B, Hd) + col);
-                    if (gbits) xb[h][sl] = gbits[g_relu_byte(gnode, B, Hd, wc, col)];
-                }
-            }
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int wb = w0 + (2 * M2 + h) * P::ROWS, w = wb + c_win(lane);
-                if (wb >= B) continue;
-#pragma unroll
-                for (int sl = 0; sl < NS; ++sl) {
-                    const int col = ct * TW + (wv0 + sl) * 32 + c_oct(lane);
-                    P::Acc ac;
-                    ac.c[0] = f32x4{o[h][8 * sl], o[h][8 * sl + 1], o[h][8 * sl + 2], o[h][8 * sl + 3]};
-                    ac.c[1] = f32x4{o[h][8 * sl + 4], o[h][8 * sl + 5], o[h][8 * sl + 6], o[h][8 * sl + 7]};
-                    if (oflags & JF_GATE_POS) {
-                        f32x4 g0, g1; unpack_oct(gv[h][sl], g0, g1);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) { ac.c[0][j] = g0[j] > 0.f ? ac.c[0][j] : 0.f; ac.c[1][j] = g1[j] > 0.f ? ac.c[1][j] : 0.f; }
-                    }
-                    if (oflags & JF_RELU) {
-                        const unsigned bits = relu_with_bits<T16>(ac);
-                        if (bout) bout[g_relu_byte(onode, B, Hd, w, col)] = (uint8_t)bits;
-                    }
-                    f32x4 y0 = ac.c[0], y1 = ac.c[1];
-                    if (oflags & JF_RES) { f32x4 r0v, r1v; unpack_oct(rv[h][sl], r0v, r1v); y0 += r0v; y1 += r1v; }
-                    if (oflags & JF_GATE_BITS) {
-                        const unsigned x = xb[h][sl];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) { y0[j] = ((x >> j) & 1u) ? y0[j] : 0.f; y1[j] = ((x >> (4 + j)) & 1u) ? y1[j] : 0.f; }
-                    }
-                    if (w < B) store_oct(outp + g_row<false>(w, onode, B, Hd) + col, y0, y1);
-                }
-            }
-        });
-    }
-#ifdef G3_STAMPS
-    if (a.slabs && tid == 0) {
-        long long* st = reinterpret_cast<long long*>(a.slabs) + (size_t)blockIdx.x * 8;
-        st[0] = tk1 - tk0; st[1] = tk2 - tk1; st[2] = tk_asm; st[3] = clock64() - tk2; st[4] = it + 1; st[5] = clock64() - tk0; st[6] = tk_stage; st[7] = tk_bar;
-    }
-#endif
-}
-
-// ------------------------------------------------------------------------------------------------------
 // decoder forward / backward on the rows of the out type (hgnn_c2.py:176-189) + fused wrapper MSE / cross entropy
 // thread = (row, 8-column chunk c of 16), looping over the Hd / 128 column groups
 // ------------------------------------------------------------------------------------------------------
@@ -1403,7 +1129,7 @@ static void g_launch_jobs(const mshgnn_plan* p, const Launch& ln, GArgs a, hipSt
     // activations fewer times (hidden / (32 NW) column groups per row of jobs): measured at h=512, B=1024: layer_fwd bf16 515 / 354 / 296 us at
     // 4 / 8 / 16 waves, split 870 / 799 / 1012 us (16 waves: 128 VGPRs, spills); 128-window tiles lose (fewer resident workgroups hide less
     // of the staging latency: 495 us at 8 waves, 389 us at 16 waves with 56 B of scratch)
-    const int mode = g_tile_blocks(a.B, gp.split);      // 0: 4 waves; 1: 8 waves, 128 windows; 2: 8 waves; 3: 16 waves; 4 / 5: k_gstep3 with 4 / 8 waves; 6: k_gstep4 (bf16, hidden % 512 == 0; the default from 256 windows)
+    const int mode = g_tile_blocks(a.B, gp.split);      // 0: 4 waves; 1: 8 waves, 128 windows; 2: 8 waves; 3: 16 waves; 6: k_gstep4 (bf16, hidden % 512 == 0; the default from 256 windows)
     if (mode == 6 && !gp.split && gp.NCT % 4 == 0) {      // k_gstep4: 16 waves on 128-window tiles (hidden a multiple of 512)
         a.tiles = (a.B + 127) / 128;
         const unsigned grid4 = (unsigned)ln.n_jobs * a.tiles * (a.NCT / 4);
@@ -1419,20 +1145,9 @@ static void g_launch_jobs(const mshgnn_plan* p, const Launch& ln, GArgs a, hipSt
         hipLaunchKernelGGL((k_gstep4<true, 4, 16>), dim3(grid4), dim3(1024), 2 * 4 * P16::BLK, st, a);
         return;
     }
-    if ((mode == 4 || mode == 5) && !gp.split && gp.NCT % 4 == 0 && a.B % G3_ROWS == 0) {      // (full 128-window tiles: the block requests the next chunk's rows without a row clamp)
-        a.tiles = a.B / G3_ROWS;
-        const unsigned grid3 = (unsigned)ln.n_jobs * a.tiles * (a.NCT / 4);
-#ifdef G3_STAMPS
-        { const char* e = getenv("MSHGNN_G3_STAMPS"); a.slabs = e ? reinterpret_cast<float*>(strtoull(e, nullptr, 16)) : nullptr; }
-#endif
-        ProfScope ps(p, ln.ks, st);
-        if (mode == 4) hipLaunchKernelGGL(k_gstep3<4>, dim3(grid3), dim3(256), 2 * G3_MB * P16::BLK + G3_META, st, a);
-        else hipLaunchKernelGGL(k_gstep3<2>, dim3(grid3), dim3(512), 2 * G3_MB * P16::BLK + G3_META, st, a);
-        return;
-    }
     int nw = 4;
     if ((mode == 1 || mode == 2) && gp.NCT % 2 == 0) nw = 8;
-    if (mode == 3 || mode >= 4) nw = gp.NCT % 4 == 0 ? 16 : (gp.NCT % 2 == 0 ? 8 : 4);
+    if (mode >= 3) nw = gp.NCT % 4 == 0 ? 16 : (gp.NCT % 2 == 0 ? 8 : 4);
     const int mb = (nw == 8 && mode == 1) ? 8 : 4;
     a.tiles = (a.B + mb * 16 - 1) / (mb * 16);
     const unsigned grid = (unsigned)ln.n_jobs * a.tiles * (a.NCT / (nw / 4));

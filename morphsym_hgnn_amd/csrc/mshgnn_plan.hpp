@@ -102,16 +102,6 @@ static_assert(FH_NEXT + 8 + 20 <= FH_SIZE && MSHGNN_MAX_TYPES <= 4, "header: nex
 constexpr int SL_HA = 12, SL_HB = 6, SL_HB_MAX = 8, SL_THREADS = 256;
 constexpr int SL_CBA = 2, SL_CBB = 3;    // bits of MAC count per slot and segment in group A / B programs (12 x 2, 6..8 x 3 bits)
 enum { FF_RESIDUAL = 1, FF_ENC_MASK = 2, FF_SCR_ALIAS = 4 };
-// WIDE variant of the stack kernels (mshgnn_wide.hip): ONE 4-wave workgroup per CU owns a tile of 32 windows (two 16-window halves, node block =
-// 2 x 4 KB) and one wave per SIMD has the whole 512-entry register file: wave wn keeps the accumulators of its 32 columns of EVERY node for both
-// halves, so a layer is a single group (no packed results waiting in registers) and each weight fragment a wave pulls from L2 is multiplied into 32
-// windows instead of 16 -- half the fragment traffic, program interpretation, header and barrier cost per window.  Same MFMA, same accumulation
-// order per (window, feature): bit-identical to the slab / 8-wave kernels.  Program of a layer = header (FH_SIZE ints, per-node arrays by node) +
-// WD_PROG_LEN ints (emit_wide below).
-constexpr int WD_ROWS = 32, WD_MAXN = 20, WD_PROG_LEN = 192, WD_THREADS = 256;
-constexpr int S2_MAXN = 18;      // slab2 geometry of the same kernels (16-window tiles, two workgroups per CU): 16 accumulator slots in a[0:127] + 2 in v[112:127]
-// the engines' jump tables (tools/gen_wide_engine.py): MAC body of (slot, weight buffer) = buffer * WD_MAXN + slot; with NBUF weight buffers the segment
-// switches are  NBUF * WD_MAXN + b (wait + request a fragment into buffer b), + NBUF (wait), + NBUF + 1 (last segment: wait for everything), + NBUF + 2 (exit)
 
 // buffer ids used by weight-gradient items
 enum { BUF_X = 0, BUF_DX = 17, BUF_DH = 34, BUF_HB = 50, BUF_T1 = 66, BUF_DU = 82, BUF_IN = 98, BUF_MASK = 102, BUF_COUNT = 118 };
@@ -173,10 +163,6 @@ struct HostPlan {
     bool slab = false;                            // slab variant available (two 4-wave workgroups per CU fit, groups fit)
     int sl_fwd_off[MAX_L]{}, sl_bwd_off[MAX_L]{}, sl_ta = -1, sl_hb = SL_HB, sl_blk = 0;      // sl_hb: group-B slots (6 / 8); sl_blk: LDS blocks of a slab workgroup
     bool sl_alias = false;                        // base_transform scratch aliases group-A node blocks
-    bool wide = false;                            // wide variant available (32-window tiles, one 4-wave workgroup per CU)
-    int wd_fwd_off[MAX_L]{}, wd_bwd_off[MAX_L]{};
-    bool slab2 = false;                           // slab2 variant available (engine-driven kernels on 16-window tiles, two 4-wave workgroups per CU)
-    int s2_fwd_off[MAX_L]{}, s2_bwd_off[MAX_L]{};
     int fs_blk = 0;                               // LDS blocks of the fused kernels (NN + base_transform scratch)
     bool x3_alias = false;                        // split plan: the base_transform scratch aliases the last n_mlp node blocks
     int ks_stack_fwd = -1, ks_stack_bwd = -1;
@@ -611,62 +597,6 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
             }
             return h;
         };
-        // wide programs (mshgnn_wide.hip, tools/gen_wide_engine.py): every node is its own accumulator slot (slot = node); a layer's MAC phase is a
-        // stream of 16-bit entries, one per executed body of the engine's jump table: {index of the NEXT body : 7, LDS block of the MAC after next : 5}.
-        // Bodies: MAC (slot, weight buffer = segment % 3), segment switches (wait for the segment's fragment, request the fragment of the segment
-        // after next), exit.  Table after the header: [64 dwords = 128 entries][pack id of segment s][dword 0: block of MAC 0 | block of MAC 1 << 8 |
-        // segments << 16 | first body << 24].
-        p.wide = !p.split && p.NN <= WD_MAXN && (int64_t)p.NN * 2 * p.blk_bytes <= LDS_LIMIT;
-        p.slab2 = !p.split && p.NN <= S2_MAXN && 2 * (int64_t)p.NN * p.blk_bytes <= LDS_LIMIT;
-        const int bias_zero = add_bias(p, {});      // a row of zeros: the accumulators of dead nodes start there (no select in the kernel)
-        auto emit_wide = [&](const std::vector<Seg>& segs_in, int hdr_src, int nbuf, bool& avail, int l, bool bwd) {
-            const int h = (int)T.size(); T.resize(T.size() + FH_SIZE, 0);
-            for (int i = 0; i < FH_SIZE; ++i) T[h + i] = T[hdr_src + i];
-            for (int i = 0; i < 32; ++i) T[h + FH_NEXT + i] = 0;
-            for (int n = 0; n < p.NN && n < WD_MAXN; ++n) {
-                const int t = p.node_type[n];
-                if (!bwd) { if (!p.live[l][t]) T[h + FH_BIAS + n] = bias_zero; T[h + FH_NEXT + 8 + n] = t; }
-                else if (l > 0) {
-                    const int kind = !p.live[l - 1][t] ? NK_DEAD : ((has_mlp && t == d.mlp_type) ? NK_MLP : NK_RELU);
-                    T[h + FH_NEXT + n] = kind | ((residual && p.live[l - 1][t] && p.need_dx[l - 1][t]) ? 4 : 0);
-                }
-            }
-            if (!bwd)      // forward: bias row of every node type in this layer and in the next one (the kernel keeps a layer's rows in LDS), type of node n
-                for (int t = 0; t < 4; ++t) {
-                    T[h + FH_NEXT + t] = (t < NT && p.live[l][t]) ? p.bias_layer[l * NT + t] : bias_zero;
-                    T[h + FH_NEXT + 4 + t] = (t < NT && l + 1 < L && p.live[l + 1][t]) ? p.bias_layer[(l + 1) * NT + t] : bias_zero;
-                }
-            const int idx_issue = nbuf * WD_MAXN, idx_noissue = idx_issue + nbuf, idx_last = idx_noissue + 1, idx_exit = idx_last + 1;
-            std::vector<Seg> segs;
-            for (const Seg& sg : segs_in) if (!sg.macs.empty()) segs.push_back(sg);
-            const int nseg = (int)segs.size();
-            std::vector<int> body, mac_blk, mac_of_body;      // table index of every executed body; block of every MAC; MAC number of a body (-1: switch)
-            for (int si = 0; si < nseg; ++si) {
-                // the switch in front of segment si waits for its fragment and requests the fragment of segment si + nbuf - 1 into the buffer that segment
-                // will use (the one segment si - 1 has just finished with)
-                const int ahead = si + nbuf - 1;
-                body.push_back(ahead < nseg ? idx_issue + ahead % nbuf : (si + 1 < nseg ? idx_noissue : idx_last));
-                mac_of_body.push_back(-1);
-                for (int u = 0; u < WD_MAXN; ++u)
-                    for (auto& m : segs[si].macs) if (m.first == u) {
-                        body.push_back((si % nbuf) * WD_MAXN + u); mac_of_body.push_back((int)mac_blk.size()); mac_blk.push_back(m.second);
-                    }
-                for (auto& m : segs[si].macs) if (m.first < 0 || m.first >= WD_MAXN || m.second < 0 || m.second >= 32) avail = false;
-            }
-            if (nseg < 1 || nseg > 64 || body.size() > 127 || mac_blk.empty()) { avail = false; return h; }
-            std::vector<int> ent(128, 0);
-            for (size_t k = 0; k < body.size(); ++k) {
-                const int next = k + 1 < body.size() ? body[k + 1] : idx_exit;
-                const int m = mac_of_body[k];
-                const int blk2 = (m >= 0 && m + 2 < (int)mac_blk.size()) ? mac_blk[m + 2] : 0;
-                ent[k] = next | (blk2 << 7);
-            }
-            for (int i = 0; i < 64; ++i) T.push_back(ent[2 * i] | (ent[2 * i + 1] << 16));
-            for (int i = 0; i < 64; ++i) T.push_back(i < nseg ? segs[i].pack : 0);
-            T.push_back(mac_blk[0] | ((mac_blk.size() > 1 ? mac_blk[1] : 0) << 8) | (nseg << 16) | (body[0] << 24));
-            for (int i = 1; i < 64; ++i) T.push_back(0);
-            return h;
-        };
         for (int l = 0; l < L && p.fused; ++l) {
             const bool mlp_live = has_mlp && p.live[l][d.mlp_type];
             // forward
@@ -698,8 +628,6 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
                 T[fh + FH_NSEG] = (int)segs.size();
                 emit_fused(segs);
                 if (p.fused && p.slab) p.sl_fwd_off[l] = emit_slab(segs, fh);
-                if (p.fused && p.wide) p.wd_fwd_off[l] = emit_wide(segs, fh, 3, p.wide, l, false);
-                if (p.fused && p.slab2) p.s2_fwd_off[l] = emit_wide(segs, fh, 2, p.slab2, l, false);
             }
             if (!p.fused) break;
             // backward
@@ -735,11 +663,9 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
                 T[bh2 + FH_NSEG] = (int)segs.size();
                 emit_fused(segs);
                 if (p.fused && p.slab) p.sl_bwd_off[l] = emit_slab(segs, bh2);
-                if (p.fused && p.wide) p.wd_bwd_off[l] = emit_wide(segs, bh2, 3, p.wide, l, true);
-                if (p.fused && p.slab2) p.s2_bwd_off[l] = emit_wide(segs, bh2, 2, p.slab2, l, true);
             }
         }
-        if (!p.fused) p.slab = p.wide = p.slab2 = false;
+        if (!p.fused) p.slab = false;
     }
     if (p.split && !p.fused) return fail(p, "the split-bf16 parity plan is not supported for this topology (a layer's MAC program exceeds the "
                                             "stack kernels' program registers); use MSHGNN_F32");
@@ -1071,7 +997,7 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
     p.info.bytes_in = bytes; p.info.n_gradw_workgroups = p.n_wg_gradw;
     p.info.n_launches_fwd = 3 + L; p.info.n_launches_bwd = 3 + L;
     p.info.grad_split = p.grad_split;
-    p.info.kernel_sets = (p.fused ? 1 : 0) | (p.slab ? 2 : 0) | (p.wide ? 8 : 0) | (p.slab2 ? 16 : 0);
+    p.info.kernel_sets = (p.fused ? 1 : 0) | (p.slab ? 2 : 0);
 
     // ---- per-kernel work table (launch order of one fwd+bwd step) -----------------------------------------
     {

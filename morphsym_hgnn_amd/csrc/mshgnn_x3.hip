@@ -1219,8 +1219,7 @@ int x3_forward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitc
         a.stamps = stamp_ptr("MSHGNN_STAMPS");
         // one-call step: the backward sweep in the same launch (the tail's reduction scratch, one decoder slab per wave at the start of LDS, must end below the
         // out-type nodes' blocks)
-        static const bool step_off = getenv("MSHGNN_STEP_KERNEL") && atoi(getenv("MSHGNN_STEP_KERNEL")) == 0;
-        const bool step = stack_step_done && y_fused && !step_off && (size_t)a.node0 * P16::BLK >= (size_t)(LAYER_THREADS / 64) * DEC_SLAB_FLOATS * sizeof(float);
+        const bool step = stack_step_done && y_fused && p->use_step && (size_t)a.node0 * P16::BLK >= (size_t)(LAYER_THREADS / 64) * DEC_SLAB_FLOATS * sizeof(float);
         ProfScope ps(p, step ? hp.ks_stack_step : hp.ks_stack_fwd, st);
         if (step) {
             a.mask0_off = lay.dd[0];

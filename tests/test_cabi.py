@@ -35,16 +35,15 @@ def test_plan_compiler_work_counts():
 
 def test_plan_compiler_kernel_sets():
     """Which stack-kernel variants a plan allows: fp32 plans use the per-layer kernels; bf16 plans the fused stack kernels, and the
-    slab variant (two 4-wave workgroups of <= 80 KB LDS per CU, <= 12 + 6 accumulator slots) and the wide variant (bit 3: one 4-wave workgroup
-    per CU, 32-window tiles, <= 20 nodes) where the topology fits."""
+    slab variant (two 4-wave workgroups of <= 80 KB LDS per CU, <= 12 + 6 / 8 accumulator slots) where the topology fits."""
     c2 = helpers.make_spec("c2", "a1-c2", "a1-c2", 128, 3)
     assert engine.compile_plan_host(c2, "f32").kernel_sets == 0
-    assert engine.compile_plan_host(c2, "bf16").kernel_sets == 27       # fused | slab | wide | slab2
-    assert engine.compile_plan_host(helpers.make_spec("c2", "a1-c2", "a1-c2", 128, 8), "bf16").kernel_sets & 11 == 11
+    assert engine.compile_plan_host(c2, "bf16").kernel_sets == 3        # fused | slab
+    assert engine.compile_plan_host(helpers.make_spec("c2", "a1-c2", "a1-c2", 128, 8), "bf16").kernel_sets & 3 == 3
     mi = helpers.make_spec("mi", "quadruped-mi", "", 128, 2, grf=1)
-    assert engine.compile_plan_host(mi, "bf16").kernel_sets & 11 == 11
+    assert engine.compile_plan_host(mi, "bf16").kernel_sets & 3 == 3
     k4 = helpers.make_spec("k4", "mini_cheetah-k4", "mini_cheetah-k4", 128, 8, regression=False)
-    assert engine.compile_plan_host(k4, "bf16").kernel_sets & 11 == 11       # wide: 20 x 8 KB = the whole LDS of a CU; 20 nodes: the base_transform scratch aliases four joint blocks (80 KB, two workgroups per CU), group B of 8 slots
+    assert engine.compile_plan_host(k4, "bf16").kernel_sets & 3 == 3       # 20 nodes: the base_transform scratch aliases four joint blocks (80 KB, two workgroups per CU), group B of 8 slots
     for kind, topo, cfg in (("k4_com", "solo-k4-com", "solo-k4-com"), ("c2_com", "solo-c2-com", "solo-c2-com")):
         try:
             spec = helpers.make_spec(kind, topo, cfg, 128, 2)

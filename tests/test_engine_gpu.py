@@ -280,8 +280,7 @@ def test_step_is_hip_graph_capturable():
                                              ("k4", "mini_cheetah-k4", "mini_cheetah-k4", 8192), ("k4", "mini_cheetah-k4", "mini_cheetah-k4", 777),
                                              ("k4_com", "solo-k4-com", "solo-k4", 500), ("c2_com", "solo-c2-com", "solo-c2", 300)])
 def test_slab_and_eight_wave_stack_kernels_agree_bit_for_bit(kind, topo, cfg, B, monkeypatch):
-    """The slab stack kernels (two 4-wave workgroups per CU, destination nodes in two groups) and the engine-driven ones (asm MAC engine, every node's
-    accumulators in fixed registers: slab2 = 16-window tiles, two workgroups per CU; wide = 32-window tiles, one workgroup per CU) accumulate every
+    """The slab stack kernels (two 4-wave workgroups per CU, destination nodes in two groups) accumulate every
     node in the same order as the 8-wave stack kernels: outputs and
     every gradient but the decoder's (whose per-tile partials are summed over fewer per-wave partials) are identical bits, for full-size and
     ragged batches."""
@@ -293,17 +292,13 @@ def test_slab_and_eight_wave_stack_kernels_agree_bit_for_bit(kind, topo, cfg, B,
     params = synth.make_params(5, spec.param_shapes())
     res = {}
     # "8wave": the two launches per step of the 8-wave kernels; "8wave-step" and "slab" run both sweeps in one launch (k_stack_step / k_slab_step)
-    modes = {"wide": ("2", "0", "2", "1"), "slab2": ("0", "2", "2", "1"), "slab": ("0", "0", "2", "1"), "slab-2launch": ("0", "0", "2", "0"),
-             "8wave-step": ("0", "0", "0", "1"), "8wave": ("0", "0", "0", "0")}
-    for mode, (wide, slab2, slab, step) in modes.items():
-        monkeypatch.setenv("MSHGNN_WIDE", wide)       # read when the plan is created
-        monkeypatch.setenv("MSHGNN_SLAB2", slab2)
-        monkeypatch.setenv("MSHGNN_SLAB", slab)
+    modes = {"slab": ("2", "1"), "slab-2launch": ("2", "0"), "8wave-step": ("0", "1"), "8wave": ("0", "0")}
+    for mode, (slab, step) in modes.items():
+        monkeypatch.setenv("MSHGNN_SLAB", slab)       # read when the plan is created
         monkeypatch.setenv("MSHGNN_STEP_KERNEL", step)
         e = eng.Engine(spec, "bf16")
-        if (mode.startswith("slab") and mode != "slab2" and not (e.info.kernel_sets & 2)) or (mode == "slab2" and not (e.info.kernel_sets & 16)):
+        if mode.startswith("slab") and not (e.info.kernel_sets & 2):
             continue
-        assert mode != "wide" or (e.info.kernel_sets & 8), "every fused topology has a wide plan"
         xs = e.cast_inputs(x_dict)
         yd = y.reshape(-1).to(e.device, torch.float32)
         flat = eng.flatten_params(spec, params, e.device)
@@ -325,10 +320,10 @@ def test_slab_and_eight_wave_stack_kernels_agree_bit_for_bit(kind, topo, cfg, B,
 
 
 @pytest.mark.parametrize("kind,topo,cfg,layers,B", [("c2", "a1-c2", "a1-c2", 8, 300), ("k4", "mini_cheetah-k4", "mini_cheetah-k4", 8, 130)])
-def test_wide_stack_kernels_on_every_entry_point(kind, topo, cfg, layers, B, monkeypatch):
-    """The wide stack kernels (opt-in, MSHGNN_WIDE=2) behind every entry point that launches a stack kernel -- inference forward (no stashes), the
-    two-call route (mshgnn_forward + mshgnn_backward_mse: the decoder backward is its own launch) and, for the classification model, the one-call
-    cross-entropy step -- at the paper's depth (L = 8): identical bits to the 8-wave kernels (decoder gradients: summation order)."""
+def test_slab_stack_kernels_on_every_entry_point(kind, topo, cfg, layers, B, monkeypatch):
+    """The slab stack kernels (forced for a small batch, MSHGNN_SLAB=2) behind every entry point that launches a stack kernel -- inference forward (no
+    stashes), the two-call route (mshgnn_forward + mshgnn_backward_mse: the decoder backward is its own launch) and, for the classification model, the
+    one-call cross-entropy step -- at the paper's depth (L = 8): identical bits to the 8-wave kernels (decoder gradients: summation order)."""
     _require_gpu()
     from morphsym_hgnn_amd import engine as eng, synth
     reg = kind == "c2"
@@ -337,13 +332,10 @@ def test_wide_stack_kernels_on_every_entry_point(kind, topo, cfg, layers, B, mon
     x_dict, y = synth.make_windows(11, B, spec.num_nodes, spec.widths, n_y, classification=not reg)
     params = synth.make_params(11, spec.param_shapes())
     res = {}
-    for mode, (wide, slab2, slab) in {"wide": ("2", "0", "2"), "slab2": ("0", "2", "2"), "8wave": ("0", "0", "0")}.items():
-        monkeypatch.setenv("MSHGNN_WIDE", wide)
-        monkeypatch.setenv("MSHGNN_SLAB2", slab2)
+    for mode, slab in {"slab": "2", "8wave": "0"}.items():
         monkeypatch.setenv("MSHGNN_SLAB", slab)
         e = eng.Engine(spec, "bf16")
-        if mode == "slab2" and not (e.info.kernel_sets & 16):
-            continue
+        assert e.info.kernel_sets & 2
         xs = e.cast_inputs(x_dict)
         flat = eng.flatten_params(spec, params, e.device)
         inf = e.forward(xs, flat, B, training=False).clone()
@@ -357,41 +349,13 @@ def test_wide_stack_kernels_on_every_entry_point(kind, topo, cfg, layers, B, mon
             out, g = out.clone(), g.clone()
         torch.cuda.synchronize()
         res[mode] = (inf, out, g)
-    for mode in res:
-        if mode == "8wave":
-            continue
-        assert torch.equal(res[mode][0], res["8wave"][0]) and torch.equal(res[mode][1], res["8wave"][1]), mode
-        ga, gb = eng.unflatten(spec, res[mode][2]), eng.unflatten(spec, res["8wave"][2])
-        for k in ga:
-            if k.startswith("decoder"):
-                assert float((ga[k] - gb[k]).abs().max()) <= 2e-6 * float(gb[k].abs().max()), (mode, k)
-            else:
-                assert torch.equal(ga[k], gb[k]), (mode, k)
-
-
-def test_default_inference_forward_uses_the_engine_kernels_and_matches(monkeypatch):
-    """With no switches set, the inference forward of a full-size batch runs on the slab2 engine kernels (the training entry points stay on the slab
-    kernels): identical bits to the slab kernels' inference forward, and the training step is the slab kernels' either way."""
-    _require_gpu()
-    from morphsym_hgnn_amd import engine as eng, synth
-    spec = helpers.make_spec("c2", "a1-c2", "a1-c2", 128, 3)
-    B = 8192
-    x_dict, y = synth.make_windows(13, B, spec.num_nodes, spec.widths, 12)
-    params = synth.make_params(13, spec.param_shapes())
-    res = {}
-    for mode, env in {"default": None, "slab": "0"}.items():
-        for k in ("MSHGNN_WIDE", "MSHGNN_SLAB"):
-            monkeypatch.delenv(k, raising=False)
-        if env is None: monkeypatch.delenv("MSHGNN_SLAB2", raising=False)
-        else: monkeypatch.setenv("MSHGNN_SLAB2", env)
-        e = eng.Engine(spec, "bf16")
-        xs = e.cast_inputs(x_dict)
-        flat = eng.flatten_params(spec, params, e.device)
-        inf = e.forward(xs, flat, B, training=False).clone()
-        out, loss, g = e.step_mse(xs, flat, y.reshape(-1).to(e.device, torch.float32), B)
-        res[mode] = (inf, out.clone(), g.clone())
-    for i in range(3):
-        assert torch.equal(res["default"][i], res["slab"][i]), i
+    assert torch.equal(res["slab"][0], res["8wave"][0]) and torch.equal(res["slab"][1], res["8wave"][1])
+    ga, gb = eng.unflatten(spec, res["slab"][2]), eng.unflatten(spec, res["8wave"][2])
+    for k in ga:
+        if k.startswith("decoder"):
+            assert float((ga[k] - gb[k]).abs().max()) <= 2e-6 * float(gb[k].abs().max()), k
+        else:
+            assert torch.equal(ga[k], gb[k]), k
 
 
 def test_full_size_batch_properties_bf16():

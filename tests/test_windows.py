@@ -246,6 +246,40 @@ def test_series_step_is_bit_identical_to_assemble_then_step(recipe_name, B):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("materialize", [True, False])
+def test_series_step_takes_node_rows_of_more_than_16_runs(materialize):
+    """A node row built from more than 16 T-long variables (18 here: the fused-gather encoder keeps the first 16 run pointers in LDS and reads the
+    rest from the global table) runs through mshgnn_step_mse_series with the same bits as assembly + mshgnn_step_mse (the route
+    used to refuse such recipes)."""
+    from morphsym_hgnn_amd import engine as eng, synth, topology
+    from morphsym_hgnn_amd.spec import ModelSpec
+    from morphsym_hgnn_amd.windows import SequenceStore, quadsdk_a1_c2_recipe
+    hist, B = 10, 77
+    recipe = quadsdk_a1_c2_recipe(JP, FP, hist, 3, n_base=1)
+    recipe.variables["base"] = recipe.variables["base"] * 3            # 18 runs of 10 steps per base row
+    assert recipe.width("base") == 180 and recipe.width("base") // hist > 16
+    spec = ModelSpec(kind="mi", topology=topology.TOPOLOGIES["quadruped-mi"](), hidden=128, num_layers=2,
+                     widths={t: recipe.width(t) for t in recipe.node_types}, regression=True, grf_dimension=3, group=None, num_timesteps=hist)
+    store = SequenceStore(SEQ, recipe, dtype="bf16")
+    e = eng.Engine(spec, "bf16")
+    g = torch.Generator().manual_seed(5)
+    starts = torch.randint(0, N - hist + 1, (B,), generator=g)
+    starts[0], starts[-1] = 0, N - hist
+    starts = starts.cuda()
+    flat = eng.flatten_params(spec, synth.make_params(8, spec.param_shapes()), e.device)
+    xs, y, _ = store.assemble(starts)
+    xs = [x.clone() for x in xs]; y = y.clone()
+    out_a, loss_a, g_a = e.step_mse(xs, flat, y.reshape(-1), B)
+    out_a, loss_a, g_a = out_a.clone(), loss_a.clone(), g_a.clone()
+    xs2, y2, out_b, loss_b, g_b = e.step_mse_series(store, starts, flat, materialize=materialize)
+    torch.cuda.synchronize()
+    if materialize:
+        for a, b in zip(xs, xs2):
+            assert torch.equal(a, b)
+    assert torch.equal(y, y2) and torch.equal(out_a, out_b) and torch.equal(loss_a, loss_b) and torch.equal(g_a, g_b)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B", [3, 130, 1000])
 def test_classification_series_step_is_bit_identical_to_assemble_then_step_ce(B):
     """MiniCheetah-K4 contact classification straight from the sequence (mshgnn_step_ce_series): labels = the contact flags of each window's

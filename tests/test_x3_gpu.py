@@ -84,6 +84,29 @@ def test_x3_one_call_step_equals_forward_plus_backward_and_repeats():
         assert float((g_a - g_b).abs().max() / g_a.abs().max()) < 2e-5
 
 
+@pytest.mark.parametrize("kind,topo,cfg,B", [("c2", "a1-c2", "a1-c2", 1000), ("k4", "mini_cheetah-k4", "mini_cheetah-k4", 333)])
+def test_x3_step_kernel_and_two_launches_agree_bit_for_bit(kind, topo, cfg, B, monkeypatch):
+    """k_stack_step_x3 (forward + backward sweep in one launch: dX_L handed over through LDS as split hi / lo rows, no tile reload) against the two
+    launches k_stack_fwd_x3 + k_stack_bwd_x3 (MSHGNN_STEP_KERNEL=0, read per plan): same code in the same order, so output, loss and every gradient
+    are identical bits -- A1-C2 and MiniCheetah-K4 (the instantiation whose scratch blocks alias the feet's blocks)."""
+    from morphsym_hgnn_amd import engine as eng, synth
+    spec = helpers.make_spec(kind, topo, cfg, 128, 3, grf=3 if kind == "c2" else 1)
+    n_y = spec.out_channels * spec.num_nodes[spec.out_type]
+    x_dict, y = synth.make_windows(31, B, spec.num_nodes, spec.widths, n_y)
+    params = synth.make_params(31, spec.param_shapes())
+    res = {}
+    for step in ("1", "0"):
+        monkeypatch.setenv("MSHGNN_STEP_KERNEL", step)      # read when the plan is created
+        e = eng.Engine(spec, "x3")
+        assert not e.generic
+        xs = e.cast_inputs(x_dict)
+        out, loss, g = e.step_mse(xs, eng.flatten_params(spec, params, e.device), y.reshape(-1).to(e.device, torch.float32), B)
+        torch.cuda.synchronize()
+        res[step] = (out.clone(), loss.clone(), g.clone())
+    for i in range(3):
+        assert torch.equal(res["1"][i], res["0"][i]), i
+
+
 def test_x3_unaligned_inputs_take_the_general_loader():
     """Dense (unpadded) fp32 inputs: joint rows of 450 floats start 8-byte aligned only -> the element-wise loaders of the encoder and
     the weight-gradient kernel; same results as the padded layout."""

@@ -28,5 +28,8 @@ if __name__ == "__main__":
         if s:
             out[s] = {"fetch_bytes": 2.0 * v * 1024.0, "write_bytes": write.get(k, 0.0) * 1024.0}
             out[s]["hbm_bytes"] = out[s]["fetch_bytes"] + out[s]["write_bytes"]
-    json.dump({"note": "per launch, averaged over launches (layer_fwd / layer_bwd: averaged over the L layers); "
+    import os
+    cfile = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), ".build_commit")      # written before the snapshot leaves the build container
+    commit = open(cfile).read().strip() if os.path.exists(cfile) else None
+    json.dump({**({"commit": commit} if commit else {}), "note": "per launch, averaged over launches (layer_fwd / layer_bwd: averaged over the L layers); "
                        "FETCH_SIZE x2 (gfx950), KiB -> bytes", "kernels": out}, sys.stdout, indent=1)
