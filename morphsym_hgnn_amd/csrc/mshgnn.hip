@@ -2026,6 +2026,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinArgs a) {
     const int* f = a.fin + blockIdx.x * FIN_INTS;
     const int64_t dst = (int64_t)(unsigned)f[0] | ((int64_t)f[1] << 32);
     const int rows = f[2], cols = f[3], ld = f[4], tg = f[5], kind = f[6];
+    const int* more = f[7] ? a.fin0 + f[7] : nullptr;      // further destinations of the same sum: {n, dst_lo, dst_hi, ...}
     const int RPB = (rows + gridDim.y - 1) / gridDim.y;
     const int r0 = blockIdx.y * RPB, r1 = min(rows, r0 + RPB);
     const int n = (r1 - r0) * cols;
@@ -2080,6 +2081,10 @@ __global__ __launch_bounds__(256) void k_finalize(FinArgs a) {
                 }
         }
         a.grad[dst + (int64_t)r * ld + cidx] = s;
+        if (more) {
+            const int nm = more[0];
+            for (int k = 0; k < nm; ++k) a.grad[((int64_t)(unsigned)more[1 + 2 * k] | ((int64_t)more[2 + 2 * k] << 32)) + (int64_t)r * ld + cidx] = s;
+        }
     }
 }
 
@@ -2247,7 +2252,7 @@ int run_finalize(const mshgnn_plan* p, const mshgnn_ws_layout& lay, char* ws, fl
                  int gw_phase, hipStream_t st) {
     const HostPlan& hp = p->hp;
     const mshgnn_desc& d = hp.d;
-    FinArgs a{p->d_tables + hp.fin_off, p->d_tables + hp.tgt_off, reinterpret_cast<const float*>(ws + lay.slabs),
+    FinArgs a{p->d_tables + hp.fin_off, p->d_tables + hp.fin_off, p->d_tables + hp.tgt_off, reinterpret_cast<const float*>(ws + lay.slabs),
               reinterpret_cast<const float*>(ws + lay.dec_slabs), gparams, hp.n_lanes, hp.n_parts, loss,
               1.0f / (float)((int64_t)B * d.type_nodes[d.out_type] * (is_ce ? 1 : d.out_channels)),
               dec_done ? (int)((B + TILE_ROWS - 1) / TILE_ROWS) : NWG_DEC};

@@ -972,7 +972,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16* tile, int w_base, int co
 }
 
 
-struct FinArgs { const int* fin; const int* targets; const float* slabs; const float* dec_slabs; float* grad; int n_lanes, n_parts; float* loss; float inv_n;
+struct FinArgs { const int* fin; const int* fin0; const int* targets; const float* slabs; const float* dec_slabs; float* grad; int n_lanes, n_parts; float* loss; float inv_n;
                  int n_dec; };   // decoder partial slabs: NWG_DEC (k_dec_bwd) or one per tile (fused forward)
 
 struct mshgnn_gen_state;      // generic-width engine (mshgnn_gen.hip)

@@ -110,7 +110,8 @@ enum { BUF_X = 0, BUF_DX = 17, BUF_DH = 34, BUF_HB = 50, BUF_T1 = 66, BUF_DU = 8
 constexpr int ITEM_INTS = 10;   // p_buf p_nodes*H p_node q_buf (q_nodes*H | -1: raw input) q_node q_col0 q_ncols sign_off pad
 constexpr int TGT_INTS = 8;     // lane_begin lane_end bias_flag pad..
 constexpr int LANE_INTS = 4;    // item_begin item_end target bias_flag
-constexpr int FIN_INTS = 8;     // dst_lo dst_hi rows cols dst_ld target kind pad
+constexpr int FIN_INTS = 8;     // dst_lo dst_hi rows cols dst_ld target kind extra (0, or the offset -- in ints, from the fin table's start -- of {n, dst_lo, dst_hi, ...}: further
+                                // destinations of the same shape that receive the same slab sum: lin_root.weight / lin_rel.bias of every relation into one destination type)
 enum { FIN_MATRIX = 0, FIN_BIAS = 1, FIN_ZERO = 2, FIN_DEC_W = 3, FIN_DEC_B = 4 };
 
 struct PackDesc {       // one packed 128x128 B-operand image (weights as the MFMA wants them)
@@ -925,12 +926,16 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
     }
 
     // finalize ops: every parameter is written exactly once
-    struct FinRec { int64_t dst; int rows, cols, ld, target, kind; };
+    struct FinRec { int64_t dst; int rows, cols, ld, target, kind; std::vector<int64_t> more; };
     std::vector<FinRec> fins;
+    // Ops that share a slab sum (the pre-summed root weight and the bias of a destination type go to EVERY relation into that type) are ONE op with
+    // several destinations: the slabs are read once (A1-C2 L=3: 75 -> 52 MB of slab reads per finalize launch).  Round 1 measured the merge slower --
+    // with its coarse grid; the (ops x 64 row groups) grid of today has one output element per thread either way.
     auto add_fin = [&](int64_t dst, int rows, int cols, int ld, int target, int kind) {
-        // (merging ops that share a slab sum into one multi-destination op was measured slower: the kernel is bound by
-        //  the serial slab chain per thread, so fewer, fatter ops lose parallelism)
-        fins.push_back({dst, rows, cols, ld, target, kind}); };
+        if (target >= 0 && (kind == FIN_MATRIX || kind == FIN_BIAS))
+            for (auto& f : fins)
+                if (f.target == target && f.kind == kind && f.rows == rows && f.cols == cols && f.ld == ld) { f.more.push_back(dst); return; }
+        fins.push_back({dst, rows, cols, ld, target, kind, {}}); };
     for (int t = 0; t < NT; ++t) {
         const int F = d.type_width[t];
         for (int kc = 0; kc < p.enc_nkc[t]; ++kc) {
@@ -981,12 +986,20 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
         auto is_ph1 = [&](const FinRec& f) { return p.grad_split >= 0 && f.dst < p.grad_split; };
         std::stable_sort(fins.begin(), fins.end(), [&](const FinRec& x, const FinRec& y) { return is_ph1(x) < is_ph1(y); });
         p.fin_off = (int)T.size(); p.n_fin = (int)fins.size(); p.n_fin_ph0 = 0;
+        std::vector<int32_t> extra;      // destination lists behind the fixed-size records
         for (auto& f : fins) {
             if (!is_ph1(f)) ++p.n_fin_ph0;
             if (is_ph1(f) && f.target >= 0 && !tgt_is_enc[f.target]) p.grad_split = -1;      // (cannot happen with the layouts the host produces)
+            for (int64_t m : f.more) if ((p.grad_split >= 0 && m < p.grad_split) != is_ph1(f)) p.grad_split = -1;      // (a merged op never straddles the phases)
             T.push_back((int32_t)(f.dst & 0xffffffff)); T.push_back((int32_t)(f.dst >> 32)); T.push_back(f.rows); T.push_back(f.cols);
-            T.push_back(f.ld); T.push_back(f.target); T.push_back(f.kind); T.push_back(0);
+            T.push_back(f.ld); T.push_back(f.target); T.push_back(f.kind);
+            T.push_back(f.more.empty() ? 0 : (int32_t)(fins.size() * FIN_INTS + extra.size()));
+            if (!f.more.empty()) {
+                extra.push_back((int32_t)f.more.size());
+                for (int64_t m : f.more) { extra.push_back((int32_t)(m & 0xffffffff)); extra.push_back((int32_t)(m >> 32)); }
+            }
         }
+        T.insert(T.end(), extra.begin(), extra.end());
         if (p.grad_split < 0) p.n_fin_ph0 = p.n_fin;
     }
 

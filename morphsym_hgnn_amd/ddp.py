@@ -43,13 +43,34 @@ def allreduce_gradients_(flat_grad: torch.Tensor, local_windows: int, global_win
     return flat_grad
 
 
-def flat_data_parallel(module, group=None):
+def exchange_flat_gradient_(buf: torch.Tensor, n_flat: int, local_windows: int, group=None, weight_by_windows: bool = True) -> torch.Tensor:
+    """The ONE exchange of a `flat_data_parallel` step, in place on `buf` (fp32, >= n_flat + 1 elements: the flat gradient of this rank's LOCAL mean
+    loss followed by one spare element).  weight_by_windows: the gradient is multiplied by this rank's window count, the count rides in the spare
+    element, ONE sum-all-reduce moves both, and the returned divisor (a 0-dim tensor on buf's device, no host sync) is the global window count --
+    buf[:n_flat] / divisor is then the gradient of the GLOBAL mean loss for ragged shards too (what `allreduce_gradients_` computes with sizes known
+    on the host).  Otherwise: plain sum, divisor = world size (torch DDP's mean of the ranks' means, gnnLightning.py:1396-1400)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    if not weight_by_windows:
+        dist.all_reduce(buf[:n_flat], op=dist.ReduceOp.SUM, group=group)
+        return torch.tensor(float(world), dtype=torch.float32, device=buf.device)
+    if buf.numel() < n_flat + 1:
+        raise ValueError("exchange_flat_gradient_: the buffer needs one spare element behind the gradient")
+    buf[:n_flat].mul_(float(local_windows))
+    buf[n_flat:n_flat + 1].fill_(float(local_windows))
+    dist.all_reduce(buf[:n_flat + 1], op=dist.ReduceOp.SUM, group=group)
+    return buf[n_flat].clone()
+
+
+def flat_data_parallel(module, group=None, weight_by_windows: bool = True):
     """Data parallelism for a training-step wrapper (wrappers.py) or a model (models.py) WITHOUT torch's DistributedDataParallel: the
     parameters (views of one flat buffer) are broadcast from rank 0 once, and from then on the fused training step
     (`training_step` -> `models.fused_training_step[_windows]`) sum-all-reduces its flat gradient in `loss.backward()` and divides by the
     world size -- the mean over ranks DDP / Lightning-DDP produce (gnnLightning.py:1396-1400), as ONE exchange of 4 MB instead of ~50
-    per-parameter buckets and autograd hooks.  Every rank feeds its own shard of the global batch (equal shard sizes give the global
-    mean loss's gradient).  The two-call route (`forward` + `loss.backward()`: `fused_training_step = False`, a frozen parameter, a
+    per-parameter buckets and autograd hooks.  Every rank feeds its own shard of the global batch; with `weight_by_windows` (the default) each
+    rank's gradient is weighted by its window count and the sum divided by the global count (`exchange_flat_gradient_`: the counts ride in the
+    same all-reduce), so ragged shards -- the last batch of an epoch -- still give the gradient of the global mean loss; False reproduces torch DDP's
+    mean over the ranks' means.  The two-call route (`forward` + `loss.backward()`: `fused_training_step = False`, a frozen parameter, a
     normalising WindowBatch) makes the same single exchange in the engine's backward.  Only the fused engine has that hook: a model that runs
     operator by operator (an activation other than ReLU, a hidden width that is not a multiple of 128) is rejected here -- wrap that one in
     torch's DistributedDataParallel.  The model must have seen its lazy-initialising forward and live on the device; do not also wrap it
@@ -69,4 +90,5 @@ def flat_data_parallel(module, group=None):
     flat = model._flat_params(p0.device)
     dist.broadcast(flat, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
     model._flat_ddp = True if group is None else group
+    model._flat_ddp_weighted = bool(weight_by_windows)
     return module

@@ -84,12 +84,13 @@ class _EngineFnP(torch.autograd.Function):
         if e.stash_ticket(ctx.B) != ctx.ticket:
             raise RuntimeError("the activation stash of this forward was overwritten by a later forward of the same "
                                "batch size on the same engine; call backward before the next forward")
-        gflat = e.backward(ctx.xs, ctx.flat, gout.contiguous().to(torch.float32), ctx.B)      # a fresh buffer per backward: .grad views never alias
+        n_flat = ctx.flat.numel()
+        full = torch.empty(n_flat + 16, dtype=torch.float32, device=ctx.flat.device)      # a fresh buffer per backward: .grad views never alias
+        gflat = e.backward(ctx.xs, ctx.flat, gout.contiguous().to(torch.float32), ctx.B, grad_flat=full[:n_flat])
         if ctx.ddp is not None:      # ddp.flat_data_parallel on the two-call route: the same single exchange the fused training step makes
-            import torch.distributed as dist
-            group = None if ctx.ddp is True else ctx.ddp
-            dist.all_reduce(gflat, op=dist.ReduceOp.SUM, group=group)
-            gflat.div_(dist.get_world_size(group))
+            from .ddp import exchange_flat_gradient_
+            group, weighted = ctx.ddp
+            gflat.div_(exchange_flat_gradient_(full, n_flat, ctx.B, None if group is True else group, weighted))
         grads = [gflat[o:o + n].view(shape) for (o, n), shape in zip(ctx.offsets, ctx.shapes)]
         return (None, None, None, None, None, None, *([None] * ctx.n_x), *grads)
 
@@ -166,10 +167,13 @@ class _FusedStepFn(torch.autograd.Function):
     def forward(ctx, anchor, model, run):
         """run(grad_flat) -> (out, loss[1]): the engine call (mshgnn_step_mse / _ce or their *_series forms)."""
         if model._gpend is None or model._gpend.device != model._flat.device:
-            model._gpend = torch.empty_like(model._flat)
+            n = model._flat.numel()      # (+ spare elements: the window count of ddp.exchange_flat_gradient_ rides behind the gradient)
+            model._gpend_full = torch.empty(n + 16, dtype=torch.float32, device=model._flat.device)
+            model._gpend = model._gpend_full[:n]
         out, loss = run(model._gpend)
         model._gpend_id += 1
         ctx.model, ctx.flat, ctx.ticket = model, model._flat, model._gpend_id
+        ctx.windows = out.shape[0] // max(1, model._spec.num_nodes[model._spec.out_type])
         ctx.mark_non_differentiable(out)
         ctx.set_materialize_grads(False)      # (no zero tensor for the output's absent gradient)
         return loss[0], out
@@ -184,11 +188,10 @@ class _FusedStepFn(torch.autograd.Function):
             raise RuntimeError("the pending gradient of this training step was overwritten by a later fused training step of the same "
                                "model; call backward before the next step")
         pend, scale = m._gpend, gl.to(device=m._gpend.device, dtype=torch.float32)
-        if m._flat_ddp is not None:      # data parallel: ONE sum-all-reduce of the flat gradient, mean over the ranks (DDP semantics)
-            import torch.distributed as dist
+        if m._flat_ddp is not None:      # data parallel: ONE sum-all-reduce of the flat gradient (weighted by the ranks' window counts: ddp.py)
+            from .ddp import exchange_flat_gradient_
             group = None if m._flat_ddp is True else m._flat_ddp
-            dist.all_reduce(pend, op=dist.ReduceOp.SUM, group=group)
-            scale = scale / dist.get_world_size(group)
+            scale = scale / exchange_flat_gradient_(m._gpend_full, pend.numel(), ctx.windows, group, m._flat_ddp_weighted)
         _deliver_gradients(m, ctx.flat, lambda target: torch.mul(pend, scale, out=target) if target is not None else pend * scale)
         return (None,) * n_in
 
@@ -218,6 +221,8 @@ class _MSHGNNBase(nn.Module):
         self._gpend = None               # the flat gradient a fused training step computed, until its backward() delivers it
         self._gpend_id = 0
         self._flat_ddp = None            # ddp.flat_data_parallel: the process group the fused training step all-reduces its flat gradient over
+        self._flat_ddp_weighted = True   # ... with each rank's gradient weighted by its window count (ragged shards)
+        self._gpend_full = None
         self._gviews = None
         self._anchor = None
         self._checked_batches = set()
@@ -230,7 +235,7 @@ class _MSHGNNBase(nn.Module):
         state["_engines"] = {}
         state["_flat"] = None
         state["_flat_ok"] = False
-        state["_gflat"] = state["_gviews"] = state["_anchor"] = state["_gpend"] = state["_flat_ddp"] = None
+        state["_gflat"] = state["_gviews"] = state["_anchor"] = state["_gpend"] = state["_gpend_full"] = state["_flat_ddp"] = None
         state["_param_list"] = None
         state["_checked_batches"] = set()
         return state
@@ -476,7 +481,7 @@ class _MSHGNNBase(nn.Module):
             if need_grad:
                 import torch.distributed as dist
                 if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-                    out = _EngineFnP.apply(e, B, flat, offsets, self._flat_ddp, len(xs), *xs, *params)      # gradients through autograd: DDP's hooks see them
+                    out = _EngineFnP.apply(e, B, flat, offsets, None if self._flat_ddp is None else (self._flat_ddp, self._flat_ddp_weighted), len(xs), *xs, *params)      # gradients through autograd: DDP's hooks see them
                 else:
                     out = _EngineFnFast.apply(self._anchor, self, e, B, *xs)
             else:

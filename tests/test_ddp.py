@@ -54,6 +54,52 @@ def test_two_rank_gradient_allreduce_matches_global_batch():
     assert ret["err"] < 1e-6   # fp32 flat buffer round-trip of fp64 oracle gradients
 
 
+def _exchange_worker(rank, world, port, B, ret):
+    """flat_data_parallel's exchange on a ragged split (ddp.exchange_flat_gradient_): every rank holds the flat gradient of its LOCAL mean loss in a
+    buffer with one spare element; ONE all-reduce carries gradients and window counts; gradient / divisor == the global batch's gradient."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import ms_hgnn_oracle as orc
+    torch.set_num_threads(2)
+    spec = helpers.make_spec("c2", "a1-c2", "a1-c2", 128, 2)
+    cfg = helpers.oracle_config(spec)
+    x_dict, y = synth.make_windows(23, B, spec.num_nodes, spec.widths, 12)
+    params = synth.make_params(23, spec.param_shapes())
+    xs, (b, e) = ddp.shard_x_dict(x_dict, spec.num_nodes, B, rank, world)
+    n = e - b
+    _, _, grads = orc.step(cfg, params, xs, spec.topology.edge_index_dict(n), y[b:e], n)
+    n_flat = spec.flat_size()
+    for weighted in (True, False):
+        buf = torch.zeros(n_flat + 16, dtype=torch.float32)
+        buf[:n_flat] = flatten_params(spec, grads)
+        div = ddp.exchange_flat_gradient_(buf, n_flat, n, None, weighted)
+        got = (buf[:n_flat] / div).double()
+        if weighted:
+            assert float(div) == B
+            if rank == 0:
+                _, _, full = orc.step(cfg, params, x_dict, spec.topology.edge_index_dict(B), y, B)
+                ref = flatten_params(spec, full).double()
+                ret["err"] = float((got - ref).abs().max() / ref.abs().max())
+        else:
+            assert float(div) == world      # torch DDP's mean over the ranks' means
+            mine = flatten_params(spec, grads).double()
+            both = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(both, mine)
+            ret[f"mean_err_{rank}"] = float((got - sum(both) / world).abs().max() / got.abs().max())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_exchange_weights_ragged_shards_by_their_windows():
+    world, B = 2, 7   # ragged split: 4 + 3 windows
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 31000 + (os.getpid() % 2000)
+    mp.spawn(_exchange_worker, args=(world, port, B, ret), nprocs=world, join=True)
+    assert ret["err"] < 1e-6 and ret["mean_err_0"] < 1e-6 and ret["mean_err_1"] < 1e-6
+
+
 def _gpu_worker(rank, world, port, B, dtype, ret):
     """One rank of a data-parallel step on the REAL engine: both ranks share cuda:0 (the only GPU of the test box), so the exchange goes
     through gloo on host copies -- everything else (sharding, per-rank engine step through the C-ABI, mean semantics) is what bench.py does
@@ -148,8 +194,9 @@ def _wrapper_worker(rank, world, port, B, ret):
 
 
 @pytest.mark.gpu
-def test_flat_data_parallel_wrappers_reproduce_the_global_batch_gradient():
-    world, B = 2, 64        # equal shards: the mean of the ranks' mean losses is the global mean
+@pytest.mark.parametrize("B", [64, 65])      # equal shards, and a ragged split (33 + 32 windows: each rank's gradient is weighted by its window count)
+def test_flat_data_parallel_wrappers_reproduce_the_global_batch_gradient(B):
+    world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
     port = 33000 + (os.getpid() % 2000)
