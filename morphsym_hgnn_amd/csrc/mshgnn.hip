@@ -2809,7 +2809,9 @@ template <int NT> __global__ __launch_bounds__(NT) void k_metrics_cls(const floa
                 gout[(w * 4 + k) * 2 + 1] = (float)((p1[k] - (lab ? 1.0 : 0.0)) * inv);
             }
             const int pred = p1[k] > p0 ? 1 : 0;             // argmax over (p0, p1): the first maximum wins
-            c[2 + 4 * k + (pred ? (lab ? 0 : 1) : (lab ? 2 : 3))] += 1;
+            const int cell = pred ? (lab ? 0 : 1) : (lab ? 2 : 3);      // tp, fp, fn, tn -- added by compare, not by a run-time index (the counters stay in registers)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c[2 + 4 * k + j] += (cell == j);
             state = state * 2 + lab;
         }
         int best = 0; double bestv = -1.0;

@@ -543,7 +543,9 @@ constexpr int PREP_PITCH0 = 132, PREP_PITCH1 = 68, PREP_TILE_FLOATS = 64 * PREP_
 template <typename T, bool SPLIT_OUT>      // T: element type of the images (float / __bf16); SPLIT_OUT: hi image at wpack, lo image n_packs images further (split plan)
 __device__ __forceinline__ void prep_pack_half(const PrepArgs& a, int pack, int h, float* tile, int tid) {
     constexpr int EPC = Prec<T>::EPC, NBV = Prec<T>::NBV;
-    const PackDesc pd = a.packs[pack];
+    // (the descriptor's scalars are copied; its src[] array is read in place -- a local copy indexed by the loop counter lives in scratch: 96 B per lane)
+    const PackDesc* pdp = a.packs + pack;
+    struct { int orient, n_src, ld, col0, ncols; } pd{pdp->orient, pdp->n_src, pdp->ld, pdp->col0, pdp->ncols};
     const bool o0 = pd.orient == 0;
     const int pitch = o0 ? PREP_PITCH0 : PREP_PITCH1;
     // ---- summed source tile -> LDS
@@ -554,8 +556,9 @@ __device__ __forceinline__ void prep_pack_half(const PrepArgs& a, int pack, int 
 #pragma unroll
         for (int ps = 0; ps < 8; ++ps) sum[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int i = 0; i < pd.n_src; ++i) {
-            const float* base = a.params + pd.src[i];
-            const bool al = ((pd.src[i] + (o0 ? pd.col0 : 0)) % 4 == 0) && pd.ld % 4 == 0;
+            const int64_t src_i = pdp->src[i];
+            const float* base = a.params + src_i;
+            const bool al = ((src_i + (o0 ? pd.col0 : 0)) % 4 == 0) && pd.ld % 4 == 0;
             f32x4 g[8];
 #pragma unroll
             for (int ps = 0; ps < 8; ++ps) {
@@ -609,9 +612,10 @@ template <typename T, bool SPLIT_OUT> __global__ __launch_bounds__(256) void k_p
     if ((int)blockIdx.x < 2 * a.n_packs) { prep_pack_half<T, SPLIT_OUT>(a, blockIdx.x >> 1, blockIdx.x & 1, tile, tid); return; }
     const int b = ((int)blockIdx.x - 2 * a.n_packs) * 256 + tid;
     if (b < a.n_biases * H) {
-        const BiasDesc bd = a.biases[b / H];
+        const BiasDesc* bd = a.biases + b / H;
+        const int ns = bd->n_src;
         float s = 0.f;
-        for (int i = 0; i < bd.n_src; ++i) s += a.params[bd.src[i] + (b % H)];
+        for (int i = 0; i < ns; ++i) s += a.params[bd->src[i] + (b % H)];
         a.bias[b] = s;
     }
 }

@@ -12,6 +12,8 @@
 // 128x128 tiles dW = P^T Q with Q aggregated the same way.  No HIP calls in this file.
 #pragma once
 #include "mshgnn_plan.hpp"
+#include <climits>
+#include <cstdlib>
 #include <map>
 
 namespace mshgnn {
@@ -464,26 +466,68 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
     // XCD's L2 (speed only).  Super-units were emitted (target, chunk)-major, so a group is a run of consecutive indices.
     // The super-units on the general streams (aggregates of many rows, raw inputs: SU_FLAGS bit 0 clear) take about twice as long per step as the lean ones:
     // they are dispatched first, so that they do not form the tail of the launch.
+    // Placement (round 4): a group goes to the XCD whose groups already read most of ITS rows -- the root-weight, relation and base_transform targets
+    // of one layer want the same dH / X rows (a joint's row is the P operand of three to four targets and the Q operand of as many), and every
+    // workgroup of the launch sweeps the batch at the same pace, so readers that sit on one XCD and start together meet in its L2 (the 32-limb model
+    // moved 5.0 GB for 1.5 GB of distinct rows with the shortest-queue placement of round 2).  Greedy in target order: overlap in row-streams
+    // (buffer, node) with the queue's groups first, queue length second, lengths kept within a slack of the balanced one; each queue is then ordered
+    // by its groups' first P row, so that the groups of one layer and limb range are dispatched side by side.  Deterministic; speed only.
     std::vector<int32_t> su_order;
+    const bool su_locality = []() { const char* e = std::getenv("MSHGNN_GGW_PLACE"); return !(e && std::atoi(e) == 0); }();      // (=0: round 2's placement, A/B runs)
     for (int cls = 0; cls <= 1; ++cls) {
-        std::vector<std::pair<int, int>> groups;      // (first super-unit, count)
+        struct Grp { int first, count; std::vector<int64_t> streams; int64_t key; };
+        std::vector<Grp> groups;
         int pos = 0;
         for (Tgt& g : tgts) {
             const int per = ((g.rows / TW + p.su_os - 1) / p.su_os) * (((g.K + TW - 1) / TW + 1) / 2);
-            for (int c = 0; c < g.chunks; ++c) { if ((sunits[(size_t)pos * SUNIT_INTS + SU_FLAGS] & 1) == cls) groups.push_back({pos, per}); pos += per; }
+            for (int c = 0; c < g.chunks; ++c) {
+                if ((sunits[(size_t)pos * SUNIT_INTS + SU_FLAGS] & 1) == cls) {
+                    Grp gr{pos, per, {}, INT64_MAX};
+                    const int ia = sunits[(size_t)pos * SUNIT_INTS + SU_ITEM0], ib = sunits[(size_t)pos * SUNIT_INTS + SU_ITEM1];
+                    for (int it = ia; it < ib; ++it) {
+                        const int32_t* im = &items[(size_t)it * GITEM_INTS];
+                        const int64_t ps = ((int64_t)im[I_PBUF] << 20) | (int64_t)im[I_PNODE];
+                        gr.streams.push_back(ps); gr.key = std::min(gr.key, ps);
+                        if (im[I_KIND] == 0)
+                            for (int k = 0; k < im[I_NSRC]; ++k) {
+                                const int32_t* sp = &srcs[(size_t)(im[I_SRC0] + k) * SRC_INTS];
+                                gr.streams.push_back(((int64_t)sp[S_BUF] << 20) | (int64_t)sp[S_NODE]);
+                            }
+                    }
+                    std::sort(gr.streams.begin(), gr.streams.end()); gr.streams.erase(std::unique(gr.streams.begin(), gr.streams.end()), gr.streams.end());
+                    groups.push_back(std::move(gr));
+                }
+                pos += per;
+            }
         }
-        std::vector<std::vector<int>> xq(8);
-        int total = 0;
-        for (auto& gr : groups) {      // to the XCD queue that is shortest so far
-            int best = 0; for (int x = 1; x < 8; ++x) if (xq[x].size() < xq[best].size()) best = x;
-            for (int k = 0; k < gr.second; ++k) xq[best].push_back(gr.first + k);
-            total += gr.second;
+        std::vector<std::vector<int>> xq(8);      // queues of group indices
+        std::vector<int> qlen(8, 0);
+        std::vector<std::map<int64_t, int>> seen(8);
+        int total = 0; for (auto& gr : groups) total += gr.count;
+        const int cap = (total + 7) / 8 + (su_locality ? std::max(4, total / 64) : 0);
+        for (int gi = 0; gi < (int)groups.size(); ++gi) {
+            const Grp& gr = groups[gi];
+            int best = -1, best_ov = -1;
+            for (int x = 0; x < 8; ++x) {
+                if (su_locality && qlen[x] + gr.count > cap) continue;
+                int ov = 0;
+                if (su_locality) for (int64_t sid : gr.streams) if (seen[x].count(sid)) ++ov;
+                if (best < 0 || ov > best_ov || (ov == best_ov && qlen[x] < qlen[best])) { best = x; best_ov = ov; }
+            }
+            if (best < 0) { best = 0; for (int x = 1; x < 8; ++x) if (qlen[x] < qlen[best]) best = x; }
+            xq[best].push_back(gi); qlen[best] += gr.count;
+            for (int64_t sid : gr.streams) ++seen[best][sid];
+        }
+        std::vector<std::vector<int>> xs(8);      // queues of super-units
+        for (int x = 0; x < 8; ++x) {
+            if (su_locality) std::stable_sort(xq[x].begin(), xq[x].end(), [&](int a, int b) { return groups[a].key < groups[b].key; });
+            for (int gi : xq[x]) for (int k = 0; k < groups[gi].count; ++k) xs[x].push_back(groups[gi].first + k);
         }
         std::vector<size_t> qpos(8, 0);
         for (int b = 0; b < total; ++b) {      // block b -> queue b % 8; an exhausted queue borrows from the longest remaining one
             int q = b % 8;
-            if (qpos[q] >= xq[q].size()) { q = 0; for (int y = 1; y < 8; ++y) if (xq[y].size() - qpos[y] > xq[q].size() - qpos[q]) q = y; }
-            su_order.push_back(xq[q][qpos[q]++]);
+            if (qpos[q] >= xs[q].size()) { q = 0; for (int y = 1; y < 8; ++y) if (xs[y].size() - qpos[y] > xs[q].size() - qpos[q]) q = y; }
+            su_order.push_back(xs[q][qpos[q]++]);
         }
     }
     auto add_fin = [&](int64_t dst, int rows, int cols, int ld, int kind, int unit0, int nunits, int row0) {
