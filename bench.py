@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=1024)
     ap.add_argument("--min-time", type=float, default=0.5, help="seconds of timed blocks to accumulate")
     ap.add_argument("--overlap", default=os.environ.get("MSHGNN_BENCH_OVERLAP", "auto"), choices=["auto", "0", "1"])
+    ap.add_argument("--grad-exchange", default=os.environ.get("MSHGNN_BENCH_GRAD_EXCHANGE", "f32"), choices=["f32", "bf16"],
+                    help="N > 1: dtype of the gradient all-reduce on the wire (bf16: opt-in, half the bytes, NOT parity-grade -- ddp.allreduce_mean_bf16_)")
     return ap.parse_args()
 
 
@@ -216,7 +218,7 @@ def cpu_baseline(spec, batch, budget_s=20.0, scan=True):
 class Workload:
     """One (spec, plan dtype, batch) on one device: resident inputs + the step closure."""
 
-    def __init__(self, spec, dtype, B, device, seed, dist=None, overlap="auto"):
+    def __init__(self, spec, dtype, B, device, seed, dist=None, overlap="auto", grad_exchange="f32"):
         import torch
         from morphsym_hgnn_amd import engine as eng, synth
         self.torch, self.dist, self.spec, self.B = torch, dist, spec, B
@@ -241,18 +243,26 @@ class Workload:
         self.overlap = self.can_overlap and overlap == "1"
         self.split = split
         self.overlap_choice = None
+        self.g16 = torch.empty(self.gflat.numel(), dtype=torch.bfloat16, device=device) if (dist is not None and grad_exchange == "bf16") else None
+
+    def _allreduce(self):
+        if self.g16 is not None:
+            from morphsym_hgnn_amd import ddp
+            ddp.allreduce_mean_bf16_(self.gflat, self.g16)
+        else:
+            self.dist.all_reduce(self.gflat, op=self.dist.ReduceOp.AVG)     # DDP semantics: mean over ranks (gnnLightning.py:1396-1400)
 
     def step(self):
         e, dist = self.e, self.dist
         if not self.spec.regression:      # classification wrapper: forward + cross entropy + backward in one call (mshgnn_step_ce)
             e.step_ce(self.xs, self.flat, self.y, self.B, out=self.out, grad_flat=self.gflat, loss=self.loss)
             if dist is not None:
-                dist.all_reduce(self.gflat, op=dist.ReduceOp.AVG)
+                self._allreduce()
             return self.loss
         if not self.overlap:
             e.step_mse(self.xs, self.flat, self.y, self.B, out=self.out, grad_flat=self.gflat, loss=self.loss)
             if dist is not None:
-                dist.all_reduce(self.gflat, op=dist.ReduceOp.AVG)     # DDP semantics: mean over ranks (gnnLightning.py:1396-1400)
+                self._allreduce()
             return self.loss
         # N > 1: the same step in two calls; the all-reduce of everything but the encoder's gradients (83 % of the buffer) runs on
         # RCCL's stream while this stream computes the encoder's weight gradients, then the encoder's slice follows.  Both
@@ -595,7 +605,9 @@ def main():
 
     B, L, hidden = defaults(args)
     spec = build_spec(L, args.config, hidden)
-    wl = Workload(spec, args.dtype, B, device, 1234 + rank, dist, args.overlap)
+    wl = Workload(spec, args.dtype, B, device, 1234 + rank, dist, args.overlap, args.grad_exchange)
+    if args.grad_exchange == "bf16":
+        wl.can_overlap = False      # (the two-phase step exchanges fp32 slices)
     if args.overlap == "auto" and wl.can_overlap and (world > 1 or os.environ.get("MSHGNN_BENCH_FORCE_DIST") == "1"):
         wl.calibrate_overlap()
     med, blocks = wl.time_blocks(args.steps, args.warmup, args.min_time)
@@ -626,7 +638,8 @@ def main():
         "config": {"workload": f"{names[args.config]}, h={hidden}, L={L}, T={spec.num_timesteps}, {B} windows/GPU, "
                                f"fwd+{'MSE' if spec.regression else 'CE'}+bwd, all parameter gradients"
                                + (f", RCCL all-reduce (mean over {world} ranks{', overlapped two-phase' if wl.overlap else ''})" if dist is not None else ""),
-                   "global_batch": B * world, "parallelism": f"dp{world}", "rccl_ranks": (dist.get_world_size() if dist is not None else 0)},
+                   "global_batch": B * world, "parallelism": f"dp{world}", "rccl_ranks": (dist.get_world_size() if dist is not None else 0),
+                   **({"grad_exchange": args.grad_exchange} if dist is not None else {})},
         "timing": {"blocks": len(blocks), "block_steps": args.steps, "median_ms": med * 1e3, "min_ms": min(blocks) * 1e3, "max_ms": max(blocks) * 1e3,
                    "timed_s": sum(blocks)},
         "overlap": wl.overlap_choice or {"mode": args.overlap, "two_phase": bool(wl.overlap)},

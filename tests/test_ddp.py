@@ -100,6 +100,32 @@ def test_flat_exchange_weights_ragged_shards_by_their_windows():
     assert ret["err"] < 1e-6 and ret["mean_err_0"] < 1e-6 and ret["mean_err_1"] < 1e-6
 
 
+def _bf16_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(100 + rank)
+    mine = torch.randn(4099, generator=g)
+    both = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(both, mine)
+    got = ddp.allreduce_mean_bf16_(mine.clone(), torch.empty(4099, dtype=torch.bfloat16))
+    ref = sum(both) / world
+    ret[f"err_{rank}"] = float((got - ref).abs().max() / ref.abs().max())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bf16_gradient_exchange_is_within_bf16_distance_of_the_fp32_mean():
+    """The opt-in bf16 gradient exchange (bench.py --grad-exchange bf16): mean over two ranks within 2^-7 of the fp32 mean, max-abs relative
+    (three bf16 roundings) -- far outside the 1e-4 parity tolerance, which is why it is opt-in."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 32000 + (os.getpid() % 2000)
+    mp.spawn(_bf16_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert 1e-4 < ret["err_0"] < 2 ** -7 and ret["err_0"] == ret["err_1"]
+
+
 def _gpu_worker(rank, world, port, B, dtype, ret):
     """One rank of a data-parallel step on the REAL engine: both ranks share cuda:0 (the only GPU of the test box), so the exchange goes
     through gloo on host copies -- everything else (sharding, per-rank engine step through the C-ABI, mean semantics) is what bench.py does
