@@ -592,6 +592,11 @@ def main():
         raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries ONE JSON line and nothing else: RCCL prints a version banner to fd 1 when its communicator is created (seen on the GPU box:
+    # "RCCL version : 2.26.6 ..."), so everything written to fd 1 from here on goes to stderr and the line is written to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     dist = None
     if world > 1 or os.environ.get("MSHGNN_BENCH_FORCE_DIST") == "1":   # (FORCE_DIST: a 1-rank RCCL group, to exercise the N > 1 code path on one GPU)
@@ -697,10 +702,12 @@ def main():
     cfile = os.path.join(ROOT, ".build_commit")      # (tools/profile_round.sh runs: the commit the snapshot was taken at)
     if os.path.exists(cfile):
         res["commit"] = open(cfile).read().strip()
-    if rank == 0:
-        print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()
+    sys.stdout.flush()
+    if rank == 0:
+        os.write(json_fd, (json.dumps(res) + "\n").encode())
+    os.close(json_fd)
 
 
 if __name__ == "__main__":
