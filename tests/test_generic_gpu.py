@@ -128,6 +128,35 @@ def test_configs4_bench_arithmetic_is_within_bf16_distance_of_the_oracle():
     assert not bad, bad
 
 
+@pytest.mark.parametrize("seed,nb,nj,nf,hidden,layers", [(1, 1, 7, 3, 128, 3), (2, 2, 15, 5, 128, 2), (3, 3, 30, 9, 256, 3), (4, 1, 5, 2, 128, 4)])
+def test_random_topologies_match_the_oracle(seed, nb, nj, nf, hidden, layers):
+    """Topologies no robot of the reference has: random edge lists over the five relation types of the MI graph (hgnn.py:5-63 takes any metadata) --
+    repeated edges, nodes without in-edges, in-degrees up to the node count, one relation left empty -- on whichever engine plan creation picks
+    (the LDS-resident kernels up to 20 nodes at h = 128, else the generic-width engine), parity arithmetic, 1e-4."""
+    import random
+    from morphsym_hgnn_amd import engine as eng, synth
+    from morphsym_hgnn_amd.spec import ModelSpec
+    from morphsym_hgnn_amd.topology import RobotTopology
+    rng = random.Random(seed)
+    n = {"base": nb, "joint": nj, "foot": nf}
+    rels = []
+    for k, (s_, d_) in enumerate((("base", "joint"), ("joint", "base"), ("joint", "joint"), ("foot", "joint"), ("joint", "foot"))):
+        ne = 0 if (k == seed % 5 and k != 4) else rng.randint(1, 2 * max(n[s_], n[d_]))      # (never the relation into the decoder's type: keep a signal path)
+        pairs = [[rng.randrange(n[s_]), rng.randrange(n[d_])] for _ in range(ne)]
+        if pairs and rng.random() < 0.7:
+            pairs.append(list(pairs[0]))                      # a repeated edge: PyG sums it twice
+        rels.append(((s_, "connect", d_), pairs))
+    topo = RobotTopology(name=f"random{seed}", num_nodes=n, relations=rels)
+    spec = ModelSpec(kind="mi", topology=topo, hidden=hidden, num_layers=layers, widths={"base": 24, "joint": 9, "foot": 5}, regression=True,
+                     grf_dimension=1, group=None, num_timesteps=3)
+    B = 21
+    x_dict, y = synth.make_windows(seed, B, spec.num_nodes, spec.widths, spec.out_channels * nf)
+    params = synth.make_params(seed, spec.param_shapes())
+    errs, *_ = helpers.run_engine_case(spec, x_dict, y, params, topo.edge_index_dict(B), B, dtype="x3")
+    bad = {k: v for k, v in errs.items() if v > RTOL}
+    assert not bad, (seed, "generic" if eng.compile_plan_host(spec, "x3").kernel_sets & 4 else "lds-resident", bad)
+
+
 def test_generic_ragged_batches_and_step_equals_two_call_sequence():
     from morphsym_hgnn_amd import engine as eng, synth
     case, spec, *_ = helpers.load_case("synth8_mi_h256_L3_B3")
