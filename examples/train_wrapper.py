@@ -50,7 +50,7 @@ def train(steps=200, batch=8192, dtype="bf16", layers=3, lr=1e-3, rows=100_000, 
     torch.manual_seed(0)
     cfg = os.path.join(bench.ROOT, "morphsym_hgnn_amd", "cfg", "a1-c2.yaml")
     # the lazy-initialising dummy forward (gnnLightning.py:593-595) must see the reference's feature widths (900 / 450 / 1), not the
-    # 16-byte-aligned pitch of assembled batches: the encoder's in-features are read off it
+    # aligned pitch of assembled batches: the encoder's in-features are read off it
     first = next_batch()
     dummy = types.SimpleNamespace(edge_index_dict=ei, x_dict={t: x[:, :store.recipe.width(t)].float().contiguous() for t, x in first.x_dict.items()})
     model = wrappers.HGNN_C2_Lightning_Reg(spec.hidden, layers, spec.topology.metadata(), dummy, optimizer="adam", lr=lr,

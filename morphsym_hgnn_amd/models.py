@@ -368,9 +368,9 @@ class _MSHGNNBase(nn.Module):
                 raise RuntimeError(f"parameter layout mismatch: {set(expect) ^ set(have)}")
         spec = self._spec
         B, nn_ = self._num_nodes(x_dict)
-        def _pitch_ok(x, F):     # the reference's width, or rows already at the engine's 16-byte-aligned pitch (on-device window assembly)
+        def _pitch_ok(x, F):     # the reference's width, or rows already at an engine pitch (on-device window assembly): whole 16-byte chunks >= F
             q = {torch.bfloat16: 8, torch.float32: 4}.get(x.dtype)
-            return x.shape[1] == F or (q is not None and x.shape[1] == (F + q - 1) // q * q)
+            return x.shape[1] == F or (q is not None and x.shape[1] > F and x.shape[1] % q == 0 and x.shape[1] < F + 128 // (16 // q))
         for t in self._node_types:
             if nn_[t] != spec.num_nodes[t] or not _pitch_ok(x_dict[t], spec.widths[t]):
                 raise ValueError(f"x_dict['{t}'] does not match the compiled topology "

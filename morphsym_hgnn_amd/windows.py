@@ -179,8 +179,7 @@ class SequenceStore:
         return self.n_rows - self.recipe.history + 1
 
     def padded_width(self, t: str) -> int:
-        epc = 8 if self.dtype == "bf16" else 4
-        return (self.recipe.width(t) + epc - 1) // epc * epc
+        return eng.row_pitch(self.recipe.width(t), 2 if self.dtype == "bf16" else 4)      # the engine's input layout
 
     def _buffers(self, B: int):
         """Output buffers for a batch of B windows, made once per batch size: the pad columns are zeroed here and never
