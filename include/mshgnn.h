@@ -113,6 +113,8 @@ typedef struct mshgnn_info {
                                      CU; used for batches of >= 1.5 tiles per CU), bit 2: generic-width engine -- what the plan allows  */
     int64_t grad_split;           /* two-phase step (mshgnn_step_mse_phase): gradients [grad_split, n_flat) are final after
                                      phase 0, [0, grad_split) (the encoder's) after phase 1; -1: the plan has no split       */
+    double bytes_in_live;         /* input bytes / window of the nodes whose inputs can reach the output at this depth (<= bytes_in): what
+                                     the plan reads.  A1-C2 at L = 3: the base nodes are four hops from the feet, their 3 600 B never matter */
 } mshgnn_info;
 
 /* Offsets (bytes) of the per-layer buffers inside the workspace, for tests / debugging.              */

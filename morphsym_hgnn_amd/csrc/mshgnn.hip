@@ -116,14 +116,15 @@ template <typename T, bool ALIGNED, bool SERIES = false> __global__ __launch_bou
     int t = 0;
     while (t + 1 < a.n_types && bid >= a.wg_prefix[t + 1]) ++t;
     const int local = bid - a.wg_prefix[t];
-    const int node = ENC_ORDER ? local % a.nodes[t] : local / a.tiles, tile = ENC_ORDER ? local / a.nodes[t] : local % a.tiles;
+    const int node = a.node_list[a.node_off[t] + (ENC_ORDER ? local % a.nodes[t] : local / a.tiles)], tile = ENC_ORDER ? local / a.nodes[t] : local % a.tiles;
+    const bool skip = SERIES && ((a.skip_mask >> (a.tbase[t] + node)) & 1ull) != 0;      // window rows only: nobody reads this node's X_0 (uniform)
     const int w0 = tile * MB * P::ROWS;
     const T* x = reinterpret_cast<const T*>(a.x[t]);
     const int64_t pitch = a.pitch[t];
-    const int F = a.width[t], nt = a.nodes[t], nkc = a.nkc[t], vb = a.vb[t];
+    const int F = a.width[t], nt = a.tbase[t + 1] - a.tbase[t], nkc = a.nkc[t], vb = a.vb[t];      // nt: nodes of the type in the input rows (not the launch's list)
     const uint8_t* sg = a.signs + a.sign_off[t] + (size_t)node * nkc * H;
     const T* wpack = reinterpret_cast<const T*>(a.wpack);
-    const float* bias = a.bias + (size_t)a.bias_idx[t] * H;
+    const float* bias = a.bias + (size_t)max(a.bias_idx[t], 0) * H;      // (a type whose X_0 nobody reads has no packs and no bias row: skip)
 
     typename P::Acc acc[MB];
 #pragma unroll
@@ -202,7 +203,7 @@ template <typename T, bool ALIGNED, bool SERIES = false> __global__ __launch_bou
                 if constexpr (SERIES) rawv[mi][it] = raw;
             }
         __syncthreads();
-        load_bfrag<T>(bf, wpack, a.pack0[t] + kc, wv, lane);   // before the prefetch: vmcnt retires in order
+        if (!skip) load_bfrag<T>(bf, wpack, a.pack0[t] + kc, wv, lane);   // before the prefetch: vmcnt retires in order
         if (kc + 1 < nkc) fetch(kc + 1);   // the next K chunk streams from HBM under this chunk's MFMAs
         if constexpr (SERIES) {
             // the materialised window rows of THIS chunk (raw values: the sign mask is applied by whoever reads them) go out BEHIND the next chunk's
@@ -216,14 +217,17 @@ template <typename T, bool ALIGNED, bool SERIES = false> __global__ __launch_bou
                     if (x != nullptr && w < a.B && k0 < (int)pitch) *reinterpret_cast<u32x4*>(const_cast<T*>(x) + ((size_t)w * nt + node) * pitch + k0) = rawv[mi][it];
                 }
         }
+        if (!skip) {
 #pragma unroll
-        for (int m = 0; m < MB; ++m) {
-            if (w0 + m * P::ROWS < a.B) {   // uniform
-                load_afrag<T>(af, smem, m, ao);
-                mac(acc[m], af, bf);
+            for (int m = 0; m < MB; ++m) {
+                if (w0 + m * P::ROWS < a.B) {   // uniform
+                    load_afrag<T>(af, smem, m, ao);
+                    mac(acc[m], af, bf);
+                }
             }
         }
     }
+    if (skip) return;
     T* x0 = reinterpret_cast<T*>(a.x0);
     const int gnode = a.tbase[t] + node;
 #pragma unroll
@@ -2302,10 +2306,21 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
             a.vb[t] = vec_bytes(a.x[t], a.pitch[t], (int)sizeof(T));
             if (t == 0) a.aligned = 1;
             if (a.vb[t] != 16 || a.pitch[t] % Prec<T>::EPC) a.aligned = 0;
-            a.width[t] = d.type_width[t]; a.nodes[t] = d.type_nodes[t]; a.tbase[t] = hp.type_base[t]; a.nkc[t] = hp.enc_nkc[t];
+            a.width[t] = d.type_width[t]; a.tbase[t] = hp.type_base[t]; a.nkc[t] = hp.enc_nkc[t];
             a.pack0[t] = hp.pack_enc_base[t]; a.bias_idx[t] = hp.bias_enc[t]; a.sign_off[t] = hp.sign_off[t];
-            a.wg_prefix[t + 1] = a.wg_prefix[t] + d.type_nodes[t] * a.tiles;
+            // the launch's nodes of this type: those whose X_0 can reach the output; with window rows to materialise (series route, x given) every node,
+            // the others marked in skip_mask
+            a.node_off[t] = t == 0 ? 0 : a.node_off[t - 1] + a.nodes[t - 1];
+            a.nodes[t] = 0;
+            const bool all_rows = series != nullptr && x != nullptr;
+            for (int i = 0; i < d.type_nodes[t]; ++i) {
+                const bool need = hp.need_n[0][hp.type_base[t] + i];
+                if (need || all_rows) a.node_list[a.node_off[t] + a.nodes[t]++] = (unsigned char)i;
+                if (!need) a.skip_mask |= 1ull << (hp.type_base[t] + i);
+            }
+            a.wg_prefix[t + 1] = a.wg_prefix[t] + a.nodes[t] * a.tiles;
         }
+        a.tbase[hp.NT] = hp.NN;
         a.wpack = ws + lay.wpack; a.bias = reinterpret_cast<const float*>(ws + lay.bias); a.signs = p->d_signs; a.x0 = ws + lay.x[0];
         a.mask0 = (training && lay.dd[0]) ? reinterpret_cast<uint8_t*>(ws + lay.dd[0]) : nullptr;
         unsigned enc_grid = (unsigned)a.wg_prefix[hp.NT];

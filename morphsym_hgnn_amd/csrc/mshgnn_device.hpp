@@ -339,9 +339,13 @@ struct PrepArgs {
 
 struct EncArgs {
     const void* x[MSHGNN_MAX_TYPES]; int64_t pitch[MSHGNN_MAX_TYPES]; int vb[MSHGNN_MAX_TYPES];
-    int width[MSHGNN_MAX_TYPES], nodes[MSHGNN_MAX_TYPES], tbase[MSHGNN_MAX_TYPES], nkc[MSHGNN_MAX_TYPES];
+    int width[MSHGNN_MAX_TYPES], nodes[MSHGNN_MAX_TYPES], tbase[MSHGNN_MAX_TYPES + 1], nkc[MSHGNN_MAX_TYPES];      // nodes: of the launch (node_list); tbase[t + 1] - tbase[t]: of the type
     int pack0[MSHGNN_MAX_TYPES], bias_idx[MSHGNN_MAX_TYPES], sign_off[MSHGNN_MAX_TYPES], wg_prefix[MSHGNN_MAX_TYPES + 1];
     int n_types, tiles, B, NN;
+    // the nodes this launch works on, per type: node_list[node_off[t] .. + nodes[t]) = indices inside the type (the plan's need_n[0]: nodes whose X_0 can
+    // reach the output; every node when the launch also materialises window rows for the caller -- skip_mask then marks the nodes whose X_0 nobody
+    // reads: bit (global node index) set = gather and write the window rows, no MACs, no X_0)
+    unsigned char node_list[64]; int node_off[MSHGNN_MAX_TYPES]; unsigned long long skip_mask;
     int aligned;   // every input row starts 16-byte aligned and its pitch is a whole number of 16-byte chunks
     const void* wpack; const float* bias; const uint8_t* signs; void* x0;
     uint8_t* mask0;   // training: relu bytes of X_0 (one byte per lane, as the layer masks), read by the backward stack kernels at layer 0

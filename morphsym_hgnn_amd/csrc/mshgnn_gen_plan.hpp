@@ -588,7 +588,7 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
 
     p.info.rows_per_tile = 64; p.info.total_nodes = p.NN; p.info.lds_bytes = 4 * 4096 * p.planes;
     p.info.flops_fwd = alg_fwd; p.info.flops_bwd = alg_bwd; p.info.flops_exec_fwd = exec_fwd; p.info.flops_exec_bwd = exec_bwd;
-    p.info.bytes_in = bytes_in; p.info.n_gradw_workgroups = p.n_sunits * p.n_parts;
+    p.info.bytes_in = bytes_in; p.info.bytes_in_live = bytes_in; p.info.n_gradw_workgroups = p.n_sunits * p.n_parts;
     p.info.n_launches_fwd = 2 + (int)p.fwd.size(); p.info.n_launches_bwd = 3 + (int)p.bwd.size();
     p.info.kernel_sets = 4;      // bit 2: generic-width engine
     p.info.grad_split = -1;

@@ -144,8 +144,15 @@ struct HostPlan {
     int n_img = 0;                 // weight images per plane (== packs.size())
     int lo_blk = 0;                // split plan: LDS block of the lo plane of node n is lo_blk + n
     int gw_target = (int)GW_TARGET_WGS;
-    bool live[MAX_L][MSHGNN_MAX_TYPES]{};     // layer output of type t reaches the decoder
-    bool need_dx[MAX_L][MSHGNN_MAX_TYPES]{};  // dX_l[t] must be produced
+    bool live[MAX_L][MSHGNN_MAX_TYPES]{};     // layer output of SOME node of type t reaches the decoder
+    bool need_dx[MAX_L][MSHGNN_MAX_TYPES]{};  // dX_l of some node of type t must be produced
+    // node-level liveness (round 4): live_n[l][n] -- X_{l+1}[n], the output of layer l at node n, can reach the decoder; need_n[l][n] -- X_l[n] is an input
+    // of a live node of layer l (itself through the root weight / residual, or a destination it has an edge to), so dX_l[n] must be produced; need_n[0] =
+    // the nodes the encoder has to compute.  A1-C2 at L = 3: the base nodes are four hops from the feet, so nothing of them is live (49 of 84 parameter
+    // tensors get exact-zero gradients in the reference too).  MSHGNN_PRUNE=0: type-level liveness only (every node of a live type is live).
+    bool live_n[MAX_L][64]{}, need_n[MAX_L][64]{};
+    bool prune_nodes = true;
+    int enc_live_nodes = 0;                   // nodes the encoder computes (need_n[0])
     // packed operands
     std::vector<PackDesc> packs;
     std::vector<BiasDesc> biases;
@@ -290,21 +297,50 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
         p.out_mask_f[i] = d.out_mask[i];
     }
 
-    // ---- liveness -------------------------------------------------------------------------------
-    for (int t = 0; t < NT; ++t) p.live[L - 1][t] = (t == d.out_type);
-    for (int l = L - 2; l >= 0; --l)
+    // ---- liveness (node level) ------------------------------------------------------------------
+    // X_{l+1}[n] is needed iff node n itself is live in layer l + 1 (root weight, residual) or it has an edge into a node that is.  Without
+    // pruning (MSHGNN_PRUNE=0) a type is live as a whole, as in rounds 1-3.  The base_transform chain works on its type's nodes together: if one of
+    // them is live in a layer, all are.
+    { const char* e = std::getenv("MSHGNN_PRUNE"); p.prune_nodes = !(e && std::atoi(e) == 0); }
+    auto widen = [&](bool (&v)[64]) {      // type-level closure: whole types (no pruning), or the base_transform type
         for (int t = 0; t < NT; ++t) {
-            bool v = p.live[l + 1][t];   // root / residual path into its own type
-            for (int r = 0; r < NR; ++r) if (p.rel_src[r] == t && p.live[l + 1][p.rel_dst[r]]) v = true;
-            p.live[l][t] = v;
+            if (p.prune_nodes && !(has_mlp && t == d.mlp_type)) continue;
+            bool any = false;
+            for (int i = 0; i < d.type_nodes[t]; ++i) any = any || v[p.type_base[t] + i];
+            if (any) for (int i = 0; i < d.type_nodes[t]; ++i) v[p.type_base[t] + i] = true;
         }
+    };
+    auto inputs_of = [&](const bool (&out)[64], bool (&in)[64]) {      // the nodes whose X feeds a live node of a layer
+        for (int n = 0; n < p.NN; ++n) in[n] = out[n];
+        for (int r = 0; r < NR; ++r)
+            for (int e = p.rel_edge_off[r]; e < p.rel_edge_off[r + 1]; ++e)
+                if (out[p.type_base[p.rel_dst[r]] + p.edges[2 * e + 1]]) in[p.type_base[p.rel_src[r]] + p.edges[2 * e]] = true;
+        if (!p.prune_nodes)      // (type-level rule of rounds 1-3: a type is needed when a relation out of it enters a live type, edges or not)
+            for (int r = 0; r < NR; ++r) {
+                bool dl = false;
+                for (int i = 0; i < d.type_nodes[p.rel_dst[r]]; ++i) dl = dl || out[p.type_base[p.rel_dst[r]] + i];
+                if (dl) for (int j = 0; j < d.type_nodes[p.rel_src[r]]; ++j) in[p.type_base[p.rel_src[r]] + j] = true;
+            }
+    };
+    for (int n = 0; n < p.NN; ++n) p.live_n[L - 1][n] = (p.node_type[n] == d.out_type);
+    for (int l = L - 1; l >= 0; --l) {
+        widen(p.live_n[l]);
+        inputs_of(p.live_n[l], p.need_n[l]);
+        if (l == 0) widen(p.need_n[0]);      // (the encoder computes whole types without pruning)
+        if (l > 0) for (int n = 0; n < p.NN; ++n) p.live_n[l - 1][n] = p.need_n[l][n];
+    }
+    // what layer l needs of X_l is what layer l - 1 has to produce: after the closure of live_n[l - 1] the two must agree again
+    for (int l = 1; l < L; ++l) for (int n = 0; n < p.NN; ++n) p.need_n[l][n] = p.live_n[l - 1][n];
+    p.enc_live_nodes = 0;
+    for (int n = 0; n < p.NN; ++n) p.enc_live_nodes += p.need_n[0][n] ? 1 : 0;
     for (int l = 0; l < L; ++l)
         for (int t = 0; t < NT; ++t) {
-            if (l >= 1) { p.need_dx[l][t] = p.live[l - 1][t]; continue; }
-            bool v = p.live[0][t];
-            for (int r = 0; r < NR; ++r) if (p.rel_src[r] == t && p.live[0][p.rel_dst[r]]) v = true;
-            p.need_dx[0][t] = v;
+            p.live[l][t] = p.need_dx[l][t] = false;
+            for (int i = 0; i < d.type_nodes[t]; ++i) { p.live[l][t] = p.live[l][t] || p.live_n[l][p.type_base[t] + i]; p.need_dx[l][t] = p.need_dx[l][t] || p.need_n[l][p.type_base[t] + i]; }
         }
+    auto rel_live = [&](int l, int r) {      // relation r has an edge into a live node of layer l
+        for (int e = p.rel_edge_off[r]; e < p.rel_edge_off[r + 1]; ++e) if (p.live_n[l][p.type_base[p.rel_dst[r]] + p.edges[2 * e + 1]]) return true;
+        return false; };
 
     // ---- packed operands --------------------------------------------------------------------------
     for (int o = 0; o < 2; ++o) { p.pack_root[o].assign((size_t)L * NT, -1); p.pack_rel[o].assign((size_t)L * NR, -1); }
@@ -320,7 +356,7 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
             p.bias_layer[l * NT + t] = add_bias(p, bs);
         }
         for (int r = 0; r < NR; ++r) {
-            if (!p.live[l][p.rel_dst[r]] || p.rel_edge_off[r + 1] == p.rel_edge_off[r]) continue;
+            if (!rel_live(l, r)) continue;
             p.pack_rel[0][l * NR + r] = add_pack(p, 0, {p.off_rel_w[l * NR + r]}, H, 0, H);
             p.pack_rel[1][l * NR + r] = add_pack(p, 1, {p.off_rel_w[l * NR + r]}, H, 0, H);
         }
@@ -335,6 +371,7 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
     }
     p.pack_enc_base.assign(NT, -1); p.bias_enc.assign(NT, -1);
     for (int t = 0; t < NT; ++t) {
+        if (!p.need_dx[0][t]) continue;      // no node of this type feeds the output at this depth: its encoder is never run
         const int F = d.type_width[t];
         for (int kc = 0; kc < p.enc_nkc[t]; ++kc) {
             const int id = add_pack(p, 0, {p.off_enc_w[t]}, F, kc * H, std::min(H, F - kc * H));
@@ -380,7 +417,16 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
             wprog[half].clear();
         }
     };
-    struct GroupDef { int type, c0, ns; bool mlp; };
+    struct GroupDef { int type, c0, ns; bool mlp; std::vector<int> idx; };      // idx: the group's nodes as indices inside their type (live nodes only)
+    auto make_groups = [&](int t, const bool (&sel)[64], bool mlp, std::vector<GroupDef>& out) {
+        std::vector<int> nodes;
+        for (int i = 0; i < d.type_nodes[t]; ++i) if (sel[p.type_base[t] + i]) nodes.push_back(i);
+        for (size_t c0 = 0; c0 < nodes.size(); c0 += p.gmax) {
+            GroupDef g{t, (int)c0, (int)std::min<size_t>(p.gmax, nodes.size() - c0), mlp, {}};
+            g.idx.assign(nodes.begin() + c0, nodes.begin() + c0 + g.ns);
+            out.push_back(g);
+        }
+    };
 
     for (int l = 0; l < L; ++l) {
         const double ef0 = exec_fwd, af0 = alg_fwd, eb0 = exec_bwd, ab0 = alg_bwd;
@@ -391,8 +437,7 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
         for (int t = 0; t < NT; ++t) {
             if (!p.live[l][t]) continue;
             const bool mlp = has_mlp && t == d.mlp_type;
-            for (int c0 = 0; c0 < d.type_nodes[t]; c0 += p.gmax)
-                (mlp ? mlp_g : relu_g).push_back({t, c0, std::min(p.gmax, d.type_nodes[t] - c0), mlp});
+            make_groups(t, p.live_n[l], mlp, mlp ? mlp_g : relu_g);
         }
         std::stable_sort(relu_g.begin(), relu_g.end(), [](const GroupDef& a, const GroupDef& b) { return a.ns < b.ns; });
         std::vector<GroupDef> fgroups;
@@ -407,7 +452,8 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
         T.push_back((int)fgroups.size());
         for (size_t gi = 0; gi < fgroups.size(); ++gi) {
             const GroupDef& G = fgroups[gi];
-            const int t = G.type, c0 = G.c0, ns = G.ns;
+            const int t = G.type, ns = G.ns;
+            auto slot_of = [&](int i) { for (int u = 0; u < ns; ++u) if (G.idx[u] == i) return u; return -1; };
             const int gh = (int)T.size(); T.resize(T.size() + GH_SIZE, 0);
             T[gh + GH_KIND] = G.mlp ? KIND_MLP : KIND_RELU; T[gh + GH_NSLOTS] = ns;
             T[gh + GH_BIAS] = p.bias_layer[l * NT + t];
@@ -415,22 +461,22 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
             T[gh + GH_FLAGS] = (residual ? GF_RESIDUAL : 0) | GF_STORE_MASK | (lds_epi ? GF_LDS_EPI : 0);
             if (G.mlp) { T[gh + GH_W1] = p.pack_mlp[0][0]; T[gh + GH_W2] = p.pack_mlp[0][1]; T[gh + GH_B1] = p.bias_mlp[0]; T[gh + GH_B2] = p.bias_mlp[1]; }
             for (int u = 0; u < ns; ++u) {
-                T[gh + GH_NODES + u] = p.type_base[t] + c0 + u; T[gh + GH_MLPIDX + u] = c0 + u;
-                T[gh + GH_SCR + u] = (G.mlp && p.mlp_scratch) ? p.NN + c0 + u : p.type_base[t] + c0 + u;
+                T[gh + GH_NODES + u] = p.type_base[t] + G.idx[u]; T[gh + GH_MLPIDX + u] = G.idx[u];
+                T[gh + GH_SCR + u] = (G.mlp && p.mlp_scratch) ? p.NN + G.idx[u] : p.type_base[t] + G.idx[u];
             }
             std::vector<Seg> segs;
             Seg root; root.pack = p.pack_root[0][l * NT + t];
-            for (int u = 0; u < ns; ++u) { root.macs.push_back({u, p.type_base[t] + c0 + u}); exec_fwd += NL; alg_fwd += NL; }
+            for (int u = 0; u < ns; ++u) { root.macs.push_back({u, p.type_base[t] + G.idx[u]}); exec_fwd += NL; alg_fwd += NL; }
             segs.push_back(root);
             for (int r = 0; r < NR; ++r) {
-                if (p.rel_dst[r] != t) continue;
+                if (p.rel_dst[r] != t || p.pack_rel[0][l * NR + r] < 0) continue;
                 Seg sg; sg.pack = p.pack_rel[0][l * NR + r];
                 std::vector<bool> hit(ns, false);
                 for (int e = p.rel_edge_off[r]; e < p.rel_edge_off[r + 1]; ++e) {
-                    const int j = p.edges[2 * e], i = p.edges[2 * e + 1];
-                    if (i < c0 || i >= c0 + ns) continue;
-                    sg.macs.push_back({i - c0, p.type_base[p.rel_src[r]] + j}); exec_fwd += NL;
-                    if (!hit[i - c0]) { hit[i - c0] = true; alg_fwd += NL; }
+                    const int j = p.edges[2 * e], u = slot_of(p.edges[2 * e + 1]);
+                    if (u < 0) continue;
+                    sg.macs.push_back({u, p.type_base[p.rel_src[r]] + j}); exec_fwd += NL;
+                    if (!hit[u]) { hit[u] = true; alg_fwd += NL; }
                 }
                 if (!sg.macs.empty()) segs.push_back(sg);
             }
@@ -448,37 +494,42 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
         if (mlp_live) { T[bh + BH_W2] = p.pack_mlp[1][1]; T[bh + BH_W1] = p.pack_mlp[1][0]; }
         for (int n = 0; n < p.NN; ++n) {
             const int t = p.node_type[n];
-            T[bh + BH_KIND + n] = !p.live[l][t] ? NK_DEAD : ((has_mlp && t == d.mlp_type) ? NK_MLP : NK_RELU);
+            T[bh + BH_KIND + n] = !p.live_n[l][n] ? NK_DEAD : ((has_mlp && t == d.mlp_type) ? NK_MLP : NK_RELU);
         }
         if (mlp_live) { for (int u = 0; u < p.n_mlp; ++u) T[bh + BH_MLPNODES + u] = p.type_base[d.mlp_type] + u; exec_bwd += 2 * NL * p.n_mlp; alg_bwd += 2 * NL * p.n_mlp; }
         std::vector<GroupDef> bgroups;
+        // (a group is homogeneous in "live in this layer": the residual term dX_{l+1}[n] exists for live nodes only, and the kernel's flag is per group)
+        bool need_live[64], need_dead[64];
+        for (int n = 0; n < p.NN; ++n) { need_live[n] = p.need_n[l][n] && p.live_n[l][n]; need_dead[n] = p.need_n[l][n] && !p.live_n[l][n]; }
         for (int t = 0; t < NT; ++t) {
             if (!p.need_dx[l][t]) continue;
-            for (int c0 = 0; c0 < d.type_nodes[t]; c0 += p.gmax) bgroups.push_back({t, c0, std::min(p.gmax, d.type_nodes[t] - c0), false});
+            make_groups(t, need_live, true, bgroups);       // (mlp field reused: the group's nodes are live in this layer)
+            make_groups(t, need_dead, false, bgroups);
         }
         std::stable_sort(bgroups.begin(), bgroups.end(), [](const GroupDef& a, const GroupDef& b) { return a.ns < b.ns; });
         for (size_t gi = 0; gi < bgroups.size(); ++gi) {
             const GroupDef& G = bgroups[gi];
-            const int t = G.type, c0 = G.c0, ns = G.ns;
+            const int t = G.type, ns = G.ns;
+            auto slot_of = [&](int i) { for (int u = 0; u < ns; ++u) if (G.idx[u] == i) return u; return -1; };
             const int gh = (int)T.size(); T.resize(T.size() + GH_SIZE, 0);
             T[gh + GH_KIND] = KIND_RELU; T[gh + GH_NSLOTS] = ns; T[gh + GH_BIAS] = -1;
             // at layer 0 the kernel finishes dY_enc = relu'(X_0) . (G_1 + D_0) itself: GF_RESIDUAL = add G_1
-            T[gh + GH_FLAGS] = ((residual && p.live[l][t]) ? GF_RESIDUAL : 0) | (l == 0 ? GF_ENC_MASK : 0) |
+            T[gh + GH_FLAGS] = ((residual && G.mlp) ? GF_RESIDUAL : 0) | (l == 0 ? GF_ENC_MASK : 0) |
                                (gi + 1 == bgroups.size() ? GF_LDS_EPI : 0);
-            for (int u = 0; u < ns; ++u) T[gh + GH_NODES + u] = p.type_base[t] + c0 + u;
+            for (int u = 0; u < ns; ++u) T[gh + GH_NODES + u] = p.type_base[t] + G.idx[u];
             std::vector<Seg> segs;
-            if (p.live[l][t]) {
+            if (G.mlp) {      // dX_l[n] += dH_l[n] W_rootsum: the group's nodes are live themselves
                 Seg root; root.pack = p.pack_root[1][l * NT + t];
-                for (int u = 0; u < ns; ++u) { root.macs.push_back({u, p.type_base[t] + c0 + u}); exec_bwd += NL; alg_bwd += NL; }
+                for (int u = 0; u < ns; ++u) { root.macs.push_back({u, p.type_base[t] + G.idx[u]}); exec_bwd += NL; alg_bwd += NL; }
                 segs.push_back(root);
             }
             for (int r = 0; r < NR; ++r) {
-                if (p.rel_src[r] != t || !p.live[l][p.rel_dst[r]]) continue;
+                if (p.rel_src[r] != t || p.pack_rel[1][l * NR + r] < 0) continue;
                 Seg sg; sg.pack = p.pack_rel[1][l * NR + r];
                 for (int e = p.rel_edge_off[r]; e < p.rel_edge_off[r + 1]; ++e) {
-                    const int j = p.edges[2 * e], i = p.edges[2 * e + 1];
-                    if (j < c0 || j >= c0 + ns) continue;
-                    sg.macs.push_back({j - c0, p.type_base[p.rel_dst[r]] + i}); exec_bwd += NL;
+                    const int u = slot_of(p.edges[2 * e]), i = p.edges[2 * e + 1];
+                    if (u < 0 || !p.live_n[l][p.type_base[p.rel_dst[r]] + i]) continue;
+                    sg.macs.push_back({u, p.type_base[p.rel_dst[r]] + i}); exec_bwd += NL;
                 }
                 if (!sg.macs.empty()) segs.push_back(sg);
             }
@@ -609,21 +660,23 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
                 if (mlp_live) { T[fh + FH_W1] = p.pack_mlp[0][0]; T[fh + FH_W2] = p.pack_mlp[0][1]; T[fh + FH_B1] = p.bias_mlp[0]; T[fh + FH_B2] = p.bias_mlp[1]; }
                 for (int n = 0; n < p.NN; ++n) {
                     const int t = p.node_type[n];
-                    T[fh + FH_KIND + n] = !p.live[l][t] ? NK_DEAD : ((has_mlp && t == d.mlp_type) ? NK_MLP : NK_RELU);
-                    T[fh + FH_BIAS + n] = p.live[l][t] ? p.bias_layer[l * NT + t] : 0;
+                    T[fh + FH_KIND + n] = !p.live_n[l][n] ? NK_DEAD : ((has_mlp && t == d.mlp_type) ? NK_MLP : NK_RELU);
+                    T[fh + FH_BIAS + n] = p.live_n[l][n] ? p.bias_layer[l * NT + t] : 0;
+                    if (l == 0) T[fh + FH_OUT + n] = p.need_n[0][n] ? 1 : 0;      // forward, layer 0: the X_0 rows the tile load has to bring in
                 }
                 std::vector<Seg> segs;
                 for (int t = 0; t < NT; ++t) {
                     if (!p.live[l][t]) continue;
                     Seg root; root.pack = p.pack_root[0][l * NT + t];
-                    for (int i = 0; i < d.type_nodes[t]; ++i) root.macs.push_back({p.type_base[t] + i, p.type_base[t] + i});
+                    for (int i = 0; i < d.type_nodes[t]; ++i) if (p.live_n[l][p.type_base[t] + i]) root.macs.push_back({p.type_base[t] + i, p.type_base[t] + i});
                     segs.push_back(root);
                     for (int r = 0; r < NR; ++r) {
                         if (p.rel_dst[r] != t || p.pack_rel[0][l * NR + r] < 0) continue;
                         Seg sg; sg.pack = p.pack_rel[0][l * NR + r];
                         for (int e = p.rel_edge_off[r]; e < p.rel_edge_off[r + 1]; ++e)
-                            sg.macs.push_back({p.type_base[t] + p.edges[2 * e + 1], p.type_base[p.rel_src[r]] + p.edges[2 * e]});
-                        segs.push_back(sg);
+                            if (p.live_n[l][p.type_base[t] + p.edges[2 * e + 1]])
+                                sg.macs.push_back({p.type_base[t] + p.edges[2 * e + 1], p.type_base[p.rel_src[r]] + p.edges[2 * e]});
+                        if (!sg.macs.empty()) segs.push_back(sg);
                     }
                 }
                 T[fh + FH_NSEG] = (int)segs.size();
@@ -641,24 +694,26 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
                 if (mlp_live) { T[bh2 + FH_W2] = p.pack_mlp[1][1]; T[bh2 + FH_W1] = p.pack_mlp[1][0]; }
                 for (int n = 0; n < p.NN; ++n) {
                     const int t = p.node_type[n];
-                    T[bh2 + FH_KIND + n] = !p.live[l][t] ? NK_DEAD : ((has_mlp && t == d.mlp_type) ? NK_MLP : NK_RELU);
-                    T[bh2 + FH_OUT + n] = p.need_dx[l][t] ? 1 : 0;
-                    T[bh2 + FH_RES + n] = (residual && p.live[l][t] && p.need_dx[l][t]) ? 1 : 0;
+                    T[bh2 + FH_KIND + n] = !p.live_n[l][n] ? NK_DEAD : ((has_mlp && t == d.mlp_type) ? NK_MLP : NK_RELU);
+                    T[bh2 + FH_OUT + n] = p.need_n[l][n] ? 1 : 0;
+                    T[bh2 + FH_RES + n] = (residual && p.live_n[l][n] && p.need_n[l][n]) ? 1 : 0;
                 }
                 std::vector<Seg> segs;
                 for (int t = 0; t < NT; ++t) {
                     if (!p.need_dx[l][t]) continue;
                     if (p.live[l][t]) {
                         Seg root; root.pack = p.pack_root[1][l * NT + t];
-                        for (int i = 0; i < d.type_nodes[t]; ++i) root.macs.push_back({p.type_base[t] + i, p.type_base[t] + i});
-                        segs.push_back(root);
+                        for (int i = 0; i < d.type_nodes[t]; ++i)
+                            if (p.live_n[l][p.type_base[t] + i] && p.need_n[l][p.type_base[t] + i]) root.macs.push_back({p.type_base[t] + i, p.type_base[t] + i});
+                        if (!root.macs.empty()) segs.push_back(root);
                     }
                     for (int r = 0; r < NR; ++r) {
-                        if (p.rel_src[r] != t || !p.live[l][p.rel_dst[r]] || p.pack_rel[1][l * NR + r] < 0) continue;
+                        if (p.rel_src[r] != t || p.pack_rel[1][l * NR + r] < 0) continue;
                         Seg sg; sg.pack = p.pack_rel[1][l * NR + r];
                         for (int e = p.rel_edge_off[r]; e < p.rel_edge_off[r + 1]; ++e)
-                            sg.macs.push_back({p.type_base[t] + p.edges[2 * e], p.type_base[p.rel_dst[r]] + p.edges[2 * e + 1]});
-                        segs.push_back(sg);
+                            if (p.live_n[l][p.type_base[p.rel_dst[r]] + p.edges[2 * e + 1]])      // (its source is needed by definition)
+                                sg.macs.push_back({p.type_base[t] + p.edges[2 * e], p.type_base[p.rel_dst[r]] + p.edges[2 * e + 1]});
+                        if (!sg.macs.empty()) segs.push_back(sg);
                     }
                 }
                 T[bh2 + FH_NSEG] = (int)segs.size();
@@ -673,9 +728,9 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
     // algorithmic dX work: one node-linear per (relation, src node with >=1 out-edge into a live dst) -- count below
     for (int l = 0; l < L; ++l)
         for (int r = 0; r < NR; ++r) {
-            if (!p.live[l][p.rel_dst[r]] || !p.need_dx[l][p.rel_src[r]]) continue;
+            if (p.pack_rel[0][l * NR + r] < 0) continue;
             std::vector<bool> hit(d.type_nodes[p.rel_src[r]], false);
-            for (int e = p.rel_edge_off[r]; e < p.rel_edge_off[r + 1]; ++e) hit[p.edges[2 * e]] = true;
+            for (int e = p.rel_edge_off[r]; e < p.rel_edge_off[r + 1]; ++e) if (p.live_n[l][p.type_base[p.rel_dst[r]] + p.edges[2 * e + 1]]) hit[p.edges[2 * e]] = true;
             for (bool b : hit) if (b) { alg_bwd += NL; lb_alg[l] += NL; }
         }
     const double gw_e0 = exec_bwd, gw_a0 = alg_bwd;
@@ -700,6 +755,7 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
             Tgt g; g.bias_flag = 1;
             for (int i = 0; i < d.type_nodes[t]; ++i) {
                 const int n = p.type_base[t] + i;
+                if (!p.live_n[l][n]) continue;      // dH of a dead node is zero: no contribution
                 g.items.push_back(add_item(BUF_DH + l, SN, n, BUF_X + l, SN, n, 0, H, -1));
                 if (!(has_mlp && t == d.mlp_type)) { items.back()[0] = BUF_DX + l + 1; items.back()[9] = BUF_MASK + l; }
                 exec_bwd += NL; alg_bwd += NL;
@@ -712,6 +768,7 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
             std::vector<bool> hit(d.type_nodes[p.rel_dst[r]], false);
             for (int e = p.rel_edge_off[r]; e < p.rel_edge_off[r + 1]; ++e) {
                 const int j = p.edges[2 * e], i = p.edges[2 * e + 1];
+                if (!p.live_n[l][p.type_base[p.rel_dst[r]] + i]) continue;
                 g.items.push_back(add_item(BUF_DH + l, SN, p.type_base[p.rel_dst[r]] + i,
                                            BUF_X + l, SN, p.type_base[p.rel_src[r]] + j, 0, H, -1));
                 if (!(has_mlp && p.rel_dst[r] == d.mlp_type)) { items.back()[0] = BUF_DX + l + 1; items.back()[9] = BUF_MASK + l; }
@@ -740,6 +797,7 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
             Tgt g; g.bias_flag = (kc == 0);
             const int nc = std::min(H, F - kc * H);
             for (int i = 0; i < d.type_nodes[t]; ++i) {
+                if (!p.need_n[0][p.type_base[t] + i]) continue;      // the encoder does not compute this node: its rows feed nothing
                 g.items.push_back(add_item(BUF_DX + 0, SN, p.type_base[t] + i, BUF_IN + t, -1, i, kc * H, nc,
                                            p.sign_off[t] + i * p.enc_nkc[t] * H + kc * H));
                 exec_bwd += NL; alg_bwd += 2.0 * H * nc;
@@ -749,10 +807,12 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
     }
     gw_alg = alg_bwd - gw_a0; gw_exec = exec_bwd - gw_e0;
     double enc_alg = 0, enc_exec = 0;
-    for (int t = 0; t < NT; ++t) { enc_exec += (double)d.type_nodes[t] * p.enc_nkc[t] * NL; enc_alg += (double)d.type_nodes[t] * 2.0 * H * d.type_width[t]; }
+    std::vector<int> enc_n(NT, 0);      // nodes of each type the encoder computes
+    for (int n = 0; n < p.NN; ++n) if (p.need_n[0][n]) ++enc_n[p.node_type[n]];
+    for (int t = 0; t < NT; ++t) { enc_exec += (double)enc_n[t] * p.enc_nkc[t] * NL; enc_alg += (double)enc_n[t] * 2.0 * H * d.type_width[t]; }
     for (int t = 0; t < NT; ++t) {   // encoder forward work
-        exec_fwd += (double)d.type_nodes[t] * p.enc_nkc[t] * NL;
-        alg_fwd += (double)d.type_nodes[t] * 2.0 * H * d.type_width[t];
+        exec_fwd += (double)enc_n[t] * p.enc_nkc[t] * NL;
+        alg_fwd += (double)enc_n[t] * 2.0 * H * d.type_width[t];
     }
     alg_fwd += 2.0 * n_out * d.out_channels * H; exec_fwd += 2.0 * n_out * d.out_channels * H;
     alg_bwd += 4.0 * n_out * d.out_channels * H; exec_bwd += 4.0 * n_out * d.out_channels * H;
@@ -1006,21 +1066,22 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
     // ---- info ---------------------------------------------------------------------------------------
     p.info.rows_per_tile = p.rows; p.info.total_nodes = p.NN; p.info.lds_bytes = (int64_t)p.n_blk * p.blk_bytes;
     p.info.flops_fwd = alg_fwd; p.info.flops_bwd = alg_bwd; p.info.flops_exec_fwd = exec_fwd; p.info.flops_exec_bwd = exec_bwd;
-    double bytes = 0; for (int t = 0; t < NT; ++t) bytes += (double)d.type_nodes[t] * d.type_width[t] * (p.split ? 4 : p.esize);     // split plan: fp32 inputs
-    p.info.bytes_in = bytes; p.info.n_gradw_workgroups = p.n_wg_gradw;
+    double bytes = 0, bytes_all = 0;     // split plan: fp32 inputs.  bytes: what the plan has to read (nodes whose inputs can reach the output); bytes_all: every node
+    for (int t = 0; t < NT; ++t) { bytes += (double)enc_n[t] * d.type_width[t] * (p.split ? 4 : p.esize); bytes_all += (double)d.type_nodes[t] * d.type_width[t] * (p.split ? 4 : p.esize); }
+    p.info.bytes_in = bytes_all; p.info.bytes_in_live = bytes; p.info.n_gradw_workgroups = p.n_wg_gradw;
     p.info.n_launches_fwd = 3 + L; p.info.n_launches_bwd = 3 + L;
     p.info.grad_split = p.grad_split;
     p.info.kernel_sets = (p.fused ? 1 : 0) | (p.slab ? 2 : 0);
 
     // ---- per-kernel work table (launch order of one fwd+bwd step) -----------------------------------------
     {
-        const double es = p.esize * p.planes, act = (double)p.NN * H * es;
+        const double es = p.esize * p.planes, act = (double)p.enc_live_nodes * H * es;      // X_0 rows that exist
         auto add = [&](const std::string& name, int bound, double fa, double fe, double by) {
             mshgnn_kernel_stat k{}; std::snprintf(k.name, sizeof(k.name), "%s", name.c_str());
             k.bound = bound; k.flops_per_window = fa; k.flops_exec_per_window = fe; k.bytes_per_window = by;
             p.kstats.push_back(k); return (int)p.kstats.size() - 1; };
-        auto live_nodes = [&](int l) { int n = 0; for (int t = 0; t < NT; ++t) if (p.live[l][t]) n += d.type_nodes[t]; return n; };
-        auto need_nodes = [&](int l) { int n = 0; for (int t = 0; t < NT; ++t) if (p.need_dx[l][t]) n += d.type_nodes[t]; return n; };
+        auto live_nodes = [&](int l) { int n = 0; for (int i = 0; i < p.NN; ++i) n += p.live_n[l][i] ? 1 : 0; return n; };
+        auto need_nodes = [&](int l) { int n = 0; for (int i = 0; i < p.NN; ++i) n += p.need_n[l][i] ? 1 : 0; return n; };
         p.ks_prep = add("prep", MSHGNN_BOUND_HBM, 0, 0, 0);
         p.ks_enc = add("enc_fwd", d.dtype == MSHGNN_F32 ? MSHGNN_BOUND_MFMA : MSHGNN_BOUND_HBM, enc_alg, enc_exec, bytes + act);
         for (int l = 0; l < L; ++l) {

@@ -45,7 +45,7 @@ class MshgnnInfo(C.Structure):
         ("rows_per_tile", C.c_int32), ("total_nodes", C.c_int32), ("lds_bytes", C.c_int64),
         ("flops_fwd", C.c_double), ("flops_bwd", C.c_double), ("flops_exec_fwd", C.c_double), ("flops_exec_bwd", C.c_double),
         ("bytes_in", C.c_double), ("n_gradw_workgroups", C.c_int32), ("n_launches_fwd", C.c_int32), ("n_launches_bwd", C.c_int32),
-        ("kernel_sets", C.c_int32), ("grad_split", C.c_int64),
+        ("kernel_sets", C.c_int32), ("grad_split", C.c_int64), ("bytes_in_live", C.c_double),
     ]
 
 

@@ -135,6 +135,50 @@ class ModelSpec:
             live = nxt
         return [t for t in self.node_types if t in live]
 
+    def node_liveness(self):
+        """Node-level liveness, the mirror of the plan compiler's (csrc/mshgnn_plan.hpp): returns (live, need) with
+        live[l][t] = the nodes of type t (indices inside the type) whose output of layer l can reach the decoder, and need[l][t] = the nodes whose
+        X_l is an input of a live node of layer l (need[0] = what the encoder has to compute; need[l] == live[l - 1] for l >= 1).  X_{l+1}[n] is needed
+        iff n itself is live in layer l + 1 (root weight, residual) or has an edge into a node that is; the base_transform type is live as a whole.
+        A1-C2 at 3 layers: the base nodes are four hops from the feet -- nothing of them is live, in the reference either (49 of its 84 parameter
+        tensors get exact-zero gradients).  MSHGNN_PRUNE=0 (read like the plan compiler does): whole types, the liveness of rounds 1-3."""
+        import os
+        prune = os.environ.get("MSHGNN_PRUNE", "1") != "0"
+        types, L = self.node_types, self.num_layers
+        rels = [(s, d, self.topology.edges(et)) for et in self.edge_types for s, _, d in [et]]
+
+        def widen(sel):
+            for t in types:
+                if prune and not (self.has_base_transform and t == "base"):
+                    continue
+                if sel[t]:
+                    sel[t] = set(range(self.num_nodes[t]))
+
+        def inputs_of(out):
+            inp = {t: set(out[t]) for t in types}
+            for s, d, edges in rels:
+                for j, i in edges:
+                    if i in out[d]:
+                        inp[s].add(j)
+                if not prune and out[d]:
+                    inp[s] = set(range(self.num_nodes[s]))
+            return inp
+
+        live = [None] * L
+        need = [None] * L
+        cur = {t: (set(range(self.num_nodes[t])) if t == self.out_type else set()) for t in types}
+        for l in range(L - 1, -1, -1):
+            widen(cur)
+            live[l] = {t: set(cur[t]) for t in types}
+            need[l] = inputs_of(live[l])
+            if l == 0:
+                widen(need[0])
+            cur = {t: set(need[l][t]) for t in types}
+        for l in range(1, L):
+            need[l] = {t: set(live[l - 1][t]) for t in types}
+        srt = lambda dd: {t: sorted(v) for t, v in dd.items()}
+        return [srt(x) for x in live], [srt(x) for x in need]
+
     # ---- parameters ------------------------------------------------------------------------
     def param_shapes(self) -> "OrderedDict[str, Tuple[int, ...]]":
         """state_dict names -> shapes, in module registration order."""

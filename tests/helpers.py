@@ -139,6 +139,8 @@ def engine_relu_decisions(e, spec, B):
         return bits.permute(2, 4, 0, 1, 3, 5).reshape(tiles * 16, nn_, h)[:B].bool()  # [B, NN, 128]
 
     out = {}
+    # (a node the plan does not compute -- spec.node_liveness -- has no decision: its rows of the relu bytes are unwritten memory; run_engine_case
+    #  gives the oracle the exact decision there, row_live_mask says which rows are real)
     m0 = from_bytes(lay.dd[0])
     for t in spec.node_types:
         out[("enc", t)] = m0[:, sl[t]].reshape(-1, h)
@@ -147,7 +149,7 @@ def engine_relu_decisions(e, spec, B):
         for t in spec.live_types(l):
             if not (spec.has_base_transform and t == "base"):
                 out[("layer", l, t)] = ml[:, sl[t]].reshape(-1, h)
-        if spec.has_base_transform and "base" in spec.live_types(l):
+        if spec.has_base_transform and spec.node_liveness()[0][l]["base"]:
             nb = spec.num_nodes["base"]
             n = nb * B * h
             if e.storage == "x3":
@@ -156,6 +158,20 @@ def engine_relu_decisions(e, spec, B):
                 t1 = ws[lay.t1[l]:lay.t1[l] + n * (4 if e.storage == "f32" else 2)].view(torch.float32 if e.storage == "f32" else torch.bfloat16).view(nb, B, h)
             out[("t1", l)] = (t1.permute(1, 0, 2).reshape(-1, h).float() > 0).cpu()
     return out
+
+
+def row_live_mask(spec, key, B):
+    """bool [B * n_type] for a decision key of engine_relu_decisions: True where the engine really took that decision (the node is computed by the plan)."""
+    live, need = spec.node_liveness()
+    if key[0] == "enc":
+        t, nodes = key[1], need[0][key[1]]
+    elif key[0] == "layer":
+        t, nodes = key[2], live[key[1]][key[2]]
+    else:      # ("t1", l): the base_transform nodes of layer l
+        t, nodes = "base", live[key[1]]["base"]
+    m = torch.zeros(spec.num_nodes[t], dtype=torch.bool)
+    m[list(nodes)] = True
+    return m.repeat(B)
 
 
 def run_engine_case(spec, x_dict, y, params, ei, B, dtype="f32", device="cuda:0", decision_tol=1e-4):
@@ -181,7 +197,8 @@ def run_engine_case(spec, x_dict, y, params, ei, B, dtype="f32", device="cuda:0"
     def relu_fn(key, h):
         if key not in decisions:
             return torch.relu(h)
-        m = decisions[key]
+        rows = row_live_mask(spec, key, B).view(-1, 1)
+        m = torch.where(rows, decisions[key], h.detach() > 0)      # nodes the plan does not compute: the exact decision (they cannot reach the output)
         diff = m != (h.detach() > 0)
         if bool(diff.any()):
             stats["differ"] += int(diff.sum())
@@ -206,9 +223,12 @@ def run_engine_case(spec, x_dict, y, params, ei, B, dtype="f32", device="cuda:0"
     for l in range(spec.num_layers + 1):
         got = e.hidden_state(B, l)
         ref = dense_hidden(spec, o_hidden[l], B)
-        live = spec.node_types if l == 0 else spec.live_types(l - 1)
-        for t in live:
-            errs[f"X{l}[{t}]"] = rel(got[:, sl[t]], ref[:, sl[t]])
+        liv, need = spec.node_liveness()
+        nodes = need[0] if l == 0 else liv[l - 1]      # the nodes of X_l the plan computes
+        for t in spec.node_types:
+            if nodes[t]:
+                idx = torch.tensor(nodes[t]) + sl[t].start
+                errs[f"X{l}[{t}]"] = rel(got[:, idx], ref[:, idx])
     errs["out"] = rel(out.view(-1), o_out.detach().reshape(-1))
     # loss + grad seed: regression uses the engine's fused MSE, classification seeds from the oracle's CE grad
     if spec.regression:

@@ -21,12 +21,22 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.mshgnn_version()
 
 
-def test_plan_compiler_work_counts():
-    # A1-C2 h=128 L=3: encoder 1 844 224 + (52 + 40 + 8) live node-linears * 32 768 + decoder 3 072 FLOP / window
+def test_plan_compiler_work_counts(monkeypatch):
+    # A1-C2 h=128 L=3 with type-level liveness (MSHGNN_PRUNE=0, rounds 1-3): encoder 1 844 224 + (52 + 40 + 8) live node-linears * 32 768 + decoder 3 072 FLOP / window
+    monkeypatch.setenv("MSHGNN_PRUNE", "0")
     info = engine.compile_plan_host(helpers.make_spec("c2", "a1-c2", "a1-c2", 128, 3), "f32")
     assert info.rows_per_tile == 16 and info.total_nodes == 18 and info.lds_bytes == 20 * 8192   # 18 node blocks + 2 base_transform scratch
     assert info.flops_fwd == 1844224 + 100 * 32768 + 3072
-    assert info.bytes_in == 7204 * 4
+    assert info.bytes_in == 7204 * 4 and info.bytes_in_live == 7204 * 4
+    # node-level liveness (the default): at 3 layers the base nodes are four hops from the feet -- the encoder runs on the 12 joints + 4 feet, layer 0
+    # on thighs, knees and feet (8 + 12 + 8 node-linears), layer 1 on knees and feet (12 + 8), layer 2 on the feet (8)
+    monkeypatch.delenv("MSHGNN_PRUNE")
+    info = engine.compile_plan_host(helpers.make_spec("c2", "a1-c2", "a1-c2", 128, 3), "f32")
+    assert info.flops_fwd == 2 * 128 * (12 * 450 + 4) + (28 + 20 + 8) * 32768 + 3072
+    assert info.bytes_in == 7204 * 4 and info.bytes_in_live == (12 * 450 + 4) * 4
+    # the paper's depth: everything is live in the first four layers
+    info8 = engine.compile_plan_host(helpers.make_spec("c2", "a1-c2", "a1-c2", 128, 8), "f32")
+    assert info8.bytes_in_live == info8.bytes_in == 7204 * 4
     info16 = engine.compile_plan_host(helpers.make_spec("c2", "a1-c2", "a1-c2", 128, 3), "bf16")
     assert info16.rows_per_tile == 16 and info16.bytes_in == 7204 * 2 and info16.lds_bytes == 20 * 4096
     k4 = engine.compile_plan_host(helpers.make_spec("k4", "mini_cheetah-k4", "mini_cheetah-k4", 128, 8, regression=False), "f32")
