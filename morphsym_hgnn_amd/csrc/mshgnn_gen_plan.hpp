@@ -154,21 +154,46 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
         p.out_mask_f[i] = d.out_mask[i];
     }
 
-    // ---- liveness (as mshgnn_plan.hpp: outputs of the last layer are read on the decoder's type only) -------------------------
-    for (int t = 0; t < NT; ++t) p.live[L - 1][t] = (t == d.out_type);
-    for (int l = L - 2; l >= 0; --l)
-        for (int t = 0; t < NT; ++t) {
-            bool v = p.live[l + 1][t];
-            for (int r = 0; r < NR; ++r) if (p.rel_src[r] == t && p.live[l + 1][p.rel_dst[r]]) v = true;
-            p.live[l][t] = v;
+    // ---- liveness, node level (as mshgnn_plan.hpp, round 4): live_n[l][n] -- the output of layer l at node n can reach the decoder; need_n[l][n] -- X_l[n]
+    // feeds a live node of layer l (itself: root weight / residual; or a destination of one of its edges), so dX_l[n] is produced; need_n[0] = the nodes
+    // the encoder computes.  MSHGNN_PRUNE=0: whole types, as in rounds 1-3.  The base_transform type is live as a whole.
+    const bool prune = []() { const char* e = std::getenv("MSHGNN_PRUNE"); return !(e && std::atoi(e) == 0); }();
+    std::vector<std::vector<char>> live_n(L, std::vector<char>(p.NN, 0)), need_n(L, std::vector<char>(p.NN, 0));
+    {
+        auto widen = [&](std::vector<char>& v) {
+            for (int t = 0; t < NT; ++t) {
+                if (prune && !(has_mlp && t == d.mlp_type)) continue;
+                bool any = false;
+                for (int i = 0; i < d.type_nodes[t]; ++i) any = any || v[p.type_base[t] + i];
+                if (any) for (int i = 0; i < d.type_nodes[t]; ++i) v[p.type_base[t] + i] = 1;
+            }
+        };
+        for (int n = 0; n < p.NN; ++n) live_n[L - 1][n] = p.node_type[n] == d.out_type;
+        for (int l = L - 1; l >= 0; --l) {
+            widen(live_n[l]);
+            need_n[l] = live_n[l];
+            for (int r = 0; r < NR; ++r) {
+                bool dl = false;
+                for (int i = 0; i < d.type_nodes[p.rel_dst[r]]; ++i) {
+                    if (!live_n[l][p.type_base[p.rel_dst[r]] + i]) continue;
+                    dl = true;
+                    for (int j : in_src[r][i]) need_n[l][p.type_base[p.rel_src[r]] + j] = 1;
+                }
+                if (!prune && dl) for (int j = 0; j < d.type_nodes[p.rel_src[r]]; ++j) need_n[l][p.type_base[p.rel_src[r]] + j] = 1;
+            }
+            if (l == 0) widen(need_n[0]);
+            if (l > 0) live_n[l - 1] = need_n[l];
         }
-    for (int l = 0; l < L; ++l)
-        for (int t = 0; t < NT; ++t) {
-            if (l >= 1) { p.need_dx[l][t] = p.live[l - 1][t]; continue; }
-            bool v = p.live[0][t];
-            for (int r = 0; r < NR; ++r) if (p.rel_src[r] == t && p.live[0][p.rel_dst[r]]) v = true;
-            p.need_dx[0][t] = v;
-        }
+        for (int l = 1; l < L; ++l) need_n[l] = live_n[l - 1];
+        for (int l = 0; l < L; ++l)
+            for (int t = 0; t < NT; ++t) {
+                p.live[l][t] = p.need_dx[l][t] = false;
+                for (int i = 0; i < d.type_nodes[t]; ++i) { p.live[l][t] = p.live[l][t] || live_n[l][p.type_base[t] + i]; p.need_dx[l][t] = p.need_dx[l][t] || need_n[l][p.type_base[t] + i]; }
+            }
+    }
+    auto rel_live = [&](int l, int r) {      // relation r has an edge into a live node of layer l
+        for (int i = 0; i < d.type_nodes[p.rel_dst[r]]; ++i) if (live_n[l][p.type_base[p.rel_dst[r]] + i] && !in_src[r][i].empty()) return true;
+        return false; };
 
     // ---- packs: a [rows x K] weight becomes ceil(K/128) x NCT(rows) images of 128x128, pack(kc, ct) = base + kc * nct + ct ------------
     // orient 0 (forward, out = A W^T):   B[k][c] = W[ct*128 + c][kc*128 + k]     orient 1 (backward, dA = dH W):   B[k][c] = W[kc*128 + k][ct*128 + c]
@@ -201,7 +226,7 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
             bias_layer[l * NT + t] = add_bias(bs);
         }
         for (int r = 0; r < NR; ++r) {
-            if (!p.live[l][p.rel_dst[r]] || p.rel_edge_off[r + 1] == p.rel_edge_off[r]) continue;
+            if (!rel_live(l, r)) continue;
             pack_rel[0][l * NR + r] = add_packs(0, {p.off_rel_w[l * NR + r]}, Hd, Hd);
             pack_rel[1][l * NR + r] = add_packs(1, {p.off_rel_w[l * NR + r]}, Hd, Hd);
         }
@@ -210,7 +235,7 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
         for (int o = 0; o < 2; ++o) { pack_mlp[o][0] = add_packs(o, {d.off_mlp[0]}, Hd, Hd); pack_mlp[o][1] = add_packs(o, {d.off_mlp[2]}, Hd, Hd); }
         bias_mlp[0] = add_bias({d.off_mlp[1]}); bias_mlp[1] = add_bias({d.off_mlp[3]});
     }
-    for (int t = 0; t < NT; ++t) { pack_enc[t] = add_packs(0, {p.off_enc_w[t]}, Hd, d.type_width[t]); bias_enc[t] = add_bias({p.off_enc_b[t]}); }
+    for (int t = 0; t < NT; ++t) if (p.need_dx[0][t]) { pack_enc[t] = add_packs(0, {p.off_enc_w[t]}, Hd, d.type_width[t]); bias_enc[t] = add_bias({p.off_enc_b[t]}); }
     p.n_img = (int)p.packs.size();
 
     // ---- job tables ---------------------------------------------------------------------------------------------------
@@ -235,7 +260,11 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
         k.bound = bound; k.flops_per_window = fa; k.flops_exec_per_window = fa; k.bytes_per_window = by;
         p.kstats.push_back(k); return (int)p.kstats.size() - 1; };
     const double es = (double)p.esize * p.planes, in_es = p.split ? 4.0 : 2.0;
-    double bytes_in = 0; for (int t = 0; t < NT; ++t) bytes_in += (double)d.type_nodes[t] * d.type_width[t] * in_es;
+    double bytes_in = 0, bytes_in_live = 0;
+    for (int t = 0; t < NT; ++t) {
+        bytes_in += (double)d.type_nodes[t] * d.type_width[t] * in_es;
+        for (int i = 0; i < d.type_nodes[t]; ++i) if (need_n[0][p.type_base[t] + i]) bytes_in_live += (double)d.type_width[t] * in_es;
+    }
     p.ks_prep = stat("prep", MSHGNN_BOUND_HBM, 0, 0);
     std::vector<int32_t> aggs;
     int agg_mark = 0;      // first aggregate op of the launch being built
@@ -265,6 +294,7 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
         const int j0 = (int)(jobs.size() / JOB_INTS); double fl = 0;
         for (int t = 0; t < NT; ++t)
             for (int i = 0; i < d.type_nodes[t]; ++i) {
+                if (!need_n[0][p.type_base[t] + i]) continue;      // its X_0 feeds nothing that reaches the decoder
                 TermDef td{pack_enc[t], p.enc_nkc[t], 1, d.type_width[t], p.sign_off[t] + i * p.enc_nkc[t] * TW, {std::array<int, 4>{t, i, -1, fbits(1.0f)}}};
                 add_job(BUF_X + 0, p.type_base[t] + i, JF_BIAS | JF_RELU | JF_BITS_OUT, bias_enc[t], -1, 0, GBUF_MASK0, -1, 0, {td});
                 fl += 2.0 * Hd * d.type_width[t];
@@ -281,6 +311,7 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
             const bool mlp = has_mlp && t == d.mlp_type;
             for (int i = 0; i < d.type_nodes[t]; ++i) {
                 const int n = p.type_base[t] + i;
+                if (!live_n[l][n]) continue;
                 std::vector<TermDef> tds;
                 tds.push_back({pack_root[0][l * NT + t], NCT, 0, Hd, 0, {one(BUF_X + l, n)}});
                 for (int r = 0; r < NR; ++r) {
@@ -339,17 +370,19 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
             if (!p.need_dx[l][s]) continue;
             for (int j = 0; j < d.type_nodes[s]; ++j) {
                 const int n = p.type_base[s] + j;
+                if (!need_n[l][n]) continue;
                 std::vector<TermDef> tds;
-                if (p.live[l][s]) tds.push_back({pack_root[1][l * NT + s], NCT, 0, Hd, 0, {dh_src(l, n)}});
+                if (live_n[l][n]) tds.push_back({pack_root[1][l * NT + s], NCT, 0, Hd, 0, {dh_src(l, n)}});
                 for (int r = 0; r < NR; ++r) {
-                    if (p.rel_src[r] != s || !p.live[l][p.rel_dst[r]] || out_dst[r][j].empty()) continue;
+                    if (p.rel_src[r] != s || pack_rel[1][l * NR + r] < 0 || out_dst[r][j].empty()) continue;
                     TermDef td{pack_rel[1][l * NR + r], NCT, 0, Hd, 0, {}};
-                    for (int i : out_dst[r][j]) td.s.push_back(dh_src(l, p.type_base[p.rel_dst[r]] + i, scale_of(r, i)));
+                    for (int i : out_dst[r][j]) if (live_n[l][p.type_base[p.rel_dst[r]] + i]) td.s.push_back(dh_src(l, p.type_base[p.rel_dst[r]] + i, scale_of(r, i)));
+                    if (td.s.empty()) continue;
                     td.s = many(td.s, 1, l, true);
                     tds.push_back(td);
                 }
                 fl += NL * tds.size();
-                const bool res = residual && p.live[l][s];
+                const bool res = residual && live_n[l][n];
                 add_job(BUF_DX + l, n, (res ? JF_RES : 0) | (l == 0 ? JF_GATE_BITS : 0), 0, BUF_DX + l + 1, n, -1, GBUF_MASK0, n, tds);
             }
         }
@@ -372,7 +405,7 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
         for (int t = 0; t < NT; ++t) {
             if (!p.live[l][t]) continue;
             Tgt g{Hd, Hd, {}, true};
-            for (int i = 0; i < d.type_nodes[t]; ++i) { const int n = p.type_base[t] + i; new_item(g, dh_src(l, n), 0, {one(BUF_X + l, n)}); gw_fl += NL; }
+            for (int i = 0; i < d.type_nodes[t]; ++i) { const int n = p.type_base[t] + i; if (!live_n[l][n]) continue; new_item(g, dh_src(l, n), 0, {one(BUF_X + l, n)}); gw_fl += NL; }
             tgt_root[l * NT + t] = (int)tgts.size(); tgts.push_back(g);
         }
         for (int r = 0; r < NR; ++r) {
@@ -380,7 +413,7 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
             Tgt g{Hd, Hd, {}, false};
             const int t = p.rel_dst[r];
             for (int i = 0; i < d.type_nodes[t]; ++i) {
-                if (in_src[r][i].empty()) continue;
+                if (in_src[r][i].empty() || !live_n[l][p.type_base[t] + i]) continue;
                 std::vector<std::array<int, 4>> qs;
                 for (int j : in_src[r][i]) qs.push_back(one(BUF_X + l, p.type_base[p.rel_src[r]] + j, -1, scale_of(r, i)));
                 new_item(g, dh_src(l, p.type_base[t] + i), 0, many(qs, 0, l, false)); gw_fl += NL;      // (the forward pass left the sum of many rows in its aggregate buffer)
@@ -404,6 +437,7 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
         if (!p.need_dx[0][t]) continue;
         Tgt g{Hd, d.type_width[t], {}, true};
         for (int i = 0; i < d.type_nodes[t]; ++i) {
+            if (!need_n[0][p.type_base[t] + i]) continue;
             new_item(g, one(BUF_DX + 0, p.type_base[t] + i), 1, {std::array<int, 4>{t, i, p.sign_off[t] + i * p.enc_nkc[t] * TW, 0}});
             gw_fl += 2.0 * Hd * d.type_width[t];
         }
@@ -588,7 +622,7 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
 
     p.info.rows_per_tile = 64; p.info.total_nodes = p.NN; p.info.lds_bytes = 4 * 4096 * p.planes;
     p.info.flops_fwd = alg_fwd; p.info.flops_bwd = alg_bwd; p.info.flops_exec_fwd = exec_fwd; p.info.flops_exec_bwd = exec_bwd;
-    p.info.bytes_in = bytes_in; p.info.bytes_in_live = bytes_in; p.info.n_gradw_workgroups = p.n_sunits * p.n_parts;
+    p.info.bytes_in = bytes_in; p.info.bytes_in_live = bytes_in_live; p.info.n_gradw_workgroups = p.n_sunits * p.n_parts;
     p.info.n_launches_fwd = 2 + (int)p.fwd.size(); p.info.n_launches_bwd = 3 + (int)p.bwd.size();
     p.info.kernel_sets = 4;      // bit 2: generic-width engine
     p.info.grad_split = -1;
