@@ -76,7 +76,8 @@ def test_base_node_of_many_limbs_goes_through_the_aggregate_launch(dtype):
     from morphsym_hgnn_amd import engine as eng, synth, topology
     from morphsym_hgnn_amd.spec import ModelSpec
     topo = topology.synthetic_limbs(40)
-    spec = ModelSpec(kind="mi", topology=topo, hidden=128, num_layers=3, widths=synth.feature_widths("mi", True), regression=True, grf_dimension=1)
+    # (5 layers: the base node is four hops from the feet, so it is live -- and its 40-row sums exist -- in the first layer only from that depth on)
+    spec = ModelSpec(kind="mi", topology=topo, hidden=128, num_layers=5, widths=synth.feature_widths("mi", True), regression=True, grf_dimension=1)
     B = 19
     n_y = spec.out_channels * spec.num_nodes[spec.out_type]
     x_dict, y = synth.make_windows(21, B, spec.num_nodes, spec.widths, n_y)
