@@ -630,7 +630,14 @@ def main():
         sf = SURVEY_8D["flops_L3" if L == 3 else "flops_L8"] * B
         roof["step"] = {"algorithmic_bytes": sb, "hbm_frac": sb / step_s / 1e9 / PEAK["hbm_GBs"],
                         "algorithmic_flops": sf, "mfma_frac": sf / step_s / 1e12 / PEAK["mfma_TFLOPs"][args.dtype],
-                        "note": "SURVEY 8(d) per-window figures x windows / measured step time"}
+                        "note": "SURVEY 8(d) per-window figures x windows / measured step time (they count every node; see step_live)"}
+        # what the plan really has to touch: inputs of the nodes that can reach the output at this depth (twice), FLOPs of the live nodes only
+        lb = 2.0 * float(wl.e.info.bytes_in_live) * B
+        lf = (wl.e.info.flops_fwd + wl.e.info.flops_bwd) * B
+        roof["step_live"] = {"algorithmic_bytes": lb, "hbm_frac": lb / step_s / 1e9 / PEAK["hbm_GBs"],
+                             "algorithmic_flops": lf, "mfma_frac": lf / step_s / 1e12 / PEAK["mfma_TFLOPs"][args.dtype],
+                             "note": "the same with node-level liveness: only nodes whose values can reach the decoder at this depth (A1-C2 at 3 layers: "
+                                     "not the base nodes -- four hops from the feet; the reference computes them and gets exact-zero gradients)"}
     kernels = {s["name"]: round(s["total_ms"] / s["launches"] * 1e3, 2) for s in stats}
 
     names = {"a1c2": "A1-C2 GRF regression (3-D)", "mck4": "MiniCheetah-K4 contact classification", "solo": "Solo-12 K4 centroidal-momentum regression (COM_HGNN_K4)",
@@ -652,6 +659,10 @@ def main():
         "algorithmic_flops_per_window": wl.e.info.flops_fwd + wl.e.info.flops_bwd,
         "loss": loss,
     }
+    res["liveness"] = {"node_level": os.environ.get("MSHGNN_PRUNE", "1") != "0",
+                       "input_bytes_per_window": float(wl.e.info.bytes_in), "live_input_bytes_per_window": float(wl.e.info.bytes_in_live),
+                       "what": "nodes whose output cannot reach the decoder within the model's depth are not computed (exact: the reference gives "
+                               "their parameters zero gradients); MSHGNN_PRUNE=0 computes every node of every live type as rounds 1-3 did"}
     extras = rank == 0 and world == 1 and not args.no_extras and args.config == "a1c2" and args.surface == "flat" and hidden == 128
     if rank == 0 and world == 1 and not args.no_extras and args.config == "mck4" and args.dtype == "bf16" and args.surface == "flat" and hidden == 128:
         del wl
@@ -686,6 +697,18 @@ def main():
         if args.dtype == "bf16" and L == 3:
             res["end_to_end"] = end_to_end(spec, B, device, args.steps, args.warmup)
             torch.cuda.empty_cache()
+        if os.environ.get("MSHGNN_PRUNE", "1") != "0":      # the same workload with every node of every live type computed (type-level liveness, rounds 1-3)
+            os.environ["MSHGNN_PRUNE"] = "0"
+            try:
+                wu = Workload(spec, args.dtype, B, device, 1234)
+                mu, _ = wu.time_blocks(args.steps, args.warmup, args.min_time / 2)
+                ku = {s_["name"]: round(s_["total_ms"] / s_["launches"] * 1e3, 2) for s_ in wu.kernel_stats(args.steps)}
+                res["liveness"]["all_nodes_computed"] = {"ms_per_step": mu / args.steps * 1e3, "value": B * args.steps / mu, "kernel_us": ku,
+                                                         "algorithmic_flops_per_window": wu.e.info.flops_fwd + wu.e.info.flops_bwd}
+                del wu
+                torch.cuda.empty_cache()
+            finally:
+                del os.environ["MSHGNN_PRUNE"]
         if L != 8:      # the paper's depth (train_regression-grf_msgn.py:94)
             w8 = Workload(build_spec(8, args.config, hidden), args.dtype, B, device, 1234)
             m8, _ = w8.time_blocks(args.steps, args.warmup, args.min_time / 2)
