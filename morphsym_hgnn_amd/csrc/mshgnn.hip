@@ -2253,11 +2253,11 @@ int launch_prep(const PrepArgs& a, bool split, hipStream_t st) {
 }
 
 int run_finalize(const mshgnn_plan* p, const mshgnn_ws_layout& lay, char* ws, float* gparams, int B, float* loss, bool is_ce, bool dec_done,
-                 int gw_phase, hipStream_t st) {
+                 int gw_phase, hipStream_t st, int gw_parts) {
     const HostPlan& hp = p->hp;
     const mshgnn_desc& d = hp.d;
     FinArgs a{p->d_tables + hp.fin_off, p->d_tables + hp.fin_off, p->d_tables + hp.tgt_off, reinterpret_cast<const float*>(ws + lay.slabs),
-              reinterpret_cast<const float*>(ws + lay.dec_slabs), gparams, hp.n_lanes, hp.n_parts, loss,
+              reinterpret_cast<const float*>(ws + lay.dec_slabs), gparams, hp.n_lanes, gw_parts, loss,
               1.0f / (float)((int64_t)B * d.type_nodes[d.out_type] * (is_ce ? 1 : d.out_channels)),
               dec_done ? (int)((B + TILE_ROWS - 1) / TILE_ROWS) : NWG_DEC};
     int f0 = 0, nf = hp.n_fin;
@@ -2479,6 +2479,7 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
         ProfScope ps(p, hp.ks_layer_bwd0 + (hp.L - 1 - l), st);
         hipLaunchKernelGGL(k_layer_bwd<T>, dim3(tiles), dim3(LAYER_THREADS), hp.n_blk * Prec<T>::BLK, st, a);
     }
+    const int gw_parts = gw_parts_for(hp.n_parts, hp.n_lanes, B, sizeof(T) == 4 ? GW_KW : GWB_KW, p->n_cu);      // window parts of this batch's weight-gradient launch (<= the plan's)
     {
         GradwArgs a{};
         a.ws = ws;
@@ -2494,21 +2495,21 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
         if (series) a.ser = *series;
         a.items = p->d_tables + hp.item_off; a.lanes = p->d_tables + hp.lane_off; a.lane_order = p->d_tables + hp.lane_order_off; a.n_pad = hp.n_lanes_pad;
         if (gw_phase >= 0) { a.lane_order = p->d_tables + hp.order_ph_off[gw_phase]; a.n_pad = hp.npad_ph[gw_phase]; }
-        a.signs = p->d_signs; a.slabs = reinterpret_cast<float*>(ws + lay.slabs); a.B = B; a.n_lanes = hp.n_lanes; a.n_parts = hp.n_parts;
+        a.signs = p->d_signs; a.slabs = reinterpret_cast<float*>(ws + lay.slabs); a.B = B; a.n_lanes = hp.n_lanes; a.n_parts = gw_parts;
         a.dbg = p->dbg_gw;
         a.stamps = stamp_ptr("MSHGNN_STAMPS_GW");
         ProfScope ps(p, hp.ks_gradw, st);
         if (a.n_pad > 0) {
             static const bool gw_general = getenv("MSHGNN_GRADW") && std::string(getenv("MSHGNN_GRADW")) == "general";   // read once: the general kernel also where the lean one applies (A/B runs)
-            if constexpr (sizeof(T) == 4) hipLaunchKernelGGL(k_gradw_f32, dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a);
-            else if (gw_general && hp.gw_ipl == 1) hipLaunchKernelGGL(k_gradw_bf16<1>, dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a);
-            else if (gw_general && hp.gw_ipl == 2) hipLaunchKernelGGL(k_gradw_bf16<2>, dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a);
-            else if (series) hipLaunchKernelGGL((k_gradw_bf16_lean<true, true>), dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a);      // raw operands from the series
-            else if (a.aligned) hipLaunchKernelGGL(k_gradw_bf16_lean<true>, dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL(k_gradw_bf16_lean<false>, dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a);
+            if constexpr (sizeof(T) == 4) hipLaunchKernelGGL(k_gradw_f32, dim3(a.n_pad * gw_parts), dim3(256), 0, st, a);
+            else if (gw_general && hp.gw_ipl == 1) hipLaunchKernelGGL(k_gradw_bf16<1>, dim3(a.n_pad * gw_parts), dim3(256), 0, st, a);
+            else if (gw_general && hp.gw_ipl == 2) hipLaunchKernelGGL(k_gradw_bf16<2>, dim3(a.n_pad * gw_parts), dim3(256), 0, st, a);
+            else if (series) hipLaunchKernelGGL((k_gradw_bf16_lean<true, true>), dim3(a.n_pad * gw_parts), dim3(256), 0, st, a);      // raw operands from the series
+            else if (a.aligned) hipLaunchKernelGGL(k_gradw_bf16_lean<true>, dim3(a.n_pad * gw_parts), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL(k_gradw_bf16_lean<false>, dim3(a.n_pad * gw_parts), dim3(256), 0, st, a);
         }
     }
-    return run_finalize(p, lay, ws, gparams, B, (y || labels) ? loss : nullptr, labels != nullptr, dec_done, gw_phase, st);
+    return run_finalize(p, lay, ws, gparams, B, (y || labels) ? loss : nullptr, labels != nullptr, dec_done, gw_phase, st, gw_parts);
 }
 
 extern "C" int mshgnn_forward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, float* out,

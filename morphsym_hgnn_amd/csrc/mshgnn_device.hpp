@@ -1042,9 +1042,29 @@ inline int vec_bytes(const void* base, int64_t pitch_elems, int esize) {
 
 
 
+// Window parts of a weight-gradient launch for THIS batch: at most the plan's n_parts (the slab buffer is sized for it).  A launch lasts as long as its
+// longest part, a part's steps slow down with the number of workgroups that stream beside it, and a grid that needs (nearly) three workgroups on EVERY CU
+// runs into the placement's slack.  Measured (round 4, A1-C2 pruned plan, 56 lanes of 2 items, 8192 windows = 128 chunks): 13 parts = 728 workgroups 89 us,
+// 12 parts 71.8, 11: 73.6, 10: 74.9, 9: 81.4, 8 (16 chunks each, 448 workgroups): 69.2, 7: 76.0, 6: 83.3; MiniCheetah-K4 L=3 (128 lanes): 6 parts = 768
+// workgroups 92 us, 5 parts 76.5, 4 parts 81.8.  Model fitted to those: time ~ ceil(chunks / q) x (137.5 + lanes q) -- a fixed latency per step plus a
+// bandwidth share --, with the grid kept at or below 2.8 workgroups per CU.
+inline int gw_parts_for(int plan_parts, int lanes, int64_t B, int chunk_windows, int n_cu) {
+    static const int forced = [] { const char* e = getenv("MSHGNN_GW_PARTS"); return e ? atoi(e) : 0; }();      // (measurements)
+    if (forced > 0) return std::min(forced, plan_parts);
+    const int64_t nchunks = (B + chunk_windows - 1) / chunk_windows;
+    const int cap_wg = 45 * std::max(1, n_cu) / 16;                                         // 720 on 256 CUs
+    const int qmax = std::max(1, std::min(plan_parts, cap_wg / std::max(1, lanes)));
+    int best = 1; double best_cost = -1;
+    for (int q = 1; q <= qmax; ++q) {
+        const double cost = (double)((nchunks + q - 1) / q) * (137.5 + (double)lanes * q);
+        if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best = q; }      // ties: the larger q
+    }
+    return best;
+}
+
 // k_finalize launch of a step (mshgnn.hip): fixed-order slab sums -> flat gradient (+ fused loss)
 int run_finalize(const mshgnn_plan* p, const mshgnn_ws_layout& lay, char* ws, float* gparams, int B, float* loss, bool is_ce, bool dec_done,
-                 int gw_phase, hipStream_t st);
+                 int gw_phase, hipStream_t st, int gw_parts);
 // split-bf16 parity plan (mshgnn_x3.hip)
 int x3_set_attrs(mshgnn_plan* p);
 int x3_forward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, float* out, char* ws, int64_t batch,

@@ -238,7 +238,8 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
 #ifndef GWX3_TARGET_WGS
 #define GWX3_TARGET_WGS 768
 #endif
-    p.gw_target = p.split ? GWX3_TARGET_WGS : (int)GW_TARGET_WGS;     // split plan: three resident workgroups per CU of its weight-gradient kernel (four 8 KB tiles per 32-window step)
+    p.gw_target = p.split ? GWX3_TARGET_WGS : (int)GW_TARGET_WGS;
+    { const char* e = std::getenv("MSHGNN_GW_TARGET"); if (e && std::atoi(e) >= 64) p.gw_target = std::atoi(e); }      // (measurements: workgroups of the weight-gradient launch)     // split plan: three resident workgroups per CU of its weight-gradient kernel (four 8 KB tiles per 32-window step)
     p.blk_bytes = TILE_ROWS * H * p.esize;
     if (!p.split && (int64_t)p.NN * p.blk_bytes > LDS_LIMIT)
         return fail(p, "topology has too many nodes per window for the LDS-resident layer kernel (max 20 fp32 / 40 bf16)");

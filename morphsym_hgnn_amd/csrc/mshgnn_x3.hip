@@ -1275,6 +1275,7 @@ int x3_backward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pit
         ProfScope ps(p, hp.ks_stack_bwd, st);
         hipLaunchKernelGGL(k_stack_bwd_x3, dim3(tiles), dim3(LAYER_THREADS), x3_lds_stack(hp), st, a);
     }
+    const int gw_parts = gw_parts_for(hp.n_parts, hp.n_lanes, B, 32, p->n_cu);      // window parts of this batch's weight-gradient launch (32-window steps)
     {
         GradwArgs a{};
         a.ws = ws;
@@ -1289,14 +1290,14 @@ int x3_backward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pit
         }
         a.items = p->d_tables + hp.item_off; a.lanes = p->d_tables + hp.lane_off; a.lane_order = p->d_tables + hp.lane_order_off; a.n_pad = hp.n_lanes_pad;
         if (gw_phase >= 0) { a.lane_order = p->d_tables + hp.order_ph_off[gw_phase]; a.n_pad = hp.npad_ph[gw_phase]; }
-        a.signs = p->d_signs; a.slabs = reinterpret_cast<float*>(ws + lay.slabs); a.B = B; a.n_lanes = hp.n_lanes; a.n_parts = hp.n_parts;
+        a.signs = p->d_signs; a.slabs = reinterpret_cast<float*>(ws + lay.slabs); a.B = B; a.n_lanes = hp.n_lanes; a.n_parts = gw_parts;
         ProfScope ps(p, hp.ks_gradw, st);
         static const bool gw_general = getenv("MSHGNN_GRADW") && std::string(getenv("MSHGNN_GRADW")) == "general";   // read once: the general kernel also where the lean one applies (A/B runs)
         if (a.n_pad > 0) {
-            if (gw_general && hp.gw_ipl == 1) hipLaunchKernelGGL(k_gradw_x3, dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a);
-            else if (a.aligned) hipLaunchKernelGGL(k_gradw_x3_lean<true>, dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL(k_gradw_x3_lean<false>, dim3(a.n_pad * hp.n_parts), dim3(256), 0, st, a);
+            if (gw_general && hp.gw_ipl == 1) hipLaunchKernelGGL(k_gradw_x3, dim3(a.n_pad * gw_parts), dim3(256), 0, st, a);
+            else if (a.aligned) hipLaunchKernelGGL(k_gradw_x3_lean<true>, dim3(a.n_pad * gw_parts), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL(k_gradw_x3_lean<false>, dim3(a.n_pad * gw_parts), dim3(256), 0, st, a);
         }
     }
-    return run_finalize(p, lay, ws, gparams, B, (y || labels) ? loss : nullptr, labels != nullptr, dec_done, gw_phase, st);
+    return run_finalize(p, lay, ws, gparams, B, (y || labels) ? loss : nullptr, labels != nullptr, dec_done, gw_phase, st, gw_parts);
 }
