@@ -358,6 +358,39 @@ def test_slab_stack_kernels_on_every_entry_point(kind, topo, cfg, layers, B, mon
             assert torch.equal(ga[k], gb[k]), k
 
 
+@pytest.mark.parametrize("dtype,kind,topo,cfg,layers,B", [("bf16", "c2", "a1-c2", "a1-c2", 3, 8192), ("x3", "c2", "a1-c2", "a1-c2", 3, 1000),
+                                                          ("bf16", "k4", "mini_cheetah-k4", "mini_cheetah-k4", 4, 777), ("f32", "c2", "a1-c2", "a1-c2", 2, 130)])
+def test_node_level_liveness_changes_no_result(dtype, kind, topo, cfg, layers, B, monkeypatch):
+    """The plan computes only the nodes whose values can reach the decoder within the model's depth (spec.node_liveness; A1-C2 at 3 layers: not the
+    base nodes).  Against the same plan with every node of every live type computed (MSHGNN_PRUNE=0, the liveness of rounds 1-3) at the headline batch:
+    the outputs and the loss are IDENTICAL BITS (a live node's accumulation order is untouched), every gradient agrees to fp32 summation order (the
+    weight-gradient launch cuts the batch into another number of window parts), and the parameters the topology predicts dead are exact zeros in both."""
+    _require_gpu()
+    from morphsym_hgnn_amd import engine as eng, synth
+    from tests.test_liveness import predicted_dead
+    spec = helpers.make_spec(kind, topo, cfg, 128, layers, grf=3 if kind == "c2" else 1)
+    n_y = spec.out_channels * spec.num_nodes[spec.out_type]
+    x_dict, y = synth.make_windows(17, B, spec.num_nodes, spec.widths, n_y)
+    params = synth.make_params(17, spec.param_shapes())
+    res = {}
+    for prune in ("1", "0"):
+        monkeypatch.setenv("MSHGNN_PRUNE", prune)      # read when the plan is compiled
+        e = eng.Engine(spec, dtype)
+        out, loss, g = e.step_mse(e.cast_inputs(x_dict), eng.flatten_params(spec, params, e.device), y.reshape(-1).to(e.device, torch.float32), B)
+        torch.cuda.synchronize()
+        res[prune] = (out.clone(), loss.clone(), eng.unflatten(spec, g.clone()), e.info.flops_fwd)
+    monkeypatch.setenv("MSHGNN_PRUNE", "1")
+    dead = predicted_dead(spec)
+    assert res["1"][3] < res["0"][3] and dead, "the case must have dead nodes inside live types"
+    assert torch.equal(res["1"][0], res["0"][0]) and torch.equal(res["1"][1], res["0"][1])
+    for k, ga in res["1"][2].items():
+        gb = res["0"][2][k]
+        if k in dead:
+            assert float(ga.abs().max()) == 0.0 and float(gb.abs().max()) == 0.0, k
+        else:
+            assert float(gb.abs().max()) > 0.0 and float((ga - gb).abs().max()) <= 2e-5 * float(gb.abs().max()), k
+
+
 def test_full_size_batch_properties_bf16():
     """The same size-independent properties on the throughput plan (bf16, B=8192: slab stack kernels; the two halves of the
     batch run on the 8-wave stack kernels): every window's output is independent of its batch -- identical bits -- and the
