@@ -2479,7 +2479,7 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
         ProfScope ps(p, hp.ks_layer_bwd0 + (hp.L - 1 - l), st);
         hipLaunchKernelGGL(k_layer_bwd<T>, dim3(tiles), dim3(LAYER_THREADS), hp.n_blk * Prec<T>::BLK, st, a);
     }
-    const int gw_parts = gw_parts_for(hp.n_parts, hp.n_lanes, B, sizeof(T) == 4 ? GW_KW : GWB_KW, p->n_cu);      // window parts of this batch's weight-gradient launch (<= the plan's)
+    const int gw_parts = gw_parts_for(hp.n_parts, hp.n_lanes, hp.gw_ipl, B, sizeof(T) == 4 ? GW_KW : GWB_KW, p->n_cu);      // window parts of this batch's weight-gradient launch (<= the plan's)
     {
         GradwArgs a{};
         a.ws = ws;

@@ -1043,23 +1043,27 @@ inline int vec_bytes(const void* base, int64_t pitch_elems, int esize) {
 
 
 // Window parts of a weight-gradient launch for THIS batch: at most the plan's n_parts (the slab buffer is sized for it).  A launch lasts as long as its
-// longest part, a part's steps slow down with the number of workgroups that stream beside it, and a grid that needs (nearly) three workgroups on EVERY CU
-// runs into the placement's slack.  Measured (round 4, A1-C2 pruned plan, 56 lanes of 2 items, 8192 windows = 128 chunks): 13 parts = 728 workgroups 89 us,
-// 12 parts 71.8, 11: 73.6, 10: 74.9, 9: 81.4, 8 (16 chunks each, 448 workgroups): 69.2, 7: 76.0, 6: 83.3; MiniCheetah-K4 L=3 (128 lanes): 6 parts = 768
-// workgroups 92 us, 5 parts 76.5, 4 parts 81.8.  Model fitted to those: time ~ ceil(chunks / q) x (137.5 + lanes q) -- a fixed latency per step plus a
-// bandwidth share --, with the grid kept at or below 2.8 workgroups per CU.
-inline int gw_parts_for(int plan_parts, int lanes, int64_t B, int chunk_windows, int n_cu) {
+// longest part, a part's steps slow down with the number of workgroups that stream beside it (more so once CUs hold a third workgroup), every part
+// costs a slab per lane that the finalize launch reads back, and a grid that needs (nearly) three workgroups on EVERY CU runs into the placement's
+// slack.  Measured (round 4, A1-C2 pruned plan, 56 lanes of 2 items, 8192 windows = 128 chunks; us): 13 parts = 728 workgroups 89.3, 12: 71.8,
+// 11: 73.6, 10: 74.9, 9: 81.4, 8 (16 chunks each, 448 workgroups): 69.2, 7: 76.0, 6: 83.3, finalize 9 + 0.012 per workgroup; MiniCheetah-K4 L=3
+// (128 lanes): 6 parts = 768 workgroups 92, 5 parts 76.5, 4 parts 81.8.  Model fitted to those, per step of one item:
+//     t(W) = 1.1 + 0.0024 W us up to 480 workgroups (under two per CU), 1.1 + 0.0032 W beyond;   launch = ceil(chunks / q) ipl t(lanes q) + 0.012 lanes q
+// with the grid kept at or below 2.8 workgroups per CU.  The plan's own count (as many parts as fit) stays unless the model sees > 3 % in another.
+inline int gw_parts_for(int plan_parts, int lanes, int ipl, int64_t B, int chunk_windows, int n_cu) {
     static const int forced = [] { const char* e = getenv("MSHGNN_GW_PARTS"); return e ? atoi(e) : 0; }();      // (measurements)
     if (forced > 0) return std::min(forced, plan_parts);
     const int64_t nchunks = (B + chunk_windows - 1) / chunk_windows;
+    const double cu_scale = 256.0 / (double)std::max(1, n_cu);                               // (the fit is per CU: workgroup counts scaled to a 256-CU chip)
     const int cap_wg = 45 * std::max(1, n_cu) / 16;                                         // 720 on 256 CUs
     const int qmax = std::max(1, std::min(plan_parts, cap_wg / std::max(1, lanes)));
-    int best = 1; double best_cost = -1;
-    for (int q = 1; q <= qmax; ++q) {
-        const double cost = (double)((nchunks + q - 1) / q) * (137.5 + (double)lanes * q);
-        if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best = q; }      // ties: the larger q
-    }
-    return best;
+    auto cost = [&](int q) {
+        const double W = (double)lanes * q * cu_scale;
+        const double t = 1.1 + (W <= 480.0 ? 0.0024 : 0.0032) * W;
+        return (double)((nchunks + q - 1) / q) * std::max(1, ipl) * t + 0.012 * W; };
+    int best = qmax; double best_cost = cost(qmax);
+    for (int q = 1; q < qmax; ++q) if (cost(q) < best_cost) { best_cost = cost(q); best = q; }
+    return best_cost < 0.97 * cost(qmax) ? best : qmax;
 }
 
 // k_finalize launch of a step (mshgnn.hip): fixed-order slab sums -> flat gradient (+ fused loss)

@@ -1275,7 +1275,7 @@ int x3_backward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pit
         ProfScope ps(p, hp.ks_stack_bwd, st);
         hipLaunchKernelGGL(k_stack_bwd_x3, dim3(tiles), dim3(LAYER_THREADS), x3_lds_stack(hp), st, a);
     }
-    const int gw_parts = gw_parts_for(hp.n_parts, hp.n_lanes, B, 32, p->n_cu);      // window parts of this batch's weight-gradient launch (32-window steps)
+    const int gw_parts = gw_parts_for(hp.n_parts, hp.n_lanes, hp.gw_ipl, B, 32, p->n_cu);      // window parts of this batch's weight-gradient launch (32-window steps)
     {
         GradwArgs a{};
         a.ws = ws;
