@@ -782,6 +782,13 @@ __device__ __forceinline__ void slab_group_fwd(const StackArgs& a, const FHdr& f
                                                int slot_base, int nmlp, bool residual, u32x4 (&keep)[HS], unsigned (&bits)[(HS + 3) / 4]) {
     using P = Prec<T>;
     const int win = c_win(lane), col = wn * 32 + c_oct(lane);
+    if (fh[FH_FLAGS] & (Q0 == 0 ? FF_A_EMPTY : FF_B_EMPTY)) {      // no live node in this group in this layer (uniform): nothing to compute or keep
+#pragma unroll
+        for (int u = 0; u < HS; ++u) keep[u] = u32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < (HS + 3) / 4; ++i) bits[i] = 0;
+        return;
+    }
     typename P::Acc acc[HS];
 #pragma unroll
     for (int u = 0; u < HS; ++u) {
@@ -1153,6 +1160,11 @@ template <typename T, int HS, int Q0>
 __device__ __forceinline__ void slab_group_bwd(const StackArgs& a, const FHdr& bh, const FProg& wp, char* smem, const T* wpack, int wn, int lane,
                                                int slot_arr, const T* xact, bool enc_mask, u32x4 (&keep)[HS]) {
     using P = Prec<T>;
+    if (bh[FH_FLAGS] & (Q0 == 0 ? FF_A_EMPTY : FF_B_EMPTY)) {      // no dX row of this group is produced in this layer (uniform)
+#pragma unroll
+        for (int u = 0; u < HS; ++u) keep[u] = u32x4{0, 0, 0, 0};
+        return;
+    }
     const int lq = opaque(lane);      // per-node global addresses are rebuilt per call: hoisted out of the layer loop they cost ~40 VGPRs and spill
     const int win = c_win(lq), col = wn * 32 + c_oct(lq), w = min(blockIdx.x * P::ROWS + win, a.B - 1);
     // The accumulators start at the residual term G_{l+1}[n]: `keep` holds it on entry -- the packed dX_{l+1} rows this wave

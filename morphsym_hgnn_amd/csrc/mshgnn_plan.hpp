@@ -101,7 +101,7 @@ static_assert(FH_NEXT + 8 + 20 <= FH_SIZE && MSHGNN_MAX_TYPES <= 4, "header: nex
 // live base_transform; group A's residual reads are over by then and its new rows wait in registers).
 constexpr int SL_HA = 12, SL_HB = 6, SL_HB_MAX = 8, SL_THREADS = 256;
 constexpr int SL_CBA = 2, SL_CBB = 3;    // bits of MAC count per slot and segment in group A / B programs (12 x 2, 6..8 x 3 bits)
-enum { FF_RESIDUAL = 1, FF_ENC_MASK = 2, FF_SCR_ALIAS = 4 };
+enum { FF_RESIDUAL = 1, FF_ENC_MASK = 2, FF_SCR_ALIAS = 4, FF_A_EMPTY = 8, FF_B_EMPTY = 16 };      // FF_x_EMPTY (slab headers): group x has no work in this layer
 
 // buffer ids used by weight-gradient items
 enum { BUF_X = 0, BUF_DX = 17, BUF_DH = 34, BUF_HB = 50, BUF_T1 = 66, BUF_DU = 82, BUF_IN = 98, BUF_MASK = 102, BUF_COUNT = 118 };
@@ -601,16 +601,51 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
                 for (int i = 0; i < 64; ++i) T.push_back(w[4 * i] | (w[4 * i + 1] << 8) | (w[4 * i + 2] << 16) | (w[4 * i + 3] << 24));
             }
         };
-        // slab programs: group A = the largest node type, group B = every other node in node order
+        // slab programs: group A = the largest node type, group B = every other node in node order.  With node-level liveness a group may have nothing
+        // to do in a layer (its pass is then skipped: FF_A_EMPTY / FF_B_EMPTY), and a pass costs ~5 k cycles of fixed latency whatever it holds -- so when
+        // the nodes differ in how often they are computed (A1-C2 at 3 layers: thighs, knees and feet in every pass, the hips only in the backward's last
+        // one, the base nodes never), group A takes the 12 busiest nodes instead: 7 group passes per tile instead of 11.  The base_transform nodes stay
+        // the first slots of group B; a node with more than 3 in- or out-edges in one relation needs group B's 3-bit MAC counts.  Slots are the same in
+        // every layer (the backward carries a slot's residual row in registers from layer to layer).
         int tA = 0; for (int t = 1; t < NT; ++t) if (d.type_nodes[t] > d.type_nodes[tA]) tA = t;
         std::vector<int> slotA, slotB;
         for (int n = 0; n < p.NN; ++n) (p.node_type[n] == tA ? slotA : slotB).push_back(n);
         p.sl_ta = tA;
+        if (p.prune_nodes && !p.split) {
+            std::vector<int> busy(p.NN, 0), deg(p.NN, 0);
+            for (int l = 0; l < L; ++l) for (int n = 0; n < p.NN; ++n) busy[n] += (p.live_n[l][n] ? 1 : 0) + (p.need_n[l][n] ? 1 : 0);
+            for (int r = 0; r < NR; ++r) {
+                std::vector<int> din(d.type_nodes[p.rel_dst[r]], 0), dout(d.type_nodes[p.rel_src[r]], 0);
+                for (int e = p.rel_edge_off[r]; e < p.rel_edge_off[r + 1]; ++e) { ++dout[p.edges[2 * e]]; ++din[p.edges[2 * e + 1]]; }
+                for (size_t i = 0; i < din.size(); ++i) deg[p.type_base[p.rel_dst[r]] + i] = std::max(deg[p.type_base[p.rel_dst[r]] + i], din[i]);
+                for (size_t j = 0; j < dout.size(); ++j) deg[p.type_base[p.rel_src[r]] + j] = std::max(deg[p.type_base[p.rel_src[r]] + j], dout[j]);
+            }
+            auto passes = [&](const std::vector<int>& A, const std::vector<int>& Bv) {      // group passes with work, over all layers and both sweeps
+                int c = 0;
+                for (int l = 0; l < L; ++l)
+                    for (int dir = 0; dir < 2; ++dir)
+                        for (const std::vector<int>* g : {&A, &Bv}) {
+                            bool any = false;
+                            for (int n : *g) any = any || (dir == 0 ? p.live_n[l][n] : p.need_n[l][n]);
+                            c += any ? 1 : 0;
+                        }
+                return c; };
+            std::vector<int> cand, A2, B2;
+            for (int n = 0; n < p.NN; ++n) {
+                if (has_mlp && p.node_type[n] == d.mlp_type) B2.push_back(n);      // (first slots of group B, in node order)
+                else cand.push_back(n);
+            }
+            std::stable_sort(cand.begin(), cand.end(), [&](int x, int y) { return busy[x] > busy[y]; });
+            for (int n : cand) { if ((int)A2.size() < SL_HA && deg[n] <= 3 && busy[n] > 0) A2.push_back(n); else B2.push_back(n); }
+            std::sort(A2.begin(), A2.end());
+            std::sort(B2.begin() + (has_mlp ? p.n_mlp : 0), B2.end());
+            if ((int)B2.size() <= SL_HB_MAX && passes(A2, B2) < passes(slotA, slotB)) { slotA = A2; slotB = B2; p.sl_ta = -1; }
+        }
         p.sl_hb = (int)slotB.size() <= SL_HB ? SL_HB : SL_HB_MAX;
         p.sl_alias = 2 * (int64_t)p.fs_blk * p.blk_bytes > LDS_LIMIT && p.n_mlp <= (int)slotA.size();
         p.sl_blk = p.sl_alias ? p.NN : p.fs_blk;
         p.slab = !p.split && 2 * (int64_t)p.sl_blk * p.blk_bytes <= LDS_LIMIT && (int)slotA.size() <= SL_HA && (int)slotB.size() <= SL_HB_MAX &&
-                 (!has_mlp || (d.mlp_type != tA && p.n_mlp <= (int)slotB.size()));     // base_transform nodes = the first slots of group B
+                 (!has_mlp || ((p.sl_ta < 0 || d.mlp_type != tA) && p.n_mlp <= (int)slotB.size()));     // base_transform nodes = the first slots of group B
         if (has_mlp) for (int u = 0; u < p.n_mlp && p.slab; ++u) if (slotB[u] != p.type_base[d.mlp_type] + u) p.slab = false;
         auto emit_slab = [&](const std::vector<Seg>& segs, int hdr_src) {
             const int h = (int)T.size(); T.resize(T.size() + FH_SIZE, 0);
@@ -627,17 +662,28 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
                 const std::vector<int>& slots = phase == 0 ? slotA : slotB;
                 std::vector<int> w, blocks, counts, packs;
                 bool ok = true;
-                for (const Seg& sg : segs) {
-                    if (sg.macs.empty() || (p.node_type[sg.macs[0].first] == tA) != (phase == 0)) continue;
-                    int cw = 0;
+                for (const Seg& sg : segs) {      // a segment's MACs go to the group that holds their destination slot (a segment may serve both groups)
+                    int cw = 0, total = 0;
+                    std::vector<int> blk;
                     for (size_t u = 0; u < slots.size(); ++u) {
                         int c = 0;
-                        for (auto& m : sg.macs) if (m.first == slots[u]) { blocks.push_back(m.second); ++c; }
+                        for (auto& m : sg.macs) if (m.first == slots[u]) { blk.push_back(m.second); ++c; }
                         const int cb = phase == 0 ? SL_CBA : SL_CBB;     // bits of MAC count per slot
                         if (c >= (1 << cb)) ok = false;
                         cw |= c << (cb * (int)u);
+                        total += c;
                     }
+                    if (total == 0) continue;
+                    blocks.insert(blocks.end(), blk.begin(), blk.end());
                     counts.push_back(cw); packs.push_back(sg.pack);
+                }
+                {   // nothing to do for this group in this layer: no live / produced slot (the forward's base_transform chain counts as work)
+                    bool any = false;
+                    for (size_t u = 0; u < slots.size(); ++u) {
+                        const int q = (phase == 0 ? 0 : SL_HA) + (int)u;
+                        any = any || T[h + FH_KIND + q] != NK_DEAD || T[h + FH_OUT + q] != 0;
+                    }
+                    if (!any && packs.empty()) T[h + FH_FLAGS] |= (phase == 0 ? FF_A_EMPTY : FF_B_EMPTY);
                 }
                 w.push_back((int)packs.size());
                 blocks.push_back(blocks.empty() ? 0 : blocks.back());
@@ -663,7 +709,6 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
                     const int t = p.node_type[n];
                     T[fh + FH_KIND + n] = !p.live_n[l][n] ? NK_DEAD : ((has_mlp && t == d.mlp_type) ? NK_MLP : NK_RELU);
                     T[fh + FH_BIAS + n] = p.live_n[l][n] ? p.bias_layer[l * NT + t] : 0;
-                    if (l == 0) T[fh + FH_OUT + n] = p.need_n[0][n] ? 1 : 0;      // forward, layer 0: the X_0 rows the tile load has to bring in
                 }
                 std::vector<Seg> segs;
                 for (int t = 0; t < NT; ++t) {
