@@ -795,7 +795,7 @@ __device__ __forceinline__ void slab_group_fwd(const StackArgs& a, const FHdr& f
         if (fh[FH_KIND + Q0 + u] != NK_DEAD) acc_init_bias<T>(acc[u], a.bias + (size_t)fh[FH_BIAS + Q0 + u] * H, wn, lane);
         else acc_fill(acc[u], 0.f);
     }
-    fs_run<T, HS, (Q0 == 0 ? SL_CBA : SL_CBB)>(wp, acc, smem, wpack, wn, lane);
+    fs_run<T, HS, (Q0 == 0 ? SL_CBA : SL_CBB)>(wp, acc, smem, wpack, wn, lane, a.dbg);      // (a.dbg: timing ablations, compiled out of the product build)
     if constexpr (Q0 > 0) if (nmlp > 0) {
         // base_transform: Y = W2 relu(W1 H + b1) + b2 on the first nmlp slots of this group (hgnn_c2.py:117-121,156); scratch
         // blocks NN + u.  The H / T1 stashes go out packed, behind the chain's last load.
@@ -1176,7 +1176,7 @@ __device__ __forceinline__ void slab_group_bwd(const StackArgs& a, const FHdr& b
         if (bh[FH_KIND + Q0 + u] != NK_DEAD && bh[FH_RES + Q0 + u]) unpack_oct(keep[u], acc[u].c[0], acc[u].c[1]);
         else acc_fill(acc[u], 0.f);
     }
-    fs_run<T, HS, (Q0 == 0 ? SL_CBA : SL_CBB)>(wp, acc, smem, wpack, wn, lane);
+    fs_run<T, HS, (Q0 == 0 ? SL_CBA : SL_CBB)>(wp, acc, smem, wpack, wn, lane, a.dbg);      // (a.dbg: timing ablations, compiled out of the product build)
     // layer 0: x relu'(X_0) (encoder activation) from the encoder's relu bytes (one per lane, written by k_enc_fwd): a byte per
     // node instead of the 16-byte X_0 octet (38 MB per launch, 4 VGPRs per node), all requested back to back
     const uint8_t* m0 = reinterpret_cast<const uint8_t*>(a.ws + a.mask0_off);
