@@ -57,8 +57,10 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=1024)
     ap.add_argument("--min-time", type=float, default=0.5, help="seconds of timed blocks to accumulate")
     ap.add_argument("--overlap", default=os.environ.get("MSHGNN_BENCH_OVERLAP", "auto"), choices=["auto", "0", "1"])
-    ap.add_argument("--grad-exchange", default=os.environ.get("MSHGNN_BENCH_GRAD_EXCHANGE", "f32"), choices=["f32", "bf16"],
-                    help="N > 1: dtype of the gradient all-reduce on the wire (bf16: opt-in, half the bytes, NOT parity-grade -- ddp.allreduce_mean_bf16_)")
+    ap.add_argument("--grad-exchange", default=os.environ.get("MSHGNN_BENCH_GRAD_EXCHANGE", "auto"), choices=["auto", "f32", "live", "bf16"],
+                    help="N > 1: what the gradient all-reduce moves.  f32: the whole flat buffer; live: only the elements that can be non-zero at this depth, "
+                         "packed (exact -- ddp.LiveGradientExchange); auto (default): times f32 and live on this machine and keeps the faster; "
+                         "bf16: opt-in, half the bytes, NOT parity-grade (ddp.allreduce_mean_bf16_)")
     return ap.parse_args()
 
 
@@ -244,11 +246,21 @@ class Workload:
         self.split = split
         self.overlap_choice = None
         self.g16 = torch.empty(self.gflat.numel(), dtype=torch.bfloat16, device=device) if (dist is not None and grad_exchange == "bf16") else None
+        self.live = None
+        if dist is not None and grad_exchange in ("auto", "live"):
+            from morphsym_hgnn_amd import ddp
+            self.live = ddp.LiveGradientExchange(spec, device)
+            if grad_exchange == "auto" and self.live.fraction > 0.9:      # nothing worth packing
+                self.live = None
+        self.use_live = self.live is not None and grad_exchange == "live"
+        self.exchange_choice = None
 
     def _allreduce(self):
         if self.g16 is not None:
             from morphsym_hgnn_amd import ddp
             ddp.allreduce_mean_bf16_(self.gflat, self.g16)
+        elif self.use_live:
+            self.live.allreduce_mean_(self.gflat)
         else:
             self.dist.all_reduce(self.gflat, op=self.dist.ReduceOp.AVG)     # DDP semantics: mean over ranks (gnnLightning.py:1396-1400)
 
@@ -277,6 +289,30 @@ class Workload:
     def barrier(self):
         if self.dist is not None:
             self.dist.barrier()
+
+    def _time_mode(self, steps, warmup):
+        torch, dist = self.torch, self.dist
+        for _ in range(warmup):
+            self.step()
+        torch.cuda.synchronize(); self.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        torch.cuda.synchronize(); self.barrier(); torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=self.e.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0]) / steps * 1e3
+
+    def calibrate_exchange(self, steps=20, warmup=3):
+        """--grad-exchange auto with more than one rank: time the step with the whole-buffer all-reduce and with the packed live-element exchange
+        (both exact) on THIS machine, MAX over ranks, and keep the faster."""
+        ms = {}
+        for mode in (False, True):
+            self.use_live = mode
+            ms[mode] = self._time_mode(steps, warmup)
+        self.use_live = ms[True] < ms[False]
+        self.exchange_choice = {"mode": "auto", "live": bool(self.use_live), "live_fraction": self.live.fraction,
+                                "ms_whole_buffer": ms[False], "ms_live_packed": ms[True]}
 
     def calibrate_overlap(self, steps=20, warmup=3):
         """--overlap auto with more than one rank: time the plain sequence (step, then ONE all-reduce of the flat gradient) and the two-phase step
@@ -611,10 +647,19 @@ def main():
     B, L, hidden = defaults(args)
     spec = build_spec(L, args.config, hidden)
     wl = Workload(spec, args.dtype, B, device, 1234 + rank, dist, args.overlap, args.grad_exchange)
-    if args.grad_exchange == "bf16":
-        wl.can_overlap = False      # (the two-phase step exchanges fp32 slices)
-    if args.overlap == "auto" and wl.can_overlap and (world > 1 or os.environ.get("MSHGNN_BENCH_FORCE_DIST") == "1"):
+    if args.grad_exchange in ("bf16", "live"):
+        wl.can_overlap = False      # (the two-phase step exchanges whole fp32 slices)
+    multi = world > 1 or os.environ.get("MSHGNN_BENCH_FORCE_DIST") == "1"
+    if args.grad_exchange == "auto" and wl.live is not None and multi:
+        wl.calibrate_exchange()
+    if args.overlap == "auto" and wl.can_overlap and multi:
+        live = wl.use_live
+        wl.use_live = False
         wl.calibrate_overlap()
+        if live and wl.overlap and wl.exchange_choice["ms_live_packed"] <= wl.overlap_choice["ms_two_phase"]:
+            wl.overlap = False
+            wl.overlap_choice["two_phase"] = False
+        wl.use_live = live and not wl.overlap
     med, blocks = wl.time_blocks(args.steps, args.warmup, args.min_time)
     value = world * B * args.steps / med
     loss = float(wl.loss.item())
@@ -651,7 +696,8 @@ def main():
                                f"fwd+{'MSE' if spec.regression else 'CE'}+bwd, all parameter gradients"
                                + (f", RCCL all-reduce (mean over {world} ranks{', overlapped two-phase' if wl.overlap else ''})" if dist is not None else ""),
                    "global_batch": B * world, "parallelism": f"dp{world}", "rccl_ranks": (dist.get_world_size() if dist is not None else 0),
-                   **({"grad_exchange": args.grad_exchange} if dist is not None else {})},
+                   **({"grad_exchange": ("live" if wl.use_live else "f32") if args.grad_exchange == "auto" else args.grad_exchange,
+                       "grad_exchange_choice": wl.exchange_choice} if dist is not None else {})},
         "timing": {"blocks": len(blocks), "block_steps": args.steps, "median_ms": med * 1e3, "min_ms": min(blocks) * 1e3, "max_ms": max(blocks) * 1e3,
                    "timed_s": sum(blocks)},
         "overlap": wl.overlap_choice or {"mode": args.overlap, "two_phase": bool(wl.overlap)},

@@ -179,6 +179,32 @@ class ModelSpec:
         srt = lambda dd: {t: sorted(v) for t, v in dd.items()}
         return [srt(x) for x in live], [srt(x) for x in need]
 
+    def dead_parameters(self):
+        """The state_dict names whose gradient is an exact zero at this depth (node_liveness): every use of the tensor sits on nodes that cannot reach
+        the decoder.  The reference's autograd leaves them None / zero, the engine writes zeros; a data-parallel exchange may skip them."""
+        live, need = self.node_liveness()
+        dead = set()
+        for t in self.node_types:
+            if not need[0][t]:
+                dead |= {f"encoder.lins.{t}.weight", f"encoder.lins.{t}.bias"}
+        for l in range(self.num_layers):
+            for et in self.edge_types:
+                pre = f"convs.{l}.convs.{rel_key(et)}."
+                if not live[l][et[2]]:                                   # root weight and bias act on the relation's destination type
+                    dead |= {pre + "lin_root.weight", pre + "lin_rel.bias"}
+                if not any(i in live[l][et[2]] for _, i in self.topology.edges(et)):
+                    dead.add(pre + "lin_rel.weight")
+        if self.has_base_transform and not any(live[l]["base"] for l in range(self.num_layers)):
+            dead |= {"base_transform.0.weight", "base_transform.0.bias", "base_transform.2.weight", "base_transform.2.bias"}
+        return dead
+
+    def live_gradient_index(self):
+        """int64 indices into the flat gradient buffer of every element that can be non-zero (every parameter not in dead_parameters), ascending."""
+        import torch as _t
+        dead = self.dead_parameters()
+        parts = [_t.arange(off, off + n, dtype=_t.int64) for k, (off, n) in self.param_offsets().items() if k not in dead]
+        return _t.cat(parts) if parts else _t.zeros(0, dtype=_t.int64)
+
     # ---- parameters ------------------------------------------------------------------------
     def param_shapes(self) -> "OrderedDict[str, Tuple[int, ...]]":
         """state_dict names -> shapes, in module registration order."""
