@@ -13,6 +13,7 @@
 //              part of the batch: dW = P^T Q with Q aggregated like a term's A tile; deterministic slab sums in k_gfinalize.
 //   SPLIT      the split-bf16 parity arithmetic of mshgnn_x3.hip (hi + lo bf16 halves, three MFMA products per term, fp32
 //              inputs, activation rows stored [hi Hd | lo Hd]): 1e-4 relative; the non-split instantiation is the bf16 plan.
+#include <type_traits>
 #include "mshgnn_device.hpp"
 #include "mshgnn_gen_plan.hpp"
 
@@ -30,7 +31,7 @@ struct GArgs {
     const void* x[MSHGNN_MAX_TYPES]; int64_t pitch[MSHGNN_MAX_TYPES]; int nodes[MSHGNN_MAX_TYPES]; int vb[MSHGNN_MAX_TYPES]; int aligned;
     const int* jobs; const int* terms; const int* srcs; const int* units; const int* items; const int* sunits; const int* su_order; const int* aggs;
     const void* wpack; const float* bias; const uint8_t* signs; float* slabs;
-    int n_img, B, Hd, NCT, tiles, training, job0, n_units, n_parts, n_sunits;
+    int n_img, B, Hd, NCT, tiles, training, job0, n_units, n_parts, n_sunits, njt;      // njt: (job, tile) pairs of a k_gstep4 launch at 8 waves
 #ifdef GGW_STAMPS
     long long* stamps;      // (phase clocks of k_ggradw, tools/stamps_ggradw.py)
 #endif
@@ -248,19 +249,32 @@ template <bool SPLIT, int MB, int NW> __global__ __launch_bounds__(64 * NW) void
 // other chunks one row at a time, and the window fragments are read per K step (4 registers) instead of per row block (16).
 // SPLIT (the split-bf16 arithmetic of section 4b: rows [hi Hd | lo Hd], three products per term) runs it on 64-window tiles (MB = 4): with the same register diet
 // its 16-wave form fits the 128 registers that k_gstep<true, 4, 16> overflowed, so the A tile is staged once for 512 columns instead of twice.
-template <bool SPLIT, int MB, int NW> __global__ __launch_bounds__(64 * NW) void k_gstep4(GArgs a) {
+template <bool SPLIT, int MB, int NW> __global__ __launch_bounds__(64 * NW, 4) void k_gstep4(GArgs a) {      // (4 waves per SIMD: 128 registers, so that two 8-wave workgroups share a CU)
     using P = P16;
     constexpr int CPW = NW / 4, NPASS = MB * 16 / (4 * NW);      // staging passes: thread = (row rr + 4 NW i, chunk c)
     static_assert(NPASS >= 1 && NPASS * 4 * NW == MB * 16, "row blocks must cover whole staging passes");
     extern __shared__ __attribute__((aligned(16))) char smem[];      // blocks [0, MB): (hi) A tile; [MB, 2 MB): lo halves (split arithmetic)
     const int tid = threadIdx.x, lane = tid & 63, wq = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nctg = a.NCT / CPW;
-    const int ct = (blockIdx.x % nctg) * CPW + (wq >> 2), wv = wq & 3, tile = (blockIdx.x / nctg) % a.tiles;
-    const int* job = a.jobs + (size_t)(a.job0 + blockIdx.x / (nctg * a.tiles)) * JOB_INTS;
+    int ctg, jt;      // column group and (job, tile) index of this workgroup
+    if constexpr (NW == 8) {
+        // two workgroups per (job, tile), one per half of the 512 columns; they read the same source rows, so they sit 8 blocks apart: same XCD (round-robin
+        // dispatch), dispatched back to back -- the second reader finds the rows in that XCD's L2 (grid padded to whole groups of 16)
+        ctg = (blockIdx.x >> 3) & 1; jt = (blockIdx.x >> 4) * 8 + (blockIdx.x & 7);
+        if (jt >= a.njt) return;
+    } else { ctg = blockIdx.x % nctg; jt = blockIdx.x / nctg; }
+    const int ct = ctg * CPW + (wq >> 2), wv = wq & 3, tile = jt % a.tiles;
+    const int* job = a.jobs + (size_t)(a.job0 + jt / a.tiles) * JOB_INTS;
     const int w0 = tile * MB * P::ROWS, B = a.B, Hd = a.Hd;
     const int flags = job[J_FLAGS];
     const T16* wpack = reinterpret_cast<const T16*>(a.wpack);
     GEN_TL(0);
+#ifdef GGW_STAMPS
+    long long tk[6] = {0, 0, 0, 0, 0, 0}, t0 = clock64(); int nchunk = 0;      // (phase clocks, tools/stamps_gstep4.py)
+#define GS_T(k) { const long long t1 = clock64(); tk[k] += t1 - t0; t0 = t1; }
+#else
+#define GS_T(k)
+#endif
 
     P::Acc acc[MB];
     {
@@ -279,25 +293,34 @@ template <bool SPLIT, int MB, int NW> __global__ __launch_bounds__(64 * NW) void
         const bool plain = kind == 0 && n_src == 1 && src[S_SCALE] == one_bits;
         for (int kc = 0; kc < nkc; ++kc) {
             __syncthreads();   // the previous chunk's MFMAs are done reading LDS
+            GS_T(0)
             if (plain) {
                 const T16* base = reinterpret_cast<const T16*>(a.ws + a.buf_off[src[S_BUF]]);
                 const bool msk = src[S_MASK] >= 0;
                 const uint8_t* mb = reinterpret_cast<const uint8_t*>(a.ws + (msk ? a.buf_off[src[S_MASK]] : 0));
                 const int col = kc * TW + c * 8;
-                u32x4 v[NPASS], vl[SPLIT ? NPASS : 1]; unsigned bm[NPASS];
+                constexpr int NIF = NPASS < 2 ? NPASS : 2;      // rows in flight per thread (two: the registers 16 waves, or two workgroups of 8, leave)
 #pragma unroll
-                for (int i = 0; i < NPASS; ++i) {
-                    const int w = min(w0 + i * (4 * NW) + rr, B - 1);
-                    const T16* rp = base + g_row<SPLIT>(w, src[S_NODE], B, Hd) + col;
-                    v[i] = *reinterpret_cast<const u32x4*>(rp);
-                    if constexpr (SPLIT) vl[i] = *reinterpret_cast<const u32x4*>(rp + Hd);
-                    bm[i] = msk ? mb[g_relu_byte(src[S_NODE], B, Hd, w, col)] : 0xffu;
-                }
+                for (int i0 = 0; i0 < NPASS; i0 += NIF) {
+                    u32x4 v[NIF], vl[SPLIT ? NIF : 1]; unsigned bm[NIF];
 #pragma unroll
-                for (int i = 0; i < NPASS; ++i) {
-                    const int grow = i * (4 * NW) + rr;
-                    *reinterpret_cast<u32x4*>(smem + lds_chunk<T16>(grow >> 4, grow & 15, c)) = chunk_mask_bits<T16>(v[i], bm[i]);
-                    if constexpr (SPLIT) *reinterpret_cast<u32x4*>(smem + lds_chunk<T16>(MB + (grow >> 4), grow & 15, c)) = chunk_mask_bits<T16>(vl[i], bm[i]);
+                    for (int i = 0; i < NIF; ++i) {
+                        const int w = min(w0 + (i0 + i) * (4 * NW) + rr, B - 1);
+                        const T16* rp = base + g_row<SPLIT>(w, src[S_NODE], B, Hd) + col;
+                        v[i] = *reinterpret_cast<const u32x4*>(rp);
+                        if constexpr (SPLIT) vl[i] = *reinterpret_cast<const u32x4*>(rp + Hd);
+                        bm[i] = msk ? mb[g_relu_byte(src[S_NODE], B, Hd, w, col)] : 0xffu;
+                    }
+#ifdef GGW_STAMPS
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    GS_T(1)
+#endif
+#pragma unroll
+                    for (int i = 0; i < NIF; ++i) {
+                        const int grow = (i0 + i) * (4 * NW) + rr;
+                        *reinterpret_cast<u32x4*>(smem + lds_chunk<T16>(grow >> 4, grow & 15, c)) = chunk_mask_bits<T16>(v[i], bm[i]);
+                        if constexpr (SPLIT) *reinterpret_cast<u32x4*>(smem + lds_chunk<T16>(MB + (grow >> 4), grow & 15, c)) = chunk_mask_bits<T16>(vl[i], bm[i]);
+                    }
                 }
             } else {
 #pragma unroll
@@ -317,9 +340,15 @@ template <bool SPLIT, int MB, int NW> __global__ __launch_bounds__(64 * NW) void
                 }
             }
             __syncthreads();
+            GS_T(2)
             const int pack = term[T_PACK] + kc * a.NCT + ct;
             load_bfrag<T16>(bfh, wpack, pack, wv, lane);
             if constexpr (SPLIT) load_bfrag<T16>(bfl, wpack, a.n_img + pack, wv, lane);
+#ifdef GGW_STAMPS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            GS_T(3)
+            ++nchunk;
+#endif
 #pragma unroll
             for (int m = 0; m < MB; ++m) {
                 // (the order of mac() in k_gstep: hi x hi over the four K steps, then hi x lo-weights, then lo x hi)
@@ -344,9 +373,262 @@ template <bool SPLIT, int MB, int NW> __global__ __launch_bounds__(64 * NW) void
                     }
                 }
             }
+#ifdef GGW_STAMPS
+            { float d; asm volatile("v_mov_b32 %0, %1" : "=v"(d) : "v"(acc[MB - 1].c[1][3])); asm volatile("" :: "v"(d)); }
+            GS_T(4)
+#endif
         }
     }
     gstep_epilogue<SPLIT, MB>(a, job, acc, ct, wv, lane, w0);
+#ifdef GGW_STAMPS
+    GS_T(5)
+    if (a.stamps && tid == 0) { for (int q = 0; q < 6; ++q) a.stamps[(size_t)blockIdx.x * 8 + q] = tk[q]; a.stamps[(size_t)blockIdx.x * 8 + 6] = nchunk; a.stamps[(size_t)blockIdx.x * 8 + 7] = job[J_NTERMS]; }
+#endif
+    GEN_TL(1);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// k_gstep5 (bf16 arithmetic): k_gstep4's tile (128 windows x 512 columns) as a software pipeline of 8 waves
+// ------------------------------------------------------------------------------------------------------
+// k_gstep4's K chunk is four phases in a row -- wait for the source rows (1.8-2.9 k clocks), LDS writes + barrier (1.2 k), wait for the weight fragment
+// (1.0-1.9 k), MFMAs (2.5 k + 3.7 k at the next barrier while the SIMD's other waves finish theirs): 12.2 k clocks per chunk against 4.1 k of MFMA work
+// (phase clocks, tools/stamps_gstep4.py).  Here the rows of chunk k + 1 are requested before the MFMAs of chunk k and written to the OTHER tile set after them
+// (two sets in LDS, one barrier per chunk), and the weight fragment is streamed: the K loop is the outer one (K step t feeds all eight row blocks), so the two
+// vectors of step t are dead after it and chunk k + 1's are requested into the same registers right there, three K steps ahead of their use.  No more registers
+// than k_gstep4 + the 10 of the rows in flight.  Every accumulator still receives its products in k_gstep4's order (chunks in order, K steps 0..3): identical bits.
+// Chunks that are not one plain row (sums of two rows, raw inputs) are gathered at staging time as before.
+// element i of a read-only int table at a UNIFORM address, as a scalar load whatever stores and barriers lie in between (constant address space)
+__device__ __forceinline__ int ro_int(const int* p, int i) {
+    typedef const int __attribute__((address_space(4))) cint;
+    const uint64_t u = reinterpret_cast<uint64_t>(p + i);
+    const uint64_t v = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(u & 0xffffffffu));
+    return *reinterpret_cast<cint*>(v);
+}
+typedef const char __attribute__((address_space(1))) gchar;      // global address space, spelled out: a pointer rebuilt from integers is otherwise generic (flat requests, which count on BOTH vmcnt and lgkmcnt)
+__device__ __forceinline__ gchar* uniform_ptr(const char* p) {      // a global pointer the compiler must keep in SGPRs (request = SGPR base + 32-bit VGPR offset)
+    const uint64_t u = reinterpret_cast<uint64_t>(p);
+    return reinterpret_cast<gchar*>(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(u & 0xffffffffu)));
+}
+__device__ __forceinline__ u32x4 gload16(gchar* base, unsigned off) { return *reinterpret_cast<const u32x4 __attribute__((address_space(1)))*>(base + off); }
+__device__ __forceinline__ unsigned gload1(gchar* base, unsigned off) { return *reinterpret_cast<const uint8_t __attribute__((address_space(1)))*>(base + off); }
+// this lane's index, recomputed where it is used (two VALU operations): a thread index kept live across k_gstep5's loop is spilled, and a scratch reload waits for every request in flight
+__device__ __forceinline__ int lane_now() { int l; asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l)); return l; }
+// Two-phase epilogue of a job tile (bf16 arithmetic, NS 32-column slices per wave): EVERY request of the tile first, then the arithmetic and the stores.
+// gstep_epilogue's request -> store per row block is one memory round trip per block (the store may alias the next block's rows, so hipcc keeps their order):
+// 15-25 k clocks per slice of eight blocks, 20-45 k for k_gstep5's two -- a third of its workgroup's time.
+template <int MB, int NS>
+__device__ __forceinline__ void gstep_epilogue2(const GArgs& a, const int* job, P16::Acc (&acc)[NS][MB], int ct, int wv0, int lane, int w0) {
+    using P = P16;
+    const int B = a.B, Hd = a.Hd, flags = ro_int(job, J_FLAGS);
+    // (the job record through the constant address space: behind the K loop's barriers plain loads of it are VECTOR loads, each awaited with vmcnt(0) -- one round trip per row block again)
+    const int j_out_buf = ro_int(job, J_OUT_BUF), j_out_node = ro_int(job, J_OUT_NODE), j_res_buf = ro_int(job, J_RES_BUF), j_res_node = ro_int(job, J_RES_NODE),
+              j_bits_buf = ro_int(job, J_BITS_BUF), j_gate_buf = ro_int(job, J_GATE_BUF), j_gate_node = ro_int(job, J_GATE_NODE);
+    if ((flags & JF_GATE_POS) && (flags & JF_RES)) {      // (no job of the plans has both; they would share the request registers)
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) gstep_epilogue<false, MB>(a, job, acc[sl], ct, wv0 + sl, lane, w0);
+        return;
+    }
+    u32x4 aux[NS][MB]; unsigned xb[NS][MB];
+    const bool want_aux = (flags & (JF_GATE_POS | JF_RES)) != 0;
+    const char* auxb = nullptr; const uint8_t* xbb = nullptr;
+    if (flags & JF_GATE_POS) auxb = a.ws + a.buf_off[j_gate_buf] + g_row<false>(0, j_gate_node, B, Hd) * 2;
+    if (flags & JF_RES) auxb = a.ws + a.buf_off[j_res_buf] + g_row<false>(0, j_res_node, B, Hd) * 2;
+    if (flags & JF_GATE_BITS) xbb = reinterpret_cast<const uint8_t*>(a.ws + a.buf_off[j_gate_buf]);
+#pragma unroll
+    for (int sl = 0; sl < NS; ++sl)
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            const int wc = min(w0 + m * P::ROWS + c_win(lane), B - 1), col = ct * TW + (wv0 + sl) * 32 + c_oct(lane);
+            if (want_aux) aux[sl][m] = *reinterpret_cast<const u32x4*>(auxb + ((size_t)wc * Hd + col) * 2);
+            if (flags & JF_GATE_BITS) xb[sl][m] = xbb[g_relu_byte(j_gate_node, B, Hd, wc, col)];
+        }
+    T16* out = reinterpret_cast<T16*>(a.ws + a.buf_off[j_out_buf]);
+#pragma unroll
+    for (int sl = 0; sl < NS; ++sl)
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            const int wb = w0 + m * P::ROWS, w = wb + c_win(lane), col = ct * TW + (wv0 + sl) * 32 + c_oct(lane);
+            if (wb >= B) continue;
+            P::Acc& ac = acc[sl][m];
+            f32x4 x0 = f32x4{0.f, 0.f, 0.f, 0.f}, x1 = x0;
+            if (want_aux) unpack_oct(aux[sl][m], x0, x1);
+            if (flags & JF_GATE_POS) {      // dU = dT1 . (T1 > 0)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { ac.c[0][q] = x0[q] > 0.f ? ac.c[0][q] : 0.f; ac.c[1][q] = x1[q] > 0.f ? ac.c[1][q] : 0.f; }
+            }
+            if (flags & JF_RELU) {
+                const unsigned bits = relu_with_bits<T16>(ac);
+                if ((flags & JF_BITS_OUT) && a.training)      // (rows past the batch inside the last 16-window block land in the buffer's padding)
+                    reinterpret_cast<uint8_t*>(a.ws + a.buf_off[j_bits_buf])[g_relu_byte(j_out_node, B, Hd, w, col)] = (uint8_t)bits;
+            }
+            f32x4 y0 = ac.c[0], y1 = ac.c[1];
+            if (flags & JF_RES) { y0 += x0; y1 += x1; }
+            if (flags & JF_GATE_BITS) {     // layer 0 of the backward pass: x relu'(X_0) from the encoder's relu bytes
+                const unsigned b8 = xb[sl][m];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { y0[q] = ((b8 >> q) & 1u) ? y0[q] : 0.f; y1[q] = ((b8 >> (4 + q)) & 1u) ? y1[q] : 0.f; }
+            }
+            if (w < B) store_oct(out + g_row<false>(w, j_out_node, B, Hd) + col, y0, y1);
+        }
+}
+
+constexpr int GS5_MAX_TERMS = 16, GS5_TERM_BYTES = 32;      // k_gstep5's term table in LDS (behind the two tile sets)
+constexpr int gs5_lds_bytes(int mb) { return 2 * mb * P16::BLK + GS5_MAX_TERMS * GS5_TERM_BYTES; }
+template <int MB, bool MASKED> __global__ __launch_bounds__(512) void k_gstep5(GArgs a) {      // MASKED: some term of the launch carries relu bits (the backward sweeps: dH = dX . relu bits)
+    using P = P16;
+    constexpr int NW = 8, NS = 2;                                // 8 waves, each NS 32-column slices (64 columns) of the 512: two waves per SIMD, up to 256 registers
+    constexpr int NPASS = MB * 16 / (4 * NW);                    // staging passes: thread = (row rr + 4 NW i, chunk c)
+    static_assert(NPASS >= 1 && NPASS * 4 * NW == MB * 16, "row blocks must cover whole staging passes");
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // two tile sets of MB blocks, then the term table
+    const int tid = threadIdx.x, lane = tid & 63, wq = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nctg = a.NCT / 4;
+    const int ctg = blockIdx.x % nctg, tile = (blockIdx.x / nctg) % a.tiles;
+    const int* job = a.jobs + (size_t)(a.job0 + blockIdx.x / (nctg * a.tiles)) * JOB_INTS;
+    const int w0 = tile * MB * P::ROWS, B = a.B, Hd = a.Hd;
+    const int flags = job[J_FLAGS], nterms = job[J_NTERMS], NCT = a.NCT;
+    const int ct0 = ctg * 4 + (wq >> 1), wv0 = (wq & 1) * 2;      // this wave's slices 2 wq and 2 wq + 1 of the 16: 128-column pack tile ct0, wave slots wv0 and wv0 + 1 of it
+    GEN_TL(0);
+#ifdef GGW_STAMPS
+    long long tk[6] = {0, 0, 0, 0, 0, 0}, t0 = clock64(); int nchunk = 0;      // (phase clocks, tools/stamps_gstep4.py)
+#define GS5_T(k) { const long long t1 = clock64(); tk[k] += t1 - t0; t0 = t1; }
+#else
+#define GS5_T(k)
+#endif
+    // term table: {row base, relu-byte base, pack, has relu bits} of each term, resolved ONCE (item -> source -> buffer offset is a chain of dependent loads) and read
+    // back per term with one LDS broadcast -- behind the loop's barrier hipcc issues plain loads of the plan tables as VECTOR loads, whose vmcnt(0) would wait
+    // for every row and weight request in flight
+    char* ttab = smem + 2 * MB * P::BLK;
+    if (tid < nterms) {
+        const int* term = a.terms + (size_t)(job[J_TERM0] + tid) * TERM_INTS;
+        const int* src = a.srcs + (size_t)term[T_SRC0] * SRC_INTS;
+        const int node = src[S_NODE], mbuf = src[S_MASK];
+        const uint64_t base = reinterpret_cast<uint64_t>(a.ws + a.buf_off[src[S_BUF]]) + g_row<false>(0, node, B, Hd) * 2;
+        const uint64_t mb = reinterpret_cast<uint64_t>(a.ws + a.buf_off[mbuf >= 0 ? mbuf : 0]) + g_relu_byte(node, B, Hd, 0, 0);      // (no relu bits: any mapped address; the bytes are requested and ignored)
+        *reinterpret_cast<u32x4*>(ttab + tid * GS5_TERM_BYTES) = u32x4{(unsigned)base, (unsigned)(base >> 32), (unsigned)mb, (unsigned)(mb >> 32)};
+        *reinterpret_cast<u32x2*>(ttab + tid * GS5_TERM_BYTES + 16) = u32x2{(unsigned)term[T_PACK], mbuf >= 0 ? 1u : 0u};
+    }
+
+    P::Acc acc[NS][MB];
+    {
+        const float* bias = (flags & JF_BIAS) ? a.bias + ((size_t)job[J_BIAS] + ct0) * TW : nullptr;
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl)
+#pragma unroll
+            for (int m = 0; m < MB; ++m) acc_init_bias<T16>(acc[sl][m], bias, wv0 + sl, lane);
+    }
+    const int ao0 = lds_chunk<T16>(0, lane & 15, (lane >> 4) * P::NAV);
+    const int nb16 = (B + 15) >> 4;
+    const char* wbase = reinterpret_cast<const char*>(a.wpack);
+    const unsigned woff = ((unsigned)wv0 * P::NBV * 64 + lane) * 16;      // + pack * (H * H * 2) + slice * 8192 + vector * 1024
+    // Per-thread offsets (32 bits, added to uniform bases) are RECOMPUTED per chunk from the lane index, a dozen VALU operations against 128 MFMAs: kept live across
+    // the loop they -- not the rows in flight -- were what hipcc spilled, and every scratch reload waits for ALL outstanding requests (scratch shares vmcnt).
+    struct Cur { int ti, kc, pack; bool msk; gchar* base; gchar* mb; };      // the chunk stream: (term, K chunk) in order
+    auto open_term = [&](Cur& q) {
+        const u32x4 e = *reinterpret_cast<const u32x4*>(ttab + q.ti * GS5_TERM_BYTES);
+        const u32x2 f = *reinterpret_cast<const u32x2*>(ttab + q.ti * GS5_TERM_BYTES + 16);
+        const uint64_t b = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)e[1]) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)e[0]);
+        const uint64_t m = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)e[3]) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)e[2]);
+        q.base = reinterpret_cast<gchar*>(b); q.mb = reinterpret_cast<gchar*>(m);
+        q.pack = __builtin_amdgcn_readfirstlane((int)f[0]); q.msk = __builtin_amdgcn_readfirstlane((int)f[1]) != 0;
+    };
+    auto advance = [&](Cur& q) { if (++q.kc == NCT) { q.kc = 0; ++q.ti; open_term(q); } };      // (every term of an all-plain launch has NCT chunks)
+    u32x4 rv[NPASS]; unsigned rm[MASKED ? NPASS : 1];
+    auto fetch = [&](const Cur& q) {      // request the rows of a chunk: thread = (window rr + 4 NW i of the tile, 16-byte chunk c); rows past the batch re-read the last window
+        gchar* rb = q.base + q.kc * (TW * 2);
+        gchar* mb = q.mb + (((size_t)(q.kc * 4) * nb16) << 6);
+        const int tt = wq * 64 + lane_now(), c = tt & 15, rr = tt >> 4;
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const unsigned w = (unsigned)min(w0 + i * (4 * NW) + rr, B - 1);
+            rv[i] = gload16(rb, w * (unsigned)(Hd * 2) + (unsigned)(c * 16));
+            if constexpr (MASKED) rm[i] = gload1(mb, ((((unsigned)(c >> 2)) * (unsigned)nb16 + (w >> 4)) << 6) + (unsigned)((c & 3) << 4) + (w & 15u));      // (requested whether or not THIS term has relu bits -- no branch; see stage)
+        }
+    };
+    auto stage = [&](const Cur& q, char* set) {
+        const int tt = wq * 64 + lane_now(), c = tt & 15, rr = tt >> 4;
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const int grow = i * (4 * NW) + rr;
+            *reinterpret_cast<u32x4*>(set + lds_chunk<T16>(grow >> 4, grow & 15, c)) = MASKED ? chunk_mask_bits<T16>(rv[i], q.msk ? rm[i] : 0xffu) : rv[i];
+        }
+    };
+    // weight fragments: a ring of two K steps (slot t & 1 holds vectors t and 4 + t of both slices); after step t its slot takes step t + 2 -- of this chunk, or
+    // steps 0 / 1 of the next one -- so a request has one whole K step (32 MFMAs per wave, two waves per SIMD: ~1 k clocks) to come back from L2
+    bf16x8 wr[2][NS][2];
+    auto wload = [&](int slot, const char* wp, int t) {
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {
+            const unsigned wo = (unsigned)opaque((int)woff);
+            wr[slot][sl][0] = __builtin_bit_cast(bf16x8, gload16(uniform_ptr(wp + sl * 8192 + t * 1024), wo));
+            wr[slot][sl][1] = __builtin_bit_cast(bf16x8, gload16(uniform_ptr(wp + sl * 8192 + (4 + t) * 1024), wo));
+        }
+    };
+    auto mfma_step = [&](const char* cur, int t, auto dbuf) {      // K step t: every row block against the step's two vectors of both slices
+        constexpr bool DBUF = decltype(dbuf)::value;            // the next block's window fragment is read under a block's MFMAs (8 registers instead of 4)
+        const char* xp = cur + (ao0 ^ (16 * t));
+        bf16x8 x0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xp)), x1;
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            if constexpr (DBUF) { if (m + 1 < MB) x1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xp + (m + 1) * P::BLK)); }
+#pragma unroll
+            for (int sl = 0; sl < NS; ++sl) {
+                acc[sl][m].c[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[t & 1][sl][0], x0, acc[sl][m].c[0], 0, 0, 0);
+                acc[sl][m].c[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[t & 1][sl][1], x0, acc[sl][m].c[1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);      // (keeps the read of block m + 1 in front of block m's MFMAs: hipcc otherwise sinks it to its use, one read in flight)
+            if constexpr (DBUF) x0 = x1;
+            else if (m + 1 < MB) x0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xp + (m + 1) * P::BLK));
+        }
+    };
+    const int nchunks = nterms * NCT;
+    __syncthreads();      // the term table
+    if (nchunks > 0) {
+        Cur nx{0, 0, 0, false, nullptr, nullptr};
+        open_term(nx);
+        fetch(nx);
+        const char* wp_cur = wbase + (size_t)(nx.pack + nx.kc * NCT + ct0) * (H * H * 2);
+        wload(0, wp_cur, 0); wload(1, wp_cur, 1);
+        stage(nx, smem);
+        if (nchunks > 1) advance(nx);
+        __syncthreads();
+        int buf = 0;
+        // One chunk per trip (`nx` is the chunk after it), NO branch between the requests and their uses: with the requests inside `if (more)` blocks hipcc's wait
+        // insertion lost count at the joins and put vmcnt(0) in front of the first MFMA.  The last trip has nothing left to prefetch; it requests its own chunk
+        // again (valid addresses, L2 hits, results unused) rather than branch.  The rows of chunk k + 1 are requested in the MIDDLE of chunk k: at its top the
+        // request queue of the CU is still draining the weight requests every wave issued at the end of the previous chunk (1.8 k clocks of stall there).
+        // Measured and not kept (HISTORY.md): the two waves of a SIMD half a chunk apart (waves 4-7 request at the top and stage in mid-chunk, so that one
+        // of the two always has MFMAs to issue while the other stages) -- as two copies of this loop hipcc allocates 256 registers and spills inside both
+        // (each copy alone: 232, none), and every scratch reload is a vmcnt(0): 321 / 455 us per layer launch against 240 / 234.
+        for (int k = 0; k < nchunks; ++k) {
+            const char* cur = smem + buf * (MB * P::BLK);
+            const char* wp_nxt = wbase + (size_t)(nx.pack + nx.kc * NCT + ct0) * (H * H * 2);
+            GS5_T(0)
+            mfma_step(cur, 0, std::true_type{}); wload(0, wp_cur, 2);
+            mfma_step(cur, 1, std::true_type{}); wload(1, wp_cur, 3);
+            fetch(nx);
+            __builtin_amdgcn_sched_barrier(0);      // (nothing of the staging -- the relu-bit select on the requested bytes -- is to be scheduled up here: it would wait for the rows)
+            mfma_step(cur, 2, std::true_type{}); wload(0, wp_nxt, 0);
+            mfma_step(cur, 3, std::true_type{}); wload(1, wp_nxt, 1);
+            wp_cur = wp_nxt;
+#ifdef GGW_STAMPS
+            { float d; asm volatile("v_mov_b32 %0, %1" : "=v"(d) : "v"(acc[NS - 1][MB - 1].c[1][3])); asm volatile("" :: "v"(d)); }
+            ++nchunk;
+#endif
+            GS5_T(1)
+            __builtin_amdgcn_sched_barrier(0);
+            stage(nx, smem + (buf ^ 1) * (MB * P::BLK));
+            if (k + 2 < nchunks) advance(nx);
+            GS5_T(2)
+            __syncthreads();
+            GS5_T(3)
+            buf ^= 1;
+        }
+    }
+    gstep_epilogue2<MB, NS>(a, job, acc, ct0, wv0, lane, w0);
+#ifdef GGW_STAMPS
+    GS5_T(5)
+    if (a.stamps && tid == 0) { for (int q = 0; q < 6; ++q) a.stamps[(size_t)blockIdx.x * 8 + q] = tk[q]; a.stamps[(size_t)blockIdx.x * 8 + 6] = nchunk; a.stamps[(size_t)blockIdx.x * 8 + 7] = nterms; }
+#endif
     GEN_TL(1);
 }
 
@@ -967,7 +1249,7 @@ int gen_create(mshgnn_plan* p, const mshgnn_desc* desc) {
     const int dec_lds = 16 * 8 * TW * 4;
     if ((rc = set_lds_attr(k_gdec_bwd<false>, dec_lds)) || (rc = set_lds_attr(k_gdec_bwd<true>, dec_lds)) ||
         (rc = set_lds_attr(k_gstep<true, 8, 8>, 16 * P16::BLK)) || (rc = set_lds_attr(k_ggradw<true, 1>, ggw_lds_bytes(true, 1))) ||
-        (rc = set_lds_attr(k_ggradw<true, 2>, ggw_lds_bytes(true, 2)))) return rc;
+        (rc = set_lds_attr(k_ggradw<true, 2>, ggw_lds_bytes(true, 2))) || (rc = set_lds_attr(k_gstep5<8, true>, gs5_lds_bytes(8))) || (rc = set_lds_attr(k_gstep5<8, false>, gs5_lds_bytes(8)))) return rc;
     return MSHGNN_OK;
 }
 
@@ -1096,11 +1378,11 @@ static int g_fill(const mshgnn_plan* p, const mshgnn_ws_layout& lay, const void*
 static int g_tile_blocks(int B, bool split) {
     const char* e = getenv("MSHGNN_GEN_TILE");      // (kernel experiments; read per launch so that a test can compare modes in one process)
     const int forced = e ? atoi(e) : -1;
-    if (forced >= 0 && forced <= 6) return forced;
-    // bf16: 16 waves; on 128-window tiles (k_gstep4) once the batch has two of them -- half the weight stream per window, 250-258 / 252-314 us per layer launch
+    if (forced >= 0 && forced <= 8) return forced;
+    // bf16: 16 waves; on 128-window tiles (k_gstep5: the software pipeline of 8 waves; k_gstep4) once the batch has two of them -- half the weight stream per window, 250-258 / 252-314 us per layer launch
     // against 285-292 / 303-357 on the 32-limb model; split arithmetic: k_gstep4 at 16 waves on 64-window tiles (720-740 / 673-766 us against 803-813 / 814-925
     // for k_gstep at 8 waves, whose 16-wave form spills)
-    return split ? 6 : (B >= 256 ? 6 : 3);      // (split, hidden % 512 != 0: the dispatch falls back to k_gstep at 8 / 4 waves)
+    return split ? 6 : (B >= 256 ? 8 : 3);      // (split, hidden % 512 != 0: the dispatch falls back to k_gstep at 8 / 4 waves; 8: k_gstep5 on the launches whose terms are all plain rows, k_gstep4 on the others)
 }
 
 #ifdef GEN_TIMELINE
@@ -1124,13 +1406,35 @@ static void g_launch_jobs(const mshgnn_plan* p, const Launch& ln, GArgs a, hipSt
 #ifdef GEN_TIMELINE
     a.tl = gen_tl(gp.kstats[ln.ks].name);
 #endif
+#ifdef GGW_STAMPS
+    {   // MSHGNN_GS4_STAMPS = "<launch name>:<hex device address>" (tools/stamps_gstep4.py)
+        const char* e = getenv("MSHGNN_GS4_STAMPS"); const char* c = e ? strchr(e, ':') : nullptr; const char* nm = gp.kstats[ln.ks].name;
+        a.stamps = (c && strlen(nm) == (size_t)(c - e) && strncmp(e, nm, (size_t)(c - e)) == 0) ? reinterpret_cast<long long*>(strtoull(c + 1, nullptr, 16)) : nullptr;
+    }
+#endif
     // windows per workgroup: a packed weight fragment (8 KB per wave and K chunk, from L2) is reused for every 16-window row block of the tile
     // output tile of a workgroup: 64 windows x (32 NW) columns.  The staged A tile is shared by all NW waves, so wider tiles re-read the
     // activations fewer times (hidden / (32 NW) column groups per row of jobs): measured at h=512, B=1024: layer_fwd bf16 515 / 354 / 296 us at
     // 4 / 8 / 16 waves, split 870 / 799 / 1012 us (16 waves: 128 VGPRs, spills); 128-window tiles lose (fewer resident workgroups hide less
     // of the staging latency: 495 us at 8 waves, 389 us at 16 waves with 56 B of scratch)
     const int mode = g_tile_blocks(a.B, gp.split);      // 0: 4 waves; 1: 8 waves, 128 windows; 2: 8 waves; 3: 16 waves; 6: k_gstep4 (bf16, hidden % 512 == 0; the default from 256 windows)
-    if (mode == 6 && !gp.split && gp.NCT % 4 == 0) {      // k_gstep4: 16 waves on 128-window tiles (hidden a multiple of 512)
+    if (mode == 8 && !gp.split && gp.NCT % 4 == 0 && ln.all_plain && ln.max_terms <= GS5_MAX_TERMS) {      // k_gstep5: k_gstep4's tile, software-pipelined (launches whose every term is one plain row)
+        a.tiles = (a.B + 127) / 128;
+        const unsigned grid4 = (unsigned)ln.n_jobs * a.tiles * (a.NCT / 4);
+        ProfScope ps(p, ln.ks, st);
+        if (ln.any_mask) hipLaunchKernelGGL((k_gstep5<8, true>), dim3(grid4), dim3(512), gs5_lds_bytes(8), st, a);
+        else hipLaunchKernelGGL((k_gstep5<8, false>), dim3(grid4), dim3(512), gs5_lds_bytes(8), st, a);
+        return;
+    }
+    if (mode == 7 && !gp.split && gp.NCT == 4) {          // k_gstep4 at 8 waves: two workgroups per CU, each 128 windows x 256 columns, out of step with each other
+        a.tiles = (a.B + 127) / 128;
+        a.njt = ln.n_jobs * a.tiles;
+        const unsigned grid8 = (unsigned)((a.njt + 7) / 8) * 16;
+        ProfScope ps(p, ln.ks, st);
+        hipLaunchKernelGGL((k_gstep4<false, 8, 8>), dim3(grid8), dim3(512), 8 * P16::BLK, st, a);
+        return;
+    }
+    if (mode >= 6 && !gp.split && gp.NCT % 4 == 0) {      // k_gstep4: 16 waves on 128-window tiles (hidden a multiple of 512)
         a.tiles = (a.B + 127) / 128;
         const unsigned grid4 = (unsigned)ln.n_jobs * a.tiles * (a.NCT / 4);
         ProfScope ps(p, ln.ks, st);
@@ -1138,7 +1442,7 @@ static void g_launch_jobs(const mshgnn_plan* p, const Launch& ln, GArgs a, hipSt
         return;
     }
     // (hidden = 256: the 8-wave form of k_gstep4 measured 1.51 against 1.47 ms/step for k_gstep on A1-C2, 8192 windows -- tools/time_h256.py; not dispatched)
-    if (mode == 6 && gp.split && gp.NCT % 4 == 0) {       // the split arithmetic: the same kernel at 16 waves on 64-window tiles
+    if (mode >= 6 && gp.split && gp.NCT % 4 == 0) {       // the split arithmetic: the same kernel at 16 waves on 64-window tiles
         a.tiles = (a.B + 63) / 64;
         const unsigned grid4 = (unsigned)ln.n_jobs * a.tiles * (a.NCT / 4);
         ProfScope ps(p, ln.ks, st);

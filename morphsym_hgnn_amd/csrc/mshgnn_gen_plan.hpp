@@ -48,7 +48,7 @@ constexpr int G_MANY = 32;
 enum { AG_OUT_BUF = 0, AG_OUT_NODE, AG_SRC0, AG_NSRC, AGG_INTS = 4 };
 constexpr int G_ITEMS_PER_UNIT = 8;     // items one weight-gradient workgroup sweeps (more units = more parallelism, more slabs to sum)
 
-struct Launch { int job0, n_jobs, ks; int agg0 = 0, n_agg = 0; };      // agg0 / n_agg: the aggregates computed in front of the launch
+struct Launch { int job0, n_jobs, ks; int agg0 = 0, n_agg = 0; bool all_plain = false, any_mask = false; int max_terms = 0; };      // agg0 / n_agg: the aggregates computed in front of the launch; all_plain: every term of every job is ONE activation row at scale 1 (k_gstep5's precondition)
 
 struct GenPlan {
     mshgnn_desc d{};
@@ -270,12 +270,35 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
     int agg_mark = 0;      // first aggregate op of the launch being built
     auto launch = [&](std::vector<Launch>& v, int j0, const std::string& name, double flops, double bytes) {
         const int n = (int)(jobs.size() / JOB_INTS) - j0, na = (int)(aggs.size() / AGG_INTS);
-        if (n > 0) { Launch ln{j0, n, stat(name, MSHGNN_BOUND_MFMA, flops, bytes)}; ln.agg0 = agg_mark; ln.n_agg = na - agg_mark; v.push_back(ln); }
+        if (n > 0) {
+            Launch ln{j0, n, stat(name, MSHGNN_BOUND_MFMA, flops, bytes)}; ln.agg0 = agg_mark; ln.n_agg = na - agg_mark;
+            ln.all_plain = true;
+            for (int j = j0; j < j0 + n && ln.all_plain; ++j) {
+                const int32_t* jb = &jobs[(size_t)j * JOB_INTS];
+                ln.max_terms = std::max(ln.max_terms, (int)jb[J_NTERMS]);
+                for (int ti = jb[J_TERM0]; ti < jb[J_TERM0] + jb[J_NTERMS]; ++ti) {
+                    const int32_t* tm = &terms[(size_t)ti * TERM_INTS];
+                    if (tm[T_NSRC] >= 1 && srcs[(size_t)tm[T_SRC0] * SRC_INTS + S_MASK] >= 0) ln.any_mask = true;
+                    if (tm[T_KIND] != 0 || tm[T_NSRC] != 1 || srcs[(size_t)tm[T_SRC0] * SRC_INTS + S_SCALE] != fbits(1.0f) || tm[T_NKC] != NCT) { ln.all_plain = false; break; }
+                }
+            }
+            v.push_back(ln);
+        }
         agg_mark = na; };
     // a term's / item's source list -> itself, or (more than G_MANY rows) one plain row of the layer's aggregate buffer + the op that fills it
     std::map<std::vector<std::array<int, 4>>, std::array<int, 4>> agg_known;      // (forward aggregates are looked up again by the weight-gradient items)
     int agg_count[2][G_MAX_L] = {};
-    const int g_many = []() { const char* e = std::getenv("MSHGNN_GEN_MANY"); return e ? std::max(2, std::atoi(e)) : G_MANY; }();      // (threshold override, read when the plan is compiled: tests, measurements)
+    // Wide bf16 plans (hidden a multiple of 512: the pipelined job kernel k_gstep5 wants every term to be ONE plain row): a sum of TWO rows at scale 1 becomes two
+    // terms on the same weights (W (a + b) = W a + W b: one more pass of MFMAs for that term, and the sum is no longer rounded to bf16 before the product), longer
+    // sums go through the aggregate buffers from three rows on.  MSHGNN_GEN_SPLIT_SUMS=0 keeps the sums (A/B runs).
+    const bool split_sums = !p.split && NCT % 4 == 0 && []() { const char* e = std::getenv("MSHGNN_GEN_SPLIT_SUMS"); return !(e && std::atoi(e) == 0); }();
+    const int g_many = [&]() { const char* e = std::getenv("MSHGNN_GEN_MANY"); return e ? std::max(2, std::atoi(e)) : (split_sums ? 2 : G_MANY); }();      // (threshold override, read when the plan is compiled: tests, measurements)
+    int n_split_terms = 0;
+    auto push_term = [&](std::vector<TermDef>& tds, const TermDef& td) {
+        bool unit = td.kind == 0 && td.s.size() == 2;
+        for (auto& q : td.s) if (q[3] != fbits(1.0f)) unit = false;
+        if (split_sums && unit) { for (auto& q : td.s) { TermDef t1 = td; t1.s = {q}; tds.push_back(t1); } ++n_split_terms; }
+        else tds.push_back(td); };
     auto many = [&](const std::vector<std::array<int, 4>>& srcl, int dir, int l, bool create) -> std::vector<std::array<int, 4>> {
         if ((int)srcl.size() <= g_many) return srcl;
         auto it = agg_known.find(srcl);
@@ -305,6 +328,7 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
     for (int l = 0; l < L; ++l) {
         // HeteroConv layer l: one job per live destination node (hgnn_c2.py:150-166)
         int j0 = (int)(jobs.size() / JOB_INTS); double fl = 0;
+        const int ns0 = n_split_terms;      // (a split sum runs its weights twice: executed, not algorithmic, work)
         const bool mlp_live = has_mlp && p.live[l][d.mlp_type];
         for (int t = 0; t < NT; ++t) {
             if (!p.live[l][t]) continue;
@@ -319,15 +343,15 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
                     TermDef td{pack_rel[0][l * NR + r], NCT, 0, Hd, 0, {}};
                     for (int j : in_src[r][i]) td.s.push_back(one(BUF_X + l, p.type_base[p.rel_src[r]] + j, -1, scale_of(r, i)));
                     td.s = many(td.s, 0, l, true);
-                    tds.push_back(td);
+                    push_term(tds, td);
                 }
                 fl += NL * tds.size();
                 if (mlp) add_job(BUF_HB + l, i, JF_BIAS, bias_layer[l * NT + t], -1, 0, -1, -1, 0, tds);      // H -> base_transform
                 else add_job(BUF_X + l + 1, n, JF_BIAS | JF_RELU | JF_BITS_OUT | (residual ? JF_RES : 0), bias_layer[l * NT + t], BUF_X + l, n, BUF_MASK + l, -1, 0, tds);
             }
         }
-        alg_fwd += fl; exec_fwd += fl;
-        launch(p.fwd, j0, "layer_fwd" + std::to_string(l), fl, 2.0 * p.NN * Hd * es);
+        alg_fwd += fl - NL * (n_split_terms - ns0); exec_fwd += fl;
+        launch(p.fwd, j0, "layer_fwd" + std::to_string(l), fl - NL * (n_split_terms - ns0), 2.0 * p.NN * Hd * es);
         if (mlp_live) {   // base_transform: Y = W2 relu(W1 H + b1) + b2, X <- Y + X    (hgnn_c2.py:117-121,156,161-166)
             j0 = (int)(jobs.size() / JOB_INTS);
             for (int u = 0; u < p.n_mlp; ++u)
@@ -366,6 +390,7 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
         }
         // dX_l[j] = (residual) + dH_j W_rootsum + sum_r W_rel^r-transposed Agg of dH over the out-edges of j; layer 0 also applies relu'(X_0)
         const int j0 = (int)(jobs.size() / JOB_INTS); double fl = 0;
+        const int ns0 = n_split_terms;
         for (int s = 0; s < NT; ++s) {
             if (!p.need_dx[l][s]) continue;
             for (int j = 0; j < d.type_nodes[s]; ++j) {
@@ -379,15 +404,15 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
                     for (int i : out_dst[r][j]) if (live_n[l][p.type_base[p.rel_dst[r]] + i]) td.s.push_back(dh_src(l, p.type_base[p.rel_dst[r]] + i, scale_of(r, i)));
                     if (td.s.empty()) continue;
                     td.s = many(td.s, 1, l, true);
-                    tds.push_back(td);
+                    push_term(tds, td);
                 }
                 fl += NL * tds.size();
                 const bool res = residual && live_n[l][n];
                 add_job(BUF_DX + l, n, (res ? JF_RES : 0) | (l == 0 ? JF_GATE_BITS : 0), 0, BUF_DX + l + 1, n, -1, GBUF_MASK0, n, tds);
             }
         }
-        alg_bwd += fl; exec_bwd += fl;
-        launch(p.bwd, j0, "layer_bwd" + std::to_string(l), fl, 3.0 * p.NN * Hd * es);
+        alg_bwd += fl - NL * (n_split_terms - ns0); exec_bwd += fl;
+        launch(p.bwd, j0, "layer_bwd" + std::to_string(l), fl - NL * (n_split_terms - ns0), 3.0 * p.NN * Hd * es);
     }
 
     // ---- weight-gradient targets / items / units / finalize ops -----------------------------------------------------------
