@@ -31,7 +31,7 @@ struct GArgs {
     const void* x[MSHGNN_MAX_TYPES]; int64_t pitch[MSHGNN_MAX_TYPES]; int nodes[MSHGNN_MAX_TYPES]; int vb[MSHGNN_MAX_TYPES]; int aligned;
     const int* jobs; const int* terms; const int* srcs; const int* units; const int* items; const int* sunits; const int* su_order; const int* aggs;
     const void* wpack; const float* bias; const uint8_t* signs; float* slabs;
-    int n_img, B, Hd, NCT, tiles, training, job0, n_units, n_parts, n_sunits, njt;      // njt: (job, tile) pairs of a k_gstep4 launch at 8 waves
+    int n_img, B, Hd, NCT, tiles, training, job0, n_units, n_parts, n_sunits;
 #ifdef GGW_STAMPS
     long long* stamps;      // (phase clocks of k_ggradw, tools/stamps_ggradw.py)
 #endif
@@ -146,6 +146,94 @@ __device__ __forceinline__ void gstep_epilogue(const GArgs& a, const int* job, P
     }
 }
 
+// element i of a read-only int table at a UNIFORM address, as a scalar load whatever stores and barriers lie in between (constant address space)
+__device__ __forceinline__ int ro_int(const int* p, int i) {
+    typedef const int __attribute__((address_space(4))) cint;
+    const uint64_t u = reinterpret_cast<uint64_t>(p + i);
+    const uint64_t v = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(u & 0xffffffffu));
+    return *reinterpret_cast<cint*>(v);
+}
+typedef const char __attribute__((address_space(1))) gchar;      // global address space, spelled out: a pointer rebuilt from integers is otherwise generic (flat requests, which count on BOTH vmcnt and lgkmcnt)
+__device__ __forceinline__ gchar* uniform_ptr(const char* p) {      // a global pointer the compiler must keep in SGPRs (request = SGPR base + 32-bit VGPR offset)
+    const uint64_t u = reinterpret_cast<uint64_t>(p);
+    return reinterpret_cast<gchar*>(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(u & 0xffffffffu)));
+}
+__device__ __forceinline__ u32x4 gload16(gchar* base, unsigned off) { return *reinterpret_cast<const u32x4 __attribute__((address_space(1)))*>(base + off); }
+__device__ __forceinline__ unsigned gload1(gchar* base, unsigned off) { return *reinterpret_cast<const uint8_t __attribute__((address_space(1)))*>(base + off); }
+// this lane's index, recomputed where it is used (two VALU operations): a thread index kept live across k_gstep5's loop is spilled, and a scratch reload waits for every request in flight
+__device__ __forceinline__ int lane_now() { int l; asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l)); return l; }
+// Two-phase epilogue of a job tile (bf16 arithmetic, NS 32-column slices per wave): EVERY request of the tile first, then the arithmetic and the stores.
+// gstep_epilogue's request -> store per row block is one memory round trip per block (the store may alias the next block's rows, so hipcc keeps their order):
+// 15-25 k clocks per slice of eight blocks, 20-45 k for k_gstep5's two -- a third of its workgroup's time.
+template <bool SPLIT, int MB, int NS>
+__device__ __forceinline__ void gstep_epilogue2(const GArgs& a, const int* job, P16::Acc (&acc)[NS][MB], int ct, int wv0, int lane, int w0) {
+    using P = P16;
+    const int B = a.B, Hd = a.Hd, flags = ro_int(job, J_FLAGS);
+    // (the job record through the constant address space: behind the K loop's barriers plain loads of it are VECTOR loads, each awaited with vmcnt(0) -- one round trip per row block again)
+    const int j_out_buf = ro_int(job, J_OUT_BUF), j_out_node = ro_int(job, J_OUT_NODE), j_res_buf = ro_int(job, J_RES_BUF), j_res_node = ro_int(job, J_RES_NODE),
+              j_bits_buf = ro_int(job, J_BITS_BUF), j_gate_buf = ro_int(job, J_GATE_BUF), j_gate_node = ro_int(job, J_GATE_NODE);
+    if ((flags & JF_GATE_POS) && (flags & JF_RES)) {      // (no job of the plans has both; they would share the request registers)
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) gstep_epilogue<SPLIT, MB>(a, job, acc[sl], ct, wv0 + sl, lane, w0);
+        return;
+    }
+    u32x4 aux[NS][MB], auxl[SPLIT ? NS : 1][SPLIT ? MB : 1]; unsigned xb[NS][MB];
+    const bool want_aux = (flags & (JF_GATE_POS | JF_RES)) != 0, want_lo = SPLIT && (flags & JF_RES) != 0;      // (the gate reads the hi half only: it carries the sign)
+    const char* auxb = nullptr; const uint8_t* xbb = nullptr;
+    if (flags & JF_GATE_POS) auxb = a.ws + a.buf_off[j_gate_buf] + g_row<SPLIT>(0, j_gate_node, B, Hd) * 2;
+    if (flags & JF_RES) auxb = a.ws + a.buf_off[j_res_buf] + g_row<SPLIT>(0, j_res_node, B, Hd) * 2;
+    if (flags & JF_GATE_BITS) xbb = reinterpret_cast<const uint8_t*>(a.ws + a.buf_off[j_gate_buf]);
+    constexpr int RS = SPLIT ? 2 : 1;      // row stride in units of Hd elements
+#pragma unroll
+    for (int sl = 0; sl < NS; ++sl)
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            const int wc = min(w0 + m * P::ROWS + c_win(lane), B - 1), col = ct * TW + (wv0 + sl) * 32 + c_oct(lane);
+            if (want_aux) aux[sl][m] = *reinterpret_cast<const u32x4*>(auxb + ((size_t)wc * (RS * Hd) + col) * 2);
+            if constexpr (SPLIT) { if (want_lo) auxl[sl][m] = *reinterpret_cast<const u32x4*>(auxb + ((size_t)wc * (RS * Hd) + Hd + col) * 2); }
+            if (flags & JF_GATE_BITS) xb[sl][m] = xbb[g_relu_byte(j_gate_node, B, Hd, wc, col)];
+        }
+    T16* out = reinterpret_cast<T16*>(a.ws + a.buf_off[j_out_buf]);
+#pragma unroll
+    for (int sl = 0; sl < NS; ++sl)
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            const int wb = w0 + m * P::ROWS, w = wb + c_win(lane), col = ct * TW + (wv0 + sl) * 32 + c_oct(lane);
+            if (wb >= B) continue;
+            P::Acc& ac = acc[sl][m];
+            f32x4 x0 = f32x4{0.f, 0.f, 0.f, 0.f}, x1 = x0;
+            if (want_aux) {
+                if constexpr (SPLIT) { if (want_lo) join_oct(aux[sl][m], auxl[sl][m], x0, x1); else unpack_oct(aux[sl][m], x0, x1); }
+                else unpack_oct(aux[sl][m], x0, x1);
+            }
+            if (flags & JF_GATE_POS) {      // dU = dT1 . (T1 > 0)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { ac.c[0][q] = x0[q] > 0.f ? ac.c[0][q] : 0.f; ac.c[1][q] = x1[q] > 0.f ? ac.c[1][q] : 0.f; }
+            }
+            if (flags & JF_RELU) {
+                const unsigned bits = relu_with_bits<T16>(ac);
+                if ((flags & JF_BITS_OUT) && a.training)      // (rows past the batch inside the last 16-window block land in the buffer's padding)
+                    reinterpret_cast<uint8_t*>(a.ws + a.buf_off[j_bits_buf])[g_relu_byte(j_out_node, B, Hd, w, col)] = (uint8_t)bits;
+            }
+            f32x4 y0 = ac.c[0], y1 = ac.c[1];
+            if (flags & JF_RES) { y0 += x0; y1 += x1; }
+            if (flags & JF_GATE_BITS) {     // layer 0 of the backward pass: x relu'(X_0) from the encoder's relu bytes
+                const unsigned b8 = xb[sl][m];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { y0[q] = ((b8 >> q) & 1u) ? y0[q] : 0.f; y1[q] = ((b8 >> (4 + q)) & 1u) ? y1[q] : 0.f; }
+            }
+            if (w < B) {
+                T16* q = out + g_row<SPLIT>(w, j_out_node, B, Hd) + col;
+                if constexpr (SPLIT) {
+                    u32x4 hi, lo;
+                    split_oct(y0, y1, hi, lo);
+                    *reinterpret_cast<u32x4*>(q) = hi;
+                    *reinterpret_cast<u32x4*>(q + Hd) = lo;
+                } else store_oct(q, y0, y1);
+            }
+        }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // k_gstep
 // ------------------------------------------------------------------------------------------------------
@@ -249,22 +337,15 @@ template <bool SPLIT, int MB, int NW> __global__ __launch_bounds__(64 * NW) void
 // other chunks one row at a time, and the window fragments are read per K step (4 registers) instead of per row block (16).
 // SPLIT (the split-bf16 arithmetic of section 4b: rows [hi Hd | lo Hd], three products per term) runs it on 64-window tiles (MB = 4): with the same register diet
 // its 16-wave form fits the 128 registers that k_gstep<true, 4, 16> overflowed, so the A tile is staged once for 512 columns instead of twice.
-template <bool SPLIT, int MB, int NW> __global__ __launch_bounds__(64 * NW, 4) void k_gstep4(GArgs a) {      // (4 waves per SIMD: 128 registers, so that two 8-wave workgroups share a CU)
+template <bool SPLIT, int MB, int NW> __global__ __launch_bounds__(64 * NW) void k_gstep4(GArgs a) {
     using P = P16;
     constexpr int CPW = NW / 4, NPASS = MB * 16 / (4 * NW);      // staging passes: thread = (row rr + 4 NW i, chunk c)
     static_assert(NPASS >= 1 && NPASS * 4 * NW == MB * 16, "row blocks must cover whole staging passes");
     extern __shared__ __attribute__((aligned(16))) char smem[];      // blocks [0, MB): (hi) A tile; [MB, 2 MB): lo halves (split arithmetic)
     const int tid = threadIdx.x, lane = tid & 63, wq = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nctg = a.NCT / CPW;
-    int ctg, jt;      // column group and (job, tile) index of this workgroup
-    if constexpr (NW == 8) {
-        // two workgroups per (job, tile), one per half of the 512 columns; they read the same source rows, so they sit 8 blocks apart: same XCD (round-robin
-        // dispatch), dispatched back to back -- the second reader finds the rows in that XCD's L2 (grid padded to whole groups of 16)
-        ctg = (blockIdx.x >> 3) & 1; jt = (blockIdx.x >> 4) * 8 + (blockIdx.x & 7);
-        if (jt >= a.njt) return;
-    } else { ctg = blockIdx.x % nctg; jt = blockIdx.x / nctg; }
-    const int ct = ctg * CPW + (wq >> 2), wv = wq & 3, tile = jt % a.tiles;
-    const int* job = a.jobs + (size_t)(a.job0 + jt / a.tiles) * JOB_INTS;
+    const int ct = (blockIdx.x % nctg) * CPW + (wq >> 2), wv = wq & 3, tile = (blockIdx.x / nctg) % a.tiles;
+    const int* job = a.jobs + (size_t)(a.job0 + blockIdx.x / (nctg * a.tiles)) * JOB_INTS;
     const int w0 = tile * MB * P::ROWS, B = a.B, Hd = a.Hd;
     const int flags = job[J_FLAGS];
     const T16* wpack = reinterpret_cast<const T16*>(a.wpack);
@@ -397,81 +478,6 @@ template <bool SPLIT, int MB, int NW> __global__ __launch_bounds__(64 * NW, 4) v
 // vectors of step t are dead after it and chunk k + 1's are requested into the same registers right there, three K steps ahead of their use.  No more registers
 // than k_gstep4 + the 10 of the rows in flight.  Every accumulator still receives its products in k_gstep4's order (chunks in order, K steps 0..3): identical bits.
 // Chunks that are not one plain row (sums of two rows, raw inputs) are gathered at staging time as before.
-// element i of a read-only int table at a UNIFORM address, as a scalar load whatever stores and barriers lie in between (constant address space)
-__device__ __forceinline__ int ro_int(const int* p, int i) {
-    typedef const int __attribute__((address_space(4))) cint;
-    const uint64_t u = reinterpret_cast<uint64_t>(p + i);
-    const uint64_t v = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(u & 0xffffffffu));
-    return *reinterpret_cast<cint*>(v);
-}
-typedef const char __attribute__((address_space(1))) gchar;      // global address space, spelled out: a pointer rebuilt from integers is otherwise generic (flat requests, which count on BOTH vmcnt and lgkmcnt)
-__device__ __forceinline__ gchar* uniform_ptr(const char* p) {      // a global pointer the compiler must keep in SGPRs (request = SGPR base + 32-bit VGPR offset)
-    const uint64_t u = reinterpret_cast<uint64_t>(p);
-    return reinterpret_cast<gchar*>(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(u & 0xffffffffu)));
-}
-__device__ __forceinline__ u32x4 gload16(gchar* base, unsigned off) { return *reinterpret_cast<const u32x4 __attribute__((address_space(1)))*>(base + off); }
-__device__ __forceinline__ unsigned gload1(gchar* base, unsigned off) { return *reinterpret_cast<const uint8_t __attribute__((address_space(1)))*>(base + off); }
-// this lane's index, recomputed where it is used (two VALU operations): a thread index kept live across k_gstep5's loop is spilled, and a scratch reload waits for every request in flight
-__device__ __forceinline__ int lane_now() { int l; asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l)); return l; }
-// Two-phase epilogue of a job tile (bf16 arithmetic, NS 32-column slices per wave): EVERY request of the tile first, then the arithmetic and the stores.
-// gstep_epilogue's request -> store per row block is one memory round trip per block (the store may alias the next block's rows, so hipcc keeps their order):
-// 15-25 k clocks per slice of eight blocks, 20-45 k for k_gstep5's two -- a third of its workgroup's time.
-template <int MB, int NS>
-__device__ __forceinline__ void gstep_epilogue2(const GArgs& a, const int* job, P16::Acc (&acc)[NS][MB], int ct, int wv0, int lane, int w0) {
-    using P = P16;
-    const int B = a.B, Hd = a.Hd, flags = ro_int(job, J_FLAGS);
-    // (the job record through the constant address space: behind the K loop's barriers plain loads of it are VECTOR loads, each awaited with vmcnt(0) -- one round trip per row block again)
-    const int j_out_buf = ro_int(job, J_OUT_BUF), j_out_node = ro_int(job, J_OUT_NODE), j_res_buf = ro_int(job, J_RES_BUF), j_res_node = ro_int(job, J_RES_NODE),
-              j_bits_buf = ro_int(job, J_BITS_BUF), j_gate_buf = ro_int(job, J_GATE_BUF), j_gate_node = ro_int(job, J_GATE_NODE);
-    if ((flags & JF_GATE_POS) && (flags & JF_RES)) {      // (no job of the plans has both; they would share the request registers)
-#pragma unroll
-        for (int sl = 0; sl < NS; ++sl) gstep_epilogue<false, MB>(a, job, acc[sl], ct, wv0 + sl, lane, w0);
-        return;
-    }
-    u32x4 aux[NS][MB]; unsigned xb[NS][MB];
-    const bool want_aux = (flags & (JF_GATE_POS | JF_RES)) != 0;
-    const char* auxb = nullptr; const uint8_t* xbb = nullptr;
-    if (flags & JF_GATE_POS) auxb = a.ws + a.buf_off[j_gate_buf] + g_row<false>(0, j_gate_node, B, Hd) * 2;
-    if (flags & JF_RES) auxb = a.ws + a.buf_off[j_res_buf] + g_row<false>(0, j_res_node, B, Hd) * 2;
-    if (flags & JF_GATE_BITS) xbb = reinterpret_cast<const uint8_t*>(a.ws + a.buf_off[j_gate_buf]);
-#pragma unroll
-    for (int sl = 0; sl < NS; ++sl)
-#pragma unroll
-        for (int m = 0; m < MB; ++m) {
-            const int wc = min(w0 + m * P::ROWS + c_win(lane), B - 1), col = ct * TW + (wv0 + sl) * 32 + c_oct(lane);
-            if (want_aux) aux[sl][m] = *reinterpret_cast<const u32x4*>(auxb + ((size_t)wc * Hd + col) * 2);
-            if (flags & JF_GATE_BITS) xb[sl][m] = xbb[g_relu_byte(j_gate_node, B, Hd, wc, col)];
-        }
-    T16* out = reinterpret_cast<T16*>(a.ws + a.buf_off[j_out_buf]);
-#pragma unroll
-    for (int sl = 0; sl < NS; ++sl)
-#pragma unroll
-        for (int m = 0; m < MB; ++m) {
-            const int wb = w0 + m * P::ROWS, w = wb + c_win(lane), col = ct * TW + (wv0 + sl) * 32 + c_oct(lane);
-            if (wb >= B) continue;
-            P::Acc& ac = acc[sl][m];
-            f32x4 x0 = f32x4{0.f, 0.f, 0.f, 0.f}, x1 = x0;
-            if (want_aux) unpack_oct(aux[sl][m], x0, x1);
-            if (flags & JF_GATE_POS) {      // dU = dT1 . (T1 > 0)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { ac.c[0][q] = x0[q] > 0.f ? ac.c[0][q] : 0.f; ac.c[1][q] = x1[q] > 0.f ? ac.c[1][q] : 0.f; }
-            }
-            if (flags & JF_RELU) {
-                const unsigned bits = relu_with_bits<T16>(ac);
-                if ((flags & JF_BITS_OUT) && a.training)      // (rows past the batch inside the last 16-window block land in the buffer's padding)
-                    reinterpret_cast<uint8_t*>(a.ws + a.buf_off[j_bits_buf])[g_relu_byte(j_out_node, B, Hd, w, col)] = (uint8_t)bits;
-            }
-            f32x4 y0 = ac.c[0], y1 = ac.c[1];
-            if (flags & JF_RES) { y0 += x0; y1 += x1; }
-            if (flags & JF_GATE_BITS) {     // layer 0 of the backward pass: x relu'(X_0) from the encoder's relu bytes
-                const unsigned b8 = xb[sl][m];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { y0[q] = ((b8 >> q) & 1u) ? y0[q] : 0.f; y1[q] = ((b8 >> (4 + q)) & 1u) ? y1[q] : 0.f; }
-            }
-            if (w < B) store_oct(out + g_row<false>(w, j_out_node, B, Hd) + col, y0, y1);
-        }
-}
-
 constexpr int GS5_MAX_TERMS = 16, GS5_TERM_BYTES = 32;      // k_gstep5's term table in LDS (behind the two tile sets)
 constexpr int gs5_lds_bytes(int mb) { return 2 * mb * P16::BLK + GS5_MAX_TERMS * GS5_TERM_BYTES; }
 template <int MB, bool MASKED> __global__ __launch_bounds__(512) void k_gstep5(GArgs a) {      // MASKED: some term of the launch carries relu bits (the backward sweeps: dH = dX . relu bits)
@@ -624,7 +630,7 @@ template <int MB, bool MASKED> __global__ __launch_bounds__(512) void k_gstep5(G
             buf ^= 1;
         }
     }
-    gstep_epilogue2<MB, NS>(a, job, acc, ct0, wv0, lane, w0);
+    gstep_epilogue2<false, MB, NS>(a, job, acc, ct0, wv0, lane, w0);
 #ifdef GGW_STAMPS
     GS5_T(5)
     if (a.stamps && tid == 0) { for (int q = 0; q < 6; ++q) a.stamps[(size_t)blockIdx.x * 8 + q] = tk[q]; a.stamps[(size_t)blockIdx.x * 8 + 6] = nchunk; a.stamps[(size_t)blockIdx.x * 8 + 7] = nterms; }
@@ -777,9 +783,17 @@ template <bool SPLIT> __global__ __launch_bounds__(256) void k_gdec_bwd(GDecArgs
 // The wave grid is a parameter (NWV / 4 wave rows x 4 wave columns) because other shapes were measured on the bf16 plan -- 8 waves of 128x64 with double-buffered
 // tiles: 12 % faster on the lean super-units, but a different block size than the general ones need, i.e. a second launch; 4 waves of 128x128 with the
 // accumulators in the AGPRs: hipcc spills 0.7-1.5 KB per lane whichever way the accumulators are pinned -- the launches use NWV = 8 OS.
-constexpr int ggw_lds_bytes(bool split, int os) { return 2 * (split ? 2 : 1) * (os + 2) * 32 * GWB_PITCH * 2; }      // k_ggradw's dynamic LDS: two tile sets per plane
+// (measured on the 32-limb model, B = 1024: 64 windows per step at 16 waves spills -- 1.99 ms; 8 waves of 128 x 64 at 64 / 32 windows per step 1.40 / 1.47 ms; 16 waves at 32: 1.16 ms)
+#ifndef GGW_KW_BF16
+#define GGW_KW_BF16 32
+#endif
+#ifndef GGW_NWV_BF16
+#define GGW_NWV_BF16 16
+#endif
+constexpr int ggw_kw(bool split, int os) { return (!split && os == 2) ? GGW_KW_BF16 : 32; }      // windows per step (= per barrier) of k_ggradw
+constexpr int ggw_lds_bytes(bool split, int os) { return 2 * (split ? 2 : 1) * (os + 2) * ggw_kw(split, os) * GWB_PITCH * 2; }      // k_ggradw's dynamic LDS: two tile sets per plane
 template <bool SPLIT, int OS, int NWV = 8 * OS> __global__ __launch_bounds__(64 * NWV) void k_ggradw(GArgs a) {
-    constexpr int KW = 32, NT = 64 * NWV, PC = 16 * OS;      // PC: 16-byte chunks per staged P row
+    constexpr int KW = ggw_kw(SPLIT, OS), NT = 64 * NWV, PC = 16 * OS;      // KW: windows per step; PC: 16-byte chunks per staged P row
     constexpr int NQ = KW * 32 / NT;                         // Q chunks per thread (1 with 1024 threads, 2 with 512)
     constexpr int NP = KW * PC / NT, PR = NT / PC;           // P chunks per thread; P rows per staging pass
     constexpr int WCOLS = 4;                                 // wave grid: NWV / WCOLS rows x WCOLS columns
@@ -1249,7 +1263,7 @@ int gen_create(mshgnn_plan* p, const mshgnn_desc* desc) {
     const int dec_lds = 16 * 8 * TW * 4;
     if ((rc = set_lds_attr(k_gdec_bwd<false>, dec_lds)) || (rc = set_lds_attr(k_gdec_bwd<true>, dec_lds)) ||
         (rc = set_lds_attr(k_gstep<true, 8, 8>, 16 * P16::BLK)) || (rc = set_lds_attr(k_ggradw<true, 1>, ggw_lds_bytes(true, 1))) ||
-        (rc = set_lds_attr(k_ggradw<true, 2>, ggw_lds_bytes(true, 2))) || (rc = set_lds_attr(k_gstep5<8, true>, gs5_lds_bytes(8))) || (rc = set_lds_attr(k_gstep5<8, false>, gs5_lds_bytes(8)))) return rc;
+        (rc = set_lds_attr(k_ggradw<true, 2>, ggw_lds_bytes(true, 2))) || (rc = set_lds_attr(k_ggradw<false, 2, GGW_NWV_BF16>, ggw_lds_bytes(false, 2))) || (rc = set_lds_attr(k_gstep5<8, true>, gs5_lds_bytes(8))) || (rc = set_lds_attr(k_gstep5<8, false>, gs5_lds_bytes(8)))) return rc;
     return MSHGNN_OK;
 }
 
@@ -1378,7 +1392,7 @@ static int g_fill(const mshgnn_plan* p, const mshgnn_ws_layout& lay, const void*
 static int g_tile_blocks(int B, bool split) {
     const char* e = getenv("MSHGNN_GEN_TILE");      // (kernel experiments; read per launch so that a test can compare modes in one process)
     const int forced = e ? atoi(e) : -1;
-    if (forced >= 0 && forced <= 8) return forced;
+    if (forced >= 0 && forced <= 8 && forced != 7) return forced;
     // bf16: 16 waves; on 128-window tiles (k_gstep5: the software pipeline of 8 waves; k_gstep4) once the batch has two of them -- half the weight stream per window, 250-258 / 252-314 us per layer launch
     // against 285-292 / 303-357 on the 32-limb model; split arithmetic: k_gstep4 at 16 waves on 64-window tiles (720-740 / 673-766 us against 803-813 / 814-925
     // for k_gstep at 8 waves, whose 16-wave form spills)
@@ -1424,14 +1438,6 @@ static void g_launch_jobs(const mshgnn_plan* p, const Launch& ln, GArgs a, hipSt
         ProfScope ps(p, ln.ks, st);
         if (ln.any_mask) hipLaunchKernelGGL((k_gstep5<8, true>), dim3(grid4), dim3(512), gs5_lds_bytes(8), st, a);
         else hipLaunchKernelGGL((k_gstep5<8, false>), dim3(grid4), dim3(512), gs5_lds_bytes(8), st, a);
-        return;
-    }
-    if (mode == 7 && !gp.split && gp.NCT == 4) {          // k_gstep4 at 8 waves: two workgroups per CU, each 128 windows x 256 columns, out of step with each other
-        a.tiles = (a.B + 127) / 128;
-        a.njt = ln.n_jobs * a.tiles;
-        const unsigned grid8 = (unsigned)((a.njt + 7) / 8) * 16;
-        ProfScope ps(p, ln.ks, st);
-        hipLaunchKernelGGL((k_gstep4<false, 8, 8>), dim3(grid8), dim3(512), 8 * P16::BLK, st, a);
         return;
     }
     if (mode >= 6 && !gp.split && gp.NCT % 4 == 0) {      // k_gstep4: 16 waves on 128-window tiles (hidden a multiple of 512)
@@ -1534,7 +1540,7 @@ int gen_backward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pi
 #endif
         if (gp.split && gp.su_os == 2) hipLaunchKernelGGL((k_ggradw<true, 2>), dim3(grid), dim3(1024), ggw_lds_bytes(true, 2), st, a);
         else if (gp.split) hipLaunchKernelGGL((k_ggradw<true, 1>), dim3(grid), dim3(512), ggw_lds_bytes(true, 1), st, a);
-        else if (gp.su_os == 2) hipLaunchKernelGGL((k_ggradw<false, 2>), dim3(grid), dim3(1024), ggw_lds_bytes(false, 2), st, a);
+        else if (gp.su_os == 2) hipLaunchKernelGGL((k_ggradw<false, 2, GGW_NWV_BF16>), dim3(grid), dim3(64 * GGW_NWV_BF16), ggw_lds_bytes(false, 2), st, a);
         else hipLaunchKernelGGL((k_ggradw<false, 1>), dim3(grid), dim3(512), ggw_lds_bytes(false, 1), st, a);
     }
     {
