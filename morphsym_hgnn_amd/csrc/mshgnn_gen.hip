@@ -609,12 +609,19 @@ template <int MB, bool MASKED> __global__ __launch_bounds__(512) void k_gstep5(G
             const char* cur = smem + buf * (MB * P::BLK);
             const char* wp_nxt = wbase + (size_t)(nx.pack + nx.kc * NCT + ct0) * (H * H * 2);
             GS5_T(0)
-            mfma_step(cur, 0, std::true_type{}); wload(0, wp_cur, 2);
-            mfma_step(cur, 1, std::true_type{}); wload(1, wp_cur, 3);
+#ifdef GS5_ABL_W      // (ablation builds, timing only: no weight requests inside the loop / no row requests and staging)
+#define GS5_WLOAD(s, p, t)
+#else
+#define GS5_WLOAD(s, p, t) wload(s, p, t)
+#endif
+            mfma_step(cur, 0, std::true_type{}); GS5_WLOAD(0, wp_cur, 2);
+            mfma_step(cur, 1, std::true_type{}); GS5_WLOAD(1, wp_cur, 3);
+#ifndef GS5_ABL_ROWS
             fetch(nx);
+#endif
             __builtin_amdgcn_sched_barrier(0);      // (nothing of the staging -- the relu-bit select on the requested bytes -- is to be scheduled up here: it would wait for the rows)
-            mfma_step(cur, 2, std::true_type{}); wload(0, wp_nxt, 0);
-            mfma_step(cur, 3, std::true_type{}); wload(1, wp_nxt, 1);
+            mfma_step(cur, 2, std::true_type{}); GS5_WLOAD(0, wp_nxt, 0);
+            mfma_step(cur, 3, std::true_type{}); GS5_WLOAD(1, wp_nxt, 1);
             wp_cur = wp_nxt;
 #ifdef GGW_STAMPS
             { float d; asm volatile("v_mov_b32 %0, %1" : "=v"(d) : "v"(acc[NS - 1][MB - 1].c[1][3])); asm volatile("" :: "v"(d)); }
@@ -622,7 +629,9 @@ template <int MB, bool MASKED> __global__ __launch_bounds__(512) void k_gstep5(G
 #endif
             GS5_T(1)
             __builtin_amdgcn_sched_barrier(0);
+#ifndef GS5_ABL_ROWS
             stage(nx, smem + (buf ^ 1) * (MB * P::BLK));
+#endif
             if (k + 2 < nchunks) advance(nx);
             GS5_T(2)
             __syncthreads();
