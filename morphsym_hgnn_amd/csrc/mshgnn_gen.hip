@@ -479,10 +479,13 @@ template <bool SPLIT, int MB, int NW> __global__ __launch_bounds__(64 * NW) void
 // than k_gstep4 + the 10 of the rows in flight.  Every accumulator still receives its products in k_gstep4's order (chunks in order, K steps 0..3): identical bits.
 // Chunks that are not one plain row (sums of two rows, raw inputs) are gathered at staging time as before.
 constexpr int GS5_MAX_TERMS = 16, GS5_TERM_BYTES = 32;      // k_gstep5's term table in LDS (behind the two tile sets)
-constexpr int gs5_lds_bytes(int mb) { return 2 * mb * P16::BLK + GS5_MAX_TERMS * GS5_TERM_BYTES; }
-template <int MB, bool MASKED> __global__ __launch_bounds__(512) void k_gstep5(GArgs a) {      // MASKED: some term of the launch carries relu bits (the backward sweeps: dH = dX . relu bits)
+constexpr int gs5_lds_bytes(bool split, int mb) { return 2 * (split ? 2 : 1) * mb * P16::BLK + GS5_MAX_TERMS * GS5_TERM_BYTES; }
+// SPLIT (the split-bf16 arithmetic of section 4b: rows [hi Hd | lo Hd], three products per term, hi x hi, lo-weights x hi, hi-weights x lo) runs it on 64-window tiles
+// (MB = 4): twice the planes in the weight ring, the rows in flight and the window fragments.
+template <bool SPLIT, int MB, bool MASKED> __global__ __launch_bounds__(512) void k_gstep5(GArgs a) {      // MASKED: some term of the launch carries relu bits (the backward sweeps: dH = dX . relu bits)
     using P = P16;
-    constexpr int NW = 8, NS = 2;                                // 8 waves, each NS 32-column slices (64 columns) of the 512: two waves per SIMD, up to 256 registers
+    constexpr int NW = 8, NS = 2, PL = SPLIT ? 2 : 1;            // 8 waves, each NS 32-column slices (64 columns) of the 512: two waves per SIMD, up to 256 registers; PL planes
+    constexpr int SET = PL * MB * P16::BLK;                      // one tile set: blocks [0, MB) the (hi) rows, [MB, 2 MB) the lo halves
     constexpr int NPASS = MB * 16 / (4 * NW);                    // staging passes: thread = (row rr + 4 NW i, chunk c)
     static_assert(NPASS >= 1 && NPASS * 4 * NW == MB * 16, "row blocks must cover whole staging passes");
     extern __shared__ __attribute__((aligned(16))) char smem[];      // two tile sets of MB blocks, then the term table
@@ -503,12 +506,12 @@ template <int MB, bool MASKED> __global__ __launch_bounds__(512) void k_gstep5(G
     // term table: {row base, relu-byte base, pack, has relu bits} of each term, resolved ONCE (item -> source -> buffer offset is a chain of dependent loads) and read
     // back per term with one LDS broadcast -- behind the loop's barrier hipcc issues plain loads of the plan tables as VECTOR loads, whose vmcnt(0) would wait
     // for every row and weight request in flight
-    char* ttab = smem + 2 * MB * P::BLK;
+    char* ttab = smem + 2 * SET;
     if (tid < nterms) {
         const int* term = a.terms + (size_t)(job[J_TERM0] + tid) * TERM_INTS;
         const int* src = a.srcs + (size_t)term[T_SRC0] * SRC_INTS;
         const int node = src[S_NODE], mbuf = src[S_MASK];
-        const uint64_t base = reinterpret_cast<uint64_t>(a.ws + a.buf_off[src[S_BUF]]) + g_row<false>(0, node, B, Hd) * 2;
+        const uint64_t base = reinterpret_cast<uint64_t>(a.ws + a.buf_off[src[S_BUF]]) + g_row<SPLIT>(0, node, B, Hd) * 2;
         const uint64_t mb = reinterpret_cast<uint64_t>(a.ws + a.buf_off[mbuf >= 0 ? mbuf : 0]) + g_relu_byte(node, B, Hd, 0, 0);      // (no relu bits: any mapped address; the bytes are requested and ignored)
         *reinterpret_cast<u32x4*>(ttab + tid * GS5_TERM_BYTES) = u32x4{(unsigned)base, (unsigned)(base >> 32), (unsigned)mb, (unsigned)(mb >> 32)};
         *reinterpret_cast<u32x2*>(ttab + tid * GS5_TERM_BYTES + 16) = u32x2{(unsigned)term[T_PACK], mbuf >= 0 ? 1u : 0u};
@@ -538,7 +541,7 @@ template <int MB, bool MASKED> __global__ __launch_bounds__(512) void k_gstep5(G
         q.pack = __builtin_amdgcn_readfirstlane((int)f[0]); q.msk = __builtin_amdgcn_readfirstlane((int)f[1]) != 0;
     };
     auto advance = [&](Cur& q) { if (++q.kc == NCT) { q.kc = 0; ++q.ti; open_term(q); } };      // (every term of an all-plain launch has NCT chunks)
-    u32x4 rv[NPASS]; unsigned rm[MASKED ? NPASS : 1];
+    u32x4 rv[PL][NPASS]; unsigned rm[MASKED ? NPASS : 1];
     auto fetch = [&](const Cur& q) {      // request the rows of a chunk: thread = (window rr + 4 NW i of the tile, 16-byte chunk c); rows past the batch re-read the last window
         gchar* rb = q.base + q.kc * (TW * 2);
         gchar* mb = q.mb + (((size_t)(q.kc * 4) * nb16) << 6);
@@ -546,7 +549,8 @@ template <int MB, bool MASKED> __global__ __launch_bounds__(512) void k_gstep5(G
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
             const unsigned w = (unsigned)min(w0 + i * (4 * NW) + rr, B - 1);
-            rv[i] = gload16(rb, w * (unsigned)(Hd * 2) + (unsigned)(c * 16));
+            rv[0][i] = gload16(rb, w * (unsigned)(PL * Hd * 2) + (unsigned)(c * 16));
+            if constexpr (SPLIT) rv[1][i] = gload16(rb, w * (unsigned)(PL * Hd * 2) + (unsigned)(Hd * 2 + c * 16));
             if constexpr (MASKED) rm[i] = gload1(mb, ((((unsigned)(c >> 2)) * (unsigned)nb16 + (w >> 4)) << 6) + (unsigned)((c & 3) << 4) + (w & 15u));      // (requested whether or not THIS term has relu bits -- no branch; see stage)
         }
     };
@@ -555,35 +559,51 @@ template <int MB, bool MASKED> __global__ __launch_bounds__(512) void k_gstep5(G
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
             const int grow = i * (4 * NW) + rr;
-            *reinterpret_cast<u32x4*>(set + lds_chunk<T16>(grow >> 4, grow & 15, c)) = MASKED ? chunk_mask_bits<T16>(rv[i], q.msk ? rm[i] : 0xffu) : rv[i];
+            const unsigned bits = MASKED ? (q.msk ? rm[i] : 0xffu) : 0xffu;
+#pragma unroll
+            for (int pl = 0; pl < PL; ++pl)
+                *reinterpret_cast<u32x4*>(set + lds_chunk<T16>(pl * MB + (grow >> 4), grow & 15, c)) = MASKED ? chunk_mask_bits<T16>(rv[pl][i], bits) : rv[pl][i];
         }
     };
     // weight fragments: a ring of two K steps (slot t & 1 holds vectors t and 4 + t of both slices); after step t its slot takes step t + 2 -- of this chunk, or
     // steps 0 / 1 of the next one -- so a request has one whole K step (32 MFMAs per wave, two waves per SIMD: ~1 k clocks) to come back from L2
-    bf16x8 wr[2][NS][2];
+    bf16x8 wr[2][PL][NS][2];
+    const size_t lo_img = (size_t)a.n_img * (H * H * 2);      // the lo halves of the packed weights: image a.n_img + pack
     auto wload = [&](int slot, const char* wp, int t) {
 #pragma unroll
-        for (int sl = 0; sl < NS; ++sl) {
-            const unsigned wo = (unsigned)opaque((int)woff);
-            wr[slot][sl][0] = __builtin_bit_cast(bf16x8, gload16(uniform_ptr(wp + sl * 8192 + t * 1024), wo));
-            wr[slot][sl][1] = __builtin_bit_cast(bf16x8, gload16(uniform_ptr(wp + sl * 8192 + (4 + t) * 1024), wo));
-        }
-    };
-    auto mfma_step = [&](const char* cur, int t, auto dbuf) {      // K step t: every row block against the step's two vectors of both slices
-        constexpr bool DBUF = decltype(dbuf)::value;            // the next block's window fragment is read under a block's MFMAs (8 registers instead of 4)
-        const char* xp = cur + (ao0 ^ (16 * t));
-        bf16x8 x0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xp)), x1;
-#pragma unroll
-        for (int m = 0; m < MB; ++m) {
-            if constexpr (DBUF) { if (m + 1 < MB) x1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xp + (m + 1) * P::BLK)); }
+        for (int pl = 0; pl < PL; ++pl)
 #pragma unroll
             for (int sl = 0; sl < NS; ++sl) {
-                acc[sl][m].c[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[t & 1][sl][0], x0, acc[sl][m].c[0], 0, 0, 0);
-                acc[sl][m].c[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[t & 1][sl][1], x0, acc[sl][m].c[1], 0, 0, 0);
+                const unsigned wo = (unsigned)opaque((int)woff);
+                wr[slot][pl][sl][0] = __builtin_bit_cast(bf16x8, gload16(uniform_ptr(wp + pl * lo_img + sl * 8192 + t * 1024), wo));
+                wr[slot][pl][sl][1] = __builtin_bit_cast(bf16x8, gload16(uniform_ptr(wp + pl * lo_img + sl * 8192 + (4 + t) * 1024), wo));
+            }
+    };
+    auto mfma_step = [&](const char* cur, int t, auto) {      // K step t: every row block against the step's vectors of both slices; the next block's window fragment(s) are read under a block's MFMAs
+        const char* xp = cur + (ao0 ^ (16 * t));
+        bf16x8 x0[PL], x1[PL];
+#pragma unroll
+        for (int pl = 0; pl < PL; ++pl) x0[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xp + pl * MB * P::BLK));
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            if (m + 1 < MB) {
+#pragma unroll
+                for (int pl = 0; pl < PL; ++pl) x1[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xp + (pl * MB + m + 1) * P::BLK));
+            }
+#pragma unroll
+            for (int sl = 0; sl < NS; ++sl) {
+                acc[sl][m].c[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[t & 1][0][sl][0], x0[0], acc[sl][m].c[0], 0, 0, 0);
+                acc[sl][m].c[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[t & 1][0][sl][1], x0[0], acc[sl][m].c[1], 0, 0, 0);
+                if constexpr (SPLIT) {
+                    acc[sl][m].c[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[t & 1][1][sl][0], x0[0], acc[sl][m].c[0], 0, 0, 0);
+                    acc[sl][m].c[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[t & 1][1][sl][1], x0[0], acc[sl][m].c[1], 0, 0, 0);
+                    acc[sl][m].c[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[t & 1][0][sl][0], x0[PL - 1], acc[sl][m].c[0], 0, 0, 0);
+                    acc[sl][m].c[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[t & 1][0][sl][1], x0[PL - 1], acc[sl][m].c[1], 0, 0, 0);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);      // (keeps the read of block m + 1 in front of block m's MFMAs: hipcc otherwise sinks it to its use, one read in flight)
-            if constexpr (DBUF) x0 = x1;
-            else if (m + 1 < MB) x0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xp + (m + 1) * P::BLK));
+#pragma unroll
+            for (int pl = 0; pl < PL; ++pl) x0[pl] = x1[pl];
         }
     };
     const int nchunks = nterms * NCT;
@@ -606,7 +626,7 @@ template <int MB, bool MASKED> __global__ __launch_bounds__(512) void k_gstep5(G
         // of the two always has MFMAs to issue while the other stages) -- as two copies of this loop hipcc allocates 256 registers and spills inside both
         // (each copy alone: 232, none), and every scratch reload is a vmcnt(0): 321 / 455 us per layer launch against 240 / 234.
         for (int k = 0; k < nchunks; ++k) {
-            const char* cur = smem + buf * (MB * P::BLK);
+            const char* cur = smem + buf * SET;
             const char* wp_nxt = wbase + (size_t)(nx.pack + nx.kc * NCT + ct0) * (H * H * 2);
             GS5_T(0)
 #ifdef GS5_ABL_W      // (ablation builds, timing only: no weight requests inside the loop / no row requests and staging)
@@ -630,7 +650,7 @@ template <int MB, bool MASKED> __global__ __launch_bounds__(512) void k_gstep5(G
             GS5_T(1)
             __builtin_amdgcn_sched_barrier(0);
 #ifndef GS5_ABL_ROWS
-            stage(nx, smem + (buf ^ 1) * (MB * P::BLK));
+            stage(nx, smem + (buf ^ 1) * SET);
 #endif
             if (k + 2 < nchunks) advance(nx);
             GS5_T(2)
@@ -639,7 +659,7 @@ template <int MB, bool MASKED> __global__ __launch_bounds__(512) void k_gstep5(G
             buf ^= 1;
         }
     }
-    gstep_epilogue2<false, MB, NS>(a, job, acc, ct0, wv0, lane, w0);
+    gstep_epilogue2<SPLIT, MB, NS>(a, job, acc, ct0, wv0, lane, w0);
 #ifdef GGW_STAMPS
     GS5_T(5)
     if (a.stamps && tid == 0) { for (int q = 0; q < 6; ++q) a.stamps[(size_t)blockIdx.x * 8 + q] = tk[q]; a.stamps[(size_t)blockIdx.x * 8 + 6] = nchunk; a.stamps[(size_t)blockIdx.x * 8 + 7] = nterms; }
@@ -1272,7 +1292,8 @@ int gen_create(mshgnn_plan* p, const mshgnn_desc* desc) {
     const int dec_lds = 16 * 8 * TW * 4;
     if ((rc = set_lds_attr(k_gdec_bwd<false>, dec_lds)) || (rc = set_lds_attr(k_gdec_bwd<true>, dec_lds)) ||
         (rc = set_lds_attr(k_gstep<true, 8, 8>, 16 * P16::BLK)) || (rc = set_lds_attr(k_ggradw<true, 1>, ggw_lds_bytes(true, 1))) ||
-        (rc = set_lds_attr(k_ggradw<true, 2>, ggw_lds_bytes(true, 2))) || (rc = set_lds_attr(k_ggradw<false, 2, GGW_NWV_BF16>, ggw_lds_bytes(false, 2))) || (rc = set_lds_attr(k_gstep5<8, true>, gs5_lds_bytes(8))) || (rc = set_lds_attr(k_gstep5<8, false>, gs5_lds_bytes(8)))) return rc;
+        (rc = set_lds_attr(k_ggradw<true, 2>, ggw_lds_bytes(true, 2))) || (rc = set_lds_attr(k_ggradw<false, 2, GGW_NWV_BF16>, ggw_lds_bytes(false, 2))) || (rc = set_lds_attr(k_gstep5<false, 8, true>, gs5_lds_bytes(false, 8))) || (rc = set_lds_attr(k_gstep5<false, 8, false>, gs5_lds_bytes(false, 8))) ||
+        (rc = set_lds_attr(k_gstep5<true, 4, true>, gs5_lds_bytes(true, 4))) || (rc = set_lds_attr(k_gstep5<true, 4, false>, gs5_lds_bytes(true, 4)))) return rc;
     return MSHGNN_OK;
 }
 
@@ -1405,7 +1426,7 @@ static int g_tile_blocks(int B, bool split) {
     // bf16: 16 waves; on 128-window tiles (k_gstep5: the software pipeline of 8 waves; k_gstep4) once the batch has two of them -- half the weight stream per window, 250-258 / 252-314 us per layer launch
     // against 285-292 / 303-357 on the 32-limb model; split arithmetic: k_gstep4 at 16 waves on 64-window tiles (720-740 / 673-766 us against 803-813 / 814-925
     // for k_gstep at 8 waves, whose 16-wave form spills)
-    return split ? 6 : (B >= 256 ? 8 : 3);      // (split, hidden % 512 != 0: the dispatch falls back to k_gstep at 8 / 4 waves; 8: k_gstep5 on the launches whose terms are all plain rows, k_gstep4 on the others)
+    return split ? 8 : (B >= 256 ? 8 : 3);      // (split, hidden % 512 != 0: the dispatch falls back to k_gstep at 8 / 4 waves; 8: k_gstep5 on the launches whose terms are all plain rows, k_gstep4 on the others)
 }
 
 #ifdef GEN_TIMELINE
@@ -1441,12 +1462,17 @@ static void g_launch_jobs(const mshgnn_plan* p, const Launch& ln, GArgs a, hipSt
     // 4 / 8 / 16 waves, split 870 / 799 / 1012 us (16 waves: 128 VGPRs, spills); 128-window tiles lose (fewer resident workgroups hide less
     // of the staging latency: 495 us at 8 waves, 389 us at 16 waves with 56 B of scratch)
     const int mode = g_tile_blocks(a.B, gp.split);      // 0: 4 waves; 1: 8 waves, 128 windows; 2: 8 waves; 3: 16 waves; 6: k_gstep4 (bf16, hidden % 512 == 0; the default from 256 windows)
-    if (mode == 8 && !gp.split && gp.NCT % 4 == 0 && ln.all_plain && ln.max_terms <= GS5_MAX_TERMS) {      // k_gstep5: k_gstep4's tile, software-pipelined (launches whose every term is one plain row)
-        a.tiles = (a.B + 127) / 128;
+    if (mode == 8 && gp.NCT % 4 == 0 && ln.all_plain && ln.max_terms <= GS5_MAX_TERMS) {      // k_gstep5: k_gstep4's tile, software-pipelined (launches whose every term is one plain row)
+        a.tiles = gp.split ? (a.B + 63) / 64 : (a.B + 127) / 128;
         const unsigned grid4 = (unsigned)ln.n_jobs * a.tiles * (a.NCT / 4);
         ProfScope ps(p, ln.ks, st);
-        if (ln.any_mask) hipLaunchKernelGGL((k_gstep5<8, true>), dim3(grid4), dim3(512), gs5_lds_bytes(8), st, a);
-        else hipLaunchKernelGGL((k_gstep5<8, false>), dim3(grid4), dim3(512), gs5_lds_bytes(8), st, a);
+        if (gp.split) {
+            if (ln.any_mask) hipLaunchKernelGGL((k_gstep5<true, 4, true>), dim3(grid4), dim3(512), gs5_lds_bytes(true, 4), st, a);
+            else hipLaunchKernelGGL((k_gstep5<true, 4, false>), dim3(grid4), dim3(512), gs5_lds_bytes(true, 4), st, a);
+        } else {
+            if (ln.any_mask) hipLaunchKernelGGL((k_gstep5<false, 8, true>), dim3(grid4), dim3(512), gs5_lds_bytes(false, 8), st, a);
+            else hipLaunchKernelGGL((k_gstep5<false, 8, false>), dim3(grid4), dim3(512), gs5_lds_bytes(false, 8), st, a);
+        }
         return;
     }
     if (mode >= 6 && !gp.split && gp.NCT % 4 == 0) {      // k_gstep4: 16 waves on 128-window tiles (hidden a multiple of 512)
