@@ -819,6 +819,9 @@ template <bool SPLIT> __global__ __launch_bounds__(256) void k_gdec_bwd(GDecArgs
 #ifndef GGW_NWV_BF16
 #define GGW_NWV_BF16 16
 #endif
+#ifndef GGW_NWV_SPLIT2
+#define GGW_NWV_SPLIT2 8      // waves of the split kernel on 256 x 256 super-units (GGW_SPLIT_OS2)
+#endif
 constexpr int ggw_kw(bool split, int os) { return (!split && os == 2) ? GGW_KW_BF16 : 32; }      // windows per step (= per barrier) of k_ggradw
 constexpr int ggw_lds_bytes(bool split, int os) { return 2 * (split ? 2 : 1) * (os + 2) * ggw_kw(split, os) * GWB_PITCH * 2; }      // k_ggradw's dynamic LDS: two tile sets per plane
 template <bool SPLIT, int OS, int NWV = 8 * OS> __global__ __launch_bounds__(64 * NWV) void k_ggradw(GArgs a) {
@@ -1292,7 +1295,7 @@ int gen_create(mshgnn_plan* p, const mshgnn_desc* desc) {
     const int dec_lds = 16 * 8 * TW * 4;
     if ((rc = set_lds_attr(k_gdec_bwd<false>, dec_lds)) || (rc = set_lds_attr(k_gdec_bwd<true>, dec_lds)) ||
         (rc = set_lds_attr(k_gstep<true, 8, 8>, 16 * P16::BLK)) || (rc = set_lds_attr(k_ggradw<true, 1>, ggw_lds_bytes(true, 1))) ||
-        (rc = set_lds_attr(k_ggradw<true, 2>, ggw_lds_bytes(true, 2))) || (rc = set_lds_attr(k_ggradw<false, 2, GGW_NWV_BF16>, ggw_lds_bytes(false, 2))) || (rc = set_lds_attr(k_gstep5<false, 8, true>, gs5_lds_bytes(false, 8))) || (rc = set_lds_attr(k_gstep5<false, 8, false>, gs5_lds_bytes(false, 8))) ||
+        (rc = set_lds_attr(k_ggradw<true, 2, GGW_NWV_SPLIT2>, ggw_lds_bytes(true, 2))) || (rc = set_lds_attr(k_ggradw<false, 2, GGW_NWV_BF16>, ggw_lds_bytes(false, 2))) || (rc = set_lds_attr(k_gstep5<false, 8, true>, gs5_lds_bytes(false, 8))) || (rc = set_lds_attr(k_gstep5<false, 8, false>, gs5_lds_bytes(false, 8))) ||
         (rc = set_lds_attr(k_gstep5<true, 4, true>, gs5_lds_bytes(true, 4))) || (rc = set_lds_attr(k_gstep5<true, 4, false>, gs5_lds_bytes(true, 4)))) return rc;
     return MSHGNN_OK;
 }
@@ -1573,7 +1576,7 @@ int gen_backward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pi
 #ifdef GEN_TIMELINE
         a.tl = gen_tl("gradw");
 #endif
-        if (gp.split && gp.su_os == 2) hipLaunchKernelGGL((k_ggradw<true, 2>), dim3(grid), dim3(1024), ggw_lds_bytes(true, 2), st, a);
+        if (gp.split && gp.su_os == 2) hipLaunchKernelGGL((k_ggradw<true, 2, GGW_NWV_SPLIT2>), dim3(grid), dim3(64 * GGW_NWV_SPLIT2), ggw_lds_bytes(true, 2), st, a);
         else if (gp.split) hipLaunchKernelGGL((k_ggradw<true, 1>), dim3(grid), dim3(512), ggw_lds_bytes(true, 1), st, a);
         else if (gp.su_os == 2) hipLaunchKernelGGL((k_ggradw<false, 2, GGW_NWV_BF16>), dim3(grid), dim3(64 * GGW_NWV_BF16), ggw_lds_bytes(false, 2), st, a);
         else hipLaunchKernelGGL((k_ggradw<false, 1>), dim3(grid), dim3(512), ggw_lds_bytes(false, 1), st, a);

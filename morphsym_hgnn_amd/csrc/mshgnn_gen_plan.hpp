@@ -500,8 +500,8 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
     // slab (the unit's), so the finalize tables do not change.  super-unit: unit[o][k] x4 (-1: absent) | item_begin item_end p_col0 q_col0 | q_ncols pad..
     std::vector<int32_t> sunits;
 #ifndef GGW_SPLIT_OS2
-#define GGW_SPLIT_OS2 0      // (16 waves of the split kernel: 128 VGPRs with 164 B of scratch, 10.1 ms against 5.8 ms at h=512)
-#endif
+#define GGW_SPLIT_OS2 1      // split arithmetic on 256 x 256 super-units too, with 8 waves of 128 x 64 (253 registers, none spilled): 2.83 ms against 3.25 ms for 128 x 256 at h=512
+#endif                       // (the 16-wave form of that: 128 registers with 164 B of scratch, 10.1 ms against 5.8 ms)
     p.su_os = ((!p.split || GGW_SPLIT_OS2) && NCT % 2 == 0) ? 2 : 1;
     for (Tgt& g : tgts) {
         const int n = (int)g.items.size(), nkt = (g.K + TW - 1) / TW, not_ = g.rows / TW, i0 = units[(size_t)g.unit0 * UNIT_INTS + U_ITEM0];
