@@ -325,7 +325,7 @@ template <bool SPLIT, int MB, int NW> __global__ __launch_bounds__(64 * NW) void
             }
         }
     }
-    gstep_epilogue<SPLIT, MB>(a, job, acc, ct, wv, lane, w0);
+    gstep_epilogue2<SPLIT, MB, 1>(a, job, reinterpret_cast<P::Acc (&)[1][MB]>(acc), ct, wv, lane, w0);      // (requests of the whole tile first: see gstep_epilogue2)
 }
 
 // ------------------------------------------------------------------------------------------------------
