@@ -1234,9 +1234,10 @@ __global__ __launch_bounds__(256) void k_gfinalize(GFinArgs a) {
         if (threadIdx.x == 0) *a.loss = l * a.inv_n;
     }
     if (kind == FIN_DEC_W || kind == FIN_DEC_B) {      // one decoder row piece: f[8] = its offset inside a decoder slab
-        if (blockIdx.y != 0) return;
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        for (int e = wave; e < rows * cols; e += 4) {
+        // one WAVE per element, elements dealt round-robin to the (gridDim.y x 4) waves of this op (four waves per op walked 32 elements each, one dependent round
+        // trip per element: ~100 us, the tail of the whole launch)
+        const int lane = threadIdx.x & 63, wave = blockIdx.y * 4 + (threadIdx.x >> 6), nwaves = gridDim.y * 4;
+        for (int e = wave; e < rows * cols; e += nwaves) {
             const int r = e / cols, cidx = e % cols;
             const int src = f[8] + cidx;
             float sum = 0.f;
@@ -1249,6 +1250,27 @@ __global__ __launch_bounds__(256) void k_gfinalize(GFinArgs a) {
     }
     // rows of the op are dealt to the gridDim.y workgroups of this op; per element a fixed-order sum over the (part, unit) slabs, 4 in flight
     const int rpb = (rows + gridDim.y - 1) / gridDim.y, r_lo = blockIdx.y * rpb, r_hi = min(rows, r_lo + rpb);
+    if (kind == FIN_MATRIX && (cols & 3) == 0 && (ld & 3) == 0 && (dst & 3) == 0) {
+        // whole 128-column tiles of an aligned matrix: four columns per thread as 16-byte loads, eight slabs in flight -- the same sums in the same order per element
+        // (150 MB of slabs on the 32-limb model: 112 us with the element-wise loop below)
+        const int c4 = cols >> 2, total = a.n_parts * nu;
+        for (int i = threadIdx.x; i < (r_hi - r_lo) * c4; i += 256) {
+            const int r = r_lo + i / c4, cidx = (i % c4) * 4, src = r * H + cidx;
+            f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int t0 = 0; t0 < total; t0 += 8) {
+                f32x4 v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int t = t0 + q;
+                    v[q] = t < total ? *reinterpret_cast<const f32x4*>(a.slabs + ((size_t)(t / nu) * a.n_units + u0 + t % nu) * SLAB_FLOATS + src) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                s += (v[0] + v[1]) + (v[2] + v[3]);
+                if (t0 + 4 < total) s += (v[4] + v[5]) + (v[6] + v[7]);
+            }
+            *reinterpret_cast<f32x4*>(a.grad + dst + (int64_t)r * ld + cidx) = s;
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < (r_hi - r_lo) * cols; i += 256) {
         const int r = r_lo + i / cols, cidx = i % cols;
         float s = 0.f;
@@ -1326,10 +1348,11 @@ int gen_host_compile(const mshgnn_desc* desc, mshgnn_info* info, int32_t* n_tabl
 // k_gagg: the aggregates of many rows of one launch (mshgnn_gen_plan.hpp, G_MANY): out[w] = round(sum_s scale_s . mask_s . X_s[w]) -- the fp32 sums of gather8 in the
 // same order, rounded (or split) once, i.e. exactly the A-tile rows the job kernels staged for such a term.  A thread owns 16-byte chunks of the workgroup's GA_ROWS
 // rows; GA_U sources are in flight per thread.
-constexpr int GA_ROWS = 8, GA_U = 16, GA_THREADS = 512, GA_TAB = 64;
+constexpr int GA_ROWS = 8, GA_U = 16, GA_THREADS = 512, GA_TAB = 64;      // (32 rows in flight: 24.7 us as with 16)
 template <bool SPLIT> __global__ __launch_bounds__(GA_THREADS) void k_gagg(GArgs a, int agg0, int row_blocks) {
     // the sources' row / relu-byte addresses and scales, resolved by one thread each (source -> buffer -> offset is a chain of dependent loads: walked per source
     // by every thread through scalar loads it made the kernel 24 us for 32 MB)
+    constexpr int U = SPLIT ? GA_U / 2 : GA_U;      // (two planes per row in the split arithmetic: half the rows in flight for the same registers)
     __shared__ unsigned long long t_row[GA_TAB], t_mask[GA_TAB];
     __shared__ float t_scale[GA_TAB];
     const int* op = a.aggs + (size_t)(agg0 + blockIdx.x / row_blocks) * AGG_INTS;
@@ -1357,10 +1380,10 @@ template <bool SPLIT> __global__ __launch_bounds__(GA_THREADS) void k_gagg(GArgs
                 t_scale[threadIdx.x] = __int_as_float(sp[S_SCALE]);
             }
             __syncthreads();
-            for (int k = 0; k < nt; k += GA_U) {
-                u32x4 vh[GA_U], vl[SPLIT ? GA_U : 1]; unsigned bm[GA_U]; float sc[GA_U];
+            for (int k = 0; k < nt; k += U) {
+                u32x4 vh[U], vl[SPLIT ? U : 1]; unsigned bm[U]; float sc[U];
 #pragma unroll
-                for (int u = 0; u < GA_U; ++u) {
+                for (int u = 0; u < U; ++u) {
                     if (k + u < nt) {      // (uniform)
                         const T16* rp = reinterpret_cast<const T16*>(t_row[k + u]) + roff;
                         const unsigned long long mk = t_mask[k + u];
@@ -1371,7 +1394,7 @@ template <bool SPLIT> __global__ __launch_bounds__(GA_THREADS) void k_gagg(GArgs
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < GA_U; ++u) {
+                for (int u = 0; u < U; ++u) {
                     if (k + u < nt) {
                         acc8(s, chunk_mask_bits<T16>(vh[u], bm[u]), sc[u]);
                         if constexpr (SPLIT) acc8(s, chunk_mask_bits<T16>(vl[u], bm[u]), sc[u]);
