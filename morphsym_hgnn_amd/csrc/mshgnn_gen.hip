@@ -1352,7 +1352,7 @@ constexpr int GA_ROWS = 8, GA_U = 16, GA_THREADS = 512, GA_TAB = 64;      // (32
 template <bool SPLIT> __global__ __launch_bounds__(GA_THREADS) void k_gagg(GArgs a, int agg0, int row_blocks) {
     // the sources' row / relu-byte addresses and scales, resolved by one thread each (source -> buffer -> offset is a chain of dependent loads: walked per source
     // by every thread through scalar loads it made the kernel 24 us for 32 MB)
-    constexpr int U = SPLIT ? GA_U / 2 : GA_U;      // (two planes per row in the split arithmetic: half the rows in flight for the same registers)
+    constexpr int U = GA_U;
     __shared__ unsigned long long t_row[GA_TAB], t_mask[GA_TAB];
     __shared__ float t_scale[GA_TAB];
     const int* op = a.aggs + (size_t)(agg0 + blockIdx.x / row_blocks) * AGG_INTS;
