@@ -171,18 +171,19 @@ __device__ __forceinline__ void gstep_epilogue2(const GArgs& a, const int* job, 
     const int B = a.B, Hd = a.Hd, flags = ro_int(job, J_FLAGS);
     // (the job record through the constant address space: behind the K loop's barriers plain loads of it are VECTOR loads, each awaited with vmcnt(0) -- one round trip per row block again)
     const int j_out_buf = ro_int(job, J_OUT_BUF), j_out_node = ro_int(job, J_OUT_NODE), j_res_buf = ro_int(job, J_RES_BUF), j_res_node = ro_int(job, J_RES_NODE),
-              j_bits_buf = ro_int(job, J_BITS_BUF), j_gate_buf = ro_int(job, J_GATE_BUF), j_gate_node = ro_int(job, J_GATE_NODE);
+              j_bits_buf = ro_int(job, J_BITS_BUF), j_gate_buf = ro_int(job, J_GATE_BUF), j_gate_node = ro_int(job, J_GATE_NODE), j_dhm_buf = ro_int(job, J_DHM_BUF);
     if ((flags & JF_GATE_POS) && (flags & JF_RES)) {      // (no job of the plans has both; they would share the request registers)
 #pragma unroll
         for (int sl = 0; sl < NS; ++sl) gstep_epilogue<SPLIT, MB>(a, job, acc[sl], ct, wv0 + sl, lane, w0);
         return;
     }
-    u32x4 aux[NS][MB], auxl[SPLIT ? NS : 1][SPLIT ? MB : 1]; unsigned xb[NS][MB];
+    u32x4 aux[NS][MB], auxl[SPLIT ? NS : 1][SPLIT ? MB : 1]; unsigned xb[NS][MB], hb[NS][MB];      // hb: the relu bytes of a JF_DHM job's second output
     const bool want_aux = (flags & (JF_GATE_POS | JF_RES)) != 0, want_lo = SPLIT && (flags & JF_RES) != 0;      // (the gate reads the hi half only: it carries the sign)
     const char* auxb = nullptr; const uint8_t* xbb = nullptr;
     if (flags & JF_GATE_POS) auxb = a.ws + a.buf_off[j_gate_buf] + g_row<SPLIT>(0, j_gate_node, B, Hd) * 2;
     if (flags & JF_RES) auxb = a.ws + a.buf_off[j_res_buf] + g_row<SPLIT>(0, j_res_node, B, Hd) * 2;
     if (flags & JF_GATE_BITS) xbb = reinterpret_cast<const uint8_t*>(a.ws + a.buf_off[j_gate_buf]);
+    const uint8_t* hbb = (flags & JF_DHM) ? reinterpret_cast<const uint8_t*>(a.ws + a.buf_off[j_bits_buf]) : nullptr;
     constexpr int RS = SPLIT ? 2 : 1;      // row stride in units of Hd elements
 #pragma unroll
     for (int sl = 0; sl < NS; ++sl)
@@ -192,8 +193,10 @@ __device__ __forceinline__ void gstep_epilogue2(const GArgs& a, const int* job, 
             if (want_aux) aux[sl][m] = *reinterpret_cast<const u32x4*>(auxb + ((size_t)wc * (RS * Hd) + col) * 2);
             if constexpr (SPLIT) { if (want_lo) auxl[sl][m] = *reinterpret_cast<const u32x4*>(auxb + ((size_t)wc * (RS * Hd) + Hd + col) * 2); }
             if (flags & JF_GATE_BITS) xb[sl][m] = xbb[g_relu_byte(j_gate_node, B, Hd, wc, col)];
+            if (flags & JF_DHM) hb[sl][m] = hbb[g_relu_byte(j_out_node, B, Hd, wc, col)];
         }
     T16* out = reinterpret_cast<T16*>(a.ws + a.buf_off[j_out_buf]);
+    T16* dhm = (flags & JF_DHM) ? reinterpret_cast<T16*>(a.ws + a.buf_off[j_dhm_buf]) : nullptr;
 #pragma unroll
     for (int sl = 0; sl < NS; ++sl)
 #pragma unroll
@@ -227,9 +230,20 @@ __device__ __forceinline__ void gstep_epilogue2(const GArgs& a, const int* job, 
                 if constexpr (SPLIT) {
                     u32x4 hi, lo;
                     split_oct(y0, y1, hi, lo);
-                    *reinterpret_cast<u32x4*>(q) = hi;
-                    *reinterpret_cast<u32x4*>(q + Hd) = lo;
-                } else store_oct(q, y0, y1);
+                    if (!(flags & JF_DHM_ONLY)) {
+                        *reinterpret_cast<u32x4*>(q) = hi;
+                        *reinterpret_cast<u32x4*>(q + Hd) = lo;
+                    }
+                    if (flags & JF_DHM) {      // the same row with the relu bits of the layer below applied: that layer's dH
+                        T16* q2 = dhm + g_row<SPLIT>(w, j_out_node, B, Hd) + col;
+                        *reinterpret_cast<u32x4*>(q2) = chunk_mask_bits<T16>(hi, hb[sl][m]);
+                        *reinterpret_cast<u32x4*>(q2 + Hd) = chunk_mask_bits<T16>(lo, hb[sl][m]);
+                    }
+                } else {
+                    const u32x4 yv = pack_oct(y0, y1);
+                    if (!(flags & JF_DHM_ONLY)) *reinterpret_cast<u32x4*>(q) = yv;
+                    if (flags & JF_DHM) *reinterpret_cast<u32x4*>(dhm + g_row<SPLIT>(w, j_out_node, B, Hd) + col) = chunk_mask_bits<T16>(yv, hb[sl][m]);
+                }
             }
         }
 }
@@ -672,7 +686,7 @@ template <bool SPLIT, int MB, bool MASKED> __global__ __launch_bounds__(512) voi
 // thread = (row, 8-column chunk c of 16), looping over the Hd / 128 column groups
 // ------------------------------------------------------------------------------------------------------
 struct GDecArgs {
-    const void* xl; void* dxl; const float* params; const float* out_mask; float* out; const float* gout; float* slabs;
+    const void* xl; void* dxl; void* dhl; const uint8_t* maskb; int dh_only; const float* params; const float* out_mask; float* out; const float* gout; float* slabs;
     int64_t off_w, off_b; int B, Hd, node0, n_out, dout;
     const float* y; const int32_t* labels; float inv_n;
 };
@@ -764,11 +778,20 @@ template <bool SPLIT> __global__ __launch_bounds__(256) void k_gdec_bwd(GDecArgs
                 }
             }
             T16* q = reinterpret_cast<T16*>(a.dxl) + idx;
+            const unsigned hbits = a.dhl ? a.maskb[g_relu_byte(a.node0 + f, a.B, a.Hd, w, cg + c * 8)] : 0u;      // (plans with dhm: dH of the last layer = dX_L . its relu bits, written here)
             if constexpr (SPLIT) {
                 u32x4 hi, lo;
                 split_oct(f32x4{dx[0], dx[1], dx[2], dx[3]}, f32x4{dx[4], dx[5], dx[6], dx[7]}, hi, lo);
-                *reinterpret_cast<u32x4*>(q) = hi; *reinterpret_cast<u32x4*>(q + a.Hd) = lo;
-            } else store8<T16>(q, dx);
+                if (!a.dh_only) { *reinterpret_cast<u32x4*>(q) = hi; *reinterpret_cast<u32x4*>(q + a.Hd) = lo; }
+                if (a.dhl) {
+                    T16* q2 = reinterpret_cast<T16*>(a.dhl) + idx;
+                    *reinterpret_cast<u32x4*>(q2) = chunk_mask_bits<T16>(hi, hbits); *reinterpret_cast<u32x4*>(q2 + a.Hd) = chunk_mask_bits<T16>(lo, hbits);
+                }
+            } else {
+                const u32x4 yv = pack_oct(f32x4{dx[0], dx[1], dx[2], dx[3]}, f32x4{dx[4], dx[5], dx[6], dx[7]});
+                if (!a.dh_only) *reinterpret_cast<u32x4*>(q) = yv;
+                if (a.dhl) *reinterpret_cast<u32x4*>(reinterpret_cast<T16*>(a.dhl) + idx) = chunk_mask_bits<T16>(yv, hbits);
+            }
         }
         __syncthreads();      // the previous column group's sums have been read
 #pragma unroll
@@ -812,9 +835,11 @@ template <bool SPLIT> __global__ __launch_bounds__(256) void k_gdec_bwd(GDecArgs
 // The wave grid is a parameter (NWV / 4 wave rows x 4 wave columns) because other shapes were measured on the bf16 plan -- 8 waves of 128x64 with double-buffered
 // tiles: 12 % faster on the lean super-units, but a different block size than the general ones need, i.e. a second launch; 4 waves of 128x128 with the
 // accumulators in the AGPRs: hipcc spills 0.7-1.5 KB per lane whichever way the accumulators are pinned -- the launches use NWV = 8 OS.
-// (measured on the 32-limb model, B = 1024: 64 windows per step at 16 waves spills -- 1.99 ms; 8 waves of 128 x 64 at 64 / 32 windows per step 1.40 / 1.47 ms; 16 waves at 32: 1.16 ms)
-#ifndef GGW_KW_BF16
-#define GGW_KW_BF16 32
+// Windows per step (= per barrier) of k_ggradw's lean streams; the general streams keep 32.  A 32-window step is 8 MFMAs per wave between barriers (the phase clocks,
+// tools/stamps_ggradw.py, put 49 % of it at the barrier); 64 need the staging registers of two steps, which the bf16 kernel's 128 only have without the relu bytes
+// (NOMASK).  Measured on the 32-limb model, B = 1024: with masks, 64 windows per step 1.80-1.99 ms against 1.16; 8 waves of 128 x 64 at 64 / 32: 1.40 / 1.47 ms.
+#ifndef GGW_KW_LEAN_NOMASK
+#define GGW_KW_LEAN_NOMASK 64
 #endif
 #ifndef GGW_NWV_BF16
 #define GGW_NWV_BF16 16
@@ -822,10 +847,13 @@ template <bool SPLIT> __global__ __launch_bounds__(256) void k_gdec_bwd(GDecArgs
 #ifndef GGW_NWV_SPLIT2
 #define GGW_NWV_SPLIT2 8      // waves of the split kernel on 256 x 256 super-units (GGW_SPLIT_OS2)
 #endif
-constexpr int ggw_kw(bool split, int os) { return (!split && os == 2) ? GGW_KW_BF16 : 32; }      // windows per step (= per barrier) of k_ggradw
-constexpr int ggw_lds_bytes(bool split, int os) { return 2 * (split ? 2 : 1) * (os + 2) * ggw_kw(split, os) * GWB_PITCH * 2; }      // k_ggradw's dynamic LDS: two tile sets per plane
-template <bool SPLIT, int OS, int NWV = 8 * OS> __global__ __launch_bounds__(64 * NWV) void k_ggradw(GArgs a) {
-    constexpr int KW = ggw_kw(SPLIT, OS), NT = 64 * NWV, PC = 16 * OS;      // KW: windows per step; PC: 16-byte chunks per staged P row
+constexpr int ggw_kw_lean(bool split, int os, bool nomask) { return (!split && os == 2 && nomask) ? GGW_KW_LEAN_NOMASK : 32; }
+constexpr int ggw_lds_bytes(bool split, int os, bool nomask = false) { return 2 * (split ? 2 : 1) * (os + 2) * ggw_kw_lean(split, os, nomask) * GWB_PITCH * 2; }      // k_ggradw's dynamic LDS: two tile sets per plane
+// The kernel's body, instantiated once per stream kind (PATH 1: lean super-units, 0: general ones) so that each kind gets its own step size KW and its own registers.
+// NOMASK (plans with dhm: no P operand carries relu bits): the relu-byte requests and the bit expansion are compiled out, which is what lets the lean streams of the
+// bf16 kernel stage 64 windows per step inside 128 registers.
+template <bool SPLIT, int OS, int NWV, int KW, int PATH, bool NOMASK> __device__ __forceinline__ void ggradw_body(const GArgs& a) {
+    constexpr int NT = 64 * NWV, PC = 16 * OS;      // KW: windows per step; PC: 16-byte chunks per staged P row
     constexpr int NQ = KW * 32 / NT;                         // Q chunks per thread (1 with 1024 threads, 2 with 512)
     constexpr int NP = KW * PC / NT, PR = NT / PC;           // P chunks per thread; P rows per staging pass
     constexpr int WCOLS = 4;                                 // wave grid: NWV / WCOLS rows x WCOLS columns
@@ -913,7 +941,7 @@ template <bool SPLIT, int OS, int NWV = 8 * OS> __global__ __launch_bounds__(64 
                 const T16* pr = q.prow + (size_t)w * (SPLIT ? 2 * Hd : Hd) + cp * 8;
                 st.pa[i] = *reinterpret_cast<const u32x4*>(pr);
                 if constexpr (SPLIT) st.pb[i] = *reinterpret_cast<const u32x4*>(pr + Hd);
-                if (q.pmask >= 0) st.mw[i] = q.pmb[mask_off(w, pcol + cp * 8)];
+                if constexpr (!NOMASK) { if (q.pmask >= 0) st.mw[i] = q.pmb[mask_off(w, pcol + cp * 8)]; }
             }
         }
 #pragma unroll
@@ -949,7 +977,7 @@ template <bool SPLIT, int OS, int NWV = 8 * OS> __global__ __launch_bounds__(64 
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             u32x4 ph = st.pa[i], pl = st.pb[i];
-            if (im[I_PMASK] >= 0) { ph = chunk_mask_bits<T16>(ph, st.mw[i]); if constexpr (SPLIT) pl = chunk_mask_bits<T16>(pl, st.mw[i]); }     // dH = dX . relu bits
+            if constexpr (!NOMASK) { if (im[I_PMASK] >= 0) { ph = chunk_mask_bits<T16>(ph, st.mw[i]); if constexpr (SPLIT) pl = chunk_mask_bits<T16>(pl, st.mw[i]); } }     // dH = dX . relu bits
             *reinterpret_cast<u32x4*>(Ph(cp >> 4) + gwb_elem(rp + PR * i, (cp & 15) * 8)) = ph;
             if constexpr (SPLIT) *reinterpret_cast<u32x4*>(Pl(cp >> 4) + gwb_elem(rp + PR * i, (cp & 15) * 8)) = pl;
 #pragma unroll
@@ -1015,7 +1043,7 @@ template <bool SPLIT, int OS, int NWV = 8 * OS> __global__ __launch_bounds__(64 
                 const char* pr = LF.pb + (poff + (unsigned)(i * PR) * rowb);
                 st.pa[i] = *reinterpret_cast<const u32x4*>(pr);
                 if constexpr (SPLIT) st.pb[i] = *reinterpret_cast<const u32x4*>(pr + 2 * Hd);
-                if (LF.msk) st.mw[i] = LF.mb[moff + (unsigned)((((PR * i) >> 4) << 6) + ((PR * i) & 15))];      // (rp < PR <= 16, or one pass)
+                if constexpr (!NOMASK) { if (LF.msk) st.mw[i] = LF.mb[moff + (unsigned)((((PR * i) >> 4) << 6) + ((PR * i) & 15))]; }      // (rp < PR <= 16, or one pass)
             }
         }
 #pragma unroll
@@ -1040,7 +1068,7 @@ template <bool SPLIT, int OS, int NWV = 8 * OS> __global__ __launch_bounds__(64 
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             u32x4 ph = st.pa[i], pl = st.pb[i];
-            if (LS.msk) { ph = chunk_mask_bits<T16>(ph, st.mw[i]); if constexpr (SPLIT) pl = chunk_mask_bits<T16>(pl, st.mw[i]); }     // dH = dX . relu bits
+            if constexpr (!NOMASK) { if (LS.msk) { ph = chunk_mask_bits<T16>(ph, st.mw[i]); if constexpr (SPLIT) pl = chunk_mask_bits<T16>(pl, st.mw[i]); } }     // dH = dX . relu bits
             *reinterpret_cast<u32x4*>(Ph(cp >> 4) + gwb_elem(rp + PR * i, (cp & 15) * 8)) = ph;
             if constexpr (SPLIT) *reinterpret_cast<u32x4*>(Pl(cp >> 4) + gwb_elem(rp + PR * i, (cp & 15) * 8)) = pl;
             if (need_bias) {
@@ -1185,7 +1213,7 @@ template <bool SPLIT, int OS, int NWV = 8 * OS> __global__ __launch_bounds__(64 
 #endif
         }
     };
-    if (su[SU_FLAGS] & 1) run(fetch_lean, stage_lean); else run(fetch, stage_to_lds);
+    if constexpr (PATH == 1) run(fetch_lean, stage_lean); else run(fetch, stage_to_lds);
     if (my_unit >= 0) {
         float* slab = a.slabs + ((size_t)part * a.n_units + my_unit) * SLAB_FLOATS;
 #pragma unroll
@@ -1220,6 +1248,11 @@ template <bool SPLIT, int OS, int NWV = 8 * OS> __global__ __launch_bounds__(64 
 }
 
 // k_gfinalize: fixed-order sums of the slabs of every destination tile -> flat gradient (every parameter written exactly once)
+template <bool SPLIT, int OS, int NWV = 8 * OS, bool NOMASK = false> __global__ __launch_bounds__(64 * NWV) void k_ggradw(GArgs a) {
+    const int su_i = a.su_order[blockIdx.x % a.n_sunits];
+    if (a.sunits[(size_t)su_i * SUNIT_INTS + SU_FLAGS] & 1) ggradw_body<SPLIT, OS, NWV, ggw_kw_lean(SPLIT, OS, NOMASK), 1, NOMASK>(a);
+    else ggradw_body<SPLIT, OS, NWV, 32, 0, NOMASK>(a);
+}
 struct GFinArgs { const int* fin; const float* slabs; const float* dec_slabs; float* grad; int n_units, n_parts, Hd; float* loss; float inv_n; };
 __global__ __launch_bounds__(256) void k_gfinalize(GFinArgs a) {
     const int* f = a.fin + (size_t)blockIdx.x * GFIN_INTS;
@@ -1317,7 +1350,8 @@ int gen_create(mshgnn_plan* p, const mshgnn_desc* desc) {
     const int dec_lds = 16 * 8 * TW * 4;
     if ((rc = set_lds_attr(k_gdec_bwd<false>, dec_lds)) || (rc = set_lds_attr(k_gdec_bwd<true>, dec_lds)) ||
         (rc = set_lds_attr(k_gstep<true, 8, 8>, 16 * P16::BLK)) || (rc = set_lds_attr(k_ggradw<true, 1>, ggw_lds_bytes(true, 1))) ||
-        (rc = set_lds_attr(k_ggradw<true, 2, GGW_NWV_SPLIT2>, ggw_lds_bytes(true, 2))) || (rc = set_lds_attr(k_ggradw<false, 2, GGW_NWV_BF16>, ggw_lds_bytes(false, 2))) || (rc = set_lds_attr(k_gstep5<false, 8, true>, gs5_lds_bytes(false, 8))) || (rc = set_lds_attr(k_gstep5<false, 8, false>, gs5_lds_bytes(false, 8))) ||
+        (rc = set_lds_attr(k_ggradw<true, 2, GGW_NWV_SPLIT2>, ggw_lds_bytes(true, 2))) || (rc = set_lds_attr(k_ggradw<true, 2, GGW_NWV_SPLIT2, true>, ggw_lds_bytes(true, 2, true))) ||
+        (rc = set_lds_attr(k_ggradw<true, 1, 8, true>, ggw_lds_bytes(true, 1, true))) || (rc = set_lds_attr(k_ggradw<false, 2, GGW_NWV_BF16, true>, ggw_lds_bytes(false, 2, true))) || (rc = set_lds_attr(k_ggradw<false, 2, GGW_NWV_BF16>, ggw_lds_bytes(false, 2))) || (rc = set_lds_attr(k_gstep5<false, 8, true>, gs5_lds_bytes(false, 8))) || (rc = set_lds_attr(k_gstep5<false, 8, false>, gs5_lds_bytes(false, 8))) ||
         (rc = set_lds_attr(k_gstep5<true, 4, true>, gs5_lds_bytes(true, 4))) || (rc = set_lds_attr(k_gstep5<true, 4, false>, gs5_lds_bytes(true, 4)))) return rc;
     return MSHGNN_OK;
 }
@@ -1577,6 +1611,7 @@ int gen_backward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pi
     {
         GDecArgs da{};
         da.xl = ws + lay.x[gp.L]; da.dxl = ws + lay.dx[gp.L]; da.params = params; da.out_mask = g->d_out_mask; da.gout = gout;
+        if (gp.dhm && gp.L >= 1 && !((d.flags & MSHGNN_FLAG_BASE_MLP) && d.out_type == d.mlp_type)) { da.dhl = ws + lay.dh[gp.L - 1]; da.maskb = reinterpret_cast<const uint8_t*>(ws + lay.mask[gp.L - 1]); da.dh_only = (d.flags & MSHGNN_FLAG_RESIDUAL) ? 0 : 1; }
         da.slabs = reinterpret_cast<float*>(ws + lay.dec_slabs); da.off_w = d.off_dec_w; da.off_b = d.off_dec_b;
         da.B = B; da.Hd = gp.Hd; da.node0 = gp.type_base[d.out_type]; da.n_out = n_out; da.dout = d.out_channels;
         if (y) { da.y = y; da.out = const_cast<float*>(out); da.inv_n = 1.0f / (float)((int64_t)B * n_out * d.out_channels); }
@@ -1599,7 +1634,13 @@ int gen_backward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pi
 #ifdef GEN_TIMELINE
         a.tl = gen_tl("gradw");
 #endif
-        if (gp.split && gp.su_os == 2) hipLaunchKernelGGL((k_ggradw<true, 2, GGW_NWV_SPLIT2>), dim3(grid), dim3(64 * GGW_NWV_SPLIT2), ggw_lds_bytes(true, 2), st, a);
+        // (gp.dhm: no P operand carries relu bits -- the NOMASK instantiations)
+        if (gp.dhm) {
+            if (gp.split && gp.su_os == 2) hipLaunchKernelGGL((k_ggradw<true, 2, GGW_NWV_SPLIT2, true>), dim3(grid), dim3(64 * GGW_NWV_SPLIT2), ggw_lds_bytes(true, 2, true), st, a);
+            else if (gp.split) hipLaunchKernelGGL((k_ggradw<true, 1, 8, true>), dim3(grid), dim3(512), ggw_lds_bytes(true, 1, true), st, a);
+            else if (gp.su_os == 2) hipLaunchKernelGGL((k_ggradw<false, 2, GGW_NWV_BF16, true>), dim3(grid), dim3(64 * GGW_NWV_BF16), ggw_lds_bytes(false, 2, true), st, a);
+            else hipLaunchKernelGGL((k_ggradw<false, 1, 8, true>), dim3(grid), dim3(512), ggw_lds_bytes(false, 1, true), st, a);
+        } else if (gp.split && gp.su_os == 2) hipLaunchKernelGGL((k_ggradw<true, 2, GGW_NWV_SPLIT2>), dim3(grid), dim3(64 * GGW_NWV_SPLIT2), ggw_lds_bytes(true, 2), st, a);
         else if (gp.split) hipLaunchKernelGGL((k_ggradw<true, 1>), dim3(grid), dim3(512), ggw_lds_bytes(true, 1), st, a);
         else if (gp.su_os == 2) hipLaunchKernelGGL((k_ggradw<false, 2, GGW_NWV_BF16>), dim3(grid), dim3(64 * GGW_NWV_BF16), ggw_lds_bytes(false, 2), st, a);
         else hipLaunchKernelGGL((k_ggradw<false, 1>), dim3(grid), dim3(512), ggw_lds_bytes(false, 1), st, a);

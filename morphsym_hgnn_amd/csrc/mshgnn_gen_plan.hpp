@@ -21,9 +21,9 @@ namespace gen {
 
 constexpr int TW = 128;                 // tile width: output-column tile of a job, K chunk of a term
 constexpr int G_MAX_L = 16;
-enum { JF_BIAS = 1, JF_RELU = 2, JF_RES = 4, JF_BITS_OUT = 8, JF_GATE_BITS = 16, JF_GATE_POS = 32 };
+enum { JF_BIAS = 1, JF_RELU = 2, JF_RES = 4, JF_BITS_OUT = 8, JF_GATE_BITS = 16, JF_GATE_POS = 32, JF_DHM = 64, JF_DHM_ONLY = 128 };      // JF_DHM: also write out . relu bits (J_BITS_BUF) to J_DHM_BUF; JF_DHM_ONLY: and nobody reads the unmasked row (no residual): only that
 // job:  out_buf out_node flags bias_idx | res_buf res_node bits_buf gate_buf | gate_node term_begin n_terms pad...
-enum { J_OUT_BUF = 0, J_OUT_NODE, J_FLAGS, J_BIAS, J_RES_BUF, J_RES_NODE, J_BITS_BUF, J_GATE_BUF, J_GATE_NODE, J_TERM0, J_NTERMS, JOB_INTS = 12 };
+enum { J_OUT_BUF = 0, J_OUT_NODE, J_FLAGS, J_BIAS, J_RES_BUF, J_RES_NODE, J_BITS_BUF, J_GATE_BUF, J_GATE_NODE, J_TERM0, J_NTERMS, J_DHM_BUF, JOB_INTS = 12 };
 // term: pack_base nkc kind(0 activation, 1 raw input) src_begin | n_src width sign_off pad     pack of (kc, ct) = pack_base + kc * NCT + ct
 enum { T_PACK = 0, T_NKC, T_KIND, T_SRC0, T_NSRC, T_WIDTH, T_SIGN, TERM_INTS = 8 };
 // source: buf (raw: node type) node mask_buf(-1: none) scale(float bits)
@@ -57,6 +57,7 @@ struct GenPlan {
     std::vector<int64_t> off_enc_w, off_enc_b, off_rel_w, off_rel_b, off_root_w;
     int L = 0, NT = 0, NR = 0, NN = 0, Hd = 0, NCT = 0, n_mlp = 0;
     bool split = false; int esize = 2, planes = 1;
+    bool dhm = false;      // dH_l = dX_{l+1} . relu bits of layer l is WRITTEN by the producer of dX_{l+1} (into the dH stash of layer l) instead of masked by every reader
     int type_base[MSHGNN_MAX_TYPES + 1]{};
     std::vector<int> node_type;
     bool live[G_MAX_L][MSHGNN_MAX_TYPES]{}, need_dx[G_MAX_L][MSHGNN_MAX_TYPES]{};
@@ -243,14 +244,14 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
     auto add_src = [&](int buf, int node, int mask, float scale) { srcs.insert(srcs.end(), {buf, node, mask, fbits(scale)}); return (int)(srcs.size() / SRC_INTS) - 1; };
     struct TermDef { int pack, nkc, kind, width, sign; std::vector<std::array<int, 4>> s; };
     auto add_job = [&](int out_buf, int out_node, int flags, int bias, int res_buf, int res_node, int bits_buf, int gate_buf, int gate_node,
-                       const std::vector<TermDef>& tds) {
+                       const std::vector<TermDef>& tds, int dhm_buf = 0) {
         const int t0 = (int)(terms.size() / TERM_INTS);
         for (const TermDef& td : tds) {
             const int s0 = (int)(srcs.size() / SRC_INTS);
             for (auto& s : td.s) srcs.insert(srcs.end(), {s[0], s[1], s[2], s[3]});
             terms.insert(terms.end(), {td.pack, td.nkc, td.kind, s0, (int)td.s.size(), td.width, td.sign, 0});
         }
-        jobs.insert(jobs.end(), {out_buf, out_node, flags, bias, res_buf, res_node, bits_buf, gate_buf, gate_node, t0, (int)tds.size(), 0});
+        jobs.insert(jobs.end(), {out_buf, out_node, flags, bias, res_buf, res_node, bits_buf, gate_buf, gate_node, t0, (int)tds.size(), dhm_buf});
         return (int)(jobs.size() / JOB_INTS) - 1; };
     auto one = [&](int buf, int node, int mask = -1, float scale = 1.0f) { return std::array<int, 4>{buf, node, mask, fbits(scale)}; };
     double alg_fwd = 0, alg_bwd = 0, exec_fwd = 0, exec_bwd = 0;
@@ -371,9 +372,15 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
     alg_fwd += 2.0 * n_out * d.out_channels * Hd; exec_fwd += 2.0 * n_out * d.out_channels * Hd;
     alg_bwd += 4.0 * n_out * d.out_channels * Hd; exec_bwd += 4.0 * n_out * d.out_channels * Hd;
     // dH of node n in layer l as a staging source: relu types = dX_{l+1}[n] . relu bits of layer l; base_transform type = the dH stash
+    // dH of a relu type: every reader (the backward jobs of the layer below: 1 + ~2 terms; the weight-gradient items: ~3) used to request the relu bytes and mask
+    // the row as it staged it.  p.dhm: the job (or the decoder's backward) that PRODUCES dX_{l+1}[n] also writes dX_{l+1}[n] . bits_l[n] into layer l's dH stash (one
+    // more row written per node and layer); the readers then see plain rows -- every backward launch qualifies for the unmasked k_gstep5, and the weight-gradient
+    // streams carry no relu bytes.  The same values, bit for bit (masking zeroes elements; it does not round).  MSHGNN_GEN_DHM=0: the readers mask.
+    p.dhm = []() { const char* e = std::getenv("MSHGNN_GEN_DHM"); return !(e && std::atoi(e) == 0); }();
     auto dh_src = [&](int l, int n, float scale = 1.0f) {
         const int t = p.node_type[n];
         if (has_mlp && t == d.mlp_type) return one(BUF_DH + l, n, -1, scale);
+        if (p.dhm) return one(BUF_DH + l, n, -1, scale);
         return one(BUF_DX + l + 1, n, BUF_MASK + l, scale); };
     for (int l = L - 1; l >= 0; --l) {
         const bool mlp_live = has_mlp && p.live[l][d.mlp_type];
@@ -408,7 +415,10 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
                 }
                 fl += NL * tds.size();
                 const bool res = residual && live_n[l][n];
-                add_job(BUF_DX + l, n, (res ? JF_RES : 0) | (l == 0 ? JF_GATE_BITS : 0), 0, BUF_DX + l + 1, n, -1, GBUF_MASK0, n, tds);
+                // (p.dhm) this job's dX_l[n] is also the dH of layer l - 1, once masked with that layer's relu bits -- where n is computed there and is a relu type
+                const bool wr_dh = p.dhm && l >= 1 && live_n[l - 1][n] && !(has_mlp && s == d.mlp_type);
+                add_job(BUF_DX + l, n, (res ? JF_RES : 0) | (l == 0 ? JF_GATE_BITS : 0) | (wr_dh ? JF_DHM | (residual ? 0 : JF_DHM_ONLY) : 0), 0, BUF_DX + l + 1, n, wr_dh ? BUF_MASK + l - 1 : -1, GBUF_MASK0, n, tds,
+                        wr_dh ? BUF_DH + l - 1 : 0);
             }
         }
         alg_bwd += fl - NL * (n_split_terms - ns0); exec_bwd += fl;
