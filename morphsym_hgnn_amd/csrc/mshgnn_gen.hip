@@ -474,7 +474,7 @@ template <bool SPLIT, int MB, int NW> __global__ __launch_bounds__(64 * NW) void
 #endif
         }
     }
-    gstep_epilogue<SPLIT, MB>(a, job, acc, ct, wv, lane, w0);
+    gstep_epilogue2<SPLIT, MB, 1>(a, job, reinterpret_cast<P::Acc (&)[1][MB]>(acc), ct, wv, lane, w0);      // (requests of the whole tile first; the JF_DHM second output)
 #ifdef GGW_STAMPS
     GS_T(5)
     if (a.stamps && tid == 0) { for (int q = 0; q < 6; ++q) a.stamps[(size_t)blockIdx.x * 8 + q] = tk[q]; a.stamps[(size_t)blockIdx.x * 8 + 6] = nchunk; a.stamps[(size_t)blockIdx.x * 8 + 7] = job[J_NTERMS]; }

@@ -330,6 +330,8 @@ class Engine:
         if ws is None:
             lay = self.layout(B, training)
             ws = torch.empty(lay.total, dtype=torch.uint8, device=self.device)
+            if os.environ.get("MSHGNN_POISON_WS") == "1":      # tests: a fresh workspace reads as NaNs / all-ones relu bytes, so that a kernel which reads what no launch
+                ws.fill_(0xFF)                                 # wrote fails loudly instead of finding an earlier engine's values in recycled memory (tests/conftest.py sets it)
             while len(self._ws) >= self.MAX_WORKSPACES:
                 old_key = next(iter(self._ws))
                 del self._ws[old_key]

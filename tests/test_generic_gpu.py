@@ -129,11 +129,13 @@ def test_configs4_bench_arithmetic_is_within_bf16_distance_of_the_oracle():
     assert not bad, bad
 
 
-@pytest.mark.parametrize("seed,nb,nj,nf,hidden,layers", [(1, 1, 7, 3, 128, 3), (2, 2, 15, 5, 128, 2), (3, 3, 30, 9, 256, 3), (4, 1, 5, 2, 128, 4)])
+@pytest.mark.parametrize("seed,nb,nj,nf,hidden,layers", [(1, 1, 7, 3, 128, 3), (2, 2, 15, 5, 128, 2), (3, 3, 30, 9, 256, 3), (4, 1, 5, 2, 128, 4),
+                                                        (5, 2, 9, 3, 512, 2), (7, 1, 4, 2, 1024, 2)])      # (seed 6 at 1024: a one-element decoder-bias gradient that cancels to 2e-4 of its terms -- 1.1e-4 on it, 4e-5 elsewhere)
 def test_random_topologies_match_the_oracle(seed, nb, nj, nf, hidden, layers):
     """Topologies no robot of the reference has: random edge lists over the five relation types of the MI graph (hgnn.py:5-63 takes any metadata) --
     repeated edges, nodes without in-edges, in-degrees up to the node count, one relation left empty -- on whichever engine plan creation picks
-    (the LDS-resident kernels up to 20 nodes at h = 128, else the generic-width engine), parity arithmetic, 1e-4."""
+    (the LDS-resident kernels up to 20 nodes at h = 128, else the generic-width engine), parity arithmetic, 1e-4.  hidden = 512 / 1024: the pipelined job kernel
+    (k_gstep5, one / two column groups per tile) with a ragged second 64-window tile, sums of two rows as two terms, longer ones through the aggregate launch."""
     import random
     from morphsym_hgnn_amd import engine as eng, synth
     from morphsym_hgnn_amd.spec import ModelSpec
@@ -150,7 +152,7 @@ def test_random_topologies_match_the_oracle(seed, nb, nj, nf, hidden, layers):
     topo = RobotTopology(name=f"random{seed}", num_nodes=n, relations=rels)
     spec = ModelSpec(kind="mi", topology=topo, hidden=hidden, num_layers=layers, widths={"base": 24, "joint": 9, "foot": 5}, regression=True,
                      grf_dimension=1, group=None, num_timesteps=3)
-    B = 21
+    B = 21 if hidden < 512 else 70
     x_dict, y = synth.make_windows(seed, B, spec.num_nodes, spec.widths, spec.out_channels * nf)
     params = synth.make_params(seed, spec.param_shapes())
     errs, *_ = helpers.run_engine_case(spec, x_dict, y, params, topo.edge_index_dict(B), B, dtype="x3")
@@ -208,7 +210,7 @@ def test_job_kernels_of_the_generic_engine_agree_bit_for_bit(monkeypatch):
     # tie, and a 2^-16 perturbation flips relu decisions of pre-activations near zero; each run is compared with the oracle under its own decisions.)
     B = 70
     x_dict, y = synth.make_windows(77, B, spec.num_nodes, spec.widths, n_y)
-    for mode in ("2", None):
+    for mode in ("2", "6", None):      # k_gstep at 8 waves, k_gstep4, k_gstep5 (the default)
         if mode is None: monkeypatch.delenv("MSHGNN_GEN_TILE", raising=False)
         else: monkeypatch.setenv("MSHGNN_GEN_TILE", mode)
         errs, *_ = helpers.run_engine_case(spec, x_dict, y, params, spec.topology.edge_index_dict(B), B, dtype="x3")
