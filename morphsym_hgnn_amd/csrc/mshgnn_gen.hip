@@ -165,10 +165,13 @@ __device__ __forceinline__ int lane_now() { int l; asm volatile("v_mbcnt_lo_u32_
 // Two-phase epilogue of a job tile (bf16 arithmetic, NS 32-column slices per wave): EVERY request of the tile first, then the arithmetic and the stores.
 // gstep_epilogue's request -> store per row block is one memory round trip per block (the store may alias the next block's rows, so hipcc keeps their order):
 // 15-25 k clocks per slice of eight blocks, 20-45 k for k_gstep5's two -- a third of its workgroup's time.
-template <bool SPLIT, int MB, int NS>
-__device__ __forceinline__ void gstep_epilogue2(const GArgs& a, const int* job, P16::Acc (&acc)[NS][MB], int ct, int wv0, int lane, int w0) {
+// FS >= 0: the job's flags (without JF_BIAS, which the accumulators already hold) as a compile-time constant -- the flag tests fold away and the tile's requests are one
+// straight run; with run-time flags every test is a branch, and at every join hipcc's wait insertion takes the stricter count: the "requests first" phase then waits
+// request by request (7 300 lines of ISA and 12.7 k clocks for the two slices of k_gstep5).  FS < 0: run-time flags (any combination).
+template <bool SPLIT, int MB, int NS, int FS>
+__device__ __forceinline__ void gstep_epilogue2_impl(const GArgs& a, const int* job, P16::Acc (&acc)[NS][MB], int ct, int wv0, int lane, int w0, int rt_flags) {
     using P = P16;
-    const int B = a.B, Hd = a.Hd, flags = ro_int(job, J_FLAGS);
+    const int B = a.B, Hd = a.Hd, flags = FS >= 0 ? FS : rt_flags;
     // (the job record through the constant address space: behind the K loop's barriers plain loads of it are VECTOR loads, each awaited with vmcnt(0) -- one round trip per row block again)
     const int j_out_buf = ro_int(job, J_OUT_BUF), j_out_node = ro_int(job, J_OUT_NODE), j_res_buf = ro_int(job, J_RES_BUF), j_res_node = ro_int(job, J_RES_NODE),
               j_bits_buf = ro_int(job, J_BITS_BUF), j_gate_buf = ro_int(job, J_GATE_BUF), j_gate_node = ro_int(job, J_GATE_NODE), j_dhm_buf = ro_int(job, J_DHM_BUF);
@@ -246,6 +249,26 @@ __device__ __forceinline__ void gstep_epilogue2(const GArgs& a, const int* job, 
                 }
             }
         }
+}
+
+template <bool SPLIT, int MB, int NS, bool SPECIALISE = false>
+__device__ __forceinline__ void gstep_epilogue2(const GArgs& a, const int* job, P16::Acc (&acc)[NS][MB], int ct, int wv0, int lane, int w0) {
+    const int flags = ro_int(job, J_FLAGS) & ~JF_BIAS;
+    if constexpr (SPECIALISE) {      // the flag sets of the plans' layer launches (k_gstep5); anything else takes the run-time form
+        switch (flags) {
+#define GS_EPI_CASE(F) case (F): gstep_epilogue2_impl<SPLIT, MB, NS, (F)>(a, job, acc, ct, wv0, lane, w0, flags); return;
+            GS_EPI_CASE(JF_RELU | JF_BITS_OUT)
+            GS_EPI_CASE(JF_RELU | JF_BITS_OUT | JF_RES)
+            GS_EPI_CASE(JF_DHM | JF_DHM_ONLY)
+            GS_EPI_CASE(JF_DHM | JF_RES)
+            GS_EPI_CASE(JF_GATE_BITS)
+            GS_EPI_CASE(JF_GATE_BITS | JF_RES)
+            GS_EPI_CASE(0)
+#undef GS_EPI_CASE
+            default: break;
+        }
+    }
+    gstep_epilogue2_impl<SPLIT, MB, NS, -1>(a, job, acc, ct, wv0, lane, w0, flags);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -631,6 +654,7 @@ template <bool SPLIT, int MB, bool MASKED> __global__ __launch_bounds__(512) voi
         stage(nx, smem);
         if (nchunks > 1) advance(nx);
         __syncthreads();
+        GS5_T(4)      // (the prologue: term table, bias, first rows and weight fragments)
         int buf = 0;
         // One chunk per trip (`nx` is the chunk after it), NO branch between the requests and their uses: with the requests inside `if (more)` blocks hipcc's wait
         // insertion lost count at the joins and put vmcnt(0) in front of the first MFMA.  The last trip has nothing left to prefetch; it requests its own chunk
@@ -673,7 +697,7 @@ template <bool SPLIT, int MB, bool MASKED> __global__ __launch_bounds__(512) voi
             buf ^= 1;
         }
     }
-    gstep_epilogue2<SPLIT, MB, NS>(a, job, acc, ct0, wv0, lane, w0);
+    gstep_epilogue2<SPLIT, MB, NS, true>(a, job, acc, ct0, wv0, lane, w0);
 #ifdef GGW_STAMPS
     GS5_T(5)
     if (a.stamps && tid == 0) { for (int q = 0; q < 6; ++q) a.stamps[(size_t)blockIdx.x * 8 + q] = tk[q]; a.stamps[(size_t)blockIdx.x * 8 + 6] = nchunk; a.stamps[(size_t)blockIdx.x * 8 + 7] = nterms; }

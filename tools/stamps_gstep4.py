@@ -23,7 +23,7 @@ for nt in sorted(set(s[:, 7].astype(int))):
     per = q[:, :5] / q[:, 6:7]
     print(f"jobs of {nt} terms: {len(q)} workgroups, {np.median(q[:, 6]):.0f} chunks; clocks per chunk (median over workgroups), epilogue {np.median(q[:, 5]):.0f}:")
     names = ["barrier", "wait for rows", "LDS + barrier", "wait for weights", "MFMAs"]
-    if os.environ.get("MSHGNN_GEN_TILE") == "8": names = ["row requests", "K steps (MFMAs + weight requests)", "stage next rows", "barrier", "-"]      # k_gstep5
+    if os.environ.get("MSHGNN_GEN_TILE") == "8": names = ["top of the chunk", "K steps (MFMAs, weight and row requests)", "stage next rows", "barrier", "(prologue / chunks)"]      # k_gstep5
     for k, nm in enumerate(names):
         print(f"  {nm:34s} {np.median(per[:, k]):8.1f}   p90 {np.percentile(per[:, k], 90):8.1f}")
     print(f"  {'sum':18s} {np.median(per.sum(1)):8.1f}")
