@@ -1,5 +1,5 @@
 """Generic-width engine: the tile modes of its job kernel (MSHGNN_GEN_TILE: 0 = 4 waves, 1 = 8 waves on 128-window tiles, 2 = 8 waves, 3 = 16 waves on 64-window
-tiles, 6 = k_gstep4: the default) on the synthetic 32-limb model (h = 512, L = 6): per-kernel times of the one-call
+tiles, 6 = k_gstep4, 8 = k_gstep5: the default) on the synthetic 32-limb model (h = 512, L = 6): per-kernel times of the one-call
 step; bf16 modes give identical bits.  `check_gen_modes.py 1024 6`; DT=x3 for the split arithmetic."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
