@@ -697,7 +697,7 @@ template <bool SPLIT, int MB, bool MASKED> __global__ __launch_bounds__(512) voi
             buf ^= 1;
         }
     }
-    gstep_epilogue2<SPLIT, MB, NS, true>(a, job, acc, ct0, wv0, lane, w0);
+    gstep_epilogue2<SPLIT, MB, NS, !MASKED>(a, job, acc, ct0, wv0, lane, w0);      // (the masked instantiations only run with MSHGNN_GEN_DHM=0: run-time flags there, for the size of the library)
 #ifdef GGW_STAMPS
     GS5_T(5)
     if (a.stamps && tid == 0) { for (int q = 0; q < 6; ++q) a.stamps[(size_t)blockIdx.x * 8 + q] = tk[q]; a.stamps[(size_t)blockIdx.x * 8 + 6] = nchunk; a.stamps[(size_t)blockIdx.x * 8 + 7] = nterms; }
