@@ -516,9 +516,12 @@ template <bool SPLIT, int MB, int NW> __global__ __launch_bounds__(64 * NW) void
 // than k_gstep4 + the 10 of the rows in flight.  Every accumulator still receives its products in k_gstep4's order (chunks in order, K steps 0..3): identical bits.
 // Chunks that are not one plain row (sums of two rows, raw inputs) are gathered at staging time as before.
 constexpr int GS5_MAX_TERMS = 16, GS5_TERM_BYTES = 32;      // k_gstep5's term table in LDS (behind the two tile sets)
+#ifndef GS5_MB_SPLIT
+#define GS5_MB_SPLIT 6      // 16-window row blocks per tile of the split arithmetic's k_gstep5 (96 windows: 253 registers, none spilled; 128: spills; 64: 7.67 vs 7.54 ms on the 32-limb model)
+#endif
 constexpr int gs5_lds_bytes(bool split, int mb) { return 2 * (split ? 2 : 1) * mb * P16::BLK + GS5_MAX_TERMS * GS5_TERM_BYTES; }
-// SPLIT (the split-bf16 arithmetic of section 4b: rows [hi Hd | lo Hd], three products per term, hi x hi, lo-weights x hi, hi-weights x lo) runs it on 64-window tiles
-// (MB = 4): twice the planes in the weight ring, the rows in flight and the window fragments.
+// SPLIT (the split-bf16 arithmetic of section 4b: rows [hi Hd | lo Hd], three products per term, hi x hi, lo-weights x hi, hi-weights x lo) runs it on 96-window tiles
+// (MB = GS5_MB_SPLIT = 6): twice the planes in the weight ring, the rows in flight and the window fragments.
 template <bool SPLIT, int MB, bool MASKED> __global__ __launch_bounds__(512) void k_gstep5(GArgs a) {      // MASKED: some term of the launch carries relu bits (the backward sweeps: dH = dX . relu bits)
     using P = P16;
     constexpr int NW = 8, NS = 2, PL = SPLIT ? 2 : 1;            // 8 waves, each NS 32-column slices (64 columns) of the 512: two waves per SIMD, up to 256 registers; PL planes
@@ -1376,7 +1379,7 @@ int gen_create(mshgnn_plan* p, const mshgnn_desc* desc) {
         (rc = set_lds_attr(k_gstep<true, 8, 8>, 16 * P16::BLK)) || (rc = set_lds_attr(k_ggradw<true, 1>, ggw_lds_bytes(true, 1))) ||
         (rc = set_lds_attr(k_ggradw<true, 2, GGW_NWV_SPLIT2>, ggw_lds_bytes(true, 2))) || (rc = set_lds_attr(k_ggradw<true, 2, GGW_NWV_SPLIT2, true>, ggw_lds_bytes(true, 2, true))) ||
         (rc = set_lds_attr(k_ggradw<true, 1, 8, true>, ggw_lds_bytes(true, 1, true))) || (rc = set_lds_attr(k_ggradw<false, 2, GGW_NWV_BF16, true>, ggw_lds_bytes(false, 2, true))) || (rc = set_lds_attr(k_ggradw<false, 2, GGW_NWV_BF16>, ggw_lds_bytes(false, 2))) || (rc = set_lds_attr(k_gstep5<false, 8, true>, gs5_lds_bytes(false, 8))) || (rc = set_lds_attr(k_gstep5<false, 8, false>, gs5_lds_bytes(false, 8))) ||
-        (rc = set_lds_attr(k_gstep5<true, 4, true>, gs5_lds_bytes(true, 4))) || (rc = set_lds_attr(k_gstep5<true, 4, false>, gs5_lds_bytes(true, 4)))) return rc;
+        (rc = set_lds_attr(k_gstep5<true, GS5_MB_SPLIT, true>, gs5_lds_bytes(true, GS5_MB_SPLIT))) || (rc = set_lds_attr(k_gstep5<true, GS5_MB_SPLIT, false>, gs5_lds_bytes(true, GS5_MB_SPLIT)))) return rc;
     return MSHGNN_OK;
 }
 
@@ -1547,12 +1550,12 @@ static void g_launch_jobs(const mshgnn_plan* p, const Launch& ln, GArgs a, hipSt
     // of the staging latency: 495 us at 8 waves, 389 us at 16 waves with 56 B of scratch)
     const int mode = g_tile_blocks(a.B, gp.split);      // 0: 4 waves; 1: 8 waves, 128 windows; 2: 8 waves; 3: 16 waves; 6: k_gstep4 (bf16, hidden % 512 == 0; the default from 256 windows)
     if (mode == 8 && gp.NCT % 4 == 0 && ln.all_plain && ln.max_terms <= GS5_MAX_TERMS) {      // k_gstep5: k_gstep4's tile, software-pipelined (launches whose every term is one plain row)
-        a.tiles = gp.split ? (a.B + 63) / 64 : (a.B + 127) / 128;
+        a.tiles = gp.split ? (a.B + 16 * GS5_MB_SPLIT - 1) / (16 * GS5_MB_SPLIT) : (a.B + 127) / 128;
         const unsigned grid4 = (unsigned)ln.n_jobs * a.tiles * (a.NCT / 4);
         ProfScope ps(p, ln.ks, st);
         if (gp.split) {
-            if (ln.any_mask) hipLaunchKernelGGL((k_gstep5<true, 4, true>), dim3(grid4), dim3(512), gs5_lds_bytes(true, 4), st, a);
-            else hipLaunchKernelGGL((k_gstep5<true, 4, false>), dim3(grid4), dim3(512), gs5_lds_bytes(true, 4), st, a);
+            if (ln.any_mask) hipLaunchKernelGGL((k_gstep5<true, GS5_MB_SPLIT, true>), dim3(grid4), dim3(512), gs5_lds_bytes(true, GS5_MB_SPLIT), st, a);
+            else hipLaunchKernelGGL((k_gstep5<true, GS5_MB_SPLIT, false>), dim3(grid4), dim3(512), gs5_lds_bytes(true, GS5_MB_SPLIT), st, a);
         } else {
             if (ln.any_mask) hipLaunchKernelGGL((k_gstep5<false, 8, true>), dim3(grid4), dim3(512), gs5_lds_bytes(false, 8), st, a);
             else hipLaunchKernelGGL((k_gstep5<false, 8, false>), dim3(grid4), dim3(512), gs5_lds_bytes(false, 8), st, a);
