@@ -31,7 +31,7 @@ struct GArgs {
     const void* x[MSHGNN_MAX_TYPES]; int64_t pitch[MSHGNN_MAX_TYPES]; int nodes[MSHGNN_MAX_TYPES]; int vb[MSHGNN_MAX_TYPES]; int aligned;
     const int* jobs; const int* terms; const int* srcs; const int* units; const int* items; const int* sunits; const int* su_order; const int* aggs;
     const void* wpack; const float* bias; const uint8_t* signs; float* slabs;
-    int n_img, B, Hd, NCT, tiles, training, job0, n_units, n_parts, n_sunits;
+    int n_img, B, Hd, NCT, tiles, training, job0, n_units, n_parts, n_sunits, njt;      // njt: (job, tile) pairs of a k_gstep5 launch at 4 waves
 #ifdef GGW_STAMPS
     long long* stamps;      // (phase clocks of k_ggradw, tools/stamps_ggradw.py)
 #endif
@@ -522,20 +522,28 @@ constexpr int GS5_MAX_TERMS = 16, GS5_TERM_BYTES = 32;      // k_gstep5's term t
 constexpr int gs5_lds_bytes(bool split, int mb) { return 2 * (split ? 2 : 1) * mb * P16::BLK + GS5_MAX_TERMS * GS5_TERM_BYTES; }
 // SPLIT (the split-bf16 arithmetic of section 4b: rows [hi Hd | lo Hd], three products per term, hi x hi, lo-weights x hi, hi-weights x lo) runs it on 96-window tiles
 // (MB = GS5_MB_SPLIT = 6): twice the planes in the weight ring, the rows in flight and the window fragments.
-template <bool SPLIT, int MB, bool MASKED> __global__ __launch_bounds__(512) void k_gstep5(GArgs a) {      // MASKED: some term of the launch carries relu bits (the backward sweeps: dH = dX . relu bits)
+template <bool SPLIT, int MB, bool MASKED, int NW = 8> __global__ __launch_bounds__(64 * NW, 2) void k_gstep5(GArgs a) {      // MASKED: some term of the launch carries relu bits (the backward sweeps: dH = dX . relu bits)
     using P = P16;
-    constexpr int NW = 8, NS = 2, PL = SPLIT ? 2 : 1;            // 8 waves, each NS 32-column slices (64 columns) of the 512: two waves per SIMD, up to 256 registers; PL planes
+    constexpr int NS = 2, PL = SPLIT ? 2 : 1;            // NW waves (8: one workgroup per CU and two waves per SIMD in step; 4: 256 columns per workgroup, TWO workgroups per CU, one wave per SIMD each, out of step)
+    //            // 8 waves, each NS 32-column slices (64 columns) of the 512: two waves per SIMD, up to 256 registers; PL planes
     constexpr int SET = PL * MB * P16::BLK;                      // one tile set: blocks [0, MB) the (hi) rows, [MB, 2 MB) the lo halves
     constexpr int NPASS = MB * 16 / (4 * NW);                    // staging passes: thread = (row rr + 4 NW i, chunk c)
     static_assert(NPASS >= 1 && NPASS * 4 * NW == MB * 16, "row blocks must cover whole staging passes");
     extern __shared__ __attribute__((aligned(16))) char smem[];      // two tile sets of MB blocks, then the term table
     const int tid = threadIdx.x, lane = tid & 63, wq = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nctg = a.NCT / 4;
-    const int ctg = blockIdx.x % nctg, tile = (blockIdx.x / nctg) % a.tiles;
-    const int* job = a.jobs + (size_t)(a.job0 + blockIdx.x / (nctg * a.tiles)) * JOB_INTS;
+    const int nctg = a.NCT * 2 / NW;      // column groups of NW * 64 columns
+    int ctg, jt;
+    if constexpr (NW == 4) {
+        // the nctg workgroups of a (job, tile) read the same source rows: 8 blocks apart, i.e. on one XCD (round-robin dispatch) and dispatched back to back, so that
+        // the later readers find the rows in that XCD's L2 (grid padded to whole groups of 8 nctg)
+        ctg = (blockIdx.x >> 3) % nctg; jt = (blockIdx.x / (8 * nctg)) * 8 + (blockIdx.x & 7);
+        if (jt >= a.njt) return;
+    } else { ctg = blockIdx.x % nctg; jt = blockIdx.x / nctg; }
+    const int tile = jt % a.tiles;
+    const int* job = a.jobs + (size_t)(a.job0 + jt / a.tiles) * JOB_INTS;
     const int w0 = tile * MB * P::ROWS, B = a.B, Hd = a.Hd;
     const int flags = job[J_FLAGS], nterms = job[J_NTERMS], NCT = a.NCT;
-    const int ct0 = ctg * 4 + (wq >> 1), wv0 = (wq & 1) * 2;      // this wave's slices 2 wq and 2 wq + 1 of the 16: 128-column pack tile ct0, wave slots wv0 and wv0 + 1 of it
+    const int ct0 = ctg * (NW / 2) + (wq >> 1), wv0 = (wq & 1) * 2;      // this wave's slices 2 wq and 2 wq + 1 of the 16: 128-column pack tile ct0, wave slots wv0 and wv0 + 1 of it
     GEN_TL(0);
 #ifdef GGW_STAMPS
     long long tk[6] = {0, 0, 0, 0, 0, 0}, t0 = clock64(); int nchunk = 0;      // (phase clocks, tools/stamps_gstep4.py)
@@ -1378,7 +1386,7 @@ int gen_create(mshgnn_plan* p, const mshgnn_desc* desc) {
     if ((rc = set_lds_attr(k_gdec_bwd<false>, dec_lds)) || (rc = set_lds_attr(k_gdec_bwd<true>, dec_lds)) ||
         (rc = set_lds_attr(k_gstep<true, 8, 8>, 16 * P16::BLK)) || (rc = set_lds_attr(k_ggradw<true, 1>, ggw_lds_bytes(true, 1))) ||
         (rc = set_lds_attr(k_ggradw<true, 2, GGW_NWV_SPLIT2>, ggw_lds_bytes(true, 2))) || (rc = set_lds_attr(k_ggradw<true, 2, GGW_NWV_SPLIT2, true>, ggw_lds_bytes(true, 2, true))) ||
-        (rc = set_lds_attr(k_ggradw<true, 1, 8, true>, ggw_lds_bytes(true, 1, true))) || (rc = set_lds_attr(k_ggradw<false, 2, GGW_NWV_BF16, true>, ggw_lds_bytes(false, 2, true))) || (rc = set_lds_attr(k_ggradw<false, 2, GGW_NWV_BF16>, ggw_lds_bytes(false, 2))) || (rc = set_lds_attr(k_gstep5<false, 8, true>, gs5_lds_bytes(false, 8))) || (rc = set_lds_attr(k_gstep5<false, 8, false>, gs5_lds_bytes(false, 8))) ||
+        (rc = set_lds_attr(k_ggradw<true, 1, 8, true>, ggw_lds_bytes(true, 1, true))) || (rc = set_lds_attr(k_ggradw<false, 2, GGW_NWV_BF16, true>, ggw_lds_bytes(false, 2, true))) || (rc = set_lds_attr(k_ggradw<false, 2, GGW_NWV_BF16>, ggw_lds_bytes(false, 2))) || (rc = set_lds_attr(k_gstep5<false, 8, true>, gs5_lds_bytes(false, 8))) || (rc = set_lds_attr(k_gstep5<false, 8, true, 4>, gs5_lds_bytes(false, 8))) || (rc = set_lds_attr(k_gstep5<false, 8, false, 4>, gs5_lds_bytes(false, 8))) || (rc = set_lds_attr(k_gstep5<false, 8, false>, gs5_lds_bytes(false, 8))) ||
         (rc = set_lds_attr(k_gstep5<true, GS5_MB_SPLIT, true>, gs5_lds_bytes(true, GS5_MB_SPLIT))) || (rc = set_lds_attr(k_gstep5<true, GS5_MB_SPLIT, false>, gs5_lds_bytes(true, GS5_MB_SPLIT)))) return rc;
     return MSHGNN_OK;
 }
@@ -1506,10 +1514,11 @@ static int g_fill(const mshgnn_plan* p, const mshgnn_ws_layout& lay, const void*
     return MSHGNN_OK;
 }
 
+static bool g_forced_tile() { const char* e = getenv("MSHGNN_GEN_TILE"); return e && atoi(e) >= 0; }
 static int g_tile_blocks(int B, bool split) {
     const char* e = getenv("MSHGNN_GEN_TILE");      // (kernel experiments; read per launch so that a test can compare modes in one process)
     const int forced = e ? atoi(e) : -1;
-    if (forced >= 0 && forced <= 8 && forced != 7) return forced;
+    if (forced >= 0 && forced <= 9 && forced != 7) return forced;
     // bf16: 16 waves; on 128-window tiles (k_gstep5: the software pipeline of 8 waves; k_gstep4) once the batch has two of them -- half the weight stream per window, 250-258 / 252-314 us per layer launch
     // against 285-292 / 303-357 on the 32-limb model; split arithmetic: k_gstep4 at 16 waves on 64-window tiles (720-740 / 673-766 us against 803-813 / 814-925
     // for k_gstep at 8 waves, whose 16-wave form spills)
@@ -1549,7 +1558,18 @@ static void g_launch_jobs(const mshgnn_plan* p, const Launch& ln, GArgs a, hipSt
     // 4 / 8 / 16 waves, split 870 / 799 / 1012 us (16 waves: 128 VGPRs, spills); 128-window tiles lose (fewer resident workgroups hide less
     // of the staging latency: 495 us at 8 waves, 389 us at 16 waves with 56 B of scratch)
     const int mode = g_tile_blocks(a.B, gp.split);      // 0: 4 waves; 1: 8 waves, 128 windows; 2: 8 waves; 3: 16 waves; 6: k_gstep4 (bf16, hidden % 512 == 0; the default from 256 windows)
-    if (mode == 8 && gp.NCT % 4 == 0 && ln.all_plain && ln.max_terms <= GS5_MAX_TERMS) {      // k_gstep5: k_gstep4's tile, software-pipelined (launches whose every term is one plain row)
+    // k_gstep5 at 4 waves (256 columns per workgroup, two workgroups per CU) when the launch has more (job, tile) pairs than CUs: half-size workgroups halve the
+    // launch's tail (1 032 pairs on 256 CUs: 209 -> 189 us; 1 024: equal; 256 pairs, a single round: 42 -> 46 us, so those keep 8 waves).  Same bits.  (=9 / =8 force one.)
+    if ((mode == 9 || (mode == 8 && !g_forced_tile() && ln.n_jobs * ((a.B + 127) / 128) > p->n_cu)) && !gp.split && gp.NCT % 4 == 0 && ln.all_plain && ln.max_terms <= GS5_MAX_TERMS) {
+        a.tiles = (a.B + 127) / 128; a.njt = ln.n_jobs * a.tiles;
+        const int nctg = gp.NCT / 2;
+        const unsigned grid9 = (unsigned)((a.njt + 7) / 8) * 8 * nctg;
+        ProfScope ps(p, ln.ks, st);
+        if (ln.any_mask) hipLaunchKernelGGL((k_gstep5<false, 8, true, 4>), dim3(grid9), dim3(256), gs5_lds_bytes(false, 8), st, a);
+        else hipLaunchKernelGGL((k_gstep5<false, 8, false, 4>), dim3(grid9), dim3(256), gs5_lds_bytes(false, 8), st, a);
+        return;
+    }
+    if ((mode == 8 || mode == 9) && gp.NCT % 4 == 0 && ln.all_plain && ln.max_terms <= GS5_MAX_TERMS) {      // k_gstep5: k_gstep4's tile, software-pipelined (launches whose every term is one plain row)
         a.tiles = gp.split ? (a.B + 16 * GS5_MB_SPLIT - 1) / (16 * GS5_MB_SPLIT) : (a.B + 127) / 128;
         const unsigned grid4 = (unsigned)ln.n_jobs * a.tiles * (a.NCT / 4);
         ProfScope ps(p, ln.ks, st);

@@ -184,13 +184,14 @@ def test_generic_ragged_batches_and_step_equals_two_call_sequence():
 
 def test_job_kernels_of_the_generic_engine_agree_bit_for_bit(monkeypatch):
     """The generic engine's job kernels on the synthetic 32-limb model (h = 512): the 16-wave kernel on 64-window tiles (MSHGNN_GEN_TILE=3, small batches), on
-    128-window tiles (k_gstep4, MSHGNN_GEN_TILE=6) and the software-pipelined 8-wave kernel on the same tiles (k_gstep5, =8: the default from 256 windows) --
+    128-window tiles (k_gstep4, MSHGNN_GEN_TILE=6) and the software-pipelined kernel on the same tiles (k_gstep5 at 8 waves, =8, and at 4 waves with two workgroups
+    per CU, =9: the default from 256 windows picks between the two per launch) --
     same operands in the same order per accumulator, so outputs, loss and every gradient are identical bits (full and ragged 128-window tiles)."""
     from morphsym_hgnn_amd import engine as eng, synth
     case, spec, *_ = helpers.load_case("synth32_mi_h512_L6_B2")
     n_y = spec.out_channels * spec.num_nodes[spec.out_type]
     params = synth.make_params(21, spec.param_shapes())
-    for B, modes in ((256, ("3", "6", "8", None)), (300, ("3", "6", "8", None))):
+    for B, modes in ((256, ("3", "6", "8", "9", None)), (300, ("3", "6", "8", "9", None))):
         x_dict, y = synth.make_windows(21 + B, B, spec.num_nodes, spec.widths, n_y)
         res = {}
         for mode in modes:
