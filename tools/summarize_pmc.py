@@ -9,7 +9,7 @@ def per_kernel(pattern, counter):
         for r in csv.DictReader(open(path)):
             if r["Counter_Name"] == counter:
                 agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in agg.items()}
+    return {k: (sum(v), len(v)) for k, v in agg.items()}      # (total, launches) per kernel name
 
 def short(name):
     for key, s in [("k_prep", "prep"), ("k_enc_fwd", "enc_fwd"), ("k_enc_x3", "enc_fwd"), ("k_gstep", "gstep"), ("k_ggradw", "ggradw"), ("k_stack_fwd", "stack_fwd"), ("k_stack_bwd", "stack_bwd"), ("k_slab_step", "stack_step"), ("k_stack_step", "stack_step"), ("k_slab_fwd", "stack_fwd"), ("k_slab_bwd", "stack_bwd"), ("k_eng_fwd", "stack_fwd"), ("k_eng_bwd", "stack_bwd"), ("k_wide_fwd", "stack_fwd"), ("k_wide_bwd", "stack_bwd"),
@@ -22,12 +22,16 @@ def short(name):
 if __name__ == "__main__":
     fetch = per_kernel(sys.argv[1] + "/**/*counter_collection.csv", "FETCH_SIZE")
     write = per_kernel(sys.argv[2] + "/**/*counter_collection.csv", "WRITE_SIZE")
-    out = {}
-    for k, v in fetch.items():
+    tot = collections.defaultdict(lambda: [0.0, 0.0, 0])      # short name -> [fetch KiB, write KiB, launches]: the instantiations of one kernel family are pooled
+    for k, (v, n) in fetch.items():
         s = short(k)
         if s:
-            out[s] = {"fetch_bytes": 2.0 * v * 1024.0, "write_bytes": write.get(k, 0.0) * 1024.0}
-            out[s]["hbm_bytes"] = out[s]["fetch_bytes"] + out[s]["write_bytes"]
+            tot[s][0] += v; tot[s][2] += n
+            tot[s][1] += write.get(k, (0.0, 0))[0]
+    out = {}
+    for s, (f, w, n) in tot.items():
+        out[s] = {"fetch_bytes": 2.0 * f / n * 1024.0, "write_bytes": w / n * 1024.0, "launches": n}
+        out[s]["hbm_bytes"] = out[s]["fetch_bytes"] + out[s]["write_bytes"]
     import os
     cfile = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), ".build_commit")      # written before the snapshot leaves the build container
     commit = open(cfile).read().strip() if os.path.exists(cfile) else None
