@@ -486,6 +486,8 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
             if (sp[S_SCALE] != fbits(1.0f) || sp[S_MASK] >= 0) return false;
         }
         return true; };
+    int ipu = G_ITEMS_PER_UNIT;      // items per weight-gradient unit
+    if (const char* e = std::getenv("MSHGNN_GGW_ITEMS")) ipu = std::max(1, std::atoi(e));      // (measurements)
     // units: for every target tile (ot, kt) one unit per chunk of <= G_ITEMS_PER_UNIT items; the units of one tile are consecutive
     for (Tgt& g : tgts) {
         g.unit0 = (int)(units.size() / UNIT_INTS);
@@ -495,12 +497,12 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
         std::stable_sort(g.items.begin(), g.items.end(), [&](const std::array<int, 6>& x, const std::array<int, 6>& y) { return item_plain(x) > item_plain(y); });
         for (auto& it : g.items) items.insert(items.end(), {it[0], it[1], it[2], it[3], it[4], it[5], 0, 0});
         const int n = (int)g.items.size();
-        g.chunks = (n + G_ITEMS_PER_UNIT - 1) / G_ITEMS_PER_UNIT;
+        g.chunks = (n + ipu - 1) / ipu;
         const int nkt = (g.K + TW - 1) / TW;
         for (int ot = 0; ot < g.rows / TW; ++ot)
             for (int kt = 0; kt < nkt; ++kt)
                 for (int c = 0; c < g.chunks; ++c)
-                    units.insert(units.end(), {i0 + c * G_ITEMS_PER_UNIT, i0 + std::min(n, (c + 1) * G_ITEMS_PER_UNIT), ot * TW, kt * TW, std::min(TW, g.K - kt * TW),
+                    units.insert(units.end(), {i0 + c * ipu, i0 + std::min(n, (c + 1) * ipu), ot * TW, kt * TW, std::min(TW, g.K - kt * TW),
                                                (g.bias && kt == 0) ? 1 : 0, 0, 0});
     }
     p.n_units = (int)(units.size() / UNIT_INTS);
@@ -522,14 +524,15 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
                     for (int a = 0; a < p.su_os; ++a) for (int b = 0; b < 2; ++b)
                         if (ot + a < not_ && kt + b < nkt) u[a * 2 + b] = g.unit0 + ((ot + a) * nkt + kt + b) * g.chunks + c;
                     int flags = 1;
-                    for (int i = c * G_ITEMS_PER_UNIT; i < std::min(n, (c + 1) * G_ITEMS_PER_UNIT); ++i) if (!item_plain(g.items[i])) flags = 0;
+                    for (int i = c * ipu; i < std::min(n, (c + 1) * ipu); ++i) if (!item_plain(g.items[i])) flags = 0;
                     if (g.bias && kt == 0) flags |= 2;
-                    sunits.insert(sunits.end(), {u[0], u[1], u[2], u[3], i0 + c * G_ITEMS_PER_UNIT, i0 + std::min(n, (c + 1) * G_ITEMS_PER_UNIT), ot * TW, kt * TW,
+                    sunits.insert(sunits.end(), {u[0], u[1], u[2], u[3], i0 + c * ipu, i0 + std::min(n, (c + 1) * ipu), ot * TW, kt * TW,
                                                  std::min(2 * TW, g.K - kt * TW), flags, 0, 0});
                 }
     }
     p.n_sunits = (int)(sunits.size() / SUNIT_INTS);
     p.n_parts = std::max(1, std::min(16, 768 / std::max(1, p.n_sunits)));
+    if (const char* e = std::getenv("MSHGNN_GGW_PARTS")) p.n_parts = std::max(1, std::min(16, std::atoi(e)));      // (measurements)
     // launch order: the super-units of ONE (target, item chunk) read the same P and Q rows (each half of them twice at hidden = 512).  Workgroups b
     // and b + 8 run on the same XCD (round-robin dispatch), so they are placed 8 apart on one XCD, back to back, and the second reader hits that
     // XCD's L2 (speed only).  Super-units were emitted (target, chunk)-major, so a group is a run of consecutive indices.
@@ -544,15 +547,16 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
     std::vector<int32_t> su_order;
     const bool su_locality = []() { const char* e = std::getenv("MSHGNN_GGW_PLACE"); return !(e && std::atoi(e) == 0); }();      // (=0: round 2's placement, A/B runs)
     for (int cls = 0; cls <= 1; ++cls) {
-        struct Grp { int first, count; std::vector<int64_t> streams; int64_t key; };
+        struct Grp { int first, count; std::vector<int64_t> streams; int64_t key; int steps; };      // steps: items of the group's super-units (their length)
         std::vector<Grp> groups;
         int pos = 0;
         for (Tgt& g : tgts) {
             const int per = ((g.rows / TW + p.su_os - 1) / p.su_os) * (((g.K + TW - 1) / TW + 1) / 2);
             for (int c = 0; c < g.chunks; ++c) {
                 if ((sunits[(size_t)pos * SUNIT_INTS + SU_FLAGS] & 1) == cls) {
-                    Grp gr{pos, per, {}, INT64_MAX};
+                    Grp gr{pos, per, {}, INT64_MAX, 0};
                     const int ia = sunits[(size_t)pos * SUNIT_INTS + SU_ITEM0], ib = sunits[(size_t)pos * SUNIT_INTS + SU_ITEM1];
+                    gr.steps = ib - ia;
                     for (int it = ia; it < ib; ++it) {
                         const int32_t* im = &items[(size_t)it * GITEM_INTS];
                         const int64_t ps = ((int64_t)im[I_PBUF] << 20) | (int64_t)im[I_PNODE];
@@ -589,7 +593,12 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
         }
         std::vector<std::vector<int>> xs(8);      // queues of super-units
         for (int x = 0; x < 8; ++x) {
-            if (su_locality) std::stable_sort(xq[x].begin(), xq[x].end(), [&](int a, int b) { return groups[a].key < groups[b].key; });
+            // longest groups first (the launch is a list schedule of ~3 rounds of workgroups: with the short ones last its tail is a short workgroup, not a long one);
+            // groups of one length by their first P row, so that the groups of one layer and limb range are still dispatched side by side
+            static const bool lpt = []() { const char* e = std::getenv("MSHGNN_GGW_LPT"); return !(e && std::atoi(e) == 0); }();
+            if (su_locality) std::stable_sort(xq[x].begin(), xq[x].end(), [&](int a, int b) {
+                if (lpt && groups[a].steps != groups[b].steps) return groups[a].steps > groups[b].steps;
+                return groups[a].key < groups[b].key; });
             for (int gi : xq[x]) for (int k = 0; k < groups[gi].count; ++k) xs[x].push_back(groups[gi].first + k);
         }
         std::vector<size_t> qpos(8, 0);
