@@ -258,3 +258,26 @@ def test_flat_data_parallel_wrappers_reproduce_the_global_batch_gradient(B):
     mp.spawn(_wrapper_worker, args=(world, port, B, ret), nprocs=world, join=True)
     assert ret["params_equal"] and ret["err"] < 1e-5
     assert ret["two_call_0"] < 1e-5 and ret["two_call_1"] < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,layers", [("bf16", 3), ("x3", 3), ("bf16", 2)])
+def test_engine_gradient_is_exactly_zero_outside_the_live_elements(dtype, layers):
+    """What makes the live-element exchange exact on the real engine: every element of the flat gradient that `spec.live_gradient_index` leaves out is an exact
+    zero after a step (A1-C2 below the graph's diameter: the base nodes cannot reach the feet), and the live part is not all zero."""
+    from morphsym_hgnn_amd import engine as eng
+    spec = helpers.make_spec("c2", "a1-c2", "a1-c2", 128, layers)
+    B = 50
+    x_dict, y = synth.make_windows(7, B, spec.num_nodes, spec.widths, 12)
+    e = eng.Engine(spec, dtype)
+    flat = eng.flatten_params(spec, synth.make_params(7, spec.param_shapes()), e.device)
+    out, loss, g = e.step_mse(e.cast_inputs(x_dict), flat, y.reshape(-1).to(e.device, torch.float32), B)
+    ex = ddp.LiveGradientExchange(spec, e.device)
+    dead = torch.ones(g.numel(), dtype=torch.bool, device=g.device)
+    dead[ex.index] = False
+    assert 0.0 < ex.fraction < 1.0 and int(dead.sum()) == g.numel() - ex.index.numel()
+    assert float(g[dead].abs().max()) == 0.0
+    assert float(g[ex.index].abs().max()) > 0.0
+    before = g.clone()
+    ex.allreduce_mean_(g)                      # no process group: pack + scatter only
+    assert torch.equal(before, g)
