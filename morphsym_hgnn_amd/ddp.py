@@ -82,7 +82,7 @@ class LiveGradientExchange:
         return flat_grad
 
 
-def exchange_flat_gradient_(buf: torch.Tensor, n_flat: int, local_windows: int, group=None, weight_by_windows: bool = True) -> torch.Tensor:
+def exchange_flat_gradient_(buf: torch.Tensor, n_flat: int, local_windows: int, group=None, weight_by_windows: bool = True, live=None) -> torch.Tensor:
     """The ONE exchange of a `flat_data_parallel` step, in place on `buf` (fp32, >= n_flat + 1 elements: the flat gradient of this rank's LOCAL mean
     loss followed by one spare element).  weight_by_windows: the gradient is multiplied by this rank's window count, the count rides in the spare
     element, ONE sum-all-reduce moves both, and the returned divisor (a 0-dim tensor on buf's device, no host sync) is the global window count --
@@ -90,6 +90,15 @@ def exchange_flat_gradient_(buf: torch.Tensor, n_flat: int, local_windows: int, 
     on the host).  Otherwise: plain sum, divisor = world size (torch DDP's mean of the ranks' means, gnnLightning.py:1396-1400)."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
+    if live is not None:      # (flat_data_parallel(live_only=True)) the same exchange on the packed live elements [+ the count]: exact, the dead elements are zeros on every rank
+        idx, packed = live
+        torch.index_select(buf, 0, idx, out=packed)
+        if weight_by_windows:
+            packed.mul_(float(local_windows))
+            packed[-1] = float(local_windows)      # (idx ends with n_flat: the spare element)
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+        buf.index_copy_(0, idx, packed)
+        return packed[-1].clone() if weight_by_windows else torch.tensor(float(world), dtype=torch.float32, device=buf.device)
     if not weight_by_windows:
         dist.all_reduce(buf[:n_flat], op=dist.ReduceOp.SUM, group=group)
         return torch.tensor(float(world), dtype=torch.float32, device=buf.device)
@@ -101,7 +110,7 @@ def exchange_flat_gradient_(buf: torch.Tensor, n_flat: int, local_windows: int, 
     return buf[n_flat].clone()
 
 
-def flat_data_parallel(module, group=None, weight_by_windows: bool = True):
+def flat_data_parallel(module, group=None, weight_by_windows: bool = True, live_only: bool = False):
     """Data parallelism for a training-step wrapper (wrappers.py) or a model (models.py) WITHOUT torch's DistributedDataParallel: the
     parameters (views of one flat buffer) are broadcast from rank 0 once, and from then on the fused training step
     (`training_step` -> `models.fused_training_step[_windows]`) sum-all-reduces its flat gradient in `loss.backward()` and divides by the
@@ -113,7 +122,8 @@ def flat_data_parallel(module, group=None, weight_by_windows: bool = True):
     normalising WindowBatch) makes the same single exchange in the engine's backward.  Only the fused engine has that hook: a model that runs
     operator by operator (an activation other than ReLU, a hidden width that is not a multiple of 128) is rejected here -- wrap that one in
     torch's DistributedDataParallel.  The model must have seen its lazy-initialising forward and live on the device; do not also wrap it
-    in DDP.  Returns `module`."""
+    in DDP.  live_only: the exchange moves only the elements that can be non-zero at the model's depth (exact; A1-C2 at 3 layers: 36 % of the
+    buffer -- `LiveGradientExchange`).  Returns `module`."""
     import torch.distributed as dist
     model = getattr(module, "model", module)
     if not (dist.is_available() and dist.is_initialized()):
@@ -130,4 +140,10 @@ def flat_data_parallel(module, group=None, weight_by_windows: bool = True):
     dist.broadcast(flat, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
     model._flat_ddp = True if group is None else group
     model._flat_ddp_weighted = bool(weight_by_windows)
+    model._flat_ddp_live = None
+    if live_only:      # exchange only the elements whose gradient can be non-zero at this depth (LiveGradientExchange's index), plus the window count's spare element
+        idx = model._spec.live_gradient_index().to(flat.device)
+        if weight_by_windows:
+            idx = torch.cat([idx, torch.tensor([flat.numel()], dtype=torch.int64, device=flat.device)])
+        model._flat_ddp_live = (idx, torch.empty(idx.numel(), dtype=torch.float32, device=flat.device))
     return module

@@ -89,8 +89,8 @@ class _EngineFnP(torch.autograd.Function):
         gflat = e.backward(ctx.xs, ctx.flat, gout.contiguous().to(torch.float32), ctx.B, grad_flat=full[:n_flat])
         if ctx.ddp is not None:      # ddp.flat_data_parallel on the two-call route: the same single exchange the fused training step makes
             from .ddp import exchange_flat_gradient_
-            group, weighted = ctx.ddp
-            gflat.div_(exchange_flat_gradient_(full, n_flat, ctx.B, None if group is True else group, weighted))
+            group, weighted, live = (*ctx.ddp, None)[:3]
+            gflat.div_(exchange_flat_gradient_(full, n_flat, ctx.B, None if group is True else group, weighted, live))
         grads = [gflat[o:o + n].view(shape) for (o, n), shape in zip(ctx.offsets, ctx.shapes)]
         return (None, None, None, None, None, None, *([None] * ctx.n_x), *grads)
 
@@ -191,7 +191,7 @@ class _FusedStepFn(torch.autograd.Function):
         if m._flat_ddp is not None:      # data parallel: ONE sum-all-reduce of the flat gradient (weighted by the ranks' window counts: ddp.py)
             from .ddp import exchange_flat_gradient_
             group = None if m._flat_ddp is True else m._flat_ddp
-            scale = scale / exchange_flat_gradient_(m._gpend_full, pend.numel(), ctx.windows, group, m._flat_ddp_weighted)
+            scale = scale / exchange_flat_gradient_(m._gpend_full, pend.numel(), ctx.windows, group, m._flat_ddp_weighted, getattr(m, "_flat_ddp_live", None))
         _deliver_gradients(m, ctx.flat, lambda target: torch.mul(pend, scale, out=target) if target is not None else pend * scale)
         return (None,) * n_in
 
@@ -222,6 +222,7 @@ class _MSHGNNBase(nn.Module):
         self._gpend_id = 0
         self._flat_ddp = None            # ddp.flat_data_parallel: the process group the fused training step all-reduces its flat gradient over
         self._flat_ddp_weighted = True   # ... with each rank's gradient weighted by its window count (ragged shards)
+        self._flat_ddp_live = None       # ... over the live elements only (flat_data_parallel(live_only=True)): (index, packed buffer)
         self._gpend_full = None
         self._gviews = None
         self._anchor = None
@@ -235,7 +236,7 @@ class _MSHGNNBase(nn.Module):
         state["_engines"] = {}
         state["_flat"] = None
         state["_flat_ok"] = False
-        state["_gflat"] = state["_gviews"] = state["_anchor"] = state["_gpend"] = state["_gpend_full"] = state["_flat_ddp"] = None
+        state["_gflat"] = state["_gviews"] = state["_anchor"] = state["_gpend"] = state["_gpend_full"] = state["_flat_ddp"] = state["_flat_ddp_live"] = None
         state["_param_list"] = None
         state["_checked_batches"] = set()
         return state
@@ -481,7 +482,7 @@ class _MSHGNNBase(nn.Module):
             if need_grad:
                 import torch.distributed as dist
                 if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-                    out = _EngineFnP.apply(e, B, flat, offsets, None if self._flat_ddp is None else (self._flat_ddp, self._flat_ddp_weighted), len(xs), *xs, *params)      # gradients through autograd: DDP's hooks see them
+                    out = _EngineFnP.apply(e, B, flat, offsets, None if self._flat_ddp is None else (self._flat_ddp, self._flat_ddp_weighted, getattr(self, "_flat_ddp_live", None)), len(xs), *xs, *params)      # gradients through autograd: DDP's hooks see them
                 else:
                     out = _EngineFnFast.apply(self._anchor, self, e, B, *xs)
             else:

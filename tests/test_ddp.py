@@ -191,7 +191,7 @@ def test_two_engine_ranks_reproduce_the_global_batch_gradient(dtype):
     assert ret["err"] < 1e-5    # same arithmetic, different summation order over the windows
 
 
-def _wrapper_worker(rank, world, port, B, ret):
+def _wrapper_worker(rank, world, port, B, live_only, ret):
     """Two wrapper ranks on the one GPU of the test box (gloo: its all-reduce takes device tensors through host copies): flat_data_parallel +
     training_step + backward on each rank's shard == the single-process step on the whole batch."""
     import types
@@ -215,7 +215,8 @@ def _wrapper_worker(rank, world, port, B, ret):
     w.model.load_state_dict(params)
     with torch.no_grad():
         w.model(x_dict=dict(mine.x_dict), edge_index_dict=mine.edge_index_dict)      # parameters become views of the flat buffer
-    ddp.flat_data_parallel(w)
+    ddp.flat_data_parallel(w, live_only=live_only)
+    assert (w.model._flat_ddp_live is not None) == live_only
     loss = w.training_step(mine, 0)
     assert w.model._gpend_id == 1                                      # the one-call step ran under torch.distributed
     w.model.zero_grad()
@@ -249,13 +250,13 @@ def _wrapper_worker(rank, world, port, B, ret):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B", [64, 65])      # equal shards, and a ragged split (33 + 32 windows: each rank's gradient is weighted by its window count)
-def test_flat_data_parallel_wrappers_reproduce_the_global_batch_gradient(B):
+@pytest.mark.parametrize("B,live_only", [(64, False), (65, False), (65, True)])      # equal shards; a ragged split (33 + 32 windows: each rank's gradient is weighted by its
+def test_flat_data_parallel_wrappers_reproduce_the_global_batch_gradient(B, live_only):      # window count); the same with only the live elements on the wire
     world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
     port = 33000 + (os.getpid() % 2000)
-    mp.spawn(_wrapper_worker, args=(world, port, B, ret), nprocs=world, join=True)
+    mp.spawn(_wrapper_worker, args=(world, port, B, live_only, ret), nprocs=world, join=True)
     assert ret["params_equal"] and ret["err"] < 1e-5
     assert ret["two_call_0"] < 1e-5 and ret["two_call_1"] < 1e-5
 
