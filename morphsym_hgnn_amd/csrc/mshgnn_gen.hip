@@ -1560,7 +1560,9 @@ static void g_launch_jobs(const mshgnn_plan* p, const Launch& ln, GArgs a, hipSt
     const int mode = g_tile_blocks(a.B, gp.split);      // 0: 4 waves; 1: 8 waves, 128 windows; 2: 8 waves; 3: 16 waves; 6: k_gstep4 (bf16, hidden % 512 == 0; the default from 256 windows)
     // k_gstep5 at 4 waves (256 columns per workgroup, two workgroups per CU) when the launch has more (job, tile) pairs than CUs: half-size workgroups halve the
     // launch's tail (1 032 pairs on 256 CUs: 209 -> 189 us; 1 024: equal; 256 pairs, a single round: 42 -> 46 us, so those keep 8 waves).  Same bits.  (=9 / =8 force one.)
-    if ((mode == 9 || (mode == 8 && !g_forced_tile() && ln.n_jobs * ((a.B + 127) / 128) > p->n_cu)) && !gp.split && gp.NCT % 4 == 0 && ln.all_plain && ln.max_terms <= GS5_MAX_TERMS) {
+    // Widths that are a multiple of 256 but not of 512 (hidden = 256, 768: the reference's --hidden_size) only have the 4-wave form.
+    const bool half_only = gp.NCT % 4 != 0;
+    if ((mode == 9 || (mode == 8 && !g_forced_tile() && (half_only || ln.n_jobs * ((a.B + 127) / 128) > p->n_cu))) && !gp.split && gp.NCT % 2 == 0 && ln.all_plain && ln.max_terms <= GS5_MAX_TERMS) {
         a.tiles = (a.B + 127) / 128; a.njt = ln.n_jobs * a.tiles;
         const int nctg = gp.NCT / 2;
         const unsigned grid9 = (unsigned)((a.njt + 7) / 8) * 8 * nctg;

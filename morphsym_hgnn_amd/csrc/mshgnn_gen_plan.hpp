@@ -289,10 +289,10 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
     // a term's / item's source list -> itself, or (more than G_MANY rows) one plain row of the layer's aggregate buffer + the op that fills it
     std::map<std::vector<std::array<int, 4>>, std::array<int, 4>> agg_known;      // (forward aggregates are looked up again by the weight-gradient items)
     int agg_count[2][G_MAX_L] = {};
-    // Wide plans (hidden a multiple of 512, both arithmetics: the pipelined job kernel k_gstep5 wants every term to be ONE plain row): a sum of TWO rows at scale 1 becomes two
+    // Wide plans (hidden a multiple of 512, both arithmetics; of 256 in bf16 arithmetic: the pipelined job kernel k_gstep5 wants every term to be ONE plain row): a sum of TWO rows at scale 1 becomes two
     // terms on the same weights (W (a + b) = W a + W b: one more pass of MFMAs for that term, and the sum is no longer rounded to bf16 before the product), longer
     // sums go through the aggregate buffers from three rows on.  MSHGNN_GEN_SPLIT_SUMS=0 keeps the sums (A/B runs).
-    const bool split_sums = NCT % 4 == 0 && []() { const char* e = std::getenv("MSHGNN_GEN_SPLIT_SUMS"); return !(e && std::atoi(e) == 0); }();
+    const bool split_sums = (NCT % 4 == 0 || (!p.split && NCT % 2 == 0)) && []() { const char* e = std::getenv("MSHGNN_GEN_SPLIT_SUMS"); return !(e && std::atoi(e) == 0); }();
     const int g_many = [&]() { const char* e = std::getenv("MSHGNN_GEN_MANY"); return e ? std::max(2, std::atoi(e)) : (split_sums ? 2 : G_MANY); }();      // (threshold override, read when the plan is compiled: tests, measurements)
     int n_split_terms = 0;
     auto push_term = [&](std::vector<TermDef>& tds, const TermDef& td) {
