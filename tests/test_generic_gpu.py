@@ -129,6 +129,27 @@ def test_configs4_bench_arithmetic_is_within_bf16_distance_of_the_oracle():
     assert not bad, bad
 
 
+@pytest.mark.parametrize("hidden,kind", [(256, "c2"), (768, "mi"), (1024, "mi")])
+def test_pipelined_job_kernel_at_other_widths_is_within_bf16_distance_of_the_oracle(hidden, kind):
+    """The widths beside 512 that the pipelined job kernel serves, at a batch that takes it (300 windows: two full 128-window tiles and a ragged one): hidden 256
+    (A1-C2 with its residual and base_transform: one 256-column group, the 4-wave form only), 768 (three column groups) and 1024 (two 512-column groups / four of
+    256) -- bf16 arithmetic against the fp64 oracle evaluated with the engine's relu decisions, 3e-2 as on the configs[4] case."""
+    from morphsym_hgnn_amd import synth, topology
+    from morphsym_hgnn_amd.spec import ModelSpec
+    if kind == "c2":
+        spec = helpers.make_spec("c2", "a1-c2", "a1-c2", hidden, 2)
+    else:
+        spec = ModelSpec(kind="mi", topology=topology.synthetic_limbs(3), hidden=hidden, num_layers=2, widths={"base": 24, "joint": 9, "foot": 5}, regression=True,
+                         grf_dimension=1, group=None, num_timesteps=3)
+    B = 300
+    n_y = spec.out_channels * spec.num_nodes[spec.out_type]
+    x_dict, y = synth.make_windows(53, B, spec.num_nodes, spec.widths, n_y)
+    params = synth.make_params(53, spec.param_shapes())
+    errs, *_ = helpers.run_engine_case(spec, x_dict, y, params, spec.topology.edge_index_dict(B), B, dtype="bf16", decision_tol=3e-2)
+    bad = {k: v for k, v in errs.items() if v > 3e-2}
+    assert not bad, bad
+
+
 @pytest.mark.parametrize("seed,nb,nj,nf,hidden,layers", [(1, 1, 7, 3, 128, 3), (2, 2, 15, 5, 128, 2), (3, 3, 30, 9, 256, 3), (4, 1, 5, 2, 128, 4),
                                                         (5, 2, 9, 3, 512, 2), (7, 1, 4, 2, 1024, 2)])      # (seed 6 at 1024: a one-element decoder-bias gradient that cancels to 2e-4 of its terms -- 1.1e-4 on it, 4e-5 elsewhere)
 def test_random_topologies_match_the_oracle(seed, nb, nj, nf, hidden, layers):
