@@ -522,7 +522,10 @@ constexpr int GS5_MAX_TERMS = 16, GS5_TERM_BYTES = 32;      // k_gstep5's term t
 constexpr int gs5_lds_bytes(bool split, int mb) { return 2 * (split ? 2 : 1) * mb * P16::BLK + GS5_MAX_TERMS * GS5_TERM_BYTES; }
 // SPLIT (the split-bf16 arithmetic of section 4b: rows [hi Hd | lo Hd], three products per term, hi x hi, lo-weights x hi, hi-weights x lo) runs it on 96-window tiles
 // (MB = GS5_MB_SPLIT = 6): twice the planes in the weight ring, the rows in flight and the window fragments.
-template <bool SPLIT, int MB, bool MASKED, int NW = 8> __global__ __launch_bounds__(64 * NW, 2) void k_gstep5(GArgs a) {      // MASKED: some term of the launch carries relu bits (the backward sweeps: dH = dX . relu bits)
+// RAW (bf16 arithmetic): every term is one RAW INPUT row of the caller's tensors (the encoder launch) -- its own row stride, its own number of K chunks, whole 16-byte
+// chunks inside the row pitch only, columns past the feature width zeroed and the symmetry signs applied as the row is staged.
+template <bool SPLIT, int MB, bool MASKED, int NW = 8, bool RAW = false> __global__ __launch_bounds__(64 * NW, 2) void k_gstep5(GArgs a) {
+    static_assert(!RAW || (!SPLIT && !MASKED), "raw-input launches: bf16 arithmetic, no relu bits");      // MASKED: some term of the launch carries relu bits (the backward sweeps: dH = dX . relu bits)
     using P = P16;
     constexpr int NS = 2, PL = SPLIT ? 2 : 1;            // NW waves (8: one workgroup per CU and two waves per SIMD in step; 4: 256 columns per workgroup, TWO workgroups per CU, one wave per SIMD each, out of step)
     //            // 8 waves, each NS 32-column slices (64 columns) of the 512: two waves per SIMD, up to 256 registers; PL planes
@@ -559,10 +562,17 @@ template <bool SPLIT, int MB, bool MASKED, int NW = 8> __global__ __launch_bound
         const int* term = a.terms + (size_t)(job[J_TERM0] + tid) * TERM_INTS;
         const int* src = a.srcs + (size_t)term[T_SRC0] * SRC_INTS;
         const int node = src[S_NODE], mbuf = src[S_MASK];
+        if constexpr (RAW) {      // {row 0 of the node, row stride in bytes, feature width | pack, K chunks, pitch in elements, first sign byte}
+            const int t = src[S_BUF];
+            const uint64_t base = reinterpret_cast<uint64_t>(a.x[t]) + (uint64_t)node * (uint64_t)a.pitch[t] * 2;
+            *reinterpret_cast<u32x4*>(ttab + tid * GS5_TERM_BYTES) = u32x4{(unsigned)base, (unsigned)(base >> 32), (unsigned)(a.nodes[t] * a.pitch[t] * 2), (unsigned)term[T_WIDTH]};
+            *reinterpret_cast<u32x4*>(ttab + tid * GS5_TERM_BYTES + 16) = u32x4{(unsigned)term[T_PACK], (unsigned)term[T_NKC], (unsigned)a.pitch[t], (unsigned)term[T_SIGN]};
+        } else {
         const uint64_t base = reinterpret_cast<uint64_t>(a.ws + a.buf_off[src[S_BUF]]) + g_row<SPLIT>(0, node, B, Hd) * 2;
         const uint64_t mb = reinterpret_cast<uint64_t>(a.ws + a.buf_off[mbuf >= 0 ? mbuf : 0]) + g_relu_byte(node, B, Hd, 0, 0);      // (no relu bits: any mapped address; the bytes are requested and ignored)
         *reinterpret_cast<u32x4*>(ttab + tid * GS5_TERM_BYTES) = u32x4{(unsigned)base, (unsigned)(base >> 32), (unsigned)mb, (unsigned)(mb >> 32)};
         *reinterpret_cast<u32x2*>(ttab + tid * GS5_TERM_BYTES + 16) = u32x2{(unsigned)term[T_PACK], mbuf >= 0 ? 1u : 0u};
+        }
     }
 
     P::Acc acc[NS][MB];
@@ -579,18 +589,40 @@ template <bool SPLIT, int MB, bool MASKED, int NW = 8> __global__ __launch_bound
     const unsigned woff = ((unsigned)wv0 * P::NBV * 64 + lane) * 16;      // + pack * (H * H * 2) + slice * 8192 + vector * 1024
     // Per-thread offsets (32 bits, added to uniform bases) are RECOMPUTED per chunk from the lane index, a dozen VALU operations against 128 MFMAs: kept live across
     // the loop they -- not the rows in flight -- were what hipcc spilled, and every scratch reload waits for ALL outstanding requests (scratch shares vmcnt).
-    struct Cur { int ti, kc, pack; bool msk; gchar* base; gchar* mb; };      // the chunk stream: (term, K chunk) in order
+    struct Cur { int ti, kc, pack; bool msk; gchar* base; gchar* mb; int nkc, stride, F, pitchc, sign; };      // the chunk stream: (term, K chunk) in order (nkc .. sign: raw-input terms)
     auto open_term = [&](Cur& q) {
         const u32x4 e = *reinterpret_cast<const u32x4*>(ttab + q.ti * GS5_TERM_BYTES);
-        const u32x2 f = *reinterpret_cast<const u32x2*>(ttab + q.ti * GS5_TERM_BYTES + 16);
         const uint64_t b = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)e[1]) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)e[0]);
-        const uint64_t m = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)e[3]) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)e[2]);
-        q.base = reinterpret_cast<gchar*>(b); q.mb = reinterpret_cast<gchar*>(m);
-        q.pack = __builtin_amdgcn_readfirstlane((int)f[0]); q.msk = __builtin_amdgcn_readfirstlane((int)f[1]) != 0;
+        q.base = reinterpret_cast<gchar*>(b);
+        if constexpr (RAW) {
+            const u32x4 f = *reinterpret_cast<const u32x4*>(ttab + q.ti * GS5_TERM_BYTES + 16);
+            q.stride = __builtin_amdgcn_readfirstlane((int)e[2]); q.F = __builtin_amdgcn_readfirstlane((int)e[3]);
+            q.pack = __builtin_amdgcn_readfirstlane((int)f[0]); q.nkc = __builtin_amdgcn_readfirstlane((int)f[1]);
+            q.pitchc = __builtin_amdgcn_readfirstlane((int)f[2]); q.sign = __builtin_amdgcn_readfirstlane((int)f[3]);
+            q.msk = false; q.mb = nullptr;
+        } else {
+            const u32x2 f = *reinterpret_cast<const u32x2*>(ttab + q.ti * GS5_TERM_BYTES + 16);
+            const uint64_t m = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)e[3]) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)e[2]);
+            q.mb = reinterpret_cast<gchar*>(m);
+            q.pack = __builtin_amdgcn_readfirstlane((int)f[0]); q.msk = __builtin_amdgcn_readfirstlane((int)f[1]) != 0;
+            q.nkc = NCT;      // (every term of an all-plain launch has NCT chunks)
+        }
     };
-    auto advance = [&](Cur& q) { if (++q.kc == NCT) { q.kc = 0; ++q.ti; open_term(q); } };      // (every term of an all-plain launch has NCT chunks)
-    u32x4 rv[PL][NPASS]; unsigned rm[MASKED ? NPASS : 1];
+    auto advance = [&](Cur& q) { if (++q.kc == q.nkc) { q.kc = 0; ++q.ti; open_term(q); } };
+    u32x4 rv[PL][NPASS]; unsigned rm[MASKED ? NPASS : 1]; u32x2 rs;      // rs: the chunk's eight sign bytes (RAW)
     auto fetch = [&](const Cur& q) {      // request the rows of a chunk: thread = (window rr + 4 NW i of the tile, 16-byte chunk c); rows past the batch re-read the last window
+        if constexpr (RAW) {
+            const int tt = wq * 64 + lane_now(), c = tt & 15, rr = tt >> 4;
+            const int col = q.kc * TW + c * 8;
+            const unsigned coff = (col + 8 <= q.pitchc) ? (unsigned)(col * 2) : 0u;      // a chunk that is not wholly inside the row pitch is not requested: it re-reads the row's first chunk and is zeroed as it is staged (no branch)
+            rs = *reinterpret_cast<const u32x2 __attribute__((address_space(1)))*>(uniform_ptr(reinterpret_cast<const char*>(a.signs) + q.sign + q.kc * TW) + (unsigned)(c * 8));
+#pragma unroll
+            for (int i = 0; i < NPASS; ++i) {
+                const unsigned w = (unsigned)min(w0 + i * (4 * NW) + rr, B - 1);
+                rv[0][i] = gload16(q.base, w * (unsigned)q.stride + coff);
+            }
+            return;
+        }
         gchar* rb = q.base + q.kc * (TW * 2);
         gchar* mb = q.mb + (((size_t)(q.kc * 4) * nb16) << 6);
         const int tt = wq * 64 + lane_now(), c = tt & 15, rr = tt >> 4;
@@ -607,6 +639,14 @@ template <bool SPLIT, int MB, bool MASKED, int NW = 8> __global__ __launch_bound
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
             const int grow = i * (4 * NW) + rr;
+            if constexpr (RAW) {      // columns past the feature width (and chunks outside the pitch: nv <= 0) zeroed, symmetry signs applied
+                const int nv = q.F - (q.kc * TW + c * 8);
+                const unsigned w0s = rs[0], w1s = rs[1];
+                const u32x4 sx = u32x4{((w0s & 1u) << 15) | (((w0s >> 8) & 1u) << 31), (((w0s >> 16) & 1u) << 15) | (((w0s >> 24) & 1u) << 31),
+                                       ((w1s & 1u) << 15) | (((w1s >> 8) & 1u) << 31), (((w1s >> 16) & 1u) << 15) | (((w1s >> 24) & 1u) << 31)};
+                *reinterpret_cast<u32x4*>(set + lds_chunk<T16>(grow >> 4, grow & 15, c)) = chunk_keep_first<T16>(rv[0][i], nv) ^ sx;
+                continue;
+            }
             const unsigned bits = MASKED ? (q.msk ? rm[i] : 0xffu) : 0xffu;
 #pragma unroll
             for (int pl = 0; pl < PL; ++pl)
@@ -654,10 +694,11 @@ template <bool SPLIT, int MB, bool MASKED, int NW = 8> __global__ __launch_bound
             for (int pl = 0; pl < PL; ++pl) x0[pl] = x1[pl];
         }
     };
-    const int nchunks = nterms * NCT;
+    int nchunks = nterms * NCT;
+    if constexpr (RAW) { nchunks = 0; for (int ti = 0; ti < nterms; ++ti) nchunks += ro_int(a.terms + (size_t)(ro_int(job, J_TERM0) + ti) * TERM_INTS, T_NKC); }
     __syncthreads();      // the term table
     if (nchunks > 0) {
-        Cur nx{0, 0, 0, false, nullptr, nullptr};
+        Cur nx{0, 0, 0, false, nullptr, nullptr, 0, 0, 0, 0, 0};
         open_term(nx);
         fetch(nx);
         const char* wp_cur = wbase + (size_t)(nx.pack + nx.kc * NCT + ct0) * (H * H * 2);
@@ -1386,7 +1427,7 @@ int gen_create(mshgnn_plan* p, const mshgnn_desc* desc) {
     if ((rc = set_lds_attr(k_gdec_bwd<false>, dec_lds)) || (rc = set_lds_attr(k_gdec_bwd<true>, dec_lds)) ||
         (rc = set_lds_attr(k_gstep<true, 8, 8>, 16 * P16::BLK)) || (rc = set_lds_attr(k_ggradw<true, 1>, ggw_lds_bytes(true, 1))) ||
         (rc = set_lds_attr(k_ggradw<true, 2, GGW_NWV_SPLIT2>, ggw_lds_bytes(true, 2))) || (rc = set_lds_attr(k_ggradw<true, 2, GGW_NWV_SPLIT2, true>, ggw_lds_bytes(true, 2, true))) ||
-        (rc = set_lds_attr(k_ggradw<true, 1, 8, true>, ggw_lds_bytes(true, 1, true))) || (rc = set_lds_attr(k_ggradw<false, 2, GGW_NWV_BF16, true>, ggw_lds_bytes(false, 2, true))) || (rc = set_lds_attr(k_ggradw<false, 2, GGW_NWV_BF16>, ggw_lds_bytes(false, 2))) || (rc = set_lds_attr(k_gstep5<false, 8, true>, gs5_lds_bytes(false, 8))) || (rc = set_lds_attr(k_gstep5<false, 8, true, 4>, gs5_lds_bytes(false, 8))) || (rc = set_lds_attr(k_gstep5<false, 8, false, 4>, gs5_lds_bytes(false, 8))) || (rc = set_lds_attr(k_gstep5<false, 8, false>, gs5_lds_bytes(false, 8))) ||
+        (rc = set_lds_attr(k_ggradw<true, 1, 8, true>, ggw_lds_bytes(true, 1, true))) || (rc = set_lds_attr(k_ggradw<false, 2, GGW_NWV_BF16, true>, ggw_lds_bytes(false, 2, true))) || (rc = set_lds_attr(k_ggradw<false, 2, GGW_NWV_BF16>, ggw_lds_bytes(false, 2))) || (rc = set_lds_attr(k_gstep5<false, 8, true>, gs5_lds_bytes(false, 8))) || (rc = set_lds_attr(k_gstep5<false, 8, false, 4, true>, gs5_lds_bytes(false, 8))) || (rc = set_lds_attr(k_gstep5<false, 8, false, 8, true>, gs5_lds_bytes(false, 8))) || (rc = set_lds_attr(k_gstep5<false, 8, true, 4>, gs5_lds_bytes(false, 8))) || (rc = set_lds_attr(k_gstep5<false, 8, false, 4>, gs5_lds_bytes(false, 8))) || (rc = set_lds_attr(k_gstep5<false, 8, false>, gs5_lds_bytes(false, 8))) ||
         (rc = set_lds_attr(k_gstep5<true, GS5_MB_SPLIT, true>, gs5_lds_bytes(true, GS5_MB_SPLIT))) || (rc = set_lds_attr(k_gstep5<true, GS5_MB_SPLIT, false>, gs5_lds_bytes(true, GS5_MB_SPLIT)))) return rc;
     return MSHGNN_OK;
 }
@@ -1514,6 +1555,13 @@ static int g_fill(const mshgnn_plan* p, const mshgnn_ws_layout& lay, const void*
     return MSHGNN_OK;
 }
 
+static bool g_raw_ok(const GenPlan& gp, const GArgs& a) {
+    static const bool off = []() { const char* e = getenv("MSHGNN_GEN_RAW5"); return e && atoi(e) == 0; }();      // (=0: the raw-input launch stays on k_gstep4)
+    if (off) return false;
+    for (int t = 0; t < gp.NT; ++t)
+        if (a.vb[t] < 16 || (a.pitch[t] & 7) != 0 || (uint64_t)a.B * (uint64_t)a.nodes[t] * (uint64_t)a.pitch[t] * 2 >= (1ull << 32)) return false;
+    return true;
+}
 static bool g_forced_tile() { const char* e = getenv("MSHGNN_GEN_TILE"); return e && atoi(e) >= 0; }
 static int g_tile_blocks(int B, bool split) {
     const char* e = getenv("MSHGNN_GEN_TILE");      // (kernel experiments; read per launch so that a test can compare modes in one process)
@@ -1560,6 +1608,16 @@ static void g_launch_jobs(const mshgnn_plan* p, const Launch& ln, GArgs a, hipSt
     const int mode = g_tile_blocks(a.B, gp.split);      // 0: 4 waves; 1: 8 waves, 128 windows; 2: 8 waves; 3: 16 waves; 6: k_gstep4 (bf16, hidden % 512 == 0; the default from 256 windows)
     // k_gstep5 at 4 waves (256 columns per workgroup, two workgroups per CU) when the launch has more (job, tile) pairs than CUs: half-size workgroups halve the
     // launch's tail (1 032 pairs on 256 CUs: 209 -> 189 us; 1 024: equal; 256 pairs, a single round: 42 -> 46 us, so those keep 8 waves).  Same bits.  (=9 / =8 force one.)
+    // The raw-input (encoder) launch on k_gstep5<RAW>: bf16 arithmetic, every input tensor 16-byte aligned with a pitch of whole chunks, row offsets inside 32 bits
+    if ((mode == 8 || mode == 9) && !gp.split && gp.NCT % 2 == 0 && ln.all_raw && g_raw_ok(gp, a)) {
+        a.tiles = (a.B + 127) / 128; a.njt = ln.n_jobs * a.tiles;
+        ProfScope ps(p, ln.ks, st);
+        if (gp.NCT % 4 != 0 || mode == 9 || (!g_forced_tile() && a.njt > p->n_cu)) {
+            const int nctg = gp.NCT / 2;
+            hipLaunchKernelGGL((k_gstep5<false, 8, false, 4, true>), dim3((unsigned)((a.njt + 7) / 8) * 8 * nctg), dim3(256), gs5_lds_bytes(false, 8), st, a);
+        } else hipLaunchKernelGGL((k_gstep5<false, 8, false, 8, true>), dim3((unsigned)a.njt * (a.NCT / 4)), dim3(512), gs5_lds_bytes(false, 8), st, a);
+        return;
+    }
     // Widths that are a multiple of 256 but not of 512 (hidden = 256, 768: the reference's --hidden_size) only have the 4-wave form.
     const bool half_only = gp.NCT % 4 != 0;
     if ((mode == 9 || (mode == 8 && !g_forced_tile() && (half_only || ln.n_jobs * ((a.B + 127) / 128) > p->n_cu))) && !gp.split && gp.NCT % 2 == 0 && ln.all_plain && ln.max_terms <= GS5_MAX_TERMS) {

@@ -48,7 +48,7 @@ constexpr int G_MANY = 32;
 enum { AG_OUT_BUF = 0, AG_OUT_NODE, AG_SRC0, AG_NSRC, AGG_INTS = 4 };
 constexpr int G_ITEMS_PER_UNIT = 8;     // items one weight-gradient workgroup sweeps (more units = more parallelism, more slabs to sum)
 
-struct Launch { int job0, n_jobs, ks; int agg0 = 0, n_agg = 0; bool all_plain = false, any_mask = false; int max_terms = 0; };      // agg0 / n_agg: the aggregates computed in front of the launch; all_plain: every term of every job is ONE activation row at scale 1 (k_gstep5's precondition)
+struct Launch { int job0, n_jobs, ks; int agg0 = 0, n_agg = 0; bool all_plain = false, any_mask = false, all_raw = false; int max_terms = 0; };      // all_raw: every term of every job is ONE raw input row (the encoder launch)      // agg0 / n_agg: the aggregates computed in front of the launch; all_plain: every term of every job is ONE activation row at scale 1 (k_gstep5's precondition)
 
 struct GenPlan {
     mshgnn_desc d{};
@@ -281,6 +281,15 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
                     const int32_t* tm = &terms[(size_t)ti * TERM_INTS];
                     if (tm[T_NSRC] >= 1 && srcs[(size_t)tm[T_SRC0] * SRC_INTS + S_MASK] >= 0) ln.any_mask = true;
                     if (tm[T_KIND] != 0 || tm[T_NSRC] != 1 || srcs[(size_t)tm[T_SRC0] * SRC_INTS + S_SCALE] != fbits(1.0f) || tm[T_NKC] != NCT) { ln.all_plain = false; break; }
+                }
+            }
+            ln.all_raw = true;
+            for (int j = j0; j < j0 + n && ln.all_raw; ++j) {
+                const int32_t* jb = &jobs[(size_t)j * JOB_INTS];
+                if (jb[J_NTERMS] > 16) ln.all_raw = false;
+                for (int ti = jb[J_TERM0]; ti < jb[J_TERM0] + jb[J_NTERMS]; ++ti) {
+                    const int32_t* tm = &terms[(size_t)ti * TERM_INTS];
+                    if (tm[T_KIND] != 1 || tm[T_NSRC] != 1) { ln.all_raw = false; break; }
                 }
             }
             v.push_back(ln);
