@@ -532,6 +532,60 @@ def _end_to_end_routes(res, e, store, flat, gflat, m, v, out, loss, gen, B, ce, 
         res[name] = {"ms_per_step": dt * 1e3, "value": B / dt}
 
 
+def source_hash():
+    """sha1 over the product's sources (kernels, C-ABI, host package, this file): the same value in a bench line and in a committed profile means the
+    profile was taken from exactly the code that produced the line, even when the profile was committed later (a commit cannot name its own hash)."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    files = sorted(glob.glob(os.path.join(ROOT, "morphsym_hgnn_amd", "csrc", "*.h*")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
+                   + glob.glob(os.path.join(ROOT, "morphsym_hgnn_amd", "*.py")) + [os.path.join(ROOT, "bench.py")])
+    for f in files:
+        h.update(os.path.relpath(f, ROOT).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
+
+
+WORKLOAD_TAGS = ("L8", "mck4", "solo", "synth32")
+
+
+def workload_tag(config, B, L, hidden):
+    """Which committed profile set (profiles/<round>_[<tag>_]<dtype>_pmc_traffic.json) belongs to a workload: "" = the headline (A1-C2 L=3, 8192 windows),
+    "L8" = the paper's depth, "mck4" / "solo" / "synth32" = BASELINE configs[2..4] at their default sizes; None = no committed profile."""
+    class A: pass
+    a = A(); a.config, a.batch, a.layers, a.hidden = config, 0, 0, 0
+    if (B, L, hidden) == defaults(a):
+        return "" if config == "a1c2" else config
+    if config == "a1c2" and (B, L, hidden) == (8192, 8, 128):
+        return "L8"
+    return None
+
+
+def committed_traffic(tag, dtype, kernel):
+    """(HBM bytes per launch of `kernel`, source file + commit) from the newest committed PMC traffic file of that workload and plan, or None."""
+    if tag is None or dtype not in ("bf16", "x3"):
+        return None
+    try:
+        import glob
+        files = []
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{dtype}_pmc_traffic.json"))):
+            name = os.path.basename(f)
+            has = [t for t in WORKLOAD_TAGS if f"_{t}_" in name]
+            if (has == [tag]) if tag else not has:
+                files.append(f)
+        if not files:
+            return None
+        meta = json.load(open(files[-1]))
+        if kernel not in meta["kernels"]:
+            return None
+        src = os.path.basename(files[-1]) + (f" (commit {meta['commit']})" if "commit" in meta else "")
+        if "source_hash" in meta:
+            src += f" (source_hash {meta['source_hash']}: {'same sources as this line' if meta['source_hash'] == source_hash() else 'OTHER sources than this line'})"
+        return meta["kernels"][kernel]["hbm_bytes"], src
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def roofline_of(stats, steps, B, dtype, e, config, L, hidden):
     """`roofline` of the dominant kernel of a step.  Top-level achieved / frac price the launch with SURVEY.md 8(d)'s ALGORITHMIC work only:
     HBM-bound kernels by the raw-input bytes they must read (+ the flat gradient written once for the weight-gradient kernel), MFMA-bound kernels
@@ -564,19 +618,10 @@ def roofline_of(stats, steps, B, dtype, e, config, L, hidden):
             roof["priced_by"] = "the launch's own operand stream (raw inputs are < 5 % of it)"
     # HBM-side traffic per launch of that kernel, from the committed rocprofv3 PMC passes (separate FETCH_SIZE /
     # WRITE_SIZE runs of this same command, gfx950 corrections applied -- tools/summarize_pmc.py); null if absent
-    try:
-        import glob
-        files = [f for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{dtype}_pmc_traffic.json")))
-                 if not any(t in os.path.basename(f) for t in ("mck4", "synth32", "solo"))]
-        if files and dtype in ("bf16", "x3") and config == "a1c2" and B == 8192 and L == 3 and hidden == 128:
-            pm = json.load(open(files[-1]))["kernels"]
-            key = dom["name"].rstrip("0123456789")
-            if key in pm:
-                roof["traffic"] = pm[key]["hbm_bytes"] / per_step
-                meta = json.load(open(files[-1]))
-                roof["traffic_source"] = os.path.basename(files[-1]) + (f" (commit {meta['commit']})" if "commit" in meta else "")
-    except Exception:  # noqa: BLE001
-        pass
+    tr = committed_traffic(workload_tag(config, B, L, hidden), dtype, dom["name"].rstrip("0123456789"))
+    if tr is not None:
+        roof["traffic"] = tr[0] / per_step
+        roof["traffic_source"] = tr[1]
     roof["kernel"] = dom["name"]
     roof["launches_per_step"] = per_step
     roof["avg_us"] = avg_s * 1e6
@@ -607,7 +652,9 @@ def side_config(config, device, steps, warmup, min_time=0.25):
         stats = w.kernel_stats(st)
         entry["kernel_us"] = {s["name"]: round(s["total_ms"] / s["launches"] * 1e3, 2) for s in stats}
         r = roofline_of(stats, st, B, plan, w.e, config, L, hidden)
-        entry["dominant"] = {k: r[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_us", "share_of_step")}
+        entry["dominant"] = {k: r[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_us", "share_of_step", "traffic")}
+        if "traffic_source" in r:
+            entry["dominant"]["traffic_source"] = r["traffic_source"]
         if "priced_by" in r:
             entry["dominant"]["priced_by"] = r["priced_by"]
         if "operands" in r:      # (HBM-bound kernel: `frac` prices the raw-input bytes only -- SURVEY 8(d); its own operand stream is reported beside it)
@@ -758,9 +805,19 @@ def main():
         if L != 8:      # the paper's depth (train_regression-grf_msgn.py:94)
             w8 = Workload(build_spec(8, args.config, hidden), args.dtype, B, device, 1234)
             m8, _ = w8.time_blocks(args.steps, args.warmup, args.min_time / 2)
+            st8 = w8.kernel_stats(args.steps)
+            r8 = roofline_of(st8, args.steps, B, args.dtype, w8.e, args.config, 8, hidden)
+            s8 = m8 / args.steps
+            f8 = (w8.e.info.flops_fwd + w8.e.info.flops_bwd) * B
+            b8 = 2.0 * float(w8.e.info.bytes_in_live) * B
+            r8["step_live"] = {"algorithmic_bytes": b8, "hbm_frac": b8 / s8 / 1e9 / PEAK["hbm_GBs"], "algorithmic_flops": f8,
+                               "mfma_frac": f8 / s8 / 1e12 / PEAK["mfma_TFLOPs"][args.dtype]}
+            res["L8"] = {"ms_per_step": s8 * 1e3, "value": B / s8, "dtype": args.dtype,
+                         "workload": "A1-C2 GRF regression at the paper's depth (train_regression-grf_msgn.py:94), h=128, L=8, 8192 windows",
+                         "kernel_us": {s_["name"]: round(s_["total_ms"] / s_["launches"] * 1e3, 2) for s_ in st8}, "roofline": r8,
+                         "algorithmic_flops_per_window": w8.e.info.flops_fwd + w8.e.info.flops_bwd}
             del w8
             torch.cuda.empty_cache()
-            res["L8"] = {"ms_per_step": m8 / args.steps * 1e3, "value": B * args.steps / m8, "dtype": args.dtype}
         if args.dtype == "bf16" and L == 3 and B == 8192:      # the other BASELINE configs, driver-visible
             res["configs"] = {c: side_config(c, device, args.steps, args.warmup) for c in ("mck4", "solo", "synth32")}
     if args.surface == "module" and rank == 0 and world == 1:
@@ -771,6 +828,7 @@ def main():
     cfile = os.path.join(ROOT, ".build_commit")      # (tools/profile_round.sh runs: the commit the snapshot was taken at)
     if os.path.exists(cfile):
         res["commit"] = open(cfile).read().strip()
+    res["source_hash"] = source_hash()
     if dist is not None:
         dist.destroy_process_group()
     sys.stdout.flush()

@@ -1193,7 +1193,7 @@ int x3_forward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitc
             a.nodes[t] = 0;
             for (int i = 0; i < d.type_nodes[t]; ++i) {
                 const bool need = hp.need_n[0][hp.type_base[t] + i];
-                if (need || series != nullptr) a.node_list[a.node_off[t] + a.nodes[t]++] = (unsigned char)i;
+                if (need || (series != nullptr && x != nullptr)) a.node_list[a.node_off[t] + a.nodes[t]++] = (unsigned char)i;
                 if (!need) a.skip_mask |= 1ull << (hp.type_base[t] + i);
             }
             a.wg_prefix[t + 1] = a.wg_prefix[t] + a.nodes[t] * a.tiles;

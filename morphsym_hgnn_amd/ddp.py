@@ -82,7 +82,7 @@ class LiveGradientExchange:
         return flat_grad
 
 
-def exchange_flat_gradient_(buf: torch.Tensor, n_flat: int, local_windows: int, group=None, weight_by_windows: bool = True, live=None) -> torch.Tensor:
+def exchange_flat_gradient_(buf: torch.Tensor, n_flat: int, local_windows: int, group=None, weight_by_windows: bool = False, live=None) -> torch.Tensor:
     """The ONE exchange of a `flat_data_parallel` step, in place on `buf` (fp32, >= n_flat + 1 elements: the flat gradient of this rank's LOCAL mean
     loss followed by one spare element).  weight_by_windows: the gradient is multiplied by this rank's window count, the count rides in the spare
     element, ONE sum-all-reduce moves both, and the returned divisor (a 0-dim tensor on buf's device, no host sync) is the global window count --
@@ -90,8 +90,21 @@ def exchange_flat_gradient_(buf: torch.Tensor, n_flat: int, local_windows: int, 
     on the host).  Otherwise: plain sum, divisor = world size (torch DDP's mean of the ranks' means, gnnLightning.py:1396-1400)."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
+    if live is not None and len(live) > 2 and not live[2].get("checked"):
+        # first exchange: the live-element route is exact only if the engine really wrote zeros everywhere else (the Python liveness mirror and the
+        # plan compiler agree, MSHGNN_PRUNE was the same when both were read) -- one host sync, once; otherwise fall back to the full exchange
+        live[2]["checked"] = True
+        dead = torch.ones(n_flat, dtype=torch.bool, device=buf.device)
+        dead[live[0][live[0] < n_flat]] = False
+        if bool(dead.any()) and float(buf[:n_flat][dead].abs().max()) != 0.0:
+            import warnings
+            warnings.warn("flat_data_parallel(live_only=True): the engine's gradient is not zero outside spec.live_gradient_index() "
+                          "(liveness mirror and plan disagree) -- exchanging the full buffer instead")
+            live[2]["disabled"] = True
+    if live is not None and len(live) > 2 and live[2].get("disabled"):
+        live = None
     if live is not None:      # (flat_data_parallel(live_only=True)) the same exchange on the packed live elements [+ the count]: exact, the dead elements are zeros on every rank
-        idx, packed = live
+        idx, packed = live[:2]
         torch.index_select(buf, 0, idx, out=packed)
         if weight_by_windows:
             packed.mul_(float(local_windows))
@@ -110,15 +123,16 @@ def exchange_flat_gradient_(buf: torch.Tensor, n_flat: int, local_windows: int, 
     return buf[n_flat].clone()
 
 
-def flat_data_parallel(module, group=None, weight_by_windows: bool = True, live_only: bool = False):
+def flat_data_parallel(module, group=None, weight_by_windows: bool = False, live_only: bool = False):
     """Data parallelism for a training-step wrapper (wrappers.py) or a model (models.py) WITHOUT torch's DistributedDataParallel: the
     parameters (views of one flat buffer) are broadcast from rank 0 once, and from then on the fused training step
     (`training_step` -> `models.fused_training_step[_windows]`) sum-all-reduces its flat gradient in `loss.backward()` and divides by the
-    world size -- the mean over ranks DDP / Lightning-DDP produce (gnnLightning.py:1396-1400), as ONE exchange of 4 MB instead of ~50
-    per-parameter buckets and autograd hooks.  Every rank feeds its own shard of the global batch; with `weight_by_windows` (the default) each
-    rank's gradient is weighted by its window count and the sum divided by the global count (`exchange_flat_gradient_`: the counts ride in the
-    same all-reduce), so ragged shards -- the last batch of an epoch -- still give the gradient of the global mean loss; False reproduces torch DDP's
-    mean over the ranks' means.  The two-call route (`forward` + `loss.backward()`: `fused_training_step = False`, a frozen parameter, a
+    world size -- the mean over the ranks' mean-loss gradients that DDP / Lightning-DDP produce (gnnLightning.py:1396-1400; the default, so a
+    multi-GPU run of the reference and one through this function exchange the same gradient, ragged last batch included), as ONE exchange of 4 MB
+    instead of ~50 per-parameter buckets and autograd hooks.  Every rank feeds its own shard of the global batch.  `weight_by_windows=True` is the
+    opt-in deviation from the reference: each rank's gradient is weighted by its window count and the sum divided by the global count
+    (`exchange_flat_gradient_`: the counts ride in the same all-reduce), so ragged shards -- the last batch of an epoch with drop_last=False --
+    give the gradient of the GLOBAL mean loss instead of the mean of the ranks' means.  The two-call route (`forward` + `loss.backward()`: `fused_training_step = False`, a frozen parameter, a
     normalising WindowBatch) makes the same single exchange in the engine's backward.  Only the fused engine has that hook: a model that runs
     operator by operator (an activation other than ReLU, a hidden width that is not a multiple of 128) is rejected here -- wrap that one in
     torch's DistributedDataParallel.  The model must have seen its lazy-initialising forward and live on the device; do not also wrap it
@@ -145,5 +159,5 @@ def flat_data_parallel(module, group=None, weight_by_windows: bool = True, live_
         idx = model._spec.live_gradient_index().to(flat.device)
         if weight_by_windows:
             idx = torch.cat([idx, torch.tensor([flat.numel()], dtype=torch.int64, device=flat.device)])
-        model._flat_ddp_live = (idx, torch.empty(idx.numel(), dtype=torch.float32, device=flat.device))
+        model._flat_ddp_live = (idx, torch.empty(idx.numel(), dtype=torch.float32, device=flat.device), {"checked": False})
     return module

@@ -248,6 +248,14 @@ def row_pitch(width: int, elem_bytes: int) -> int:
     return (width + q - 1) // q * q
 
 
+def accepted_pitches(width: int, elem_bytes: int):
+    """The row pitches (elements) a device tensor of an input type may arrive at: the reference's dense width, the engine's own pitch (`row_pitch`)
+    and the plain 16-byte-rounded width (what `MSHGNN_ROW_ALIGN=16` / the on-device window assembly of round 2 produced).  Anything else --
+    e.g. a tensor with a few MORE real feature columns than the model was built for -- is a shape error, not padding."""
+    q = 16 // elem_bytes
+    return {width, row_pitch(width, elem_bytes), (width + q - 1) // q * q}
+
+
 def compile_plan_host(spec: ModelSpec, dtype: str = "f32") -> MshgnnInfo:
     """Run the plan compiler only (no GPU needed) and return its work/traffic summary."""
     lib = load_library()
@@ -353,15 +361,14 @@ class Engine:
             x = x_dict[t]
             F = self.spec.widths[t]
             P = self.padded_width(t) if pad else F
-            q16 = 8 if self.dtype == "bf16" else 4
-            if x.is_cuda and x.device == self.device and x.dtype == self.torch_dtype and x.is_contiguous() and x.dim() == 2 and (
-                    x.shape[1] in (F, P) or (x.shape[1] > F and x.shape[1] % q16 == 0)):
+            if x.is_cuda and x.device == self.device and x.dtype == self.torch_dtype and x.is_contiguous() and x.dim() == 2 and x.shape[1] in accepted_pitches(F, x.element_size()):
                 out.append(x)          # already what the kernels read (an unpadded width takes their element-wise loaders): no copy
             elif P == F:
                 out.append(x.to(device=self.device, dtype=self.torch_dtype).contiguous())
             else:
-                buf = torch.empty(x.shape[0], P, dtype=self.torch_dtype, device=self.device)      # pad columns are never read as data
+                buf = torch.empty(x.shape[0], P, dtype=self.torch_dtype, device=self.device)
                 buf[:, :F].copy_(x, non_blocking=True)       # one fused cast + re-pitch kernel (host tensors: plus the PCIe copy)
+                buf[:, F:].zero_()                           # pad columns: never read as data by the kernels, and never NaN for a future reader
                 out.append(buf)
         return out
 

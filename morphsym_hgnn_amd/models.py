@@ -20,6 +20,7 @@ from torch import nn
 
 from . import nn as pnn
 from .spec import ModelSpec, rel_key
+from .engine import accepted_pitches
 from .topology import NODE_TYPES, RobotTopology, infer_window_edges
 
 
@@ -221,7 +222,7 @@ class _MSHGNNBase(nn.Module):
         self._gpend = None               # the flat gradient a fused training step computed, until its backward() delivers it
         self._gpend_id = 0
         self._flat_ddp = None            # ddp.flat_data_parallel: the process group the fused training step all-reduces its flat gradient over
-        self._flat_ddp_weighted = True   # ... with each rank's gradient weighted by its window count (ragged shards)
+        self._flat_ddp_weighted = False  # ... True: each rank's gradient weighted by its window count (opt-in; the default is DDP's mean of the ranks' means)
         self._flat_ddp_live = None       # ... over the live elements only (flat_data_parallel(live_only=True)): (index, packed buffer)
         self._gpend_full = None
         self._gviews = None
@@ -370,8 +371,7 @@ class _MSHGNNBase(nn.Module):
         spec = self._spec
         B, nn_ = self._num_nodes(x_dict)
         def _pitch_ok(x, F):     # the reference's width, or rows already at an engine pitch (on-device window assembly): whole 16-byte chunks >= F
-            q = {torch.bfloat16: 8, torch.float32: 4}.get(x.dtype)
-            return x.shape[1] == F or (q is not None and x.shape[1] > F and x.shape[1] % q == 0 and x.shape[1] < F + 128 // (16 // q))
+            return x.shape[1] == F or (x.dtype in (torch.bfloat16, torch.float32) and x.shape[1] in accepted_pitches(F, x.element_size()))
         for t in self._node_types:
             if nn_[t] != spec.num_nodes[t] or not _pitch_ok(x_dict[t], spec.widths[t]):
                 raise ValueError(f"x_dict['{t}'] does not match the compiled topology "

@@ -250,3 +250,81 @@ def run_engine_case(spec, x_dict, y, params, ei, B, dtype="f32", device="cuda:0"
             errs["grad:" + k] = rel(grads[k], g)
     run_engine_case.last_decisions_differing = stats["differ"]
     return errs, out.detach().cpu(), (loss.detach().cpu() if loss is not None else o_loss.detach()), grads
+
+
+def random_case(spec, B, seed):
+    """Seeded random minibatch + weights at any size (torch.Generator: synth.make_windows' hash-based draws take ~3 ms per window): x_dict in the
+    reference's convention (fp64, [B * n_t, F_t]), y ([B, n_out * d] regression targets or {0, 1} contact flags), params (synth.make_params)."""
+    g = torch.Generator().manual_seed(seed)
+    x_dict = {t: torch.randn(B * spec.num_nodes[t], spec.widths[t], generator=g, dtype=torch.float64) for t in spec.node_types}
+    n_out = spec.num_nodes[spec.out_type]
+    if spec.regression:
+        y = torch.randn(B, n_out * spec.out_channels, generator=g, dtype=torch.float64)
+    else:
+        y = (torch.rand(B, n_out, generator=g) > 0.5).to(torch.float64)
+    return x_dict, y, synth.make_params(seed, spec.param_shapes())
+
+
+def run_step_case(spec, x_dict, y, params, B, dtype="x3", device="cuda:0", decision_tol=1e-4, engine=None):
+    """The ONE-CALL training step (mshgnn_step_mse / mshgnn_step_ce: the entry points bench.py times) against the fp64 oracle evaluated with the engine's
+    own relu decisions (see run_engine_case) -- usable at BASELINE's full batch sizes: the oracle does ~1 000-7 000 windows/s on the host.
+    Returns (errs, out, loss, grads): errs = max-abs error / max-abs reference per stage (hidden states the plan computes, output, loss, every gradient;
+    exact-zero reference gradients must be exactly zero) + the number of relu decisions that differ OUTSIDE the tolerance band (must be 0)."""
+    from morphsym_hgnn_amd import engine as eng
+    from oracle import ms_hgnn_oracle as orc
+    cfg = oracle_config(spec)
+    e = engine or eng.Engine(spec, dtype=dtype, device=device)
+    xs = e.cast_inputs(x_dict)
+    flat = eng.flatten_params(spec, params, device=e.device)
+    n_out = spec.num_nodes[spec.out_type]
+    if spec.regression:
+        out, loss, gflat = e.step_mse(xs, flat, y.reshape(-1).to(e.device, torch.float32), B)
+    else:
+        out, loss, gflat = e.step_ce(xs, flat, y.reshape(B, n_out).to(e.device, torch.int32).contiguous(), B)
+    torch.cuda.synchronize()
+    decisions = engine_relu_decisions(e, spec, B)
+    stats = {"differ": 0, "outside": 0}
+
+    def relu_fn(key, h):
+        if key not in decisions:
+            return torch.relu(h)
+        rows = row_live_mask(spec, key, B).view(-1, 1)
+        exact = h.detach() > 0
+        m = torch.where(rows, decisions[key], exact)
+        diff = m != exact
+        if bool(diff.any()):
+            stats["differ"] += int(diff.sum())
+            stats["outside"] += int((h.detach().abs()[diff] > decision_tol * float(h.detach().abs().max())).sum())
+        return h * m.to(h.dtype)
+
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+    ei = spec.topology.edge_index_dict(B)
+    o_out, o_hidden = orc.forward(cfg, leaves, {k: v.clone() for k, v in x_dict.items()}, ei, return_hidden=True, relu_fn=relu_fn)
+    yy, yp = orc.wrapper_outputs(cfg, o_out, y, B)
+    o_loss = orc.mse_loss(yy, yp) if spec.regression else orc.cross_entropy_loss(yy, yp, B)
+    o_loss.backward()
+    errs = {"relu_decisions_outside_tolerance": float(stats["outside"])}
+
+    def rel(a, b):
+        a = a.detach().double().cpu(); b = b.detach().double().cpu()
+        return float((a - b).abs().max() / max(float(b.abs().max()), 1e-300))
+
+    sl = node_slices(spec)
+    liv, need = spec.node_liveness()
+    for l in range(spec.num_layers + 1):
+        got = e.hidden_state(B, l)
+        ref = dense_hidden(spec, o_hidden[l], B)
+        nodes = need[0] if l == 0 else liv[l - 1]
+        for t in spec.node_types:
+            if nodes[t]:
+                idx = torch.tensor(nodes[t]) + sl[t].start
+                errs[f"X{l}[{t}]"] = rel(got[:, idx], ref[:, idx])
+    errs["out"] = rel(out.reshape(-1), o_out.detach().reshape(-1))
+    errs["loss"] = rel(loss.reshape(1), o_loss.reshape(1))
+    grads = {k: v.detach().cpu() for k, v in eng.unflatten(spec, gflat).items()}
+    for k, v in leaves.items():
+        g = v.grad if v.grad is not None else torch.zeros_like(v)
+        ref_max = float(g.abs().max())
+        errs["grad:" + k] = float(grads[k].abs().max()) if ref_max == 0.0 else rel(grads[k], g)
+    run_step_case.last_decisions_differing = stats["differ"]
+    return errs, out.detach().cpu(), loss.detach().cpu(), grads

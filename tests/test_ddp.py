@@ -191,7 +191,7 @@ def test_two_engine_ranks_reproduce_the_global_batch_gradient(dtype):
     assert ret["err"] < 1e-5    # same arithmetic, different summation order over the windows
 
 
-def _wrapper_worker(rank, world, port, B, live_only, ret):
+def _wrapper_worker(rank, world, port, B, live_only, weighted, ret):
     """Two wrapper ranks on the one GPU of the test box (gloo: its all-reduce takes device tensors through host copies): flat_data_parallel +
     training_step + backward on each rank's shard == the single-process step on the whole batch."""
     import types
@@ -215,7 +215,8 @@ def _wrapper_worker(rank, world, port, B, live_only, ret):
     w.model.load_state_dict(params)
     with torch.no_grad():
         w.model(x_dict=dict(mine.x_dict), edge_index_dict=mine.edge_index_dict)      # parameters become views of the flat buffer
-    ddp.flat_data_parallel(w, live_only=live_only)
+    ddp.flat_data_parallel(w, live_only=live_only, **({"weight_by_windows": True} if weighted else {}))      # (the default must be DDP's mean of means)
+    assert w.model._flat_ddp_weighted == weighted
     assert (w.model._flat_ddp_live is not None) == live_only
     loss = w.training_step(mine, 0)
     assert w.model._gpend_id == 1                                      # the one-call step ran under torch.distributed
@@ -236,13 +237,22 @@ def _wrapper_worker(rank, world, port, B, live_only, ret):
         ref = wrappers.HGNN_C2_Lightning_Reg(128, 2, spec.topology.metadata(), mine, symmetry_mode="MorphSym", group_operator_path=cfg).to(dev)
         ref.model.load_state_dict(synth.make_params(41, spec.param_shapes()))
         ref.model._flat_ddp = None
-        full = batch_of(x_dict, y, B)
         ref.fused_training_step = False                                # (single-process reference through autograd)
-        lf = ref.training_step(full, 0)
-        lf.backward()
-        gf = torch.zeros_like(g)                                       # (under torch.distributed the two-call route goes through autograd)
-        for (o, n), q in zip(spec.param_offsets().values(), ref.model._params_in_flat_order()):
-            gf[o:o + n] = q.grad.flatten()
+
+        def grad_of(xd, yy, n):
+            ref.model.zero_grad()
+            ref.training_step(batch_of(xd, yy, n), 0).backward()
+            gg = torch.zeros_like(g)                                   # (under torch.distributed the two-call route goes through autograd)
+            for (o, m), q in zip(spec.param_offsets().values(), ref.model._params_in_flat_order()):
+                gg[o:o + m] = q.grad.flatten()
+            return gg
+        if weighted:      # opt-in: the gradient of the GLOBAL mean loss, ragged shards included
+            gf = grad_of(x_dict, y, B)
+        else:             # the default, torch DDP / Lightning-DDP (gnnLightning.py:1396-1400): the mean over the ranks of each rank's mean-loss gradient
+            gf = torch.zeros_like(g)
+            for r in range(world):
+                xr, (rb, re_) = ddp.shard_x_dict(x_dict, spec.num_nodes, B, r, world)
+                gf += grad_of(xr, y[rb:re_], re_ - rb) / world
         ret["err"] = float((g - gf).abs().max() / gf.abs().max())
         ret["params_equal"] = bool(torch.equal(w.model._flat, ref.model._flat))
     dist.barrier()
@@ -250,34 +260,46 @@ def _wrapper_worker(rank, world, port, B, live_only, ret):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,live_only", [(64, False), (65, False), (65, True)])      # equal shards; a ragged split (33 + 32 windows: each rank's gradient is weighted by its
-def test_flat_data_parallel_wrappers_reproduce_the_global_batch_gradient(B, live_only):      # window count); the same with only the live elements on the wire
+@pytest.mark.parametrize("B,live_only,weighted", [(64, False, False), (65, False, False), (65, False, True), (65, True, True), (65, True, False)])
+def test_flat_data_parallel_wrappers_reproduce_the_global_batch_gradient(B, live_only, weighted):
+    """Equal shards; a ragged split (33 + 32 windows) with the default exchange == DDP's mean of the ranks' means, and with weight_by_windows=True == the
+    global-batch gradient; both again with only the live elements on the wire."""
     world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
     port = 33000 + (os.getpid() % 2000)
-    mp.spawn(_wrapper_worker, args=(world, port, B, live_only, ret), nprocs=world, join=True)
+    mp.spawn(_wrapper_worker, args=(world, port, B, live_only, weighted, ret), nprocs=world, join=True)
     assert ret["params_equal"] and ret["err"] < 1e-5
     assert ret["two_call_0"] < 1e-5 and ret["two_call_1"] < 1e-5
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dtype,layers", [("bf16", 3), ("x3", 3), ("bf16", 2)])
-def test_engine_gradient_is_exactly_zero_outside_the_live_elements(dtype, layers):
+@pytest.mark.parametrize("dtype,layers,hidden,regression", [("bf16", 3, 128, True), ("x3", 3, 128, True), ("bf16", 2, 128, True), ("f32", 3, 128, True),
+                                                            ("bf16", 3, 128, False), ("x3", 2, 128, False), ("bf16", 3, 512, True), ("x3", 2, 256, True),
+                                                            ("bf16", 5, 128, True)])
+def test_engine_gradient_is_exactly_zero_outside_the_live_elements(dtype, layers, hidden, regression):
     """What makes the live-element exchange exact on the real engine: every element of the flat gradient that `spec.live_gradient_index` leaves out is an exact
-    zero after a step (A1-C2 below the graph's diameter: the base nodes cannot reach the feet), and the live part is not all zero."""
+    zero after a step (A1-C2 below the graph's diameter: the base nodes cannot reach the feet), and the live part is not all zero -- on the LDS-resident
+    kernels (bf16 / split / fp32 plans), the cross-entropy step, the generic-width engine (hidden 256 / 512: FIN_ZERO ops of mshgnn_gen_plan.hpp) and at a
+    depth where base_transform is live (5 layers: nothing is dead, the index is the whole buffer)."""
     from morphsym_hgnn_amd import engine as eng
-    spec = helpers.make_spec("c2", "a1-c2", "a1-c2", 128, layers)
+    spec = helpers.make_spec("c2", "a1-c2", "a1-c2", hidden, layers, regression=regression)
     B = 50
-    x_dict, y = synth.make_windows(7, B, spec.num_nodes, spec.widths, 12)
+    x_dict, y = synth.make_windows(7, B, spec.num_nodes, spec.widths, 12 if regression else 4, classification=not regression)
     e = eng.Engine(spec, dtype)
+    assert e.generic == (hidden != 128)
     flat = eng.flatten_params(spec, synth.make_params(7, spec.param_shapes()), e.device)
-    out, loss, g = e.step_mse(e.cast_inputs(x_dict), flat, y.reshape(-1).to(e.device, torch.float32), B)
+    if regression:
+        out, loss, g = e.step_mse(e.cast_inputs(x_dict), flat, y.reshape(-1).to(e.device, torch.float32), B)
+    else:
+        out, loss, g = e.step_ce(e.cast_inputs(x_dict), flat, y.reshape(-1).to(e.device, torch.int32), B)
     ex = ddp.LiveGradientExchange(spec, e.device)
     dead = torch.ones(g.numel(), dtype=torch.bool, device=g.device)
     dead[ex.index] = False
-    assert 0.0 < ex.fraction < 1.0 and int(dead.sum()) == g.numel() - ex.index.numel()
-    assert float(g[dead].abs().max()) == 0.0
+    assert 0.0 < ex.fraction <= 1.0 and int(dead.sum()) == g.numel() - ex.index.numel()
+    assert (ex.fraction < 1.0) == (layers < 4)
+    if bool(dead.any()):
+        assert float(g[dead].abs().max()) == 0.0
     assert float(g[ex.index].abs().max()) > 0.0
     before = g.clone()
     ex.allreduce_mean_(g)                      # no process group: pack + scatter only

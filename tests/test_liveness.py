@@ -67,3 +67,25 @@ def test_type_level_liveness_is_a_superset(monkeypatch):
         for t in a:
             assert set(a[t]) <= set(b[t])
     assert coarse[1][0] == {"base": [0, 1], "joint": list(range(12)), "foot": [0, 1, 2, 3]}
+
+
+@pytest.mark.parametrize("hidden", [128, 512])
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_python_liveness_mirror_agrees_with_both_plan_compilers(seed, hidden):
+    """`ddp.flat_data_parallel(live_only=True)` is exact only if spec.node_liveness (Python) and the C plan compilers (mshgnn_plan.hpp at hidden 128,
+    mshgnn_gen_plan.hpp at 512) prune the same nodes.  Host-only cross-check on random topologies: the input bytes the plan reports as live
+    (`mshgnn_info.bytes_in_live`, summed over the nodes ITS liveness keeps) == the same sum over the Python mirror's `need[0]`."""
+    from morphsym_hgnn_amd import engine
+    rng = random.Random(100 + seed)
+    n = {"base": rng.randint(1, 3), "joint": rng.randint(3, 9), "foot": rng.randint(1, 4)}
+    rels = []
+    for s_, d_ in (("base", "joint"), ("joint", "base"), ("joint", "joint"), ("foot", "joint"), ("joint", "foot")):
+        pairs = [[rng.randrange(n[s_]), rng.randrange(n[d_])] for _ in range(rng.randint(0 if d_ != "foot" else 1, max(n[s_], n[d_])))]
+        rels.append(((s_, "connect", d_), pairs))
+    widths = {"base": 6, "joint": 5, "foot": 3}
+    spec = ModelSpec(kind="mi", topology=RobotTopology(name=f"x{seed}", num_nodes=n, relations=rels), hidden=hidden, num_layers=rng.randint(1, 4),
+                     widths=widths, regression=True, grf_dimension=1, group=None, num_timesteps=1)
+    info = engine.compile_plan_host(spec, "bf16")
+    _, need = spec.node_liveness()
+    assert info.bytes_in_live == 2 * sum(len(need[0][t]) * widths[t] for t in widths)
+    assert info.bytes_in == 2 * sum(n[t] * widths[t] for t in widths)

@@ -35,5 +35,7 @@ if __name__ == "__main__":
     import os
     cfile = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), ".build_commit")      # written before the snapshot leaves the build container
     commit = open(cfile).read().strip() if os.path.exists(cfile) else None
-    json.dump({**({"commit": commit} if commit else {}), "note": "per launch, averaged over launches (layer_fwd / layer_bwd: averaged over the L layers); "
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import source_hash
+    json.dump({**({"commit": commit} if commit else {}), "source_hash": source_hash(), "note": "per launch, averaged over launches (layer_fwd / layer_bwd: averaged over the L layers); "
                        "FETCH_SIZE x2 (gfx950), KiB -> bytes", "kernels": out}, sys.stdout, indent=1)
