@@ -61,6 +61,10 @@ def parse():
                     help="N > 1: what the gradient all-reduce moves.  f32: the whole flat buffer; live: only the elements that can be non-zero at this depth, "
                          "packed (exact -- ddp.LiveGradientExchange); auto (default): times f32 and live on this machine and keeps the faster; "
                          "bf16: opt-in, half the bytes, NOT parity-grade (ddp.allreduce_mean_bf16_)")
+    ap.add_argument("--collective", default=os.environ.get("MSHGNN_BENCH_COLLECTIVE", "auto"), choices=["auto", "torch", "stream"],
+                    help="N > 1: who enqueues the gradient all-reduce.  stream: ncclAllReduce on the step's own HIP stream through the C-ABI "
+                         "(mshgnn_comm_allreduce_mean, ddp.StreamAllReduce); torch: torch.distributed.all_reduce (its side stream + event hand-over); "
+                         "auto (default): times both on this machine and keeps the faster")
     return ap.parse_args()
 
 
@@ -220,7 +224,7 @@ def cpu_baseline(spec, batch, budget_s=20.0, scan=True):
 class Workload:
     """One (spec, plan dtype, batch) on one device: resident inputs + the step closure."""
 
-    def __init__(self, spec, dtype, B, device, seed, dist=None, overlap="auto", grad_exchange="f32"):
+    def __init__(self, spec, dtype, B, device, seed, dist=None, overlap="auto", grad_exchange="f32", collective="torch"):
         import torch
         from morphsym_hgnn_amd import engine as eng, synth
         self.torch, self.dist, self.spec, self.B = torch, dist, spec, B
@@ -254,13 +258,25 @@ class Workload:
                 self.live = None
         self.use_live = self.live is not None and grad_exchange == "live"
         self.exchange_choice = None
+        # the whole-buffer fp32 exchange can be enqueued on the step's own stream through the C-ABI (ddp.StreamAllReduce) instead of torch.distributed
+        self.stream_comm, self.use_stream, self.collective_choice = None, False, None
+        if dist is not None and collective in ("auto", "stream"):
+            from morphsym_hgnn_amd import ddp
+            try:
+                self.stream_comm = ddp.StreamAllReduce(device)
+                self.use_stream = collective == "stream"
+            except Exception as ex:  # noqa: BLE001  (no librccl the loader can find: torch.distributed's collective stays)
+                sys.stderr.write(f"bench.py: StreamAllReduce unavailable ({ex}); using torch.distributed.all_reduce\n")
+                self.collective_choice = {"mode": collective, "stream": False, "error": str(ex)[:200]}
 
     def _allreduce(self):
         if self.g16 is not None:
             from morphsym_hgnn_amd import ddp
             ddp.allreduce_mean_bf16_(self.gflat, self.g16)
         elif self.use_live:
-            self.live.allreduce_mean_(self.gflat)
+            self.live.allreduce_mean_(self.gflat, comm=self.stream_comm if self.use_stream else None)
+        elif self.use_stream:
+            self.stream_comm.allreduce_mean_(self.gflat)      # ncclAllReduce(avg) on this stream, behind the step's last kernel
         else:
             self.dist.all_reduce(self.gflat, op=self.dist.ReduceOp.AVG)     # DDP semantics: mean over ranks (gnnLightning.py:1396-1400)
 
@@ -302,6 +318,19 @@ class Workload:
         t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=self.e.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t[0]) / steps * 1e3
+
+    def calibrate_collective(self, steps=20, warmup=3):
+        """--collective auto with more than one rank: the plain sequence with torch.distributed's all-reduce and with the C-ABI's on the step's own stream,
+        MAX over ranks, keep the faster."""
+        live, ov = self.use_live, self.overlap
+        self.use_live, self.overlap = False, False
+        ms = {}
+        for mode in (False, True):
+            self.use_stream = mode
+            ms[mode] = self._time_mode(steps, warmup)
+        self.use_stream = ms[True] <= ms[False]
+        self.use_live, self.overlap = live, ov
+        self.collective_choice = {"mode": "auto", "stream": bool(self.use_stream), "ms_torch_distributed": ms[False], "ms_stream_c_abi": ms[True]}
 
     def calibrate_exchange(self, steps=20, warmup=3):
         """--grad-exchange auto with more than one rank: time the step with the whole-buffer all-reduce and with the packed live-element exchange
@@ -693,10 +722,12 @@ def main():
 
     B, L, hidden = defaults(args)
     spec = build_spec(L, args.config, hidden)
-    wl = Workload(spec, args.dtype, B, device, 1234 + rank, dist, args.overlap, args.grad_exchange)
+    wl = Workload(spec, args.dtype, B, device, 1234 + rank, dist, args.overlap, args.grad_exchange, args.collective)
     if args.grad_exchange in ("bf16", "live"):
         wl.can_overlap = False      # (the two-phase step exchanges whole fp32 slices)
     multi = world > 1 or os.environ.get("MSHGNN_BENCH_FORCE_DIST") == "1"
+    if args.collective == "auto" and wl.stream_comm is not None and multi:
+        wl.calibrate_collective()
     if args.grad_exchange == "auto" and wl.live is not None and multi:
         wl.calibrate_exchange()
     if args.overlap == "auto" and wl.can_overlap and multi:
@@ -744,7 +775,9 @@ def main():
                                + (f", RCCL all-reduce (mean over {world} ranks{', overlapped two-phase' if wl.overlap else ''})" if dist is not None else ""),
                    "global_batch": B * world, "parallelism": f"dp{world}", "rccl_ranks": (dist.get_world_size() if dist is not None else 0),
                    **({"grad_exchange": ("live" if wl.use_live else "f32") if args.grad_exchange == "auto" else args.grad_exchange,
-                       "grad_exchange_choice": wl.exchange_choice} if dist is not None else {})},
+                       "grad_exchange_choice": wl.exchange_choice,
+                       "collective": "stream (C-ABI ncclAllReduce on the step's stream)" if (wl.use_stream and not wl.overlap) else "torch.distributed",
+                       "collective_choice": wl.collective_choice or {"mode": args.collective, "stream": bool(wl.use_stream)}} if dist is not None else {})},
         "timing": {"blocks": len(blocks), "block_steps": args.steps, "median_ms": med * 1e3, "min_ms": min(blocks) * 1e3, "max_ms": max(blocks) * 1e3,
                    "timed_s": sum(blocks)},
         "overlap": wl.overlap_choice or {"mode": args.overlap, "two_phase": bool(wl.overlap)},

@@ -150,6 +150,12 @@ typedef struct mshgnn_kernel_stat {
 
 const char* mshgnn_last_error(void);
 const char* mshgnn_version(void);
+/* ABI guard for callers that keep their own copy of this header: MSHGNN_ABI_VERSION changes whenever a struct below changes size or meaning (5: mshgnn_info
+ * gained bytes_in_live; kernel_sets bits 3 / 4 retired), and the sizes the LIBRARY was built with can be compared with the caller's sizeof() before any
+ * struct crosses the boundary -- mshgnn_plan_info / mshgnn_workspace_layout write sizeof(struct) bytes through the pointer they are given.                */
+#define MSHGNN_ABI_VERSION 5
+int mshgnn_abi_version(void);
+size_t mshgnn_struct_size(int which);      /* 0: mshgnn_desc, 1: mshgnn_info, 2: mshgnn_ws_layout, 3: mshgnn_window_desc, 4: mshgnn_kernel_stat; else 0 */
 
 int mshgnn_plan_create(const mshgnn_desc* desc, mshgnn_plan** plan_out);
 void mshgnn_plan_destroy(mshgnn_plan* plan);
@@ -345,6 +351,20 @@ int mshgnn_op_aggregate(const float* x, int64_t ldx, const int32_t* rowptr, cons
 /* bias gradient: out[n] = sum_m X[m ldx + n], two fixed-order stages; workspace bytes from mshgnn_op_colsum_workspace.      */
 int64_t mshgnn_op_colsum_workspace(int64_t M, int64_t N);
 int mshgnn_op_colsum(const float* X, int64_t ldx, float* out, int64_t M, int64_t N, void* workspace, void* stream);
+
+/* ---- data-parallel gradient exchange on the caller's stream (replaces the bucketed all-reduce of Lightning-DDP, ---------------------
+ * gnnLightning.py:1396-1400) -- one process per GPU, replicated weights, windows sharded: the ONLY collective of a step is the mean of the flat fp32
+ * gradient over the ranks.  RCCL is bound at run time (dlopen of `rccl_path`, else librccl.so as the process already has it / as the loader finds it):
+ * no link-time dependency, single-GPU callers never load it.  mshgnn_comm_unique_id on rank 0 -> the 128 bytes travel to every rank by any means
+ * (torch.distributed's store, MPI, a file) -> mshgnn_comm_create on every rank with its device current (collective: ncclCommInitRank).
+ * mshgnn_comm_allreduce_mean enqueues ncclAllReduce(buf, buf, n, float32, avg) on `stream` and returns: stream-ordered behind the step that produced
+ * buf, no host synchronisation, capturable in a HIP graph together with the step.  _sum: the same with ncclSum (callers that weight by window counts). */
+typedef struct mshgnn_comm mshgnn_comm;
+int mshgnn_comm_unique_id(const char* rccl_path, void* id_out_128_bytes);
+int mshgnn_comm_create(const char* rccl_path, const void* id_128_bytes, int nranks, int rank, mshgnn_comm** comm_out);
+void mshgnn_comm_destroy(mshgnn_comm* comm);
+int mshgnn_comm_allreduce_mean(mshgnn_comm* comm, float* buf, int64_t n, void* stream);
+int mshgnn_comm_allreduce_sum(mshgnn_comm* comm, float* buf, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -15,7 +15,18 @@
 // No CPU fallback exists: every entry point launches HIP kernels or fails loudly.
 #include "mshgnn_device.hpp"
 extern "C" const char* mshgnn_last_error(void) { return g_err.c_str(); }
-extern "C" const char* mshgnn_version(void) { return "mshgnn 0.1 (gfx950)"; }
+extern "C" const char* mshgnn_version(void) { return "mshgnn 0.5 (gfx950)"; }
+extern "C" int mshgnn_abi_version(void) { return MSHGNN_ABI_VERSION; }
+extern "C" size_t mshgnn_struct_size(int which) {
+    switch (which) {
+        case 0: return sizeof(mshgnn_desc);
+        case 1: return sizeof(mshgnn_info);
+        case 2: return sizeof(mshgnn_ws_layout);
+        case 3: return sizeof(mshgnn_window_desc);
+        case 4: return sizeof(mshgnn_kernel_stat);
+        default: return 0;
+    }
+}
 
 // ------------------------------------------------------------------------------------------------------
 // k_prep: pack weights into MFMA B-fragment images (root-sum, transpose, dtype) and sum biases

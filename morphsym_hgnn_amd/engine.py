@@ -81,7 +81,10 @@ EXPORTS = [
     "mshgnn_metrics_regression", "mshgnn_metrics_classification", "mshgnn_grf_body_to_world", "mshgnn_assemble_windows",
     "mshgnn_backward_ce", "mshgnn_step_mse", "mshgnn_step_mse_phase",
     "mshgnn_step_mse_series", "mshgnn_step_ce_series", "mshgnn_step_ce", "mshgnn_op_gemm", "mshgnn_op_gemm_workspace", "mshgnn_op_aggregate", "mshgnn_op_colsum", "mshgnn_op_colsum_workspace",
+    "mshgnn_abi_version", "mshgnn_struct_size",
+    "mshgnn_comm_unique_id", "mshgnn_comm_create", "mshgnn_comm_destroy", "mshgnn_comm_allreduce_mean", "mshgnn_comm_allreduce_sum",
 ]
+ABI_VERSION = 5      # include/mshgnn.h MSHGNN_ABI_VERSION: the ctypes structures above mirror THAT header
 
 _lib = None
 
@@ -156,6 +159,21 @@ def load_library():
     lib.mshgnn_op_colsum_workspace.restype = C.c_int64
     lib.mshgnn_op_colsum_workspace.argtypes = [C.c_int64, C.c_int64]
     lib.mshgnn_op_colsum.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+    lib.mshgnn_struct_size.restype = C.c_size_t
+    lib.mshgnn_struct_size.argtypes = [C.c_int]
+    lib.mshgnn_comm_unique_id.argtypes = [C.c_char_p, C.c_void_p]
+    lib.mshgnn_comm_create.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    lib.mshgnn_comm_destroy.argtypes = [C.c_void_p]
+    lib.mshgnn_comm_destroy.restype = None
+    lib.mshgnn_comm_allreduce_mean.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.mshgnn_comm_allreduce_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    # ABI guard: the structures of this binding and the library's must be the same header version and the same sizes (a stale .so, or a binding
+    # edited without the header, would otherwise have the library write past a smaller struct)
+    if lib.mshgnn_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH}: ABI version {lib.mshgnn_abi_version()} != {ABI_VERSION} of this binding -- rebuild (make -C morphsym_hgnn_amd/csrc)")
+    for which, st in enumerate((MshgnnDesc, MshgnnInfo, MshgnnWsLayout, MshgnnWindowDesc, MshgnnKernelStat)):
+        if lib.mshgnn_struct_size(which) != C.sizeof(st):
+            raise RuntimeError(f"{LIB_PATH}: sizeof({st.__name__}) is {lib.mshgnn_struct_size(which)} in the library, {C.sizeof(st)} in engine.py")
     _lib = lib
     return lib
 

@@ -14,6 +14,10 @@ os.environ.setdefault("MSHGNN_POISON_WS", "1")      # engine.workspace(): fresh 
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the fp64 oracle is small-matrix torch code: on a many-core host (the GPU box shows 256 cpus, 16 of them this job's share) the default of one
+    # thread per visible core makes it SLOWER (bench.py's cpu_baseline scan: best at 16) -- cap it for every oracle evaluation of the suite
+    import torch
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), 16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 16)))
 
 
 @pytest.fixture(autouse=True)

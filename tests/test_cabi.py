@@ -102,3 +102,28 @@ def test_engine_fails_loudly_without_gpu():
         pytest.skip("GPU present")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         engine.Engine(helpers.make_spec("c2", "a1-c2", "a1-c2", 128, 1))
+
+
+def test_abi_guard_reports_the_bindings_struct_sizes():
+    """include/mshgnn.h MSHGNN_ABI_VERSION == the library's == engine.ABI_VERSION, and every struct that crosses the boundary has the size the ctypes
+    mirror has (mshgnn_plan_info writes sizeof(mshgnn_info) bytes through the caller's pointer: a stale binding must be caught before that)."""
+    import ctypes as C
+    lib = engine.load_library()
+    hdr = open(os.path.join(ROOT, "include", "mshgnn.h")).read()
+    assert int(re.search(r"#define MSHGNN_ABI_VERSION (\d+)", hdr).group(1)) == lib.mshgnn_abi_version() == engine.ABI_VERSION
+    for which, st in enumerate((engine.MshgnnDesc, engine.MshgnnInfo, engine.MshgnnWsLayout, engine.MshgnnWindowDesc, engine.MshgnnKernelStat)):
+        assert lib.mshgnn_struct_size(which) == C.sizeof(st) > 0, st.__name__
+    assert lib.mshgnn_struct_size(99) == 0
+
+
+def test_comm_entry_points_reject_bad_arguments_without_touching_rccl():
+    """The data-parallel collective's entry points validate their arguments before RCCL is even loaded (no GPU, no librccl needed for that)."""
+    import ctypes as C
+    lib = engine.load_library()
+    out = C.c_void_p()
+    assert lib.mshgnn_comm_create(None, None, 2, 0, C.byref(out)) == -1 and b"mshgnn_comm_create" in lib.mshgnn_last_error()
+    ident = C.create_string_buffer(128)
+    assert lib.mshgnn_comm_create(None, ident, 2, 5, C.byref(out)) == -1      # rank out of range
+    assert lib.mshgnn_comm_unique_id(None, None) == -1
+    assert lib.mshgnn_comm_allreduce_mean(None, None, 4, None) == -1
+    lib.mshgnn_comm_destroy(None)      # a null communicator is a no-op

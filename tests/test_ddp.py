@@ -304,3 +304,55 @@ def test_engine_gradient_is_exactly_zero_outside_the_live_elements(dtype, layers
     before = g.clone()
     ex.allreduce_mean_(g)                      # no process group: pack + scatter only
     assert torch.equal(before, g)
+
+
+def _stream_comm_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # (any backend: it only carries the 128-byte communicator id)
+    from morphsym_hgnn_amd import engine as eng
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    comm = ddp.StreamAllReduce(dev)
+    spec = helpers.make_spec("c2", "a1-c2", "a1-c2", 128, 3)
+    B = 64
+    e = eng.Engine(spec, "bf16")
+    x_dict, y = synth.make_windows(3, B, spec.num_nodes, spec.widths, 12)
+    xs, yd = e.cast_inputs(x_dict), y.reshape(-1).to(dev, torch.float32)
+    flat = eng.flatten_params(spec, synth.make_params(3, spec.param_shapes()), dev)
+    out, loss, g = e.step_mse(xs, flat, yd, B)
+    ref = g.clone()
+    comm.allreduce_mean_(g)                                # one rank: the mean over the ranks is the buffer itself
+    torch.cuda.synchronize()
+    ret["same"] = bool(torch.equal(g, ref))
+    # step + exchange as ONE captured HIP graph on a side stream (the collective is stream-ordered behind the step's last kernel)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        e.step_mse(xs, flat, yd, B, out=out, grad_flat=g, loss=loss); comm.allreduce_mean_(g)      # warm-up on the capture stream
+        s.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        g.zero_()
+        with torch.cuda.graph(graph, stream=s):
+            e.step_mse(xs, flat, yd, B, out=out, grad_flat=g, loss=loss)
+            comm.allreduce_mean_(g)
+        g.zero_()
+        graph.replay()
+    torch.cuda.synchronize()
+    ret["graph_same"] = bool(torch.equal(g, ref))
+    live = ddp.LiveGradientExchange(spec, dev)
+    g2 = ref.clone()
+    live.allreduce_mean_(g2, comm=comm)
+    torch.cuda.synchronize()
+    ret["live_same"] = bool(torch.equal(g2, ref))
+    comm.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_stream_allreduce_through_the_c_abi_on_a_one_rank_group_and_inside_a_graph():
+    """ddp.StreamAllReduce (mshgnn_comm_*: ncclAllReduce(avg) enqueued on the step's own stream, RCCL bound with dlopen): on a 1-rank communicator the mean
+    is the identity -- bit for bit -- eagerly, captured in one HIP graph together with the step, and on the packed live elements."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_stream_comm_worker, args=(1, 35000 + (os.getpid() % 2000), ret), nprocs=1, join=True)
+    assert ret["same"] and ret["graph_same"] and ret["live_same"]
