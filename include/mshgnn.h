@@ -352,6 +352,23 @@ int mshgnn_op_aggregate(const float* x, int64_t ldx, const int32_t* rowptr, cons
 int64_t mshgnn_op_colsum_workspace(int64_t M, int64_t N);
 int mshgnn_op_colsum(const float* X, int64_t ldx, float* out, int64_t M, int64_t N, void* workspace, void* stream);
 
+/* ---- the reference's own input tensors, uncast ---------------------------------------------------------------------------------------------------
+ * The reference's datasets hand the model fp64 tensors at the dense pitch (torch.set_default_dtype(float64), gnnLightning.py:1183; x_dict[type] is
+ * [B n_t, F_t]).  These three entry points are mshgnn_forward / mshgnn_step_mse / mshgnn_step_ce for such tensors: src[t] = device pointer to the caller's
+ * rows, src_bytes = 8 (fp64) or 4 (fp32), src_pitch[t] in elements (NULL = dense).  The encoder converts in registers (fp64 -> fp32 -> bf16, round to nearest
+ * even at each step: the values torch's .to() produces) and WRITES the plan-dtype rows into x_rows[t] ([batch][n_t][x_pitch[t]], 16-byte aligned, pitch a
+ * whole number of 16-byte chunks: what mshgnn_backward* and the weight-gradient pass of the step read) for the nodes the plan reads -- instead of a separate
+ * cast + re-pitch pass over the batch (A1-C2, 8192 windows: 472 MB read + 118 MB written + 118 MB re-read).  bf16 and split-bf16 plans of the LDS-resident
+ * kernels; MSHGNN_EUNSUPPORTED on the fp32 plan and the generic-width engine (cast there).  fp32 rows of an even width must start 8-byte aligned.      */
+int mshgnn_forward_src(const mshgnn_plan* plan, int src_bytes, const void* const* src, const int64_t* src_pitch, void* const* x_rows,
+                       const int64_t* x_pitch, const float* params, float* out, void* workspace, int64_t batch, int training, void* stream);
+int mshgnn_step_mse_src(const mshgnn_plan* plan, int src_bytes, const void* const* src, const int64_t* src_pitch, void* const* x_rows,
+                        const int64_t* x_pitch, const float* params, const float* y, float* out, float* loss_out, float* grad_params,
+                        void* workspace, int64_t batch, void* stream);
+int mshgnn_step_ce_src(const mshgnn_plan* plan, int src_bytes, const void* const* src, const int64_t* src_pitch, void* const* x_rows,
+                       const int64_t* x_pitch, const float* params, const int32_t* labels, float* out, float* loss_out, float* grad_params,
+                       void* workspace, int64_t batch, void* stream);
+
 /* ---- data-parallel gradient exchange on the caller's stream (replaces the bucketed all-reduce of Lightning-DDP, ---------------------
  * gnnLightning.py:1396-1400) -- one process per GPU, replicated weights, windows sharded: the ONLY collective of a step is the mean of the flat fp32
  * gradient over the ranks.  RCCL is bound at run time (dlopen of `rccl_path`, else librccl.so as the process already has it / as the loader finds it):

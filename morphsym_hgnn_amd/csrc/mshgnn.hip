@@ -102,9 +102,12 @@ __device__ __forceinline__ u32x4 splice8(u32x4 A, u32x4 B, int n0) {      // bf1
     const unsigned __int128 r = (a & ((((unsigned __int128)1) << sh) - 1)) | (b << sh);
     return u32x4{(unsigned)r, (unsigned)(r >> 32), (unsigned)(r >> 64), (unsigned)(r >> 96)};
 }
-template <typename T, bool ALIGNED, bool SERIES = false> __global__ __launch_bounds__(256) void k_enc_fwd(EncArgs a, SeriesSrc ser) {
+// SRC (bf16, ALIGNED; 8 / 4): the rows come from the caller's own fp64 / fp32 tensors at their dense pitch (WideSrc), are converted in registers and ALSO
+// written to a.x as plan-dtype rows for the weight-gradient kernel -- the cast + re-pitch pass fused into the encoder (mshgnn_*_src entry points).
+template <typename T, bool ALIGNED, bool SERIES = false, int SRC = 0> __global__ __launch_bounds__(256) void k_enc_fwd(EncArgs a, SeriesSrc ser, WideSrc wsrc) {
     using P = Prec<T>;
     static_assert(!SERIES || (sizeof(T) == 2 && ALIGNED), "the series gather is a bf16 path");
+    static_assert(SRC == 0 || (sizeof(T) == 2 && ALIGNED && !SERIES), "wide source rows: bf16 plan, aligned destination rows");
     constexpr int MB = P::ENC_MB;                       // row blocks (of 16 windows) per workgroup
     constexpr int VPB = P::ROWS * P::CPR, NIT = VPB / 256 > 0 ? VPB / 256 : 1, BPP = 256 / VPB > 0 ? 256 / VPB : 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -146,7 +149,10 @@ template <typename T, bool ALIGNED, bool SERIES = false> __global__ __launch_bou
     typename P::AFrag af;
     const AOff<T> ao(lane);      // fragment offsets once per kernel (the generic load_afrag rebuilds them per call: 14 VALU instructions)
     u32x4 v[MB / BPP][NIT];
-    u32x4 rawv[SERIES ? MB / BPP : 1][NIT];      // SERIES: the chunk being multiplied, kept until its window rows have been written
+    u32x4 rawv[(SERIES || SRC) ? MB / BPP : 1][NIT];      // SERIES / SRC: the chunk being multiplied, kept until its window rows have been written
+    u32x2 wv8[SRC ? MB / BPP : 1][SRC ? SRC : 1];          // SRC: the chunk's 8 source elements as 8-byte units, untouched until the staging pass
+    const bool unit_ok = SRC == 8 || (F & 1) == 0;        // every 8-byte unit of a row is wholly valid or wholly past its end (uniform)
+    const int64_t spitch = SRC ? wsrc.pitch[t] : 0;
     // SERIES: first series row of this thread's window rows, the node row's first run
     int srow[SERIES ? MB / BPP : 1];
     __shared__ unsigned long long rp_s[SERIES ? 16 : 1];      // SERIES: the column pointers of this node row's first 16 runs (a chunk takes its pieces from runs j, j + 1)
@@ -183,6 +189,15 @@ template <typename T, bool ALIGNED, bool SERIES = false> __global__ __launch_bou
             }
             return;
         }
+        if constexpr (SRC > 0) {
+#pragma unroll
+            for (int mi = 0; mi < MB / BPP; ++mi) {
+                const int w = w0 + (mi * BPP + sub) * P::ROWS + r0;
+                const char* row = reinterpret_cast<const char*>(wsrc.p[t]) + ((size_t)min(w, a.B - 1) * nt + node) * spitch * SRC;
+                wide_fetch<SRC>(wv8[mi], row, k0, F, unit_ok, w < a.B);
+            }
+            return;
+        }
 #pragma unroll
         for (int mi = 0; mi < MB / BPP; ++mi)
 #pragma unroll
@@ -209,14 +224,20 @@ template <typename T, bool ALIGNED, bool SERIES = false> __global__ __launch_bou
         for (int mi = 0; mi < MB / BPP; ++mi)
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
-                const u32x4 raw = kc + 1 == nkc ? chunk_keep_first<T>(v[mi][it], nv) : v[mi][it];      // only the last K chunk has pad columns
+                u32x4 raw;
+                if constexpr (SRC > 0) {      // fp64 / fp32 -> (fp32 ->) bf16, round to nearest even twice as torch's .to(bfloat16) does; elements past the row: zero
+                    f32x4 lo4, hi4;
+                    wide_to_f32<SRC>(wv8[mi], nv, lo4, hi4);
+                    raw = pack_oct(lo4, hi4);
+                } else
+                raw = kc + 1 == nkc ? chunk_keep_first<T>(v[mi][it], nv) : v[mi][it];      // only the last K chunk has pad columns
                 *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(mi * BPP + sub, r0 + it * (256 / P::CPR), c)) = raw ^ sx;
-                if constexpr (SERIES) rawv[mi][it] = raw;
+                if constexpr (SERIES || SRC > 0) rawv[mi][it] = raw;
             }
         __syncthreads();
         if (!skip) load_bfrag<T>(bf, wpack, a.pack0[t] + kc, wv, lane);   // before the prefetch: vmcnt retires in order
         if (kc + 1 < nkc) fetch(kc + 1);   // the next K chunk streams from HBM under this chunk's MFMAs
-        if constexpr (SERIES) {
+        if constexpr (SERIES || SRC > 0) {
             // the materialised window rows of THIS chunk (raw values: the sign mask is applied by whoever reads them) go out BEHIND the next chunk's
             // loads: vmcnt retires in issue order, so a load issued after stores can only be waited for together with them -- with the stores
             // youngest, the next chunk's wait leaves them in flight
@@ -2185,7 +2206,7 @@ extern "C" int mshgnn_plan_create(const mshgnn_desc* desc, mshgnn_plan** out) {
             (rc = set_lds_attr(k_enc_fwd<float, true>, Prec<float>::ENC_MB * Prec<float>::BLK)) || (rc = set_lds_attr(k_enc_fwd<float, false>, Prec<float>::ENC_MB * Prec<float>::BLK))) { mshgnn_plan_destroy(p); return rc; }
     } else {
         if ((rc = set_lds_attr(k_layer_fwd<__bf16>, lds)) || (rc = set_lds_attr(k_layer_bwd<__bf16>, lds)) ||
-            (rc = set_lds_attr(k_enc_fwd<__bf16, true>, Prec<__bf16>::ENC_MB * Prec<__bf16>::BLK)) || (rc = set_lds_attr(k_enc_fwd<__bf16, true, true>, Prec<__bf16>::ENC_MB * Prec<__bf16>::BLK)) || (rc = set_lds_attr(k_enc_fwd<__bf16, false>, Prec<__bf16>::ENC_MB * Prec<__bf16>::BLK))) { mshgnn_plan_destroy(p); return rc; }
+            (rc = set_lds_attr(k_enc_fwd<__bf16, true>, Prec<__bf16>::ENC_MB * Prec<__bf16>::BLK)) || (rc = set_lds_attr(k_enc_fwd<__bf16, true, true>, Prec<__bf16>::ENC_MB * Prec<__bf16>::BLK)) || (rc = set_lds_attr(k_enc_fwd<__bf16, true, false, 8>, Prec<__bf16>::ENC_MB * Prec<__bf16>::BLK)) || (rc = set_lds_attr(k_enc_fwd<__bf16, true, false, 4>, Prec<__bf16>::ENC_MB * Prec<__bf16>::BLK)) || (rc = set_lds_attr(k_enc_fwd<__bf16, false>, Prec<__bf16>::ENC_MB * Prec<__bf16>::BLK))) { mshgnn_plan_destroy(p); return rc; }
         const char* e = getenv("MSHGNN_FUSED");
         p->use_fused = hp.fused && !(e && atoi(e) == 0);
         if (p->use_fused) {
@@ -2319,6 +2340,7 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
         else hipLaunchKernelGGL(k_prep<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
     }
     // 2. encoder
+    const WideSrc* wide = series ? nullptr : g_wide_src;      // (mshgnn_*_src: the caller's fp64 / fp32 rows; x = the plan-dtype rows to materialise, may be null)
     {
         EncArgs a{};
         a.n_types = hp.NT; a.B = B; a.NN = hp.NN; a.tiles = (B + Prec<T>::ENC_MB * Prec<T>::ROWS - 1) / (Prec<T>::ENC_MB * Prec<T>::ROWS);
@@ -2360,12 +2382,17 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
             if (series) {
                 if (x && !a.aligned) return set_err(MSHGNN_EINVAL, "the fused window assembly needs 16-byte aligned window rows (pitch a multiple of 8)");
                 enc_grid += (unsigned)((series->lab.B + 255) / 256);      // the label workgroups
-                hipLaunchKernelGGL((k_enc_fwd<T, true, true>), dim3(enc_grid), dim3(256), Prec<T>::ENC_MB * Prec<T>::BLK, st, a, *series);
-            } else if (a.aligned) hipLaunchKernelGGL((k_enc_fwd<T, true>), dim3(enc_grid), dim3(256), Prec<T>::ENC_MB * Prec<T>::BLK, st, a, SeriesSrc{});
-            else hipLaunchKernelGGL((k_enc_fwd<T, false>), dim3(enc_grid), dim3(256), Prec<T>::ENC_MB * Prec<T>::BLK, st, a, SeriesSrc{});
+                hipLaunchKernelGGL((k_enc_fwd<T, true, true>), dim3(enc_grid), dim3(256), Prec<T>::ENC_MB * Prec<T>::BLK, st, a, *series, WideSrc{});
+            } else if (wide) {      // the caller's fp64 / fp32 rows: converted by the encoder, plan-dtype rows written to x on the side
+                if (x && !a.aligned) return set_err(MSHGNN_EINVAL, "wide source rows: the plan-dtype rows need 16-byte alignment and a pitch that is a multiple of 8");
+                if (wide->bytes == 8) hipLaunchKernelGGL((k_enc_fwd<T, true, false, 8>), dim3(enc_grid), dim3(256), Prec<T>::ENC_MB * Prec<T>::BLK, st, a, SeriesSrc{}, *wide);
+                else hipLaunchKernelGGL((k_enc_fwd<T, true, false, 4>), dim3(enc_grid), dim3(256), Prec<T>::ENC_MB * Prec<T>::BLK, st, a, SeriesSrc{}, *wide);
+            } else if (a.aligned) hipLaunchKernelGGL((k_enc_fwd<T, true>), dim3(enc_grid), dim3(256), Prec<T>::ENC_MB * Prec<T>::BLK, st, a, SeriesSrc{}, WideSrc{});
+            else hipLaunchKernelGGL((k_enc_fwd<T, false>), dim3(enc_grid), dim3(256), Prec<T>::ENC_MB * Prec<T>::BLK, st, a, SeriesSrc{}, WideSrc{});
         } else {
-            if (a.aligned) hipLaunchKernelGGL((k_enc_fwd<T, true>), dim3(enc_grid), dim3(256), Prec<T>::ENC_MB * Prec<T>::BLK, st, a, SeriesSrc{});
-            else hipLaunchKernelGGL((k_enc_fwd<T, false>), dim3(enc_grid), dim3(256), Prec<T>::ENC_MB * Prec<T>::BLK, st, a, SeriesSrc{});
+            if (wide) return set_err(MSHGNN_EUNSUPPORTED, "wide source rows: not on the fp32 plan (cast the inputs)");
+            if (a.aligned) hipLaunchKernelGGL((k_enc_fwd<T, true>), dim3(enc_grid), dim3(256), Prec<T>::ENC_MB * Prec<T>::BLK, st, a, SeriesSrc{}, WideSrc{});
+            else hipLaunchKernelGGL((k_enc_fwd<T, false>), dim3(enc_grid), dim3(256), Prec<T>::ENC_MB * Prec<T>::BLK, st, a, SeriesSrc{}, WideSrc{});
         }
     }
     // 3. layers (+ decoder): one fused launch on the bf16 plan, else one kernel per layer and the decoder kernel
@@ -2614,6 +2641,54 @@ extern "C" int mshgnn_step_ce(const mshgnn_plan* p, const void* const* x, const 
     int rc = mshgnn_forward(p, x, x_pitch, params, out, workspace, batch, 1, stream);
     if (rc) return rc;
     return mshgnn_backward_ce(p, x, x_pitch, params, out, labels, loss_out, grad_params, workspace, batch, stream);
+}
+
+// ---- the caller's own fp64 / fp32 tensors as inputs (the reference's datasets produce fp64, gnnLightning.py:1183): the encoder converts in registers and
+// writes the plan-dtype rows the weight-gradient kernel needs on the side -- no separate cast + re-pitch pass.  Thin wrappers: they publish the source
+// descriptor to the encoder launch of the plain entry point they forward to (same thread, synchronous on the host).
+namespace {
+struct WideGuard {
+    WideSrc w{};
+    int rc = MSHGNN_OK;
+    WideGuard(const mshgnn_plan* p, int src_bytes, const void* const* src, const int64_t* src_pitch, const char* who) {
+        if (!p || !src) { rc = set_err(MSHGNN_EINVAL, std::string("null argument to ") + who); return; }
+        if (src_bytes != 4 && src_bytes != 8) { rc = set_err(MSHGNN_EINVAL, std::string(who) + ": src_bytes must be 4 (fp32) or 8 (fp64)"); return; }
+        if (p->gen || p->hp.d.dtype == MSHGNN_F32) { rc = set_err(MSHGNN_EUNSUPPORTED, std::string(who) + ": wide source rows run on the bf16 and split-bf16 plans of the LDS-resident kernels"); return; }
+        w.bytes = src_bytes;
+        for (int t = 0; t < p->n_types; ++t) {
+            if (!src[t]) { rc = set_err(MSHGNN_EINVAL, std::string(who) + ": null source tensor"); return; }
+            w.p[t] = src[t]; w.pitch[t] = src_pitch ? src_pitch[t] : p->hp.d.type_width[t];
+            if (w.pitch[t] < p->hp.d.type_width[t]) { rc = set_err(MSHGNN_EINVAL, std::string(who) + ": src_pitch smaller than the feature width"); return; }
+            if (((uintptr_t)src[t] % (src_bytes == 8 ? 8 : 4)) != 0) { rc = set_err(MSHGNN_EINVAL, std::string(who) + ": source tensor not aligned to its element size"); return; }
+            // fp32 rows are read in 8-byte units where the width allows it: rows must then start on 8 bytes
+            if (src_bytes == 4 && (p->hp.d.type_width[t] & 1) == 0 && ((((uintptr_t)src[t]) | (uintptr_t)(w.pitch[t] * 4)) & 7) != 0) {
+                rc = set_err(MSHGNN_EINVAL, std::string(who) + ": fp32 source rows of an even width must start 8-byte aligned (base and pitch)"); return; }
+        }
+        g_wide_src = &w;
+    }
+    ~WideGuard() { g_wide_src = nullptr; }
+};
+}  // namespace
+extern "C" int mshgnn_forward_src(const mshgnn_plan* p, int src_bytes, const void* const* src, const int64_t* src_pitch, void* const* x_rows, const int64_t* x_pitch,
+                                  const float* params, float* out, void* workspace, int64_t batch, int training, void* stream) {
+    if (!x_rows) return set_err(MSHGNN_EINVAL, "mshgnn_forward_src: x_rows is null (the plan-dtype rows the encoder materialises)");
+    WideGuard g(p, src_bytes, src, src_pitch, "mshgnn_forward_src");
+    if (g.rc) return g.rc;
+    return mshgnn_forward(p, x_rows, x_pitch, params, out, workspace, batch, training, stream);
+}
+extern "C" int mshgnn_step_mse_src(const mshgnn_plan* p, int src_bytes, const void* const* src, const int64_t* src_pitch, void* const* x_rows, const int64_t* x_pitch,
+                                   const float* params, const float* y, float* out, float* loss_out, float* grad_params, void* workspace, int64_t batch, void* stream) {
+    if (!x_rows) return set_err(MSHGNN_EINVAL, "mshgnn_step_mse_src: x_rows is null (the plan-dtype rows the encoder materialises)");
+    WideGuard g(p, src_bytes, src, src_pitch, "mshgnn_step_mse_src");
+    if (g.rc) return g.rc;
+    return mshgnn_step_mse(p, x_rows, x_pitch, params, y, out, loss_out, grad_params, workspace, batch, stream);
+}
+extern "C" int mshgnn_step_ce_src(const mshgnn_plan* p, int src_bytes, const void* const* src, const int64_t* src_pitch, void* const* x_rows, const int64_t* x_pitch,
+                                  const float* params, const int32_t* labels, float* out, float* loss_out, float* grad_params, void* workspace, int64_t batch, void* stream) {
+    if (!x_rows) return set_err(MSHGNN_EINVAL, "mshgnn_step_ce_src: x_rows is null (the plan-dtype rows the encoder materialises)");
+    WideGuard g(p, src_bytes, src, src_pitch, "mshgnn_step_ce_src");
+    if (g.rc) return g.rc;
+    return mshgnn_step_ce(p, x_rows, x_pitch, params, labels, out, loss_out, grad_params, workspace, batch, stream);
 }
 
 extern "C" int mshgnn_step_mse_phase(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, const float* y,

@@ -424,6 +424,58 @@ struct SeriesSrc {
     LabelArgs lab;                       // the batch's labels: computed by extra workgroups of the fused-gather encoder launch (lab.B == 0: none)
 };
 
+// WIDE SOURCE ROWS (mshgnn_*_src entry points): the encoder reads the reference's own tensors -- fp64 (the reference's default dtype, gnnLightning.py:1183) or fp32,
+// at their dense pitch -- converts in registers and writes the plan-dtype rows at the engine's pitch on the side (what the weight-gradient kernel reads
+// later): the separate cast + re-pitch pass over the batch (472 MB read + 118 MB written + 118 MB re-read at A1-C2, 8192 windows) disappears.
+// Loads are 8-byte units (one fp64 / two fp32 elements): a unit is either wholly inside its row or not requested at all (fp32: even widths), so nothing is
+// ever read past the end of the caller's tensor; odd fp32 widths (the 1-wide foot rows) take guarded element loads.
+struct WideSrc {
+    int bytes;                               // element size of the source rows: 8 (fp64) or 4 (fp32); 0: none
+    const void* p[MSHGNN_MAX_TYPES];         // per type: [B][n_t][pitch] source rows
+    int64_t pitch[MSHGNN_MAX_TYPES];         // elements
+};
+inline thread_local const WideSrc* g_wide_src = nullptr;      // set by the _src entry points around the plain call they forward to (host side, same thread)
+// 8 source elements held as 8-byte units -> 8 fp32 values (two f32x4); units past `nvalid` elements were not requested: zero
+template <int SB> __device__ __forceinline__ void wide_to_f32(const u32x2 (&u)[SB], int nvalid, f32x4& lo, f32x4& hi) {
+    float f[8];
+    if constexpr (SB == 8) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const double d = __builtin_bit_cast(double, u[e]);
+            f[e] = e < nvalid ? (float)d : 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = e < nvalid ? __builtin_bit_cast(float, u[e >> 1][e & 1]) : 0.f;
+    }
+    lo = f32x4{f[0], f[1], f[2], f[3]}; hi = f32x4{f[4], f[5], f[6], f[7]};
+}
+// request this thread's 8-element chunk [k0, k0 + 8) of a source row (row = first byte of the row; F = row width).  unit_ok (uniform per type): every 8-byte
+// unit is wholly valid or wholly invalid; invalid units re-read the row's first unit (never used).  Otherwise guarded element loads.
+template <int SB> __device__ __forceinline__ void wide_fetch(u32x2 (&u)[SB], const char* row, int k0, int F, bool unit_ok, bool row_ok) {
+    constexpr int EU = 8 / SB;      // elements per unit
+    if (unit_ok) {
+#pragma unroll
+        for (int i = 0; i < SB; ++i) {
+            const int e0 = k0 + i * EU;
+            u[i] = *reinterpret_cast<const u32x2*>(row + (size_t)(e0 + EU <= F ? e0 : 0) * SB);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < SB; ++i) {
+            u[i] = u32x2{0, 0};
+#pragma unroll
+            for (int j = 0; j < EU; ++j) {
+                const int e = k0 + i * EU + j;
+                if (row_ok && e < F) {
+                    if constexpr (SB == 8) u[i] = *reinterpret_cast<const u32x2*>(row + (size_t)e * 8);
+                    else u[i][j] = *reinterpret_cast<const unsigned*>(row + (size_t)e * 4);
+                }
+            }
+        }
+    }
+}
+
 // load up to EPC elements starting at p with the widest vector the alignment `vb` (bytes) allows
 template <typename T> __device__ __forceinline__ u32x4 load_chunk(const T* p, int nvalid, int vb) {
     constexpr int EPC = Prec<T>::EPC;

@@ -104,8 +104,11 @@ __device__ __forceinline__ void splice8f(u32x4& a0, u32x4& a1, const u32x4 b0, c
 // SERIES (with ALIGNED): the fp32 inputs are gathered from the sequence's resident series like the bf16 encoder's (k_enc_fwd<.., SERIES>): element k
 // of a node row = element starts[w] + k % T of run k / T -- two 4-byte-aligned 16-byte loads per (window, chunk), four and a splice where the chunk
 // straddles two runs -- and the materialised window rows are written on the side for the weight-gradient pass (a.x: the window buffers).
-template <bool ALIGNED, bool SERIES = false> __global__ __launch_bounds__(256) void k_enc_x3(EncArgs a, int n_img, SeriesSrc ser) {
+// SRC (8 / 4, with ALIGNED): the rows come from the caller's own fp64 / fp32 tensors at their dense pitch (WideSrc, mshgnn_device.hpp) and are also written to
+// a.x as fp32 rows at the engine's pitch for the weight-gradient kernel (mshgnn_*_src entry points)
+template <bool ALIGNED, bool SERIES = false, int SRC = 0> __global__ __launch_bounds__(256) void k_enc_x3(EncArgs a, int n_img, SeriesSrc ser, WideSrc wsrc) {
     static_assert(!SERIES || ALIGNED, "the series gather writes aligned window buffers");
+    static_assert(SRC == 0 || (ALIGNED && !SERIES), "wide source rows: aligned destination rows, no series gather");
     using P = P16;
     constexpr int MB = 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -144,6 +147,9 @@ template <bool ALIGNED, bool SERIES = false> __global__ __launch_bounds__(256) v
     P::AFrag af;
     const AOff<T16> ao(lane);
     u32x4 v[MB][2];                             // the 8 fp32 elements of the chunk (two 16-byte loads)
+    u32x2 wv8[SRC ? MB : 1][SRC ? SRC : 1];     // SRC: the chunk's 8 source elements as 8-byte units, untouched until the staging pass
+    const bool unit_ok = SRC == 8 || (F & 1) == 0;
+    const int64_t spitch = SRC ? wsrc.pitch[t] : 0;
     int srow[SERIES ? MB : 1]; int rfirst = 0;  // SERIES: first series row of this thread's window rows, the node row's first run
     if constexpr (SERIES) {
 #pragma unroll
@@ -178,6 +184,15 @@ template <bool ALIGNED, bool SERIES = false> __global__ __launch_bounds__(256) v
             }
             return;
         }
+        if constexpr (SRC > 0) {
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+                const int w = w0 + m * P::ROWS + r0;
+                const char* row = reinterpret_cast<const char*>(wsrc.p[t]) + ((size_t)min(w, a.B - 1) * nt + node) * spitch * SRC;
+                wide_fetch<SRC>(wv8[m], row, k0, F, unit_ok, w < a.B);
+            }
+            return;
+        }
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
             const int w = w0 + m * P::ROWS + r0;
@@ -205,8 +220,13 @@ template <bool ALIGNED, bool SERIES = false> __global__ __launch_bounds__(256) v
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
             u32x4 fa = v[m][0], fb = v[m][1];
+            if constexpr (SRC > 0) {      // fp64 -> fp32 (round to nearest even, as torch's .float()), or the fp32 units as they are; elements past the row: zero
+                f32x4 lo4, hi4;
+                wide_to_f32<SRC>(wv8[m], nv, lo4, hi4);
+                fa = __builtin_bit_cast(u32x4, lo4); fb = __builtin_bit_cast(u32x4, hi4);
+            } else
             if (kc + 1 == nkc) { fa = chunk_keep_first<float>(fa, nv); fb = chunk_keep_first<float>(fb, nv - 4); }     // only the last K chunk has pad columns
-            if constexpr (SERIES) {      // the materialised window row (raw values: the sign mask is applied by whoever reads it)
+            if constexpr (SERIES || SRC > 0) {      // the materialised window row (raw values: the sign mask is applied by whoever reads it)
                 const int w = w0 + m * P::ROWS + r0, k0 = kc * H + c * 8;
                 if (x != nullptr && w < a.B) {
                     float* dst = const_cast<float*>(x) + ((size_t)w * nt + node) * pitch + k0;
@@ -1142,7 +1162,7 @@ int x3_set_attrs(mshgnn_plan* p) {
     if ((rc = set_lds_attr(k_stack_fwd_x3<false>, flds)) || (rc = set_lds_attr(k_stack_fwd_x3<true>, flds)) || (rc = set_lds_attr(k_stack_bwd_x3, flds)) ||
         (rc = set_lds_attr(k_stack_step_x3<false>, flds)) || (rc = set_lds_attr(k_stack_step_x3<true>, flds)) ||
         (rc = set_lds_attr(k_enc_x3<true>, 8 * P16::BLK)) || (rc = set_lds_attr(k_enc_x3<false>, 8 * P16::BLK)) ||
-        (rc = set_lds_attr(k_enc_x3<true, true>, 8 * P16::BLK))) return rc;
+        (rc = set_lds_attr(k_enc_x3<true, true>, 8 * P16::BLK)) || (rc = set_lds_attr(k_enc_x3<true, false, 8>, 8 * P16::BLK)) || (rc = set_lds_attr(k_enc_x3<true, false, 4>, 8 * P16::BLK))) return rc;
     return MSHGNN_OK;
 }
 
@@ -1176,6 +1196,7 @@ int x3_forward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitc
         if (prep_use_tiled(a.n_packs)) hipLaunchKernelGGL((k_prep_tiled<__bf16, true>), dim3(prep_tiled_grid(a.n_packs, a.n_biases)), dim3(256), 0, st, a);
         else hipLaunchKernelGGL(k_prep_x3, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
     }
+    const WideSrc* wide = series ? nullptr : g_wide_src;      // (mshgnn_*_src: the caller's fp64 / fp32 rows; x = the fp32 rows to materialise)
     {   // 2. encoder (fp32 inputs)
         EncArgs a{};
         a.n_types = hp.NT; a.B = B; a.NN = hp.NN; a.tiles = (B + 63) / 64;
@@ -1214,10 +1235,15 @@ int x3_forward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitc
         if (series) {      // inputs gathered from the sequence's series; x = the window buffers the rows are materialised into
             if (!a.aligned) return set_err(MSHGNN_EINVAL, "the series gather writes 16-byte-aligned window buffers whose pitch is a multiple of 4");
             enc_grid += (unsigned)((series->lab.B + 255) / 256);      // the label workgroups
-            hipLaunchKernelGGL((k_enc_x3<true, true>), dim3(enc_grid), dim3(256), 8 * P16::BLK, st, a, hp.n_img, *series);
+            hipLaunchKernelGGL((k_enc_x3<true, true>), dim3(enc_grid), dim3(256), 8 * P16::BLK, st, a, hp.n_img, *series, WideSrc{});
         }
-        else if (a.aligned) hipLaunchKernelGGL(k_enc_x3<true>, dim3(enc_grid), dim3(256), 8 * P16::BLK, st, a, hp.n_img, SeriesSrc{});
-        else hipLaunchKernelGGL(k_enc_x3<false>, dim3(enc_grid), dim3(256), 8 * P16::BLK, st, a, hp.n_img, SeriesSrc{});
+        else if (wide) {      // the caller's fp64 / fp32 rows: converted by the encoder, fp32 rows written to x on the side
+            if (!a.aligned) return set_err(MSHGNN_EINVAL, "wide source rows: the fp32 rows need 16-byte alignment and a pitch that is a multiple of 4");
+            if (wide->bytes == 8) hipLaunchKernelGGL((k_enc_x3<true, false, 8>), dim3(enc_grid), dim3(256), 8 * P16::BLK, st, a, hp.n_img, SeriesSrc{}, *wide);
+            else hipLaunchKernelGGL((k_enc_x3<true, false, 4>), dim3(enc_grid), dim3(256), 8 * P16::BLK, st, a, hp.n_img, SeriesSrc{}, *wide);
+        }
+        else if (a.aligned) hipLaunchKernelGGL(k_enc_x3<true>, dim3(enc_grid), dim3(256), 8 * P16::BLK, st, a, hp.n_img, SeriesSrc{}, WideSrc{});
+        else hipLaunchKernelGGL(k_enc_x3<false>, dim3(enc_grid), dim3(256), 8 * P16::BLK, st, a, hp.n_img, SeriesSrc{}, WideSrc{});
     }
     {   // 3. all layers + decoder (+ MSE and decoder backward when y_fused)
         StackArgs a{};

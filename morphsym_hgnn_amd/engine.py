@@ -81,7 +81,7 @@ EXPORTS = [
     "mshgnn_metrics_regression", "mshgnn_metrics_classification", "mshgnn_grf_body_to_world", "mshgnn_assemble_windows",
     "mshgnn_backward_ce", "mshgnn_step_mse", "mshgnn_step_mse_phase",
     "mshgnn_step_mse_series", "mshgnn_step_ce_series", "mshgnn_step_ce", "mshgnn_op_gemm", "mshgnn_op_gemm_workspace", "mshgnn_op_aggregate", "mshgnn_op_colsum", "mshgnn_op_colsum_workspace",
-    "mshgnn_abi_version", "mshgnn_struct_size",
+    "mshgnn_abi_version", "mshgnn_struct_size", "mshgnn_forward_src", "mshgnn_step_mse_src", "mshgnn_step_ce_src",
     "mshgnn_comm_unique_id", "mshgnn_comm_create", "mshgnn_comm_destroy", "mshgnn_comm_allreduce_mean", "mshgnn_comm_allreduce_sum",
 ]
 ABI_VERSION = 5      # include/mshgnn.h MSHGNN_ABI_VERSION: the ctypes structures above mirror THAT header
@@ -159,6 +159,10 @@ def load_library():
     lib.mshgnn_op_colsum_workspace.restype = C.c_int64
     lib.mshgnn_op_colsum_workspace.argtypes = [C.c_int64, C.c_int64]
     lib.mshgnn_op_colsum.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+    src6 = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+    lib.mshgnn_forward_src.argtypes = src6 + [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+    lib.mshgnn_step_mse_src.argtypes = src6 + [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.mshgnn_step_ce_src.argtypes = src6 + [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.mshgnn_struct_size.restype = C.c_size_t
     lib.mshgnn_struct_size.argtypes = [C.c_int]
     lib.mshgnn_comm_unique_id.argtypes = [C.c_char_p, C.c_void_p]
@@ -298,6 +302,18 @@ def unflatten(spec: ModelSpec, flat: torch.Tensor) -> Dict[str, torch.Tensor]:
     return {k: flat[off:off + n].view(shapes[k]) for k, (off, n) in spec.param_offsets().items()}
 
 
+class WideInputs(list):
+    """What `Engine.cast_inputs` hands back for the reference's own device tensors (fp64, or fp32 at the dense pitch) on the bf16 / split plans: no cast
+    pass has run.  The list holds the engine's plan-dtype row buffers (what the weight-gradient kernel and any later backward read -- the encoder of
+    the next forward / step on this object WRITES them while it converts the source rows in registers: `mshgnn_*_src`); `.src` are the caller's
+    tensors, `.pending` says the rows have not been materialised yet.  The row buffers belong to the engine (one set per batch size): a later
+    `cast_inputs` of the same batch size reuses them, exactly as a later forward reuses the activation stash."""
+
+    def __init__(self, rows, src, src_bytes):
+        super().__init__(rows)
+        self.src, self.src_bytes, self.pending = list(src), int(src_bytes), True
+
+
 class Engine:
     """One compiled plan (topology x model dims x precision) on one GPU."""
 
@@ -324,6 +340,8 @@ class Engine:
         self._ws: Dict[Tuple[int, int], torch.Tensor] = {}
         self._tickets: Dict[int, int] = {}
         self._lay: Dict[Tuple[int, int], MshgnnWsLayout] = {}
+        self._rows: Dict[int, List[torch.Tensor]] = {}      # plan-dtype input rows the encoder materialises from wide source tensors (WideInputs)
+        self._pending_wide: Optional[WideInputs] = None     # the last WideInputs handed out whose rows have not been materialised yet
         self.types = spec.node_types
         self.n_out = spec.num_nodes[spec.out_type]
 
@@ -374,6 +392,9 @@ class Engine:
         """Reference-convention inputs ([B*n_t, F_t], any float dtype) -> plan-dtype device tensors.  The cast writes
         rows at the engine's pitch (`row_pitch`: 450 -> 512 bf16 elements for A1 joints, 900 -> 960 for the base nodes), so the kernels
         stream them with 16-byte loads and every K chunk is whole cache lines; the pad columns are never read as data."""
+        wide = self._wide_inputs(x_dict) if pad else None
+        if wide is not None:
+            return wide
         out = []
         for t in self.types:
             x = x_dict[t]
@@ -389,6 +410,58 @@ class Engine:
                 buf[:, F:].zero_()                           # pad columns: never read as data by the kernels, and never NaN for a future reader
                 out.append(buf)
         return out
+
+    def _wide_inputs(self, x_dict) -> Optional[WideInputs]:
+        """The no-cast route (bf16 and split plans of the LDS-resident kernels): every type arrives as a contiguous fp64 / fp32 tensor on this device
+        that the kernels cannot take as it is (fp64; or fp32 whose dense rows are not whole 16-byte chunks) -> the encoder reads it directly
+        (`mshgnn_forward_src` / `mshgnn_step_*_src`) and writes the plan-dtype rows into the engine's row buffers.  MSHGNN_WIDE_SRC=0: always cast."""
+        if self.generic or self.dtype not in ("bf16", "x3") or os.environ.get("MSHGNN_WIDE_SRC", "1") == "0":
+            return None
+        xs = [x_dict[t] for t in self.types]
+        dt = xs[0].dtype
+        if dt not in (torch.float64, torch.float32):
+            return None
+        rows = None
+        for t, x in zip(self.types, xs):
+            F = self.spec.widths[t]
+            if not (x.is_cuda and x.device == self.device and x.dtype == dt and x.dim() == 2 and x.is_contiguous() and x.shape[1] == F):
+                return None
+            if rows is None:
+                rows = x.shape[0] // self.spec.num_nodes[t]
+            if x.shape[0] != rows * self.spec.num_nodes[t] or x.data_ptr() % 8 or (dt == torch.float32 and F % 2 == 0 and (F * 4) % 8):
+                return None
+        if dt == self.torch_dtype and all((self.spec.widths[t] * 4) % 16 == 0 for t in self.types):
+            return None      # fp32 rows the kernels' 16-byte loaders take as they are
+        self._pending_wide = WideInputs(self._row_buffers(rows), xs, 8 if dt == torch.float64 else 4)
+        return self._pending_wide
+
+    def _rewrap(self, xs):
+        """A caller that unpacked a pending WideInputs into its row-buffer tensors (autograd Functions take `*xs`) still means the wide route: the row
+        buffers are the engine's own, recognised by address."""
+        w = self._pending_wide
+        if isinstance(xs, WideInputs) or w is None or not w.pending:
+            return xs
+        if len(xs) == len(w) and all(a.data_ptr() == b.data_ptr() for a, b in zip(xs, w)):
+            return w
+        return xs
+
+    def _row_buffers(self, B: int) -> List[torch.Tensor]:
+        """Plan-dtype input rows at the engine's pitch for batch size B, owned by the engine (zeroed once: pad columns and the rows of nodes the plan
+        never reads stay zero); kept for the batch sizes that have a workspace."""
+        bufs = self._rows.get(B)
+        if bufs is None:
+            bufs = [torch.zeros(B * self.spec.num_nodes[t], self.padded_width(t), dtype=self.torch_dtype, device=self.device) for t in self.types]
+            while len(self._rows) >= self.MAX_WORKSPACES:
+                del self._rows[next(iter(self._rows))]
+            self._rows[B] = bufs
+        return bufs
+
+    def _src_args(self, xs: "WideInputs"):
+        n = len(xs.src)
+        sp, spitch = (C.c_void_p * n)(), (C.c_int64 * n)()
+        for i, x in enumerate(xs.src):
+            sp[i], spitch[i] = x.data_ptr(), x.shape[1]
+        return xs.src_bytes, sp, spitch
 
     def _xptrs(self, xs: Sequence[torch.Tensor], B: int):
         ptrs = (C.c_void_p * len(xs))()
@@ -410,6 +483,7 @@ class Engine:
     # ---- hot path ------------------------------------------------------------------------------
     def forward(self, xs: Sequence[torch.Tensor], params_flat: torch.Tensor, B: int, training: bool = True,
                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        xs = self._rewrap(xs)
         self._check_flat(params_flat, "params_flat")
         ptrs, pitch = self._xptrs(xs, B)
         if out is None:
@@ -419,8 +493,14 @@ class Engine:
             self._tickets[B] = self._tickets.get(B, 0) + 1
         stream = torch.cuda.current_stream(self.device).cuda_stream
         with torch.cuda.device(self.device):
-            _check(self.lib, self.lib.mshgnn_forward(self._plan, ptrs, pitch, params_flat.data_ptr(), out.data_ptr(),
-                                                 ws.data_ptr(), B, int(training), stream), "mshgnn_forward")
+            if isinstance(xs, WideInputs) and xs.pending:      # the caller's fp64 / fp32 tensors: the encoder converts them and writes the plan-dtype rows `xs` holds
+                sb, sp, spitch = self._src_args(xs)
+                _check(self.lib, self.lib.mshgnn_forward_src(self._plan, sb, sp, spitch, ptrs, pitch, params_flat.data_ptr(), out.data_ptr(),
+                                                             ws.data_ptr(), B, int(training), stream), "mshgnn_forward_src")
+                xs.pending = False
+            else:
+                _check(self.lib, self.lib.mshgnn_forward(self._plan, ptrs, pitch, params_flat.data_ptr(), out.data_ptr(),
+                                                         ws.data_ptr(), B, int(training), stream), "mshgnn_forward")
         return out
 
     def backward(self, xs: Sequence[torch.Tensor], params_flat: torch.Tensor, grad_out: torch.Tensor, B: int,
@@ -463,6 +543,7 @@ class Engine:
                  grad_flat: Optional[torch.Tensor] = None, loss: Optional[torch.Tensor] = None):
         """One training step of the regression wrappers in one call (forward + MSE + backward, mshgnn_step_mse):
         returns (out, loss[1], grad_flat)."""
+        xs = self._rewrap(xs)
         self._check_flat(params_flat, "params_flat")
         ptrs, pitch = self._xptrs(xs, B)
         n = B * self.n_out * self.spec.out_channels
@@ -478,14 +559,21 @@ class Engine:
         self._tickets[B] = self._tickets.get(B, 0) + 1      # the activation stash of this batch size is overwritten
         stream = torch.cuda.current_stream(self.device).cuda_stream
         with torch.cuda.device(self.device):
-            _check(self.lib, self.lib.mshgnn_step_mse(self._plan, ptrs, pitch, params_flat.data_ptr(), y.data_ptr(), out.data_ptr(), loss.data_ptr(),
-                                                  grad_flat.data_ptr(), ws.data_ptr(), B, stream), "mshgnn_step_mse")
+            if isinstance(xs, WideInputs) and xs.pending:
+                sb, sp, spitch = self._src_args(xs)
+                _check(self.lib, self.lib.mshgnn_step_mse_src(self._plan, sb, sp, spitch, ptrs, pitch, params_flat.data_ptr(), y.data_ptr(), out.data_ptr(),
+                                                              loss.data_ptr(), grad_flat.data_ptr(), ws.data_ptr(), B, stream), "mshgnn_step_mse_src")
+                xs.pending = False
+            else:
+                _check(self.lib, self.lib.mshgnn_step_mse(self._plan, ptrs, pitch, params_flat.data_ptr(), y.data_ptr(), out.data_ptr(), loss.data_ptr(),
+                                                          grad_flat.data_ptr(), ws.data_ptr(), B, stream), "mshgnn_step_mse")
         return out, loss, grad_flat
 
     def step_ce(self, xs: Sequence[torch.Tensor], params_flat: torch.Tensor, labels: torch.Tensor, B: int, out: Optional[torch.Tensor] = None,
                 grad_flat: Optional[torch.Tensor] = None, loss: Optional[torch.Tensor] = None):
         """One training step of the classification wrappers in one call (forward + cross entropy + backward, mshgnn_step_ce):
         returns (out, loss[1], grad_flat).  labels: int32 [B, n_out] in {0, 1}."""
+        xs = self._rewrap(xs)
         self._check_flat(params_flat, "params_flat")
         ptrs, pitch = self._xptrs(xs, B)
         if labels.dtype != torch.int32 or labels.numel() != B * self.n_out or not labels.is_contiguous():
@@ -500,8 +588,14 @@ class Engine:
         self._tickets[B] = self._tickets.get(B, 0) + 1
         stream = torch.cuda.current_stream(self.device).cuda_stream
         with torch.cuda.device(self.device):
-            _check(self.lib, self.lib.mshgnn_step_ce(self._plan, ptrs, pitch, params_flat.data_ptr(), labels.data_ptr(), out.data_ptr(), loss.data_ptr(),
-                                                 grad_flat.data_ptr(), ws.data_ptr(), B, stream), "mshgnn_step_ce")
+            if isinstance(xs, WideInputs) and xs.pending:
+                sb, sp, spitch = self._src_args(xs)
+                _check(self.lib, self.lib.mshgnn_step_ce_src(self._plan, sb, sp, spitch, ptrs, pitch, params_flat.data_ptr(), labels.data_ptr(), out.data_ptr(),
+                                                             loss.data_ptr(), grad_flat.data_ptr(), ws.data_ptr(), B, stream), "mshgnn_step_ce_src")
+                xs.pending = False
+            else:
+                _check(self.lib, self.lib.mshgnn_step_ce(self._plan, ptrs, pitch, params_flat.data_ptr(), labels.data_ptr(), out.data_ptr(), loss.data_ptr(),
+                                                         grad_flat.data_ptr(), ws.data_ptr(), B, stream), "mshgnn_step_ce")
         return out, loss, grad_flat
 
     def step_ce_series(self, store, starts: torch.Tensor, params_flat: torch.Tensor, out: Optional[torch.Tensor] = None,

@@ -281,7 +281,7 @@ def test_engine_gradient_is_exactly_zero_outside_the_live_elements(dtype, layers
     """What makes the live-element exchange exact on the real engine: every element of the flat gradient that `spec.live_gradient_index` leaves out is an exact
     zero after a step (A1-C2 below the graph's diameter: the base nodes cannot reach the feet), and the live part is not all zero -- on the LDS-resident
     kernels (bf16 / split / fp32 plans), the cross-entropy step, the generic-width engine (hidden 256 / 512: FIN_ZERO ops of mshgnn_gen_plan.hpp) and at a
-    depth where base_transform is live (5 layers: nothing is dead, the index is the whole buffer)."""
+    depth where the base nodes and base_transform are live in the first layers (5 layers: the last layers still have dead relations)."""
     from morphsym_hgnn_amd import engine as eng
     spec = helpers.make_spec("c2", "a1-c2", "a1-c2", hidden, layers, regression=regression)
     B = 50
@@ -297,7 +297,6 @@ def test_engine_gradient_is_exactly_zero_outside_the_live_elements(dtype, layers
     dead = torch.ones(g.numel(), dtype=torch.bool, device=g.device)
     dead[ex.index] = False
     assert 0.0 < ex.fraction <= 1.0 and int(dead.sum()) == g.numel() - ex.index.numel()
-    assert (ex.fraction < 1.0) == (layers < 4)
     if bool(dead.any()):
         assert float(g[dead].abs().max()) == 0.0
     assert float(g[ex.index].abs().max()) > 0.0
