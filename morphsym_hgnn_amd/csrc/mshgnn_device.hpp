@@ -446,7 +446,11 @@ template <int SB> __device__ __forceinline__ void wide_to_f32(const u32x2 (&u)[S
         }
     } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = e < nvalid ? __builtin_bit_cast(float, u[e >> 1][e & 1]) : 0.f;
+        for (int i = 0; i < 4; ++i) {      // (the whole unit is cast: hipcc 7.2 miscompiles __builtin_bit_cast applied to ONE element of a vector)
+            const f32x2 v = __builtin_bit_cast(f32x2, u[i]);
+            f[2 * i] = 2 * i < nvalid ? v[0] : 0.f;
+            f[2 * i + 1] = 2 * i + 1 < nvalid ? v[1] : 0.f;
+        }
     }
     lo = f32x4{f[0], f[1], f[2], f[3]}; hi = f32x4{f[4], f[5], f[6], f[7]};
 }
