@@ -356,7 +356,7 @@ int mshgnn_op_colsum(const float* X, int64_t ldx, float* out, int64_t M, int64_t
  * The reference's datasets hand the model fp64 tensors at the dense pitch (torch.set_default_dtype(float64), gnnLightning.py:1183; x_dict[type] is
  * [B n_t, F_t]).  These three entry points are mshgnn_forward / mshgnn_step_mse / mshgnn_step_ce for such tensors: src[t] = device pointer to the caller's
  * rows, src_bytes = 8 (fp64) or 4 (fp32), src_pitch[t] in elements (NULL = dense).  The encoder converts in registers (fp64 -> fp32 -> bf16, round to nearest
- * even at each step -- the values torch's host-side .to() produces; its device-side fp64 -> bf16 copy rounds once and differs by one bf16 ulp on ~3 values in a million) and WRITES the plan-dtype rows into x_rows[t] ([batch][n_t][x_pitch[t]], 16-byte aligned, pitch a
+ * even at each step: exactly the values torch's .to() produces, two roundings included) and WRITES the plan-dtype rows into x_rows[t] ([batch][n_t][x_pitch[t]], 16-byte aligned, pitch a
  * whole number of 16-byte chunks: what mshgnn_backward* and the weight-gradient pass of the step read) for the nodes the plan reads -- instead of a separate
  * cast + re-pitch pass over the batch (A1-C2, 8192 windows: 472 MB read + 118 MB written + 118 MB re-read).  bf16 and split-bf16 plans of the LDS-resident
  * kernels; MSHGNN_EUNSUPPORTED on the fp32 plan and the generic-width engine (cast there).  fp32 rows of an even width must start 8-byte aligned.      */

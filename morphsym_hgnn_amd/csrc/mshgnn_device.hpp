@@ -442,7 +442,11 @@ template <int SB> __device__ __forceinline__ void wide_to_f32(const u32x2 (&u)[S
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const double d = __builtin_bit_cast(double, u[e]);
-            f[e] = e < nvalid ? (float)d : 0.f;
+            float fe = (float)d;
+            // the fp32 value must EXIST: torch rounds fp64 -> fp32 -> bf16 (two roundings, host and device alike); without this the compiler folds the two
+            // conversions into one fp64 -> bf16 rounding, which differs on fp32 values that land exactly between two bf16 (seen: -0x1.22ffff259b41fp-1)
+            asm volatile("" : "+v"(fe));
+            f[e] = e < nvalid ? fe : 0.f;
         }
     } else {
 #pragma unroll

@@ -1,7 +1,7 @@
 """The reference's own input tensors, uncast (mshgnn_forward_src / mshgnn_step_mse_src / mshgnn_step_ce_src, engine.WideInputs): fp64 -- the reference's default
 dtype, gnnLightning.py:1183 -- or fp32 device tensors at the dense pitch are converted by the encoder in registers, which also writes the plan-dtype rows
 the weight-gradient pass reads.  The conversions are the ones torch's .to() makes (round to nearest even, fp64 -> fp32 -> bf16), so the route is
-BIT-IDENTICAL to cast-then-step on every output, loss, gradient and materialised row (bf16 plan from fp64: to the cast of the tensors' .float()); against the oracle it therefore inherits the cast route's parity
+BIT-IDENTICAL to cast-then-step on every output, loss, gradient and materialised row; against the oracle it therefore inherits the cast route's parity
 (tests/test_x3_gpu.py, tests/test_bf16_emulation.py), which is re-checked here on the golden vectors for the parity plan."""
 import pytest
 import torch
@@ -32,10 +32,7 @@ def test_uncast_inputs_are_bit_identical_to_cast_then_step(name, dtype, src):
     e = eng.Engine(spec, dtype)
     flat = eng.flatten_params(spec, params, e.device)
     x_src = {k: v.to(src) for k, v in x_dict.items()}
-    # the cast + re-pitch pass (host tensors).  bf16 plan from fp64: the encoder rounds fp64 -> fp32 -> bf16 (nearest even at each step, what torch's CPU
-    # conversion does); torch's DEVICE copy kernel rounds fp64 -> bf16 once, which differs by one bf16 ulp on ~3 values in a million -- the reference of the
-    # bit-identity check therefore goes through .float() (measured: one of 266 000 values of the B = 37 case, outputs within 1e-3)
-    xs_cast = e.cast_inputs({k: v.float() for k, v in x_src.items()} if dtype == "bf16" else x_src)
+    xs_cast = e.cast_inputs(x_src)                                         # host tensors: the cast + re-pitch pass (torch rounds fp64 -> fp32 -> bf16, and so does the encoder)
     assert not isinstance(xs_cast, eng.WideInputs)
     xw = e.cast_inputs({k: v.to(e.device) for k, v in x_src.items()})      # device tensors at the reference's pitch: no cast pass
     if dtype == "x3" and src == torch.float32 and all((spec.widths[t] * 4) % 16 == 0 for t in e.types):

@@ -27,3 +27,13 @@ d0 = (X0a.float() - X0b.float()).abs()
 print("X0 diff per node", d0.amax(dim=(0, 2)).tolist() if d0.dim() == 3 else d0.max())
 bad = (d0 > 0).nonzero()
 print("X0 bad windows", sorted(set(bad[:, 0].tolist()))[:40], "nodes", sorted(set(bad[:, 1].tolist())))
+t = "joint"; i = e.types.index(t)
+n, F = spec.num_nodes[t], spec.widths[t]
+a = xs_cast[i].view(B, n, -1)[:, :, :F]; b = list(xw)[i].view(B, n, -1)[:, :, :F]
+bad = (a != b).nonzero()
+bad = bad[(bad[:, 1] == 1)]
+xj = x_dict[t].view(B, n, F)
+for w_, n_, k_ in bad[:4].tolist():
+    d = xj[w_, n_, k_]
+    print("elem", w_, n_, k_, d.item().hex(), "cpu->bf16", d.to(torch.bfloat16).item(), "cpu f32", d.float().item().hex(), "f32->bf16 cpu", d.float().to(torch.bfloat16).item(),
+          "gpu f64->bf16", d.cuda().to(torch.bfloat16).item(), "gpu f32->bf16", d.float().cuda().to(torch.bfloat16).item(), "cast path", a[w_, n_, k_].item(), "kernel", b[w_, n_, k_].item())
