@@ -151,9 +151,9 @@ typedef struct mshgnn_kernel_stat {
 const char* mshgnn_last_error(void);
 const char* mshgnn_version(void);
 /* ABI guard for callers that keep their own copy of this header: MSHGNN_ABI_VERSION changes whenever a struct below changes size or meaning (5: mshgnn_info
- * gained bytes_in_live; kernel_sets bits 3 / 4 retired), and the sizes the LIBRARY was built with can be compared with the caller's sizeof() before any
+ * gained bytes_in_live, kernel_sets bits 3 / 4 retired; 6: mshgnn_window_desc gained run_ptrs_ready), and the sizes the LIBRARY was built with can be compared with the caller's sizeof() before any
  * struct crosses the boundary -- mshgnn_plan_info / mshgnn_workspace_layout write sizeof(struct) bytes through the pointer they are given.                */
-#define MSHGNN_ABI_VERSION 5
+#define MSHGNN_ABI_VERSION 6
 int mshgnn_abi_version(void);
 size_t mshgnn_struct_size(int which);      /* 0: mshgnn_desc, 1: mshgnn_info, 2: mshgnn_ws_layout, 3: mshgnn_window_desc, 4: mshgnn_kernel_stat; else 0 */
 
@@ -302,6 +302,10 @@ typedef struct mshgnn_window_desc {
     const int32_t* rows;
     int32_t n_label, label_src, label_rotate, quat_src;      /* quat_src = -1: none */
     const int32_t* label_cols;
+    int32_t run_ptrs_ready;   /* mshgnn_step_*_series: != 0 = the caller states that the run_ptrs scratch still holds what an earlier call with THIS descriptor and
+                               * THESE source arrays wrote there (the runs' column pointers depend on nothing else): the one-workgroup launch that resolves them
+                               * in front of the encoder (4.8 us) is skipped.  0: resolve them (always safe).                                       */
+    int32_t reserved_;
 } mshgnn_window_desc;
 
 int mshgnn_assemble_windows(const mshgnn_window_desc* desc, const float* const* src, const int64_t* src_cstride,

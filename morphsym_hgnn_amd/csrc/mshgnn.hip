@@ -779,7 +779,7 @@ template <typename T, bool STEP> __device__ __forceinline__ void stack_fwd_body(
                                     __builtin_bit_cast(float, r[3] << 16), __builtin_bit_cast(float, r[3] & 0xffff0000u)};
                     }
                     lds_store_oct<T>(smem, n, win, col, y0, y1);
-                    if (train && w_ok && !ABL(a.dbg & 16)) store_oct(xo + act_idx(w, n, B) + col, y0, y1);
+                    if (train && w_ok && !ABL(a.dbg & 16) && !(STEP && l + 1 == a.L)) store_oct(xo + act_idx(w, n, B) + col, y0, y1);      // (X_L of a one-launch step is read by nobody: the decoder's gradients come from the tile in LDS)
                 }
             }
         }
@@ -910,7 +910,7 @@ __device__ __forceinline__ void slab_group_fwd(const StackArgs& a, const FHdr& f
 // write one group's new activations: LDS block, stash, relu bytes
 template <typename T, int HS, int Q0>
 __device__ __forceinline__ void slab_group_store(const StackArgs& a, const FHdr& fh, char* smem, int wn, int lane, int slot_arr, int l,
-                                                 const u32x4 (&keep)[HS], const unsigned (&bits)[(HS + 3) / 4]) {
+                                                 const u32x4 (&keep)[HS], const unsigned (&bits)[(HS + 3) / 4], bool stash_x = true) {
     using P = Prec<T>;
     const int win = c_win(lane), col = wn * 32 + c_oct(lane), w = blockIdx.x * P::ROWS + win;
     T* xo = reinterpret_cast<T*>(a.ws + a.x_off[l + 1]);
@@ -923,7 +923,7 @@ __device__ __forceinline__ void slab_group_store(const StackArgs& a, const FHdr&
             *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(n, win, col / P::EPC)) = keep[u];
             if (a.training) {
                 if (kind == NK_RELU) maskbytes[relu_tile_base(n, a.B, blockIdx.x, wn) + lane] = (uint8_t)(bits[u >> 2] >> (8 * (u & 3)));
-                if (w < a.B) *reinterpret_cast<u32x4*>(xo + act_idx(w, n, a.B) + col) = keep[u];
+                if (w < a.B && stash_x) *reinterpret_cast<u32x4*>(xo + act_idx(w, n, a.B) + col) = keep[u];
             }
         }
     }
@@ -979,8 +979,9 @@ template <typename T, int NM, int HB, bool STEP> __device__ __forceinline__ void
         __syncthreads();   // every wave is done reading X_l: the node blocks may be overwritten
         FS_STAMP(4 + 4 * l);
         fhn.settle(); wan.settle(); wbn.settle();      // the next header / programs have landed before the stores go out (no drain at the top of the next layer)
-        slab_group_store<T, SL_HA, 0>(a, fh, smem, wn, lane, FH_SLOTA, l, keepA, bitsA);
-        slab_group_store<T, HB, SL_HA>(a, fh, smem, wn, lane, FH_SLOTB, l, keepB, bitsB);
+        const bool stash_x = !(STEP && l + 1 == a.L);      // X_L of a one-launch step is read by nobody (the decoder's gradients come from the tile in LDS)
+        slab_group_store<T, SL_HA, 0>(a, fh, smem, wn, lane, FH_SLOTA, l, keepA, bitsA, stash_x);
+        slab_group_store<T, HB, SL_HA>(a, fh, smem, wn, lane, FH_SLOTB, l, keepB, bitsB, stash_x);
         __syncthreads();
         FS_STAMP(5 + 4 * l);
     }
@@ -2638,6 +2639,12 @@ extern "C" int mshgnn_step_ce(const mshgnn_plan* p, const void* const* x, const 
         if (rc) return rc;
         return backward_impl<__bf16>(p, x, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, st, out, nullptr, loss_out, labels, true, -1, nullptr, stack_done);
     }
+    if (!p->gen && p->hp.d.dtype == MSHGNN_BF16X3) {      // split plan: decoder, cross entropy and decoder backward in the tail of its fused forward kernel as well
+        bool stack_done = false;
+        int rc = x3_forward(p, x, x_pitch, params, out, (char*)workspace, batch, 1, st, nullptr, nullptr, &stack_done, labels);
+        if (rc) return rc;
+        return x3_backward(p, x, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, st, out, nullptr, loss_out, labels, true, -1, stack_done);
+    }
     int rc = mshgnn_forward(p, x, x_pitch, params, out, workspace, batch, 1, stream);
     if (rc) return rc;
     return mshgnn_backward_ce(p, x, x_pitch, params, out, labels, loss_out, grad_params, workspace, batch, stream);
@@ -3455,7 +3462,8 @@ static int step_series(const mshgnn_plan* p, const mshgnn_window_desc* d, const 
     if (d->label_rotate && (d->n_label % 3 != 0 || d->quat_src < 0)) return set_err(MSHGNN_EINVAL, "label rotation needs 3-D labels and a quaternion source");
     static_assert(WIN_MAX_RUNS <= 256, "k_series_run_ptrs resolves the runs in one 256-thread workgroup");
     if (ce && d->label_rotate) return set_err(MSHGNN_EINVAL, "mshgnn_step_ce_series: contact labels are not rotated");
-    hipLaunchKernelGGL(k_series_run_ptrs, dim3(1), dim3(256), 0, st, d->runs, d->n_runs, wa, x3 ? 4 : 2, reinterpret_cast<unsigned long long*>(run_ptrs));
+    if (!d->run_ptrs_ready)      // (the caller vouches for the scratch's contents otherwise: same descriptor, same source arrays as the call that filled it)
+        hipLaunchKernelGGL(k_series_run_ptrs, dim3(1), dim3(256), 0, st, d->runs, d->n_runs, wa, x3 ? 4 : 2, reinterpret_cast<unsigned long long*>(run_ptrs));
     SeriesSrc ser{};
     {   // labels: extra workgroups of the encoder launch
         LabelArgs& l = ser.lab;
@@ -3468,10 +3476,10 @@ static int step_series(const mshgnn_plan* p, const mshgnn_window_desc* d, const 
     { int r0 = 0; for (int t = 0; t < d->n_types; ++t) { ser.row0[t] = r0; r0 += d->type_nodes[t]; } }
     if (x3) {      // (the split plan fuses the MSE into its forward kernel's tail; cross entropy: forward, then the fused-loss backward)
         bool x3_stack_done = false;
-        int rc = x3_forward(p, x_out, x_pitch, params, out, (char*)workspace, batch, 1, st, ce ? nullptr : y_out, &ser, &x3_stack_done);
+        int rc = x3_forward(p, x_out, x_pitch, params, out, (char*)workspace, batch, 1, st, ce ? nullptr : y_out, &ser, &x3_stack_done, ce ? labels_out : nullptr);
         if (rc) return rc;
         return x3_backward(p, x_out, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, st, out, ce ? nullptr : y_out, loss_out,
-                           ce ? labels_out : nullptr, !ce, -1, x3_stack_done);
+                           ce ? labels_out : nullptr, true, -1, x3_stack_done);
     }
     bool stack_done = false;
     int rc = forward_impl<__bf16>(p, x_out, x_pitch, params, out, (char*)workspace, batch, 1, st, ce ? nullptr : y_out, &ser, ce ? labels_out : nullptr, &stack_done);

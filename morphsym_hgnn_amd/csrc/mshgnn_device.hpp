@@ -816,6 +816,9 @@ __device__ __forceinline__ void fs_run(const FProg& wp, typename Prec<T>::Acc (&
 #else
 #define FS_SEGCLK(i) do { } while (0)
 #endif
+#ifdef MSHGNN_MAC_PRIO
+    __builtin_amdgcn_s_setprio(MSHGNN_MAC_PRIO);      // (experiment: the MAC phase's wave wins issue arbitration against the co-resident workgroup's epilogue wave)
+#endif
     for (int sgi = 0; sgi < nseg; sgi += 2) {
         load_bfrag<T>(bfb, wpack, wp.pack(min(sgi + 1, nseg - 1)), wn, lane);
         FS_SEGCLK(sgi);
@@ -827,6 +830,9 @@ __device__ __forceinline__ void fs_run(const FProg& wp, typename Prec<T>::Acc (&
         }
     }
     FS_SEGCLK(nseg);
+#ifdef MSHGNN_MAC_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
 }
 
 // decoder (+ fused wrapper MSE and decoder backward) on the X_L tile in LDS: shared tail of k_stack_fwd / k_slab_fwd
@@ -1132,7 +1138,8 @@ int run_finalize(const mshgnn_plan* p, const mshgnn_ws_layout& lay, char* ws, fl
 // split-bf16 parity plan (mshgnn_x3.hip)
 int x3_set_attrs(mshgnn_plan* p);
 int x3_forward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, float* out, char* ws, int64_t batch,
-               int training, hipStream_t st, const float* y_fused, const SeriesSrc* series = nullptr, bool* stack_step_done = nullptr);
+               int training, hipStream_t st, const float* y_fused, const SeriesSrc* series = nullptr, bool* stack_step_done = nullptr,
+               const int32_t* labels_fused = nullptr);
 int x3_backward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, const float* gout, float* gparams, char* ws,
                 int64_t batch, hipStream_t st, const float* out, const float* y, float* loss, const int32_t* labels, bool dec_done, int gw_phase, bool stack_done = false);
 int x3_launch_prep(const PrepArgs& a, hipStream_t st);

@@ -468,7 +468,7 @@ template <bool ALIAS, bool STEP> __device__ __forceinline__ void stack_fwd_x3_bo
                     split_oct(y0, y1, hi, lo);
                     *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(n, win, col / P::EPC)) = hi;
                     *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(LO + n, win, col / P::EPC)) = lo;
-                    if (train && w_ok) {
+                    if (train && w_ok && !(STEP && l + 1 == a.L)) {      // (X_L of a one-launch step is read by nobody)
                         T* q = xo + x3_idx(w, n, B) + col;
                         *reinterpret_cast<u32x4*>(q) = hi;
                         *reinterpret_cast<u32x4*>(q + H) = lo;
@@ -1177,7 +1177,7 @@ static void x3_stack_args(const mshgnn_plan* p, const mshgnn_ws_layout& lay, cha
 }
 
 int x3_forward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, float* out, char* ws, int64_t batch,
-               int training, hipStream_t st, const float* y_fused, const SeriesSrc* series, bool* stack_step_done) {
+               int training, hipStream_t st, const float* y_fused, const SeriesSrc* series, bool* stack_step_done, const int32_t* labels_fused) {
     const HostPlan& hp = p->hp;
     const mshgnn_desc& d = hp.d;
     mshgnn_ws_layout lay; layout_workspace(hp, batch, training, &lay);
@@ -1255,12 +1255,15 @@ int x3_forward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitc
         if (y_fused) {
             a.y = y_fused; a.dec_slabs = reinterpret_cast<float*>(ws + lay.dec_slabs);
             a.inv_n = 1.0f / (float)((int64_t)B * a.n_out * a.dout);
+        } else if (labels_fused) {      // mshgnn_step_ce: cross entropy over the per-foot logit pairs, mean over B * n_out rows (the tail is the bf16 plan's)
+            a.labels = labels_fused; a.dec_slabs = reinterpret_cast<float*>(ws + lay.dec_slabs);
+            a.inv_n = 1.0f / (float)((int64_t)B * a.n_out);
         }
         const int tiles = (B + P16::ROWS - 1) / P16::ROWS;
         a.stamps = stamp_ptr("MSHGNN_STAMPS");
         // one-call step: the backward sweep in the same launch (the tail's reduction scratch, one decoder slab per wave at the start of LDS, must end below the
         // out-type nodes' blocks)
-        const bool step = stack_step_done && y_fused && p->use_step && (size_t)a.node0 * P16::BLK >= (size_t)(LAYER_THREADS / 64) * DEC_SLAB_FLOATS * sizeof(float);
+        const bool step = stack_step_done && (y_fused || labels_fused) && p->use_step && (size_t)a.node0 * P16::BLK >= (size_t)(LAYER_THREADS / 64) * DEC_SLAB_FLOATS * sizeof(float);
         ProfScope ps(p, step ? hp.ks_stack_step : hp.ks_stack_fwd, st);
         if (step) {
             a.mask0_off = lay.dd[0];

@@ -63,7 +63,7 @@ class MshgnnWindowDesc(C.Structure):
         ("type_nodes", C.c_int32 * 4), ("type_width", C.c_int32 * 4),
         ("n_src", C.c_int32), ("n_runs", C.c_int32), ("n_rows", C.c_int32), ("fast_layout", C.c_int32), ("runs", C.c_void_p), ("rows", C.c_void_p),
         ("n_label", C.c_int32), ("label_src", C.c_int32), ("label_rotate", C.c_int32), ("quat_src", C.c_int32),
-        ("label_cols", C.c_void_p),
+        ("label_cols", C.c_void_p), ("run_ptrs_ready", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 
@@ -84,7 +84,7 @@ EXPORTS = [
     "mshgnn_abi_version", "mshgnn_struct_size", "mshgnn_forward_src", "mshgnn_step_mse_src", "mshgnn_step_ce_src",
     "mshgnn_comm_unique_id", "mshgnn_comm_create", "mshgnn_comm_destroy", "mshgnn_comm_allreduce_mean", "mshgnn_comm_allreduce_sum",
 ]
-ABI_VERSION = 5      # include/mshgnn.h MSHGNN_ABI_VERSION: the ctypes structures above mirror THAT header
+ABI_VERSION = 6      # include/mshgnn.h MSHGNN_ABI_VERSION: the ctypes structures above mirror THAT header
 
 _lib = None
 
@@ -641,6 +641,11 @@ class Engine:
         ws = self.workspace(B, True)
         self._tickets[B] = self._tickets.get(B, 0) + 1
         stream = torch.cuda.current_stream(self.device).cuda_stream
+        # the runs' column pointers in the store's scratch depend only on the series' addresses and the element size: resolved by the first step of this
+        # store on this stream at this storage, vouched for afterwards (mshgnn_window_desc.run_ptrs_ready: one launch less in front of every encoder)
+        key = (self.storage == "x3", stream, tuple(a.data_ptr() for a in store.series))
+        store.desc.run_ptrs_ready = 1 if getattr(store, "_run_ptrs_key", None) == key and os.environ.get("MSHGNN_RUN_PTRS_CACHE", "1") != "0" else 0
+        store._run_ptrs_key = key
         with torch.cuda.device(self.device):
             if ce:
                 labels = torch.empty(B, self.n_out, dtype=torch.int32, device=self.device)

@@ -311,7 +311,7 @@ def run_step_case(spec, x_dict, y, params, B, dtype="x3", device="cuda:0", decis
 
     sl = node_slices(spec)
     liv, need = spec.node_liveness()
-    for l in range(spec.num_layers + 1):
+    for l in range(spec.num_layers):      # (X_L is not stashed by a one-launch step: nobody reads it -- the output and the decoder's gradients cover it)
         got = e.hidden_state(B, l)
         ref = dense_hidden(spec, o_hidden[l], B)
         nodes = need[0] if l == 0 else liv[l - 1]
