@@ -797,6 +797,7 @@ def main():
         "overlap": wl.overlap_choice or {"mode": args.overlap, "two_phase": bool(wl.overlap)},
         "roofline": roof, "kernel_us": kernels,
         "algorithmic_flops_per_window": wl.e.info.flops_fwd + wl.e.info.flops_bwd,
+        "flat_gradient_bytes": 4 * spec.flat_size(),
         "loss": loss,
     }
     res["liveness"] = {"node_level": os.environ.get("MSHGNN_PRUNE", "1") != "0",

@@ -14,7 +14,7 @@ def per_kernel(pattern, counter):
 def short(name):
     for key, s in [("k_prep", "prep"), ("k_enc_fwd", "enc_fwd"), ("k_enc_x3", "enc_fwd"), ("k_gstep", "gstep"), ("k_ggradw", "ggradw"), ("k_stack_fwd", "stack_fwd"), ("k_stack_bwd", "stack_bwd"), ("k_slab_step", "stack_step"), ("k_stack_step", "stack_step"), ("k_slab_fwd", "stack_fwd"), ("k_slab_bwd", "stack_bwd"), ("k_eng_fwd", "stack_fwd"), ("k_eng_bwd", "stack_bwd"), ("k_wide_fwd", "stack_fwd"), ("k_wide_bwd", "stack_bwd"),
                    ("k_layer_fwd", "layer_fwd"), ("k_dec_fwd", "dec_fwd"),
-                   ("k_dec_bwd", "dec_bwd"), ("k_layer_bwd", "layer_bwd"), ("k_gradw", "gradw"), ("k_finalize", "finalize"), ("k_mse", "mse")]:
+                   ("k_dec_bwd", "dec_bwd"), ("k_layer_bwd", "layer_bwd"), ("k_gradw", "gradw"), ("k_finalize", "finalize"), ("k_gfinalize", "gfinalize"), ("k_mse", "mse")]:
         if key in name:
             return s
     return None
@@ -32,10 +32,28 @@ if __name__ == "__main__":
     for s, (f, w, n) in tot.items():
         out[s] = {"fetch_bytes": 2.0 * f / n * 1024.0, "write_bytes": w / n * 1024.0, "launches": n}
         out[s]["hbm_bytes"] = out[s]["fetch_bytes"] + out[s]["write_bytes"]
+    # WRITE_SIZE known answer: k_finalize writes every element of the flat fp32 gradient exactly once and nothing else of size (bench line key
+    # flat_gradient_bytes).  Some boxes of the pool report WRITE_SIZE ~1.30x high for EVERY kernel of a run (round 5: finalize 5.2 MB for a 3.98 MB
+    # buffer, the stack launch's stashes 169 MB for 130 MB, while FETCH_SIZE agrees to 0.1 % with round 4's passes) -- when the finalize figure is off by
+    # more than 5 %, every write figure of the run is scaled by known / measured and the raw value is kept beside it.
+    scale = 1.0
+    if len(sys.argv) > 3:
+        try:
+            known = float(json.loads(open(sys.argv[3]).read().strip().splitlines()[-1])["flat_gradient_bytes"])
+            fin = out.get("finalize", {}).get("write_bytes") or out.get("gfinalize", {}).get("write_bytes")
+            if fin and abs(fin / known - 1.0) > 0.05:
+                scale = known / fin
+        except Exception:  # noqa: BLE001
+            pass
+    if scale != 1.0:
+        for s_, o in out.items():
+            o["write_bytes_raw"] = o["write_bytes"]
+            o["write_bytes"] = o["write_bytes"] * scale
+            o["hbm_bytes"] = o["fetch_bytes"] + o["write_bytes"]
     import os
     cfile = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), ".build_commit")      # written before the snapshot leaves the build container
     commit = open(cfile).read().strip() if os.path.exists(cfile) else None
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from bench import source_hash
-    json.dump({**({"commit": commit} if commit else {}), "source_hash": source_hash(), "note": "per launch, averaged over launches (layer_fwd / layer_bwd: averaged over the L layers); "
+    json.dump({**({"commit": commit} if commit else {}), "source_hash": source_hash(), **({"write_scale": scale, "write_scale_note": "WRITE_SIZE of this run calibrated on k_finalize's known answer (the flat gradient, written once)"} if scale != 1.0 else {}), "note": "per launch, averaged over launches (layer_fwd / layer_bwd: averaged over the L layers); "
                        "FETCH_SIZE x2 (gfx950), KiB -> bytes", "kernels": out}, sys.stdout, indent=1)
