@@ -197,7 +197,7 @@ def flat_data_parallel(module, group=None, weight_by_windows: bool = False, live
     (`exchange_flat_gradient_`: the counts ride in the same all-reduce), so ragged shards -- the last batch of an epoch with drop_last=False --
     give the gradient of the GLOBAL mean loss instead of the mean of the ranks' means.  The two-call route (`forward` + `loss.backward()`: `fused_training_step = False`, a frozen parameter, a
     normalising WindowBatch) makes the same single exchange in the engine's backward.  Only the fused engine has that hook: a model that runs
-    operator by operator (an activation other than ReLU, a hidden width that is not a multiple of 128) is rejected here -- wrap that one in
+    operator by operator (an activation other than ReLU) is rejected here -- wrap that one in
     torch's DistributedDataParallel.  The model must have seen its lazy-initialising forward and live on the device; do not also wrap it
     in DDP.  live_only: the exchange moves only the elements that can be non-zero at the model's depth (exact; A1-C2 at 3 layers: 36 % of the
     buffer -- `LiveGradientExchange`).  Returns `module`."""
@@ -208,8 +208,8 @@ def flat_data_parallel(module, group=None, weight_by_windows: bool = False, live
     if getattr(model, "_spec", None) is None:
         raise RuntimeError("flat_data_parallel: run the lazy-initialising forward first (the wrappers' constructors do)")
     if not getattr(model, "_fused_activation", True):
-        raise RuntimeError("flat_data_parallel: this model runs operator by operator (activation other than ReLU, or a hidden width that is not a "
-                           "multiple of 128): its gradients never pass the engine's flat buffer -- wrap it in torch.nn.parallel.DistributedDataParallel")
+        raise RuntimeError("flat_data_parallel: this model runs operator by operator (an activation other than ReLU): its gradients never pass the engine's "
+                           "flat buffer -- wrap it in torch.nn.parallel.DistributedDataParallel")
     p0 = model._params_in_flat_order()[0]
     if p0.device.type != "cuda":
         raise RuntimeError("flat_data_parallel: move the model to its GPU first")

@@ -756,3 +756,112 @@ class Engine:
 
     def grad_hidden(self, B: int, layer: int) -> torch.Tensor:
         return self._act_tensor(self.layout(B, True).dx[layer], B)
+
+
+class PaddedEngine:
+    """A model whose hidden width is NOT a multiple of 128 (the reference takes any `hidden_channels`, hgnn_c2.py:11; its scripts expose it as
+    --hidden_size) on the fused engines: the same model at the next multiple of 128 with every added weight row / column and bias element zero.
+    The added features are then exactly zero in every layer (zero rows + zero bias -> relu(0) = 0, the residual adds 0 to 0, base_transform maps 0
+    to 0 through zero rows), contribute exact zeros to every product they enter, and receive exact-zero activation gradients (their columns of the
+    next weight are zero and relu'(0) = 0): outputs, loss and the gradients of the REAL parameters are those of the unpadded model -- to fp32
+    summation order -- on the same kernels and at the same parity as a 128-wide model.  The caller sees the true layout (state_dict order, true shapes,
+    `spec.flat_size()` elements); the parameters are scattered into the padded flat buffer before a call and the gradient gathered out of the padded
+    one after it (two index kernels each way, ~4 MB)."""
+
+    padded = True
+
+    def __init__(self, spec: ModelSpec, dtype: str = "f32", device: Optional[torch.device] = None):
+        import dataclasses
+        self.spec = spec
+        hp = (spec.hidden + 127) // 128 * 128
+        self.inner_spec = dataclasses.replace(spec, hidden=hp)
+        self.inner = Engine(self.inner_spec, dtype=dtype, device=device)
+        e = self.inner
+        self.lib, self.device, self.dtype, self.torch_dtype, self.types, self.n_out = e.lib, e.device, e.dtype, e.torch_dtype, e.types, e.n_out
+        self.generic, self.storage, self.info = e.generic, e.storage, e.info
+        true_pos, pad_pos = [], []
+        shp_t, shp_p, off_t, off_p = spec.param_shapes(), self.inner_spec.param_shapes(), spec.param_offsets(), self.inner_spec.param_offsets()
+        for k, st in shp_t.items():
+            sp, (ot, nt_), (op, _) = shp_p[k], off_t[k], off_p[k]
+            true_pos.append(torch.arange(ot, ot + nt_, dtype=torch.int64))
+            if len(st) == 1:
+                pad_pos.append(op + torch.arange(st[0], dtype=torch.int64))
+            else:
+                pad_pos.append((op + torch.arange(st[0], dtype=torch.int64)[:, None] * sp[1] + torch.arange(st[1], dtype=torch.int64)[None, :]).reshape(-1))
+        self._true_pos = torch.cat(true_pos).to(self.device)
+        self._pad_pos = torch.cat(pad_pos).to(self.device)
+        self._pflat = torch.zeros(self.inner_spec.flat_size(), dtype=torch.float32, device=self.device)      # everything outside _pad_pos stays zero for ever
+        self._pgrad = torch.empty_like(self._pflat)
+        self._tmp = torch.empty(self._true_pos.numel(), dtype=torch.float32, device=self.device)
+
+    # ---- layout translation ----
+    def _pad(self, params_flat: torch.Tensor) -> torch.Tensor:
+        if params_flat.dtype != torch.float32 or not params_flat.is_cuda or params_flat.numel() != self.spec.flat_size():
+            raise ValueError(f"params_flat must be a contiguous fp32 device tensor of {self.spec.flat_size()} elements")
+        torch.index_select(params_flat, 0, self._true_pos, out=self._tmp)
+        self._pflat.index_copy_(0, self._pad_pos, self._tmp)
+        return self._pflat
+
+    def _unpad_grad(self, grad_flat: Optional[torch.Tensor]) -> torch.Tensor:
+        if grad_flat is None:
+            grad_flat = torch.empty(self.spec.flat_size(), dtype=torch.float32, device=self.device)
+        torch.index_select(self._pgrad, 0, self._pad_pos, out=self._tmp)
+        grad_flat.zero_()
+        grad_flat.index_copy_(0, self._true_pos, self._tmp)
+        return grad_flat
+
+    # ---- the Engine surface models.py / wrappers.py / tests use ----
+    def cast_inputs(self, x_dict, pad: bool = True):
+        return self.inner.cast_inputs(x_dict, pad)
+
+    def workspace(self, B, training=True):
+        return self.inner.workspace(B, training)
+
+    def layout(self, B, training=True):
+        return self.inner.layout(B, training)
+
+    def stash_ticket(self, B):
+        return self.inner.stash_ticket(B)
+
+    def forward(self, xs, params_flat, B, training=True, out=None):
+        return self.inner.forward(xs, self._pad(params_flat), B, training=training, out=out)
+
+    def backward(self, xs, params_flat, grad_out, B, grad_flat=None):
+        self.inner.backward(xs, self._pad(params_flat), grad_out, B, grad_flat=self._pgrad)
+        return self._unpad_grad(grad_flat)
+
+    def backward_mse(self, xs, params_flat, out, y, B, grad_flat=None, loss=None):
+        loss, _ = self.inner.backward_mse(xs, self._pad(params_flat), out, y, B, grad_flat=self._pgrad, loss=loss)
+        return loss, self._unpad_grad(grad_flat)
+
+    def backward_ce(self, xs, params_flat, out, labels, B, grad_flat=None, loss=None):
+        loss, _ = self.inner.backward_ce(xs, self._pad(params_flat), out, labels, B, grad_flat=self._pgrad, loss=loss)
+        return loss, self._unpad_grad(grad_flat)
+
+    def step_mse(self, xs, params_flat, y, B, out=None, grad_flat=None, loss=None):
+        out, loss, _ = self.inner.step_mse(xs, self._pad(params_flat), y, B, out=out, grad_flat=self._pgrad, loss=loss)
+        return out, loss, self._unpad_grad(grad_flat)
+
+    def step_ce(self, xs, params_flat, labels, B, out=None, grad_flat=None, loss=None):
+        out, loss, _ = self.inner.step_ce(xs, self._pad(params_flat), labels, B, out=out, grad_flat=self._pgrad, loss=loss)
+        return out, loss, self._unpad_grad(grad_flat)
+
+    def mse_loss(self, out, y, want_grad=True):
+        return self.inner.mse_loss(out, y, want_grad)
+
+    def adam_step(self, *args, **kw):
+        return self.inner.adam_step(*args, **kw)      # (elementwise on whatever flat buffers it is handed)
+
+    def hidden_state(self, B, layer):
+        return self.inner.hidden_state(B, layer)[..., :self.spec.hidden]
+
+    def profile(self, on):
+        return self.inner.profile(on)
+
+    def profile_read(self):
+        return self.inner.profile_read()
+
+
+def make_engine(spec: ModelSpec, dtype: str = "f32", device: Optional[torch.device] = None):
+    """Engine for any hidden width: multiples of 128 as they are, other widths zero-padded to the next one (PaddedEngine)."""
+    return Engine(spec, dtype=dtype, device=device) if spec.hidden % 128 == 0 else PaddedEngine(spec, dtype=dtype, device=device)

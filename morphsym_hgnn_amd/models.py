@@ -202,11 +202,11 @@ class _MSHGNNBase(nn.Module):
     num_bases = 2
 
     def _init_common(self, hidden_channels, num_layers, data_metadata, regression, activation_fn):
-        # The fused engines implement the reference's default, nn.ReLU(), at hidden widths that are multiples of 128.  Any other activation module
-        # (the constructors accept one, hgnn_c2.py:10-12) or width runs the same forward operator by operator on the stand-alone HIP operators
+        # The fused engines implement the reference's default, nn.ReLU().  Any other activation module
+        # (the constructors accept one, hgnn_c2.py:10-12) runs the same forward operator by operator on the stand-alone HIP operators
         # of ops.py (_forward_operators): PyG-style launches instead of the fused kernels -- slower, same numerics, still no CPU path.
-        self._fused_activation = isinstance(activation_fn, nn.ReLU) and hidden_channels % 128 == 0      # (the engines' widths are multiples of 128: any
-                                                                                                      # other hidden_channels runs on the operators too)
+        self._fused_activation = isinstance(activation_fn, nn.ReLU)      # (any hidden width: the engines' widths are multiples of 128, other widths run
+                                                                       #  zero-padded to the next one -- engine.PaddedEngine -- with identical results)
         self.regression = regression
         self.activation = activation_fn
         self.hidden_channels = hidden_channels
@@ -344,10 +344,10 @@ class _MSHGNNBase(nn.Module):
                          com_dimension=getattr(self, "num_dimensions_per_base", 6) if self.kind == "s4_com" else 6)
 
     def _engine(self, device):
-        from .engine import Engine
+        from .engine import make_engine
         key = (self._precision, str(device))
         if key not in self._engines:
-            self._engines[key] = Engine(self._spec, dtype=self._precision, device=device)
+            self._engines[key] = make_engine(self._spec, dtype=self._precision, device=device)
         return self._engines[key]
 
     # ---- forward --------------------------------------------------------------------------------------
@@ -448,7 +448,7 @@ class _MSHGNNBase(nn.Module):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and self._flat_ddp is None:
             return None
         e = self._engine(store.device)
-        if e.generic or e.storage not in ("bf16", "x3") or (e.storage == "bf16") != (store.dtype == "bf16"):      # (the split plan gathers fp32 series)
+        if e.generic or getattr(e, "padded", False) or e.storage not in ("bf16", "x3") or (e.storage == "bf16") != (store.dtype == "bf16"):      # (the split plan gathers fp32 series)
             return None
         if B not in self._checked_batches:   # one host-side check per batch size: B copies of the compiled graph
             for et in self._edge_types:
