@@ -32,6 +32,9 @@ if __name__ == "__main__":
     for s, (f, w, n) in tot.items():
         out[s] = {"fetch_bytes": 2.0 * f / n * 1024.0, "write_bytes": w / n * 1024.0, "launches": n}
         out[s]["hbm_bytes"] = out[s]["fetch_bytes"] + out[s]["write_bytes"]
+    for a_, b_ in (("ggradw", "gradw"), ("gfinalize", "finalize")):      # the generic engine's launches under the names bench.py's kernel stats use
+        if a_ in out and b_ not in out:
+            out[b_] = dict(out[a_], alias_of=a_)
     # WRITE_SIZE known answer: k_finalize writes every element of the flat fp32 gradient exactly once and nothing else of size (bench line key
     # flat_gradient_bytes).  Some boxes of the pool report WRITE_SIZE ~1.30x high for EVERY kernel of a run (round 5: finalize 5.2 MB for a 3.98 MB
     # buffer, the stack launch's stashes 169 MB for 130 MB, while FETCH_SIZE agrees to 0.1 % with round 4's passes) -- when the finalize figure is off by
