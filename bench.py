@@ -878,6 +878,12 @@ def main():
         res["commit"] = open(cfile).read().strip()
     res["source_hash"] = source_hash()
     if dist is not None:
+        try:      # the C-ABI communicator goes first, on every rank, while all of them are still alive
+            sc = locals().get("wl") and wl.stream_comm
+            if sc:
+                sc.close()
+        except Exception:  # noqa: BLE001
+            pass
         dist.destroy_process_group()
     sys.stdout.flush()
     if rank == 0:

@@ -104,11 +104,16 @@ class StreamAllReduce:
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
         self._path = cand.encode() if os.path.exists(cand) else None
-        ident = [None]
-        if self.rank == 0:
-            raw = C.create_string_buffer(128)
-            eng._check(self.lib, self.lib.mshgnn_comm_unique_id(self._path, raw), "mshgnn_comm_unique_id")
-            ident[0] = raw.raw
+        # every rank first proves it can bind RCCL (drawing an id loads the library and is local); the verdicts are combined BEFORE the collective
+        # ncclCommInitRank, so that one rank without a loadable librccl makes every rank raise instead of leaving the others inside the rendezvous
+        raw = C.create_string_buffer(128)
+        rc = self.lib.mshgnn_comm_unique_id(self._path, raw)
+        err = self.lib.mshgnn_last_error().decode() if rc else ""
+        oks = [None] * self.world
+        dist.all_gather_object(oks, rc == 0, group=group)
+        if not all(oks):
+            raise RuntimeError(f"StreamAllReduce: RCCL could not be bound on rank(s) {[i for i, o in enumerate(oks) if not o]}" + (f" (this rank: {err})" if err else ""))
+        ident = [raw.raw if self.rank == 0 else None]
         dist.broadcast_object_list(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         self._comm = C.c_void_p()
         with torch.cuda.device(self.device):
