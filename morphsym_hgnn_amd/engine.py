@@ -428,7 +428,8 @@ class Engine:
                 return None
             if rows is None:
                 rows = x.shape[0] // self.spec.num_nodes[t]
-            if x.shape[0] != rows * self.spec.num_nodes[t] or x.data_ptr() % 8 or (dt == torch.float32 and F % 2 == 0 and (F * 4) % 8):
+            need = 8 if (dt == torch.float64 or F % 2 == 0) else 4      # fp64 units, fp32 rows of an even width: 8-byte loads; odd fp32 widths: element loads
+            if x.shape[0] != rows * self.spec.num_nodes[t] or x.data_ptr() % need:
                 return None
         if dt == self.torch_dtype and all((self.spec.widths[t] * 4) % 16 == 0 for t in self.types):
             return None      # fp32 rows the kernels' 16-byte loaders take as they are
