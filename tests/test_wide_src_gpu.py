@@ -119,3 +119,37 @@ def test_module_surface_with_reference_dtype_inputs_matches_golden_on_the_parity
     loss.backward()
     grads = {k: (p.grad.detach().cpu() if p.grad is not None else torch.zeros_like(p).cpu()) for k, p in m.named_parameters()}
     helpers.check_against_fixture(fx, out.detach().cpu(), loss.detach().cpu(), grads, rtol=1e-4, what=name)
+
+
+def test_uncast_entry_points_refuse_what_they_cannot_run():
+    """The _src entry points run on the bf16 and split plans of the LDS-resident kernels: the fp32 plan and the generic-width engine answer
+    MSHGNN_EUNSUPPORTED (the binding casts there: Engine.cast_inputs hands out plain tensors), a bad element size MSHGNN_EINVAL -- before anything is launched."""
+    import ctypes as C
+    from morphsym_hgnn_amd import engine as eng, synth
+    spec = helpers.make_spec("c2", "a1-c2", "a1-c2", 128, 2)
+    B = 4
+    x_dict, y = synth.make_windows(1, B, spec.num_nodes, spec.widths, 12)
+    xd = {k: v.cuda() for k, v in x_dict.items()}
+    for dtype, hidden in (("f32", 128), ("bf16", 256)):
+        sp = helpers.make_spec("c2", "a1-c2", "a1-c2", hidden, 2)
+        e = eng.Engine(sp, dtype)
+        assert not isinstance(e.cast_inputs(xd), eng.WideInputs)          # the binding never takes the uncast route there
+        flat = eng.flatten_params(sp, synth.make_params(1, sp.param_shapes()), e.device)
+        rows = e._row_buffers(B)
+        n = len(rows)
+        src = (C.c_void_p * n)(*[xd[t].data_ptr() for t in e.types])
+        rp = (C.c_void_p * n)(*[r.data_ptr() for r in rows])
+        pitch = (C.c_int64 * n)(*[r.shape[1] for r in rows])
+        out = torch.empty(B * 4, 3, device="cuda")
+        ws = e.workspace(B, True)
+        rc = e.lib.mshgnn_forward_src(e._plan, 8, src, None, rp, pitch, flat.data_ptr(), out.data_ptr(), ws.data_ptr(), B, 1, None)
+        assert rc == -2 and b"wide source rows" in e.lib.mshgnn_last_error()
+    e = eng.Engine(spec, "bf16")
+    rows = e._row_buffers(B)
+    src = (C.c_void_p * 3)(*[xd[t].data_ptr() for t in e.types])
+    rp = (C.c_void_p * 3)(*[r.data_ptr() for r in rows])
+    pitch = (C.c_int64 * 3)(*[r.shape[1] for r in rows])
+    flat = eng.flatten_params(spec, synth.make_params(1, spec.param_shapes()), e.device)
+    out = torch.empty(B * 4, 3, device="cuda")
+    assert e.lib.mshgnn_forward_src(e._plan, 2, src, None, rp, pitch, flat.data_ptr(), out.data_ptr(), e.workspace(B, True).data_ptr(), B, 1, None) == -1
+    assert e.lib.mshgnn_forward_src(e._plan, 8, src, None, None, pitch, flat.data_ptr(), out.data_ptr(), e.workspace(B, True).data_ptr(), B, 1, None) == -1

@@ -235,6 +235,7 @@ def test_series_step_is_bit_identical_to_assemble_then_step(recipe_name, B):
     out_a, loss_a, g_a = out_a.clone(), loss_a.clone(), g_a.clone()
     xs2, y2, out_b, loss_b, g_b = e.step_mse_series(store, starts, flat, materialize=True)
     torch.cuda.synchronize()
+    assert store.desc.run_ptrs_ready == 0                   # the first step of a store resolves the runs' column pointers ...
     for a, b in zip(xs, xs2):
         assert torch.equal(a, b)
     assert torch.equal(y, y2) and torch.equal(out_a, out_b) and torch.equal(loss_a, loss_b) and torch.equal(g_a, g_b)
@@ -242,6 +243,7 @@ def test_series_step_is_bit_identical_to_assemble_then_step(recipe_name, B):
     out_b, loss_b, g_b = out_b.clone(), loss_b.clone(), g_b.clone()
     xs3, y3, out_c, loss_c, g_c = e.step_mse_series(store, starts, flat, materialize=False)
     torch.cuda.synchronize()
+    assert store.desc.run_ptrs_ready == 1                   # ... later steps on the same stream vouch for the scratch (mshgnn_window_desc.run_ptrs_ready): same bits
     assert xs3 is None and torch.equal(y, y3) and torch.equal(out_a, out_c) and torch.equal(loss_a, loss_c) and torch.equal(g_a, g_c)
 
 
