@@ -923,9 +923,7 @@ __device__ __forceinline__ void slab_group_store(const StackArgs& a, const FHdr&
             *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(n, win, col / P::EPC)) = keep[u];
             if (a.training) {
                 if (kind == NK_RELU) maskbytes[relu_tile_base(n, a.B, blockIdx.x, wn) + lane] = (uint8_t)(bits[u >> 2] >> (8 * (u & 3)));
-#ifndef MSHGNN_NO_STASH
                 if (w < a.B && stash_x) *reinterpret_cast<u32x4*>(xo + act_idx(w, n, a.B) + col) = keep[u];
-#endif
             }
         }
     }
@@ -1398,9 +1396,7 @@ template <typename T, int NM, int HB, bool STEP> __device__ __forceinline__ void
                 const int n = bh[(q < SL_HA ? FH_SLOTA : FH_SLOTB - SL_HA) + q];
                 const u32x4 v = q < SL_HA ? keepA[q < SL_HA ? q : 0] : keepB[q < SL_HA ? 0 : q - SL_HA];
                 if (l > 0) *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(n, win, col / P::EPC)) = v;
-#ifndef MSHGNN_NO_STASH
                 if (w_ok) *reinterpret_cast<u32x4*>(dxo + act_idx(w, n, B) + col) = v;
-#endif
             }
         }
         __syncthreads();
