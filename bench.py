@@ -268,6 +268,14 @@ class Workload:
             except Exception as ex:  # noqa: BLE001  (no librccl the loader can find: torch.distributed's collective stays)
                 sys.stderr.write(f"bench.py: StreamAllReduce unavailable ({ex}); using torch.distributed.all_reduce\n")
                 self.collective_choice = {"mode": collective, "stream": False, "error": str(ex)[:200]}
+            # every rank must take the same route (the calibration passes and the step itself are collectives): one rank without the communicator
+            # puts all of them back on torch.distributed's all-reduce
+            ok = torch.tensor([1.0 if self.stream_comm is not None else 0.0], device=device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if float(ok[0]) == 0.0 and self.stream_comm is not None:
+                self.stream_comm.close()
+                self.stream_comm, self.use_stream = None, False
+                self.collective_choice = {"mode": collective, "stream": False, "error": "another rank could not create the communicator"}
 
     def _allreduce(self):
         if self.g16 is not None:
