@@ -843,6 +843,14 @@ def main():
                                           "reference run.  max_rel_err_vs_oracle: max-abs error / max-abs reference over every hidden state, output, loss "
                                           "and parameter gradient against the fp64 oracle on 48 seeded windows, the oracle evaluated with the engine's relu "
                                           "decisions (flipped_relu_decisions of them differ from the exact ones, each within 1e-4 of its tensor's scale of zero)"}
+        # evaluation: the forward alone, no stashes (training=False) -- what `evaluate_model` / validation_step drive (gnnLightning.py:1004-1100, 724-741)
+        res["forward_only"] = {"what": "mshgnn_forward(training=0): encoder + L layers + decoder, no stashes, inputs resident; same windows as the headline"}
+        for plan in dict.fromkeys((args.dtype, PARITY_DTYPE)):
+            wf = Workload(spec, plan, B, device, 1234)
+            dtf = median_step_s(lambda: wf.e.forward(wf.xs, wf.flat, B, training=False, out=wf.out), torch.cuda.synchronize, args.steps, args.warmup)
+            res["forward_only"][plan] = {"ms_per_step": dtf * 1e3, "value": B / dtf}
+            del wf
+            torch.cuda.empty_cache()
         if args.dtype == "bf16" and L == 3:
             res["end_to_end"] = end_to_end(spec, B, device, args.steps, args.warmup)
             torch.cuda.empty_cache()

@@ -150,6 +150,19 @@ class StreamAllReduce:
             pass
 
 
+_STREAM_COMMS = {}      # process group (None: the default one) -> StreamAllReduce registered by flat_data_parallel(stream_collective=True)
+
+
+def _sum_all_reduce_(t: torch.Tensor, group=None) -> None:
+    """Sum over the ranks, in place: through the group's registered C-ABI communicator on the current stream where there is one, else torch.distributed."""
+    import torch.distributed as dist
+    comm = _STREAM_COMMS.get(group)
+    if comm is not None and t.is_cuda and t.device == comm.device and t.dtype == torch.float32 and t.is_contiguous():
+        comm.allreduce_sum_(t)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
 def exchange_flat_gradient_(buf: torch.Tensor, n_flat: int, local_windows: int, group=None, weight_by_windows: bool = False, live=None) -> torch.Tensor:
     """The ONE exchange of a `flat_data_parallel` step, in place on `buf` (fp32, >= n_flat + 1 elements: the flat gradient of this rank's LOCAL mean
     loss followed by one spare element).  weight_by_windows: the gradient is multiplied by this rank's window count, the count rides in the spare
@@ -177,21 +190,21 @@ def exchange_flat_gradient_(buf: torch.Tensor, n_flat: int, local_windows: int, 
         if weight_by_windows:
             packed.mul_(float(local_windows))
             packed[-1] = float(local_windows)      # (idx ends with n_flat: the spare element)
-        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+        _sum_all_reduce_(packed, group)
         buf.index_copy_(0, idx, packed)
         return packed[-1].clone() if weight_by_windows else torch.tensor(float(world), dtype=torch.float32, device=buf.device)
     if not weight_by_windows:
-        dist.all_reduce(buf[:n_flat], op=dist.ReduceOp.SUM, group=group)
+        _sum_all_reduce_(buf[:n_flat], group)
         return torch.tensor(float(world), dtype=torch.float32, device=buf.device)
     if buf.numel() < n_flat + 1:
         raise ValueError("exchange_flat_gradient_: the buffer needs one spare element behind the gradient")
     buf[:n_flat].mul_(float(local_windows))
     buf[n_flat:n_flat + 1].fill_(float(local_windows))
-    dist.all_reduce(buf[:n_flat + 1], op=dist.ReduceOp.SUM, group=group)
+    _sum_all_reduce_(buf[:n_flat + 1], group)
     return buf[n_flat].clone()
 
 
-def flat_data_parallel(module, group=None, weight_by_windows: bool = False, live_only: bool = False):
+def flat_data_parallel(module, group=None, weight_by_windows: bool = False, live_only: bool = False, stream_collective: bool = False):
     """Data parallelism for a training-step wrapper (wrappers.py) or a model (models.py) WITHOUT torch's DistributedDataParallel: the
     parameters (views of one flat buffer) are broadcast from rank 0 once, and from then on the fused training step
     (`training_step` -> `models.fused_training_step[_windows]`) sum-all-reduces its flat gradient in `loss.backward()` and divides by the
@@ -205,7 +218,8 @@ def flat_data_parallel(module, group=None, weight_by_windows: bool = False, live
     operator by operator (an activation other than ReLU) is rejected here -- wrap that one in
     torch's DistributedDataParallel.  The model must have seen its lazy-initialising forward and live on the device; do not also wrap it
     in DDP.  live_only: the exchange moves only the elements that can be non-zero at the model's depth (exact; A1-C2 at 3 layers: 36 % of the
-    buffer -- `LiveGradientExchange`).  Returns `module`."""
+    buffer -- `LiveGradientExchange`).  stream_collective: the exchange is enqueued on the step's own stream through the C-ABI (`StreamAllReduce`, RCCL bound at
+    run time; GPUs only, one rank per device) instead of torch.distributed's all_reduce -- same sums, no hand-over to its side stream.  Returns `module`."""
     import torch.distributed as dist
     model = getattr(module, "model", module)
     if not (dist.is_available() and dist.is_initialized()):
@@ -220,6 +234,8 @@ def flat_data_parallel(module, group=None, weight_by_windows: bool = False, live
         raise RuntimeError("flat_data_parallel: move the model to its GPU first")
     flat = model._flat_params(p0.device)
     dist.broadcast(flat, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    if stream_collective and group not in _STREAM_COMMS:
+        _STREAM_COMMS[group] = StreamAllReduce(flat.device, group)      # (collective: every rank of the group gets here)
     model._flat_ddp = True if group is None else group
     model._flat_ddp_weighted = bool(weight_by_windows)
     model._flat_ddp_live = None

@@ -191,7 +191,7 @@ def test_two_engine_ranks_reproduce_the_global_batch_gradient(dtype):
     assert ret["err"] < 1e-5    # same arithmetic, different summation order over the windows
 
 
-def _wrapper_worker(rank, world, port, B, live_only, weighted, ret):
+def _wrapper_worker(rank, world, port, B, live_only, weighted, ret, stream=False):
     """Two wrapper ranks on the one GPU of the test box (gloo: its all-reduce takes device tensors through host copies): flat_data_parallel +
     training_step + backward on each rank's shard == the single-process step on the whole batch."""
     import types
@@ -215,7 +215,8 @@ def _wrapper_worker(rank, world, port, B, live_only, weighted, ret):
     w.model.load_state_dict(params)
     with torch.no_grad():
         w.model(x_dict=dict(mine.x_dict), edge_index_dict=mine.edge_index_dict)      # parameters become views of the flat buffer
-    ddp.flat_data_parallel(w, live_only=live_only, **({"weight_by_windows": True} if weighted else {}))      # (the default must be DDP's mean of means)
+    ddp.flat_data_parallel(w, live_only=live_only, stream_collective=stream, **({"weight_by_windows": True} if weighted else {}))      # (the default must be DDP's mean of means)
+    assert (None in ddp._STREAM_COMMS) == stream
     assert w.model._flat_ddp_weighted == weighted
     assert (w.model._flat_ddp_live is not None) == live_only
     loss = w.training_step(mine, 0)
@@ -256,6 +257,8 @@ def _wrapper_worker(rank, world, port, B, live_only, weighted, ret):
         ret["err"] = float((g - gf).abs().max() / gf.abs().max())
         ret["params_equal"] = bool(torch.equal(w.model._flat, ref.model._flat))
     dist.barrier()
+    if stream:
+        ddp._STREAM_COMMS.pop(None).close()
     dist.destroy_process_group()
 
 
@@ -355,3 +358,15 @@ def test_stream_allreduce_through_the_c_abi_on_a_one_rank_group_and_inside_a_gra
     ret = mgr.dict()
     mp.spawn(_stream_comm_worker, args=(1, 35000 + (os.getpid() % 2000), ret), nprocs=1, join=True)
     assert ret["same"] and ret["graph_same"] and ret["live_same"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("live_only,weighted", [(False, False), (True, True)])
+def test_flat_data_parallel_through_the_stream_collective_on_a_one_rank_group(live_only, weighted):
+    """flat_data_parallel(stream_collective=True): the wrapper's one exchange goes through the C-ABI communicator on the step's stream (RCCL refuses two ranks on
+    one GPU, so a 1-rank group: the exchange must leave the single-process gradient untouched on both routes, whole buffer and live elements + window count)."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 36000 + (os.getpid() % 2000)
+    mp.spawn(_wrapper_worker, args=(1, port, 64, live_only, weighted, ret, True), nprocs=1, join=True)
+    assert ret["params_equal"] and ret["err"] < 1e-5 and ret["two_call_0"] < 1e-5
