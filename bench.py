@@ -818,9 +818,11 @@ def main():
         torch.cuda.empty_cache()
         res["end_to_end"] = end_to_end(spec, B, device, args.steps, args.warmup, "mck4")
     if extras:
-        del wl      # free the 0.6 GB workspace before the side measurements
-        torch.cuda.empty_cache()
-        res["module_surface"] = module_surface(spec, B, device, args.steps, args.warmup, args.dtype)      # (first: its host-side share is sensitive to allocator state)
+        # the module surface first, with the headline's workspace still allocated: its two-call route is host-bound on the pool's slower hosts and measured
+        # 0.44-0.60 ms/step right after that workspace had been returned to the driver (torch's allocator re-growing its pools), 0.37 in a process that keeps it
+        # (`--surface module`) -- the state a training process is in
+        res["module_surface"] = module_surface(spec, B, device, args.steps, args.warmup, args.dtype)
+        del wl      # free the 0.6 GB workspace before the other side measurements
         torch.cuda.empty_cache()
         # the same workload on the parity-grade plan (north_star tolerance 1e-4), driver-visible
         if args.dtype != PARITY_DTYPE:
