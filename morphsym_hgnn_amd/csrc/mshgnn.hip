@@ -923,7 +923,7 @@ __device__ __forceinline__ void slab_group_store(const StackArgs& a, const FHdr&
             *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(n, win, col / P::EPC)) = keep[u];
             if (a.training) {
                 if (kind == NK_RELU) maskbytes[relu_tile_base(n, a.B, blockIdx.x, wn) + lane] = (uint8_t)(bits[u >> 2] >> (8 * (u & 3)));
-                if (w < a.B && stash_x) *reinterpret_cast<u32x4*>(xo + act_idx(w, n, a.B) + col) = keep[u];
+                if (w < a.B && stash_x) stash_store(xo + act_idx(w, n, a.B) + col, keep[u], a.stash_nt != 0);
             }
         }
     }
@@ -1396,7 +1396,7 @@ template <typename T, int NM, int HB, bool STEP> __device__ __forceinline__ void
                 const int n = bh[(q < SL_HA ? FH_SLOTA : FH_SLOTB - SL_HA) + q];
                 const u32x4 v = q < SL_HA ? keepA[q < SL_HA ? q : 0] : keepB[q < SL_HA ? 0 : q - SL_HA];
                 if (l > 0) *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(n, win, col / P::EPC)) = v;
-                if (w_ok) *reinterpret_cast<u32x4*>(dxo + act_idx(w, n, B) + col) = v;
+                if (w_ok) stash_store(dxo + act_idx(w, n, B) + col, v, a.stash_nt != 0);
             }
         }
         __syncthreads();
@@ -2418,6 +2418,7 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
             }
             a.stamps = stamp_ptr("MSHGNN_STAMPS");
             a.stagger = p->slab_for(tiles) && tiles > p->n_cu ? p->stagger : 0;
+            a.stash_nt = training ? stash_nt_for(B, stash_rows_of(hp), H * (int)sizeof(T)) : 0;
             // the tail's reduction scratch (one decoder slab per wave) must not touch the out-type nodes' blocks, which receive dX_L for the backward sweep: it sits
             // in the blocks in front of them, or (models whose out type comes first: the centroidal-momentum ones) in the blocks behind them
             const bool step_slab = p->slab_for(tiles);
@@ -2511,6 +2512,7 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
             a.dbg = p->dbg;
             a.stamps = stamp_ptr("MSHGNN_STAMPS_BWD");
             a.stagger = p->slab_for(tiles) && tiles > p->n_cu ? p->stagger : 0;
+            a.stash_nt = stash_nt_for(B, stash_rows_of(hp), H * (int)sizeof(T));
             ProfScope ps(p, hp.ks_stack_bwd, st);
             if (p->slab_for(tiles)) {
                 for (int l = 0; l < hp.L; ++l) a.prog_off[l] = hp.sl_bwd_off[l];

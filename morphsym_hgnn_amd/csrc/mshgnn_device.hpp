@@ -708,9 +708,38 @@ struct StackArgs {
     int lo_blk, n_img;
     int scr0;            // split plan: first base_transform scratch block (NN, or NN - n_mlp when the scratch aliases the last nodes' blocks)
     int red_off;         // byte offset in LDS of the decoder tail's reduction scratch (0: the first blocks; one-launch steps whose out-type nodes come first: the blocks behind them)
+    int stash_nt;        // stash rows (X_l, dX_l) are stored non-temporally: for stashes far beyond the Infinity Cache the weight-gradient pass that reads them next
+                         // runs 11 % faster when the stack launch's writes do not allocate on their way out (stash_nt_for); a uniform choice per launch, same bits
     int stagger;         // two workgroups per CU: the second half of the grid starts this many cycles late, so that one workgroup's MAC phases
                          // (matrix pipe) run beside the other's epilogues (stores) instead of both competing for the same unit (0: off)
 };
+// one 16-byte stash store, plain or non-temporal (StackArgs.stash_nt: uniform)
+__device__ __forceinline__ void stash_store(void* p, u32x4 v, bool nt) {
+    // (two arms that differ only in the cache hint are merged by the optimiser into ONE plain store, and an opaque copy of the address turns it into a flat
+    //  store: the non-temporal arm is therefore the instruction itself.  Nothing in a stack kernel loads what it stashed, and every MAC phase starts with an
+    //  explicit vmcnt(0), so a store the compiler's wait counts do not know about is only ever waited for too long, never too short.)
+    if (nt) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(p), "v"(v) : "memory");
+    else *reinterpret_cast<u32x4*>(p) = v;
+}
+// Stash rows one step writes for the weight-gradient pass: X_{l+1} of every node computed in layer l and dX_l of every node whose X_l was needed (plan liveness).  When they add
+// up to more than MSHGNN_STASH_NT_MB (default 200, counted at 256 bytes per row on both plans: what the step launch pays grows with the number of stores, and the split plan's
+// 512-byte rows at 3 layers -- 250 MB -- lose where the bf16 plan's 5 layers -- 230 MB -- win) the stores go out non-temporally -- the weight-gradient launch that reads them next then runs ~10 % faster
+// (its shared rows keep meeting in L2 instead of being evicted by write-allocated stash lines) at no cost to the step launch.  Measured, 8192 windows (plain -> nt, ms/step):
+// A1-C2 bf16 at 8 layers (640 MB) 0.6385 -> 0.6112, at 5 layers (~300 MB) 0.3738 -> 0.3649, MiniCheetah-K4 L = 8 0.7215 -> 0.6849, Solo K4 COM 5.16 -> 5.07, split plan at 8 layers
+// 1.502 -> 1.458; below the limit the step launch pays for it instead (A1-C2 at 3 layers, 125 MB: step launch +3-5 us, weight gradients -3: -0.5 %; split plan, 250 MB: +1 %):
+// plain stores stay there.  MSHGNN_STASH_NT=0 / 1 forces either; the bits are the same.
+inline int stash_nt_for(int64_t B, int stash_rows, int row_bytes) {
+    static const int force = []() { const char* e = getenv("MSHGNN_STASH_NT"); return e ? atoi(e) : -1; }();
+    static const int64_t limit_mb = []() { const char* e = getenv("MSHGNN_STASH_NT_MB"); return (int64_t)(e ? atoi(e) : 200); }();
+    if (force == 0 || force == 1) return force;
+    return (int64_t)stash_rows * B * row_bytes > (limit_mb << 20) ? 1 : 0;
+}
+template <typename HP> inline int stash_rows_of(const HP& hp) {
+    int rows = 0;
+    for (int l = 0; l < hp.L; ++l)
+        for (int n = 0; n < hp.NN; ++n) rows += (hp.live_n[l][n] && l + 1 < hp.L ? 1 : 0) + (hp.need_n[l][n] ? 1 : 0);
+    return rows;
+}
 // start-up delay of the workgroups that share a CU with an earlier one (the first gridDim.x / 2 workgroups fill one slot per CU)
 __device__ __forceinline__ void stack_stagger(const StackArgs& a) {
     if (a.stagger > 0 && blockIdx.x >= (gridDim.x + 1) / 2)

@@ -470,8 +470,8 @@ template <bool ALIAS, bool STEP> __device__ __forceinline__ void stack_fwd_x3_bo
                     *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(LO + n, win, col / P::EPC)) = lo;
                     if (train && w_ok && !(STEP && l + 1 == a.L)) {      // (X_L of a one-launch step is read by nobody)
                         T* q = xo + x3_idx(w, n, B) + col;
-                        *reinterpret_cast<u32x4*>(q) = hi;
-                        *reinterpret_cast<u32x4*>(q + H) = lo;
+                        stash_store(q, hi, a.stash_nt != 0);
+                        stash_store(q + H, lo, a.stash_nt != 0);
                     }
                 }
             }
@@ -647,8 +647,8 @@ template <bool STEP> __device__ __forceinline__ void stack_bwd_x3_body(const Sta
                 }
                 if (w_ok) {
                     T* q = dxo + x3_idx(w, n, B) + col;
-                    *reinterpret_cast<u32x4*>(q) = hi;
-                    *reinterpret_cast<u32x4*>(q + H) = lo;
+                    stash_store(q, hi, a.stash_nt != 0);
+                    stash_store(q + H, lo, a.stash_nt != 0);
                 }
             }
         }
@@ -1174,6 +1174,7 @@ static void x3_stack_args(const mshgnn_plan* p, const mshgnn_ws_layout& lay, cha
     a.wpack = ws + lay.wpack; a.bias = reinterpret_cast<const float*>(ws + lay.bias); a.tables = p->d_tables;
     a.B = B; a.NN = hp.NN; a.L = hp.L;
     a.lo_blk = hp.lo_blk; a.n_img = hp.n_img; a.scr0 = hp.x3_alias ? hp.NN - hp.n_mlp : hp.NN;
+    a.stash_nt = stash_nt_for(B, stash_rows_of(hp), H * 2);      // (counted per row, not per byte: stash_nt_for)
 }
 
 int x3_forward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, float* out, char* ws, int64_t batch,
