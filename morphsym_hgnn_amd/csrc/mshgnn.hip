@@ -950,7 +950,8 @@ template <typename T, int NM, int HB, bool STEP> __device__ __forceinline__ void
 #pragma unroll
             for (int i = 0; i < BATCH; ++i) {
                 v[i] = u32x4{0, 0, 0, 0};
-                if (nb + i < NN && w0 + row < B) v[i] = *reinterpret_cast<const u32x4*>(src + act_idx(w0 + row, nb + i, B) + c * P::EPC);
+                // (read once by this kernel: non-temporal -- 0.2026 -> 0.2004 ms/step over six alternating runs at 3 layers, nothing at 8)
+                if (nb + i < NN && w0 + row < B) v[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src + act_idx(w0 + row, nb + i, B) + c * P::EPC));
             }
 #pragma unroll
             for (int i = 0; i < BATCH; ++i)
