@@ -1096,8 +1096,10 @@ struct mshgnn_plan {
     int n_types = 0;
     mshgnn_gen_state* gen = nullptr;    // set: this plan runs on the generic-width engine (hidden != 128, many nodes, ...), hp is unused
     int dbg = 0, dbg_gw = 0;            // timing ablations (instrumented builds only: read once from MSHGNN_DBG / MSHGNN_DBG_GW at plan creation)
-    // a slab workgroup has 4 waves for a whole tile: it pays off once there are enough tiles for two workgroups per CU
-    bool slab_for(int tiles) const { return use_slab && (slab_force || tiles >= 2 * n_cu * 3 / 4); }
+    // a slab workgroup has 4 waves for a whole tile (a lone one is ~12 % slower than the 8-wave kernels' workgroup: 69 against 62 us at 3 layers), two fit a CU:
+    // it pays off from the first tile the 8-wave kernels would need a second round for (257 .. 383 tiles, 8-wave against slab launch: 113 / 77 us at 3 layers,
+    // 425 / 295 at 8, MiniCheetah-K4 440 / 330 -- tools/slab_threshold_sweep.py; rounds 3-4 switched at 1.5 tiles per CU)
+    bool slab_for(int tiles) const { return use_slab && (slab_force || tiles > n_cu); }
 };
 
 // in-kernel stamp buffers of the instrumented builds (tools/stamps_*.py pass a device pointer through the environment)
