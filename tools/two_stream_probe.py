@@ -1,128 +1,49 @@
-"""Go / no-go probe: do two half-batch steps on two HIP streams beat one full-batch step?
-
-The step's launches run strictly in series: enc (HBM-bound) -> stack_step (latency-bound, 2.3 TB/s, 18 % MFMA) -> gradw (HBM-bound) -> finalize.
-If the stack launch of one half-batch can run beside the HBM-bound launches of the other, the pair should finish sooner than the serial sum.
-Existing kernels, existing entry points; two Engines (two workspaces), two streams.
-
-  python tools/two_stream_probe.py [--trace]      (MSHGNN_SLAB is set per engine through the environment at plan creation)
-
-Modes timed (ms per 8192 windows):
-  full            one mshgnn_step_mse of 8192 windows
-  halves_serial   two steps of 4096 on ONE stream
-  halves_joined   two steps of 4096 on two streams, streams joined after every pair (what a training step needs: one optimizer update per pair)
-  halves_free     the two streams free-running (steady-state pipeline, upper bound of what an offset schedule could reach)
-  halves_offset   stream B's step starts when stream A's FORWARD launch sequence is done (forward / backward_mse two-call route, event between them)
-"""
-import json
-import os
-import sys
-import time
-
+"""Does the chip have room for two half-batch steps side by side?  Two engines (own workspaces) on two streams, each stepping B/2 windows, against one engine stepping B:
+aggregate windows/s.  The half steps' issue-bound stack launch and HBM-bound weight-gradient launch can then share CUs.  usage: python tools/two_stream_probe.py [B] [layers] [dtype]"""
+import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch  # noqa: E402
+import torch
+import bench
+from morphsym_hgnn_amd import engine as eng, synth
 
-import bench  # noqa: E402
-from morphsym_hgnn_amd import engine as eng, synth  # noqa: E402
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+L = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+dtype = sys.argv[3] if len(sys.argv) > 3 else "bf16"
+dev = torch.device("cuda:0")
+spec = bench.build_spec(L, "a1c2", 128)
 
-dev = torch.device("cuda", 0)
-spec = bench.build_spec(3)
 
-
-def mk(B, seed, slab):
-    if slab is None:
-        os.environ.pop("MSHGNN_SLAB", None)
-    else:
-        os.environ["MSHGNN_SLAB"] = str(slab)
-    e = eng.Engine(spec, dtype="bf16", device=dev)
-    x, y = bench.make_batch(spec, B, seed)
-    xs = e.cast_inputs(x)
-    y = y.to(dev)
+def setup(b, seed):
+    e = eng.Engine(spec, dtype, device=dev)
+    x, y = bench.make_batch(spec, b, seed)
+    xs = e.cast_inputs({k: v.to(dev) for k, v in x.items()})
     flat = eng.flatten_params(spec, synth.make_params(0, spec.param_shapes()), dev)
-    gflat = torch.empty_like(flat)
-    out = torch.empty(B * 4, 3, dtype=torch.float32, device=dev)
-    loss = torch.empty(1, device=dev)
-
-    def step():
-        e.step_mse(xs, flat, y, B, out=out, grad_flat=gflat, loss=loss)
-
-    def fwd():
-        e.forward(xs, flat, B, training=True, out=out)
-
-    def bwd():
-        e.backward_mse(xs, flat, out, y, B, grad_flat=gflat, loss=loss)
-
-    step.fwd, step.bwd, step.engine = fwd, bwd, e
-    return step
+    yd = y.reshape(-1).to(dev, torch.float32)
+    out = torch.empty(b * spec.num_nodes[spec.out_type], spec.out_channels, dtype=torch.float32, device=dev)
+    loss = torch.empty(1, dtype=torch.float32, device=dev); g = torch.empty_like(flat)
+    return lambda: e.step_mse(xs, flat, yd, b, out=out, loss=loss, grad_flat=g)
 
 
-def timeit(fn, n=60, reps=5):
-    for _ in range(8):
-        fn()
-    ts = []
-    for _ in range(reps):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(n):
-            fn()
-        torch.cuda.synchronize()
-        ts.append((time.perf_counter() - t0) / n * 1e3)
-    return sorted(ts)[len(ts) // 2]
+def timed(fns, streams, n=200):
+    for _ in range(20):
+        for f, s in zip(fns, streams):
+            with torch.cuda.stream(s):
+                f()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        for f, s in zip(fns, streams):
+            with torch.cuda.stream(s):
+                f()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
 
 
-def main():
-    trace = "--trace" in sys.argv
-    n = 6 if trace else 60
-    reps = 1 if trace else 5
-    res = {"what": __doc__.split("\n")[0], "workload": "A1-C2 h=128 L=3 bf16 plan, 8192 windows per pair", "ms_per_8192_windows": {}}
-    r = res["ms_per_8192_windows"]
-    full = mk(8192, 1, None)
-    r["full"] = timeit(full, n, reps)
-    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
-    for slab, tag in ((2, "slab_1wg_per_cu"), (0, "eight_wave")):
-        a, b = mk(4096, 2, slab), mk(4096, 3, slab)
-        r[f"{tag}.one_half"] = timeit(a, n, reps)
-
-        def serial():
-            a(); b()
-        r[f"{tag}.halves_serial"] = timeit(serial, n, reps)
-
-        def joined():
-            cur = torch.cuda.current_stream()
-            s1.wait_stream(cur); s2.wait_stream(cur)
-            with torch.cuda.stream(s1):
-                a()
-            with torch.cuda.stream(s2):
-                b()
-            cur.wait_stream(s1); cur.wait_stream(s2)
-        r[f"{tag}.halves_joined"] = timeit(joined, n, reps)
-
-        def free():
-            with torch.cuda.stream(s1):
-                a()
-            with torch.cuda.stream(s2):
-                b()
-        r[f"{tag}.halves_free"] = timeit(free, n, reps)
-
-        def offset():
-            cur = torch.cuda.current_stream()
-            s1.wait_stream(cur); s2.wait_stream(cur)
-            with torch.cuda.stream(s1):
-                a.fwd()
-                ev = torch.cuda.Event(); ev.record(s1)
-                a.bwd()
-            with torch.cuda.stream(s2):
-                s2.wait_event(ev)
-                b.fwd(); b.bwd()
-            cur.wait_stream(s1); cur.wait_stream(s2)
-        r[f"{tag}.halves_offset_two_call"] = timeit(offset, n, reps)
-
-        def two_call_serial():
-            a.fwd(); a.bwd(); b.fwd(); b.bwd()
-        r[f"{tag}.halves_serial_two_call"] = timeit(two_call_serial, n, reps)
-        del a, b
-        torch.cuda.empty_cache()
-    print(json.dumps(res))
-
-
-if __name__ == "__main__":
-    main()
+one = timed([setup(B, 1)], [torch.cuda.Stream(dev)])
+print(f"one stream,  B={B}: {one * 1e3:.4f} ms/step = {B / one / 1e6:.2f} M windows/s", flush=True)
+for parts in (2, 4):
+    fns = [setup(B // parts, 10 + i) for i in range(parts)]
+    t = timed(fns, [torch.cuda.Stream(dev) for _ in range(parts)])
+    print(f"{parts} streams, B={B // parts} each: {t * 1e3:.4f} ms per round = {B / t / 1e6:.2f} M windows/s", flush=True)
+    t1 = timed(fns, [torch.cuda.current_stream(dev)] * parts)
+    print(f"   (the same {parts} steps on one stream: {t1 * 1e3:.4f} ms per round = {B / t1 / 1e6:.2f} M windows/s)", flush=True)
