@@ -2085,7 +2085,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinArgs a) {
         for (int b = threadIdx.x; b < a.n_dec; b += 64) l += a.dec_slabs[(size_t)b * DEC_SLAB_FLOATS + 8 * H + 8];
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) l += __shfl_xor(l, m, 64);
-        if (threadIdx.x == 0) *a.loss = l * a.inv_n;
+        if (threadIdx.x == 0) *a.loss = l * a.inv_n + (a.accumulate ? *a.loss : 0.f);      // (accumulate: a later sub-step of a chunked step, mshgnn_device.hpp StepChunk)
     }
     const bool is_mat = (kind == FIN_MATRIX || kind == FIN_DEC_W);
     if (kind == FIN_DEC_W || kind == FIN_DEC_B) {
@@ -2104,7 +2104,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinArgs a) {
             }
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) sum += __shfl_xor(sum, m, 64);
-            if (lane == 0) a.grad[dst + (int64_t)r * ld + cidx] = sum;
+            if (lane == 0) { float* gp = a.grad + dst + (int64_t)r * ld + cidx; *gp = a.accumulate ? *gp + sum : sum; }
         }
         return;
     }
@@ -2130,6 +2130,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinArgs a) {
                     for (int jj = 0; jj < FIN_LB; ++jj) s += (v[jj][0] + v[jj][1]) + (v[jj][2] + v[jj][3]);
                 }
         }
+        if (a.accumulate) s += a.grad[dst + (int64_t)r * ld + cidx];      // (the further destinations of a shared sum held the same value)
         a.grad[dst + (int64_t)r * ld + cidx] = s;
         if (more) {
             const int nm = more[0];
@@ -2149,6 +2150,7 @@ extern "C" int mshgnn_plan_create(const mshgnn_desc* desc, mshgnn_plan** out) {
     if (!p) return set_err(MSHGNN_ENOMEM, "out of host memory");
     if (!desc) { delete p; return set_err(MSHGNN_EINVAL, "null descriptor"); }
     p->n_types = desc->n_types;
+    if (const char* e = getenv("MSHGNN_STEP_CHUNK")) p->step_chunk = std::max<int64_t>(0, atoll(e));
     // Engine choice: the LDS-resident kernels (hidden == 128, <= 20 nodes, in-degree 1 on mean relations) where they apply, else the
     // generic-width engine of mshgnn_gen.hip.  MSHGNN_ENGINE=generic forces the latter (the GPU tests run the golden cases through both).
     const char* eng_env = getenv("MSHGNN_ENGINE");
@@ -2304,8 +2306,8 @@ int run_finalize(const mshgnn_plan* p, const mshgnn_ws_layout& lay, char* ws, fl
     const mshgnn_desc& d = hp.d;
     FinArgs a{p->d_tables + hp.fin_off, p->d_tables + hp.fin_off, p->d_tables + hp.tgt_off, reinterpret_cast<const float*>(ws + lay.slabs),
               reinterpret_cast<const float*>(ws + lay.dec_slabs), gparams, hp.n_lanes, gw_parts, loss,
-              1.0f / (float)((int64_t)B * d.type_nodes[d.out_type] * (is_ce ? 1 : d.out_channels)),
-              dec_done ? (int)((B + TILE_ROWS - 1) / TILE_ROWS) : NWG_DEC};
+              1.0f / (float)(loss_windows(B) * d.type_nodes[d.out_type] * (is_ce ? 1 : d.out_channels)),
+              dec_done ? (int)((B + TILE_ROWS - 1) / TILE_ROWS) : NWG_DEC, step_accumulates()};
     int f0 = 0, nf = hp.n_fin;
     if (gw_phase == 0) nf = hp.n_fin_ph0;
     if (gw_phase == 1) { f0 = hp.n_fin_ph0; nf = hp.n_fin - hp.n_fin_ph0; a.loss = nullptr; }
@@ -2412,10 +2414,10 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
             a.node0 = hp.type_base[d.out_type]; a.n_out = d.type_nodes[d.out_type]; a.dout = d.out_channels;
             if (y_fused) {
                 a.y = y_fused; a.dec_slabs = reinterpret_cast<float*>(ws + lay.dec_slabs); a.dx_off[hp.L] = lay.dx[hp.L];
-                a.inv_n = 1.0f / (float)((int64_t)B * a.n_out * a.dout);
+                a.inv_n = 1.0f / (float)(loss_windows(B) * a.n_out * a.dout);
             } else if (labels_fused) {      // mshgnn_step_ce: cross entropy over the per-foot logit pairs, mean over B * n_out rows
                 a.labels = labels_fused; a.dec_slabs = reinterpret_cast<float*>(ws + lay.dec_slabs); a.dx_off[hp.L] = lay.dx[hp.L];
-                a.inv_n = 1.0f / (float)((int64_t)B * a.n_out);
+                a.inv_n = 1.0f / (float)(loss_windows(B) * a.n_out);
             }
             a.stamps = stamp_ptr("MSHGNN_STAMPS");
             a.stagger = p->slab_for(tiles) && tiles > p->n_cu ? p->stagger : 0;
@@ -2490,10 +2492,10 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
         a.slabs = reinterpret_cast<float*>(ws + lay.dec_slabs); a.off_w = d.off_dec_w; a.off_b = d.off_dec_b;
         a.B = B; a.NN = hp.NN; a.node0 = hp.type_base[d.out_type]; a.n_out = d.type_nodes[d.out_type]; a.dout = d.out_channels; a.slab0 = 0;
         if (y) {
-            a.y = y; a.out = const_cast<float*>(out); a.loss = loss; a.inv_n = 1.0f / (float)((int64_t)B * a.n_out * a.dout);
+            a.y = y; a.out = const_cast<float*>(out); a.loss = loss; a.inv_n = 1.0f / (float)(loss_windows(B) * a.n_out * a.dout);
         }
         if (labels) {
-            a.labels = labels; a.out = const_cast<float*>(out); a.loss = loss; a.inv_n = 1.0f / (float)((int64_t)B * a.n_out);
+            a.labels = labels; a.out = const_cast<float*>(out); a.loss = loss; a.inv_n = 1.0f / (float)(loss_windows(B) * a.n_out);
         }
         ProfScope ps(p, hp.ks_dec_bwd, st);
         hipLaunchKernelGGL(k_dec_bwd<T>, dim3(NWG_DEC), dim3(256), 0, st, a);
@@ -2597,11 +2599,43 @@ extern "C" int mshgnn_backward_mse(const mshgnn_plan* p, const void* const* x, c
     return backward_impl<__bf16>(p, x, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, (hipStream_t)stream, out, y, loss_out);
 }
 
+// ---- long batches as sub-steps (StepChunk, mshgnn_device.hpp) ----
+// Windows per sub-step of a one-call step over `batch` windows, 0: the step runs whole.  Whole: batches up to MSHGNN_STEP_CHUNK (read when the plan is created; default 32 768; 0 = always whole), the
+// generic-width engine (its finalize kernel overwrites), wide-source calls (their source pointers are not offset here) and the sub-steps themselves.  Equal sub-steps of
+// whole 16-window tiles.
+static int64_t step_chunk_windows(const mshgnn_plan* p, int64_t batch) {
+    const int64_t limit = p->step_chunk;
+    if (limit <= 0 || batch <= limit || p->gen || g_wide_src || g_step_chunk) return 0;
+    const int64_t n = (batch + limit - 1) / limit;
+    return ((batch + n - 1) / n + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS;
+}
+template <typename F> static int chunked_step(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, int64_t batch, int64_t cw, F&& sub_step) {
+    const mshgnn_desc& d = p->hp.d;
+    const int64_t eb = d.dtype == MSHGNN_BF16 ? 2 : 4;      // input rows: bf16 on the bf16 plan, fp32 on the split and fp32 plans
+    int idx = 0;
+    for (int64_t w0 = 0; w0 < batch; w0 += cw, ++idx) {
+        const void* xc[MSHGNN_MAX_TYPES] = {};
+        for (int t = 0; t < p->n_types; ++t)
+            xc[t] = static_cast<const char*>(x[t]) + w0 * d.type_nodes[t] * (x_pitch ? x_pitch[t] : (int64_t)d.type_width[t]) * eb;
+        const StepChunk ck{batch, idx};
+        g_step_chunk = &ck;
+        const int rc = sub_step(xc, w0, std::min(cw, batch - w0));
+        g_step_chunk = nullptr;
+        if (rc) return rc;
+    }
+    return MSHGNN_OK;
+}
+
 extern "C" int mshgnn_step_mse(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, const float* y,
                                float* out, float* loss_out, float* grad_params, void* workspace, int64_t batch, void* stream) {
     if (!p || !x || !params || !y || !out || !loss_out || !grad_params || !workspace) return set_err(MSHGNN_EINVAL, "null argument to mshgnn_step_mse");
     if (batch < 1 || batch > (1 << 24)) return set_err(MSHGNN_EINVAL, "batch must be in [1, 2^24]");
     for (int t = 0; t < p->n_types; ++t) if (!x[t]) return set_err(MSHGNN_EINVAL, "null input tensor");
+    if (const int64_t cw = step_chunk_windows(p, batch)) {      // a long batch: sub-steps over contiguous window ranges, one gradient (StepChunk)
+        const int64_t orow = (int64_t)p->hp.d.type_nodes[p->hp.d.out_type] * p->hp.d.out_channels;
+        return chunked_step(p, x, x_pitch, batch, cw, [&](const void* const* xc, int64_t w0, int64_t bc) {
+            return mshgnn_step_mse(p, xc, x_pitch, params, y + w0 * orow, out + w0 * orow, loss_out, grad_params, workspace, bc, stream); });
+    }
     hipStream_t st = (hipStream_t)stream;
     if (p->gen) {      // generic-width engine: the two-call sequence
         const int rc = gen_forward(p, x, x_pitch, params, out, (char*)workspace, batch, 1, st);
@@ -2633,6 +2667,11 @@ extern "C" int mshgnn_step_ce(const mshgnn_plan* p, const void* const* x, const 
     if (batch < 1 || batch > (1 << 24)) return set_err(MSHGNN_EINVAL, "batch must be in [1, 2^24]");
     for (int t = 0; t < p->n_types; ++t) if (!x[t]) return set_err(MSHGNN_EINVAL, "null input tensor");
     if (p->hp.d.out_channels != 2) return set_err(MSHGNN_EINVAL, "mshgnn_step_ce: the classification wrappers have two logits per foot");
+    if (const int64_t cw = step_chunk_windows(p, batch)) {
+        const int64_t n_out = p->hp.d.type_nodes[p->hp.d.out_type];
+        return chunked_step(p, x, x_pitch, batch, cw, [&](const void* const* xc, int64_t w0, int64_t bc) {
+            return mshgnn_step_ce(p, xc, x_pitch, params, labels + w0 * n_out, out + w0 * n_out * 2, loss_out, grad_params, workspace, bc, stream); });
+    }
     hipStream_t st = (hipStream_t)stream;
     // bf16 plan with the fused stack kernels: decoder, cross entropy and decoder backward in the tail of the forward kernel; every other plan: the
     // two-call sequence (mshgnn_forward + mshgnn_backward_ce)

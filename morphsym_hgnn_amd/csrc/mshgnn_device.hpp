@@ -435,6 +435,14 @@ struct WideSrc {
     int64_t pitch[MSHGNN_MAX_TYPES];         // elements
 };
 inline thread_local const WideSrc* g_wide_src = nullptr;      // set by the _src entry points around the plain call they forward to (host side, same thread)
+// One-call steps over more windows than MSHGNN_STEP_CHUNK (default 32 768) run as a sequence of sub-steps over contiguous window ranges on the same workspace
+// (mshgnn_step_mse / mshgnn_step_ce): every sub-step scales its loss terms by the WHOLE batch's element count and the finalize launches after the first add to the
+// flat gradient and the loss instead of overwriting them.  Measured on Solo-12 K4 (BASELINE configs[3], 65 536 windows): the weight-gradient launch of one 65 536-window
+// step costs 1.03x (bf16) / 1.21x (split plan) two 32 768-window ones, and the step's stash footprint halves.  Set by the entry point around its sub-steps (host side).
+struct StepChunk { int64_t total_windows; int index; };
+inline thread_local const StepChunk* g_step_chunk = nullptr;
+inline int64_t loss_windows(int64_t B) { return g_step_chunk ? g_step_chunk->total_windows : B; }
+inline int step_accumulates() { return g_step_chunk && g_step_chunk->index > 0 ? 1 : 0; }
 // 8 source elements held as 8-byte units -> 8 fp32 values (two f32x4); units past `nvalid` elements were not requested: zero
 template <int SB> __device__ __forceinline__ void wide_to_f32(const u32x2 (&u)[SB], int nvalid, f32x4& lo, f32x4& hi) {
     float f[8];
@@ -1076,7 +1084,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16* tile, int w_base, int co
 
 
 struct FinArgs { const int* fin; const int* fin0; const int* targets; const float* slabs; const float* dec_slabs; float* grad; int n_lanes, n_parts; float* loss; float inv_n;
-                 int n_dec; };   // decoder partial slabs: NWG_DEC (k_dec_bwd) or one per tile (fused forward)
+                 int n_dec; int accumulate; };   // decoder partial slabs: NWG_DEC (k_dec_bwd) or one per tile (fused forward)
 
 struct mshgnn_gen_state;      // generic-width engine (mshgnn_gen.hip)
 struct ProfRec { int slot; hipEvent_t a, b; };
@@ -1091,6 +1099,7 @@ struct mshgnn_plan {
     bool use_fused = false;             // bf16 plan: fused stack kernels (MSHGNN_FUSED=0 selects the per-layer kernels)
     bool use_slab = false;              // slab variant of the stack kernels (MSHGNN_SLAB=0 selects the 8-wave ones)
     bool slab_force = false; int n_cu = 256;
+    int64_t step_chunk = 32768;         // one-call steps over more windows run as sub-steps (StepChunk; MSHGNN_STEP_CHUNK, 0 = never)
     bool use_step = false;              // one-call steps on the slab kernels: k_slab_step (MSHGNN_STEP_KERNEL=0: two launches)
     int stagger = 0;                             // StackArgs.stagger of the two-workgroups-per-CU stack kernels (MSHGNN_STAGGER)
     int n_types = 0;

@@ -1255,10 +1255,10 @@ int x3_forward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitc
         a.node0 = hp.type_base[d.out_type]; a.n_out = d.type_nodes[d.out_type]; a.dout = d.out_channels;
         if (y_fused) {
             a.y = y_fused; a.dec_slabs = reinterpret_cast<float*>(ws + lay.dec_slabs);
-            a.inv_n = 1.0f / (float)((int64_t)B * a.n_out * a.dout);
+            a.inv_n = 1.0f / (float)(loss_windows(B) * a.n_out * a.dout);
         } else if (labels_fused) {      // mshgnn_step_ce: cross entropy over the per-foot logit pairs, mean over B * n_out rows (the tail is the bf16 plan's)
             a.labels = labels_fused; a.dec_slabs = reinterpret_cast<float*>(ws + lay.dec_slabs);
-            a.inv_n = 1.0f / (float)((int64_t)B * a.n_out);
+            a.inv_n = 1.0f / (float)(loss_windows(B) * a.n_out);
         }
         const int tiles = (B + P16::ROWS - 1) / P16::ROWS;
         a.stamps = stamp_ptr("MSHGNN_STAMPS");
@@ -1291,8 +1291,8 @@ int x3_backward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pit
         a.xl = ws + lay.x[hp.L]; a.dxl = ws + lay.dx[hp.L]; a.params = params; a.out_mask = p->d_out_mask; a.gout = gout;
         a.slabs = reinterpret_cast<float*>(ws + lay.dec_slabs); a.off_w = d.off_dec_w; a.off_b = d.off_dec_b;
         a.B = B; a.NN = hp.NN; a.node0 = hp.type_base[d.out_type]; a.n_out = d.type_nodes[d.out_type]; a.dout = d.out_channels; a.slab0 = 0;
-        if (y) { a.y = y; a.out = const_cast<float*>(out); a.loss = loss; a.inv_n = 1.0f / (float)((int64_t)B * a.n_out * a.dout); }
-        if (labels) { a.labels = labels; a.out = const_cast<float*>(out); a.loss = loss; a.inv_n = 1.0f / (float)((int64_t)B * a.n_out); }
+        if (y) { a.y = y; a.out = const_cast<float*>(out); a.loss = loss; a.inv_n = 1.0f / (float)(loss_windows(B) * a.n_out * a.dout); }
+        if (labels) { a.labels = labels; a.out = const_cast<float*>(out); a.loss = loss; a.inv_n = 1.0f / (float)(loss_windows(B) * a.n_out); }
         ProfScope ps(p, hp.ks_dec_bwd, st);
         hipLaunchKernelGGL(k_dec_bwd_x3, dim3(NWG_DEC), dim3(256), 0, st, a);
     }
