@@ -1262,9 +1262,14 @@ int x3_forward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitc
         }
         const int tiles = (B + P16::ROWS - 1) / P16::ROWS;
         a.stamps = stamp_ptr("MSHGNN_STAMPS");
-        // one-call step: the backward sweep in the same launch (the tail's reduction scratch, one decoder slab per wave at the start of LDS, must end below the
-        // out-type nodes' blocks)
-        const bool step = stack_step_done && (y_fused || labels_fused) && p->use_step && (size_t)a.node0 * P16::BLK >= (size_t)(LAYER_THREADS / 64) * DEC_SLAB_FLOATS * sizeof(float);
+        // one-call step: the backward sweep in the same launch.  The tail's reduction scratch (one decoder slab per wave) must not touch the out-type nodes' blocks
+        // of either plane, which receive dX_L for the backward sweep: it sits in the hi plane's blocks in front of them, or (models whose out type comes first: the
+        // centroidal-momentum ones) in the hi plane's blocks behind them -- as on the bf16 plan (forward_impl, mshgnn.hip)
+        const size_t red_need = (size_t)(LAYER_THREADS / 64) * DEC_SLAB_FLOATS * sizeof(float);
+        const size_t red_back = (size_t)(a.node0 + a.n_out) * P16::BLK, plane = (size_t)hp.fs_blk * P16::BLK;
+        const bool red_front_ok = (size_t)a.node0 * P16::BLK >= red_need, red_back_ok = red_back + red_need <= plane;
+        const bool step = stack_step_done && (y_fused || labels_fused) && p->use_step && (red_front_ok || red_back_ok);
+        if (step && !red_front_ok) a.red_off = (int)red_back;
         ProfScope ps(p, step ? hp.ks_stack_step : hp.ks_stack_fwd, st);
         if (step) {
             a.mask0_off = lay.dd[0];

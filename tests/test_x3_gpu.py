@@ -84,11 +84,13 @@ def test_x3_one_call_step_equals_forward_plus_backward_and_repeats():
         assert float((g_a - g_b).abs().max() / g_a.abs().max()) < 2e-5
 
 
-@pytest.mark.parametrize("kind,topo,cfg,B", [("c2", "a1-c2", "a1-c2", 1000), ("k4", "mini_cheetah-k4", "mini_cheetah-k4", 333)])
+@pytest.mark.parametrize("kind,topo,cfg,B", [("c2", "a1-c2", "a1-c2", 1000), ("k4", "mini_cheetah-k4", "mini_cheetah-k4", 333),
+                                             ("k4_com", "solo-k4-com", "solo-k4", 500), ("c2_com", "solo-c2-com", "solo-c2", 77)])
 def test_x3_step_kernel_and_two_launches_agree_bit_for_bit(kind, topo, cfg, B, monkeypatch):
     """k_stack_step_x3 (forward + backward sweep in one launch: dX_L handed over through LDS as split hi / lo rows, no tile reload) against the two
     launches k_stack_fwd_x3 + k_stack_bwd_x3 (MSHGNN_STEP_KERNEL=0, read per plan): same code in the same order, so output, loss and every gradient
-    are identical bits -- A1-C2 and MiniCheetah-K4 (the instantiation whose scratch blocks alias the feet's blocks)."""
+    are identical bits -- A1-C2, MiniCheetah-K4 (the instantiation whose scratch blocks alias the feet's blocks) and the Solo centroidal-momentum models, whose
+    out type (the base) comes first: the tail's reduction scratch then sits behind the base blocks (StackArgs.red_off)."""
     from morphsym_hgnn_amd import engine as eng, synth
     spec = helpers.make_spec(kind, topo, cfg, 128, 3, grf=3 if kind == "c2" else 1)
     n_y = spec.out_channels * spec.num_nodes[spec.out_type]
