@@ -197,8 +197,8 @@ int mshgnn_backward_mse(const mshgnn_plan* plan, const void* const* x, const int
  * mshgnn_backward_mse, same results up to fp32 summation order.  On the bf16 plan the decoder, the loss and the decoder
  * backward all run inside the fused forward kernel (one launch less, no X_L / dX_L round trip); other plans run the
  * two-call sequence.  out receives the forward output, loss_out mean((out - y)^2), grad_params every gradient.
- * Batches of more than MSHGNN_STEP_CHUNK windows (read at plan creation, default 32768, 0 = never; mshgnn_step_ce alike; not the generic-width engine, not the
- * _src / _series forms) run as equal sub-steps over contiguous window ranges on the front of the same workspace: same out, loss and gradient up to fp32
+ * Batches of at least twice MSHGNN_STEP_CHUNK windows (read at plan creation, default 32768, 0 = never; mshgnn_step_ce alike; not the generic-width engine, not the
+ * _src / _series forms) run as equal sub-steps of at least that many windows over contiguous window ranges on the front of the same workspace: same out, loss and gradient up to fp32
  * summation order (sub-step sums are added in order: still deterministic); afterwards the workspace holds the stashes of the LAST sub-step only.             */
 int mshgnn_step_mse(const mshgnn_plan* plan, const void* const* x, const int64_t* x_pitch, const float* params, const float* y,
                     float* out, float* loss_out, float* grad_params, void* workspace, int64_t batch, void* stream);

@@ -2600,13 +2600,13 @@ extern "C" int mshgnn_backward_mse(const mshgnn_plan* p, const void* const* x, c
 }
 
 // ---- long batches as sub-steps (StepChunk, mshgnn_device.hpp) ----
-// Windows per sub-step of a one-call step over `batch` windows, 0: the step runs whole.  Whole: batches up to MSHGNN_STEP_CHUNK (read when the plan is created; default 32 768; 0 = always whole), the
+// Windows per sub-step of a one-call step over `batch` windows, 0: the step runs whole.  Whole: batches under twice MSHGNN_STEP_CHUNK (read when the plan is created; default 32 768; 0 = always whole), the
 // generic-width engine (its finalize kernel overwrites), wide-source calls (their source pointers are not offset here) and the sub-steps themselves.  Equal sub-steps of
 // whole 16-window tiles.
 static int64_t step_chunk_windows(const mshgnn_plan* p, int64_t batch) {
     const int64_t limit = p->step_chunk;
-    if (limit <= 0 || batch <= limit || p->gen || g_wide_src || g_step_chunk) return 0;
-    const int64_t n = (batch + limit - 1) / limit;
+    if (limit <= 0 || batch < 2 * limit || p->gen || g_wide_src || g_step_chunk) return 0;
+    const int64_t n = batch / limit;      // sub-steps of at least `limit` windows each (a step's cost per window is flat from there up; shorter ones cost ~5 % more)
     return ((batch + n - 1) / n + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS;
 }
 template <typename F> static int chunked_step(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, int64_t batch, int64_t cw, F&& sub_step) {

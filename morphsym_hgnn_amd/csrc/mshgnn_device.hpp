@@ -435,7 +435,7 @@ struct WideSrc {
     int64_t pitch[MSHGNN_MAX_TYPES];         // elements
 };
 inline thread_local const WideSrc* g_wide_src = nullptr;      // set by the _src entry points around the plain call they forward to (host side, same thread)
-// One-call steps over more windows than MSHGNN_STEP_CHUNK (default 32 768) run as a sequence of sub-steps over contiguous window ranges on the same workspace
+// One-call steps over at least twice MSHGNN_STEP_CHUNK windows (default 32 768) run as a sequence of equal sub-steps of at least that many windows over contiguous window ranges on the same workspace
 // (mshgnn_step_mse / mshgnn_step_ce): every sub-step scales its loss terms by the WHOLE batch's element count and the finalize launches after the first add to the
 // flat gradient and the loss instead of overwriting them.  Measured on Solo-12 K4 (BASELINE configs[3], 65 536 windows): the weight-gradient launch of one 65 536-window
 // step costs 1.03x (bf16) / 1.21x (split plan) two 32 768-window ones, and the step's stash footprint halves.  Set by the entry point around its sub-steps (host side).
@@ -1099,7 +1099,7 @@ struct mshgnn_plan {
     bool use_fused = false;             // bf16 plan: fused stack kernels (MSHGNN_FUSED=0 selects the per-layer kernels)
     bool use_slab = false;              // slab variant of the stack kernels (MSHGNN_SLAB=0 selects the 8-wave ones)
     bool slab_force = false; int n_cu = 256;
-    int64_t step_chunk = 32768;         // one-call steps over more windows run as sub-steps (StepChunk; MSHGNN_STEP_CHUNK, 0 = never)
+    int64_t step_chunk = 32768;         // one-call steps over at least twice as many windows run as sub-steps of at least this many (StepChunk; MSHGNN_STEP_CHUNK, 0 = never)
     bool use_step = false;              // one-call steps on the slab kernels: k_slab_step (MSHGNN_STEP_KERNEL=0: two launches)
     int stagger = 0;                             // StackArgs.stagger of the two-workgroups-per-CU stack kernels (MSHGNN_STAGGER)
     int n_types = 0;
