@@ -5,12 +5,12 @@ import torch
 import bench
 
 orig = bench.median_step_s
-names = iter(["module fp64", "module plan-dtype", "wrapper plan-dtype", "wrapper fp64", "module cast pass"])
+names = iter([f"{n}, pass {i}" for n in ("module fp64", "module plan-dtype", "wrapper plan-dtype", "wrapper fp64", "module cast pass") for i in (1, 2)])      # (bench takes the better of two passes per route)
 
 
 def twice(step, sync, steps, warmup, *a, **k):
     n = next(names)
-    r = [orig(step, sync, steps, warmup, *a, **k) for _ in range(3)]
+    r = [orig(step, sync, steps, warmup, *a, **k) for _ in range(2)]
     print(n, [round(x * 1e3, 4) for x in r], flush=True)
     return r[-1]
 
