@@ -809,8 +809,8 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
 // under this one's MAC phases.  The destination nodes are processed in two groups (mshgnn_plan.hpp, SL_HA / SL_HB) so that
 // the accumulators stay in registers; group A's new activations wait, packed, while group B is multiplied.
 // ------------------------------------------------------------------------------------------------------
-template <typename T, int HS, int Q0, int NM = 4>     // one group: slots q = Q0 + u of the slab header; NM: compile-time bound on the base_transform nodes
-__device__ __forceinline__ void slab_group_fwd(const StackArgs& a, const FHdr& fh, const FProg& wp, char* smem, const T* wpack, int wn, int lane,
+template <typename T, int HS, int Q0, int NM = 4, class FH = FHdr, class FP = FProg>     // one group: slots q = Q0 + u of the slab header; NM: compile-time bound on the base_transform nodes
+__device__ __forceinline__ void slab_group_fwd(const StackArgs& a, const FH& fh, const FP& wp, char* smem, const T* wpack, int wn, int lane,
                                                int slot_base, int nmlp, bool residual, u32x4 (&keep)[HS], unsigned (&bits)[(HS + 3) / 4]) {
     using P = Prec<T>;
     const int win = c_win(lane), col = wn * 32 + c_oct(lane);
@@ -904,12 +904,13 @@ __device__ __forceinline__ void slab_group_fwd(const StackArgs& a, const FHdr& f
                 y0 += r0; y1 += r1;
             }
             keep[u] = pack_oct(y0, y1);
+            pad_valu();
         }
     }
 }
 // write one group's new activations: LDS block, stash, relu bytes
-template <typename T, int HS, int Q0>
-__device__ __forceinline__ void slab_group_store(const StackArgs& a, const FHdr& fh, char* smem, int wn, int lane, int slot_arr, int l,
+template <typename T, int HS, int Q0, class FH = FHdr>
+__device__ __forceinline__ void slab_group_store(const StackArgs& a, const FH& fh, char* smem, int wn, int lane, int slot_arr, int l,
                                                  const u32x4 (&keep)[HS], const unsigned (&bits)[(HS + 3) / 4], bool stash_x = true) {
     using P = Prec<T>;
     const int win = c_win(lane), col = wn * 32 + c_oct(lane), w = blockIdx.x * P::ROWS + win;
@@ -929,9 +930,41 @@ __device__ __forceinline__ void slab_group_store(const StackArgs& a, const FHdr&
     }
 }
 
+// one forward layer of a slab workgroup: both groups' MAC passes, then the layer's stores.  FH / FP: the layer's header and wave programs, interpreted (FHdr /
+// FProg: plan tables in VGPRs) or compile-time (SHdr / SProg: specialised kernels); mid(): what has to settle between the MACs and the stores
+template <typename T, int NM, int HB, bool STEP, class FH, class FP, class FPB, class Mid>
+__device__ __forceinline__ void slab_fwd_layer(const StackArgs& a, char* smem, const T* wpack, int wn, int lane, int l, int L, const FH& fh, const FP& wa, const FPB& wb, Mid&& mid) {
+    const int tid = threadIdx.x;
+    const int nmlp = fh[FH_NMLP];
+    const bool residual = (fh[FH_FLAGS] & FF_RESIDUAL) != 0;
+    u32x4 keepA[SL_HA], keepB[HB]; unsigned bitsA[(SL_HA + 3) / 4], bitsB[(HB + 3) / 4];
+    slab_group_fwd<T, SL_HA, 0>(a, fh, wa, smem, wpack, wn, lane, FH_SLOTA | (l << 8), 0, residual, keepA, bitsA);
+    FS_STAMP(2 + 4 * l);
+    slab_group_fwd<T, HB, SL_HA, NM>(a, fh, wb, smem, wpack, wn, lane, FH_SLOTB | (l << 8), nmlp, residual, keepB, bitsB);
+    FS_STAMP(3 + 4 * l);
+    __syncthreads();   // every wave is done reading X_l: the node blocks may be overwritten
+    FS_STAMP(4 + 4 * l);
+    mid();      // the next header / programs have landed before the stores go out (no drain at the top of the next layer)
+    const bool stash_x = !(STEP && l + 1 == L);      // X_L of a one-launch step is read by nobody (the decoder's gradients come from the tile in LDS)
+    slab_group_store<T, SL_HA, 0>(a, fh, smem, wn, lane, FH_SLOTA, l, keepA, bitsA, stash_x);
+    slab_group_store<T, HB, SL_HA>(a, fh, smem, wn, lane, FH_SLOTB, l, keepB, bitsB, stash_x);
+    __syncthreads();
+    FS_STAMP(5 + 4 * l);
+}
+// the layers of a compile-time program SP, unrolled
+template <typename T, int NM, int HB, bool STEP, class SP, int l = 0>
+__device__ __forceinline__ void slab_fwd_layers_static(const StackArgs& a, char* smem, const T* wpack, int wn, int lane) {
+    if constexpr (l < SP::L) {
+        slab_fwd_layer<T, NM, HB, STEP>(a, smem, wpack, wn, lane, l, SP::L, SHdr<SP, 0, l>{}, SProg<SP, 0, l, 0>{}, SProg<SP, 0, l, 1>{}, [] {});
+        slab_fwd_layers_static<T, NM, HB, STEP, SP, l + 1>(a, smem, wpack, wn, lane);
+    }
+}
+
 // STEP: part of k_slab_step -- the decoder tail leaves dX_L in the out-type nodes' LDS blocks for the backward sweep that follows in the same launch
-template <typename T, int NM, int HB, bool STEP> __device__ __forceinline__ void slab_fwd_body(const StackArgs& a, char* smem) {
+// SP: void = the plan's tables are interpreted; else the compile-time program of one (topology, depth) (mshgnn_spec_tables.inc)
+template <typename T, int NM, int HB, bool STEP, class SP = void> __device__ __forceinline__ void slab_fwd_body(const StackArgs& a, char* smem) {
     using P = Prec<T>;
+    constexpr bool DYN = std::is_void<SP>::value;
     const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int w0 = blockIdx.x * P::ROWS, B = a.B, NN = a.NN;
     const T* wpack = reinterpret_cast<const T*>(a.wpack);
@@ -939,8 +972,11 @@ template <typename T, int NM, int HB, bool STEP> __device__ __forceinline__ void
     FS_STAMP(0);
 
     // layer 0's header and programs stream in under the tile load
-    FHdr fhn(a.tables + a.prog_off[0], lane);
-    FProg wan(a.tables + a.prog_off[0] + FH_SIZE, lane), wbn(a.tables + a.prog_off[0] + FH_SIZE + FPROG_LEN, lane);
+    FHdr fhn; FProg wan, wbn;
+    if constexpr (DYN) {
+        fhn = FHdr(a.tables + a.prog_off[0], lane);
+        wan = FProg(a.tables + a.prog_off[0] + FH_SIZE, lane); wbn = FProg(a.tables + a.prog_off[0] + FH_SIZE + FPROG_LEN, lane);
+    }
     {   // X_0 tile -> LDS: thread = (row, 16-byte chunk), one node per pass, 6 loads in flight
         const T* src = reinterpret_cast<const T*>(a.tile_in);
         const int row = tid >> 4, c = tid & 15;
@@ -961,31 +997,19 @@ template <typename T, int NM, int HB, bool STEP> __device__ __forceinline__ void
     __syncthreads();
     FS_STAMP(1);
 
-    fhn.settle(); wan.settle(); wbn.settle();      // (waited for here, not by a vmcnt(0) at the top of every layer)
-    for (int l = 0; l < a.L; ++l) {
-        const FHdr fh = fhn;
-        const FProg wa = wan, wb = wbn;
-        if (l + 1 < a.L) {    // the next layer's header and wave programs stream in under this layer's MACs
-            fhn = FHdr(a.tables + a.prog_off[l + 1], lane);
-            wan = FProg(a.tables + a.prog_off[l + 1] + FH_SIZE, lane);
-            wbn = FProg(a.tables + a.prog_off[l + 1] + FH_SIZE + FPROG_LEN, lane);
+    if constexpr (DYN) {
+        fhn.settle(); wan.settle(); wbn.settle();      // (waited for here, not by a vmcnt(0) at the top of every layer)
+        for (int l = 0; l < a.L; ++l) {
+            const FHdr fh = fhn;
+            const FProg wa = wan, wb = wbn;
+            if (l + 1 < a.L) {    // the next layer's header and wave programs stream in under this layer's MACs
+                fhn = FHdr(a.tables + a.prog_off[l + 1], lane);
+                wan = FProg(a.tables + a.prog_off[l + 1] + FH_SIZE, lane);
+                wbn = FProg(a.tables + a.prog_off[l + 1] + FH_SIZE + FPROG_LEN, lane);
+            }
+            slab_fwd_layer<T, NM, HB, STEP>(a, smem, wpack, wn, lane, l, a.L, fh, wa, wb, [&] { fhn.settle(); wan.settle(); wbn.settle(); });
         }
-        const int nmlp = fh[FH_NMLP];
-        const bool residual = (fh[FH_FLAGS] & FF_RESIDUAL) != 0;
-        u32x4 keepA[SL_HA], keepB[HB]; unsigned bitsA[(SL_HA + 3) / 4], bitsB[(HB + 3) / 4];
-        slab_group_fwd<T, SL_HA, 0>(a, fh, wa, smem, wpack, wn, lane, FH_SLOTA | (l << 8), 0, residual, keepA, bitsA);
-        FS_STAMP(2 + 4 * l);
-        slab_group_fwd<T, HB, SL_HA, NM>(a, fh, wb, smem, wpack, wn, lane, FH_SLOTB | (l << 8), nmlp, residual, keepB, bitsB);
-        FS_STAMP(3 + 4 * l);
-        __syncthreads();   // every wave is done reading X_l: the node blocks may be overwritten
-        FS_STAMP(4 + 4 * l);
-        fhn.settle(); wan.settle(); wbn.settle();      // the next header / programs have landed before the stores go out (no drain at the top of the next layer)
-        const bool stash_x = !(STEP && l + 1 == a.L);      // X_L of a one-launch step is read by nobody (the decoder's gradients come from the tile in LDS)
-        slab_group_store<T, SL_HA, 0>(a, fh, smem, wn, lane, FH_SLOTA, l, keepA, bitsA, stash_x);
-        slab_group_store<T, HB, SL_HA>(a, fh, smem, wn, lane, FH_SLOTB, l, keepB, bitsB, stash_x);
-        __syncthreads();
-        FS_STAMP(5 + 4 * l);
-    }
+    } else slab_fwd_layers_static<T, NM, HB, STEP, SP>(a, smem, wpack, wn, lane);
     decoder_tail<T, SL_THREADS, false, STEP>(a, smem, tid, lane, wn, w0, B);
     FS_STAMP(30);
 }
@@ -1190,8 +1214,8 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
 // packed dX_{l+1} row this wave produced one layer earlier and kept in registers (for the last layer: the decoder
 // backward's dX_L, read once before the loop).
 // ------------------------------------------------------------------------------------------------------
-template <typename T, int HS, int Q0>
-__device__ __forceinline__ void slab_group_bwd(const StackArgs& a, const FHdr& bh, const FProg& wp, char* smem, const T* wpack, int wn, int lane,
+template <typename T, int HS, int Q0, class FH = FHdr, class FP = FProg>
+__device__ __forceinline__ void slab_group_bwd(const StackArgs& a, const FH& bh, const FP& wp, char* smem, const T* wpack, int wn, int lane,
                                                int slot_arr, const T* xact, bool enc_mask, u32x4 (&keep)[HS]) {
     using P = Prec<T>;
     if (bh[FH_FLAGS] & (Q0 == 0 ? FF_A_EMPTY : FF_B_EMPTY)) {      // no dX row of this group is produced in this layer (uniform)
@@ -1228,23 +1252,179 @@ __device__ __forceinline__ void slab_group_bwd(const StackArgs& a, const FHdr& b
         if (bh[FH_OUT + Q0 + u]) {
             const u32x4 pk = pack_oct(acc[u].c[0], acc[u].c[1]);
             keep[u] = enc_mask ? chunk_mask_bits<T>(pk, xb[u]) : pk;
+            pad_valu();
         }
     }
 }
 
-// STEP: part of k_slab_step -- the forward's decoder tail of the same launch left the dX_L tile in LDS; the layers' programs are a.prog_off_b
-template <typename T, int NM, int HB, bool STEP> __device__ __forceinline__ void slab_bwd_body(const StackArgs& a, char* smem) {
+// one backward layer of a slab workgroup (FH / FP / mid: see slab_fwd_layer); keepA / keepB carry the packed dX rows from layer to layer
+template <typename T, int NM, int HB, class FH, class FP, class FPB, class Mid>
+__device__ __forceinline__ void slab_bwd_layer(const StackArgs& a, char* smem, const T* wpack, int wn, int lane, int l, int li, const FH& bh, const FP& wa, const FPB& wb,
+                                               u32x4 (&keepA)[SL_HA], u32x4 (&keepB)[HB], Mid&& mid) {
     using P = Prec<T>;
+    const int tid = threadIdx.x, w0 = blockIdx.x * P::ROWS, B = a.B;
+    const int nmlp = bh[FH_NMLP], flags = bh[FH_FLAGS];
+    const uint8_t* maskbytes = reinterpret_cast<const uint8_t*>(a.ws + a.mask_off[l]);
+    // lane constants rebuilt per layer from an opaque copy of the lane id: the per-node global addresses derived from them
+    // would otherwise be hoisted out of the layer loop (dozens of VGPRs, spilled)
+    const int lq = opaque(lane);
+    const int win = c_win(lq), w = w0 + win, col = wn * 32 + c_oct(lq), wc = min(w, B - 1);
+    const bool w_ok = w < B;
+
+    // mask phase (each lane on the octets it owns): relu nodes are masked in place -> dH_l[n]; group A's accumulators start
+    // at the residual term G_{l+1}[n].  Every relu byte and every LDS read is issued before the first use.
+    {
+        // (the unmasked rows are the carried `keep` registers: the packed dX_{l+1} this wave wrote into the blocks itself)
+        unsigned mb[SL_HA + HB];
+#pragma unroll
+        for (int q = 0; q < SL_HA + HB; ++q) {
+            mb[q] = 0xffu;
+            if (bh[FH_KIND + q] == NK_RELU) mb[q] = maskbytes[relu_tile_base(bh[(q < SL_HA ? FH_SLOTA : FH_SLOTB - SL_HA) + q], B, blockIdx.x, wn) + lane];
+        }
+#pragma unroll
+        for (int q = 0; q < SL_HA + HB; ++q) {
+            if (bh[FH_KIND + q] == NK_RELU) {
+                const u32x4 raw = q < SL_HA ? keepA[q < SL_HA ? q : 0] : keepB[q < SL_HA ? 0 : q - SL_HA];
+                *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(bh[(q < SL_HA ? FH_SLOTA : FH_SLOTB - SL_HA) + q], win, col / P::EPC)) = chunk_mask_bits<T>(raw, mb[q]);
+            }
+        }
+    }
+    __syncthreads();
+    FS_STAMP2(1 + 6 * li);
+
+    if (nmlp > 0) {
+        // dT1 = dY W2 ; dU = dT1 . (T1 > 0) ; dH = dU W1     (backward of base_transform, in place on nodes 0..nmlp-1 = the
+        // first slots of group B); the dU / dH stashes go out behind the chain's last load
+        const T* t1 = reinterpret_cast<const T*>(a.ws + a.t1_off[l]);
+        T* du = reinterpret_cast<T*>(a.ws + a.du_off[l]);
+        T* dh = reinterpret_cast<T*>(a.ws + a.dh_off[l]);
+        // Two nodes at a time (K4 has four base_transform nodes: all four at once need 16 accumulator + 16 staging registers the kernel does not have next
+        // to the carried residual rows; each pair pays its own three barriers -- the chain is a few hundred cycles, the spills were round trips)
+        typename P::BFrag bf;      // one buffer for both weights: a carried residual (72 VGPRs) lives through this chain
+        typename P::AFrag af;
+        for (int u0 = 0; u0 < NM; u0 += 2) {
+            if (u0 >= nmlp) break;      // (uniform)
+            typename P::Acc tm[2];
+            u32x4 traw[2], dupk[2];
+            load_bfrag<T>(bf, wpack, bh[FH_W2], wn, lane);
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const int u = u0 + v;
+                traw[v] = u32x4{0, 0, 0, 0};
+                if (u < nmlp) {
+                    traw[v] = *reinterpret_cast<const u32x4*>(t1 + act_idx(wc, u, B) + col);
+                    acc_fill(tm[v], 0.f);
+                    load_afrag<T>(af, smem, u, lane);
+                    mac(tm[v], af, bf);
+                }
+            }
+            load_bfrag<T>(bf, wpack, bh[FH_W1], wn, lane);
+            __syncthreads();   // all reads of the dY blocks done
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const int u = u0 + v;
+                dupk[v] = u32x4{0, 0, 0, 0};
+                if (u < nmlp) {
+                    f32x4 t0, t1v, r0, r1; unpack_oct(traw[v], t0, t1v);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { r0[j] = t0[j] > 0.f ? tm[v].c[0][j] : 0.f; r1[j] = t1v[j] > 0.f ? tm[v].c[1][j] : 0.f; }
+                    dupk[v] = pack_oct(r0, r1);
+                    *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(u, win, col / P::EPC)) = dupk[v];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const int u = u0 + v;
+                if (u < nmlp) { acc_fill(tm[v], 0.f); load_afrag<T>(af, smem, u, lane); mac(tm[v], af, bf); }
+            }
+            __syncthreads();   // all reads of the dU blocks done
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const int u = u0 + v;
+                if (u < nmlp) {
+                    const u32x4 hp = pack_oct(tm[v].c[0], tm[v].c[1]);
+                    *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(u, win, col / P::EPC)) = hp;
+                    if (w_ok) {
+                        *reinterpret_cast<u32x4*>(du + act_idx(w, u, B) + col) = dupk[v];
+                        *reinterpret_cast<u32x4*>(dh + act_idx(w, u, B) + col) = hp;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // dX_l[j] = (residual) + dH_j W_rootsum + sum_r sum_{j->i} dH_i W_rel^r, group A then group B
+    const T* xact = reinterpret_cast<const T*>(a.ws + a.x_off[0]);
+    const bool enc_mask = (flags & FF_ENC_MASK) != 0;
+    FS_STAMP2(2 + 6 * li);
+    slab_group_bwd<T, SL_HA, 0>(a, bh, wa, smem, wpack, wn, lane, FH_SLOTA, xact, enc_mask, keepA);
+    FS_STAMP2(3 + 6 * li);
+    slab_group_bwd<T, HB, SL_HA>(a, bh, wb, smem, wpack, wn, lane, FH_SLOTB, xact, enc_mask, keepB);
+    FS_STAMP2(4 + 6 * li);
+    __syncthreads();   // every wave is done reading dH_l
+    FS_STAMP2(5 + 6 * li);
+    mid();      // next header / programs landed before the stores go out (FProg::settle)
+    T* dxo = reinterpret_cast<T*>(a.ws + a.dx_off[l]);
+#pragma unroll
+    for (int q = 0; q < SL_HA + HB; ++q) {
+        if (bh[FH_OUT + q]) {
+            const int n = bh[(q < SL_HA ? FH_SLOTA : FH_SLOTB - SL_HA) + q];
+            const u32x4 v = q < SL_HA ? keepA[q < SL_HA ? q : 0] : keepB[q < SL_HA ? 0 : q - SL_HA];
+            if (l > 0) *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(n, win, col / P::EPC)) = v;
+            if (w_ok) stash_store(dxo + act_idx(w, n, B) + col, v, a.stash_nt != 0);
+        }
+    }
+    __syncthreads();
+    FS_STAMP2(6 + 6 * li);
+}
+// the layers of a compile-time program SP, last to first, unrolled
+template <typename T, int NM, int HB, class SP, int l>
+__device__ __forceinline__ void slab_bwd_layers_static(const StackArgs& a, char* smem, const T* wpack, int wn, int lane, u32x4 (&keepA)[SL_HA], u32x4 (&keepB)[HB]) {
+    if constexpr (l >= 0) {
+        slab_bwd_layer<T, NM, HB>(a, smem, wpack, wn, lane, l, SP::L - 1 - l, SHdr<SP, 1, l>{}, SProg<SP, 1, l, 0>{}, SProg<SP, 1, l, 1>{}, keepA, keepB, [] {});
+        slab_bwd_layers_static<T, NM, HB, SP, l - 1>(a, smem, wpack, wn, lane, keepA, keepB);
+    }
+}
+// the carried rows at the start of the sweep: the decoder backward's dX_L, read back from the tile in LDS (rows past the batch are zero there)
+template <typename T, int HB, class FH>
+__device__ __forceinline__ void slab_bwd_keep_init(const FH& bh, const char* smem, int wn, int lane, u32x4 (&keepA)[SL_HA], u32x4 (&keepB)[HB]) {
+    using P = Prec<T>;
+    const int loffq = lds_chunk<T>(0, c_win(lane), (wn * 32 + c_oct(lane)) / P::EPC);
+#pragma unroll
+    for (int u = 0; u < SL_HA; ++u) {
+        keepA[u] = u32x4{0, 0, 0, 0};
+        const int n = bh[FH_SLOTA + u];
+        if (n >= 0 && bh[FH_KIND + u] != NK_DEAD) keepA[u] = *reinterpret_cast<const u32x4*>(smem + n * P::BLK + loffq);
+    }
+#pragma unroll
+    for (int u = 0; u < HB; ++u) {
+        keepB[u] = u32x4{0, 0, 0, 0};
+        const int n = bh[FH_SLOTB + u];
+        if (n >= 0 && bh[FH_KIND + SL_HA + u] != NK_DEAD) keepB[u] = *reinterpret_cast<const u32x4*>(smem + n * P::BLK + loffq);
+    }
+}
+
+// STEP: part of k_slab_step -- the forward's decoder tail of the same launch left the dX_L tile in LDS; the layers' programs are a.prog_off_b
+// SP: void = the plan's tables are interpreted; else the compile-time program of one (topology, depth)
+template <typename T, int NM, int HB, bool STEP, class SP = void> __device__ __forceinline__ void slab_bwd_body(const StackArgs& a, char* smem) {
+    using P = Prec<T>;
+    constexpr bool DYN = std::is_void<SP>::value;
     const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int w0 = blockIdx.x * P::ROWS, B = a.B, NN = a.NN;
     const T* wpack = reinterpret_cast<const T*>(a.wpack);
     static_assert(sizeof(T) == 2, "fused stack kernels are bf16");
+    static_assert(DYN || STEP, "compile-time programs exist for the one-launch step only");
     auto prog_of = [&](int l) { return STEP ? a.prog_off_b[l] : a.prog_off[l]; };
     if constexpr (!STEP) stack_stagger(a);
 
     // the last layer's header and programs stream in under the tile load
-    FHdr bhn(a.tables + prog_of(a.L - 1), lane);
-    FProg wan(a.tables + prog_of(a.L - 1) + FH_SIZE, lane), wbn(a.tables + prog_of(a.L - 1) + FH_SIZE + FPROG_LEN, lane);
+    FHdr bhn; FProg wan, wbn;
+    if constexpr (DYN) {
+        bhn = FHdr(a.tables + prog_of(a.L - 1), lane);
+        wan = FProg(a.tables + prog_of(a.L - 1) + FH_SIZE, lane); wbn = FProg(a.tables + prog_of(a.L - 1) + FH_SIZE + FPROG_LEN, lane);
+    }
     // dX_L tile: only the nodes that are live in the last layer carry a gradient -- the output type's [node0, node0 + n_out), known from the arguments, so
     // the loads do not wait for the header; four nodes per round trip
     if constexpr (!STEP) {
@@ -1267,140 +1447,24 @@ template <typename T, int NM, int HB, bool STEP> __device__ __forceinline__ void
     // group A's residual term travels from layer to layer in registers (the packed dX rows of the previous epilogue); for the
     // last layer it is the decoder backward's dX_L
     u32x4 keepA[SL_HA], keepB[HB];
-    {
-        // (read back from the tile in LDS: rows past the batch are zero there)
-        const int loffq = lds_chunk<T>(0, c_win(lane), (wn * 32 + c_oct(lane)) / P::EPC);
-#pragma unroll
-        for (int u = 0; u < SL_HA; ++u) {
-            keepA[u] = u32x4{0, 0, 0, 0};
-            const int n = bhn[FH_SLOTA + u];
-            if (n >= 0 && bhn[FH_KIND + u] != NK_DEAD) keepA[u] = *reinterpret_cast<const u32x4*>(smem + n * P::BLK + loffq);
-        }
-#pragma unroll
-        for (int u = 0; u < HB; ++u) {
-            keepB[u] = u32x4{0, 0, 0, 0};
-            const int n = bhn[FH_SLOTB + u];
-            if (n >= 0 && bhn[FH_KIND + SL_HA + u] != NK_DEAD) keepB[u] = *reinterpret_cast<const u32x4*>(smem + n * P::BLK + loffq);
-        }
-    }
-    bhn.settle(); wan.settle(); wbn.settle();
-    for (int l = a.L - 1; l >= 0; --l) {
-        const FHdr bh = bhn;
-        const FProg wa = wan, wb = wbn;
-        if (l > 0) {
-            bhn = FHdr(a.tables + prog_of(l - 1), lane);
-            wan = FProg(a.tables + prog_of(l - 1) + FH_SIZE, lane);
-            wbn = FProg(a.tables + prog_of(l - 1) + FH_SIZE + FPROG_LEN, lane);
-        }
-        const int nmlp = bh[FH_NMLP], flags = bh[FH_FLAGS];
-        const uint8_t* maskbytes = reinterpret_cast<const uint8_t*>(a.ws + a.mask_off[l]);
-        // lane constants rebuilt per layer from an opaque copy of the lane id: the per-node global addresses derived from them
-        // would otherwise be hoisted out of the layer loop (dozens of VGPRs, spilled)
-        const int lq = opaque(lane);
-        const int win = c_win(lq), w = w0 + win, col = wn * 32 + c_oct(lq), wc = min(w, B - 1);
-        const bool w_ok = w < B;
-
-        // mask phase (each lane on the octets it owns): relu nodes are masked in place -> dH_l[n]; group A's accumulators start
-        // at the residual term G_{l+1}[n].  Every relu byte and every LDS read is issued before the first use.
-        {
-            // (the unmasked rows are the carried `keep` registers: the packed dX_{l+1} this wave wrote into the blocks itself)
-            unsigned mb[SL_HA + HB];
-#pragma unroll
-            for (int q = 0; q < SL_HA + HB; ++q) {
-                mb[q] = 0xffu;
-                if (bh[FH_KIND + q] == NK_RELU) mb[q] = maskbytes[relu_tile_base(bh[(q < SL_HA ? FH_SLOTA : FH_SLOTB - SL_HA) + q], B, blockIdx.x, wn) + lane];
+    if constexpr (DYN) {
+        slab_bwd_keep_init<T, HB>(bhn, smem, wn, lane, keepA, keepB);
+        bhn.settle(); wan.settle(); wbn.settle();
+        FS_STAMP2(0);
+        for (int l = a.L - 1; l >= 0; --l) {
+            const FHdr bh = bhn;
+            const FProg wa = wan, wb = wbn;
+            if (l > 0) {
+                bhn = FHdr(a.tables + prog_of(l - 1), lane);
+                wan = FProg(a.tables + prog_of(l - 1) + FH_SIZE, lane);
+                wbn = FProg(a.tables + prog_of(l - 1) + FH_SIZE + FPROG_LEN, lane);
             }
-#pragma unroll
-            for (int q = 0; q < SL_HA + HB; ++q) {
-                if (bh[FH_KIND + q] == NK_RELU) {
-                    const u32x4 raw = q < SL_HA ? keepA[q < SL_HA ? q : 0] : keepB[q < SL_HA ? 0 : q - SL_HA];
-                    *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(bh[(q < SL_HA ? FH_SLOTA : FH_SLOTB - SL_HA) + q], win, col / P::EPC)) = chunk_mask_bits<T>(raw, mb[q]);
-                }
-            }
+            slab_bwd_layer<T, NM, HB>(a, smem, wpack, wn, lane, l, a.L - 1 - l, bh, wa, wb, keepA, keepB, [&] { bhn.settle(); wan.settle(); wbn.settle(); });
         }
-        __syncthreads();
-
-        if (nmlp > 0) {
-            // dT1 = dY W2 ; dU = dT1 . (T1 > 0) ; dH = dU W1     (backward of base_transform, in place on nodes 0..nmlp-1 = the
-            // first slots of group B); the dU / dH stashes go out behind the chain's last load
-            const T* t1 = reinterpret_cast<const T*>(a.ws + a.t1_off[l]);
-            T* du = reinterpret_cast<T*>(a.ws + a.du_off[l]);
-            T* dh = reinterpret_cast<T*>(a.ws + a.dh_off[l]);
-            // Two nodes at a time (K4 has four base_transform nodes: all four at once need 16 accumulator + 16 staging registers the kernel does not have next
-            // to the carried residual rows; each pair pays its own three barriers -- the chain is a few hundred cycles, the spills were round trips)
-            typename P::BFrag bf;      // one buffer for both weights: a carried residual (72 VGPRs) lives through this chain
-            typename P::AFrag af;
-            for (int u0 = 0; u0 < NM; u0 += 2) {
-                if (u0 >= nmlp) break;      // (uniform)
-                typename P::Acc tm[2];
-                u32x4 traw[2], dupk[2];
-                load_bfrag<T>(bf, wpack, bh[FH_W2], wn, lane);
-#pragma unroll
-                for (int v = 0; v < 2; ++v) {
-                    const int u = u0 + v;
-                    traw[v] = u32x4{0, 0, 0, 0};
-                    if (u < nmlp) {
-                        traw[v] = *reinterpret_cast<const u32x4*>(t1 + act_idx(wc, u, B) + col);
-                        acc_fill(tm[v], 0.f);
-                        load_afrag<T>(af, smem, u, lane);
-                        mac(tm[v], af, bf);
-                    }
-                }
-                load_bfrag<T>(bf, wpack, bh[FH_W1], wn, lane);
-                __syncthreads();   // all reads of the dY blocks done
-#pragma unroll
-                for (int v = 0; v < 2; ++v) {
-                    const int u = u0 + v;
-                    dupk[v] = u32x4{0, 0, 0, 0};
-                    if (u < nmlp) {
-                        f32x4 t0, t1v, r0, r1; unpack_oct(traw[v], t0, t1v);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) { r0[j] = t0[j] > 0.f ? tm[v].c[0][j] : 0.f; r1[j] = t1v[j] > 0.f ? tm[v].c[1][j] : 0.f; }
-                        dupk[v] = pack_oct(r0, r1);
-                        *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(u, win, col / P::EPC)) = dupk[v];
-                    }
-                }
-                __syncthreads();
-#pragma unroll
-                for (int v = 0; v < 2; ++v) {
-                    const int u = u0 + v;
-                    if (u < nmlp) { acc_fill(tm[v], 0.f); load_afrag<T>(af, smem, u, lane); mac(tm[v], af, bf); }
-                }
-                __syncthreads();   // all reads of the dU blocks done
-#pragma unroll
-                for (int v = 0; v < 2; ++v) {
-                    const int u = u0 + v;
-                    if (u < nmlp) {
-                        const u32x4 hp = pack_oct(tm[v].c[0], tm[v].c[1]);
-                        *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(u, win, col / P::EPC)) = hp;
-                        if (w_ok) {
-                            *reinterpret_cast<u32x4*>(du + act_idx(w, u, B) + col) = dupk[v];
-                            *reinterpret_cast<u32x4*>(dh + act_idx(w, u, B) + col) = hp;
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-        }
-
-        // dX_l[j] = (residual) + dH_j W_rootsum + sum_r sum_{j->i} dH_i W_rel^r, group A then group B
-        const T* xact = reinterpret_cast<const T*>(a.ws + a.x_off[0]);
-        const bool enc_mask = (flags & FF_ENC_MASK) != 0;
-        slab_group_bwd<T, SL_HA, 0>(a, bh, wa, smem, wpack, wn, lane, FH_SLOTA, xact, enc_mask, keepA);
-        slab_group_bwd<T, HB, SL_HA>(a, bh, wb, smem, wpack, wn, lane, FH_SLOTB, xact, enc_mask, keepB);
-        __syncthreads();   // every wave is done reading dH_l
-        bhn.settle(); wan.settle(); wbn.settle();      // next header / programs landed before the stores go out (FProg::settle)
-        T* dxo = reinterpret_cast<T*>(a.ws + a.dx_off[l]);
-#pragma unroll
-        for (int q = 0; q < SL_HA + HB; ++q) {
-            if (bh[FH_OUT + q]) {
-                const int n = bh[(q < SL_HA ? FH_SLOTA : FH_SLOTB - SL_HA) + q];
-                const u32x4 v = q < SL_HA ? keepA[q < SL_HA ? q : 0] : keepB[q < SL_HA ? 0 : q - SL_HA];
-                if (l > 0) *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(n, win, col / P::EPC)) = v;
-                if (w_ok) stash_store(dxo + act_idx(w, n, B) + col, v, a.stash_nt != 0);
-            }
-        }
-        __syncthreads();
+    } else {
+        slab_bwd_keep_init<T, HB>(SHdr<SP, 1, SP::L - 1>{}, smem, wn, lane, keepA, keepB);
+        FS_STAMP2(0);
+        slab_bwd_layers_static<T, NM, HB, SP, SP::L - 1>(a, smem, wpack, wn, lane, keepA, keepB);
     }
 }
 template <typename T, int NM, int HB> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_bwd(StackArgs a) {
@@ -1410,11 +1474,11 @@ template <typename T, int NM, int HB> __global__ __launch_bounds__(SL_THREADS, 2
 // One-call training step (mshgnn_step_mse / mshgnn_step_ce): the forward layers, decoder + loss + decoder backward and the backward layers of a tile in ONE
 // launch.  The tail leaves dX_L in the node blocks, so the backward sweep starts without a launch boundary, without the header / tile round trips of
 // k_slab_bwd's start and without re-reading dX_L (stamps: 16 k of its 163 k cycles).  Same code, same order of every accumulation: identical bits.
-template <typename T, int NM, int HB> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_step(StackArgs a) {
+template <typename T, int NM, int HB, class SP = void> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_step(StackArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    slab_fwd_body<T, NM, HB, true>(a, smem);
+    slab_fwd_body<T, NM, HB, true, SP>(a, smem);
     __syncthreads();      // the tile's dX_L rows are in the out-type blocks, the tail's reduction scratch has been read
-    slab_bwd_body<T, NM, HB, true>(a, smem);
+    slab_bwd_body<T, NM, HB, true, SP>(a, smem);
 }
 
 // the slab instantiation of a plan: NM = bound on the base_transform nodes (2 / 4), HB = group-B slots (6 / 8)
@@ -1423,7 +1487,29 @@ static StackKernel slab_fwd_kernel(const HostPlan& hp) {
     if (hp.sl_hb <= SL_HB) return hp.n_mlp <= 2 ? k_slab_fwd<__bf16, 2, SL_HB> : k_slab_fwd<__bf16, 4, SL_HB>;
     return hp.n_mlp <= 2 ? k_slab_fwd<__bf16, 2, SL_HB_MAX> : k_slab_fwd<__bf16, 4, SL_HB_MAX>;
 }
+// Specialised step kernels: k_slab_step over the COMPILE-TIME program of one (topology, depth) -- mshgnn_spec_tables.inc, generated from this library's own plan
+// compiler by tools/gen_spec_tables.py.  A plan takes one only when its slab tables are exactly the ints the kernel was compiled from (same packs, same
+// slots, same liveness), so a stale table file costs speed, never results; MSHGNN_SPEC=0 keeps the interpreting kernel (A/B runs, bit-identity tests).
+#include "mshgnn_spec_tables.inc"
+template <class SP> static bool spec_matches(const HostPlan& hp) {
+    if (!hp.slab || hp.L != SP::L || hp.NN != SP::NN || hp.sl_hb != SP::HB || (hp.n_mlp <= 2 ? 2 : 4) != SP::NM) return false;
+    for (int l = 0; l < SP::L; ++l) {
+        if (hp.sl_fwd_off[l] + SP::ROW > (int)hp.tables.size() || hp.sl_bwd_off[l] + SP::ROW > (int)hp.tables.size()) return false;
+        if (memcmp(hp.tables.data() + hp.sl_fwd_off[l], SP::fwd[l], sizeof(int32_t) * SP::ROW) != 0) return false;
+        if (memcmp(hp.tables.data() + hp.sl_bwd_off[l], SP::bwd[l], sizeof(int32_t) * SP::ROW) != 0) return false;
+    }
+    return true;
+}
+static StackKernel slab_step_spec_kernel(const HostPlan& hp) {
+    static const bool on = []() { const char* e = getenv("MSHGNN_SPEC"); return !(e && atoi(e) == 0); }();
+    if (!on) return nullptr;
+#define MSHGNN_SPEC_TRY(SP) if (spec_matches<SP>(hp)) return k_slab_step<__bf16, SP::NM, SP::HB, SP>;
+    MSHGNN_SPEC_LIST(MSHGNN_SPEC_TRY)
+#undef MSHGNN_SPEC_TRY
+    return nullptr;
+}
 static StackKernel slab_step_kernel(const HostPlan& hp) {
+    if (StackKernel k = slab_step_spec_kernel(hp)) return k;
     if (hp.sl_hb <= SL_HB) return hp.n_mlp <= 2 ? k_slab_step<__bf16, 2, SL_HB> : k_slab_step<__bf16, 4, SL_HB>;
     return hp.n_mlp <= 2 ? k_slab_step<__bf16, 2, SL_HB_MAX> : k_slab_step<__bf16, 4, SL_HB_MAX>;
 }

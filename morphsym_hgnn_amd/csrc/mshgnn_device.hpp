@@ -1,6 +1,7 @@
 // Shared device helpers, argument structs and the plan object of libmshgnn (included by every .hip translation unit of the
 // library: mshgnn.hip = fp32 / bf16 plans + C-ABI, mshgnn_x3.hip = split-bf16 parity plan, mshgnn_gen.hip = generic-width engine).
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -760,14 +761,39 @@ constexpr int FS_EXTRA_BLK = 0;
 #endif
 #if defined(MSHGNN_FS_STAMPS) || defined(MSHGNN_SEG_STAMPS)
 #define FS_STAMP(k) do { if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 32 + (k)] = clock64(); } while (0)
+#define FS_STAMP2(k) do { if (a.stamps && tid == 0) a.stamps[(size_t)gridDim.x * 32 + (size_t)blockIdx.x * 32 + (k)] = clock64(); } while (0)      // backward sweep of a one-launch step
 #else
 #define FS_STAMP(k) do { } while (0)     // the stamp stores are compiled out of the product build (they cost waits at phase boundaries)
+#define FS_STAMP2(k) do { } while (0)
+#endif
+
+// Issue-sensitivity experiment (instrumented builds only: -DMSHGNN_PAD_VALU=n / -DMSHGNN_PAD_SALU=n): n extra independent vector instructions per node epilogue /
+// n extra scalar instructions per MAC of the stack kernels.  If the launch were bound by instruction issue its time would follow the added count.
+#ifdef MSHGNN_PAD_VALU
+__device__ __forceinline__ void pad_valu() {
+    int d0 = 0, d1 = 0;
+#pragma unroll
+    for (int i = 0; i < MSHGNN_PAD_VALU; i += 2) { asm volatile("v_add_u32 %0, %0, 1" : "+v"(d0)); asm volatile("v_add_u32 %0, %0, 1" : "+v"(d1)); }
+}
+#else
+__device__ __forceinline__ void pad_valu() {}
+#endif
+#ifdef MSHGNN_PAD_SALU
+__device__ __forceinline__ void pad_salu() {
+    int d0 = 0;
+#pragma unroll
+    for (int i = 0; i < MSHGNN_PAD_SALU; ++i) asm volatile("s_add_u32 %0, %0, 1" : "+s"(d0) :: "scc");
+}
+#else
+__device__ __forceinline__ void pad_salu() {}
 #endif
 
 // wave program in three VGPRs, fetched with v_readlane: pk = pack id of segment `lane`; pcnt = its MAC counts (3 bits per
 // accumulator); pb = 256 byte entries, 4 per lane (entry 0 = number of segments, then the block stream)
 struct FProg {
+    static constexpr bool is_static = false;
     int pk, pcnt, pb;
+    __device__ __forceinline__ FProg() : pk(0), pcnt(0), pb(0) {}
     __device__ __forceinline__ FProg(const int* prog, int lane) : pk(prog[lane]), pcnt(prog[64 + lane]), pb(prog[128 + lane]) {}
     __device__ __forceinline__ int pack(int sgi) const { return __builtin_amdgcn_readlane(pk, sgi); }
     __device__ __forceinline__ int counts(int sgi) const { return __builtin_amdgcn_readlane(pcnt, sgi); }
@@ -780,6 +806,7 @@ struct FProg {
 // a layer header (FH_SIZE = 88 ints) held in two VGPRs and read with v_readlane: per-node flags cost no scalar-memory round
 // trip (measured with in-kernel stamps: ~40 dependent s_loads of the header were 6.6k cycles before the first MAC of a layer)
 struct FHdr {
+    static constexpr bool is_static = false;
     int h0, h1;
     __device__ __forceinline__ FHdr() : h0(0), h1(0) {}
     __device__ __forceinline__ FHdr(const int* hdr, int lane) : h0(hdr[lane]), h1(lane < FH_SIZE - 64 ? hdr[64 + lane] : 0) {}
@@ -787,10 +814,29 @@ struct FHdr {
     __device__ __forceinline__ void settle() { asm volatile("" : "+v"(h0), "+v"(h1)); }      // see FProg::settle
 };
 
+// The same header / wave program as COMPILE-TIME constants (specialised step kernels, mshgnn_spec_tables.inc): SP::fwd[l] / SP::bwd[l] are the ints the plan
+// compiler emits for layer l of one (topology, depth) -- FH_SIZE header ints, then group A's and group B's wave programs.  Every accessor folds to a literal
+// once the slot / segment loops are unrolled, so the slot walk (readlanes, count decoding, skipped slot headers, dead-node branches) leaves no instructions
+// behind and LDS block addresses become immediate offsets.  DIR: 0 forward, 1 backward tables.
+template <class SP, int DIR, int LL> struct SHdr {
+    static constexpr bool is_static = true;
+    __device__ __forceinline__ constexpr int operator[](int i) const { return DIR ? SP::bwd[LL][i] : SP::fwd[LL][i]; }
+    __device__ __forceinline__ void settle() const {}
+};
+template <class SP, int DIR, int LL, int G> struct SProg {
+    static constexpr bool is_static = true;
+    static constexpr int BASE = FH_SIZE + G * FPROG_LEN;
+    __device__ __forceinline__ constexpr int raw(int i) const { return DIR ? SP::bwd[LL][BASE + i] : SP::fwd[LL][BASE + i]; }
+    __device__ __forceinline__ constexpr int pack(int sgi) const { return raw(sgi); }
+    __device__ __forceinline__ constexpr int counts(int sgi) const { return raw(64 + sgi); }
+    __device__ __forceinline__ constexpr int at(int i) const { return (raw(128 + (i >> 2)) >> ((i & 3) << 3)) & 0xff; }
+    __device__ __forceinline__ void settle() const {}
+};
+
 // one segment: walk the accumulators in static order, each with its run-time MAC count; the source blocks come from the
 // program's block stream in execution order, so the fragment of the NEXT MAC is read from LDS under this MAC's MFMAs
-template <typename T, int HS = FS_HS, int CB = 3>      // HS accumulators, CB bits of MAC count per accumulator
-__device__ __forceinline__ void fs_walk(const FProg& wp, int sgi, int& pb, typename Prec<T>::AFrag& afn, typename Prec<T>::Acc (&acc)[HS],
+template <typename T, int HS = FS_HS, int CB = 3, class FP = FProg>      // HS accumulators, CB bits of MAC count per accumulator
+__device__ __forceinline__ void fs_walk(const FP& wp, int sgi, int& pb, typename Prec<T>::AFrag& afn, typename Prec<T>::Acc (&acc)[HS],
                                         const typename Prec<T>::BFrag& bf, const char* smem, const AOff<T>& lane, int dbg = 0) {
     const int cw = wp.counts(sgi);      // one readlane per segment: 3 bits of MAC count per accumulator
 #pragma unroll
@@ -806,6 +852,7 @@ __device__ __forceinline__ void fs_walk(const FProg& wp, int sgi, int& pb, typen
             mac(acc[u], afn, bf);
             load_afrag<T>(afn, smem, wp.at(++pb), lane);
 #endif
+            pad_salu();
             if constexpr (sizeof(T) == 4) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 8 * Prec<T>::NAV, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, Prec<T>::NAV, 0);
@@ -820,11 +867,65 @@ __device__ __forceinline__ void fs_walk(const FProg& wp, int sgi, int& pb, typen
         }
     }
 }
+// compile-time iteration: f(integral_constant<int, I>) for I in [I0, N)
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+// position in the block stream of the first MAC of (segment sgi, slot u) of a compile-time program
+template <class FP, int HS, int CB> constexpr int fs_static_pb(int sgi, int u) {
+    constexpr FP cp{};
+    int pb = 1;
+    for (int sg = 0; sg <= sgi; ++sg)
+        for (int v = 0; v < HS; ++v) {
+            if (sg == sgi && v == u) return pb;
+            pb += (cp.counts(sg) >> (CB * v)) & ((1 << CB) - 1);
+        }
+    return pb;
+}
+// fs_run over a compile-time program (SProg): the same MACs in the same order on the same accumulators (identical bits), as straight-line code -- no slot
+// headers, no count decoding, no block-stream readlanes, LDS blocks as immediate offsets, exact counted waits (no branch between a request and its use).
+template <typename T, int HS, int CB, class FP>
+__device__ __forceinline__ void fs_run_static(typename Prec<T>::Acc (&acc)[HS], const char* smem, const T* wpack, int wn, int lane) {
+    constexpr FP cp{};
+    constexpr int nseg = cp.at(0);
+    if constexpr (nseg > 0) {
+        constexpr int total = fs_static_pb<FP, HS, CB>(nseg - 1, HS) - 1;      // MACs of the run
+        typename Prec<T>::BFrag bf[2];
+        typename Prec<T>::AFrag afn;
+        const AOff<T> ao(lane);
+        __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));      // (as fs_run: the previous epilogue's stores are drained before the first request)
+        load_bfrag<T>(bf[0], wpack, cp.pack(0), wn, lane);
+        load_afrag<T>(afn, smem, cp.at(1), ao);
+        static_for<0, nseg>([&](auto SG) {
+            constexpr int sgi = decltype(SG)::value;
+            if constexpr (sgi + 1 < nseg) load_bfrag<T>(bf[(sgi + 1) & 1], wpack, cp.pack(sgi + 1), wn, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, HS>([&](auto U) {
+                constexpr int u = decltype(U)::value;
+                constexpr int cnt = (cp.counts(sgi) >> (CB * u)) & ((1 << CB) - 1);
+                constexpr int pb0 = fs_static_pb<FP, HS, CB>(sgi, u);
+                static_for<0, cnt>([&](auto K) {
+                    constexpr int pb = pb0 + decltype(K)::value;
+                    mac(acc[u], afn, bf[sgi & 1]);
+                    if constexpr (pb < total) load_afrag<T>(afn, smem, cp.at(pb + 1), ao);
+#pragma unroll
+                    for (int t = 0; t < Prec<T>::NAV; ++t) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                        if (pb < total) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                });
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+}
+
 // all segments of a layer.  The next segment's weight fragment streams from L2 while the current one is multiplied
 // (two register buffers).
-template <typename T, int HS = FS_HS, int CB = 3>
-__device__ __forceinline__ void fs_run(const FProg& wp, typename Prec<T>::Acc (&acc)[HS], const char* smem, const T* wpack, int wn, int lane, int dbg = 0,
+template <typename T, int HS = FS_HS, int CB = 3, class FP = FProg>
+__device__ __forceinline__ void fs_run(const FP& wp, typename Prec<T>::Acc (&acc)[HS], const char* smem, const T* wpack, int wn, int lane, int dbg = 0,
                                        long long* segclk = nullptr) {
+    if constexpr (FP::is_static) { fs_run_static<T, HS, CB, FP>(acc, smem, wpack, wn, lane); return; }
     const int nseg = wp.at(0);
     int pb = 1;
     typename Prec<T>::BFrag bfa, bfb;
