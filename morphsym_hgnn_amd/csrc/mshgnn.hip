@@ -809,9 +809,9 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
 // under this one's MAC phases.  The destination nodes are processed in two groups (mshgnn_plan.hpp, SL_HA / SL_HB) so that
 // the accumulators stay in registers; group A's new activations wait, packed, while group B is multiplied.
 // ------------------------------------------------------------------------------------------------------
-template <typename T, int HS, int Q0, int NM = 4, class FH = FHdr, class FP = FProg>     // one group: slots q = Q0 + u of the slab header; NM: compile-time bound on the base_transform nodes
-__device__ __forceinline__ void slab_group_fwd(const StackArgs& a, const FH& fh, const FP& wp, char* smem, const T* wpack, int wn, int lane,
-                                               int slot_base, int nmlp, bool residual, u32x4 (&keep)[HS], unsigned (&bits)[(HS + 3) / 4]) {
+template <typename T, int HS, int Q0, int NM = 4, bool PRE = false, class A = StackArgs, class FH = FHdr, class FP = FProg>     // one group: slots q = Q0 + u of the slab header; NM: compile-time bound on the base_transform nodes; PRE: (*pre) = the run's first two weight fragments, already requested
+__device__ __forceinline__ void slab_group_fwd(const A& a, const FH& fh, const FP& wp, char* smem, const T* wpack, int wn, int lane,
+                                               int slot_base, int nmlp, bool residual, u32x4 (&keep)[HS], unsigned (&bits)[(HS + 3) / 4], typename Prec<T>::BFrag (*pre)[2] = nullptr) {
     using P = Prec<T>;
     const int win = c_win(lane), col = wn * 32 + c_oct(lane);
     if (fh[FH_FLAGS] & (Q0 == 0 ? FF_A_EMPTY : FF_B_EMPTY)) {      // no live node in this group in this layer (uniform): nothing to compute or keep
@@ -822,12 +822,16 @@ __device__ __forceinline__ void slab_group_fwd(const StackArgs& a, const FH& fh,
         return;
     }
     typename P::Acc acc[HS];
+    const unsigned boff = (unsigned)c_oct(opaque(lane)) * 4u;      // (compile-time programs) this lane's 8 floats in a wave's 32-float slice of a bias row
 #pragma unroll
     for (int u = 0; u < HS; ++u) {
-        if (fh[FH_KIND + Q0 + u] != NK_DEAD) acc_init_bias<T>(acc[u], a.bias + (size_t)fh[FH_BIAS + Q0 + u] * H, wn, lane);
-        else acc_fill(acc[u], 0.f);
+        if (fh[FH_KIND + Q0 + u] != NK_DEAD) {
+            if constexpr (FH::is_static) acc_init_bias_u<T>(acc[u], a.bias + (size_t)fh[FH_BIAS + Q0 + u] * H, wn, boff);
+            else acc_init_bias<T>(acc[u], a.bias + (size_t)fh[FH_BIAS + Q0 + u] * H, wn, lane);
+        } else acc_fill(acc[u], 0.f);
     }
-    fs_run<T, HS, (Q0 == 0 ? SL_CBA : SL_CBB)>(wp, acc, smem, wpack, wn, lane, a.dbg);      // (a.dbg: timing ablations, compiled out of the product build)
+    if constexpr (PRE) fs_run_static<T, HS, (Q0 == 0 ? SL_CBA : SL_CBB), FP, true>(acc, smem, wpack, wn, lane, *pre);
+    else fs_run<T, HS, (Q0 == 0 ? SL_CBA : SL_CBB)>(wp, acc, smem, wpack, wn, lane, a.dbg);      // (a.dbg: timing ablations, compiled out of the product build)
     if constexpr (Q0 > 0) if (nmlp > 0) {
         // base_transform: Y = W2 relu(W1 H + b1) + b2 on the first nmlp slots of this group (hgnn_c2.py:117-121,156); scratch
         // blocks NN + u.  The H / T1 stashes go out packed, behind the chain's last load.
@@ -874,14 +878,20 @@ __device__ __forceinline__ void slab_group_fwd(const StackArgs& a, const FH& fh,
         __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));      // every load has landed before the first store
         if (a.training) {
             const int w = blockIdx.x * P::ROWS + win;
-            if (w < a.B) {
+            if (A::full || w < a.B) {
                 T* hb = reinterpret_cast<T*>(a.ws + a.hb_off[slot_base >> 8]);
                 T* t1 = reinterpret_cast<T*>(a.ws + a.t1_off[slot_base >> 8]);
+                const unsigned roff = (unsigned)((w * H + col) * (int)sizeof(T));
 #pragma unroll
                 for (int u = 0; u < NM && u < HS; ++u) {
                     if (u < nmlp) {
-                        *reinterpret_cast<u32x4*>(hb + act_idx(w, u, a.B) + col) = hpk[u];
-                        *reinterpret_cast<u32x4*>(t1 + act_idx(w, u, a.B) + col) = tpk[u];
+                        if constexpr (FH::is_static) {
+                            gstore16(uniform_wptr(reinterpret_cast<char*>(hb + act_idx(0, u, a.B))), roff, hpk[u]);
+                            gstore16(uniform_wptr(reinterpret_cast<char*>(t1 + act_idx(0, u, a.B))), roff, tpk[u]);
+                        } else {
+                            *reinterpret_cast<u32x4*>(hb + act_idx(w, u, a.B) + col) = hpk[u];
+                            *reinterpret_cast<u32x4*>(t1 + act_idx(w, u, a.B) + col) = tpk[u];
+                        }
                     }
                 }
             }
@@ -909,13 +919,41 @@ __device__ __forceinline__ void slab_group_fwd(const StackArgs& a, const FH& fh,
     }
 }
 // write one group's new activations: LDS block, stash, relu bytes
-template <typename T, int HS, int Q0, class FH = FHdr>
-__device__ __forceinline__ void slab_group_store(const StackArgs& a, const FH& fh, char* smem, int wn, int lane, int slot_arr, int l,
+template <typename T, int HS, int Q0, class A = StackArgs, class FH = FHdr>
+__device__ __forceinline__ void slab_group_store(const A& a, const FH& fh, char* smem, int wn, int lane, int slot_arr, int l,
                                                  const u32x4 (&keep)[HS], const unsigned (&bits)[(HS + 3) / 4], bool stash_x = true) {
     using P = Prec<T>;
     const int win = c_win(lane), col = wn * 32 + c_oct(lane), w = blockIdx.x * P::ROWS + win;
     T* xo = reinterpret_cast<T*>(a.ws + a.x_off[l + 1]);
     uint8_t* maskbytes = reinterpret_cast<uint8_t*>(a.ws + a.mask_off[l]);
+    if constexpr (FH::is_static) {
+        // compile-time program: the LDS rows and relu bytes of every live slot first, then all stash rows under ONE lane predicate (one exec switch per group
+        // instead of a compare + branch per node)
+        // every global address = a scalar base (layer, node) + this lane's 32-bit offset, rebuilt from an opaque copy of the lane id per call: per-node 64-bit
+        // addresses would be shared between the unrolled layers and live (two registers per node) through the whole kernel
+        const int lq = opaque(lane);
+        const unsigned roff = (unsigned)(((blockIdx.x * P::ROWS + c_win(lq)) * H + wn * 32 + c_oct(lq)) * (int)sizeof(T));      // this lane's octet in a [B][128] row block
+#pragma unroll
+        for (int u = 0; u < HS; ++u) {
+            const int kind = fh[FH_KIND + Q0 + u];
+            if (kind != NK_DEAD) {
+                const int n = fh[slot_arr + u];
+                *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(n, win, col / P::EPC)) = keep[u];
+                if (a.training && kind == NK_RELU) gstore1(uniform_wptr(reinterpret_cast<char*>(maskbytes) + relu_tile_base(n, a.B, blockIdx.x, wn)), (unsigned)lq, bits[u >> 2] >> (8 * (u & 3)));
+            }
+        }
+        if (a.training && stash_x && (A::full || w < a.B)) {
+#ifdef MSHGNN_STASH_ALIAS      // timing experiment (wrong results): every tile's stash rows land on the rows of 32 tiles, a footprint the L2 holds -- is the store phase bound by HBM writes?
+            const unsigned soff = (unsigned)((((blockIdx.x & 31) * P::ROWS + c_win(lq)) * H + wn * 32 + c_oct(lq)) * (int)sizeof(T));
+#else
+            const unsigned soff = roff;
+#endif
+#pragma unroll
+            for (int u = 0; u < HS; ++u)
+                if (fh[FH_KIND + Q0 + u] != NK_DEAD) stash_store_u(a, uniform_wptr(reinterpret_cast<char*>(xo + act_idx(0, fh[slot_arr + u], a.B))), soff, keep[u]);
+        }
+        return;
+    }
 #pragma unroll
     for (int u = 0; u < HS; ++u) {
         const int kind = fh[FH_KIND + Q0 + u];
@@ -932,15 +970,31 @@ __device__ __forceinline__ void slab_group_store(const StackArgs& a, const FH& f
 
 // one forward layer of a slab workgroup: both groups' MAC passes, then the layer's stores.  FH / FP: the layer's header and wave programs, interpreted (FHdr /
 // FProg: plan tables in VGPRs) or compile-time (SHdr / SProg: specialised kernels); mid(): what has to settle between the MACs and the stores
-template <typename T, int NM, int HB, bool STEP, class FH, class FP, class FPB, class Mid>
-__device__ __forceinline__ void slab_fwd_layer(const StackArgs& a, char* smem, const T* wpack, int wn, int lane, int l, int L, const FH& fh, const FP& wa, const FPB& wb, Mid&& mid) {
+// PRE (compile-time programs): (*pre) holds the first two weight fragments of the layer's first pass, requested before the previous store phase; bits_out: the
+// layer's relu bits (12 + HB bytes in 3 + 2 registers) for the backward sweep of the same launch
+template <typename T, int NM, int HB, bool STEP, bool PRE = false, class A, class FH, class FP, class FPB, class Mid>
+__device__ __forceinline__ void slab_fwd_layer(const A& a, char* smem, const T* wpack, int wn, int lane, int l, int L, const FH& fh, const FP& wa, const FPB& wb, Mid&& mid,
+                                               typename Prec<T>::BFrag (*pre)[2] = nullptr, unsigned* bits_out = nullptr) {
     const int tid = threadIdx.x;
     const int nmlp = fh[FH_NMLP];
     const bool residual = (fh[FH_FLAGS] & FF_RESIDUAL) != 0;
     u32x4 keepA[SL_HA], keepB[HB]; unsigned bitsA[(SL_HA + 3) / 4], bitsB[(HB + 3) / 4];
-    slab_group_fwd<T, SL_HA, 0>(a, fh, wa, smem, wpack, wn, lane, FH_SLOTA | (l << 8), 0, residual, keepA, bitsA);
-    FS_STAMP(2 + 4 * l);
-    slab_group_fwd<T, HB, SL_HA, NM>(a, fh, wb, smem, wpack, wn, lane, FH_SLOTB | (l << 8), nmlp, residual, keepB, bitsB);
+    if constexpr (PRE) {      // the requested fragments belong to the first group with work
+        constexpr bool a_first = !(FH{}[FH_FLAGS] & FF_A_EMPTY);
+        slab_group_fwd<T, SL_HA, 0, 4, a_first>(a, fh, wa, smem, wpack, wn, lane, FH_SLOTA | (l << 8), 0, residual, keepA, bitsA, pre);
+        FS_STAMP(2 + 4 * l);
+        slab_group_fwd<T, HB, SL_HA, NM, !a_first>(a, fh, wb, smem, wpack, wn, lane, FH_SLOTB | (l << 8), nmlp, residual, keepB, bitsB, pre);
+    } else {
+        slab_group_fwd<T, SL_HA, 0>(a, fh, wa, smem, wpack, wn, lane, FH_SLOTA | (l << 8), 0, residual, keepA, bitsA);
+        FS_STAMP(2 + 4 * l);
+        slab_group_fwd<T, HB, SL_HA, NM>(a, fh, wb, smem, wpack, wn, lane, FH_SLOTB | (l << 8), nmlp, residual, keepB, bitsB);
+    }
+    if (bits_out) {
+#pragma unroll
+        for (int i = 0; i < (SL_HA + 3) / 4; ++i) bits_out[i] = bitsA[i];
+#pragma unroll
+        for (int i = 0; i < (HB + 3) / 4; ++i) bits_out[(SL_HA + 3) / 4 + i] = bitsB[i];
+    }
     FS_STAMP(3 + 4 * l);
     __syncthreads();   // every wave is done reading X_l: the node blocks may be overwritten
     FS_STAMP(4 + 4 * l);
@@ -952,17 +1006,30 @@ __device__ __forceinline__ void slab_fwd_layer(const StackArgs& a, char* smem, c
     FS_STAMP(5 + 4 * l);
 }
 // the layers of a compile-time program SP, unrolled
-template <typename T, int NM, int HB, bool STEP, class SP, int l = 0>
-__device__ __forceinline__ void slab_fwd_layers_static(const StackArgs& a, char* smem, const T* wpack, int wn, int lane) {
+// the first pass with work of forward (DIR 0) / backward (DIR 1) layer l of a compile-time program: request its first two weight fragments
+template <typename T, class SP, int DIR, int l> __device__ __forceinline__ void slab_prefetch_static(typename Prec<T>::BFrag (&pre)[2], const T* wpack, int wn, int lane) {
+    if constexpr (!(SHdr<SP, DIR, l>{}[FH_FLAGS] & FF_A_EMPTY)) fs_prefetch_static<T, SProg<SP, DIR, l, 0>>(pre, wpack, wn, lane);
+    else fs_prefetch_static<T, SProg<SP, DIR, l, 1>>(pre, wpack, wn, lane);
+}
+// Between a layer's MACs and its stores a compile-time program requests what the phase AFTER the stores starts with -- the next layer's first two weight
+// fragments, or (last layer) the decoder tail's operands -- so that phase begins under the store drain instead of behind it.
+template <typename T, int NM, int HB, bool STEP, class SP, int l = 0, class A>
+__device__ __forceinline__ void slab_fwd_layers_static(const A& a, char* smem, const T* wpack, int wn, int lane, typename Prec<T>::BFrag (&pre)[2],
+                                                       unsigned* lastbits, DecOps<SP::DMAX, DEC_NPP_STATIC>& dops) {
     if constexpr (l < SP::L) {
-        slab_fwd_layer<T, NM, HB, STEP>(a, smem, wpack, wn, lane, l, SP::L, SHdr<SP, 0, l>{}, SProg<SP, 0, l, 0>{}, SProg<SP, 0, l, 1>{}, [] {});
-        slab_fwd_layers_static<T, NM, HB, STEP, SP, l + 1>(a, smem, wpack, wn, lane);
+        auto mid = [&] {
+            if constexpr (l + 1 < SP::L) { if constexpr ((SP::PRE & 1) != 0) slab_prefetch_static<T, SP, 0, l + 1>(pre, wpack, wn, lane); }
+            else if constexpr ((SP::PRE & 4) != 0) decoder_ops_load<SL_THREADS, SP::DMAX, DEC_NPP_STATIC>(args_of(a), threadIdx.x, blockIdx.x * Prec<T>::ROWS, a.B, threadIdx.x >> 8, true, dops);
+        };
+        slab_fwd_layer<T, NM, HB, STEP, (SP::PRE & 1) != 0>(a, smem, wpack, wn, lane, l, SP::L, SHdr<SP, 0, l>{}, SProg<SP, 0, l, 0>{}, SProg<SP, 0, l, 1>{}, mid, &pre,
+                                                            l + 1 == SP::L ? lastbits : nullptr);
+        slab_fwd_layers_static<T, NM, HB, STEP, SP, l + 1>(a, smem, wpack, wn, lane, pre, lastbits, dops);
     }
 }
 
 // STEP: part of k_slab_step -- the decoder tail leaves dX_L in the out-type nodes' LDS blocks for the backward sweep that follows in the same launch
 // SP: void = the plan's tables are interpreted; else the compile-time program of one (topology, depth) (mshgnn_spec_tables.inc)
-template <typename T, int NM, int HB, bool STEP, class SP = void> __device__ __forceinline__ void slab_fwd_body(const StackArgs& a, char* smem) {
+template <typename T, int NM, int HB, bool STEP, class SP = void, class A = StackArgs> __device__ __forceinline__ void slab_fwd_body(const A& a, char* smem, unsigned* lastbits = nullptr) {
     using P = Prec<T>;
     constexpr bool DYN = std::is_void<SP>::value;
     const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -973,10 +1040,11 @@ template <typename T, int NM, int HB, bool STEP, class SP = void> __device__ __f
 
     // layer 0's header and programs stream in under the tile load
     FHdr fhn; FProg wan, wbn;
+    typename P::BFrag pre[2];
     if constexpr (DYN) {
         fhn = FHdr(a.tables + a.prog_off[0], lane);
         wan = FProg(a.tables + a.prog_off[0] + FH_SIZE, lane); wbn = FProg(a.tables + a.prog_off[0] + FH_SIZE + FPROG_LEN, lane);
-    }
+    } else if constexpr ((SP::PRE & 1) != 0) slab_prefetch_static<T, SP, 0, 0>(pre, wpack, wn, lane);      // layer 0's first weight fragments stream in under the tile load
     {   // X_0 tile -> LDS: thread = (row, 16-byte chunk), one node per pass, 6 loads in flight
         const T* src = reinterpret_cast<const T*>(a.tile_in);
         const int row = tid >> 4, c = tid & 15;
@@ -987,7 +1055,7 @@ template <typename T, int NM, int HB, bool STEP, class SP = void> __device__ __f
             for (int i = 0; i < BATCH; ++i) {
                 v[i] = u32x4{0, 0, 0, 0};
                 // (read once by this kernel: non-temporal -- 0.2026 -> 0.2004 ms/step over six alternating runs at 3 layers, nothing at 8)
-                if (nb + i < NN && w0 + row < B) v[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src + act_idx(w0 + row, nb + i, B) + c * P::EPC));
+                if (nb + i < NN && (A::full || w0 + row < B)) v[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src + act_idx(w0 + row, nb + i, B) + c * P::EPC));
             }
 #pragma unroll
             for (int i = 0; i < BATCH; ++i)
@@ -1009,8 +1077,12 @@ template <typename T, int NM, int HB, bool STEP, class SP = void> __device__ __f
             }
             slab_fwd_layer<T, NM, HB, STEP>(a, smem, wpack, wn, lane, l, a.L, fh, wa, wb, [&] { fhn.settle(); wan.settle(); wbn.settle(); });
         }
-    } else slab_fwd_layers_static<T, NM, HB, STEP, SP>(a, smem, wpack, wn, lane);
-    decoder_tail<T, SL_THREADS, false, STEP>(a, smem, tid, lane, wn, w0, B);
+        decoder_tail<T, SL_THREADS, false, STEP>(args_of(a), smem, tid, lane, wn, w0, B);
+    } else {
+        DecOps<SP::DMAX, DEC_NPP_STATIC> dops;
+        slab_fwd_layers_static<T, NM, HB, STEP, SP>(a, smem, wpack, wn, lane, pre, lastbits, dops);
+        decoder_tail_impl<T, SL_THREADS, SP::DMAX, false, STEP, DEC_NPP_STATIC, (SP::PRE & 4) != 0>(args_of(a), smem, tid, lane, wn, w0, B, &dops);
+    }
     FS_STAMP(30);
 }
 template <typename T, int NM, int HB> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_fwd(StackArgs a) {
@@ -1214,9 +1286,9 @@ template <typename T> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
 // packed dX_{l+1} row this wave produced one layer earlier and kept in registers (for the last layer: the decoder
 // backward's dX_L, read once before the loop).
 // ------------------------------------------------------------------------------------------------------
-template <typename T, int HS, int Q0, class FH = FHdr, class FP = FProg>
-__device__ __forceinline__ void slab_group_bwd(const StackArgs& a, const FH& bh, const FP& wp, char* smem, const T* wpack, int wn, int lane,
-                                               int slot_arr, const T* xact, bool enc_mask, u32x4 (&keep)[HS]) {
+template <typename T, int HS, int Q0, bool PRE = false, class A = StackArgs, class FH = FHdr, class FP = FProg>
+__device__ __forceinline__ void slab_group_bwd(const A& a, const FH& bh, const FP& wp, char* smem, const T* wpack, int wn, int lane,
+                                               int slot_arr, const T* xact, bool enc_mask, u32x4 (&keep)[HS], typename Prec<T>::BFrag (*pre)[2] = nullptr) {
     using P = Prec<T>;
     if (bh[FH_FLAGS] & (Q0 == 0 ? FF_A_EMPTY : FF_B_EMPTY)) {      // no dX row of this group is produced in this layer (uniform)
 #pragma unroll
@@ -1234,7 +1306,8 @@ __device__ __forceinline__ void slab_group_bwd(const StackArgs& a, const FH& bh,
         if (bh[FH_KIND + Q0 + u] != NK_DEAD && bh[FH_RES + Q0 + u]) unpack_oct(keep[u], acc[u].c[0], acc[u].c[1]);
         else acc_fill(acc[u], 0.f);
     }
-    fs_run<T, HS, (Q0 == 0 ? SL_CBA : SL_CBB)>(wp, acc, smem, wpack, wn, lane, a.dbg);      // (a.dbg: timing ablations, compiled out of the product build)
+    if constexpr (PRE) fs_run_static<T, HS, (Q0 == 0 ? SL_CBA : SL_CBB), FP, true>(acc, smem, wpack, wn, lane, *pre);
+    else fs_run<T, HS, (Q0 == 0 ? SL_CBA : SL_CBB)>(wp, acc, smem, wpack, wn, lane, a.dbg);      // (a.dbg: timing ablations, compiled out of the product build)
     // layer 0: x relu'(X_0) (encoder activation) from the encoder's relu bytes (one per lane, written by k_enc_fwd): a byte per
     // node instead of the 16-byte X_0 octet (38 MB per launch, 4 VGPRs per node), all requested back to back
     const uint8_t* m0 = reinterpret_cast<const uint8_t*>(a.ws + a.mask0_off);
@@ -1243,7 +1316,10 @@ __device__ __forceinline__ void slab_group_bwd(const StackArgs& a, const FH& bh,
 #pragma unroll
         for (int u = 0; u < HS; ++u) {
             xb[u] = 0;
-            if (bh[FH_OUT + Q0 + u]) xb[u] = m0[relu_tile_base(bh[slot_arr + u], a.B, blockIdx.x, wn) + lq];
+            if (bh[FH_OUT + Q0 + u]) {
+                if constexpr (FH::is_static) xb[u] = gload1(uniform_ptr(reinterpret_cast<const char*>(m0) + relu_tile_base(bh[slot_arr + u], a.B, blockIdx.x, wn)), (unsigned)lq);
+                else xb[u] = m0[relu_tile_base(bh[slot_arr + u], a.B, blockIdx.x, wn) + lq];
+            }
         }
     }
 #pragma unroll
@@ -1258,9 +1334,11 @@ __device__ __forceinline__ void slab_group_bwd(const StackArgs& a, const FH& bh,
 }
 
 // one backward layer of a slab workgroup (FH / FP / mid: see slab_fwd_layer); keepA / keepB carry the packed dX rows from layer to layer
-template <typename T, int NM, int HB, class FH, class FP, class FPB, class Mid>
-__device__ __forceinline__ void slab_bwd_layer(const StackArgs& a, char* smem, const T* wpack, int wn, int lane, int l, int li, const FH& bh, const FP& wa, const FPB& wb,
-                                               u32x4 (&keepA)[SL_HA], u32x4 (&keepB)[HB], Mid&& mid) {
+// PRE (compile-time programs): mbq holds this layer's relu bytes (requested before the previous store phase, or the forward's own bits for the last layer) and
+// (*pre) the first two weight fragments of the layer's first pass with work; mid() requests the same for the layer that follows
+template <typename T, int NM, int HB, bool PRE = false, bool PREM = false, class A, class FH, class FP, class FPB, class Mid>
+__device__ __forceinline__ void slab_bwd_layer(const A& a, char* smem, const T* wpack, int wn, int lane, int l, int li, const FH& bh, const FP& wa, const FPB& wb,
+                                               u32x4 (&keepA)[SL_HA], u32x4 (&keepB)[HB], Mid&& mid, unsigned* mbq = nullptr, typename Prec<T>::BFrag (*pre)[2] = nullptr) {
     using P = Prec<T>;
     const int tid = threadIdx.x, w0 = blockIdx.x * P::ROWS, B = a.B;
     const int nmlp = bh[FH_NMLP], flags = bh[FH_FLAGS];
@@ -1269,7 +1347,7 @@ __device__ __forceinline__ void slab_bwd_layer(const StackArgs& a, char* smem, c
     // would otherwise be hoisted out of the layer loop (dozens of VGPRs, spilled)
     const int lq = opaque(lane);
     const int win = c_win(lq), w = w0 + win, col = wn * 32 + c_oct(lq), wc = min(w, B - 1);
-    const bool w_ok = w < B;
+    const bool w_ok = A::full || w < B;
 
     // mask phase (each lane on the octets it owns): relu nodes are masked in place -> dH_l[n]; group A's accumulators start
     // at the residual term G_{l+1}[n].  Every relu byte and every LDS read is issued before the first use.
@@ -1279,7 +1357,11 @@ __device__ __forceinline__ void slab_bwd_layer(const StackArgs& a, char* smem, c
 #pragma unroll
         for (int q = 0; q < SL_HA + HB; ++q) {
             mb[q] = 0xffu;
-            if (bh[FH_KIND + q] == NK_RELU) mb[q] = maskbytes[relu_tile_base(bh[(q < SL_HA ? FH_SLOTA : FH_SLOTB - SL_HA) + q], B, blockIdx.x, wn) + lane];
+            if (bh[FH_KIND + q] == NK_RELU) {
+                if constexpr (PREM) mb[q] = mbq[q];
+                else if constexpr (FH::is_static) mb[q] = gload1(uniform_ptr(reinterpret_cast<const char*>(maskbytes) + relu_tile_base(bh[(q < SL_HA ? FH_SLOTA : FH_SLOTB - SL_HA) + q], B, blockIdx.x, wn)), (unsigned)lq);
+                else mb[q] = maskbytes[relu_tile_base(bh[(q < SL_HA ? FH_SLOTA : FH_SLOTB - SL_HA) + q], B, blockIdx.x, wn) + lane];
+            }
         }
 #pragma unroll
         for (int q = 0; q < SL_HA + HB; ++q) {
@@ -1312,7 +1394,8 @@ __device__ __forceinline__ void slab_bwd_layer(const StackArgs& a, char* smem, c
                 const int u = u0 + v;
                 traw[v] = u32x4{0, 0, 0, 0};
                 if (u < nmlp) {
-                    traw[v] = *reinterpret_cast<const u32x4*>(t1 + act_idx(wc, u, B) + col);
+                    if constexpr (FH::is_static) traw[v] = gload16(uniform_ptr(reinterpret_cast<const char*>(t1 + act_idx(0, u, B))), (unsigned)((wc * H + col) * (int)sizeof(T)));
+                    else traw[v] = *reinterpret_cast<const u32x4*>(t1 + act_idx(wc, u, B) + col);
                     acc_fill(tm[v], 0.f);
                     load_afrag<T>(af, smem, u, lane);
                     mac(tm[v], af, bf);
@@ -1346,8 +1429,13 @@ __device__ __forceinline__ void slab_bwd_layer(const StackArgs& a, char* smem, c
                     const u32x4 hp = pack_oct(tm[v].c[0], tm[v].c[1]);
                     *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(u, win, col / P::EPC)) = hp;
                     if (w_ok) {
-                        *reinterpret_cast<u32x4*>(du + act_idx(w, u, B) + col) = dupk[v];
-                        *reinterpret_cast<u32x4*>(dh + act_idx(w, u, B) + col) = hp;
+                        if constexpr (FH::is_static) {
+                            gstore16(uniform_wptr(reinterpret_cast<char*>(du + act_idx(0, u, B))), (unsigned)((w * H + col) * (int)sizeof(T)), dupk[v]);
+                            gstore16(uniform_wptr(reinterpret_cast<char*>(dh + act_idx(0, u, B))), (unsigned)((w * H + col) * (int)sizeof(T)), hp);
+                        } else {
+                            *reinterpret_cast<u32x4*>(du + act_idx(w, u, B) + col) = dupk[v];
+                            *reinterpret_cast<u32x4*>(dh + act_idx(w, u, B) + col) = hp;
+                        }
                     }
                 }
             }
@@ -1359,33 +1447,98 @@ __device__ __forceinline__ void slab_bwd_layer(const StackArgs& a, char* smem, c
     const T* xact = reinterpret_cast<const T*>(a.ws + a.x_off[0]);
     const bool enc_mask = (flags & FF_ENC_MASK) != 0;
     FS_STAMP2(2 + 6 * li);
-    slab_group_bwd<T, SL_HA, 0>(a, bh, wa, smem, wpack, wn, lane, FH_SLOTA, xact, enc_mask, keepA);
-    FS_STAMP2(3 + 6 * li);
-    slab_group_bwd<T, HB, SL_HA>(a, bh, wb, smem, wpack, wn, lane, FH_SLOTB, xact, enc_mask, keepB);
+    if constexpr (PRE) {
+        constexpr bool a_first = !(FH{}[FH_FLAGS] & FF_A_EMPTY);
+        slab_group_bwd<T, SL_HA, 0, a_first>(a, bh, wa, smem, wpack, wn, lane, FH_SLOTA, xact, enc_mask, keepA, pre);
+        FS_STAMP2(3 + 6 * li);
+        slab_group_bwd<T, HB, SL_HA, !a_first>(a, bh, wb, smem, wpack, wn, lane, FH_SLOTB, xact, enc_mask, keepB, pre);
+    } else {
+        slab_group_bwd<T, SL_HA, 0>(a, bh, wa, smem, wpack, wn, lane, FH_SLOTA, xact, enc_mask, keepA);
+        FS_STAMP2(3 + 6 * li);
+        slab_group_bwd<T, HB, SL_HA>(a, bh, wb, smem, wpack, wn, lane, FH_SLOTB, xact, enc_mask, keepB);
+    }
     FS_STAMP2(4 + 6 * li);
     __syncthreads();   // every wave is done reading dH_l
     FS_STAMP2(5 + 6 * li);
     mid();      // next header / programs landed before the stores go out (FProg::settle)
     T* dxo = reinterpret_cast<T*>(a.ws + a.dx_off[l]);
+    if constexpr (FH::is_static) {      // (as slab_group_store: LDS rows first, then every stash row under one lane predicate)
+        if (l > 0) {
 #pragma unroll
-    for (int q = 0; q < SL_HA + HB; ++q) {
-        if (bh[FH_OUT + q]) {
-            const int n = bh[(q < SL_HA ? FH_SLOTA : FH_SLOTB - SL_HA) + q];
-            const u32x4 v = q < SL_HA ? keepA[q < SL_HA ? q : 0] : keepB[q < SL_HA ? 0 : q - SL_HA];
-            if (l > 0) *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(n, win, col / P::EPC)) = v;
-            if (w_ok) stash_store(dxo + act_idx(w, n, B) + col, v, a.stash_nt != 0);
+            for (int q = 0; q < SL_HA + HB; ++q)
+                if (bh[FH_OUT + q])
+                    *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(bh[(q < SL_HA ? FH_SLOTA : FH_SLOTB - SL_HA) + q], win, col / P::EPC)) = q < SL_HA ? keepA[q < SL_HA ? q : 0] : keepB[q < SL_HA ? 0 : q - SL_HA];
+        }
+        if (w_ok) {
+#ifdef MSHGNN_STASH_ALIAS
+            const unsigned soff = (unsigned)((((blockIdx.x & 31) * P::ROWS + win) * H + col) * (int)sizeof(T));
+#else
+            const unsigned soff = (unsigned)((w * H + col) * (int)sizeof(T));
+#endif
+#pragma unroll
+            for (int q = 0; q < SL_HA + HB; ++q)
+                if (bh[FH_OUT + q])
+                    stash_store_u(a, uniform_wptr(reinterpret_cast<char*>(dxo + act_idx(0, bh[(q < SL_HA ? FH_SLOTA : FH_SLOTB - SL_HA) + q], B))), soff, q < SL_HA ? keepA[q < SL_HA ? q : 0] : keepB[q < SL_HA ? 0 : q - SL_HA]);
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < SL_HA + HB; ++q) {
+            if (bh[FH_OUT + q]) {
+                const int n = bh[(q < SL_HA ? FH_SLOTA : FH_SLOTB - SL_HA) + q];
+                const u32x4 v = q < SL_HA ? keepA[q < SL_HA ? q : 0] : keepB[q < SL_HA ? 0 : q - SL_HA];
+                if (l > 0) *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(n, win, col / P::EPC)) = v;
+                if (w_ok) stash_store(dxo + act_idx(w, n, B) + col, v, a.stash_nt != 0);
+            }
         }
     }
     __syncthreads();
     FS_STAMP2(6 + 6 * li);
 }
 // the layers of a compile-time program SP, last to first, unrolled
-template <typename T, int NM, int HB, class SP, int l>
-__device__ __forceinline__ void slab_bwd_layers_static(const StackArgs& a, char* smem, const T* wpack, int wn, int lane, u32x4 (&keepA)[SL_HA], u32x4 (&keepB)[HB]) {
+template <typename T, int NM, int HB, class SP, int l, class A>
+__device__ __forceinline__ void slab_bwd_layers_static(const A& a, char* smem, const T* wpack, int wn, int lane, u32x4 (&keepA)[SL_HA], u32x4 (&keepB)[HB],
+                                                       unsigned (&mbq)[SL_HA + HB], typename Prec<T>::BFrag (&pre)[2]) {
     if constexpr (l >= 0) {
-        slab_bwd_layer<T, NM, HB>(a, smem, wpack, wn, lane, l, SP::L - 1 - l, SHdr<SP, 1, l>{}, SProg<SP, 1, l, 0>{}, SProg<SP, 1, l, 1>{}, keepA, keepB, [] {});
-        slab_bwd_layers_static<T, NM, HB, SP, l - 1>(a, smem, wpack, wn, lane, keepA, keepB);
+        auto mid = [&] {      // before layer l's stores: layer l - 1's relu bytes (written by the forward sweep long ago) and first weight fragments
+            if constexpr (l > 0) {
+                if constexpr ((SP::PRE & 2) != 0) {
+                    constexpr SHdr<SP, 1, l - 1> nh{};
+                    const uint8_t* mbn = reinterpret_cast<const uint8_t*>(a.ws + a.mask_off[l - 1]);
+#pragma unroll
+                    for (int q = 0; q < SL_HA + HB; ++q) {
+                        mbq[q] = 0xffu;
+                        if (nh[FH_KIND + q] == NK_RELU) mbq[q] = gload1(uniform_ptr(reinterpret_cast<const char*>(mbn) + relu_tile_base(nh[(q < SL_HA ? FH_SLOTA : FH_SLOTB - SL_HA) + q], a.B, blockIdx.x, wn)), (unsigned)lane);
+                    }
+                }
+                if constexpr ((SP::PRE & 1) != 0) slab_prefetch_static<T, SP, 1, l - 1>(pre, wpack, wn, lane);
+            }
+        };
+        // (the last layer's bytes are the forward's own bits whatever SP::PRE says)
+        slab_bwd_layer<T, NM, HB, (SP::PRE & 1) != 0, (SP::PRE & 2) != 0 || l == SP::L - 1>(a, smem, wpack, wn, lane, l, SP::L - 1 - l, SHdr<SP, 1, l>{}, SProg<SP, 1, l, 0>{}, SProg<SP, 1, l, 1>{},
+                                                                                              keepA, keepB, mid, mbq, &pre);
+        slab_bwd_layers_static<T, NM, HB, SP, l - 1>(a, smem, wpack, wn, lane, keepA, keepB, mbq, pre);
     }
+}
+// the last layer's relu bytes of a one-launch step are the forward's own bits (same wave, same lane, same slots): no load
+template <class SP, int HB> __device__ __forceinline__ void slab_bits_to_bytes(const unsigned* lastbits, unsigned (&mbq)[SL_HA + HB]) {
+    constexpr SHdr<SP, 1, SP::L - 1> bh{};
+    constexpr SHdr<SP, 0, SP::L - 1> fh{};
+#pragma unroll
+    for (int q = 0; q < SL_HA + HB; ++q) {
+        mbq[q] = 0xffu;
+        if (bh[FH_KIND + q] == NK_RELU) {
+            const int u = q < SL_HA ? q : q - SL_HA;
+            const unsigned word = lastbits[(q < SL_HA ? 0 : (SL_HA + 3) / 4) + (u >> 2)];
+            mbq[q] = (word >> (8 * (u & 3))) & 0xffu;
+        }
+    }
+}
+template <class SP, int HB> constexpr bool slab_bits_consistent() {      // a node masked by the backward's last layer was a relu node of the forward's last layer, in the same slot
+    for (int q = 0; q < SL_HA + HB; ++q)
+        if (SP::bwd[SP::L - 1][FH_KIND + q] == NK_RELU && SP::fwd[SP::L - 1][FH_KIND + q] != NK_RELU) return false;
+    for (int u = 0; u < 16; ++u)
+        if (SP::bwd[SP::L - 1][FH_SLOTA + u] != SP::fwd[SP::L - 1][FH_SLOTA + u] || SP::bwd[SP::L - 1][FH_SLOTB + u] != SP::fwd[SP::L - 1][FH_SLOTB + u]) return false;
+    return true;
 }
 // the carried rows at the start of the sweep: the decoder backward's dX_L, read back from the tile in LDS (rows past the batch are zero there)
 template <typename T, int HB, class FH>
@@ -1408,7 +1561,7 @@ __device__ __forceinline__ void slab_bwd_keep_init(const FH& bh, const char* sme
 
 // STEP: part of k_slab_step -- the forward's decoder tail of the same launch left the dX_L tile in LDS; the layers' programs are a.prog_off_b
 // SP: void = the plan's tables are interpreted; else the compile-time program of one (topology, depth)
-template <typename T, int NM, int HB, bool STEP, class SP = void> __device__ __forceinline__ void slab_bwd_body(const StackArgs& a, char* smem) {
+template <typename T, int NM, int HB, bool STEP, class SP = void, class A = StackArgs> __device__ __forceinline__ void slab_bwd_body(const A& a, char* smem, const unsigned* lastbits = nullptr) {
     using P = Prec<T>;
     constexpr bool DYN = std::is_void<SP>::value;
     const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1462,9 +1615,14 @@ template <typename T, int NM, int HB, bool STEP, class SP = void> __device__ __f
             slab_bwd_layer<T, NM, HB>(a, smem, wpack, wn, lane, l, a.L - 1 - l, bh, wa, wb, keepA, keepB, [&] { bhn.settle(); wan.settle(); wbn.settle(); });
         }
     } else {
+        static_assert(slab_bits_consistent<SP, HB>(), "forward / backward tables of the last layer disagree");
+        typename P::BFrag pre[2];
+        if constexpr ((SP::PRE & 1) != 0) slab_prefetch_static<T, SP, 1, SP::L - 1>(pre, wpack, wn, lane);      // (nothing is stored between here and the first pass: the mask phase writes LDS only)
         slab_bwd_keep_init<T, HB>(SHdr<SP, 1, SP::L - 1>{}, smem, wn, lane, keepA, keepB);
+        unsigned mbq[SL_HA + HB];
+        slab_bits_to_bytes<SP, HB>(lastbits, mbq);
         FS_STAMP2(0);
-        slab_bwd_layers_static<T, NM, HB, SP, SP::L - 1>(a, smem, wpack, wn, lane, keepA, keepB);
+        slab_bwd_layers_static<T, NM, HB, SP, SP::L - 1>(a, smem, wpack, wn, lane, keepA, keepB, mbq, pre);
     }
 }
 template <typename T, int NM, int HB> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_bwd(StackArgs a) {
@@ -1474,11 +1632,19 @@ template <typename T, int NM, int HB> __global__ __launch_bounds__(SL_THREADS, 2
 // One-call training step (mshgnn_step_mse / mshgnn_step_ce): the forward layers, decoder + loss + decoder backward and the backward layers of a tile in ONE
 // launch.  The tail leaves dX_L in the node blocks, so the backward sweep starts without a launch boundary, without the header / tile round trips of
 // k_slab_bwd's start and without re-reading dX_L (stamps: 16 k of its 163 k cycles).  Same code, same order of every accumulation: identical bits.
-template <typename T, int NM, int HB, class SP = void> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_step(StackArgs a) {
+template <typename T, int NM, int HB, class SP = void, int NT = 0> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_step(StackArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    slab_fwd_body<T, NM, HB, true, SP>(a, smem);
-    __syncthreads();      // the tile's dX_L rows are in the out-type blocks, the tail's reduction scratch has been read
-    slab_bwd_body<T, NM, HB, true, SP>(a, smem);
+    if constexpr (!std::is_void<SP>::value) {      // compile-time program (whole tiles only: StackView); NT: the stash store policy
+        const StackView<NT> v(a, true);
+        unsigned lastbits[(SL_HA + 3) / 4 + (HB + 3) / 4];
+        slab_fwd_body<T, NM, HB, true, SP>(v, smem, lastbits);
+        __syncthreads();
+        slab_bwd_body<T, NM, HB, true, SP>(v, smem, lastbits);
+    } else {
+        slab_fwd_body<T, NM, HB, true, SP>(a, smem);
+        __syncthreads();      // the tile's dX_L rows are in the out-type blocks, the tail's reduction scratch has been read
+        slab_bwd_body<T, NM, HB, true, SP>(a, smem);
+    }
 }
 
 // the slab instantiation of a plan: NM = bound on the base_transform nodes (2 / 4), HB = group-B slots (6 / 8)
@@ -1492,7 +1658,7 @@ static StackKernel slab_fwd_kernel(const HostPlan& hp) {
 // slots, same liveness), so a stale table file costs speed, never results; MSHGNN_SPEC=0 keeps the interpreting kernel (A/B runs, bit-identity tests).
 #include "mshgnn_spec_tables.inc"
 template <class SP> static bool spec_matches(const HostPlan& hp) {
-    if (!hp.slab || hp.L != SP::L || hp.NN != SP::NN || hp.sl_hb != SP::HB || (hp.n_mlp <= 2 ? 2 : 4) != SP::NM) return false;
+    if (!hp.slab || hp.L != SP::L || hp.NN != SP::NN || hp.sl_hb != SP::HB || (hp.n_mlp <= 2 ? 2 : 4) != SP::NM || (hp.d.out_channels <= 4 ? 4 : 8) != SP::DMAX) return false;
     for (int l = 0; l < SP::L; ++l) {
         if (hp.sl_fwd_off[l] + SP::ROW > (int)hp.tables.size() || hp.sl_bwd_off[l] + SP::ROW > (int)hp.tables.size()) return false;
         if (memcmp(hp.tables.data() + hp.sl_fwd_off[l], SP::fwd[l], sizeof(int32_t) * SP::ROW) != 0) return false;
@@ -1500,16 +1666,17 @@ template <class SP> static bool spec_matches(const HostPlan& hp) {
     }
     return true;
 }
-static StackKernel slab_step_spec_kernel(const HostPlan& hp) {
+static StackKernel slab_step_spec_kernel(const HostPlan& hp, int nt) {      // nt: the launch's stash store policy (stash_nt_for)
     static const bool on = []() { const char* e = getenv("MSHGNN_SPEC"); return !(e && atoi(e) == 0); }();
     if (!on) return nullptr;
-#define MSHGNN_SPEC_TRY(SP) if (spec_matches<SP>(hp)) return k_slab_step<__bf16, SP::NM, SP::HB, SP>;
+#define MSHGNN_SPEC_TRY(SP) if (spec_matches<SP>(hp)) return nt ? k_slab_step<__bf16, SP::NM, SP::HB, SP, 1> : k_slab_step<__bf16, SP::NM, SP::HB, SP, 0>;
     MSHGNN_SPEC_LIST(MSHGNN_SPEC_TRY)
 #undef MSHGNN_SPEC_TRY
     return nullptr;
 }
-static StackKernel slab_step_kernel(const HostPlan& hp) {
-    if (StackKernel k = slab_step_spec_kernel(hp)) return k;
+// the step kernel of a launch: the specialised one where the plan has one and the batch is whole tiles (its stores are unpredicated), else the interpreter
+static StackKernel slab_step_kernel(const HostPlan& hp, int64_t B = -1, int nt = 0) {
+    if (B > 0 && B % TILE_ROWS == 0) if (StackKernel k = slab_step_spec_kernel(hp, nt)) return k;
     if (hp.sl_hb <= SL_HB) return hp.n_mlp <= 2 ? k_slab_step<__bf16, 2, SL_HB> : k_slab_step<__bf16, 4, SL_HB>;
     return hp.n_mlp <= 2 ? k_slab_step<__bf16, 2, SL_HB_MAX> : k_slab_step<__bf16, 4, SL_HB_MAX>;
 }
@@ -2308,6 +2475,8 @@ extern "C" int mshgnn_plan_create(const mshgnn_desc* desc, mshgnn_plan** out) {
             { int dev = 0, cus = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); p->n_cu = cus > 0 ? cus : 256; }
             if (p->use_slab && ((rc = set_lds_attr(slab_fwd_kernel(hp), flds)) || (rc = set_lds_attr(slab_bwd_kernel(hp), flds)) ||
                                 (rc = set_lds_attr(slab_step_kernel(hp), flds)))) { mshgnn_plan_destroy(p); return rc; }
+            if (p->use_slab) for (int nt = 0; nt < 2; ++nt)      // the specialised step kernels of this plan, if it has any (both store policies)
+                if (StackKernel k = slab_step_spec_kernel(hp, nt)) if ((rc = set_lds_attr(k, flds))) { mshgnn_plan_destroy(p); return rc; }
             { const char* et = getenv("MSHGNN_STEP_KERNEL"); p->use_step = !(et && atoi(et) == 0); }      // one-call steps: forward + backward sweep in one launch
             { const char* eg = getenv("MSHGNN_STAGGER"); p->stagger = eg ? atoi(eg) : 0; }
         }
@@ -2523,7 +2692,7 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
                     for (int l = 0; l <= hp.L; ++l) a.dx_off[l] = lay.dx[l];
                     for (int l = 0; l < hp.L; ++l) { a.dh_off[l] = lay.dh[l]; a.du_off[l] = lay.du[l]; a.prog_off_b[l] = hp.sl_bwd_off[l]; }
                     a.mask0_off = lay.dd[0];
-                    hipLaunchKernelGGL(slab_step_kernel(hp), dim3(tiles), dim3(SL_THREADS), (hp.sl_blk + FS_EXTRA_BLK) * Prec<T>::BLK, st, a);
+                    hipLaunchKernelGGL(slab_step_kernel(hp, B, a.stash_nt), dim3(tiles), dim3(SL_THREADS), (hp.sl_blk + FS_EXTRA_BLK) * Prec<T>::BLK, st, a);
                     *stack_step_done = true;
                 } else
                 hipLaunchKernelGGL(slab_fwd_kernel(hp), dim3(tiles), dim3(SL_THREADS), (hp.sl_blk + FS_EXTRA_BLK) * Prec<T>::BLK, st, a);

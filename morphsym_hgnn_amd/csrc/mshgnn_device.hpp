@@ -89,6 +89,18 @@ template <> struct Prec<__bf16> {
 // Make a lane-dependent value opaque so the compiler cannot hoist the address math derived from it out of the
 // group loop (hoisted per-register epilogue addresses were being spilled to scratch -- guide, Appendix B pitfalls).
 __device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); return x; }
+typedef const char __attribute__((address_space(1))) gchar;      // global address space, spelled out: a pointer rebuilt from integers is otherwise generic (flat requests, which count on BOTH vmcnt and lgkmcnt)
+typedef char __attribute__((address_space(1))) gwchar;
+__device__ __forceinline__ gchar* uniform_ptr(const char* p) {      // a global pointer the compiler must keep in SGPRs (request = SGPR base + 32-bit VGPR offset)
+    const uint64_t u = reinterpret_cast<uint64_t>(p);
+    return reinterpret_cast<gchar*>(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(u & 0xffffffffu)));
+}
+__device__ __forceinline__ gwchar* uniform_wptr(char* p) { return const_cast<gwchar*>(uniform_ptr(p)); }
+__device__ __forceinline__ u32x4 gload16(gchar* base, unsigned off) { return *reinterpret_cast<const u32x4 __attribute__((address_space(1)))*>(base + off); }
+__device__ __forceinline__ unsigned gload1(gchar* base, unsigned off) { return *reinterpret_cast<const uint8_t __attribute__((address_space(1)))*>(base + off); }
+__device__ __forceinline__ void gstore16(gwchar* base, unsigned off, u32x4 v) { *reinterpret_cast<u32x4 __attribute__((address_space(1)))*>(base + off) = v; }
+__device__ __forceinline__ void gstore16_nt(gwchar* base, unsigned off, u32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<u32x4 __attribute__((address_space(1)))*>(base + off)); }
+__device__ __forceinline__ void gstore1(gwchar* base, unsigned off, unsigned v) { *reinterpret_cast<uint8_t __attribute__((address_space(1)))*>(base + off) = (uint8_t)v; }
 
 __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(__bf16 v) { return (float)v; }
@@ -236,6 +248,15 @@ template <typename T> __device__ __forceinline__ void load_bfrag(typename Prec<T
     }
 }
 
+// the same fragment requested as SGPR base + this lane's 32-bit offset (16 lane): compile-time programs, whose pack ids are literals -- no 64-bit address
+// arithmetic and no address register pair per fragment
+template <typename T> __device__ __forceinline__ void load_bfrag_u(typename Prec<T>::BFrag& b, const T* wpack, int pack, int wv, unsigned lane16) {
+    constexpr int NBV = Prec<T>::NBV;
+    gchar* base = uniform_ptr(reinterpret_cast<const char*>(wpack) + ((size_t)pack * H * H * sizeof(T)) + (size_t)wv * NBV * 64 * 16);
+#pragma unroll
+    for (int v = 0; v < NBV; ++v) b.v[v] = __builtin_bit_cast(typename Prec<T>::Vec, gload16(base + v * 1024, lane16));
+}
+
 // acc^T += W_frag . X_frag  (A operand = packed weights, B operand = the window tile)
 __device__ __forceinline__ void mac(Prec<float>::Acc& acc, const Prec<float>::AFrag& x, const Prec<float>::BFrag& w) {
 #pragma unroll
@@ -259,6 +280,12 @@ template <typename T> __device__ __forceinline__ void acc_init_bias(typename Pre
     if (bias == nullptr) { acc_fill(a, 0.f); return; }
     a.c[0] = *reinterpret_cast<const f32x4*>(bias + wv * 32 + c_feat(0, lane));
     a.c[1] = *reinterpret_cast<const f32x4*>(bias + wv * 32 + c_feat(1, lane));
+}
+// (compile-time programs: scalar base of the row slice + this lane's byte offset)
+template <typename T> __device__ __forceinline__ void acc_init_bias_u(typename Prec<T>::Acc& a, const float* bias_row, int wv, unsigned loff) {
+    gchar* base = uniform_ptr(reinterpret_cast<const char*>(bias_row + wv * 32));
+    a.c[0] = __builtin_bit_cast(f32x4, gload16(base, loff));
+    a.c[1] = __builtin_bit_cast(f32x4, gload16(base + 16, loff));
 }
 // this lane's bias values, fetched at group start and ADDED in the epilogue so the load's latency hides under the MACs
 struct BiasQ { f32x4 b[2]; };
@@ -700,6 +727,8 @@ inline bool prep_use_tiled(int n_packs) {      // MSHGNN_PREP_TILED=0 / 1 forces
 inline unsigned prep_tiled_grid(int n_packs, int n_biases) { return (unsigned)(2 * n_packs + (n_biases * H + 255) / 256); }
 
 struct StackArgs {
+    static constexpr bool full = false;           // (StackView: every tile of the launch is complete)
+    static constexpr int nt_mode = -1;            // (StackView: the stash store policy is a template parameter; -1: read stash_nt)
     const void* tile_in;                          // fwd: X_0                       bwd: dX_L
     char* ws;
     size_t x_off[MAX_L + 1], dx_off[MAX_L + 1];   // X_l stashes (fwd: written for l >= 1; bwd: X_0 read for the encoder mask), dX_l (bwd: written)
@@ -722,6 +751,32 @@ struct StackArgs {
     int stagger;         // two workgroups per CU: the second half of the grid starts this many cycles late, so that one workgroup's MAC phases
                          // (matrix pipe) run beside the other's epilogues (stores) instead of both competing for the same unit (0: off)
 };
+// The arguments as the kernel of a compile-time program sees them: the same member names (references into the kernel-argument segment), except the scalars
+// that every node's stores read -- batch size, store policy, training flag -- which are COPIES pinned in SGPRs.  hipcc otherwise re-loads those from the
+// kernel arguments wherever it runs short of scalar registers: a scalar-memory round trip (s_load + lgkmcnt(0)) per node in the store phases.
+// full: the host launches these kernels only over batches of whole 16-window tiles (B % 16 == 0), so no store is predicated and the number of stores between a
+// request and its use is the same on every path -- what lets the compiler wait for a load issued BEFORE a store phase with a counted vmcnt instead of a drain.
+// NT: the stash store policy (StackArgs.stash_nt) as a template parameter, for the same reason (one arm, compiler-visible stores).
+template <int NT> struct StackView {
+    static constexpr bool full = true;
+    static constexpr int nt_mode = NT;
+    const StackArgs& s;
+    const void* const& tile_in; char* const& ws;
+    const size_t (&x_off)[MAX_L + 1]; const size_t (&dx_off)[MAX_L + 1];
+    const size_t (&mask_off)[MAX_L]; const size_t (&hb_off)[MAX_L]; const size_t (&t1_off)[MAX_L]; const size_t (&dh_off)[MAX_L]; const size_t (&du_off)[MAX_L];
+    const void* const& wpack; const float* const& bias; const int* const& tables; const int (&prog_off)[MAX_L]; const int (&prog_off_b)[MAX_L];
+    const int& NN; const int& L; const int& dbg; const int& node0; const int& n_out; const size_t& mask0_off; long long* const& stamps; const int& stagger;
+    int B, training, stash_nt;
+    __device__ __forceinline__ StackView(const StackArgs& a, bool step)
+        : s(a), tile_in(a.tile_in), ws(a.ws), x_off(a.x_off), dx_off(a.dx_off), mask_off(a.mask_off), hb_off(a.hb_off), t1_off(a.t1_off), dh_off(a.dh_off), du_off(a.du_off),
+          wpack(a.wpack), bias(a.bias), tables(a.tables), prog_off(a.prog_off), prog_off_b(a.prog_off_b), NN(a.NN), L(a.L), dbg(a.dbg), node0(a.node0), n_out(a.n_out),
+          mask0_off(a.mask0_off), stamps(a.stamps), stagger(a.stagger), B(a.B), training(step ? 1 : a.training), stash_nt(a.stash_nt) {
+        asm volatile("" : "+s"(B));
+    }
+};
+__device__ __forceinline__ const StackArgs& args_of(const StackArgs& a) { return a; }
+template <int NT> __device__ __forceinline__ const StackArgs& args_of(const StackView<NT>& v) { return v.s; }
+
 // one 16-byte stash store, plain or non-temporal (StackArgs.stash_nt: uniform)
 __device__ __forceinline__ void stash_store(void* p, u32x4 v, bool nt) {
     // (two arms that differ only in the cache hint are merged by the optimiser into ONE plain store, and an opaque copy of the address turns it into a flat
@@ -737,6 +792,17 @@ __device__ __forceinline__ void stash_store(void* p, u32x4 v, bool nt) {
 // A1-C2 bf16 at 8 layers (640 MB) 0.6385 -> 0.6112, at 5 layers (~300 MB) 0.3738 -> 0.3649, MiniCheetah-K4 L = 8 0.7215 -> 0.6849, Solo K4 COM 5.16 -> 5.07, split plan at 8 layers
 // 1.502 -> 1.458; below the limit the step launch pays for it instead (A1-C2 at 3 layers, 125 MB: step launch +3-5 us, weight gradients -3: -0.5 %; split plan, 250 MB: +1 %):
 // plain stores stay there.  MSHGNN_STASH_NT=0 / 1 forces either; the bits are the same.
+// the stash store of a kernel over argument type A (StackArgs: policy read at run time; StackView<NT>: compile-time, the non-temporal form through the builtin --
+// with one arm only the optimiser has nothing to merge, and the store stays visible to the compiler's wait counting)
+template <class A> __device__ __forceinline__ void stash_store_a(const A& a, void* p, u32x4 v) {
+    if constexpr (A::nt_mode == 1) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
+    else if constexpr (A::nt_mode == 0) *reinterpret_cast<u32x4*>(p) = v;
+    else stash_store(p, v, a.stash_nt != 0);
+}
+template <class A> __device__ __forceinline__ void stash_store_u(const A& a, gwchar* base, unsigned off, u32x4 v) {      // uniform base + lane offset (compile-time programs)
+    static_assert(A::nt_mode >= 0, "compile-time store policy");
+    if constexpr (A::nt_mode == 1) gstore16_nt(base, off, v); else gstore16(base, off, v);
+}
 inline int stash_nt_for(int64_t B, int stash_rows, int row_bytes) {
     static const int force = []() { const char* e = getenv("MSHGNN_STASH_NT"); return e ? atoi(e) : -1; }();
     static const int64_t limit_mb = []() { const char* e = getenv("MSHGNN_STASH_NT_MB"); return (int64_t)(e ? atoi(e) : 200); }();
@@ -750,7 +816,7 @@ template <typename HP> inline int stash_rows_of(const HP& hp) {
     return rows;
 }
 // start-up delay of the workgroups that share a CU with an earlier one (the first gridDim.x / 2 workgroups fill one slot per CU)
-__device__ __forceinline__ void stack_stagger(const StackArgs& a) {
+template <class A> __device__ __forceinline__ void stack_stagger(const A& a) {
     if (a.stagger > 0 && blockIdx.x >= (gridDim.x + 1) / 2)
         for (int i = 0; i < a.stagger; i += 1024) __builtin_amdgcn_s_sleep(16);      // (s_sleep n = 64 n cycles)
 }
@@ -884,21 +950,33 @@ template <class FP, int HS, int CB> constexpr int fs_static_pb(int sgi, int u) {
 }
 // fs_run over a compile-time program (SProg): the same MACs in the same order on the same accumulators (identical bits), as straight-line code -- no slot
 // headers, no count decoding, no block-stream readlanes, LDS blocks as immediate offsets, exact counted waits (no branch between a request and its use).
-template <typename T, int HS, int CB, class FP>
-__device__ __forceinline__ void fs_run_static(typename Prec<T>::Acc (&acc)[HS], const char* smem, const T* wpack, int wn, int lane) {
+// the first two weight fragments of a compile-time program's run, requested ahead of it (before the store phase that precedes the run: fs_run_static<PRE>)
+template <typename T, class FP> __device__ __forceinline__ void fs_prefetch_static(typename Prec<T>::BFrag (&bf)[2], const T* wpack, int wn, int lane) {
+    constexpr FP cp{};
+    constexpr int nseg = cp.at(0);
+    const unsigned lane16 = (unsigned)opaque(lane) * 16u;
+    if constexpr (nseg > 0) load_bfrag_u<T>(bf[0], wpack, cp.pack(0), wn, lane16);
+    if constexpr (nseg > 1) load_bfrag_u<T>(bf[1], wpack, cp.pack(1), wn, lane16);
+}
+// PRE: bf[0] / bf[1] were requested by fs_prefetch_static<FP> before the preceding store phase; the compiler waits for them with a counted vmcnt that leaves
+// those stores in flight (same store count on every path: StackView), so the run starts under the drain instead of behind it
+template <typename T, int HS, int CB, class FP, bool PRE = false>
+__device__ __forceinline__ void fs_run_static(typename Prec<T>::Acc (&acc)[HS], const char* smem, const T* wpack, int wn, int lane, typename Prec<T>::BFrag (&bf)[2]) {
     constexpr FP cp{};
     constexpr int nseg = cp.at(0);
     if constexpr (nseg > 0) {
         constexpr int total = fs_static_pb<FP, HS, CB>(nseg - 1, HS) - 1;      // MACs of the run
-        typename Prec<T>::BFrag bf[2];
         typename Prec<T>::AFrag afn;
         const AOff<T> ao(lane);
-        __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));      // (as fs_run: the previous epilogue's stores are drained before the first request)
-        load_bfrag<T>(bf[0], wpack, cp.pack(0), wn, lane);
+        const unsigned lane16 = (unsigned)opaque(lane) * 16u;
+        if constexpr (!PRE) {
+            __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));      // (as fs_run: the previous epilogue's stores are drained before the first request)
+            load_bfrag_u<T>(bf[0], wpack, cp.pack(0), wn, lane16);
+        }
         load_afrag<T>(afn, smem, cp.at(1), ao);
         static_for<0, nseg>([&](auto SG) {
             constexpr int sgi = decltype(SG)::value;
-            if constexpr (sgi + 1 < nseg) load_bfrag<T>(bf[(sgi + 1) & 1], wpack, cp.pack(sgi + 1), wn, lane);
+            if constexpr (sgi + 1 < nseg && !(PRE && sgi == 0)) load_bfrag_u<T>(bf[(sgi + 1) & 1], wpack, cp.pack(sgi + 1), wn, lane16);
             __builtin_amdgcn_sched_barrier(0);
             static_for<0, HS>([&](auto U) {
                 constexpr int u = decltype(U)::value;
@@ -925,7 +1003,7 @@ __device__ __forceinline__ void fs_run_static(typename Prec<T>::Acc (&acc)[HS], 
 template <typename T, int HS = FS_HS, int CB = 3, class FP = FProg>
 __device__ __forceinline__ void fs_run(const FP& wp, typename Prec<T>::Acc (&acc)[HS], const char* smem, const T* wpack, int wn, int lane, int dbg = 0,
                                        long long* segclk = nullptr) {
-    if constexpr (FP::is_static) { fs_run_static<T, HS, CB, FP>(acc, smem, wpack, wn, lane); return; }
+    if constexpr (FP::is_static) { typename Prec<T>::BFrag bf[2]; fs_run_static<T, HS, CB, FP>(acc, smem, wpack, wn, lane, bf); return; }
     const int nseg = wp.at(0);
     int pb = 1;
     typename Prec<T>::BFrag bfa, bfb;
@@ -976,8 +1054,40 @@ __device__ __forceinline__ void fs_run(const FP& wp, typename Prec<T>::Acc (&acc
 // decoder (+ fused wrapper MSE and decoder backward) on the X_L tile in LDS: shared tail of k_stack_fwd / k_slab_fwd
 // TOLDS (k_slab_step): the dX_L rows also go into the out-type nodes' LDS blocks (rows past the batch: zeros), where the backward sweep of the same launch
 // picks them up; the reduction scratch at the start of LDS must not reach those blocks (checked on the host)
-template <typename T, int THREADS, int DMAX, bool SPLIT = false, bool TOLDS = false>      // DMAX: compile-time bound on the output channels (4 or 8): loops, loads and registers scale with it
-__device__ __forceinline__ void decoder_tail_impl(const StackArgs& a, char* smem, int tid, int lane, int wv, int w0, int B) {
+// the tail's global operands of one pass (decoder weights / bias, output mask, labels of this thread's rows): requested in one go -- by the tail itself, or
+// (compile-time programs) before the last layer's store phase, so that the tail starts with its operands in registers instead of behind that phase's drain
+template <int DMAX, int NPP> struct DecOps { float Wv[DMAX][8], bv[DMAX], mk[NPP][DMAX], yv[NPP][DMAX]; int labv[NPP]; };
+template <int THREADS, int DMAX, int NPP>
+__device__ __forceinline__ void decoder_ops_load(const StackArgs& a, int tid, int w0, int B, int f0, bool with_w, DecOps<DMAX, NPP>& o) {
+    const int c = tid & 15, row = (tid >> 4) & 15;
+    const float* W = a.params + a.off_dec_w;
+    const bool ce = a.labels != nullptr;
+    if (with_w) {
+#pragma unroll
+        for (int dd = 0; dd < DMAX; ++dd) {
+            const int dc = min(dd, a.dout - 1);
+            const f32x4 wa = *reinterpret_cast<const f32x4*>(W + dc * H + c * 8), wb = *reinterpret_cast<const f32x4*>(W + dc * H + c * 8 + 4);
+            o.Wv[dd][0] = wa[0]; o.Wv[dd][1] = wa[1]; o.Wv[dd][2] = wa[2]; o.Wv[dd][3] = wa[3];
+            o.Wv[dd][4] = wb[0]; o.Wv[dd][5] = wb[1]; o.Wv[dd][6] = wb[2]; o.Wv[dd][7] = wb[3];
+            o.bv[dd] = a.params[a.off_dec_b + dc];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NPP; ++i) {
+        const int f = min(f0 + i * (THREADS / 256), a.n_out - 1);
+        const size_t r = (size_t)min(w0 + row, B - 1) * a.n_out + f;
+        o.labv[i] = 0;
+        if (ce) o.labv[i] = a.labels[r] != 0;
+#pragma unroll
+        for (int dd = 0; dd < DMAX; ++dd) {
+            const int dc = min(dd, a.dout - 1);
+            o.mk[i][dd] = a.out_mask[f * a.dout + dc];
+            o.yv[i][dd] = a.y ? a.y[r * a.dout + dc] : 0.f;
+        }
+    }
+}
+template <typename T, int THREADS, int DMAX, bool SPLIT = false, bool TOLDS = false, int NPP = 2, bool PRE = false>      // DMAX: compile-time bound on the output channels (4 or 8): loops, loads and registers scale with it; NPP: nodes per pass; PRE: *pre holds pass 0's operands
+__device__ __forceinline__ void decoder_tail_impl(const StackArgs& a, char* smem, int tid, int lane, int wv, int w0, int B, DecOps<DMAX, NPP>* pre = nullptr) {
     // decoder on the out-type rows of X_L (hgnn_c2.py:176-189): thread = (node, row, 8-column chunk).  With y (mshgnn_step_mse) the
     // same threads also take the wrapper MSE (gnnLightning.py:633-639) and the decoder backward: dX_L rows to global for
     // k_stack_bwd, and this tile's partial decoder gradients + loss partial into dec_slabs[tile] (summed by k_finalize).
@@ -996,31 +1106,14 @@ __device__ __forceinline__ void decoder_tail_impl(const StackArgs& a, char* smem
         // two nodes per pass, every global load of a pass before its first store: a load waited for while stores are in flight
         // costs a full vmcnt(0) drain (loads and stores retire out of order with respect to each other)
         // (unconditional loads with clamped indices, so that they are issued back to back and waited for once)
-        float Wv[DMAX][8], bv[DMAX];
+        DecOps<DMAX, NPP> ops;
+        if constexpr (PRE) ops = *pre;
+        auto& Wv = ops.Wv; auto& bv = ops.bv; auto& mk = ops.mk; auto& yv = ops.yv; auto& labv = ops.labv;
+        for (int f0 = tid >> 8; f0 < a.n_out; f0 += NPP * (THREADS / 256)) {
+            float ov[NPP][DMAX], dxv[NPP][8];
+            if (!(PRE && f0 == (tid >> 8))) decoder_ops_load<THREADS, DMAX, NPP>(a, tid, w0, B, f0, !PRE && f0 == (tid >> 8), ops);
 #pragma unroll
-        for (int dd = 0; dd < DMAX; ++dd) {
-            const int dc = min(dd, a.dout - 1);
-            const f32x4 wa = *reinterpret_cast<const f32x4*>(W + dc * H + c * 8), wb = *reinterpret_cast<const f32x4*>(W + dc * H + c * 8 + 4);
-            Wv[dd][0] = wa[0]; Wv[dd][1] = wa[1]; Wv[dd][2] = wa[2]; Wv[dd][3] = wa[3];
-            Wv[dd][4] = wb[0]; Wv[dd][5] = wb[1]; Wv[dd][6] = wb[2]; Wv[dd][7] = wb[3];
-            bv[dd] = a.params[a.off_dec_b + dc];
-        }
-        for (int f0 = tid >> 8; f0 < a.n_out; f0 += 2 * (THREADS / 256)) {
-            float ov[2][DMAX], dxv[2][8], mk[2][DMAX], yv[2][DMAX]; int labv[2] = {0, 0};
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int f = min(f0 + i * (THREADS / 256), a.n_out - 1);
-                const size_t r = (size_t)min(w0 + row, B - 1) * a.n_out + f;
-                if (ce) labv[i] = a.labels[r] != 0;
-#pragma unroll
-                for (int dd = 0; dd < DMAX; ++dd) {
-                    const int dc = min(dd, a.dout - 1);
-                    mk[i][dd] = a.out_mask[f * a.dout + dc];
-                    yv[i][dd] = a.y ? a.y[r * a.dout + dc] : 0.f;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < NPP; ++i) {
                 const int f = f0 + i * (THREADS / 256);
                 const bool live = f < a.n_out;
                 f32x4 x0, x1;
@@ -1071,7 +1164,7 @@ __device__ __forceinline__ void decoder_tail_impl(const StackArgs& a, char* smem
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < NPP; ++i) {
                 const int f = f0 + i * (THREADS / 256);
                 const bool ok = f < a.n_out && w0 + row < B;
                 const size_t r = (size_t)(w0 + row) * a.n_out + f;
@@ -1143,6 +1236,8 @@ __device__ __forceinline__ void decoder_tail(const StackArgs& a, char* smem, int
     if (a.dout <= 4) decoder_tail_impl<T, THREADS, 4, SPLIT, TOLDS>(a, smem, tid, lane, wv, w0, B);
     else decoder_tail_impl<T, THREADS, 8, SPLIT, TOLDS>(a, smem, tid, lane, wv, w0, B);
 }
+// compile-time programs: out channels bound DMAX from the program, all (<= 4 per 256 threads) output nodes in one pass
+constexpr int DEC_NPP_STATIC = 4;
 
 struct DecArgs {
     const void* xl; void* dxl; const float* params; const float* out_mask; float* out; const float* gout; float* slabs;

@@ -153,13 +153,6 @@ __device__ __forceinline__ int ro_int(const int* p, int i) {
     const uint64_t v = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(u & 0xffffffffu));
     return *reinterpret_cast<cint*>(v);
 }
-typedef const char __attribute__((address_space(1))) gchar;      // global address space, spelled out: a pointer rebuilt from integers is otherwise generic (flat requests, which count on BOTH vmcnt and lgkmcnt)
-__device__ __forceinline__ gchar* uniform_ptr(const char* p) {      // a global pointer the compiler must keep in SGPRs (request = SGPR base + 32-bit VGPR offset)
-    const uint64_t u = reinterpret_cast<uint64_t>(p);
-    return reinterpret_cast<gchar*>(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(u & 0xffffffffu)));
-}
-__device__ __forceinline__ u32x4 gload16(gchar* base, unsigned off) { return *reinterpret_cast<const u32x4 __attribute__((address_space(1)))*>(base + off); }
-__device__ __forceinline__ unsigned gload1(gchar* base, unsigned off) { return *reinterpret_cast<const uint8_t __attribute__((address_space(1)))*>(base + off); }
 // this lane's index, recomputed where it is used (two VALU operations): a thread index kept live across k_gstep5's loop is spilled, and a scratch reload waits for every request in flight
 __device__ __forceinline__ int lane_now() { int l; asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l)); return l; }
 // Two-phase epilogue of a job tile (bf16 arithmetic, NS 32-column slices per wave): EVERY request of the tile first, then the arithmetic and the stores.
