@@ -806,6 +806,9 @@ def main():
                    "timed_s": sum(blocks)},
         "overlap": wl.overlap_choice or {"mode": args.overlap, "two_phase": bool(wl.overlap)},
         "roofline": roof, "kernel_us": kernels,
+        "step_kernel": {"specialised": getattr(wl.e, "specialised", ""),
+                        "what": "compile-time program the one-call step's stack launch runs on (csrc/mshgnn_spec_tables.inc; '' = the plan tables are interpreted; "
+                                "MSHGNN_SPEC=0 forces that -- same bits, tests/test_spec_gpu.py)"},
         "algorithmic_flops_per_window": wl.e.info.flops_fwd + wl.e.info.flops_bwd,
         "flat_gradient_bytes": 4 * spec.flat_size(),
         "loss": loss,

@@ -1666,17 +1666,15 @@ template <class SP> static bool spec_matches(const HostPlan& hp) {
     }
     return true;
 }
-static StackKernel slab_step_spec_kernel(const HostPlan& hp, int nt) {      // nt: the launch's stash store policy (stash_nt_for)
-    static const bool on = []() { const char* e = getenv("MSHGNN_SPEC"); return !(e && atoi(e) == 0); }();
-    if (!on) return nullptr;
-#define MSHGNN_SPEC_TRY(SP) if (spec_matches<SP>(hp)) return nt ? k_slab_step<__bf16, SP::NM, SP::HB, SP, 1> : k_slab_step<__bf16, SP::NM, SP::HB, SP, 0>;
+static StackKernel slab_step_spec_kernel(const HostPlan& hp, int nt, const char** name = nullptr) {      // nt: the launch's stash store policy (stash_nt_for)
+#define MSHGNN_SPEC_TRY(SP) if (spec_matches<SP>(hp)) { if (name) *name = #SP; return nt ? k_slab_step<__bf16, SP::NM, SP::HB, SP, 1> : k_slab_step<__bf16, SP::NM, SP::HB, SP, 0>; }
     MSHGNN_SPEC_LIST(MSHGNN_SPEC_TRY)
 #undef MSHGNN_SPEC_TRY
     return nullptr;
 }
 // the step kernel of a launch: the specialised one where the plan has one and the batch is whole tiles (its stores are unpredicated), else the interpreter
-static StackKernel slab_step_kernel(const HostPlan& hp, int64_t B = -1, int nt = 0) {
-    if (B > 0 && B % TILE_ROWS == 0) if (StackKernel k = slab_step_spec_kernel(hp, nt)) return k;
+static StackKernel slab_step_kernel(const HostPlan& hp, int64_t B = -1, int nt = 0, bool use_spec = false) {
+    if (use_spec && B > 0 && B % TILE_ROWS == 0) if (StackKernel k = slab_step_spec_kernel(hp, nt)) return k;
     if (hp.sl_hb <= SL_HB) return hp.n_mlp <= 2 ? k_slab_step<__bf16, 2, SL_HB> : k_slab_step<__bf16, 4, SL_HB>;
     return hp.n_mlp <= 2 ? k_slab_step<__bf16, 2, SL_HB_MAX> : k_slab_step<__bf16, 4, SL_HB_MAX>;
 }
@@ -2475,8 +2473,14 @@ extern "C" int mshgnn_plan_create(const mshgnn_desc* desc, mshgnn_plan** out) {
             { int dev = 0, cus = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); p->n_cu = cus > 0 ? cus : 256; }
             if (p->use_slab && ((rc = set_lds_attr(slab_fwd_kernel(hp), flds)) || (rc = set_lds_attr(slab_bwd_kernel(hp), flds)) ||
                                 (rc = set_lds_attr(slab_step_kernel(hp), flds)))) { mshgnn_plan_destroy(p); return rc; }
-            if (p->use_slab) for (int nt = 0; nt < 2; ++nt)      // the specialised step kernels of this plan, if it has any (both store policies)
-                if (StackKernel k = slab_step_spec_kernel(hp, nt)) if ((rc = set_lds_attr(k, flds))) { mshgnn_plan_destroy(p); return rc; }
+            { const char* esp = getenv("MSHGNN_SPEC"); p->use_spec = p->use_slab && !(esp && atoi(esp) == 0); }
+            if (p->use_spec) {      // the specialised step kernels of this plan, if it has any (both store policies)
+                const char* nm = nullptr;
+                for (int nt = 0; nt < 2; ++nt)
+                    if (StackKernel k = slab_step_spec_kernel(hp, nt, &nm)) if ((rc = set_lds_attr(k, flds))) { mshgnn_plan_destroy(p); return rc; }
+                if (nm) p->spec_name = nm + 6;      // (past "spec::")
+                else p->use_spec = false;
+            }
             { const char* et = getenv("MSHGNN_STEP_KERNEL"); p->use_step = !(et && atoi(et) == 0); }      // one-call steps: forward + backward sweep in one launch
             { const char* eg = getenv("MSHGNN_STAGGER"); p->stagger = eg ? atoi(eg) : 0; }
         }
@@ -2521,6 +2525,7 @@ extern "C" int mshgnn_profile_read(mshgnn_plan* p, mshgnn_kernel_stat* stats, in
     return MSHGNN_OK;
 }
 
+extern "C" const char* mshgnn_plan_specialised(const mshgnn_plan* p) { return p && !p->gen && p->use_spec ? p->spec_name : ""; }
 extern "C" int mshgnn_plan_info(const mshgnn_plan* p, mshgnn_info* info) {
     if (!p || !info) return set_err(MSHGNN_EINVAL, "null argument");
     *info = p->gen ? *gen_info(p) : p->hp.info;
@@ -2692,7 +2697,7 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
                     for (int l = 0; l <= hp.L; ++l) a.dx_off[l] = lay.dx[l];
                     for (int l = 0; l < hp.L; ++l) { a.dh_off[l] = lay.dh[l]; a.du_off[l] = lay.du[l]; a.prog_off_b[l] = hp.sl_bwd_off[l]; }
                     a.mask0_off = lay.dd[0];
-                    hipLaunchKernelGGL(slab_step_kernel(hp, B, a.stash_nt), dim3(tiles), dim3(SL_THREADS), (hp.sl_blk + FS_EXTRA_BLK) * Prec<T>::BLK, st, a);
+                    hipLaunchKernelGGL(slab_step_kernel(hp, B, a.stash_nt, p->use_spec), dim3(tiles), dim3(SL_THREADS), (hp.sl_blk + FS_EXTRA_BLK) * Prec<T>::BLK, st, a);
                     *stack_step_done = true;
                 } else
                 hipLaunchKernelGGL(slab_fwd_kernel(hp), dim3(tiles), dim3(SL_THREADS), (hp.sl_blk + FS_EXTRA_BLK) * Prec<T>::BLK, st, a);

@@ -1297,6 +1297,8 @@ struct mshgnn_plan {
     bool slab_force = false; int n_cu = 256;
     int64_t step_chunk = 32768;         // one-call steps over at least twice as many windows run as sub-steps of at least this many (StepChunk; MSHGNN_STEP_CHUNK, 0 = never)
     bool use_step = false;              // one-call steps on the slab kernels: k_slab_step (MSHGNN_STEP_KERNEL=0: two launches)
+    bool use_spec = true;               // ... on the specialised kernel where the plan has one (MSHGNN_SPEC=0 at plan creation: the interpreting kernel)
+    const char* spec_name = "";         // the compile-time program this plan's tables equal ("" = none)
     int stagger = 0;                             // StackArgs.stagger of the two-workgroups-per-CU stack kernels (MSHGNN_STAGGER)
     int n_types = 0;
     mshgnn_gen_state* gen = nullptr;    // set: this plan runs on the generic-width engine (hidden != 128, many nodes, ...), hp is unused

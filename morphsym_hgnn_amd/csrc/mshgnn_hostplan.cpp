@@ -81,6 +81,71 @@ std::string check_tables(const HostPlan& p) {
     }
     return "";
 }
+// generic-width engine: jobs -> terms -> sources, weight-gradient units -> items -> sources, aggregates; every range inside its table
+std::string check_gen_tables(const gen::GenPlan& p) {
+    using namespace gen;
+    char buf[256];
+    auto bad = [&](const char* what, int i, long long v, long long lim) { snprintf(buf, sizeof buf, "%s: entry %d value %lld limit %lld", what, i, v, lim); return std::string(buf); };
+    const int32_t* T = p.tables.data();
+    const int n_jobs = (p.term_off - p.job_off) / JOB_INTS, n_terms = (p.src_off - p.term_off) / TERM_INTS, n_srcs = (p.unit_off - p.src_off) / SRC_INTS;
+    const int n_units = (p.sunit_off - p.unit_off) / UNIT_INTS, n_sunits = (p.su_order_off - p.sunit_off) / SUNIT_INTS, n_items = (p.fin_off - p.item_off) / GITEM_INTS;
+    const int n_packs = (int)p.packs.size() * (p.split ? 2 : 1), n_bias = (int)p.biases.size();
+    if (!(p.job_off <= p.term_off && p.term_off <= p.src_off && p.src_off <= p.unit_off && p.unit_off <= p.sunit_off && p.sunit_off <= p.su_order_off &&
+          p.su_order_off <= p.item_off && p.item_off <= p.fin_off && p.fin_off <= p.agg_off && p.agg_off <= (int)p.tables.size())) return "table offsets out of order";
+    for (const auto* ls : {&p.fwd, &p.bwd}) for (const Launch& ln : *ls) {
+        if (ln.job0 < 0 || ln.n_jobs < 0 || ln.job0 + ln.n_jobs > n_jobs) return bad("launch job range", ln.job0, ln.job0 + ln.n_jobs, n_jobs);
+    }
+    for (int j = 0; j < n_jobs; ++j) {
+        const int32_t* jb = T + p.job_off + j * JOB_INTS;
+        if (jb[J_TERM0] < 0 || jb[J_NTERMS] < 0 || jb[J_TERM0] + jb[J_NTERMS] > n_terms) return bad("job term range", j, jb[J_TERM0] + jb[J_NTERMS], n_terms);
+        if (jb[J_OUT_BUF] < 0 || jb[J_OUT_BUF] >= GBUF_COUNT) return bad("job out buffer", j, jb[J_OUT_BUF], GBUF_COUNT);
+        if (jb[J_OUT_NODE] < 0 || jb[J_OUT_NODE] >= std::max(p.NN, p.n_aggbuf)) return bad("job out node", j, jb[J_OUT_NODE], std::max(p.NN, p.n_aggbuf));
+        if ((jb[J_FLAGS] & JF_BIAS) && (jb[J_BIAS] < 0 || jb[J_BIAS] >= std::max(n_bias, 1))) return bad("job bias row", j, jb[J_BIAS], n_bias);
+    }
+    for (int t = 0; t < n_terms; ++t) {
+        const int32_t* tm = T + p.term_off + t * TERM_INTS;
+        if (tm[T_SRC0] < 0 || tm[T_NSRC] < 1 || tm[T_SRC0] + tm[T_NSRC] > n_srcs) return bad("term source range", t, tm[T_SRC0] + tm[T_NSRC], n_srcs);
+        if (tm[T_NKC] < 1) return bad("term K chunks", t, tm[T_NKC], 1);
+        if (tm[T_PACK] < 0 || tm[T_PACK] + tm[T_NKC] * p.NCT > std::max(n_packs, 1)) return bad("term pack range", t, tm[T_PACK] + (long long)tm[T_NKC] * p.NCT, n_packs);
+    }
+    // a source row is read as an activation row (buffer id, node, optional relu-byte buffer) or, from a raw-input term / item (kind 1), as an input row
+    // (node type, node inside the type, offset of its sign bytes)
+    auto check_srcs = [&](int s0, int ns, int kind, const char* who, int idx) -> std::string {
+        for (int i = s0; i < s0 + ns; ++i) {
+            const int32_t* sr = T + p.src_off + i * SRC_INTS;
+            if (kind == 1) {
+                if (sr[S_BUF] < 0 || sr[S_BUF] >= p.NT) return bad("raw source type", idx, sr[S_BUF], p.NT);
+                if (sr[S_NODE] < 0 || sr[S_NODE] >= p.d.type_nodes[sr[S_BUF]]) return bad("raw source node", idx, sr[S_NODE], p.d.type_nodes[sr[S_BUF]]);
+                if (sr[S_MASK] < -1 || sr[S_MASK] >= (int)p.signs.size()) return bad("raw source sign offset", idx, sr[S_MASK], (long long)p.signs.size());
+            } else {
+                if (sr[S_BUF] < 0 || sr[S_BUF] >= GBUF_COUNT) return bad("source buffer", idx, sr[S_BUF], GBUF_COUNT);
+                if (sr[S_NODE] < 0 || sr[S_NODE] >= std::max(p.NN, p.n_aggbuf)) return bad("source node", idx, sr[S_NODE], std::max(p.NN, p.n_aggbuf));
+                if (sr[S_MASK] < -1 || sr[S_MASK] >= GBUF_COUNT) return bad("source mask buffer", idx, sr[S_MASK], GBUF_COUNT);
+            }
+        }
+        (void)who; return "";
+    };
+    for (int t = 0; t < n_terms; ++t) {
+        const int32_t* tm = T + p.term_off + t * TERM_INTS;
+        const std::string e = check_srcs(tm[T_SRC0], tm[T_NSRC], tm[T_KIND], "term", t);
+        if (!e.empty()) return e;
+    }
+    for (int u = 0; u < n_units; ++u) {
+        const int32_t* un = T + p.unit_off + u * UNIT_INTS;
+        if (un[U_ITEM0] < 0 || un[U_ITEM1] < un[U_ITEM0] || un[U_ITEM1] > n_items) return bad("unit item range", u, un[U_ITEM1], n_items);
+    }
+    for (int u = 0; u < n_sunits; ++u) {
+        const int32_t* su = T + p.sunit_off + u * SUNIT_INTS;
+        if (su[SU_ITEM0] < 0 || su[SU_ITEM1] < su[SU_ITEM0] || su[SU_ITEM1] > n_items) return bad("super-unit item range", u, su[SU_ITEM1], n_items);
+    }
+    for (int i = 0; i < n_items; ++i) {
+        const int32_t* it = T + p.item_off + i * GITEM_INTS;
+        if (it[I_PBUF] < 0 || it[I_PBUF] >= GBUF_COUNT) return bad("item P buffer", i, it[I_PBUF], GBUF_COUNT);
+        if (it[I_SRC0] < 0 || it[I_NSRC] < 1 || it[I_SRC0] + it[I_NSRC] > n_srcs) return bad("item source range", i, it[I_SRC0] + it[I_NSRC], n_srcs);
+        { const std::string e = check_srcs(it[I_SRC0], it[I_NSRC], it[I_KIND], "item", i); if (!e.empty()) return e; }
+    }
+    return "";
+}
 }  // namespace
 
 extern "C" {
@@ -111,6 +176,22 @@ int mshgnn_hostplan_compile(const mshgnn_desc* desc, int32_t* tables, int cap, i
     }
     if (tables) std::memcpy(tables, hp.tables.data(), sizeof(int32_t) * std::min<size_t>(cap > 0 ? cap : 0, hp.tables.size()));
     return (int)hp.tables.size();
+}
+
+// The generic-width plan of `desc` (any hidden multiple of 128, any node count).  meta (>= 16 ints): [0] ok, [1] L, [2] NN, [3] hidden, [4] n table ints, [5] packs, [6] jobs, [7] terms,
+// [8] sources, [9] units, [10] items.  Returns the number of table ints, -1 on a descriptor the engine refuses, -2 when a table entry is out of range (check != 0).
+int mshgnn_hostplan_compile_gen(const mshgnn_desc* desc, int32_t* meta, int check) {
+    gen::GenPlan gp;
+    if (!gen::compile_gen_plan(desc, gp)) { g_hp_err = gp.err; return -1; }
+    if (check) { const std::string e = check_gen_tables(gp); if (!e.empty()) { g_hp_err = "generic table check: " + e; return -2; } }
+    if (meta) {
+        using namespace gen;
+        std::memset(meta, 0, sizeof(int32_t) * 16);
+        meta[0] = 1; meta[1] = gp.L; meta[2] = gp.NN; meta[3] = gp.Hd; meta[4] = (int)gp.tables.size(); meta[5] = (int)gp.packs.size();
+        meta[6] = (gp.term_off - gp.job_off) / JOB_INTS; meta[7] = (gp.src_off - gp.term_off) / TERM_INTS; meta[8] = (gp.unit_off - gp.src_off) / SRC_INTS;
+        meta[9] = gp.n_units; meta[10] = (gp.fin_off - gp.item_off) / GITEM_INTS;
+    }
+    return (int)gp.tables.size();
 }
 
 }  // extern "C"

@@ -1,0 +1,49 @@
+"""The specialised one-call step kernels (k_slab_step over the compile-time programs of csrc/mshgnn_spec_tables.inc) against the interpreting kernel of the
+same plan: the same MACs in the same order on the same accumulators, so output, loss and every gradient must be IDENTICAL BITS -- for each BASELINE
+topology that has a program (A1-C2 at 3 and 8 layers, MiniCheetah-K4 classification, Solo-12 K4 COM), both stash store policies, whole-tile batches;
+a ragged batch must fall back to the interpreter.  (Oracle parity of the specialised kernels at the timed sizes: tests/test_full_size_gpu.py, which runs them
+by default.)"""
+import pytest
+import torch
+
+import bench
+from morphsym_hgnn_amd import engine as eng, synth
+
+pytestmark = pytest.mark.gpu
+CASES = [("a1c2", 3, "A1C2_L3"), ("a1c2", 8, "A1C2_L8"), ("mck4", 8, "MCK4_L8"), ("solo", 8, "SOLO_L8")]
+
+
+def _step(e, spec, x, y, flat, B):
+    xs = e.cast_inputs(x)
+    if spec.regression:
+        out, loss, g = e.step_mse(xs, flat, y.to(e.device, torch.float32).reshape(-1), B)
+    else:
+        out, loss, g = e.step_ce(xs, flat, y.to(e.device, torch.int32).reshape(B, -1).contiguous(), B)
+    torch.cuda.synchronize()
+    return out.clone(), loss.clone(), g.clone()
+
+
+@pytest.mark.parametrize("nt", ["0", "1"])
+@pytest.mark.parametrize("config,layers,name", CASES)
+def test_specialised_step_is_bit_identical_to_the_interpreter(monkeypatch, config, layers, name, nt):
+    spec = bench.build_spec(layers, config)
+    monkeypatch.setenv("MSHGNN_SLAB", "2")          # the slab kernels also below one tile per CU (the test batch is small)
+    monkeypatch.setenv("MSHGNN_STASH_NT", nt)       # both compile-time store policies
+    monkeypatch.setenv("MSHGNN_SPEC", "1")
+    e1 = eng.Engine(spec, "bf16")
+    monkeypatch.setenv("MSHGNN_SPEC", "0")
+    e0 = eng.Engine(spec, "bf16")
+    assert e1.specialised == name and e0.specialised == "", (e1.specialised, e0.specialised)
+    flat = eng.flatten_params(spec, synth.make_params(3, spec.param_shapes()), e1.device)
+    for B in (64, 48, 50):      # whole tiles (specialised kernel) ... and a ragged batch (both engines interpret)
+        x, y = bench.make_batch(spec, B, 11 + B)
+        r1 = _step(e1, spec, x, y, flat, B)
+        r0 = _step(e0, spec, x, y, flat, B)
+        for what, a, b in zip(("out", "loss", "grad"), r1, r0):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), f"{name} B={B} nt={nt}: {what} differs, max abs {float((a - b).abs().max())}"
+        assert float(r1[2].abs().max()) > 0 and torch.isfinite(r1[1]).all()
+
+
+def test_unlisted_topologies_keep_the_interpreter():
+    spec = bench.build_spec(5, "a1c2")      # a depth no program was generated for
+    assert eng.Engine(spec, "bf16").specialised == ""
