@@ -1133,8 +1133,8 @@ __device__ __forceinline__ void decoder_tail_impl(const StackArgs& a, char* smem
                     if (dd < a.dout && live) {
                         float sum = 0.f;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) sum += x[e] * Wv[dd][e];
-                        sum = row16_sum(sum);
+                        for (int e = 0; e < 8; ++e) sum = __builtin_fmaf(x[e], Wv[dd][e], sum);      // (explicit fused multiply-adds in this tail: every instantiation -- one-launch
+                        sum = row16_sum(sum);                                                     //  step or not, 4 / 8 waves, preloaded operands or not -- then rounds the same way)
                         ov[i][dd] = (sum + bv[dd]) * mk[i][dd];
                     }
                 }
@@ -1154,11 +1154,11 @@ __device__ __forceinline__ void decoder_tail_impl(const StackArgs& a, char* smem
                             else {
                                 const float dlt = ov[i][dd] - yv[i][dd];
                                 g = 2.0f * dlt * a.inv_n * mk[i][dd];
-                                if (c == 0) lsum += dlt * dlt;
+                                if (c == 0) lsum = __builtin_fmaf(dlt, dlt, lsum);
                             }
                             accb[dd] += g;
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) { accw[dd][e] += g * x[e]; dxv[i][e] += g * Wv[dd][e]; }
+                            for (int e = 0; e < 8; ++e) { accw[dd][e] = __builtin_fmaf(g, x[e], accw[dd][e]); dxv[i][e] = __builtin_fmaf(g, Wv[dd][e], dxv[i][e]); }
                         }
                     }
                 }

@@ -113,8 +113,9 @@ def load_library():
     lib.mshgnn_plan_destroy.argtypes = [C.c_void_p]
     lib.mshgnn_plan_destroy.restype = None
     lib.mshgnn_plan_info.argtypes = [C.c_void_p, C.POINTER(MshgnnInfo)]
-    lib.mshgnn_plan_specialised.argtypes = [C.c_void_p]
-    lib.mshgnn_plan_specialised.restype = C.c_char_p
+    if hasattr(lib, "mshgnn_plan_specialised"):      # (absent from older builds of the library handed over through MSHGNN_LIB for A/B runs)
+        lib.mshgnn_plan_specialised.argtypes = [C.c_void_p]
+        lib.mshgnn_plan_specialised.restype = C.c_char_p
     lib.mshgnn_plan_compile_host.argtypes = [C.POINTER(MshgnnDesc), C.POINTER(MshgnnInfo), C.POINTER(C.c_int32)]
     lib.mshgnn_workspace_layout.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.POINTER(MshgnnWsLayout)]
     lib.mshgnn_forward.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p, C.c_void_p,
@@ -335,7 +336,8 @@ class Engine:
             _check(self.lib, self.lib.mshgnn_plan_create(C.byref(self._holder.desc), C.byref(self._plan)), "mshgnn_plan_create")
         self.info = MshgnnInfo()
         _check(self.lib, self.lib.mshgnn_plan_info(self._plan, C.byref(self.info)), "mshgnn_plan_info")
-        self.specialised = self.lib.mshgnn_plan_specialised(self._plan).decode()      # "" or the compile-time program of the one-call steps ("A1C2_L3", ...)
+        # "" or the compile-time program of the one-call steps ("A1C2_L3", ...)
+        self.specialised = self.lib.mshgnn_plan_specialised(self._plan).decode() if hasattr(self.lib, "mshgnn_plan_specialised") else ""
         # generic-width engine (hidden != 128, many nodes, ...: kernel_sets bit 2) and how activations are stored: "x3" = rows of
         # [hi | lo] bf16 halves (the split plan, and MSHGNN_F32 requests served by the generic engine's split arithmetic)
         self.generic = bool(self.info.kernel_sets & 4)
