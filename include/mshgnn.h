@@ -50,8 +50,9 @@ extern "C" {
 #define MSHGNN_BF16 1
 #define MSHGNN_BF16X3 2   /* split-bf16 parity plan: fp32 inputs; every activation stored as two bf16 planes (hi + lo, 16 mantissa
                              bits); products on the bf16 MFMA as hi*hi + hi*lo + lo*hi, fp32 accumulate -- 1e-4 relative like
-                             MSHGNN_F32 at a multiple of its speed.  Topologies with <= 20 nodes and 2 (nodes + base_transform
-                             nodes) <= 40 (every A1 / Solo graph; MiniCheetah-K4 has 48: use MSHGNN_F32)                         */
+                             MSHGNN_F32 at a multiple of its speed.  LDS-resident for topologies with <= 20 nodes whose two planes fit a
+                             CU's LDS: 2 x nodes <= 40 blocks (every A1 / Solo graph; MiniCheetah-K4's 20 nodes exactly, its four
+                             base_transform scratch blocks aliasing node blocks) -- anything larger runs on the generic-width engine */
 
 #define MSHGNN_OK 0
 #define MSHGNN_EINVAL (-1)      /* bad descriptor / argument */

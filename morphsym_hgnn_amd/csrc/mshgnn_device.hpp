@@ -1057,21 +1057,24 @@ __device__ __forceinline__ void fs_run(const FP& wp, typename Prec<T>::Acc (&acc
 // the tail's global operands of one pass (decoder weights / bias, output mask, labels of this thread's rows): requested in one go -- by the tail itself, or
 // (compile-time programs) before the last layer's store phase, so that the tail starts with its operands in registers instead of behind that phase's drain
 template <int DMAX, int NPP> struct DecOps { float Wv[DMAX][8], bv[DMAX], mk[NPP][DMAX], yv[NPP][DMAX]; int labv[NPP]; };
-template <int THREADS, int DMAX, int NPP>
-__device__ __forceinline__ void decoder_ops_load(const StackArgs& a, int tid, int w0, int B, int f0, bool with_w, DecOps<DMAX, NPP>& o) {
-    const int c = tid & 15, row = (tid >> 4) & 15;
+template <int DMAX, int NPP>
+__device__ __forceinline__ void decoder_ops_load_w(const StackArgs& a, int tid, DecOps<DMAX, NPP>& o) {      // decoder weights / bias: once per tile
+    const int c = tid & 15;
     const float* W = a.params + a.off_dec_w;
-    const bool ce = a.labels != nullptr;
-    if (with_w) {
 #pragma unroll
-        for (int dd = 0; dd < DMAX; ++dd) {
-            const int dc = min(dd, a.dout - 1);
-            const f32x4 wa = *reinterpret_cast<const f32x4*>(W + dc * H + c * 8), wb = *reinterpret_cast<const f32x4*>(W + dc * H + c * 8 + 4);
-            o.Wv[dd][0] = wa[0]; o.Wv[dd][1] = wa[1]; o.Wv[dd][2] = wa[2]; o.Wv[dd][3] = wa[3];
-            o.Wv[dd][4] = wb[0]; o.Wv[dd][5] = wb[1]; o.Wv[dd][6] = wb[2]; o.Wv[dd][7] = wb[3];
-            o.bv[dd] = a.params[a.off_dec_b + dc];
-        }
+    for (int dd = 0; dd < DMAX; ++dd) {
+        const int dc = min(dd, a.dout - 1);
+        const f32x4 wa = *reinterpret_cast<const f32x4*>(W + dc * H + c * 8), wb = *reinterpret_cast<const f32x4*>(W + dc * H + c * 8 + 4);
+        o.Wv[dd][0] = wa[0]; o.Wv[dd][1] = wa[1]; o.Wv[dd][2] = wa[2]; o.Wv[dd][3] = wa[3];
+        o.Wv[dd][4] = wb[0]; o.Wv[dd][5] = wb[1]; o.Wv[dd][6] = wb[2]; o.Wv[dd][7] = wb[3];
+        o.bv[dd] = a.params[a.off_dec_b + dc];
     }
+}
+template <int THREADS, int DMAX, int NPP>
+__device__ __forceinline__ void decoder_ops_load(const StackArgs& a, int tid, int w0, int B, int f0, bool with_w, DecOps<DMAX, NPP>& o) {      // one pass's output mask and labels (+ the weights)
+    const int c = tid & 15, row = (tid >> 4) & 15;
+    const bool ce = a.labels != nullptr;
+    if (with_w) decoder_ops_load_w<DMAX, NPP>(a, tid, o);
 #pragma unroll
     for (int i = 0; i < NPP; ++i) {
         const int f = min(f0 + i * (THREADS / 256), a.n_out - 1);
@@ -1107,11 +1110,11 @@ __device__ __forceinline__ void decoder_tail_impl(const StackArgs& a, char* smem
         // costs a full vmcnt(0) drain (loads and stores retire out of order with respect to each other)
         // (unconditional loads with clamped indices, so that they are issued back to back and waited for once)
         DecOps<DMAX, NPP> ops;
-        if constexpr (PRE) ops = *pre;
+        if constexpr (PRE) ops = *pre; else decoder_ops_load_w<DMAX, NPP>(a, tid, ops);
         auto& Wv = ops.Wv; auto& bv = ops.bv; auto& mk = ops.mk; auto& yv = ops.yv; auto& labv = ops.labv;
         for (int f0 = tid >> 8; f0 < a.n_out; f0 += NPP * (THREADS / 256)) {
             float ov[NPP][DMAX], dxv[NPP][8];
-            if (!(PRE && f0 == (tid >> 8))) decoder_ops_load<THREADS, DMAX, NPP>(a, tid, w0, B, f0, !PRE && f0 == (tid >> 8), ops);
+            if (!(PRE && f0 == (tid >> 8))) decoder_ops_load<THREADS, DMAX, NPP>(a, tid, w0, B, f0, false, ops);
 #pragma unroll
             for (int i = 0; i < NPP; ++i) {
                 const int f = f0 + i * (THREADS / 256);

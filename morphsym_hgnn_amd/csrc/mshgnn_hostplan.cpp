@@ -153,7 +153,7 @@ extern "C" {
 const char* mshgnn_hostplan_last_error() { return g_hp_err.c_str(); }
 
 enum { HPM_OK = 0, HPM_L, HPM_NN, HPM_NMLP, HPM_FUSED, HPM_SLAB, HPM_SL_HB, HPM_SL_BLK, HPM_FS_BLK, HPM_NTABLES, HPM_NPACKS, HPM_NBIASES, HPM_SL_ALIAS, HPM_NITEMS, HPM_NLANES, HPM_NFIN,
-       HPM_SL_FWD = 16, HPM_SL_BWD = 32, HPM_FS_FWD = 48, HPM_FS_BWD = 64, HPM_LIVE = 80 /* [l] low / high 32 bits of the node bit mask: 2 ints per layer */, HPM_NEED = 112, HPM_COUNT = 144 };
+       HPM_SL_FWD = 16, HPM_SL_BWD = 32, HPM_FS_FWD = 48, HPM_FS_BWD = 64, HPM_LIVE = 80 /* [l] low / high 32 bits of the node bit mask: 2 ints per layer */, HPM_NEED = 112, HPM_X3_ALIAS = 144, HPM_SPLIT = 145, HPM_COUNT = 160 };
 
 // Compile the LDS-resident plan of `desc` on the host.  tables (may be null): receives min(cap, n) table ints; meta: HPM_COUNT ints (layout above).
 // Returns the number of table ints, or -1 (mshgnn_hostplan_last_error()).  check != 0: also bounds-check every index table (error text names the first violation).
@@ -165,6 +165,7 @@ int mshgnn_hostplan_compile(const mshgnn_desc* desc, int32_t* tables, int cap, i
         std::memset(meta, 0, sizeof(int32_t) * HPM_COUNT);
         meta[HPM_OK] = 1; meta[HPM_L] = hp.L; meta[HPM_NN] = hp.NN; meta[HPM_NMLP] = hp.n_mlp; meta[HPM_FUSED] = hp.fused; meta[HPM_SLAB] = hp.slab; meta[HPM_SL_HB] = hp.sl_hb;
         meta[HPM_SL_BLK] = hp.sl_blk; meta[HPM_FS_BLK] = hp.fs_blk; meta[HPM_NTABLES] = (int)hp.tables.size(); meta[HPM_NPACKS] = (int)hp.packs.size(); meta[HPM_NBIASES] = (int)hp.biases.size();
+        meta[HPM_X3_ALIAS] = hp.x3_alias; meta[HPM_SPLIT] = hp.split;
         meta[HPM_SL_ALIAS] = hp.sl_alias; meta[HPM_NITEMS] = hp.n_items; meta[HPM_NLANES] = hp.n_lanes; meta[HPM_NFIN] = hp.n_fin;
         for (int l = 0; l < hp.L; ++l) {
             meta[HPM_SL_FWD + l] = hp.sl_fwd_off[l]; meta[HPM_SL_BWD + l] = hp.sl_bwd_off[l]; meta[HPM_FS_FWD + l] = hp.fs_fwd_off[l]; meta[HPM_FS_BWD + l] = hp.fs_bwd_off[l];

@@ -321,34 +321,20 @@ template <int N> __device__ __forceinline__ void mlp_mac3(P16::Acc (&acc)[N], co
 // ------------------------------------------------------------------------------------------------------
 // ALIAS: the base_transform scratch blocks are the blocks of the last nodes (topologies whose doubled tile leaves no room: MiniCheetah-K4)
 // STEP: part of k_stack_step_x3 -- the decoder tail leaves dX_L (both planes) in the out-type nodes' LDS blocks for the backward sweep of the same launch
-template <bool ALIAS, bool STEP> __device__ __forceinline__ void stack_fwd_x3_body(const StackArgs& a, char* smem) {
+// one forward layer of the split plan's 8-wave workgroup.  FH / FP: the layer's header and this wave half's program, interpreted (FHdr / FProg) or compile-time
+// (SHdr / SProg: specialised kernels); WHS: the wave half as a template constant (compile-time programs: the per-node header reads fold) or -1; mid(): what has
+// to settle between the MACs and the stores
+template <bool ALIAS, bool STEP, int WHS, class FH, class FP, class Mid>
+__device__ __forceinline__ void x3_fwd_layer(const StackArgs& a, char* smem, const T16* wpack, int wn, int wh, int lane, int l, int L, const FH& fh, const FP& wp, Mid&& mid) {
     using T = T16; using P = P16;
-    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wv & 3, wh = wv >> 2;
-    const int w0 = blockIdx.x * P::ROWS, B = a.B, NN = a.NN, LO = a.lo_blk, SCR = a.scr0;
-    const T* wpack = reinterpret_cast<const T*>(a.wpack);
+    const int tid = threadIdx.x, w0 = blockIdx.x * P::ROWS, B = a.B, NN = a.NN, LO = a.lo_blk, SCR = a.scr0;
+    const int whv = WHS >= 0 ? WHS : wh;
     const bool train = a.training != 0;
-
-    FS_STAMP(0);
-    stage_tile_x3(smem, reinterpret_cast<const T*>(a.tile_in), NN, LO, w0, B, tid, [](int) { return true; });
-    __syncthreads();
-    FS_STAMP(1);
-
     P::Acc acc[FS_HS];
-    FHdr fhn(a.tables + a.prog_off[0], lane);
-    FProg wpn(a.tables + a.prog_off[0] + FH_SIZE + wh * FPROG_LEN, lane);
-    fhn.settle(); wpn.settle();
-    for (int l = 0; l < a.L; ++l) {
-        const FHdr fh = fhn;
-        const FProg wp = wpn;
-        if (l + 1 < a.L) {    // the next layer's header and wave program stream in under this layer's MACs
-            fhn = FHdr(a.tables + a.prog_off[l + 1], lane);
-            wpn = FProg(a.tables + a.prog_off[l + 1] + FH_SIZE + wh * FPROG_LEN, lane);
-        }
         const int nmlp = fh[FH_NMLP], flags = fh[FH_FLAGS];
 #pragma unroll
         for (int u = 0; u < FS_HS; ++u) {
-            const int n = 2 * u + wh;
+            const int n = 2 * u + whv;
             if (n < NN && fh[FH_KIND + n] != NK_DEAD) acc_init_bias<T>(acc[u], a.bias + (size_t)fh[FH_BIAS + n] * H, wn, lane);
             else acc_fill(acc[u], 0.f);
         }
@@ -369,7 +355,7 @@ template <bool ALIAS, bool STEP> __device__ __forceinline__ void stack_fwd_x3_bo
             if (nmlp > 0 && (flags & FF_RESIDUAL)) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const int v = SCR + wh + 2 * j;
+                    const int v = SCR + whv + 2 * j;
                     if (v < SCR + nmlp && fh[FH_KIND + v] != NK_DEAD) {
                         vrh[j] = *reinterpret_cast<const u32x4*>(smem + lds_chunk<T>(v, win, col / P::EPC));
                         vrl[j] = *reinterpret_cast<const u32x4*>(smem + lds_chunk<T>(LO + v, win, col / P::EPC));
@@ -385,7 +371,7 @@ template <bool ALIAS, bool STEP> __device__ __forceinline__ void stack_fwd_x3_bo
             load_bfrag<T>(bfl, wpack, a.n_img + fh[FH_W1], wn, lane);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int n = 2 * u + wh;
+                const int n = 2 * u + whv;
                 if (n < nmlp) {
                     split_oct(acc[u].c[0], acc[u].c[1], hph[u], hpl[u]);
                     *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(SCR + n, win, col / P::EPC)) = hph[u];
@@ -394,13 +380,13 @@ template <bool ALIAS, bool STEP> __device__ __forceinline__ void stack_fwd_x3_bo
                 }
             }
             __syncthreads();
-            mlp_mac3(acc, smem, SCR, LO, nmlp, wh, bfh, bfl, lane);      // accumulators 0..1 = nodes 0..3
+            mlp_mac3(acc, smem, SCR, LO, nmlp, whv, bfh, bfl, lane);      // accumulators 0..1 = nodes 0..3
             load_bfrag<T>(bfh, wpack, fh[FH_W2], wn, lane);
             load_bfrag<T>(bfl, wpack, a.n_img + fh[FH_W2], wn, lane);
             __syncthreads();   // all reads of H done before T1 overwrites the scratch blocks
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int n = 2 * u + wh;
+                const int n = 2 * u + whv;
                 if (n < nmlp) {
                     split_oct(relu4(acc[u].c[0]), relu4(acc[u].c[1]), tph[u], tpl[u]);
                     *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(SCR + n, win, col / P::EPC)) = tph[u];
@@ -409,18 +395,18 @@ template <bool ALIAS, bool STEP> __device__ __forceinline__ void stack_fwd_x3_bo
                 }
             }
             __syncthreads();
-            mlp_mac3(acc, smem, SCR, LO, nmlp, wh, bfh, bfl, lane);      // accumulators 0..1 = nodes 0..3
+            mlp_mac3(acc, smem, SCR, LO, nmlp, whv, bfh, bfl, lane);      // accumulators 0..1 = nodes 0..3
         }
         FS_STAMP(16 + l);
         // every load issued so far has landed before the first store of the epilogue goes out
         __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));
-        fhn.settle(); wpn.settle();      // (FProg::settle: no vmcnt(0) for them at the top of the next layer)
+        mid();      // (FProg::settle of the next header / program: no vmcnt(0) for them at the top of the next layer)
         if (nmlp > 0 && train && w_ok) {
             T* hb = reinterpret_cast<T*>(a.ws + a.hb_off[l]);
             T* t1 = reinterpret_cast<T*>(a.ws + a.t1_off[l]);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int n = 2 * u + wh;
+                const int n = 2 * u + whv;
                 if (n < nmlp) {
                     *reinterpret_cast<u32x4*>(hb + x3_idx(w, n, B) + col) = hph[u];
                     *reinterpret_cast<u32x4*>(hb + x3_idx(w, n, B) + H + col) = hpl[u];
@@ -436,7 +422,7 @@ template <bool ALIAS, bool STEP> __device__ __forceinline__ void stack_fwd_x3_bo
         u32x4 resh[FS_HS], resl[FS_HS]; int kindv[FS_HS];     // the residual octets of every node, all LDS reads in flight together
 #pragma unroll
         for (int u = 0; u < FS_HS; ++u) {
-            const int n = 2 * u + wh;
+            const int n = 2 * u + whv;
             kindv[u] = n < NN ? fh[FH_KIND + n] : NK_DEAD;
             resh[u] = u32x4{0, 0, 0, 0}; resl[u] = u32x4{0, 0, 0, 0};
             if (kindv[u] != NK_DEAD && (flags & FF_RESIDUAL)) {
@@ -450,7 +436,7 @@ template <bool ALIAS, bool STEP> __device__ __forceinline__ void stack_fwd_x3_bo
         }
 #pragma unroll
         for (int u = 0; u < FS_HS; ++u) {
-            const int n = 2 * u + wh;
+            const int n = 2 * u + whv;
             if (n < NN) {
                 const int kind = kindv[u];
                 if (kind != NK_DEAD) {
@@ -468,7 +454,7 @@ template <bool ALIAS, bool STEP> __device__ __forceinline__ void stack_fwd_x3_bo
                     split_oct(y0, y1, hi, lo);
                     *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(n, win, col / P::EPC)) = hi;
                     *reinterpret_cast<u32x4*>(smem + lds_chunk<T>(LO + n, win, col / P::EPC)) = lo;
-                    if (train && w_ok && !(STEP && l + 1 == a.L)) {      // (X_L of a one-launch step is read by nobody)
+                    if (train && w_ok && !(STEP && l + 1 == L)) {      // (X_L of a one-launch step is read by nobody)
                         T* q = xo + x3_idx(w, n, B) + col;
                         stash_store(q, hi, a.stash_nt != 0);
                         stash_store(q + H, lo, a.stash_nt != 0);
@@ -478,7 +464,43 @@ template <bool ALIAS, bool STEP> __device__ __forceinline__ void stack_fwd_x3_bo
         }
         __syncthreads();
         FS_STAMP(5 + 4 * l);
+}
+// the layers of a compile-time program SP for wave half WH, unrolled
+template <bool ALIAS, bool STEP, class SP, int WH, int l = 0>
+__device__ __forceinline__ void x3_fwd_layers_static(const StackArgs& a, char* smem, const T16* wpack, int wn, int lane) {
+    if constexpr (l < SP::L) {
+        x3_fwd_layer<ALIAS, STEP, WH>(a, smem, wpack, wn, WH, lane, l, SP::L, SHdr<SP, 0, l>{}, SProg<SP, 0, l, WH>{}, [] {});
+        x3_fwd_layers_static<ALIAS, STEP, SP, WH, l + 1>(a, smem, wpack, wn, lane);
     }
+}
+
+template <bool ALIAS, bool STEP, class SP = void> __device__ __forceinline__ void stack_fwd_x3_body(const StackArgs& a, char* smem) {
+    using T = T16; using P = P16;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wv & 3, wh = wv >> 2;
+    const int w0 = blockIdx.x * P::ROWS, B = a.B, NN = a.NN, LO = a.lo_blk;
+    const T* wpack = reinterpret_cast<const T*>(a.wpack);
+
+    FS_STAMP(0);
+    stage_tile_x3(smem, reinterpret_cast<const T*>(a.tile_in), NN, LO, w0, B, tid, [](int) { return true; });
+    __syncthreads();
+    FS_STAMP(1);
+
+    if constexpr (std::is_void<SP>::value) {
+        FHdr fhn(a.tables + a.prog_off[0], lane);
+        FProg wpn(a.tables + a.prog_off[0] + FH_SIZE + wh * FPROG_LEN, lane);
+        fhn.settle(); wpn.settle();
+        for (int l = 0; l < a.L; ++l) {
+            const FHdr fh = fhn;
+            const FProg wp = wpn;
+            if (l + 1 < a.L) {    // the next layer's header and wave program stream in under this layer's MACs
+                fhn = FHdr(a.tables + a.prog_off[l + 1], lane);
+                wpn = FProg(a.tables + a.prog_off[l + 1] + FH_SIZE + wh * FPROG_LEN, lane);
+            }
+            x3_fwd_layer<ALIAS, STEP, -1>(a, smem, wpack, wn, wh, lane, l, a.L, fh, wp, [&] { fhn.settle(); wpn.settle(); });
+        }
+    } else if (wh == 0) x3_fwd_layers_static<ALIAS, STEP, SP, 0>(a, smem, wpack, wn, lane);      // (uniform per wave: each half runs its own straight-line program; the
+    else x3_fwd_layers_static<ALIAS, STEP, SP, 1>(a, smem, wpack, wn, lane);                      //  barriers pair up by count)
     decoder_tail<T, LAYER_THREADS, true, STEP>(a, smem, tid, lane, wv, w0, B);
     FS_STAMP(30);
 }
@@ -491,32 +513,13 @@ template <bool ALIAS> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stac
 // k_stack_bwd_x3: the L backward layers of a tile -- k_stack_bwd of the bf16 plan on hi/lo planes
 // ------------------------------------------------------------------------------------------------------
 // STEP: part of k_stack_step_x3 -- the forward's decoder tail of the same launch left the dX_L tile in LDS; the layers' programs are a.prog_off_b
-template <bool STEP> __device__ __forceinline__ void stack_bwd_x3_body(const StackArgs& a, char* smem) {
+// one backward layer (see x3_fwd_layer); acc carries nothing between layers: the residual term is re-read from the tile
+template <int WHS, class FH, class FP, class Mid>
+__device__ __forceinline__ void x3_bwd_layer(const StackArgs& a, char* smem, const T16* wpack, int wn, int wh, int lane, int l, const FH& bh, const FP& wp, Mid&& mid) {
     using T = T16; using P = P16;
-    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wv & 3, wh = wv >> 2;
     const int w0 = blockIdx.x * P::ROWS, B = a.B, NN = a.NN, LO = a.lo_blk;
-    const T* wpack = reinterpret_cast<const T*>(a.wpack);
-    auto prog_of = [&](int l) { return STEP ? a.prog_off_b[l] : a.prog_off[l]; };
-
-    // dX_L tile: only the nodes that are live in the last layer carry a gradient
-    if constexpr (!STEP) {
-        const FHdr bh(a.tables + prog_of(a.L - 1), lane);
-        stage_tile_x3(smem, reinterpret_cast<const T*>(a.tile_in), NN, LO, w0, B, tid, [&](int n) { return bh[FH_KIND + n] != NK_DEAD; });
-    }
-    __syncthreads();
-
+    const int whv = WHS >= 0 ? WHS : wh;
     P::Acc acc[FS_HS];
-    FHdr bhn(a.tables + prog_of(a.L - 1), lane);
-    FProg wpn(a.tables + prog_of(a.L - 1) + FH_SIZE + wh * FPROG_LEN, lane);
-    bhn.settle(); wpn.settle();
-    for (int l = a.L - 1; l >= 0; --l) {
-        const FHdr bh = bhn;
-        const FProg wp = wpn;
-        if (l > 0) {          // the next layer's header and wave program stream in under this layer's MACs
-            bhn = FHdr(a.tables + prog_of(l - 1), lane);
-            wpn = FProg(a.tables + prog_of(l - 1) + FH_SIZE + wh * FPROG_LEN, lane);
-        }
         const int nmlp = bh[FH_NMLP], flags = bh[FH_FLAGS];
         const uint8_t* maskbytes = reinterpret_cast<const uint8_t*>(a.ws + a.mask_off[l]);
         // lane constants rebuilt per layer from an opaque copy of the lane id: the per-node 64-bit addresses derived from them were hoisted out of
@@ -531,7 +534,7 @@ template <bool STEP> __device__ __forceinline__ void stack_bwd_x3_body(const Sta
             unsigned mword[FS_HS]; u32x4 rawh[FS_HS], rawl[FS_HS]; int kindv[FS_HS];
 #pragma unroll
             for (int u = 0; u < FS_HS; ++u) {
-                const int n = 2 * u + wh;
+                const int n = 2 * u + whv;
                 kindv[u] = n < NN ? bh[FH_KIND + n] : NK_DEAD;
                 mword[u] = 0u; rawh[u] = u32x4{0, 0, 0, 0}; rawl[u] = u32x4{0, 0, 0, 0};
                 if (kindv[u] == NK_RELU && w_ok) mword[u] = maskbytes[relu_byte(n, B, w, wn * 32 + g8)];
@@ -542,7 +545,7 @@ template <bool STEP> __device__ __forceinline__ void stack_bwd_x3_body(const Sta
             }
 #pragma unroll
             for (int u = 0; u < FS_HS; ++u) {
-                const int n = 2 * u + wh;
+                const int n = 2 * u + whv;
                 acc_fill(acc[u], 0.f);
                 if (kindv[u] != NK_DEAD) {
                     if (bh[FH_RES + n]) join_oct(rawh[u], rawl[u], acc[u].c[0], acc[u].c[1]);
@@ -567,19 +570,19 @@ template <bool STEP> __device__ __forceinline__ void stack_bwd_x3_body(const Sta
             load_bfrag<T>(bfl, wpack, a.n_img + bh[FH_W2], wn, lane);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int n = 2 * u + wh;
+                const int n = 2 * u + whv;
                 traw[u] = u32x4{0, 0, 0, 0};
                 acc_fill(tm[u], 0.f);
                 if (n < nmlp && w_ok) traw[u] = *reinterpret_cast<const u32x4*>(t1 + x3_idx(w, n, B) + col);     // the hi half carries the sign of T1
             }
-            mlp_mac3(tm, smem, 0, LO, nmlp, wh, bfh, bfl, lane);
+            mlp_mac3(tm, smem, 0, LO, nmlp, whv, bfh, bfl, lane);
             load_bfrag<T>(bfh, wpack, bh[FH_W1], wn, lane);
             load_bfrag<T>(bfl, wpack, a.n_img + bh[FH_W1], wn, lane);
             __syncthreads();   // all reads of the dY blocks done
             u32x4 duh[2] = {}, dul[2] = {};
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int n = 2 * u + wh;
+                const int n = 2 * u + whv;
                 if (n < nmlp) {
                     f32x4 t0, t1v, r0, r1; unpack_oct(traw[u], t0, t1v);
 #pragma unroll
@@ -591,12 +594,12 @@ template <bool STEP> __device__ __forceinline__ void stack_bwd_x3_body(const Sta
                 }
             }
             __syncthreads();
-            mlp_mac3(tm, smem, 0, LO, nmlp, wh, bfh, bfl, lane);
+            mlp_mac3(tm, smem, 0, LO, nmlp, whv, bfh, bfl, lane);
             __syncthreads();   // all reads of the dU blocks done
             __builtin_amdgcn_s_waitcnt((7 << 4) | (15 << 8));
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int n = 2 * u + wh;
+                const int n = 2 * u + whv;
                 if (n < nmlp) {
                     u32x4 hh, hl;
                     split_oct(tm[u].c[0], tm[u].c[1], hh, hl);
@@ -619,19 +622,19 @@ template <bool STEP> __device__ __forceinline__ void stack_bwd_x3_body(const Sta
 
         T* dxo = reinterpret_cast<T*>(a.ws + a.dx_off[l]);
         const uint8_t* m0 = reinterpret_cast<const uint8_t*>(a.ws + a.mask0_off);
-        bhn.settle(); wpn.settle();      // next header / program landed before the stores go out (FProg::settle)
+        mid();      // next header / program landed before the stores go out (FProg::settle)
         // layer 0: the encoder's relu bytes of every node are requested before the first store of the epilogue (one round trip; a load waited for
         // while stores are in flight drains them all)
         unsigned xbv[FS_HS];
 #pragma unroll
         for (int u = 0; u < FS_HS; ++u) {
-            const int n = 2 * u + wh;
+            const int n = 2 * u + whv;
             xbv[u] = 0xffu;
             if ((flags & FF_ENC_MASK) && w_ok && n < NN && bh[FH_OUT + n]) xbv[u] = m0[relu_byte(n, B, w, wn * 32 + g8)];
         }
 #pragma unroll
         for (int u = 0; u < FS_HS; ++u) {
-            const int n = 2 * u + wh;
+            const int n = 2 * u + whv;
             if (n < NN && bh[FH_OUT + n]) {
                 f32x4 y0 = acc[u].c[0], y1 = acc[u].c[1];
                 if ((flags & FF_ENC_MASK) && w_ok) {   // layer 0: x relu'(X_0): the encoder's relu byte of this lane
@@ -653,18 +656,58 @@ template <bool STEP> __device__ __forceinline__ void stack_bwd_x3_body(const Sta
             }
         }
         __syncthreads();
+}
+template <class SP, int WH, int l>
+__device__ __forceinline__ void x3_bwd_layers_static(const StackArgs& a, char* smem, const T16* wpack, int wn, int lane) {
+    if constexpr (l >= 0) {
+        x3_bwd_layer<WH>(a, smem, wpack, wn, WH, lane, l, SHdr<SP, 1, l>{}, SProg<SP, 1, l, WH>{}, [] {});
+        x3_bwd_layers_static<SP, WH, l - 1>(a, smem, wpack, wn, lane);
     }
+}
+
+template <bool STEP, class SP = void> __device__ __forceinline__ void stack_bwd_x3_body(const StackArgs& a, char* smem) {
+    using T = T16; using P = P16;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wv & 3, wh = wv >> 2;
+    const int w0 = blockIdx.x * P::ROWS, B = a.B, NN = a.NN, LO = a.lo_blk;
+    const T* wpack = reinterpret_cast<const T*>(a.wpack);
+    auto prog_of = [&](int l) { return STEP ? a.prog_off_b[l] : a.prog_off[l]; };
+    static_assert(std::is_void<SP>::value || STEP, "compile-time programs exist for the one-launch step only");
+
+    // dX_L tile: only the nodes that are live in the last layer carry a gradient
+    if constexpr (!STEP) {
+        const FHdr bh(a.tables + prog_of(a.L - 1), lane);
+        stage_tile_x3(smem, reinterpret_cast<const T*>(a.tile_in), NN, LO, w0, B, tid, [&](int n) { return bh[FH_KIND + n] != NK_DEAD; });
+    }
+    __syncthreads();
+
+    if constexpr (std::is_void<SP>::value) {
+        FHdr bhn(a.tables + prog_of(a.L - 1), lane);
+        FProg wpn(a.tables + prog_of(a.L - 1) + FH_SIZE + wh * FPROG_LEN, lane);
+        bhn.settle(); wpn.settle();
+        for (int l = a.L - 1; l >= 0; --l) {
+            const FHdr bh = bhn;
+            const FProg wp = wpn;
+            if (l > 0) {          // the next layer's header and wave program stream in under this layer's MACs
+                bhn = FHdr(a.tables + prog_of(l - 1), lane);
+                wpn = FProg(a.tables + prog_of(l - 1) + FH_SIZE + wh * FPROG_LEN, lane);
+            }
+            x3_bwd_layer<-1>(a, smem, wpack, wn, wh, lane, l, bh, wp, [&] { bhn.settle(); wpn.settle(); });
+        }
+    } else if (wh == 0) x3_bwd_layers_static<SP, 0, SP::L - 1>(a, smem, wpack, wn, lane);
+    else x3_bwd_layers_static<SP, 1, SP::L - 1>(a, smem, wpack, wn, lane);
 }
 __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_bwd_x3(StackArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     stack_bwd_x3_body<false>(a, smem);
 }
 // mshgnn_step_mse on the split plan: both sweeps of a tile in one launch (k_slab_step of mshgnn.hip: dX_L stays in LDS, no second launch, no tile reload)
-template <bool ALIAS> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_step_x3(StackArgs a) {
+// SP: void = the plan's tables are interpreted; else the compile-time program of one (topology, depth) on the split plan (mshgnn_spec_tables.inc, X3_*)
+template <bool ALIAS, class SP = void> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_step_x3(StackArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    stack_fwd_x3_body<ALIAS, true>(a, smem);
+    stack_fwd_x3_body<ALIAS, true, SP>(a, smem);
     __syncthreads();
-    stack_bwd_x3_body<true>(a, smem);
+    stack_bwd_x3_body<true, SP>(a, smem);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1156,9 +1199,35 @@ int x3_launch_prep(const PrepArgs& a, hipStream_t st) {
 
 static int x3_lds_stack(const HostPlan& hp) { return 2 * hp.fs_blk * P16::BLK; }
 
+// Specialised one-call step kernels of the split plan: k_stack_step_x3 over the compile-time program of one (topology, depth) -- mshgnn_spec_tables.inc (X3_*),
+// generated from this library's own plan compiler.  A plan takes one only when its fused tables are exactly the ints the kernel was compiled from.
+#include "mshgnn_spec_tables.inc"
+using StackKernelX3 = void (*)(StackArgs);
+template <class SP> static bool spec_matches_x3(const HostPlan& hp) {
+    if (!hp.split || !hp.fused || hp.L != SP::L || hp.NN != SP::NN || (hp.x3_alias ? 1 : 0) != SP::ALIAS) return false;
+    for (int l = 0; l < SP::L; ++l) {
+        if (hp.fs_fwd_off[l] + SP::ROW > (int)hp.tables.size() || hp.fs_bwd_off[l] + SP::ROW > (int)hp.tables.size()) return false;
+        if (memcmp(hp.tables.data() + hp.fs_fwd_off[l], SP::fwd[l], sizeof(int32_t) * SP::ROW) != 0) return false;
+        if (memcmp(hp.tables.data() + hp.fs_bwd_off[l], SP::bwd[l], sizeof(int32_t) * SP::ROW) != 0) return false;
+    }
+    return true;
+}
+static StackKernelX3 x3_step_spec_kernel(const HostPlan& hp, const char** name = nullptr) {
+#define MSHGNN_SPEC_TRY(SP) if (spec_matches_x3<SP>(hp)) { if (name) *name = #SP; return k_stack_step_x3<SP::ALIAS != 0, SP>; }
+    MSHGNN_SPEC_X3_LIST(MSHGNN_SPEC_TRY)
+#undef MSHGNN_SPEC_TRY
+    return nullptr;
+}
+
 int x3_set_attrs(mshgnn_plan* p) {
     int rc;
     const int flds = x3_lds_stack(p->hp);
+    { const char* esp = getenv("MSHGNN_SPEC"); p->use_spec = !(esp && atoi(esp) == 0); }
+    if (p->use_spec) {
+        const char* nm = nullptr;
+        if (StackKernelX3 k = x3_step_spec_kernel(p->hp, &nm)) { if ((rc = set_lds_attr(k, flds))) return rc; p->spec_name = nm + 6; }
+        else p->use_spec = false;
+    }
     if ((rc = set_lds_attr(k_stack_fwd_x3<false>, flds)) || (rc = set_lds_attr(k_stack_fwd_x3<true>, flds)) || (rc = set_lds_attr(k_stack_bwd_x3, flds)) ||
         (rc = set_lds_attr(k_stack_step_x3<false>, flds)) || (rc = set_lds_attr(k_stack_step_x3<true>, flds)) ||
         (rc = set_lds_attr(k_enc_x3<true>, 8 * P16::BLK)) || (rc = set_lds_attr(k_enc_x3<false>, 8 * P16::BLK)) ||
@@ -1274,7 +1343,9 @@ int x3_forward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitc
         if (step) {
             a.mask0_off = lay.dd[0];
             for (int l = 0; l < hp.L; ++l) a.prog_off_b[l] = hp.fs_bwd_off[l];
-            if (hp.x3_alias) hipLaunchKernelGGL(k_stack_step_x3<true>, dim3(tiles), dim3(LAYER_THREADS), x3_lds_stack(hp), st, a);
+            StackKernelX3 ks = p->use_spec ? x3_step_spec_kernel(hp) : nullptr;      // (predicated stores: ragged batches run it too)
+            if (ks) hipLaunchKernelGGL(ks, dim3(tiles), dim3(LAYER_THREADS), x3_lds_stack(hp), st, a);
+            else if (hp.x3_alias) hipLaunchKernelGGL(k_stack_step_x3<true>, dim3(tiles), dim3(LAYER_THREADS), x3_lds_stack(hp), st, a);
             else hipLaunchKernelGGL(k_stack_step_x3<false>, dim3(tiles), dim3(LAYER_THREADS), x3_lds_stack(hp), st, a);
             *stack_step_done = true;
         } else

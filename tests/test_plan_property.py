@@ -18,7 +18,7 @@ from morphsym_hgnn_amd.topology import RobotTopology
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "morphsym_hgnn_amd", "csrc")
-HPM = dict(OK=0, L=1, NN=2, NMLP=3, FUSED=4, SLAB=5, SL_HB=6, SL_BLK=7, FS_BLK=8, NTABLES=9, LIVE=80, NEED=112, COUNT=144)
+HPM = dict(OK=0, L=1, NN=2, NMLP=3, FUSED=4, SLAB=5, SL_HB=6, SL_BLK=7, FS_BLK=8, NTABLES=9, LIVE=80, NEED=112, COUNT=160)
 PAIRS = (("base", "joint"), ("joint", "base"), ("joint", "joint"), ("foot", "joint"), ("joint", "foot"), ("base", "base"))
 
 
@@ -112,7 +112,7 @@ def test_host_compilers_under_address_sanitizer():
             "for cfg, L in (('a1c2', 3), ('a1c2', 8), ('mck4', 8), ('solo', 8), ('synth32', 6)):\n"
             "    spec = bench.build_spec(L, cfg, 512 if cfg == 'synth32' else 128)\n"
             "    h = t.eng._DescHolder(spec, t.eng.DTYPE_CODES['bf16']); import ctypes as C\n"
-            "    m = (C.c_int32 * 144)(); rc = lib.mshgnn_hostplan_compile(C.byref(h.desc), None, 0, m, 1)\n"
+            "    m = (C.c_int32 * 160)(); rc = lib.mshgnn_hostplan_compile(C.byref(h.desc), None, 0, m, 1)\n"
             "    assert rc != -2, lib.mshgnn_hostplan_last_error()\n"
             "    if rc < 0: assert lib.mshgnn_hostplan_compile_gen(C.byref(h.desc), (C.c_int32 * 16)(), 1) > 0, lib.mshgnn_hostplan_last_error()\n"
             "print('asan ok', taken)\n") % ROOT

@@ -44,6 +44,27 @@ def test_specialised_step_is_bit_identical_to_the_interpreter(monkeypatch, confi
         assert float(r1[2].abs().max()) > 0 and torch.isfinite(r1[1]).all()
 
 
+X3_CASES = [("a1c2", 3, "X3_A1C2_L3"), ("a1c2", 8, "X3_A1C2_L8"), ("mck4", 8, "X3_MCK4_L8"), ("solo", 8, "X3_SOLO_L8")]
+
+
+@pytest.mark.parametrize("config,layers,name", X3_CASES)
+def test_specialised_split_plan_step_is_bit_identical_to_the_interpreter(monkeypatch, config, layers, name):
+    """The parity plan's one-call step (k_stack_step_x3) over its compile-time program: predicated stores, so ragged batches run it too."""
+    spec = bench.build_spec(layers, config)
+    monkeypatch.setenv("MSHGNN_SPEC", "1")
+    e1 = eng.Engine(spec, "x3")
+    monkeypatch.setenv("MSHGNN_SPEC", "0")
+    e0 = eng.Engine(spec, "x3")
+    assert e1.specialised == name and e0.specialised == "", (e1.specialised, e0.specialised)
+    flat = eng.flatten_params(spec, synth.make_params(3, spec.param_shapes()), e1.device)
+    for B in (64, 50, 1040):
+        x, y = bench.make_batch(spec, B, 21 + B)
+        r1 = _step(e1, spec, x, y, flat, B)
+        r0 = _step(e0, spec, x, y, flat, B)
+        for what, a, b in zip(("out", "loss", "grad"), r1, r0):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), f"{name} B={B}: {what} differs, max abs {float((a - b).abs().max())}"
+
+
 def test_unlisted_topologies_keep_the_interpreter():
     spec = bench.build_spec(5, "a1c2")      # a depth no program was generated for
     assert eng.Engine(spec, "bf16").specialised == ""
