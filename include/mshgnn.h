@@ -237,6 +237,12 @@ int mshgnn_backward_ce(const mshgnn_plan* plan, const void* const* x, const int6
  * All four buffers: device fp32, n elements, 16-byte aligned; updated in place.                                     */
 int mshgnn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t step,
                      float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
+/* The same update with the step count kept on the DEVICE: *step_count = steps taken so far (int64, device memory); the launch uses t = *step_count + 1 for
+ * the bias corrections and stores t behind the update.  Nothing that changes from step to step is a launch argument, so a training step (forward, loss,
+ * backward, this) can be captured once in a HIP graph and replayed -- what torch.optim.Adam(capturable=True) does for the reference's optimizer
+ * (gnnLightning.py:258-265).  morphsym_hgnn_amd.optim.FlatAdam(graph_safe=True), wrappers.GraphedTrainingStep.                                          */
+int mshgnn_adam_step_counted(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t* step_count,
+                             float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
 
 /* Loss of the Lightning wrapper (gnnLightning.py:633-639): loss = mean((out - y)^2) over n elements and
  * grad_out = 2 (out - y) / n.  loss_out: device float[1].                                               */

@@ -3070,6 +3070,42 @@ extern "C" int mshgnn_adam_step(float* params, const float* grads, float* exp_av
     return MSHGNN_OK;
 }
 
+// The same update with the step count on the DEVICE (capturable in a HIP graph: nothing of the bias corrections is baked into the launch arguments).  The kernel
+// reads t = *step_count + 1 and derives 1 - beta^t itself; a one-thread launch behind it stores t.  FlatAdam(graph_safe=True), wrappers.GraphedTrainingStep.
+__global__ void k_adam_counted(float* p, const float* g, float* m, float* v, int64_t n, const int64_t* step_count, float lr, float b1, float b2, float eps, float gscale) {
+    const float t = (float)(*step_count + 1);
+    const float bc1 = 1.0f - powf(b1, t), bc2_sqrt = sqrtf(1.0f - powf(b2, t));
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * blockDim.x * 4) {
+        if (i + 4 <= n) {
+            f32x4 pp = *reinterpret_cast<f32x4*>(p + i), gg = *reinterpret_cast<const f32x4*>(g + i) * gscale;
+            f32x4 mm = *reinterpret_cast<f32x4*>(m + i), vv = *reinterpret_cast<f32x4*>(v + i);
+            mm = b1 * mm + (1.f - b1) * gg;
+            vv = b2 * vv + (1.f - b2) * gg * gg;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pp[e] -= lr / bc1 * mm[e] / (sqrtf(vv[e]) / bc2_sqrt + eps);
+            *reinterpret_cast<f32x4*>(p + i) = pp; *reinterpret_cast<f32x4*>(m + i) = mm; *reinterpret_cast<f32x4*>(v + i) = vv;
+        } else {
+            for (int64_t k = i; k < n; ++k) {
+                const float gg = g[k] * gscale;
+                m[k] = b1 * m[k] + (1.f - b1) * gg; v[k] = b2 * v[k] + (1.f - b2) * gg * gg;
+                p[k] -= lr / bc1 * m[k] / (sqrtf(v[k]) / bc2_sqrt + eps);
+            }
+        }
+    }
+}
+__global__ void k_step_count_inc(int64_t* step_count) { *step_count += 1; }
+
+extern "C" int mshgnn_adam_step_counted(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t* step_count,
+                                        float lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !step_count || n < 1) return set_err(MSHGNN_EINVAL, "bad argument to mshgnn_adam_step_counted");
+    if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return set_err(MSHGNN_EINVAL, "adam buffers must be 16-byte aligned");
+    const int blocks = (int)std::min<int64_t>((n / 4 + 255) / 256 + 1, 2048);
+    hipLaunchKernelGGL(k_adam_counted, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, n, step_count, lr, beta1, beta2, eps, grad_scale);
+    hipLaunchKernelGGL(k_step_count_inc, dim3(1), dim3(1), 0, (hipStream_t)stream, step_count);
+    HIPCHK(hipGetLastError());
+    return MSHGNN_OK;
+}
+
 extern "C" int mshgnn_mse_loss(const float* out, const float* y, int64_t n, float* loss_out, float* grad_out, void* stream) {
     if (!out || !y || !loss_out || n < 1) return set_err(MSHGNN_EINVAL, "bad argument to mshgnn_mse_loss");
     hipStream_t st = (hipStream_t)stream;

@@ -177,9 +177,15 @@ def exchange_flat_gradient_(buf: torch.Tensor, n_flat: int, local_windows: int, 
         live[2]["checked"] = True
         dead = torch.ones(n_flat, dtype=torch.bool, device=buf.device)
         dead[live[0][live[0] < n_flat]] = False
-        if bool(dead.any()) and float(buf[:n_flat][dead].abs().max()) != 0.0:
+        # (NaN counts as non-zero; the verdict is combined over the ranks -- a MAX all-reduce of one flag -- so that every rank takes the same route: ranks that
+        #  disagreed would issue all-reduces of different element counts, which is a hang, not a fallback)
+        bad_here = bool(dead.any()) and not bool((buf[:n_flat][dead] == 0).all())
+        flag = torch.tensor([1.0 if bad_here else 0.0], dtype=torch.float32, device=buf.device)
+        if world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+        if float(flag) != 0.0:
             import warnings
-            warnings.warn("flat_data_parallel(live_only=True): the engine's gradient is not zero outside spec.live_gradient_index() "
+            warnings.warn("flat_data_parallel(live_only=True): the engine's gradient is not zero outside spec.live_gradient_index() on some rank "
                           "(liveness mirror and plan disagree) -- exchanging the full buffer instead")
             live[2]["disabled"] = True
     if live is not None and len(live) > 2 and live[2].get("disabled"):

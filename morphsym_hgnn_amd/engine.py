@@ -77,7 +77,7 @@ class MshgnnKernelStat(C.Structure):
 EXPORTS = [
     "mshgnn_last_error", "mshgnn_version", "mshgnn_plan_create", "mshgnn_plan_destroy", "mshgnn_plan_info", "mshgnn_plan_specialised",
     "mshgnn_plan_compile_host", "mshgnn_workspace_layout", "mshgnn_forward", "mshgnn_backward", "mshgnn_mse_loss", "mshgnn_ce_loss", "mshgnn_metrics_regression_step", "mshgnn_metrics_classification_step", "mshgnn_metrics_com_step",
-    "mshgnn_profile_enable", "mshgnn_profile_read", "mshgnn_backward_mse", "mshgnn_adam_step",
+    "mshgnn_profile_enable", "mshgnn_profile_read", "mshgnn_backward_mse", "mshgnn_adam_step", "mshgnn_adam_step_counted",
     "mshgnn_metrics_regression", "mshgnn_metrics_classification", "mshgnn_grf_body_to_world", "mshgnn_assemble_windows",
     "mshgnn_backward_ce", "mshgnn_step_mse", "mshgnn_step_mse_phase",
     "mshgnn_step_mse_series", "mshgnn_step_ce_series", "mshgnn_step_ce", "mshgnn_op_gemm", "mshgnn_op_gemm_workspace", "mshgnn_op_aggregate", "mshgnn_op_colsum", "mshgnn_op_colsum_workspace",
@@ -134,6 +134,9 @@ def load_library():
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
     lib.mshgnn_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_float, C.c_float,
                                      C.c_float, C.c_float, C.c_float, C.c_void_p]
+    if hasattr(lib, "mshgnn_adam_step_counted"):
+        lib.mshgnn_adam_step_counted.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_float, C.c_float,
+                                                 C.c_float, C.c_float, C.c_float, C.c_void_p]
     lib.mshgnn_profile_enable.argtypes = [C.c_void_p, C.c_int]
     lib.mshgnn_profile_read.argtypes = [C.c_void_p, C.POINTER(MshgnnKernelStat), C.POINTER(C.c_int32)]
     lib.mshgnn_mse_loss.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -315,6 +318,7 @@ class WideInputs(list):
     def __init__(self, rows, src, src_bytes):
         super().__init__(rows)
         self.src, self.src_bytes, self.pending = list(src), int(src_bytes), True
+        self.gen = None      # generation of the engine's row buffers this object's rows were written as (set when the encoder materialises them)
 
 
 class Engine:
@@ -344,6 +348,8 @@ class Engine:
         self.storage = "x3" if (dtype == "x3" or (self.generic and dtype == "f32")) else dtype
         self._ws: Dict[Tuple[int, int], torch.Tensor] = {}
         self._tickets: Dict[int, int] = {}
+        self._chunked: Dict[int, bool] = {}      # batch size -> the last training call on it was a one-call step (which the library may run as sub-steps)
+        self._rows_gen: Dict[int, int] = {}      # batch size -> how many times the encoder has written the engine's input row buffers of that size
         self._lay: Dict[Tuple[int, int], MshgnnWsLayout] = {}
         self._rows: Dict[int, List[torch.Tensor]] = {}      # plan-dtype input rows the encoder materialises from wide source tensors (WideInputs)
         self._pending_wide: Optional[WideInputs] = None     # the last WideInputs handed out whose rows have not been materialised yet
@@ -438,7 +444,13 @@ class Engine:
                 return None
         if dt == self.torch_dtype and all((self.spec.widths[t] * 4) % 16 == 0 for t in self.types):
             return None      # fp32 rows the kernels' 16-byte loaders take as they are
-        self._pending_wide = WideInputs(self._row_buffers(rows), xs, 8 if dt == torch.float64 else 4)
+        bufs = self._row_buffers(rows)
+        w = self._pending_wide
+        if w is not None and w.pending and len(w) == len(bufs) and all(a.data_ptr() == b.data_ptr() for a, b in zip(w, bufs)):
+            # a second batch of the same size before the first was run (prefetch, train + validation): both would name the same row buffers, and a forward on the
+            # unpacked rows of the first could not be told from one on the second -- this one takes the cast pass (tensors of its own)
+            return None
+        self._pending_wide = WideInputs(bufs, xs, 8 if dt == torch.float64 else 4)
         return self._pending_wide
 
     def _rewrap(self, xs):
@@ -450,6 +462,21 @@ class Engine:
         if len(xs) == len(w) and all(a.data_ptr() == b.data_ptr() for a, b in zip(xs, w)):
             return w
         return xs
+
+    def _rows_written(self, xs: "WideInputs", B: int):
+        """The encoder is about to (re)write the engine's row buffers of batch size B from `xs.src`: whatever was materialised there before -- an earlier
+        WideInputs of this size, and the rows a pending autograd backward of this size would read for the encoder's weight gradients -- is gone.  The stash
+        ticket is bumped whatever `training` is (an evaluation forward on other data between a training forward and its backward must make that backward
+        raise, not read the wrong rows), and `xs` remembers the generation it was written as."""
+        self._tickets[B] = self._tickets.get(B, 0) + 1
+        self._rows_gen[B] = self._rows_gen.get(B, 0) + 1
+        xs.gen = self._rows_gen[B]
+
+    def _check_rows_fresh(self, xs, B: int):
+        """A materialised WideInputs is only as good as the row buffers it points into: refuse it once another batch of the same size has been written there."""
+        if isinstance(xs, WideInputs) and not xs.pending and xs.gen != self._rows_gen.get(B, 0):
+            raise RuntimeError(f"these inputs were converted into the engine's row buffers for batch size {B}, which a later batch of the same size has since "
+                               "overwritten -- call cast_inputs again (or keep your own cast: MSHGNN_WIDE_SRC=0)")
 
     def _row_buffers(self, B: int) -> List[torch.Tensor]:
         """Plan-dtype input rows at the engine's pitch for batch size B, owned by the engine (zeroed once: pad columns and the rows of nodes the plan
@@ -490,16 +517,18 @@ class Engine:
     def forward(self, xs: Sequence[torch.Tensor], params_flat: torch.Tensor, B: int, training: bool = True,
                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
         xs = self._rewrap(xs)
+        self._check_rows_fresh(xs, B)
         self._check_flat(params_flat, "params_flat")
         ptrs, pitch = self._xptrs(xs, B)
         if out is None:
             out = torch.empty(B * self.n_out, self.spec.out_channels, dtype=torch.float32, device=self.device)
         ws = self.workspace(B, training)
         if training:
-            self._tickets[B] = self._tickets.get(B, 0) + 1
+            self._tickets[B] = self._tickets.get(B, 0) + 1; self._chunked[B] = False
         stream = torch.cuda.current_stream(self.device).cuda_stream
         with torch.cuda.device(self.device):
             if isinstance(xs, WideInputs) and xs.pending:      # the caller's fp64 / fp32 tensors: the encoder converts them and writes the plan-dtype rows `xs` holds
+                self._rows_written(xs, B)
                 sb, sp, spitch = self._src_args(xs)
                 _check(self.lib, self.lib.mshgnn_forward_src(self._plan, sb, sp, spitch, ptrs, pitch, params_flat.data_ptr(), out.data_ptr(),
                                                              ws.data_ptr(), B, int(training), stream), "mshgnn_forward_src")
@@ -511,6 +540,7 @@ class Engine:
 
     def backward(self, xs: Sequence[torch.Tensor], params_flat: torch.Tensor, grad_out: torch.Tensor, B: int,
                  grad_flat: Optional[torch.Tensor] = None) -> torch.Tensor:
+        self._check_rows_fresh(xs, B)
         self._check_flat(params_flat, "params_flat")
         ptrs, pitch = self._xptrs(xs, B)
         if grad_out.dtype != torch.float32 or not grad_out.is_contiguous() or grad_out.numel() != B * self.n_out * self.spec.out_channels:
@@ -529,6 +559,7 @@ class Engine:
     def backward_mse(self, xs: Sequence[torch.Tensor], params_flat: torch.Tensor, out: torch.Tensor, y: torch.Tensor, B: int,
                      grad_flat: Optional[torch.Tensor] = None, loss: Optional[torch.Tensor] = None):
         """Fused wrapper-MSE + backward (gnnLightning.py:633-639 + autograd): returns (loss[1], grad_flat)."""
+        self._check_rows_fresh(xs, B)
         self._check_flat(params_flat, "params_flat")
         ptrs, pitch = self._xptrs(xs, B)
         n = B * self.n_out * self.spec.out_channels
@@ -550,6 +581,7 @@ class Engine:
         """One training step of the regression wrappers in one call (forward + MSE + backward, mshgnn_step_mse):
         returns (out, loss[1], grad_flat)."""
         xs = self._rewrap(xs)
+        self._check_rows_fresh(xs, B)
         self._check_flat(params_flat, "params_flat")
         ptrs, pitch = self._xptrs(xs, B)
         n = B * self.n_out * self.spec.out_channels
@@ -562,10 +594,11 @@ class Engine:
         if loss is None:
             loss = torch.empty(1, dtype=torch.float32, device=self.device)
         ws = self.workspace(B, True)
-        self._tickets[B] = self._tickets.get(B, 0) + 1      # the activation stash of this batch size is overwritten
+        self._tickets[B] = self._tickets.get(B, 0) + 1; self._chunked[B] = True      # the activation stash of this batch size is overwritten
         stream = torch.cuda.current_stream(self.device).cuda_stream
         with torch.cuda.device(self.device):
             if isinstance(xs, WideInputs) and xs.pending:
+                self._rows_written(xs, B)
                 sb, sp, spitch = self._src_args(xs)
                 _check(self.lib, self.lib.mshgnn_step_mse_src(self._plan, sb, sp, spitch, ptrs, pitch, params_flat.data_ptr(), y.data_ptr(), out.data_ptr(),
                                                               loss.data_ptr(), grad_flat.data_ptr(), ws.data_ptr(), B, stream), "mshgnn_step_mse_src")
@@ -580,6 +613,7 @@ class Engine:
         """One training step of the classification wrappers in one call (forward + cross entropy + backward, mshgnn_step_ce):
         returns (out, loss[1], grad_flat).  labels: int32 [B, n_out] in {0, 1}."""
         xs = self._rewrap(xs)
+        self._check_rows_fresh(xs, B)
         self._check_flat(params_flat, "params_flat")
         ptrs, pitch = self._xptrs(xs, B)
         if labels.dtype != torch.int32 or labels.numel() != B * self.n_out or not labels.is_contiguous():
@@ -591,10 +625,11 @@ class Engine:
         if loss is None:
             loss = torch.empty(1, dtype=torch.float32, device=self.device)
         ws = self.workspace(B, True)
-        self._tickets[B] = self._tickets.get(B, 0) + 1
+        self._tickets[B] = self._tickets.get(B, 0) + 1; self._chunked[B] = True
         stream = torch.cuda.current_stream(self.device).cuda_stream
         with torch.cuda.device(self.device):
             if isinstance(xs, WideInputs) and xs.pending:
+                self._rows_written(xs, B)
                 sb, sp, spitch = self._src_args(xs)
                 _check(self.lib, self.lib.mshgnn_step_ce_src(self._plan, sb, sp, spitch, ptrs, pitch, params_flat.data_ptr(), labels.data_ptr(), out.data_ptr(),
                                                              loss.data_ptr(), grad_flat.data_ptr(), ws.data_ptr(), B, stream), "mshgnn_step_ce_src")
@@ -645,7 +680,7 @@ class Engine:
         if not materialize:
             xs = None
         ws = self.workspace(B, True)
-        self._tickets[B] = self._tickets.get(B, 0) + 1
+        self._tickets[B] = self._tickets.get(B, 0) + 1; self._chunked[B] = True
         stream = torch.cuda.current_stream(self.device).cuda_stream
         # the runs' column pointers in the store's scratch depend only on the series' addresses and the element size: resolved by the first step of this
         # store on this stream at this storage, vouched for afterwards (mshgnn_window_desc.run_ptrs_ready: one launch less in front of every encoder)
@@ -684,6 +719,7 @@ class Engine:
                     grad_flat: Optional[torch.Tensor] = None, loss: Optional[torch.Tensor] = None):
         """Fused wrapper cross entropy + backward (gnnLightning.py:640-648 + autograd): labels int32 [B, n_out] in {0,1};
         returns (loss[1], grad_flat)."""
+        self._check_rows_fresh(xs, B)
         self._check_flat(params_flat, "params_flat")
         ptrs, pitch = self._xptrs(xs, B)
         if out.dtype != torch.float32 or out.numel() != B * self.n_out * 2 or labels.dtype != torch.int32 or labels.numel() != B * self.n_out:
@@ -756,11 +792,21 @@ class Engine:
         es = 4 if self.storage == "f32" else 2
         return ws[off:off + n * es].view(torch.float32 if self.storage == "f32" else torch.bfloat16).view(nn_, B, self.spec.hidden).permute(1, 0, 2)
 
+    def _stash_is_whole(self, B: int):
+        """One-call steps over >= 2 x MSHGNN_STEP_CHUNK windows (default 32 768) run as sub-steps on the FRONT of the workspace (include/mshgnn.h, StepChunk): what
+        the stash holds afterwards is the last sub-step's rows in a sub-batch layout, not the batch's -- the introspection below would read garbage."""
+        chunk = int(os.environ.get("MSHGNN_STEP_CHUNK", "32768"))
+        if not self.generic and chunk > 0 and B >= 2 * chunk and self._chunked.get(B):
+            raise RuntimeError(f"the last one-call step of {B} windows ran as sub-steps of >= {chunk}: the workspace holds only the last sub-step "
+                               "(MSHGNN_STEP_CHUNK=0 keeps whole-batch steps)")
+
     def hidden_state(self, B: int, layer: int) -> torch.Tensor:
         """X_layer as [B, NN, hidden]."""
+        self._stash_is_whole(B)
         return self._act_tensor(self.layout(B, True).x[layer], B)
 
     def grad_hidden(self, B: int, layer: int) -> torch.Tensor:
+        self._stash_is_whole(B)
         return self._act_tensor(self.layout(B, True).dx[layer], B)
 
 
@@ -855,11 +901,32 @@ class PaddedEngine:
     def mse_loss(self, out, y, want_grad=True):
         return self.inner.mse_loss(out, y, want_grad)
 
-    def adam_step(self, *args, **kw):
-        return self.inner.adam_step(*args, **kw)      # (elementwise on whatever flat buffers it is handed)
+    def adam_step(self, params_flat, grad_flat, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
+        """Adam is elementwise: it runs on the caller's TRUE-size flat buffers as they are (the inner engine's own check would demand the padded size)."""
+        n = self.spec.flat_size()
+        for t, name in ((params_flat, "params"), (grad_flat, "grads"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+            if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous() or t.numel() != n:
+                raise ValueError(f"{name} must be a contiguous fp32 device tensor of {n} elements")
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        with torch.cuda.device(self.device):
+            _check(self.inner.lib, self.inner.lib.mshgnn_adam_step(params_flat.data_ptr(), grad_flat.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
+                                                                   n, step, lr, betas[0], betas[1], eps, grad_scale, stream), "mshgnn_adam_step")
+
+    def padded_width(self, t):
+        return self.inner.padded_width(t)
+
+    def step_mse_phase(self, phase, xs, params_flat, y, B, out, grad_flat, loss):
+        """Two-phase step (multi-GPU overlap): phase 0 pads the parameters and runs the inner phase on the padded gradient buffer, phase 1 finishes it and unpads."""
+        r = self.inner.step_mse_phase(phase, xs, self._pad(params_flat) if phase == 0 else self._pflat, y, B, out, self._pgrad, loss)
+        if phase == 1:
+            self._unpad_grad(grad_flat)
+        return r
 
     def hidden_state(self, B, layer):
         return self.inner.hidden_state(B, layer)[..., :self.spec.hidden]
+
+    def grad_hidden(self, B, layer):
+        return self.inner.grad_hidden(B, layer)[..., :self.spec.hidden]
 
     def profile(self, on):
         return self.inner.profile(on)

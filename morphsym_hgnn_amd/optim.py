@@ -19,9 +19,13 @@ from . import engine as eng
 
 
 class FlatAdam(torch.optim.Adam):
-    def __init__(self, model, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, **kw):
+    def __init__(self, model, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, graph_safe: bool = False, **kw):
+        """graph_safe: the step count lives on the device (`mshgnn_adam_step_counted`), so `step()` can be captured in a HIP graph and replayed
+        (wrappers.GraphedTrainingStep) -- the flat route's counterpart of torch.optim.Adam(capturable=True)."""
         super().__init__(model.parameters(), lr=lr, betas=betas, eps=eps, **kw)
         self._model = model
+        self._graph_safe = bool(graph_safe)
+        self._t_dev = None                # graph_safe: device int64 step count (the truth; self._t is refreshed from it when the state is published)
         self._m = self._v = None          # flat exp_avg / exp_avg_sq (the per-parameter state entries are views of them)
         self._t = 0                       # steps taken on the flat route since the state was last synchronised with self.state
         self._owner = None                # the flat parameter buffer the flat state belongs to
@@ -62,6 +66,8 @@ class FlatAdam(torch.optim.Adam):
         if len(steps) > 1:
             raise RuntimeError("FlatAdam: the parameters' step counts differ; use torch.optim.Adam for this state")
         self._t = steps.pop() if steps else 0
+        if self._graph_safe:
+            self._t_dev = torch.tensor([self._t], dtype=torch.int64, device=flat.device)
         self._publish(params)
 
     def _publish(self, params):
@@ -70,6 +76,8 @@ class FlatAdam(torch.optim.Adam):
             self.state[p] = {"step": torch.tensor(float(self._t)), "exp_avg": self._m[o:o + n].view(p.shape), "exp_avg_sq": self._v[o:o + n].view(p.shape)}
 
     def _sync_steps(self):
+        if self._graph_safe and self._t_dev is not None and self._owner is not None:
+            self._t = int(self._t_dev.item())      # (a host sync: state_dict / route changes only, never inside a captured step)
         if self._owner is not None:
             for st in self.state.values():
                 if "step" in st:
@@ -99,8 +107,14 @@ class FlatAdam(torch.optim.Adam):
         flat, gflat, params, g = route
         if self._owner is not flat:
             self._adopt(flat, params)
-        self._t += 1
         lib = eng.load_library()
+        if self._graph_safe:
+            with torch.cuda.device(flat.device):
+                eng._check(lib, lib.mshgnn_adam_step_counted(flat.data_ptr(), gflat.data_ptr(), self._m.data_ptr(), self._v.data_ptr(), flat.numel(),
+                                                             self._t_dev.data_ptr(), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), 1.0,
+                                                             torch.cuda.current_stream(flat.device).cuda_stream), "mshgnn_adam_step_counted")
+            return loss
+        self._t += 1
         with torch.cuda.device(flat.device):
             eng._check(lib, lib.mshgnn_adam_step(flat.data_ptr(), gflat.data_ptr(), self._m.data_ptr(), self._v.data_ptr(), flat.numel(), self._t,
                                                  float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), 1.0,

@@ -159,7 +159,7 @@ class Base_Lightning(_Base):
             model = getattr(self, "model", None)
             if isinstance(model, models._MSHGNNBase) and len(list(self.parameters())) == len(list(model.parameters())):
                 from .optim import FlatAdam      # a torch.optim.Adam whose step is one launch on the flat buffers (torch's own step otherwise)
-                return FlatAdam(model, lr=self.lr)
+                return FlatAdam(model, lr=self.lr, graph_safe=bool(getattr(self, "graph_safe_optimizer", False)))      # (graph_safe: GraphedTrainingStep)
             return optim.Adam(self.parameters(), lr=self.lr)
         if self.optimizer == "sgd":
             return optim.SGD(self.parameters(), lr=self.lr)
@@ -505,3 +505,99 @@ class COM_HGNN_SYM_Lightning(COM_Base_Lightning):
             raise ValueError(f"unknown model_type '{model_type}'")
         self.regression = regression
         self._finish_init(dummy_batch)
+
+
+class GraphedTrainingStep:
+    """One training step of a wrapper -- `optimizer.zero_grad(); loss = wrapper.training_step(batch, i); loss.backward(); optimizer.step()` -- captured ONCE in a
+    HIP graph and replayed per batch.
+
+    Why: at the reference's own batch size (32, train_regression-grf_msgn.py:93) a step is a handful of short launches and the Python between them (autograd,
+    metric bookkeeping, the optimizer) costs more than the GPU work: 0.32 ms eager against 0.13 ms replayed on one MI355X.  From ~4 000 windows on the step is
+    GPU-bound and the replay buys nothing.
+
+    The graph reads its inputs from STATIC device tensors (copies of `example_batch`'s tensors, made here); `__call__(batch)` copies the new batch's tensors
+    into them (same shapes and dtypes) and replays.  Everything the step touches lives on the device: the loss / metric sums (metrics.py), the flat gradient
+    buffer, and the optimizer's step count -- which is why the optimizer must be `FlatAdam(graph_safe=True)` (set `wrapper.graph_safe_optimizer = True`
+    before `configure_optimizers()`) or a `torch.optim` optimizer created with `capturable=True`.  The model's parameters, the optimizer state and the metric
+    state are restored after the warm-up steps the capture needs, so constructing this object does not train.
+
+    Returns the step's loss as a device tensor (a static buffer: read it before the next call)."""
+
+    def __init__(self, wrapper, optimizer, example_batch, warmup: int = 3):
+        import copy
+        from .optim import FlatAdam
+        if isinstance(optimizer, FlatAdam) and not optimizer._graph_safe:
+            raise ValueError("GraphedTrainingStep needs FlatAdam(graph_safe=True): set wrapper.graph_safe_optimizer = True before configure_optimizers()")
+        if not isinstance(optimizer, FlatAdam) and not all(g.get("capturable", False) for g in optimizer.param_groups):
+            raise ValueError("GraphedTrainingStep needs an optimizer whose step count lives on the device (capturable=True)")
+        self.wrapper, self.optimizer = wrapper, optimizer
+        self.batch = self._static_copy(example_batch)
+        dev = next(wrapper.parameters()).device
+        snap_p = [p.detach().clone() for p in wrapper.parameters()]
+        flat_opt = isinstance(optimizer, FlatAdam)
+        if flat_opt:      # FlatAdam's state lives in flat device buffers the captured launches will address: snapshot / restore them IN PLACE
+            optimizer._sync_steps()
+            snap_o = None if optimizer._m is None or optimizer._owner is None else (optimizer._m.clone(), optimizer._v.clone(), int(optimizer._t))
+        else:
+            snap_o = copy.deepcopy(optimizer.state_dict())
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                self._eager_step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = self._eager_step()
+        with torch.no_grad():      # un-train: parameters and optimizer state as they were (the metric sums of the warm-up steps are cleared with the epoch's)
+            for p, q in zip(wrapper.parameters(), snap_p):
+                p.copy_(q)
+            if flat_opt:
+                if optimizer._m is None or optimizer._t_dev is None:
+                    raise RuntimeError("GraphedTrainingStep: the optimizer did not take the flat route during capture (parameters or gradients are not the flat views)")
+                if snap_o is None:
+                    optimizer._m.zero_(); optimizer._v.zero_(); optimizer._t = 0
+                else:
+                    optimizer._m.copy_(snap_o[0]); optimizer._v.copy_(snap_o[1]); optimizer._t = snap_o[2]
+                optimizer._t_dev.fill_(optimizer._t)
+                optimizer._sync_steps()
+            else:
+                optimizer.load_state_dict(snap_o)
+        if hasattr(wrapper, "reset_all_metrics"):
+            wrapper.reset_all_metrics()
+
+    @staticmethod
+    def _static_copy(batch):
+        import types
+        out = types.SimpleNamespace()
+        for k, v in vars(batch).items():
+            if torch.is_tensor(v):
+                setattr(out, k, v.detach().clone())
+            elif isinstance(v, dict) and k == "x_dict":
+                setattr(out, k, {kk: vv.detach().clone() for kk, vv in v.items()})
+            else:
+                setattr(out, k, v)      # edge_index_dict, batch_size, ...: the same for every batch of this size
+        return out
+
+    def _eager_step(self):
+        self.optimizer.zero_grad(set_to_none=True)
+        loss = self.wrapper.training_step(self.batch, 0)
+        loss.backward()
+        self.optimizer.step()
+        return loss.detach()
+
+    def load(self, batch):
+        """Copy a batch's tensors into the static ones (host or device sources; same shapes)."""
+        for k, v in vars(batch).items():
+            dst = getattr(self.batch, k, None)
+            if torch.is_tensor(v) and torch.is_tensor(dst):
+                dst.copy_(v, non_blocking=True)
+            elif isinstance(v, dict) and k == "x_dict":
+                for kk, vv in v.items():
+                    dst[kk].copy_(vv, non_blocking=True)
+
+    def __call__(self, batch=None):
+        if batch is not None:
+            self.load(batch)
+        self.graph.replay()
+        return self.loss

@@ -288,3 +288,91 @@ def test_wrapper_state_dict_is_the_lightning_checkpoint_layout():
         out = w.model(x_dict=batch.x_dict, edge_index_dict=batch.edge_index_dict)
     ref = torch.from_numpy(fx["out"])
     assert float((out.double().cpu().reshape(ref.shape) - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+
+
+@pytest.mark.gpu
+def test_graphed_training_step_replays_the_eager_step_bit_for_bit():
+    """wrappers.GraphedTrainingStep: zero_grad + training_step + backward + FlatAdam(graph_safe).step captured once in a HIP graph.  Three batches through the
+    replayed graph == the same three batches through the eager step on a twin (same kernels, same order: identical parameter bits, identical losses), and
+    building the graph does not train (parameters, optimizer state untouched by its warm-up)."""
+    from morphsym_hgnn_amd import wrappers
+    from morphsym_hgnn_amd.optim import FlatAdam
+    torch.set_default_dtype(torch.float64)
+    case, spec, fx, x_dict, y, params, ei = helpers.load_case("a1c2_h128_L3_d3_B3")
+    dev = torch.device("cuda")
+    B = case["B"]
+    batches = []
+    for s in range(4):
+        g = torch.Generator().manual_seed(100 + s)
+        xb = {k: torch.randn(v.shape, generator=g, dtype=torch.float64) * (0.0 if k == "foot" else 1.0) + (1.0 if k == "foot" else 0.0) for k, v in x_dict.items()}
+        batches.append(_batch(xb, ei, torch.randn(y.shape, generator=g, dtype=torch.float64), B, dev))
+    twins = []
+    for _ in range(2):
+        w = _wrapper(case, spec, batches[0]).to(dev)
+        w.model.load_state_dict(params)
+        w.lr = 1e-3
+        w.graph_safe_optimizer = True
+        twins.append((w, w.configure_optimizers()))
+    (a, oa), (b, ob) = twins
+    assert isinstance(oa, FlatAdam) and oa._graph_safe
+    before = [p.detach().clone() for p in a.parameters()]
+    gs = wrappers.GraphedTrainingStep(a, oa, batches[0])
+    for p, q in zip(a.parameters(), before):
+        assert torch.equal(p.detach().float(), q.float()), "building the graph must not train"      # (the first forward moves the parameters into the flat fp32 buffer)
+    assert int(oa._t_dev.item()) == 0
+    losses_a, losses_b = [], []
+    for bt in batches[1:]:
+        losses_a.append(float(gs(bt)))
+        ob.zero_grad(set_to_none=True)
+        l = b.training_step(bt, 0); l.backward(); ob.step()
+        losses_b.append(float(l))
+    torch.cuda.synchronize()
+    assert losses_a == losses_b, (losses_a, losses_b)
+    for p, q in zip(a.model.parameters(), b.model.parameters()):
+        assert torch.equal(p.detach(), q.detach())
+    assert int(oa._t_dev.item()) == 3 and oa.state_dict()["state"][0]["step"] == 3
+    # the device-counted Adam tracks torch.optim.Adam like the host-counted one (bias corrections from the device's powf)
+    c = _wrapper(case, spec, batches[0]).to(dev)
+    c.model.load_state_dict(params)
+    oc = torch.optim.Adam(c.parameters(), lr=1e-3)
+    for bt in batches[1:]:
+        oc.zero_grad(set_to_none=True)
+        l = c.training_step(bt, 0); l.backward(); oc.step()
+    worst = max(float((p.detach() - q.detach()).abs().max() / q.detach().abs().max().clamp_min(1e-12)) for p, q in zip(a.model.parameters(), c.model.parameters()))
+    assert worst < 5e-5, worst
+    with pytest.raises(ValueError, match="graph_safe"):
+        wrappers.GraphedTrainingStep(c, FlatAdam(c.model, lr=1e-3), batches[0])
+
+
+@pytest.mark.gpu
+def test_a_forward_on_other_data_between_forward_and_backward_is_refused():
+    """the encoder of the no-cast route writes the engine's own row buffers on EVERY forward of a batch size, training or not -- a no_grad forward
+    on other data of the same size between a training forward and its backward must make that backward raise (it would read the other batch's rows for the
+    encoder's weight gradients), and a materialised WideInputs is refused once its rows have been overwritten."""
+    from morphsym_hgnn_amd import engine as eng, models, synth
+    torch.set_default_dtype(torch.float64)
+    case, spec, fx, x_dict, y, params, ei = helpers.load_case("a1c2_h128_L3_d3_B3")
+    dev = torch.device("cuda", 0)
+    B = case["B"]
+    e = eng.Engine(spec, "bf16", device=dev)
+    flat = eng.flatten_params(spec, params, dev)
+    x1 = {k: v.to(dev, torch.float64) for k, v in x_dict.items()}
+    x2 = {k: (v * 0.5 + 0.25).to(dev, torch.float64) for k, v in x_dict.items()}
+    xs1 = e.cast_inputs(x1)
+    assert isinstance(xs1, eng.WideInputs)
+    t0 = e.stash_ticket(B)
+    e.forward(xs1, flat, B, training=True)
+    t1 = e.stash_ticket(B)
+    assert t1 > t0
+    xs2 = e.cast_inputs(x2)
+    e.forward(xs2, flat, B, training=False)      # evaluation forward on OTHER data, same batch size: rewrites the row buffers
+    assert e.stash_ticket(B) > t1, "an evaluation forward that rewrites the input rows must invalidate pending backwards"
+    with pytest.raises(RuntimeError, match="overwritten"):
+        e.backward(xs1, flat, torch.zeros(B * e.n_out, spec.out_channels, dtype=torch.float32, device=dev), B)
+    # two batches of one size cast before either runs: the second takes the cast pass (tensors of its own), so the first still means its own data
+    xa, xb = e.cast_inputs(x1), e.cast_inputs(x2)
+    assert isinstance(xa, eng.WideInputs) and not isinstance(xb, eng.WideInputs)
+    oa = e.forward(xa, flat, B, training=False).clone()
+    ob = e.forward(xb, flat, B, training=False).clone()
+    ra = e.forward(e.cast_inputs(x1), flat, B, training=False)
+    assert torch.equal(oa, ra) and not torch.equal(oa, ob)
