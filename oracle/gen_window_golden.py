@@ -95,17 +95,30 @@ def main():
         ds = stub_dataset(mod, seq, T, c["grf"], c["body"], c["norm"])
         for st in starts:
             if c["norm"]:
-                # the reference's standardisation line (quadSDKDataset_Morph.py:170) calls np.nan_to_num(tensor, copy=False),
-                # which numpy 2.x (this image) rejects, so that branch cannot be executed here: run the reference WITHOUT it
-                # and apply the same torch expression -- (x - mean) / std(correction=1), NaN -> 0 -- to its raw features
+                # The reference's standardisation line (quadSDKDataset_Morph.py:170) hands a torch tensor to np.nan_to_num(..., copy=False): numpy 1.x (what the
+                # reference ran on) turned it into an array through Tensor.__array__ without a copy and replaced the NaNs in place; numpy 2.x (this image) refuses
+                # `copy=False` on an object it has to convert.  The REFERENCE'S OWN branch is executed here under a one-function numpy-1.x shim -- np.nan_to_num
+                # converting a non-array first, exactly what 1.x did -- in this generator only (build container; nothing of it ships), and checked against the same
+                # expression written in torch (what rounds 1-5 pinned the option by).
+                _orig_nan_to_num = np.nan_to_num
+                def _nan_to_num_numpy1(x, copy=True, nan=0.0, posinf=None, neginf=None):
+                    return _orig_nan_to_num(x if isinstance(x, np.ndarray) else np.asarray(x), copy=copy, nan=nan, posinf=posinf, neginf=neginf)
+                np.nan_to_num = _nan_to_num_numpy1
+                try:
+                    ds.normalize = True
+                    data = ds.get(st)
+                finally:
+                    np.nan_to_num = _orig_nan_to_num
+                rb, rj, rf, ry = data["base"].x.numpy(), data["joint"].x.numpy(), data["foot"].x.numpy(), data.y.numpy()
                 ds.normalize = False
-                data = ds.get(st)
+                raw = ds.get(st)
                 def nz(x, nvar, axes):   # rows [node][var][axis][T] -> standardise every T-run
                     v = x.reshape(x.shape[0], nvar * axes, T)
                     v = torch.nan_to_num((v - v.mean(dim=2, keepdim=True)) / v.std(dim=2, correction=1, keepdim=True), nan=0.0)
                     return v.reshape(x.shape[0], -1).numpy()
-                rb, rj = nz(data["base"].x, 2, 3), nz(data["joint"].x, 3, 1)
-                rf, ry = data["foot"].x.numpy(), data.y.numpy()
+                for got, want, what in ((rb, nz(raw["base"].x, 2, 3), "base"), (rj, nz(raw["joint"].x, 3, 1), "joint")):
+                    assert got.shape == want.shape and np.abs(got - want).max() <= 1e-12 * np.abs(want).max(), ("normalize=True: reference branch vs torch expression", what)
+                assert np.array_equal(rf, raw["foot"].x.numpy()) and np.array_equal(ry, raw.y.numpy())
             else:
                 data = ds.get(st)
                 rb, rj, rf, ry = data["base"].x.numpy(), data["joint"].x.numpy(), data["foot"].x.numpy(), data.y.numpy()
@@ -150,6 +163,23 @@ def main():
         fx4[f"k4:{st}:y"] = data.y.numpy(); fx4[f"k4:{st}:base"] = data["base"].x.numpy()[:, ::7].copy()
         fx4[f"k4:{st}:joint"] = data["joint"].x.numpy()[:, ::11].copy(); fx4[f"k4:{st}:foot"] = data["foot"].x.numpy()[:, ::13].copy()
     print("k4 oracle == reference on", len(starts), "windows")
+    # normalize=True -- what BASELINE configs[2] trains with (train_classification_msgn.py passes it): the reference's own branch (LinTzuYaunDataset_Morph.py:337-345)
+    # under the numpy-1.x nan_to_num shim described above
+    _orig_nan_to_num = np.nan_to_num
+    np.nan_to_num = lambda x, copy=True, nan=0.0, posinf=None, neginf=None: _orig_nan_to_num(x if isinstance(x, np.ndarray) else np.asarray(x), copy=copy, nan=nan, posinf=posinf, neginf=neginf)
+    try:
+        s4.normalize = True
+        for st in starts:
+            data = s4.get(st)
+            ob, oj, of, oy = wo.minicheetah_k4_window(seq4, st, T, JOINT_PERM.astype(int), FOOT_PERM.astype(int), normalize=True)
+            for a, b, what in ((data["base"].x.numpy(), ob, "base"), (data["joint"].x.numpy(), oj, "joint"), (data["foot"].x.numpy(), of, "foot"), (data.y.numpy(), oy, "y")):
+                assert a.shape == b.shape and np.abs(a - b).max() <= 1e-12 * max(np.abs(a).max(), 1.0), ("k4_norm", st, what, np.abs(a - b).max())
+            fx4[f"k4_norm:{st}:y"] = data.y.numpy(); fx4[f"k4_norm:{st}:base"] = data["base"].x.numpy()[:, ::7].copy()
+            fx4[f"k4_norm:{st}:joint"] = data["joint"].x.numpy()[:, ::11].copy(); fx4[f"k4_norm:{st}:foot"] = data["foot"].x.numpy()[:, ::13].copy()
+    finally:
+        np.nan_to_num = _orig_nan_to_num
+        s4.normalize = False
+    print("k4 normalize=True: oracle == reference branch on", len(starts), "windows")
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "windows_mck4.npz"), **fx4)
 
     # Solo-12 centroidal-momentum task (soloDataset.py), K4 / C2 / S4 graphs, history 1 (the COM models' setting) and 5

@@ -67,6 +67,9 @@ def oracle_config(spec):
                             num_timesteps=spec.num_timesteps)
 
 
+SAMPLE_SLACK = 2.0      # sampled gradient entries: error <= SAMPLE_SLACK x rtol in units of the reference gradient's rms (and <= rtol in units of the largest sampled entry)
+
+
 def check_against_fixture(fx, out, loss, grads, rtol, what=""):
     """Compare (out, loss, grads) with a golden fixture.  Tolerance is relative to each tensor's max-abs
     (outputs) / L2 norm (gradients)."""
@@ -91,7 +94,10 @@ def check_against_fixture(fx, out, loss, grads, rtol, what=""):
             continue
         e1 = float(np.abs(g[idx] - fx["gsample:" + name]).max()) / denom
         e2 = abs(float(np.sqrt((g ** 2).sum())) - gn) / gn
-        e = max(e1 / 30.0, e2)  # samples: allow 30x the rms-relative tolerance (outliers of tiny entries)
+        # samples: a single entry's error in units of the tensor's rms is allowed SAMPLE_SLACK x the tolerance (an L2-relative bound of rtol would allow
+        # sqrt(N) x; rounds 1-5 allowed 30 x without knowing what the plans use: measured over every golden case, tools/sample_tolerance_probe.py, the worst
+        # sampled entry sits at 0.76 x rtol on the fp32 plan and 0.92 x on the split plan, 0.34 x in units of the largest sampled reference entry)
+        e = max(e1 / SAMPLE_SLACK, e2)
         if e > worst[0]:
             worst = (e, name)
         assert e2 <= rtol, f"{what} grad-norm {name} rel err {e2:.3e} > {rtol}"
@@ -102,7 +108,9 @@ def check_against_fixture(fx, out, loss, grads, rtol, what=""):
         if "gproj:" + name in fx.files:
             e4 = float(np.abs(projection_signs(name, g.size) @ g - fx["gproj:" + name]).max()) / gn
             assert e4 <= 4 * rtol, f"{what} grad-projection {name} err {e4:.3e} > {4 * rtol}"
-        assert e1 <= 30 * rtol, f"{what} grad samples {name} err/rms {e1:.3e} > {30 * rtol}"
+        assert e1 <= SAMPLE_SLACK * rtol, f"{what} grad samples {name} err/rms {e1:.3e} > {SAMPLE_SLACK * rtol}"
+        e5 = float(np.abs(g[idx] - fx["gsample:" + name]).max()) / max(float(np.abs(fx["gsample:" + name]).max()), 1e-30)
+        assert e5 <= rtol, f"{what} grad samples {name} err / largest sampled reference entry {e5:.3e} > {rtol}"
     return err, worst
 
 
@@ -283,7 +291,7 @@ def run_step_case(spec, x_dict, y, params, B, dtype="x3", device="cuda:0", decis
         out, loss, gflat = e.step_ce(xs, flat, y.reshape(B, n_out).to(e.device, torch.int32).contiguous(), B)
     torch.cuda.synchronize()
     decisions = engine_relu_decisions(e, spec, B)
-    stats = {"differ": 0, "outside": 0}
+    stats = {"differ": 0, "outside": 0, "total": 0}
 
     def relu_fn(key, h):
         if key not in decisions:
@@ -292,6 +300,7 @@ def run_step_case(spec, x_dict, y, params, B, dtype="x3", device="cuda:0", decis
         exact = h.detach() > 0
         m = torch.where(rows, decisions[key], exact)
         diff = m != exact
+        stats["total"] += int(rows.sum()) * h.shape[-1]      # decisions the engine really took (nodes its plan computes)
         if bool(diff.any()):
             stats["differ"] += int(diff.sum())
             stats["outside"] += int((h.detach().abs()[diff] > decision_tol * float(h.detach().abs().max())).sum())
@@ -327,4 +336,5 @@ def run_step_case(spec, x_dict, y, params, B, dtype="x3", device="cuda:0", decis
         ref_max = float(g.abs().max())
         errs["grad:" + k] = float(grads[k].abs().max()) if ref_max == 0.0 else rel(grads[k], g)
     run_step_case.last_decisions_differing = stats["differ"]
+    run_step_case.last_decisions_total = stats["total"]
     return errs, out.detach().cpu(), loss.detach().cpu(), grads

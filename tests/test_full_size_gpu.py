@@ -13,6 +13,7 @@ from tests import helpers
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-4          # BASELINE.json north_star: 1e-4 relative fp32
+FLIP_BOUND = 1e-5    # share of the parity plan's relu decisions that may differ from the exact ones at the timed batch (each within 1e-4 of zero)
 # bf16 plan vs its rounding-point emulation: gradients 1.5e-2 L2 (tests/test_bf16_emulation.py); outputs 4e-3 L2, and max-abs 1.5e-2 -- the small-batch
 # tests bound the max-abs by 4e-3 over <= 444 output values; over the 65 536 logits of a full MiniCheetah batch at 8 layers the largest single deviation
 # measured is 7.5e-3 (rare 1-ulp bf16 re-roundings compound through the depth), so the full-size bound on single values is the gradients' 1.5e-2
@@ -38,6 +39,11 @@ def test_parity_plan_step_matches_the_oracle_at_the_timed_batch(name):
     bad = {k: v for k, v in errs.items() if v > RTOL}
     assert not bad, f"{name} B={c['B']}: stages above {RTOL}: {bad}"
     assert len([k for k in errs if k.startswith("grad:")]) == len(params)
+    # the oracle above is evaluated with the engine's relu decisions: how many of them are NOT the exact ones is part of the result (every one of them sits
+    # within 1e-4 of its tensor's scale of zero: "relu_decisions_outside_tolerance" == 0 above) -- reported, and bounded
+    differ, total = helpers.run_step_case.last_decisions_differing, helpers.run_step_case.last_decisions_total
+    print(f"\n{name}: {differ} of {total} relu decisions differ from the exact ones ({differ / max(total, 1):.2e})")
+    assert total > 0 and differ / total <= FLIP_BOUND, f"{name}: {differ} of {total} relu decisions flipped ({differ / total:.2e} > {FLIP_BOUND})"
 
 
 @pytest.mark.parametrize("name", ["a1c2_L3", "mck4_cls_L8", "a1c2_L8"])

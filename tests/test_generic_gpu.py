@@ -113,14 +113,14 @@ def test_generic_bf16_arithmetic_is_within_bf16_distance_of_the_oracle(name):
     assert torch.equal(out_inf.cpu(), out)
 
 
-def test_configs4_bench_arithmetic_is_within_bf16_distance_of_the_oracle():
+@pytest.mark.parametrize("B", [300, 1024])      # 1024: the batch bench.py times configs[4] at
+def test_configs4_bench_arithmetic_is_within_bf16_distance_of_the_oracle(B):
     """BASELINE configs[4] at a batch that takes the kernels the bench line is quoted on (>= 256 windows: k_gstep4 on 128-window tiles, the lean
     weight-gradient streams, one ragged tile): the generic engine's bf16 arithmetic at h = 512, L = 6, 129 nodes per window against the fp64 oracle
     evaluated with the engine's relu decisions -- every hidden state, the output, the loss and every parameter gradient within 3e-2 (max-abs
     relative), every differing decision within 3e-2 of zero."""
     from morphsym_hgnn_amd import synth
     case, spec, *_ = helpers.load_case("synth32_mi_h512_L6_B2")
-    B = 300
     n_y = spec.out_channels * spec.num_nodes[spec.out_type]
     x_dict, y = synth.make_windows(41, B, spec.num_nodes, spec.widths, n_y)
     params = synth.make_params(41, spec.param_shapes())

@@ -97,6 +97,17 @@ def test_k4_oracle_matches_reference_fixture():
         assert b.shape == (4, 6 * T) and j.shape == (12, 2 * T) and f.shape == (4, 6 * T)
 
 
+def test_k4_standardised_windows_match_the_reference_branch():
+    """normalize=True (what BASELINE configs[2] trains with): the oracle against the vectors the REFERENCE'S OWN standardisation branch produced
+    (LinTzuYaunDataset_Morph.py:337-345, run by oracle/gen_window_golden.py under a numpy-1.x np.nan_to_num shim; the A1 counterpart is the d3_norm case above)."""
+    for st in FX4["starts"]:
+        b, j, f, y = wo.minicheetah_k4_window(SEQ4, int(st), T, JP, FP, normalize=True)
+        k = f"k4_norm:{int(st)}"
+        for got, key in ((y, ":y"), (b[:, ::7], ":base"), (j[:, ::11], ":joint"), (f[:, ::13], ":foot")):
+            ref = FX4[k + key]
+            assert got.shape == ref.shape and np.abs(got - ref).max() <= 1e-12 * max(np.abs(ref).max(), 1.0), (k, key)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("normalize", [False, True])
 def test_k4_device_assembly_matches_oracle(normalize):
