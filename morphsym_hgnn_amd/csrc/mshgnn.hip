@@ -2482,6 +2482,7 @@ extern "C" int mshgnn_plan_create(const mshgnn_desc* desc, mshgnn_plan** out) {
                 else p->use_spec = false;
             }
             { const char* et = getenv("MSHGNN_STEP_KERNEL"); p->use_step = !(et && atoi(et) == 0); }      // one-call steps: forward + backward sweep in one launch
+
             { const char* eg = getenv("MSHGNN_STAGGER"); p->stagger = eg ? atoi(eg) : 0; }
         }
     }
@@ -2815,15 +2816,20 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
         a.dbg = p->dbg_gw;
         a.stamps = stamp_ptr("MSHGNN_STAMPS_GW");
         ProfScope ps(p, hp.ks_gradw, st);
-        if (a.n_pad > 0) {
+        auto launch_gradw = [&](const GradwArgs& ga, hipStream_t s_) {
             static const bool gw_general = getenv("MSHGNN_GRADW") && std::string(getenv("MSHGNN_GRADW")) == "general";   // read once: the general kernel also where the lean one applies (A/B runs)
-            if constexpr (sizeof(T) == 4) hipLaunchKernelGGL(k_gradw_f32, dim3(a.n_pad * gw_parts), dim3(256), 0, st, a);
-            else if (gw_general && hp.gw_ipl == 1) hipLaunchKernelGGL(k_gradw_bf16<1>, dim3(a.n_pad * gw_parts), dim3(256), 0, st, a);
-            else if (gw_general && hp.gw_ipl == 2) hipLaunchKernelGGL(k_gradw_bf16<2>, dim3(a.n_pad * gw_parts), dim3(256), 0, st, a);
-            else if (series) hipLaunchKernelGGL((k_gradw_bf16_lean<true, true>), dim3(a.n_pad * gw_parts), dim3(256), 0, st, a);      // raw operands from the series
-            else if (a.aligned) hipLaunchKernelGGL(k_gradw_bf16_lean<true>, dim3(a.n_pad * gw_parts), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL(k_gradw_bf16_lean<false>, dim3(a.n_pad * gw_parts), dim3(256), 0, st, a);
-        }
+            if (ga.n_pad <= 0) return;
+            if constexpr (sizeof(T) == 4) hipLaunchKernelGGL(k_gradw_f32, dim3(ga.n_pad * gw_parts), dim3(256), 0, s_, ga);
+            else if (gw_general && hp.gw_ipl == 1) hipLaunchKernelGGL(k_gradw_bf16<1>, dim3(ga.n_pad * gw_parts), dim3(256), 0, s_, ga);
+            else if (gw_general && hp.gw_ipl == 2) hipLaunchKernelGGL(k_gradw_bf16<2>, dim3(ga.n_pad * gw_parts), dim3(256), 0, s_, ga);
+            else if (series) hipLaunchKernelGGL((k_gradw_bf16_lean<true, true>), dim3(ga.n_pad * gw_parts), dim3(256), 0, s_, ga);      // raw operands from the series
+            else if (ga.aligned) hipLaunchKernelGGL(k_gradw_bf16_lean<true>, dim3(ga.n_pad * gw_parts), dim3(256), 0, s_, ga);
+            else hipLaunchKernelGGL(k_gradw_bf16_lean<false>, dim3(ga.n_pad * gw_parts), dim3(256), 0, s_, ga);
+        };
+        // (round 6, measured and not kept: phase 1's lanes on a side stream BESIDE phase 0's -- forked behind the stack launch, joined by phase 1's finalize.  On a
+        //  1-rank RCCL group the two-phase step took 0.306 ms that way against 0.268 back to back and 0.186 for the plain step: two concurrent sweeps of the batch
+        //  evict each other's shared rows.)
+        launch_gradw(a, st);
     }
     return run_finalize(p, lay, ws, gparams, B, (y || labels) ? loss : nullptr, labels != nullptr, dec_done, gw_phase, st, gw_parts);
 }
@@ -3013,13 +3019,14 @@ extern "C" int mshgnn_step_mse_phase(const mshgnn_plan* p, const void* const* x,
         return x3_backward(p, x, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, st, out, y, loss_out, nullptr, true, phase);
     }
     const bool f32 = p->hp.d.dtype == MSHGNN_F32, fused = !f32 && p->use_fused;
+    bool stack_done = false;      // phase 0 on the fused plans: both sweeps of the stack in the one-launch step kernel, as mshgnn_step_mse (the specialised one where the plan has it)
     if (phase == 0) {
         int rc = f32 ? forward_impl<float>(p, x, x_pitch, params, out, (char*)workspace, batch, 1, st)
-                     : forward_impl<__bf16>(p, x, x_pitch, params, out, (char*)workspace, batch, 1, st, fused ? y : nullptr);
+                     : forward_impl<__bf16>(p, x, x_pitch, params, out, (char*)workspace, batch, 1, st, fused ? y : nullptr, nullptr, nullptr, fused ? &stack_done : nullptr);
         if (rc) return rc;
     }
     return f32 ? backward_impl<float>(p, x, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, st, out, y, loss_out, nullptr, false, phase)
-               : backward_impl<__bf16>(p, x, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, st, out, y, loss_out, nullptr, fused, phase);
+               : backward_impl<__bf16>(p, x, x_pitch, params, nullptr, grad_params, (char*)workspace, batch, st, out, y, loss_out, nullptr, fused, phase, nullptr, stack_done);
 }
 
 extern "C" int mshgnn_backward_ce(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, const float* out,

@@ -1112,6 +1112,7 @@ __device__ __forceinline__ void decoder_tail_impl(const StackArgs& a, char* smem
         DecOps<DMAX, NPP> ops;
         if constexpr (PRE) ops = *pre; else decoder_ops_load_w<DMAX, NPP>(a, tid, ops);
         auto& Wv = ops.Wv; auto& bv = ops.bv; auto& mk = ops.mk; auto& yv = ops.yv; auto& labv = ops.labv;
+        FS_STAMP(24);
         for (int f0 = tid >> 8; f0 < a.n_out; f0 += NPP * (THREADS / 256)) {
             float ov[NPP][DMAX], dxv[NPP][8];
             if (!(PRE && f0 == (tid >> 8))) decoder_ops_load<THREADS, DMAX, NPP>(a, tid, w0, B, f0, false, ops);
@@ -1199,6 +1200,7 @@ __device__ __forceinline__ void decoder_tail_impl(const StackArgs& a, char* smem
                 }
             }
         }
+        FS_STAMP(25);
         if (fuse) {
             // reduce over the 4 rows of the wave (lanes 16 apart), then over the 8 waves through LDS (the X tile is dead after the barrier)
 #pragma unroll
@@ -1210,6 +1212,7 @@ __device__ __forceinline__ void decoder_tail_impl(const StackArgs& a, char* smem
                 }
             }
             lsum += __shfl_xor(lsum, 16, 64); lsum += __shfl_xor(lsum, 32, 64);
+            FS_STAMP(26);
             __syncthreads();
             float* red = reinterpret_cast<float*>(smem + a.red_off);          // [waves][8 H + 16]
             if (lane < 16) {
@@ -1222,6 +1225,7 @@ __device__ __forceinline__ void decoder_tail_impl(const StackArgs& a, char* smem
                 if (lane == 0) red[wv * DEC_SLAB_FLOATS + 8 * H + 8] = lsum;
             }
             __syncthreads();
+            FS_STAMP(27);
             float* slab = a.dec_slabs + (size_t)blockIdx.x * DEC_SLAB_FLOATS;
             for (int i = tid; i < 8 * H + 9; i += THREADS) {
                 if (i >= a.dout * H && i < 8 * H) continue;       // rows of unused output channels (k_finalize reads dout rows only)

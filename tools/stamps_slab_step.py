@@ -25,7 +25,8 @@ f = s[:G * 32].reshape(G, 32); b = s[G * 32:].reshape(G, 32)
 rows = [("start", f[:, 0]), ("tile staged", f[:, 1])]
 for l in range(L):
     rows += [(f"F L{l} group A", f[:, 2 + 4 * l]), (f"F L{l} group B (+ base MLP)", f[:, 3 + 4 * l]), (f"F L{l} barrier", f[:, 4 + 4 * l]), (f"F L{l} stores + barrier", f[:, 5 + 4 * l])]
-rows += [("decoder + loss tail", f[:, 30]), ("B start (residual rows read)", b[:, 0])]
+rows += [("tail: operands / entry", f[:, 24]), ("tail: decoder + loss + dX_L passes", f[:, 25]), ("tail: row shuffles", f[:, 26]), ("tail: partials to LDS + barriers", f[:, 27]),
+         ("tail: slab sums written (end)", f[:, 30]), ("B start (residual rows read)", b[:, 0])]
 for i in range(L):
     l = L - 1 - i
     rows += [(f"B L{l} mask + barrier", b[:, 1 + 6 * i]), (f"B L{l} base MLP chain", b[:, 2 + 6 * i]), (f"B L{l} group A", b[:, 3 + 6 * i]), (f"B L{l} group B", b[:, 4 + 6 * i]),
