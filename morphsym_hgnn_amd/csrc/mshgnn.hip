@@ -2483,7 +2483,7 @@ extern "C" int mshgnn_plan_create(const mshgnn_desc* desc, mshgnn_plan** out) {
             }
             { const char* et = getenv("MSHGNN_STEP_KERNEL"); p->use_step = !(et && atoi(et) == 0); }      // one-call steps: forward + backward sweep in one launch
 
-            { const char* eg = getenv("MSHGNN_STAGGER"); p->stagger = eg ? atoi(eg) : 0; }
+            { const char* eg = TUNE_ENV("MSHGNN_STAGGER"); p->stagger = eg ? atoi(eg) : 0; }
         }
     }
     *out = p;
@@ -2594,7 +2594,7 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
     PrepArgs pa{params, ws + lay.wpack, reinterpret_cast<float*>(ws + lay.bias), p->d_packs, p->d_biases, (int)hp.packs.size(), (int)hp.biases.size()};
     int enc_pack0 = (int)hp.packs.size();
     for (int t = 0; t < hp.NT; ++t) if (hp.pack_enc_base[t] >= 0) enc_pack0 = std::min(enc_pack0, hp.pack_enc_base[t]);
-    static const bool embed_off = getenv("MSHGNN_PREP_EMBED") && atoi(getenv("MSHGNN_PREP_EMBED")) == 0;      // (A/B runs)
+    static const bool embed_off = TUNE_ENV("MSHGNN_PREP_EMBED") && atoi(TUNE_ENV("MSHGNN_PREP_EMBED")) == 0;      // (A/B runs)
     const bool embed = sizeof(T) == 2 && !series && !prep_use_tiled(pa.n_packs) && enc_pack0 > 0 && !embed_off;
     {
         PrepArgs a = pa;
@@ -2817,11 +2817,13 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
         a.stamps = stamp_ptr("MSHGNN_STAMPS_GW");
         ProfScope ps(p, hp.ks_gradw, st);
         auto launch_gradw = [&](const GradwArgs& ga, hipStream_t s_) {
-            static const bool gw_general = getenv("MSHGNN_GRADW") && std::string(getenv("MSHGNN_GRADW")) == "general";   // read once: the general kernel also where the lean one applies (A/B runs)
+            [[maybe_unused]] static const bool gw_general = TUNE_ENV("MSHGNN_GRADW") && std::string(TUNE_ENV("MSHGNN_GRADW")) == "general";   // read once: the general kernel also where the lean one applies (A/B runs)
             if (ga.n_pad <= 0) return;
             if constexpr (sizeof(T) == 4) hipLaunchKernelGGL(k_gradw_f32, dim3(ga.n_pad * gw_parts), dim3(256), 0, s_, ga);
+#ifdef MSHGNN_TUNING      // (the general bf16 kernel of rounds 1-3: kept for A/B runs in tuning builds, not in the product binary)
             else if (gw_general && hp.gw_ipl == 1) hipLaunchKernelGGL(k_gradw_bf16<1>, dim3(ga.n_pad * gw_parts), dim3(256), 0, s_, ga);
             else if (gw_general && hp.gw_ipl == 2) hipLaunchKernelGGL(k_gradw_bf16<2>, dim3(ga.n_pad * gw_parts), dim3(256), 0, s_, ga);
+#endif
             else if (series) hipLaunchKernelGGL((k_gradw_bf16_lean<true, true>), dim3(ga.n_pad * gw_parts), dim3(256), 0, s_, ga);      // raw operands from the series
             else if (ga.aligned) hipLaunchKernelGGL(k_gradw_bf16_lean<true>, dim3(ga.n_pad * gw_parts), dim3(256), 0, s_, ga);
             else hipLaunchKernelGGL(k_gradw_bf16_lean<false>, dim3(ga.n_pad * gw_parts), dim3(256), 0, s_, ga);

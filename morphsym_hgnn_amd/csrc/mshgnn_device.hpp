@@ -721,7 +721,7 @@ template <typename T, bool SPLIT_OUT> __global__ __launch_bounds__(256) void k_p
 }
 constexpr int PREP_TILED_MIN = 200;       // packs from which the tiled kernel wins
 inline bool prep_use_tiled(int n_packs) {      // MSHGNN_PREP_TILED=0 / 1 forces either kernel (A/B runs)
-    static const int forced = [] { const char* e = getenv("MSHGNN_PREP_TILED"); return e ? atoi(e) : -1; }();
+    static const int forced = [] { const char* e = TUNE_ENV("MSHGNN_PREP_TILED"); return e ? atoi(e) : -1; }();
     return forced >= 0 ? forced != 0 : n_packs >= PREP_TILED_MIN;
 }
 inline unsigned prep_tiled_grid(int n_packs, int n_biases) { return (unsigned)(2 * n_packs + (n_biases * H + 255) / 256); }
@@ -805,7 +805,7 @@ template <class A> __device__ __forceinline__ void stash_store_u(const A& a, gwc
 }
 inline int stash_nt_for(int64_t B, int stash_rows, int row_bytes) {
     static const int force = []() { const char* e = getenv("MSHGNN_STASH_NT"); return e ? atoi(e) : -1; }();
-    static const int64_t limit_mb = []() { const char* e = getenv("MSHGNN_STASH_NT_MB"); return (int64_t)(e ? atoi(e) : 200); }();
+    static const int64_t limit_mb = []() { const char* e = TUNE_ENV("MSHGNN_STASH_NT_MB"); return (int64_t)(e ? atoi(e) : 200); }();
     if (force == 0 || force == 1) return force;
     return (int64_t)stash_rows * B * row_bytes > (limit_mb << 20) ? 1 : 0;
 }
@@ -1362,7 +1362,7 @@ inline int vec_bytes(const void* base, int64_t pitch_elems, int esize) {
 //     t(W) = 1.1 + 0.0024 W us up to 480 workgroups (under two per CU), 1.1 + 0.0032 W beyond;   launch = ceil(chunks / q) ipl t(lanes q) + 0.012 lanes q
 // with the grid kept at or below 2.8 workgroups per CU.  The plan's own count (as many parts as fit) stays unless the model sees > 3 % in another.
 inline int gw_parts_for(int plan_parts, int lanes, int ipl, int64_t B, int chunk_windows, int n_cu) {
-    static const int forced = [] { const char* e = getenv("MSHGNN_GW_PARTS"); return e ? atoi(e) : 0; }();      // (measurements)
+    static const int forced = [] { const char* e = TUNE_ENV("MSHGNN_GW_PARTS"); return e ? atoi(e) : 0; }();      // (measurements)
     if (forced > 0) return std::min(forced, plan_parts);
     const int64_t nchunks = (B + chunk_windows - 1) / chunk_windows;
     const double cu_scale = 256.0 / (double)std::max(1, n_cu);                               // (the fit is per CU: workgroup counts scaled to a 256-CU chip)

@@ -1549,7 +1549,7 @@ static int g_fill(const mshgnn_plan* p, const mshgnn_ws_layout& lay, const void*
 }
 
 static bool g_raw_ok(const GenPlan& gp, const GArgs& a) {
-    static const bool off = []() { const char* e = getenv("MSHGNN_GEN_RAW5"); return e && atoi(e) == 0; }();      // (=0: the raw-input launch stays on k_gstep4)
+    static const bool off = []() { const char* e = TUNE_ENV("MSHGNN_GEN_RAW5"); return e && atoi(e) == 0; }();      // (=0: the raw-input launch stays on k_gstep4)
     if (off) return false;
     for (int t = 0; t < gp.NT; ++t)
         if (a.vb[t] < 16 || (a.pitch[t] & 7) != 0 || (uint64_t)a.B * (uint64_t)a.nodes[t] * (uint64_t)a.pitch[t] * 2 >= (1ull << 32)) return false;
@@ -1568,7 +1568,7 @@ static int g_tile_blocks(int B, bool split) {
 
 #ifdef GEN_TIMELINE
 static long long* gen_tl(const char* which) {      // MSHGNN_GEN_TL = "<launch name>:<hex device address>"
-    const char* e = getenv("MSHGNN_GEN_TL");
+    const char* e = TUNE_ENV("MSHGNN_GEN_TL");
     if (!e) return nullptr;
     const char* c = strchr(e, ':');
     if (!c || strncmp(e, which, (size_t)(c - e)) != 0 || strlen(which) != (size_t)(c - e)) return nullptr;

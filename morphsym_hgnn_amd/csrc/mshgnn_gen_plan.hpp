@@ -301,7 +301,7 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
     // Wide plans (hidden a multiple of 512, both arithmetics; of 256 in bf16 arithmetic: the pipelined job kernel k_gstep5 wants every term to be ONE plain row): a sum of TWO rows at scale 1 becomes two
     // terms on the same weights (W (a + b) = W a + W b: one more pass of MFMAs for that term, and the sum is no longer rounded to bf16 before the product), longer
     // sums go through the aggregate buffers from three rows on.  MSHGNN_GEN_SPLIT_SUMS=0 keeps the sums (A/B runs).
-    const bool split_sums = (NCT % 4 == 0 || (!p.split && NCT % 2 == 0)) && []() { const char* e = std::getenv("MSHGNN_GEN_SPLIT_SUMS"); return !(e && std::atoi(e) == 0); }();
+    const bool split_sums = (NCT % 4 == 0 || (!p.split && NCT % 2 == 0)) && []() { const char* e = TUNE_ENV("MSHGNN_GEN_SPLIT_SUMS"); return !(e && std::atoi(e) == 0); }();
     const int g_many = [&]() { const char* e = std::getenv("MSHGNN_GEN_MANY"); return e ? std::max(2, std::atoi(e)) : (split_sums ? 2 : G_MANY); }();      // (threshold override, read when the plan is compiled: tests, measurements)
     int n_split_terms = 0;
     auto push_term = [&](std::vector<TermDef>& tds, const TermDef& td) {
@@ -385,7 +385,7 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
     // the row as it staged it.  p.dhm: the job (or the decoder's backward) that PRODUCES dX_{l+1}[n] also writes dX_{l+1}[n] . bits_l[n] into layer l's dH stash (one
     // more row written per node and layer); the readers then see plain rows -- every backward launch qualifies for the unmasked k_gstep5, and the weight-gradient
     // streams carry no relu bytes.  The same values, bit for bit (masking zeroes elements; it does not round).  MSHGNN_GEN_DHM=0: the readers mask.
-    p.dhm = []() { const char* e = std::getenv("MSHGNN_GEN_DHM"); return !(e && std::atoi(e) == 0); }();
+    p.dhm = []() { const char* e = TUNE_ENV("MSHGNN_GEN_DHM"); return !(e && std::atoi(e) == 0); }();
     auto dh_src = [&](int l, int n, float scale = 1.0f) {
         const int t = p.node_type[n];
         if (has_mlp && t == d.mlp_type) return one(BUF_DH + l, n, -1, scale);
@@ -496,7 +496,7 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
         }
         return true; };
     int ipu = G_ITEMS_PER_UNIT;      // items per weight-gradient unit
-    if (const char* e = std::getenv("MSHGNN_GGW_ITEMS")) ipu = std::max(1, std::atoi(e));      // (measurements)
+    if (const char* e = TUNE_ENV("MSHGNN_GGW_ITEMS")) ipu = std::max(1, std::atoi(e));      // (measurements)
     // units: for every target tile (ot, kt) one unit per chunk of <= G_ITEMS_PER_UNIT items; the units of one tile are consecutive
     for (Tgt& g : tgts) {
         g.unit0 = (int)(units.size() / UNIT_INTS);
@@ -541,7 +541,7 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
     }
     p.n_sunits = (int)(sunits.size() / SUNIT_INTS);
     p.n_parts = std::max(1, std::min(16, 768 / std::max(1, p.n_sunits)));
-    if (const char* e = std::getenv("MSHGNN_GGW_PARTS")) p.n_parts = std::max(1, std::min(16, std::atoi(e)));      // (measurements)
+    if (const char* e = TUNE_ENV("MSHGNN_GGW_PARTS")) p.n_parts = std::max(1, std::min(16, std::atoi(e)));      // (measurements)
     // launch order: the super-units of ONE (target, item chunk) read the same P and Q rows (each half of them twice at hidden = 512).  Workgroups b
     // and b + 8 run on the same XCD (round-robin dispatch), so they are placed 8 apart on one XCD, back to back, and the second reader hits that
     // XCD's L2 (speed only).  Super-units were emitted (target, chunk)-major, so a group is a run of consecutive indices.
@@ -554,7 +554,7 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
     // (buffer, node) with the queue's groups first, queue length second, lengths kept within a slack of the balanced one; each queue is then ordered
     // by its groups' first P row, so that the groups of one layer and limb range are dispatched side by side.  Deterministic; speed only.
     std::vector<int32_t> su_order;
-    const bool su_locality = []() { const char* e = std::getenv("MSHGNN_GGW_PLACE"); return !(e && std::atoi(e) == 0); }();      // (=0: round 2's placement, A/B runs)
+    const bool su_locality = []() { const char* e = TUNE_ENV("MSHGNN_GGW_PLACE"); return !(e && std::atoi(e) == 0); }();      // (=0: round 2's placement, A/B runs)
     for (int cls = 0; cls <= 1; ++cls) {
         struct Grp { int first, count; std::vector<int64_t> streams; int64_t key; int steps; };      // steps: items of the group's super-units (their length)
         std::vector<Grp> groups;
@@ -604,7 +604,7 @@ inline bool compile_gen_plan(const mshgnn_desc* din, GenPlan& p) {
         for (int x = 0; x < 8; ++x) {
             // longest groups first (the launch is a list schedule of ~3 rounds of workgroups: with the short ones last its tail is a short workgroup, not a long one);
             // groups of one length by their first P row, so that the groups of one layer and limb range are still dispatched side by side
-            static const bool lpt = []() { const char* e = std::getenv("MSHGNN_GGW_LPT"); return !(e && std::atoi(e) == 0); }();
+            static const bool lpt = []() { const char* e = TUNE_ENV("MSHGNN_GGW_LPT"); return !(e && std::atoi(e) == 0); }();
             if (su_locality) std::stable_sort(xq[x].begin(), xq[x].end(), [&](int a, int b) {
                 if (lpt && groups[a].steps != groups[b].steps) return groups[a].steps > groups[b].steps;
                 return groups[a].key < groups[b].key; });

@@ -21,6 +21,16 @@
 
 #include "../../include/mshgnn.h"
 
+// Run-time switches.  The product library reads the ones README.md documents (what selects a route a test or the bench compares: MSHGNN_SPEC, _PRUNE, _SLAB,
+// _STEP_KERNEL, _FUSED, _ENGINE, _STASH_NT, _STEP_CHUNK, _GEN_TILE, _GEN_MANY).  Everything that only ever served a measurement (grid targets, placement
+// heuristics, alternative kernels kept for A/B runs) is read in TUNING builds only (make EXTRA=-DMSHGNN_TUNING): in the product build TUNE_ENV() is a constant,
+// the branches behind it fold away and the kernels only they reach are not in the binary.
+#ifdef MSHGNN_TUNING
+#define TUNE_ENV(name) std::getenv(name)
+#else
+#define TUNE_ENV(name) (static_cast<const char*>(nullptr))
+#endif
+
 namespace mshgnn {
 
 constexpr int H = 128;            // hidden width the kernels are built for
@@ -239,7 +249,7 @@ inline bool compile_plan(const mshgnn_desc* din, HostPlan& p) {
 #define GWX3_TARGET_WGS 768
 #endif
     p.gw_target = p.split ? GWX3_TARGET_WGS : (int)GW_TARGET_WGS;
-    { const char* e = std::getenv("MSHGNN_GW_TARGET"); if (e && std::atoi(e) >= 64) p.gw_target = std::atoi(e); }      // (measurements: workgroups of the weight-gradient launch)     // split plan: three resident workgroups per CU of its weight-gradient kernel (four 8 KB tiles per 32-window step)
+    { const char* e = TUNE_ENV("MSHGNN_GW_TARGET"); if (e && std::atoi(e) >= 64) p.gw_target = std::atoi(e); }      // (measurements: workgroups of the weight-gradient launch)     // split plan: three resident workgroups per CU of its weight-gradient kernel (four 8 KB tiles per 32-window step)
     p.blk_bytes = TILE_ROWS * H * p.esize;
     if (!p.split && (int64_t)p.NN * p.blk_bytes > LDS_LIMIT)
         return fail(p, "topology has too many nodes per window for the LDS-resident layer kernel (max 20 fp32 / 40 bf16)");

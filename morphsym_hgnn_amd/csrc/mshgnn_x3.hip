@@ -805,6 +805,7 @@ __global__ __launch_bounds__(256) void k_dec_bwd_x3(DecArgs a) {
 #ifndef GWX3_NST
 #define GWX3_NST 1          // register stages: global loads run NST steps ahead of the LDS writes
 #endif
+#ifdef MSHGNN_TUNING      // (the general split-plan weight-gradient kernel of round 2: A/B runs in tuning builds only; the lean kernel below is the product's)
 __global__ __launch_bounds__(256, GWX3_WPS) void k_gradw_x3(GradwArgs a) {
     using T = T16;
     constexpr int KW = GWX3_KW, NP = KW / 16, NST = GWX3_NST;      // NP: staging passes (16 rows each)
@@ -984,6 +985,7 @@ __global__ __launch_bounds__(256, GWX3_WPS) void k_gradw_x3(GradwArgs a) {
         }
     }
 }
+#endif
 
 // k_gradw_x3_lean: the same 32-window step loop with the addressing of k_gradw_bf16_lean (mshgnn.hip): a thread owns TWO CONSECUTIVE windows of
 // one 16-byte column chunk, so every global address is  workgroup-uniform stream pointer (scalar registers, advanced by scalar adds)  +  ONE
@@ -1256,7 +1258,7 @@ int x3_forward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitc
     PrepArgs pa{params, ws + lay.wpack, reinterpret_cast<float*>(ws + lay.bias), p->d_packs, p->d_biases, hp.n_img, (int)hp.biases.size()};
     int enc_pack0 = hp.n_img;
     for (int t = 0; t < hp.NT; ++t) if (hp.pack_enc_base[t] >= 0) enc_pack0 = std::min(enc_pack0, hp.pack_enc_base[t]);
-    static const bool embed_off = getenv("MSHGNN_PREP_EMBED") && atoi(getenv("MSHGNN_PREP_EMBED")) == 0;
+    static const bool embed_off = TUNE_ENV("MSHGNN_PREP_EMBED") && atoi(TUNE_ENV("MSHGNN_PREP_EMBED")) == 0;
     const bool embed = !prep_use_tiled(pa.n_packs) && enc_pack0 > 0 && !embed_off && !series;
     {
         PrepArgs a = pa;
@@ -1398,10 +1400,13 @@ int x3_backward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pit
         if (gw_phase >= 0) { a.lane_order = p->d_tables + hp.order_ph_off[gw_phase]; a.n_pad = hp.npad_ph[gw_phase]; }
         a.signs = p->d_signs; a.slabs = reinterpret_cast<float*>(ws + lay.slabs); a.B = B; a.n_lanes = hp.n_lanes; a.n_parts = gw_parts;
         ProfScope ps(p, hp.ks_gradw, st);
-        static const bool gw_general = getenv("MSHGNN_GRADW") && std::string(getenv("MSHGNN_GRADW")) == "general";   // read once: the general kernel also where the lean one applies (A/B runs)
+        [[maybe_unused]] static const bool gw_general = TUNE_ENV("MSHGNN_GRADW") && std::string(TUNE_ENV("MSHGNN_GRADW")) == "general";   // read once: the general kernel also where the lean one applies (A/B runs)
         if (a.n_pad > 0) {
+#ifdef MSHGNN_TUNING
             if (gw_general && hp.gw_ipl == 1) hipLaunchKernelGGL(k_gradw_x3, dim3(a.n_pad * gw_parts), dim3(256), 0, st, a);
-            else if (a.aligned) hipLaunchKernelGGL(k_gradw_x3_lean<true>, dim3(a.n_pad * gw_parts), dim3(256), 0, st, a);
+            else
+#endif
+            if (a.aligned) hipLaunchKernelGGL(k_gradw_x3_lean<true>, dim3(a.n_pad * gw_parts), dim3(256), 0, st, a);
             else hipLaunchKernelGGL(k_gradw_x3_lean<false>, dim3(a.n_pad * gw_parts), dim3(256), 0, st, a);
         }
     }
