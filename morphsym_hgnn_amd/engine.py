@@ -266,19 +266,22 @@ class _DescHolder:
         self.desc = d
 
 
+ROW_ALIGN = 128      # bytes; see row_pitch (a module constant since round 6: the A/B run it served as an environment switch was made in round 4)
+
+
 def row_pitch(width: int, elem_bytes: int) -> int:
     """Row pitch (elements) of an input type in the engine's own layout.  Rows start 16-byte aligned (what the kernels' 16-byte loads need); rows
     longer than a cache line start ON a cache line (128 bytes): a 128-column K chunk of a row is then exactly two lines, and a line is never shared
     by two chunks that different workgroups read at different times (measured, A1-C2 8192 windows bf16: the weight-gradient launch 110 -> 101 us,
-    step 0.298 -> 0.288 ms on the same box).  The pad columns are never read as data.  MSHGNN_ROW_ALIGN=16 restores the 16-byte pitch (A/B runs)."""
-    align = int(os.environ.get("MSHGNN_ROW_ALIGN", "128"))
+    step 0.298 -> 0.288 ms on the same box).  The pad columns are never read as data.  (ROW_ALIGN = 16 restores the 16-byte pitch of rounds 1-3.)"""
+    align = ROW_ALIGN
     q = (align if (align > 16 and width * elem_bytes > align) else 16) // elem_bytes
     return (width + q - 1) // q * q
 
 
 def accepted_pitches(width: int, elem_bytes: int):
     """The row pitches (elements) a device tensor of an input type may arrive at: the reference's dense width, the engine's own pitch (`row_pitch`)
-    and the plain 16-byte-rounded width (what `MSHGNN_ROW_ALIGN=16` / the on-device window assembly of round 2 produced).  Anything else --
+    and the plain 16-byte-rounded width (what `ROW_ALIGN = 16` / the on-device window assembly of round 2 produced).  Anything else --
     e.g. a tensor with a few MORE real feature columns than the model was built for -- is a shape error, not padding."""
     q = 16 // elem_bytes
     return {width, row_pitch(width, elem_bytes), (width + q - 1) // q * q}
@@ -685,7 +688,7 @@ class Engine:
         # the runs' column pointers in the store's scratch depend only on the series' addresses and the element size: resolved by the first step of this
         # store on this stream at this storage, vouched for afterwards (mshgnn_window_desc.run_ptrs_ready: one launch less in front of every encoder)
         key = (self.storage == "x3", stream, tuple(a.data_ptr() for a in store.series))
-        store.desc.run_ptrs_ready = 1 if getattr(store, "_run_ptrs_key", None) == key and os.environ.get("MSHGNN_RUN_PTRS_CACHE", "1") != "0" else 0
+        store.desc.run_ptrs_ready = 1 if getattr(store, "_run_ptrs_key", None) == key else 0
         store._run_ptrs_key = key
         with torch.cuda.device(self.device):
             if ce:

@@ -250,8 +250,8 @@ class WindowBatch:
         st = st.flatten().to(torch.int64)
         # Contract: every start index i satisfies 0 <= i and i + history <= store.n_rows (the fused-gather kernels read the series at
         # [i, i + history) without a bound check).  Host indices are checked here; DEVICE indices are taken as they are, because checking them costs a
-        # host synchronisation per batch -- MSHGNN_CHECK_STARTS=1 turns that check on (debugging a sampler).
-        if not st.is_cuda or os.environ.get("MSHGNN_CHECK_STARTS") == "1":
+        # host synchronisation per batch -- `store.check_starts = True` turns that check on (debugging a sampler).
+        if not st.is_cuda or getattr(store, "check_starts", False):
             if st.numel() < 1 or int(st.min()) < 0 or int(st.max()) + store.recipe.history > store.n_rows:
                 raise IndexError("window index out of range")
             st = st.to(store.device)

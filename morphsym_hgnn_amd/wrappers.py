@@ -60,8 +60,8 @@ class Base_Lightning(_Base):
     # training_step hands the labels to the model, which runs forward + loss + backward as ONE engine call (models.fused_training_step:
     # the decoder, the loss and the decoder's backward sit in the tail of the fused forward kernel); the returned loss delivers those
     # gradients when backward() is called on it.  Same loss and gradients as the two-call route, which is taken when this is False
-    # (or MSHGNN_FUSED_TRAINING_STEP=0), under torch.distributed, with host parameters, or without autograd.
-    fused_training_step = os.environ.get("MSHGNN_FUSED_TRAINING_STEP", "1") != "0"
+    # (an attribute, set per wrapper or on the class), under torch.distributed, with host parameters, or without autograd.
+    fused_training_step = True
 
     def __init__(self, optimizer: str, lr: float, regression: bool):
         super().__init__()
