@@ -743,6 +743,23 @@ def roofline_of(stats, steps, B, dtype, e, config, L, hidden):
     roof["launches_per_step"] = per_step
     roof["avg_us"] = avg_s * 1e6
     roof["share_of_step"] = dom["total_ms"] / max(total_ms, 1e-9)
+    # every launch of the step against its own roof, by the same algorithmic figures (the plan's live FLOPs / the raw-input bytes a launch must read): the
+    # dominant launch changes with the build (round 5: the MFMA-classified stack launch; round 6: the HBM-classified weight-gradient launch), the table does not
+    per = {}
+    for s_ in stats:
+        if not s_["launches"]:
+            continue
+        n_ = max(1, round(s_["launches"] / steps))
+        t_ = s_["total_ms"] / s_["launches"] * 1e-3
+        if s_["bound"] == "mfma":
+            ach = s_["flops_per_window"] / n_ * B / t_ / 1e12
+            per[s_["name"]] = {"bound": "mfma", "avg_us": t_ * 1e6, "achieved": ach, "unit": "TFLOP/s", "frac": ach / PEAK["mfma_TFLOPs"][dtype],
+                               "algorithmic_flops": s_["flops_per_window"] / n_ * B}
+        else:
+            ob = s_["bytes_per_window"] / n_ * B
+            per[s_["name"]] = {"bound": "hbm", "avg_us": t_ * 1e6, "achieved": ob / t_ / 1e9, "unit": "GB/s", "frac": ob / t_ / 1e9 / PEAK["hbm_GBs"],
+                               "operand_bytes": ob, "priced_by": "the launch's own operand stream"}
+    roof["per_kernel"] = per
     return roof
 
 
