@@ -195,4 +195,17 @@ int mshgnn_hostplan_compile_gen(const mshgnn_desc* desc, int32_t* meta, int chec
     return (int)gp.tables.size();
 }
 
+// The generic plan's tables themselves (tools/ggradw_traffic_model.py): `tables` receives min(cap, n) ints; meta (>= 16 ints): [0] sunit_off, [1] su_order_off, [2] item_off,
+// [3] src_off, [4] n_sunits, [5] n_parts, [6] su_os, [7] n_units, [8] fin_off, [9] unit_off.  Returns the number of table ints or -1.
+int mshgnn_hostplan_gen_tables(const mshgnn_desc* desc, int32_t* tables, int cap, int32_t* meta) {
+    gen::GenPlan gp;
+    if (!gen::compile_gen_plan(desc, gp)) { g_hp_err = gp.err; return -1; }
+    if (meta) {
+        meta[0] = gp.sunit_off; meta[1] = gp.su_order_off; meta[2] = gp.item_off; meta[3] = gp.src_off; meta[4] = gp.n_sunits; meta[5] = gp.n_parts; meta[6] = gp.su_os; meta[7] = gp.n_units;
+        meta[8] = gp.fin_off; meta[9] = gp.unit_off;
+    }
+    if (tables) std::memcpy(tables, gp.tables.data(), sizeof(int32_t) * std::min<size_t>(cap > 0 ? cap : 0, gp.tables.size()));
+    return (int)gp.tables.size();
+}
+
 }  // extern "C"
