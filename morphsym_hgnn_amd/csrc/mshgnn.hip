@@ -2685,14 +2685,24 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
             a.stash_nt = training ? stash_nt_for(B, stash_rows_of(hp), H * (int)sizeof(T)) : 0;
             // the tail's reduction scratch (one decoder slab per wave) must not touch the out-type nodes' blocks, which receive dX_L for the backward sweep: it sits
             // in the blocks in front of them, or (models whose out type comes first: the centroidal-momentum ones) in the blocks behind them
-            const bool step_slab = p->slab_for(tiles);
-            const size_t red_need = (size_t)((step_slab ? SL_THREADS : LAYER_THREADS) / 64) * DEC_SLAB_FLOATS * sizeof(float);
-            const size_t lds_launch = (size_t)((step_slab ? hp.sl_blk : hp.fs_blk) + FS_EXTRA_BLK) * Prec<T>::BLK, red_back = (size_t)(a.node0 + a.n_out) * Prec<T>::BLK;
-            const bool red_front_ok = (size_t)a.node0 * Prec<T>::BLK >= red_need, red_back_ok = red_back + red_need <= lds_launch;
-            const bool step = stack_step_done && p->use_step && (y_fused || labels_fused) && (red_front_ok || red_back_ok);
+            const bool want_step = stack_step_done && p->use_step && (y_fused || labels_fused);
+            // Slab or 8-wave kernels: the 8-wave ones take batches of at most one tile per CU -- unless the one-call step has a compile-time program for this plan
+            // (whole tiles): a single tile's chain on the specialised slab kernel is 37-42 us where the interpreting 8-wave kernel takes 57-62 (A1-C2, 32 .. 4 096 windows;
+            // 8 layers: 140-166 against 202-209), so the specialised step runs at every batch size.  MSHGNN_SLAB=0 / MSHGNN_SPEC=0 keep the 8-wave kernels there.
+            bool step_slab = p->slab_for(tiles);
+            const bool spec_small = !step_slab && want_step && p->use_slab && p->use_spec && B % TILE_ROWS == 0 && slab_step_spec_kernel(hp, a.stash_nt) != nullptr;
+            bool red_front_ok = false, red_back_ok = false; size_t red_back = 0;
+            auto red_fits = [&](bool slab) {
+                const size_t red_need = (size_t)((slab ? SL_THREADS : LAYER_THREADS) / 64) * DEC_SLAB_FLOATS * sizeof(float);
+                const size_t lds_launch = (size_t)((slab ? hp.sl_blk : hp.fs_blk) + FS_EXTRA_BLK) * Prec<T>::BLK;
+                red_back = (size_t)(a.node0 + a.n_out) * Prec<T>::BLK;
+                red_front_ok = (size_t)a.node0 * Prec<T>::BLK >= red_need; red_back_ok = red_back + red_need <= lds_launch;
+                return red_front_ok || red_back_ok; };
+            if (spec_small && red_fits(true)) step_slab = true;
+            const bool step = want_step && red_fits(step_slab);
             if (step && !red_front_ok) a.red_off = (int)red_back;
             ProfScope ps(p, step ? hp.ks_stack_step : hp.ks_stack_fwd, st);
-            if (p->slab_for(tiles)) {
+            if (step_slab) {
                 for (int l = 0; l < hp.L; ++l) a.prog_off[l] = hp.sl_fwd_off[l];
                 if (step) {
                     for (int l = 0; l <= hp.L; ++l) a.dx_off[l] = lay.dx[l];
