@@ -1672,6 +1672,24 @@ static StackKernel slab_step_spec_kernel(const HostPlan& hp, int nt, const char*
 #undef MSHGNN_SPEC_TRY
     return nullptr;
 }
+// The forward launch alone (mshgnn_forward: evaluation, or the first call of the two-call training route) over the same compile-time programs: whole tiles; TR (training:
+// stashes and relu bytes written) and NT (their store policy) are template parameters like the step kernels' NT -- with them at run time the 8-layer programs keep their
+// store addresses live across the unrolled layers and spill (256-492 B of scratch: slower than the interpreter at 8 192 windows).  The decoder tail runs without the fused
+// loss.  Same MACs, same order: the interpreter's bits.
+template <typename T, int NM, int HB, class SP, int TR, int NT> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_fwd_spec(StackArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    StackView<NT> v(a, false);
+    v.training = TR;
+    unsigned lastbits[(SL_HA + 3) / 4 + (HB + 3) / 4];
+    slab_fwd_body<T, NM, HB, false, SP>(v, smem, lastbits);
+}
+static StackKernel slab_fwd_spec_kernel(const HostPlan& hp, int training, int nt) {
+#define MSHGNN_SPEC_TRY(SP) if (spec_matches<SP>(hp)) return !training ? k_slab_fwd_spec<__bf16, SP::NM, SP::HB, SP, 0, 0> : \
+                                                                     (nt ? k_slab_fwd_spec<__bf16, SP::NM, SP::HB, SP, 1, 1> : k_slab_fwd_spec<__bf16, SP::NM, SP::HB, SP, 1, 0>);
+    MSHGNN_SPEC_LIST(MSHGNN_SPEC_TRY)
+#undef MSHGNN_SPEC_TRY
+    return nullptr;
+}
 // the step kernel of a launch: the specialised one where the plan has one and the batch is whole tiles (its stores are unpredicated), else the interpreter
 static StackKernel slab_step_kernel(const HostPlan& hp, int64_t B = -1, int nt = 0, bool use_spec = false) {
     if (use_spec && B > 0 && B % TILE_ROWS == 0) if (StackKernel k = slab_step_spec_kernel(hp, nt)) return k;
@@ -2480,6 +2498,8 @@ extern "C" int mshgnn_plan_create(const mshgnn_desc* desc, mshgnn_plan** out) {
                     if (StackKernel k = slab_step_spec_kernel(hp, nt, &nm)) if ((rc = set_lds_attr(k, flds))) { mshgnn_plan_destroy(p); return rc; }
                 if (nm) p->spec_name = nm + 6;      // (past "spec::")
                 else p->use_spec = false;
+                for (int v = 0; v < 3; ++v)
+                    if (StackKernel k = slab_fwd_spec_kernel(hp, v > 0, v - 1)) if ((rc = set_lds_attr(k, flds))) { mshgnn_plan_destroy(p); return rc; }
             }
             { const char* et = getenv("MSHGNN_STEP_KERNEL"); p->use_step = !(et && atoi(et) == 0); }      // one-call steps: forward + backward sweep in one launch
 
@@ -2701,6 +2721,9 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
             if (spec_small && red_fits(true)) step_slab = true;
             const bool step = want_step && red_fits(step_slab);
             if (step && !red_front_ok) a.red_off = (int)red_back;
+            // the forward launch alone (evaluation / two-call training) on its compile-time program, at every whole-tile batch size
+            const StackKernel fwd_spec = (!step && p->use_slab && p->use_spec && B % TILE_ROWS == 0) ? slab_fwd_spec_kernel(hp, training, a.stash_nt) : nullptr;
+            if (fwd_spec) step_slab = true;
             ProfScope ps(p, step ? hp.ks_stack_step : hp.ks_stack_fwd, st);
             if (step_slab) {
                 for (int l = 0; l < hp.L; ++l) a.prog_off[l] = hp.sl_fwd_off[l];
@@ -2711,7 +2734,7 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
                     hipLaunchKernelGGL(slab_step_kernel(hp, B, a.stash_nt, p->use_spec), dim3(tiles), dim3(SL_THREADS), (hp.sl_blk + FS_EXTRA_BLK) * Prec<T>::BLK, st, a);
                     *stack_step_done = true;
                 } else
-                hipLaunchKernelGGL(slab_fwd_kernel(hp), dim3(tiles), dim3(SL_THREADS), (hp.sl_blk + FS_EXTRA_BLK) * Prec<T>::BLK, st, a);
+                hipLaunchKernelGGL(fwd_spec ? fwd_spec : slab_fwd_kernel(hp), dim3(tiles), dim3(SL_THREADS), (hp.sl_blk + FS_EXTRA_BLK) * Prec<T>::BLK, st, a);
             } else if (step) {
                 for (int l = 0; l <= hp.L; ++l) a.dx_off[l] = lay.dx[l];
                 for (int l = 0; l < hp.L; ++l) { a.dh_off[l] = lay.dh[l]; a.du_off[l] = lay.du[l]; a.prog_off_b[l] = hp.fs_bwd_off[l]; }

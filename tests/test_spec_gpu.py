@@ -98,3 +98,35 @@ def test_small_batches_take_the_specialised_step_by_default(monkeypatch, config,
         else:
             for what, a, b in zip(("out", "loss", "grad"), r1, r8):
                 assert torch.equal(a.view(torch.int32), b.view(torch.int32)), f"{config} B={B}: {what} differs (ragged batch: both on the 8-wave kernel)"
+
+
+@pytest.mark.parametrize("nt", ["0", "1"])
+@pytest.mark.parametrize("config,layers,name", CASES)
+def test_specialised_forward_is_bit_identical_to_the_interpreter(monkeypatch, config, layers, name, nt):
+    """mshgnn_forward alone (evaluation, and the first call of the two-call training route) over the compile-time programs (k_slab_fwd_spec<.., TR, NT>):
+    output bits == the interpreting slab kernel's in evaluation and training mode, and the backward pass that follows a specialised training forward
+    (stashes and relu bytes it wrote) gives the same gradient bits.  Whole tiles only: a ragged batch takes the interpreters on both engines."""
+    spec = bench.build_spec(layers, config)
+    monkeypatch.setenv("MSHGNN_STASH_NT", nt)
+    monkeypatch.delenv("MSHGNN_SLAB", raising=False); monkeypatch.setenv("MSHGNN_SPEC", "1")
+    e1 = eng.Engine(spec, "bf16")
+    monkeypatch.setenv("MSHGNN_SLAB", "2"); monkeypatch.setenv("MSHGNN_SPEC", "0")
+    e0 = eng.Engine(spec, "bf16")
+    assert e1.specialised == name and e0.specialised == ""
+    flat = eng.flatten_params(spec, synth.make_params(7, spec.param_shapes()), e1.device)
+    for B in (32, 4128, 50):
+        x, y = bench.make_batch(spec, B, 41 + B)
+        res = []
+        for e in (e1, e0):
+            xs = e.cast_inputs(x)
+            o_eval = e.forward(xs, flat, B, training=False).clone()
+            o_tr = e.forward(xs, flat, B, training=True).clone()
+            g = e.backward(xs, flat, torch.ones_like(o_tr) / o_tr.numel(), B).clone()
+            torch.cuda.synchronize()
+            res.append((o_eval, o_tr, g))
+        for what, a, b in zip(("eval out", "training out", "grad"), res[0], res[1]):
+            if B % 16 == 0:
+                assert torch.equal(a.view(torch.int32), b.view(torch.int32)), f"{name} B={B} nt={nt}: {what} differs, max abs {float((a - b).abs().max())}"
+            else:      # ragged: e1 falls back to the 8-wave kernels below one tile per CU, e0 runs the interpreting slab ones -- same bits up to the decoder's partial sums
+                assert float((a - b).norm() / b.norm()) < 1e-6, (name, B, what)
+        assert torch.equal(res[0][0].view(torch.int32), res[0][1].view(torch.int32)) and float(res[0][2].abs().max()) > 0

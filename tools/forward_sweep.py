@@ -1,5 +1,5 @@
 """Evaluation forward (mshgnn_forward, training=0) over batch sizes, 8-wave stack kernel against the slab one, us per launch sequence.
-usage: python tools/forward_sweep.py "2048 4096 4112 6144 8192" [layers] [dtype] [config]"""
+usage: python tools/forward_sweep.py "32 2048 4096 4112 6144 8192" [layers] [dtype] [config]"""
 import os, subprocess, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
@@ -30,14 +30,13 @@ if len(sys.argv) > 5 and sys.argv[5] == "child":
 L = sys.argv[2] if len(sys.argv) > 2 else "3"
 dtype = sys.argv[3] if len(sys.argv) > 3 else "bf16"
 config = sys.argv[4] if len(sys.argv) > 4 else "a1c2"
-print("B: us (eval, training) per MSHGNN_SLAB setting", flush=True)
+print("B: us (eval, training) per route: default (compile-time program where the plan has one) | MSHGNN_SLAB=0 (8-wave kernels) | MSHGNN_SPEC=0 (interpreting kernels, round 5's routing) | MSHGNN_SPEC=0 MSHGNN_SLAB=2", flush=True)
 for b in sys.argv[1].split():
     row = {}
-    for v in ("-", "0", "2"):
+    for name, over in (("default", {}), ("8wave", {"MSHGNN_SLAB": "0"}), ("interp", {"MSHGNN_SPEC": "0"}), ("interp_slab", {"MSHGNN_SPEC": "0", "MSHGNN_SLAB": "2"})):
         env = dict(os.environ)
-        env.pop("MSHGNN_SLAB", None)
-        if v != "-":
-            env["MSHGNN_SLAB"] = v
+        env.pop("MSHGNN_SLAB", None); env.pop("MSHGNN_SPEC", None)
+        env.update(over)
         p = subprocess.run([sys.executable, __file__, b, L, dtype, config, "child"], capture_output=True, text=True, env=env)
-        row[v] = p.stdout.strip().splitlines()[-1] if p.stdout.strip() else p.stderr[-200:]
-    print("B", b, "tiles", (int(b) + 15) // 16, "default", row["-"], "| 8wave", row["0"], "| slab", row["2"], flush=True)
+        row[name] = p.stdout.strip().splitlines()[-1] if p.stdout.strip() else p.stderr[-200:]
+    print("B", b, "tiles", (int(b) + 15) // 16, " | ".join(f"{k} {v}" for k, v in row.items()), flush=True)
