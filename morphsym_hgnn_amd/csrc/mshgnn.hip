@@ -1568,7 +1568,6 @@ template <typename T, int NM, int HB, bool STEP, class SP = void, class A = Stac
     const int w0 = blockIdx.x * P::ROWS, B = a.B, NN = a.NN;
     const T* wpack = reinterpret_cast<const T*>(a.wpack);
     static_assert(sizeof(T) == 2, "fused stack kernels are bf16");
-    static_assert(DYN || STEP, "compile-time programs exist for the one-launch step only");
     auto prog_of = [&](int l) { return STEP ? a.prog_off_b[l] : a.prog_off[l]; };
     if constexpr (!STEP) stack_stagger(a);
 
@@ -1620,7 +1619,16 @@ template <typename T, int NM, int HB, bool STEP, class SP = void, class A = Stac
         if constexpr ((SP::PRE & 1) != 0) slab_prefetch_static<T, SP, 1, SP::L - 1>(pre, wpack, wn, lane);      // (nothing is stored between here and the first pass: the mask phase writes LDS only)
         slab_bwd_keep_init<T, HB>(SHdr<SP, 1, SP::L - 1>{}, smem, wn, lane, keepA, keepB);
         unsigned mbq[SL_HA + HB];
-        slab_bits_to_bytes<SP, HB>(lastbits, mbq);
+        if constexpr (STEP) slab_bits_to_bytes<SP, HB>(lastbits, mbq);
+        else {      // the backward launch alone: the last layer's relu bytes come from the forward launch's stash, like every other layer's
+            constexpr SHdr<SP, 1, SP::L - 1> nh{};
+            const uint8_t* mbn = reinterpret_cast<const uint8_t*>(a.ws + a.mask_off[SP::L - 1]);
+#pragma unroll
+            for (int q = 0; q < SL_HA + HB; ++q) {
+                mbq[q] = 0xffu;
+                if (nh[FH_KIND + q] == NK_RELU) mbq[q] = gload1(uniform_ptr(reinterpret_cast<const char*>(mbn) + relu_tile_base(nh[(q < SL_HA ? FH_SLOTA : FH_SLOTB - SL_HA) + q], a.B, blockIdx.x, wn)), (unsigned)lane);
+            }
+        }
         FS_STAMP2(0);
         slab_bwd_layers_static<T, NM, HB, SP, SP::L - 1>(a, smem, wpack, wn, lane, keepA, keepB, mbq, pre);
     }
@@ -1628,6 +1636,13 @@ template <typename T, int NM, int HB, bool STEP, class SP = void, class A = Stac
 template <typename T, int NM, int HB> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_bwd(StackArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     slab_bwd_body<T, NM, HB, false>(a, smem);
+}
+// The backward launch alone (second call of the two-call training route: mshgnn_backward / _mse / _ce after mshgnn_forward(training = 1)) over the compile-time programs:
+// whole tiles, NT = the stash store policy.  Same MACs, same order as k_slab_bwd: identical bits.
+template <typename T, int NM, int HB, class SP, int NT> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_bwd_spec(StackArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const StackView<NT> v(a, true);
+    slab_bwd_body<T, NM, HB, false, SP>(v, smem);
 }
 // One-call training step (mshgnn_step_mse / mshgnn_step_ce): the forward layers, decoder + loss + decoder backward and the backward layers of a tile in ONE
 // launch.  The tail leaves dX_L in the node blocks, so the backward sweep starts without a launch boundary, without the header / tile round trips of
@@ -1686,6 +1701,12 @@ template <typename T, int NM, int HB, class SP, int TR, int NT> __global__ __lau
 static StackKernel slab_fwd_spec_kernel(const HostPlan& hp, int training, int nt) {
 #define MSHGNN_SPEC_TRY(SP) if (spec_matches<SP>(hp)) return !training ? k_slab_fwd_spec<__bf16, SP::NM, SP::HB, SP, 0, 0> : \
                                                                      (nt ? k_slab_fwd_spec<__bf16, SP::NM, SP::HB, SP, 1, 1> : k_slab_fwd_spec<__bf16, SP::NM, SP::HB, SP, 1, 0>);
+    MSHGNN_SPEC_LIST(MSHGNN_SPEC_TRY)
+#undef MSHGNN_SPEC_TRY
+    return nullptr;
+}
+static StackKernel slab_bwd_spec_kernel(const HostPlan& hp, int nt) {
+#define MSHGNN_SPEC_TRY(SP) if (spec_matches<SP>(hp)) return nt ? k_slab_bwd_spec<__bf16, SP::NM, SP::HB, SP, 1> : k_slab_bwd_spec<__bf16, SP::NM, SP::HB, SP, 0>;
     MSHGNN_SPEC_LIST(MSHGNN_SPEC_TRY)
 #undef MSHGNN_SPEC_TRY
     return nullptr;
@@ -2500,6 +2521,8 @@ extern "C" int mshgnn_plan_create(const mshgnn_desc* desc, mshgnn_plan** out) {
                 else p->use_spec = false;
                 for (int v = 0; v < 3; ++v)
                     if (StackKernel k = slab_fwd_spec_kernel(hp, v > 0, v - 1)) if ((rc = set_lds_attr(k, flds))) { mshgnn_plan_destroy(p); return rc; }
+                for (int nt = 0; nt < 2; ++nt)
+                    if (StackKernel k = slab_bwd_spec_kernel(hp, nt)) if ((rc = set_lds_attr(k, flds))) { mshgnn_plan_destroy(p); return rc; }
             }
             { const char* et = getenv("MSHGNN_STEP_KERNEL"); p->use_step = !(et && atoi(et) == 0); }      // one-call steps: forward + backward sweep in one launch
 
@@ -2811,9 +2834,10 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
             a.stagger = p->slab_for(tiles) && tiles > p->n_cu ? p->stagger : 0;
             a.stash_nt = stash_nt_for(B, stash_rows_of(hp), H * (int)sizeof(T));
             ProfScope ps(p, hp.ks_stack_bwd, st);
-            if (p->slab_for(tiles)) {
+            const StackKernel bwd_spec = (p->use_slab && p->use_spec && B % TILE_ROWS == 0) ? slab_bwd_spec_kernel(hp, a.stash_nt) : nullptr;      // (at every whole-tile batch size, like the forward)
+            if (bwd_spec || p->slab_for(tiles)) {
                 for (int l = 0; l < hp.L; ++l) a.prog_off[l] = hp.sl_bwd_off[l];
-                hipLaunchKernelGGL(slab_bwd_kernel(hp), dim3(tiles), dim3(SL_THREADS), (hp.sl_blk + FS_EXTRA_BLK) * Prec<T>::BLK, st, a);
+                hipLaunchKernelGGL(bwd_spec ? bwd_spec : slab_bwd_kernel(hp), dim3(tiles), dim3(SL_THREADS), (hp.sl_blk + FS_EXTRA_BLK) * Prec<T>::BLK, st, a);
             } else
             hipLaunchKernelGGL(k_stack_bwd<T>, dim3(tiles), dim3(LAYER_THREADS), (hp.fs_blk + FS_EXTRA_BLK) * Prec<T>::BLK, st, a);
             fused_done = true;

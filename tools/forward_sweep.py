@@ -24,13 +24,22 @@ if len(sys.argv) > 5 and sys.argv[5] == "child":
             e.forward(xs, flat, B, training=tr, out=out)
         torch.cuda.synchronize()
         print(f"{(time.perf_counter() - t0) / 200 * 1e6:.1f}", end=" ")
+    gout = torch.full_like(out, 1.0 / out.numel()); g = torch.empty_like(flat)
+    for _ in range(20):
+        e.forward(xs, flat, B, training=True, out=out); e.backward(xs, flat, gout, B, grad_flat=g)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(200):
+        e.forward(xs, flat, B, training=True, out=out); e.backward(xs, flat, gout, B, grad_flat=g)
+    torch.cuda.synchronize()
+    print(f"{(time.perf_counter() - t0) / 200 * 1e6:.1f}", end=" ")
     print()
     sys.exit(0)
 
 L = sys.argv[2] if len(sys.argv) > 2 else "3"
 dtype = sys.argv[3] if len(sys.argv) > 3 else "bf16"
 config = sys.argv[4] if len(sys.argv) > 4 else "a1c2"
-print("B: us (eval, training) per route: default (compile-time program where the plan has one) | MSHGNN_SLAB=0 (8-wave kernels) | MSHGNN_SPEC=0 (interpreting kernels, round 5's routing) | MSHGNN_SPEC=0 MSHGNN_SLAB=2", flush=True)
+print("B: us (eval forward, training forward, training forward + backward) per route: default (compile-time program where the plan has one) | MSHGNN_SLAB=0 (8-wave kernels) | MSHGNN_SPEC=0 (interpreting kernels, round 5's routing) | MSHGNN_SPEC=0 MSHGNN_SLAB=2", flush=True)
 for b in sys.argv[1].split():
     row = {}
     for name, over in (("default", {}), ("8wave", {"MSHGNN_SLAB": "0"}), ("interp", {"MSHGNN_SPEC": "0"}), ("interp_slab", {"MSHGNN_SPEC": "0", "MSHGNN_SLAB": "2"})):
