@@ -10,7 +10,8 @@ import bench
 from morphsym_hgnn_amd import engine as eng, synth
 
 pytestmark = pytest.mark.gpu
-CASES = [("a1c2", 3, "A1C2_L3"), ("a1c2", 8, "A1C2_L8"), ("mck4", 8, "MCK4_L8"), ("solo", 8, "SOLO_L8")]
+CASES = [("a1c2", 3, "A1C2_L3"), ("a1c2", 8, "A1C2_L8"), ("mck4", 8, "MCK4_L8"), ("solo", 8, "SOLO_L8"),
+         ("mcc2", 8, "MCC2_L8"), ("solo_s4", 8, "SOLO_S4_L8")]      # (the last two: the model types the reference's classification / COM scripts default to; bf16 plan only)
 
 
 def _step(e, spec, x, y, flat, B):
