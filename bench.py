@@ -957,6 +957,15 @@ def main():
             res["forward_only"][plan] = {"ms_per_step": dtf * 1e3, "value": B / dtf}
             del wf
             torch.cuda.empty_cache()
+        # the reference's own batch sizes (train_regression-grf_msgn.py:93: 32; train_classification_msgn.py:750 / train_regression-com_msgn.py:76: 64): a step is one
+        # tile chain + four short launches -- the one-call step on its compile-time program (the specialised slab kernel at every whole-tile batch size)
+        res["small_batches"] = {"what": "mshgnn_step_mse of the headline model at the reference's batch sizes, inputs resident, eager launches (ms per step; windows/s)"}
+        for b in (32, 64, 256):
+            ws_ = Workload(spec, args.dtype, b, device, 1234)
+            dts = median_step_s(ws_.step, torch.cuda.synchronize, max(args.steps, 50), args.warmup, min_time=0.1)
+            res["small_batches"][str(b)] = {"ms_per_step": dts * 1e3, "value": b / dts}
+            del ws_
+        torch.cuda.empty_cache()
         if args.dtype == "bf16" and L == 3:
             res["end_to_end"] = end_to_end(spec, B, device, args.steps, args.warmup)
             torch.cuda.empty_cache()
