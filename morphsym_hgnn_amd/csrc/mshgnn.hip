@@ -14,6 +14,10 @@
 //
 // No CPU fallback exists: every entry point launches HIP kernels or fails loudly.
 #include "mshgnn_device.hpp"
+#ifndef MSHGNN_SPEC_SHARD
+#define MSHGNN_SPEC_SHARD 0      // 1..3: this source compiled as one of the translation units that only instantiate the compile-time programs' kernels (csrc/Makefile; see spec_shard1 below)
+#endif
+#if MSHGNN_SPEC_SHARD == 0
 extern "C" const char* mshgnn_last_error(void) { return g_err.c_str(); }
 extern "C" const char* mshgnn_version(void) { return "mshgnn 0.5 (gfx950)"; }
 extern "C" int mshgnn_abi_version(void) { return MSHGNN_ABI_VERSION; }
@@ -27,6 +31,7 @@ extern "C" size_t mshgnn_struct_size(int which) {
         default: return 0;
     }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------------
 // k_prep: pack weights into MFMA B-fragment images (root-sum, transpose, dtype) and sum biases
@@ -1664,10 +1669,6 @@ template <typename T, int NM, int HB, class SP = void, int NT = 0> __global__ __
 
 // the slab instantiation of a plan: NM = bound on the base_transform nodes (2 / 4), HB = group-B slots (6 / 8)
 using StackKernel = void (*)(StackArgs);
-static StackKernel slab_fwd_kernel(const HostPlan& hp) {
-    if (hp.sl_hb <= SL_HB) return hp.n_mlp <= 2 ? k_slab_fwd<__bf16, 2, SL_HB> : k_slab_fwd<__bf16, 4, SL_HB>;
-    return hp.n_mlp <= 2 ? k_slab_fwd<__bf16, 2, SL_HB_MAX> : k_slab_fwd<__bf16, 4, SL_HB_MAX>;
-}
 // Specialised step kernels: k_slab_step over the COMPILE-TIME program of one (topology, depth) -- mshgnn_spec_tables.inc, generated from this library's own plan
 // compiler by tools/gen_spec_tables.py.  A plan takes one only when its slab tables are exactly the ints the kernel was compiled from (same packs, same
 // slots, same liveness), so a stale table file costs speed, never results; MSHGNN_SPEC=0 keeps the interpreting kernel (A/B runs, bit-identity tests).
@@ -1681,12 +1682,6 @@ template <class SP> static bool spec_matches(const HostPlan& hp) {
     }
     return true;
 }
-static StackKernel slab_step_spec_kernel(const HostPlan& hp, int nt, const char** name = nullptr) {      // nt: the launch's stash store policy (stash_nt_for)
-#define MSHGNN_SPEC_TRY(SP) if (spec_matches<SP>(hp)) { if (name) *name = #SP; return nt ? k_slab_step<__bf16, SP::NM, SP::HB, SP, 1> : k_slab_step<__bf16, SP::NM, SP::HB, SP, 0>; }
-    MSHGNN_SPEC_LIST(MSHGNN_SPEC_TRY)
-#undef MSHGNN_SPEC_TRY
-    return nullptr;
-}
 // The forward launch alone (mshgnn_forward: evaluation, or the first call of the two-call training route) over the same compile-time programs: whole tiles; TR (training:
 // stashes and relu bytes written) and NT (their store policy) are template parameters like the step kernels' NT -- with them at run time the 8-layer programs keep their
 // store addresses live across the unrolled layers and spill (256-492 B of scratch: slower than the interpreter at 8 192 windows).  The decoder tail runs without the fused
@@ -1698,19 +1693,39 @@ template <typename T, int NM, int HB, class SP, int TR, int NT> __global__ __lau
     unsigned lastbits[(SL_HA + 3) / 4 + (HB + 3) / 4];
     slab_fwd_body<T, NM, HB, false, SP>(v, smem, lastbits);
 }
-static StackKernel slab_fwd_spec_kernel(const HostPlan& hp, int training, int nt) {
-#define MSHGNN_SPEC_TRY(SP) if (spec_matches<SP>(hp)) return !training ? k_slab_fwd_spec<__bf16, SP::NM, SP::HB, SP, 0, 0> : \
-                                                                     (nt ? k_slab_fwd_spec<__bf16, SP::NM, SP::HB, SP, 1, 1> : k_slab_fwd_spec<__bf16, SP::NM, SP::HB, SP, 1, 0>);
-    MSHGNN_SPEC_LIST(MSHGNN_SPEC_TRY)
+// The kernels over the compile-time programs are instantiated in their own translation units -- this source compiled with -DMSHGNN_SPEC_SHARD=1..3 (csrc/Makefile:
+// mshgnn_spec<k>.o), a third of the programs each (MSHGNN_SPEC_LIST_<k>), side by side with the rest of the library (shard 0: everything else).  A shard exports one
+// selector: kind 0 = one-call step, 1 = forward alone (tr: training), 2 = backward alone; nt = the launch's stash store policy (stash_nt_for); name: the program's name.
+StackKernel spec_shard1(const HostPlan& hp, int kind, int tr, int nt, const char** name);
+StackKernel spec_shard2(const HostPlan& hp, int kind, int tr, int nt, const char** name);
+StackKernel spec_shard3(const HostPlan& hp, int kind, int tr, int nt, const char** name);
+#if MSHGNN_SPEC_SHARD != 0
+#define MSHGNN_SPEC_TRY(SP) if (spec_matches<SP>(hp)) { \
+        if (name) *name = #SP; \
+        if (kind == 0) return nt ? k_slab_step<__bf16, SP::NM, SP::HB, SP, 1> : k_slab_step<__bf16, SP::NM, SP::HB, SP, 0>; \
+        if (kind == 1) return !tr ? k_slab_fwd_spec<__bf16, SP::NM, SP::HB, SP, 0, 0> : (nt ? k_slab_fwd_spec<__bf16, SP::NM, SP::HB, SP, 1, 1> : k_slab_fwd_spec<__bf16, SP::NM, SP::HB, SP, 1, 0>); \
+        return nt ? k_slab_bwd_spec<__bf16, SP::NM, SP::HB, SP, 1> : k_slab_bwd_spec<__bf16, SP::NM, SP::HB, SP, 0>; }
+#if MSHGNN_SPEC_SHARD == 1
+StackKernel spec_shard1(const HostPlan& hp, int kind, int tr, int nt, const char** name) { MSHGNN_SPEC_LIST_1(MSHGNN_SPEC_TRY) return nullptr; }
+#elif MSHGNN_SPEC_SHARD == 2
+StackKernel spec_shard2(const HostPlan& hp, int kind, int tr, int nt, const char** name) { MSHGNN_SPEC_LIST_2(MSHGNN_SPEC_TRY) return nullptr; }
+#else
+StackKernel spec_shard3(const HostPlan& hp, int kind, int tr, int nt, const char** name) { MSHGNN_SPEC_LIST_3(MSHGNN_SPEC_TRY) return nullptr; }
+#endif
 #undef MSHGNN_SPEC_TRY
-    return nullptr;
+#else      // MSHGNN_SPEC_SHARD == 0: the library proper, to the end of this file
+static StackKernel slab_fwd_kernel(const HostPlan& hp) {
+    if (hp.sl_hb <= SL_HB) return hp.n_mlp <= 2 ? k_slab_fwd<__bf16, 2, SL_HB> : k_slab_fwd<__bf16, 4, SL_HB>;
+    return hp.n_mlp <= 2 ? k_slab_fwd<__bf16, 2, SL_HB_MAX> : k_slab_fwd<__bf16, 4, SL_HB_MAX>;
 }
-static StackKernel slab_bwd_spec_kernel(const HostPlan& hp, int nt) {
-#define MSHGNN_SPEC_TRY(SP) if (spec_matches<SP>(hp)) return nt ? k_slab_bwd_spec<__bf16, SP::NM, SP::HB, SP, 1> : k_slab_bwd_spec<__bf16, SP::NM, SP::HB, SP, 0>;
-    MSHGNN_SPEC_LIST(MSHGNN_SPEC_TRY)
-#undef MSHGNN_SPEC_TRY
-    return nullptr;
+static StackKernel spec_kernel(const HostPlan& hp, int kind, int tr, int nt, const char** name = nullptr) {
+    if (StackKernel k = spec_shard1(hp, kind, tr, nt, name)) return k;
+    if (StackKernel k = spec_shard2(hp, kind, tr, nt, name)) return k;
+    return spec_shard3(hp, kind, tr, nt, name);
 }
+static StackKernel slab_step_spec_kernel(const HostPlan& hp, int nt, const char** name = nullptr) { return spec_kernel(hp, 0, 1, nt, name); }
+static StackKernel slab_fwd_spec_kernel(const HostPlan& hp, int training, int nt) { return spec_kernel(hp, 1, training, nt); }
+static StackKernel slab_bwd_spec_kernel(const HostPlan& hp, int nt) { return spec_kernel(hp, 2, 1, nt); }
 // the step kernel of a launch: the specialised one where the plan has one and the batch is whole tiles (its stores are unpredicated), else the interpreter
 static StackKernel slab_step_kernel(const HostPlan& hp, int64_t B = -1, int nt = 0, bool use_spec = false) {
     if (use_spec && B > 0 && B % TILE_ROWS == 0) if (StackKernel k = slab_step_spec_kernel(hp, nt)) return k;
@@ -3909,3 +3924,4 @@ extern "C" int mshgnn_step_ce_series(const mshgnn_plan* p, const mshgnn_window_d
     return step_series(p, d, src, src_bf16, src_cstride, src_rows, starts, batch, x_out, x_pitch, y_out, nullptr, run_ptrs, params, out, loss_out, grad_params,
                        workspace, stream, labels_out);
 }
+#endif      // MSHGNN_SPEC_SHARD == 0

@@ -72,7 +72,12 @@ __device__ __forceinline__ void prep_one_x3(const PrepArgs& a, int idx, bool wit
         }
     }
 }
+#ifndef MSHGNN_SPEC_SHARD
+#define MSHGNN_SPEC_SHARD 0      // 1 / 2: this source compiled as one of the translation units that instantiate the compile-time programs' kernels (below, csrc/Makefile)
+#endif
+#if MSHGNN_SPEC_SHARD == 0
 __global__ void k_prep_x3(PrepArgs a) { prep_one_x3(a, blockIdx.x * blockDim.x + threadIdx.x, true); }
+#endif
 
 // ------------------------------------------------------------------------------------------------------
 // k_enc_x3: X_0[node] = relu((mask . x) W_enc^T + b) from fp32 inputs (hgnn_c2.py:143-147); one workgroup = 64 windows of ONE
@@ -697,10 +702,12 @@ template <bool STEP, class SP = void> __device__ __forceinline__ void stack_bwd_
     } else if (wh == 0) x3_bwd_layers_static<SP, 0, SP::L - 1>(a, smem, wpack, wn, lane);
     else x3_bwd_layers_static<SP, 1, SP::L - 1>(a, smem, wpack, wn, lane);
 }
+#if MSHGNN_SPEC_SHARD == 0
 __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_bwd_x3(StackArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     stack_bwd_x3_body<false>(a, smem);
 }
+#endif
 // mshgnn_step_mse on the split plan: both sweeps of a tile in one launch (k_slab_step of mshgnn.hip: dX_L stays in LDS, no second launch, no tile reload)
 // SP: void = the plan's tables are interpreted; else the compile-time program of one (topology, depth) on the split plan (mshgnn_spec_tables.inc, X3_*)
 template <bool ALIAS, class SP = void> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_step_x3(StackArgs a) {
@@ -709,6 +716,37 @@ template <bool ALIAS, class SP = void> __global__ __launch_bounds__(LAYER_THREAD
     __syncthreads();
     stack_bwd_x3_body<true, SP>(a, smem);
 }
+
+// Specialised one-call step kernels of the split plan: k_stack_step_x3 over the compile-time program of one (topology, depth) -- mshgnn_spec_tables.inc (X3_*),
+// generated from this library's own plan compiler.  A plan takes one only when its fused tables are exactly the ints the kernel was compiled from.  The kernels are
+// instantiated in two translation units of their own (this source with -DMSHGNN_SPEC_SHARD=1 / 2: csrc/Makefile), half of the programs each, side by side with the rest.
+#include "mshgnn_spec_tables.inc"
+using StackKernelX3 = void (*)(StackArgs);
+template <class SP> static bool spec_matches_x3(const HostPlan& hp) {
+    if (!hp.split || !hp.fused || hp.L != SP::L || hp.NN != SP::NN || (hp.x3_alias ? 1 : 0) != SP::ALIAS) return false;
+    for (int l = 0; l < SP::L; ++l) {
+        if (hp.fs_fwd_off[l] + SP::ROW > (int)hp.tables.size() || hp.fs_bwd_off[l] + SP::ROW > (int)hp.tables.size()) return false;
+        if (memcmp(hp.tables.data() + hp.fs_fwd_off[l], SP::fwd[l], sizeof(int32_t) * SP::ROW) != 0) return false;
+        if (memcmp(hp.tables.data() + hp.fs_bwd_off[l], SP::bwd[l], sizeof(int32_t) * SP::ROW) != 0) return false;
+    }
+    return true;
+}
+StackKernelX3 x3_spec_shard1(const HostPlan& hp, const char** name);
+StackKernelX3 x3_spec_shard2(const HostPlan& hp, const char** name);
+#if MSHGNN_SPEC_SHARD != 0
+#define MSHGNN_SPEC_TRY(SP) if (spec_matches_x3<SP>(hp)) { if (name) *name = #SP; return k_stack_step_x3<SP::ALIAS != 0, SP>; }
+#if MSHGNN_SPEC_SHARD == 1
+StackKernelX3 x3_spec_shard1(const HostPlan& hp, const char** name) { MSHGNN_SPEC_X3_LIST_1(MSHGNN_SPEC_TRY) return nullptr; }
+#else
+StackKernelX3 x3_spec_shard2(const HostPlan& hp, const char** name) { MSHGNN_SPEC_X3_LIST_2(MSHGNN_SPEC_TRY) return nullptr; }
+#endif
+#undef MSHGNN_SPEC_TRY
+#else      // MSHGNN_SPEC_SHARD == 0: the library proper, to the end of this file
+static StackKernelX3 x3_step_spec_kernel(const HostPlan& hp, const char** name = nullptr) {
+    if (StackKernelX3 k = x3_spec_shard1(hp, name)) return k;
+    return x3_spec_shard2(hp, name);
+}
+
 
 // ------------------------------------------------------------------------------------------------------
 // k_dec_bwd_x3: decoder backward (+ fused wrapper MSE / cross entropy) on the hi/lo planes of X_L -> dX_L planes
@@ -1201,26 +1239,6 @@ int x3_launch_prep(const PrepArgs& a, hipStream_t st) {
 
 static int x3_lds_stack(const HostPlan& hp) { return 2 * hp.fs_blk * P16::BLK; }
 
-// Specialised one-call step kernels of the split plan: k_stack_step_x3 over the compile-time program of one (topology, depth) -- mshgnn_spec_tables.inc (X3_*),
-// generated from this library's own plan compiler.  A plan takes one only when its fused tables are exactly the ints the kernel was compiled from.
-#include "mshgnn_spec_tables.inc"
-using StackKernelX3 = void (*)(StackArgs);
-template <class SP> static bool spec_matches_x3(const HostPlan& hp) {
-    if (!hp.split || !hp.fused || hp.L != SP::L || hp.NN != SP::NN || (hp.x3_alias ? 1 : 0) != SP::ALIAS) return false;
-    for (int l = 0; l < SP::L; ++l) {
-        if (hp.fs_fwd_off[l] + SP::ROW > (int)hp.tables.size() || hp.fs_bwd_off[l] + SP::ROW > (int)hp.tables.size()) return false;
-        if (memcmp(hp.tables.data() + hp.fs_fwd_off[l], SP::fwd[l], sizeof(int32_t) * SP::ROW) != 0) return false;
-        if (memcmp(hp.tables.data() + hp.fs_bwd_off[l], SP::bwd[l], sizeof(int32_t) * SP::ROW) != 0) return false;
-    }
-    return true;
-}
-static StackKernelX3 x3_step_spec_kernel(const HostPlan& hp, const char** name = nullptr) {
-#define MSHGNN_SPEC_TRY(SP) if (spec_matches_x3<SP>(hp)) { if (name) *name = #SP; return k_stack_step_x3<SP::ALIAS != 0, SP>; }
-    MSHGNN_SPEC_X3_LIST(MSHGNN_SPEC_TRY)
-#undef MSHGNN_SPEC_TRY
-    return nullptr;
-}
-
 int x3_set_attrs(mshgnn_plan* p) {
     int rc;
     const int flds = x3_lds_stack(p->hp);
@@ -1412,3 +1430,4 @@ int x3_backward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pit
     }
     return run_finalize(p, lay, ws, gparams, B, (y || labels) ? loss : nullptr, labels != nullptr, dec_done, gw_phase, st, gw_parts);
 }
+#endif      // MSHGNN_SPEC_SHARD == 0
