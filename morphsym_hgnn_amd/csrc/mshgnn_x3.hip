@@ -73,7 +73,7 @@ __device__ __forceinline__ void prep_one_x3(const PrepArgs& a, int idx, bool wit
     }
 }
 #ifndef MSHGNN_SPEC_SHARD
-#define MSHGNN_SPEC_SHARD 0      // 1 / 2: this source compiled as one of the translation units that instantiate the compile-time programs' kernels (below, csrc/Makefile)
+#define MSHGNN_SPEC_SHARD 0      // 1..6: this source compiled as one of the translation units that instantiate the compile-time programs' kernels (below, csrc/Makefile)
 #endif
 #if MSHGNN_SPEC_SHARD == 0
 __global__ void k_prep_x3(PrepArgs a) { prep_one_x3(a, blockIdx.x * blockDim.x + threadIdx.x, true); }
@@ -719,7 +719,7 @@ template <bool ALIAS, class SP = void> __global__ __launch_bounds__(LAYER_THREAD
 
 // Specialised one-call step kernels of the split plan: k_stack_step_x3 over the compile-time program of one (topology, depth) -- mshgnn_spec_tables.inc (X3_*),
 // generated from this library's own plan compiler.  A plan takes one only when its fused tables are exactly the ints the kernel was compiled from.  The kernels are
-// instantiated in two translation units of their own (this source with -DMSHGNN_SPEC_SHARD=1 / 2: csrc/Makefile), half of the programs each, side by side with the rest.
+// instantiated in translation units of their own (this source with -DMSHGNN_SPEC_SHARD=1..6: csrc/Makefile), side by side with the rest.
 #include "mshgnn_spec_tables.inc"
 using StackKernelX3 = void (*)(StackArgs);
 template <class SP> static bool spec_matches_x3(const HostPlan& hp) {
@@ -731,20 +731,21 @@ template <class SP> static bool spec_matches_x3(const HostPlan& hp) {
     }
     return true;
 }
-StackKernelX3 x3_spec_shard1(const HostPlan& hp, const char** name);
-StackKernelX3 x3_spec_shard2(const HostPlan& hp, const char** name);
+#define X3_SHARD_LIST(X) X(1) X(2) X(3) X(4) X(5) X(6)      // one program per shard (tools/gen_spec_tables.py X3_SHARDS; a split-plan step kernel compiles for 75-95 s)
+#define X3_SHARD_DECL(k) StackKernelX3 x3_spec_shard##k(const HostPlan& hp, const char** name);
+X3_SHARD_LIST(X3_SHARD_DECL)
 #if MSHGNN_SPEC_SHARD != 0
 #define MSHGNN_SPEC_TRY(SP) if (spec_matches_x3<SP>(hp)) { if (name) *name = #SP; return k_stack_step_x3<SP::ALIAS != 0, SP>; }
-#if MSHGNN_SPEC_SHARD == 1
-StackKernelX3 x3_spec_shard1(const HostPlan& hp, const char** name) { MSHGNN_SPEC_X3_LIST_1(MSHGNN_SPEC_TRY) return nullptr; }
-#else
-StackKernelX3 x3_spec_shard2(const HostPlan& hp, const char** name) { MSHGNN_SPEC_X3_LIST_2(MSHGNN_SPEC_TRY) return nullptr; }
-#endif
+#define X3_CAT2(a, b) a##b
+#define X3_CAT(a, b) X3_CAT2(a, b)
+StackKernelX3 X3_CAT(x3_spec_shard, MSHGNN_SPEC_SHARD)(const HostPlan& hp, const char** name) { X3_CAT(MSHGNN_SPEC_X3_LIST_, MSHGNN_SPEC_SHARD)(MSHGNN_SPEC_TRY) return nullptr; }
 #undef MSHGNN_SPEC_TRY
 #else      // MSHGNN_SPEC_SHARD == 0: the library proper, to the end of this file
 static StackKernelX3 x3_step_spec_kernel(const HostPlan& hp, const char** name = nullptr) {
-    if (StackKernelX3 k = x3_spec_shard1(hp, name)) return k;
-    return x3_spec_shard2(hp, name);
+#define X3_SHARD_TRY(k) if (StackKernelX3 kk = x3_spec_shard##k(hp, name)) return kk;
+    X3_SHARD_LIST(X3_SHARD_TRY)
+#undef X3_SHARD_TRY
+    return nullptr;
 }
 
 
