@@ -677,7 +677,6 @@ template <bool STEP, class SP = void> __device__ __forceinline__ void stack_bwd_
     const int w0 = blockIdx.x * P::ROWS, B = a.B, NN = a.NN, LO = a.lo_blk;
     const T* wpack = reinterpret_cast<const T*>(a.wpack);
     auto prog_of = [&](int l) { return STEP ? a.prog_off_b[l] : a.prog_off[l]; };
-    static_assert(std::is_void<SP>::value || STEP, "compile-time programs exist for the one-launch step only");
 
     // dX_L tile: only the nodes that are live in the last layer carry a gradient
     if constexpr (!STEP) {
@@ -716,6 +715,16 @@ template <bool ALIAS, class SP = void> __global__ __launch_bounds__(LAYER_THREAD
     __syncthreads();
     stack_bwd_x3_body<true, SP>(a, smem);
 }
+// the forward launch alone (evaluation / first call of the two-call training route: what the nn.Module surface -- default precision "x3" -- runs) and the backward launch alone over
+// the same programs; predicated stores like the interpreters', so ragged batches take them too.  Same MACs, same order: the interpreters' bits.
+template <bool ALIAS, class SP> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_fwd_x3_spec(StackArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    stack_fwd_x3_body<ALIAS, false, SP>(a, smem);
+}
+template <class SP> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_bwd_x3_spec(StackArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    stack_bwd_x3_body<false, SP>(a, smem);
+}
 
 // Specialised one-call step kernels of the split plan: k_stack_step_x3 over the compile-time program of one (topology, depth) -- mshgnn_spec_tables.inc (X3_*),
 // generated from this library's own plan compiler.  A plan takes one only when its fused tables are exactly the ints the kernel was compiled from.  The kernels are
@@ -732,21 +741,23 @@ template <class SP> static bool spec_matches_x3(const HostPlan& hp) {
     return true;
 }
 #define X3_SHARD_LIST(X) X(1) X(2) X(3) X(4) X(5) X(6)      // one program per shard (tools/gen_spec_tables.py X3_SHARDS; a split-plan step kernel compiles for 75-95 s)
-#define X3_SHARD_DECL(k) StackKernelX3 x3_spec_shard##k(const HostPlan& hp, const char** name);
+#define X3_SHARD_DECL(k) StackKernelX3 x3_spec_shard##k(const HostPlan& hp, int kind, const char** name);      // kind 0: one-call step, 1: forward alone, 2: backward alone
 X3_SHARD_LIST(X3_SHARD_DECL)
 #if MSHGNN_SPEC_SHARD != 0
-#define MSHGNN_SPEC_TRY(SP) if (spec_matches_x3<SP>(hp)) { if (name) *name = #SP; return k_stack_step_x3<SP::ALIAS != 0, SP>; }
+#define MSHGNN_SPEC_TRY(SP) if (spec_matches_x3<SP>(hp)) { if (name) *name = #SP; \
+        return kind == 0 ? k_stack_step_x3<SP::ALIAS != 0, SP> : (kind == 1 ? k_stack_fwd_x3_spec<SP::ALIAS != 0, SP> : k_stack_bwd_x3_spec<SP>); }
 #define X3_CAT2(a, b) a##b
 #define X3_CAT(a, b) X3_CAT2(a, b)
-StackKernelX3 X3_CAT(x3_spec_shard, MSHGNN_SPEC_SHARD)(const HostPlan& hp, const char** name) { X3_CAT(MSHGNN_SPEC_X3_LIST_, MSHGNN_SPEC_SHARD)(MSHGNN_SPEC_TRY) return nullptr; }
+StackKernelX3 X3_CAT(x3_spec_shard, MSHGNN_SPEC_SHARD)(const HostPlan& hp, int kind, const char** name) { X3_CAT(MSHGNN_SPEC_X3_LIST_, MSHGNN_SPEC_SHARD)(MSHGNN_SPEC_TRY) return nullptr; }
 #undef MSHGNN_SPEC_TRY
 #else      // MSHGNN_SPEC_SHARD == 0: the library proper, to the end of this file
-static StackKernelX3 x3_step_spec_kernel(const HostPlan& hp, const char** name = nullptr) {
-#define X3_SHARD_TRY(k) if (StackKernelX3 kk = x3_spec_shard##k(hp, name)) return kk;
+static StackKernelX3 x3_spec_kernel(const HostPlan& hp, int kind, const char** name = nullptr) {
+#define X3_SHARD_TRY(k) if (StackKernelX3 kk = x3_spec_shard##k(hp, kind, name)) return kk;
     X3_SHARD_LIST(X3_SHARD_TRY)
 #undef X3_SHARD_TRY
     return nullptr;
 }
+static StackKernelX3 x3_step_spec_kernel(const HostPlan& hp, const char** name = nullptr) { return x3_spec_kernel(hp, 0, name); }
 
 
 // ------------------------------------------------------------------------------------------------------
@@ -1246,7 +1257,10 @@ int x3_set_attrs(mshgnn_plan* p) {
     { const char* esp = getenv("MSHGNN_SPEC"); p->use_spec = !(esp && atoi(esp) == 0); }
     if (p->use_spec) {
         const char* nm = nullptr;
-        if (StackKernelX3 k = x3_step_spec_kernel(p->hp, &nm)) { if ((rc = set_lds_attr(k, flds))) return rc; p->spec_name = nm + 6; }
+        if (StackKernelX3 k = x3_step_spec_kernel(p->hp, &nm)) {
+            if ((rc = set_lds_attr(k, flds)) || (rc = set_lds_attr(x3_spec_kernel(p->hp, 1), flds)) || (rc = set_lds_attr(x3_spec_kernel(p->hp, 2), flds))) return rc;
+            p->spec_name = nm + 6;
+        }
         else p->use_spec = false;
     }
     if ((rc = set_lds_attr(k_stack_fwd_x3<false>, flds)) || (rc = set_lds_attr(k_stack_fwd_x3<true>, flds)) || (rc = set_lds_attr(k_stack_bwd_x3, flds)) ||
@@ -1370,7 +1384,8 @@ int x3_forward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitc
             else hipLaunchKernelGGL(k_stack_step_x3<false>, dim3(tiles), dim3(LAYER_THREADS), x3_lds_stack(hp), st, a);
             *stack_step_done = true;
         } else
-        if (hp.x3_alias) hipLaunchKernelGGL(k_stack_fwd_x3<true>, dim3(tiles), dim3(LAYER_THREADS), x3_lds_stack(hp), st, a);
+        if (StackKernelX3 kf = p->use_spec ? x3_spec_kernel(hp, 1) : nullptr) hipLaunchKernelGGL(kf, dim3(tiles), dim3(LAYER_THREADS), x3_lds_stack(hp), st, a);
+        else if (hp.x3_alias) hipLaunchKernelGGL(k_stack_fwd_x3<true>, dim3(tiles), dim3(LAYER_THREADS), x3_lds_stack(hp), st, a);
         else hipLaunchKernelGGL(k_stack_fwd_x3<false>, dim3(tiles), dim3(LAYER_THREADS), x3_lds_stack(hp), st, a);
     }
     HIPCHK(hipGetLastError());
@@ -1400,7 +1415,8 @@ int x3_backward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pit
         for (int l = 0; l < hp.L; ++l) a.prog_off[l] = hp.fs_bwd_off[l];
         const int tiles = (B + P16::ROWS - 1) / P16::ROWS;
         ProfScope ps(p, hp.ks_stack_bwd, st);
-        hipLaunchKernelGGL(k_stack_bwd_x3, dim3(tiles), dim3(LAYER_THREADS), x3_lds_stack(hp), st, a);
+        if (StackKernelX3 kb = p->use_spec ? x3_spec_kernel(hp, 2) : nullptr) hipLaunchKernelGGL(kb, dim3(tiles), dim3(LAYER_THREADS), x3_lds_stack(hp), st, a);
+        else hipLaunchKernelGGL(k_stack_bwd_x3, dim3(tiles), dim3(LAYER_THREADS), x3_lds_stack(hp), st, a);
     }
     const int gw_parts = gw_parts_for(hp.n_parts, hp.n_lanes, hp.gw_ipl, B, 32, p->n_cu);      // window parts of this batch's weight-gradient launch (32-window steps)
     {

@@ -131,3 +131,29 @@ def test_specialised_forward_is_bit_identical_to_the_interpreter(monkeypatch, co
             else:      # ragged: e1 falls back to the 8-wave kernels below one tile per CU, e0 runs the interpreting slab ones -- same bits up to the decoder's partial sums
                 assert float((a - b).norm() / b.norm()) < 1e-6, (name, B, what)
         assert torch.equal(res[0][0].view(torch.int32), res[0][1].view(torch.int32)) and float(res[0][2].abs().max()) > 0
+
+
+@pytest.mark.parametrize("config,layers,name", X3_CASES)
+def test_specialised_split_plan_forward_backward_are_bit_identical_to_the_interpreter(monkeypatch, config, layers, name):
+    """The parity plan's forward launch alone (evaluation; first call of the two-call route -- what the nn.Module surface, default precision "x3", runs) and its backward launch
+    alone over the compile-time programs (k_stack_fwd_x3_spec / k_stack_bwd_x3_spec): predicated stores, so ragged batches too.  Bits == the interpreting kernels'."""
+    spec = bench.build_spec(layers, config)
+    monkeypatch.setenv("MSHGNN_SPEC", "1")
+    e1 = eng.Engine(spec, "x3")
+    monkeypatch.setenv("MSHGNN_SPEC", "0")
+    e0 = eng.Engine(spec, "x3")
+    assert e1.specialised == name and e0.specialised == ""
+    flat = eng.flatten_params(spec, synth.make_params(9, spec.param_shapes()), e1.device)
+    for B in (32, 50, 1040):
+        x, y = bench.make_batch(spec, B, 51 + B)
+        res = []
+        for e in (e1, e0):
+            xs = e.cast_inputs(x)
+            o_eval = e.forward(xs, flat, B, training=False).clone()
+            o_tr = e.forward(xs, flat, B, training=True).clone()
+            g = e.backward(xs, flat, torch.ones_like(o_tr) / o_tr.numel(), B).clone()
+            torch.cuda.synchronize()
+            res.append((o_eval, o_tr, g))
+        for what, a, b in zip(("eval out", "training out", "grad"), res[0], res[1]):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), f"{name} B={B}: {what} differs, max abs {float((a - b).abs().max())}"
+        assert float(res[0][2].abs().max()) > 0
