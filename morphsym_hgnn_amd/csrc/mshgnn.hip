@@ -15,7 +15,7 @@
 // No CPU fallback exists: every entry point launches HIP kernels or fails loudly.
 #include "mshgnn_device.hpp"
 #ifndef MSHGNN_SPEC_SHARD
-#define MSHGNN_SPEC_SHARD 0      // 1..3: this source compiled as one of the translation units that only instantiate the compile-time programs' kernels (csrc/Makefile; see spec_shard1 below)
+#define MSHGNN_SPEC_SHARD 0      // 1..6: this source compiled as one of the translation units that only instantiate the compile-time programs' kernels (csrc/Makefile; see spec_shard1 below)
 #endif
 #if MSHGNN_SPEC_SHARD == 0
 extern "C" const char* mshgnn_last_error(void) { return g_err.c_str(); }
@@ -1652,10 +1652,10 @@ template <typename T, int NM, int HB, class SP, int NT> __global__ __launch_boun
 // One-call training step (mshgnn_step_mse / mshgnn_step_ce): the forward layers, decoder + loss + decoder backward and the backward layers of a tile in ONE
 // launch.  The tail leaves dX_L in the node blocks, so the backward sweep starts without a launch boundary, without the header / tile round trips of
 // k_slab_bwd's start and without re-reading dX_L (stamps: 16 k of its 163 k cycles).  Same code, same order of every accumulation: identical bits.
-template <typename T, int NM, int HB, class SP = void, int NT = 0> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_step(StackArgs a) {
+template <typename T, int NM, int HB, class SP = void, int NT = 0, bool FULL = true> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_step(StackArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if constexpr (!std::is_void<SP>::value) {      // compile-time program (whole tiles only: StackView); NT: the stash store policy
-        const StackView<NT> v(a, true);
+    if constexpr (!std::is_void<SP>::value) {      // compile-time program; NT: the stash store policy; FULL: whole tiles only, unpredicated stores (else any batch size)
+        const StackView<NT, FULL> v(a, true);
         unsigned lastbits[(SL_HA + 3) / 4 + (HB + 3) / 4];
         slab_fwd_body<T, NM, HB, true, SP>(v, smem, lastbits);
         __syncthreads();
@@ -1686,49 +1686,54 @@ template <class SP> static bool spec_matches(const HostPlan& hp) {
 // stashes and relu bytes written) and NT (their store policy) are template parameters like the step kernels' NT -- with them at run time the 8-layer programs keep their
 // store addresses live across the unrolled layers and spill (256-492 B of scratch: slower than the interpreter at 8 192 windows).  The decoder tail runs without the fused
 // loss.  Same MACs, same order: the interpreter's bits.
-template <typename T, int NM, int HB, class SP, int TR, int NT> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_fwd_spec(StackArgs a) {
+template <typename T, int NM, int HB, class SP, int TR, int NT, bool FULL = true> __global__ __launch_bounds__(SL_THREADS, 2) void k_slab_fwd_spec(StackArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    StackView<NT> v(a, false);
+    StackView<NT, FULL> v(a, false);
     v.training = TR;
     unsigned lastbits[(SL_HA + 3) / 4 + (HB + 3) / 4];
     slab_fwd_body<T, NM, HB, false, SP>(v, smem, lastbits);
 }
-// The kernels over the compile-time programs are instantiated in their own translation units -- this source compiled with -DMSHGNN_SPEC_SHARD=1..3 (csrc/Makefile:
-// mshgnn_spec<k>.o), a third of the programs each (MSHGNN_SPEC_LIST_<k>), side by side with the rest of the library (shard 0: everything else).  A shard exports one
+// The kernels over the compile-time programs are instantiated in their own translation units -- this source compiled with -DMSHGNN_SPEC_SHARD=1..6 (csrc/Makefile:
+// mshgnn_spec<k>.o), one program each (MSHGNN_SPEC_LIST_<k>), side by side with the rest of the library (shard 0: everything else).  A shard exports one
 // selector: kind 0 = one-call step, 1 = forward alone (tr: training), 2 = backward alone; nt = the launch's stash store policy (stash_nt_for); name: the program's name.
-StackKernel spec_shard1(const HostPlan& hp, int kind, int tr, int nt, const char** name);
-StackKernel spec_shard2(const HostPlan& hp, int kind, int tr, int nt, const char** name);
-StackKernel spec_shard3(const HostPlan& hp, int kind, int tr, int nt, const char** name);
+#define SPEC_SHARD_LIST(X) X(1) X(2) X(3) X(4) X(5) X(6)      // one program per shard (tools/gen_spec_tables.py SHARDS)
+#define SPEC_SHARD_DECL(k) StackKernel spec_shard##k(const HostPlan& hp, int kind, int tr, int nt, int full, const char** name);
+SPEC_SHARD_LIST(SPEC_SHARD_DECL)
+// full (the batch is whole 16-window tiles): the unpredicated kernels, both store policies.  Else: the predicated forms that exist -- the one-call step with plain stash stores
+// (a ragged batch whose stash wants non-temporal stores keeps the interpreter: the weight-gradient launch behind plain stores loses more than the program wins at 8 layers)
+// and the evaluation forward; the two-call training route of a ragged batch keeps the interpreters (nullptr).
 #if MSHGNN_SPEC_SHARD != 0
 #define MSHGNN_SPEC_TRY(SP) if (spec_matches<SP>(hp)) { \
         if (name) *name = #SP; \
+        if (kind == 0 && !full) return nt ? nullptr : k_slab_step<__bf16, SP::NM, SP::HB, SP, 0, false>; \
         if (kind == 0) return nt ? k_slab_step<__bf16, SP::NM, SP::HB, SP, 1> : k_slab_step<__bf16, SP::NM, SP::HB, SP, 0>; \
-        if (kind == 1) return !tr ? k_slab_fwd_spec<__bf16, SP::NM, SP::HB, SP, 0, 0> : (nt ? k_slab_fwd_spec<__bf16, SP::NM, SP::HB, SP, 1, 1> : k_slab_fwd_spec<__bf16, SP::NM, SP::HB, SP, 1, 0>); \
+        if (kind == 1 && !tr) return full ? k_slab_fwd_spec<__bf16, SP::NM, SP::HB, SP, 0, 0> : k_slab_fwd_spec<__bf16, SP::NM, SP::HB, SP, 0, 0, false>; \
+        if (!full) return nullptr; \
+        if (kind == 1) return nt ? k_slab_fwd_spec<__bf16, SP::NM, SP::HB, SP, 1, 1> : k_slab_fwd_spec<__bf16, SP::NM, SP::HB, SP, 1, 0>; \
         return nt ? k_slab_bwd_spec<__bf16, SP::NM, SP::HB, SP, 1> : k_slab_bwd_spec<__bf16, SP::NM, SP::HB, SP, 0>; }
-#if MSHGNN_SPEC_SHARD == 1
-StackKernel spec_shard1(const HostPlan& hp, int kind, int tr, int nt, const char** name) { MSHGNN_SPEC_LIST_1(MSHGNN_SPEC_TRY) return nullptr; }
-#elif MSHGNN_SPEC_SHARD == 2
-StackKernel spec_shard2(const HostPlan& hp, int kind, int tr, int nt, const char** name) { MSHGNN_SPEC_LIST_2(MSHGNN_SPEC_TRY) return nullptr; }
-#else
-StackKernel spec_shard3(const HostPlan& hp, int kind, int tr, int nt, const char** name) { MSHGNN_SPEC_LIST_3(MSHGNN_SPEC_TRY) return nullptr; }
-#endif
+#define SPEC_CAT2(a, b) a##b
+#define SPEC_CAT(a, b) SPEC_CAT2(a, b)
+StackKernel SPEC_CAT(spec_shard, MSHGNN_SPEC_SHARD)(const HostPlan& hp, int kind, int tr, int nt, int full, const char** name) { SPEC_CAT(MSHGNN_SPEC_LIST_, MSHGNN_SPEC_SHARD)(MSHGNN_SPEC_TRY) return nullptr; }
 #undef MSHGNN_SPEC_TRY
 #else      // MSHGNN_SPEC_SHARD == 0: the library proper, to the end of this file
 static StackKernel slab_fwd_kernel(const HostPlan& hp) {
     if (hp.sl_hb <= SL_HB) return hp.n_mlp <= 2 ? k_slab_fwd<__bf16, 2, SL_HB> : k_slab_fwd<__bf16, 4, SL_HB>;
     return hp.n_mlp <= 2 ? k_slab_fwd<__bf16, 2, SL_HB_MAX> : k_slab_fwd<__bf16, 4, SL_HB_MAX>;
 }
-static StackKernel spec_kernel(const HostPlan& hp, int kind, int tr, int nt, const char** name = nullptr) {
-    if (StackKernel k = spec_shard1(hp, kind, tr, nt, name)) return k;
-    if (StackKernel k = spec_shard2(hp, kind, tr, nt, name)) return k;
-    return spec_shard3(hp, kind, tr, nt, name);
+static StackKernel spec_kernel(const HostPlan& hp, int kind, int tr, int nt, int full, const char** name = nullptr) {
+    const char* nm = nullptr;      // (a shard that holds the plan's program sets the name even where it has no kernel of that kind: stop there)
+#define SPEC_SHARD_TRY(k) { StackKernel kk = spec_shard##k(hp, kind, tr, nt, full, &nm); if (nm) { if (name) *name = nm; return kk; } }
+    SPEC_SHARD_LIST(SPEC_SHARD_TRY)
+#undef SPEC_SHARD_TRY
+    return nullptr;
 }
-static StackKernel slab_step_spec_kernel(const HostPlan& hp, int nt, const char** name = nullptr) { return spec_kernel(hp, 0, 1, nt, name); }
-static StackKernel slab_fwd_spec_kernel(const HostPlan& hp, int training, int nt) { return spec_kernel(hp, 1, training, nt); }
-static StackKernel slab_bwd_spec_kernel(const HostPlan& hp, int nt) { return spec_kernel(hp, 2, 1, nt); }
+inline bool whole_tiles(int64_t B) { return B > 0 && B % TILE_ROWS == 0; }
+static StackKernel slab_step_spec_kernel(const HostPlan& hp, int nt, const char** name = nullptr, bool full = true) { return spec_kernel(hp, 0, 1, nt, full, name); }
+static StackKernel slab_fwd_spec_kernel(const HostPlan& hp, int training, int nt, bool full = true) { return spec_kernel(hp, 1, training, nt, full); }
+static StackKernel slab_bwd_spec_kernel(const HostPlan& hp, int nt, bool full = true) { return spec_kernel(hp, 2, 1, nt, full); }
 // the step kernel of a launch: the specialised one where the plan has one and the batch is whole tiles (its stores are unpredicated), else the interpreter
 static StackKernel slab_step_kernel(const HostPlan& hp, int64_t B = -1, int nt = 0, bool use_spec = false) {
-    if (use_spec && B > 0 && B % TILE_ROWS == 0) if (StackKernel k = slab_step_spec_kernel(hp, nt)) return k;
+    if (use_spec && B > 0) if (StackKernel k = slab_step_spec_kernel(hp, nt, nullptr, whole_tiles(B))) return k;
     if (hp.sl_hb <= SL_HB) return hp.n_mlp <= 2 ? k_slab_step<__bf16, 2, SL_HB> : k_slab_step<__bf16, 4, SL_HB>;
     return hp.n_mlp <= 2 ? k_slab_step<__bf16, 2, SL_HB_MAX> : k_slab_step<__bf16, 4, SL_HB_MAX>;
 }
@@ -2538,6 +2543,8 @@ extern "C" int mshgnn_plan_create(const mshgnn_desc* desc, mshgnn_plan** out) {
                     if (StackKernel k = slab_fwd_spec_kernel(hp, v > 0, v - 1)) if ((rc = set_lds_attr(k, flds))) { mshgnn_plan_destroy(p); return rc; }
                 for (int nt = 0; nt < 2; ++nt)
                     if (StackKernel k = slab_bwd_spec_kernel(hp, nt)) if ((rc = set_lds_attr(k, flds))) { mshgnn_plan_destroy(p); return rc; }
+                if (StackKernel k = slab_step_spec_kernel(hp, 0, nullptr, false)) if ((rc = set_lds_attr(k, flds))) { mshgnn_plan_destroy(p); return rc; }      // (ragged batches)
+                if (StackKernel k = slab_fwd_spec_kernel(hp, 0, 0, false)) if ((rc = set_lds_attr(k, flds))) { mshgnn_plan_destroy(p); return rc; }
             }
             { const char* et = getenv("MSHGNN_STEP_KERNEL"); p->use_step = !(et && atoi(et) == 0); }      // one-call steps: forward + backward sweep in one launch
 
@@ -2748,7 +2755,7 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
             // (whole tiles): a single tile's chain on the specialised slab kernel is 37-42 us where the interpreting 8-wave kernel takes 57-62 (A1-C2, 32 .. 4 096 windows;
             // 8 layers: 140-166 against 202-209), so the specialised step runs at every batch size.  MSHGNN_SLAB=0 / MSHGNN_SPEC=0 keep the 8-wave kernels there.
             bool step_slab = p->slab_for(tiles);
-            const bool spec_small = !step_slab && want_step && p->use_slab && p->use_spec && B % TILE_ROWS == 0 && slab_step_spec_kernel(hp, a.stash_nt) != nullptr;
+            const bool spec_small = !step_slab && want_step && p->use_slab && p->use_spec && slab_step_spec_kernel(hp, a.stash_nt, nullptr, whole_tiles(B)) != nullptr;
             bool red_front_ok = false, red_back_ok = false; size_t red_back = 0;
             auto red_fits = [&](bool slab) {
                 const size_t red_need = (size_t)((slab ? SL_THREADS : LAYER_THREADS) / 64) * DEC_SLAB_FLOATS * sizeof(float);
@@ -2760,7 +2767,7 @@ static int forward_impl(const mshgnn_plan* p, const void* const* x, const int64_
             const bool step = want_step && red_fits(step_slab);
             if (step && !red_front_ok) a.red_off = (int)red_back;
             // the forward launch alone (evaluation / two-call training) on its compile-time program, at every whole-tile batch size
-            const StackKernel fwd_spec = (!step && p->use_slab && p->use_spec && B % TILE_ROWS == 0) ? slab_fwd_spec_kernel(hp, training, a.stash_nt) : nullptr;
+            const StackKernel fwd_spec = (!step && p->use_slab && p->use_spec) ? slab_fwd_spec_kernel(hp, training, a.stash_nt, whole_tiles(B)) : nullptr;
             if (fwd_spec) step_slab = true;
             ProfScope ps(p, step ? hp.ks_stack_step : hp.ks_stack_fwd, st);
             if (step_slab) {
@@ -2849,7 +2856,7 @@ static int backward_impl(const mshgnn_plan* p, const void* const* x, const int64
             a.stagger = p->slab_for(tiles) && tiles > p->n_cu ? p->stagger : 0;
             a.stash_nt = stash_nt_for(B, stash_rows_of(hp), H * (int)sizeof(T));
             ProfScope ps(p, hp.ks_stack_bwd, st);
-            const StackKernel bwd_spec = (p->use_slab && p->use_spec && B % TILE_ROWS == 0) ? slab_bwd_spec_kernel(hp, a.stash_nt) : nullptr;      // (at every whole-tile batch size, like the forward)
+            const StackKernel bwd_spec = (p->use_slab && p->use_spec) ? slab_bwd_spec_kernel(hp, a.stash_nt, whole_tiles(B)) : nullptr;      // (at every whole-tile batch size, like the forward)
             if (bwd_spec || p->slab_for(tiles)) {
                 for (int l = 0; l < hp.L; ++l) a.prog_off[l] = hp.sl_bwd_off[l];
                 hipLaunchKernelGGL(bwd_spec ? bwd_spec : slab_bwd_kernel(hp), dim3(tiles), dim3(SL_THREADS), (hp.sl_blk + FS_EXTRA_BLK) * Prec<T>::BLK, st, a);

@@ -757,8 +757,10 @@ struct StackArgs {
 // full: the host launches these kernels only over batches of whole 16-window tiles (B % 16 == 0), so no store is predicated and the number of stores between a
 // request and its use is the same on every path -- what lets the compiler wait for a load issued BEFORE a store phase with a counted vmcnt instead of a drain.
 // NT: the stash store policy (StackArgs.stash_nt) as a template parameter, for the same reason (one arm, compiler-visible stores).
-template <int NT> struct StackView {
-    static constexpr bool full = true;
+// FULL = false: the same view with every tile-edge predicate kept (rows past the batch are neither loaded nor stored, as in the interpreters): the kernels over compile-time
+// programs that batches of other sizes take.  Measured (round 6): free at 3 layers (58 us either way), +22-27 % on the 8-layer programs (registers) -- hence both forms.
+template <int NT, bool FULL = true> struct StackView {
+    static constexpr bool full = FULL;
     static constexpr int nt_mode = NT;
     const StackArgs& s;
     const void* const& tile_in; char* const& ws;
@@ -775,7 +777,7 @@ template <int NT> struct StackView {
     }
 };
 __device__ __forceinline__ const StackArgs& args_of(const StackArgs& a) { return a; }
-template <int NT> __device__ __forceinline__ const StackArgs& args_of(const StackView<NT>& v) { return v.s; }
+template <int NT, bool FULL> __device__ __forceinline__ const StackArgs& args_of(const StackView<NT, FULL>& v) { return v.s; }
 
 // one 16-byte stash store, plain or non-temporal (StackArgs.stash_nt: uniform)
 __device__ __forceinline__ void stash_store(void* p, u32x4 v, bool nt) {
