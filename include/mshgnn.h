@@ -161,10 +161,11 @@ size_t mshgnn_struct_size(int which);      /* 0: mshgnn_desc, 1: mshgnn_info, 2:
 int mshgnn_plan_create(const mshgnn_desc* desc, mshgnn_plan** plan_out);
 void mshgnn_plan_destroy(mshgnn_plan* plan);
 int mshgnn_plan_info(const mshgnn_plan* plan, mshgnn_info* info);
-/* Name of the compile-time program ("A1C2_L3", ...) the one-call training steps of this plan run on for batches of whole 16-window tiles, or "" when the
- * plan's tables are interpreted at run time.  The step kernels are specialised at build time for the topologies BASELINE.json names (csrc/mshgnn_spec_tables.inc,
- * generated from this library's own plan compiler); a plan takes one only when its tables equal the kernel's, and MSHGNN_SPEC=0 at plan creation keeps the
- * interpreting kernel (same bits either way: tests/test_spec_gpu.py).  Nothing in the reference corresponds: its forward is interpreted by PyTorch
+/* Name of the compile-time program ("A1C2_L3", ...) this plan's stack launches run on -- the one-call training steps, the forward alone (evaluation) and the two-call training
+ * route; at every batch size (batches that are not whole 16-window tiles: predicated forms of the step and of the evaluation forward) -- or "" when the plan's tables are
+ * interpreted at run time.  The kernels are specialised at build time for the topologies BASELINE.json names and the model types the reference's scripts default to
+ * (csrc/mshgnn_spec_tables.inc, generated from this library's own plan compiler); a plan takes one only when its tables equal the kernel's, and MSHGNN_SPEC=0 at plan creation
+ * keeps the interpreting kernels (same bits either way: tests/test_spec_gpu.py).  Nothing in the reference corresponds: its forward is interpreted by PyTorch
  * (hgnn_c2.py:150-166). */
 const char* mshgnn_plan_specialised(const mshgnn_plan* plan);
 /* The plan compiler alone, on the host: no HIP device is touched, nothing is allocated.  Fills `info` (work counts, LDS bytes, kernel sets: what
