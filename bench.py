@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="a1c2", choices=["a1c2", "mck4", "solo", "synth32", "mcc2", "solo_s4"])
+    ap.add_argument("--config", default="a1c2", choices=["a1c2", "mck4", "solo", "synth32", "mcc2", "solo_s4", "mi_quad"])
     ap.add_argument("--batch", type=int, default=0, help="windows per GPU (default: 8192 a1c2, 8192 mck4, 65536 solo, 1024 synth32)")
     ap.add_argument("--layers", type=int, default=0, help="message-passing layers (default: 3 a1c2, 8 mck4, 8 solo, 6 synth32)")
     ap.add_argument("--hidden", type=int, default=0, help="hidden channels (default 128; 512 for synth32)")
@@ -155,6 +155,9 @@ def build_spec(layers=3, config="a1c2", hidden=128):
             group = yaml.safe_load(f)
         return ModelSpec(kind="s4_com", topology=topology.TOPOLOGIES["solo-s4-com"](), hidden=hidden, num_layers=layers,
                          widths=synth.feature_widths("s4_com", True), regression=True, grf_dimension=3, group=group)
+    if config == "mi_quad":   # the MI-HGNN baseline (hgnn.py:GRF_HGNN) on a quadruped, contact classification at the reference's depth (train_classification.py:650-652: heterogeneous_gnn, 8 layers, 128)
+        return ModelSpec(kind="mi", topology=topology.TOPOLOGIES["quadruped-mi"](), hidden=hidden, num_layers=layers,
+                         widths=synth.feature_widths("mi", False), regression=False, grf_dimension=3, group=None)
     if config == "synth32":   # BASELINE configs[4]: synthetic 32-limb robot, MI-HGNN model (hgnn.py:GRF_HGNN)
         return ModelSpec(kind="mi", topology=topology.synthetic_limbs(32), hidden=hidden, num_layers=layers,
                          widths=synth.feature_widths("mi", True), regression=True, grf_dimension=3, group=None)
@@ -162,7 +165,7 @@ def build_spec(layers=3, config="a1c2", hidden=128):
 
 
 def defaults(args):
-    d = {"a1c2": (8192, 3, 128), "mck4": (8192, 8, 128), "solo": (65536, 8, 128), "synth32": (1024, 6, 512), "mcc2": (8192, 8, 128), "solo_s4": (65536, 8, 128)}[args.config]
+    d = {"a1c2": (8192, 3, 128), "mck4": (8192, 8, 128), "solo": (65536, 8, 128), "synth32": (1024, 6, 512), "mcc2": (8192, 8, 128), "solo_s4": (65536, 8, 128), "mi_quad": (8192, 8, 128)}[args.config]
     return (args.batch or d[0], args.layers or d[1], args.hidden or d[2])
 
 
@@ -886,7 +889,7 @@ def main():
     kernels = {s["name"]: round(s["total_ms"] / s["launches"] * 1e3, 2) for s in stats}
 
     names = {"a1c2": "A1-C2 GRF regression (3-D)", "mck4": "MiniCheetah-K4 contact classification", "solo": "Solo-12 K4 centroidal-momentum regression (COM_HGNN_K4)",
-             "synth32": "synthetic 32-limb MI-HGNN GRF regression", "mcc2": "MiniCheetah-C2 contact classification", "solo_s4": "Solo-12 S4 centroidal-momentum regression (COM_HGNN_S4)"}
+             "synth32": "synthetic 32-limb MI-HGNN GRF regression", "mcc2": "MiniCheetah-C2 contact classification", "solo_s4": "Solo-12 S4 centroidal-momentum regression (COM_HGNN_S4)", "mi_quad": "MI-HGNN quadruped contact classification (GRF_HGNN)"}
     res = {
         "metric": "graph-windows/sec fwd+bwd, A1-C2 GRF regression" if args.config == "a1c2" else f"graph-windows/sec fwd+bwd, {names[args.config]}",
         "value": value, "unit": "windows/s",

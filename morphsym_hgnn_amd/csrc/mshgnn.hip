@@ -15,7 +15,7 @@
 // No CPU fallback exists: every entry point launches HIP kernels or fails loudly.
 #include "mshgnn_device.hpp"
 #ifndef MSHGNN_SPEC_SHARD
-#define MSHGNN_SPEC_SHARD 0      // 1..6: this source compiled as one of the translation units that only instantiate the compile-time programs' kernels (csrc/Makefile; see spec_shard1 below)
+#define MSHGNN_SPEC_SHARD 0      // 1..7: this source compiled as one of the translation units that only instantiate the compile-time programs' kernels (csrc/Makefile; see spec_shard1 below)
 #endif
 #if MSHGNN_SPEC_SHARD == 0
 extern "C" const char* mshgnn_last_error(void) { return g_err.c_str(); }
@@ -1693,10 +1693,10 @@ template <typename T, int NM, int HB, class SP, int TR, int NT, bool FULL = true
     unsigned lastbits[(SL_HA + 3) / 4 + (HB + 3) / 4];
     slab_fwd_body<T, NM, HB, false, SP>(v, smem, lastbits);
 }
-// The kernels over the compile-time programs are instantiated in their own translation units -- this source compiled with -DMSHGNN_SPEC_SHARD=1..6 (csrc/Makefile:
+// The kernels over the compile-time programs are instantiated in their own translation units -- this source compiled with -DMSHGNN_SPEC_SHARD=1..7 (csrc/Makefile:
 // mshgnn_spec<k>.o), one program each (MSHGNN_SPEC_LIST_<k>), side by side with the rest of the library (shard 0: everything else).  A shard exports one
 // selector: kind 0 = one-call step, 1 = forward alone (tr: training), 2 = backward alone; nt = the launch's stash store policy (stash_nt_for); name: the program's name.
-#define SPEC_SHARD_LIST(X) X(1) X(2) X(3) X(4) X(5) X(6)      // one program per shard (tools/gen_spec_tables.py SHARDS)
+#define SPEC_SHARD_LIST(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7)      // one program per shard (tools/gen_spec_tables.py SHARDS)
 #define SPEC_SHARD_DECL(k) StackKernel spec_shard##k(const HostPlan& hp, int kind, int tr, int nt, int full, const char** name);
 SPEC_SHARD_LIST(SPEC_SHARD_DECL)
 // full (the batch is whole 16-window tiles): the unpredicated kernels, both store policies.  Else: the predicated forms that exist -- the one-call step with plain stash stores

@@ -73,7 +73,7 @@ __device__ __forceinline__ void prep_one_x3(const PrepArgs& a, int idx, bool wit
     }
 }
 #ifndef MSHGNN_SPEC_SHARD
-#define MSHGNN_SPEC_SHARD 0      // 1..6: this source compiled as one of the translation units that instantiate the compile-time programs' kernels (below, csrc/Makefile)
+#define MSHGNN_SPEC_SHARD 0      // 1..7: this source compiled as one of the translation units that instantiate the compile-time programs' kernels (below, csrc/Makefile)
 #endif
 #if MSHGNN_SPEC_SHARD == 0
 __global__ void k_prep_x3(PrepArgs a) { prep_one_x3(a, blockIdx.x * blockDim.x + threadIdx.x, true); }
@@ -728,7 +728,7 @@ template <class SP> __global__ __launch_bounds__(LAYER_THREADS, 2) void k_stack_
 
 // Specialised one-call step kernels of the split plan: k_stack_step_x3 over the compile-time program of one (topology, depth) -- mshgnn_spec_tables.inc (X3_*),
 // generated from this library's own plan compiler.  A plan takes one only when its fused tables are exactly the ints the kernel was compiled from.  The kernels are
-// instantiated in translation units of their own (this source with -DMSHGNN_SPEC_SHARD=1..6: csrc/Makefile), side by side with the rest.
+// instantiated in translation units of their own (this source with -DMSHGNN_SPEC_SHARD=1..7: csrc/Makefile), side by side with the rest.
 #include "mshgnn_spec_tables.inc"
 using StackKernelX3 = void (*)(StackArgs);
 template <class SP> static bool spec_matches_x3(const HostPlan& hp) {
@@ -740,7 +740,7 @@ template <class SP> static bool spec_matches_x3(const HostPlan& hp) {
     }
     return true;
 }
-#define X3_SHARD_LIST(X) X(1) X(2) X(3) X(4) X(5) X(6)      // one program per shard (tools/gen_spec_tables.py X3_SHARDS; a split-plan step kernel compiles for 75-95 s)
+#define X3_SHARD_LIST(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7)      // one program per shard (tools/gen_spec_tables.py X3_SHARDS; a split-plan step kernel compiles for 75-95 s)
 #define X3_SHARD_DECL(k) StackKernelX3 x3_spec_shard##k(const HostPlan& hp, int kind, const char** name);      // kind 0: one-call step, 1: forward alone, 2: backward alone
 X3_SHARD_LIST(X3_SHARD_DECL)
 #if MSHGNN_SPEC_SHARD != 0

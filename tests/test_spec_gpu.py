@@ -11,7 +11,7 @@ from morphsym_hgnn_amd import engine as eng, synth
 
 pytestmark = pytest.mark.gpu
 CASES = [("a1c2", 3, "A1C2_L3"), ("a1c2", 8, "A1C2_L8"), ("mck4", 8, "MCK4_L8"), ("solo", 8, "SOLO_L8"),
-         ("mcc2", 8, "MCC2_L8"), ("solo_s4", 8, "SOLO_S4_L8")]      # (the last two: the model types the reference's classification / COM scripts default to)
+         ("mcc2", 8, "MCC2_L8"), ("solo_s4", 8, "SOLO_S4_L8"), ("mi_quad", 8, "MI_QUAD_L8")]      # (the last three: the model types the reference's classification / COM scripts default to, the MI-HGNN baseline)
 
 
 def _step(e, spec, x, y, flat, B):
@@ -45,7 +45,7 @@ def test_specialised_step_is_bit_identical_to_the_interpreter(monkeypatch, confi
         assert float(r1[2].abs().max()) > 0 and torch.isfinite(r1[1]).all()
 
 
-X3_CASES = [("a1c2", 3, "X3_A1C2_L3"), ("a1c2", 8, "X3_A1C2_L8"), ("mck4", 8, "X3_MCK4_L8"), ("solo", 8, "X3_SOLO_L8"), ("mcc2", 8, "X3_MCC2_L8"), ("solo_s4", 8, "X3_SOLO_S4_L8")]
+X3_CASES = [("a1c2", 3, "X3_A1C2_L3"), ("a1c2", 8, "X3_A1C2_L8"), ("mck4", 8, "X3_MCK4_L8"), ("solo", 8, "X3_SOLO_L8"), ("mcc2", 8, "X3_MCC2_L8"), ("solo_s4", 8, "X3_SOLO_S4_L8"), ("mi_quad", 8, "X3_MI_QUAD_L8")]
 
 
 @pytest.mark.parametrize("config,layers,name", X3_CASES)
