@@ -960,6 +960,30 @@ def main():
             res["forward_only"][plan] = {"ms_per_step": dtf * 1e3, "value": B / dtf}
             del wf
             torch.cuda.empty_cache()
+        # the other model types the reference's scripts default to, each on its compile-time program (and on the interpreting kernels beside it: MSHGNN_SPEC=0 is read per plan)
+        res["other_models"] = {"what": "one-call step (mshgnn_step_mse / _ce), bf16 plan, 8 layers, h=128, 8192 windows, inputs resident: ms per step on the plan's compile-time program / "
+                                       "on the interpreting kernels (MSHGNN_SPEC=0)"}
+        for cfg_ in ("mcc2", "mi_quad"):
+            entry = {}
+            for label, env in (("ms_per_step", None), ("interpreted_ms_per_step", "0")):
+                prev_ = os.environ.get("MSHGNN_SPEC")
+                if env is not None:
+                    os.environ["MSHGNN_SPEC"] = env
+                try:
+                    wo = Workload(build_spec(8, cfg_, 128), "bf16", 8192, device, 1234)
+                    mo, _ = wo.time_blocks(10, 3, 0.1)
+                    entry[label] = mo / 10 * 1e3
+                    if env is None:
+                        entry["program"] = wo.e.specialised
+                    del wo
+                finally:
+                    if env is not None:
+                        if prev_ is None:
+                            del os.environ["MSHGNN_SPEC"]
+                        else:
+                            os.environ["MSHGNN_SPEC"] = prev_
+                torch.cuda.empty_cache()
+            res["other_models"][cfg_] = entry
         # the reference's own batch sizes (train_regression-grf_msgn.py:93: 32; train_classification_msgn.py:750 / train_regression-com_msgn.py:76: 64): a step is one
         # tile chain + four short launches -- the one-call step on its compile-time program (the specialised slab kernel at every whole-tile batch size)
         res["small_batches"] = {"what": "mshgnn_step_mse of the headline model at the reference's batch sizes, inputs resident, eager launches (ms per step; windows/s)"}
