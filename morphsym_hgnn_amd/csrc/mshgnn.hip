@@ -1713,15 +1713,29 @@ SPEC_SHARD_LIST(SPEC_SHARD_DECL)
         return nt ? k_slab_bwd_spec<__bf16, SP::NM, SP::HB, SP, 1> : k_slab_bwd_spec<__bf16, SP::NM, SP::HB, SP, 0>; }
 #define SPEC_CAT2(a, b) a##b
 #define SPEC_CAT(a, b) SPEC_CAT2(a, b)
+#if MSHGNN_SPEC_SHARD == 99
+// Shard 99 is not part of the library: it is this source compiled AFTER the build, for one plan's own tables (morphsym_hgnn_amd/jit.py renders them as MSHGNN_JIT_TABLES -- a
+// struct spec::JIT_<hash> and MSHGNN_SPEC_LIST_99 -- and compiles a small shared library of the program's kernels), for topologies the build has no program for.  The library
+// takes its selector through mshgnn_plan_attach_program and checks the tables like every shard does.
+#include MSHGNN_JIT_TABLES
+#endif
 StackKernel SPEC_CAT(spec_shard, MSHGNN_SPEC_SHARD)(const HostPlan& hp, int kind, int tr, int nt, int full, const char** name) { SPEC_CAT(MSHGNN_SPEC_LIST_, MSHGNN_SPEC_SHARD)(MSHGNN_SPEC_TRY) return nullptr; }
+#if MSHGNN_SPEC_SHARD == 99
+extern "C" StackKernel mshgnn_jit_program(const HostPlan& hp, int kind, int tr, int nt, int full, const char** name) { return spec_shard99(hp, kind, tr, nt, full, name); }
+#endif
 #undef MSHGNN_SPEC_TRY
 #else      // MSHGNN_SPEC_SHARD == 0: the library proper, to the end of this file
 static StackKernel slab_fwd_kernel(const HostPlan& hp) {
     if (hp.sl_hb <= SL_HB) return hp.n_mlp <= 2 ? k_slab_fwd<__bf16, 2, SL_HB> : k_slab_fwd<__bf16, 4, SL_HB>;
     return hp.n_mlp <= 2 ? k_slab_fwd<__bf16, 2, SL_HB_MAX> : k_slab_fwd<__bf16, 4, SL_HB_MAX>;
 }
+using SpecSelector = StackKernel (*)(const HostPlan& hp, int kind, int tr, int nt, int full, const char** name);
 static StackKernel spec_kernel(const HostPlan& hp, int kind, int tr, int nt, int full, const char** name = nullptr) {
     const char* nm = nullptr;      // (a shard that holds the plan's program sets the name even where it has no kernel of that kind: stop there)
+    if (hp.jit_prog) {             // a program compiled for this plan after the build
+        StackKernel kk = reinterpret_cast<SpecSelector>(hp.jit_prog)(hp, kind, tr, nt, full, &nm);
+        if (nm) { if (name) *name = nm; return kk; }
+    }
 #define SPEC_SHARD_TRY(k) { StackKernel kk = spec_shard##k(hp, kind, tr, nt, full, &nm); if (nm) { if (name) *name = nm; return kk; } }
     SPEC_SHARD_LIST(SPEC_SHARD_TRY)
 #undef SPEC_SHARD_TRY
@@ -2453,6 +2467,43 @@ __global__ __launch_bounds__(256) void k_finalize(FinArgs a) {
 // plan object + C-ABI
 // ------------------------------------------------------------------------------------------------------
 
+// the kernels over this plan's compile-time program, if one exists (built in, or attached): their dynamic-LDS attribute, the program's name; else use_spec = false
+static int set_spec_attrs(mshgnn_plan* p, int flds) {
+    const HostPlan& hp = p->hp;
+    int rc;
+    const char* nm = nullptr;
+    for (int nt = 0; nt < 2; ++nt)
+        if (StackKernel k = slab_step_spec_kernel(hp, nt, &nm)) if ((rc = set_lds_attr(k, flds))) return rc;
+    if (!nm) { p->use_spec = false; return MSHGNN_OK; }
+    p->spec_name_buf = strncmp(nm, "spec::", 6) == 0 ? nm + 6 : nm;
+    p->spec_name = p->spec_name_buf.c_str();
+    for (int v = 0; v < 3; ++v)
+        if (StackKernel k = slab_fwd_spec_kernel(hp, v > 0, v - 1)) if ((rc = set_lds_attr(k, flds))) return rc;
+    for (int nt = 0; nt < 2; ++nt)
+        if (StackKernel k = slab_bwd_spec_kernel(hp, nt)) if ((rc = set_lds_attr(k, flds))) return rc;
+    if (StackKernel k = slab_step_spec_kernel(hp, 0, nullptr, false)) if ((rc = set_lds_attr(k, flds))) return rc;      // (ragged batches)
+    if (StackKernel k = slab_fwd_spec_kernel(hp, 0, 0, false)) if ((rc = set_lds_attr(k, flds))) return rc;
+    return MSHGNN_OK;
+}
+
+// A program compiled for this plan after the library was built (morphsym_hgnn_amd/jit.py: this source as shard 99 over the plan's own tables): `selector` is that
+// library's mshgnn_jit_program.  Only LDS-resident bf16 plans whose slab kernels are in use take one; the tables are compared like a built-in program's.
+extern "C" int mshgnn_plan_attach_program(mshgnn_plan* p, void* selector) {
+    if (!p || !selector) return set_err(MSHGNN_EINVAL, "plan or selector is null");
+    if (p->gen || p->hp.d.dtype != MSHGNN_BF16 || !p->use_fused || !p->use_slab) return set_err(MSHGNN_EINVAL, "attached programs exist for LDS-resident bf16 plans on the slab kernels only");
+    void* const prev = p->hp.jit_prog;
+    p->hp.jit_prog = selector;
+    const char* nm = nullptr;
+    if (!reinterpret_cast<SpecSelector>(selector)(p->hp, 0, 1, 0, 1, &nm) || !nm) {
+        p->hp.jit_prog = prev;
+        return set_err(MSHGNN_EINVAL, "the program's tables are not this plan's");
+    }
+    p->use_spec = true;
+    const int rc = set_spec_attrs(p, (p->hp.fs_blk + FS_EXTRA_BLK) * Prec<__bf16>::BLK);
+    if (rc || !p->use_spec) { p->hp.jit_prog = prev; p->use_spec = false; return rc ? rc : set_err(MSHGNN_EINVAL, "no kernel of the attached program could be used"); }
+    return MSHGNN_OK;
+}
+
 extern "C" int mshgnn_plan_create(const mshgnn_desc* desc, mshgnn_plan** out) {
     if (!out) return set_err(MSHGNN_EINVAL, "plan_out is null");
     *out = nullptr;
@@ -2533,19 +2584,7 @@ extern "C" int mshgnn_plan_create(const mshgnn_desc* desc, mshgnn_plan** out) {
             if (p->use_slab && ((rc = set_lds_attr(slab_fwd_kernel(hp), flds)) || (rc = set_lds_attr(slab_bwd_kernel(hp), flds)) ||
                                 (rc = set_lds_attr(slab_step_kernel(hp), flds)))) { mshgnn_plan_destroy(p); return rc; }
             { const char* esp = getenv("MSHGNN_SPEC"); p->use_spec = p->use_slab && !(esp && atoi(esp) == 0); }
-            if (p->use_spec) {      // the specialised step kernels of this plan, if it has any (both store policies)
-                const char* nm = nullptr;
-                for (int nt = 0; nt < 2; ++nt)
-                    if (StackKernel k = slab_step_spec_kernel(hp, nt, &nm)) if ((rc = set_lds_attr(k, flds))) { mshgnn_plan_destroy(p); return rc; }
-                if (nm) p->spec_name = nm + 6;      // (past "spec::")
-                else p->use_spec = false;
-                for (int v = 0; v < 3; ++v)
-                    if (StackKernel k = slab_fwd_spec_kernel(hp, v > 0, v - 1)) if ((rc = set_lds_attr(k, flds))) { mshgnn_plan_destroy(p); return rc; }
-                for (int nt = 0; nt < 2; ++nt)
-                    if (StackKernel k = slab_bwd_spec_kernel(hp, nt)) if ((rc = set_lds_attr(k, flds))) { mshgnn_plan_destroy(p); return rc; }
-                if (StackKernel k = slab_step_spec_kernel(hp, 0, nullptr, false)) if ((rc = set_lds_attr(k, flds))) { mshgnn_plan_destroy(p); return rc; }      // (ragged batches)
-                if (StackKernel k = slab_fwd_spec_kernel(hp, 0, 0, false)) if ((rc = set_lds_attr(k, flds))) { mshgnn_plan_destroy(p); return rc; }
-            }
+            if (p->use_spec && (rc = set_spec_attrs(p, flds))) { mshgnn_plan_destroy(p); return rc; }
             { const char* et = getenv("MSHGNN_STEP_KERNEL"); p->use_step = !(et && atoi(et) == 0); }      // one-call steps: forward + backward sweep in one launch
 
             { const char* eg = TUNE_ENV("MSHGNN_STAGGER"); p->stagger = eg ? atoi(eg) : 0; }

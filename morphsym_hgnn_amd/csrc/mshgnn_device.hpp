@@ -1308,6 +1308,7 @@ struct mshgnn_plan {
     bool use_step = false;              // one-call steps on the slab kernels: k_slab_step (MSHGNN_STEP_KERNEL=0: two launches)
     bool use_spec = true;               // ... on the specialised kernel where the plan has one (MSHGNN_SPEC=0 at plan creation: the interpreting kernel)
     const char* spec_name = "";         // the compile-time program this plan's tables equal ("" = none)
+    std::string spec_name_buf;          // (owner of that name for a program attached after the build: mshgnn_plan_attach_program)
     int stagger = 0;                             // StackArgs.stagger of the two-workgroups-per-CU stack kernels (MSHGNN_STAGGER)
     int n_types = 0;
     mshgnn_gen_state* gen = nullptr;    // set: this plan runs on the generic-width engine (hidden != 128, many nodes, ...), hp is unused

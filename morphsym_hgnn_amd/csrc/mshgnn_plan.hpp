@@ -136,6 +136,7 @@ struct BiasDesc { int n_src; int64_t src[8]; };
 
 struct HostPlan {
     mshgnn_desc d{};
+    void* jit_prog = nullptr;      // selector of a program compiled for THIS plan after the library was built (mshgnn_plan_attach_program; same signature as the shards' selectors)
     std::vector<int32_t> rel_src, rel_dst, rel_mean, rel_edge_off, edges;
     std::vector<float> in_mask[MSHGNN_MAX_TYPES], out_mask;
     std::vector<int64_t> off_enc_w, off_enc_b, off_rel_w, off_rel_b, off_root_w;

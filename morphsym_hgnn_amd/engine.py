@@ -75,7 +75,7 @@ class MshgnnKernelStat(C.Structure):
 
 
 EXPORTS = [
-    "mshgnn_last_error", "mshgnn_version", "mshgnn_plan_create", "mshgnn_plan_destroy", "mshgnn_plan_info", "mshgnn_plan_specialised",
+    "mshgnn_last_error", "mshgnn_version", "mshgnn_plan_create", "mshgnn_plan_destroy", "mshgnn_plan_info", "mshgnn_plan_specialised", "mshgnn_plan_attach_program",
     "mshgnn_plan_compile_host", "mshgnn_workspace_layout", "mshgnn_forward", "mshgnn_backward", "mshgnn_mse_loss", "mshgnn_ce_loss", "mshgnn_metrics_regression_step", "mshgnn_metrics_classification_step", "mshgnn_metrics_com_step",
     "mshgnn_profile_enable", "mshgnn_profile_read", "mshgnn_backward_mse", "mshgnn_adam_step", "mshgnn_adam_step_counted",
     "mshgnn_metrics_regression", "mshgnn_metrics_classification", "mshgnn_grf_body_to_world", "mshgnn_assemble_windows",
@@ -113,6 +113,9 @@ def load_library():
     lib.mshgnn_plan_destroy.argtypes = [C.c_void_p]
     lib.mshgnn_plan_destroy.restype = None
     lib.mshgnn_plan_info.argtypes = [C.c_void_p, C.POINTER(MshgnnInfo)]
+    if hasattr(lib, "mshgnn_plan_attach_program"):
+        lib.mshgnn_plan_attach_program.argtypes = [C.c_void_p, C.c_void_p]
+        lib.mshgnn_plan_attach_program.restype = C.c_int
     if hasattr(lib, "mshgnn_plan_specialised"):      # (absent from older builds of the library handed over through MSHGNN_LIB for A/B runs)
         lib.mshgnn_plan_specialised.argtypes = [C.c_void_p]
         lib.mshgnn_plan_specialised.restype = C.c_char_p
@@ -349,6 +352,14 @@ class Engine:
         # [hi | lo] bf16 halves (the split plan, and MSHGNN_F32 requests served by the generic engine's split arithmetic)
         self.generic = bool(self.info.kernel_sets & 4)
         self.storage = "x3" if (dtype == "x3" or (self.generic and dtype == "f32")) else dtype
+        # MSHGNN_JIT=1: a topology the build has no compile-time program for gets one compiled now (hipcc, minutes, cached by table hash) -- morphsym_hgnn_amd/jit.py
+        if os.environ.get("MSHGNN_JIT") == "1" and not self.specialised and dtype == "bf16" and not self.generic and os.environ.get("MSHGNN_SPEC") != "0":
+            from . import jit
+            try:
+                jit.attach_program(self)
+            except Exception as ex:  # noqa: BLE001  (no hipcc, no sources: the interpreting kernels stay -- same results)
+                import warnings
+                warnings.warn(f"MSHGNN_JIT=1: no program compiled for this plan ({str(ex)[:300]}); the interpreting kernels are used")
         self._ws: Dict[Tuple[int, int], torch.Tensor] = {}
         self._tickets: Dict[int, int] = {}
         self._chunked: Dict[int, bool] = {}      # batch size -> the last training call on it was a one-call step (which the library may run as sub-steps)

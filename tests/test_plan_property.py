@@ -127,3 +127,19 @@ def test_spec_tables_in_sync():
     subprocess.run(["make", "-C", CSRC, "../libmshgnn_hostplan.so"], check=True, capture_output=True)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_spec_tables.py"), "--check"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_on_demand_program_tables_equal_the_generated_ones():
+    """morphsym_hgnn_amd/jit.py renders a plan's tables the way tools/gen_spec_tables.py does: for a plan that HAS a built-in program the two texts hold the same rows."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench
+    from morphsym_hgnn_amd import jit
+    subprocess.run(["make", "-C", CSRC, "../libmshgnn_hostplan.so"], check=True, capture_output=True)
+    spec = bench.build_spec(3, "a1c2")
+    holder = eng._DescHolder(spec, eng.DTYPE_CODES["bf16"])
+    tables, meta = jit.plan_tables(holder.desc)
+    name, txt = jit.render_program(tables, meta, spec.out_channels)
+    inc = open(os.path.join(CSRC, "mshgnn_spec_tables.inc")).read()
+    built_in = inc[inc.index("struct A1C2_L3 {"):inc.index("struct A1C2_L8 {")]
+    rows = lambda t: [l.strip() for l in t.splitlines() if l.strip().startswith("{")]
+    assert name.startswith("JIT_") and rows(txt) == rows(built_in) and "PRE = 7" in txt and "PRE = 7" in built_in
