@@ -171,7 +171,7 @@ const char* mshgnn_plan_specialised(const mshgnn_plan* plan);
 /* Attach a program compiled for THIS plan after the library was built: `selector` is the `mshgnn_jit_program` symbol of a small shared library made from the library's own
  * kernel source over the plan's own tables (csrc/mshgnn.hip as -DMSHGNN_SPEC_SHARD=99; morphsym_hgnn_amd/jit.py renders the tables, compiles with hipcc and caches the result).
  * For topologies the build has no program for (any URDF through the topology compiler): their stack launches then run straight-line code like the BASELINE topologies' instead of
- * the interpreting kernels -- same MACs, same order, same bits.  LDS-resident bf16 plans only; the tables are compared with the plan's, a mismatch is MSHGNN_EINVAL and changes
+ * the interpreting kernels -- same MACs, same order, same bits.  LDS-resident bf16 and split-bf16 plans (the latter: `mshgnn_jit_program_x3` of csrc/mshgnn_x3.hip); the tables are compared with the plan's, a mismatch is MSHGNN_EINVAL and changes
  * nothing.  The caller keeps that shared library loaded for the plan's lifetime.  Nothing in the reference corresponds (its forward is interpreted by PyTorch). */
 int mshgnn_plan_attach_program(mshgnn_plan* plan, void* selector);
 /* The plan compiler alone, on the host: no HIP device is touched, nothing is allocated.  Fills `info` (work counts, LDS bytes, kernel sets: what

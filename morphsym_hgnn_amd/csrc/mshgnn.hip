@@ -2490,7 +2490,8 @@ static int set_spec_attrs(mshgnn_plan* p, int flds) {
 // library's mshgnn_jit_program.  Only LDS-resident bf16 plans whose slab kernels are in use take one; the tables are compared like a built-in program's.
 extern "C" int mshgnn_plan_attach_program(mshgnn_plan* p, void* selector) {
     if (!p || !selector) return set_err(MSHGNN_EINVAL, "plan or selector is null");
-    if (p->gen || p->hp.d.dtype != MSHGNN_BF16 || !p->use_fused || !p->use_slab) return set_err(MSHGNN_EINVAL, "attached programs exist for LDS-resident bf16 plans on the slab kernels only");
+    if (!p->gen && p->hp.d.dtype == MSHGNN_BF16X3) return x3_attach_program(p, selector);      // (the split plan: selector = mshgnn_jit_program_x3)
+    if (p->gen || p->hp.d.dtype != MSHGNN_BF16 || !p->use_fused || !p->use_slab) return set_err(MSHGNN_EINVAL, "attached programs exist for LDS-resident bf16 / split-bf16 plans (bf16: on the slab kernels) only");
     void* const prev = p->hp.jit_prog;
     p->hp.jit_prog = selector;
     const char* nm = nullptr;

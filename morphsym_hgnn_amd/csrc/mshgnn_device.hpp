@@ -1385,6 +1385,7 @@ int run_finalize(const mshgnn_plan* p, const mshgnn_ws_layout& lay, char* ws, fl
                  int gw_phase, hipStream_t st, int gw_parts);
 // split-bf16 parity plan (mshgnn_x3.hip)
 int x3_set_attrs(mshgnn_plan* p);
+int x3_attach_program(mshgnn_plan* p, void* selector);
 int x3_forward(const mshgnn_plan* p, const void* const* x, const int64_t* x_pitch, const float* params, float* out, char* ws, int64_t batch,
                int training, hipStream_t st, const float* y_fused, const SeriesSrc* series = nullptr, bool* stack_step_done = nullptr,
                const int32_t* labels_fused = nullptr);

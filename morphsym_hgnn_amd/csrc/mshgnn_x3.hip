@@ -748,10 +748,18 @@ X3_SHARD_LIST(X3_SHARD_DECL)
         return kind == 0 ? k_stack_step_x3<SP::ALIAS != 0, SP> : (kind == 1 ? k_stack_fwd_x3_spec<SP::ALIAS != 0, SP> : k_stack_bwd_x3_spec<SP>); }
 #define X3_CAT2(a, b) a##b
 #define X3_CAT(a, b) X3_CAT2(a, b)
+#if MSHGNN_SPEC_SHARD == 99      // a program compiled for one plan after the build (morphsym_hgnn_amd/jit.py; see shard 99 of mshgnn.hip)
+#include MSHGNN_JIT_TABLES
+#endif
 StackKernelX3 X3_CAT(x3_spec_shard, MSHGNN_SPEC_SHARD)(const HostPlan& hp, int kind, const char** name) { X3_CAT(MSHGNN_SPEC_X3_LIST_, MSHGNN_SPEC_SHARD)(MSHGNN_SPEC_TRY) return nullptr; }
+#if MSHGNN_SPEC_SHARD == 99
+extern "C" StackKernelX3 mshgnn_jit_program_x3(const HostPlan& hp, int kind, const char** name) { return x3_spec_shard99(hp, kind, name); }
+#endif
 #undef MSHGNN_SPEC_TRY
 #else      // MSHGNN_SPEC_SHARD == 0: the library proper, to the end of this file
+using SpecSelectorX3 = StackKernelX3 (*)(const HostPlan& hp, int kind, const char** name);
 static StackKernelX3 x3_spec_kernel(const HostPlan& hp, int kind, const char** name = nullptr) {
+    if (hp.jit_prog) if (StackKernelX3 kk = reinterpret_cast<SpecSelectorX3>(hp.jit_prog)(hp, kind, name)) return kk;      // a program compiled for this plan after the build
 #define X3_SHARD_TRY(k) if (StackKernelX3 kk = x3_spec_shard##k(hp, kind, name)) return kk;
     X3_SHARD_LIST(X3_SHARD_TRY)
 #undef X3_SHARD_TRY
@@ -1251,18 +1259,35 @@ int x3_launch_prep(const PrepArgs& a, hipStream_t st) {
 
 static int x3_lds_stack(const HostPlan& hp) { return 2 * hp.fs_blk * P16::BLK; }
 
+// the kernels over this plan's compile-time program, if it has one (built in, or attached): dynamic-LDS attribute, name; else use_spec = false
+static int x3_set_spec_attrs(mshgnn_plan* p) {
+    int rc;
+    const int flds = x3_lds_stack(p->hp);
+    const char* nm = nullptr;
+    if (StackKernelX3 k = x3_step_spec_kernel(p->hp, &nm)) {
+        if ((rc = set_lds_attr(k, flds)) || (rc = set_lds_attr(x3_spec_kernel(p->hp, 1), flds)) || (rc = set_lds_attr(x3_spec_kernel(p->hp, 2), flds))) return rc;
+        p->spec_name_buf = strncmp(nm, "spec::", 6) == 0 ? nm + 6 : nm;
+        p->spec_name = p->spec_name_buf.c_str();
+    }
+    else p->use_spec = false;
+    return MSHGNN_OK;
+}
+// mshgnn_plan_attach_program on a split plan: `selector` is the mshgnn_jit_program_x3 of a program compiled for this plan
+int x3_attach_program(mshgnn_plan* p, void* selector) {
+    void* const prev = p->hp.jit_prog;
+    p->hp.jit_prog = selector;
+    const char* nm = nullptr;
+    if (!reinterpret_cast<SpecSelectorX3>(selector)(p->hp, 0, &nm) || !nm) { p->hp.jit_prog = prev; return set_err(MSHGNN_EINVAL, "the program's tables are not this plan's"); }
+    p->use_spec = true;
+    const int rc = x3_set_spec_attrs(p);
+    if (rc || !p->use_spec) { p->hp.jit_prog = prev; p->use_spec = false; return rc ? rc : set_err(MSHGNN_EINVAL, "no kernel of the attached program could be used"); }
+    return MSHGNN_OK;
+}
 int x3_set_attrs(mshgnn_plan* p) {
     int rc;
     const int flds = x3_lds_stack(p->hp);
     { const char* esp = getenv("MSHGNN_SPEC"); p->use_spec = !(esp && atoi(esp) == 0); }
-    if (p->use_spec) {
-        const char* nm = nullptr;
-        if (StackKernelX3 k = x3_step_spec_kernel(p->hp, &nm)) {
-            if ((rc = set_lds_attr(k, flds)) || (rc = set_lds_attr(x3_spec_kernel(p->hp, 1), flds)) || (rc = set_lds_attr(x3_spec_kernel(p->hp, 2), flds))) return rc;
-            p->spec_name = nm + 6;
-        }
-        else p->use_spec = false;
-    }
+    if (p->use_spec && (rc = x3_set_spec_attrs(p))) return rc;
     if ((rc = set_lds_attr(k_stack_fwd_x3<false>, flds)) || (rc = set_lds_attr(k_stack_fwd_x3<true>, flds)) || (rc = set_lds_attr(k_stack_bwd_x3, flds)) ||
         (rc = set_lds_attr(k_stack_step_x3<false>, flds)) || (rc = set_lds_attr(k_stack_step_x3<true>, flds)) ||
         (rc = set_lds_attr(k_enc_x3<true>, 8 * P16::BLK)) || (rc = set_lds_attr(k_enc_x3<false>, 8 * P16::BLK)) ||

@@ -353,7 +353,7 @@ class Engine:
         self.generic = bool(self.info.kernel_sets & 4)
         self.storage = "x3" if (dtype == "x3" or (self.generic and dtype == "f32")) else dtype
         # MSHGNN_JIT=1: a topology the build has no compile-time program for gets one compiled now (hipcc, minutes, cached by table hash) -- morphsym_hgnn_amd/jit.py
-        if os.environ.get("MSHGNN_JIT") == "1" and not self.specialised and dtype == "bf16" and not self.generic and os.environ.get("MSHGNN_SPEC") != "0":
+        if os.environ.get("MSHGNN_JIT") == "1" and not self.specialised and dtype in ("bf16", "x3") and not self.generic and os.environ.get("MSHGNN_SPEC") != "0":
             from . import jit
             try:
                 jit.attach_program(self)

@@ -54,8 +54,25 @@ def test_program_of_other_tables_is_refused():
     flat = eng.flatten_params(spec4, synth.make_params(1, spec4.param_shapes()), e4.device)
     out, loss, g = e4.step_mse(e4.cast_inputs(x), flat, y.to(e4.device, torch.float32).reshape(-1), 32)
     assert torch.isfinite(loss).all()
-    with pytest.raises(RuntimeError):      # plans of the generic engine / other dtypes take no program
-        jit.attach_program(eng.Engine(spec4, "x3"))
+    with pytest.raises(RuntimeError):      # the exact-fp32 plan (per-layer kernels) takes no program
+        jit.attach_program(eng.Engine(spec4, "f32"))
+
+
+def test_split_plan_program_compiled_on_demand_is_bit_identical_to_the_interpreter(monkeypatch):
+    monkeypatch.delenv("MSHGNN_JIT", raising=False)
+    spec = bench.build_spec(5, "a1c2")
+    monkeypatch.setenv("MSHGNN_SPEC", "0")
+    e0 = eng.Engine(spec, "x3")
+    monkeypatch.delenv("MSHGNN_SPEC")
+    e1 = eng.Engine(spec, "x3")
+    assert e1.specialised == ""
+    assert jit.attach_program(e1).startswith("JIT_X3_")
+    flat = eng.flatten_params(spec, synth.make_params(13, spec.param_shapes()), e1.device)
+    for B in (32, 50):
+        x, y = bench.make_batch(spec, B, 91 + B)
+        r1, r0 = _routes(e1, spec, x, y, flat, B), _routes(e0, spec, x, y, flat, B)
+        for what, a, b in zip(("step out", "step loss", "step grad", "eval out", "two-call grad"), r1, r0):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), f"B={B}: {what} differs, max abs {float((a - b).abs().max())}"
 
 
 def test_environment_switch_attaches_at_plan_creation(monkeypatch):
